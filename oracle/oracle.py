@@ -1,0 +1,243 @@
+"""ctypes bindings for the parity oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product package `platypus_amd` never does.
+
+  * `Oracle`     -> oracle/liborc.so, our C restatement (oracle/plat_oracle.c)
+  * `RefAlign`   -> oracle/_ref/libalign_ref.so, the UNMODIFIED reference src/c/align.c
+                    (C ABI from the reference's src/c/align.h:8-12)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBORC = os.path.join(HERE, "liborc.so")
+LIBREF = os.path.join(HERE, "_ref", "libalign_ref.so")
+
+
+def build(quiet=True):
+    """Compile liborc.so (and _ref/libalign_ref.so when /root/reference is present)."""
+    out = subprocess.run(["make", "-C", HERE], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + out.stdout + out.stderr)
+    if not quiet:
+        print(out.stdout)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _bytes_arr(b):
+    return np.frombuffer(bytes(b), dtype=np.int8).copy() if not isinstance(b, np.ndarray) else b
+
+
+class Oracle:
+    def __init__(self):
+        if not os.path.exists(LIBORC):
+            build()
+        self.lib = L = C.CDLL(LIBORC)
+        L.orc_dp_align.restype = C.c_int
+        L.orc_dp_align.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
+        L.orc_dp_score.restype = C.c_int
+        L.orc_dp_score.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p]
+        L.orc_dp_batch.restype = None
+        L.orc_dp_batch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_flank_score.restype = C.c_int
+        L.orc_flank_score.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_char_p, C.c_char_p]
+        L.orc_kmer_code.restype = C.c_uint
+        L.orc_kmer_code.argtypes = [C.c_char_p]
+        L.orc_gap_open.restype = None
+        L.orc_gap_open.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+        L.orc_loglik.restype = C.c_double
+        L.orc_loglik.argtypes = [C.c_int, C.c_int]
+        L.orc_align_read_to_hap.restype = C.c_int
+        L.orc_align_read_to_hap.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.orc_align_window.restype = None
+        L.orc_align_window.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.POINTER(C.c_longlong)]
+        L.orc_genotype_loglik.restype = C.c_double
+        L.orc_genotype_loglik.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_population_setup_ind.restype = None
+        L.orc_population_setup_ind.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]
+        L.orc_assemble.restype = C.c_int
+        L.orc_assemble.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.POINTER(C.c_int)]
+
+    # -- a1 ------------------------------------------------------------------------------------
+    def dp_score(self, hap_slice, read, qual, go, gapextend=3, nucprior=2):
+        assert len(hap_slice) >= len(read) + 15 and len(go) >= len(read) + 15
+        return self.lib.orc_dp_score(bytes(hap_slice), bytes(read), bytes(qual), len(read), gapextend,
+                                     nucprior, bytes(go))
+
+    def dp_align(self, hap_slice, read, qual, go, gapextend=3, nucprior=2):
+        n = len(read)
+        a1 = C.create_string_buffer(2 * n + 16)
+        a2 = C.create_string_buffer(2 * n + 16)
+        fp = C.c_int(0)
+        sc = self.lib.orc_dp_align(bytes(hap_slice), bytes(read), bytes(qual), n, gapextend, nucprior,
+                                   bytes(go), a1, a2, C.byref(fp))
+        return sc, a1.value, a2.value, fp.value
+
+    def dp_batch(self, haps, reads, quals, gos, len2, gapextend=3, nucprior=2):
+        n, lmax = reads.shape
+        out = np.empty(n, dtype=np.int32)
+        len2 = np.ascontiguousarray(len2, dtype=np.int32)
+        self.lib.orc_dp_batch(n, lmax, haps.ctypes.data, reads.ctypes.data, quals.ctypes.data,
+                              gos.ctypes.data, len2.ctypes.data, gapextend, nucprior, out.ctypes.data)
+        return out
+
+    def flank_score(self, hapLen, hapFlank, quals, go, firstpos, aln1, aln2, gapextend=3, nucprior=2):
+        return self.lib.orc_flank_score(hapLen, hapFlank, bytes(quals), bytes(go), gapextend, nucprior,
+                                        firstpos, bytes(aln1), bytes(aln2))
+
+    # -- a3..a8 --------------------------------------------------------------------------------
+    def kmer_code(self, seq7):
+        return self.lib.orc_kmer_code(bytes(seq7))
+
+    def gap_open(self, hap):
+        out = C.create_string_buffer(len(hap) + 1)
+        self.lib.orc_gap_open(bytes(hap), len(hap), out)
+        return out.raw[:len(hap) + 1]
+
+    def loglik(self, score, mapq):
+        return self.lib.orc_loglik(int(score), int(mapq))
+
+    def align_read_to_hap(self, read, qual, read_start, hap, hap_start, hap_flank, do_flank=0):
+        nd = C.c_int(0)
+        sc = self.lib.orc_align_read_to_hap(bytes(read), bytes(qual), len(read), read_start, bytes(hap),
+                                            len(hap), hap_start, hap_flank, do_flank, C.byref(nd))
+        return sc, nd.value
+
+    # -- a9 ------------------------------------------------------------------------------------
+    def align_window(self, haps, hap_start_pos, hap_end_pos, end_buffer, reads, do_flank=0):
+        """haps: list[bytes]; reads: dict of arrays (seq list, qual list, pos, end, mapq, flags, kind)."""
+        nH = len(haps)
+        hap_blob = b"".join(haps)
+        hap_len = np.array([len(h) for h in haps], dtype=np.int32)
+        hap_off = np.concatenate([[0], np.cumsum(hap_len)[:-1]]).astype(np.int32)
+        seqs, quals = reads["seq"], reads["qual"]
+        nR = len(seqs)
+        seq_blob = b"".join(seqs)
+        qual_blob = b"".join(quals)
+        rlen = np.array([len(s) for s in seqs], dtype=np.int32)
+        roff = (np.concatenate([[0], np.cumsum(rlen)[:-1]]) if nR else np.zeros(0)).astype(np.int32)
+        pos = np.ascontiguousarray(reads["pos"], dtype=np.int32)
+        end = np.ascontiguousarray(reads["end"], dtype=np.int32)
+        mapq = np.ascontiguousarray(reads["mapq"], dtype=np.uint8)
+        flags = np.ascontiguousarray(reads["flags"], dtype=np.int32)
+        kind = np.ascontiguousarray(reads["kind"], dtype=np.uint8)
+        ll = np.zeros((nH, nR), dtype=np.float64)
+        sc = np.zeros((nH, nR), dtype=np.int32)
+        ndp = C.c_longlong(0)
+        hb = np.frombuffer(hap_blob, dtype=np.uint8)
+        sb = np.frombuffer(seq_blob + b"\0", dtype=np.uint8)
+        qb = np.frombuffer(qual_blob + b"\0", dtype=np.uint8)
+        self.lib.orc_align_window(nH, hb.ctypes.data, hap_off.ctypes.data, hap_len.ctypes.data,
+                                  hap_start_pos, hap_end_pos, end_buffer, nR, sb.ctypes.data, qb.ctypes.data,
+                                  roff.ctypes.data, rlen.ctypes.data, pos.ctypes.data, end.ctypes.data,
+                                  mapq.ctypes.data, flags.ctypes.data, kind.ctypes.data, do_flank,
+                                  ll.ctypes.data, sc.ctypes.data, C.byref(ndp))
+        return ll, sc, ndp.value
+
+    # -- a11 / a12 -----------------------------------------------------------------------------
+    def genotype_loglik(self, arr1, arr2, same_hap, n_good):
+        a1 = np.ascontiguousarray(arr1, dtype=np.float64)
+        a2 = a1 if same_hap else np.ascontiguousarray(arr2, dtype=np.float64)
+        gof = C.c_double(0)
+        h1 = C.c_double(0)
+        h2 = C.c_double(0)
+        L = self.lib.orc_genotype_loglik(a1.ctypes.data, a2.ctypes.data, int(same_hap), len(a1) - 1,
+                                         n_good, C.byref(gof), C.byref(h1), C.byref(h2))
+        return L, gof.value, h1.value, h2.value
+
+    def population_setup_ind(self, ll_rows, n_good):
+        """ll_rows: [nHaps][totalReads] (no sentinel).  Returns (logl, gl, gof) per genotype."""
+        ll_rows = np.asarray(ll_rows, dtype=np.float64)
+        nH, nR = ll_rows.shape
+        withs = np.concatenate([ll_rows, np.full((nH, 1), 999.0)], axis=1).copy()
+        nG = nH * (nH + 1) // 2
+        logl = np.zeros(nG)
+        gl = np.zeros(nG)
+        gof = np.zeros(nG)
+        self.lib.orc_population_setup_ind(nH, withs.ctypes.data, nR, n_good, logl.ctypes.data,
+                                          gl.ctypes.data, gof.ctypes.data)
+        return logl, gl, gof
+
+    # -- a14..a18 ------------------------------------------------------------------------------
+    def assemble(self, ref, ref_start, assem_start, assem_end, seqs, quals, k=15, min_qual=20,
+                 min_weight=40, no_cycles=0):
+        nR = len(seqs)
+        rlen = np.array([len(s) for s in seqs], dtype=np.int32)
+        roff = (np.concatenate([[0], np.cumsum(rlen)[:-1]]) if nR else np.zeros(0)).astype(np.int32)
+        sb = np.frombuffer(b"".join(seqs) + b"\0", dtype=np.uint8)
+        qb = np.frombuffer(b"".join(quals) + b"\0", dtype=np.uint8)
+        cap, blobcap = 4096, 1 << 20
+        pos = np.zeros(cap, dtype=np.int32)
+        nrem = np.zeros(cap, dtype=np.int32)
+        nadd = np.zeros(cap, dtype=np.int32)
+        off = np.zeros(cap, dtype=np.int32)
+        blob = np.zeros(blobcap, dtype=np.uint8)
+        nn = C.c_int(0)
+        n = self.lib.orc_assemble(bytes(ref), len(ref), ref_start, assem_start, assem_end, nR,
+                                  sb.ctypes.data, qb.ctypes.data, roff.ctypes.data, rlen.ctypes.data, k,
+                                  min_qual, min_weight, no_cycles, cap, pos.ctypes.data, nrem.ctypes.data,
+                                  nadd.ctypes.data, off.ctypes.data, blob.ctypes.data, blobcap, C.byref(nn))
+        if n < 0:
+            raise RuntimeError("orc_assemble: output capacity too small")
+        out = []
+        raw = blob.tobytes()
+        for i in range(n):
+            o = off[i]
+            out.append((int(pos[i]), raw[o:o + nrem[i]], raw[o + nrem[i]:o + nrem[i] + nadd[i]]))
+        return out, nn.value
+
+
+class RefAlign:
+    """The unmodified reference align.c (fastAlignmentRoutine / calculateFlankScore)."""
+
+    def __init__(self):
+        if not os.path.exists(LIBREF):
+            raise FileNotFoundError(LIBREF + " (build with `make -C oracle` where /root/reference exists)")
+        self.lib = L = C.CDLL(LIBREF)
+        L.fastAlignmentRoutine.restype = C.c_int
+        L.fastAlignmentRoutine.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
+        L.calculateFlankScore.restype = C.c_int
+        L.calculateFlankScore.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                          C.c_char_p, C.c_char_p]
+
+    @staticmethod
+    def available():
+        return os.path.exists(LIBREF)
+
+    def dp_score(self, hap_slice, read, qual, go, gapextend=3, nucprior=2):
+        n = len(read)
+        return self.lib.fastAlignmentRoutine(bytes(hap_slice), bytes(read), bytes(qual), n + 15, n, gapextend,
+                                             nucprior, bytes(go), None, None, None)
+
+    def dp_align(self, hap_slice, read, qual, go, gapextend=3, nucprior=2):
+        n = len(read)
+        a1 = C.create_string_buffer(2 * n + 16)
+        a2 = C.create_string_buffer(2 * n + 16)
+        fp = C.c_int(0)
+        sc = self.lib.fastAlignmentRoutine(bytes(hap_slice), bytes(read), bytes(qual), n + 15, n, gapextend,
+                                           nucprior, bytes(go), a1, a2, C.byref(fp))
+        return sc, a1.value, a2.value, fp.value
+
+    def flank_score(self, hapLen, hapFlank, quals, go, firstpos, aln1, aln2, gapextend=3, nucprior=2):
+        return self.lib.calculateFlankScore(hapLen, hapFlank, bytes(quals), bytes(go), gapextend, nucprior,
+                                            firstpos, bytes(aln1), bytes(aln2))

@@ -1,0 +1,754 @@
+/*
+ * plat_oracle.c -- CPU restatement of the Platypus read->haplotype likelihood and
+ * local-assembly hot path.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE.  It is the parity oracle for the HIP path in
+ * platypus_amd/csrc.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product path never does (it fails loudly
+ * when the HIP library is missing).
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * the reference tree, andyrimmer/Platypus v0.8.1.1).  Nothing here is copied from
+ * the reference: the DP is written from the behavioural description in
+ * SURVEY.md App. A (8 x int16 lanes, wrapping adds, signed mins), as plain
+ * scalar C over int16_t[8] arrays -- no SSE intrinsics.
+ *
+ * Pinning (see oracle/README.md):
+ *   orc_dp_*          pinned against the UNMODIFIED reference src/c/align.c built
+ *                     into oracle/_ref/libalign_ref.so (tests/test_oracle_vs_ref.py)
+ *                     and against tests/golden/dp_cases.npz.
+ *   orc_map_align,    pinned against golden vectors generated in this container
+ *   orc_assemble      from the reference's own Cython sources (tests/golden/README.md).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * a1: fastAlignmentRoutine  (src/c/align.c:77-586)
+ * ------------------------------------------------------------------------------------------ */
+
+#define POS_INF ((int16_t)0x7800)
+
+static inline int16_t w16(int v) { return (int16_t)(uint16_t)v; }          /* wrapping narrow */
+static inline int16_t add16(int16_t a, int16_t b) { return w16((int)a + (int)b); }
+static inline int16_t min16(int16_t a, int16_t b) { return a < b ? a : b; }
+
+/* lane k <- lane k-1, lane 0 <- fill   (the reference's _mm_slli_si128(v,2) + insert lane 0) */
+static inline void shift_up(int16_t* v, int16_t fill) {
+    for (int k = 7; k > 0; --k) v[k] = v[k - 1];
+    v[0] = fill;
+}
+/* lane k <- lane k+1, lane 7 <- fill   (_mm_srli_si128(v,2) + insert lane 7) */
+static inline void shift_down(int16_t* v, int16_t fill) {
+    for (int k = 0; k < 7; ++k) v[k] = v[k + 1];
+    v[7] = fill;
+}
+
+/*
+ * Lane-exact restatement of align.c:94-586.  seq1 = haplotype slice (len2+15 bytes),
+ * seq2/qual2 = read (len2 bytes), go = local gap-open slice (len2+15 bytes).
+ * If aln1 != NULL the traceback (align.c:345-365,494-515,518-577) is also produced.
+ * Returns the alignment score; -1 on allocation failure.
+ */
+ORC_API int orc_dp_align(const char* seq1, const char* seq2, const char* qual2, int len2,
+                         int gapextend, int nucprior, const char* go,
+                         char* aln1, char* aln2, int* firstpos)
+{
+    const int len1 = len2 + 15;                      /* align.c:88 */
+    const int16_t GE = w16(gapextend * 4);           /* align.c:94 */
+    const int16_t NP = w16(nucprior * 4);            /* align.c:95 */
+    const int traceback = (aln1 != NULL);            /* align.c:96 */
+    int16_t m1[8], i1[8], d1[8], m2[8], i2[8], d2[8];
+    int16_t s1w[8], s1n[8], gop[8], s2w[8], q2w[8];
+    int mask[8];
+    int16_t (*bp)[8] = NULL;                         /* backpointers, align.c:126 */
+
+    if (traceback) {
+        bp = (int16_t (*)[8])malloc(sizeof(int16_t[8]) * 2 * (size_t)(len1 + 8));
+        if (!bp) return -1;
+    }
+    for (int k = 0; k < 8; ++k) {
+        m1[k] = i1[k] = d1[k] = m2[k] = i2[k] = d2[k] = POS_INF;      /* :139-144 */
+        s1w[k] = (int16_t)seq1[k];                                    /* :157 */
+        s2w[k] = POS_INF;                                             /* :158 */
+        q2w[k] = 64 * 4;                                              /* :159 */
+        s1n[k] = (s1w[k] == 'N') ? 0 : POS_INF;                       /* :175-178, n_score=0 :17 */
+        gop[k] = w16(4 * (int)go[k]);                                 /* :181 */
+        mask[k] = (k == 0);                                           /* :124 */
+    }
+    int16_t minscore = POS_INF;                                       /* :186 */
+    int minscoreidx = -1;
+
+    for (int h = 0; h < len2 + 8; ++h) {                              /* :199, s = 2h */
+        int16_t t[8];
+        /* ---- even half-step ------------------------------------------------ */
+        if (h < len2) {                                               /* :218-226 */
+            shift_up(s2w, (int16_t)seq2[h]);
+            shift_up(q2w, w16(4 * (int)qual2[h]));
+        } else {
+            shift_up(s2w, (int16_t)'0');
+            shift_up(q2w, 64 * 4);
+        }
+        for (int k = 0; k < 8; ++k)                                   /* :249-250 free start */
+            if (mask[k]) { m1[k] = (int16_t)-0x8000; m2[k] = (int16_t)-0x8000; }
+        for (int k = 0; k < 8; ++k) m1[k] = min16(m1[k], min16(i1[k], d1[k]));   /* :251 */
+        if (h >= len2) {                                              /* :261-288 */
+            int16_t sc = m1[h - len2];
+            if (sc < minscore) { minscore = sc; minscoreidx = 2 * h; }
+        }
+        for (int k = 0; k < 8; ++k) {                                 /* :314-318 */
+            int16_t sub = (s2w[k] == s1w[k]) ? 0 : q2w[k];
+            m1[k] = add16(m1[k], min16(sub, s1n[k]));
+        }
+        for (int k = 0; k < 8; ++k) {                                 /* :320-324 */
+            int16_t g = (k < 7) ? gop[k + 1] : 0;                     /* _mm_srli_si128(gap_open,2) */
+            t[k] = min16(add16(d2[k], GE), add16(min16(m2[k], i2[k]), g));
+        }
+        for (int k = 7; k > 0; --k) d1[k] = t[k - 1];                 /* :326-329 */
+        d1[0] = POS_INF;
+        for (int k = 0; k < 8; ++k)                                   /* :331-335 */
+            i1[k] = add16(min16(add16(i2[k], GE), add16(m2[k], gop[k])), NP);
+        if (traceback) {                                              /* :345-365 */
+            for (int k = 0; k < 8; ++k) {
+                bp[2 * h][k] = w16((m1[k] & 3) | ((i1[k] & 3) << 2) | ((d1[k] & 3) << 6));
+                m1[k] = w16(m1[k] & ~3);
+                i1[k] = w16((i1[k] & ~3) | 1);
+                d1[k] = w16((d1[k] & ~3) | 3);
+            }
+        }
+        /* ---- odd half-step ------------------------------------------------- */
+        {
+            char c = (8 + h < len1) ? seq1[8 + h] : 'N';              /* :376 */
+            int gi = (8 + h < len1) ? 8 + h : len1 - 1;               /* :387 */
+            shift_down(s1w, (int16_t)c);                              /* :384 */
+            shift_down(s1n, (c == 'N') ? 0 : POS_INF);                /* :385 */
+            shift_down(gop, w16(4 * (int)go[gi]));                    /* :386-388 */
+        }
+        for (int k = 7; k > 0; --k) mask[k] = mask[k - 1];            /* :405-406 */
+        mask[0] = 0;
+        for (int k = 0; k < 8; ++k) m2[k] = min16(m2[k], min16(i2[k], d2[k]));   /* :407 */
+        if (h >= len2) {                                              /* :416-443 */
+            int16_t sc = m2[h - len2];
+            if (sc < minscore) { minscore = sc; minscoreidx = 2 * h + 1; }
+        }
+        for (int k = 0; k < 8; ++k) {                                 /* :466-470 */
+            int16_t sub = (s2w[k] == s1w[k]) ? 0 : q2w[k];
+            m2[k] = add16(m2[k], min16(sub, s1n[k]));
+        }
+        for (int k = 0; k < 8; ++k)                                   /* :472-476 */
+            d2[k] = min16(add16(d1[k], GE), add16(min16(m1[k], i1[k]), gop[k]));
+        for (int k = 0; k < 7; ++k)                                   /* :478-484 */
+            i2[k] = add16(min16(add16(i1[k + 1], GE), add16(m1[k + 1], gop[k])), NP);
+        i2[7] = POS_INF;
+        if (traceback) {                                              /* :494-515 */
+            for (int k = 0; k < 8; ++k) {
+                bp[2 * h + 1][k] = w16((m2[k] & 3) | ((i2[k] & 3) << 2) | ((d2[k] & 3) << 6));
+                m2[k] = w16(m2[k] & ~3);
+                i2[k] = w16((i2[k] & ~3) | 1);
+                d2[k] = w16((d2[k] & ~3) | 3);
+            }
+        }
+    }
+    const int score = ((int)minscore + 0x8000) >> 2;                  /* :520,585 */
+    if (!traceback) return score;
+
+    /* Backtrace, align.c:523-577.  States: match 0, insert 1, delete 3. */
+    {
+        int s = minscoreidx;
+        int i = s / 2 - len2;
+        int y = len2;
+        int x = s - y;
+        int alnidx = 0;
+        int state = (bp[s][i] >> 0) & 3;
+        s -= 2;
+        while (y > 0) {
+            int newstate = (bp[s][i] >> (2 * state)) & 3;
+            if (state == 0) {
+                s -= 2;
+                aln1[alnidx] = seq1[--x];
+                aln2[alnidx] = seq2[--y];
+            } else if (state == 1) {
+                i += s & 1;
+                s -= 1;
+                aln1[alnidx] = '-';
+                aln2[alnidx] = seq2[--y];
+            } else {
+                s -= 1;
+                i -= s & 1;
+                aln1[alnidx] = seq1[--x];
+                aln2[alnidx] = '-';
+            }
+            state = newstate;
+            alnidx++;
+        }
+        aln1[alnidx] = 0;
+        aln2[alnidx] = 0;
+        if (firstpos) *firstpos = x;
+        for (int a = 0, b = alnidx - 1; a < b; ++a, --b) {
+            char ta = aln1[a], tb = aln2[a];
+            aln1[a] = aln1[b]; aln2[a] = aln2[b];
+            aln1[b] = ta;      aln2[b] = tb;
+        }
+    }
+    free(bp);
+    return score;
+}
+
+/* score-only convenience */
+ORC_API int orc_dp_score(const char* seq1, const char* seq2, const char* qual2, int len2,
+                         int gapextend, int nucprior, const char* go)
+{
+    return orc_dp_align(seq1, seq2, qual2, len2, gapextend, nucprior, go, NULL, NULL, NULL);
+}
+
+/* batched score-only DP over padded rows (mirrors plat_dp_batch's layout) */
+ORC_API void orc_dp_batch(int n, int lmax, const char* haps, const char* reads, const char* quals,
+                          const char* gos, const int* len2, int gapextend, int nucprior, int* out)
+{
+    for (int j = 0; j < n; ++j)
+        out[j] = orc_dp_score(haps + (size_t)j * (lmax + 15), reads + (size_t)j * lmax,
+                              quals + (size_t)j * lmax, len2[j], gapextend, nucprior,
+                              gos + (size_t)j * (lmax + 15));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a2: calculateFlankScore  (src/c/align.c:593-644)
+ * ------------------------------------------------------------------------------------------ */
+ORC_API int orc_flank_score(int hapLen, int hapFlank, const char* quals, const char* go,
+                            int gapextend, int nucprior, int firstpos,
+                            const char* aln1, const char* aln2)
+{
+    char prev = 'M';
+    int x = firstpos, y = 0, score = 0;
+    for (int i = 0; aln1[i]; ++i) {
+        char st = 'M';
+        if (aln1[i] == '-') st = 'I';
+        if (aln2[i] == '-') st = 'D';
+        const int inflank = (x < hapFlank || x >= hapLen - hapFlank);
+        if (st == 'M') {
+            if (aln1[i] != aln2[i] && inflank) score += (aln1[i] == 'N') ? 0 : quals[y];
+            ++x; ++y;
+        } else if (st == 'I') {
+            if (inflank) score += (prev == 'I') ? gapextend + nucprior : go[x - 1] + nucprior;
+            ++y;
+        } else {
+            if (inflank) score += (prev == 'D') ? gapextend : go[x];
+            ++x;
+        }
+        prev = st;
+    }
+    return score;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a3-a5: 7-mer hashing  (src/cython/calign.pyx:61-165)
+ * ------------------------------------------------------------------------------------------ */
+#define HASH_NUCS 7
+#define HASH_SIZE 16384
+
+static inline unsigned base_code(char ch) {          /* calign.pyx:69-74 */
+    int c = ch & 7;
+    if (c == 7) c = 2;
+    return (unsigned)(c & 3);
+}
+
+ORC_API unsigned orc_kmer_code(const char* seq) {     /* my_hash, calign.pyx:61-76 */
+    unsigned h = 0;
+    for (int i = 0; i < HASH_NUCS; ++i) h = (h << 2) + base_code(seq[i]);
+    return h;
+}
+
+/* hash_sequence_multihit, calign.pyx:94-124.  table/next: HASH_SIZE shorts each, zeroed here. */
+ORC_API void orc_hash_haplotype(const char* seq, int n, int16_t* table, int16_t* next)
+{
+    memset(table, 0, sizeof(int16_t) * HASH_SIZE);
+    memset(next, 0, sizeof(int16_t) * HASH_SIZE);
+    if (n < HASH_NUCS) return;
+    for (int i = 0; i < n - HASH_NUCS; ++i) {
+        unsigned h = orc_kmer_code(seq + i);
+        int slot = i + 1;
+        if (table[h] == 0) table[h] = (int16_t)slot;
+        else {
+            int j = table[h];
+            while (next[j] != 0) j = next[j];
+            next[j] = (int16_t)slot;
+        }
+    }
+}
+
+/* hashReadForMapping, calign.pyx:155-165.  out: rlen-7 shorts. */
+ORC_API void orc_hash_read(const char* seq, int rlen, int16_t* out)
+{
+    for (int i = 0; i < rlen - HASH_NUCS; ++i) out[i] = (int16_t)orc_kmer_code(seq + i);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a6: mapAndAlignReadToHaplotype  (src/cython/calign.pyx:170-272)
+ *
+ * The strncmp shortcut at calign.pyx:196 reads one byte before the haplotype buffer
+ * (indexOfReadIntoHap is still -1 there); it is treated as never taken.
+ * n_dp (optional) receives the number of fastAlignmentRoutine calls the reference makes.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API int orc_map_align(const char* read, const char* quals, int readStart, int hapStart,
+                          int readLen, int hapLen, const int16_t* hapHash, const int16_t* hapNext,
+                          const int16_t* readHash, const char* hap, int gapExtend, int nucprior,
+                          const char* go, int hapFlank, int doFlank, int* n_dp)
+{
+    if (n_dp) *n_dp = 0;
+    if (readLen < HASH_NUCS) return 0;                                /* :179-180 */
+    const int nCounts = hapLen + readLen;
+    int* counts = (int*)calloc((size_t)nCounts + 1, sizeof(int));     /* :206 */
+    char* aln1 = NULL; char* aln2 = NULL;
+    int firstpos = 0, maxcount = 0, best = 1000000, bestPos = -1;
+    if (hapFlank > 0) {                                               /* :199-202 */
+        aln1 = (char*)malloc((size_t)2 * readLen + 16);
+        aln2 = (char*)malloc((size_t)2 * readLen + 16);
+    }
+    for (int i = 0; i < readLen - HASH_NUCS; ++i) {                   /* :209-220 */
+        int hidx = hapHash[(uint16_t)readHash[i]];
+        while (hidx != 0) {
+            int pos = hidx - i - 1;
+            int c = ++counts[pos + readLen];
+            if (c > maxcount) maxcount = c;
+            hidx = hapNext[hidx];
+        }
+    }
+    if (maxcount > 0) {                                               /* :222-247 */
+        for (int j = 0; j < nCounts; ++j) {
+            if (counts[j] != maxcount) continue;
+            int idx = j - readLen;
+            if (idx >= -readLen && idx + readLen + 15 < hapLen) {
+                int st = idx - 8 > 0 ? idx - 8 : 0;
+                int sc = orc_dp_align(hap + st, read, quals, readLen, gapExtend, nucprior,
+                                      go + st, aln1, aln2, &firstpos);
+                if (n_dp) ++*n_dp;
+                if (doFlank == 1 && sc > 0 && hapFlank > 0)
+                    sc -= orc_flank_score(hapLen, hapFlank, quals, go, gapExtend, nucprior,
+                                          firstpos + st, aln1, aln2);
+                if (sc < best) {
+                    best = sc; bestPos = idx;
+                    if (best == 0) { free(aln1); free(aln2); free(counts); return 0; }
+                }
+            }
+        }
+    }
+    {                                                                 /* :252-267 */
+        int idx = readStart - hapStart;
+        if (hapLen - readLen - 15 < idx) idx = hapLen - readLen - 15;
+        if (idx != bestPos) {
+            int st = idx - 8 > 0 ? idx - 8 : 0;
+            int sc = orc_dp_align(hap + st, read, quals, readLen, gapExtend, nucprior,
+                                  go + st, aln1, aln2, &firstpos);
+            if (n_dp) ++*n_dp;
+            if (doFlank == 1 && sc > 0 && hapLen > 0)
+                sc -= orc_flank_score(hapLen, hapFlank, quals, go, gapExtend, nucprior,
+                                      firstpos + st, aln1, aln2);
+            if (sc < best) best = sc;
+        }
+    }
+    free(aln1); free(aln2); free(counts);
+    return best;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a7: Haplotype.annotateWithGapOpen  (src/cython/chaplotype.pyx:552-590; table :64-67)
+ * The 49-entry table is homopolq[i]-'!' for the reference's per_base_indel_errors model;
+ * tests/test_oracle.py recomputes it from the formula at chaplotype.pyx:64-67.
+ * ------------------------------------------------------------------------------------------ */
+static const signed char ORC_HOMOPOL_GO[50] = {
+    45,42,41,39,37,32,28,23,20,19,17,16,15,14,13,12,11,11,10,9,9,8,8,7,7,7,6,6,6,5,5,5,
+    4,4,4,3,3,3,3,2,2,2,2,2,1,1,1,1,1, /* NUL terminator of the byte string: */ -33 };
+
+ORC_API void orc_gap_open(const char* seq, int hapLen, char* out /* hapLen+1 */)
+{
+    int homopol = -1, homopollen = 0;
+    out[hapLen] = 0;
+    for (int index = hapLen - 1; index >= 0; --index) {
+        if ((int)seq[index] == homopol) {
+            if (homopollen + 1 < 49) homopollen += 1;     /* errorModel[homopollen+1] != 0 */
+        } else homopollen = 0;
+        out[index] = (char)ORC_HOMOPOL_GO[homopollen];
+        homopol = seq[index];
+        if (homopol == 'N') homopol = 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a8: alignReadToHaplotype's score -> log-likelihood  (src/cython/chaplotype.pyx:594-676,
+ * standard mode useMapQualCap=0).
+ * ------------------------------------------------------------------------------------------ */
+static const double mLTOT = -0.23025850929940459;                     /* chaplotype.pyx / calign.pyx:31 */
+
+ORC_API double orc_loglik(int score, int mapq)
+{
+    double probMapRight = log(1.0 - exp(mLTOT * mapq));               /* :621 */
+    double v = mLTOT * score + probMapRight;                          /* :676 */
+    return v > -300.0 ? v : -300.0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a8-a10 for one (read, haplotype): hashes + gap-open are built here for convenience.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API int orc_align_read_to_hap(const char* read, const char* quals, int readLen, int readStart,
+                                  const char* hap, int hapLen, int hapStart, int hapFlank,
+                                  int doFlank, int* n_dp)
+{
+    int16_t* table = (int16_t*)malloc(sizeof(int16_t) * HASH_SIZE);
+    int16_t* next = (int16_t*)malloc(sizeof(int16_t) * HASH_SIZE);
+    int16_t* rh = (int16_t*)malloc(sizeof(int16_t) * (size_t)(readLen > 7 ? readLen : 8));
+    char* go = (char*)malloc((size_t)hapLen + 1);
+    orc_hash_haplotype(hap, hapLen, table, next);
+    if (readLen >= HASH_NUCS) orc_hash_read(read, readLen, rh);
+    orc_gap_open(hap, hapLen, go);
+    int sc = orc_map_align(read, quals, readStart, hapStart, readLen, hapLen, table, next, rh, hap,
+                           3, 2, go, hapFlank, doFlank, n_dp);
+    free(table); free(next); free(rh); free(go);
+    return sc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a9: Haplotype.alignReads over a whole window  (src/cython/chaplotype.pyx:306-377)
+ *
+ * Reads are given as one concatenated list in the reference's order good -> bad -> broken
+ * (chaplotype.pyx:341-373).  kind[r]: 0 good, 1 bad, 2 brokenMate.  flags = BAM bitFlag
+ * (QCFail = 512, htslibWrapper.pxd:243).  out_ll[h*(nReads)+r]; the caller appends the 999
+ * sentinel.  out_score (optional) gets the raw integer score (-1 for skipped reads).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_align_window(int nHaps, const char* hapBlob, const int* hapOff, const int* hapLen,
+                              int hapStartPos /* Haplotype.startPos */, int hapEndPos, int endBuffer,
+                              int nReads, const char* seqBlob, const char* qualBlob, const int* readOff,
+                              const int* readLen, const int* readPos, const int* readEnd,
+                              const unsigned char* mapq, const int* flags, const unsigned char* kind,
+                              int doFlank, double* out_ll, int* out_score, long long* n_dp_total)
+{
+    int16_t* table = (int16_t*)malloc(sizeof(int16_t) * HASH_SIZE);
+    int16_t* next = (int16_t*)malloc(sizeof(int16_t) * HASH_SIZE);
+    long long ndp = 0;
+    for (int h = 0; h < nHaps; ++h) {
+        const char* hap = hapBlob + hapOff[h];
+        const int hl = hapLen[h];
+        char* go = (char*)malloc((size_t)hl + 1);
+        orc_hash_haplotype(hap, hl, table, next);
+        orc_gap_open(hap, hl, go);
+        for (int r = 0; r < nReads; ++r) {
+            const size_t o = (size_t)h * nReads + r;
+            int skip = 0;
+            if (kind[r] != 2) {                                      /* :343-346, :358-361 */
+                int os = hapStartPos > readPos[r] ? hapStartPos : readPos[r];
+                int oe = hapEndPos < readEnd[r] ? hapEndPos : readEnd[r];
+                int ov = oe > os ? oe - os : -1;                     /* chaplotype.pyx:103-115 */
+                if ((flags[r] & 512) || ov < HASH_NUCS) skip = 1;
+            }
+            if (skip) { out_ll[o] = 0.0; if (out_score) out_score[o] = -1; continue; }
+            const int rl = readLen[r];
+            int16_t* rh = (int16_t*)malloc(sizeof(int16_t) * (size_t)(rl > 7 ? rl : 8));
+            if (rl >= HASH_NUCS) orc_hash_read(seqBlob + readOff[r], rl, rh);
+            int nd = 0;
+            int sc = orc_map_align(seqBlob + readOff[r], qualBlob + readOff[r], readPos[r],
+                                   hapStartPos - endBuffer, rl, hl, table, next, rh, hap, 3, 2, go,
+                                   endBuffer, doFlank, &nd);
+            ndp += nd;
+            free(rh);
+            out_ll[o] = orc_loglik(sc, mapq[r]);
+            if (out_score) out_score[o] = sc;
+        }
+        free(go);
+    }
+    if (n_dp_total) *n_dp_total = ndp;
+    free(table); free(next);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a11: DiploidGenotype.calculateDataLikelihood  (src/cython/cgenotype.pyx:131-189)
+ * arr1/arr2: per-read log-likelihood arrays terminated by 999; same_hap = (hap1 is hap2).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API double orc_genotype_loglik(const double* arr1, const double* arr2, int same_hap,
+                                   int totalReads, int nGoodReads, double* gof,
+                                   double* hap1Like, double* hap2Like)
+{
+    const double log10E = 0.43429448190325182;      /* cgenotype.pyx:24 */
+    const double logHalf = -0.69314718055994529;    /* cgenotype.pyx:28 */
+    double likelihood = 0.0, g = 0.0, h1 = 0.0, h2 = 0.0;
+    for (int r = 0; r <= totalReads; ++r) {
+        double l1 = arr1[r], l2 = arr2[r];
+        if (l1 == 999 && l2 == 999) break;
+        double ll1 = log10E * l1, ll2 = log10E * l2;
+        h1 += ll1; h2 += ll2;
+        g += (ll1 > ll2 ? ll1 : ll2);
+        if (same_hap) likelihood += l1;
+        else if (fabs(l1 - l2) >= 3) likelihood += (logHalf + (l1 > l2 ? l1 : l2));
+        else if (fabs(l1 - l2) <= 1e-3) likelihood += l1;
+        else likelihood += log(0.5 * (exp(l1) + exp(l2)));
+    }
+    if (gof) *gof = nGoodReads > 0 ? (-10 * g) / nGoodReads : 0.0;
+    if (hap1Like) *hap1Like = h1;
+    if (hap2Like) *hap2Like = h2;
+    return likelihood;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a12: Population.setup for one individual  (src/cython/cpopulation.pyx:283-309)
+ * ll: [nHaps][totalReads+1] (999-terminated rows).  Genotypes in the order of
+ * generateAllGenotypesFromHaplotypeList (cgenotype.pyx:193-218): (i,j), i<=j.
+ * out_gl[g] = rescaled likelihood, out_logl[g] = raw log-likelihood, out_gof[g].
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_population_setup_ind(int nHaps, const double* ll, int totalReads, int nGoodReads,
+                                      double* out_logl, double* out_gl, double* out_gof)
+{
+    int g = 0;
+    double maxLL = -1e7;                                              /* cpopulation.pyx:288 */
+    const int stride = totalReads + 1;
+    for (int a = 0; a < nHaps; ++a)
+        for (int b = a; b < nHaps; ++b, ++g) {
+            if (nGoodReads == 0) { out_logl[g] = 1.0; out_gl[g] = 1.0; out_gof[g] = 0.0; continue; }
+            double L = orc_genotype_loglik(ll + (size_t)a * stride, ll + (size_t)b * stride, a == b,
+                                           totalReads, nGoodReads, &out_gof[g], NULL, NULL);
+            if (L > maxLL) maxLL = L;
+            out_logl[g] = L;
+        }
+    if (nGoodReads != 0)
+        for (int k = 0; k < g; ++k) {                                 /* :304-309 */
+            double v = exp(out_logl[k] - maxLL);
+            out_gl[k] = v > 1e-300 ? v : 1e-300;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a14-a18: coloured de-Bruijn assembler  (src/cython/assembler.pyx:73-1476)
+ * ------------------------------------------------------------------------------------------ */
+#define COL_REF 1
+#define COL_READ 2
+#define COL_BOTH 3
+
+typedef struct {
+    const char* seq;        /* k-mer bytes (points into ref / read blob), assembler.pyx:73-81 */
+    int colours, position;
+    int nEdges;
+    int edgeEnd[4];
+    double edgeW[4];
+    double weight;
+    char dfs;
+    int hnext;              /* hash chain */
+} ONode;
+
+typedef struct {
+    ONode* nodes; int nNodes, cap;      /* allNodes, insertion order (assembler.pyx:788) */
+    int* heads; int nHeads; int k;
+} OGraph;
+
+static unsigned kmer_hash(const char* s, int k) {
+    unsigned h = 2166136261u;
+    for (int i = 0; i < k; ++i) { h ^= (unsigned char)s[i]; h *= 16777619u; }
+    return h;
+}
+
+static OGraph* og_new(int k) {
+    OGraph* g = (OGraph*)calloc(1, sizeof(OGraph));
+    g->k = k; g->cap = 8192; g->nodes = (ONode*)malloc(sizeof(ONode) * g->cap);
+    g->nHeads = 1 << 16; g->heads = (int*)malloc(sizeof(int) * g->nHeads);
+    for (int i = 0; i < g->nHeads; ++i) g->heads[i] = -1;
+    return g;
+}
+static void og_free(OGraph* g) { free(g->nodes); free(g->heads); free(g); }
+
+/* DeBruijnGraph_InsertOrUpdateNode + NodeDict_FindOrInsert (assembler.pyx:668-797):
+ * identity = exact k bytes; new -> appended to allNodes; existing -> colours |=, weight += */
+static int og_touch(OGraph* g, const char* seq, int colour, int position, double weight) {
+    unsigned b = kmer_hash(seq, g->k) & (unsigned)(g->nHeads - 1);
+    for (int n = g->heads[b]; n >= 0; n = g->nodes[n].hnext)
+        if (g->nodes[n].seq == seq || strncmp(g->nodes[n].seq, seq, (size_t)g->k) == 0) {
+            g->nodes[n].colours |= colour;
+            g->nodes[n].weight += weight;
+            return n;
+        }
+    if (g->nNodes == g->cap) { g->cap *= 2; g->nodes = (ONode*)realloc(g->nodes, sizeof(ONode) * g->cap); }
+    ONode* nd = &g->nodes[g->nNodes];
+    memset(nd, 0, sizeof(*nd));
+    nd->seq = seq; nd->colours = colour; nd->position = position; nd->weight = weight; nd->dfs = 'N';
+    nd->hnext = g->heads[b]; g->heads[b] = g->nNodes;
+    return g->nNodes++;
+}
+
+/* DeBruijnGraph_AddEdge, assembler.pyx:801-827 */
+static void og_add_edge(OGraph* g, const char* s, const char* e, int colour, int ps, int pe, double w) {
+    int a = og_touch(g, s, colour, ps, w);
+    int b = og_touch(g, e, colour, pe, w);
+    ONode* A = &g->nodes[a];
+    for (int i = 0; i < 4; ++i) {
+        if (i >= A->nEdges) { A->edgeEnd[i] = b; A->edgeW[i] = w; A->nEdges++; return; }
+        if (A->edgeEnd[i] == b) { A->edgeW[i] += w; return; }
+    }
+    /* >4 distinct successors (non-ACGT bases only): silently dropped, :823-824 */
+}
+
+static void og_load(OGraph* g, const char* ref, int refLen, int refStart,
+                    int nReads, const char* seqBlob, const char* qualBlob, const int* off,
+                    const int* len, int minQual)
+{
+    const int k = g->k;
+    for (int i = 0; i < refLen - k - 1; ++i)                          /* loadReferenceIntoGraph :1295-1319 */
+        og_add_edge(g, ref + i, ref + i + 1, COL_REF, refStart + i, refStart + i + 1, 1.0);
+    for (int r = 0; r < nReads; ++r) {                                /* loadReadIntoGraph :1348-1387 */
+        const char* s = seqBlob + off[r]; const char* q = qualBlob + off[r];
+        for (int i = 0; i < len[r] - k - 1; ++i) {
+            int mq = 100000000, hasN = 0;
+            for (int j = i; j < i + k + 1; ++j) { if (q[j] < mq) mq = q[j]; if (s[j] == 'N') hasN = 1; }
+            if (mq >= minQual && !hasN) og_add_edge(g, s + i, s + i + 1, COL_READ, -1, -1, (double)mq);
+        }
+    }
+}
+
+/* dfsVisit / detectCyclesInGraph_Recursive, assembler.pyx:831-898 */
+static int og_dfs(OGraph* g, int n, double minWeight) {
+    ONode* nd = &g->nodes[n];
+    nd->dfs = 'g';
+    for (int i = 0; i < nd->nEdges; ++i) {
+        ONode* e = &g->nodes[nd->edgeEnd[i]];
+        if (e->colours == COL_READ && nd->edgeW[i] < minWeight) continue;
+        if (e->dfs == 'w') { if (og_dfs(g, nd->edgeEnd[i], minWeight)) return 1; }
+        else if (e->dfs == 'g') return 1;
+    }
+    nd->dfs = 'b';
+    return 0;
+}
+static int og_has_cycle(OGraph* g, double minWeight) {
+    for (int i = 0; i < g->nNodes; ++i) g->nodes[i].dfs = 'w';
+    for (int i = 0; i < g->nNodes; ++i)
+        if (g->nodes[i].dfs == 'w' && og_dfs(g, i, minWeight)) return 1;
+    return 0;
+}
+
+typedef struct { int* n; int len; } OPath;
+static OPath path_ext(const OPath* p, int node) {
+    OPath q; q.len = (p ? p->len : 0) + 1; q.n = (int*)malloc(sizeof(int) * q.len);
+    if (p) memcpy(q.n, p->n, sizeof(int) * p->len);
+    q.n[q.len - 1] = node; return q;
+}
+
+typedef struct { int pos, nrem, nadd, type; int roff, aoff; int seq; } OVar;
+
+/*
+ * orc_assemble: assembleReadsAndDetectVariants (assembler.pyx:1429-1476) for reads already
+ * selected/ordered as loadBAMDataIntoGraph does (:1391-1425; QCFail reads removed by the caller).
+ * Outputs, sorted as sorted(theVars) (Variant.__richcmp__ '<', variant.pyx:282-363):
+ *   out_pos[i], out_nrem[i], out_nadd[i], and out_blob holding removed||added per variant at
+ *   out_off[i].  Returns the number of variants, or -(needed) if capacity is too small.
+ * out_nnodes (optional) = node count of the final graph.
+ */
+ORC_API int orc_assemble(const char* ref, int refLen, int refStart, int assemStart, int assemEnd,
+                         int nReads, const char* seqBlob, const char* qualBlob, const int* off,
+                         const int* len, int kmerSize, int minQual, int minWeightI, int noCycles,
+                         int maxVars, int* out_pos, int* out_nrem, int* out_nadd, int* out_off,
+                         char* out_blob, int blobCap, int* out_nnodes)
+{
+    const double minWeight = (double)minWeightI;
+    int k = kmerSize;
+    OGraph* g = og_new(k);
+    og_load(g, ref, refLen, refStart, nReads, seqBlob, qualBlob, off, len, minQual);
+    int find = 1;
+    if (noCycles) {                                                   /* :1453-1471 */
+        while (og_has_cycle(g, minWeight)) {
+            if (k > 50) { find = 0; break; }
+            k += 5; og_free(g); g = og_new(k);
+            og_load(g, ref, refLen, refStart, nReads, seqBlob, qualBlob, off, len, minQual);
+        }
+    }
+    if (out_nnodes) *out_nnodes = g->nNodes;
+
+    int nv = 0, vcap = 64, blobUsed = 0, blobNeed = 0;
+    OVar* vars = (OVar*)malloc(sizeof(OVar) * vcap);
+    char* tmpblob = NULL; int tmpcap = 0;
+
+    /* findBubblesInGraph, assembler.pyx:1116-1177 */
+    for (int ni = 0; find && ni < g->nNodes; ++ni) {
+        ONode* nd = &g->nodes[ni];
+        if (!(nd->colours == COL_BOTH && nd->position >= assemStart && nd->position < assemEnd)) continue;
+        for (int ej = 0; ej < nd->nEdges; ++ej) {
+            if (g->nodes[nd->edgeEnd[ej]].colours != COL_READ) continue;
+            /* getVariantPathsThroughGraphFromNode, :1027-1112 */
+            OPath stack[64]; int top = 0;
+            OPath fin[64]; int nfin = 0;
+            int aborted = 0;
+            { OPath p0 = path_ext(NULL, ni); OPath p1 = path_ext(&p0, nd->edgeEnd[ej]); free(p0.n); stack[top++] = p1; }
+            while (top > 0) {
+                OPath p = stack[--top];
+                if (top > 20 || nfin > 20) { free(p.n); aborted = 1; break; }          /* :1052-1057 */
+                int cyc = 0;                                                           /* :999-1023 */
+                for (int a = 0; a < p.len; ++a) g->nodes[p.n[a]].dfs = 'w';
+                for (int a = 0; a < p.len; ++a) {
+                    if (g->nodes[p.n[a]].dfs == 'w') g->nodes[p.n[a]].dfs = 'g'; else { cyc = 1; break; }
+                }
+                ONode* end = &g->nodes[p.n[p.len - 1]];
+                if (cyc) { free(p.n); }
+                else if (end->colours == COL_BOTH) { fin[nfin++] = p; }
+                else if (end->colours == COL_REF) { free(p.n); }
+                else {
+                    for (int i = 0; i < end->nEdges; ++i) {                            /* :1091-1107 */
+                        int ne = end->edgeEnd[i];
+                        int c = g->nodes[ne].colours;
+                        if (end->edgeW[i] >= minWeight || c == COL_BOTH || c == COL_REF)
+                            stack[top++] = path_ext(&p, ne);
+                    }
+                    free(p.n);
+                }
+            }
+            if (aborted) {
+                for (int a = 0; a < top; ++a) free(stack[a].n);
+                for (int a = 0; a < nfin; ++a) free(fin[a].n);
+                continue;
+            }
+            for (int f = 0; f < nfin; ++f) {                          /* extractVarFromBubblePath :1196-1291 */
+                OPath p = fin[f];
+                int s = g->nodes[p.n[0]].position, t = g->nodes[p.n[p.len - 1]].position;
+                if (t >= s) {
+                    int rl = t - s + 1, al = p.len;
+                    const char* r = ref + (s - refStart);
+                    char* a = (char*)malloc((size_t)al + 1);
+                    for (int i = 0; i < al; ++i) a[i] = g->nodes[p.n[i]].seq[0];
+                    while (al > 0 && rl > 0 && r[rl - 1] == a[al - 1]) { --rl; --al; }   /* suffix first */
+                    int ao = 0;
+                    while (al > 0 && rl > 0 && r[0] == a[ao]) { ++r; ++ao; --rl; --al; ++s; }
+                    if (nv == vcap) { vcap *= 2; vars = (OVar*)realloc(vars, sizeof(OVar) * vcap); }
+                    if (blobUsed + rl + al > tmpcap) { tmpcap = (blobUsed + rl + al) * 2 + 256; tmpblob = (char*)realloc(tmpblob, (size_t)tmpcap); }
+                    OVar* v = &vars[nv];
+                    v->pos = s > 0 ? s : 0;                           /* variant.pyx:121 */
+                    v->nrem = rl; v->nadd = al; v->roff = blobUsed; v->aoff = blobUsed + rl; v->seq = nv;
+                    memcpy(tmpblob + blobUsed, r, (size_t)rl);
+                    memcpy(tmpblob + blobUsed + rl, a + ao, (size_t)al);
+                    blobUsed += rl + al;
+                    if (rl == al) v->type = (al == 1) ? 0 : 1;        /* variant.pyx:136-144 */
+                    else if (rl == 0) v->type = 2; else if (al == 0) v->type = 3; else v->type = 4;
+                    ++nv;
+                    free(a);
+                }
+                free(p.n);
+            }
+        }
+    }
+    og_free(g);
+
+    /* stable insertion sort by (pos, type, nRemoved)  -- sorted(), assembler.pyx:1476 */
+    for (int i = 1; i < nv; ++i) {
+        OVar v = vars[i]; int j = i - 1;
+        while (j >= 0 && (vars[j].pos > v.pos || (vars[j].pos == v.pos && (vars[j].type > v.type ||
+               (vars[j].type == v.type && vars[j].nrem > v.nrem))))) { vars[j + 1] = vars[j]; --j; }
+        vars[j + 1] = v;
+    }
+    blobNeed = blobUsed;
+    int ret = nv;
+    if (nv > maxVars || blobNeed > blobCap) ret = -(nv > 0 ? nv : 1);
+    else {
+        int o = 0;
+        for (int i = 0; i < nv; ++i) {
+            out_pos[i] = vars[i].pos; out_nrem[i] = vars[i].nrem; out_nadd[i] = vars[i].nadd; out_off[i] = o;
+            memcpy(out_blob + o, tmpblob + vars[i].roff, (size_t)(vars[i].nrem + vars[i].nadd));
+            o += vars[i].nrem + vars[i].nadd;
+        }
+    }
+    free(vars); free(tmpblob);
+    return ret;
+}

@@ -1,0 +1,133 @@
+"""CPU tests: pin the oracle (oracle/plat_oracle.c) to the reference.
+
+ * against the committed golden vectors (generated from the reference's own code by
+   tests/golden/gen_golden.py), and
+ * directly against the unmodified reference align.c when oracle/_ref/libalign_ref.so is present.
+"""
+import gzip
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle.oracle import RefAlign
+
+
+def test_dp_golden_scores(oracle, golden_dir):
+    g = np.load(os.path.join(golden_dir, "dp_cases.npz"))
+    got = oracle.dp_batch(g["haps"], g["reads"], g["quals"], g["gos"], g["lens"])
+    assert np.array_equal(got, g["score"])
+    assert len(got) >= 2000
+
+
+def test_dp_golden_traceback(oracle, golden_dir):
+    g = np.load(os.path.join(golden_dir, "dp_cases.npz"))
+    for n, j in enumerate(g["tb_idx"]):
+        L = int(g["lens"][j])
+        sc, a1, a2, fp = oracle.dp_align(g["haps"][j, :L + 15].tobytes(), g["reads"][j, :L].tobytes(),
+                                         g["quals"][j, :L].tobytes(), g["gos"][j, :L + 15].tobytes())
+        assert sc == g["score"][j]
+        assert a1.decode() == str(g["tb_aln1"][n]) and a2.decode() == str(g["tb_aln2"][n])
+        assert fp == g["tb_firstpos"][n]
+
+
+def test_dp_known_answers(oracle):
+    # exact match -> 0, one Q30 mismatch -> 30, 2-bp del -> 43, 2-bp ins -> 47, N in hap -> 0
+    rng = np.random.default_rng(1)
+    hap = bytes(rng.choice(list(b"ACGT"), 115).tolist())
+    go = bytes([40] * 115)
+    q = bytes([30] * 100)
+    read = hap[8:108]
+    assert oracle.dp_score(hap, read, q, go) == 0
+    r2 = bytearray(read); r2[50] = ord("A") if r2[50] != ord("A") else ord("C")
+    assert oracle.dp_score(hap, bytes(r2), q, go) == 30
+    h2 = bytearray(hap); h2[58] = ord("N")
+    assert oracle.dp_score(bytes(h2), bytes(r2), q, go) == 0
+
+
+@pytest.mark.skipif(not RefAlign.available(), reason="oracle/_ref not built (reference tree absent)")
+def test_dp_fuzz_against_reference_build(oracle):
+    ref = RefAlign()
+    rng = np.random.default_rng(99)
+    B = b"ACGT"
+    for it in range(1500):
+        L = int(rng.choice([7, 9, 25, 64, 101, 150, 250]))
+        hap = bytearray(rng.choice(list(B + b"N"), L + 15, p=[.24, .24, .24, .24, .04]).tolist())
+        off = int(rng.integers(0, 16))
+        read = bytearray(hap[off:off + L])
+        for _ in range(int(rng.integers(0, 6))):
+            read[int(rng.integers(0, L))] = B[int(rng.integers(0, 4))]
+        if L > 30 and rng.random() < 0.5:
+            p = int(rng.integers(5, L - 8)); k = int(rng.integers(1, 7))
+            read = (read[:p] + read[p + k:] + bytearray(rng.choice(list(B), k).tolist()))[:L]
+        q = bytes(rng.integers(0, 94, L).astype(np.uint8).tolist())
+        go = bytes(rng.integers(1, 46, L + 15).astype(np.uint8).tolist())
+        a = oracle.dp_align(bytes(hap), bytes(read), q, go)
+        b = ref.dp_align(bytes(hap), bytes(read), q, go)
+        assert a == b
+        assert oracle.dp_score(bytes(hap), bytes(read), q, go) == ref.dp_score(bytes(hap), bytes(read), q, go) == a[0]
+        if a[0] > 0:
+            fa = oracle.flank_score(L + 15, 20, q, go, a[3], a[1], a[2])
+            fb = ref.flank_score(L + 15, 20, q, go, b[3], b[1], b[2])
+            assert fa == fb
+
+
+def test_mapalign_golden(oracle, golden_dir):
+    cases = json.load(gzip.open(os.path.join(golden_dir, "mapalign_cases.json.gz"), "rt"))
+    assert len(cases) >= 500
+    for c in cases:
+        sc, _ = oracle.align_read_to_hap(c["read"].encode(), bytes(c["qual"]), c["readStart"], c["hap"].encode(),
+                                         c["hapStart"], c["flank"], c["doFlank"])
+        assert sc == c["score"]
+
+
+def test_assembler_golden(oracle, golden_dir):
+    cases = json.load(gzip.open(os.path.join(golden_dir, "assembler_cases.json.gz"), "rt"))
+    assert len(cases) >= 100
+    nvar = 0
+    for c in cases:
+        got, nn = oracle.assemble(c["ref"].encode(), c["refStart"], c["assemStart"], c["assemEnd"],
+                                  [s.encode() for s in c["seqs"]], [q.encode("latin1") for q in c["quals"]],
+                                  c["k"], c["minQual"], c["minWeight"], c["noCycles"])
+        exp = [(p, r.encode(), a.encode()) for p, r, a in c["variants"]]
+        assert got == exp
+        assert nn == c["nNodes"]
+        nvar += len(exp)
+    assert nvar > 100
+
+
+def test_gap_open_table_matches_reference_formula(oracle):
+    # chaplotype.pyx:64-67: homopolq = chr(int(33.5 + 10*log((idx+1)*q)/log(0.1))) ; gap-open = char - '!'
+    errs = [2.9e-5, 2.9e-5, 2.9e-5, 2.9e-5, 4.3e-5, 1.1e-4, 2.4e-4, 5.7e-4, 1.0e-3, 1.4e-3] + \
+           [1.4e-3 + 4.3e-4 * (n - 10) for n in range(11, 50)]
+    table = [int(33.5 + 10 * math.log((i + 1) * q) / math.log(0.1)) - 33 for i, q in enumerate(errs)]
+    assert len(table) == 49
+    # a homopolymer run of 60 A's exposes the whole table (run length to the right, capped at 48)
+    go = oracle.gap_open(b"C" + b"A" * 60 + b"G")
+    assert go[-1] == 0
+    assert list(go[1:61]) == [table[min(59 - i, 48)] for i in range(60)]
+    assert go[0] == table[0] and go[61] == table[0]
+    # 'N' resets the run (chaplotype.pyx:588-590)
+    go = oracle.gap_open(b"ANNNA")
+    assert list(go[:5]) == [table[0]] * 5
+
+
+def test_loglik_known_answers(oracle):
+    assert oracle.loglik(0, 60) == math.log(1.0 - 1e-6) or abs(oracle.loglik(0, 60) - math.log(1 - 1e-6)) < 1e-15
+    assert oracle.loglik(0, 0) == -300.0
+    assert oracle.loglik(10, 60) == -0.23025850929940459 * 10 + math.log(1.0 - math.exp(-0.23025850929940459 * 60))
+    assert oracle.loglik(5000, 60) == -300.0
+
+
+def test_genotype_known_answers(oracle):
+    a = np.array([-1.0, -2.0, -0.5, 999.0])
+    b = np.array([-5.0, -2.0005, -1.5, 999.0])
+    L, gof, h1, h2 = oracle.genotype_loglik(a, a, True, 3)
+    assert L == (-1.0 + -2.0) + -0.5
+    L, gof, h1, h2 = oracle.genotype_loglik(a, b, False, 3)
+    exp = (math.log(0.5) + -1.0) + (-2.0) + math.log(0.5 * (math.exp(-0.5) + math.exp(-1.5)))
+    assert abs(L - exp) < 1e-14
+    log10e = 0.43429448190325182
+    assert abs(gof - (-10 * (log10e * -1.0 + log10e * -2.0 + log10e * -0.5)) / 3) < 1e-14
