@@ -1,0 +1,192 @@
+/*
+ * platypus_mi355x.h -- C ABI of libplat_mi355x.so
+ *
+ * MI355X-native (gfx950, hand-written HIP) replacement for the read->haplotype likelihood and
+ * local-assembly hot path of andyrimmer/Platypus v0.8.1.1.  Every entry point names the reference
+ * interface it replaces (file:line relative to the reference tree).  Plain C, plain pointers and
+ * sizes, no C++/torch types; intended to be bound with cgo / JNI / ctypes / Cython `cdef extern`
+ * (see INTEGRATION.md for the Cython stub a Platypus maintainer would add).
+ *
+ * Conventions
+ *  - every function returns int: 0 = PLAT_OK, negative = error (plat_strerror()).  No exceptions
+ *    cross the boundary (the reference raises Python exceptions: chaplotype.pyx:325-334,585-586).
+ *  - all *batch* entry points take DEVICE pointers (HBM-resident; obtain with plat_malloc or pass
+ *    e.g. torch.Tensor.data_ptr()) and a `stream` (hipStream_t as void*; NULL = default stream).
+ *    They enqueue work and return; call plat_stream_sync() (or synchronise the stream yourself)
+ *    before reading results.  Exceptions are flagged "[syncs]".
+ *  - byte blobs (sequences, qualities) are 7-bit ASCII exactly as the reference holds them in
+ *    cAlignedRead.seq / .qual (raw phred, NOT +33; htslibWrapper.pyx:366-368) and
+ *    Haplotype.cHaplotypeSequence.  Every blob must be followed by >= PLAT_BLOB_PAD readable bytes.
+ *  - the caller owns all buffers it passes; the context owns only its internal scratch.
+ *  - a context is bound to one GPU and is not thread-safe (the reference is single-threaded per
+ *    process: SURVEY.md 8(b)); use one context per process/rank.
+ */
+#ifndef PLATYPUS_MI355X_H
+#define PLATYPUS_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLAT_ABI_VERSION 1
+#define PLAT_BLOB_PAD 32
+
+/* error codes */
+#define PLAT_OK 0
+#define PLAT_ERR_INVALID (-1)       /* bad argument (NULL pointer, negative size, ...)              */
+#define PLAT_ERR_HIP (-2)           /* HIP runtime error; plat_last_hip_error() has the code        */
+#define PLAT_ERR_NOMEM (-3)         /* device allocation failed ("Out of memory in cHaplotype.alignReads") */
+#define PLAT_ERR_HAP_TOO_LONG (-4)  /* haplotype longer than 16384 (chaplotype.pyx:180-183)         */
+#define PLAT_ERR_HAP_TOO_SHORT (-5) /* hapLen < readLen+15: the reference reads past the buffer here */
+#define PLAT_ERR_UNSUPPORTED (-6)   /* option combination not implemented on the device path         */
+#define PLAT_ERR_NO_DEVICE (-7)     /* no gfx950 device / HIP runtime unavailable                    */
+#define PLAT_ERR_OVERFLOW (-8)      /* an output capacity given by the caller was too small          */
+#define PLAT_ERR_BAD_INPUT (-9)     /* device-side input validation failed (non-ASCII byte, ...)     */
+
+typedef struct plat_ctx plat_ctx;
+
+/* ---- context & memory ------------------------------------------------------------------------- */
+int plat_abi_version(void);
+const char* plat_strerror(int code);
+int plat_device_count(int* out_count);
+int plat_ctx_create(int device, plat_ctx** out_ctx);
+int plat_ctx_destroy(plat_ctx* ctx);
+int plat_last_hip_error(const plat_ctx* ctx);               /* hipError_t of the last PLAT_ERR_HIP   */
+int plat_malloc(plat_ctx* ctx, size_t bytes, void** out_dev_ptr);
+int plat_free(plat_ctx* ctx, void* dev_ptr);
+int plat_memcpy_h2d(plat_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int plat_memcpy_d2h(plat_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int plat_memset(plat_ctx* ctx, void* dst_dev, int value, size_t bytes, void* stream);
+int plat_stream_sync(plat_ctx* ctx, void* stream);          /* [syncs] */
+
+/* ---- a1: fastAlignmentRoutine, score only -------------------------------------------------------
+ * Replaces  int fastAlignmentRoutine(seq1, seq2, qual2, len1, len2, gapextend, nucprior,
+ *                                    localgapopen, aln1=NULL, aln2=NULL, firstpos)
+ *           src/c/align.h:8-10, src/c/align.c:77-586  (called from calign.pyx:232,258)
+ * for n independent DP instances in padded rows:
+ *   hap_slices [n][lmax+15], reads [n][lmax], quals [n][lmax], gapopen [n][lmax+15], len2 [n]
+ *   (7 <= len2[i] <= lmax; rows need no particular alignment).  out_score [n].
+ * The returned score is bit-identical to the reference's (8 x int16 wrapping lanes).          */
+int plat_dp_batch(plat_ctx* ctx, int n, int lmax,
+                  const uint8_t* hap_slices, const uint8_t* reads, const uint8_t* quals,
+                  const uint8_t* gapopen, const int32_t* len2, int gapextend, int nucprior,
+                  int32_t* out_score, void* stream);
+
+/* ---- a3..a10: Haplotype.alignReads / alignSingleRead for whole windows -------------------------
+ * Replaces, for every haplotype of every window in the batch,
+ *   cdef double* Haplotype.alignReads(individualIndex, start,end, badStart,badEnd, brokenStart,
+ *        brokenEnd, useMapQualCap)                       chaplotype.pxd:44, chaplotype.pyx:306-377
+ *   cdef double  Haplotype.alignSingleRead(read, useMapQualCap)            chaplotype.pyx:379-384
+ * including hash_sequence_multihit / hashReadForMapping / mapAndAlignReadToHaplotype
+ * (calign.pyx:94-272), annotateWithGapOpen (chaplotype.pyx:552-590) and the score -> log
+ * likelihood transform (chaplotype.pyx:621-676, standard mode).
+ *
+ * Ragged (CSR) layout, all arrays in device memory:
+ *   windows  w in [0,n_windows):  haplotypes  win_hap_begin[w]..win_hap_begin[w+1]
+ *                                 reads       win_read_begin[w]..win_read_begin[w+1]
+ *                                 win_start[w], win_end[w] = Haplotype.startPos / endPos
+ *                                 win_flank[w]             = Haplotype.endBufferSize
+ *                                 pair_off[w]  = offset of the window's output block (int64)
+ *   haplotypes h: bytes hap_seq[hap_off[h] .. hap_off[h+1])   (Haplotype.cHaplotypeSequence)
+ *   reads r (reference order good -> bad -> brokenMates per sample, chaplotype.pyx:341-373):
+ *       seq/qual bytes read_seq|read_qual[read_off[r] .. read_off[r+1]),
+ *       read_pos[r], read_end[r] (cAlignedRead.pos/.end), read_mapq[r], read_flags[r] (bitFlag),
+ *       read_kind[r] 0 = reads, 1 = badReads, 2 = brokenMates.
+ * Output: out_loglik[pair_off[w] + hl*R_w + rl] for local haplotype hl, local read rl -- exactly
+ * the concatenation of the per-haplotype likelihoodCache arrays without the 999 terminator
+ * (0.0 for QCFail / overlap<7 reads, chaplotype.pyx:343-346).  out_score (optional, may be NULL)
+ * receives the integer alignment score (-1 for skipped reads).
+ * Options: calc_flank_score (runner.py:559, default 0) and use_mapq_cap (HLATyping) must be 0 in
+ * this version (PLAT_ERR_UNSUPPORTED otherwise).
+ * [syncs] once internally (job-count read-back).                                                 */
+typedef struct plat_window_batch {
+    int32_t n_windows, n_haps, n_reads, _pad;
+    const int32_t* win_hap_begin;   /* [n_windows+1] */
+    const int32_t* win_read_begin;  /* [n_windows+1] */
+    const int32_t* win_start;       /* [n_windows] */
+    const int32_t* win_end;         /* [n_windows] */
+    const int32_t* win_flank;       /* [n_windows] */
+    const int64_t* pair_off;        /* [n_windows+1] */
+    const uint8_t* hap_seq;         /* blob */
+    const int64_t* hap_off;         /* [n_haps+1] */
+    const uint8_t* read_seq;        /* blob */
+    const uint8_t* read_qual;       /* blob, same offsets */
+    const int64_t* read_off;        /* [n_reads+1] */
+    const int32_t* read_pos;        /* [n_reads] */
+    const int32_t* read_end;        /* [n_reads] */
+    const uint8_t* read_mapq;       /* [n_reads] */
+    const int32_t* read_flags;      /* [n_reads] */
+    const uint8_t* read_kind;       /* [n_reads] */
+} plat_window_batch;
+
+typedef struct plat_align_stats {
+    int64_t n_pairs;          /* read x haplotype pairs in the batch                                  */
+    int64_t n_pairs_aligned;  /* pairs not skipped by the QCFail / overlap<7 rule                     */
+    int64_t n_dp_launched;    /* banded DPs the device actually ran                                    */
+    int64_t n_dp_reference;   /* fastAlignmentRoutine calls the reference would have made             */
+    int64_t cells_reference;  /* sum over those calls of 16*len2 (the GCUPS numerator)   */
+    int64_t cells_launched;   /* sum over launched DPs of 16*len2                                      */
+} plat_align_stats;
+
+int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* batch, int calc_flank_score,
+                            int use_mapq_cap, double* out_loglik, int32_t* out_score,
+                            plat_align_stats* out_stats /* host, may be NULL */, void* stream);
+
+/* ---- a11/a12: DiploidGenotype.calculateDataLikelihood + Population.setup ------------------------
+ * Replaces  cdef double DiploidGenotype.calculateDataLikelihood(...)   cgenotype.pxd:14, .pyx:131-189
+ *           cdef void   Population.setup(...)  (likelihood part)     cpopulation.pyx:283-309
+ * Consumes the array written by plat_align_window_batch.  Individuals: the reads of window w are
+ * segmented per individual by seg_read_begin[(w*n_ind + i)] .. [+1] (absolute read indices, must
+ * tile win_read_begin) and seg_n_good[w*n_ind+i] = number of `reads` (good) entries
+ * (bamReadBuffer.reads.windowEnd - windowStart, cpopulation.pyx:286).
+ * Genotypes of a window are all unordered haplotype pairs (i<=j) in the order of
+ * generateAllGenotypesFromHaplotypeList (cgenotype.pyx:193-218); G_w = H_w(H_w+1)/2;
+ * gl_off[w] = offset of the window's block in units of genotypes*individuals:
+ *   out_gl  [gl_off[w] + i*G_w + g]  = Population.genotypeLikelihoods[i][g] (rescaled, max 1.0)
+ *   out_logl[same index]             = raw log-likelihood from calculateDataLikelihood
+ *   out_gof [gl_off[w] + g*n_ind + i]= Population.goodnessOfFitValues[g][i]
+ * Sums run over reads in index order, in fp64, without FMA contraction.                          */
+int plat_genotype_window_batch(plat_ctx* ctx, const plat_window_batch* batch, int n_ind,
+                               const int32_t* seg_read_begin, const int32_t* seg_n_good,
+                               const double* loglik, const int64_t* gl_off,
+                               double* out_gl, double* out_logl, double* out_gof, void* stream);
+
+/* ---- a14..a18: assembleReadsAndDetectVariants ---------------------------------------------------
+ * Replaces  cdef list assembleReadsAndDetectVariants(chrom, assemStart, assemEnd, refStart, refEnd,
+ *                                                    readBuffers, refSeq, options)
+ *           assembler.pxd:3, assembler.pyx:1429-1476
+ * for n_regions independent assembly tiles.  Reads of a region are those loadBAMDataIntoGraph
+ * (assembler.pyx:1391-1425) would load, in its order, QCFail reads already removed.
+ *   region g: reference bytes ref_seq[ref_off[g]..ref_off[g+1]) starting at genome coordinate
+ *             ref_start[g]; assembly interval [assem_start[g], assem_end[g]);
+ *             reads reg_read_begin[g]..reg_read_begin[g+1].
+ * Options: kmer_size (assemblerKmerSize, 15), min_qual (minBaseQual, 20), min_weight
+ * (minReads*minBaseQual, 40), no_cycles (noCycles, 0).
+ * Output (device): per region up to max_vars_per_region variants, in the reference's sorted()
+ * order: var_count[g]; var_pos/var_nrem/var_nadd [g*max_vars+i]; removed||added bytes at
+ * var_blob[g*blob_per_region + var_off[g*max_vars+i]].  status[g] = 0 or PLAT_ERR_OVERFLOW.     */
+typedef struct plat_assembly_batch {
+    int32_t n_regions, n_reads;
+    const uint8_t* ref_seq;
+    const int64_t* ref_off;          /* [n_regions+1] */
+    const int32_t* ref_start;        /* [n_regions] */
+    const int32_t* assem_start;      /* [n_regions] */
+    const int32_t* assem_end;        /* [n_regions] */
+    const int32_t* reg_read_begin;   /* [n_regions+1] */
+    const uint8_t* read_seq;
+    const uint8_t* read_qual;
+    const int64_t* read_off;         /* [n_reads+1] */
+} plat_assembly_batch;
+
+int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* batch, int kmer_size, int min_qual,
+                        int min_weight, int no_cycles, int max_vars_per_region, int blob_per_region,
+                        int32_t* var_count, int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd,
+                        int32_t* var_off, uint8_t* var_blob, int32_t* status, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLATYPUS_MI355X_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of libplat_mi355x.so (include/platypus_mi355x.h).
+
+The HIP library is the product path.  There is NO CPU fallback: if the shared object is missing it is
+built with hipcc (gfx950); if that is impossible, or if no GPU is present when a device entry point is
+called, an exception is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libplat_mi355x.so")
+CSRC = os.path.join(HERE, "csrc")
+
+PLAT_BLOB_PAD = 32
+PLAT_ABI_VERSION = 1
+
+ERRORS = {
+    0: "PLAT_OK", -1: "PLAT_ERR_INVALID", -2: "PLAT_ERR_HIP", -3: "PLAT_ERR_NOMEM", -4: "PLAT_ERR_HAP_TOO_LONG",
+    -5: "PLAT_ERR_HAP_TOO_SHORT", -6: "PLAT_ERR_UNSUPPORTED", -7: "PLAT_ERR_NO_DEVICE", -8: "PLAT_ERR_OVERFLOW",
+    -9: "PLAT_ERR_BAD_INPUT",
+}
+
+
+class PlatypusDeviceError(RuntimeError):
+    def __init__(self, code, msg, where=""):
+        self.code = code
+        super().__init__("%s%s (%d): %s" % (where + ": " if where else "", ERRORS.get(code, "?"), code, msg))
+
+
+class WindowBatch(C.Structure):
+    _fields_ = [("n_windows", C.c_int32), ("n_haps", C.c_int32), ("n_reads", C.c_int32), ("_pad", C.c_int32),
+                ("win_hap_begin", C.c_void_p), ("win_read_begin", C.c_void_p), ("win_start", C.c_void_p),
+                ("win_end", C.c_void_p), ("win_flank", C.c_void_p), ("pair_off", C.c_void_p),
+                ("hap_seq", C.c_void_p), ("hap_off", C.c_void_p), ("read_seq", C.c_void_p),
+                ("read_qual", C.c_void_p), ("read_off", C.c_void_p), ("read_pos", C.c_void_p),
+                ("read_end", C.c_void_p), ("read_mapq", C.c_void_p), ("read_flags", C.c_void_p),
+                ("read_kind", C.c_void_p)]
+
+
+class AlignStats(C.Structure):
+    _fields_ = [("n_pairs", C.c_int64), ("n_pairs_aligned", C.c_int64), ("n_dp_launched", C.c_int64),
+                ("n_dp_reference", C.c_int64), ("cells_reference", C.c_int64), ("cells_launched", C.c_int64)]
+
+
+class AssemblyBatch(C.Structure):
+    _fields_ = [("n_regions", C.c_int32), ("n_reads", C.c_int32), ("ref_seq", C.c_void_p), ("ref_off", C.c_void_p),
+                ("ref_start", C.c_void_p), ("assem_start", C.c_void_p), ("assem_end", C.c_void_p),
+                ("reg_read_begin", C.c_void_p), ("read_seq", C.c_void_p), ("read_qual", C.c_void_p),
+                ("read_off", C.c_void_p)]
+
+
+# symbol -> (restype, argtypes): exactly the declarations of include/platypus_mi355x.h
+SIGNATURES = {
+    "plat_abi_version": (C.c_int, []),
+    "plat_strerror": (C.c_char_p, [C.c_int]),
+    "plat_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "plat_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "plat_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "plat_last_hip_error": (C.c_int, [C.c_void_p]),
+    "plat_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "plat_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "plat_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "plat_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "plat_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "plat_stream_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "plat_dp_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "plat_align_window_batch": (C.c_int, [C.c_void_p, C.POINTER(WindowBatch), C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.POINTER(AlignStats), C.c_void_p]),
+    "plat_genotype_window_batch": (C.c_int, [C.c_void_p, C.POINTER(WindowBatch), C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]),
+    "plat_assemble_batch": (C.c_int, [C.c_void_p, C.POINTER(AssemblyBatch), C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libplat_mi355x.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose:
+        print(r.stdout)
+    if r.returncode != 0:
+        raise RuntimeError("building libplat_mi355x.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def load():
+    """Load the HIP library (building it first if needed).  Never falls back to a CPU implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here == the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.plat_abi_version() != PLAT_ABI_VERSION:
+        raise RuntimeError("libplat_mi355x.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code, where=""):
+    if code != 0:
+        msg = load().plat_strerror(code).decode()
+        raise PlatypusDeviceError(code, msg, where)

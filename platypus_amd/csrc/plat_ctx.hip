@@ -1,0 +1,107 @@
+// plat_ctx.hip -- context, memory helpers and error strings of libplat_mi355x.so.
+#include <math.h>
+
+#include "plat_internal.hpp"
+
+PLAT_EXPORT int plat_abi_version(void) { return PLAT_ABI_VERSION; }
+
+PLAT_EXPORT const char* plat_strerror(int code) {
+    switch (code) {
+        case PLAT_OK: return "ok";
+        case PLAT_ERR_INVALID: return "invalid argument";
+        case PLAT_ERR_HIP: return "HIP runtime error (see plat_last_hip_error)";
+        case PLAT_ERR_NOMEM: return "out of device memory";
+        case PLAT_ERR_HAP_TOO_LONG: return "haplotype is too long (max allowed length is 16384)";
+        case PLAT_ERR_HAP_TOO_SHORT: return "haplotype shorter than read length + 15";
+        case PLAT_ERR_UNSUPPORTED: return "option not supported by the device path";
+        case PLAT_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case PLAT_ERR_OVERFLOW: return "output capacity too small";
+        case PLAT_ERR_BAD_INPUT: return "input failed device-side validation";
+        default: return "unknown error";
+    }
+}
+
+PLAT_EXPORT int plat_device_count(int* out_count) {
+    if (!out_count) return PLAT_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *out_count = 0; return PLAT_ERR_NO_DEVICE; }
+    *out_count = n;
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_ctx_create(int device, plat_ctx** out_ctx) {
+    if (!out_ctx) return PLAT_ERR_INVALID;
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return PLAT_ERR_NO_DEVICE;
+    plat_ctx* ctx = new plat_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return PLAT_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return PLAT_ERR_NO_DEVICE; }
+    ctx->n_cu = prop.multiProcessorCount;
+    ctx->lds_max = prop.sharedMemPerBlock;
+    // probMapRight table: host libm, identical to the reference's own log/exp (chaplotype.pyx:621)
+    double lut[256];
+    const double mLTOT = -0.23025850929940459;
+    for (int q = 0; q < 256; ++q) lut[q] = log(1.0 - exp(mLTOT * q));
+    hipError_t e = hipMalloc(&ctx->d_mapq_lut, sizeof(lut));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_mapq_lut, lut, sizeof(lut), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_readback, 64 * sizeof(int64_t));
+    if (e != hipSuccess) { delete ctx; return PLAT_ERR_HIP; }
+    *out_ctx = ctx;
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_ctx_destroy(plat_ctx* ctx) {
+    if (!ctx) return PLAT_ERR_INVALID;
+    hipError_t e;
+    plat_scratch* all[] = {&ctx->go_blob, &ctx->pair_rec, &ctx->jobs, &ctx->job_score, &ctx->counters};
+    for (plat_scratch* s : all)
+        if (s->ptr) { e = hipFree(s->ptr); (void)e; }
+    if (ctx->d_mapq_lut) { e = hipFree(ctx->d_mapq_lut); (void)e; }
+    if (ctx->h_readback) { e = hipHostFree(ctx->h_readback); (void)e; }
+    delete ctx;
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_last_hip_error(const plat_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+
+PLAT_EXPORT int plat_malloc(plat_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return PLAT_ERR_INVALID;
+    *out = nullptr;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    PLAT_HIP(ctx, hipMalloc(out, bytes ? bytes : 1));
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_free(plat_ctx* ctx, void* p) {
+    if (!ctx) return PLAT_ERR_INVALID;
+    if (p) PLAT_HIP(ctx, hipFree(p));
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_memcpy_h2d(plat_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return PLAT_ERR_INVALID;
+    if (bytes) PLAT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_memcpy_d2h(plat_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return PLAT_ERR_INVALID;
+    if (bytes) PLAT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_memset(plat_ctx* ctx, void* dst, int value, size_t bytes, void* stream) {
+    if (!ctx || (!dst && bytes)) return PLAT_ERR_INVALID;
+    if (bytes) PLAT_HIP(ctx, hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_stream_sync(plat_ctx* ctx, void* stream) {
+    if (!ctx) return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return PLAT_OK;
+}

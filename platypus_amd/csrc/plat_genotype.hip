@@ -1,0 +1,95 @@
+// plat_genotype.hip -- DiploidGenotype.calculateDataLikelihood + the likelihood part of Population.setup
+// (cgenotype.pyx:131-189, cpopulation.pyx:283-309) on the device.
+//
+// One wave per (window, individual); lane g owns genotype g (looping when G > 64) and walks the
+// individual's reads IN INDEX ORDER in fp64 (no FMA contraction: built with -ffp-contract=off), so the
+// sums are the reference's sums.  Only the rarely taken branch log(0.5*(exp(l1)+exp(l2))) and the
+// final exp() rescale go through the device libm instead of glibc (difference <= a few ulp).
+#include "plat_internal.hpp"
+
+namespace plat {
+
+__global__ void __launch_bounds__(64)
+k_genotype(plat_window_batch b, int n_ind, const int32_t* __restrict__ seg_read_begin,
+           const int32_t* __restrict__ seg_n_good, const double* __restrict__ loglik,
+           const int64_t* __restrict__ gl_off, double* __restrict__ out_gl, double* __restrict__ out_logl,
+           double* __restrict__ out_gof)
+{
+    const int w = blockIdx.x / n_ind, ind = blockIdx.x % n_ind;
+    const int lane = threadIdx.x;
+    const int H = b.win_hap_begin[w + 1] - b.win_hap_begin[w];
+    const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
+    const int G = H * (H + 1) / 2;
+    if (G == 0) return;
+    const long long seg = (long long)w * n_ind + ind;
+    const int s0 = seg_read_begin[seg] - rb, s1 = seg_read_begin[seg + 1] - rb;
+    const int nGood = seg_n_good[seg];
+    const double* ll = loglik + b.pair_off[w];
+    const long long gbase = gl_off[w];
+    const double log10E = 0.43429448190325182;      // cgenotype.pyx:24
+    const double logHalf = -0.69314718055994529;    // cgenotype.pyx:28
+
+    double mymax = -1e7;                            // cpopulation.pyx:288
+    for (int g0 = 0; g0 < G; g0 += 64) {
+        const int g = g0 + lane;
+        if (g < G) {
+            // genotype g -> (a, b), a <= b, in the order of cgenotype.pyx:212-216
+            int a = 0, rem = g;
+            while (rem >= H - a) { rem -= H - a; ++a; }
+            const int bb = a + rem;
+            double L = 1.0, gof = 0.0;
+            if (nGood != 0) {                       // cpopulation.pyx:293
+                const double* arr1 = ll + (long long)a * R;
+                const double* arr2 = ll + (long long)bb * R;
+                double like = 0.0, gsum = 0.0;
+                for (int r = s0; r < s1; ++r) {     // cgenotype.pyx:151-180
+                    const double l1 = arr1[r], l2 = arr2[r];
+                    const double ll1 = log10E * l1, ll2 = log10E * l2;
+                    gsum += (ll1 > ll2 ? ll1 : ll2);
+                    if (a == bb) like += l1;
+                    else if (fabs(l1 - l2) >= 3) like += (logHalf + (l1 > l2 ? l1 : l2));
+                    else if (fabs(l1 - l2) <= 1e-3) like += l1;
+                    else like += log(0.5 * (exp(l1) + exp(l2)));
+                }
+                L = like;
+                gof = (-10 * gsum) / nGood;         // cgenotype.pyx:182-183
+                if (L > mymax) mymax = L;
+            }
+            out_logl[gbase + (long long)ind * G + g] = L;
+            out_gof[gbase + (long long)g * n_ind + ind] = gof;
+        }
+    }
+    for (int s = 32; s > 0; s >>= 1) {
+        double o = __shfl_xor(mymax, s);
+        mymax = o > mymax ? o : mymax;
+    }
+    for (int g = lane; g < G; g += 64) {            // cpopulation.pyx:304-309
+        const long long o = gbase + (long long)ind * G + g;
+        double v = 1.0;
+        if (nGood != 0) {
+            v = exp(out_logl[o] - mymax);
+            v = v > 1e-300 ? v : 1e-300;
+        }
+        out_gl[o] = v;
+    }
+}
+
+}  // namespace plat
+
+PLAT_EXPORT int plat_genotype_window_batch(plat_ctx* ctx, const plat_window_batch* batch, int n_ind,
+                                           const int32_t* seg_read_begin, const int32_t* seg_n_good,
+                                           const double* loglik, const int64_t* gl_off, double* out_gl,
+                                           double* out_logl, double* out_gof, void* stream)
+{
+    if (!ctx || !batch || n_ind <= 0) return PLAT_ERR_INVALID;
+    if (batch->n_windows == 0) return PLAT_OK;
+    if (!seg_read_begin || !seg_n_good || !loglik || !gl_off || !out_gl || !out_logl || !out_gof)
+        return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    const long long nblk = (long long)batch->n_windows * n_ind;
+    if (nblk > 0x7FFFFFFFll) return PLAT_ERR_INVALID;
+    hipLaunchKernelGGL(plat::k_genotype, dim3((unsigned)nblk), dim3(64), 0, (hipStream_t)stream, *batch, n_ind,
+                       seg_read_begin, seg_n_good, loglik, gl_off, out_gl, out_logl, out_gof);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}

@@ -1,0 +1,163 @@
+"""Synthetic workloads of BASELINE.json `configs`, generated in memory.
+
+The generator reproduces what reaches the kernel in the reference: haplotype byte
+strings `ref[start-buf:start) + mutated(start,end) + ref[end:end+buf)` with buf = min(2*rlen, 500)
+(chaplotype.pyx:142,165-172), and per-window read slices in buffer order (reads sorted by position,
+then badReads; cwindow.pyx:208-236,748-759).  All randomness is numpy PCG64 with fixed seeds.
+"""
+import numpy as np
+
+from .batch import BAM_FQCFAIL, KIND_BAD, KIND_GOOD, HostBatch
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _rand_bases(rng, shape):
+    return ACGT[rng.integers(0, 4, size=shape)]
+
+
+def _other_base(rng, base):
+    """A uniformly random base different from `base` (uint8 arrays of ACGT)."""
+    idx = np.searchsorted(ACGT, base)          # ACGT is sorted
+    return ACGT[(idx + rng.integers(1, 4, size=base.shape)) % 4]
+
+
+def make_snp_windows(n_windows, seed, read_len=150, depth=30, n_ind=1, ref_len=1200, max_snps=3,
+                     cluster=40, min_var_dist=9, err=1e-3, frac_bad=0.02, hap_freq_beta=None):
+    """Config-2 style windows: 1..max_snps SNPs in a `cluster`-bp cluster, all 2^n haplotypes
+    (the `nVars <= log2(maxHaplotypes-1)` branch, variantFilter.pyx:411-438), window = cluster +- 9
+    (minVarDist), `read_len` reads at `depth`x per individual, diploid truth, 0.1% substitution errors,
+    quals ~ clipped N(35,5) -> [2,41], `frac_bad` of reads with mapq < 20 (-> badReads, QCFail)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nW = n_windows
+    buf = min(2 * read_len, 500)                                   # chaplotype.pyx:142
+    ref = _rand_bases(rng, (nW, ref_len))
+    nvar = rng.integers(1, max_snps + 1, size=nW)
+    cs = rng.integers(ref_len // 2 - cluster, ref_len // 2, size=nW)
+    # distinct sorted SNP offsets inside the cluster
+    offs = np.sort(np.argsort(rng.random((nW, cluster)), axis=1)[:, :max_snps], axis=1)
+    snp_pos = cs[:, None] + offs                                   # [nW, max_snps]; first nvar[w] are used
+    # use the first nvar columns: re-sort so the used ones are ascending
+    for w in np.nonzero(nvar < max_snps)[0]:
+        snp_pos[w, :nvar[w]] = np.sort(snp_pos[w, :nvar[w]])
+    snp_alt = _other_base(rng, np.take_along_axis(ref, snp_pos, axis=1))
+    first = snp_pos[:, 0]
+    last = snp_pos[np.arange(nW), nvar - 1]
+    wstart = (first - min_var_dist).astype(np.int32)
+    wend = (last + min_var_dist + 1).astype(np.int32)
+    H = (1 << nvar).astype(np.int64)
+    hap_len = (wend - wstart + 2 * buf).astype(np.int64)
+
+    # ---- haplotypes: combination c (bit k set = SNP k alt), c = 0 is the reference haplotype
+    nH = int(H.sum())
+    win_hap_begin = np.concatenate([[0], np.cumsum(H)]).astype(np.int32)
+    hap_w = np.repeat(np.arange(nW), H)
+    hap_c = np.arange(nH) - win_hap_begin[hap_w]
+    hlen = hap_len[hap_w]
+    hap_off = np.concatenate([[0], np.cumsum(hlen)]).astype(np.int64)
+    hap_seq = np.empty(int(hap_off[-1]), dtype=np.uint8)
+    # gather ref[w, wstart-buf + j]
+    pos_in = np.arange(int(hap_off[-1])) - np.repeat(hap_off[:-1], hlen)
+    src = np.repeat((wstart[hap_w] - buf).astype(np.int64), hlen) + pos_in
+    hap_seq[:] = ref[np.repeat(hap_w, hlen), src]
+    for k in range(max_snps):
+        sel = np.nonzero((k < nvar[hap_w]) & (((hap_c >> k) & 1) == 1))[0]
+        p = hap_off[sel] + (snp_pos[hap_w[sel], k] - (wstart[hap_w[sel]] - buf))
+        hap_seq[p] = snp_alt[hap_w[sel], k]
+
+    # ---- truth genotypes per (window, individual): two haplotype combinations
+    if hap_freq_beta is None:
+        g1 = rng.integers(0, 1 << 30, size=(nW, n_ind)) % H[:, None]
+        g2 = rng.integers(0, 1 << 30, size=(nW, n_ind)) % H[:, None]
+    else:   # population mode: per-window haplotype frequencies ~ Beta(a, b) (config 5)
+        f = rng.beta(hap_freq_beta[0], hap_freq_beta[1], size=(nW, 8)) + 1e-9
+        f[np.arange(8)[None, :] >= H[:, None]] = 0
+        cdf = np.cumsum(f / f.sum(axis=1, keepdims=True), axis=1)
+        u1, u2 = rng.random((nW, n_ind)), rng.random((nW, n_ind))
+        g1 = np.minimum((u1[:, :, None] > cdf[:, None, :]).sum(axis=2), H[:, None] - 1)
+        g2 = np.minimum((u2[:, :, None] > cdf[:, None, :]).sum(axis=2), H[:, None] - 1)
+
+    # ---- reads: starts uniform over every position with >= 1 bp overlap of the window
+    span = (wend - wstart) + read_len - 1
+    n_per = np.maximum(1, np.rint(depth * span / read_len)).astype(np.int64)       # per (window, individual)
+    R_wi = np.repeat(n_per, n_ind).reshape(nW, n_ind)
+    nR = int(R_wi.sum())
+    seg_len = R_wi.reshape(-1)
+    seg_read_begin = np.concatenate([[0], np.cumsum(seg_len)]).astype(np.int32)
+    r_seg = np.repeat(np.arange(nW * n_ind), seg_len)
+    r_w = r_seg // n_ind
+    r_i = r_seg % n_ind
+    pos = (wstart[r_w] - read_len + 1 + (rng.random(nR) * span[r_w]).astype(np.int64)).astype(np.int32)
+    bad = rng.random(nR) < frac_bad
+    mapq = np.where(bad, rng.integers(0, 20, size=nR), 60).astype(np.uint8)
+    kind = np.where(bad, KIND_BAD, KIND_GOOD).astype(np.uint8)
+    flags = np.where(bad, BAM_FQCFAIL | 3, 3).astype(np.int32)      # paired + proper pair (+ QCFail)
+    # buffer order inside each (window, individual): good by pos, then bad by pos
+    order = np.lexsort((pos, kind, r_seg))
+    pos, mapq, kind, flags, r_w, r_i = pos[order], mapq[order], kind[order], flags[order], r_w[order], r_i[order]
+    n_good = np.bincount(r_seg[order][kind == KIND_GOOD], minlength=nW * n_ind).astype(np.int32)
+    allele = rng.integers(0, 2, size=nR)
+    donor = np.where(allele == 0, g1[r_w, r_i], g2[r_w, r_i])
+    cols = pos[:, None].astype(np.int64) + np.arange(read_len)[None, :]
+    seq = ref[r_w[:, None], cols]
+    for k in range(max_snps):
+        has = (k < nvar[r_w]) & (((donor >> k) & 1) == 1)
+        sp = snp_pos[r_w, k]
+        inside = has & (sp >= pos) & (sp < pos + read_len)
+        idx = np.nonzero(inside)[0]
+        seq[idx, sp[idx] - pos[idx]] = snp_alt[r_w[idx], k]
+    e = rng.random(seq.shape) < err
+    seq[e] = _other_base(rng, seq[e])
+    qual = np.clip(np.rint(rng.normal(35, 5, size=seq.shape)), 2, 41).astype(np.uint8)
+    read_off = (np.arange(nR + 1, dtype=np.int64) * read_len)
+    win_read_begin = np.concatenate([[0], np.cumsum(R_wi.sum(axis=1))]).astype(np.int32)
+    return HostBatch(
+        n_ind=n_ind, win_hap_begin=win_hap_begin, win_read_begin=win_read_begin, win_start=wstart, win_end=wend,
+        win_flank=np.full(nW, buf, dtype=np.int32), hap_seq=hap_seq, hap_off=hap_off,
+        read_seq=seq.reshape(-1), read_qual=qual.reshape(-1), read_off=read_off, read_pos=pos,
+        read_end=(pos + read_len).astype(np.int32), read_mapq=mapq, read_flags=flags, read_kind=kind,
+        seg_read_begin=seg_read_begin, seg_n_good=n_good,
+        meta=dict(kind="snp_windows", seed=seed, read_len=read_len, depth=depth, n_windows=nW, n_ind=n_ind))
+
+
+def config1(seed=1001):
+    """BASELINE config 1: single 1-kb window, 64 synthetic 100 bp reads x 4 haplotypes (ref + 3 single-SNP
+    haplotypes at 1250/1500/1750), reads from a het 0/1 genotype, mapq 60, buf = 200, hapLen = 1400."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    L, buf, ws, we = 100, 200, 1000, 2000
+    ref = _rand_bases(rng, 3000)
+    snps = [1250, 1500, 1750]
+    haps = [ref[ws - buf:we + buf].copy()]
+    for s in snps:
+        h = ref[ws - buf:we + buf].copy()
+        h[s - (ws - buf)] = _other_base(rng, ref[s:s + 1])[0]
+        haps.append(h)
+    donors = [ref.copy(), ref.copy()]
+    donors[1][snps[0]] = haps[1][snps[0] - (ws - buf)]
+    nR = 64
+    pos = np.sort(rng.integers(ws - L + 7, we - 7, size=nR)).astype(np.int32)
+    seq = np.stack([donors[int(rng.integers(0, 2))][p:p + L] for p in pos])
+    e = rng.random(seq.shape) < 1e-3
+    seq[e] = _other_base(rng, seq[e])
+    qual = np.clip(np.rint(rng.normal(35, 5, size=seq.shape)), 2, 41).astype(np.uint8)
+    hap_seq = np.concatenate(haps)
+    return HostBatch(
+        n_ind=1, win_hap_begin=np.array([0, 4], dtype=np.int32), win_read_begin=np.array([0, nR], dtype=np.int32),
+        win_start=np.array([ws], dtype=np.int32), win_end=np.array([we], dtype=np.int32),
+        win_flank=np.array([buf], dtype=np.int32), hap_seq=hap_seq,
+        hap_off=(np.arange(5, dtype=np.int64) * (we - ws + 2 * buf)), read_seq=seq.reshape(-1),
+        read_qual=qual.reshape(-1), read_off=np.arange(nR + 1, dtype=np.int64) * L, read_pos=pos,
+        read_end=(pos + L).astype(np.int32), read_mapq=np.full(nR, 60, dtype=np.uint8),
+        read_flags=np.full(nR, 3, dtype=np.int32), read_kind=np.zeros(nR, dtype=np.uint8),
+        seg_read_begin=np.array([0, nR], dtype=np.int32), seg_n_good=np.array([nR], dtype=np.int32),
+        meta=dict(kind="config1", seed=seed))
+
+
+def config2(n_windows=10000, seed=2002):
+    """BASELINE config 2: 10k windows, 150 bp reads, 30x, <= 8 haplotypes/window, SNP-only."""
+    return make_snp_windows(n_windows, seed, read_len=150, depth=30)
+
+
+def config5(n_windows=2000, n_ind=100, seed=5005):
+    """BASELINE config 5: population mode, 100 samples at 30x each, haplotype frequencies ~ Beta(0.5, 2)."""
+    return make_snp_windows(n_windows, seed, read_len=150, depth=30, n_ind=n_ind, hap_freq_beta=(0.5, 2.0))

@@ -1,0 +1,363 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI,
+against the oracle on the same seeded inputs, against the committed golden vectors, and -- at
+BASELINE.json's full size -- through size-independent properties.
+
+Bar: bit-exact integer scores; log-likelihoods bit-identical except where the device libm is involved
+(tolerance written at the assert)."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from platypus_amd import _lib, synth
+from platypus_amd.batch import HostBatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from platypus_amd.engine import Engine
+    return Engine(0)
+
+
+def oracle_windows(oracle, hb, windows=None):
+    """Oracle results for a HostBatch: per-window (loglik [H,R], score [H,R], n_dp)."""
+    out = []
+    for w in (range(hb.n_windows) if windows is None else windows):
+        out.append(oracle.align_window(hb.window_haps(w), int(hb.win_start[w]), int(hb.win_end[w]),
+                                       int(hb.win_flank[w]), hb.window_reads(w)))
+    return out
+
+
+def run_align(eng, hb):
+    db = eng.upload(hb)
+    st = eng.align(db)
+    eng.synchronize()
+    return db, st, db.loglik.cpu().numpy()[:hb.n_pairs], db.score.cpu().numpy()[:hb.n_pairs]
+
+
+def check_against_oracle(oracle, hb, ll, sc, st=None):
+    ndp = 0
+    for w, (oll, osc, n) in enumerate(oracle_windows(oracle, hb)):
+        a, b = hb.pair_off[w], hb.pair_off[w + 1]
+        assert np.array_equal(sc[a:b].reshape(osc.shape), osc), "scores differ in window %d" % w
+        # score -> log-likelihood is one fp64 multiply + one add of a host-computed table entry: bit-identical
+        assert np.array_equal(ll[a:b].reshape(oll.shape), oll), "log-likelihoods differ in window %d" % w
+        ndp += n
+    if st is not None:
+        assert st.n_dp_reference == ndp
+        assert st.n_pairs == hb.n_pairs
+
+
+# ---- a1 ------------------------------------------------------------------------------------------
+def test_dp_golden_vectors_bit_exact(eng, golden_dir):
+    g = np.load(os.path.join(golden_dir, "dp_cases.npz"))
+    got = eng.dp_batch(g["haps"], g["reads"], g["quals"], g["gos"], g["lens"])
+    assert np.array_equal(got, g["score"])
+
+
+def test_dp_fuzz_vs_oracle_all_lengths(eng, oracle):
+    rng = np.random.default_rng(4242)
+    n, lmax = 4096, 300
+    lens = rng.integers(7, lmax + 1, n).astype(np.int32)
+    lens[:64] = np.arange(7, 71)
+    haps = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), (n, lmax + 15), p=[.24, .24, .24, .24, .04])
+    reads = np.empty((n, lmax), dtype=np.uint8)
+    for j in range(n):
+        off = int(rng.integers(0, 16))
+        seg = haps[j, off:off + lmax]
+        reads[j, :len(seg)] = seg
+        reads[j, len(seg):] = ord("A")
+    mut = rng.random((n, lmax)) < 0.03
+    reads[mut] = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(mut.sum()))
+    for j in range(0, n, 3):          # indels
+        L = int(lens[j]); p = int(rng.integers(1, max(2, L - 2))); k = int(rng.integers(1, 9))
+        reads[j, p:lmax - k] = reads[j, p + k:lmax].copy()
+    quals = rng.integers(0, 94, (n, lmax)).astype(np.uint8)
+    quals[rng.random((n, lmax)) < 0.1] = 0
+    gos = rng.integers(1, 46, (n, lmax + 15)).astype(np.uint8)
+    got = eng.dp_batch(haps, reads, quals, gos, lens)
+    exp = oracle.dp_batch(haps, reads, quals, gos, lens)
+    assert np.array_equal(got, exp)
+
+
+def test_dp_nonstandard_gap_parameters(eng, oracle):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dp_cases.npz"))
+    sl = slice(0, 400)
+    for ge, npri in ((1, 0), (5, 3), (3, 2)):
+        got = eng.dp_batch(g["haps"][sl], g["reads"][sl], g["quals"][sl], g["gos"][sl], g["lens"][sl], ge, npri)
+        exp = oracle.dp_batch(g["haps"][sl], g["reads"][sl], g["quals"][sl], g["gos"][sl], g["lens"][sl], ge, npri)
+        assert np.array_equal(got, exp)
+
+
+# ---- a3..a10 -------------------------------------------------------------------------------------
+def test_config1_window(eng, oracle):
+    hb = synth.config1()
+    db, st, ll, sc = run_align(eng, hb)
+    check_against_oracle(oracle, hb, ll, sc, st)
+    assert st.n_pairs_aligned == 256
+
+
+def test_config2_subset_vs_oracle(eng, oracle):
+    hb = synth.config2(300)
+    db, st, ll, sc = run_align(eng, hb)
+    check_against_oracle(oracle, hb, ll, sc, st)
+    assert st.cells_reference == st.n_dp_reference * 16 * 150
+
+
+def single_pair_batch(cases):
+    """One window per golden map-and-align case: 1 haplotype, 1 read (kind=brokenMate: never skipped)."""
+    nW = len(cases)
+    haps = [c["hap"].encode() for c in cases]
+    reads = [c["read"].encode() for c in cases]
+    quals = [bytes(c["qual"]) for c in cases]
+    hl = np.array([len(h) for h in haps]); rl = np.array([len(r) for r in reads])
+    pos = np.array([c["readStart"] for c in cases], dtype=np.int32)
+    flank = np.array([c["flank"] for c in cases], dtype=np.int32)
+    ws = np.array([c["hapStart"] + c["flank"] for c in cases], dtype=np.int32)
+    return HostBatch(
+        n_ind=1, win_hap_begin=np.arange(nW + 1, dtype=np.int32), win_read_begin=np.arange(nW + 1, dtype=np.int32),
+        win_start=ws, win_end=ws + 10, win_flank=flank,
+        hap_seq=np.frombuffer(b"".join(haps), dtype=np.uint8), hap_off=np.concatenate([[0], np.cumsum(hl)]).astype(np.int64),
+        read_seq=np.frombuffer(b"".join(reads), dtype=np.uint8), read_qual=np.frombuffer(b"".join(quals), dtype=np.uint8),
+        read_off=np.concatenate([[0], np.cumsum(rl)]).astype(np.int64), read_pos=pos, read_end=pos + rl.astype(np.int32),
+        read_mapq=np.full(nW, 60, dtype=np.uint8), read_flags=np.zeros(nW, dtype=np.int32),
+        read_kind=np.full(nW, 2, dtype=np.uint8), seg_read_begin=np.arange(nW + 1, dtype=np.int32),
+        seg_n_good=np.zeros(nW, dtype=np.int32))
+
+
+def test_mapalign_golden_vectors(eng, golden_dir):
+    """Golden vectors from the reference's own calign.pyx: tandem repeats (hundreds of arg-max diagonals),
+    N's, reads hanging off either haplotype end, wrong mapping hints.  (doCalculateFlankScore=1 cases
+    are not supported on the device yet and are checked to fail loudly in test_unsupported_options.)"""
+    cases = [c for c in json.load(gzip.open(os.path.join(golden_dir, "mapalign_cases.json.gz"), "rt"))
+             if c["doFlank"] == 0]
+    assert len(cases) > 300
+    hb = single_pair_batch(cases)
+    db, st, ll, sc = run_align(eng, hb)
+    exp = np.array([c["score"] for c in cases], dtype=np.int32)
+    assert np.array_equal(sc, exp)
+    assert st.n_dp_launched >= len(cases)
+
+
+def edge_batch():
+    """Ragged / degenerate windows: reads of every length 5..260 (shorter than 7 -> score 0), QCFail and
+    overlap<7 reads (-> 0.0), brokenMates far outside the window, N runs and tandem repeats in the
+    haplotypes, a window with no reads, a window whose haplotypes are identical, mapq 0."""
+    rng = np.random.default_rng(77)
+    B = np.frombuffer(b"ACGT", dtype=np.uint8)
+    wins = []
+    for w in range(24):
+        W = int(rng.integers(10, 120)); buf = 500
+        ref = B[rng.integers(0, 4, W + 2 * buf + 400)]
+        if w % 3 == 1:
+            u = B[rng.integers(0, 4, int(rng.integers(1, 6)))]
+            p = int(rng.integers(300, 500)); ref[p:p + 90] = np.resize(u, 90)
+        if w % 4 == 2:
+            ref[int(rng.integers(400, 600)):][:7] = ord("N")
+        ws = 200 + buf
+        haps = [ref[ws - buf:ws + W + buf].copy()]
+        for k in range(int(rng.integers(0, 4))):
+            h = haps[0].copy()
+            t = int(rng.integers(0, 3)); p = buf + int(rng.integers(0, W))
+            if t == 0:
+                h[p] = B[(int(np.searchsorted(B, h[p])) + 1) % 4] if h[p] != ord("N") else ord("A")
+            elif t == 1:
+                h = np.concatenate([h[:p], B[rng.integers(0, 4, int(rng.integers(1, 20)))], h[p:]])
+            else:
+                h = np.concatenate([h[:p], h[p + int(rng.integers(1, 20)):]])
+            haps.append(h)
+        if w == 5:
+            haps = [haps[0], haps[0].copy()]
+        reads = []
+        nR = 0 if w == 7 else int(rng.integers(1, 40))
+        for r in range(nR):
+            L = int(rng.integers(5, 261))
+            src = haps[int(rng.integers(0, len(haps)))]
+            p0 = int(rng.integers(max(0, buf - L + 1), min(len(src) - L, buf + W)))
+            s = src[p0:p0 + L].copy()
+            e = rng.random(L) < 0.02
+            s[e] = B[rng.integers(0, 4, int(e.sum()))]
+            q = rng.integers(0, 60, L).astype(np.uint8)
+            kind = int(rng.choice([0, 0, 0, 1, 2]))
+            flags = 512 if (kind == 1 and rng.random() < 0.5) else 0
+            pos = ws - buf + p0 + int(rng.choice([0, 0, 0, 3, -40, 150]))
+            if kind == 2:
+                pos += int(rng.integers(-3000, 3000))
+            mapq = int(rng.choice([0, 5, 29, 60, 60, 255]))
+            reads.append((kind, pos, s, q, flags, mapq))
+        reads.sort(key=lambda x: (x[0], x[1]))
+        wins.append((ws, ws + W, buf, haps, reads))
+    hap_seq = np.concatenate([h for w in wins for h in w[3]])
+    hl = np.array([len(h) for w in wins for h in w[3]])
+    allr = [r for w in wins for r in w[4]]
+    rl = np.array([len(r[2]) for r in allr])
+    return HostBatch(
+        n_ind=1, win_hap_begin=np.concatenate([[0], np.cumsum([len(w[3]) for w in wins])]).astype(np.int32),
+        win_read_begin=np.concatenate([[0], np.cumsum([len(w[4]) for w in wins])]).astype(np.int32),
+        win_start=np.array([w[0] for w in wins], dtype=np.int32), win_end=np.array([w[1] for w in wins], dtype=np.int32),
+        win_flank=np.array([w[2] for w in wins], dtype=np.int32), hap_seq=hap_seq,
+        hap_off=np.concatenate([[0], np.cumsum(hl)]).astype(np.int64),
+        read_seq=np.concatenate([r[2] for r in allr]), read_qual=np.concatenate([r[3] for r in allr]),
+        read_off=np.concatenate([[0], np.cumsum(rl)]).astype(np.int64),
+        read_pos=np.array([r[1] for r in allr], dtype=np.int32),
+        read_end=np.array([r[1] + len(r[2]) for r in allr], dtype=np.int32),
+        read_mapq=np.array([r[5] for r in allr], dtype=np.uint8), read_flags=np.array([r[4] for r in allr], dtype=np.int32),
+        read_kind=np.array([r[0] for r in allr], dtype=np.uint8),
+        seg_read_begin=np.concatenate([[0], np.cumsum([len(w[4]) for w in wins])]).astype(np.int32),
+        seg_n_good=np.array([sum(1 for r in w[4] if r[0] == 0) for w in wins], dtype=np.int32))
+
+
+def test_edge_cases_vs_oracle(eng, oracle):
+    hb = edge_batch()
+    db, st, ll, sc = run_align(eng, hb)
+    check_against_oracle(oracle, hb, ll, sc, st)
+    assert (sc == -1).any() and (ll == -300.0).any()          # skipped reads and mapq-0 reads are present
+
+
+def test_empty_batch_and_null_checks(eng):
+    import ctypes as C
+    lib = _lib.load()
+    z = _lib.WindowBatch()
+    assert lib.plat_align_window_batch(eng.ctx, C.byref(z), 0, 0, None, None, None, None) == 0
+    assert lib.plat_align_window_batch(eng.ctx, None, 0, 0, None, None, None, None) == -1
+    assert lib.plat_dp_batch(eng.ctx, 0, 100, None, None, None, None, None, 3, 2, None, None) == 0
+
+
+def test_unsupported_options_fail_loudly(eng):
+    hb = synth.config1()
+    db = eng.upload(hb)
+    with pytest.raises(_lib.PlatypusDeviceError) as e:
+        eng.align(db, calc_flank_score=1)
+    assert e.value.code == -6
+    with pytest.raises(_lib.PlatypusDeviceError):
+        eng.align(db, use_mapq_cap=1)
+
+
+def test_error_codes_from_device_validation(eng):
+    hb = synth.config1()
+    # haplotype longer than 16384 (chaplotype.pyx:180-183)
+    big = HostBatch(**{**hb.__dict__, "hap_seq": np.full(4 * 17000, ord("A"), dtype=np.uint8),
+                       "hap_off": np.arange(5, dtype=np.int64) * 17000, "pair_off": None, "gl_off": None})
+    with pytest.raises(_lib.PlatypusDeviceError) as e:
+        eng.align(eng.upload(big))
+    assert e.value.code == -4
+    # haplotype shorter than read + 15 (the reference reads past the buffer here)
+    short = HostBatch(**{**hb.__dict__, "hap_seq": hb.hap_seq[:4 * 110].copy(),
+                         "hap_off": np.arange(5, dtype=np.int64) * 110, "pair_off": None, "gl_off": None})
+    with pytest.raises(_lib.PlatypusDeviceError) as e:
+        eng.align(eng.upload(short))
+    assert e.value.code == -5
+    # non-ASCII byte
+    bad = HostBatch(**{**hb.__dict__, "read_seq": np.where(np.arange(len(hb.read_seq)) == 5, 200, hb.read_seq).astype(np.uint8),
+                       "pair_off": None, "gl_off": None})
+    with pytest.raises(_lib.PlatypusDeviceError) as e:
+        eng.align(eng.upload(bad))
+    assert e.value.code == -9
+
+
+def test_maximum_haplotype_length(eng, oracle):
+    """hapLen = 16384 (the reference's hard cap) with a tandem-repeat stretch: the largest LDS configuration
+    of the seeding kernel and a job list far larger than the initial capacity (re-run path)."""
+    rng = np.random.default_rng(5)
+    B = np.frombuffer(b"ACGT", dtype=np.uint8)
+    hap = B[rng.integers(0, 4, 16384)]
+    hap[8000:8400] = np.resize(np.frombuffer(b"AC", dtype=np.uint8), 400)
+    reads, pos = [], []
+    for p in (100, 7990, 8100, 8200, 16000, 16384 - 250):
+        reads.append(hap[p:p + 250].copy()); pos.append(p)
+    reads[2][100] = ord("G")
+    nR = len(reads)
+    hb = HostBatch(
+        n_ind=1, win_hap_begin=np.array([0, 1], dtype=np.int32), win_read_begin=np.array([0, nR], dtype=np.int32),
+        win_start=np.array([500], dtype=np.int32), win_end=np.array([15884], dtype=np.int32),
+        win_flank=np.array([500], dtype=np.int32), hap_seq=hap, hap_off=np.array([0, 16384], dtype=np.int64),
+        read_seq=np.concatenate(reads), read_qual=np.full(nR * 250, 30, dtype=np.uint8),
+        read_off=np.arange(nR + 1, dtype=np.int64) * 250, read_pos=np.array(pos, dtype=np.int32),
+        read_end=np.array(pos, dtype=np.int32) + 250, read_mapq=np.full(nR, 60, dtype=np.uint8),
+        read_flags=np.zeros(nR, dtype=np.int32), read_kind=np.zeros(nR, dtype=np.uint8),
+        seg_read_begin=np.array([0, nR], dtype=np.int32), seg_n_good=np.array([nR], dtype=np.int32))
+    db, st, ll, sc = run_align(eng, hb)
+    check_against_oracle(oracle, hb, ll, sc, st)
+
+
+# ---- a11 / a12 -----------------------------------------------------------------------------------
+def check_genotypes(oracle, hb, ll, logl, gl, gof):
+    for w in range(hb.n_windows):
+        H = hb.win_hap_begin[w + 1] - hb.win_hap_begin[w]
+        R = hb.win_read_begin[w + 1] - hb.win_read_begin[w]
+        G = H * (H + 1) // 2
+        llw = ll[hb.pair_off[w]:hb.pair_off[w + 1]].reshape(H, R)
+        for i in range(hb.n_ind):
+            s = w * hb.n_ind + i
+            a, b = hb.seg_read_begin[s] - hb.win_read_begin[w], hb.seg_read_begin[s + 1] - hb.win_read_begin[w]
+            ol, og, of = oracle.population_setup_ind(llw[:, a:b], int(hb.seg_n_good[s]))
+            o = hb.gl_off[w]
+            got_l = logl[o + i * G:o + (i + 1) * G]
+            # sums of fp64 terms in read order: identical, except for the log(0.5(e^a+e^b)) branch which
+            # uses the device libm instead of glibc (<= few ulp per term): tolerance 1e-12 relative,
+            # far inside north_star's 1e-4.
+            assert np.allclose(got_l, ol, rtol=1e-12, atol=0), (w, i)
+            assert np.allclose(gl[o + i * G:o + (i + 1) * G], og, rtol=1e-10, atol=1e-300)
+            assert np.allclose(gof[o + np.arange(G) * hb.n_ind + i], of, rtol=1e-13, atol=0)
+
+
+def test_genotype_likelihoods_vs_oracle(eng, oracle):
+    for hb in (synth.config1(), synth.config2(150), edge_batch(), synth.config5(12, n_ind=7)):
+        db = eng.upload(hb)
+        eng.call_windows(db)
+        eng.synchronize()
+        ll = db.loglik.cpu().numpy()[:hb.n_pairs]
+        check_genotypes(oracle, hb, ll, db.logl.cpu().numpy(), db.gl.cpu().numpy(), db.gof.cpu().numpy())
+
+
+def test_population_mode_vs_oracle(eng, oracle):
+    hb = synth.config5(6, n_ind=20)
+    db, st, ll, sc = run_align(eng, hb)
+    check_against_oracle(oracle, hb, ll, sc, st)
+
+
+# ---- full BASELINE size: size-independent properties --------------------------------------------------
+def test_config2_full_size_properties(eng, oracle):
+    """10k windows (BASELINE config 2).  The oracle cannot do this in seconds, so check
+    (1) a random sample of windows against the oracle, (2) invariance under window permutation,
+    (3) identical haplotype rows / homozygous-genotype identity, (4) bounds."""
+    hb = synth.config2(10000)
+    db = eng.upload(hb)
+    st = eng.call_windows(db)
+    eng.synchronize()
+    ll = db.loglik.cpu().numpy()[:hb.n_pairs]
+    sc = db.score.cpu().numpy()[:hb.n_pairs]
+    logl = db.logl.cpu().numpy()
+    rng = np.random.default_rng(0)
+    sample = sorted(rng.choice(hb.n_windows, 120, replace=False).tolist())
+    for w, (oll, osc, n) in zip(sample, oracle_windows(oracle, hb, sample)):
+        a, b = hb.pair_off[w], hb.pair_off[w + 1]
+        assert np.array_equal(sc[a:b].reshape(osc.shape), osc)
+        assert np.array_equal(ll[a:b].reshape(oll.shape), oll)
+    assert (ll <= 0).all() and (ll >= -300).all() and (sc >= -1).all()
+    assert st.n_pairs == hb.n_pairs and st.n_dp_reference >= st.n_pairs_aligned
+    # homozygous genotype (a,a): logl == in-order sum of that haplotype's row
+    for w in sample[:40]:
+        H = hb.win_hap_begin[w + 1] - hb.win_hap_begin[w]; R = hb.win_read_begin[w + 1] - hb.win_read_begin[w]
+        rows = ll[hb.pair_off[w]:hb.pair_off[w + 1]].reshape(H, R)
+        g = 0
+        for a in range(H):
+            acc = 0.0
+            for x in rows[a]:
+                acc += x
+            assert logl[hb.gl_off[w] + g] == acc
+            g += H - a
+    # permutation invariance: reversed window order gives the same per-window blocks
+    perm = np.arange(hb.n_windows)[::-1]
+    hb2 = hb.subset(perm[:2000])
+    db2 = eng.upload(hb2)
+    eng.call_windows(db2)
+    eng.synchronize()
+    ll2 = db2.loglik.cpu().numpy()[:hb2.n_pairs]
+    for k in range(0, 2000, 7):
+        w = perm[k]
+        assert np.array_equal(ll2[hb2.pair_off[k]:hb2.pair_off[k + 1]], ll[hb.pair_off[w]:hb.pair_off[w + 1]])
