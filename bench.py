@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: pair-HMM GCUPS (+ variant windows/sec) on BASELINE config 2.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic windows that is already resident
+in HBM: haplotype k-mer index + gap-open annotation + diagonal vote + candidate DPs + candidate
+selection + log-likelihood arrays (Haplotype.alignReads for every haplotype) + genotype likelihoods
+(Population.setup).  Windows shard across ranks with no data-path collective (weak scaling: every
+rank owns `--windows` windows generated from seed+rank); the only collectives are the barriers and
+the max-over-ranks timing reduction.
+
+GCUPS counts REFERENCE-EQUIVALENT work: sum over the fastAlignmentRoutine calls the
+reference would make of 16*len2 band cells, divided by wall time.  `cells_launched` (what the device
+actually ran) is reported next to it.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(hb, seconds=12.0):
+    """The reference's own kernel (unmodified align.c in oracle/_ref, traceback on = production mode) timed
+    on ONE host core over the DP instances of a bounded sample of the same workload; plus the oracle
+    port of the whole per-window path as a secondary figure."""
+    from oracle.oracle import LIBREF, Oracle, HERE as ORC_DIR
+    o = Oracle()
+    nwin = min(hb.n_windows, 150)
+    rows = []
+    for w in range(nwin):
+        haps = hb.window_haps(w)
+        rd = hb.window_reads(w)
+        ws, we, fl = int(hb.win_start[w]), int(hb.win_end[w]), int(hb.win_flank[w])
+        gos = [o.gap_open(h) for h in haps]
+        for h, g in zip(haps, gos):
+            for r in range(len(rd["seq"])):
+                L = len(rd["seq"][r])
+                ov = min(we, int(rd["end"][r])) - max(ws, int(rd["pos"][r]))
+                if rd["kind"][r] != 2 and ((rd["flags"][r] & 512) or ov < 7):
+                    continue
+                idx = min(int(rd["pos"][r]) - (ws - fl), len(h) - L - 15)      # calign.pyx:252
+                st = max(0, idx - 8)
+                rows.append((h[st:st + L + 15], rd["seq"][r], rd["qual"][r], g[st:st + L + 15]))
+    n = len(rows)
+    lmax = max(len(r[1]) for r in rows)
+    H = np.full((n, lmax + 15), ord("A"), dtype=np.uint8); R = np.full((n, lmax), ord("A"), dtype=np.uint8)
+    Q = np.zeros((n, lmax), dtype=np.uint8); G = np.ones((n, lmax + 15), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.int32)
+    for j, (h, r, q, g) in enumerate(rows):
+        L = len(r); lens[j] = L
+        H[j, :L + 15] = np.frombuffer(h, dtype=np.uint8); R[j, :L] = np.frombuffer(r, dtype=np.uint8)
+        Q[j, :L] = np.frombuffer(q, dtype=np.uint8); G[j, :L + 15] = np.frombuffer(g, dtype=np.uint8)
+    out = {"cores": 1, "sample": "DP instances (one per aligned read x haplotype pair, at the read's mapping offset) of the "
+                                 "first %d windows of the workload = %d DPs, repeated to ~%.0f s" % (nwin, n, seconds)}
+    lib = C.CDLL(os.path.join(ORC_DIR, "libcpubench.so"))
+    lib.cpu_time_reference_dp.restype = C.c_double
+    lib.cpu_time_reference_dp.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    if os.path.exists(LIBREF):
+        cs, cells = C.c_longlong(0), C.c_longlong(0)
+
+        def run(tb, reps):
+            return lib.cpu_time_reference_dp(LIBREF.encode(), n, lmax, H.ctypes.data, R.ctypes.data, Q.ctypes.data,
+                                             G.ctypes.data, lens.ctypes.data, tb, reps, C.byref(cs), C.byref(cells))
+        t1 = run(1, 1)
+        reps = max(1, int(seconds / max(t1, 1e-6)))
+        t = run(1, reps)
+        out.update(kind="reference", value=cells.value / t / 1e9, unit="GCUPS",
+                   what="unmodified src/c/align.c fastAlignmentRoutine, traceback on (production mode), gcc -O2, 1 thread")
+        t0 = run(0, max(1, reps // 4))
+        out["score_only_gcups"] = cells.value / t0 / 1e9
+    else:
+        # no prebuilt reference .so on this box: time the oracle port's DP instead
+        t0 = time.perf_counter()
+        o.dp_batch(H, R, Q, G, lens)
+        t = time.perf_counter() - t0
+        out.update(kind="port", value=float((16 * lens.astype(np.int64)).sum()) / t / 1e9, unit="GCUPS",
+                   what="oracle/plat_oracle.c scalar restatement (no SIMD), 1 thread")
+    # secondary: whole per-window path (hash + vote + DP with traceback + log-likelihood) with the oracle port
+    t0 = time.perf_counter(); ndp = 0
+    for w in range(min(nwin, 60)):
+        ndp += o.align_window(hb.window_haps(w), int(hb.win_start[w]), int(hb.win_end[w]), int(hb.win_flank[w]),
+                              hb.window_reads(w))[2]
+    tp = time.perf_counter() - t0
+    out["port_whole_path_windows_per_sec"] = min(nwin, 60) / tp
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--windows", type=int, default=10000, help="windows per GPU (BASELINE config 2: 10000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from platypus_amd import synth
+    from platypus_amd.engine import Engine
+
+    eng = Engine(local)
+    hb = synth.config2(a.windows, seed=2002 + rank)
+    db = eng.upload(hb)                         # inputs resident in HBM before the timed region
+    eng.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    st = None
+    for _ in range(a.warmup):
+        st = eng.call_windows(db, want_stats=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.call_windows(db, want_stats=False)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    if st is None:
+        st = eng.call_windows(db, want_stats=True)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=eng.device)
+    tot = torch.tensor([float(st.cells_reference), float(st.cells_launched), float(hb.n_windows),
+                        float(st.n_dp_reference), float(st.n_dp_launched)], dtype=torch.float64, device=eng.device)
+    if dist is not None:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    T = float(elapsed.item())
+    cells_ref, cells_run, nwin, ndp_ref, ndp_run = [float(x) for x in tot.tolist()]
+
+    # live per-kernel timing of the dominant kernel (HIP events on the launch stream), untimed extra steps
+    eng.profile_enable(True)
+    dp_ms, seed_ms, fin_ms, gen_ms, prep_ms = [], [], [], [], []
+    prof = None
+    for _ in range(5):
+        eng.call_windows(db, want_stats=False)
+        prof = eng.profile_last()
+        dp_ms.append(prof.ms_dp); seed_ms.append(prof.ms_seed); fin_ms.append(prof.ms_finalize)
+        gen_ms.append(prof.ms_genotype); prep_ms.append(prof.ms_prepare)
+    eng.profile_enable(False)
+
+    if rank == 0:
+        ms_step = 1e3 * T / a.steps
+        dp_avg = float(np.mean(dp_ms))
+        achieved = prof.dp_alg_bytes / (dp_avg * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "dp_traffic.json")      # HBM bytes/launch from rocprofv3 --pmc (see profiles/README.md)
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "pair-HMM GCUPS (reference-equivalent band cells/s, read->haplotype likelihood path)",
+            "value": cells_ref * a.steps / T / 1e9,
+            "unit": "GCUPS",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int16", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: %d windows/GPU, 150 bp reads, 30x, <=8 haplotypes/window, SNP-only; "
+                                   "step = alignReads for all haplotypes + genotype likelihoods" % a.windows,
+                       "windows_per_gpu": a.windows, "read_len": 150, "depth": 30, "sharding": "windows by rank, no collective"},
+            "windows_per_sec": nwin * a.steps / T,
+            "gcups_executed": cells_run * a.steps / T / 1e9,
+            "dp_reference_per_step": ndp_ref, "dp_launched_per_step": ndp_run,
+            "kernel_ms": {"prepare": float(np.mean(prep_ms)), "seed": float(np.mean(seed_ms)), "dp": dp_avg,
+                          "finalize": float(np.mean(fin_ms)), "genotype": float(np.mean(gen_ms))},
+            "dp_kernel_gcups": 4.0 * (prof.dp_alg_bytes - 34 * prof.dp_jobs) / (dp_avg * 1e-3) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "k_dp_jobs", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(prof.dp_alg_bytes), "avg_launch_ms": dp_avg,
+                         "note": "recurrence is VALU-issue bound (packed int16), not HBM bound: see DESIGN.md"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(hb)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

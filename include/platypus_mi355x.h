@@ -62,6 +62,24 @@ int plat_memcpy_d2h(plat_ctx* ctx, void* dst_host, const void* src_dev, size_t b
 int plat_memset(plat_ctx* ctx, void* dst_dev, int value, size_t bytes, void* stream);
 int plat_stream_sync(plat_ctx* ctx, void* stream);          /* [syncs] */
 
+/* ---- live kernel timing (HIP events recorded on the caller's stream around each kernel) ----------
+ * Used by bench.py for the roofline line; off by default (no overhead).  plat_profile_last [syncs]
+ * on the recorded events and returns the durations of the kernels of the most recent
+ * plat_align_window_batch / plat_genotype_window_batch call, plus the algorithmic byte count of
+ * the DP launch: sum over launched DPs of (4*len2 + 34) bytes.                  */
+typedef struct plat_profile {
+    float ms_prepare;     /* validation + haplotype->window map (+ read-back)                     */
+    float ms_seed;        /* gap-open annotation + 7-mer index + diagonal vote + candidate lists  */
+    float ms_dp;          /* banded DP kernel (the dominant kernel)                               */
+    float ms_finalize;    /* candidate selection + score -> log-likelihood                        */
+    float ms_genotype;    /* genotype likelihood kernel                                           */
+    float _pad;
+    int64_t dp_jobs;      /* DPs in the DP launch                                                 */
+    int64_t dp_alg_bytes; /* algorithmic bytes of the DP launch                                   */
+} plat_profile;
+int plat_profile_enable(plat_ctx* ctx, int on);
+int plat_profile_last(plat_ctx* ctx, plat_profile* out);   /* [syncs] */
+
 /* ---- a1: fastAlignmentRoutine, score only -------------------------------------------------------
  * Replaces  int fastAlignmentRoutine(seq1, seq2, qual2, len1, len2, gapextend, nucprior,
  *                                    localgapopen, aln1=NULL, aln2=NULL, firstpos)

@@ -43,6 +43,11 @@ class AlignStats(C.Structure):
                 ("n_dp_reference", C.c_int64), ("cells_reference", C.c_int64), ("cells_launched", C.c_int64)]
 
 
+class Profile(C.Structure):
+    _fields_ = [("ms_prepare", C.c_float), ("ms_seed", C.c_float), ("ms_dp", C.c_float), ("ms_finalize", C.c_float),
+                ("ms_genotype", C.c_float), ("_pad", C.c_float), ("dp_jobs", C.c_int64), ("dp_alg_bytes", C.c_int64)]
+
+
 class AssemblyBatch(C.Structure):
     _fields_ = [("n_regions", C.c_int32), ("n_reads", C.c_int32), ("ref_seq", C.c_void_p), ("ref_off", C.c_void_p),
                 ("ref_start", C.c_void_p), ("assem_start", C.c_void_p), ("assem_end", C.c_void_p),
@@ -64,6 +69,8 @@ SIGNATURES = {
     "plat_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "plat_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "plat_stream_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "plat_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "plat_profile_last": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
     "plat_dp_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "plat_align_window_batch": (C.c_int, [C.c_void_p, C.POINTER(WindowBatch), C.c_int, C.c_int, C.c_void_p,

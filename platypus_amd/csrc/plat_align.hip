@@ -415,6 +415,8 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     if (rc) return rc;
     long long* cnt = (long long*)ctx->counters.ptr;
     int32_t* hap_win = (int32_t*)(cnt + CNT_N + 8);
+    ctx->ev_valid_align = 0;
+    PLAT_EV(ctx, 0, st);
     PLAT_HIP(ctx, hipMemsetAsync(cnt, 0, (CNT_N + 8) * sizeof(long long), st));
     hipLaunchKernelGGL(k_validate, dim3(1024), dim3(256), 0, st, b, cnt);
     hipLaunchKernelGGL(k_hap_window, dim3((b.n_windows + 255) / 256), dim3(256), 0, st, b, hap_win);
@@ -436,6 +438,7 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     if (job_cap > 0x7FFFFF00ll) job_cap = 0x7FFFFF00ll;
 
     long long njobs = 0;
+    PLAT_EV(ctx, 1, st);
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = plat_reserve(ctx, ctx->jobs, (size_t)job_cap * sizeof(Job)))) return rc;
         PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_NJOBS], 0, sizeof(long long), st));
@@ -450,20 +453,28 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
         if (attempt == 1) return PLAT_ERR_OVERFLOW;
     }
     if ((rc = plat_reserve(ctx, ctx->job_score, (size_t)(njobs + 1) * sizeof(int32_t)))) return rc;
+    PLAT_EV(ctx, 2, st);
     if (njobs > 0) {
         hipLaunchKernelGGL(k_dp_jobs, dim3((unsigned)((njobs + 255) / 256)), dim3(256), 0, st, b,
                            (const uint8_t*)ctx->go_blob.ptr, (const Job*)ctx->jobs.ptr, (int)njobs,
                            (int32_t*)ctx->job_score.ptr);
-        if (out_stats)
-            hipLaunchKernelGGL(k_sum_job_cells, dim3(256), dim3(256), 0, st, (const Job*)ctx->jobs.ptr, (int)njobs, cnt);
     }
+    PLAT_EV(ctx, 3, st);
+    if (njobs > 0 && (out_stats || ctx->profile))
+        hipLaunchKernelGGL(k_sum_job_cells, dim3(256), dim3(256), 0, st, (const Job*)ctx->jobs.ptr, (int)njobs, cnt);
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, b,
                        (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr,
                        (const int32_t*)ctx->job_score.ptr, ctx->d_mapq_lut, npairs, out_loglik, out_score, cnt);
     PLAT_HIP(ctx, hipGetLastError());
-    if (out_stats) {
+    PLAT_EV(ctx, 4, st);
+    if (out_stats || ctx->profile) {
         PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
         PLAT_HIP(ctx, hipStreamSynchronize(st));
+        ctx->ev_valid_align = ctx->profile;
+        ctx->prof_dp_jobs = njobs;
+        ctx->prof_dp_bytes = hb[CNT_CELLS_RUN] / 4 + 34 * njobs;     // sum(4*len2 + 34); cells = 16*len2
+    }
+    if (out_stats) {
         out_stats->n_pairs = npairs;
         out_stats->n_pairs_aligned = hb[CNT_PAIRS_ALIGNED];
         out_stats->n_dp_launched = njobs;

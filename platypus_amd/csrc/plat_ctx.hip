@@ -62,7 +62,38 @@ PLAT_EXPORT int plat_ctx_destroy(plat_ctx* ctx) {
         if (s->ptr) { e = hipFree(s->ptr); (void)e; }
     if (ctx->d_mapq_lut) { e = hipFree(ctx->d_mapq_lut); (void)e; }
     if (ctx->h_readback) { e = hipHostFree(ctx->h_readback); (void)e; }
+    for (int i = 0; i < 8; ++i)
+        if (ctx->ev[i]) { e = hipEventDestroy(ctx->ev[i]); (void)e; }
     delete ctx;
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_profile_enable(plat_ctx* ctx, int on) {
+    if (!ctx) return PLAT_ERR_INVALID;
+    if (on && !ctx->ev[0])
+        for (int i = 0; i < 8; ++i) PLAT_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+    ctx->profile = on ? 1 : 0;
+    ctx->ev_valid_align = ctx->ev_valid_geno = 0;
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_profile_last(plat_ctx* ctx, plat_profile* out) {
+    if (!ctx || !out) return PLAT_ERR_INVALID;
+    memset(out, 0, sizeof(*out));
+    if (!ctx->profile) return PLAT_ERR_INVALID;
+    if (ctx->ev_valid_align) {
+        PLAT_HIP(ctx, hipEventSynchronize(ctx->ev[4]));
+        PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_prepare, ctx->ev[0], ctx->ev[1]));
+        PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_seed, ctx->ev[1], ctx->ev[2]));
+        PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_dp, ctx->ev[2], ctx->ev[3]));
+        PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_finalize, ctx->ev[3], ctx->ev[4]));
+        out->dp_jobs = ctx->prof_dp_jobs;
+        out->dp_alg_bytes = ctx->prof_dp_bytes;
+    }
+    if (ctx->ev_valid_geno) {
+        PLAT_HIP(ctx, hipEventSynchronize(ctx->ev[7]));
+        PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_genotype, ctx->ev[6], ctx->ev[7]));
+    }
     return PLAT_OK;
 }
 

@@ -24,6 +24,11 @@ struct plat_ctx {
     plat_scratch go_blob, pair_rec, jobs, job_score, counters;
     // pinned host read-back area
     int64_t* h_readback = nullptr;
+    // optional live timing: events 0..5 bracket prepare|seed|dp|finalize, 6..7 bracket genotype
+    int profile = 0;
+    hipEvent_t ev[8] = {};
+    int ev_valid_align = 0, ev_valid_geno = 0;
+    int64_t prof_dp_jobs = 0, prof_dp_bytes = 0;
 };
 
 #define PLAT_HIP(ctx, call)                                   \
@@ -34,6 +39,8 @@ struct plat_ctx {
             return _e == hipErrorOutOfMemory ? PLAT_ERR_NOMEM : PLAT_ERR_HIP; \
         }                                                     \
     } while (0)
+
+#define PLAT_EV(ctx, i, st) do { if ((ctx)->profile) PLAT_HIP(ctx, hipEventRecord((ctx)->ev[i], st)); } while (0)
 
 static inline int plat_reserve(plat_ctx* ctx, plat_scratch& s, size_t bytes) {
     if (bytes <= s.cap) return PLAT_OK;

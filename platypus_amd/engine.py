@@ -119,5 +119,13 @@ class Engine:
         self.genotype(db)
         return st
 
+    def profile_enable(self, on=True):
+        _lib.check(self.lib.plat_profile_enable(self.ctx, int(on)), "plat_profile_enable")
+
+    def profile_last(self):
+        p = _lib.Profile()
+        _lib.check(self.lib.plat_profile_last(self.ctx, C.byref(p)), "plat_profile_last")
+        return p
+
     def synchronize(self):
         _torch().cuda.synchronize(self.device)
