@@ -103,6 +103,13 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
+    try:
+        # torch is the device-memory/stream plumbing of the Python host and ships its own libamdhip64:
+        # import it first so the process holds ONE HIP runtime (loading /opt/rocm's copy first and torch's
+        # second leaves this library without a usable device).  A host without torch simply uses /opt/rocm's.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here == the library does not export a declared symbol

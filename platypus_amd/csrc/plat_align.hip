@@ -15,10 +15,17 @@
 
 namespace plat {
 
-struct PairRec { int32_t job_base, ncand, orig_job, idx0; };   // ncand: -1 skipped read, -2 read shorter than 7
+// Job slots: pair p owns slot p for its first DP (99% of pairs need exactly one); further candidate DPs
+// (tandem repeats: many arg-max diagonals) go to an overflow area behind the npairs primary slots, reserved
+// with one global atomic per such pair.  (A single job counter bumped by every pair saturates one L2
+// atomic unit: ~90 atomics/us, i.e. ~20 ms for 2M pairs -- measured in round 1.)
+struct PairRec { int32_t extra_base, ncand, orig_k, idx0; };   // ncand: -1 skipped read, -2 read shorter than 7
+__device__ __forceinline__ long long job_slot(long long pair, long long npairs, int extra_base, int k) {
+    return k == 0 ? pair : npairs + extra_base + (k - 1);
+}
 struct Job { int32_t read, hap, idx, len; };
 
-enum { CNT_ERR = 0, CNT_MAXHAP, CNT_MAXREAD, CNT_NJOBS, CNT_PAIRS_ALIGNED, CNT_NDP_REF, CNT_CELLS_REF, CNT_CELLS_RUN, CNT_N };
+enum { CNT_ERR = 0, CNT_MAXHAP, CNT_MAXREAD, CNT_NEXTRA, CNT_PAIRS_ALIGNED, CNT_NDP_REF, CNT_CELLS_REF, CNT_CELLS_RUN, CNT_NJOBS_RUN, CNT_N };
 
 __constant__ signed char c_homopol_go[49] = {   // homopolq[i]-'!' (chaplotype.pyx:64-67); see tests/test_oracle.py
     45, 42, 41, 39, 37, 32, 28, 23, 20, 19, 17, 16, 15, 14, 13, 12, 11, 11, 10, 9, 9, 8, 8, 7, 7, 7, 6, 6, 6, 5, 5, 5,
@@ -83,7 +90,7 @@ __device__ __forceinline__ unsigned tbl_slot(unsigned code, unsigned mask) { ret
 // directly, as the reference does (calign.pyx:98-99).
 __global__ void __launch_bounds__(256)
 k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, uint8_t* __restrict__ go_blob,
-       PairRec* __restrict__ pairs, Job* __restrict__ jobs, int job_cap, long long* cnt,
+       PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
        int tsize_max, int maxhap, int cw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -172,11 +179,11 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, uint8_t* __rest
             skip = (b.read_flags[r] & 512) || ov < 7;
         }
         if (skip || L < 7) {                                                // calign.pyx:179-180
-            if (lane == 0) pairs[pidx] = PairRec{0, skip ? -1 : -2, 0, 0};
+            if (lane == 0) { pairs[pidx] = PairRec{0, skip ? -1 : -2, 0, 0}; jobs[pidx] = Job{r, h, 0, 0}; }
             continue;
         }
         if (hapLen < L + 15) {
-            if (lane == 0) { set_err(cnt, PLAT_ERR_HAP_TOO_SHORT); pairs[pidx] = PairRec{0, -1, 0, 0}; }
+            if (lane == 0) { set_err(cnt, PLAT_ERR_HAP_TOO_SHORT); pairs[pidx] = PairRec{0, -1, 0, 0}; jobs[pidx] = Job{r, h, 0, 0}; }
             continue;
         }
         const int n = hapLen + L;
@@ -221,10 +228,12 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, uint8_t* __rest
         const bool orig_in = maxcount > 0 && j0i >= 0 && j0i < n && CNT16(counts, j0i) == maxcount && idx0 + L + 15 < hapLen;
         const int njobs = ncand + (orig_in ? 0 : 1);
         int base = 0;
-        if (lane == 0) base = (int)atomicAdd((unsigned long long*)&cnt[CNT_NJOBS], (unsigned long long)njobs);
-        base = __shfl(base, 0);
-        const bool fits = base + njobs <= job_cap;
-        int orig_job = base + ncand;
+        if (njobs > 1) {
+            if (lane == 0) base = (int)atomicAdd((unsigned long long*)&cnt[CNT_NEXTRA], (unsigned long long)(njobs - 1));
+            base = __shfl(base, 0);
+        }
+        const bool fits = njobs == 1 || (long long)base + (njobs - 1) <= (long long)extra_cap;
+        int orig_k = ncand;
         if (maxcount > 0) {
             int k = 0;
             for (int j0 = 0; j0 < n; j0 += 64) {
@@ -233,16 +242,16 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, uint8_t* __rest
                 unsigned long long bal = __ballot(is);
                 if (is) {
                     int mypos = k + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (fits) jobs[base + mypos] = Job{r, h, j - L, L};
+                    if (fits || mypos == 0) jobs[job_slot(pidx, npairs, base, mypos)] = Job{r, h, j - L, L};
                 }
                 if (orig_in && j0i >= j0 && j0i < j0 + 64)
-                    orig_job = base + k + __popcll(bal & ((1ull << (j0i - j0)) - 1ull));
+                    orig_k = k + __popcll(bal & ((1ull << (j0i - j0)) - 1ull));
                 k += __popcll(bal);
             }
         }
         if (lane == 0) {
-            if (!orig_in && fits) jobs[base + ncand] = Job{r, h, idx0, L};
-            pairs[pidx] = PairRec{base, ncand, orig_job, idx0};
+            if (!orig_in && (fits || ncand == 0)) jobs[job_slot(pidx, npairs, base, ncand)] = Job{r, h, idx0, L};
+            pairs[pidx] = PairRec{base, ncand, orig_k, idx0};
         }
     }
 }
@@ -250,11 +259,12 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, uint8_t* __rest
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_dp_jobs(plat_window_batch b, const uint8_t* __restrict__ go_blob, const Job* __restrict__ jobs,
-          int njobs, int32_t* __restrict__ job_score)
+          long long njobs, int32_t* __restrict__ job_score)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= njobs) return;
     const Job jb = jobs[j];
+    if (jb.len == 0) return;                                                // slot of a skipped pair
     const int st = max(0, jb.idx - 8);                                      // calign.pyx:229,256
     const long long hoff = b.hap_off[jb.hap] + st;
     const long long roff = b.read_off[jb.read];
@@ -302,17 +312,18 @@ k_finalize(plat_window_batch b, const PairRec* __restrict__ pairs, const Job* __
                 best = 1000000;                                              // calign.pyx:190
                 int bestPos = -1;
                 bool done = false;
-                const int L = jobs[pr.orig_job].len;
+                const int L = jobs[p].len;
                 for (int k = 0; k < pr.ncand; ++k) {                        // calign.pyx:223-247
-                    int sc = job_score[pr.job_base + k];
+                    const long long js = job_slot(p, npairs, pr.extra_base, k);
+                    int sc = job_score[js];
                     ++ndp;
                     if (sc < best) {
-                        best = sc; bestPos = jobs[pr.job_base + k].idx;
+                        best = sc; bestPos = jobs[js].idx;
                         if (best == 0) { done = true; break; }
                     }
                 }
                 if (!done && pr.idx0 != bestPos) {                          // calign.pyx:255-267
-                    int sc = job_score[pr.orig_job];
+                    int sc = job_score[job_slot(p, npairs, pr.extra_base, pr.orig_k)];
                     ++ndp;
                     if (sc < best) best = sc;
                 }
@@ -343,10 +354,15 @@ k_finalize(plat_window_batch b, const PairRec* __restrict__ pairs, const Job* __
     }
 }
 
-__global__ void k_sum_job_cells(const Job* __restrict__ jobs, int njobs, long long* cnt)
+__global__ void k_sum_job_cells(const Job* __restrict__ jobs, long long njobs, long long* cnt)
 {
-    unsigned long long c = 0;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < njobs; j += gridDim.x * blockDim.x) c += 16ull * jobs[j].len;
+    unsigned long long c = 0, n = 0;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < njobs; j += (long long)gridDim.x * blockDim.x) {
+        c += 16ull * jobs[j].len;
+        n += jobs[j].len != 0;
+    }
+    for (int s = 32; s > 0; s >>= 1) n += __shfl_xor((long long)n, s);
+    if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)&cnt[CNT_NJOBS_RUN], n);
     for (int s = 32; s > 0; s >>= 1) c += __shfl_xor((long long)c, s);
     if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)&cnt[CNT_CELLS_RUN], c);
 }
@@ -371,7 +387,7 @@ PLAT_EXPORT int plat_dp_batch(plat_ctx* ctx, int n, int lmax, const uint8_t* hap
 }
 
 static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStream_t st, long long* cnt, int maxhap,
-                             int maxread, int job_cap, const int32_t* hap_win)
+                             int maxread, long long npairs, int extra_cap, const int32_t* hap_win)
 {
     int tsize_max = 64;
     if (maxhap > 4096) tsize_max = 16384;
@@ -387,7 +403,7 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     if (lds > 64 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_seed, dim3(b.n_haps), dim3(64 * nw), lds, st, b, hap_win, (uint8_t*)ctx->go_blob.ptr,
-                       (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, job_cap, cnt, tsize_max, maxhap, cw);
+                       (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt, tsize_max, maxhap, cw);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -433,35 +449,35 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     if (npairs == 0) return PLAT_OK;
     if ((rc = plat_reserve(ctx, ctx->go_blob, (size_t)hapblob + 64))) return rc;
     if ((rc = plat_reserve(ctx, ctx->pair_rec, (size_t)npairs * sizeof(PairRec)))) return rc;
-    long long job_cap = npairs + npairs / 2 + 1024;
-    if (ctx->jobs.cap / sizeof(Job) > (size_t)job_cap) job_cap = (long long)(ctx->jobs.cap / sizeof(Job));
-    if (job_cap > 0x7FFFFF00ll) job_cap = 0x7FFFFF00ll;
+    long long extra_cap = npairs / 4 + 4096;
+    if ((long long)(ctx->jobs.cap / sizeof(Job)) - npairs > extra_cap) extra_cap = (long long)(ctx->jobs.cap / sizeof(Job)) - npairs;
+    if (extra_cap > 0x7FFFFF00ll) extra_cap = 0x7FFFFF00ll;
 
     long long njobs = 0;
     PLAT_EV(ctx, 1, st);
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if ((rc = plat_reserve(ctx, ctx->jobs, (size_t)job_cap * sizeof(Job)))) return rc;
-        PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_NJOBS], 0, sizeof(long long), st));
-        if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, (int)job_cap, hap_win))) return rc;
+        if ((rc = plat_reserve(ctx, ctx->jobs, (size_t)(npairs + extra_cap) * sizeof(Job)))) return rc;
+        PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_NEXTRA], 0, sizeof(long long), st));
+        if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, npairs, (int)extra_cap, hap_win))) return rc;
         PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
         PLAT_HIP(ctx, hipStreamSynchronize(st));
         if (hb[CNT_ERR] != 0) return (int)hb[CNT_ERR];
-        njobs = hb[CNT_NJOBS];
-        if (njobs <= job_cap) break;
-        if (njobs > 0x7FFFFF00ll) return PLAT_ERR_OVERFLOW;
-        job_cap = njobs;                       // tandem-rich batch: re-run the seeding with the exact capacity
-        if (attempt == 1) return PLAT_ERR_OVERFLOW;
+        const long long nextra = hb[CNT_NEXTRA];
+        njobs = npairs + nextra;
+        if (nextra <= extra_cap) break;
+        if (nextra > 0x7FFFFF00ll || attempt == 1) return PLAT_ERR_OVERFLOW;
+        extra_cap = nextra;                    // tandem-rich batch: re-run the seeding with the exact capacity
     }
     if ((rc = plat_reserve(ctx, ctx->job_score, (size_t)(njobs + 1) * sizeof(int32_t)))) return rc;
     PLAT_EV(ctx, 2, st);
     if (njobs > 0) {
         hipLaunchKernelGGL(k_dp_jobs, dim3((unsigned)((njobs + 255) / 256)), dim3(256), 0, st, b,
-                           (const uint8_t*)ctx->go_blob.ptr, (const Job*)ctx->jobs.ptr, (int)njobs,
+                           (const uint8_t*)ctx->go_blob.ptr, (const Job*)ctx->jobs.ptr, njobs,
                            (int32_t*)ctx->job_score.ptr);
     }
     PLAT_EV(ctx, 3, st);
     if (njobs > 0 && (out_stats || ctx->profile))
-        hipLaunchKernelGGL(k_sum_job_cells, dim3(256), dim3(256), 0, st, (const Job*)ctx->jobs.ptr, (int)njobs, cnt);
+        hipLaunchKernelGGL(k_sum_job_cells, dim3(256), dim3(256), 0, st, (const Job*)ctx->jobs.ptr, njobs, cnt);
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, b,
                        (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr,
                        (const int32_t*)ctx->job_score.ptr, ctx->d_mapq_lut, npairs, out_loglik, out_score, cnt);
@@ -471,13 +487,13 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
         PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
         PLAT_HIP(ctx, hipStreamSynchronize(st));
         ctx->ev_valid_align = ctx->profile;
-        ctx->prof_dp_jobs = njobs;
-        ctx->prof_dp_bytes = hb[CNT_CELLS_RUN] / 4 + 34 * njobs;     // sum(4*len2 + 34); cells = 16*len2
+        ctx->prof_dp_jobs = hb[CNT_NJOBS_RUN];
+        ctx->prof_dp_bytes = hb[CNT_CELLS_RUN] / 4 + 34 * hb[CNT_NJOBS_RUN];     // sum(4*len2 + 34); cells = 16*len2
     }
     if (out_stats) {
         out_stats->n_pairs = npairs;
         out_stats->n_pairs_aligned = hb[CNT_PAIRS_ALIGNED];
-        out_stats->n_dp_launched = njobs;
+        out_stats->n_dp_launched = hb[CNT_NJOBS_RUN];
         out_stats->n_dp_reference = hb[CNT_NDP_REF];
         out_stats->cells_reference = hb[CNT_CELLS_REF];
         out_stats->cells_launched = hb[CNT_CELLS_RUN];
