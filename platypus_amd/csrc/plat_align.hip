@@ -1,15 +1,20 @@
 // plat_align.hip -- device path for Haplotype.alignReads / alignSingleRead.
 //
-// Pipeline of plat_align_window_batch (one stream, one host read-back):
-//   k_validate   : input checks + maxima                     (chaplotype.pyx:180-183 length rule)
-//   k_hap_window : haplotype -> window map
-//   k_seed       : one workgroup per haplotype: haplotype bytes staged in LDS, gap-open annotation
-//                  (a7, chaplotype.pyx:552-590), 7-mer index in LDS (a4, calign.pyx:94-124), then one
-//                  wave per read: diagonal vote (calign.pyx:206-220), arg-max candidate list in
-//                  ascending order (calign.pyx:222-233) -> DP job list in HBM
-//   k_dp_jobs    : one lane per banded DP (a1, align.c:77-586), see dp_core.hpp
-//   k_finalize   : per (read, haplotype): the reference's candidate selection replayed on the job
-//                  scores (calign.pyx:235-267), score -> log-likelihood (a8, chaplotype.pyx:621-676)
+// Pipeline of plat_align_window_batch (one stream, two small host read-backs):
+//   k_validate    input checks + maxima (chaplotype.pyx:180-183 length rule), per-window read-tile shape
+//   k_tile_scan   exclusive scan of the per-window tile sizes
+//   k_prep_reads  one workgroup per window: reads re-laid out as a TRANSPOSED tile of pre-converted words
+//                 tile[w][i][rl] = (base<<9) | (4*qual)<<16  (row i = read position, column rl = read), with 8
+//                 pad rows ('0', 64*4: align.c:223-226) so the DP's 8 extra steps need no branch and a wave's
+//                 64 consecutive reads load 256 contiguous bytes per DP step; plus the rolling 7-mer codes of
+//                 every read (a5 hashReadForMapping, calign.pyx:155-165) and a per-read descriptor.
+//   k_seed        one workgroup per haplotype: bytes staged in LDS, gap-open annotation (a7, chaplotype.pyx:552-590)
+//                 written as haplotype words (base<<9)|(4*gapopen)<<16, 7-mer index in LDS (a4, calign.pyx:94-124),
+//                 then one wave per read: diagonal vote (calign.pyx:206-220) with 16-bit LDS counters and the
+//                 arg-max candidate list in ascending order (calign.pyx:222-233) -> DP jobs
+//   k_dp_jobs     one lane per banded DP (a1, align.c:77-586), see dp_core.hpp
+//   k_finalize    per (read, haplotype): the reference's candidate selection replayed on the job scores
+//                 (calign.pyx:235-267), score -> log-likelihood (a8, chaplotype.pyx:621-676)
 #include "dp_core.hpp"
 #include "plat_internal.hpp"
 
@@ -19,13 +24,15 @@ namespace plat {
 // (tandem repeats: many arg-max diagonals) go to an overflow area behind the npairs primary slots, reserved
 // with one global atomic per such pair.  (A single job counter bumped by every pair saturates one L2
 // atomic unit: ~90 atomics/us, i.e. ~20 ms for 2M pairs -- measured in round 1.)
-struct PairRec { int32_t extra_base, ncand, orig_k, idx0; };   // ncand: -1 skipped read, -2 read shorter than 7
+struct PairRec { int32_t extra_base, idx0; int16_t ncand, orig_k; uint8_t mapq, pad[3]; };   // ncand: -1 skipped, -2 read < 7 bp
+struct Job { uint32_t col; int32_t hap, idx, len; };     // col = tile dword index of the read's column; len 0 = empty slot
+struct ReadInfo { uint32_t col; int32_t stride, len, flags; };   // flags bit0: skipped (QCFail / overlap < 7)
 __device__ __forceinline__ long long job_slot(long long pair, long long npairs, int extra_base, int k) {
     return k == 0 ? pair : npairs + extra_base + (k - 1);
 }
-struct Job { int32_t read, hap, idx, len; };
 
-enum { CNT_ERR = 0, CNT_MAXHAP, CNT_MAXREAD, CNT_NEXTRA, CNT_PAIRS_ALIGNED, CNT_NDP_REF, CNT_CELLS_REF, CNT_CELLS_RUN, CNT_NJOBS_RUN, CNT_N };
+enum { CNT_ERR = 0, CNT_MAXHAP, CNT_MAXREAD, CNT_NEXTRA, CNT_PAIRS_ALIGNED, CNT_NDP_REF, CNT_CELLS_REF, CNT_CELLS_RUN,
+       CNT_NJOBS_RUN, CNT_TILE_TOTAL, CNT_N };
 
 __constant__ signed char c_homopol_go[49] = {   // homopolq[i]-'!' (chaplotype.pyx:64-67); see tests/test_oracle.py
     45, 42, 41, 39, 37, 32, 28, 23, 20, 19, 17, 16, 15, 14, 13, 12, 11, 11, 10, 9, 9, 8, 8, 7, 7, 7, 6, 6, 6, 5, 5, 5,
@@ -36,7 +43,9 @@ __device__ __forceinline__ void set_err(long long* cnt, int code) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void k_validate(plat_window_batch b, long long* cnt)
+// win_rows[w] = max read length in window w + 8 (rows of its read tile); hap_win[h] = window of haplotype h
+__global__ void k_validate(plat_window_batch b, long long* cnt, int32_t* __restrict__ hap_win,
+                           int32_t* __restrict__ win_rows)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
     int maxhap = 0, maxread = 0;
@@ -46,32 +55,66 @@ __global__ void k_validate(plat_window_batch b, long long* cnt)
         if (len < 0) set_err(cnt, PLAT_ERR_BAD_INPUT);
         maxhap = max(maxhap, (int)min(len, 1ll << 20));
     }
-    for (int r = tid; r < b.n_reads; r += nt) {
-        long long len = b.read_off[r + 1] - b.read_off[r];
-        if (len < 0 || len > 32767) set_err(cnt, PLAT_ERR_BAD_INPUT);      // cAlignedRead.rlen is a short
-        maxread = max(maxread, (int)min(max(len, 0ll), 1ll << 20));
-    }
     for (int w = tid; w < b.n_windows; w += nt) {
-        long long H = b.win_hap_begin[w + 1] - b.win_hap_begin[w], R = b.win_read_begin[w + 1] - b.win_read_begin[w];
-        if (H < 0 || R < 0 || b.pair_off[w + 1] - b.pair_off[w] != H * R) set_err(cnt, PLAT_ERR_BAD_INPUT);
+        const int h0 = b.win_hap_begin[w], h1 = b.win_hap_begin[w + 1];
+        const int r0 = b.win_read_begin[w], r1 = b.win_read_begin[w + 1];
+        const long long H = h1 - h0, R = r1 - r0;
+        win_rows[w] = 8;
+        if (H < 0 || R < 0 || b.pair_off[w + 1] - b.pair_off[w] != H * R) { set_err(cnt, PLAT_ERR_BAD_INPUT); continue; }
+        for (int h = h0; h < h1; ++h) hap_win[h] = w;
+        int lm = 0;
+        for (int r = r0; r < r1; ++r) {
+            long long len = b.read_off[r + 1] - b.read_off[r];
+            if (len < 0 || len > 32767) { set_err(cnt, PLAT_ERR_BAD_INPUT); len = 0; }      // cAlignedRead.rlen is a short
+            lm = max(lm, (int)len);
+        }
+        win_rows[w] = lm + 8;
+        maxread = max(maxread, lm);
     }
-    // 7-bit ASCII check over the blobs (the DP packs bases as byte << 9)
+    // 7-bit ASCII check over the blobs (the DP packs bases as byte << 9, qualities as 4*q in 16 bits)
     {
         const long long nh = b.n_haps ? b.hap_off[b.n_haps] : 0, nr = b.n_reads ? b.read_off[b.n_reads] : 0;
+        const long long nh4 = nh >> 2, nr4 = nr >> 2;
         unsigned bad = 0;
-        for (long long i = tid; i < nh; i += nt) bad |= b.hap_seq[i];
-        for (long long i = tid; i < nr; i += nt) bad |= b.read_seq[i] | b.read_qual[i];
-        if (bad & 0x80u) set_err(cnt, PLAT_ERR_BAD_INPUT);
+        const uint32_t* h4 = (const uint32_t*)b.hap_seq;
+        const uint32_t* s4 = (const uint32_t*)b.read_seq;
+        const uint32_t* q4 = (const uint32_t*)b.read_qual;
+        for (long long i = tid; i < nh4; i += nt) bad |= h4[i];
+        for (long long i = tid; i < nr4; i += nt) bad |= s4[i] | q4[i];
+        if (tid < 4) {
+            for (long long i = nh4 * 4 + tid; i < nh; i += 4) bad |= (unsigned)b.hap_seq[i] * 0x01010101u;
+            for (long long i = nr4 * 4 + tid; i < nr; i += 4) bad |= (unsigned)(b.read_seq[i] | b.read_qual[i]) * 0x01010101u;
+        }
+        if (bad & 0x80808080u) set_err(cnt, PLAT_ERR_BAD_INPUT);
     }
     atomicMax((unsigned long long*)&cnt[CNT_MAXHAP], (unsigned long long)maxhap);
     atomicMax((unsigned long long*)&cnt[CNT_MAXREAD], (unsigned long long)maxread);
 }
 
-__global__ void k_hap_window(plat_window_batch b, int32_t* hap_win)
+// exclusive scan of rows*R per window -> tile_off (dwords); single workgroup
+__global__ void __launch_bounds__(1024)
+k_tile_scan(plat_window_batch b, const int32_t* __restrict__ win_rows, long long* __restrict__ tile_off, long long* cnt)
 {
-    int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= b.n_windows) return;
-    for (int h = b.win_hap_begin[w]; h < b.win_hap_begin[w + 1]; ++h) hap_win[h] = w;
+    __shared__ long long part[1024];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int per = (b.n_windows + nt - 1) / nt;
+    const int w0 = min(b.n_windows, t * per), w1 = min(b.n_windows, w0 + per);
+    long long s = 0;
+    for (int w = w0; w < w1; ++w) s += (long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]);
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < nt; d <<= 1) {
+        long long v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    long long run = part[t] - s;
+    for (int w = w0; w < w1; ++w) {
+        tile_off[w] = run;
+        run += (long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]);
+    }
+    if (t == nt - 1) cnt[CNT_TILE_TOTAL] = part[t];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -80,16 +123,71 @@ __device__ __forceinline__ unsigned base2(unsigned ch) {      // calign.pyx:69-7
     if (c == 7u) c = 2u;
     return c & 3u;
 }
-#define CNT16(c, j) (((c)[(j) >> 1] >> (16 * ((j) & 1))) & 0xFFFFu)
+
+__global__ void __launch_bounds__(256)
+k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const long long* __restrict__ tile_off,
+             uint32_t* __restrict__ tile, uint16_t* __restrict__ codes, ReadInfo* __restrict__ rinfo, long long* cnt)
+{
+    const int w = blockIdx.x;
+    const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
+    if (R <= 0) return;
+    const int rows = win_rows[w];
+    const long long toff = tile_off[w];
+    if (toff + (long long)rows * R > 0xFFFFFFFFll) { if (threadIdx.x == 0) set_err(cnt, PLAT_ERR_OVERFLOW); return; }
+    const int wstart = b.win_start[w], wend = b.win_end[w];
+    for (int rl = threadIdx.x; rl < R; rl += blockDim.x) {
+        const int r = rb + rl;
+        const int L = (int)(b.read_off[r + 1] - b.read_off[r]);
+        // skip rule, chaplotype.pyx:343-346 / 358-361 (brokenMates are always aligned, :366-373)
+        int skip = 0;
+        if (b.read_kind[r] != 2) {
+            const int os = max(wstart, b.read_pos[r]), oe = min(wend, b.read_end[r]);
+            const int ov = oe > os ? oe - os : -1;                       // chaplotype.pyx:103-115
+            skip = (b.read_flags[r] & 512) || ov < 7;
+        }
+        rinfo[r] = ReadInfo{(uint32_t)(toff + rl), R, L, skip};
+    }
+    // tile: element (i, rl), rl fastest -> coalesced stores
+    const long long n = (long long)rows * R;
+    for (long long e = threadIdx.x; e < n; e += blockDim.x) {
+        const int i = (int)(e / R), rl = (int)(e - (long long)i * R);
+        const long long ro = b.read_off[rb + rl];
+        const int L = (int)(b.read_off[rb + rl + 1] - ro);
+        tile[toff + e] = i < L ? read_word(b.read_seq[ro + i], b.read_qual[ro + i]) : READ_PAD_WORD;
+    }
+    // rolling 7-mer codes (a5): codes[read_off[r] + i], i < L-7
+    const long long c0 = b.read_off[rb], c1 = b.read_off[rb + R];
+    for (long long e = c0 + threadIdx.x; e < c1; e += blockDim.x) {
+        unsigned code = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) code = (code << 2) + base2(b.read_seq[e + k]);   // entries past L-8 are never used
+        codes[e] = (uint16_t)code;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+#define CNT16(c, j) (((c)[(j) >> 1] >> (16 * ((j) & 1))) & 0x7FFFu)
 __device__ __forceinline__ unsigned tbl_slot(unsigned code, unsigned mask) { return (code * 40503u + (code >> 5)) & mask; }
 
+// k-mer lookup: first haplotype position (+1) holding this code, 0 if none
+__device__ __forceinline__ unsigned kmer_head(const unsigned* table, unsigned code, bool direct, unsigned tmask) {
+    if (direct) return table[code];
+    const unsigned key = (code + 1u) << 16;
+    unsigned slot = tbl_slot(code, tmask);
+    unsigned e = table[slot];
+    while (e != 0u && (e & 0xFFFF0000u) != key) { slot = (slot + 1u) & tmask; e = table[slot]; }
+    return e & 0xFFFFu;
+}
+
 // LDS carve (dynamic):  table u32[tsize_max] | next u16[maxhap+2] | hapb u8[maxhap+16] | counts u16[nw][cw]
-// (counts are 16-bit, two per dword, updated with 32-bit LDS atomics: a count never exceeds readLen-7 < 65536)
+// Counters are 16-bit, two per dword, updated with 32-bit LDS atomics (a count never exceeds readLen-7 < 32768;
+// bit 15 is a claim flag used to pick one representative lane per arg-max diagonal).
 // The k-mer index has two modes: haplotypes up to 4096 bp use a small open-addressing table (>= 2*hapLen
 // entries, more workgroups per CU); longer ones (up to the reference's cap of 16384) index all 4^7 codes
 // directly, as the reference does (calign.pyx:98-99).
 __global__ void __launch_bounds__(256)
-k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, uint8_t* __restrict__ go_blob,
+k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo* __restrict__ rinfo,
+       const uint16_t* __restrict__ codes, uint32_t* __restrict__ hapw, uint8_t* __restrict__ hap_has_n,
        PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
        int tsize_max, int maxhap, int cw)
 {
@@ -98,6 +196,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, uint8_t* __rest
     unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);
     unsigned char* hapb = smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 3 & ~(size_t)3);
     unsigned* counts_all = (unsigned*)(hapb + (((size_t)maxhap + 16) + 3 & ~(size_t)3));
+    int* s_has_n = (int*)(counts_all + (size_t)(blockDim.x >> 6) * (cw >> 1));
 
     const int h = blockIdx.x;
     const int w = hap_win[h];
@@ -114,21 +213,28 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, uint8_t* __rest
     else while (tsize < 2 * hapLen) tsize <<= 1;
     const unsigned tmask = (unsigned)tsize - 1u;
 
+    if (tid == 0) *s_has_n = 0;
     for (int i = tid; i < tsize; i += nthr) table[i] = 0u;
+    for (int i = tid; i < nw * (cw >> 1); i += nthr) counts_all[i] = 0u;
     for (int i = tid; i < hapLen; i += nthr) hapb[i] = b.hap_seq[hoff + i];
     __syncthreads();
 
     // a7: gap-open annotation (chaplotype.pyx:552-590): table[min(48, #following bytes equal to this one)], 'N' -> table[0]
-    for (int p = tid; p < hapLen; p += nthr) {
-        unsigned char c = hapb[p];
-        int run = 0;
-        if (c != 'N') {
-            for (int q = p + 1; q < hapLen && run < 48 && hapb[q] == c; ++q) ++run;
+    // written together with the base as the DP's haplotype word
+    {
+        int anyn = 0;
+        for (int p = tid; p < hapLen; p += nthr) {
+            const unsigned char c = hapb[p];
+            int run = 0;
+            if (c != 'N') {
+                for (int q = p + 1; q < hapLen && run < 48 && hapb[q] == c; ++q) ++run;
+            } else anyn = 1;
+            hapw[hoff + p] = hap_word(c, (unsigned)c_homopol_go[run]);
         }
-        go_blob[hoff + p] = (uint8_t)c_homopol_go[run];
+        if (anyn) *s_has_n = 1;
     }
-    // a4: k-mer index (positions 0..hapLen-8; calign.pyx:109): open addressing on the 14-bit code,
-    // entry = (code+1)<<16 | (pos+1); equal codes are chained through nxt[] (order is irrelevant to the vote)
+    // a4: k-mer index (positions 0..hapLen-8; calign.pyx:109): entry = (code+1)<<16 | (pos+1);
+    // equal codes are chained through nxt[] (the chain order is irrelevant to the vote)
     for (int p = tid; p < hapLen - 7; p += nthr) {
         unsigned code = 0;
 #pragma unroll
@@ -158,56 +264,44 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, uint8_t* __rest
         }
     }
     __syncthreads();
+    if (tid == 0) hap_has_n[h] = (uint8_t)*s_has_n;
 
     const int rb = b.win_read_begin[w], re = b.win_read_begin[w + 1];
     const int R = re - rb;
     const int hl = h - b.win_hap_begin[w];
-    const int wstart = b.win_start[w], wend = b.win_end[w], flank = b.win_flank[w];
-    const int hapStart = wstart - flank;                                    // chaplotype.pyx:606
+    const int hapStart = b.win_start[w] - b.win_flank[w];                   // chaplotype.pyx:606
 
     for (int rl = wave; rl < R; rl += nw) {
         const int r = rb + rl;
         const long long pidx = b.pair_off[w] + (long long)hl * R + rl;
-        const long long roff = b.read_off[r];
-        const int L = (int)(b.read_off[r + 1] - roff);
-        const int rpos = b.read_pos[r];
-        // skip rule, chaplotype.pyx:343-346 / 358-361 (brokenMates are always aligned, :366-373)
-        bool skip = false;
-        if (b.read_kind[r] != 2) {
-            int os = max(wstart, rpos), oe = min(wend, b.read_end[r]);
-            int ov = oe > os ? oe - os : -1;
-            skip = (b.read_flags[r] & 512) || ov < 7;
-        }
-        if (skip || L < 7) {                                                // calign.pyx:179-180
-            if (lane == 0) { pairs[pidx] = PairRec{0, skip ? -1 : -2, 0, 0}; jobs[pidx] = Job{r, h, 0, 0}; }
+        const ReadInfo ri = rinfo[r];
+        const int L = ri.len;
+        const uint8_t mapq = b.read_mapq[r];
+        if ((ri.flags & 1) || L < 7) {                                      // calign.pyx:179-180
+            if (lane == 0) {
+                pairs[pidx] = PairRec{0, 0, (int16_t)((ri.flags & 1) ? -1 : -2), 0, mapq, {0, 0, 0}};
+                jobs[pidx] = Job{ri.col, h, 0, 0};
+            }
             continue;
         }
         if (hapLen < L + 15) {
-            if (lane == 0) { set_err(cnt, PLAT_ERR_HAP_TOO_SHORT); pairs[pidx] = PairRec{0, -1, 0, 0}; jobs[pidx] = Job{r, h, 0, 0}; }
+            if (lane == 0) {
+                set_err(cnt, PLAT_ERR_HAP_TOO_SHORT);
+                pairs[pidx] = PairRec{0, 0, -1, 0, mapq, {0, 0, 0}};
+                jobs[pidx] = Job{ri.col, h, 0, 0};
+            }
             continue;
         }
         const int n = hapLen + L;
-        for (int j = lane; j < ((n + 1) >> 1); j += 64) counts[j] = 0u;
-        // diagonal vote, calign.pyx:209-220
+        const uint16_t* rc = codes + b.read_off[r];
+        // ---- pass 1: diagonal vote, calign.pyx:209-220
         unsigned mymax = 0;
-        const uint8_t* rs = b.read_seq + roff;
         for (int i = lane; i < L - 7; i += 64) {
-            unsigned code = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) code = (code << 2) + base2(rs[i + k]);
-            unsigned hidx;
-            if (direct) hidx = table[code];
-            else {
-                const unsigned key = (code + 1u) << 16;
-                unsigned slot = tbl_slot(code, tmask);
-                unsigned e = table[slot];
-                while (e != 0u && (e & 0xFFFF0000u) != key) { slot = (slot + 1u) & tmask; e = table[slot]; }
-                hidx = e & 0xFFFFu;
-            }
+            unsigned hidx = kmer_head(table, rc[i], direct, tmask);
             while (hidx != 0u) {
                 const int j = (int)hidx - i - 1 + L;
                 const unsigned sh = 16u * (unsigned)(j & 1);
-                unsigned c = ((atomicAdd(&counts[j >> 1], 1u << sh) >> sh) & 0xFFFFu) + 1u;
+                const unsigned c = ((atomicAdd(&counts[j >> 1], 1u << sh) >> sh) & 0x7FFFu) + 1u;
                 mymax = max(mymax, c);
                 hidx = nxt[hidx];
             }
@@ -215,17 +309,31 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, uint8_t* __rest
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) mymax = max(mymax, (unsigned)__shfl_xor((int)mymax, s));
         const unsigned maxcount = mymax;
-        // candidates: counts == maxcount, ascending, idx + L + 15 < hapLen  (calign.pyx:222-228)
-        int ncand = 0;
-        if (maxcount > 0)
-            for (int j0 = 0; j0 < n; j0 += 64) {
-                int j = j0 + lane;
-                bool is = j < n && CNT16(counts, j) == maxcount && (j - L) + L + 15 < hapLen;
-                ncand += __popcll(__ballot(is));
-            }
-        int idx0 = min(rpos - hapStart, hapLen - L - 15);                   // calign.pyx:252
+        const int idx0 = min(b.read_pos[r] - hapStart, hapLen - L - 15);    // calign.pyx:252
         const int j0i = idx0 + L;
         const bool orig_in = maxcount > 0 && j0i >= 0 && j0i < n && CNT16(counts, j0i) == maxcount && idx0 + L + 15 < hapLen;
+        // ---- pass 2: one representative lane per arg-max diagonal (claim bit 15); count the valid ones
+        int ncand = 0, myidx = 0x7FFFFFFF;
+        for (int i = lane; i < L - 7; i += 64) {
+            unsigned hidx = kmer_head(table, rc[i], direct, tmask);
+            while (hidx != 0u) {
+                const int j = (int)hidx - i - 1 + L;
+                const unsigned sh = 16u * (unsigned)(j & 1);
+                if (((counts[j >> 1] >> sh) & 0xFFFFu) == maxcount) {            // arg-max and not yet claimed
+                    const unsigned old = atomicOr(&counts[j >> 1], 0x8000u << sh);
+                    if (!((old >> sh) & 0x8000u) && (j - L) + L + 15 < hapLen) {   // calign.pyx:228
+                        myidx = min(myidx, j - L);
+                        ++ncand;
+                    }
+                }
+                hidx = nxt[hidx];
+            }
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            ncand += __shfl_xor(ncand, s);
+            myidx = min(myidx, __shfl_xor(myidx, s));
+        }
         const int njobs = ncand + (orig_in ? 0 : 1);
         int base = 0;
         if (njobs > 1) {
@@ -234,41 +342,79 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, uint8_t* __rest
         }
         const bool fits = njobs == 1 || (long long)base + (njobs - 1) <= (long long)extra_cap;
         int orig_k = ncand;
-        if (maxcount > 0) {
+        if (ncand == 1) {
+            if (lane == 0) jobs[pidx] = Job{ri.col, h, myidx, L};
+            if (orig_in) orig_k = 0;
+        } else if (ncand > 1) {
+            // several arg-max diagonals (repeats): ordered emission (ascending, calign.pyx:223) by scanning
+            // this read's counters
             int k = 0;
             for (int j0 = 0; j0 < n; j0 += 64) {
-                int j = j0 + lane;
-                bool is = j < n && CNT16(counts, j) == maxcount && (j - L) + L + 15 < hapLen;
-                unsigned long long bal = __ballot(is);
+                const int j = j0 + lane;
+                const bool is = j < n && CNT16(counts, j) == maxcount && (j - L) + L + 15 < hapLen;
+                const unsigned long long bal = __ballot(is);
                 if (is) {
-                    int mypos = k + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (fits || mypos == 0) jobs[job_slot(pidx, npairs, base, mypos)] = Job{r, h, j - L, L};
+                    const int mypos = k + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (fits || mypos == 0) jobs[job_slot(pidx, npairs, base, mypos)] = Job{ri.col, h, j - L, L};
                 }
-                if (orig_in && j0i >= j0 && j0i < j0 + 64)
-                    orig_k = k + __popcll(bal & ((1ull << (j0i - j0)) - 1ull));
+                if (orig_in && j0i >= j0 && j0i < j0 + 64) orig_k = k + __popcll(bal & ((1ull << (j0i - j0)) - 1ull));
                 k += __popcll(bal);
             }
         }
         if (lane == 0) {
-            if (!orig_in && (fits || ncand == 0)) jobs[job_slot(pidx, npairs, base, ncand)] = Job{r, h, idx0, L};
-            pairs[pidx] = PairRec{base, ncand, orig_k, idx0};
+            if (!orig_in && (fits || ncand == 0)) jobs[job_slot(pidx, npairs, base, ncand)] = Job{ri.col, h, idx0, L};
+            pairs[pidx] = PairRec{base, idx0, (int16_t)ncand, (int16_t)orig_k, mapq, {0, 0, 0}};
+        }
+        // ---- pass 3: clear the counters this read touched
+        for (int i = lane; i < L - 7; i += 64) {
+            unsigned hidx = kmer_head(table, rc[i], direct, tmask);
+            while (hidx != 0u) {
+                counts[((int)hidx - i - 1 + L) >> 1] = 0u;
+                hidx = nxt[hidx];
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
+template <bool HAS_N>
+__device__ __forceinline__ int dp_tile(const uint32_t* __restrict__ rp, int stride, const uint32_t* __restrict__ hp, int len2)
+{
+    DP<HAS_N> dp;
+    uint32_t w0[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w0[k] = hp[k];
+    dp.init(w0, 3, 2);                                                       // chaplotype.pyx:607-608
+    hp += 8;
+    auto rw = [&](int h) -> uint32_t { return rp[(long long)h * stride]; };
+    auto hw = [&](int h) -> uint32_t { return hp[h]; };
+    return dp_run<HAS_N>(dp, len2, rw, hw);
+}
+
 __global__ void __launch_bounds__(256)
-k_dp_jobs(plat_window_batch b, const uint8_t* __restrict__ go_blob, const Job* __restrict__ jobs,
+k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32_t* __restrict__ tile,
+          const uint32_t* __restrict__ hapw, const uint8_t* __restrict__ hap_has_n, const Job* __restrict__ jobs,
           long long njobs, int32_t* __restrict__ job_score)
 {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= njobs) return;
-    const Job jb = jobs[j];
-    if (jb.len == 0) return;                                                // slot of a skipped pair
-    const int st = max(0, jb.idx - 8);                                      // calign.pyx:229,256
-    const long long hoff = b.hap_off[jb.hap] + st;
-    const long long roff = b.read_off[jb.read];
-    job_score[j] = dp_score(b.hap_seq + hoff, go_blob + hoff, b.read_seq + roff, b.read_qual + roff, jb.len, 3, 2);
+    bool active = j < njobs;
+    Job jb = Job{0, 0, 0, 0};
+    if (active) jb = jobs[j];
+    active = active && jb.len != 0;                                          // len 0: slot of a skipped pair
+    int has_n = 0, stride = 0;
+    if (active) {
+        has_n = hap_has_n[jb.hap];
+        const int w = hap_win[jb.hap];
+        stride = b.win_read_begin[w + 1] - b.win_read_begin[w];
+    }
+    const int st = max(0, jb.idx - 8);                                       // calign.pyx:229,256
+    const uint32_t* hp = hapw + (active ? b.hap_off[jb.hap] + st : 0);
+    const uint32_t* rp = tile + jb.col;
+    if (__any(has_n)) {                                                      // wave-uniform choice of the code path
+        if (active) job_score[j] = dp_tile<true>(rp, stride, hp, jb.len);
+    } else {
+        if (active) job_score[j] = dp_tile<false>(rp, stride, hp, jb.len);
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -279,14 +425,14 @@ k_dp_rows(int n, int lmax, const uint8_t* __restrict__ haps, const uint8_t* __re
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const size_t ho = (size_t)j * (lmax + 15), ro = (size_t)j * lmax;
-    out[j] = dp_score(haps + ho, gos + ho, reads + ro, quals + ro, len2[j], gapextend, nucprior);
+    out[j] = dp_score_bytes(haps + ho, gos + ho, reads + ro, quals + ro, len2[j], gapextend, nucprior);
 }
 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_finalize(plat_window_batch b, const PairRec* __restrict__ pairs, const Job* __restrict__ jobs,
-           const int32_t* __restrict__ job_score, const double* __restrict__ mapq_lut, long long npairs,
-           double* __restrict__ out_ll, int32_t* __restrict__ out_score, long long* cnt)
+k_finalize(const PairRec* __restrict__ pairs, const Job* __restrict__ jobs, const int32_t* __restrict__ job_score,
+           const double* __restrict__ mapq_lut, long long npairs, double* __restrict__ out_ll,
+           int32_t* __restrict__ out_score, long long* cnt)
 {
     __shared__ unsigned long long s_acc[4];
     if (threadIdx.x < 4) s_acc[threadIdx.x] = 0ull;
@@ -294,15 +440,6 @@ k_finalize(plat_window_batch b, const PairRec* __restrict__ pairs, const Job* __
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long aligned = 0, ndp = 0, cells = 0;
     if (p < npairs) {
-        // window of this pair: largest w with pair_off[w] <= p
-        int lo = 0, hi = b.n_windows;
-        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (b.pair_off[mid] <= p) lo = mid; else hi = mid; }
-        // windows with zero pairs share offsets: step to the last window whose offset <= p and that is non-empty
-        while (lo + 1 < b.n_windows && b.pair_off[lo + 1] <= p) ++lo;
-        const int w = lo;
-        const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
-        const int rl = (int)((p - b.pair_off[w]) % R);
-        const int r = rb + rl;
         const PairRec pr = pairs[p];
         double ll = 0.0;
         int score = -1;
@@ -315,7 +452,7 @@ k_finalize(plat_window_batch b, const PairRec* __restrict__ pairs, const Job* __
                 const int L = jobs[p].len;
                 for (int k = 0; k < pr.ncand; ++k) {                        // calign.pyx:223-247
                     const long long js = job_slot(p, npairs, pr.extra_base, k);
-                    int sc = job_score[js];
+                    const int sc = job_score[js];
                     ++ndp;
                     if (sc < best) {
                         best = sc; bestPos = jobs[js].idx;
@@ -323,21 +460,20 @@ k_finalize(plat_window_batch b, const PairRec* __restrict__ pairs, const Job* __
                     }
                 }
                 if (!done && pr.idx0 != bestPos) {                          // calign.pyx:255-267
-                    int sc = job_score[job_slot(p, npairs, pr.extra_base, pr.orig_k)];
+                    const int sc = job_score[job_slot(p, npairs, pr.extra_base, pr.orig_k)];
                     ++ndp;
                     if (sc < best) best = sc;
                 }
                 cells = ndp * 16ull * (unsigned long long)L;
             }
             score = best;
-            const double v = -0.23025850929940459 * (double)best + mapq_lut[b.read_mapq[r]];   // chaplotype.pyx:676
+            const double v = -0.23025850929940459 * (double)best + mapq_lut[pr.mapq];   // chaplotype.pyx:676
             ll = v > -300.0 ? v : -300.0;
             aligned = 1;
         }
         out_ll[p] = ll;
         if (out_score) out_score[p] = score;
     }
-    // block reduction of the statistics
     for (int s = 32; s > 0; s >>= 1) {
         aligned += __shfl_xor((long long)aligned, s);
         ndp += __shfl_xor((long long)ndp, s);
@@ -361,10 +497,11 @@ __global__ void k_sum_job_cells(const Job* __restrict__ jobs, long long njobs, l
         c += 16ull * jobs[j].len;
         n += jobs[j].len != 0;
     }
-    for (int s = 32; s > 0; s >>= 1) n += __shfl_xor((long long)n, s);
-    if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)&cnt[CNT_NJOBS_RUN], n);
-    for (int s = 32; s > 0; s >>= 1) c += __shfl_xor((long long)c, s);
-    if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)&cnt[CNT_CELLS_RUN], c);
+    for (int s = 32; s > 0; s >>= 1) { c += __shfl_xor((long long)c, s); n += __shfl_xor((long long)n, s); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long*)&cnt[CNT_CELLS_RUN], c);
+        atomicAdd((unsigned long long*)&cnt[CNT_NJOBS_RUN], n);
+    }
 }
 
 }  // namespace plat
@@ -394,15 +531,16 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     else while (tsize_max < 2 * maxhap) tsize_max <<= 1;
     const int cw = (maxhap + maxread + 8 + 1) & ~1;            // 16-bit counters, even count
     const size_t fixed = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 3) & ~(size_t)3) +
-                         ((((size_t)maxhap + 16) + 3) & ~(size_t)3);
+                         ((((size_t)maxhap + 16) + 3) & ~(size_t)3) + 16;
     const size_t lds_cap = 160 * 1024;
     int nw = 4;
     while (nw > 1 && fixed + (size_t)nw * cw * 2 > lds_cap) nw >>= 1;
     const size_t lds = fixed + (size_t)nw * cw * 2;
     if (lds > lds_cap) return PLAT_ERR_HAP_TOO_LONG;
-    if (lds > 64 * 1024)
+    if (lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_seed, dim3(b.n_haps), dim3(64 * nw), lds, st, b, hap_win, (uint8_t*)ctx->go_blob.ptr,
+    hipLaunchKernelGGL(k_seed, dim3(b.n_haps), dim3(64 * nw), lds, st, b, hap_win, (const ReadInfo*)ctx->rinfo.ptr,
+                       (const uint16_t*)ctx->codes.ptr, (uint32_t*)ctx->hapw.ptr, (uint8_t*)ctx->hap_flags.ptr,
                        (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt, tsize_max, maxhap, cw);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
@@ -427,32 +565,48 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     hipStream_t st = (hipStream_t)stream;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
 
-    int rc = plat_reserve(ctx, ctx->counters, (CNT_N + 8) * sizeof(long long) + (size_t)b.n_haps * sizeof(int32_t));
+    // small per-batch arrays: counters | hap_win[n_haps] | win_rows[n_windows] | tile_off[n_windows]
+    const size_t o_hapwin = (CNT_N + 8) * sizeof(long long);
+    const size_t o_rows = o_hapwin + (((size_t)b.n_haps * 4 + 7) & ~(size_t)7);
+    const size_t o_toff = o_rows + (((size_t)b.n_windows * 4 + 7) & ~(size_t)7);
+    int rc = plat_reserve(ctx, ctx->counters, o_toff + (size_t)b.n_windows * 8 + 64);
     if (rc) return rc;
-    long long* cnt = (long long*)ctx->counters.ptr;
-    int32_t* hap_win = (int32_t*)(cnt + CNT_N + 8);
+    char* cbase = (char*)ctx->counters.ptr;
+    long long* cnt = (long long*)cbase;
+    int32_t* hap_win = (int32_t*)(cbase + o_hapwin);
+    int32_t* win_rows = (int32_t*)(cbase + o_rows);
+    long long* tile_off = (long long*)(cbase + o_toff);
+    if ((rc = plat_reserve(ctx, ctx->rinfo, (size_t)(b.n_reads + 1) * sizeof(ReadInfo)))) return rc;
+    if ((rc = plat_reserve(ctx, ctx->hap_flags, (size_t)b.n_haps + 64))) return rc;
+
     ctx->ev_valid_align = 0;
     PLAT_EV(ctx, 0, st);
     PLAT_HIP(ctx, hipMemsetAsync(cnt, 0, (CNT_N + 8) * sizeof(long long), st));
-    hipLaunchKernelGGL(k_validate, dim3(1024), dim3(256), 0, st, b, cnt);
-    hipLaunchKernelGGL(k_hap_window, dim3((b.n_windows + 255) / 256), dim3(256), 0, st, b, hap_win);
+    hipLaunchKernelGGL(k_validate, dim3(1024), dim3(256), 0, st, b, cnt, hap_win, win_rows);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, b, win_rows, tile_off, cnt);
     PLAT_HIP(ctx, hipGetLastError());
-    // read back: error, maxima, blob length, number of pairs
+    // read back: error, maxima, blob lengths, number of pairs, tile size
     int64_t* hb = ctx->h_readback;
     PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
     PLAT_HIP(ctx, hipMemcpyAsync(hb + 16, b.hap_off + b.n_haps, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     PLAT_HIP(ctx, hipMemcpyAsync(hb + 17, b.pair_off + b.n_windows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PLAT_HIP(ctx, hipMemcpyAsync(hb + 18, b.read_off + b.n_reads, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     PLAT_HIP(ctx, hipStreamSynchronize(st));
     if (hb[CNT_ERR] != 0) return (int)hb[CNT_ERR];
     const int maxhap = (int)hb[CNT_MAXHAP], maxread = (int)hb[CNT_MAXREAD];
-    const long long hapblob = hb[16], npairs = hb[17];
+    const long long hapblob = hb[16], npairs = hb[17], readblob = hb[18], tile_total = hb[CNT_TILE_TOTAL];
     if (npairs == 0) return PLAT_OK;
-    if ((rc = plat_reserve(ctx, ctx->go_blob, (size_t)hapblob + 64))) return rc;
+    if (tile_total > 0xFFFFFFF0ll) return PLAT_ERR_OVERFLOW;        // split the batch: a tile column index is 32 bits
+    if ((rc = plat_reserve(ctx, ctx->hapw, ((size_t)hapblob + 64) * 4))) return rc;
+    if ((rc = plat_reserve(ctx, ctx->tile, ((size_t)tile_total + 64) * 4))) return rc;
+    if ((rc = plat_reserve(ctx, ctx->codes, ((size_t)readblob + 64) * 2))) return rc;
     if ((rc = plat_reserve(ctx, ctx->pair_rec, (size_t)npairs * sizeof(PairRec)))) return rc;
     long long extra_cap = npairs / 4 + 4096;
     if ((long long)(ctx->jobs.cap / sizeof(Job)) - npairs > extra_cap) extra_cap = (long long)(ctx->jobs.cap / sizeof(Job)) - npairs;
     if (extra_cap > 0x7FFFFF00ll) extra_cap = 0x7FFFFF00ll;
 
+    hipLaunchKernelGGL(k_prep_reads, dim3(b.n_windows), dim3(256), 0, st, b, win_rows, tile_off, (uint32_t*)ctx->tile.ptr,
+                       (uint16_t*)ctx->codes.ptr, (ReadInfo*)ctx->rinfo.ptr, cnt);
     long long njobs = 0;
     PLAT_EV(ctx, 1, st);
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -470,15 +624,14 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     }
     if ((rc = plat_reserve(ctx, ctx->job_score, (size_t)(njobs + 1) * sizeof(int32_t)))) return rc;
     PLAT_EV(ctx, 2, st);
-    if (njobs > 0) {
-        hipLaunchKernelGGL(k_dp_jobs, dim3((unsigned)((njobs + 255) / 256)), dim3(256), 0, st, b,
-                           (const uint8_t*)ctx->go_blob.ptr, (const Job*)ctx->jobs.ptr, njobs,
-                           (int32_t*)ctx->job_score.ptr);
-    }
+    hipLaunchKernelGGL(k_dp_jobs, dim3((unsigned)((njobs + 255) / 256)), dim3(256), 0, st, b, hap_win,
+                       (const uint32_t*)ctx->tile.ptr, (const uint32_t*)ctx->hapw.ptr,
+                       (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr, njobs,
+                       (int32_t*)ctx->job_score.ptr);
     PLAT_EV(ctx, 3, st);
-    if (njobs > 0 && (out_stats || ctx->profile))
+    if (out_stats || ctx->profile)
         hipLaunchKernelGGL(k_sum_job_cells, dim3(256), dim3(256), 0, st, (const Job*)ctx->jobs.ptr, njobs, cnt);
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, b,
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
                        (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr,
                        (const int32_t*)ctx->job_score.ptr, ctx->d_mapq_lut, npairs, out_loglik, out_score, cnt);
     PLAT_HIP(ctx, hipGetLastError());
