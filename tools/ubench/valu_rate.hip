@@ -1,0 +1,82 @@
+// Micro-benchmark: issue rate of the integer VALU ops the DP kernel is made of (gfx950), inline asm so
+// nothing is folded.  8 independent dependency chains per lane, 8 waves/SIMD resident.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+template <int OP>
+__global__ void __launch_bounds__(256) k(uint32_t* out, int iters, uint32_t seed)
+{
+    uint32_t a[8], b = seed ^ threadIdx.x, c = 0x05040100u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = seed + i * 77 + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (OP == 0) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 1) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 2) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 3) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 4) asm volatile("v_min_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 5) asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 6) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 7) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 8) asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 9) asm volatile("v_min_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 10) asm volatile("v_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 11) asm volatile("v_lshl_or_b32 %0, %0, 16, %1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 12) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 13) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 14) asm volatile("v_pk_mad_u16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 15) asm volatile("v_pk_sub_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 16) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 17) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 18) asm volatile("v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b), "v"(c));
+            }
+        }
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s ^= a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int OP> void run(const char* name, uint32_t* d, int blocks)
+{
+    const int iters = 2000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<OP><<<blocks, 256>>>(d, 10, 1);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k<OP><<<blocks, 256>>>(d, iters, 7);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double wave_instr = (double)blocks * 256 * iters * 16 * 8 / 64;
+    printf("%-22s %8.3f ms  %8.1f G wave-instr/s   %.2f cycles per wave-instr per SIMD (if 2.4 GHz, 1024 SIMDs)\n", name, ms,
+           wave_instr / ms / 1e6, 2.4e9 * 1024 / (wave_instr / (ms * 1e-3)));
+}
+int main()
+{
+    uint32_t* d; const int blocks = 256 * 8;
+    hipMalloc(&d, (size_t)blocks * 256 * 4);
+    run<0>("v_pk_add_u16", d, blocks);
+    run<1>("v_pk_min_i16", d, blocks);
+    run<2>("v_pk_min_u16", d, blocks);
+    run<3>("v_add_u32", d, blocks);
+    run<4>("v_min_i32", d, blocks);
+    run<5>("v_alignbit_b32", d, blocks);
+    run<6>("v_perm_b32", d, blocks);
+    run<7>("v_xor_b32", d, blocks);
+    run<8>("v_min3_i32", d, blocks);
+    run<9>("v_min_i16", d, blocks);
+    run<10>("v_add_u16", d, blocks);
+    run<11>("v_lshl_or_b32", d, blocks);
+    run<12>("v_and_or_b32", d, blocks);
+    run<13>("v_pk_add_i16_2indep", d, blocks);
+    run<14>("v_pk_mad_u16", d, blocks);
+    run<15>("v_pk_sub_u16", d, blocks);
+    run<16>("v_pk_max_i16", d, blocks);
+    run<17>("v_mov_b32_dpp_shr1", d, blocks);
+    run<18>("v_add_u32_dpp", d, blocks);
+    return 0;
+}
