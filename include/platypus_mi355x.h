@@ -147,6 +147,8 @@ typedef struct plat_align_stats {
     int64_t n_dp_reference;   /* fastAlignmentRoutine calls the reference would have made             */
     int64_t cells_reference;  /* sum over those calls of 16*len2 (the GCUPS numerator)   */
     int64_t cells_launched;   /* sum over launched DPs of 16*len2                                      */
+    int64_t n_seed_fallback;  /* pairs whose candidate diagonals needed the full vote (not provably unique)   */
+    int64_t _reserved;
 } plat_align_stats;
 
 int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* batch, int calc_flank_score,

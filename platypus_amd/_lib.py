@@ -40,7 +40,8 @@ class WindowBatch(C.Structure):
 
 class AlignStats(C.Structure):
     _fields_ = [("n_pairs", C.c_int64), ("n_pairs_aligned", C.c_int64), ("n_dp_launched", C.c_int64),
-                ("n_dp_reference", C.c_int64), ("cells_reference", C.c_int64), ("cells_launched", C.c_int64)]
+                ("n_dp_reference", C.c_int64), ("cells_reference", C.c_int64), ("cells_launched", C.c_int64),
+                ("n_seed_fallback", C.c_int64), ("_reserved", C.c_int64)]
 
 
 class Profile(C.Structure):

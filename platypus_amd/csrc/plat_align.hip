@@ -26,13 +26,15 @@ namespace plat {
 // atomic unit: ~90 atomics/us, i.e. ~20 ms for 2M pairs -- measured in round 1.)
 struct PairRec { int32_t extra_base, idx0; int16_t ncand, orig_k; uint8_t mapq, pad[3]; };   // ncand: -1 skipped, -2 read < 7 bp
 struct Job { uint32_t col; int32_t hap, idx, len; };     // col = tile dword index of the read's column; len 0 = empty slot
-struct ReadInfo { uint32_t col; int32_t stride, len, flags; };   // flags bit0: skipped (QCFail / overlap < 7)
+// per-read descriptor: tile column, offset of the k-mer codes, mapping position, len | flags<<16 | mapq<<24
+// (flags bit0: skipped by the QCFail / overlap < 7 rule)
+struct ReadInfo { uint32_t col, code_off; int32_t pos; uint32_t lfm; };
 __device__ __forceinline__ long long job_slot(long long pair, long long npairs, int extra_base, int k) {
     return k == 0 ? pair : npairs + extra_base + (k - 1);
 }
 
 enum { CNT_ERR = 0, CNT_MAXHAP, CNT_MAXREAD, CNT_NEXTRA, CNT_PAIRS_ALIGNED, CNT_NDP_REF, CNT_CELLS_REF, CNT_CELLS_RUN,
-       CNT_NJOBS_RUN, CNT_TILE_TOTAL, CNT_N };
+       CNT_NJOBS_RUN, CNT_TILE_TOTAL, CNT_SLOW_SEED, CNT_N };
 
 __constant__ signed char c_homopol_go[49] = {   // homopolq[i]-'!' (chaplotype.pyx:64-67); see tests/test_oracle.py
     45, 42, 41, 39, 37, 32, 28, 23, 20, 19, 17, 16, 15, 14, 13, 12, 11, 11, 10, 9, 9, 8, 8, 7, 7, 7, 6, 6, 6, 5, 5, 5,
@@ -145,7 +147,8 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             const int ov = oe > os ? oe - os : -1;                       // chaplotype.pyx:103-115
             skip = (b.read_flags[r] & 512) || ov < 7;
         }
-        rinfo[r] = ReadInfo{(uint32_t)(toff + rl), R, L, skip};
+        rinfo[r] = ReadInfo{(uint32_t)(toff + rl), (uint32_t)b.read_off[r], b.read_pos[r],
+                            (uint32_t)L | ((uint32_t)skip << 16) | ((uint32_t)b.read_mapq[r] << 24)};
     }
     // tile: element (i, rl), rl fastest -> coalesced stores
     const long long n = (long long)rows * R;
@@ -275,11 +278,12 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
         const int r = rb + rl;
         const long long pidx = b.pair_off[w] + (long long)hl * R + rl;
         const ReadInfo ri = rinfo[r];
-        const int L = ri.len;
-        const uint8_t mapq = b.read_mapq[r];
-        if ((ri.flags & 1) || L < 7) {                                      // calign.pyx:179-180
+        const int L = (int)(ri.lfm & 0xFFFFu);
+        const int rflags = (int)((ri.lfm >> 16) & 0xFFu);
+        const uint8_t mapq = (uint8_t)(ri.lfm >> 24);
+        if ((rflags & 1) || L < 7) {                                        // calign.pyx:179-180
             if (lane == 0) {
-                pairs[pidx] = PairRec{0, 0, (int16_t)((ri.flags & 1) ? -1 : -2), 0, mapq, {0, 0, 0}};
+                pairs[pidx] = PairRec{0, 0, (int16_t)((rflags & 1) ? -1 : -2), 0, mapq, {0, 0, 0}};
                 jobs[pidx] = Job{ri.col, h, 0, 0};
             }
             continue;
@@ -292,47 +296,104 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
             }
             continue;
         }
-        const int n = hapLen + L;
-        const uint16_t* rc = codes + b.read_off[r];
-        // ---- pass 1: diagonal vote, calign.pyx:209-220
-        unsigned mymax = 0;
-        for (int i = lane; i < L - 7; i += 64) {
-            unsigned hidx = kmer_head(table, rc[i], direct, tmask);
-            while (hidx != 0u) {
-                const int j = (int)hidx - i - 1 + L;
-                const unsigned sh = 16u * (unsigned)(j & 1);
-                const unsigned c = ((atomicAdd(&counts[j >> 1], 1u << sh) >> sh) & 0x7FFFu) + 1u;
-                mymax = max(mymax, c);
-                hidx = nxt[hidx];
-            }
-        }
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) mymax = max(mymax, (unsigned)__shfl_xor((int)mymax, s));
-        const unsigned maxcount = mymax;
-        const int idx0 = min(b.read_pos[r] - hapStart, hapLen - L - 15);    // calign.pyx:252
+        const int n = hapLen + L, nk = L - 7;
+        const uint16_t* rc = codes + ri.code_off;
+        const int idx0 = min(ri.pos - hapStart, hapLen - L - 15);           // calign.pyx:252
         const int j0i = idx0 + L;
-        const bool orig_in = maxcount > 0 && j0i >= 0 && j0i < n && CNT16(counts, j0i) == maxcount && idx0 + L + 15 < hapLen;
-        // ---- pass 2: one representative lane per arg-max diagonal (claim bit 15); count the valid ones
         int ncand = 0, myidx = 0x7FFFFFFF;
-        for (int i = lane; i < L - 7; i += 64) {
-            unsigned hidx = kmer_head(table, rc[i], direct, tmask);
-            while (hidx != 0u) {
-                const int j = (int)hidx - i - 1 + L;
-                const unsigned sh = 16u * (unsigned)(j & 1);
-                if (((counts[j >> 1] >> sh) & 0xFFFFu) == maxcount) {            // arg-max and not yet claimed
-                    const unsigned old = atomicOr(&counts[j >> 1], 0x8000u << sh);
-                    if (!((old >> sh) & 0x8000u) && (j - L) + L + 15 < hapLen) {   // calign.pyx:228
-                        myidx = min(myidx, j - L);
-                        ++ncand;
-                    }
+        bool orig_in = false, decided = false;
+
+        // ---- fast path: prove that ONE diagonal d* is the unique arg-max of the vote without counting.
+        // C = #k-mers with an occurrence on d*; X = #occurrences of the read's k-mers off d*.  Any other diagonal
+        // collects at most X votes, so X < C  =>  d* is the only candidate of calign.pyx:222-233.
+        if (nk <= 256) {
+            unsigned head[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int i = lane + 64 * t;
+                head[t] = i < nk ? kmer_head(table, rc[i], direct, tmask) : 0u;
+            }
+            int dstar = 0;
+            bool have = false;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const unsigned long long m = __ballot(head[t] != 0u);
+                if (!have && m) {
+                    dstar = __shfl((int)head[t] - (lane + 64 * t) - 1, (int)__ffsll((long long)m) - 1);
+                    have = true;
                 }
-                hidx = nxt[hidx];
+            }
+            if (!have) decided = true;                                      // no k-mer hit at all: maxcount == 0
+            else {
+                int C = 0, X = 0, myC = 0, myX = 0;
+                unsigned long long anymulti = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int i = lane + 64 * t;
+                    const bool hit = head[t] != 0u;
+                    const unsigned nx = hit ? nxt[head[t]] : 0u;
+                    const bool on = hit && ((int)head[t] - i - 1 == dstar);
+                    C += __popcll(__ballot(hit && nx == 0u && on));
+                    X += __popcll(__ballot(hit && nx == 0u && !on));
+                    const bool multi = hit && nx != 0u;
+                    if (multi) {
+                        int occ = 0, onany = 0;
+                        for (unsigned hh = head[t]; hh != 0u; hh = nxt[hh]) { ++occ; onany |= ((int)hh - i - 1 == dstar); }
+                        myC += onany; myX += occ - onany;
+                    }
+                    anymulti |= __ballot(multi);
+                }
+                if (anymulti) {
+#pragma unroll
+                    for (int s2 = 32; s2 > 0; s2 >>= 1) { myC += __shfl_xor(myC, s2); myX += __shfl_xor(myX, s2); }
+                    C += myC; X += myX;
+                }
+                if (X < C) {
+                    decided = true;
+                    if (dstar + L + 15 < hapLen) { ncand = 1; myidx = dstar; orig_in = (idx0 == dstar); }   // calign.pyx:228
+                }
             }
         }
+        unsigned maxcount = 0;
+        if (!decided) {
+            if (lane == 0) atomicAdd((unsigned long long*)&cnt[CNT_SLOW_SEED], 1ull);
+            // ---- pass 1: diagonal vote, calign.pyx:209-220
+            unsigned mymax = 0;
+            for (int i = lane; i < nk; i += 64) {
+                unsigned hidx = kmer_head(table, rc[i], direct, tmask);
+                while (hidx != 0u) {
+                    const int j = (int)hidx - i - 1 + L;
+                    const unsigned sh = 16u * (unsigned)(j & 1);
+                    const unsigned c = ((atomicAdd(&counts[j >> 1], 1u << sh) >> sh) & 0x7FFFu) + 1u;
+                    mymax = max(mymax, c);
+                    hidx = nxt[hidx];
+                }
+            }
 #pragma unroll
-        for (int s = 32; s > 0; s >>= 1) {
-            ncand += __shfl_xor(ncand, s);
-            myidx = min(myidx, __shfl_xor(myidx, s));
+            for (int s2 = 32; s2 > 0; s2 >>= 1) mymax = max(mymax, (unsigned)__shfl_xor((int)mymax, s2));
+            maxcount = mymax;
+            orig_in = maxcount > 0 && j0i >= 0 && j0i < n && CNT16(counts, j0i) == maxcount && idx0 + L + 15 < hapLen;
+            // ---- pass 2: one representative lane per arg-max diagonal (claim bit 15); count the valid ones
+            for (int i = lane; i < nk; i += 64) {
+                unsigned hidx = kmer_head(table, rc[i], direct, tmask);
+                while (hidx != 0u) {
+                    const int j = (int)hidx - i - 1 + L;
+                    const unsigned sh = 16u * (unsigned)(j & 1);
+                    if (((counts[j >> 1] >> sh) & 0xFFFFu) == maxcount) {        // arg-max and not yet claimed
+                        const unsigned old = atomicOr(&counts[j >> 1], 0x8000u << sh);
+                        if (!((old >> sh) & 0x8000u) && (j - L) + L + 15 < hapLen) {   // calign.pyx:228
+                            myidx = min(myidx, j - L);
+                            ++ncand;
+                        }
+                    }
+                    hidx = nxt[hidx];
+                }
+            }
+#pragma unroll
+            for (int s2 = 32; s2 > 0; s2 >>= 1) {
+                ncand += __shfl_xor(ncand, s2);
+                myidx = min(myidx, __shfl_xor(myidx, s2));
+            }
         }
         const int njobs = ncand + (orig_in ? 0 : 1);
         int base = 0;
@@ -346,8 +407,8 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
             if (lane == 0) jobs[pidx] = Job{ri.col, h, myidx, L};
             if (orig_in) orig_k = 0;
         } else if (ncand > 1) {
-            // several arg-max diagonals (repeats): ordered emission (ascending, calign.pyx:223) by scanning
-            // this read's counters
+            // several arg-max diagonals (repeats; slow path only): ordered emission (ascending, calign.pyx:223)
+            // by scanning this read's counters
             int k = 0;
             for (int j0 = 0; j0 < n; j0 += 64) {
                 const int j = j0 + lane;
@@ -365,12 +426,14 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
             if (!orig_in && (fits || ncand == 0)) jobs[job_slot(pidx, npairs, base, ncand)] = Job{ri.col, h, idx0, L};
             pairs[pidx] = PairRec{base, idx0, (int16_t)ncand, (int16_t)orig_k, mapq, {0, 0, 0}};
         }
-        // ---- pass 3: clear the counters this read touched
-        for (int i = lane; i < L - 7; i += 64) {
-            unsigned hidx = kmer_head(table, rc[i], direct, tmask);
-            while (hidx != 0u) {
-                counts[((int)hidx - i - 1 + L) >> 1] = 0u;
-                hidx = nxt[hidx];
+        if (!decided) {
+            // ---- pass 3: clear the counters this read touched
+            for (int i = lane; i < nk; i += 64) {
+                unsigned hidx = kmer_head(table, rc[i], direct, tmask);
+                while (hidx != 0u) {
+                    counts[((int)hidx - i - 1 + L) >> 1] = 0u;
+                    hidx = nxt[hidx];
+                }
             }
         }
     }
@@ -391,15 +454,33 @@ __device__ __forceinline__ int dp_tile(const uint32_t* __restrict__ rp, int stri
     return dp_run<HAS_N>(dp, len2, rw, hw);
 }
 
+__device__ __forceinline__ double loglik_of(int score, const double* __restrict__ mapq_lut, int mapq) {
+    const double v = -0.23025850929940459 * (double)score + mapq_lut[mapq];   // chaplotype.pyx:676 (no FMA: -ffp-contract=off)
+    return v > -300.0 ? v : -300.0;
+}
+
+// Slot j < npairs is the primary DP of pair j.  Pairs that need a single DP (one candidate that is also the mapping
+// position, or no candidate at all) are finished right here: score -> log-likelihood (a8).  Only pairs with several
+// candidate DPs go through k_finalize_multi.
 __global__ void __launch_bounds__(256)
 k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32_t* __restrict__ tile,
           const uint32_t* __restrict__ hapw, const uint8_t* __restrict__ hap_has_n, const Job* __restrict__ jobs,
-          long long njobs, int32_t* __restrict__ job_score)
+          const PairRec* __restrict__ pairs, const double* __restrict__ mapq_lut, long long npairs,
+          long long njobs, int32_t* __restrict__ job_score, double* __restrict__ out_ll, int32_t* __restrict__ out_score)
 {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     bool active = j < njobs;
     Job jb = Job{0, 0, 0, 0};
+    PairRec pr = PairRec{0, 0, 1, 1, 0, {0, 0, 0}};
     if (active) jb = jobs[j];
+    const bool primary = active && j < npairs;
+    if (primary) {
+        pr = pairs[j];
+        if (pr.ncand < 0) {                                                 // skipped read (0.0, chaplotype.pyx:345-346) or read < 7 bp (score 0)
+            out_ll[j] = pr.ncand == -1 ? 0.0 : loglik_of(0, mapq_lut, pr.mapq);
+            if (out_score) out_score[j] = pr.ncand == -1 ? -1 : 0;
+        }
+    }
     active = active && jb.len != 0;                                          // len 0: slot of a skipped pair
     int has_n = 0, stride = 0;
     if (active) {
@@ -410,10 +491,18 @@ k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32
     const int st = max(0, jb.idx - 8);                                       // calign.pyx:229,256
     const uint32_t* hp = hapw + (active ? b.hap_off[jb.hap] + st : 0);
     const uint32_t* rp = tile + jb.col;
+    int sc = 0;
     if (__any(has_n)) {                                                      // wave-uniform choice of the code path
-        if (active) job_score[j] = dp_tile<true>(rp, stride, hp, jb.len);
+        if (active) sc = dp_tile<true>(rp, stride, hp, jb.len);
     } else {
-        if (active) job_score[j] = dp_tile<false>(rp, stride, hp, jb.len);
+        if (active) sc = dp_tile<false>(rp, stride, hp, jb.len);
+    }
+    if (active) {
+        const bool single = primary && (pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0));
+        if (single) {
+            out_ll[j] = loglik_of(sc, mapq_lut, pr.mapq);
+            if (out_score) out_score[j] = sc;
+        } else job_score[j] = sc;
     }
 }
 
@@ -429,10 +518,49 @@ k_dp_rows(int n, int lmax, const uint8_t* __restrict__ haps, const uint8_t* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// The reference's candidate selection (calign.pyx:223-267) replayed on the job scores of one pair.
+__device__ __forceinline__ int select_best(const PairRec& pr, long long p, long long npairs, const Job* __restrict__ jobs,
+                                           const int32_t* __restrict__ job_score, int* ndp)
+{
+    int best = 1000000, bestPos = -1, n = 0;                                 // calign.pyx:190
+    bool done = false;
+    for (int k = 0; k < pr.ncand; ++k) {                                    // calign.pyx:223-247
+        const long long js = job_slot(p, npairs, pr.extra_base, k);
+        const int sc = job_score[js];
+        ++n;
+        if (sc < best) {
+            best = sc; bestPos = jobs[js].idx;
+            if (best == 0) { done = true; break; }
+        }
+    }
+    if (!done && pr.idx0 != bestPos) {                                      // calign.pyx:255-267
+        const int sc = job_score[job_slot(p, npairs, pr.extra_base, pr.orig_k)];
+        ++n;
+        if (sc < best) best = sc;
+    }
+    *ndp = n;
+    return best;
+}
+
 __global__ void __launch_bounds__(256)
-k_finalize(const PairRec* __restrict__ pairs, const Job* __restrict__ jobs, const int32_t* __restrict__ job_score,
-           const double* __restrict__ mapq_lut, long long npairs, double* __restrict__ out_ll,
-           int32_t* __restrict__ out_score, long long* cnt)
+k_finalize_multi(const PairRec* __restrict__ pairs, const Job* __restrict__ jobs, const int32_t* __restrict__ job_score,
+                 const double* __restrict__ mapq_lut, long long npairs, double* __restrict__ out_ll,
+                 int32_t* __restrict__ out_score)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    const PairRec pr = pairs[p];
+    if (pr.ncand < 0 || pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0)) return;     // finished by k_dp_jobs
+    int ndp;
+    const int best = select_best(pr, p, npairs, jobs, job_score, &ndp);
+    out_ll[p] = loglik_of(best, mapq_lut, pr.mapq);
+    if (out_score) out_score[p] = best;
+}
+
+// statistics for plat_align_stats (only launched when the caller asks for them)
+__global__ void __launch_bounds__(256)
+k_stats(const PairRec* __restrict__ pairs, const Job* __restrict__ jobs, const int32_t* __restrict__ job_score,
+        long long npairs, long long* cnt)
 {
     __shared__ unsigned long long s_acc[4];
     if (threadIdx.x < 4) s_acc[threadIdx.x] = 0ull;
@@ -441,38 +569,15 @@ k_finalize(const PairRec* __restrict__ pairs, const Job* __restrict__ jobs, cons
     unsigned long long aligned = 0, ndp = 0, cells = 0;
     if (p < npairs) {
         const PairRec pr = pairs[p];
-        double ll = 0.0;
-        int score = -1;
         if (pr.ncand != -1) {
-            int best = 0;
-            if (pr.ncand >= 0) {
-                best = 1000000;                                              // calign.pyx:190
-                int bestPos = -1;
-                bool done = false;
-                const int L = jobs[p].len;
-                for (int k = 0; k < pr.ncand; ++k) {                        // calign.pyx:223-247
-                    const long long js = job_slot(p, npairs, pr.extra_base, k);
-                    const int sc = job_score[js];
-                    ++ndp;
-                    if (sc < best) {
-                        best = sc; bestPos = jobs[js].idx;
-                        if (best == 0) { done = true; break; }
-                    }
-                }
-                if (!done && pr.idx0 != bestPos) {                          // calign.pyx:255-267
-                    const int sc = job_score[job_slot(p, npairs, pr.extra_base, pr.orig_k)];
-                    ++ndp;
-                    if (sc < best) best = sc;
-                }
-                cells = ndp * 16ull * (unsigned long long)L;
-            }
-            score = best;
-            const double v = -0.23025850929940459 * (double)best + mapq_lut[pr.mapq];   // chaplotype.pyx:676
-            ll = v > -300.0 ? v : -300.0;
             aligned = 1;
+            if (pr.ncand >= 0) {
+                int n = 1;
+                if (!(pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0))) select_best(pr, p, npairs, jobs, job_score, &n);
+                ndp = (unsigned long long)n;
+                cells = ndp * 16ull * (unsigned long long)jobs[p].len;
+            }
         }
-        out_ll[p] = ll;
-        if (out_score) out_score[p] = score;
     }
     for (int s = 32; s > 0; s >>= 1) {
         aligned += __shfl_xor((long long)aligned, s);
@@ -596,7 +701,7 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     const int maxhap = (int)hb[CNT_MAXHAP], maxread = (int)hb[CNT_MAXREAD];
     const long long hapblob = hb[16], npairs = hb[17], readblob = hb[18], tile_total = hb[CNT_TILE_TOTAL];
     if (npairs == 0) return PLAT_OK;
-    if (tile_total > 0xFFFFFFF0ll) return PLAT_ERR_OVERFLOW;        // split the batch: a tile column index is 32 bits
+    if (tile_total > 0xFFFFFFF0ll || readblob > 0xFFFFFFF0ll) return PLAT_ERR_OVERFLOW;   // split the batch: 32-bit tile/code offsets
     if ((rc = plat_reserve(ctx, ctx->hapw, ((size_t)hapblob + 64) * 4))) return rc;
     if ((rc = plat_reserve(ctx, ctx->tile, ((size_t)tile_total + 64) * 4))) return rc;
     if ((rc = plat_reserve(ctx, ctx->codes, ((size_t)readblob + 64) * 2))) return rc;
@@ -626,16 +731,21 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     PLAT_EV(ctx, 2, st);
     hipLaunchKernelGGL(k_dp_jobs, dim3((unsigned)((njobs + 255) / 256)), dim3(256), 0, st, b, hap_win,
                        (const uint32_t*)ctx->tile.ptr, (const uint32_t*)ctx->hapw.ptr,
-                       (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr, njobs,
-                       (int32_t*)ctx->job_score.ptr);
+                       (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
+                       (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, njobs,
+                       (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
     PLAT_EV(ctx, 3, st);
+    hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
+                       (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr,
+                       (const int32_t*)ctx->job_score.ptr, ctx->d_mapq_lut, npairs, out_loglik, out_score);
+    PLAT_EV(ctx, 4, st);
     if (out_stats || ctx->profile)
         hipLaunchKernelGGL(k_sum_job_cells, dim3(256), dim3(256), 0, st, (const Job*)ctx->jobs.ptr, njobs, cnt);
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
-                       (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr,
-                       (const int32_t*)ctx->job_score.ptr, ctx->d_mapq_lut, npairs, out_loglik, out_score, cnt);
+    if (out_stats)
+        hipLaunchKernelGGL(k_stats, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
+                           (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr,
+                           (const int32_t*)ctx->job_score.ptr, npairs, cnt);
     PLAT_HIP(ctx, hipGetLastError());
-    PLAT_EV(ctx, 4, st);
     if (out_stats || ctx->profile) {
         PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
         PLAT_HIP(ctx, hipStreamSynchronize(st));
@@ -650,6 +760,7 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
         out_stats->n_dp_reference = hb[CNT_NDP_REF];
         out_stats->cells_reference = hb[CNT_CELLS_REF];
         out_stats->cells_launched = hb[CNT_CELLS_RUN];
+        out_stats->n_seed_fallback = hb[CNT_SLOW_SEED];
     }
     return PLAT_OK;
 }
