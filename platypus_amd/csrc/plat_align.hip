@@ -64,7 +64,7 @@ __global__ void k_validate(plat_window_batch b, long long* cnt, int32_t* __restr
         win_rows[w] = 8;
         if (H < 0 || R < 0 || b.pair_off[w + 1] - b.pair_off[w] != H * R) { set_err(cnt, PLAT_ERR_BAD_INPUT); continue; }
         for (int h = h0; h < h1; ++h) hap_win[h] = w;
-        maxH = max(maxH, (int)H);
+        maxH = max(maxH, (int)min(R, 1ll << 30));          // (re-used slot: largest number of reads in a window)
         int lm = 0;
         for (int r = r0; r < r1; ++r) {
             long long len = b.read_off[r + 1] - b.read_off[r];
@@ -149,7 +149,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             const int ov = oe > os ? oe - os : -1;                       // chaplotype.pyx:103-115
             skip = (b.read_flags[r] & 512) || ov < 7;
         }
-        rinfo[r] = ReadInfo{(uint32_t)(toff + rl), (uint32_t)b.read_off[r], b.read_pos[r],
+        rinfo[r] = ReadInfo{(uint32_t)(toff + rl), 0u, b.read_pos[r],
                             (uint32_t)L | ((uint32_t)skip << 16) | ((uint32_t)b.read_mapq[r] << 24)};
     }
     // tile: element (i, rl), rl fastest -> coalesced stores
@@ -159,14 +159,14 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
         const long long ro = b.read_off[rb + rl];
         const int L = (int)(b.read_off[rb + rl + 1] - ro);
         tile[toff + e] = i < L ? read_word(b.read_seq[ro + i], b.read_qual[ro + i]) : READ_PAD_WORD;
-    }
-    // rolling 7-mer codes (a5): codes[read_off[r] + i], i < L-7
-    const long long c0 = b.read_off[rb], c1 = b.read_off[rb + R];
-    for (long long e = c0 + threadIdx.x; e < c1; e += blockDim.x) {
-        unsigned code = 0;
+        // rolling 7-mer codes (a5, calign.pyx:155-165), same transposed shape as the tile: codes[toff + i*R + rl], i < L-7
+        unsigned code = 0xFFFFu;
+        if (i < L - 7) {
+            code = 0;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) code = (code << 2) + base2(b.read_seq[e + k]);   // entries past L-8 are never used
-        codes[e] = (uint16_t)code;
+            for (int k = 0; k < 7; ++k) code = (code << 2) + base2(b.read_seq[ro + i + k]);
+        }
+        codes[toff + e] = (uint16_t)code;
     }
 }
 
@@ -184,57 +184,55 @@ __device__ __forceinline__ unsigned kmer_head(const unsigned* table, unsigned co
     return e & 0xFFFFu;
 }
 
-// k_seed: one workgroup per (window, group of <= G haplotypes).  All haplotype k-mer indexes of the group live in
-// LDS at once, so the rolling codes of a read are fetched once and probed against every haplotype.
-// LDS carve (dynamic), per haplotype slot g (stride `hap_stride` bytes):
-//     table u32[tsize] | next u16[maxhap+2] | hapb u8[maxhap+16]
-// followed by  counts u16[nw][cw]  (full-vote fallback only) and has_n int[G].
-// Counters are 16-bit, two per dword, updated with 32-bit LDS atomics (a count never exceeds readLen-7 < 32768;
-// bit 15 is a claim flag used to pick one representative lane per arg-max diagonal).
-// The k-mer index has two modes: haplotypes up to 4096 bp use a small open-addressing table (>= 2*hapLen
-// entries); longer ones (up to the reference's cap of 16384) index all 4^7 codes directly, as the reference does
+// k_seed: one workgroup per haplotype; ONE LANE PER (read, haplotype) PAIR.
+// LDS carve (dynamic):  table u32[tsize] | next u16[maxhap+2] | hapb u8[maxhap+16] | counts u16[nw][cw] | has_n
+// The k-mer index has two modes: haplotypes up to 4096 bp use a small open-addressing table (load factor <= 0.8);
+// longer ones (up to the reference's cap of 16384) index all 4^7 codes directly, as the reference does
 // (calign.pyx:98-99).
+//
+// Every lane walks the 7-mer codes of its own read (transposed code tile => one coalesced 128-byte load per
+// k-mer position per wave) through the haplotype index and tries to PROVE that one diagonal d* is the unique
+// arg-max of the reference's diagonal vote (calign.pyx:206-233) without counting votes:
+//   C = #k-mers with an occurrence on d*,  X = #occurrences of the read's k-mers off d*.
+//   Any other diagonal collects at most X votes, hence X < C  =>  d* is the only candidate.
+// Pairs that cannot be decided this way (tandem repeats, ties) fall back to the exact vote: the whole wave counts
+// that pair's diagonals in 16-bit LDS counters (two per dword, 32-bit LDS atomics; bit 15 = claim flag used to
+// pick one representative lane per arg-max diagonal) and emits the candidates in ascending order.
 __global__ void __launch_bounds__(256)
-k_seed(plat_window_batch b, const ReadInfo* __restrict__ rinfo, const uint16_t* __restrict__ codes,
-       uint32_t* __restrict__ hapw, uint8_t* __restrict__ hap_has_n, PairRec* __restrict__ pairs,
-       Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
-       int tsize, int maxhap, int cw, int G, int hap_stride)
+k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo* __restrict__ rinfo,
+       const uint16_t* __restrict__ codes, uint32_t* __restrict__ hapw, uint8_t* __restrict__ hap_has_n,
+       PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
+       int tsize_max, int maxhap, int cw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int w = blockIdx.x;
-    const int hbeg = b.win_hap_begin[w] + (int)blockIdx.y * G;
-    const int ng = min(G, b.win_hap_begin[w + 1] - hbeg);
-    if (ng <= 0) return;
+    unsigned* table = (unsigned*)smem;
+    unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);
+    unsigned char* hapb = smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 3 & ~(size_t)3);
+    unsigned* counts_all = (unsigned*)(hapb + (((size_t)maxhap + 16) + 3 & ~(size_t)3));
+    int* s_has_n = (int*)(counts_all + (size_t)(blockDim.x >> 6) * (cw >> 1));
+
+    const int h = blockIdx.x;
+    const int w = hap_win[h];
+    const long long hoff = b.hap_off[h];
+    const int hapLen = (int)(b.hap_off[h + 1] - hoff);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
-    unsigned* counts_all = (unsigned*)(smem + (size_t)G * hap_stride);
     unsigned* counts = counts_all + (size_t)wave * (cw >> 1);
-    int* s_has_n = (int*)(counts_all + (size_t)nw * (cw >> 1));
-    const size_t o_nxt = (size_t)tsize * 4, o_hapb = o_nxt + ((((size_t)maxhap + 2) * 2 + 3) & ~(size_t)3);
-    const bool direct = tsize == 16384 && maxhap > 4096;
+
+    const bool direct = hapLen > 4096;
+    int tsize = 64;
+    if (direct) tsize = 16384;
+    else while (tsize < hapLen + hapLen / 4) tsize <<= 1;
     const unsigned tmask = (unsigned)tsize - 1u;
 
-    // ---- setup: zero the tables, stage the haplotype bytes
-    for (int i = tid; i < ng * tsize; i += nthr) {
-        const int g = i / tsize;
-        ((unsigned*)(smem + (size_t)g * hap_stride))[i - g * tsize] = 0u;
-    }
-    if (tid < G) s_has_n[tid] = 0;
-    for (int g = 0; g < ng; ++g) {
-        const long long hoff = b.hap_off[hbeg + g];
-        const int hapLen = (int)(b.hap_off[hbeg + g + 1] - hoff);
-        unsigned char* hapb = smem + (size_t)g * hap_stride + o_hapb;
-        for (int i = tid; i < hapLen; i += nthr) hapb[i] = b.hap_seq[hoff + i];
-    }
+    if (tid == 0) *s_has_n = 0;
+    for (int i = tid; i < tsize; i += nthr) table[i] = 0u;
+    for (int i = tid; i < hapLen; i += nthr) hapb[i] = b.hap_seq[hoff + i];
     __syncthreads();
-    for (int g = 0; g < ng; ++g) {
-        const long long hoff = b.hap_off[hbeg + g];
-        const int hapLen = (int)(b.hap_off[hbeg + g + 1] - hoff);
-        unsigned* table = (unsigned*)(smem + (size_t)g * hap_stride);
-        unsigned short* nxt = (unsigned short*)(smem + (size_t)g * hap_stride + o_nxt);
-        const unsigned char* hapb = smem + (size_t)g * hap_stride + o_hapb;
-        // a7: gap-open annotation (chaplotype.pyx:552-590): table[min(48, #following bytes equal to this one)],
-        // 'N' -> table[0]; written together with the base as the DP's haplotype word
+
+    // a7: gap-open annotation (chaplotype.pyx:552-590): table[min(48, #following bytes equal to this one)], 'N' -> table[0]
+    // written together with the base as the DP's haplotype word
+    {
         int anyn = 0;
         for (int p = tid; p < hapLen; p += nthr) {
             const unsigned char c = hapb[p];
@@ -244,222 +242,203 @@ k_seed(plat_window_batch b, const ReadInfo* __restrict__ rinfo, const uint16_t* 
             } else anyn = 1;
             hapw[hoff + p] = hap_word(c, (unsigned)c_homopol_go[run]);
         }
-        if (anyn) s_has_n[g] = 1;
-        // a4: k-mer index (positions 0..hapLen-8; calign.pyx:109): entry = (code+1)<<16 | (pos+1);
-        // equal codes are chained through nxt[] (the chain order is irrelevant to the vote)
-        for (int p = tid; p < hapLen - 7; p += nthr) {
-            unsigned code = 0;
+        if (anyn) *s_has_n = 1;
+    }
+    // a4: k-mer index (positions 0..hapLen-8; calign.pyx:109): entry = (code+1)<<16 | (pos+1);
+    // equal codes are chained through nxt[] (the chain order is irrelevant to the vote)
+    for (int p = tid; p < hapLen - 7; p += nthr) {
+        unsigned code = 0;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) code = (code << 2) + base2(hapb[p + k]);
-            if (direct) {
-                unsigned old = atomicExch(&table[code], (unsigned)(p + 1));
-                nxt[p + 1] = (unsigned short)old;
-                continue;
+        for (int k = 0; k < 7; ++k) code = (code << 2) + base2(hapb[p + k]);
+        if (direct) {
+            unsigned old = atomicExch(&table[code], (unsigned)(p + 1));
+            nxt[p + 1] = (unsigned short)old;
+            continue;
+        }
+        const unsigned key = (code + 1u) << 16;
+        unsigned slot = tbl_slot(code, tmask);
+        unsigned e = table[slot];
+        for (;;) {
+            if (e == 0u) {
+                unsigned old = atomicCAS(&table[slot], 0u, key | (unsigned)(p + 1));
+                if (old == 0u) { nxt[p + 1] = 0; break; }
+                e = old;
             }
-            const unsigned key = (code + 1u) << 16;
-            unsigned slot = tbl_slot(code, tmask);
-            unsigned e = table[slot];
-            for (;;) {
-                if (e == 0u) {
-                    unsigned old = atomicCAS(&table[slot], 0u, key | (unsigned)(p + 1));
-                    if (old == 0u) { nxt[p + 1] = 0; break; }
-                    e = old;
-                }
-                if ((e & 0xFFFF0000u) == key) {
-                    unsigned old = atomicCAS(&table[slot], e, key | (unsigned)(p + 1));
-                    if (old == e) { nxt[p + 1] = (unsigned short)(e & 0xFFFFu); break; }
-                    e = old;
-                } else {
-                    slot = (slot + 1u) & tmask;
-                    e = table[slot];
-                }
+            if ((e & 0xFFFF0000u) == key) {
+                unsigned old = atomicCAS(&table[slot], e, key | (unsigned)(p + 1));
+                if (old == e) { nxt[p + 1] = (unsigned short)(e & 0xFFFFu); break; }
+                e = old;
+            } else {
+                slot = (slot + 1u) & tmask;
+                e = table[slot];
             }
         }
     }
     __syncthreads();
-    if (tid < ng) hap_has_n[hbeg + tid] = (uint8_t)s_has_n[tid];
+    if (tid == 0) hap_has_n[h] = (uint8_t)*s_has_n;
 
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
+    const int hl = h - b.win_hap_begin[w];
     const int hapStart = b.win_start[w] - b.win_flank[w];                   // chaplotype.pyx:606
-    const int hl0 = (int)blockIdx.y * G;
-    const long long pbase = b.pair_off[w];
-    bool counts_clean = false;                                               // the fallback zeroes its counters on first use
+    const long long pbase = b.pair_off[w] + (long long)hl * R;
+    bool counts_clean = false;
 
-    ReadInfo ri_next = wave < R ? rinfo[rb + wave] : ReadInfo{0, 0, 0, 0};
-    for (int rl = wave; rl < R; rl += nw) {
-        const ReadInfo ri = ri_next;
-        if (rl + nw < R) ri_next = rinfo[rb + rl + nw];                     // prefetch the next descriptor
+    for (int c0 = wave * 64; c0 < R; c0 += nw * 64) {
+        const int rl = c0 + lane;
+        const bool valid = rl < R;
+        ReadInfo ri = ReadInfo{0, 0, 0, 0};
+        if (valid) ri = rinfo[rb + rl];
         const int L = (int)(ri.lfm & 0xFFFFu);
         const int rflags = (int)((ri.lfm >> 16) & 0xFFu);
         const uint8_t mapq = (uint8_t)(ri.lfm >> 24);
-        if ((rflags & 1) || L < 7) {                                        // calign.pyx:179-180
-            if (lane < ng) {
-                const long long pidx = pbase + (long long)(hl0 + lane) * R + rl;
-                pairs[pidx] = PairRec{0, 0, (int16_t)((rflags & 1) ? -1 : -2), 0, mapq, {0, 0, 0}};
-                jobs[pidx] = Job{ri.col, hbeg + lane, 0, 0};
+        const long long pidx = pbase + rl;
+        const bool skipped = (rflags & 1) != 0, tooshort = L < 7;
+        const bool hapshort = valid && !skipped && !tooshort && hapLen < L + 15;
+        if (hapshort) set_err(cnt, PLAT_ERR_HAP_TOO_SHORT);
+        const bool live = valid && !skipped && !tooshort && !hapshort;
+        const int nk = live ? L - 7 : 0;
+        const int idx0 = min(ri.pos - hapStart, hapLen - L - 15);           // calign.pyx:252
+        // ---- per-lane proof of a unique arg-max diagonal
+        int dstar = 0, C = 0, X = 0;
+        bool have = false;
+        int nkmax = nk;
+#pragma unroll
+        for (int s2 = 32; s2 > 0; s2 >>= 1) nkmax = max(nkmax, __shfl_xor(nkmax, s2));
+        const uint16_t* cp = codes + ri.col;
+        for (int i = 0; i < nkmax; ++i) {
+            if (i < nk) {
+                const unsigned code = cp[(long long)i * R];
+                unsigned hd = kmer_head(table, code, direct, tmask);
+                if (hd != 0u) {
+                    if (!have) { have = true; dstar = (int)hd - i - 1; }
+                    const unsigned nx = nxt[hd];
+                    if (nx == 0u) {
+                        const bool on = ((int)hd - i - 1 == dstar);
+                        C += on; X += !on;
+                    } else {
+                        int occ = 0, onany = 0;
+                        for (; hd != 0u; hd = nxt[hd]) { ++occ; onany |= ((int)hd - i - 1 == dstar); }
+                        C += onany; X += occ - onany;
+                    }
+                }
             }
-            continue;
         }
-        const int nk = L - 7;
-        const uint16_t* rc = codes + ri.code_off;
-        unsigned code[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int i = lane + 64 * t;
-            code[t] = i < nk ? rc[i] : 0u;
+        const bool decided = !live || !have || X < C;
+        int ncand = 0, cidx = idx0;
+        bool orig_in = false;
+        if (live && have && X < C && dstar + L + 15 < hapLen) { ncand = 1; cidx = dstar; orig_in = (idx0 == dstar); }   // calign.pyx:228
+        // extra job slot for (one candidate that is not the mapping position): one atomic per wave
+        int base = 0;
+        {
+            const bool need = decided && live && ncand == 1 && !orig_in;
+            const unsigned long long m = __ballot(need);
+            if (m) {
+                int wb = 0;
+                if (lane == 0) wb = (int)atomicAdd((unsigned long long*)&cnt[CNT_NEXTRA], (unsigned long long)__popcll(m));
+                wb = __shfl(wb, 0);
+                base = wb + __popcll(m & ((1ull << lane) - 1ull));
+                if (need && (long long)base + 1 <= (long long)extra_cap) jobs[npairs + base] = Job{ri.col, h, idx0, L};
+            }
         }
-        for (int g = 0; g < ng; ++g) {
-            const int h = hbeg + g;
-            const int hapLen = (int)(b.hap_off[h + 1] - b.hap_off[h]);
-            const unsigned* table = (const unsigned*)(smem + (size_t)g * hap_stride);
-            const unsigned short* nxt = (const unsigned short*)(smem + (size_t)g * hap_stride + o_nxt);
-            const long long pidx = pbase + (long long)(hl0 + g) * R + rl;
-            if (hapLen < L + 15) {
-                if (lane == 0) {
-                    set_err(cnt, PLAT_ERR_HAP_TOO_SHORT);
-                    pairs[pidx] = PairRec{0, 0, -1, 0, mapq, {0, 0, 0}};
-                    jobs[pidx] = Job{ri.col, h, 0, 0};
-                }
-                continue;
+        if (valid && decided) {
+            if (!live) {
+                pairs[pidx] = PairRec{0, 0, (int16_t)((skipped || hapshort) ? -1 : -2), 0, mapq, {0, 0, 0}};
+                jobs[pidx] = Job{ri.col, h, 0, 0};
+            } else {
+                jobs[pidx] = Job{ri.col, h, cidx, L};
+                pairs[pidx] = PairRec{base, idx0, (int16_t)ncand, (int16_t)(orig_in ? 0 : ncand), mapq, {0, 0, 0}};
             }
-            const int n = hapLen + L;
-            const int idx0 = min(ri.pos - hapStart, hapLen - L - 15);       // calign.pyx:252
-            const int j0i = idx0 + L;
-            int ncand = 0, myidx = 0x7FFFFFFF;
-            bool orig_in = false, decided = false;
-
-            // ---- fast path: prove that ONE diagonal d* is the unique arg-max of the vote without counting.
-            // C = #k-mers with an occurrence on d*; X = #occurrences of the read's k-mers off d*.  Any other
-            // diagonal collects at most X votes, so X < C  =>  d* is the only candidate of calign.pyx:222-233.
-            if (nk <= 256) {
-                unsigned head[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) head[t] = (lane + 64 * t) < nk ? kmer_head(table, code[t], direct, tmask) : 0u;
-                int dstar = 0;
-                bool have = false;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const unsigned long long m = __ballot(head[t] != 0u);
-                    if (!have && m) {
-                        dstar = __shfl((int)head[t] - (lane + 64 * t) - 1, (int)__ffsll((long long)m) - 1);
-                        have = true;
-                    }
+        }
+        // ---- exact vote for the pairs that could not be decided: the whole wave works on one pair at a time
+        unsigned long long todo = __ballot(valid && !decided);
+        if (todo && lane == 0) atomicAdd((unsigned long long*)&cnt[CNT_SLOW_SEED], (unsigned long long)__popcll(todo));
+        while (todo) {
+            const int src = (int)__ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int sL = __shfl(L, src), sidx0 = __shfl(idx0, src);
+            const unsigned scol = (unsigned)__shfl((int)ri.col, src);
+            const int smapq = __shfl((int)mapq, src);
+            const long long spidx = pbase + c0 + src;
+            const int n = hapLen + sL, snk = sL - 7, j0i = sidx0 + sL;
+            const uint16_t* scp = codes + scol;
+            if (!counts_clean) {
+                for (int j = lane; j < (cw >> 1); j += 64) counts[j] = 0u;
+                counts_clean = true;
+            }
+            // pass 1: diagonal vote, calign.pyx:209-220
+            unsigned mymax = 0;
+            for (int i = lane; i < snk; i += 64) {
+                unsigned hidx = kmer_head(table, scp[(long long)i * R], direct, tmask);
+                while (hidx != 0u) {
+                    const int j = (int)hidx - i - 1 + sL;
+                    const unsigned sh = 16u * (unsigned)(j & 1);
+                    const unsigned c = ((atomicAdd(&counts[j >> 1], 1u << sh) >> sh) & 0x7FFFu) + 1u;
+                    mymax = max(mymax, c);
+                    hidx = nxt[hidx];
                 }
-                if (!have) decided = true;                                  // no k-mer hit at all: maxcount == 0
-                else {
-                    int C = 0, X = 0, myC = 0, myX = 0;
-                    unsigned long long anymulti = 0;
+            }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int i = lane + 64 * t;
-                        const bool hit = head[t] != 0u;
-                        const unsigned nx = hit ? nxt[head[t]] : 0u;
-                        const bool on = hit && ((int)head[t] - i - 1 == dstar);
-                        C += __popcll(__ballot(hit && nx == 0u && on));
-                        X += __popcll(__ballot(hit && nx == 0u && !on));
-                        const bool multi = hit && nx != 0u;
-                        if (multi) {
-                            int occ = 0, onany = 0;
-                            for (unsigned hh = head[t]; hh != 0u; hh = nxt[hh]) { ++occ; onany |= ((int)hh - i - 1 == dstar); }
-                            myC += onany; myX += occ - onany;
+            for (int s2 = 32; s2 > 0; s2 >>= 1) mymax = max(mymax, (unsigned)__shfl_xor((int)mymax, s2));
+            const unsigned maxcount = mymax;
+            const bool s_orig_in = maxcount > 0 && j0i >= 0 && j0i < n && CNT16(counts, j0i) == maxcount && sidx0 + sL + 15 < hapLen;
+            // pass 2: one representative lane per arg-max diagonal (claim bit 15); count the valid ones
+            int sncand = 0, myidx = 0x7FFFFFFF;
+            for (int i = lane; i < snk; i += 64) {
+                unsigned hidx = kmer_head(table, scp[(long long)i * R], direct, tmask);
+                while (hidx != 0u) {
+                    const int j = (int)hidx - i - 1 + sL;
+                    const unsigned sh = 16u * (unsigned)(j & 1);
+                    if (((counts[j >> 1] >> sh) & 0xFFFFu) == maxcount) {            // arg-max and not yet claimed
+                        const unsigned old = atomicOr(&counts[j >> 1], 0x8000u << sh);
+                        if (!((old >> sh) & 0x8000u) && (j - sL) + sL + 15 < hapLen) {   // calign.pyx:228
+                            myidx = min(myidx, j - sL);
+                            ++sncand;
                         }
-                        anymulti |= __ballot(multi);
                     }
-                    if (anymulti) {
-#pragma unroll
-                        for (int s2 = 32; s2 > 0; s2 >>= 1) { myC += __shfl_xor(myC, s2); myX += __shfl_xor(myX, s2); }
-                        C += myC; X += myX;
-                    }
-                    if (X < C) {
-                        decided = true;
-                        if (dstar + L + 15 < hapLen) { ncand = 1; myidx = dstar; orig_in = (idx0 == dstar); }   // calign.pyx:228
-                    }
+                    hidx = nxt[hidx];
                 }
             }
-            unsigned maxcount = 0;
-            if (!decided) {
-                if (lane == 0) atomicAdd((unsigned long long*)&cnt[CNT_SLOW_SEED], 1ull);
-                if (!counts_clean) {
-                    for (int j = lane; j < (cw >> 1); j += 64) counts[j] = 0u;
-                    counts_clean = true;
-                }
-                // ---- pass 1: diagonal vote, calign.pyx:209-220
-                unsigned mymax = 0;
-                for (int i = lane; i < nk; i += 64) {
-                    unsigned hidx = kmer_head(table, rc[i], direct, tmask);
-                    while (hidx != 0u) {
-                        const int j = (int)hidx - i - 1 + L;
-                        const unsigned sh = 16u * (unsigned)(j & 1);
-                        const unsigned c = ((atomicAdd(&counts[j >> 1], 1u << sh) >> sh) & 0x7FFFu) + 1u;
-                        mymax = max(mymax, c);
-                        hidx = nxt[hidx];
-                    }
-                }
 #pragma unroll
-                for (int s2 = 32; s2 > 0; s2 >>= 1) mymax = max(mymax, (unsigned)__shfl_xor((int)mymax, s2));
-                maxcount = mymax;
-                orig_in = maxcount > 0 && j0i >= 0 && j0i < n && CNT16(counts, j0i) == maxcount && idx0 + L + 15 < hapLen;
-                // ---- pass 2: one representative lane per arg-max diagonal (claim bit 15); count the valid ones
-                for (int i = lane; i < nk; i += 64) {
-                    unsigned hidx = kmer_head(table, rc[i], direct, tmask);
-                    while (hidx != 0u) {
-                        const int j = (int)hidx - i - 1 + L;
-                        const unsigned sh = 16u * (unsigned)(j & 1);
-                        if (((counts[j >> 1] >> sh) & 0xFFFFu) == maxcount) {        // arg-max and not yet claimed
-                            const unsigned old = atomicOr(&counts[j >> 1], 0x8000u << sh);
-                            if (!((old >> sh) & 0x8000u) && (j - L) + L + 15 < hapLen) {   // calign.pyx:228
-                                myidx = min(myidx, j - L);
-                                ++ncand;
-                            }
-                        }
-                        hidx = nxt[hidx];
-                    }
-                }
-#pragma unroll
-                for (int s2 = 32; s2 > 0; s2 >>= 1) {
-                    ncand += __shfl_xor(ncand, s2);
-                    myidx = min(myidx, __shfl_xor(myidx, s2));
-                }
+            for (int s2 = 32; s2 > 0; s2 >>= 1) {
+                sncand += __shfl_xor(sncand, s2);
+                myidx = min(myidx, __shfl_xor(myidx, s2));
             }
-            const int njobs = ncand + (orig_in ? 0 : 1);
-            int base = 0;
+            const int njobs = sncand + (s_orig_in ? 0 : 1);
+            int sbase = 0;
             if (njobs > 1) {
-                if (lane == 0) base = (int)atomicAdd((unsigned long long*)&cnt[CNT_NEXTRA], (unsigned long long)(njobs - 1));
-                base = __shfl(base, 0);
+                if (lane == 0) sbase = (int)atomicAdd((unsigned long long*)&cnt[CNT_NEXTRA], (unsigned long long)(njobs - 1));
+                sbase = __shfl(sbase, 0);
             }
-            const bool fits = njobs == 1 || (long long)base + (njobs - 1) <= (long long)extra_cap;
-            int orig_k = ncand;
-            if (ncand == 1) {
-                if (lane == 0) jobs[pidx] = Job{ri.col, h, myidx, L};
-                if (orig_in) orig_k = 0;
-            } else if (ncand > 1) {
-                // several arg-max diagonals (repeats; fallback only): ordered emission (ascending, calign.pyx:223)
-                // by scanning this read's counters
+            const bool fits = njobs == 1 || (long long)sbase + (njobs - 1) <= (long long)extra_cap;
+            int orig_k = sncand;
+            if (sncand == 1) {
+                if (lane == 0) jobs[spidx] = Job{scol, h, myidx, sL};
+                if (s_orig_in) orig_k = 0;
+            } else if (sncand > 1) {
+                // ordered emission (ascending diagonal, calign.pyx:223) by scanning this read's counters
                 int k = 0;
                 for (int j0 = 0; j0 < n; j0 += 64) {
                     const int j = j0 + lane;
-                    const bool is = j < n && CNT16(counts, j) == maxcount && (j - L) + L + 15 < hapLen;
+                    const bool is = j < n && CNT16(counts, j) == maxcount && (j - sL) + sL + 15 < hapLen;
                     const unsigned long long bal = __ballot(is);
                     if (is) {
                         const int mypos = k + __popcll(bal & ((1ull << lane) - 1ull));
-                        if (fits || mypos == 0) jobs[job_slot(pidx, npairs, base, mypos)] = Job{ri.col, h, j - L, L};
+                        if (fits || mypos == 0) jobs[job_slot(spidx, npairs, sbase, mypos)] = Job{scol, h, j - sL, sL};
                     }
-                    if (orig_in && j0i >= j0 && j0i < j0 + 64) orig_k = k + __popcll(bal & ((1ull << (j0i - j0)) - 1ull));
+                    if (s_orig_in && j0i >= j0 && j0i < j0 + 64) orig_k = k + __popcll(bal & ((1ull << (j0i - j0)) - 1ull));
                     k += __popcll(bal);
                 }
             }
             if (lane == 0) {
-                if (!orig_in && (fits || ncand == 0)) jobs[job_slot(pidx, npairs, base, ncand)] = Job{ri.col, h, idx0, L};
-                pairs[pidx] = PairRec{base, idx0, (int16_t)ncand, (int16_t)orig_k, mapq, {0, 0, 0}};
+                if (!s_orig_in && (fits || sncand == 0)) jobs[job_slot(spidx, npairs, sbase, sncand)] = Job{scol, h, sidx0, sL};
+                pairs[spidx] = PairRec{sbase, sidx0, (int16_t)sncand, (int16_t)orig_k, (uint8_t)smapq, {0, 0, 0}};
             }
-            if (!decided) {
-                // ---- pass 3: clear the counters this read touched
-                for (int i = lane; i < nk; i += 64) {
-                    unsigned hidx = kmer_head(table, rc[i], direct, tmask);
-                    while (hidx != 0u) {
-                        counts[((int)hidx - i - 1 + L) >> 1] = 0u;
-                        hidx = nxt[hidx];
-                    }
+            // pass 3: clear the counters this read touched
+            for (int i = lane; i < snk; i += 64) {
+                unsigned hidx = kmer_head(table, scp[(long long)i * R], direct, tmask);
+                while (hidx != 0u) {
+                    counts[((int)hidx - i - 1 + sL) >> 1] = 0u;
+                    hidx = nxt[hidx];
                 }
             }
         }
@@ -656,31 +635,24 @@ PLAT_EXPORT int plat_dp_batch(plat_ctx* ctx, int n, int lmax, const uint8_t* hap
 }
 
 static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStream_t st, long long* cnt, int maxhap,
-                             int maxread, int maxH, long long npairs, int extra_cap)
+                             int maxread, int maxR, long long npairs, int extra_cap, const int32_t* hap_win)
 {
-    int tsize = 64;
-    if (maxhap > 4096) tsize = 16384;
-    else while (tsize < maxhap + maxhap / 4) tsize <<= 1;      // open addressing, load factor <= 0.8
+    int tsize_max = 64;
+    if (maxhap > 4096) tsize_max = 16384;
+    else while (tsize_max < maxhap + maxhap / 4) tsize_max <<= 1;
     const int cw = (maxhap + maxread + 8 + 1) & ~1;            // 16-bit counters, even count
-    const size_t per_hap = ((size_t)tsize * 4 + ((((size_t)maxhap + 2) * 2 + 3) & ~(size_t)3) +
-                            ((((size_t)maxhap + 16) + 3) & ~(size_t)3) + 15) & ~(size_t)15;
+    const size_t fixed = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 3) & ~(size_t)3) +
+                         ((((size_t)maxhap + 16) + 3) & ~(size_t)3) + 16;
     const size_t lds_cap = 160 * 1024;
-    size_t budget = 40 * 1024;                                 // ~4 workgroups per CU when the haplotypes are small
-    if (const char* e = getenv("PLAT_SEED_LDS_KB")) budget = (size_t)atoi(e) * 1024;
-    int nw = 4;
-    while (nw > 1 && per_hap + (size_t)nw * cw * 2 + 64 > lds_cap) nw >>= 1;
-    const size_t tail = (size_t)nw * cw * 2 + 64;
-    if (per_hap + tail > lds_cap) return PLAT_ERR_HAP_TOO_LONG;
-    int G = 1;
-    while (G < 8 && G < maxH && (size_t)(G + 1) * per_hap + tail <= budget) ++G;
-    const size_t lds = (size_t)G * per_hap + tail;
+    int nw = maxR > 128 ? 4 : (maxR > 64 ? 2 : 1);             // one lane per read: waves per haplotype workgroup
+    while (nw > 1 && fixed + (size_t)nw * cw * 2 > lds_cap) nw >>= 1;
+    const size_t lds = fixed + (size_t)nw * cw * 2;
+    if (lds > lds_cap) return PLAT_ERR_HAP_TOO_LONG;
     if (lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int ngroups = (maxH + G - 1) / G;
-    hipLaunchKernelGGL(k_seed, dim3(b.n_windows, ngroups), dim3(64 * nw), lds, st, b, (const ReadInfo*)ctx->rinfo.ptr,
+    hipLaunchKernelGGL(k_seed, dim3(b.n_haps), dim3(64 * nw), lds, st, b, hap_win, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (uint32_t*)ctx->hapw.ptr, (uint8_t*)ctx->hap_flags.ptr,
-                       (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt, tsize, maxhap, cw, G,
-                       (int)per_hap);
+                       (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt, tsize_max, maxhap, cw);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -732,13 +704,13 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     PLAT_HIP(ctx, hipMemcpyAsync(hb + 18, b.read_off + b.n_reads, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     PLAT_HIP(ctx, hipStreamSynchronize(st));
     if (hb[CNT_ERR] != 0) return (int)hb[CNT_ERR];
-    const int maxhap = (int)hb[CNT_MAXHAP], maxread = (int)hb[CNT_MAXREAD], maxH = (int)hb[CNT_MAXH];
+    const int maxhap = (int)hb[CNT_MAXHAP], maxread = (int)hb[CNT_MAXREAD], maxR = (int)hb[CNT_MAXH];
     const long long hapblob = hb[16], npairs = hb[17], readblob = hb[18], tile_total = hb[CNT_TILE_TOTAL];
     if (npairs == 0) return PLAT_OK;
     if (tile_total > 0xFFFFFFF0ll || readblob > 0xFFFFFFF0ll) return PLAT_ERR_OVERFLOW;   // split the batch: 32-bit tile/code offsets
     if ((rc = plat_reserve(ctx, ctx->hapw, ((size_t)hapblob + 64) * 4))) return rc;
     if ((rc = plat_reserve(ctx, ctx->tile, ((size_t)tile_total + 64) * 4))) return rc;
-    if ((rc = plat_reserve(ctx, ctx->codes, ((size_t)readblob + 64) * 2))) return rc;
+    if ((rc = plat_reserve(ctx, ctx->codes, ((size_t)tile_total + 64) * 2))) return rc;
     if ((rc = plat_reserve(ctx, ctx->pair_rec, (size_t)npairs * sizeof(PairRec)))) return rc;
     long long extra_cap = npairs / 4 + 4096;
     if ((long long)(ctx->jobs.cap / sizeof(Job)) - npairs > extra_cap) extra_cap = (long long)(ctx->jobs.cap / sizeof(Job)) - npairs;
@@ -751,7 +723,7 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = plat_reserve(ctx, ctx->jobs, (size_t)(npairs + extra_cap) * sizeof(Job)))) return rc;
         PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_NEXTRA], 0, sizeof(long long), st));
-        if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxH, npairs, (int)extra_cap))) return rc;
+        if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win))) return rc;
         PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
         PLAT_HIP(ctx, hipStreamSynchronize(st));
         if (hb[CNT_ERR] != 0) return (int)hb[CNT_ERR];
