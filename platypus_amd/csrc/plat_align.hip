@@ -305,19 +305,43 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
 #pragma unroll
         for (int s2 = 32; s2 > 0; s2 >>= 1) nkmax = max(nkmax, __shfl_xor(nkmax, s2));
         const uint16_t* cp = codes + ri.col;
-        for (int i = 0; i < nkmax; ++i) {
-            if (i < nk) {
-                const unsigned code = cp[(long long)i * R];
-                unsigned hd = kmer_head(table, code, direct, tmask);
-                if (hd != 0u) {
-                    if (!have) { have = true; dstar = (int)hd - i - 1; }
-                    const unsigned nx = nxt[hd];
-                    if (nx == 0u) {
-                        const bool on = ((int)hd - i - 1 == dstar);
+        // blocks of 8 k-mer positions: the 8 code loads, then the 8 index probes, then the 8 chain heads are each
+        // issued back to back so that global and LDS latencies overlap (the next block's codes are prefetched)
+        unsigned cd[8], cn[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cn[u] = u < nk ? cp[(long long)u * R] : 0u;
+        for (int i0 = 0; i0 < nkmax; i0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cd[u] = cn[u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cn[u] = (i0 + 8 + u) < nk ? cp[(long long)(i0 + 8 + u) * R] : 0u;
+            unsigned slot[8], e[8], hd[8], nx[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                slot[u] = direct ? cd[u] : tbl_slot(cd[u], tmask);
+                e[u] = table[slot[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (!direct) {
+                    const unsigned key = (cd[u] + 1u) << 16;
+                    while (e[u] != 0u && (e[u] & 0xFFFF0000u) != key) { slot[u] = (slot[u] + 1u) & tmask; e[u] = table[slot[u]]; }
+                }
+                hd[u] = (i0 + u) < nk ? (e[u] & 0xFFFFu) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) nx[u] = nxt[hd[u]];                  // nxt[0] is a harmless dummy read
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (hd[u] != 0u) {
+                    const int i = i0 + u;
+                    if (!have) { have = true; dstar = (int)hd[u] - i - 1; }
+                    if (nx[u] == 0u) {
+                        const bool on = ((int)hd[u] - i - 1 == dstar);
                         C += on; X += !on;
                     } else {
                         int occ = 0, onany = 0;
-                        for (; hd != 0u; hd = nxt[hd]) { ++occ; onany |= ((int)hd - i - 1 == dstar); }
+                        for (unsigned hh = hd[u]; hh != 0u; hh = nxt[hh]) { ++occ; onany |= ((int)hh - i - 1 == dstar); }
                         C += onany; X += occ - onany;
                     }
                 }
