@@ -16,6 +16,8 @@
 //   k_finalize    per (read, haplotype): the reference's candidate selection replayed on the job scores
 //                 (calign.pyx:235-267), score -> log-likelihood (a8, chaplotype.pyx:621-676)
 #include "dp_core.hpp"
+#include <stdio.h>
+
 #include "plat_internal.hpp"
 
 namespace plat {
@@ -34,7 +36,7 @@ __device__ __forceinline__ long long job_slot(long long pair, long long npairs, 
 }
 
 enum { CNT_ERR = 0, CNT_MAXHAP, CNT_MAXREAD, CNT_NEXTRA, CNT_PAIRS_ALIGNED, CNT_NDP_REF, CNT_CELLS_REF, CNT_CELLS_RUN,
-       CNT_NJOBS_RUN, CNT_TILE_TOTAL, CNT_SLOW_SEED, CNT_MAXH, CNT_N };
+       CNT_NJOBS_RUN, CNT_TILE_TOTAL, CNT_SLOW_SEED, CNT_MAXH, CNT_T0, CNT_T1, CNT_T2, CNT_T3, CNT_T4, CNT_N };
 
 __constant__ signed char c_homopol_go[49] = {   // homopolq[i]-'!' (chaplotype.pyx:64-67); see tests/test_oracle.py
     45, 42, 41, 39, 37, 32, 28, 23, 20, 19, 17, 16, 15, 14, 13, 12, 11, 11, 10, 9, 9, 8, 8, 7, 7, 7, 6, 6, 6, 5, 5, 5,
@@ -176,7 +178,7 @@ __device__ __forceinline__ unsigned tbl_slot(unsigned code, unsigned mask) { ret
 
 // k-mer lookup: first haplotype position (+1) holding this code, 0 if none
 __device__ __forceinline__ unsigned kmer_head(const unsigned* table, unsigned code, bool direct, unsigned tmask) {
-    if (direct) return table[code];
+    if (direct) return ((const unsigned short*)table)[code];           // direct mode: u16 head per 14-bit code
     const unsigned key = (code + 1u) << 16;
     unsigned slot = tbl_slot(code, tmask);
     unsigned e = table[slot];
@@ -202,13 +204,15 @@ __global__ void __launch_bounds__(256)
 k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo* __restrict__ rinfo,
        const uint16_t* __restrict__ codes, uint32_t* __restrict__ hapw, uint8_t* __restrict__ hap_has_n,
        PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
-       int tsize_max, int maxhap, int cw)
+       int tsize_max, int maxhap, int cw, int want_stats)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* table = (unsigned*)smem;
     unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);
     unsigned char* hapb = smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 3 & ~(size_t)3);
-    unsigned* counts_all = (unsigned*)(hapb + (((size_t)maxhap + 16) + 3 & ~(size_t)3));
+    unsigned char* mult8 = hapb;           // multiplicity of the k-mer at every position (capped 255); re-uses hapb after the index is built
+    unsigned short* hapcode = (unsigned short*)(hapb + (((size_t)maxhap + 16) + 3 & ~(size_t)3));   // 7-mer code at every haplotype position
+    unsigned* counts_all = (unsigned*)(hapcode + (((size_t)maxhap + 2) + 1 & ~(size_t)1));
     int* s_has_n = (int*)(counts_all + (size_t)(blockDim.x >> 6) * (cw >> 1));
 
     const int h = blockIdx.x;
@@ -225,10 +229,12 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
     else while (tsize < hapLen + hapLen / 4) tsize <<= 1;
     const unsigned tmask = (unsigned)tsize - 1u;
 
+    long long tq0 = want_stats ? (long long)__builtin_readcyclecounter() : 0;
     if (tid == 0) *s_has_n = 0;
-    for (int i = tid; i < tsize; i += nthr) table[i] = 0u;
+    for (int i = tid; i < (direct ? tsize / 2 : tsize); i += nthr) table[i] = 0u;
     for (int i = tid; i < hapLen; i += nthr) hapb[i] = b.hap_seq[hoff + i];
     __syncthreads();
+    long long tq1 = want_stats ? (long long)__builtin_readcyclecounter() : 0;
 
     // a7: gap-open annotation (chaplotype.pyx:552-590): table[min(48, #following bytes equal to this one)], 'N' -> table[0]
     // written together with the base as the DP's haplotype word
@@ -250,9 +256,15 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
         unsigned code = 0;
 #pragma unroll
         for (int k = 0; k < 7; ++k) code = (code << 2) + base2(hapb[p + k]);
-        if (direct) {
-            unsigned old = atomicExch(&table[code], (unsigned)(p + 1));
-            nxt[p + 1] = (unsigned short)old;
+        hapcode[p] = (unsigned short)code;
+        if (direct) {                                   // u16 heads, two per dword: exchange one half with a CAS loop
+            const unsigned sh = 16u * (code & 1u);
+            unsigned cur = table[code >> 1], seen;
+            do {
+                seen = cur;
+                cur = atomicCAS(&table[code >> 1], seen, (seen & ~(0xFFFFu << sh)) | ((unsigned)(p + 1) << sh));
+            } while (cur != seen);
+            nxt[p + 1] = (unsigned short)((seen >> sh) & 0xFFFFu);
             continue;
         }
         const unsigned key = (code + 1u) << 16;
@@ -275,6 +287,15 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
         }
     }
     __syncthreads();
+    // multiplicity of every haplotype k-mer (length of its chain)
+    for (int p = tid; p < hapLen - 7; p += nthr) {
+        int c = 0;
+        for (unsigned hh = kmer_head(table, hapcode[p], direct, tmask); hh != 0u; hh = nxt[hh]) ++c;
+        mult8[p] = (unsigned char)min(c, 255);
+    }
+    __syncthreads();
+    long long tq2 = want_stats ? (long long)__builtin_readcyclecounter() : 0;
+    long long tq_loop = 0, tq_fall = 0;
     if (tid == 0) hap_has_n[h] = (uint8_t)*s_has_n;
 
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
@@ -298,59 +319,71 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
         const bool live = valid && !skipped && !tooshort && !hapshort;
         const int nk = live ? L - 7 : 0;
         const int idx0 = min(ri.pos - hapStart, hapLen - L - 15);           // calign.pyx:252
-        // ---- per-lane proof of a unique arg-max diagonal
-        int dstar = 0, C = 0, X = 0;
-        bool have = false;
-        int nkmax = nk;
-#pragma unroll
-        for (int s2 = 32; s2 > 0; s2 >>= 1) nkmax = max(nkmax, __shfl_xor(nkmax, s2));
+        // ---- per-lane proof of a unique arg-max diagonal.  For a hypothesis d*:
+        //   C = #k-mers i of the read whose code equals the haplotype's code at i + d*      (votes for d*)
+        //   X = #occurrences of the read's k-mers anywhere else in the haplotype            (votes for all others)
+        // Any other diagonal collects at most X votes, hence X < C  =>  d* is the only candidate (calign.pyx:222-233).
+        // Hypothesis A = the read's mapping offset (calign.pyx:252); if that fails, hypothesis B = the diagonal of
+        // the first k-mer of the read that is unique in the haplotype.
+        const int nkp = hapLen - 7;                      // haplotype k-mer positions 0..hapLen-8 (calign.pyx:109)
         const uint16_t* cp = codes + ri.col;
-        // blocks of 8 k-mer positions: the 8 code loads, then the 8 index probes, then the 8 chain heads are each
-        // issued back to back so that global and LDS latencies overlap (the next block's codes are prefetched)
-        unsigned cd[8], cn[8];
+        long long tq3 = want_stats ? (long long)__builtin_readcyclecounter() : 0;
+        int dstar = idx0, C = 0, X = 0;
+        bool haveB = false, proven = false, sat = false;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool run = live && !proven && (attempt == 0 || haveB);
+            if (!__any(run)) break;
+            if (run) { C = 0; X = 0; sat = false; }
+            const int lim = run ? nk : 0;
+            int limmax = lim;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cn[u] = u < nk ? cp[(long long)u * R] : 0u;
-        for (int i0 = 0; i0 < nkmax; i0 += 8) {
+            for (int s2 = 32; s2 > 0; s2 >>= 1) limmax = max(limmax, __shfl_xor(limmax, s2));
+            unsigned cn[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) cd[u] = cn[u];
+            for (int u = 0; u < 8; ++u) cn[u] = u < lim ? cp[(unsigned)u * (unsigned)R] : 0u;
+            for (int i0 = 0; i0 < limmax; i0 += 8) {
+                unsigned cd[8], hc[8], mu[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) cn[u] = (i0 + 8 + u) < nk ? cp[(long long)(i0 + 8 + u) * R] : 0u;
-            unsigned slot[8], e[8], hd[8], nx[8];
+                for (int u = 0; u < 8; ++u) cd[u] = cn[u];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                slot[u] = direct ? cd[u] : tbl_slot(cd[u], tmask);
-                e[u] = table[slot[u]];
-            }
+                for (int u = 0; u < 8; ++u) cn[u] = (i0 + 8 + u) < lim ? cp[(unsigned)(i0 + 8 + u) * (unsigned)R] : 0u;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (!direct) {
-                    const unsigned key = (cd[u] + 1u) << 16;
-                    while (e[u] != 0u && (e[u] & 0xFFFF0000u) != key) { slot[u] = (slot[u] + 1u) & tmask; e[u] = table[slot[u]]; }
+                for (int u = 0; u < 8; ++u) {
+                    const int pp = i0 + u + dstar;
+                    const bool inr = (i0 + u) < lim && pp >= 0 && pp < nkp;
+                    hc[u] = inr ? (unsigned)hapcode[pp] : 0xFFFFFFFFu;
+                    mu[u] = inr ? (unsigned)mult8[pp] : 0u;
                 }
-                hd[u] = (i0 + u) < nk ? (e[u] & 0xFFFFu) : 0u;
-            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) nx[u] = nxt[hd[u]];                  // nxt[0] is a harmless dummy read
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (hd[u] != 0u) {
-                    const int i = i0 + u;
-                    if (!have) { have = true; dstar = (int)hd[u] - i - 1; }
-                    if (nx[u] == 0u) {
-                        const bool on = ((int)hd[u] - i - 1 == dstar);
-                        C += on; X += !on;
-                    } else {
-                        int occ = 0, onany = 0;
-                        for (unsigned hh = hd[u]; hh != 0u; hh = nxt[hh]) { ++occ; onany |= ((int)hh - i - 1 == dstar); }
-                        C += onany; X += occ - onany;
+                for (int u = 0; u < 8; ++u) {
+                    if ((i0 + u) < lim) {
+                        if (hc[u] == cd[u]) { C += 1; X += (int)mu[u] - 1; sat |= mu[u] == 255u; }
+                        else {
+                            // k-mer does not vote for d*: count its occurrences elsewhere (rare: k-mers overlapping a mismatch)
+                            for (unsigned hh = kmer_head(table, cd[u], direct, tmask); hh != 0u; hh = nxt[hh]) ++X;
+                        }
                     }
                 }
             }
+            if (run && !sat && X < C) proven = true;
+            if (attempt == 0 && __any(live && !proven)) {
+                // hypothesis B: diagonal of the first read k-mer that occurs exactly once in the haplotype
+                if (live && !proven) {
+                    for (int i = 0; i < nk && !haveB; ++i) {
+                        const unsigned hd = kmer_head(table, cp[(unsigned)i * (unsigned)R], direct, tmask);
+                        if (hd != 0u && nxt[hd] == 0u) { haveB = true; dstar = (int)hd - i - 1; }
+                    }
+                    if (haveB && dstar == idx0) haveB = false;          // same hypothesis as A: already failed
+                }
+            }
         }
-        const bool decided = !live || !have || X < C;
+        // a pair whose k-mers occur nowhere in the haplotype has maxcount == 0: no candidate, only the mapping offset
+        const bool novote = live && !proven && C == 0 && X == 0 && !sat;
+        if (want_stats) tq_loop += (long long)__builtin_readcyclecounter() - tq3;
+        const bool decided = !live || novote || proven;
         int ncand = 0, cidx = idx0;
         bool orig_in = false;
-        if (live && have && X < C && dstar + L + 15 < hapLen) { ncand = 1; cidx = dstar; orig_in = (idx0 == dstar); }   // calign.pyx:228
+        if (live && proven && dstar + L + 15 < hapLen) { ncand = 1; cidx = dstar; orig_in = (idx0 == dstar); }   // calign.pyx:228
         // extra job slot for (one candidate that is not the mapping position): one atomic per wave
         int base = 0;
         {
@@ -375,7 +408,8 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
         }
         // ---- exact vote for the pairs that could not be decided: the whole wave works on one pair at a time
         unsigned long long todo = __ballot(valid && !decided);
-        if (todo && lane == 0) atomicAdd((unsigned long long*)&cnt[CNT_SLOW_SEED], (unsigned long long)__popcll(todo));
+        if (want_stats && todo && lane == 0) atomicAdd((unsigned long long*)&cnt[CNT_SLOW_SEED], (unsigned long long)__popcll(todo));
+        long long tq4 = want_stats ? (long long)__builtin_readcyclecounter() : 0;
         while (todo) {
             const int src = (int)__ffsll((long long)todo) - 1;
             todo &= todo - 1;
@@ -466,6 +500,15 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
                 }
             }
         }
+        if (want_stats) tq_fall += (long long)__builtin_readcyclecounter() - tq4;
+    }
+    if (want_stats && tid == 0) {
+        const long long tq5 = (long long)__builtin_readcyclecounter();
+        atomicAdd((unsigned long long*)&cnt[CNT_T0], (unsigned long long)(tq1 - tq0));
+        atomicAdd((unsigned long long*)&cnt[CNT_T1], (unsigned long long)(tq2 - tq1));
+        atomicAdd((unsigned long long*)&cnt[CNT_T2], (unsigned long long)tq_loop);
+        atomicAdd((unsigned long long*)&cnt[CNT_T3], (unsigned long long)tq_fall);
+        atomicAdd((unsigned long long*)&cnt[CNT_T4], (unsigned long long)(tq5 - tq0));
     }
 }
 
@@ -659,14 +702,14 @@ PLAT_EXPORT int plat_dp_batch(plat_ctx* ctx, int n, int lmax, const uint8_t* hap
 }
 
 static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStream_t st, long long* cnt, int maxhap,
-                             int maxread, int maxR, long long npairs, int extra_cap, const int32_t* hap_win)
+                             int maxread, int maxR, long long npairs, int extra_cap, const int32_t* hap_win, int want_stats)
 {
-    int tsize_max = 64;
-    if (maxhap > 4096) tsize_max = 16384;
+    int tsize_max = 64;                                        // in dwords (direct mode: 16384 u16 heads = 8192 dwords)
+    if (maxhap > 4096) tsize_max = 8192;
     else while (tsize_max < maxhap + maxhap / 4) tsize_max <<= 1;
     const int cw = (maxhap + maxread + 8 + 1) & ~1;            // 16-bit counters, even count
     const size_t fixed = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 3) & ~(size_t)3) +
-                         ((((size_t)maxhap + 16) + 3) & ~(size_t)3) + 16;
+                         ((((size_t)maxhap + 16) + 3) & ~(size_t)3) + (((size_t)maxhap + 3) & ~(size_t)1) * 2 + 16;
     const size_t lds_cap = 160 * 1024;
     int nw = maxR > 128 ? 4 : (maxR > 64 ? 2 : 1);             // one lane per read: waves per haplotype workgroup
     while (nw > 1 && fixed + (size_t)nw * cw * 2 > lds_cap) nw >>= 1;
@@ -676,7 +719,7 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_seed, dim3(b.n_haps), dim3(64 * nw), lds, st, b, hap_win, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (uint32_t*)ctx->hapw.ptr, (uint8_t*)ctx->hap_flags.ptr,
-                       (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt, tsize_max, maxhap, cw);
+                       (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt, tsize_max, maxhap, cw, want_stats);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -747,7 +790,7 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = plat_reserve(ctx, ctx->jobs, (size_t)(npairs + extra_cap) * sizeof(Job)))) return rc;
         PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_NEXTRA], 0, sizeof(long long), st));
-        if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win))) return rc;
+        if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win, out_stats != NULL))) return rc;
         PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
         PLAT_HIP(ctx, hipStreamSynchronize(st));
         if (hb[CNT_ERR] != 0) return (int)hb[CNT_ERR];
@@ -791,6 +834,9 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
         out_stats->cells_reference = hb[CNT_CELLS_REF];
         out_stats->cells_launched = hb[CNT_CELLS_RUN];
         out_stats->n_seed_fallback = hb[CNT_SLOW_SEED];
+        if (getenv("PLAT_SEED_TIMING"))
+            fprintf(stderr, "[seed timing, cycles summed over workgroups] stage %lld index %lld proof %lld fallback %lld total %lld\n",
+                    (long long)hb[CNT_T0], (long long)hb[CNT_T1], (long long)hb[CNT_T2], (long long)hb[CNT_T3], (long long)hb[CNT_T4]);
     }
     return PLAT_OK;
 }
