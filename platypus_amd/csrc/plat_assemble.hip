@@ -1,14 +1,509 @@
-// plat_assemble.hip -- coloured de-Bruijn local assembler.
+// plat_assemble.hip -- coloured de-Bruijn local assembler on the device.
+//
+// Reference: src/cython/assembler.pyx (assembleReadsAndDetectVariants :1429-1476, graph construction :668-827,
+// :1295-1387, bubble walk :1027-1177, variant extraction :1196-1291).  The reference builds the graph
+// SEQUENTIALLY and its result depends on insertion order (node order = first insertion, edge slots = first
+// insertion, at most 4 out-edges, LIFO path stack with ">20" aborts).  The device build is parallel over k-mer
+// occurrences and reconstructs exactly that order from TICKETS: every AddEdge event e has the ticket the
+// sequential loader would give it (reference edges first, then reads in buffer order), and
+//   * a node's identity is its k bytes; its weight is the sum over all touches, its colours the OR;
+//   * a node's position is that of its first touch when that touch comes from the reference (the reference is
+//     loaded first, assembler.pyx:1449), else -1;
+//   * a node keeps the (up to) four successors with the smallest first-occurrence tickets, in ticket order
+//     (assembler.pyx:813-824: a fifth distinct successor is silently dropped);
+//   * bubble starts are visited in allNodes order, which for REF_AND_READ nodes is increasing position.
+// One workgroup assembles one region; the node table and the per-task path arenas live in a per-workgroup slice
+// of a global scratch buffer (the graph does not fit the LDS: ~10^4..10^5 nodes).
 #include "plat_internal.hpp"
+
+namespace plat {
+
+constexpr int ASM_MAX_SUCC = 8;        // distinct successor bytes tracked per node before the "first four" cut
+constexpr int ASM_MAX_TASKS = 512;     // bubble-start (node, edge) pairs per region
+constexpr int ASM_ARENA = 2048;        // path elements per task (each pop extends a path by <= 4 elements)
+constexpr int ASM_MAX_FIN = 21;        // finished paths per task before the reference aborts (assembler.pyx:1052)
+
+struct AsmParams {
+    int kmer, min_qual, min_weight, no_cycles, max_vars, blob_per_region;
+    long long scratch_per_block;       // bytes
+    int cap;                           // hash slots per region (power of two)
+    int max_pos;                       // max k-mer occurrences per region (dense node capacity)
+};
+
+struct AsmNodeE { int end[4]; int w[4]; int n; };   // finalised out-edges
+
+// scratch layout per workgroup (all int32 unless noted)
+struct AsmScratch {
+    int* key;            // [cap]      byte offset of a representative occurrence, -1 empty
+    int* slot_id;        // [cap]      dense node id
+    unsigned* first;     // [max_pos]  min touch code (2*ticket + isEnd)
+    int* weight;         // [max_pos]
+    int* colour;         // [max_pos]
+    int* rep;            // [max_pos]  representative byte offset
+    unsigned char* succ_c;   // [max_pos][8]
+    unsigned* succ_t;    // [max_pos][8]
+    int* succ_w;         // [max_pos][8]
+    int* succ_n;         // [max_pos][8]
+    AsmNodeE* edges;     // [max_pos]
+    char* dfs;           // [max_pos]
+    int* ref_node;       // [refLen]
+    int* read_base;      // [nReads+1] ticket base per read
+    int* task_node;      // [MAX_TASKS]
+    int* task_edge;      // [MAX_TASKS]
+    int* task_nfin;      // [MAX_TASKS]  (-1 aborted)
+    int* task_fin;       // [MAX_TASKS][MAX_FIN] arena index of the last element
+    int* arena;          // [MAX_TASKS][ARENA][3] node, parent, depth
+    int* var_task_off;   // [MAX_TASKS+1]
+    int* stack;          // [max_pos*2] iterative DFS stack for the cycle check
+};
+
+__host__ __device__ inline size_t asm_align(size_t x) { return (x + 15) & ~(size_t)15; }
+
+__host__ __device__ inline size_t asm_scratch_bytes(int cap, int max_pos, int max_ref, int max_reads) {
+    size_t b = 0;
+    b += asm_align((size_t)cap * 4) * 2;
+    b += asm_align((size_t)max_pos * 4) * 4;
+    b += asm_align((size_t)max_pos * ASM_MAX_SUCC);
+    b += asm_align((size_t)max_pos * ASM_MAX_SUCC * 4) * 3;
+    b += asm_align((size_t)max_pos * sizeof(AsmNodeE));
+    b += asm_align((size_t)max_pos);
+    b += asm_align((size_t)(max_ref + 1) * 4);
+    b += asm_align((size_t)(max_reads + 1) * 4);
+    b += asm_align((size_t)ASM_MAX_TASKS * 4) * 3;
+    b += asm_align((size_t)ASM_MAX_TASKS * ASM_MAX_FIN * 4);
+    b += asm_align((size_t)ASM_MAX_TASKS * ASM_ARENA * 3 * 4);
+    b += asm_align((size_t)(ASM_MAX_TASKS + 1) * 4);
+    b += asm_align((size_t)max_pos * 2 * 4);
+    return b;
+}
+
+__device__ inline AsmScratch asm_carve(char* p, int cap, int max_pos, int max_ref, int max_reads) {
+    AsmScratch s;
+    auto take = [&](size_t bytes) { char* r = p; p += asm_align(bytes); return r; };
+    s.key = (int*)take((size_t)cap * 4);
+    s.slot_id = (int*)take((size_t)cap * 4);
+    s.first = (unsigned*)take((size_t)max_pos * 4);
+    s.weight = (int*)take((size_t)max_pos * 4);
+    s.colour = (int*)take((size_t)max_pos * 4);
+    s.rep = (int*)take((size_t)max_pos * 4);
+    s.succ_c = (unsigned char*)take((size_t)max_pos * ASM_MAX_SUCC);
+    s.succ_t = (unsigned*)take((size_t)max_pos * ASM_MAX_SUCC * 4);
+    s.succ_w = (int*)take((size_t)max_pos * ASM_MAX_SUCC * 4);
+    s.succ_n = (int*)take((size_t)max_pos * ASM_MAX_SUCC * 4);
+    s.edges = (AsmNodeE*)take((size_t)max_pos * sizeof(AsmNodeE));
+    s.dfs = (char*)take((size_t)max_pos);
+    s.ref_node = (int*)take((size_t)(max_ref + 1) * 4);
+    s.read_base = (int*)take((size_t)(max_reads + 1) * 4);
+    s.task_node = (int*)take((size_t)ASM_MAX_TASKS * 4);
+    s.task_edge = (int*)take((size_t)ASM_MAX_TASKS * 4);
+    s.task_nfin = (int*)take((size_t)ASM_MAX_TASKS * 4);
+    s.task_fin = (int*)take((size_t)ASM_MAX_TASKS * ASM_MAX_FIN * 4);
+    s.arena = (int*)take((size_t)ASM_MAX_TASKS * ASM_ARENA * 3 * 4);
+    s.var_task_off = (int*)take((size_t)(ASM_MAX_TASKS + 1) * 4);
+    s.stack = (int*)take((size_t)max_pos * 2 * 4);
+    return s;
+}
+
+__device__ __forceinline__ unsigned asm_hash(const uint8_t* p, int k) {
+    unsigned h = 2166136261u;
+    for (int i = 0; i < k; ++i) { h ^= p[i]; h *= 16777619u; }
+    return h ^ (h >> 15);
+}
+__device__ __forceinline__ bool asm_eq(const uint8_t* a, const uint8_t* b, int k) {
+    for (int i = 0; i < k; ++i) if (a[i] != b[i]) return false;
+    return true;
+}
+// byte pointer of an occurrence: offsets < 0x40000000 index the reference, others the read blob
+__device__ __forceinline__ const uint8_t* asm_ptr(const uint8_t* ref, const uint8_t* rseq, int off) {
+    return off >= 0x40000000 ? rseq + (off - 0x40000000) : ref + off;
+}
+
+// find (or, if insert, create) the slot of the k-mer starting at byte offset `off`
+__device__ inline int asm_slot(AsmScratch& S, const uint8_t* ref, const uint8_t* rseq, int off, int k, int capmask, bool insert) {
+    const uint8_t* me = asm_ptr(ref, rseq, off);
+    unsigned s = asm_hash(me, k) & (unsigned)capmask;
+    for (;;) {
+        int cur = S.key[s];
+        if (cur == -1) {
+            if (!insert) return -1;
+            int old = atomicCAS(&S.key[s], -1, off);
+            if (old == -1) return (int)s;
+            cur = old;
+        }
+        if (cur == off || asm_eq(asm_ptr(ref, rseq, cur), me, k)) return (int)s;
+        s = (s + 1u) & (unsigned)capmask;
+    }
+}
+
+// does read r pass the k+1-base quality / N filter at position i (assembler.pyx:1362-1373)?  returns min qual or -1
+__device__ __forceinline__ int asm_read_edge_q(const uint8_t* s, const uint8_t* q, int i, int k, int min_qual) {
+    int mq = 100000000, hasn = 0;
+    for (int j = i; j < i + k + 1; ++j) { int v = (int)(signed char)q[j]; mq = v < mq ? v : mq; hasn |= s[j] == 'N'; }
+    return (mq >= min_qual && !hasn) ? mq : -1;
+}
+
+// workgroup barrier + agent-scope acquire: the graph lives in global memory and is updated with L2 atomics, so the
+// CU's vector L1 must be invalidated before plain loads re-read it (MI355X_MICROARCH.md, inter-workgroup visibility;
+// here producer and consumer are the same CU but the stale-L1 hazard is the same).
+__device__ __forceinline__ void asm_sync() {
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__global__ void __launch_bounds__(256)
+k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int max_reads, int32_t* var_count,
+           int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob,
+           int32_t* status)
+{
+    __shared__ int s_n, s_ntasks, s_err, s_cycle, s_k;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    AsmScratch S = asm_carve(scratch + (size_t)blockIdx.x * P.scratch_per_block, P.cap, P.max_pos, max_ref, max_reads);
+    const int capmask = P.cap - 1;
+
+    for (int g = blockIdx.x; g < b.n_regions; g += gridDim.x) {
+        const uint8_t* ref = b.ref_seq + b.ref_off[g];
+        const int refLen = (int)(b.ref_off[g + 1] - b.ref_off[g]);
+        const int refStart = b.ref_start[g], aStart = b.assem_start[g], aEnd = b.assem_end[g];
+        const int rb = b.reg_read_begin[g], nR = b.reg_read_begin[g + 1] - rb;
+        const long long rblob0 = nR > 0 ? b.read_off[rb] : 0;
+        const uint8_t* rseq = b.read_seq + rblob0;        // region-relative read blob
+        const uint8_t* rqual = b.read_qual + rblob0;
+        if (tid == 0) { s_err = 0; s_k = P.kmer; s_cycle = 0; }
+        asm_sync();
+
+        for (;;) {   // (re)build with the current k (assembler.pyx:1453-1469: k += 5 while cycles, noCycles only)
+            const int k = s_k;
+            const int nRefE = refLen - k - 1 > 0 ? refLen - k - 1 : 0;
+            // ticket bases of the reads
+            if (tid == 0) {
+                int acc = 0;
+                for (int r = 0; r < nR; ++r) {
+                    S.read_base[r] = acc;
+                    int L = (int)(b.read_off[rb + r + 1] - b.read_off[rb + r]);
+                    acc += L - k - 1 > 0 ? L - k - 1 : 0;
+                }
+                S.read_base[nR] = acc;
+                s_n = 0; s_ntasks = 0;
+            }
+            for (int i = tid; i < P.cap; i += nthr) S.key[i] = -1;
+            asm_sync();
+            const int nReadE = S.read_base[nR];
+            const int nEv = nRefE + nReadE;
+            if ((long long)nEv * 2 + 2 > (long long)P.max_pos || (long long)nEv * 4 > (long long)P.cap * 3) {
+                if (tid == 0) s_err = PLAT_ERR_OVERFLOW;
+                asm_sync();
+                break;
+            }
+            // ---- phase A: insert every k-mer that takes part in a (valid) edge
+            for (int e = tid; e < nEv; e += nthr) {
+                if (e < nRefE) {
+                    asm_slot(S, ref, rseq, e, k, capmask, true);
+                    if (e == nRefE - 1) asm_slot(S, ref, rseq, e + 1, k, capmask, true);
+                } else {
+                    // locate the read of this event
+                    int lo = 0, hi = nR;
+                    const int x = e - nRefE;
+                    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (S.read_base[mid] <= x) lo = mid; else hi = mid; }
+                    while (lo + 1 < nR && S.read_base[lo + 1] <= x) ++lo;
+                    const int i = x - S.read_base[lo];
+                    const int ro = (int)(b.read_off[rb + lo] - rblob0);
+                    if (asm_read_edge_q(rseq + ro, rqual + ro, i, k, P.min_qual) >= 0) {
+                        asm_slot(S, ref, rseq, 0x40000000 + ro + i, k, capmask, true);
+                        asm_slot(S, ref, rseq, 0x40000000 + ro + i + 1, k, capmask, true);
+                    }
+                }
+            }
+            asm_sync();
+            // ---- phase B: dense node ids + field initialisation
+            for (int sidx = tid; sidx < P.cap; sidx += nthr) {
+                if (S.key[sidx] != -1) {
+                    const int id = atomicAdd(&s_n, 1);
+                    S.slot_id[sidx] = id;
+                    S.first[id] = 0xFFFFFFFFu; S.weight[id] = 0; S.colour[id] = 0; S.rep[id] = S.key[sidx];
+                    for (int j = 0; j < ASM_MAX_SUCC; ++j) {
+                        S.succ_c[id * ASM_MAX_SUCC + j] = 0; S.succ_t[id * ASM_MAX_SUCC + j] = 0xFFFFFFFFu;
+                        S.succ_w[id * ASM_MAX_SUCC + j] = 0; S.succ_n[id * ASM_MAX_SUCC + j] = -1;
+                    }
+                }
+            }
+            asm_sync();
+            const int nNodes = s_n;
+            // ---- phase C: AddEdge events (assembler.pyx:801-827)
+            for (int e = tid; e < nEv; e += nthr) {
+                int so, eo, col, w;
+                if (e < nRefE) { so = e; eo = e + 1; col = 1; w = 1; }
+                else {
+                    int lo = 0, hi = nR;
+                    const int x = e - nRefE;
+                    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (S.read_base[mid] <= x) lo = mid; else hi = mid; }
+                    while (lo + 1 < nR && S.read_base[lo + 1] <= x) ++lo;
+                    const int i = x - S.read_base[lo];
+                    const int ro = (int)(b.read_off[rb + lo] - rblob0);
+                    w = asm_read_edge_q(rseq + ro, rqual + ro, i, k, P.min_qual);
+                    if (w < 0) continue;
+                    so = 0x40000000 + ro + i; eo = so + 1; col = 2;
+                }
+                const int sn = S.slot_id[asm_slot(S, ref, rseq, so, k, capmask, false)];
+                const int en = S.slot_id[asm_slot(S, ref, rseq, eo, k, capmask, false)];
+                atomicMin(&S.first[sn], 2u * (unsigned)e);
+                atomicMin(&S.first[en], 2u * (unsigned)e + 1u);
+                atomicAdd(&S.weight[sn], w); atomicAdd(&S.weight[en], w);
+                atomicOr(&S.colour[sn], col); atomicOr(&S.colour[en], col);
+                if (e < nRefE) { S.ref_node[e] = sn; if (e == nRefE - 1) S.ref_node[e + 1] = en; }
+                // successor slot keyed by the byte appended to the start k-mer
+                const unsigned char c = asm_ptr(ref, rseq, eo)[k - 1];
+                unsigned* cw = (unsigned*)(S.succ_c + (size_t)sn * ASM_MAX_SUCC);       // 8 bytes = 2 dwords
+                int slot = -1;
+                for (int j = 0; j < ASM_MAX_SUCC && slot < 0; ++j) {
+                    for (;;) {
+                        const unsigned word = cw[j >> 2];
+                        const unsigned cur = (word >> (8 * (j & 3))) & 0xFFu;
+                        if (cur == c) { slot = j; break; }
+                        if (cur != 0u) break;
+                        const unsigned old = atomicCAS(&cw[j >> 2], word, word | ((unsigned)c << (8 * (j & 3))));
+                        if (old == word) { slot = j; break; }
+                    }
+                }
+                if (slot < 0) { s_err = PLAT_ERR_UNSUPPORTED; continue; }                // > 8 distinct successor bytes
+                atomicMin(&S.succ_t[sn * ASM_MAX_SUCC + slot], (unsigned)e);
+                atomicAdd(&S.succ_w[sn * ASM_MAX_SUCC + slot], w);
+                S.succ_n[sn * ASM_MAX_SUCC + slot] = en;
+            }
+            asm_sync();
+            // ---- phase D: per node, the four successors with the smallest first tickets, in ticket order
+            for (int n = tid; n < nNodes; n += nthr) {
+                AsmNodeE E; E.n = 0;
+                unsigned last = 0; bool firstpick = true;
+                for (int pick = 0; pick < 4; ++pick) {
+                    int bj = -1; unsigned bt = 0xFFFFFFFFu;
+                    for (int j = 0; j < ASM_MAX_SUCC; ++j) {
+                        const unsigned t = S.succ_t[n * ASM_MAX_SUCC + j];
+                        if (t == 0xFFFFFFFFu) continue;
+                        if (!firstpick && t <= last) continue;
+                        if (t < bt) { bt = t; bj = j; }
+                    }
+                    if (bj < 0) break;
+                    E.end[E.n] = S.succ_n[n * ASM_MAX_SUCC + bj]; E.w[E.n] = S.succ_w[n * ASM_MAX_SUCC + bj]; ++E.n;
+                    last = bt; firstpick = false;
+                }
+                S.edges[n] = E;
+            }
+            asm_sync();
+            // ---- noCycles: detectCyclesInGraph_Recursive (assembler.pyx:831-898), iterative, one thread
+            if (P.no_cycles) {
+                if (tid == 0) {
+                    int cyc = 0;
+                    for (int n = 0; n < nNodes; ++n) S.dfs[n] = 'w';
+                    for (int n0 = 0; n0 < nNodes && !cyc; ++n0) {
+                        if (S.dfs[n0] != 'w') continue;
+                        int sp = 0;
+                        S.stack[0] = n0; S.stack[1] = 0; sp = 1; S.dfs[n0] = 'g';
+                        while (sp > 0 && !cyc) {
+                            const int n = S.stack[2 * (sp - 1)];
+                            int ei = S.stack[2 * (sp - 1) + 1];
+                            const AsmNodeE& E = S.edges[n];
+                            bool descended = false;
+                            while (ei < E.n) {
+                                const int m = E.end[ei]; const int wgt = E.w[ei]; ++ei;
+                                if (S.colour[m] == 2 && wgt < P.min_weight) continue;
+                                if (S.dfs[m] == 'w') {
+                                    S.stack[2 * (sp - 1) + 1] = ei;
+                                    S.stack[2 * sp] = m; S.stack[2 * sp + 1] = 0; ++sp; S.dfs[m] = 'g';
+                                    descended = true; break;
+                                } else if (S.dfs[m] == 'g') { cyc = 1; break; }
+                            }
+                            if (!descended && !cyc) { S.dfs[n] = 'b'; --sp; }
+                        }
+                    }
+                    s_cycle = cyc;
+                    if (cyc && k <= 50) s_k = k + 5;
+                }
+                asm_sync();
+                if (s_cycle && k <= 50) continue;          // rebuild with a longer k
+                if (s_cycle) break;                        // k > 50 and still cyclic: no variants (assembler.pyx:1454-1457)
+            }
+            // ---- phase E: bubble starts in allNodes order (= increasing position for REF_AND_READ nodes)
+            if (tid == 0) {
+                int nt = 0;
+                const int i0 = aStart - refStart > 0 ? aStart - refStart : 0;
+                const int i1 = aEnd - refStart < nRefE + 1 ? aEnd - refStart : nRefE + 1;
+                for (int i = i0; i < i1 && s_err == 0; ++i) {
+                    if (nRefE == 0) break;
+                    const int n = S.ref_node[i];
+                    const unsigned ft = S.first[n];
+                    if ((int)(ft >> 1) + (int)(ft & 1u) != i) continue;          // not the first occurrence of this k-mer
+                    if (S.colour[n] != 3) continue;                                // assembler.pyx:1144
+                    const AsmNodeE& E = S.edges[n];
+                    for (int j = 0; j < E.n; ++j)
+                        if (S.colour[E.end[j]] == 2) {                             // assembler.pyx:1153
+                            if (nt >= ASM_MAX_TASKS) { s_err = PLAT_ERR_OVERFLOW; break; }
+                            S.task_node[nt] = n; S.task_edge[nt] = j; ++nt;
+                        }
+                }
+                s_ntasks = nt;
+            }
+            asm_sync();
+            const int nTasks = s_ntasks;
+            // ---- phase F: getVariantPathsThroughGraphFromNode (assembler.pyx:1027-1112), one thread per start edge
+            for (int t = tid; t < nTasks; t += nthr) {
+                int* A = S.arena + (size_t)t * ASM_ARENA * 3;
+                int na = 0;
+                int stk[28]; int top = 0, nfin = 0;
+                A[0] = S.task_node[t]; A[1] = -1; A[2] = 1;
+                A[3] = S.edges[S.task_node[t]].end[S.task_edge[t]]; A[4] = 0; A[5] = 2; na = 2;
+                stk[top++] = 1;
+                bool aborted = false, overflow = false;
+                while (top > 0) {
+                    const int pe = stk[--top];
+                    if (top > 20 || nfin > 20) { aborted = true; break; }          // assembler.pyx:1052-1057
+                    const int endn = A[3 * pe];
+                    // checkPathForCycles (:999-1023): a path is only ever extended from a cycle-free path, so it
+                    // suffices to compare its last node with its ancestors
+                    bool cyc = false;
+                    for (int a = A[3 * pe + 1]; a >= 0; a = A[3 * a + 1]) if (A[3 * a] == endn) { cyc = true; break; }
+                    if (cyc) continue;
+                    const int col = S.colour[endn];
+                    if (col == 3) { S.task_fin[t * ASM_MAX_FIN + nfin] = pe; ++nfin; }
+                    else if (col == 1) continue;
+                    else {
+                        const AsmNodeE& E = S.edges[endn];
+                        for (int i = 0; i < E.n; ++i) {                            // assembler.pyx:1091-1107
+                            const int c2 = S.colour[E.end[i]];
+                            if (E.w[i] >= P.min_weight || c2 == 3 || c2 == 1) {
+                                if (na >= ASM_ARENA) { overflow = true; break; }
+                                A[3 * na] = E.end[i]; A[3 * na + 1] = pe; A[3 * na + 2] = A[3 * pe + 2] + 1;
+                                stk[top++] = na; ++na;
+                            }
+                        }
+                        if (overflow) break;
+                    }
+                }
+                if (overflow) s_err = PLAT_ERR_OVERFLOW;
+                S.task_nfin[t] = aborted ? 0 : nfin;
+            }
+            asm_sync();
+            break;
+        }
+        asm_sync();
+
+        // ---- phase G/H: variants in emission order, then the stable sort of sorted(theVars) (assembler.pyx:1476)
+        if (tid == 0) {
+            int nv = 0, blob = 0, err = s_err;
+            const int k = s_k;
+            const int nTasks = (err == 0 && !(P.no_cycles && s_cycle)) ? s_ntasks : 0;
+            int32_t* vp = var_pos + (size_t)g * P.max_vars; int32_t* vr = var_nrem + (size_t)g * P.max_vars;
+            int32_t* va = var_nadd + (size_t)g * P.max_vars; int32_t* vo = var_off + (size_t)g * P.max_vars;
+            uint8_t* vb = var_blob + (size_t)g * P.blob_per_region;
+            (void)k;
+            for (int t = 0; t < nTasks && err == 0; ++t) {
+                const int* A = S.arena + (size_t)t * ASM_ARENA * 3;
+                for (int f = 0; f < S.task_nfin[t] && err == 0; ++f) {             // extractVarFromBubblePath :1196-1291
+                    const int last = S.task_fin[t * ASM_MAX_FIN + f];
+                    const int plen = A[3 * last + 2];
+                    const int startn = S.task_node[t], endn = A[3 * last];
+                    const unsigned fs = S.first[startn], fe = S.first[endn];
+                    int s = refStart + (int)(fs >> 1) + (int)(fs & 1u), te = refStart + (int)(fe >> 1) + (int)(fe & 1u);
+                    if (te < s) continue;                                          // :1213-1218
+                    int rl = te - s + 1, al = plen;
+                    const uint8_t* r = ref + (s - refStart);
+                    // alt = first byte of every node on the path; element `last` is the path's last node
+                    // suffix trim first (:1253), then prefix trim advancing the position (:1262-1270)
+                    // walk helper: byte of path element at index q (0-based from the path start)
+                    auto alt_at = [&](int q) -> uint8_t {
+                        int e = last;
+                        for (int d = plen - 1; d > q; --d) e = A[3 * e + 1];
+                        return asm_ptr(ref, rseq, S.rep[A[3 * e]])[0];
+                    };
+                    while (al > 0 && rl > 0 && r[rl - 1] == alt_at(al - 1)) { --rl; --al; }
+                    int ao = 0;
+                    while (al > 0 && rl > 0 && r[0] == alt_at(ao)) { ++r; ++ao; --rl; --al; ++s; }
+                    if (nv >= P.max_vars || blob + rl + al > P.blob_per_region) { err = PLAT_ERR_OVERFLOW; break; }
+                    vp[nv] = s > 0 ? s : 0;                                        // variant.pyx:121
+                    vr[nv] = rl; va[nv] = al; vo[nv] = blob;
+                    for (int i = 0; i < rl; ++i) vb[blob + i] = r[i];
+                    for (int i = 0; i < al; ++i) vb[blob + rl + i] = alt_at(ao + i);
+                    blob += rl + al; ++nv;
+                }
+            }
+            // stable insertion sort by (pos, varType, nRemoved)  (Variant.__richcmp__ '<', variant.pyx:282-363)
+            auto vtype = [&](int i) { const int a = va[i], rr = vr[i]; return rr == a ? (a == 1 ? 0 : 1) : (rr == 0 ? 2 : (a == 0 ? 3 : 4)); };
+            for (int i = 1; i < nv; ++i) {
+                const int p0 = vp[i], r0 = vr[i], a0 = va[i], o0 = vo[i], t0 = vtype(i);
+                int j = i - 1;
+                while (j >= 0 && (vp[j] > p0 || (vp[j] == p0 && (vtype(j) > t0 || (vtype(j) == t0 && vr[j] > r0))))) {
+                    vp[j + 1] = vp[j]; vr[j + 1] = vr[j]; va[j + 1] = va[j]; vo[j + 1] = vo[j]; --j;
+                }
+                vp[j + 1] = p0; vr[j + 1] = r0; va[j + 1] = a0; vo[j + 1] = o0;
+            }
+            var_count[g] = err ? 0 : nv;
+            status[g] = err;
+        }
+        asm_sync();
+    }
+}
+
+__global__ void k_asm_sizes(plat_assembly_batch b, long long* out /* [0]=max ref, [1]=max reads, [2]=max positions, [3]=err */)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= b.n_regions) return;
+    const long long rl = b.ref_off[g + 1] - b.ref_off[g];
+    const int r0 = b.reg_read_begin[g], r1 = b.reg_read_begin[g + 1];
+    if (rl < 0 || rl >= 0x40000000ll || r1 < r0) { out[3] = PLAT_ERR_BAD_INPUT; return; }
+    long long pos = rl + 2;
+    const long long bytes = r1 > r0 ? b.read_off[r1] - b.read_off[r0] : 0;
+    if (bytes < 0 || bytes >= 0x3FFFFFFFll) { out[3] = PLAT_ERR_BAD_INPUT; return; }
+    pos += bytes + 2 * (long long)(r1 - r0);
+    atomicMax((unsigned long long*)&out[0], (unsigned long long)rl);
+    atomicMax((unsigned long long*)&out[1], (unsigned long long)(r1 - r0));
+    atomicMax((unsigned long long*)&out[2], (unsigned long long)pos);
+}
+
+}  // namespace plat
+
+using namespace plat;
 
 PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* batch, int kmer_size, int min_qual,
                                     int min_weight, int no_cycles, int max_vars_per_region, int blob_per_region,
                                     int32_t* var_count, int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd,
                                     int32_t* var_off, uint8_t* var_blob, int32_t* status, void* stream)
 {
-    (void)batch; (void)kmer_size; (void)min_qual; (void)min_weight; (void)no_cycles; (void)max_vars_per_region;
-    (void)blob_per_region; (void)var_count; (void)var_pos; (void)var_nrem; (void)var_nadd; (void)var_off;
-    (void)var_blob; (void)status; (void)stream;
-    if (!ctx) return PLAT_ERR_INVALID;
-    return PLAT_ERR_UNSUPPORTED;   // device assembler not built yet: fail loudly, never fall back to the CPU
+    if (!ctx || !batch) return PLAT_ERR_INVALID;
+    const plat_assembly_batch b = *batch;
+    if (b.n_regions < 0 || b.n_reads < 0 || kmer_size < 5 || kmer_size > 200 || max_vars_per_region <= 0 ||
+        blob_per_region <= 0)
+        return PLAT_ERR_INVALID;
+    if (b.n_regions == 0) return PLAT_OK;
+    if (!b.ref_seq || !b.ref_off || !b.ref_start || !b.assem_start || !b.assem_end || !b.reg_read_begin ||
+        !b.read_off || !var_count || !var_pos || !var_nrem || !var_nadd || !var_off || !var_blob || !status)
+        return PLAT_ERR_INVALID;
+    if (b.n_reads > 0 && (!b.read_seq || !b.read_qual)) return PLAT_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = plat_reserve(ctx, ctx->counters, 64 * sizeof(long long));
+    if (rc) return rc;
+    long long* d_sz = (long long*)ctx->counters.ptr;
+    PLAT_HIP(ctx, hipMemsetAsync(d_sz, 0, 8 * sizeof(long long), st));
+    hipLaunchKernelGGL(k_asm_sizes, dim3((b.n_regions + 255) / 256), dim3(256), 0, st, b, d_sz);
+    int64_t* hb = ctx->h_readback;
+    PLAT_HIP(ctx, hipMemcpyAsync(hb, d_sz, 4 * sizeof(long long), hipMemcpyDeviceToHost, st));
+    PLAT_HIP(ctx, hipStreamSynchronize(st));
+    if (hb[3] != 0) return (int)hb[3];
+    const int max_ref = (int)hb[0], max_reads = (int)hb[1];
+    // k may grow to 55 under noCycles, which only lowers the number of edges: size for the initial k
+    long long max_pos = hb[2] + 16;
+    if (max_pos > 0x3FFFFFFFll) return PLAT_ERR_OVERFLOW;
+    int cap = 1024;
+    while ((long long)cap * 3 < max_pos * 4 * 2) cap <<= 1;     // load factor <= 3/8 even if every occurrence were distinct
+    AsmParams P;
+    P.kmer = kmer_size; P.min_qual = min_qual; P.min_weight = min_weight; P.no_cycles = no_cycles;
+    P.max_vars = max_vars_per_region; P.blob_per_region = blob_per_region; P.cap = cap; P.max_pos = (int)max_pos;
+    const size_t per_block = asm_scratch_bytes(cap, (int)max_pos, max_ref, max_reads);
+    P.scratch_per_block = (long long)per_block;
+    int nblk = b.n_regions < 2 * ctx->n_cu ? b.n_regions : 2 * ctx->n_cu;
+    while (nblk > 1 && per_block * (size_t)nblk > ((size_t)48 << 30)) nblk /= 2;
+    if ((rc = plat_reserve(ctx, ctx->asm_scratch, per_block * (size_t)nblk))) return rc;
+    hipLaunchKernelGGL(k_assemble, dim3(nblk), dim3(256), 0, st, b, P, (char*)ctx->asm_scratch.ptr, max_ref, max_reads,
+                       var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
 }

@@ -1,0 +1,106 @@
+"""GPU parity tests of the device assembler (a14-a18) against the golden vectors generated from the reference's
+own assembler.pyx and against the oracle on fresh fuzz regions.  Bar: identical variant tuples in identical order."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from platypus_amd.engine import Engine
+    return Engine(0)
+
+
+def to_region(c):
+    return dict(ref=c["ref"].encode(), ref_start=c["refStart"], assem_start=c["assemStart"], assem_end=c["assemEnd"],
+                seqs=[s.encode() for s in c["seqs"]], quals=[q.encode("latin1") for q in c["quals"]])
+
+
+def test_assembler_golden_vectors(eng, golden_dir):
+    cases = json.load(gzip.open(os.path.join(golden_dir, "assembler_cases.json.gz"), "rt"))
+    for nc in (0, 1):
+        sel = [c for c in cases if c["noCycles"] == nc]
+        got = eng.assemble([to_region(c) for c in sel], kmer_size=15, min_qual=20, min_weight=40, no_cycles=nc)
+        for c, g in zip(sel, got):
+            exp = [(p, r.encode(), a.encode()) for p, r, a in c["variants"]]
+            assert g == exp
+
+
+def synth_region(rng, ref_len, nh, L, depth, nvar):
+    B = b"ACGT"
+
+    def rnd(n):
+        return bytes(rng.choice(list(B), n).tolist())
+    ref = bytearray(rnd(ref_len))
+    if rng.random() < 0.4:
+        p = int(rng.integers(100, ref_len - 200)); ln = int(rng.integers(20, 120)); u = rnd(int(rng.integers(1, 7)))
+        ref[p:p + ln] = (u * (ln // len(u) + 1))[:ln]
+    if rng.random() < 0.2:
+        ref[int(rng.integers(0, ref_len))] = ord("N")
+    ref = bytes(ref)
+    ref_start = int(rng.integers(0, 100000))
+    a0 = ref_start + int(rng.integers(0, ref_len // 3)); a1 = a0 + int(rng.integers(100, 1500))
+    donors = []
+    for _ in range(nh):
+        d = bytearray(ref)
+        for _ in range(int(rng.integers(0, nvar + 1))):
+            lo, hi = max(50, a0 - ref_start), min(len(d) - 100, a1 - ref_start) + 1
+            p = int(rng.integers(lo, hi)) if hi > lo else 60
+            t = int(rng.integers(0, 3))
+            if t == 0:
+                d[p] = B[int(rng.integers(0, 4))]
+            elif t == 1:
+                d[p:p] = rnd(int(rng.integers(1, 41)))
+            else:
+                del d[p:p + int(rng.integers(1, 41))]
+        donors.append(bytes(d))
+    seqs, quals = [], []
+    for _ in range(depth * ref_len // L):
+        d = donors[int(rng.integers(0, nh))]
+        if len(d) <= L:
+            continue
+        p = int(rng.integers(0, len(d) - L)); s = bytearray(d[p:p + L])
+        q = np.clip(rng.normal(35, 5, L), 2, 41).astype(np.uint8)
+        lo = rng.random(L) < 0.05; q[lo] = rng.integers(2, 20, int(lo.sum()))
+        for e in np.nonzero(rng.random(L) < 0.002)[0]:
+            s[e] = B[int(rng.integers(0, 4))]
+        if rng.random() < 0.02:
+            s[int(rng.integers(0, L))] = ord("N")
+        seqs.append(bytes(s)); quals.append(bytes(q.tolist()))
+    return dict(ref=ref, ref_start=ref_start, assem_start=a0, assem_end=a1, seqs=seqs, quals=quals)
+
+
+def test_assembler_fuzz_vs_oracle(eng, oracle):
+    rng = np.random.default_rng(31337)
+    regions = [synth_region(rng, int(rng.integers(600, 4500)), int(rng.choice([1, 2, 2, 4])),
+                            int(rng.choice([100, 150, 250])), int(rng.choice([15, 30])), int(rng.choice([0, 3, 6])))
+               for _ in range(60)]
+    regions.append(dict(ref=b"ACGT" * 30, ref_start=5, assem_start=0, assem_end=200, seqs=[], quals=[]))     # no reads
+    regions.append(dict(ref=b"ACGTACG", ref_start=0, assem_start=0, assem_end=7, seqs=[b"ACGTACGTAC"], quals=[b"\x28" * 10]))  # ref shorter than k
+    for k, nc in ((15, 0), (15, 1), (21, 0), (11, 0)):
+        got = eng.assemble(regions, kmer_size=k, no_cycles=nc)
+        nvar = 0
+        for r, g in zip(regions, got):
+            exp, _ = oracle.assemble(r["ref"], r["ref_start"], r["assem_start"], r["assem_end"], r["seqs"], r["quals"],
+                                     k, 20, 40, nc)
+            assert g == exp
+            nvar += len(exp)
+        assert nvar > 20
+
+
+def test_config3_shape_regions(eng, oracle):
+    """BASELINE config 3 shape: 4.5 kb reference (1.5 kb tile +- 1.5 kb), 250 bp reads at 30x, 1-3 indels + SNPs."""
+    rng = np.random.default_rng(3003)
+    regions = [synth_region(rng, 4500, 2, 250, 30, 4) for _ in range(24)]
+    got = eng.assemble(regions)
+    tot = 0
+    for r, g in zip(regions, got):
+        exp, _ = oracle.assemble(r["ref"], r["ref_start"], r["assem_start"], r["assem_end"], r["seqs"], r["quals"])
+        assert g == exp
+        tot += len(exp)
+    assert tot > 0
