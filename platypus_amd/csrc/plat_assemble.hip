@@ -20,7 +20,7 @@ namespace plat {
 
 constexpr int ASM_MAX_SUCC = 8;        // distinct successor bytes tracked per node before the "first four" cut
 constexpr int ASM_MAX_TASKS = 512;     // bubble-start (node, edge) pairs per region
-constexpr int ASM_ARENA = 2048;        // path elements per task (each pop extends a path by <= 4 elements)
+constexpr int ASM_POOL = 1 << 20;      // path elements per region, shared by its tasks (bump-allocated)
 constexpr int ASM_MAX_FIN = 21;        // finished paths per task before the reference aborts (assembler.pyx:1052)
 
 struct AsmParams {
@@ -52,7 +52,7 @@ struct AsmScratch {
     int* task_edge;      // [MAX_TASKS]
     int* task_nfin;      // [MAX_TASKS]  (-1 aborted)
     int* task_fin;       // [MAX_TASKS][MAX_FIN] arena index of the last element
-    int* arena;          // [MAX_TASKS][ARENA][3] node, parent, depth
+    int* arena;          // [POOL][3] node, parent, depth (parent = pool index)
     int* var_task_off;   // [MAX_TASKS+1]
     int* stack;          // [max_pos*2] iterative DFS stack for the cycle check
 };
@@ -71,7 +71,7 @@ __host__ __device__ inline size_t asm_scratch_bytes(int cap, int max_pos, int ma
     b += asm_align((size_t)(max_reads + 1) * 4);
     b += asm_align((size_t)ASM_MAX_TASKS * 4) * 3;
     b += asm_align((size_t)ASM_MAX_TASKS * ASM_MAX_FIN * 4);
-    b += asm_align((size_t)ASM_MAX_TASKS * ASM_ARENA * 3 * 4);
+    b += asm_align((size_t)ASM_POOL * 3 * 4);
     b += asm_align((size_t)(ASM_MAX_TASKS + 1) * 4);
     b += asm_align((size_t)max_pos * 2 * 4);
     return b;
@@ -98,7 +98,7 @@ __device__ inline AsmScratch asm_carve(char* p, int cap, int max_pos, int max_re
     s.task_edge = (int*)take((size_t)ASM_MAX_TASKS * 4);
     s.task_nfin = (int*)take((size_t)ASM_MAX_TASKS * 4);
     s.task_fin = (int*)take((size_t)ASM_MAX_TASKS * ASM_MAX_FIN * 4);
-    s.arena = (int*)take((size_t)ASM_MAX_TASKS * ASM_ARENA * 3 * 4);
+    s.arena = (int*)take((size_t)ASM_POOL * 3 * 4);
     s.var_task_off = (int*)take((size_t)(ASM_MAX_TASKS + 1) * 4);
     s.stack = (int*)take((size_t)max_pos * 2 * 4);
     return s;
@@ -155,7 +155,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
            int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob,
            int32_t* status)
 {
-    __shared__ int s_n, s_ntasks, s_err, s_cycle, s_k;
+    __shared__ int s_n, s_ntasks, s_err, s_cycle, s_k, s_pool;
     const int tid = threadIdx.x, nthr = blockDim.x;
     AsmScratch S = asm_carve(scratch + (size_t)blockIdx.x * P.scratch_per_block, P.cap, P.max_pos, max_ref, max_reads);
     const int capmask = P.cap - 1;
@@ -183,13 +183,13 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     acc += L - k - 1 > 0 ? L - k - 1 : 0;
                 }
                 S.read_base[nR] = acc;
-                s_n = 0; s_ntasks = 0;
+                s_n = 0; s_ntasks = 0; s_pool = 0;
             }
             for (int i = tid; i < P.cap; i += nthr) S.key[i] = -1;
             asm_sync();
             const int nReadE = S.read_base[nR];
             const int nEv = nRefE + nReadE;
-            if ((long long)nEv * 2 + 2 > (long long)P.max_pos || (long long)nEv * 4 > (long long)P.cap * 3) {
+            if ((long long)nEv + 2ll * (nR + 1) > (long long)P.max_pos || (long long)nEv * 4 > (long long)P.cap * 3) {   // distinct k-mers <= occurrences
                 if (tid == 0) s_err = PLAT_ERR_OVERFLOW;
                 asm_sync();
                 break;
@@ -346,13 +346,15 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             const int nTasks = s_ntasks;
             // ---- phase F: getVariantPathsThroughGraphFromNode (assembler.pyx:1027-1112), one thread per start edge
             for (int t = tid; t < nTasks; t += nthr) {
-                int* A = S.arena + (size_t)t * ASM_ARENA * 3;
-                int na = 0;
+                int* A = S.arena;
                 int stk[28]; int top = 0, nfin = 0;
-                A[0] = S.task_node[t]; A[1] = -1; A[2] = 1;
-                A[3] = S.edges[S.task_node[t]].end[S.task_edge[t]]; A[4] = 0; A[5] = 2; na = 2;
-                stk[top++] = 1;
-                bool aborted = false, overflow = false;
+                const int e0 = atomicAdd(&s_pool, 2);
+                bool aborted = false, overflow = e0 + 2 > ASM_POOL;
+                if (!overflow) {
+                    A[3 * e0] = S.task_node[t]; A[3 * e0 + 1] = -1; A[3 * e0 + 2] = 1;
+                    A[3 * e0 + 3] = S.edges[S.task_node[t]].end[S.task_edge[t]]; A[3 * e0 + 4] = e0; A[3 * e0 + 5] = 2;
+                    stk[top++] = e0 + 1;
+                }
                 while (top > 0) {
                     const int pe = stk[--top];
                     if (top > 20 || nfin > 20) { aborted = true; break; }          // assembler.pyx:1052-1057
@@ -370,9 +372,10 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         for (int i = 0; i < E.n; ++i) {                            // assembler.pyx:1091-1107
                             const int c2 = S.colour[E.end[i]];
                             if (E.w[i] >= P.min_weight || c2 == 3 || c2 == 1) {
-                                if (na >= ASM_ARENA) { overflow = true; break; }
+                                const int na = atomicAdd(&s_pool, 1);
+                                if (na >= ASM_POOL) { overflow = true; break; }
                                 A[3 * na] = E.end[i]; A[3 * na + 1] = pe; A[3 * na + 2] = A[3 * pe + 2] + 1;
-                                stk[top++] = na; ++na;
+                                stk[top++] = na;
                             }
                         }
                         if (overflow) break;
@@ -396,7 +399,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             uint8_t* vb = var_blob + (size_t)g * P.blob_per_region;
             (void)k;
             for (int t = 0; t < nTasks && err == 0; ++t) {
-                const int* A = S.arena + (size_t)t * ASM_ARENA * 3;
+                const int* A = S.arena;
                 for (int f = 0; f < S.task_nfin[t] && err == 0; ++f) {             // extractVarFromBubblePath :1196-1291
                     const int last = S.task_fin[t * ASM_MAX_FIN + f];
                     const int plen = A[3 * last + 2];
