@@ -1,0 +1,334 @@
+"""Python 3 mirror of the reference's operator interface for the hot path: same class and
+method names, argument meaning and error behaviour as the Cython classes it stands in for, with all scoring
+done by the HIP library (never on the CPU).
+
+    Variant                      src/cython/variant.pyx:100-454      (value type, ordering)
+    AlignedRead                  src/cython/htslibWrapper.pxd:187-201 (cAlignedRead fields)
+    ReadArray / bamReadBuffer    src/cython/cwindow.pyx:92-236,485-513 (window pointers)
+    FastaFile (in-memory)        src/cython/fastafile.pyx:173-207     (getSequence semantics)
+    Haplotype                    src/cython/chaplotype.pyx:127-191,306-384,397-449
+    DiploidGenotype              src/cython/cgenotype.pyx:131-218
+    Population.setup             src/cython/cpopulation.pyx:197-309
+    assembleReadsAndDetectVariants  src/cython/assembler.pyx:1429-1476
+
+The per-call methods (`alignReads`, `alignSingleRead`, `calculateDataLikelihood`) exist for drop-in compatibility
+and launch tiny batches; throughput comes from `Population.setup` (all haplotypes x all individuals of a window in
+one launch) and, beyond that, from batching many windows through `Engine.call_windows` directly.
+"""
+import bisect
+from types import SimpleNamespace
+
+import numpy as np
+
+from .batch import BAM_FQCFAIL, HostBatch
+from .options import default_options
+
+PLATYPUS_VAR, FILE_VAR, ASSEMBLER_VAR = 1, 2, 4               # variant.pyx:43-45
+SNP, MNP, INS, DEL, REP = 0, 1, 2, 3, 4                       # variant.pyx:49-53
+hash_nucs, hash_size = 7, 16384                               # calign.pyx:25-26
+
+_engine = None
+
+
+def get_engine():
+    """One Engine (one plat_ctx) per process, like the single Population object per worker (variantcaller.pyx:959)."""
+    global _engine
+    if _engine is None:
+        from .engine import Engine
+        import os
+        _engine = Engine(int(os.environ.get("LOCAL_RANK", "0")))
+    return _engine
+
+
+class Variant:
+    """variant.pyx:100-146; ordering = Variant.__richcmp__ (variant.pyx:282-363)."""
+
+    def __init__(self, refName, refPos, removed, added, nSupportingReads=0, varSource=PLATYPUS_VAR):
+        refPos = max(0, refPos)
+        self.refName, self.refPos = refName, refPos
+        self.removed, self.added = bytes(removed), bytes(added)
+        self.nRemoved, self.nAdded = len(self.removed), len(self.added)
+        self.nSupportingReads, self.varSource = nSupportingReads, varSource
+        self.minRefPos = refPos
+        self.maxRefPos = max(refPos, refPos + self.nRemoved - 1)
+        if self.nRemoved == self.nAdded:
+            self.varType = SNP if self.nAdded == 1 else MNP
+        elif self.nRemoved == 0:
+            self.varType = INS
+        elif self.nAdded == 0:
+            self.varType = DEL
+        else:
+            self.varType = REP
+
+    def _key(self):
+        return (self.refName, self.refPos, self.varType, self.nRemoved)
+
+    def __lt__(self, o):
+        return self._key() < o._key()
+
+    def __eq__(self, o):
+        return (self.refName, self.refPos, self.added, self.removed) == (o.refName, o.refPos, o.added, o.removed)
+
+    def __hash__(self):
+        return hash((self.refName, self.refPos, self.removed, self.added))
+
+    def __repr__(self):
+        return "Variant(%s:%d %s->%s)" % (self.refName, self.refPos, self.removed.decode(), self.added.decode())
+
+
+class AlignedRead:
+    """The fields of cAlignedRead the hot path reads (htslibWrapper.pxd:187-201).  qual is raw phred."""
+
+    def __init__(self, seq, qual, pos, mapq=60, bitFlag=3, end=None):
+        self.seq, self.qual = bytes(seq), bytes(qual)
+        if len(self.seq) != len(self.qual):
+            raise ValueError("seq and qual differ in length")
+        self.rlen = len(self.seq)
+        self.pos = int(pos)
+        self.end = int(end) if end is not None else self.pos + self.rlen
+        self.mapq, self.bitFlag = int(mapq), int(bitFlag)
+
+    def isQCFail(self):
+        return (self.bitFlag & BAM_FQCFAIL) != 0
+
+
+class ReadArray:
+    """cwindow.pyx:92-236: reads sorted by position with [windowStart, windowEnd) pointers."""
+
+    def __init__(self, reads=()):
+        self.array = sorted(reads, key=lambda r: r.pos)
+        self._pos = [r.pos for r in self.array]
+        self.longestRead = max([r.end - r.pos for r in self.array], default=0)
+        self.windowStart = self.windowEnd = 0
+
+    def setWindowPointers(self, start, end):
+        if not self.array:
+            self.windowStart = self.windowEnd = 0
+            return
+        s = bisect.bisect_left(self._pos, max(1, start - self.longestRead))      # cwindow.pyx:222-224
+        e = bisect.bisect_left(self._pos, end)
+        while s < len(self.array) and self.array[s].end <= start:                 # :226-227
+            s += 1
+        self.windowStart, self.windowEnd = s, min(e, len(self.array))
+        if s > e:
+            raise RuntimeError("This should never happen. Read start pointer > read end pointer!!")
+
+    def window(self):
+        return self.array[self.windowStart:self.windowEnd]
+
+
+class bamReadBuffer:
+    """cwindow.pyx:485-513: per-sample reads / badReads / brokenMates."""
+
+    def __init__(self, reads=(), badReads=(), brokenMates=(), sample="sample"):
+        self.reads, self.badReads, self.brokenMates = ReadArray(reads), ReadArray(badReads), ReadArray(brokenMates)
+        self.sample = sample
+
+    def setWindowPointers(self, start, end):                                      # cwindow.pyx:655-689
+        self.reads.setWindowPointers(start, end)
+        self.badReads.setWindowPointers(start, end)
+        self.brokenMates.setWindowPointers(start, end)
+
+    def windowReads(self):
+        """good -> bad -> brokenMates, the order Haplotype.alignReads walks them (chaplotype.pyx:341-373)."""
+        return ([(r, 0) for r in self.reads.window()] + [(r, 1) for r in self.badReads.window()] +
+                [(r, 2) for r in self.brokenMates.window()])
+
+
+class FastaFile:
+    """In-memory stand-in for fastafile.pyx: upper-cased sequence, half-open getSequence clamped to [0, len-1]."""
+
+    def __init__(self, sequences):
+        self._seq = {k: bytes(v).upper() for k, v in sequences.items()}
+        self.refs = {k: SimpleNamespace(SeqLength=len(v)) for k, v in self._seq.items()}
+
+    def getSequence(self, seqName, beginPos, endPos):                             # fastafile.pyx:173-207
+        n = self.refs[seqName].SeqLength
+        beginPos, endPos = max(0, beginPos), min(n - 1, endPos)
+        if endPos < beginPos:
+            raise IndexError("Cannot have beginPos = %s, endPos = %s" % (beginPos, endPos))
+        return self._seq[seqName][beginPos:endPos]
+
+    def getCharacter(self, seqName, pos):
+        return self._seq[seqName][pos:pos + 1]
+
+
+def _pack_window(haps, startPos, endPos, endBufferSize, buffers):
+    """One-window HostBatch from haplotype byte strings and per-individual bamReadBuffers."""
+    reads, seg_b, seg_g = [], [0], []
+    for buf in buffers:
+        rs = buf.windowReads()
+        reads += rs
+        seg_b.append(len(reads))
+        seg_g.append(buf.reads.windowEnd - buf.reads.windowStart)
+    nH, nR = len(haps), len(reads)
+    hl = np.array([len(h) for h in haps], dtype=np.int64)
+    rl = np.array([r.rlen for r, _ in reads], dtype=np.int64)
+    cat = lambda parts: np.frombuffer(b"".join(parts), dtype=np.uint8)
+    return HostBatch(
+        n_ind=len(buffers), win_hap_begin=np.array([0, nH], dtype=np.int32), win_read_begin=np.array([0, nR], dtype=np.int32),
+        win_start=np.array([startPos], dtype=np.int32), win_end=np.array([endPos], dtype=np.int32),
+        win_flank=np.array([endBufferSize], dtype=np.int32), hap_seq=cat(haps),
+        hap_off=np.concatenate([[0], np.cumsum(hl)]).astype(np.int64), read_seq=cat([r.seq for r, _ in reads]),
+        read_qual=cat([r.qual for r, _ in reads]), read_off=np.concatenate([[0], np.cumsum(rl)]).astype(np.int64),
+        read_pos=np.array([r.pos for r, _ in reads], dtype=np.int32), read_end=np.array([r.end for r, _ in reads], dtype=np.int32),
+        read_mapq=np.array([r.mapq for r, _ in reads], dtype=np.uint8), read_flags=np.array([r.bitFlag for r, _ in reads], dtype=np.int32),
+        read_kind=np.array([k for _, k in reads], dtype=np.uint8), seg_read_begin=np.array(seg_b, dtype=np.int32),
+        seg_n_good=np.array(seg_g, dtype=np.int32))
+
+
+class Haplotype:
+    """chaplotype.pyx:127-191 (construction), :306-384 (alignReads / alignSingleRead), :397-449 (mutated sequence)."""
+
+    def __init__(self, refName, startPos, endPos, variants, refFile, maxReadLength, options=None):
+        self.refName, self.refFile, self.variants = refName, refFile, tuple(variants)
+        self.options = options if options is not None else default_options()
+        self.startPos = max(0, startPos)
+        self.endPos = min(endPos, refFile.refs[refName].SeqLength - 1)
+        self.maxReadLength = maxReadLength
+        self.endBufferSize = min(2 * maxReadLength, 500)                        # :142
+        self.lastIndividualIndex = -1
+        self.likelihoodCache = None
+        self.referenceSequence = refFile.getSequence(refName, self.startPos - self.endBufferSize, self.endPos + self.endBufferSize)
+        if len(self.variants) == 0:
+            self.haplotypeSequence = self.referenceSequence
+        else:
+            left = refFile.getSequence(refName, self.startPos - self.endBufferSize, self.startPos)
+            right = refFile.getSequence(refName, self.endPos, self.endPos + self.endBufferSize)
+            self.haplotypeSequence = left + self.getMutatedSequence() + right
+        self.hapLen = len(self.haplotypeSequence)
+        if self.hapLen > hash_size:                                              # :180-183
+            raise Exception("Haplotype is too long. Max allowed length is %s" % hash_size)
+
+    def getMutatedSequence(self):                                                # :397-449
+        ref, name = self.refFile, self.refName
+        cur = self.startPos
+        bits = []
+        first = self.variants[0]
+        if first.refPos != cur:
+            bits.append(ref.getSequence(name, cur, first.refPos))
+            cur = first.refPos
+        for v in self.variants:
+            if v.refPos > cur:
+                bits.append(ref.getSequence(name, cur, v.refPos))
+                cur = v.refPos
+            if v.nAdded == v.nRemoved:
+                bits.append(v.added)
+                cur += v.nRemoved
+            else:
+                if len(v.added) == 0 or len(v.removed) == 0:
+                    if v.refPos == cur:
+                        bits.append(ref.getCharacter(name, v.refPos))
+                        cur += 1
+                cur += v.nRemoved
+                bits.append(v.added)
+        if cur < self.endPos:
+            bits.append(ref.getSequence(name, cur, self.endPos))
+        return b"".join(bits)
+
+    def __eq__(self, o):
+        return (self.refName, self.startPos, self.endPos, self.haplotypeSequence) == (o.refName, o.startPos, o.endPos, o.haplotypeSequence)
+
+    def __hash__(self):
+        return hash((self.refName, self.startPos, self.endPos, self.haplotypeSequence))
+
+    def alignReads(self, individualIndex, readBuffer, useMapQualCap=False):
+        """-> numpy array of totalReads+1 natural-log likelihoods terminated by 999 (likelihoodCache, :306-377)."""
+        if individualIndex != self.lastIndividualIndex or self.likelihoodCache is None:
+            eng = get_engine()
+            hb = _pack_window([self.haplotypeSequence], self.startPos, self.endPos, self.endBufferSize, [readBuffer])
+            db = eng.upload(hb)
+            eng.align(db, want_stats=False, calc_flank_score=int(self.options.calculateFlankScore),
+                      use_mapq_cap=int(bool(useMapQualCap)))
+            eng.synchronize()
+            ll = db.loglik.cpu().numpy()[:hb.n_pairs]
+            self.likelihoodCache = np.concatenate([ll, [999.0]])
+            self.lastIndividualIndex = individualIndex
+        return self.likelihoodCache
+
+    def alignSingleRead(self, theRead, useMapQualCap=False):                     # :379-384 (never skipped: no overlap test)
+        buf = bamReadBuffer(brokenMates=[theRead])
+        buf.brokenMates.windowStart, buf.brokenMates.windowEnd = 0, 1
+        eng = get_engine()
+        hb = _pack_window([self.haplotypeSequence], self.startPos, self.endPos, self.endBufferSize, [buf])
+        db = eng.upload(hb)
+        eng.align(db, want_stats=False, calc_flank_score=int(self.options.calculateFlankScore),
+                  use_mapq_cap=int(bool(useMapQualCap)))
+        eng.synchronize()
+        return float(db.loglik.cpu().numpy()[0])
+
+
+class DiploidGenotype:
+    """cgenotype.pyx:131-189."""
+
+    def __init__(self, hap1, hap2):
+        self.hap1, self.hap2 = hap1, hap2
+        self.hap1Like = self.hap2Like = 0.0
+
+    def calculateDataLikelihood(self, readBuffer, individualIndex, nIndividuals, gof=None, useMapQualCap=False):
+        eng = get_engine()
+        haps = [self.hap1.haplotypeSequence] if self.hap1 is self.hap2 else [self.hap1.haplotypeSequence, self.hap2.haplotypeSequence]
+        hb = _pack_window(haps, self.hap1.startPos, self.hap1.endPos, self.hap1.endBufferSize, [readBuffer])
+        db = eng.upload(hb)
+        eng.call_windows(db, want_stats=False)
+        eng.synchronize()
+        logl = db.logl.cpu().numpy()
+        g = 0 if self.hap1 is self.hap2 else 1                                   # genotypes of [h1,h2]: (0,0),(0,1),(1,1)
+        if gof is not None:
+            gof[individualIndex] = float(db.gof.cpu().numpy()[g])
+        return float(logl[g])
+
+
+def generateAllGenotypesFromHaplotypeList(haplotypes):                           # cgenotype.pyx:193-218
+    return [DiploidGenotype(haplotypes[i], haplotypes[j]) for i in range(len(haplotypes)) for j in range(i, len(haplotypes))]
+
+
+class Population:
+    """cpopulation.pyx:197-309: the likelihood-array interface consumed by EM / VCF output."""
+
+    def __init__(self, options=None):
+        self.options = options if options is not None else default_options()
+
+    def setup(self, variants, haplotypes, genotypes, nInd, verbosity, readBuffers):
+        if nInd != len(readBuffers):
+            raise Exception("Error in cPopulation.setup")                        # :215-219
+        self.variants, self.haplotypes, self.genotypes, self.readBuffers = variants, haplotypes, genotypes, readBuffers
+        self.nGenotypes, self.nVariants, self.nHaplotypes, self.nIndividuals = len(genotypes), len(variants), len(haplotypes), nInd
+        index = {id(h): i for i, h in enumerate(haplotypes)}
+        self.haplotypeIndexes = np.array([[index[id(g.hap1)], index[id(g.hap2)]] for g in genotypes], dtype=np.int32)
+        H = len(haplotypes)
+        expected = [(i, j) for i in range(H) for j in range(i, H)]
+        if [tuple(x) for x in self.haplotypeIndexes.tolist()] != expected:
+            raise ValueError("genotypes must be generateAllGenotypesFromHaplotypeList(haplotypes)")
+        h0 = haplotypes[0]
+        eng = get_engine()
+        hb = _pack_window([h.haplotypeSequence for h in haplotypes], h0.startPos, h0.endPos, h0.endBufferSize, readBuffers)
+        db = eng.upload(hb)
+        eng.call_windows(db, want_stats=False)
+        eng.synchronize()
+        G = self.nGenotypes
+        self.nReads = np.array(hb.seg_n_good, dtype=np.int32)                                        # :286-287
+        self.genotypeLikelihoods = db.gl.cpu().numpy()[:nInd * G].reshape(nInd, G).copy()            # [ind][genotype]
+        self.genotypeLogLikelihoods = db.logl.cpu().numpy()[:nInd * G].reshape(nInd, G).copy()
+        self.goodnessOfFitValues = db.gof.cpu().numpy()[:nInd * G].reshape(G, nInd).copy()           # [genotype][ind]
+        self.haplotypeLikelihoods = db.loglik.cpu().numpy()[:hb.n_pairs].reshape(H, -1).copy()
+        return self
+
+
+def assembleReadsAndDetectVariants(chrom, assemStart, assemEnd, refStart, refEnd, readBuffers, refSeq, options=None):
+    """assembler.pyx:1429-1476; read selection as loadBAMDataIntoGraph (:1391-1425)."""
+    options = options if options is not None else default_options()
+    seqs, quals = [], []
+    for buf in readBuffers:
+        sel = list(buf.reads.window())
+        if options.assembleBadReads:
+            sel += list(buf.badReads.window())
+        if options.assembleBrokenPairs:
+            sel += list(buf.brokenMates.window())
+        for r in sel:
+            if not r.isQCFail():
+                seqs.append(r.seq); quals.append(r.qual)
+    region = dict(ref=bytes(refSeq), ref_start=refStart, assem_start=assemStart, assem_end=assemEnd, seqs=seqs, quals=quals)
+    out = get_engine().assemble([region], kmer_size=options.assemblerKmerSize, min_qual=options.minBaseQual,
+                                min_weight=options.minReads * options.minBaseQual, no_cycles=options.noCycles)[0]
+    return sorted(Variant(chrom, p, r, a, 0, ASSEMBLER_VAR) for p, r, a in out)

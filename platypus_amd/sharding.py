@@ -1,0 +1,85 @@
+"""Multi-GPU sharding of the hot path.
+
+The reference parallelises by giving every worker process a share of the sorted region list,
+`regionsForEachProcess[index % nCPU]` (runner.py:473-474), and merging the per-worker temporary VCFs with a
+k-way heap merge keyed by (chromosome, position) (runner.py:301-352, key: runner.py:47-50,77-82).  Here one
+process drives one GPU; regions / windows are assigned the same way (index % world), there is NO data-path
+collective, and the only exchange is ONE variable-length gather of the per-region record bytes to rank 0
+(RCCL over xGMI on GPUs via backend "nccl"; gloo on CPU for the tests) followed by the same ordered merge.
+"""
+import heapq
+
+import numpy as np
+
+
+def regions_for_rank(n_regions, rank, world):
+    """Indices of the regions owned by `rank` (runner.py:473-474: round-robin over the sorted region list)."""
+    return list(range(rank, n_regions, world))
+
+
+def chrom_key(chrom):
+    """Sort key of a chromosome name as in runner.py:47-50: integer if it looks like one, else the string."""
+    try:
+        return (0, int(chrom.upper().strip("CHR")), "")
+    except ValueError:
+        return (1, 0, chrom)
+
+
+def gather_records(payload: bytes, dist=None, device=None):
+    """Gather one byte string per rank to rank 0.  Returns list[bytes] on rank 0, None elsewhere.
+
+    Sizes travel in one all_gather(int64); payloads in one padded all_gather(uint8) -- a few KB..MB per rank,
+    so link bandwidth is irrelevant ('Distributed communication backend')."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [payload]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else torch.device("cpu")
+    n = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(max(sizes), 1)
+    buf = torch.zeros(m, dtype=torch.uint8, device=dev)
+    if payload:
+        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
+    out = [torch.zeros(m, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(out, buf)
+    if rank != 0:
+        return None
+    return [bytes(out[r][:sizes[r]].cpu().numpy().tobytes()) for r in range(world)]
+
+
+def merge_record_streams(streams):
+    """k-way merge of per-rank record lists, each already sorted by (chrom key, pos): runner.py:301-352.
+    A record is a tuple (chrom, pos, line)."""
+    keyed = [[(chrom_key(c), p, i, line) for i, (c, p, line) in enumerate(s)] for s in streams]
+    return [line for _, _, _, line in heapq.merge(*keyed)]
+
+
+def format_window_records(hb, logl, windows=None, chrom="1"):
+    """Deterministic per-window text records (chrom, window start, H, genotype log-likelihoods rounded to 2 dp as the
+    VCF GL field is, vcfutils.pyx) used as the gather payload until the VCF writer ('next' row f3) exists."""
+    out = []
+    ws = range(hb.n_windows) if windows is None else windows
+    for w in ws:
+        H = int(hb.win_hap_begin[w + 1] - hb.win_hap_begin[w])
+        G = H * (H + 1) // 2
+        o = int(hb.gl_off[w])
+        gls = ",".join("%.2f" % v for v in logl[o:o + G * hb.n_ind])
+        out.append((chrom, int(hb.win_start[w]), "%s\t%d\t%d\t%s" % (chrom, int(hb.win_start[w]), H, gls)))
+    return out
+
+
+def encode_records(records):
+    return "\n".join("%s\x1f%d\x1f%s" % r for r in records).encode()
+
+
+def decode_records(payload):
+    if not payload:
+        return []
+    out = []
+    for ln in payload.decode().split("\n"):
+        c, p, line = ln.split("\x1f")
+        out.append((c, int(p), line))
+    return out

@@ -1,0 +1,113 @@
+"""GPU tests of the drop-in interface: Haplotype.alignReads / alignSingleRead, DiploidGenotype, Population.setup and
+assembleReadsAndDetectVariants through the reference-named classes, checked against the oracle."""
+import numpy as np
+import pytest
+
+from platypus_amd import hostapi as H
+
+pytestmark = pytest.mark.gpu
+
+
+def make_window(seed=5, n_ind=2):
+    rng = np.random.default_rng(seed)
+    B = b"ACGT"
+    ref = bytes(rng.choice(list(B), 3000).tolist())
+    fasta = H.FastaFile({"20": ref})
+    ws, we, L = 1500, 1560, 100
+    snp = H.Variant("20", 1520, ref[1520:1521], b"A" if ref[1520:1521] != b"A" else b"C")
+    dele = H.Variant("20", 1535, ref[1536:1539], b"")
+    haps = [H.Haplotype("20", ws, we, v, fasta, L) for v in ((), (snp,), (dele,), (snp, dele))]
+    donors = [h.haplotypeSequence for h in haps]
+    buffers = []
+    for i in range(n_ind):
+        good, bad = [], []
+        for _ in range(40):
+            d = donors[int(rng.integers(0, 4))]
+            off = int(rng.integers(120, 280))
+            seq = bytearray(d[off:off + L])
+            if rng.random() < 0.2:
+                seq[int(rng.integers(0, L))] = B[int(rng.integers(0, 4))]
+            q = bytes(np.clip(rng.normal(33, 6, L), 2, 41).astype(np.uint8).tolist())
+            pos = ws - haps[0].endBufferSize + off
+            r = H.AlignedRead(bytes(seq), q, pos, mapq=int(rng.choice([60, 60, 29, 0])))
+            if rng.random() < 0.15:
+                r.bitFlag |= 512 if rng.random() < 0.5 else 0
+                bad.append(r)
+            else:
+                good.append(r)
+        buffers.append(H.bamReadBuffer(good, bad))
+        buffers[-1].setWindowPointers(ws, we)
+    return fasta, haps, buffers, ws, we
+
+
+def oracle_rows(oracle, haps, buf, ws, we):
+    rs = buf.windowReads()
+    reads = dict(seq=[r.seq for r, _ in rs], qual=[r.qual for r, _ in rs], pos=[r.pos for r, _ in rs],
+                 end=[r.end for r, _ in rs], mapq=[r.mapq for r, _ in rs], flags=[r.bitFlag for r, _ in rs],
+                 kind=[k for _, k in rs])
+    return oracle.align_window([h.haplotypeSequence for h in haps], ws, we, haps[0].endBufferSize, reads)[0]
+
+
+def test_alignReads_cache_layout_and_values(oracle):
+    fasta, haps, buffers, ws, we = make_window()
+    exp = oracle_rows(oracle, haps, buffers[0], ws, we)
+    for hi, h in enumerate(haps):
+        arr = h.alignReads(0, buffers[0])
+        assert arr[-1] == 999 and len(arr) == exp.shape[1] + 1          # chaplotype.pyx:375
+        assert np.array_equal(arr[:-1], exp[hi])
+        assert h.alignReads(0, buffers[0]) is arr                       # cached while individualIndex is unchanged (:320,339)
+    r = buffers[0].reads.window()[3]
+    one = haps[1].alignSingleRead(r)
+    k = [x for x, _ in buffers[0].windowReads()].index(r)
+    assert one == exp[1][k]
+
+
+def test_population_setup_matches_oracle(oracle):
+    fasta, haps, buffers, ws, we = make_window(n_ind=3)
+    genotypes = H.generateAllGenotypesFromHaplotypeList(haps)
+    pop = H.Population().setup([], haps, genotypes, 3, 0, buffers)
+    assert pop.haplotypeIndexes.tolist()[:5] == [[0, 0], [0, 1], [0, 2], [0, 3], [1, 1]]
+    for i, buf in enumerate(buffers):
+        rows = oracle_rows(oracle, haps, buf, ws, we)
+        logl, gl, gof = oracle.population_setup_ind(rows, buf.reads.windowEnd - buf.reads.windowStart)
+        assert np.allclose(pop.genotypeLogLikelihoods[i], logl, rtol=1e-12, atol=0)      # device libm only in one rare branch
+        assert np.allclose(pop.genotypeLikelihoods[i], gl, rtol=1e-10, atol=1e-300)
+        assert np.allclose(pop.goodnessOfFitValues[:, i], gof, rtol=1e-13, atol=0)
+        assert pop.nReads[i] == buf.reads.windowEnd - buf.reads.windowStart
+    g = genotypes[1]
+    gofv = np.zeros(3)
+    L = g.calculateDataLikelihood(buffers[1], 1, 3, gofv)
+    assert np.isclose(L, pop.genotypeLogLikelihoods[1][1], rtol=1e-12, atol=0) and gofv[1] != 0
+
+
+def test_unsupported_modes_raise():
+    fasta, haps, buffers, ws, we = make_window()
+    from platypus_amd._lib import PlatypusDeviceError
+    haps[0].options.calculateFlankScore = 1
+    with pytest.raises(PlatypusDeviceError):
+        haps[0].alignReads(5, buffers[0])
+    haps[0].options.calculateFlankScore = 0
+    with pytest.raises(PlatypusDeviceError):
+        haps[0].alignSingleRead(buffers[0].reads.window()[0], useMapQualCap=True)
+
+
+def test_assembleReadsAndDetectVariants(oracle):
+    rng = np.random.default_rng(12)
+    B = b"ACGT"
+    ref = bytes(rng.choice(list(B), 3000).tolist())
+    donor = bytearray(ref); donor[1500:1500] = b"GATTACAGATT"; del donor[1800:1806]; donor[1200] = ord("A") if donor[1200] != ord("A") else ord("C")
+    donor = bytes(donor)
+    good, bad = [], []
+    for _ in range(360):
+        p = int(rng.integers(0, len(donor) - 250))
+        r = H.AlignedRead(donor[p:p + 250], bytes([35] * 250), 1000 + p)
+        (bad if rng.random() < 0.1 else good).append(r)
+    bad[0].bitFlag |= 512
+    buf = H.bamReadBuffer(good, bad)
+    buf.setWindowPointers(1000 + 700, 1000 + 2200)
+    out = H.assembleReadsAndDetectVariants("20", 1000 + 750, 1000 + 2250, 1000, 4000, [buf], ref)
+    seqs = [r.seq for r in buf.reads.window()] + [r.seq for r in buf.badReads.window() if not r.isQCFail()]
+    quals = [r.qual for r in buf.reads.window()] + [r.qual for r in buf.badReads.window() if not r.isQCFail()]
+    exp, _ = oracle.assemble(ref, 1000, 1750, 3250, seqs, quals)
+    assert [(v.refPos, v.removed, v.added) for v in out] == exp
+    assert len(out) >= 3 and all(v.varSource == H.ASSEMBLER_VAR for v in out)

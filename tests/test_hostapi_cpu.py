@@ -1,0 +1,69 @@
+"""CPU tests of the host-side mirror of the reference interface (no device calls): haplotype byte-string
+construction (chaplotype.pyx:127-191,397-449), Variant ordering (variant.pyx:282-363), window
+pointers (cwindow.pyx:208-236) and the callVariants option surface (runner.py:519-597)."""
+import numpy as np
+import pytest
+
+from platypus_amd import hostapi as H
+from platypus_amd.options import CALL_VARIANTS_OPTIONS, build_parser, default_options
+
+
+@pytest.fixture()
+def fasta():
+    rng = np.random.default_rng(3)
+    return H.FastaFile({"20": bytes(rng.choice(list(b"ACGT"), 5000).tolist())})
+
+
+def test_reference_haplotype_bytes(fasta):
+    h = H.Haplotype("20", 1000, 1100, (), fasta, 150)
+    assert h.endBufferSize == 300 and h.hapLen == 100 + 600
+    assert h.haplotypeSequence == fasta.getSequence("20", 700, 1400)
+
+
+def test_snp_insertion_deletion_haplotypes(fasta):
+    ref = fasta._seq["20"]
+    snp = H.Variant("20", 1010, ref[1010:1011], b"A" if ref[1010:1011] != b"A" else b"C")
+    ins = H.Variant("20", 1020, b"", b"GATTACA")            # refPos = last base before the insertion
+    dele = H.Variant("20", 1030, ref[1031:1035], b"")       # refPos = base before the deleted bases
+    h = H.Haplotype("20", 1000, 1100, (snp, ins, dele), fasta, 100)
+    buf = 200
+    expect = (ref[1000 - buf:1010] + snp.added + ref[1011:1021] + b"GATTACA" + ref[1021:1031] + ref[1035:1100 + buf])
+    assert h.haplotypeSequence == expect
+    assert h.hapLen == 100 + 2 * buf + 7 - 4
+    # buffers are clamped at the contig start (fastafile.pyx:188-189) but hapStart is not (chaplotype.pyx:606)
+    h0 = H.Haplotype("20", 50, 120, (), fasta, 100)
+    assert h0.haplotypeSequence == ref[0:320] and h0.startPos - h0.endBufferSize == -150
+
+
+def test_haplotype_too_long_raises(fasta):
+    big = H.FastaFile({"1": b"A" * 40000})
+    with pytest.raises(Exception, match="too long"):
+        H.Haplotype("1", 1000, 1000 + 16000, (), big, 150)
+
+
+def test_variant_ordering_and_types():
+    a = H.Variant("1", 10, b"A", b"C"); b = H.Variant("1", 10, b"", b"GG"); c = H.Variant("1", 10, b"ACG", b"")
+    d = H.Variant("1", 9, b"AC", b"GT"); e = H.Variant("1", 10, b"AT", b"G")
+    assert (a.varType, b.varType, c.varType, d.varType, e.varType) == (H.SNP, H.INS, H.DEL, H.MNP, H.REP)
+    assert sorted([e, c, b, a, d]) == [d, a, b, c, e]
+    assert H.Variant("1", -5, b"A", b"C").refPos == 0 and c.maxRefPos == 12
+
+
+def test_window_pointers_follow_cwindow_rules():
+    reads = [H.AlignedRead(b"A" * 100, b"\x1e" * 100, pos) for pos in (100, 150, 195, 210, 260, 305, 330)]
+    ra = H.ReadArray(reads)
+    ra.setWindowPointers(300, 320)
+    # first index: pos >= max(1, start - longestRead) = 200, advanced past reads with end <= start (pos 200..)
+    assert [r.pos for r in ra.window()] == [210, 260, 305]
+    ra.setWindowPointers(0, 50)
+    assert ra.window() == []
+
+
+def test_option_surface_matches_reference():
+    assert len(CALL_VARIANTS_OPTIONS) == 69
+    o = default_options()
+    assert (o.rlen, o.bufferSize, o.maxVariants, o.maxHaplotypes, o.minBaseQual, o.minMapQual, o.minReads) == (150, 100000, 8, 50, 20, 20, 2)
+    assert (o.assemble, o.assembleAll, o.assemblyRegionSize, o.assemblerKmerSize, o.assembleBadReads, o.assembleBrokenPairs, o.noCycles) == (0, 1, 1500, 15, 1, 0, 0)
+    assert (o.calculateFlankScore, o.HLATyping, o.nCPU, o.coverageSamplingLevel) == (0, 0, 1, 30)
+    p = build_parser().parse_args(["--bamFiles=a.bam,b.bam", "--refFile=r.fa", "--maxReadLength=250", "-o", "x.vcf"])
+    assert p.bamFiles == ["a.bam", "b.bam"] and p.rlen == 250 and p.output == "x.vcf"
