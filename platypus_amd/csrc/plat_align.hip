@@ -106,7 +106,7 @@ k_tile_scan(plat_window_batch b, const int32_t* __restrict__ win_rows, long long
     const int per = (b.n_windows + nt - 1) / nt;
     const int w0 = min(b.n_windows, t * per), w1 = min(b.n_windows, w0 + per);
     long long s = 0;
-    for (int w = w0; w < w1; ++w) s += (long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]);
+    for (int w = w0; w < w1; ++w) s += ((long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]) + 3) & ~3ll;
     part[t] = s;
     __syncthreads();
     for (int d = 1; d < nt; d <<= 1) {
@@ -118,7 +118,7 @@ k_tile_scan(plat_window_batch b, const int32_t* __restrict__ win_rows, long long
     long long run = part[t] - s;
     for (int w = w0; w < w1; ++w) {
         tile_off[w] = run;
-        run += (long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]);
+        run += ((long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]) + 3) & ~3ll;
     }
     if (t == nt - 1) cnt[CNT_TILE_TOTAL] = part[t];
 }
@@ -133,6 +133,11 @@ __device__ __forceinline__ unsigned base2(unsigned ch) {      // calign.pyx:69-7
 __global__ void __launch_bounds__(256)
 k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const long long* __restrict__ tile_off,
              uint32_t* __restrict__ tile, uint16_t* __restrict__ codes, ReadInfo* __restrict__ rinfo, long long* cnt)
+// `codes` holds, per window and in the tile's footprint (2 bytes per tile element), the reads' bases PACKED 2 bits each
+// (calign.pyx:69-74 coding: A=1 C=3 G=2 T=0, N=2), 32 bases per 64-bit word, transposed: word j of read rl at
+// ((u64*)(codes + tile_off[w]))[j*R + rl].  A 7-mer code (a5, hashReadForMapping calign.pyx:155-165) is 14 consecutive
+// bits of that stream; only equality of codes matters to the vote, so the little-endian order is as good as the
+// reference's big-endian one.
 {
     const int w = blockIdx.x;
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
@@ -161,14 +166,19 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
         const long long ro = b.read_off[rb + rl];
         const int L = (int)(b.read_off[rb + rl + 1] - ro);
         tile[toff + e] = i < L ? read_word(b.read_seq[ro + i], b.read_qual[ro + i]) : READ_PAD_WORD;
-        // rolling 7-mer codes (a5, calign.pyx:155-165), same transposed shape as the tile: codes[toff + i*R + rl], i < L-7
-        unsigned code = 0xFFFFu;
-        if (i < L - 7) {
-            code = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) code = (code << 2) + base2(b.read_seq[ro + i + k]);
+    }
+    unsigned long long* rd2 = (unsigned long long*)(codes + toff);
+    const int nwords = (rows - 8 + 31) >> 5;
+    for (int e = threadIdx.x; e < nwords * R; e += blockDim.x) {
+        const int j = e / R, rl = e - j * R;
+        const long long ro = b.read_off[rb + rl];
+        const int L = (int)(b.read_off[rb + rl + 1] - ro);
+        unsigned long long wd = 0;
+        for (int q = 0; q < 32; ++q) {
+            const int i = 32 * j + q;
+            if (i < L) wd |= (unsigned long long)base2(b.read_seq[ro + i]) << (2 * q);
         }
-        codes[toff + e] = (uint16_t)code;
+        rd2[e] = wd;
     }
 }
 
@@ -187,33 +197,52 @@ __device__ __forceinline__ unsigned kmer_head(const unsigned* table, unsigned co
 }
 
 // k_seed: one workgroup per haplotype; ONE LANE PER (read, haplotype) PAIR.
-// LDS carve (dynamic):  table u32[tsize] | next u16[maxhap+2] | hapb u8[maxhap+16] | counts u16[nw][cw] | has_n
+// LDS carve (dynamic):  table u32[tsize] | next u16[maxhap+2] | hapb u8[maxhap+16] | hap2 u64[nw64] | nu2 u64[nw64] |
+//                       counts u16[nwaves][cw] | scalars
 // The k-mer index has two modes: haplotypes up to 4096 bp use a small open-addressing table (load factor <= 0.8);
 // longer ones (up to the reference's cap of 16384) index all 4^7 codes directly, as the reference does
 // (calign.pyx:98-99).
 //
-// Every lane walks the 7-mer codes of its own read (transposed code tile => one coalesced 128-byte load per
-// k-mer position per wave) through the haplotype index and tries to PROVE that one diagonal d* is the unique
-// arg-max of the reference's diagonal vote (calign.pyx:206-233) without counting votes:
-//   C = #k-mers with an occurrence on d*,  X = #occurrences of the read's k-mers off d*.
-//   Any other diagonal collects at most X votes, hence X < C  =>  d* is the only candidate.
-// Pairs that cannot be decided this way (tandem repeats, ties) fall back to the exact vote: the whole wave counts
-// that pair's diagonals in 16-bit LDS counters (two per dword, 32-bit LDS atomics; bit 15 = claim flag used to
-// pick one representative lane per arg-max diagonal) and emits the candidates in ascending order.
+// Every lane tries to PROVE that one diagonal d* is the unique arg-max of the reference's diagonal vote
+// (calign.pyx:206-233) without counting votes, bit-parallel on 2-bit packed bases:
+//   the read (<= 256 bp: 8 x 64-bit words in registers) is XORed with the haplotype's packed bases shifted to the
+//   hypothesis diagonal; a shift-AND ladder marks every read position where 7 consecutive bases match = a k-mer that
+//   votes for d*;  C = popcount of those marks.  Votes for any OTHER diagonal are at most
+//       X = (#matching k-mers whose haplotype k-mer is not unique) * (maxmult-1) + (#non-matching k-mers) * maxmult
+//   (nu2 = per-position "k-mer occurs more than once in this haplotype" bits, maxmult = largest multiplicity),
+//   so X < C  =>  d* is the only candidate of calign.pyx:222-233.
+// Hypothesis A = the read's mapping offset (calign.pyx:252); B = the diagonal of the read's first haplotype-unique k-mer.
+// Pairs that cannot be decided (tandem repeats, ties, reads longer than 256 bp) fall back to the exact vote: the whole
+// wave counts that pair's diagonals in 16-bit LDS counters (two per dword, 32-bit LDS atomics; bit 15 = claim flag
+// that picks one representative lane per arg-max diagonal) and emits the candidates in ascending order.
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 funnel(u64 lo, u64 hi, int sh) { return sh ? (lo >> sh) | (hi << (64 - sh)) : lo; }
+
+// k-mer code (14 bits, little-endian base order) of read position i from the packed transposed words of one read
+__device__ __forceinline__ unsigned read_code(const u64* __restrict__ rd2col, int R, int i) {
+    const int j = i >> 5, sh = 2 * (i & 31);
+    const u64 lo = rd2col[(long long)j * R];
+    const u64 hi = sh > 50 ? rd2col[(long long)(j + 1) * R] : 0ull;      // 14 bits cross the word only when sh > 50
+    return (unsigned)(funnel(lo, hi, sh) & 0x3FFFull);
+}
+
 __global__ void __launch_bounds__(256)
-k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo* __restrict__ rinfo,
+k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* __restrict__ win_rows,
+       const long long* __restrict__ tile_off, const ReadInfo* __restrict__ rinfo,
        const uint16_t* __restrict__ codes, uint32_t* __restrict__ hapw, uint8_t* __restrict__ hap_has_n,
        PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
        int tsize_max, int maxhap, int cw, int want_stats)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nw64 = ((maxhap + 63) >> 5) + 10;          // packed words incl. slack for the 9-word window of a hypothesis
     unsigned* table = (unsigned*)smem;
     unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);
     unsigned char* hapb = smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 3 & ~(size_t)3);
-    unsigned char* mult8 = hapb;           // multiplicity of the k-mer at every position (capped 255); re-uses hapb after the index is built
-    unsigned short* hapcode = (unsigned short*)(hapb + (((size_t)maxhap + 16) + 3 & ~(size_t)3));   // 7-mer code at every haplotype position
-    unsigned* counts_all = (unsigned*)(hapcode + (((size_t)maxhap + 2) + 1 & ~(size_t)1));
-    int* s_has_n = (int*)(counts_all + (size_t)(blockDim.x >> 6) * (cw >> 1));
+    u64* hap2 = (u64*)(hapb + (((size_t)maxhap + 16) + 7 & ~(size_t)7));
+    u64* nu2 = hap2 + nw64;
+    unsigned* counts_all = (unsigned*)(nu2 + nw64);
+    int* s_scal = (int*)(counts_all + (size_t)(blockDim.x >> 6) * (cw >> 1));     // [0] has_n  [1] maxmult
 
     const int h = blockIdx.x;
     const int w = hap_win[h];
@@ -229,12 +258,11 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
     else while (tsize < hapLen + hapLen / 4) tsize <<= 1;
     const unsigned tmask = (unsigned)tsize - 1u;
 
-    long long tq0 = want_stats ? (long long)__builtin_readcyclecounter() : 0;
-    if (tid == 0) *s_has_n = 0;
+    if (tid < 2) s_scal[tid] = tid;                      // has_n = 0, maxmult = 1
     for (int i = tid; i < (direct ? tsize / 2 : tsize); i += nthr) table[i] = 0u;
+    for (int i = tid; i < 2 * nw64; i += nthr) hap2[i] = 0ull;          // hap2 and nu2 are contiguous
     for (int i = tid; i < hapLen; i += nthr) hapb[i] = b.hap_seq[hoff + i];
     __syncthreads();
-    long long tq1 = want_stats ? (long long)__builtin_readcyclecounter() : 0;
 
     // a7: gap-open annotation (chaplotype.pyx:552-590): table[min(48, #following bytes equal to this one)], 'N' -> table[0]
     // written together with the base as the DP's haplotype word
@@ -248,15 +276,23 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
             } else anyn = 1;
             hapw[hoff + p] = hap_word(c, (unsigned)c_homopol_go[run]);
         }
-        if (anyn) *s_has_n = 1;
+        if (anyn) s_scal[0] = 1;
+    }
+    // packed bases of the haplotype
+    for (int j = tid; j < (hapLen + 31) >> 5; j += nthr) {
+        u64 wd = 0;
+        for (int q = 0; q < 32; ++q) {
+            const int pp = 32 * j + q;
+            if (pp < hapLen) wd |= (u64)base2(hapb[pp]) << (2 * q);
+        }
+        hap2[j] = wd;
     }
     // a4: k-mer index (positions 0..hapLen-8; calign.pyx:109): entry = (code+1)<<16 | (pos+1);
     // equal codes are chained through nxt[] (the chain order is irrelevant to the vote)
     for (int p = tid; p < hapLen - 7; p += nthr) {
         unsigned code = 0;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) code = (code << 2) + base2(hapb[p + k]);
-        hapcode[p] = (unsigned short)code;
+        for (int k = 0; k < 7; ++k) code |= base2(hapb[p + k]) << (2 * k);
         if (direct) {                                   // u16 heads, two per dword: exchange one half with a CAS loop
             const unsigned sh = 16u * (code & 1u);
             unsigned cur = table[code >> 1], seen;
@@ -287,21 +323,33 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
         }
     }
     __syncthreads();
-    // multiplicity of every haplotype k-mer (length of its chain)
+    // multiplicity of every haplotype k-mer: only the chain HEAD walks its chain; members of chains longer than one
+    // are flagged in nu2, the longest chain gives maxmult
     for (int p = tid; p < hapLen - 7; p += nthr) {
-        int c = 0;
-        for (unsigned hh = kmer_head(table, hapcode[p], direct, tmask); hh != 0u; hh = nxt[hh]) ++c;
-        mult8[p] = (unsigned char)min(c, 255);
+        unsigned code = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) code |= base2(hapb[p + k]) << (2 * k);
+        const unsigned hd = kmer_head(table, code, direct, tmask);
+        if (hd == (unsigned)(p + 1) && nxt[hd] != 0u) {
+            int c = 0;
+            for (unsigned hh = hd; hh != 0u; hh = nxt[hh]) {
+                ++c;
+                const int q = (int)hh - 1;
+                atomicOr((unsigned*)nu2 + 2 * (q >> 5) + ((q & 31) >> 4), 1u << (2 * (q & 15)));
+            }
+            atomicMax(&s_scal[1], c);
+        }
     }
     __syncthreads();
-    long long tq2 = want_stats ? (long long)__builtin_readcyclecounter() : 0;
-    long long tq_loop = 0, tq_fall = 0;
-    if (tid == 0) hap_has_n[h] = (uint8_t)*s_has_n;
+    if (tid == 0) hap_has_n[h] = (uint8_t)s_scal[0];
+    const int maxmult = s_scal[1];
 
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
     const int hl = h - b.win_hap_begin[w];
     const int hapStart = b.win_start[w] - b.win_flank[w];                   // chaplotype.pyx:606
     const long long pbase = b.pair_off[w] + (long long)hl * R;
+    const u64* rd2 = (const u64*)(codes + tile_off[w]);
+    const int nkp = hapLen - 7;                          // haplotype k-mer positions 0..hapLen-8 (calign.pyx:109)
     bool counts_clean = false;
 
     for (int c0 = wave * 64; c0 < R; c0 += nw * 64) {
@@ -319,67 +367,76 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
         const bool live = valid && !skipped && !tooshort && !hapshort;
         const int nk = live ? L - 7 : 0;
         const int idx0 = min(ri.pos - hapStart, hapLen - L - 15);           // calign.pyx:252
-        // ---- per-lane proof of a unique arg-max diagonal.  For a hypothesis d*:
-        //   C = #k-mers i of the read whose code equals the haplotype's code at i + d*      (votes for d*)
-        //   X = #occurrences of the read's k-mers anywhere else in the haplotype            (votes for all others)
-        // Any other diagonal collects at most X votes, hence X < C  =>  d* is the only candidate (calign.pyx:222-233).
-        // Hypothesis A = the read's mapping offset (calign.pyx:252); if that fails, hypothesis B = the diagonal of
-        // the first k-mer of the read that is unique in the haplotype.
-        const int nkp = hapLen - 7;                      // haplotype k-mer positions 0..hapLen-8 (calign.pyx:109)
-        const uint16_t* cp = codes + ri.col;
-        long long tq3 = want_stats ? (long long)__builtin_readcyclecounter() : 0;
-        int dstar = idx0, C = 0, X = 0;
-        bool haveB = false, proven = false, sat = false;
+        const u64* col = rd2 + (valid ? rl : 0);
+
+        // ---- bit-parallel proof
+        const bool canfast = live && L <= 256;
+        int nWl = canfast ? (L + 31) >> 5 : 0, nWmax = nWl;
+#pragma unroll
+        for (int s2 = 32; s2 > 0; s2 >>= 1) nWmax = max(nWmax, __shfl_xor(nWmax, s2));
+        u64 rw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rw[j] = j < nWl ? col[(long long)j * R] : 0ull;
+        int dstar = idx0;
+        bool proven = false, triedB = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
-            const bool run = live && !proven && (attempt == 0 || haveB);
-            if (!__any(run)) break;
-            if (run) { C = 0; X = 0; sat = false; }
-            const int lim = run ? nk : 0;
-            int limmax = lim;
+            const bool run = canfast && !proven && dstar >= 0 && (attempt == 0 || triedB);
+            if (!__any(run)) { if (attempt == 1) break; }
+            if (__any(run)) {
+                const int wq = run ? (dstar >> 5) : 0, sb = 2 * (dstar & 31);
+                const int nvalid = min(nk, nkp - dstar);                 // k-mers i < nvalid lie on haplotype positions
+                u64 Z[9], NUw[8];
 #pragma unroll
-            for (int s2 = 32; s2 > 0; s2 >>= 1) limmax = max(limmax, __shfl_xor(limmax, s2));
-            unsigned cn[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) cn[u] = u < lim ? cp[(unsigned)u * (unsigned)R] : 0u;
-            for (int i0 = 0; i0 < limmax; i0 += 8) {
-                unsigned cd[8], hc[8], mu[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) cd[u] = cn[u];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) cn[u] = (i0 + 8 + u) < lim ? cp[(unsigned)(i0 + 8 + u) * (unsigned)R] : 0u;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int pp = i0 + u + dstar;
-                    const bool inr = (i0 + u) < lim && pp >= 0 && pp < nkp;
-                    hc[u] = inr ? (unsigned)hapcode[pp] : 0xFFFFFFFFu;
-                    mu[u] = inr ? (unsigned)mult8[pp] : 0u;
+                for (int j = 0; j < 8; ++j) {
+                    if (j < nWmax) {
+                        const u64 x = funnel(hap2[wq + j], hap2[wq + j + 1], sb) ^ rw[j];
+                        Z[j] = ~(x | (x >> 1)) & 0x5555555555555555ull;
+                        NUw[j] = funnel(nu2[wq + j], nu2[wq + j + 1], sb);
+                    } else { Z[j] = 0ull; NUw[j] = 0ull; }
                 }
+                Z[8] = 0ull;
+                u64 P2[9];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if ((i0 + u) < lim) {
-                        if (hc[u] == cd[u]) { C += 1; X += (int)mu[u] - 1; sat |= mu[u] == 255u; }
-                        else {
-                            // k-mer does not vote for d*: count its occurrences elsewhere (rare: k-mers overlapping a mismatch)
-                            for (unsigned hh = kmer_head(table, cd[u], direct, tmask); hh != 0u; hh = nxt[hh]) ++X;
+                for (int j = 0; j < 8; ++j) P2[j] = Z[j] & ((Z[j] >> 2) | (Z[j + 1] << 62));
+                P2[8] = 0ull;
+                int C = 0, NUc = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j < nWmax) {
+                        const u64 P4 = P2[j] & ((P2[j] >> 4) | (P2[j + 1] << 60));
+                        u64 P7 = P4 & ((P2[j] >> 8) | (P2[j + 1] << 56)) & ((Z[j] >> 12) | (Z[j + 1] << 52));
+                        const int nb = nvalid - 32 * j;
+                        const u64 msk = nb >= 32 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << (2 * nb)) - 1ull));
+                        P7 &= msk;
+                        C += __popcll(P7);
+                        NUc += __popcll(P7 & NUw[j]);
+                    }
+                }
+                const int X = NUc * (maxmult - 1) + (nk - C) * maxmult;
+                if (run && maxmult < 255 && X < C) proven = true;
+            }
+            if (attempt == 0) {
+                // hypothesis B for the lanes A could not prove: diagonal of the first haplotype-unique k-mer
+                if (canfast && !proven) {
+                    for (int i = 0; i < nk; ++i) {
+                        const unsigned hd = kmer_head(table, read_code(col, R, i), direct, tmask);
+                        if (hd != 0u && nxt[hd] == 0u) {
+                            const int d = (int)hd - i - 1;
+                            if (d != idx0 && d >= 0) { dstar = d; triedB = true; }
+                            break;
                         }
                     }
                 }
             }
-            if (run && !sat && X < C) proven = true;
-            if (attempt == 0 && __any(live && !proven)) {
-                // hypothesis B: diagonal of the first read k-mer that occurs exactly once in the haplotype
-                if (live && !proven) {
-                    for (int i = 0; i < nk && !haveB; ++i) {
-                        const unsigned hd = kmer_head(table, cp[(unsigned)i * (unsigned)R], direct, tmask);
-                        if (hd != 0u && nxt[hd] == 0u) { haveB = true; dstar = (int)hd - i - 1; }
-                    }
-                    if (haveB && dstar == idx0) haveB = false;          // same hypothesis as A: already failed
-                }
-            }
         }
-        // a pair whose k-mers occur nowhere in the haplotype has maxcount == 0: no candidate, only the mapping offset
-        const bool novote = live && !proven && C == 0 && X == 0 && !sat;
-        if (want_stats) tq_loop += (long long)__builtin_readcyclecounter() - tq3;
+        // no k-mer of the read occurs in the haplotype <=> maxcount == 0 (calign.pyx:222): decided, no candidate.
+        // (cheap test only for pairs the proof left open)
+        bool novote = false;
+        if (live && !proven) {
+            novote = true;
+            for (int i = 0; i < nk && novote; ++i)
+                if (kmer_head(table, read_code(col, R, i), direct, tmask) != 0u) novote = false;
+        }
         const bool decided = !live || novote || proven;
         int ncand = 0, cidx = idx0;
         bool orig_in = false;
@@ -409,7 +466,6 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
         // ---- exact vote for the pairs that could not be decided: the whole wave works on one pair at a time
         unsigned long long todo = __ballot(valid && !decided);
         if (want_stats && todo && lane == 0) atomicAdd((unsigned long long*)&cnt[CNT_SLOW_SEED], (unsigned long long)__popcll(todo));
-        long long tq4 = want_stats ? (long long)__builtin_readcyclecounter() : 0;
         while (todo) {
             const int src = (int)__ffsll((long long)todo) - 1;
             todo &= todo - 1;
@@ -418,7 +474,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
             const int smapq = __shfl((int)mapq, src);
             const long long spidx = pbase + c0 + src;
             const int n = hapLen + sL, snk = sL - 7, j0i = sidx0 + sL;
-            const uint16_t* scp = codes + scol;
+            const u64* scp = rd2 + (c0 + src);
             if (!counts_clean) {
                 for (int j = lane; j < (cw >> 1); j += 64) counts[j] = 0u;
                 counts_clean = true;
@@ -426,7 +482,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
             // pass 1: diagonal vote, calign.pyx:209-220
             unsigned mymax = 0;
             for (int i = lane; i < snk; i += 64) {
-                unsigned hidx = kmer_head(table, scp[(long long)i * R], direct, tmask);
+                unsigned hidx = kmer_head(table, read_code(scp, R, i), direct, tmask);
                 while (hidx != 0u) {
                     const int j = (int)hidx - i - 1 + sL;
                     const unsigned sh = 16u * (unsigned)(j & 1);
@@ -442,7 +498,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
             // pass 2: one representative lane per arg-max diagonal (claim bit 15); count the valid ones
             int sncand = 0, myidx = 0x7FFFFFFF;
             for (int i = lane; i < snk; i += 64) {
-                unsigned hidx = kmer_head(table, scp[(long long)i * R], direct, tmask);
+                unsigned hidx = kmer_head(table, read_code(scp, R, i), direct, tmask);
                 while (hidx != 0u) {
                     const int j = (int)hidx - i - 1 + sL;
                     const unsigned sh = 16u * (unsigned)(j & 1);
@@ -493,22 +549,13 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const ReadInfo*
             }
             // pass 3: clear the counters this read touched
             for (int i = lane; i < snk; i += 64) {
-                unsigned hidx = kmer_head(table, scp[(long long)i * R], direct, tmask);
+                unsigned hidx = kmer_head(table, read_code(scp, R, i), direct, tmask);
                 while (hidx != 0u) {
                     counts[((int)hidx - i - 1 + sL) >> 1] = 0u;
                     hidx = nxt[hidx];
                 }
             }
         }
-        if (want_stats) tq_fall += (long long)__builtin_readcyclecounter() - tq4;
-    }
-    if (want_stats && tid == 0) {
-        const long long tq5 = (long long)__builtin_readcyclecounter();
-        atomicAdd((unsigned long long*)&cnt[CNT_T0], (unsigned long long)(tq1 - tq0));
-        atomicAdd((unsigned long long*)&cnt[CNT_T1], (unsigned long long)(tq2 - tq1));
-        atomicAdd((unsigned long long*)&cnt[CNT_T2], (unsigned long long)tq_loop);
-        atomicAdd((unsigned long long*)&cnt[CNT_T3], (unsigned long long)tq_fall);
-        atomicAdd((unsigned long long*)&cnt[CNT_T4], (unsigned long long)(tq5 - tq0));
     }
 }
 
@@ -702,14 +749,16 @@ PLAT_EXPORT int plat_dp_batch(plat_ctx* ctx, int n, int lmax, const uint8_t* hap
 }
 
 static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStream_t st, long long* cnt, int maxhap,
-                             int maxread, int maxR, long long npairs, int extra_cap, const int32_t* hap_win, int want_stats)
+                             int maxread, int maxR, long long npairs, int extra_cap, const int32_t* hap_win, const int32_t* win_rows,
+                             const long long* tile_off, int want_stats)
 {
     int tsize_max = 64;                                        // in dwords (direct mode: 16384 u16 heads = 8192 dwords)
     if (maxhap > 4096) tsize_max = 8192;
     else while (tsize_max < maxhap + maxhap / 4) tsize_max <<= 1;
     const int cw = (maxhap + maxread + 8 + 1) & ~1;            // 16-bit counters, even count
+    const size_t nw64 = (((size_t)maxhap + 63) >> 5) + 10;
     const size_t fixed = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 3) & ~(size_t)3) +
-                         ((((size_t)maxhap + 16) + 3) & ~(size_t)3) + (((size_t)maxhap + 3) & ~(size_t)1) * 2 + 16;
+                         ((((size_t)maxhap + 16) + 7) & ~(size_t)7) + 2 * nw64 * 8 + 16;
     const size_t lds_cap = 160 * 1024;
     int nw = maxR > 128 ? 4 : (maxR > 64 ? 2 : 1);             // one lane per read: waves per haplotype workgroup
     while (nw > 1 && fixed + (size_t)nw * cw * 2 > lds_cap) nw >>= 1;
@@ -717,7 +766,7 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     if (lds > lds_cap) return PLAT_ERR_HAP_TOO_LONG;
     if (lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_seed, dim3(b.n_haps), dim3(64 * nw), lds, st, b, hap_win, (const ReadInfo*)ctx->rinfo.ptr,
+    hipLaunchKernelGGL(k_seed, dim3(b.n_haps), dim3(64 * nw), lds, st, b, hap_win, win_rows, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (uint32_t*)ctx->hapw.ptr, (uint8_t*)ctx->hap_flags.ptr,
                        (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt, tsize_max, maxhap, cw, want_stats);
     PLAT_HIP(ctx, hipGetLastError());
@@ -790,7 +839,7 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = plat_reserve(ctx, ctx->jobs, (size_t)(npairs + extra_cap) * sizeof(Job)))) return rc;
         PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_NEXTRA], 0, sizeof(long long), st));
-        if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win, out_stats != NULL))) return rc;
+        if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win, win_rows, tile_off, out_stats != NULL))) return rc;
         PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
         PLAT_HIP(ctx, hipStreamSynchronize(st));
         if (hb[CNT_ERR] != 0) return (int)hb[CNT_ERR];
@@ -834,9 +883,6 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
         out_stats->cells_reference = hb[CNT_CELLS_REF];
         out_stats->cells_launched = hb[CNT_CELLS_RUN];
         out_stats->n_seed_fallback = hb[CNT_SLOW_SEED];
-        if (getenv("PLAT_SEED_TIMING"))
-            fprintf(stderr, "[seed timing, cycles summed over workgroups] stage %lld index %lld proof %lld fallback %lld total %lld\n",
-                    (long long)hb[CNT_T0], (long long)hb[CNT_T1], (long long)hb[CNT_T2], (long long)hb[CNT_T3], (long long)hb[CNT_T4]);
     }
     return PLAT_OK;
 }
