@@ -216,6 +216,7 @@ __device__ __forceinline__ unsigned kmer_head(const unsigned* table, unsigned co
 // wave counts that pair's diagonals in 16-bit LDS counters (two per dword, 32-bit LDS atomics; bit 15 = claim flag
 // that picks one representative lane per arg-max diagonal) and emits the candidates in ascending order.
 typedef unsigned long long u64;
+constexpr int SEED_CHUNKS = 4;
 
 __device__ __forceinline__ u64 funnel(u64 lo, u64 hi, int sh) { return sh ? (lo >> sh) | (hi << (64 - sh)) : lo; }
 
@@ -246,10 +247,15 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
 
     const int h = blockIdx.x;
     const int w = hap_win[h];
-    const long long hoff = b.hap_off[h];
-    const int hapLen = (int)(b.hap_off[h + 1] - hoff);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    {   // this workgroup's group of read chunks lies beyond the window's reads: nothing to do
+        const int Rw = b.win_read_begin[w + 1] - b.win_read_begin[w];
+        if (blockIdx.y > 0 && (int)blockIdx.y * SEED_CHUNKS * nw * 64 >= Rw) return;
+    }
+    const bool first_group = blockIdx.y == 0;            // writes the per-haplotype outputs (hapw, has_n)
+    const long long hoff = b.hap_off[h];
+    const int hapLen = (int)(b.hap_off[h + 1] - hoff);
     unsigned* counts = counts_all + (size_t)wave * (cw >> 1);
 
     const bool direct = hapLen > 4096;
@@ -274,7 +280,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
             if (c != 'N') {
                 for (int q = p + 1; q < hapLen && run < 48 && hapb[q] == c; ++q) ++run;
             } else anyn = 1;
-            hapw[hoff + p] = hap_word(c, (unsigned)c_homopol_go[run]);
+            if (first_group) hapw[hoff + p] = hap_word(c, (unsigned)c_homopol_go[run]);
         }
         if (anyn) s_scal[0] = 1;
     }
@@ -341,7 +347,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         }
     }
     __syncthreads();
-    if (tid == 0) hap_has_n[h] = (uint8_t)s_scal[0];
+    if (tid == 0 && first_group) hap_has_n[h] = (uint8_t)s_scal[0];
     const int maxmult = s_scal[1];
 
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
@@ -352,7 +358,11 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     const int nkp = hapLen - 7;                          // haplotype k-mer positions 0..hapLen-8 (calign.pyx:109)
     bool counts_clean = false;
 
-    for (int c0 = wave * 64; c0 < R; c0 += nw * 64) {
+    // reads are processed in chunks of 64 (one lane per read); blockIdx.y selects a group of SEED_CHUNKS chunks so that
+    // windows with thousands of reads (population mode) spread over many workgroups (each rebuilds the small index)
+    const int cbeg = (int)blockIdx.y * SEED_CHUNKS * nw * 64;
+    const int cend = min(R, cbeg + SEED_CHUNKS * nw * 64);
+    for (int c0 = cbeg + wave * 64; c0 < cend; c0 += nw * 64) {
         const int rl = c0 + lane;
         const bool valid = rl < R;
         ReadInfo ri = ReadInfo{0, 0, 0, 0};
@@ -760,13 +770,15 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     const size_t fixed = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 3) & ~(size_t)3) +
                          ((((size_t)maxhap + 16) + 7) & ~(size_t)7) + 2 * nw64 * 8 + 16;
     const size_t lds_cap = 160 * 1024;
-    int nw = maxR > 128 ? 4 : (maxR > 64 ? 2 : 1);             // one lane per read: waves per haplotype workgroup
+    int nw = 1;                                                // one wave per workgroup measured best (profiles/): setup is instruction-bound
+    if (const char* e = getenv("PLAT_SEED_NW")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) nw = v; }
     while (nw > 1 && fixed + (size_t)nw * cw * 2 > lds_cap) nw >>= 1;
     const size_t lds = fixed + (size_t)nw * cw * 2;
     if (lds > lds_cap) return PLAT_ERR_HAP_TOO_LONG;
     if (lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_seed, dim3(b.n_haps), dim3(64 * nw), lds, st, b, hap_win, win_rows, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
+    const int ngroups = (maxR + SEED_CHUNKS * nw * 64 - 1) / (SEED_CHUNKS * nw * 64);
+    hipLaunchKernelGGL(k_seed, dim3(b.n_haps, ngroups > 0 ? ngroups : 1), dim3(64 * nw), lds, st, b, hap_win, win_rows, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (uint32_t*)ctx->hapw.ptr, (uint8_t*)ctx->hap_flags.ptr,
                        (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt, tsize_max, maxhap, cw, want_stats);
     PLAT_HIP(ctx, hipGetLastError());

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Secondary measurements for DESIGN.md: BASELINE configs 3 (assembler) and 5 (population mode), plus the oracle's
+single-core time on a sample for scale.  Not the headline bench (that is bench.py / config 2)."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from platypus_amd import synth
+from platypus_amd.engine import Engine
+from tests.test_gpu_assembler import synth_region
+
+
+def main():
+    import torch
+    eng = Engine(0)
+    out = {}
+    # ---- config 3: 4.5 kb regions, 250 bp reads at 30x, indels + SNPs
+    rng = np.random.default_rng(3003)
+    nreg = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    regions = [synth_region(rng, 4500, 2, 250, 30, 4) for _ in range(nreg)]
+    eng.assemble(regions[:8])
+    t0 = time.perf_counter(); res = eng.assemble(regions); t = time.perf_counter() - t0
+    from oracle.oracle import Oracle
+    o = Oracle()
+    t0 = time.perf_counter()
+    for r in regions[:16]:
+        o.assemble(r["ref"], r["ref_start"], r["assem_start"], r["assem_end"], r["seqs"], r["quals"])
+    tc = (time.perf_counter() - t0) / 16
+    out["config3_assembler"] = dict(regions=nreg, reads_per_region=len(regions[0]["seqs"]), gpu_regions_per_sec_incl_h2d=nreg / t,
+                                    oracle_1core_regions_per_sec=1 / tc, variants=sum(len(v) for v in res))
+    # ---- config 5: population mode
+    hb = synth.config5(200, 100)
+    db = eng.upload(hb)
+    st = eng.call_windows(db); eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        eng.call_windows(db, want_stats=False)
+    eng.synchronize(); t = (time.perf_counter() - t0) / 5
+    out["config5_population"] = dict(windows=hb.n_windows, n_ind=hb.n_ind, reads=hb.n_reads, pairs=int(st.n_pairs),
+                                     ms_per_step=1e3 * t, gcups=st.cells_reference / t / 1e9, windows_per_sec=hb.n_windows / t)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
