@@ -48,53 +48,66 @@ __device__ __forceinline__ void set_err(long long* cnt, int code) {
 
 // ------------------------------------------------------------------------------------------------
 // win_rows[w] = max read length in window w + 8 (rows of its read tile); hap_win[h] = window of haplotype h
-__global__ void k_validate(plat_window_batch b, long long* cnt, int32_t* __restrict__ hap_win,
-                           int32_t* __restrict__ win_rows)
+__global__ void __launch_bounds__(256)
+k_validate(plat_window_batch b, long long* cnt, int32_t* __restrict__ hap_win, int32_t* __restrict__ win_rows)
 {
+    __shared__ int s_max[3];
+    if (threadIdx.x < 3) s_max[threadIdx.x] = 0;
+    __syncthreads();
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    int maxhap = 0, maxread = 0, maxH = 0;
+    const int lane = threadIdx.x & 63, gwave = tid >> 6, nwaves = nt >> 6;
+    int maxhap = 0, maxread = 0, maxR = 0;
     for (int h = tid; h < b.n_haps; h += nt) {
         long long len = b.hap_off[h + 1] - b.hap_off[h];
         if (len > 16384) set_err(cnt, PLAT_ERR_HAP_TOO_LONG);
         if (len < 0) set_err(cnt, PLAT_ERR_BAD_INPUT);
         maxhap = max(maxhap, (int)min(len, 1ll << 20));
     }
-    for (int w = tid; w < b.n_windows; w += nt) {
+    // one wave per window: shape checks, haplotype -> window map, longest read
+    for (int w = gwave; w < b.n_windows; w += nwaves) {
         const int h0 = b.win_hap_begin[w], h1 = b.win_hap_begin[w + 1];
         const int r0 = b.win_read_begin[w], r1 = b.win_read_begin[w + 1];
         const long long H = h1 - h0, R = r1 - r0;
-        win_rows[w] = 8;
-        if (H < 0 || R < 0 || b.pair_off[w + 1] - b.pair_off[w] != H * R) { set_err(cnt, PLAT_ERR_BAD_INPUT); continue; }
-        for (int h = h0; h < h1; ++h) hap_win[h] = w;
-        maxH = max(maxH, (int)min(R, 1ll << 30));          // (re-used slot: largest number of reads in a window)
+        if (H < 0 || R < 0 || b.pair_off[w + 1] - b.pair_off[w] != H * R) {
+            if (lane == 0) { set_err(cnt, PLAT_ERR_BAD_INPUT); win_rows[w] = 8; }
+            continue;
+        }
+        for (int h = h0 + lane; h < h1; h += 64) hap_win[h] = w;
         int lm = 0;
-        for (int r = r0; r < r1; ++r) {
+        for (int r = r0 + lane; r < r1; r += 64) {
             long long len = b.read_off[r + 1] - b.read_off[r];
             if (len < 0 || len > 32767) { set_err(cnt, PLAT_ERR_BAD_INPUT); len = 0; }      // cAlignedRead.rlen is a short
             lm = max(lm, (int)len);
         }
-        win_rows[w] = lm + 8;
+#pragma unroll
+        for (int s2 = 32; s2 > 0; s2 >>= 1) lm = max(lm, __shfl_xor(lm, s2));
+        if (lane == 0) win_rows[w] = lm + 8;
         maxread = max(maxread, lm);
+        maxR = max(maxR, (int)min(R, 1ll << 30));
     }
     // 7-bit ASCII check over the blobs (the DP packs bases as byte << 9, qualities as 4*q in 16 bits)
     {
         const long long nh = b.n_haps ? b.hap_off[b.n_haps] : 0, nr = b.n_reads ? b.read_off[b.n_reads] : 0;
-        const long long nh4 = nh >> 2, nr4 = nr >> 2;
+        const long long nh16 = nh >> 4, nr16 = nr >> 4;
         unsigned bad = 0;
-        const uint32_t* h4 = (const uint32_t*)b.hap_seq;
-        const uint32_t* s4 = (const uint32_t*)b.read_seq;
-        const uint32_t* q4 = (const uint32_t*)b.read_qual;
-        for (long long i = tid; i < nh4; i += nt) bad |= h4[i];
-        for (long long i = tid; i < nr4; i += nt) bad |= s4[i] | q4[i];
-        if (tid < 4) {
-            for (long long i = nh4 * 4 + tid; i < nh; i += 4) bad |= (unsigned)b.hap_seq[i] * 0x01010101u;
-            for (long long i = nr4 * 4 + tid; i < nr; i += 4) bad |= (unsigned)(b.read_seq[i] | b.read_qual[i]) * 0x01010101u;
+        const uint4* h4 = (const uint4*)b.hap_seq;
+        const uint4* s4 = (const uint4*)b.read_seq;
+        const uint4* q4 = (const uint4*)b.read_qual;
+        for (long long i = tid; i < nh16; i += nt) { const uint4 v = h4[i]; bad |= v.x | v.y | v.z | v.w; }
+        for (long long i = tid; i < nr16; i += nt) { const uint4 v = s4[i], q = q4[i]; bad |= v.x | v.y | v.z | v.w | q.x | q.y | q.z | q.w; }
+        if (tid < 16) {
+            for (long long i = nh16 * 16 + tid; i < nh; i += 16) bad |= (unsigned)b.hap_seq[i] * 0x01010101u;
+            for (long long i = nr16 * 16 + tid; i < nr; i += 16) bad |= (unsigned)(b.read_seq[i] | b.read_qual[i]) * 0x01010101u;
         }
         if (bad & 0x80808080u) set_err(cnt, PLAT_ERR_BAD_INPUT);
     }
-    atomicMax((unsigned long long*)&cnt[CNT_MAXHAP], (unsigned long long)maxhap);
-    atomicMax((unsigned long long*)&cnt[CNT_MAXREAD], (unsigned long long)maxread);
-    atomicMax((unsigned long long*)&cnt[CNT_MAXH], (unsigned long long)maxH);
+    atomicMax(&s_max[0], maxhap); atomicMax(&s_max[1], maxread); atomicMax(&s_max[2], maxR);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax((unsigned long long*)&cnt[CNT_MAXHAP], (unsigned long long)s_max[0]);
+        atomicMax((unsigned long long*)&cnt[CNT_MAXREAD], (unsigned long long)s_max[1]);
+        atomicMax((unsigned long long*)&cnt[CNT_MAXH], (unsigned long long)s_max[2]);
+    }
 }
 
 // exclusive scan of rows*R per window -> tile_off (dwords); single workgroup
@@ -137,17 +150,20 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
 // (calign.pyx:69-74 coding: A=1 C=3 G=2 T=0, N=2), 32 bases per 64-bit word, transposed: word j of read rl at
 // ((u64*)(codes + tile_off[w]))[j*R + rl].  A 7-mer code (a5, hashReadForMapping calign.pyx:155-165) is 14 consecutive
 // bits of that stream; only equality of codes matters to the vote, so the little-endian order is as good as the
-// reference's big-endian one.
+// reference's big-endian one.  grid = (windows, slices): the slices of one window interleave over its elements.
 {
     const int w = blockIdx.x;
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
     if (R <= 0) return;
     const int rows = win_rows[w];
     const long long toff = tile_off[w];
-    if (toff + (long long)rows * R > 0xFFFFFFFFll) { if (threadIdx.x == 0) set_err(cnt, PLAT_ERR_OVERFLOW); return; }
+    const long long n = (long long)rows * R;
+    const long long t0 = (long long)blockIdx.y * blockDim.x + threadIdx.x, tstride = (long long)gridDim.y * blockDim.x;
+    if ((long long)blockIdx.y * blockDim.x >= n) return;
+    if (toff + n > 0xFFFFFFFFll) { if (t0 == 0) set_err(cnt, PLAT_ERR_OVERFLOW); return; }
     const int wstart = b.win_start[w], wend = b.win_end[w];
-    for (int rl = threadIdx.x; rl < R; rl += blockDim.x) {
-        const int r = rb + rl;
+    for (long long rl = t0; rl < R; rl += tstride) {
+        const int r = rb + (int)rl;
         const int L = (int)(b.read_off[r + 1] - b.read_off[r]);
         // skip rule, chaplotype.pyx:343-346 / 358-361 (brokenMates are always aligned, :366-373)
         int skip = 0;
@@ -160,8 +176,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
                             (uint32_t)L | ((uint32_t)skip << 16) | ((uint32_t)b.read_mapq[r] << 24)};
     }
     // tile: element (i, rl), rl fastest -> coalesced stores
-    const long long n = (long long)rows * R;
-    for (long long e = threadIdx.x; e < n; e += blockDim.x) {
+    for (long long e = t0; e < n; e += tstride) {
         const int i = (int)(e / R), rl = (int)(e - (long long)i * R);
         const long long ro = b.read_off[rb + rl];
         const int L = (int)(b.read_off[rb + rl + 1] - ro);
@@ -169,8 +184,8 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     }
     unsigned long long* rd2 = (unsigned long long*)(codes + toff);
     const int nwords = (rows - 8 + 31) >> 5;
-    for (int e = threadIdx.x; e < nwords * R; e += blockDim.x) {
-        const int j = e / R, rl = e - j * R;
+    for (long long e = t0; e < (long long)nwords * R; e += tstride) {
+        const int j = (int)(e / R), rl = (int)(e - (long long)j * R);
         const long long ro = b.read_off[rb + rl];
         const int L = (int)(b.read_off[rb + rl + 1] - ro);
         unsigned long long wd = 0;
@@ -821,7 +836,7 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     ctx->ev_valid_align = 0;
     PLAT_EV(ctx, 0, st);
     PLAT_HIP(ctx, hipMemsetAsync(cnt, 0, (CNT_N + 8) * sizeof(long long), st));
-    hipLaunchKernelGGL(k_validate, dim3(1024), dim3(256), 0, st, b, cnt, hap_win, win_rows);
+    hipLaunchKernelGGL(k_validate, dim3(2048), dim3(256), 0, st, b, cnt, hap_win, win_rows);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, b, win_rows, tile_off, cnt);
     PLAT_HIP(ctx, hipGetLastError());
     // read back: error, maxima, blob lengths, number of pairs, tile size
@@ -844,7 +859,11 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     if ((long long)(ctx->jobs.cap / sizeof(Job)) - npairs > extra_cap) extra_cap = (long long)(ctx->jobs.cap / sizeof(Job)) - npairs;
     if (extra_cap > 0x7FFFFF00ll) extra_cap = 0x7FFFFF00ll;
 
-    hipLaunchKernelGGL(k_prep_reads, dim3(b.n_windows), dim3(256), 0, st, b, win_rows, tile_off, (uint32_t*)ctx->tile.ptr,
+    // slices per window so that one workgroup handles <= ~16k tile elements (population-mode windows are large)
+    int prep_slices = (int)((((long long)maxread + 8) * maxR + 16383) / 16384);
+    if (prep_slices < 1) prep_slices = 1;
+    if (prep_slices > 1024) prep_slices = 1024;
+    hipLaunchKernelGGL(k_prep_reads, dim3(b.n_windows, prep_slices), dim3(256), 0, st, b, win_rows, tile_off, (uint32_t*)ctx->tile.ptr,
                        (uint16_t*)ctx->codes.ptr, (ReadInfo*)ctx->rinfo.ptr, cnt);
     long long njobs = 0;
     PLAT_EV(ctx, 1, st);
