@@ -143,6 +143,8 @@ __device__ __forceinline__ unsigned base2(unsigned ch) {      // calign.pyx:69-7
     return c & 3u;
 }
 
+constexpr int PREP_LMAX = 448;          // reads up to this length are staged through LDS (64 reads x seq+qual <= 56 KB)
+
 __global__ void __launch_bounds__(256)
 k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const long long* __restrict__ tile_off,
              uint32_t* __restrict__ tile, uint16_t* __restrict__ codes, ReadInfo* __restrict__ rinfo, long long* cnt)
@@ -150,20 +152,34 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
 // (calign.pyx:69-74 coding: A=1 C=3 G=2 T=0, N=2), 32 bases per 64-bit word, transposed: word j of read rl at
 // ((u64*)(codes + tile_off[w]))[j*R + rl].  A 7-mer code (a5, hashReadForMapping calign.pyx:155-165) is 14 consecutive
 // bits of that stream; only equality of codes matters to the vote, so the little-endian order is as good as the
-// reference's big-endian one.  grid = (windows, slices): the slices of one window interleave over its elements.
+// reference's big-endian one.
+// grid = (windows, groups of 64 reads).  The 64 reads of a group are contiguous in the blobs: they are copied to LDS
+// with coalesced loads and transposed from there (a direct strided gather thrashes the L1 for windows with
+// thousands of reads).
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    __shared__ int s_off[65];
     const int w = blockIdx.x;
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
-    if (R <= 0) return;
+    const int c0 = (int)blockIdx.y * 64;
+    if (c0 >= R) return;
+    const int nr = min(64, R - c0);
     const int rows = win_rows[w];
     const long long toff = tile_off[w];
-    const long long n = (long long)rows * R;
-    const long long t0 = (long long)blockIdx.y * blockDim.x + threadIdx.x, tstride = (long long)gridDim.y * blockDim.x;
-    if ((long long)blockIdx.y * blockDim.x >= n) return;
-    if (toff + n > 0xFFFFFFFFll) { if (t0 == 0) set_err(cnt, PLAT_ERR_OVERFLOW); return; }
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (toff + (long long)rows * R > 0xFFFFFFFFll) { if (tid == 0 && c0 == 0) set_err(cnt, PLAT_ERR_OVERFLOW); return; }
+    const long long blob0 = b.read_off[rb + c0];
+    const int nbytes = (int)(b.read_off[rb + c0 + nr] - blob0);
+    const bool staged = rows - 8 <= PREP_LMAX;
+    unsigned char* lseq = psm;
+    unsigned char* lqual = psm + 64 * PREP_LMAX;
+    if (tid <= nr) s_off[tid] = (int)(b.read_off[rb + c0 + tid] - blob0);
+    if (staged) {
+        for (int i = tid; i < nbytes; i += nthr) { lseq[i] = b.read_seq[blob0 + i]; lqual[i] = b.read_qual[blob0 + i]; }
+    }
     const int wstart = b.win_start[w], wend = b.win_end[w];
-    for (long long rl = t0; rl < R; rl += tstride) {
-        const int r = rb + (int)rl;
+    if (tid < nr) {
+        const int r = rb + c0 + tid;
         const int L = (int)(b.read_off[r + 1] - b.read_off[r]);
         // skip rule, chaplotype.pyx:343-346 / 358-361 (brokenMates are always aligned, :366-373)
         int skip = 0;
@@ -172,28 +188,31 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             const int ov = oe > os ? oe - os : -1;                       // chaplotype.pyx:103-115
             skip = (b.read_flags[r] & 512) || ov < 7;
         }
-        rinfo[r] = ReadInfo{(uint32_t)(toff + rl), 0u, b.read_pos[r],
+        rinfo[r] = ReadInfo{(uint32_t)(toff + c0 + tid), 0u, b.read_pos[r],
                             (uint32_t)L | ((uint32_t)skip << 16) | ((uint32_t)b.read_mapq[r] << 24)};
     }
+    __syncthreads();
+    const unsigned char* gs = b.read_seq + blob0;
+    const unsigned char* gq = b.read_qual + blob0;
     // tile: element (i, rl), rl fastest -> coalesced stores
-    for (long long e = t0; e < n; e += tstride) {
-        const int i = (int)(e / R), rl = (int)(e - (long long)i * R);
-        const long long ro = b.read_off[rb + rl];
-        const int L = (int)(b.read_off[rb + rl + 1] - ro);
-        tile[toff + e] = i < L ? read_word(b.read_seq[ro + i], b.read_qual[ro + i]) : READ_PAD_WORD;
+    for (int e = tid; e < rows * nr; e += nthr) {
+        const int i = e / nr, rl = e - i * nr;
+        const int o = s_off[rl], L = s_off[rl + 1] - o;
+        uint32_t wd = READ_PAD_WORD;
+        if (i < L) wd = staged ? read_word(lseq[o + i], lqual[o + i]) : read_word(gs[o + i], gq[o + i]);
+        tile[toff + (long long)i * R + c0 + rl] = wd;
     }
     unsigned long long* rd2 = (unsigned long long*)(codes + toff);
     const int nwords = (rows - 8 + 31) >> 5;
-    for (long long e = t0; e < (long long)nwords * R; e += tstride) {
-        const int j = (int)(e / R), rl = (int)(e - (long long)j * R);
-        const long long ro = b.read_off[rb + rl];
-        const int L = (int)(b.read_off[rb + rl + 1] - ro);
+    for (int e = tid; e < nwords * nr; e += nthr) {
+        const int j = e / nr, rl = e - j * nr;
+        const int o = s_off[rl], L = s_off[rl + 1] - o;
         unsigned long long wd = 0;
         for (int q = 0; q < 32; ++q) {
             const int i = 32 * j + q;
-            if (i < L) wd |= (unsigned long long)base2(b.read_seq[ro + i]) << (2 * q);
+            if (i < L) wd |= (unsigned long long)base2(staged ? lseq[o + i] : gs[o + i]) << (2 * q);
         }
-        rd2[e] = wd;
+        rd2[(long long)j * R + c0 + rl] = wd;
     }
 }
 
@@ -859,11 +878,11 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     if ((long long)(ctx->jobs.cap / sizeof(Job)) - npairs > extra_cap) extra_cap = (long long)(ctx->jobs.cap / sizeof(Job)) - npairs;
     if (extra_cap > 0x7FFFFF00ll) extra_cap = 0x7FFFFF00ll;
 
-    // slices per window so that one workgroup handles <= ~16k tile elements (population-mode windows are large)
-    int prep_slices = (int)((((long long)maxread + 8) * maxR + 16383) / 16384);
-    if (prep_slices < 1) prep_slices = 1;
-    if (prep_slices > 1024) prep_slices = 1024;
-    hipLaunchKernelGGL(k_prep_reads, dim3(b.n_windows, prep_slices), dim3(256), 0, st, b, win_rows, tile_off, (uint32_t*)ctx->tile.ptr,
+    const int prep_groups = maxR > 0 ? (maxR + 63) / 64 : 1;
+    const size_t prep_lds = maxread <= PREP_LMAX ? (size_t)2 * 64 * PREP_LMAX : 16;
+    if (prep_lds > 48 * 1024)
+        PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_reads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
+    hipLaunchKernelGGL(k_prep_reads, dim3(b.n_windows, prep_groups), dim3(256), prep_lds, st, b, win_rows, tile_off, (uint32_t*)ctx->tile.ptr,
                        (uint16_t*)ctx->codes.ptr, (ReadInfo*)ctx->rinfo.ptr, cnt);
     long long njobs = 0;
     PLAT_EV(ctx, 1, st);
