@@ -148,11 +148,10 @@ constexpr int PREP_LMAX = 448;          // reads up to this length are staged th
 __global__ void __launch_bounds__(256)
 k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const long long* __restrict__ tile_off,
              uint32_t* __restrict__ tile, uint16_t* __restrict__ codes, ReadInfo* __restrict__ rinfo, long long* cnt)
-// `codes` holds, per window and in the tile's footprint (2 bytes per tile element), the reads' bases PACKED 2 bits each
-// (calign.pyx:69-74 coding: A=1 C=3 G=2 T=0, N=2), 32 bases per 64-bit word, transposed: word j of read rl at
-// ((u64*)(codes + tile_off[w]))[j*R + rl].  A 7-mer code (a5, hashReadForMapping calign.pyx:155-165) is 14 consecutive
-// bits of that stream; only equality of codes matters to the vote, so the little-endian order is as good as the
-// reference's big-endian one.
+// `codes` holds, per window and in the tile's footprint (2 bytes per tile element), the reads' 2-bit base codes
+// (calign.pyx:69-74 coding: A=1 C=3 G=2 T=0, N=2) as two BIT PLANES, 64 bases per 64-bit word, transposed (see below).
+// A 7-mer code (a5, hashReadForMapping calign.pyx:155-165) is 7 consecutive bits of plane 0 and 7 of plane 1; only
+// equality of codes matters to the vote, so this bit order is as good as the reference's.
 // grid = (windows, groups of 64 reads).  The 64 reads of a group are contiguous in the blobs: they are copied to LDS
 // with coalesced loads and transposed from there (a direct strided gather thrashes the L1 for windows with
 // thousands of reads).
@@ -202,17 +201,22 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
         if (i < L) wd = staged ? read_word(lseq[o + i], lqual[o + i]) : read_word(gs[o + i], gq[o + i]);
         tile[toff + (long long)i * R + c0 + rl] = wd;
     }
+    // bit planes: for every read and every chunk c of 64 bases, plane0 = bit 0 and plane1 = bit 1 of the 2-bit base code,
+    // one bit per base (ballot over the 64 lanes); word (2c+plane) of read rl at rd2[(2c+plane)*R + rl]
     unsigned long long* rd2 = (unsigned long long*)(codes + toff);
-    const int nwords = (rows - 8 + 31) >> 5;
-    for (int e = tid; e < nwords * nr; e += nthr) {
-        const int j = e / nr, rl = e - j * nr;
+    const int nchunks = (rows - 8 + 63) >> 6;
+    const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+    for (int e = wv; e < nchunks * nr; e += nwv) {
+        const int c = e / nr, rl = e - c * nr;
         const int o = s_off[rl], L = s_off[rl + 1] - o;
-        unsigned long long wd = 0;
-        for (int q = 0; q < 32; ++q) {
-            const int i = 32 * j + q;
-            if (i < L) wd |= (unsigned long long)base2(staged ? lseq[o + i] : gs[o + i]) << (2 * q);
+        const int i = 64 * c + lane;
+        unsigned b2 = 0;
+        if (i < L) b2 = base2(staged ? lseq[o + i] : gs[o + i]);
+        const unsigned long long m0 = __ballot(b2 & 1u), m1 = __ballot(b2 & 2u);
+        if (lane == 0) {
+            rd2[(long long)(2 * c) * R + c0 + rl] = m0;
+            rd2[(long long)(2 * c + 1) * R + c0 + rl] = m1;
         }
-        rd2[(long long)j * R + c0 + rl] = wd;
     }
 }
 
@@ -231,20 +235,22 @@ __device__ __forceinline__ unsigned kmer_head(const unsigned* table, unsigned co
 }
 
 // k_seed: one workgroup per haplotype; ONE LANE PER (read, haplotype) PAIR.
-// LDS carve (dynamic):  table u32[tsize] | next u16[maxhap+2] | hapb u8[maxhap+16] | hap2 u64[nw64] | nu2 u64[nw64] |
+// LDS carve (dynamic):  table u32[tsize] | next u16[maxhap+2] | planes u64[4][nw64] (h0, h1, eq, nu) |
 //                       counts u16[nwaves][cw] | scalars
 // The k-mer index has two modes: haplotypes up to 4096 bp use a small open-addressing table (load factor <= 0.8);
 // longer ones (up to the reference's cap of 16384) index all 4^7 codes directly, as the reference does
 // (calign.pyx:98-99).
 //
+// Everything is bit-parallel on BIT PLANES (one bit per base, 64 bases per word, built with wave ballots):
+//   h0/h1 = the two bits of the haplotype's 2-bit base codes, eq = "byte equals its right neighbour" (gives the
+//   homopolymer run lengths of annotateWithGapOpen by count-trailing-ones), nu = "the 7-mer starting here occurs more
+//   than once in this haplotype".
 // Every lane tries to PROVE that one diagonal d* is the unique arg-max of the reference's diagonal vote
-// (calign.pyx:206-233) without counting votes, bit-parallel on 2-bit packed bases:
-//   the read (<= 256 bp: 8 x 64-bit words in registers) is XORed with the haplotype's packed bases shifted to the
-//   hypothesis diagonal; a shift-AND ladder marks every read position where 7 consecutive bases match = a k-mer that
-//   votes for d*;  C = popcount of those marks.  Votes for any OTHER diagonal are at most
-//       X = (#matching k-mers whose haplotype k-mer is not unique) * (maxmult-1) + (#non-matching k-mers) * maxmult
-//   (nu2 = per-position "k-mer occurs more than once in this haplotype" bits, maxmult = largest multiplicity),
-//   so X < C  =>  d* is the only candidate of calign.pyx:222-233.
+// (calign.pyx:206-233) without counting votes: the read's planes (<= 256 bp: 4 x 2 words in registers) are XORed
+// with the haplotype's planes shifted to the hypothesis diagonal; a shift-AND ladder marks every read position where 7
+// consecutive bases match = a k-mer that votes for d*;  C = popcount of those marks.  Votes for any OTHER diagonal are
+// at most  X = (#matching k-mers flagged nu) * (maxmult-1) + (#non-matching k-mers) * maxmult  (maxmult = largest
+// 7-mer multiplicity in the haplotype), so X < C  =>  d* is the only candidate of calign.pyx:222-233.
 // Hypothesis A = the read's mapping offset (calign.pyx:252); B = the diagonal of the read's first haplotype-unique k-mer.
 // Pairs that cannot be decided (tandem repeats, ties, reads longer than 256 bp) fall back to the exact vote: the whole
 // wave counts that pair's diagonals in 16-bit LDS counters (two per dword, 32-bit LDS atomics; bit 15 = claim flag
@@ -254,12 +260,17 @@ constexpr int SEED_CHUNKS = 4;
 
 __device__ __forceinline__ u64 funnel(u64 lo, u64 hi, int sh) { return sh ? (lo >> sh) | (hi << (64 - sh)) : lo; }
 
-// k-mer code (14 bits, little-endian base order) of read position i from the packed transposed words of one read
-__device__ __forceinline__ unsigned read_code(const u64* __restrict__ rd2col, int R, int i) {
-    const int j = i >> 5, sh = 2 * (i & 31);
-    const u64 lo = rd2col[(long long)j * R];
-    const u64 hi = sh > 50 ? rd2col[(long long)(j + 1) * R] : 0ull;      // 14 bits cross the word only when sh > 50
-    return (unsigned)(funnel(lo, hi, sh) & 0x3FFFull);
+// 14-bit k-mer code at position i from two bit planes given as (lo, hi) word pairs
+__device__ __forceinline__ unsigned plane_code(u64 a_lo, u64 a_hi, u64 b_lo, u64 b_hi, int sh) {
+    return (unsigned)(funnel(a_lo, a_hi, sh) & 0x7Full) | ((unsigned)(funnel(b_lo, b_hi, sh) & 0x7Full) << 7);
+}
+// k-mer code of read position i from the transposed bit planes of one read (column pointer, row stride R)
+__device__ __forceinline__ unsigned read_code(const u64* __restrict__ col, int R, int i) {
+    const int c = i >> 6, sh = i & 63;
+    const bool cross = sh > 57;
+    const u64 a_lo = col[(long long)(2 * c) * R], b_lo = col[(long long)(2 * c + 1) * R];
+    const u64 a_hi = cross ? col[(long long)(2 * c + 2) * R] : 0ull, b_hi = cross ? col[(long long)(2 * c + 3) * R] : 0ull;
+    return plane_code(a_lo, a_hi, b_lo, b_hi, sh);
 }
 
 __global__ void __launch_bounds__(256)
@@ -270,13 +281,14 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
        int tsize_max, int maxhap, int cw, int want_stats)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nw64 = ((maxhap + 63) >> 5) + 10;          // packed words incl. slack for the 9-word window of a hypothesis
+    const int nw64 = ((maxhap + 63) >> 6) + 8;           // plane words incl. slack for the shifted window of a hypothesis
     unsigned* table = (unsigned*)smem;
     unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);
-    unsigned char* hapb = smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 3 & ~(size_t)3);
-    u64* hap2 = (u64*)(hapb + (((size_t)maxhap + 16) + 7 & ~(size_t)7));
-    u64* nu2 = hap2 + nw64;
-    unsigned* counts_all = (unsigned*)(nu2 + nw64);
+    u64* h0 = (u64*)(smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 7 & ~(size_t)7));
+    u64* h1 = h0 + nw64;
+    u64* eqp = h1 + nw64;
+    u64* nup = eqp + nw64;
+    unsigned* counts_all = (unsigned*)(nup + nw64);
     int* s_scal = (int*)(counts_all + (size_t)(blockDim.x >> 6) * (cw >> 1));     // [0] has_n  [1] maxmult
 
     const int h = blockIdx.x;
@@ -290,6 +302,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     const bool first_group = blockIdx.y == 0;            // writes the per-haplotype outputs (hapw, has_n)
     const long long hoff = b.hap_off[h];
     const int hapLen = (int)(b.hap_off[h + 1] - hoff);
+    const uint8_t* hs = b.hap_seq + hoff;
     unsigned* counts = counts_all + (size_t)wave * (cw >> 1);
 
     const bool direct = hapLen > 4096;
@@ -297,87 +310,83 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     if (direct) tsize = 16384;
     else while (tsize < hapLen + hapLen / 4) tsize <<= 1;
     const unsigned tmask = (unsigned)tsize - 1u;
+    const int nch = (hapLen + 63) >> 6;                  // chunks of 64 haplotype positions
 
     if (tid < 2) s_scal[tid] = tid;                      // has_n = 0, maxmult = 1
     for (int i = tid; i < (direct ? tsize / 2 : tsize); i += nthr) table[i] = 0u;
-    for (int i = tid; i < 2 * nw64; i += nthr) hap2[i] = 0ull;          // hap2 and nu2 are contiguous
-    for (int i = tid; i < hapLen; i += nthr) hapb[i] = b.hap_seq[hoff + i];
+    for (int i = tid; i < 4 * nw64; i += nthr) h0[i] = 0ull;            // h0, h1, eqp, nup are contiguous
     __syncthreads();
-
-    // a7: gap-open annotation (chaplotype.pyx:552-590): table[min(48, #following bytes equal to this one)], 'N' -> table[0]
-    // written together with the base as the DP's haplotype word
-    {
-        int anyn = 0;
-        for (int p = tid; p < hapLen; p += nthr) {
-            const unsigned char c = hapb[p];
-            int run = 0;
-            if (c != 'N') {
-                for (int q = p + 1; q < hapLen && run < 48 && hapb[q] == c; ++q) ++run;
-            } else anyn = 1;
-            if (first_group) hapw[hoff + p] = hap_word(c, (unsigned)c_homopol_go[run]);
-        }
-        if (anyn) s_scal[0] = 1;
+    // ---- pass A: planes by ballot
+    for (int t = wave; t < nch; t += nw) {
+        const int p = 64 * t + lane;
+        const unsigned c = p < hapLen ? hs[p] : 0u;
+        const unsigned cn = p + 1 < hapLen ? hs[p + 1] : 0xFFFFu;
+        const unsigned b2 = p < hapLen ? base2(c) : 0u;
+        const u64 m0 = __ballot(b2 & 1u), m1 = __ballot(b2 & 2u);
+        const u64 me = __ballot(c == cn && c != (unsigned)'N');
+        const u64 mn = __ballot(c == (unsigned)'N');
+        if (lane == 0) { h0[t] = m0; h1[t] = m1; eqp[t] = me; if (mn) s_scal[0] = 1; }
     }
-    // packed bases of the haplotype
-    for (int j = tid; j < (hapLen + 31) >> 5; j += nthr) {
-        u64 wd = 0;
-        for (int q = 0; q < 32; ++q) {
-            const int pp = 32 * j + q;
-            if (pp < hapLen) wd |= (u64)base2(hapb[pp]) << (2 * q);
+    __syncthreads();
+    // ---- pass B: a7 gap-open annotation (chaplotype.pyx:552-590): table[min(48, #following bytes equal to this one)],
+    // 'N' -> table[0], written together with the base as the DP's haplotype word; a4 k-mer index (positions
+    // 0..hapLen-8, calign.pyx:109): entry = (code+1)<<16 | (pos+1), equal codes chained through nxt[]
+    for (int t = wave; t < nch; t += nw) {
+        const int p = 64 * t + lane;
+        if (p < hapLen && first_group) {
+            const u64 v = funnel(eqp[t], eqp[t + 1], lane);
+            const int run = min(48, (int)__ffsll((long long)~v) - 1);     // trailing ones of v (v never has 64 ones beyond the cap)
+            hapw[hoff + p] = hap_word(hs[p], (unsigned)c_homopol_go[run < 0 ? 48 : run]);
         }
-        hap2[j] = wd;
-    }
-    // a4: k-mer index (positions 0..hapLen-8; calign.pyx:109): entry = (code+1)<<16 | (pos+1);
-    // equal codes are chained through nxt[] (the chain order is irrelevant to the vote)
-    for (int p = tid; p < hapLen - 7; p += nthr) {
-        unsigned code = 0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) code |= base2(hapb[p + k]) << (2 * k);
-        if (direct) {                                   // u16 heads, two per dword: exchange one half with a CAS loop
-            const unsigned sh = 16u * (code & 1u);
-            unsigned cur = table[code >> 1], seen;
-            do {
-                seen = cur;
-                cur = atomicCAS(&table[code >> 1], seen, (seen & ~(0xFFFFu << sh)) | ((unsigned)(p + 1) << sh));
-            } while (cur != seen);
-            nxt[p + 1] = (unsigned short)((seen >> sh) & 0xFFFFu);
-            continue;
-        }
-        const unsigned key = (code + 1u) << 16;
-        unsigned slot = tbl_slot(code, tmask);
-        unsigned e = table[slot];
-        for (;;) {
-            if (e == 0u) {
-                unsigned old = atomicCAS(&table[slot], 0u, key | (unsigned)(p + 1));
-                if (old == 0u) { nxt[p + 1] = 0; break; }
-                e = old;
-            }
-            if ((e & 0xFFFF0000u) == key) {
-                unsigned old = atomicCAS(&table[slot], e, key | (unsigned)(p + 1));
-                if (old == e) { nxt[p + 1] = (unsigned short)(e & 0xFFFFu); break; }
-                e = old;
+        if (p < hapLen - 7) {
+            const unsigned code = plane_code(h0[t], h0[t + 1], h1[t], h1[t + 1], lane);
+            if (direct) {                               // u16 heads, two per dword: exchange one half with a CAS loop
+                const unsigned sh = 16u * (code & 1u);
+                unsigned cur = table[code >> 1], seen;
+                do {
+                    seen = cur;
+                    cur = atomicCAS(&table[code >> 1], seen, (seen & ~(0xFFFFu << sh)) | ((unsigned)(p + 1) << sh));
+                } while (cur != seen);
+                nxt[p + 1] = (unsigned short)((seen >> sh) & 0xFFFFu);
             } else {
-                slot = (slot + 1u) & tmask;
-                e = table[slot];
+                const unsigned key = (code + 1u) << 16;
+                unsigned slot = tbl_slot(code, tmask);
+                unsigned e = table[slot];
+                for (;;) {
+                    if (e == 0u) {
+                        unsigned old = atomicCAS(&table[slot], 0u, key | (unsigned)(p + 1));
+                        if (old == 0u) { nxt[p + 1] = 0; break; }
+                        e = old;
+                    }
+                    if ((e & 0xFFFF0000u) == key) {
+                        unsigned old = atomicCAS(&table[slot], e, key | (unsigned)(p + 1));
+                        if (old == e) { nxt[p + 1] = (unsigned short)(e & 0xFFFFu); break; }
+                        e = old;
+                    } else {
+                        slot = (slot + 1u) & tmask;
+                        e = table[slot];
+                    }
+                }
             }
         }
     }
     __syncthreads();
-    // multiplicity of every haplotype k-mer: only the chain HEAD walks its chain; members of chains longer than one
-    // are flagged in nu2, the longest chain gives maxmult
-    for (int p = tid; p < hapLen - 7; p += nthr) {
-        unsigned code = 0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) code |= base2(hapb[p + k]) << (2 * k);
-        const unsigned hd = kmer_head(table, code, direct, tmask);
-        if (hd == (unsigned)(p + 1) && nxt[hd] != 0u) {
-            int c = 0;
-            for (unsigned hh = hd; hh != 0u; hh = nxt[hh]) {
-                ++c;
-                const int q = (int)hh - 1;
-                atomicOr((unsigned*)nu2 + 2 * (q >> 5) + ((q & 31) >> 4), 1u << (2 * (q & 15)));
+    // ---- pass C: multiplicities: only a chain HEAD walks its chain; members of chains longer than one are flagged in
+    // nu, the longest chain gives maxmult
+    for (int t = wave; t < nch; t += nw) {
+        const int p = 64 * t + lane;
+        if (p < hapLen - 7) {
+            const unsigned code = plane_code(h0[t], h0[t + 1], h1[t], h1[t + 1], lane);
+            const unsigned hd = kmer_head(table, code, direct, tmask);
+            if (hd == (unsigned)(p + 1) && nxt[hd] != 0u) {
+                int c = 0;
+                for (unsigned hh = hd; hh != 0u; hh = nxt[hh]) {
+                    ++c;
+                    const int q = (int)hh - 1;
+                    atomicOr((unsigned*)nup + 2 * (q >> 6) + ((q & 63) >> 5), 1u << (q & 31));
+                }
+                atomicMax(&s_scal[1], c);
             }
-            atomicMax(&s_scal[1], c);
         }
     }
     __syncthreads();
@@ -415,49 +424,51 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
 
         // ---- bit-parallel proof
         const bool canfast = live && L <= 256;
-        int nWl = canfast ? (L + 31) >> 5 : 0, nWmax = nWl;
+        int nCl = canfast ? (L + 63) >> 6 : 0, nCmax = nCl;
 #pragma unroll
-        for (int s2 = 32; s2 > 0; s2 >>= 1) nWmax = max(nWmax, __shfl_xor(nWmax, s2));
-        u64 rw[8];
+        for (int s2 = 32; s2 > 0; s2 >>= 1) nCmax = max(nCmax, __shfl_xor(nCmax, s2));
+        u64 r0[4], r1[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rw[j] = j < nWl ? col[(long long)j * R] : 0ull;
+        for (int c = 0; c < 4; ++c) {
+            r0[c] = c < nCl ? col[(long long)(2 * c) * R] : 0ull;
+            r1[c] = c < nCl ? col[(long long)(2 * c + 1) * R] : 0ull;
+        }
         int dstar = idx0;
         bool proven = false, triedB = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool run = canfast && !proven && dstar >= 0 && (attempt == 0 || triedB);
-            if (!__any(run)) { if (attempt == 1) break; }
             if (__any(run)) {
-                const int wq = run ? (dstar >> 5) : 0, sb = 2 * (dstar & 31);
+                const int wq = run ? (dstar >> 6) : 0, sb = dstar & 63;
                 const int nvalid = min(nk, nkp - dstar);                 // k-mers i < nvalid lie on haplotype positions
-                u64 Z[9], NUw[8];
+                u64 Z[5], NU[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (j < nWmax) {
-                        const u64 x = funnel(hap2[wq + j], hap2[wq + j + 1], sb) ^ rw[j];
-                        Z[j] = ~(x | (x >> 1)) & 0x5555555555555555ull;
-                        NUw[j] = funnel(nu2[wq + j], nu2[wq + j + 1], sb);
-                    } else { Z[j] = 0ull; NUw[j] = 0ull; }
+                for (int c = 0; c < 4; ++c) {
+                    if (c < nCmax) {
+                        const u64 x = (funnel(h0[wq + c], h0[wq + c + 1], sb) ^ r0[c]) | (funnel(h1[wq + c], h1[wq + c + 1], sb) ^ r1[c]);
+                        Z[c] = ~x;
+                        NU[c] = funnel(nup[wq + c], nup[wq + c + 1], sb);
+                    } else { Z[c] = 0ull; NU[c] = 0ull; }
                 }
-                Z[8] = 0ull;
-                u64 P2[9];
+                Z[4] = 0ull;
+                u64 P2[5];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) P2[j] = Z[j] & ((Z[j] >> 2) | (Z[j + 1] << 62));
-                P2[8] = 0ull;
+                for (int c = 0; c < 4; ++c) P2[c] = Z[c] & ((Z[c] >> 1) | (Z[c + 1] << 63));
+                P2[4] = 0ull;
                 int C = 0, NUc = 0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (j < nWmax) {
-                        const u64 P4 = P2[j] & ((P2[j] >> 4) | (P2[j + 1] << 60));
-                        u64 P7 = P4 & ((P2[j] >> 8) | (P2[j + 1] << 56)) & ((Z[j] >> 12) | (Z[j + 1] << 52));
-                        const int nb = nvalid - 32 * j;
-                        const u64 msk = nb >= 32 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << (2 * nb)) - 1ull));
+                for (int c = 0; c < 4; ++c) {
+                    if (c < nCmax) {
+                        const u64 P4 = P2[c] & ((P2[c] >> 2) | (P2[c + 1] << 62));
+                        u64 P7 = P4 & ((P2[c] >> 4) | (P2[c + 1] << 60)) & ((Z[c] >> 6) | (Z[c + 1] << 58));
+                        const int nb = nvalid - 64 * c;
+                        const u64 msk = nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull));
                         P7 &= msk;
                         C += __popcll(P7);
-                        NUc += __popcll(P7 & NUw[j]);
+                        NUc += __popcll(P7 & NU[c]);
                     }
                 }
                 const int X = NUc * (maxmult - 1) + (nk - C) * maxmult;
-                if (run && maxmult < 255 && X < C) proven = true;
+                if (run && X < C) proven = true;
             }
             if (attempt == 0) {
                 // hypothesis B for the lanes A could not prove: diagonal of the first haplotype-unique k-mer
@@ -471,10 +482,11 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                         }
                     }
                 }
+                if (!__any(triedB)) break;
             }
         }
         // no k-mer of the read occurs in the haplotype <=> maxcount == 0 (calign.pyx:222): decided, no candidate.
-        // (cheap test only for pairs the proof left open)
+        // (tested only for pairs the proof left open)
         bool novote = false;
         if (live && !proven) {
             novote = true;
@@ -800,9 +812,8 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     if (maxhap > 4096) tsize_max = 8192;
     else while (tsize_max < maxhap + maxhap / 4) tsize_max <<= 1;
     const int cw = (maxhap + maxread + 8 + 1) & ~1;            // 16-bit counters, even count
-    const size_t nw64 = (((size_t)maxhap + 63) >> 5) + 10;
-    const size_t fixed = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 3) & ~(size_t)3) +
-                         ((((size_t)maxhap + 16) + 7) & ~(size_t)7) + 2 * nw64 * 8 + 16;
+    const size_t nw64 = (((size_t)maxhap + 63) >> 6) + 8;
+    const size_t fixed = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 7) & ~(size_t)7) + 4 * nw64 * 8 + 16;
     const size_t lds_cap = 160 * 1024;
     int nw = 1;                                                // one wave per workgroup measured best (profiles/): setup is instruction-bound
     if (const char* e = getenv("PLAT_SEED_NW")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) nw = v; }
