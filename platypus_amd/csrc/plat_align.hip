@@ -85,22 +85,7 @@ k_validate(plat_window_batch b, long long* cnt, int32_t* __restrict__ hap_win, i
         maxread = max(maxread, lm);
         maxR = max(maxR, (int)min(R, 1ll << 30));
     }
-    // 7-bit ASCII check over the blobs (the DP packs bases as byte << 9, qualities as 4*q in 16 bits)
-    {
-        const long long nh = b.n_haps ? b.hap_off[b.n_haps] : 0, nr = b.n_reads ? b.read_off[b.n_reads] : 0;
-        const long long nh16 = nh >> 4, nr16 = nr >> 4;
-        unsigned bad = 0;
-        const uint4* h4 = (const uint4*)b.hap_seq;
-        const uint4* s4 = (const uint4*)b.read_seq;
-        const uint4* q4 = (const uint4*)b.read_qual;
-        for (long long i = tid; i < nh16; i += nt) { const uint4 v = h4[i]; bad |= v.x | v.y | v.z | v.w; }
-        for (long long i = tid; i < nr16; i += nt) { const uint4 v = s4[i], q = q4[i]; bad |= v.x | v.y | v.z | v.w | q.x | q.y | q.z | q.w; }
-        if (tid < 16) {
-            for (long long i = nh16 * 16 + tid; i < nh; i += 16) bad |= (unsigned)b.hap_seq[i] * 0x01010101u;
-            for (long long i = nr16 * 16 + tid; i < nr; i += 16) bad |= (unsigned)(b.read_seq[i] | b.read_qual[i]) * 0x01010101u;
-        }
-        if (bad & 0x80808080u) set_err(cnt, PLAT_ERR_BAD_INPUT);
-    }
+    // (the 7-bit ASCII check of the blobs is done where the bytes are read anyway: k_prep_reads and k_seed)
     atomicMax(&s_max[0], maxhap); atomicMax(&s_max[1], maxread); atomicMax(&s_max[2], maxR);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -173,8 +158,14 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     unsigned char* lseq = psm;
     unsigned char* lqual = psm + 64 * PREP_LMAX;
     if (tid <= nr) s_off[tid] = (int)(b.read_off[rb + c0 + tid] - blob0);
-    if (staged) {
-        for (int i = tid; i < nbytes; i += nthr) { lseq[i] = b.read_seq[blob0 + i]; lqual[i] = b.read_qual[blob0 + i]; }
+    {   // copy to LDS + 7-bit ASCII check (the DP packs bases as byte << 9 and qualities as 4*q in 16 bits)
+        unsigned bad = 0;
+        for (int i = tid; i < nbytes; i += nthr) {
+            const unsigned char cs = b.read_seq[blob0 + i], cq = b.read_qual[blob0 + i];
+            bad |= cs | cq;
+            if (staged) { lseq[i] = cs; lqual[i] = cq; }
+        }
+        if (bad & 0x80u) set_err(cnt, PLAT_ERR_BAD_INPUT);
     }
     const int wstart = b.win_start[w], wend = b.win_end[w];
     if (tid < nr) {
@@ -194,28 +185,37 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     const unsigned char* gs = b.read_seq + blob0;
     const unsigned char* gq = b.read_qual + blob0;
     // tile: element (i, rl), rl fastest -> coalesced stores
-    for (int e = tid; e < rows * nr; e += nthr) {
-        const int i = e / nr, rl = e - i * nr;
-        const int o = s_off[rl], L = s_off[rl + 1] - o;
-        uint32_t wd = READ_PAD_WORD;
-        if (i < L) wd = staged ? read_word(lseq[o + i], lqual[o + i]) : read_word(gs[o + i], gq[o + i]);
-        tile[toff + (long long)i * R + c0 + rl] = wd;
+    // tile: element (i, rl), rl fastest -> coalesced stores.  e / nr by multiply-shift (exact for e < 16384, nr <= 64)
+    {
+        const int ne = rows * nr;
+        const unsigned M = (1u << 22) / (unsigned)nr + 1u;
+        for (int e = tid; e < ne; e += nthr) {
+            const int i = ne <= 16384 ? (int)(((unsigned)e * M) >> 22) : e / nr;
+            const int rl = e - i * nr;
+            const int o = s_off[rl], L = s_off[rl + 1] - o;
+            uint32_t wd = READ_PAD_WORD;
+            if (i < L) wd = staged ? read_word(lseq[o + i], lqual[o + i]) : read_word(gs[o + i], gq[o + i]);
+            tile[toff + (long long)i * R + c0 + rl] = wd;
+        }
     }
     // bit planes: for every read and every chunk c of 64 bases, plane0 = bit 0 and plane1 = bit 1 of the 2-bit base code,
     // one bit per base (ballot over the 64 lanes); word (2c+plane) of read rl at rd2[(2c+plane)*R + rl]
     unsigned long long* rd2 = (unsigned long long*)(codes + toff);
     const int nchunks = (rows - 8 + 63) >> 6;
     const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
-    for (int e = wv; e < nchunks * nr; e += nwv) {
-        const int c = e / nr, rl = e - c * nr;
-        const int o = s_off[rl], L = s_off[rl + 1] - o;
-        const int i = 64 * c + lane;
-        unsigned b2 = 0;
-        if (i < L) b2 = base2(staged ? lseq[o + i] : gs[o + i]);
-        const unsigned long long m0 = __ballot(b2 & 1u), m1 = __ballot(b2 & 2u);
-        if (lane == 0) {
-            rd2[(long long)(2 * c) * R + c0 + rl] = m0;
-            rd2[(long long)(2 * c + 1) * R + c0 + rl] = m1;
+    for (int c = wv; c < nchunks; c += nwv) {            // one wave per chunk; lane rl keeps read rl's two words
+        unsigned long long my0 = 0, my1 = 0;
+        for (int rl = 0; rl < nr; ++rl) {
+            const int o = s_off[rl], L = s_off[rl + 1] - o;
+            const int i = 64 * c + lane;
+            unsigned b2 = 0;
+            if (i < L) b2 = base2(staged ? lseq[o + i] : gs[o + i]);
+            const unsigned long long m0 = __ballot(b2 & 1u), m1 = __ballot(b2 & 2u);
+            if (lane == rl) { my0 = m0; my1 = m1; }
+        }
+        if (lane < nr) {
+            rd2[(long long)(2 * c) * R + c0 + lane] = my0;
+            rd2[(long long)(2 * c + 1) * R + c0 + lane] = my1;
         }
     }
 }
@@ -320,6 +320,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     for (int t = wave; t < nch; t += nw) {
         const int p = 64 * t + lane;
         const unsigned c = p < hapLen ? hs[p] : 0u;
+        if (c & 0x80u) set_err(cnt, PLAT_ERR_BAD_INPUT);                 // 7-bit ASCII only (the DP packs bases as byte << 9)
         const unsigned cn = p + 1 < hapLen ? hs[p + 1] : 0xFFFFu;
         const unsigned b2 = p < hapLen ? base2(c) : 0u;
         const u64 m0 = __ballot(b2 & 1u), m1 = __ballot(b2 & 2u);
