@@ -155,17 +155,28 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     const long long blob0 = b.read_off[rb + c0];
     const int nbytes = (int)(b.read_off[rb + c0 + nr] - blob0);
     const bool staged = rows - 8 <= PREP_LMAX;
-    unsigned char* lseq = psm;
-    unsigned char* lqual = psm + 64 * PREP_LMAX;
+    // the group's bytes are copied as ALIGNED dwords; the LDS image keeps the blob's misalignment (mis = blob0 & 3)
+    const int misS = (int)((uintptr_t)(b.read_seq + blob0) & 3), misQ = (int)((uintptr_t)(b.read_qual + blob0) & 3);
+    unsigned char* lseq = psm + misS;
+    unsigned char* lqual = psm + 64 * PREP_LMAX + 16 + misQ;
     if (tid <= nr) s_off[tid] = (int)(b.read_off[rb + c0 + tid] - blob0);
-    {   // copy to LDS + 7-bit ASCII check (the DP packs bases as byte << 9 and qualities as 4*q in 16 bits)
+    {   // copy to LDS + 7-bit ASCII check (the DP packs bases as byte << 9 and qualities as 4*q in 16 bits).  Bytes before
+        // blob0 / after the group inside the first / last dword belong to neighbouring reads (or the blob's slack).
+        const uint32_t* gs4 = (const uint32_t*)(b.read_seq + blob0 - misS);
+        const uint32_t* gq4 = (const uint32_t*)(b.read_qual + blob0 - misQ);
+        const int ndS = (misS + nbytes + 3) >> 2, ndQ = (misQ + nbytes + 3) >> 2;
         unsigned bad = 0;
-        for (int i = tid; i < nbytes; i += nthr) {
-            const unsigned char cs = b.read_seq[blob0 + i], cq = b.read_qual[blob0 + i];
-            bad |= cs | cq;
-            if (staged) { lseq[i] = cs; lqual[i] = cq; }
+        for (int i = tid; i < ndS; i += nthr) {
+            const uint32_t vs = gs4[i];
+            bad |= vs;
+            if (staged) ((uint32_t*)psm)[i] = vs;
         }
-        if (bad & 0x80u) set_err(cnt, PLAT_ERR_BAD_INPUT);
+        for (int i = tid; i < ndQ; i += nthr) {
+            const uint32_t vq = gq4[i];
+            bad |= vq;
+            if (staged) ((uint32_t*)(psm + 64 * PREP_LMAX + 16))[i] = vq;
+        }
+        if (bad & 0x80808080u) set_err(cnt, PLAT_ERR_BAD_INPUT);
     }
     const int wstart = b.win_start[w], wend = b.win_end[w];
     if (tid < nr) {
@@ -891,7 +902,7 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     if (extra_cap > 0x7FFFFF00ll) extra_cap = 0x7FFFFF00ll;
 
     const int prep_groups = maxR > 0 ? (maxR + 63) / 64 : 1;
-    const size_t prep_lds = maxread <= PREP_LMAX ? (size_t)2 * 64 * PREP_LMAX : 16;
+    const size_t prep_lds = maxread <= PREP_LMAX ? (size_t)2 * (64 * PREP_LMAX + 16) : 64;
     if (prep_lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_reads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
     hipLaunchKernelGGL(k_prep_reads, dim3(b.n_windows, prep_groups), dim3(256), prep_lds, st, b, win_rows, tile_off, (uint32_t*)ctx->tile.ptr,
