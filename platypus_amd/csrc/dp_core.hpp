@@ -17,8 +17,8 @@
 // Differences in FORM (not in values) from the SSE formulation, each verified against the oracle:
 //  * bases are held pre-shifted (byte << 9) so that "mismatch ? qual : 0" is
 //    v_pk_min_u16(hap ^ read, qual4): the XOR of two different 7-bit bytes is >= 512 > 4*127.
-//  * min(M,I) of each parity is cached (it is needed by the D update of the other parity and by
-//    the next min(M,I,D) of its own), saving one packed min per register per half-step.
+//  * only min(M,I) and D of each parity and the next step's "I before + nucprior" are carried between steps
+//    (M and I are transient): one packed min less per register per half-step and < 80 VGPRs.
 //  * I of the odd parity is computed as shift_down(min(I1+ge, M1+go_even)) + np: one lane shift
 //    instead of two (go_odd[k] == go_even[k+1]).
 //  * HAS_N = false drops the "haplotype base is N -> cost 0" vector (align.c:175-178,385) when the
@@ -89,7 +89,10 @@ constexpr uint32_t READ_PAD_WORD = ((((uint32_t)'0') & 0x7Fu) << 9) | ((64u * 4u
 
 template <bool HAS_N>
 struct DP {
-    V8 m1, i1, d1, m2, i2, d2, mi1, mi2, s1w, s1n, gop, s2w, q2w;
+    // carried between steps: min(M,I) and D of both parities, and un = min(I2 + ge, M2 + go) = the even I of the NEXT
+    // step before "+ nucprior" (the odd half-step's gap-open window is the next step's even window).  M and I
+    // themselves are transient, which keeps the kernel under 80 VGPRs.
+    V8 mi1, d1, mi2, d2, un, i2p, s1w, s1n, gop, s2w, q2w;
     uint32_t GE, NP, FILLI;
     int minscore;
 
@@ -101,7 +104,7 @@ struct DP {
         minscore = 0x7800;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            m1.v[j] = i1.v[j] = d1.v[j] = m2.v[j] = i2.v[j] = d2.v[j] = mi1.v[j] = mi2.v[j] = INF2;
+            d1.v[j] = d2.v[j] = mi1.v[j] = mi2.v[j] = i2p.v[j] = INF2;
             s2w.v[j] = 0x01FF01FFu;   // never equals a base code; XOR with any code is >= 511
             q2w.v[j] = 0x01000100u;   // 64*4, align.c:159
             s1w.v[j] = (hw[2 * j] & 0xFFFFu) | (hw[2 * j + 1] << 16);
@@ -109,6 +112,7 @@ struct DP {
             if (HAS_N)
                 s1n.v[j] = ((hw[2 * j] & 0xFFFFu) == CODE_N ? 0u : INF16) |
                            ((hw[2 * j + 1] & 0xFFFFu) == CODE_N ? 0u : (INF16 << 16));
+            un.v[j] = pk_min_i(pk_add(INF2, GE), pk_add(INF2, gop.v[j]));     // i2 = m2 = pos_inf before step 0
         }
     }
 
@@ -118,17 +122,18 @@ struct DP {
     //  EL >= 0 : h >= len2 -> candidate final score in lane EL = h - len2 (align.c:261-288,416-443)
     template <int FL, int EL>
     __device__ __forceinline__ void step(uint32_t rw, uint32_t hw, bool ext_rt = false) {
-        V8 S, T, U;
+        V8 S, T, U, m1, i1;
         // ---------------- even half-step
         shift_up(s2w, rw);
         shift_up_hi(q2w, rw);
         if (FL >= 0) {
             constexpr uint32_t msk = (FL & 1) ? 0xFFFF0000u : 0x0000FFFFu;
             constexpr int j = (FL >= 0 ? FL : 0) >> 1;
-            m1.v[j] = (m1.v[j] & ~msk) | (NEG2 & msk);
-            m2.v[j] = (m2.v[j] & ~msk) | (NEG2 & msk);
             mi1.v[j] = (mi1.v[j] & ~msk) | (NEG2 & msk);
             mi2.v[j] = (mi2.v[j] & ~msk) | (NEG2 & msk);
+            // the forced m2 also feeds this step's I (align.c:331-335): redo that lane of un with m2 = -0x8000
+            const uint32_t uf = pk_min_i(pk_add(i2p.v[j], GE), pk_add(NEG2, gop.v[j]));
+            un.v[j] = (un.v[j] & ~msk) | (uf & msk);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) S.v[j] = pk_min_i(mi1.v[j], d1.v[j]);
@@ -139,7 +144,7 @@ struct DP {
             uint32_t c = pk_min_u(s1w.v[j] ^ s2w.v[j], q2w.v[j]);
             if (HAS_N) c = pk_min_i(c, s1n.v[j]);
             m1.v[j] = pk_add(S.v[j], c);
-            U.v[j] = pk_min_i(pk_add(i2.v[j], GE), pk_add(m2.v[j], gop.v[j]));   // i1 before +NP
+            i1.v[j] = pk_add(un.v[j], NP);
         }
         // gap-open vector of the odd half-step (== srli(gap_open) of the even one, lane 7 unused)
         V8 gopE = gop;
@@ -151,7 +156,6 @@ struct DP {
         d1 = T;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            i1.v[j] = pk_add(U.v[j], NP);
             mi1.v[j] = pk_min_i(m1.v[j], i1.v[j]);
             U.v[j] = pk_min_i(pk_add(i1.v[j], GE), pk_add(m1.v[j], gopE.v[j]));   // -> i2 after shift
         }
@@ -167,10 +171,12 @@ struct DP {
         for (int j = 0; j < 4; ++j) {
             uint32_t c = pk_min_u(s1w.v[j] ^ s2w.v[j], q2w.v[j]);
             if (HAS_N) c = pk_min_i(c, s1n.v[j]);
-            m2.v[j] = pk_add(S.v[j], c);
+            const uint32_t m2 = pk_add(S.v[j], c);
+            const uint32_t i2 = pk_add(U.v[j], NP);
             d2.v[j] = pk_min_i(pk_add(d1.v[j], GE), pk_add(mi1.v[j], gop.v[j]));
-            i2.v[j] = pk_add(U.v[j], NP);
-            mi2.v[j] = pk_min_i(m2.v[j], i2.v[j]);
+            mi2.v[j] = pk_min_i(m2, i2);
+            un.v[j] = pk_min_i(pk_add(i2, GE), pk_add(m2, gop.v[j]));            // next step's even I before + np
+            if (FL >= 0) i2p.v[j] = i2;
         }
     }
 

@@ -16,6 +16,7 @@
 //   k_finalize    per (read, haplotype): the reference's candidate selection replayed on the job scores
 //                 (calign.pyx:235-267), score -> log-likelihood (a8, chaplotype.pyx:621-676)
 #include "dp_core.hpp"
+#include "dp_unpacked.hpp"
 #include <stdio.h>
 
 #include "plat_internal.hpp"
@@ -628,18 +629,24 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_N>
+template <bool HAS_N, bool UNPACKED>
 __device__ __forceinline__ int dp_tile(const uint32_t* __restrict__ rp, int stride, const uint32_t* __restrict__ hp, int len2)
 {
-    DP<HAS_N> dp;
     uint32_t w0[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) w0[k] = hp[k];
-    dp.init(w0, 3, 2);                                                       // chaplotype.pyx:607-608
     hp += 8;
     auto rw = [&](int h) -> uint32_t { return rp[(long long)h * stride]; };
     auto hw = [&](int h) -> uint32_t { return hp[h]; };
-    return dp_run<HAS_N>(dp, len2, rw, hw);
+    if (UNPACKED) {
+        DPU<HAS_N> dp;
+        dp.init(w0);                                                         // gapextend 3, nucprior 2: chaplotype.pyx:607-608
+        return dp_run_u<HAS_N>(dp, len2, rw, hw);
+    } else {
+        DP<HAS_N> dp;
+        dp.init(w0, 3, 2);
+        return dp_run<HAS_N>(dp, len2, rw, hw);
+    }
 }
 
 __device__ __forceinline__ double loglik_of(int score, const double* __restrict__ mapq_lut, int mapq) {
@@ -650,6 +657,7 @@ __device__ __forceinline__ double loglik_of(int score, const double* __restrict_
 // Slot j < npairs is the primary DP of pair j.  Pairs that need a single DP (one candidate that is also the mapping
 // position, or no candidate at all) are finished right here: score -> log-likelihood (a8).  Only pairs with several
 // candidate DPs go through k_finalize_multi.
+template <bool UNPACKED>
 __global__ void __launch_bounds__(256)
 k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32_t* __restrict__ tile,
           const uint32_t* __restrict__ hapw, const uint8_t* __restrict__ hap_has_n, const Job* __restrict__ jobs,
@@ -659,16 +667,8 @@ k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     bool active = j < njobs;
     Job jb = Job{0, 0, 0, 0};
-    PairRec pr = PairRec{0, 0, 1, 1, 0, {0, 0, 0}};
     if (active) jb = jobs[j];
     const bool primary = active && j < npairs;
-    if (primary) {
-        pr = pairs[j];
-        if (pr.ncand < 0) {                                                 // skipped read (0.0, chaplotype.pyx:345-346) or read < 7 bp (score 0)
-            out_ll[j] = pr.ncand == -1 ? 0.0 : loglik_of(0, mapq_lut, pr.mapq);
-            if (out_score) out_score[j] = pr.ncand == -1 ? -1 : 0;
-        }
-    }
     active = active && jb.len != 0;                                          // len 0: slot of a skipped pair
     int has_n = 0, stride = 0;
     if (active) {
@@ -681,13 +681,20 @@ k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32
     const uint32_t* rp = tile + jb.col;
     int sc = 0;
     if (__any(has_n)) {                                                      // wave-uniform choice of the code path
-        if (active) sc = dp_tile<true>(rp, stride, hp, jb.len);
+        if (active) sc = dp_tile<true, UNPACKED>(rp, stride, hp, jb.len);
     } else {
-        if (active) sc = dp_tile<false>(rp, stride, hp, jb.len);
+        if (active) sc = dp_tile<false, UNPACKED>(rp, stride, hp, jb.len);
     }
-    if (active) {
-        const bool single = primary && (pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0));
-        if (single) {
+    if (!primary) {
+        if (active) job_score[j] = sc;
+        return;
+    }
+    const PairRec pr = pairs[j];                                             // read after the DP: nothing of it is live across the loop
+    if (pr.ncand < 0) {                                                      // skipped read (0.0, chaplotype.pyx:345-346) or read < 7 bp (score 0)
+        out_ll[j] = pr.ncand == -1 ? 0.0 : loglik_of(0, mapq_lut, pr.mapq);
+        if (out_score) out_score[j] = pr.ncand == -1 ? -1 : 0;
+    } else if (active) {
+        if (pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0)) {
             out_ll[j] = loglik_of(sc, mapq_lut, pr.mapq);
             if (out_score) out_score[j] = sc;
         } else job_score[j] = sc;
@@ -924,11 +931,21 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     }
     if ((rc = plat_reserve(ctx, ctx->job_score, (size_t)(njobs + 1) * sizeof(int32_t)))) return rc;
     PLAT_EV(ctx, 2, st);
-    hipLaunchKernelGGL(k_dp_jobs, dim3((unsigned)((njobs + 255) / 256)), dim3(256), 0, st, b, hap_win,
-                       (const uint32_t*)ctx->tile.ptr, (const uint32_t*)ctx->hapw.ptr,
-                       (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
-                       (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, njobs,
-                       (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
+    {
+        static int dp_impl = -1;                 // 1 = one int16 lane per VGPR (dp_unpacked.hpp), 0 = packed (dp_core.hpp)
+        if (dp_impl < 0) { const char* e = getenv("PLAT_DP_IMPL"); dp_impl = e ? (strcmp(e, "unpacked") == 0) : 0; }   // packed measured faster
+        const dim3 grid((unsigned)((njobs + 255) / 256));
+        if (dp_impl)
+            hipLaunchKernelGGL(k_dp_jobs<true>, grid, dim3(256), 0, st, b, hap_win, (const uint32_t*)ctx->tile.ptr,
+                               (const uint32_t*)ctx->hapw.ptr, (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
+                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, njobs,
+                               (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
+        else
+            hipLaunchKernelGGL(k_dp_jobs<false>, grid, dim3(256), 0, st, b, hap_win, (const uint32_t*)ctx->tile.ptr,
+                               (const uint32_t*)ctx->hapw.ptr, (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
+                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, njobs,
+                               (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
+    }
     PLAT_EV(ctx, 3, st);
     hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
                        (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr,

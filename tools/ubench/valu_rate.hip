@@ -33,6 +33,12 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, int iters, uint32_t seed
                 if (OP == 16) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
                 if (OP == 17) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b), "v"(c));
                 if (OP == 18) asm volatile("v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 19) asm volatile("v_add_u16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 20) asm volatile("v_min_i16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 21) asm volatile("v_min_i16_sdwa %0, %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 22) asm volatile("v_min_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 23) asm volatile("v_add_u16_sdwa %0, %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 24) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b), "v"(c));
             }
         }
     }
@@ -78,5 +84,11 @@ int main()
     run<16>("v_pk_max_i16", d, blocks);
     run<17>("v_mov_b32_dpp_shr1", d, blocks);
     run<18>("v_add_u32_dpp", d, blocks);
+    run<19>("v_add_u16_sdwa_w1", d, blocks);
+    run<20>("v_min_i16_sdwa_w1", d, blocks);
+    run<21>("v_min_i16_sdwa_w0", d, blocks);
+    run<22>("v_min_u16", d, blocks);
+    run<23>("v_add_u16_sdwa_pad", d, blocks);
+    run<24>("v_cndmask_b32", d, blocks);
     return 0;
 }
