@@ -117,8 +117,11 @@ int plat_dp_batch(plat_ctx* ctx, int n, int lmax,
  * the concatenation of the per-haplotype likelihoodCache arrays without the 999 terminator
  * (0.0 for QCFail / overlap<7 reads, chaplotype.pyx:343-346).  out_score (optional, may be NULL)
  * receives the integer alignment score (-1 for skipped reads).
- * Options: calc_flank_score (runner.py:559, default 0) and use_mapq_cap (HLATyping) must be 0 in
- * this version (PLAT_ERR_UNSUPPORTED otherwise).
+ * Options: calc_flank_score (--calculateFlankScore, runner.py:559, default 0): when 1 every DP runs in
+ * the reference's traceback mode (align.c:96,345-365,494-577) and calculateFlankScore (align.c:593-644)
+ * is subtracted as calign.pyx:235-245,261-264 do; needs win_flank > 0 (the reference dereferences a NULL
+ * alignment buffer otherwise) else PLAT_ERR_UNSUPPORTED.  use_mapq_cap (HLATyping mode) must be 0 in this
+ * version (PLAT_ERR_UNSUPPORTED otherwise).
  * [syncs] once internally (job-count read-back).                                                 */
 typedef struct plat_window_batch {
     int32_t n_windows, n_haps, n_reads, _pad;

@@ -17,6 +17,7 @@
 //                 (calign.pyx:235-267), score -> log-likelihood (a8, chaplotype.pyx:621-676)
 #include "dp_core.hpp"
 #include "dp_unpacked.hpp"
+#include "dp_traceback.hpp"
 #include <stdio.h>
 
 #include "plat_internal.hpp"
@@ -50,7 +51,7 @@ __device__ __forceinline__ void set_err(long long* cnt, int code) {
 // ------------------------------------------------------------------------------------------------
 // win_rows[w] = max read length in window w + 8 (rows of its read tile); hap_win[h] = window of haplotype h
 __global__ void __launch_bounds__(256)
-k_validate(plat_window_batch b, long long* cnt, int32_t* __restrict__ hap_win, int32_t* __restrict__ win_rows)
+k_validate(plat_window_batch b, long long* cnt, int32_t* __restrict__ hap_win, int32_t* __restrict__ win_rows, int calc_flank)
 {
     __shared__ int s_max[3];
     if (threadIdx.x < 3) s_max[threadIdx.x] = 0;
@@ -73,6 +74,8 @@ k_validate(plat_window_batch b, long long* cnt, int32_t* __restrict__ hap_win, i
             if (lane == 0) { set_err(cnt, PLAT_ERR_BAD_INPUT); win_rows[w] = 8; }
             continue;
         }
+        // --calculateFlankScore=1 with hapFlank == 0 dereferences a NULL alignment buffer in the reference (calign.pyx:199-202,261-264)
+        if (calc_flank && b.win_flank[w] <= 0 && lane == 0) set_err(cnt, PLAT_ERR_UNSUPPORTED);
         for (int h = h0 + lane; h < h1; h += 64) hap_win[h] = w;
         int lm = 0;
         for (int r = r0 + lane; r < r1; r += 64) {
@@ -701,6 +704,58 @@ k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32
     }
 }
 
+// --calculateFlankScore=1 (a2): the same job list, but every DP runs in the reference's traceback mode and its score is
+// reduced by the part of the alignment that lies in the haplotype's flanks (calign.pyx:235-245,261-264).  Jobs
+// [j0, j0+jn) of the list; bpbuf holds 2*(maxread+8) rows of `bstride` 64-bit back-pointer words.
+__global__ void __launch_bounds__(256)
+k_dp_tb_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32_t* __restrict__ tile,
+             const uint32_t* __restrict__ hapw, const Job* __restrict__ jobs, const PairRec* __restrict__ pairs,
+             const double* __restrict__ mapq_lut, long long npairs, long long j0, long long jn,
+             unsigned long long* __restrict__ bpbuf, long long bstride, int32_t* __restrict__ job_score,
+             double* __restrict__ out_ll, int32_t* __restrict__ out_score)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= jn) return;
+    const long long j = j0 + t;
+    const Job jb = jobs[j];
+    const bool primary = j < npairs;
+    const bool active = jb.len != 0;
+    int sc = 0;
+    if (active) {
+        const int w = hap_win[jb.hap];
+        const long long stride = b.win_read_begin[w + 1] - b.win_read_begin[w];
+        const long long hoff = b.hap_off[jb.hap];
+        const int hapLen = (int)(b.hap_off[jb.hap + 1] - hoff), hapFlank = b.win_flank[w];
+        const int st = max(0, jb.idx - 8);                                   // calign.pyx:229,256
+        const uint32_t* hfull = hapw + hoff;
+        const uint32_t* hp = hfull + st;
+        const uint32_t* rp = tile + jb.col;
+        uint32_t w0[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w0[k] = hp[k];
+        auto rw = [&](int h) -> uint32_t { return rp[(long long)h * stride]; };
+        auto hw = [&](int h) -> uint32_t { return hp[8 + h]; };
+        const TbView bp{bpbuf + t, (size_t)bstride};
+        int midx;
+        sc = dp_forward_tb(w0, jb.len, rw, hw, bp, &midx);
+        if (sc > 0) sc -= tb_flank_score(bp, midx, jb.len, hfull, st, hapLen, hapFlank, rp, stride);
+    }
+    if (!primary) {
+        if (active) job_score[j] = sc;
+        return;
+    }
+    const PairRec pr = pairs[j];
+    if (pr.ncand < 0) {
+        out_ll[j] = pr.ncand == -1 ? 0.0 : loglik_of(0, mapq_lut, pr.mapq);
+        if (out_score) out_score[j] = pr.ncand == -1 ? -1 : 0;
+    } else if (active) {
+        if (pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0)) {
+            out_ll[j] = loglik_of(sc, mapq_lut, pr.mapq);
+            if (out_score) out_score[j] = sc;
+        } else job_score[j] = sc;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_dp_rows(int n, int lmax, const uint8_t* __restrict__ haps, const uint8_t* __restrict__ reads,
           const uint8_t* __restrict__ quals, const uint8_t* __restrict__ gos, const int32_t* __restrict__ len2,
@@ -854,7 +909,8 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
                                         plat_align_stats* out_stats, void* stream)
 {
     if (!ctx || !batch) return PLAT_ERR_INVALID;
-    if (calc_flank_score || use_mapq_cap) return PLAT_ERR_UNSUPPORTED;
+    if (use_mapq_cap) return PLAT_ERR_UNSUPPORTED;
+    calc_flank_score = calc_flank_score != 0;
     const plat_window_batch b = *batch;
     if (b.n_windows < 0 || b.n_haps < 0 || b.n_reads < 0) return PLAT_ERR_INVALID;
     if (out_stats) memset(out_stats, 0, sizeof(*out_stats));
@@ -885,7 +941,7 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     ctx->ev_valid_align = 0;
     PLAT_EV(ctx, 0, st);
     PLAT_HIP(ctx, hipMemsetAsync(cnt, 0, (CNT_N + 8) * sizeof(long long), st));
-    hipLaunchKernelGGL(k_validate, dim3(2048), dim3(256), 0, st, b, cnt, hap_win, win_rows);
+    hipLaunchKernelGGL(k_validate, dim3(2048), dim3(256), 0, st, b, cnt, hap_win, win_rows, calc_flank_score);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, b, win_rows, tile_off, cnt);
     PLAT_HIP(ctx, hipGetLastError());
     // read back: error, maxima, blob lengths, number of pairs, tile size
@@ -931,7 +987,21 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     }
     if ((rc = plat_reserve(ctx, ctx->job_score, (size_t)(njobs + 1) * sizeof(int32_t)))) return rc;
     PLAT_EV(ctx, 2, st);
-    {
+    if (calc_flank_score) {
+        // traceback mode: 2*(maxread+8) back-pointer words per job; the job list is processed in slabs of bounded size
+        const long long rows = 2ll * (maxread + 8);
+        long long slab = (long long)((6ull << 30) / ((unsigned long long)rows * 8ull));
+        if (slab > njobs) slab = njobs;
+        slab = (slab + 255) & ~255ll;
+        if ((rc = plat_reserve(ctx, ctx->tb, (size_t)rows * (size_t)slab * 8))) return rc;
+        for (long long j0 = 0; j0 < njobs; j0 += slab) {
+            const long long jn = njobs - j0 < slab ? njobs - j0 : slab;
+            hipLaunchKernelGGL(k_dp_tb_jobs, dim3((unsigned)((jn + 255) / 256)), dim3(256), 0, st, b, hap_win,
+                               (const uint32_t*)ctx->tile.ptr, (const uint32_t*)ctx->hapw.ptr, (const Job*)ctx->jobs.ptr,
+                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, j0, jn,
+                               (unsigned long long*)ctx->tb.ptr, slab, (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
+        }
+    } else {
         static int dp_impl = -1;                 // 1 = one int16 lane per VGPR (dp_unpacked.hpp), 0 = packed (dp_core.hpp)
         if (dp_impl < 0) { const char* e = getenv("PLAT_DP_IMPL"); dp_impl = e ? (strcmp(e, "unpacked") == 0) : 0; }   // packed measured faster
         const dim3 grid((unsigned)((njobs + 255) / 256));

@@ -23,25 +23,25 @@ def eng():
     return Engine(0)
 
 
-def oracle_windows(oracle, hb, windows=None):
+def oracle_windows(oracle, hb, windows=None, do_flank=0):
     """Oracle results for a HostBatch: per-window (loglik [H,R], score [H,R], n_dp)."""
     out = []
     for w in (range(hb.n_windows) if windows is None else windows):
         out.append(oracle.align_window(hb.window_haps(w), int(hb.win_start[w]), int(hb.win_end[w]),
-                                       int(hb.win_flank[w]), hb.window_reads(w)))
+                                       int(hb.win_flank[w]), hb.window_reads(w), do_flank=do_flank))
     return out
 
 
-def run_align(eng, hb):
+def run_align(eng, hb, do_flank=0):
     db = eng.upload(hb)
-    st = eng.align(db)
+    st = eng.align(db, calc_flank_score=do_flank)
     eng.synchronize()
     return db, st, db.loglik.cpu().numpy()[:hb.n_pairs], db.score.cpu().numpy()[:hb.n_pairs]
 
 
-def check_against_oracle(oracle, hb, ll, sc, st=None):
+def check_against_oracle(oracle, hb, ll, sc, st=None, do_flank=0):
     ndp = 0
-    for w, (oll, osc, n) in enumerate(oracle_windows(oracle, hb)):
+    for w, (oll, osc, n) in enumerate(oracle_windows(oracle, hb, do_flank=do_flank)):
         a, b = hb.pair_off[w], hb.pair_off[w + 1]
         assert np.array_equal(sc[a:b].reshape(osc.shape), osc), "scores differ in window %d" % w
         # score -> log-likelihood is one fp64 multiply + one add of a host-computed table entry: bit-identical
@@ -129,15 +129,16 @@ def single_pair_batch(cases):
         seg_n_good=np.zeros(nW, dtype=np.int32))
 
 
-def test_mapalign_golden_vectors(eng, golden_dir):
+@pytest.mark.parametrize("do_flank", [0, 1])
+def test_mapalign_golden_vectors(eng, golden_dir, do_flank):
     """Golden vectors from the reference's own calign.pyx: tandem repeats (hundreds of arg-max diagonals),
-    N's, reads hanging off either haplotype end, wrong mapping hints.  (doCalculateFlankScore=1 cases
-    are not supported on the device yet and are checked to fail loudly in test_unsupported_options.)"""
+    N's, reads hanging off either haplotype end, wrong mapping hints; with and without
+    doCalculateFlankScore (the latter exercises the device traceback + calculateFlankScore, a2)."""
     cases = [c for c in json.load(gzip.open(os.path.join(golden_dir, "mapalign_cases.json.gz"), "rt"))
-             if c["doFlank"] == 0]
-    assert len(cases) > 300
+             if c["doFlank"] == do_flank]
+    assert len(cases) > (100 if do_flank else 300)
     hb = single_pair_batch(cases)
-    db, st, ll, sc = run_align(eng, hb)
+    db, st, ll, sc = run_align(eng, hb, do_flank)
     exp = np.array([c["score"] for c in cases], dtype=np.int32)
     assert np.array_equal(sc, exp)
     assert st.n_dp_launched >= len(cases)
@@ -231,10 +232,25 @@ def test_unsupported_options_fail_loudly(eng):
     hb = synth.config1()
     db = eng.upload(hb)
     with pytest.raises(_lib.PlatypusDeviceError) as e:
-        eng.align(db, calc_flank_score=1)
-    assert e.value.code == -6
-    with pytest.raises(_lib.PlatypusDeviceError):
         eng.align(db, use_mapq_cap=1)
+    assert e.value.code == -6
+    # --calculateFlankScore=1 without flanks makes the reference dereference a NULL alignment buffer: refused
+    nf = HostBatch(**{**hb.__dict__, "win_flank": np.zeros_like(hb.win_flank), "pair_off": None, "gl_off": None})
+    with pytest.raises(_lib.PlatypusDeviceError) as e:
+        eng.align(eng.upload(nf), calc_flank_score=1)
+    assert e.value.code == -6
+
+
+def test_flank_score_mode_vs_oracle(eng, oracle):
+    """a2: every DP in traceback mode, flank part of the alignment subtracted (calign.pyx:235-245,261-264)."""
+    for hb in (synth.config2(120), edge_batch()):
+        db, st, ll, sc = run_align(eng, hb, do_flank=1)
+        check_against_oracle(oracle, hb, ll, sc, st, do_flank=1)
+    # the option changes results (reads with errors in the flanks score lower), so the test is not vacuous
+    hb = synth.config2(120)
+    sc0 = run_align(eng, hb, 0)[3]
+    sc1 = run_align(eng, hb, 1)[3]
+    assert (sc1 <= sc0).all() and (sc1 < sc0).any()
 
 
 def test_error_codes_from_device_validation(eng):
