@@ -16,6 +16,7 @@
 //   k_finalize    per (read, haplotype): the reference's candidate selection replayed on the job scores
 //                 (calign.pyx:235-267), score -> log-likelihood (a8, chaplotype.pyx:621-676)
 #include "dp_core.hpp"
+#include <algorithm>
 #include "dp_unpacked.hpp"
 #include "dp_traceback.hpp"
 #include <stdio.h>
@@ -136,7 +137,8 @@ constexpr int PREP_LMAX = 448;          // reads up to this length are staged th
 
 __global__ void __launch_bounds__(256)
 k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const long long* __restrict__ tile_off,
-             uint32_t* __restrict__ tile, uint16_t* __restrict__ codes, ReadInfo* __restrict__ rinfo, long long* cnt)
+             uint32_t* __restrict__ tile, uint16_t* __restrict__ codes, ReadInfo* __restrict__ rinfo, long long* cnt, int qoff)
+// qoff = byte offset of the quality image in the dynamic LDS (= 64 * min(longest read, PREP_LMAX) + 16).
 // `codes` holds, per window and in the tile's footprint (2 bytes per tile element), the reads' 2-bit base codes
 // (calign.pyx:69-74 coding: A=1 C=3 G=2 T=0, N=2) as two BIT PLANES, 64 bases per 64-bit word, transposed (see below).
 // A 7-mer code (a5, hashReadForMapping calign.pyx:155-165) is 7 consecutive bits of plane 0 and 7 of plane 1; only
@@ -162,7 +164,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     // the group's bytes are copied as ALIGNED dwords; the LDS image keeps the blob's misalignment (mis = blob0 & 3)
     const int misS = (int)((uintptr_t)(b.read_seq + blob0) & 3), misQ = (int)((uintptr_t)(b.read_qual + blob0) & 3);
     unsigned char* lseq = psm + misS;
-    unsigned char* lqual = psm + 64 * PREP_LMAX + 16 + misQ;
+    unsigned char* lqual = psm + qoff + misQ;
     if (tid <= nr) s_off[tid] = (int)(b.read_off[rb + c0 + tid] - blob0);
     {   // copy to LDS + 7-bit ASCII check (the DP packs bases as byte << 9 and qualities as 4*q in 16 bits).  Bytes before
         // blob0 / after the group inside the first / last dword belong to neighbouring reads (or the blob's slack).
@@ -178,7 +180,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
         for (int i = tid; i < ndQ; i += nthr) {
             const uint32_t vq = gq4[i];
             bad |= vq;
-            if (staged) ((uint32_t*)(psm + 64 * PREP_LMAX + 16))[i] = vq;
+            if (staged) ((uint32_t*)(psm + qoff))[i] = vq;
         }
         if (bad & 0x80808080u) set_err(cnt, PLAT_ERR_BAD_INPUT);
     }
@@ -965,11 +967,13 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     if (extra_cap > 0x7FFFFF00ll) extra_cap = 0x7FFFFF00ll;
 
     const int prep_groups = maxR > 0 ? (maxR + 63) / 64 : 1;
-    const size_t prep_lds = maxread <= PREP_LMAX ? (size_t)2 * (64 * PREP_LMAX + 16) : 64;
+    // LDS image of a group of 64 reads, sized by the batch's longest read: occupancy of this kernel is LDS-limited
+    const int prep_qoff = 64 * ((std::min(maxread, PREP_LMAX) + 3) & ~3) + 16;
+    const size_t prep_lds = (size_t)2 * prep_qoff;
     if (prep_lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_reads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
     hipLaunchKernelGGL(k_prep_reads, dim3(b.n_windows, prep_groups), dim3(256), prep_lds, st, b, win_rows, tile_off, (uint32_t*)ctx->tile.ptr,
-                       (uint16_t*)ctx->codes.ptr, (ReadInfo*)ctx->rinfo.ptr, cnt);
+                       (uint16_t*)ctx->codes.ptr, (ReadInfo*)ctx->rinfo.ptr, cnt, prep_qoff);
     long long njobs = 0;
     PLAT_EV(ctx, 1, st);
     for (int attempt = 0; attempt < 2; ++attempt) {

@@ -40,12 +40,12 @@ def make_window(seed=5, n_ind=2):
     return fasta, haps, buffers, ws, we
 
 
-def oracle_rows(oracle, haps, buf, ws, we):
+def oracle_rows(oracle, haps, buf, ws, we, do_flank=0):
     rs = buf.windowReads()
     reads = dict(seq=[r.seq for r, _ in rs], qual=[r.qual for r, _ in rs], pos=[r.pos for r, _ in rs],
                  end=[r.end for r, _ in rs], mapq=[r.mapq for r, _ in rs], flags=[r.bitFlag for r, _ in rs],
                  kind=[k for _, k in rs])
-    return oracle.align_window([h.haplotypeSequence for h in haps], ws, we, haps[0].endBufferSize, reads)[0]
+    return oracle.align_window([h.haplotypeSequence for h in haps], ws, we, haps[0].endBufferSize, reads, do_flank=do_flank)[0]
 
 
 def test_alignReads_cache_layout_and_values(oracle):
@@ -80,13 +80,20 @@ def test_population_setup_matches_oracle(oracle):
     assert np.isclose(L, pop.genotypeLogLikelihoods[1][1], rtol=1e-12, atol=0) and gofv[1] != 0
 
 
+def test_calculateFlankScore_option(oracle):
+    fasta, haps, buffers, ws, we = make_window()
+    exp0 = oracle_rows(oracle, haps, buffers[0], ws, we)
+    exp1 = oracle_rows(oracle, haps, buffers[0], ws, we, do_flank=1)
+    assert not np.array_equal(exp0, exp1)
+    for h in haps:
+        h.options.calculateFlankScore = 1                                  # runner.py:559
+    for hi, h in enumerate(haps):
+        assert np.array_equal(h.alignReads(5, buffers[0])[:-1], exp1[hi])
+
+
 def test_unsupported_modes_raise():
     fasta, haps, buffers, ws, we = make_window()
     from platypus_amd._lib import PlatypusDeviceError
-    haps[0].options.calculateFlankScore = 1
-    with pytest.raises(PlatypusDeviceError):
-        haps[0].alignReads(5, buffers[0])
-    haps[0].options.calculateFlankScore = 0
     with pytest.raises(PlatypusDeviceError):
         haps[0].alignSingleRead(buffers[0].reads.window()[0], useMapQualCap=True)
 
