@@ -290,72 +290,18 @@ __device__ __forceinline__ unsigned read_code(const u64* __restrict__ col, int R
     return plane_code(a_lo, a_hi, b_lo, b_hi, sh);
 }
 
-__global__ void __launch_bounds__(256)
-k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* __restrict__ win_rows,
-       const long long* __restrict__ tile_off, const ReadInfo* __restrict__ rinfo,
-       const uint16_t* __restrict__ codes, uint32_t* __restrict__ hapw, uint8_t* __restrict__ hap_has_n,
-       PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
-       int tsize_max, int maxhap, int cw, int want_stats)
+// a4: the haplotype's k-mer index (hash_sequence_multihit, calign.pyx:94-124) in LDS: positions 0..hapLen-8, entry =
+// (code+1)<<16 | (pos+1) in an open-addressing table (or u16 heads indexed by code when direct), equal codes chained
+// through nxt[] from the LAST position to the first.  exact_mult: also walk the chains for the largest multiplicity.
+__device__ __forceinline__ void seed_build_index(unsigned* table, unsigned short* nxt, const u64* h0, const u64* h1, u64* nup,
+                                                 int* s_scal, int hapLen, int nch, bool direct, int tsize, unsigned tmask,
+                                                 bool exact_mult)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nw64 = ((maxhap + 63) >> 6) + 8;           // plane words incl. slack for the shifted window of a hypothesis
-    unsigned* table = (unsigned*)smem;
-    unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);
-    u64* h0 = (u64*)(smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 7 & ~(size_t)7));
-    u64* h1 = h0 + nw64;
-    u64* eqp = h1 + nw64;
-    u64* nup = eqp + nw64;
-    unsigned* counts_all = (unsigned*)(nup + nw64);
-    int* s_scal = (int*)(counts_all + (size_t)(blockDim.x >> 6) * (cw >> 1));     // [0] has_n  [1] maxmult
-
-    const int h = blockIdx.x;
-    const int w = hap_win[h];
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
-    {   // this workgroup's group of read chunks lies beyond the window's reads: nothing to do
-        const int Rw = b.win_read_begin[w + 1] - b.win_read_begin[w];
-        if (blockIdx.y > 0 && (int)blockIdx.y * SEED_CHUNKS * nw * 64 >= Rw) return;
-    }
-    const bool first_group = blockIdx.y == 0;            // writes the per-haplotype outputs (hapw, has_n)
-    const long long hoff = b.hap_off[h];
-    const int hapLen = (int)(b.hap_off[h + 1] - hoff);
-    const uint8_t* hs = b.hap_seq + hoff;
-    unsigned* counts = counts_all + (size_t)wave * (cw >> 1);
-
-    const bool direct = hapLen > 4096;
-    int tsize = 64;
-    if (direct) tsize = 16384;
-    else while (tsize < hapLen + hapLen / 4) tsize <<= 1;
-    const unsigned tmask = (unsigned)tsize - 1u;
-    const int nch = (hapLen + 63) >> 6;                  // chunks of 64 haplotype positions
-
-    if (tid < 2) s_scal[tid] = tid;                      // has_n = 0, maxmult = 1
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
     for (int i = tid; i < (direct ? tsize / 2 : tsize); i += nthr) table[i] = 0u;
-    for (int i = tid; i < 4 * nw64; i += nthr) h0[i] = 0ull;            // h0, h1, eqp, nup are contiguous
     __syncthreads();
-    // ---- pass A: planes by ballot
     for (int t = wave; t < nch; t += nw) {
         const int p = 64 * t + lane;
-        const unsigned c = p < hapLen ? hs[p] : 0u;
-        if (c & 0x80u) set_err(cnt, PLAT_ERR_BAD_INPUT);                 // 7-bit ASCII only (the DP packs bases as byte << 9)
-        const unsigned cn = p + 1 < hapLen ? hs[p + 1] : 0xFFFFu;
-        const unsigned b2 = p < hapLen ? base2(c) : 0u;
-        const u64 m0 = __ballot(b2 & 1u), m1 = __ballot(b2 & 2u);
-        const u64 me = __ballot(c == cn && c != (unsigned)'N');
-        const u64 mn = __ballot(c == (unsigned)'N');
-        if (lane == 0) { h0[t] = m0; h1[t] = m1; eqp[t] = me; if (mn) s_scal[0] = 1; }
-    }
-    __syncthreads();
-    // ---- pass B: a7 gap-open annotation (chaplotype.pyx:552-590): table[min(48, #following bytes equal to this one)],
-    // 'N' -> table[0], written together with the base as the DP's haplotype word; a4 k-mer index (positions
-    // 0..hapLen-8, calign.pyx:109): entry = (code+1)<<16 | (pos+1), equal codes chained through nxt[]
-    for (int t = wave; t < nch; t += nw) {
-        const int p = 64 * t + lane;
-        if (p < hapLen && first_group) {
-            const u64 v = funnel(eqp[t], eqp[t + 1], lane);
-            const int run = min(48, (int)__ffsll((long long)~v) - 1);     // trailing ones of v (v never has 64 ones beyond the cap)
-            hapw[hoff + p] = hap_word(hs[p], (unsigned)c_homopol_go[run < 0 ? 48 : run]);
-        }
         if (p < hapLen - 7) {
             const unsigned code = plane_code(h0[t], h0[t + 1], h1[t], h1[t + 1], lane);
             if (direct) {                               // u16 heads, two per dword: exchange one half with a CAS loop
@@ -389,8 +335,8 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         }
     }
     __syncthreads();
-    // ---- pass C: multiplicities: only a chain HEAD walks its chain; members of chains longer than one are flagged in
-    // nu, the longest chain gives maxmult
+    if (!exact_mult) return;
+    // only a chain HEAD walks its chain; the longest chain gives maxmult
     for (int t = wave; t < nch; t += nw) {
         const int p = 64 * t + lane;
         if (p < hapLen - 7) {
@@ -398,16 +344,139 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
             const unsigned hd = kmer_head(table, code, direct, tmask);
             if (hd == (unsigned)(p + 1) && nxt[hd] != 0u) {
                 int c = 0;
-                for (unsigned hh = hd; hh != 0u; hh = nxt[hh]) {
-                    ++c;
-                    const int q = (int)hh - 1;
-                    atomicOr((unsigned*)nup + 2 * (q >> 6) + ((q & 63) >> 5), 1u << (q & 31));
-                }
+                for (unsigned hh = hd; hh != 0u; hh = nxt[hh]) ++c;
                 atomicMax(&s_scal[1], c);
             }
         }
     }
     __syncthreads();
+}
+
+__global__ void __launch_bounds__(64)
+k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* __restrict__ win_rows,
+       const long long* __restrict__ tile_off, const ReadInfo* __restrict__ rinfo,
+       const uint16_t* __restrict__ codes, uint32_t* __restrict__ hapw, uint8_t* __restrict__ hap_has_n,
+       PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
+       int tsize_max, int maxhap, int cw, int want_stats)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nw64 = ((maxhap + 63) >> 6) + 8;           // plane words incl. slack for the shifted window of a hypothesis
+    unsigned* table = (unsigned*)smem;
+    unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);      // tsize_max = carve size >= 1536 dwords: the multiplicity maps overlay the table
+    u64* h0 = (u64*)(smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 7 & ~(size_t)7));
+    u64* h1 = h0 + nw64;
+    u64* eqp = h1 + nw64;
+    u64* nup = eqp + nw64;
+    unsigned* counts_all = (unsigned*)(nup + nw64);
+    int* s_scal = (int*)(counts_all + (size_t)(blockDim.x >> 6) * (cw >> 1));     // [0] has_n  [1] maxmult
+
+    const int h = blockIdx.x;
+    const int w = hap_win[h];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    {   // this workgroup's group of read chunks lies beyond the window's reads: nothing to do
+        const int Rw = b.win_read_begin[w + 1] - b.win_read_begin[w];
+        if (blockIdx.y > 0 && (int)blockIdx.y * SEED_CHUNKS * nw * 64 >= Rw) return;
+    }
+    const bool first_group = blockIdx.y == 0;            // writes the per-haplotype outputs (hapw, has_n)
+    const long long hoff = b.hap_off[h];
+    const int hapLen = (int)(b.hap_off[h + 1] - hoff);
+    const uint8_t* hs = b.hap_seq + hoff;
+    unsigned* counts = counts_all + (size_t)wave * (cw >> 1);
+
+    const bool direct = hapLen > 4096;
+    int tsize = 64;
+    if (direct) tsize = 16384;
+    else while (tsize < hapLen + hapLen / 4) tsize <<= 1;
+    const unsigned tmask = (unsigned)tsize - 1u;
+    const int nch = (hapLen + 63) >> 6;                  // chunks of 64 haplotype positions
+
+    // Setup, fast part: the proof of hypothesis A only needs the planes, nu and maxmult.  Multiplicities come from three
+    // 16384-bit maps over the 14-bit k-mer codes ("seen at least once / twice / three times"), filled with one LDS
+    // atomicOr per k-mer; they overlay the k-mer index, which is only built (seed_build_index) when some pair of this
+    // workgroup needs a look-up: hypothesis B, the no-vote test, the exact vote, or a multiplicity above 3.
+    unsigned* seen1 = table;
+    unsigned* seen2 = table + 512;
+    unsigned* seen3 = table + 1024;
+    if (tid < 2) s_scal[tid] = tid;                      // has_n = 0, maxmult = 1
+    signed char* s_go = (signed char*)(s_scal + 4);      // LDS copy of the gap-open table
+    if (tid < 49) s_go[tid] = c_homopol_go[tid];
+    for (int i = tid; i < 384; i += nthr) ((uint4*)table)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < 4 * nw64; i += nthr) h0[i] = 0ull;            // h0, h1, eqp, nup are contiguous
+    __syncthreads();
+    // ---- passes A + B, one sweep over the haplotype in chunks of 64 bases (nw == 1: this wave sees every chunk).
+    // A: planes by ballot.  B: a7 gap-open annotation (chaplotype.pyx:552-590): table[min(48, #following bytes equal to
+    // this one)], 'N' -> table[0], written together with the base as the DP's haplotype word; multiplicity maps of the
+    // k-mers at positions 0..hapLen-8 (the positions hash_sequence_multihit indexes, calign.pyx:109).
+    // B of chunk t needs the planes of chunks t and t+1 (and the first byte of t+2): the bytes are loaded three chunks
+    // ahead so that the global-load latency hides behind a whole iteration of work.
+    int level = 1;
+    {
+        auto ldb = [&](int t) -> unsigned { const int p = 64 * t + lane; return p < hapLen ? (unsigned)hs[p] : 0u; };
+        struct Planes { u64 m0, m1, me; };
+        auto mk = [&](int t, unsigned c, unsigned cnext_chunk) -> Planes {
+            const int p = 64 * t + lane;
+            if (c & 0x80u) set_err(cnt, PLAT_ERR_BAD_INPUT);             // 7-bit ASCII only (the DP packs bases as byte << 9)
+            unsigned cn = (unsigned)__shfl_down((int)c, 1);
+            const unsigned first_next = (unsigned)__shfl((int)cnext_chunk, 0);
+            if (lane == 63) cn = first_next;
+            const unsigned b2 = base2(c);                                // bytes past the end are 0 -> code 0
+            Planes P;
+            P.m0 = __ballot(p < hapLen && (b2 & 1u));
+            P.m1 = __ballot(p < hapLen && (b2 & 2u));
+            P.me = __ballot(p + 1 < hapLen && c == cn && c != (unsigned)'N');
+            if (__ballot(c == (unsigned)'N') && lane == 0) s_scal[0] = 1;
+            return P;
+        };
+        unsigned b0 = ldb(0), b1 = ldb(1), b2_ = ldb(2);
+        Planes P0 = mk(0, b0, b1), P1 = mk(1, b1, b2_);
+        for (int t = 0; t < nch; ++t) {
+            const unsigned b3 = ldb(t + 3);
+            const int p = 64 * t + lane;
+            if (lane == 0) { h0[t] = P0.m0; h1[t] = P0.m1; eqp[t] = P0.me; }
+            if (p < hapLen && first_group) {
+                const u64 v = funnel(P0.me, P1.me, lane);
+                const int run = min(48, (int)__ffsll((long long)~v) - 1);     // trailing ones of v (v never has 64 ones beyond the cap)
+                hapw[hoff + p] = hap_word(b0, (unsigned)s_go[run < 0 ? 48 : run]);
+            }
+            if (p < hapLen - 7) {
+                const unsigned code = plane_code(P0.m0, P1.m0, P0.m1, P1.m1, lane);
+                const unsigned wd = code >> 5, bit = 1u << (code & 31u);
+                if (atomicOr(&seen1[wd], bit) & bit) {
+                    level = max(level, 2);
+                    if (atomicOr(&seen2[wd], bit) & bit) {
+                        level = max(level, 3);
+                        if (atomicOr(&seen3[wd], bit) & bit) level = 4;
+                    }
+                }
+            }
+            b0 = b1; b1 = b2_; b2_ = b3;
+            P0 = P1;
+            P1 = mk(t + 2, b1, b2_);
+        }
+    }
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) level = max(level, __shfl_xor(level, s2));
+    if (lane == 0 && level > 1) atomicMax(&s_scal[1], level);
+    __syncthreads();
+    // ---- pass C: nu = "this k-mer occurs more than once"
+    for (int t = wave; t < nch; t += nw) {
+        const int p = 64 * t + lane;
+        bool dup = false;
+        if (p < hapLen - 7) {
+            const unsigned code = plane_code(h0[t], h0[t + 1], h1[t], h1[t + 1], lane);
+            dup = (seen2[code >> 5] >> (code & 31u)) & 1u;
+        }
+        const u64 md = __ballot(dup);
+        if (lane == 0) nup[t] = md;
+    }
+    __syncthreads();
+    bool have_index = false;
+    if (s_scal[1] >= 4) {                                // multiplicity 4 or more: the exact maximum comes from the index chains
+        __syncthreads();
+        seed_build_index(table, nxt, h0, h1, nup, s_scal, hapLen, nch, direct, tsize, tmask, true);
+        have_index = true;
+    }
     if (tid == 0 && first_group) hap_has_n[h] = (uint8_t)s_scal[0];
     const int maxmult = s_scal[1];
 
@@ -489,6 +558,11 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 if (run && X < C) proven = true;
             }
             if (attempt == 0) {
+                // everything below needs k-mer look-ups: build the index now if this workgroup (= one wave) has not yet
+                if (!have_index && __any(live && !proven)) {
+                    seed_build_index(table, nxt, h0, h1, nup, s_scal, hapLen, nch, direct, tsize, tmask, false);
+                    have_index = true;
+                }
                 // hypothesis B for the lanes A could not prove: diagonal of the first haplotype-unique k-mer
                 if (canfast && !proven) {
                     for (int i = 0; i < nk; ++i) {
@@ -884,16 +958,15 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
                              int maxread, int maxR, long long npairs, int extra_cap, const int32_t* hap_win, const int32_t* win_rows,
                              const long long* tile_off, int want_stats)
 {
-    int tsize_max = 64;                                        // in dwords (direct mode: 16384 u16 heads = 8192 dwords)
-    if (maxhap > 4096) tsize_max = 8192;
+    int tsize_max = 64;                                        // in dwords
+    if (maxhap > 4096) tsize_max = 8192;                       // direct mode: 16384 u16 heads
     else while (tsize_max < maxhap + maxhap / 4) tsize_max <<= 1;
+    if (tsize_max < 1536) tsize_max = 1536;                    // the 3 x 512 dwords of the multiplicity maps overlay the table
     const int cw = (maxhap + maxread + 8 + 1) & ~1;            // 16-bit counters, even count
     const size_t nw64 = (((size_t)maxhap + 63) >> 6) + 8;
-    const size_t fixed = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 7) & ~(size_t)7) + 4 * nw64 * 8 + 16;
+    const size_t fixed = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 7) & ~(size_t)7) + 4 * nw64 * 8 + 16 + 64;
     const size_t lds_cap = 160 * 1024;
-    int nw = 1;                                                // one wave per workgroup measured best (profiles/): setup is instruction-bound
-    if (const char* e = getenv("PLAT_SEED_NW")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) nw = v; }
-    while (nw > 1 && fixed + (size_t)nw * cw * 2 > lds_cap) nw >>= 1;
+    const int nw = 1;                                          // one wave per workgroup: the lazy index build is wave-local
     const size_t lds = fixed + (size_t)nw * cw * 2;
     if (lds > lds_cap) return PLAT_ERR_HAP_TOO_LONG;
     if (lds > 48 * 1024)
