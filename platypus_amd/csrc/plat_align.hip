@@ -290,6 +290,76 @@ __device__ __forceinline__ unsigned read_code(const u64* __restrict__ col, int R
     return plane_code(a_lo, a_hi, b_lo, b_hi, sh);
 }
 
+struct SlowRec { int32_t hap, rl; };     // a (haplotype, read-in-window) pair the bit-parallel proof left undecided
+
+// The reference's diagonal vote for ONE pair (calign.pyx:206-233,252-267), worked by a whole wave: counts in 16-bit LDS
+// counters (two per dword, 32-bit LDS atomics), candidates emitted in ascending diagonal order.  `counts` must be zero on entry and is zero again on exit.
+__device__ __forceinline__ void seed_exact_vote(const unsigned* table, const unsigned short* nxt, unsigned* counts, bool direct,
+                                                unsigned tmask, int hapLen, int h, const u64* scp, int R, int sL, int sidx0,
+                                                unsigned scol, int smapq, long long spidx, long long npairs, int extra_cap,
+                                                Job* __restrict__ jobs, PairRec* __restrict__ pairs, long long* cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = hapLen + sL, snk = sL - 7, j0i = sidx0 + sL;
+    // pass 1: diagonal vote, calign.pyx:209-220
+    unsigned mymax = 0;
+    for (int i = lane; i < snk; i += 64) {
+        unsigned hidx = kmer_head(table, read_code(scp, R, i), direct, tmask);
+        while (hidx != 0u) {
+            const int j = (int)hidx - i - 1 + sL;
+            const unsigned sh = 16u * (unsigned)(j & 1);
+            const unsigned c = ((atomicAdd(&counts[j >> 1], 1u << sh) >> sh) & 0x7FFFu) + 1u;
+            mymax = max(mymax, c);
+            hidx = nxt[hidx];
+        }
+    }
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) mymax = max(mymax, (unsigned)__shfl_xor((int)mymax, s2));
+    const unsigned maxcount = mymax;
+    const bool s_orig_in = maxcount > 0 && j0i >= 0 && j0i < n && CNT16(counts, j0i) == maxcount && sidx0 + sL + 15 < hapLen;
+    // the arg-max diagonals that may be aligned (calign.pyx:228), found by scanning this read's counters
+    int sncand = 0, myidx = 0x7FFFFFFF;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const bool is = maxcount > 0 && j < n && CNT16(counts, j) == maxcount && (j - sL) + sL + 15 < hapLen;
+        const unsigned long long bal = __ballot(is);
+        if (bal && myidx == 0x7FFFFFFF) myidx = j0 + (int)__ffsll((long long)bal) - 1 - sL;
+        sncand += __popcll(bal);
+    }
+    const int njobs = sncand + (s_orig_in ? 0 : 1);
+    int sbase = 0;
+    if (njobs > 1) {
+        if (lane == 0) sbase = (int)atomicAdd((unsigned long long*)&cnt[CNT_NEXTRA], (unsigned long long)(njobs - 1));
+        sbase = __shfl(sbase, 0);
+    }
+    const bool fits = njobs == 1 || (long long)sbase + (njobs - 1) <= (long long)extra_cap;
+    int orig_k = sncand;
+    if (sncand == 1) {
+        if (lane == 0) jobs[spidx] = Job{scol, h, myidx, sL};
+        if (s_orig_in) orig_k = 0;
+    } else if (sncand > 1) {
+        // ordered emission (ascending diagonal, calign.pyx:223) by scanning this read's counters
+        int k = 0;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            const bool is = j < n && CNT16(counts, j) == maxcount && (j - sL) + sL + 15 < hapLen;
+            const unsigned long long bal = __ballot(is);
+            if (is) {
+                const int mypos = k + __popcll(bal & ((1ull << lane) - 1ull));
+                if (fits || mypos == 0) jobs[job_slot(spidx, npairs, sbase, mypos)] = Job{scol, h, j - sL, sL};
+            }
+            if (s_orig_in && j0i >= j0 && j0i < j0 + 64) orig_k = k + __popcll(bal & ((1ull << (j0i - j0)) - 1ull));
+            k += __popcll(bal);
+        }
+    }
+    if (lane == 0) {
+        if (!s_orig_in && (fits || sncand == 0)) jobs[job_slot(spidx, npairs, sbase, sncand)] = Job{scol, h, sidx0, sL};
+        pairs[spidx] = PairRec{sbase, sidx0, (int16_t)sncand, (int16_t)orig_k, (uint8_t)smapq, {0, 0, 0}};
+    }
+    // all counters back to zero (cheaper than walking the chains again)
+    for (int j = lane; j < ((n + 2) >> 1); j += 64) counts[j] = 0u;
+}
+
 // a4: the haplotype's k-mer index (hash_sequence_multihit, calign.pyx:94-124) in LDS: positions 0..hapLen-8, entry =
 // (code+1)<<16 | (pos+1) in an open-addressing table (or u16 heads indexed by code when direct), equal codes chained
 // through nxt[] from the LAST position to the first.  exact_mult: also walk the chains for the largest multiplicity.
@@ -357,7 +427,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
        const long long* __restrict__ tile_off, const ReadInfo* __restrict__ rinfo,
        const uint16_t* __restrict__ codes, uint32_t* __restrict__ hapw, uint8_t* __restrict__ hap_has_n,
        PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
-       int tsize_max, int maxhap, int cw, int want_stats)
+       SlowRec* __restrict__ slow_list, int tsize_max, int maxhap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nw64 = ((maxhap + 63) >> 6) + 8;           // plane words incl. slack for the shifted window of a hypothesis
@@ -367,8 +437,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     u64* h1 = h0 + nw64;
     u64* eqp = h1 + nw64;
     u64* nup = eqp + nw64;
-    unsigned* counts_all = (unsigned*)(nup + nw64);
-    int* s_scal = (int*)(counts_all + (size_t)(blockDim.x >> 6) * (cw >> 1));     // [0] has_n  [1] maxmult
+    int* s_scal = (int*)(nup + nw64);                    // [0] has_n  [1] maxmult, then the gap-open table
 
     const int h = blockIdx.x;
     const int w = hap_win[h];
@@ -382,7 +451,6 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     const long long hoff = b.hap_off[h];
     const int hapLen = (int)(b.hap_off[h + 1] - hoff);
     const uint8_t* hs = b.hap_seq + hoff;
-    unsigned* counts = counts_all + (size_t)wave * (cw >> 1);
 
     const bool direct = hapLen > 4096;
     int tsize = 64;
@@ -486,7 +554,6 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     const long long pbase = b.pair_off[w] + (long long)hl * R;
     const u64* rd2 = (const u64*)(codes + tile_off[w]);
     const int nkp = hapLen - 7;                          // haplotype k-mer positions 0..hapLen-8 (calign.pyx:109)
-    bool counts_clean = false;
 
     // reads are processed in chunks of 64 (one lane per read); blockIdx.y selects a group of SEED_CHUNKS chunks so that
     // windows with thousands of reads (population mode) spread over many workgroups (each rebuilds the small index)
@@ -611,98 +678,80 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 pairs[pidx] = PairRec{base, idx0, (int16_t)ncand, (int16_t)(orig_in ? 0 : ncand), mapq, {0, 0, 0}};
             }
         }
-        // ---- exact vote for the pairs that could not be decided: the whole wave works on one pair at a time
-        unsigned long long todo = __ballot(valid && !decided);
-        if (want_stats && todo && lane == 0) atomicAdd((unsigned long long*)&cnt[CNT_SLOW_SEED], (unsigned long long)__popcll(todo));
-        while (todo) {
-            const int src = (int)__ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int sL = __shfl(L, src), sidx0 = __shfl(idx0, src);
-            const unsigned scol = (unsigned)__shfl((int)ri.col, src);
-            const int smapq = __shfl((int)mapq, src);
-            const long long spidx = pbase + c0 + src;
-            const int n = hapLen + sL, snk = sL - 7, j0i = sidx0 + sL;
-            const u64* scp = rd2 + (c0 + src);
-            if (!counts_clean) {
-                for (int j = lane; j < (cw >> 1); j += 64) counts[j] = 0u;
-                counts_clean = true;
-            }
-            // pass 1: diagonal vote, calign.pyx:209-220
-            unsigned mymax = 0;
-            for (int i = lane; i < snk; i += 64) {
-                unsigned hidx = kmer_head(table, read_code(scp, R, i), direct, tmask);
-                while (hidx != 0u) {
-                    const int j = (int)hidx - i - 1 + sL;
-                    const unsigned sh = 16u * (unsigned)(j & 1);
-                    const unsigned c = ((atomicAdd(&counts[j >> 1], 1u << sh) >> sh) & 0x7FFFu) + 1u;
-                    mymax = max(mymax, c);
-                    hidx = nxt[hidx];
+        // ---- pairs that could not be decided go to the exact vote in k_seed_slow (one wave per pair, spread over the
+        // whole device: a tandem-repeat window would otherwise serialise all its reads on this one wave)
+        const unsigned long long todo = __ballot(valid && !decided);
+        if (todo) {
+            long long sb = 0;
+            if (lane == 0) sb = (long long)atomicAdd((unsigned long long*)&cnt[CNT_SLOW_SEED], (unsigned long long)__popcll(todo));
+            sb = __shfl((int)sb, 0);
+            if (valid && !decided) slow_list[sb + __popcll(todo & ((1ull << lane) - 1ull))] = SlowRec{h, rl};
+        }
+    }
+}
+
+// k_seed_slow: the exact vote for the pairs k_seed queued.  Persistent grid; a workgroup (one wave) takes groups of 4 (1 when the queue is short)
+// consecutive queue entries (entries of one k_seed wave are consecutive and share their haplotype) and rebuilds the
+// haplotype's planes and k-mer index only when the haplotype changes.  Same LDS carve as k_seed.
+__global__ void __launch_bounds__(64)
+k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long long* __restrict__ tile_off,
+            const ReadInfo* __restrict__ rinfo, const uint16_t* __restrict__ codes, PairRec* __restrict__ pairs,
+            Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt, const SlowRec* __restrict__ slow_list,
+            int tsize_max, int maxhap, int cw)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nw64 = ((maxhap + 63) >> 6) + 8;
+    unsigned* table = (unsigned*)smem;
+    unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);
+    u64* h0 = (u64*)(smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 7 & ~(size_t)7));
+    u64* h1 = h0 + nw64;
+    u64* nup = h1 + 2 * nw64;
+    unsigned* counts = (unsigned*)(nup + nw64);
+    int* s_scal = (int*)(counts + (cw >> 1));
+    const int lane = threadIdx.x & 63;
+    long long nslow = cnt[CNT_SLOW_SEED];
+    if (nslow > npairs) nslow = npairs;
+    for (int j = lane; j < (cw >> 1); j += 64) counts[j] = 0u;
+    int cur = -1, hapLen = 0, tsize = 64;
+    bool direct = false;
+    unsigned tmask = 0;
+    const long long G = nslow <= 4 * (long long)gridDim.x ? 1 : 4;       // few entries: one each, for the shortest critical path
+    for (long long g = blockIdx.x; G * g < nslow; g += gridDim.x) {
+        for (long long e = G * g; e < min(nslow, G * g + G); ++e) {
+            const SlowRec rec = slow_list[e];
+            const int h = rec.hap, w = hap_win[h];
+            if (h != cur) {
+                cur = h;
+                const long long hoff = b.hap_off[h];
+                hapLen = (int)(b.hap_off[h + 1] - hoff);
+                const uint8_t* hs = b.hap_seq + hoff;
+                direct = hapLen > 4096;
+                tsize = 64;
+                if (direct) tsize = 16384;
+                else while (tsize < hapLen + hapLen / 4) tsize <<= 1;
+                tmask = (unsigned)tsize - 1u;
+                const int nch = (hapLen + 63) >> 6;
+                __syncthreads();
+                for (int i = lane; i < 2 * nw64; i += 64) h0[i] = 0ull;                  // h0, h1 contiguous
+                __syncthreads();
+                for (int t = 0; t < nch; ++t) {
+                    const int p = 64 * t + lane;
+                    const unsigned b2 = p < hapLen ? base2(hs[p]) : 0u;
+                    const u64 m0 = __ballot(b2 & 1u), m1 = __ballot(b2 & 2u);
+                    if (lane == 0) { h0[t] = m0; h1[t] = m1; }
                 }
+                __syncthreads();
+                seed_build_index(table, nxt, h0, h1, nup, s_scal, hapLen, nch, direct, tsize, tmask, false);
             }
-#pragma unroll
-            for (int s2 = 32; s2 > 0; s2 >>= 1) mymax = max(mymax, (unsigned)__shfl_xor((int)mymax, s2));
-            const unsigned maxcount = mymax;
-            const bool s_orig_in = maxcount > 0 && j0i >= 0 && j0i < n && CNT16(counts, j0i) == maxcount && sidx0 + sL + 15 < hapLen;
-            // pass 2: one representative lane per arg-max diagonal (claim bit 15); count the valid ones
-            int sncand = 0, myidx = 0x7FFFFFFF;
-            for (int i = lane; i < snk; i += 64) {
-                unsigned hidx = kmer_head(table, read_code(scp, R, i), direct, tmask);
-                while (hidx != 0u) {
-                    const int j = (int)hidx - i - 1 + sL;
-                    const unsigned sh = 16u * (unsigned)(j & 1);
-                    if (((counts[j >> 1] >> sh) & 0xFFFFu) == maxcount) {            // arg-max and not yet claimed
-                        const unsigned old = atomicOr(&counts[j >> 1], 0x8000u << sh);
-                        if (!((old >> sh) & 0x8000u) && (j - sL) + sL + 15 < hapLen) {   // calign.pyx:228
-                            myidx = min(myidx, j - sL);
-                            ++sncand;
-                        }
-                    }
-                    hidx = nxt[hidx];
-                }
-            }
-#pragma unroll
-            for (int s2 = 32; s2 > 0; s2 >>= 1) {
-                sncand += __shfl_xor(sncand, s2);
-                myidx = min(myidx, __shfl_xor(myidx, s2));
-            }
-            const int njobs = sncand + (s_orig_in ? 0 : 1);
-            int sbase = 0;
-            if (njobs > 1) {
-                if (lane == 0) sbase = (int)atomicAdd((unsigned long long*)&cnt[CNT_NEXTRA], (unsigned long long)(njobs - 1));
-                sbase = __shfl(sbase, 0);
-            }
-            const bool fits = njobs == 1 || (long long)sbase + (njobs - 1) <= (long long)extra_cap;
-            int orig_k = sncand;
-            if (sncand == 1) {
-                if (lane == 0) jobs[spidx] = Job{scol, h, myidx, sL};
-                if (s_orig_in) orig_k = 0;
-            } else if (sncand > 1) {
-                // ordered emission (ascending diagonal, calign.pyx:223) by scanning this read's counters
-                int k = 0;
-                for (int j0 = 0; j0 < n; j0 += 64) {
-                    const int j = j0 + lane;
-                    const bool is = j < n && CNT16(counts, j) == maxcount && (j - sL) + sL + 15 < hapLen;
-                    const unsigned long long bal = __ballot(is);
-                    if (is) {
-                        const int mypos = k + __popcll(bal & ((1ull << lane) - 1ull));
-                        if (fits || mypos == 0) jobs[job_slot(spidx, npairs, sbase, mypos)] = Job{scol, h, j - sL, sL};
-                    }
-                    if (s_orig_in && j0i >= j0 && j0i < j0 + 64) orig_k = k + __popcll(bal & ((1ull << (j0i - j0)) - 1ull));
-                    k += __popcll(bal);
-                }
-            }
-            if (lane == 0) {
-                if (!s_orig_in && (fits || sncand == 0)) jobs[job_slot(spidx, npairs, sbase, sncand)] = Job{scol, h, sidx0, sL};
-                pairs[spidx] = PairRec{sbase, sidx0, (int16_t)sncand, (int16_t)orig_k, (uint8_t)smapq, {0, 0, 0}};
-            }
-            // pass 3: clear the counters this read touched
-            for (int i = lane; i < snk; i += 64) {
-                unsigned hidx = kmer_head(table, read_code(scp, R, i), direct, tmask);
-                while (hidx != 0u) {
-                    counts[((int)hidx - i - 1 + sL) >> 1] = 0u;
-                    hidx = nxt[hidx];
-                }
-            }
+            const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
+            const ReadInfo ri = rinfo[rb + rec.rl];
+            const int L = (int)(ri.lfm & 0xFFFFu);
+            const int hapStart = b.win_start[w] - b.win_flank[w];                        // chaplotype.pyx:606
+            const int idx0 = min(ri.pos - hapStart, hapLen - L - 15);                    // calign.pyx:252
+            const long long pidx = b.pair_off[w] + (long long)(h - b.win_hap_begin[w]) * R + rec.rl;
+            const u64* scp = (const u64*)(codes + tile_off[w]) + rec.rl;
+            seed_exact_vote(table, nxt, counts, direct, tmask, hapLen, h, scp, R, L, idx0, ri.col, (int)(ri.lfm >> 24), pidx,
+                            npairs, extra_cap, jobs, pairs, cnt);
         }
     }
 }
@@ -956,25 +1005,30 @@ PLAT_EXPORT int plat_dp_batch(plat_ctx* ctx, int n, int lmax, const uint8_t* hap
 
 static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStream_t st, long long* cnt, int maxhap,
                              int maxread, int maxR, long long npairs, int extra_cap, const int32_t* hap_win, const int32_t* win_rows,
-                             const long long* tile_off, int want_stats)
+                             const long long* tile_off)
 {
     int tsize_max = 64;                                        // in dwords
     if (maxhap > 4096) tsize_max = 8192;                       // direct mode: 16384 u16 heads
     else while (tsize_max < maxhap + maxhap / 4) tsize_max <<= 1;
     if (tsize_max < 1536) tsize_max = 1536;                    // the 3 x 512 dwords of the multiplicity maps overlay the table
-    const int cw = (maxhap + maxread + 8 + 1) & ~1;            // 16-bit counters, even count
+    const int cw = (maxhap + maxread + 8 + 1) & ~1;            // 16-bit diagonal counters of the exact vote, even count
     const size_t nw64 = (((size_t)maxhap + 63) >> 6) + 8;
-    const size_t fixed = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 7) & ~(size_t)7) + 4 * nw64 * 8 + 16 + 64;
-    const size_t lds_cap = 160 * 1024;
-    const int nw = 1;                                          // one wave per workgroup: the lazy index build is wave-local
-    const size_t lds = fixed + (size_t)nw * cw * 2;
-    if (lds > lds_cap) return PLAT_ERR_HAP_TOO_LONG;
+    const size_t lds = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 7) & ~(size_t)7) + 4 * nw64 * 8 + 16 + 64;
+    const size_t lds_slow = lds + (size_t)cw * 2;
+    if (lds_slow > 160 * 1024) return PLAT_ERR_HAP_TOO_LONG;
     if (lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int ngroups = (maxR + SEED_CHUNKS * nw * 64 - 1) / (SEED_CHUNKS * nw * 64);
-    hipLaunchKernelGGL(k_seed, dim3(b.n_haps, ngroups > 0 ? ngroups : 1), dim3(64 * nw), lds, st, b, hap_win, win_rows, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
-                       (const uint16_t*)ctx->codes.ptr, (uint32_t*)ctx->hapw.ptr, (uint8_t*)ctx->hap_flags.ptr,
-                       (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt, tsize_max, maxhap, cw, want_stats);
+    if (lds_slow > 48 * 1024)
+        PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_seed_slow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_slow));
+    // one wave per workgroup (the lazy index build is wave-local); blockIdx.y = group of SEED_CHUNKS x 64 reads
+    const int ngroups = (maxR + SEED_CHUNKS * 64 - 1) / (SEED_CHUNKS * 64);
+    hipLaunchKernelGGL(k_seed, dim3(b.n_haps, ngroups > 0 ? ngroups : 1), dim3(64), lds, st, b, hap_win, win_rows, tile_off,
+                       (const ReadInfo*)ctx->rinfo.ptr, (const uint16_t*)ctx->codes.ptr, (uint32_t*)ctx->hapw.ptr,
+                       (uint8_t*)ctx->hap_flags.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
+                       (SlowRec*)ctx->slow.ptr, tsize_max, maxhap);
+    hipLaunchKernelGGL(k_seed_slow, dim3(4096), dim3(64), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
+                       (const uint16_t*)ctx->codes.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
+                       (const SlowRec*)ctx->slow.ptr, tsize_max, maxhap, cw);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -1035,6 +1089,7 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     if ((rc = plat_reserve(ctx, ctx->tile, ((size_t)tile_total + 64) * 4))) return rc;
     if ((rc = plat_reserve(ctx, ctx->codes, ((size_t)tile_total + 64) * 2))) return rc;
     if ((rc = plat_reserve(ctx, ctx->pair_rec, (size_t)npairs * sizeof(PairRec)))) return rc;
+    if ((rc = plat_reserve(ctx, ctx->slow, (size_t)npairs * sizeof(SlowRec)))) return rc;
     long long extra_cap = npairs / 4 + 4096;
     if ((long long)(ctx->jobs.cap / sizeof(Job)) - npairs > extra_cap) extra_cap = (long long)(ctx->jobs.cap / sizeof(Job)) - npairs;
     if (extra_cap > 0x7FFFFF00ll) extra_cap = 0x7FFFFF00ll;
@@ -1052,7 +1107,8 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = plat_reserve(ctx, ctx->jobs, (size_t)(npairs + extra_cap) * sizeof(Job)))) return rc;
         PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_NEXTRA], 0, sizeof(long long), st));
-        if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win, win_rows, tile_off, out_stats != NULL))) return rc;
+        PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_SLOW_SEED], 0, sizeof(long long), st));
+        if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win, win_rows, tile_off))) return rc;
         PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
         PLAT_HIP(ctx, hipStreamSynchronize(st));
         if (hb[CNT_ERR] != 0) return (int)hb[CNT_ERR];
