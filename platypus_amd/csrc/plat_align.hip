@@ -29,17 +29,18 @@ namespace plat {
 // (tandem repeats: many arg-max diagonals) go to an overflow area behind the npairs primary slots, reserved
 // with one global atomic per such pair.  (A single job counter bumped by every pair saturates one L2
 // atomic unit: ~90 atomics/us, i.e. ~20 ms for 2M pairs -- measured in round 1.)
-struct PairRec { int32_t extra_base, idx0; int16_t ncand, orig_k; uint8_t mapq, pad[3]; };   // ncand: -1 skipped, -2 read < 7 bp
+struct PairRec { int32_t extra_base, idx0; int16_t ncand, orig_k; uint8_t mapq, pad[3]; };   // ncand: -1 skipped, -2 read < 7 bp, -3 exact match (idx0 = read length)
 struct Job { uint32_t col; int32_t hap, idx, len; };     // col = tile dword index of the read's column; len 0 = empty slot
 // per-read descriptor: tile column, offset of the k-mer codes, mapping position, len | flags<<16 | mapq<<24
-// (flags bit0: skipped by the QCFail / overlap < 7 rule)
+// (flags bit0: skipped by the QCFail / overlap < 7 rule; bit1: the read holds a byte other than A, C, G, T)
 struct ReadInfo { uint32_t col, code_off; int32_t pos; uint32_t lfm; };
 __device__ __forceinline__ long long job_slot(long long pair, long long npairs, int extra_base, int k) {
     return k == 0 ? pair : npairs + extra_base + (k - 1);
 }
 
 enum { CNT_ERR = 0, CNT_MAXHAP, CNT_MAXREAD, CNT_NEXTRA, CNT_PAIRS_ALIGNED, CNT_NDP_REF, CNT_CELLS_REF, CNT_CELLS_RUN,
-       CNT_NJOBS_RUN, CNT_TILE_TOTAL, CNT_SLOW_SEED, CNT_MAXH, CNT_T0, CNT_T1, CNT_T2, CNT_T3, CNT_T4, CNT_N };
+       CNT_NJOBS_RUN, CNT_TILE_TOTAL, CNT_SLOW_SEED, CNT_MAXH, CNT_NDENSE, CNT_T0, CNT_T1, CNT_T2, CNT_T3, CNT_T4, CNT_N };
+static_assert(CNT_N <= 32, "the pinned read-back area keeps the counters in [0,32) and three blob lengths at 32..34");
 
 __constant__ signed char c_homopol_go[49] = {   // homopolq[i]-'!' (chaplotype.pyx:64-67); see tests/test_oracle.py
     45, 42, 41, 39, 37, 32, 28, 23, 20, 19, 17, 16, 15, 14, 13, 12, 11, 11, 10, 9, 9, 8, 8, 7, 7, 7, 6, 6, 6, 5, 5, 5,
@@ -94,9 +95,12 @@ k_validate(plat_window_batch b, long long* cnt, int32_t* __restrict__ hap_win, i
     atomicMax(&s_max[0], maxhap); atomicMax(&s_max[1], maxread); atomicMax(&s_max[2], maxR);
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicMax((unsigned long long*)&cnt[CNT_MAXHAP], (unsigned long long)s_max[0]);
-        atomicMax((unsigned long long*)&cnt[CNT_MAXREAD], (unsigned long long)s_max[1]);
-        atomicMax((unsigned long long*)&cnt[CNT_MAXH], (unsigned long long)s_max[2]);
+        // thousands of workgroups hitting three words of one cache line serialise in the L2 (~90 atomics/us): look first,
+        // most workgroups find their maxima already there
+        const int idx[3] = {CNT_MAXHAP, CNT_MAXREAD, CNT_MAXH};
+        for (int k = 0; k < 3; ++k)
+            if ((long long)s_max[k] > __atomic_load_n(&cnt[idx[k]], __ATOMIC_RELAXED))
+                atomicMax((unsigned long long*)&cnt[idx[k]], (unsigned long long)s_max[k]);
     }
 }
 
@@ -149,6 +153,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
     __shared__ int s_off[65];
+    __shared__ unsigned s_dirty[2];                      // bit rl: read rl of the group holds a byte other than A, C, G, T
     const int w = blockIdx.x;
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
     const int c0 = (int)blockIdx.y * 64;
@@ -184,20 +189,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
         }
         if (bad & 0x80808080u) set_err(cnt, PLAT_ERR_BAD_INPUT);
     }
-    const int wstart = b.win_start[w], wend = b.win_end[w];
-    if (tid < nr) {
-        const int r = rb + c0 + tid;
-        const int L = (int)(b.read_off[r + 1] - b.read_off[r]);
-        // skip rule, chaplotype.pyx:343-346 / 358-361 (brokenMates are always aligned, :366-373)
-        int skip = 0;
-        if (b.read_kind[r] != 2) {
-            const int os = max(wstart, b.read_pos[r]), oe = min(wend, b.read_end[r]);
-            const int ov = oe > os ? oe - os : -1;                       // chaplotype.pyx:103-115
-            skip = (b.read_flags[r] & 512) || ov < 7;
-        }
-        rinfo[r] = ReadInfo{(uint32_t)(toff + c0 + tid), 0u, b.read_pos[r],
-                            (uint32_t)L | ((uint32_t)skip << 16) | ((uint32_t)b.read_mapq[r] << 24)};
-    }
+    if (tid < 2) s_dirty[tid] = 0u;
     __syncthreads();
     const unsigned char* gs = b.read_seq + blob0;
     const unsigned char* gq = b.read_qual + blob0;
@@ -211,7 +203,11 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             const int rl = e - i * nr;
             const int o = s_off[rl], L = s_off[rl + 1] - o;
             uint32_t wd = READ_PAD_WORD;
-            if (i < L) wd = staged ? read_word(lseq[o + i], lqual[o + i]) : read_word(gs[o + i], gq[o + i]);
+            if (i < L) {
+                const unsigned ch = staged ? lseq[o + i] : gs[o + i];
+                wd = read_word(ch, staged ? lqual[o + i] : gq[o + i]);
+                if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') atomicOr(&s_dirty[rl >> 5], 1u << (rl & 31));
+            }
             tile[toff + (long long)i * R + c0 + rl] = wd;
         }
     }
@@ -234,6 +230,22 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             rd2[(long long)(2 * c) * R + c0 + lane] = my0;
             rd2[(long long)(2 * c + 1) * R + c0 + lane] = my1;
         }
+    }
+    __syncthreads();
+    const int wstart = b.win_start[w], wend = b.win_end[w];
+    if (tid < nr) {
+        const int r = rb + c0 + tid;
+        const int L = (int)(b.read_off[r + 1] - b.read_off[r]);
+        // skip rule, chaplotype.pyx:343-346 / 358-361 (brokenMates are always aligned, :366-373)
+        int skip = 0;
+        if (b.read_kind[r] != 2) {
+            const int os = max(wstart, b.read_pos[r]), oe = min(wend, b.read_end[r]);
+            const int ov = oe > os ? oe - os : -1;                       // chaplotype.pyx:103-115
+            skip = (b.read_flags[r] & 512) || ov < 7;
+        }
+        const unsigned dirty = (s_dirty[tid >> 5] >> (tid & 31)) & 1u;
+        rinfo[r] = ReadInfo{(uint32_t)(toff + c0 + tid), 0u, b.read_pos[r],
+                            (uint32_t)L | ((uint32_t)skip << 16) | (dirty << 17) | ((uint32_t)b.read_mapq[r] << 24)};
     }
 }
 
@@ -466,7 +478,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     unsigned* seen1 = table;
     unsigned* seen2 = table + 512;
     unsigned* seen3 = table + 1024;
-    if (tid < 2) s_scal[tid] = tid;                      // has_n = 0, maxmult = 1
+    if (tid < 3) s_scal[tid] = tid == 1;                 // has_n = 0, maxmult = 1, other-than-ACGTN = 0
     signed char* s_go = (signed char*)(s_scal + 4);      // LDS copy of the gap-open table
     if (tid < 49) s_go[tid] = c_homopol_go[tid];
     for (int i = tid; i < 384; i += nthr) ((uint4*)table)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -494,6 +506,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
             P.m1 = __ballot(p < hapLen && (b2 & 2u));
             P.me = __ballot(p + 1 < hapLen && c == cn && c != (unsigned)'N');
             if (__ballot(c == (unsigned)'N') && lane == 0) s_scal[0] = 1;
+            if (__ballot(p < hapLen && c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') && lane == 0) s_scal[2] = 1;
             return P;
         };
         unsigned b0 = ldb(0), b1 = ldb(1), b2_ = ldb(2);
@@ -547,6 +560,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     }
     if (tid == 0 && first_group) hap_has_n[h] = (uint8_t)s_scal[0];
     const int maxmult = s_scal[1];
+    const bool hap_plain = s_scal[2] == 0;               // only A, C, G, T, N: equal 2-bit codes of plain read bases mean equal bytes or a haplotype N
 
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
     const int hl = h - b.win_hap_begin[w];
@@ -588,7 +602,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
             r1[c] = c < nCl ? col[(long long)(2 * c + 1) * R] : 0ull;
         }
         int dstar = idx0;
-        bool proven = false, triedB = false;
+        bool proven = false, triedB = false, exact = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool run = canfast && !proven && dstar >= 0 && (attempt == 0 || triedB);
             if (__any(run)) {
@@ -622,7 +636,17 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                     }
                 }
                 const int X = NUc * (maxmult - 1) + (nk - C) * maxmult;
-                if (run && X < C) proven = true;
+                if (run && X < C) {
+                    proven = true;
+                    // does the whole read match the haplotype on d*?  (Z: one bit per base, 1 = equal codes)
+                    u64 miss = 0ull;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int nb = L - 64 * c;
+                        miss |= ~Z[c] & (nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull)));
+                    }
+                    exact = miss == 0ull;
+                }
             }
             if (attempt == 0) {
                 // everything below needs k-mer look-ups: build the index now if this workgroup (= one wave) has not yet
@@ -656,10 +680,14 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         int ncand = 0, cidx = idx0;
         bool orig_in = false;
         if (live && proven && dstar + L + 15 < hapLen) { ncand = 1; cidx = dstar; orig_in = (idx0 == dstar); }   // calign.pyx:228
+        // The read equals the haplotype on the one candidate diagonal: that DP scores 0 (no cost is negative and the
+        // all-match path costs 0; a haplotype N costs 0 as well, align.c:17,314-318) and calign.pyx:242-247 returns it
+        // at once.  No DP is launched for the pair.
+        const bool zero = ncand == 1 && exact && hap_plain && !((rflags >> 1) & 1);
         // extra job slot for (one candidate that is not the mapping position): one atomic per wave
         int base = 0;
         {
-            const bool need = decided && live && ncand == 1 && !orig_in;
+            const bool need = decided && live && ncand == 1 && !orig_in && !zero;
             const unsigned long long m = __ballot(need);
             if (m) {
                 int wb = 0;
@@ -673,6 +701,9 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
             if (!live) {
                 pairs[pidx] = PairRec{0, 0, (int16_t)((skipped || hapshort) ? -1 : -2), 0, mapq, {0, 0, 0}};
                 jobs[pidx] = Job{ri.col, h, 0, 0};
+            } else if (zero) {
+                pairs[pidx] = PairRec{0, L, (int16_t)-3, 0, mapq, {0, 0, 0}};
+                jobs[pidx] = Job{ri.col, h, cidx, 0};
             } else {
                 jobs[pidx] = Job{ri.col, h, cidx, L};
                 pairs[pidx] = PairRec{base, idx0, (int16_t)ncand, (int16_t)(orig_in ? 0 : ncand), mapq, {0, 0, 0}};
@@ -756,6 +787,77 @@ k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long
     }
 }
 
+__device__ __forceinline__ double loglik_of(int score, const double* __restrict__ mapq_lut, int mapq) {
+    const double v = -0.23025850929940459 * (double)score + mapq_lut[mapq];   // chaplotype.pyx:676 (no FMA: -ffp-contract=off)
+    return v > -300.0 ? v : -300.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Job compaction.  Slot j < npairs belongs to pair j, slots npairs.. hold the extra candidates; slots of pairs that need
+// no DP (skipped reads, reads < 7 bp, exact matches) are empty (len 0).  One lane per DP means an empty slot would idle a
+// lane for the whole DP, so the live slots are listed densely (in slot order: neighbouring lanes keep neighbouring reads
+// of one haplotype, i.e. coalesced tile columns).  k_compact_count also finishes the pairs that need no DP.
+constexpr int COMPACT_BLOCK = 1024;
+
+__global__ void __launch_bounds__(COMPACT_BLOCK)
+k_compact_count(const Job* __restrict__ jobs, const PairRec* __restrict__ pairs, const double* __restrict__ mapq_lut,
+                long long npairs, long long extra_cap, const long long* __restrict__ cnt, int32_t* __restrict__ block_cnt,
+                double* __restrict__ out_ll, int32_t* __restrict__ out_score)
+{
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const long long nslots = npairs + min(cnt[CNT_NEXTRA], extra_cap);   // more than extra_cap: the host re-runs the seeding
+    const long long j = (long long)blockIdx.x * COMPACT_BLOCK + threadIdx.x;
+    bool live = false;
+    if (j < nslots) {
+        live = jobs[j].len != 0;
+        if (j < npairs && !live) {
+            const PairRec pr = pairs[j];
+            if (pr.ncand < 0) {                          // skipped read: 0.0 (chaplotype.pyx:345-346); read < 7 bp or exact match: score 0
+                out_ll[j] = pr.ncand == -1 ? 0.0 : loglik_of(0, mapq_lut, pr.mapq);
+                if (out_score) out_score[j] = pr.ncand == -1 ? -1 : 0;
+            }
+        }
+    }
+    const unsigned long long m = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_n, (int)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_n;
+}
+
+__global__ void __launch_bounds__(COMPACT_BLOCK)
+k_compact_scatter(const Job* __restrict__ jobs, long long npairs, long long extra_cap, long long* __restrict__ cnt,
+                  const int32_t* __restrict__ block_cnt, int32_t* __restrict__ dense)
+{
+    __shared__ long long s_part[COMPACT_BLOCK / 64];
+    __shared__ int s_wave[COMPACT_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long nslots = npairs + min(cnt[CNT_NEXTRA], extra_cap);
+    // exclusive prefix of this block = sum of the counts of all blocks before it
+    long long acc = 0;
+    for (int i = tid; i < (int)blockIdx.x; i += COMPACT_BLOCK) acc += block_cnt[i];
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) acc += __shfl_xor(acc, s2);
+    if (lane == 0) s_part[wv] = acc;
+    const long long j = (long long)blockIdx.x * COMPACT_BLOCK + tid;
+    const bool live = j < nslots && jobs[j].len != 0;
+    const unsigned long long m = __ballot(live);
+    if (lane == 0) s_wave[wv] = (int)__popcll(m);
+    __syncthreads();
+    long long base = 0;
+    for (int i = 0; i < COMPACT_BLOCK / 64; ++i) base += s_part[i];
+    for (int i = 0; i < wv; ++i) base += s_wave[i];
+    if (live) dense[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)j;
+    if (blockIdx.x == gridDim.x - 1 && tid == COMPACT_BLOCK - 1) {
+        int tot = 0;
+        for (int i = 0; i < COMPACT_BLOCK / 64; ++i) tot += s_wave[i];
+        long long pre = 0;
+        for (int i = 0; i < COMPACT_BLOCK / 64; ++i) pre += s_part[i];
+        cnt[CNT_NDENSE] = pre + tot;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 template <bool HAS_N, bool UNPACKED>
 __device__ __forceinline__ int dp_tile(const uint32_t* __restrict__ rp, int stride, const uint32_t* __restrict__ hp, int len2)
@@ -777,27 +879,23 @@ __device__ __forceinline__ int dp_tile(const uint32_t* __restrict__ rp, int stri
     }
 }
 
-__device__ __forceinline__ double loglik_of(int score, const double* __restrict__ mapq_lut, int mapq) {
-    const double v = -0.23025850929940459 * (double)score + mapq_lut[mapq];   // chaplotype.pyx:676 (no FMA: -ffp-contract=off)
-    return v > -300.0 ? v : -300.0;
-}
 
-// Slot j < npairs is the primary DP of pair j.  Pairs that need a single DP (one candidate that is also the mapping
-// position, or no candidate at all) are finished right here: score -> log-likelihood (a8).  Only pairs with several
-// candidate DPs go through k_finalize_multi.
+// One lane per live job slot (dense list).  Slot j < npairs is the primary DP of pair j.  Pairs that need a single DP (one
+// candidate that is also the mapping position, or no candidate at all) are finished right here: score -> log-likelihood
+// (a8).  Only pairs with several candidate DPs go through k_finalize_multi.
 template <bool UNPACKED>
 __global__ void __launch_bounds__(256)
 k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32_t* __restrict__ tile,
           const uint32_t* __restrict__ hapw, const uint8_t* __restrict__ hap_has_n, const Job* __restrict__ jobs,
           const PairRec* __restrict__ pairs, const double* __restrict__ mapq_lut, long long npairs,
-          long long njobs, int32_t* __restrict__ job_score, double* __restrict__ out_ll, int32_t* __restrict__ out_score)
+          const int32_t* __restrict__ dense, long long ndense, int32_t* __restrict__ job_score, double* __restrict__ out_ll,
+          int32_t* __restrict__ out_score)
 {
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = j < njobs;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = t < ndense;
+    const long long j = active ? dense[t] : 0;
     Job jb = Job{0, 0, 0, 0};
     if (active) jb = jobs[j];
-    const bool primary = active && j < npairs;
-    active = active && jb.len != 0;                                          // len 0: slot of a skipped pair
     int has_n = 0, stride = 0;
     if (active) {
         has_n = hap_has_n[jb.hap];
@@ -813,20 +911,13 @@ k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32
     } else {
         if (active) sc = dp_tile<false, UNPACKED>(rp, stride, hp, jb.len);
     }
-    if (!primary) {
-        if (active) job_score[j] = sc;
-        return;
-    }
+    if (!active) return;
+    if (j >= npairs) { job_score[j] = sc; return; }
     const PairRec pr = pairs[j];                                             // read after the DP: nothing of it is live across the loop
-    if (pr.ncand < 0) {                                                      // skipped read (0.0, chaplotype.pyx:345-346) or read < 7 bp (score 0)
-        out_ll[j] = pr.ncand == -1 ? 0.0 : loglik_of(0, mapq_lut, pr.mapq);
-        if (out_score) out_score[j] = pr.ncand == -1 ? -1 : 0;
-    } else if (active) {
-        if (pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0)) {
-            out_ll[j] = loglik_of(sc, mapq_lut, pr.mapq);
-            if (out_score) out_score[j] = sc;
-        } else job_score[j] = sc;
-    }
+    if (pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0)) {
+        out_ll[j] = loglik_of(sc, mapq_lut, pr.mapq);
+        if (out_score) out_score[j] = sc;
+    } else job_score[j] = sc;
 }
 
 // --calculateFlankScore=1 (a2): the same job list, but every DP runs in the reference's traceback mode and its score is
@@ -835,18 +926,16 @@ k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32
 __global__ void __launch_bounds__(256)
 k_dp_tb_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32_t* __restrict__ tile,
              const uint32_t* __restrict__ hapw, const Job* __restrict__ jobs, const PairRec* __restrict__ pairs,
-             const double* __restrict__ mapq_lut, long long npairs, long long j0, long long jn,
+             const double* __restrict__ mapq_lut, long long npairs, const int32_t* __restrict__ dense, long long j0, long long jn,
              unsigned long long* __restrict__ bpbuf, long long bstride, int32_t* __restrict__ job_score,
              double* __restrict__ out_ll, int32_t* __restrict__ out_score)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= jn) return;
-    const long long j = j0 + t;
+    const long long j = dense[j0 + t];
     const Job jb = jobs[j];
-    const bool primary = j < npairs;
-    const bool active = jb.len != 0;
-    int sc = 0;
-    if (active) {
+    int sc;
+    {
         const int w = hap_win[jb.hap];
         const long long stride = b.win_read_begin[w + 1] - b.win_read_begin[w];
         const long long hoff = b.hap_off[jb.hap];
@@ -865,20 +954,12 @@ k_dp_tb_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uin
         sc = dp_forward_tb(w0, jb.len, rw, hw, bp, &midx);
         if (sc > 0) sc -= tb_flank_score(bp, midx, jb.len, hfull, st, hapLen, hapFlank, rp, stride);
     }
-    if (!primary) {
-        if (active) job_score[j] = sc;
-        return;
-    }
+    if (j >= npairs) { job_score[j] = sc; return; }
     const PairRec pr = pairs[j];
-    if (pr.ncand < 0) {
-        out_ll[j] = pr.ncand == -1 ? 0.0 : loglik_of(0, mapq_lut, pr.mapq);
-        if (out_score) out_score[j] = pr.ncand == -1 ? -1 : 0;
-    } else if (active) {
-        if (pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0)) {
-            out_ll[j] = loglik_of(sc, mapq_lut, pr.mapq);
-            if (out_score) out_score[j] = sc;
-        } else job_score[j] = sc;
-    }
+    if (pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0)) {
+        out_ll[j] = loglik_of(sc, mapq_lut, pr.mapq);
+        if (out_score) out_score[j] = sc;
+    } else job_score[j] = sc;
 }
 
 __global__ void __launch_bounds__(256)
@@ -946,6 +1027,7 @@ k_stats(const PairRec* __restrict__ pairs, const Job* __restrict__ jobs, const i
         const PairRec pr = pairs[p];
         if (pr.ncand != -1) {
             aligned = 1;
+            if (pr.ncand == -3) { ndp = 1; cells = 16ull * (unsigned long long)pr.idx0; }   // exact match: the reference runs (and returns from) one DP
             if (pr.ncand >= 0) {
                 int n = 1;
                 if (!(pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0))) select_best(pr, p, npairs, jobs, job_score, &n);
@@ -1076,13 +1158,13 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     // read back: error, maxima, blob lengths, number of pairs, tile size
     int64_t* hb = ctx->h_readback;
     PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
-    PLAT_HIP(ctx, hipMemcpyAsync(hb + 16, b.hap_off + b.n_haps, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    PLAT_HIP(ctx, hipMemcpyAsync(hb + 17, b.pair_off + b.n_windows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    PLAT_HIP(ctx, hipMemcpyAsync(hb + 18, b.read_off + b.n_reads, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PLAT_HIP(ctx, hipMemcpyAsync(hb + 32, b.hap_off + b.n_haps, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PLAT_HIP(ctx, hipMemcpyAsync(hb + 33, b.pair_off + b.n_windows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PLAT_HIP(ctx, hipMemcpyAsync(hb + 34, b.read_off + b.n_reads, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     PLAT_HIP(ctx, hipStreamSynchronize(st));
     if (hb[CNT_ERR] != 0) return (int)hb[CNT_ERR];
     const int maxhap = (int)hb[CNT_MAXHAP], maxread = (int)hb[CNT_MAXREAD], maxR = (int)hb[CNT_MAXH];
-    const long long hapblob = hb[16], npairs = hb[17], readblob = hb[18], tile_total = hb[CNT_TILE_TOTAL];
+    const long long hapblob = hb[32], npairs = hb[33], readblob = hb[34], tile_total = hb[CNT_TILE_TOTAL];
     if (npairs == 0) return PLAT_OK;
     if (tile_total > 0xFFFFFFF0ll || readblob > 0xFFFFFFF0ll) return PLAT_ERR_OVERFLOW;   // split the batch: 32-bit tile/code offsets
     if ((rc = plat_reserve(ctx, ctx->hapw, ((size_t)hapblob + 64) * 4))) return rc;
@@ -1109,6 +1191,18 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
         PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_NEXTRA], 0, sizeof(long long), st));
         PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_SLOW_SEED], 0, sizeof(long long), st));
         if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win, win_rows, tile_off))) return rc;
+        {   // dense list of the live job slots; pairs that need no DP are finished by k_compact_count
+            const long long slots_cap = npairs + extra_cap;
+            const unsigned nblk = (unsigned)((slots_cap + COMPACT_BLOCK - 1) / COMPACT_BLOCK);
+            if ((rc = plat_reserve(ctx, ctx->dense, ((size_t)slots_cap + nblk + 64) * sizeof(int32_t)))) return rc;
+            int32_t* dense = (int32_t*)ctx->dense.ptr;
+            int32_t* block_cnt = dense + slots_cap;
+            hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(COMPACT_BLOCK), 0, st, (const Job*)ctx->jobs.ptr,
+                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, extra_cap, cnt, block_cnt,
+                               out_loglik, out_score);
+            hipLaunchKernelGGL(k_compact_scatter, dim3(nblk), dim3(COMPACT_BLOCK), 0, st, (const Job*)ctx->jobs.ptr, npairs,
+                               extra_cap, cnt, block_cnt, dense);
+        }
         PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
         PLAT_HIP(ctx, hipStreamSynchronize(st));
         if (hb[CNT_ERR] != 0) return (int)hb[CNT_ERR];
@@ -1118,35 +1212,39 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
         if (nextra > 0x7FFFFF00ll || attempt == 1) return PLAT_ERR_OVERFLOW;
         extra_cap = nextra;                    // tandem-rich batch: re-run the seeding with the exact capacity
     }
+    const long long ndense = hb[CNT_NDENSE];
+    const int32_t* dense = (const int32_t*)ctx->dense.ptr;
     if ((rc = plat_reserve(ctx, ctx->job_score, (size_t)(njobs + 1) * sizeof(int32_t)))) return rc;
     PLAT_EV(ctx, 2, st);
-    if (calc_flank_score) {
+    if (ndense == 0) {
+        // nothing to align
+    } else if (calc_flank_score) {
         // traceback mode: 2*(maxread+8) back-pointer words per job; the job list is processed in slabs of bounded size
         const long long rows = 2ll * (maxread + 8);
         long long slab = (long long)((6ull << 30) / ((unsigned long long)rows * 8ull));
-        if (slab > njobs) slab = njobs;
+        if (slab > ndense) slab = ndense;
         slab = (slab + 255) & ~255ll;
         if ((rc = plat_reserve(ctx, ctx->tb, (size_t)rows * (size_t)slab * 8))) return rc;
-        for (long long j0 = 0; j0 < njobs; j0 += slab) {
-            const long long jn = njobs - j0 < slab ? njobs - j0 : slab;
+        for (long long j0 = 0; j0 < ndense; j0 += slab) {
+            const long long jn = ndense - j0 < slab ? ndense - j0 : slab;
             hipLaunchKernelGGL(k_dp_tb_jobs, dim3((unsigned)((jn + 255) / 256)), dim3(256), 0, st, b, hap_win,
                                (const uint32_t*)ctx->tile.ptr, (const uint32_t*)ctx->hapw.ptr, (const Job*)ctx->jobs.ptr,
-                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, j0, jn,
+                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, j0, jn,
                                (unsigned long long*)ctx->tb.ptr, slab, (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
         }
     } else {
         static int dp_impl = -1;                 // 1 = one int16 lane per VGPR (dp_unpacked.hpp), 0 = packed (dp_core.hpp)
         if (dp_impl < 0) { const char* e = getenv("PLAT_DP_IMPL"); dp_impl = e ? (strcmp(e, "unpacked") == 0) : 0; }   // packed measured faster
-        const dim3 grid((unsigned)((njobs + 255) / 256));
+        const dim3 grid((unsigned)((ndense + 255) / 256));
         if (dp_impl)
             hipLaunchKernelGGL(k_dp_jobs<true>, grid, dim3(256), 0, st, b, hap_win, (const uint32_t*)ctx->tile.ptr,
                                (const uint32_t*)ctx->hapw.ptr, (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
-                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, njobs,
+                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, ndense,
                                (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
         else
             hipLaunchKernelGGL(k_dp_jobs<false>, grid, dim3(256), 0, st, b, hap_win, (const uint32_t*)ctx->tile.ptr,
                                (const uint32_t*)ctx->hapw.ptr, (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
-                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, njobs,
+                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, ndense,
                                (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
     }
     PLAT_EV(ctx, 3, st);
