@@ -39,8 +39,8 @@ __device__ __forceinline__ long long job_slot(long long pair, long long npairs, 
 }
 
 enum { CNT_ERR = 0, CNT_MAXHAP, CNT_MAXREAD, CNT_NEXTRA, CNT_PAIRS_ALIGNED, CNT_NDP_REF, CNT_CELLS_REF, CNT_CELLS_RUN,
-       CNT_NJOBS_RUN, CNT_TILE_TOTAL, CNT_SLOW_SEED, CNT_MAXH, CNT_NDENSE, CNT_T0, CNT_T1, CNT_T2, CNT_T3, CNT_T4, CNT_N };
-static_assert(CNT_N <= 32, "the pinned read-back area keeps the counters in [0,32) and three blob lengths at 32..34");
+       CNT_NJOBS_RUN, CNT_TILE_TOTAL, CNT_SLOW_SEED, CNT_MAXH, CNT_NDENSE, CNT_HAPBLOB, CNT_NPAIRS, CNT_READBLOB, CNT_T0, CNT_T1, CNT_T2, CNT_T3, CNT_T4, CNT_N };
+static_assert(CNT_N <= 64, "the pinned read-back area holds 64 words");
 
 __constant__ signed char c_homopol_go[49] = {   // homopolq[i]-'!' (chaplotype.pyx:64-67); see tests/test_oracle.py
     45, 42, 41, 39, 37, 32, 28, 23, 20, 19, 17, 16, 15, 14, 13, 12, 11, 11, 10, 9, 9, 8, 8, 7, 7, 7, 6, 6, 6, 5, 5, 5,
@@ -127,7 +127,13 @@ k_tile_scan(plat_window_batch b, const int32_t* __restrict__ win_rows, long long
         tile_off[w] = run;
         run += ((long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]) + 3) & ~3ll;
     }
-    if (t == nt - 1) cnt[CNT_TILE_TOTAL] = part[t];
+    if (t == nt - 1) {
+        cnt[CNT_TILE_TOTAL] = part[t];
+        // everything the host needs before it can size the scratch buffers travels in ONE read-back of cnt[]
+        cnt[CNT_HAPBLOB] = b.hap_off[b.n_haps];
+        cnt[CNT_NPAIRS] = b.pair_off[b.n_windows];
+        cnt[CNT_READBLOB] = b.read_off[b.n_reads];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -190,50 +196,9 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
         if (bad & 0x80808080u) set_err(cnt, PLAT_ERR_BAD_INPUT);
     }
     if (tid < 2) s_dirty[tid] = 0u;
-    __syncthreads();
-    const unsigned char* gs = b.read_seq + blob0;
-    const unsigned char* gq = b.read_qual + blob0;
-    // tile: element (i, rl), rl fastest -> coalesced stores
-    // tile: element (i, rl), rl fastest -> coalesced stores.  e / nr by multiply-shift (exact for e < 16384, nr <= 64)
-    {
-        const int ne = rows * nr;
-        const unsigned M = (1u << 22) / (unsigned)nr + 1u;
-        for (int e = tid; e < ne; e += nthr) {
-            const int i = ne <= 16384 ? (int)(((unsigned)e * M) >> 22) : e / nr;
-            const int rl = e - i * nr;
-            const int o = s_off[rl], L = s_off[rl + 1] - o;
-            uint32_t wd = READ_PAD_WORD;
-            if (i < L) {
-                const unsigned ch = staged ? lseq[o + i] : gs[o + i];
-                wd = read_word(ch, staged ? lqual[o + i] : gq[o + i]);
-                if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') atomicOr(&s_dirty[rl >> 5], 1u << (rl & 31));
-            }
-            tile[toff + (long long)i * R + c0 + rl] = wd;
-        }
-    }
-    // bit planes: for every read and every chunk c of 64 bases, plane0 = bit 0 and plane1 = bit 1 of the 2-bit base code,
-    // one bit per base (ballot over the 64 lanes); word (2c+plane) of read rl at rd2[(2c+plane)*R + rl]
-    unsigned long long* rd2 = (unsigned long long*)(codes + toff);
-    const int nchunks = (rows - 8 + 63) >> 6;
-    const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
-    for (int c = wv; c < nchunks; c += nwv) {            // one wave per chunk; lane rl keeps read rl's two words
-        unsigned long long my0 = 0, my1 = 0;
-        for (int rl = 0; rl < nr; ++rl) {
-            const int o = s_off[rl], L = s_off[rl + 1] - o;
-            const int i = 64 * c + lane;
-            unsigned b2 = 0;
-            if (i < L) b2 = base2(staged ? lseq[o + i] : gs[o + i]);
-            const unsigned long long m0 = __ballot(b2 & 1u), m1 = __ballot(b2 & 2u);
-            if (lane == rl) { my0 = m0; my1 = m1; }
-        }
-        if (lane < nr) {
-            rd2[(long long)(2 * c) * R + c0 + lane] = my0;
-            rd2[(long long)(2 * c + 1) * R + c0 + lane] = my1;
-        }
-    }
-    __syncthreads();
-    const int wstart = b.win_start[w], wend = b.win_end[w];
+    ReadInfo my_ri = ReadInfo{0u, 0u, 0, 0u};            // loaded now, stored at the end together with the "dirty" bit
     if (tid < nr) {
+        const int wstart = b.win_start[w], wend = b.win_end[w];
         const int r = rb + c0 + tid;
         const int L = (int)(b.read_off[r + 1] - b.read_off[r]);
         // skip rule, chaplotype.pyx:343-346 / 358-361 (brokenMates are always aligned, :366-373)
@@ -243,9 +208,71 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             const int ov = oe > os ? oe - os : -1;                       // chaplotype.pyx:103-115
             skip = (b.read_flags[r] & 512) || ov < 7;
         }
-        const unsigned dirty = (s_dirty[tid >> 5] >> (tid & 31)) & 1u;
-        rinfo[r] = ReadInfo{(uint32_t)(toff + c0 + tid), 0u, b.read_pos[r],
-                            (uint32_t)L | ((uint32_t)skip << 16) | (dirty << 17) | ((uint32_t)b.read_mapq[r] << 24)};
+        my_ri = ReadInfo{(uint32_t)(toff + c0 + tid), 0u, b.read_pos[r],
+                         (uint32_t)L | ((uint32_t)skip << 16) | ((uint32_t)b.read_mapq[r] << 24)};
+    }
+    __syncthreads();
+    const unsigned char* gs = b.read_seq + blob0;
+    const unsigned char* gq = b.read_qual + blob0;
+    // tile: a thread takes 4 consecutive rows i of one read rl; lanes run over rl, so every row store of a wave is
+    // contiguous.  e / nr by multiply-shift (exact for e < 16384, nr <= 64).
+    {
+        const int ngrp = (rows + 3) >> 2;
+        const int ne = ngrp * nr;
+        const unsigned M = (1u << 22) / (unsigned)nr + 1u;
+        for (int e = tid; e < ne; e += nthr) {
+            const int g = ne <= 16384 ? (int)(((unsigned)e * M) >> 22) : e / nr;
+            const int rl = e - g * nr;
+            const int o = s_off[rl], L = s_off[rl + 1] - o;
+            uint32_t* tp = tile + toff + (long long)(4 * g) * R + c0 + rl;
+            bool dirty = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = 4 * g + j;
+                uint32_t wd = READ_PAD_WORD;
+                if (i < L) {
+                    const unsigned ch = staged ? lseq[o + i] : gs[o + i];
+                    wd = read_word(ch, staged ? lqual[o + i] : gq[o + i]);
+                    const unsigned dch = ch - 65u;                               // 'A' 'C' 'G' 'T' = 65 + {0, 2, 6, 19}
+                    dirty |= dch > 19u || !((0x80045u >> dch) & 1u);
+                }
+                if (i < rows) tp[(long long)j * R] = wd;
+            }
+            if (dirty) atomicOr(&s_dirty[rl >> 5], 1u << (rl & 31));
+        }
+    }
+    // bit planes: for every read and every chunk c of 64 bases, plane0 = bit 0 and plane1 = bit 1 of the 2-bit base code,
+    // one bit per base (ballot over the 64 lanes); word (2c+plane) of read rl at rd2[(2c+plane)*R + rl]
+    unsigned long long* rd2 = (unsigned long long*)(codes + toff);
+    const int nchunks = (rows - 8 + 63) >> 6;
+    const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+    for (int c = wv; c < nchunks; c += nwv) {            // one wave per chunk; lane rl keeps read rl's two words
+        unsigned long long my0 = 0, my1 = 0;
+        const int i = 64 * c + lane;
+        for (int rl0 = 0; rl0 < nr; rl0 += 4) {          // 4 reads per trip: their LDS round trips overlap
+            unsigned b2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rl = min(rl0 + k, nr - 1);
+                const int o = s_off[rl], L = s_off[rl + 1] - o;
+                b2[k] = 0;
+                if (i < L) b2[k] = base2(staged ? lseq[o + i] : gs[o + i]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long m0 = __ballot(b2[k] & 1u), m1 = __ballot(b2[k] & 2u);
+                if (lane == rl0 + k) { my0 = m0; my1 = m1; }
+            }
+        }
+        if (lane < nr) {
+            rd2[(long long)(2 * c) * R + c0 + lane] = my0;
+            rd2[(long long)(2 * c + 1) * R + c0 + lane] = my1;
+        }
+    }
+    __syncthreads();
+    if (tid < nr) {
+        my_ri.lfm |= ((s_dirty[tid >> 5] >> (tid & 31)) & 1u) << 17;
+        rinfo[rb + c0 + tid] = my_ri;
     }
 }
 
@@ -1158,13 +1185,10 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     // read back: error, maxima, blob lengths, number of pairs, tile size
     int64_t* hb = ctx->h_readback;
     PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
-    PLAT_HIP(ctx, hipMemcpyAsync(hb + 32, b.hap_off + b.n_haps, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    PLAT_HIP(ctx, hipMemcpyAsync(hb + 33, b.pair_off + b.n_windows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    PLAT_HIP(ctx, hipMemcpyAsync(hb + 34, b.read_off + b.n_reads, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     PLAT_HIP(ctx, hipStreamSynchronize(st));
     if (hb[CNT_ERR] != 0) return (int)hb[CNT_ERR];
     const int maxhap = (int)hb[CNT_MAXHAP], maxread = (int)hb[CNT_MAXREAD], maxR = (int)hb[CNT_MAXH];
-    const long long hapblob = hb[32], npairs = hb[33], readblob = hb[34], tile_total = hb[CNT_TILE_TOTAL];
+    const long long hapblob = hb[CNT_HAPBLOB], npairs = hb[CNT_NPAIRS], readblob = hb[CNT_READBLOB], tile_total = hb[CNT_TILE_TOTAL];
     if (npairs == 0) return PLAT_OK;
     if (tile_total > 0xFFFFFFF0ll || readblob > 0xFFFFFFF0ll) return PLAT_ERR_OVERFLOW;   // split the batch: 32-bit tile/code offsets
     if ((rc = plat_reserve(ctx, ctx->hapw, ((size_t)hapblob + 64) * 4))) return rc;
@@ -1188,8 +1212,10 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     PLAT_EV(ctx, 1, st);
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = plat_reserve(ctx, ctx->jobs, (size_t)(npairs + extra_cap) * sizeof(Job)))) return rc;
-        PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_NEXTRA], 0, sizeof(long long), st));
-        PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_SLOW_SEED], 0, sizeof(long long), st));
+        if (attempt > 0) {                     // (the first pass starts from the memset of all counters above)
+            PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_NEXTRA], 0, sizeof(long long), st));
+            PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_SLOW_SEED], 0, sizeof(long long), st));
+        }
         if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win, win_rows, tile_off))) return rc;
         {   // dense list of the live job slots; pairs that need no DP are finished by k_compact_count
             const long long slots_cap = npairs + extra_cap;
