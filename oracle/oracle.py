@@ -65,6 +65,13 @@ class Oracle:
                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p, C.POINTER(C.c_longlong)]
+        L.orc_em_call.restype = C.c_int
+        L.orc_em_call.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.POINTER(C.c_double)]
+        L.orc_variant_posterior.restype = C.c_double
+        L.orc_variant_posterior.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        L.orc_genotype_call.restype = None
+        L.orc_genotype_call.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8
         L.orc_genotype_loglik.restype = C.c_double
         L.orc_genotype_loglik.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -176,6 +183,45 @@ class Oracle:
         self.lib.orc_population_setup_ind(nH, withs.ctypes.data, nR, n_good, logl.ctypes.data,
                                           gl.ctypes.data, gof.ctypes.data)
         return logl, gl, gof
+
+    # -- EM, genotype calls, posteriors -----------------------------------------
+    def em_call(self, n_reads, gl, max_iters=100, use_em=0):
+        """gl: [nInd][nGen].  Returns (freqs[nHap], em[nInd][nGen], calls[nInd], iters, max_change)."""
+        gl = np.ascontiguousarray(gl, dtype=np.float64)
+        nInd, nGen = gl.shape
+        nHap = int(round((np.sqrt(8 * nGen + 1) - 1) / 2))
+        nr = np.ascontiguousarray(n_reads, dtype=np.int32)
+        freq = np.zeros(nHap)
+        em = np.zeros((nInd, nGen))
+        calls = np.zeros(nInd, dtype=np.int32)
+        mc = C.c_double(0)
+        it = self.lib.orc_em_call(nInd, nHap, nr.ctypes.data, gl.ctypes.data, max_iters, use_em, freq.ctypes.data,
+                                  em.ctypes.data, calls.ctypes.data, C.byref(mc))
+        return freq, em, calls, it, mc.value
+
+    def variant_posterior(self, n_reads, gl, freq, hap_has_var, prior):
+        gl = np.ascontiguousarray(gl, dtype=np.float64)
+        nInd = gl.shape[0]
+        freq = np.ascontiguousarray(freq, dtype=np.float64)
+        nr = np.ascontiguousarray(n_reads, dtype=np.int32)
+        hv = np.ascontiguousarray(hap_has_var, dtype=np.uint8)
+        return self.lib.orc_variant_posterior(nInd, len(freq), nr.ctypes.data, gl.ctypes.data, freq.ctypes.data,
+                                              hv.ctypes.data, float(prior))
+
+    def genotype_call(self, freq, gl_row, gof_row, var_in_hap, is_ref, n_individuals):
+        """vcfutils.computeGenotypeCallAndLikelihoods for one sample.  Returns (phased, likelihoods, out4)."""
+        freq = np.ascontiguousarray(freq, dtype=np.float64)
+        gl_row = np.ascontiguousarray(gl_row, dtype=np.float64)
+        gof_row = np.ascontiguousarray(gof_row, dtype=np.float64)
+        vih = np.ascontiguousarray(var_in_hap, dtype=np.int32)
+        nHap, nVar = vih.shape
+        ir = np.ascontiguousarray(is_ref, dtype=np.int32)
+        ph = np.zeros(2, dtype=np.int32)
+        lik = np.zeros((nVar + 1) * (nVar + 2) // 2)
+        out4 = np.zeros(4)
+        self.lib.orc_genotype_call(nHap, nVar, n_individuals, freq.ctypes.data, gl_row.ctypes.data, gof_row.ctypes.data,
+                                   vih.ctypes.data, ir.ctypes.data, ph.ctypes.data, lik.ctypes.data, out4.ctypes.data)
+        return ph, lik, out4
 
     # -- a14..a18 ------------------------------------------------------------------------------
     def assemble(self, ref, ref_start, assem_start, assem_end, seqs, quals, k=15, min_qual=20,

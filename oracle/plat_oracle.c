@@ -518,6 +518,191 @@ ORC_API void orc_population_setup_ind(int nHaps, const double* ll, int totalRead
 }
 
 /* ------------------------------------------------------------------------------------------
+ * EM haplotype frequencies, genotype calls, variant posteriors, per-position
+ * genotype marginalisation.  Genotype g <-> haplotype pair (i,j), i<=j, in the order of
+ * generateAllGenotypesFromHaplotypeList.  gl: [nInd][nGen] rescaled genotype likelihoods
+ * (a12); nReads[i] = number of good reads of individual i (cpopulation.pyx:286-287).
+ * Pinned by tests/golden/population_cases.json.gz (outputs of the reference's own method texts).
+ * ------------------------------------------------------------------------------------------ */
+static void hap_pair_of(int g, int nHap, int* a, int* b) {
+    int i = 0, rowlen = nHap;
+    while (g >= rowlen) { g -= rowlen; --rowlen; ++i; }
+    *a = i; *b = i + g;
+}
+
+/* Population.EMiteration, cpopulation.pyx:384-457 */
+static double em_iteration(int nInd, int nHap, int nGen, const int* nReads, const double* gl,
+                           const int* hidx, double* freq, double* newFreqs, double* em)
+{
+    double maxChange = 0.0;
+    int nIndWithData = 0;
+    for (int i = 0; i < nInd; ++i) {
+        if (nReads[i] == 0) continue;
+        const double* L = gl + (size_t)i * nGen;
+        double* csr = em + (size_t)i * nGen;
+        double csrSum = 0.0;
+        ++nIndWithData;
+        for (int j = 0; j < nGen; ++j) {
+            const int s = hidx[2 * j], r = hidx[2 * j + 1];
+            const double thisCSR = L[j] * freq[s] * freq[r] * (1 + (r != s));       /* :421 */
+            csr[j] = thisCSR;
+            csrSum += thisCSR;
+        }
+        if (csrSum > 0.0)
+            for (int j = 0; j < nGen; ++j) csr[j] /= csrSum;
+    }
+    for (int k = 0; k < nHap; ++k) newFreqs[k] = 0.0;
+    for (int i = 0; i < nInd; ++i) {
+        if (nReads[i] == 0) continue;
+        const double* csr = em + (size_t)i * nGen;
+        for (int j = 0; j < nGen; ++j) {
+            newFreqs[hidx[2 * j]] += csr[j];                                        /* :443-444 */
+            newFreqs[hidx[2 * j + 1]] += csr[j];
+        }
+    }
+    for (int k = 0; k < nHap; ++k) {
+        newFreqs[k] = newFreqs[k] / (2 * nIndWithData);
+        const double freqChange = fabs(freq[k] - newFreqs[k]);
+        if (freqChange > maxChange) maxChange = freqChange;
+        freq[k] = newFreqs[k];
+    }
+    return maxChange;
+}
+
+/* Population.call (cpopulation.pyx:678-703) + callGenotypes (:623-676).
+ * freq[nHap], em[nInd][nGen] (rows of individuals without reads are left as passed in), calls[nInd]
+ * (-1 = None).  Returns the number of EM iterations; *maxChangeOut = last maximum frequency change. */
+ORC_API int orc_em_call(int nInd, int nHap, const int* nReads, const double* gl, int maxIters, int useEM,
+                        double* freq, double* em, int* calls, double* maxChangeOut)
+{
+    const int nGen = nHap * (nHap + 1) / 2;
+    int* hidx = (int*)malloc(sizeof(int) * 2 * (size_t)nGen);
+    double* newFreqs = (double*)malloc(sizeof(double) * (size_t)nHap);
+    for (int g = 0; g < nGen; ++g) hap_pair_of(g, nHap, &hidx[2 * g], &hidx[2 * g + 1]);
+    double eps = 1.0 / (nInd * 2 * 2);                                              /* :684 */
+    if (1e-3 < eps) eps = 1e-3;
+    double maxChange = eps + 1;
+    const double uniformFreq = 1.0 / nHap;
+    int iters = 0;
+    for (int k = 0; k < nHap; ++k) freq[k] = uniformFreq;
+    while (maxChange > eps && iters < maxIters) {                                   /* :700-702 */
+        maxChange = em_iteration(nInd, nHap, nGen, nReads, gl, hidx, freq, newFreqs, em);
+        ++iters;
+    }
+    for (int i = 0; i < nInd; ++i) {                                                /* callGenotypes */
+        if (nReads[i] == 0) { calls[i] = -1; continue; }
+        int best = -1;
+        double maxL = 0.0;
+        for (int g = 0; g < nGen; ++g) {
+            const double v = useEM == 1 ? em[(size_t)i * nGen + g] : gl[(size_t)i * nGen + g];
+            if (best == -1 || v > maxL) { maxL = v; best = g; }
+        }
+        calls[i] = best;
+    }
+    if (maxChangeOut) *maxChangeOut = maxChange;
+    free(hidx); free(newFreqs);
+    return iters;
+}
+
+/* Population.calculatePosterior, cpopulation.pyx:459-594.  hapHasVar[h] != 0 iff the variant is one
+ * of haplotype h's variants; prior = var.calculatePrior(refFile) (or 0.5 for flatPrior).  Returns the
+ * rounded phred-scaled posterior. */
+ORC_API double orc_variant_posterior(int nInd, int nHap, const int* nReads, const double* gl, const double* freq,
+                                     const unsigned char* hapHasVar, double prior)
+{
+    const int nGen = nHap * (nHap + 1) / 2;
+    const int logOfMinFloat = -708;
+    double* fprime = (double*)malloc(sizeof(double) * (size_t)nHap);
+    double sumFreqs = 0.0, sumLogProbVariant = 0.0, sumLogProbNoVariant = 0.0;
+    for (int i = 0; i < nHap; ++i) {                                                /* :509-518 */
+        if (!hapHasVar[i]) { fprime[i] = freq[i]; sumFreqs += freq[i]; }
+        else fprime[i] = 0.0;
+    }
+    if (sumFreqs > 0)
+        for (int i = 0; i < nHap; ++i) fprime[i] /= sumFreqs;                       /* :527-534 */
+    for (int i = 0; i < nInd; ++i) {
+        if (nReads[i] == 0) continue;
+        const double* L = gl + (size_t)i * nGen;
+        double sumVar = 0.0, sumNoVar = 0.0;
+        int g = 0;
+        for (int r = 0; r < nHap; ++r)
+            for (int s2 = r; s2 < nHap; ++s2, ++g) {
+                const double factor = r != s2 ? 2.0 : 1.0;
+                sumVar += (factor * freq[r] * freq[s2] * L[g]);                      /* :564 */
+                sumNoVar += (factor * fprime[r] * fprime[s2] * L[g]);               /* :569 */
+            }
+        sumLogProbVariant += sumVar > 0 ? log(sumVar) : logOfMinFloat;
+        sumLogProbNoVariant += sumNoVar > 0 ? log(sumNoVar) : logOfMinFloat;
+    }
+    free(fprime);
+    double ratio = exp(sumLogProbNoVariant - sumLogProbVariant);                    /* :586 */
+    if (!(ratio > 1e-300)) ratio = 1e-300;
+    return round(-10.0 * (log10(ratio * (1.0 - prior)) - log10(prior + ratio * (1.0 - prior))));
+}
+
+/* computeGenotypeCallAndLikelihoods, vcfutils.pyx:163-334, for one sample.
+ * varInHap: [nHap][nVar]; isRef[nHap]; gl, gof: this sample's [nGen] rows.
+ * phased[2]; likelihoods[(nVar+1)(nVar+2)/2] in (index1, index2<=index1) order;
+ * out4 = {bestLikelihood/sum, nonRefPosterior/sum, refPosterior/sum, bestGoodnessOfFitValue}. */
+ORC_API void orc_genotype_call(int nHap, int nVar, int nIndividuals, const double* freq, const double* gl,
+                               const double* gof, const int* varInHap, const int* isRef,
+                               int* phased, double* likelihoods, double* out4)
+{
+    double sumLikelihoods = 0.0, bestGof = 1e6, bestLikelihood = -1.0, nonRefPosterior = 0.0, refPosterior = 0.0;
+    double phasedMaxLike = -1e6;
+    int phasedIndex1 = -1, phasedIndex2 = -1, nl = 0;
+    for (int index1 = 0; index1 <= nVar; ++index1)
+        for (int index2 = 0; index2 <= index1; ++index2) {
+            double marginal = 0.0;
+            int g = 0;
+            for (int h1 = 0; h1 < nHap; ++h1)
+                for (int h2 = h1; h2 < nHap; ++h2, ++g) {
+                    const int ref1 = isRef[h1], ref2 = isRef[h2];
+                    const double factor = h1 != h2 ? 2.0 : 1.0;
+                    int matching = 0, v1h1 = 0, v1h2 = 0, v2h1 = 0, v2h2 = 0;
+                    if (index1 == 0 && index2 == 0) {
+                        if (ref1 && ref2) matching = 1;
+                    } else if (index2 == 0) {
+                        v1h1 = varInHap[h1 * nVar + index1 - 1]; v1h2 = varInHap[h2 * nVar + index1 - 1];
+                        if ((ref2 && v1h1) || (ref1 && v1h2)) matching = 1;
+                    } else {
+                        v1h1 = varInHap[h1 * nVar + index1 - 1]; v1h2 = varInHap[h2 * nVar + index1 - 1];
+                        v2h1 = varInHap[h1 * nVar + index2 - 1]; v2h2 = varInHap[h2 * nVar + index2 - 1];
+                        if ((v1h1 && v2h2) || (v2h1 && v1h2)) matching = 1;
+                    }
+                    if (!matching) continue;
+                    double cur;
+                    if (nIndividuals > 25) cur = (factor * freq[h1] * freq[h2] * gl[g]);       /* :252-255 */
+                    else cur = (factor * gl[g]);
+                    marginal += cur;
+                    if (cur > phasedMaxLike) {                                                    /* :260-303 */
+                        phasedMaxLike = cur;
+                        if (index1 == 0 && index2 == 0) { phasedIndex1 = index1; phasedIndex2 = index2; }
+                        else if (index2 == 0 && index1 != 0) {
+                            if (v1h1) { phasedIndex1 = index1; phasedIndex2 = index2; }
+                            else if (v1h2) { phasedIndex1 = index2; phasedIndex2 = index1; }
+                        } else if (index2 == index1 && index1 > 0) { phasedIndex1 = index1; phasedIndex2 = index2; }
+                        else if (index2 > 0 && index1 > 0 && index2 != index1) {
+                            if (v1h1 && v2h2) { phasedIndex1 = index1; phasedIndex2 = index2; }
+                            else if (v1h2 && v2h1) { phasedIndex1 = index2; phasedIndex2 = index1; }
+                        }
+                    }
+                    if (gof[g] < bestGof) bestGof = gof[g];
+                }
+            if (marginal > bestLikelihood) bestLikelihood = marginal;
+            if ((index1 == 1 && index2 == 0) || (index1 == 1 && index2 == 1)) nonRefPosterior += marginal;
+            else if (index1 == 0 && index2 == 0) refPosterior += marginal;
+            sumLikelihoods += marginal;
+            likelihoods[nl++] = marginal;
+        }
+    phased[0] = phasedIndex1; phased[1] = phasedIndex2;
+    out4[0] = bestLikelihood / sumLikelihoods;
+    out4[1] = nonRefPosterior / sumLikelihoods;
+    out4[2] = refPosterior / sumLikelihoods;
+    out4[3] = bestGof;
+}
+
+/* ------------------------------------------------------------------------------------------
  * a14-a18: coloured de-Bruijn assembler  (src/cython/assembler.pyx:73-1476)
  * ------------------------------------------------------------------------------------------ */
 #define COL_REF 1

@@ -142,12 +142,184 @@ def assemble(bytes chrom, int assemStart, int assemEnd, int refStart, int refEnd
     return [(v.refPos, v.removed, v.added) for v in theVars], nNodes
 '''
 
+
+POP_HEAD = r"""
+from __future__ import division
+cimport cython
+import logging
+logger = logging.getLogger("Log")
+
+ctypedef struct cAlignedRead:
+    char* seq
+
+cdef extern from "stdlib.h":
+    void free(void *)
+    void* malloc(size_t)
+    void* calloc(size_t, size_t)
+cdef extern from "math.h":
+    double exp(double)
+    double log(double)
+    double log10(double)
+    double fabs(double)
+    double round(double)
+
+cdef class Variant:
+    cdef public double prior
+    def __init__(self, double prior):
+        self.prior = prior
+    cdef double calculatePrior(self, refFile):
+        return self.prior
+
+cdef class Haplotype:
+    cdef public tuple variants
+    cdef double* cache
+    def __init__(self, tuple variants, list lls):
+        cdef int i
+        self.variants = variants
+        self.cache = <double*>malloc((len(lls) + 1) * sizeof(double))
+        for i in range(len(lls)):
+            self.cache[i] = lls[i]
+        self.cache[len(lls)] = 999
+    def __dealloc__(self):
+        free(self.cache)
+    cdef double* alignReads(self, int individualIndex, cAlignedRead** start, cAlignedRead** end, cAlignedRead** badReadsStart, cAlignedRead** badReadsEnd, cAlignedRead** brokenReadsStart, cAlignedRead** brokenReadsEnd, int useMapQualCap):
+        return self.cache
+
+cdef class bamReadBuffer:
+    pass
+"""
+
+POP_GENO_CLASS = r"""
+cdef class DiploidGenotype:
+    cdef public Haplotype hap1
+    cdef public Haplotype hap2
+    cdef public double hap1Like
+    cdef public double hap2Like
+    cdef public int idx
+    def __init__(self, Haplotype hap1, Haplotype hap2, int idx=-1):
+        self.hap1 = hap1
+        self.hap2 = hap2
+        self.idx = idx
+"""
+
+POP_CLASS = r"""
+cdef class Population:
+    cdef int nIndividuals, nGenotypes, nHaplotypes, verbosity, useEMLikelihoods
+    cdef int* nReads
+    cdef double** genotypeLikelihoods
+    cdef double** EMLikelihoods
+    cdef int** haplotypeIndexes
+    cdef double* frequencies
+    cdef double* newFrequencies
+    cdef double* freqsPrimeByHapIndex
+    cdef list haplotypes, genotypes, genotypeCalls, readBuffers
+    cdef object refFile
+
+    def __init__(self, list haplotypes, list nReads, list gl, int useEM):
+        cdef int i, j, g
+        self.haplotypes = haplotypes
+        self.nHaplotypes = len(haplotypes)
+        self.nIndividuals = len(nReads)
+        self.nGenotypes = self.nHaplotypes * (self.nHaplotypes + 1) // 2
+        self.verbosity = 0
+        self.useEMLikelihoods = useEM
+        self.refFile = None
+        self.genotypes = [DiploidGenotype(None, None, g) for g in range(self.nGenotypes)]
+        self.genotypeCalls = []
+        self.readBuffers = []
+        self.nReads = <int*>calloc(self.nIndividuals, sizeof(int))
+        self.genotypeLikelihoods = <double**>calloc(self.nIndividuals, sizeof(double*))
+        self.EMLikelihoods = <double**>calloc(self.nIndividuals, sizeof(double*))
+        self.haplotypeIndexes = <int**>calloc(self.nGenotypes, sizeof(int*))
+        self.frequencies = <double*>calloc(self.nHaplotypes, sizeof(double))
+        self.newFrequencies = <double*>calloc(self.nHaplotypes, sizeof(double))
+        self.freqsPrimeByHapIndex = <double*>calloc(self.nHaplotypes, sizeof(double))
+        for i in range(self.nIndividuals):
+            self.nReads[i] = nReads[i]
+            self.genotypeLikelihoods[i] = <double*>calloc(self.nGenotypes, sizeof(double))
+            self.EMLikelihoods[i] = <double*>calloc(self.nGenotypes, sizeof(double))
+            for g in range(self.nGenotypes):
+                self.genotypeLikelihoods[i][g] = gl[i][g]
+        g = 0
+        for i in range(self.nHaplotypes):          # order of generateAllGenotypesFromHaplotypeList
+            for j in range(i, self.nHaplotypes):
+                self.haplotypeIndexes[g] = <int*>calloc(2, sizeof(int))
+                self.haplotypeIndexes[g][0] = i
+                self.haplotypeIndexes[g][1] = j
+                g += 1
+"""
+
+POP_TAIL = r"""
+    def run(self, int maxIters):
+        # driver mirroring Population.call, cpopulation.pyx:684-702 (everything it calls is the reference's own text)
+        cdef double eps = min(1e-3, 1.0 / (self.nIndividuals*2*2))
+        cdef double maxChange = eps + 1
+        cdef double uniformFreq = 1.0/self.nHaplotypes
+        cdef int iters = 0
+        cdef int index = 0
+        for index from 0 <= index < self.nHaplotypes:
+            self.frequencies[index] = uniformFreq
+        while maxChange > eps and iters < maxIters:
+            maxChange = self.EMiteration(self.frequencies, self.newFrequencies)
+            iters += 1
+        self.callGenotypes()
+        return iters, maxChange
+
+    def results(self):
+        freqs = [self.frequencies[k] for k in range(self.nHaplotypes)]
+        em = [[self.EMLikelihoods[i][g] for g in range(self.nGenotypes)] for i in range(self.nIndividuals)]
+        return freqs, em, [(-1 if c is None else c.idx) for c in self.genotypeCalls]
+
+    def posterior(self, Variant v, int flatPrior=0):
+        return self.calculatePosterior(v, flatPrior)
+
+
+def genotype_loglik(DiploidGenotype g, int nReads, int nBad, int nBroken, int individualIndex, int nIndividuals):
+    cdef cAlignedRead** base = <cAlignedRead**>0
+    cdef double* gof = <double*>calloc(nIndividuals, sizeof(double))
+    cdef double ll = g.calculateDataLikelihood(base, base + nReads, base, base + nBad, base, base + nBroken, individualIndex, nIndividuals, gof, 0)
+    cdef double gv = gof[individualIndex]
+    free(gof)
+    return ll, gv, g.hap1Like, g.hap2Like
+
+
+def genotype_call(int nHap, list freqs, list gl_sample, list gof_sample, list varInHapRows, list isRef, int nVariants, int nIndividuals):
+    cdef int nG = nHap * (nHap + 1) // 2
+    cdef int i, j, g
+    cdef double* hf = <double*>calloc(nHap, sizeof(double))
+    cdef double** gls = <double**>calloc(1, sizeof(double*))
+    cdef double** gofs = <double**>calloc(nG, sizeof(double*))
+    cdef int** hidx = <int**>calloc(nG, sizeof(int*))
+    cdef int** vih = <int**>calloc(nHap, sizeof(int*))
+    cdef int* ref = <int*>calloc(nHap, sizeof(int))
+    gls[0] = <double*>calloc(nG, sizeof(double))
+    for i in range(nHap):
+        hf[i] = freqs[i]
+        ref[i] = isRef[i]
+        vih[i] = <int*>calloc(nVariants + 1, sizeof(int))
+        for j in range(nVariants):
+            vih[i][j] = varInHapRows[i][j]
+    g = 0
+    for i in range(nHap):
+        for j in range(i, nHap):
+            hidx[g] = <int*>calloc(2, sizeof(int))
+            hidx[g][0] = i
+            hidx[g][1] = j
+            gls[0][g] = gl_sample[g]
+            gofs[g] = <double*>calloc(1, sizeof(double))
+            gofs[g][0] = gof_sample[g]
+            g += 1
+    out = computeGenotypeCallAndLikelihoods(0, [None] * nHap, [None] * nG, 0, hf, gls, gofs, hidx, vih, [None] * nVariants, ref, nIndividuals, None)
+    return out
+"""
+
 SETUP = r'''
 from setuptools import setup, Extension
 from Cython.Build import cythonize
 exts = [Extension("calign", ["calign.pyx", "align.c"], include_dirs=["."]),
         Extension("calign_drv", ["calign_drv.pyx"], include_dirs=["."]),
-        Extension("asm_drv", ["asm_drv.pyx"])]
+        Extension("asm_drv", ["asm_drv.pyx"]),
+        Extension("pop_drv", ["pop_drv.pyx"])]
 setup(ext_modules=cythonize(exts, language_level=2,
       compiler_directives=dict(cdivision=True, cpow=True, legacy_implicit_noexcept=True)))
 '''
@@ -169,6 +341,22 @@ def build_scratch(scratch):
     open(os.path.join(scratch, "asm_core.pxi"), "w").write("\n".join(asm[29:1389]) + "\n")
     open(os.path.join(scratch, "calign_drv.pyx"), "w").write(CALIGN_DRV)
     open(os.path.join(scratch, "asm_drv.pyx"), "w").write(ASM_DRV)
+    # population driver: the reference's own method texts (cgenotype.pyx:131-189 calculateDataLikelihood,
+    # cpopulation.pyx:384-457 EMiteration, :459-594 calculatePosterior, :623-676 callGenotypes, vcfutils.pyx:163-334
+    # computeGenotypeCallAndLikelihoods, constants cgenotype.pyx:22-27) placed into stub classes that only provide the
+    # attributes those methods touch
+    gen = open(os.path.join(src, "cython/cgenotype.pyx")).read().split("\n")
+    pop = open(os.path.join(src, "cython/cpopulation.pyx")).read().split("\n")
+    vcu = open(os.path.join(src, "cython/vcfutils.pyx")).read().split("\n")
+    consts = [l for l in gen[:60] if l.startswith("cdef double ")]
+    assert any("log10E" in l for l in consts) and any("logHalf" in l for l in consts)
+    assert gen[130].lstrip().startswith("cdef double calculateDataLikelihood") and pop[383].lstrip().startswith("cdef double EMiteration")
+    assert pop[458].lstrip().startswith("cdef double calculatePosterior") and pop[622].lstrip().startswith("cdef void callGenotypes")
+    assert vcu[162].startswith("cdef tuple computeGenotypeCallAndLikelihoods")
+    drv = (POP_HEAD + "\n".join(consts) + "\n" + POP_GENO_CLASS + "\n" + "\n".join(gen[130:189]) + "\n" + POP_CLASS + "\n"
+           + "\n".join(pop[383:457]) + "\n\n" + "\n".join(pop[458:594]) + "\n\n" + "\n".join(pop[622:676]) + "\n"
+           + POP_TAIL.split("def genotype_loglik")[0] + "\n" + "\n".join(vcu[162:334]) + "\n\ndef genotype_loglik" + POP_TAIL.split("def genotype_loglik")[1])
+    open(os.path.join(scratch, "pop_drv.pyx"), "w").write(drv)
     open(os.path.join(scratch, "setup.py"), "w").write(SETUP)
     r = subprocess.run([sys.executable, "setup.py", "build_ext", "--inplace"], cwd=scratch,
                        capture_output=True, text=True)
@@ -399,6 +587,86 @@ def gen_assembler(out):
     print("assembler_cases:", len(cases), "regions,", tot, "variants")
 
 
+def gen_population(out):
+    """a11/a12 + SURVEY 8(f) rank 1: per-read log-likelihood arrays -> genotype log-likelihoods (calculateDataLikelihood),
+    rescaled likelihoods (the loop at cpopulation.pyx:283-309, mirrored here around the compiled method), EM haplotype
+    frequencies, EM likelihoods, genotype calls, variant posteriors, per-position genotype marginalisation -- all outputs
+    come from the reference's own method texts compiled in the scratch directory."""
+    import math
+    import pop_drv
+    rng = np.random.default_rng(606)
+    cases = []
+    shapes = [(1, 2), (1, 4), (1, 8), (2, 3), (3, 4), (5, 2), (8, 5), (30, 4), (30, 8), (100, 8), (100, 3), (2, 12)]
+    for ci in range(60):
+        nInd, H = shapes[ci % len(shapes)]
+        G = H * (H + 1) // 2
+        nVar = max(1, int(math.ceil(math.log2(H))))
+        variants = [pop_drv.Variant(float(rng.choice([1e-3 / 3, 1e-4, 5e-6, 4.5e-5, 1e-10, 0.02]))) for _ in range(nVar)]
+        member = [[(h >> k) & 1 for k in range(nVar)] for h in range(H)]            # haplotype h holds variant k
+        true_freq = rng.dirichlet(np.full(H, 0.5))
+        inds = []
+        gl, nReadsAll, logl_all, gof_all = [], [], [], []
+        for i in range(nInd):
+            nR = 0 if (ci % 5 == 3 and i % 3 == 1) else int(rng.integers(1, 8 if ci % 4 == 2 else 40))
+            nBad = int(rng.integers(0, 4)); nBroken = int(rng.integers(0, 3))
+            tot = nR + nBad + nBroken
+            g1, g2 = rng.choice(H, 2, p=true_freq)
+            ll = np.zeros((H, tot))
+            for r in range(tot):
+                src = g1 if rng.random() < 0.5 else g2
+                for h in range(H):
+                    d = bin(h ^ int(src)).count("1")
+                    v = -0.23025850929940459 * (d * float(rng.integers(1, 5) if ci % 4 == 2 else rng.integers(20, 41)) + (float(rng.integers(10, 40)) if rng.random() < 0.05 else 0.0)) + math.log(1 - 10 ** (-float(rng.choice([60, 60, 29, 3])) / 10))
+                    ll[h, r] = max(-300.0, v)
+                if rng.random() < 0.03:
+                    ll[:, r] = 0.0                                                   # skipped read (chaplotype.pyx:345-346)
+                if rng.random() < 0.03:
+                    ll[:, r] = -300.0                                                # cap
+                if rng.random() < 0.05:
+                    ll[:, r] = ll[0, r] + rng.uniform(-2e-3, 2e-3, H)                # the |l1-l2| <= 1e-3 branch and its edge
+            haps = [pop_drv.Haplotype(tuple(variants[k] for k in range(nVar) if member[h][k]), ll[h].tolist()) for h in range(H)]
+            logl, gof = [], []
+            for a in range(H):
+                for b in range(a, H):
+                    g = pop_drv.DiploidGenotype(haps[a], haps[b])
+                    L, gv, h1, h2 = pop_drv.genotype_loglik(g, nR, nBad, nBroken, 0, 1)
+                    logl.append(L); gof.append(gv)
+            if nR == 0:
+                row = [1.0] * G                                                       # cpopulation.pyx:291-292,308-309
+            else:
+                mx = -1e7
+                for L in logl:
+                    if L > mx:
+                        mx = L
+                row = [max(1e-300, math.exp(L - mx)) for L in logl]                  # :304-307
+            inds.append(dict(n_reads=nR, n_bad=nBad, n_broken=nBroken, loglik=ll.tolist()))
+            gl.append(row); nReadsAll.append(nR); logl_all.append(logl); gof_all.append(gof)
+        haps0 = [pop_drv.Haplotype(tuple(variants[k] for k in range(nVar) if member[h][k]), []) for h in range(H)]
+        useEM = ci % 2
+        popn = pop_drv.Population(haps0, nReadsAll, gl, useEM)
+        iters, maxChange = popn.run(100)
+        freqs, em, calls = popn.results()
+        post = [popn.posterior(v) for v in variants]
+        post_flat = [popn.posterior(v, 1) for v in variants]
+        # per-position marginalisation (vcfutils.pyx:163-334): all variants at one "position", then each alone
+        gcalls = []
+        for vset in [list(range(nVar))] + [[k] for k in range(nVar)]:
+            rows = [[member[h][k] for k in vset] for h in range(H)]
+            isref = [int(not any(rows[h])) for h in range(H)]
+            for i in range(min(nInd, 3)):
+                for nI in (nInd, 30):
+                    o = pop_drv.genotype_call(H, freqs, gl[i], gof_all[i], rows, isref, len(vset), nI)
+                    gcalls.append(dict(vset=vset, ind=i, n_individuals=nI, phased=[o[0], o[1]], likelihoods=list(o[2]),
+                                       genotype_posterior=o[3], nonref_posterior=o[4], ref_posterior=o[5], gof=o[6]))
+        cases.append(dict(n_ind=nInd, n_hap=H, n_var=nVar, priors=[v.prior for v in variants], member=member,
+                          use_em=useEM, individuals=inds, logl=logl_all, gof=gof_all, gl=gl,
+                          iters=iters, max_change=maxChange, freqs=freqs, em=em, calls=calls,
+                          posterior=post, posterior_flat=post_flat, genotype_calls=gcalls))
+    with gzip.open(os.path.join(out, "population_cases.json.gz"), "wt") as f:
+        json.dump(cases, f)
+    print("population: %d cases, %d genotype-call records" % (len(cases), sum(len(c["genotype_calls"]) for c in cases)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scratch", default="/tmp/platgold")
@@ -408,13 +676,15 @@ def main():
         sys.exit("reference tree not found at %s: golden vectors can only be regenerated in the build container" % REF)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     build_scratch(a.scratch)
-    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler"]
+    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population"]
     if "dp" in todo:
         gen_dp(HERE)
     if "mapalign" in todo:
         gen_mapalign(HERE)
     if "assembler" in todo:
         gen_assembler(HERE)
+    if "population" in todo:
+        gen_population(HERE)
 
 
 if __name__ == "__main__":

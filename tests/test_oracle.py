@@ -131,3 +131,61 @@ def test_genotype_known_answers(oracle):
     assert abs(L - exp) < 1e-14
     log10e = 0.43429448190325182
     assert abs(gof - (-10 * (log10e * -1.0 + log10e * -2.0 + log10e * -0.5)) / 3) < 1e-14
+
+
+# ---- a11/a12 + SURVEY 8(f) rank 1, pinned by the reference's own method texts (tests/golden/gen_golden.py) ------------
+def _population_cases(golden_dir):
+    import gzip, json
+    return json.load(gzip.open(os.path.join(golden_dir, "population_cases.json.gz"), "rt"))
+
+
+def test_genotype_likelihoods_match_reference_golden(oracle, golden_dir):
+    """calculateDataLikelihood (cgenotype.pyx:131-189) + the rescaling of Population.setup (cpopulation.pyx:283-309)."""
+    n = 0
+    for c in _population_cases(golden_dir):
+        for i, ind in enumerate(c["individuals"]):
+            ll = np.array(ind["loglik"], dtype=np.float64).reshape(c["n_hap"], -1)
+            logl, gl, gof = oracle.population_setup_ind(ll, ind["n_reads"])
+            assert np.array_equal(gl, np.array(c["gl"][i]))
+            if ind["n_reads"] > 0:
+                assert np.array_equal(logl, np.array(c["logl"][i]))
+                assert np.array_equal(gof, np.array(c["gof"][i]))
+            n += 1
+    assert n > 500
+
+
+def test_em_calls_and_posteriors_match_reference_golden(oracle, golden_dir):
+    """EMiteration / call / callGenotypes / calculatePosterior (cpopulation.pyx:384-703): bit-identical doubles."""
+    long_runs = 0
+    for c in _population_cases(golden_dir):
+        nr = [ind["n_reads"] for ind in c["individuals"]]
+        gl = np.array(c["gl"])
+        freq, em, calls, iters, mc = oracle.em_call(nr, gl, 100, c["use_em"])
+        assert iters == c["iters"] and mc == c["max_change"]
+        assert np.array_equal(freq, np.array(c["freqs"]))
+        live = np.array(nr) > 0
+        assert np.array_equal(em[live], np.array(c["em"])[live])
+        assert calls.tolist() == c["calls"]
+        member = np.array(c["member"])
+        for k, prior in enumerate(c["priors"]):
+            assert oracle.variant_posterior(nr, gl, freq, member[:, k], prior) == c["posterior"][k]
+            assert oracle.variant_posterior(nr, gl, freq, member[:, k], 0.5) == c["posterior_flat"][k]
+        long_runs += iters > 5
+    assert long_runs >= 5
+
+
+def test_genotype_marginalisation_matches_reference_golden(oracle, golden_dir):
+    """computeGenotypeCallAndLikelihoods (vcfutils.pyx:163-334)."""
+    n = 0
+    for c in _population_cases(golden_dir):
+        member = np.array(c["member"])
+        for gc in c["genotype_calls"]:
+            rows = member[:, gc["vset"]]
+            isref = (rows.sum(axis=1) == 0).astype(np.int32)
+            ph, lik, out4 = oracle.genotype_call(c["freqs"], c["gl"][gc["ind"]], c["gof"][gc["ind"]], rows, isref, gc["n_individuals"])
+            assert ph.tolist() == gc["phased"]
+            assert np.array_equal(lik, np.array(gc["likelihoods"]))
+            exp4 = np.array([gc["genotype_posterior"], gc["nonref_posterior"], gc["ref_posterior"], gc["gof"]])
+            assert np.array_equal(out4, exp4, equal_nan=True)
+            n += 1
+    assert n > 900
