@@ -177,6 +177,54 @@ int plat_genotype_window_batch(plat_ctx* ctx, const plat_window_batch* batch, in
                                const double* loglik, const int64_t* gl_off,
                                double* out_gl, double* out_logl, double* out_gof, void* stream);
 
+/* ---- what follows the genotype likelihoods in a calling window -----------------
+ * All arrays are device pointers.  Windows/haplotypes/genotypes are indexed as in
+ * plat_genotype_window_batch: win_hap_begin[n_windows+1]; gl[gl_off[w] + i*G_w + g]; n_reads[w*n_ind+i]
+ * = seg_n_good (Population.nReads, cpopulation.pyx:286-287).  max_haps_per_window bounds H_w (LDS size).
+ *
+ * plat_em_window_batch replaces  cdef void Population.call(maxIters, ...)   cpopulation.pyx:678-703
+ *   (EMiteration :384-457, callGenotypes :623-676) for every window:
+ *     out_freq[win_hap_begin[w] + h]   = Population.frequencies[h]
+ *     out_em  [gl_off[w] + i*G_w + g]  = Population.EMLikelihoods[i][g]  (rows of individuals without
+ *                                         reads are zero; the reference leaves stale values there)
+ *     out_call[w*n_ind + i]            = index of the called genotype, -1 for "None" (no reads);
+ *                                         use_em_likelihoods = --useEMLikelihoods (runner.py:557)
+ *     out_iters[w] (optional)          = EM iterations run (max_iters = 100 at variantcaller.pyx:140)
+ *
+ * plat_variant_posterior_batch replaces  cdef double Population.calculatePosterior(var)  :459-594
+ *   for n_vars variants: variant v lives in window var_window[v]; hap_has_var[var_mask_off[v] + h] != 0
+ *   iff the variant is one of haplotype h's variants (`var in hap.variants`); prior[v] =
+ *   var.calculatePrior(refFile) computed by the caller (variant.pyx:219-259), or 0.5 for flatPrior;
+ *   freq = out_freq of the EM.  out_posterior[v] = the rounded phred value the reference returns.
+ *
+ * plat_genotype_call_batch replaces  cdef tuple computeGenotypeCallAndLikelihoods(...)  vcfutils.pyx:163-334
+ *   for n_sites VCF positions x n_ind samples: site s lies in window site_window[s] and holds
+ *   site_nvar[s] variants; var_in_hap[site_vih_off[s] + h*nvar + k] = varThisPosInHap[h][k];
+ *   is_ref[site_ref_off[s] + h] = haplotypeIsRefAtThisPos[h]; gof as written by
+ *   plat_genotype_window_batch ([g][ind]).  Outputs per (s, i), t = s*n_ind + i:
+ *     out_phased[2t..]  = (phasedIndex1, phasedIndex2)
+ *     out_lik[lik_off[s] + i*NL_s ..], NL_s = (nvar+1)(nvar+2)/2 marginal likelihoods in the
+ *                         reference's (index1, index2 <= index1) order
+ *     out4[4t..]        = genotype posterior, non-ref posterior, ref posterior, best goodness of fit
+ * Sums run in the reference's order in fp64 without FMA contraction.                               */
+int plat_em_window_batch(plat_ctx* ctx, int n_windows, int n_ind, int max_haps_per_window,
+                         const int32_t* win_hap_begin, const int64_t* gl_off, const int32_t* n_reads,
+                         const double* gl, int max_iters, int use_em_likelihoods, double* out_freq,
+                         double* out_em, int32_t* out_call, int32_t* out_iters, void* stream);
+
+int plat_variant_posterior_batch(plat_ctx* ctx, int n_vars, int n_ind, int max_haps_per_window,
+                                 const int32_t* win_hap_begin, const int64_t* gl_off, const int32_t* n_reads,
+                                 const double* gl, const double* freq, const int32_t* var_window,
+                                 const int64_t* var_mask_off, const uint8_t* hap_has_var, const double* prior,
+                                 double* out_posterior, void* stream);
+
+int plat_genotype_call_batch(plat_ctx* ctx, int n_sites, int n_ind, const int32_t* win_hap_begin,
+                             const int64_t* gl_off, const double* gl, const double* gof, const double* freq,
+                             const int32_t* site_window, const int32_t* site_nvar, const int64_t* site_vih_off,
+                             const int64_t* site_ref_off, const int32_t* var_in_hap, const int32_t* is_ref,
+                             const int64_t* lik_off, int32_t* out_phased, double* out_lik, double* out4,
+                             void* stream);
+
 /* ---- a14..a18: assembleReadsAndDetectVariants ---------------------------------------------------
  * Replaces  cdef list assembleReadsAndDetectVariants(chrom, assemStart, assemEnd, refStart, refEnd,
  *                                                    readBuffers, refSeq, options)

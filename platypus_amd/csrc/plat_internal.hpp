@@ -21,7 +21,7 @@ struct plat_ctx {
     size_t lds_max = 0;
     double* d_mapq_lut = nullptr;       // log(1 - exp(mLTOT*mapq)), chaplotype.pyx:621, host libm
     // device scratch (grow-only)
-    plat_scratch hapw, tile, codes, rinfo, hap_flags, pair_rec, jobs, job_score, counters, asm_scratch, tb, slow, dense;
+    plat_scratch hapw, tile, codes, rinfo, hap_flags, pair_rec, jobs, job_score, counters, asm_scratch, tb, slow, dense, pop_scratch;
     // pinned host read-back area
     int64_t* h_readback = nullptr;
     // optional live timing: events 0..5 bracket prepare|seed|dp|finalize, 6..7 bracket genotype

@@ -1,0 +1,319 @@
+// plat_population.hip -- what follows the genotype likelihoods in a calling window:
+//   Population.call            cpopulation.pyx:678-703   EM for the haplotype frequencies (EMiteration :384-457)
+//   Population.callGenotypes   cpopulation.pyx:623-676   arg-max genotype per individual
+//   Population.calculatePosterior            :459-594   phred-scaled posterior of one variant
+//   computeGenotypeCallAndLikelihoods  vcfutils.pyx:163-334   per-site genotype marginalisation of one sample
+//
+// Everything is fp64 and every sum runs in the reference's order (built with -ffp-contract=off), so frequencies, EM
+// likelihoods, calls and marginal likelihoods are the reference's doubles bit for bit; only calculatePosterior goes
+// through log/exp/log10 of the device libm before its final round().
+//
+// Genotype g <-> haplotype pair (a, b), a <= b, in the order of generateAllGenotypesFromHaplotypeList
+// (cgenotype.pyx:193-218): g(a, b) = a*H - a*(a-1)/2 + (b - a).
+#include "plat_internal.hpp"
+
+namespace plat {
+
+__device__ __forceinline__ int geno_index(int a, int b, int H) { return a * H - a * (a - 1) / 2 + (b - a); }
+
+// One single-wave workgroup per window.  E-step: one lane per individual (the genotype loop is sequential, :411-429);
+// M-step: one lane per haplotype k, which adds the responsibilities of the genotypes that contain k in exactly the
+// order the reference's double loop reaches them (:437-446).
+__global__ void __launch_bounds__(64)
+k_em(int n_ind, const int32_t* __restrict__ win_hap_begin, const int64_t* __restrict__ gl_off,
+     const int32_t* __restrict__ n_reads, const double* __restrict__ gl, int max_iters, int use_em,
+     double* __restrict__ out_freq, double* __restrict__ out_em, int32_t* __restrict__ out_call,
+     int32_t* __restrict__ out_iters)
+{
+    extern __shared__ double s_freq[];                 // [H]
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const int h0 = win_hap_begin[w], H = win_hap_begin[w + 1] - h0;
+    const int G = H * (H + 1) / 2;
+    if (H <= 0) { if (lane == 0 && out_iters) out_iters[w] = 0; return; }
+    const double* L = gl + gl_off[w];
+    double* em = out_em + gl_off[w];
+    const int32_t* nr = n_reads + (long long)w * n_ind;
+
+    double eps = 1.0 / (n_ind * 2 * 2);                // :684
+    if (1e-3 < eps) eps = 1e-3;
+    double maxChange = eps + 1;
+    const double uniformFreq = 1.0 / H;
+    for (int k = lane; k < H; k += 64) s_freq[k] = uniformFreq;
+    int nWithData = 0;
+    for (int i = lane; i < n_ind; i += 64) {
+        nWithData += nr[i] != 0;
+        if (nr[i] == 0)                                // the reference leaves stale values here and never reads them
+            for (int j = 0; j < G; ++j) em[(long long)i * G + j] = 0.0;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) nWithData += __shfl_xor(nWithData, s);
+    __syncthreads();
+    int iters = 0;
+    while (maxChange > eps && iters < max_iters) {     // :700-702
+        // E-step
+        for (int i = lane; i < n_ind; i += 64) {
+            if (nr[i] == 0) continue;
+            const double* Li = L + (long long)i * G;
+            double* csr = em + (long long)i * G;
+            double csrSum = 0.0;
+            int j = 0;
+            for (int s = 0; s < H; ++s)
+                for (int r = s; r < H; ++r, ++j) {
+                    const double thisCSR = Li[j] * s_freq[s] * s_freq[r] * (1 + (r != s));   // :421
+                    csr[j] = thisCSR;
+                    csrSum += thisCSR;
+                }
+            if (csrSum > 0.0)
+                for (j = 0; j < G; ++j) csr[j] /= csrSum;
+        }
+        __syncthreads();                               // (one wave: orders the global em writes before the reads below)
+        __threadfence_block();
+        // M-step
+        double change = 0.0;
+        for (int k = lane; k < H; k += 64) {
+            double acc = 0.0;
+            for (int i = 0; i < n_ind; ++i) {
+                if (nr[i] == 0) continue;
+                const double* csr = em + (long long)i * G;
+                for (int a = 0; a < k; ++a) acc += csr[geno_index(a, k, H)];       // genotypes (a, k): k is the second haplotype
+                { const double c = csr[geno_index(k, k, H)]; acc += c; acc += c; }  // (k, k): added as first and as second
+                for (int bb = k + 1; bb < H; ++bb) acc += csr[geno_index(k, bb, H)];
+            }
+            const double nf = acc / (2 * nWithData);   // :449
+            const double fc = fabs(s_freq[k] - nf);
+            if (fc > change) change = fc;
+            s_freq[k] = nf;                            // each lane owns its k: no other lane reads freq in this phase
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            const double o = __shfl_xor(change, s);
+            if (o > change) change = o;
+        }
+        maxChange = change;
+        ++iters;
+        __syncthreads();
+    }
+    for (int k = lane; k < H; k += 64) out_freq[h0 + k] = s_freq[k];
+    if (lane == 0 && out_iters) out_iters[w] = iters;
+    // callGenotypes, :623-676
+    for (int i = lane; i < n_ind; i += 64) {
+        int best = -1;
+        if (nr[i] != 0) {
+            const double* row = (use_em == 1 ? em : L) + (long long)i * G;
+            double maxL = 0.0;
+            for (int g = 0; g < G; ++g) {
+                const double v = row[g];
+                if (best == -1 || v > maxL) { maxL = v; best = g; }
+            }
+        }
+        out_call[(long long)w * n_ind + i] = best;
+    }
+}
+
+// One single-wave workgroup per variant: lanes over individuals, then lane 0 adds the per-individual logs in
+// individual order (:576-584).
+__global__ void __launch_bounds__(64)
+k_variant_posterior(int n_ind, const int32_t* __restrict__ win_hap_begin, const int64_t* __restrict__ gl_off,
+                    const int32_t* __restrict__ n_reads, const double* __restrict__ gl, const double* __restrict__ freq,
+                    const int32_t* __restrict__ var_window, const int64_t* __restrict__ var_mask_off,
+                    const uint8_t* __restrict__ hap_has_var, const double* __restrict__ prior,
+                    double* __restrict__ scratch, double* __restrict__ out_post)
+{
+    extern __shared__ double s_f[];                    // freq[H] | freqsPrime[H]
+    const int v = blockIdx.x, lane = threadIdx.x;
+    const int w = var_window[v];
+    const int h0 = win_hap_begin[w], H = win_hap_begin[w + 1] - h0;
+    const int G = H * (H + 1) / 2;
+    double* f = s_f;
+    double* fp = s_f + H;
+    const uint8_t* has = hap_has_var + var_mask_off[v];
+    const double* L = gl + gl_off[w];
+    const int32_t* nr = n_reads + (long long)w * n_ind;
+    double* logs = scratch + (long long)v * 2 * n_ind;
+    for (int k = lane; k < H; k += 64) f[k] = freq[h0 + k];
+    __syncthreads();
+    if (lane == 0) {                                   // :509-534
+        double sumFreqs = 0.0;
+        for (int i = 0; i < H; ++i) {
+            if (!has[i]) { fp[i] = f[i]; sumFreqs += f[i]; }
+            else fp[i] = 0.0;
+        }
+        if (sumFreqs > 0)
+            for (int i = 0; i < H; ++i) fp[i] /= sumFreqs;
+    }
+    __syncthreads();
+    for (int i = lane; i < n_ind; i += 64) {
+        if (nr[i] == 0) continue;
+        const double* Li = L + (long long)i * G;
+        double sumVar = 0.0, sumNoVar = 0.0;
+        int g = 0;
+        for (int r = 0; r < H; ++r)
+            for (int s = r; s < H; ++s, ++g) {
+                const double factor = r != s ? 2.0 : 1.0;
+                sumVar += (factor * f[r] * f[s] * Li[g]);            // :564
+                sumNoVar += (factor * fp[r] * fp[s] * Li[g]);        // :569
+            }
+        logs[2 * i] = sumVar > 0 ? log(sumVar) : -708.0;             // :576-584
+        logs[2 * i + 1] = sumNoVar > 0 ? log(sumNoVar) : -708.0;
+    }
+    __syncthreads();
+    __threadfence_block();
+    if (lane == 0) {
+        double sv = 0.0, sn = 0.0;
+        for (int i = 0; i < n_ind; ++i) {
+            if (nr[i] == 0) continue;
+            sv += logs[2 * i];
+            sn += logs[2 * i + 1];
+        }
+        double ratio = exp(sn - sv);                                 // :586
+        if (!(ratio > 1e-300)) ratio = 1e-300;
+        const double p = prior[v];
+        out_post[v] = round(-10.0 * (log10(ratio * (1.0 - p)) - log10(p + ratio * (1.0 - p))));   // :594
+    }
+}
+
+// One lane per (site, individual).
+__global__ void __launch_bounds__(64)
+k_genotype_call(int n_sites, int n_ind, const int32_t* __restrict__ win_hap_begin,
+                const int64_t* __restrict__ gl_off, const double* __restrict__ gl, const double* __restrict__ gof,
+                const double* __restrict__ freq, const int32_t* __restrict__ site_window,
+                const int32_t* __restrict__ site_nvar, const int64_t* __restrict__ site_vih_off,
+                const int64_t* __restrict__ site_ref_off, const int32_t* __restrict__ var_in_hap,
+                const int32_t* __restrict__ is_ref,
+                const int64_t* __restrict__ lik_off, int32_t* __restrict__ out_phased, double* __restrict__ out_lik,
+                double* __restrict__ out4)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_sites * n_ind) return;
+    const int s = (int)(t / n_ind), ind = (int)(t % n_ind);
+    const int w = site_window[s], nVar = site_nvar[s];
+    const int h0 = win_hap_begin[w], H = win_hap_begin[w + 1] - h0;
+    const int G = H * (H + 1) / 2;
+    const double* L = gl + gl_off[w] + (long long)ind * G;
+    const double* gf = gof + gl_off[w];                               // [g][ind]
+    const double* f = freq + h0;
+    const int32_t* vih = var_in_hap + site_vih_off[s];                // varThisPosInHap [H][nVar]
+    const int32_t* ref = is_ref + site_ref_off[s];                    // haplotypeIsRefAtThisPos [H]
+    const int NL = (nVar + 1) * (nVar + 2) / 2;
+    double* lik = out_lik + lik_off[s] + (long long)ind * NL;
+
+    double sumLikelihoods = 0.0, bestGof = 1e6, bestLikelihood = -1.0, nonRefPosterior = 0.0, refPosterior = 0.0;
+    double phasedMaxLike = -1e6;
+    int phasedIndex1 = -1, phasedIndex2 = -1, nl = 0;
+    for (int index1 = 0; index1 <= nVar; ++index1)
+        for (int index2 = 0; index2 <= index1; ++index2) {
+            double marginal = 0.0;
+            int g = 0;
+            for (int a = 0; a < H; ++a)
+                for (int bb = a; bb < H; ++bb, ++g) {
+                    const int ref1 = ref[a], ref2 = ref[bb];
+                    const double factor = a != bb ? 2.0 : 1.0;
+                    int matching = 0, v1h1 = 0, v1h2 = 0, v2h1 = 0, v2h2 = 0;
+                    if (index1 == 0 && index2 == 0) {
+                        if (ref1 && ref2) matching = 1;
+                    } else if (index2 == 0) {
+                        v1h1 = vih[a * nVar + index1 - 1]; v1h2 = vih[bb * nVar + index1 - 1];
+                        if ((ref2 && v1h1) || (ref1 && v1h2)) matching = 1;
+                    } else {
+                        v1h1 = vih[a * nVar + index1 - 1]; v1h2 = vih[bb * nVar + index1 - 1];
+                        v2h1 = vih[a * nVar + index2 - 1]; v2h2 = vih[bb * nVar + index2 - 1];
+                        if ((v1h1 && v2h2) || (v2h1 && v1h2)) matching = 1;
+                    }
+                    if (!matching) continue;
+                    double cur;
+                    if (n_ind > 25) cur = (factor * f[a] * f[bb] * L[g]);     // vcfutils.pyx:252-255
+                    else cur = (factor * L[g]);
+                    marginal += cur;
+                    if (cur > phasedMaxLike) {                                                // :260-303
+                        phasedMaxLike = cur;
+                        if (index1 == 0 && index2 == 0) { phasedIndex1 = index1; phasedIndex2 = index2; }
+                        else if (index2 == 0 && index1 != 0) {
+                            if (v1h1) { phasedIndex1 = index1; phasedIndex2 = index2; }
+                            else if (v1h2) { phasedIndex1 = index2; phasedIndex2 = index1; }
+                        } else if (index2 == index1 && index1 > 0) { phasedIndex1 = index1; phasedIndex2 = index2; }
+                        else if (index2 > 0 && index1 > 0 && index2 != index1) {
+                            if (v1h1 && v2h2) { phasedIndex1 = index1; phasedIndex2 = index2; }
+                            else if (v1h2 && v2h1) { phasedIndex1 = index2; phasedIndex2 = index1; }
+                        }
+                    }
+                    const double gv = gf[(long long)g * n_ind + ind];
+                    if (gv < bestGof) bestGof = gv;
+                }
+            if (marginal > bestLikelihood) bestLikelihood = marginal;
+            if ((index1 == 1 && index2 == 0) || (index1 == 1 && index2 == 1)) nonRefPosterior += marginal;
+            else if (index1 == 0 && index2 == 0) refPosterior += marginal;
+            sumLikelihoods += marginal;
+            lik[nl++] = marginal;
+        }
+    out_phased[2 * t] = phasedIndex1;
+    out_phased[2 * t + 1] = phasedIndex2;
+    out4[4 * t] = bestLikelihood / sumLikelihoods;
+    out4[4 * t + 1] = nonRefPosterior / sumLikelihoods;
+    out4[4 * t + 2] = refPosterior / sumLikelihoods;
+    out4[4 * t + 3] = bestGof;
+}
+
+}  // namespace plat
+
+using namespace plat;
+
+PLAT_EXPORT int plat_em_window_batch(plat_ctx* ctx, int n_windows, int n_ind, int max_haps_per_window,
+                                     const int32_t* win_hap_begin, const int64_t* gl_off, const int32_t* n_reads,
+                                     const double* gl, int max_iters, int use_em_likelihoods, double* out_freq,
+                                     double* out_em, int32_t* out_call, int32_t* out_iters, void* stream)
+{
+    if (!ctx || n_windows < 0 || n_ind < 1 || max_haps_per_window < 0 || max_iters < 0) return PLAT_ERR_INVALID;
+    if (n_windows == 0) return PLAT_OK;
+    if (!win_hap_begin || !gl_off || !n_reads || !gl || !out_freq || !out_em || !out_call) return PLAT_ERR_INVALID;
+    const size_t lds = (size_t)max_haps_per_window * sizeof(double) + 16;
+    if (lds > 64 * 1024) return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_em, dim3(n_windows), dim3(64), lds, (hipStream_t)stream, n_ind, win_hap_begin, gl_off, n_reads, gl,
+                       max_iters, use_em_likelihoods, out_freq, out_em, out_call, out_iters);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_variant_posterior_batch(plat_ctx* ctx, int n_vars, int n_ind, int max_haps_per_window,
+                                             const int32_t* win_hap_begin, const int64_t* gl_off, const int32_t* n_reads,
+                                             const double* gl, const double* freq, const int32_t* var_window,
+                                             const int64_t* var_mask_off, const uint8_t* hap_has_var, const double* prior,
+                                             double* out_posterior, void* stream)
+{
+    if (!ctx || n_vars < 0 || n_ind < 1 || max_haps_per_window < 0) return PLAT_ERR_INVALID;
+    if (n_vars == 0) return PLAT_OK;
+    if (!win_hap_begin || !gl_off || !n_reads || !gl || !freq || !var_window || !var_mask_off || !hap_has_var || !prior ||
+        !out_posterior)
+        return PLAT_ERR_INVALID;
+    const size_t lds = (size_t)2 * max_haps_per_window * sizeof(double) + 16;
+    if (lds > 64 * 1024) return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = plat_reserve(ctx, ctx->pop_scratch, (size_t)n_vars * 2 * n_ind * sizeof(double));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_variant_posterior, dim3(n_vars), dim3(64), lds, (hipStream_t)stream, n_ind, win_hap_begin, gl_off,
+                       n_reads, gl, freq, var_window, var_mask_off, hap_has_var, prior, (double*)ctx->pop_scratch.ptr,
+                       out_posterior);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_genotype_call_batch(plat_ctx* ctx, int n_sites, int n_ind, const int32_t* win_hap_begin,
+                                         const int64_t* gl_off, const double* gl, const double* gof, const double* freq,
+                                         const int32_t* site_window, const int32_t* site_nvar, const int64_t* site_vih_off,
+                                         const int64_t* site_ref_off, const int32_t* var_in_hap, const int32_t* is_ref,
+                                         const int64_t* lik_off,
+                                         int32_t* out_phased, double* out_lik, double* out4, void* stream)
+{
+    if (!ctx || n_sites < 0 || n_ind < 1) return PLAT_ERR_INVALID;
+    if (n_sites == 0) return PLAT_OK;
+    if (!win_hap_begin || !gl_off || !gl || !gof || !freq || !site_window || !site_nvar || !site_vih_off || !site_ref_off || !var_in_hap ||
+        !is_ref || !lik_off || !out_phased || !out_lik || !out4)
+        return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    const long long n = (long long)n_sites * n_ind;
+    hipLaunchKernelGGL(k_genotype_call, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n_sites, n_ind,
+                       win_hap_begin, gl_off, gl, gof, freq, site_window, site_nvar, site_vih_off, site_ref_off, var_in_hap,
+                       is_ref, lik_off, out_phased, out_lik, out4);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}

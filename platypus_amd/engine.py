@@ -51,6 +51,34 @@ class DeviceBatch:
         self.gof = torch.empty(ng, dtype=torch.float64, device=device)
 
 
+class LikelihoodBatch:
+    """HBM image of genotype likelihoods that were computed elsewhere (e.g. handed over by a caller that kept
+    Population.setup on its side): what em() / variant_posteriors() / genotype_calls() need of a DeviceBatch.
+
+    hap_counts[w] = H_w; n_reads [nW][n_ind]; gl[w] = [n_ind][G_w]; gof[w] = [G_w][n_ind] (optional)."""
+
+    class _Host:
+        pass
+
+    def __init__(self, n_ind, hap_counts, n_reads, gl, gof, device):
+        torch = _torch()
+        hb = self.host = LikelihoodBatch._Host()
+        hb.n_ind, hb.n_windows = int(n_ind), len(hap_counts)
+        hb.win_hap_begin = np.concatenate([[0], np.cumsum(hap_counts)]).astype(np.int32)
+        hb.n_haps = int(hb.win_hap_begin[-1])
+        G = np.asarray(hap_counts, dtype=np.int64) * (np.asarray(hap_counts, dtype=np.int64) + 1) // 2
+        hb.gl_off = np.concatenate([[0], np.cumsum(G * n_ind)]).astype(np.int64)
+
+        def up(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(device)
+        self.t = dict(win_hap_begin=up(hb.win_hap_begin, np.int32), gl_off=up(hb.gl_off, np.int64),
+                      seg_n_good=up(np.asarray(n_reads).reshape(-1), np.int32))
+        self.gl = up(np.concatenate([np.asarray(x, dtype=np.float64).reshape(-1) for x in gl] + [np.zeros(1)]), np.float64)
+        if gof is None:
+            gof = [np.zeros(int(g) * n_ind) for g in G]
+        self.gof = up(np.concatenate([np.asarray(x, dtype=np.float64).reshape(-1) for x in gof] + [np.zeros(1)]), np.float64)
+
+
 class Engine:
     def __init__(self, device_index=0):
         torch = _torch()
@@ -118,6 +146,85 @@ class Engine:
         st = self.align(db, want_stats=want_stats)
         self.genotype(db)
         return st
+
+    # ---- EM, genotype calls, posteriors, per-site marginalisation -------------------
+    def upload_likelihoods(self, n_ind, hap_counts, n_reads, gl, gof=None) -> LikelihoodBatch:
+        return LikelihoodBatch(n_ind, hap_counts, n_reads, gl, gof, self.device)
+
+    def em(self, db, max_iters=100, use_em_likelihoods=0):
+        """Population.call (EM + callGenotypes) for every window of `db`, on the genotype likelihoods left in HBM by
+        genotype().  Results stay in HBM: db.freq [n_haps], db.em [like db.gl], db.calls [n_windows*n_ind], db.em_iters."""
+        torch = _torch()
+        hb = db.host
+        db.freq = torch.empty(max(hb.n_haps, 1), dtype=torch.float64, device=self.device)
+        db.em = torch.empty_like(db.gl)
+        db.calls = torch.empty(max(hb.n_windows * hb.n_ind, 1), dtype=torch.int32, device=self.device)
+        db.em_iters = torch.empty(max(hb.n_windows, 1), dtype=torch.int32, device=self.device)
+        maxh = int(np.max(np.diff(hb.win_hap_begin))) if hb.n_windows else 0
+        db.max_haps = maxh
+        rc = self.lib.plat_em_window_batch(self.ctx, hb.n_windows, hb.n_ind, maxh, db.t["win_hap_begin"].data_ptr(),
+                                           db.t["gl_off"].data_ptr(), db.t["seg_n_good"].data_ptr(), db.gl.data_ptr(),
+                                           max_iters, use_em_likelihoods, db.freq.data_ptr(), db.em.data_ptr(),
+                                           db.calls.data_ptr(), db.em_iters.data_ptr(), self._stream())
+        _lib.check(rc, "plat_em_window_batch")
+
+    def variant_posteriors(self, db, var_window, hap_masks, priors):
+        """Population.calculatePosterior for a list of variants: var_window[v] = window, hap_masks[v] = 0/1 per haplotype
+        of that window (`var in hap.variants`), priors[v].  Needs em().  Returns a numpy array of phred posteriors."""
+        torch = _torch()
+        n = len(var_window)
+        if n == 0:
+            return np.zeros(0)
+        hb = db.host
+        off = np.concatenate([[0], np.cumsum([len(m) for m in hap_masks])]).astype(np.int64)
+        blob = np.concatenate([np.asarray(m, dtype=np.uint8) for m in hap_masks])
+
+        def up(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.device)
+        d_w, d_off, d_blob, d_pr = up(var_window, np.int32), up(off, np.int64), up(blob, np.uint8), up(priors, np.float64)
+        out = torch.empty(n, dtype=torch.float64, device=self.device)
+        rc = self.lib.plat_variant_posterior_batch(self.ctx, n, hb.n_ind, db.max_haps, db.t["win_hap_begin"].data_ptr(),
+                                                   db.t["gl_off"].data_ptr(), db.t["seg_n_good"].data_ptr(),
+                                                   db.gl.data_ptr(), db.freq.data_ptr(), d_w.data_ptr(), d_off.data_ptr(),
+                                                   d_blob.data_ptr(), d_pr.data_ptr(), out.data_ptr(), self._stream())
+        _lib.check(rc, "plat_variant_posterior_batch")
+        torch.cuda.synchronize(self.device)
+        return out.cpu().numpy()
+
+    def genotype_calls(self, db, sites):
+        """computeGenotypeCallAndLikelihoods for every (site, sample).  `sites`: list of dicts {window, var_in_hap
+        [H][nVar], is_ref [H]}.  Needs em().  Returns per site (phased [n_ind][2], likelihoods [n_ind][NL], out4 [n_ind][4])."""
+        torch = _torch()
+        nS = len(sites)
+        if nS == 0:
+            return []
+        hb = db.host
+        nvar = np.array([np.asarray(s["var_in_hap"]).shape[1] for s in sites], dtype=np.int32)
+        vih = [np.asarray(s["var_in_hap"], dtype=np.int32).reshape(-1) for s in sites]
+        ref = [np.asarray(s["is_ref"], dtype=np.int32) for s in sites]
+        vih_off = np.concatenate([[0], np.cumsum([len(v) for v in vih])]).astype(np.int64)
+        ref_off = np.concatenate([[0], np.cumsum([len(r) for r in ref])]).astype(np.int64)
+        NL = (nvar.astype(np.int64) + 1) * (nvar + 2) // 2
+        lik_off = np.concatenate([[0], np.cumsum(NL * hb.n_ind)]).astype(np.int64)
+
+        def up(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.device)
+        d_win = up([s["window"] for s in sites], np.int32)
+        d_nvar, d_vo, d_ro, d_lo = up(nvar, np.int32), up(vih_off, np.int64), up(ref_off, np.int64), up(lik_off, np.int64)
+        d_vih = up(np.concatenate(vih + [np.zeros(1, dtype=np.int32)]), np.int32)
+        d_ref = up(np.concatenate(ref), np.int32)
+        ph = torch.empty(nS * hb.n_ind * 2, dtype=torch.int32, device=self.device)
+        lik = torch.empty(int(lik_off[-1]), dtype=torch.float64, device=self.device)
+        out4 = torch.empty(nS * hb.n_ind * 4, dtype=torch.float64, device=self.device)
+        rc = self.lib.plat_genotype_call_batch(self.ctx, nS, hb.n_ind, db.t["win_hap_begin"].data_ptr(),
+                                               db.t["gl_off"].data_ptr(), db.gl.data_ptr(), db.gof.data_ptr(),
+                                               db.freq.data_ptr(), d_win.data_ptr(), d_nvar.data_ptr(), d_vo.data_ptr(),
+                                               d_ro.data_ptr(), d_vih.data_ptr(), d_ref.data_ptr(), d_lo.data_ptr(),
+                                               ph.data_ptr(), lik.data_ptr(), out4.data_ptr(), self._stream())
+        _lib.check(rc, "plat_genotype_call_batch")
+        torch.cuda.synchronize(self.device)
+        ph, lik, out4 = ph.cpu().numpy().reshape(nS, hb.n_ind, 2), lik.cpu().numpy(), out4.cpu().numpy().reshape(nS, hb.n_ind, 4)
+        return [(ph[s], lik[lik_off[s]:lik_off[s + 1]].reshape(hb.n_ind, int(NL[s])), out4[s]) for s in range(nS)]
 
     # ---- a14..a18 ------------------------------------------------------------------------------------
     def assemble(self, regions, kmer_size=15, min_qual=20, min_weight=40, no_cycles=0, max_vars=512,

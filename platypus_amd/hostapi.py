@@ -75,6 +75,23 @@ class Variant:
     def __repr__(self):
         return "Variant(%s:%d %s->%s)" % (self.refName, self.refPos, self.removed.decode(), self.added.decode())
 
+    def calculatePrior(self, refFile=None):
+        """variant.pyx:219-259.  The indel branch (indelPrior, :146-217: homopolymer-context error model tables) is host
+        logic outside the accelerated path: give indels an explicit `prior` attribute."""
+        explicit = getattr(self, "prior", None)
+        if explicit is not None:
+            return max(float(explicit), 1e-10)
+        if self.nAdded == 1 and self.nRemoved == 1:
+            prior = 1e-3 / 3
+        elif self.nAdded == self.nRemoved:
+            nDiffs = len([1 for x, y in zip(self.added, self.removed) if x != y])
+            prior = 5e-5 * (0.1 ** (nDiffs - 1)) * (1.0 - 0.1)
+        elif self.nAdded == 0 or self.nRemoved == 0:
+            raise NotImplementedError("indel priors (variant.pyx:146-217) are not part of the device path: set Variant.prior")
+        else:
+            prior = 5e-6
+        return max(prior, 1e-10)
+
 
 class AlignedRead:
     """The fields of cAlignedRead the hot path reads (htslibWrapper.pxd:187-201).  qual is raw phred."""
@@ -312,7 +329,53 @@ class Population:
         self.genotypeLogLikelihoods = db.logl.cpu().numpy()[:nInd * G].reshape(nInd, G).copy()
         self.goodnessOfFitValues = db.gof.cpu().numpy()[:nInd * G].reshape(G, nInd).copy()           # [genotype][ind]
         self.haplotypeLikelihoods = db.loglik.cpu().numpy()[:hb.n_pairs].reshape(H, -1).copy()
+        self._db = db
         return self
+
+    # ---- SURVEY 8(f) rank 1 ----------------------------------------------------------------------------
+    def call(self, maxIters=100, computeVCFFields=0):
+        """cpopulation.pyx:678-720: EM frequencies, genotype calls, variant posteriors (INFO/FILTER fields are not built)."""
+        eng = get_engine()
+        db = self._db
+        eng.em(db, maxIters, int(self.options.useEMLikelihoods))
+        eng.synchronize()
+        nInd, G = self.nIndividuals, self.nGenotypes
+        self.frequencies = db.freq.cpu().numpy()[:self.nHaplotypes].copy()
+        self.EMLikelihoods = db.em.cpu().numpy()[:nInd * G].reshape(nInd, G).copy()
+        idx = db.calls.cpu().numpy()[:nInd]
+        self.genotypeCalls = [None if g < 0 else self.genotypes[g] for g in idx]                     # :623-676
+        self.emIterations = int(db.em_iters.cpu().numpy()[0])
+        self.computeVariantPosteriors()
+        return self
+
+    def _masks(self, vs):
+        return [np.array([v in h.variants for h in self.haplotypes], dtype=np.uint8) for v in vs]
+
+    def calculatePosterior(self, var, flatPrior=0):                                                   # :459-594
+        prior = 0.5 if flatPrior == 1 else var.calculatePrior(getattr(self, "refFile", None))
+        return float(get_engine().variant_posteriors(self._db, [0], self._masks([var]), [prior])[0])
+
+    def computeVariantPosteriors(self):                                                               # :596-621
+        vs, done = [], set()
+        for h in self.haplotypes:
+            for v in h.variants:
+                if v not in done:
+                    done.add(v); vs.append(v)
+        self.variantPosteriors, self.varsByPos = {}, {}
+        if not vs:
+            return
+        post = get_engine().variant_posteriors(self._db, [0] * len(vs), self._masks(vs), [v.calculatePrior(None) for v in vs])
+        for v, p in zip(vs, post):
+            if p >= self.options.minPosterior:
+                self.variantPosteriors[v] = float(p)
+                self.varsByPos.setdefault(v.refPos, []).append(v)
+
+    def computeGenotypeCallAndLikelihoods(self, sampleIndex, variantsThisPos, haplotypeIsRefAtThisPos):
+        """vcfutils.pyx:163-334 for one sample and one VCF position.  Returns the reference's 7-tuple."""
+        vih = np.array([[v in h.variants for v in variantsThisPos] for h in self.haplotypes], dtype=np.int32)
+        ph, lik, out4 = get_engine().genotype_calls(self._db, [dict(window=0, var_in_hap=vih, is_ref=haplotypeIsRefAtThisPos)])[0]
+        i = sampleIndex
+        return (int(ph[i][0]), int(ph[i][1]), lik[i].tolist(), float(out4[i][0]), float(out4[i][1]), float(out4[i][2]), float(out4[i][3]))
 
 
 def assembleReadsAndDetectVariants(chrom, assemStart, assemEnd, refStart, refEnd, readBuffers, refSeq, options=None):

@@ -80,6 +80,34 @@ def test_population_setup_matches_oracle(oracle):
     assert np.isclose(L, pop.genotypeLogLikelihoods[1][1], rtol=1e-12, atol=0) and gofv[1] != 0
 
 
+def test_population_call_matches_oracle(oracle):
+    """Population.call: EM frequencies, EM likelihoods, genotype calls, variant posteriors, per-site marginalisation."""
+    fasta, haps, buffers, ws, we = make_window(n_ind=3)
+    for h in haps:
+        for v in h.variants:
+            if v.nAdded != v.nRemoved:
+                v.prior = 1e-4                                         # indel priors are host logic (variant.pyx:146-217)
+    genotypes = H.generateAllGenotypesFromHaplotypeList(haps)
+    pop = H.Population().setup([], haps, genotypes, 3, 0, buffers).call(100, 0)
+    f, em, calls, iters, _ = oracle.em_call(pop.nReads, pop.genotypeLikelihoods, 100, 0)
+    assert iters == pop.emIterations and np.array_equal(f, pop.frequencies)
+    assert np.array_equal(em, pop.EMLikelihoods)
+    assert [genotypes[c] if c >= 0 else None for c in calls] == pop.genotypeCalls
+    variants = sorted({v for h in haps for v in h.variants})
+    assert len(variants) == 2
+    for v in variants:
+        mask = [v in h.variants for h in haps]
+        exp = oracle.variant_posterior(pop.nReads, pop.genotypeLikelihoods, f, mask, v.calculatePrior())
+        assert pop.calculatePosterior(v) == exp
+        assert (pop.variantPosteriors.get(v) == exp) if exp >= 5 else (v not in pop.variantPosteriors)
+    v = variants[0]
+    isref = np.array([v not in h.variants for h in haps], dtype=np.int32)
+    got = pop.computeGenotypeCallAndLikelihoods(1, [v], isref)
+    ph, lik, out4 = oracle.genotype_call(f, pop.genotypeLikelihoods[1], pop.goodnessOfFitValues[:, 1],
+                                         np.array([[v in h.variants] for h in haps]), isref, 3)
+    assert got[:2] == tuple(ph.tolist()) and got[2] == lik.tolist() and got[3:] == tuple(out4.tolist())
+
+
 def test_calculateFlankScore_option(oracle):
     fasta, haps, buffers, ws, we = make_window()
     exp0 = oracle_rows(oracle, haps, buffers[0], ws, we)

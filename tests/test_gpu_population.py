@@ -1,0 +1,124 @@
+"""GPU parity of SURVEY 8(f) rank 1 (EM, genotype calls, variant posteriors, per-site genotype marginalisation) through
+the C ABI, against golden vectors produced by the reference's own method texts (tests/golden/gen_golden.py) and against
+the oracle on the likelihoods the device itself computed."""
+import collections
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from platypus_amd import synth
+from platypus_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _cases(golden_dir):
+    return json.load(gzip.open(os.path.join(golden_dir, "population_cases.json.gz"), "rt"))
+
+
+def _groups(cases):
+    g = collections.defaultdict(list)
+    for c in cases:
+        g[(c["n_ind"], c["use_em"])].append(c)
+    return g
+
+
+def test_em_and_calls_bit_identical_to_reference_golden(eng, golden_dir):
+    """Frequencies, EM likelihoods, genotype calls and iteration counts: only + * / in the reference's order -> equal doubles."""
+    for (n_ind, use_em), cs in _groups(_cases(golden_dir)).items():
+        lb = eng.upload_likelihoods(n_ind, [c["n_hap"] for c in cs], [[i["n_reads"] for i in c["individuals"]] for c in cs],
+                                    [c["gl"] for c in cs], [np.array(c["gof"]).T for c in cs])
+        eng.em(lb, 100, use_em)
+        freq, em = lb.freq.cpu().numpy(), lb.em.cpu().numpy()
+        calls, iters = lb.calls.cpu().numpy().reshape(len(cs), n_ind), lb.em_iters.cpu().numpy()
+        for w, c in enumerate(cs):
+            h0, h1 = lb.host.win_hap_begin[w], lb.host.win_hap_begin[w + 1]
+            assert iters[w] == c["iters"]
+            assert np.array_equal(freq[h0:h1], np.array(c["freqs"]))
+            G = c["n_hap"] * (c["n_hap"] + 1) // 2
+            got = em[lb.host.gl_off[w]:lb.host.gl_off[w] + n_ind * G].reshape(n_ind, G)
+            live = np.array([i["n_reads"] for i in c["individuals"]]) > 0
+            assert np.array_equal(got[live], np.array(c["em"])[live]) and not got[~live].any()
+            assert calls[w].tolist() == c["calls"]
+
+
+def test_variant_posteriors_match_reference_golden(eng, golden_dir):
+    """calculatePosterior: log/exp/log10 come from the device libm, the result is a rounded phred value -> equal."""
+    n = 0
+    for (n_ind, use_em), cs in _groups(_cases(golden_dir)).items():
+        lb = eng.upload_likelihoods(n_ind, [c["n_hap"] for c in cs], [[i["n_reads"] for i in c["individuals"]] for c in cs],
+                                    [c["gl"] for c in cs])
+        eng.em(lb, 100, use_em)
+        vw, masks, priors, exp = [], [], [], []
+        for w, c in enumerate(cs):
+            member = np.array(c["member"])
+            for k, p in enumerate(c["priors"]):
+                vw += [w, w]; masks += [member[:, k], member[:, k]]; priors += [p, 0.5]
+                exp += [c["posterior"][k], c["posterior_flat"][k]]
+        got = eng.variant_posteriors(lb, vw, masks, priors)
+        assert np.array_equal(got, np.array(exp))
+        n += len(exp)
+    assert n > 200
+
+
+def test_genotype_marginalisation_bit_identical_to_reference_golden(eng, golden_dir):
+    n = 0
+    for (n_ind, use_em), cs in _groups(_cases(golden_dir)).items():
+        lb = eng.upload_likelihoods(n_ind, [c["n_hap"] for c in cs], [[i["n_reads"] for i in c["individuals"]] for c in cs],
+                                    [c["gl"] for c in cs], [np.array(c["gof"]).T for c in cs])
+        eng.em(lb, 100, use_em)
+        sites, expect = [], []
+        for w, c in enumerate(cs):
+            member = np.array(c["member"])
+            seen = set()
+            for gc in c["genotype_calls"]:
+                if gc["n_individuals"] != n_ind:
+                    continue                    # (those records exercise the > 25 rule on the oracle only)
+                key = tuple(gc["vset"])
+                if key not in seen:
+                    seen.add(key)
+                    rows = member[:, gc["vset"]]
+                    sites.append(dict(window=w, var_in_hap=rows, is_ref=(rows.sum(axis=1) == 0).astype(np.int32)))
+                expect.append((len(sites) - 1, gc))
+        res = eng.genotype_calls(lb, sites)
+        for s, gc in expect:
+            ph, lik, out4 = res[s]
+            i = gc["ind"]
+            assert ph[i].tolist() == gc["phased"]
+            assert np.array_equal(lik[i], np.array(gc["likelihoods"]))
+            exp4 = np.array([gc["genotype_posterior"], gc["nonref_posterior"], gc["ref_posterior"], gc["gof"]])
+            assert np.array_equal(out4[i], exp4, equal_nan=True)
+            n += 1
+    assert n > 400
+
+
+def test_population_path_end_to_end_vs_oracle(eng, oracle):
+    """align -> genotype likelihoods -> EM on the device (population config: 12 samples), EM checked against the oracle
+    run on the device's own likelihoods."""
+    hb = synth.config5(6, 12)
+    db = eng.upload(hb)
+    eng.call_windows(db, want_stats=False)
+    eng.em(db, 100, 0)
+    gl = db.gl.cpu().numpy()
+    freq, em = db.freq.cpu().numpy(), db.em.cpu().numpy()
+    calls, iters = db.calls.cpu().numpy().reshape(hb.n_windows, hb.n_ind), db.em_iters.cpu().numpy()
+    for w in range(hb.n_windows):
+        H = hb.win_hap_begin[w + 1] - hb.win_hap_begin[w]
+        G = H * (H + 1) // 2
+        nr = hb.seg_n_good[w * hb.n_ind:(w + 1) * hb.n_ind]
+        rows = gl[hb.gl_off[w]:hb.gl_off[w] + hb.n_ind * G].reshape(hb.n_ind, G)
+        f, e, c, it, mc = oracle.em_call(nr, rows, 100, 0)
+        assert it == iters[w] and np.array_equal(f, freq[hb.win_hap_begin[w]:hb.win_hap_begin[w + 1]])
+        assert c.tolist() == calls[w].tolist()
+        live = np.asarray(nr) > 0
+        assert np.array_equal(e[live], em[hb.gl_off[w]:hb.gl_off[w] + hb.n_ind * G].reshape(hb.n_ind, G)[live])

@@ -41,6 +41,14 @@ def main():
     eng.synchronize(); t = (time.perf_counter() - t0) / 5
     out["config5_population"] = dict(windows=hb.n_windows, n_ind=hb.n_ind, reads=hb.n_reads, pairs=int(st.n_pairs),
                                      ms_per_step=1e3 * t, gcups=st.cells_reference / t / 1e9, windows_per_sec=hb.n_windows / t)
+    # EM + genotype calls for the same windows
+    eng.em(db, 100, 0); eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        eng.em(db, 100, 0)
+    eng.synchronize(); t = (time.perf_counter() - t0) / 5
+    it = db.em_iters.cpu().numpy()
+    out["config5_population"].update(em_ms=1e3 * t, em_iterations_mean=float(it.mean()), em_iterations_max=int(it.max()))
     print(json.dumps(out, indent=1))
 
 
