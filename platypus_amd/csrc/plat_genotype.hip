@@ -42,14 +42,26 @@ k_genotype(plat_window_batch b, int n_ind, const int32_t* __restrict__ seg_read_
                 const double* arr1 = ll + (long long)a * R;
                 const double* arr2 = ll + (long long)bb * R;
                 double like = 0.0, gsum = 0.0;
-                for (int r = s0; r < s1; ++r) {     // cgenotype.pyx:151-180
-                    const double l1 = arr1[r], l2 = arr2[r];
-                    const double ll1 = log10E * l1, ll2 = log10E * l2;
-                    gsum += (ll1 > ll2 ? ll1 : ll2);
-                    if (a == bb) like += l1;
-                    else if (fabs(l1 - l2) >= 3) like += (logHalf + (l1 > l2 ? l1 : l2));
-                    else if (fabs(l1 - l2) <= 1e-3) like += l1;
-                    else like += log(0.5 * (exp(l1) + exp(l2)));
+                // reads in index order (cgenotype.pyx:151-180); the loads of 8 reads are issued together so that the
+                // serial fp64 chain does not wait for a memory round trip per read
+                for (int r0 = s0; r0 < s1; r0 += 8) {
+                    double v1[8], v2[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = min(r0 + k, s1 - 1);
+                        v1[k] = arr1[r]; v2[k] = arr2[r];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (r0 + k >= s1) break;
+                        const double l1 = v1[k], l2 = v2[k];
+                        const double ll1 = log10E * l1, ll2 = log10E * l2;
+                        gsum += (ll1 > ll2 ? ll1 : ll2);
+                        if (a == bb) like += l1;
+                        else if (fabs(l1 - l2) >= 3) like += (logHalf + (l1 > l2 ? l1 : l2));
+                        else if (fabs(l1 - l2) <= 1e-3) like += l1;
+                        else like += log(0.5 * (exp(l1) + exp(l2)));
+                    }
                 }
                 L = like;
                 gof = (-10 * gsum) / nGood;         // cgenotype.pyx:182-183

@@ -313,13 +313,113 @@ def genotype_call(int nHap, list freqs, list gl_sample, list gof_sample, list va
     return out
 """
 
+HAP_HEAD = r"""
+from __future__ import division
+cimport cython
+import logging
+import math
+from calign cimport hash_sequence_multihit, hashReadForMapping, mapAndAlignReadToHaplotype
+from calign cimport hash_nucs, hash_size
+from htslibWrapper cimport cAlignedRead
+logger = logging.getLogger("Log")
+StandardError = Exception
+
+cdef extern from "math.h":
+    double exp(double)
+    double log(double)
+cdef extern from "stdlib.h":
+    void free(void *)
+    void *malloc(size_t)
+    void *calloc(size_t, size_t)
+    void *realloc(void *, size_t)
+
+cdef void* my_malloc(size_t n):
+    return malloc(n)
+
+cdef inline int Read_IsQCFail(cAlignedRead* theRead) nogil:      # htslibWrapper.pxd:271-272, BAM_FQCFAIL = 512
+    return ((theRead.bitFlag & 512) != 0)
+
+cdef class Options:
+    cdef public int calculateFlankScore
+    def __init__(self, int calculateFlankScore):
+        self.calculateFlankScore = calculateFlankScore
+"""
+
+HAP_CLASS = r"""
+cdef class Haplotype:
+    cdef public int startPos, endPos, endBufferSize, hapLen, lastIndividualIndex, lenCache, mapCountsLen
+    cdef public bytes haplotypeSequence
+    cdef public object options
+    cdef char* cHaplotypeSequence
+    cdef char* cHomopolQ
+    cdef char* localGapOpen
+    cdef short* hapSequenceHash
+    cdef short* hapSequenceNextArray
+    cdef double* likelihoodCache
+    cdef int* mapCounts
+
+    def __init__(self, bytes haplotypeSequence, int startPos, int endPos, int endBufferSize, int maxReadLength, options):
+        # the tail of the reference constructor (chaplotype.pyx:175-191) for a given haplotype sequence
+        self.haplotypeSequence = haplotypeSequence
+        self.startPos, self.endPos, self.endBufferSize = startPos, endPos, endBufferSize
+        self.options = options
+        self.lastIndividualIndex = -1
+        self.localGapOpen = NULL
+        self.cHaplotypeSequence = self.haplotypeSequence
+        self.hapLen = len(self.haplotypeSequence)
+        self.cHomopolQ = homopolq
+        self.hapSequenceHash = NULL
+        self.hapSequenceNextArray = NULL
+        self.likelihoodCache = NULL
+        self.lenCache = 0
+        self.mapCounts = <int*>malloc((2*(self.hapLen+maxReadLength))*sizeof(int))
+        self.mapCountsLen = 2 * (self.hapLen + maxReadLength)
+
+    def gap_open(self):
+        self.annotateWithGapOpen()
+        return bytes(self.localGapOpen[:self.hapLen + 1])
+"""
+
+HAP_TAIL = r"""
+cdef cAlignedRead* make_read(bytes seq, bytes qual, int pos, int end, int mapq, int flag):
+    cdef cAlignedRead* r = <cAlignedRead*>calloc(1, sizeof(cAlignedRead))
+    r.seq = seq
+    r.qual = qual
+    r.rlen = len(seq)
+    r.pos = pos
+    r.end = end
+    r.mapq = mapq
+    r.bitFlag = flag
+    r.hash = NULL
+    return r
+
+def align_reads(Haplotype hap, list good, list bad, list broken, int individualIndex):
+    # each read: (seq, qual, pos, end, mapq, bitFlag); returns the likelihoodCache INCLUDING the 999 terminator
+    cdef int ng = len(good), nb = len(bad), nk = len(broken), i
+    cdef cAlignedRead** arr = <cAlignedRead**>calloc(ng + nb + nk + 1, sizeof(cAlignedRead*))
+    keep = []
+    for i, t in enumerate(good + bad + broken):
+        keep.append(t)
+        arr[i] = make_read(t[0], t[1], t[2], t[3], t[4], t[5])
+    cdef double* out = hap.alignReads(individualIndex, arr, arr + ng, arr + ng, arr + ng + nb, arr + ng + nb, arr + ng + nb + nk, 0)
+    res = [out[i] for i in range(ng + nb + nk + 1)]
+    single = [hap.alignSingleRead(arr[i], 0) for i in range(ng + nb + nk)]
+    for i in range(ng + nb + nk):
+        if arr[i].hash != NULL:
+            free(arr[i].hash)
+        free(arr[i])
+    free(arr)
+    return res, single
+"""
+
 SETUP = r'''
 from setuptools import setup, Extension
 from Cython.Build import cythonize
 exts = [Extension("calign", ["calign.pyx", "align.c"], include_dirs=["."]),
         Extension("calign_drv", ["calign_drv.pyx"], include_dirs=["."]),
         Extension("asm_drv", ["asm_drv.pyx"]),
-        Extension("pop_drv", ["pop_drv.pyx"])]
+        Extension("pop_drv", ["pop_drv.pyx"]),
+        Extension("hap_drv", ["hap_drv.pyx"], include_dirs=["."])]
 setup(ext_modules=cythonize(exts, language_level=2,
       compiler_directives=dict(cdivision=True, cpow=True, legacy_implicit_noexcept=True)))
 '''
@@ -357,6 +457,22 @@ def build_scratch(scratch):
            + "\n".join(pop[383:457]) + "\n\n" + "\n".join(pop[458:594]) + "\n\n" + "\n".join(pop[622:676]) + "\n"
            + POP_TAIL.split("def genotype_loglik")[0] + "\n" + "\n".join(vcu[162:334]) + "\n\ndef genotype_loglik" + POP_TAIL.split("def genotype_loglik")[1])
     open(os.path.join(scratch, "pop_drv.pyx"), "w").write(drv)
+    # haplotype driver: chaplotype.pyx's own texts of computeOverlapOfReadAndHaplotype (:103-115), Haplotype.alignReads
+    # (:306-377), alignSingleRead (:379-384), annotateWithGapOpen (:552-590) and alignReadToHaplotype (:594-676), the
+    # constants mLTOT (:49) and per_base_indel_errors (:64), compiled against the scratch build of calign.pyx/align.c.
+    # One line cannot be compiled under Python 3 and is adapted: homopolq (:67) builds a byte string from chr() values;
+    # the same expression is evaluated here with bytes([...]).
+    chp = open(os.path.join(src, "cython/chaplotype.pyx")).read().split("\n")
+    assert chp[102].startswith("cdef int computeOverlapOfReadAndHaplotype") and chp[305].lstrip().startswith("cdef double* alignReads")
+    assert chp[378].lstrip().startswith("cdef inline double alignSingleRead") and chp[551].lstrip().startswith("cdef void annotateWithGapOpen")
+    assert chp[593].startswith("cdef double alignReadToHaplotype") and chp[63].startswith("cdef list per_base_indel_errors")
+    assert chp[66].startswith("cdef bytes homopolq = bytes(''.join([chr(int(33.5 + 10*log( (idx+1)*q )/log(0.1) )) for idx,q in enumerate(per_base_indel_errors)]))")
+    mltot = [l for l in chp[:60] if l.startswith("cdef double mLTOT")][0]
+    homopol = "cdef bytes homopolq = bytes([int(33.5 + 10*log( (idx+1)*q )/log(0.1) ) for idx,q in enumerate(per_base_indel_errors)])"
+    drv = (HAP_HEAD + mltot + "\n" + chp[63] + "\n" + homopol + "\n\n" + "\n".join(chp[102:115]) + "\n"
+           + HAP_CLASS + "\n" + "\n".join(chp[305:384]) + "\n\n" + "\n".join(chp[551:590]) + "\n\n"
+           + "\n".join(chp[593:676]) + "\n" + HAP_TAIL)
+    open(os.path.join(scratch, "hap_drv.pyx"), "w").write(drv)
     open(os.path.join(scratch, "setup.py"), "w").write(SETUP)
     r = subprocess.run([sys.executable, "setup.py", "build_ext", "--inplace"], cwd=scratch,
                        capture_output=True, text=True)
@@ -587,6 +703,78 @@ def gen_assembler(out):
     print("assembler_cases:", len(cases), "regions,", tot, "variants")
 
 
+def gen_haplotype(out):
+    """a7-a10: Haplotype.annotateWithGapOpen, alignReadToHaplotype, Haplotype.alignReads / alignSingleRead -- the
+    reference's own texts (chaplotype.pyx) on top of the scratch build of calign.pyx + align.c.  Output: the
+    likelihoodCache arrays (999-terminated), alignSingleRead values and the local gap-open bytes."""
+    import hap_drv
+    rng = np.random.default_rng(909)
+    cases = []
+    for ci in range(48):
+        L = int(rng.choice([36, 100, 150, 250]))
+        buf = min(2 * L, 500)
+        W = int(rng.integers(8, 140))
+        ref = bytearray(rnd(rng, W + 2 * buf + 600))
+        if ci % 4 == 1:                                      # homopolymers and short tandem repeats (gap-open model, re-seeding)
+            p = int(rng.integers(buf, buf + W)); ref[p:p + int(rng.integers(3, 60))] = bytes([B[int(rng.integers(0, 4))]]) * 60
+            ref = ref[:W + 2 * buf + 600]
+            u = rnd(rng, int(rng.integers(2, 5))); p = int(rng.integers(100, 300)); ref[p:p + 40] = (u * 40)[:40]
+        if ci % 6 == 2:
+            p = int(rng.integers(buf - 20, buf + W)); ref[p:p + 5] = b"NNNNN"
+        ws = 300 + buf
+        we = ws + W
+        base = bytes(ref[ws - buf:we + buf])
+        haps = [base]
+        for k in range(int(rng.integers(1, 5))):
+            h = bytearray(base)
+            for _ in range(int(rng.integers(1, 3))):
+                t = int(rng.integers(0, 3)); p = buf + int(rng.integers(0, W))
+                if t == 0:
+                    h[p] = B[(B.index(h[p]) + 1) % 4] if h[p] in B else B[0]
+                elif t == 1:
+                    h[p:p] = rnd(rng, int(rng.integers(1, 25)))
+                else:
+                    del h[p:p + int(rng.integers(1, 25))]
+            haps.append(bytes(h))
+        reads = []
+        nR = int(rng.integers(4, 40))
+        for r in range(nR):
+            src = haps[int(rng.integers(0, len(haps)))]
+            off = int(rng.integers(max(0, buf - L + 5), min(len(src) - L, buf + W - 5) + 1))
+            seq = bytearray(src[off:off + L])
+            for _ in range(int(rng.integers(0, 3))):
+                seq[int(rng.integers(0, L))] = B[int(rng.integers(0, 4))]
+            if rng.random() < 0.05:
+                seq[int(rng.integers(0, L))] = ord("N")
+            q = np.clip(rng.normal(32, 8, L), 0, 93).astype(np.uint8)
+            if rng.random() < 0.2:
+                q[:int(rng.integers(1, 20))] = 0
+            pos = ws - buf + off + int(rng.choice([0, 0, 0, 0, -3, 7, 150, -400]))
+            mapq = int(rng.choice([60, 60, 60, 29, 3, 0, 255]))
+            flag = 3 | (512 if rng.random() < 0.06 else 0)
+            kind = int(rng.choice([0, 0, 0, 0, 1, 2]))
+            reads.append(dict(seq=bytes(seq).decode(), qual=q.tolist(), pos=pos, end=pos + L, mapq=mapq, flag=flag, kind=kind))
+        # (no reads of <= 7 bp here: hashReadForMapping, calign.pyx:160-161, writes hash[0] into a malloc of rlen-7 shorts,
+        #  so the reference itself crashes on them in this path)
+        reads.sort(key=lambda r: r["kind"])                                   # good, bad, brokenMates (chaplotype.pyx:341-373)
+        tup = lambda r: (r["seq"].encode(), bytes(r["qual"]), r["pos"], r["end"], r["mapq"], r["flag"])
+        good = [tup(r) for r in reads if r["kind"] == 0]
+        bad = [tup(r) for r in reads if r["kind"] == 1]
+        brk = [tup(r) for r in reads if r["kind"] == 2]
+        flank = ci % 3 == 1
+        opt = hap_drv.Options(1 if flank else 0)
+        caches, singles, gos = [], [], []
+        for h in haps:
+            H = hap_drv.Haplotype(h, ws, we, buf, L, opt)
+            c, sgl = hap_drv.align_reads(H, good, bad, brk, 0)
+            caches.append(c); singles.append(sgl); gos.append(list(H.gap_open()))
+        cases.append(dict(start=ws, end=we, buf=buf, calc_flank=int(flank), haps=[h.decode() for h in haps], reads=reads,
+                          cache=caches, single=singles, gapopen=gos))
+    with gzip.open(os.path.join(out, "haplotype_cases.json.gz"), "wt") as f:
+        json.dump(cases, f)
+    print("haplotype: %d windows, %d (haplotype, read) likelihoods" % (len(cases), sum(len(c["cache"]) * (len(c["cache"][0]) - 1) for c in cases)))
+
+
 def gen_population(out):
     """a11/a12 + SURVEY 8(f) rank 1: per-read log-likelihood arrays -> genotype log-likelihoods (calculateDataLikelihood),
     rescaled likelihoods (the loop at cpopulation.pyx:283-309, mirrored here around the compiled method), EM haplotype
@@ -676,7 +864,7 @@ def main():
         sys.exit("reference tree not found at %s: golden vectors can only be regenerated in the build container" % REF)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     build_scratch(a.scratch)
-    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population"]
+    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype"]
     if "dp" in todo:
         gen_dp(HERE)
     if "mapalign" in todo:
@@ -685,6 +873,8 @@ def main():
         gen_assembler(HERE)
     if "population" in todo:
         gen_population(HERE)
+    if "haplotype" in todo:
+        gen_haplotype(HERE)
 
 
 if __name__ == "__main__":

@@ -212,6 +212,44 @@ def edge_batch():
         seg_n_good=np.array([sum(1 for r in w[4] if r[0] == 0) for w in wins], dtype=np.int32))
 
 
+@pytest.mark.parametrize("do_flank", [0, 1])
+def test_likelihood_cache_golden_vectors(eng, golden_dir, do_flank):
+    """a7-a10 end to end against outputs of the reference's own chaplotype.pyx texts (Haplotype.alignReads with its skip
+    rules and read-class order, alignReadToHaplotype, annotateWithGapOpen) -- bit-identical log-likelihoods."""
+    cases = [c for c in json.load(gzip.open(os.path.join(golden_dir, "haplotype_cases.json.gz"), "rt"))
+             if c["calc_flank"] == do_flank]
+    assert len(cases) >= 16
+    u8 = lambda b: np.frombuffer(b, dtype=np.uint8)
+    haps = [u8(h.encode()) for c in cases for h in c["haps"]]
+    reads = [r for c in cases for r in c["reads"]]
+    hl = np.array([len(h) for h in haps]); rl = np.array([len(r["seq"]) for r in reads])
+    nh = [len(c["haps"]) for c in cases]; nr = [len(c["reads"]) for c in cases]
+    hb = HostBatch(
+        n_ind=1, win_hap_begin=np.concatenate([[0], np.cumsum(nh)]).astype(np.int32),
+        win_read_begin=np.concatenate([[0], np.cumsum(nr)]).astype(np.int32),
+        win_start=np.array([c["start"] for c in cases], dtype=np.int32), win_end=np.array([c["end"] for c in cases], dtype=np.int32),
+        win_flank=np.array([c["buf"] for c in cases], dtype=np.int32), hap_seq=np.concatenate(haps),
+        hap_off=np.concatenate([[0], np.cumsum(hl)]).astype(np.int64),
+        read_seq=np.concatenate([u8(r["seq"].encode()) for r in reads]),
+        read_qual=np.concatenate([np.array(r["qual"], dtype=np.uint8) for r in reads]),
+        read_off=np.concatenate([[0], np.cumsum(rl)]).astype(np.int64),
+        read_pos=np.array([r["pos"] for r in reads], dtype=np.int32), read_end=np.array([r["end"] for r in reads], dtype=np.int32),
+        read_mapq=np.array([r["mapq"] for r in reads], dtype=np.uint8), read_flags=np.array([r["flag"] for r in reads], dtype=np.int32),
+        read_kind=np.array([r["kind"] for r in reads], dtype=np.uint8),
+        seg_read_begin=np.concatenate([[0], np.cumsum(nr)]).astype(np.int32),
+        seg_n_good=np.array([sum(1 for r in c["reads"] if r["kind"] == 0) for c in cases], dtype=np.int32))
+    db, st, ll, sc = run_align(eng, hb, do_flank)
+    for w, c in enumerate(cases):
+        exp = np.array([row[:-1] for row in c["cache"]])
+        assert np.array_equal(ll[hb.pair_off[w]:hb.pair_off[w + 1]].reshape(exp.shape), exp), "window %d" % w
+    # alignSingleRead (no skip rule): the same windows with every read passed as a brokenMate
+    hb2 = HostBatch(**{**hb.__dict__, "read_kind": np.full(len(reads), 2, dtype=np.uint8), "pair_off": None, "gl_off": None})
+    db, st, ll, sc = run_align(eng, hb2, do_flank)
+    for w, c in enumerate(cases):
+        exp = np.array(c["single"])
+        assert np.array_equal(ll[hb.pair_off[w]:hb.pair_off[w + 1]].reshape(exp.shape), exp), "window %d" % w
+
+
 def test_edge_cases_vs_oracle(eng, oracle):
     hb = edge_batch()
     db, st, ll, sc = run_align(eng, hb)

@@ -189,3 +189,33 @@ def test_genotype_marginalisation_matches_reference_golden(oracle, golden_dir):
             assert np.array_equal(out4, exp4, equal_nan=True)
             n += 1
     assert n > 900
+
+
+# ---- a7-a10 pinned by the reference's own chaplotype.pyx texts (tests/golden/gen_golden.py: gen_haplotype) -----------
+def _haplotype_cases(golden_dir):
+    import gzip, json
+    return json.load(gzip.open(os.path.join(golden_dir, "haplotype_cases.json.gz"), "rt"))
+
+
+def _reads_dict(case, all_broken=False):
+    r = case["reads"]
+    return dict(seq=[x["seq"].encode() for x in r], qual=[bytes(x["qual"]) for x in r], pos=[x["pos"] for x in r],
+                end=[x["end"] for x in r], mapq=[x["mapq"] for x in r], flags=[x["flag"] for x in r],
+                kind=[2 if all_broken else x["kind"] for x in r])
+
+
+def test_likelihood_cache_matches_reference_golden(oracle, golden_dir):
+    """Haplotype.alignReads / alignSingleRead / annotateWithGapOpen (chaplotype.pyx:306-384,552-676): same doubles, same bytes."""
+    n = flank = 0
+    for c in _haplotype_cases(golden_dir):
+        haps = [h.encode() for h in c["haps"]]
+        ll, sc, _ = oracle.align_window(haps, c["start"], c["end"], c["buf"], _reads_dict(c), do_flank=c["calc_flank"])
+        single, _, _ = oracle.align_window(haps, c["start"], c["end"], c["buf"], _reads_dict(c, True), do_flank=c["calc_flank"])
+        for hi, h in enumerate(haps):
+            assert c["cache"][hi][-1] == 999                                  # terminator, chaplotype.pyx:375
+            assert np.array_equal(ll[hi], np.array(c["cache"][hi][:-1]))
+            assert np.array_equal(single[hi], np.array(c["single"][hi]))
+            assert list(oracle.gap_open(h)) == c["gapopen"][hi]
+            n += len(c["single"][hi])
+        flank += c["calc_flank"]
+    assert n > 3000 and flank > 10
