@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--windows", type=int, default=10000, help="windows per GPU (BASELINE config 2: 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-entry", action="store_true",
+                    help="time plat_align_window_batch (two internal read-backs) instead of plat_align_window_batch_async")
     a = ap.parse_args()
 
     import torch
@@ -132,11 +134,12 @@ def main():
     st = None
     for _ in range(a.warmup):
         st = eng.call_windows(db, want_stats=True)
+        eng.call_windows(db, want_stats=False, asynchronous=not a.sync_entry)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        eng.call_windows(db, want_stats=False)
-    torch.cuda.synchronize()
+        eng.call_windows(db, want_stats=False, asynchronous=not a.sync_entry)
+    eng.synchronize()                           # also raises any error an asynchronous step recorded on the device
     t1 = time.perf_counter()
     barrier()
     if st is None:
@@ -181,7 +184,8 @@ def main():
             "dtype": "int16", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: %d windows/GPU, 150 bp reads, 30x, <=8 haplotypes/window, SNP-only; "
                                    "step = alignReads for all haplotypes + genotype likelihoods" % a.windows,
-                       "windows_per_gpu": a.windows, "read_len": 150, "depth": 30, "sharding": "windows by rank, no collective"},
+                       "windows_per_gpu": a.windows, "read_len": 150, "depth": 30, "sharding": "windows by rank, no collective",
+                       "entry": "plat_align_window_batch" if a.sync_entry else "plat_align_window_batch_async"},
             "windows_per_sec": nwin * a.steps / T,
             "gcups_executed": cells_run * a.steps / T / 1e9,
             "dp_reference_per_step": ndp_ref, "dp_launched_per_step": ndp_run,

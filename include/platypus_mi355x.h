@@ -45,6 +45,7 @@ extern "C" {
 #define PLAT_ERR_NO_DEVICE (-7)     /* no gfx950 device / HIP runtime unavailable                    */
 #define PLAT_ERR_OVERFLOW (-8)      /* an output capacity given by the caller was too small          */
 #define PLAT_ERR_BAD_INPUT (-9)     /* device-side input validation failed (non-ASCII byte, ...)     */
+#define PLAT_ERR_BAD_HINTS (-10)    /* plat_batch_hints do not cover the batch (asynchronous entry point) */
 
 typedef struct plat_ctx plat_ctx;
 
@@ -157,6 +158,27 @@ typedef struct plat_align_stats {
 int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* batch, int calc_flank_score,
                             int use_mapq_cap, double* out_loglik, int32_t* out_score,
                             plat_align_stats* out_stats /* host, may be NULL */, void* stream);
+
+/* Asynchronous variant: the same work, but NOTHING is read back and the call never waits for the GPU
+ * (plat_align_window_batch reads two small counters blocks back: after validation, to size its scratch
+ * buffers, and after seeding, to size the DP launch -- ~55 us of idle GPU per call).  The caller, who
+ * built the offset arrays, states the sizes up front:
+ *   max_hap_len / max_read_len / max_reads_per_window  upper bounds over the batch
+ *   n_pairs = pair_off[n_windows] (exact); hap_blob_len >= hap_off[n_haps]; read_blob_len >= read_off[n_reads]
+ *   extra_jobs_cap  capacity for candidate DPs beyond one per pair (0 = n_pairs/4 + 4096)
+ * The device checks the hints against the batch; errors that the synchronous call returns directly
+ * (PLAT_ERR_BAD_INPUT, _HAP_TOO_LONG, ..., plus PLAT_ERR_BAD_HINTS and PLAT_ERR_OVERFLOW when
+ * extra_jobs_cap was too small) are returned by the next plat_stream_sync(ctx, stream) instead; outputs of
+ * a refused batch are undefined.  Scratch buffers grow on the host as before (hipMalloc may synchronise
+ * the first time a larger batch is seen).                                                          */
+typedef struct plat_batch_hints {
+    int32_t max_hap_len, max_read_len, max_reads_per_window, _pad;
+    int64_t n_pairs, hap_blob_len, read_blob_len, extra_jobs_cap;
+} plat_batch_hints;
+
+int plat_align_window_batch_async(plat_ctx* ctx, const plat_window_batch* batch, const plat_batch_hints* hints,
+                                  int calc_flank_score, int use_mapq_cap, double* out_loglik,
+                                  int32_t* out_score, void* stream);
 
 /* ---- a11/a12: DiploidGenotype.calculateDataLikelihood + Population.setup ------------------------
  * Replaces  cdef double DiploidGenotype.calculateDataLikelihood(...)   cgenotype.pxd:14, .pyx:131-189

@@ -18,7 +18,7 @@ PLAT_ABI_VERSION = 1
 ERRORS = {
     0: "PLAT_OK", -1: "PLAT_ERR_INVALID", -2: "PLAT_ERR_HIP", -3: "PLAT_ERR_NOMEM", -4: "PLAT_ERR_HAP_TOO_LONG",
     -5: "PLAT_ERR_HAP_TOO_SHORT", -6: "PLAT_ERR_UNSUPPORTED", -7: "PLAT_ERR_NO_DEVICE", -8: "PLAT_ERR_OVERFLOW",
-    -9: "PLAT_ERR_BAD_INPUT",
+    -9: "PLAT_ERR_BAD_INPUT", -10: "PLAT_ERR_BAD_HINTS",
 }
 
 
@@ -49,6 +49,12 @@ class Profile(C.Structure):
                 ("ms_genotype", C.c_float), ("_pad", C.c_float), ("dp_jobs", C.c_int64), ("dp_alg_bytes", C.c_int64)]
 
 
+class BatchHints(C.Structure):
+    _fields_ = [("max_hap_len", C.c_int32), ("max_read_len", C.c_int32), ("max_reads_per_window", C.c_int32),
+                ("_pad", C.c_int32), ("n_pairs", C.c_int64), ("hap_blob_len", C.c_int64), ("read_blob_len", C.c_int64),
+                ("extra_jobs_cap", C.c_int64)]
+
+
 class AssemblyBatch(C.Structure):
     _fields_ = [("n_regions", C.c_int32), ("n_reads", C.c_int32), ("ref_seq", C.c_void_p), ("ref_off", C.c_void_p),
                 ("ref_start", C.c_void_p), ("assem_start", C.c_void_p), ("assem_end", C.c_void_p),
@@ -76,6 +82,8 @@ SIGNATURES = {
                                 C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "plat_align_window_batch": (C.c_int, [C.c_void_p, C.POINTER(WindowBatch), C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p, C.POINTER(AlignStats), C.c_void_p]),
+    "plat_align_window_batch_async": (C.c_int, [C.c_void_p, C.POINTER(WindowBatch), C.POINTER(BatchHints), C.c_int, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_genotype_window_batch": (C.c_int, [C.c_void_p, C.POINTER(WindowBatch), C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p]),

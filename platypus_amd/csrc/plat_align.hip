@@ -106,7 +106,8 @@ k_validate(plat_window_batch b, long long* cnt, int32_t* __restrict__ hap_win, i
 
 // exclusive scan of rows*R per window -> tile_off (dwords); single workgroup
 __global__ void __launch_bounds__(1024)
-k_tile_scan(plat_window_batch b, const int32_t* __restrict__ win_rows, long long* __restrict__ tile_off, long long* cnt)
+k_tile_scan(plat_window_batch b, const int32_t* __restrict__ win_rows, long long* __restrict__ tile_off, long long* cnt,
+            plat_batch_hints hints, int check_hints)
 {
     __shared__ long long part[1024];
     const int t = threadIdx.x, nt = blockDim.x;
@@ -133,6 +134,12 @@ k_tile_scan(plat_window_batch b, const int32_t* __restrict__ win_rows, long long
         cnt[CNT_HAPBLOB] = b.hap_off[b.n_haps];
         cnt[CNT_NPAIRS] = b.pair_off[b.n_windows];
         cnt[CNT_READBLOB] = b.read_off[b.n_reads];
+        // asynchronous mode: the host sized every buffer and launch from the caller's hints; anything they do not cover
+        // stops the pipeline here (every later kernel returns at once when the error word is set)
+        if (check_hints && (cnt[CNT_MAXHAP] > hints.max_hap_len || cnt[CNT_MAXREAD] > hints.max_read_len ||
+                            cnt[CNT_MAXH] > hints.max_reads_per_window || cnt[CNT_NPAIRS] != hints.n_pairs ||
+                            cnt[CNT_HAPBLOB] > hints.hap_blob_len || cnt[CNT_READBLOB] > hints.read_blob_len))
+            set_err(cnt, PLAT_ERR_BAD_HINTS);
     }
 }
 
@@ -162,6 +169,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     __shared__ unsigned s_dirty[2];                      // bit rl: read rl of the group holds a byte other than A, C, G, T
     const int w = blockIdx.x;
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
+    if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
     const int c0 = (int)blockIdx.y * 64;
     if (c0 >= R) return;
     const int nr = min(64, R - c0);
@@ -479,6 +487,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     int* s_scal = (int*)(nup + nw64);                    // [0] has_n  [1] maxmult, then the gap-open table
 
     const int h = blockIdx.x;
+    if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
     const int w = hap_win[h];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
@@ -768,6 +777,7 @@ k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long
     int* s_scal = (int*)(counts + (cw >> 1));
     const int lane = threadIdx.x & 63;
     long long nslow = cnt[CNT_SLOW_SEED];
+    if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
     if (nslow > npairs) nslow = npairs;
     for (int j = lane; j < (cw >> 1); j += 64) counts[j] = 0u;
     int cur = -1, hapLen = 0, tsize = 64;
@@ -831,6 +841,7 @@ k_compact_count(const Job* __restrict__ jobs, const PairRec* __restrict__ pairs,
                 long long npairs, long long extra_cap, const long long* __restrict__ cnt, int32_t* __restrict__ block_cnt,
                 double* __restrict__ out_ll, int32_t* __restrict__ out_score)
 {
+    if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
     __shared__ int s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
@@ -857,6 +868,7 @@ __global__ void __launch_bounds__(COMPACT_BLOCK)
 k_compact_scatter(const Job* __restrict__ jobs, long long npairs, long long extra_cap, long long* __restrict__ cnt,
                   const int32_t* __restrict__ block_cnt, int32_t* __restrict__ dense)
 {
+    if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
     __shared__ long long s_part[COMPACT_BLOCK / 64];
     __shared__ int s_wave[COMPACT_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -915,9 +927,11 @@ __global__ void __launch_bounds__(256)
 k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32_t* __restrict__ tile,
           const uint32_t* __restrict__ hapw, const uint8_t* __restrict__ hap_has_n, const Job* __restrict__ jobs,
           const PairRec* __restrict__ pairs, const double* __restrict__ mapq_lut, long long npairs,
-          const int32_t* __restrict__ dense, long long ndense, int32_t* __restrict__ job_score, double* __restrict__ out_ll,
-          int32_t* __restrict__ out_score)
+          const int32_t* __restrict__ dense, long long ndense, const long long* __restrict__ cnt, long long extra_cap,
+          int32_t* __restrict__ job_score, double* __restrict__ out_ll, int32_t* __restrict__ out_score)
 {
+    if (cnt[CNT_ERR] != 0 || cnt[CNT_NEXTRA] > extra_cap) return;   // refused batch / job overflow (reported by the host)
+    if (ndense < 0) ndense = cnt[CNT_NDENSE];            // asynchronous mode: the grid covers every job slot
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = t < ndense;
     const long long j = active ? dense[t] : 0;
@@ -954,11 +968,12 @@ __global__ void __launch_bounds__(256)
 k_dp_tb_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32_t* __restrict__ tile,
              const uint32_t* __restrict__ hapw, const Job* __restrict__ jobs, const PairRec* __restrict__ pairs,
              const double* __restrict__ mapq_lut, long long npairs, const int32_t* __restrict__ dense, long long j0, long long jn,
-             unsigned long long* __restrict__ bpbuf, long long bstride, int32_t* __restrict__ job_score,
+             const long long* __restrict__ cnt, long long extra_cap, unsigned long long* __restrict__ bpbuf, long long bstride, int32_t* __restrict__ job_score,
              double* __restrict__ out_ll, int32_t* __restrict__ out_score)
 {
+    if (cnt[CNT_ERR] != 0 || cnt[CNT_NEXTRA] > extra_cap) return;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= jn) return;
+    if (t >= jn || j0 + t >= cnt[CNT_NDENSE]) return;
     const long long j = dense[j0 + t];
     const Job jb = jobs[j];
     int sc;
@@ -1027,9 +1042,10 @@ __device__ __forceinline__ int select_best(const PairRec& pr, long long p, long 
 
 __global__ void __launch_bounds__(256)
 k_finalize_multi(const PairRec* __restrict__ pairs, const Job* __restrict__ jobs, const int32_t* __restrict__ job_score,
-                 const double* __restrict__ mapq_lut, long long npairs, double* __restrict__ out_ll,
-                 int32_t* __restrict__ out_score)
+                 const double* __restrict__ mapq_lut, long long npairs, const long long* __restrict__ cnt, long long extra_cap,
+                 double* __restrict__ out_ll, int32_t* __restrict__ out_score)
 {
+    if (cnt[CNT_ERR] != 0 || cnt[CNT_NEXTRA] > extra_cap) return;
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npairs) return;
     const PairRec pr = pairs[p];
@@ -1093,6 +1109,15 @@ __global__ void k_sum_job_cells(const Job* __restrict__ jobs, long long njobs, l
     }
 }
 
+// asynchronous mode: what the host would have checked after its read-backs is recorded in a pinned host word that
+// plat_stream_sync returns (first error wins until it is read)
+__global__ void k_async_epilogue(const long long* __restrict__ cnt, long long extra_cap, long long* sticky)
+{
+    long long e = cnt[CNT_ERR];
+    if (e == 0 && cnt[CNT_NEXTRA] > extra_cap) e = PLAT_ERR_OVERFLOW;
+    if (e != 0 && *sticky == 0) *sticky = e;
+}
+
 }  // namespace plat
 
 using namespace plat;
@@ -1142,9 +1167,11 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     return PLAT_OK;
 }
 
-PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* batch, int calc_flank_score,
-                                        int use_mapq_cap, double* out_loglik, int32_t* out_score,
-                                        plat_align_stats* out_stats, void* stream)
+// Shared body of the synchronous and the asynchronous entry point.  hints == NULL: the sizes come from two internal
+// read-backs (after validation, after seeding); otherwise from the caller, nothing is read back and the device refuses
+// the batch (PLAT_ERR_BAD_HINTS via plat_stream_sync) if the hints do not cover it.
+static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_batch_hints* hints, int calc_flank_score,
+                      int use_mapq_cap, double* out_loglik, int32_t* out_score, plat_align_stats* out_stats, void* stream)
 {
     if (!ctx || !batch) return PLAT_ERR_INVALID;
     if (use_mapq_cap) return PLAT_ERR_UNSUPPORTED;
@@ -1158,6 +1185,10 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
         return PLAT_ERR_INVALID;
     if (b.n_reads > 0 && (!b.read_seq || !b.read_qual || !b.read_pos || !b.read_end || !b.read_mapq ||
                           !b.read_flags || !b.read_kind))
+        return PLAT_ERR_INVALID;
+    const bool async = hints != NULL;
+    if (async && (hints->max_hap_len < 0 || hints->max_read_len < 0 || hints->max_reads_per_window < 0 || hints->n_pairs < 0 ||
+                  hints->hap_blob_len < 0 || hints->read_blob_len < 0 || hints->extra_jobs_cap < 0))
         return PLAT_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1179,16 +1210,26 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     ctx->ev_valid_align = 0;
     PLAT_EV(ctx, 0, st);
     PLAT_HIP(ctx, hipMemsetAsync(cnt, 0, (CNT_N + 8) * sizeof(long long), st));
+    plat_batch_hints hv = {};
+    if (async) hv = *hints;
     hipLaunchKernelGGL(k_validate, dim3(2048), dim3(256), 0, st, b, cnt, hap_win, win_rows, calc_flank_score);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, b, win_rows, tile_off, cnt);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, b, win_rows, tile_off, cnt, hv, async ? 1 : 0);
     PLAT_HIP(ctx, hipGetLastError());
-    // read back: error, maxima, blob lengths, number of pairs, tile size
     int64_t* hb = ctx->h_readback;
-    PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
-    PLAT_HIP(ctx, hipStreamSynchronize(st));
-    if (hb[CNT_ERR] != 0) return (int)hb[CNT_ERR];
-    const int maxhap = (int)hb[CNT_MAXHAP], maxread = (int)hb[CNT_MAXREAD], maxR = (int)hb[CNT_MAXH];
-    const long long hapblob = hb[CNT_HAPBLOB], npairs = hb[CNT_NPAIRS], readblob = hb[CNT_READBLOB], tile_total = hb[CNT_TILE_TOTAL];
+    long long tile_total;
+    if (!async) {
+        // read back: error, maxima, blob lengths, number of pairs, tile size
+        PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
+        PLAT_HIP(ctx, hipStreamSynchronize(st));
+        if (hb[CNT_ERR] != 0) return (int)hb[CNT_ERR];
+        hv.max_hap_len = (int)hb[CNT_MAXHAP]; hv.max_read_len = (int)hb[CNT_MAXREAD]; hv.max_reads_per_window = (int)hb[CNT_MAXH];
+        hv.hap_blob_len = hb[CNT_HAPBLOB]; hv.n_pairs = hb[CNT_NPAIRS]; hv.read_blob_len = hb[CNT_READBLOB];
+        tile_total = hb[CNT_TILE_TOTAL];
+    } else {
+        tile_total = (long long)(hv.max_read_len + 8) * b.n_reads + 4ll * b.n_windows;     // upper bound of k_tile_scan's total
+    }
+    const int maxhap = hv.max_hap_len, maxread = hv.max_read_len, maxR = hv.max_reads_per_window;
+    const long long hapblob = hv.hap_blob_len, npairs = hv.n_pairs, readblob = hv.read_blob_len;
     if (npairs == 0) return PLAT_OK;
     if (tile_total > 0xFFFFFFF0ll || readblob > 0xFFFFFFF0ll) return PLAT_ERR_OVERFLOW;   // split the batch: 32-bit tile/code offsets
     if ((rc = plat_reserve(ctx, ctx->hapw, ((size_t)hapblob + 64) * 4))) return rc;
@@ -1197,6 +1238,7 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
     if ((rc = plat_reserve(ctx, ctx->pair_rec, (size_t)npairs * sizeof(PairRec)))) return rc;
     if ((rc = plat_reserve(ctx, ctx->slow, (size_t)npairs * sizeof(SlowRec)))) return rc;
     long long extra_cap = npairs / 4 + 4096;
+    if (async && hv.extra_jobs_cap > 0) extra_cap = hv.extra_jobs_cap;
     if ((long long)(ctx->jobs.cap / sizeof(Job)) - npairs > extra_cap) extra_cap = (long long)(ctx->jobs.cap / sizeof(Job)) - npairs;
     if (extra_cap > 0x7FFFFF00ll) extra_cap = 0x7FFFFF00ll;
 
@@ -1229,6 +1271,8 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
             hipLaunchKernelGGL(k_compact_scatter, dim3(nblk), dim3(COMPACT_BLOCK), 0, st, (const Job*)ctx->jobs.ptr, npairs,
                                extra_cap, cnt, block_cnt, dense);
         }
+        njobs = npairs + extra_cap;
+        if (async) break;                      // job overflow is caught on the device and reported by plat_stream_sync
         PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
         PLAT_HIP(ctx, hipStreamSynchronize(st));
         if (hb[CNT_ERR] != 0) return (int)hb[CNT_ERR];
@@ -1238,46 +1282,56 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
         if (nextra > 0x7FFFFF00ll || attempt == 1) return PLAT_ERR_OVERFLOW;
         extra_cap = nextra;                    // tandem-rich batch: re-run the seeding with the exact capacity
     }
-    const long long ndense = hb[CNT_NDENSE];
+    // synchronous mode: exact number of live slots; asynchronous: the kernels read it on the device (ndense < 0) and the
+    // launch covers every slot
+    const long long ndense = async ? -1 : hb[CNT_NDENSE];
+    const long long ngrid = async ? npairs + extra_cap : ndense;
     const int32_t* dense = (const int32_t*)ctx->dense.ptr;
     if ((rc = plat_reserve(ctx, ctx->job_score, (size_t)(njobs + 1) * sizeof(int32_t)))) return rc;
     PLAT_EV(ctx, 2, st);
-    if (ndense == 0) {
+    if (ngrid == 0) {
         // nothing to align
     } else if (calc_flank_score) {
         // traceback mode: 2*(maxread+8) back-pointer words per job; the job list is processed in slabs of bounded size
         const long long rows = 2ll * (maxread + 8);
         long long slab = (long long)((6ull << 30) / ((unsigned long long)rows * 8ull));
-        if (slab > ndense) slab = ndense;
+        if (slab > ngrid) slab = ngrid;
         slab = (slab + 255) & ~255ll;
         if ((rc = plat_reserve(ctx, ctx->tb, (size_t)rows * (size_t)slab * 8))) return rc;
-        for (long long j0 = 0; j0 < ndense; j0 += slab) {
-            const long long jn = ndense - j0 < slab ? ndense - j0 : slab;
+        for (long long j0 = 0; j0 < ngrid; j0 += slab) {
+            const long long jn = ngrid - j0 < slab ? ngrid - j0 : slab;
             hipLaunchKernelGGL(k_dp_tb_jobs, dim3((unsigned)((jn + 255) / 256)), dim3(256), 0, st, b, hap_win,
                                (const uint32_t*)ctx->tile.ptr, (const uint32_t*)ctx->hapw.ptr, (const Job*)ctx->jobs.ptr,
-                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, j0, jn,
+                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, j0, jn, cnt, extra_cap,
                                (unsigned long long*)ctx->tb.ptr, slab, (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
         }
     } else {
         static int dp_impl = -1;                 // 1 = one int16 lane per VGPR (dp_unpacked.hpp), 0 = packed (dp_core.hpp)
         if (dp_impl < 0) { const char* e = getenv("PLAT_DP_IMPL"); dp_impl = e ? (strcmp(e, "unpacked") == 0) : 0; }   // packed measured faster
-        const dim3 grid((unsigned)((ndense + 255) / 256));
+        const dim3 grid((unsigned)((ngrid + 255) / 256));
         if (dp_impl)
             hipLaunchKernelGGL(k_dp_jobs<true>, grid, dim3(256), 0, st, b, hap_win, (const uint32_t*)ctx->tile.ptr,
                                (const uint32_t*)ctx->hapw.ptr, (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
-                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, ndense,
+                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, ndense, cnt, extra_cap,
                                (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
         else
             hipLaunchKernelGGL(k_dp_jobs<false>, grid, dim3(256), 0, st, b, hap_win, (const uint32_t*)ctx->tile.ptr,
                                (const uint32_t*)ctx->hapw.ptr, (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
-                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, ndense,
+                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, ndense, cnt, extra_cap,
                                (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
     }
     PLAT_EV(ctx, 3, st);
     hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
                        (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr,
-                       (const int32_t*)ctx->job_score.ptr, ctx->d_mapq_lut, npairs, out_loglik, out_score);
+                       (const int32_t*)ctx->job_score.ptr, ctx->d_mapq_lut, npairs, cnt, extra_cap, out_loglik, out_score);
     PLAT_EV(ctx, 4, st);
+    if (async) {
+        hipLaunchKernelGGL(k_async_epilogue, dim3(1), dim3(1), 0, st, cnt, extra_cap, (long long*)ctx->d_sticky);
+        PLAT_HIP(ctx, hipGetLastError());
+        ctx->ev_valid_align = ctx->profile;
+        ctx->prof_dp_jobs = 0; ctx->prof_dp_bytes = 0;
+        return PLAT_OK;
+    }
     if (out_stats || ctx->profile)
         hipLaunchKernelGGL(k_sum_job_cells, dim3(256), dim3(256), 0, st, (const Job*)ctx->jobs.ptr, njobs, cnt);
     if (out_stats)
@@ -1302,4 +1356,19 @@ PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* 
         out_stats->n_seed_fallback = hb[CNT_SLOW_SEED];
     }
     return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_align_window_batch(plat_ctx* ctx, const plat_window_batch* batch, int calc_flank_score,
+                                        int use_mapq_cap, double* out_loglik, int32_t* out_score,
+                                        plat_align_stats* out_stats, void* stream)
+{
+    return align_impl(ctx, batch, NULL, calc_flank_score, use_mapq_cap, out_loglik, out_score, out_stats, stream);
+}
+
+PLAT_EXPORT int plat_align_window_batch_async(plat_ctx* ctx, const plat_window_batch* batch, const plat_batch_hints* hints,
+                                              int calc_flank_score, int use_mapq_cap, double* out_loglik,
+                                              int32_t* out_score, void* stream)
+{
+    if (!hints) return PLAT_ERR_INVALID;
+    return align_impl(ctx, batch, hints, calc_flank_score, use_mapq_cap, out_loglik, out_score, NULL, stream);
 }

@@ -14,6 +14,7 @@ PLAT_EXPORT const char* plat_strerror(int code) {
         case PLAT_ERR_HAP_TOO_LONG: return "haplotype is too long (max allowed length is 16384)";
         case PLAT_ERR_HAP_TOO_SHORT: return "haplotype shorter than read length + 15";
         case PLAT_ERR_UNSUPPORTED: return "option not supported by the device path";
+        case PLAT_ERR_BAD_HINTS: return "plat_batch_hints do not cover the batch";
         case PLAT_ERR_NO_DEVICE: return "no usable gfx950 device";
         case PLAT_ERR_OVERFLOW: return "output capacity too small";
         case PLAT_ERR_BAD_INPUT: return "input failed device-side validation";
@@ -49,6 +50,8 @@ PLAT_EXPORT int plat_ctx_create(int device, plat_ctx** out_ctx) {
     hipError_t e = hipMalloc(&ctx->d_mapq_lut, sizeof(lut));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_mapq_lut, lut, sizeof(lut), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_readback, 64 * sizeof(int64_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_sticky, 8 * sizeof(int64_t), hipHostMallocMapped);
+    if (e == hipSuccess) { ctx->h_sticky[0] = 0; e = hipHostGetDevicePointer(&ctx->d_sticky, ctx->h_sticky, 0); }
     if (e != hipSuccess) { delete ctx; return PLAT_ERR_HIP; }
     *out_ctx = ctx;
     return PLAT_OK;
@@ -63,6 +66,7 @@ PLAT_EXPORT int plat_ctx_destroy(plat_ctx* ctx) {
         if (s->ptr) { e = hipFree(s->ptr); (void)e; }
     if (ctx->d_mapq_lut) { e = hipFree(ctx->d_mapq_lut); (void)e; }
     if (ctx->h_readback) { e = hipHostFree(ctx->h_readback); (void)e; }
+    if (ctx->h_sticky) { e = hipHostFree(ctx->h_sticky); (void)e; }
     for (int i = 0; i < 8; ++i)
         if (ctx->ev[i]) { e = hipEventDestroy(ctx->ev[i]); (void)e; }
     delete ctx;
@@ -135,5 +139,10 @@ PLAT_EXPORT int plat_memset(plat_ctx* ctx, void* dst, int value, size_t bytes, v
 PLAT_EXPORT int plat_stream_sync(plat_ctx* ctx, void* stream) {
     if (!ctx) return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    if (ctx->h_sticky && ctx->h_sticky[0] != 0) {          // error recorded by an asynchronous call since the last sync
+        const int rc = (int)ctx->h_sticky[0];
+        ctx->h_sticky[0] = 0;
+        return rc;
+    }
     return PLAT_OK;
 }

@@ -24,6 +24,9 @@ struct plat_ctx {
     plat_scratch hapw, tile, codes, rinfo, hap_flags, pair_rec, jobs, job_score, counters, asm_scratch, tb, slow, dense, pop_scratch;
     // pinned host read-back area
     int64_t* h_readback = nullptr;
+    // asynchronous entry points: first device-side error since the last plat_stream_sync (pinned, device-visible)
+    int64_t* h_sticky = nullptr;
+    void* d_sticky = nullptr;
     // optional live timing: events 0..5 bracket prepare|seed|dp|finalize, 6..7 bracket genotype
     int profile = 0;
     hipEvent_t ev[8] = {};

@@ -43,6 +43,15 @@ class DeviceBatch:
         for name, _ in _lib.WindowBatch._fields_[4:]:
             setattr(s, name, self.t[name].data_ptr())
         self.struct = s
+        # what the host knows about its own batch: lets the asynchronous entry point skip the internal read-backs
+        hl = np.diff(hb.hap_off)
+        rl = np.diff(hb.read_off)
+        h = _lib.BatchHints()
+        h.max_hap_len = int(hl.max()) if len(hl) else 0
+        h.max_read_len = int(rl.max()) if len(rl) else 0
+        h.max_reads_per_window = int(np.diff(hb.win_read_begin).max()) if hb.n_windows else 0
+        h.n_pairs, h.hap_blob_len, h.read_blob_len, h.extra_jobs_cap = int(hb.n_pairs), int(hb.hap_off[-1]), int(hb.read_off[-1]), 0
+        self.hints = h
         self.loglik = torch.empty(max(hb.n_pairs, 1), dtype=torch.float64, device=device)
         self.score = torch.empty(max(hb.n_pairs, 1), dtype=torch.int32, device=device)
         ng = max(int(hb.gl_off[-1]), 1)
@@ -124,6 +133,14 @@ class Engine:
     def upload(self, hb: HostBatch) -> DeviceBatch:
         return DeviceBatch(hb, self.device)
 
+    def align_async(self, db: DeviceBatch, want_score=True, calc_flank_score=0, use_mapq_cap=0, hints=None):
+        """Same as align(), enqueued without any internal read-back (sizes from db.hints).  Device-side errors are
+        raised by the next synchronize()."""
+        rc = self.lib.plat_align_window_batch_async(self.ctx, C.byref(db.struct), C.byref(hints if hints is not None else db.hints),
+                                                    calc_flank_score, use_mapq_cap, db.loglik.data_ptr(),
+                                                    db.score.data_ptr() if want_score else None, self._stream())
+        _lib.check(rc, "plat_align_window_batch_async")
+
     def align(self, db: DeviceBatch, want_stats=True, want_score=True, calc_flank_score=0, use_mapq_cap=0):
         """Haplotype.alignReads for every haplotype of every window.  Results stay in HBM (db.loglik)."""
         st = _lib.AlignStats()
@@ -141,9 +158,14 @@ class Engine:
                                                  db.logl.data_ptr(), db.gof.data_ptr(), self._stream())
         _lib.check(rc, "plat_genotype_window_batch")
 
-    def call_windows(self, db: DeviceBatch, want_stats=True):
-        """One pass of the hot path: likelihood arrays, then genotype likelihoods (Population.setup)."""
-        st = self.align(db, want_stats=want_stats)
+    def call_windows(self, db: DeviceBatch, want_stats=True, asynchronous=False):
+        """One pass of the hot path: likelihood arrays, then genotype likelihoods (Population.setup).
+        asynchronous=True: nothing is read back and nothing waits (no statistics; errors surface in synchronize())."""
+        if asynchronous and not want_stats:
+            self.align_async(db)
+            st = None
+        else:
+            st = self.align(db, want_stats=want_stats)
         self.genotype(db)
         return st
 
@@ -293,4 +315,6 @@ class Engine:
         return p
 
     def synchronize(self):
+        """Waits for the stream and raises the first error an asynchronous call recorded since the last synchronize()."""
+        _lib.check(self.lib.plat_stream_sync(self.ctx, self._stream()), "plat_stream_sync")
         _torch().cuda.synchronize(self.device)

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from platypus_amd import _lib, synth
+from platypus_amd.engine import Engine
 from platypus_amd.batch import HostBatch
 
 pytestmark = pytest.mark.gpu
@@ -264,6 +265,47 @@ def test_empty_batch_and_null_checks(eng):
     assert lib.plat_align_window_batch(eng.ctx, C.byref(z), 0, 0, None, None, None, None) == 0
     assert lib.plat_align_window_batch(eng.ctx, None, 0, 0, None, None, None, None) == -1
     assert lib.plat_dp_batch(eng.ctx, 0, 100, None, None, None, None, None, 3, 2, None, None) == 0
+
+
+def test_async_entry_point_matches_sync_and_reports_errors(eng):
+    """plat_align_window_batch_async: identical outputs without any read-back; bad hints / bad input / job overflow come
+    back from plat_stream_sync."""
+    for hb, flank in ((synth.config2(200), 0), (edge_batch(), 0), (synth.config2(60), 1)):
+        db = eng.upload(hb)
+        eng.align(db, want_stats=False, calc_flank_score=flank); eng.synchronize()
+        ll0, sc0 = db.loglik.cpu().numpy().copy(), db.score.cpu().numpy().copy()
+        db.loglik.zero_(); db.score.zero_()
+        eng.align_async(db, calc_flank_score=flank); eng.synchronize()
+        assert np.array_equal(db.loglik.cpu().numpy(), ll0) and np.array_equal(db.score.cpu().numpy(), sc0)
+    hb = synth.config2(50)
+    db = eng.upload(hb)
+    for field, val in (("max_read_len", 100), ("max_hap_len", 300), ("n_pairs", hb.n_pairs - 1), ("max_reads_per_window", 3)):
+        h = _lib.BatchHints.from_buffer_copy(db.hints)
+        setattr(h, field, val)
+        eng.align_async(db, hints=h)
+        with pytest.raises(_lib.PlatypusDeviceError) as e:
+            eng.synchronize()
+        assert e.value.code == -10, field
+    eng.synchronize()                                                       # the error is reported once
+    # a tandem-repeat batch needs more extra job slots than a tiny explicit capacity: overflow is reported, not UB
+    eb = edge_batch()
+    db = eng.upload(eb)
+    h = _lib.BatchHints.from_buffer_copy(db.hints)
+    h.extra_jobs_cap = 1
+    eng2 = Engine(0)                                                        # fresh context: its job buffer has no spare capacity yet
+    db2 = eng2.upload(eb)
+    eng2.align_async(db2, hints=h)
+    with pytest.raises(_lib.PlatypusDeviceError) as e:
+        eng2.synchronize()
+    assert e.value.code == -8
+    eng2.close()
+    bad = HostBatch(**{**hb.__dict__, "read_seq": np.where(np.arange(len(hb.read_seq)) == 77, 200, hb.read_seq).astype(np.uint8),
+                       "pair_off": None, "gl_off": None})
+    db = eng.upload(bad)
+    eng.align_async(db)
+    with pytest.raises(_lib.PlatypusDeviceError) as e:
+        eng.synchronize()
+    assert e.value.code == -9
 
 
 def test_unsupported_options_fail_loudly(eng):
