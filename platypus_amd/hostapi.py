@@ -377,6 +377,134 @@ class Population:
         i = sampleIndex
         return (int(ph[i][0]), int(ph[i][1]), lik[i].tolist(), float(out4[i][0]), float(out4[i][1]), float(out4[i][2]), float(out4[i][3]))
 
+# ---- haplotype enumeration and the greedy haplotype filter ------------------------------------------
+def isHaplotypeValid(variants):
+    """platypusutils.pyx:735-802: variants (sorted by co-ordinate) must not overlap."""
+    n = len(variants)
+    if n <= 1:
+        return True
+    for i in range(n - 1):
+        a, b = variants[i], variants[i + 1]
+        if a.minRefPos > b.minRefPos:
+            raise Exception("Variants out of order in haplotype!")
+        if a.maxRefPos > b.minRefPos:
+            return False
+        if a.maxRefPos == b.minRefPos:
+            # a SNP/MNP at the labelled base of an indel is fine (the indel really starts one base later), :790-799
+            if a.nAdded == a.nRemoved and b.nAdded != b.nRemoved:
+                continue
+            return False
+    return True
+
+
+def computeBestScoresForHaplotypes(readBuffers, refHaplotype, haplotypes, windowSize, targetCoverage):
+    """computeBestScoreForGenotype (variantFilter.pyx:237-283) for the genotypes (refHaplotype, h), h in `haplotypes`,
+    in ONE device batch: the sampled reads of every sample are aligned to the reference haplotype and to every candidate
+    (alignSingleRead semantics: no overlap rule), the per-sample sums run on the host in the reference's order with the
+    C library's log/exp."""
+    assert targetCoverage > 0
+    import math
+    sampled, seg = [], [0]
+    for buf in readBuffers:
+        reads = buf.reads.window()
+        if reads:
+            meanCoverage = reads[0].rlen * len(reads) // windowSize                                # :264
+            sampleRate = max(1, meanCoverage // targetCoverage)
+            sampled += list(reads[::sampleRate])                                                   # :269-274
+        seg.append(len(sampled))
+    nH = len(haplotypes)
+    if not sampled or nH == 0:
+        return [-1e20] * nH
+    buf = bamReadBuffer()
+    buf.brokenMates.array = sampled                        # keep the per-sample order (ReadArray() would re-sort by position)
+    buf.brokenMates.windowStart, buf.brokenMates.windowEnd = 0, len(sampled)
+    eng = get_engine()
+    seqs = [refHaplotype.haplotypeSequence] + [h.haplotypeSequence for h in haplotypes]
+    hb = _pack_window(seqs, refHaplotype.startPos, refHaplotype.endPos, refHaplotype.endBufferSize, [buf])
+    db = eng.upload(hb)
+    eng.align(db, want_stats=False, calc_flank_score=int(refHaplotype.options.calculateFlankScore))
+    eng.synchronize()
+    ll = db.loglik.cpu().numpy()[:hb.n_pairs].reshape(nH + 1, len(sampled))
+    ref = ll[0].tolist()
+    out = []
+    for k in range(nH):
+        row = ll[k + 1].tolist()
+        best = -1e20
+        for i in range(len(readBuffers)):
+            if seg[i] == seg[i + 1]:
+                continue                                                                           # :261-262
+            score = 0.0
+            for r in range(seg[i], seg[i + 1]):
+                score += math.log(0.5 * (math.exp(ref[r]) + math.exp(row[r])))                    # :270-272
+            best = max(best, score)
+        out.append(best)
+    return out
+
+
+def getFilteredHaplotypes(chrom, windowStart, windowEnd, refFile, options, variants, refHaplotype, readBuffers):
+    """variantFilter.pyx:377-506.  Few variants: every valid combination.  Many: greedy growth of the best haplotypes, one
+    variant at a time (most supported first); the candidates of one step are independent and go to the device together."""
+    import math
+    from heapq import heappush, heappushpop
+    from itertools import combinations
+    originalMaxHaplotypes = options.originalMaxHaplotypes - 1      # ref will be added later
+    maxHaplotypes = options.maxHaplotypes - 1
+    maxReadLength = options.rlen
+    nVars = len(variants)
+    windowSize = windowEnd - windowStart
+    targetCoverage = options.coverageSamplingLevel
+    mk = lambda vs: Haplotype(chrom, windowStart, windowEnd, vs, refFile, maxReadLength, options)
+    if nVars <= math.log2(maxHaplotypes) or (options.filterVarsByCoverage and options.maxVariants <= math.log2(maxHaplotypes)):
+        return [mk(vs) for n in range(1, nVars + 1) for vs in combinations(variants, n) if isHaplotypeValid(vs)]   # :411-438
+    varsSortedByCoverage = sorted(variants, key=lambda v: v.nSupportingReads, reverse=True)
+    hapsByBestScore = []
+
+    def push(item):
+        if len(hapsByBestScore) < originalMaxHaplotypes:
+            heappush(hapsByBestScore, item)
+        else:
+            heappushpop(hapsByBestScore, item)
+    for tempVar in varsSortedByCoverage:                                                           # :453-489
+        tempOldHaps = sorted(hapsByBestScore)
+        varThisHap = (tempVar,)
+        cands = [varThisHap]
+        for score, varsThisHap2 in tempOldHaps:
+            both = tuple(sorted(varThisHap + varsThisHap2))
+            if isHaplotypeValid(both):
+                cands.append(both)
+        scores = computeBestScoresForHaplotypes(readBuffers, refHaplotype, [mk(vs) for vs in cands], windowSize, targetCoverage)
+        for sc, vs in zip(scores, cands):
+            push((sc, vs))
+    allHaps = []
+    for index, (score, vs) in enumerate(sorted(hapsByBestScore, reverse=True)):                    # :499-504
+        if index < maxHaplotypes:
+            allHaps.append(mk(vs))
+        else:
+            break
+    return allHaps
+
+
+def mergeHaplotypes(haplotypes, refFile=None):
+    """variantcaller.pyx:325-383: of haplotypes with the same sequence keep the one whose variants have the larger combined prior."""
+    merged, last = [], None
+    for hap in sorted(haplotypes, key=lambda h: (h.refName, h.startPos, h.haplotypeSequence)):
+        if last is None:
+            last = hap
+        elif hap == last:
+            p1 = p2 = 1.0
+            for v in last.variants:
+                p1 *= v.calculatePrior(refFile)
+            for v in hap.variants:
+                p2 *= v.calculatePrior(refFile)
+            if p2 > p1:
+                last = hap
+        else:
+            merged.append(last)
+            last = hap
+    if last is not None:
+        merged.append(last)
+    return merged
+
 
 def assembleReadsAndDetectVariants(chrom, assemStart, assemEnd, refStart, refEnd, readBuffers, refSeq, options=None):
     """assembler.pyx:1429-1476; read selection as loadBAMDataIntoGraph (:1391-1425)."""

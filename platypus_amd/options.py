@@ -72,4 +72,5 @@ def default_options(**overrides):
         if not hasattr(ns, k):
             raise AttributeError("unknown Platypus option %r" % k)
         setattr(ns, k, v)
+    ns.originalMaxHaplotypes = ns.maxHaplotypes          # set once per process by the reference, variantcaller.pyx:920
     return ns

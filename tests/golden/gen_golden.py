@@ -339,16 +339,120 @@ cdef void* my_malloc(size_t n):
 cdef inline int Read_IsQCFail(cAlignedRead* theRead) nogil:      # htslibWrapper.pxd:271-272, BAM_FQCFAIL = 512
     return ((theRead.bitFlag & 512) != 0)
 
+from operator import attrgetter
+from itertools import combinations
+from heapq import heappush, heappop, heappushpop
+nSupportingReadsGetter = attrgetter("nSupportingReads")
+cdef extern from "math.h":
+    double log2(double)
+
+cdef int SNP = 0
+cdef int MNP = 1
+cdef int INS = 2
+cdef int DEL = 3
+cdef int REP = 4
+
+cdef class FastaFile:
+    cdef public object seq_fn
+    def __init__(self, seq_fn):
+        self.seq_fn = seq_fn
+    def haplotype_sequence(self, refName, startPos, endPos, variants, maxReadLength):
+        return self.seq_fn(refName, startPos, endPos, variants, maxReadLength)
+
+cdef class ReadArray:
+    cdef cAlignedRead** windowStart
+    cdef cAlignedRead** windowEnd
+
+cdef class bamReadBuffer:
+    cdef ReadArray reads
+    cdef ReadArray badReads
+    cdef ReadArray brokenMates
+
 cdef class Options:
-    cdef public int calculateFlankScore
-    def __init__(self, int calculateFlankScore):
+    cdef public int calculateFlankScore, originalMaxHaplotypes, maxHaplotypes, rlen, verbosity, coverageSamplingLevel
+    cdef public int filterVarsByCoverage, maxVariants
+    def __init__(self, int calculateFlankScore, int maxHaplotypes=50, int rlen=150, int coverageSamplingLevel=30,
+                 int filterVarsByCoverage=1, int maxVariants=8):
         self.calculateFlankScore = calculateFlankScore
+        self.originalMaxHaplotypes = self.maxHaplotypes = maxHaplotypes
+        self.rlen, self.verbosity, self.coverageSamplingLevel = rlen, 0, coverageSamplingLevel
+        self.filterVarsByCoverage, self.maxVariants = filterVarsByCoverage, maxVariants
 """
+
+VAR_CLASS = r"""
+cdef class Variant:
+    cdef public bytes refName, added, removed
+    cdef public int refPos, nAdded, nRemoved, minRefPos, maxRefPos, varType, nSupportingReads, varSource, idx
+    cdef public long hashValue
+    def __init__(self, bytes refName, int refPos, bytes removed, bytes added, int nSupportingReads, int varSource, int idx=-1):
+        # variant.pyx:109-144
+        refPos = max(0, refPos)
+        self.refName, self.refPos, self.removed, self.added = refName, refPos, removed, added
+        self.nAdded, self.nRemoved = len(added), len(removed)
+        self.nSupportingReads, self.varSource, self.hashValue, self.idx = nSupportingReads, varSource, -1, idx
+        self.minRefPos = refPos
+        self.maxRefPos = max(refPos, refPos + self.nRemoved - 1)
+        if self.nRemoved == self.nAdded:
+            self.varType = SNP if self.nAdded == 1 else MNP
+        else:
+            if self.nRemoved == 0:
+                self.varType = INS
+            elif self.nAdded == 0:
+                self.varType = DEL
+            else:
+                self.varType = REP
+"""
+
+GENO2_CLASS = r"""
+cdef class DiploidGenotype:
+    cdef public Haplotype hap1
+    cdef public Haplotype hap2
+    def __init__(self, Haplotype hap1, Haplotype hap2):
+        self.hap1 = hap1
+        self.hap2 = hap2
+"""
+
+FILT_TAIL = r"""
+def filtered_haplotypes(bytes chrom, int windowStart, int windowEnd, FastaFile refFile, options, list variants, list samples):
+    # samples: per individual the list of good reads (seq, qual, pos, end, mapq, bitFlag); returns the variant-index tuples of
+    # the haplotypes getFilteredHaplotypes returns, in its order
+    cdef list buffers = []
+    cdef bamReadBuffer b
+    cdef ReadArray ra
+    cdef int i
+    keep = []
+    for reads in samples:
+        b = bamReadBuffer()
+        for name in ("reads", "badReads", "brokenMates"):
+            ra = ReadArray()
+            ra.windowStart = ra.windowEnd = NULL
+            if name == "reads":
+                b.reads = ra
+            elif name == "badReads":
+                b.badReads = ra
+            else:
+                b.brokenMates = ra
+        ra = b.reads
+        ra.windowStart = <cAlignedRead**>calloc(len(reads) + 1, sizeof(cAlignedRead*))
+        for i, t in enumerate(reads):
+            keep.append(t)
+            ra.windowStart[i] = make_read(t[0], t[1], t[2], t[3], t[4], t[5])
+        ra.windowEnd = ra.windowStart + len(reads)
+        buffers.append(b)
+    refHap = Haplotype(chrom, windowStart, windowEnd, (), refFile, options.rlen, options)
+    haps = getFilteredHaplotypes({}, chrom, windowStart, windowEnd, refFile, options, variants, refHap, buffers)
+    return [tuple(v.idx for v in h.variants) for h in haps]
+
+def haplotype_valid(tuple variants):
+    return bool(isHaplotypeValid(variants))
+"""
+
 
 HAP_CLASS = r"""
 cdef class Haplotype:
     cdef public int startPos, endPos, endBufferSize, hapLen, lastIndividualIndex, lenCache, mapCountsLen
-    cdef public bytes haplotypeSequence
+    cdef public bytes haplotypeSequence, refName
+    cdef public tuple variants
     cdef public object options
     cdef char* cHaplotypeSequence
     cdef char* cHomopolQ
@@ -358,10 +462,14 @@ cdef class Haplotype:
     cdef double* likelihoodCache
     cdef int* mapCounts
 
-    def __init__(self, bytes haplotypeSequence, int startPos, int endPos, int endBufferSize, int maxReadLength, options):
-        # the tail of the reference constructor (chaplotype.pyx:175-191) for a given haplotype sequence
-        self.haplotypeSequence = haplotypeSequence
-        self.startPos, self.endPos, self.endBufferSize = startPos, endPos, endBufferSize
+    def __init__(self, bytes refName, int startPos, int endPos, tuple variants, refFile, int maxReadLength, options):
+        # the reference constructor's signature; the haplotype SEQUENCE is supplied by the caller through refFile (the
+        # construction of the sequence from variants is host logic pinned elsewhere), then the tail of the reference
+        # constructor (chaplotype.pyx:175-191)
+        self.refName, self.variants = refName, variants
+        self.haplotypeSequence = refFile.haplotype_sequence(refName, startPos, endPos, variants, maxReadLength)
+        self.startPos, self.endPos = startPos, endPos
+        self.endBufferSize = min(2*maxReadLength, 500)
         self.options = options
         self.lastIndividualIndex = -1
         self.localGapOpen = NULL
@@ -469,9 +577,19 @@ def build_scratch(scratch):
     assert chp[66].startswith("cdef bytes homopolq = bytes(''.join([chr(int(33.5 + 10*log( (idx+1)*q )/log(0.1) )) for idx,q in enumerate(per_base_indel_errors)]))")
     mltot = [l for l in chp[:60] if l.startswith("cdef double mLTOT")][0]
     homopol = "cdef bytes homopolq = bytes([int(33.5 + 10*log( (idx+1)*q )/log(0.1) ) for idx,q in enumerate(per_base_indel_errors)])"
-    drv = (HAP_HEAD + mltot + "\n" + chp[63] + "\n" + homopol + "\n\n" + "\n".join(chp[102:115]) + "\n"
+    # + SURVEY 8(f) rank 2: Variant ordering/hash (variant.pyx:270-280,282-363), isHaplotypeValid (platypusutils.pyx:735-802),
+    # computeBestScoreForGenotype and getFilteredHaplotypes (variantFilter.pyx:237-283,377-506)
+    var = open(os.path.join(src, "cython/variant.pyx")).read().split("\n")
+    utl = open(os.path.join(src, "cython/platypusutils.pyx")).read().split("\n")
+    vfl = open(os.path.join(src, "cython/variantFilter.pyx")).read().split("\n")
+    assert var[269].lstrip().startswith("def __hash__") and var[281].lstrip().startswith("def __richcmp__") and var[364].lstrip().startswith("def __str__")
+    assert utl[734].startswith("cdef int isHaplotypeValid") and vfl[236].startswith("cdef double computeBestScoreForGenotype")
+    assert vfl[376].startswith("cdef list getFilteredHaplotypes") and vfl[507].startswith("#####") and vfl[282].lstrip().startswith("return bestScoreThisHap")
+    drv = (HAP_HEAD + mltot + "\n" + chp[63] + "\n" + homopol + "\n\n" + VAR_CLASS + "\n" + "\n".join(var[269:280]) + "\n\n"
+           + "\n".join(var[281:363]) + "\n\n" + "\n".join(chp[102:115]) + "\n"
            + HAP_CLASS + "\n" + "\n".join(chp[305:384]) + "\n\n" + "\n".join(chp[551:590]) + "\n\n"
-           + "\n".join(chp[593:676]) + "\n" + HAP_TAIL)
+           + "\n".join(chp[593:676]) + "\n" + GENO2_CLASS + "\n" + "\n".join(utl[734:802]) + "\n\n" + "\n".join(vfl[236:283]) + "\n\n"
+           + "\n".join(vfl[376:506]) + "\n" + HAP_TAIL + FILT_TAIL)
     open(os.path.join(scratch, "hap_drv.pyx"), "w").write(drv)
     open(os.path.join(scratch, "setup.py"), "w").write(SETUP)
     r = subprocess.run([sys.executable, "setup.py", "build_ext", "--inplace"], cwd=scratch,
@@ -765,7 +883,8 @@ def gen_haplotype(out):
         opt = hap_drv.Options(1 if flank else 0)
         caches, singles, gos = [], [], []
         for h in haps:
-            H = hap_drv.Haplotype(h, ws, we, buf, L, opt)
+            H = hap_drv.Haplotype(b"20", ws, we, (), hap_drv.FastaFile(lambda *a, _h=h: _h), L, opt)
+            assert H.endBufferSize == buf
             c, sgl = hap_drv.align_reads(H, good, bad, brk, 0)
             caches.append(c); singles.append(sgl); gos.append(list(H.gap_open()))
         cases.append(dict(start=ws, end=we, buf=buf, calc_flank=int(flank), haps=[h.decode() for h in haps], reads=reads,
@@ -773,6 +892,95 @@ def gen_haplotype(out):
     with gzip.open(os.path.join(out, "haplotype_cases.json.gz"), "wt") as f:
         json.dump(cases, f)
     print("haplotype: %d windows, %d (haplotype, read) likelihoods" % (len(cases), sum(len(c["cache"]) * (len(c["cache"][0]) - 1) for c in cases)))
+
+
+def gen_filter(out):
+    """isHaplotypeValid (platypusutils.pyx:735-802) and getFilteredHaplotypes with
+    computeBestScoreForGenotype (variantFilter.pyx:237-283,377-506) -- the reference's own texts, aligning with the scratch
+    build of calign.pyx + align.c.  The haplotype SEQUENCES are built by platypus_amd.hostapi.Haplotype (they are inputs
+    here).  Output: which variant combinations survive, in the order the reference returns them."""
+    import hap_drv
+    from platypus_amd import hostapi as HA
+    rng = np.random.default_rng(4711)
+    # ---- isHaplotypeValid
+    valid_cases = []
+    for _ in range(400):
+        n = int(rng.integers(2, 5))
+        pos = np.sort(rng.integers(100, 112, n))
+        vs = []
+        for p_ in pos:
+            t = int(rng.integers(0, 4))
+            rem, add = [(b"A", b"C"), (b"", b"GT"), (b"ACG", b""), (b"AC", b"GT")][t]
+            vs.append((int(p_), rem.decode(), add.decode()))
+        tup = tuple(hap_drv.Variant(b"20", p_, r.encode(), a.encode(), 1, 1) for p_, r, a in vs)
+        ok = all(tup[i].minRefPos <= tup[i + 1].minRefPos for i in range(n - 1))
+        if ok:
+            valid_cases.append(dict(variants=vs, valid=hap_drv.haplotype_valid(tup)))
+    # ---- getFilteredHaplotypes
+    cases = []
+    for ci in range(14):
+        L = int(rng.choice([100, 150]))
+        ref = rnd(rng, 3000)
+        fasta = HA.FastaFile({"20": ref})
+        ws = 1400; we = ws + int(rng.integers(60, 160))
+        nVars = int(rng.integers(6, 10)) if ci % 5 else int(rng.integers(2, 6))      # a few small cases: the enumeration branch
+        used, vs = set(), []
+        while len(vs) < nVars:
+            p_ = int(rng.integers(ws + 3, we - 8))
+            if any(abs(p_ - q) < 3 for q in used):
+                continue
+            used.add(p_)
+            t = rng.random()
+            if t < 0.7:
+                rem = ref[p_:p_ + 1]; add = bytes([B[(B.index(rem[0]) + 1 + int(rng.integers(0, 3))) % 4]])
+            elif t < 0.85:
+                rem = b""; add = rnd(rng, int(rng.integers(1, 5)))
+            else:
+                rem = ref[p_:p_ + int(rng.integers(1, 5))]; add = b""
+            vs.append((p_, rem, add, int(rng.choice([2, 2, 3, 5, 9, 14]))))
+        vs.sort(key=lambda v: (v[0], len(v[1]) != len(v[2])))
+        # platypus variants are sorted with Variant's own ordering; let the compiled class sort them
+        variants = sorted(hap_drv.Variant(b"20", p_, r, a, n, 1, i) for i, (p_, r, a, n) in enumerate(vs))
+        for i, v in enumerate(variants):
+            v.idx = i
+        vrec = [dict(pos=v.refPos, removed=v.removed.decode(), added=v.added.decode(), n_supporting=v.nSupportingReads) for v in variants]
+
+        def seq_fn(refName, startPos, endPos, vtuple, maxReadLength, _f=fasta):
+            hv = tuple(HA.Variant(refName.decode(), v.refPos, v.removed, v.added, v.nSupportingReads) for v in vtuple)
+            return HA.Haplotype(refName.decode(), startPos, endPos, hv, _f, maxReadLength).haplotypeSequence
+        rf = hap_drv.FastaFile(seq_fn)
+        nInd = int(rng.integers(1, 4))
+        buf = min(2 * L, 500)
+        samples = []
+        for i in range(nInd):
+            truth = []
+            for _ in range(2):
+                sel = tuple(v for v in variants if rng.random() < 0.4)
+                while not hap_drv.haplotype_valid(sel):
+                    sel = tuple(v for v in variants if rng.random() < 0.3)
+                truth.append(seq_fn(b"20", ws, we, sel, L))
+            reads = []
+            for _ in range(int(rng.integers(15, 70))):
+                src = truth[int(rng.integers(0, 2))]
+                off = int(rng.integers(max(0, buf - L + 8), min(len(src) - L, buf + (we - ws) - 8) + 1))
+                seq = bytearray(src[off:off + L])
+                if rng.random() < 0.3:
+                    seq[int(rng.integers(0, L))] = B[int(rng.integers(0, 4))]
+                q = np.clip(rng.normal(33, 6, L), 2, 41).astype(np.uint8)
+                pos = ws - buf + off
+                reads.append(dict(seq=bytes(seq).decode(), qual=q.tolist(), pos=pos, end=pos + L, mapq=int(rng.choice([60, 60, 40])), flag=3))
+            reads.sort(key=lambda r: r["pos"])
+            samples.append(reads)
+        maxhap = int(rng.choice([50, 50, 12, 6]))
+        opt = hap_drv.Options(0, maxhap, L, int(rng.choice([30, 30, 8])))
+        tup = lambda r: (r["seq"].encode(), bytes(r["qual"]), r["pos"], r["end"], r["mapq"], r["flag"])
+        res = hap_drv.filtered_haplotypes(b"20", ws, we, rf, opt, variants, [[tup(r) for r in s_] for s_ in samples])
+        cases.append(dict(ref=ref.decode(), start=ws, end=we, rlen=L, max_haplotypes=maxhap, coverage_sampling_level=opt.coverageSamplingLevel,
+                          variants=vrec, samples=samples, haplotypes=[list(t) for t in res]))
+        print("  filter case %d: %d vars -> %d haplotypes" % (ci, nVars, len(res)))
+    with gzip.open(os.path.join(out, "filter_cases.json.gz"), "wt") as f:
+        json.dump(dict(valid=valid_cases, filter=cases), f)
+    print("filter: %d validity cases, %d windows" % (len(valid_cases), len(cases)))
 
 
 def gen_population(out):
@@ -864,7 +1072,7 @@ def main():
         sys.exit("reference tree not found at %s: golden vectors can only be regenerated in the build container" % REF)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     build_scratch(a.scratch)
-    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype"]
+    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter"]
     if "dp" in todo:
         gen_dp(HERE)
     if "mapalign" in todo:
@@ -875,6 +1083,8 @@ def main():
         gen_population(HERE)
     if "haplotype" in todo:
         gen_haplotype(HERE)
+    if "filter" in todo:
+        gen_filter(HERE)
 
 
 if __name__ == "__main__":

@@ -108,6 +108,32 @@ def test_population_call_matches_oracle(oracle):
     assert got[:2] == tuple(ph.tolist()) and got[2] == lik.tolist() and got[3:] == tuple(out4.tolist())
 
 
+def test_getFilteredHaplotypes_matches_reference_golden(golden_dir):
+    """haplotype enumeration / greedy haplotype filter (variantFilter.pyx:377-506 with
+    computeBestScoreForGenotype :237-283) -- the surviving variant combinations, in the reference's order.  Every alignment
+    runs on the device (one batch per greedy step); the per-sample sums use the C library's log/exp on the host."""
+    import gzip, json, os
+    from platypus_amd.options import default_options
+    cases = json.load(gzip.open(os.path.join(golden_dir, "filter_cases.json.gz"), "rt"))["filter"]
+    greedy = 0
+    for c in cases:
+        fasta = H.FastaFile({"20": c["ref"].encode()})
+        variants = [H.Variant("20", v["pos"], v["removed"].encode(), v["added"].encode(), v["n_supporting"]) for v in c["variants"]]
+        assert variants == sorted(variants)
+        buffers = []
+        for reads in c["samples"]:
+            buf = H.bamReadBuffer([H.AlignedRead(r["seq"].encode(), bytes(r["qual"]), r["pos"], mapq=r["mapq"], bitFlag=r["flag"]) for r in reads])
+            buf.reads.windowStart, buf.reads.windowEnd = 0, len(reads)
+            buffers.append(buf)
+        opt = default_options(rlen=c["rlen"], maxHaplotypes=c["max_haplotypes"], coverageSamplingLevel=c["coverage_sampling_level"])
+        refHap = H.Haplotype("20", c["start"], c["end"], (), fasta, c["rlen"], opt)
+        haps = H.getFilteredHaplotypes("20", c["start"], c["end"], fasta, opt, variants, refHap, buffers)
+        got = [[variants.index(v) for v in h.variants] for h in haps]
+        assert got == c["haplotypes"]
+        greedy += len(variants) > 5
+    assert greedy >= 8
+
+
 def test_calculateFlankScore_option(oracle):
     fasta, haps, buffers, ws, we = make_window()
     exp0 = oracle_rows(oracle, haps, buffers[0], ws, we)

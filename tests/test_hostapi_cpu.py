@@ -67,3 +67,14 @@ def test_option_surface_matches_reference():
     assert (o.calculateFlankScore, o.HLATyping, o.nCPU, o.coverageSamplingLevel) == (0, 0, 1, 30)
     p = build_parser().parse_args(["--bamFiles=a.bam,b.bam", "--refFile=r.fa", "--maxReadLength=250", "-o", "x.vcf"])
     assert p.bamFiles == ["a.bam", "b.bam"] and p.rlen == 250 and p.output == "x.vcf"
+
+
+def test_isHaplotypeValid_matches_reference_golden(golden_dir):
+    """platypusutils.pyx:735-802, against outputs of the reference's own text (tests/golden/gen_golden.py: gen_filter)."""
+    import gzip, json, os
+    from platypus_amd import hostapi as H
+    cases = json.load(gzip.open(os.path.join(golden_dir, "filter_cases.json.gz"), "rt"))["valid"]
+    assert len(cases) > 300 and {c["valid"] for c in cases} == {True, False}
+    for c in cases:
+        vs = tuple(H.Variant("20", p, r.encode(), a.encode()) for p, r, a in c["variants"])
+        assert H.isHaplotypeValid(vs) == c["valid"], c
