@@ -479,7 +479,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nw64 = ((maxhap + 63) >> 6) + 8;           // plane words incl. slack for the shifted window of a hypothesis
     unsigned* table = (unsigned*)smem;
-    unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);      // tsize_max = carve size >= 1536 dwords: the multiplicity maps overlay the table
+    unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);      // tsize_max = carve size >= 1024 dwords: the multiplicity maps overlay the table
     u64* h0 = (u64*)(smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 7 & ~(size_t)7));
     u64* h1 = h0 + nw64;
     u64* eqp = h1 + nw64;
@@ -507,17 +507,20 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     const unsigned tmask = (unsigned)tsize - 1u;
     const int nch = (hapLen + 63) >> 6;                  // chunks of 64 haplotype positions
 
-    // Setup, fast part: the proof of hypothesis A only needs the planes, nu and maxmult.  Multiplicities come from three
-    // 16384-bit maps over the 14-bit k-mer codes ("seen at least once / twice / three times"), filled with one LDS
-    // atomicOr per k-mer; they overlay the k-mer index, which is only built (seed_build_index) when some pair of this
-    // workgroup needs a look-up: hypothesis B, the no-vote test, the exact vote, or a multiplicity above 3.
+    // Setup, fast part: the proof of hypothesis A only needs the planes, nu and maxmult.  Multiplicities come from two
+    // 16384-bit maps over the 14-bit k-mer codes ("seen at least once / twice"), filled with one LDS atomicOr per k-mer,
+    // plus a 32-entry counting table for the few codes seen three times or more.  The maps overlay the k-mer index, which
+    // is only built (seed_build_index) when some pair of this workgroup needs a look-up: hypothesis B, the no-vote test,
+    // the exact vote, or more than 32 distinct codes of multiplicity >= 3.  (LDS per workgroup decides how many
+    // haplotypes a CU works on at once: 6 KB instead of 9.4 KB with a third map.)
     unsigned* seen1 = table;
     unsigned* seen2 = table + 512;
-    unsigned* seen3 = table + 1024;
     if (tid < 3) s_scal[tid] = tid == 1;                 // has_n = 0, maxmult = 1, other-than-ACGTN = 0
     signed char* s_go = (signed char*)(s_scal + 4);      // LDS copy of the gap-open table
+    unsigned* trip = (unsigned*)(s_scal + 4 + 16);       // [32] (code + 1) | (occurrences beyond the second) << 16
     if (tid < 49) s_go[tid] = c_homopol_go[tid];
-    for (int i = tid; i < 384; i += nthr) ((uint4*)table)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 32) trip[tid] = 0u;
+    for (int i = tid; i < 256; i += nthr) ((uint4*)table)[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < 4 * nw64; i += nthr) h0[i] = 0ull;            // h0, h1, eqp, nup are contiguous
     __syncthreads();
     // ---- passes A + B, one sweep over the haplotype in chunks of 64 bases (nw == 1: this wave sees every chunk).
@@ -561,9 +564,20 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 const unsigned wd = code >> 5, bit = 1u << (code & 31u);
                 if (atomicOr(&seen1[wd], bit) & bit) {
                     level = max(level, 2);
-                    if (atomicOr(&seen2[wd], bit) & bit) {
-                        level = max(level, 3);
-                        if (atomicOr(&seen3[wd], bit) & bit) level = 4;
+                    if (atomicOr(&seen2[wd], bit) & bit) {                  // third or later occurrence: count it
+                        const unsigned key = code + 1u;
+                        unsigned slot = code & 31u;
+                        int probes = 0;
+                        for (;;) {
+                            unsigned e = trip[slot];
+                            if (e == 0u) {
+                                e = atomicCAS(&trip[slot], 0u, key | (1u << 16));
+                                if (e == 0u) break;
+                            }
+                            if ((e & 0xFFFFu) == key) { atomicAdd(&trip[slot], 1u << 16); break; }
+                            slot = (slot + 1u) & 31u;
+                            if (++probes == 32) { level = 0x7FFF; break; }     // table full: the exact maximum comes from the index
+                        }
                     }
                 }
             }
@@ -572,6 +586,8 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
             P1 = mk(t + 2, b1, b2_);
         }
     }
+    __syncthreads();
+    if (lane < 32) level = max(level, trip[lane] ? 2 + (int)(trip[lane] >> 16) : 0);
 #pragma unroll
     for (int s2 = 32; s2 > 0; s2 >>= 1) level = max(level, __shfl_xor(level, s2));
     if (lane == 0 && level > 1) atomicMax(&s_scal[1], level);
@@ -589,7 +605,9 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     }
     __syncthreads();
     bool have_index = false;
-    if (s_scal[1] >= 4) {                                // multiplicity 4 or more: the exact maximum comes from the index chains
+    if (s_scal[1] >= 0x7FFF) {                           // counting table overflowed: the exact maximum comes from the index chains
+        __syncthreads();
+        if (tid == 0) s_scal[1] = 1;
         __syncthreads();
         seed_build_index(table, nxt, h0, h1, nup, s_scal, hapLen, nch, direct, tsize, tmask, true);
         have_index = true;
@@ -1144,10 +1162,10 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     int tsize_max = 64;                                        // in dwords
     if (maxhap > 4096) tsize_max = 8192;                       // direct mode: 16384 u16 heads
     else while (tsize_max < maxhap + maxhap / 4) tsize_max <<= 1;
-    if (tsize_max < 1536) tsize_max = 1536;                    // the 3 x 512 dwords of the multiplicity maps overlay the table
+    if (tsize_max < 1024) tsize_max = 1024;                    // the 2 x 512 dwords of the multiplicity maps overlay the table
     const int cw = (maxhap + maxread + 8 + 1) & ~1;            // 16-bit diagonal counters of the exact vote, even count
     const size_t nw64 = (((size_t)maxhap + 63) >> 6) + 8;
-    const size_t lds = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 7) & ~(size_t)7) + 4 * nw64 * 8 + 16 + 64;
+    const size_t lds = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 7) & ~(size_t)7) + 4 * nw64 * 8 + 16 + 64 + 128;
     const size_t lds_slow = lds + (size_t)cw * 2;
     if (lds_slow > 160 * 1024) return PLAT_ERR_HAP_TOO_LONG;
     if (lds > 48 * 1024)
