@@ -820,11 +820,20 @@ k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long
                 __syncthreads();
                 for (int i = lane; i < 2 * nw64; i += 64) h0[i] = 0ull;                  // h0, h1 contiguous
                 __syncthreads();
-                for (int t = 0; t < nch; ++t) {
-                    const int p = 64 * t + lane;
-                    const unsigned b2 = p < hapLen ? base2(hs[p]) : 0u;
-                    const u64 m0 = __ballot(b2 & 1u), m1 = __ballot(b2 & 2u);
-                    if (lane == 0) { h0[t] = m0; h1[t] = m1; }
+                for (int t0 = 0; t0 < nch; t0 += 16) {           // 16 chunks of bytes per memory round trip
+                    unsigned by[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int p = 64 * (t0 + k) + lane;
+                        by[k] = p < hapLen ? (unsigned)hs[p] : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int p = 64 * (t0 + k) + lane;
+                        const unsigned b2 = p < hapLen ? base2(by[k]) : 0u;
+                        const u64 m0 = __ballot(b2 & 1u), m1 = __ballot(b2 & 2u);
+                        if (lane == 0 && t0 + k < nch) { h0[t0 + k] = m0; h1[t0 + k] = m1; }
+                    }
                 }
                 __syncthreads();
                 seed_build_index(table, nxt, h0, h1, nup, s_scal, hapLen, nch, direct, tsize, tmask, false);
