@@ -949,8 +949,10 @@ __device__ __forceinline__ int dp_tile(const uint32_t* __restrict__ rp, int stri
 // One lane per live job slot (dense list).  Slot j < npairs is the primary DP of pair j.  Pairs that need a single DP (one
 // candidate that is also the mapping position, or no candidate at all) are finished right here: score -> log-likelihood
 // (a8).  Only pairs with several candidate DPs go through k_finalize_multi.
+// Occupancy is pinned at 4 waves/SIMD: the kernel is VALU-issue bound (5 or 6 waves measured no faster), and the registers it
+// leaves free let the latency-bound kernels of ANOTHER batch (other plat_ctx / stream) run next to it (bench.py --streams).
 template <bool UNPACKED>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32_t* __restrict__ tile,
           const uint32_t* __restrict__ hapw, const uint8_t* __restrict__ hap_has_n, const Job* __restrict__ jobs,
           const PairRec* __restrict__ pairs, const double* __restrict__ mapq_lut, long long npairs,
