@@ -1,7 +1,8 @@
 // plat_genotype.hip -- DiploidGenotype.calculateDataLikelihood + the likelihood part of Population.setup
 // (cgenotype.pyx:131-189, cpopulation.pyx:283-309) on the device.
 //
-// One wave per (window, individual); lane g owns genotype g (looping when G > 64) and walks the
+// One quarter-wave (16 lanes) per (window, individual): most windows have 3..10 genotypes, a full wave per unit left
+// three quarters of the fp64 lanes idle.  Lane g owns genotype g (looping when G > 16) and walks the
 // individual's reads IN INDEX ORDER in fp64 (no FMA contraction: built with -ffp-contract=off), so the
 // sums are the reference's sums.  Only the rarely taken branch log(0.5*(exp(l1)+exp(l2))) and the
 // final exp() rescale go through the device libm instead of glibc (difference <= a few ulp).
@@ -9,14 +10,18 @@
 
 namespace plat {
 
+constexpr int GENO_GROUP = 16;       // lanes per (window, individual) unit
+
 __global__ void __launch_bounds__(64)
-k_genotype(plat_window_batch b, int n_ind, const int32_t* __restrict__ seg_read_begin,
+k_genotype(plat_window_batch b, int n_ind, long long n_units, const int32_t* __restrict__ seg_read_begin,
            const int32_t* __restrict__ seg_n_good, const double* __restrict__ loglik,
            const int64_t* __restrict__ gl_off, double* __restrict__ out_gl, double* __restrict__ out_logl,
            double* __restrict__ out_gof)
 {
-    const int w = blockIdx.x / n_ind, ind = blockIdx.x % n_ind;
-    const int lane = threadIdx.x;
+    const long long unit = (long long)blockIdx.x * (64 / GENO_GROUP) + threadIdx.x / GENO_GROUP;
+    if (unit >= n_units) return;
+    const int w = (int)(unit / n_ind), ind = (int)(unit % n_ind);
+    const int lane = threadIdx.x % GENO_GROUP;
     const int H = b.win_hap_begin[w + 1] - b.win_hap_begin[w];
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
     const int G = H * (H + 1) / 2;
@@ -30,7 +35,7 @@ k_genotype(plat_window_batch b, int n_ind, const int32_t* __restrict__ seg_read_
     const double logHalf = -0.69314718055994529;    // cgenotype.pyx:28
 
     double mymax = -1e7;                            // cpopulation.pyx:288
-    for (int g0 = 0; g0 < G; g0 += 64) {
+    for (int g0 = 0; g0 < G; g0 += GENO_GROUP) {
         const int g = g0 + lane;
         if (g < G) {
             // genotype g -> (a, b), a <= b, in the order of cgenotype.pyx:212-216
@@ -71,11 +76,11 @@ k_genotype(plat_window_batch b, int n_ind, const int32_t* __restrict__ seg_read_
             out_gof[gbase + (long long)g * n_ind + ind] = gof;
         }
     }
-    for (int s = 32; s > 0; s >>= 1) {
+    for (int s = GENO_GROUP / 2; s > 0; s >>= 1) {  // stays inside the unit's 16 lanes
         double o = __shfl_xor(mymax, s);
         mymax = o > mymax ? o : mymax;
     }
-    for (int g = lane; g < G; g += 64) {            // cpopulation.pyx:304-309
+    for (int g = lane; g < G; g += GENO_GROUP) {    // cpopulation.pyx:304-309
         const long long o = gbase + (long long)ind * G + g;
         double v = 1.0;
         if (nGood != 0) {
@@ -98,11 +103,12 @@ PLAT_EXPORT int plat_genotype_window_batch(plat_ctx* ctx, const plat_window_batc
     if (!seg_read_begin || !seg_n_good || !loglik || !gl_off || !out_gl || !out_logl || !out_gof)
         return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
-    const long long nblk = (long long)batch->n_windows * n_ind;
+    const long long nunits = (long long)batch->n_windows * n_ind;
+    const long long nblk = (nunits + 64 / plat::GENO_GROUP - 1) / (64 / plat::GENO_GROUP);
     if (nblk > 0x7FFFFFFFll) return PLAT_ERR_INVALID;
     ctx->ev_valid_geno = 0;
     PLAT_EV(ctx, 6, (hipStream_t)stream);
-    hipLaunchKernelGGL(plat::k_genotype, dim3((unsigned)nblk), dim3(64), 0, (hipStream_t)stream, *batch, n_ind,
+    hipLaunchKernelGGL(plat::k_genotype, dim3((unsigned)nblk), dim3(64), 0, (hipStream_t)stream, *batch, n_ind, nunits,
                        seg_read_begin, seg_n_good, loglik, gl_off, out_gl, out_logl, out_gof);
     PLAT_HIP(ctx, hipGetLastError());
     PLAT_EV(ctx, 7, (hipStream_t)stream);
