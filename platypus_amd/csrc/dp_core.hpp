@@ -205,12 +205,14 @@ __device__ __forceinline__ int dp_run(DP<HAS_N>& dp, int len2, RW rw, HW hw)
     dp.template step<6, -1>(rw(6), hw(6));
     dp.template step<7, -1>(rw(7), hw(7), l7);
     int h = 8;
-    for (; h + 1 < len2; h += 2) {
-        const uint32_t r0 = rw(h), h0 = hw(h), r1 = rw(h + 1), h1 = hw(h + 1);
-        dp.template step<-1, -1>(r0, h0);
-        dp.template step<-1, -1>(r1, h1);
+    for (; h + 7 < len2; h += 8) {               // 8 steps per trip: the loop-carried register copies are paid once per trip
+        uint32_t r[8], w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { r[k] = rw(h + k); w[k] = hw(h + k); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dp.template step<-1, -1>(r[k], w[k]);
     }
-    if (h < len2) { dp.template step<-1, -1>(rw(h), hw(h)); ++h; }
+    for (; h < len2; ++h) dp.template step<-1, -1>(rw(h), hw(h));
     // h == max(len2, 8) here
     if (!l7) { dp.template step<-1, 0>(rw(h), hw(h)); ++h; }
     dp.template step<-1, 1>(rw(h), hw(h)); ++h;
