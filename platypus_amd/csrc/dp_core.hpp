@@ -25,6 +25,16 @@
 //    haplotype holds no 'N' at all (a per-haplotype flag computed while it is staged in LDS).
 //  * the last extra step reads the haplotype word one past the slice instead of 'N'
 //    (align.c:376): that lane only feeds cells x >= len1, which never reach the result.
+//  * values are held RE-BIASED: v' = v + 0x8000 (mod 2^16), so the reference's "zero" -0x8000 is 0, pos_inf 0x7800 is 0xF800
+//    and every signed 16-bit min is an unsigned one.  The map is an order-preserving bijection that commutes with
+//    wrapping addition, so all values correspond one to one, wrap-arounds included.
+//  * SWAR = true adds both 16-bit halves with ONE 32-bit v_add_u32 (a full-rate VOP2 op; v_pk_add_u16 issues at half
+//    rate, profiles/r01_valu_issue_rates.txt).  That is the same result unless a low half carries out, i.e. unless the
+//    reference's own 16-bit add wraps.  Every finite value of the DP is at most 4*(sum of the read's qualities) + 1100
+//    (the cost of the all-mismatch path on the cell's diagonal, plus one gap open / extend / nucprior / substitution
+//    pending in a sum), and values derived from pos_inf stay within 0xF800 + 1100: the kernel picks SWAR only for
+//    reads whose quality sum is at most DP_SWAR_MAX_QSUM, for which no add can reach 0x10000.  All other reads take the
+//    packed adds, which wrap exactly like _mm_add_epi16.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -77,9 +87,12 @@ __device__ __forceinline__ void shift_down_hi(V8& a, uint32_t fill) {
     a.v[3] = (a.v[3] >> 16) | (fill & 0xFFFF0000u);
 }
 
-constexpr uint32_t INF16 = 0x7800u;          // pos_inf, align.c:97
+constexpr uint32_t INF16 = 0x7800u;          // pos_inf, align.c:97 (as a cost; haplotype-N masks, unpacked/traceback variants)
 constexpr uint32_t INF2 = 0x78007800u;
 constexpr uint32_t NEG2 = 0x80008000u;       // -0x8000 in both halves (free start, align.c:249)
+constexpr uint32_t INFB = 0xF800u;           // pos_inf re-biased (+0x8000)
+constexpr uint32_t INFB2 = 0xF800F800u;
+constexpr int DP_SWAR_MAX_QSUM = 15000;      // 4*15000 + 1100 < 0xF800 - 0x200
 constexpr uint32_t CODE_N = ((uint32_t)'N') << 9;
 
 __device__ __forceinline__ uint32_t code9(uint32_t byte) { return (byte & 0x7Fu) << 9; }
@@ -87,24 +100,26 @@ __device__ __forceinline__ uint32_t read_word(uint32_t base, uint32_t qual) { re
 __device__ __forceinline__ uint32_t hap_word(uint32_t base, uint32_t gapopen) { return code9(base) | ((gapopen * 4u) << 16); }
 constexpr uint32_t READ_PAD_WORD = ((((uint32_t)'0') & 0x7Fu) << 9) | ((64u * 4u) << 16);   // align.c:224-225
 
-template <bool HAS_N>
+template <bool HAS_N, bool SWAR = false>
 struct DP {
     // carried between steps: min(M,I) and D of both parities, and un = min(I2 + ge, M2 + go) = the even I of the NEXT
     // step before "+ nucprior" (the odd half-step's gap-open window is the next step's even window).  M and I
-    // themselves are transient, which keeps the kernel under 80 VGPRs.
+    // themselves are transient.  All of them re-biased (see the header of this file).
     V8 mi1, d1, mi2, d2, un, i2p, s1w, s1n, gop, s2w, q2w;
     uint32_t GE, NP, FILLI;
-    int minscore;
+    unsigned minscore;
+
+    static __device__ __forceinline__ uint32_t add(uint32_t a, uint32_t b) { return SWAR ? a + b : pk_add(a, b); }
 
     // hw[0..7]: haplotype words of slice positions 0..7 (align.c:157,181)
     __device__ __forceinline__ void init(const uint32_t (&hw)[8], int gapextend, int nucprior) {
         GE = splat16((uint32_t)(gapextend * 4));
         NP = splat16((uint32_t)(nucprior * 4));
-        FILLI = (INF16 - (uint32_t)(nucprior * 4)) & 0xFFFFu;   // + NP == pos_inf (align.c:483)
-        minscore = 0x7800;
+        FILLI = (INFB - (uint32_t)(nucprior * 4)) & 0xFFFFu;    // + NP == pos_inf (align.c:483)
+        minscore = INFB;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            d1.v[j] = d2.v[j] = mi1.v[j] = mi2.v[j] = i2p.v[j] = INF2;
+            d1.v[j] = d2.v[j] = mi1.v[j] = mi2.v[j] = i2p.v[j] = INFB2;
             s2w.v[j] = 0x01FF01FFu;   // never equals a base code; XOR with any code is >= 511
             q2w.v[j] = 0x01000100u;   // 64*4, align.c:159
             s1w.v[j] = (hw[2 * j] & 0xFFFFu) | (hw[2 * j + 1] << 16);
@@ -112,7 +127,7 @@ struct DP {
             if (HAS_N)
                 s1n.v[j] = ((hw[2 * j] & 0xFFFFu) == CODE_N ? 0u : INF16) |
                            ((hw[2 * j + 1] & 0xFFFFu) == CODE_N ? 0u : (INF16 << 16));
-            un.v[j] = pk_min_i(pk_add(INF2, GE), pk_add(INF2, gop.v[j]));     // i2 = m2 = pos_inf before step 0
+            un.v[j] = pk_min_u(add(INFB2, GE), add(INFB2, gop.v[j]));         // i2 = m2 = pos_inf before step 0
         }
     }
 
@@ -129,53 +144,53 @@ struct DP {
         if (FL >= 0) {
             constexpr uint32_t msk = (FL & 1) ? 0xFFFF0000u : 0x0000FFFFu;
             constexpr int j = (FL >= 0 ? FL : 0) >> 1;
-            mi1.v[j] = (mi1.v[j] & ~msk) | (NEG2 & msk);
-            mi2.v[j] = (mi2.v[j] & ~msk) | (NEG2 & msk);
+            mi1.v[j] = mi1.v[j] & ~msk;                          // -0x8000 re-biased = 0
+            mi2.v[j] = mi2.v[j] & ~msk;
             // the forced m2 also feeds this step's I (align.c:331-335): redo that lane of un with m2 = -0x8000
-            const uint32_t uf = pk_min_i(pk_add(i2p.v[j], GE), pk_add(NEG2, gop.v[j]));
+            const uint32_t uf = pk_min_u(add(i2p.v[j], GE), gop.v[j]);
             un.v[j] = (un.v[j] & ~msk) | (uf & msk);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) S.v[j] = pk_min_i(mi1.v[j], d1.v[j]);
+        for (int j = 0; j < 4; ++j) S.v[j] = pk_min_u(mi1.v[j], d1.v[j]);
         if (EL >= 0) take<(EL >= 0 ? EL : 0)>(S);
         else if (FL == 7) { if (ext_rt) take<0>(S); }          // len2 == 7: h = 7 is both the last forced and the first extra step
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             uint32_t c = pk_min_u(s1w.v[j] ^ s2w.v[j], q2w.v[j]);
-            if (HAS_N) c = pk_min_i(c, s1n.v[j]);
-            m1.v[j] = pk_add(S.v[j], c);
-            i1.v[j] = pk_add(un.v[j], NP);
+            if (HAS_N) c = pk_min_u(c, s1n.v[j]);
+            m1.v[j] = add(S.v[j], c);
+            i1.v[j] = add(un.v[j], NP);
         }
         // gap-open vector of the odd half-step (== srli(gap_open) of the even one, lane 7 unused)
         V8 gopE = gop;
         shift_down_hi(gop, hw);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            T.v[j] = pk_min_i(pk_add(d2.v[j], GE), pk_add(mi2.v[j], gop.v[j]));
-        shift_up(T, INF16);
+            T.v[j] = pk_min_u(add(d2.v[j], GE), add(mi2.v[j], gop.v[j]));
+        shift_up(T, INFB);
         d1 = T;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            mi1.v[j] = pk_min_i(m1.v[j], i1.v[j]);
-            U.v[j] = pk_min_i(pk_add(i1.v[j], GE), pk_add(m1.v[j], gopE.v[j]));   // -> i2 after shift
+            mi1.v[j] = pk_min_u(m1.v[j], i1.v[j]);
+            U.v[j] = pk_min_u(add(i1.v[j], GE), add(m1.v[j], gopE.v[j]));      // -> i2 after shift
         }
         // ---------------- odd half-step
         shift_down(s1w, hw);
         if (HAS_N) shift_down(s1n, (hw & 0xFFFFu) == CODE_N ? 0u : INF16);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) S.v[j] = pk_min_i(mi2.v[j], d2.v[j]);
+        for (int j = 0; j < 4; ++j) S.v[j] = pk_min_u(mi2.v[j], d2.v[j]);
         if (EL >= 0) take<(EL >= 0 ? EL : 0)>(S);
         else if (FL == 7) { if (ext_rt) take<0>(S); }
         shift_down(U, FILLI);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             uint32_t c = pk_min_u(s1w.v[j] ^ s2w.v[j], q2w.v[j]);
-            if (HAS_N) c = pk_min_i(c, s1n.v[j]);
-            const uint32_t m2 = pk_add(S.v[j], c);
-            const uint32_t i2 = pk_add(U.v[j], NP);
-            d2.v[j] = pk_min_i(pk_add(d1.v[j], GE), pk_add(mi1.v[j], gop.v[j]));
-            mi2.v[j] = pk_min_i(m2, i2);
-            un.v[j] = pk_min_i(pk_add(i2, GE), pk_add(m2, gop.v[j]));            // next step's even I before + np
+            if (HAS_N) c = pk_min_u(c, s1n.v[j]);
+            const uint32_t m2 = add(S.v[j], c);
+            const uint32_t i2 = add(U.v[j], NP);
+            d2.v[j] = pk_min_u(add(d1.v[j], GE), add(mi1.v[j], gop.v[j]));
+            mi2.v[j] = pk_min_u(m2, i2);
+            un.v[j] = pk_min_u(add(i2, GE), add(m2, gop.v[j]));               // next step's even I before + np
             if (FL >= 0) i2p.v[j] = i2;
         }
     }
@@ -183,17 +198,17 @@ struct DP {
     template <int E>
     __device__ __forceinline__ void take(const V8& S) {
         const uint32_t r = S.v[E >> 1];
-        const int sc = (int)(short)((E & 1) ? (r >> 16) : (r & 0xFFFFu));
+        const unsigned sc = (E & 1) ? (r >> 16) : (r & 0xFFFFu);
         minscore = sc < minscore ? sc : minscore;
     }
 
-    __device__ __forceinline__ int result() const { return (minscore + 0x8000) >> 2; }   // align.c:520
+    __device__ __forceinline__ int result() const { return (int)(minscore >> 2); }   // (minscore + 0x8000) >> 2, align.c:520
 };
 
 // The 8 forced steps h = 0..7 and the 8 extra steps h = len2..len2+7 are fully unrolled with
 // compile-time lane indices; RW(h) / HW(h) are callables returning the read / haplotype word of step h.
-template <bool HAS_N, class RW, class HW>
-__device__ __forceinline__ int dp_run(DP<HAS_N>& dp, int len2, RW rw, HW hw)
+template <bool HAS_N, bool SWAR, class RW, class HW>
+__device__ __forceinline__ int dp_run(DP<HAS_N, SWAR>& dp, int len2, RW rw, HW hw)
 {
     const bool l7 = (len2 == 7);
     dp.template step<0, -1>(rw(0), hw(0));
@@ -231,7 +246,7 @@ __device__ __forceinline__ int dp_score_bytes(const uint8_t* __restrict__ hap, c
                                               int len2, int gapextend, int nucprior)
 {
     const int len1 = len2 + 15;
-    DP<true> dp;
+    DP<true, false> dp;
     uint32_t w0[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) w0[k] = hap_word(hap[k], go[k]);
@@ -240,7 +255,7 @@ __device__ __forceinline__ int dp_score_bytes(const uint8_t* __restrict__ hap, c
     auto hw = [&](int h) -> uint32_t {
         return 8 + h < len1 ? hap_word(hap[8 + h], go[8 + h]) : hap_word((uint32_t)'N', go[len1 - 1]);
     };
-    return dp_run<true>(dp, len2, rw, hw);
+    return dp_run<true, false>(dp, len2, rw, hw);
 }
 
 }  // namespace plat

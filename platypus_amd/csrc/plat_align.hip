@@ -30,9 +30,13 @@ namespace plat {
 // with one global atomic per such pair.  (A single job counter bumped by every pair saturates one L2
 // atomic unit: ~90 atomics/us, i.e. ~20 ms for 2M pairs -- measured in round 1.)
 struct PairRec { int32_t extra_base, idx0; int16_t ncand, orig_k; uint8_t mapq, pad[3]; };   // ncand: -1 skipped, -2 read < 7 bp, -3 exact match (idx0 = read length)
-struct Job { uint32_t col; int32_t hap, idx, len; };     // col = tile dword index of the read's column; len 0 = empty slot
+struct Job { uint32_t col; int32_t hap, idx, len; };     // col = tile dword index of the read's column; len 0 = empty slot;
+                                                         // hap bit 30 (JOB_BIGQ): the read's quality sum forbids the 32-bit SWAR adds
+constexpr int32_t JOB_BIGQ = 1 << 30;
+__device__ __forceinline__ int job_hap(const Job& j) { return j.hap & (JOB_BIGQ - 1); }
 // per-read descriptor: tile column, offset of the k-mer codes, mapping position, len | flags<<16 | mapq<<24
-// (flags bit0: skipped by the QCFail / overlap < 7 rule; bit1: the read holds a byte other than A, C, G, T)
+// (flags bit0: skipped by the QCFail / overlap < 7 rule; bit1: the read holds a byte other than A, C, G, T;
+//  bit2: quality sum above DP_SWAR_MAX_QSUM -> its DPs use the packed 16-bit adds)
 struct ReadInfo { uint32_t col, code_off; int32_t pos; uint32_t lfm; };
 __device__ __forceinline__ long long job_slot(long long pair, long long npairs, int extra_base, int k) {
     return k == 0 ? pair : npairs + extra_base + (k - 1);
@@ -167,6 +171,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
     __shared__ int s_off[65];
     __shared__ unsigned s_dirty[2];                      // bit rl: read rl of the group holds a byte other than A, C, G, T
+    __shared__ unsigned s_qsum[64];                      // sum of the base qualities of read rl (picks the DP's add flavour)
     const int w = blockIdx.x;
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
     if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
@@ -204,6 +209,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
         if (bad & 0x80808080u) set_err(cnt, PLAT_ERR_BAD_INPUT);
     }
     if (tid < 2) s_dirty[tid] = 0u;
+    if (tid < 64) s_qsum[tid] = 0u;
     ReadInfo my_ri = ReadInfo{0u, 0u, 0, 0u};            // loaded now, stored at the end together with the "dirty" bit
     if (tid < nr) {
         const int wstart = b.win_start[w], wend = b.win_end[w];
@@ -234,19 +240,23 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             const int o = s_off[rl], L = s_off[rl + 1] - o;
             uint32_t* tp = tile + toff + (long long)(4 * g) * R + c0 + rl;
             bool dirty = false;
+            unsigned qs = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = 4 * g + j;
                 uint32_t wd = READ_PAD_WORD;
                 if (i < L) {
                     const unsigned ch = staged ? lseq[o + i] : gs[o + i];
-                    wd = read_word(ch, staged ? lqual[o + i] : gq[o + i]);
+                    const unsigned ql = staged ? lqual[o + i] : gq[o + i];
+                    qs += ql;
+                    wd = read_word(ch, ql);
                     const unsigned dch = ch - 65u;                               // 'A' 'C' 'G' 'T' = 65 + {0, 2, 6, 19}
                     dirty |= dch > 19u || !((0x80045u >> dch) & 1u);
                 }
                 if (i < rows) tp[(long long)j * R] = wd;
             }
             if (dirty) atomicOr(&s_dirty[rl >> 5], 1u << (rl & 31));
+            if (qs) atomicAdd(&s_qsum[rl], qs);
         }
     }
     // bit planes: for every read and every chunk c of 64 bases, plane0 = bit 0 and plane1 = bit 1 of the 2-bit base code,
@@ -280,6 +290,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     __syncthreads();
     if (tid < nr) {
         my_ri.lfm |= ((s_dirty[tid >> 5] >> (tid & 31)) & 1u) << 17;
+        my_ri.lfm |= (s_qsum[tid] > (unsigned)DP_SWAR_MAX_QSUM ? 1u : 0u) << 18;
         rinfo[rb + c0 + tid] = my_ri;
     }
 }
@@ -637,6 +648,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         const uint8_t mapq = (uint8_t)(ri.lfm >> 24);
         const long long pidx = pbase + rl;
         const bool skipped = (rflags & 1) != 0, tooshort = L < 7;
+        const int hq = h | ((rflags & 4) ? JOB_BIGQ : 0);                   // haplotype index + the read's add-flavour flag
         const bool hapshort = valid && !skipped && !tooshort && hapLen < L + 15;
         if (hapshort) set_err(cnt, PLAT_ERR_HAP_TOO_SHORT);
         const bool live = valid && !skipped && !tooshort && !hapshort;
@@ -748,7 +760,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 if (lane == 0) wb = (int)atomicAdd((unsigned long long*)&cnt[CNT_NEXTRA], (unsigned long long)__popcll(m));
                 wb = __shfl(wb, 0);
                 base = wb + __popcll(m & ((1ull << lane) - 1ull));
-                if (need && (long long)base + 1 <= (long long)extra_cap) jobs[npairs + base] = Job{ri.col, h, idx0, L};
+                if (need && (long long)base + 1 <= (long long)extra_cap) jobs[npairs + base] = Job{ri.col, hq, idx0, L};
             }
         }
         if (valid && decided) {
@@ -759,7 +771,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 pairs[pidx] = PairRec{0, L, (int16_t)-3, 0, mapq, {0, 0, 0}};
                 jobs[pidx] = Job{ri.col, h, cidx, 0};
             } else {
-                jobs[pidx] = Job{ri.col, h, cidx, L};
+                jobs[pidx] = Job{ri.col, hq, cidx, L};
                 pairs[pidx] = PairRec{base, idx0, (int16_t)ncand, (int16_t)(orig_in ? 0 : ncand), mapq, {0, 0, 0}};
             }
         }
@@ -845,7 +857,7 @@ k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long
             const int idx0 = min(ri.pos - hapStart, hapLen - L - 15);                    // calign.pyx:252
             const long long pidx = b.pair_off[w] + (long long)(h - b.win_hap_begin[w]) * R + rec.rl;
             const u64* scp = (const u64*)(codes + tile_off[w]) + rec.rl;
-            seed_exact_vote(table, nxt, counts, direct, tmask, hapLen, h, scp, R, L, idx0, ri.col, (int)(ri.lfm >> 24), pidx,
+            seed_exact_vote(table, nxt, counts, direct, tmask, hapLen, h | (((ri.lfm >> 18) & 1u) ? JOB_BIGQ : 0), scp, R, L, idx0, ri.col, (int)(ri.lfm >> 24), pidx,
                             npairs, extra_cap, jobs, pairs, cnt);
         }
     }
@@ -925,7 +937,7 @@ k_compact_scatter(const Job* __restrict__ jobs, long long npairs, long long extr
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_N, bool UNPACKED>
+template <bool HAS_N, bool SWAR, bool UNPACKED>
 __device__ __forceinline__ int dp_tile(const uint32_t* __restrict__ rp, int stride, const uint32_t* __restrict__ hp, int len2)
 {
     uint32_t w0[8];
@@ -939,12 +951,11 @@ __device__ __forceinline__ int dp_tile(const uint32_t* __restrict__ rp, int stri
         dp.init(w0);                                                         // gapextend 3, nucprior 2: chaplotype.pyx:607-608
         return dp_run_u<HAS_N>(dp, len2, rw, hw);
     } else {
-        DP<HAS_N> dp;
+        DP<HAS_N, SWAR> dp;
         dp.init(w0, 3, 2);
-        return dp_run<HAS_N>(dp, len2, rw, hw);
+        return dp_run<HAS_N, SWAR>(dp, len2, rw, hw);
     }
 }
-
 
 // One lane per live job slot (dense list).  Slot j < npairs is the primary DP of pair j.  Pairs that need a single DP (one
 // candidate that is also the mapping position, or no candidate at all) are finished right here: score -> log-likelihood
@@ -967,19 +978,26 @@ k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32
     Job jb = Job{0, 0, 0, 0};
     if (active) jb = jobs[j];
     int has_n = 0, stride = 0;
+    const int hap = job_hap(jb);
+    const int bigq = active && (jb.hap & JOB_BIGQ) != 0;
     if (active) {
-        has_n = hap_has_n[jb.hap];
-        const int w = hap_win[jb.hap];
+        has_n = hap_has_n[hap];
+        const int w = hap_win[hap];
         stride = b.win_read_begin[w + 1] - b.win_read_begin[w];
     }
     const int st = max(0, jb.idx - 8);                                       // calign.pyx:229,256
-    const uint32_t* hp = hapw + (active ? b.hap_off[jb.hap] + st : 0);
+    const uint32_t* hp = hapw + (active ? b.hap_off[hap] + st : 0);
     const uint32_t* rp = tile + jb.col;
     int sc = 0;
-    if (__any(has_n)) {                                                      // wave-uniform choice of the code path
-        if (active) sc = dp_tile<true, UNPACKED>(rp, stride, hp, jb.len);
+    // wave-uniform choice of the code path: haplotype N's need the extra mask; the 32-bit SWAR adds are only taken when
+    // every read of the wave has a quality sum that rules out a carry between the packed halves (dp_core.hpp)
+    const bool anyN = __any(has_n), anyBig = UNPACKED || __any(bigq);
+    if (anyN) {
+        if (anyBig) { if (active) sc = dp_tile<true, false, UNPACKED>(rp, stride, hp, jb.len); }
+        else        { if (active) sc = dp_tile<true, true, UNPACKED>(rp, stride, hp, jb.len); }
     } else {
-        if (active) sc = dp_tile<false, UNPACKED>(rp, stride, hp, jb.len);
+        if (anyBig) { if (active) sc = dp_tile<false, false, UNPACKED>(rp, stride, hp, jb.len); }
+        else        { if (active) sc = dp_tile<false, true, UNPACKED>(rp, stride, hp, jb.len); }
     }
     if (!active) return;
     if (j >= npairs) { job_score[j] = sc; return; }
@@ -1007,10 +1025,11 @@ k_dp_tb_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uin
     const Job jb = jobs[j];
     int sc;
     {
-        const int w = hap_win[jb.hap];
+        const int hap = job_hap(jb);
+        const int w = hap_win[hap];
         const long long stride = b.win_read_begin[w + 1] - b.win_read_begin[w];
-        const long long hoff = b.hap_off[jb.hap];
-        const int hapLen = (int)(b.hap_off[jb.hap + 1] - hoff), hapFlank = b.win_flank[w];
+        const long long hoff = b.hap_off[hap];
+        const int hapLen = (int)(b.hap_off[hap + 1] - hoff), hapFlank = b.win_flank[w];
         const int st = max(0, jb.idx - 8);                                   // calign.pyx:229,256
         const uint32_t* hfull = hapw + hoff;
         const uint32_t* hp = hfull + st;

@@ -457,3 +457,55 @@ def test_config2_full_size_properties(eng, oracle):
     for k in range(0, 2000, 7):
         w = perm[k]
         assert np.array_equal(ll2[hb2.pair_off[k]:hb2.pair_off[k + 1]], ll[hb.pair_off[w]:hb.pair_off[w + 1]])
+
+
+def test_dp_add_flavours_agree_with_oracle(eng, oracle):
+    """The DP adds both packed halves with one 32-bit add when the read's quality sum rules out a carry (dp_core.hpp),
+    and with true 16-bit packed adds otherwise.  Windows whose reads straddle the threshold (quality sums 9 000 .. 24 000,
+    many mismatches so that costs get large) must match the oracle either way."""
+    rng = np.random.default_rng(31337)
+    B = np.frombuffer(b"ACGT", dtype=np.uint8)
+    wins = []
+    for w in range(12):
+        L = 250
+        buf = 500
+        W = 60
+        ref = B[rng.integers(0, 4, W + 2 * buf + 200)]
+        ws = 100 + buf
+        hap0 = ref[ws - buf:ws + W + buf].copy()
+        hap1 = hap0.copy(); hap1[buf + 20] = B[(int(np.searchsorted(B, hap1[buf + 20])) + 1) % 4]
+        reads = []
+        for r in range(48):
+            off = int(rng.integers(buf - L + 10, buf + W - 10))
+            seq = hap0[off:off + L].copy()
+            nmm = int(rng.choice([0, 2, 30, 120, 250]))
+            idx = rng.choice(L, nmm, replace=False)
+            seq[idx] = B[rng.integers(0, 4, nmm)]
+            qmean = float(rng.choice([36, 60, 75, 93]))                     # quality sums from ~9 000 to ~23 000
+            q = np.clip(rng.normal(qmean, 3, L), 0, 93).astype(np.uint8)
+            reads.append((0, ws - buf + off, seq, q, 0, 60))
+        reads.sort(key=lambda x: (x[0], x[1]))
+        wins.append((ws, ws + W, buf, [hap0, hap1], reads))
+    hap_seq = np.concatenate([h for w in wins for h in w[3]])
+    hl = np.array([len(h) for w in wins for h in w[3]])
+    allr = [r for w in wins for r in w[4]]
+    rl = np.array([len(r[2]) for r in allr])
+    qsum = np.array([int(r[3].sum()) for r in allr])
+    assert (qsum <= 15000).sum() > 50 and (qsum > 15000).sum() > 50
+    hb = HostBatch(
+        n_ind=1, win_hap_begin=np.concatenate([[0], np.cumsum([len(w[3]) for w in wins])]).astype(np.int32),
+        win_read_begin=np.concatenate([[0], np.cumsum([len(w[4]) for w in wins])]).astype(np.int32),
+        win_start=np.array([w[0] for w in wins], dtype=np.int32), win_end=np.array([w[1] for w in wins], dtype=np.int32),
+        win_flank=np.array([w[2] for w in wins], dtype=np.int32), hap_seq=hap_seq,
+        hap_off=np.concatenate([[0], np.cumsum(hl)]).astype(np.int64),
+        read_seq=np.concatenate([r[2] for r in allr]), read_qual=np.concatenate([r[3] for r in allr]),
+        read_off=np.concatenate([[0], np.cumsum(rl)]).astype(np.int64),
+        read_pos=np.array([r[1] for r in allr], dtype=np.int32),
+        read_end=np.array([r[1] + len(r[2]) for r in allr], dtype=np.int32),
+        read_mapq=np.array([r[5] for r in allr], dtype=np.uint8), read_flags=np.array([r[4] for r in allr], dtype=np.int32),
+        read_kind=np.array([r[0] for r in allr], dtype=np.uint8),
+        seg_read_begin=np.concatenate([[0], np.cumsum([len(w[4]) for w in wins])]).astype(np.int32),
+        seg_n_good=np.array([len(w[4]) for w in wins], dtype=np.int32))
+    db, st, ll, sc = run_align(eng, hb)
+    check_against_oracle(oracle, hb, ll, sc, st)
+    assert sc.max() > 1000                                                   # costs far beyond anything config 2 produces
