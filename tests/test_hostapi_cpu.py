@@ -78,3 +78,24 @@ def test_isHaplotypeValid_matches_reference_golden(golden_dir):
     for c in cases:
         vs = tuple(H.Variant("20", p, r.encode(), a.encode()) for p, r, a in c["variants"])
         assert H.isHaplotypeValid(vs) == c["valid"], c
+
+
+def test_mergeHaplotypes_keeps_the_better_prior():
+    """variantcaller.pyx:325-383: haplotypes with identical sequences collapse to the one whose variants have the larger
+    combined prior; distinct sequences all survive, sorted like Haplotype.__richcmp__."""
+    from platypus_amd import hostapi as H
+    ref = bytearray(b"ACGTACGTAC" * 60)
+    ref[300:305] = b"AAAAA"
+    ref = bytes(ref)
+    fasta = H.FastaFile({"20": ref})
+    # deleting either of two neighbouring A's of the run gives the same sequence
+    d1 = H.Variant("20", 300, ref[301:302], b""); d1.prior = 1e-4
+    d2 = H.Variant("20", 301, ref[302:303], b""); d2.prior = 3e-4
+    snp = H.Variant("20", 310, ref[310:311], b"T" if ref[310:311] != b"T" else b"A")
+    mk = lambda vs: H.Haplotype("20", 290, 330, vs, fasta, 100)
+    h1, h2, h3, h0 = mk((d1,)), mk((d2,)), mk((snp,)), mk(())
+    assert h1.haplotypeSequence == h2.haplotypeSequence and h1 == h2 and h1 != h3
+    merged = H.mergeHaplotypes([h3, h1, h0, h2])
+    assert len(merged) == 3
+    assert [m.variants for m in merged if m == h1] == [(d2,)]                 # 3e-4 beats 1e-4
+    assert [m.haplotypeSequence for m in merged] == sorted(m.haplotypeSequence for m in merged)
