@@ -39,6 +39,15 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, int iters, uint32_t seed
                 if (OP == 22) asm volatile("v_min_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b), "v"(c));
                 if (OP == 23) asm volatile("v_add_u16_sdwa %0, %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0" : "+v"(a[i]) : "v"(b), "v"(c));
                 if (OP == 24) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b), "v"(c));
+                // mixes (the DP's add -> min pattern); counted as ONE op of the loop below, i.e. halve the printed cycles
+                if (OP == 25) asm volatile("v_add_u32 %0, %0, %1\n\tv_pk_min_u16 %0, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 26) asm volatile("v_pk_add_u16 %0, %0, %1\n\tv_pk_min_u16 %0, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 27) asm volatile("v_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                // the DP's  min(x + GE, y + gop)  shape: two adds then one packed min (THREE instructions per counted op)
+                if (OP == 28) asm volatile("v_add_u32 %0, %0, %2\n\tv_add_u32 %1, %1, %3\n\tv_pk_min_u16 %0, %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) & 7]) : "v"(b), "v"(c));
+                if (OP == 29) asm volatile("v_pk_add_u16 %0, %0, %2\n\tv_pk_add_u16 %1, %1, %3\n\tv_pk_min_u16 %0, %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) & 7]) : "v"(b), "v"(c));
+                // four adds then two mins (SIX instructions per counted op)
+                if (OP == 30) asm volatile("v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %5\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %5\n\tv_pk_min_u16 %0, %0, %1\n\tv_pk_min_u16 %2, %2, %3" : "+v"(a[i]), "+v"(a[(i + 1) & 7]), "+v"(a[(i + 2) & 7]), "+v"(a[(i + 3) & 7]) : "v"(b), "v"(c));
             }
         }
     }
@@ -90,5 +99,14 @@ int main()
     run<22>("v_min_u16", d, blocks);
     run<23>("v_add_u16_sdwa_pad", d, blocks);
     run<24>("v_cndmask_b32", d, blocks);
+    for (int occ = 8; occ >= 4; occ >>= 1) {                   // mixes at 8 / 4 / 2 waves per SIMD (2 instructions per counted op)
+        printf("# %d waves/SIMD\n", occ);
+        run<25>("add_u32+pk_min_u16", d, 256 * occ);
+        run<26>("pk_add_u16+pk_min_u16", d, 256 * occ);
+        run<27>("add_u32+add_u32", d, 256 * occ);
+        run<28>("add32,add32,pkmin (x3)", d, 256 * occ);
+        run<29>("pkadd,pkadd,pkmin (x3)", d, 256 * occ);
+        run<30>("4xadd32,2xpkmin (x6)", d, 256 * occ);
+    }
     return 0;
 }
