@@ -166,8 +166,9 @@ class FastaFile:
             raise IndexError("Cannot have beginPos = %s, endPos = %s" % (beginPos, endPos))
         return self._seq[seqName][beginPos:endPos]
 
-    def getCharacter(self, seqName, pos):
-        return self._seq[seqName][pos:pos + 1]
+    def getCharacter(self, seqName, pos):                                         # fastafile.pyx:120-132
+        s = self._seq[seqName]
+        return b"-" if (pos >= len(s) or pos < 0) else s[pos:pos + 1]
 
 
 def _pack_window(haps, startPos, endPos, endBufferSize, buffers):
@@ -206,6 +207,13 @@ class Haplotype:
         self.endBufferSize = min(2 * maxReadLength, 500)                        # :142
         self.lastIndividualIndex = -1
         self.likelihoodCache = None
+        if len(self.variants) > 0:                                               # :151-156
+            self.minVarPos = min(v.minRefPos for v in self.variants)
+            self.maxVarPos = max(v.maxRefPos for v in self.variants)
+            if self.minVarPos == self.maxVarPos:
+                self.maxVarPos += 1
+        else:
+            self.minVarPos, self.maxVarPos = self.startPos, self.endPos          # :159-160
         self.referenceSequence = refFile.getSequence(refName, self.startPos - self.endBufferSize, self.endPos + self.endBufferSize)
         if len(self.variants) == 0:
             self.haplotypeSequence = self.referenceSequence

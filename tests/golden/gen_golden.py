@@ -352,12 +352,35 @@ cdef int INS = 2
 cdef int DEL = 3
 cdef int REP = 4
 
+cdef class SeqInfo:
+    cdef public long long SeqLength
+    def __init__(self, n):
+        self.SeqLength = n
+
 cdef class FastaFile:
     cdef public object seq_fn
-    def __init__(self, seq_fn):
+    cdef public dict refs
+    cdef public dict seqs
+    def __init__(self, seq_fn=None, seqs=None):
         self.seq_fn = seq_fn
+        self.seqs = seqs or {}
+        self.refs = dict((k, SeqInfo(len(v))) for k, v in self.seqs.items())
     def haplotype_sequence(self, refName, startPos, endPos, variants, maxReadLength):
         return self.seq_fn(refName, startPos, endPos, variants, maxReadLength)
+    # in-memory stand-in for fastafile.pyx:120-207 (file I/O is outside the scope): half-open interval clamped to
+    # [0, len-1]; "-" for a position outside the sequence
+    def getSequence(self, seqName, beginPos, endPos):
+        s = self.seqs[seqName]
+        beginPos = max(0, beginPos)
+        endPos = min(len(s) - 1, endPos)
+        if endPos < beginPos:
+            raise IndexError("Cannot have beginPos = %s, endPos = %s" % (beginPos, endPos))
+        return s[beginPos:endPos]
+    def getCharacter(self, seqName, pos):
+        s = self.seqs[seqName]
+        if pos >= len(s) or pos < 0:
+            return b"-"
+        return s[pos:pos + 1]
 
 cdef class ReadArray:
     cdef cAlignedRead** windowStart
@@ -401,6 +424,15 @@ cdef class Variant:
                 self.varType = DEL
             else:
                 self.varType = REP
+"""
+
+HAPSEQ_CLASS = r"""
+cdef class HaplotypeSeq:
+    cdef public bytes refName
+    cdef public object refFile, variants, haplotypeSequence, options, longVar, shortReferenceSequence, shortHaplotypeSequence, referenceSequence
+    cdef public int hash, startPos, endPos, maxReadLength, endBufferSize, verbosity, lastIndividualIndex, minVarPos, maxVarPos, hapLen
+    cdef char* localGapOpen
+    cdef char* cHaplotypeSequence
 """
 
 GENO2_CLASS = r"""
@@ -574,6 +606,11 @@ def build_scratch(scratch):
     assert chp[102].startswith("cdef int computeOverlapOfReadAndHaplotype") and chp[305].lstrip().startswith("cdef double* alignReads")
     assert chp[378].lstrip().startswith("cdef inline double alignSingleRead") and chp[551].lstrip().startswith("cdef void annotateWithGapOpen")
     assert chp[593].startswith("cdef double alignReadToHaplotype") and chp[63].startswith("cdef list per_base_indel_errors")
+    assert chp[126].lstrip().startswith("def __init__(self, bytes refName, int startPos") and chp[174].lstrip().startswith("self.hapLen")
+    assert chp[385].lstrip().startswith("cdef char* getReferenceSequence") and chp[396].lstrip().startswith("cdef char* getMutatedSequence")
+    assert chp[450].lstrip().startswith("cdef list homopolymerLengths")
+    # (second Python-2-only expression: chaplotype.pyx:447 joins byte strings with '' -- evaluated as b''.join here)
+    assert "bytes(''.join(bitsOfMutatedSeq))" in chp[446]
     assert chp[66].startswith("cdef bytes homopolq = bytes(''.join([chr(int(33.5 + 10*log( (idx+1)*q )/log(0.1) )) for idx,q in enumerate(per_base_indel_errors)]))")
     mltot = [l for l in chp[:60] if l.startswith("cdef double mLTOT")][0]
     homopol = "cdef bytes homopolq = bytes([int(33.5 + 10*log( (idx+1)*q )/log(0.1) ) for idx,q in enumerate(per_base_indel_errors)])"
@@ -588,7 +625,8 @@ def build_scratch(scratch):
     drv = (HAP_HEAD + mltot + "\n" + chp[63] + "\n" + homopol + "\n\n" + VAR_CLASS + "\n" + "\n".join(var[269:280]) + "\n\n"
            + "\n".join(var[281:363]) + "\n\n" + "\n".join(chp[102:115]) + "\n"
            + HAP_CLASS + "\n" + "\n".join(chp[305:384]) + "\n\n" + "\n".join(chp[551:590]) + "\n\n"
-           + "\n".join(chp[593:676]) + "\n" + GENO2_CLASS + "\n" + "\n".join(utl[734:802]) + "\n\n" + "\n".join(vfl[236:283]) + "\n\n"
+           + "\n".join(chp[593:676]) + "\n" + HAPSEQ_CLASS + "\n".join(chp[126:175]) + "\n\n" + "\n".join(chp[385:395]) + "\n\n"
+           + "\n".join(chp[396:449]).replace("bytes(''.join(bitsOfMutatedSeq))", "b''.join(bitsOfMutatedSeq)") + "\n" + GENO2_CLASS + "\n" + "\n".join(utl[734:802]) + "\n\n" + "\n".join(vfl[236:283]) + "\n\n"
            + "\n".join(vfl[376:506]) + "\n" + HAP_TAIL + FILT_TAIL)
     open(os.path.join(scratch, "hap_drv.pyx"), "w").write(drv)
     open(os.path.join(scratch, "setup.py"), "w").write(SETUP)
@@ -983,6 +1021,54 @@ def gen_filter(out):
     print("filter: %d validity cases, %d windows" % (len(valid_cases), len(cases)))
 
 
+def gen_hapseq(out):
+    """The construction of a haplotype's sequence from its variants: the reference's own constructor head and
+    getMutatedSequence / getReferenceSequence (chaplotype.pyx:127-175,386-449) over an in-memory FastaFile stand-in."""
+    import hap_drv
+    rng = np.random.default_rng(1212)
+    cases = []
+    for ci in range(160):
+        n = int(rng.choice([700, 1500, 3000]))
+        ref = rnd(rng, n)
+        fasta = hap_drv.FastaFile(None, {b"20": ref})
+        L = int(rng.choice([36, 100, 150, 250, 400]))
+        if ci % 9 == 0:
+            ws = int(rng.integers(0, 30))                            # window at the start of the contig (left buffer clamps)
+        elif ci % 9 == 1:
+            ws = n - int(rng.integers(20, 120))                      # ... at its end
+        else:
+            ws = int(rng.integers(0, n - 50))
+        we = min(n + 5, ws + int(rng.integers(1, 200)))
+        vs = []
+        pos = ws + int(rng.integers(0, 3))
+        while pos < min(we, n - 8) and len(vs) < 6:
+            t = rng.random()
+            if t < 0.45:
+                rem = ref[pos:pos + 1]; add = bytes([B[(B.index(rem[0]) + 1) % 4]])
+            elif t < 0.55:
+                k = int(rng.integers(2, 5)); rem = ref[pos:pos + k]; add = rnd(rng, k)
+            elif t < 0.75:
+                rem = b""; add = rnd(rng, int(rng.integers(1, 12)))
+            elif t < 0.95:
+                rem = ref[pos + 1:pos + 1 + int(rng.integers(1, 12))]; add = b""
+            else:
+                rem = ref[pos:pos + int(rng.integers(1, 4))]; add = rnd(rng, int(rng.integers(4, 8)))       # replacement
+            vs.append((pos, rem, add))
+            pos += len(rem) + int(rng.integers(0, 40)) + (0 if rng.random() < 0.2 else 1)
+        variants = tuple(sorted(hap_drv.Variant(b"20", p_, r, a, 1, 1) for p_, r, a in vs))
+        if not hap_drv.haplotype_valid(variants):
+            continue
+        h = hap_drv.HaplotypeSeq(b"20", ws, we, variants, fasta, L, hap_drv.Options(0))
+        cases.append(dict(ref=ref.decode(), start=ws, end=we, rlen=L,
+                          variants=[dict(pos=v.refPos, removed=v.removed.decode(), added=v.added.decode()) for v in variants],
+                          haplotype=h.haplotypeSequence.decode(), start_pos=h.startPos, end_pos=h.endPos, end_buffer=h.endBufferSize,
+                          min_var_pos=h.minVarPos, max_var_pos=h.maxVarPos,
+                          short_hap=bytes(h.shortHaplotypeSequence).decode(), short_ref=bytes(h.shortReferenceSequence).decode()))
+    with gzip.open(os.path.join(out, "hapseq_cases.json.gz"), "wt") as f:
+        json.dump(cases, f)
+    print("hapseq: %d haplotypes" % len(cases))
+
+
 def gen_population(out):
     """a11/a12 + SURVEY 8(f) rank 1: per-read log-likelihood arrays -> genotype log-likelihoods (calculateDataLikelihood),
     rescaled likelihoods (the loop at cpopulation.pyx:283-309, mirrored here around the compiled method), EM haplotype
@@ -1072,7 +1158,7 @@ def main():
         sys.exit("reference tree not found at %s: golden vectors can only be regenerated in the build container" % REF)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     build_scratch(a.scratch)
-    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter"]
+    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq"]
     if "dp" in todo:
         gen_dp(HERE)
     if "mapalign" in todo:
@@ -1085,6 +1171,8 @@ def main():
         gen_haplotype(HERE)
     if "filter" in todo:
         gen_filter(HERE)
+    if "hapseq" in todo:
+        gen_hapseq(HERE)
 
 
 if __name__ == "__main__":

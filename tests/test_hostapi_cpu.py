@@ -99,3 +99,19 @@ def test_mergeHaplotypes_keeps_the_better_prior():
     assert len(merged) == 3
     assert [m.variants for m in merged if m == h1] == [(d2,)]                 # 3e-4 beats 1e-4
     assert [m.haplotypeSequence for m in merged] == sorted(m.haplotypeSequence for m in merged)
+
+
+def test_haplotype_sequence_construction_matches_reference_golden(golden_dir):
+    """chaplotype.pyx:127-175,386-449 (constructor + getMutatedSequence): SNPs, MNPs, insertions, deletions, replacements,
+    adjacent variants, windows clamped at either end of the contig."""
+    import gzip, json, os
+    from platypus_amd import hostapi as H
+    cases = json.load(gzip.open(os.path.join(golden_dir, "hapseq_cases.json.gz"), "rt"))
+    assert len(cases) > 100
+    for c in cases:
+        fasta = H.FastaFile({"20": c["ref"].encode()})
+        vs = tuple(H.Variant("20", v["pos"], v["removed"].encode(), v["added"].encode()) for v in c["variants"])
+        h = H.Haplotype("20", c["start"], c["end"], vs, fasta, c["rlen"])
+        assert h.haplotypeSequence == c["haplotype"].encode(), c["variants"]
+        assert (h.startPos, h.endPos, h.endBufferSize) == (c["start_pos"], c["end_pos"], c["end_buffer"])
+        assert (h.minVarPos, h.maxVarPos) == (c["min_var_pos"], c["max_var_pos"])
