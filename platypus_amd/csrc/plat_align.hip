@@ -159,7 +159,8 @@ constexpr int PREP_LMAX = 448;          // reads up to this length are staged th
 __global__ void __launch_bounds__(256)
 k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const long long* __restrict__ tile_off,
              uint32_t* __restrict__ tile, uint16_t* __restrict__ codes, ReadInfo* __restrict__ rinfo, long long* cnt, int qoff)
-// qoff = byte offset of the quality image in the dynamic LDS (= 64 * min(longest read, PREP_LMAX) + 16).
+// qoff = byte offset of the quality image in the dynamic LDS (= 64 * min(longest read, PREP_LMAX) + 16); the bit-plane
+// accumulators of staged windows follow at 2 * qoff (1 KB per 64-base chunk).
 // `codes` holds, per window and in the tile's footprint (2 bytes per tile element), the reads' 2-bit base codes
 // (calign.pyx:69-74 coding: A=1 C=3 G=2 T=0, N=2) as two BIT PLANES, 64 bases per 64-bit word, transposed (see below).
 // A 7-mer code (a5, hashReadForMapping calign.pyx:155-165) is 7 consecutive bits of plane 0 and 7 of plane 1; only
@@ -210,6 +211,10 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     }
     if (tid < 2) s_dirty[tid] = 0u;
     if (tid < 64) s_qsum[tid] = 0u;
+    unsigned* s_pl = (unsigned*)(psm + 2 * qoff);        // [chunk][plane][half][64 reads] bit-plane accumulators (staged windows)
+    const int nchunks = (rows - 8 + 63) >> 6;
+    if (staged)
+        for (int i = tid; i < nchunks * 256; i += nthr) s_pl[i] = 0u;
     ReadInfo my_ri = ReadInfo{0u, 0u, 0, 0u};            // loaded now, stored at the end together with the "dirty" bit
     if (tid < nr) {
         const int wstart = b.win_start[w], wend = b.win_end[w];
@@ -240,7 +245,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             const int o = s_off[rl], L = s_off[rl + 1] - o;
             uint32_t* tp = tile + toff + (long long)(4 * g) * R + c0 + rl;
             bool dirty = false;
-            unsigned qs = 0;
+            unsigned qs = 0, n0 = 0, n1 = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = 4 * g + j;
@@ -249,6 +254,9 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
                     const unsigned ch = staged ? lseq[o + i] : gs[o + i];
                     const unsigned ql = staged ? lqual[o + i] : gq[o + i];
                     qs += ql;
+                    const unsigned b2 = base2(ch);
+                    n0 |= (b2 & 1u) << j;
+                    n1 |= (b2 >> 1) << j;
                     wd = read_word(ch, ql);
                     const unsigned dch = ch - 65u;                               // 'A' 'C' 'G' 'T' = 65 + {0, 2, 6, 19}
                     dirty |= dch > 19u || !((0x80045u >> dch) & 1u);
@@ -257,34 +265,39 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             }
             if (dirty) atomicOr(&s_dirty[rl >> 5], 1u << (rl & 31));
             if (qs) atomicAdd(&s_qsum[rl], qs);
+            if (staged && 4 * g < rows - 8) {               // the 4 bases of this thread: 4 bits of each plane, inside one 32-bit half
+                const int c = (4 * g) >> 6, half = ((4 * g) >> 5) & 1, sh = (4 * g) & 31;
+                if (n0) atomicOr(&s_pl[((c * 2 + 0) * 2 + half) * 64 + rl], n0 << sh);
+                if (n1) atomicOr(&s_pl[((c * 2 + 1) * 2 + half) * 64 + rl], n1 << sh);
+            }
         }
     }
     // bit planes: for every read and every chunk c of 64 bases, plane0 = bit 0 and plane1 = bit 1 of the 2-bit base code,
-    // one bit per base (ballot over the 64 lanes); word (2c+plane) of read rl at rd2[(2c+plane)*R + rl]
+    // one bit per base; word (2c+plane) of read rl at rd2[(2c+plane)*R + rl].  Staged windows: the tile loop above has
+    // OR-ed every thread's 4 bits into LDS; otherwise (reads too long for the LDS image) ballots over the 64 lanes.
     unsigned long long* rd2 = (unsigned long long*)(codes + toff);
-    const int nchunks = (rows - 8 + 63) >> 6;
-    const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
-    for (int c = wv; c < nchunks; c += nwv) {            // one wave per chunk; lane rl keeps read rl's two words
-        unsigned long long my0 = 0, my1 = 0;
-        const int i = 64 * c + lane;
-        for (int rl0 = 0; rl0 < nr; rl0 += 4) {          // 4 reads per trip: their LDS round trips overlap
-            unsigned b2[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int rl = min(rl0 + k, nr - 1);
-                const int o = s_off[rl], L = s_off[rl + 1] - o;
-                b2[k] = 0;
-                if (i < L) b2[k] = base2(staged ? lseq[o + i] : gs[o + i]);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned long long m0 = __ballot(b2[k] & 1u), m1 = __ballot(b2[k] & 2u);
-                if (lane == rl0 + k) { my0 = m0; my1 = m1; }
-            }
+    if (staged) {
+        __syncthreads();
+        for (int e = tid; e < nchunks * 2 * nr; e += nthr) {
+            const int cp = e / nr, rl = e - cp * nr;      // cp = 2*chunk + plane
+            const unsigned long long lo = s_pl[(cp * 2 + 0) * 64 + rl], hi = s_pl[(cp * 2 + 1) * 64 + rl];
+            rd2[(long long)cp * R + c0 + rl] = lo | (hi << 32);
         }
-        if (lane < nr) {
-            rd2[(long long)(2 * c) * R + c0 + lane] = my0;
-            rd2[(long long)(2 * c + 1) * R + c0 + lane] = my1;
+    } else {
+        const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+        for (int c = wv; c < nchunks; c += nwv) {        // one wave per chunk; lane rl keeps read rl's two words
+            unsigned long long my0 = 0, my1 = 0;
+            const int i = 64 * c + lane;
+            for (int rl = 0; rl < nr; ++rl) {
+                const int o = s_off[rl], L = s_off[rl + 1] - o;
+                const unsigned b2 = i < L ? base2(gs[o + i]) : 0u;
+                const unsigned long long m0 = __ballot(b2 & 1u), m1 = __ballot(b2 & 2u);
+                if (lane == rl) { my0 = m0; my1 = m1; }
+            }
+            if (lane < nr) {
+                rd2[(long long)(2 * c) * R + c0 + lane] = my0;
+                rd2[(long long)(2 * c + 1) * R + c0 + lane] = my1;
+            }
         }
     }
     __syncthreads();
@@ -1293,7 +1306,7 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
     const int prep_groups = maxR > 0 ? (maxR + 63) / 64 : 1;
     // LDS image of a group of 64 reads, sized by the batch's longest read: occupancy of this kernel is LDS-limited
     const int prep_qoff = 64 * ((std::min(maxread, PREP_LMAX) + 3) & ~3) + 16;
-    const size_t prep_lds = (size_t)2 * prep_qoff;
+    const size_t prep_lds = (size_t)2 * prep_qoff + (size_t)((std::min(maxread, PREP_LMAX) + 63) >> 6) * 1024;
     if (prep_lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_reads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
     hipLaunchKernelGGL(k_prep_reads, dim3(b.n_windows, prep_groups), dim3(256), prep_lds, st, b, win_rows, tile_off, (uint32_t*)ctx->tile.ptr,
