@@ -207,13 +207,21 @@ def main():
         ms_step = 1e3 * T / a.steps
         dp_avg = float(np.mean(dp_ms))
         achieved = prof.dp_alg_bytes / (dp_avg * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "dp_traffic.json")      # HBM bytes/launch from rocprofv3 --pmc (see profiles/README.md)
+        traffic, valu = None, None
+        tf = os.path.join(ROOT, "profiles", "dp_traffic.json")      # per-launch PMC figures from rocprofv3 --pmc (see profiles/README.md)
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                pm = json.load(open(tf))
+                traffic = pm.get("hbm_bytes_per_launch")
+                if pm.get("valu_insts_per_launch") and pm.get("busy_cycles_per_launch"):
+                    # what actually bounds the kernel (SURVEY 8(d) "secondary"): wave-instructions issued per SIMD-cycle.
+                    # A half-rate packed op (v_pk_*, v_alignbit, v_perm: 85 % of this kernel's mix) takes ~4.2 cycles.
+                    cpi = pm["busy_cycles_per_launch"] * 1024.0 / pm["valu_insts_per_launch"]
+                    valu = {"bound": "valu-issue", "insts_per_launch": pm["valu_insts_per_launch"],
+                            "busy_cycles_per_launch": pm["busy_cycles_per_launch"], "simds": 1024,
+                            "cycles_per_inst_per_simd": cpi, "frac_of_half_rate_issue_peak": 4.2 / cpi}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         line = {
             "metric": "pair-HMM GCUPS (reference-equivalent band cells/s, read->haplotype likelihood path)",
             "value": cells_ref / T / 1e9,
@@ -235,7 +243,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_dp_jobs", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(prof.dp_alg_bytes), "avg_launch_ms": dp_avg,
-                         "note": "recurrence is VALU-issue bound (packed int16), not HBM bound: see DESIGN.md"},
+                         "note": "recurrence is VALU-issue bound (packed int16), not HBM bound: see DESIGN.md",
+                         "secondary": valu},
         }
         line["record_gather"] = gather
         if world == 1 and not a.no_cpu_baseline:
