@@ -72,6 +72,8 @@ class Oracle:
         L.orc_variant_posterior.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
         L.orc_genotype_call.restype = None
         L.orc_genotype_call.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8
+        L.orc_variant_candidates.restype = C.c_int
+        L.orc_variant_candidates.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p, C.c_int]
         L.orc_genotype_loglik.restype = C.c_double
         L.orc_genotype_loglik.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -222,6 +224,35 @@ class Oracle:
         self.lib.orc_genotype_call(nHap, nVar, n_individuals, freq.ctypes.data, gl_row.ctypes.data, gof_row.ctypes.data,
                                    vih.ctypes.data, ir.ctypes.data, ph.ctypes.data, lik.ctypes.data, out4.ctypes.data)
         return ph, lik, out4
+
+    # -- VariantCandidateGenerator -----------------------------------------------
+    def variant_candidates(self, ref, ref_seq_start, contig_len, reads, min_flank=10, min_base_qual=20, gen_snps=1, gen_indels=1):
+        """reads: list of dicts {seq, qual (bytes), pos, flag, cigar [(op, len), ...]}.  Returns the per-occurrence records
+        [(pos, removed, added, read index)] in the reference's emission order."""
+        seqs = [r["seq"] for r in reads]
+        off = np.concatenate([[0], np.cumsum([len(x) for x in seqs])]).astype(np.int64)
+        sb = b"".join(seqs) + b"\0"
+        qb = b"".join(r["qual"] for r in reads) + b"\0"
+        pos = np.array([r["pos"] for r in reads], dtype=np.int32)
+        flags = np.array([r["flag"] for r in reads], dtype=np.int32)
+        cig = np.array([x for r in reads for c in r["cigar"] for x in c] + [0, 0], dtype=np.int16)
+        coff = np.concatenate([[0], np.cumsum([len(r["cigar"]) for r in reads])]).astype(np.int32)
+        cap = 64 * max(1, len(reads))
+        while True:
+            rec = np.zeros((cap, 6), dtype=np.int32)
+            n = self.lib.orc_variant_candidates(bytes(ref), len(ref), ref_seq_start, contig_len, len(reads), sb, qb,
+                                                off.ctypes.data, pos.ctypes.data, flags.ctypes.data, cig.ctypes.data,
+                                                coff.ctypes.data, min_flank, min_base_qual, gen_snps, gen_indels,
+                                                rec.ctypes.data, cap)
+            if n != -1:
+                break
+            cap *= 4
+        if n < 0:
+            raise RuntimeError("orc_variant_candidates: %d" % n)
+        out = []
+        for p, nrem, nadd, ro, ao, ri in rec[:n].tolist():
+            out.append((p, bytes(ref[ro:ro + nrem]) if nrem else b"", sb[ao:ao + nadd] if nadd else b"", ri))
+        return out
 
     # -- a14..a18 ------------------------------------------------------------------------------
     def assemble(self, ref, ref_start, assem_start, assem_end, seqs, quals, k=15, min_qual=20,

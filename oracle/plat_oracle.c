@@ -703,6 +703,113 @@ ORC_API void orc_genotype_call(int nHap, int nVar, int nIndividuals, const doubl
 }
 
 /* ------------------------------------------------------------------------------------------
+ * VariantCandidateGenerator (src/cython/variant.pyx:459-751) -- variant candidates
+ * from the CIGARs and mismatches of a set of reads.  One record per candidate occurrence, in the
+ * reference's emission order; merging equal variants (addVariantToList, :510-527) is left to the
+ * caller.  ref = contig[refSeqStart .. refSeqStart+refLen), contigLen = FastaFile SeqLength.
+ * cigar: (op,len) int16 pairs per read, cig_off[r] .. cig_off[r+1] pairs.
+ * rec: 6 ints per record {pos, nRemoved, nAdded, removed offset in ref (or -1), added offset in the
+ * read blob (or -1), read index}.  Returns the number of records, or -1 if maxRec was too small, or -2
+ * if a deletion reaches outside the reference window that was handed over.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int* rec; int n, max, err; } CandOut;
+
+static void cand_emit(CandOut* o, int pos, int nrem, int nadd, int remOff, int addOff, int read) {
+    if (o->n >= o->max) { o->err = -1; return; }
+    int* r = o->rec + 6 * (size_t)o->n++;
+    r[0] = pos < 0 ? 0 : pos;                                          /* Variant.__init__: max(0, refPos), variant.pyx:118 */
+    r[1] = nrem; r[2] = nadd; r[3] = remOff; r[4] = addOff; r[5] = read;
+}
+
+/* getSnpCandidatesFromReadSegment, variant.pyx:529-612 */
+static void cand_snps(CandOut* o, const char* refSeq, int refSeqStart, const char* readSeq, const char* readQual,
+                      long long seqBlobOff, int rlen, int readStart, int readOffset, int refOffset, int lenSeqToCheck,
+                      int minFlank, int minBaseQual, int read)
+{
+    int msr = -1, mer = -1, msd = -1, med = -1;       /* misMatchStartRef/EndRef/StartRead/EndRead */
+    for (int index = 0; index < lenSeqToCheck; ++index) {
+        if (readOffset == 0 && index < minFlank) continue;
+        if (index + readOffset >= rlen - minFlank) continue;
+        const int readIndex = index + readOffset;
+        const int refIndex = (index + refOffset + readStart) - refSeqStart;
+        const char readChar = readSeq[readIndex], refChar = refSeq[refIndex];
+        const int baseQual = readQual[readIndex];
+        if (readChar != refChar) {
+            if (readChar != 'N' && refChar != 'N' && baseQual >= minBaseQual) {
+                if (msr == -1) { msr = mer = refIndex; msd = med = readIndex; }
+                else if (refIndex - mer <= minFlank) { mer = refIndex; med = readIndex; }
+                else {
+                    cand_emit(o, msr + refSeqStart, mer - msr + 1, med - msd + 1, msr, (int)(seqBlobOff + msd), read);
+                    msr = mer = refIndex; msd = med = readIndex;
+                }
+            }
+        } else if (msr != -1 && refIndex - mer > minFlank) {
+            cand_emit(o, msr + refSeqStart, mer - msr + 1, med - msd + 1, msr, (int)(seqBlobOff + msd), read);
+            msr = mer = msd = med = -1;
+        }
+    }
+    if (msr != -1) cand_emit(o, msr + refSeqStart, mer - msr + 1, med - msd + 1, msr, (int)(seqBlobOff + msd), read);
+}
+
+static int count_n(const char* s, int n) { int c = 0; for (int i = 0; i < n; ++i) c += s[i] == 'N'; return c; }
+
+ORC_API int orc_variant_candidates(const char* ref, int refLen, int refSeqStart, int contigLen,
+                                   int nReads, const char* seq, const char* qual, const long long* read_off,
+                                   const int* pos, const int* flags, const short* cigar, const int* cig_off,
+                                   int minFlank, int minBaseQual, int genSNPs, int genIndels,
+                                   int* rec, int maxRec)
+{
+    CandOut o = { rec, 0, maxRec, 0 };
+    for (int r = 0; r < nReads; ++r) {                                 /* addCandidatesFromReads, :722-743 */
+        if (flags[r] & 512) continue;                                  /* Read_IsQCFail */
+        const char* readSeq = seq + read_off[r];
+        const char* readQual = qual + read_off[r];
+        const int rlen = (int)(read_off[r + 1] - read_off[r]);
+        const int readStart = pos[r];
+        const short* ops = cigar + 2 * (size_t)cig_off[r];
+        const int cigarLength = cig_off[r + 1] - cig_off[r];
+        int refOffset = 0, readOffset = 0;
+        for (int ci = 0; ci < cigarLength; ++ci) {                     /* getVariantCandidatesFromSingleRead, :614-720 */
+            const int flag = ops[2 * ci], length = ops[2 * ci + 1];
+            if (flag == 1 || flag == 2) {                              /* insertion / deletion */
+                int flanked = 0;
+                if (ci > 0 && ops[2 * ci - 2] == 0 && ops[2 * ci - 1] >= minFlank) flanked = 1;
+                else if (ci < cigarLength - 1 && ops[2 * ci + 2] == 0 && ops[2 * ci + 3] >= minFlank) flanked = 1;
+                if (flag == 1) {
+                    if (flanked && count_n(readSeq + readOffset, length) == 0 && genIndels)
+                        cand_emit(&o, readStart + refOffset - 1, 0, length, -1, (int)(read_off[r] + readOffset), r);
+                    readOffset += length;
+                } else {
+                    if (flanked) {
+                        /* refFile.getSequence(rname, a, a+length): clamped to [0, contigLen-1], fastafile.pyx:186-187 */
+                        int a = readStart + refOffset, b = a + length;
+                        if (a < 0) a = 0;
+                        if (b > contigLen - 1) b = contigLen - 1;
+                        const int n = b > a ? b - a : 0;
+                        if (a - refSeqStart < 0 || a - refSeqStart + n > refLen) o.err = -2;
+                        else if (count_n(ref + (a - refSeqStart), n) == 0 && genIndels)
+                            cand_emit(&o, readStart + refOffset - 1, n, 0, a - refSeqStart, -1, r);
+                    }
+                    refOffset += length;
+                }
+            } else if (flag == 0 || flag == 7 || flag == 8) {          /* M, =, X */
+                if (!(flag == 7 || (length < minFlank && flag == 0)) && genSNPs)
+                    cand_snps(&o, ref, refSeqStart, readSeq, readQual, read_off[r], rlen, readStart, readOffset, refOffset,
+                              length, minFlank, minBaseQual, r);
+                readOffset += length;
+                refOffset += length;
+            } else if (flag == 3) {                                    /* N: skipped reference */
+                refOffset += length;
+            } else if (flag == 4) {                                    /* soft clip */
+                readOffset += length;
+                if (ci == 0) refOffset += length;
+            }                                                          /* H, P, others: nothing */
+        }
+    }
+    return o.err ? o.err : o.n;
+}
+
+/* ------------------------------------------------------------------------------------------
  * a14-a18: coloured de-Bruijn assembler  (src/cython/assembler.pyx:73-1476)
  * ------------------------------------------------------------------------------------------ */
 #define COL_REF 1

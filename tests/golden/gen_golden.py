@@ -391,25 +391,35 @@ cdef class bamReadBuffer:
     cdef ReadArray badReads
     cdef ReadArray brokenMates
 
+cdef int PLATYPUS_VAR = 1
+cdef inline int Read_IsCompressed(cAlignedRead* theRead) nogil:      # (compressed reads are not part of the fixtures)
+    return 0
+cdef void compressRead(cAlignedRead* read, char* refSeq, int refStart, int refEnd, int qualBinSize, int fullComp):
+    pass
+cdef void uncompressRead(cAlignedRead* read, char* refSeq, int refStart, int refEnd, int qualBinSize):
+    pass
+
 cdef class Options:
     cdef public int calculateFlankScore, originalMaxHaplotypes, maxHaplotypes, rlen, verbosity, coverageSamplingLevel
-    cdef public int filterVarsByCoverage, maxVariants
+    cdef public int filterVarsByCoverage, maxVariants, qualBinSize
     def __init__(self, int calculateFlankScore, int maxHaplotypes=50, int rlen=150, int coverageSamplingLevel=30,
                  int filterVarsByCoverage=1, int maxVariants=8):
         self.calculateFlankScore = calculateFlankScore
         self.originalMaxHaplotypes = self.maxHaplotypes = maxHaplotypes
         self.rlen, self.verbosity, self.coverageSamplingLevel = rlen, 0, coverageSamplingLevel
         self.filterVarsByCoverage, self.maxVariants = filterVarsByCoverage, maxVariants
+        self.qualBinSize = 1
 """
 
 VAR_CLASS = r"""
 cdef class Variant:
     cdef public bytes refName, added, removed
-    cdef public int refPos, nAdded, nRemoved, minRefPos, maxRefPos, varType, nSupportingReads, varSource, idx
+    cdef public int refPos, nAdded, nRemoved, minRefPos, maxRefPos, varType, nSupportingReads, varSource, idx, bamMinPos, bamMaxPos
     cdef public long hashValue
-    def __init__(self, bytes refName, int refPos, bytes removed, bytes added, int nSupportingReads, int varSource, int idx=-1):
-        # variant.pyx:109-144
+    def __init__(self, bytes refName, int refPos, char* removed, char* added, int nSupportingReads, int varSource, int idx=-1):
+        # variant.pyx:109-144 (char* parameters as in the reference: its callers pass '' literals)
         refPos = max(0, refPos)
+        self.bamMinPos = self.bamMaxPos = refPos
         self.refName, self.refPos, self.removed, self.added = refName, refPos, removed, added
         self.nAdded, self.nRemoved = len(added), len(removed)
         self.nSupportingReads, self.varSource, self.hashValue, self.idx = nSupportingReads, varSource, -1, idx
@@ -442,6 +452,31 @@ cdef class DiploidGenotype:
     def __init__(self, Haplotype hap1, Haplotype hap2):
         self.hap1 = hap1
         self.hap2 = hap2
+"""
+
+CAND_TAIL = r"""
+def variant_candidates(bytes chrom, int start, int end, FastaFile refFile, list reads, int minFlank, int minBaseQual, int genSNPs, int genIndels):
+    # reads: (seq, qual, pos, bitFlag, [(op, len), ...]); returns the candidates in getCandidates() order and in insertion order
+    cdef VariantCandidateGenerator g = VariantCandidateGenerator((chrom, start, end), refFile, 20, minFlank, minBaseQual, 5000000, 150, Options(0), 0, genSNPs, genIndels)
+    cdef int n = len(reads), i, k
+    cdef cAlignedRead** arr = <cAlignedRead**>calloc(n + 1, sizeof(cAlignedRead*))
+    keep = []
+    for i, t in enumerate(reads):
+        keep.append(t)
+        arr[i] = make_read(t[0], t[1], t[2], t[2] + len(t[0]), 60, t[3])
+        arr[i].cigarLen = len(t[4])
+        arr[i].cigarOps = <short*>calloc(2 * len(t[4]) + 2, sizeof(short))
+        for k, (op, ln) in enumerate(t[4]):
+            arr[i].cigarOps[2 * k] = op
+            arr[i].cigarOps[2 * k + 1] = ln
+    g.addCandidatesFromReads(arr, arr + n)
+    srt = [(v.refPos, v.removed, v.added, v.nSupportingReads) for v in g.getCandidates(0)]
+    ins = [(v.refPos, v.removed, v.added, v.nSupportingReads) for v in g.variantHeap.values()]
+    for i in range(n):
+        free(arr[i].cigarOps)
+        free(arr[i])
+    free(arr)
+    return srt, ins
 """
 
 FILT_TAIL = r"""
@@ -561,7 +596,8 @@ exts = [Extension("calign", ["calign.pyx", "align.c"], include_dirs=["."]),
         Extension("pop_drv", ["pop_drv.pyx"]),
         Extension("hap_drv", ["hap_drv.pyx"], include_dirs=["."])]
 setup(ext_modules=cythonize(exts, language_level=2,
-      compiler_directives=dict(cdivision=True, cpow=True, legacy_implicit_noexcept=True)))
+      compiler_directives=dict(cdivision=True, cpow=True, legacy_implicit_noexcept=True,
+                               c_string_type='bytes', c_string_encoding='ascii')))
 '''
 
 
@@ -620,14 +656,24 @@ def build_scratch(scratch):
     utl = open(os.path.join(src, "cython/platypusutils.pyx")).read().split("\n")
     vfl = open(os.path.join(src, "cython/variantFilter.pyx")).read().split("\n")
     assert var[269].lstrip().startswith("def __hash__") and var[281].lstrip().startswith("def __richcmp__") and var[364].lstrip().startswith("def __str__")
+    # + SURVEY 8(f) rank 4: VariantCandidateGenerator (variant.pyx:463-751, attribute declarations variant.pxd:45-73) and
+    # Variant.addVariant (variant.pyx:261-268)
+    vpx = open(os.path.join(src, "cython/variant.pxd")).read().split("\n")
+    assert vpx[43].startswith("cdef class VariantCandidateGenerator") and vpx[72].lstrip().startswith("cdef int qualBinSize")
+    assert var[458].startswith("cdef class VariantCandidateGenerator") and var[462].lstrip().startswith("def __init__(self, tuple region")
+    assert var[746].lstrip().startswith("cdef list getCandidates") and var[260].lstrip().startswith("cdef void addVariant")
+    # (Python-2-only expressions adapted: bytes.count('N') at variant.pyx:652,672 -> count(b'N'))
+    assert "insertedSequence.count('N')" in var[651] and 'deletedSequence.count("N")' in var[671]
     assert utl[734].startswith("cdef int isHaplotypeValid") and vfl[236].startswith("cdef double computeBestScoreForGenotype")
     assert vfl[376].startswith("cdef list getFilteredHaplotypes") and vfl[507].startswith("#####") and vfl[282].lstrip().startswith("return bestScoreThisHap")
     drv = (HAP_HEAD + mltot + "\n" + chp[63] + "\n" + homopol + "\n\n" + VAR_CLASS + "\n" + "\n".join(var[269:280]) + "\n\n"
-           + "\n".join(var[281:363]) + "\n\n" + "\n".join(chp[102:115]) + "\n"
+           + "\n".join(var[281:363]) + "\n\n" + "\n".join(var[260:268]) + "\n\n" + "\n".join(chp[102:115]) + "\n"
            + HAP_CLASS + "\n" + "\n".join(chp[305:384]) + "\n\n" + "\n".join(chp[551:590]) + "\n\n"
            + "\n".join(chp[593:676]) + "\n" + HAPSEQ_CLASS + "\n".join(chp[126:175]) + "\n\n" + "\n".join(chp[385:395]) + "\n\n"
            + "\n".join(chp[396:449]).replace("bytes(''.join(bitsOfMutatedSeq))", "b''.join(bitsOfMutatedSeq)") + "\n" + GENO2_CLASS + "\n" + "\n".join(utl[734:802]) + "\n\n" + "\n".join(vfl[236:283]) + "\n\n"
-           + "\n".join(vfl[376:506]) + "\n" + HAP_TAIL + FILT_TAIL)
+           + "\n".join(vfl[376:506]) + "\n"
+           + "cdef class VariantCandidateGenerator:\n" + "\n".join(vpx[44:73]) + "\n" + "\n".join(var[462:751]).replace("insertedSequence.count('N')", "insertedSequence.count(b'N')").replace('deletedSequence.count("N")', "deletedSequence.count(b'N')") + "\n"
+           + HAP_TAIL + FILT_TAIL + CAND_TAIL)
     open(os.path.join(scratch, "hap_drv.pyx"), "w").write(drv)
     open(os.path.join(scratch, "setup.py"), "w").write(SETUP)
     r = subprocess.run([sys.executable, "setup.py", "build_ext", "--inplace"], cwd=scratch,
@@ -1069,6 +1115,96 @@ def gen_hapseq(out):
     print("hapseq: %d haplotypes" % len(cases))
 
 
+def gen_candidates(out):
+    """VariantCandidateGenerator (variant.pyx:459-751): candidates from CIGARs and mismatches, merged
+    by Variant equality, in getCandidates() order and in first-seen order (what sorted() keeps for ties)."""
+    import hap_drv
+    rng = np.random.default_rng(8080)
+    cases = []
+    for ci in range(40):
+        n = 6000
+        ref = bytearray(rnd(rng, n))
+        if ci % 4 == 1:
+            for _ in range(3):
+                p_ = int(rng.integers(2100, 3900)); ref[p_:p_ + 4] = b"NNNN"
+        ref = bytes(ref)
+        start, end = 2200, 3800
+        fasta = hap_drv.FastaFile(None, {b"20": ref})
+        minFlank = int(rng.choice([10, 10, 3, 0]))
+        minBaseQual = int(rng.choice([20, 20, 5]))
+        # a donor: the reference with a few shared variants, so that candidates recur across reads
+        shared = sorted(set(int(x) for x in rng.integers(start, end, 25)))
+        reads = []
+        for r in range(int(rng.integers(60, 220))):
+            L = int(rng.choice([100, 150]))
+            p0 = int(rng.integers(start - 60, end - 40))
+            rp = p0                       # reference cursor
+            seq, cig = bytearray(), []
+            def push(op, ln):
+                if ln <= 0:
+                    return
+                if cig and cig[-1][0] == op and op in (0, 1, 2):
+                    cig[-1] = (op, cig[-1][1] + ln)
+                else:
+                    cig.append((op, ln))
+            if rng.random() < 0.15:
+                k = int(rng.integers(1, 12)); seq += rnd(rng, k); push(4, k)          # leading soft clip
+                if rng.random() < 0.3:
+                    cig.insert(0, (5, int(rng.integers(1, 9))))                       # hard clip before it
+            while len(seq) < L:
+                seg = int(rng.integers(1, 60)) if rng.random() < 0.3 else int(rng.integers(20, 120))
+                seg = min(seg, L - len(seq))
+                piece = bytearray(ref[rp:rp + seg])
+                for k in range(seg):
+                    if (rp + k) in shared and rng.random() < 0.8:
+                        piece[k] = B[(B.index(piece[k]) + 1) % 4] if piece[k] in B else ord("A")
+                    elif rng.random() < 0.01:
+                        piece[k] = B[int(rng.integers(0, 4))]
+                    elif rng.random() < 0.003:
+                        piece[k] = ord("N")
+                op = 0
+                t = rng.random()
+                if t < 0.04 and piece == bytearray(ref[rp:rp + seg]):
+                    op = 7                                                             # '=' segment
+                elif t < 0.06:
+                    op = 8                                                             # 'X' segment
+                if rng.random() < 0.1 and seg > 6:                                     # a run of adjacent mismatches (MNP)
+                    q_ = int(rng.integers(0, seg - 3))
+                    for k in range(q_, q_ + int(rng.integers(2, 4))):
+                        piece[k] = B[(B.index(piece[k]) + 2) % 4] if piece[k] in B else ord("C")
+                seq += piece; push(op, seg); rp += seg
+                if len(seq) >= L:
+                    break
+                t = rng.random()
+                if t < 0.25:
+                    k = min(int(rng.integers(1, 9)), L - len(seq))
+                    ins = rnd(rng, k) if rng.random() > 0.1 else b"N" * k
+                    seq += ins; push(1, k)
+                elif t < 0.5:
+                    k = int(rng.integers(1, 15)); push(2, k); rp += k
+                elif t < 0.55:
+                    k = int(rng.integers(20, 300)); push(3, k); rp += k                # skipped region
+                elif t < 0.6:
+                    push(6, int(rng.integers(1, 4)))                                   # padding
+            if rng.random() < 0.1:
+                k = int(rng.integers(1, 12)); seq += rnd(rng, k); push(4, k)           # trailing soft clip
+            q = np.clip(rng.normal(32, 9, len(seq)), 0, 93).astype(np.uint8)
+            flag = 3 | (512 if rng.random() < 0.04 else 0)
+            # BAM positions of soft-clipped reads are moved back by the clip (htslibWrapper.pyx:386-387), which is what the
+            # "refOffset += length" for a leading soft clip undoes
+            lead = cig[1][1] if (cig[0][0] == 5 and len(cig) > 1 and cig[1][0] == 4) else (cig[0][1] if cig[0][0] == 4 else 0)
+            reads.append(dict(seq=bytes(seq).decode(), qual=q.tolist(), pos=p0 - (lead if cig[0][0] == 4 else 0), flag=flag, cigar=[list(c) for c in cig]))
+        tup = [(r["seq"].encode(), bytes(r["qual"]), r["pos"], r["flag"], [tuple(c) for c in r["cigar"]]) for r in reads]
+        gs, gi = int(ci % 7 != 3), int(ci % 7 != 5)
+        srt, ins = hap_drv.variant_candidates(b"20", start, end, fasta, tup, minFlank, minBaseQual, gs, gi)
+        enc = lambda L_: [[p_, r.decode(), a.decode(), c] for p_, r, a, c in L_]
+        cases.append(dict(ref=ref.decode(), start=start, end=end, min_flank=minFlank, min_base_qual=minBaseQual, gen_snps=gs, gen_indels=gi,
+                          reads=reads, sorted=enc(srt), first_seen=enc(ins)))
+    with gzip.open(os.path.join(out, "candidate_cases.json.gz"), "wt") as f:
+        json.dump(cases, f)
+    print("candidates: %d regions, %d reads, %d distinct candidates" % (len(cases), sum(len(c["reads"]) for c in cases), sum(len(c["sorted"]) for c in cases)))
+
+
 def gen_population(out):
     """a11/a12 + SURVEY 8(f) rank 1: per-read log-likelihood arrays -> genotype log-likelihoods (calculateDataLikelihood),
     rescaled likelihoods (the loop at cpopulation.pyx:283-309, mirrored here around the compiled method), EM haplotype
@@ -1158,7 +1294,7 @@ def main():
         sys.exit("reference tree not found at %s: golden vectors can only be regenerated in the build container" % REF)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     build_scratch(a.scratch)
-    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq"]
+    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq", "candidates"]
     if "dp" in todo:
         gen_dp(HERE)
     if "mapalign" in todo:
@@ -1173,6 +1309,8 @@ def main():
         gen_filter(HERE)
     if "hapseq" in todo:
         gen_hapseq(HERE)
+    if "candidates" in todo:
+        gen_candidates(HERE)
 
 
 if __name__ == "__main__":

@@ -219,3 +219,43 @@ def test_likelihood_cache_matches_reference_golden(oracle, golden_dir):
             n += len(c["single"][hi])
         flank += c["calc_flank"]
     assert n > 3000 and flank > 10
+
+
+# ---- VariantCandidateGenerator, pinned by the reference's own text --------------------------------
+def merge_candidates(records):
+    """addVariantToList (variant.pyx:499-527): equal variants merge, supporting reads add up; dict order = first seen."""
+    heap = {}
+    for pos, rem, add, _ in records:
+        heap[(pos, rem, add)] = heap.get((pos, rem, add), 0) + 1
+    return [[p, r.decode(), a.decode(), c] for (p, r, a), c in heap.items()]
+
+
+def variant_sort_key(v):
+    """Variant.__richcmp__ ordering (variant.pyx:282-363): refPos, varType, nRemoved (refName is constant here)."""
+    pos, rem, add, _ = v
+    if len(rem) == len(add):
+        vt = 0 if len(add) == 1 else 1
+    elif len(rem) == 0:
+        vt = 2
+    elif len(add) == 0:
+        vt = 3
+    else:
+        vt = 4
+    return (pos, vt, len(rem))
+
+
+def test_variant_candidates_match_reference_golden(oracle, golden_dir):
+    import gzip, json
+    cases = json.load(gzip.open(os.path.join(golden_dir, "candidate_cases.json.gz"), "rt"))
+    n = 0
+    for c in cases:
+        ref = c["ref"].encode()
+        rs = max(0, c["start"] - 2000)
+        re_ = min(c["end"] + 2000, len(ref) - 1)                               # variant.pyx:486-488
+        reads = [dict(seq=r["seq"].encode(), qual=bytes(r["qual"]), pos=r["pos"], flag=r["flag"], cigar=r["cigar"]) for r in c["reads"]]
+        recs = oracle.variant_candidates(ref[rs:re_], rs, len(ref), reads, c["min_flank"], c["min_base_qual"], c["gen_snps"], c["gen_indels"])
+        first_seen = merge_candidates(recs)
+        assert first_seen == c["first_seen"]
+        assert sorted(first_seen, key=variant_sort_key) == c["sorted"]          # sorted() is stable: ties keep first-seen order
+        n += len(first_seen)
+    assert n > 5000
