@@ -247,6 +247,40 @@ int plat_genotype_call_batch(plat_ctx* ctx, int n_sites, int n_ind, const int32_
                              const int64_t* lik_off, int32_t* out_phased, double* out_lik, double* out4,
                              void* stream);
 
+/* ---- VariantCandidateGenerator ------------------------------------------------
+ * Replaces  VariantCandidateGenerator.addCandidatesFromReads(readStart, readEnd)   variant.pyx:722-743
+ *           (getVariantCandidatesFromSingleRead :614-720, getSnpCandidatesFromReadSegment :529-612)
+ * for the reads of n_regions regions.  Region g: reference bytes ref_seq[ref_off[g]..ref_off[g+1]) =
+ * contig[ref_seq_start[g] ...) (the generator's cached pyRefSeq, region +- 2000, variant.pyx:486-489),
+ * contig_len[g] = FastaFile SeqLength (deletions read the contig through getSequence, which clamps to it);
+ * read r belongs to region read_region[r]: bases/qualities at read_off[r]..read_off[r+1], read_pos,
+ * read_flags (bitFlag: QCFail reads are skipped), CIGAR as (op, length) int16 pairs
+ * cigar[2*cig_off[r] .. 2*cig_off[r+1]).  Options: minFlank, minBaseQual, genSNPs, genIndels
+ * (runner.py: 10, 20, 1, 1).
+ * Output: read r owns records out_rec[5*(r*max_per_read + k)], k < out_count[r], in the reference's
+ * emission order: {refPos, nRemoved, nAdded, offset of the removed bases in ref_seq (or -1), offset of
+ * the added bases in read_seq (or -1)}.  out_status[r] = 0, PLAT_ERR_OVERFLOW (more than max_per_read;
+ * out_count[r] is the number needed) or PLAT_ERR_BAD_INPUT (the read reaches outside the reference
+ * window that was handed over).  Merging equal variants (addVariantToList :499-527) is left to the caller. */
+typedef struct plat_candidate_batch {
+    int32_t n_regions, n_reads;
+    const uint8_t* ref_seq;
+    const int64_t* ref_off;          /* [n_regions+1] */
+    const int32_t* ref_seq_start;    /* [n_regions] */
+    const int32_t* contig_len;       /* [n_regions] */
+    const uint8_t* read_seq;
+    const uint8_t* read_qual;
+    const int64_t* read_off;         /* [n_reads+1] */
+    const int32_t* read_pos;         /* [n_reads] */
+    const int32_t* read_flags;       /* [n_reads] */
+    const int16_t* cigar;            /* (op, len) pairs */
+    const int32_t* cig_off;          /* [n_reads+1], in pairs */
+} plat_candidate_batch;
+
+int plat_candidates_batch(plat_ctx* ctx, const plat_candidate_batch* batch, int min_flank, int min_base_qual,
+                          int gen_snps, int gen_indels, int max_per_read, const int32_t* read_region,
+                          int32_t* out_rec, int32_t* out_count, int32_t* out_status, void* stream);
+
 /* ---- a14..a18: assembleReadsAndDetectVariants ---------------------------------------------------
  * Replaces  cdef list assembleReadsAndDetectVariants(chrom, assemStart, assemEnd, refStart, refEnd,
  *                                                    readBuffers, refSeq, options)

@@ -62,6 +62,13 @@ class AssemblyBatch(C.Structure):
                 ("read_off", C.c_void_p)]
 
 
+class CandidateBatch(C.Structure):
+    _fields_ = [("n_regions", C.c_int32), ("n_reads", C.c_int32), ("ref_seq", C.c_void_p), ("ref_off", C.c_void_p),
+                ("ref_seq_start", C.c_void_p), ("contig_len", C.c_void_p), ("read_seq", C.c_void_p),
+                ("read_qual", C.c_void_p), ("read_off", C.c_void_p), ("read_pos", C.c_void_p), ("read_flags", C.c_void_p),
+                ("cigar", C.c_void_p), ("cig_off", C.c_void_p)]
+
+
 # symbol -> (restype, argtypes): exactly the declarations of include/platypus_mi355x.h
 SIGNATURES = {
     "plat_abi_version": (C.c_int, []),
@@ -92,6 +99,8 @@ SIGNATURES = {
                                        C.c_void_p]),
     "plat_variant_posterior_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 11),
     "plat_genotype_call_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 16),
+    "plat_candidates_batch": (C.c_int, [C.c_void_p, C.POINTER(CandidateBatch), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_assemble_batch": (C.c_int, [C.c_void_p, C.POINTER(AssemblyBatch), C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),

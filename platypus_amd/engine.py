@@ -248,6 +248,65 @@ class Engine:
         ph, lik, out4 = ph.cpu().numpy().reshape(nS, hb.n_ind, 2), lik.cpu().numpy(), out4.cpu().numpy().reshape(nS, hb.n_ind, 4)
         return [(ph[s], lik[lik_off[s]:lik_off[s + 1]].reshape(hb.n_ind, int(NL[s])), out4[s]) for s in range(nS)]
 
+    # ---- VariantCandidateGenerator ------------------------------------------------------
+    def candidates(self, regions, min_flank=10, min_base_qual=20, gen_snps=1, gen_indels=1, max_per_read=64):
+        """VariantCandidateGenerator.addCandidatesFromReads for a list of regions.
+
+        `regions`: list of dicts {ref: bytes (contig[ref_seq_start:...]), ref_seq_start, contig_len, reads: [dict(seq, qual,
+        pos, flag, cigar [(op, len), ...])]}.  Returns per region the per-occurrence records [(refPos, removed, added,
+        read index)] in the reference's emission order (merging equal variants is the caller's dictionary step)."""
+        torch = _torch()
+        nG = len(regions)
+        reads = [r for g in regions for r in g["reads"]]
+        nR = len(reads)
+        if nR == 0:
+            return [[] for _ in regions]
+
+        def dev(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.device)
+        ref_blob = b"".join(bytes(g["ref"]) for g in regions)
+        ref_off = np.concatenate([[0], np.cumsum([len(g["ref"]) for g in regions])]).astype(np.int64)
+        seq_blob = b"".join(r["seq"] for r in reads)
+        qual_blob = b"".join(r["qual"] for r in reads)
+        read_off = np.concatenate([[0], np.cumsum([len(r["seq"]) for r in reads])]).astype(np.int64)
+        cig = np.array([x for r in reads for c in r["cigar"] for x in c] + [0, 0], dtype=np.int16)
+        cig_off = np.concatenate([[0], np.cumsum([len(r["cigar"]) for r in reads])]).astype(np.int32)
+        region_of = np.repeat(np.arange(nG, dtype=np.int32), [len(g["reads"]) for g in regions])
+        t = dict(ref=dev(pad_blob(np.frombuffer(ref_blob, dtype=np.uint8)), np.uint8), ref_off=dev(ref_off, np.int64),
+                 rss=dev([g["ref_seq_start"] for g in regions], np.int32), clen=dev([g["contig_len"] for g in regions], np.int32),
+                 seq=dev(pad_blob(np.frombuffer(seq_blob, dtype=np.uint8)), np.uint8),
+                 qual=dev(pad_blob(np.frombuffer(qual_blob, dtype=np.uint8)), np.uint8), read_off=dev(read_off, np.int64),
+                 pos=dev([r["pos"] for r in reads], np.int32), flags=dev([r["flag"] for r in reads], np.int32),
+                 cig=dev(cig, np.int16), cig_off=dev(cig_off, np.int32), region_of=dev(region_of, np.int32))
+        b = _lib.CandidateBatch()
+        b.n_regions, b.n_reads = nG, nR
+        b.ref_seq, b.ref_off, b.ref_seq_start, b.contig_len = t["ref"].data_ptr(), t["ref_off"].data_ptr(), t["rss"].data_ptr(), t["clen"].data_ptr()
+        b.read_seq, b.read_qual, b.read_off = t["seq"].data_ptr(), t["qual"].data_ptr(), t["read_off"].data_ptr()
+        b.read_pos, b.read_flags, b.cigar, b.cig_off = t["pos"].data_ptr(), t["flags"].data_ptr(), t["cig"].data_ptr(), t["cig_off"].data_ptr()
+        while True:
+            rec = torch.empty(nR * max_per_read * 5, dtype=torch.int32, device=self.device)
+            cnt = torch.empty(nR, dtype=torch.int32, device=self.device)
+            stt = torch.empty(nR, dtype=torch.int32, device=self.device)
+            rc = self.lib.plat_candidates_batch(self.ctx, C.byref(b), min_flank, min_base_qual, gen_snps, gen_indels, max_per_read,
+                                                t["region_of"].data_ptr(), rec.data_ptr(), cnt.data_ptr(), stt.data_ptr(), self._stream())
+            _lib.check(rc, "plat_candidates_batch")
+            torch.cuda.synchronize(self.device)
+            cnt_h, st_h = cnt.cpu().numpy(), stt.cpu().numpy()
+            if (st_h == -9).any():
+                raise _lib.PlatypusDeviceError(-9, "a read reaches outside the reference window handed over", "plat_candidates_batch")
+            if (st_h == -8).any():
+                max_per_read = int(cnt_h.max())            # a read with more candidates than the slice: rerun with room for it
+                continue
+            break
+        rec_h = rec.cpu().numpy().reshape(nR, max_per_read, 5)
+        out = [[] for _ in regions]
+        first = np.concatenate([[0], np.cumsum([len(g["reads"]) for g in regions])])
+        for r in np.nonzero(cnt_h)[0].tolist():
+            g = int(region_of[r])
+            for p_, nrem, nadd, ro, ao in rec_h[r, :cnt_h[r]].tolist():
+                out[g].append((p_, ref_blob[ro:ro + nrem] if nrem else b"", seq_blob[ao:ao + nadd] if nadd else b"", r - int(first[g])))
+        return out
+
     # ---- a14..a18 ------------------------------------------------------------------------------------
     def assemble(self, regions, kmer_size=15, min_qual=20, min_weight=40, no_cycles=0, max_vars=512,
                  blob_per_region=1 << 16):

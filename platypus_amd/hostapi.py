@@ -96,7 +96,7 @@ class Variant:
 class AlignedRead:
     """The fields of cAlignedRead the hot path reads (htslibWrapper.pxd:187-201).  qual is raw phred."""
 
-    def __init__(self, seq, qual, pos, mapq=60, bitFlag=3, end=None):
+    def __init__(self, seq, qual, pos, mapq=60, bitFlag=3, end=None, cigarOps=None):
         self.seq, self.qual = bytes(seq), bytes(qual)
         if len(self.seq) != len(self.qual):
             raise ValueError("seq and qual differ in length")
@@ -104,6 +104,7 @@ class AlignedRead:
         self.pos = int(pos)
         self.end = int(end) if end is not None else self.pos + self.rlen
         self.mapq, self.bitFlag = int(mapq), int(bitFlag)
+        self.cigarOps = [tuple(c) for c in cigarOps] if cigarOps is not None else [(0, self.rlen)]   # (op, len) pairs; default = one match
 
     def isQCFail(self):
         return (self.bitFlag & BAM_FQCFAIL) != 0
@@ -384,6 +385,39 @@ class Population:
         ph, lik, out4 = get_engine().genotype_calls(self._db, [dict(window=0, var_in_hap=vih, is_ref=haplotypeIsRefAtThisPos)])[0]
         i = sampleIndex
         return (int(ph[i][0]), int(ph[i][1]), lik[i].tolist(), float(out4[i][0]), float(out4[i][1]), float(out4[i][2]), float(out4[i][3]))
+
+# ---- variant candidates from the reads' CIGARs and mismatches ----------------------------------------
+class VariantCandidateGenerator:
+    """variant.pyx:459-751.  The per-read scan runs on the device (plat_candidates_batch); merging equal variants and
+    counting their supporting reads (addVariantToList, :499-527) is the dictionary step below."""
+
+    def __init__(self, region, referenceFile, minMapQual, minFlank, minBaseQual, maxCoverage, maxReadLength, options,
+                 verbosity=2, genSNPs=1, genIndels=1):
+        self.rname, self.rStart, self.rEnd = region
+        self.refFile = referenceFile
+        self.minFlank, self.minBaseQual, self.genSNPs, self.genIndels = minFlank, minBaseQual, genSNPs, genIndels
+        self.refSeqStart = max(0, region[1] - 2000)                                                  # :486
+        self.refSeqEnd = min(region[2] + 2000, referenceFile.refs[region[0]].SeqLength - 1)        # :487
+        self.pyRefSeq = referenceFile.getSequence(self.rname, self.refSeqStart, self.refSeqEnd)     # :488
+        self.variantHeap = {}
+
+    def addVariantToList(self, var):                                                                # :499-527
+        old = self.variantHeap.get(var)
+        if old is None:
+            self.variantHeap[var] = var
+        else:
+            old.nSupportingReads += var.nSupportingReads
+            old.varSource |= var.varSource
+
+    def addCandidatesFromReads(self, reads):                                                        # :722-743
+        rs = [dict(seq=r.seq, qual=r.qual, pos=r.pos, flag=r.bitFlag, cigar=r.cigarOps) for r in reads]
+        region = dict(ref=self.pyRefSeq, ref_seq_start=self.refSeqStart, contig_len=self.refFile.refs[self.rname].SeqLength, reads=rs)
+        for pos, removed, added, _ in get_engine().candidates([region], self.minFlank, self.minBaseQual, self.genSNPs, self.genIndels)[0]:
+            self.addVariantToList(Variant(self.rname, pos, removed, added, 1, PLATYPUS_VAR))
+
+    def getCandidates(self, minReads=0):                                                            # :747-751
+        return sorted(self.variantHeap.values())
+
 
 # ---- SURVEY 8(f) rank 2: haplotype enumeration and the greedy haplotype filter ------------------------------------------
 def isHaplotypeValid(variants):

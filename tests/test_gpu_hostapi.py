@@ -190,3 +190,21 @@ def test_cli_synthetic_run_writes_records(tmp_path):
     assert len(f[3].split(",")) == nh * (nh + 1) // 2 and len(f[4].split(",")) == nh and abs(sum(map(float, f[4].split(","))) - 1) < 1e-3
     r = subprocess.run([sys.executable, "-m", "platypus_amd", "callVariants", "--bamFiles", "x.bam"], capture_output=True, text=True)
     assert r.returncode != 0 and "outside this build's scope" in r.stderr
+
+
+def test_variant_candidates_match_reference_golden(golden_dir):
+    """VariantCandidateGenerator (variant.pyx:459-751) -- device scan + host merge against outputs of the
+    reference's own text: same candidates, same supporting-read counts, same getCandidates() order."""
+    import gzip, json, os
+    cases = json.load(gzip.open(os.path.join(golden_dir, "candidate_cases.json.gz"), "rt"))
+    n = 0
+    for c in cases:
+        fasta = H.FastaFile({"20": c["ref"].encode()})
+        reads = [H.AlignedRead(r["seq"].encode(), bytes(r["qual"]), r["pos"], bitFlag=r["flag"], cigarOps=r["cigar"]) for r in c["reads"]]
+        gen = H.VariantCandidateGenerator(("20", c["start"], c["end"]), fasta, 20, c["min_flank"], c["min_base_qual"], 5000000, 150,
+                                          None, 0, c["gen_snps"], c["gen_indels"])
+        gen.addCandidatesFromReads(reads)
+        got = [[v.refPos, v.removed.decode(), v.added.decode(), v.nSupportingReads] for v in gen.getCandidates(0)]
+        assert got == c["sorted"]
+        n += len(got)
+    assert n > 5000
