@@ -49,6 +49,25 @@ def main():
     eng.synchronize(); t = (time.perf_counter() - t0) / 5
     it = db.em_iters.cpu().numpy()
     out["config5_population"].update(em_ms=1e3 * t, em_iterations_mean=float(it.mean()), em_iterations_max=int(it.max()))
+    # ---- candidate generation from CIGARs: 400 regions x 400 reads x 150 bp
+    rng = np.random.default_rng(99)
+    Bs = np.frombuffer(b"ACGT", dtype=np.uint8)
+    regs = []
+    for g in range(400):
+        ref = Bs[rng.integers(0, 4, 6000)].tobytes()
+        reads = []
+        for r in range(400):
+            p0 = int(rng.integers(2000, 3800))
+            seq = bytearray(ref[p0:p0 + 70] + ref[p0 + 73:p0 + 153])           # a 3-bp deletion after 70 matched bases
+            for k in rng.integers(12, 138, 2):
+                seq[int(k)] = Bs[int(rng.integers(0, 4))]
+            reads.append(dict(seq=bytes(seq), qual=bytes([35] * 150), pos=p0, flag=3, cigar=[(0, 70), (2, 3), (0, 80)]))
+        regs.append(dict(ref=ref, ref_seq_start=0, contig_len=6000, reads=reads))
+    eng.candidates(regs[:4])
+    t0 = time.perf_counter()
+    res = eng.candidates(regs)
+    t = time.perf_counter() - t0
+    out["candidates"] = dict(regions=len(regs), reads=160000, records=sum(len(x) for x in res), reads_per_sec_incl_host_packing=160000 / t)
     print(json.dumps(out, indent=1))
 
 
