@@ -74,6 +74,8 @@ class Oracle:
         L.orc_genotype_call.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8
         L.orc_variant_candidates.restype = C.c_int
         L.orc_variant_candidates.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p, C.c_int]
+        L.orc_check_and_trim.restype = None
+        L.orc_check_and_trim.argtypes = [C.c_int] + [C.c_void_p] * 11 + [C.c_int] * 7 + [C.c_void_p] * 3
         L.orc_genotype_loglik.restype = C.c_double
         L.orc_genotype_loglik.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -253,6 +255,27 @@ class Oracle:
         for p, nrem, nadd, ro, ao, ri in rec[:n].tolist():
             out.append((p, bytes(ref[ro:ro + nrem]) if nrem else b"", sb[ao:ao + nadd] if nadd else b"", ri))
         return out
+
+    # -- read QC / trimming ---------------------------------------------------------------------------
+    def check_and_trim(self, reads, opt):
+        """reads: one stream, dicts {qual (list/bytes), pos, mapq, flag, chromID, mateChromID, insertSize, matePos, cigar}.
+        Returns (ok, flags_out, quals_out(list of lists), reason)."""
+        n = len(reads)
+        off = np.concatenate([[0], np.cumsum([len(r["qual"]) for r in reads])]).astype(np.int64)
+        qual = np.concatenate([np.asarray(r["qual"], dtype=np.int8) for r in reads] + [np.zeros(1, dtype=np.int8)])
+        arr = lambda k, dt: np.array([r[k] for r in reads], dtype=dt)
+        pos, mapq, flags = arr("pos", np.int32), arr("mapq", np.uint8), arr("flag", np.int32)
+        cid, mcid, ins, mpos = arr("chromID", np.int16), arr("mateChromID", np.int16), arr("insertSize", np.int32), arr("matePos", np.int32)
+        cig = np.array([x for r in reads for c in r["cigar"] for x in c] + [0, 0], dtype=np.int16)
+        coff = np.concatenate([[0], np.cumsum([len(r["cigar"]) for r in reads])]).astype(np.int32)
+        en = np.array(opt["enabled"], dtype=np.int32)
+        ok = np.zeros(n, dtype=np.int32); reason = np.zeros(n, dtype=np.int32)
+        self.lib.orc_check_and_trim(n, qual.ctypes.data, off.ctypes.data, pos.ctypes.data, mapq.ctypes.data, flags.ctypes.data,
+                                    cid.ctypes.data, mcid.ctypes.data, ins.ctypes.data, mpos.ctypes.data, cig.ctypes.data,
+                                    coff.ctypes.data, opt["minGoodQualBases"], opt["minMapQual"], opt["minBaseQual"],
+                                    opt["trimOverlapping"], opt["trimAdapter"], opt["trimReadFlank"], opt["trimSoftClipped"],
+                                    en.ctypes.data, ok.ctypes.data, reason.ctypes.data)
+        return ok, flags, [qual[off[i]:off[i + 1]].tolist() for i in range(n)], reason
 
     # -- a14..a18 ------------------------------------------------------------------------------
     def assemble(self, ref, ref_start, assem_start, assem_end, seqs, quals, k=15, min_qual=20,

@@ -810,6 +810,74 @@ ORC_API int orc_variant_candidates(const char* ref, int refLen, int refSeqStart,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Read QC / trimming: checkAndTrimRead (src/cython/cwindow.pyx:332-481) for one stream of reads
+ * (bamReadBuffer.addReadToBuffer, :560-595: `theLastRead` is the previous read of the stream).
+ * qual is modified in place (trimmed bases get quality 0), flags get BAM_FQCFAIL where the reference
+ * sets it; ok[r] = return value; reason[r] = filter type that rejected the read (0..6 as
+ * cwindow.pyx:40-46, 7 = secondary alignment, -1 = accepted).  enabled[4]: MATE_UNMAPPED, MATE_DISTANT,
+ * SMALL_INSERT, DUPLICATE filters on/off (a counter of -1 switches the filter off in the reference).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_check_and_trim(int nReads, char* qual, const long long* read_off, const int* pos, const unsigned char* mapq,
+                                int* flags, const short* chromID, const short* mateChromID, const int* insertSize,
+                                const int* matePos, const short* cigar, const int* cig_off,
+                                int minGoodQualBases, int minMapQual, int minBaseQual, int trimOverlapping, int trimAdapter,
+                                int trimReadFlank, int trimSoftClipped, const int* enabled, int* ok, int* reason)
+{
+    for (int r = 0; r < nReads; ++r) {
+        char* q = qual + read_off[r];
+        const int rlen = (int)(read_off[r + 1] - read_off[r]);
+        const int f = flags[r];
+        const int paired = f & 1, proper = f & 2, unmapped = f & 4, mateUnmapped = f & 8, reverse = f & 16, mateReverse = f & 32;
+        ok[r] = 0; reason[r] = -1;
+        if (f & 256) { flags[r] |= 512; reason[r] = 7; continue; }                               /* :337-339 */
+        if (mapq[r] < minMapQual) { flags[r] |= 512; reason[r] = 6; continue; }                  /* :341-344 */
+        int nBelow = 0;
+        for (int i = 0; i < rlen; ++i) nBelow += q[i] < minBaseQual;
+        if (rlen - nBelow < minGoodQualBases) { flags[r] |= 512; reason[r] = 0; continue; }      /* :354-357 */
+        if (unmapped) { flags[r] |= 512; reason[r] = 1; continue; }                              /* :360-363 */
+        if (enabled[0] && paired && mateUnmapped) { reason[r] = 2; continue; }                   /* :367-371 (no QCFail) */
+        if (enabled[1] && paired && (chromID[r] != mateChromID[r] || !proper)) { reason[r] = 3; continue; }
+        if (enabled[2] && paired && insertSize[r] != 0 && abs(insertSize[r]) < rlen) { flags[r] |= 512; reason[r] = 4; continue; }
+        if (enabled[3]) {                                                                        /* :389-409 */
+            if (f & 1024) { flags[r] |= 512; reason[r] = 5; continue; }
+            if (r > 0 && pos[r] == pos[r - 1] && rlen == (int)(read_off[r] - read_off[r - 1])) {
+                if (paired) {
+                    if (matePos[r - 1] == matePos[r]) { flags[r] |= 512; reason[r] = 5; continue; }
+                } else { flags[r] |= 512; reason[r] = 5; continue; }
+            }
+        }
+        if (!reverse) {                                                                          /* :415-421 */
+            for (int i = 1; i <= rlen; ++i) {
+                if (i < trimReadFlank || q[rlen - i] < 5) q[rlen - i] = 0; else break;
+            }
+        } else {
+            for (int i = 0; i < rlen; ++i) {
+                if (i < trimReadFlank || q[i] < 5) q[i] = 0; else break;
+            }
+        }
+        const int absIns = abs(insertSize[r]);
+        if (trimOverlapping == 1 && paired && absIns > 0 && !reverse && mateReverse && absIns < 2 * rlen) {   /* :438-440 */
+            int lim = (2 * rlen - insertSize[r]) + 1;
+            if (lim > rlen) lim = rlen;
+            for (int i = 1; i <= lim; ++i) q[rlen - i] = 0;
+        }
+        if (trimAdapter == 1 && paired && absIns > 0 && absIns < rlen) {                          /* :445-452 */
+            if (reverse) { for (int i = 1; i < rlen - absIns + 1; ++i) q[rlen - i] = 0; }
+            else { for (int i = absIns; i < rlen; ++i) q[i] = 0; }
+        }
+        if (trimSoftClipped == 1) {                                                               /* :462-479 */
+            int index = 0;
+            for (int c = cig_off[r]; c < cig_off[r + 1]; ++c) {
+                const int op = cigar[2 * c], len = cigar[2 * c + 1];
+                if (op == 0 || op == 1) index += len;
+                else if (op == 4) for (int j = 0; j < len; ++j) q[index++] = 0;
+            }
+        }
+        ok[r] = 1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * a14-a18: coloured de-Bruijn assembler  (src/cython/assembler.pyx:73-1476)
  * ------------------------------------------------------------------------------------------ */
 #define COL_REF 1

@@ -336,8 +336,7 @@ cdef extern from "stdlib.h":
 cdef void* my_malloc(size_t n):
     return malloc(n)
 
-cdef inline int Read_IsQCFail(cAlignedRead* theRead) nogil:      # htslibWrapper.pxd:271-272, BAM_FQCFAIL = 512
-    return ((theRead.bitFlag & 512) != 0)
+@@FLAGS@@
 
 from operator import attrgetter
 from itertools import combinations
@@ -392,8 +391,7 @@ cdef class bamReadBuffer:
     cdef ReadArray brokenMates
 
 cdef int PLATYPUS_VAR = 1
-cdef inline int Read_IsCompressed(cAlignedRead* theRead) nogil:      # (compressed reads are not part of the fixtures)
-    return 0
+# (Read_IsCompressed & co. come from the verbatim flag block above; compressed reads are not part of the fixtures)
 cdef void compressRead(cAlignedRead* read, char* refSeq, int refStart, int refEnd, int qualBinSize, int fullComp):
     pass
 cdef void uncompressRead(cAlignedRead* read, char* refSeq, int refStart, int refEnd, int qualBinSize):
@@ -477,6 +475,47 @@ def variant_candidates(bytes chrom, int start, int end, FastaFile refFile, list 
         free(arr[i])
     free(arr)
     return srt, ins
+"""
+
+QC_TAIL = r"""
+def check_and_trim(list reads, int minGoodQualBases, int minMapQual, int minBaseQual, int minFlank, int trimOverlapping,
+                   int trimAdapter, int trimReadFlank, int trimSoftClipped, list enabled):
+    # reads (one stream, in order): dict(seq, qual, pos, mapq, flag, chromID, mateChromID, insertSize, matePos, cigar).  enabled: 4 ints
+    # for MATE_UNMAPPED, MATE_DISTANT, SMALL_INSERT, DUPLICATE (0 = the filter is off, i.e. its counter is -1)
+    cdef int counts[7]
+    cdef int i, k, ok
+    cdef cAlignedRead* last = NULL
+    cdef cAlignedRead* r
+    for i in range(7):
+        counts[i] = 0
+    for i in range(4):
+        if not enabled[i]:
+            counts[2 + i] = -1
+    out = []
+    ptrs = []
+    keep = []
+    for t in reads:
+        qual = bytearray(t["qual"]) + b"\\0"
+        keep.append(qual)
+        r = make_read(t["seq"], bytes(qual), t["pos"], t["pos"] + len(t["seq"]), t["mapq"], t["flag"])
+        r.qual = <char*>malloc(len(t["seq"]) + 1)
+        for k in range(len(t["seq"])):
+            r.qual[k] = t["qual"][k]
+        r.chromID, r.mateChromID, r.insertSize, r.matePos = t["chromID"], t["mateChromID"], t["insertSize"], t["matePos"]
+        r.cigarLen = len(t["cigar"])
+        r.cigarOps = <short*>calloc(2 * len(t["cigar"]) + 2, sizeof(short))
+        for k, (op, ln) in enumerate(t["cigar"]):
+            r.cigarOps[2 * k] = op
+            r.cigarOps[2 * k + 1] = ln
+        ok = checkAndTrimRead(r, last, minGoodQualBases, counts, minMapQual, minBaseQual, minFlank, trimOverlapping, trimAdapter,
+                              trimReadFlank, trimSoftClipped)
+        out.append((ok, r.bitFlag, [r.qual[k] for k in range(r.rlen)]))
+        if last != NULL:
+            free(last.qual); free(last.cigarOps); free(last)
+        last = r
+    if last != NULL:
+        free(last.qual); free(last.cigarOps); free(last)
+    return out, [counts[i] for i in range(7)]
 """
 
 FILT_TAIL = r"""
@@ -666,14 +705,22 @@ def build_scratch(scratch):
     assert "insertedSequence.count('N')" in var[651] and 'deletedSequence.count("N")' in var[671]
     assert utl[734].startswith("cdef int isHaplotypeValid") and vfl[236].startswith("cdef double computeBestScoreForGenotype")
     assert vfl[376].startswith("cdef list getFilteredHaplotypes") and vfl[507].startswith("#####") and vfl[282].lstrip().startswith("return bestScoreThisHap")
-    drv = (HAP_HEAD + mltot + "\n" + chp[63] + "\n" + homopol + "\n\n" + VAR_CLASS + "\n" + "\n".join(var[269:280]) + "\n\n"
+    # + read QC / trimming: checkAndTrimRead (cwindow.pyx:332-481) with its filter-type constants (:40-46) and the BAM flag
+    # constants / accessors of htslibWrapper.pxd:234-296
+    cwn = open(os.path.join(src, "cython/cwindow.pyx")).read().split("\n")
+    hpx = open(os.path.join(src, "cython/htslibWrapper.pxd")).read().split("\n")
+    assert hpx[233].startswith("DEF BAM_FPAIRED") and hpx[294].startswith("cdef inline void Read_SetUnCompressed")
+    assert cwn[39].startswith("cdef int LOW_QUAL_BASES") and cwn[45].startswith("cdef int LOW_MAP_QUAL")
+    assert cwn[331].startswith("cdef int checkAndTrimRead") and cwn[480].strip() == "return True" and cwn[484].startswith("cdef class bamReadBuffer")
+    qc_text = "\n".join(cwn[39:46]) + "\n\n" + "\n".join(cwn[331:481]) + "\n"
+    drv = (HAP_HEAD.replace("@@FLAGS@@", "\n".join(hpx[233:296])) + mltot + "\n" + chp[63] + "\n" + homopol + "\n\n" + VAR_CLASS + "\n" + "\n".join(var[269:280]) + "\n\n"
            + "\n".join(var[281:363]) + "\n\n" + "\n".join(var[260:268]) + "\n\n" + "\n".join(chp[102:115]) + "\n"
            + HAP_CLASS + "\n" + "\n".join(chp[305:384]) + "\n\n" + "\n".join(chp[551:590]) + "\n\n"
            + "\n".join(chp[593:676]) + "\n" + HAPSEQ_CLASS + "\n".join(chp[126:175]) + "\n\n" + "\n".join(chp[385:395]) + "\n\n"
            + "\n".join(chp[396:449]).replace("bytes(''.join(bitsOfMutatedSeq))", "b''.join(bitsOfMutatedSeq)") + "\n" + GENO2_CLASS + "\n" + "\n".join(utl[734:802]) + "\n\n" + "\n".join(vfl[236:283]) + "\n\n"
            + "\n".join(vfl[376:506]) + "\n"
            + "cdef class VariantCandidateGenerator:\n" + "\n".join(vpx[44:73]) + "\n" + "\n".join(var[462:751]).replace("insertedSequence.count('N')", "insertedSequence.count(b'N')").replace('deletedSequence.count("N")', "deletedSequence.count(b'N')") + "\n"
-           + HAP_TAIL + FILT_TAIL + CAND_TAIL)
+           + qc_text + HAP_TAIL + FILT_TAIL + CAND_TAIL + QC_TAIL)
     open(os.path.join(scratch, "hap_drv.pyx"), "w").write(drv)
     open(os.path.join(scratch, "setup.py"), "w").write(SETUP)
     r = subprocess.run([sys.executable, "setup.py", "build_ext", "--inplace"], cwd=scratch,
@@ -1205,6 +1252,63 @@ def gen_candidates(out):
     print("candidates: %d regions, %d reads, %d distinct candidates" % (len(cases), sum(len(c["reads"]) for c in cases), sum(len(c["sorted"]) for c in cases)))
 
 
+def gen_readqc(out):
+    """Read QC / trimming: checkAndTrimRead (cwindow.pyx:332-481), read by read with the previous read of the stream as
+    `theLastRead` (bamReadBuffer.addReadToBuffer, :560-595)."""
+    import hap_drv
+    rng = np.random.default_rng(2468)
+    cases = []
+    for ci in range(30):
+        L = int(rng.choice([36, 100, 150]))
+        reads = []
+        pos = 1000
+        for r in range(int(rng.integers(80, 300))):
+            if rng.random() > 0.15:
+                pos += int(rng.integers(0, 6))                                   # sorted stream with repeated positions (duplicate rule)
+            rl = L if rng.random() > 0.05 else int(rng.integers(20, L))
+            q = np.clip(rng.normal(30, 12, rl), 0, 60).astype(np.uint8)
+            if rng.random() < 0.3:
+                q[-int(rng.integers(1, 25)):] = rng.integers(0, 5)               # low-quality tail
+            if rng.random() < 0.3:
+                q[:int(rng.integers(1, 25))] = rng.integers(0, 5)
+            flag = 0
+            paired = rng.random() < 0.8
+            if paired:
+                flag |= 1
+                if rng.random() < 0.95: flag |= 2
+                if rng.random() < 0.04: flag |= 8
+                if rng.random() < 0.5: flag |= 32
+                flag |= 64 if rng.random() < 0.5 else 128
+            if rng.random() < 0.5: flag |= 16
+            if rng.random() < 0.03: flag |= 4
+            if rng.random() < 0.03: flag |= 256
+            if rng.random() < 0.05: flag |= 1024
+            ins = int(rng.choice([0, 300, 420, -380, 300, 350, rl - 10, -(rl - 5), int(1.5 * rl), -int(1.3 * rl), 2 * rl + 5]))
+            cig = [(0, rl)]
+            t = rng.random()
+            if t < 0.15:
+                a = int(rng.integers(1, 15)); cig = [(4, a), (0, rl - a)]
+            elif t < 0.3:
+                a = int(rng.integers(1, 15)); cig = [(0, rl - a), (4, a)]
+            elif t < 0.4:
+                a, b_ = int(rng.integers(1, 8)), int(rng.integers(1, 8)); cig = [(5, 3), (4, a), (0, 20), (1, 2), (0, rl - a - b_ - 22), (2, 4), (4, b_)]
+            elif t < 0.45:
+                cig = [(7, 10), (4, 5), (0, rl - 15)]                            # '=' does not advance the soft-clip cursor (reference quirk)
+            reads.append(dict(seq="A" * rl, qual=q.tolist(), pos=pos, mapq=int(rng.choice([60] * 9 + [25, 19, 3])), flag=flag,
+                              chromID=1, mateChromID=int(rng.choice([1] * 12 + [2])), insertSize=ins,
+                              matePos=int(rng.choice([pos + 200, pos + 200, pos + 150])), cigar=[list(c) for c in cig]))
+        opt = dict(minGoodQualBases=int(rng.choice([20, 20, 40])), minMapQual=20, minBaseQual=int(rng.choice([20, 10])), minFlank=10,
+                   trimOverlapping=int(rng.random() < 0.8), trimAdapter=int(rng.random() < 0.8), trimReadFlank=int(rng.choice([0, 0, 5])),
+                   trimSoftClipped=int(rng.random() < 0.8), enabled=[int(rng.random() < 0.8) for _ in range(4)])
+        tup = [dict(r, seq=r["seq"].encode(), cigar=[tuple(c) for c in r["cigar"]]) for r in reads]
+        res, counts = hap_drv.check_and_trim(tup, opt["minGoodQualBases"], opt["minMapQual"], opt["minBaseQual"], opt["minFlank"],
+                                             opt["trimOverlapping"], opt["trimAdapter"], opt["trimReadFlank"], opt["trimSoftClipped"], opt["enabled"])
+        cases.append(dict(options=opt, reads=reads, ok=[int(x[0]) for x in res], flag_out=[x[1] for x in res], qual_out=[(None if x[2] == r["qual"] else x[2]) for x, r in zip(res, reads)], counts=counts))   # None: unchanged
+    with gzip.open(os.path.join(out, "readqc_cases.json.gz"), "wt") as f:
+        json.dump(cases, f)
+    print("readqc: %d streams, %d reads, %d rejected" % (len(cases), sum(len(c["reads"]) for c in cases), sum(len(c["ok"]) - sum(c["ok"]) for c in cases)))
+
+
 def gen_population(out):
     """a11/a12 + SURVEY 8(f) rank 1: per-read log-likelihood arrays -> genotype log-likelihoods (calculateDataLikelihood),
     rescaled likelihoods (the loop at cpopulation.pyx:283-309, mirrored here around the compiled method), EM haplotype
@@ -1294,7 +1398,7 @@ def main():
         sys.exit("reference tree not found at %s: golden vectors can only be regenerated in the build container" % REF)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     build_scratch(a.scratch)
-    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq", "candidates"]
+    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq", "candidates", "readqc"]
     if "dp" in todo:
         gen_dp(HERE)
     if "mapalign" in todo:
@@ -1311,6 +1415,8 @@ def main():
         gen_hapseq(HERE)
     if "candidates" in todo:
         gen_candidates(HERE)
+    if "readqc" in todo:
+        gen_readqc(HERE)
 
 
 if __name__ == "__main__":

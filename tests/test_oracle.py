@@ -259,3 +259,21 @@ def test_variant_candidates_match_reference_golden(oracle, golden_dir):
         assert sorted(first_seen, key=variant_sort_key) == c["sorted"]          # sorted() is stable: ties keep first-seen order
         n += len(first_seen)
     assert n > 5000
+
+
+# ---- read QC / trimming (checkAndTrimRead), pinned by the reference's own text ---------------------------------------------
+def test_check_and_trim_matches_reference_golden(oracle, golden_dir):
+    import gzip, json
+    cases = json.load(gzip.open(os.path.join(golden_dir, "readqc_cases.json.gz"), "rt"))
+    trimmed = 0
+    for c in cases:
+        ok, flags, quals, reason = oracle.check_and_trim(c["reads"], c["options"])
+        assert ok.tolist() == c["ok"] and flags.tolist() == c["flag_out"]
+        for r, q, exp in zip(c["reads"], quals, c["qual_out"]):
+            assert q == (r["qual"] if exp is None else exp)
+            trimmed += exp is not None
+        counts = [int((reason == k).sum()) for k in range(7)]
+        for k in range(7):
+            if c["counts"][k] != -1:
+                assert counts[k] == c["counts"][k]
+    assert trimmed > 500
