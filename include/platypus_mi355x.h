@@ -281,6 +281,41 @@ int plat_candidates_batch(plat_ctx* ctx, const plat_candidate_batch* batch, int 
                           int gen_snps, int gen_indels, int max_per_read, const int32_t* read_region,
                           int32_t* out_rec, int32_t* out_count, int32_t* out_status, void* stream);
 
+/* ---- read QC / trimming ----------------------------------------------------------------------------
+ * Replaces  cdef int checkAndTrimRead(theRead, theLastRead, ...)   cwindow.pyx:332-481
+ * as driven by bamReadBuffer.addReadToBuffer (:560-595) for whole streams of reads: read r's
+ * `theLastRead` is read r-1 when stream_of[r-1] == stream_of[r].  read_qual is modified in place (trimmed
+ * bases get quality 0), read_flags get BAM_FQCFAIL (512) where the reference sets it.
+ *   out_ok[r]      the function's return value (1: goes to `reads`, 0: goes to `badReads`)
+ *   out_reason[r]  -1 accepted, else the filteredReadCountsByType slot that was bumped (cwindow.pyx:40-46:
+ *                  0 LOW_QUAL_BASES, 1 UNMAPPED_READ, 2 MATE_UNMAPPED, 3 MATE_DISTANT, 4 SMALL_INSERT,
+ *                  5 DUPLICATE, 6 LOW_MAP_QUAL) or 7 for a secondary alignment
+ * filter_* = 0 switches a filter off (the reference uses a counter value of -1 for that).        */
+typedef struct plat_readqc_batch {
+    int32_t n_reads, _pad;
+    uint8_t* read_qual;              /* raw phred, in/out */
+    const int64_t* read_off;         /* [n_reads+1] */
+    const int32_t* read_pos;
+    const uint8_t* read_mapq;
+    int32_t* read_flags;             /* bitFlag, in/out */
+    const int16_t* chrom_id;
+    const int16_t* mate_chrom_id;
+    const int32_t* insert_size;
+    const int32_t* mate_pos;
+    const int16_t* cigar;            /* (op, len) pairs */
+    const int32_t* cig_off;          /* [n_reads+1], in pairs */
+    const int32_t* stream_of;        /* [n_reads] id of the read's stream (sample buffer) */
+} plat_readqc_batch;
+
+typedef struct plat_readqc_options {
+    int32_t min_good_qual_bases, min_map_qual, min_base_qual;           /* minGoodQualBases 20, minMapQual 20, minBaseQual 20 */
+    int32_t trim_overlapping, trim_adapter, trim_read_flank, trim_soft_clipped;   /* 1, 1, 0, 1 */
+    int32_t filter_mate_unmapped, filter_mate_distant, filter_small_insert, filter_duplicates;
+} plat_readqc_options;
+
+int plat_read_qc_batch(plat_ctx* ctx, const plat_readqc_batch* batch, const plat_readqc_options* options,
+                       int32_t* out_ok, int32_t* out_reason, void* stream);
+
 /* ---- a14..a18: assembleReadsAndDetectVariants ---------------------------------------------------
  * Replaces  cdef list assembleReadsAndDetectVariants(chrom, assemStart, assemEnd, refStart, refEnd,
  *                                                    readBuffers, refSeq, options)

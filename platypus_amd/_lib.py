@@ -69,6 +69,19 @@ class CandidateBatch(C.Structure):
                 ("cigar", C.c_void_p), ("cig_off", C.c_void_p)]
 
 
+class ReadQCBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("_pad", C.c_int32), ("read_qual", C.c_void_p), ("read_off", C.c_void_p),
+                ("read_pos", C.c_void_p), ("read_mapq", C.c_void_p), ("read_flags", C.c_void_p), ("chrom_id", C.c_void_p),
+                ("mate_chrom_id", C.c_void_p), ("insert_size", C.c_void_p), ("mate_pos", C.c_void_p), ("cigar", C.c_void_p),
+                ("cig_off", C.c_void_p), ("stream_of", C.c_void_p)]
+
+
+class ReadQCOptions(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("min_good_qual_bases", "min_map_qual", "min_base_qual", "trim_overlapping", "trim_adapter",
+                                         "trim_read_flank", "trim_soft_clipped", "filter_mate_unmapped", "filter_mate_distant",
+                                         "filter_small_insert", "filter_duplicates")]
+
+
 # symbol -> (restype, argtypes): exactly the declarations of include/platypus_mi355x.h
 SIGNATURES = {
     "plat_abi_version": (C.c_int, []),
@@ -101,6 +114,7 @@ SIGNATURES = {
     "plat_genotype_call_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 16),
     "plat_candidates_batch": (C.c_int, [C.c_void_p, C.POINTER(CandidateBatch), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "plat_read_qc_batch": (C.c_int, [C.c_void_p, C.POINTER(ReadQCBatch), C.POINTER(ReadQCOptions), C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_assemble_batch": (C.c_int, [C.c_void_p, C.POINTER(AssemblyBatch), C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -132,3 +132,92 @@ PLAT_EXPORT int plat_candidates_batch(plat_ctx* ctx, const plat_candidate_batch*
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Read QC / trimming: checkAndTrimRead (cwindow.pyx:332-481).  One lane per read; `theLastRead` of
+// bamReadBuffer.addReadToBuffer (:560-595) is simply the previous read of the same stream and only its position, length
+// and mate position are looked at, so the reads of a stream are independent of each other.
+namespace plat {
+
+__global__ void __launch_bounds__(64)
+k_read_qc(plat_readqc_batch b, plat_readqc_options o, int32_t* __restrict__ ok, int32_t* __restrict__ reason)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= b.n_reads) return;
+    int8_t* q = (int8_t*)b.read_qual + b.read_off[r];
+    const int rlen = (int)(b.read_off[r + 1] - b.read_off[r]);
+    const int f = b.read_flags[r];
+    const bool paired = f & 1, proper = f & 2, unmapped = f & 4, mateUnmapped = f & 8, reverse = f & 16, mateReverse = f & 32;
+    const int ins = b.insert_size[r];
+    const int absIns = ins < 0 ? -ins : ins;
+    int why = -1, qcfail = 1;
+    if (f & 256) why = 7;                                                            // secondary alignment, :337-339
+    else if ((int)b.read_mapq[r] < o.min_map_qual) why = 6;                          // :341-344
+    else {
+        int nBelow = 0;
+        for (int i = 0; i < rlen; ++i) nBelow += q[i] < o.min_base_qual;
+        if (rlen - nBelow < o.min_good_qual_bases) why = 0;                          // :354-357
+        else if (unmapped) why = 1;                                                  // :360-363
+        else if (o.filter_mate_unmapped && paired && mateUnmapped) { why = 2; qcfail = 0; }          // :367-371 (no QCFail flag)
+        else if (o.filter_mate_distant && paired && (b.chrom_id[r] != b.mate_chrom_id[r] || !proper)) { why = 3; qcfail = 0; }
+        else if (o.filter_small_insert && paired && ins != 0 && absIns < rlen) why = 4;
+        else if (o.filter_duplicates) {                                              // :389-409
+            if (f & 1024) why = 5;
+            else if (r > 0 && b.stream_of[r - 1] == b.stream_of[r] && b.read_pos[r] == b.read_pos[r - 1] &&
+                     rlen == (int)(b.read_off[r] - b.read_off[r - 1])) {
+                if (!paired || b.mate_pos[r - 1] == b.mate_pos[r]) why = 5;
+            }
+        }
+    }
+    if (why >= 0) {
+        if (qcfail) b.read_flags[r] = f | 512;
+        ok[r] = 0; reason[r] = why;
+        return;
+    }
+    if (!reverse) {                                                                  // low-quality tail, :415-421
+        for (int i = 1; i <= rlen; ++i) {
+            if (i < o.trim_read_flank || q[rlen - i] < 5) q[rlen - i] = 0; else break;
+        }
+    } else {
+        for (int i = 0; i < rlen; ++i) {
+            if (i < o.trim_read_flank || q[i] < 5) q[i] = 0; else break;
+        }
+    }
+    if (o.trim_overlapping == 1 && paired && absIns > 0 && !reverse && mateReverse && absIns < 2 * rlen) {   // :438-440
+        int lim = (2 * rlen - ins) + 1;
+        if (lim > rlen) lim = rlen;
+        for (int i = 1; i <= lim; ++i) q[rlen - i] = 0;
+    }
+    if (o.trim_adapter == 1 && paired && absIns > 0 && absIns < rlen) {               // :445-452
+        if (reverse) { for (int i = 1; i < rlen - absIns + 1; ++i) q[rlen - i] = 0; }
+        else { for (int i = absIns; i < rlen; ++i) q[i] = 0; }
+    }
+    if (o.trim_soft_clipped == 1) {                                                   // :462-479 (only M and I advance the cursor)
+        int index = 0;
+        for (int c = b.cig_off[r]; c < b.cig_off[r + 1]; ++c) {
+            const int op = b.cigar[2 * c], len = b.cigar[2 * c + 1];
+            if (op == 0 || op == 1) index += len;
+            else if (op == 4) for (int j = 0; j < len && index < rlen; ++j) q[index++] = 0;
+        }
+    }
+    ok[r] = 1; reason[r] = -1;
+}
+
+}  // namespace plat
+
+PLAT_EXPORT int plat_read_qc_batch(plat_ctx* ctx, const plat_readqc_batch* batch, const plat_readqc_options* options,
+                                   int32_t* out_ok, int32_t* out_reason, void* stream)
+{
+    if (!ctx || !batch || !options) return PLAT_ERR_INVALID;
+    const plat_readqc_batch b = *batch;
+    if (b.n_reads < 0) return PLAT_ERR_INVALID;
+    if (b.n_reads == 0) return PLAT_OK;
+    if (!b.read_qual || !b.read_off || !b.read_pos || !b.read_mapq || !b.read_flags || !b.chrom_id || !b.mate_chrom_id ||
+        !b.insert_size || !b.mate_pos || !b.cigar || !b.cig_off || !b.stream_of || !out_ok || !out_reason)
+        return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(plat::k_read_qc, dim3((unsigned)((b.n_reads + 63) / 64)), dim3(64), 0, (hipStream_t)stream, b, *options,
+                       out_ok, out_reason);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}

@@ -307,6 +307,49 @@ class Engine:
                 out[g].append((p_, ref_blob[ro:ro + nrem] if nrem else b"", seq_blob[ao:ao + nadd] if nadd else b"", r - int(first[g])))
         return out
 
+    # ---- read QC / trimming (checkAndTrimRead) ---------------------------------------------------------------
+    def read_qc(self, streams, min_good_qual_bases=20, min_map_qual=20, min_base_qual=20, trim_overlapping=1, trim_adapter=1,
+                trim_read_flank=0, trim_soft_clipped=1, enabled=(1, 1, 1, 1)):
+        """checkAndTrimRead over whole streams of reads (one stream = the reads one bamReadBuffer sees, in order).
+        `streams`: list of lists of dicts {qual, pos, mapq, flag, chromID, mateChromID, insertSize, matePos, cigar}.
+        Returns per stream (ok [n], flags_out [n], quals_out [list of uint8 arrays], reason [n])."""
+        torch = _torch()
+        reads = [r for st in streams for r in st]
+        n = len(reads)
+        if n == 0:
+            return [(np.zeros(0, np.int32), np.zeros(0, np.int32), [], np.zeros(0, np.int32)) for _ in streams]
+
+        def dev(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.device)
+        off = np.concatenate([[0], np.cumsum([len(r["qual"]) for r in reads])]).astype(np.int64)
+        qual = dev(pad_blob(np.concatenate([np.asarray(r["qual"], dtype=np.uint8) for r in reads])), np.uint8)
+        t = dict(off=dev(off, np.int64), pos=dev([r["pos"] for r in reads], np.int32), mapq=dev([r["mapq"] for r in reads], np.uint8),
+                 flags=dev([r["flag"] for r in reads], np.int32), cid=dev([r["chromID"] for r in reads], np.int16),
+                 mcid=dev([r["mateChromID"] for r in reads], np.int16), ins=dev([r["insertSize"] for r in reads], np.int32),
+                 mpos=dev([r["matePos"] for r in reads], np.int32),
+                 cig=dev([x for r in reads for c in r["cigar"] for x in c] + [0, 0], np.int16),
+                 coff=dev(np.concatenate([[0], np.cumsum([len(r["cigar"]) for r in reads])]), np.int32),
+                 sof=dev(np.repeat(np.arange(len(streams)), [len(st) for st in streams]), np.int32))
+        b = _lib.ReadQCBatch()
+        b.n_reads = n
+        b.read_qual, b.read_off, b.read_pos, b.read_mapq, b.read_flags = qual.data_ptr(), t["off"].data_ptr(), t["pos"].data_ptr(), t["mapq"].data_ptr(), t["flags"].data_ptr()
+        b.chrom_id, b.mate_chrom_id, b.insert_size, b.mate_pos = t["cid"].data_ptr(), t["mcid"].data_ptr(), t["ins"].data_ptr(), t["mpos"].data_ptr()
+        b.cigar, b.cig_off, b.stream_of = t["cig"].data_ptr(), t["coff"].data_ptr(), t["sof"].data_ptr()
+        o = _lib.ReadQCOptions(min_good_qual_bases, min_map_qual, min_base_qual, trim_overlapping, trim_adapter, trim_read_flank,
+                               trim_soft_clipped, *[int(x) for x in enabled])
+        ok = torch.empty(n, dtype=torch.int32, device=self.device)
+        why = torch.empty(n, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.plat_read_qc_batch(self.ctx, C.byref(b), C.byref(o), ok.data_ptr(), why.data_ptr(), self._stream()),
+                   "plat_read_qc_batch")
+        torch.cuda.synchronize(self.device)
+        ok_h, why_h, fl_h, q_h = ok.cpu().numpy(), why.cpu().numpy(), t["flags"].cpu().numpy(), qual.cpu().numpy()
+        out, a = [], 0
+        for st in streams:
+            e = a + len(st)
+            out.append((ok_h[a:e], fl_h[a:e], [q_h[off[i]:off[i + 1]] for i in range(a, e)], why_h[a:e]))
+            a = e
+        return out
+
     # ---- a14..a18 ------------------------------------------------------------------------------------
     def assemble(self, regions, kmer_size=15, min_qual=20, min_weight=40, no_cycles=0, max_vars=512,
                  blob_per_region=1 << 16):

@@ -96,7 +96,7 @@ class Variant:
 class AlignedRead:
     """The fields of cAlignedRead the hot path reads (htslibWrapper.pxd:187-201).  qual is raw phred."""
 
-    def __init__(self, seq, qual, pos, mapq=60, bitFlag=3, end=None, cigarOps=None):
+    def __init__(self, seq, qual, pos, mapq=60, bitFlag=3, end=None, cigarOps=None, chromID=0, mateChromID=0, insertSize=0, matePos=-1):
         self.seq, self.qual = bytes(seq), bytes(qual)
         if len(self.seq) != len(self.qual):
             raise ValueError("seq and qual differ in length")
@@ -105,6 +105,7 @@ class AlignedRead:
         self.end = int(end) if end is not None else self.pos + self.rlen
         self.mapq, self.bitFlag = int(mapq), int(bitFlag)
         self.cigarOps = [tuple(c) for c in cigarOps] if cigarOps is not None else [(0, self.rlen)]   # (op, len) pairs; default = one match
+        self.chromID, self.mateChromID, self.insertSize, self.matePos = chromID, mateChromID, insertSize, matePos
 
     def isQCFail(self):
         return (self.bitFlag & BAM_FQCFAIL) != 0
@@ -385,6 +386,25 @@ class Population:
         ph, lik, out4 = get_engine().genotype_calls(self._db, [dict(window=0, var_in_hap=vih, is_ref=haplotypeIsRefAtThisPos)])[0]
         i = sampleIndex
         return (int(ph[i][0]), int(ph[i][1]), lik[i].tolist(), float(out4[i][0]), float(out4[i][1]), float(out4[i][2]), float(out4[i][3]))
+
+# ---- read QC / trimming ----------------------------------------------------------------------------------------------------
+def checkAndTrimReads(reads, options=None, enabled=(1, 1, 1, 1)):
+    """checkAndTrimRead (cwindow.pyx:332-481) for a stream of AlignedRead objects in buffer order, as
+    bamReadBuffer.addReadToBuffer (:560-595) applies it: qualities are trimmed and QCFail flags set IN PLACE; returns
+    (ok list, filteredReadCountsByType-style counts [7]).  `enabled`: MATE_UNMAPPED, MATE_DISTANT, SMALL_INSERT, DUPLICATE filters
+    (filterReadsWithUnmappedMates, filterReadsWithDistantMates, filterReadPairsWithSmallInserts, filterDuplicates)."""
+    options = options if options is not None else default_options()
+    st = [dict(qual=r.qual, pos=r.pos, mapq=r.mapq, flag=r.bitFlag, chromID=r.chromID, mateChromID=r.mateChromID,
+               insertSize=r.insertSize, matePos=r.matePos, cigar=r.cigarOps) for r in reads]
+    st = [dict(d, qual=list(d["qual"])) for d in st]
+    ok, flags, quals, why = get_engine().read_qc([st], options.minGoodQualBases, options.minMapQual, options.minBaseQual,
+                                                 options.trimOverlapping, options.trimAdapter, options.trimReadFlank,
+                                                 options.trimSoftClipped, enabled)[0]
+    for r, f, q in zip(reads, flags.tolist(), quals):
+        r.bitFlag, r.qual = int(f), bytes(q.tolist())
+    counts = [int((why == k).sum()) if (k < 2 or k == 6 or enabled[k - 2]) else -1 for k in range(7)]
+    return [bool(x) for x in ok.tolist()], counts
+
 
 # ---- SURVEY 8(f) rank 4: variant candidates from the reads' CIGARs and mismatches ----------------------------------------
 class VariantCandidateGenerator:

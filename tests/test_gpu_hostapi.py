@@ -208,3 +208,26 @@ def test_variant_candidates_match_reference_golden(golden_dir):
         assert got == c["sorted"]
         n += len(got)
     assert n > 5000
+
+
+def test_check_and_trim_reads_match_reference_golden(golden_dir):
+    """checkAndTrimRead (cwindow.pyx:332-481) on the device: accept/reject, QCFail flags, trimmed qualities, per-type counts."""
+    import gzip, json, os
+    from platypus_amd.options import default_options
+    cases = json.load(gzip.open(os.path.join(golden_dir, "readqc_cases.json.gz"), "rt"))
+    trimmed = 0
+    for c in cases:
+        o = c["options"]
+        opt = default_options(minGoodQualBases=o["minGoodQualBases"], minMapQual=o["minMapQual"], minBaseQual=o["minBaseQual"],
+                              trimOverlapping=o["trimOverlapping"], trimAdapter=o["trimAdapter"], trimReadFlank=o["trimReadFlank"],
+                              trimSoftClipped=o["trimSoftClipped"])
+        reads = [H.AlignedRead(r["seq"].encode(), bytes(r["qual"]), r["pos"], mapq=r["mapq"], bitFlag=r["flag"], cigarOps=r["cigar"],
+                               chromID=r["chromID"], mateChromID=r["mateChromID"], insertSize=r["insertSize"], matePos=r["matePos"])
+                 for r in c["reads"]]
+        ok, counts = H.checkAndTrimReads(reads, opt, o["enabled"])
+        assert [int(x) for x in ok] == c["ok"] and counts == c["counts"]
+        assert [r.bitFlag for r in reads] == c["flag_out"]
+        for r, src, exp in zip(reads, c["reads"], c["qual_out"]):
+            assert list(r.qual) == (src["qual"] if exp is None else exp)
+            trimmed += exp is not None
+    assert trimmed > 500
