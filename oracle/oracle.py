@@ -76,6 +76,8 @@ class Oracle:
         L.orc_variant_candidates.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p, C.c_int]
         L.orc_check_and_trim.restype = None
         L.orc_check_and_trim.argtypes = [C.c_int] + [C.c_void_p] * 11 + [C.c_int] * 7 + [C.c_void_p] * 3
+        L.orc_variant_read_stats.restype = None
+        L.orc_variant_read_stats.argtypes = [C.c_int] + [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 14 + [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
         L.orc_genotype_loglik.restype = C.c_double
         L.orc_genotype_loglik.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -276,6 +278,41 @@ class Oracle:
                                     opt["trimOverlapping"], opt["trimAdapter"], opt["trimReadFlank"], opt["trimSoftClipped"],
                                     en.ctypes.data, ok.ctypes.data, reason.ctypes.data)
         return ok, flags, [qual[off[i]:off[i + 1]].tolist() for i in range(n)], reason
+
+    # -- read statistics of the VCF INFO field --------------------------------------------------------
+    def variant_read_stats(self, variants, samples, var_in_genotype, min_base_qual=20, bad_reads_window=11, exact=0):
+        """variants: dicts {pos, removed, added (bytes), bam_min, bam_max}; samples: dicts {good: [reads], bad: [reads]}, a read =
+        {seq, qual (bytes), pos, end, mapq, flag, cigar}.  Returns per variant (counts[16], n_reads[nInd], n_var_reads[nInd], min_quals)."""
+        reads, gb, ge, bb, be = [], [], [], [], []
+        for s_ in samples:
+            gb.append(len(reads)); reads += s_["good"]; ge.append(len(reads))
+            bb.append(len(reads)); reads += s_["bad"]; be.append(len(reads))
+        nV, nI = len(variants), len(samples)
+        off = np.concatenate([[0], np.cumsum([len(r["seq"]) for r in reads])]).astype(np.int64)
+        sb = b"".join(r["seq"] for r in reads) + b"\0"
+        qb = b"".join(r["qual"] for r in reads) + b"\0"
+        arr = lambda k, dt: np.array([r[k] for r in reads], dtype=dt)
+        pos, end, mapq, flags = arr("pos", np.int32), arr("end", np.int32), arr("mapq", np.uint8), arr("flag", np.int32)
+        cig = np.array([x for r in reads for c in r["cigar"] for x in c] + [0, 0], dtype=np.int16)
+        coff = np.concatenate([[0], np.cumsum([len(r["cigar"]) for r in reads])]).astype(np.int32)
+        va = lambda k: np.array([v[k] for v in variants], dtype=np.int32)
+        vpos, vmin, vmax = va("pos"), va("bam_min"), va("bam_max")
+        nadd = np.array([len(v["added"]) for v in variants], dtype=np.int32)
+        nrem = np.array([len(v["removed"]) for v in variants], dtype=np.int32)
+        ablob = b"".join(v["added"] for v in variants) + b"\0"
+        aoff = np.concatenate([[0], np.cumsum(nadd)[:-1]]).astype(np.int32) if nV else np.zeros(0, np.int32)
+        vig = np.ascontiguousarray(var_in_genotype, dtype=np.uint8).reshape(nV, nI)
+        maxq = max(1, len(reads))
+        out = np.zeros((nV, 16), dtype=np.int64); ps = np.zeros((nV, nI, 2), dtype=np.int32)
+        minq = np.zeros((nV, maxq), dtype=np.int32); nminq = np.zeros(nV, dtype=np.int32)
+        i32 = lambda a: np.array(a, dtype=np.int32)
+        gb, ge, bb, be = i32(gb), i32(ge), i32(bb), i32(be)
+        self.lib.orc_variant_read_stats(nV, vpos.ctypes.data, vmin.ctypes.data, vmax.ctypes.data, nadd.ctypes.data, nrem.ctypes.data,
+                                        ablob, aoff.ctypes.data, nI, gb.ctypes.data, ge.ctypes.data, bb.ctypes.data, be.ctypes.data,
+                                        vig.ctypes.data, sb, qb, off.ctypes.data, pos.ctypes.data, end.ctypes.data, mapq.ctypes.data,
+                                        flags.ctypes.data, cig.ctypes.data, coff.ctypes.data, min_base_qual, bad_reads_window, exact,
+                                        out.ctypes.data, ps.ctypes.data, minq.ctypes.data, maxq, nminq.ctypes.data)
+        return [(out[v].tolist(), ps[v, :, 0].tolist(), ps[v, :, 1].tolist(), minq[v, :nminq[v]].tolist()) for v in range(nV)]
 
     # -- a14..a18 ------------------------------------------------------------------------------
     def assemble(self, ref, ref_start, assem_start, assem_end, seqs, quals, k=15, min_qual=20,

@@ -878,6 +878,129 @@ ORC_API void orc_check_and_trim(int nReads, char* qual, const long long* read_of
 }
 
 /* ------------------------------------------------------------------------------------------
+ * SURVEY 8(f) rank 3 (read statistics of the VCF INFO field): the per-variant loop over the reads of a
+ * window in vcfINFO (src/cython/vcfutils.pyx:1300-1390) with readOverlapsVariant (:901-913),
+ * readQualIsGoodVariantPosition (:917-943) and variantSupportedByRead (:961-1072).
+ * Reads: one table; sample i's good reads are [good_begin[i], good_end[i]), its bad reads
+ * [bad_begin[i], bad_end[i]).  out[v*16 + k]: 0 TC, 1 TC_bad, 2 TR, 3 TC_ab, 4 TR_ab, 5 NR_sb, 6 NF_sb,
+ * 7 TCR, 8 TCF, 9 TCR_sb, 10 TCF_sb, 11 NR, 12 NF, 13 nGoodReads, 14 nBadReads, 15 sum(mapq^2);
+ * per_sample[(v*nInd + i)*2 + {0,1}] = nReadsThisSample, nVarReadsThisSample; minq[v*maxq + k] (k <
+ * nminq[v]) = the MMLQ window minima in read order.
+ * ------------------------------------------------------------------------------------------ */
+static int read_overlaps_variant(int readStart, int readEnd, int vmin, int vmax) { return readStart <= vmax && readEnd > vmin; }
+
+static int read_qual_good(const char* qual, int rlen, int readPos, int vmin, int vmax) {
+    int a = vmin - readPos, b = vmax - readPos;
+    if (a > rlen) a = rlen; if (a < 0) a = 0;
+    if (b > rlen) b = rlen; if (b < 0) b = 0;
+    for (int i = a; i != b; ++i) {                                     /* pointer walk qualStart != qualEnd, :931-941 */
+        if (i > rlen + 64) return 1;                                   /* (a > b never happens: vmin <= vmax) */
+        if (qual[i] < 5) return 0;
+    }
+    return 1;
+}
+
+static int variant_supported_by_read(const char* seq, int rlen, int readStart, const short* ops, int cigarLength,
+                                     int varPos, int nAdded, int nRemoved, const char* added, int exactIndel)
+{
+    int refOffset = 0, readOffset = 0;
+    for (int ci = 0; ci < cigarLength; ++ci) {
+        const int flag = ops[2 * ci], length = ops[2 * ci + 1];
+        if (flag == 1) {
+            if (nAdded != nRemoved) {
+                if (exactIndel) {
+                    if (nAdded - nRemoved == length) {
+                        /* pRead.seq[start:start+nAdded] == varAdded (Python slice, clipped at the NUL-terminated length) */
+                        int n = nAdded;
+                        if (readOffset + n > rlen) n = rlen - readOffset > 0 ? rlen - readOffset : 0;
+                        if (n == nAdded && memcmp(seq + readOffset, added, (size_t)nAdded) == 0) return 1;
+                    }
+                    return 0;
+                }
+                return 1;
+            }
+            readOffset += length;
+        } else if (flag == 2) {
+            if (nAdded != nRemoved) {
+                if (exactIndel) return nRemoved - nAdded == length;
+                return 1;
+            }
+            refOffset += length;
+        } else if (flag == 0 || flag == 7 || flag == 8) {
+            const int start = varPos - readStart + readOffset - refOffset;
+            if (refOffset + readStart <= varPos && refOffset + readStart + length > varPos && nAdded == nRemoved)
+                if (start + nAdded <= rlen && start >= 0 && memcmp(seq + start, added, (size_t)nAdded) == 0) return 1;
+            readOffset += length;
+            refOffset += length;
+        } else if (flag == 3) {
+            readOffset += length;                                      /* (the reference advances both here, :1056-1058) */
+            refOffset += length;
+        } else if (flag == 4) {
+            readOffset += length;
+            if (ci == 0) refOffset += length;
+        }
+    }
+    return 0;
+}
+
+ORC_API void orc_variant_read_stats(int nVars, const int* varPos, const int* bamMin, const int* bamMax, const int* nAdded,
+                                    const int* nRemoved, const char* addedBlob, const int* addedOff,
+                                    int nInd, const int* good_begin, const int* good_end, const int* bad_begin, const int* bad_end,
+                                    const unsigned char* varInGenotype /* [nVars][nInd] */,
+                                    const char* seq, const char* qual, const long long* read_off, const int* pos, const int* end,
+                                    const unsigned char* mapq, const int* flags, const short* cigar, const int* cig_off,
+                                    int minBaseQual, int badReadsWindow, int exactIndel,
+                                    long long* out, int* per_sample, int* minq, int maxq, int* nminq)
+{
+    (void)minBaseQual;
+    for (int v = 0; v < nVars; ++v) {
+        long long* o = out + 16 * (size_t)v;
+        for (int k = 0; k < 16; ++k) o[k] = 0;
+        nminq[v] = 0;
+        const int vmin = bamMin[v], vmax = bamMax[v];
+        for (int i = 0; i < nInd; ++i) {
+            const int inGt = varInGenotype[(size_t)v * nInd + i];
+            int nReads = 0, nVarReads = 0;
+            o[13] += good_end[i] - good_begin[i];
+            o[14] += bad_end[i] - bad_begin[i];
+            for (int r = bad_begin[i]; r < bad_end[i]; ++r) {          /* :1316-1333 */
+                const int rlen = (int)(read_off[r + 1] - read_off[r]);
+                if (!read_overlaps_variant(pos[r], end[r], vmin, vmax)) continue;
+                if (!read_qual_good(qual + read_off[r], rlen, pos[r], vmin, vmax)) continue;
+                o[1] += 1; o[15] += (long long)mapq[r] * mapq[r];
+            }
+            for (int r = good_begin[i]; r < good_end[i]; ++r) {        /* :1335-1387 */
+                const int rlen = (int)(read_off[r + 1] - read_off[r]);
+                const char* q = qual + read_off[r];
+                if (!read_overlaps_variant(pos[r], end[r], vmin, vmax)) continue;
+                if (!read_qual_good(q, rlen, pos[r], vmin, vmax)) continue;
+                const int rev = (flags[r] & 16) != 0;
+                ++nReads; o[0] += 1; o[15] += (long long)mapq[r] * mapq[r];
+                if (inGt) { o[3] += 1; if (rev) o[9] += 1; else o[10] += 1; }
+                if (rev) o[7] += 1; else o[8] += 1;
+                if (variant_supported_by_read(seq + read_off[r], rlen, pos[r], cigar + 2 * (size_t)cig_off[r], cig_off[r + 1] - cig_off[r],
+                                              varPos[v], nAdded[v], nRemoved[v], addedBlob + addedOff[v], exactIndel)) {
+                    o[2] += 1; ++nVarReads;
+                    if (inGt) { o[4] += 1; if (rev) o[5] += 1; else o[6] += 1; }
+                    if (rev) o[11] += 1; else o[12] += 1;
+                    if (inGt) {
+                        int ws = vmin - pos[r] - (badReadsWindow - 1) / 2, we = vmax - pos[r] + (badReadsWindow - 1) / 2;
+                        if (ws < 0) ws = 0;
+                        if (we > rlen) we = rlen;
+                        int m = 0;
+                        for (int k = ws; k < we; ++k) m = (k == ws) ? q[k] : (q[k] < m ? q[k] : m);
+                        if (nminq[v] < maxq) minq[(size_t)v * maxq + nminq[v]] = m;
+                        nminq[v] += 1;
+                    }
+                }
+            }
+            per_sample[((size_t)v * nInd + i) * 2] = nReads;
+            per_sample[((size_t)v * nInd + i) * 2 + 1] = nVarReads;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * a14-a18: coloured de-Bruijn assembler  (src/cython/assembler.pyx:73-1476)
  * ------------------------------------------------------------------------------------------ */
 #define COL_REF 1

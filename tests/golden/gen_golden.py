@@ -518,6 +518,104 @@ def check_and_trim(list reads, int minGoodQualBases, int minMapQual, int minBase
     return out, [counts[i] for i in range(7)]
 """
 
+INFO_TAIL = r"""
+def variant_read_stats(list variants, list samples, list var_in_genotype, int minBaseQual, int badReadsWindow, int exact):
+    # variants: Variant objects; samples: per sample (good reads, bad reads), each read (seq, qual, pos, end, mapq, flag, cigar);
+    # var_in_genotype[v][i].  The loop below mirrors vcfINFO (vcfutils.pyx:1300-1390); every test it applies is the reference's
+    # own function.
+    cdef Variant variant
+    cdef cAlignedRead* pRead
+    cdef int i, k, windowStart, windowEnd, windowIndex, minBaseQualInWindow, windowSize = badReadsWindow
+    keep = []
+    built = []
+    for good, bad in samples:
+        arrs = []
+        for lst in (good, bad):
+            ptrs = []
+            for t in lst:
+                keep.append(t)
+                pRead = make_read(t[0], t[1], t[2], t[3], t[4], t[5])
+                pRead.cigarLen = len(t[6])
+                pRead.cigarOps = <short*>calloc(2 * len(t[6]) + 2, sizeof(short))
+                for k, (op, ln) in enumerate(t[6]):
+                    pRead.cigarOps[2 * k] = op
+                    pRead.cigarOps[2 * k + 1] = ln
+                ptrs.append(<size_t>pRead)
+            arrs.append(ptrs)
+        built.append(arrs)
+    out = []
+    for vi, variant in enumerate(variants):
+        TC = TC_bad = TR = TC_ab = TR_ab = NR_sb = NF_sb = TCR = TCF = TCR_sb = TCF_sb = NR = NF = nGoodReads = nBadReads = 0
+        RMSMQ = 0
+        nReadsPerSample, nVarReadsPerSample, listOfMinBaseQuals = [], [], []
+        varBAMMinPos, varBAMMaxPos = variant.bamMinPos, variant.bamMaxPos
+        for index, (goodp, badp) in enumerate(built):
+            varInGenotype = var_in_genotype[vi][index]
+            nGoodReads += len(goodp); nBadReads += len(badp)
+            nReadsThisSample = nVarReadsThisSample = 0
+            for pp in badp:
+                pRead = <cAlignedRead*><size_t>pp
+                if not readOverlapsVariant(pRead, varBAMMinPos, varBAMMaxPos):
+                    continue
+                if not readQualIsGoodVariantPosition(pRead, varBAMMinPos, varBAMMaxPos, minBaseQual):
+                    continue
+                TC_bad += 1
+                RMSMQ += (pRead.mapq*pRead.mapq)
+            for pp in goodp:
+                pRead = <cAlignedRead*><size_t>pp
+                if not readOverlapsVariant(pRead, varBAMMinPos, varBAMMaxPos):
+                    continue
+                if not readQualIsGoodVariantPosition(pRead, varBAMMinPos, varBAMMaxPos, minBaseQual):
+                    continue
+                nReadsThisSample += 1
+                TC += 1
+                RMSMQ += (pRead.mapq*pRead.mapq)
+                if varInGenotype:
+                    TC_ab += 1
+                    if Read_IsReverse(pRead):
+                        TCR_sb += 1
+                    else:
+                        TCF_sb += 1
+                if Read_IsReverse(pRead):
+                    TCR += 1
+                else:
+                    TCF += 1
+                if variantSupportedByRead(pRead, varBAMMinPos, varBAMMaxPos, variant, exact):
+                    TR += 1
+                    nVarReadsThisSample += 1
+                    if varInGenotype:
+                        TR_ab += 1
+                        if Read_IsReverse(pRead):
+                            NR_sb += 1
+                        else:
+                            NF_sb += 1
+                    if Read_IsReverse(pRead):
+                        NR += 1
+                    else:
+                        NF += 1
+                    if varInGenotype:
+                        windowStart = max(0, varBAMMinPos - pRead.pos - (windowSize-1)//2)
+                        windowEnd = min(pRead.rlen, varBAMMaxPos - pRead.pos + (windowSize-1)//2)
+                        minBaseQualInWindow = 0
+                        for windowIndex in range(windowStart, windowEnd):
+                            if windowIndex == windowStart:
+                                minBaseQualInWindow = pRead.qual[windowIndex]
+                            else:
+                                minBaseQualInWindow = min(minBaseQualInWindow, pRead.qual[windowIndex])
+                        listOfMinBaseQuals.append(minBaseQualInWindow)
+            nReadsPerSample.append(nReadsThisSample)
+            nVarReadsPerSample.append(nVarReadsThisSample)
+        out.append(dict(counts=[TC, TC_bad, TR, TC_ab, TR_ab, NR_sb, NF_sb, TCR, TCF, TCR_sb, TCF_sb, NR, NF, nGoodReads, nBadReads, RMSMQ],
+                        n_reads=nReadsPerSample, n_var_reads=nVarReadsPerSample, min_quals=listOfMinBaseQuals))
+    for arrs in built:
+        for ptrs in arrs:
+            for pp in ptrs:
+                pRead = <cAlignedRead*><size_t>pp
+                free(pRead.cigarOps)
+                free(pRead)
+    return out
+"""
+
 FILT_TAIL = r"""
 def filtered_haplotypes(bytes chrom, int windowStart, int windowEnd, FastaFile refFile, options, list variants, list samples):
     # samples: per individual the list of good reads (seq, qual, pos, end, mapq, bitFlag); returns the variant-index tuples of
@@ -703,6 +801,10 @@ def build_scratch(scratch):
     assert var[746].lstrip().startswith("cdef list getCandidates") and var[260].lstrip().startswith("cdef void addVariant")
     # (Python-2-only expressions adapted: bytes.count('N') at variant.pyx:652,672 -> count(b'N'))
     assert "insertedSequence.count('N')" in var[651] and 'deletedSequence.count("N")' in var[671]
+    # + read statistics of the VCF INFO field: readOverlapsVariant, readQualIsGoodVariantPosition, variantSupportedByRead
+    # (vcfutils.pyx:901-943,961-1072) with the CIGAR constants (:59-67)
+    assert vcu[58].startswith("cdef int CIGAR_M") and vcu[66].startswith("cdef int CIGAR_X") and vcu[900].startswith("cdef int readOverlapsVariant")
+    assert vcu[946].startswith("cdef int overlap") and vcu[960].startswith("cdef int variantSupportedByRead") and vcu[1071].strip() == "return False"
     assert utl[734].startswith("cdef int isHaplotypeValid") and vfl[236].startswith("cdef double computeBestScoreForGenotype")
     assert vfl[376].startswith("cdef list getFilteredHaplotypes") and vfl[507].startswith("#####") and vfl[282].lstrip().startswith("return bestScoreThisHap")
     # + read QC / trimming: checkAndTrimRead (cwindow.pyx:332-481) with its filter-type constants (:40-46) and the BAM flag
@@ -720,7 +822,8 @@ def build_scratch(scratch):
            + "\n".join(chp[396:449]).replace("bytes(''.join(bitsOfMutatedSeq))", "b''.join(bitsOfMutatedSeq)") + "\n" + GENO2_CLASS + "\n" + "\n".join(utl[734:802]) + "\n\n" + "\n".join(vfl[236:283]) + "\n\n"
            + "\n".join(vfl[376:506]) + "\n"
            + "cdef class VariantCandidateGenerator:\n" + "\n".join(vpx[44:73]) + "\n" + "\n".join(var[462:751]).replace("insertedSequence.count('N')", "insertedSequence.count(b'N')").replace('deletedSequence.count("N")', "deletedSequence.count(b'N')") + "\n"
-           + qc_text + HAP_TAIL + FILT_TAIL + CAND_TAIL + QC_TAIL)
+           + qc_text + "\n".join(vcu[58:67]) + "\n\n" + "\n".join(vcu[900:944]) + "\n\n" + "\n".join(vcu[960:1073]) + "\n"
+           + HAP_TAIL + FILT_TAIL + CAND_TAIL + QC_TAIL + INFO_TAIL)
     open(os.path.join(scratch, "hap_drv.pyx"), "w").write(drv)
     open(os.path.join(scratch, "setup.py"), "w").write(SETUP)
     r = subprocess.run([sys.executable, "setup.py", "build_ext", "--inplace"], cwd=scratch,
@@ -1309,6 +1412,90 @@ def gen_readqc(out):
     print("readqc: %d streams, %d reads, %d rejected" % (len(cases), sum(len(c["reads"]) for c in cases), sum(len(c["ok"]) - sum(c["ok"]) for c in cases)))
 
 
+def gen_infostats(out):
+    """Read statistics of the VCF INFO field: the reference's readOverlapsVariant / readQualIsGoodVariantPosition /
+    variantSupportedByRead (vcfutils.pyx:901-943,961-1072) driven by a loop that mirrors vcfINFO (:1300-1390)."""
+    import hap_drv
+    rng = np.random.default_rng(1357)
+    cases = []
+    for ci in range(24):
+        n = 3000
+        ref = rnd(rng, n)
+        L = int(rng.choice([100, 150]))
+        nInd = int(rng.integers(1, 4))
+        # variants: SNPs, MNPs, insertions, deletions in [1200, 1800)
+        vs = []
+        for p_ in sorted(set(int(x) for x in rng.integers(1200, 1800, int(rng.integers(2, 8))))):
+            t = rng.random()
+            if t < 0.5:
+                rem = ref[p_:p_ + 1]; add = bytes([B[(B.index(rem[0]) + 1) % 4]])
+            elif t < 0.6:
+                rem = ref[p_:p_ + 2]; add = bytes([B[(B.index(c_) + 2) % 4] for c_ in rem])
+            elif t < 0.8:
+                rem = b""; add = rnd(rng, int(rng.integers(1, 6)))
+            else:
+                rem = ref[p_ + 1:p_ + 1 + int(rng.integers(1, 6))]; add = b""
+            vs.append((p_, rem, add))
+        variants = [hap_drv.Variant(b"20", p_, r, a, 1, 1) for p_, r, a in vs]
+        samples, samples_rec = [], []
+        for i in range(nInd):
+            good, bad = [], []
+            for r in range(int(rng.integers(20, 90))):
+                p0 = int(rng.integers(1100, 1850))
+                carry = [v for v in vs if rng.random() < 0.4]
+                seq, cig, rp = bytearray(), [], p0
+                def push(op, ln):
+                    if ln > 0:
+                        if cig and cig[-1][0] == op:
+                            cig[-1] = (op, cig[-1][1] + ln)
+                        else:
+                            cig.append((op, ln))
+                if rng.random() < 0.1:
+                    k = int(rng.integers(1, 8)); seq += rnd(rng, k); push(4, k)
+                while len(seq) < L:
+                    nxt = [v for v in carry if v[0] >= rp]
+                    v = min(nxt, key=lambda x: x[0]) if nxt else None
+                    if v is None or v[0] - rp >= L - len(seq):
+                        k = L - len(seq); seq += ref[rp:rp + k]; push(0, k); rp += k
+                        break
+                    p_, rem, add = v
+                    if len(rem) == len(add):
+                        k = p_ - rp; seq += ref[rp:rp + k] + add; push(0, k + len(add)); rp = p_ + len(add)
+                    elif len(rem) == 0:
+                        k = p_ - rp + 1; seq += ref[rp:rp + k]; push(0, k); seq += add; push(1, len(add)); rp = p_ + 1
+                    else:
+                        k = p_ - rp + 1; seq += ref[rp:rp + k]; push(0, k); push(2, len(rem)); rp = p_ + 1 + len(rem)
+                    carry = [x for x in carry if x[0] > p_]
+                seq = seq[:L + 12]
+                # re-cut the CIGAR to the final read length
+                tot, cg = 0, []
+                for op, ln in cig:
+                    if op in (0, 1, 4):
+                        ln = min(ln, len(seq) - tot); tot += ln
+                    if ln > 0:
+                        cg.append((op, ln))
+                while cg and cg[-1][0] == 2:
+                    cg.pop()
+                q = np.clip(rng.normal(30, 10, len(seq)), 0, 60).astype(np.uint8)
+                refspan = sum(ln for op, ln in cg if op in (0, 2))
+                lead = cg[0][1] if cg[0][0] == 4 else 0
+                rec = dict(seq=bytes(seq).decode(), qual=q.tolist(), pos=p0 - lead, end=p0 + refspan, mapq=int(rng.choice([60, 60, 40, 25])),
+                           flag=(16 if rng.random() < 0.5 else 0) | 3, cigar=[list(c) for c in cg])
+                (bad if rng.random() < 0.15 else good).append(rec)
+            tup = lambda r: (r["seq"].encode(), bytes(r["qual"]), r["pos"], r["end"], r["mapq"], r["flag"], [tuple(c) for c in r["cigar"]])
+            samples.append(([tup(r) for r in good], [tup(r) for r in bad]))
+            samples_rec.append(dict(good=good, bad=bad))
+        vig = [[int(rng.random() < 0.6) for _ in range(nInd)] for _ in variants]
+        exact = ci % 2
+        brw = int(rng.choice([11, 11, 7])) if ci % 3 else 11
+        res = hap_drv.variant_read_stats(variants, samples, vig, 20, brw, exact)
+        cases.append(dict(variants=[dict(pos=p_, removed=r.decode(), added=a.decode()) for p_, r, a in vs], samples=samples_rec,
+                          var_in_genotype=vig, exact=exact, bad_reads_window=brw, results=res))
+    with gzip.open(os.path.join(out, "infostats_cases.json.gz"), "wt") as f:
+        json.dump(cases, f)
+    print("infostats: %d windows, %d variants" % (len(cases), sum(len(c["variants"]) for c in cases)))
+
+
 def gen_population(out):
     """a11/a12 + SURVEY 8(f) rank 1: per-read log-likelihood arrays -> genotype log-likelihoods (calculateDataLikelihood),
     rescaled likelihoods (the loop at cpopulation.pyx:283-309, mirrored here around the compiled method), EM haplotype
@@ -1398,7 +1585,7 @@ def main():
         sys.exit("reference tree not found at %s: golden vectors can only be regenerated in the build container" % REF)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     build_scratch(a.scratch)
-    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq", "candidates", "readqc"]
+    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq", "candidates", "readqc", "infostats"]
     if "dp" in todo:
         gen_dp(HERE)
     if "mapalign" in todo:
@@ -1417,6 +1604,8 @@ def main():
         gen_candidates(HERE)
     if "readqc" in todo:
         gen_readqc(HERE)
+    if "infostats" in todo:
+        gen_infostats(HERE)
 
 
 if __name__ == "__main__":

@@ -277,3 +277,24 @@ def test_check_and_trim_matches_reference_golden(oracle, golden_dir):
             if c["counts"][k] != -1:
                 assert counts[k] == c["counts"][k]
     assert trimmed > 500
+
+
+# ---- read statistics of the VCF INFO field, pinned by the reference's own leaf functions ------------------------------------
+def infostats_inputs(c):
+    variants = [dict(pos=v["pos"], removed=v["removed"].encode(), added=v["added"].encode(), bam_min=v["pos"], bam_max=v["pos"]) for v in c["variants"]]
+    conv = lambda r: dict(seq=r["seq"].encode(), qual=bytes(r["qual"]), pos=r["pos"], end=r["end"], mapq=r["mapq"], flag=r["flag"], cigar=r["cigar"])
+    samples = [dict(good=[conv(r) for r in s_["good"]], bad=[conv(r) for r in s_["bad"]]) for s_ in c["samples"]]
+    return variants, samples
+
+
+def test_variant_read_stats_match_reference_golden(oracle, golden_dir):
+    import gzip, json
+    cases = json.load(gzip.open(os.path.join(golden_dir, "infostats_cases.json.gz"), "rt"))
+    nsup = 0
+    for c in cases:
+        variants, samples = infostats_inputs(c)
+        res = oracle.variant_read_stats(variants, samples, c["var_in_genotype"], 20, c["bad_reads_window"], c["exact"])
+        for (counts, nr, nvr, mq), exp in zip(res, c["results"]):
+            assert counts == exp["counts"] and nr == exp["n_reads"] and nvr == exp["n_var_reads"] and mq == exp["min_quals"]
+            nsup += counts[2]
+    assert nsup > 400
