@@ -316,6 +316,51 @@ typedef struct plat_readqc_options {
 int plat_read_qc_batch(plat_ctx* ctx, const plat_readqc_batch* batch, const plat_readqc_options* options,
                        int32_t* out_ok, int32_t* out_reason, void* stream);
 
+/* ---- read statistics of the VCF INFO field ---------------------------------------
+ * Replaces the per-variant loop over a window's reads in  cdef dict vcfINFO(...)   vcfutils.pyx:1300-1390
+ * (readOverlapsVariant :901-913, readQualIsGoodVariantPosition :917-943, variantSupportedByRead :961-1072).
+ * Variant v lies in window var_window[v]; sample i of window w owns the good reads
+ * [good_begin[w*n_ind+i], good_end[..]) and the bad reads [bad_begin[..], bad_end[..]) of one read table
+ * (bases, raw phred qualities, pos, end, mapq, bitFlag, CIGAR pairs); var_in_genotype[v*n_ind+i] =
+ * `variant in genotypeCalls[i]`; the added bases of v at var_added[var_added_off[v] ..+var_n_added[v]).
+ * Options: badReadsWindow (runner.py: 11), countOnlyExactIndelMatches (0).
+ * Output: out_counts[16*v + k]: 0 TC, 1 TC_bad, 2 TR, 3 TC_ab, 4 TR_ab, 5 NR_sb, 6 NF_sb, 7 TCR, 8 TCF,
+ * 9 TCR_sb, 10 TCF_sb, 11 NR, 12 NF, 13 nGoodReads, 14 nBadReads, 15 sum of mapq^2 (the reference keeps this
+ * sum in a float: identical below 2^24); out_per_sample[(v*n_ind+i)*2 + {0,1}] = nReadsThisSample,
+ * nVarReadsThisSample; out_minq[minq_off[v] + k], k < out_nminq[v]: the MMLQ window minima in read order
+ * (room for the window's good reads).  The INFO values follow by arithmetic the caller keeps
+ * (MQ = sqrt(sum/(TC+TC_bad)), BRF, MMLQ = median, ABPV / SbPval from the _ab / _sb counts).      */
+typedef struct plat_infostats_batch {
+    int32_t n_vars, n_ind;
+    const int32_t* var_window;       /* [n_vars] */
+    const int32_t* var_pos;          /* Variant.refPos */
+    const int32_t* var_bam_min;      /* Variant.bamMinPos */
+    const int32_t* var_bam_max;      /* Variant.bamMaxPos */
+    const int32_t* var_n_added;
+    const int32_t* var_n_removed;
+    const uint8_t* var_added;
+    const int64_t* var_added_off;    /* [n_vars] */
+    const uint8_t* var_in_genotype;  /* [n_vars*n_ind] */
+    const int64_t* minq_off;         /* [n_vars] */
+    const int32_t* good_begin;       /* [n_windows*n_ind] */
+    const int32_t* good_end;
+    const int32_t* bad_begin;
+    const int32_t* bad_end;
+    const uint8_t* read_seq;
+    const uint8_t* read_qual;
+    const int64_t* read_off;         /* [n_reads+1] */
+    const int32_t* read_pos;
+    const int32_t* read_end;
+    const uint8_t* read_mapq;
+    const int32_t* read_flags;
+    const int16_t* cigar;
+    const int32_t* cig_off;          /* [n_reads+1] */
+} plat_infostats_batch;
+
+int plat_variant_read_stats_batch(plat_ctx* ctx, const plat_infostats_batch* batch, int bad_reads_window,
+                                  int count_only_exact_indel_matches, int64_t* out_counts, int32_t* out_per_sample,
+                                  int32_t* out_minq, int32_t* out_nminq, void* stream);
+
 /* ---- a14..a18: assembleReadsAndDetectVariants ---------------------------------------------------
  * Replaces  cdef list assembleReadsAndDetectVariants(chrom, assemStart, assemEnd, refStart, refEnd,
  *                                                    readBuffers, refSeq, options)

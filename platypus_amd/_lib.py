@@ -82,6 +82,13 @@ class ReadQCOptions(C.Structure):
                                          "filter_small_insert", "filter_duplicates")]
 
 
+class InfoStatsBatch(C.Structure):
+    _fields_ = [("n_vars", C.c_int32), ("n_ind", C.c_int32)] + [(k, C.c_void_p) for k in (
+        "var_window", "var_pos", "var_bam_min", "var_bam_max", "var_n_added", "var_n_removed", "var_added", "var_added_off",
+        "var_in_genotype", "minq_off", "good_begin", "good_end", "bad_begin", "bad_end", "read_seq", "read_qual", "read_off",
+        "read_pos", "read_end", "read_mapq", "read_flags", "cigar", "cig_off")]
+
+
 # symbol -> (restype, argtypes): exactly the declarations of include/platypus_mi355x.h
 SIGNATURES = {
     "plat_abi_version": (C.c_int, []),
@@ -115,6 +122,8 @@ SIGNATURES = {
     "plat_candidates_batch": (C.c_int, [C.c_void_p, C.POINTER(CandidateBatch), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_read_qc_batch": (C.c_int, [C.c_void_p, C.POINTER(ReadQCBatch), C.POINTER(ReadQCOptions), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "plat_variant_read_stats_batch": (C.c_int, [C.c_void_p, C.POINTER(InfoStatsBatch), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_assemble_batch": (C.c_int, [C.c_void_p, C.POINTER(AssemblyBatch), C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -221,3 +221,158 @@ PLAT_EXPORT int plat_read_qc_batch(plat_ctx* ctx, const plat_readqc_batch* batch
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Read statistics of the VCF INFO field: vcfINFO's loop over the reads of a window
+// (vcfutils.pyx:1300-1390) with readOverlapsVariant (:901-913), readQualIsGoodVariantPosition (:917-943) and
+// variantSupportedByRead (:961-1072).  One wave per variant; lanes over the reads of one sample at a time; every count is a
+// ballot popcount, the MMLQ window minima are written in read order (prefix popcount).
+namespace plat {
+
+__device__ __forceinline__ bool qual_good_at(const int8_t* q, int rlen, int readPos, int vmin, int vmax) {
+    int a = max(0, min(rlen, vmin - readPos)), e = max(0, min(rlen, vmax - readPos));
+    for (int i = a; i < e; ++i) if (q[i] < 5) return false;
+    return true;
+}
+
+__device__ __forceinline__ bool bytes_equal(const uint8_t* a, const uint8_t* b, int n) {
+    for (int i = 0; i < n; ++i) if (a[i] != b[i]) return false;
+    return true;
+}
+
+__device__ __forceinline__ bool read_supports(const uint8_t* seq, int rlen, int readStart, const int16_t* ops, int ncig, int varPos,
+                                              int nAdded, int nRemoved, const uint8_t* added, int exact)
+{
+    int refOffset = 0, readOffset = 0;
+    for (int ci = 0; ci < ncig; ++ci) {
+        const int flag = ops[2 * ci], length = ops[2 * ci + 1];
+        if (flag == 1) {                                                     // insertion, :984-1003
+            if (nAdded != nRemoved) {
+                if (!exact) return true;
+                if (nAdded - nRemoved == length && readOffset + nAdded <= rlen && bytes_equal(seq + readOffset, added, nAdded)) return true;
+                return false;
+            }
+            readOffset += length;
+        } else if (flag == 2) {                                              // deletion, :1005-1024
+            if (nAdded != nRemoved) return exact ? (nRemoved - nAdded == length) : true;
+            refOffset += length;
+        } else if (flag == 0 || flag == 7 || flag == 8) {                    // M, =, X, :1027-1048
+            const int start = varPos - readStart + readOffset - refOffset;
+            if (refOffset + readStart <= varPos && refOffset + readStart + length > varPos && nAdded == nRemoved &&
+                start >= 0 && start + nAdded <= rlen && bytes_equal(seq + start, added, nAdded))
+                return true;
+            readOffset += length;
+            refOffset += length;
+        } else if (flag == 3) {                                              // N: the reference advances both, :1051-1053
+            readOffset += length;
+            refOffset += length;
+        } else if (flag == 4) {
+            readOffset += length;
+            if (ci == 0) refOffset += length;
+        }
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(64)
+k_variant_read_stats(plat_infostats_batch b, int bad_reads_window, int exact, int64_t* __restrict__ out, int32_t* __restrict__ per_sample,
+                     int32_t* __restrict__ minq, int32_t* __restrict__ nminq)
+{
+    const int v = blockIdx.x, lane = threadIdx.x;
+    const int w = b.var_window[v];
+    const int vmin = b.var_bam_min[v], vmax = b.var_bam_max[v], varPos = b.var_pos[v];
+    const int nAdded = b.var_n_added[v], nRemoved = b.var_n_removed[v];
+    const uint8_t* added = b.var_added + b.var_added_off[v];
+    int32_t* mq = minq + b.minq_off[v];
+    long long c[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c[k] = 0;
+    int nmq = 0;
+    const int half = (bad_reads_window - 1) / 2;
+    for (int i = 0; i < b.n_ind; ++i) {
+        const long long seg = (long long)w * b.n_ind + i;
+        const bool inGt = b.var_in_genotype[(long long)v * b.n_ind + i] != 0;
+        const int gb = b.good_begin[seg], ge = b.good_end[seg], bb = b.bad_begin[seg], be = b.bad_end[seg];
+        c[13] += ge - gb; c[14] += be - bb;
+        for (int r0 = bb; r0 < be; r0 += 64) {                               // bad reads: coverage and mapping quality only
+            const int r = r0 + lane;
+            bool hit = false; long long m2 = 0;
+            if (r < be) {
+                const int rlen = (int)(b.read_off[r + 1] - b.read_off[r]);
+                hit = b.read_pos[r] <= vmax && b.read_end[r] > vmin &&
+                      qual_good_at((const int8_t*)b.read_qual + b.read_off[r], rlen, b.read_pos[r], vmin, vmax);
+                if (hit) m2 = (long long)b.read_mapq[r] * b.read_mapq[r];
+            }
+            c[1] += __popcll(__ballot(hit));
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) m2 += __shfl_xor(m2, s);
+            c[15] += m2;
+        }
+        int nReads = 0, nVarReads = 0;
+        for (int r0 = gb; r0 < ge; r0 += 64) {
+            const int r = r0 + lane;
+            bool hit = false, rev = false, sup = false; long long m2 = 0; int wmin = 0;
+            if (r < ge) {
+                const long long so = b.read_off[r];
+                const int rlen = (int)(b.read_off[r + 1] - so);
+                const int8_t* q = (const int8_t*)b.read_qual + so;
+                const int rp = b.read_pos[r];
+                hit = rp <= vmax && b.read_end[r] > vmin && qual_good_at(q, rlen, rp, vmin, vmax);
+                if (hit) {
+                    rev = (b.read_flags[r] & 16) != 0;
+                    m2 = (long long)b.read_mapq[r] * b.read_mapq[r];
+                    sup = read_supports(b.read_seq + so, rlen, rp, b.cigar + 2ll * b.cig_off[r], b.cig_off[r + 1] - b.cig_off[r], varPos,
+                                        nAdded, nRemoved, added, exact);
+                    if (sup && inGt) {                                       // MMLQ window, :1372-1383
+                        const int ws = max(0, vmin - rp - half), we = min(rlen, vmax - rp + half);
+                        for (int k = ws; k < we; ++k) wmin = (k == ws) ? (int)q[k] : min(wmin, (int)q[k]);
+                    }
+                }
+            }
+            const unsigned long long mh = __ballot(hit), mr = __ballot(hit && rev), ms = __ballot(sup), msr = __ballot(sup && rev);
+            const int nh = __popcll(mh), nhr = __popcll(mr), ns = __popcll(ms), nsr = __popcll(msr);
+            nReads += nh; c[0] += nh; c[7] += nhr; c[8] += nh - nhr;
+            c[2] += ns; nVarReads += ns; c[11] += nsr; c[12] += ns - nsr;
+            if (inGt) {
+                c[3] += nh; c[9] += nhr; c[10] += nh - nhr;
+                c[4] += ns; c[5] += nsr; c[6] += ns - nsr;
+                if (sup) mq[nmq + __popcll(ms & ((1ull << lane) - 1ull))] = wmin;
+                nmq += ns;
+            }
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) m2 += __shfl_xor(m2, s);
+            c[15] += m2;
+        }
+        if (lane == 0) {
+            per_sample[((long long)v * b.n_ind + i) * 2] = nReads;
+            per_sample[((long long)v * b.n_ind + i) * 2 + 1] = nVarReads;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) out[16ll * v + k] = c[k];
+        nminq[v] = nmq;
+    }
+}
+
+}  // namespace plat
+
+PLAT_EXPORT int plat_variant_read_stats_batch(plat_ctx* ctx, const plat_infostats_batch* batch, int bad_reads_window,
+                                              int count_only_exact_indel_matches, int64_t* out_counts, int32_t* out_per_sample,
+                                              int32_t* out_minq, int32_t* out_nminq, void* stream)
+{
+    if (!ctx || !batch || bad_reads_window < 1) return PLAT_ERR_INVALID;
+    const plat_infostats_batch b = *batch;
+    if (b.n_vars < 0 || b.n_ind < 1) return PLAT_ERR_INVALID;
+    if (b.n_vars == 0) return PLAT_OK;
+    if (!b.var_window || !b.var_pos || !b.var_bam_min || !b.var_bam_max || !b.var_n_added || !b.var_n_removed || !b.var_added ||
+        !b.var_added_off || !b.var_in_genotype || !b.minq_off || !b.good_begin || !b.good_end || !b.bad_begin || !b.bad_end ||
+        !b.read_seq || !b.read_qual || !b.read_off || !b.read_pos || !b.read_end || !b.read_mapq || !b.read_flags || !b.cigar ||
+        !b.cig_off || !out_counts || !out_per_sample || !out_minq || !out_nminq)
+        return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(plat::k_variant_read_stats, dim3(b.n_vars), dim3(64), 0, (hipStream_t)stream, b, bad_reads_window,
+                       count_only_exact_indel_matches, out_counts, out_per_sample, out_minq, out_nminq);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}

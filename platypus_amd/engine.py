@@ -350,6 +350,64 @@ class Engine:
             a = e
         return out
 
+    # ---- read statistics of the VCF INFO field --------------------------------------------
+    def variant_read_stats(self, windows, bad_reads_window=11, exact=0):
+        """vcfINFO's per-read loop for a list of windows.  A window: dict {variants: [dict(pos, removed, added, bam_min,
+        bam_max)], samples: [dict(good=[reads], bad=[reads])], var_in_genotype: [nVars][nInd]}; a read = dict(seq, qual, pos, end,
+        mapq, flag, cigar).  All windows must have the same number of samples.  Returns per window a list over its variants of
+        (counts[16], n_reads[nInd], n_var_reads[nInd], min_quals)."""
+        torch = _torch()
+        nI = len(windows[0]["samples"]) if windows else 0
+        reads, gb, ge, bb, be, vw, vars_, vig, moff = [], [], [], [], [], [], [], [], []
+        mtot = 0
+        for w, win in enumerate(windows):
+            assert len(win["samples"]) == nI
+            ngood = 0
+            for s_ in win["samples"]:
+                gb.append(len(reads)); reads += s_["good"]; ge.append(len(reads)); ngood += len(s_["good"])
+                bb.append(len(reads)); reads += s_["bad"]; be.append(len(reads))
+            for k, v in enumerate(win["variants"]):
+                vw.append(w); vars_.append(v); vig.append(win["var_in_genotype"][k]); moff.append(mtot); mtot += max(ngood, 1)
+        nV = len(vars_)
+        if nV == 0:
+            return [[] for _ in windows]
+
+        def dev(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.device)
+        blob = lambda parts: dev(pad_blob(np.frombuffer(b"".join(parts), dtype=np.uint8)), np.uint8)
+        nadd = [len(v["added"]) for v in vars_]
+        t = dict(vw=dev(vw, np.int32), vpos=dev([v["pos"] for v in vars_], np.int32), vmin=dev([v["bam_min"] for v in vars_], np.int32),
+                 vmax=dev([v["bam_max"] for v in vars_], np.int32), nadd=dev(nadd, np.int32),
+                 nrem=dev([len(v["removed"]) for v in vars_], np.int32), added=blob([v["added"] for v in vars_]),
+                 aoff=dev(np.concatenate([[0], np.cumsum(nadd)[:-1]]), np.int64), vig=dev(np.asarray(vig, dtype=np.uint8).reshape(-1), np.uint8),
+                 moff=dev(moff, np.int64), gb=dev(gb, np.int32), ge=dev(ge, np.int32), bb=dev(bb, np.int32), be=dev(be, np.int32),
+                 seq=blob([r["seq"] for r in reads]), qual=blob([r["qual"] for r in reads]),
+                 off=dev(np.concatenate([[0], np.cumsum([len(r["seq"]) for r in reads])]), np.int64),
+                 pos=dev([r["pos"] for r in reads], np.int32), end=dev([r["end"] for r in reads], np.int32),
+                 mapq=dev([r["mapq"] for r in reads], np.uint8), flags=dev([r["flag"] for r in reads], np.int32),
+                 cig=dev([x for r in reads for c in r["cigar"] for x in c] + [0, 0], np.int16),
+                 coff=dev(np.concatenate([[0], np.cumsum([len(r["cigar"]) for r in reads])]), np.int32))
+        b = _lib.InfoStatsBatch()
+        b.n_vars, b.n_ind = nV, nI
+        for name, key in (("var_window", "vw"), ("var_pos", "vpos"), ("var_bam_min", "vmin"), ("var_bam_max", "vmax"), ("var_n_added", "nadd"),
+                          ("var_n_removed", "nrem"), ("var_added", "added"), ("var_added_off", "aoff"), ("var_in_genotype", "vig"),
+                          ("minq_off", "moff"), ("good_begin", "gb"), ("good_end", "ge"), ("bad_begin", "bb"), ("bad_end", "be"),
+                          ("read_seq", "seq"), ("read_qual", "qual"), ("read_off", "off"), ("read_pos", "pos"), ("read_end", "end"),
+                          ("read_mapq", "mapq"), ("read_flags", "flags"), ("cigar", "cig"), ("cig_off", "coff")):
+            setattr(b, name, t[key].data_ptr())
+        out = torch.empty(nV * 16, dtype=torch.int64, device=self.device)
+        ps = torch.empty(nV * nI * 2, dtype=torch.int32, device=self.device)
+        mq = torch.empty(max(mtot, 1), dtype=torch.int32, device=self.device)
+        nmq = torch.empty(nV, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.plat_variant_read_stats_batch(self.ctx, C.byref(b), bad_reads_window, exact, out.data_ptr(), ps.data_ptr(),
+                                                          mq.data_ptr(), nmq.data_ptr(), self._stream()), "plat_variant_read_stats_batch")
+        torch.cuda.synchronize(self.device)
+        out_h, ps_h, mq_h, nmq_h = out.cpu().numpy().reshape(nV, 16), ps.cpu().numpy().reshape(nV, nI, 2), mq.cpu().numpy(), nmq.cpu().numpy()
+        res = [[] for _ in windows]
+        for v in range(nV):
+            res[vw[v]].append((out_h[v].tolist(), ps_h[v, :, 0].tolist(), ps_h[v, :, 1].tolist(), mq_h[moff[v]:moff[v] + nmq_h[v]].tolist()))
+        return res
+
     # ---- a14..a18 ------------------------------------------------------------------------------------
     def assemble(self, regions, kmer_size=15, min_qual=20, min_weight=40, no_cycles=0, max_vars=512,
                  blob_per_region=1 << 16):

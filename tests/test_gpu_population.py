@@ -122,3 +122,25 @@ def test_population_path_end_to_end_vs_oracle(eng, oracle):
         assert c.tolist() == calls[w].tolist()
         live = np.asarray(nr) > 0
         assert np.array_equal(e[live], em[hb.gl_off[w]:hb.gl_off[w] + hb.n_ind * G].reshape(hb.n_ind, G)[live])
+
+
+def test_variant_read_stats_match_reference_golden(eng, golden_dir):
+    """SURVEY 8(f) rank 3 (INFO read statistics): coverage / support / strand counts, per-sample counts and the MMLQ window minima
+    per variant, against the reference's own leaf functions driven as vcfINFO drives them."""
+    cases = json.load(gzip.open(os.path.join(golden_dir, "infostats_cases.json.gz"), "rt"))
+    conv = lambda r: dict(seq=r["seq"].encode(), qual=bytes(r["qual"]), pos=r["pos"], end=r["end"], mapq=r["mapq"], flag=r["flag"], cigar=r["cigar"])
+    groups = collections.defaultdict(list)
+    for c in cases:
+        groups[(len(c["samples"]), c["bad_reads_window"], c["exact"])].append(c)
+    nsup = 0
+    for (nI, brw, exact), cs in groups.items():
+        wins = [dict(variants=[dict(pos=v["pos"], removed=v["removed"].encode(), added=v["added"].encode(), bam_min=v["pos"], bam_max=v["pos"])
+                               for v in c["variants"]],
+                     samples=[dict(good=[conv(r) for r in s_["good"]], bad=[conv(r) for r in s_["bad"]]) for s_ in c["samples"]],
+                     var_in_genotype=c["var_in_genotype"]) for c in cs]
+        res = eng.variant_read_stats(wins, brw, exact)
+        for c, rw in zip(cs, res):
+            for (counts, nr, nvr, mq), exp in zip(rw, c["results"]):
+                assert counts == exp["counts"] and nr == exp["n_reads"] and nvr == exp["n_var_reads"] and mq == exp["min_quals"]
+                nsup += counts[2]
+    assert nsup > 400
