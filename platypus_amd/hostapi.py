@@ -567,6 +567,89 @@ def mergeHaplotypes(haplotypes, refFile=None):
         merged.append(last)
     return merged
 
+# ---- the INFO arithmetic on top of the device's read statistics ------------------------------------------
+def logFactorial(x):                                                                                  # platypusutils.pyx:178-191
+    import math
+    if x < 15:
+        ans = 0.0
+        for i in range(1, x + 1):
+            ans += math.log(i)
+        return ans
+    y = float(x)
+    return (y * math.log(y) + math.log(2.0 * math.pi * y) / 2 - y + (pow(y, -1)) / 12 - (pow(y, -3)) / 360 + (pow(y, -5)) / 1260
+            - (pow(y, -7)) / 1680 + (pow(y, -9)) / 1188)
+
+
+def logBetaFunction(x, y):                                                                            # :213-218
+    return (logFactorial(x - 1) + logFactorial(y - 1)) - logFactorial(x + y - 1)
+
+
+def threeFTwo(k, n, alpha, beta):                                                                     # :267-295
+    a_2, a_3, b_1, b_2 = alpha + k + 1.0, k - n + 1.0, k + 2.0, -beta - n + k + 2.0
+    theSum = lastTerm = 1.0
+    for i in range(1, abs(k - n + 1) + 1):
+        newTerm = lastTerm * (a_2 + i - 1) * (a_3 + i - 1) / ((b_1 + i - 1) * (b_2 + i - 1))
+        theSum += newTerm
+        lastTerm = newTerm
+    return theSum
+
+
+def betaBinomialCDF(k, n, alpha, beta):                                                               # :306-315
+    import math
+    if k == n:
+        return 1.0
+    numerator = logBetaFunction(beta + n - k - 1, alpha + k + 1) + math.log(threeFTwo(k, n, alpha, beta))
+    denominator = logBetaFunction(alpha, beta) + logBetaFunction(n - k, k + 2) + math.log(n + 1)
+    return max(1e-30, 1.0 - math.exp(numerator - denominator))
+
+
+def computeAlleleBiasPValue(totalReads, variantReads):                                                # vcfutils.pyx:1156-1173
+    if totalReads > 0 and float(variantReads) / float(totalReads) >= 0.5:
+        return 1.0
+    if totalReads == 0:
+        return 1.0
+    pValue = betaBinomialCDF(variantReads, totalReads, 20, 20)
+    return min(pValue, 1.0 - pValue)
+
+
+def computeStrandBiasPValue(nFwdReads, nRevReads, nFwdVarReads, nRevVarReads):                        # vcfutils.pyx:1177-1222
+    if nFwdReads == 0 or nRevReads == 0:
+        return 1.0
+    useForward = not (nFwdReads < nRevReads)
+    if nFwdReads + nRevReads > 0 and nFwdVarReads + nRevVarReads > 0:
+        freq = float(nFwdReads if useForward else nRevReads) / float(nFwdReads + nRevReads)
+        if freq < 0.5:
+            alpha = 20
+            beta = int(float(alpha) / freq - alpha)
+        elif freq > 0.5:
+            beta = 20
+            alpha = int(beta * freq / (1.0 - freq))
+        else:
+            alpha = beta = 20
+        return betaBinomialCDF(nFwdVarReads if useForward else nRevVarReads, nFwdVarReads + nRevVarReads, alpha, beta)
+    return 1.0
+
+
+def _round2(x):
+    """Python 2's round(x, 2) (the reference's interpreter): correctly rounded on the exact binary value, ties away from zero."""
+    from decimal import Decimal, ROUND_HALF_UP
+    return float(Decimal(x).quantize(Decimal("0.01"), rounding=ROUND_HALF_UP))
+
+
+def infoFieldsFromReadStats(counts, nReadsPerSample, nVarReadsPerSample, minBaseQuals):
+    """The INFO fields vcfINFO derives from its per-read loop (vcfutils.pyx:1392-1440), from the counters of
+    plat_variant_read_stats_batch (Engine.variant_read_stats)."""
+    import math
+    TC, TC_bad, TR, TC_ab, TR_ab, NR_sb, NF_sb, TCR, TCF, TCR_sb, TCF_sb, NR, NF, nGood, nBad, sumsq = counts
+    info = dict(ABPV=[_round2(computeAlleleBiasPValue(TC_ab, TR_ab))], SbPval=[_round2(computeStrandBiasPValue(TCF_sb, TCR_sb, NF_sb, NR_sb))],
+                TR=[TR], NF=[NF], NR=[NR], BRF=[_round2(nBad / float(nGood + nBad))], TC=[TC], TCR=[TCR], TCF=[TCF],
+                nReadsPerSample=list(nReadsPerSample), nVarReadsPerSample=list(nVarReadsPerSample))
+    rms = float(np.float32(sumsq))                                                                    # `cdef float RMSMQ`
+    info["MQ"] = [_round2(math.sqrt(rms / (TC + TC_bad)))] if (TC + TC_bad > 0 and rms > 0) else [0]
+    q = sorted(minBaseQuals)
+    info["MMLQ"] = [q[len(q) // 2]] if q else [100]
+    return info
+
 
 def assembleReadsAndDetectVariants(chrom, assemStart, assemEnd, refStart, refEnd, readBuffers, refSeq, options=None):
     """assembler.pyx:1429-1476; read selection as loadBAMDataIntoGraph (:1391-1425)."""

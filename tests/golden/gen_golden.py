@@ -616,6 +616,14 @@ def variant_read_stats(list variants, list samples, list var_in_genotype, int mi
     return out
 """
 
+PVAL_TAIL = r"""
+def pvalues(int totalReads, int variantReads, int nFwd, int nRev, int nFwdVar, int nRevVar):
+    return computeAlleleBiasPValue(totalReads, variantReads), computeStrandBiasPValue(nFwd, nRev, nFwdVar, nRevVar)
+
+def beta_binomial_cdf(int k, int n, int alpha, int beta):
+    return betaBinomialCDF(k, n, alpha, beta)
+"""
+
 FILT_TAIL = r"""
 def filtered_haplotypes(bytes chrom, int windowStart, int windowEnd, FastaFile refFile, options, list variants, list samples):
     # samples: per individual the list of good reads (seq, qual, pos, end, mapq, bitFlag); returns the variant-index tuples of
@@ -805,6 +813,12 @@ def build_scratch(scratch):
     # (vcfutils.pyx:901-943,961-1072) with the CIGAR constants (:59-67)
     assert vcu[58].startswith("cdef int CIGAR_M") and vcu[66].startswith("cdef int CIGAR_X") and vcu[900].startswith("cdef int readOverlapsVariant")
     assert vcu[946].startswith("cdef int overlap") and vcu[960].startswith("cdef int variantSupportedByRead") and vcu[1071].strip() == "return False"
+    # + the p-values of the INFO field: logFactorial, logBetaFunction, threeFTwo, betaBinomialCDF (platypusutils.pyx:178-193,
+    # 213-218,267-295,306-315), computeAlleleBiasPValue / computeStrandBiasPValue (vcfutils.pyx:1156-1222)
+    assert utl[177].startswith("cdef double logFactorial") and utl[212].startswith("cdef double logBetaFunction") and utl[266].startswith("cdef double threeFTwo")
+    assert utl[192].strip() == "return ans" and utl[218].strip() == "return logNumerator - logDenominator" and utl[293].strip() == "return theSum"
+    assert utl[305].startswith("cdef double betaBinomialCDF") and utl[314].lstrip().startswith("return max(1e-30")
+    assert vcu[1155].startswith("cdef double computeAlleleBiasPValue") and vcu[1176].startswith("cdef double computeStrandBiasPValue") and vcu[1225].startswith("cdef dict vcfINFO")
     assert utl[734].startswith("cdef int isHaplotypeValid") and vfl[236].startswith("cdef double computeBestScoreForGenotype")
     assert vfl[376].startswith("cdef list getFilteredHaplotypes") and vfl[507].startswith("#####") and vfl[282].lstrip().startswith("return bestScoreThisHap")
     # + read QC / trimming: checkAndTrimRead (cwindow.pyx:332-481) with its filter-type constants (:40-46) and the BAM flag
@@ -823,7 +837,9 @@ def build_scratch(scratch):
            + "\n".join(vfl[376:506]) + "\n"
            + "cdef class VariantCandidateGenerator:\n" + "\n".join(vpx[44:73]) + "\n" + "\n".join(var[462:751]).replace("insertedSequence.count('N')", "insertedSequence.count(b'N')").replace('deletedSequence.count("N")', "deletedSequence.count(b'N')") + "\n"
            + qc_text + "\n".join(vcu[58:67]) + "\n\n" + "\n".join(vcu[900:944]) + "\n\n" + "\n".join(vcu[960:1073]) + "\n"
-           + HAP_TAIL + FILT_TAIL + CAND_TAIL + QC_TAIL + INFO_TAIL)
+           + "xrange = range\ncdef double PI = math.pi\n" + "\n".join(utl[177:193]) + "\n\n" + "\n".join(utl[212:219]) + "\n\n"
+           + "\n".join(utl[266:296]) + "\n\n" + "\n".join(utl[305:316]) + "\n\n" + "\n".join(vcu[1155:1223]) + "\n"
+           + HAP_TAIL + FILT_TAIL + CAND_TAIL + QC_TAIL + INFO_TAIL + PVAL_TAIL)
     open(os.path.join(scratch, "hap_drv.pyx"), "w").write(drv)
     open(os.path.join(scratch, "setup.py"), "w").write(SETUP)
     r = subprocess.run([sys.executable, "setup.py", "build_ext", "--inplace"], cwd=scratch,
@@ -1496,6 +1512,30 @@ def gen_infostats(out):
     print("infostats: %d windows, %d variants" % (len(cases), sum(len(c["variants"]) for c in cases)))
 
 
+def gen_pvalues(out):
+    """ABPV / SbPval of the INFO field: computeAlleleBiasPValue, computeStrandBiasPValue and betaBinomialCDF with its helpers
+    (vcfutils.pyx:1156-1222, platypusutils.pyx:178-315), the reference's own texts."""
+    import hap_drv
+    rng = np.random.default_rng(97)
+    ab, sb, bb = [], [], []
+    for _ in range(600):
+        tot = int(rng.choice([0, 1, 2, 5, 14, 15, 16, 30, 60, 200, 1000]))
+        var = int(rng.integers(0, tot + 1)) if tot else 0
+        nf, nr = int(rng.integers(0, 80)), int(rng.integers(0, 80))
+        if rng.random() < 0.1:
+            nf = nr
+        vf, vr = int(rng.integers(0, nf + 1)), int(rng.integers(0, nr + 1))
+        a, s_ = hap_drv.pvalues(tot, var, nf, nr, vf, vr)
+        ab.append([tot, var, a]); sb.append([nf, nr, vf, vr, s_])
+    for _ in range(300):
+        n = int(rng.integers(1, 300)); k = int(rng.integers(0, n + 1))
+        al, be = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+        bb.append([k, n, al, be, hap_drv.beta_binomial_cdf(k, n, al, be)])
+    with gzip.open(os.path.join(out, "pvalue_cases.json.gz"), "wt") as f:
+        json.dump(dict(allele_bias=ab, strand_bias=sb, beta_binomial=bb), f)
+    print("pvalues: %d + %d + %d cases" % (len(ab), len(sb), len(bb)))
+
+
 def gen_population(out):
     """a11/a12 + SURVEY 8(f) rank 1: per-read log-likelihood arrays -> genotype log-likelihoods (calculateDataLikelihood),
     rescaled likelihoods (the loop at cpopulation.pyx:283-309, mirrored here around the compiled method), EM haplotype
@@ -1585,7 +1625,7 @@ def main():
         sys.exit("reference tree not found at %s: golden vectors can only be regenerated in the build container" % REF)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     build_scratch(a.scratch)
-    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq", "candidates", "readqc", "infostats"]
+    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq", "candidates", "readqc", "infostats", "pvalues"]
     if "dp" in todo:
         gen_dp(HERE)
     if "mapalign" in todo:
@@ -1606,6 +1646,8 @@ def main():
         gen_readqc(HERE)
     if "infostats" in todo:
         gen_infostats(HERE)
+    if "pvalues" in todo:
+        gen_pvalues(HERE)
 
 
 if __name__ == "__main__":

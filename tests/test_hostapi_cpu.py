@@ -115,3 +115,19 @@ def test_haplotype_sequence_construction_matches_reference_golden(golden_dir):
         assert h.haplotypeSequence == c["haplotype"].encode(), c["variants"]
         assert (h.startPos, h.endPos, h.endBufferSize) == (c["start_pos"], c["end_pos"], c["end_buffer"])
         assert (h.minVarPos, h.maxVarPos) == (c["min_var_pos"], c["max_var_pos"])
+
+
+def test_info_pvalues_match_reference_golden(golden_dir):
+    """ABPV / SbPval arithmetic (vcfutils.pyx:1156-1222, platypusutils.pyx:178-315): the same doubles as the reference's texts."""
+    import gzip, json, os
+    from platypus_amd import hostapi as H
+    g = json.load(gzip.open(os.path.join(golden_dir, "pvalue_cases.json.gz"), "rt"))
+    for tot, var, exp in g["allele_bias"]:
+        assert H.computeAlleleBiasPValue(tot, var) == exp
+    for nf, nr, vf, vr, exp in g["strand_bias"]:
+        assert H.computeStrandBiasPValue(nf, nr, vf, vr) == exp
+    for k, n, a, b, exp in g["beta_binomial"]:
+        assert H.betaBinomialCDF(k, n, a, b) == exp
+    info = H.infoFieldsFromReadStats([10, 2, 4, 10, 4, 1, 3, 5, 5, 5, 5, 1, 3, 30, 10, 12 * 3600], [10], [4], [30, 12, 25])
+    assert info["BRF"] == [0.25] and info["MQ"] == [60.0] and info["MMLQ"] == [25] and info["TR"] == [4]
+    assert H._round2(0.125) == 0.13 and H._round2(2.675) == 2.67          # Python-2 rounding: ties away from zero, exact binary value
