@@ -247,6 +247,19 @@ int plat_genotype_call_batch(plat_ctx* ctx, int n_sites, int n_ind, const int32_
                              const int64_t* lik_off, int32_t* out_phased, double* out_lik, double* out4,
                              void* stream);
 
+/* ---- the HapScore of the INFO field ----------------------------------------------
+ * Replaces  cdef int computeHaplotypeScore(list genotypes)                 vcfutils.pyx:1076-1114
+ * together with the state it reads: DiploidGenotype.hap1Like / hap2Like, which calculateDataLikelihood resets
+ * and refills on every call (cgenotype.pyx:148-161), so that after Population.setup they hold, per haplotype,
+ * the sum over the reads of the LAST individual with reads of log10E * likelihood (read order, fp64).
+ * Arguments as for plat_genotype_window_batch (loglik = the array written by plat_align_window_batch);
+ * max_haps_per_window bounds H_w (LDS size).
+ *   out_hap_like[h]  (optional, n_haps) = that sum for haplotype h of the batch
+ *   out_hap_score[w] = the value vcfINFO stores as INFO['HapScore'] for every variant of window w          */
+int plat_haplotype_score_batch(plat_ctx* ctx, const plat_window_batch* batch, int n_ind, int max_haps_per_window,
+                               const int32_t* seg_read_begin, const int32_t* seg_n_good, const double* loglik,
+                               double* out_hap_like, int32_t* out_hap_score, void* stream);
+
 /* ---- VariantCandidateGenerator ------------------------------------------------
  * Replaces  VariantCandidateGenerator.addCandidatesFromReads(readStart, readEnd)   variant.pyx:722-743
  *           (getVariantCandidatesFromSingleRead :614-720, getSnpCandidatesFromReadSegment :529-612)

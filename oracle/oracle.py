@@ -78,6 +78,8 @@ class Oracle:
         L.orc_check_and_trim.argtypes = [C.c_int] + [C.c_void_p] * 11 + [C.c_int] * 7 + [C.c_void_p] * 3
         L.orc_variant_read_stats.restype = None
         L.orc_variant_read_stats.argtypes = [C.c_int] + [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 14 + [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
+        L.orc_haplotype_score.restype = C.c_int
+        L.orc_haplotype_score.argtypes = [C.c_int, C.c_void_p]
         L.orc_genotype_loglik.restype = C.c_double
         L.orc_genotype_loglik.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -176,6 +178,10 @@ class Oracle:
         L = self.lib.orc_genotype_loglik(a1.ctypes.data, a2.ctypes.data, int(same_hap), len(a1) - 1,
                                          n_good, C.byref(gof), C.byref(h1), C.byref(h2))
         return L, gof.value, h1.value, h2.value
+
+    def haplotype_score(self, hap_likes):
+        a = np.ascontiguousarray(hap_likes, dtype=np.float64)
+        return int(self.lib.orc_haplotype_score(len(a), a.ctypes.data))
 
     def population_setup_ind(self, ll_rows, n_good):
         """ll_rows: [nHaps][totalReads] (no sentinel).  Returns (logl, gl, gof) per genotype."""

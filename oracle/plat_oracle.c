@@ -1235,3 +1235,38 @@ ORC_API int orc_assemble(const char* ref, int refLen, int refStart, int assemSta
     free(vars); free(tmpblob);
     return ret;
 }
+
+
+/* ------------------------------------------------------------------------------------------
+ * computeHaplotypeScore  (src/cython/vcfutils.pyx:1076-1114)
+ * hapLike[h] = DiploidGenotype.hap1Like of haplotype h (orc_genotype_loglik's hap1Like for the
+ * last individual with reads).  Sort the negated values; the first cluster ends at the first gap
+ * > 20; if that gap is < 50 the second cluster (up to the next gap > 20) is added.
+ * Pinned by tests/golden/vcf_cases.json.gz (HapScore of the reference's vcfINFO text).
+ * ------------------------------------------------------------------------------------------ */
+static int orc_cmp_double(const void* a, const void* b)
+{
+    const double x = *(const double*)a, y = *(const double*)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+ORC_API int orc_haplotype_score(int nHaps, const double* hapLike)
+{
+    if (nHaps <= 0) return 0;
+    double* v = (double*)malloc((size_t)nHaps * sizeof(double));
+    for (int h = 0; h < nHaps; ++h) v[h] = -hapLike[h];
+    qsort(v, (size_t)nHaps, sizeof(double), orc_cmp_double);
+    int sizes[2] = {1, 0}, nClusters = 1;
+    double dist = 0;
+    for (int i = 1; i < nHaps; ++i) {
+        if (v[i] - v[i - 1] > 20) {
+            if (nClusters == 1) dist = v[i] - v[i - 1];
+            if (nClusters == 2) break;
+            ++nClusters;
+            sizes[1] = 1;
+        } else
+            ++sizes[nClusters - 1];
+    }
+    free(v);
+    return sizes[0] + ((dist < 50 && dist > 0) ? sizes[1] : 0);
+}

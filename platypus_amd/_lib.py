@@ -119,6 +119,7 @@ SIGNATURES = {
                                        C.c_void_p]),
     "plat_variant_posterior_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 11),
     "plat_genotype_call_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 16),
+    "plat_haplotype_score_batch": (C.c_int, [C.c_void_p, C.POINTER(WindowBatch), C.c_int, C.c_int] + [C.c_void_p] * 6),
     "plat_candidates_batch": (C.c_int, [C.c_void_p, C.POINTER(CandidateBatch), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_read_qc_batch": (C.c_int, [C.c_void_p, C.POINTER(ReadQCBatch), C.POINTER(ReadQCOptions), C.c_void_p, C.c_void_p, C.c_void_p]),

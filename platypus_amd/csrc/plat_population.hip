@@ -253,6 +253,83 @@ k_genotype_call(int n_sites, int n_ind, const int32_t* __restrict__ win_hap_begi
     out4[4 * t + 3] = bestGof;
 }
 
+
+// ---- computeHaplotypeScore (vcfutils.pyx:1076-1114) ------------------------------------------------------------------------
+// The reference reads DiploidGenotype.hap1Like / hap2Like, which calculateDataLikelihood (cgenotype.pyx:148-161) resets and
+// refills on every call: after Population.setup they hold, for each haplotype, the sum over the reads of the LAST individual
+// with reads of log10E * likelihood, in read order.  One quarter-wave per window: lane h sums haplotype h (fp64, read order,
+// no FMA contraction), then lane 0 walks the negated sums in ascending order and sizes the first two clusters.
+constexpr int HS_GROUP = 16;
+
+__global__ void __launch_bounds__(64)
+k_haplotype_score(plat_window_batch b, int n_ind, int max_haps, const int32_t* __restrict__ seg_read_begin,
+                  const int32_t* __restrict__ seg_n_good, const double* __restrict__ loglik,
+                  double* __restrict__ out_hap_like, int32_t* __restrict__ out_hap_score)
+{
+    extern __shared__ double s_hs[];
+    const int grp = threadIdx.x / HS_GROUP, lane = threadIdx.x % HS_GROUP;
+    const int w = blockIdx.x * (64 / HS_GROUP) + grp;
+    const bool live = w < b.n_windows;
+    double* mine = s_hs + (size_t)grp * max_haps;
+    int H = 0;
+    if (live) {
+        const int hb = b.win_hap_begin[w];
+        H = b.win_hap_begin[w + 1] - hb;
+        const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
+        int ind = -1;
+        for (int i = 0; i < n_ind; ++i)
+            if (seg_n_good[(long long)w * n_ind + i] != 0) ind = i;            // cpopulation.pyx:293: only these are aligned
+        int s0 = 0, s1 = 0;
+        if (ind >= 0) {
+            s0 = seg_read_begin[(long long)w * n_ind + ind] - rb;
+            s1 = seg_read_begin[(long long)w * n_ind + ind + 1] - rb;
+        }
+        const double log10E = 0.43429448190325182;                              // cgenotype.pyx:24
+        const double* ll = loglik + b.pair_off[w];
+        for (int h = lane; h < H; h += HS_GROUP) {
+            const double* arr = ll + (long long)h * R;
+            double sum = 0.0;
+            for (int r0 = s0; r0 < s1; r0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = arr[min(r0 + k, s1 - 1)];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (r0 + k >= s1) break;
+                    sum += log10E * v[k];
+                }
+            }
+            if (out_hap_like) out_hap_like[hb + h] = sum;
+            if (h < max_haps) mine[h] = -sum;                                   // hapScores[hap] = -hapLike
+        }
+    }
+    __syncthreads();
+    if (!live || lane != 0) return;
+    if (H > max_haps || H == 0) { out_hap_score[w] = H == 0 ? 0 : -1; return; }
+    // ascending walk without a sort: next = smallest (value, index) above the previous one
+    double prev = 0.0;
+    int prev_i = -1, n1 = 0, n2 = 0, clusters = 1;
+    double dist = 0.0;
+    for (int k = 0; k < H; ++k) {
+        double best = 0.0;
+        int bi = -1;
+        for (int h = 0; h < H; ++h) {
+            const double v = mine[h];
+            const bool after = k == 0 || v > prev || (v == prev && h > prev_i);
+            if (after && (bi < 0 || v < best)) { best = v; bi = h; }
+        }
+        if (k == 0) n1 = 1;
+        else if (best - prev > 20) {                                            // vcfutils.pyx:1099-1104
+            if (clusters == 1) dist = best - prev;
+            if (clusters == 2) break;
+            clusters = 2; n2 = 1;
+        } else if (clusters == 1) ++n1;
+        else ++n2;
+        prev = best; prev_i = bi;
+    }
+    out_hap_score[w] = n1 + ((dist < 50 && dist > 0) ? n2 : 0);                 // :1109-1112
+}
+
 }  // namespace plat
 
 using namespace plat;
@@ -314,6 +391,23 @@ PLAT_EXPORT int plat_genotype_call_batch(plat_ctx* ctx, int n_sites, int n_ind, 
     hipLaunchKernelGGL(k_genotype_call, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n_sites, n_ind,
                        win_hap_begin, gl_off, gl, gof, freq, site_window, site_nvar, site_vih_off, site_ref_off, var_in_hap,
                        is_ref, lik_off, out_phased, out_lik, out4);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_haplotype_score_batch(plat_ctx* ctx, const plat_window_batch* batch, int n_ind, int max_haps_per_window,
+                                           const int32_t* seg_read_begin, const int32_t* seg_n_good, const double* loglik,
+                                           double* out_hap_like, int32_t* out_hap_score, void* stream)
+{
+    if (!ctx || !batch || n_ind < 1 || max_haps_per_window < 0) return PLAT_ERR_INVALID;
+    if (batch->n_windows == 0) return PLAT_OK;
+    if (!seg_read_begin || !seg_n_good || !loglik || !out_hap_score) return PLAT_ERR_INVALID;
+    const size_t lds = (size_t)(64 / HS_GROUP) * max_haps_per_window * sizeof(double) + 16;
+    if (lds > 64 * 1024) return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned nblk = (unsigned)((batch->n_windows + 64 / HS_GROUP - 1) / (64 / HS_GROUP));
+    hipLaunchKernelGGL(k_haplotype_score, dim3(nblk), dim3(64), lds, (hipStream_t)stream, *batch, n_ind, max_haps_per_window,
+                       seg_read_begin, seg_n_good, loglik, out_hap_like, out_hap_score);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }

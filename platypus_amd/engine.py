@@ -173,6 +173,21 @@ class Engine:
     def upload_likelihoods(self, n_ind, hap_counts, n_reads, gl, gof=None) -> LikelihoodBatch:
         return LikelihoodBatch(n_ind, hap_counts, n_reads, gl, gof, self.device)
 
+    def haplotype_scores(self, db: DeviceBatch):
+        """computeHaplotypeScore (INFO['HapScore']) for every window of `db` from the likelihoods left in HBM by align().
+        Returns (hap_like [n_haps] = what DiploidGenotype.hap1Like holds after Population.setup, hap_score [n_windows])."""
+        torch = _torch()
+        hb = db.host
+        like = torch.empty(max(hb.n_haps, 1), dtype=torch.float64, device=self.device)
+        score = torch.empty(max(hb.n_windows, 1), dtype=torch.int32, device=self.device)
+        maxh = int(np.max(np.diff(hb.win_hap_begin))) if hb.n_windows else 0
+        rc = self.lib.plat_haplotype_score_batch(self.ctx, C.byref(db.struct), hb.n_ind, maxh, db.t["seg_read_begin"].data_ptr(),
+                                                 db.t["seg_n_good"].data_ptr(), db.loglik.data_ptr(), like.data_ptr(),
+                                                 score.data_ptr(), self._stream())
+        _lib.check(rc, "plat_haplotype_score_batch")
+        torch.cuda.synchronize(self.device)
+        return like.cpu().numpy()[:hb.n_haps], score.cpu().numpy()[:hb.n_windows]
+
     def em(self, db, max_iters=100, use_em_likelihoods=0):
         """Population.call (EM + callGenotypes) for every window of `db`, on the genotype likelihoods left in HBM by
         genotype().  Results stay in HBM: db.freq [n_haps], db.em [like db.gl], db.calls [n_windows*n_ind], db.em_iters."""

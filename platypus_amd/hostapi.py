@@ -22,6 +22,8 @@ import numpy as np
 
 from .batch import BAM_FQCFAIL, HostBatch
 from .options import default_options
+from .vcfrecords import (VCF, computeHaplotypeScore, computeSCValue, getHaplotypeInfo, outputCallToVCF, refAndAlt,  # noqa: F401
+                         trimLeftPadding, vcfFILTER, vcfINFO)
 
 PLATYPUS_VAR, FILE_VAR, ASSEMBLER_VAR = 1, 2, 4               # variant.pyx:43-45
 SNP, MNP, INS, DEL, REP = 0, 1, 2, 3, 4                       # variant.pyx:49-53
@@ -51,6 +53,7 @@ class Variant:
         self.nSupportingReads, self.varSource = nSupportingReads, varSource
         self.minRefPos = refPos
         self.maxRefPos = max(refPos, refPos + self.nRemoved - 1)
+        self.bamMinPos = self.bamMaxPos = refPos                                 # variant.pyx:125-126
         if self.nRemoved == self.nAdded:
             self.varType = SNP if self.nAdded == 1 else MNP
         elif self.nRemoved == 0:
@@ -253,6 +256,22 @@ class Haplotype:
             bits.append(ref.getSequence(name, cur, self.endPos))
         return b"".join(bits)
 
+    def homopolymerLengthForOneVariant(self, variant):                          # :462-498
+        left = self.refFile.getSequence(variant.refName, variant.refPos - 20, variant.refPos)
+        right = self.refFile.getSequence(variant.refName, variant.refPos + 1, variant.refPos + 21)
+        if len(left) == 0 or len(right) == 0:
+            return 0
+        nl = len(left) - len(left.rstrip(left[-1:]))
+        nr = len(right) - len(right.lstrip(right[:1]))
+        return max(nl, nr) if left[-1] != right[0] else nl + nr
+
+    def getSequenceContext(self, variant):                                       # :500-506
+        return self.refFile.getSequence(variant.refName, variant.refPos - 10, variant.refPos + 11)
+
+    def vcfINFO(self):                                                           # :508-530
+        return {v: {"HP": [self.homopolymerLengthForOneVariant(v)], "SC": [self.getSequenceContext(v).decode("ascii")]}
+                for v in self.variants}
+
     def __eq__(self, o):
         return (self.refName, self.startPos, self.endPos, self.haplotypeSequence) == (o.refName, o.startPos, o.endPos, o.haplotypeSequence)
 
@@ -290,7 +309,10 @@ class DiploidGenotype:
 
     def __init__(self, hap1, hap2):
         self.hap1, self.hap2 = hap1, hap2
-        self.hap1Like = self.hap2Like = 0.0
+        self.hap1Like = self.hap2Like = 0.0                                      # filled by Population.setup (device sums)
+
+    def __contains__(self, v):                                                   # :98-105
+        return v in self.hap1.variants or v in self.hap2.variants
 
     def calculateDataLikelihood(self, readBuffer, individualIndex, nIndividuals, gof=None, useMapQualCap=False):
         eng = get_engine()
@@ -339,12 +361,17 @@ class Population:
         self.genotypeLogLikelihoods = db.logl.cpu().numpy()[:nInd * G].reshape(nInd, G).copy()
         self.goodnessOfFitValues = db.gof.cpu().numpy()[:nInd * G].reshape(G, nInd).copy()           # [genotype][ind]
         self.haplotypeLikelihoods = db.loglik.cpu().numpy()[:hb.n_pairs].reshape(H, -1).copy()
+        like, score = eng.haplotype_scores(db)                                                        # cgenotype.pyx:148-161
+        self.haplotypeScore = int(score[0])
+        for g in genotypes:
+            g.hap1Like, g.hap2Like = float(like[index[id(g.hap1)]]), float(like[index[id(g.hap2)]])
         self._db = db
         return self
 
     # ---- SURVEY 8(f) rank 1 ----------------------------------------------------------------------------
     def call(self, maxIters=100, computeVCFFields=0):
-        """cpopulation.pyx:678-720: EM frequencies, genotype calls, variant posteriors (INFO/FILTER fields are not built)."""
+        """cpopulation.pyx:678-720: EM frequencies, genotype calls, variant posteriors and, for computeVCFFields != 0, the
+        INFO / FILTER dictionaries of the window."""
         eng = get_engine()
         db = self._db
         eng.em(db, maxIters, int(self.options.useEMLikelihoods))
@@ -356,7 +383,19 @@ class Population:
         self.genotypeCalls = [None if g < 0 else self.genotypes[g] for g in idx]                     # :623-676
         self.emIterations = int(db.em_iters.cpu().numpy()[0])
         self.computeVariantPosteriors()
+        self.vcfInfo, self.vcfFilter = {}, {}
+        if computeVCFFields != 0 and len(self.variantPosteriors) > 0:                                # :718-720
+            self.computeVariantINFO()
+            self.computeVariantFILTER()
         return self
+
+    def computeVariantINFO(self):                                                                     # :155-158
+        self.vcfInfo = vcfINFO(self.frequencies, self.variantPosteriors, self.genotypeCalls, self.genotypes, self.haplotypes,
+                               self.readBuffers, self.nHaplotypes, self.options, getattr(self, "refFile", None),
+                               hapScore=self.haplotypeScore)
+
+    def computeVariantFILTER(self):                                                                   # :160-164
+        self.vcfFilter = vcfFILTER(self.genotypeCalls, self.haplotypes, self.vcfInfo, self.varsByPos, self.options)
 
     def _masks(self, vs):
         return [np.array([v in h.variants for h in self.haplotypes], dtype=np.uint8) for v in vs]
@@ -374,7 +413,8 @@ class Population:
         self.variantPosteriors, self.varsByPos = {}, {}
         if not vs:
             return
-        post = get_engine().variant_posteriors(self._db, [0] * len(vs), self._masks(vs), [v.calculatePrior(None) for v in vs])
+        post = get_engine().variant_posteriors(self._db, [0] * len(vs), self._masks(vs),
+                                               [v.calculatePrior(getattr(self, "refFile", None)) for v in vs])
         for v, p in zip(vs, post):
             if p >= self.options.minPosterior:
                 self.variantPosteriors[v] = float(p)
@@ -644,8 +684,8 @@ def infoFieldsFromReadStats(counts, nReadsPerSample, nVarReadsPerSample, minBase
     info = dict(ABPV=[_round2(computeAlleleBiasPValue(TC_ab, TR_ab))], SbPval=[_round2(computeStrandBiasPValue(TCF_sb, TCR_sb, NF_sb, NR_sb))],
                 TR=[TR], NF=[NF], NR=[NR], BRF=[_round2(nBad / float(nGood + nBad))], TC=[TC], TCR=[TCR], TCF=[TCF],
                 nReadsPerSample=list(nReadsPerSample), nVarReadsPerSample=list(nVarReadsPerSample))
-    rms = float(np.float32(sumsq))                                                                    # `cdef float RMSMQ`
-    info["MQ"] = [_round2(math.sqrt(rms / (TC + TC_bad)))] if (TC + TC_bad > 0 and rms > 0) else [0]
+    rms = np.float32(sumsq)                                                                           # `cdef float RMSMQ`: the quotient is
+    info["MQ"] = [_round2(math.sqrt(float(rms / np.float32(TC + TC_bad))))] if (TC + TC_bad > 0 and rms > 0) else [0]   # a C float too
     q = sorted(minBaseQuals)
     info["MMLQ"] = [q[len(q) // 2]] if q else [100]
     return info

@@ -231,3 +231,52 @@ def test_check_and_trim_reads_match_reference_golden(golden_dir):
             assert list(r.qual) == (src["qual"] if exp is None else exp)
             trimmed += exp is not None
     assert trimmed > 500
+
+
+def test_vcf_records_end_to_end_match_reference_golden(golden_dir, oracle):
+    """reads + haplotypes -> Population.setup / call(computeVCFFields=1) on the device -> INFO, FILTER, VCF text: every value the
+    reference's texts produced for the 48 windows of vcf_cases.json.gz (likelihoods, hapLikes, frequencies, posteriors, calls,
+    HapScore, INFO dictionaries, filters, record lines)."""
+    import gzip, io, json, os
+    from test_hostapi_cpu import _vcf_case_objects, _info_equal
+    from platypus_amd import vcfrecords as V
+    from platypus_amd.options import default_options
+    cases = json.load(gzip.open(os.path.join(golden_dir, "vcf_cases.json.gz"), "rt"))
+    nlines = 0
+    for c in cases:
+        fasta, variants, haps, buffers, o = _vcf_case_objects(c)
+        opts = default_options(**vars(o))
+        opts.rlen = c["rlen"]
+        genotypes = H.generateAllGenotypesFromHaplotypeList(haps)
+        pop = H.Population(opts)
+        pop.refFile = fasta
+        pop.setup(variants, haps, genotypes, len(buffers), 0, buffers)
+        nInd, nH = len(buffers), len(haps)
+        for i in range(nInd):
+            tot = len(c["samples"][i]["good"]) + len(c["samples"][i]["bad"])
+            if tot:
+                assert np.array_equal(pop.haplotypeLikelihoods[:, sum(len(s["good"]) + len(s["bad"]) for s in c["samples"][:i]):][:, :tot],
+                                      np.array(c["loglik"][i]).reshape(nH, tot))
+        assert [g.hap1Like for g in genotypes if g.hap1 is g.hap2] == c["hap_likes"]
+        # exp() of the rescaling comes from the device libm (glibc in the reference): a few ulp, tolerance 1e-12 relative
+        assert np.allclose(pop.genotypeLikelihoods, np.array(c["gl"]), rtol=1e-12, atol=0)
+        pop.call(100, 1)
+        assert np.allclose(pop.frequencies, np.array(c["freqs"]), rtol=1e-10, atol=1e-300)
+        assert [(-1 if g is None else genotypes.index(g)) for g in pop.genotypeCalls] == c["calls"]
+        for k, v in enumerate(variants):
+            assert pop.calculatePosterior(v) == c["posteriors"][k]
+        if c["info"] is None:
+            assert not pop.variantPosteriors
+            continue
+        assert pop.haplotypeScore == oracle.haplotype_score(c["hap_likes"])
+        assert sorted(variants.index(v) for v in pop.vcfInfo) == sorted(int(k) for k in c["info"])
+        for v, d in pop.vcfInfo.items():
+            _info_equal(d, c["info"][str(variants.index(v))])
+        assert {str(variants.index(v)): f for v, f in pop.vcfFilter.items()} == c["filter"]
+        out = io.StringIO()
+        V.outputCallToVCF(pop.varsByPos, pop.vcfInfo, pop.vcfFilter, pop.haplotypes, pop.genotypes, pop.frequencies, pop.genotypeLikelihoods,
+                          pop.goodnessOfFitValues, pop.haplotypeIndexes, pop.readBuffers, pop.nIndividuals,
+                          V.VCF([s["name"] for s in c["samples"]]), fasta, out, opts, pop.variants, c["start"], c["end"], population=pop)
+        assert out.getvalue().split("\n")[:-1] == c["lines"]
+        nlines += len(c["lines"])
+    assert nlines > 50

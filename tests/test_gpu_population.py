@@ -124,6 +124,32 @@ def test_population_path_end_to_end_vs_oracle(eng, oracle):
         assert np.array_equal(e[live], em[hb.gl_off[w]:hb.gl_off[w] + hb.n_ind * G].reshape(hb.n_ind, G)[live])
 
 
+def test_haplotype_scores_vs_oracle(eng, oracle):
+    """plat_haplotype_score_batch on multi-window batches (1 and 12 samples, some samples without reads): per-haplotype sums =
+    the oracle's hap1Like on the device's own likelihoods (same doubles), HapScore = the oracle's clustering of them."""
+    for hb in (synth.config2(300, seed=77), synth.config5(6, 12)):
+        hb.seg_n_good = np.array(hb.seg_n_good).copy()
+        if hb.n_ind > 1:
+            hb.seg_n_good[hb.n_ind - 1::hb.n_ind] = 0          # the last sample has no good reads: the one before it counts
+        db = eng.upload(hb)
+        eng.align(db, want_stats=False)
+        like, score = eng.haplotype_scores(db)
+        ll = db.loglik.cpu().numpy()
+        for w in range(hb.n_windows):
+            h0, h1 = hb.win_hap_begin[w], hb.win_hap_begin[w + 1]
+            R = hb.win_read_begin[w + 1] - hb.win_read_begin[w]
+            rows = ll[hb.pair_off[w]:hb.pair_off[w] + (h1 - h0) * R].reshape(h1 - h0, R)
+            ind = max(i for i in range(hb.n_ind) if hb.seg_n_good[w * hb.n_ind + i] != 0)
+            s0 = hb.seg_read_begin[w * hb.n_ind + ind] - hb.win_read_begin[w]
+            s1 = hb.seg_read_begin[w * hb.n_ind + ind + 1] - hb.win_read_begin[w]
+            exp = []
+            for h in range(h1 - h0):
+                arr = np.concatenate([rows[h, s0:s1], [999.0]])
+                exp.append(oracle.genotype_loglik(arr, arr, True, 1)[2])
+            assert like[h0:h1].tolist() == exp
+            assert score[w] == oracle.haplotype_score(exp)
+
+
 def test_variant_read_stats_match_reference_golden(eng, golden_dir):
     """SURVEY 8(f) rank 3 (INFO read statistics): coverage / support / strand counts, per-sample counts and the MMLQ window minima
     per variant, against the reference's own leaf functions driven as vcfINFO drives them."""

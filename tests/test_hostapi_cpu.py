@@ -131,3 +131,99 @@ def test_info_pvalues_match_reference_golden(golden_dir):
     info = H.infoFieldsFromReadStats([10, 2, 4, 10, 4, 1, 3, 5, 5, 5, 5, 1, 3, 30, 10, 12 * 3600], [10], [4], [30, 12, 25])
     assert info["BRF"] == [0.25] and info["MQ"] == [60.0] and info["MMLQ"] == [25] and info["TR"] == [4]
     assert H._round2(0.125) == 0.13 and H._round2(2.675) == 2.67          # Python-2 rounding: ties away from zero, exact binary value
+
+
+def _vcf_case_objects(c):
+    """hostapi objects of one vcf_cases.json.gz window (shared with the GPU test)."""
+    from platypus_amd import hostapi as H
+    fasta = H.FastaFile({"20": c["ref"].encode()})
+    variants = []
+    for v in c["variants"]:
+        var = H.Variant("20", v["pos"], v["removed"].encode(), v["added"].encode(), 3, v["source"])
+        if len(v["removed"]) != len(v["added"]):
+            var.prior = v["indel_prior"]                   # indelPrior (tandem.c tables) is outside the scope: an input
+        variants.append(var)
+    haps = [H.Haplotype("20", c["start"], c["end"], tuple(variants[k] for k in h), fasta, c["rlen"]) for h in c["haplotypes"]]
+    rd = lambda r: H.AlignedRead(r["seq"].encode(), bytes(r["qual"]), r["pos"], r["mapq"], r["flag"], end=r["end"], cigarOps=r["cigar"])
+    buffers = []
+    for s in c["samples"]:
+        b = H.bamReadBuffer([rd(r) for r in s["good"]], [rd(r) for r in s["bad"]], [], sample=s["name"])
+        assert [r.pos for r in b.reads.array] == [r["pos"] for r in s["good"]]
+        b.reads.windowStart, b.reads.windowEnd = 0, len(s["good"])
+        b.badReads.windowStart, b.badReads.windowEnd = 0, len(s["bad"])
+        buffers.append(b)
+    from types import SimpleNamespace
+    return fasta, variants, haps, buffers, SimpleNamespace(**c["options"])
+
+
+def _info_equal(got, exp):
+    assert sorted(got) == sorted(exp), (sorted(got), sorted(exp))
+    for k in exp:
+        assert got[k] == exp[k] and [type(x) for x in got[k]] == [type(x) for x in exp[k]], (k, got[k], exp[k])
+
+
+def test_py2_semantics():
+    from platypus_amd import vcfrecords as V
+    assert V.py2_set_order(["a", "b", "c"]) == ["a", "c", "b"]            # the well-known CPython 2 order of set(['a','b','c'])
+    assert V.py2_round(0.125, 2) == 0.13 and V.py2_round(2.675, 2) == 2.67 and V.py2_round(2.5) == 3.0 and V.py2_round(-0.5) == -1.0
+    assert V.py2_str(28.452738944123456) == "28.4527389441" and V.py2_str(20.0) == "20.0" and V.py2_str(1e-05) == "1e-05"
+    assert V.py2_str(7) == "7" and V.py2_str(0.1 + 0.2) == "0.3"
+
+
+def test_vcf_layer_matches_reference_golden(golden_dir, oracle):
+    """INFO, FILTER and the VCF text of 48 windows equal what the reference's vcfINFO / vcfFILTER / outputCallToVCF / VCF.write_data
+    texts produced; the device's share (read statistics, genotype marginalisation, HapScore) comes from the oracle here."""
+    import gzip, io, json, os
+    from platypus_amd import hostapi as H, vcfrecords as V
+    cases = json.load(gzip.open(os.path.join(golden_dir, "vcf_cases.json.gz"), "rt"))
+    nlines = 0
+    for c in cases:
+        fasta, variants, haps, buffers, options = _vcf_case_objects(c)
+        for k, v in enumerate(variants):
+            assert v.calculatePrior(fasta) == c["variants"][k]["prior"]
+        if c["info"] is None:
+            continue
+        genotypes = H.generateAllGenotypesFromHaplotypeList(haps)
+        hidx = {id(h): i for i, h in enumerate(haps)}
+        for g in genotypes:
+            g.hap1Like, g.hap2Like = c["hap_likes"][hidx[id(g.hap1)]], c["hap_likes"][hidx[id(g.hap2)]]
+        calls = [None if g < 0 else genotypes[g] for g in c["calls"]]
+        post = {variants[int(k)]: c["posteriors"][int(k)] for k in c["info"]}
+        # order of computeVariantPosteriors (haplotypes, then their variants)
+        order, varsByPos = [], {}
+        for h in haps:
+            for v in h.variants:
+                if v in post and v not in order:
+                    order.append(v); varsByPos.setdefault(v.refPos, []).append(v)
+        assert oracle.haplotype_score(c["hap_likes"]) == V.computeHaplotypeScore(genotypes)
+        info0 = V.getHaplotypeInfo(haps, post, c["freqs"], len(haps))
+        rd = lambda r: dict(seq=r["seq"].encode(), qual=bytes(r["qual"]), pos=r["pos"], end=r["end"], mapq=r["mapq"], flag=r["flag"], cigar=r["cigar"])
+        vs = list(info0.keys())
+        stats = oracle.variant_read_stats([dict(pos=v.refPos, removed=v.removed, added=v.added, bam_min=v.bamMinPos, bam_max=v.bamMaxPos) for v in vs],
+                                          [dict(good=[rd(r) for r in s["good"]], bad=[rd(r) for r in s["bad"]]) for s in c["samples"]],
+                                          [[int(g is not None and v in g) for g in calls] for v in vs], options.minBaseQual,
+                                          options.badReadsWindow, options.countOnlyExactIndelMatches)
+        info = V.vcfINFO(c["freqs"], post, calls, genotypes, haps, buffers, len(haps), options, fasta, readStats=stats)
+        for v in vs:
+            _info_equal(info[v], c["info"][str(variants.index(v))])
+        flt = V.vcfFILTER(calls, haps, info, varsByPos, options)
+        assert {str(variants.index(v)): f for v, f in flt.items()} == c["filter"]
+        # per-position genotype calls from the oracle (the device's plat_genotype_call_batch in the product path)
+        nInd, G = len(buffers), len(genotypes)
+        gofT = np.array(c["gof"]).reshape(nInd, G)
+        gcalls = []
+        for POS in sorted(varsByPos):
+            vp = varsByPos[POS]
+            vih = [[int(v in h.variants) for v in vp] for h in haps]
+            isref = [int(not any(v.minRefPos <= POS <= v.maxRefPos for v in h.variants)) for h in haps]
+            row = []
+            for i in range(nInd):
+                ph, lik, o4 = oracle.genotype_call(c["freqs"], c["gl"][i], gofT[i], vih, isref, nInd)
+                row.append((int(ph[0]), int(ph[1]), lik.tolist(), float(o4[0]), float(o4[1]), float(o4[2]), float(o4[3])))
+            gcalls.append(row)
+        out = io.StringIO()
+        V.outputCallToVCF(varsByPos, info, flt, haps, genotypes, c["freqs"], c["gl"], None, None, buffers, nInd, V.VCF([s["name"] for s in c["samples"]]),
+                          fasta, out, options, variants, c["start"], c["end"], genotypeCalls=gcalls)
+        assert out.getvalue().split("\n")[:-1] == c["lines"]
+        nlines += len(c["lines"])
+    assert nlines > 50
