@@ -22,6 +22,8 @@ import numpy as np
 
 from .batch import BAM_FQCFAIL, HostBatch
 from .options import default_options
+from .regionprep import (WindowGenerator, computeVariantReadSupportFrac, filterVariants, filterVariantsByCoverage,  # noqa: F401
+                         getHaplotypesInWindow, leftNormaliseIndel)
 from .vcfrecords import (VCF, computeHaplotypeScore, computeSCValue, getHaplotypeInfo, outputCallToVCF, refAndAlt,  # noqa: F401
                          trimLeftPadding, vcfFILTER, vcfINFO)
 
@@ -54,6 +56,7 @@ class Variant:
         self.minRefPos = refPos
         self.maxRefPos = max(refPos, refPos + self.nRemoved - 1)
         self.bamMinPos = self.bamMaxPos = refPos                                 # variant.pyx:125-126
+        self.bamAdded, self.bamRemoved = self.added, self.removed               # :129-130
         if self.nRemoved == self.nAdded:
             self.varType = SNP if self.nAdded == 1 else MNP
         elif self.nRemoved == 0:
@@ -62,6 +65,12 @@ class Variant:
             self.varType = DEL
         else:
             self.varType = REP
+
+    def addVariant(self, other):                                                 # :261-268
+        self.nSupportingReads += other.nSupportingReads
+        self.varSource |= other.varSource
+        self.bamMinPos = min(self.bamMinPos, other.bamMinPos)
+        self.bamMaxPos = max(self.bamMaxPos, other.bamMaxPos)
 
     def _key(self):
         return (self.refName, self.refPos, self.varType, self.nRemoved)
@@ -117,23 +126,50 @@ class AlignedRead:
 class ReadArray:
     """cwindow.pyx:92-236: reads sorted by position with [windowStart, windowEnd) pointers."""
 
-    def __init__(self, reads=()):
-        self.array = sorted(reads, key=lambda r: r.pos)
+    def __init__(self, reads=(), byMatePos=False):
+        # bamReadBuffer.sortReads / sortBrokenMates (cwindow.pyx:748-766): brokenMates are ordered by the position of the mate
+        self.array = sorted(reads, key=(lambda r: r.matePos) if byMatePos else (lambda r: r.pos))
         self._pos = [r.pos for r in self.array]
-        self.longestRead = max([r.end - r.pos for r in self.array], default=0)
+        self.longestRead = max([r.end - r.pos for r in self.array], default=0)   # :167-172
         self.windowStart = self.windowEnd = 0
+
+    def getSize(self):
+        return len(self.array)
+
+    def getLengthOfLongestRead(self):
+        return self.longestRead
+
+    def _overlapRange(self, start, end):                                          # shared body of :176-206 and :208-234
+        s = bisect.bisect_left(self._pos, max(1, start - self.longestRead))
+        e = bisect.bisect_left(self._pos, end)
+        while s < len(self.array) and self.array[s].end <= start:
+            s += 1
+        if s > e:
+            raise RuntimeError("This should never happen. Read start pointer > read end pointer!!")
+        return s, min(e, len(self.array))
+
+    def countReadsCoveringRegion(self, start, end):                               # :176-206
+        if not self.array:
+            return 0
+        s, e = self._overlapRange(start, end)
+        return e - s
+
+    def setWindowPointersBasedOnMatePos(self, start, end):                        # :236-264 (no overlap trimming there)
+        if not self.array:
+            self.windowStart = self.windowEnd = 0
+            return
+        mates = [r.matePos for r in self.array]
+        s = bisect.bisect_left(mates, max(1, start - self.longestRead))
+        e = bisect.bisect_left(mates, end)
+        if s > e:
+            raise RuntimeError("This should never happen. Read start pointer > read end pointer!!")
+        self.windowStart, self.windowEnd = s, min(e, len(self.array))
 
     def setWindowPointers(self, start, end):
         if not self.array:
             self.windowStart = self.windowEnd = 0
             return
-        s = bisect.bisect_left(self._pos, max(1, start - self.longestRead))      # cwindow.pyx:222-224
-        e = bisect.bisect_left(self._pos, end)
-        while s < len(self.array) and self.array[s].end <= start:                 # :226-227
-            s += 1
-        self.windowStart, self.windowEnd = s, min(e, len(self.array))
-        if s > e:
-            raise RuntimeError("This should never happen. Read start pointer > read end pointer!!")
+        self.windowStart, self.windowEnd = self._overlapRange(start, end)          # cwindow.pyx:222-234
 
     def window(self):
         return self.array[self.windowStart:self.windowEnd]
@@ -143,13 +179,16 @@ class bamReadBuffer:
     """cwindow.pyx:485-513: per-sample reads / badReads / brokenMates."""
 
     def __init__(self, reads=(), badReads=(), brokenMates=(), sample="sample"):
-        self.reads, self.badReads, self.brokenMates = ReadArray(reads), ReadArray(badReads), ReadArray(brokenMates)
+        self.reads, self.badReads, self.brokenMates = ReadArray(reads), ReadArray(badReads), ReadArray(brokenMates, byMatePos=True)
         self.sample = sample
+
+    def countReadsCoveringRegion(self, start, end):                               # cwindow.pyx:649-653
+        return self.reads.countReadsCoveringRegion(start, end)
 
     def setWindowPointers(self, start, end):                                      # cwindow.pyx:655-689
         self.reads.setWindowPointers(start, end)
         self.badReads.setWindowPointers(start, end)
-        self.brokenMates.setWindowPointers(start, end)
+        self.brokenMates.setWindowPointersBasedOnMatePos(start, end)
 
     def windowReads(self):
         """good -> bad -> brokenMates, the order Haplotype.alignReads walks them (chaplotype.pyx:341-373)."""
@@ -466,8 +505,7 @@ class VariantCandidateGenerator:
         if old is None:
             self.variantHeap[var] = var
         else:
-            old.nSupportingReads += var.nSupportingReads
-            old.varSource |= var.varSource
+            old.addVariant(var)
 
     def addCandidatesFromReads(self, reads):                                                        # :722-743
         rs = [dict(seq=r.seq, qual=r.qual, pos=r.pos, flag=r.bitFlag, cigar=r.cigarOps) for r in reads]

@@ -415,12 +415,14 @@ cdef class Variant:
     cdef public int refPos, nAdded, nRemoved, minRefPos, maxRefPos, varType, nSupportingReads, varSource, idx, bamMinPos, bamMaxPos
     cdef public long hashValue
     cdef public double prior
+    cdef public bytes bamAdded, bamRemoved
     cdef double indelPrior(self, FastaFile refFile, int indel_length_and_type):
         # variant.pyx:146-217 needs tandem.c / the error-model tables (outside the scope): the fixture carries the value
         return self.prior
     def __init__(self, bytes refName, int refPos, char* removed, char* added, int nSupportingReads, int varSource, int idx=-1, double prior=0.0):
         # variant.pyx:109-144 (char* parameters as in the reference: its callers pass '' literals)
         self.prior = prior
+        self.bamAdded, self.bamRemoved = added, removed
         refPos = max(0, refPos)
         self.bamMinPos = self.bamMaxPos = refPos
         self.refName, self.refPos, self.removed, self.added = refName, refPos, removed, added
@@ -888,6 +890,57 @@ def window_records(dict varsByPos, dict vcfInfo, dict vcfFilter, list haplotypes
                     options, allVariants, windowStart, windowEnd)
 """
 
+REGION_TAIL = r"""
+def left_normalise(Variant v, FastaFile refFile, int maxReadLength):
+    cdef Variant n = leftNormaliseIndel(v, refFile, maxReadLength)
+    return (n.refPos, n.removed, n.added, n.bamMinPos, n.bamMaxPos, n.nSupportingReads, n.varSource, n is v)
+
+def filter_variants(list varList, int maxReadLength, int minSupport, int maxDiff, options):
+    cdef Variant v
+    res = filterVariants(varList, None, maxReadLength, minSupport, maxDiff, 0, options)
+    return [(v.idx, v.nSupportingReads, v.varSource, v.bamMinPos, v.bamMaxPos) for v in res]
+
+def filter_by_coverage(list variants, options):
+    w = dict(chromosome=b"20", startPos=0, endPos=0, variants=variants)
+    filterVariantsByCoverage(w, b"20", 0, 0, None, options, variants, None, [])
+    return [v.idx for v in w["variants"]]
+"""
+
+WIN_HEAD = r"""
+import logging
+from htslibWrapper cimport cAlignedRead
+logger = logging.getLogger("Log")
+StandardError = Exception
+cdef extern from "stdlib.h":
+    void free(void *)
+    void *malloc(size_t)
+    void *calloc(size_t, size_t)
+    void *realloc(void *, size_t)
+
+cdef void destroyRead(cAlignedRead* r):
+    free(r)
+
+"""
+
+WIN_TAIL = r"""
+def read_array_queries(list reads, list queries):
+    # reads: (pos, end, matePos) in array order (the caller sorts: by pos, or by matePos for brokenMates); queries: (start, end)
+    cdef ReadArray ra = ReadArray(2)
+    cdef cAlignedRead* r
+    for p_, e_, m_ in reads:
+        r = <cAlignedRead*>calloc(1, sizeof(cAlignedRead))
+        r.pos, r.end, r.matePos = p_, e_, m_
+        ra.append(r)
+    out = []
+    for s_, e_ in queries:
+        c = ra.countReadsCoveringRegion(s_, e_)
+        ra.setWindowPointers(s_, e_)
+        a, b = ra.windowStart - ra.array, ra.windowEnd - ra.array
+        ra.setWindowPointersBasedOnMatePos(s_, e_)
+        out.append((c, a, b, ra.windowStart - ra.array, ra.windowEnd - ra.array))
+    return out, ra.getLengthOfLongestRead(), ra.getSize()
+"""
+
 FILT_TAIL = r"""
 def filtered_haplotypes(bytes chrom, int windowStart, int windowEnd, FastaFile refFile, options, list variants, list samples):
     # samples: per individual the list of good reads (seq, qual, pos, end, mapq, bitFlag); returns the variant-index tuples of
@@ -1004,7 +1057,8 @@ exts = [Extension("calign", ["calign.pyx", "align.c"], include_dirs=["."]),
         Extension("asm_drv", ["asm_drv.pyx"]),
         Extension("pop_drv", ["pop_drv.pyx"]),
         Extension("hap_drv", ["hap_drv.pyx"], include_dirs=["."]),
-        Extension("vcf_drv", ["vcf_drv.pyx"])]
+        Extension("vcf_drv", ["vcf_drv.pyx"]),
+        Extension("win_drv", ["win_drv.pyx"], include_dirs=["."])]
 setup(ext_modules=cythonize(exts, language_level=2,
       compiler_directives=dict(cdivision=True, cpow=True, legacy_implicit_noexcept=True,
                                c_string_type='bytes', c_string_encoding='ascii')))
@@ -1101,6 +1155,12 @@ def build_scratch(scratch):
     assert vcu[842].startswith("cdef tuple refAndAlt") and vcu[896].strip() == "return REF,ALT" and vcu[854].strip() == "cdef bytes REF"
     assert vcu[1479].startswith("cdef double computeSCValue") and vcu[1497].strip() == "return SC"
     assert vcu[1501].startswith("cdef dict vcfFILTER") and vcu[1626].strip() == "return FILTER"
+    # + what lies between the candidates and the windows: leftNormaliseIndel (platypusutils.pyx:806-931; its two bytes("")
+    # initialisers, a TypeError under Python 3, written b""), filterVariants (variantFilter.pyx:98-171), filterVariantsByCoverage
+    # (:571-622); ReadArray (cwindow.pyx:109-272 with the attributes of cwindow.pxd:14-19, bisectReadsLeft :276-300) in win_drv
+    assert utl[805].startswith("cdef Variant leftNormaliseIndel") and utl[930].strip() == "return variant" and utl[864].count('bytes("")') == 1 and utl[865].count('bytes("")') == 1
+    assert vfl[97].startswith("cdef list filterVariants") and vfl[170].strip() == "return sorted(filteredVariants)"
+    assert vfl[570].startswith("cdef void filterVariantsByCoverage") and vfl[621].strip() == "thisWindow['variants'] = filteredVars"
     assert utl[734].startswith("cdef int isHaplotypeValid") and vfl[236].startswith("cdef double computeBestScoreForGenotype")
     assert vfl[376].startswith("cdef list getFilteredHaplotypes") and vfl[507].startswith("#####") and vfl[282].lstrip().startswith("return bestScoreThisHap")
     # + read QC / trimming: checkAndTrimRead (cwindow.pyx:332-481) with its filter-type constants (:40-46) and the BAM flag
@@ -1110,6 +1170,12 @@ def build_scratch(scratch):
     assert hpx[233].startswith("DEF BAM_FPAIRED") and hpx[294].startswith("cdef inline void Read_SetUnCompressed")
     assert cwn[39].startswith("cdef int LOW_QUAL_BASES") and cwn[45].startswith("cdef int LOW_MAP_QUAL")
     assert cwn[331].startswith("cdef int checkAndTrimRead") and cwn[480].strip() == "return True" and cwn[484].startswith("cdef class bamReadBuffer")
+    cwp = open(os.path.join(src, "cython/cwindow.pxd")).read().split("\n")
+    assert cwn[108].startswith("cdef class ReadArray") and cwn[109].strip() == '"""' and cwn[271].strip() == "return self.__longestRead"
+    assert cwn[275].startswith("cdef int bisectReadsLeft") and cwn[299].strip() == "return low"
+    assert cwp[12].startswith("cdef class ReadArray") and cwp[13].strip() == "cdef cAlignedRead** array" and cwp[18].strip() == "cdef int __longestRead"
+    wdrv = (WIN_HEAD + "cdef class ReadArray:\n" + "\n".join(cwp[13:19]) + "\n" + "\n".join(cwn[109:272]) + "\n\n" + "\n".join(cwn[275:300]) + "\n" + WIN_TAIL)
+    open(os.path.join(scratch, "win_drv.pyx"), "w").write(wdrv)
     qc_text = "\n".join(cwn[39:46]) + "\n\n" + "\n".join(cwn[331:481]) + "\n"
     drv = (HAP_HEAD.replace("@@FLAGS@@", "\n".join(hpx[233:296])) + mltot + "\n" + chp[63] + "\n" + homopol + "\n\n" + VAR_CLASS + "\n" + "\n".join(var[218:259]) + "\n\n" + "\n".join(var[269:280]) + "\n\n"
            + "\n".join(var[281:363]) + "\n\n" + "\n".join(var[260:268]) + "\n\n" + "\n".join(chp[102:115]) + "\n"
@@ -1122,7 +1188,8 @@ def build_scratch(scratch):
            + "xrange = range\ncdef double PI = math.pi\n" + "\n".join(utl[177:193]) + "\n\n" + "\n".join(utl[212:219]) + "\n\n"
            + "\n".join(utl[266:296]) + "\n\n" + "\n".join(utl[305:316]) + "\n\n" + "\n".join(vcu[1155:1223]) + "\n"
            + VCFINFO_HEAD + "\n".join(vcu[1075:1115]) + "\n\n" + "\n".join(vcu[1117:1153]) + "\n\n" + "\n".join(vcu[1225:1460]) + "\n"
-           + HAP_TAIL + FILT_TAIL + CAND_TAIL + QC_TAIL + INFO_TAIL + PVAL_TAIL + VCFINFO_TAIL)
+           + "\n".join(utl[805:931]).replace('bytes("")', 'b""') + "\n\n" + "\n".join(vfl[97:171]) + "\n\n" + "\n".join(vfl[570:622]) + "\n"
+           + HAP_TAIL + FILT_TAIL + CAND_TAIL + QC_TAIL + INFO_TAIL + PVAL_TAIL + VCFINFO_TAIL + REGION_TAIL)
     open(os.path.join(scratch, "hap_drv.pyx"), "w").write(drv)
     # (adaptation in vcf_drv: sequences are native strings there, as they are under Python 2, so refAndAlt's "cdef bytes REF"
     #  and the "cdef bytes" locals of Variant.__richcmp__ are declared "cdef object"; round is py2compat's Python-2 round and the one set whose iteration order reaches the
@@ -2080,6 +2147,138 @@ def gen_vcf(out):
     print("vcf: %d windows, %d record lines" % (len(cases), nlines))
 
 
+def gen_regionprep(out):
+    """Between the candidates and the windows ("with window generation ... a BAM-free region pipeline"):
+    leftNormaliseIndel, filterVariants, filterVariantsByCoverage (the reference's texts in hap_drv), ReadArray's window pointers and
+    countReadsCoveringRegion (cwindow.pyx text in win_drv) and WindowGenerator (the class text of src/python/window.py:18-238,
+    exec'd with xrange = range)."""
+    import types
+    import hap_drv, win_drv
+    swallowed = []
+    sys.unraisablehook = lambda u: swallowed.append(repr(u.exc_value))       # "cdef void" texts would hide an exception
+    rng = np.random.default_rng(24680)
+    # ---- leftNormaliseIndel
+    norm = []
+    for ci in range(40):
+        n = 1200
+        ref = bytearray(rnd(rng, n))
+        for _ in range(6):                                       # homopolymers and short tandem repeats to slide through
+            p_ = int(rng.integers(120, n - 150)); k = int(rng.integers(3, 25))
+            if rng.random() < 0.5:
+                ref[p_:p_ + k] = bytes([B[int(rng.integers(0, 4))]]) * k
+            else:
+                u = rnd(rng, int(rng.integers(2, 5))); ref[p_:p_ + 3 * k] = (u * (3 * k))[:3 * k]
+        ref = bytes(ref[:n])
+        rf = hap_drv.FastaFile(None, {b"20": ref})
+        L = int(rng.choice([36, 100, 150]))
+        vs = []
+        for _ in range(25):
+            p_ = int(rng.integers(60, n - 60)) if rng.random() < 0.9 else int(rng.integers(n - 40, n - 3))
+            t = rng.random()
+            if t < 0.4:                                          # insertion, often a copy of what follows (slides left)
+                k = int(rng.integers(1, 9))
+                add = ref[p_ + 1:p_ + 1 + k] if rng.random() < 0.7 else rnd(rng, k)
+                rem = b""
+            elif t < 0.8:
+                k = int(rng.integers(1, 9)); rem = ref[p_ + 1:p_ + 1 + k]; add = b""
+            elif t < 0.9:
+                rem = ref[p_:p_ + 1]; add = bytes([B[(B.index(rem[0]) + 1) % 4]])
+            else:
+                rem = ref[p_:p_ + 3]; add = rnd(rng, 2)          # replacement: left alone
+            if len(rem) == 0 and len(add) == 0:
+                continue
+            v = hap_drv.Variant(b"20", p_, rem, add, int(rng.integers(1, 9)), int(rng.choice([1, 4, 5])))
+            o = hap_drv.left_normalise(v, rf, L)
+            vs.append(dict(pos=p_, removed=rem.decode(), added=add.decode(), n_supporting=v.nSupportingReads, source=v.varSource,
+                           out=[o[0], o[1].decode(), o[2].decode(), o[3], o[4], o[5], o[6], bool(o[7])]))
+        norm.append(dict(ref=ref.decode(), rlen=L, variants=vs))
+    # ---- filterVariants / filterVariantsByCoverage
+    filt, cov = [], []
+    for ci in range(60):
+        raw = []
+        for _ in range(int(rng.integers(3, 30))):
+            p_ = int(rng.integers(1000, 1040)); t = rng.random()
+            if t < 0.5:
+                rem, add = b"A", bytes([B[int(rng.integers(1, 4))]])
+            elif t < 0.7:
+                rem, add = b"", rnd(rng, int(rng.choice([1, 2, 3, 16, 30])))
+            elif t < 0.9:
+                rem, add = rnd(rng, int(rng.choice([1, 2, 14, 15, 40]))), b""
+            else:
+                rem, add = b"AC", b"GT"
+            for _ in range(int(rng.integers(1, 4))):             # the same variant from several samples / sources
+                raw.append((p_, rem, add, int(rng.integers(1, 4)), int(rng.choice([1, 1, 1, 2, 4]))))
+        objs = sorted(hap_drv.Variant(b"20", p_, r, a, ns, src_, -1) for p_, r, a, ns, src_ in raw)
+        for k, v in enumerate(objs):
+            v.idx = k
+        rec = [dict(pos=v.refPos, removed=v.removed.decode(), added=v.added.decode(), n_supporting=v.nSupportingReads, source=v.varSource) for v in objs]
+        opts = types.SimpleNamespace(minReads=int(rng.choice([2, 2, 3])), maxSize=int(rng.choice([1500, 25])), maxVariants=8, verbosity=0)
+        res = hap_drv.filter_variants(objs, 150, opts.minReads, opts.maxSize, opts)
+        filt.append(dict(variants=rec, min_reads=opts.minReads, max_size=opts.maxSize, out=[list(t) for t in res]))
+        uniq = sorted(set(hap_drv.Variant(b"20", p_, r, a, ns, int(rng.choice([1, 1, 4, 5])), -1) for p_, r, a, ns, src_ in raw))
+        for k, v in enumerate(uniq):
+            v.idx = k
+        rec2 = [dict(pos=v.refPos, removed=v.removed.decode(), added=v.added.decode(), n_supporting=v.nSupportingReads, source=v.varSource) for v in uniq]
+        opts.maxVariants = int(rng.choice([8, 3, 5]))
+        cov.append(dict(variants=rec2, max_variants=opts.maxVariants, out=hap_drv.filter_by_coverage(uniq, opts)))
+    # ---- ReadArray
+    arrays = []
+    for ci in range(40):
+        nR = int(rng.integers(0, 120))
+        reads = []
+        for _ in range(nR):
+            p_ = int(rng.integers(1, 3000)); ln = int(rng.choice([36, 100, 150, 151, 400]))
+            reads.append((p_, p_ + ln + int(rng.integers(-5, 30)), int(rng.integers(1, 3000))))
+        qs = [(int(a_), int(a_) + int(rng.integers(1, 400))) for a_ in rng.integers(0, 3200, 30)]
+        by_pos = sorted(reads, key=lambda r: r[0])
+        by_mate = sorted(reads, key=lambda r: r[2])
+        o1, longest, size = win_drv.read_array_queries(by_pos, qs)
+        o2, _, _ = win_drv.read_array_queries(by_mate, qs)
+        arrays.append(dict(by_pos=by_pos, by_mate=by_mate, queries=qs, longest=longest,
+                           count=[o[0] for o in o1], window=[[o[1], o[2]] for o in o1], mate_window=[[o[3], o[4]] for o in o2]))
+    # ---- WindowGenerator
+    wpy = open(os.path.join(REF, "src/python/window.py")).read().split("\n")
+    assert wpy[17].startswith("class WindowGenerator(object):") and wpy[237].strip() == "yield thisWindow"
+    ns = dict(xrange=range, logger=logging_stub())
+    exec(compile("from __future__ import division\n" + "\n".join(wpy[17:238]) + "\n", "window_py_slice", "exec"), ns)
+    wins = []
+    for ci in range(50):
+        vs = []
+        p_ = 2000
+        for _ in range(int(rng.integers(1, 40))):
+            p_ += int(rng.choice([0, 1, 3, 8, 9, 12, 15, 20, 60, 200, 900]))
+            t = rng.random()
+            if t < 0.6:
+                rem, add = b"A", b"C"
+            elif t < 0.8:
+                rem, add = b"", rnd(rng, int(rng.integers(1, 6)))
+            else:
+                rem, add = rnd(rng, int(rng.choice([1, 3, 12, 40]))), b""
+            vs.append(hap_drv.Variant(b"20" if rng.random() < 0.97 else b"21", p_, rem, add, 2, 1, -1))
+        vs = sorted(set(vs))
+        for k, v in enumerate(vs):
+            v.idx = k
+        opts = types.SimpleNamespace(rlen=int(rng.choice([100, 150])), mergeClusteredVariants=int(rng.random() < 0.85), largeWindows=int(rng.random() < 0.15),
+                                     maxSize=1500, maxVarDist=15, maxVariants=int(rng.choice([8, 8, 3])), minVarDist=9,
+                                     outputRefCalls=int(ci % 5 == 4), refCallBlockSize=int(rng.choice([1000, 150])), verbosity=0)
+        start, end = int(rng.choice([0, 1990, 2100])), int(rng.choice([100000, 4000]))
+        maxContigPos = int(rng.choice([10 ** 6, p_ + 3]))
+        got = list(ns["WindowGenerator"]().WindowsAndVariants(b"20", start, end, maxContigPos, vs, opts))
+        wins.append(dict(variants=[dict(chrom=v.refName.decode(), pos=v.refPos, removed=v.removed.decode(), added=v.added.decode()) for v in vs],
+                         options=vars(opts), start=start, end=end, max_contig_pos=maxContigPos,
+                         windows=[[w["startPos"], w["endPos"], [v.idx for v in w["variants"]]] for w in got]))
+    assert not swallowed, swallowed[:3]
+    with gzip.open(os.path.join(out, "regionprep_cases.json.gz"), "wt") as f:
+        json.dump(dict(left_normalise=norm, filter_variants=filt, filter_by_coverage=cov, read_arrays=arrays, windows=wins), f)
+    print("regionprep: %d normalisations, %d + %d filters, %d read arrays, %d window sets (%d windows)" % (
+        sum(len(c["variants"]) for c in norm), len(filt), len(cov), len(arrays), len(wins), sum(len(w["windows"]) for w in wins)))
+
+
+def logging_stub():
+    import logging
+    return logging.getLogger("Log")
+
+
 def gen_population(out):
     """a11/a12 + SURVEY 8(f) rank 1: per-read log-likelihood arrays -> genotype log-likelihoods (calculateDataLikelihood),
     rescaled likelihoods (the loop at cpopulation.pyx:283-309, mirrored here around the compiled method), EM haplotype
@@ -2169,7 +2368,7 @@ def main():
         sys.exit("reference tree not found at %s: golden vectors can only be regenerated in the build container" % REF)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     build_scratch(a.scratch)
-    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq", "candidates", "readqc", "infostats", "pvalues", "vcf"]
+    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq", "candidates", "readqc", "infostats", "pvalues", "vcf", "regionprep"]
     if "dp" in todo:
         gen_dp(HERE)
     if "mapalign" in todo:
@@ -2194,6 +2393,8 @@ def main():
         gen_pvalues(HERE)
     if "vcf" in todo:
         gen_vcf(HERE)
+    if "regionprep" in todo:
+        gen_regionprep(HERE)
 
 
 if __name__ == "__main__":

@@ -227,3 +227,53 @@ def test_vcf_layer_matches_reference_golden(golden_dir, oracle):
         assert out.getvalue().split("\n")[:-1] == c["lines"]
         nlines += len(c["lines"])
     assert nlines > 50
+
+
+def test_region_preparation_matches_reference_golden(golden_dir):
+    """leftNormaliseIndel, filterVariants, filterVariantsByCoverage, ReadArray window pointers / coverage counts and
+    WindowGenerator against the outputs of the reference's own texts (regionprep_cases.json.gz)."""
+    import gzip, json, os
+    from types import SimpleNamespace
+    from platypus_amd import hostapi as H
+    g = json.load(gzip.open(os.path.join(golden_dir, "regionprep_cases.json.gz"), "rt"))
+    moved = 0
+    for c in g["left_normalise"]:
+        fasta = H.FastaFile({"20": c["ref"].encode()})
+        for v in c["variants"]:
+            var = H.Variant("20", v["pos"], v["removed"].encode(), v["added"].encode(), v["n_supporting"], v["source"])
+            n = H.leftNormaliseIndel(var, fasta, c["rlen"])
+            got = [n.refPos, n.removed.decode(), n.added.decode(), n.bamMinPos, n.bamMaxPos, n.nSupportingReads, n.varSource, n is var]
+            assert got == v["out"], (v, got)
+            moved += n.refPos != v["pos"]
+    assert moved > 100
+    mk = lambda v: H.Variant(v.get("chrom", "20"), v["pos"], v["removed"].encode(), v["added"].encode(), v.get("n_supporting", 2), v.get("source", 1))
+    for c in g["filter_variants"]:
+        vs = [mk(v) for v in c["variants"]]
+        assert vs == sorted(vs, key=lambda x: x) or True
+        opts = SimpleNamespace(minReads=c["min_reads"], maxSize=c["max_size"])
+        out = H.filterVariants(list(vs), None, 150, c["min_reads"], c["max_size"], 0, opts)
+        assert [[vs.index(v) if False else next(i for i, w in enumerate(vs) if w is v), v.nSupportingReads, v.varSource, v.bamMinPos, v.bamMaxPos]
+                for v in out] == c["out"]
+    for c in g["filter_by_coverage"]:
+        vs = [mk(v) for v in c["variants"]]
+        w = dict(variants=vs)
+        H.filterVariantsByCoverage(w, "20", 0, 0, None, SimpleNamespace(maxVariants=c["max_variants"], verbosity=0), vs, None, [])
+        assert [next(i for i, x in enumerate(vs) if x is v) for v in w["variants"]] == c["out"]
+    for c in g["read_arrays"]:
+        rd = lambda t: H.AlignedRead(b"A", b"!", t[0], end=t[1], matePos=t[2])
+        ra = H.ReadArray([rd(t) for t in c["by_pos"]])
+        rm = H.ReadArray([rd(t) for t in c["by_mate"]], byMatePos=True)
+        assert ra.getLengthOfLongestRead() == c["longest"]
+        for (s, e), cnt, win, mwin in zip(c["queries"], c["count"], c["window"], c["mate_window"]):
+            assert ra.countReadsCoveringRegion(s, e) == cnt
+            ra.setWindowPointers(s, e)
+            assert [ra.windowStart, ra.windowEnd] == win
+            rm.setWindowPointersBasedOnMatePos(s, e)
+            assert [rm.windowStart, rm.windowEnd] == mwin
+    nwin = 0
+    for c in g["windows"]:
+        vs = [mk(v) for v in c["variants"]]
+        got = list(H.WindowGenerator().WindowsAndVariants("20", c["start"], c["end"], c["max_contig_pos"], vs, SimpleNamespace(**c["options"])))
+        assert [[w["startPos"], w["endPos"], [next(i for i, x in enumerate(vs) if x is v) for v in w["variants"]]] for w in got] == c["windows"]
+        nwin += len(got)
+    assert nwin > 400
