@@ -1,0 +1,222 @@
+"""The region loop around the hot path, on in-memory read buffers (BAM-free): candidates -> windows -> haplotypes ->
+likelihoods / EM / posteriors -> VCF records.  Same names and argument meaning as the reference:
+
+    callVariantsInWindow        src/cython/variantcaller.pyx:74-141
+    generateVariantsInRegion    src/cython/variantcaller.pyx:412-531   (BAM candidates; source VCFs and the assembler tiling are
+                                                                        not wired into this loop)
+    callVariantsInRegion        src/cython/variantcaller.pyx:535-615   (loadBAMData replaced by the caller's read buffers)
+
+in two shapes.  `callVariantsInRegion` walks the windows one at a time exactly as the reference does (a handful of device
+calls per window).  `callVariantsInRegions` is the shape the device wants: the same windows, the same records, but every
+device stage runs ONCE over all windows of all regions -- one candidate scan, one likelihood / genotype / HapScore / EM
+pass, one posterior pass, one read-statistics pass, one genotype-marginalisation pass -- with the host logic (window
+generation, haplotype enumeration, dictionary assembly, text) in between.  Both produce the same text
+(tests/test_gpu_caller.py)."""
+import numpy as np
+
+from . import hostapi as H
+from .regionprep import (WindowGenerator, computeVariantReadSupportFrac, filterVariants, filterVariantsByCoverage,
+                         getHaplotypesInWindow, leftNormaliseIndel)
+from .vcfrecords import (genotypeCallSites, genotypeCallTuples, getHaplotypeInfo, infoStatsWindow, outputCallToVCF, vcfFILTER,
+                         vcfINFO)
+
+
+def _unsupported(options):
+    if getattr(options, "outputRefCalls", 0):
+        raise NotImplementedError("reference-call blocks (outputRefCall, variantcaller.pyx:764-867) are not built")
+    if getattr(options, "sourceFile", None):
+        raise NotImplementedError("candidates from a source VCF (variantutils.VariantCandidateReader) are not built")
+    if getattr(options, "assemble", 0):
+        raise NotImplementedError("the assembler tiling of generateVariantsInRegion (variantcaller.pyx:496-519) is not wired into "
+                                  "this loop; call assembleReadsAndDetectVariants per tile and add its variants yourself")
+    if getattr(options, "HLATyping", 0):
+        raise NotImplementedError("HLA mode")
+
+
+# ---- candidates -> filtered, left-normalised variants ---------------------------------------------------------------------
+
+def _candidateRegion(gen, reads):
+    return dict(ref=gen.pyRefSeq, ref_seq_start=gen.refSeqStart, contig_len=gen.refFile.refs[gen.rname].SeqLength,
+                reads=[dict(seq=r.seq, qual=r.qual, pos=r.pos, flag=r.bitFlag, cigar=r.cigarOps) for r in reads])
+
+
+def generateVariantsInRegions(regions, refFile, options):
+    """generateVariantsInRegion for a list of (chrom, start, end, readBuffers): ONE candidate scan on the device for every
+    sample of every region, then the reference's per-sample support filter, merge, left-normalisation and filterVariants.
+    Returns the per-region variant lists; options.rlen follows the longest read as in the reference (:470-481)."""
+    mk = lambda chrom, start, end: H.VariantCandidateGenerator((chrom, start, end), refFile, options.minMapQual, options.minFlank,
+                                                               options.minBaseQual, options.maxReads, options.rlen, options,
+                                                               options.verbosity, options.genSNPs, options.genIndels)
+    out = [[] for _ in regions]
+    if not options.getVariantsFromBAMs:
+        return out
+    gens = [[mk(chrom, start, end) for _ in buffers] for chrom, start, end, buffers in regions]
+    scans = [_candidateRegion(g, b.reads.array) for (_, _, _, buffers), gs in zip(regions, gens) for g, b in zip(gs, buffers)]
+    found = iter(H.get_engine().candidates(scans, options.minFlank, options.minBaseQual, options.genSNPs, options.genIndels))
+    longest = 0
+    merged = []
+    for (chrom, start, end, buffers), gs in zip(regions, gens):
+        everyone = mk(chrom, start, end)
+        for g, b in zip(gs, buffers):
+            longest = max(longest, b.reads.getLengthOfLongestRead())
+            for pos, removed, added, _ in next(found):
+                g.addVariantToList(H.Variant(chrom, pos, removed, added, 1, H.PLATYPUS_VAR))
+            for v in g.variantHeap.values():                                     # :456-467: per-sample support, indels always
+                if computeVariantReadSupportFrac(v, b) >= options.minVarFreq or v.nAdded != v.nRemoved:
+                    everyone.addVariantToList(v)
+        merged.append(everyone.getCandidates(0))
+    if longest > 0:
+        options.rlen = options.maxSize if longest >= options.maxSize else longest
+    for k, cands in enumerate(merged):
+        norm = sorted(leftNormaliseIndel(v, refFile, options.rlen) for v in cands)
+        out[k] = filterVariants(norm, refFile, options.rlen, options.minReads, options.maxSize, options.verbosity, options)
+    return out
+
+
+def generateVariantsInRegion(chrom, start, end, refFile, options, readBuffers):
+    return generateVariantsInRegions([(chrom, start, end, readBuffers)], refFile, options)[0]
+
+
+# ---- one window -----------------------------------------------------------------------------------------------------------
+
+def _prepareWindow(window, options, refFile, readBuffers):
+    """The host part of callVariantsInWindow up to Population.setup (:74-136).  Returns None for a window the reference
+    leaves without calling, else (variants, haplotypes, genotypes)."""
+    chrom, variants = window["chromosome"], window["variants"]
+    windowStart, windowEnd = window["startPos"], window["endPos"]
+    refHaplotype = H.Haplotype(chrom, windowStart, windowEnd, (), refFile, options.rlen, options)
+    nReads = 0
+    for b in readBuffers:
+        b.setWindowPointers(windowStart, windowEnd)
+        nReads += b.reads.windowEnd - b.reads.windowStart
+    if nReads == 0 or nReads > options.maxReads:
+        return None
+    if len(variants) > options.maxVariants:
+        if options.skipDifficultWindows:
+            return None
+        if options.filterVarsByCoverage:
+            filterVariantsByCoverage(window, chrom, windowStart, windowEnd, refFile, options, variants, refHaplotype, readBuffers)
+    haps = getHaplotypesInWindow(window, nReads, refFile, options.maxReads, options.minMapQual, options.minBaseQual, options.maxHaplotypes,
+                                 options.maxVariants, options.rlen, options.verbosity, readBuffers, options)
+    unique = H.mergeHaplotypes([refHaplotype] + haps, refFile)
+    if len(unique) <= 1:
+        return None
+    return variants, unique, H.generateAllGenotypesFromHaplotypeList(unique)      # `variants`: the unfiltered list, as there
+
+
+def callVariantsInWindow(window, options, refFile, readBuffers, pop):
+    pop.reset()
+    pop.refFile = refFile
+    prep = _prepareWindow(window, options, refFile, readBuffers)
+    if prep is None:
+        return
+    variants, haps, genotypes = prep
+    pop.setup(variants, haps, genotypes, len(readBuffers), options.verbosity, readBuffers)
+    pop.call(100, 1)
+
+
+def _windowsOfRegion(chrom, start, end, refFile, options, variants, windowGenerator):
+    maxContigPos = refFile.refs[chrom].SeqLength - 1
+    for window in windowGenerator.WindowsAndVariants(chrom, start, end, maxContigPos, variants, options):
+        if len(window["variants"]) == 0:
+            continue
+        if window["endPos"] - window["startPos"] > options.maxSize:              # :566-568
+            continue
+        yield window
+
+
+def callVariantsInRegion(chrom, start, end, readBuffers, refFile, options, vcfFile, outputFile, windowGenerator=None, pop=None):
+    """Window by window, as the reference."""
+    _unsupported(options)
+    windowGenerator = windowGenerator or WindowGenerator()
+    pop = pop or H.Population(options)
+    variants = generateVariantsInRegion(chrom, start, end, refFile, options, readBuffers)
+    for window in _windowsOfRegion(chrom, start, end, refFile, options, variants, windowGenerator):
+        callVariantsInWindow(window, options, refFile, readBuffers, pop)
+        if len(pop.variantPosteriors) > 0:
+            outputCallToVCF(pop.varsByPos, pop.vcfInfo, pop.vcfFilter, pop.haplotypes, pop.genotypes, pop.frequencies,
+                            pop.genotypeLikelihoods, pop.goodnessOfFitValues, pop.haplotypeIndexes, pop.readBuffers, pop.nIndividuals,
+                            vcfFile, refFile, outputFile, options, pop.variants, window["startPos"], window["endPos"], population=pop)
+
+
+# ---- all windows of all regions at once -----------------------------------------------------------------------------------
+
+def callWindowsBatched(specs, options, refFile):
+    """Population.setup + call(computeVCFFields=1) for a list of windows in ONE pass per device stage.
+    spec = dict(variants, haplotypes, genotypes, readBuffers (frozen per window)).  Returns one Population per spec with the
+    same fields the per-window path fills, plus `_genotypeCalls` (the per-position 7-tuples of outputCallToVCF)."""
+    if not specs:
+        return []
+    eng = H.get_engine()
+    pops = []
+    for sp in specs:
+        p = H.Population(options)
+        p.refFile = refFile
+        p._bind(sp["variants"], sp["haplotypes"], sp["genotypes"], len(sp["readBuffers"]), sp["readBuffers"])
+        pops.append(p)
+    hb = H._pack_windows([([h.haplotypeSequence for h in p.haplotypes], p.haplotypes[0].startPos, p.haplotypes[0].endPos,
+                           p.haplotypes[0].endBufferSize, p.readBuffers) for p in pops])
+    db = eng.upload(hb)
+    eng.call_windows(db, want_stats=False)                                       # likelihoods + genotype likelihoods
+    like, score = eng.haplotype_scores(db)
+    eng.em(db, 100, int(options.useEMLikelihoods))
+    eng.synchronize()
+    setup_arrays = (db.gl.cpu().numpy(), db.logl.cpu().numpy(), db.gof.cpu().numpy(), db.loglik.cpu().numpy(), like, score)
+    call_arrays = (db.freq.cpu().numpy(), db.em.cpu().numpy(), db.calls.cpu().numpy(), db.em_iters.cpu().numpy())
+    var_w, masks, priors, owners = [], [], [], []
+    for w, p in enumerate(pops):
+        p._readSetup(db, w, *setup_arrays)
+        p._readCall(*call_arrays)
+        vs = p._distinctVariants()
+        owners.append(len(vs))
+        var_w += [w] * len(vs)
+        masks += p._masks(vs)
+        priors += [v.calculatePrior(refFile) for v in vs]
+    post = eng.variant_posteriors(db, var_w, masks, priors) if var_w else np.zeros(0)
+    at = 0
+    for p, n in zip(pops, owners):
+        p.computeVariantPosteriors(posteriors=post[at:at + n])
+        p.vcfInfo, p.vcfFilter, p._genotypeCalls = {}, {}, []
+        at += n
+    live = [p for p in pops if len(p.variantPosteriors) > 0]
+    if not live:
+        return pops
+    order = [list(getHaplotypeInfo(p.haplotypes, p.variantPosteriors, p.frequencies, p.nHaplotypes).keys()) for p in live]
+    stats = eng.variant_read_stats([infoStatsWindow(vs, p.readBuffers, p.genotypeCalls) for p, vs in zip(live, order)],
+                                   bad_reads_window=options.badReadsWindow, exact=options.countOnlyExactIndelMatches)
+    sites, nsites = [], []
+    for p in live:
+        s_ = genotypeCallSites(p.varsByPos, p.haplotypes, p.variants, p._w)
+        sites += s_
+        nsites.append(len(s_))
+    tuples = genotypeCallTuples(eng.genotype_calls(db, sites), hb.n_ind)
+    at = 0
+    for p, st, n in zip(live, stats, nsites):
+        p.vcfInfo = vcfINFO(p.frequencies, p.variantPosteriors, p.genotypeCalls, p.genotypes, p.haplotypes, p.readBuffers,
+                            p.nHaplotypes, options, refFile, hapScore=p.haplotypeScore, readStats=st)
+        p.vcfFilter = vcfFILTER(p.genotypeCalls, p.haplotypes, p.vcfInfo, p.varsByPos, options)
+        p._genotypeCalls = tuples[at:at + n]
+        at += n
+    return pops
+
+
+def callVariantsInRegions(regions, refFile, options, vcfFile, outputFile, windowGenerator=None):
+    """regions: list of (chrom, start, end, readBuffers) with the same samples.  Records are written in region order, then
+    window order, then position order -- the order callVariantsInRegion would write them one region after the other."""
+    _unsupported(options)
+    windowGenerator = windowGenerator or WindowGenerator()
+    variants = generateVariantsInRegions(regions, refFile, options)
+    specs = []
+    for (chrom, start, end, buffers), vs in zip(regions, variants):
+        for window in _windowsOfRegion(chrom, start, end, refFile, options, vs, windowGenerator):
+            prep = _prepareWindow(window, options, refFile, buffers)             # (greedy haplotype filter: device calls of its own)
+            if prep is not None:
+                specs.append(dict(variants=prep[0], haplotypes=prep[1], genotypes=prep[2], window=window,
+                                  readBuffers=[b.frozenWindow() for b in buffers]))
+    pops = callWindowsBatched(specs, options, refFile)
+    for sp, p in zip(specs, pops):
+        if len(p.variantPosteriors) > 0:
+            outputCallToVCF(p.varsByPos, p.vcfInfo, p.vcfFilter, p.haplotypes, p.genotypes, p.frequencies, p.genotypeLikelihoods,
+                            p.goodnessOfFitValues, p.haplotypeIndexes, p.readBuffers, p.nIndividuals, vcfFile, refFile, outputFile,
+                            options, p.variants, sp["window"]["startPos"], sp["window"]["endPos"], genotypeCalls=p._genotypeCalls)
+    return len(specs)

@@ -88,8 +88,8 @@ class Variant:
         return "Variant(%s:%d %s->%s)" % (self.refName, self.refPos, self.removed.decode(), self.added.decode())
 
     def calculatePrior(self, refFile=None):
-        """variant.pyx:219-259.  The indel branch (indelPrior, :146-217: homopolymer-context error model tables) is host
-        logic outside the accelerated path: give indels an explicit `prior` attribute."""
+        """variant.pyx:219-259.  Indels: the tandem-repeat error model of variant.pyx:146-217 (platypus_amd/indelprior.py);
+        an explicit `prior` attribute, when set, replaces the model (callers with their own priors)."""
         explicit = getattr(self, "prior", None)
         if explicit is not None:
             return max(float(explicit), 1e-10)
@@ -98,11 +98,19 @@ class Variant:
         elif self.nAdded == self.nRemoved:
             nDiffs = len([1 for x, y in zip(self.added, self.removed) if x != y])
             prior = 5e-5 * (0.1 ** (nDiffs - 1)) * (1.0 - 0.1)
-        elif self.nAdded == 0 or self.nRemoved == 0:
-            raise NotImplementedError("indel priors (variant.pyx:146-217) are not part of the device path: set Variant.prior")
+        elif self.nAdded > 0 and self.nRemoved == 0:
+            prior = self.indelPrior(refFile, self.nAdded)
+        elif self.nAdded == 0 and self.nRemoved > 0:
+            prior = self.indelPrior(refFile, -self.nRemoved)
         else:
             prior = 5e-6
         return max(prior, 1e-10)
+
+    def indelPrior(self, refFile, indel_length_and_type):                        # :146-217
+        from .indelprior import indelPrior
+        if refFile is None:
+            raise ValueError("the indel prior needs the reference sequence around the variant: pass refFile (or set Variant.prior)")
+        return indelPrior(self, refFile, indel_length_and_type)
 
 
 class AlignedRead:
@@ -132,6 +140,16 @@ class ReadArray:
         self._pos = [r.pos for r in self.array]
         self.longestRead = max([r.end - r.pos for r in self.array], default=0)   # :167-172
         self.windowStart = self.windowEnd = 0
+
+    @classmethod
+    def view(cls, reads):
+        """The reads between another array's window pointers, frozen: window = everything, order kept."""
+        a = cls.__new__(cls)
+        a.array = list(reads)
+        a._pos = [r.pos for r in a.array]
+        a.longestRead = max([r.end - r.pos for r in a.array], default=0)
+        a.windowStart, a.windowEnd = 0, len(a.array)
+        return a
 
     def getSize(self):
         return len(self.array)
@@ -185,6 +203,15 @@ class bamReadBuffer:
     def countReadsCoveringRegion(self, start, end):                               # cwindow.pyx:649-653
         return self.reads.countReadsCoveringRegion(start, end)
 
+    def frozenWindow(self):
+        """A buffer holding exactly the reads between the current window pointers (batched calling keeps one per window,
+        where the reference moves the pointers of the one buffer from window to window)."""
+        b = bamReadBuffer.__new__(bamReadBuffer)
+        b.sample = self.sample
+        b.reads, b.badReads, b.brokenMates = (ReadArray.view(self.reads.window()), ReadArray.view(self.badReads.window()),
+                                              ReadArray.view(self.brokenMates.window()))
+        return b
+
     def setWindowPointers(self, start, end):                                      # cwindow.pyx:655-689
         self.reads.setWindowPointers(start, end)
         self.badReads.setWindowPointers(start, end)
@@ -215,28 +242,36 @@ class FastaFile:
         return b"-" if (pos >= len(s) or pos < 0) else s[pos:pos + 1]
 
 
-def _pack_window(haps, startPos, endPos, endBufferSize, buffers):
-    """One-window HostBatch from haplotype byte strings and per-individual bamReadBuffers."""
-    reads, seg_b, seg_g = [], [0], []
-    for buf in buffers:
-        rs = buf.windowReads()
-        reads += rs
-        seg_b.append(len(reads))
-        seg_g.append(buf.reads.windowEnd - buf.reads.windowStart)
-    nH, nR = len(haps), len(reads)
+def _pack_windows(specs):
+    """HostBatch of several calling windows; spec = (haplotype byte strings, startPos, endPos, endBufferSize, per-individual
+    bamReadBuffers with their window pointers set).  All windows must have the same number of individuals."""
+    haps, reads, whb, wrb, seg_b, seg_g, ws, we, wf = [], [], [0], [0], [0], [], [], [], []
+    for hs, startPos, endPos, endBufferSize, buffers in specs:
+        haps += hs
+        for buf in buffers:
+            reads += buf.windowReads()
+            seg_b.append(len(reads))
+            seg_g.append(buf.reads.windowEnd - buf.reads.windowStart)
+        whb.append(len(haps)); wrb.append(len(reads))
+        ws.append(startPos); we.append(endPos); wf.append(endBufferSize)
+    n_ind = len(specs[0][4])
+    assert all(len(sp[4]) == n_ind for sp in specs)
     hl = np.array([len(h) for h in haps], dtype=np.int64)
     rl = np.array([r.rlen for r, _ in reads], dtype=np.int64)
     cat = lambda parts: np.frombuffer(b"".join(parts), dtype=np.uint8)
+    i32 = lambda a: np.array(a, dtype=np.int32)
     return HostBatch(
-        n_ind=len(buffers), win_hap_begin=np.array([0, nH], dtype=np.int32), win_read_begin=np.array([0, nR], dtype=np.int32),
-        win_start=np.array([startPos], dtype=np.int32), win_end=np.array([endPos], dtype=np.int32),
-        win_flank=np.array([endBufferSize], dtype=np.int32), hap_seq=cat(haps),
-        hap_off=np.concatenate([[0], np.cumsum(hl)]).astype(np.int64), read_seq=cat([r.seq for r, _ in reads]),
+        n_ind=n_ind, win_hap_begin=i32(whb), win_read_begin=i32(wrb), win_start=i32(ws), win_end=i32(we), win_flank=i32(wf),
+        hap_seq=cat(haps), hap_off=np.concatenate([[0], np.cumsum(hl)]).astype(np.int64), read_seq=cat([r.seq for r, _ in reads]),
         read_qual=cat([r.qual for r, _ in reads]), read_off=np.concatenate([[0], np.cumsum(rl)]).astype(np.int64),
-        read_pos=np.array([r.pos for r, _ in reads], dtype=np.int32), read_end=np.array([r.end for r, _ in reads], dtype=np.int32),
-        read_mapq=np.array([r.mapq for r, _ in reads], dtype=np.uint8), read_flags=np.array([r.bitFlag for r, _ in reads], dtype=np.int32),
-        read_kind=np.array([k for _, k in reads], dtype=np.uint8), seg_read_begin=np.array(seg_b, dtype=np.int32),
-        seg_n_good=np.array(seg_g, dtype=np.int32))
+        read_pos=i32([r.pos for r, _ in reads]), read_end=i32([r.end for r, _ in reads]),
+        read_mapq=np.array([r.mapq for r, _ in reads], dtype=np.uint8), read_flags=i32([r.bitFlag for r, _ in reads]),
+        read_kind=np.array([k for _, k in reads], dtype=np.uint8), seg_read_begin=i32(seg_b), seg_n_good=i32(seg_g))
+
+
+def _pack_window(haps, startPos, endPos, endBufferSize, buffers):
+    """One-window HostBatch from haplotype byte strings and per-individual bamReadBuffers."""
+    return _pack_windows([(list(haps), startPos, endPos, endBufferSize, buffers)])
 
 
 class Haplotype:
@@ -376,35 +411,55 @@ class Population:
 
     def __init__(self, options=None):
         self.options = options if options is not None else default_options()
+        self._w = 0
+        self.reset()
 
-    def setup(self, variants, haplotypes, genotypes, nInd, verbosity, readBuffers):
+    def _bind(self, variants, haplotypes, genotypes, nInd, readBuffers):
         if nInd != len(readBuffers):
             raise Exception("Error in cPopulation.setup")                        # :215-219
         self.variants, self.haplotypes, self.genotypes, self.readBuffers = variants, haplotypes, genotypes, readBuffers
         self.nGenotypes, self.nVariants, self.nHaplotypes, self.nIndividuals = len(genotypes), len(variants), len(haplotypes), nInd
-        index = {id(h): i for i, h in enumerate(haplotypes)}
-        self.haplotypeIndexes = np.array([[index[id(g.hap1)], index[id(g.hap2)]] for g in genotypes], dtype=np.int32)
+        self._hapIndex = {id(h): i for i, h in enumerate(haplotypes)}
+        self.haplotypeIndexes = np.array([[self._hapIndex[id(g.hap1)], self._hapIndex[id(g.hap2)]] for g in genotypes], dtype=np.int32)
         H = len(haplotypes)
         expected = [(i, j) for i in range(H) for j in range(i, H)]
         if [tuple(x) for x in self.haplotypeIndexes.tolist()] != expected:
             raise ValueError("genotypes must be generateAllGenotypesFromHaplotypeList(haplotypes)")
+
+    def _readSetup(self, db, w, gl, logl, gof, loglik, like, score):
+        """Take window w's slices of the batch results (host copies of db.gl / logl / gof / loglik, hap likes, HapScores)."""
+        hb = db.host
+        nInd, G, H = self.nIndividuals, self.nGenotypes, self.nHaplotypes
+        o, h0 = int(hb.gl_off[w]), int(hb.win_hap_begin[w])
+        self.nReads = np.array(hb.seg_n_good[w * nInd:(w + 1) * nInd], dtype=np.int32)               # :286-287
+        self.genotypeLikelihoods = gl[o:o + nInd * G].reshape(nInd, G).copy()                        # [ind][genotype]
+        self.genotypeLogLikelihoods = logl[o:o + nInd * G].reshape(nInd, G).copy()
+        self.goodnessOfFitValues = gof[o:o + nInd * G].reshape(G, nInd).copy()                       # [genotype][ind]
+        self.haplotypeLikelihoods = loglik[int(hb.pair_off[w]):int(hb.pair_off[w + 1])].reshape(H, -1).copy()
+        self.haplotypeScore = int(score[w])
+        for g in self.genotypes:                                                                     # cgenotype.pyx:148-161
+            g.hap1Like, g.hap2Like = float(like[h0 + self._hapIndex[id(g.hap1)]]), float(like[h0 + self._hapIndex[id(g.hap2)]])
+        self._db, self._w = db, w
+
+    def _readCall(self, freq, em, calls, iters):
+        db, w = self._db, self._w
+        hb = db.host
+        nInd, G = self.nIndividuals, self.nGenotypes
+        o, h0 = int(hb.gl_off[w]), int(hb.win_hap_begin[w])
+        self.frequencies = freq[h0:h0 + self.nHaplotypes].copy()
+        self.EMLikelihoods = em[o:o + nInd * G].reshape(nInd, G).copy()
+        self.genotypeCalls = [None if g < 0 else self.genotypes[g] for g in calls[w * nInd:(w + 1) * nInd]]   # :623-676
+        self.emIterations = int(iters[w])
+
+    def setup(self, variants, haplotypes, genotypes, nInd, verbosity, readBuffers):
+        self._bind(variants, haplotypes, genotypes, nInd, readBuffers)
         h0 = haplotypes[0]
         eng = get_engine()
         hb = _pack_window([h.haplotypeSequence for h in haplotypes], h0.startPos, h0.endPos, h0.endBufferSize, readBuffers)
         db = eng.upload(hb)
         eng.call_windows(db, want_stats=False)
-        eng.synchronize()
-        G = self.nGenotypes
-        self.nReads = np.array(hb.seg_n_good, dtype=np.int32)                                        # :286-287
-        self.genotypeLikelihoods = db.gl.cpu().numpy()[:nInd * G].reshape(nInd, G).copy()            # [ind][genotype]
-        self.genotypeLogLikelihoods = db.logl.cpu().numpy()[:nInd * G].reshape(nInd, G).copy()
-        self.goodnessOfFitValues = db.gof.cpu().numpy()[:nInd * G].reshape(G, nInd).copy()           # [genotype][ind]
-        self.haplotypeLikelihoods = db.loglik.cpu().numpy()[:hb.n_pairs].reshape(H, -1).copy()
-        like, score = eng.haplotype_scores(db)                                                        # cgenotype.pyx:148-161
-        self.haplotypeScore = int(score[0])
-        for g in genotypes:
-            g.hap1Like, g.hap2Like = float(like[index[id(g.hap1)]]), float(like[index[id(g.hap2)]])
-        self._db = db
+        like, score = eng.haplotype_scores(db)
+        self._readSetup(db, 0, db.gl.cpu().numpy(), db.logl.cpu().numpy(), db.gof.cpu().numpy(), db.loglik.cpu().numpy(), like, score)
         return self
 
     # ---- SURVEY 8(f) rank 1 ----------------------------------------------------------------------------
@@ -415,18 +470,17 @@ class Population:
         db = self._db
         eng.em(db, maxIters, int(self.options.useEMLikelihoods))
         eng.synchronize()
-        nInd, G = self.nIndividuals, self.nGenotypes
-        self.frequencies = db.freq.cpu().numpy()[:self.nHaplotypes].copy()
-        self.EMLikelihoods = db.em.cpu().numpy()[:nInd * G].reshape(nInd, G).copy()
-        idx = db.calls.cpu().numpy()[:nInd]
-        self.genotypeCalls = [None if g < 0 else self.genotypes[g] for g in idx]                     # :623-676
-        self.emIterations = int(db.em_iters.cpu().numpy()[0])
+        self._readCall(db.freq.cpu().numpy(), db.em.cpu().numpy(), db.calls.cpu().numpy(), db.em_iters.cpu().numpy())
         self.computeVariantPosteriors()
         self.vcfInfo, self.vcfFilter = {}, {}
         if computeVCFFields != 0 and len(self.variantPosteriors) > 0:                                # :718-720
             self.computeVariantINFO()
             self.computeVariantFILTER()
         return self
+
+    def reset(self):                                                                                  # :166-195
+        self.variantPosteriors, self.varsByPos, self.vcfInfo, self.vcfFilter = {}, {}, {}, {}
+        self.variants, self.haplotypes, self.genotypes, self.genotypeCalls = [], [], [], []
 
     def computeVariantINFO(self):                                                                     # :155-158
         self.vcfInfo = vcfINFO(self.frequencies, self.variantPosteriors, self.genotypeCalls, self.genotypes, self.haplotypes,
@@ -441,19 +495,23 @@ class Population:
 
     def calculatePosterior(self, var, flatPrior=0):                                                   # :459-594
         prior = 0.5 if flatPrior == 1 else var.calculatePrior(getattr(self, "refFile", None))
-        return float(get_engine().variant_posteriors(self._db, [0], self._masks([var]), [prior])[0])
+        return float(get_engine().variant_posteriors(self._db, [self._w], self._masks([var]), [prior])[0])
 
-    def computeVariantPosteriors(self):                                                               # :596-621
+    def _distinctVariants(self):
         vs, done = [], set()
         for h in self.haplotypes:
             for v in h.variants:
                 if v not in done:
                     done.add(v); vs.append(v)
+        return vs
+
+    def computeVariantPosteriors(self, posteriors=None):                                              # :596-621
+        vs = self._distinctVariants()
         self.variantPosteriors, self.varsByPos = {}, {}
         if not vs:
             return
-        post = get_engine().variant_posteriors(self._db, [0] * len(vs), self._masks(vs),
-                                               [v.calculatePrior(getattr(self, "refFile", None)) for v in vs])
+        post = posteriors if posteriors is not None else get_engine().variant_posteriors(
+            self._db, [self._w] * len(vs), self._masks(vs), [v.calculatePrior(getattr(self, "refFile", None)) for v in vs])
         for v, p in zip(vs, post):
             if p >= self.options.minPosterior:
                 self.variantPosteriors[v] = float(p)
@@ -462,7 +520,7 @@ class Population:
     def computeGenotypeCallAndLikelihoods(self, sampleIndex, variantsThisPos, haplotypeIsRefAtThisPos):
         """vcfutils.pyx:163-334 for one sample and one VCF position.  Returns the reference's 7-tuple."""
         vih = np.array([[v in h.variants for v in variantsThisPos] for h in self.haplotypes], dtype=np.int32)
-        ph, lik, out4 = get_engine().genotype_calls(self._db, [dict(window=0, var_in_hap=vih, is_ref=haplotypeIsRefAtThisPos)])[0]
+        ph, lik, out4 = get_engine().genotype_calls(self._db, [dict(window=self._w, var_in_hap=vih, is_ref=haplotypeIsRefAtThisPos)])[0]
         i = sampleIndex
         return (int(ph[i][0]), int(ph[i][1]), lik[i].tolist(), float(out4[i][0]), float(out4[i][1]), float(out4[i][2]), float(out4[i][3]))
 

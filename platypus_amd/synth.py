@@ -161,3 +161,92 @@ def config2(n_windows=10000, seed=2002):
 def config5(n_windows=2000, n_ind=100, seed=5005):
     """BASELINE config 5: population mode, 100 samples at 30x each, haplotype frequencies ~ Beta(0.5, 2)."""
     return make_snp_windows(n_windows, seed, read_len=150, depth=30, n_ind=n_ind, hap_freq_beta=(0.5, 2.0))
+
+
+# ---- BASELINE config 4: regions with reads, for the region pipeline (candidates -> windows -> records) ---------------------
+
+def _read_with_cigar(ref, p0, L, carried):
+    """Sequence, CIGAR [(op, len)] and end position of a read starting at reference position p0 that carries the variants
+    `carried` = sorted [(pos, removed, added)] (Platypus position convention: an indel sits after the base at pos)."""
+    seq, cig, rp = bytearray(), [], p0
+
+    def push(op, n):
+        if n > 0:
+            if cig and cig[-1][0] == op:
+                cig[-1] = (op, cig[-1][1] + n)
+            else:
+                cig.append((op, n))
+    todo = [v for v in carried if v[0] >= p0]
+    while len(seq) < L:
+        v = todo[0] if todo else None
+        if v is None or v[0] - rp >= L - len(seq):
+            k = L - len(seq); seq += ref[rp:rp + k]; push(0, k); rp += k
+            break
+        pos, rem, add = v
+        if len(rem) == len(add):
+            k = pos - rp; seq += ref[rp:rp + k] + add; push(0, k + len(add)); rp = pos + len(add)
+        elif len(rem) == 0:
+            k = pos - rp + 1; seq += ref[rp:rp + k]; push(0, k); seq += add; push(1, len(add)); rp = pos + 1
+        else:
+            k = pos - rp + 1; seq += ref[rp:rp + k]; push(0, k); push(2, len(rem)); rp = pos + 1 + len(rem)
+        todo = [x for x in todo if x[0] >= rp]
+    seq = seq[:L]
+    out, used = [], 0
+    for op, n in cig:
+        if op in (0, 1):
+            n = min(n, L - used); used += n
+        if n > 0:
+            out.append((op, n))
+    while out and out[-1][0] == 2:
+        out.pop()
+    return bytes(seq), out, p0 + sum(n for op, n in out if op in (0, 2))
+
+
+def config4_region(index, seed=4004, region_len=100000, n_samples=1, depth=30, read_len=150, snp_rate=1e-3, indel_rate=1e-4,
+                   flank=1000, err=1e-3):
+    """One region of BASELINE config 4, generated procedurally from (seed, index): its own contig `r<index>` (flank + region +
+    flank), SNPs at snp_rate and 1..10 bp indels at indel_rate inside the region, a diploid donor per sample (each variant on
+    either haplotype with probability 1/2, so hets and homs mix), `depth`x reads of read_len with the CIGAR an aligner
+    would report, 0.1 % substitution errors, qualities ~ clipped N(35, 5), mapq 60.
+    Returns dict(chrom, start, end, ref (bytes), variants [(pos, removed, added)], samples [list of read dicts])."""
+    rng = np.random.Generator(np.random.PCG64([seed, index]))
+    n = region_len + 2 * flank
+    ref = bytes(_rand_bases(rng, n))
+    start, end = flank, flank + region_len
+    acgt = b"ACGT"
+    variants, last = [], start + 20
+    n_snp, n_indel = rng.poisson(region_len * snp_rate), rng.poisson(region_len * indel_rate)
+    kinds = [0] * int(n_snp) + [1] * int(n_indel)
+    spots = np.sort(rng.choice(np.arange(start + 20, end - 40), size=min(len(kinds), max(0, region_len - 60)), replace=False))
+    rng.shuffle(kinds)
+    for p, kind in zip(spots.tolist(), kinds):
+        if p < last:
+            continue
+        if kind == 0:
+            variants.append((p, ref[p:p + 1], bytes([acgt[(acgt.index(ref[p]) + 1 + int(rng.integers(0, 3))) % 4]])))
+            last = p + 2
+        else:
+            k = 1 + int(min(9, rng.geometric(0.4) - 1))
+            if rng.random() < 0.5:
+                variants.append((p, b"", bytes(_rand_bases(rng, k))))
+                last = p + 3
+            else:
+                variants.append((p, ref[p + 1:p + 1 + k], b""))
+                last = p + k + 3
+    samples = []
+    for _ in range(n_samples):
+        carry = [[v for v in variants if rng.random() < 0.5] for _ in range(2)]
+        reads = []
+        for _ in range(int(depth * region_len / read_len)):
+            h = carry[int(rng.integers(0, 2))]
+            p0 = int(rng.integers(start - read_len + 10, end - 10))
+            seq, cig, e = _read_with_cigar(ref, p0, read_len, [v for v in h if p0 <= v[0] < p0 + read_len + 12])
+            s = np.frombuffer(seq, dtype=np.uint8).copy()
+            bad = np.nonzero(rng.random(len(s)) < err)[0]
+            if len(bad):
+                s[bad] = _other_base(rng, s[bad])
+            q = np.clip(np.rint(rng.normal(35, 5, size=len(s))), 2, 41).astype(np.uint8)
+            reads.append(dict(seq=s.tobytes(), qual=q.tobytes(), pos=p0, end=e, mapq=60, flag=3 | (16 if rng.random() < 0.5 else 0), cigar=cig))
+        reads.sort(key=lambda r: r["pos"])
+        samples.append(reads)
+    return dict(chrom="r%d" % index, start=start, end=end, ref=ref, variants=variants, samples=samples)

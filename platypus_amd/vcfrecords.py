@@ -126,6 +126,15 @@ def _read_dict(r):
     return dict(seq=r.seq, qual=r.qual, pos=r.pos, end=r.end, mapq=r.mapq, flag=r.bitFlag, cigar=r.cigarOps)
 
 
+def infoStatsWindow(variants, readBuffers, genotypeCalls):
+    """One window of Engine.variant_read_stats: the variants of the INFO dictionary (in its order), the good and bad reads
+    between the window pointers of every sample, and `variant in genotypeCall` per (variant, sample)."""
+    return dict(variants=[dict(pos=v.refPos, removed=v.removed, added=v.added, bam_min=v.bamMinPos, bam_max=v.bamMaxPos) for v in variants],
+                samples=[dict(good=[_read_dict(r) for r in b.reads.window()], bad=[_read_dict(r) for r in b.badReads.window()])
+                         for b in readBuffers],
+                var_in_genotype=[[int(g is not None and v in g) for g in genotypeCalls] for v in variants])
+
+
 def vcfINFO(haplotypeFrequencies, variantPosteriors, genotypeCalls, genotypes, haplotypes, readBuffers, nHaplotypes, options, refFile,
             hapScore=None, readStats=None):
     """vcfutils.pyx:1226-1460.  The loop over every read of every sample (:1300-1390) is plat_variant_read_stats_batch; pass
@@ -137,11 +146,8 @@ def vcfINFO(haplotypeFrequencies, variantPosteriors, genotypeCalls, genotypes, h
     info = getHaplotypeInfo(haplotypes, variantPosteriors, haplotypeFrequencies, nHaplotypes)
     vs = list(info.keys())
     if readStats is None:
-        win = dict(variants=[dict(pos=v.refPos, removed=v.removed, added=v.added, bam_min=v.bamMinPos, bam_max=v.bamMaxPos) for v in vs],
-                   samples=[dict(good=[_read_dict(r) for r in b.reads.window()], bad=[_read_dict(r) for r in b.badReads.window()])
-                            for b in readBuffers],
-                   var_in_genotype=[[int(g is not None and v in g) for g in genotypeCalls] for v in vs])
-        readStats = hostapi.get_engine().variant_read_stats([win], bad_reads_window=options.badReadsWindow,
+        readStats = hostapi.get_engine().variant_read_stats([infoStatsWindow(vs, readBuffers, genotypeCalls)],
+                                                            bad_reads_window=options.badReadsWindow,
                                                             exact=options.countOnlyExactIndelMatches)[0]
     for v, (counts, nReads, nVarReads, minQuals) in zip(vs, readStats):
         d = info[v]
@@ -305,6 +311,25 @@ def _phred(p):
     return int(min(99, py2_round(-10.0 * math.log10(max(1e-10, 1.0 - p)))))
 
 
+def genotypeCallSites(varsByPos, haplotypes, allVariants, window=0):
+    """The inputs of computeGenotypeCallAndLikelihoods for every position of a window, as outputCallToVCF builds them
+    (vcfutils.pyx:400-426): varThisPosInHap[h][k] and haplotypeIsRefAtThisPos[h]."""
+    sites = []
+    for POS in sorted(varsByPos.keys()):
+        variants = varsByPos[POS]
+        vih = np.array([[int(v in h.variants) for v in variants] for h in haplotypes], dtype=np.int32).reshape(len(haplotypes), len(variants))
+        isRef = np.array([int(not any(v.minRefPos <= POS <= v.maxRefPos for v in h.variants if v in variants or v in allVariants))
+                          for h in haplotypes], dtype=np.int32)
+        sites.append(dict(window=window, var_in_hap=vih, is_ref=isRef))
+    return sites
+
+
+def genotypeCallTuples(results, nIndividuals):
+    """Engine.genotype_calls output -> the reference's 7-tuples, [site][sample]."""
+    return [[(int(ph[i][0]), int(ph[i][1]), lik[i].tolist(), float(o4[i][0]), float(o4[i][1]), float(o4[i][2]), float(o4[i][3]))
+             for i in range(nIndividuals)] for ph, lik, o4 in results]
+
+
 def outputCallToVCF(varsByPos, vcfInfo, vcfFilter, haplotypes, genotypes, haplotypeFrequencies, genotypeLikelihoods, gofValues,
                     haplotypeIndexes, readBuffers, nIndividuals, vcfFile, refFile, outputFile, options, allVariants, windowStart, windowEnd,
                     population=None, genotypeCalls=None):
@@ -316,18 +341,10 @@ def outputCallToVCF(varsByPos, vcfInfo, vcfFilter, haplotypes, genotypes, haplot
     positions = sorted(varsByPos.keys())
     if not positions:
         return
-    sites = []
-    for POS in positions:                                                                            # :400-426
-        variants = varsByPos[POS]
-        vih = np.array([[int(v in h.variants) for v in variants] for h in haplotypes], dtype=np.int32).reshape(len(haplotypes), len(variants))
-        isRef = np.array([int(not any(v.minRefPos <= POS <= v.maxRefPos for v in h.variants if v in variants or v in allVariants))
-                          for h in haplotypes], dtype=np.int32)
-        sites.append(dict(window=0, var_in_hap=vih, is_ref=isRef))
     if genotypeCalls is None:
         from . import hostapi
-        res = hostapi.get_engine().genotype_calls(population._db, sites)
-        genotypeCalls = [[(int(ph[i][0]), int(ph[i][1]), lik[i].tolist(), float(o4[i][0]), float(o4[i][1]), float(o4[i][2]), float(o4[i][3]))
-                          for i in range(nIndividuals)] for ph, lik, o4 in res]
+        sites = genotypeCallSites(varsByPos, haplotypes, allVariants, getattr(population, "_w", 0))
+        genotypeCalls = genotypeCallTuples(hostapi.get_engine().genotype_calls(population._db, sites), nIndividuals)
     known = vcfFile.getfilter()
     for pi, POS in enumerate(positions):
         variants = varsByPos[POS]

@@ -298,3 +298,30 @@ def test_variant_read_stats_match_reference_golden(oracle, golden_dir):
             assert counts == exp["counts"] and nr == exp["n_reads"] and nvr == exp["n_var_reads"] and mq == exp["min_quals"]
             nsup += counts[2]
     assert nsup > 400
+
+
+def test_tandem_annotation_matches_unmodified_reference_build():
+    """platypus_amd.indelprior.annotate against oracle/_ref/libtandem_ref.so = the UNMODIFIED src/c/tandem.c (built by
+    oracle/Makefile from where it lies in the reference tree; the prebuilt file travels to the GPU box)."""
+    import ctypes as C
+    import os
+    import numpy as np
+    import pytest
+    from platypus_amd.indelprior import annotate
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libtandem_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libtandem_ref.so not built (reference tree absent)")
+    lib = C.CDLL(so)
+    rng = np.random.default_rng(11)
+    for it in range(400):
+        n = int(rng.integers(1, 300))
+        seq = bytearray(bytes(rng.choice(list(b"ACGT" if it % 3 else b"ACGTNacgtn"), n).astype(np.uint8)))
+        for _ in range(int(rng.integers(0, 5))):
+            p = int(rng.integers(0, n)); u = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 13))).astype(np.uint8)); k = int(rng.integers(2, 90))
+            seq[p:p + k] = (u * k)[:k]
+        seq = bytes(seq[:n])
+        for full in (True, False):
+            s, d = C.create_string_buffer(n + 1), C.create_string_buffer(n + 1)
+            lib.annotate(seq, s, d, -n if full else n)
+            got = annotate(seq, full)
+            assert (list(got[0]), list(got[1])) == (list(s.raw[:n]), list(d.raw[:n])), (seq, full)
