@@ -19,6 +19,8 @@ def call_variants(argv):
     from . import synth
     from .engine import Engine
     name, _, n = opts.synthetic.partition(":")
+    if name == "config4":
+        return call_variants_config4(opts, int(n or 8))
     hb = {"config1": lambda: synth.config1(), "config2": lambda: synth.config2(int(n or 10000)),
           "config5": lambda: synth.config5(int(n or 200), 100)}[name]()
     from . import sharding
@@ -38,6 +40,55 @@ def call_variants(argv):
             f.write("%s\t%s\t%s\n" % (line, fr, ",".join(str(int(c)) for c in calls[w])))
     print(json.dumps(dict(windows=hb.n_windows, pairs=int(st.n_pairs), dp_reference=int(st.n_dp_reference),
                           dp_launched=int(st.n_dp_launched), output=opts.output)))
+
+
+def call_variants_config4(opts, n_regions):
+    """BASELINE config 4 in miniature: procedurally generated regions with reads -> candidates -> windows -> records, every
+    device stage batched over all windows (platypus_amd.caller.callVariantsInRegions).  Under torch.distributed.run the regions
+    are dealt round-robin to the ranks (runner.py:473-474), each rank drives its own GPU, and the record lines are gathered to
+    rank 0 and merged in (chromosome, position) order (runner.py:301-352).  VCF records (no header) go to --output."""
+    import io
+    import os
+    import time
+    from . import caller, hostapi as H, sharding, synth
+    from .vcfrecords import VCF
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        gpu = torch.cuda.is_available()
+        # (PLAT_DIST_BACKEND=gloo: ranks sharing one GPU, as the single-GPU test box needs; RCCL wants one device per rank)
+        dist.init_process_group(os.environ.get("PLAT_DIST_BACKEND", "nccl" if gpu else "gloo"), rank=rank, world_size=world)
+        if gpu:
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count())
+    opts.originalMaxHaplotypes = opts.maxHaplotypes
+    size = min(int(opts.bufferSize), 100000)
+    mine = sharding.regions_for_rank(n_regions, rank, world)
+    regs = [synth.config4_region(i, region_len=size, n_samples=1, read_len=int(opts.rlen)) for i in mine]
+    fasta = H.FastaFile({r["chrom"]: r["ref"] for r in regs})
+    work = [(r["chrom"], r["start"], r["end"],
+             [H.bamReadBuffer([H.AlignedRead(x["seq"], x["qual"], x["pos"], x["mapq"], x["flag"], end=x["end"], cigarOps=x["cigar"])
+                               for x in r["samples"][0]], sample="S1")]) for r in regs]
+    t0 = time.time()
+    text = io.StringIO()
+    n_windows = caller.callVariantsInRegions(work, fasta, opts, VCF(["S1"]), text) if work else 0
+    recs = sorted(sharding.records_from_vcf_text(text.getvalue()), key=lambda r: (sharding.chrom_key(r[0]), r[1]))
+    device = None
+    if dist is not None and dist.get_backend() == "nccl":
+        import torch
+        device = torch.device("cuda", torch.cuda.current_device())
+    got = sharding.gather_records(sharding.encode_records(recs), dist, device)
+    dt = time.time() - t0
+    if rank == 0:
+        merged = sharding.merge_record_streams([sharding.decode_records(p) for p in got])
+        with open(opts.output, "w") as f:
+            f.write("".join(line + "\n" for line in merged))
+        print(json.dumps(dict(regions=n_regions, region_len=size, ranks=world, windows_rank0=n_windows, records=len(merged),
+                              seconds=round(dt, 3), output=opts.output)))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():

@@ -40,7 +40,8 @@ def get_engine():
     if _engine is None:
         from .engine import Engine
         import os
-        _engine = Engine(int(os.environ.get("LOCAL_RANK", "0")))
+        import torch
+        _engine = Engine(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
     return _engine
 
 

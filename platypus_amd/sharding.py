@@ -59,7 +59,8 @@ def merge_record_streams(streams):
 
 def format_window_records(hb, logl, windows=None, chrom="1"):
     """Deterministic per-window text records (chrom, window start, H, genotype log-likelihoods rounded to 2 dp as the
-    VCF GL field is, vcfutils.pyx) used as the gather payload until the VCF writer ('next' row f3) exists."""
+    VCF GL field is, vcfutils.pyx): the gather payload of the likelihood-only configurations (the region pipeline gathers real VCF
+    record lines, records_from_vcf_text)."""
     out = []
     ws = range(hb.n_windows) if windows is None else windows
     for w in ws:
@@ -68,6 +69,16 @@ def format_window_records(hb, logl, windows=None, chrom="1"):
         o = int(hb.gl_off[w])
         gls = ",".join("%.2f" % v for v in logl[o:o + G * hb.n_ind])
         out.append((chrom, int(hb.win_start[w]), "%s\t%d\t%d\t%s" % (chrom, int(hb.win_start[w]), H, gls)))
+    return out
+
+
+def records_from_vcf_text(text):
+    """(chrom, 0-based position, line) per VCF record line: the unit the ordered merge works on (runner.py:77-82)."""
+    out = []
+    for line in text.split("\n"):
+        if line and not line.startswith("#"):
+            chrom, pos = line.split("\t", 2)[:2]
+            out.append((chrom, int(pos) - 1, line))
     return out
 
 

@@ -62,3 +62,21 @@ def test_batched_caller_handles_samples_without_reads_and_empty_regions():
                                  [(regs[0]["chrom"], 10, 60, [H.bamReadBuffer([], sample=s) for s in names])], fasta, opts, VCF(names), out)
     lines = out.getvalue().split("\n")[:-1]
     assert lines and all(ln.split("\t")[10].startswith("./.") for ln in lines if ln.startswith(regs[0]["chrom"] + "\t"))
+
+
+def test_cli_config4_two_ranks_equals_one_rank(tmp_path):
+    """`callVariants --synthetic config4:N`: the same VCF records from one process and from two ranks (regions dealt round-robin,
+    record lines gathered to rank 0 and merged in (chromosome, position) order) -- the two ranks share the one GPU here."""
+    import json, os, socket, subprocess, sys
+    one, two = tmp_path / "one.vcf", tmp_path / "two.vcf"
+    base = ["callVariants", "--synthetic", "config4:5", "--bufferSize", "4000"]
+    r = subprocess.run([sys.executable, "-m", "platypus_amd"] + base + ["--output", str(one)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-800:]
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["records"] > 10
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, PLAT_DIST_BACKEND="gloo")        # both ranks drive GPU 0; RCCL needs one device per rank
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "platypus_amd"] + base + ["--output", str(two)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, (r.stderr[-1500:], r.stdout[-500:])
+    assert one.read_text() == two.read_text()

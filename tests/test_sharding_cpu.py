@@ -60,3 +60,12 @@ def test_record_roundtrip():
     recs = [("1", 5, "1\t5\t2\t-1.00,-2.50"), ("X", 7, "x")]
     assert sharding.decode_records(sharding.encode_records(recs)) == recs
     assert sharding.decode_records(b"") == []
+
+
+def test_vcf_text_to_merge_records():
+    text = "r1\t101\t.\tA\tC\t50\tPASS\tx\tGT\t0/1\nr0\t7\t.\tG\tT\t9\tQ20\ty\tGT\t1/1\n#comment\n"
+    recs = sharding.records_from_vcf_text(text)
+    assert [(c, p) for c, p, _ in recs] == [("r1", 100), ("r0", 6)]
+    merged = sharding.merge_record_streams([[recs[1]], [recs[0]]])
+    assert merged == [text.split("\n")[1], text.split("\n")[0]]
+    assert sharding.chrom_key("r10") > sharding.chrom_key("r9")             # numeric once the letters of "CHR" are stripped
