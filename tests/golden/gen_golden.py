@@ -2240,7 +2240,7 @@ def gen_regionprep(out):
         opts = types.SimpleNamespace(minReads=int(rng.choice([2, 2, 3])), maxSize=int(rng.choice([1500, 25])), maxVariants=8, verbosity=0)
         res = hap_drv.filter_variants(objs, 150, opts.minReads, opts.maxSize, opts)
         filt.append(dict(variants=rec, min_reads=opts.minReads, max_size=opts.maxSize, out=[list(t) for t in res]))
-        uniq = sorted(set(hap_drv.Variant(b"20", p_, r, a, ns, int(rng.choice([1, 1, 4, 5])), -1) for p_, r, a, ns, src_ in raw))
+        uniq = sorted(dict.fromkeys(hap_drv.Variant(b"20", p_, r, a, ns, int(rng.choice([1, 1, 4, 5])), -1) for p_, r, a, ns, src_ in raw))
         for k, v in enumerate(uniq):
             v.idx = k
         rec2 = [dict(pos=v.refPos, removed=v.removed.decode(), added=v.added.decode(), n_supporting=v.nSupportingReads, source=v.varSource) for v in uniq]
@@ -2280,7 +2280,7 @@ def gen_regionprep(out):
             else:
                 rem, add = rnd(rng, int(rng.choice([1, 3, 12, 40]))), b""
             vs.append(hap_drv.Variant(b"20" if rng.random() < 0.97 else b"21", p_, rem, add, 2, 1, -1))
-        vs = sorted(set(vs))
+        vs = sorted(dict.fromkeys(vs))          # (insertion order: reproducible, unlike a set of hashed byte strings)
         for k, v in enumerate(vs):
             v.idx = k
         opts = types.SimpleNamespace(rlen=int(rng.choice([100, 150])), mergeClusteredVariants=int(rng.random() < 0.85), largeWindows=int(rng.random() < 0.15),
