@@ -29,7 +29,7 @@ namespace plat {
 // (tandem repeats: many arg-max diagonals) go to an overflow area behind the npairs primary slots, reserved
 // with one global atomic per such pair.  (A single job counter bumped by every pair saturates one L2
 // atomic unit: ~90 atomics/us, i.e. ~20 ms for 2M pairs -- measured in round 1.)
-struct PairRec { int32_t extra_base, idx0; int16_t ncand, orig_k; uint8_t mapq, pad[3]; };   // ncand: -1 skipped, -2 read < 7 bp, -3 exact match (idx0 = read length)
+struct PairRec { int32_t extra_base, idx0; int16_t ncand, orig_k; uint8_t mapq, pad[3]; };   // ncand: -1 skipped, -2 read < 7 bp, -3 exact match (idx0 = read length), -4 ungapped alignment proven optimal (idx0 = read length, extra_base = score)
 struct Job { uint32_t col; int32_t hap, idx, len; };     // col = tile dword index of the read's column; len 0 = empty slot;
                                                          // hap bit 30 (JOB_BIGQ): the read's quality sum forbids the 32-bit SWAR adds
 constexpr int32_t JOB_BIGQ = 1 << 30;
@@ -173,6 +173,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     __shared__ int s_off[65];
     __shared__ unsigned s_dirty[2];                      // bit rl: read rl of the group holds a byte other than A, C, G, T
     __shared__ unsigned s_qsum[64];                      // sum of the base qualities of read rl (picks the DP's add flavour)
+    __shared__ unsigned s_qmin[64];                      // smallest base quality of read rl (k_seed's ungapped-alignment proof)
     const int w = blockIdx.x;
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
     if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
@@ -210,7 +211,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
         if (bad & 0x80808080u) set_err(cnt, PLAT_ERR_BAD_INPUT);
     }
     if (tid < 2) s_dirty[tid] = 0u;
-    if (tid < 64) s_qsum[tid] = 0u;
+    if (tid < 64) { s_qsum[tid] = 0u; s_qmin[tid] = 255u; }
     unsigned* s_pl = (unsigned*)(psm + 2 * qoff);        // [chunk][plane][half][64 reads] bit-plane accumulators (staged windows)
     const int nchunks = (rows - 8 + 63) >> 6;
     if (staged)
@@ -245,7 +246,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             const int o = s_off[rl], L = s_off[rl + 1] - o;
             uint32_t* tp = tile + toff + (long long)(4 * g) * R + c0 + rl;
             bool dirty = false;
-            unsigned qs = 0, n0 = 0, n1 = 0;
+            unsigned qs = 0, qm = 255u, n0 = 0, n1 = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = 4 * g + j;
@@ -254,6 +255,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
                     const unsigned ch = staged ? lseq[o + i] : gs[o + i];
                     const unsigned ql = staged ? lqual[o + i] : gq[o + i];
                     qs += ql;
+                    qm = min(qm, ql);
                     const unsigned b2 = base2(ch);
                     n0 |= (b2 & 1u) << j;
                     n1 |= (b2 >> 1) << j;
@@ -265,6 +267,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             }
             if (dirty) atomicOr(&s_dirty[rl >> 5], 1u << (rl & 31));
             if (qs) atomicAdd(&s_qsum[rl], qs);
+            if (qm < s_qmin[rl]) atomicMin(&s_qmin[rl], qm);   // look first: most threads do not lower the minimum
             if (staged && 4 * g < rows - 8) {               // the 4 bases of this thread: 4 bits of each plane, inside one 32-bit half
                 const int c = (4 * g) >> 6, half = ((4 * g) >> 5) & 1, sh = (4 * g) & 31;
                 if (n0) atomicOr(&s_pl[((c * 2 + 0) * 2 + half) * 64 + rl], n0 << sh);
@@ -304,6 +307,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     if (tid < nr) {
         my_ri.lfm |= ((s_dirty[tid >> 5] >> (tid & 31)) & 1u) << 17;
         my_ri.lfm |= (s_qsum[tid] > (unsigned)DP_SWAR_MAX_QSUM ? 1u : 0u) << 18;
+        my_ri.lfm |= min(s_qmin[tid], 31u) << 19;        // flags bits 3..7
         rinfo[rb + c0 + tid] = my_ri;
     }
 }
@@ -498,7 +502,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
        const long long* __restrict__ tile_off, const ReadInfo* __restrict__ rinfo,
        const uint16_t* __restrict__ codes, uint32_t* __restrict__ hapw, uint8_t* __restrict__ hap_has_n,
        PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
-       SlowRec* __restrict__ slow_list, int tsize_max, int maxhap)
+       SlowRec* __restrict__ slow_list, int tsize_max, int maxhap, int allow_ungapped, const uint32_t* __restrict__ tile)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nw64 = ((maxhap + 63) >> 6) + 8;           // plane words incl. slack for the shifted window of a hypothesis
@@ -542,6 +546,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     if (tid < 3) s_scal[tid] = tid == 1;                 // has_n = 0, maxmult = 1, other-than-ACGTN = 0
     signed char* s_go = (signed char*)(s_scal + 4);      // LDS copy of the gap-open table
     unsigned* trip = (unsigned*)(s_scal + 4 + 16);       // [32] (code + 1) | (occurrences beyond the second) << 16
+    unsigned char* s_gmin = (unsigned char*)(trip + 32); // [nw64] smallest gap-open penalty of each chunk of 64 haplotype positions
     if (tid < 49) s_go[tid] = c_homopol_go[tid];
     if (tid < 32) trip[tid] = 0u;
     for (int i = tid; i < 256; i += nthr) ((uint4*)table)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -578,10 +583,15 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
             const unsigned b3 = ldb(t + 3);
             const int p = 64 * t + lane;
             if (lane == 0) { h0[t] = P0.m0; h1[t] = P0.m1; eqp[t] = P0.me; }
-            if (p < hapLen && first_group) {
+            {
                 const u64 v = funnel(P0.me, P1.me, lane);
                 const int run = min(48, (int)__ffsll((long long)~v) - 1);     // trailing ones of v (v never has 64 ones beyond the cap)
-                hapw[hoff + p] = hap_word(b0, (unsigned)s_go[run < 0 ? 48 : run]);
+                const int go = s_go[run < 0 ? 48 : run];
+                if (p < hapLen && first_group) hapw[hoff + p] = hap_word(b0, (unsigned)go);
+                int gm = p < hapLen ? go : 127;
+#pragma unroll
+                for (int s2 = 32; s2 > 0; s2 >>= 1) gm = min(gm, __shfl_xor(gm, s2));
+                if (lane == 0) s_gmin[t] = (unsigned char)gm;
             }
             if (p < hapLen - 7) {
                 const unsigned code = plane_code(P0.m0, P1.m0, P0.m1, P1.m1, lane);
@@ -682,6 +692,8 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         }
         int dstar = idx0;
         bool proven = false, triedB = false, exact = false;
+        u64 missA[4] = {0ull, 0ull, 0ull, 0ull}, uniqA[4] = {0ull, 0ull, 0ull, 0ull};   // of hypothesis A, when it is proven (see "ungapped" below)
+        bool provenA = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool run = canfast && !proven && dstar >= 0 && (attempt == 0 || triedB);
             if (__any(run)) {
@@ -702,8 +714,10 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 for (int c = 0; c < 4; ++c) P2[c] = Z[c] & ((Z[c] >> 1) | (Z[c + 1] << 63));
                 P2[4] = 0ull;
                 int C = 0, NUc = 0;
+                u64 U7[4];                               // k-mer i of the read equals the haplotype's at d*+i AND that k-mer is unique in the haplotype
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
+                    U7[c] = 0ull;
                     if (c < nCmax) {
                         const u64 P4 = P2[c] & ((P2[c] >> 2) | (P2[c + 1] << 62));
                         u64 P7 = P4 & ((P2[c] >> 4) | (P2[c + 1] << 60)) & ((Z[c] >> 6) | (Z[c + 1] << 58));
@@ -712,6 +726,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                         P7 &= msk;
                         C += __popcll(P7);
                         NUc += __popcll(P7 & NU[c]);
+                        U7[c] = P7 & ~NU[c];
                     }
                 }
                 const int X = NUc * (maxmult - 1) + (nk - C) * maxmult;
@@ -722,9 +737,12 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int nb = L - 64 * c;
-                        miss |= ~Z[c] & (nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull)));
+                        const u64 mc = ~Z[c] & (nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull)));
+                        miss |= mc;
+                        if (attempt == 0) { missA[c] = mc; uniqA[c] = U7[c]; }
                     }
                     exact = miss == 0ull;
+                    provenA = attempt == 0;
                 }
             }
             if (attempt == 0) {
@@ -763,6 +781,70 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         // all-match path costs 0; a haplotype N costs 0 as well, align.c:17,314-318) and calign.pyx:242-247 returns it
         // at once.  No DP is launched for the pair.
         const bool zero = ncand == 1 && exact && hap_plain && !((rflags >> 1) & 1);
+        // ---- "ungapped": the read differs from the haplotype in one or two bases on the one candidate diagonal, which is
+        // also the mapping position, and NO other path of the band can be cheaper than paying those mismatches.  Then
+        // the single DP of the pair returns U = sum of the mismatching bases' qualities (align.c cost model: a mismatch costs
+        // qual[y], opening a gap at haplotype position x costs go[x] (+2 for an insertion), nothing is negative) and is not
+        // launched.  Every alternative path is bounded from below with one fact: where 7-mer i of the read equals the
+        // haplotype's 7-mer at d*+i and that 7-mer occurs ONCE in the haplotype, the read has a mismatch in [i, i+7) on every
+        // other diagonal; n such k-mer starts inside an interval give ceil(n/7) disjoint windows, each worth >= the read's
+        // smallest quality m.  With W(a,b) = ceil(#unique-matching starts in [a, b-6) / 7), G = smallest gap-open penalty
+        // of the slice, p_j / q_j the mismatches, Q_j / R_j the suffix / prefix sums of q:
+        //   two or more gap openings                          2G >= U
+        //   another diagonal, no gap                          m W(0,L) >= U
+        //   on d* up to a gap before p_j, then elsewhere      G + m W(p_j+8, L) >= Q_j      (an insertion moves <= 8 bases on)
+        //   elsewhere, one gap, on d* from after p_j          G + m W(0, p_j-7) >= R_j
+        //   elsewhere, one gap, elsewhere again               G + m min(W(0,h), W(h+15,L)) >= U,  h = (L-15)/2
+        // (needs d* >= 8 so that the band is d*-8 .. d*+7; haplotype without N, read of plain A/C/G/T: equal codes = equal bytes)
+        int ung_score = -1;
+        {
+            const int mq = (rflags >> 3) & 31;
+            const bool cand = allow_ungapped && ncand == 1 && orig_in && provenA && !exact && hap_plain && s_scal[0] == 0 &&
+                              !((rflags >> 1) & 1) && mq > 0 && cidx >= 8 && L >= 32;
+            int k = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) k += __popcll(missA[c]);
+            if (cand && k >= 1 && k <= 2) {
+                auto nth = [&](int which) -> int {           // position of the first / last mismatch
+                    int pos = -1;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (missA[c]) {
+                            const int lo = 64 * c + (int)__ffsll((long long)missA[c]) - 1, hi = 64 * c + 63 - (int)__clzll((long long)missA[c]);
+                            if (which == 0) { if (pos < 0) pos = lo; } else pos = hi;
+                        }
+                    }
+                    return pos;
+                };
+                auto cnt7 = [&](int a, int e) -> int {       // unique-matching k-mer starts in [a, e)
+                    int n = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int lo = max(a - 64 * c, 0), hi = min(e - 64 * c, 64);
+                        if (hi > lo) {
+                            const u64 m1 = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+                            n += __popcll(uniqA[c] & m1);
+                        }
+                    }
+                    return n;
+                };
+                auto W = [&](int a, int bnd) -> int { return (cnt7(max(a, 0), bnd - 6) + 6) / 7; };
+                const int p1 = nth(0), p2 = nth(1);          // k == 1: p1 == p2
+                const uint8_t* rq = b.read_qual + b.read_off[rb + rl];
+                const int q1 = rq[p1], q2 = k == 2 ? rq[p2] : 0;
+                const int U = q1 + q2;
+                const int st = cidx - 8;
+                int G = 127;
+                for (int t = st >> 6; t <= (st + L + 14) >> 6; ++t) G = min(G, (int)s_gmin[t]);
+                const int hh = (L - 15) / 2;
+                bool ok = U <= 2 * G && mq * W(0, L) >= U && G + mq * min(W(0, hh), W(hh + 15, L)) >= U;
+                // first mismatch: Q = U, R = q1; last mismatch (k == 2): Q = q2, R = U
+                ok = ok && G + mq * W(p1 + 8, L) >= U && G + mq * W(0, p1 - 7) >= q1;
+                if (k == 2) ok = ok && G + mq * W(p2 + 8, L) >= q2 && G + mq * W(0, p2 - 7) >= U;
+                if (ok) ung_score = U;
+            }
+        }
+        const bool ungapped = ung_score >= 0;
         // extra job slot for (one candidate that is not the mapping position): one atomic per wave
         int base = 0;
         {
@@ -782,6 +864,9 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 jobs[pidx] = Job{ri.col, h, 0, 0};
             } else if (zero) {
                 pairs[pidx] = PairRec{0, L, (int16_t)-3, 0, mapq, {0, 0, 0}};
+                jobs[pidx] = Job{ri.col, h, cidx, 0};
+            } else if (ungapped) {
+                pairs[pidx] = PairRec{ung_score, L, (int16_t)-4, 0, mapq, {0, 0, 0}};
                 jobs[pidx] = Job{ri.col, h, cidx, 0};
             } else {
                 jobs[pidx] = Job{ri.col, hq, cidx, L};
@@ -904,9 +989,10 @@ k_compact_count(const Job* __restrict__ jobs, const PairRec* __restrict__ pairs,
         live = jobs[j].len != 0;
         if (j < npairs && !live) {
             const PairRec pr = pairs[j];
-            if (pr.ncand < 0) {                          // skipped read: 0.0 (chaplotype.pyx:345-346); read < 7 bp or exact match: score 0
-                out_ll[j] = pr.ncand == -1 ? 0.0 : loglik_of(0, mapq_lut, pr.mapq);
-                if (out_score) out_score[j] = pr.ncand == -1 ? -1 : 0;
+            if (pr.ncand < 0) {                          // skipped read: 0.0 (chaplotype.pyx:345-346); read < 7 bp or exact match: score 0;
+                const int sc = pr.ncand == -4 ? pr.extra_base : 0;       // ungapped alignment proven optimal in k_seed: its score
+                out_ll[j] = pr.ncand == -1 ? 0.0 : loglik_of(sc, mapq_lut, pr.mapq);
+                if (out_score) out_score[j] = pr.ncand == -1 ? -1 : sc;
             }
         }
     }
@@ -1131,7 +1217,7 @@ k_stats(const PairRec* __restrict__ pairs, const Job* __restrict__ jobs, const i
         const PairRec pr = pairs[p];
         if (pr.ncand != -1) {
             aligned = 1;
-            if (pr.ncand == -3) { ndp = 1; cells = 16ull * (unsigned long long)pr.idx0; }   // exact match: the reference runs (and returns from) one DP
+            if (pr.ncand == -3 || pr.ncand == -4) { ndp = 1; cells = 16ull * (unsigned long long)pr.idx0; }   // exact / ungapped: the reference runs one DP
             if (pr.ncand >= 0) {
                 int n = 1;
                 if (!(pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0))) select_best(pr, p, npairs, jobs, job_score, &n);
@@ -1200,7 +1286,7 @@ PLAT_EXPORT int plat_dp_batch(plat_ctx* ctx, int n, int lmax, const uint8_t* hap
 
 static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStream_t st, long long* cnt, int maxhap,
                              int maxread, int maxR, long long npairs, int extra_cap, const int32_t* hap_win, const int32_t* win_rows,
-                             const long long* tile_off)
+                             const long long* tile_off, int allow_ungapped)
 {
     int tsize_max = 64;                                        // in dwords
     if (maxhap > 4096) tsize_max = 8192;                       // direct mode: 16384 u16 heads
@@ -1208,9 +1294,10 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     if (tsize_max < 1024) tsize_max = 1024;                    // the 2 x 512 dwords of the multiplicity maps overlay the table
     const int cw = (maxhap + maxread + 8 + 1) & ~1;            // 16-bit diagonal counters of the exact vote, even count
     const size_t nw64 = (((size_t)maxhap + 63) >> 6) + 8;
-    const size_t lds = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 7) & ~(size_t)7) + 4 * nw64 * 8 + 16 + 64 + 128;
-    const size_t lds_slow = lds + (size_t)cw * 2;
-    if (lds_slow > 160 * 1024) return PLAT_ERR_HAP_TOO_LONG;
+    const size_t lds0 = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 7) & ~(size_t)7) + 4 * nw64 * 8 + 16 + 64 + 128;
+    const size_t lds = lds0 + ((nw64 + 15) & ~(size_t)15);    // k_seed: + one byte per chunk of 64 positions (gap-open minima)
+    const size_t lds_slow = lds0 + (size_t)cw * 2;
+    if (lds_slow > 160 * 1024 || lds > 160 * 1024) return PLAT_ERR_HAP_TOO_LONG;
     if (lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (lds_slow > 48 * 1024)
@@ -1220,7 +1307,7 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     hipLaunchKernelGGL(k_seed, dim3(b.n_haps, ngroups > 0 ? ngroups : 1), dim3(64), lds, st, b, hap_win, win_rows, tile_off,
                        (const ReadInfo*)ctx->rinfo.ptr, (const uint16_t*)ctx->codes.ptr, (uint32_t*)ctx->hapw.ptr,
                        (uint8_t*)ctx->hap_flags.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
-                       (SlowRec*)ctx->slow.ptr, tsize_max, maxhap);
+                       (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, allow_ungapped, (const uint32_t*)ctx->tile.ptr);
     hipLaunchKernelGGL(k_seed_slow, dim3(4096), dim3(64), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
                        (const SlowRec*)ctx->slow.ptr, tsize_max, maxhap, cw);
@@ -1319,7 +1406,12 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
             PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_NEXTRA], 0, sizeof(long long), st));
             PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_SLOW_SEED], 0, sizeof(long long), st));
         }
-        if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win, win_rows, tile_off))) return rc;
+        // the ungapped-alignment shortcut applies to plain scores only (the flank score needs the traceback);
+        // PLAT_NO_UNGAPPED=1 sends every such pair through the DP instead (cross-check in tests/test_gpu_parity.py)
+        const char* e_ung = getenv("PLAT_NO_UNGAPPED");    // (read per call: the test flips it inside one process)
+        const int no_ungapped = e_ung && e_ung[0] == '1';
+        if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win, win_rows, tile_off,
+                                    !calc_flank_score && !no_ungapped))) return rc;
         {   // dense list of the live job slots; pairs that need no DP are finished by k_compact_count
             const long long slots_cap = npairs + extra_cap;
             const unsigned nblk = (unsigned)((slots_cap + COMPACT_BLOCK - 1) / COMPACT_BLOCK);

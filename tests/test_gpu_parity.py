@@ -509,3 +509,91 @@ def test_dp_add_flavours_agree_with_oracle(eng, oracle):
     db, st, ll, sc = run_align(eng, hb)
     check_against_oracle(oracle, hb, ll, sc, st)
     assert sc.max() > 1000                                                   # costs far beyond anything config 2 produces
+
+
+def _adversarial_batch(seed, n_windows=260):
+    """Windows built to stress k_seed's ungapped-alignment proof: references with homopolymers and tandem repeats (cheap gaps,
+    non-unique k-mers), reads of 36..250 bp with 0..3 substitutions anywhere -- first and last bases included --, low-quality
+    tails, quality minima down to 1, haplotypes differing by SNPs next to repeats."""
+    from platypus_amd import hostapi as H
+    rng = np.random.default_rng(seed)
+    B = b"ACGT"
+    rnd = lambda n: bytes(rng.choice(list(B), n).astype(np.uint8))
+    specs = []
+    for w in range(n_windows):
+        L = int(rng.choice([36, 76, 100, 150, 150, 250]))
+        buf = min(2 * L, 500)
+        W = int(rng.integers(20, 80))
+        ref = bytearray(rnd(W + 2 * buf + 40))
+        for _ in range(int(rng.integers(0, 6))):
+            p = int(rng.integers(0, len(ref) - 60)); k = int(rng.integers(3, 40))
+            u = rnd(int(rng.choice([1, 1, 1, 2, 3, 4, 6])))
+            ref[p:p + k] = (u * k)[:k]
+        ref = bytes(ref[:W + 2 * buf + 40])
+        ws = 5000
+        base = ref[:W + 2 * buf]
+        haps = [base]
+        for _ in range(int(rng.integers(1, 4))):
+            h = bytearray(base)
+            for _ in range(int(rng.integers(1, 3))):
+                p = buf + int(rng.integers(0, W))
+                h[p] = B[(B.index(h[p]) + 1 + int(rng.integers(0, 3))) % 4]
+            if bytes(h) not in haps:
+                haps.append(bytes(h))
+        reads = []
+        for _ in range(int(rng.integers(20, 60))):
+            src = haps[int(rng.integers(0, len(haps)))]
+            off = int(rng.integers(max(0, buf - L + 7), min(len(src) - L, buf + W - 7) + 1))
+            seq = bytearray(src[off:off + L])
+            for _ in range(int(rng.choice([0, 0, 1, 1, 1, 2, 2, 3]))):
+                p = int(rng.choice([0, 1, 2, L - 1, L - 2, L - 3, int(rng.integers(0, L)), int(rng.integers(0, L))]))
+                seq[p] = B[(B.index(seq[p]) + 1 + int(rng.integers(0, 3))) % 4]
+            q = np.clip(rng.normal(33, 6, L), 1, 60).astype(np.uint8)
+            mode = rng.random()
+            if mode < 0.2:
+                q[L - int(rng.integers(1, 30)):] = rng.integers(1, 12, 1)[0]
+            elif mode < 0.3:
+                q[:] = rng.integers(1, 6, L)
+            elif mode < 0.35:
+                q[int(rng.integers(0, L))] = 0
+            reads.append(H.AlignedRead(bytes(seq), bytes(q.tolist()), ws - buf + off + int(rng.choice([0, 0, 0, 0, 1, -2])), 60, 3))
+        specs.append((haps, ws, ws + W, buf, [H.bamReadBuffer(reads)]))
+        for b_ in specs[-1][4]:
+            b_.setWindowPointers(ws, ws + W)
+    return H._pack_windows(specs)
+
+
+def test_ungapped_shortcut_equals_the_dp_everywhere(eng, oracle):
+    """k_seed finishes pairs whose read differs from the haplotype in one or two bases without a DP when it can prove that no
+    other path of the band is cheaper.  Every score must equal what the DP gives for the same pair (PLAT_NO_UNGAPPED=1 sends
+    all of them through the DP), on a stress batch and on BASELINE config 2; a sample is checked against the oracle too."""
+    import os
+    from platypus_amd import synth
+    used = 0
+    for hb in (_adversarial_batch(1), _adversarial_batch(2), synth.config2(1500, seed=9)):
+        res = {}
+        for mode in ("0", "1"):
+            os.environ["PLAT_NO_UNGAPPED"] = mode
+            try:
+                db = eng.upload(hb)
+                st = eng.align(db, want_stats=True)
+                eng.synchronize()
+                res[mode] = (db.score.cpu().numpy()[:hb.n_pairs].copy(), db.loglik.cpu().numpy()[:hb.n_pairs].copy(), int(st.n_dp_launched))
+            finally:
+                os.environ.pop("PLAT_NO_UNGAPPED", None)
+        assert np.array_equal(res["0"][0], res["1"][0])
+        assert np.array_equal(res["0"][1], res["1"][1])
+        assert res["0"][2] < res["1"][2]                       # the shortcut did take pairs away from the DP
+        used += res["1"][2] - res["0"][2]
+    assert used > 10000
+    hb = _adversarial_batch(3, 40)
+    db = eng.upload(hb)
+    eng.align(db, want_stats=False)
+    eng.synchronize()
+    got = db.loglik.cpu().numpy()
+    for w in range(hb.n_windows):
+        rd = hb.window_reads(w)
+        exp = oracle.align_window(hb.window_haps(w), int(hb.win_start[w]), int(hb.win_end[w]), int(hb.win_flank[w]), rd)
+        R = len(rd["seq"])
+        H_ = hb.win_hap_begin[w + 1] - hb.win_hap_begin[w]
+        assert np.array_equal(got[hb.pair_off[w]:hb.pair_off[w] + H_ * R].reshape(H_, R), np.asarray(exp[0]).reshape(H_, R))
