@@ -176,13 +176,13 @@ def main():
 
     # live per-kernel timing of the dominant kernel (HIP events on the launch stream), untimed extra steps
     eng.profile_enable(True)
-    dp_ms, seed_ms, fin_ms, gen_ms, prep_ms = [], [], [], [], []
+    dp_ms, seed_ms, seedk_ms, fin_ms, gen_ms, prep_ms = [], [], [], [], [], []
     prof = None
     for _ in range(5):
         eng.call_windows(db, want_stats=False)
         prof = eng.profile_last()
         dp_ms.append(prof.ms_dp); seed_ms.append(prof.ms_seed); fin_ms.append(prof.ms_finalize)
-        gen_ms.append(prof.ms_genotype); prep_ms.append(prof.ms_prepare)
+        gen_ms.append(prof.ms_genotype); prep_ms.append(prof.ms_prepare); seedk_ms.append(prof.ms_seed_kernel)
     eng.profile_enable(False)
 
     # the job's one real exchange -- per-rank result records gathered to rank 0 and merged by (chrom, pos)
@@ -206,22 +206,38 @@ def main():
     if rank == 0:
         ms_step = 1e3 * T / a.steps
         dp_avg = float(np.mean(dp_ms))
-        achieved = prof.dp_alg_bytes / (dp_avg * 1e-3) / 1e9
-        traffic, valu = None, None
+        # roofline entries of the two kernels that share the top of the profile: k_dp_jobs (the recurrence) and k_seed
+        # (candidate diagonals + the ungapped-alignment proof).  `roofline` is the one with the longer launch.
+        pm = {}
         tf = os.path.join(ROOT, "profiles", "dp_traffic.json")      # per-launch PMC figures from rocprofv3 --pmc (see profiles/README.md)
         if os.path.exists(tf):
             try:
                 pm = json.load(open(tf))
-                traffic = pm.get("hbm_bytes_per_launch")
-                if pm.get("valu_insts_per_launch") and pm.get("busy_cycles_per_launch"):
-                    # what actually bounds the kernel (SURVEY 8(d) "secondary"): wave-instructions issued per SIMD-cycle.
-                    # A half-rate packed op (v_pk_*, v_alignbit, v_perm: 85 % of this kernel's mix) takes ~4.2 cycles.
-                    cpi = pm["busy_cycles_per_launch"] * 1024.0 / pm["valu_insts_per_launch"]
-                    valu = {"bound": "valu-issue", "insts_per_launch": pm["valu_insts_per_launch"],
-                            "busy_cycles_per_launch": pm["busy_cycles_per_launch"], "simds": 1024,
-                            "cycles_per_inst_per_simd": cpi, "frac_of_half_rate_issue_peak": 4.2 / cpi}
             except Exception:
-                traffic, valu = None, None
+                pm = {}
+
+        def entry(kernel, alg_bytes, ms, counters, note):
+            ach = alg_bytes / (ms * 1e-3) / 1e9
+            sec = None
+            if counters.get("valu_insts_per_launch") and counters.get("busy_cycles_per_launch"):
+                # what actually bounds these kernels (SURVEY 8(d) "secondary"): wave-instructions issued per SIMD-cycle.
+                # A half-rate packed op (v_pk_*, v_alignbit, v_perm: 85 % of the DP's mix) takes ~4.2 cycles.
+                cpi = counters["busy_cycles_per_launch"] * 1024.0 / counters["valu_insts_per_launch"]
+                sec = {"bound": "valu-issue", "insts_per_launch": counters["valu_insts_per_launch"],
+                       "busy_cycles_per_launch": counters["busy_cycles_per_launch"], "simds": 1024,
+                       "cycles_per_inst_per_simd": cpi, "frac_of_half_rate_issue_peak": 4.2 / cpi}
+            return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBPS, "traffic": counters.get("hbm_bytes_per_launch"),
+                    "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": ms, "note": note, "secondary": sec}
+        seedk_avg = float(np.mean(seedk_ms))
+        # k_seed per launch: haplotype bytes in (1 B/base) + DP haplotype words out (4 B/base), read bit planes in (2 bits/base)
+        # + ReadInfo (16 B/read), one PairRec + one Job out per (haplotype, read) pair (32 B)
+        seed_alg = 5 * int(hb.hap_off[-1]) + int(hb.read_off[-1]) // 4 + 16 * hb.n_reads + 32 * hb.n_pairs
+        r_dp = entry("k_dp_jobs", prof.dp_alg_bytes, dp_avg, pm,
+                     "recurrence is VALU-issue bound (packed int16), not HBM bound: see DESIGN.md")
+        r_seed = entry("k_seed", seed_alg, seedk_avg, pm.get("k_seed", {}),
+                       "one wave per (haplotype, 256 reads): LDS k-mer maps + bit-parallel proofs, latency / VALU bound: see DESIGN.md")
+        roof, roof_other = (r_seed, r_dp) if seedk_avg > dp_avg else (r_dp, r_seed)
         line = {
             "metric": "pair-HMM GCUPS (reference-equivalent band cells/s, read->haplotype likelihood path)",
             "value": cells_ref / T / 1e9,
@@ -237,14 +253,11 @@ def main():
             "windows_per_sec": nwin / T,
             "gcups_executed": cells_run / T / 1e9,
             "dp_reference_per_step": ndp_ref / a.steps, "dp_launched_per_step": ndp_run / a.steps,
-            "kernel_ms": {"prepare": float(np.mean(prep_ms)), "seed": float(np.mean(seed_ms)), "dp": dp_avg,
+            "kernel_ms": {"prepare": float(np.mean(prep_ms)), "seed": float(np.mean(seed_ms)), "seed_kernel": seedk_avg, "dp": dp_avg,
                           "finalize": float(np.mean(fin_ms)), "genotype": float(np.mean(gen_ms))},
             "dp_kernel_gcups": 4.0 * (prof.dp_alg_bytes - 34 * prof.dp_jobs) / (dp_avg * 1e-3) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "k_dp_jobs", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(prof.dp_alg_bytes), "avg_launch_ms": dp_avg,
-                         "note": "recurrence is VALU-issue bound (packed int16), not HBM bound: see DESIGN.md",
-                         "secondary": valu},
+            "roofline": roof,
+            "roofline_other": roof_other,
         }
         line["record_gather"] = gather
         if world == 1 and not a.no_cpu_baseline:

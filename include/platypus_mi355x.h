@@ -74,7 +74,7 @@ typedef struct plat_profile {
     float ms_dp;          /* banded DP kernel (the dominant kernel)                               */
     float ms_finalize;    /* candidate selection + score -> log-likelihood                        */
     float ms_genotype;    /* genotype likelihood kernel                                           */
-    float _pad;
+    float ms_seed_kernel; /* k_seed alone (the first and largest kernel of the seed stage)         */
     int64_t dp_jobs;      /* DPs in the DP launch                                                 */
     int64_t dp_alg_bytes; /* algorithmic bytes of the DP launch                                   */
 } plat_profile;

@@ -1308,6 +1308,7 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
                        (const ReadInfo*)ctx->rinfo.ptr, (const uint16_t*)ctx->codes.ptr, (uint32_t*)ctx->hapw.ptr,
                        (uint8_t*)ctx->hap_flags.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
                        (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, allow_ungapped, (const uint32_t*)ctx->tile.ptr);
+    PLAT_EV(ctx, 5, st);                                       // k_seed alone: ev[1] .. ev[5]
     hipLaunchKernelGGL(k_seed_slow, dim3(4096), dim3(64), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
                        (const SlowRec*)ctx->slow.ptr, tsize_max, maxhap, cw);

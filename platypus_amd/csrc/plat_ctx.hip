@@ -90,6 +90,7 @@ PLAT_EXPORT int plat_profile_last(plat_ctx* ctx, plat_profile* out) {
         PLAT_HIP(ctx, hipEventSynchronize(ctx->ev[4]));
         PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_prepare, ctx->ev[0], ctx->ev[1]));
         PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_seed, ctx->ev[1], ctx->ev[2]));
+        PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_seed_kernel, ctx->ev[1], ctx->ev[5]));
         PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_dp, ctx->ev[2], ctx->ev[3]));
         PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_finalize, ctx->ev[3], ctx->ev[4]));
         out->dp_jobs = ctx->prof_dp_jobs;
