@@ -2,8 +2,8 @@
 likelihoods / EM / posteriors -> VCF records.  Same names and argument meaning as the reference:
 
     callVariantsInWindow        src/cython/variantcaller.pyx:74-141
-    generateVariantsInRegion    src/cython/variantcaller.pyx:412-531   (BAM candidates; source VCFs and the assembler tiling are
-                                                                        not wired into this loop)
+    generateVariantsInRegion    src/cython/variantcaller.pyx:412-531   (BAM candidates + assembler tiles; source VCFs are not built)
+    doWeNeedToAssembleThisRegion                          :276-321
     callVariantsInRegion        src/cython/variantcaller.pyx:535-615   (loadBAMData replaced by the caller's read buffers)
 
 in two shapes.  `callVariantsInRegion` walks the windows one at a time exactly as the reference does (a handful of device
@@ -26,9 +26,6 @@ def _unsupported(options):
         raise NotImplementedError("reference-call blocks (outputRefCall, variantcaller.pyx:764-867) are not built")
     if getattr(options, "sourceFile", None):
         raise NotImplementedError("candidates from a source VCF (variantutils.VariantCandidateReader) are not built")
-    if getattr(options, "assemble", 0):
-        raise NotImplementedError("the assembler tiling of generateVariantsInRegion (variantcaller.pyx:496-519) is not wired into "
-                                  "this loop; call assembleReadsAndDetectVariants per tile and add its variants yourself")
     if getattr(options, "HLATyping", 0):
         raise NotImplementedError("HLA mode")
 
@@ -40,6 +37,44 @@ def _candidateRegion(gen, reads):
                 reads=[dict(seq=r.seq, qual=r.qual, pos=r.pos, flag=r.bitFlag, cigar=r.cigarOps) for r in reads])
 
 
+def doWeNeedToAssembleThisRegion(readBuffers, chrom, start, end, options, refSeq=None):
+    """variantcaller.pyx:276-321: window pointers to the tile, then: always (assembleAll, the default), or when a sample's reads
+    carry more than two alignment gaps each or more than a tenth of them are improperly paired."""
+    for b in readBuffers:
+        b.setWindowPointers(start, end)
+    if options.assembleAll:
+        return True
+    for b in readBuffers:
+        n = float(b.reads.windowEnd - b.reads.windowStart)
+        nBad = float(b.badReads.windowEnd - b.badReads.windowStart)
+        if n == 0:
+            continue
+        if b.countAlignmentGaps() / n > 2 or b.countImproperPairs() / (n + nBad) > 0.1:
+            return True
+    return False
+
+
+def _assemblerVariants(regions, refFile, options):
+    """The assembler part of generateVariantsInRegion (:496-519) for every region: tiles of assemblyRegionSize starting
+    every max(100, min(1000, size/2)) bases, ALL tiles of ALL regions assembled in one device batch."""
+    size = options.assemblyRegionSize
+    shift = max(100, min(1000, size // 2))
+    tiles, owner, chroms = [], [], []
+    for k, (chrom, start, end, buffers) in enumerate(regions):
+        for assemStart in range(start, end, shift):
+            assemEnd = min(assemStart + size, end)
+            refStart, refEnd = max(0, assemStart - size), assemEnd + size
+            refSeq = refFile.getSequence(chrom, refStart, refEnd)
+            if doWeNeedToAssembleThisRegion(buffers, chrom, assemStart, assemEnd, options, refSeq):
+                tiles.append(H.assemblyRegion(assemStart, assemEnd, refStart, refEnd, buffers, refSeq, options))
+                owner.append(k); chroms.append(chrom)
+    out = [[] for _ in regions]
+    if tiles:
+        for k, vs in zip(owner, H.assembleRegions(chroms, tiles, options)):
+            out[k].extend(vs)
+    return out
+
+
 def generateVariantsInRegions(regions, refFile, options):
     """generateVariantsInRegion for a list of (chrom, start, end, readBuffers): ONE candidate scan on the device for every
     sample of every region, then the reference's per-sample support filter, merge, left-normalisation and filterVariants.
@@ -49,6 +84,12 @@ def generateVariantsInRegions(regions, refFile, options):
                                                                options.verbosity, options.genSNPs, options.genIndels)
     out = [[] for _ in regions]
     if not options.getVariantsFromBAMs:
+        if not options.assemble:
+            return out
+        merged = _assemblerVariants(regions, refFile, options)
+        for k, cands in enumerate(merged):
+            norm = sorted(leftNormaliseIndel(v, refFile, options.rlen) for v in cands)
+            out[k] = filterVariants(norm, refFile, options.rlen, options.minReads, options.maxSize, options.verbosity, options)
         return out
     gens = [[mk(chrom, start, end) for _ in buffers] for chrom, start, end, buffers in regions]
     scans = [_candidateRegion(g, b.reads.array) for (_, _, _, buffers), gs in zip(regions, gens) for g, b in zip(gs, buffers)]
@@ -67,6 +108,9 @@ def generateVariantsInRegions(regions, refFile, options):
         merged.append(everyone.getCandidates(0))
     if longest > 0:
         options.rlen = options.maxSize if longest >= options.maxSize else longest
+    if options.assemble:
+        for cands, extra in zip(merged, _assemblerVariants(regions, refFile, options)):
+            cands.extend(extra)                                                  # rawBamVariants + assemblerVariants (:521)
     for k, cands in enumerate(merged):
         norm = sorted(leftNormaliseIndel(v, refFile, options.rlen) for v in cands)
         out[k] = filterVariants(norm, refFile, options.rlen, options.minReads, options.maxSize, options.verbosity, options)

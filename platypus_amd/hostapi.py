@@ -204,6 +204,12 @@ class bamReadBuffer:
     def countReadsCoveringRegion(self, start, end):                               # cwindow.pyx:649-653
         return self.reads.countReadsCoveringRegion(start, end)
 
+    def countAlignmentGaps(self):                                                 # cwindow.pyx:598-622
+        return sum(1 for r in list(self.reads.window()) + list(self.badReads.window()) for op, _ in r.cigarOps if 1 <= op <= 4)
+
+    def countImproperPairs(self):                                                 # cwindow.pyx:624-647
+        return sum(1 for r in list(self.reads.window()) + list(self.badReads.window()) if not (r.bitFlag & 2))
+
     def frozenWindow(self):
         """A buffer holding exactly the reads between the current window pointers (batched calling keeps one per window,
         where the reference moves the pointers of the one buffer from window to window)."""
@@ -788,9 +794,9 @@ def infoFieldsFromReadStats(counts, nReadsPerSample, nVarReadsPerSample, minBase
     return info
 
 
-def assembleReadsAndDetectVariants(chrom, assemStart, assemEnd, refStart, refEnd, readBuffers, refSeq, options=None):
-    """assembler.pyx:1429-1476; read selection as loadBAMDataIntoGraph (:1391-1425)."""
-    options = options if options is not None else default_options()
+def assemblyRegion(assemStart, assemEnd, refStart, refEnd, readBuffers, refSeq, options):
+    """One entry of Engine.assemble: the reads loadBAMDataIntoGraph (assembler.pyx:1391-1425) would feed the graph -- the good
+    reads between the window pointers of every sample, bad reads and broken mates if the options say so, QCFail reads never."""
     seqs, quals = [], []
     for buf in readBuffers:
         sel = list(buf.reads.window())
@@ -801,7 +807,17 @@ def assembleReadsAndDetectVariants(chrom, assemStart, assemEnd, refStart, refEnd
         for r in sel:
             if not r.isQCFail():
                 seqs.append(r.seq); quals.append(r.qual)
-    region = dict(ref=bytes(refSeq), ref_start=refStart, assem_start=assemStart, assem_end=assemEnd, seqs=seqs, quals=quals)
-    out = get_engine().assemble([region], kmer_size=options.assemblerKmerSize, min_qual=options.minBaseQual,
-                                min_weight=options.minReads * options.minBaseQual, no_cycles=options.noCycles)[0]
-    return sorted(Variant(chrom, p, r, a, 0, ASSEMBLER_VAR) for p, r, a in out)
+    return dict(ref=bytes(refSeq), ref_start=refStart, assem_start=assemStart, assem_end=assemEnd, seqs=seqs, quals=quals)
+
+
+def assembleRegions(chroms, regions, options):
+    """assembleReadsAndDetectVariants for a list of assemblyRegion()s in one device batch -> per region the sorted variants."""
+    out = get_engine().assemble(regions, kmer_size=options.assemblerKmerSize, min_qual=options.minBaseQual,
+                                min_weight=options.minReads * options.minBaseQual, no_cycles=options.noCycles)
+    return [sorted(Variant(c, p, r, a, 0, ASSEMBLER_VAR) for p, r, a in vs) for c, vs in zip(chroms, out)]
+
+
+def assembleReadsAndDetectVariants(chrom, assemStart, assemEnd, refStart, refEnd, readBuffers, refSeq, options=None):
+    """assembler.pyx:1429-1476; read selection as loadBAMDataIntoGraph (:1391-1425)."""
+    options = options if options is not None else default_options()
+    return assembleRegions([chrom], [assemblyRegion(assemStart, assemEnd, refStart, refEnd, readBuffers, refSeq, options)], options)[0]

@@ -80,3 +80,39 @@ def test_cli_config4_two_ranks_equals_one_rank(tmp_path):
                         "--master-port", str(port), "-m", "platypus_amd"] + base + ["--output", str(two)], capture_output=True, text=True, env=env)
     assert r.returncode == 0, (r.stderr[-1500:], r.stdout[-500:])
     assert one.read_text() == two.read_text()
+
+
+def test_assembler_tiles_feed_the_region_pipeline():
+    """--assemble=1: a 30-bp deletion whose reads were aligned WITHOUT a gap (plain M CIGARs, as a mapper that soft-clips or
+    mis-places them would) is invisible to the CIGAR scan; the assembler tiles of generateVariantsInRegion find it and the
+    record carries Source=Assembler.  Batched and window-by-window shapes agree here too."""
+    rng = np.random.default_rng(77)
+    B = b"ACGT"
+    n = 4000
+    ref = bytes(rng.choice(list(B), n).astype(np.uint8))
+    start, end = 1000, 3000
+    dp, dl = 2000, 30                                            # deletion of ref[dp+1 : dp+1+dl]
+    alt = ref[:dp + 1] + ref[dp + 1 + dl:]
+    reads = []
+    for _ in range(500):
+        src, shift = (alt, 1) if rng.random() < 0.5 else (ref, 0)
+        L = 100
+        p0 = int(rng.integers(start - 50, end - 60))
+        seq = src[p0:p0 + L] if not shift or p0 + L <= dp else alt[p0 - (dl if p0 > dp else 0):p0 - (dl if p0 > dp else 0) + L]
+        q = np.clip(rng.normal(35, 4, L), 20, 41).astype(np.uint8)
+        reads.append(H.AlignedRead(seq, bytes(q.tolist()), p0, 60, 3 | (16 if rng.random() < 0.5 else 0)))   # default CIGAR: 100M
+    fasta = H.FastaFile({"20": ref})
+    texts = []
+    for batched in (False, True):
+        opts = default_options(assemble=1, getVariantsFromBAMs=0)
+        buf = [H.bamReadBuffer(reads, sample="S1")]
+        out = io.StringIO()
+        if batched:
+            caller.callVariantsInRegions([("20", start, end, buf)], fasta, opts, VCF(["S1"]), out)
+        else:
+            caller.callVariantsInRegion("20", start, end, buf, fasta, opts, VCF(["S1"]), out)
+        texts.append(out.getvalue())
+    assert texts[0] == texts[1] and texts[0]
+    recs = [ln.split("\t") for ln in texts[0].split("\n")[:-1]]
+    dels = [f for f in recs if len(f[3]) - len(f[4]) == dl]
+    assert dels and all("Source=Assembler" in f[7] for f in dels) and abs(int(dels[0][1]) - (dp + 1)) <= 30
