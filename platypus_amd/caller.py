@@ -100,8 +100,12 @@ def generateVariantsInRegions(regions, refFile, options):
         everyone = mk(chrom, start, end)
         for g, b in zip(gs, buffers):
             longest = max(longest, b.reads.getLengthOfLongestRead())
-            for pos, removed, added, _ in next(found):
-                g.addVariantToList(H.Variant(chrom, pos, removed, added, 1, H.PLATYPUS_VAR))
+            tally = {}                                                          # equal records merge into one variant with
+            for pos, removed, added, _ in next(found):                          # the number of reads showing it (addVariantToList)
+                key = (pos, removed, added)
+                tally[key] = tally.get(key, 0) + 1
+            for (pos, removed, added), n in tally.items():
+                g.addVariantToList(H.Variant(chrom, pos, removed, added, n, H.PLATYPUS_VAR))
             for v in g.variantHeap.values():                                     # :456-467: per-sample support, indels always
                 if computeVariantReadSupportFrac(v, b) >= options.minVarFreq or v.nAdded != v.nRemoved:
                     everyone.addVariantToList(v)
