@@ -513,8 +513,8 @@ def test_dp_add_flavours_agree_with_oracle(eng, oracle):
 
 def _adversarial_batch(seed, n_windows=260):
     """Windows built to stress k_seed's ungapped-alignment proof: references with homopolymers and tandem repeats (cheap gaps,
-    non-unique k-mers), reads of 36..250 bp with 0..3 substitutions anywhere -- first and last bases included --, low-quality
-    tails, quality minima down to 1, haplotypes differing by SNPs next to repeats."""
+    non-unique k-mers) and N runs, reads of 36..250 bp with 0..3 substitutions anywhere -- first and last bases included --, read
+    N's, low-quality tails, quality minima down to 0, haplotypes differing by SNPs next to repeats."""
     from platypus_amd import hostapi as H
     rng = np.random.default_rng(seed)
     B = b"ACGT"
@@ -529,6 +529,8 @@ def _adversarial_batch(seed, n_windows=260):
             p = int(rng.integers(0, len(ref) - 60)); k = int(rng.integers(3, 40))
             u = rnd(int(rng.choice([1, 1, 1, 2, 3, 4, 6])))
             ref[p:p + k] = (u * k)[:k]
+        if rng.random() < 0.12:                                  # haplotype N's (cost 0 in the DP): the proof must stand aside
+            p = int(rng.integers(0, len(ref) - 8)); ref[p:p + int(rng.integers(1, 6))] = b"N" * 5
         ref = bytes(ref[:W + 2 * buf + 40])
         ws = 5000
         base = ref[:W + 2 * buf]
@@ -537,7 +539,7 @@ def _adversarial_batch(seed, n_windows=260):
             h = bytearray(base)
             for _ in range(int(rng.integers(1, 3))):
                 p = buf + int(rng.integers(0, W))
-                h[p] = B[(B.index(h[p]) + 1 + int(rng.integers(0, 3))) % 4]
+                h[p] = B[((B.index(h[p]) if h[p] in B else 0) + 1 + int(rng.integers(0, 3))) % 4]
             if bytes(h) not in haps:
                 haps.append(bytes(h))
         reads = []
@@ -547,7 +549,9 @@ def _adversarial_batch(seed, n_windows=260):
             seq = bytearray(src[off:off + L])
             for _ in range(int(rng.choice([0, 0, 1, 1, 1, 2, 2, 3]))):
                 p = int(rng.choice([0, 1, 2, L - 1, L - 2, L - 3, int(rng.integers(0, L)), int(rng.integers(0, L))]))
-                seq[p] = B[(B.index(seq[p]) + 1 + int(rng.integers(0, 3))) % 4]
+                seq[p] = B[((B.index(seq[p]) if seq[p] in B else 0) + 1 + int(rng.integers(0, 3))) % 4]
+            if rng.random() < 0.05:
+                seq[int(rng.integers(0, L))] = ord("N")          # read N: costs its quality against any base
             q = np.clip(rng.normal(33, 6, L), 1, 60).astype(np.uint8)
             mode = rng.random()
             if mode < 0.2:
