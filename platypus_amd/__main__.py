@@ -82,7 +82,12 @@ def call_variants_config4(opts, n_regions):
     dt = time.time() - t0
     if rank == 0:
         merged = sharding.merge_record_streams([sharding.decode_records(p) for p in got])
+        import datetime
+        vcf = VCF(["S1"])
+        vcf.setheader([("fileDate", datetime.date.today()), ("source", "platypus_amd (records as Platypus_Version_0.8.1.1 writes them)"),
+                       ("platypusOptions", str(dict(sorted(vars(opts).items()))))])         # variantcaller.pyx:51,942
         with open(opts.output, "w") as f:
+            vcf.writeheader(f)
             f.write("".join(line + "\n" for line in merged))
         print(json.dumps(dict(regions=n_regions, region_len=size, ranks=world, windows_rank0=n_windows, records=len(merged),
                               seconds=round(dt, 3), output=opts.output)))

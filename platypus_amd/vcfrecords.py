@@ -246,12 +246,84 @@ FORMAT_MISSING = {k: "." for k in ("GT", "GL", "GQ", "GOF", "NR", "NV")}
 FILTER_IDS = ("alleleBias", "strandBias", "badReads", "MQ", "Q20", "QualDepth", "HapScore", "GOF", "hp10", "REFCALL", "QD", "SC")
 
 
+# header definitions (vcfutils.pyx:72-123): (id, Number, Type, Description).  The FILTER dictionary of the reference files the
+# "HapScore" definition under the key "QualDepth" and vice versa; the header shows the ids, as there.
+INFO_DEFS = [
+    ("FR", ".", "Float", "Estimated population frequency of variant"),
+    ("PP", ".", "Float", "Posterior probability (phred scaled) that this variant segregates"),
+    ("TC", "1", "Integer", "Total coverage at this locus"),
+    ("WS", "1", "Integer", "Starting position of calling window"),
+    ("WE", "1", "Integer", "End position of calling window"),
+    ("TCR", "1", "Integer", "Total reverse strand coverage at this locus"),
+    ("TCF", "1", "Integer", "Total forward strand coverage at this locus"),
+    ("TR", ".", "Integer", "Total number of reads containing this variant"),
+    ("NF", ".", "Integer", "Total number of forward reads containing this variant"),
+    ("NR", ".", "Integer", "Total number of reverse reads containing this variant"),
+    ("MGOF", ".", "Integer", "Worst goodness-of-fit value reported across all samples"),
+    ("SC", "1", "String", "Genomic sequence 10 bases either side of variant position"),
+    ("HP", "1", "Integer", "Homopolymer run length around variant locus"),
+    ("BRF", "1", "Float", "Fraction of reads around this variant that failed filters"),
+    ("MMLQ", "1", "Float", "Median minimum base quality for bases around variant"),
+    ("QD", "1", "Float", "Variant-quality/read-depth for this variant"),
+    ("Source", ".", "String", "Was this variant suggested by Playtypus, Assembler, or from a VCF?"),
+    ("START", ".", "Integer", "Start position of reference call block"),
+    ("END", ".", "Integer", "End position of reference call block"),
+    ("Size", ".", "Integer", "Size of reference call block"),
+    ("HapScore", ".", "Integer", "Haplotype score measuring the number of haplotypes the variant is segregating into in a window"),
+    ("MQ", ".", "Float", "Root mean square of mapping qualities of reads at the variant position"),
+    ("FS", ".", "Float", "Fisher's exact test for strand bias (Phred scale)"),
+    ("SbPval", ".", "Float", "Binomial P-value for strand bias test"),
+    ("ReadPosRankSum", ".", "Float", "Mann-Whitney Rank sum test for difference between in positions of variants in reads from ref and alt"),
+]
+FILTER_DEFS = [
+    ("alleleBias", "Variant frequency is lower than expected for het"),
+    ("strandBias", "Variant fails strand-bias filter"),
+    ("badReads", "Variant supported only by reads with low quality bases close to variant position, and not present on both strands."),
+    ("MQ", "Root-mean-square mapping quality across calling region is low."),
+    ("Q20", "Variant quality is below 20."),
+    ("HapScore", "Too many haplotypes are supported by the data in this region."),
+    ("QualDepth", "Variant quality/Read depth ratio is low."),
+    ("GOF", "Variant fails goodness-of-fit test."),
+    ("hp10", "Flanking sequence contains homopolymer of length 10 or greater"),
+    ("REFCALL", "This line represents a homozygous reference call"),
+    ("QD", "Variants fail quality/depth filter."),
+    ("SC", "Variants fail sequence-context filter. Surrounding sequence is low-complexity"),
+]
+FORMAT_DEFS = [
+    ("GT", "1", "String", "Unphased genotypes"),
+    ("GL", ".", "Float", "Genotype log10-likelihoods for AA,AB and BB genotypes, where A = ref and B = variant. Only applicable for bi-allelic sites"),
+    ("GQ", ".", "Integer", "Genotype quality as phred score"),
+    ("GOF", ".", "Float", "Goodness of fit value"),
+    ("NR", ".", "Integer", "Number of reads covering variant location in this sample"),
+    ("NV", ".", "Integer", "Number of reads containing variant in this sample"),
+]
+
+
 class VCF:
-    """The writing half of vcf.py's VCF class (write_data :710-739, format_formatdata :297-329)."""
+    """The writing half of vcf.py's VCF class (write_data :710-739, format_formatdata :297-329, writeheader :371-409,844-848)."""
 
     def __init__(self, samples=()):
         self._samples = list(samples)
         self._version = 40
+        self._header = []
+
+    def setheader(self, header):
+        self._header = list(header)
+
+    def writeheader(self, stream):
+        """##fileformat, the caller's key=value lines, the INFO / FILTER / FORMAT definitions and the #CHROM line.  The
+        reference writes the definitions in the iteration order of three Python-2 dictionaries; here they come in the order of
+        its source, which is the one difference from its header apart from the date and the option string."""
+        stream.write("##fileformat=VCFv%s.%s\n" % (self._version // 10, self._version % 10))
+        for key, value in self._header:
+            stream.write("##%s=%s\n" % (key, value))
+        for i, n, t, d in INFO_DEFS:
+            stream.write('##INFO=<ID=%s,Number=%s,Type=%s,Description="%s">\n' % (i, n, t, d))
+        for i, d in FILTER_DEFS:
+            stream.write('##FILTER=<ID=%s,Description="%s">\n' % (i, d))
+        for i, n, t, d in FORMAT_DEFS:
+            stream.write('##FORMAT=<ID=%s,Number=%s,Type=%s,Description="%s">\n' % (i, n, t, d))
+        stream.write("#" + "\t".join(["CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT"] + [py2_str(x) for x in self._samples]) + "\n")
 
     def setsamples(self, samples):
         self._samples = list(samples)

@@ -294,3 +294,24 @@ def test_indel_prior_matches_reference_golden(golden_dir):
             assert H.Variant("20", v["pos"], v["removed"].encode(), v["added"].encode()).calculatePrior(fasta) == v["prior"], v
             n += 1
     assert n == 2400
+
+
+def test_vcf_header_lists_every_field_the_records_use(golden_dir):
+    """writeheader: fileformat, caller lines, one definition per INFO / FILTER / FORMAT id, the #CHROM line; every key that
+    appears in the golden record lines is defined."""
+    import gzip, io, json, os, re
+    from platypus_amd.vcfrecords import VCF
+    v = VCF(["S1", "S2"])
+    v.setheader([("fileDate", "2026-01-01"), ("source", "x")])
+    out = io.StringIO()
+    v.writeheader(out)
+    lines = out.getvalue().split("\n")[:-1]
+    assert lines[0] == "##fileformat=VCFv4.0" and lines[1] == "##fileDate=2026-01-01" and lines[-1].split("\t")[-2:] == ["S1", "S2"]
+    ids = {kind: set(re.findall(r"##%s=<ID=([^,]+)," % kind, out.getvalue())) for kind in ("INFO", "FILTER", "FORMAT")}
+    cases = json.load(gzip.open(os.path.join(golden_dir, "vcf_cases.json.gz"), "rt"))
+    for c in cases:
+        for ln in c["lines"]:
+            f = ln.split("\t")
+            assert {kv.split("=")[0] for kv in f[7].split(";")} <= ids["INFO"]
+            assert f[6] == "PASS" or set(f[6].split(";")) <= ids["FILTER"]
+            assert set(f[8].split(":")) <= ids["FORMAT"]
