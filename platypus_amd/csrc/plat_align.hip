@@ -805,25 +805,31 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
 #pragma unroll
             for (int c = 0; c < 4; ++c) k += __popcll(missA[c]);
             if (cand && k >= 1 && k <= 2) {
-                // (straight-line code on purpose: every lane-divergent `if` costs four scalar instructions of exec-mask
-                //  bookkeeping, and this kernel is bound by the number of instructions it issues)
-                int p1 = -1, p2 = -1;                        // first / last mismatch position (k == 1: the same)
+                auto nth = [&](int which) -> int {           // position of the first / last mismatch
+                    int pos = -1;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const bool has = missA[c] != 0ull;
-                    const int lo = 64 * c + (int)__ffsll((long long)missA[c]) - 1, hi = 64 * c + 63 - (int)__clzll((long long)(missA[c] | 1ull));
-                    p1 = (has && p1 < 0) ? lo : p1;
-                    p2 = has ? hi : p2;
-                }
-                auto below_mask = [](int x) -> u64 { return x >= 64 ? ~0ull : (x <= 0 ? 0ull : ((1ull << x) - 1ull)); };
+                    for (int c = 0; c < 4; ++c) {
+                        if (missA[c]) {
+                            const int lo = 64 * c + (int)__ffsll((long long)missA[c]) - 1, hi = 64 * c + 63 - (int)__clzll((long long)missA[c]);
+                            if (which == 0) { if (pos < 0) pos = lo; } else pos = hi;
+                        }
+                    }
+                    return pos;
+                };
                 auto cnt7 = [&](int a, int e) -> int {       // unique-matching k-mer starts in [a, e)
                     int n = 0;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        n += __popcll(uniqA[c] & below_mask(e - 64 * c) & ~below_mask(a - 64 * c));
+                    for (int c = 0; c < 4; ++c) {
+                        const int lo = max(a - 64 * c, 0), hi = min(e - 64 * c, 64);
+                        if (hi > lo) {
+                            const u64 m1 = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+                            n += __popcll(uniqA[c] & m1);
+                        }
+                    }
                     return n;
                 };
                 auto W = [&](int a, int bnd) -> int { return (cnt7(max(a, 0), bnd - 6) + 6) / 7; };
+                const int p1 = nth(0), p2 = nth(1);          // k == 1: p1 == p2
                 const uint8_t* rq = b.read_qual + b.read_off[rb + rl];
                 const int q1 = rq[p1], q2 = k == 2 ? rq[p2] : 0;
                 const int U = q1 + q2;
@@ -831,13 +837,10 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 int G = 127;
                 for (int t = st >> 6; t <= (st + L + 14) >> 6; ++t) G = min(G, (int)s_gmin[t]);
                 const int hh = (L - 15) / 2;
-                const int wAll = W(0, L), wHead = W(0, hh), wTail = W(hh + 15, L);
-                const int wAfter1 = W(p1 + 8, L), wBefore1 = W(0, p1 - 7), wAfter2 = W(p2 + 8, L), wBefore2 = W(0, p2 - 7);
-                // first mismatch: Q = U, R = q1; last mismatch: Q = q2 (k == 2) or U (k == 1), R = U
-                const int Q2 = k == 2 ? q2 : U;
-                const bool ok = (U <= 2 * G) & (mq * wAll >= U) & (G + mq * min(wHead, wTail) >= U) &
-                                (G + mq * wAfter1 >= U) & (G + mq * wBefore1 >= q1) &
-                                (G + mq * wAfter2 >= Q2) & (G + mq * wBefore2 >= U);
+                bool ok = U <= 2 * G && mq * W(0, L) >= U && G + mq * min(W(0, hh), W(hh + 15, L)) >= U;
+                // first mismatch: Q = U, R = q1; last mismatch (k == 2): Q = q2, R = U
+                ok = ok && G + mq * W(p1 + 8, L) >= U && G + mq * W(0, p1 - 7) >= q1;
+                if (k == 2) ok = ok && G + mq * W(p2 + 8, L) >= q2 && G + mq * W(0, p2 - 7) >= U;
                 if (ok) ung_score = U;
             }
         }

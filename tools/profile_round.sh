@@ -1,3 +1,6 @@
+#!/bin/bash
+# One round of profile evidence for profiles/: kernel-trace stats (1 and 3 batches in flight) and three separate PMC passes.
+# Run on the GPU box:  gpurun -- 'bash tools/profile_round.sh'
 set -x
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
@@ -11,7 +14,6 @@ done
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $O/pmc_SQ -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --streams 1 > $O/pmc_SQ.log 2>&1
 cd $R
 python tools/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ > $O/pmc_summary.txt 2>&1
-python tools/rocprof_summary.py $O/stats1 > $O/stats1_summary.txt 2>&1
-python tools/rocprof_summary.py $O/stats3 > $O/stats3_summary.txt 2>&1
+python tools/profile_round_summary.py $O
 find $O -name "*.csv" -size +2M -delete
-tail -5 $O/pmc_summary.txt; head -20 $O/stats1_summary.txt
+head -12 profiles/r01_kernel_stats.txt; cat profiles/dp_traffic.json
