@@ -1,7 +1,7 @@
 """Cross-check of k_seed's ungapped-alignment shortcut against the DP it replaces: the same batches aligned with the shortcut and
 with PLAT_NO_UNGAPPED=1 (every pair through the DP) must give identical scores.  Stress batches (tests/test_gpu_parity.py::
 _adversarial_batch: repeats, cheap gaps, mismatches at the read ends, quality minima down to 1) with fresh seeds until the time
-budget is used, then BASELINE config 2 and a config-5 sample.   usage: python tools/ungapped_crosscheck.py [seconds]"""
+budget is used, then BASELINE config 2 and a config-5 sample.   usage: python tools/ungapped_crosscheck.py [seconds] [first seed]"""
 import json
 import os
 import sys
@@ -34,7 +34,7 @@ def main():
     eng = Engine(0)
     t0 = time.time()
     pairs = shortcut = bad = batches = 0
-    seed = 1000
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     fixed = [("config2", lambda: synth.config2(10000)), ("config5", lambda: synth.config5(100, 100))]
     while time.time() - t0 < budget or fixed:
         if time.time() - t0 >= budget:
