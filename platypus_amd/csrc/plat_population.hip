@@ -23,15 +23,19 @@ __global__ void __launch_bounds__(64)
 k_em(int n_ind, const int32_t* __restrict__ win_hap_begin, const int64_t* __restrict__ gl_off,
      const int32_t* __restrict__ n_reads, const double* __restrict__ gl, int max_iters, int use_em,
      double* __restrict__ out_freq, double* __restrict__ out_em, int32_t* __restrict__ out_call,
-     int32_t* __restrict__ out_iters)
+     int32_t* __restrict__ out_iters, int max_haps, int csr_in_lds)
 {
-    extern __shared__ double s_freq[];                 // [H]
+    extern __shared__ double s_freq[];                 // [max_haps], then (csr_in_lds) the responsibilities [n_ind][G] of this window
     const int w = blockIdx.x, lane = threadIdx.x;
     const int h0 = win_hap_begin[w], H = win_hap_begin[w + 1] - h0;
     const int G = H * (H + 1) / 2;
     if (H <= 0) { if (lane == 0 && out_iters) out_iters[w] = 0; return; }
     const double* L = gl + gl_off[w];
     double* em = out_em + gl_off[w];
+    // The M-step is a serial chain per haplotype over all individuals (the reference's order of additions); reading the
+    // responsibilities back from global memory made it a chain of dependent L2 round trips (350 us for 100 samples x 8
+    // haplotypes).  When they fit they are kept in LDS as well (the global copy is the EMLikelihoods output).
+    double* rsp = csr_in_lds ? s_freq + max_haps : em;
     const int32_t* nr = n_reads + (long long)w * n_ind;
 
     double eps = 1.0 / (n_ind * 2 * 2);                // :684
@@ -54,7 +58,7 @@ k_em(int n_ind, const int32_t* __restrict__ win_hap_begin, const int64_t* __rest
         for (int i = lane; i < n_ind; i += 64) {
             if (nr[i] == 0) continue;
             const double* Li = L + (long long)i * G;
-            double* csr = em + (long long)i * G;
+            double* csr = rsp + (long long)i * G;
             double csrSum = 0.0;
             int j = 0;
             for (int s = 0; s < H; ++s)
@@ -65,6 +69,8 @@ k_em(int n_ind, const int32_t* __restrict__ win_hap_begin, const int64_t* __rest
                 }
             if (csrSum > 0.0)
                 for (j = 0; j < G; ++j) csr[j] /= csrSum;
+            if (csr_in_lds)
+                for (j = 0; j < G; ++j) em[(long long)i * G + j] = csr[j];
         }
         __syncthreads();                               // (one wave: orders the global em writes before the reads below)
         __threadfence_block();
@@ -74,10 +80,23 @@ k_em(int n_ind, const int32_t* __restrict__ win_hap_begin, const int64_t* __rest
             double acc = 0.0;
             for (int i = 0; i < n_ind; ++i) {
                 if (nr[i] == 0) continue;
-                const double* csr = em + (long long)i * G;
-                for (int a = 0; a < k; ++a) acc += csr[geno_index(a, k, H)];       // genotypes (a, k): k is the second haplotype
-                { const double c = csr[geno_index(k, k, H)]; acc += c; acc += c; }  // (k, k): added as first and as second
-                for (int bb = k + 1; bb < H; ++bb) acc += csr[geno_index(k, bb, H)];
+                const double* csr = rsp + (long long)i * G;
+                // genotypes that contain k, in the order the reference's double loop reaches them: (a, k) for a < k (k is the
+                // second haplotype), (k, k) added as first and as second, (k, b) for b > k.  Eight loads are issued
+                // together so that the chain of additions does not wait for a memory round trip per term.
+                for (int a0 = 0; a0 < H; a0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int a = min(a0 + u, H - 1);
+                        v[u] = csr[a < k ? geno_index(a, k, H) : geno_index(k, a, H)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int a = a0 + u;
+                        if (a < H) { acc += v[u]; if (a == k) acc += v[u]; }
+                    }
+                }
             }
             const double nf = acc / (2 * nWithData);   // :449
             const double fc = fabs(s_freq[k] - nf);
@@ -342,11 +361,17 @@ PLAT_EXPORT int plat_em_window_batch(plat_ctx* ctx, int n_windows, int n_ind, in
     if (!ctx || n_windows < 0 || n_ind < 1 || max_haps_per_window < 0 || max_iters < 0) return PLAT_ERR_INVALID;
     if (n_windows == 0) return PLAT_OK;
     if (!win_hap_begin || !gl_off || !n_reads || !gl || !out_freq || !out_em || !out_call) return PLAT_ERR_INVALID;
-    const size_t lds = (size_t)max_haps_per_window * sizeof(double) + 16;
+    size_t lds = (size_t)max_haps_per_window * sizeof(double) + 16;
     if (lds > 64 * 1024) return PLAT_ERR_INVALID;
+    const size_t maxG = (size_t)max_haps_per_window * (max_haps_per_window + 1) / 2;
+    const size_t csr_bytes = (size_t)n_ind * maxG * sizeof(double);
+    const int csr_in_lds = n_ind >= 8 && lds + csr_bytes <= 60 * 1024;   // responsibilities of one window next to the frequencies (pays with many samples)
+    if (csr_in_lds) lds += csr_bytes;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    if (lds > 48 * 1024)
+        PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_em, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_em, dim3(n_windows), dim3(64), lds, (hipStream_t)stream, n_ind, win_hap_begin, gl_off, n_reads, gl,
-                       max_iters, use_em_likelihoods, out_freq, out_em, out_call, out_iters);
+                       max_iters, use_em_likelihoods, out_freq, out_em, out_call, out_iters, max_haps_per_window, csr_in_lds);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
