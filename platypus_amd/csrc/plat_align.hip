@@ -247,13 +247,40 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             uint32_t* tp = tile + toff + (long long)(4 * g) * R + c0 + rl;
             bool dirty = false;
             unsigned qs = 0, qm = 255u, n0 = 0, n1 = 0;
+            if (staged) {
+                // the thread's 4 bases and 4 qualities as two dwords (unaligned reads of the LDS images), then 4 at a time
+                const int nval = min(max(L - 4 * g, 0), 4);
+                const unsigned as_ = (unsigned)(misS + o + 4 * g), aq_ = (unsigned)(qoff + misQ + o + 4 * g);
+                const uint32_t* P = (const uint32_t*)psm;
+                const uint32_t keep = nval >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nval)) - 1u);
+                const uint32_t vs = __builtin_amdgcn_alignbyte(P[(as_ >> 2) + 1], P[as_ >> 2], as_ & 3u) & keep;
+                const uint32_t vq = __builtin_amdgcn_alignbyte(P[(aq_ >> 2) + 1], P[aq_ >> 2], aq_ & 3u) & keep;
+                // 2-bit codes (calign.pyx:69-74: c = ch & 7; 7 -> 2; c & 3), one per byte
+                uint32_t x = vs & 0x07070707u;
+                const uint32_t t7 = x & (x >> 1) & (x >> 2) & 0x01010101u;       // bytes that are 7
+                x = (x ^ (t7 | (t7 << 2))) & 0x03030303u;                        // 7 ^ 5 = 2
+                const uint32_t y0 = x & 0x01010101u, y1 = (x >> 1) & 0x01010101u;
+                n0 = (y0 | (y0 >> 7) | (y0 >> 14) | (y0 >> 21)) & 0xFu;
+                n1 = (y1 | (y1 >> 7) | (y1 >> 14) | (y1 >> 21)) & 0xFu;
+                // plain base <=> the byte is the letter of its own code (code 0..3 = T, A, G, C)
+                const uint32_t expect = __builtin_amdgcn_perm(0u, 0x43474154u, x);
+                dirty = ((expect ^ vs) & keep) != 0u;
+                qs = __builtin_amdgcn_sad_u8(vq, 0u, 0u);
+                const uint32_t vqm = vq | ~keep;
+                qm = min(min(vqm & 0xFFu, (vqm >> 8) & 0xFFu), min((vqm >> 16) & 0xFFu, vqm >> 24));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t wd = j < nval ? ((((vs >> (8 * j)) & 0x7Fu) << 9) | (((vq >> (8 * j)) & 0xFFu) << 18)) : READ_PAD_WORD;
+                    if (4 * g + j < rows) tp[(long long)j * R] = wd;
+                }
+            } else
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = 4 * g + j;
                 uint32_t wd = READ_PAD_WORD;
                 if (i < L) {
-                    const unsigned ch = staged ? lseq[o + i] : gs[o + i];
-                    const unsigned ql = staged ? lqual[o + i] : gq[o + i];
+                    const unsigned ch = gs[o + i];
+                    const unsigned ql = gq[o + i];
                     qs += ql;
                     qm = min(qm, ql);
                     const unsigned b2 = base2(ch);
