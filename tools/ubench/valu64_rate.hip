@@ -33,6 +33,10 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, int iters, uint32_t seed
                 if (OP == 13) asm volatile("v_bfe_u32 %0, %0, %1, 7" : "+v"(lo) : "v"(b));
                 if (OP == 14) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(lo) : "v"(c));
                 if (OP == 15) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(lo) : "v"(c), "v"(b));
+                if (OP == 16) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(lo) : "v"(c) : "s20", "s21");
+                if (OP == 17) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(lo) : "v"(c) : "vcc");
+                if (OP == 18) asm volatile("v_max_u32 %0, %0, %1" : "+v"(lo) : "v"(c));
+                if (OP == 19) asm volatile("v_min_u32 %0, %0, %1" : "+v"(lo) : "v"(c));
             }
         }
     }
@@ -75,5 +79,9 @@ int main()
     run<13>("v_bfe_u32", d, blocks);
     run<14>("v_xor_b32", d, blocks);
     run<15>("v_or3_b32", d, blocks);
+    run<16>("v_cndmask_b32 (sgpr pair)", d, blocks);
+    run<17>("v_cmp + v_cndmask (2 instr)", d, blocks);
+    run<18>("v_max_u32", d, blocks);
+    run<19>("v_min_u32", d, blocks);
     return 0;
 }
