@@ -80,6 +80,28 @@ def cpu_baseline(hb, seconds=12.0):
                    what="unmodified src/c/align.c fastAlignmentRoutine, traceback on (production mode), gcc -O2, 1 thread")
         t0 = run(0, max(1, reps // 4))
         out["score_only_gcups"] = cells.value / t0 / 1e9
+        # every host core at once ("one worker per core over the same batches"): one thread per core, each
+        # running the same rows through the reference kernel (ctypes releases the GIL; align.c keeps no global state)
+        import threading
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncores = min(ncores, 32)                 # bounded: the container may grant far fewer CPUs than it shows
+        if ncores > 1:
+            times = [0.0] * ncores
+            per = max(1, reps // 6)
+
+            def worker(k):
+                c1, c2 = C.c_longlong(0), C.c_longlong(0)
+                times[k] = lib.cpu_time_reference_dp(LIBREF.encode(), n, lmax, H.ctypes.data, R.ctypes.data, Q.ctypes.data,
+                                                     G.ctypes.data, lens.ctypes.data, 1, per, C.byref(c1), C.byref(c2))
+            tw = time.perf_counter()
+            th = [threading.Thread(target=worker, args=(k,)) for k in range(ncores)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            tw = time.perf_counter() - tw
+            out["all_cores"] = {"cores": ncores, "value": ncores * per * float((16 * lens.astype(np.int64)).sum()) / tw / 1e9,
+                                "unit": "GCUPS", "what": "the same, %d threads at once (traceback on; the box shows %d CPUs)" % (ncores, os.cpu_count() or 0)}
     else:
         # no prebuilt reference .so on this box: time the oracle port's DP instead
         t0 = time.perf_counter()
