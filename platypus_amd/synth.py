@@ -208,7 +208,8 @@ def config4_region(index, seed=4004, region_len=100000, n_samples=1, depth=30, r
     flank), SNPs at snp_rate and 1..10 bp indels at indel_rate inside the region, a diploid donor per sample (each variant on
     either haplotype with probability 1/2, so hets and homs mix), `depth`x reads of read_len with the CIGAR an aligner
     would report, 0.1 % substitution errors, qualities ~ clipped N(35, 5), mapq 60.
-    Returns dict(chrom, start, end, ref (bytes), variants [(pos, removed, added)], samples [list of read dicts])."""
+    Returns dict(chrom, start, end, ref (bytes), variants [(pos, removed, added)], samples [list of read dicts], truth
+    [sample][variant] = copies of the alternative allele in the donor)."""
     rng = np.random.Generator(np.random.PCG64([seed, index]))
     n = region_len + 2 * flank
     ref = bytes(_rand_bases(rng, n))
@@ -233,9 +234,10 @@ def config4_region(index, seed=4004, region_len=100000, n_samples=1, depth=30, r
             else:
                 variants.append((p, ref[p + 1:p + 1 + k], b""))
                 last = p + k + 3
-    samples = []
+    samples, truth = [], []
     for _ in range(n_samples):
         carry = [[v for v in variants if rng.random() < 0.5] for _ in range(2)]
+        truth.append([sum(v in c for c in carry) for v in variants])             # copies of the alternative allele: 0, 1 or 2
         reads = []
         for _ in range(int(depth * region_len / read_len)):
             h = carry[int(rng.integers(0, 2))]
@@ -249,4 +251,4 @@ def config4_region(index, seed=4004, region_len=100000, n_samples=1, depth=30, r
             reads.append(dict(seq=s.tobytes(), qual=q.tobytes(), pos=p0, end=e, mapq=60, flag=3 | (16 if rng.random() < 0.5 else 0), cigar=cig))
         reads.sort(key=lambda r: r["pos"])
         samples.append(reads)
-    return dict(chrom="r%d" % index, start=start, end=end, ref=ref, variants=variants, samples=samples)
+    return dict(chrom="r%d" % index, start=start, end=end, ref=ref, variants=variants, samples=samples, truth=truth)

@@ -118,3 +118,29 @@ def test_assembler_tiles_feed_the_region_pipeline():
     recs = [ln.split("\t") for ln in texts[0].split("\n")[:-1]]
     dels = [f for f in recs if len(f[3]) - len(f[4]) == dl]
     assert dels and all("Source=Assembler" in f[7] for f in dels) and abs(int(dels[0][1]) - (dp + 1)) <= 30
+
+
+def test_called_genotypes_agree_with_the_planted_donors():
+    """Beyond self-consistency: at 40x the genotype written for a planted SNP (0/1 vs 1/1, or no call / 0/0 when the donor does
+    not carry it) equals the donor's number of alternative alleles for almost every (variant, sample)."""
+    regs, fasta, names, buffers = _regions(3, 2, region_len=3000, snp_rate=3e-3, indel_rate=0, read_len=100, depth=40)
+    out = io.StringIO()
+    caller.callVariantsInRegions([(r["chrom"], r["start"], r["end"], buffers(r)) for r in regs], fasta, default_options(), VCF(names), out)
+    recs = {}
+    for ln in out.getvalue().split("\n")[:-1]:
+        f = ln.split("\t")
+        recs[(f[0], int(f[1]) - 1, f[3], f[4])] = f
+    agree = total = 0
+    for r in regs:
+        for k, (p, rem, add) in enumerate(r["variants"]):
+            f = recs.get((r["chrom"], p, rem.decode(), add.decode()))
+            for i in range(len(names)):
+                want = r["truth"][i][k]
+                if f is None:
+                    got = 0
+                else:
+                    gt = f[9 + i].split(":")[0]
+                    got = 0 if "." in gt else sum(int(a) != 0 for a in gt.split("/"))
+                total += 1
+                agree += got == want
+    assert total > 30 and agree >= 0.95 * total, (agree, total)
