@@ -46,3 +46,21 @@ def test_population_mode_segments():
     assert b.n_ind == 5 and len(b.seg_n_good) == 40
     assert b.seg_read_begin[-1] == b.n_reads
     assert np.array_equal(b.seg_read_begin[::5], b.win_read_begin)
+
+
+def test_config4_region_is_procedural_and_consistent():
+    """Region i of config 4 depends on (seed, i) only; reads carry the CIGAR an aligner would give them and reproduce the
+    reference outside their planted variants."""
+    a = synth.config4_region(3, region_len=4000, n_samples=2, indel_rate=2e-3)
+    b = synth.config4_region(3, region_len=4000, n_samples=2, indel_rate=2e-3)
+    c = synth.config4_region(4, region_len=4000, n_samples=2, indel_rate=2e-3)
+    assert a["ref"] == b["ref"] and a["variants"] == b["variants"] and a["samples"][1][7] == b["samples"][1][7]
+    assert a["ref"] != c["ref"] and a["chrom"] == "r3" and c["chrom"] == "r4"
+    assert len(a["truth"]) == 2 and all(len(t) == len(a["variants"]) and set(t) <= {0, 1, 2} for t in a["truth"])
+    assert any(len(rem) != len(add) for _, rem, add in a["variants"])
+    for r in a["samples"][0][:200]:
+        span = sum(n for op, n in r["cigar"] if op in (0, 2))
+        assert r["end"] - r["pos"] == span and sum(n for op, n in r["cigar"] if op in (0, 1)) == len(r["seq"]) == len(r["qual"])
+        if r["cigar"] == [(0, len(r["seq"]))]:
+            mism = sum(x != y for x, y in zip(r["seq"], a["ref"][r["pos"]:r["pos"] + len(r["seq"])]))
+            assert mism <= 6                                        # planted SNPs + 0.1 % errors
