@@ -7,13 +7,16 @@
 One "step" = one pass of the hot path over one batch of synthetic windows that is already resident
 in HBM: haplotype k-mer index + gap-open annotation + diagonal vote + candidate DPs + candidate
 selection + log-likelihood arrays (Haplotype.alignReads for every haplotype) + genotype likelihoods
-(Population.setup).  Windows shard across ranks with no data-path collective (weak scaling: every
-rank owns `--windows` windows generated from seed+rank); the only collectives are the barriers and
-the max-over-ranks timing reduction.
+(Population.setup).  `--batches` DISTINCT batches (different seeds) are resident per GPU and consecutive
+steps walk through them, so no step re-reads the inputs of the step before it.  Windows shard across
+ranks with no data-path collective (weak scaling: every rank owns its own batches generated from
+seed+rank); the only collectives are the barriers and the max-over-ranks timing reduction.
 
 GCUPS counts REFERENCE-EQUIVALENT work: sum over the fastAlignmentRoutine calls the
-reference would make of 16*len2 band cells, divided by wall time.  `cells_launched` (what the device
-actually ran) is reported next to it.
+reference would make of 16*len2 band cells, divided by wall time.  What the device actually ran is
+reported next to it (`gcups_executed`, `dp_launched_per_step`), and so are the figures without the two
+shortcuts (`gcups_all_dp`: every reference DP executed) and on reads the shortcuts like less
+(`hard_workload`).  `--config 3|4|5` puts another BASELINE config on the line instead (same contract).
 """
 import argparse
 import ctypes as C
@@ -30,10 +33,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(hb, seconds=12.0):
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(hb, seconds=10.0):
     """The reference's own kernel (unmodified align.c in oracle/_ref, traceback on = production mode) timed
-    on ONE host core over the DP instances of a bounded sample of the same workload; plus the oracle
-    port of the whole per-window path as a secondary figure."""
+    on ONE host core over the DP instances of a bounded sample of the same workload, then on every core the
+    process may run on; plus the oracle port of the whole per-window path as a secondary figure."""
     from oracle.oracle import LIBREF, Oracle, HERE as ORC_DIR
     o = Oracle()
     nwin = min(hb.n_windows, 150)
@@ -61,8 +74,9 @@ def cpu_baseline(hb, seconds=12.0):
         L = len(r); lens[j] = L
         H[j, :L + 15] = np.frombuffer(h, dtype=np.uint8); R[j, :L] = np.frombuffer(r, dtype=np.uint8)
         Q[j, :L] = np.frombuffer(q, dtype=np.uint8); G[j, :L + 15] = np.frombuffer(g, dtype=np.uint8)
-    out = {"cores": 1, "sample": "DP instances (one per aligned read x haplotype pair, at the read's mapping offset) of the "
-                                 "first %d windows of the workload = %d DPs, repeated to ~%.0f s" % (nwin, n, seconds)}
+    out = {"cores": 1, "cpu": cpu_model(),
+           "sample": "DP instances (one per aligned read x haplotype pair, at the read's mapping offset) of the "
+                     "first %d windows of the workload = %d DPs, repeated to ~%.0f s" % (nwin, n, seconds)}
     lib = C.CDLL(os.path.join(ORC_DIR, "libcpubench.so"))
     lib.cpu_time_reference_dp.restype = C.c_double
     lib.cpu_time_reference_dp.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -80,14 +94,14 @@ def cpu_baseline(hb, seconds=12.0):
                    what="unmodified src/c/align.c fastAlignmentRoutine, traceback on (production mode), gcc -O2, 1 thread")
         t0 = run(0, max(1, reps // 4))
         out["score_only_gcups"] = cells.value / t0 / 1e9
-        # every host core at once ("one worker per core over the same batches"): one thread per core, each
-        # running the same rows through the reference kernel (ctypes releases the GIL; align.c keeps no global state)
+        # every host core at once ("one worker per core over the same batches"): one thread per CPU this process
+        # may run on, each running the same rows through the reference kernel (ctypes releases the GIL; align.c keeps no
+        # global state)
         import threading
         ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        ncores = min(ncores, 32)                 # bounded: the container may grant far fewer CPUs than it shows
         if ncores > 1:
             times = [0.0] * ncores
-            per = max(1, reps // 6)
+            per = max(1, reps // 4)
 
             def worker(k):
                 c1, c2 = C.c_longlong(0), C.c_longlong(0)
@@ -101,7 +115,8 @@ def cpu_baseline(hb, seconds=12.0):
                 x.join()
             tw = time.perf_counter() - tw
             out["all_cores"] = {"cores": ncores, "value": ncores * per * float((16 * lens.astype(np.int64)).sum()) / tw / 1e9,
-                                "unit": "GCUPS", "what": "the same, %d threads at once (traceback on; the box shows %d CPUs)" % (ncores, os.cpu_count() or 0)}
+                                "unit": "GCUPS", "what": "the same, one thread on each of the %d CPUs this process may run on "
+                                                         "(sched_getaffinity; the box shows %d), traceback on" % (ncores, os.cpu_count() or 0)}
     else:
         # no prebuilt reference .so on this box: time the oracle port's DP instead
         t0 = time.perf_counter()
@@ -111,24 +126,47 @@ def cpu_baseline(hb, seconds=12.0):
                    what="oracle/plat_oracle.c scalar restatement (no SIMD), 1 thread")
     # secondary: whole per-window path (hash + vote + DP with traceback + log-likelihood) with the oracle port
     t0 = time.perf_counter(); ndp = 0
-    for w in range(min(nwin, 60)):
+    for w in range(min(nwin, 40)):
         ndp += o.align_window(hb.window_haps(w), int(hb.win_start[w]), int(hb.win_end[w]), int(hb.win_flank[w]),
                               hb.window_reads(w))[2]
     tp = time.perf_counter() - t0
-    out["port_whole_path_windows_per_sec"] = min(nwin, 60) / tp
+    out["port_whole_path_windows_per_sec"] = min(nwin, 40) / tp
     return out
+
+
+class Env:
+    """Temporarily set environment switches the library reads per call (PLAT_NO_UNGAPPED, PLAT_NO_EXACT, PLAT_NO_NLOW)."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--windows", type=int, default=10000, help="windows per GPU (BASELINE config 2: 10000)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5), help="BASELINE config on the line (default 2, the headline)")
+    ap.add_argument("--windows", type=int, default=None, help="windows per GPU per batch (config 2: 10000; config 5: 200)")
+    ap.add_argument("--regions", type=int, default=None, help="config 3: assembly tiles per step (2000); config 4: regions (64)")
+    ap.add_argument("--batches", type=int, default=8, help="distinct resident batches the steps walk through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (all-DP, hard workload, other configs)")
     ap.add_argument("--streams", type=int, default=3,
-                    help="independent batches in flight per GPU: one plat_ctx + HIP stream + resident batch each; step i "
-                         "runs on stream i %% S (1 = strictly one batch at a time)")
+                    help="independent batches in flight per GPU: one plat_ctx + HIP stream each; step i runs on stream i %% S "
+                         "(1 = strictly one batch at a time)")
     ap.add_argument("--sync-entry", action="store_true",
                     help="time plat_align_window_batch (two internal read-backs) instead of plat_align_window_batch_async")
     a = ap.parse_args()
@@ -138,22 +176,35 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if "RANK" in os.environ:                    # launched by torch.distributed.run (also with one rank): RCCL process group
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if a.config != 2:
+        from tools import bench_other
+        line = bench_other.run(a, rank, local, world, dist)
+        if rank == 0:
+            print(json.dumps(line))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     from platypus_amd import synth
     from platypus_amd.engine import Engine
+    from concurrent.futures import ThreadPoolExecutor
 
-    # S independent batches (different seeds) stay resident in HBM; consecutive steps go to different plat_ctx / HIP streams so
-    # that the latency-bound stages of one batch (prepare, seeding, genotype) overlap the VALU-bound DP of another -- what a
-    # caller streaming regions through the library does.  Every step still is one full pass over one batch of `--windows`.
+    # B distinct batches stay resident in HBM; consecutive steps go to different plat_ctx / HIP streams so that the
+    # latency-bound stages of one batch (prepare, seeding, genotype) overlap the VALU-bound DP of another -- what a caller
+    # streaming regions through the library does.  Every step is one full pass over one batch of `--windows` windows.
     S = max(1, a.streams)
+    B = max(1, a.batches)
+    nwin_batch = a.windows or 10000
     engs = [Engine(local) for _ in range(S)]
-    hbs = [synth.config2(a.windows, seed=2002 + rank + 1000 * j) for j in range(S)]
+    with ThreadPoolExecutor(min(B, 8)) as ex:   # (numpy releases the GIL in the generator's big array operations)
+        hbs = list(ex.map(lambda j: synth.config2(nwin_batch, seed=2002 + rank + 1000 * j), range(B)))
     streams = [torch.cuda.Stream(device=engs[0].device) for _ in range(S)]
-    dbs = [e.upload(h) for e, h in zip(engs, hbs)]     # inputs resident in HBM before the timed region
+    dbs = [engs[0].upload(h) for h in hbs]      # inputs resident in HBM before the timed region
     eng, hb, db = engs[0], hbs[0], dbs[0]
     torch.cuda.synchronize()
 
@@ -162,31 +213,36 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def step(i, **kw):
+    def step(i, dbl=dbs, **kw):
         j = i % S
         with torch.cuda.stream(streams[j]):
-            return engs[j].call_windows(dbs[j], **kw)
+            return engs[j].call_windows(dbl[i % len(dbl)], **kw)
 
-    sts = [None] * S
+    def sync_all():
+        for j in range(S):
+            with torch.cuda.stream(streams[j]):
+                engs[j].synchronize()           # also raises any error an asynchronous step recorded on the device
+        torch.cuda.synchronize()
+
+    def timed(nsteps, dbl=dbs):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            step(i, dbl, want_stats=False, asynchronous=not a.sync_entry)
+        sync_all()
+        t1 = time.perf_counter()
+        barrier()
+        return t1 - t0
+
+    sts = [eng.call_windows(d, want_stats=True) for d in dbs]      # per-batch statistics (and scratch buffers at full size)
     for i in range(max(a.warmup, 1) * S):
-        if i < S or a.warmup > 0:
-            sts[i % S] = step(i, want_stats=True)
-            step(i, want_stats=False, asynchronous=not a.sync_entry)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
         step(i, want_stats=False, asynchronous=not a.sync_entry)
-    for j in range(S):
-        with torch.cuda.stream(streams[j]):
-            engs[j].synchronize()               # also raises any error an asynchronous step recorded on the device
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    barrier()
-    st = sts[0]
+    sync_all()
+    wall = timed(a.steps)
 
     def over_steps(f):                          # sum of a per-batch statistic over the K timed steps
-        return float(sum(f(sts[i % S], hbs[i % S]) for i in range(a.steps)))
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=eng.device)
+        return float(sum(f(sts[i % B], hbs[i % B]) for i in range(a.steps)))
+    elapsed = torch.tensor([wall], dtype=torch.float64, device=eng.device)
     tot = torch.tensor([over_steps(lambda q, h: q.cells_reference), over_steps(lambda q, h: q.cells_launched),
                         over_steps(lambda q, h: h.n_windows), over_steps(lambda q, h: q.n_dp_reference),
                         over_steps(lambda q, h: q.n_dp_launched)], dtype=torch.float64, device=eng.device)
@@ -218,10 +274,11 @@ def main():
         recs = sharding.format_window_records(hb, db.logl.cpu().numpy(), windows=range(nrec), chrom=str(rank + 1))
         recs.sort(key=lambda r: (sharding.chrom_key(r[0]), r[1]))
         tg = time.perf_counter()
-        streams = sharding.gather_records(sharding.encode_records(recs), dist, device=eng.device)
+        got = sharding.gather_records(sharding.encode_records(recs), dist, device=eng.device)
         if rank == 0:
-            merged = sharding.merge_record_streams([sharding.decode_records(x) for x in streams])
-            gather = {"records": len(merged), "ranks": len(streams), "ms": 1e3 * (time.perf_counter() - tg)}
+            merged = sharding.merge_record_streams([sharding.decode_records(x) for x in got])
+            gather = {"records": len(merged), "ranks": len(got), "ms": 1e3 * (time.perf_counter() - tg),
+                      "backend": dist.get_backend() if dist is not None else None}
     except Exception as exc:                    # pragma: no cover
         gather = {"error": repr(exc)[:200]}
 
@@ -258,7 +315,7 @@ def main():
         r_dp = entry("k_dp_jobs", prof.dp_alg_bytes, dp_avg, pm,
                      "recurrence is VALU-issue bound (packed int16), not HBM bound: see DESIGN.md")
         r_seed = entry("k_seed", seed_alg, seedk_avg, pm.get("k_seed", {}),
-                       "one wave per (haplotype, 256 reads): LDS k-mer maps + bit-parallel proofs, latency / VALU bound: see DESIGN.md")
+                       "LDS k-mer maps + bit-parallel proofs, latency / VALU bound: see DESIGN.md")
         roof, roof_other = (r_seed, r_dp) if seedk_avg > dp_avg else (r_dp, r_seed)
         line = {
             "metric": "pair-HMM GCUPS (reference-equivalent band cells/s, read->haplotype likelihood path)",
@@ -267,11 +324,11 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: %d windows/GPU, 150 bp reads, 30x, <=8 haplotypes/window, SNP-only; "
-                                   "step = alignReads for all haplotypes + genotype likelihoods" % a.windows,
-                       "windows_per_gpu": a.windows, "read_len": 150, "depth": 30, "sharding": "windows by rank, no collective",
+            "config": {"workload": "BASELINE config 2: %d windows/GPU per step, 150 bp reads, 30x, <=8 haplotypes/window, SNP-only; "
+                                   "step = alignReads for all haplotypes + genotype likelihoods" % nwin_batch,
+                       "windows_per_gpu": nwin_batch, "read_len": 150, "depth": 30, "sharding": "windows by rank, no collective",
                        "entry": "plat_align_window_batch" if a.sync_entry else "plat_align_window_batch_async",
-                       "batches_in_flight": S},
+                       "batches_in_flight": S, "distinct_resident_batches": B, "timed_region_ms": 1e3 * T},
             "windows_per_sec": nwin / T,
             "gcups_executed": cells_run / T / 1e9,
             "dp_reference_per_step": ndp_ref / a.steps, "dp_launched_per_step": ndp_run / a.steps,
@@ -282,6 +339,42 @@ def main():
             "roofline_other": roof_other,
         }
         line["record_gather"] = gather
+        if world == 1 and not a.no_extras:
+            # ---- the same batches with the shortcuts switched off (the library reads the switches per call)
+            def mode(nsteps, dbl=dbs, hbl=hbs, **env):
+                with Env(**env):
+                    st_ = [eng.call_windows(d, want_stats=True) for d in dbl[:2]]
+                    for i in range(S):
+                        step(i, dbl, want_stats=False, asynchronous=not a.sync_entry)
+                    sync_all()
+                    t_ = timed(nsteps, dbl)
+                cells = sum(st_[i % len(st_)].cells_reference for i in range(nsteps))
+                run_ = sum(st_[i % len(st_)].cells_launched for i in range(nsteps))
+                return {"gcups": cells / t_ / 1e9, "gcups_executed": run_ / t_ / 1e9, "ms_per_step": 1e3 * t_ / nsteps,
+                        "dp_launched_per_step": float(st_[0].n_dp_launched), "dp_reference_per_step": float(st_[0].n_dp_reference)}
+            n2 = max(20, a.steps // 8)
+            alldp = mode(n2, PLAT_NO_UNGAPPED=1, PLAT_NO_EXACT=1)
+            line["gcups_all_dp"] = alldp["gcups_executed"]
+            line["all_dp"] = dict(alldp, what="both shortcuts off (PLAT_NO_UNGAPPED=1 PLAT_NO_EXACT=1): every reference DP is executed")
+            line["exact_match_shortcut_only"] = dict(mode(n2, PLAT_NO_UNGAPPED=1), what="ungapped-alignment proof off")
+            # ---- reads the ungapped proof likes less
+            hh = synth.config2_hard(nwin_batch)
+            dh = [eng.upload(hh)]
+            hard = mode(n2, dh, [hh])
+            hard_nolow = mode(n2, dh, [hh], PLAT_NO_NLOW=1)
+            hard_alldp = mode(max(10, n2 // 2), dh, [hh], PLAT_NO_UNGAPPED=1, PLAT_NO_EXACT=1)
+            line["hard_workload"] = {
+                "what": "config-2 geometry, 1 % substitution errors, 5 % of the bases below Q20 incl. Q2 tails of 5..40 bases on a "
+                        "tenth of the reads, 1e-4 sequencing indels per base (synth.config2_hard)",
+                "gcups": hard["gcups"], "gcups_executed": hard["gcups_executed"], "ms_per_step": hard["ms_per_step"],
+                "dp_launched_per_step": hard["dp_launched_per_step"], "dp_reference_per_step": hard["dp_reference_per_step"],
+                "without_low_quality_valuation": hard_nolow, "all_dp": hard_alldp}
+            del dh
+            try:
+                from tools import bench_other
+                line["other_configs"] = bench_other.summary(eng)
+            except Exception as exc:            # pragma: no cover
+                line["other_configs"] = {"error": repr(exc)[:300]}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hb)
         print(json.dumps(line))

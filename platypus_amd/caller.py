@@ -78,26 +78,31 @@ def _assemblerVariants(regions, refFile, options):
 def generateVariantsInRegions(regions, refFile, options):
     """generateVariantsInRegion for a list of (chrom, start, end, readBuffers): ONE candidate scan on the device for every
     sample of every region, then the reference's per-sample support filter, merge, left-normalisation and filterVariants.
-    Returns the per-region variant lists; options.rlen follows the longest read as in the reference (:470-481)."""
+    Returns (per-region variant lists, per-region rlen): options.rlen follows the longest read of EACH region as in the
+    reference (:470-488: set per region before left-normalisation, kept from the region before when a region has no reads);
+    the value a region was prepared with is the one its windows and haplotypes must be built with, so it is returned and
+    options.rlen is left at the last region's value, as after the reference's last call."""
     mk = lambda chrom, start, end: H.VariantCandidateGenerator((chrom, start, end), refFile, options.minMapQual, options.minFlank,
                                                                options.minBaseQual, options.maxReads, options.rlen, options,
                                                                options.verbosity, options.genSNPs, options.genIndels)
     out = [[] for _ in regions]
     if not options.getVariantsFromBAMs:
+        rlens = [options.rlen] * len(regions)
         if not options.assemble:
-            return out
+            return out, rlens
         merged = _assemblerVariants(regions, refFile, options)
         for k, cands in enumerate(merged):
             norm = sorted(leftNormaliseIndel(v, refFile, options.rlen) for v in cands)
             out[k] = filterVariants(norm, refFile, options.rlen, options.minReads, options.maxSize, options.verbosity, options)
-        return out
+        return out, rlens
     gens = [[mk(chrom, start, end) for _ in buffers] for chrom, start, end, buffers in regions]
     scans = [_candidateRegion(g, b.reads.array) for (_, _, _, buffers), gs in zip(regions, gens) for g, b in zip(gs, buffers)]
     found = iter(H.get_engine().candidates(scans, options.minFlank, options.minBaseQual, options.genSNPs, options.genIndels))
-    longest = 0
-    merged = []
+    merged, rlens = [], []
+    rlen = options.rlen
     for (chrom, start, end, buffers), gs in zip(regions, gens):
         everyone = mk(chrom, start, end)
+        longest = 0
         for g, b in zip(gs, buffers):
             longest = max(longest, b.reads.getLengthOfLongestRead())
             tally = {}                                                          # equal records merge into one variant with
@@ -110,19 +115,22 @@ def generateVariantsInRegions(regions, refFile, options):
                 if computeVariantReadSupportFrac(v, b) >= options.minVarFreq or v.nAdded != v.nRemoved:
                     everyone.addVariantToList(v)
         merged.append(everyone.getCandidates(0))
-    if longest > 0:
-        options.rlen = options.maxSize if longest >= options.maxSize else longest
+        if longest > 0:                                                          # :476-488
+            rlen = options.maxSize if longest >= options.maxSize else longest
+        rlens.append(rlen)
     if options.assemble:
         for cands, extra in zip(merged, _assemblerVariants(regions, refFile, options)):
             cands.extend(extra)                                                  # rawBamVariants + assemblerVariants (:521)
     for k, cands in enumerate(merged):
-        norm = sorted(leftNormaliseIndel(v, refFile, options.rlen) for v in cands)
-        out[k] = filterVariants(norm, refFile, options.rlen, options.minReads, options.maxSize, options.verbosity, options)
-    return out
+        norm = sorted(leftNormaliseIndel(v, refFile, rlens[k]) for v in cands)
+        out[k] = filterVariants(norm, refFile, rlens[k], options.minReads, options.maxSize, options.verbosity, options)
+    if rlens:
+        options.rlen = rlens[-1]
+    return out, rlens
 
 
 def generateVariantsInRegion(chrom, start, end, refFile, options, readBuffers):
-    return generateVariantsInRegions([(chrom, start, end, readBuffers)], refFile, options)[0]
+    return generateVariantsInRegions([(chrom, start, end, readBuffers)], refFile, options)[0][0]
 
 
 # ---- one window -----------------------------------------------------------------------------------------------------------
@@ -173,6 +181,12 @@ def _windowsOfRegion(chrom, start, end, refFile, options, variants, windowGenera
         yield window
 
 
+def _windowFailed(window, exc):
+    import logging
+    logging.getLogger("Log").exception("Problem calling variants in window %s:%d-%d. Skipping it: %r", window["chromosome"],
+                                       window["startPos"], window["endPos"], exc)
+
+
 def callVariantsInRegion(chrom, start, end, readBuffers, refFile, options, vcfFile, outputFile, windowGenerator=None, pop=None):
     """Window by window, as the reference."""
     _unsupported(options)
@@ -180,11 +194,14 @@ def callVariantsInRegion(chrom, start, end, readBuffers, refFile, options, vcfFi
     pop = pop or H.Population(options)
     variants = generateVariantsInRegion(chrom, start, end, refFile, options, readBuffers)
     for window in _windowsOfRegion(chrom, start, end, refFile, options, variants, windowGenerator):
-        callVariantsInWindow(window, options, refFile, readBuffers, pop)
-        if len(pop.variantPosteriors) > 0:
-            outputCallToVCF(pop.varsByPos, pop.vcfInfo, pop.vcfFilter, pop.haplotypes, pop.genotypes, pop.frequencies,
-                            pop.genotypeLikelihoods, pop.goodnessOfFitValues, pop.haplotypeIndexes, pop.readBuffers, pop.nIndividuals,
-                            vcfFile, refFile, outputFile, options, pop.variants, window["startPos"], window["endPos"], population=pop)
+        try:                                                                     # :568-615: a failing window is logged and skipped
+            callVariantsInWindow(window, options, refFile, readBuffers, pop)
+            if len(pop.variantPosteriors) > 0:
+                outputCallToVCF(pop.varsByPos, pop.vcfInfo, pop.vcfFilter, pop.haplotypes, pop.genotypes, pop.frequencies,
+                                pop.genotypeLikelihoods, pop.goodnessOfFitValues, pop.haplotypeIndexes, pop.readBuffers, pop.nIndividuals,
+                                vcfFile, refFile, outputFile, options, pop.variants, window["startPos"], window["endPos"], population=pop)
+        except Exception as exc:
+            _windowFailed(window, exc)
 
 
 # ---- all windows of all regions at once -----------------------------------------------------------------------------------
@@ -253,18 +270,37 @@ def callVariantsInRegions(regions, refFile, options, vcfFile, outputFile, window
     window order, then position order -- the order callVariantsInRegion would write them one region after the other."""
     _unsupported(options)
     windowGenerator = windowGenerator or WindowGenerator()
-    variants = generateVariantsInRegions(regions, refFile, options)
+    variants, rlens = generateVariantsInRegions(regions, refFile, options)
     specs = []
-    for (chrom, start, end, buffers), vs in zip(regions, variants):
+    for (chrom, start, end, buffers), vs, rlen in zip(regions, variants, rlens):
+        options.rlen = rlen                                                      # the region's own value (see generateVariantsInRegions)
         for window in _windowsOfRegion(chrom, start, end, refFile, options, vs, windowGenerator):
-            prep = _prepareWindow(window, options, refFile, buffers)             # (greedy haplotype filter: device calls of its own)
+            try:
+                prep = _prepareWindow(window, options, refFile, buffers)         # (greedy haplotype filter: device calls of its own)
+            except Exception as exc:                                             # :568-615: logged and skipped, as window by window
+                _windowFailed(window, exc)
+                continue
             if prep is not None:
                 specs.append(dict(variants=prep[0], haplotypes=prep[1], genotypes=prep[2], window=window,
                                   readBuffers=[b.frozenWindow() for b in buffers]))
-    pops = callWindowsBatched(specs, options, refFile)
+    try:
+        pops = callWindowsBatched(specs, options, refFile)
+    except Exception:
+        # one window the device refuses would take every other window of the batch with it: call them one at a time instead,
+        # so that only the failing ones are skipped
+        pops = []
+        for sp in specs:
+            try:
+                pops.append(callWindowsBatched([sp], options, refFile)[0])
+            except Exception as exc:
+                _windowFailed(sp["window"], exc)
+                pops.append(None)
     for sp, p in zip(specs, pops):
-        if len(p.variantPosteriors) > 0:
-            outputCallToVCF(p.varsByPos, p.vcfInfo, p.vcfFilter, p.haplotypes, p.genotypes, p.frequencies, p.genotypeLikelihoods,
-                            p.goodnessOfFitValues, p.haplotypeIndexes, p.readBuffers, p.nIndividuals, vcfFile, refFile, outputFile,
-                            options, p.variants, sp["window"]["startPos"], sp["window"]["endPos"], genotypeCalls=p._genotypeCalls)
+        if p is not None and len(p.variantPosteriors) > 0:
+            try:
+                outputCallToVCF(p.varsByPos, p.vcfInfo, p.vcfFilter, p.haplotypes, p.genotypes, p.frequencies, p.genotypeLikelihoods,
+                                p.goodnessOfFitValues, p.haplotypeIndexes, p.readBuffers, p.nIndividuals, vcfFile, refFile, outputFile,
+                                options, p.variants, sp["window"]["startPos"], sp["window"]["endPos"], genotypeCalls=p._genotypeCalls)
+            except Exception as exc:
+                _windowFailed(sp["window"], exc)
     return len(specs)

@@ -37,7 +37,10 @@ __device__ __forceinline__ int job_hap(const Job& j) { return j.hap & (JOB_BIGQ 
 // per-read descriptor: tile column, offset of the k-mer codes, mapping position, len | flags<<16 | mapq<<24
 // (flags bit0: skipped by the QCFail / overlap < 7 rule; bit1: the read holds a byte other than A, C, G, T;
 //  bit2: quality sum above DP_SWAR_MAX_QSUM -> its DPs use the packed 16-bit adds)
-struct ReadInfo { uint32_t col, code_off; int32_t pos; uint32_t lfm; };
+struct ReadInfo { uint32_t col, aux; int32_t pos; uint32_t lfm; };      // aux bits 0..15: number of bases with quality < LOWQ (the ungapped proof)
+constexpr unsigned LOWQ = 20u;
+enum { SHORTCUT_UNGAPPED = 1, SHORTCUT_EXACT = 2, SHORTCUT_NLOW = 4 };   // what k_seed may finish without a DP (PLAT_NO_UNGAPPED / PLAT_NO_EXACT
+                                                                         // switch them off; PLAT_NO_NLOW values unique windows by the smallest quality only)
 __device__ __forceinline__ long long job_slot(long long pair, long long npairs, int extra_base, int k) {
     return k == 0 ? pair : npairs + extra_base + (k - 1);
 }
@@ -174,6 +177,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     __shared__ unsigned s_dirty[2];                      // bit rl: read rl of the group holds a byte other than A, C, G, T
     __shared__ unsigned s_qsum[64];                      // sum of the base qualities of read rl (picks the DP's add flavour)
     __shared__ unsigned s_qmin[64];                      // smallest base quality of read rl (k_seed's ungapped-alignment proof)
+    __shared__ unsigned s_nlow[64];                      // number of bases of read rl with quality < LOWQ (same proof)
     const int w = blockIdx.x;
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
     if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
@@ -211,7 +215,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
         if (bad & 0x80808080u) set_err(cnt, PLAT_ERR_BAD_INPUT);
     }
     if (tid < 2) s_dirty[tid] = 0u;
-    if (tid < 64) { s_qsum[tid] = 0u; s_qmin[tid] = 255u; }
+    if (tid < 64) { s_qsum[tid] = 0u; s_qmin[tid] = 255u; s_nlow[tid] = 0u; }
     unsigned* s_pl = (unsigned*)(psm + 2 * qoff);        // [chunk][plane][half][64 reads] bit-plane accumulators (staged windows)
     const int nchunks = (rows - 8 + 63) >> 6;
     if (staged)
@@ -246,7 +250,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             const int o = s_off[rl], L = s_off[rl + 1] - o;
             uint32_t* tp = tile + toff + (long long)(4 * g) * R + c0 + rl;
             bool dirty = false;
-            unsigned qs = 0, qm = 255u, n0 = 0, n1 = 0;
+            unsigned qs = 0, qm = 255u, n0 = 0, n1 = 0, nl = 0;
             if (staged) {
                 // the thread's 4 bases and 4 qualities as two dwords (unaligned reads of the LDS images), then 4 at a time
                 const int nval = min(max(L - 4 * g, 0), 4);
@@ -268,6 +272,8 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
                 qs = __builtin_amdgcn_sad_u8(vq, 0u, 0u);
                 const uint32_t vqm = vq | ~keep;
                 qm = min(min(vqm & 0xFFu, (vqm >> 8) & 0xFFu), min((vqm >> 16) & 0xFFu, vqm >> 24));
+                // bytes >= LOWQ get bit 7 (7-bit qualities; the bytes past the read are 0xFF): the others are the low ones
+                nl = 4u - (unsigned)__popc((((vqm & 0x7F7F7F7Fu) + 0x01010101u * (128u - LOWQ)) | vqm) & 0x80808080u);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t wd = j < nval ? ((((vs >> (8 * j)) & 0x7Fu) << 9) | (((vq >> (8 * j)) & 0xFFu) << 18)) : READ_PAD_WORD;
@@ -283,6 +289,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
                     const unsigned ql = gq[o + i];
                     qs += ql;
                     qm = min(qm, ql);
+                    nl += ql < LOWQ;
                     const unsigned b2 = base2(ch);
                     n0 |= (b2 & 1u) << j;
                     n1 |= (b2 >> 1) << j;
@@ -295,6 +302,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             if (dirty) atomicOr(&s_dirty[rl >> 5], 1u << (rl & 31));
             if (qs) atomicAdd(&s_qsum[rl], qs);
             if (qm < s_qmin[rl]) atomicMin(&s_qmin[rl], qm);   // look first: most threads do not lower the minimum
+            if (nl) atomicAdd(&s_nlow[rl], nl);
             if (staged && 4 * g < rows - 8) {               // the 4 bases of this thread: 4 bits of each plane, inside one 32-bit half
                 const int c = (4 * g) >> 6, half = ((4 * g) >> 5) & 1, sh = (4 * g) & 31;
                 if (n0) atomicOr(&s_pl[((c * 2 + 0) * 2 + half) * 64 + rl], n0 << sh);
@@ -335,6 +343,7 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
         my_ri.lfm |= ((s_dirty[tid >> 5] >> (tid & 31)) & 1u) << 17;
         my_ri.lfm |= (s_qsum[tid] > (unsigned)DP_SWAR_MAX_QSUM ? 1u : 0u) << 18;
         my_ri.lfm |= min(s_qmin[tid], 31u) << 19;        // flags bits 3..7
+        my_ri.aux = min(s_nlow[tid], 0xFFFFu);
         rinfo[rb + c0 + tid] = my_ri;
     }
 }
@@ -529,7 +538,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
        const long long* __restrict__ tile_off, const ReadInfo* __restrict__ rinfo,
        const uint16_t* __restrict__ codes, uint32_t* __restrict__ hapw, uint8_t* __restrict__ hap_has_n,
        PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
-       SlowRec* __restrict__ slow_list, int tsize_max, int maxhap, int allow_ungapped, const uint32_t* __restrict__ tile)
+       SlowRec* __restrict__ slow_list, int tsize_max, int maxhap, int shortcuts, const uint32_t* __restrict__ tile)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nw64 = ((maxhap + 63) >> 6) + 8;           // plane words incl. slack for the shifted window of a hypothesis
@@ -807,7 +816,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         // The read equals the haplotype on the one candidate diagonal: that DP scores 0 (no cost is negative and the
         // all-match path costs 0; a haplotype N costs 0 as well, align.c:17,314-318) and calign.pyx:242-247 returns it
         // at once.  No DP is launched for the pair.
-        const bool zero = ncand == 1 && exact && hap_plain && !((rflags >> 1) & 1);
+        const bool zero = (shortcuts & SHORTCUT_EXACT) && ncand == 1 && exact && hap_plain && !((rflags >> 1) & 1);
         // ---- "ungapped": the read differs from the haplotype in one or two bases on the one candidate diagonal, which is
         // also the mapping position, and NO other path of the band can be cheaper than paying those mismatches.  Then
         // the single DP of the pair returns U = sum of the mismatching bases' qualities (align.c cost model: a mismatch costs
@@ -826,8 +835,8 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         int ung_score = -1;
         {
             const int mq = (rflags >> 3) & 31;
-            const bool cand = allow_ungapped && ncand == 1 && orig_in && provenA && !exact && hap_plain && s_scal[0] == 0 &&
-                              !((rflags >> 1) & 1) && mq > 0 && cidx >= 8 && L >= 32;
+            const bool cand = (shortcuts & SHORTCUT_UNGAPPED) && ncand == 1 && orig_in && provenA && !exact && hap_plain && s_scal[0] == 0 &&
+                              !((rflags >> 1) & 1) && cidx >= 8 && L >= 32;
             int k = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) k += __popcll(missA[c]);
@@ -856,6 +865,10 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                     return n;
                 };
                 auto W = [&](int a, int bnd) -> int { return (cnt7(max(a, 0), bnd - 6) + 6) / 7; };
+                // what n disjoint windows are worth at least: each holds a mismatching base, a base costs its quality, every
+                // quality is >= mq and all but nlow of the read's bases are >= LOWQ
+                const int nlow = (shortcuts & SHORTCUT_NLOW) ? (int)(ri.aux & 0xFFFFu) : 0x7FFF;
+                auto V = [&](int n) -> int { return max(mq * n, (int)LOWQ * max(n - nlow, 0) + mq * min(n, nlow)); };
                 const int p1 = nth(0), p2 = nth(1);          // k == 1: p1 == p2
                 const uint8_t* rq = b.read_qual + b.read_off[rb + rl];
                 const int q1 = rq[p1], q2 = k == 2 ? rq[p2] : 0;
@@ -864,10 +877,10 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 int G = 127;
                 for (int t = st >> 6; t <= (st + L + 14) >> 6; ++t) G = min(G, (int)s_gmin[t]);
                 const int hh = (L - 15) / 2;
-                bool ok = U <= 2 * G && mq * W(0, L) >= U && G + mq * min(W(0, hh), W(hh + 15, L)) >= U;
+                bool ok = U <= 2 * G && V(W(0, L)) >= U && G + V(min(W(0, hh), W(hh + 15, L))) >= U;
                 // first mismatch: Q = U, R = q1; last mismatch (k == 2): Q = q2, R = U
-                ok = ok && G + mq * W(p1 + 8, L) >= U && G + mq * W(0, p1 - 7) >= q1;
-                if (k == 2) ok = ok && G + mq * W(p2 + 8, L) >= q2 && G + mq * W(0, p2 - 7) >= U;
+                ok = ok && G + V(W(p1 + 8, L)) >= U && G + V(W(0, p1 - 7)) >= q1;
+                if (k == 2) ok = ok && G + V(W(p2 + 8, L)) >= q2 && G + V(W(0, p2 - 7)) >= U;
                 if (ok) ung_score = U;
             }
         }
@@ -1313,7 +1326,7 @@ PLAT_EXPORT int plat_dp_batch(plat_ctx* ctx, int n, int lmax, const uint8_t* hap
 
 static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStream_t st, long long* cnt, int maxhap,
                              int maxread, int maxR, long long npairs, int extra_cap, const int32_t* hap_win, const int32_t* win_rows,
-                             const long long* tile_off, int allow_ungapped)
+                             const long long* tile_off, int shortcuts)
 {
     int tsize_max = 64;                                        // in dwords
     if (maxhap > 4096) tsize_max = 8192;                       // direct mode: 16384 u16 heads
@@ -1334,7 +1347,7 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     hipLaunchKernelGGL(k_seed, dim3(b.n_haps, ngroups > 0 ? ngroups : 1), dim3(64), lds, st, b, hap_win, win_rows, tile_off,
                        (const ReadInfo*)ctx->rinfo.ptr, (const uint16_t*)ctx->codes.ptr, (uint32_t*)ctx->hapw.ptr,
                        (uint8_t*)ctx->hap_flags.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
-                       (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, allow_ungapped, (const uint32_t*)ctx->tile.ptr);
+                       (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, shortcuts, (const uint32_t*)ctx->tile.ptr);
     PLAT_EV(ctx, 5, st);                                       // k_seed alone: ev[1] .. ev[5]
     hipLaunchKernelGGL(k_seed_slow, dim3(4096), dim3(64), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
@@ -1438,8 +1451,13 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         // PLAT_NO_UNGAPPED=1 sends every such pair through the DP instead (cross-check in tests/test_gpu_parity.py)
         const char* e_ung = getenv("PLAT_NO_UNGAPPED");    // (read per call: the test flips it inside one process)
         const int no_ungapped = e_ung && e_ung[0] == '1';
+        const char* e_ex = getenv("PLAT_NO_EXACT");        // every reference DP is then run (bench.py's gcups_all_dp)
+        const int no_exact = e_ex && e_ex[0] == '1';
+        const char* e_nl = getenv("PLAT_NO_NLOW");
+        const int shortcuts = ((!calc_flank_score && !no_ungapped) ? SHORTCUT_UNGAPPED : 0) | (no_exact ? 0 : SHORTCUT_EXACT) |
+                              ((e_nl && e_nl[0] == '1') ? 0 : SHORTCUT_NLOW);
         if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win, win_rows, tile_off,
-                                    !calc_flank_score && !no_ungapped))) return rc;
+                                    shortcuts))) return rc;
         {   // dense list of the live job slots; pairs that need no DP are finished by k_compact_count
             const long long slots_cap = npairs + extra_cap;
             const unsigned nblk = (unsigned)((slots_cap + COMPACT_BLOCK - 1) / COMPACT_BLOCK);

@@ -88,6 +88,52 @@ class LikelihoodBatch:
         self.gof = up(np.concatenate([np.asarray(x, dtype=np.float64).reshape(-1) for x in gof] + [np.zeros(1)]), np.float64)
 
 
+class AssemblyDeviceBatch:
+    """HBM image of a plat_assembly_batch + the output buffers of plat_assemble_batch."""
+
+    def __init__(self, ab, device, max_vars=512, blob_per_region=1 << 16):
+        torch = _torch()
+
+        def dev(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(device)
+        self.device, self.max_vars, self.blob_per_region = device, max_vars, blob_per_region
+        nG = self.n_regions = int(ab["n_regions"])
+        self.t = dict(ref_seq=dev(pad_blob(ab["ref_seq"]), np.uint8), ref_off=dev(ab["ref_off"], np.int64),
+                      ref_start=dev(ab["ref_start"], np.int32), assem_start=dev(ab["assem_start"], np.int32),
+                      assem_end=dev(ab["assem_end"], np.int32), reg_read_begin=dev(ab["reg_read_begin"], np.int32),
+                      read_seq=dev(pad_blob(ab["read_seq"]), np.uint8), read_qual=dev(pad_blob(ab["read_qual"]), np.uint8),
+                      read_off=dev(ab["read_off"], np.int64))
+        s = _lib.AssemblyBatch()
+        s.n_regions, s.n_reads = nG, int(ab["n_reads"])
+        for name, _ in _lib.AssemblyBatch._fields_[2:]:
+            setattr(s, name, self.t[name].data_ptr())
+        self.struct = s
+        i32 = dict(dtype=torch.int32, device=device)
+        self.cnt = torch.zeros(nG, **i32); self.status = torch.zeros(nG, **i32)
+        self.pos = torch.zeros(nG * max_vars, **i32); self.nrem = torch.zeros(nG * max_vars, **i32)
+        self.nadd = torch.zeros(nG * max_vars, **i32); self.off = torch.zeros(nG * max_vars, **i32)
+        self.blob = torch.zeros(nG * blob_per_region, dtype=torch.uint8, device=device)
+
+    def results(self):
+        """[syncs] per region the list of (pos, removed, added) in the reference's sorted() order."""
+        _torch().cuda.synchronize(self.device)
+        cnt, status, pos, nrem, nadd, off = (x.cpu().numpy() for x in (self.cnt, self.status, self.pos, self.nrem, self.nadd, self.off))
+        blob = self.blob.cpu().numpy()
+        out = []
+        for g in range(self.n_regions):
+            if status[g] != 0:
+                _lib.check(int(status[g]), "plat_assemble_batch(region %d)" % g)
+            vs = []
+            if cnt[g]:
+                raw = blob[g * self.blob_per_region:(g + 1) * self.blob_per_region].tobytes()
+                for i in range(cnt[g]):
+                    k = g * self.max_vars + i
+                    o = off[k]
+                    vs.append((int(pos[k]), raw[o:o + nrem[k]], raw[o + nrem[k]:o + nrem[k] + nadd[k]]))
+            out.append(vs)
+        return out
+
+
 class Engine:
     def __init__(self, device_index=0):
         torch = _torch()
@@ -424,6 +470,18 @@ class Engine:
         return res
 
     # ---- a14..a18 ------------------------------------------------------------------------------------
+    def upload_assembly(self, ab, max_vars=512, blob_per_region=1 << 16):
+        """HBM image of the host arrays of plat_assembly_batch (dict as synth.config3 returns) + output buffers."""
+        return AssemblyDeviceBatch(ab, self.device, max_vars, blob_per_region)
+
+    def assemble_device(self, adb, kmer_size=15, min_qual=20, min_weight=40, no_cycles=0):
+        """plat_assemble_batch on a resident batch; enqueues only, results stay in HBM (adb.results() reads them)."""
+        rc = self.lib.plat_assemble_batch(self.ctx, C.byref(adb.struct), kmer_size, min_qual, min_weight, no_cycles, adb.max_vars,
+                                          adb.blob_per_region, adb.cnt.data_ptr(), adb.pos.data_ptr(), adb.nrem.data_ptr(),
+                                          adb.nadd.data_ptr(), adb.off.data_ptr(), adb.blob.data_ptr(), adb.status.data_ptr(),
+                                          self._stream())
+        _lib.check(rc, "plat_assemble_batch")
+
     def assemble(self, regions, kmer_size=15, min_qual=20, min_weight=40, no_cycles=0, max_vars=512,
                  blob_per_region=1 << 16):
         """assembleReadsAndDetectVariants for a list of regions.
@@ -431,55 +489,23 @@ class Engine:
         `regions`: list of dicts {ref: bytes, ref_start, assem_start, assem_end, seqs: [bytes], quals: [bytes]}
         (reads already in loadBAMDataIntoGraph order, QCFail reads removed).  Returns per region the list of
         (pos, removed, added) in the reference's sorted() order."""
-        torch = _torch()
         nG = len(regions)
         if nG == 0:
             return []
         ref_len = np.array([len(r["ref"]) for r in regions], dtype=np.int64)
         nreads = np.array([len(r["seqs"]) for r in regions], dtype=np.int64)
         rl = np.array([len(s) for r in regions for s in r["seqs"]], dtype=np.int64)
-
-        def dev(a, dt):
-            return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.device)
-        t = dict(
-            ref_seq=dev(pad_blob(np.frombuffer(b"".join(r["ref"] for r in regions), dtype=np.uint8)), np.uint8),
-            ref_off=dev(np.concatenate([[0], np.cumsum(ref_len)]), np.int64),
-            ref_start=dev([r["ref_start"] for r in regions], np.int32),
-            assem_start=dev([r["assem_start"] for r in regions], np.int32),
-            assem_end=dev([r["assem_end"] for r in regions], np.int32),
-            reg_read_begin=dev(np.concatenate([[0], np.cumsum(nreads)]), np.int32),
-            read_seq=dev(pad_blob(np.frombuffer(b"".join(s for r in regions for s in r["seqs"]), dtype=np.uint8)), np.uint8),
-            read_qual=dev(pad_blob(np.frombuffer(b"".join(q for r in regions for q in r["quals"]), dtype=np.uint8)), np.uint8),
-            read_off=dev(np.concatenate([[0], np.cumsum(rl)]), np.int64))
-        ab = _lib.AssemblyBatch()
-        ab.n_regions, ab.n_reads = nG, int(nreads.sum())
-        for name, _ in _lib.AssemblyBatch._fields_[2:]:
-            setattr(ab, name, t[name].data_ptr())
-        i32 = dict(dtype=torch.int32, device=self.device)
-        cnt = torch.zeros(nG, **i32); status = torch.zeros(nG, **i32)
-        pos = torch.zeros(nG * max_vars, **i32); nrem = torch.zeros(nG * max_vars, **i32)
-        nadd = torch.zeros(nG * max_vars, **i32); off = torch.zeros(nG * max_vars, **i32)
-        blob = torch.zeros(nG * blob_per_region, dtype=torch.uint8, device=self.device)
-        rc = self.lib.plat_assemble_batch(self.ctx, C.byref(ab), kmer_size, min_qual, min_weight, no_cycles, max_vars,
-                                          blob_per_region, cnt.data_ptr(), pos.data_ptr(), nrem.data_ptr(),
-                                          nadd.data_ptr(), off.data_ptr(), blob.data_ptr(), status.data_ptr(),
-                                          self._stream())
-        _lib.check(rc, "plat_assemble_batch")
-        torch.cuda.synchronize(self.device)
-        cnt, status, pos, nrem, nadd, off = (x.cpu().numpy() for x in (cnt, status, pos, nrem, nadd, off))
-        blob = blob.cpu().numpy()
-        out = []
-        for g in range(nG):
-            if status[g] != 0:
-                _lib.check(int(status[g]), "plat_assemble_batch(region %d)" % g)
-            vs = []
-            raw = blob[g * blob_per_region:(g + 1) * blob_per_region].tobytes()
-            for i in range(cnt[g]):
-                k = g * max_vars + i
-                o = off[k]
-                vs.append((int(pos[k]), raw[o:o + nrem[k]], raw[o + nrem[k]:o + nrem[k] + nadd[k]]))
-            out.append(vs)
-        return out
+        ab = dict(n_regions=nG, n_reads=int(nreads.sum()),
+                  ref_seq=np.frombuffer(b"".join(r["ref"] for r in regions), dtype=np.uint8),
+                  ref_off=np.concatenate([[0], np.cumsum(ref_len)]),
+                  ref_start=[r["ref_start"] for r in regions], assem_start=[r["assem_start"] for r in regions],
+                  assem_end=[r["assem_end"] for r in regions], reg_read_begin=np.concatenate([[0], np.cumsum(nreads)]),
+                  read_seq=np.frombuffer(b"".join(s for r in regions for s in r["seqs"]), dtype=np.uint8),
+                  read_qual=np.frombuffer(b"".join(q for r in regions for q in r["quals"]), dtype=np.uint8),
+                  read_off=np.concatenate([[0], np.cumsum(rl)]))
+        adb = self.upload_assembly(ab, max_vars, blob_per_region)
+        self.assemble_device(adb, kmer_size, min_qual, min_weight, no_cycles)
+        return adb.results()
 
     def profile_enable(self, on=True):
         _lib.check(self.lib.plat_profile_enable(self.ctx, int(on)), "plat_profile_enable")

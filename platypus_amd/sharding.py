@@ -5,7 +5,8 @@ The reference parallelises by giving every worker process a share of the sorted 
 k-way heap merge keyed by (chromosome, position) (runner.py:301-352, key: runner.py:47-50,77-82).  Here one
 process drives one GPU; regions / windows are assigned the same way (index % world), there is NO data-path
 collective, and the only exchange is ONE variable-length gather of the per-region record bytes to rank 0
-(RCCL over xGMI on GPUs via backend "nccl"; gloo on CPU for the tests) followed by the same ordered merge.
+(sizes by all_gather, payloads point to point; RCCL over xGMI on GPUs via backend "nccl", gloo on CPU for the tests)
+followed by the same ordered merge.
 """
 import heapq
 
@@ -26,12 +27,14 @@ def chrom_key(chrom):
 
 
 def gather_records(payload: bytes, dist=None, device=None):
-    """Gather one byte string per rank to rank 0.  Returns list[bytes] on rank 0, None elsewhere.
+    """Gather one byte string per rank to rank 0 (SURVEY 8(e)).  Returns list[bytes] on rank 0, None elsewhere.
 
-    Sizes travel in one all_gather(int64); payloads in one padded all_gather(uint8) -- a few KB..MB per rank,
-    so link bandwidth is irrelevant ('Distributed communication backend')."""
+    Sizes travel in one all_gather(int64); each payload then goes point to point to rank 0 only (one send per rank, rank 0
+    posts the matching receives at their exact sizes) -- no rank but 0 ever holds another rank's records, and nothing is padded
+    to the largest payload.  With a process group of one rank the size exchange still runs (it is the whole collective
+    then).  `device`: where the staging tensors live -- the GPU for backend "nccl" (RCCL), None = CPU for gloo."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return [payload]
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = device if device is not None else torch.device("cpu")
@@ -39,15 +42,18 @@ def gather_records(payload: bytes, dist=None, device=None):
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, n)
     sizes = [int(s.item()) for s in sizes]
-    m = max(max(sizes), 1)
-    buf = torch.zeros(m, dtype=torch.uint8, device=dev)
-    if payload:
-        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
-    out = [torch.zeros(m, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(out, buf)
+    mine = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev) if payload else torch.zeros(0, dtype=torch.uint8, device=dev)
     if rank != 0:
+        if sizes[rank] > 0:
+            dist.send(mine, dst=0)
         return None
-    return [bytes(out[r][:sizes[r]].cpu().numpy().tobytes()) for r in range(world)]
+    out = [payload]
+    bufs = [torch.empty(sizes[r], dtype=torch.uint8, device=dev) for r in range(1, world)]
+    reqs = [dist.irecv(b, src=r) for r, b in zip(range(1, world), bufs) if b.numel() > 0]
+    for q in reqs:
+        q.wait()
+    out += [bytes(b.cpu().numpy().tobytes()) for b in bufs]
+    return out
 
 
 def merge_record_streams(streams):

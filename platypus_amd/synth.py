@@ -23,11 +23,15 @@ def _other_base(rng, base):
 
 
 def make_snp_windows(n_windows, seed, read_len=150, depth=30, n_ind=1, ref_len=1200, max_snps=3,
-                     cluster=40, min_var_dist=9, err=1e-3, frac_bad=0.02, hap_freq_beta=None):
+                     cluster=40, min_var_dist=9, err=1e-3, frac_bad=0.02, hap_freq_beta=None, lowq_frac=0.0, q2_tail_reads=0.0,
+                     read_indel_rate=0.0):
     """Config-2 style windows: 1..max_snps SNPs in a `cluster`-bp cluster, all 2^n haplotypes
     (the `nVars <= log2(maxHaplotypes-1)` branch, variantFilter.pyx:411-438), window = cluster +- 9
     (minVarDist), `read_len` reads at `depth`x per individual, diploid truth, 0.1% substitution errors,
-    quals ~ clipped N(35,5) -> [2,41], `frac_bad` of reads with mapq < 20 (-> badReads, QCFail)."""
+    quals ~ clipped N(35,5) -> [2,41], `frac_bad` of reads with mapq < 20 (-> badReads, QCFail).
+    Harder reads (config2_hard): `lowq_frac` of the bases get a quality uniform in [2, 19], `q2_tail_reads` of the reads end
+    in a run of 5..40 bases of quality 2, and `read_indel_rate` per base of sequencing indels (one base inserted or skipped;
+    the read keeps its length and its reported position)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     nW = n_windows
     buf = min(2 * read_len, 500)                                   # chaplotype.pyx:142
@@ -109,6 +113,23 @@ def make_snp_windows(n_windows, seed, read_len=150, depth=30, n_ind=1, ref_len=1
     e = rng.random(seq.shape) < err
     seq[e] = _other_base(rng, seq[e])
     qual = np.clip(np.rint(rng.normal(35, 5, size=seq.shape)), 2, 41).astype(np.uint8)
+    if read_indel_rate > 0:
+        rows, cols_ = np.nonzero(rng.random(seq.shape) < read_indel_rate)
+        ins = rng.random(len(rows)) < 0.5
+        for r_, c_, i_ in zip(rows.tolist(), cols_.tolist(), ins.tolist()):
+            if i_:                                                   # one base inserted at c_: the rest moves right
+                seq[r_, c_ + 1:] = seq[r_, c_:-1].copy()
+                seq[r_, c_] = ACGT[rng.integers(0, 4)]
+            else:                                                    # the base at c_ is skipped: the rest moves left
+                seq[r_, c_:-1] = seq[r_, c_ + 1:].copy()
+    if lowq_frac > 0:
+        low = rng.random(seq.shape) < lowq_frac
+        qual[low] = rng.integers(2, 20, size=int(low.sum())).astype(np.uint8)
+    if q2_tail_reads > 0:
+        tails = np.nonzero(rng.random(nR) < q2_tail_reads)[0]
+        tl = rng.integers(5, 41, size=len(tails))
+        for r_, t_ in zip(tails.tolist(), tl.tolist()):
+            qual[r_, read_len - t_:] = 2
     read_off = (np.arange(nR + 1, dtype=np.int64) * read_len)
     win_read_begin = np.concatenate([[0], np.cumsum(R_wi.sum(axis=1))]).astype(np.int32)
     return HostBatch(
@@ -156,6 +177,13 @@ def config1(seed=1001):
 def config2(n_windows=10000, seed=2002):
     """BASELINE config 2: 10k windows, 150 bp reads, 30x, <= 8 haplotypes/window, SNP-only."""
     return make_snp_windows(n_windows, seed, read_len=150, depth=30)
+
+
+def config2_hard(n_windows=10000, seed=2202):
+    """Config-2 geometry with reads an ungapped-alignment proof likes less: 1 % substitution errors, 3.5 % of the bases below
+    Q20 plus Q2 tails of 5..40 bases on a tenth of the reads (5 % of all bases below Q20), 1e-4 sequencing indels per base."""
+    return make_snp_windows(n_windows, seed, read_len=150, depth=30, err=1e-2, lowq_frac=0.035, q2_tail_reads=0.1,
+                            read_indel_rate=1e-4)
 
 
 def config5(n_windows=2000, n_ind=100, seed=5005):
@@ -252,3 +280,68 @@ def config4_region(index, seed=4004, region_len=100000, n_samples=1, depth=30, r
         reads.sort(key=lambda r: r["pos"])
         samples.append(reads)
     return dict(chrom="r%d" % index, start=start, end=end, ref=ref, variants=variants, samples=samples, truth=truth)
+
+
+# ---- BASELINE config 3: assembly tiles ---------------------------------------------------------------------------------------
+
+def config3(n_regions=2000, seed=3003, ref_len=4500, tile=1500, read_len=250, depth=30, lowq_frac=0.05, err=1e-3):
+    """BASELINE config 3: `n_regions` assembly tiles.  Each: `ref_len` bp of random reference (the 1.5 kb tile +- 1.5 kb), a
+    diploid donor carrying 1..3 indels (length geometric, 1..60 bp, half insertions) and 0..3 SNPs inside the tile, `read_len` bp
+    reads at `depth`x from either donor haplotype, qualities ~ clipped N(35, 5) with `lowq_frac` of the bases below Q20,
+    0.1 % substitution errors.  Returns the host arrays of plat_assembly_batch (dict: ref_seq, ref_off, ref_start, assem_start,
+    assem_end, reg_read_begin, read_seq, read_qual, read_off, n_regions, n_reads) plus `truth` = planted variants per region."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    refs, seqs, ref_start, a0s, a1s, nreads, truth = [], [], [], [], [], [], []
+    n_per = depth * ref_len // read_len
+    for g in range(n_regions):
+        ref = _rand_bases(rng, ref_len)
+        rs = int(rng.integers(0, 1 << 20))
+        lo = (ref_len - tile) // 2
+        nind, nsnp = int(rng.integers(1, 4)), int(rng.integers(0, 4))
+        spots = np.sort(rng.choice(np.arange(lo + 30, lo + tile - 100), size=nind + nsnp, replace=False)).tolist()
+        kinds = [1] * nind + [0] * nsnp
+        rng.shuffle(kinds)
+        planted = []
+        for p, kd in zip(spots, kinds):
+            if kd == 0:
+                planted.append((p, 0, _other_base(rng, ref[p:p + 1])))
+            else:
+                k = int(min(60, rng.geometric(0.15)))
+                planted.append((p, -k, None) if rng.random() < 0.5 else (p, k, _rand_bases(rng, k)))
+        donors = []
+        for _ in range(2):
+            parts, cur = [], 0
+            for p, k, bases in planted:
+                if p < cur or rng.random() < 0.5:
+                    continue
+                if k == 0:
+                    parts += [ref[cur:p], bases]; cur = p + 1
+                elif k > 0:
+                    parts += [ref[cur:p + 1], bases]; cur = p + 1
+                else:
+                    parts += [ref[cur:p + 1]]; cur = p + 1 - k
+            parts.append(ref[cur:])
+            donors.append(np.concatenate(parts))
+        which = rng.integers(0, 2, size=n_per)
+        out = np.empty((n_per, read_len), dtype=np.uint8)
+        for d in (0, 1):
+            sel = np.nonzero(which == d)[0]
+            st = rng.integers(0, len(donors[d]) - read_len, size=len(sel))
+            out[sel] = donors[d][st[:, None] + np.arange(read_len)[None, :]]
+        refs.append(ref); seqs.append(out); ref_start.append(rs); a0s.append(rs + lo); a1s.append(rs + lo + tile)
+        nreads.append(n_per); truth.append([(rs + p, k) for p, k, _ in planted])
+    seq = np.concatenate(seqs)
+    e = rng.random(seq.shape, dtype=np.float32) < err
+    seq[e] = _other_base(rng, seq[e])
+    qual = rng.standard_normal(seq.shape, dtype=np.float32)
+    qual *= 5.0
+    qual += 35.5                                                         # floor(x + 0.5): round half up is as good as rint here
+    np.clip(qual, 2, 41.5, out=qual)
+    qual = qual.astype(np.uint8)
+    low = rng.random(seq.shape, dtype=np.float32) < lowq_frac
+    qual[low] = rng.integers(2, 20, size=int(low.sum()), dtype=np.uint8)
+    nR = seq.shape[0]
+    return dict(n_regions=n_regions, n_reads=nR, ref_seq=np.concatenate(refs), ref_off=np.arange(n_regions + 1, dtype=np.int64) * ref_len,
+                ref_start=np.array(ref_start, dtype=np.int32), assem_start=np.array(a0s, dtype=np.int32),
+                assem_end=np.array(a1s, dtype=np.int32), reg_read_begin=np.concatenate([[0], np.cumsum(nreads)]).astype(np.int32),
+                read_seq=seq.reshape(-1), read_qual=qual.reshape(-1), read_off=np.arange(nR + 1, dtype=np.int64) * read_len, truth=truth)

@@ -144,3 +144,32 @@ def test_called_genotypes_agree_with_the_planted_donors():
                 total += 1
                 agree += got == want
     assert total > 30 and agree >= 0.95 * total, (agree, total)
+
+
+def test_batched_caller_uses_each_regions_own_read_length():
+    """options.rlen follows the longest read of each region (variantcaller.pyx:476-488) and is what its indels are
+    left-normalised with, its windows are merged with and its haplotypes are padded with; a region without reads keeps the value
+    of the region before it.  Regions with 150 / 76 / no / 100 bp reads: the batched shape must write what the sequence of
+    per-region calls with ONE options object writes."""
+    specs = [dict(read_len=150), dict(read_len=76), None, dict(read_len=100)]
+    regs, names = [], ["S1"]
+    for i, kw in enumerate(specs):
+        r = synth.config4_region(40 + i, n_samples=1, region_len=2200, snp_rate=5e-3, indel_rate=2e-3, depth=35, **(kw or dict(read_len=100)))
+        if kw is None:
+            r["samples"] = [[]]
+        regs.append(r)
+    fasta = H.FastaFile({r["chrom"]: r["ref"] for r in regs})
+    buffers = lambda r: [H.bamReadBuffer([H.AlignedRead(x["seq"], x["qual"], x["pos"], x["mapq"], x["flag"], end=x["end"], cigarOps=x["cigar"])
+                                          for x in r["samples"][0]], sample="S1")]
+    opts = default_options()
+    one = io.StringIO()
+    seen = []
+    for r in regs:
+        caller.callVariantsInRegion(r["chrom"], r["start"], r["end"], buffers(r), fasta, opts, VCF(names), one)
+        seen.append(opts.rlen)
+    assert len(set(seen)) >= 3 and seen[2] == seen[1]                         # the empty region kept the value of the one before
+    opts2 = default_options()
+    many = io.StringIO()
+    caller.callVariantsInRegions([(r["chrom"], r["start"], r["end"], buffers(r)) for r in regs], fasta, opts2, VCF(names), many)
+    assert one.getvalue() == many.getvalue() and one.getvalue().count("\n") > 20
+    assert opts2.rlen == seen[-1]

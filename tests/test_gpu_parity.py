@@ -574,20 +574,29 @@ def test_ungapped_shortcut_equals_the_dp_everywhere(eng, oracle):
     import os
     from platypus_amd import synth
     used = 0
-    for hb in (_adversarial_batch(1), _adversarial_batch(2), synth.config2(1500, seed=9)):
+    for hb in (_adversarial_batch(1), _adversarial_batch(2), synth.config2(1500, seed=9), synth.config2_hard(1200, seed=11)):
         res = {}
-        for mode in ("0", "1"):
-            os.environ["PLAT_NO_UNGAPPED"] = mode
+        # "0": both shortcuts; "1": the ungapped proof off; "all": the exact-match shortcut off too (every reference DP is run);
+        # "nolow": the proof values its unique windows by the smallest quality only (no count of low-quality bases)
+        for mode, env in (("0", {}), ("1", {"PLAT_NO_UNGAPPED": "1"}), ("all", {"PLAT_NO_UNGAPPED": "1", "PLAT_NO_EXACT": "1"}),
+                          ("nolow", {"PLAT_NO_NLOW": "1"})):
+            os.environ.update(env)
             try:
                 db = eng.upload(hb)
                 st = eng.align(db, want_stats=True)
                 eng.synchronize()
-                res[mode] = (db.score.cpu().numpy()[:hb.n_pairs].copy(), db.loglik.cpu().numpy()[:hb.n_pairs].copy(), int(st.n_dp_launched))
+                res[mode] = (db.score.cpu().numpy()[:hb.n_pairs].copy(), db.loglik.cpu().numpy()[:hb.n_pairs].copy(), int(st.n_dp_launched),
+                             int(st.n_dp_reference))
             finally:
-                os.environ.pop("PLAT_NO_UNGAPPED", None)
-        assert np.array_equal(res["0"][0], res["1"][0])
-        assert np.array_equal(res["0"][1], res["1"][1])
-        assert res["0"][2] < res["1"][2]                       # the shortcut did take pairs away from the DP
+                for k in env:
+                    os.environ.pop(k, None)
+        for mode in ("1", "all", "nolow"):
+            assert np.array_equal(res["0"][0], res[mode][0]), mode
+            assert np.array_equal(res["0"][1], res[mode][1]), mode
+        assert res["0"][2] < res["1"][2] < res["all"][2]       # each shortcut did take pairs away from the DP
+        assert res["0"][2] <= res["nolow"][2]
+        assert res["all"][2] >= res["all"][3] == res["0"][3]   # with both off the device runs every DP of the reference (and the later
+                                                               # candidates of a pair whose earlier one scored 0, where the reference stops)
         used += res["1"][2] - res["0"][2]
     assert used > 10000
     hb = _adversarial_batch(3, 40)
@@ -601,3 +610,80 @@ def test_ungapped_shortcut_equals_the_dp_everywhere(eng, oracle):
         R = len(rd["seq"])
         H_ = hb.win_hap_begin[w + 1] - hb.win_hap_begin[w]
         assert np.array_equal(got[hb.pair_off[w]:hb.pair_off[w] + H_ * R].reshape(H_, R), np.asarray(exp[0]).reshape(H_, R))
+
+
+def test_config5_real_width(eng, oracle):
+    """BASELINE config 5 at its real width: 100 samples per window.  The oracle on a sample of windows (per-read
+    log-likelihoods bit for bit, genotype log-likelihoods to 1e-12), invariance under a permutation of the windows, and the EM /
+    genotype calls against the oracle's on the device's own likelihoods."""
+    from platypus_amd import synth
+    hb = synth.config5(60, 100, seed=5005)
+    assert hb.n_ind == 100 and hb.n_windows == 60
+    db = eng.upload(hb)
+    eng.call_windows(db, want_stats=False)
+    eng.em(db, 100, 0)
+    eng.synchronize()
+    ll, logl, gl = db.loglik.cpu().numpy(), db.logl.cpu().numpy(), db.gl.cpu().numpy()
+    freq, calls = db.freq.cpu().numpy(), db.calls.cpu().numpy().reshape(hb.n_windows, hb.n_ind)
+    rng = np.random.default_rng(5)
+    for w in rng.choice(hb.n_windows, 6, replace=False).tolist():
+        rd = hb.window_reads(w)
+        H_ = int(hb.win_hap_begin[w + 1] - hb.win_hap_begin[w])
+        R = len(rd["seq"])
+        exp = oracle.align_window(hb.window_haps(w), int(hb.win_start[w]), int(hb.win_end[w]), int(hb.win_flank[w]), rd)
+        oll = np.asarray(exp[0]).reshape(H_, R)
+        assert np.array_equal(ll[hb.pair_off[w]:hb.pair_off[w] + H_ * R].reshape(H_, R), oll)
+        G = H_ * (H_ + 1) // 2
+        r0 = int(hb.win_read_begin[w])
+        for i in rng.choice(hb.n_ind, 8, replace=False).tolist():
+            s = w * hb.n_ind + i
+            a, b = int(hb.seg_read_begin[s]) - r0, int(hb.seg_read_begin[s + 1]) - r0
+            ol, ogl, _ = oracle.population_setup_ind(np.ascontiguousarray(oll[:, a:b]), int(hb.seg_n_good[s]))
+            o = int(hb.gl_off[w]) + i * G
+            assert np.allclose(logl[o:o + G], ol, rtol=1e-12, atol=0)
+            assert np.allclose(gl[o:o + G], ogl, rtol=1e-12, atol=0)
+        # EM + calls on the device's own genotype likelihoods
+        o = int(hb.gl_off[w])
+        nreads = hb.seg_n_good[w * hb.n_ind:(w + 1) * hb.n_ind]
+        of, _, oc, _, _ = oracle.em_call(nreads, gl[o:o + hb.n_ind * G].reshape(hb.n_ind, G), 100, 0)
+        h0 = int(hb.win_hap_begin[w])
+        assert np.array_equal(freq[h0:h0 + H_], of)
+        assert np.array_equal(calls[w], oc)
+    # the windows in another order give the same per-window results
+    perm = rng.permutation(hb.n_windows).tolist()
+    hp = hb.subset(perm)
+    dp_ = eng.upload(hp)
+    eng.call_windows(dp_, want_stats=False)
+    eng.em(dp_, 100, 0)
+    eng.synchronize()
+    logl2, freq2 = dp_.logl.cpu().numpy(), dp_.freq.cpu().numpy()
+    for k, w in enumerate(perm):
+        n = int(hb.gl_off[w + 1] - hb.gl_off[w])
+        assert np.array_equal(logl2[hp.gl_off[k]:hp.gl_off[k] + n], logl[hb.gl_off[w]:hb.gl_off[w] + n])
+        H_ = int(hb.win_hap_begin[w + 1] - hb.win_hap_begin[w])
+        assert np.array_equal(freq2[hp.win_hap_begin[k]:hp.win_hap_begin[k] + H_], freq[hb.win_hap_begin[w]:hb.win_hap_begin[w] + H_])
+
+
+def test_rccl_process_group_of_one_rank_gathers_and_merges():
+    """What one GPU allows of the multi-GPU exchange: an RCCL ("nccl") process group with one rank on cuda:0, the size
+    all_gather of gather_records on device tensors, and the ordered merge (runner.py:301-352)."""
+    import os, socket, subprocess, sys
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from platypus_amd import sharding
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+recs = [("2", 7, "b"), ("1", 5, "a"), ("X", 1, "c")]
+recs.sort(key=lambda r: (sharding.chrom_key(r[0]), r[1]))
+got = sharding.gather_records(sharding.encode_records(recs), dist, device=torch.device("cuda", 0))
+t = torch.ones(4, device="cuda"); dist.all_reduce(t); dist.barrier()
+assert dist.get_backend() == "nccl" and len(got) == 1 and float(t.sum()) == 4.0
+print("MERGED", ",".join(sharding.merge_record_streams([sharding.decode_records(p) for p in got])))
+dist.destroy_process_group()
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "MERGED a,b,c" in r.stdout
