@@ -62,6 +62,12 @@ int plat_memcpy_h2d(plat_ctx* ctx, void* dst_dev, const void* src_host, size_t b
 int plat_memcpy_d2h(plat_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream);
 int plat_memset(plat_ctx* ctx, void* dst_dev, int value, size_t bytes, void* stream);
 int plat_stream_sync(plat_ctx* ctx, void* stream);          /* [syncs] */
+/* a HIP stream of the context's device (hipStream_t as void*), for callers without a HIP runtime binding of their own;
+ * pinned (page-locked) host memory for staging buffers: copies from / to it are asynchronous and run at link speed */
+int plat_stream_create(plat_ctx* ctx, void** out_stream);
+int plat_stream_destroy(plat_ctx* ctx, void* stream);
+int plat_host_alloc(plat_ctx* ctx, size_t bytes, void** out_host_ptr);
+int plat_host_free(plat_ctx* ctx, void* host_ptr);
 
 /* ---- live kernel timing (HIP events recorded on the caller's stream around each kernel) ----------
  * Used by bench.py for the roofline line; off by default (no overhead).  plat_profile_last [syncs]
@@ -373,6 +379,20 @@ typedef struct plat_infostats_batch {
 int plat_variant_read_stats_batch(plat_ctx* ctx, const plat_infostats_batch* batch, int bad_reads_window,
                                   int count_only_exact_indel_matches, int64_t* out_counts, int32_t* out_per_sample,
                                   int32_t* out_minq, int32_t* out_nminq, void* stream);
+
+/* ---- window read slices out of a resident read table ---------------------------------------------
+ * Replaces the per-window walk over  bamReadBuffer.reads / badReads / brokenMates  between the window
+ * pointers (cwindow.pyx:208-264,655-689) that feeds Haplotype.alignReads: the reads of a whole region are
+ * uploaded ONCE (one table: bases, qualities, offsets, pos, end, mapq, bitFlag) and the read arrays of a
+ * plat_window_batch are gathered from it on the device.  Destination read d is source read src_index[d];
+ * its bases / qualities go to dst_seq|dst_qual[dst_off[d] .. dst_off[d+1]) (dst_off is what the batch then
+ * uses as read_off, computed by the caller from the read lengths), its pos / end / mapq / bitFlag to
+ * dst_*[d].  All pointers are device pointers.                                                       */
+int plat_gather_reads(plat_ctx* ctx, int64_t n_dst, const int32_t* src_index, const int64_t* dst_off,
+                      const uint8_t* src_seq, const uint8_t* src_qual, const int64_t* src_off,
+                      const int32_t* src_pos, const int32_t* src_end, const uint8_t* src_mapq,
+                      const int32_t* src_flags, uint8_t* dst_seq, uint8_t* dst_qual, int32_t* dst_pos,
+                      int32_t* dst_end, uint8_t* dst_mapq, int32_t* dst_flags, void* stream);
 
 /* ---- a14..a18: assembleReadsAndDetectVariants ---------------------------------------------------
  * Replaces  cdef list assembleReadsAndDetectVariants(chrom, assemStart, assemEnd, refStart, refEnd,

@@ -103,6 +103,11 @@ SIGNATURES = {
     "plat_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "plat_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "plat_stream_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "plat_stream_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "plat_stream_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "plat_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "plat_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "plat_gather_reads": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 16),
     "plat_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "plat_profile_last": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
     "plat_dp_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -376,3 +376,48 @@ PLAT_EXPORT int plat_variant_read_stats_batch(plat_ctx* ctx, const plat_infostat
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
+
+
+// ---- window read slices out of a resident read table (plat_gather_reads) --------------------------------------------------
+namespace plat {
+// one wave per destination read: 64 bytes of bases and 64 of qualities per pass, coalesced on both sides
+__global__ void __launch_bounds__(256)
+k_gather_reads(long long n_dst, const int32_t* __restrict__ src_index, const int64_t* __restrict__ dst_off,
+               const uint8_t* __restrict__ src_seq, const uint8_t* __restrict__ src_qual, const int64_t* __restrict__ src_off,
+               const int32_t* __restrict__ src_pos, const int32_t* __restrict__ src_end, const uint8_t* __restrict__ src_mapq,
+               const int32_t* __restrict__ src_flags, uint8_t* __restrict__ dst_seq, uint8_t* __restrict__ dst_qual,
+               int32_t* __restrict__ dst_pos, int32_t* __restrict__ dst_end, uint8_t* __restrict__ dst_mapq, int32_t* __restrict__ dst_flags)
+{
+    const int lane = threadIdx.x & 63;
+    const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long d = (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6); d < n_dst; d += nw) {
+        const int s = src_index[d];
+        const long long so = src_off[s], n = src_off[s + 1] - so, to = dst_off[d];
+        for (long long i = lane; i < n; i += 64) {
+            dst_seq[to + i] = src_seq[so + i];
+            dst_qual[to + i] = src_qual[so + i];
+        }
+        if (lane == 0) { dst_pos[d] = src_pos[s]; dst_end[d] = src_end[s]; dst_mapq[d] = src_mapq[s]; dst_flags[d] = src_flags[s]; }
+    }
+}
+}  // namespace plat
+
+PLAT_EXPORT int plat_gather_reads(plat_ctx* ctx, int64_t n_dst, const int32_t* src_index, const int64_t* dst_off,
+                                  const uint8_t* src_seq, const uint8_t* src_qual, const int64_t* src_off, const int32_t* src_pos,
+                                  const int32_t* src_end, const uint8_t* src_mapq, const int32_t* src_flags, uint8_t* dst_seq,
+                                  uint8_t* dst_qual, int32_t* dst_pos, int32_t* dst_end, uint8_t* dst_mapq, int32_t* dst_flags,
+                                  void* stream)
+{
+    if (!ctx || n_dst < 0) return PLAT_ERR_INVALID;
+    if (n_dst == 0) return PLAT_OK;
+    if (!src_index || !dst_off || !src_seq || !src_qual || !src_off || !src_pos || !src_end || !src_mapq || !src_flags || !dst_seq ||
+        !dst_qual || !dst_pos || !dst_end || !dst_mapq || !dst_flags)
+        return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    const long long nblk = (n_dst + 3) / 4;
+    hipLaunchKernelGGL(plat::k_gather_reads, dim3((unsigned)(nblk < 65535 * 8 ? nblk : 65535 * 8)), dim3(256), 0, (hipStream_t)stream, (long long)n_dst,
+                       src_index, dst_off, src_seq, src_qual, src_off, src_pos, src_end, src_mapq, src_flags, dst_seq, dst_qual, dst_pos,
+                       dst_end, dst_mapq, dst_flags);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}

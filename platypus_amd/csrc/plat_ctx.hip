@@ -137,6 +137,36 @@ PLAT_EXPORT int plat_memset(plat_ctx* ctx, void* dst, int value, size_t bytes, v
     return PLAT_OK;
 }
 
+PLAT_EXPORT int plat_stream_create(plat_ctx* ctx, void** out_stream) {
+    if (!ctx || !out_stream) return PLAT_ERR_INVALID;
+    *out_stream = nullptr;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st;
+    PLAT_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *out_stream = (void*)st;
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_stream_destroy(plat_ctx* ctx, void* stream) {
+    if (!ctx) return PLAT_ERR_INVALID;
+    if (stream) PLAT_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_host_alloc(plat_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return PLAT_ERR_INVALID;
+    *out = nullptr;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    PLAT_HIP(ctx, hipHostMalloc(out, bytes ? bytes : 1));
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_host_free(plat_ctx* ctx, void* p) {
+    if (!ctx) return PLAT_ERR_INVALID;
+    if (p) PLAT_HIP(ctx, hipHostFree(p));
+    return PLAT_OK;
+}
+
 PLAT_EXPORT int plat_stream_sync(plat_ctx* ctx, void* stream) {
     if (!ctx) return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
