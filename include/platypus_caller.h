@@ -1,0 +1,118 @@
+/*
+ * platypus_caller.h -- C ABI of libplat_caller.so: the region loop around the device hot path, native.
+ *
+ * Replaces, for a list of regions whose reads are already in host memory (structure-of-arrays, as a BAM
+ * loader would leave them), the reference's per-region driver
+ *
+ *     PlatypusSingleProcess.run -> callVariantsInRegion        src/cython/variantcaller.pyx:535-615, 935-1012
+ *         generateVariantsInRegion                             src/cython/variantcaller.pyx:412-531
+ *         WindowGenerator.WindowsAndVariants                   src/python/window.py:140-238
+ *         callVariantsInWindow                                 src/cython/variantcaller.pyx:74-141
+ *         outputCallToVCF / VCF.write_data                     src/cython/vcfutils.pyx:338-599, src/python/vcf.py:710-739
+ *
+ * and writes the same VCF record lines.  It is host code (C++, threads) on top of libplat_mi355x.so
+ * (include/platypus_mi355x.h): every O(reads) stage -- candidate scan, window read slices, likelihoods,
+ * genotype likelihoods, HapScore, EM, posteriors, read statistics, per-site genotype calls -- is one device
+ * call per chunk of regions; the host keeps what the reference keeps in Python (merging candidates, indel
+ * left-normalisation, windows, haplotype enumeration, INFO / FILTER arithmetic, text).  Regions are
+ * processed in chunks by worker threads, each with its own plat_ctx and HIP stream, so uploads, kernels and
+ * host work of different chunks overlap.  The Python layer platypus_amd/caller.py does the same job one
+ * window or one batch at a time and is what the parity tests compare this library with.
+ *
+ * Plain C: pointers and sizes, int status (0 = ok, negative = error of platypus_mi355x.h), no exceptions.
+ * All pointers here are HOST pointers.  Not built: reference-call blocks (outputRefCalls), source VCFs,
+ * assembler candidates (assemble=1) -- PLAT_ERR_UNSUPPORTED, use the Python layer for those.
+ */
+#ifndef PLATYPUS_CALLER_H
+#define PLATYPUS_CALLER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One ReadArray (cwindow.pyx:92-236) as arrays: cAlignedRead fields (htslibWrapper.pxd:187-201) of n_reads reads.
+ * seq / qual: byte blobs (7-bit ASCII bases, raw phred), read r at [off[r], off[r+1]); both followed by >= 32
+ * readable bytes.  cigar: (op, length) int16 pairs, read r owns pairs [cig_off[r], cig_off[r+1]). */
+typedef struct plat_read_table {
+    int32_t n_reads, _pad;
+    const uint8_t* seq;
+    const uint8_t* qual;
+    const int64_t* off;        /* [n_reads+1] */
+    const int32_t* pos;        /* cAlignedRead.pos */
+    const int32_t* end;        /* cAlignedRead.end */
+    const uint8_t* mapq;
+    const int32_t* flags;      /* bitFlag */
+    const int32_t* mate_pos;   /* matePos (orders brokenMates) */
+    const int16_t* cigar;
+    const int32_t* cig_off;    /* [n_reads+1], in pairs */
+} plat_read_table;
+
+/* One bamReadBuffer (cwindow.pyx:485-513): reads and badReads sorted by pos, brokenMates sorted by mate_pos
+ * (bamReadBuffer.sortReads / sortBrokenMates, cwindow.pyx:748-766). */
+typedef struct plat_sample_reads {
+    plat_read_table reads, bad_reads, broken_mates;
+} plat_sample_reads;
+
+/* One region of the region list (runner.py:454-474): chrom:start-end, the contig's sequence (upper case; what
+ * FastaFile.getSequence reads from, fastafile.pyx:173-207) and one plat_sample_reads per sample. */
+typedef struct plat_region {
+    const char* chrom;
+    int32_t start, end;
+    const uint8_t* contig_seq;
+    int64_t contig_len;
+    const plat_sample_reads* samples;   /* [n_samples] */
+} plat_region;
+
+/* The callVariants options the region loop reads (names and defaults of runner.py:519-597). */
+typedef struct plat_caller_options {
+    int32_t rlen;                        /* maxReadLength 150; in/out: follows the longest read (variantcaller.pyx:476-488) */
+    int32_t minReads;                    /* 2 */
+    double maxReads;                     /* 5000000 */
+    int32_t maxSize, largeWindows;       /* 1500, 0 */
+    int32_t maxVariants, coverageSamplingLevel, maxHaplotypes, originalMaxHaplotypes, skipDifficultWindows;   /* 8, 30, 50, 50, 0 */
+    int32_t getVariantsFromBAMs, genSNPs, genIndels, mergeClusteredVariants, minFlank;                        /* 1, 1, 1, 1, 10 */
+    int32_t filterVarsByCoverage;        /* 1 */
+    double filteredReadsFrac;            /* 0.7 */
+    int32_t maxVarDist, minVarDist;      /* 15, 9 */
+    int32_t useEMLikelihoods, countOnlyExactIndelMatches, calculateFlankScore;                                /* 0, 0, 0 */
+    int32_t assemble, outputRefCalls;    /* 0, 0: anything else is PLAT_ERR_UNSUPPORTED here */
+    int32_t minMapQual, minBaseQual;     /* 20, 20 */
+    int32_t minPosterior;                /* 5 */
+    double sbThreshold, scThreshold, abThreshold, minVarFreq;                                                 /* 1e-3, 0.95, 1e-3, 0.05 */
+    int32_t badReadsWindow, badReadsThreshold, rmsmqThreshold, qdThreshold, hapScoreThreshold;                /* 11, 15, 40, 10, 4 */
+    int32_t _pad;
+} plat_caller_options;
+
+typedef struct plat_caller_stats {
+    int64_t n_regions, n_reads, n_candidate_records, n_variants, n_windows, n_windows_called, n_records;
+    int64_t n_windows_greedy;            /* windows whose haplotypes came from the greedy filter (variantFilter.pyx:440-506) */
+    int64_t n_windows_failed;            /* windows skipped after an error, as the reference's try/except does (:568-615) */
+    double seconds_total;                /* wall time of the call */
+    double seconds_host;                 /* sum over worker threads of time spent in host stages */
+    double seconds_device_wait;          /* sum over worker threads of time spent waiting for the device */
+} plat_caller_stats;
+
+typedef struct plat_caller plat_caller;
+
+void plat_caller_default_options(plat_caller_options* out);
+/* n_workers worker threads (each owns a plat_ctx + stream on `device`); regions_per_chunk regions go through the device
+ * stages together (0 = default). */
+int plat_caller_create(int device, int n_workers, int regions_per_chunk, plat_caller** out);
+int plat_caller_destroy(plat_caller* c);
+/* Calls every region; the record lines of all regions, in region order, are returned as one malloc'ed,
+ * NUL-terminated buffer (*out_text, *out_len without the NUL; free with plat_caller_free).  options->rlen is
+ * left at the last region's value, as after the reference's last callVariantsInRegion. */
+int plat_call_regions(plat_caller* c, const plat_region* regions, int n_regions, int n_samples,
+                      const char* const* sample_names, plat_caller_options* options, char** out_text,
+                      size_t* out_len, plat_caller_stats* stats /* may be NULL */);
+void plat_caller_free(void* p);
+/* Human-readable message of the last error of a failing plat_call_regions on this caller. */
+const char* plat_caller_last_error(const plat_caller* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLATYPUS_CALLER_H */

@@ -65,14 +65,30 @@ def call_variants_config4(opts, n_regions):
     opts.originalMaxHaplotypes = opts.maxHaplotypes
     size = min(int(opts.bufferSize), 100000)
     mine = sharding.regions_for_rank(n_regions, rank, world)
-    regs = [synth.config4_region(i, region_len=size, n_samples=1, read_len=int(opts.rlen)) for i in mine]
-    fasta = H.FastaFile({r["chrom"]: r["ref"] for r in regs})
-    work = [(r["chrom"], r["start"], r["end"],
-             [H.bamReadBuffer([H.AlignedRead(x["seq"], x["qual"], x["pos"], x["mapq"], x["flag"], end=x["end"], cigarOps=x["cigar"])
-                               for x in r["samples"][0]], sample="S1")]) for r in regs]
     t0 = time.time()
     text = io.StringIO()
-    n_windows = caller.callVariantsInRegions(work, fasta, opts, VCF(["S1"]), text) if work else 0
+    if os.environ.get("PLAT_PYTHON_CALLER") == "1" or opts.assemble or not opts.getVariantsFromBAMs:
+        # the Python region loop (platypus_amd.caller): window lists, haplotypes and records as Python objects
+        regs = [synth.config4_region(i, region_len=size, n_samples=1, read_len=int(opts.rlen)) for i in mine]
+        fasta = H.FastaFile({r["chrom"]: r["ref"] for r in regs})
+        work = [(r["chrom"], r["start"], r["end"],
+                 [H.bamReadBuffer([H.AlignedRead(x["seq"], x["qual"], x["pos"], x["mapq"], x["flag"], end=x["end"], cigarOps=x["cigar"])
+                                   for x in r["samples"][0]], sample="S1")]) for r in regs]
+        t0 = time.time()
+        n_windows = caller.callVariantsInRegions(work, fasta, opts, VCF(["S1"]), text) if work else 0
+    else:
+        # the native region loop (libplat_caller.so): reads as arrays, host threads, every device stage batched per chunk
+        from . import fastcaller as F
+        regs = [synth.config4_region_arrays(i, region_len=size, n_samples=1, read_len=int(opts.rlen)) for i in mine]
+        rr = [F.region_from_arrays(r) for r in regs]
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        import torch
+        nc = F.NativeCaller(local % max(1, torch.cuda.device_count()), int(os.environ.get("PLAT_CALLER_WORKERS", "4")),
+                            int(os.environ.get("PLAT_CALLER_CHUNK", "2")))
+        t0 = time.time()
+        text.write(nc.call_regions(rr, ["S1"], opts) if rr else "")
+        n_windows = nc.stats["n_windows"] if rr else 0
+        nc.close()
     recs = sorted(sharding.records_from_vcf_text(text.getvalue()), key=lambda r: (sharding.chrom_key(r[0]), r[1]))
     device = None
     if dist is not None and dist.get_backend() == "nccl":

@@ -162,14 +162,18 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = C.CDLL(LIB_PATH)
+    _lib = bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def bind(lib):
+    """Attach the prototypes of include/platypus_mi355x.h to a loaded library exporting that ABI."""
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here == the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
     if lib.plat_abi_version() != PLAT_ABI_VERSION:
         raise RuntimeError("libplat_mi355x.so ABI version mismatch")
-    _lib = lib
     return lib
 
 

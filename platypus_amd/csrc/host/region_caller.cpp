@@ -1,0 +1,1327 @@
+// region_caller.cpp -- libplat_caller.so: the region loop around the device hot path (include/platypus_caller.h).
+//
+//   generateVariantsInRegion      src/cython/variantcaller.pyx:412-531   (BAM candidates; assembler / source VCFs not built here)
+//   callVariantsInRegion          src/cython/variantcaller.pyx:535-615
+//   callVariantsInWindow          src/cython/variantcaller.pyx:74-141
+//   ReadArray window pointers     src/cython/cwindow.pyx:176-264
+//   Haplotype construction        src/cython/chaplotype.pyx:127-191,397-449
+//   getFilteredHaplotypes, computeBestScoreForGenotype   src/cython/variantFilter.pyx:237-283,377-506
+//   mergeHaplotypes               src/cython/variantcaller.pyx:325-383
+//   Population.setup / call, vcfINFO, vcfFILTER, outputCallToVCF   (device stages + records.hpp)
+//
+// Host code only: every O(reads) stage is a call into libplat_mi355x.so (include/platypus_mi355x.h) on device pointers.
+// Regions are processed in chunks; a chunk goes through
+//   A  upload of its reads (one table) + candidate scan            plat_candidates_batch
+//   B  host: merge / normalise / filter candidates, windows, window pointers, haplotypes (greedy rounds: plat_align_window_batch)
+//   C  window read slices gathered on the device, likelihoods, genotype likelihoods, HapScore, EM
+//      plat_gather_reads, plat_align_window_batch_async, plat_genotype_window_batch, plat_haplotype_score_batch, plat_em_window_batch
+//   D  host: priors, variant masks -> posteriors (plat_variant_posterior_batch) -> INFO variants, call sites
+//   E  read statistics + per-site genotype calls                   plat_variant_read_stats_batch, plat_genotype_call_batch
+//   F  host: INFO / FILTER arithmetic, record text
+// on one worker thread with its own plat_ctx and stream; several workers run side by side, so the uploads, kernels and host
+// stages of different chunks overlap.  Same text as platypus_amd/caller.py::callVariantsInRegions (tests/test_native_caller_*.py).
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
+
+#include "../../../include/platypus_caller.h"
+#include "../../../include/platypus_mi355x.h"
+#include "records.hpp"
+#include "variants.hpp"
+
+#define CALLER_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace plathost {
+
+typedef std::chrono::steady_clock Clock;
+static inline double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+
+struct DeviceError : std::runtime_error {
+    int code;
+    DeviceError(int c, const std::string& where) : std::runtime_error(where + ": device error " + std::to_string(c) + " (" + plat_strerror(c) + ")"), code(c) {}
+};
+static inline void ck(int rc, const char* where) { if (rc != PLAT_OK) throw DeviceError(rc, where); }
+
+// ---- grow-only buffers: pinned host + device mirror -----------------------------------------------------------------------------
+struct Slot;                                                              // one worker's device context
+template <class T> struct Staged {
+    T* h = nullptr; T* d = nullptr; size_t hcap = 0, dcap = 0, n = 0;
+    void reserve(plat_ctx* ctx, size_t want, bool host = true, bool dev = true) {
+        if (host && want > hcap) {
+            const size_t ncap = want + want / 2 + 64;
+            T* nh = nullptr;
+            ck(plat_host_alloc(ctx, ncap * sizeof(T), (void**)&nh), "plat_host_alloc");
+            if (h) { if (n) memcpy(nh, h, std::min(n, hcap) * sizeof(T)); plat_host_free(ctx, h); }
+            h = nh; hcap = ncap;
+        }
+        if (dev && want > dcap) {
+            const size_t ncap = want + want / 2 + 64;
+            T* nd = nullptr;
+            ck(plat_malloc(ctx, ncap * sizeof(T) + PLAT_BLOB_PAD, (void**)&nd), "plat_malloc");
+            if (d) plat_free(ctx, d);                                      // (contents are rewritten by whoever grows a buffer)
+            d = nd; dcap = ncap;
+        }
+    }
+    void release(plat_ctx* ctx) { if (h) plat_host_free(ctx, h); if (d) plat_free(ctx, d); h = nullptr; d = nullptr; hcap = dcap = n = 0; }
+};
+
+struct Slot {
+    plat_ctx* ctx = nullptr;
+    void* stream = nullptr;
+    // chunk read table (device): bases, qualities, offsets, per-read fields, CIGARs
+    Staged<uint8_t> t_seq, t_qual, t_mapq;
+    Staged<int64_t> t_off;
+    Staged<int32_t> t_pos, t_end, t_flags, t_cigoff, t_region;
+    Staged<int16_t> t_cigar;
+    // candidate scan
+    Staged<uint8_t> c_ref;
+    Staged<int64_t> c_refoff;
+    Staged<int32_t> c_rss, c_clen, c_rec, c_cnt, c_status;
+    // window batch
+    Staged<int32_t> w_hapbegin, w_readbegin, w_start, w_end, w_flank, w_segbegin, w_ngood, w_src, g_pos, g_end, g_flags, o_calls, o_iters, o_hapscore, o_score;
+    Staged<int64_t> w_pairoff, w_hapoff, w_readoff, w_gloff;
+    Staged<uint8_t> w_hapseq, w_kind, g_seq, g_qual, g_mapq;
+    Staged<double> o_loglik, o_gl, o_logl, o_gof, o_freq, o_em;
+    // posteriors / stats / calls
+    Staged<int32_t> p_win, s_vw, s_pos, s_min, s_max, s_nadd, s_nrem, s_gb, s_ge, s_bb, s_be, s_ps, s_minq, s_nminq, k_win, k_nvar, k_vih, k_ref, k_ph;
+    Staged<int64_t> p_off, s_aoff, s_moff, s_counts, k_vo, k_ro, k_lo;
+    Staged<uint8_t> p_mask, s_added, s_vig;
+    Staged<double> p_prior, p_post, k_lik, k_out4;
+    double t_host = 0, t_wait = 0;
+
+    void sync(const char* where) {
+        const auto t0 = Clock::now();
+        const int rc = plat_stream_sync(ctx, stream);
+        t_wait += secs(t0, Clock::now());
+        ck(rc, where);
+    }
+    template <class T> void up(Staged<T>& s, size_t n) { if (n) ck(plat_memcpy_h2d(ctx, s.d, s.h, n * sizeof(T), stream), "plat_memcpy_h2d"); }
+    template <class T> void down(Staged<T>& s, size_t n) { if (n) ck(plat_memcpy_d2h(ctx, s.h, s.d, n * sizeof(T), stream), "plat_memcpy_d2h"); }
+};
+
+// ---- a read table of the caller as the region loop sees it (ReadArray, cwindow.pyx:92-236) --------------------------------------
+struct TableView {
+    const plat_read_table* t = nullptr;
+    int64_t base = 0;                                                     // index of its first read in the chunk's device table
+    int longest = 0;                                                      // getLengthOfLongestRead (:167-172)
+    int n() const { return t->n_reads; }
+    static int lowerBound(const int32_t* a, int n, int64_t key) { return (int)(std::lower_bound(a, a + n, key, [](int32_t x, int64_t k) { return (int64_t)x < k; }) - a); }
+    // shared body of countReadsCoveringRegion (:176-206) and setWindowPointers (:208-234)
+    void overlapRange(int start, int end, int& s, int& e) const {
+        const int N = n();
+        if (N == 0) { s = e = 0; return; }
+        s = lowerBound(t->pos, N, std::max<int64_t>(1, (int64_t)start - longest));
+        e = lowerBound(t->pos, N, end);
+        while (s < N && t->end[s] <= start) ++s;
+        if (s > e) throw WindowError("This should never happen. Read start pointer > read end pointer!!");
+        e = std::min(e, N);
+    }
+    void matePosRange(int start, int end, int& s, int& e) const {         // setWindowPointersBasedOnMatePos (:236-264)
+        const int N = n();
+        if (N == 0) { s = e = 0; return; }
+        s = lowerBound(t->mate_pos, N, std::max<int64_t>(1, (int64_t)start - longest));
+        e = lowerBound(t->mate_pos, N, end);
+        if (s > e) throw WindowError("This should never happen. Read start pointer > read end pointer!!");
+        e = std::min(e, N);
+    }
+    int rlen(int i) const { return (int)(t->off[i + 1] - t->off[i]); }
+};
+struct SampleView { TableView reads, bad, broken; };
+
+static int longestRead(const plat_read_table& t) {
+    int m = 0;
+    for (int i = 0; i < t.n_reads; ++i) m = std::max(m, t.end[i] - t.pos[i]);
+    return m;
+}
+
+// ---- haplotypes ---------------------------------------------------------------------------------------------------------------
+struct Hap {
+    VarList variants;
+    std::string seq;
+};
+
+// chaplotype.pyx:127-191 + getMutatedSequence :397-449.  startPos / endPos already clamped as the constructor does.
+static std::string haplotypeSequence(const Fasta& fa, int startPos, int endPos, int endBuf, const VarList& variants) {
+    if (variants.empty()) return fa.getSequence((int64_t)startPos - endBuf, (int64_t)endPos + endBuf);
+    std::string out = fa.getSequence((int64_t)startPos - endBuf, startPos);
+    int cur = startPos;
+    const Variant* first = variants[0];
+    if (first->refPos != cur) { out += fa.getSequence(cur, first->refPos); cur = first->refPos; }
+    for (const Variant* v : variants) {
+        if (v->refPos > cur) { out += fa.getSequence(cur, v->refPos); cur = v->refPos; }
+        if (v->nAdded == v->nRemoved) { out += v->added; cur += v->nRemoved; }
+        else {
+            if (v->added.empty() || v->removed.empty()) {
+                if (v->refPos == cur) { out += fa.getCharacter(v->refPos); cur += 1; }
+            }
+            cur += v->nRemoved;
+            out += v->added;
+        }
+    }
+    if (cur < endPos) out += fa.getSequence(cur, endPos);
+    out += fa.getSequence(endPos, (int64_t)endPos + endBuf);
+    return out;
+}
+
+// Python tuple comparison of (score, variants) as the heap of getFilteredHaplotypes orders them
+struct ScoredHap { double score; VarList vs; };
+static bool scoredLess(const ScoredHap& a, const ScoredHap& b) {
+    if (a.score != b.score) return a.score < b.score;
+    const size_t n = std::min(a.vs.size(), b.vs.size());
+    for (size_t i = 0; i < n; ++i) {
+        if (a.vs[i] == b.vs[i] || a.vs[i]->same(*b.vs[i])) continue;
+        return variantLess(a.vs[i], b.vs[i]);
+    }
+    return a.vs.size() < b.vs.size();
+}
+// heapq (CPython): _siftdown / _siftup / heappush / heappushpop
+static void heapSiftDown(std::vector<ScoredHap>& h, size_t startpos, size_t pos) {
+    ScoredHap item = h[pos];
+    while (pos > startpos) {
+        const size_t parentpos = (pos - 1) >> 1;
+        if (scoredLess(item, h[parentpos])) { h[pos] = h[parentpos]; pos = parentpos; continue; }
+        break;
+    }
+    h[pos] = item;
+}
+static void heapSiftUp(std::vector<ScoredHap>& h, size_t pos) {
+    const size_t endpos = h.size(), startpos = pos;
+    ScoredHap item = h[pos];
+    size_t childpos = 2 * pos + 1;
+    while (childpos < endpos) {
+        const size_t rightpos = childpos + 1;
+        if (rightpos < endpos && !scoredLess(h[childpos], h[rightpos])) childpos = rightpos;
+        h[pos] = h[childpos];
+        pos = childpos;
+        childpos = 2 * pos + 1;
+    }
+    h[pos] = item;
+    heapSiftDown(h, startpos, pos);
+}
+static void heapPush(std::vector<ScoredHap>& h, const ScoredHap& item) { h.push_back(item); heapSiftDown(h, 0, h.size() - 1); }
+static void heapPushPop(std::vector<ScoredHap>& h, ScoredHap item) {
+    if (!h.empty() && scoredLess(h[0], item)) { std::swap(item, h[0]); heapSiftUp(h, 0); }
+}
+
+// ---- per-window and per-region working state ---------------------------------------------------------------------------------------
+struct Ptrs { int gs, ge, bs, be, ks, ke; };                               // window pointers of one sample: reads, badReads, brokenMates
+
+struct WindowWork {
+    int region = 0, startPos = 0, endPos = 0;
+    VarList vars;                                                          // window["variants"] (after filterVariantsByCoverage)
+    VarList allVars;                                                       // the unfiltered list callVariantsInWindow keeps as `variants`
+    std::vector<Ptrs> ptrs;
+    int nReads = 0;
+    int hapStart = 0, hapEnd = 0, endBuf = 0;                              // Haplotype.startPos / endPos / endBufferSize
+    std::string refSeq;                                                    // reference haplotype
+    std::vector<Hap> haps;                                                 // merged, sorted (Population.haplotypes)
+    bool live = false;                                                     // goes to the device
+    // greedy filter state
+    bool greedy = false;
+    VarList byCoverage;
+    size_t step = 0;
+    std::vector<ScoredHap> heap;
+    std::vector<VarList> cands;
+    std::vector<int> sampledSeg;                                           // per sample: [begin, end) into `sampled`
+    std::vector<std::pair<int, int>> sampled;                              // (sample, local index in reads table)
+    // results
+    int bw = -1;                                                           // window index in the device batch
+    std::vector<Variant*> distinct;                                        // _distinctVariants
+    std::vector<double> posterior;                                         // aligned with distinct
+    VarList called;                                                        // variantPosteriors keys, in insertion order
+    std::vector<double> calledPost;
+    std::vector<std::pair<int, VarList>> byPos;                            // varsByPos, insertion order
+    std::vector<VarInfo> info;                                             // vcfInfo in getHaplotypeInfo order
+    int firstStatVar = 0, firstSite = 0;
+};
+
+struct VariantPool {
+    std::deque<Variant> store;
+    Variant* make(int pos, const std::string& rem, const std::string& add, int nSupp, int source) {
+        store.emplace_back(pos, rem, add, nSupp, source);
+        return &store.back();
+    }
+};
+
+struct RegionWork {
+    const plat_region* in = nullptr;
+    int index = 0;
+    Fasta fa;
+    int rlen = 0;
+    std::vector<SampleView> samples;
+    VariantPool pool;
+    VarList variants;
+    std::vector<WindowWork> windows;
+    std::string text;
+    int64_t nRecords = 0, nCandRecords = 0;
+};
+
+struct Options : plat_caller_options {};
+
+static void logWindowFailure(const char* chrom, int s, int e, const char* what) {
+    fprintf(stderr, "platypus caller: problem calling variants in window %s:%d-%d, skipping it: %s\n", chrom, s, e, what);
+}
+
+// ---- the device window batch ---------------------------------------------------------------------------------------------------------
+struct BatchBuilder {
+    int nInd = 0;
+    std::vector<int32_t> hapbegin{0}, readbegin{0}, start, end, flank, segbegin{0}, ngood, src;
+    std::vector<int64_t> pairoff{0}, hapoff{0}, readoff{0}, gloff{0};
+    std::vector<uint8_t> kind;
+    std::string hapseq;
+    int maxHap = 0, maxRead = 0, maxR = 0, maxH = 0;
+    void beginWindow(int s, int e, int fl) { start.push_back(s); end.push_back(e); flank.push_back(fl); }
+    void addHap(const std::string& seq) {
+        hapseq += seq;
+        hapoff.push_back((int64_t)hapseq.size());
+        maxHap = std::max(maxHap, (int)seq.size());
+    }
+    void addRead(const TableView& tv, int i, int k) {
+        src.push_back((int32_t)(tv.base + i));
+        kind.push_back((uint8_t)k);
+        const int L = tv.rlen(i);
+        readoff.push_back(readoff.back() + L);
+        maxRead = std::max(maxRead, L);
+    }
+    void endSegment(int nGood) { segbegin.push_back((int32_t)src.size()); ngood.push_back(nGood); }
+    void endWindow() {
+        const int H = (int)hapoff.size() - 1 - hapbegin.back(), R = (int)src.size() - readbegin.back();
+        hapbegin.push_back((int32_t)hapoff.size() - 1);
+        readbegin.push_back((int32_t)src.size());
+        pairoff.push_back(pairoff.back() + (int64_t)H * R);
+        gloff.push_back(gloff.back() + (int64_t)(H * (H + 1) / 2) * nInd);
+        maxR = std::max(maxR, R); maxH = std::max(maxH, H);
+    }
+    int nWindows() const { return (int)start.size(); }
+    int nHaps() const { return (int)hapoff.size() - 1; }
+    int nReads() const { return (int)src.size(); }
+};
+
+template <class T, class V> static void fill(Slot& s, Staged<T>& st, const V& v, bool dev = true) {
+    st.reserve(s.ctx, v.size() + 1, true, dev);
+    for (size_t i = 0; i < v.size(); ++i) st.h[i] = (T)v[i];
+    st.n = v.size();
+}
+
+struct DeviceBatch {                                                       // what stays valid on the device after runWindows
+    plat_window_batch wb;
+    int nWindows = 0, nHaps = 0, nReads = 0, nInd = 0, maxH = 0;
+    int64_t nPairs = 0, nGl = 0;
+};
+
+// Upload a BatchBuilder, gather its reads from the chunk table and run Haplotype.alignReads for all of it; full = also
+// Population.setup, HapScore and EM.  Results are copied to the pinned host mirrors; waits for them.
+static DeviceBatch runWindows(Slot& s, const BatchBuilder& b, const Options& o, bool full, bool wantLoglik) {
+    DeviceBatch db;
+    db.nWindows = b.nWindows(); db.nHaps = b.nHaps(); db.nReads = b.nReads(); db.nInd = b.nInd; db.maxH = b.maxH;
+    db.nPairs = b.pairoff.back(); db.nGl = b.gloff.back();
+    if (db.nWindows == 0) return db;
+    fill(s, s.w_hapbegin, b.hapbegin); fill(s, s.w_readbegin, b.readbegin); fill(s, s.w_start, b.start); fill(s, s.w_end, b.end);
+    fill(s, s.w_flank, b.flank); fill(s, s.w_pairoff, b.pairoff); fill(s, s.w_hapoff, b.hapoff); fill(s, s.w_readoff, b.readoff);
+    fill(s, s.w_gloff, b.gloff); fill(s, s.w_segbegin, b.segbegin); fill(s, s.w_ngood, b.ngood); fill(s, s.w_src, b.src); fill(s, s.w_kind, b.kind);
+    s.w_hapseq.reserve(s.ctx, b.hapseq.size() + PLAT_BLOB_PAD);
+    memcpy(s.w_hapseq.h, b.hapseq.data(), b.hapseq.size());
+    memset(s.w_hapseq.h + b.hapseq.size(), 0, PLAT_BLOB_PAD);
+    s.up(s.w_hapbegin, b.hapbegin.size()); s.up(s.w_readbegin, b.readbegin.size()); s.up(s.w_start, b.start.size()); s.up(s.w_end, b.end.size());
+    s.up(s.w_flank, b.flank.size()); s.up(s.w_pairoff, b.pairoff.size()); s.up(s.w_hapoff, b.hapoff.size()); s.up(s.w_readoff, b.readoff.size());
+    s.up(s.w_gloff, b.gloff.size()); s.up(s.w_segbegin, b.segbegin.size()); s.up(s.w_ngood, b.ngood.size()); s.up(s.w_src, b.src.size());
+    s.up(s.w_kind, b.kind.size()); s.up(s.w_hapseq, b.hapseq.size() + PLAT_BLOB_PAD);
+    const size_t blob = (size_t)b.readoff.back();
+    s.g_seq.reserve(s.ctx, blob + PLAT_BLOB_PAD, false); s.g_qual.reserve(s.ctx, blob + PLAT_BLOB_PAD, false);
+    const size_t nR = (size_t)db.nReads;
+    s.g_pos.reserve(s.ctx, nR + 1, false); s.g_end.reserve(s.ctx, nR + 1, false); s.g_flags.reserve(s.ctx, nR + 1, false); s.g_mapq.reserve(s.ctx, nR + 1, false);
+    ck(plat_memset(s.ctx, s.g_seq.d + blob, 0, PLAT_BLOB_PAD, s.stream), "plat_memset");
+    ck(plat_memset(s.ctx, s.g_qual.d + blob, 0, PLAT_BLOB_PAD, s.stream), "plat_memset");
+    ck(plat_gather_reads(s.ctx, (int64_t)nR, s.w_src.d, s.w_readoff.d, s.t_seq.d, s.t_qual.d, s.t_off.d, s.t_pos.d, s.t_end.d, s.t_mapq.d,
+                         s.t_flags.d, s.g_seq.d, s.g_qual.d, s.g_pos.d, s.g_end.d, s.g_mapq.d, s.g_flags.d, s.stream), "plat_gather_reads");
+    plat_window_batch& wb = db.wb;
+    memset(&wb, 0, sizeof wb);
+    wb.n_windows = db.nWindows; wb.n_haps = db.nHaps; wb.n_reads = db.nReads;
+    wb.win_hap_begin = s.w_hapbegin.d; wb.win_read_begin = s.w_readbegin.d; wb.win_start = s.w_start.d; wb.win_end = s.w_end.d;
+    wb.win_flank = s.w_flank.d; wb.pair_off = s.w_pairoff.d; wb.hap_seq = s.w_hapseq.d; wb.hap_off = s.w_hapoff.d;
+    wb.read_seq = s.g_seq.d; wb.read_qual = s.g_qual.d; wb.read_off = s.w_readoff.d; wb.read_pos = s.g_pos.d; wb.read_end = s.g_end.d;
+    wb.read_mapq = s.g_mapq.d; wb.read_flags = s.g_flags.d; wb.read_kind = s.w_kind.d;
+    s.o_loglik.reserve(s.ctx, (size_t)db.nPairs + 1, wantLoglik);
+    plat_batch_hints h;
+    memset(&h, 0, sizeof h);
+    h.max_hap_len = b.maxHap; h.max_read_len = b.maxRead; h.max_reads_per_window = b.maxR;
+    h.n_pairs = db.nPairs; h.hap_blob_len = (int64_t)b.hapseq.size(); h.read_blob_len = (int64_t)blob; h.extra_jobs_cap = 0;
+    ck(plat_align_window_batch_async(s.ctx, &wb, &h, o.calculateFlankScore ? 1 : 0, 0, s.o_loglik.d, nullptr, s.stream), "plat_align_window_batch_async");
+    if (wantLoglik) s.down(s.o_loglik, (size_t)db.nPairs);
+    if (full) {
+        const size_t nG = (size_t)db.nGl + 1;
+        s.o_gl.reserve(s.ctx, nG, false); s.o_logl.reserve(s.ctx, nG, false); s.o_gof.reserve(s.ctx, nG, false); s.o_em.reserve(s.ctx, nG, false);
+        s.o_freq.reserve(s.ctx, (size_t)db.nHaps + 1); s.o_calls.reserve(s.ctx, (size_t)db.nWindows * db.nInd + 1);
+        s.o_iters.reserve(s.ctx, (size_t)db.nWindows + 1, false); s.o_hapscore.reserve(s.ctx, (size_t)db.nWindows + 1);
+        ck(plat_genotype_window_batch(s.ctx, &wb, db.nInd, s.w_segbegin.d, s.w_ngood.d, s.o_loglik.d, s.w_gloff.d, s.o_gl.d, s.o_logl.d, s.o_gof.d,
+                                      s.stream), "plat_genotype_window_batch");
+        ck(plat_haplotype_score_batch(s.ctx, &wb, db.nInd, db.maxH, s.w_segbegin.d, s.w_ngood.d, s.o_loglik.d, nullptr, s.o_hapscore.d, s.stream),
+           "plat_haplotype_score_batch");
+        ck(plat_em_window_batch(s.ctx, db.nWindows, db.nInd, db.maxH, s.w_hapbegin.d, s.w_gloff.d, s.w_ngood.d, s.o_gl.d, 100, o.useEMLikelihoods,
+                                s.o_freq.d, s.o_em.d, s.o_calls.d, s.o_iters.d, s.stream), "plat_em_window_batch");
+        s.down(s.o_freq, (size_t)db.nHaps); s.down(s.o_calls, (size_t)db.nWindows * db.nInd); s.down(s.o_hapscore, (size_t)db.nWindows);
+    }
+    s.sync("window batch");
+    return db;
+}
+
+// ---- the chunk pipeline ----------------------------------------------------------------------------------------------------------------
+struct Chunk {
+    Slot& s;
+    const Options& o;
+    int nInd;
+    const char* const* names;
+    std::vector<RegionWork*> regions;
+    plat_caller_stats& st;
+    std::mutex& stMutex;
+
+    // -- A: one device table for every read of the chunk; layout: all `reads` of every (region, sample), then all badReads, then all brokenMates
+    void uploadReads() {
+        size_t nReads[3] = {0, 0, 0}, nBytes[3] = {0, 0, 0}, nCig[3] = {0, 0, 0};
+        for (RegionWork* r : regions)
+            for (SampleView& sv : r->samples) {
+                TableView* tv[3] = {&sv.reads, &sv.bad, &sv.broken};
+                for (int k = 0; k < 3; ++k) {
+                    nReads[k] += (size_t)tv[k]->n();
+                    nBytes[k] += (size_t)tv[k]->t->off[tv[k]->n()];
+                    nCig[k] += (size_t)tv[k]->t->cig_off[tv[k]->n()];
+                }
+            }
+        const size_t N = nReads[0] + nReads[1] + nReads[2], B = nBytes[0] + nBytes[1] + nBytes[2], Cg = nCig[0] + nCig[1] + nCig[2];
+        if (N > 0x7FFFFFF0ull) throw DeviceError(PLAT_ERR_OVERFLOW, "chunk read table");
+        Slot& z = s;
+        z.t_seq.reserve(z.ctx, B + PLAT_BLOB_PAD, false); z.t_qual.reserve(z.ctx, B + PLAT_BLOB_PAD, false);
+        z.t_off.reserve(z.ctx, N + 1); z.t_pos.reserve(z.ctx, N + 1); z.t_end.reserve(z.ctx, N + 1); z.t_flags.reserve(z.ctx, N + 1);
+        z.t_mapq.reserve(z.ctx, N + 1); z.t_cigoff.reserve(z.ctx, N + 1); z.t_cigar.reserve(z.ctx, 2 * Cg + 2); z.t_region.reserve(z.ctx, nReads[0] + 1);
+        size_t ri = 0, bo = 0, co = 0;
+        int scan = 0;
+        for (int k = 0; k < 3; ++k) {
+            scan = 0;
+            for (RegionWork* r : regions)
+                for (SampleView& sv : r->samples) {
+                    TableView& tv = k == 0 ? sv.reads : (k == 1 ? sv.bad : sv.broken);
+                    const plat_read_table& t = *tv.t;
+                    const int n = t.n_reads;
+                    tv.base = (int64_t)ri;
+                    const size_t nb = (size_t)t.off[n], nc = (size_t)t.cig_off[n];
+                    if (nb) {                                              // bases and qualities go straight from the caller's memory
+                        ck(plat_memcpy_h2d(z.ctx, z.t_seq.d + bo, t.seq, nb, z.stream), "plat_memcpy_h2d(seq)");
+                        ck(plat_memcpy_h2d(z.ctx, z.t_qual.d + bo, t.qual, nb, z.stream), "plat_memcpy_h2d(qual)");
+                    }
+                    for (int i = 0; i < n; ++i) {
+                        z.t_off.h[ri + i] = (int64_t)bo + t.off[i];
+                        z.t_cigoff.h[ri + i] = (int32_t)(co + (size_t)t.cig_off[i]);
+                    }
+                    if (n) {
+                        memcpy(z.t_pos.h + ri, t.pos, sizeof(int32_t) * (size_t)n); memcpy(z.t_end.h + ri, t.end, sizeof(int32_t) * (size_t)n);
+                        memcpy(z.t_flags.h + ri, t.flags, sizeof(int32_t) * (size_t)n); memcpy(z.t_mapq.h + ri, t.mapq, (size_t)n);
+                        if (nc) memcpy(z.t_cigar.h + 2 * co, t.cigar, sizeof(int16_t) * 2 * nc);
+                        if (k == 0) for (int i = 0; i < n; ++i) z.t_region.h[ri + i] = scan;
+                    }
+                    ri += (size_t)n; bo += nb; co += nc;
+                    ++scan;
+                }
+        }
+        z.t_off.h[N] = (int64_t)B; z.t_cigoff.h[N] = (int32_t)Cg;
+        z.t_cigar.h[2 * Cg] = 0; z.t_cigar.h[2 * Cg + 1] = 0;
+        ck(plat_memset(z.ctx, z.t_seq.d + B, 0, PLAT_BLOB_PAD, z.stream), "plat_memset");
+        ck(plat_memset(z.ctx, z.t_qual.d + B, 0, PLAT_BLOB_PAD, z.stream), "plat_memset");
+        z.up(z.t_off, N + 1); z.up(z.t_pos, N); z.up(z.t_end, N); z.up(z.t_flags, N); z.up(z.t_mapq, N); z.up(z.t_cigoff, N + 1); z.up(z.t_cigar, 2 * Cg + 2);
+        z.up(z.t_region, nReads[0]);
+        nGood = nReads[0]; nScan = scan;
+        std::lock_guard<std::mutex> g(stMutex);
+        st.n_reads += (int64_t)N;
+    }
+    size_t nGood = 0;
+    int nScan = 0;
+    int maxPerRead = 8;
+
+    // -- A2: VariantCandidateGenerator.addCandidatesFromReads over the `reads` of every (region, sample) (variant.pyx:459-751)
+    void scanCandidates() {
+        Slot& z = s;
+        std::vector<int64_t> refoff{0};
+        std::vector<int32_t> rss, clen;
+        std::string blob;
+        for (RegionWork* r : regions)
+            for (size_t i = 0; i < r->samples.size(); ++i) {
+                const int64_t a = std::max<int64_t>(0, (int64_t)r->in->start - 2000);                   // variant.pyx:486-488
+                const int64_t e = std::min<int64_t>((int64_t)r->in->end + 2000, r->fa.len - 1);
+                blob += r->fa.getSequence(a, e);
+                refoff.push_back((int64_t)blob.size());
+                rss.push_back((int32_t)a); clen.push_back((int32_t)r->fa.len);
+            }
+        z.c_ref.reserve(z.ctx, blob.size() + PLAT_BLOB_PAD);
+        memcpy(z.c_ref.h, blob.data(), blob.size()); memset(z.c_ref.h + blob.size(), 0, PLAT_BLOB_PAD);
+        fill(z, z.c_refoff, refoff); fill(z, z.c_rss, rss); fill(z, z.c_clen, clen);
+        z.up(z.c_ref, blob.size() + PLAT_BLOB_PAD); z.up(z.c_refoff, refoff.size()); z.up(z.c_rss, rss.size()); z.up(z.c_clen, clen.size());
+        refBlob.swap(blob);
+        if (nGood == 0) return;
+        plat_candidate_batch cb;
+        memset(&cb, 0, sizeof cb);
+        cb.n_regions = nScan; cb.n_reads = (int32_t)nGood;
+        cb.ref_seq = z.c_ref.d; cb.ref_off = z.c_refoff.d; cb.ref_seq_start = z.c_rss.d; cb.contig_len = z.c_clen.d;
+        cb.read_seq = z.t_seq.d; cb.read_qual = z.t_qual.d; cb.read_off = z.t_off.d; cb.read_pos = z.t_pos.d; cb.read_flags = z.t_flags.d;
+        cb.cigar = z.t_cigar.d; cb.cig_off = z.t_cigoff.d;
+        for (;;) {
+            z.c_rec.reserve(z.ctx, nGood * (size_t)maxPerRead * 5 + 8); z.c_cnt.reserve(z.ctx, nGood + 1); z.c_status.reserve(z.ctx, nGood + 1);
+            ck(plat_candidates_batch(z.ctx, &cb, o.minFlank, o.minBaseQual, o.genSNPs, o.genIndels, maxPerRead, z.t_region.d, z.c_rec.d, z.c_cnt.d,
+                                     z.c_status.d, z.stream), "plat_candidates_batch");
+            z.down(z.c_cnt, nGood); z.down(z.c_status, nGood); z.down(z.c_rec, nGood * (size_t)maxPerRead * 5);
+            z.sync("candidate scan");
+            int need = 0;
+            for (size_t i = 0; i < nGood; ++i) {
+                if (z.c_status.h[i] == PLAT_ERR_BAD_INPUT) throw DeviceError(PLAT_ERR_BAD_INPUT, "a read reaches outside the reference window handed over");
+                if (z.c_status.h[i] == PLAT_ERR_OVERFLOW) need = std::max(need, z.c_cnt.h[i]);
+            }
+            if (!need) break;
+            maxPerRead = need;                                              // a read with more candidates than its slice: again with room for it
+        }
+    }
+    std::string refBlob;
+
+    // -- B1: candidates of one region -> merged, per-sample support filter, left-normalised, filtered (variantcaller.pyx:439-531)
+    void regionVariants(RegionWork& r, int scan0) {
+        Slot& z = s;
+        VarList everyone;                                                   // the all-samples generator's variantHeap, insertion order
+        std::unordered_map<std::string, Variant*> everyoneIndex;
+        for (size_t i = 0; i < r.samples.size(); ++i) {
+            const TableView& tv = r.samples[i].reads;
+            VarList heap;                                                   // this sample's variantHeap, first-occurrence order
+            // open hash over (pos, removed, added) of this sample's records
+            const int64_t refBase = 0;
+            (void)refBase;
+            struct Key { int pos, nrem, nadd; const char* rem; const char* add; };
+            std::vector<std::pair<Key, Variant*>> table;
+            size_t tmask = 1023;
+            table.assign(tmask + 1, {Key{0, 0, 0, nullptr, nullptr}, nullptr});
+            size_t used = 0;
+            auto hashKey = [](const Key& k) -> size_t {
+                size_t h = (size_t)k.pos * 1000003u + (size_t)k.nrem * 131u + (size_t)k.nadd;
+                for (int j = 0; j < k.nrem; ++j) h = h * 31u + (unsigned char)k.rem[j];
+                for (int j = 0; j < k.nadd; ++j) h = h * 37u + (unsigned char)k.add[j];
+                return h;
+            };
+            auto sameKey = [](const Key& a, const Key& b) {
+                return a.pos == b.pos && a.nrem == b.nrem && a.nadd == b.nadd && memcmp(a.rem, b.rem, (size_t)a.nrem) == 0 && memcmp(a.add, b.add, (size_t)a.nadd) == 0;
+            };
+            for (int q = 0; q < tv.n(); ++q) {
+                const size_t g = (size_t)(tv.base + q);
+                const int cnt = z.c_cnt.h[g];
+                for (int k = 0; k < cnt; ++k) {
+                    const int32_t* rec = z.c_rec.h + 5 * (g * (size_t)maxPerRead + (size_t)k);
+                    Key key{std::max(0, rec[0]), rec[1], rec[2], rec[1] ? refBlob.data() + rec[3] : "", rec[2] ? (const char*)tv.t->seq + (rec[4] - z.t_off.h[tv.base]) : ""};
+                    ++r.nCandRecords;
+                    size_t slot = hashKey(key) & tmask;
+                    while (table[slot].second && !sameKey(table[slot].first, key)) slot = (slot + 1) & tmask;
+                    if (table[slot].second) { table[slot].second->nSupportingReads += 1; continue; }
+                    Variant* v = r.pool.make(rec[0], std::string(key.rem, (size_t)key.nrem), std::string(key.add, (size_t)key.nadd), 1, PLATYPUS_VAR);
+                    table[slot] = {key, v};
+                    heap.push_back(v);
+                    if (++used * 2 > tmask) {                               // grow
+                        std::vector<std::pair<Key, Variant*>> old;
+                        old.swap(table);
+                        tmask = tmask * 2 + 1;
+                        table.assign(tmask + 1, {Key{0, 0, 0, nullptr, nullptr}, nullptr});
+                        for (auto& e : old) if (e.second) { size_t s2 = hashKey(e.first) & tmask; while (table[s2].second) s2 = (s2 + 1) & tmask; table[s2] = e; }
+                    }
+                }
+            }
+            (void)scan0;
+            // :456-467: per-sample support, indels always; equal variants of different samples merge (addVariantToList)
+            for (Variant* v : heap) {
+                int s0, e0;
+                tv.overlapRange(v->refPos, v->refPos + 1, s0, e0);
+                const int total = e0 - s0;
+                const double frac = total == 0 ? 0.0 : (double)v->nSupportingReads / total;
+                if (frac >= o.minVarFreq || v->nAdded != v->nRemoved) {
+                    std::string key = std::to_string(v->refPos);
+                    key += '|'; key += v->removed; key += '|'; key += v->added;
+                    auto it = everyoneIndex.find(key);
+                    if (it != everyoneIndex.end()) it->second->addVariant(*v);
+                    else { everyoneIndex.emplace(std::move(key), v); everyone.push_back(v); }
+                }
+            }
+        }
+        std::stable_sort(everyone.begin(), everyone.end(), variantLess);    // getCandidates(): sorted(values)
+        VarList norm;
+        for (Variant* v : everyone) norm.push_back(leftNormaliseIndel(v, r.fa, r.rlen, r.pool));
+        std::stable_sort(norm.begin(), norm.end(), variantLess);
+        r.variants = filterVariants(norm, o.minReads, o.minReads, o.maxSize);
+    }
+
+    // -- B2/B3: windows, window pointers, haplotype enumeration (callVariantsInWindow up to Population.setup)
+    Hap makeHap(const RegionWork& r, const WindowWork& w, const VarList& vs) const {
+        Hap h;
+        h.variants = vs;
+        h.seq = haplotypeSequence(r.fa, w.hapStart, w.hapEnd, w.endBuf, vs);
+        if (h.seq.size() > 16384) throw WindowError("Haplotype is too long. Max allowed length is 16384");   // chaplotype.pyx:180-183
+        return h;
+    }
+
+    void regionWindows(RegionWork& r) {
+        WindowOptions wo{o.mergeClusteredVariants, o.maxVarDist, o.minVarDist, o.maxSize, o.largeWindows, r.rlen, o.maxVariants};
+        std::vector<Window> wins = windowsAndVariants(r.in->start, r.in->end, r.fa.len - 1, r.variants, wo);
+        for (Window& win : wins) {
+            if (win.variants.empty() || win.endPos - win.startPos > o.maxSize) continue;       // variantcaller.pyx:560-568
+            WindowWork w;
+            w.region = r.index; w.startPos = win.startPos; w.endPos = win.endPos;
+            w.vars = win.variants; w.allVars = win.variants;
+            try {
+                prepareWindow(r, w);
+            } catch (const WindowError& e) {
+                logWindowFailure(r.in->chrom, w.startPos, w.endPos, e.what());
+                std::lock_guard<std::mutex> g(stMutex);
+                ++st.n_windows_failed;
+                w.live = false; w.greedy = false;
+            }
+            r.windows.push_back(std::move(w));
+        }
+    }
+
+    void prepareWindow(RegionWork& r, WindowWork& w) {
+        w.hapStart = std::max(0, w.startPos);
+        w.hapEnd = (int)std::min<int64_t>(w.endPos, r.fa.len - 1);
+        w.endBuf = std::min(2 * r.rlen, 500);                               // chaplotype.pyx:142
+        w.refSeq = haplotypeSequence(r.fa, w.hapStart, w.hapEnd, w.endBuf, VarList());
+        if (w.refSeq.size() > 16384) throw WindowError("Haplotype is too long. Max allowed length is 16384");
+        w.ptrs.resize(r.samples.size());
+        w.nReads = 0;
+        for (size_t i = 0; i < r.samples.size(); ++i) {                    // bamReadBuffer.setWindowPointers (cwindow.pyx:655-689)
+            Ptrs& p = w.ptrs[i];
+            r.samples[i].reads.overlapRange(w.startPos, w.endPos, p.gs, p.ge);
+            r.samples[i].bad.overlapRange(w.startPos, w.endPos, p.bs, p.be);
+            r.samples[i].broken.matePosRange(w.startPos, w.endPos, p.ks, p.ke);
+            w.nReads += p.ge - p.gs;
+        }
+        if (w.nReads == 0 || (double)w.nReads > o.maxReads) return;
+        if ((int)w.vars.size() > o.maxVariants) {
+            if (o.skipDifficultWindows) return;
+            if (o.filterVarsByCoverage) w.vars = filterVariantsByCoverage(w.vars, o.maxVariants);
+        }
+        // getFilteredHaplotypes (variantFilter.pyx:377-506)
+        const int maxHaplotypes = o.maxHaplotypes - 1;
+        const int nVars = (int)w.vars.size();
+        const double lg = log2((double)maxHaplotypes);
+        if (nVars <= lg || (o.filterVarsByCoverage && o.maxVariants <= lg)) {
+            std::vector<Hap> haps;
+            std::vector<int> idx;
+            for (int n = 1; n <= nVars; ++n) {                             // itertools.combinations order
+                idx.resize((size_t)n);
+                for (int i = 0; i < n; ++i) idx[(size_t)i] = i;
+                for (;;) {
+                    VarList vs;
+                    for (int i : idx) vs.push_back(w.vars[(size_t)i]);
+                    if (isHaplotypeValid(vs)) haps.push_back(makeHap(r, w, vs));
+                    int i = n - 1;
+                    while (i >= 0 && idx[(size_t)i] == i + nVars - n) --i;
+                    if (i < 0) break;
+                    ++idx[(size_t)i];
+                    for (int j = i + 1; j < n; ++j) idx[(size_t)j] = idx[(size_t)j - 1] + 1;
+                }
+            }
+            finishHaplotypes(r, w, haps);
+            return;
+        }
+        // greedy growth of the best haplotypes, one variant at a time (most supported first); the alignments of a step are
+        // batched over every such window of the chunk (greedyRounds)
+        w.greedy = true;
+        w.byCoverage = w.vars;
+        std::stable_sort(w.byCoverage.begin(), w.byCoverage.end(), [](const Variant* a, const Variant* b) { return a->nSupportingReads > b->nSupportingReads; });
+        w.step = 0;
+        // the sampled reads of computeBestScoreForGenotype (variantFilter.pyx:237-283)
+        const int windowSize = w.endPos - w.startPos, target = o.coverageSamplingLevel;
+        if (windowSize <= 0 || target <= 0) throw WindowError("integer division or modulo by zero");
+        w.sampledSeg.assign(1, 0);
+        for (size_t i = 0; i < r.samples.size(); ++i) {
+            const Ptrs& p = w.ptrs[i];
+            const int n = p.ge - p.gs;
+            if (n > 0) {
+                const int meanCoverage = r.samples[i].reads.rlen(p.gs) * n / windowSize;            // :264
+                const int sampleRate = std::max(1, meanCoverage / target);
+                for (int q = p.gs; q < p.ge; q += sampleRate) w.sampled.push_back({(int)i, q});
+            }
+            w.sampledSeg.push_back((int)w.sampled.size());
+        }
+    }
+
+    // mergeHaplotypes (variantcaller.pyx:325-383) over [reference haplotype] + haps; a window with one haplotype is not called
+    void finishHaplotypes(RegionWork& r, WindowWork& w, std::vector<Hap>& haps) {
+        std::vector<Hap> all;
+        all.reserve(haps.size() + 1);
+        Hap ref;
+        ref.seq = w.refSeq;
+        all.push_back(std::move(ref));
+        for (Hap& h : haps) all.push_back(std::move(h));
+        std::vector<size_t> order(all.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return all[a].seq < all[b].seq; });
+        std::vector<Hap> merged;
+        int last = -1;
+        for (size_t k : order) {
+            if (last < 0) { last = (int)k; continue; }
+            if (all[k].seq == all[(size_t)last].seq) {
+                double p1 = 1.0, p2 = 1.0;
+                for (Variant* v : all[(size_t)last].variants) p1 *= calculatePrior(*v, r.fa);
+                for (Variant* v : all[k].variants) p2 *= calculatePrior(*v, r.fa);
+                if (p2 > p1) last = (int)k;
+            } else {
+                merged.push_back(std::move(all[(size_t)last]));
+                last = (int)k;
+            }
+        }
+        if (last >= 0) merged.push_back(std::move(all[(size_t)last]));
+        w.greedy = false;
+        if (merged.size() <= 1) { w.live = false; return; }
+        w.haps.swap(merged);
+        w.live = true;
+    }
+
+    // -- the greedy haplotype filter, one variant per round for every window that needs it (variantFilter.pyx:440-506)
+    void greedyRounds() {
+        std::vector<WindowWork*> todo;
+        for (RegionWork* r : regions) for (WindowWork& w : r->windows) if (w.greedy) todo.push_back(&w);
+        if (todo.empty()) return;
+        { std::lock_guard<std::mutex> g(stMutex); st.n_windows_greedy += (int64_t)todo.size(); }
+        const int originalMax = o.originalMaxHaplotypes - 1, maxHaplotypes = o.maxHaplotypes - 1;
+        for (;;) {
+            std::vector<WindowWork*> active;
+            BatchBuilder b;
+            b.nInd = 1;
+            for (WindowWork* w : todo) {
+                if (!w->greedy || w->step >= w->byCoverage.size()) continue;
+                RegionWork& r = *regions[(size_t)regionSlot(w->region)];
+                try {
+                    Variant* tempVar = w->byCoverage[w->step];
+                    std::vector<ScoredHap> old = w->heap;
+                    std::stable_sort(old.begin(), old.end(), scoredLess);
+                    w->cands.clear();
+                    w->cands.push_back(VarList{tempVar});
+                    for (const ScoredHap& sh : old) {
+                        VarList both{tempVar};
+                        both.insert(both.end(), sh.vs.begin(), sh.vs.end());
+                        std::stable_sort(both.begin(), both.end(), variantLess);
+                        if (isHaplotypeValid(both)) w->cands.push_back(both);
+                    }
+                    if (w->sampled.empty()) {                               // no reads sampled: every score is -1e20
+                        for (const VarList& vs : w->cands) makeHap(r, *w, vs);
+                        for (const VarList& vs : w->cands) pushScored(*w, ScoredHap{-1e20, vs}, originalMax);
+                        ++w->step;
+                        active.push_back(nullptr);                          // (keeps the loop going without a device window)
+                        continue;
+                    }
+                    std::vector<std::string> seqs;
+                    for (const VarList& vs : w->cands) seqs.push_back(makeHap(r, *w, vs).seq);
+                    b.beginWindow(w->hapStart, w->hapEnd, w->endBuf);
+                    b.addHap(w->refSeq);
+                    for (const std::string& q : seqs) b.addHap(q);
+                    for (auto& sq : w->sampled) b.addRead(r.samples[(size_t)sq.first].reads, sq.second, 2);   // alignSingleRead: never skipped
+                    b.endSegment(0);
+                    b.endWindow();
+                    active.push_back(w);
+                } catch (const WindowError& e) {
+                    logWindowFailure(r.in->chrom, w->startPos, w->endPos, e.what());
+                    { std::lock_guard<std::mutex> g(stMutex); ++st.n_windows_failed; }
+                    w->greedy = false; w->live = false;
+                }
+            }
+            if (active.empty()) break;
+            if (b.nWindows() > 0) {
+                runWindows(s, b, o, false, true);
+                int bw = 0;
+                for (WindowWork* w : active) {
+                    if (!w) continue;
+                    const int nH = (int)w->cands.size(), n = (int)w->sampled.size();
+                    const double* ll = s.o_loglik.h + b.pairoff[(size_t)bw];
+                    for (int k = 0; k < nH; ++k) {
+                        const double* row = ll + (size_t)(k + 1) * (size_t)n;
+                        double best = -1e20;
+                        for (size_t i = 0; i + 1 < w->sampledSeg.size(); ++i) {
+                            if (w->sampledSeg[i] == w->sampledSeg[i + 1]) continue;                     // :261-262
+                            double score = 0.0;
+                            for (int q = w->sampledSeg[i]; q < w->sampledSeg[i + 1]; ++q) score += log(0.5 * (exp(ll[q]) + exp(row[q])));   // :270-272
+                            best = std::max(best, score);
+                        }
+                        pushScored(*w, ScoredHap{best, w->cands[(size_t)k]}, originalMax);
+                    }
+                    ++w->step;
+                    ++bw;
+                }
+            }
+        }
+        for (WindowWork* w : todo) {
+            if (!w->greedy) continue;
+            RegionWork& r = *regions[(size_t)regionSlot(w->region)];
+            try {
+                std::vector<ScoredHap> best = w->heap;                      // sorted(hapsByBestScore, reverse=True): descending, equal ones keep their order
+                std::stable_sort(best.begin(), best.end(), [](const ScoredHap& a, const ScoredHap& b) { return scoredLess(b, a); });
+                std::vector<Hap> haps;
+                for (size_t i = 0; i < best.size() && (int)i < maxHaplotypes; ++i) haps.push_back(makeHap(r, *w, best[i].vs));
+                finishHaplotypes(r, *w, haps);
+            } catch (const WindowError& e) {
+                logWindowFailure(r.in->chrom, w->startPos, w->endPos, e.what());
+                { std::lock_guard<std::mutex> g(stMutex); ++st.n_windows_failed; }
+                w->greedy = false; w->live = false;
+            }
+        }
+    }
+    static void pushScored(WindowWork& w, const ScoredHap& item, int originalMax) {
+        if ((int)w.heap.size() < originalMax) heapPush(w.heap, item); else heapPushPop(w.heap, item);
+    }
+    int regionSlot(int regionIndex) const { return regionIndex - regions[0]->index; }
+
+    // -- C..F for a list of windows
+    void callWindows(std::vector<WindowWork*>& wins) {
+        if (wins.empty()) return;
+        Slot& z = s;
+        BatchBuilder b;
+        b.nInd = nInd;
+        for (WindowWork* w : wins) {
+            RegionWork& r = *regions[(size_t)regionSlot(w->region)];
+            w->bw = b.nWindows();
+            b.beginWindow(w->hapStart, w->hapEnd, w->endBuf);
+            for (const Hap& h : w->haps) b.addHap(h.seq);
+            for (size_t i = 0; i < r.samples.size(); ++i) {                // good -> bad -> brokenMates (chaplotype.pyx:341-373)
+                const Ptrs& p = w->ptrs[i];
+                for (int q = p.gs; q < p.ge; ++q) b.addRead(r.samples[i].reads, q, 0);
+                for (int q = p.bs; q < p.be; ++q) b.addRead(r.samples[i].bad, q, 1);
+                for (int q = p.ks; q < p.ke; ++q) b.addRead(r.samples[i].broken, q, 2);
+                b.endSegment(p.ge - p.gs);
+            }
+            b.endWindow();
+        }
+        DeviceBatch db = runWindows(z, b, o, true, false);
+
+        // D: distinct variants, masks, priors -> posteriors (Population.computeVariantPosteriors, cpopulation.pyx:596-621)
+        std::vector<int32_t> pwin;
+        std::vector<int64_t> poff{0};
+        std::vector<uint8_t> pmask;
+        std::vector<double> pprior;
+        for (WindowWork* w : wins) {
+            RegionWork& r = *regions[(size_t)regionSlot(w->region)];
+            w->distinct.clear();
+            for (const Hap& h : w->haps)
+                for (Variant* v : h.variants) if (!contains(w->distinct, v)) w->distinct.push_back(v);
+            for (Variant* v : w->distinct) {
+                pwin.push_back(w->bw);
+                for (const Hap& h : w->haps) pmask.push_back(contains(h.variants, v) ? 1 : 0);
+                poff.push_back((int64_t)pmask.size());
+                pprior.push_back(calculatePrior(*v, r.fa));
+            }
+        }
+        const size_t nV = pwin.size();
+        if (nV) {
+            fill(z, z.p_win, pwin); fill(z, z.p_off, poff); fill(z, z.p_mask, pmask); fill(z, z.p_prior, pprior);
+            z.p_post.reserve(z.ctx, nV + 1);
+            z.up(z.p_win, nV); z.up(z.p_off, nV + 1); z.up(z.p_mask, pmask.size()); z.up(z.p_prior, nV);
+            ck(plat_variant_posterior_batch(z.ctx, (int)nV, nInd, db.maxH, z.w_hapbegin.d, z.w_gloff.d, z.w_ngood.d, z.o_gl.d, z.o_freq.d, z.p_win.d,
+                                            z.p_off.d, z.p_mask.d, z.p_prior.d, z.p_post.d, z.stream), "plat_variant_posterior_batch");
+            z.down(z.p_post, nV);
+            z.sync("posteriors");
+        }
+        // varsByPos, INFO variants (getHaplotypeInfo order, vcfutils.pyx:1118-1152), read statistics and call sites of the live windows
+        std::vector<int32_t> svw, spos, smin, smax, snadd, snrem, sgb, sge, sbb, sbe, kwin, knvar, kvih, kref;
+        std::vector<int64_t> saoff, smoff, kvo{0}, kro{0}, klo{0};
+        std::vector<uint8_t> svig;
+        std::string sadded;
+        int64_t mtot = 0;
+        size_t at = 0;
+        std::vector<WindowWork*> live;
+        for (WindowWork* w : wins) {
+            RegionWork& r = *regions[(size_t)regionSlot(w->region)];
+            w->called.clear(); w->calledPost.clear(); w->byPos.clear(); w->info.clear();
+            for (size_t k = 0; k < w->distinct.size(); ++k, ++at) {
+                const double p = z.p_post.h[at];
+                if (p >= (double)o.minPosterior) {
+                    Variant* v = w->distinct[k];
+                    w->called.push_back(v); w->calledPost.push_back(p);
+                    bool found = false;
+                    for (auto& pv : w->byPos) if (pv.first == v->refPos) { pv.second.push_back(v); found = true; break; }
+                    if (!found) w->byPos.push_back({v->refPos, VarList{v}});
+                }
+            }
+            // good / bad read ranges of every (window, sample) in the chunk table, for the statistics kernel
+            for (size_t i = 0; i < r.samples.size(); ++i) {
+                const Ptrs& p = w->ptrs[i];
+                sgb.push_back((int32_t)(r.samples[i].reads.base + p.gs)); sge.push_back((int32_t)(r.samples[i].reads.base + p.ge));
+                sbb.push_back((int32_t)(r.samples[i].bad.base + p.bs)); sbe.push_back((int32_t)(r.samples[i].bad.base + p.be));
+            }
+            if (w->called.empty()) continue;
+            live.push_back(w);
+            const double* freq = z.o_freq.h + b.hapbegin[(size_t)w->bw];
+            const int32_t* calls = z.o_calls.h + (size_t)w->bw * (size_t)nInd;
+            for (size_t h = 0; h < w->haps.size(); ++h) {
+                VarList seen;                                               // Haplotype.vcfINFO(): a dictionary over the haplotype's variants
+                for (Variant* v : w->haps[h].variants) {
+                    if (contains(seen, v)) continue;
+                    seen.push_back(v);
+                    int ci = -1;
+                    for (size_t c = 0; c < w->called.size(); ++c) if (w->called[c]->same(*v)) { ci = (int)c; break; }
+                    if (ci < 0) continue;
+                    VarInfo* d = nullptr;
+                    for (VarInfo& x : w->info) if (x.var->same(*v)) { d = &x; break; }
+                    if (!d) {
+                        VarInfo n;
+                        n.var = v;
+                        n.HP = homopolymerLengthForOneVariant(*v, r.fa);
+                        n.SC = getSequenceContext(*v, r.fa);
+                        char buf[64];
+                        snprintf(buf, sizeof buf, "%.0f", w->calledPost[(size_t)ci]);
+                        n.PP = buf;
+                        n.FRsum = freq[h];
+                        w->info.push_back(std::move(n));
+                    } else d->FRsum += freq[h];
+                }
+            }
+            int ngood = 0;
+            for (const Ptrs& p : w->ptrs) ngood += p.ge - p.gs;
+            w->firstStatVar = (int)svw.size();
+            for (VarInfo& d : w->info) {
+                const Variant* v = d.var;
+                svw.push_back(w->bw); spos.push_back(v->refPos); smin.push_back(v->bamMinPos); smax.push_back(v->bamMaxPos);
+                snadd.push_back(v->nAdded); snrem.push_back(v->nRemoved);
+                saoff.push_back((int64_t)sadded.size());
+                sadded += v->added;
+                for (int i = 0; i < nInd; ++i) {                            // `variant in genotypeCalls[i]` (cgenotype.pyx:98-105)
+                    const int g = calls[i];
+                    bool in = false;
+                    if (g >= 0) {
+                        int a = 0, bq = 0, rowlen = (int)w->haps.size(), gg = g;
+                        while (gg >= rowlen) { gg -= rowlen; --rowlen; ++a; }
+                        bq = a + gg;
+                        in = contains(w->haps[(size_t)a].variants, v) || contains(w->haps[(size_t)bq].variants, v);
+                    }
+                    svig.push_back(in ? 1 : 0);
+                }
+                smoff.push_back(mtot);
+                mtot += std::max(ngood, 1);
+            }
+            // call sites: varThisPosInHap / haplotypeIsRefAtThisPos per VCF position (vcfutils.pyx:400-426)
+            std::vector<std::pair<int, VarList>*> positions;
+            for (auto& pv : w->byPos) positions.push_back(&pv);
+            std::sort(positions.begin(), positions.end(), [](const std::pair<int, VarList>* a, const std::pair<int, VarList>* bb) { return a->first < bb->first; });
+            w->firstSite = (int)kwin.size();
+            for (auto* pv : positions) {
+                const int POS = pv->first;
+                const VarList& vars = pv->second;
+                kwin.push_back(w->bw); knvar.push_back((int32_t)vars.size());
+                for (const Hap& h : w->haps) for (Variant* v : vars) kvih.push_back(contains(h.variants, v) ? 1 : 0);
+                for (const Hap& h : w->haps) {
+                    bool any = false;
+                    for (Variant* v : h.variants)
+                        if ((contains(vars, v) || contains(w->allVars, v)) && v->minRefPos <= POS && POS <= v->maxRefPos) { any = true; break; }
+                    kref.push_back(any ? 0 : 1);
+                }
+                kvo.push_back((int64_t)kvih.size()); kro.push_back((int64_t)kref.size());
+                const int64_t NL = (int64_t)(vars.size() + 1) * (int64_t)(vars.size() + 2) / 2;
+                klo.push_back(klo.back() + NL * nInd);
+            }
+        }
+        {
+            std::lock_guard<std::mutex> g(stMutex);
+            st.n_windows_called += (int64_t)wins.size();
+        }
+        if (live.empty()) return;
+        // E: read statistics + per-site genotype calls
+        const size_t nSV = svw.size(), nSites = kwin.size();
+        fill(z, z.s_vw, svw); fill(z, z.s_pos, spos); fill(z, z.s_min, smin); fill(z, z.s_max, smax); fill(z, z.s_nadd, snadd); fill(z, z.s_nrem, snrem);
+        fill(z, z.s_aoff, saoff); fill(z, z.s_moff, smoff); fill(z, z.s_vig, svig); fill(z, z.s_gb, sgb); fill(z, z.s_ge, sge); fill(z, z.s_bb, sbb); fill(z, z.s_be, sbe);
+        z.s_added.reserve(z.ctx, sadded.size() + PLAT_BLOB_PAD);
+        memcpy(z.s_added.h, sadded.data(), sadded.size()); memset(z.s_added.h + sadded.size(), 0, PLAT_BLOB_PAD);
+        z.s_counts.reserve(z.ctx, nSV * 16 + 16); z.s_ps.reserve(z.ctx, nSV * (size_t)nInd * 2 + 2); z.s_minq.reserve(z.ctx, (size_t)mtot + 1); z.s_nminq.reserve(z.ctx, nSV + 1);
+        z.up(z.s_vw, nSV); z.up(z.s_pos, nSV); z.up(z.s_min, nSV); z.up(z.s_max, nSV); z.up(z.s_nadd, nSV); z.up(z.s_nrem, nSV); z.up(z.s_aoff, nSV);
+        z.up(z.s_moff, nSV); z.up(z.s_vig, svig.size()); z.up(z.s_gb, sgb.size()); z.up(z.s_ge, sge.size()); z.up(z.s_bb, sbb.size()); z.up(z.s_be, sbe.size());
+        z.up(z.s_added, sadded.size() + PLAT_BLOB_PAD);
+        plat_infostats_batch ib;
+        memset(&ib, 0, sizeof ib);
+        ib.n_vars = (int32_t)nSV; ib.n_ind = nInd;
+        ib.var_window = z.s_vw.d; ib.var_pos = z.s_pos.d; ib.var_bam_min = z.s_min.d; ib.var_bam_max = z.s_max.d; ib.var_n_added = z.s_nadd.d;
+        ib.var_n_removed = z.s_nrem.d; ib.var_added = z.s_added.d; ib.var_added_off = z.s_aoff.d; ib.var_in_genotype = z.s_vig.d; ib.minq_off = z.s_moff.d;
+        ib.good_begin = z.s_gb.d; ib.good_end = z.s_ge.d; ib.bad_begin = z.s_bb.d; ib.bad_end = z.s_be.d;
+        ib.read_seq = z.t_seq.d; ib.read_qual = z.t_qual.d; ib.read_off = z.t_off.d; ib.read_pos = z.t_pos.d; ib.read_end = z.t_end.d; ib.read_mapq = z.t_mapq.d;
+        ib.read_flags = z.t_flags.d; ib.cigar = z.t_cigar.d; ib.cig_off = z.t_cigoff.d;
+        ck(plat_variant_read_stats_batch(z.ctx, &ib, o.badReadsWindow, o.countOnlyExactIndelMatches, z.s_counts.d, z.s_ps.d, z.s_minq.d, z.s_nminq.d, z.stream),
+           "plat_variant_read_stats_batch");
+        z.down(z.s_counts, nSV * 16); z.down(z.s_ps, nSV * (size_t)nInd * 2); z.down(z.s_nminq, nSV); z.down(z.s_minq, (size_t)mtot);
+        fill(z, z.k_win, kwin); fill(z, z.k_nvar, knvar); fill(z, z.k_vo, kvo); fill(z, z.k_ro, kro); fill(z, z.k_lo, klo); fill(z, z.k_ref, kref);
+        kvih.push_back(0);
+        fill(z, z.k_vih, kvih);
+        z.k_ph.reserve(z.ctx, nSites * (size_t)nInd * 2 + 2); z.k_lik.reserve(z.ctx, (size_t)klo.back() + 1); z.k_out4.reserve(z.ctx, nSites * (size_t)nInd * 4 + 4);
+        z.up(z.k_win, nSites); z.up(z.k_nvar, nSites); z.up(z.k_vo, nSites + 1); z.up(z.k_ro, nSites + 1); z.up(z.k_lo, nSites + 1); z.up(z.k_ref, kref.size());
+        z.up(z.k_vih, kvih.size());
+        ck(plat_genotype_call_batch(z.ctx, (int)nSites, nInd, z.w_hapbegin.d, z.w_gloff.d, z.o_gl.d, z.o_gof.d, z.o_freq.d, z.k_win.d, z.k_nvar.d, z.k_vo.d,
+                                    z.k_ro.d, z.k_vih.d, z.k_ref.d, z.k_lo.d, z.k_ph.d, z.k_lik.d, z.k_out4.d, z.stream), "plat_genotype_call_batch");
+        z.down(z.k_ph, nSites * (size_t)nInd * 2); z.down(z.k_lik, (size_t)klo.back()); z.down(z.k_out4, nSites * (size_t)nInd * 4);
+        z.sync("read statistics / genotype calls");
+        // F: INFO, FILTER, text
+        for (WindowWork* w : live) {
+            RegionWork& r = *regions[(size_t)regionSlot(w->region)];
+            try {
+                writeWindow(r, *w, klo);
+            } catch (const WindowError& e) {
+                logWindowFailure(r.in->chrom, w->startPos, w->endPos, e.what());
+                std::lock_guard<std::mutex> g(stMutex);
+                ++st.n_windows_failed;
+            }
+        }
+    }
+
+    // vcfINFO (vcfutils.pyx:1226-1460), vcfFILTER (:1502-1627), outputCallToVCF (:338-599), VCF.write_data (vcf.py:710-739)
+    void writeWindow(RegionWork& r, WindowWork& w, const std::vector<int64_t>& klo) {
+        Slot& z = s;
+        const int hapScore = z.o_hapscore.h[w.bw];
+        for (size_t k = 0; k < w.info.size(); ++k) {
+            VarInfo& d = w.info[k];
+            const size_t sv = (size_t)w.firstStatVar + k;
+            infoFieldsFromReadStats(d, z.s_counts.h + 16 * sv, z.s_ps.h + 2 * sv * (size_t)nInd, nInd, z.s_minq.h + z.s_moff.h[sv], z.s_nminq.h[sv]);
+            if (d.TR > 0) {                                                // :1400-1409
+                const double qual = strtod(d.PP.c_str(), nullptr);
+                if (qual > 2500) d.QD = Num::I(o.qdThreshold + 10);
+                else d.QD = Num::D((qual + (-10 * log10(calculatePrior(*d.var, r.fa)))) / (double)d.TR);
+            } else d.QD = Num::I(0);
+            char buf[64];
+            snprintf(buf, sizeof buf, "%1.4f", d.FRsum);
+            d.FRtext = buf;
+            d.HapScore = hapScore;
+            d.Source.clear();
+            if (d.var->varSource & PLATYPUS_VAR) d.Source.push_back("Platypus");
+            if (d.var->varSource & ASSEMBLER_VAR) d.Source.push_back("Assembler");
+            if (d.var->varSource & FILE_VAR) d.Source.push_back("File");
+            d.filters.clear();
+        }
+        auto infoOf = [&](const Variant* v) -> VarInfo& {
+            for (VarInfo& d : w.info) if (d.var->same(*v)) return d;
+            throw WindowError("variant without INFO");
+        };
+        // vcfFILTER
+        for (auto& pv : w.byPos) {
+            const VarList& varsAtPos = pv.second;
+            const int n = (int)varsAtPos.size();
+            const bool failsSC = computeSCValue(infoOf(varsAtPos[0]).SC) > o.scThreshold;
+            int fQD = 0, fHap = 0, fMQ = 0, fSB = 0, fAB = 0, fMMLQ = 0, bestQual = 0;
+            double BRF = 0.0;
+            for (Variant* v : varsAtPos) {
+                VarInfo& d = infoOf(v);
+                d.filters.clear();
+                if (failsSC) d.filters.push_back("SC");
+                BRF = d.BRF.value();
+                bestQual = std::max(bestQual, atoi(d.PP.c_str()));
+                fMMLQ += d.MMLQ < o.badReadsThreshold;
+                fQD += d.QD.value() < (double)o.qdThreshold;
+                fHap += d.HapScore > o.hapScoreThreshold;
+                fAB += d.TC > 0 && d.ABPV.value() < o.abThreshold;
+                fSB += d.SbPval.value() < o.sbThreshold;
+                fMQ += d.MQ.value() < (double)o.rmsmqThreshold;
+            }
+            for (Variant* v : varsAtPos) {                                  // BRF: of the last variant, as there
+                VarInfo& d = infoOf(v);
+                if (fQD == n) d.filters.push_back("QD");
+                if (fHap == n) d.filters.push_back("HapScore");
+                if (fMQ == n) d.filters.push_back("MQ");
+                if (fSB == n) d.filters.push_back("strandBias");
+                if (fAB == n) d.filters.push_back("alleleBias");
+                if (fMMLQ == n || BRF >= o.filteredReadsFrac) d.filters.push_back("badReads");
+                if (bestQual < 20) d.filters.push_back("Q20");
+            }
+        }
+        // outputCallToVCF
+        std::vector<std::pair<int, VarList>*> positions;
+        for (auto& pv : w.byPos) positions.push_back(&pv);
+        std::sort(positions.begin(), positions.end(), [](const std::pair<int, VarList>* a, const std::pair<int, VarList>* b) { return a->first < b->first; });
+        std::string& out = r.text;
+        char buf[128];
+        for (size_t pi = 0; pi < positions.size(); ++pi) {
+            int POS = positions[pi]->first;
+            const VarList& variants = positions[pi]->second;
+            const int nVariants = (int)variants.size();
+            const size_t site = (size_t)w.firstSite + pi;
+            std::string ref;
+            std::vector<std::string> alt;
+            refAndAlt(POS, variants, r.fa, ref, alt);
+            VarInfo& lead = infoOf(variants[0]);
+            std::vector<std::string> linefilter, FR, PP;
+            std::vector<long long> NF, NR, TR;
+            for (Variant* v : variants) {
+                VarInfo& d = infoOf(v);
+                for (const std::string& f : d.filters) linefilter.push_back(f);
+                FR.push_back(d.FRtext); PP.push_back(d.PP); NF.push_back(d.NF); NR.push_back(d.NR); TR.push_back(d.TR);
+            }
+            int qual = 0;
+            bool first = true;
+            for (const std::string& pp : PP) { const int q = atoi(pp.c_str()); if (first || q > qual) qual = q; first = false; }
+            // per-sample columns
+            double maxGof = 0.0;
+            int nNonRefCalls = 0;
+            std::vector<std::string> sampleCols;
+            const int64_t NL = (int64_t)(nVariants + 1) * (nVariants + 2) / 2;
+            for (int i = 0; i < nInd; ++i) {
+                const Ptrs& p = w.ptrs[(size_t)i];
+                if (p.ge - p.gs == 0) { sampleCols.push_back("./.:0,0,0:0:0:0:0"); continue; }        // :498-500
+                const size_t t = site * (size_t)nInd + (size_t)i;
+                const int index1 = z.k_ph.h[2 * t], index2 = z.k_ph.h[2 * t + 1];
+                const double* lik = z.k_lik.h + klo[site] + (int64_t)i * NL;
+                const double gtPost = z.k_out4.h[4 * t], nonRefPost = z.k_out4.h[4 * t + 1], refPost = z.k_out4.h[4 * t + 2], gofValue = z.k_out4.h[4 * t + 3];
+                if (!(index1 == 0 && index2 == 0)) ++nNonRefCalls;
+                std::string GT = std::to_string(index1) + "/" + std::to_string(index2);
+                std::string GL;
+                if (nVariants == 1) {                                       // :524-542
+                    if (phred(nonRefPost) < o.minPosterior) GT = phred(refPost) < o.minPosterior ? "./." : "0/0";
+                    double top = lik[0];
+                    for (int64_t q = 1; q < NL; ++q) top = std::max(top, lik[q]);
+                    for (int64_t q = 0; q < NL; ++q) {                   // (FORMAT fields have no numeric missing value: -1.0 stays -1.0)
+                        if (q) GL += ",";
+                        GL += py2_str(py2_round2(log10(std::max(lik[q] / top, 1e-300))));
+                    }
+                } else GL = "-1,-1,-1";
+                std::string NRs, NVs;
+                for (int k = 0; k < nVariants; ++k) {
+                    VarInfo& d = infoOf(variants[(size_t)k]);
+                    if (k) { NRs += ","; NVs += ","; }
+                    NRs += std::to_string(d.nReadsPerSample[(size_t)i]); NVs += std::to_string(d.nVarReadsPerSample[(size_t)i]);
+                }
+                if (nVariants == 1 && infoOf(variants[0]).nReadsPerSample[(size_t)i] < o.minReads) GT = "./.";      // :550-553
+                std::vector<std::string> cols{GT, GL, std::to_string((long long)gofValue), std::to_string(phred(gtPost)), NRs, NVs};
+                // format_formatdata(key=False): trailing entries made only of "," and "." are dropped
+                while (cols.size() > 1) {
+                    bool onlyDots = true;
+                    for (char c : cols.back()) if (c != ',' && c != '.') { onlyDots = false; break; }
+                    if (!onlyDots) break;
+                    cols.pop_back();
+                }
+                std::string col;
+                for (size_t q = 0; q < cols.size(); ++q) { if (q) col += ":"; col += cols[q]; }
+                sampleCols.push_back(col);
+                maxGof = std::max(maxGof, gofValue);
+            }
+            const long long MGOF = (long long)py2_round2(maxGof);
+            if (!(nNonRefCalls > 0 || o.minPosterior == 0 || o.outputRefCalls == 1)) continue;
+            trimLeftPadding(POS, ref, alt);
+            bool plain = true;
+            for (char c : ref) if (c != 'A' && c != 'C' && c != 'T' && c != 'G') { plain = false; break; }
+            if (!plain) continue;                                           // :583-592
+            // VCF.write_data
+            out += r.in->chrom; out += '\t';
+            out += std::to_string(POS + 1); out += "\t.\t"; out += ref; out += '\t';
+            if (alt.empty()) out += "."; else for (size_t q = 0; q < alt.size(); ++q) { if (q) out += ","; out += alt[q]; }
+            out += '\t'; out += std::to_string(qual); out += '\t';
+            std::vector<std::string> flt = py2_set_order(linefilter);
+            if (flt.empty()) out += "PASS"; else for (size_t q = 0; q < flt.size(); ++q) { if (q) out += ";"; out += flt[q]; }
+            out += '\t';
+            auto joinLL = [](const std::vector<long long>& v) { std::string t; for (size_t q = 0; q < v.size(); ++q) { if (q) t += ","; t += Num::I(v[q]).text(); } return t; };
+            auto joinS = [](const std::vector<std::string>& v) { std::string t; for (size_t q = 0; q < v.size(); ++q) { if (q) t += ","; t += v[q]; } return t; };
+            // INFO keys in sorted order: BRF FR HP HapScore MGOF MMLQ MQ NF NR PP QD SC SbPval Source TC TCF TCR TR WE WS
+            out += "BRF="; out += lead.BRF.text();
+            out += ";FR="; out += joinS(FR);
+            out += ";HP="; out += Num::I(lead.HP).text();
+            out += ";HapScore="; out += Num::I(lead.HapScore).text();
+            out += ";MGOF="; out += Num::I(MGOF).text();
+            out += ";MMLQ="; out += Num::I(lead.MMLQ).text();
+            out += ";MQ="; out += lead.MQ.text();
+            out += ";NF="; out += joinLL(NF);
+            out += ";NR="; out += joinLL(NR);
+            out += ";PP="; out += joinS(PP);
+            out += ";QD="; out += lead.QD.text();
+            out += ";SC="; out += lead.SC;
+            out += ";SbPval="; out += lead.SbPval.text();
+            out += ";Source="; out += joinS(lead.Source);
+            out += ";TC="; out += Num::I(lead.TC).text();
+            out += ";TCF="; out += Num::I(lead.TCF).text();
+            out += ";TCR="; out += Num::I(lead.TCR).text();
+            out += ";TR="; out += joinLL(TR);
+            snprintf(buf, sizeof buf, ";WE=%s;WS=%s", Num::I(w.endPos).text().c_str(), Num::I(w.startPos).text().c_str());
+            out += buf;
+            out += "\tGT:GL:GOF:GQ:NR:NV";
+            for (const std::string& c : sampleCols) { out += '\t'; out += c; }
+            out += '\n';
+            ++r.nRecords;
+        }
+    }
+
+    void run() {
+        const auto t0 = Clock::now();
+        double wait0 = s.t_wait;
+        uploadReads();
+        scanCandidates();
+        int scan0 = 0;
+        for (RegionWork* r : regions) {
+            regionVariants(*r, scan0);
+            scan0 += (int)r->samples.size();
+            regionWindows(*r);
+        }
+        greedyRounds();
+        std::vector<WindowWork*> wins;
+        int64_t nWin = 0, nVar = 0, nCand = 0;
+        for (RegionWork* r : regions) {
+            nVar += (int64_t)r->variants.size(); nCand += r->nCandRecords;
+            for (WindowWork& w : r->windows) if (w.live) { ++nWin; wins.push_back(&w); }
+        }
+        try {
+            callWindows(wins);
+        } catch (const DeviceError& e) {
+            // one window the device refuses would take every other window of the chunk with it: call them one at a time, so that
+            // only the failing ones are skipped (what the reference's per-window try/except does, variantcaller.pyx:568-615)
+            for (RegionWork* r : regions) { r->text.clear(); r->nRecords = 0; }
+            for (WindowWork* w : wins) {
+                std::vector<WindowWork*> one{w};
+                try { callWindows(one); }
+                catch (const DeviceError& e2) {
+                    logWindowFailure(regions[(size_t)regionSlot(w->region)]->in->chrom, w->startPos, w->endPos, e2.what());
+                    std::lock_guard<std::mutex> g(stMutex);
+                    ++st.n_windows_failed;
+                }
+            }
+        }
+        int64_t nRec = 0;
+        for (RegionWork* r : regions) nRec += r->nRecords;
+        const double total = secs(t0, Clock::now()), waited = s.t_wait - wait0;
+        std::lock_guard<std::mutex> g(stMutex);
+        st.n_windows += nWin; st.n_variants += nVar; st.n_candidate_records += nCand; st.n_records += nRec;
+        st.seconds_host += total - waited; st.seconds_device_wait += waited;
+    }
+};
+
+}  // namespace plathost
+
+using namespace plathost;
+
+struct plat_caller {
+    int device = 0, nWorkers = 1, regionsPerChunk = 4;
+    std::vector<std::unique_ptr<Slot>> slots;
+    std::string lastError;
+};
+
+CALLER_EXPORT void plat_caller_default_options(plat_caller_options* o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->rlen = 150; o->minReads = 2; o->maxReads = 5000000; o->maxSize = 1500; o->largeWindows = 0; o->maxVariants = 8; o->coverageSamplingLevel = 30;
+    o->maxHaplotypes = 50; o->originalMaxHaplotypes = 50; o->skipDifficultWindows = 0; o->getVariantsFromBAMs = 1; o->genSNPs = 1; o->genIndels = 1;
+    o->mergeClusteredVariants = 1; o->minFlank = 10; o->filterVarsByCoverage = 1; o->filteredReadsFrac = 0.7; o->maxVarDist = 15; o->minVarDist = 9;
+    o->useEMLikelihoods = 0; o->countOnlyExactIndelMatches = 0; o->calculateFlankScore = 0; o->assemble = 0; o->outputRefCalls = 0; o->minMapQual = 20;
+    o->minBaseQual = 20; o->minPosterior = 5; o->sbThreshold = 1e-3; o->scThreshold = 0.95; o->abThreshold = 1e-3; o->minVarFreq = 0.05;
+    o->badReadsWindow = 11; o->badReadsThreshold = 15; o->rmsmqThreshold = 40; o->qdThreshold = 10; o->hapScoreThreshold = 4;
+}
+
+CALLER_EXPORT int plat_caller_create(int device, int n_workers, int regions_per_chunk, plat_caller** out) {
+    if (!out || n_workers < 1) return PLAT_ERR_INVALID;
+    *out = nullptr;
+    std::unique_ptr<plat_caller> c(new plat_caller());
+    c->device = device; c->nWorkers = n_workers; c->regionsPerChunk = regions_per_chunk > 0 ? regions_per_chunk : 4;
+    for (int i = 0; i < n_workers; ++i) {
+        std::unique_ptr<Slot> s(new Slot());
+        int rc = plat_ctx_create(device, &s->ctx);
+        if (rc == PLAT_OK) rc = plat_stream_create(s->ctx, &s->stream);
+        if (rc != PLAT_OK) {
+            if (s->ctx) plat_ctx_destroy(s->ctx);
+            for (auto& q : c->slots) { plat_stream_destroy(q->ctx, q->stream); plat_ctx_destroy(q->ctx); }
+            return rc;
+        }
+        c->slots.push_back(std::move(s));
+    }
+    *out = c.release();
+    return PLAT_OK;
+}
+
+template <class... S> static void releaseAll(plat_ctx* ctx, S&... s) { (void)std::initializer_list<int>{(s.release(ctx), 0)...}; }
+
+CALLER_EXPORT int plat_caller_destroy(plat_caller* c) {
+    if (!c) return PLAT_ERR_INVALID;
+    for (auto& q : c->slots) {
+        Slot& z = *q;
+        releaseAll(z.ctx, z.t_seq, z.t_qual, z.t_mapq, z.t_off, z.t_pos, z.t_end, z.t_flags, z.t_cigoff, z.t_region, z.t_cigar, z.c_ref, z.c_refoff, z.c_rss,
+                   z.c_clen, z.c_rec, z.c_cnt, z.c_status, z.w_hapbegin, z.w_readbegin, z.w_start, z.w_end, z.w_flank, z.w_segbegin, z.w_ngood, z.w_src, z.g_pos,
+                   z.g_end, z.g_flags, z.o_calls, z.o_iters, z.o_hapscore, z.o_score, z.w_pairoff, z.w_hapoff, z.w_readoff, z.w_gloff, z.w_hapseq, z.w_kind, z.g_seq,
+                   z.g_qual, z.g_mapq, z.o_loglik, z.o_gl, z.o_logl, z.o_gof, z.o_freq, z.o_em, z.p_win, z.s_vw, z.s_pos, z.s_min, z.s_max, z.s_nadd, z.s_nrem,
+                   z.s_gb, z.s_ge, z.s_bb, z.s_be, z.s_ps, z.s_minq, z.s_nminq, z.k_win, z.k_nvar, z.k_vih, z.k_ref, z.k_ph, z.p_off, z.s_aoff, z.s_moff, z.s_counts,
+                   z.k_vo, z.k_ro, z.k_lo, z.p_mask, z.s_added, z.s_vig, z.p_prior, z.p_post, z.k_lik, z.k_out4);
+        plat_stream_destroy(z.ctx, z.stream);
+        plat_ctx_destroy(z.ctx);
+    }
+    delete c;
+    return PLAT_OK;
+}
+
+CALLER_EXPORT const char* plat_caller_last_error(const plat_caller* c) { return c ? c->lastError.c_str() : ""; }
+CALLER_EXPORT void plat_caller_free(void* p) { free(p); }
+
+CALLER_EXPORT int plat_call_regions(plat_caller* c, const plat_region* regions, int n_regions, int n_samples, const char* const* sample_names,
+                                    plat_caller_options* options, char** out_text, size_t* out_len, plat_caller_stats* stats)
+{
+    if (!c || !options || !out_text || !out_len || n_regions < 0 || n_samples < 1 || (n_regions > 0 && !regions)) return PLAT_ERR_INVALID;
+    *out_text = nullptr; *out_len = 0;
+    if (options->assemble || options->outputRefCalls || !options->getVariantsFromBAMs) {
+        c->lastError = "assemble=1, outputRefCalls=1 and getVariantsFromBAMs=0 are not built in the native region loop (use platypus_amd.caller)";
+        return PLAT_ERR_UNSUPPORTED;
+    }
+    const auto t0 = Clock::now();
+    plat_caller_stats st;
+    memset(&st, 0, sizeof st);
+    st.n_regions = n_regions;
+    Options o;
+    static_cast<plat_caller_options&>(o) = *options;
+    // per-region state; options.rlen follows the longest read of each region and is kept from the region before when a region has no
+    // reads (variantcaller.pyx:476-488)
+    std::vector<std::unique_ptr<RegionWork>> work;
+    int rlen = options->rlen;
+    for (int k = 0; k < n_regions; ++k) {
+        std::unique_ptr<RegionWork> r(new RegionWork());
+        r->in = &regions[k]; r->index = k;
+        r->fa.seq = regions[k].contig_seq; r->fa.len = regions[k].contig_len;
+        r->samples.resize((size_t)n_samples);
+        int longest = 0;
+        for (int i = 0; i < n_samples; ++i) {
+            const plat_sample_reads& sr = regions[k].samples[i];
+            SampleView& sv = r->samples[(size_t)i];
+            sv.reads.t = &sr.reads; sv.bad.t = &sr.bad_reads; sv.broken.t = &sr.broken_mates;
+            sv.reads.longest = longestRead(sr.reads); sv.bad.longest = longestRead(sr.bad_reads); sv.broken.longest = longestRead(sr.broken_mates);
+            longest = std::max(longest, sv.reads.longest);
+        }
+        if (longest > 0) rlen = longest >= options->maxSize ? options->maxSize : longest;
+        r->rlen = rlen;
+        work.push_back(std::move(r));
+    }
+    std::mutex stMutex, errMutex;
+    std::atomic<int> next(0);
+    int firstError = PLAT_OK;
+    std::string errText;
+    const int per = c->regionsPerChunk, nChunks = (n_regions + per - 1) / per;
+    auto worker = [&](Slot* slot) {
+        for (;;) {
+            const int ch = next.fetch_add(1);
+            if (ch >= nChunks) break;
+            { std::lock_guard<std::mutex> g(errMutex); if (firstError != PLAT_OK) break; }
+            Chunk chunk{*slot, o, n_samples, sample_names, {}, st, stMutex};
+            for (int k = ch * per; k < std::min(n_regions, (ch + 1) * per); ++k) chunk.regions.push_back(work[(size_t)k].get());
+            try {
+                chunk.run();
+            } catch (const DeviceError& e) {
+                std::lock_guard<std::mutex> g(errMutex);
+                if (firstError == PLAT_OK) { firstError = e.code; errText = e.what(); }
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> g(errMutex);
+                if (firstError == PLAT_OK) { firstError = PLAT_ERR_BAD_INPUT; errText = e.what(); }
+            }
+        }
+    };
+    const int nThreads = std::min<int>((int)c->slots.size(), std::max(1, nChunks));
+    std::vector<std::thread> threads;
+    for (int i = 1; i < nThreads; ++i) threads.emplace_back(worker, c->slots[(size_t)i].get());
+    worker(c->slots[0].get());
+    for (std::thread& t : threads) t.join();
+    if (firstError != PLAT_OK) { c->lastError = errText; return firstError; }
+    size_t total = 0;
+    for (auto& r : work) total += r->text.size();
+    char* text = (char*)malloc(total + 1);
+    if (!text) return PLAT_ERR_NOMEM;
+    size_t at = 0;
+    for (auto& r : work) { memcpy(text + at, r->text.data(), r->text.size()); at += r->text.size(); }
+    text[total] = 0;
+    *out_text = text; *out_len = total;
+    options->rlen = rlen;
+    st.seconds_total = secs(t0, Clock::now());
+    if (stats) *stats = st;
+    return PLAT_OK;
+}

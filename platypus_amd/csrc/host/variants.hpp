@@ -1,0 +1,352 @@
+// variants.hpp -- host logic between the candidate scan and the calling windows, native (libplat_caller.so).
+//
+//   Variant, ordering, addVariant                      src/cython/variant.pyx:100-146,261-268,282-363
+//   Variant.calculatePrior, indelPrior                 src/cython/variant.pyx:146-259
+//   annotate (tandem repeat tracts)                    src/c/tandem.c:11-262, src/cython/cerrormodel.pyx:23-36
+//   FastaFile.getSequence / getCharacter semantics     src/cython/fastafile.pyx:120-132,173-207
+//   leftNormaliseIndel                                 src/cython/platypusutils.pyx:806-931
+//   filterVariants, filterVariantsByCoverage           src/cython/variantFilter.pyx:98-171,571-622
+//   isHaplotypeValid                                   src/cython/platypusutils.pyx:735-802
+//   WindowGenerator                                    src/python/window.py:18-238
+//
+// Same results as platypus_amd/hostapi.py / regionprep.py / indelprior.py (the Python mirror of the same reference
+// functions, pinned by tests/golden/*): tests/test_native_caller_cpu.py compares the two function by function.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace plathost {
+
+constexpr int PLATYPUS_VAR = 1, FILE_VAR = 2, ASSEMBLER_VAR = 4;       // variant.pyx:43-45
+constexpr int SNP = 0, MNP = 1, INS = 2, DEL = 3, REP = 4;             // variant.pyx:49-53
+
+struct WindowError : std::runtime_error { using std::runtime_error::runtime_error; };   // what the reference's per-window try/except swallows
+
+// ---- FastaFile (in memory) ------------------------------------------------------------------------------------------------
+struct Fasta {
+    const uint8_t* seq = nullptr;
+    int64_t len = 0;                                                    // SeqLength
+    // fastafile.pyx:173-207: half-open, clamped to [0, len-1]; an empty or inverted interval after clamping raises there
+    std::string getSequence(int64_t beginPos, int64_t endPos) const {
+        beginPos = std::max<int64_t>(0, beginPos);
+        endPos = std::min<int64_t>(len - 1, endPos);
+        if (endPos < beginPos) throw WindowError("Cannot have beginPos > endPos in getSequence");
+        return std::string((const char*)seq + beginPos, (size_t)(endPos - beginPos));
+    }
+    char getCharacter(int64_t pos) const { return (pos >= len || pos < 0) ? '-' : (char)seq[pos]; }   // :120-132
+};
+
+// ---- Variant ----------------------------------------------------------------------------------------------------------------
+struct Variant {
+    int refPos = 0;
+    std::string removed, added;
+    int nRemoved = 0, nAdded = 0, nSupportingReads = 0, varSource = PLATYPUS_VAR;
+    int minRefPos = 0, maxRefPos = 0, bamMinPos = 0, bamMaxPos = 0, varType = SNP;
+    double prior = -1.0;                                                // cached calculatePrior (< 0: not yet)
+
+    Variant() {}
+    Variant(int pos, std::string rem, std::string add, int nSupp, int source) {
+        refPos = std::max(0, pos);
+        removed = std::move(rem); added = std::move(add);
+        nRemoved = (int)removed.size(); nAdded = (int)added.size();
+        nSupportingReads = nSupp; varSource = source;
+        minRefPos = refPos;
+        maxRefPos = std::max(refPos, refPos + nRemoved - 1);
+        bamMinPos = bamMaxPos = refPos;                                  // variant.pyx:125-126
+        if (nRemoved == nAdded) varType = nAdded == 1 ? SNP : MNP;
+        else if (nRemoved == 0) varType = INS;
+        else if (nAdded == 0) varType = DEL;
+        else varType = REP;
+    }
+    void addVariant(const Variant& o) {                                 // :261-268
+        nSupportingReads += o.nSupportingReads;
+        varSource |= o.varSource;
+        bamMinPos = std::min(bamMinPos, o.bamMinPos);
+        bamMaxPos = std::max(bamMaxPos, o.bamMaxPos);
+    }
+    bool same(const Variant& o) const { return refPos == o.refPos && added == o.added && removed == o.removed; }   // __eq__ within a contig
+};
+// Variant.__richcmp__ order within one contig: (refPos, varType, nRemoved); used with std::stable_sort (Python's sorted is stable)
+inline bool variantLess(const Variant* a, const Variant* b) {
+    if (a->refPos != b->refPos) return a->refPos < b->refPos;
+    if (a->varType != b->varType) return a->varType < b->varType;
+    return a->nRemoved < b->nRemoved;
+}
+typedef std::vector<Variant*> VarList;
+inline bool contains(const VarList& vs, const Variant* v) {
+    for (const Variant* x : vs) if (x == v || x->same(*v)) return true;
+    return false;
+}
+
+// ---- indel prior --------------------------------------------------------------------------------------------------------------
+namespace tandem {
+constexpr int MAX_UNIT_LENGTH = 12, MIN_PARTIAL_MATCH = 5;             // tandem.c:6-7
+inline int rate(int size, int displacement) {                            // tandem.c:61-70
+    if (displacement == 1) return -360 + 24 * size;
+    if (displacement == 2) return -327 + 15 * size;
+    if (displacement == 3) return -291 + 8 * size;
+    return -282 + 6 * size;
+}
+// per position the length of the local repeat tract and its unit length, as tandem.c's annotate() leaves them in the
+// `length < 0` ("markfull") mode calculate_size_and_displacement uses.  What the C code computes per start position p (group
+// start g = p & ~3) and unit d is the distance from p to the first mismatch between the sequence and itself shifted by d,
+// looking only as far as g + 64 (g + 32 when the shifted second word would start past the end).
+inline void annotate(const std::string& sequence, std::vector<int>& sizes, std::vector<int>& disps) {
+    const int L = (int)sequence.size();
+    sizes.assign(L, 1); disps.assign(L, 1);
+    if (L == 0) return;
+    const int ext = L + 80 + MAX_UNIT_LENGTH;
+    std::vector<int> code(ext + MAX_UNIT_LENGTH, 0);
+    for (int i = 0; i < L; ++i) {
+        const int b = sequence[i] & 0xDF;
+        const long long idx = i;
+        const int noise = (int)((((idx % 257) * (1 + idx % 257)) / 2 + (idx % 5)) % 4);
+        code[i] = b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : noise;
+    }
+    std::vector<std::vector<int>> nx(MAX_UNIT_LENGTH);
+    for (int d = 1; d < MAX_UNIT_LENGTH; ++d) {
+        nx[d].assign(ext + 1, ext);
+        for (int i = ext - 1; i >= 0; --i) nx[d][i] = code[i] != code[i + d] ? i : nx[d][i + 1];
+    }
+    for (int g = 0; g < L; g += 4)
+        for (int d = 1; d < MAX_UNIT_LENGTH; ++d) {
+            if (g + d >= L) break;
+            const bool second = g + d + 32 < L;
+            for (int k = 0; k < 4; ++k) {
+                const int p = g + k;
+                int m = nx[d][p] - g;                                    // first mismatch >= p, relative to the group
+                if (m > 31) m = second ? std::min(m, 64) : 32;
+                int size = m - k;
+                const int pos = p;
+                if (pos + d + size > L) size = L - d - pos;             // foundmatch (tandem.c:87-121)
+                size += d;
+                if (size < d + std::min(MIN_PARTIAL_MATCH, d)) continue;
+                if (pos >= L) continue;
+                if (rate(sizes[pos], disps[pos]) < rate(size, d)) {
+                    sizes[pos] = size; disps[pos] = d;
+                    for (int i = pos + 1; i < std::min(L, pos + size); ++i) { sizes[i] = size; disps[i] = d; }
+                }
+            }
+        }
+}
+}  // namespace tandem
+
+// phred+33 strings of the model, one per repeat-unit length (variant.pyx:68-91): entry [tract length - 1]
+inline const char* indel_prior_model(int disp) {
+    static const char* M[25] = {nullptr,
+        "LIGC@:62/-*'&%$",
+        "LIGDB@><9630.,+**)(''&&%%%$$$",
+        "LIGA@B@><;8763220/.-,+++)*))(((''''&&&&&&%%%%%%%%$$$$$$$",
+        "LIGA@?\?\?=<886533210/.--,+**))))((('''''&&&&&&&&%%%%%%%%%%%$$$$$$$$",
+        "LIGA@?\?>=>=;966543210///-,,++*",
+        "LIGA@?\?>>=<=;:764532210/----,++",
+        "LIGA@?\?>>==<;;987543210/....-,,,++++",
+        "LIGA@?\?>>==<<;9876432200/..--,,,+++",
+        "LIGA@?\?>>==<<;;9966432100//../..----,,,,,++++++",
+        "LIGA@?\?>>==<<;;:986432110//..----,,,,++++",
+        "LIGA@?\?>>==<<<;;:87642210////..--,,,,,+++",
+        "LIGA@?\?>>==<<<;;;:986532110000/...-----,,,,,+++++",
+        "LIGA@?\?>>==<<<;;;::987543111000/////.......--------,,,,,,,,,,,,,+++++++++",
+        "LIGA@?\?>>==<<<;;;::987642210/0/.....-------,,,,,,,,+++++++",
+        "LIGA@?\?>>==<<<;;;;::988754322110000////////.......------------,,,,,,,,,,,,,,,,,++++++++++",
+        "LIGA@?\?>>==<<<;;;;:::98765321110////........-------,,,,,,,,,,,,,,+++++++++",
+        "LIGA@?\?>>==<<<;;;;::::988764433211110000000///////.............-----------------,,,,,,,,,,,,,,,,,,,",
+        "LIGA@?\?>>==<<<;;;:::::998875433221111000000///////.............-----------------,,,,,,,,,,,,,,,,,,,",
+        "LIGA@?\?>>==<<<;;;;::::999887654433222221111111100000000//////////////..................------------",
+        "LIGA@?\?>>==<<<;;;;::::9999876543322111000000///////............-----------------,,,,,,,,,,,,,,,,,,,",
+        "LIGA@?\?>>==<<<;;;;::::9999988765544433322222221111111100000000000000//////////////////.............",
+        "LIGA@?\?>>==<<<;;;;::::9999987765432221000000////////...........-----------------,,,,,,,,,,,,,,,,,,,",
+        "LIGA@?\?>>==<<<;;;;::::9999998776543322111100000000////////................-------------------,,,,,,",
+        "LIGA@?\?>>==<<<;;;;::::9999998887654433322111111100000000/////////////...................-----------"};
+    return (disp >= 1 && disp <= 24) ? M[disp] : nullptr;
+}
+
+// variant.pyx:146-217: the smaller of the model's priors for the repeat tracts at the two bases next to the indel; for tracts
+// of length <= 3 a length-dependent prior for complex insertions / deletions instead
+inline double indelPrior(const Variant& v, const Fasta& fa, int indel_length_and_type) {
+    const int context = 100;
+    const int leftPos = std::max(0, v.refPos - context), rightPos = v.refPos + context, rel = v.refPos - leftPos;
+    std::string sequence;
+    try { sequence = fa.getSequence(leftPos + 1, rightPos + 1); } catch (const WindowError&) { sequence.clear(); }
+    std::vector<int> sizes, disps;
+    tandem::annotate(sequence, sizes, disps);
+    int prior = indel_prior_model(1)[0] - 33, tract = 255;
+    for (int i : {rel - 1, rel}) {
+        const int disp = (i >= 0 && i < (int)disps.size()) ? disps[i] : 0;
+        const char* model = indel_prior_model(disp);
+        if (model) {
+            const int size = std::min(sizes[i], (int)strlen(model));
+            const int q = model[size - 1] - 33;
+            if (q < prior) { prior = q; tract = size; }
+        }
+    }
+    double dprior = pow(0.1, prior / 10.0);
+    if (tract <= 3) {
+        const int n = indel_length_and_type;
+        if (n < 0) dprior = 5e-5 * pow(0.75, (-n) - 1) * (1.0 - 0.75);                      // complex_deletion_prior, variant.pyx:94
+        else dprior = 5e-6 * pow(0.75, n - 1) * (1.0 - 0.75) * pow(0.33, n);                // complex_insertion_prior, :95
+    }
+    return dprior;
+}
+
+inline double calculatePrior(Variant& v, const Fasta& fa) {                                // variant.pyx:219-259
+    if (v.prior >= 0) return v.prior;
+    double prior;
+    if (v.nAdded == 1 && v.nRemoved == 1) prior = 1e-3 / 3;
+    else if (v.nAdded == v.nRemoved) {
+        int nDiffs = 0;
+        for (int i = 0; i < v.nAdded; ++i) nDiffs += v.added[i] != v.removed[i];
+        prior = 5e-5 * pow(0.1, nDiffs - 1) * (1.0 - 0.1);
+    } else if (v.nAdded > 0 && v.nRemoved == 0) prior = indelPrior(v, fa, v.nAdded);
+    else if (v.nAdded == 0 && v.nRemoved > 0) prior = indelPrior(v, fa, -v.nRemoved);
+    else prior = 5e-6;
+    v.prior = std::max(prior, 1e-10);
+    return v.prior;
+}
+
+// ---- leftNormaliseIndel (platypusutils.pyx:806-931) --------------------------------------------------------------------------
+// Returns the variant itself, or a new one allocated in `pool`.
+template <class Pool>
+inline Variant* leftNormaliseIndel(Variant* variant, const Fasta& fa, int maxReadLength, Pool& pool) {
+    const int nAdded = variant->nAdded, nRemoved = variant->nRemoved;
+    if (nAdded == nRemoved || (nAdded > 0 && nRemoved > 0) || variant->refPos < 100) return variant;
+    const int window = std::max(nAdded, nRemoved) + maxReadLength;
+    const int64_t seqMax = fa.len - 1;
+    const int64_t windowMin = std::max<int64_t>(1, variant->refPos - window), windowMax = std::min<int64_t>(variant->refPos + window, seqMax);
+    const std::string ref = fa.getSequence(windowMin, windowMax);
+    const int cut = (int)(variant->refPos - windowMin);
+    auto slice = [](const std::string& s, int64_t a, int64_t b) -> std::string {            // Python s[a:b] for a, b >= 0
+        a = std::min<int64_t>(a, (int64_t)s.size()); b = std::min<int64_t>(b, (int64_t)s.size());
+        return b > a ? s.substr((size_t)a, (size_t)(b - a)) : std::string();
+    };
+    const std::string hap = slice(ref, 0, cut + 1) + variant->added + slice(ref, cut + nRemoved + 1, (int64_t)ref.size());
+    if (hap.empty() || ref.empty()) throw WindowError("Variant not correctly normalised (empty context)");
+    if (hap.back() != ref.back() && windowMax != seqMax) throw WindowError("Variant not correctly normalised");
+    const int n = (int)std::min(ref.size(), hap.size());
+    int fwd = n;
+    for (int i = 0; i < n; ++i) if (hap[i] != ref[i]) { fwd = i; break; }                    // rightmost placement: first mismatch from the left
+    const int maxPos = (int)(windowMin + fwd + nRemoved);
+    for (int back = 0; back < n; ++back) {                                                     // leftmost: first mismatch from the right
+        if (hap[hap.size() - back - 1] == ref[ref.size() - back - 1]) continue;
+        const int newPos = (int)(windowMin + (int64_t)ref.size() - back - nRemoved - 1);
+        const int64_t first = newPos - windowMin + 1;
+        if (first < 0) throw WindowError("Error in variant conversion to standard format");
+        const std::string newAdded = nAdded > 0 ? slice(hap, first, first + nAdded) : std::string();
+        const std::string newRemoved = nRemoved > 0 ? slice(ref, first, first + nRemoved) : std::string();
+        if ((int)newAdded.size() != nAdded || (int)newRemoved.size() != nRemoved) throw WindowError("Error in variant conversion to standard format");
+        Variant* out = pool.make(newPos, newRemoved, newAdded, variant->nSupportingReads, variant->varSource);
+        out->bamMinPos = newPos; out->bamMaxPos = maxPos;
+        return out;
+    }
+    return variant;
+}
+
+// ---- filterVariants (variantFilter.pyx:98-171) ---------------------------------------------------------------------------------
+inline bool onlyFromReads(int source) { return (source & PLATYPUS_VAR) && !(source & ASSEMBLER_VAR) && !(source & FILE_VAR); }
+
+inline VarList filterVariants(const VarList& varList, int minSupport, int optMinReads, int optMaxSize) {
+    VarList kept;
+    Variant* last = nullptr;
+    for (Variant* v : varList) {
+        if (!last) last = v;
+        else if (v->same(*last)) last->addVariant(*v);
+        else {
+            const int size = std::max(last->nAdded, last->nRemoved);
+            const bool weak = onlyFromReads(last->varSource) && ((last->nSupportingReads < minSupport && size < 15) ||
+                                                                 (last->nSupportingReads < optMinReads && size >= 15));
+            if (!weak && size <= optMaxSize) kept.push_back(last);
+            last = v;
+        }
+    }
+    if (last && !(last->nSupportingReads < minSupport && onlyFromReads(last->varSource))) kept.push_back(last);
+    std::stable_sort(kept.begin(), kept.end(), variantLess);
+    return kept;
+}
+
+// keep the maxVariants best supported variants of an over-full window (assembler-only variants first), variantFilter.pyx:571-622
+inline VarList filterVariantsByCoverage(const VarList& variants, int maxVariants) {
+    int top = 0;
+    for (const Variant* v : variants) top = std::max(top, v->nSupportingReads);
+    // Python: sorted(((rank, v) ...), reverse=True) on (rank, Variant) tuples: descending by rank, ties by Variant order descending,
+    // ties of that keep their relative order (reverse=True preserves the original order of equal elements)
+    struct Item { int rank; Variant* v; };
+    std::vector<Item> items;
+    for (Variant* v : variants) items.push_back({v->varSource == ASSEMBLER_VAR ? top + 1 : v->nSupportingReads, v});
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
+        if (a.rank != b.rank) return a.rank > b.rank;
+        return variantLess(b.v, a.v);
+    });
+    VarList out;
+    for (size_t i = 0; i < items.size() && (int)i < maxVariants; ++i) out.push_back(items[i].v);
+    std::stable_sort(out.begin(), out.end(), variantLess);
+    return out;
+}
+
+// platypusutils.pyx:735-802: variants (sorted by co-ordinate) must not overlap
+inline bool isHaplotypeValid(const VarList& variants) {
+    const size_t n = variants.size();
+    if (n <= 1) return true;
+    for (size_t i = 0; i + 1 < n; ++i) {
+        const Variant* a = variants[i], *b = variants[i + 1];
+        if (a->minRefPos > b->minRefPos) throw WindowError("Variants out of order in haplotype!");
+        if (a->maxRefPos > b->minRefPos) return false;
+        if (a->maxRefPos == b->minRefPos) {
+            if (a->nAdded == a->nRemoved && b->nAdded != b->nRemoved) continue;               // :790-799
+            return false;
+        }
+    }
+    return true;
+}
+
+// ---- WindowGenerator (window.py:18-238) -----------------------------------------------------------------------------------------
+struct Window { int startPos, endPos; VarList variants; };
+
+struct WindowOptions { int mergeClusteredVariants, maxVarDist, minVarDist, maxSize, largeWindows, rlen, maxVariants; };
+
+inline std::vector<Window> windowsAndVariants(int start, int end, int64_t maxContigPos, const VarList& sortedVariants, const WindowOptions& o) {
+    // getVariantsByPos: groups of equal refPos, ascending
+    std::vector<VarList> byPos;
+    {
+        std::vector<std::pair<int, Variant*>> in;
+        for (Variant* v : sortedVariants) if (start <= v->refPos && v->refPos < end) in.push_back({v->refPos, v});
+        std::stable_sort(in.begin(), in.end(), [](const std::pair<int, Variant*>& a, const std::pair<int, Variant*>& b) { return a.first < b.first; });
+        for (auto& pv : in) {
+            if (byPos.empty() || byPos.back().front()->refPos != pv.first) byPos.emplace_back();
+            byPos.back().push_back(pv.second);
+        }
+    }
+    auto minOf = [](const VarList& g) { int m = g[0]->minRefPos; for (const Variant* v : g) m = std::min(m, v->minRefPos); return m; };
+    auto maxOf = [](const VarList& g) { int m = g[0]->maxRefPos; for (const Variant* v : g) m = std::max(m, v->maxRefPos); return m; };
+    std::vector<VarList> bunches;
+    for (VarList& group : byPos) {
+        if (bunches.empty()) { bunches.push_back(group); continue; }
+        const int lastMin = minOf(bunches.back()), lastMax = maxOf(bunches.back());
+        const int thisMin = minOf(group), thisMax = maxOf(group);
+        const int gap = thisMin - lastMax;
+        bool merge;
+        if (lastMax >= thisMin) merge = true;                                                // overlapping variants always share a window
+        else if (!o.mergeClusteredVariants || gap >= o.maxVarDist) merge = false;
+        else if (thisMax - lastMin > (o.largeWindows == 1 ? o.maxSize : o.rlen)) merge = false;
+        else if ((int)(bunches.back().size() + group.size()) <= o.maxVariants) merge = true;
+        else merge = gap < o.minVarDist;                                                      // too many variants: split only at a wide gap
+        if (merge) bunches.back().insert(bunches.back().end(), group.begin(), group.end());
+        else bunches.push_back(group);
+    }
+    std::vector<Window> out;
+    for (VarList& vs : bunches) {
+        const int lo = minOf(vs), hi = maxOf(vs);
+        Window w;
+        w.startPos = std::max(lo - o.minVarDist, start);
+        w.endPos = (int)std::min<int64_t>(hi + o.minVarDist, maxContigPos);
+        w.variants = vs;
+        out.push_back(std::move(w));
+    }
+    return out;
+}
+
+}  // namespace plathost

@@ -116,7 +116,8 @@ class AssemblyDeviceBatch:
 
     def results(self):
         """[syncs] per region the list of (pos, removed, added) in the reference's sorted() order."""
-        _torch().cuda.synchronize(self.device)
+        if self.device.type == "cuda":
+            _torch().cuda.synchronize(self.device)
         cnt, status, pos, nrem, nadd, off = (x.cpu().numpy() for x in (self.cnt, self.status, self.pos, self.nrem, self.nadd, self.off))
         blob = self.blob.cpu().numpy()
         out = []
@@ -160,6 +161,9 @@ class Engine:
     def _stream(self):
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
+    def _sync(self):
+        _torch().cuda.synchronize(self.device)
+
     # ---- a1 --------------------------------------------------------------------------------------
     def dp_batch(self, haps, reads, quals, gos, lens, gapextend=3, nucprior=2):
         """Score-only fastAlignmentRoutine for padded rows (numpy in, numpy out)."""
@@ -172,7 +176,7 @@ class Engine:
         _lib.check(self.lib.plat_dp_batch(self.ctx, n, lmax, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
                                           d[3].data_ptr(), dl.data_ptr(), gapextend, nucprior, out.data_ptr(),
                                           self._stream()), "plat_dp_batch")
-        torch.cuda.synchronize(self.device)
+        self._sync()
         return out.cpu().numpy()
 
     # ---- a3..a10 ---------------------------------------------------------------------------------
@@ -231,7 +235,7 @@ class Engine:
                                                  db.t["seg_n_good"].data_ptr(), db.loglik.data_ptr(), like.data_ptr(),
                                                  score.data_ptr(), self._stream())
         _lib.check(rc, "plat_haplotype_score_batch")
-        torch.cuda.synchronize(self.device)
+        self._sync()
         return like.cpu().numpy()[:hb.n_haps], score.cpu().numpy()[:hb.n_windows]
 
     def em(self, db, max_iters=100, use_em_likelihoods=0):
@@ -271,7 +275,7 @@ class Engine:
                                                    db.gl.data_ptr(), db.freq.data_ptr(), d_w.data_ptr(), d_off.data_ptr(),
                                                    d_blob.data_ptr(), d_pr.data_ptr(), out.data_ptr(), self._stream())
         _lib.check(rc, "plat_variant_posterior_batch")
-        torch.cuda.synchronize(self.device)
+        self._sync()
         return out.cpu().numpy()
 
     def genotype_calls(self, db, sites):
@@ -305,7 +309,7 @@ class Engine:
                                                d_ro.data_ptr(), d_vih.data_ptr(), d_ref.data_ptr(), d_lo.data_ptr(),
                                                ph.data_ptr(), lik.data_ptr(), out4.data_ptr(), self._stream())
         _lib.check(rc, "plat_genotype_call_batch")
-        torch.cuda.synchronize(self.device)
+        self._sync()
         ph, lik, out4 = ph.cpu().numpy().reshape(nS, hb.n_ind, 2), lik.cpu().numpy(), out4.cpu().numpy().reshape(nS, hb.n_ind, 4)
         return [(ph[s], lik[lik_off[s]:lik_off[s + 1]].reshape(hb.n_ind, int(NL[s])), out4[s]) for s in range(nS)]
 
@@ -351,7 +355,7 @@ class Engine:
             rc = self.lib.plat_candidates_batch(self.ctx, C.byref(b), min_flank, min_base_qual, gen_snps, gen_indels, max_per_read,
                                                 t["region_of"].data_ptr(), rec.data_ptr(), cnt.data_ptr(), stt.data_ptr(), self._stream())
             _lib.check(rc, "plat_candidates_batch")
-            torch.cuda.synchronize(self.device)
+            self._sync()
             cnt_h, st_h = cnt.cpu().numpy(), stt.cpu().numpy()
             if (st_h == -9).any():
                 raise _lib.PlatypusDeviceError(-9, "a read reaches outside the reference window handed over", "plat_candidates_batch")
@@ -402,7 +406,7 @@ class Engine:
         why = torch.empty(n, dtype=torch.int32, device=self.device)
         _lib.check(self.lib.plat_read_qc_batch(self.ctx, C.byref(b), C.byref(o), ok.data_ptr(), why.data_ptr(), self._stream()),
                    "plat_read_qc_batch")
-        torch.cuda.synchronize(self.device)
+        self._sync()
         ok_h, why_h, fl_h, q_h = ok.cpu().numpy(), why.cpu().numpy(), t["flags"].cpu().numpy(), qual.cpu().numpy()
         out, a = [], 0
         for st in streams:
@@ -462,7 +466,7 @@ class Engine:
         nmq = torch.empty(nV, dtype=torch.int32, device=self.device)
         _lib.check(self.lib.plat_variant_read_stats_batch(self.ctx, C.byref(b), bad_reads_window, exact, out.data_ptr(), ps.data_ptr(),
                                                           mq.data_ptr(), nmq.data_ptr(), self._stream()), "plat_variant_read_stats_batch")
-        torch.cuda.synchronize(self.device)
+        self._sync()
         out_h, ps_h, mq_h, nmq_h = out.cpu().numpy().reshape(nV, 16), ps.cpu().numpy().reshape(nV, nI, 2), mq.cpu().numpy(), nmq.cpu().numpy()
         res = [[] for _ in windows]
         for v in range(nV):
@@ -518,4 +522,4 @@ class Engine:
     def synchronize(self):
         """Waits for the stream and raises the first error an asynchronous call recorded since the last synchronize()."""
         _lib.check(self.lib.plat_stream_sync(self.ctx, self._stream()), "plat_stream_sync")
-        _torch().cuda.synchronize(self.device)
+        self._sync()

@@ -345,3 +345,114 @@ def config3(n_regions=2000, seed=3003, ref_len=4500, tile=1500, read_len=250, de
                 ref_start=np.array(ref_start, dtype=np.int32), assem_start=np.array(a0s, dtype=np.int32),
                 assem_end=np.array(a1s, dtype=np.int32), reg_read_begin=np.concatenate([[0], np.cumsum(nreads)]).astype(np.int32),
                 read_seq=seq.reshape(-1), read_qual=qual.reshape(-1), read_off=np.arange(nR + 1, dtype=np.int64) * read_len, truth=truth)
+
+
+def config4_region_arrays(index, seed=4004, region_len=100000, n_samples=1, depth=30, read_len=150, snp_rate=1e-3, indel_rate=1e-4,
+                          flank=1000, err=1e-3):
+    """One region of BASELINE config 4 as ARRAYS (the form a BAM loader leaves reads in, and what the native region loop takes):
+    the same recipe as config4_region -- own contig `r<index>`, SNPs at snp_rate and 1..10 bp indels at indel_rate, a diploid donor
+    per sample, `depth`x reads of read_len with the CIGAR an aligner would report, 0.1 % substitution errors, qualities ~ clipped
+    N(35, 5), mapq 60 -- generated with array operations (a 100 kb region at 30x in a fraction of a second), so the draws differ
+    from config4_region's.  Returns dict(chrom, start, end, ref (uint8 array), variants [(pos, removed, added)], samples = [dict(seq,
+    qual, off, pos, end, mapq, flags, mate_pos, cigar, cig_off)] sorted by position, truth)."""
+    rng = np.random.Generator(np.random.PCG64([seed, index, 7]))
+    n = region_len + 2 * flank
+    ref = _rand_bases(rng, n)
+    start, end = flank, flank + region_len
+    n_snp, n_indel = int(rng.poisson(region_len * snp_rate)), int(rng.poisson(region_len * indel_rate))
+    kinds = np.array([0] * n_snp + [1] * n_indel)
+    rng.shuffle(kinds)
+    spots = np.sort(rng.choice(np.arange(start + 20, end - 40), size=min(len(kinds), max(0, region_len - 60)), replace=False))
+    variants, last = [], start + 20                                              # (pos, kind, length, bases): kind 0 SNP, 1 insertion, 2 deletion
+    for p, kd in zip(spots.tolist(), kinds.tolist()):
+        if p < last:
+            continue
+        if kd == 0:
+            variants.append((p, 0, 1, _other_base(rng, ref[p:p + 1])))
+            last = p + 2
+        else:
+            k = 1 + int(min(9, rng.geometric(0.4) - 1))
+            if rng.random() < 0.5:
+                variants.append((p, 1, k, _rand_bases(rng, k)))
+                last = p + 3
+            else:
+                variants.append((p, 2, k, None))
+                last = p + k + 3
+    out_vars = [(p, bytes(ref[p:p + 1]) if kd == 0 else (b"" if kd == 1 else bytes(ref[p + 1:p + 1 + k])),
+                 bytes(b) if kd != 2 else b"") for p, kd, k, b in variants]
+    samples, truth = [], []
+    n_reads = int(depth * region_len / read_len)
+    L = read_len
+    for _ in range(n_samples):
+        carry = rng.random((2, len(variants))) < 0.5
+        truth.append(carry.sum(axis=0).astype(int).tolist())
+        haps = []
+        for h in range(2):
+            parts, maps, cur = [], [], 0
+            for (p, kd, k, b), c in zip(variants, carry[h].tolist()):
+                if not c:
+                    continue
+                if kd == 0:
+                    parts += [ref[cur:p], b]; maps += [np.arange(cur, p, dtype=np.int32), np.array([p], dtype=np.int32)]; cur = p + 1
+                elif kd == 1:                                                    # insertion after the base at p
+                    parts += [ref[cur:p + 1], b]; maps += [np.arange(cur, p + 1, dtype=np.int32), np.full(k, -1, dtype=np.int32)]; cur = p + 1
+                else:                                                            # deletion of ref[p+1 : p+1+k]
+                    parts += [ref[cur:p + 1]]; maps += [np.arange(cur, p + 1, dtype=np.int32)]; cur = p + 1 + k
+            parts.append(ref[cur:]); maps.append(np.arange(cur, n, dtype=np.int32))
+            hs, h2r = np.concatenate(parts), np.concatenate(maps)
+            r2h = np.full(n + 1, len(hs), dtype=np.int64)
+            m = np.nonzero(h2r >= 0)[0]
+            r2h[h2r[m]] = m
+            r2h = np.minimum.accumulate(r2h[::-1])[::-1]                         # a deleted reference base maps to the next base that exists
+            haps.append((hs, h2r, r2h))
+        which = rng.integers(0, 2, size=n_reads)
+        p0 = rng.integers(start - L + 10, end - 10, size=n_reads)
+        seq = np.empty((n_reads, L), dtype=np.uint8)
+        refpos = np.empty((n_reads, L), dtype=np.int32)
+        for h in range(2):
+            hs, h2r, r2h = haps[h]
+            sel = np.nonzero(which == h)[0]
+            i0 = np.minimum(r2h[p0[sel]], len(hs) - L)
+            idx = i0[:, None] + np.arange(L)[None, :]
+            seq[sel] = hs[idx]
+            refpos[sel] = h2r[idx]
+        pos = refpos[:, 0].astype(np.int32)                                      # (the first base of a read is a reference base by construction)
+        simple = (refpos[:, -1] - refpos[:, 0] == L - 1) & (refpos.min(axis=1) >= 0)
+        endp = np.where(simple, pos + L, 0).astype(np.int32)
+        cigs = [None] * n_reads
+        for r_ in np.nonzero(~simple)[0].tolist():
+            rp = refpos[r_]
+            ops, lastref = [], None
+            for x in rp.tolist():
+                if x < 0:
+                    op, ln = 1, 1
+                else:
+                    if lastref is not None and x - lastref > 1:
+                        ops.append((2, x - lastref - 1))
+                    op, ln, lastref = 0, 1, x
+                if ops and ops[-1][0] == op:
+                    ops[-1] = (op, ops[-1][1] + ln)
+                else:
+                    ops.append((op, ln))
+            cigs[r_] = ops
+            endp[r_] = lastref + 1
+        e = rng.random(seq.shape, dtype=np.float32) < err
+        seq[e] = _other_base(rng, seq[e])
+        qual = rng.standard_normal(seq.shape, dtype=np.float32)
+        qual *= 5.0
+        qual += 35.5
+        np.clip(qual, 2, 41.5, out=qual)
+        qual = qual.astype(np.uint8)
+        flags = (3 | (16 * (rng.random(n_reads) < 0.5))).astype(np.int32)
+        order = np.argsort(pos, kind="stable")
+        ncig = np.array([1 if c is None else len(c) for c in cigs], dtype=np.int64)[order]
+        cig_off = np.concatenate([[0], np.cumsum(ncig)]).astype(np.int32)
+        cigar = np.zeros((int(cig_off[-1]), 2), dtype=np.int16)
+        cigar[cig_off[:-1], 1] = L                                               # default: one match of the whole read
+        for k_, r_ in enumerate(order.tolist()):
+            if cigs[r_] is not None:
+                cigar[cig_off[k_]:cig_off[k_ + 1]] = np.array(cigs[r_], dtype=np.int16)
+        samples.append(dict(seq=seq[order].reshape(-1), qual=qual[order].reshape(-1), off=np.arange(n_reads + 1, dtype=np.int64) * L,
+                            pos=pos[order], end=endp[order], mapq=np.full(n_reads, 60, dtype=np.uint8), flags=flags[order],
+                            mate_pos=np.full(n_reads, -1, dtype=np.int32), cigar=cigar.reshape(-1), cig_off=cig_off))
+    return dict(chrom="r%d" % index, start=start, end=end, ref=ref, variants=out_vars, samples=samples, truth=truth)

@@ -70,3 +70,45 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
                 txt = open(os.path.join(dp, f)).read()
                 assert not bad.search(txt), (dp, f)
+
+
+def test_caller_library_builds_and_matches_its_header(tmp_path):
+    """libplat_caller.so (the native region loop, include/platypus_caller.h): builds, links against the device library only,
+    exports every declared symbol, and the ctypes mirrors of its structs have the header's layout."""
+    from platypus_amd import fastcaller as F
+    F.build()
+    lib = C.CDLL(F.LIB_PATH)
+    text = open(os.path.join(ROOT, "include", "platypus_caller.h")).read()
+    declared = set(re.findall(r"\b(plat_call[a-z0-9_]*)\s*\(", text))
+    assert declared == {"plat_caller_default_options", "plat_caller_create", "plat_caller_destroy", "plat_call_regions", "plat_caller_free",
+                        "plat_caller_last_error"}
+    for name in declared:
+        assert hasattr(lib, name), name
+    needed = subprocess.check_output(["readelf", "-d", F.LIB_PATH], text=True)
+    assert "libplat_mi355x.so" in needed and "orc" not in needed and "fake" not in needed
+    src = tmp_path / "lay.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "platypus_caller.h"
+int main(void){
+  printf("%zu %zu %zu %zu %zu\n", sizeof(plat_read_table), sizeof(plat_sample_reads), sizeof(plat_region), sizeof(plat_caller_options), sizeof(plat_caller_stats));
+  printf("%zu %zu %zu %zu\n", offsetof(plat_caller_options, maxReads), offsetof(plat_caller_options, filteredReadsFrac),
+         offsetof(plat_caller_options, sbThreshold), offsetof(plat_caller_options, hapScoreThreshold));
+  plat_caller_options o; plat_caller_default_options(&o);
+  printf("%d %d %d %d\n", o.rlen, o.maxVariants, o.minPosterior, o.badReadsWindow);
+  return 0; }''')
+    exe = tmp_path / "lay"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L" + os.path.dirname(F.LIB_PATH), "-lplat_caller",
+                           "-lplat_mi355x", "-Wl,-rpath," + os.path.dirname(F.LIB_PATH)])
+    vals = list(map(int, subprocess.check_output([str(exe)], text=True).split()))
+    O = F.CallerOptions
+    assert vals[:5] == [C.sizeof(F._ReadTable), C.sizeof(F._SampleReads), C.sizeof(F._Region), C.sizeof(O), C.sizeof(F.CallerStats)]
+    assert vals[5:9] == [O.maxReads.offset, O.filteredReadsFrac.offset, O.sbThreshold.offset, O.hapScoreThreshold.offset]
+    assert vals[9:] == [150, 8, 5, 11]
+    from platypus_amd.options import default_options
+    o = O.from_options(default_options())
+    d = O()
+    lib.plat_caller_default_options.argtypes = [C.POINTER(O)]
+    lib.plat_caller_default_options(C.byref(d))
+    assert all(getattr(o, k) == getattr(d, k) for k, _ in O._fields_ if k != "_pad")

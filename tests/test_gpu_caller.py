@@ -173,3 +173,75 @@ def test_batched_caller_uses_each_regions_own_read_length():
     caller.callVariantsInRegions([(r["chrom"], r["start"], r["end"], buffers(r)) for r in regs], fasta, opts2, VCF(names), many)
     assert one.getvalue() == many.getvalue() and one.getvalue().count("\n") > 20
     assert opts2.rlen == seen[-1]
+
+
+def _array_regions(n, ns, **kw):
+    from platypus_amd import fastcaller as F
+    regs = [synth.config4_region_arrays(500 + i, n_samples=ns, **kw) for i in range(n)]
+    names = ["S%d" % (i + 1) for i in range(ns)]
+    fasta = H.FastaFile({r["chrom"]: r["ref"].tobytes() for r in regs})
+    work = [(r["chrom"], r["start"], r["end"], [H.bamReadBuffer(F.aligned_reads_from_arrays(s), sample=names[i]) for i, s in enumerate(r["samples"])])
+            for r in regs]
+    return regs, names, fasta, work
+
+
+def test_native_region_loop_equals_python_region_loop_on_the_device():
+    """libplat_caller.so (host threads + batched device stages) writes the text platypus_amd.caller writes: 8 regions x 20 kb, two
+    samples, indels, several chunks in flight on several workers."""
+    from platypus_amd import fastcaller as F
+    regs, names, fasta, work = _array_regions(8, 2, region_len=20000, snp_rate=2e-3, indel_rate=4e-4, read_len=150, depth=30)
+    o1, o2 = default_options(), default_options()
+    py = io.StringIO()
+    nw = caller.callVariantsInRegions(work, fasta, o1, VCF(names), py)
+    nc = F.NativeCaller(0, 4, 2)
+    txt = nc.call_regions([F.region_from_arrays(r) for r in regs], names, o2)
+    assert txt == py.getvalue() and nc.stats["n_windows"] == nw and txt.count("\n") > 200
+    # and again from the same caller object (scratch buffers re-used), one region per chunk
+    nc2 = F.NativeCaller(0, 3, 1)
+    assert nc2.call_regions([F.region_from_arrays(r) for r in regs], names, default_options()) == txt
+    assert nc.call_regions([F.region_from_arrays(r) for r in regs[:3]], names, default_options()) == "".join(
+        ln + "\n" for ln in txt.split("\n")[:-1] if ln.split("\t")[0] in {r["chrom"] for r in regs[:3]})
+
+
+def test_native_region_loop_greedy_windows_and_read_classes_on_the_device():
+    """Dense variants (greedy haplotype filter rounds on the device), badReads and brokenMates."""
+    from platypus_amd import fastcaller as F
+    rng = np.random.default_rng(4)
+    regs = [synth.config4_region(600 + i, n_samples=2, region_len=2500, snp_rate=6e-2, indel_rate=8e-3, read_len=100, depth=30) for i in range(3)]
+    names = ["A", "B"]
+    fasta = H.FastaFile({r["chrom"]: r["ref"] for r in regs})
+    work = []
+    for r in regs:
+        bufs = []
+        for i, reads in enumerate(r["samples"]):
+            good, bad, broken = [], [], []
+            for x in reads:
+                a = H.AlignedRead(x["seq"], x["qual"], x["pos"], x["mapq"], x["flag"], end=x["end"], cigarOps=x["cigar"])
+                u = rng.random()
+                if u < 0.06:
+                    a.mapq = 5; a.bitFlag |= 512; bad.append(a)
+                elif u < 0.1:
+                    a.matePos = a.pos + int(rng.integers(-300, 300)); broken.append(a)
+                else:
+                    good.append(a)
+            bufs.append(H.bamReadBuffer(good, bad, broken, sample=names[i]))
+        work.append((r["chrom"], r["start"], r["end"], bufs))
+    py = io.StringIO()
+    caller.callVariantsInRegions(work, fasta, default_options(), VCF(names), py)
+    nc = F.NativeCaller(0, 2, 2)
+    txt = nc.call_regions([F.RegionReads.from_buffers(c, s, e, fasta, b) for c, s, e, b in work], names, default_options())
+    assert txt == py.getvalue() and nc.stats["n_windows_greedy"] > 10
+
+
+def test_fake_device_of_the_cpu_suite_agrees_with_the_device():
+    """tests/fakedev (the C ABI implemented with the oracle, what the CPU suite runs the region loop on) gives the text the HIP
+    library gives -- the whole device share of the region pipeline against the oracle, through the records."""
+    import ctypes as C
+    from platypus_amd import fastcaller as F
+    from tests import fakedev
+    regs, names, fasta, work = _array_regions(3, 2, region_len=5000, snp_rate=4e-3, indel_rate=1e-3, read_len=150, depth=30)
+    nc = F.NativeCaller(0, 2, 2)
+    real = nc.call_regions([F.region_from_arrays(r) for r in regs], names, default_options())
+    nf = F.NativeCaller(0, 2, 2, lib=fakedev.fake_caller_lib())
+    fake = nf.call_regions([F.region_from_arrays(r) for r in regs], names, default_options())
+    assert real == fake and real.count("\n") > 30

@@ -1,0 +1,139 @@
+"""The region loop's HOST logic, end to end on the CPU: platypus_amd.caller (Python mirror of the reference's
+callVariantsInRegion) and the native libplat_caller.so (platypus_amd/csrc/host) must write the same VCF record text.
+
+No GPU here, so both run on tests/fakedev: the C ABI of include/platypus_mi355x.h implemented with the parity oracle (test
+infrastructure only; the product binds the HIP library and has no CPU path).  The GPU suite repeats the comparison on the real
+device (tests/test_gpu_caller.py) and checks the fake against it."""
+import io
+
+import numpy as np
+import pytest
+
+from platypus_amd import caller, fastcaller as F, hostapi as H, synth
+from platypus_amd.options import default_options
+from platypus_amd.vcfrecords import VCF
+
+
+@pytest.fixture(scope="module")
+def fake():
+    from tests import fakedev
+    old = H._engine
+    H._engine = fakedev.fake_engine()
+    yield fakedev.fake_caller_lib()
+    H._engine = old
+
+
+def _work(regs, names, extra=None):
+    fasta = H.FastaFile({r["chrom"]: r["ref"] for r in regs})
+    out = []
+    for k, r in enumerate(regs):
+        bufs = []
+        for i, reads in enumerate(r["samples"]):
+            rs = [H.AlignedRead(x["seq"], x["qual"], x["pos"], x["mapq"], x["flag"], end=x["end"], cigarOps=x["cigar"], matePos=x.get("matePos", -1))
+                  for x in reads]
+            good, bad, broken = rs, [], []
+            if extra:
+                good, bad, broken = extra(k, i, rs)
+            bufs.append(H.bamReadBuffer(good, bad, broken, sample=names[i]))
+        out.append((r["chrom"], r["start"], r["end"], bufs))
+    return fasta, out
+
+
+def _both(lib, regs, names, extra=None, workers=2, per_chunk=2, **opt):
+    fasta, work = _work(regs, names, extra)
+    o1 = default_options(**opt)
+    py = io.StringIO()
+    nw = caller.callVariantsInRegions(work, fasta, o1, VCF(names), py)
+    nc = F.NativeCaller(0, workers, per_chunk, lib=lib)
+    o2 = default_options(**opt)
+    txt = nc.call_regions([F.RegionReads.from_buffers(c, s, e, fasta, b) for c, s, e, b in work], names, o2)
+    st = nc.stats
+    nc.close()
+    assert txt.split("\n") == py.getvalue().split("\n")
+    assert o1.rlen == o2.rlen and st["n_windows"] == nw and st["n_records"] == txt.count("\n")
+    return txt, st
+
+
+def test_native_equals_python_one_and_three_samples(fake):
+    for ns, n, kw in ((1, 3, dict(region_len=4000, snp_rate=3e-3, indel_rate=1e-3, read_len=100, depth=30)),
+                      (3, 2, dict(region_len=5000, snp_rate=4e-3, indel_rate=2e-3, read_len=150, depth=25))):
+        regs = [synth.config4_region(10 * ns + i, n_samples=ns, **kw) for i in range(n)]
+        txt, st = _both(fake, regs, ["S%d" % (i + 1) for i in range(ns)])
+        assert st["n_records"] > 15 and st["n_windows_failed"] == 0
+
+
+def test_native_equals_python_greedy_haplotype_filter(fake):
+    """More than five variants in a window: getFilteredHaplotypes grows the best haplotypes greedily, one alignment batch per
+    variant (variantFilter.pyx:440-506); coverage filter on and off, a small maxHaplotypes."""
+    regs = [synth.config4_region(70 + i, n_samples=2, region_len=2500, snp_rate=8e-2, indel_rate=1e-2, read_len=100, depth=30) for i in range(2)]
+    txt, st = _both(fake, regs, ["A", "B"])
+    assert st["n_windows_greedy"] > 20
+    txt, st = _both(fake, regs[:1], ["A", "B"], filterVarsByCoverage=0, maxVariants=12, maxHaplotypes=20)
+    assert st["n_windows_greedy"] > 5
+
+
+def test_native_equals_python_bad_reads_broken_mates_and_empty_samples(fake):
+    """badReads and brokenMates take part in the likelihoods and the read statistics (chaplotype.pyx:341-373, vcfutils.pyx:1300-1390);
+    a sample without reads in one region, a region without reads at all, regions of different read lengths (options.rlen)."""
+    rng = np.random.default_rng(8)
+    regs = [synth.config4_region(90 + i, n_samples=2, region_len=3000, snp_rate=4e-3, indel_rate=1.5e-3, read_len=[100, 76, 125][i], depth=40)
+            for i in range(3)]
+    regs.append(synth.config4_region(99, n_samples=2, region_len=1500, read_len=100, depth=20))
+    regs[3]["samples"] = [[], []]
+
+    def split(k, i, rs):
+        if k == 1 and i == 1:
+            return [], [], []
+        good, bad, broken = [], [], []
+        for r in rs:
+            u = rng.random()
+            if u < 0.08:
+                r.mapq = int(rng.integers(0, 20)); r.bitFlag |= 512
+                bad.append(r)
+            elif u < 0.12:
+                r.matePos = r.pos + int(rng.integers(-400, 400))
+                broken.append(r)
+            else:
+                good.append(r)
+        return good, bad, broken
+    txt, st = _both(fake, regs, ["S1", "S2"], extra=split, workers=3, per_chunk=1)
+    assert st["n_records"] > 20
+
+
+@pytest.mark.parametrize("opt", [dict(minPosterior=0), dict(maxVariants=3, minPosterior=20), dict(mergeClusteredVariants=0, minReads=3),
+                                 dict(largeWindows=1, maxVarDist=30, minVarDist=5), dict(skipDifficultWindows=1, maxVariants=4),
+                                 dict(genIndels=0), dict(minVarFreq=0.2, badReadsThreshold=30, qdThreshold=30, hapScoreThreshold=1)])
+def test_native_equals_python_option_variants(fake, opt):
+    regs = [synth.config4_region(200 + i, n_samples=1, region_len=3000, snp_rate=1.2e-2, indel_rate=3e-3, read_len=100, depth=30) for i in range(2)]
+    _both(fake, regs, ["S1"], **opt)
+
+
+def test_native_refuses_what_it_does_not_build(fake):
+    regs = [synth.config4_region(1, region_len=1000, read_len=100)]
+    fasta, work = _work(regs, ["S1"])
+    nc = F.NativeCaller(0, 1, 1, lib=fake)
+    from platypus_amd._lib import PlatypusDeviceError
+    for bad in (dict(assemble=1), dict(outputRefCalls=1), dict(getVariantsFromBAMs=0)):
+        with pytest.raises(PlatypusDeviceError) as e:
+            nc.call_regions([F.RegionReads.from_buffers(c, s, e_, fasta, b) for c, s, e_, b in work], ["S1"], default_options(**bad))
+        assert e.value.code == -6
+
+
+def test_native_equals_python_on_array_regions(fake):
+    """synth.config4_region_arrays (the generator of the config-4 benchmark): arrays straight into the native loop, the same reads
+    as objects into the Python loop."""
+    regs = [synth.config4_region_arrays(300 + i, region_len=6000, snp_rate=3e-3, indel_rate=1e-3, n_samples=2, read_len=150, depth=30) for i in range(3)]
+    names = ["S1", "S2"]
+    fasta = H.FastaFile({r["chrom"]: r["ref"].tobytes() for r in regs})
+    work = [(r["chrom"], r["start"], r["end"], [H.bamReadBuffer(F.aligned_reads_from_arrays(s), sample=names[i]) for i, s in enumerate(r["samples"])])
+            for r in regs]
+    o1, o2 = default_options(), default_options()
+    py = io.StringIO()
+    caller.callVariantsInRegions(work, fasta, o1, VCF(names), py)
+    nc = F.NativeCaller(0, 2, 2, lib=fake)
+    txt = nc.call_regions([F.region_from_arrays(r) for r in regs], names, o2)
+    assert txt == py.getvalue() and txt.count("\n") > 30
+    # the planted variants come back
+    called = {(ln.split("\t")[0], int(ln.split("\t")[1])) for ln in txt.split("\n")[:-1]}
+    snps = [(r["chrom"], p + 1) for r in regs for (p, rem, add), t0, t1 in zip(r["variants"], r["truth"][0], r["truth"][1]) if len(rem) == len(add) and t0 + t1 > 0]
+    assert sum(k in called for k in snps) >= 0.9 * len(snps)

@@ -146,8 +146,58 @@ def run(a, rank, local, world, dist):
     return {3: line_config3, 4: line_config4, 5: line_config5}[a.config](a, rank, local, world, dist)
 
 
+# ---- config 4 -----------------------------------------------------------------------------------------------------------------
+
+def config4(device, n_regions, region_len, workers, per_chunk, first_region=0, repeats=1, n_samples=1):
+    """The region pipeline end to end: reads of `n_regions` regions in host memory (arrays) -> VCF record text, through the native
+    region loop (libplat_caller.so: host threads + every device stage batched per chunk of regions)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from platypus_amd import fastcaller as F, synth
+    from platypus_amd.options import default_options
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(min(16, n_regions)) as ex:
+        regs = list(ex.map(lambda i: synth.config4_region_arrays(first_region + i, region_len=region_len, n_samples=n_samples), range(n_regions)))
+    rr = [F.region_from_arrays(r) for r in regs]
+    t_synth = time.perf_counter() - t0
+    names = ["S%d" % (i + 1) for i in range(n_samples)]
+    nc = F.NativeCaller(device, workers, per_chunk)
+    nc.call_regions(rr[:max(1, min(len(rr), 2 * per_chunk))], names, default_options())            # scratch buffers, code paths warm
+    best = None
+    for _ in range(repeats):
+        opts = default_options()
+        t0 = time.perf_counter()
+        text = nc.call_regions(rr, names, opts)
+        t = time.perf_counter() - t0
+        if best is None or t < best[0]:
+            best = (t, text, dict(nc.stats))
+    nc.close()
+    t, text, st = best
+    planted = sum(len(r["variants"]) for r in regs)
+    return dict(T=t, text=text, stats=st, regions=n_regions, region_len=region_len, reads=int(st["n_reads"]), windows=int(st["n_windows"]),
+                records=int(st["n_records"]), planted=planted, synth_s=t_synth, workers=workers, per_chunk=per_chunk)
+
+
 def line_config4(a, rank, local, world, dist):
-    raise SystemExit("bench.py --config 4: the region pipeline benchmark is not wired in yet")
+    import torch
+    nreg = a.regions or 64
+    workers = int(os.environ.get("PLAT_CALLER_WORKERS", "12"))
+    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "2"))
+    r = config4(local, nreg, 100000, workers, per_chunk, first_region=rank * nreg, repeats=max(1, min(a.steps, 3)))
+    dev = torch.device("cuda", local)
+    T, (wins, regs, recs, reads) = _reduce(torch, dist, dev, r["T"], [r["windows"], r["regions"], r["records"], r["reads"]])
+    st = r["stats"]
+    return {"metric": "variant windows/sec end to end (reads in host memory -> VCF record text)", "value": wins / T, "unit": "windows/s",
+            "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * T, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int16", "data": "synthetic",
+            "config": {"workload": "BASELINE config 4: %d regions/GPU x 100 kb, 30x 150 bp reads, SNPs 1e-3 + indels 1e-4, one sample; step = "
+                                   "candidates -> windows -> haplotypes -> likelihoods / EM / posteriors -> INFO / FILTER -> record text for all "
+                                   "regions (native region loop, %d host threads, %d regions per chunk)" % (nreg, r["workers"], r["per_chunk"]),
+                       "regions_per_gpu": nreg, "region_len": 100000, "sharding": "regions by rank, records gathered to rank 0"},
+            "regions_per_sec": regs / T, "reads_per_sec": reads / T, "records": recs, "windows": wins, "planted_variants": r["planted"],
+            "host_seconds_per_region": st["seconds_host"] / max(1, r["regions"]),
+            "device_wait_seconds_per_region": st["seconds_device_wait"] / max(1, r["regions"]),
+            "host_input_bytes_per_region": 2 * 150 * r["reads"] // max(1, r["regions"]),
+            "python_region_loop_windows_per_sec_round1": 1100.0}
 
 
 def summary(eng):
@@ -164,4 +214,12 @@ def summary(eng):
     out["config3_assembler"] = dict(regions=500, reads=int(r["ab"]["n_reads"]), regions_per_sec=500 * r["steps"] / r["T"],
                                     kernel_ms=r["kernel_ms"], hbm_frac=r["alg_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                     variants_found=r["variants"], variants_planted=r["planted"])
+    r = config4(0, 32, 100000, int(os.environ.get("PLAT_CALLER_WORKERS", "12")), int(os.environ.get("PLAT_CALLER_CHUNK", "2")))
+    st = r["stats"]
+    out["config4_region_pipeline"] = dict(regions=r["regions"], region_len=r["region_len"], reads=r["reads"], windows=r["windows"], records=r["records"],
+                                          planted_variants=r["planted"], seconds=r["T"], windows_per_sec=r["windows"] / r["T"],
+                                          regions_per_sec=r["regions"] / r["T"], reads_per_sec=r["reads"] / r["T"],
+                                          host_seconds_per_region=st["seconds_host"] / r["regions"],
+                                          device_wait_seconds_per_region=st["seconds_device_wait"] / r["regions"], host_threads=r["workers"],
+                                          regions_per_chunk=r["per_chunk"], what="reads in host memory (arrays) -> VCF record text, native region loop")
     return out
