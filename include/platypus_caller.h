@@ -93,6 +93,10 @@ typedef struct plat_caller_stats {
     double seconds_total;                /* wall time of the call */
     double seconds_host;                 /* sum over worker threads of time spent in host stages */
     double seconds_device_wait;          /* sum over worker threads of time spent waiting for the device */
+    /* sum over worker threads, per stage: 0 upload of the reads, 1 candidate scan, 2 candidates -> variants -> windows ->
+     * haplotypes (host), 3 greedy haplotype filter rounds, 4 window batch (pack, likelihoods, EM), 5 posteriors,
+     * 6 read statistics + genotype calls, 7 INFO / FILTER / text */
+    double seconds_stage[8];
 } plat_caller_stats;
 
 typedef struct plat_caller plat_caller;

@@ -795,6 +795,7 @@ struct Chunk {
             b.endWindow();
         }
         DeviceBatch db = runWindows(z, b, o, true, false);
+        lap(4);
 
         // D: distinct variants, masks, priors -> posteriors (Population.computeVariantPosteriors, cpopulation.pyx:596-621)
         std::vector<int32_t> pwin;
@@ -823,6 +824,7 @@ struct Chunk {
             z.down(z.p_post, nV);
             z.sync("posteriors");
         }
+        lap(5);
         // varsByPos, INFO variants (getHaplotypeInfo order, vcfutils.pyx:1118-1152), read statistics and call sites of the live windows
         std::vector<int32_t> svw, spos, smin, smax, snadd, snrem, sgb, sge, sbb, sbe, kwin, knvar, kvih, kref;
         std::vector<int64_t> saoff, smoff, kvo{0}, kro{0}, klo{0};
@@ -957,6 +959,7 @@ struct Chunk {
                                     z.k_ro.d, z.k_vih.d, z.k_ref.d, z.k_lo.d, z.k_ph.d, z.k_lik.d, z.k_out4.d, z.stream), "plat_genotype_call_batch");
         z.down(z.k_ph, nSites * (size_t)nInd * 2); z.down(z.k_lik, (size_t)klo.back()); z.down(z.k_out4, nSites * (size_t)nInd * 4);
         z.sync("read statistics / genotype calls");
+        lap(6);
         // F: INFO, FILTER, text
         for (WindowWork* w : live) {
             RegionWork& r = *regions[(size_t)regionSlot(w->region)];
@@ -968,6 +971,7 @@ struct Chunk {
                 ++st.n_windows_failed;
             }
         }
+        lap(7);
     }
 
     // vcfINFO (vcfutils.pyx:1226-1460), vcfFILTER (:1502-1627), outputCallToVCF (:338-599), VCF.write_data (vcf.py:710-739)
@@ -1141,18 +1145,27 @@ struct Chunk {
         }
     }
 
+    double stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    Clock::time_point mark;
+    void lap(int k) { const auto now = Clock::now(); stage[k] += secs(mark, now); mark = now; }
+
     void run() {
         const auto t0 = Clock::now();
         double wait0 = s.t_wait;
+        mark = t0;
         uploadReads();
+        lap(0);
         scanCandidates();
+        lap(1);
         int scan0 = 0;
         for (RegionWork* r : regions) {
             regionVariants(*r, scan0);
             scan0 += (int)r->samples.size();
             regionWindows(*r);
         }
+        lap(2);
         greedyRounds();
+        lap(3);
         std::vector<WindowWork*> wins;
         int64_t nWin = 0, nVar = 0, nCand = 0;
         for (RegionWork* r : regions) {
@@ -1181,6 +1194,7 @@ struct Chunk {
         std::lock_guard<std::mutex> g(stMutex);
         st.n_windows += nWin; st.n_variants += nVar; st.n_candidate_records += nCand; st.n_records += nRec;
         st.seconds_host += total - waited; st.seconds_device_wait += waited;
+        for (int k = 0; k < 8; ++k) st.seconds_stage[k] += stage[k];
     }
 };
 

@@ -657,6 +657,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         }
     }
     __syncthreads();
+    if (shortcuts & 256) return;                         // (measurement only, PLAT_SEED_DEBUG: the haplotype sweep alone)
     if (lane < 32) level = max(level, trip[lane] ? 2 + (int)(trip[lane] >> 16) : 0);
 #pragma unroll
     for (int s2 = 32; s2 > 0; s2 >>= 1) level = max(level, __shfl_xor(level, s2));
@@ -1453,9 +1454,10 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         const int no_ungapped = e_ung && e_ung[0] == '1';
         const char* e_ex = getenv("PLAT_NO_EXACT");        // every reference DP is then run (bench.py's gcups_all_dp)
         const int no_exact = e_ex && e_ex[0] == '1';
+        const char* e_dbg = getenv("PLAT_SEED_DEBUG");     // measurement only: 256 = k_seed stops after the haplotype sweep (results are garbage)
         const char* e_nl = getenv("PLAT_NO_NLOW");
         const int shortcuts = ((!calc_flank_score && !no_ungapped) ? SHORTCUT_UNGAPPED : 0) | (no_exact ? 0 : SHORTCUT_EXACT) |
-                              ((e_nl && e_nl[0] == '1') ? 0 : SHORTCUT_NLOW);
+                              ((e_nl && e_nl[0] == '1') ? 0 : SHORTCUT_NLOW) | (e_dbg ? (atoi(e_dbg) & 0x300) : 0);
         if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win, win_rows, tile_off,
                                     shortcuts))) return rc;
         {   // dense list of the live job slots; pairs that need no DP are finished by k_compact_count

@@ -61,22 +61,33 @@ class CallerOptions(C.Structure):
 class CallerStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("n_regions", "n_reads", "n_candidate_records", "n_variants", "n_windows", "n_windows_called",
                                          "n_records", "n_windows_greedy", "n_windows_failed")] + \
-               [(k, C.c_double) for k in ("seconds_total", "seconds_host", "seconds_device_wait")]
+               [(k, C.c_double) for k in ("seconds_total", "seconds_host", "seconds_device_wait")] + [("seconds_stage", C.c_double * 8)]
+
+    STAGES = ("upload", "candidate_scan", "variants_windows_haplotypes", "greedy_rounds", "window_batch", "posteriors", "read_stats_calls", "text")
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "seconds_stage"}
+        d["seconds_stage"] = dict(zip(self.STAGES, list(self.seconds_stage)))
+        return d
 
 
 class ReadTable:
     """One ReadArray as arrays (cAlignedRead fields, htslibWrapper.pxd:187-201).  `reads`: the order the ReadArray holds them in
     (sorted by pos; brokenMates by mate position)."""
-    __slots__ = ("n", "seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off")
+    __slots__ = ("n", "seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off", "_pinned")
 
-    def __init__(self, seq, qual, off, pos, end, mapq, flags, mate_pos, cigar, cig_off):
+    def __init__(self, seq, qual, off, pos, end, mapq, flags, mate_pos, cigar, cig_off, pin=False):
+        """pin=True keeps the two byte blobs in page-locked memory (what a loader that decodes into pinned buffers hands over):
+        their upload is then asynchronous and runs at link speed instead of going through the driver's staging copies."""
         self.n = len(pos)
         pad = np.zeros(_lib.PLAT_BLOB_PAD, dtype=np.uint8)
         c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
         self.seq, self.qual = np.concatenate([c(seq, np.uint8), pad]), np.concatenate([c(qual, np.uint8), pad])
+        self._pinned = None
+        if pin and self.n:
+            import torch
+            self._pinned = [torch.from_numpy(self.seq).pin_memory(), torch.from_numpy(self.qual).pin_memory()]
+            self.seq, self.qual = self._pinned[0].numpy(), self._pinned[1].numpy()
         self.off, self.pos, self.end = c(off, np.int64), c(pos, np.int32), c(end, np.int32)
         self.mapq, self.flags, self.mate_pos = c(mapq, np.uint8), c(flags, np.int32), c(mate_pos, np.int32)
         self.cigar, self.cig_off = np.concatenate([c(cigar, np.int16).reshape(-1), np.zeros(2, dtype=np.int16)]), c(cig_off, np.int32)
@@ -117,12 +128,12 @@ class RegionReads:
                     for b in buffers])
 
 
-def region_from_arrays(reg):
+def region_from_arrays(reg, pin=False):
     """RegionReads of a synth.config4_region_arrays() region (every read in `reads`; no badReads / brokenMates)."""
     empty = ReadTable([], [], [0], [], [], [], [], [], [], [0])
     return RegionReads(reg["chrom"], reg["start"], reg["end"], reg["ref"],
-                       [(ReadTable(s["seq"], s["qual"], s["off"], s["pos"], s["end"], s["mapq"], s["flags"], s["mate_pos"], s["cigar"], s["cig_off"]),
-                         empty, empty) for s in reg["samples"]])
+                       [(ReadTable(s["seq"], s["qual"], s["off"], s["pos"], s["end"], s["mapq"], s["flags"], s["mate_pos"], s["cigar"], s["cig_off"],
+                                   pin=pin), empty, empty) for s in reg["samples"]])
 
 
 def aligned_reads_from_arrays(s):

@@ -148,7 +148,7 @@ def run(a, rank, local, world, dist):
 
 # ---- config 4 -----------------------------------------------------------------------------------------------------------------
 
-def config4(device, n_regions, region_len, workers, per_chunk, first_region=0, repeats=1, n_samples=1):
+def config4(device, n_regions, region_len, workers, per_chunk, first_region=0, repeats=1, n_samples=1, pin=True):
     """The region pipeline end to end: reads of `n_regions` regions in host memory (arrays) -> VCF record text, through the native
     region loop (libplat_caller.so: host threads + every device stage batched per chunk of regions)."""
     from concurrent.futures import ThreadPoolExecutor
@@ -157,7 +157,7 @@ def config4(device, n_regions, region_len, workers, per_chunk, first_region=0, r
     t0 = time.perf_counter()
     with ThreadPoolExecutor(min(16, n_regions)) as ex:
         regs = list(ex.map(lambda i: synth.config4_region_arrays(first_region + i, region_len=region_len, n_samples=n_samples), range(n_regions)))
-    rr = [F.region_from_arrays(r) for r in regs]
+    rr = [F.region_from_arrays(r, pin=pin) for r in regs]
     t_synth = time.perf_counter() - t0
     names = ["S%d" % (i + 1) for i in range(n_samples)]
     nc = F.NativeCaller(device, workers, per_chunk)
@@ -182,7 +182,8 @@ def line_config4(a, rank, local, world, dist):
     nreg = a.regions or 64
     workers = int(os.environ.get("PLAT_CALLER_WORKERS", "12"))
     per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "2"))
-    r = config4(local, nreg, 100000, workers, per_chunk, first_region=rank * nreg, repeats=max(1, min(a.steps, 3)))
+    pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1"
+    r = config4(local, nreg, 100000, workers, per_chunk, first_region=rank * nreg, repeats=max(1, min(a.steps, 3)), pin=pin)
     dev = torch.device("cuda", local)
     T, (wins, regs, recs, reads) = _reduce(torch, dist, dev, r["T"], [r["windows"], r["regions"], r["records"], r["reads"]])
     st = r["stats"]
@@ -196,7 +197,8 @@ def line_config4(a, rank, local, world, dist):
             "regions_per_sec": regs / T, "reads_per_sec": reads / T, "records": recs, "windows": wins, "planted_variants": r["planted"],
             "host_seconds_per_region": st["seconds_host"] / max(1, r["regions"]),
             "device_wait_seconds_per_region": st["seconds_device_wait"] / max(1, r["regions"]),
-            "host_input_bytes_per_region": 2 * 150 * r["reads"] // max(1, r["regions"]),
+            "host_input_bytes_per_region": 2 * 150 * r["reads"] // max(1, r["regions"]), "input_blobs_pinned": pin,
+            "stage_seconds_per_region": {k: v / max(1, r["regions"]) for k, v in st["seconds_stage"].items()},
             "python_region_loop_windows_per_sec_round1": 1100.0}
 
 
