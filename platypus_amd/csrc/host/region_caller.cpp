@@ -487,63 +487,65 @@ struct Chunk {
     // -- B1: candidates of one region -> merged, per-sample support filter, left-normalised, filtered (variantcaller.pyx:439-531)
     void regionVariants(RegionWork& r, int scan0) {
         Slot& z = s;
+        (void)scan0;
         VarList everyone;                                                   // the all-samples generator's variantHeap, insertion order
         std::unordered_map<std::string, Variant*> everyoneIndex;
+        struct Key { int pos, nrem, nadd, count; const char* rem; const char* add; };
+        std::vector<Key> keys;                                              // this sample's variantHeap: distinct records, first-occurrence order
+        std::vector<int32_t> table;                                         // open addressing over `keys` (index + 1, 0 = empty)
         for (size_t i = 0; i < r.samples.size(); ++i) {
             const TableView& tv = r.samples[i].reads;
-            VarList heap;                                                   // this sample's variantHeap, first-occurrence order
-            // open hash over (pos, removed, added) of this sample's records
-            const int64_t refBase = 0;
-            (void)refBase;
-            struct Key { int pos, nrem, nadd; const char* rem; const char* add; };
-            std::vector<std::pair<Key, Variant*>> table;
-            size_t tmask = 1023;
-            table.assign(tmask + 1, {Key{0, 0, 0, nullptr, nullptr}, nullptr});
-            size_t used = 0;
+            keys.clear();
+            size_t tmask = 4095;
+            table.assign(tmask + 1, 0);
             auto hashKey = [](const Key& k) -> size_t {
                 size_t h = (size_t)k.pos * 1000003u + (size_t)k.nrem * 131u + (size_t)k.nadd;
                 for (int j = 0; j < k.nrem; ++j) h = h * 31u + (unsigned char)k.rem[j];
                 for (int j = 0; j < k.nadd; ++j) h = h * 37u + (unsigned char)k.add[j];
-                return h;
+                return h * 0x9E3779B97F4A7C15ull >> 20;
             };
             auto sameKey = [](const Key& a, const Key& b) {
                 return a.pos == b.pos && a.nrem == b.nrem && a.nadd == b.nadd && memcmp(a.rem, b.rem, (size_t)a.nrem) == 0 && memcmp(a.add, b.add, (size_t)a.nadd) == 0;
             };
+            const int64_t blobBase = tv.n() ? z.t_off.h[tv.base] : 0;
             for (int q = 0; q < tv.n(); ++q) {
                 const size_t g = (size_t)(tv.base + q);
                 const int cnt = z.c_cnt.h[g];
                 for (int k = 0; k < cnt; ++k) {
                     const int32_t* rec = z.c_rec.h + 5 * (g * (size_t)maxPerRead + (size_t)k);
-                    Key key{std::max(0, rec[0]), rec[1], rec[2], rec[1] ? refBlob.data() + rec[3] : "", rec[2] ? (const char*)tv.t->seq + (rec[4] - z.t_off.h[tv.base]) : ""};
+                    Key key{std::max(0, rec[0]), rec[1], rec[2], 1, rec[1] ? refBlob.data() + rec[3] : "", rec[2] ? (const char*)tv.t->seq + (rec[4] - blobBase) : ""};
                     ++r.nCandRecords;
                     size_t slot = hashKey(key) & tmask;
-                    while (table[slot].second && !sameKey(table[slot].first, key)) slot = (slot + 1) & tmask;
-                    if (table[slot].second) { table[slot].second->nSupportingReads += 1; continue; }
-                    Variant* v = r.pool.make(rec[0], std::string(key.rem, (size_t)key.nrem), std::string(key.add, (size_t)key.nadd), 1, PLATYPUS_VAR);
-                    table[slot] = {key, v};
-                    heap.push_back(v);
-                    if (++used * 2 > tmask) {                               // grow
-                        std::vector<std::pair<Key, Variant*>> old;
-                        old.swap(table);
+                    while (table[slot] && !sameKey(keys[(size_t)table[slot] - 1], key)) slot = (slot + 1) & tmask;
+                    if (table[slot]) { ++keys[(size_t)table[slot] - 1].count; continue; }    // one more read showing it (addVariantToList)
+                    keys.push_back(key);
+                    table[slot] = (int32_t)keys.size();
+                    if (keys.size() * 2 > tmask) {                          // grow
                         tmask = tmask * 2 + 1;
-                        table.assign(tmask + 1, {Key{0, 0, 0, nullptr, nullptr}, nullptr});
-                        for (auto& e : old) if (e.second) { size_t s2 = hashKey(e.first) & tmask; while (table[s2].second) s2 = (s2 + 1) & tmask; table[s2] = e; }
+                        table.assign(tmask + 1, 0);
+                        for (size_t e = 0; e < keys.size(); ++e) { size_t s2 = hashKey(keys[e]) & tmask; while (table[s2]) s2 = (s2 + 1) & tmask; table[s2] = (int32_t)e + 1; }
                     }
                 }
             }
-            (void)scan0;
-            // :456-467: per-sample support, indels always; equal variants of different samples merge (addVariantToList)
-            for (Variant* v : heap) {
+            // :456-467: per-sample support, indels always; equal variants of different samples merge (addVariantToList).  Only the
+            // candidates that pass become Variant objects (the sample's own heap is not looked at again).
+            for (const Key& k : keys) {
                 int s0, e0;
-                tv.overlapRange(v->refPos, v->refPos + 1, s0, e0);
+                tv.overlapRange(k.pos, k.pos + 1, s0, e0);
                 const int total = e0 - s0;
-                const double frac = total == 0 ? 0.0 : (double)v->nSupportingReads / total;
-                if (frac >= o.minVarFreq || v->nAdded != v->nRemoved) {
-                    std::string key = std::to_string(v->refPos);
-                    key += '|'; key += v->removed; key += '|'; key += v->added;
+                const double frac = total == 0 ? 0.0 : (double)k.count / total;
+                if (frac >= o.minVarFreq || k.nadd != k.nrem) {
+                    std::string key = std::to_string(k.pos);
+                    key += '|'; key.append(k.rem, (size_t)k.nrem); key += '|'; key.append(k.add, (size_t)k.nadd);
                     auto it = everyoneIndex.find(key);
-                    if (it != everyoneIndex.end()) it->second->addVariant(*v);
-                    else { everyoneIndex.emplace(std::move(key), v); everyone.push_back(v); }
+                    if (it != everyoneIndex.end()) {
+                        Variant tmp(k.pos, std::string(), std::string(), k.count, PLATYPUS_VAR);
+                        it->second->addVariant(tmp);
+                    } else {
+                        Variant* v = r.pool.make(k.pos, std::string(k.rem, (size_t)k.nrem), std::string(k.add, (size_t)k.nadd), k.count, PLATYPUS_VAR);
+                        everyoneIndex.emplace(std::move(key), v);
+                        everyone.push_back(v);
+                    }
                 }
             }
         }
