@@ -1341,3 +1341,22 @@ CALLER_EXPORT int plat_call_regions(plat_caller* c, const plat_region* regions, 
     if (stats) *stats = st;
     return PLAT_OK;
 }
+
+// ---- probes of the Python-2 restatements (records.hpp), for tests/test_py2_semantics_cpu.py; not part of the caller's interface
+CALLER_EXPORT double plat_caller_debug_round2(double x) { return py2_round2(x); }
+CALLER_EXPORT double plat_caller_debug_round0(double x) { return py2_round0(x); }
+CALLER_EXPORT unsigned long long plat_caller_debug_string_hash(const char* s) { return (unsigned long long)py2_string_hash(s ? s : ""); }
+CALLER_EXPORT void plat_caller_debug_str(double x, char* out, size_t cap) {
+    const std::string t = py2_str(x);
+    snprintf(out, cap, "%s", t.c_str());
+}
+// names: '\n'-separated, in insertion order; out: the iteration order of the set, '\n'-separated
+CALLER_EXPORT void plat_caller_debug_set_order(const char* names, char* out, size_t cap) {
+    std::vector<std::string> in;
+    std::string cur;
+    for (const char* p = names; p && *p; ++p) { if (*p == '\n') { in.push_back(cur); cur.clear(); } else cur += *p; }
+    if (!cur.empty()) in.push_back(cur);
+    std::string t;
+    for (const std::string& k : py2_set_order(in)) { if (!t.empty()) t += '\n'; t += k; }
+    snprintf(out, cap, "%s", t.c_str());
+}

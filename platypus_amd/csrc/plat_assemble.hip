@@ -12,8 +12,13 @@
 //   * a node keeps the (up to) four successors with the smallest first-occurrence tickets, in ticket order
 //     (assembler.pyx:813-824: a fifth distinct successor is silently dropped);
 //   * bubble starts are visited in allNodes order, which for REF_AND_READ nodes is increasing position.
-// One workgroup assembles one region; the node table and the per-task path arenas live in a per-workgroup slice
-// of a global scratch buffer (the graph does not fit the LDS: ~10^4..10^5 nodes).
+// One workgroup assembles one region.  The k-mer hash table -- the structure every k-mer occurrence of every read probes
+// twice -- and the per-node words every AddEdge event updates (first-touch code, weight and colour) live in the workgroup's
+// LDS: ASM_LDS_SLOTS table slots (byte offsets of representative occurrences while the nodes are inserted, dense node ids
+// afterwards) and ASM_LDS_NODES nodes; measured, the kernel was bound by the rate of L2 atomics (nine per event), not by
+// occupancy or probe latency.  A region with more distinct k-mers than ASM_LDS_LIMIT (deep or very divergent data) is redone
+// with table and node words in the workgroup's slice of a global scratch buffer.  The successor lists (one atomicAdd per
+// event) and the per-task path arenas live in that slice too.
 #include "plat_internal.hpp"
 
 namespace plat {
@@ -22,6 +27,12 @@ constexpr int ASM_MAX_SUCC = 8;        // distinct successor bytes tracked per n
 constexpr int ASM_MAX_TASKS = 512;     // bubble-start (node, edge) pairs per region
 constexpr int ASM_POOL = 1 << 20;      // path elements per region, shared by its tasks (bump-allocated)
 constexpr int ASM_MAX_FIN = 21;        // finished paths per task before the reference aborts (assembler.pyx:1052)
+constexpr int ASM_THREADS = 1024;      // threads per workgroup (one workgroup per CU: the graph takes most of the LDS)
+constexpr int ASM_LDS_SLOTS = 16384;   // k-mer table in LDS: 64 KB
+constexpr int ASM_LDS_NODES = 11264;   // per-node first-touch codes and (weight | colour << 30) words in LDS: 2 x 44 KB
+constexpr int ASM_LDS_LIMIT = ASM_LDS_NODES - ASM_THREADS;   // distinct k-mers the LDS path takes (threads in flight may overshoot by one each)
+constexpr int ASM_LDS_BYTES = (ASM_LDS_SLOTS + 2 * ASM_LDS_NODES) * 4;
+static_assert(ASM_LDS_NODES < ASM_LDS_SLOTS * 3 / 4, "the table must stay sparse");
 
 struct AsmParams {
     int kmer, min_qual, min_weight, no_cycles, max_vars, blob_per_region;
@@ -104,13 +115,23 @@ __device__ inline AsmScratch asm_carve(char* p, int cap, int max_pos, int max_re
     return s;
 }
 
+// Sequence bytes are read eight at a time (unaligned 64-bit loads; every blob is followed by PLAT_BLOB_PAD readable bytes):
+// measured, the kernel was bound by the rate of byte loads once its atomics had moved to the LDS.
+typedef unsigned long long asm_u64 __attribute__((aligned(1)));
+__device__ __forceinline__ unsigned long long asm_ld8(const uint8_t* p) { return *(const asm_u64*)p; }
+__device__ __forceinline__ unsigned long long asm_tailmask(int nbytes) { return nbytes >= 8 ? ~0ull : ((1ull << (8 * nbytes)) - 1ull); }
 __device__ __forceinline__ unsigned asm_hash(const uint8_t* p, int k) {
-    unsigned h = 2166136261u;
-    for (int i = 0; i < k; ++i) { h ^= p[i]; h *= 16777619u; }
-    return h ^ (h >> 15);
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < k; i += 8) {
+        const unsigned long long w = asm_ld8(p + i) & asm_tailmask(k - i);
+        h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 29;
+    }
+    return (unsigned)(h ^ (h >> 32));
 }
 __device__ __forceinline__ bool asm_eq(const uint8_t* a, const uint8_t* b, int k) {
-    for (int i = 0; i < k; ++i) if (a[i] != b[i]) return false;
+    for (int i = 0; i < k; i += 8)
+        if ((asm_ld8(a + i) ^ asm_ld8(b + i)) & asm_tailmask(k - i)) return false;
     return true;
 }
 // byte pointer of an occurrence: offsets < 0x40000000 index the reference, others the read blob
@@ -135,10 +156,48 @@ __device__ inline int asm_slot(AsmScratch& S, const uint8_t* ref, const uint8_t*
     }
 }
 
+// the same with the table in LDS.  Insert phase: tab[s] = byte offset of a representative occurrence (-1 empty), *distinct counts
+// the insertions.  Lookup phase (after the slots were turned into dense node ids): returns the node id.
+__device__ inline void asm_lds_insert(int* tab, const uint8_t* ref, const uint8_t* rseq, int off, int k, int* distinct) {
+    const uint8_t* me = asm_ptr(ref, rseq, off);
+    unsigned s = asm_hash(me, k) & (unsigned)(ASM_LDS_SLOTS - 1);
+    for (;;) {
+        int cur = tab[s];
+        if (cur == -1) {
+            const int old = atomicCAS(&tab[s], -1, off);
+            if (old == -1) { atomicAdd(distinct, 1); return; }
+            cur = old;
+        }
+        if (cur == off || asm_eq(asm_ptr(ref, rseq, cur), me, k)) return;
+        s = (s + 1u) & (unsigned)(ASM_LDS_SLOTS - 1);
+    }
+}
+__device__ inline int asm_lds_node(const int* tab, const int* rep, const uint8_t* ref, const uint8_t* rseq, int off, int k) {
+    const uint8_t* me = asm_ptr(ref, rseq, off);
+    unsigned s = asm_hash(me, k) & (unsigned)(ASM_LDS_SLOTS - 1);
+    for (;;) {
+        const int id = tab[s];
+        if (id < 0) return -1;
+        const int o = rep[id];
+        if (o == off || asm_eq(asm_ptr(ref, rseq, o), me, k)) return id;
+        s = (s + 1u) & (unsigned)(ASM_LDS_SLOTS - 1);
+    }
+}
+
 // does read r pass the k+1-base quality / N filter at position i (assembler.pyx:1362-1373)?  returns min qual or -1
 __device__ __forceinline__ int asm_read_edge_q(const uint8_t* s, const uint8_t* q, int i, int k, int min_qual) {
     int mq = 100000000, hasn = 0;
-    for (int j = i; j < i + k + 1; ++j) { int v = (int)(signed char)q[j]; mq = v < mq ? v : mq; hasn |= s[j] == 'N'; }
+    const int n = k + 1;
+    for (int j = 0; j < n; j += 8) {
+        unsigned long long wq = asm_ld8(q + i + j), ws = asm_ld8(s + i + j);
+        const int m = n - j < 8 ? n - j : 8;
+        for (int t = 0; t < m; ++t) {
+            const int v = (int)(signed char)(wq & 0xFFu);
+            mq = v < mq ? v : mq;
+            hasn |= (ws & 0xFFu) == (unsigned long long)'N';
+            wq >>= 8; ws >>= 8;
+        }
+    }
     return (mq >= min_qual && !hasn) ? mq : -1;
 }
 
@@ -150,12 +209,16 @@ __device__ __forceinline__ void asm_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(ASM_THREADS)
 k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int max_reads, int32_t* var_count,
            int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob,
            int32_t* status)
 {
-    __shared__ int s_n, s_ntasks, s_err, s_cycle, s_k, s_pool;
+    __shared__ int s_n, s_ntasks, s_err, s_cycle, s_k, s_pool, s_distinct, s_lds;
+    __shared__ int s_scan[ASM_THREADS];
+    extern __shared__ int s_tab[];                       // [ASM_LDS_SLOTS] the k-mer table, then the node words
+    unsigned* s_first = (unsigned*)(s_tab + ASM_LDS_SLOTS);      // [ASM_LDS_NODES] min touch code (2*ticket + isEnd)
+    unsigned* s_wc = s_first + ASM_LDS_NODES;                    // [ASM_LDS_NODES] weight | colour << 30
     const int tid = threadIdx.x, nthr = blockDim.x;
     AsmScratch S = asm_carve(scratch + (size_t)blockIdx.x * P.scratch_per_block, P.cap, P.max_pos, max_ref, max_reads);
     const int capmask = P.cap - 1;
@@ -174,81 +237,127 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
         for (;;) {   // (re)build with the current k (assembler.pyx:1453-1469: k += 5 while cycles, noCycles only)
             const int k = s_k;
             const int nRefE = refLen - k - 1 > 0 ? refLen - k - 1 : 0;
-            // ticket bases of the reads
-            if (tid == 0) {
+            // ticket bases of the reads: exclusive scan of max(L - k - 1, 0) (each thread sums a run of reads, thread 0 scans the
+            // per-thread sums in LDS, each thread writes its run)
+            {
+                const int per = (nR + nthr - 1) / nthr;
+                const int r0 = min(nR, tid * per), r1 = min(nR, r0 + per);
                 int acc = 0;
-                for (int r = 0; r < nR; ++r) {
-                    S.read_base[r] = acc;
-                    int L = (int)(b.read_off[rb + r + 1] - b.read_off[rb + r]);
+                for (int r = r0; r < r1; ++r) {
+                    const int L = (int)(b.read_off[rb + r + 1] - b.read_off[rb + r]);
                     acc += L - k - 1 > 0 ? L - k - 1 : 0;
                 }
-                S.read_base[nR] = acc;
-                s_n = 0; s_ntasks = 0; s_pool = 0;
+                s_scan[tid] = acc;
+                __syncthreads();
+                if (tid == 0) {
+                    int run = 0;
+                    for (int t = 0; t < nthr; ++t) { const int v = s_scan[t]; s_scan[t] = run; run += v; }
+                    S.read_base[nR] = run;
+                    s_n = 0; s_ntasks = 0; s_pool = 0;
+                }
+                __syncthreads();
+                acc = s_scan[tid];
+                for (int r = r0; r < r1; ++r) {
+                    S.read_base[r] = acc;
+                    const int L = (int)(b.read_off[rb + r + 1] - b.read_off[rb + r]);
+                    acc += L - k - 1 > 0 ? L - k - 1 : 0;
+                }
             }
-            for (int i = tid; i < P.cap; i += nthr) S.key[i] = -1;
             asm_sync();
             const int nReadE = S.read_base[nR];
             const int nEv = nRefE + nReadE;
-            if ((long long)nEv + 2ll * (nR + 1) > (long long)P.max_pos || (long long)nEv * 4 > (long long)P.cap * 3) {   // distinct k-mers <= occurrences
+            if ((long long)nEv + 2ll * (nR + 1) > (long long)P.max_pos) {                       // distinct k-mers <= occurrences
                 if (tid == 0) s_err = PLAT_ERR_OVERFLOW;
                 asm_sync();
                 break;
             }
-            // ---- phase A: insert every k-mer that takes part in a (valid) edge
-            for (int e = tid; e < nEv; e += nthr) {
-                if (e < nRefE) {
-                    asm_slot(S, ref, rseq, e, k, capmask, true);
-                    if (e == nRefE - 1) asm_slot(S, ref, rseq, e + 1, k, capmask, true);
-                } else {
-                    // locate the read of this event
-                    int lo = 0, hi = nR;
-                    const int x = e - nRefE;
-                    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (S.read_base[mid] <= x) lo = mid; else hi = mid; }
-                    while (lo + 1 < nR && S.read_base[lo + 1] <= x) ++lo;
-                    const int i = x - S.read_base[lo];
-                    const int ro = (int)(b.read_off[rb + lo] - rblob0);
-                    if (asm_read_edge_q(rseq + ro, rqual + ro, i, k, P.min_qual) >= 0) {
-                        asm_slot(S, ref, rseq, 0x40000000 + ro + i, k, capmask, true);
-                        asm_slot(S, ref, rseq, 0x40000000 + ro + i + 1, k, capmask, true);
+            // every AddEdge event: the reference's edges one per thread, then the reads one per wave at a time (lanes over the read's
+            // edges: no search for the read of an event).  fn(ticket, start offset, end offset, colour, weight) -> false stops this thread.
+            auto for_each_event = [&](auto&& fn) {
+                for (int e = tid; e < nRefE; e += nthr)
+                    if (!fn(e, e, e + 1, 1, 1)) return;
+                const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+                for (int r = wv; r < nR; r += nwv) {
+                    const int base = S.read_base[r], cnt = S.read_base[r + 1] - base;
+                    const int ro = (int)(b.read_off[rb + r] - rblob0);
+                    for (int i = lane; i < cnt; i += 64) {
+                        const int w = asm_read_edge_q(rseq + ro, rqual + ro, i, k, P.min_qual);
+                        if (w < 0) continue;
+                        if (!fn(nRefE + base + i, 0x40000000 + ro + i, 0x40000000 + ro + i + 1, 2, w)) return;
                     }
                 }
+            };
+            // ---- phase A: insert every k-mer that takes part in a (valid) edge; LDS table first, the global one if it overflows
+            if (tid == 0) s_lds = 1;
+            __syncthreads();
+            bool failed = false;
+            for (;;) {
+                const bool lds = s_lds != 0;
+                if (lds) { for (int i = tid; i < ASM_LDS_SLOTS; i += nthr) s_tab[i] = -1; if (tid == 0) s_distinct = 0; }
+                else {
+                    if ((long long)nEv * 4 > (long long)P.cap * 3) { failed = true; break; }
+                    for (int i = tid; i < P.cap; i += nthr) S.key[i] = -1;
+                }
+                asm_sync();
+                for_each_event([&](int e, int so, int eo, int col, int w) -> bool {
+                    (void)w;
+                    if (lds) {
+                        if (*(volatile int*)&s_distinct > ASM_LDS_LIMIT) return false;
+                        asm_lds_insert(s_tab, ref, rseq, so, k, &s_distinct);
+                        if (col == 2 || e == nRefE - 1) asm_lds_insert(s_tab, ref, rseq, eo, k, &s_distinct);
+                    } else {
+                        asm_slot(S, ref, rseq, so, k, capmask, true);
+                        if (col == 2 || e == nRefE - 1) asm_slot(S, ref, rseq, eo, k, capmask, true);
+                    }
+                    return true;
+                });
+                asm_sync();
+                if (!lds || s_distinct <= ASM_LDS_LIMIT) break;
+                __syncthreads();
+                if (tid == 0) s_lds = 0;                                    // more distinct k-mers than the LDS table takes: global table
+                __syncthreads();
             }
-            asm_sync();
+            if (failed) {
+                if (tid == 0) s_err = PLAT_ERR_OVERFLOW;
+                asm_sync();
+                break;
+            }
+            const bool lds = s_lds != 0;
             // ---- phase B: dense node ids + field initialisation
-            for (int sidx = tid; sidx < P.cap; sidx += nthr) {
-                if (S.key[sidx] != -1) {
-                    const int id = atomicAdd(&s_n, 1);
-                    S.slot_id[sidx] = id;
-                    S.first[id] = 0xFFFFFFFFu; S.weight[id] = 0; S.colour[id] = 0; S.rep[id] = S.key[sidx];
-                    for (int j = 0; j < ASM_MAX_SUCC; ++j) {
-                        S.succ_c[id * ASM_MAX_SUCC + j] = 0; S.succ_t[id * ASM_MAX_SUCC + j] = 0xFFFFFFFFu;
-                        S.succ_w[id * ASM_MAX_SUCC + j] = 0; S.succ_n[id * ASM_MAX_SUCC + j] = -1;
-                    }
+            auto init_node = [&](int id, int rep_off) {
+                S.first[id] = 0xFFFFFFFFu; S.weight[id] = 0; S.colour[id] = 0; S.rep[id] = rep_off;
+                for (int j = 0; j < ASM_MAX_SUCC; ++j) {
+                    S.succ_c[id * ASM_MAX_SUCC + j] = 0; S.succ_t[id * ASM_MAX_SUCC + j] = 0xFFFFFFFFu;
+                    S.succ_w[id * ASM_MAX_SUCC + j] = 0; S.succ_n[id * ASM_MAX_SUCC + j] = -1;
                 }
+            };
+            if (lds) {
+                for (int sidx = tid; sidx < ASM_LDS_SLOTS; sidx += nthr) {
+                    const int off = s_tab[sidx];
+                    if (off != -1) { const int id = atomicAdd(&s_n, 1); init_node(id, off); s_tab[sidx] = id; s_first[id] = 0xFFFFFFFFu; s_wc[id] = 0u; }
+                }
+            } else {
+                for (int sidx = tid; sidx < P.cap; sidx += nthr)
+                    if (S.key[sidx] != -1) { const int id = atomicAdd(&s_n, 1); S.slot_id[sidx] = id; init_node(id, S.key[sidx]); }
             }
             asm_sync();
             const int nNodes = s_n;
             // ---- phase C: AddEdge events (assembler.pyx:801-827)
-            for (int e = tid; e < nEv; e += nthr) {
-                int so, eo, col, w;
-                if (e < nRefE) { so = e; eo = e + 1; col = 1; w = 1; }
-                else {
-                    int lo = 0, hi = nR;
-                    const int x = e - nRefE;
-                    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (S.read_base[mid] <= x) lo = mid; else hi = mid; }
-                    while (lo + 1 < nR && S.read_base[lo + 1] <= x) ++lo;
-                    const int i = x - S.read_base[lo];
-                    const int ro = (int)(b.read_off[rb + lo] - rblob0);
-                    w = asm_read_edge_q(rseq + ro, rqual + ro, i, k, P.min_qual);
-                    if (w < 0) continue;
-                    so = 0x40000000 + ro + i; eo = so + 1; col = 2;
+            for_each_event([&](int e, int so, int eo, int col, int w) -> bool {
+                const int sn = lds ? asm_lds_node(s_tab, S.rep, ref, rseq, so, k) : S.slot_id[asm_slot(S, ref, rseq, so, k, capmask, false)];
+                const int en = lds ? asm_lds_node(s_tab, S.rep, ref, rseq, eo, k) : S.slot_id[asm_slot(S, ref, rseq, eo, k, capmask, false)];
+                if (lds) {                                                   // node words in LDS
+                    atomicMin(&s_first[sn], 2u * (unsigned)e);
+                    atomicMin(&s_first[en], 2u * (unsigned)e + 1u);
+                    atomicAdd(&s_wc[sn], (unsigned)w); atomicAdd(&s_wc[en], (unsigned)w);
+                    if ((s_wc[sn] >> 30 & (unsigned)col) == 0u) atomicOr(&s_wc[sn], (unsigned)col << 30);
+                    if ((s_wc[en] >> 30 & (unsigned)col) == 0u) atomicOr(&s_wc[en], (unsigned)col << 30);
+                } else {
+                    atomicMin(&S.first[sn], 2u * (unsigned)e);
+                    atomicMin(&S.first[en], 2u * (unsigned)e + 1u);
+                    atomicAdd(&S.weight[sn], w); atomicAdd(&S.weight[en], w);
+                    atomicOr(&S.colour[sn], col); atomicOr(&S.colour[en], col);
                 }
-                const int sn = S.slot_id[asm_slot(S, ref, rseq, so, k, capmask, false)];
-                const int en = S.slot_id[asm_slot(S, ref, rseq, eo, k, capmask, false)];
-                atomicMin(&S.first[sn], 2u * (unsigned)e);
-                atomicMin(&S.first[en], 2u * (unsigned)e + 1u);
-                atomicAdd(&S.weight[sn], w); atomicAdd(&S.weight[en], w);
-                atomicOr(&S.colour[sn], col); atomicOr(&S.colour[en], col);
                 if (e < nRefE) { S.ref_node[e] = sn; if (e == nRefE - 1) S.ref_node[e + 1] = en; }
                 // successor slot keyed by the byte appended to the start k-mer
                 const unsigned char c = asm_ptr(ref, rseq, eo)[k - 1];
@@ -264,12 +373,18 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         if (old == word) { slot = j; break; }
                     }
                 }
-                if (slot < 0) { s_err = PLAT_ERR_UNSUPPORTED; continue; }                // > 8 distinct successor bytes
-                atomicMin(&S.succ_t[sn * ASM_MAX_SUCC + slot], (unsigned)e);
+                if (slot < 0) { s_err = PLAT_ERR_UNSUPPORTED; return true; }             // > 8 distinct successor bytes
+                // (a stale look at the ticket only costs the atomic it could have saved)
+                if (S.succ_t[sn * ASM_MAX_SUCC + slot] > (unsigned)e) atomicMin(&S.succ_t[sn * ASM_MAX_SUCC + slot], (unsigned)e);
                 atomicAdd(&S.succ_w[sn * ASM_MAX_SUCC + slot], w);
                 S.succ_n[sn * ASM_MAX_SUCC + slot] = en;
-            }
+                return true;
+            });
             asm_sync();
+            if (lds) {                                                        // the node words the later phases read, to the slice
+                for (int n = tid; n < nNodes; n += nthr) { S.first[n] = s_first[n]; S.weight[n] = (int)(s_wc[n] & 0x0FFFFFFFu); S.colour[n] = (int)(s_wc[n] >> 30); }
+                asm_sync();
+            }
             // ---- phase D: per node, the four successors with the smallest first tickets, in ticket order
             for (int n = tid; n < nNodes; n += nthr) {
                 AsmNodeE E; E.n = 0;
@@ -322,25 +437,37 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 if (s_cycle && k <= 50) continue;          // rebuild with a longer k
                 if (s_cycle) break;                        // k > 50 and still cyclic: no variants (assembler.pyx:1454-1457)
             }
-            // ---- phase E: bubble starts in allNodes order (= increasing position for REF_AND_READ nodes)
-            if (tid == 0) {
-                int nt = 0;
+            // ---- phase E: bubble starts in allNodes order (= increasing position for REF_AND_READ nodes): positions in chunks of
+            // nthr, one thread per position, the tasks of a chunk written in position order behind those of the chunk before
+            {
                 const int i0 = aStart - refStart > 0 ? aStart - refStart : 0;
                 const int i1 = aEnd - refStart < nRefE + 1 ? aEnd - refStart : nRefE + 1;
-                for (int i = i0; i < i1 && s_err == 0; ++i) {
-                    if (nRefE == 0) break;
-                    const int n = S.ref_node[i];
-                    const unsigned ft = S.first[n];
-                    if ((int)(ft >> 1) + (int)(ft & 1u) != i) continue;          // not the first occurrence of this k-mer
-                    if (S.colour[n] != 3) continue;                                // assembler.pyx:1144
-                    const AsmNodeE& E = S.edges[n];
-                    for (int j = 0; j < E.n; ++j)
-                        if (S.colour[E.end[j]] == 2) {                             // assembler.pyx:1153
-                            if (nt >= ASM_MAX_TASKS) { s_err = PLAT_ERR_OVERFLOW; break; }
-                            S.task_node[nt] = n; S.task_edge[nt] = j; ++nt;
+                for (int c0 = i0; c0 < i1 && nRefE > 0; c0 += nthr) {
+                    const int i = c0 + tid;
+                    int n = -1, cnt = 0, mask = 0;
+                    if (i < i1) {
+                        n = S.ref_node[i];
+                        const unsigned ft = S.first[n];
+                        if ((int)(ft >> 1) + (int)(ft & 1u) == i && S.colour[n] == 3) {        // first occurrence of this k-mer; assembler.pyx:1144
+                            const AsmNodeE& E = S.edges[n];
+                            for (int j = 0; j < E.n; ++j)
+                                if (S.colour[E.end[j]] == 2) { mask |= 1 << j; ++cnt; }           // assembler.pyx:1153
                         }
+                    }
+                    s_scan[tid] = cnt;
+                    __syncthreads();
+                    if (tid == 0) {
+                        int run = s_ntasks;
+                        for (int t = 0; t < nthr; ++t) { const int v = s_scan[t]; s_scan[t] = run; run += v; }
+                        if (run > ASM_MAX_TASKS) { s_err = PLAT_ERR_OVERFLOW; run = s_ntasks; for (int t = 0; t < nthr; ++t) s_scan[t] = ASM_MAX_TASKS; }
+                        s_ntasks = run;
+                    }
+                    __syncthreads();
+                    int at = s_scan[tid];
+                    for (int j = 0; j < 4 && cnt > 0; ++j)
+                        if ((mask >> j) & 1) { if (at < ASM_MAX_TASKS) { S.task_node[at] = n; S.task_edge[at] = j; } ++at; }
+                    __syncthreads();
                 }
-                s_ntasks = nt;
             }
             asm_sync();
             const int nTasks = s_ntasks;
@@ -409,14 +536,15 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     if (te < s) continue;                                          // :1213-1218
                     int rl = te - s + 1, al = plen;
                     const uint8_t* r = ref + (s - refStart);
-                    // alt = first byte of every node on the path; element `last` is the path's last node
+                    // alt = first byte of every node on the path; element `last` is the path's last node.  The path is walked once
+                    // (parent pointers) into a byte buffer: the DFS stack of the cycle check is free by now
                     // suffix trim first (:1253), then prefix trim advancing the position (:1262-1270)
-                    // walk helper: byte of path element at index q (0-based from the path start)
-                    auto alt_at = [&](int q) -> uint8_t {
+                    uint8_t* pathb = (uint8_t*)S.stack;
+                    {
                         int e = last;
-                        for (int d = plen - 1; d > q; --d) e = A[3 * e + 1];
-                        return asm_ptr(ref, rseq, S.rep[A[3 * e]])[0];
-                    };
+                        for (int d = plen - 1; d >= 0; --d) { pathb[d] = asm_ptr(ref, rseq, S.rep[A[3 * e]])[0]; e = A[3 * e + 1]; }
+                    }
+                    auto alt_at = [&](int q) -> uint8_t { return pathb[q]; };
                     while (al > 0 && rl > 0 && r[rl - 1] == alt_at(al - 1)) { --rl; --al; }
                     int ao = 0;
                     while (al > 0 && rl > 0 && r[0] == alt_at(ao)) { ++r; ++ao; --rl; --al; ++s; }
@@ -502,10 +630,16 @@ PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* ba
     P.max_vars = max_vars_per_region; P.blob_per_region = blob_per_region; P.cap = cap; P.max_pos = (int)max_pos;
     const size_t per_block = asm_scratch_bytes(cap, (int)max_pos, max_ref, max_reads);
     P.scratch_per_block = (long long)per_block;
-    int nblk = b.n_regions < 2 * ctx->n_cu ? b.n_regions : 2 * ctx->n_cu;
-    while (nblk > 1 && per_block * (size_t)nblk > ((size_t)48 << 30)) nblk /= 2;
+    // the kernel is bound by the latency of dependent L2 accesses, not by bandwidth or issue: one region per CU at a time (its graph takes
+    // most of the CU's LDS) and as the scratch memory allows (PLAT_ASM_WG_PER_CU overrides, for measurements)
+    int per_cu = 1;                                  // (the graph of a region takes most of a CU's LDS)
+    if (const char* e = getenv("PLAT_ASM_WG_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+    int nblk = b.n_regions < per_cu * ctx->n_cu ? b.n_regions : per_cu * ctx->n_cu;
+    while (nblk > 1 && per_block * (size_t)nblk > ((size_t)96 << 30)) nblk = nblk * 3 / 4;
     if ((rc = plat_reserve(ctx, ctx->asm_scratch, per_block * (size_t)nblk))) return rc;
-    hipLaunchKernelGGL(k_assemble, dim3(nblk), dim3(256), 0, st, b, P, (char*)ctx->asm_scratch.ptr, max_ref, max_reads,
+    const int lds_bytes = ASM_LDS_BYTES;
+    PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(k_assemble, dim3(nblk), dim3(ASM_THREADS), lds_bytes, st, b, P, (char*)ctx->asm_scratch.ptr, max_ref, max_reads,
                        var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
