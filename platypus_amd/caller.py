@@ -12,18 +12,18 @@ device stage runs ONCE over all windows of all regions -- one candidate scan, on
 pass, one posterior pass, one read-statistics pass, one genotype-marginalisation pass -- with the host logic (window
 generation, haplotype enumeration, dictionary assembly, text) in between.  Both produce the same text
 (tests/test_gpu_caller.py)."""
+from types import SimpleNamespace
+
 import numpy as np
 
 from . import hostapi as H
 from .regionprep import (WindowGenerator, computeVariantReadSupportFrac, filterVariants, filterVariantsByCoverage,
                          getHaplotypesInWindow, leftNormaliseIndel)
-from .vcfrecords import (genotypeCallSites, genotypeCallTuples, getHaplotypeInfo, infoStatsWindow, outputCallToVCF, vcfFILTER,
-                         vcfINFO)
+from .vcfrecords import (genotypeCallSites, genotypeCallTuples, getHaplotypeInfo, infoStatsWindow, outputCallToVCF, outputRefCall,
+                         py2_dict_order, vcfFILTER, vcfINFO)
 
 
 def _unsupported(options):
-    if getattr(options, "outputRefCalls", 0):
-        raise NotImplementedError("reference-call blocks (outputRefCall, variantcaller.pyx:764-867) are not built")
     if getattr(options, "sourceFile", None):
         raise NotImplementedError("candidates from a source VCF (variantutils.VariantCandidateReader) are not built")
     if getattr(options, "HLATyping", 0):
@@ -175,6 +175,8 @@ def _windowsOfRegion(chrom, start, end, refFile, options, variants, windowGenera
     maxContigPos = refFile.refs[chrom].SeqLength - 1
     for window in windowGenerator.WindowsAndVariants(chrom, start, end, maxContigPos, variants, options):
         if len(window["variants"]) == 0:
+            if options.outputRefCalls:                                           # a reference-call block (:605-607)
+                yield window
             continue
         if window["endPos"] - window["startPos"] > options.maxSize:              # :566-568
             continue
@@ -187,19 +189,42 @@ def _windowFailed(window, exc):
                                        window["startPos"], window["endPos"], exc)
 
 
+def _refCallBlocksBetween(varsByPos, chrom, options):
+    """:584-603: reference-call blocks between the called positions of one window, walked in the order a Python-2 dictionary holds
+    its integer keys (pop.varsByPos.iteritems())."""
+    last = None
+    for index, pos in enumerate(py2_dict_order(list(varsByPos.keys()))):
+        these = varsByPos[pos]
+        if index > 0:
+            lastVarPos = max(v.maxRefPos for v in last)
+            nextVarPos = min(v.minRefPos for v in these) + 1
+            if nextVarPos - lastVarPos > 1:
+                for blockStart in range(lastVarPos + 1, nextVarPos, options.refCallBlockSize):
+                    blockEnd = min(blockStart + options.refCallBlockSize, nextVarPos - 1)
+                    if blockStart != blockEnd:
+                        yield dict(chromosome=chrom, startPos=blockStart, endPos=blockEnd, variants=[], nVar=0)
+        last = these
+
+
 def callVariantsInRegion(chrom, start, end, readBuffers, refFile, options, vcfFile, outputFile, windowGenerator=None, pop=None):
     """Window by window, as the reference."""
     _unsupported(options)
     windowGenerator = windowGenerator or WindowGenerator()
     pop = pop or H.Population(options)
     variants = generateVariantsInRegion(chrom, start, end, refFile, options, readBuffers)
-    for window in _windowsOfRegion(chrom, start, end, refFile, options, variants, windowGenerator):
+    for windowIndex, window in enumerate(_windowsOfRegion(chrom, start, end, refFile, options, variants, windowGenerator)):
         try:                                                                     # :568-615: a failing window is logged and skipped
-            callVariantsInWindow(window, options, refFile, readBuffers, pop)
-            if len(pop.variantPosteriors) > 0:
+            if len(window["variants"]) > 0:
+                callVariantsInWindow(window, options, refFile, readBuffers, pop)
+            if len(window["variants"]) > 0 and len(pop.variantPosteriors) > 0:
                 outputCallToVCF(pop.varsByPos, pop.vcfInfo, pop.vcfFilter, pop.haplotypes, pop.genotypes, pop.frequencies,
                                 pop.genotypeLikelihoods, pop.goodnessOfFitValues, pop.haplotypeIndexes, pop.readBuffers, pop.nIndividuals,
                                 vcfFile, refFile, outputFile, options, pop.variants, window["startPos"], window["endPos"], population=pop)
+                if options.outputRefCalls and len(pop.varsByPos) > 1:
+                    for block in _refCallBlocksBetween(pop.varsByPos, chrom, options):
+                        outputRefCall(chrom, pop, vcfFile, refFile, outputFile, windowIndex, block, options, readBuffers)
+            elif options.outputRefCalls:
+                outputRefCall(chrom, pop, vcfFile, refFile, outputFile, windowIndex, window, options, readBuffers)
         except Exception as exc:
             _windowFailed(window, exc)
 
@@ -265,24 +290,47 @@ def callWindowsBatched(specs, options, refFile):
     return pops
 
 
+class _RefCallBuffer:
+    """What outputRefCall reads of a bamReadBuffer, with the window pointers as they stood when the reference would have written the
+    block (it does not move them for a block without variants, so they are those of the window called before it)."""
+
+    def __init__(self, buf):
+        self.sample, self._buf = buf.sample, buf
+        self.reads = SimpleNamespace(windowStart=buf.reads.windowStart, windowEnd=buf.reads.windowEnd)
+
+    def countReadsCoveringRegion(self, start, end):
+        return self._buf.countReadsCoveringRegion(start, end)
+
+
 def callVariantsInRegions(regions, refFile, options, vcfFile, outputFile, windowGenerator=None):
     """regions: list of (chrom, start, end, readBuffers) with the same samples.  Records are written in region order, then
-    window order, then position order -- the order callVariantsInRegion would write them one region after the other."""
+    window order, then position order -- the order callVariantsInRegion would write them one region after the other (reference-call
+    blocks of --outputRefCalls=1 in their places between them)."""
     _unsupported(options)
     windowGenerator = windowGenerator or WindowGenerator()
     variants, rlens = generateVariantsInRegions(regions, refFile, options)
-    specs = []
+    specs, items = [], []                       # items: ("call", spec index) | ("ref", chrom, window, buffers as outputRefCall sees them, Population stand-in)
     for (chrom, start, end, buffers), vs, rlen in zip(regions, variants, rlens):
         options.rlen = rlen                                                      # the region's own value (see generateVariantsInRegions)
+        nHapLast = 0                                                             # haplotypes of the last window set up in this region
         for window in _windowsOfRegion(chrom, start, end, refFile, options, vs, windowGenerator):
+            if len(window["variants"]) == 0:                                     # reference-call block
+                items.append(("ref", chrom, window, [_RefCallBuffer(b) for b in buffers], None))
+                continue
             try:
                 prep = _prepareWindow(window, options, refFile, buffers)         # (greedy haplotype filter: device calls of its own)
             except Exception as exc:                                             # :568-615: logged and skipped, as window by window
                 _windowFailed(window, exc)
                 continue
             if prep is not None:
-                specs.append(dict(variants=prep[0], haplotypes=prep[1], genotypes=prep[2], window=window,
-                                  readBuffers=[b.frozenWindow() for b in buffers]))
+                specs.append(dict(variants=prep[0], haplotypes=prep[1], genotypes=prep[2], window=window, chrom=chrom,
+                                  readBuffers=[b.frozenWindow() for b in buffers], refBuffers=[_RefCallBuffer(b) for b in buffers]))
+                items.append(("call", len(specs) - 1))
+                nHapLast = len(prep[1])
+            elif options.outputRefCalls:
+                stub = H.Population(options)                                     # a Population that was reset and not set up for this window
+                stub.nHaplotypes = nHapLast
+                items.append(("ref", chrom, window, [_RefCallBuffer(b) for b in buffers], stub))
     try:
         pops = callWindowsBatched(specs, options, refFile)
     except Exception:
@@ -295,12 +343,24 @@ def callVariantsInRegions(regions, refFile, options, vcfFile, outputFile, window
             except Exception as exc:
                 _windowFailed(sp["window"], exc)
                 pops.append(None)
-    for sp, p in zip(specs, pops):
-        if p is not None and len(p.variantPosteriors) > 0:
-            try:
+    for it in items:
+        try:
+            if it[0] == "ref":
+                outputRefCall(it[1], it[4], vcfFile, refFile, outputFile, 0, it[2], options, it[3])
+                continue
+            sp, p = specs[it[1]], pops[it[1]]
+            if p is None:
+                continue
+            window = sp["window"]
+            if len(p.variantPosteriors) > 0:
                 outputCallToVCF(p.varsByPos, p.vcfInfo, p.vcfFilter, p.haplotypes, p.genotypes, p.frequencies, p.genotypeLikelihoods,
                                 p.goodnessOfFitValues, p.haplotypeIndexes, p.readBuffers, p.nIndividuals, vcfFile, refFile, outputFile,
-                                options, p.variants, sp["window"]["startPos"], sp["window"]["endPos"], genotypeCalls=p._genotypeCalls)
-            except Exception as exc:
-                _windowFailed(sp["window"], exc)
+                                options, p.variants, window["startPos"], window["endPos"], genotypeCalls=p._genotypeCalls)
+                if options.outputRefCalls and len(p.varsByPos) > 1:
+                    for block in _refCallBlocksBetween(p.varsByPos, sp["chrom"], options):
+                        outputRefCall(sp["chrom"], p, vcfFile, refFile, outputFile, 0, block, options, sp["refBuffers"])
+            elif options.outputRefCalls:
+                outputRefCall(sp["chrom"], p, vcfFile, refFile, outputFile, 0, window, options, sp["refBuffers"])
+        except Exception as exc:
+            _windowFailed(it[2] if it[0] == "ref" else specs[it[1]]["window"], exc)
     return len(specs)

@@ -24,8 +24,8 @@ from .batch import BAM_FQCFAIL, HostBatch
 from .options import default_options
 from .regionprep import (WindowGenerator, computeVariantReadSupportFrac, filterVariants, filterVariantsByCoverage,  # noqa: F401
                          getHaplotypesInWindow, leftNormaliseIndel)
-from .vcfrecords import (VCF, computeHaplotypeScore, computeSCValue, getHaplotypeInfo, outputCallToVCF, refAndAlt,  # noqa: F401
-                         trimLeftPadding, vcfFILTER, vcfINFO)
+from .vcfrecords import (VCF, computeHaplotypeScore, computeSCValue, getHaplotypeInfo, outputCallToVCF, outputRefCall, py2_round,  # noqa: F401
+                         refAndAlt, trimLeftPadding, vcfFILTER, vcfINFO)
 
 PLATYPUS_VAR, FILE_VAR, ASSEMBLER_VAR = 1, 2, 4               # variant.pyx:43-45
 SNP, MNP, INS, DEL, REP = 0, 1, 2, 3, 4                       # variant.pyx:49-53
@@ -502,6 +502,14 @@ class Population:
 
     def calculatePosterior(self, var, flatPrior=0):                                                   # :459-594
         prior = 0.5 if flatPrior == 1 else var.calculatePrior(getattr(self, "refFile", None))
+        if not self.haplotypes:
+            # asked about a window it was not set up for (outputRefCall on a window whose calling stopped early): the reference's
+            # object still holds the haplotype COUNT of the last window it was set up for and an empty haplotype list (reset(),
+            # :166-195), so its loop over the haplotypes raises -- unless it never was set up, then every sum is empty
+            if getattr(self, "nHaplotypes", 0) > 0:
+                raise IndexError("list index out of range")
+            import math
+            return float(py2_round(-10.0 * (math.log10(1.0 * (1.0 - prior)) - math.log10(prior + 1.0 * (1.0 - prior)))))
         return float(get_engine().variant_posteriors(self._db, [self._w], self._masks([var]), [prior])[0])
 
     def _distinctVariants(self):

@@ -402,6 +402,78 @@ def genotypeCallTuples(results, nIndividuals):
              for i in range(nIndividuals)] for ph, lik, o4 in results]
 
 
+def _c_log10(x):
+    """log10 of math.h (the reference's is the C function: -inf at zero instead of an exception)."""
+    return -math.inf if x == 0 else math.log10(x)
+
+
+def outputRefCall(chrom, pop, vcfFile, refFile, outputFile, windowIndex, window, options, readBuffers):
+    """variantcaller.pyx:764-867: one REFCALL line for a block without called variants.  QUAL: 0 without coverage somewhere in the
+    block; else the phred-scaled beta-binomial p-value of seeing no variant read at the block's smallest coverage, capped -- when the
+    block holds candidates -- by the posterior of the best candidate under a flat prior (pop.calculatePosterior(v, 1)).
+    Pinned by tests/golden/refcall_cases.json.gz (the reference's own text)."""
+    from .hostapi import betaBinomialCDF
+    windowStart, windowEnd = window["startPos"], window["endPos"]
+    variants = window["variants"]
+    minCov = -1
+    for buf in readBuffers:
+        for p in range(windowStart, windowEnd):
+            c = buf.countReadsCoveringRegion(p, p + 1)
+            minCov = c if minCov == -1 else min(minCov, c)
+    phredPValue = int(-10 * _c_log10(betaBinomialCDF(0, minCov, 20, 20)))
+    if minCov == 0:
+        qual = 0
+    elif len(variants) == 0:
+        qual = phredPValue
+    else:
+        maxPost = max(pop.calculatePosterior(v, 1) for v in variants)
+        maxProbVar = 1.0 - 10 ** (-0.1 * maxPost)
+        probRef = 1.0 - maxProbVar
+        qual = min(int(py2_round(-10.0 * _c_log10(1.0 - probRef))), phredPValue)       # (an infinite value raises here, as there)
+    ref = py2_str(refFile.getSequence(chrom, windowStart, windowStart + 1))
+    alt = ["T"] if ref == "N" else ["N"]                                                 # REF and ALT must differ
+    lineinfo = {k: ["."] for k in ("FR", "MMLQ", "HP", "TCR", "WE", "WS", "Source", "FS", "START", "PP", "TR", "NF", "TCF", "NR", "TC", "MGOF",
+                                   "SbPval", "ReadPosRankSum", "MQ", "QD", "SC", "BRF", "HapScore")}
+    lineinfo["END"], lineinfo["Size"] = [windowEnd], [windowEnd - windowStart]
+    line = dict(chrom=chrom, pos=windowStart, ref=ref, alt=alt, id=".", info=lineinfo, filter=["REFCALL"], qual=qual, format=["GT:GL:GOF:GQ:NR:NV"])
+    for buf in readBuffers:
+        n = buf.reads.windowEnd - buf.reads.windowStart
+        line[buf.sample] = dict(GT=[[".", "/", "."]], GL=[-1, -1, -1], GQ=[-1], GOF=[-1], NR=[n], NV=[0])
+    vcfFile.write_data(outputFile, line)
+
+
+def py2_dict_order(keys):
+    """Iteration order of a Python-2 dict holding these integer keys, inserted in this order (dictobject.c: the same open addressing
+    and growth as the set of py2_set_order; hash(int) is the int, -1 -> -2)."""
+    m = (1 << 64) - 1
+
+    def slot(table, key):
+        h = (-2 if key == -1 else key) & m
+        mask = len(table) - 1
+        i, perturb = h & mask, h
+        while table[i & mask] is not None and table[i & mask] != key:
+            i = (5 * i + perturb + 1) & m
+            perturb >>= 5
+        return i & mask
+    table, used = [None] * 8, 0
+    for key in keys:
+        j = slot(table, key)
+        if table[j] is not None:
+            continue
+        table[j] = key
+        used += 1
+        if used * 3 >= len(table) * 2:
+            size = 8
+            while size <= used * (2 if used > 50000 else 4):
+                size <<= 1
+            grown = [None] * size
+            for k in table:
+                if k is not None:
+                    grown[slot(grown, k)] = k
+            table = grown
+    return [k for k in table if k is not None]
+
+
 def outputCallToVCF(varsByPos, vcfInfo, vcfFilter, haplotypes, genotypes, haplotypeFrequencies, genotypeLikelihoods, gofValues,
                     haplotypeIndexes, readBuffers, nIndividuals, vcfFile, refFile, outputFile, options, allVariants, windowStart, windowEnd,
                     population=None, genotypeCalls=None):

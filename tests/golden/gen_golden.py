@@ -897,6 +897,41 @@ def window_records(dict varsByPos, dict vcfInfo, dict vcfFilter, list haplotypes
                     options, allVariants, windowStart, windowEnd)
 """
 
+REFCALL_HEAD = r"""
+import math
+xrange = range
+cdef double PI = math.pi
+cdef extern from "math.h":
+    double pow(double, double)
+
+cdef class CoverageBuffer(bamReadBuffer):
+    # a bamReadBuffer whose countReadsCoveringRegion (cwindow.pyx:649-653) reads a per-position coverage array
+    cdef public list cov
+    cdef public long covStart
+    cpdef int countReadsCoveringRegion(self, int start, int end):
+        return self.cov[start - self.covStart]
+
+cdef class Population:
+    # calculatePosterior(var, flatPrior=1) of the window's Population (cpopulation.pyx:459-594): supplied by the fixture
+    cdef public dict post
+    def __init__(self, dict post):
+        self.post = post
+    cpdef double calculatePosterior(self, Variant var, int flatPrior=0):
+        return self.post[var.idx]
+
+"""
+
+REFCALL_TAIL = r"""
+def ref_call(chrom, dict post, vcfFile, FastaFile refFile, outputFile, dict window, options, list sampleNames, list covs, long covStart, list nWindowReads):
+    buffers = []
+    for i in range(len(sampleNames)):
+        b = CoverageBuffer(sampleNames[i], nWindowReads[i])
+        b.cov = covs[i]
+        b.covStart = covStart
+        buffers.append(b)
+    outputRefCall(chrom, Population(post), vcfFile, refFile, outputFile, 0, window, options, buffers)
+"""
+
 REGION_TAIL = r"""
 def left_normalise(Variant v, FastaFile refFile, int maxReadLength):
     cdef Variant n = leftNormaliseIndel(v, refFile, maxReadLength)
@@ -1224,6 +1259,13 @@ def build_scratch(scratch):
             + "\n".join(vcu[126:133]) + "\n\n" + "\n".join(vcu[146:334]) + "\n\n" + "\n".join(vcu[795:839]) + "\n\n"
             + "\n".join(vcu[842:897]).replace("cdef bytes REF", "cdef object REF") + "\n\n" + "\n".join(vcu[337:599]).replace("linefilter = list(set(linefilter))", "linefilter = list(Py2Set(linefilter))") + "\n\n"
             + "\n".join(vcu[1479:1498]) + "\n\n" + "\n".join(vcu[1501:1627]) + "\n" + VCFDRV_TAIL)
+    # + reference-call blocks: outputRefCall (variantcaller.pyx:764-867) with the beta-binomial functions it calls (platypusutils.pyx,
+    # the slices hap_drv uses too).  Adaptation: its first parameter is declared `bytes chrom`; sequences and names are native
+    # strings in this driver (as under Python 2), so the declaration is dropped.
+    vca = open(os.path.join(src, "cython/variantcaller.pyx")).read().split("\n")
+    assert vca[763].startswith("def outputRefCall(bytes chrom, Population pop") and vca[866].strip() == "vcfFile.write_data(outputFile, vcfDataLine)"
+    vdrv += (REFCALL_HEAD + "\n".join(utl[177:193]) + "\n\n" + "\n".join(utl[212:219]) + "\n\n" + "\n".join(utl[266:296]) + "\n\n" + "\n".join(utl[305:316]) + "\n\n"
+             + "\n".join(vca[763:867]).replace("def outputRefCall(bytes chrom,", "def outputRefCall(chrom,") + "\n" + REFCALL_TAIL)
     open(os.path.join(scratch, "vcf_drv.pyx"), "w").write(vdrv)
     open(os.path.join(scratch, "py2compat.py"), "w").write(PY2COMPAT)
     open(os.path.join(scratch, "setup.py"), "w").write(SETUP)
@@ -2172,6 +2214,55 @@ def gen_vcf(out):
     print("vcf: %d windows, %d record lines" % (len(cases), nlines))
 
 
+def gen_refcall(out):
+    """Reference-call blocks (--outputRefCalls=1): the text of outputRefCall (variantcaller.pyx:764-867) over the reference's own
+    betaBinomialCDF and VCF.write_data, on blocks with and without variants, with and without coverage, 1-3 samples, an N as the
+    first reference base.  The window's Population (flat-prior posteriors) and the buffers' coverage are inputs of the fixture."""
+    import io, types
+    import vcf_drv
+    VCF, infoSig, filterSig, formatSig = build_vcf_writer()
+    rng = np.random.default_rng(764867)
+    cases = []
+    for ci in range(90):
+        ref = bytearray(rnd(rng, 2600))
+        ws = int(rng.integers(200, 900)); size = int(rng.choice([1, 2, 7, 40, 150, 400, 1000])); we = ws + size
+        if ci % 7 == 3:
+            ref[ws] = ord("N")
+        ref = bytes(ref).decode()
+        nInd = int(rng.integers(1, 4))
+        names = [("S%d" % (i + 1)).encode() for i in range(nInd)]
+        covs, nwin = [], []
+        for i in range(nInd):
+            mode = int(rng.integers(0, 5))
+            base = 0 if mode == 0 else int(rng.integers(1, 70))
+            c = np.maximum(0, base + np.cumsum(rng.integers(-1, 2, size))).astype(int)
+            if mode == 1:
+                c[int(rng.integers(0, size))] = 0
+            covs.append(c.tolist()); nwin.append(int(0 if mode == 0 else max(1, c.max() + rng.integers(0, 9))))
+        nVar = int(rng.choice([0, 0, 1, 2, 3]))
+        vs, post = [], {}
+        for k in range(nVar):
+            p_ = int(rng.integers(ws, we))
+            vs.append(vcf_drv.Variant("20", p_, ref[p_:p_ + 1], "ACGT"[(("ACGTN".index(ref[p_]) + 1) % 4)], k))
+            post[k] = float(rng.choice([0.0, 1.0, 3.0, 4.0, 7.0, 19.0, 45.0, 120.0, 200.0]))
+        options = types.SimpleNamespace(outputRefCalls=1, refCallBlockSize=1000)
+        vf = VCF()
+        vf.setsamples(list(names)); vf.setinfo(infoSig); vf.setfilter(filterSig); vf.setformat(formatSig)
+        stream = io.StringIO()
+        window = dict(chromosome="20", startPos=ws, endPos=we, variants=vs, nVar=len(vs))
+        err = None
+        try:
+            vcf_drv.ref_call("20", post, vf, vcf_drv.FastaFile({"20": ref}), stream, window, options, list(names), covs, ws, nwin)
+        except Exception as e:
+            err = type(e).__name__
+        cases.append(dict(ref=ref, start=ws, end=we, samples=[n.decode() for n in names], coverage=covs, window_reads=nwin,
+                          variants=[dict(pos=v.refPos, removed=v.removed, added=v.added, flat_posterior=post[v.idx]) for v in vs],
+                          error=err, lines=stream.getvalue().split("\n")[:-1]))
+    with gzip.open(os.path.join(out, "refcall_cases.json.gz"), "wt") as f:
+        json.dump(cases, f)
+    print("refcall: %d blocks, %d lines, %d errors" % (len(cases), sum(len(c["lines"]) for c in cases), sum(c["error"] is not None for c in cases)))
+
+
 def gen_regionprep(out):
     """Between the candidates and the windows ("with window generation ... a BAM-free region pipeline"):
     leftNormaliseIndel, filterVariants, filterVariantsByCoverage (the reference's texts in hap_drv), ReadArray's window pointers and
@@ -2440,7 +2531,7 @@ def main():
         sys.exit("reference tree not found at %s: golden vectors can only be regenerated in the build container" % REF)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     build_scratch(a.scratch)
-    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq", "candidates", "readqc", "infostats", "pvalues", "vcf", "regionprep", "indelprior"]
+    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq", "candidates", "readqc", "infostats", "pvalues", "vcf", "regionprep", "indelprior", "refcall"]
     if "dp" in todo:
         gen_dp(HERE)
     if "mapalign" in todo:
@@ -2469,6 +2560,8 @@ def main():
         gen_regionprep(HERE)
     if "indelprior" in todo:
         gen_indelprior(HERE)
+    if "refcall" in todo:
+        gen_refcall(HERE)
 
 
 if __name__ == "__main__":

@@ -315,3 +315,46 @@ def test_vcf_header_lists_every_field_the_records_use(golden_dir):
             assert {kv.split("=")[0] for kv in f[7].split(";")} <= ids["INFO"]
             assert f[6] == "PASS" or set(f[6].split(";")) <= ids["FILTER"]
             assert set(f[8].split(":")) <= ids["FORMAT"]
+
+
+def test_outputRefCall_matches_reference_golden(golden_dir):
+    """variantcaller.pyx:764-867 (REFCALL lines of --outputRefCalls=1) against the reference's own text (tests/golden/gen_golden.py:
+    gen_refcall): the block's coverage and the flat-prior posteriors of its candidates are inputs of the fixture."""
+    import gzip, io, json, os
+    from types import SimpleNamespace
+    from platypus_amd import hostapi as H, vcfrecords as V
+    cases = json.load(gzip.open(os.path.join(golden_dir, "refcall_cases.json.gz"), "rt"))
+    assert len(cases) >= 80 and sum(len(c["lines"]) for c in cases) >= 80 and any(c["error"] for c in cases)
+    assert len({ln.split("\t")[5] for c in cases for ln in c["lines"]}) >= 10            # a spread of QUAL values
+
+    class Buf:
+        def __init__(self, name, cov, start, n):
+            self.sample, self.cov, self.start = name, cov, start
+            self.reads = SimpleNamespace(windowStart=0, windowEnd=n)
+
+        def countReadsCoveringRegion(self, s, e):
+            return self.cov[s - self.start]
+    for c in cases:
+        fasta = H.FastaFile({"20": c["ref"].encode()})
+        vs = [H.Variant("20", v["pos"], v["removed"].encode(), v["added"].encode()) for v in c["variants"]]
+        post = {id(v): d["flat_posterior"] for v, d in zip(vs, c["variants"])}
+        pop = SimpleNamespace(calculatePosterior=lambda v, flat: post[id(v)])
+        bufs = [Buf(n, cov, c["start"], nr) for n, cov, nr in zip(c["samples"], c["coverage"], c["window_reads"])]
+        out = io.StringIO()
+        err = None
+        try:
+            V.outputRefCall("20", pop, V.VCF(c["samples"]), fasta, out, 0, dict(chromosome="20", startPos=c["start"], endPos=c["end"], variants=vs),
+                            SimpleNamespace(outputRefCalls=1), bufs)
+        except Exception as e:
+            err = type(e).__name__
+        assert err == c["error"] and out.getvalue().split("\n")[:-1] == c["lines"], (c["start"], c["end"])
+
+
+def test_py2_dict_order_of_small_integer_keys():
+    """The order pop.varsByPos.iteritems() walks the positions of a window in (between-variant REFCALL blocks, variantcaller.pyx:584-603):
+    a Python-2 dict of ints iterates in slot order = key modulo the table size, collisions by the perturbed probe."""
+    from platypus_amd.vcfrecords import py2_dict_order
+    assert py2_dict_order([3, 1, 2]) == [1, 2, 3]                    # {3: .., 1: .., 2: ..}.keys() under Python 2
+    assert py2_dict_order([9, 1]) == [9, 1] and py2_dict_order([1, 9]) == [1, 9]        # 9 and 1 share slot 1: first come, first kept
+    assert py2_dict_order([1000, 1001, 1008]) == [1000, 1001, 1008] and py2_dict_order([15, 8]) == [8, 15]
+    assert sorted(py2_dict_order(list(range(100, 160, 7)))) == list(range(100, 160, 7))

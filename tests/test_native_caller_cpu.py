@@ -137,3 +137,28 @@ def test_native_equals_python_on_array_regions(fake):
     called = {(ln.split("\t")[0], int(ln.split("\t")[1])) for ln in txt.split("\n")[:-1]}
     snps = [(r["chrom"], p + 1) for r in regs for (p, rem, add), t0, t1 in zip(r["variants"], r["truth"][0], r["truth"][1]) if len(rem) == len(add) and t0 + t1 > 0]
     assert sum(k in called for k in snps) >= 0.9 * len(snps)
+
+
+def test_reference_call_blocks_batched_equals_window_by_window(fake):
+    """--outputRefCalls=1 (variantcaller.pyx:584-607,764-867): REFCALL lines for the blocks between calling windows, between the
+    called positions of a window and for windows without a call; the batched shape of the Python region loop writes what the
+    window-by-window shape writes.  (The native loop does not build them: PLAT_ERR_UNSUPPORTED, covered above.)"""
+    regs = [synth.config4_region(400 + i, n_samples=2, region_len=2500, snp_rate=5e-3, indel_rate=1.5e-3, read_len=100, depth=[30, 4][i % 2]) for i in range(3)]
+    names = ["S1", "S2"]
+    fasta, work = _work(regs, names)
+    for opt in (dict(outputRefCalls=1), dict(outputRefCalls=1, refCallBlockSize=150, minPosterior=60)):
+        one = io.StringIO()
+        for c, s_, e, bufs in _work(regs, names)[1]:
+            caller.callVariantsInRegion(c, s_, e, bufs, fasta, default_options(**opt), VCF(names), one)
+        many = io.StringIO()
+        caller.callVariantsInRegions(_work(regs, names)[1], fasta, default_options(**opt), VCF(names), many)
+        lines = many.getvalue().split("\n")[:-1]
+        assert one.getvalue() == many.getvalue()
+        ref = [ln for ln in lines if "\tREFCALL\t" in ln]
+        var = [ln for ln in lines if "\tREFCALL\t" not in ln]
+        assert len(ref) >= 20 and len(var) >= 5
+        # the blocks tile the gaps: every REFCALL line carries END and Size = END - POS + 1 - 1 (0-based start, half-open end)
+        for ln in ref:
+            f = ln.split("\t")
+            info = dict(kv.split("=") for kv in f[7].split(";"))
+            assert int(info["Size"]) == int(info["END"]) - (int(f[1]) - 1) and f[4] in ("N", "T") and f[9].startswith("./.:-1,-1,-1:-1:-1:")
