@@ -624,10 +624,20 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 const int run = min(48, (int)__ffsll((long long)~v) - 1);     // trailing ones of v (v never has 64 ones beyond the cap)
                 const int go = s_go[run < 0 ? 48 : run];
                 if (p < hapLen && first_group) hapw[hoff + p] = hap_word(b0, (unsigned)go);
-                int gm = p < hapLen ? go : 127;
-#pragma unroll
-                for (int s2 = 32; s2 > 0; s2 >>= 1) gm = min(gm, __shfl_xor(gm, s2));
-                if (lane == 0) s_gmin[t] = (unsigned char)gm;
+                // smallest gap-open penalty of the chunk = the table entry of its LONGEST run (the table never rises with the run
+                // length): found on the wave-uniform run plane with scalar shifts -- positions where k consecutive bits are set,
+                // k = 1, 2, ... until none is left -- instead of a reduction over the lanes
+                {
+                    const int nvalid = min(64, hapLen - 64 * t);
+                    u64 left = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+                    int longest = 0;
+                    while (longest < 48) {
+                        left &= funnel(P0.me, P1.me, longest);
+                        if (left == 0ull) break;
+                        ++longest;
+                    }
+                    if (lane == 0) s_gmin[t] = (unsigned char)s_go[longest];
+                }
             }
             if (p < hapLen - 7) {
                 const unsigned code = plane_code(P0.m0, P1.m0, P0.m1, P1.m1, lane);
