@@ -51,7 +51,10 @@ static inline void ck(int rc, const char* where) { if (rc != PLAT_OK) throw Devi
 struct Slot;                                                              // one worker's device context
 template <class T> struct Staged {
     T* h = nullptr; T* d = nullptr; size_t hcap = 0, dcap = 0, n = 0;
-    void reserve(plat_ctx* ctx, size_t want, bool host = true, bool dev = true) {
+    bool view = false;                                                     // h / d point into an arena (Layout): nothing owned
+    // zeroStream != nullptr: a grown device buffer is zeroed once, on that stream (blob slack must hold 7-bit bytes for the kernels
+    // that validate whole dwords; afterwards it only ever holds old, valid bytes)
+    void reserve(plat_ctx* ctx, size_t want, bool host = true, bool dev = true, void* zeroStream = nullptr) {
         if (host && want > hcap) {
             const size_t ncap = want + want / 2 + 64;
             T* nh = nullptr;
@@ -65,10 +68,15 @@ template <class T> struct Staged {
             ck(plat_malloc(ctx, ncap * sizeof(T) + PLAT_BLOB_PAD, (void**)&nd), "plat_malloc");
             if (d) plat_free(ctx, d);                                      // (contents are rewritten by whoever grows a buffer)
             d = nd; dcap = ncap;
+            if (zeroStream) ck(plat_memset(ctx, d, 0, ncap * sizeof(T) + PLAT_BLOB_PAD, zeroStream), "plat_memset");
         }
     }
-    void release(plat_ctx* ctx) { if (h) plat_host_free(ctx, h); if (d) plat_free(ctx, d); h = nullptr; d = nullptr; hcap = dcap = n = 0; }
+    void release(plat_ctx* ctx) {
+        if (!view) { if (h) plat_host_free(ctx, h); if (d) plat_free(ctx, d); }
+        h = nullptr; d = nullptr; hcap = dcap = n = 0;
+    }
 };
+typedef Staged<uint8_t> Arena;
 
 struct Slot {
     plat_ctx* ctx = nullptr;
@@ -92,6 +100,8 @@ struct Slot {
     Staged<int64_t> p_off, s_aoff, s_moff, s_counts, k_vo, k_ro, k_lo;
     Staged<uint8_t> p_mask, s_added, s_vig;
     Staged<double> p_prior, p_post, k_lik, k_out4;
+    // many small arrays travel as ONE copy: they are views into these blocks (Layout)
+    Arena a_tab, a_cin, a_cout, a_win, a_wout, a_pin, a_sin, a_sout;
     double t_host = 0, t_wait = 0;
 
     void sync(const char* where) {
@@ -102,6 +112,26 @@ struct Slot {
     }
     template <class T> void up(Staged<T>& s, size_t n) { if (n) ck(plat_memcpy_h2d(ctx, s.d, s.h, n * sizeof(T), stream), "plat_memcpy_h2d"); }
     template <class T> void down(Staged<T>& s, size_t n) { if (n) ck(plat_memcpy_d2h(ctx, s.h, s.d, n * sizeof(T), stream), "plat_memcpy_d2h"); }
+};
+
+// Arrays of one stage laid out back to back in one pinned block + one device block: one copy per stage and direction instead of one per
+// array (a copy costs ~5 us of GPU time and as much host time however small it is).
+struct Layout {
+    struct Item { void** h; void** d; size_t bytes, off; };
+    std::vector<Item> items;
+    size_t total = 0;
+    template <class T> void add(Staged<T>& st, size_t n) {
+        st.view = true; st.n = n;
+        items.push_back(Item{(void**)&st.h, (void**)&st.d, (n + 8) * sizeof(T), 0});
+    }
+    void commit(Slot& s, Arena& a) {
+        total = 0;
+        for (Item& it : items) { it.off = total; total += (it.bytes + 255) & ~(size_t)255; }
+        a.reserve(s.ctx, total + PLAT_BLOB_PAD);
+        for (Item& it : items) { *it.h = a.h + it.off; *it.d = a.d + it.off; }
+    }
+    void upload(Slot& s, Arena& a) { if (total) ck(plat_memcpy_h2d(s.ctx, a.d, a.h, total, s.stream), "plat_memcpy_h2d"); }
+    void download(Slot& s, Arena& a) { if (total) ck(plat_memcpy_d2h(s.ctx, a.h, a.d, total, s.stream), "plat_memcpy_d2h"); }
 };
 
 // ---- a read table of the caller as the region loop sees it (ReadArray, cwindow.pyx:92-236) --------------------------------------
@@ -303,7 +333,7 @@ struct BatchBuilder {
 };
 
 template <class T, class V> static void fill(Slot& s, Staged<T>& st, const V& v, bool dev = true) {
-    st.reserve(s.ctx, v.size() + 1, true, dev);
+    if (!st.view) st.reserve(s.ctx, v.size() + 1, true, dev);
     for (size_t i = 0; i < v.size(); ++i) st.h[i] = (T)v[i];
     st.n = v.size();
 }
@@ -321,22 +351,24 @@ static DeviceBatch runWindows(Slot& s, const BatchBuilder& b, const Options& o, 
     db.nWindows = b.nWindows(); db.nHaps = b.nHaps(); db.nReads = b.nReads(); db.nInd = b.nInd; db.maxH = b.maxH;
     db.nPairs = b.pairoff.back(); db.nGl = b.gloff.back();
     if (db.nWindows == 0) return db;
-    fill(s, s.w_hapbegin, b.hapbegin); fill(s, s.w_readbegin, b.readbegin); fill(s, s.w_start, b.start); fill(s, s.w_end, b.end);
-    fill(s, s.w_flank, b.flank); fill(s, s.w_pairoff, b.pairoff); fill(s, s.w_hapoff, b.hapoff); fill(s, s.w_readoff, b.readoff);
-    fill(s, s.w_gloff, b.gloff); fill(s, s.w_segbegin, b.segbegin); fill(s, s.w_ngood, b.ngood); fill(s, s.w_src, b.src); fill(s, s.w_kind, b.kind);
-    s.w_hapseq.reserve(s.ctx, b.hapseq.size() + PLAT_BLOB_PAD);
-    memcpy(s.w_hapseq.h, b.hapseq.data(), b.hapseq.size());
-    memset(s.w_hapseq.h + b.hapseq.size(), 0, PLAT_BLOB_PAD);
-    s.up(s.w_hapbegin, b.hapbegin.size()); s.up(s.w_readbegin, b.readbegin.size()); s.up(s.w_start, b.start.size()); s.up(s.w_end, b.end.size());
-    s.up(s.w_flank, b.flank.size()); s.up(s.w_pairoff, b.pairoff.size()); s.up(s.w_hapoff, b.hapoff.size()); s.up(s.w_readoff, b.readoff.size());
-    s.up(s.w_gloff, b.gloff.size()); s.up(s.w_segbegin, b.segbegin.size()); s.up(s.w_ngood, b.ngood.size()); s.up(s.w_src, b.src.size());
-    s.up(s.w_kind, b.kind.size()); s.up(s.w_hapseq, b.hapseq.size() + PLAT_BLOB_PAD);
+    {
+        Layout L;
+        L.add(s.w_hapbegin, b.hapbegin.size()); L.add(s.w_readbegin, b.readbegin.size()); L.add(s.w_start, b.start.size()); L.add(s.w_end, b.end.size());
+        L.add(s.w_flank, b.flank.size()); L.add(s.w_pairoff, b.pairoff.size()); L.add(s.w_hapoff, b.hapoff.size()); L.add(s.w_readoff, b.readoff.size());
+        L.add(s.w_gloff, b.gloff.size()); L.add(s.w_segbegin, b.segbegin.size()); L.add(s.w_ngood, b.ngood.size()); L.add(s.w_src, b.src.size());
+        L.add(s.w_kind, b.kind.size()); L.add(s.w_hapseq, b.hapseq.size() + PLAT_BLOB_PAD);
+        L.commit(s, s.a_win);
+        fill(s, s.w_hapbegin, b.hapbegin); fill(s, s.w_readbegin, b.readbegin); fill(s, s.w_start, b.start); fill(s, s.w_end, b.end);
+        fill(s, s.w_flank, b.flank); fill(s, s.w_pairoff, b.pairoff); fill(s, s.w_hapoff, b.hapoff); fill(s, s.w_readoff, b.readoff);
+        fill(s, s.w_gloff, b.gloff); fill(s, s.w_segbegin, b.segbegin); fill(s, s.w_ngood, b.ngood); fill(s, s.w_src, b.src); fill(s, s.w_kind, b.kind);
+        memcpy(s.w_hapseq.h, b.hapseq.data(), b.hapseq.size());
+        memset(s.w_hapseq.h + b.hapseq.size(), 0, PLAT_BLOB_PAD);
+        L.upload(s, s.a_win);
+    }
     const size_t blob = (size_t)b.readoff.back();
-    s.g_seq.reserve(s.ctx, blob + PLAT_BLOB_PAD, false); s.g_qual.reserve(s.ctx, blob + PLAT_BLOB_PAD, false);
+    s.g_seq.reserve(s.ctx, blob + PLAT_BLOB_PAD, false, true, s.stream); s.g_qual.reserve(s.ctx, blob + PLAT_BLOB_PAD, false, true, s.stream);
     const size_t nR = (size_t)db.nReads;
     s.g_pos.reserve(s.ctx, nR + 1, false); s.g_end.reserve(s.ctx, nR + 1, false); s.g_flags.reserve(s.ctx, nR + 1, false); s.g_mapq.reserve(s.ctx, nR + 1, false);
-    ck(plat_memset(s.ctx, s.g_seq.d + blob, 0, PLAT_BLOB_PAD, s.stream), "plat_memset");
-    ck(plat_memset(s.ctx, s.g_qual.d + blob, 0, PLAT_BLOB_PAD, s.stream), "plat_memset");
     ck(plat_gather_reads(s.ctx, (int64_t)nR, s.w_src.d, s.w_readoff.d, s.t_seq.d, s.t_qual.d, s.t_off.d, s.t_pos.d, s.t_end.d, s.t_mapq.d,
                          s.t_flags.d, s.g_seq.d, s.g_qual.d, s.g_pos.d, s.g_end.d, s.g_mapq.d, s.g_flags.d, s.stream), "plat_gather_reads");
     plat_window_batch& wb = db.wb;
@@ -356,15 +388,17 @@ static DeviceBatch runWindows(Slot& s, const BatchBuilder& b, const Options& o, 
     if (full) {
         const size_t nG = (size_t)db.nGl + 1;
         s.o_gl.reserve(s.ctx, nG, false); s.o_logl.reserve(s.ctx, nG, false); s.o_gof.reserve(s.ctx, nG, false); s.o_em.reserve(s.ctx, nG, false);
-        s.o_freq.reserve(s.ctx, (size_t)db.nHaps + 1); s.o_calls.reserve(s.ctx, (size_t)db.nWindows * db.nInd + 1);
-        s.o_iters.reserve(s.ctx, (size_t)db.nWindows + 1, false); s.o_hapscore.reserve(s.ctx, (size_t)db.nWindows + 1);
+        Layout LO;
+        LO.add(s.o_freq, (size_t)db.nHaps); LO.add(s.o_calls, (size_t)db.nWindows * db.nInd); LO.add(s.o_hapscore, (size_t)db.nWindows);
+        LO.commit(s, s.a_wout);
+        s.o_iters.reserve(s.ctx, (size_t)db.nWindows + 1, false);
         ck(plat_genotype_window_batch(s.ctx, &wb, db.nInd, s.w_segbegin.d, s.w_ngood.d, s.o_loglik.d, s.w_gloff.d, s.o_gl.d, s.o_logl.d, s.o_gof.d,
                                       s.stream), "plat_genotype_window_batch");
         ck(plat_haplotype_score_batch(s.ctx, &wb, db.nInd, db.maxH, s.w_segbegin.d, s.w_ngood.d, s.o_loglik.d, nullptr, s.o_hapscore.d, s.stream),
            "plat_haplotype_score_batch");
         ck(plat_em_window_batch(s.ctx, db.nWindows, db.nInd, db.maxH, s.w_hapbegin.d, s.w_gloff.d, s.w_ngood.d, s.o_gl.d, 100, o.useEMLikelihoods,
                                 s.o_freq.d, s.o_em.d, s.o_calls.d, s.o_iters.d, s.stream), "plat_em_window_batch");
-        s.down(s.o_freq, (size_t)db.nHaps); s.down(s.o_calls, (size_t)db.nWindows * db.nInd); s.down(s.o_hapscore, (size_t)db.nWindows);
+        LO.download(s, s.a_wout);
     }
     s.sync("window batch");
     return db;
@@ -395,9 +429,11 @@ struct Chunk {
         const size_t N = nReads[0] + nReads[1] + nReads[2], B = nBytes[0] + nBytes[1] + nBytes[2], Cg = nCig[0] + nCig[1] + nCig[2];
         if (N > 0x7FFFFFF0ull) throw DeviceError(PLAT_ERR_OVERFLOW, "chunk read table");
         Slot& z = s;
-        z.t_seq.reserve(z.ctx, B + PLAT_BLOB_PAD, false); z.t_qual.reserve(z.ctx, B + PLAT_BLOB_PAD, false);
-        z.t_off.reserve(z.ctx, N + 1); z.t_pos.reserve(z.ctx, N + 1); z.t_end.reserve(z.ctx, N + 1); z.t_flags.reserve(z.ctx, N + 1);
-        z.t_mapq.reserve(z.ctx, N + 1); z.t_cigoff.reserve(z.ctx, N + 1); z.t_cigar.reserve(z.ctx, 2 * Cg + 2); z.t_region.reserve(z.ctx, nReads[0] + 1);
+        z.t_seq.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream); z.t_qual.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream);
+        Layout L;
+        L.add(z.t_off, N + 1); L.add(z.t_pos, N + 1); L.add(z.t_end, N + 1); L.add(z.t_flags, N + 1); L.add(z.t_mapq, N + 1); L.add(z.t_cigoff, N + 1);
+        L.add(z.t_cigar, 2 * Cg + 2); L.add(z.t_region, nReads[0] + 1);
+        L.commit(z, z.a_tab);
         size_t ri = 0, bo = 0, co = 0;
         int scan = 0;
         for (int k = 0; k < 3; ++k) {
@@ -429,10 +465,7 @@ struct Chunk {
         }
         z.t_off.h[N] = (int64_t)B; z.t_cigoff.h[N] = (int32_t)Cg;
         z.t_cigar.h[2 * Cg] = 0; z.t_cigar.h[2 * Cg + 1] = 0;
-        ck(plat_memset(z.ctx, z.t_seq.d + B, 0, PLAT_BLOB_PAD, z.stream), "plat_memset");
-        ck(plat_memset(z.ctx, z.t_qual.d + B, 0, PLAT_BLOB_PAD, z.stream), "plat_memset");
-        z.up(z.t_off, N + 1); z.up(z.t_pos, N); z.up(z.t_end, N); z.up(z.t_flags, N); z.up(z.t_mapq, N); z.up(z.t_cigoff, N + 1); z.up(z.t_cigar, 2 * Cg + 2);
-        z.up(z.t_region, nReads[0]);
+        L.upload(z, z.a_tab);
         nGood = nReads[0]; nScan = scan;
         std::lock_guard<std::mutex> g(stMutex);
         st.n_reads += (int64_t)N;
@@ -455,10 +488,14 @@ struct Chunk {
                 refoff.push_back((int64_t)blob.size());
                 rss.push_back((int32_t)a); clen.push_back((int32_t)r->fa.len);
             }
-        z.c_ref.reserve(z.ctx, blob.size() + PLAT_BLOB_PAD);
-        memcpy(z.c_ref.h, blob.data(), blob.size()); memset(z.c_ref.h + blob.size(), 0, PLAT_BLOB_PAD);
-        fill(z, z.c_refoff, refoff); fill(z, z.c_rss, rss); fill(z, z.c_clen, clen);
-        z.up(z.c_ref, blob.size() + PLAT_BLOB_PAD); z.up(z.c_refoff, refoff.size()); z.up(z.c_rss, rss.size()); z.up(z.c_clen, clen.size());
+        {
+            Layout L;
+            L.add(z.c_ref, blob.size() + PLAT_BLOB_PAD); L.add(z.c_refoff, refoff.size()); L.add(z.c_rss, rss.size()); L.add(z.c_clen, clen.size());
+            L.commit(z, z.a_cin);
+            memcpy(z.c_ref.h, blob.data(), blob.size()); memset(z.c_ref.h + blob.size(), 0, PLAT_BLOB_PAD);
+            fill(z, z.c_refoff, refoff); fill(z, z.c_rss, rss); fill(z, z.c_clen, clen);
+            L.upload(z, z.a_cin);
+        }
         refBlob.swap(blob);
         if (nGood == 0) return;
         plat_candidate_batch cb;
@@ -468,10 +505,12 @@ struct Chunk {
         cb.read_seq = z.t_seq.d; cb.read_qual = z.t_qual.d; cb.read_off = z.t_off.d; cb.read_pos = z.t_pos.d; cb.read_flags = z.t_flags.d;
         cb.cigar = z.t_cigar.d; cb.cig_off = z.t_cigoff.d;
         for (;;) {
-            z.c_rec.reserve(z.ctx, nGood * (size_t)maxPerRead * 5 + 8); z.c_cnt.reserve(z.ctx, nGood + 1); z.c_status.reserve(z.ctx, nGood + 1);
+            Layout LO;
+            LO.add(z.c_cnt, nGood); LO.add(z.c_status, nGood); LO.add(z.c_rec, nGood * (size_t)maxPerRead * 5);
+            LO.commit(z, z.a_cout);
             ck(plat_candidates_batch(z.ctx, &cb, o.minFlank, o.minBaseQual, o.genSNPs, o.genIndels, maxPerRead, z.t_region.d, z.c_rec.d, z.c_cnt.d,
                                      z.c_status.d, z.stream), "plat_candidates_batch");
-            z.down(z.c_cnt, nGood); z.down(z.c_status, nGood); z.down(z.c_rec, nGood * (size_t)maxPerRead * 5);
+            LO.download(z, z.a_cout);
             z.sync("candidate scan");
             int need = 0;
             for (size_t i = 0; i < nGood; ++i) {
@@ -818,9 +857,12 @@ struct Chunk {
         }
         const size_t nV = pwin.size();
         if (nV) {
+            Layout L;
+            L.add(z.p_win, nV); L.add(z.p_off, nV + 1); L.add(z.p_mask, pmask.size()); L.add(z.p_prior, nV);
+            L.commit(z, z.a_pin);
             fill(z, z.p_win, pwin); fill(z, z.p_off, poff); fill(z, z.p_mask, pmask); fill(z, z.p_prior, pprior);
             z.p_post.reserve(z.ctx, nV + 1);
-            z.up(z.p_win, nV); z.up(z.p_off, nV + 1); z.up(z.p_mask, pmask.size()); z.up(z.p_prior, nV);
+            L.upload(z, z.a_pin);
             ck(plat_variant_posterior_batch(z.ctx, (int)nV, nInd, db.maxH, z.w_hapbegin.d, z.w_gloff.d, z.w_ngood.d, z.o_gl.d, z.o_freq.d, z.p_win.d,
                                             z.p_off.d, z.p_mask.d, z.p_prior.d, z.p_post.d, z.stream), "plat_variant_posterior_batch");
             z.down(z.p_post, nV);
@@ -932,14 +974,22 @@ struct Chunk {
         if (live.empty()) return;
         // E: read statistics + per-site genotype calls
         const size_t nSV = svw.size(), nSites = kwin.size();
+        kvih.push_back(0);
+        Layout L, LO;
+        L.add(z.s_vw, nSV); L.add(z.s_pos, nSV); L.add(z.s_min, nSV); L.add(z.s_max, nSV); L.add(z.s_nadd, nSV); L.add(z.s_nrem, nSV); L.add(z.s_aoff, nSV);
+        L.add(z.s_moff, nSV); L.add(z.s_vig, svig.size()); L.add(z.s_gb, sgb.size()); L.add(z.s_ge, sge.size()); L.add(z.s_bb, sbb.size()); L.add(z.s_be, sbe.size());
+        L.add(z.s_added, sadded.size() + PLAT_BLOB_PAD);
+        L.add(z.k_win, nSites); L.add(z.k_nvar, nSites); L.add(z.k_vo, nSites + 1); L.add(z.k_ro, nSites + 1); L.add(z.k_lo, nSites + 1); L.add(z.k_ref, kref.size());
+        L.add(z.k_vih, kvih.size());
+        L.commit(z, z.a_sin);
         fill(z, z.s_vw, svw); fill(z, z.s_pos, spos); fill(z, z.s_min, smin); fill(z, z.s_max, smax); fill(z, z.s_nadd, snadd); fill(z, z.s_nrem, snrem);
         fill(z, z.s_aoff, saoff); fill(z, z.s_moff, smoff); fill(z, z.s_vig, svig); fill(z, z.s_gb, sgb); fill(z, z.s_ge, sge); fill(z, z.s_bb, sbb); fill(z, z.s_be, sbe);
-        z.s_added.reserve(z.ctx, sadded.size() + PLAT_BLOB_PAD);
         memcpy(z.s_added.h, sadded.data(), sadded.size()); memset(z.s_added.h + sadded.size(), 0, PLAT_BLOB_PAD);
-        z.s_counts.reserve(z.ctx, nSV * 16 + 16); z.s_ps.reserve(z.ctx, nSV * (size_t)nInd * 2 + 2); z.s_minq.reserve(z.ctx, (size_t)mtot + 1); z.s_nminq.reserve(z.ctx, nSV + 1);
-        z.up(z.s_vw, nSV); z.up(z.s_pos, nSV); z.up(z.s_min, nSV); z.up(z.s_max, nSV); z.up(z.s_nadd, nSV); z.up(z.s_nrem, nSV); z.up(z.s_aoff, nSV);
-        z.up(z.s_moff, nSV); z.up(z.s_vig, svig.size()); z.up(z.s_gb, sgb.size()); z.up(z.s_ge, sge.size()); z.up(z.s_bb, sbb.size()); z.up(z.s_be, sbe.size());
-        z.up(z.s_added, sadded.size() + PLAT_BLOB_PAD);
+        fill(z, z.k_win, kwin); fill(z, z.k_nvar, knvar); fill(z, z.k_vo, kvo); fill(z, z.k_ro, kro); fill(z, z.k_lo, klo); fill(z, z.k_ref, kref); fill(z, z.k_vih, kvih);
+        L.upload(z, z.a_sin);
+        LO.add(z.s_counts, nSV * 16); LO.add(z.s_ps, nSV * (size_t)nInd * 2); LO.add(z.s_nminq, nSV); LO.add(z.s_minq, (size_t)mtot);
+        LO.add(z.k_ph, nSites * (size_t)nInd * 2); LO.add(z.k_lik, (size_t)klo.back()); LO.add(z.k_out4, nSites * (size_t)nInd * 4);
+        LO.commit(z, z.a_sout);
         plat_infostats_batch ib;
         memset(&ib, 0, sizeof ib);
         ib.n_vars = (int32_t)nSV; ib.n_ind = nInd;
@@ -950,16 +1000,9 @@ struct Chunk {
         ib.read_flags = z.t_flags.d; ib.cigar = z.t_cigar.d; ib.cig_off = z.t_cigoff.d;
         ck(plat_variant_read_stats_batch(z.ctx, &ib, o.badReadsWindow, o.countOnlyExactIndelMatches, z.s_counts.d, z.s_ps.d, z.s_minq.d, z.s_nminq.d, z.stream),
            "plat_variant_read_stats_batch");
-        z.down(z.s_counts, nSV * 16); z.down(z.s_ps, nSV * (size_t)nInd * 2); z.down(z.s_nminq, nSV); z.down(z.s_minq, (size_t)mtot);
-        fill(z, z.k_win, kwin); fill(z, z.k_nvar, knvar); fill(z, z.k_vo, kvo); fill(z, z.k_ro, kro); fill(z, z.k_lo, klo); fill(z, z.k_ref, kref);
-        kvih.push_back(0);
-        fill(z, z.k_vih, kvih);
-        z.k_ph.reserve(z.ctx, nSites * (size_t)nInd * 2 + 2); z.k_lik.reserve(z.ctx, (size_t)klo.back() + 1); z.k_out4.reserve(z.ctx, nSites * (size_t)nInd * 4 + 4);
-        z.up(z.k_win, nSites); z.up(z.k_nvar, nSites); z.up(z.k_vo, nSites + 1); z.up(z.k_ro, nSites + 1); z.up(z.k_lo, nSites + 1); z.up(z.k_ref, kref.size());
-        z.up(z.k_vih, kvih.size());
         ck(plat_genotype_call_batch(z.ctx, (int)nSites, nInd, z.w_hapbegin.d, z.w_gloff.d, z.o_gl.d, z.o_gof.d, z.o_freq.d, z.k_win.d, z.k_nvar.d, z.k_vo.d,
                                     z.k_ro.d, z.k_vih.d, z.k_ref.d, z.k_lo.d, z.k_ph.d, z.k_lik.d, z.k_out4.d, z.stream), "plat_genotype_call_batch");
-        z.down(z.k_ph, nSites * (size_t)nInd * 2); z.down(z.k_lik, (size_t)klo.back()); z.down(z.k_out4, nSites * (size_t)nInd * 4);
+        LO.download(z, z.a_sout);
         z.sync("read statistics / genotype calls");
         lap(6);
         // F: INFO, FILTER, text
@@ -1252,7 +1295,8 @@ CALLER_EXPORT int plat_caller_destroy(plat_caller* c) {
                    z.g_end, z.g_flags, z.o_calls, z.o_iters, z.o_hapscore, z.o_score, z.w_pairoff, z.w_hapoff, z.w_readoff, z.w_gloff, z.w_hapseq, z.w_kind, z.g_seq,
                    z.g_qual, z.g_mapq, z.o_loglik, z.o_gl, z.o_logl, z.o_gof, z.o_freq, z.o_em, z.p_win, z.s_vw, z.s_pos, z.s_min, z.s_max, z.s_nadd, z.s_nrem,
                    z.s_gb, z.s_ge, z.s_bb, z.s_be, z.s_ps, z.s_minq, z.s_nminq, z.k_win, z.k_nvar, z.k_vih, z.k_ref, z.k_ph, z.p_off, z.s_aoff, z.s_moff, z.s_counts,
-                   z.k_vo, z.k_ro, z.k_lo, z.p_mask, z.s_added, z.s_vig, z.p_prior, z.p_post, z.k_lik, z.k_out4);
+                   z.k_vo, z.k_ro, z.k_lo, z.p_mask, z.s_added, z.s_vig, z.p_prior, z.p_post, z.k_lik, z.k_out4, z.a_tab, z.a_cin, z.a_cout, z.a_win, z.a_wout,
+                   z.a_pin, z.a_sin, z.a_sout);
         plat_stream_destroy(z.ctx, z.stream);
         plat_ctx_destroy(z.ctx);
     }
