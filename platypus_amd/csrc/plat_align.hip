@@ -49,9 +49,37 @@ enum { CNT_ERR = 0, CNT_MAXHAP, CNT_MAXREAD, CNT_NEXTRA, CNT_PAIRS_ALIGNED, CNT_
        CNT_NJOBS_RUN, CNT_TILE_TOTAL, CNT_SLOW_SEED, CNT_MAXH, CNT_NDENSE, CNT_HAPBLOB, CNT_NPAIRS, CNT_READBLOB, CNT_T0, CNT_T1, CNT_T2, CNT_T3, CNT_T4, CNT_N };
 static_assert(CNT_N <= 64, "the pinned read-back area holds 64 words");
 
+// The dense list of live DP job slots, built where the jobs are made (k_seed / k_seed_slow): DENSE_SEGS segments of `segcap`
+// entries, one counter each, a whole window's jobs in one segment (w % DENSE_SEGS); a wave reserves room for its live jobs
+// with ONE atomic.  The counters sit 4 KB apart (different L2 channels: one address takes ~90 atomics/us) behind the
+// other counters; k_dense_total copies them into cnt[] for the host and sums them.
+constexpr int DENSE_SEGS = 8;
+constexpr int DENSE_CNT_STRIDE = 512;                    // in long longs
+constexpr int CNT_AREA = 64 + DENSE_SEGS * DENSE_CNT_STRIDE;   // long longs reserved (and zeroed) for counters per batch
+__device__ __forceinline__ long long* dense_counter(long long* cnt, int seg) { return cnt + 64 + seg * DENSE_CNT_STRIDE; }
+__device__ __forceinline__ long long dense_count(const long long* cnt, int seg, long long segcap) {
+    const long long c = cnt[64 + seg * DENSE_CNT_STRIDE];
+    return c < segcap ? c : segcap;
+}
+// flat index g over the concatenation of the segments -> job slot, -1 past the end
+__device__ __forceinline__ long long dense_slot(const int32_t* __restrict__ dense, long long segcap, const long long* __restrict__ cnt, long long g) {
+#pragma unroll
+    for (int k = 0; k < DENSE_SEGS; ++k) {
+        const long long c = dense_count(cnt, k, segcap);
+        if (g < c) return (long long)dense[k * segcap + g];
+        g -= c;
+    }
+    return -1;
+}
+
 __constant__ signed char c_homopol_go[49] = {   // homopolq[i]-'!' (chaplotype.pyx:64-67); see tests/test_oracle.py
     45, 42, 41, 39, 37, 32, 28, 23, 20, 19, 17, 16, 15, 14, 13, 12, 11, 11, 10, 9, 9, 8, 8, 7, 7, 7, 6, 6, 6, 5, 5, 5,
     4, 4, 4, 3, 3, 3, 3, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1};
+
+__device__ __forceinline__ double loglik_of(int score, const double* __restrict__ mapq_lut, int mapq) {
+    const double v = -0.23025850929940459 * (double)score + mapq_lut[mapq];   // chaplotype.pyx:676 (no FMA: -ffp-contract=off)
+    return v > -300.0 ? v : -300.0;
+}
 
 __device__ __forceinline__ void set_err(long long* cnt, int code) {
     atomicCAS((unsigned long long*)&cnt[CNT_ERR], 0ull, (unsigned long long)(long long)code);
@@ -408,7 +436,8 @@ struct SlowRec { int32_t hap, rl; };     // a (haplotype, read-in-window) pair t
 __device__ __forceinline__ void seed_exact_vote(const unsigned* table, const unsigned short* nxt, unsigned* counts, bool direct,
                                                 unsigned tmask, int hapLen, int h, const u64* scp, int R, int sL, int sidx0,
                                                 unsigned scol, int smapq, long long spidx, long long npairs, int extra_cap,
-                                                Job* __restrict__ jobs, PairRec* __restrict__ pairs, long long* cnt)
+                                                Job* __restrict__ jobs, PairRec* __restrict__ pairs, long long* cnt,
+                                                int32_t* __restrict__ dense, long long segcap, int seg)
 {
     const int lane = threadIdx.x & 63;
     const int n = hapLen + sL, snk = sL - 7, j0i = sidx0 + sL;
@@ -466,6 +495,14 @@ __device__ __forceinline__ void seed_exact_vote(const unsigned* table, const uns
     if (lane == 0) {
         if (!s_orig_in && (fits || sncand == 0)) jobs[job_slot(spidx, npairs, sbase, sncand)] = Job{scol, h, sidx0, sL};
         pairs[spidx] = PairRec{sbase, sidx0, (int16_t)sncand, (int16_t)orig_k, (uint8_t)smapq, {0, 0, 0}};
+    }
+    // the pair's job slots join the dense list (when they do not fit the batch is re-run or refused anyway)
+    if (fits) {
+        long long db = 0;
+        if (lane == 0) db = (long long)atomicAdd((unsigned long long*)dense_counter(cnt, seg), (unsigned long long)njobs);
+        db = ((long long)(unsigned)__shfl((int)db, 0)) | ((long long)__shfl((int)(db >> 32), 0) << 32);
+        if (db + njobs <= segcap)
+            for (int k = lane; k < njobs; k += 64) dense[seg * segcap + db + k] = (int32_t)job_slot(spidx, npairs, sbase, k);
     }
     // all counters back to zero (cheaper than walking the chains again)
     for (int j = lane; j < ((n + 2) >> 1); j += 64) counts[j] = 0u;
@@ -538,7 +575,9 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
        const long long* __restrict__ tile_off, const ReadInfo* __restrict__ rinfo,
        const uint16_t* __restrict__ codes, uint32_t* __restrict__ hapw, uint8_t* __restrict__ hap_has_n,
        PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
-       SlowRec* __restrict__ slow_list, int tsize_max, int maxhap, int shortcuts, const uint32_t* __restrict__ tile)
+       SlowRec* __restrict__ slow_list, int tsize_max, int maxhap, int shortcuts, const uint32_t* __restrict__ tile,
+       int32_t* __restrict__ dense, long long segcap, const double* __restrict__ mapq_lut, double* __restrict__ out_ll,
+       int32_t* __restrict__ out_score)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nw64 = ((maxhap + 63) >> 6) + 8;           // plane words incl. slack for the shifted window of a hypothesis
@@ -596,21 +635,25 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     // ahead so that the global-load latency hides behind a whole iteration of work.
     int level = 1;
     {
+        // (the loop is written without divergent branches: every `if` on a lane condition costs half a dozen scalar
+        //  instructions of exec-mask bookkeeping, and this sweep had three scalar instructions for every vector one)
         auto ldb = [&](int t) -> unsigned { const int p = 64 * t + lane; return p < hapLen ? (unsigned)hs[p] : 0u; };
         struct Planes { u64 m0, m1, me; };
+        u64 anyN = 0ull, anyOther = 0ull;                // wave-uniform: a byte 'N' / a byte other than A, C, G, T, N was seen
+        unsigned accBits = 0u;                           // per lane: OR of its bytes (7-bit ASCII check after the loop)
         auto mk = [&](int t, unsigned c, unsigned cnext_chunk) -> Planes {
             const int p = 64 * t + lane;
-            if (c & 0x80u) set_err(cnt, PLAT_ERR_BAD_INPUT);             // 7-bit ASCII only (the DP packs bases as byte << 9)
+            accBits |= c;
             unsigned cn = (unsigned)__shfl_down((int)c, 1);
             const unsigned first_next = (unsigned)__shfl((int)cnext_chunk, 0);
-            if (lane == 63) cn = first_next;
+            cn = lane == 63 ? first_next : cn;
             const unsigned b2 = base2(c);                                // bytes past the end are 0 -> code 0
             Planes P;
             P.m0 = __ballot(p < hapLen && (b2 & 1u));
             P.m1 = __ballot(p < hapLen && (b2 & 2u));
             P.me = __ballot(p + 1 < hapLen && c == cn && c != (unsigned)'N');
-            if (__ballot(c == (unsigned)'N') && lane == 0) s_scal[0] = 1;
-            if (__ballot(p < hapLen && c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') && lane == 0) s_scal[2] = 1;
+            anyN |= __ballot(c == (unsigned)'N');
+            anyOther |= __ballot(p < hapLen && c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N');
             return P;
         };
         unsigned b0 = ldb(0), b1 = ldb(1), b2_ = ldb(2);
@@ -618,33 +661,24 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         for (int t = 0; t < nch; ++t) {
             const unsigned b3 = ldb(t + 3);
             const int p = 64 * t + lane;
-            if (lane == 0) { h0[t] = P0.m0; h1[t] = P0.m1; eqp[t] = P0.me; }
+            {   // the chunk's three plane words: lanes 0..2 store one each (h0, h1, eqp lie nw64 words apart)
+                const u64 val = lane == 0 ? P0.m0 : (lane == 1 ? P0.m1 : P0.me);
+                if (lane < 3) h0[lane * nw64 + t] = val;
+            }
             {
                 const u64 v = funnel(P0.me, P1.me, lane);
                 const int run = min(48, (int)__ffsll((long long)~v) - 1);     // trailing ones of v (v never has 64 ones beyond the cap)
                 const int go = s_go[run < 0 ? 48 : run];
                 if (p < hapLen && first_group) hapw[hoff + p] = hap_word(b0, (unsigned)go);
-                // smallest gap-open penalty of the chunk = the table entry of its LONGEST run (the table never rises with the run
-                // length): found on the wave-uniform run plane with scalar shifts -- positions where k consecutive bits are set,
-                // k = 1, 2, ... until none is left -- instead of a reduction over the lanes
-                {
-                    const int nvalid = min(64, hapLen - 64 * t);
-                    u64 left = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
-                    int longest = 0;
-                    while (longest < 48) {
-                        left &= funnel(P0.me, P1.me, longest);
-                        if (left == 0ull) break;
-                        ++longest;
-                    }
-                    if (lane == 0) s_gmin[t] = (unsigned char)s_go[longest];
-                }
             }
-            if (p < hapLen - 7) {
+            {   // multiplicity maps of the k-mers at positions 0..hapLen-8: "seen", "seen twice"; lanes past the last k-mer OR in nothing
                 const unsigned code = plane_code(P0.m0, P1.m0, P0.m1, P1.m1, lane);
-                const unsigned wd = code >> 5, bit = 1u << (code & 31u);
-                if (atomicOr(&seen1[wd], bit) & bit) {
-                    level = max(level, 2);
-                    if (atomicOr(&seen2[wd], bit) & bit) {                  // third or later occurrence: count it
+                const unsigned wd = code >> 5, bit = p < hapLen - 7 ? 1u << (code & 31u) : 0u;
+                const unsigned dup = atomicOr(&seen1[wd], bit) & bit;
+                const unsigned third = atomicOr(&seen2[wd], dup) & dup;
+                level = max(level, dup ? 2 : 1);
+                if (__any(third != 0u)) {                                   // third or later occurrence (rare): count it
+                    if (third) {
                         const unsigned key = code + 1u;
                         unsigned slot = code & 31u;
                         int probes = 0;
@@ -665,6 +699,23 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
             P0 = P1;
             P1 = mk(t + 2, b1, b2_);
         }
+        if (accBits & 0x80u) set_err(cnt, PLAT_ERR_BAD_INPUT);             // 7-bit ASCII only (the DP packs bases as byte << 9)
+        if (lane == 0) { if (anyN) s_scal[0] = 1; if (anyOther) s_scal[2] = 1; }
+    }
+    __syncthreads();
+    // smallest gap-open penalty of every chunk of 64 positions = the table entry of the chunk's LONGEST run (the table never rises
+    // with the run length): one lane per chunk, on the run plane: positions where k consecutive bits are set, k = 1, 2, ...
+    for (int t = tid; t < nch; t += nthr) {
+        const u64 e0 = eqp[t], e1 = eqp[t + 1];
+        const int nvalid = min(64, hapLen - 64 * t);
+        u64 left = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+        int longest = 0;
+        while (longest < 48) {
+            left &= funnel(e0, e1, longest);
+            if (left == 0ull) break;
+            ++longest;
+        }
+        s_gmin[t] = (unsigned char)s_go[longest];
     }
     __syncthreads();
     if (shortcuts & 256) return;                         // (measurement only, PLAT_SEED_DEBUG: the haplotype sweep alone)
@@ -909,19 +960,46 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 if (need && (long long)base + 1 <= (long long)extra_cap) jobs[npairs + base] = Job{ri.col, hq, idx0, L};
             }
         }
+        // Decided pairs: the ones that need no DP are finished here (skipped read: 0.0, chaplotype.pyx:345-346; read < 7 bp or exact
+        // match: score 0; ungapped alignment proven optimal: its score), the others leave a job in their slot.
+        bool prim = false;                                   // the pair's primary slot holds a DP
         if (valid && decided) {
             if (!live) {
-                pairs[pidx] = PairRec{0, 0, (int16_t)((skipped || hapshort) ? -1 : -2), 0, mapq, {0, 0, 0}};
+                const bool sk = skipped || hapshort;
+                pairs[pidx] = PairRec{0, 0, (int16_t)(sk ? -1 : -2), 0, mapq, {0, 0, 0}};
                 jobs[pidx] = Job{ri.col, h, 0, 0};
+                out_ll[pidx] = sk ? 0.0 : loglik_of(0, mapq_lut, mapq);
+                if (out_score) out_score[pidx] = sk ? -1 : 0;
             } else if (zero) {
                 pairs[pidx] = PairRec{0, L, (int16_t)-3, 0, mapq, {0, 0, 0}};
                 jobs[pidx] = Job{ri.col, h, cidx, 0};
+                out_ll[pidx] = loglik_of(0, mapq_lut, mapq);
+                if (out_score) out_score[pidx] = 0;
             } else if (ungapped) {
                 pairs[pidx] = PairRec{ung_score, L, (int16_t)-4, 0, mapq, {0, 0, 0}};
                 jobs[pidx] = Job{ri.col, h, cidx, 0};
+                out_ll[pidx] = loglik_of(ung_score, mapq_lut, mapq);
+                if (out_score) out_score[pidx] = ung_score;
             } else {
                 jobs[pidx] = Job{ri.col, hq, cidx, L};
                 pairs[pidx] = PairRec{base, idx0, (int16_t)ncand, (int16_t)(orig_in ? 0 : ncand), mapq, {0, 0, 0}};
+                prim = true;
+            }
+        }
+        {   // the wave's live job slots join the dense list: primary slots, then the extra ones, room reserved with one atomic
+            const bool extra = decided && live && ncand == 1 && !orig_in && !zero && valid && (long long)base + 1 <= (long long)extra_cap;
+            const unsigned long long m1 = __ballot(prim), m2 = __ballot(extra);
+            const int n1 = __popcll(m1), n2 = __popcll(m2);
+            if (n1 + n2) {
+                const int seg = w % DENSE_SEGS;
+                long long db = 0;
+                if (lane == 0) db = (long long)atomicAdd((unsigned long long*)dense_counter(cnt, seg), (unsigned long long)(n1 + n2));
+                db = ((long long)(unsigned)__shfl((int)db, 0)) | ((long long)__shfl((int)(db >> 32), 0) << 32);
+                if (db + n1 + n2 <= segcap) {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    if (prim) dense[seg * segcap + db + __popcll(m1 & below)] = (int32_t)pidx;
+                    if (extra) dense[seg * segcap + db + n1 + __popcll(m2 & below)] = (int32_t)(npairs + base);
+                }
             }
         }
         // ---- pairs that could not be decided go to the exact vote in k_seed_slow (one wave per pair, spread over the
@@ -943,7 +1021,7 @@ __global__ void __launch_bounds__(64)
 k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long long* __restrict__ tile_off,
             const ReadInfo* __restrict__ rinfo, const uint16_t* __restrict__ codes, PairRec* __restrict__ pairs,
             Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt, const SlowRec* __restrict__ slow_list,
-            int tsize_max, int maxhap, int cw)
+            int tsize_max, int maxhap, int cw, int32_t* __restrict__ dense, long long segcap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nw64 = ((maxhap + 63) >> 6) + 8;
@@ -1007,83 +1085,19 @@ k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long
             const long long pidx = b.pair_off[w] + (long long)(h - b.win_hap_begin[w]) * R + rec.rl;
             const u64* scp = (const u64*)(codes + tile_off[w]) + rec.rl;
             seed_exact_vote(table, nxt, counts, direct, tmask, hapLen, h | (((ri.lfm >> 18) & 1u) ? JOB_BIGQ : 0), scp, R, L, idx0, ri.col, (int)(ri.lfm >> 24), pidx,
-                            npairs, extra_cap, jobs, pairs, cnt);
+                            npairs, extra_cap, jobs, pairs, cnt, dense, segcap, w % DENSE_SEGS);
         }
     }
 }
 
-__device__ __forceinline__ double loglik_of(int score, const double* __restrict__ mapq_lut, int mapq) {
-    const double v = -0.23025850929940459 * (double)score + mapq_lut[mapq];   // chaplotype.pyx:676 (no FMA: -ffp-contract=off)
-    return v > -300.0 ? v : -300.0;
-}
 
 // ------------------------------------------------------------------------------------------------
-// Job compaction.  Slot j < npairs belongs to pair j, slots npairs.. hold the extra candidates; slots of pairs that need
-// no DP (skipped reads, reads < 7 bp, exact matches) are empty (len 0).  One lane per DP means an empty slot would idle a
-// lane for the whole DP, so the live slots are listed densely (in slot order: neighbouring lanes keep neighbouring reads
-// of one haplotype, i.e. coalesced tile columns).  k_compact_count also finishes the pairs that need no DP.
-constexpr int COMPACT_BLOCK = 1024;
-
-__global__ void __launch_bounds__(COMPACT_BLOCK)
-k_compact_count(const Job* __restrict__ jobs, const PairRec* __restrict__ pairs, const double* __restrict__ mapq_lut,
-                long long npairs, long long extra_cap, const long long* __restrict__ cnt, int32_t* __restrict__ block_cnt,
-                double* __restrict__ out_ll, int32_t* __restrict__ out_score)
+// number of live job slots for the host (synchronous entry point, statistics) and for the traceback kernel's slabs
+__global__ void k_dense_total(long long* cnt, long long segcap)
 {
-    if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
-    __shared__ int s_n;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const long long nslots = npairs + min(cnt[CNT_NEXTRA], extra_cap);   // more than extra_cap: the host re-runs the seeding
-    const long long j = (long long)blockIdx.x * COMPACT_BLOCK + threadIdx.x;
-    bool live = false;
-    if (j < nslots) {
-        live = jobs[j].len != 0;
-        if (j < npairs && !live) {
-            const PairRec pr = pairs[j];
-            if (pr.ncand < 0) {                          // skipped read: 0.0 (chaplotype.pyx:345-346); read < 7 bp or exact match: score 0;
-                const int sc = pr.ncand == -4 ? pr.extra_base : 0;       // ungapped alignment proven optimal in k_seed: its score
-                out_ll[j] = pr.ncand == -1 ? 0.0 : loglik_of(sc, mapq_lut, pr.mapq);
-                if (out_score) out_score[j] = pr.ncand == -1 ? -1 : sc;
-            }
-        }
-    }
-    const unsigned long long m = __ballot(live);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_n, (int)__popcll(m));
-    __syncthreads();
-    if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_n;
-}
-
-__global__ void __launch_bounds__(COMPACT_BLOCK)
-k_compact_scatter(const Job* __restrict__ jobs, long long npairs, long long extra_cap, long long* __restrict__ cnt,
-                  const int32_t* __restrict__ block_cnt, int32_t* __restrict__ dense)
-{
-    if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
-    __shared__ long long s_part[COMPACT_BLOCK / 64];
-    __shared__ int s_wave[COMPACT_BLOCK / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long long nslots = npairs + min(cnt[CNT_NEXTRA], extra_cap);
-    // exclusive prefix of this block = sum of the counts of all blocks before it
-    long long acc = 0;
-    for (int i = tid; i < (int)blockIdx.x; i += COMPACT_BLOCK) acc += block_cnt[i];
-#pragma unroll
-    for (int s2 = 32; s2 > 0; s2 >>= 1) acc += __shfl_xor(acc, s2);
-    if (lane == 0) s_part[wv] = acc;
-    const long long j = (long long)blockIdx.x * COMPACT_BLOCK + tid;
-    const bool live = j < nslots && jobs[j].len != 0;
-    const unsigned long long m = __ballot(live);
-    if (lane == 0) s_wave[wv] = (int)__popcll(m);
-    __syncthreads();
-    long long base = 0;
-    for (int i = 0; i < COMPACT_BLOCK / 64; ++i) base += s_part[i];
-    for (int i = 0; i < wv; ++i) base += s_wave[i];
-    if (live) dense[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)j;
-    if (blockIdx.x == gridDim.x - 1 && tid == COMPACT_BLOCK - 1) {
-        int tot = 0;
-        for (int i = 0; i < COMPACT_BLOCK / 64; ++i) tot += s_wave[i];
-        long long pre = 0;
-        for (int i = 0; i < COMPACT_BLOCK / 64; ++i) pre += s_part[i];
-        cnt[CNT_NDENSE] = pre + tot;
-    }
+    long long t = 0;
+    for (int k = 0; k < DENSE_SEGS; ++k) t += dense_count(cnt, k, segcap);
+    cnt[CNT_NDENSE] = t;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1117,45 +1131,50 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32_t* __restrict__ tile,
           const uint32_t* __restrict__ hapw, const uint8_t* __restrict__ hap_has_n, const Job* __restrict__ jobs,
           const PairRec* __restrict__ pairs, const double* __restrict__ mapq_lut, long long npairs,
-          const int32_t* __restrict__ dense, long long ndense, const long long* __restrict__ cnt, long long extra_cap,
+          const int32_t* __restrict__ dense, long long segcap, const long long* __restrict__ cnt, long long extra_cap,
           int32_t* __restrict__ job_score, double* __restrict__ out_ll, int32_t* __restrict__ out_score)
 {
     if (cnt[CNT_ERR] != 0 || cnt[CNT_NEXTRA] > extra_cap) return;   // refused batch / job overflow (reported by the host)
-    if (ndense < 0) ndense = cnt[CNT_NDENSE];            // asynchronous mode: the grid covers every job slot
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = t < ndense;
-    const long long j = active ? dense[t] : 0;
-    Job jb = Job{0, 0, 0, 0};
-    if (active) jb = jobs[j];
-    int has_n = 0, stride = 0;
-    const int hap = job_hap(jb);
-    const int bigq = active && (jb.hap & JOB_BIGQ) != 0;
-    if (active) {
-        has_n = hap_has_n[hap];
-        const int w = hap_win[hap];
-        stride = b.win_read_begin[w + 1] - b.win_read_begin[w];
+    // a fixed grid walks the dense list in tiles of 256 jobs (the list's length is only known on the device)
+    long long ndense = 0;
+#pragma unroll
+    for (int k = 0; k < DENSE_SEGS; ++k) ndense += dense_count(cnt, k, segcap);
+    for (long long t0 = (long long)blockIdx.x * blockDim.x; t0 < ndense; t0 += (long long)gridDim.x * blockDim.x) {
+        const long long t = t0 + threadIdx.x;
+        const bool active = t < ndense;
+        const long long j = active ? dense_slot(dense, segcap, cnt, t) : 0;
+        Job jb = Job{0, 0, 0, 0};
+        if (active) jb = jobs[j];
+        int has_n = 0, stride = 0;
+        const int hap = job_hap(jb);
+        const int bigq = active && (jb.hap & JOB_BIGQ) != 0;
+        if (active) {
+            has_n = hap_has_n[hap];
+            const int w = hap_win[hap];
+            stride = b.win_read_begin[w + 1] - b.win_read_begin[w];
+        }
+        const int st = max(0, jb.idx - 8);                                       // calign.pyx:229,256
+        const uint32_t* hp = hapw + (active ? b.hap_off[hap] + st : 0);
+        const uint32_t* rp = tile + jb.col;
+        int sc = 0;
+        // wave-uniform choice of the code path: haplotype N's need the extra mask; the 32-bit SWAR adds are only taken when
+        // every read of the wave has a quality sum that rules out a carry between the packed halves (dp_core.hpp)
+        const bool anyN = __any(has_n), anyBig = UNPACKED || __any(bigq);
+        if (anyN) {
+            if (anyBig) { if (active) sc = dp_tile<true, false, UNPACKED>(rp, stride, hp, jb.len); }
+            else        { if (active) sc = dp_tile<true, true, UNPACKED>(rp, stride, hp, jb.len); }
+        } else {
+            if (anyBig) { if (active) sc = dp_tile<false, false, UNPACKED>(rp, stride, hp, jb.len); }
+            else        { if (active) sc = dp_tile<false, true, UNPACKED>(rp, stride, hp, jb.len); }
+        }
+        if (!active) continue;
+        if (j >= npairs) { job_score[j] = sc; continue; }
+        const PairRec pr = pairs[j];                                             // read after the DP: nothing of it is live across the loop
+        if (pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0)) {
+            out_ll[j] = loglik_of(sc, mapq_lut, pr.mapq);
+            if (out_score) out_score[j] = sc;
+        } else job_score[j] = sc;
     }
-    const int st = max(0, jb.idx - 8);                                       // calign.pyx:229,256
-    const uint32_t* hp = hapw + (active ? b.hap_off[hap] + st : 0);
-    const uint32_t* rp = tile + jb.col;
-    int sc = 0;
-    // wave-uniform choice of the code path: haplotype N's need the extra mask; the 32-bit SWAR adds are only taken when
-    // every read of the wave has a quality sum that rules out a carry between the packed halves (dp_core.hpp)
-    const bool anyN = __any(has_n), anyBig = UNPACKED || __any(bigq);
-    if (anyN) {
-        if (anyBig) { if (active) sc = dp_tile<true, false, UNPACKED>(rp, stride, hp, jb.len); }
-        else        { if (active) sc = dp_tile<true, true, UNPACKED>(rp, stride, hp, jb.len); }
-    } else {
-        if (anyBig) { if (active) sc = dp_tile<false, false, UNPACKED>(rp, stride, hp, jb.len); }
-        else        { if (active) sc = dp_tile<false, true, UNPACKED>(rp, stride, hp, jb.len); }
-    }
-    if (!active) return;
-    if (j >= npairs) { job_score[j] = sc; return; }
-    const PairRec pr = pairs[j];                                             // read after the DP: nothing of it is live across the loop
-    if (pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0)) {
-        out_ll[j] = loglik_of(sc, mapq_lut, pr.mapq);
-        if (out_score) out_score[j] = sc;
-    } else job_score[j] = sc;
 }
 
 // --calculateFlankScore=1 (a2): the same job list, but every DP runs in the reference's traceback mode and its score is
@@ -1164,14 +1183,15 @@ k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32
 __global__ void __launch_bounds__(256)
 k_dp_tb_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32_t* __restrict__ tile,
              const uint32_t* __restrict__ hapw, const Job* __restrict__ jobs, const PairRec* __restrict__ pairs,
-             const double* __restrict__ mapq_lut, long long npairs, const int32_t* __restrict__ dense, long long j0, long long jn,
+             const double* __restrict__ mapq_lut, long long npairs, const int32_t* __restrict__ dense, long long segcap, long long j0, long long jn,
              const long long* __restrict__ cnt, long long extra_cap, unsigned long long* __restrict__ bpbuf, long long bstride, int32_t* __restrict__ job_score,
              double* __restrict__ out_ll, int32_t* __restrict__ out_score)
 {
     if (cnt[CNT_ERR] != 0 || cnt[CNT_NEXTRA] > extra_cap) return;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= jn || j0 + t >= cnt[CNT_NDENSE]) return;
-    const long long j = dense[j0 + t];
+    if (t >= jn) return;
+    const long long j = dense_slot(dense, segcap, cnt, j0 + t);
+    if (j < 0) return;
     const Job jb = jobs[j];
     int sc;
     {
@@ -1337,7 +1357,7 @@ PLAT_EXPORT int plat_dp_batch(plat_ctx* ctx, int n, int lmax, const uint8_t* hap
 
 static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStream_t st, long long* cnt, int maxhap,
                              int maxread, int maxR, long long npairs, int extra_cap, const int32_t* hap_win, const int32_t* win_rows,
-                             const long long* tile_off, int shortcuts)
+                             const long long* tile_off, int shortcuts, int32_t* dense, long long segcap, double* out_ll, int32_t* out_score)
 {
     int tsize_max = 64;                                        // in dwords
     if (maxhap > 4096) tsize_max = 8192;                       // direct mode: 16384 u16 heads
@@ -1358,11 +1378,13 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     hipLaunchKernelGGL(k_seed, dim3(b.n_haps, ngroups > 0 ? ngroups : 1), dim3(64), lds, st, b, hap_win, win_rows, tile_off,
                        (const ReadInfo*)ctx->rinfo.ptr, (const uint16_t*)ctx->codes.ptr, (uint32_t*)ctx->hapw.ptr,
                        (uint8_t*)ctx->hap_flags.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
-                       (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, shortcuts, (const uint32_t*)ctx->tile.ptr);
+                       (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, shortcuts, (const uint32_t*)ctx->tile.ptr, dense, segcap,
+                       (const double*)ctx->d_mapq_lut, out_ll, out_score);
     PLAT_EV(ctx, 5, st);                                       // k_seed alone: ev[1] .. ev[5]
     hipLaunchKernelGGL(k_seed_slow, dim3(4096), dim3(64), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
-                       (const SlowRec*)ctx->slow.ptr, tsize_max, maxhap, cw);
+                       (const SlowRec*)ctx->slow.ptr, tsize_max, maxhap, cw, dense, segcap);
+    hipLaunchKernelGGL(k_dense_total, dim3(1), dim3(1), 0, st, cnt, segcap);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -1394,7 +1416,7 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
 
     // small per-batch arrays: counters | hap_win[n_haps] | win_rows[n_windows] | tile_off[n_windows]
-    const size_t o_hapwin = (CNT_N + 8) * sizeof(long long);
+    const size_t o_hapwin = (size_t)CNT_AREA * sizeof(long long);
     const size_t o_rows = o_hapwin + (((size_t)b.n_haps * 4 + 7) & ~(size_t)7);
     const size_t o_toff = o_rows + (((size_t)b.n_windows * 4 + 7) & ~(size_t)7);
     int rc = plat_reserve(ctx, ctx->counters, o_toff + (size_t)b.n_windows * 8 + 64);
@@ -1409,7 +1431,7 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
 
     ctx->ev_valid_align = 0;
     PLAT_EV(ctx, 0, st);
-    PLAT_HIP(ctx, hipMemsetAsync(cnt, 0, (CNT_N + 8) * sizeof(long long), st));
+    PLAT_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)CNT_AREA * sizeof(long long), st));
     plat_batch_hints hv = {};
     if (async) hv = *hints;
     hipLaunchKernelGGL(k_validate, dim3(2048), dim3(256), 0, st, b, cnt, hap_win, win_rows, calc_flank_score);
@@ -1457,6 +1479,7 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         if (attempt > 0) {                     // (the first pass starts from the memset of all counters above)
             PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_NEXTRA], 0, sizeof(long long), st));
             PLAT_HIP(ctx, hipMemsetAsync(&cnt[CNT_SLOW_SEED], 0, sizeof(long long), st));
+            PLAT_HIP(ctx, hipMemsetAsync(cnt + 64, 0, (size_t)DENSE_SEGS * DENSE_CNT_STRIDE * sizeof(long long), st));
         }
         // the ungapped-alignment shortcut applies to plain scores only (the flank score needs the traceback);
         // PLAT_NO_UNGAPPED=1 sends every such pair through the DP instead (cross-check in tests/test_gpu_parity.py)
@@ -1468,20 +1491,11 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         const char* e_nl = getenv("PLAT_NO_NLOW");
         const int shortcuts = ((!calc_flank_score && !no_ungapped) ? SHORTCUT_UNGAPPED : 0) | (no_exact ? 0 : SHORTCUT_EXACT) |
                               ((e_nl && e_nl[0] == '1') ? 0 : SHORTCUT_NLOW) | (e_dbg ? (atoi(e_dbg) & 0x300) : 0);
+        // the dense list of live job slots is built by the seeding kernels themselves (DENSE_SEGS segments, each able to hold every slot)
+        const long long segcap = npairs + extra_cap;
+        if ((rc = plat_reserve(ctx, ctx->dense, ((size_t)segcap * DENSE_SEGS + 64) * sizeof(int32_t)))) return rc;
         if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win, win_rows, tile_off,
-                                    shortcuts))) return rc;
-        {   // dense list of the live job slots; pairs that need no DP are finished by k_compact_count
-            const long long slots_cap = npairs + extra_cap;
-            const unsigned nblk = (unsigned)((slots_cap + COMPACT_BLOCK - 1) / COMPACT_BLOCK);
-            if ((rc = plat_reserve(ctx, ctx->dense, ((size_t)slots_cap + nblk + 64) * sizeof(int32_t)))) return rc;
-            int32_t* dense = (int32_t*)ctx->dense.ptr;
-            int32_t* block_cnt = dense + slots_cap;
-            hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(COMPACT_BLOCK), 0, st, (const Job*)ctx->jobs.ptr,
-                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, extra_cap, cnt, block_cnt,
-                               out_loglik, out_score);
-            hipLaunchKernelGGL(k_compact_scatter, dim3(nblk), dim3(COMPACT_BLOCK), 0, st, (const Job*)ctx->jobs.ptr, npairs,
-                               extra_cap, cnt, block_cnt, dense);
-        }
+                                    shortcuts, (int32_t*)ctx->dense.ptr, segcap, out_loglik, out_score))) return rc;
         njobs = npairs + extra_cap;
         if (async) break;                      // job overflow is caught on the device and reported by plat_stream_sync
         PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
@@ -1493,10 +1507,9 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         if (nextra > 0x7FFFFF00ll || attempt == 1) return PLAT_ERR_OVERFLOW;
         extra_cap = nextra;                    // tandem-rich batch: re-run the seeding with the exact capacity
     }
-    // synchronous mode: exact number of live slots; asynchronous: the kernels read it on the device (ndense < 0) and the
-    // launch covers every slot
-    const long long ndense = async ? -1 : hb[CNT_NDENSE];
-    const long long ngrid = async ? npairs + extra_cap : ndense;
+    // synchronous mode: exact number of live slots; asynchronous: only the device knows it
+    const long long segcap = npairs + extra_cap;
+    const long long ngrid = async ? npairs + extra_cap : hb[CNT_NDENSE];
     const int32_t* dense = (const int32_t*)ctx->dense.ptr;
     if ((rc = plat_reserve(ctx, ctx->job_score, (size_t)(njobs + 1) * sizeof(int32_t)))) return rc;
     PLAT_EV(ctx, 2, st);
@@ -1513,22 +1526,24 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
             const long long jn = ngrid - j0 < slab ? ngrid - j0 : slab;
             hipLaunchKernelGGL(k_dp_tb_jobs, dim3((unsigned)((jn + 255) / 256)), dim3(256), 0, st, b, hap_win,
                                (const uint32_t*)ctx->tile.ptr, (const uint32_t*)ctx->hapw.ptr, (const Job*)ctx->jobs.ptr,
-                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, j0, jn, cnt, extra_cap,
+                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, segcap, j0, jn, cnt, extra_cap,
                                (unsigned long long*)ctx->tb.ptr, slab, (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
         }
     } else {
         static int dp_impl = -1;                 // 1 = one int16 lane per VGPR (dp_unpacked.hpp), 0 = packed (dp_core.hpp)
         if (dp_impl < 0) { const char* e = getenv("PLAT_DP_IMPL"); dp_impl = e ? (strcmp(e, "unpacked") == 0) : 0; }   // packed measured faster
-        const dim3 grid((unsigned)((ngrid + 255) / 256));
+        // a fixed grid walks the list (its length lives on the device): two rounds of the blocks a device holds at 4 waves/SIMD
+        const long long want = (ngrid + 255) / 256, fixed = 8ll * ctx->n_cu;
+        const dim3 grid((unsigned)(want < fixed ? want : fixed));
         if (dp_impl)
             hipLaunchKernelGGL(k_dp_jobs<true>, grid, dim3(256), 0, st, b, hap_win, (const uint32_t*)ctx->tile.ptr,
                                (const uint32_t*)ctx->hapw.ptr, (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
-                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, ndense, cnt, extra_cap,
+                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, segcap, cnt, extra_cap,
                                (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
         else
             hipLaunchKernelGGL(k_dp_jobs<false>, grid, dim3(256), 0, st, b, hap_win, (const uint32_t*)ctx->tile.ptr,
                                (const uint32_t*)ctx->hapw.ptr, (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
-                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, ndense, cnt, extra_cap,
+                               (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, segcap, cnt, extra_cap,
                                (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
     }
     PLAT_EV(ctx, 3, st);
