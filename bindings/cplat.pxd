@@ -155,6 +155,12 @@ cdef extern from "platypus_mi355x.h":
                               int gen_indels, int max_per_read, const int32_t* read_region, int32_t* out_rec, int32_t* out_count,
                               int32_t* out_status, void* stream) nogil
 
+    # ---- addVariantToList + the per-sample support filter (variant.pyx:499-527, variantcaller.pyx:456-467)
+    int plat_candidates_merge_batch(plat_ctx* ctx, const plat_candidate_batch* batch, const int32_t* read_end, int n_scans,
+                                    const int32_t* scan_read_begin, const int32_t* scan_longest, int max_per_read, const int32_t* rec,
+                                    const int32_t* count, const int32_t* status, double min_var_freq, int cap_per_scan,
+                                    int32_t* out_cand, int32_t* out_n, void* stream) nogil
+
     # ---- checkAndTrimRead (cwindow.pyx:332-481)
     ctypedef struct plat_readqc_batch:
         int32_t n_reads

@@ -300,6 +300,23 @@ int plat_candidates_batch(plat_ctx* ctx, const plat_candidate_batch* batch, int 
                           int gen_snps, int gen_indels, int max_per_read, const int32_t* read_region,
                           int32_t* out_rec, int32_t* out_count, int32_t* out_status, void* stream);
 
+/* The dictionary step behind the scan and the per-sample support filter, on the device:
+ * Replaces  VariantCandidateGenerator.addVariantToList (variant.pyx:499-527: equal records merge, supporting reads count) and
+ *           `computeVariantReadSupportFrac(v, buffer) >= minVarFreq or v.nAdded != v.nRemoved`  (variantcaller.pyx:456-467,
+ *           variantFilter.pyx:359-373 over ReadArray.countReadsCoveringRegion, cwindow.pyx:176-206)
+ * for n_scans scans (a scan = the `reads` of one sample of one region) of a batch whose records plat_candidates_batch wrote:
+ * the reads of scan g are [scan_read_begin[g], scan_read_begin[g+1]) (sorted by position; read_end = cAlignedRead.end),
+ * scan_longest[g] = ReadArray.getLengthOfLongestRead().  Output per scan: out_n[2g] candidates that pass, unordered, 8 ints each at
+ * out_cand[8*(g*cap_per_scan + i)]: {id of the first record with this content (read index * max_per_read + k: sort by it for
+ * the dictionary's order), reads showing it, reads covering its position, then the record's five fields}.  out_n[2g+1] = 0,
+ * PLAT_ERR_BAD_INPUT (a read outside its reference window, or read pointers out of order: the reference raises),
+ * PLAT_ERR_OVERFLOW (more than 6144 distinct records or more than cap_per_scan candidates: merge this scan on the host) or
+ * -(2^20 + n) when a read has n > max_per_read records (scan again with room for n).                                        */
+int plat_candidates_merge_batch(plat_ctx* ctx, const plat_candidate_batch* batch, const int32_t* read_end, int n_scans,
+                                const int32_t* scan_read_begin, const int32_t* scan_longest, int max_per_read,
+                                const int32_t* rec, const int32_t* count, const int32_t* status, double min_var_freq,
+                                int cap_per_scan, int32_t* out_cand, int32_t* out_n, void* stream);
+
 /* ---- read QC / trimming ----------------------------------------------------------------------------
  * Replaces  cdef int checkAndTrimRead(theRead, theLastRead, ...)   cwindow.pyx:332-481
  * as driven by bamReadBuffer.addReadToBuffer (:560-595) for whole streams of reads: read r's

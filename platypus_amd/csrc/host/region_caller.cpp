@@ -89,7 +89,7 @@ struct Slot {
     // candidate scan
     Staged<uint8_t> c_ref;
     Staged<int64_t> c_refoff;
-    Staged<int32_t> c_rss, c_clen, c_rec, c_cnt, c_status;
+    Staged<int32_t> c_rss, c_clen, c_rec, c_cnt, c_status, c_scanbegin, c_scanlongest, m_cand, m_n;
     // window batch
     Staged<int32_t> w_hapbegin, w_readbegin, w_start, w_end, w_flank, w_segbegin, w_ngood, w_src, g_pos, g_end, g_flags, o_calls, o_iters, o_hapscore, o_score;
     Staged<int64_t> w_pairoff, w_hapoff, w_readoff, w_gloff;
@@ -101,7 +101,7 @@ struct Slot {
     Staged<uint8_t> p_mask, s_added, s_vig;
     Staged<double> p_prior, p_post, k_lik, k_out4;
     // many small arrays travel as ONE copy: they are views into these blocks (Layout)
-    Arena a_tab, a_cin, a_cout, a_win, a_wout, a_pin, a_sin, a_sout;
+    Arena a_tab, a_cin, a_cout, a_mout, a_win, a_wout, a_pin, a_sin, a_sout;
     double t_host = 0, t_wait = 0;
 
     void sync(const char* where) {
@@ -478,10 +478,11 @@ struct Chunk {
     void scanCandidates() {
         Slot& z = s;
         std::vector<int64_t> refoff{0};
-        std::vector<int32_t> rss, clen;
+        std::vector<int32_t> rss, clen, scanbegin, scanlongest;
         std::string blob;
         for (RegionWork* r : regions)
             for (size_t i = 0; i < r->samples.size(); ++i) {
+                scanbegin.push_back((int32_t)r->samples[i].reads.base); scanlongest.push_back(r->samples[i].reads.longest);
                 const int64_t a = std::max<int64_t>(0, (int64_t)r->in->start - 2000);                   // variant.pyx:486-488
                 const int64_t e = std::min<int64_t>((int64_t)r->in->end + 2000, r->fa.len - 1);
                 blob += r->fa.getSequence(a, e);
@@ -490,29 +491,52 @@ struct Chunk {
             }
         {
             Layout L;
+            scanbegin.push_back((int32_t)nGood);
             L.add(z.c_ref, blob.size() + PLAT_BLOB_PAD); L.add(z.c_refoff, refoff.size()); L.add(z.c_rss, rss.size()); L.add(z.c_clen, clen.size());
+            L.add(z.c_scanbegin, scanbegin.size()); L.add(z.c_scanlongest, scanlongest.size());
             L.commit(z, z.a_cin);
             memcpy(z.c_ref.h, blob.data(), blob.size()); memset(z.c_ref.h + blob.size(), 0, PLAT_BLOB_PAD);
-            fill(z, z.c_refoff, refoff); fill(z, z.c_rss, rss); fill(z, z.c_clen, clen);
+            fill(z, z.c_refoff, refoff); fill(z, z.c_rss, rss); fill(z, z.c_clen, clen); fill(z, z.c_scanbegin, scanbegin); fill(z, z.c_scanlongest, scanlongest);
             L.upload(z, z.a_cin);
         }
         refBlob.swap(blob);
-        if (nGood == 0) return;
+        if (nGood == 0) { hostTally = true; return; }                       // nothing to scan: the (empty) host tally
         plat_candidate_batch cb;
         memset(&cb, 0, sizeof cb);
         cb.n_regions = nScan; cb.n_reads = (int32_t)nGood;
         cb.ref_seq = z.c_ref.d; cb.ref_off = z.c_refoff.d; cb.ref_seq_start = z.c_rss.d; cb.contig_len = z.c_clen.d;
         cb.read_seq = z.t_seq.d; cb.read_qual = z.t_qual.d; cb.read_off = z.t_off.d; cb.read_pos = z.t_pos.d; cb.read_flags = z.t_flags.d;
         cb.cigar = z.t_cigar.d; cb.cig_off = z.t_cigoff.d;
+        hostTally = getenv("PLAT_CALLER_HOST_TALLY") != nullptr;         // (measurements / tests: merge the records on the host)
         for (;;) {
+            // records stay on the device when the merge kernel can take them: c_cnt / c_status / c_rec are laid out for a download
+            // all the same (the host tally needs them when a scan overflows the kernel's table)
             Layout LO;
             LO.add(z.c_cnt, nGood); LO.add(z.c_status, nGood); LO.add(z.c_rec, nGood * (size_t)maxPerRead * 5);
             LO.commit(z, z.a_cout);
             ck(plat_candidates_batch(z.ctx, &cb, o.minFlank, o.minBaseQual, o.genSNPs, o.genIndels, maxPerRead, z.t_region.d, z.c_rec.d, z.c_cnt.d,
                                      z.c_status.d, z.stream), "plat_candidates_batch");
+            int need = 0;
+            if (!hostTally) {
+                // addVariantToList + the per-sample support filter on the device (variant.pyx:499-527, variantcaller.pyx:456-467)
+                Layout LM;
+                LM.add(z.m_n, (size_t)nScan * 2); LM.add(z.m_cand, (size_t)nScan * mergeCap * 8);
+                LM.commit(z, z.a_mout);
+                ck(plat_candidates_merge_batch(z.ctx, &cb, z.t_end.d, nScan, z.c_scanbegin.d, z.c_scanlongest.d, maxPerRead, z.c_rec.d, z.c_cnt.d,
+                                               z.c_status.d, o.minVarFreq, mergeCap, z.m_cand.d, z.m_n.d, z.stream), "plat_candidates_merge_batch");
+                LM.download(z, z.a_mout);
+                z.sync("candidate scan");
+                for (int g = 0; g < nScan; ++g) {
+                    const int st_ = z.m_n.h[2 * g + 1];
+                    if (st_ == PLAT_ERR_BAD_INPUT) throw DeviceError(PLAT_ERR_BAD_INPUT, "a read reaches outside the reference window handed over, or read pointers out of order");
+                    if (st_ <= -(1 << 20)) need = std::max(need, -st_ - (1 << 20));
+                    else if (st_ != 0) hostTally = true;                    // more distinct records / candidates than the kernel takes
+                }
+                if (!need && !hostTally) break;
+                if (need) { maxPerRead = need; continue; }
+            }
             LO.download(z, z.a_cout);
             z.sync("candidate scan");
-            int need = 0;
             for (size_t i = 0; i < nGood; ++i) {
                 if (z.c_status.h[i] == PLAT_ERR_BAD_INPUT) throw DeviceError(PLAT_ERR_BAD_INPUT, "a read reaches outside the reference window handed over");
                 if (z.c_status.h[i] == PLAT_ERR_OVERFLOW) need = std::max(need, z.c_cnt.h[i]);
@@ -521,18 +545,49 @@ struct Chunk {
             maxPerRead = need;                                              // a read with more candidates than its slice: again with room for it
         }
     }
+    bool hostTally = false;
+    int mergeCap = 2048;
     std::string refBlob;
 
     // -- B1: candidates of one region -> merged, per-sample support filter, left-normalised, filtered (variantcaller.pyx:439-531)
     void regionVariants(RegionWork& r, int scan0) {
         Slot& z = s;
-        (void)scan0;
         VarList everyone;                                                   // the all-samples generator's variantHeap, insertion order
         std::unordered_map<std::string, Variant*> everyoneIndex;
+        // a candidate of one sample that passed the support filter joins the all-samples dictionary: equal variants of different
+        // samples merge (addVariantToList, variant.pyx:499-527)
+        auto pass = [&](int pos, const char* rem, int nrem, const char* add, int nadd, int count) {
+            std::string key = std::to_string(pos);
+            key += '|'; key.append(rem, (size_t)nrem); key += '|'; key.append(add, (size_t)nadd);
+            auto it = everyoneIndex.find(key);
+            if (it != everyoneIndex.end()) {
+                Variant tmp(pos, std::string(), std::string(), count, PLATYPUS_VAR);
+                it->second->addVariant(tmp);
+            } else {
+                Variant* v = r.pool.make(pos, std::string(rem, (size_t)nrem), std::string(add, (size_t)nadd), count, PLATYPUS_VAR);
+                everyoneIndex.emplace(std::move(key), v);
+                everyone.push_back(v);
+            }
+        };
+        if (!hostTally) {
+            // merged and filtered on the device (plat_candidates_merge_batch): the scan's candidates in the order of their first records
+            for (size_t i = 0; i < r.samples.size(); ++i) {
+                const TableView& tv = r.samples[i].reads;
+                const int g = scan0 + (int)i, n = z.m_n.h[2 * g];
+                const int64_t blobBase = tv.n() ? z.t_off.h[tv.base] : 0;
+                std::vector<const int32_t*> cands((size_t)n);
+                for (int k = 0; k < n; ++k) cands[(size_t)k] = z.m_cand.h + 8 * ((size_t)g * (size_t)mergeCap + (size_t)k);
+                std::sort(cands.begin(), cands.end(), [](const int32_t* a, const int32_t* b) { return a[0] < b[0]; });
+                for (const int32_t* c : cands) {
+                    r.nCandRecords += c[1];
+                    pass(std::max(0, c[3]), c[4] ? refBlob.data() + c[6] : "", c[4], c[5] ? (const char*)tv.t->seq + (c[7] - blobBase) : "", c[5], c[1]);
+                }
+            }
+        }
         struct Key { int pos, nrem, nadd, count; const char* rem; const char* add; };
         std::vector<Key> keys;                                              // this sample's variantHeap: distinct records, first-occurrence order
         std::vector<int32_t> table;                                         // open addressing over `keys` (index + 1, 0 = empty)
-        for (size_t i = 0; i < r.samples.size(); ++i) {
+        for (size_t i = 0; hostTally && i < r.samples.size(); ++i) {
             const TableView& tv = r.samples[i].reads;
             keys.clear();
             size_t tmask = 4095;
@@ -573,19 +628,7 @@ struct Chunk {
                 tv.overlapRange(k.pos, k.pos + 1, s0, e0);
                 const int total = e0 - s0;
                 const double frac = total == 0 ? 0.0 : (double)k.count / total;
-                if (frac >= o.minVarFreq || k.nadd != k.nrem) {
-                    std::string key = std::to_string(k.pos);
-                    key += '|'; key.append(k.rem, (size_t)k.nrem); key += '|'; key.append(k.add, (size_t)k.nadd);
-                    auto it = everyoneIndex.find(key);
-                    if (it != everyoneIndex.end()) {
-                        Variant tmp(k.pos, std::string(), std::string(), k.count, PLATYPUS_VAR);
-                        it->second->addVariant(tmp);
-                    } else {
-                        Variant* v = r.pool.make(k.pos, std::string(k.rem, (size_t)k.nrem), std::string(k.add, (size_t)k.nadd), k.count, PLATYPUS_VAR);
-                        everyoneIndex.emplace(std::move(key), v);
-                        everyone.push_back(v);
-                    }
-                }
+                if (frac >= o.minVarFreq || k.nadd != k.nrem) pass(k.pos, k.rem, k.nrem, k.add, k.nadd, k.count);
             }
         }
         std::stable_sort(everyone.begin(), everyone.end(), variantLess);    // getCandidates(): sorted(values)
@@ -1295,7 +1338,7 @@ CALLER_EXPORT int plat_caller_destroy(plat_caller* c) {
                    z.g_end, z.g_flags, z.o_calls, z.o_iters, z.o_hapscore, z.o_score, z.w_pairoff, z.w_hapoff, z.w_readoff, z.w_gloff, z.w_hapseq, z.w_kind, z.g_seq,
                    z.g_qual, z.g_mapq, z.o_loglik, z.o_gl, z.o_logl, z.o_gof, z.o_freq, z.o_em, z.p_win, z.s_vw, z.s_pos, z.s_min, z.s_max, z.s_nadd, z.s_nrem,
                    z.s_gb, z.s_ge, z.s_bb, z.s_be, z.s_ps, z.s_minq, z.s_nminq, z.k_win, z.k_nvar, z.k_vih, z.k_ref, z.k_ph, z.p_off, z.s_aoff, z.s_moff, z.s_counts,
-                   z.k_vo, z.k_ro, z.k_lo, z.p_mask, z.s_added, z.s_vig, z.p_prior, z.p_post, z.k_lik, z.k_out4, z.a_tab, z.a_cin, z.a_cout, z.a_win, z.a_wout,
+                   z.k_vo, z.k_ro, z.k_lo, z.p_mask, z.s_added, z.s_vig, z.p_prior, z.p_post, z.k_lik, z.k_out4, z.a_tab, z.a_cin, z.a_cout, z.a_mout, z.c_scanbegin, z.c_scanlongest, z.m_cand, z.m_n, z.a_win, z.a_wout,
                    z.a_pin, z.a_sin, z.a_sout);
         plat_stream_destroy(z.ctx, z.stream);
         plat_ctx_destroy(z.ctx);

@@ -134,6 +134,125 @@ PLAT_EXPORT int plat_candidates_batch(plat_ctx* ctx, const plat_candidate_batch*
 }
 
 // ------------------------------------------------------------------------------------------------
+// The dictionary step behind the scan (VariantCandidateGenerator.addVariantToList, variant.pyx:499-527) and the per-sample support
+// filter of generateVariantsInRegion (variantcaller.pyx:456-467) for every scan (= region x sample) of a candidate batch:
+// one workgroup per scan, the DISTINCT records (position, removed bases, added bases) in an LDS hash table -- slot = the record
+// with the smallest id (first occurrence: the reference's dictionary order) + the number of reads showing it -- then, per distinct
+// record, the reads covering its position (ReadArray.countReadsCoveringRegion, cwindow.pyx:176-206) and the filter.
+namespace plat {
+constexpr int MERGE_SLOTS = 8192, MERGE_LIMIT = 6144, MERGE_THREADS = 256;
+
+__device__ __forceinline__ bool rec_same(const plat_candidate_batch& b, const int32_t* x, const int32_t* y) {
+    if (x[0] != y[0] || x[1] != y[1] || x[2] != y[2]) return false;
+    for (int i = 0; i < x[1]; ++i) if (b.ref_seq[(long long)x[3] + i] != b.ref_seq[(long long)y[3] + i]) return false;
+    for (int i = 0; i < x[2]; ++i) if (b.read_seq[(long long)x[4] + i] != b.read_seq[(long long)y[4] + i]) return false;
+    return true;
+}
+
+__global__ void __launch_bounds__(MERGE_THREADS)
+k_candidates_merge(plat_candidate_batch b, const int32_t* __restrict__ read_end, const int32_t* __restrict__ scan_read_begin,
+                   const int32_t* __restrict__ scan_longest, int max_per_read, const int32_t* __restrict__ rec,
+                   const int32_t* __restrict__ count, const int32_t* __restrict__ status, double min_var_freq, int cap,
+                   int32_t* __restrict__ out_cand, int32_t* __restrict__ out_n)
+{
+    __shared__ int s_rep[MERGE_SLOTS];                   // smallest record id with this content, -1 empty
+    __shared__ int s_cnt[MERGE_SLOTS];
+    __shared__ int s_distinct, s_status, s_need, s_out;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int r0 = scan_read_begin[g], N = scan_read_begin[g + 1] - r0;
+    for (int i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) { s_rep[i] = -1; s_cnt[i] = 0; }
+    if (tid == 0) { s_distinct = 0; s_status = 0; s_need = 0; s_out = 0; }
+    __syncthreads();
+    for (int q = tid; q < N; q += MERGE_THREADS) {
+        const int r = r0 + q, c = count[r];
+        if (status[r] == PLAT_ERR_BAD_INPUT) s_status = PLAT_ERR_BAD_INPUT;
+        if (c > max_per_read) { atomicMax(&s_need, c); continue; }
+        for (int k = 0; k < c; ++k) {
+            if (*(volatile int*)&s_distinct > MERGE_LIMIT) break;
+            const int id = r * max_per_read + k;
+            const int32_t* me = rec + 5ll * id;
+            unsigned h = (unsigned)me[0] * 2654435761u + (unsigned)me[1] * 40503u + (unsigned)me[2] * 97u;
+            for (int i = 0; i < me[1]; ++i) h = h * 31u + b.ref_seq[(long long)me[3] + i];
+            for (int i = 0; i < me[2]; ++i) h = h * 37u + b.read_seq[(long long)me[4] + i];
+            unsigned sl = (h ^ (h >> 15)) & (MERGE_SLOTS - 1);
+            for (;;) {
+                int cur = s_rep[sl];
+                if (cur == -1) {
+                    const int old = atomicCAS(&s_rep[sl], -1, id);
+                    if (old == -1) { atomicAdd(&s_distinct, 1); atomicAdd(&s_cnt[sl], 1); break; }
+                    cur = old;
+                }
+                if (cur == id || rec_same(b, rec + 5ll * cur, me)) { atomicMin(&s_rep[sl], id); atomicAdd(&s_cnt[sl], 1); break; }
+                sl = (sl + 1u) & (MERGE_SLOTS - 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (s_need > 0 || s_status != 0 || s_distinct > MERGE_LIMIT) {
+        if (tid == 0) {
+            out_n[2 * g] = 0;
+            out_n[2 * g + 1] = s_status != 0 ? s_status : (s_need > 0 ? -(1 << 20) - s_need : PLAT_ERR_OVERFLOW);   // -(2^20 + needed records per read) | overflow of the table
+        }
+        return;
+    }
+    const int32_t* pos = b.read_pos + r0;
+    const int32_t* endp = read_end + r0;
+    const int longest = scan_longest[g];
+    for (int sl = tid; sl < MERGE_SLOTS; sl += MERGE_THREADS) {
+        const int id = s_rep[sl];
+        if (id < 0) continue;
+        const int32_t* me = rec + 5ll * id;
+        const int start = me[0], c = s_cnt[sl];
+        // countReadsCoveringRegion(start, start + 1), cwindow.pyx:176-206
+        int total = 0;
+        if (N > 0) {
+            const long long key = (long long)start - longest > 1 ? (long long)start - longest : 1;
+            int lo = 0, hi = N;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)pos[mid] < key) lo = mid + 1; else hi = mid; }
+            int s = lo;
+            lo = 0; hi = N;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (pos[mid] < start + 1) lo = mid + 1; else hi = mid; }
+            const int e = lo;
+            while (s < N && endp[s] <= start) ++s;
+            if (s > e) { s_status = PLAT_ERR_BAD_INPUT; continue; }       // "Read start pointer > read end pointer": the reference raises
+            total = e - s;
+        }
+        const double frac = total == 0 ? 0.0 : (double)c / (double)total;
+        if (frac >= min_var_freq || me[1] != me[2]) {
+            const int at = atomicAdd(&s_out, 1);
+            if (at < cap) {
+                int32_t* o = out_cand + 8ll * ((long long)g * cap + at);
+                o[0] = id; o[1] = c; o[2] = total; o[3] = me[0]; o[4] = me[1]; o[5] = me[2]; o[6] = me[3]; o[7] = me[4];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const bool over = s_out > cap;
+        out_n[2 * g] = over ? 0 : s_out;
+        out_n[2 * g + 1] = s_status != 0 ? s_status : (over ? PLAT_ERR_OVERFLOW : 0);
+    }
+}
+}  // namespace plat
+
+PLAT_EXPORT int plat_candidates_merge_batch(plat_ctx* ctx, const plat_candidate_batch* batch, const int32_t* read_end, int n_scans,
+                                            const int32_t* scan_read_begin, const int32_t* scan_longest, int max_per_read,
+                                            const int32_t* rec, const int32_t* count, const int32_t* status, double min_var_freq,
+                                            int cap_per_scan, int32_t* out_cand, int32_t* out_n, void* stream)
+{
+    if (!ctx || !batch || n_scans < 0 || max_per_read < 1 || cap_per_scan < 1) return PLAT_ERR_INVALID;
+    if (n_scans == 0) return PLAT_OK;
+    const plat_candidate_batch b = *batch;
+    if (!b.ref_seq || !b.read_seq || !b.read_pos || !read_end || !scan_read_begin || !scan_longest || !rec || !count || !status || !out_cand || !out_n)
+        return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(plat::k_candidates_merge, dim3((unsigned)n_scans), dim3(plat::MERGE_THREADS), 0, (hipStream_t)stream, b, read_end,
+                       scan_read_begin, scan_longest, max_per_read, rec, count, status, min_var_freq, cap_per_scan, out_cand, out_n);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Read QC / trimming: checkAndTrimRead (cwindow.pyx:332-481).  One lane per read; `theLastRead` of
 // bamReadBuffer.addReadToBuffer (:560-595) is simply the previous read of the same stream and only its position, length
 // and mate position are looked at, so the reads of a stream are independent of each other.

@@ -293,6 +293,76 @@ API int plat_candidates_batch(plat_ctx* c, const plat_candidate_batch* b, int mi
     return PLAT_OK;
 }
 
+/* the dictionary step + support filter: a straightforward restatement (sort the scan's records by content, count runs) */
+typedef struct { const int32_t* rec; int id; } fk_rec;
+static __thread const plat_candidate_batch* fk_b;       /* (the caller library runs several worker threads) */
+static int fk_cmp_content(const int32_t* x, const int32_t* y) {
+    if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
+    if (x[1] != y[1]) return x[1] < y[1] ? -1 : 1;
+    if (x[2] != y[2]) return x[2] < y[2] ? -1 : 1;
+    int c = x[1] ? memcmp(fk_b->ref_seq + x[3], fk_b->ref_seq + y[3], (size_t)x[1]) : 0;
+    if (c) return c;
+    return x[2] ? memcmp(fk_b->read_seq + x[4], fk_b->read_seq + y[4], (size_t)x[2]) : 0;
+}
+static int fk_cmp(const void* a, const void* b) {
+    const fk_rec* x = (const fk_rec*)a, *y = (const fk_rec*)b;
+    const int c = fk_cmp_content(x->rec, y->rec);
+    if (c) return c;
+    return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);
+}
+API int plat_candidates_merge_batch(plat_ctx* c, const plat_candidate_batch* b, const int32_t* read_end, int n_scans,
+                                    const int32_t* scan_read_begin, const int32_t* scan_longest, int max_per_read, const int32_t* rec,
+                                    const int32_t* count, const int32_t* status, double min_var_freq, int cap, int32_t* out_cand,
+                                    int32_t* out_n, void* stream)
+{
+    (void)c; (void)stream;
+    fk_b = b;
+    for (int g = 0; g < n_scans; ++g) {
+        const int r0 = scan_read_begin[g], N = scan_read_begin[g + 1] - r0;
+        int st = 0, need = 0, n = 0;
+        for (int q = 0; q < N; ++q) {
+            if (status[r0 + q] == PLAT_ERR_BAD_INPUT) st = PLAT_ERR_BAD_INPUT;
+            if (count[r0 + q] > max_per_read) { if (count[r0 + q] > need) need = count[r0 + q]; } else n += count[r0 + q];
+        }
+        if (st || need) { out_n[2 * g] = 0; out_n[2 * g + 1] = st ? st : -(1 << 20) - need; continue; }
+        fk_rec* v = (fk_rec*)malloc(sizeof(fk_rec) * (size_t)(n + 1));
+        n = 0;
+        for (int q = 0; q < N; ++q)
+            for (int k = 0; k < count[r0 + q]; ++k) { const int id = (r0 + q) * max_per_read + k; v[n].rec = rec + 5ll * id; v[n].id = id; ++n; }
+        qsort(v, (size_t)n, sizeof(fk_rec), fk_cmp);
+        int nout = 0;
+        const int32_t* pos = b->read_pos + r0; const int32_t* endp = read_end + r0;
+        for (int i = 0; i < n && st == 0;) {
+            int j = i + 1;
+            while (j < n && fk_cmp_content(v[i].rec, v[j].rec) == 0) ++j;
+            const int32_t* me = v[i].rec;
+            const int start = me[0], cnt = j - i;
+            int total = 0;
+            if (N > 0) {
+                long long key = (long long)start - scan_longest[g]; if (key < 1) key = 1;
+                int s = 0; while (s < N && (long long)pos[s] < key) ++s;
+                int e = 0; while (e < N && pos[e] < start + 1) ++e;
+                while (s < N && endp[s] <= start) ++s;
+                if (s > e) { st = PLAT_ERR_BAD_INPUT; break; }
+                total = e - s;
+            }
+            const double frac = total == 0 ? 0.0 : (double)cnt / (double)total;
+            if (frac >= min_var_freq || me[1] != me[2]) {
+                if (nout < cap) {
+                    int32_t* o = out_cand + 8ll * ((long long)g * cap + nout);
+                    o[0] = v[i].id; o[1] = cnt; o[2] = total; memcpy(o + 3, me, 5 * sizeof(int32_t));
+                }
+                ++nout;
+            }
+            i = j;
+        }
+        free(v);
+        out_n[2 * g] = (st || nout > cap) ? 0 : nout;
+        out_n[2 * g + 1] = st ? st : (nout > cap ? PLAT_ERR_OVERFLOW : 0);
+    }
+    return PLAT_OK;
+}
+
 API int plat_gather_reads(plat_ctx* c, int64_t n_dst, const int32_t* src_index, const int64_t* dst_off, const uint8_t* src_seq,
                           const uint8_t* src_qual, const int64_t* src_off, const int32_t* src_pos, const int32_t* src_end,
                           const uint8_t* src_mapq, const int32_t* src_flags, uint8_t* dst_seq, uint8_t* dst_qual, int32_t* dst_pos,
