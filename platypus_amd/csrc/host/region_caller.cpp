@@ -289,6 +289,13 @@ struct RegionWork {
     std::vector<WindowWork> windows;
     std::string text;
     int64_t nRecords = 0, nCandRecords = 0;
+    // frees everything but the record text (called by the worker that finished the region, so that the cost of freeing thousands of
+    // windows and haplotypes is spread over the workers instead of being paid serially at the end of plat_call_regions)
+    void release() {
+        std::vector<WindowWork>().swap(windows);
+        VarList().swap(variants);
+        pool = VariantPool();
+    }
 };
 
 struct Options : plat_caller_options {};
@@ -1277,7 +1284,7 @@ struct Chunk {
             }
         }
         int64_t nRec = 0;
-        for (RegionWork* r : regions) nRec += r->nRecords;
+        for (RegionWork* r : regions) { nRec += r->nRecords; r->release(); }
         const double total = secs(t0, Clock::now()), waited = s.t_wait - wait0;
         std::lock_guard<std::mutex> g(stMutex);
         st.n_windows += nWin; st.n_variants += nVar; st.n_candidate_records += nCand; st.n_records += nRec;

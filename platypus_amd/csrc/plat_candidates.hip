@@ -140,7 +140,7 @@ PLAT_EXPORT int plat_candidates_batch(plat_ctx* ctx, const plat_candidate_batch*
 // with the smallest id (first occurrence: the reference's dictionary order) + the number of reads showing it -- then, per distinct
 // record, the reads covering its position (ReadArray.countReadsCoveringRegion, cwindow.pyx:176-206) and the filter.
 namespace plat {
-constexpr int MERGE_SLOTS = 8192, MERGE_LIMIT = 6144, MERGE_THREADS = 256;
+constexpr int MERGE_SLOTS = 8192, MERGE_LIMIT = 6144, MERGE_THREADS = 1024;
 
 __device__ __forceinline__ bool rec_same(const plat_candidate_batch& b, const int32_t* x, const int32_t* y) {
     if (x[0] != y[0] || x[1] != y[1] || x[2] != y[2]) return false;

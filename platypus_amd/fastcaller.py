@@ -74,7 +74,7 @@ class CallerStats(C.Structure):
 class ReadTable:
     """One ReadArray as arrays (cAlignedRead fields, htslibWrapper.pxd:187-201).  `reads`: the order the ReadArray holds them in
     (sorted by pos; brokenMates by mate position)."""
-    __slots__ = ("n", "seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off", "_pinned")
+    __slots__ = ("n", "seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off", "_pinned", "_struct")
 
     def __init__(self, seq, qual, off, pos, end, mapq, flags, mate_pos, cigar, cig_off, pin=False):
         """pin=True keeps the two byte blobs in page-locked memory (what a loader that decodes into pinned buffers hands over):
@@ -104,10 +104,14 @@ class ReadTable:
                    np.concatenate([[0], np.cumsum([len(r.cigarOps) for r in reads])]))
 
     def struct(self):
-        t = _ReadTable()
-        t.n_reads = self.n
-        for k in ("seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off"):
-            setattr(t, k, getattr(self, k).ctypes.data)
+        """The plat_read_table of these arrays (built once: the arrays are kept alive by, and never replaced on, this object)."""
+        t = getattr(self, "_struct", None)
+        if t is None:
+            t = _ReadTable()
+            t.n_reads = self.n
+            for k in ("seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off"):
+                setattr(t, k, getattr(self, k).ctypes.data)
+            self._struct = t
         return t
 
 
@@ -119,6 +123,16 @@ class RegionReads:
         self.contig = np.ascontiguousarray(np.frombuffer(contig_seq, dtype=np.uint8) if isinstance(contig_seq, (bytes, bytearray)) else contig_seq,
                                            dtype=np.uint8)
         self.samples = samples                                  # [(reads, bad, broken)]
+        self._c = None
+
+    def c_region(self):
+        """(plat_region fields, the plat_sample_reads array they point to), built once per region."""
+        if self._c is None:
+            ss = (_SampleReads * len(self.samples))()
+            for i, (a, b, c) in enumerate(self.samples):
+                ss[i].reads, ss[i].bad_reads, ss[i].broken_mates = a.struct(), b.struct(), c.struct()
+            self._c = (self.chrom.encode(), self.contig.ctypes.data, len(self.contig), ss)
+        return self._c
 
     @classmethod
     def from_buffers(cls, chrom, start, end, fasta, buffers):
@@ -217,17 +231,12 @@ class NativeCaller:
         as the reference updates it."""
         n, nS = len(regions), len(sample_names)
         arr = (_Region * max(n, 1))()
-        keep = []
         for k, r in enumerate(regions):
             assert len(r.samples) == nS
-            ss = (_SampleReads * nS)()
-            for i, (a, b, c) in enumerate(r.samples):
-                ss[i].reads, ss[i].bad_reads, ss[i].broken_mates = a.struct(), b.struct(), c.struct()
-            keep.append(ss)
-            arr[k].chrom = r.chrom.encode()
-            arr[k].start, arr[k].end = r.start, r.end
-            arr[k].contig_seq, arr[k].contig_len = r.contig.ctypes.data, len(r.contig)
-            arr[k].samples = ss
+            a = arr[k]
+            a.chrom, a.contig_seq, a.contig_len, ss = r.c_region()
+            a.start, a.end = r.start, r.end
+            a.samples = ss
         names = (C.c_char_p * nS)(*[s.encode() for s in sample_names])
         o = CallerOptions.from_options(options)
         text, length, st = C.c_void_p(), C.c_size_t(), CallerStats()
