@@ -83,7 +83,7 @@ def call_variants_config4(opts, n_regions):
         rr = [F.region_from_arrays(r) for r in regs]
         local = int(os.environ.get("LOCAL_RANK", rank))
         import torch
-        nc = F.NativeCaller(local % max(1, torch.cuda.device_count()), int(os.environ.get("PLAT_CALLER_WORKERS", "4")),
+        nc = F.NativeCaller(local % max(1, torch.cuda.device_count()), int(os.environ.get("PLAT_CALLER_WORKERS", "8")),
                             int(os.environ.get("PLAT_CALLER_CHUNK", "2")))
         t0 = time.time()
         text.write(nc.call_regions(rr, ["S1"], opts) if rr else "")

@@ -38,7 +38,7 @@ def main(o):
     stats(o + "/stats3", prof + "/r02_kernel_stats_pipelined.txt", CMD + b2 + "   (MI355X; config 2, default: 3 batches in flight, kernels of different batches overlap)")
     stats(o + "/stats_c3", prof + "/r02_assemble_stats.txt", CMD + "--config 3 --regions 2000 --steps 5   (MI355X; config 3: 2000 assembly tiles per launch)")
     stats(o + "/stats_c5", prof + "/r02_config5_stats.txt", CMD + "--config 5 --windows 200 --steps 10 --warmup 2   (MI355X; config 5: 200 windows x 100 samples per step)")
-    stats(o + "/stats_c4", prof + "/r02_config4_stats.txt", CMD + "--config 4 --regions 64 --steps 1   (MI355X; config 4: 64 regions x 100 kb through the native region loop, 12 host threads)")
+    stats(o + "/stats_c4", prof + "/r02_config4_stats.txt", CMD + "--config 4 --regions 64 --steps 1   (MI355X; config 4: 64 regions x 100 kb through the native region loop, 16 host threads)")
     hdr = ("# rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python bench.py %s   (MI355X; tools/profile_round2.sh)\n"
            "# three separate passes: C = FETCH_SIZE | WRITE_SIZE | SQ counters\n"
            "# mean per kernel launch; FETCH_SIZE / WRITE_SIZE in KB (raw counters, see MI355X_MICROARCH.md: FETCH_SIZE under-reports 16 B/lane streaming reads 2x; "
