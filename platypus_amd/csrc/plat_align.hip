@@ -413,6 +413,7 @@ __device__ __forceinline__ unsigned kmer_head(const unsigned* table, unsigned co
 // that picks one representative lane per arg-max diagonal) and emits the candidates in ascending order.
 typedef unsigned long long u64;
 constexpr int SEED_CHUNKS = 4;
+constexpr int UNG_KMAX = 4;           // mismatches on the candidate diagonal the ungapped-alignment proof takes on
 
 __device__ __forceinline__ u64 funnel(u64 lo, u64 hi, int sh) { return sh ? (lo >> sh) | (hi << (64 - sh)) : lo; }
 
@@ -879,22 +880,35 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         // all-match path costs 0; a haplotype N costs 0 as well, align.c:17,314-318) and calign.pyx:242-247 returns it
         // at once.  No DP is launched for the pair.
         const bool zero = (shortcuts & SHORTCUT_EXACT) && ncand == 1 && exact && hap_plain && !((rflags >> 1) & 1);
-        // ---- "ungapped": the read differs from the haplotype in one or two bases on the one candidate diagonal, which is
-        // also the mapping position, and NO other path of the band can be cheaper than paying those mismatches.  Then
-        // the single DP of the pair returns U = sum of the mismatching bases' qualities (align.c cost model: a mismatch costs
-        // qual[y], opening a gap at haplotype position x costs go[x] (+2 for an insertion), nothing is negative) and is not
-        // launched.  Every alternative path is bounded from below with one fact: where 7-mer i of the read equals the
-        // haplotype's 7-mer at d*+i and that 7-mer occurs ONCE in the haplotype, the read has a mismatch in [i, i+7) on every
-        // other diagonal; n such k-mer starts inside an interval give ceil(n/7) disjoint windows, each worth >= the read's
-        // smallest quality m.  With W(a,b) = ceil(#unique-matching starts in [a, b-6) / 7), G = smallest gap-open penalty
-        // of the slice, p_j / q_j the mismatches, Q_j / R_j the suffix / prefix sums of q:
-        //   two or more gap openings                          2G >= U
-        //   another diagonal, no gap                          m W(0,L) >= U
-        //   on d* up to a gap before p_j, then elsewhere      G + m W(p_j+8, L) >= Q_j      (an insertion moves <= 8 bases on)
-        //   elsewhere, one gap, on d* from after p_j          G + m W(0, p_j-7) >= R_j
-        //   elsewhere, one gap, elsewhere again               G + m min(W(0,h), W(h+15,L)) >= U,  h = (L-15)/2
-        // (needs d* >= 8 so that the band is d*-8 .. d*+7; haplotype without N, read of plain A/C/G/T: equal codes = equal bytes)
+        // ---- "ungapped": the read differs from the haplotype in 1..UNG_KMAX bases on the one candidate diagonal d*, which is also
+        // the mapping position, and NO other path of the band can be cheaper than paying those mismatches.  Then the single DP
+        // of the pair returns U = sum of the mismatching bases' qualities and is not launched.  Cost model (align.c:314-335,
+        // 466-484): a mismatch costs qual[y]; a deletion of l bases go[x] + 3 (l - 1); an insertion of l bases go[x] + 2 + 5 (l - 1);
+        // nothing is negative; the band is d*-8 .. d*+7 (needs d* >= 8), the path may start and end on any diagonal.
+        // The one fact every bound uses: where 7-mer i of the read equals the haplotype's 7-mer at d*+i and that 7-mer occurs
+        // ONCE in the haplotype, the read has a mismatch in [i, i+7) on every other diagonal; n such starts inside a stretch the
+        // path spends on ONE other diagonal give ceil(n/7) disjoint windows, together worth V(.) (each holds a mismatching base,
+        // a base costs >= the read's smallest quality m, all but n_low of its bases cost >= 20).  A gap opening costs >= G, the
+        // smallest gap-open penalty of the slice, and an insertion skips read bases: <= 8 when it leaves or rejoins d*, <= 15
+        // otherwise, so a gap in the middle of a stretch spoils <= 21 starts = 3 windows.
+        // A path is a chain of stretches ON d*, which pay exactly the mismatches p_j inside them, and EXCURSIONS, each of which
+        // dodges a run of mismatches j..j'.  If every possible excursion costs at least the qualities it dodges, and a path that
+        // never touches d* costs >= U, no path beats U.  Windows are counted per stretch between two mismatches (they cannot
+        // overlap across a mismatching base): W(a,b) = sum over those stretches of ceil(#unique-matching starts inside [a,b) / 7).
+        // A FURTHER gap inside an excursion spoils the windows it cuts or skips, at a price: a deletion or a one-base insertion
+        // one window for >= G, an insertion of 2..8 two for >= G+7, of 9..15 three for >= G+42; so spoiling windows costs
+        // >= v'' = min((G+7)/2, (G+42)/3) apiece, and windows are worth phi(n) = V(n) with its slopes capped at v''
+        // (= V itself once G >= 33):
+        //   never on d*                                     phi(W(0, L-6)) >= U
+        //   elsewhere, then on d* from after p_j            G + phi(W(0, p_j-13)) >= q_1 + .. + q_j
+        //   on d* up to a gap before p_j, then elsewhere    G + phi(W(p_j+8, L-6)) >= q_j + .. + q_k
+        //   leaves d* before p_j, rejoins after p_j'        two gaps = an insertion and a deletion of l bases each:
+        //                                                   2G + 8l - 6 + windows, i.e. >= 2G + min(2 + phi(W), 10 + phi(W-1));
+        //                                                   more gaps: >= 2G + max(G, phi(W-2));  W = W(p_j+1, p_j'-6);
+        //                                                   all >= q_j + .. + q_j'
+        // (haplotype without N, read of plain A/C/G/T: equal codes = equal bytes.)
         int ung_score = -1;
+        int why = 0;                                     // (PLAT_SEED_DEBUG=512: why the pair reached the DP; counted below)
         {
             const int mq = (rflags >> 3) & 31;
             const bool cand = (shortcuts & SHORTCUT_UNGAPPED) && ncand == 1 && orig_in && provenA && !exact && hap_plain && s_scal[0] == 0 &&
@@ -902,48 +916,105 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
             int k = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) k += __popcll(missA[c]);
-            if (cand && k >= 1 && k <= 2) {
-                auto nth = [&](int which) -> int {           // position of the first / last mismatch
-                    int pos = -1;
+            const bool part = cand && k >= 1 && k <= UNG_KMAX;
+            why = !(ncand == 1) ? 1 : !orig_in ? 2 : !provenA ? 3 : exact ? 4 : k > UNG_KMAX ? 5 : !cand ? 8 : 0;
+            int kmw = part ? k : 0;                          // most mismatches any lane of the wave has to look at
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (missA[c]) {
-                            const int lo = 64 * c + (int)__ffsll((long long)missA[c]) - 1, hi = 64 * c + 63 - (int)__clzll((long long)missA[c]);
-                            if (which == 0) { if (pos < 0) pos = lo; } else pos = hi;
-                        }
-                    }
-                    return pos;
-                };
-                auto cnt7 = [&](int a, int e) -> int {       // unique-matching k-mer starts in [a, e)
-                    int n = 0;
+            for (int s2 = 32; s2 > 0; s2 >>= 1) kmw = max(kmw, __shfl_xor(kmw, s2));
+            if (kmw > 0) {
+                int cw[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int lo = max(a - 64 * c, 0), hi = min(e - 64 * c, 64);
-                        if (hi > lo) {
-                            const u64 m1 = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-                            n += __popcll(uniqA[c] & m1);
-                        }
-                    }
-                    return n;
+                for (int c = 0; c < 4; ++c) cw[c] = __popcll(uniqA[c]);
+                auto Cpre = [&](int x) -> int {              // unique-matching k-mer starts in [0, x)
+                    x = min(max(x, 0), 256);
+                    const int wi = x >> 6, sh = x & 63;
+                    const u64 wsel = wi == 0 ? uniqA[0] : wi == 1 ? uniqA[1] : wi == 2 ? uniqA[2] : wi == 3 ? uniqA[3] : 0ull;
+                    const int below = (wi > 0 ? cw[0] : 0) + (wi > 1 ? cw[1] : 0) + (wi > 2 ? cw[2] : 0) + (wi > 3 ? cw[3] : 0);
+                    return below + __popcll(wsel & ((1ull << sh) - 1ull));
                 };
-                auto W = [&](int a, int bnd) -> int { return (cnt7(max(a, 0), bnd - 6) + 6) / 7; };
-                // what n disjoint windows are worth at least: each holds a mismatching base, a base costs its quality, every
-                // quality is >= mq and all but nlow of the read's bases are >= LOWQ
+                auto Wof = [&](int n) -> int { return (max(n, 0) + 6) / 7; };
+                // n_low: how many of the read's bases may cost less than LOWQ (n disjoint windows are worth V(n) = mq min(n, n_low) + LOWQ max(n - n_low, 0))
                 const int nlow = (shortcuts & SHORTCUT_NLOW) ? (int)(ri.aux & 0xFFFFu) : 0x7FFF;
-                auto V = [&](int n) -> int { return max(mq * n, (int)LOWQ * max(n - nlow, 0) + mq * min(n, nlow)); };
-                const int p1 = nth(0), p2 = nth(1);          // k == 1: p1 == p2
-                const uint8_t* rq = b.read_qual + b.read_off[rb + rl];
-                const int q1 = rq[p1], q2 = k == 2 ? rq[p2] : 0;
-                const int U = q1 + q2;
+                // the mismatches in read order (lanes with fewer than kmw repeat their last one with quality 0: its tests repeat too)
+                const uint8_t* rq = b.read_qual + b.read_off[rb + (valid ? rl : 0)];
+                u64 mm[4] = {missA[0], missA[1], missA[2], missA[3]};
+                int pp[UNG_KMAX], qq[UNG_KMAX];
+#pragma unroll
+                for (int j = 0; j < UNG_KMAX; ++j) {
+                    pp[j] = j ? pp[j - 1] : 0; qq[j] = 0;
+                    if (j < kmw) {                           // wave-uniform
+                        int pos = -1;
+#pragma unroll
+                        for (int c = 3; c >= 0; --c) if (mm[c]) pos = 64 * c + (int)__ffsll((long long)mm[c]) - 1;
+                        if (part && pos >= 0) { pp[j] = pos; qq[j] = rq[pos]; }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (pos >= 0 && (pos >> 6) == c) mm[c] &= mm[c] - 1ull;
+                    }
+                }
+                int U = 0;
+#pragma unroll
+                for (int j = 0; j < UNG_KMAX; ++j) U += qq[j];
                 const int st = cidx - 8;
                 int G = 127;
-                for (int t = st >> 6; t <= (st + L + 14) >> 6; ++t) G = min(G, (int)s_gmin[t]);
-                const int hh = (L - 15) / 2;
-                bool ok = U <= 2 * G && V(W(0, L)) >= U && G + V(min(W(0, hh), W(hh + 15, L))) >= U;
-                // first mismatch: Q = U, R = q1; last mismatch (k == 2): Q = q2, R = U
-                ok = ok && G + V(W(p1 + 8, L)) >= U && G + V(W(0, p1 - 7)) >= q1;
-                if (k == 2) ok = ok && G + V(W(p2 + 8, L)) >= q2 && G + V(W(0, p2 - 7)) >= U;
-                if (ok) ung_score = U;
+                if (part) for (int t = st >> 6; t <= (st + L + 14) >> 6; ++t) G = min(G, (int)s_gmin[t]);
+                // everything below in units of 1/6 (v'' has a half and a third in it)
+                const int v6 = min(3 * (G + 7), 2 * (G + 42));
+                const int c_lo = min(6 * mq, v6), c_hi = min(6 * max(mq, (int)LOWQ), v6);
+                auto phi6 = [&](int n) -> int { n = max(n, 0); return c_lo * min(n, nlow) + c_hi * max(n - nlow, 0); };
+                // unique-matching starts before p_j - 13, p_j - 6, p_j + 1, p_j + 8
+                int cm13[UNG_KMAX], cm6[UNG_KMAX], cp1[UNG_KMAX], cp8[UNG_KMAX];
+#pragma unroll
+                for (int j = 0; j < UNG_KMAX; ++j) {
+                    if (j < kmw) { cm13[j] = Cpre(pp[j] - 13); cm6[j] = Cpre(pp[j] - 6); cp1[j] = Cpre(pp[j] + 1); cp8[j] = Cpre(pp[j] + 8); }
+                    else { cm13[j] = cm13[j - (j > 0)]; cm6[j] = cm6[j - (j > 0)]; cp1[j] = cp1[j - (j > 0)]; cp8[j] = cp8[j - (j > 0)]; }
+                }
+                const int Ctot = Cpre(L - 6);
+                int Iw[UNG_KMAX];                            // windows between mismatch j and the next
+#pragma unroll
+                for (int j = 0; j + 1 < UNG_KMAX; ++j) Iw[j] = Wof(cm6[j + 1] - cp1[j]);
+                Iw[UNG_KMAX - 1] = 0;
+                int bad = 0;
+                {   // never on d*
+                    int Wall = Wof(cm6[0]) + Wof(Ctot - cp1[UNG_KMAX - 1]);
+#pragma unroll
+                    for (int j = 0; j + 1 < UNG_KMAX; ++j) Wall += Iw[j];
+                    if (phi6(Wall) < 6 * U) bad = 10;
+                }
+                int Rs = 0, Qs = U;
+#pragma unroll
+                for (int j = 0; j < UNG_KMAX; ++j) {
+                    if (j < kmw) {
+                        Rs += qq[j];
+                        {   // elsewhere, then on d* from after p_j: windows before p_j - 13
+                            int Wp = Wof(min(cm6[0], cm13[j]));
+#pragma unroll
+                            for (int a2 = 0; a2 < j; ++a2) Wp += Wof(min(cm6[a2 + 1], cm13[j]) - cp1[a2]);
+                            if (!bad && 6 * (G - Rs) + phi6(Wp) < 0) bad = 11;
+                        }
+                        {   // on d* up to a gap before p_j, then elsewhere: windows from p_j + 8 on
+                            int Ws = Wof(Ctot - max(cp1[UNG_KMAX - 1], cp8[j]));
+#pragma unroll
+                            for (int a2 = j; a2 + 1 < UNG_KMAX; ++a2) Ws += Wof(cm6[a2 + 1] - max(cp1[a2], cp8[j]));
+                            if (!bad && 6 * (G - Qs) + phi6(Ws) < 0) bad = 12;
+                        }
+                        Qs -= qq[j];
+                        int T = qq[j], Wm = 0;
+                        if (!bad && 2 * G + 2 < T) bad = 13;                          // an excursion around p_j alone
+#pragma unroll
+                        for (int j2 = j + 1; j2 < UNG_KMAX; ++j2) {
+                            if (j2 < kmw) {
+                                T += qq[j2];
+                                Wm += Iw[j2 - 1];
+                                const int slack = 6 * (2 * G - T);
+                                const bool two = slack + 12 + phi6(Wm) >= 0 && slack + 60 + phi6(Wm - 1) >= 0;
+                                const bool more = slack + max(6 * G, phi6(Wm - 2)) >= 0;
+                                if (!bad && !(two && more)) bad = 14;
+                            }
+                        }
+                    }
+                }
+                if (part && !bad) ung_score = U;
+                else if (part) why = bad;
             }
         }
         const bool ungapped = ung_score >= 0;
@@ -984,6 +1055,12 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 jobs[pidx] = Job{ri.col, hq, cidx, L};
                 pairs[pidx] = PairRec{base, idx0, (int16_t)ncand, (int16_t)(orig_in ? 0 : ncand), mapq, {0, 0, 0}};
                 prim = true;
+            }
+        }
+        if (shortcuts & 512) {                              // measurement only
+            for (int r = 0; r < 16; ++r) {
+                const unsigned long long m = __ballot(prim && why == r);
+                if (m && lane == 0) atomicAdd((unsigned long long*)&cnt[32 + r], (unsigned long long)__popcll(m));
             }
         }
         {   // the wave's live job slots join the dense list: primary slots, then the extra ones, room reserved with one atomic
@@ -1566,8 +1643,13 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
                            (const int32_t*)ctx->job_score.ptr, npairs, cnt);
     PLAT_HIP(ctx, hipGetLastError());
     if (out_stats || ctx->profile) {
-        PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));
+        PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, 64 * sizeof(long long), hipMemcpyDeviceToHost, st));
         PLAT_HIP(ctx, hipStreamSynchronize(st));
+        if (getenv("PLAT_SEED_DEBUG") && (atoi(getenv("PLAT_SEED_DEBUG")) & 512)) {
+            fprintf(stderr, "k_seed, pairs that left a DP job, by reason:");
+            for (int r = 0; r < 16; ++r) fprintf(stderr, " %lld", (long long)hb[32 + r]);
+            fprintf(stderr, "\n");
+        }
         ctx->ev_valid_align = ctx->profile;
         ctx->prof_dp_jobs = hb[CNT_NJOBS_RUN];
         ctx->prof_dp_bytes = hb[CNT_CELLS_RUN] / 4 + 34 * hb[CNT_NJOBS_RUN];     // sum(4*len2 + 34); cells = 16*len2

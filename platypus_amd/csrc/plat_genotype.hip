@@ -2,15 +2,33 @@
 // (cgenotype.pyx:131-189, cpopulation.pyx:283-309) on the device.
 //
 // One quarter-wave (16 lanes) per (window, individual): most windows have 3..10 genotypes, a full wave per unit left
-// three quarters of the fp64 lanes idle.  Lane g owns genotype g (looping when G > 16) and walks the
-// individual's reads IN INDEX ORDER in fp64 (no FMA contraction: built with -ffp-contract=off), so the
-// sums are the reference's sums.  Only the rarely taken branch log(0.5*(exp(l1)+exp(l2))) and the
-// final exp() rescale go through the device libm instead of glibc (difference <= a few ulp).
+// three quarters of the fp64 lanes idle.  Lane g owns genotype g (looping when G > 16) and adds the terms of the
+// individual's reads IN INDEX ORDER in fp64 (no FMA contraction: built with -ffp-contract=off), so the sums are the
+// reference's sums.  The order of the ADDITIONS is fixed, the order in which the terms are COMPUTED is not: the rarely
+// taken term log(0.5*(exp(l1)+exp(l2))) (a few per cent of the (genotype, read) pairs, but with 64 lanes some lane takes
+// it at almost every read, and a wave pays for a branch any of its lanes takes) is queued in LDS per block of 8 reads
+// and evaluated by all lanes of the wave together, before the block's additions.  Only that term and the final exp()
+// rescale go through the device libm instead of glibc (difference <= a few ulp).
 #include "plat_internal.hpp"
 
 namespace plat {
 
 constexpr int GENO_GROUP = 16;       // lanes per (window, individual) unit
+
+constexpr int GENO_BLOCK = 8;        // reads per block of additions
+
+// Exclusive prefix sum over the wave of a per-lane count <= 15, and the wave's total (ballot per bit + mbcnt).
+__device__ __forceinline__ int geno_wave_prefix(int cnt, int& total) {
+    int pre = 0;
+    total = 0;
+#pragma unroll
+    for (int bit = 0; bit < 4; ++bit) {
+        const unsigned long long m = __ballot((cnt >> bit) & 1);
+        pre += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) << bit;
+        total += __popcll(m) << bit;
+    }
+    return pre;
+}
 
 __global__ void __launch_bounds__(64)
 k_genotype(plat_window_batch b, int n_ind, long long n_units, const int32_t* __restrict__ seg_read_begin,
@@ -18,16 +36,16 @@ k_genotype(plat_window_batch b, int n_ind, long long n_units, const int32_t* __r
            const int64_t* __restrict__ gl_off, double* __restrict__ out_gl, double* __restrict__ out_logl,
            double* __restrict__ out_gof)
 {
+    __shared__ double s_q1[64 * GENO_BLOCK], s_q2[64 * GENO_BLOCK];    // queued (l1, l2); s_q1 takes the results
     const long long unit = (long long)blockIdx.x * (64 / GENO_GROUP) + threadIdx.x / GENO_GROUP;
-    if (unit >= n_units) return;
-    const int w = (int)(unit / n_ind), ind = (int)(unit % n_ind);
+    const bool live = unit < n_units;                                    // (the wave's queue needs every lane to stay)
+    const int w = live ? (int)(unit / n_ind) : 0, ind = live ? (int)(unit % n_ind) : 0;
     const int lane = threadIdx.x % GENO_GROUP;
-    const int H = b.win_hap_begin[w + 1] - b.win_hap_begin[w];
+    const int H = live ? b.win_hap_begin[w + 1] - b.win_hap_begin[w] : 0;
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
     const int G = H * (H + 1) / 2;
-    if (G == 0) return;
     const long long seg = (long long)w * n_ind + ind;
-    const int s0 = seg_read_begin[seg] - rb, s1 = seg_read_begin[seg + 1] - rb;
+    const int s0 = seg_read_begin[seg] - rb, s1 = live ? seg_read_begin[seg + 1] - rb : s0;
     const int nGood = seg_n_good[seg];
     const double* ll = loglik + b.pair_off[w];
     const long long gbase = gl_off[w];
@@ -35,39 +53,59 @@ k_genotype(plat_window_batch b, int n_ind, long long n_units, const int32_t* __r
     const double logHalf = -0.69314718055994529;    // cgenotype.pyx:28
 
     double mymax = -1e7;                            // cpopulation.pyx:288
-    for (int g0 = 0; g0 < G; g0 += GENO_GROUP) {
+    int Gmax = G;                                   // rounds of 16 genotypes: as many as the unit of the wave with most
+    for (int s = 32; s >= GENO_GROUP; s >>= 1) Gmax = max(Gmax, __shfl_xor(Gmax, s));
+    for (int g0 = 0; g0 < Gmax; g0 += GENO_GROUP) {
         const int g = g0 + lane;
-        if (g < G) {
-            // genotype g -> (a, b), a <= b, in the order of cgenotype.pyx:212-216
-            int a = 0, rem = g;
-            while (rem >= H - a) { rem -= H - a; ++a; }
-            const int bb = a + rem;
+        const bool mine = g < G;
+        // genotype g -> (a, b), a <= b, in the order of cgenotype.pyx:212-216
+        int a = 0, rem = mine ? g : 0;
+        while (rem >= H - a && a < H) { rem -= H - a; ++a; }
+        const int bb = a + rem;
+        const bool summing = mine && nGood != 0;    // cpopulation.pyx:293
+        const double* arr1 = ll + (long long)a * R;
+        const double* arr2 = ll + (long long)bb * R;
+        double like = 0.0, gsum = 0.0;
+        // reads in index order (cgenotype.pyx:151-180), a block of 8 at a time: loads issued together, the slow terms of the
+        // whole wave evaluated together, then the additions in order
+        for (int r0 = s0; __any(summing && r0 < s1); r0 += GENO_BLOCK) {
+            double v1[GENO_BLOCK], v2[GENO_BLOCK];
+            unsigned slow = 0;
+#pragma unroll
+            for (int k = 0; k < GENO_BLOCK; ++k) {
+                const bool in = summing && r0 + k < s1;
+                v1[k] = in ? arr1[r0 + k] : 0.0; v2[k] = in ? arr2[r0 + k] : 0.0;
+                const double d = fabs(v1[k] - v2[k]);
+                if (in && a != bb && d < 3 && d > 1e-3) slow |= 1u << k;
+            }
+            int total;
+            const int pre = geno_wave_prefix(__popc(slow), total);
+            if (total > 0) {                        // wave-uniform
+                int j = pre;
+#pragma unroll
+                for (int k = 0; k < GENO_BLOCK; ++k)
+                    if (slow >> k & 1) { s_q1[j] = v1[k]; s_q2[j] = v2[k]; ++j; }
+                __syncthreads();
+                for (int i = threadIdx.x; i < total; i += 64) s_q1[i] = log(0.5 * (exp(s_q1[i]) + exp(s_q2[i])));
+                __syncthreads();
+            }
+            int j = pre;
+#pragma unroll
+            for (int k = 0; k < GENO_BLOCK; ++k) {
+                if (!summing || r0 + k >= s1) continue;
+                const double l1 = v1[k], l2 = v2[k];
+                const double ll1 = log10E * l1, ll2 = log10E * l2;
+                gsum += (ll1 > ll2 ? ll1 : ll2);
+                if (a == bb) like += l1;
+                else if (fabs(l1 - l2) >= 3) like += (logHalf + (l1 > l2 ? l1 : l2));
+                else if (fabs(l1 - l2) <= 1e-3) like += l1;
+                else like += s_q1[j++];
+            }
+            if (total > 0) __syncthreads();         // the queue is rewritten by the next block
+        }
+        if (mine) {
             double L = 1.0, gof = 0.0;
-            if (nGood != 0) {                       // cpopulation.pyx:293
-                const double* arr1 = ll + (long long)a * R;
-                const double* arr2 = ll + (long long)bb * R;
-                double like = 0.0, gsum = 0.0;
-                // reads in index order (cgenotype.pyx:151-180); the loads of 8 reads are issued together so that the
-                // serial fp64 chain does not wait for a memory round trip per read
-                for (int r0 = s0; r0 < s1; r0 += 8) {
-                    double v1[8], v2[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int r = min(r0 + k, s1 - 1);
-                        v1[k] = arr1[r]; v2[k] = arr2[r];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if (r0 + k >= s1) break;
-                        const double l1 = v1[k], l2 = v2[k];
-                        const double ll1 = log10E * l1, ll2 = log10E * l2;
-                        gsum += (ll1 > ll2 ? ll1 : ll2);
-                        if (a == bb) like += l1;
-                        else if (fabs(l1 - l2) >= 3) like += (logHalf + (l1 > l2 ? l1 : l2));
-                        else if (fabs(l1 - l2) <= 1e-3) like += l1;
-                        else like += log(0.5 * (exp(l1) + exp(l2)));
-                    }
-                }
+            if (nGood != 0) {
                 L = like;
                 gof = (-10 * gsum) / nGood;         // cgenotype.pyx:182-183
                 if (L > mymax) mymax = L;

@@ -511,10 +511,12 @@ def test_dp_add_flavours_agree_with_oracle(eng, oracle):
     assert sc.max() > 1000                                                   # costs far beyond anything config 2 produces
 
 
-def _adversarial_batch(seed, n_windows=260):
+def _adversarial_batch(seed, n_windows=260, gapped=False):
     """Windows built to stress k_seed's ungapped-alignment proof: references with homopolymers and tandem repeats (cheap gaps,
     non-unique k-mers) and N runs, reads of 36..250 bp with 0..3 substitutions anywhere -- first and last bases included --, read
-    N's, low-quality tails, quality minima down to 0, haplotypes differing by SNPs next to repeats."""
+    N's, low-quality tails, quality minima down to 0, haplotypes differing by SNPs next to repeats.  gapped: a third of the reads
+    also carry a 1..4 base insertion or deletion (often within 20 bases of an end, where the ungapped alignment shows only a
+    few mismatches and a gapped one is cheaper), a third a tight cluster of 2..4 substitutions, and qualities reach 41 more often."""
     from platypus_amd import hostapi as H
     rng = np.random.default_rng(seed)
     B = b"ACGT"
@@ -550,9 +552,26 @@ def _adversarial_batch(seed, n_windows=260):
             for _ in range(int(rng.choice([0, 0, 1, 1, 1, 2, 2, 3]))):
                 p = int(rng.choice([0, 1, 2, L - 1, L - 2, L - 3, int(rng.integers(0, L)), int(rng.integers(0, L))]))
                 seq[p] = B[((B.index(seq[p]) if seq[p] in B else 0) + 1 + int(rng.integers(0, 3))) % 4]
+            if gapped:
+                u = rng.random()
+                if u < 0.35:
+                    n = int(rng.integers(1, 5))
+                    p = int(rng.choice([int(rng.integers(1, 20)), L - int(rng.integers(2, 20)), int(rng.integers(1, L - 1))]))
+                    if rng.random() < 0.5:                       # bases inserted into the read, its tail drops off
+                        seq[p:p] = rnd(n) if rng.random() < 0.5 else bytes(seq[max(0, p - 1):p] or b"A") * n
+                        del seq[L:]
+                    else:                                        # bases deleted from the read, the source fills the tail
+                        del seq[p:p + n]
+                        seq += src[off + L:off + L + (L - len(seq))]
+                        seq += rnd(L - len(seq))
+                elif u < 0.7:
+                    c0 = int(rng.integers(0, L - 15)); span = int(rng.integers(3, 15))
+                    for p in sorted(set(int(x) for x in rng.integers(c0, c0 + span, int(rng.integers(2, 5))))):
+                        seq[p] = B[((B.index(seq[p]) if seq[p] in B else 0) + 1 + int(rng.integers(0, 3))) % 4]
+                assert len(seq) == L
             if rng.random() < 0.05:
                 seq[int(rng.integers(0, L))] = ord("N")          # read N: costs its quality against any base
-            q = np.clip(rng.normal(33, 6, L), 1, 60).astype(np.uint8)
+            q = np.clip(rng.normal(36 if gapped else 33, 6, L), 1, 41 if gapped else 60).astype(np.uint8)
             mode = rng.random()
             if mode < 0.2:
                 q[L - int(rng.integers(1, 30)):] = rng.integers(1, 12, 1)[0]
@@ -574,7 +593,8 @@ def test_ungapped_shortcut_equals_the_dp_everywhere(eng, oracle):
     import os
     from platypus_amd import synth
     used = 0
-    for hb in (_adversarial_batch(1), _adversarial_batch(2), synth.config2(1500, seed=9), synth.config2_hard(1200, seed=11)):
+    for hb in (_adversarial_batch(1), _adversarial_batch(2), _adversarial_batch(3, gapped=True), _adversarial_batch(4, gapped=True),
+               synth.config2(1500, seed=9), synth.config2_hard(1200, seed=11)):
         res = {}
         # "0": both shortcuts; "1": the ungapped proof off; "all": the exact-match shortcut off too (every reference DP is run);
         # "nolow": the proof values its unique windows by the smallest quality only (no count of low-quality bases)
@@ -601,7 +621,7 @@ def test_ungapped_shortcut_equals_the_dp_everywhere(eng, oracle):
         assert res["all"][3] == res["0"][3] and res["all"][2] >= 0.98 * res["all"][3]
         used += res["1"][2] - res["0"][2]
     assert used > 10000
-    hb = _adversarial_batch(3, 40)
+    hb = _adversarial_batch(3, 40, gapped=True)
     db = eng.upload(hb)
     eng.align(db, want_stats=False)
     eng.synchronize()

@@ -41,7 +41,7 @@ def main():
             name, mk = fixed.pop(0)
             hb = mk()
         else:
-            name, hb = "stress", _adversarial_batch(seed, 200)
+            name, hb = "stress", _adversarial_batch(seed, 200, gapped=bool(seed & 1))
             seed += 1
         r = both(eng, hb)
         diff = int((r["0"][0] != r["1"][0]).sum())
