@@ -900,8 +900,10 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         // >= v'' = min((G+7)/2, (G+42)/3) apiece, and windows are worth phi(n) = V(n) with its slopes capped at v''
         // (= V itself once G >= 33):
         //   never on d*                                     phi(W(0, L-6)) >= U
-        //   elsewhere, then on d* from after p_j            G + phi(W(0, p_j-13)) >= q_1 + .. + q_j
-        //   on d* up to a gap before p_j, then elsewhere    G + phi(W(p_j+8, L-6)) >= q_j + .. + q_k
+        //   elsewhere, then on d* from after p_j            G + min(phi(W), 7 + phi(W-1)) >= q_1 + .. + q_j,  W = W(0, p_j-6): the gap
+        //                                                   that joins d* is a deletion or a one-base insertion, or a longer
+        //                                                   insertion that costs >= 7 more and skips <= 7 more starts
+        //   on d* up to a gap before p_j, then elsewhere    the same with W = W(p_j+1, L-6) and q_j + .. + q_k
         //   leaves d* before p_j, rejoins after p_j'        two gaps = an insertion and a deletion of l bases each:
         //                                                   2G + 8l - 6 + windows, i.e. >= 2G + min(2 + phi(W), 10 + phi(W-1));
         //                                                   more gaps: >= 2G + max(G, phi(W-2));  W = W(p_j+1, p_j'-6);
@@ -961,42 +963,33 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 const int v6 = min(3 * (G + 7), 2 * (G + 42));
                 const int c_lo = min(6 * mq, v6), c_hi = min(6 * max(mq, (int)LOWQ), v6);
                 auto phi6 = [&](int n) -> int { n = max(n, 0); return c_lo * min(n, nlow) + c_hi * max(n - nlow, 0); };
-                // unique-matching starts before p_j - 13, p_j - 6, p_j + 1, p_j + 8
-                int cm13[UNG_KMAX], cm6[UNG_KMAX], cp1[UNG_KMAX], cp8[UNG_KMAX];
+                // unique-matching starts before p_j - 6 and before p_j + 1 (none start in between: those 7-mers hold the mismatch)
+                int cm6[UNG_KMAX], cp1[UNG_KMAX];
 #pragma unroll
                 for (int j = 0; j < UNG_KMAX; ++j) {
-                    if (j < kmw) { cm13[j] = Cpre(pp[j] - 13); cm6[j] = Cpre(pp[j] - 6); cp1[j] = Cpre(pp[j] + 1); cp8[j] = Cpre(pp[j] + 8); }
-                    else { cm13[j] = cm13[j - (j > 0)]; cm6[j] = cm6[j - (j > 0)]; cp1[j] = cp1[j - (j > 0)]; cp8[j] = cp8[j - (j > 0)]; }
+                    if (j < kmw) { cm6[j] = Cpre(pp[j] - 6); cp1[j] = Cpre(pp[j] + 1); }
+                    else { cm6[j] = cm6[j - (j > 0)]; cp1[j] = cp1[j - (j > 0)]; }
                 }
                 const int Ctot = Cpre(L - 6);
                 int Iw[UNG_KMAX];                            // windows between mismatch j and the next
 #pragma unroll
                 for (int j = 0; j + 1 < UNG_KMAX; ++j) Iw[j] = Wof(cm6[j + 1] - cp1[j]);
                 Iw[UNG_KMAX - 1] = 0;
-                int bad = 0;
-                {   // never on d*
-                    int Wall = Wof(cm6[0]) + Wof(Ctot - cp1[UNG_KMAX - 1]);
+                int Wall = Wof(cm6[0]) + Wof(Ctot - cp1[UNG_KMAX - 1]);
 #pragma unroll
-                    for (int j = 0; j + 1 < UNG_KMAX; ++j) Wall += Iw[j];
-                    if (phi6(Wall) < 6 * U) bad = 10;
-                }
-                int Rs = 0, Qs = U;
+                for (int j = 0; j + 1 < UNG_KMAX; ++j) Wall += Iw[j];
+                int bad = phi6(Wall) < 6 * U ? 10 : 0;       // never on d*
+                // an excursion at the head or the tail of the read: its gap next to d* is a deletion or a one-base insertion
+                // (no window lost) or a longer insertion (>= 7 more, one window lost)
+                auto edge = [&](int W, int T) -> bool { return 6 * (G - T) + min(phi6(W), 42 + phi6(W - 1)) >= 0; };
+                int Rs = 0, Qs = U, Wbefore = Wof(cm6[0]);   // windows before mismatch j
 #pragma unroll
                 for (int j = 0; j < UNG_KMAX; ++j) {
                     if (j < kmw) {
                         Rs += qq[j];
-                        {   // elsewhere, then on d* from after p_j: windows before p_j - 13
-                            int Wp = Wof(min(cm6[0], cm13[j]));
-#pragma unroll
-                            for (int a2 = 0; a2 < j; ++a2) Wp += Wof(min(cm6[a2 + 1], cm13[j]) - cp1[a2]);
-                            if (!bad && 6 * (G - Rs) + phi6(Wp) < 0) bad = 11;
-                        }
-                        {   // on d* up to a gap before p_j, then elsewhere: windows from p_j + 8 on
-                            int Ws = Wof(Ctot - max(cp1[UNG_KMAX - 1], cp8[j]));
-#pragma unroll
-                            for (int a2 = j; a2 + 1 < UNG_KMAX; ++a2) Ws += Wof(cm6[a2 + 1] - max(cp1[a2], cp8[j]));
-                            if (!bad && 6 * (G - Qs) + phi6(Ws) < 0) bad = 12;
-                        }
+                        if (!bad && !edge(Wbefore, Rs)) bad = 11;                     // elsewhere, then on d* from after p_j
+                        if (!bad && !edge(Wall - Wbefore, Qs)) bad = 12;              // on d* up to a gap before p_j, then elsewhere
+                        Wbefore += Iw[j];
                         Qs -= qq[j];
                         int T = qq[j], Wm = 0;
                         if (!bad && 2 * G + 2 < T) bad = 13;                          // an excursion around p_j alone
