@@ -12,14 +12,28 @@
 //   * a node keeps the (up to) four successors with the smallest first-occurrence tickets, in ticket order
 //     (assembler.pyx:813-824: a fifth distinct successor is silently dropped);
 //   * bubble starts are visited in allNodes order, which for REF_AND_READ nodes is increasing position.
-// One workgroup assembles one region.  The k-mer hash table -- the structure every k-mer occurrence of every read probes
-// twice -- and the per-node words every AddEdge event updates (first-touch code, weight and colour) live in the workgroup's
-// LDS: ASM_LDS_SLOTS table slots (byte offsets of representative occurrences while the nodes are inserted, dense node ids
-// afterwards) and ASM_LDS_NODES nodes; measured, the kernel was bound by the rate of L2 atomics (nine per event), not by
-// occupancy or probe latency.  A region with more distinct k-mers than ASM_LDS_LIMIT (deep or very divergent data) is redone
-// with table and node words in the workgroup's slice of a global scratch buffer.  The successor lists (one atomicAdd per
-// event) and the per-task path arenas live in that slice too.
+// One workgroup assembles one region; everything an AddEdge event touches lives in the workgroup's LDS (the "LDS path"):
+//   * the k-mer hash table (ASM_LDS_SLOTS slots: byte offsets of representative occurrences while the k-mers are inserted, then
+//     node id << 18 | offset), one word per node for its first touch and one for its colours + the summed weight of its
+//     first-claimed successor slot (ASM_LDS_NODES nodes), and the region's reference bytes (ASM_REF_CACHE);
+//   * phase A inserts the reference's k-mers first, so a k-mer the reference holds is represented by a reference occurrence
+//     and a read's k-mer is compared with its representative in LDS; the reads' bases and qualities are loaded as 256-byte
+//     windows, one aligned dword per lane, and every lane gathers its edge's k+1 bytes from the other lanes (per-lane
+//     unaligned 64-bit loads were bound by the texture addresser); every edge leaves one word (table slot, weight, appended
+//     base) so that phase C neither hashes nor compares: it is a loop over tickets;
+//   * node ids follow the reference (bitmap of representative positions + popcount ranks): reads are sorted by position,
+//     so the few global words an event still updates (successor slots other than a node's first-claimed one) are neighbours
+//     in memory and stay in the L2;
+//   * which node a successor slot leads to is looked up once per slot (phase D), and first tickets -- which only order the
+//     successors of a node that has several -- are collected for those nodes alone in a second pass over the event words.
+// Measured on BASELINE config 3 (2000 tiles, PLAT_ASM_TIMING=1 prints the split): 84 k regions/s with the table in LDS but
+// three global atomics and two hash look-ups per event; 123 k with reference-first insertion + LDS reference + one look-up per
+// event; 141 k with the window loads; 174 k with one global atomic per event; 183 k with ordered ids; 214 k with the
+// first-claimed slot's weight in LDS.  A region with more distinct k-mers than ASM_LDS_LIMIT (deep or very divergent data),
+// k > 31, or a reference / read blob beyond 2^18 bytes is done with table, node words and successor lists in the workgroup's
+// slice of a global scratch buffer (the "global path", the round-1 code).
 #include "plat_internal.hpp"
+#include <type_traits>
 
 namespace plat {
 
@@ -31,7 +45,10 @@ constexpr int ASM_THREADS = 1024;      // threads per workgroup (one workgroup p
 constexpr int ASM_LDS_SLOTS = 16384;   // k-mer table in LDS: 64 KB
 constexpr int ASM_LDS_NODES = 11264;   // per-node first-touch codes and (weight | colour << 30) words in LDS: 2 x 44 KB
 constexpr int ASM_LDS_LIMIT = ASM_LDS_NODES - ASM_THREADS;   // distinct k-mers the LDS path takes (threads in flight may overshoot by one each)
-constexpr int ASM_LDS_BYTES = (ASM_LDS_SLOTS + 2 * ASM_LDS_NODES) * 4;
+constexpr int ASM_REF_CACHE = 7552;    // bytes of the region's reference kept in LDS (k-mers of reads are compared with their representative, which is a
+                                       // reference k-mer whenever the reference holds one: the reference's k-mers are inserted first)
+constexpr int ASM_LDS_BYTES = (ASM_LDS_SLOTS + 2 * ASM_LDS_NODES) * 4 + ASM_REF_CACHE;
+constexpr int ASM_OFF_BITS = 18;       // LDS path: a table slot packs (node id << 18 | byte offset of the representative)
 static_assert(ASM_LDS_NODES < ASM_LDS_SLOTS * 3 / 4, "the table must stay sparse");
 
 struct AsmParams {
@@ -39,6 +56,7 @@ struct AsmParams {
     long long scratch_per_block;       // bytes
     int cap;                           // hash slots per region (power of two)
     int max_pos;                       // max k-mer occurrences per region (dense node capacity)
+    int timing;                        // PLAT_ASM_TIMING: phase timers on
 };
 
 struct AsmNodeE { int end[4]; int w[4]; int n; };   // finalised out-edges
@@ -55,6 +73,7 @@ struct AsmScratch {
     unsigned* succ_t;    // [max_pos][8]
     int* succ_w;         // [max_pos][8]
     int* succ_n;         // [max_pos][8]
+    unsigned long long* succ_cw;   // [max_pos][8]  LDS path: events << 32 | weight of the successor slot
     AsmNodeE* edges;     // [max_pos]
     char* dfs;           // [max_pos]
     int* ref_node;       // [refLen]
@@ -76,6 +95,7 @@ __host__ __device__ inline size_t asm_scratch_bytes(int cap, int max_pos, int ma
     b += asm_align((size_t)max_pos * 4) * 4;
     b += asm_align((size_t)max_pos * ASM_MAX_SUCC);
     b += asm_align((size_t)max_pos * ASM_MAX_SUCC * 4) * 3;
+    b += asm_align((size_t)max_pos * ASM_MAX_SUCC * 8);
     b += asm_align((size_t)max_pos * sizeof(AsmNodeE));
     b += asm_align((size_t)max_pos);
     b += asm_align((size_t)(max_ref + 1) * 4);
@@ -101,6 +121,7 @@ __device__ inline AsmScratch asm_carve(char* p, int cap, int max_pos, int max_re
     s.succ_t = (unsigned*)take((size_t)max_pos * ASM_MAX_SUCC * 4);
     s.succ_w = (int*)take((size_t)max_pos * ASM_MAX_SUCC * 4);
     s.succ_n = (int*)take((size_t)max_pos * ASM_MAX_SUCC * 4);
+    s.succ_cw = (unsigned long long*)take((size_t)max_pos * ASM_MAX_SUCC * 8);
     s.edges = (AsmNodeE*)take((size_t)max_pos * sizeof(AsmNodeE));
     s.dfs = (char*)take((size_t)max_pos);
     s.ref_node = (int*)take((size_t)(max_ref + 1) * 4);
@@ -156,34 +177,6 @@ __device__ inline int asm_slot(AsmScratch& S, const uint8_t* ref, const uint8_t*
     }
 }
 
-// the same with the table in LDS.  Insert phase: tab[s] = byte offset of a representative occurrence (-1 empty), *distinct counts
-// the insertions.  Lookup phase (after the slots were turned into dense node ids): returns the node id.
-__device__ inline void asm_lds_insert(int* tab, const uint8_t* ref, const uint8_t* rseq, int off, int k, int* distinct) {
-    const uint8_t* me = asm_ptr(ref, rseq, off);
-    unsigned s = asm_hash(me, k) & (unsigned)(ASM_LDS_SLOTS - 1);
-    for (;;) {
-        int cur = tab[s];
-        if (cur == -1) {
-            const int old = atomicCAS(&tab[s], -1, off);
-            if (old == -1) { atomicAdd(distinct, 1); return; }
-            cur = old;
-        }
-        if (cur == off || asm_eq(asm_ptr(ref, rseq, cur), me, k)) return;
-        s = (s + 1u) & (unsigned)(ASM_LDS_SLOTS - 1);
-    }
-}
-__device__ inline int asm_lds_node(const int* tab, const int* rep, const uint8_t* ref, const uint8_t* rseq, int off, int k) {
-    const uint8_t* me = asm_ptr(ref, rseq, off);
-    unsigned s = asm_hash(me, k) & (unsigned)(ASM_LDS_SLOTS - 1);
-    for (;;) {
-        const int id = tab[s];
-        if (id < 0) return -1;
-        const int o = rep[id];
-        if (o == off || asm_eq(asm_ptr(ref, rseq, o), me, k)) return id;
-        s = (s + 1u) & (unsigned)(ASM_LDS_SLOTS - 1);
-    }
-}
-
 // does read r pass the k+1-base quality / N filter at position i (assembler.pyx:1362-1373)?  returns min qual or -1
 __device__ __forceinline__ int asm_read_edge_q(const uint8_t* s, const uint8_t* q, int i, int k, int min_qual) {
     int mq = 100000000, hasn = 0;
@@ -201,6 +194,173 @@ __device__ __forceinline__ int asm_read_edge_q(const uint8_t* s, const uint8_t* 
     return (mq >= min_qual && !hasn) ? mq : -1;
 }
 
+// ---- the LDS path works on an edge's k+1 bytes held in registers: KW 64-bit words, zero beyond the k+1 bytes (KW = 2 for k <= 15, the
+// default; 4 for k <= 31)
+template <int KW> struct AsmWords { unsigned long long w[KW]; };
+template <int KW> __device__ __forceinline__ AsmWords<KW> asm_load_words(const uint8_t* p, int nbytes) {
+    AsmWords<KW> W;
+#pragma unroll
+    for (int c = 0; c < KW; ++c) W.w[c] = 8 * c < nbytes ? asm_ld8(p + 8 * c) & asm_tailmask(nbytes - 8 * c) : 0ull;
+    return W;
+}
+// 8 bytes at byte offset o of the reference cached in LDS (aligned 64-bit reads + funnel)
+__device__ __forceinline__ unsigned long long asm_lds8(const unsigned long long* s_ref, int o) {
+    const int wi = o >> 3, sh = (o & 7) * 8;
+    const unsigned long long a = s_ref[wi], b2 = s_ref[wi + 1];
+    return sh ? (a >> sh) | (b2 << (64 - sh)) : a;
+}
+template <int KW> __device__ __forceinline__ AsmWords<KW> asm_load_words_lds(const unsigned long long* s_ref, int o, int nbytes) {
+    AsmWords<KW> W;
+#pragma unroll
+    for (int c = 0; c < KW; ++c) W.w[c] = 8 * c < nbytes ? asm_lds8(s_ref, o + 8 * c) & asm_tailmask(nbytes - 8 * c) : 0ull;
+    return W;
+}
+// The bytes [pos, pos + 8 KW) of a 256-byte window the wave holds one dword per lane (`d` = dword `lane` of the window): 2 KW + 1
+// lane exchanges and a byte alignment instead of unaligned 64-bit loads per lane (which the texture addresser serialises).
+template <int KW> __device__ __forceinline__ AsmWords<KW> asm_gather_words(unsigned d, int pos) {
+    const int d0 = pos >> 2;
+    const unsigned bo = (unsigned)pos & 3u;
+    unsigned x[2 * KW + 1];
+#pragma unroll
+    for (int m = 0; m <= 2 * KW; ++m) x[m] = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (d0 + m), (int)d);
+    AsmWords<KW> W;
+#pragma unroll
+    for (int c = 0; c < KW; ++c) {
+        const unsigned lo = __builtin_amdgcn_alignbyte(x[2 * c + 1], x[2 * c], bo), hi = __builtin_amdgcn_alignbyte(x[2 * c + 2], x[2 * c + 1], bo);
+        W.w[c] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    }
+    return W;
+}
+template <int KW> __device__ __forceinline__ AsmWords<KW> asm_mask_words(AsmWords<KW> W, int nbytes) {
+#pragma unroll
+    for (int c = 0; c < KW; ++c) W.w[c] = 8 * c < nbytes ? W.w[c] & asm_tailmask(nbytes - 8 * c) : 0ull;
+    return W;
+}
+// the first k bytes of the words (the start k-mer), and bytes 1..k (the end k-mer)
+template <int KW> __device__ __forceinline__ AsmWords<KW> asm_kmer_start(const AsmWords<KW>& E, int k) {
+    AsmWords<KW> W;
+#pragma unroll
+    for (int c = 0; c < KW; ++c) W.w[c] = 8 * c < k ? E.w[c] & asm_tailmask(k - 8 * c) : 0ull;
+    return W;
+}
+template <int KW> __device__ __forceinline__ AsmWords<KW> asm_kmer_end(const AsmWords<KW>& E, int k) {
+    AsmWords<KW> W;
+#pragma unroll
+    for (int c = 0; c < KW; ++c) {
+        const unsigned long long v = (E.w[c] >> 8) | (c + 1 < KW ? E.w[c + 1] << 56 : 0ull);
+        W.w[c] = 8 * c < k ? v & asm_tailmask(k - 8 * c) : 0ull;
+    }
+    return W;
+}
+// Table hash of a k-mer: bits 1 and 2 of an ASCII base tell A, C, G, T apart (N falls on G, other bytes wherever: the comparison
+// decides), so four dwords of bases pack into one word without losing anything; one multiplication scatters it.
+template <int KW> __device__ __forceinline__ unsigned asm_hash_words(const AsmWords<KW>& K, int k) {
+    unsigned h = 0u;
+#pragma unroll
+    for (int c = 0; c < KW; c += 2) {
+        const unsigned x0 = (unsigned)K.w[c] & 0x06060606u, x1 = (unsigned)(K.w[c] >> 32) & 0x06060606u;
+        const unsigned x2 = c + 1 < KW ? (unsigned)K.w[c + 1] & 0x06060606u : 0u, x3 = c + 1 < KW ? (unsigned)(K.w[c + 1] >> 32) & 0x06060606u : 0u;
+        const unsigned p = (x0 >> 1) | (x1 << 1) | (x2 << 3) | (x3 << 5);
+        h = (h << 7 | h >> 25) ^ p;
+    }
+    (void)k;
+    h *= 0x9E3779B1u;
+    return h ^ (h >> 15);
+}
+// does the k-mer K equal the k bytes at `off` (reference offset if isref, else read-blob offset)?
+template <int KW> __device__ __forceinline__ bool asm_eq_words(const AsmWords<KW>& K, int k, bool isref, int off, const unsigned long long* s_ref, bool refc,
+                                             const uint8_t* ref, const uint8_t* rseq) {
+    unsigned long long diff = 0ull;
+    if (isref && refc) {
+#pragma unroll
+        for (int c = 0; c < KW; ++c) if (8 * c < k) diff |= (asm_lds8(s_ref, off + 8 * c) & asm_tailmask(k - 8 * c)) ^ K.w[c];
+    } else {
+        const uint8_t* rp = isref ? ref + off : rseq + off;
+#pragma unroll
+        for (int c = 0; c < KW; ++c) if (8 * c < k) diff |= (asm_ld8(rp + 8 * c) & asm_tailmask(k - 8 * c)) ^ K.w[c];
+    }
+    return diff == 0ull;
+}
+// byte k of the words (the base an edge appends to its start k-mer)
+template <int KW> __device__ __forceinline__ unsigned asm_byte_k(const AsmWords<KW>& E, int k) {
+    unsigned long long w = E.w[0];
+#pragma unroll
+    for (int c = 1; c < KW; ++c) w = (k >> 3) == c ? E.w[c] : w;
+    return (unsigned)(w >> (8 * (k & 7))) & 0xFFu;
+}
+// insert phase: tab[s] = byte offset of a representative occurrence (reads: 0x40000000 + blob offset), -1 empty; returns the slot
+template <int KW> __device__ inline int asm_lds_insert_words(int* tab, const AsmWords<KW>& K, int k, int off, const unsigned long long* s_ref, bool refc,
+                                            const uint8_t* ref, const uint8_t* rseq, int* distinct) {
+    unsigned s = asm_hash_words(K, k) & (unsigned)(ASM_LDS_SLOTS - 1);
+    for (;;) {
+        int cur = tab[s];
+        if (cur == -1) {
+            const int old = atomicCAS(&tab[s], -1, off);
+            if (old == -1) { atomicAdd(distinct, 1); return (int)s; }
+            cur = old;
+        }
+        if (cur == off) return (int)s;
+        const bool isref = cur < 0x40000000;
+        if (asm_eq_words(K, k, isref, isref ? cur : cur - 0x40000000, s_ref, refc, ref, rseq)) return (int)s;
+        s = (s + 1u) & (unsigned)(ASM_LDS_SLOTS - 1);
+    }
+}
+// lookup phase: slots hold (node id << ASM_OFF_BITS | offset); ids below n_ref_nodes have their representative in the reference
+template <int KW> __device__ inline int asm_lds_node_words(const int* tab, const AsmWords<KW>& K, int k, int n_ref_nodes, const unsigned long long* s_ref, bool refc,
+                                         const uint8_t* ref, const uint8_t* rseq) {
+    unsigned s = asm_hash_words(K, k) & (unsigned)(ASM_LDS_SLOTS - 1);
+    for (;;) {
+        const int v = tab[s];
+        if (v == -1) return -1;
+        const int id = (int)((unsigned)v >> ASM_OFF_BITS), o = v & ((1 << ASM_OFF_BITS) - 1);
+        if (asm_eq_words(K, k, id < n_ref_nodes, o, s_ref, refc, ref, rseq)) return id;
+        s = (s + 1u) & (unsigned)(ASM_LDS_SLOTS - 1);
+    }
+}
+// asm_read_edge_q on the words of the edge's k+1 bases (S) and qualities (Q): min quality, or -1 when the edge is filtered
+template <int KW> __device__ __forceinline__ int asm_edge_q_words(const AsmWords<KW>& S, const AsmWords<KW>& Q, int k, int min_qual) {
+    const int n = k + 1;
+    unsigned mn = 255u;
+    unsigned long long neg = 0ull, zero = 0ull;
+#pragma unroll
+    for (int c = 0; c < KW; ++c) {
+        if (8 * c < n) {
+            const unsigned long long m = asm_tailmask(n - 8 * c);
+            const unsigned long long q = Q.w[c] | (0x7F7F7F7F7F7F7F7Full & ~m);          // bytes past the edge never lower the minimum
+            neg |= q & 0x8080808080808080ull;
+            const unsigned lo = (unsigned)q, hi = (unsigned)(q >> 32);
+            mn = min(mn, min(min(lo & 0xFFu, (lo >> 8) & 0xFFu), min((lo >> 16) & 0xFFu, lo >> 24)));
+            mn = min(mn, min(min(hi & 0xFFu, (hi >> 8) & 0xFFu), min((hi >> 16) & 0xFFu, hi >> 24)));
+            const unsigned long long x = (S.w[c] ^ 0x4E4E4E4E4E4E4E4Eull) | ~m;            // a zero byte = an 'N' inside the edge
+            zero |= (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+        }
+    }
+    if (neg) return -2;                                   // a quality byte >= 128 (negative as the reference reads it): the caller takes the byte loop
+    return ((int)mn >= min_qual && !zero) ? (int)mn : -1;
+}
+
+// exclusive prefix sum of one value per thread over the workgroup (wave scans by lane shifts, the wave totals through `s_wsum`);
+// every thread gets the total too.  All threads must call it.
+__device__ __forceinline__ int asm_block_exscan(int v, int* s_wsum, int& total) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_wsum[wv] = x;
+    __syncthreads();
+    if (tid < 64) {
+        int t = tid < nw ? s_wsum[tid] : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(t, o); if (lane >= o) t += y; }
+        s_wsum[tid] = t;
+    }
+    __syncthreads();
+    const int before = wv ? s_wsum[wv - 1] : 0;
+    total = s_wsum[nw - 1];
+    __syncthreads();
+    return before + x - v;
+}
+
 // workgroup barrier + agent-scope acquire: the graph lives in global memory and is updated with L2 atomics, so the
 // CU's vector L1 must be invalidated before plain loads re-read it (MI355X_MICROARCH.md, inter-workgroup visibility;
 // here producer and consumer are the same CU but the stale-L1 hazard is the same).
@@ -209,19 +369,25 @@ __device__ __forceinline__ void asm_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
+// measurement only (PLAT_ASM_TIMING=1): 100 MHz ticks the first thread of every workgroup spent up to each phase boundary, summed
+__device__ unsigned long long g_asm_ticks[16];
+#define ASM_TICK(i) do { if (P.timing && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_asm_ticks[i], now_ - tick_); tick_ = now_; } } while (0)
+
 __global__ void __launch_bounds__(ASM_THREADS)
 k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int max_reads, int32_t* var_count,
            int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob,
            int32_t* status)
 {
-    __shared__ int s_n, s_ntasks, s_err, s_cycle, s_k, s_pool, s_distinct, s_lds;
-    __shared__ int s_scan[ASM_THREADS];
-    extern __shared__ int s_tab[];                       // [ASM_LDS_SLOTS] the k-mer table, then the node words
+    __shared__ int s_n, s_ntasks, s_err, s_cycle, s_k, s_pool, s_distinct, s_lds, s_nrefnodes, s_nreadnodes;
+    extern __shared__ __attribute__((aligned(16))) int s_tab[];  // [ASM_LDS_SLOTS] the k-mer table, then the node words, then the reference
     unsigned* s_first = (unsigned*)(s_tab + ASM_LDS_SLOTS);      // [ASM_LDS_NODES] min touch code (2*ticket + isEnd)
     unsigned* s_wc = s_first + ASM_LDS_NODES;                    // [ASM_LDS_NODES] weight | colour << 30
+    unsigned long long* s_ref = (unsigned long long*)(s_wc + ASM_LDS_NODES);   // [ASM_REF_CACHE / 8] the region's reference bytes
+    __shared__ int s_wsum[64];
     const int tid = threadIdx.x, nthr = blockDim.x;
     AsmScratch S = asm_carve(scratch + (size_t)blockIdx.x * P.scratch_per_block, P.cap, P.max_pos, max_ref, max_reads);
     const int capmask = P.cap - 1;
+    unsigned long long tick_ = P.timing ? wall_clock64() : 0ull;
 
     for (int g = blockIdx.x; g < b.n_regions; g += gridDim.x) {
         const uint8_t* ref = b.ref_seq + b.ref_off[g];
@@ -232,6 +398,10 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
         const uint8_t* rseq = b.read_seq + rblob0;        // region-relative read blob
         const uint8_t* rqual = b.read_qual + rblob0;
         if (tid == 0) { s_err = 0; s_k = P.kmer; s_cycle = 0; }
+        const bool refc = refLen + 24 <= ASM_REF_CACHE;   // the reference fits the LDS cache (with the slack 8-byte reads need)
+        if (refc)
+            for (int i = tid; 8 * i < refLen + 16; i += nthr) s_ref[i] = asm_ld8(ref + 8 * i);
+        const long long blobLen = nR > 0 ? b.read_off[rb + nR] - rblob0 : 0;
         asm_sync();
 
         for (;;) {   // (re)build with the current k (assembler.pyx:1453-1469: k += 5 while cycles, noCycles only)
@@ -247,16 +417,9 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     const int L = (int)(b.read_off[rb + r + 1] - b.read_off[rb + r]);
                     acc += L - k - 1 > 0 ? L - k - 1 : 0;
                 }
-                s_scan[tid] = acc;
-                __syncthreads();
-                if (tid == 0) {
-                    int run = 0;
-                    for (int t = 0; t < nthr; ++t) { const int v = s_scan[t]; s_scan[t] = run; run += v; }
-                    S.read_base[nR] = run;
-                    s_n = 0; s_ntasks = 0; s_pool = 0;
-                }
-                __syncthreads();
-                acc = s_scan[tid];
+                int total;
+                acc = asm_block_exscan(acc, s_wsum, total);
+                if (tid == 0) { S.read_base[nR] = total; s_n = 0; s_ntasks = 0; s_pool = 0; }
                 for (int r = r0; r < r1; ++r) {
                     S.read_base[r] = acc;
                     const int L = (int)(b.read_off[rb + r + 1] - b.read_off[rb + r]);
@@ -264,6 +427,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 }
             }
             asm_sync();
+            ASM_TICK(0);
             const int nReadE = S.read_base[nR];
             const int nEv = nRefE + nReadE;
             if ((long long)nEv + 2ll * (nR + 1) > (long long)P.max_pos) {                       // distinct k-mers <= occurrences
@@ -287,8 +451,49 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     }
                 }
             };
+            const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+            // LDS path: the edges of the reads, one read per wave at a time.  A window of 256 bytes of the read's bases and one of its
+            // qualities are loaded one aligned dword per lane; the lanes then take the window's edges in rounds of 64, each gathering
+            // its k+1 bytes from the other lanes.  stage1(i, ro, E, w) -> tag >= 0 for every valid edge; stage2(ticket offset, ro + i,
+            // E, w, tag, tag of the next edge or -1) after the wave has exchanged tags; skipped(ticket offset) for a filtered edge.
+            auto read_pass = [&](auto KWc, auto&& stage1, auto&& stage2, auto&& skipped, auto&& stop) {
+                constexpr int KW = decltype(KWc)::value;
+                constexpr int WIN = 4 * (64 - 2 * KW) - 3;     // edges per window: the last one still finds its 2 KW + 1 dwords in lanes <= 63
+                for (int r = wv; r < nR; r += nwv) {
+                    const int base = S.read_base[r], cnt = S.read_base[r + 1] - base;
+                    const int ro = (int)(b.read_off[rb + r] - rblob0);
+                    for (int c0 = 0; c0 < cnt; c0 += WIN) {
+                        if (stop()) return;
+                        const int nE = min(WIN, cnt - c0);
+                        const uintptr_t pS = (uintptr_t)(rseq + ro + c0), pQ = (uintptr_t)(rqual + ro + c0);
+                        const int sS = (int)(pS & 3), sQ = (int)(pQ & 3);
+                        // (lanes past the window's last needed byte load nothing: the blobs' slack is a few bytes, not a window)
+                        const unsigned dS = 4 * lane < sS + nE + k + 1 ? *(const unsigned*)((pS & ~(uintptr_t)3) + 4 * lane) : 0u;
+                        const unsigned dQ = 4 * lane < sQ + nE + k + 1 ? *(const unsigned*)((pQ & ~(uintptr_t)3) + 4 * lane) : 0u;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (64 * u < nE) {                              // wave-uniform
+                                const int j = 64 * u + lane, i = c0 + j;
+                                const AsmWords<KW> E = asm_mask_words(asm_gather_words<KW>(dS, j + sS), k + 1);
+                                const AsmWords<KW> Q = asm_mask_words(asm_gather_words<KW>(dQ, j + sQ), k + 1);
+                                int w = -1, tag = -1;
+                                if (j < nE) {
+                                    w = asm_edge_q_words(E, Q, k, P.min_qual);
+                                    if (w == -2) w = asm_read_edge_q(rseq + ro, rqual + ro, i, k, P.min_qual);
+                                    if (w >= 0) tag = stage1(i, ro, E, w);
+                                }
+                                int ntag = __shfl_down(tag, 1);
+                                if (lane == 63) ntag = -1;
+                                if (w >= 0) stage2(base + i, ro + i, E, w, tag, ntag);
+                                else if (j < nE) skipped(base + i);
+                            }
+                        }
+                    }
+                }
+            };
             // ---- phase A: insert every k-mer that takes part in a (valid) edge; LDS table first, the global one if it overflows
-            if (tid == 0) s_lds = 1;
+            // (or if k, the reference or the reads' bytes are beyond what the LDS path packs into its words)
+            if (tid == 0) s_lds = (k <= 31 && nRefE < ASM_LDS_LIMIT && refLen < (1 << ASM_OFF_BITS) && blobLen < (1ll << ASM_OFF_BITS)) ? 1 : 0;
             __syncthreads();
             bool failed = false;
             for (;;) {
@@ -299,18 +504,52 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     for (int i = tid; i < P.cap; i += nthr) S.key[i] = -1;
                 }
                 asm_sync();
-                for_each_event([&](int e, int so, int eo, int col, int w) -> bool {
-                    (void)w;
-                    if (lds) {
-                        if (*(volatile int*)&s_distinct > ASM_LDS_LIMIT) return false;
-                        asm_lds_insert(s_tab, ref, rseq, so, k, &s_distinct);
-                        if (col == 2 || e == nRefE - 1) asm_lds_insert(s_tab, ref, rseq, eo, k, &s_distinct);
-                    } else {
+                if (lds) {
+                    // every edge leaves a word for phase C: table slot of its start k-mer | weight << 14 | appended base << 22 |
+                    // (its end k-mer was inserted by this edge and its slot is in ev_end) << 30;  -1 for a filtered edge
+                    int* ev = S.stack;
+                    int* ev_end = S.stack + P.max_pos;
+                    auto insert_all = [&](auto KWc) {
+                        constexpr int KW = decltype(KWc)::value;
+                        // the reference's k-mers first: a k-mer the reference holds is then represented by a reference occurrence, and
+                        // comparing a read's k-mer with its representative reads the LDS copy of the reference
+                        for (int e = tid; e < nRefE; e += nthr) {
+                            const AsmWords<KW> E = refc ? asm_load_words_lds<KW>(s_ref, e, k + 1) : asm_load_words<KW>(ref + e, k + 1);
+                            const int slot = asm_lds_insert_words(s_tab, asm_kmer_start(E, k), k, e, s_ref, refc, ref, rseq, &s_distinct);
+                            int word = slot | 1 << 14 | (int)(asm_byte_k(E, k) & 0xFFu) << 22;
+                            if (e == nRefE - 1) {
+                                ev_end[e] = asm_lds_insert_words(s_tab, asm_kmer_end(E, k), k, e + 1, s_ref, refc, ref, rseq, &s_distinct);
+                                word |= 1 << 30;
+                            }
+                            ev[e] = word;
+                        }
+                        __syncthreads();
+                        // the reads: the end k-mer of an edge is the start k-mer of the next one, which inserts it unless it is filtered
+                        read_pass(KWc,
+                            [&](int i, int ro, const AsmWords<KW>& E, int w) -> int {
+                                (void)w;
+                                return asm_lds_insert_words(s_tab, asm_kmer_start(E, k), k, 0x40000000 + ro + i, s_ref, refc, ref, rseq, &s_distinct);
+                            },
+                            [&](int t, int off, const AsmWords<KW>& E, int w, int slot, int nslot) {
+                                int word = slot | (w & 0xFF) << 14 | (int)(asm_byte_k(E, k) & 0xFFu) << 22;
+                                if (nslot < 0) {
+                                    ev_end[nRefE + t] = asm_lds_insert_words(s_tab, asm_kmer_end(E, k), k, 0x40000000 + off + 1, s_ref, refc, ref, rseq, &s_distinct);
+                                    word |= 1 << 30;
+                                }
+                                ev[nRefE + t] = word;
+                            },
+                            [&](int t) { ev[nRefE + t] = -1; },
+                            [&]() -> bool { return *(volatile int*)&s_distinct > ASM_LDS_LIMIT; });
+                    };
+                    if (k <= 15) insert_all(std::integral_constant<int, 2>{}); else insert_all(std::integral_constant<int, 4>{});
+                } else {
+                    for_each_event([&](int e, int so, int eo, int col, int w) -> bool {
+                        (void)w;
                         asm_slot(S, ref, rseq, so, k, capmask, true);
                         if (col == 2 || e == nRefE - 1) asm_slot(S, ref, rseq, eo, k, capmask, true);
-                    }
-                    return true;
-                });
+                        return true;
+                    });
+                }
                 asm_sync();
                 if (!lds || s_distinct <= ASM_LDS_LIMIT) break;
                 __syncthreads();
@@ -322,42 +561,138 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 asm_sync();
                 break;
             }
+            ASM_TICK(1);
             const bool lds = s_lds != 0;
             // ---- phase B: dense node ids + field initialisation
             auto init_node = [&](int id, int rep_off) {
                 S.first[id] = 0xFFFFFFFFu; S.weight[id] = 0; S.colour[id] = 0; S.rep[id] = rep_off;
                 for (int j = 0; j < ASM_MAX_SUCC; ++j) {
                     S.succ_c[id * ASM_MAX_SUCC + j] = 0; S.succ_t[id * ASM_MAX_SUCC + j] = 0xFFFFFFFFu;
-                    S.succ_w[id * ASM_MAX_SUCC + j] = 0; S.succ_n[id * ASM_MAX_SUCC + j] = -1;
+                    if (lds) S.succ_cw[id * ASM_MAX_SUCC + j] = 0ull;
+                    else { S.succ_w[id * ASM_MAX_SUCC + j] = 0; S.succ_n[id * ASM_MAX_SUCC + j] = -1; }
                 }
             };
             if (lds) {
+                // Nodes represented by a reference occurrence get the low ids (a slot then tells where its representative lives), in the
+                // order of their representatives along the reference when the LDS has room for a bitmap of the positions: reads arrive
+                // sorted by position and walk along the reference, so the successor slots they update then lie next to each other in
+                // memory and stay in the L2 (with ids in table order every update was an L2 miss).
+                const int refBytes = ((refLen + 16 + 7) >> 3) << 3, nW32 = (refLen >> 5) + 1;
+                const bool ordered = refc && refBytes + 8 * nW32 <= ASM_REF_CACHE && nW32 <= nthr;
+                unsigned* s_bm = (unsigned*)((char*)s_ref + refBytes);       // [nW32] bit p: reference position p represents a node
+                unsigned* s_bp = s_bm + nW32;                                // [nW32] nodes before the word
+                if (tid == 0) { s_nrefnodes = 0; s_nreadnodes = 0; }
+                if (ordered) for (int i = tid; i < nW32; i += nthr) s_bm[i] = 0u;
+                __syncthreads();
+                int nRefNodes0;
+                if (ordered) {
+                    for (int sidx = tid; sidx < ASM_LDS_SLOTS; sidx += nthr) {
+                        const int off = s_tab[sidx];
+                        if (off != -1 && off < 0x40000000) atomicOr(&s_bm[off >> 5], 1u << (off & 31));
+                    }
+                    __syncthreads();
+                    const int mine = tid < nW32 ? __popc(s_bm[tid]) : 0;
+                    const int before = asm_block_exscan(mine, s_wsum, nRefNodes0);
+                    if (tid < nW32) s_bp[tid] = (unsigned)before;
+                    __syncthreads();
+                } else {
+                    int mine = 0;
+                    for (int sidx = tid; sidx < ASM_LDS_SLOTS; sidx += nthr) { const int off = s_tab[sidx]; mine += off != -1 && off < 0x40000000; }
+                    if (mine) atomicAdd(&s_nrefnodes, mine);
+                    __syncthreads();
+                    nRefNodes0 = s_nrefnodes;
+                    __syncthreads();
+                    if (tid == 0) s_nrefnodes = 0;
+                    __syncthreads();
+                }
                 for (int sidx = tid; sidx < ASM_LDS_SLOTS; sidx += nthr) {
                     const int off = s_tab[sidx];
-                    if (off != -1) { const int id = atomicAdd(&s_n, 1); init_node(id, off); s_tab[sidx] = id; s_first[id] = 0xFFFFFFFFu; s_wc[id] = 0u; }
+                    if (off != -1) {
+                        const bool isref = off < 0x40000000;
+                        int id;
+                        if (!isref) id = nRefNodes0 + atomicAdd(&s_nreadnodes, 1);
+                        else if (ordered) id = (int)s_bp[off >> 5] + __popc(s_bm[off >> 5] & ((1u << (off & 31)) - 1u));
+                        else id = atomicAdd(&s_nrefnodes, 1);
+                        init_node(id, off);
+                        s_tab[sidx] = (int)(((unsigned)id << ASM_OFF_BITS) | (unsigned)(isref ? off : off - 0x40000000));
+                        s_first[id] = 0xFFFFFFFFu; s_wc[id] = 0u;
+                    }
                 }
+                __syncthreads();
+                if (tid == 0) { s_nrefnodes = nRefNodes0; s_n = nRefNodes0 + s_nreadnodes; }
             } else {
                 for (int sidx = tid; sidx < P.cap; sidx += nthr)
                     if (S.key[sidx] != -1) { const int id = atomicAdd(&s_n, 1); S.slot_id[sidx] = id; init_node(id, S.key[sidx]); }
             }
             asm_sync();
+            ASM_TICK(2);
             const int nNodes = s_n;
             // ---- phase C: AddEdge events (assembler.pyx:801-827)
-            for_each_event([&](int e, int so, int eo, int col, int w) -> bool {
-                const int sn = lds ? asm_lds_node(s_tab, S.rep, ref, rseq, so, k) : S.slot_id[asm_slot(S, ref, rseq, so, k, capmask, false)];
-                const int en = lds ? asm_lds_node(s_tab, S.rep, ref, rseq, eo, k) : S.slot_id[asm_slot(S, ref, rseq, eo, k, capmask, false)];
-                if (lds) {                                                   // node words in LDS
+            const int nRefNodes = s_nrefnodes;
+            if (lds) {
+                // one event per thread, from the word phase A left: node words in LDS; the successor slot of the start node is picked by the
+                // byte the edge appends (A, C, G, T: slots 0..3 by the byte's bits; anything else shares slots 4..7 by search), and takes ONE
+                // global atomic: its event count and weight.  Which node a slot leads to is looked up once per slot in phase D; first
+                // tickets only matter where a node has several successors and are collected for those nodes alone in a second pass.
+                const int* ev = S.stack;
+                const int* ev_end = S.stack + P.max_pos;
+                for (int e = tid; e < nEv; e += nthr) {
+                    const int word = ev[e];
+                    if (word < 0) continue;
+                    const int w = (word >> 14) & 0xFF, col = e < nRefE ? 1 : 2;
+                    const unsigned c = (unsigned)(word >> 22) & 0xFFu;
+                    const int sn = (int)((unsigned)s_tab[word & 0x3FFF] >> ASM_OFF_BITS);
+                    const int en = (int)((unsigned)s_tab[(word >> 30 & 1) ? ev_end[e] : (ev[e + 1] & 0x3FFF)] >> ASM_OFF_BITS);
                     atomicMin(&s_first[sn], 2u * (unsigned)e);
                     atomicMin(&s_first[en], 2u * (unsigned)e + 1u);
-                    atomicAdd(&s_wc[sn], (unsigned)w); atomicAdd(&s_wc[en], (unsigned)w);
-                    if ((s_wc[sn] >> 30 & (unsigned)col) == 0u) atomicOr(&s_wc[sn], (unsigned)col << 30);
+                    // (a node's own weight, assembler.pyx:795, is never read again: only its colours are kept)
+                    unsigned x = s_wc[sn];
+                    if ((x >> 30 & (unsigned)col) == 0u) atomicOr(&s_wc[sn], (unsigned)col << 30);
                     if ((s_wc[en] >> 30 & (unsigned)col) == 0u) atomicOr(&s_wc[en], (unsigned)col << 30);
-                } else {
-                    atomicMin(&S.first[sn], 2u * (unsigned)e);
-                    atomicMin(&S.first[en], 2u * (unsigned)e + 1u);
-                    atomicAdd(&S.weight[sn], w); atomicAdd(&S.weight[en], w);
-                    atomicOr(&S.colour[sn], col); atomicOr(&S.colour[en], col);
+                    if (e < nRefE) { S.ref_node[e] = sn; if (e == nRefE - 1) S.ref_node[e + 1] = en; }
+                    int slot = -1;
+                    if (c == 'A' || c == 'C' || c == 'G' || c == 'T') slot = (int)((c >> 1) & 3u);
+                    else {
+                        unsigned* cw = (unsigned*)(S.succ_c + (size_t)sn * ASM_MAX_SUCC) + 1;         // bytes 4..7
+                        for (int j = 0; j < 4 && slot < 0; ++j) {
+                            for (;;) {
+                                const unsigned wd = *(volatile unsigned*)cw;
+                                const unsigned cur = (wd >> (8 * j)) & 0xFFu;
+                                if (cur == c) { slot = 4 + j; break; }
+                                if (cur != 0u) break;
+                                const unsigned old = atomicCAS(cw, wd, wd | (c << (8 * j)));
+                                if (old == wd) { slot = 4 + j; break; }
+                            }
+                        }
+                        if (slot < 0) { s_err = PLAT_ERR_UNSUPPORTED; continue; }                     // > 4 distinct other bytes
+                    }
+                    // The weight of the node's FIRST-CLAIMED successor slot is summed in the node's LDS word (bits 0..22, the slot + 1 in
+                    // bits 23..25): the edges along the path most reads take never leave the CU.  Other slots, and a sum about to leave
+                    // its 23 bits, take a global atomic on the slot's (event count, weight) word.
+                    bool local = false;
+                    if (slot < 7) {
+                        for (;;) {
+                            const unsigned d = (x >> 23) & 7u;
+                            if (d == 0u) {
+                                const unsigned old = atomicCAS(&s_wc[sn], x, x | (unsigned)(slot + 1) << 23);
+                                x = old == x ? (x | (unsigned)(slot + 1) << 23) : old;
+                                continue;
+                            }
+                            local = d == (unsigned)slot + 1u && (x & 0x7FFFFFu) < 0x780000u;
+                            break;
+                        }
+                    }
+                    if (local) atomicAdd(&s_wc[sn], (unsigned)w);
+                    else atomicAdd(&S.succ_cw[sn * ASM_MAX_SUCC + slot], (1ull << 32) | (unsigned long long)(unsigned)w);
                 }
+            } else
+            for_each_event([&](int e, int so, int eo, int col, int w) -> bool {
+                const int sn = S.slot_id[asm_slot(S, ref, rseq, so, k, capmask, false)];
+                const int en = S.slot_id[asm_slot(S, ref, rseq, eo, k, capmask, false)];
+                atomicMin(&S.first[sn], 2u * (unsigned)e);
+                atomicMin(&S.first[en], 2u * (unsigned)e + 1u);
+                atomicAdd(&S.weight[sn], w); atomicAdd(&S.weight[en], w);
+                atomicOr(&S.colour[sn], col); atomicOr(&S.colour[en], col);
                 if (e < nRefE) { S.ref_node[e] = sn; if (e == nRefE - 1) S.ref_node[e + 1] = en; }
                 // successor slot keyed by the byte appended to the start k-mer
                 const unsigned char c = asm_ptr(ref, rseq, eo)[k - 1];
@@ -381,11 +716,77 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 return true;
             });
             asm_sync();
+            ASM_TICK(3);
             if (lds) {                                                        // the node words the later phases read, to the slice
-                for (int n = tid; n < nNodes; n += nthr) { S.first[n] = s_first[n]; S.weight[n] = (int)(s_wc[n] & 0x0FFFFFFFu); S.colour[n] = (int)(s_wc[n] >> 30); }
+                for (int n = tid; n < nNodes; n += nthr) { S.first[n] = s_first[n]; S.weight[n] = 0; S.colour[n] = (int)(s_wc[n] >> 30); }
                 asm_sync();
             }
             // ---- phase D: per node, the four successors with the smallest first tickets, in ticket order
+            if (lds) {
+                // nodes with more than one successor slot in use (few): their slots' first tickets from a second pass over the events
+                for (int n = tid; n < nNodes; n += nthr) {
+                    int used = 0;
+                    const int own = (int)(s_wc[n] >> 23 & 7u) - 1;      // the slot summed in the LDS word, -1 none
+                    for (int j = 0; j < ASM_MAX_SUCC; ++j) used += j == own || (S.succ_cw[n * ASM_MAX_SUCC + j] >> 32) != 0ull;
+                    if (used > 1) s_wc[n] |= 1u << 29;
+                }
+                __syncthreads();
+                {
+                    const int* ev = S.stack;
+                    for (int e = tid; e < nEv; e += nthr) {
+                        const int word = ev[e];
+                        if (word < 0) continue;
+                        const int sn = (int)((unsigned)s_tab[word & 0x3FFF] >> ASM_OFF_BITS);
+                        if (!(s_wc[sn] >> 29 & 1u)) continue;
+                        const unsigned c = (unsigned)(word >> 22) & 0xFFu;
+                        int slot = -1;
+                        if (c == 'A' || c == 'C' || c == 'G' || c == 'T') slot = (int)((c >> 1) & 3u);
+                        else for (int j = 4; j < ASM_MAX_SUCC; ++j) if (S.succ_c[sn * ASM_MAX_SUCC + j] == c) slot = j;
+                        if (slot >= 0) atomicMin(&S.succ_t[sn * ASM_MAX_SUCC + slot], (unsigned)e);
+                    }
+                }
+                asm_sync();
+                auto pick_edges = [&](auto KWc) {
+                    constexpr int KW = decltype(KWc)::value;
+                    for (int n = tid; n < nNodes; n += nthr) {
+                        AsmNodeE E; E.n = 0;
+                        const bool several = (s_wc[n] >> 29 & 1u) != 0u;
+                        const int own = (int)(s_wc[n] >> 23 & 7u) - 1;
+                        int rep_off = -1;
+                        AsmWords<KW> R;
+                        unsigned last = 0; bool firstpick = true;
+                        for (int pick = 0; pick < 4; ++pick) {
+                            int bj = -1; unsigned bt = 0xFFFFFFFFu;
+                            for (int j = 0; j < ASM_MAX_SUCC; ++j) {
+                                if (j != own && (S.succ_cw[n * ASM_MAX_SUCC + j] >> 32) == 0ull) continue;
+                                const unsigned t = several ? S.succ_t[n * ASM_MAX_SUCC + j] : 0u;
+                                if (!firstpick && t <= last) continue;
+                                if (t < bt) { bt = t; bj = j; }
+                            }
+                            if (bj < 0) break;
+                            // the node the slot leads to: this node's k-mer without its first base, plus the slot's byte
+                            if (rep_off < 0) {
+                                rep_off = S.rep[n];
+                                const bool isref = rep_off < 0x40000000;
+                                R = (isref && refc) ? asm_load_words_lds<KW>(s_ref, rep_off, k + 1)
+                                                    : asm_load_words<KW>(isref ? ref + rep_off : rseq + (rep_off - 0x40000000), k + 1);
+                            }
+                            const unsigned c = bj < 4 ? (unsigned)"ACTG"[bj] : (unsigned)S.succ_c[n * ASM_MAX_SUCC + bj];
+                            AsmWords<KW> T = asm_kmer_end(R, k);
+#pragma unroll
+                            for (int cc = 0; cc < KW; ++cc)
+                                if (((k - 1) >> 3) == cc) T.w[cc] = (T.w[cc] & ~(0xFFull << (8 * ((k - 1) & 7)))) | ((unsigned long long)c << (8 * ((k - 1) & 7)));
+                            E.end[E.n] = asm_lds_node_words(s_tab, T, k, nRefNodes, s_ref, refc, ref, rseq);
+                            E.w[E.n] = (int)(unsigned)S.succ_cw[n * ASM_MAX_SUCC + bj] + (bj == own ? (int)(s_wc[n] & 0x7FFFFFu) : 0);
+                            ++E.n;
+                            last = bt; firstpick = false;
+                            if (!several) break;
+                        }
+                        S.edges[n] = E;
+                    }
+                };
+                if (k <= 15) pick_edges(std::integral_constant<int, 2>{}); else pick_edges(std::integral_constant<int, 4>{});
+            } else
             for (int n = tid; n < nNodes; n += nthr) {
                 AsmNodeE E; E.n = 0;
                 unsigned last = 0; bool firstpick = true;
@@ -404,6 +805,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 S.edges[n] = E;
             }
             asm_sync();
+            ASM_TICK(4);
             // ---- noCycles: detectCyclesInGraph_Recursive (assembler.pyx:831-898), iterative, one thread
             if (P.no_cycles) {
                 if (tid == 0) {
@@ -437,6 +839,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 if (s_cycle && k <= 50) continue;          // rebuild with a longer k
                 if (s_cycle) break;                        // k > 50 and still cyclic: no variants (assembler.pyx:1454-1457)
             }
+            ASM_TICK(5);
             // ---- phase E: bubble starts in allNodes order (= increasing position for REF_AND_READ nodes): positions in chunks of
             // nthr, one thread per position, the tasks of a chunk written in position order behind those of the chunk before
             {
@@ -454,22 +857,18 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                                 if (S.colour[E.end[j]] == 2) { mask |= 1 << j; ++cnt; }           // assembler.pyx:1153
                         }
                     }
-                    s_scan[tid] = cnt;
-                    __syncthreads();
-                    if (tid == 0) {
-                        int run = s_ntasks;
-                        for (int t = 0; t < nthr; ++t) { const int v = s_scan[t]; s_scan[t] = run; run += v; }
-                        if (run > ASM_MAX_TASKS) { s_err = PLAT_ERR_OVERFLOW; run = s_ntasks; for (int t = 0; t < nthr; ++t) s_scan[t] = ASM_MAX_TASKS; }
-                        s_ntasks = run;
-                    }
-                    __syncthreads();
-                    int at = s_scan[tid];
+                    int total;
+                    const int sofar = s_ntasks;
+                    int at = sofar + asm_block_exscan(cnt, s_wsum, total);
+                    if (sofar + total > ASM_MAX_TASKS) { at = ASM_MAX_TASKS; if (tid == 0) s_err = PLAT_ERR_OVERFLOW; }
+                    else if (tid == 0) s_ntasks = sofar + total;
                     for (int j = 0; j < 4 && cnt > 0; ++j)
                         if ((mask >> j) & 1) { if (at < ASM_MAX_TASKS) { S.task_node[at] = n; S.task_edge[at] = j; } ++at; }
                     __syncthreads();
                 }
             }
             asm_sync();
+            ASM_TICK(6);
             const int nTasks = s_ntasks;
             // ---- phase F: getVariantPathsThroughGraphFromNode (assembler.pyx:1027-1112), one thread per start edge
             for (int t = tid; t < nTasks; t += nthr) {
@@ -512,6 +911,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 S.task_nfin[t] = aborted ? 0 : nfin;
             }
             asm_sync();
+            ASM_TICK(7);
             break;
         }
         asm_sync();
@@ -570,6 +970,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             status[g] = err;
         }
         asm_sync();
+        ASM_TICK(8);
     }
 }
 
@@ -628,6 +1029,7 @@ PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* ba
     AsmParams P;
     P.kmer = kmer_size; P.min_qual = min_qual; P.min_weight = min_weight; P.no_cycles = no_cycles;
     P.max_vars = max_vars_per_region; P.blob_per_region = blob_per_region; P.cap = cap; P.max_pos = (int)max_pos;
+    P.timing = getenv("PLAT_ASM_TIMING") != nullptr;
     const size_t per_block = asm_scratch_bytes(cap, (int)max_pos, max_ref, max_reads);
     P.scratch_per_block = (long long)per_block;
     // the kernel is bound by the latency of dependent L2 accesses, not by bandwidth or issue: one region per CU at a time (its graph takes
@@ -642,5 +1044,15 @@ PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* ba
     hipLaunchKernelGGL(k_assemble, dim3(nblk), dim3(ASM_THREADS), lds_bytes, st, b, P, (char*)ctx->asm_scratch.ptr, max_ref, max_reads,
                        var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status);
     PLAT_HIP(ctx, hipGetLastError());
+    if (P.timing) {
+        unsigned long long t[16];
+        PLAT_HIP(ctx, hipStreamSynchronize(st));
+        PLAT_HIP(ctx, hipMemcpyFromSymbol(t, HIP_SYMBOL(g_asm_ticks), sizeof t));
+        fprintf(stderr, "k_assemble, 10 ns ticks per phase summed over %d workgroups (ticket scan, A insert, B ids, C events, D successors, cycles, E starts, F paths, G variants):", nblk);
+        for (int i = 0; i < 9; ++i) fprintf(stderr, " %llu", t[i]);
+        fprintf(stderr, "\n");
+        memset(t, 0, sizeof t);
+        PLAT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_asm_ticks), t, sizeof t));
+    }
     return PLAT_OK;
 }
