@@ -93,6 +93,46 @@ def test_assembler_fuzz_vs_oracle(eng, oracle):
         assert nvar > 20
 
 
+def test_assembler_fuzz_edge_paths(eng, oracle):
+    """The paths of k_assemble the plain fuzz does not reach: reads longer than one 256-byte window, reference bytes other than
+    A/C/G/T (N runs, an IUPAC letter, lower case: successor slots 4..7), quality bytes >= 128 (negative as the reference reads
+    them), enough distinct k-mers to overflow the LDS table (global path), k > 31 (global path), a reference longer than the
+    LDS cache, and reads that start a few bases apart (every dword alignment of the window loads)."""
+    rng = np.random.default_rng(424242)
+    regions = []
+    for _ in range(10):                                   # long reads, odd reference bytes
+        r = synth_region(rng, int(rng.integers(900, 3000)), 2, int(rng.choice([300, 400, 520])), 20, 4)
+        ref = bytearray(r["ref"])
+        for _ in range(3):
+            q = int(rng.integers(0, len(ref) - 10))
+            ref[q:q + int(rng.integers(1, 4))] = bytes(rng.choice([ord("N"), ord("R"), ord("a"), ord("n")], 1).tolist()) * 3
+        r["ref"] = bytes(ref[:len(r["ref"])])
+        regions.append(r)
+    for _ in range(4):                                    # quality bytes >= 128 and 0
+        r = synth_region(rng, 1500, 2, 150, 25, 3)
+        qs = []
+        for q in r["quals"]:
+            q = bytearray(q)
+            for _ in range(int(rng.integers(0, 3))):
+                q[int(rng.integers(0, len(q)))] = int(rng.choice([0, 128, 200, 255]))
+            qs.append(bytes(q))
+        r["quals"] = qs
+        regions.append(r)
+    for _ in range(3):                                    # many distinct k-mers: reads from elsewhere (no bubble starts, but 40 k nodes)
+        r = synth_region(rng, 4000, 2, 150, 30, 3)
+        junk = [bytes(rng.choice(list(b"ACGT"), 150).tolist()) for _ in range(400)]
+        at = sorted(int(x) for x in rng.integers(0, len(r["seqs"]), len(junk)))
+        for j, sq in zip(reversed(at), junk):
+            r["seqs"].insert(j, sq); r["quals"].insert(j, bytes([35]) * 150)
+        regions.append(r)
+    regions.append(synth_region(rng, 9000, 2, 150, 12, 4))     # reference beyond the LDS cache
+    for k, nc in ((15, 0), (15, 1), (25, 0), (35, 0)):
+        got = eng.assemble(regions, kmer_size=k, no_cycles=nc)
+        for r, g in zip(regions, got):
+            exp, _ = oracle.assemble(r["ref"], r["ref_start"], r["assem_start"], r["assem_end"], r["seqs"], r["quals"], k, 20, 40, nc)
+            assert g == exp
+
+
 def test_config3_shape_regions(eng, oracle):
     """BASELINE config 3 shape: 4.5 kb reference (1.5 kb tile +- 1.5 kb), 250 bp reads at 30x, 1-3 indels + SNPs."""
     rng = np.random.default_rng(3003)
