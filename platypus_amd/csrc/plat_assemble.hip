@@ -388,6 +388,9 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
     AsmScratch S = asm_carve(scratch + (size_t)blockIdx.x * P.scratch_per_block, P.cap, P.max_pos, max_ref, max_reads);
     const int capmask = P.cap - 1;
     unsigned long long tick_ = P.timing ? wall_clock64() : 0ull;
+    // LDS path: the successor slot words of the first ASM_LDS_NODES nodes are kept CLEAN between regions (zeroed here once, and by
+    // every region for the few nodes it dirtied): a node's first-claimed slot lives in LDS, so most nodes never touch theirs
+    for (int i = tid; i < ASM_LDS_NODES * ASM_MAX_SUCC; i += nthr) { S.succ_cw[i] = 0ull; S.succ_c[i] = 0; }
 
     for (int g = blockIdx.x; g < b.n_regions; g += gridDim.x) {
         const uint8_t* ref = b.ref_seq + b.ref_off[g];
@@ -565,11 +568,12 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             const bool lds = s_lds != 0;
             // ---- phase B: dense node ids + field initialisation
             auto init_node = [&](int id, int rep_off) {
-                S.first[id] = 0xFFFFFFFFu; S.weight[id] = 0; S.colour[id] = 0; S.rep[id] = rep_off;
+                S.rep[id] = rep_off;
+                if (lds) return;                          // (first touch / colours come from the LDS words; the slot words are clean)
+                S.first[id] = 0xFFFFFFFFu; S.weight[id] = 0; S.colour[id] = 0;
                 for (int j = 0; j < ASM_MAX_SUCC; ++j) {
                     S.succ_c[id * ASM_MAX_SUCC + j] = 0; S.succ_t[id * ASM_MAX_SUCC + j] = 0xFFFFFFFFu;
-                    if (lds) S.succ_cw[id * ASM_MAX_SUCC + j] = 0ull;
-                    else { S.succ_w[id * ASM_MAX_SUCC + j] = 0; S.succ_n[id * ASM_MAX_SUCC + j] = -1; }
+                    S.succ_w[id * ASM_MAX_SUCC + j] = 0; S.succ_n[id * ASM_MAX_SUCC + j] = -1;
                 }
             };
             if (lds) {
@@ -665,6 +669,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             }
                         }
                         if (slot < 0) { s_err = PLAT_ERR_UNSUPPORTED; continue; }                     // > 4 distinct other bytes
+                        if (!(x >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);                           // the node's global slot words are in use
                     }
                     // The weight of the node's FIRST-CLAIMED successor slot is summed in the node's LDS word (bits 0..22, the slot + 1 in
                     // bits 23..25): the edges along the path most reads take never leave the CU.  Other slots, and a sum about to leave
@@ -683,7 +688,10 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         }
                     }
                     if (local) atomicAdd(&s_wc[sn], (unsigned)w);
-                    else atomicAdd(&S.succ_cw[sn * ASM_MAX_SUCC + slot], (1ull << 32) | (unsigned long long)(unsigned)w);
+                    else {
+                        if (!(x >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);                           // (bit 26: global slot words in use)
+                        atomicAdd(&S.succ_cw[sn * ASM_MAX_SUCC + slot], (1ull << 32) | (unsigned long long)(unsigned)w);
+                    }
                 }
             } else
             for_each_event([&](int e, int so, int eo, int col, int w) -> bool {
@@ -725,12 +733,16 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             if (lds) {
                 // nodes with more than one successor slot in use (few): their slots' first tickets from a second pass over the events
                 for (int n = tid; n < nNodes; n += nthr) {
+                    if (!(s_wc[n] >> 26 & 1u)) continue;               // only its LDS slot, or none
                     int used = 0;
                     const int own = (int)(s_wc[n] >> 23 & 7u) - 1;      // the slot summed in the LDS word, -1 none
                     for (int j = 0; j < ASM_MAX_SUCC; ++j) used += j == own || (S.succ_cw[n * ASM_MAX_SUCC + j] >> 32) != 0ull;
-                    if (used > 1) s_wc[n] |= 1u << 29;
+                    if (used > 1) {
+                        s_wc[n] |= 1u << 29;
+                        for (int j = 0; j < ASM_MAX_SUCC; ++j) S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu;
+                    }
                 }
-                __syncthreads();
+                asm_sync();
                 {
                     const int* ev = S.stack;
                     for (int e = tid; e < nEv; e += nthr) {
@@ -750,7 +762,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     constexpr int KW = decltype(KWc)::value;
                     for (int n = tid; n < nNodes; n += nthr) {
                         AsmNodeE E; E.n = 0;
-                        const bool several = (s_wc[n] >> 29 & 1u) != 0u;
+                        const bool several = (s_wc[n] >> 29 & 1u) != 0u, dirty = (s_wc[n] >> 26 & 1u) != 0u;
                         const int own = (int)(s_wc[n] >> 23 & 7u) - 1;
                         int rep_off = -1;
                         AsmWords<KW> R;
@@ -758,7 +770,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         for (int pick = 0; pick < 4; ++pick) {
                             int bj = -1; unsigned bt = 0xFFFFFFFFu;
                             for (int j = 0; j < ASM_MAX_SUCC; ++j) {
-                                if (j != own && (S.succ_cw[n * ASM_MAX_SUCC + j] >> 32) == 0ull) continue;
+                                if (j != own && (!dirty || (S.succ_cw[n * ASM_MAX_SUCC + j] >> 32) == 0ull)) continue;
                                 const unsigned t = several ? S.succ_t[n * ASM_MAX_SUCC + j] : 0u;
                                 if (!firstpick && t <= last) continue;
                                 if (t < bt) { bt = t; bj = j; }
@@ -777,12 +789,14 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             for (int cc = 0; cc < KW; ++cc)
                                 if (((k - 1) >> 3) == cc) T.w[cc] = (T.w[cc] & ~(0xFFull << (8 * ((k - 1) & 7)))) | ((unsigned long long)c << (8 * ((k - 1) & 7)));
                             E.end[E.n] = asm_lds_node_words(s_tab, T, k, nRefNodes, s_ref, refc, ref, rseq);
-                            E.w[E.n] = (int)(unsigned)S.succ_cw[n * ASM_MAX_SUCC + bj] + (bj == own ? (int)(s_wc[n] & 0x7FFFFFu) : 0);
+                            E.w[E.n] = (dirty ? (int)(unsigned)S.succ_cw[n * ASM_MAX_SUCC + bj] : 0) + (bj == own ? (int)(s_wc[n] & 0x7FFFFFu) : 0);
                             ++E.n;
                             last = bt; firstpick = false;
                             if (!several) break;
                         }
                         S.edges[n] = E;
+                        if (dirty)                                  // leave the node's slot words clean for the next region
+                            for (int j = 0; j < ASM_MAX_SUCC; ++j) { S.succ_cw[n * ASM_MAX_SUCC + j] = 0ull; S.succ_c[n * ASM_MAX_SUCC + j] = 0; }
                     }
                 };
                 if (k <= 15) pick_edges(std::integral_constant<int, 2>{}); else pick_edges(std::integral_constant<int, 4>{});
@@ -969,6 +983,8 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             var_count[g] = err ? 0 : nv;
             status[g] = err;
         }
+        if (s_lds == 0)                                   // a region done on the global path has written successor bytes of low node ids
+            for (int i = tid; i < ASM_LDS_NODES * ASM_MAX_SUCC; i += nthr) S.succ_c[i] = 0;
         asm_sync();
         ASM_TICK(8);
     }
