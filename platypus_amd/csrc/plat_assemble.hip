@@ -29,8 +29,8 @@
 // Measured on BASELINE config 3 (2000 tiles, PLAT_ASM_TIMING=1 prints the split): 84 k regions/s with the table in LDS but
 // three global atomics and two hash look-ups per event; 123 k with reference-first insertion + LDS reference + one look-up per
 // event; 141 k with the window loads; 174 k with one global atomic per event; 183 k with ordered ids; 214 k with the
-// first-claimed slot's weight in LDS.  A region with more distinct k-mers than ASM_LDS_LIMIT (deep or very divergent data),
-// k > 31, or a reference / read blob beyond 2^18 bytes is done with table, node words and successor lists in the workgroup's
+// first-claimed slot's weight in LDS; 246 k with the slot words kept clean between regions.  A region with more distinct k-mers than ASM_LDS_LIMIT (deep or very divergent data),
+// k > 15, or a reference / read blob beyond 2^18 bytes is done with table, node words and successor lists in the workgroup's
 // slice of a global scratch buffer (the "global path", the round-1 code).
 #include "plat_internal.hpp"
 #include <type_traits>
@@ -195,7 +195,7 @@ __device__ __forceinline__ int asm_read_edge_q(const uint8_t* s, const uint8_t* 
 }
 
 // ---- the LDS path works on an edge's k+1 bytes held in registers: KW 64-bit words, zero beyond the k+1 bytes (KW = 2 for k <= 15, the
-// default; 4 for k <= 31)
+// default: the only instantiation, a longer k takes the global path)
 template <int KW> struct AsmWords { unsigned long long w[KW]; };
 template <int KW> __device__ __forceinline__ AsmWords<KW> asm_load_words(const uint8_t* p, int nbytes) {
     AsmWords<KW> W;
@@ -462,41 +462,60 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             auto read_pass = [&](auto KWc, auto&& stage1, auto&& stage2, auto&& skipped, auto&& stop) {
                 constexpr int KW = decltype(KWc)::value;
                 constexpr int WIN = 4 * (64 - 2 * KW) - 3;     // edges per window: the last one still finds its 2 KW + 1 dwords in lanes <= 63
+                // A wave's reads are a chain of dependent round trips (the read's offsets, then its bytes): the offsets of the read after
+                // next and the first window of the next read are requested before the current read is worked on.
+                struct Meta { int base, cnt, ro; };
+                struct Win { unsigned dS, dQ; int sS, sQ, nE; };
+                auto load_meta = [&](int r) -> Meta {
+                    Meta m{0, 0, 0};
+                    if (r < nR) { m.base = S.read_base[r]; m.cnt = S.read_base[r + 1] - m.base; m.ro = (int)(b.read_off[rb + r] - rblob0); }
+                    return m;
+                };
+                auto load_win = [&](const Meta& m, int c0) -> Win {
+                    Win w;
+                    w.nE = max(0, min(WIN, m.cnt - c0));
+                    const uintptr_t pS = (uintptr_t)(rseq + m.ro + c0), pQ = (uintptr_t)(rqual + m.ro + c0);
+                    w.sS = (int)(pS & 3); w.sQ = (int)(pQ & 3);
+                    // (lanes past the window's last needed byte load nothing: the blobs' slack is a few bytes, not a window)
+                    w.dS = (w.nE > 0 && 4 * lane < w.sS + w.nE + k + 1) ? *(const unsigned*)((pS & ~(uintptr_t)3) + 4 * lane) : 0u;
+                    w.dQ = (w.nE > 0 && 4 * lane < w.sQ + w.nE + k + 1) ? *(const unsigned*)((pQ & ~(uintptr_t)3) + 4 * lane) : 0u;
+                    return w;
+                };
+                Meta m0 = load_meta(wv), m1 = load_meta(wv + nwv);
+                Win w0 = load_win(m0, 0);
                 for (int r = wv; r < nR; r += nwv) {
-                    const int base = S.read_base[r], cnt = S.read_base[r + 1] - base;
-                    const int ro = (int)(b.read_off[rb + r] - rblob0);
+                    const Meta m2 = load_meta(r + 2 * nwv);
+                    const Win w1 = load_win(m1, 0);
+                    const int base = m0.base, cnt = m0.cnt, ro = m0.ro;
                     for (int c0 = 0; c0 < cnt; c0 += WIN) {
                         if (stop()) return;
-                        const int nE = min(WIN, cnt - c0);
-                        const uintptr_t pS = (uintptr_t)(rseq + ro + c0), pQ = (uintptr_t)(rqual + ro + c0);
-                        const int sS = (int)(pS & 3), sQ = (int)(pQ & 3);
-                        // (lanes past the window's last needed byte load nothing: the blobs' slack is a few bytes, not a window)
-                        const unsigned dS = 4 * lane < sS + nE + k + 1 ? *(const unsigned*)((pS & ~(uintptr_t)3) + 4 * lane) : 0u;
-                        const unsigned dQ = 4 * lane < sQ + nE + k + 1 ? *(const unsigned*)((pQ & ~(uintptr_t)3) + 4 * lane) : 0u;
+                        const Win w = c0 == 0 ? w0 : load_win(m0, c0);
+                        const int nE = w.nE;
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             if (64 * u < nE) {                              // wave-uniform
                                 const int j = 64 * u + lane, i = c0 + j;
-                                const AsmWords<KW> E = asm_mask_words(asm_gather_words<KW>(dS, j + sS), k + 1);
-                                const AsmWords<KW> Q = asm_mask_words(asm_gather_words<KW>(dQ, j + sQ), k + 1);
-                                int w = -1, tag = -1;
+                                const AsmWords<KW> E = asm_mask_words(asm_gather_words<KW>(w.dS, j + w.sS), k + 1);
+                                const AsmWords<KW> Q = asm_mask_words(asm_gather_words<KW>(w.dQ, j + w.sQ), k + 1);
+                                int wq = -1, tag = -1;
                                 if (j < nE) {
-                                    w = asm_edge_q_words(E, Q, k, P.min_qual);
-                                    if (w == -2) w = asm_read_edge_q(rseq + ro, rqual + ro, i, k, P.min_qual);
-                                    if (w >= 0) tag = stage1(i, ro, E, w);
+                                    wq = asm_edge_q_words(E, Q, k, P.min_qual);
+                                    if (wq == -2) wq = asm_read_edge_q(rseq + ro, rqual + ro, i, k, P.min_qual);
+                                    if (wq >= 0) tag = stage1(i, ro, E, wq);
                                 }
                                 int ntag = __shfl_down(tag, 1);
                                 if (lane == 63) ntag = -1;
-                                if (w >= 0) stage2(base + i, ro + i, E, w, tag, ntag);
+                                if (wq >= 0) stage2(base + i, ro + i, E, wq, tag, ntag);
                                 else if (j < nE) skipped(base + i);
                             }
                         }
                     }
+                    m0 = m1; m1 = m2; w0 = w1;
                 }
             };
             // ---- phase A: insert every k-mer that takes part in a (valid) edge; LDS table first, the global one if it overflows
             // (or if k, the reference or the reads' bytes are beyond what the LDS path packs into its words)
-            if (tid == 0) s_lds = (k <= 31 && nRefE < ASM_LDS_LIMIT && refLen < (1 << ASM_OFF_BITS) && blobLen < (1ll << ASM_OFF_BITS)) ? 1 : 0;
+            if (tid == 0) s_lds = (k <= 15 && nRefE < ASM_LDS_LIMIT && refLen < (1 << ASM_OFF_BITS) && blobLen < (1ll << ASM_OFF_BITS)) ? 1 : 0;
             __syncthreads();
             bool failed = false;
             for (;;) {
@@ -544,7 +563,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             [&](int t) { ev[nRefE + t] = -1; },
                             [&]() -> bool { return *(volatile int*)&s_distinct > ASM_LDS_LIMIT; });
                     };
-                    if (k <= 15) insert_all(std::integral_constant<int, 2>{}); else insert_all(std::integral_constant<int, 4>{});
+                    insert_all(std::integral_constant<int, 2>{});
                 } else {
                     for_each_event([&](int e, int so, int eo, int col, int w) -> bool {
                         (void)w;
@@ -799,7 +818,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             for (int j = 0; j < ASM_MAX_SUCC; ++j) { S.succ_cw[n * ASM_MAX_SUCC + j] = 0ull; S.succ_c[n * ASM_MAX_SUCC + j] = 0; }
                     }
                 };
-                if (k <= 15) pick_edges(std::integral_constant<int, 2>{}); else pick_edges(std::integral_constant<int, 4>{});
+                pick_edges(std::integral_constant<int, 2>{});
             } else
             for (int n = tid; n < nNodes; n += nthr) {
                 AsmNodeE E; E.n = 0;
