@@ -16,6 +16,169 @@ namespace plat {
 
 __device__ __forceinline__ int geno_index(int a, int b, int H) { return a * H - a * (a - 1) / 2 + (b - a); }
 
+// k_em_wide: the same arithmetic with the window's genotype likelihoods and responsibilities in LDS and the E-step spread over
+// (individual, genotype) pairs.  k_em's E-step is one lane per individual walking its G genotypes through global memory: with one
+// wave per window that is a chain of memory round trips (187 us for 200 windows x 100 samples, 76 us for 10 000 windows x 1).
+// Here the likelihoods are copied in once (coalesced); every product L * f_s * f_r * (1 + (r != s)) is one lane's (:421); the sums
+// that have an order -- csrSum over a sample's genotypes (:422), the M-step's per-haplotype sum over samples and genotypes
+// (:437-446) -- are still walked in that order by one lane each, from LDS.  Same expressions, same order: same doubles.
+__global__ void __launch_bounds__(256)
+k_em_wide(int n_ind, const int32_t* __restrict__ win_hap_begin, const int64_t* __restrict__ gl_off,
+          const int32_t* __restrict__ n_reads, const double* __restrict__ gl, int max_iters, int use_em,
+          double* __restrict__ out_freq, double* __restrict__ out_em, int32_t* __restrict__ out_call,
+          int32_t* __restrict__ out_iters, int max_haps, int maxG, int use_streams)
+{
+    extern __shared__ double s_freq[];                 // [max_haps] | Ls [n_ind][G] | rsp [n_ind][G] | csum [n_ind] | streams | nr, gs, gr
+    __shared__ unsigned long long s_change;
+    __shared__ int s_with;
+    const int w = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int h0 = win_hap_begin[w], H = win_hap_begin[w + 1] - h0;
+    const int G = H * (H + 1) / 2;
+    if (H <= 0) { if (tid == 0 && out_iters) out_iters[w] = 0; return; }
+    const double* L = gl + gl_off[w];
+    double* em = out_em + gl_off[w];
+    double* Ls = s_freq + max_haps;
+    double* rsp = Ls + (size_t)n_ind * maxG;
+    double* csum = rsp + (size_t)n_ind * maxG;
+    // M-step streams (use_streams): T[k][i][0..H] = the terms haplotype k's frequency sum takes from sample i, in the order it
+    // takes them ((a, k) for a < k, (k, k) twice, (k, b) for b > k): the lane that owns k then only reads and adds
+    double* T = csum + n_ind;
+    const int SL = H + 1;                              // terms per (haplotype, sample)
+    const int TS = (n_ind * SL + 7) & ~7;               // stream length per haplotype, padded with zeros to the M-step's batches of 8
+    int* nr = (int*)(T + (use_streams ? (size_t)max_haps * ((n_ind * (max_haps + 1) + 7) & ~7) : 0));
+    short* gs = (short*)(nr + n_ind);
+    short* gr = gs + maxG;
+    const int nP = n_ind * G;
+    double eps = 1.0 / (n_ind * 2 * 2);                // :684
+    if (1e-3 < eps) eps = 1e-3;
+    const double uniformFreq = 1.0 / H;
+    if (tid == 0) { s_with = 0; s_change = 0ull; }
+    for (int k = tid; k < H; k += nthr) s_freq[k] = uniformFreq;
+    for (int j = tid; j < G; j += nthr) {              // genotype j = (s, r), s <= r, cgenotype.pyx:212-216
+        int a = 0, rem = j;
+        while (rem >= H - a) { rem -= H - a; ++a; }
+        gs[j] = (short)a; gr[j] = (short)(a + rem);
+    }
+    for (int i = tid; i < n_ind; i += nthr) nr[i] = n_reads[(long long)w * n_ind + i];
+    {   // (four loads in flight per thread)
+        int p = tid;
+        for (; p + 3 * nthr < nP; p += 4 * nthr) {
+            const double a0 = L[p], a1 = L[p + nthr], a2 = L[p + 2 * nthr], a3 = L[p + 3 * nthr];
+            Ls[p] = a0; Ls[p + nthr] = a1; Ls[p + 2 * nthr] = a2; Ls[p + 3 * nthr] = a3;
+        }
+        for (; p < nP; p += nthr) Ls[p] = L[p];
+    }
+    __syncthreads();
+    {
+        int mine = 0;
+        for (int i = tid; i < n_ind; i += nthr) mine += nr[i] != 0;
+        if (mine) atomicAdd(&s_with, mine);
+        for (int p = tid; p < nP; p += nthr)           // the reference leaves stale values for samples without reads and never reads them
+            if (nr[p / G] == 0) em[p] = 0.0;
+        if (use_streams)                               // samples without reads contribute nothing: their terms stay 0.0 (x + 0.0 == x)
+            for (int t = tid; t < H * TS; t += nthr) T[t] = 0.0;
+    }
+    __syncthreads();
+    const int nWithData = s_with;
+    double maxChange = eps + 1;
+    int iters = 0;
+    while (maxChange > eps && iters < max_iters) {     // :700-702
+        for (int p = tid; p < nP; p += nthr) {         // E-step: the products
+            const int i = p / G, j = p - i * G;
+            if (nr[i] == 0) continue;
+            const int s2 = gs[j], r2 = gr[j];
+            rsp[p] = Ls[p] * s_freq[s2] * s_freq[r2] * (1 + (r2 != s2));   // :421
+        }
+        __syncthreads();
+        for (int i = tid; i < n_ind; i += nthr) {      // csrSum in genotype order
+            if (nr[i] == 0) continue;
+            double cs = 0.0;
+            const double* row = rsp + i * G;
+            int j = 0;
+            for (; j + 4 <= G; j += 4) {               // (four reads in flight, additions in order)
+                const double a0 = row[j], a1 = row[j + 1], a2 = row[j + 2], a3 = row[j + 3];
+                cs += a0; cs += a1; cs += a2; cs += a3;
+            }
+            for (; j < G; ++j) cs += row[j];
+            csum[i] = cs;
+        }
+        __syncthreads();
+        for (int p = tid; p < nP; p += nthr) {         // normalise; the responsibilities are the EMLikelihoods output too
+            const int i = p / G;
+            if (nr[i] == 0) continue;
+            double v = rsp[p];
+            if (csum[i] > 0.0) v /= csum[i];
+            rsp[p] = v;
+            em[p] = v;
+            if (use_streams) {
+                const int j = p - i * G, s2 = gs[j], r2 = gr[j];
+                if (s2 == r2) { T[s2 * TS + i * SL + s2] = v; T[s2 * TS + i * SL + s2 + 1] = v; }
+                else {
+                    T[s2 * TS + i * SL + r2 + 1] = v;               // stream s2, partner r2 > s2: behind the doubled diagonal
+                    T[r2 * TS + i * SL + s2] = v;                   // stream r2, partner s2 < r2
+                }
+            }
+        }
+        if (tid == 0) s_change = 0ull;
+        __syncthreads();
+        // M-step: one lane per haplotype k adds the responsibilities of the genotypes that contain k in the order the reference's
+        // double loop reaches them: (a, k) for a < k, (k, k) added as first and as second, (k, b) for b > k
+        for (int k = tid; k < H; k += nthr) {
+            double acc = 0.0;
+            if (use_streams) {
+                const double* tk = T + (size_t)k * TS;
+                for (int t0 = 0; t0 < TS; t0 += 8) {   // eight LDS reads in flight; the padding adds 0.0
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = tk[t0 + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += v[u];
+                }
+            } else
+            for (int i = 0; i < n_ind; ++i) {
+                if (nr[i] == 0) continue;
+                const double* csr = rsp + i * G;
+                for (int a0 = 0; a0 < H; a0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int a = min(a0 + u, H - 1);
+                        v[u] = csr[a < k ? geno_index(a, k, H) : geno_index(k, a, H)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int a = a0 + u;
+                        if (a < H) { acc += v[u]; if (a == k) acc += v[u]; }
+                    }
+                }
+            }
+            const double nf = acc / (2 * nWithData);   // :449
+            const double fc = fabs(s_freq[k] - nf);
+            if (fc > 0.0) atomicMax(&s_change, (unsigned long long)__double_as_longlong(fc));   // (fc > 0: the bit patterns order like the values; a NaN never raises the maximum, as in `if fc > change`)
+            s_freq[k] = nf;                            // each thread owns its k: nobody else reads freq in this phase
+        }
+        __syncthreads();
+        maxChange = __longlong_as_double((long long)s_change);
+        ++iters;
+        __syncthreads();
+    }
+    for (int k = tid; k < H; k += nthr) out_freq[h0 + k] = s_freq[k];
+    if (tid == 0 && out_iters) out_iters[w] = iters;
+    // callGenotypes, :623-676
+    for (int i = tid; i < n_ind; i += nthr) {
+        int best = -1;
+        if (nr[i] != 0) {
+            const double* row = (use_em == 1 ? rsp : Ls) + i * G;
+            double maxL = 0.0;
+            for (int g = 0; g < G; ++g) {
+                const double v = row[g];
+                if (best == -1 || v > maxL) { maxL = v; best = g; }
+            }
+        }
+        out_call[(long long)w * n_ind + i] = best;
+    }
+}
+
 // One single-wave workgroup per window.  E-step: one lane per individual (the genotype loop is sequential, :411-429);
 // M-step: one lane per haplotype k, which adds the responsibilities of the genotypes that contain k in exactly the
 // order the reference's double loop reaches them (:437-446).
@@ -365,9 +528,25 @@ PLAT_EXPORT int plat_em_window_batch(plat_ctx* ctx, int n_windows, int n_ind, in
     if (lds > 64 * 1024) return PLAT_ERR_INVALID;
     const size_t maxG = (size_t)max_haps_per_window * (max_haps_per_window + 1) / 2;
     const size_t csr_bytes = (size_t)n_ind * maxG * sizeof(double);
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    // likelihoods and responsibilities of one window in LDS when they fit: k_em_wide
+    const size_t wide = (size_t)max_haps_per_window * 8 + 2 * csr_bytes + (size_t)n_ind * 12 + maxG * 4 + 64;
+    static const bool no_wide = getenv("PLAT_EM_NARROW") != nullptr;      // (measurement: the one-wave kernel)
+    if (wide <= 96 * 1024 && max_haps_per_window < 32768 && !no_wide) {
+        const size_t pairs = (size_t)n_ind * maxG;
+        const int threads = pairs > 128 ? 256 : (pairs > 64 ? 128 : 64);
+        const size_t streams = (size_t)max_haps_per_window * (((size_t)n_ind * (max_haps_per_window + 1) + 7) & ~(size_t)7) * 8;
+        const int use_streams = wide + streams <= 150 * 1024;
+        const size_t lds_wide = wide + (use_streams ? streams : 0);
+        if (lds_wide > 48 * 1024)
+            PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_em_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide));
+        hipLaunchKernelGGL(k_em_wide, dim3(n_windows), dim3(threads), lds_wide, (hipStream_t)stream, n_ind, win_hap_begin, gl_off, n_reads, gl,
+                           max_iters, use_em_likelihoods, out_freq, out_em, out_call, out_iters, max_haps_per_window, (int)maxG, use_streams);
+        PLAT_HIP(ctx, hipGetLastError());
+        return PLAT_OK;
+    }
     const int csr_in_lds = n_ind >= 8 && lds + csr_bytes <= 60 * 1024;   // responsibilities of one window next to the frequencies (pays with many samples)
     if (csr_in_lds) lds += csr_bytes;
-    PLAT_HIP(ctx, hipSetDevice(ctx->device));
     if (lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_em, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_em, dim3(n_windows), dim3(64), lds, (hipStream_t)stream, n_ind, win_hap_begin, gl_off, n_reads, gl,
