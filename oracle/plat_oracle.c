@@ -13,9 +13,9 @@
  * SURVEY.md App. A (8 x int16 lanes, wrapping adds, signed mins), as plain
  * scalar C over int16_t[8] arrays -- no SSE intrinsics.
  *
- * Pinning (see oracle/README.md):
+ * Pinning (see tests/golden/README.md):
  *   orc_dp_*          pinned against the UNMODIFIED reference src/c/align.c built
- *                     into oracle/_ref/libalign_ref.so (tests/test_oracle_vs_ref.py)
+ *                     into oracle/_ref/libalign_ref.so (tests/test_oracle.py)
  *                     and against tests/golden/dp_cases.npz.
  *   orc_map_align,    pinned against golden vectors generated in this container
  *   orc_assemble      from the reference's own Cython sources (tests/golden/README.md).

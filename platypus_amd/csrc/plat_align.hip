@@ -1078,7 +1078,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         if (todo) {
             long long sb = 0;
             if (lane == 0) sb = (long long)atomicAdd((unsigned long long*)&cnt[CNT_SLOW_SEED], (unsigned long long)__popcll(todo));
-            sb = __shfl((int)sb, 0);
+            sb = ((long long)(unsigned)__shfl((int)sb, 0)) | ((long long)__shfl((int)(sb >> 32), 0) << 32);
             if (valid && !decided) slow_list[sb + __popcll(todo & ((1ull << lane) - 1ull))] = SlowRec{h, rl};
         }
     }
