@@ -378,6 +378,9 @@ def main():
             try:
                 from tools import bench_other
                 line["other_configs"] = bench_other.summary(eng)
+                c4 = line["other_configs"].get("config4_region_pipeline") or {}
+                if "windows_per_sec" in c4:      # north_star's second metric: reads in host memory -> VCF record text (config 4, this GPU)
+                    line["windows_per_sec_end_to_end"] = c4["windows_per_sec"]
             except Exception as exc:            # pragma: no cover
                 line["other_configs"] = {"error": repr(exc)[:300]}
         if world == 1 and not a.no_cpu_baseline:
