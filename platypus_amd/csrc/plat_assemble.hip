@@ -494,6 +494,8 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             if (64 * u < nE) {                              // wave-uniform
+                                if (u > 0 && stop()) return;                // (checked every round: between two checks the workgroup inserts
+                                                                            //  at most 2 x 1024 k-mers, which the table's spare slots take)
                                 const int j = 64 * u + lane, i = c0 + j;
                                 const AsmWords<KW> E = asm_mask_words(asm_gather_words<KW>(w.dS, j + w.sS), k + 1);
                                 const AsmWords<KW> Q = asm_mask_words(asm_gather_words<KW>(w.dQ, j + w.sQ), k + 1);
