@@ -661,13 +661,23 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 // tickets only matter where a node has several successors and are collected for those nodes alone in a second pass.
                 const int* ev = S.stack;
                 const int* ev_end = S.stack + P.max_pos;
-                for (int e = tid; e < nEv; e += nthr) {
-                    const int word = ev[e];
+                // (four tickets per thread and trip, their words loaded before the first is used)
+                for (int e0 = tid; e0 < nEv; e0 += 4 * nthr) {
+                  int words[4], nexts[4];
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) {
+                      const int e = e0 + u * nthr;
+                      words[u] = e < nEv ? ev[e] : -1;
+                      nexts[u] = e + 1 < nEv ? ev[e + 1] : -1;
+                  }
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * nthr, word = words[u];
                     if (word < 0) continue;
                     const int w = (word >> 14) & 0xFF, col = e < nRefE ? 1 : 2;
                     const unsigned c = (unsigned)(word >> 22) & 0xFFu;
                     const int sn = (int)((unsigned)s_tab[word & 0x3FFF] >> ASM_OFF_BITS);
-                    const int en = (int)((unsigned)s_tab[(word >> 30 & 1) ? ev_end[e] : (ev[e + 1] & 0x3FFF)] >> ASM_OFF_BITS);
+                    const int en = (int)((unsigned)s_tab[(word >> 30 & 1) ? ev_end[e] : (nexts[u] & 0x3FFF)] >> ASM_OFF_BITS);
                     atomicMin(&s_first[sn], 2u * (unsigned)e);
                     atomicMin(&s_first[en], 2u * (unsigned)e + 1u);
                     // (a node's own weight, assembler.pyx:795, is never read again: only its colours are kept)
@@ -713,6 +723,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         if (!(x >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);                           // (bit 26: global slot words in use)
                         atomicAdd(&S.succ_cw[sn * ASM_MAX_SUCC + slot], (1ull << 32) | (unsigned long long)(unsigned)w);
                     }
+                  }
                 }
             } else
             for_each_event([&](int e, int so, int eo, int col, int w) -> bool {
@@ -766,8 +777,13 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 asm_sync();
                 {
                     const int* ev = S.stack;
-                    for (int e = tid; e < nEv; e += nthr) {
-                        const int word = ev[e];
+                    for (int e0 = tid; e0 < nEv; e0 += 4 * nthr) {
+                      int words[4];
+#pragma unroll
+                      for (int u = 0; u < 4; ++u) words[u] = e0 + u * nthr < nEv ? ev[e0 + u * nthr] : -1;
+#pragma unroll
+                      for (int u = 0; u < 4; ++u) {
+                        const int e = e0 + u * nthr, word = words[u];
                         if (word < 0) continue;
                         const int sn = (int)((unsigned)s_tab[word & 0x3FFF] >> ASM_OFF_BITS);
                         if (!(s_wc[sn] >> 29 & 1u)) continue;
@@ -776,6 +792,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         if (c == 'A' || c == 'C' || c == 'G' || c == 'T') slot = (int)((c >> 1) & 3u);
                         else for (int j = 4; j < ASM_MAX_SUCC; ++j) if (S.succ_c[sn * ASM_MAX_SUCC + j] == c) slot = j;
                         if (slot >= 0) atomicMin(&S.succ_t[sn * ASM_MAX_SUCC + slot], (unsigned)e);
+                      }
                     }
                 }
                 asm_sync();
