@@ -108,6 +108,17 @@ def test_native_equals_python_option_variants(fake, opt):
     _both(fake, regs, ["S1"], **opt)
 
 
+def test_native_many_chunks_per_worker(fake):
+    """Several chunks per worker, one region per chunk, a region without reads in the middle: the same text whatever the split."""
+    regs = [synth.config4_region(40 + i, n_samples=2, region_len=2500, snp_rate=4e-3, indel_rate=1e-3, read_len=100, depth=20) for i in range(7)]
+    regs[3]["samples"] = [[], []]
+    names = ["A", "B"]
+    a, _ = _both(fake, regs, names, workers=1, per_chunk=1)
+    b, _ = _both(fake, regs, names, workers=2, per_chunk=1)
+    c, _ = _both(fake, regs, names, workers=2, per_chunk=3)
+    assert a == b == c and a.count("\n") > 20
+
+
 def test_native_refuses_what_it_does_not_build(fake):
     regs = [synth.config4_region(1, region_len=1000, read_len=100)]
     fasta, work = _work(regs, ["S1"])
