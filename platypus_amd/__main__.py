@@ -84,7 +84,7 @@ def call_variants_config4(opts, n_regions):
         local = int(os.environ.get("LOCAL_RANK", rank))
         import torch
         nc = F.NativeCaller(local % max(1, torch.cuda.device_count()), int(os.environ.get("PLAT_CALLER_WORKERS", "8")),
-                            int(os.environ.get("PLAT_CALLER_CHUNK", "2")))
+                            int(os.environ.get("PLAT_CALLER_CHUNK", "4")))
         t0 = time.time()
         text.write(nc.call_regions(rr, ["S1"], opts) if rr else "")
         n_windows = nc.stats["n_windows"] if rr else 0

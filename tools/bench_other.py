@@ -181,7 +181,7 @@ def line_config4(a, rank, local, world, dist):
     import torch
     nreg = a.regions or 64
     workers = int(os.environ.get("PLAT_CALLER_WORKERS", "16"))
-    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "2"))
+    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "4"))
     pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1"
     r = config4(local, nreg, 100000, workers, per_chunk, first_region=rank * nreg, repeats=max(1, min(a.steps, 3)), pin=pin)
     dev = torch.device("cuda", local)
@@ -216,7 +216,7 @@ def summary(eng):
     out["config3_assembler"] = dict(regions=500, reads=int(r["ab"]["n_reads"]), regions_per_sec=500 * r["steps"] / r["T"],
                                     kernel_ms=r["kernel_ms"], hbm_frac=r["alg_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                     variants_found=r["variants"], variants_planted=r["planted"])
-    r = config4(0, 64, 100000, int(os.environ.get("PLAT_CALLER_WORKERS", "16")), int(os.environ.get("PLAT_CALLER_CHUNK", "2")), repeats=3)
+    r = config4(0, 64, 100000, int(os.environ.get("PLAT_CALLER_WORKERS", "16")), int(os.environ.get("PLAT_CALLER_CHUNK", "4")), repeats=3)
     st = r["stats"]
     out["config4_region_pipeline"] = dict(regions=r["regions"], region_len=r["region_len"], reads=r["reads"], windows=r["windows"], records=r["records"],
                                           planted_variants=r["planted"], seconds=r["T"], windows_per_sec=r["windows"] / r["T"],
