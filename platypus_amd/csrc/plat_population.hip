@@ -531,7 +531,7 @@ PLAT_EXPORT int plat_em_window_batch(plat_ctx* ctx, int n_windows, int n_ind, in
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
     // likelihoods and responsibilities of one window in LDS when they fit: k_em_wide
     const size_t wide = (size_t)max_haps_per_window * 8 + 2 * csr_bytes + (size_t)n_ind * 12 + maxG * 4 + 64;
-    static const bool no_wide = getenv("PLAT_EM_NARROW") != nullptr;      // (measurement: the one-wave kernel)
+    const bool no_wide = getenv("PLAT_EM_NARROW") != nullptr;             // (read per call: the one-wave kernel, for measurements and the cross-check test)
     if (wide <= 96 * 1024 && max_haps_per_window < 32768 && !no_wide) {
         const size_t pairs = (size_t)n_ind * maxG;
         const int threads = pairs > 128 ? 256 : (pairs > 64 ? 128 : 64);

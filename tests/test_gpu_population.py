@@ -124,6 +124,37 @@ def test_population_path_end_to_end_vs_oracle(eng, oracle):
         assert np.array_equal(e[live], em[hb.gl_off[w]:hb.gl_off[w] + hb.n_ind * G].reshape(hb.n_ind, G)[live])
 
 
+def test_em_wide_kernel_equals_the_one_wave_kernel(eng, monkeypatch):
+    """k_em_wide (likelihoods, responsibilities and the M-step's term streams in LDS) against k_em (one wave per window; PLAT_EM_NARROW=1)
+    on the same likelihoods: frequencies, EM likelihoods, calls and iteration counts bit for bit -- with and without useEMLikelihoods,
+    at 1, 7 and 100 samples, with samples that have no reads, and with likelihood rows replaced by random ones (the synthetic windows
+    converge in two iterations: random rows make the EM run longer)."""
+    rng = np.random.default_rng(77)
+    for hb in (synth.config2(300, seed=5), synth.config5(12, 7), synth.config5(30, 100)):
+        db = eng.upload(hb)
+        eng.call_windows(db, want_stats=False)
+        for flavour in range(2):
+            if flavour == 1:                                                    # random likelihoods in (0, 1], some rows of a sample all tiny
+                g = rng.random(db.gl.numel()) ** 4 + 1e-300
+                g[rng.random(g.size) < 0.02] = 1e-300
+                db.gl.copy_(__import__("torch").from_numpy(g).to(db.gl.device))
+            for use_em in (0, 1):
+                res = []
+                for narrow in (False, True):
+                    if narrow:
+                        monkeypatch.setenv("PLAT_EM_NARROW", "1")
+                    else:
+                        monkeypatch.delenv("PLAT_EM_NARROW", raising=False)
+                    eng.em(db, 100, use_em)
+                    eng.synchronize()
+                    res.append((db.freq.cpu().numpy().copy(), db.em.cpu().numpy().copy(), db.calls.cpu().numpy().copy(), db.em_iters.cpu().numpy().copy()))
+                monkeypatch.delenv("PLAT_EM_NARROW", raising=False)
+                for a, b in zip(res[0], res[1]):
+                    assert np.array_equal(a, b, equal_nan=True)
+                if flavour == 1:
+                    assert res[0][3][:hb.n_windows].max() > 2
+
+
 def test_haplotype_scores_vs_oracle(eng, oracle):
     """plat_haplotype_score_batch on multi-window batches (1 and 12 samples, some samples without reads): per-haplotype sums =
     the oracle's hap1Like on the device's own likelihoods (same doubles), HapScore = the oracle's clustering of them."""
