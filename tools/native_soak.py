@@ -1,6 +1,6 @@
 """Soak of the native region loop (libplat_caller.so) against the Python region loop (platypus_amd.caller): text equality over
 many synthetic regions, sample counts, read lengths, variant densities (greedy haplotype filter included), read classes and
-option variants.  usage: python tools/native_soak.py [seconds] [--fake]   (--fake: tests/fakedev instead of the GPU)"""
+option variants.  usage: python tools/native_soak.py [seconds]   (tests/soak/native_soak_fake.py runs the same loop on tests/fakedev)"""
 import io
 import json
 import os
@@ -15,13 +15,9 @@ from platypus_amd.options import default_options                           # noq
 from platypus_amd.vcfrecords import VCF                                     # noqa: E402
 
 
-def main():
+def main(lib=None):
+    """lib: a libplat_caller.so handle to use instead of the product one (tests/soak/native_soak_fake.py passes the fake device's)."""
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    lib = None
-    if "--fake" in sys.argv:
-        from tests import fakedev
-        H._engine = fakedev.fake_engine()
-        lib = fakedev.fake_caller_lib()
     t0 = time.time()
     rounds = lines = windows = greedy = 0
     seed = 90000
