@@ -70,6 +70,12 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
                 txt = open(os.path.join(dp, f)).read()
                 assert not bad.search(txt), (dp, f)
+    # tools/ and the headers neither: what calls the oracle lives under tests/ (tests/soak for the long runs)
+    bad2 = re.compile(r"import\s+oracle|from\s+oracle|liborc|libalign_ref|fakedev")
+    for dp in (os.path.join(ROOT, "tools"), os.path.join(ROOT, "include"), os.path.join(ROOT, "bindings")):
+        for f in os.listdir(dp):
+            if f.endswith((".py", ".sh", ".h", ".pxd", ".pyx")):
+                assert not bad2.search(open(os.path.join(dp, f)).read()), (dp, f)
 
 
 def test_caller_library_builds_and_matches_its_header(tmp_path):
