@@ -1,6 +1,6 @@
 """Soak of the native region loop (libplat_caller.so) against the Python region loop (platypus_amd.caller): text equality over
 many synthetic regions, sample counts, read lengths, variant densities (greedy haplotype filter included), read classes and
-option variants.  usage: python tools/native_soak.py [seconds]   (tests/soak/native_soak_fake.py runs the same loop on tests/fakedev)"""
+option variants.  usage: python tools/native_soak.py [seconds]   (tests/soak/native_soak_fake.py runs the same loop without a GPU)"""
 import io
 import json
 import os
@@ -16,7 +16,7 @@ from platypus_amd.vcfrecords import VCF                                     # no
 
 
 def main(lib=None):
-    """lib: a libplat_caller.so handle to use instead of the product one (tests/soak/native_soak_fake.py passes the fake device's)."""
+    """lib: a libplat_caller.so handle to use instead of the product one (tests/soak/native_soak_fake.py passes its own)."""
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     t0 = time.time()
     rounds = lines = windows = greedy = 0
@@ -71,7 +71,7 @@ def main(lib=None):
         rounds += 1
         seed += 1
     print(json.dumps(dict(tool="tools/native_soak.py", rounds=rounds, regions=3 * rounds, windows=windows, greedy_windows=greedy, record_lines=lines,
-                          identical=True, seconds=round(time.time() - t0, 1), device="fake (oracle)" if lib else "MI355X")))
+                          identical=True, seconds=round(time.time() - t0, 1), device="caller library handed in" if lib else "MI355X")))
 
 
 if __name__ == "__main__":
