@@ -34,7 +34,10 @@ k_em_wide(int n_ind, const int32_t* __restrict__ win_hap_begin, const int64_t* _
     const int w = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int h0 = win_hap_begin[w], H = win_hap_begin[w + 1] - h0;
     const int G = H * (H + 1) / 2;
-    if (H <= 0) { if (tid == 0 && out_iters) out_iters[w] = 0; return; }
+    if (H <= 0 || H > max_haps) {                      // (more haplotypes than the caller sized the LDS for: nothing is written but -1 iterations)
+        if (tid == 0 && out_iters) out_iters[w] = H <= 0 ? 0 : -1;
+        return;
+    }
     const double* L = gl + gl_off[w];
     double* em = out_em + gl_off[w];
     double* Ls = s_freq + max_haps;
