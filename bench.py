@@ -158,6 +158,148 @@ class Env:
                 os.environ[k] = v
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_launch_command(n, argv, port=None):
+    """The command `bench.py --gpus N` re-executes itself under when it was started WITHOUT a launcher: one rank per GPU of this node,
+    rendezvous on 127.0.0.1 (the reference's fan-out being replaced: runner.py:470-500, one PlatypusSingleProcess per share of the
+    region list)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+            "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def numa_cpus_of_device(torch, index):
+    """CPUs of the NUMA node the GPU hangs off (sysfs), or None when the box does not say."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        return cpus
+    except Exception:
+        return None
+
+
+def pin_rank_cpus(torch, rank, world, dev_index):
+    """Give every rank of the node its own share of the host CPUs, on the GPU's NUMA node when sysfs names it (the ranks' worker
+    threads and pinned buffers then stay local); contiguous shares of the affinity mask otherwise.  Returns the number of CPUs."""
+    if not hasattr(os, "sched_getaffinity"):
+        return os.cpu_count() or 1
+    allowed = sorted(os.sched_getaffinity(0))
+    if world <= 1 or len(allowed) < 2 * world:
+        return len(allowed)
+    mine = None
+    local = numa_cpus_of_device(torch, dev_index) if torch.cuda.is_available() else None
+    if local:
+        loc = [c for c in allowed if c in local]
+        # the ranks whose GPUs share this node split it between them: assume the usual layout (consecutive GPUs on one node)
+        per_node = max(1, world // max(1, len({tuple(sorted(numa_cpus_of_device(torch, d) or [])) for d in range(torch.cuda.device_count())})))
+        k = rank % per_node
+        share = len(loc) // per_node
+        if share >= 2:
+            mine = loc[k * share:(k + 1) * share]
+    if not mine:
+        share = len(allowed) // world
+        mine = allowed[rank * share:(rank + 1) * share]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return len(allowed)
+    return len(mine)
+
+
+class Ranks:
+    """This process as one rank of the job: RANK / LOCAL_RANK / WORLD_SIZE from the launcher, one GPU per rank, a process group over
+    RCCL (backend "nccl") -- or gloo when PLAT_DIST_BACKEND says so or the ranks have to share GPUs (a one-GPU box running the
+    two-rank path: RCCL wants one device per rank)."""
+
+    def __init__(self, want_gpus, need_gpu=True):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        ndev = torch.cuda.device_count() if (need_gpu or torch.cuda.is_available()) else 0
+        self.shared = ndev > 0 and ndev < min(self.world, int(os.environ.get("LOCAL_WORLD_SIZE", self.world)))
+        self.dev_index = self.local % ndev if ndev else 0
+        self.device = torch.device("cuda", self.dev_index) if ndev else torch.device("cpu")
+        self.backend = None
+        self.cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        if "RANK" in os.environ:                # under a launcher (also with one rank): a process group
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            self.backend = os.environ.get("PLAT_DIST_BACKEND") or ("nccl" if ndev and not self.shared else "gloo")
+            if ndev:
+                torch.cuda.set_device(self.dev_index)
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
+            self.cpus = pin_rank_cpus(torch, self.rank, self.world, self.dev_index)
+        # tensors of the collectives live where the backend wants them
+        self.coll_device = self.device if self.backend in (None, "nccl") else torch.device("cpu")
+
+    def barrier(self):
+        if self.device.type == "cuda":
+            self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def reduce(self, seconds, sums):
+        """(max over ranks of `seconds`, sums over ranks of `sums`)."""
+        torch = self.torch
+        el = torch.tensor([seconds], dtype=torch.float64, device=self.coll_device)
+        tot = torch.tensor([float(x) for x in sums], dtype=torch.float64, device=self.coll_device)
+        if self.dist is not None:
+            self.dist.all_reduce(el, op=self.dist.ReduceOp.MAX)
+            self.dist.all_reduce(tot, op=self.dist.ReduceOp.SUM)
+        return float(el.item()), [float(x) for x in tot.tolist()]
+
+    def gather(self, payload):
+        from platypus_amd import sharding
+        return sharding.gather_records(payload, self.dist, device=self.coll_device if self.coll_device.type == "cuda" else None)
+
+    def describe(self):
+        return {"ranks": self.world, "backend": self.backend, "gpus_shared_between_ranks": bool(self.shared), "cpus_per_rank": self.cpus}
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def selftest_ranks(a):
+    """`--selftest-ranks` (CPU suite): the launch path alone -- N ranks, process group, the record gather and merge, one JSON line
+    from rank 0 -- with no device work, so that `bench.py --gpus N` can be exercised where there is no GPU."""
+    from platypus_amd import sharding
+    rk = Ranks(a.gpus, need_gpu=False)
+    mine = sharding.regions_for_rank(23, rk.rank, rk.world)
+    recs = [("r%d" % g, 100 + g, "r%d\t%d\t.\tA\tC" % (g, 101 + g)) for g in mine]
+    t0 = time.perf_counter()
+    rk.barrier()
+    got = rk.gather(sharding.encode_records(recs))
+    T, (n,) = rk.reduce(time.perf_counter() - t0, [len(recs)])
+    if rk.rank == 0:
+        merged = sharding.merge_record_streams([sharding.decode_records(x) for x in got])
+        print(json.dumps({"metric": "selftest", "n_gpus": rk.world, "record_gather": dict(rk.describe(), records=len(merged)),
+                          "records_sum": n, "in_order": merged == ["r%d\t%d\t.\tA\tC" % (g, 101 + g) for g in range(23)]}))
+    rk.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,7 +307,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5), help="BASELINE config on the line (default 2, the headline)")
     ap.add_argument("--windows", type=int, default=None, help="windows per GPU per batch (config 2: 10000; config 5: 200)")
-    ap.add_argument("--regions", type=int, default=None, help="config 3: assembly tiles per step (2000); config 4: regions (64)")
+    ap.add_argument("--regions", type=int, default=None, help="config 3: assembly tiles per GPU per step (2000); config 4: regions of the WHOLE job "
+                                                              "(default 3875 per GPU), region i -> rank i %% N")
     ap.add_argument("--batches", type=int, default=8, help="distinct resident batches the steps walk through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (all-DP, hard workload, other configs)")
@@ -174,26 +317,26 @@ def main():
                          "(1 = strictly one batch at a time)")
     ap.add_argument("--sync-entry", action="store_true",
                     help="time plat_align_window_batch (two internal read-backs) instead of plat_align_window_batch_async")
+    ap.add_argument("--selftest-ranks", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # started without a launcher: become N ranks, one per GPU (the driver's N>1 form goes through torch.distributed.run itself)
+        import subprocess
+        sys.exit(subprocess.call(rank_launch_command(a.gpus, sys.argv[1:])))
+    if a.selftest_ranks:
+        return selftest_ranks(a)
+
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if "RANK" in os.environ:                    # launched by torch.distributed.run (also with one rank): RCCL process group
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    rk = Ranks(a.gpus)
+    rank, local, world, dist = rk.rank, rk.dev_index, rk.world, rk.dist
     if a.config != 2:
         from tools import bench_other
-        line = bench_other.run(a, rank, local, world, dist)
+        line = bench_other.run(a, rk)
         if rank == 0:
+            line.pop("merged_text", None)
             print(json.dumps(line))
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        rk.close()
         return
     from platypus_amd import synth
     from platypus_amd.engine import Engine
@@ -202,8 +345,8 @@ def main():
     # B distinct batches stay resident in HBM; consecutive steps go to different plat_ctx / HIP streams so that the
     # latency-bound stages of one batch (prepare, seeding, genotype) overlap the VALU-bound DP of another -- what a caller
     # streaming regions through the library does.  Every step is one full pass over one batch of `--windows` windows.
-    S = max(1, a.streams)
     B = max(1, a.batches)
+    S = max(1, min(a.streams, B))
     nwin_batch = a.windows or 10000
     engs = [Engine(local) for _ in range(S)]
     with ThreadPoolExecutor(min(B, 8)) as ex:   # (numpy releases the GIL in the generator's big array operations)
@@ -213,15 +356,13 @@ def main():
     eng, hb, db = engs[0], hbs[0], dbs[0]
     torch.cuda.synchronize()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+    barrier = rk.barrier
 
     def step(i, dbl=dbs, **kw):
-        j = i % S
+        k = i % len(dbl)
+        j = k % S                               # a batch always goes to the same stream: its output buffers are never written by two at once
         with torch.cuda.stream(streams[j]):
-            return engs[j].call_windows(dbl[i % len(dbl)], **kw)
+            return engs[j].call_windows(dbl[k], **kw)
 
     def sync_all():
         for j in range(S):
@@ -247,15 +388,9 @@ def main():
 
     def over_steps(f):                          # sum of a per-batch statistic over the K timed steps
         return float(sum(f(sts[i % B], hbs[i % B]) for i in range(a.steps)))
-    elapsed = torch.tensor([wall], dtype=torch.float64, device=eng.device)
-    tot = torch.tensor([over_steps(lambda q, h: q.cells_reference), over_steps(lambda q, h: q.cells_launched),
-                        over_steps(lambda q, h: h.n_windows), over_steps(lambda q, h: q.n_dp_reference),
-                        over_steps(lambda q, h: q.n_dp_launched)], dtype=torch.float64, device=eng.device)
-    if dist is not None:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    T = float(elapsed.item())
-    cells_ref, cells_run, nwin, ndp_ref, ndp_run = [float(x) for x in tot.tolist()]
+    T, (cells_ref, cells_run, nwin, ndp_ref, ndp_run) = rk.reduce(wall, [
+        over_steps(lambda q, h: q.cells_reference), over_steps(lambda q, h: q.cells_launched), over_steps(lambda q, h: h.n_windows),
+        over_steps(lambda q, h: q.n_dp_reference), over_steps(lambda q, h: q.n_dp_launched)])
 
     # live per-kernel timing of the dominant kernel (HIP events on the launch stream), untimed extra steps
     eng.profile_enable(True)
@@ -279,11 +414,10 @@ def main():
         recs = sharding.format_window_records(hb, db.logl.cpu().numpy(), windows=range(nrec), chrom=str(rank + 1))
         recs.sort(key=lambda r: (sharding.chrom_key(r[0]), r[1]))
         tg = time.perf_counter()
-        got = sharding.gather_records(sharding.encode_records(recs), dist, device=eng.device)
+        got = rk.gather(sharding.encode_records(recs))
         if rank == 0:
             merged = sharding.merge_record_streams([sharding.decode_records(x) for x in got])
-            gather = {"records": len(merged), "ranks": len(got), "ms": 1e3 * (time.perf_counter() - tg),
-                      "backend": dist.get_backend() if dist is not None else None}
+            gather = dict(rk.describe(), records=len(merged), ranks=len(got), ms=1e3 * (time.perf_counter() - tg))
     except Exception as exc:                    # pragma: no cover
         gather = {"error": repr(exc)[:200]}
 
@@ -389,9 +523,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hb)
         print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rk.close()
 
 
 if __name__ == "__main__":

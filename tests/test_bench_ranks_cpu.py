@@ -1,0 +1,72 @@
+"""`bench.py --gpus N` as the driver starts it for N = 1 (no launcher): it must become N ranks by itself; and the strong-scaling
+config-4 line (one region list, region i -> rank i % N, records gathered to rank 0 and merged, runner.py:454,470-500,301-352) run by
+two gloo ranks must give the text one rank gives.  No GPU here: the launch path runs without device work (`--selftest-ranks`), the
+config-4 line on tests/fakedev (the C ABI implemented with the oracle: test infrastructure, never shipped)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+REGION_KW = dict(snp_rate=3e-3, indel_rate=1e-3, read_len=100, depth=25)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    env = dict(os.environ, PLAT_DIST_BACKEND="gloo")
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-ranks"], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.split("\n") if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["record_gather"]["ranks"] == 2 and line["record_gather"]["backend"] == "gloo"
+    assert line["record_gather"]["records"] == 23 and line["in_order"]
+
+
+def test_launch_command_is_the_drivers_form():
+    import bench
+    cmd = bench.rank_launch_command(8, ["--gpus", "8", "--steps", "5"], port=29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")
+
+
+def _args(regions):
+    return SimpleNamespace(regions=regions, steps=1, warmup=1, gpus=2, config=4, windows=None)
+
+
+def _rank_worker(rank, world, port, out_path):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), PLAT_DIST_BACKEND="gloo", PLAT_CALLER_WORKERS="2", PLAT_CALLER_CHUNK="2")
+    import bench
+    from tests import fakedev
+    from tools import bench_other
+    rk = bench.Ranks(world, need_gpu=False)
+    line = bench_other.line_config4(_args(5), rk, lib=fakedev.fake_caller_lib(), region_len=3000, region_kw=REGION_KW)
+    if rank == 0:
+        json.dump(line, open(out_path, "w"))
+    rk.close()
+
+
+def test_config4_two_ranks_give_the_text_of_one_rank(tmp_path):
+    import torch.multiprocessing as mp
+    import bench
+    from tests import fakedev
+    from tools import bench_other
+    fakedev.fake_caller_lib()                                                # built once, before the ranks race for it
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "line.json")
+    mp.spawn(_rank_worker, args=(2, port, out), nprocs=2, join=True)
+    two = json.load(open(out))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    os.environ.update(PLAT_CALLER_WORKERS="2", PLAT_CALLER_CHUNK="2")
+    one = bench_other.line_config4(_args(5), bench.Ranks(1, need_gpu=False), lib=fakedev.fake_caller_lib(), region_len=3000, region_kw=REGION_KW)
+    assert two["n_gpus"] == 2 and two["record_gather"]["ranks"] == 2 and two["scaling"] == "strong"
+    assert one["n_gpus"] == 1 and one["record_gather"]["ranks"] == 1
+    assert two["merged_text"] == one["merged_text"] and one["merged_text"].count("\n") > 10
+    assert two["windows"] == one["windows"] and two["records"] == one["records"] == one["merged_text"].count("\n")

@@ -18,32 +18,39 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0
 
 
-def _time_steps(torch, fn, nsteps, dist=None):
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+class _Solo:
+    """bench.Ranks for a caller that is not one of several ranks (the default line's `other_configs`)."""
+    rank, world, dev_index, dist = 0, 1, 0, None
+
+    def barrier(self):
+        import torch
+        torch.cuda.synchronize()
+
+    def reduce(self, seconds, sums):
+        return seconds, [float(x) for x in sums]
+
+    def gather(self, payload):
+        return [payload]
+
+    def describe(self):
+        return {"ranks": 1, "backend": None, "gpus_shared_between_ranks": False}
+
+
+def _time_steps(torch, fn, nsteps, rk=None):
+    rk = rk or _Solo()
+    rk.barrier()
     t0 = time.perf_counter()
     for i in range(nsteps):
         fn(i)
     torch.cuda.synchronize()
     t = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
+    rk.barrier()
     return t
-
-
-def _reduce(torch, dist, device, T, sums):
-    el = torch.tensor([T], dtype=torch.float64, device=device)
-    tot = torch.tensor(sums, dtype=torch.float64, device=device)
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    return float(el.item()), [float(x) for x in tot.tolist()]
 
 
 # ---- config 5 -----------------------------------------------------------------------------------------------------------------
 
-def config5(eng, n_windows, n_ind, steps, warmup, seed=5005, dist=None):
+def config5(eng, n_windows, n_ind, steps, warmup, seed=5005, rk=None):
     import torch
     from platypus_amd import synth
     hb = synth.config5(n_windows, n_ind, seed=seed)
@@ -58,7 +65,7 @@ def config5(eng, n_windows, n_ind, steps, warmup, seed=5005, dist=None):
     def one(i):
         eng.call_windows(db, want_stats=False, asynchronous=True)    # likelihood arrays + Population.setup
         eng.em(db, 100, 0)                                            # Population.call: EM + callGenotypes
-    T = _time_steps(torch, one, steps, dist)
+    T = _time_steps(torch, one, steps, rk)
     eng.synchronize()
     eng.profile_enable(True)
     prof = []
@@ -77,14 +84,14 @@ def config5(eng, n_windows, n_ind, steps, warmup, seed=5005, dist=None):
                 dp_jobs=int(prof[-1].dp_jobs))
 
 
-def line_config5(a, rank, local, world, dist):
-    import torch
+def line_config5(a, rk):
     from platypus_amd.engine import Engine
-    eng = Engine(local)
+    rank, world = rk.rank, rk.world
+    eng = Engine(rk.dev_index)
     nwin = a.windows or 200
-    r = config5(eng, nwin, 100, a.steps, a.warmup, seed=5005 + rank, dist=dist)
+    r = config5(eng, nwin, 100, a.steps, a.warmup, seed=5005 + rank, rk=rk)
     st, hb = r["st"], r["hb"]
-    T, (cells, run, nw) = _reduce(torch, dist, eng.device, r["T"], [st.cells_reference * a.steps, st.cells_launched * a.steps, hb.n_windows * a.steps])
+    T, (cells, run, nw) = rk.reduce(r["T"], [st.cells_reference * a.steps, st.cells_launched * a.steps, hb.n_windows * a.steps])
     dp_ms = r["kernel_ms"]["dp"]
     ach = r["dp_alg_bytes"] / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
     return {"metric": "pair-HMM GCUPS (reference-equivalent band cells/s, read->haplotype likelihood path)", "value": cells / T / 1e9,
@@ -102,7 +109,7 @@ def line_config5(a, rank, local, world, dist):
 
 # ---- config 3 -----------------------------------------------------------------------------------------------------------------
 
-def config3(eng, n_regions, steps, warmup, seed=3003, dist=None):
+def config3(eng, n_regions, steps, warmup, seed=3003, rk=None):
     import torch
     from platypus_amd import synth
     ab = synth.config3(n_regions, seed=seed)
@@ -110,7 +117,7 @@ def config3(eng, n_regions, steps, warmup, seed=3003, dist=None):
     for _ in range(max(1, warmup)):
         eng.assemble_device(adb)
     torch.cuda.synchronize()
-    T = _time_steps(torch, lambda i: eng.assemble_device(adb), steps, dist)
+    T = _time_steps(torch, lambda i: eng.assemble_device(adb), steps, rk)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(); eng.assemble_device(adb); ev1.record(); torch.cuda.synchronize()
     res = adb.results()
@@ -121,14 +128,14 @@ def config3(eng, n_regions, steps, warmup, seed=3003, dist=None):
                 planted=sum(len(t) for t in ab["truth"]))
 
 
-def line_config3(a, rank, local, world, dist):
-    import torch
+def line_config3(a, rk):
     from platypus_amd.engine import Engine
-    eng = Engine(local)
+    rank, world = rk.rank, rk.world
+    eng = Engine(rk.dev_index)
     nreg = a.regions or 2000
     steps = min(a.steps, 50)
-    r = config3(eng, nreg, steps, a.warmup, seed=3003 + rank, dist=dist)
-    T, (regs,) = _reduce(torch, dist, eng.device, r["T"], [nreg * steps])
+    r = config3(eng, nreg, steps, a.warmup, seed=3003 + rank, rk=rk)
+    T, (regs,) = rk.reduce(r["T"], [nreg * steps])
     ach = r["alg_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9
     return {"metric": "assembly tiles/s (assembleReadsAndDetectVariants, coloured de-Bruijn graph + bubble walk)", "value": regs / T,
             "unit": "regions/s", "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": 1e3 * T / steps,
@@ -142,64 +149,86 @@ def line_config3(a, rank, local, world, dist):
                          "avg_launch_ms": r["kernel_ms"]}}
 
 
-def run(a, rank, local, world, dist):
-    return {3: line_config3, 4: line_config4, 5: line_config5}[a.config](a, rank, local, world, dist)
+def run(a, rk):
+    return {3: line_config3, 4: line_config4, 5: line_config5}[a.config](a, rk)
 
 
 # ---- config 4 -----------------------------------------------------------------------------------------------------------------
 
-def config4(device, n_regions, region_len, workers, per_chunk, first_region=0, repeats=1, n_samples=1, pin=True):
-    """The region pipeline end to end: reads of `n_regions` regions in host memory (arrays) -> VCF record text, through the native
-    region loop (libplat_caller.so: host threads + every device stage batched per chunk of regions)."""
+def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_samples=1, pin=True, lib=None, region_kw=None, rk=None):
+    """The region pipeline end to end: reads of the regions `indices` of the job's region list in host memory (arrays) -> VCF record
+    text, through the native region loop (libplat_caller.so: host threads + every device stage batched per chunk of regions); then the
+    job's one exchange: record lines to rank 0, merged there."""
     from concurrent.futures import ThreadPoolExecutor
-    from platypus_amd import fastcaller as F, synth
+    from platypus_amd import fastcaller as F, sharding, synth
     from platypus_amd.options import default_options
+    rk = rk or _Solo()
+    indices = list(indices)
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(min(16, n_regions)) as ex:
-        regs = list(ex.map(lambda i: synth.config4_region_arrays(first_region + i, region_len=region_len, n_samples=n_samples), range(n_regions)))
+    kw = dict(region_len=region_len, n_samples=n_samples, **(region_kw or {}))
+    with ThreadPoolExecutor(max(1, min(16, len(indices)))) as ex:
+        regs = list(ex.map(lambda i: synth.config4_region_arrays(i, **kw), indices))
     rr = [F.region_from_arrays(r, pin=pin) for r in regs]
     t_synth = time.perf_counter() - t0
     names = ["S%d" % (i + 1) for i in range(n_samples)]
-    nc = F.NativeCaller(device, workers, per_chunk)
+    nc = F.NativeCaller(device, workers, per_chunk, lib=lib)
     nc.call_regions(rr, names, default_options())                          # every worker's scratch buffers at full size, code paths warm
     best = None
     for _ in range(repeats):
         opts = default_options()
+        rk.barrier()
         t0 = time.perf_counter()
         text = nc.call_regions(rr, names, opts)
-        t = time.perf_counter() - t0
-        if best is None or t < best[0]:
-            best = (t, text, dict(nc.stats))
+        t1 = time.perf_counter()
+        got = rk.gather(sharding.encode_records(sharding.records_from_vcf_text(text)))
+        merged = None
+        if got is not None:
+            merged = "".join(ln + "\n" for ln in sharding.merge_record_streams([sharding.decode_records(x) for x in got]))
+        t2 = time.perf_counter()
+        rk.barrier()
+        if best is None or t2 - t0 < best[0]:
+            best = (t2 - t0, text, dict(nc.stats), t1 - t0, merged, dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=len(got) if got else None,
+                                                                         records=merged.count("\n") if merged is not None else None))
     nc.close()
-    t, text, st = best
+    t, text, st, tcall, merged, gather = best
     planted = sum(len(r["variants"]) for r in regs)
-    return dict(T=t, text=text, stats=st, regions=n_regions, region_len=region_len, reads=int(st["n_reads"]), windows=int(st["n_windows"]),
-                records=int(st["n_records"]), planted=planted, synth_s=t_synth, workers=workers, per_chunk=per_chunk)
+    return dict(T=t, T_call=tcall, text=text, merged=merged, gather=gather, stats=st, regions=len(indices), region_len=region_len,
+                reads=int(st["n_reads"]), windows=int(st["n_windows"]), records=int(st["n_records"]), planted=planted, synth_s=t_synth,
+                workers=workers, per_chunk=per_chunk)
 
 
-def line_config4(a, rank, local, world, dist):
-    import torch
-    nreg = a.regions or 64
-    workers = int(os.environ.get("PLAT_CALLER_WORKERS", "16"))
+def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
+    """STRONG scaling: ONE region list for the whole job (`--regions`, default 64 per rank), region i -> rank i % N (runner.py:473-474);
+    every rank calls its share, the record lines travel to rank 0 (sizes all-gather + point to point) and are merged by (chrom, pos)
+    (runner.py:301-352).  The timed region covers the calls, the gather and the merge."""
+    from platypus_amd import sharding
+    rank, world = rk.rank, rk.world
+    total = a.regions or 64 * world
+    mine = sharding.regions_for_rank(total, rank, world)
+    workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, getattr(rk, "cpus", 16))))))
     per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "4"))
-    pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1"
-    r = config4(local, nreg, 100000, workers, per_chunk, first_region=rank * nreg, repeats=max(1, min(a.steps, 3)), pin=pin)
-    dev = torch.device("cuda", local)
-    T, (wins, regs, recs, reads) = _reduce(torch, dist, dev, r["T"], [r["windows"], r["regions"], r["records"], r["reads"]])
+    pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1" and lib is None
+    r = config4(rk.dev_index, mine, region_len, workers, per_chunk, repeats=max(1, min(a.steps, 3)), pin=pin, lib=lib, region_kw=region_kw, rk=rk)
+    T, (wins, regs, recs, reads, tcall) = rk.reduce(r["T"], [r["windows"], r["regions"], r["records"], r["reads"], r["T_call"]])
     st = r["stats"]
-    return {"metric": "variant windows/sec end to end (reads in host memory -> VCF record text)", "value": wins / T, "unit": "windows/s",
-            "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * T, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+    line = {"metric": "variant windows/sec end to end (reads in host memory -> VCF record text)", "value": wins / T, "unit": "windows/s",
+            "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * T, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "BASELINE config 4: %d regions/GPU x 100 kb, 30x 150 bp reads, SNPs 1e-3 + indels 1e-4, one sample; step = "
+            "config": {"workload": "BASELINE config 4: %d regions x %d bp for the whole job, 30x 150 bp reads, SNPs 1e-3 + indels 1e-4, one sample; step = "
                                    "candidates -> windows -> haplotypes -> likelihoods / EM / posteriors -> INFO / FILTER -> record text for all "
-                                   "regions (native region loop, %d host threads, %d regions per chunk)" % (nreg, r["workers"], r["per_chunk"]),
-                       "regions_per_gpu": nreg, "region_len": 100000, "sharding": "regions by rank, records gathered to rank 0"},
+                                   "regions (native region loop, %d host threads, %d regions per chunk), then the gather of the record lines to "
+                                   "rank 0 and their merge" % (total, region_len, r["workers"], r["per_chunk"]),
+                       "regions": total, "region_len": region_len, "sharding": "region i -> rank i % N, records gathered to rank 0 and merged by (chrom, pos)"},
             "regions_per_sec": regs / T, "reads_per_sec": reads / T, "records": recs, "windows": wins, "planted_variants": r["planted"],
+            "seconds_calls_mean_over_ranks": tcall / world,
             "host_seconds_per_region": st["seconds_host"] / max(1, r["regions"]),
             "device_wait_seconds_per_region": st["seconds_device_wait"] / max(1, r["regions"]),
             "host_input_bytes_per_region": 2 * 150 * r["reads"] // max(1, r["regions"]), "input_blobs_pinned": pin,
             "stage_seconds_per_region": {k: v / max(1, r["regions"]) for k, v in st["seconds_stage"].items()},
-            "python_region_loop_windows_per_sec_round1": 1100.0}
+            "record_gather": r["gather"], "python_region_loop_windows_per_sec_round1": 1100.0}
+    if rank == 0:
+        line["merged_text"] = r["merged"]                                   # (popped by bench.py before printing; the tests read it)
+    return line
 
 
 def summary(eng):
@@ -216,7 +245,7 @@ def summary(eng):
     out["config3_assembler"] = dict(regions=500, reads=int(r["ab"]["n_reads"]), regions_per_sec=500 * r["steps"] / r["T"],
                                     kernel_ms=r["kernel_ms"], hbm_frac=r["alg_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                     variants_found=r["variants"], variants_planted=r["planted"])
-    r = config4(0, 64, 100000, int(os.environ.get("PLAT_CALLER_WORKERS", "16")), int(os.environ.get("PLAT_CALLER_CHUNK", "4")), repeats=3)
+    r = config4(0, range(64), 100000, int(os.environ.get("PLAT_CALLER_WORKERS", "16")), int(os.environ.get("PLAT_CALLER_CHUNK", "4")), repeats=3)
     st = r["stats"]
     out["config4_region_pipeline"] = dict(regions=r["regions"], region_len=r["region_len"], reads=r["reads"], windows=r["windows"], records=r["records"],
                                           planted_variants=r["planted"], seconds=r["T"], windows_per_sec=r["windows"] / r["T"],
