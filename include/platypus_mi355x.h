@@ -208,7 +208,7 @@ int plat_genotype_window_batch(plat_ctx* ctx, const plat_window_batch* batch, in
 /* ---- what follows the genotype likelihoods in a calling window -----------------
  * All arrays are device pointers.  Windows/haplotypes/genotypes are indexed as in
  * plat_genotype_window_batch: win_hap_begin[n_windows+1]; gl[gl_off[w] + i*G_w + g]; n_reads[w*n_ind+i]
- * = seg_n_good (Population.nReads, cpopulation.pyx:286-287).  max_haps_per_window bounds H_w (LDS size); a window with more haplotypes is left untouched and gets out_iters = -1.
+ * = seg_n_good (Population.nReads, cpopulation.pyx:286-287).  max_haps_per_window bounds H_w (LDS size); a window with more haplotypes is REFUSED: its out_iters and its out_call entries are -1, nothing else of it is written, and the next plat_stream_sync on this context returns PLAT_ERR_INVALID (no silent partial result).
  *
  * plat_em_window_batch replaces  cdef void Population.call(maxIters, ...)   cpopulation.pyx:678-703
  *   (EMiteration :384-457, callGenotypes :623-676) for every window:

@@ -46,6 +46,11 @@ struct DeviceError : std::runtime_error {
     DeviceError(int c, const std::string& where) : std::runtime_error(where + ": device error " + std::to_string(c) + " (" + plat_strerror(c) + ")"), code(c) {}
 };
 static inline void ck(int rc, const char* where) { if (rc != PLAT_OK) throw DeviceError(rc, where); }
+// errors one calling window's data can cause (retried window by window, the guilty window skipped) -- as opposed to the runtime's
+static inline bool windowClassError(int code) {
+    return code == PLAT_ERR_BAD_INPUT || code == PLAT_ERR_OVERFLOW || code == PLAT_ERR_INVALID || code == PLAT_ERR_HAP_TOO_LONG ||
+           code == PLAT_ERR_HAP_TOO_SHORT || code == PLAT_ERR_BAD_HINTS;
+}
 
 // ---- grow-only buffers: pinned host + device mirror -----------------------------------------------------------------------------
 struct Slot;                                                              // one worker's device context
@@ -1017,11 +1022,7 @@ struct Chunk {
                 klo.push_back(klo.back() + NL * nInd);
             }
         }
-        {
-            std::lock_guard<std::mutex> g(stMutex);
-            st.n_windows_called += (int64_t)wins.size();
-        }
-        if (live.empty()) return;
+        if (live.empty()) { countCalled(wins.size()); return; }
         // E: read statistics + per-site genotype calls
         const size_t nSV = svw.size(), nSites = kwin.size();
         kvih.push_back(0);
@@ -1067,7 +1068,9 @@ struct Chunk {
             }
         }
         lap(7);
+        countCalled(wins.size());                                           // (once per window: a batch that failed half way counted nothing)
     }
+    void countCalled(size_t n) { std::lock_guard<std::mutex> g(stMutex); st.n_windows_called += (int64_t)n; }
 
     // vcfINFO (vcfutils.pyx:1226-1460), vcfFILTER (:1502-1627), outputCallToVCF (:338-599), VCF.write_data (vcf.py:710-739)
     void writeWindow(RegionWork& r, WindowWork& w, const std::vector<int64_t>& klo) {
@@ -1270,13 +1273,17 @@ struct Chunk {
         try {
             callWindows(wins);
         } catch (const DeviceError& e) {
-            // one window the device refuses would take every other window of the chunk with it: call them one at a time, so that
-            // only the failing ones are skipped (what the reference's per-window try/except does, variantcaller.pyx:568-615)
+            // Only what a single WINDOW can be guilty of is retried: one window the device refuses (bad input, a haplotype too long or
+            // too short, a size that overflows) would take every other window of the chunk with it, so they are called one at a time and
+            // only the failing ones are skipped (what the reference's per-window try/except does, variantcaller.pyx:568-615).  A failing
+            // runtime, an exhausted device or a lost GPU is nobody's window: it ends plat_call_regions with that error.
+            if (!windowClassError(e.code)) throw;
             for (RegionWork* r : regions) { r->text.clear(); r->nRecords = 0; }
             for (WindowWork* w : wins) {
                 std::vector<WindowWork*> one{w};
                 try { callWindows(one); }
                 catch (const DeviceError& e2) {
+                    if (!windowClassError(e2.code)) throw;
                     logWindowFailure(regions[(size_t)regionSlot(w->region)]->in->chrom, w->startPos, w->endPos, e2.what());
                     std::lock_guard<std::mutex> g(stMutex);
                     ++st.n_windows_failed;

@@ -39,7 +39,7 @@ __device__ __forceinline__ int job_hap(const Job& j) { return j.hap & (JOB_BIGQ 
 //  bit2: quality sum above DP_SWAR_MAX_QSUM -> its DPs use the packed 16-bit adds)
 struct ReadInfo { uint32_t col, aux; int32_t pos; uint32_t lfm; };      // aux bits 0..15: number of bases with quality < LOWQ (the ungapped proof)
 constexpr unsigned LOWQ = 20u;
-enum { SHORTCUT_UNGAPPED = 1, SHORTCUT_EXACT = 2, SHORTCUT_NLOW = 4 };   // what k_seed may finish without a DP (PLAT_NO_UNGAPPED / PLAT_NO_EXACT
+enum { SHORTCUT_UNGAPPED = 1, SHORTCUT_EXACT = 2, SHORTCUT_NLOW = 4, SHORTCUT_BIGQ = 8 };   // what k_seed may finish without a DP (PLAT_NO_UNGAPPED / PLAT_NO_EXACT
                                                                          // switch them off; PLAT_NO_NLOW values unique windows by the smallest quality only)
 __device__ __forceinline__ long long job_slot(long long pair, long long npairs, int extra_base, int k) {
     return k == 0 ? pair : npairs + extra_base + (k - 1);
@@ -913,8 +913,13 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         int why = 0;                                     // (PLAT_SEED_DEBUG=512: why the pair reached the DP; counted below)
         {
             const int mq = (rflags >> 3) & 31;
+            // The proof's cost model is exact arithmetic; align.c adds in wrapping int16 ("no overflow checks", align.c:81).  A read whose
+            // quality sum allows a band cell to pass 0x7FFF (rflags bit 2, the flag that also picks the DP's add flavour, dp_core.hpp)
+            // is left to the DP, which wraps as the reference does.  (The exact-match shortcut above needs no such guard: re-biased
+            // values are unsigned, nothing is below 0, and the all-match path stays at 0 whatever the other cells do.)
+            const bool wrapfree = !(rflags & 4) || (shortcuts & SHORTCUT_BIGQ);      // (SHORTCUT_BIGQ: measurement only, PLAT_UNGAPPED_BIGQ=1)
             const bool cand = (shortcuts & SHORTCUT_UNGAPPED) && ncand == 1 && orig_in && provenA && !exact && hap_plain && s_scal[0] == 0 &&
-                              !((rflags >> 1) & 1) && cidx >= 8 && L >= 32;
+                              !((rflags >> 1) & 1) && cidx >= 8 && L >= 32 && wrapfree;
             int k = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) k += __popcll(missA[c]);
@@ -1559,8 +1564,10 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         const int no_exact = e_ex && e_ex[0] == '1';
         const char* e_dbg = getenv("PLAT_SEED_DEBUG");     // measurement only: 256 = k_seed stops after the haplotype sweep (results are garbage)
         const char* e_nl = getenv("PLAT_NO_NLOW");
+        const char* e_bq = getenv("PLAT_UNGAPPED_BIGQ");   // measurement only: lets the ungapped proof take reads in the wrap regime too (tools/ungapped_crosscheck.py --bigq)
         const int shortcuts = ((!calc_flank_score && !no_ungapped) ? SHORTCUT_UNGAPPED : 0) | (no_exact ? 0 : SHORTCUT_EXACT) |
-                              ((e_nl && e_nl[0] == '1') ? 0 : SHORTCUT_NLOW) | (e_dbg ? (atoi(e_dbg) & 0x300) : 0);
+                              ((e_nl && e_nl[0] == '1') ? 0 : SHORTCUT_NLOW) | ((e_bq && e_bq[0] == '1') ? SHORTCUT_BIGQ : 0) |
+                              (e_dbg ? (atoi(e_dbg) & 0x300) : 0);
         // the dense list of live job slots is built by the seeding kernels themselves (DENSE_SEGS segments, each able to hold every slot)
         const long long segcap = npairs + extra_cap;
         if ((rc = plat_reserve(ctx, ctx->dense, ((size_t)segcap * DENSE_SEGS + 64) * sizeof(int32_t)))) return rc;

@@ -1,6 +1,7 @@
 // plat_ctx.hip -- context, memory helpers and error strings of libplat_mi355x.so.
 #include <math.h>
 
+#include <algorithm>
 #include "plat_internal.hpp"
 
 PLAT_EXPORT int plat_abi_version(void) { return PLAT_ABI_VERSION; }
@@ -42,7 +43,8 @@ PLAT_EXPORT int plat_ctx_create(int device, plat_ctx** out_ctx) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return PLAT_ERR_NO_DEVICE; }
     ctx->n_cu = prop.multiProcessorCount;
-    ctx->lds_max = prop.sharedMemPerBlock;
+    // LDS one workgroup may ask for (160 KB on gfx950; the opt-in figure where the runtime reports a smaller default)
+    ctx->lds_max = std::max<size_t>(prop.sharedMemPerBlock, std::max<size_t>(prop.sharedMemPerBlockOptin, prop.maxSharedMemoryPerMultiProcessor));
     // probMapRight table: host libm, identical to the reference's own log/exp (chaplotype.pyx:621)
     double lut[256];
     const double mLTOT = -0.23025850929940459;

@@ -76,7 +76,7 @@ k_genotype(plat_window_batch b, int n_ind, long long n_units, const int32_t* __r
                 const bool in = summing && r0 + k < s1;
                 v1[k] = in ? arr1[r0 + k] : 0.0; v2[k] = in ? arr2[r0 + k] : 0.0;
                 const double d = fabs(v1[k] - v2[k]);
-                if (in && a != bb && d < 3 && d > 1e-3) slow |= 1u << k;
+                if (in && a != bb && !(d >= 3) && !(d <= 1e-3)) slow |= 1u << k;   // exactly the adds' last branch below (NaN included)
             }
             int total;
             const int pre = geno_wave_prefix(__popc(slow), total);
@@ -97,9 +97,9 @@ k_genotype(plat_window_batch b, int n_ind, long long n_units, const int32_t* __r
                 const double ll1 = log10E * l1, ll2 = log10E * l2;
                 gsum += (ll1 > ll2 ? ll1 : ll2);
                 if (a == bb) like += l1;
+                else if (slow >> k & 1) like += s_q1[j++];                   // the queued term: the class is decided once, above
                 else if (fabs(l1 - l2) >= 3) like += (logHalf + (l1 > l2 ? l1 : l2));
-                else if (fabs(l1 - l2) <= 1e-3) like += l1;
-                else like += s_q1[j++];
+                else like += l1;
             }
             if (total > 0) __syncthreads();         // the queue is rewritten by the next block
         }

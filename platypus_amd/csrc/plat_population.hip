@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256)
 k_em_wide(int n_ind, const int32_t* __restrict__ win_hap_begin, const int64_t* __restrict__ gl_off,
           const int32_t* __restrict__ n_reads, const double* __restrict__ gl, int max_iters, int use_em,
           double* __restrict__ out_freq, double* __restrict__ out_em, int32_t* __restrict__ out_call,
-          int32_t* __restrict__ out_iters, int max_haps, int maxG, int use_streams)
+          int32_t* __restrict__ out_iters, int max_haps, int maxG, int use_streams, long long* sticky)
 {
     extern __shared__ double s_freq[];                 // [max_haps] | Ls [n_ind][G] | rsp [n_ind][G] | csum [n_ind] | streams | nr, gs, gr
     __shared__ unsigned long long s_change;
@@ -34,8 +34,14 @@ k_em_wide(int n_ind, const int32_t* __restrict__ win_hap_begin, const int64_t* _
     const int w = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int h0 = win_hap_begin[w], H = win_hap_begin[w + 1] - h0;
     const int G = H * (H + 1) / 2;
-    if (H <= 0 || H > max_haps) {                      // (more haplotypes than the caller sized the LDS for: nothing is written but -1 iterations)
+    if (H <= 0 || H > max_haps) {
+        // more haplotypes than the caller sized the LDS for: the window is refused -- calls and iterations -1, and the error is left
+        // in the context's sticky word, so that the next plat_stream_sync fails (a caller that never reads out_iters sees it too)
         if (tid == 0 && out_iters) out_iters[w] = H <= 0 ? 0 : -1;
+        if (H > max_haps) {
+            for (int i = tid; i < n_ind; i += nthr) out_call[(long long)w * n_ind + i] = -1;
+            if (tid == 0 && *sticky == 0) *sticky = PLAT_ERR_INVALID;
+        }
         return;
     }
     const double* L = gl + gl_off[w];
@@ -189,13 +195,19 @@ __global__ void __launch_bounds__(64)
 k_em(int n_ind, const int32_t* __restrict__ win_hap_begin, const int64_t* __restrict__ gl_off,
      const int32_t* __restrict__ n_reads, const double* __restrict__ gl, int max_iters, int use_em,
      double* __restrict__ out_freq, double* __restrict__ out_em, int32_t* __restrict__ out_call,
-     int32_t* __restrict__ out_iters, int max_haps, int csr_in_lds)
+     int32_t* __restrict__ out_iters, int max_haps, int csr_in_lds, long long* sticky)
 {
     extern __shared__ double s_freq[];                 // [max_haps], then (csr_in_lds) the responsibilities [n_ind][G] of this window
     const int w = blockIdx.x, lane = threadIdx.x;
     const int h0 = win_hap_begin[w], H = win_hap_begin[w + 1] - h0;
     const int G = H * (H + 1) / 2;
     if (H <= 0) { if (lane == 0 && out_iters) out_iters[w] = 0; return; }
+    if (H > max_haps) {                                // refused as k_em_wide refuses it (the frequencies would not fit the LDS carve)
+        if (lane == 0 && out_iters) out_iters[w] = -1;
+        for (int i = lane; i < n_ind; i += 64) out_call[(long long)w * n_ind + i] = -1;
+        if (lane == 0 && *sticky == 0) *sticky = PLAT_ERR_INVALID;
+        return;
+    }
     const double* L = gl + gl_off[w];
     double* em = out_em + gl_off[w];
     // The M-step is a serial chain per haplotype over all individuals (the reference's order of additions); reading the
@@ -535,25 +547,26 @@ PLAT_EXPORT int plat_em_window_batch(plat_ctx* ctx, int n_windows, int n_ind, in
     // likelihoods and responsibilities of one window in LDS when they fit: k_em_wide
     const size_t wide = (size_t)max_haps_per_window * 8 + 2 * csr_bytes + (size_t)n_ind * 12 + maxG * 4 + 64;
     const bool no_wide = getenv("PLAT_EM_NARROW") != nullptr;             // (read per call: the one-wave kernel, for measurements and the cross-check test)
-    if (wide <= 96 * 1024 && max_haps_per_window < 32768 && !no_wide) {
+    const size_t lds_dev = ctx->lds_max ? ctx->lds_max : 64 * 1024;     // what a workgroup of this device may ask for (160 KB on gfx950)
+    if (wide <= 96 * 1024 && wide <= lds_dev && max_haps_per_window < 32768 && !no_wide) {
         const size_t pairs = (size_t)n_ind * maxG;
         const int threads = pairs > 128 ? 256 : (pairs > 64 ? 128 : 64);
         const size_t streams = (size_t)max_haps_per_window * (((size_t)n_ind * (max_haps_per_window + 1) + 7) & ~(size_t)7) * 8;
-        const int use_streams = wide + streams <= 150 * 1024;
+        const int use_streams = wide + streams <= 150 * 1024 && wide + streams <= lds_dev;
         const size_t lds_wide = wide + (use_streams ? streams : 0);
         if (lds_wide > 48 * 1024)
             PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_em_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide));
         hipLaunchKernelGGL(k_em_wide, dim3(n_windows), dim3(threads), lds_wide, (hipStream_t)stream, n_ind, win_hap_begin, gl_off, n_reads, gl,
-                           max_iters, use_em_likelihoods, out_freq, out_em, out_call, out_iters, max_haps_per_window, (int)maxG, use_streams);
+                           max_iters, use_em_likelihoods, out_freq, out_em, out_call, out_iters, max_haps_per_window, (int)maxG, use_streams, (long long*)ctx->d_sticky);
         PLAT_HIP(ctx, hipGetLastError());
         return PLAT_OK;
     }
-    const int csr_in_lds = n_ind >= 8 && lds + csr_bytes <= 60 * 1024;   // responsibilities of one window next to the frequencies (pays with many samples)
+    const int csr_in_lds = n_ind >= 8 && lds + csr_bytes <= 60 * 1024 && lds + csr_bytes <= lds_dev;   // responsibilities of one window next to the frequencies (pays with many samples)
     if (csr_in_lds) lds += csr_bytes;
     if (lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_em, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_em, dim3(n_windows), dim3(64), lds, (hipStream_t)stream, n_ind, win_hap_begin, gl_off, n_reads, gl,
-                       max_iters, use_em_likelihoods, out_freq, out_em, out_call, out_iters, max_haps_per_window, csr_in_lds);
+                       max_iters, use_em_likelihoods, out_freq, out_em, out_call, out_iters, max_haps_per_window, csr_in_lds, (long long*)ctx->d_sticky);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }

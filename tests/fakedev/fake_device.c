@@ -69,7 +69,18 @@ API int plat_memcpy_d2h(plat_ctx* c, void* d, const void* s, size_t n, void* st)
 API int plat_memset(plat_ctx* c, void* d, int v, size_t n, void* st) { (void)c; (void)st; if (n) memset(d, v, n); return PLAT_OK; }
 API int plat_stream_create(plat_ctx* c, void** out) { (void)c; *out = (void*)(uintptr_t)0x10; return PLAT_OK; }
 API int plat_stream_destroy(plat_ctx* c, void* s) { (void)c; (void)s; return PLAT_OK; }
-API int plat_stream_sync(plat_ctx* c, void* s) { (void)s; int e = c->sticky; c->sticky = 0; return e; }
+/* fault injection for the host-side error handling: PLAT_FAKE_FAIL_SYNC="<code>:<n>" makes the n-th plat_stream_sync of the process
+ * (counted from 1, over all contexts) return <code> */
+static int g_sync_calls = 0;
+API int plat_stream_sync(plat_ctx* c, void* s) {
+    (void)s;
+    int e = c->sticky; c->sticky = 0;
+    const char* f = getenv("PLAT_FAKE_FAIL_SYNC");
+    const int k = __sync_add_and_fetch(&g_sync_calls, 1);
+    if (f) { int code = 0, nth = 0; if (sscanf(f, "%d:%d", &code, &nth) == 2 && k == nth) return code; }
+    return e;
+}
+API void plat_fake_reset_sync_count(void) { g_sync_calls = 0; }
 API int plat_profile_enable(plat_ctx* c, int on) { (void)c; (void)on; return PLAT_OK; }
 API int plat_profile_last(plat_ctx* c, plat_profile* p) { (void)c; memset(p, 0, sizeof(*p)); return PLAT_OK; }
 API int plat_dp_batch(plat_ctx* c, int n, int lmax, const uint8_t* a, const uint8_t* b, const uint8_t* q, const uint8_t* g,

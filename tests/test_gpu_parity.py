@@ -511,19 +511,21 @@ def test_dp_add_flavours_agree_with_oracle(eng, oracle):
     assert sc.max() > 1000                                                   # costs far beyond anything config 2 produces
 
 
-def _adversarial_batch(seed, n_windows=260, gapped=False):
+def _adversarial_batch(seed, n_windows=260, gapped=False, bigq=False):
     """Windows built to stress k_seed's ungapped-alignment proof: references with homopolymers and tandem repeats (cheap gaps,
     non-unique k-mers) and N runs, reads of 36..250 bp with 0..3 substitutions anywhere -- first and last bases included --, read
     N's, low-quality tails, quality minima down to 0, haplotypes differing by SNPs next to repeats.  gapped: a third of the reads
     also carry a 1..4 base insertion or deletion (often within 20 bases of an end, where the ungapped alignment shows only a
-    few mismatches and a gapped one is cheaper), a third a tight cluster of 2..4 substitutions, and qualities reach 41 more often."""
+    few mismatches and a gapped one is cheaper), a third a tight cluster of 2..4 substitutions, and qualities reach 41 more often.
+    bigq: the WRAP regime of align.c's int16 adds (align.c:81 "no overflow checks"): reads of 150 / 250 bp with qualities 60..93
+    (quality sums 9 000 .. 23 000, most above dp_core.hpp's 15 000), homopolymers of 45..70 bases (gap-open penalties down to 1)."""
     from platypus_amd import hostapi as H
     rng = np.random.default_rng(seed)
     B = b"ACGT"
     rnd = lambda n: bytes(rng.choice(list(B), n).astype(np.uint8))
     specs = []
     for w in range(n_windows):
-        L = int(rng.choice([36, 76, 100, 150, 150, 250]))
+        L = int(rng.choice([150, 250, 250, 250])) if bigq else int(rng.choice([36, 76, 100, 150, 150, 250]))
         buf = min(2 * L, 500)
         W = int(rng.integers(20, 80))
         ref = bytearray(rnd(W + 2 * buf + 40))
@@ -531,6 +533,9 @@ def _adversarial_batch(seed, n_windows=260, gapped=False):
             p = int(rng.integers(0, len(ref) - 60)); k = int(rng.integers(3, 40))
             u = rnd(int(rng.choice([1, 1, 1, 2, 3, 4, 6])))
             ref[p:p + k] = (u * k)[:k]
+        if bigq and rng.random() < 0.5:                          # a long homopolymer near the window: gap-open penalties 1..3
+            k = int(rng.integers(45, 70)); p = int(rng.integers(buf - 60, buf + W))
+            ref[p:p + k] = rnd(1) * k
         if rng.random() < 0.12:                                  # haplotype N's (cost 0 in the DP): the proof must stand aside
             p = int(rng.integers(0, len(ref) - 8)); ref[p:p + int(rng.integers(1, 6))] = b"N" * 5
         ref = bytes(ref[:W + 2 * buf + 40])
@@ -572,7 +577,10 @@ def _adversarial_batch(seed, n_windows=260, gapped=False):
             if rng.random() < 0.05:
                 seq[int(rng.integers(0, L))] = ord("N")          # read N: costs its quality against any base
             q = np.clip(rng.normal(36 if gapped else 33, 6, L), 1, 41 if gapped else 60).astype(np.uint8)
-            mode = rng.random()
+            if bigq:
+                lo = int(rng.choice([60, 60, 70, 85]))
+                q = rng.integers(lo, 94, L).astype(np.uint8)
+            mode = rng.random() if not bigq else 0.2 + 0.8 * rng.random()
             if mode < 0.2:
                 q[L - int(rng.integers(1, 30)):] = rng.integers(1, 12, 1)[0]
             elif mode < 0.3:
@@ -621,6 +629,30 @@ def test_ungapped_shortcut_equals_the_dp_everywhere(eng, oracle):
         assert res["all"][3] == res["0"][3] and res["all"][2] >= 0.98 * res["all"][3]
         used += res["1"][2] - res["0"][2]
     assert used > 10000
+    # the wrap regime of the reference's int16 adds (quality sums above 15 000): the ungapped proof stands aside for these reads
+    # (its cost model is exact arithmetic), the exact-match shortcut does not have to; the DP wraps as align.c does.  Same scores
+    # with the shortcuts, without them, and from the oracle.
+    for seed, gp in ((21, False), (22, True)):
+        hb = _adversarial_batch(seed, 60, gapped=gp, bigq=True)
+        assert (np.add.reduceat(hb.read_qual.astype(np.int64), hb.read_off[:-1]) > 15000).mean() > 0.4
+        res = {}
+        for mode, env in (("0", {}), ("all", {"PLAT_NO_UNGAPPED": "1", "PLAT_NO_EXACT": "1"})):
+            os.environ.update(env)
+            try:
+                db = eng.upload(hb)
+                st = eng.align(db, want_stats=True)
+                eng.synchronize()
+                res[mode] = (db.score.cpu().numpy()[:hb.n_pairs].copy(), db.loglik.cpu().numpy()[:hb.n_pairs].copy(), int(st.n_dp_launched))
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+        assert np.array_equal(res["0"][0], res["all"][0]) and np.array_equal(res["0"][1], res["all"][1])
+        assert res["0"][2] < res["all"][2]
+        for w in range(0, hb.n_windows, 3):
+            rd = hb.window_reads(w)
+            exp = oracle.align_window(hb.window_haps(w), int(hb.win_start[w]), int(hb.win_end[w]), int(hb.win_flank[w]), rd)
+            R, H_ = len(rd["seq"]), hb.win_hap_begin[w + 1] - hb.win_hap_begin[w]
+            assert np.array_equal(res["0"][1][hb.pair_off[w]:hb.pair_off[w] + H_ * R].reshape(H_, R), np.asarray(exp[0]).reshape(H_, R))
     hb = _adversarial_batch(3, 40, gapped=True)
     db = eng.upload(hb)
     eng.align(db, want_stats=False)

@@ -173,3 +173,32 @@ def test_reference_call_blocks_batched_equals_window_by_window(fake):
             f = ln.split("\t")
             info = dict(kv.split("=") for kv in f[7].split(";"))
             assert int(info["Size"]) == int(info["END"]) - (int(f[1]) - 1) and f[4] in ("N", "T") and f[9].startswith("./.:-1,-1,-1:-1:-1:")
+
+
+def test_runtime_errors_end_the_call_and_window_errors_skip_the_window(fake, monkeypatch):
+    """A device error that no single window can be guilty of (HIP runtime, out of memory) in the window batch must end plat_call_regions
+    with that code -- not be swallowed window by window with PLAT_OK and records missing; an input-class error is retried per window
+    and only costs the windows that fail again (variantcaller.pyx:568-615)."""
+    import ctypes as C
+    from platypus_amd._lib import PlatypusDeviceError
+    from tests import fakedev
+    dev = C.CDLL(fakedev.FAKE_LIB)
+    regs = [synth.config4_region(500, n_samples=1, region_len=3000, snp_rate=4e-3, indel_rate=1e-3, read_len=100, depth=30)]
+    fasta, work = _work(regs, ["S1"])
+    rr = [F.RegionReads.from_buffers(c, s, e, fasta, b) for c, s, e, b in work]
+    nc = F.NativeCaller(0, 1, 1, lib=fake)
+    good = nc.call_regions(rr, ["S1"], default_options())
+    assert good.count("\n") > 5 and nc.stats["n_windows_called"] == nc.stats["n_windows"]
+    # syncs of a chunk: 1 = candidate scan, 2 = window batch (no greedy rounds here)
+    for code in (-2, -3):                                                    # PLAT_ERR_HIP, PLAT_ERR_NOMEM
+        dev.plat_fake_reset_sync_count()
+        monkeypatch.setenv("PLAT_FAKE_FAIL_SYNC", "%d:2" % code)
+        with pytest.raises(PlatypusDeviceError) as e:
+            nc.call_regions(rr, ["S1"], default_options())
+        assert e.value.code == code
+    dev.plat_fake_reset_sync_count()
+    monkeypatch.setenv("PLAT_FAKE_FAIL_SYNC", "-9:2")                        # PLAT_ERR_BAD_INPUT once: the retry goes through
+    again = nc.call_regions(rr, ["S1"], default_options())
+    assert again == good and nc.stats["n_windows_failed"] == 0 and nc.stats["n_windows_called"] == nc.stats["n_windows"]
+    monkeypatch.delenv("PLAT_FAKE_FAIL_SYNC")
+    nc.close()
