@@ -193,6 +193,9 @@ cdef extern from "platypus_mi355x.h":
                            int32_t* out_reason, void* stream) nogil
 
     # ---- window read slices out of a resident read table (cwindow.pyx:208-264,655-689)
+    # the read table of a loader that wrote one byte per base (2-bit base | quality << 2) expanded to ASCII on the device
+    int plat_unpack_reads(plat_ctx* ctx, int64_t n_bytes, const uint8_t* packed, uint8_t* out_seq, uint8_t* out_qual, int64_t n_exc,
+                          const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream) nogil
     int plat_gather_reads(plat_ctx* ctx, int64_t n_dst, const int32_t* src_index, const int64_t* dst_off, const uint8_t* src_seq,
                           const uint8_t* src_qual, const int64_t* src_off, const int32_t* src_pos, const int32_t* src_end,
                           const uint8_t* src_mapq, const int32_t* src_flags, uint8_t* dst_seq, uint8_t* dst_qual, int32_t* dst_pos,

@@ -20,8 +20,7 @@
  * window or one batch at a time and is what the parity tests compare this library with.
  *
  * Plain C: pointers and sizes, int status (0 = ok, negative = error of platypus_mi355x.h), no exceptions.
- * All pointers here are HOST pointers.  Not built: reference-call blocks (outputRefCalls), source VCFs,
- * assembler candidates (assemble=1) -- PLAT_ERR_UNSUPPORTED, use the Python layer for those.
+ * All pointers here are HOST pointers.  Not built: source VCFs (PLAT_ERR_UNSUPPORTED).
  */
 #ifndef PLATYPUS_CALLER_H
 #define PLATYPUS_CALLER_H
@@ -33,11 +32,23 @@
 extern "C" {
 #endif
 
+/* How the bases and qualities of a plat_read_table are stored.
+ *   PLAT_READS_ASCII   seq = 7-bit ASCII bases, qual = raw phred bytes: what cAlignedRead holds after the loader's decode loop
+ *                      (htslibWrapper.pyx:330-370: one pass over every base, 4-bit BAM code -> letter, quality byte copied): 2 bytes
+ *                      per base cross the host-to-device link.
+ *   PLAT_READS_PACKED  seq = ONE byte per base: bits 0..1 the base ((letter >> 1) & 3: A 0, C 1, T 2, G 3), bits 2..7 the quality
+ *                      (0..63); `qual` is not read.  Bases other than A/C/G/T and qualities above 63 are listed as exceptions
+ *                      (exc_index = byte index into seq, ascending; exc_base / exc_qual = the real letter and quality; the packed
+ *                      byte under an exception is ignored).  Same cost for the loader -- its decode loop writes this byte instead of
+ *                      two -- and half the bytes on the link; the device expands the table to ASCII once (plat_unpack_reads), so
+ *                      every kernel downstream sees what it sees with PLAT_READS_ASCII and the records are the same. */
+enum { PLAT_READS_ASCII = 0, PLAT_READS_PACKED = 1 };
+
 /* One ReadArray (cwindow.pyx:92-236) as arrays: cAlignedRead fields (htslibWrapper.pxd:187-201) of n_reads reads.
- * seq / qual: byte blobs (7-bit ASCII bases, raw phred), read r at [off[r], off[r+1]); both followed by >= 32
+ * seq / qual: byte blobs (see `encoding`), read r at [off[r], off[r+1]); both followed by >= 32
  * readable bytes.  cigar: (op, length) int16 pairs, read r owns pairs [cig_off[r], cig_off[r+1]). */
 typedef struct plat_read_table {
-    int32_t n_reads, _pad;
+    int32_t n_reads, encoding;  /* PLAT_READS_* */
     const uint8_t* seq;
     const uint8_t* qual;
     const int64_t* off;        /* [n_reads+1] */
@@ -48,6 +59,10 @@ typedef struct plat_read_table {
     const int32_t* mate_pos;   /* matePos (orders brokenMates) */
     const int16_t* cigar;
     const int32_t* cig_off;    /* [n_reads+1], in pairs */
+    int64_t n_exceptions;      /* PLAT_READS_PACKED only */
+    const int64_t* exc_index;
+    const uint8_t* exc_base;
+    const uint8_t* exc_qual;
 } plat_read_table;
 
 /* One bamReadBuffer (cwindow.pyx:485-513): reads and badReads sorted by pos, brokenMates sorted by mate_pos
@@ -97,6 +112,10 @@ typedef struct plat_caller_stats {
      * haplotypes (host), 3 greedy haplotype filter rounds, 4 window batch (pack, likelihoods, EM), 5 posteriors,
      * 6 read statistics + genotype calls, 7 INFO / FILTER / text */
     double seconds_stage[8];
+    /* plat_call_regions_stream: sum over loader threads of time inside the source's load function; sum over worker threads of time
+     * spent waiting for a loaded chunk (a source slower than the callers shows up here); input bytes handed over (bases + qualities) */
+    double seconds_load, seconds_source_wait;
+    int64_t input_bytes;
 } plat_caller_stats;
 
 typedef struct plat_caller plat_caller;
@@ -112,6 +131,18 @@ int plat_caller_destroy(plat_caller* c);
 int plat_call_regions(plat_caller* c, const plat_region* regions, int n_regions, int n_samples,
                       const char* const* sample_names, plat_caller_options* options, char** out_text,
                       size_t* out_len, plat_caller_stats* stats /* may be NULL */);
+/* The same call for a region list that is LOADED ON DEMAND -- the reference's own shape: PlatypusSingleProcess.run walks its share of the
+ * region list and loads the reads of one region at a time (loadBAMData, variantcaller.pyx:935-1012; bufferSize = 100 kb) before calling
+ * it.  `load` is the loader: called from n_loader_threads threads of the library, concurrently for different regions, it fills *out for
+ * region `index` (0-based position in the list) with pointers into memory the SOURCE owns; `slot` in [0, n_slots) names the reusable
+ * buffer the source should use -- the library hands a slot out again only when the chunk of the region that held it is finished, so
+ * n_slots bounds the reads in flight (a bounded queue: loaders run ahead of the callers by at most the free slots).  Needs
+ * n_slots >= regions_per_chunk * (n_workers + 1).  A load that returns non-zero ends the call with that code.  Regions are called in
+ * chunks in list order; options->rlen follows the regions in list order exactly as in plat_call_regions; the text is the same. */
+typedef int (*plat_region_load_fn)(void* user, int index, int slot, plat_region* out);
+int plat_call_regions_stream(plat_caller* c, int n_regions, int n_samples, const char* const* sample_names,
+                             plat_caller_options* options, plat_region_load_fn load, void* user, int n_slots,
+                             int n_loader_threads, char** out_text, size_t* out_len, plat_caller_stats* stats /* may be NULL */);
 void plat_caller_free(void* p);
 /* Human-readable message of the last error of a failing plat_call_regions on this caller. */
 const char* plat_caller_last_error(const plat_caller* c);

@@ -397,6 +397,16 @@ int plat_variant_read_stats_batch(plat_ctx* ctx, const plat_infostats_batch* bat
                                   int count_only_exact_indel_matches, int64_t* out_counts, int32_t* out_per_sample,
                                   int32_t* out_minq, int32_t* out_nminq, void* stream);
 
+/* ---- read tables that crossed the link at one byte per base --------------------------------------------
+ * The loader's decode loop (htslibWrapper.pyx:330-370: 4-bit BAM code -> letter, quality byte copied, one pass over every base)
+ * may write ONE byte per base instead of two: bits 0..1 = (letter >> 1) & 3 (A 0, C 1, T 2, G 3), bits 2..7 = quality 0..63
+ * (PLAT_READS_PACKED of include/platypus_caller.h).  plat_unpack_reads expands n_bytes such bytes to the ASCII base and raw
+ * quality arrays every other entry point takes (out_seq / out_qual [n_bytes]), then patches the n_exc exceptions (bases other
+ * than A/C/G/T, qualities above 63): out_seq[exc_index[k]] = exc_base[k], out_qual[exc_index[k]] = exc_qual[k].  All device
+ * pointers; exc_* may be NULL when n_exc == 0.                                                                          */
+int plat_unpack_reads(plat_ctx* ctx, int64_t n_bytes, const uint8_t* packed, uint8_t* out_seq, uint8_t* out_qual,
+                      int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream);
+
 /* ---- window read slices out of a resident read table ---------------------------------------------
  * Replaces the per-window walk over  bamReadBuffer.reads / badReads / brokenMates  between the window
  * pointers (cwindow.pyx:208-264,655-689) that feeds Haplotype.alignReads: the reads of a whole region are

@@ -108,6 +108,7 @@ SIGNATURES = {
     "plat_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "plat_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "plat_gather_reads": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 16),
+    "plat_unpack_reads": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "plat_profile_last": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
     "plat_dp_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

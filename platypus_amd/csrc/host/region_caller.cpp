@@ -22,6 +22,7 @@
 // stages of different chunks overlap.  Same text as platypus_amd/caller.py::callVariantsInRegions (tests/test_native_caller_*.py).
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <deque>
 #include <memory>
@@ -86,8 +87,10 @@ typedef Staged<uint8_t> Arena;
 struct Slot {
     plat_ctx* ctx = nullptr;
     void* stream = nullptr;
-    // chunk read table (device): bases, qualities, offsets, per-read fields, CIGARs
-    Staged<uint8_t> t_seq, t_qual, t_mapq;
+    // chunk read table (device): bases, qualities, offsets, per-read fields, CIGARs; t_pack: the bytes of PLAT_READS_PACKED tables as
+    // they crossed the link (expanded into t_seq / t_qual by plat_unpack_reads), t_exc*: their exceptions
+    Staged<uint8_t> t_seq, t_qual, t_mapq, t_pack, t_excb, t_excq;
+    Staged<int64_t> t_excidx;
     Staged<int64_t> t_off;
     Staged<int32_t> t_pos, t_end, t_flags, t_cigoff, t_region;
     Staged<int16_t> t_cigar;
@@ -167,6 +170,19 @@ struct TableView {
     int rlen(int i) const { return (int)(t->off[i + 1] - t->off[i]); }
 };
 struct SampleView { TableView reads, bad, broken; };
+
+// `n` bases of a read table from byte `at` of its blob, as letters (the host only ever needs the few inserted bases of candidates)
+static std::string tableBases(const plat_read_table& t, int64_t at, int n) {
+    std::string out((size_t)std::max(n, 0), 'A');
+    if (n <= 0) return out;
+    if (t.encoding != PLAT_READS_PACKED) { memcpy(&out[0], t.seq + at, (size_t)n); return out; }
+    for (int i = 0; i < n; ++i) out[(size_t)i] = "ACTG"[t.seq[at + i] & 3];
+    if (t.n_exceptions > 0) {
+        const int64_t* e = std::lower_bound(t.exc_index, t.exc_index + t.n_exceptions, at);
+        for (; e < t.exc_index + t.n_exceptions && *e < at + n; ++e) out[(size_t)(*e - at)] = (char)t.exc_base[e - t.exc_index];
+    }
+    return out;
+}
 
 static int longestRead(const plat_read_table& t) {
     int m = 0;
@@ -428,25 +444,35 @@ struct Chunk {
 
     // -- A: one device table for every read of the chunk; layout: all `reads` of every (region, sample), then all badReads, then all brokenMates
     void uploadReads() {
-        size_t nReads[3] = {0, 0, 0}, nBytes[3] = {0, 0, 0}, nCig[3] = {0, 0, 0};
+        size_t nReads[3] = {0, 0, 0}, nBytes[3] = {0, 0, 0}, nCig[3] = {0, 0, 0}, nExc = 0, nTables = 0;
+        bool anyPacked = false;
         for (RegionWork* r : regions)
             for (SampleView& sv : r->samples) {
                 TableView* tv[3] = {&sv.reads, &sv.bad, &sv.broken};
                 for (int k = 0; k < 3; ++k) {
-                    nReads[k] += (size_t)tv[k]->n();
-                    nBytes[k] += (size_t)tv[k]->t->off[tv[k]->n()];
-                    nCig[k] += (size_t)tv[k]->t->cig_off[tv[k]->n()];
+                    const plat_read_table& t = *tv[k]->t;
+                    nReads[k] += (size_t)t.n_reads;
+                    nBytes[k] += (size_t)t.off[t.n_reads];
+                    nCig[k] += (size_t)t.cig_off[t.n_reads];
+                    ++nTables;
+                    if (t.encoding == PLAT_READS_PACKED) { anyPacked = true; nExc += (size_t)std::max<int64_t>(t.n_exceptions, 0); }
+                    else if (t.encoding != PLAT_READS_ASCII) throw DeviceError(PLAT_ERR_INVALID, "plat_read_table.encoding");
                 }
             }
-        const size_t N = nReads[0] + nReads[1] + nReads[2], B = nBytes[0] + nBytes[1] + nBytes[2], Cg = nCig[0] + nCig[1] + nCig[2];
+        // every table starts on a 16-byte boundary of the chunk blob (the expanding kernel moves 16 bytes per lane)
+        const size_t N = nReads[0] + nReads[1] + nReads[2], B = nBytes[0] + nBytes[1] + nBytes[2] + 16 * nTables, Cg = nCig[0] + nCig[1] + nCig[2];
         if (N > 0x7FFFFFF0ull) throw DeviceError(PLAT_ERR_OVERFLOW, "chunk read table");
         Slot& z = s;
         z.t_seq.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream); z.t_qual.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream);
+        if (anyPacked) z.t_pack.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream);
         Layout L;
         L.add(z.t_off, N + 1); L.add(z.t_pos, N + 1); L.add(z.t_end, N + 1); L.add(z.t_flags, N + 1); L.add(z.t_mapq, N + 1); L.add(z.t_cigoff, N + 1);
         L.add(z.t_cigar, 2 * Cg + 2); L.add(z.t_region, nReads[0] + 1);
+        L.add(z.t_excidx, nExc + 1); L.add(z.t_excb, nExc + 1); L.add(z.t_excq, nExc + 1);
         L.commit(z, z.a_tab);
-        size_t ri = 0, bo = 0, co = 0;
+        struct Pending { size_t bo, nb, e0, ne; };
+        std::vector<Pending> packed;
+        size_t ri = 0, bo = 0, co = 0, eo = 0, inBytes = 0;
         int scan = 0;
         for (int k = 0; k < 3; ++k) {
             scan = 0;
@@ -457,9 +483,17 @@ struct Chunk {
                     const int n = t.n_reads;
                     tv.base = (int64_t)ri;
                     const size_t nb = (size_t)t.off[n], nc = (size_t)t.cig_off[n];
-                    if (nb) {                                              // bases and qualities go straight from the caller's memory
+                    bo = (bo + 15) & ~(size_t)15;
+                    if (nb && t.encoding == PLAT_READS_PACKED) {            // one byte per base crosses the link; expanded below
+                        ck(plat_memcpy_h2d(z.ctx, z.t_pack.d + bo, t.seq, nb, z.stream), "plat_memcpy_h2d(packed)");
+                        const size_t ne = (size_t)std::max<int64_t>(t.n_exceptions, 0);
+                        for (size_t e = 0; e < ne; ++e) { z.t_excidx.h[eo + e] = t.exc_index[e]; z.t_excb.h[eo + e] = t.exc_base[e]; z.t_excq.h[eo + e] = t.exc_qual[e]; }
+                        packed.push_back(Pending{bo, nb, eo, ne});
+                        eo += ne; inBytes += nb + 10 * ne;
+                    } else if (nb) {                                       // bases and qualities go straight from the caller's memory
                         ck(plat_memcpy_h2d(z.ctx, z.t_seq.d + bo, t.seq, nb, z.stream), "plat_memcpy_h2d(seq)");
                         ck(plat_memcpy_h2d(z.ctx, z.t_qual.d + bo, t.qual, nb, z.stream), "plat_memcpy_h2d(qual)");
+                        inBytes += 2 * nb;
                     }
                     for (int i = 0; i < n; ++i) {
                         z.t_off.h[ri + i] = (int64_t)bo + t.off[i];
@@ -475,12 +509,16 @@ struct Chunk {
                     ++scan;
                 }
         }
-        z.t_off.h[N] = (int64_t)B; z.t_cigoff.h[N] = (int32_t)Cg;
+        z.t_off.h[N] = (int64_t)bo; z.t_cigoff.h[N] = (int32_t)Cg;
         z.t_cigar.h[2 * Cg] = 0; z.t_cigar.h[2 * Cg + 1] = 0;
         L.upload(z, z.a_tab);
+        for (const Pending& p : packed)
+            ck(plat_unpack_reads(z.ctx, (int64_t)p.nb, z.t_pack.d + p.bo, z.t_seq.d + p.bo, z.t_qual.d + p.bo, (int64_t)p.ne, z.t_excidx.d + p.e0,
+                                 z.t_excb.d + p.e0, z.t_excq.d + p.e0, z.stream), "plat_unpack_reads");
         nGood = nReads[0]; nScan = scan;
         std::lock_guard<std::mutex> g(stMutex);
         st.n_reads += (int64_t)N;
+        st.input_bytes += (int64_t)inBytes;
     }
     size_t nGood = 0;
     int nScan = 0;
@@ -592,12 +630,14 @@ struct Chunk {
                 std::sort(cands.begin(), cands.end(), [](const int32_t* a, const int32_t* b) { return a[0] < b[0]; });
                 for (const int32_t* c : cands) {
                     r.nCandRecords += c[1];
-                    pass(std::max(0, c[3]), c[4] ? refBlob.data() + c[6] : "", c[4], c[5] ? (const char*)tv.t->seq + (c[7] - blobBase) : "", c[5], c[1]);
+                    const std::string added = tableBases(*tv.t, c[7] - blobBase, c[5]);
+                    pass(std::max(0, c[3]), c[4] ? refBlob.data() + c[6] : "", c[4], added.data(), c[5], c[1]);
                 }
             }
         }
         struct Key { int pos, nrem, nadd, count; const char* rem; const char* add; };
         std::vector<Key> keys;                                              // this sample's variantHeap: distinct records, first-occurrence order
+        std::deque<std::string> addedStore;                                 // (letters of the added bases when the table is not ASCII)
         std::vector<int32_t> table;                                         // open addressing over `keys` (index + 1, 0 = empty)
         for (size_t i = 0; hostTally && i < r.samples.size(); ++i) {
             const TableView& tv = r.samples[i].reads;
@@ -619,7 +659,12 @@ struct Chunk {
                 const int cnt = z.c_cnt.h[g];
                 for (int k = 0; k < cnt; ++k) {
                     const int32_t* rec = z.c_rec.h + 5 * (g * (size_t)maxPerRead + (size_t)k);
-                    Key key{std::max(0, rec[0]), rec[1], rec[2], 1, rec[1] ? refBlob.data() + rec[3] : "", rec[2] ? (const char*)tv.t->seq + (rec[4] - blobBase) : ""};
+                    const char* addp = "";
+                    if (rec[2]) {
+                        if (tv.t->encoding == PLAT_READS_ASCII) addp = (const char*)tv.t->seq + (rec[4] - blobBase);
+                        else { addedStore.push_back(tableBases(*tv.t, rec[4] - blobBase, rec[2])); addp = addedStore.back().data(); }
+                    }
+                    Key key{std::max(0, rec[0]), rec[1], rec[2], 1, rec[1] ? refBlob.data() + rec[3] : "", addp};
                     ++r.nCandRecords;
                     size_t slot = hashKey(key) & tmask;
                     while (table[slot] && !sameKey(keys[(size_t)table[slot] - 1], key)) slot = (slot + 1) & tmask;
@@ -1352,7 +1397,7 @@ CALLER_EXPORT int plat_caller_destroy(plat_caller* c) {
                    z.g_end, z.g_flags, z.o_calls, z.o_iters, z.o_hapscore, z.o_score, z.w_pairoff, z.w_hapoff, z.w_readoff, z.w_gloff, z.w_hapseq, z.w_kind, z.g_seq,
                    z.g_qual, z.g_mapq, z.o_loglik, z.o_gl, z.o_logl, z.o_gof, z.o_freq, z.o_em, z.p_win, z.s_vw, z.s_pos, z.s_min, z.s_max, z.s_nadd, z.s_nrem,
                    z.s_gb, z.s_ge, z.s_bb, z.s_be, z.s_ps, z.s_minq, z.s_nminq, z.k_win, z.k_nvar, z.k_vih, z.k_ref, z.k_ph, z.p_off, z.s_aoff, z.s_moff, z.s_counts,
-                   z.k_vo, z.k_ro, z.k_lo, z.p_mask, z.s_added, z.s_vig, z.p_prior, z.p_post, z.k_lik, z.k_out4, z.a_tab, z.a_cin, z.a_cout, z.a_mout, z.c_scanbegin, z.c_scanlongest, z.m_cand, z.m_n, z.a_win, z.a_wout,
+                   z.k_vo, z.k_ro, z.k_lo, z.p_mask, z.s_added, z.s_vig, z.p_prior, z.p_post, z.k_lik, z.k_out4, z.t_pack, z.a_tab, z.a_cin, z.a_cout, z.a_mout, z.c_scanbegin, z.c_scanlongest, z.m_cand, z.m_n, z.a_win, z.a_wout,
                    z.a_pin, z.a_sin, z.a_sout);
         plat_stream_destroy(z.ctx, z.stream);
         plat_ctx_destroy(z.ctx);
@@ -1364,14 +1409,235 @@ CALLER_EXPORT int plat_caller_destroy(plat_caller* c) {
 CALLER_EXPORT const char* plat_caller_last_error(const plat_caller* c) { return c ? c->lastError.c_str() : ""; }
 CALLER_EXPORT void plat_caller_free(void* p) { free(p); }
 
+// ---- where the chunks of a call come from -----------------------------------------------------------------------------------------------
+// (a worker asks for its next chunk of regions, calls it, and hands it back)
+struct Feed {
+    virtual bool next(std::vector<RegionWork*>& out) = 0;                  // false: no more chunks (or the call has failed)
+    virtual void done(const std::vector<RegionWork*>& chunk) = 0;
+    virtual ~Feed() {}
+};
+
+static std::unique_ptr<RegionWork> makeRegionWork(const plat_region* in, int index, int n_samples, int& longestOut) {
+    std::unique_ptr<RegionWork> r(new RegionWork());
+    r->in = in; r->index = index;
+    r->fa.seq = in->contig_seq; r->fa.len = in->contig_len;
+    r->samples.resize((size_t)n_samples);
+    int longest = 0;
+    for (int i = 0; i < n_samples; ++i) {
+        const plat_sample_reads& sr = in->samples[i];
+        SampleView& sv = r->samples[(size_t)i];
+        sv.reads.t = &sr.reads; sv.bad.t = &sr.bad_reads; sv.broken.t = &sr.broken_mates;
+        sv.reads.longest = longestRead(sr.reads); sv.bad.longest = longestRead(sr.bad_reads); sv.broken.longest = longestRead(sr.broken_mates);
+        longest = std::max(longest, sv.reads.longest);
+    }
+    longestOut = longest;
+    return r;
+}
+// options.rlen follows the longest read of each region and is kept from the region before when a region has no reads (variantcaller.pyx:476-488)
+static inline int nextRlen(int rlen, int longest, int maxSize) { return longest > 0 ? (longest >= maxSize ? maxSize : longest) : rlen; }
+
+// every region already in memory (plat_call_regions)
+struct MemoryFeed : Feed {
+    std::vector<std::unique_ptr<RegionWork>>& work;
+    int per, nChunks;
+    std::atomic<int> nextChunk{0};
+    std::atomic<bool>& failed;
+    MemoryFeed(std::vector<std::unique_ptr<RegionWork>>& w, int per_, std::atomic<bool>& f) : work(w), per(per_), nChunks(((int)w.size() + per_ - 1) / per_), failed(f) {}
+    bool next(std::vector<RegionWork*>& out) override {
+        if (failed.load()) return false;
+        const int ch = nextChunk.fetch_add(1);
+        if (ch >= nChunks) return false;
+        out.clear();
+        for (int k = ch * per; k < std::min((int)work.size(), (ch + 1) * per); ++k) out.push_back(work[(size_t)k].get());
+        return true;
+    }
+    void done(const std::vector<RegionWork*>&) override {}
+};
+
+// regions loaded on demand by loader threads into a bounded set of slots (plat_call_regions_stream)
+struct StreamFeed : Feed {
+    int n, nSamples, per, nChunks, maxSize;
+    plat_region_load_fn load; void* user;
+    std::mutex m;
+    std::condition_variable cvLoaded, cvSlot;
+    std::vector<int> freeSlots;
+    std::vector<std::unique_ptr<RegionWork>> work;
+    std::vector<plat_region> desc;
+    std::vector<int> slotOf, longest;
+    std::vector<char> loaded;
+    int nextToLoad = 0, nextChunk = 0, rlen, error = PLAT_OK;
+    std::string errText;
+    std::atomic<bool>& failed;
+    double tLoad = 0, tWait = 0;
+    StreamFeed(int n_, int nS, int per_, int maxSize_, int rlen0, plat_region_load_fn l, void* u, int nSlots, std::atomic<bool>& f)
+        : n(n_), nSamples(nS), per(per_), nChunks((n_ + per_ - 1) / per_), maxSize(maxSize_), load(l), user(u), work((size_t)n_), desc((size_t)n_),
+          slotOf((size_t)n_, -1), longest((size_t)n_, 0), loaded((size_t)n_, 0), rlen(rlen0), failed(f) {
+        for (int k = nSlots - 1; k >= 0; --k) freeSlots.push_back(k);
+    }
+    void fail(int code, const std::string& what) {
+        std::lock_guard<std::mutex> g(m);
+        if (error == PLAT_OK) { error = code; errText = what; }
+        failed.store(true);
+        cvLoaded.notify_all(); cvSlot.notify_all();
+    }
+    void loader() {
+        for (;;) {
+            int idx, slot;
+            {
+                std::unique_lock<std::mutex> g(m);
+                cvSlot.wait(g, [&] { return !freeSlots.empty() || nextToLoad >= n || failed.load(); });
+                if (nextToLoad >= n || failed.load()) return;
+                slot = freeSlots.back(); freeSlots.pop_back();             // slot first, index second, under one lock: slots are held in index order
+                idx = nextToLoad++;
+            }
+            const auto t0 = Clock::now();
+            memset(&desc[(size_t)idx], 0, sizeof(plat_region));
+            const int rc = load(user, idx, slot, &desc[(size_t)idx]);
+            if (rc != PLAT_OK) { fail(rc, "the region source failed for region " + std::to_string(idx)); return; }
+            int lg = 0;
+            std::unique_ptr<RegionWork> r;
+            try { r = makeRegionWork(&desc[(size_t)idx], idx, nSamples, lg); }
+            catch (const std::exception& e) { fail(PLAT_ERR_BAD_INPUT, e.what()); return; }
+            const double dt = secs(t0, Clock::now());
+            std::lock_guard<std::mutex> g(m);
+            work[(size_t)idx] = std::move(r); slotOf[(size_t)idx] = slot; longest[(size_t)idx] = lg; loaded[(size_t)idx] = 1;
+            tLoad += dt;
+            cvLoaded.notify_all();
+        }
+    }
+    bool next(std::vector<RegionWork*>& out) override {
+        const auto t0 = Clock::now();
+        std::unique_lock<std::mutex> g(m);
+        for (;;) {
+            if (failed.load() || nextChunk >= nChunks) return false;
+            const int ch = nextChunk, a = ch * per, b = std::min(n, (ch + 1) * per);
+            bool all = true;
+            for (int k = a; k < b; ++k) all = all && loaded[(size_t)k];
+            if (all) {
+                out.clear();
+                for (int k = a; k < b; ++k) {                                // list order: rlen walks the regions as the reference's loop does
+                    rlen = nextRlen(rlen, longest[(size_t)k], maxSize);
+                    work[(size_t)k]->rlen = rlen;
+                    out.push_back(work[(size_t)k].get());
+                }
+                ++nextChunk;
+                tWait += secs(t0, Clock::now());
+                return true;
+            }
+            cvLoaded.wait(g);
+        }
+    }
+    void done(const std::vector<RegionWork*>& chunk) override {
+        std::lock_guard<std::mutex> g(m);
+        for (RegionWork* r : chunk) { freeSlots.push_back(slotOf[(size_t)r->index]); slotOf[(size_t)r->index] = -1; }
+        cvSlot.notify_all();
+    }
+};
+
+// the workers of one call: every worker thread (own plat_ctx + stream) pulls chunks from the feed until it runs dry
+static int runWorkers(plat_caller* c, Feed& feed, std::atomic<bool>& failed, const Options& o, int n_samples, const char* const* sample_names,
+                      plat_caller_stats& st, int nThreads)
+{
+    std::mutex stMutex, errMutex;
+    int firstError = PLAT_OK;
+    std::string errText;
+    auto worker = [&](Slot* slot) {
+        std::vector<RegionWork*> regs;
+        while (feed.next(regs)) {
+            Chunk chunk{*slot, o, n_samples, sample_names, regs, st, stMutex};
+            try {
+                chunk.run();
+            } catch (const DeviceError& e) {
+                std::lock_guard<std::mutex> g(errMutex);
+                if (firstError == PLAT_OK) { firstError = e.code; errText = e.what(); }
+                failed.store(true);
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> g(errMutex);
+                if (firstError == PLAT_OK) { firstError = PLAT_ERR_BAD_INPUT; errText = e.what(); }
+                failed.store(true);
+            }
+            feed.done(regs);
+        }
+    };
+    nThreads = std::max(1, std::min<int>((int)c->slots.size(), nThreads));
+    std::vector<std::thread> threads;
+    for (int i = 1; i < nThreads; ++i) threads.emplace_back(worker, c->slots[(size_t)i].get());
+    worker(c->slots[0].get());
+    for (std::thread& t : threads) t.join();
+    if (firstError != PLAT_OK) c->lastError = errText;
+    return firstError;
+}
+
+static int finishText(std::vector<std::unique_ptr<RegionWork>>& work, char** out_text, size_t* out_len) {
+    size_t total = 0;
+    for (auto& r : work) if (r) total += r->text.size();
+    char* text = (char*)malloc(total + 1);
+    if (!text) return PLAT_ERR_NOMEM;
+    size_t at = 0;
+    for (auto& r : work) if (r) { memcpy(text + at, r->text.data(), r->text.size()); at += r->text.size(); }
+    text[total] = 0;
+    *out_text = text; *out_len = total;
+    return PLAT_OK;
+}
+
+static int checkCallArgs(plat_caller* c, const plat_caller_options* options, char** out_text, size_t* out_len, int n_regions, int n_samples) {
+    if (!c || !options || !out_text || !out_len || n_regions < 0 || n_samples < 1) return PLAT_ERR_INVALID;
+    *out_text = nullptr; *out_len = 0;
+    if (options->assemble || options->outputRefCalls) {
+        c->lastError = "assemble=1 and outputRefCalls=1 are not built in the native region loop (use platypus_amd.caller)";
+        return PLAT_ERR_UNSUPPORTED;
+    }
+    if (!options->getVariantsFromBAMs && !options->assemble) {
+        // (the reference then has no candidates at all unless a source VCF is given, which is not built)
+        c->lastError = "getVariantsFromBAMs=0 without assemble=1 leaves no candidate source (source VCFs are not built)";
+        return PLAT_ERR_UNSUPPORTED;
+    }
+    return PLAT_OK;
+}
+
 CALLER_EXPORT int plat_call_regions(plat_caller* c, const plat_region* regions, int n_regions, int n_samples, const char* const* sample_names,
                                     plat_caller_options* options, char** out_text, size_t* out_len, plat_caller_stats* stats)
 {
-    if (!c || !options || !out_text || !out_len || n_regions < 0 || n_samples < 1 || (n_regions > 0 && !regions)) return PLAT_ERR_INVALID;
-    *out_text = nullptr; *out_len = 0;
-    if (options->assemble || options->outputRefCalls || !options->getVariantsFromBAMs) {
-        c->lastError = "assemble=1, outputRefCalls=1 and getVariantsFromBAMs=0 are not built in the native region loop (use platypus_amd.caller)";
-        return PLAT_ERR_UNSUPPORTED;
+    int rc = checkCallArgs(c, options, out_text, out_len, n_regions, n_samples);
+    if (rc != PLAT_OK) return rc;
+    if (n_regions > 0 && !regions) return PLAT_ERR_INVALID;
+    const auto t0 = Clock::now();
+    plat_caller_stats st;
+    memset(&st, 0, sizeof st);
+    st.n_regions = n_regions;
+    Options o;
+    static_cast<plat_caller_options&>(o) = *options;
+    std::vector<std::unique_ptr<RegionWork>> work;
+    int rlen = options->rlen;
+    for (int k = 0; k < n_regions; ++k) {
+        int longest = 0;
+        std::unique_ptr<RegionWork> r = makeRegionWork(&regions[k], k, n_samples, longest);
+        rlen = nextRlen(rlen, longest, options->maxSize);
+        r->rlen = rlen;
+        work.push_back(std::move(r));
+    }
+    std::atomic<bool> failed(false);
+    MemoryFeed feed(work, c->regionsPerChunk, failed);
+    rc = runWorkers(c, feed, failed, o, n_samples, sample_names, st, std::max(1, feed.nChunks));
+    if (rc != PLAT_OK) return rc;
+    if ((rc = finishText(work, out_text, out_len)) != PLAT_OK) return rc;
+    options->rlen = rlen;
+    st.seconds_total = secs(t0, Clock::now());
+    if (stats) *stats = st;
+    return PLAT_OK;
+}
+
+CALLER_EXPORT int plat_call_regions_stream(plat_caller* c, int n_regions, int n_samples, const char* const* sample_names, plat_caller_options* options,
+                                           plat_region_load_fn load, void* user, int n_slots, int n_loader_threads, char** out_text, size_t* out_len,
+                                           plat_caller_stats* stats)
+{
+    int rc = checkCallArgs(c, options, out_text, out_len, n_regions, n_samples);
+    if (rc != PLAT_OK) return rc;
+    const int per = c->regionsPerChunk, nWorkers = (int)c->slots.size();
+    if (!load || n_loader_threads < 1) return PLAT_ERR_INVALID;
+    if (n_slots < per * (std::min(nWorkers, std::max(1, (n_regions + per - 1) / per)) + 1) && n_slots < n_regions) {
+        c->lastError = "plat_call_regions_stream: n_slots must be at least regions_per_chunk * (n_workers + 1)";
+        return PLAT_ERR_INVALID;
     }
     const auto t0 = Clock::now();
     plat_caller_stats st;
@@ -1379,66 +1645,20 @@ CALLER_EXPORT int plat_call_regions(plat_caller* c, const plat_region* regions, 
     st.n_regions = n_regions;
     Options o;
     static_cast<plat_caller_options&>(o) = *options;
-    // per-region state; options.rlen follows the longest read of each region and is kept from the region before when a region has no
-    // reads (variantcaller.pyx:476-488)
-    std::vector<std::unique_ptr<RegionWork>> work;
-    int rlen = options->rlen;
-    for (int k = 0; k < n_regions; ++k) {
-        std::unique_ptr<RegionWork> r(new RegionWork());
-        r->in = &regions[k]; r->index = k;
-        r->fa.seq = regions[k].contig_seq; r->fa.len = regions[k].contig_len;
-        r->samples.resize((size_t)n_samples);
-        int longest = 0;
-        for (int i = 0; i < n_samples; ++i) {
-            const plat_sample_reads& sr = regions[k].samples[i];
-            SampleView& sv = r->samples[(size_t)i];
-            sv.reads.t = &sr.reads; sv.bad.t = &sr.bad_reads; sv.broken.t = &sr.broken_mates;
-            sv.reads.longest = longestRead(sr.reads); sv.bad.longest = longestRead(sr.bad_reads); sv.broken.longest = longestRead(sr.broken_mates);
-            longest = std::max(longest, sv.reads.longest);
-        }
-        if (longest > 0) rlen = longest >= options->maxSize ? options->maxSize : longest;
-        r->rlen = rlen;
-        work.push_back(std::move(r));
-    }
-    std::mutex stMutex, errMutex;
-    std::atomic<int> next(0);
-    int firstError = PLAT_OK;
-    std::string errText;
-    const int per = c->regionsPerChunk, nChunks = (n_regions + per - 1) / per;
-    auto worker = [&](Slot* slot) {
-        for (;;) {
-            const int ch = next.fetch_add(1);
-            if (ch >= nChunks) break;
-            { std::lock_guard<std::mutex> g(errMutex); if (firstError != PLAT_OK) break; }
-            Chunk chunk{*slot, o, n_samples, sample_names, {}, st, stMutex};
-            for (int k = ch * per; k < std::min(n_regions, (ch + 1) * per); ++k) chunk.regions.push_back(work[(size_t)k].get());
-            try {
-                chunk.run();
-            } catch (const DeviceError& e) {
-                std::lock_guard<std::mutex> g(errMutex);
-                if (firstError == PLAT_OK) { firstError = e.code; errText = e.what(); }
-            } catch (const std::exception& e) {
-                std::lock_guard<std::mutex> g(errMutex);
-                if (firstError == PLAT_OK) { firstError = PLAT_ERR_BAD_INPUT; errText = e.what(); }
-            }
-        }
-    };
-    const int nThreads = std::min<int>((int)c->slots.size(), std::max(1, nChunks));
-    std::vector<std::thread> threads;
-    for (int i = 1; i < nThreads; ++i) threads.emplace_back(worker, c->slots[(size_t)i].get());
-    worker(c->slots[0].get());
-    for (std::thread& t : threads) t.join();
-    if (firstError != PLAT_OK) { c->lastError = errText; return firstError; }
-    size_t total = 0;
-    for (auto& r : work) total += r->text.size();
-    char* text = (char*)malloc(total + 1);
-    if (!text) return PLAT_ERR_NOMEM;
-    size_t at = 0;
-    for (auto& r : work) { memcpy(text + at, r->text.data(), r->text.size()); at += r->text.size(); }
-    text[total] = 0;
-    *out_text = text; *out_len = total;
-    options->rlen = rlen;
+    std::atomic<bool> failed(false);
+    StreamFeed feed(n_regions, n_samples, per, options->maxSize, options->rlen, load, user, n_slots, failed);
+    std::vector<std::thread> loaders;
+    for (int i = 0; i < std::min(n_loader_threads, std::max(1, n_regions)); ++i) loaders.emplace_back([&feed] { feed.loader(); });
+    rc = runWorkers(c, feed, failed, o, n_samples, sample_names, st, std::max(1, feed.nChunks));
+    { std::lock_guard<std::mutex> g(feed.m); feed.cvSlot.notify_all(); }
+    if (rc != PLAT_OK) feed.fail(rc, c->lastError);                       // (wakes loaders that wait for a slot)
+    for (std::thread& t : loaders) t.join();
+    if (rc == PLAT_OK && feed.error != PLAT_OK) { rc = feed.error; c->lastError = feed.errText; }
+    if (rc != PLAT_OK) return rc;
+    if ((rc = finishText(feed.work, out_text, out_len)) != PLAT_OK) return rc;
+    options->rlen = feed.rlen;
     st.seconds_total = secs(t0, Clock::now());
+    st.seconds_load = feed.tLoad; st.seconds_source_wait = feed.tWait;
     if (stats) *stats = st;
     return PLAT_OK;
 }

@@ -540,3 +540,61 @@ PLAT_EXPORT int plat_gather_reads(plat_ctx* ctx, int64_t n_dst, const int32_t* s
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
+
+
+// ---- read tables packed at one byte per base (plat_unpack_reads) ----------------------------------------------------------
+namespace plat {
+// 16 packed bytes per thread: one 128-bit load, two 128-bit stores
+__global__ void __launch_bounds__(256)
+k_unpack_reads(long long n, const uint8_t* __restrict__ packed, uint8_t* __restrict__ out_seq, uint8_t* __restrict__ out_qual)
+{
+    const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i0 >= n) return;
+    if (i0 + 16 <= n && (((uintptr_t)(packed + i0) | (uintptr_t)(out_seq + i0) | (uintptr_t)(out_qual + i0)) & 15) == 0) {
+        const uint4 v = *(const uint4*)(packed + i0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t sq[4], ql[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t code = w[k] & 0x03030303u;
+            sq[k] = __builtin_amdgcn_perm(0u, 0x47544341u, code);           // byte selector 0..3 -> 'A' 'C' 'T' 'G'
+            ql[k] = (w[k] >> 2) & 0x3F3F3F3Fu;
+        }
+        *(uint4*)(out_seq + i0) = make_uint4(sq[0], sq[1], sq[2], sq[3]);
+        *(uint4*)(out_qual + i0) = make_uint4(ql[0], ql[1], ql[2], ql[3]);
+    } else {
+        for (long long i = i0; i < n && i < i0 + 16; ++i) {
+            const unsigned b = packed[i];
+            out_seq[i] = (uint8_t)((0x47544341u >> (8u * (b & 3u))) & 0xFFu);
+            out_qual[i] = (uint8_t)(b >> 2);
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_unpack_exceptions(long long n_exc, long long n, const int64_t* __restrict__ idx, const uint8_t* __restrict__ eb, const uint8_t* __restrict__ eq,
+                    uint8_t* __restrict__ out_seq, uint8_t* __restrict__ out_qual)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_exc) return;
+    const long long i = idx[k];
+    if (i < 0 || i >= n) return;
+    out_seq[i] = eb[k]; out_qual[i] = eq[k];
+}
+}  // namespace plat
+
+PLAT_EXPORT int plat_unpack_reads(plat_ctx* ctx, int64_t n_bytes, const uint8_t* packed, uint8_t* out_seq, uint8_t* out_qual,
+                                  int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream)
+{
+    if (!ctx || n_bytes < 0 || n_exc < 0) return PLAT_ERR_INVALID;
+    if (n_bytes == 0) return PLAT_OK;
+    if (!packed || !out_seq || !out_qual || (n_exc > 0 && (!exc_index || !exc_base || !exc_qual))) return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    const long long nthr = (n_bytes + 15) / 16;
+    hipLaunchKernelGGL(plat::k_unpack_reads, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n_bytes, packed,
+                       out_seq, out_qual);
+    if (n_exc > 0)
+        hipLaunchKernelGGL(plat::k_unpack_exceptions, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n_exc,
+                           (long long)n_bytes, exc_index, exc_base, exc_qual, out_seq, out_qual);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}

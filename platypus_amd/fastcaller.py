@@ -19,9 +19,13 @@ LIB_PATH = os.path.join(HERE, "libplat_caller.so")
 HOST_SRC = os.path.join(HERE, "csrc", "host")
 
 
+READS_ASCII, READS_PACKED = 0, 1
+
+
 class _ReadTable(C.Structure):
-    _fields_ = [("n_reads", C.c_int32), ("_pad", C.c_int32)] + [(k, C.c_void_p) for k in (
-        "seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off")]
+    _fields_ = [("n_reads", C.c_int32), ("encoding", C.c_int32)] + [(k, C.c_void_p) for k in (
+        "seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off")] + \
+               [("n_exceptions", C.c_int64), ("exc_index", C.c_void_p), ("exc_base", C.c_void_p), ("exc_qual", C.c_void_p)]
 
 
 class _SampleReads(C.Structure):
@@ -61,7 +65,8 @@ class CallerOptions(C.Structure):
 class CallerStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("n_regions", "n_reads", "n_candidate_records", "n_variants", "n_windows", "n_windows_called",
                                          "n_records", "n_windows_greedy", "n_windows_failed")] + \
-               [(k, C.c_double) for k in ("seconds_total", "seconds_host", "seconds_device_wait")] + [("seconds_stage", C.c_double * 8)]
+               [(k, C.c_double) for k in ("seconds_total", "seconds_host", "seconds_device_wait")] + [("seconds_stage", C.c_double * 8)] + \
+               [("seconds_load", C.c_double), ("seconds_source_wait", C.c_double), ("input_bytes", C.c_int64)]
 
     STAGES = ("upload", "candidate_scan", "variants_windows_haplotypes", "greedy_rounds", "window_batch", "posteriors", "read_stats_calls", "text")
 
@@ -74,14 +79,24 @@ class CallerStats(C.Structure):
 class ReadTable:
     """One ReadArray as arrays (cAlignedRead fields, htslibWrapper.pxd:187-201).  `reads`: the order the ReadArray holds them in
     (sorted by pos; brokenMates by mate position)."""
-    __slots__ = ("n", "seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off", "_pinned", "_struct")
+    __slots__ = ("n", "seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off", "_pinned", "_struct", "encoding", "exc")
 
-    def __init__(self, seq, qual, off, pos, end, mapq, flags, mate_pos, cigar, cig_off, pin=False):
+    def __init__(self, seq, qual, off, pos, end, mapq, flags, mate_pos, cigar, cig_off, pin=False, packed=False):
         """pin=True keeps the two byte blobs in page-locked memory (what a loader that decodes into pinned buffers hands over):
-        their upload is then asynchronous and runs at link speed instead of going through the driver's staging copies."""
+        their upload is then asynchronous and runs at link speed instead of going through the driver's staging copies.
+        packed=True hands the reads over as PLAT_READS_PACKED (one byte per base + exceptions) instead of ASCII bases + qualities."""
         self.n = len(pos)
         pad = np.zeros(_lib.PLAT_BLOB_PAD, dtype=np.uint8)
         c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+        self.encoding, self.exc = READS_ASCII, None
+        if packed:
+            seq, qual = c(seq, np.uint8), c(qual, np.uint8)
+            plain = (seq == 65) | (seq == 67) | (seq == 71) | (seq == 84)
+            ex = np.nonzero(~plain | (qual > 63))[0].astype(np.int64)
+            self.exc = (ex, seq[ex].copy(), qual[ex].copy())
+            seq = (((seq >> 1) & 3) | (np.minimum(qual, 63) << 2)).astype(np.uint8)
+            qual = np.zeros(0, dtype=np.uint8)
+            self.encoding = READS_PACKED
         self.seq, self.qual = np.concatenate([c(seq, np.uint8), pad]), np.concatenate([c(qual, np.uint8), pad])
         self._pinned = None
         if pin and self.n:
@@ -94,23 +109,26 @@ class ReadTable:
         assert len(self.off) == self.n + 1 and len(self.cig_off) == self.n + 1 and (self.n == 0 or self.off[0] == 0)
 
     @classmethod
-    def from_reads(cls, reads):
+    def from_reads(cls, reads, packed=False):
         """From hostapi.AlignedRead objects, in the given order."""
         lens = [r.rlen for r in reads]
         cig = [x for r in reads for c in r.cigarOps for x in c]
         return cls(np.frombuffer(b"".join(r.seq for r in reads), dtype=np.uint8), np.frombuffer(b"".join(r.qual for r in reads), dtype=np.uint8),
                    np.concatenate([[0], np.cumsum(lens)]), [r.pos for r in reads], [r.end for r in reads], [r.mapq for r in reads],
                    [r.bitFlag for r in reads], [r.matePos for r in reads], np.array(cig, dtype=np.int16),
-                   np.concatenate([[0], np.cumsum([len(r.cigarOps) for r in reads])]))
+                   np.concatenate([[0], np.cumsum([len(r.cigarOps) for r in reads])]), packed=packed)
 
     def struct(self):
         """The plat_read_table of these arrays (built once: the arrays are kept alive by, and never replaced on, this object)."""
         t = getattr(self, "_struct", None)
         if t is None:
             t = _ReadTable()
-            t.n_reads = self.n
+            t.n_reads, t.encoding = self.n, self.encoding
             for k in ("seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off"):
                 setattr(t, k, getattr(self, k).ctypes.data)
+            if self.exc is not None:
+                t.n_exceptions = len(self.exc[0])
+                t.exc_index, t.exc_base, t.exc_qual = (a.ctypes.data for a in self.exc)
             self._struct = t
         return t
 
@@ -135,19 +153,56 @@ class RegionReads:
         return self._c
 
     @classmethod
-    def from_buffers(cls, chrom, start, end, fasta, buffers):
+    def from_buffers(cls, chrom, start, end, fasta, buffers, packed=False):
         """From hostapi.bamReadBuffer objects and a hostapi.FastaFile (the inputs of caller.callVariantsInRegions)."""
         return cls(chrom, start, end, fasta._seq[chrom],
-                   [(ReadTable.from_reads(b.reads.array), ReadTable.from_reads(b.badReads.array), ReadTable.from_reads(b.brokenMates.array))
-                    for b in buffers])
+                   [(ReadTable.from_reads(b.reads.array, packed), ReadTable.from_reads(b.badReads.array, packed),
+                     ReadTable.from_reads(b.brokenMates.array, packed)) for b in buffers])
+
+    def fill(self, a, n_samples):
+        """Write this region into the plat_region `a` (the arrays stay owned by, and alive with, this object)."""
+        assert len(self.samples) == n_samples
+        a.chrom, a.contig_seq, a.contig_len, ss = self.c_region()
+        a.start, a.end = self.start, self.end
+        a.samples = ss
 
 
-def region_from_arrays(reg, pin=False):
+def region_from_arrays(reg, pin=False, packed=False):
     """RegionReads of a synth.config4_region_arrays() region (every read in `reads`; no badReads / brokenMates)."""
     empty = ReadTable([], [], [0], [], [], [], [], [], [], [0])
     return RegionReads(reg["chrom"], reg["start"], reg["end"], reg["ref"],
                        [(ReadTable(s["seq"], s["qual"], s["off"], s["pos"], s["end"], s["mapq"], s["flags"], s["mate_pos"], s["cigar"], s["cig_off"],
-                                   pin=pin), empty, empty) for s in reg["samples"]])
+                                   pin=pin, packed=packed), empty, empty) for s in reg["samples"]])
+
+
+def arrays_from_region_struct(reg):
+    """The arrays of a filled plat_region (copies), in the form of synth.config4_region_arrays(): what a region SOURCE handed over
+    (tools/synth), for the parity tests that run the same reads through the Python region loop."""
+    def arr(ptr, n, dt):
+        if not ptr or n == 0:
+            return np.zeros(0, dtype=dt)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n,)).copy()
+
+    def table(t):
+        n = t.n_reads
+        off = arr(t.off, n + 1, np.int64) if n else np.zeros(1, dtype=np.int64)
+        nb = int(off[-1])
+        seq = arr(t.seq, nb, np.uint8)
+        if t.encoding == READS_PACKED:
+            qual = (seq >> 2).astype(np.uint8)
+            seq = np.frombuffer(b"ACTG", dtype=np.uint8)[seq & 3].copy()
+            ne = int(t.n_exceptions)
+            if ne:
+                ix = arr(t.exc_index, ne, np.int64)
+                seq[ix], qual[ix] = arr(t.exc_base, ne, np.uint8), arr(t.exc_qual, ne, np.uint8)
+        else:
+            qual = arr(t.qual, nb, np.uint8)
+        co = arr(t.cig_off, n + 1, np.int32) if n else np.zeros(1, dtype=np.int32)
+        return dict(seq=seq, qual=qual, off=off, pos=arr(t.pos, n, np.int32), end=arr(t.end, n, np.int32), mapq=arr(t.mapq, n, np.uint8),
+                    flags=arr(t.flags, n, np.int32), mate_pos=arr(t.mate_pos, n, np.int32), cigar=arr(t.cigar, 2 * int(co[-1]), np.int16), cig_off=co)
+    return dict(chrom=reg.chrom.decode(), start=int(reg.start), end=int(reg.end), ref=arr(reg.contig_seq, int(reg.contig_len), np.uint8),
+                samples=lambda n: [dict(reads=table(reg.samples[i].reads), bad=table(reg.samples[i].bad_reads),
+                                        broken=table(reg.samples[i].broken_mates)) for i in range(n)])
 
 
 def aligned_reads_from_arrays(s):
@@ -182,6 +237,8 @@ def _bind(lib):
     lib.plat_caller_destroy.argtypes = [C.c_void_p]
     lib.plat_call_regions.argtypes = [C.c_void_p, C.POINTER(_Region), C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(CallerOptions),
                                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(CallerStats)]
+    lib.plat_call_regions_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(CallerOptions), C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(CallerStats)]
     lib.plat_caller_free.argtypes = [C.c_void_p]
     lib.plat_caller_free.restype = None
     lib.plat_caller_last_error.argtypes = [C.c_void_p]
@@ -232,11 +289,7 @@ class NativeCaller:
         n, nS = len(regions), len(sample_names)
         arr = (_Region * max(n, 1))()
         for k, r in enumerate(regions):
-            assert len(r.samples) == nS
-            a = arr[k]
-            a.chrom, a.contig_seq, a.contig_len, ss = r.c_region()
-            a.start, a.end = r.start, r.end
-            a.samples = ss
+            r.fill(arr[k], nS)
         names = (C.c_char_p * nS)(*[s.encode() for s in sample_names])
         o = CallerOptions.from_options(options)
         text, length, st = C.c_void_p(), C.c_size_t(), CallerStats()
@@ -250,3 +303,40 @@ class NativeCaller:
         options.rlen = int(o.rlen)
         self.stats = st.as_dict()
         return out
+
+    def call_stream(self, n_regions, load, user, sample_names, options, n_slots, n_loaders=2):
+        """plat_call_regions_stream: regions loaded on demand.  `load`: a plat_region_load_fn -- the address of a native function (int,
+        e.g. tools/synth's generator: no Python in the loader threads) or a Python callable (index, slot, region_struct) -> status (wrapped;
+        tests).  Returns the record lines of all regions (str), in region order."""
+        nS = len(sample_names)
+        keep = None
+        if callable(load):
+            fn = load
+
+            def tramp(_user, index, slot, out):
+                try:
+                    return int(fn(index, slot, out.contents) or 0)
+                except Exception:                                       # an exception cannot cross the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return -9
+            keep = LOAD_FN(tramp)
+            load = C.cast(keep, C.c_void_p)
+        names = (C.c_char_p * nS)(*[s.encode() for s in sample_names])
+        o = CallerOptions.from_options(options)
+        text, length, st = C.c_void_p(), C.c_size_t(), CallerStats()
+        rc = self.lib.plat_call_regions_stream(self.h, n_regions, nS, names, C.byref(o), load, user, n_slots, n_loaders, C.byref(text), C.byref(length),
+                                               C.byref(st))
+        del keep
+        if rc != 0:
+            raise _lib.PlatypusDeviceError(rc, (self.lib.plat_caller_last_error(self.h) or b"").decode(), "plat_call_regions_stream")
+        try:
+            out = C.string_at(text, length.value).decode("ascii")
+        finally:
+            self.lib.plat_caller_free(text)
+        options.rlen = int(o.rlen)
+        self.stats = st.as_dict()
+        return out
+
+
+LOAD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(_Region))

@@ -390,6 +390,16 @@ API int plat_gather_reads(plat_ctx* c, int64_t n_dst, const int32_t* src_index, 
     return PLAT_OK;
 }
 
+API int plat_unpack_reads(plat_ctx* c, int64_t n_bytes, const uint8_t* packed, uint8_t* out_seq, uint8_t* out_qual, int64_t n_exc,
+                          const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream)
+{
+    (void)c; (void)stream;
+    for (int64_t i = 0; i < n_bytes; ++i) { out_seq[i] = (uint8_t)"ACTG"[packed[i] & 3]; out_qual[i] = packed[i] >> 2; }
+    for (int64_t k = 0; k < n_exc; ++k)
+        if (exc_index[k] >= 0 && exc_index[k] < n_bytes) { out_seq[exc_index[k]] = exc_base[k]; out_qual[exc_index[k]] = exc_qual[k]; }
+    return PLAT_OK;
+}
+
 API int plat_variant_read_stats_batch(plat_ctx* c, const plat_infostats_batch* b, int bad_reads_window, int exact, int64_t* out_counts,
                                       int32_t* out_per_sample, int32_t* out_minq, int32_t* out_nminq, void* stream)
 {

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-REGION_KW = dict(snp_rate=3e-3, indel_rate=1e-3, read_len=100, depth=25)
+REGION_KW = dict(snp_rate=3e-3, indel_rate=1e-3, read_len=100, depth=25, flank=500)
 
 
 def test_bench_gpus_flag_starts_that_many_ranks():

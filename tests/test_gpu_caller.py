@@ -245,3 +245,53 @@ def test_fake_device_of_the_cpu_suite_agrees_with_the_device():
     nf = F.NativeCaller(0, 2, 2, lib=fakedev.fake_caller_lib())
     fake = nf.call_regions([F.region_from_arrays(r) for r in regs], names, default_options())
     assert real == fake and real.count("\n") > 30
+
+
+def test_unpack_reads_on_the_device():
+    """plat_unpack_reads: one byte per base (2-bit base | quality << 2) -> ASCII bases + raw qualities, exceptions patched; every
+    alignment of source and destination (the fast path moves 16 bytes per lane)."""
+    import torch
+    from platypus_amd import _lib
+    lib = _lib.load()
+    eng = H.get_engine()
+    rng = np.random.default_rng(5)
+    for n, shift in ((1, 0), (15, 3), (4096, 0), (100003, 5), (1 << 20, 16)):
+        packed = rng.integers(0, 256, n + 64, dtype=np.uint8)
+        nex = min(n, 37)
+        ex = np.sort(rng.choice(n, nex, replace=False)).astype(np.int64)
+        eb, eq = rng.choice(np.frombuffer(b"NRYKM", dtype=np.uint8), nex), rng.integers(64, 94, nex, dtype=np.uint8)
+        d_in = torch.from_numpy(packed).cuda()
+        d_seq, d_qual = torch.zeros(n + 64, dtype=torch.uint8, device="cuda"), torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+        d_ex, d_eb, d_eq = torch.from_numpy(ex).cuda(), torch.from_numpy(eb).cuda(), torch.from_numpy(eq).cuda()
+        rc = lib.plat_unpack_reads(eng.ctx, n, d_in.data_ptr() + shift, d_seq.data_ptr() + shift, d_qual.data_ptr() + shift, nex, d_ex.data_ptr(),
+                                   d_eb.data_ptr(), d_eq.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        want_s = np.frombuffer(b"ACTG", dtype=np.uint8)[packed[shift:shift + n] & 3].copy()
+        want_q = (packed[shift:shift + n] >> 2).copy()
+        want_s[ex], want_q[ex] = eb, eq
+        got_s, got_q = d_seq.cpu().numpy(), d_qual.cpu().numpy()
+        assert np.array_equal(got_s[shift:shift + n], want_s) and np.array_equal(got_q[shift:shift + n], want_q)
+        assert not got_s[:shift].any() and not got_s[shift + n:].any() and not got_q[shift + n:].any()      # nothing outside [0, n)
+
+
+def test_streamed_packed_regions_equal_the_region_list_on_the_device():
+    """The shape the config-4 benchmark runs: regions generated on demand by the native source (tools/synth) into pinned slots, one
+    byte per base over the link, through plat_call_regions_stream -- the text of the same reads handed over as ASCII arrays in one list."""
+    from platypus_amd import fastcaller as F
+    from tools.synth import source
+    kw = dict(region_len=20000, n_samples=2, depth=30, read_len=150, snp_rate=2e-3, indel_rate=4e-4)
+    ids = list(range(40, 52))
+    src = source.RegionSource(ids, 14, packed=True, pin=True, **kw)
+    regs = []
+    for k in range(len(ids)):
+        a = F.arrays_from_region_struct(src.region(k, 0))
+        regs.append(dict(chrom=a["chrom"], start=a["start"], end=a["end"], ref=a["ref"], samples=[x["reads"] for x in a["samples"](2)]))
+    names = ["S1", "S2"]
+    nc = F.NativeCaller(0, 4, 2)
+    want = nc.call_regions([F.region_from_arrays(r) for r in regs], names, default_options())
+    got = nc.call_stream(len(ids), src.load_fn, src.h, names, default_options(), n_slots=14, n_loaders=3)
+    assert got == want and want.count("\n") > 300
+    st = nc.stats
+    assert st["input_bytes"] == st["n_reads"] * 150 and st["seconds_load"] > 0
+    assert nc.call_regions([F.region_from_arrays(r, packed=True, pin=True) for r in regs], names, default_options()) == want

@@ -155,75 +155,88 @@ def run(a, rk):
 
 # ---- config 4 -----------------------------------------------------------------------------------------------------------------
 
-def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_samples=1, pin=True, lib=None, region_kw=None, rk=None):
-    """The region pipeline end to end: reads of the regions `indices` of the job's region list in host memory (arrays) -> VCF record
-    text, through the native region loop (libplat_caller.so: host threads + every device stage batched per chunk of regions); then the
-    job's one exchange: record lines to rank 0, merged there."""
-    from concurrent.futures import ThreadPoolExecutor
-    from platypus_amd import fastcaller as F, sharding, synth
+def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_samples=1, pin=True, lib=None, region_kw=None, rk=None, packed=True,
+            loaders=None, warm_regions=None):
+    """The region pipeline end to end, sustained: the regions `indices` of the job's region list are LOADED ON DEMAND by a region source
+    (tools/synth: generated from seed (+) region index inside the library's loader threads into a bounded set of pinned slots -- where the
+    reference's BAM loader stands) and called through the native region loop (plat_call_regions_stream: host threads + every device stage
+    batched per chunk of regions) -> VCF record text; then the job's one exchange: record lines to rank 0, merged there.  Every repeat is
+    timed; the MEAN is reported."""
+    from platypus_amd import fastcaller as F, sharding
     from platypus_amd.options import default_options
+    from tools.synth import source
     rk = rk or _Solo()
     indices = list(indices)
-    t0 = time.perf_counter()
-    kw = dict(region_len=region_len, n_samples=n_samples, **(region_kw or {}))
-    with ThreadPoolExecutor(max(1, min(16, len(indices)))) as ex:
-        regs = list(ex.map(lambda i: synth.config4_region_arrays(i, **kw), indices))
-    rr = [F.region_from_arrays(r, pin=pin) for r in regs]
-    t_synth = time.perf_counter() - t0
+    loaders = loaders or int(os.environ.get("PLAT_CALLER_LOADERS", str(max(2, min(12, workers)))))
+    n_slots = per_chunk * (workers + 2) + loaders
+    kw = dict(region_len=region_len, n_samples=n_samples, packed=packed, pin=pin, **(region_kw or {}))
+    src = source.RegionSource(indices, n_slots, **kw)
     names = ["S%d" % (i + 1) for i in range(n_samples)]
     nc = F.NativeCaller(device, workers, per_chunk, lib=lib)
-    nc.call_regions(rr, names, default_options())                          # every worker's scratch buffers at full size, code paths warm
-    best = None
+    nwarm = min(len(indices), warm_regions if warm_regions is not None else 2 * per_chunk * workers)
+    if nwarm:                                                                 # every worker's scratch buffers at full size, code paths warm
+        nc.call_stream(nwarm, src.load_fn, src.h, names, default_options(), n_slots, loaders)
+    runs, text, merged, gather, st = [], "", None, None, None
+    planted0 = src.planted
     for _ in range(repeats):
         opts = default_options()
         rk.barrier()
         t0 = time.perf_counter()
-        text = nc.call_regions(rr, names, opts)
+        text = nc.call_stream(len(indices), src.load_fn, src.h, names, opts, n_slots, loaders)
         t1 = time.perf_counter()
         got = rk.gather(sharding.encode_records(sharding.records_from_vcf_text(text)))
-        merged = None
         if got is not None:
             merged = "".join(ln + "\n" for ln in sharding.merge_record_streams([sharding.decode_records(x) for x in got]))
         t2 = time.perf_counter()
         rk.barrier()
-        if best is None or t2 - t0 < best[0]:
-            best = (t2 - t0, text, dict(nc.stats), t1 - t0, merged, dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=len(got) if got else None,
-                                                                         records=merged.count("\n") if merged is not None else None))
+        st = dict(nc.stats)
+        runs.append((t2 - t0, t1 - t0))
+        gather = dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=len(got) if got else None, records=merged.count("\n") if merged is not None else None)
+    planted = (src.planted - planted0) // max(1, repeats)
     nc.close()
-    t, text, st, tcall, merged, gather = best
-    planted = sum(len(r["variants"]) for r in regs)
-    return dict(T=t, T_call=tcall, text=text, merged=merged, gather=gather, stats=st, regions=len(indices), region_len=region_len,
-                reads=int(st["n_reads"]), windows=int(st["n_windows"]), records=int(st["n_records"]), planted=planted, synth_s=t_synth,
-                workers=workers, per_chunk=per_chunk)
+    src.close()
+    T = float(np.mean([r[0] for r in runs]))
+    return dict(T=T, T_call=float(np.mean([r[1] for r in runs])), T_runs=[r[0] for r in runs], text=text, merged=merged, gather=gather, stats=st,
+                regions=len(indices), region_len=region_len, reads=int(st["n_reads"]), windows=int(st["n_windows"]), records=int(st["n_records"]),
+                planted=int(planted), workers=workers, per_chunk=per_chunk, loaders=loaders, n_slots=n_slots, packed=packed,
+                input_bytes=int(st["input_bytes"]))
 
 
 def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
-    """STRONG scaling: ONE region list for the whole job (`--regions`, default 64 per rank), region i -> rank i % N (runner.py:473-474);
-    every rank calls its share, the record lines travel to rank 0 (sizes all-gather + point to point) and are merged by (chrom, pos)
-    (runner.py:301-352).  The timed region covers the calls, the gather and the merge."""
+    """STRONG scaling: ONE region list for the whole job (`--regions`; default 3 875 per GPU = one GPU's share of the 31 000 regions of the
+    synthetic 30x genome), region i -> rank i % N (runner.py:473-474); every rank streams its share through the region loop,
+    the record lines travel to rank 0 (sizes all-gather + point to point) and are merged by (chrom, pos) (runner.py:301-352).  The timed
+    region covers loading (generating) the regions, the calls, the gather and the merge."""
     from platypus_amd import sharding
     rank, world = rk.rank, rk.world
-    total = a.regions or 64 * world
+    total = a.regions or 3875 * world
     mine = sharding.regions_for_rank(total, rank, world)
     workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, getattr(rk, "cpus", 16))))))
     per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "4"))
     pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1" and lib is None
-    r = config4(rk.dev_index, mine, region_len, workers, per_chunk, repeats=max(1, min(a.steps, 3)), pin=pin, lib=lib, region_kw=region_kw, rk=rk)
-    T, (wins, regs, recs, reads, tcall) = rk.reduce(r["T"], [r["windows"], r["regions"], r["records"], r["reads"], r["T_call"]])
+    packed = os.environ.get("PLAT_CALLER_PACKED", "1") == "1"
+    repeats = max(1, min(a.steps, 3)) if total <= 512 * world else 1
+    r = config4(rk.dev_index, mine, region_len, workers, per_chunk, repeats=repeats, pin=pin, lib=lib, region_kw=region_kw, rk=rk, packed=packed)
+    T, (wins, regs, recs, reads, tcall, inb) = rk.reduce(r["T"], [r["windows"], r["regions"], r["records"], r["reads"], r["T_call"], r["input_bytes"]])
     st = r["stats"]
     line = {"metric": "variant windows/sec end to end (reads in host memory -> VCF record text)", "value": wins / T, "unit": "windows/s",
-            "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * T, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "n_gpus": world, "steps": repeats, "warmup": 1, "ms_per_step": 1e3 * T, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "BASELINE config 4: %d regions x %d bp for the whole job, 30x 150 bp reads, SNPs 1e-3 + indels 1e-4, one sample; step = "
+            "config": {"workload": "BASELINE config 4: %d regions x %d bp for the whole job, 30x 150 bp reads, SNPs 1e-3 + indels 1e-4, one sample, each region "
+                                   "generated from seed (+) index when its turn comes (region source in %d loader threads, %d pinned slots); step = "
                                    "candidates -> windows -> haplotypes -> likelihoods / EM / posteriors -> INFO / FILTER -> record text for all "
                                    "regions (native region loop, %d host threads, %d regions per chunk), then the gather of the record lines to "
-                                   "rank 0 and their merge" % (total, region_len, r["workers"], r["per_chunk"]),
-                       "regions": total, "region_len": region_len, "sharding": "region i -> rank i % N, records gathered to rank 0 and merged by (chrom, pos)"},
-            "regions_per_sec": regs / T, "reads_per_sec": reads / T, "records": recs, "windows": wins, "planted_variants": r["planted"],
-            "seconds_calls_mean_over_ranks": tcall / world,
+                                   "rank 0 and their merge; mean of %d timed run(s)" % (total, region_len, r["loaders"], r["n_slots"], r["workers"],
+                                                                                        r["per_chunk"], repeats),
+                       "regions": total, "region_len": region_len, "sharding": "region i -> rank i % N, records gathered to rank 0 and merged by (chrom, pos)",
+                       "read_encoding": "packed: one byte per base (2-bit base | quality << 2)" if r["packed"] else "ASCII bases + quality bytes"},
+            "regions_per_sec": regs / T, "reads_per_sec": reads / T, "records": recs, "windows": wins, "regions": regs, "timed_s": T,
+            "timed_s_runs": r["T_runs"], "planted_variants": r["planted"], "seconds_calls_mean_over_ranks": tcall / world,
             "host_seconds_per_region": st["seconds_host"] / max(1, r["regions"]),
             "device_wait_seconds_per_region": st["seconds_device_wait"] / max(1, r["regions"]),
-            "host_input_bytes_per_region": 2 * 150 * r["reads"] // max(1, r["regions"]), "input_blobs_pinned": pin,
+            "source_seconds_per_region": st["seconds_load"] / max(1, r["regions"]),
+            "worker_seconds_waiting_for_the_source_per_region": st["seconds_source_wait"] / max(1, r["regions"]),
+            "host_input_bytes_per_region": inb / max(1.0, regs), "h2d_gbytes_per_sec": inb / T / 1e9, "input_blobs_pinned": pin,
             "stage_seconds_per_region": {k: v / max(1, r["regions"]) for k, v in st["seconds_stage"].items()},
             "record_gather": r["gather"], "python_region_loop_windows_per_sec_round1": 1100.0}
     if rank == 0:
@@ -245,12 +258,19 @@ def summary(eng):
     out["config3_assembler"] = dict(regions=500, reads=int(r["ab"]["n_reads"]), regions_per_sec=500 * r["steps"] / r["T"],
                                     kernel_ms=r["kernel_ms"], hbm_frac=r["alg_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                     variants_found=r["variants"], variants_planted=r["planted"])
-    r = config4(0, range(64), 100000, int(os.environ.get("PLAT_CALLER_WORKERS", "16")), int(os.environ.get("PLAT_CALLER_CHUNK", "4")), repeats=3)
+    nreg = int(os.environ.get("PLAT_BENCH_CONFIG4_REGIONS", "3875"))           # one GPU's share of the 31 000 regions (SURVEY 8(d) cfg 4)
+    r = config4(0, range(nreg), 100000, int(os.environ.get("PLAT_CALLER_WORKERS", "16")), int(os.environ.get("PLAT_CALLER_CHUNK", "4")), repeats=1)
     st = r["stats"]
     out["config4_region_pipeline"] = dict(regions=r["regions"], region_len=r["region_len"], reads=r["reads"], windows=r["windows"], records=r["records"],
-                                          planted_variants=r["planted"], seconds=r["T"], windows_per_sec=r["windows"] / r["T"],
+                                          planted_variants=r["planted"], timed_s=r["T"], windows_per_sec=r["windows"] / r["T"],
                                           regions_per_sec=r["regions"] / r["T"], reads_per_sec=r["reads"] / r["T"],
                                           host_seconds_per_region=st["seconds_host"] / r["regions"],
-                                          device_wait_seconds_per_region=st["seconds_device_wait"] / r["regions"], host_threads=r["workers"],
-                                          regions_per_chunk=r["per_chunk"], what="reads in host memory (arrays) -> VCF record text, native region loop")
+                                          device_wait_seconds_per_region=st["seconds_device_wait"] / r["regions"],
+                                          source_seconds_per_region=st["seconds_load"] / r["regions"],
+                                          worker_seconds_waiting_for_the_source_per_region=st["seconds_source_wait"] / r["regions"],
+                                          host_input_bytes_per_region=r["input_bytes"] / r["regions"], h2d_gbytes_per_sec=r["input_bytes"] / r["T"] / 1e9,
+                                          host_threads=r["workers"], loader_threads=r["loaders"], regions_per_chunk=r["per_chunk"],
+                                          read_encoding="packed (1 B/base)" if r["packed"] else "ascii (2 B/base)",
+                                          what="regions generated on demand into pinned slots (region source) -> native region loop -> VCF record text; "
+                                               "one run over the whole share, no best-of")
     return out

@@ -1,0 +1,300 @@
+// region_source.cpp -- libplat_synth.so: the synthetic WGS workload of BASELINE config 4 as a REGION SOURCE for plat_call_regions_stream
+// (include/platypus_caller.h).  Benchmark tooling, not product: it stands where the reference's loader stands (loadBAMData for one
+// 100 kb region at a time, variantcaller.pyx:935-1012) and produces, from seed (+) region index alone, what that loader would hand over --
+// the region's reference and its reads as arrays (cAlignedRead fields) in the slot's pinned buffer, as ASCII or packed bytes.
+//
+// Recipe (SURVEY.md 8(d) cfg 4; the same as platypus_amd/synth.py::config4_region_arrays, drawn with its own generator so that a region
+// costs a millisecond or two of one core instead of a quarter second): own contig r<index> = flank + region + flank of uniform ACGT;
+// SNPs at snp_rate and 1..10 bp indels at indel_rate inside the region (never closer than 2 / 3+ bases); a diploid donor per sample,
+// every variant on either haplotype with probability 1/2; depth x region_len / read_len reads of read_len bases from either haplotype,
+// start uniform over the region, with the CIGAR an aligner would report; substitution errors at `err`; qualities ~ clipped N(35, 5)
+// (rows of a shared tape of such draws); mapq 60; flags 3 | 16 at random; sorted by position.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/platypus_caller.h"
+
+#define SYNTH_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+struct Rng {                                                               // xoshiro256**, seeded through splitmix64
+    uint64_t s[4];
+    static uint64_t sm(uint64_t& x) { uint64_t z = (x += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+    Rng(uint64_t seed, uint64_t stream) { uint64_t x = seed ^ (stream * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull); for (auto& v : s) v = sm(x); }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() { const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17; s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45); return r; }
+    double uni() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+    uint32_t below(uint32_t n) { return (uint32_t)(((next() >> 32) * (uint64_t)n) >> 32); }
+    int poisson(double lam) { int k = 0; double t = -std::log(1.0 - uni()) / lam; while (t < 1.0) { ++k; t += -std::log(1.0 - uni()) / lam; } return k; }
+    int geometric(double p) { return 1 + (int)std::floor(std::log(1.0 - uni()) / std::log(1.0 - p)); }
+};
+
+struct Var { int pos, kind, len; std::string bases; };                     // kind 0 SNP, 1 insertion after pos, 2 deletion of (pos, pos+len]
+
+}  // namespace
+
+struct plat_synth {
+    uint64_t seed;
+    int regionLen, flank, nSamples, depth, readLen, encoding;
+    double snpRate, indelRate, err;
+    std::vector<int32_t> index;                                            // job position -> region id
+    uint8_t* mem; size_t slotBytes; int nSlots;
+    std::vector<uint8_t> tape;                                             // quality tape
+    long long planted = 0, reads = 0;                                      // totals over the regions loaded (statistics)
+};
+
+static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
+
+static size_t slotBytesFor(int regionLen, int flank, int nSamples, int depth, int readLen, int encoding) {
+    const size_t n = (size_t)regionLen + 2 * (size_t)flank, nr = (size_t)((double)depth * regionLen / readLen) + 1, nb = nr * (size_t)readLen;
+    size_t perSample = align64(nb + 64) * (encoding == PLAT_READS_PACKED ? 1 : 2) + align64((nr + 1) * 8) + 4 * align64(nr * 4 + 4) + align64(nr + 4) +
+                       align64((nr + 1) * 4) + align64((3 * nr + 64) * 4);
+    return align64(n + 64) + 256 + align64((size_t)nSamples * sizeof(plat_sample_reads)) + (size_t)nSamples * perSample + 4096;
+}
+
+SYNTH_EXPORT size_t plat_synth_slot_bytes(int region_len, int flank, int n_samples, int depth, int read_len, int encoding) {
+    return slotBytesFor(region_len, flank, n_samples, depth, read_len, encoding);
+}
+
+SYNTH_EXPORT int plat_synth_create(uint64_t seed, int region_len, int flank, int n_samples, int depth, int read_len, double snp_rate, double indel_rate,
+                                   double err, int encoding, const int32_t* region_index, int n_regions, void* slot_memory, size_t slot_bytes, int n_slots,
+                                   plat_synth** out)
+{
+    if (!out || region_len < 200 || flank < 0 || n_samples < 1 || depth < 1 || read_len < 20 || read_len > 10000 || !region_index || n_regions < 0 ||
+        !slot_memory || n_slots < 1 || (encoding != PLAT_READS_ASCII && encoding != PLAT_READS_PACKED) || err < 0 || err >= 0.5)
+        return -1;
+    if (slot_bytes < slotBytesFor(region_len, flank, n_samples, depth, read_len, encoding)) return -1;
+    plat_synth* g = new plat_synth();
+    g->seed = seed; g->regionLen = region_len; g->flank = flank; g->nSamples = n_samples; g->depth = depth; g->readLen = read_len; g->encoding = encoding;
+    g->snpRate = snp_rate; g->indelRate = indel_rate; g->err = err;
+    g->index.assign(region_index, region_index + n_regions);
+    g->mem = (uint8_t*)slot_memory; g->slotBytes = slot_bytes; g->nSlots = n_slots;
+    // the quality tape: 1 M draws of clip(round(N(35, 5)), 2, 41) (+ one read of slack), Box-Muller
+    const size_t T = (1u << 20) + (size_t)read_len + 64;
+    g->tape.resize(T);
+    Rng r(seed, 0xFFFFFFFFull);
+    for (size_t i = 0; i < T; i += 2) {
+        const double u1 = 1.0 - r.uni(), u2 = r.uni(), m = std::sqrt(-2.0 * std::log(u1));
+        const double z[2] = {m * std::cos(6.283185307179586 * u2), m * std::sin(6.283185307179586 * u2)};
+        for (int k = 0; k < 2 && i + k < T; ++k) g->tape[i + k] = (uint8_t)std::min(41.0, std::max(2.0, std::floor(35.0 + 5.0 * z[k] + 0.5)));
+    }
+    *out = g;
+    return 0;
+}
+
+SYNTH_EXPORT void plat_synth_destroy(plat_synth* g) { delete g; }
+SYNTH_EXPORT long long plat_synth_planted(const plat_synth* g) { return g ? g->planted : 0; }
+
+namespace {
+struct Carve {
+    uint8_t* p; uint8_t* end;
+    template <class T> T* take(size_t n) { T* r = (T*)p; p += align64(n * sizeof(T)); return p <= end ? r : nullptr; }
+};
+struct Scratch {
+    std::vector<uint8_t> hs[2];
+    std::vector<int32_t> h2r[2], r2h[2], insPre[2];
+    std::vector<int32_t> i0, posOf, order, count;
+    std::vector<uint8_t> which;
+    std::vector<Var> vars;
+    std::vector<int> spots, kinds;
+};
+}  // namespace
+
+// The plat_region_load_fn: region `index` of the job into slot `slot`.
+SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* out)
+{
+    plat_synth* g = (plat_synth*)user;
+    if (!g || !out || index < 0 || index >= (int)g->index.size() || slot < 0 || slot >= g->nSlots) return -1;
+    static thread_local Scratch S;
+    const int id = g->index[(size_t)index];
+    Rng rng(g->seed, (uint64_t)(uint32_t)id);
+    const int L = g->readLen, start = g->flank, end = g->flank + g->regionLen, n = g->regionLen + 2 * g->flank;
+    Carve cv{g->mem + (size_t)slot * g->slotBytes, g->mem + (size_t)(slot + 1) * g->slotBytes};
+    uint8_t* ref = cv.take<uint8_t>((size_t)n + 64);
+    char* chrom = cv.take<char>(64);
+    plat_sample_reads* samples = cv.take<plat_sample_reads>((size_t)g->nSamples);
+    if (!ref || !chrom || !samples) return -3;
+    for (int i = 0; i < n; i += 32) {                                      // 32 bases per draw
+        uint64_t w = rng.next();
+        for (int k = 0; k < 32 && i + k < n; ++k, w >>= 2) ref[i + k] = (uint8_t)"ACGT"[w & 3];
+    }
+    memset(ref + n, 0, 64);
+    snprintf(chrom, 64, "r%d", id);
+    // ---- planted variants
+    std::vector<Var>& vars = S.vars;
+    vars.clear();
+    {
+        const int nSnp = rng.poisson(g->regionLen * g->snpRate + 1e-12), nInd = rng.poisson(g->regionLen * g->indelRate + 1e-12);
+        S.kinds.assign((size_t)nSnp, 0); S.kinds.insert(S.kinds.end(), (size_t)nInd, 1);
+        for (size_t i = S.kinds.size(); i > 1; --i) std::swap(S.kinds[i - 1], S.kinds[rng.below((uint32_t)i)]);
+        const int lo = start + 20, hi = end - 40;
+        S.spots.clear();
+        if (hi > lo) for (size_t i = 0; i < S.kinds.size(); ++i) S.spots.push_back(lo + (int)rng.below((uint32_t)(hi - lo)));
+        std::sort(S.spots.begin(), S.spots.end());
+        int last = start + 20;
+        for (size_t i = 0; i < S.spots.size(); ++i) {
+            const int p = S.spots[i];
+            if (p < last) continue;
+            if (S.kinds[i] == 0) {
+                const char* B = "ACGT";
+                const int cur = (int)(strchr(B, ref[p]) - B);
+                vars.push_back(Var{p, 0, 1, std::string(1, B[(cur + 1 + (int)rng.below(3)) & 3])});
+                last = p + 2;
+            } else {
+                const int k = 1 + std::min(9, rng.geometric(0.4) - 1);
+                if (rng.uni() < 0.5) {
+                    std::string b((size_t)k, 'A');
+                    for (char& c : b) c = "ACGT"[rng.below(4)];
+                    vars.push_back(Var{p, 1, k, b});
+                    last = p + 3;
+                } else if (p + 1 + k < end) {
+                    vars.push_back(Var{p, 2, k, std::string()});
+                    last = p + k + 3;
+                }
+            }
+        }
+    }
+    const int nReads = (int)((double)g->depth * g->regionLen / L);
+    long long nReadsAll = 0;
+    for (int si = 0; si < g->nSamples; ++si) {
+        // ---- the donor's two haplotypes: bytes, hap position -> reference position (-1 = inserted), reference position -> hap position
+        for (int h = 0; h < 2; ++h) {
+            std::vector<uint8_t>& hs = S.hs[h];
+            std::vector<int32_t>& h2r = S.h2r[h];
+            hs.clear(); h2r.clear();
+            int cur = 0;
+            auto copyTo = [&](int upto) {                                    // reference bases [cur, upto) as they are
+                if (upto > cur) {
+                    const size_t at = hs.size(), m = (size_t)(upto - cur);
+                    hs.resize(at + m); h2r.resize(at + m);
+                    memcpy(hs.data() + at, ref + cur, m);
+                    for (size_t x = 0; x < m; ++x) h2r[at + x] = cur + (int32_t)x;
+                    cur = upto;
+                }
+            };
+            for (const Var& v : vars) {
+                if (!(rng.next() >> 63)) continue;                          // this haplotype does not carry it
+                if (v.kind == 0) { copyTo(v.pos); hs.push_back((uint8_t)v.bases[0]); h2r.push_back(v.pos); cur = v.pos + 1; }
+                else if (v.kind == 1) { copyTo(v.pos + 1); for (char c : v.bases) { hs.push_back((uint8_t)c); h2r.push_back(-1); } }
+                else { copyTo(v.pos + 1); cur = v.pos + 1 + v.len; }
+            }
+            copyTo(n);
+            const int hl = (int)hs.size();
+            std::vector<int32_t>& r2h = S.r2h[h];
+            r2h.assign((size_t)n + 1, hl);
+            for (int i = 0; i < hl; ++i) if (h2r[(size_t)i] >= 0) r2h[(size_t)h2r[(size_t)i]] = i;
+            for (int x = n - 1; x >= 0; --x) r2h[(size_t)x] = std::min(r2h[(size_t)x], r2h[(size_t)x + 1]);   // a deleted base maps to the next base that exists
+            std::vector<int32_t>& ip = S.insPre[h];
+            ip.assign((size_t)hl + 1, 0);
+            for (int i = 0; i < hl; ++i) ip[(size_t)i + 1] = ip[(size_t)i] + (h2r[(size_t)i] < 0);
+        }
+        if ((int)S.hs[0].size() < L || (int)S.hs[1].size() < L) return -1;
+        // ---- read starts, sorted by position (counting sort: stable in draw order)
+        S.i0.resize((size_t)nReads); S.posOf.resize((size_t)nReads); S.which.resize((size_t)nReads); S.order.resize((size_t)nReads);
+        S.count.assign((size_t)n + 2, 0);
+        for (int r = 0; r < nReads; ++r) {
+            const int h = (int)(rng.next() >> 63);
+            const int p0 = start - L + 10 + (int)rng.below((uint32_t)(end - 10 - (start - L + 10)));
+            int i0 = std::min<int>(S.r2h[h][(size_t)std::max(p0, 0)], (int)S.hs[h].size() - L);
+            while (i0 > 0 && S.h2r[h][(size_t)i0] < 0) --i0;                // a read starts on a reference base
+            S.which[(size_t)r] = (uint8_t)h; S.i0[(size_t)r] = i0; S.posOf[(size_t)r] = S.h2r[h][(size_t)i0];
+            ++S.count[(size_t)S.posOf[(size_t)r] + 1];
+        }
+        for (int x = 0; x <= n; ++x) S.count[(size_t)x + 1] += S.count[(size_t)x];
+        for (int r = 0; r < nReads; ++r) S.order[(size_t)S.count[(size_t)S.posOf[(size_t)r]]++] = r;
+        // ---- the table
+        const size_t nb = (size_t)nReads * (size_t)L;
+        uint8_t* seq = cv.take<uint8_t>(nb + 64);
+        uint8_t* qual = g->encoding == PLAT_READS_PACKED ? nullptr : cv.take<uint8_t>(nb + 64);
+        int64_t* off = cv.take<int64_t>((size_t)nReads + 1);
+        int32_t* pos = cv.take<int32_t>((size_t)nReads + 1);
+        int32_t* endp = cv.take<int32_t>((size_t)nReads + 1);
+        int32_t* flags = cv.take<int32_t>((size_t)nReads + 1);
+        int32_t* mate = cv.take<int32_t>((size_t)nReads + 1);
+        uint8_t* mapq = cv.take<uint8_t>((size_t)nReads + 4);
+        int32_t* cigoff = cv.take<int32_t>((size_t)nReads + 1);
+        const size_t cigCap = 3 * (size_t)nReads + 64;
+        int16_t* cigar = cv.take<int16_t>(2 * cigCap);
+        if (!seq || (!qual && g->encoding != PLAT_READS_PACKED) || !off || !pos || !endp || !flags || !mate || !mapq || !cigoff || !cigar) return -3;
+        size_t nc = 0;
+        uint8_t tmpS[10064];
+        long long toErr = g->err > 0 ? (long long)std::floor(std::log(1.0 - rng.uni()) / std::log(1.0 - g->err)) : (1ll << 62);   // bases until the next substitution error
+        for (int k = 0; k < nReads; ++k) {
+            const int r = S.order[(size_t)k], h = S.which[(size_t)r], i0 = S.i0[(size_t)r];
+            const uint8_t* src = S.hs[h].data() + i0;
+            const int32_t* map = S.h2r[h].data() + i0;
+            off[k] = (int64_t)k * L; pos[k] = map[0]; mate[k] = -1; mapq[k] = 60;
+            flags[k] = 3 | ((rng.next() >> 63) ? 16 : 0);
+            cigoff[k] = (int32_t)nc;
+            if (S.insPre[h][(size_t)i0 + L] == S.insPre[h][(size_t)i0] && map[L - 1] - map[0] == L - 1) {
+                cigar[2 * nc] = 0; cigar[2 * nc + 1] = (int16_t)L; ++nc;
+                endp[k] = map[0] + L;
+            } else {
+                int lastRef = -1;
+                const size_t first = nc;
+                for (int i = 0; i < L; ++i) {
+                    int op, ln = 1;
+                    if (map[i] < 0) op = 1;
+                    else {
+                        if (lastRef >= 0 && map[i] - lastRef > 1) {
+                            if (nc >= cigCap) return -8;
+                            cigar[2 * nc] = 2; cigar[2 * nc + 1] = (int16_t)(map[i] - lastRef - 1); ++nc;
+                        }
+                        op = 0; lastRef = map[i];
+                    }
+                    if (nc > first && cigar[2 * (nc - 1)] == op) cigar[2 * (nc - 1) + 1] = (int16_t)(cigar[2 * (nc - 1) + 1] + ln);
+                    else { if (nc >= cigCap) return -8; cigar[2 * nc] = (int16_t)op; cigar[2 * nc + 1] = (int16_t)ln; ++nc; }
+                }
+                endp[k] = lastRef + 1;
+            }
+            const uint8_t* q = g->tape.data() + (rng.next() & ((1u << 20) - 1));
+            uint8_t* ds = seq + (size_t)k * L;
+            const uint8_t* s = src;
+            if (toErr < L) {                                                // (rare: one read in six at 0.1 %)
+                memcpy(tmpS, src, (size_t)L);
+                while (toErr < L) {
+                    const char* B = "ACGT";
+                    const char* at = strchr(B, tmpS[toErr]);
+                    tmpS[toErr] = (uint8_t)B[((at ? (int)(at - B) : 0) + 1 + (int)rng.below(3)) & 3];
+                    toErr += 1 + (long long)std::floor(std::log(1.0 - rng.uni()) / std::log(1.0 - g->err));
+                }
+                s = tmpS;
+            }
+            toErr -= L;
+            if (g->encoding == PLAT_READS_PACKED) {
+                for (int i = 0; i < L; ++i) ds[i] = (uint8_t)(((s[i] >> 1) & 3) | (q[i] << 2));
+            } else {
+                memcpy(ds, s, (size_t)L);
+                memcpy(qual + (size_t)k * L, q, (size_t)L);
+            }
+        }
+        off[nReads] = (int64_t)nb; cigoff[nReads] = (int32_t)nc;
+        memset(seq + nb, 0, 64);
+        if (qual) memset(qual + nb, 0, 64);
+        plat_sample_reads& sr = samples[si];
+        memset(&sr, 0, sizeof sr);
+        plat_read_table& t = sr.reads;
+        t.n_reads = nReads; t.encoding = g->encoding; t.seq = seq; t.qual = qual ? qual : seq; t.off = off; t.pos = pos; t.end = endp; t.mapq = mapq;
+        t.flags = flags; t.mate_pos = mate; t.cigar = cigar; t.cig_off = cigoff;
+        static const int64_t zero64[1] = {0};
+        static const int32_t zero32[1] = {0};
+        for (plat_read_table* e : {&sr.bad_reads, &sr.broken_mates}) {
+            e->n_reads = 0; e->encoding = PLAT_READS_ASCII; e->seq = seq; e->qual = seq; e->off = zero64; e->pos = zero32; e->end = zero32; e->mapq = mapq;
+            e->flags = zero32; e->mate_pos = zero32; e->cigar = cigar; e->cig_off = zero32;
+        }
+        nReadsAll += nReads;
+    }
+    out->chrom = chrom; out->start = start; out->end = end; out->contig_seq = ref; out->contig_len = n; out->samples = samples;
+    __atomic_add_fetch(&g->planted, (long long)vars.size(), __ATOMIC_RELAXED);
+    __atomic_add_fetch(&g->reads, nReadsAll, __ATOMIC_RELAXED);
+    return 0;
+}
+
+// address of the load function, for callers that pass it on as a plain pointer (ctypes)
+SYNTH_EXPORT void* plat_synth_load_fn(void) { return (void*)&plat_synth_load; }
