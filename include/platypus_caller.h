@@ -143,6 +143,11 @@ typedef int (*plat_region_load_fn)(void* user, int index, int slot, plat_region*
 int plat_call_regions_stream(plat_caller* c, int n_regions, int n_samples, const char* const* sample_names,
                              plat_caller_options* options, plat_region_load_fn load, void* user, int n_slots,
                              int n_loader_threads, char** out_text, size_t* out_len, plat_caller_stats* stats /* may be NULL */);
+/* The merge of the per-process record files (runner.py:301-352: a k-way heap merge of the workers' temporary VCFs by chromosome and
+ * position; key of a chromosome name runner.py:47-50: int(name.upper().strip("CHR")) if that parses, else the name, integers first):
+ * n texts of record lines, each already in that order, -> one text in that order (ties: the earlier text first).  For the job's one
+ * exchange: every rank's record text gathered to rank 0, merged there.  *out_text is malloc'ed (plat_caller_free). */
+int plat_merge_record_texts(const char* const* texts, const size_t* lengths, int n, char** out_text, size_t* out_len);
 void plat_caller_free(void* p);
 /* Human-readable message of the last error of a failing plat_call_regions on this caller. */
 const char* plat_caller_last_error(const plat_caller* c);

@@ -444,7 +444,7 @@ struct Chunk {
 
     // -- A: one device table for every read of the chunk; layout: all `reads` of every (region, sample), then all badReads, then all brokenMates
     void uploadReads() {
-        size_t nReads[3] = {0, 0, 0}, nBytes[3] = {0, 0, 0}, nCig[3] = {0, 0, 0}, nExc = 0, nTables = 0;
+        size_t nReads[3] = {0, 0, 0}, nBytes[3] = {0, 0, 0}, nCig[3] = {0, 0, 0}, nExc = 0;
         bool anyPacked = false;
         for (RegionWork* r : regions)
             for (SampleView& sv : r->samples) {
@@ -454,13 +454,11 @@ struct Chunk {
                     nReads[k] += (size_t)t.n_reads;
                     nBytes[k] += (size_t)t.off[t.n_reads];
                     nCig[k] += (size_t)t.cig_off[t.n_reads];
-                    ++nTables;
                     if (t.encoding == PLAT_READS_PACKED) { anyPacked = true; nExc += (size_t)std::max<int64_t>(t.n_exceptions, 0); }
                     else if (t.encoding != PLAT_READS_ASCII) throw DeviceError(PLAT_ERR_INVALID, "plat_read_table.encoding");
                 }
             }
-        // every table starts on a 16-byte boundary of the chunk blob (the expanding kernel moves 16 bytes per lane)
-        const size_t N = nReads[0] + nReads[1] + nReads[2], B = nBytes[0] + nBytes[1] + nBytes[2] + 16 * nTables, Cg = nCig[0] + nCig[1] + nCig[2];
+        const size_t N = nReads[0] + nReads[1] + nReads[2], B = nBytes[0] + nBytes[1] + nBytes[2], Cg = nCig[0] + nCig[1] + nCig[2];
         if (N > 0x7FFFFFF0ull) throw DeviceError(PLAT_ERR_OVERFLOW, "chunk read table");
         Slot& z = s;
         z.t_seq.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream); z.t_qual.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream);
@@ -483,7 +481,6 @@ struct Chunk {
                     const int n = t.n_reads;
                     tv.base = (int64_t)ri;
                     const size_t nb = (size_t)t.off[n], nc = (size_t)t.cig_off[n];
-                    bo = (bo + 15) & ~(size_t)15;
                     if (nb && t.encoding == PLAT_READS_PACKED) {            // one byte per base crosses the link; expanded below
                         ck(plat_memcpy_h2d(z.ctx, z.t_pack.d + bo, t.seq, nb, z.stream), "plat_memcpy_h2d(packed)");
                         const size_t ne = (size_t)std::max<int64_t>(t.n_exceptions, 0);
@@ -1660,6 +1657,91 @@ CALLER_EXPORT int plat_call_regions_stream(plat_caller* c, int n_regions, int n_
     st.seconds_total = secs(t0, Clock::now());
     st.seconds_load = feed.tLoad; st.seconds_source_wait = feed.tWait;
     if (stats) *stats = st;
+    return PLAT_OK;
+}
+
+// ---- runner.py:301-352: the merge of the per-process record texts by (chromosome key, position) ------------------------------------------------
+namespace plathost {
+struct MergeKey { int kind; long long num; const char* name; size_t nameLen; long long pos; };
+// runner.py:47-50: int(chrom.upper().strip("CHR")) if it is one, else the name itself; integers sort before names (Python 2 orders int < str)
+static MergeKey mergeKeyOf(const char* line, const char* end) {
+    const char* t1 = (const char*)memchr(line, '\t', (size_t)(end - line));
+    MergeKey k{1, 0, line, t1 ? (size_t)(t1 - line) : (size_t)(end - line), 0};
+    if (t1) {
+        const char* p = t1 + 1;
+        long long v = 0;
+        while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
+        k.pos = v - 1;                                                     // (record positions are 1-based in the text: runner.py:77-82 keys on int(cols[1]))
+    }
+    const char* a = line; const char* b = line + k.nameLen;
+    auto strip = [](char c) { c = (char)toupper((unsigned char)c); return c == 'C' || c == 'H' || c == 'R'; };
+    while (a < b && strip(*a)) ++a;
+    while (b > a && strip(b[-1])) --b;
+    if (a < b) {
+        const char* p = a;
+        bool neg = false;
+        if (*p == '+' || *p == '-') { neg = *p == '-'; ++p; }
+        bool digits = p < b;
+        long long v = 0;
+        for (const char* q = p; q < b; ++q) { if (*q < '0' || *q > '9') { digits = false; break; } v = v * 10 + (*q - '0'); }
+        if (digits) { k.kind = 0; k.num = neg ? -v : v; }
+    }
+    return k;
+}
+static bool mergeLess(const MergeKey& a, const MergeKey& b) {
+    if (a.kind != b.kind) return a.kind < b.kind;
+    if (a.kind == 0) { if (a.num != b.num) return a.num < b.num; }
+    else {
+        const int c = memcmp(a.name, b.name, std::min(a.nameLen, b.nameLen));
+        if (c != 0) return c < 0;
+        if (a.nameLen != b.nameLen) return a.nameLen < b.nameLen;
+    }
+    return a.pos < b.pos;
+}
+}  // namespace plathost
+
+CALLER_EXPORT int plat_merge_record_texts(const char* const* texts, const size_t* lengths, int n, char** out_text, size_t* out_len) {
+    if (!out_text || !out_len || n < 0 || (n > 0 && (!texts || !lengths))) return PLAT_ERR_INVALID;
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += lengths[i] + 1;
+    char* out = (char*)malloc(total + 1);
+    if (!out) return PLAT_ERR_NOMEM;
+    struct Cur { const char* p; const char* end; const char* eol; MergeKey key; bool live; };
+    std::vector<Cur> cur((size_t)n);
+    auto advance = [](Cur& c) {
+        while (c.p < c.end && (*c.p == '\n' || *c.p == '#')) {             // empty and header lines do not take part
+            const char* e = (const char*)memchr(c.p, '\n', (size_t)(c.end - c.p));
+            c.p = e ? e + 1 : c.end;
+        }
+        c.live = c.p < c.end;
+        if (c.live) {
+            const char* e = (const char*)memchr(c.p, '\n', (size_t)(c.end - c.p));
+            c.eol = e ? e : c.end;
+            c.key = mergeKeyOf(c.p, c.eol);
+        }
+    };
+    for (int i = 0; i < n; ++i) { cur[(size_t)i] = Cur{texts[i], texts[i] + lengths[i], nullptr, MergeKey{}, false}; advance(cur[(size_t)i]); }
+    size_t at = 0;
+    for (;;) {
+        int best = -1;
+        for (int i = 0; i < n; ++i)                                        // (a handful of streams: a scan is as good as a heap)
+            if (cur[(size_t)i].live && (best < 0 || mergeLess(cur[(size_t)i].key, cur[(size_t)best].key))) best = i;
+        if (best < 0) break;
+        Cur& c = cur[(size_t)best];
+        // a run of lines of this stream that stay in front of every other stream's head moves as one block
+        const char* from = c.p;
+        for (;;) {
+            c.p = c.eol < c.end ? c.eol + 1 : c.end;
+            const char* lastEol = c.eol;
+            advance(c);
+            bool still = c.live;
+            for (int i = 0; still && i < n; ++i)
+                if (i != best && cur[(size_t)i].live && (mergeLess(cur[(size_t)i].key, c.key) || (i < best && !mergeLess(c.key, cur[(size_t)i].key)))) still = false;
+            if (!still) { const size_t len = (size_t)(lastEol - from); memcpy(out + at, from, len); at += len; out[at++] = '\n'; break; }
+        }
+    }
+    out[at] = 0;
+    *out_text = out; *out_len = at;
     return PLAT_OK;
 }
 

@@ -54,6 +54,7 @@ PLAT_EXPORT int plat_ctx_create(int device, plat_ctx** out_ctx) {
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_readback, 64 * sizeof(int64_t));
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_sticky, 8 * sizeof(int64_t), hipHostMallocMapped);
     if (e == hipSuccess) { ctx->h_sticky[0] = 0; e = hipHostGetDevicePointer(&ctx->d_sticky, ctx->h_sticky, 0); }
+    if (e == hipSuccess) { hipEvent_t ev = nullptr; e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming); ctx->sync_event = ev; }
     if (e != hipSuccess) { delete ctx; return PLAT_ERR_HIP; }
     *out_ctx = ctx;
     return PLAT_OK;
@@ -69,6 +70,7 @@ PLAT_EXPORT int plat_ctx_destroy(plat_ctx* ctx) {
     if (ctx->d_mapq_lut) { e = hipFree(ctx->d_mapq_lut); (void)e; }
     if (ctx->h_readback) { e = hipHostFree(ctx->h_readback); (void)e; }
     if (ctx->h_sticky) { e = hipHostFree(ctx->h_sticky); (void)e; }
+    if (ctx->sync_event) { e = hipEventDestroy((hipEvent_t)ctx->sync_event); (void)e; }
     for (int i = 0; i < 8; ++i)
         if (ctx->ev[i]) { e = hipEventDestroy(ctx->ev[i]); (void)e; }
     delete ctx;
@@ -171,7 +173,15 @@ PLAT_EXPORT int plat_host_free(plat_ctx* ctx, void* p) {
 
 PLAT_EXPORT int plat_stream_sync(plat_ctx* ctx, void* stream) {
     if (!ctx) return PLAT_ERR_INVALID;
-    PLAT_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    // The waiting thread SLEEPS (an event with hipEventBlockingSync) instead of spinning on the stream: a caller with many worker
+    // threads, most of them waiting for the device at any time, would otherwise burn the cores its host stages need
+    // (PLAT_SYNC_SPIN=1: hipStreamSynchronize, the runtime's default wait).
+    static const bool spin = [] { const char* e = getenv("PLAT_SYNC_SPIN"); return e && e[0] == '1'; }();
+    if (spin || !ctx->sync_event) PLAT_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    else {
+        PLAT_HIP(ctx, hipEventRecord((hipEvent_t)ctx->sync_event, (hipStream_t)stream));
+        PLAT_HIP(ctx, hipEventSynchronize((hipEvent_t)ctx->sync_event));
+    }
     if (ctx->h_sticky && ctx->h_sticky[0] != 0) {          // error recorded by an asynchronous call since the last sync
         const int rc = (int)ctx->h_sticky[0];
         ctx->h_sticky[0] = 0;

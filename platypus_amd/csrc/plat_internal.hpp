@@ -27,6 +27,7 @@ struct plat_ctx {
     // asynchronous entry points: first device-side error since the last plat_stream_sync (pinned, device-visible)
     int64_t* h_sticky = nullptr;
     void* d_sticky = nullptr;
+    void* sync_event = nullptr;         // hipEvent_t with hipEventBlockingSync: plat_stream_sync sleeps on it
     // optional live timing: events 0..5 bracket prepare|seed|dp|finalize, 6..7 bracket genotype
     int profile = 0;
     hipEvent_t ev[8] = {};

@@ -239,6 +239,7 @@ def _bind(lib):
                                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(CallerStats)]
     lib.plat_call_regions_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(CallerOptions), C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(CallerStats)]
+    lib.plat_merge_record_texts.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.plat_caller_free.argtypes = [C.c_void_p]
     lib.plat_caller_free.restype = None
     lib.plat_caller_last_error.argtypes = [C.c_void_p]
@@ -257,6 +258,22 @@ def load():
             build()
         _caller_lib = _bind(C.CDLL(LIB_PATH))
     return _caller_lib
+
+
+def merge_record_texts(texts, lib=None):
+    """runner.py:301-352 natively: k-way merge of record texts (bytes, each sorted by (chromosome key, position)) -> one str."""
+    lib = lib if lib is not None else load()
+    n = len(texts)
+    arr = (C.c_char_p * max(n, 1))(*texts)
+    lens = (C.c_size_t * max(n, 1))(*[len(t) for t in texts])
+    out, length = C.c_void_p(), C.c_size_t()
+    rc = lib.plat_merge_record_texts(arr, lens, n, C.byref(out), C.byref(length))
+    if rc != 0:
+        raise _lib.PlatypusDeviceError(rc, "merge failed", "plat_merge_record_texts")
+    try:
+        return C.string_at(out, length.value).decode("ascii")
+    finally:
+        lib.plat_caller_free(out)
 
 
 class NativeCaller:

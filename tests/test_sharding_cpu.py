@@ -69,3 +69,35 @@ def test_vcf_text_to_merge_records():
     merged = sharding.merge_record_streams([[recs[1]], [recs[0]]])
     assert merged == [text.split("\n")[1], text.split("\n")[0]]
     assert sharding.chrom_key("r10") > sharding.chrom_key("r9")             # numeric once the letters of "CHR" are stripped
+
+
+def test_native_merge_of_record_texts_equals_the_python_merge():
+    """plat_merge_record_texts (the (chrom, pos) merge of runner.py:301-352 in libplat_caller.so, what rank 0 runs on the gathered
+    texts) against merge_record_streams: integer-like names with and without a chr prefix, names that are not integers, header and
+    empty lines, empty streams (no two streams hold the same (chrom, pos): regions belong to one rank, and the reference leaves such
+    ties to the shape of its heap)."""
+    from platypus_amd import fastcaller as F
+    from tests import fakedev
+    lib = fakedev.fake_caller_lib()
+    rng = np.random.default_rng(3)
+    names = ["1", "2", "chr2", "10", "chr11", "X", "Y", "MT", "r7", "r12", "hs37d5", "GL000207.1", "chrR3", "c-5"]
+    for trial in range(30):
+        n = int(rng.integers(1, 6))
+        streams, taken = [], set()
+        for k in range(n):
+            recs = {(str(rng.choice(names)), int(rng.integers(0, 50))) for _ in range(int(rng.integers(0, 40)))}
+            recs = {r for r in recs if (sharding.chrom_key(r[0]), r[1]) not in taken}
+            taken |= {(sharding.chrom_key(r[0]), r[1]) for r in recs}
+            recs = sorted(recs, key=lambda r: (sharding.chrom_key(r[0]), r[1]))
+            streams.append([(c, p, "%s\t%d\t.\tA\tC\t%d" % (c, p + 1, k)) for c, p in recs])
+        want = "".join(ln + "\n" for ln in sharding.merge_record_streams(streams))
+        texts = []
+        for k, s in enumerate(streams):
+            t = "".join(ln + "\n" for _, _, ln in s)
+            if k == 0:
+                t = "#header\n\n" + t
+            if k == 1 and t:
+                t = t[:-1]                                                  # no newline at the end
+            texts.append(t.encode())
+        assert F.merge_record_texts(texts, lib=lib) == want
+    assert F.merge_record_texts([], lib=lib) == "" and F.merge_record_texts([b"", b""], lib=lib) == ""

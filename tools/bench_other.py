@@ -184,9 +184,9 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
         t0 = time.perf_counter()
         text = nc.call_stream(len(indices), src.load_fn, src.h, names, opts, n_slots, loaders)
         t1 = time.perf_counter()
-        got = rk.gather(sharding.encode_records(sharding.records_from_vcf_text(text)))
+        got = rk.gather(text.encode("ascii"))                               # every rank's record lines to rank 0 ...
         if got is not None:
-            merged = "".join(ln + "\n" for ln in sharding.merge_record_streams([sharding.decode_records(x) for x in got]))
+            merged = F.merge_record_texts(got, lib=lib)                      # ... merged there by (chromosome, position), runner.py:301-352
         t2 = time.perf_counter()
         rk.barrier()
         st = dict(nc.stats)

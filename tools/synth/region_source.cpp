@@ -10,6 +10,7 @@
 // start uniform over the region, with the CIGAR an aligner would report; substitution errors at `err`; qualities ~ clipped N(35, 5)
 // (rows of a shared tape of such draws); mapq 60; flags 3 | 16 at random; sorted by position.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -47,6 +48,7 @@ struct plat_synth {
     uint8_t* mem; size_t slotBytes; int nSlots;
     std::vector<uint8_t> tape;                                             // quality tape
     long long planted = 0, reads = 0;                                      // totals over the regions loaded (statistics)
+    long long phaseNs[6] = {0, 0, 0, 0, 0, 0};                             // reference, variants, haplotypes, read starts + sort, reads, rest
 };
 
 static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
@@ -75,8 +77,8 @@ SYNTH_EXPORT int plat_synth_create(uint64_t seed, int region_len, int flank, int
     g->snpRate = snp_rate; g->indelRate = indel_rate; g->err = err;
     g->index.assign(region_index, region_index + n_regions);
     g->mem = (uint8_t*)slot_memory; g->slotBytes = slot_bytes; g->nSlots = n_slots;
-    // the quality tape: 1 M draws of clip(round(N(35, 5)), 2, 41) (+ one read of slack), Box-Muller
-    const size_t T = (1u << 20) + (size_t)read_len + 64;
+    // the quality tape: 64 K draws of clip(round(N(35, 5)), 2, 41) (+ one read of slack), Box-Muller; a read's qualities are a row of it
+    const size_t T = (1u << 16) + (size_t)read_len + 64;
     g->tape.resize(T);
     Rng r(seed, 0xFFFFFFFFull);
     for (size_t i = 0; i < T; i += 2) {
@@ -90,6 +92,7 @@ SYNTH_EXPORT int plat_synth_create(uint64_t seed, int region_len, int flank, int
 
 SYNTH_EXPORT void plat_synth_destroy(plat_synth* g) { delete g; }
 SYNTH_EXPORT long long plat_synth_planted(const plat_synth* g) { return g ? g->planted : 0; }
+SYNTH_EXPORT void plat_synth_phase_seconds(const plat_synth* g, double* out6) { for (int k = 0; k < 6; ++k) out6[k] = g ? 1e-9 * (double)g->phaseNs[k] : 0.0; }
 
 namespace {
 struct Carve {
@@ -98,9 +101,10 @@ struct Carve {
 };
 struct Scratch {
     std::vector<uint8_t> hs[2];
-    std::vector<int32_t> h2r[2], r2h[2], insPre[2];
-    std::vector<int32_t> i0, posOf, order, count;
-    std::vector<uint8_t> which;
+    std::vector<int32_t> h2r[2];
+    std::vector<std::pair<int32_t, int32_t>> gaps[2];                      // per haplotype, ascending: hap positions [a, b) a read must not touch to be one plain match
+    std::vector<int32_t> i0, posOf, order, tmpOrder;
+    std::vector<uint64_t> draw;
     std::vector<Var> vars;
     std::vector<int> spots, kinds;
 };
@@ -112,6 +116,9 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
     plat_synth* g = (plat_synth*)user;
     if (!g || !out || index < 0 || index >= (int)g->index.size() || slot < 0 || slot >= g->nSlots) return -1;
     static thread_local Scratch S;
+    typedef std::chrono::steady_clock Clk;
+    auto tmark = Clk::now();
+    auto lap = [&](int k) { const auto now = Clk::now(); __atomic_add_fetch(&g->phaseNs[k], (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(now - tmark).count(), __ATOMIC_RELAXED); tmark = now; };
     const int id = g->index[(size_t)index];
     Rng rng(g->seed, (uint64_t)(uint32_t)id);
     const int L = g->readLen, start = g->flank, end = g->flank + g->regionLen, n = g->regionLen + 2 * g->flank;
@@ -120,11 +127,15 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
     char* chrom = cv.take<char>(64);
     plat_sample_reads* samples = cv.take<plat_sample_reads>((size_t)g->nSamples);
     if (!ref || !chrom || !samples) return -3;
-    for (int i = 0; i < n; i += 32) {                                      // 32 bases per draw
-        uint64_t w = rng.next();
-        for (int k = 0; k < 32 && i + k < n; ++k, w >>= 2) ref[i + k] = (uint8_t)"ACGT"[w & 3];
+    {   // 32 bases per draw, four per table look-up (the slot has 64 bytes of slack behind the reference)
+        static const struct Lut { uint32_t w[256]; Lut() { for (int b = 0; b < 256; ++b) { uint32_t v = 0; for (int k = 0; k < 4; ++k) v |= (uint32_t)"ACGT"[(b >> (2 * k)) & 3] << (8 * k); w[b] = v; } } } lut;
+        for (int i = 0; i < n; i += 32) {
+            uint64_t w = rng.next();
+            for (int k = 0; k < 8; ++k, w >>= 8) memcpy(ref + i + 4 * k, &lut.w[w & 255], 4);
+        }
     }
     memset(ref + n, 0, 64);
+    lap(0);
     snprintf(chrom, 64, "r%d", id);
     // ---- planted variants
     std::vector<Var>& vars = S.vars;
@@ -160,6 +171,7 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
             }
         }
     }
+    lap(1);
     const int nReads = (int)((double)g->depth * g->regionLen / L);
     long long nReadsAll = 0;
     for (int si = 0; si < g->nSamples; ++si) {
@@ -168,6 +180,8 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
             std::vector<uint8_t>& hs = S.hs[h];
             std::vector<int32_t>& h2r = S.h2r[h];
             hs.clear(); h2r.clear();
+            std::vector<std::pair<int32_t, int32_t>>& gaps = S.gaps[h];
+            gaps.clear();
             int cur = 0;
             auto copyTo = [&](int upto) {                                    // reference bases [cur, upto) as they are
                 if (upto > cur) {
@@ -181,33 +195,57 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
             for (const Var& v : vars) {
                 if (!(rng.next() >> 63)) continue;                          // this haplotype does not carry it
                 if (v.kind == 0) { copyTo(v.pos); hs.push_back((uint8_t)v.bases[0]); h2r.push_back(v.pos); cur = v.pos + 1; }
-                else if (v.kind == 1) { copyTo(v.pos + 1); for (char c : v.bases) { hs.push_back((uint8_t)c); h2r.push_back(-1); } }
-                else { copyTo(v.pos + 1); cur = v.pos + 1 + v.len; }
+                else if (v.kind == 1) {                                     // a read holding any inserted base is not a plain match
+                    copyTo(v.pos + 1);
+                    gaps.push_back({(int32_t)hs.size(), (int32_t)(hs.size() + v.bases.size())});
+                    for (char c : v.bases) { hs.push_back((uint8_t)c); h2r.push_back(-1); }
+                } else {                                                    // nor one holding the bases on both sides of a deletion
+                    copyTo(v.pos + 1); cur = v.pos + 1 + v.len;
+                    gaps.push_back({(int32_t)hs.size() - 1, (int32_t)hs.size() + 1});
+                }
             }
             copyTo(n);
-            const int hl = (int)hs.size();
-            std::vector<int32_t>& r2h = S.r2h[h];
-            r2h.assign((size_t)n + 1, hl);
-            for (int i = 0; i < hl; ++i) if (h2r[(size_t)i] >= 0) r2h[(size_t)h2r[(size_t)i]] = i;
-            for (int x = n - 1; x >= 0; --x) r2h[(size_t)x] = std::min(r2h[(size_t)x], r2h[(size_t)x + 1]);   // a deleted base maps to the next base that exists
-            std::vector<int32_t>& ip = S.insPre[h];
-            ip.assign((size_t)hl + 1, 0);
-            for (int i = 0; i < hl; ++i) ip[(size_t)i + 1] = ip[(size_t)i] + (h2r[(size_t)i] < 0);
         }
         if ((int)S.hs[0].size() < L || (int)S.hs[1].size() < L) return -1;
-        // ---- read starts, sorted by position (counting sort: stable in draw order)
-        S.i0.resize((size_t)nReads); S.posOf.resize((size_t)nReads); S.which.resize((size_t)nReads); S.order.resize((size_t)nReads);
-        S.count.assign((size_t)n + 2, 0);
-        for (int r = 0; r < nReads; ++r) {
-            const int h = (int)(rng.next() >> 63);
-            const int p0 = start - L + 10 + (int)rng.below((uint32_t)(end - 10 - (start - L + 10)));
-            int i0 = std::min<int>(S.r2h[h][(size_t)std::max(p0, 0)], (int)S.hs[h].size() - L);
-            while (i0 > 0 && S.h2r[h][(size_t)i0] < 0) --i0;                // a read starts on a reference base
-            S.which[(size_t)r] = (uint8_t)h; S.i0[(size_t)r] = i0; S.posOf[(size_t)r] = S.h2r[h][(size_t)i0];
-            ++S.count[(size_t)S.posOf[(size_t)r] + 1];
+        lap(2);
+        // ---- read starts: ONE 64-bit draw per read (bit 0 haplotype, bit 1 strand, bits 2..17 quality row, bits 32..63 the start, uniform
+        // over the haplotype's stretch of the region), then sorted by reference position (two stable 9-bit radix passes over pos - lo)
+        S.i0.resize((size_t)nReads); S.posOf.resize((size_t)nReads); S.draw.resize((size_t)nReads); S.order.resize((size_t)nReads);
+        S.tmpOrder.resize((size_t)nReads);
+        int hLo[2], hHi[2];
+        for (int h = 0; h < 2; ++h) {                                       // hap positions of the reference positions start-L+10 and end-10
+            const std::vector<int32_t>& m = S.h2r[h];
+            auto at = [&](int x) { int i = std::min<int>(std::max(x, 0), (int)m.size() - 1); while (i > 0 && (m[(size_t)i] < 0 || m[(size_t)i] > x)) --i;
+                                   while (i + 1 < (int)m.size() && (m[(size_t)i] < 0 || m[(size_t)i] < x)) ++i; return i; };
+            hLo[h] = at(start - L + 10); hHi[h] = std::max(hLo[h] + 1, at(end - 10));
         }
-        for (int x = 0; x <= n; ++x) S.count[(size_t)x + 1] += S.count[(size_t)x];
-        for (int r = 0; r < nReads; ++r) S.order[(size_t)S.count[(size_t)S.posOf[(size_t)r]]++] = r;
+        const int lo = std::max(0, start - L);
+        for (int r = 0; r < nReads; ++r) {
+            const uint64_t w = rng.next();
+            const int h = (int)(w & 1);
+            int i0 = hLo[h] + (int)(((w >> 32) * (uint64_t)(hHi[h] - hLo[h])) >> 32);
+            i0 = std::min(i0, (int)S.hs[h].size() - L);
+            while (i0 > 0 && S.h2r[h][(size_t)i0] < 0) --i0;                // a read starts on a reference base
+            S.draw[(size_t)r] = w; S.i0[(size_t)r] = i0; S.posOf[(size_t)r] = S.h2r[h][(size_t)i0];
+        }
+        {
+            uint32_t hist[512];
+            const int32_t* key = S.posOf.data();
+            int32_t* src = S.tmpOrder.data();
+            int32_t* dst = S.order.data();
+            for (int r = 0; r < nReads; ++r) src[r] = r;
+            for (int pass = 0; pass < 2; ++pass) {                          // positions span < 2^18
+                memset(hist, 0, sizeof hist);
+                const int sh = 9 * pass;
+                for (int r = 0; r < nReads; ++r) ++hist[((uint32_t)(key[src[r]] - lo) >> sh) & 511];
+                uint32_t run = 0;
+                for (int b = 0; b < 512; ++b) { const uint32_t c = hist[b]; hist[b] = run; run += c; }
+                for (int r = 0; r < nReads; ++r) dst[hist[((uint32_t)(key[src[r]] - lo) >> sh) & 511]++] = src[r];
+                std::swap(src, dst);
+            }
+            if (src != S.order.data()) S.order.swap(S.tmpOrder);
+        }
+        lap(3);
         // ---- the table
         const size_t nb = (size_t)nReads * (size_t)L;
         uint8_t* seq = cv.take<uint8_t>(nb + 64);
@@ -226,13 +264,17 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
         uint8_t tmpS[10064];
         long long toErr = g->err > 0 ? (long long)std::floor(std::log(1.0 - rng.uni()) / std::log(1.0 - g->err)) : (1ll << 62);   // bases until the next substitution error
         for (int k = 0; k < nReads; ++k) {
-            const int r = S.order[(size_t)k], h = S.which[(size_t)r], i0 = S.i0[(size_t)r];
+            const int r = S.order[(size_t)k], i0 = S.i0[(size_t)r];
+            const uint64_t w = S.draw[(size_t)r];
+            const int h = (int)(w & 1);
             const uint8_t* src = S.hs[h].data() + i0;
             const int32_t* map = S.h2r[h].data() + i0;
             off[k] = (int64_t)k * L; pos[k] = map[0]; mate[k] = -1; mapq[k] = 60;
-            flags[k] = 3 | ((rng.next() >> 63) ? 16 : 0);
+            flags[k] = 3 | ((w & 2) ? 16 : 0);
             cigoff[k] = (int32_t)nc;
-            if (S.insPre[h][(size_t)i0 + L] == S.insPre[h][(size_t)i0] && map[L - 1] - map[0] == L - 1) {
+            bool plain = true;
+            for (const auto& gp : S.gaps[h]) { if (gp.first >= i0 + L) break; if (gp.second > i0) { plain = false; break; } }
+            if (plain) {
                 cigar[2 * nc] = 0; cigar[2 * nc + 1] = (int16_t)L; ++nc;
                 endp[k] = map[0] + L;
             } else {
@@ -253,7 +295,7 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
                 }
                 endp[k] = lastRef + 1;
             }
-            const uint8_t* q = g->tape.data() + (rng.next() & ((1u << 20) - 1));
+            const uint8_t* q = g->tape.data() + ((w >> 2) & 0xFFFFu);
             uint8_t* ds = seq + (size_t)k * L;
             const uint8_t* s = src;
             if (toErr < L) {                                                // (rare: one read in six at 0.1 %)
@@ -268,12 +310,16 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
             }
             toErr -= L;
             if (g->encoding == PLAT_READS_PACKED) {
-                for (int i = 0; i < L; ++i) ds[i] = (uint8_t)(((s[i] >> 1) & 3) | (q[i] << 2));
+                uint8_t* __restrict d = ds;
+                const uint8_t* __restrict sb = s;
+                const uint8_t* __restrict qb = q;
+                for (int i = 0; i < L; ++i) d[i] = (uint8_t)(((sb[i] >> 1) & 3) | (qb[i] << 2));
             } else {
                 memcpy(ds, s, (size_t)L);
                 memcpy(qual + (size_t)k * L, q, (size_t)L);
             }
         }
+        lap(4);
         off[nReads] = (int64_t)nb; cigoff[nReads] = (int32_t)nc;
         memset(seq + nb, 0, 64);
         if (qual) memset(qual + nb, 0, 64);

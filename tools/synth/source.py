@@ -34,6 +34,7 @@ def load():
         lib.plat_synth_destroy.argtypes = [C.c_void_p]
         lib.plat_synth_planted.restype = C.c_longlong
         lib.plat_synth_planted.argtypes = [C.c_void_p]
+        lib.plat_synth_phase_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         lib.plat_synth_load_fn.restype = C.c_void_p
         lib.plat_synth_load.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib = lib
@@ -70,6 +71,12 @@ class RegionSource:
     @property
     def planted(self):
         return int(self.lib.plat_synth_planted(self.h))
+
+    @property
+    def phase_seconds(self):
+        out = (C.c_double * 6)()
+        self.lib.plat_synth_phase_seconds(self.h, out)
+        return dict(zip(("reference", "variants", "haplotypes", "read_starts_and_sort", "reads", "rest"), list(out)))
 
     def region(self, index, slot=0):
         """Region `index` generated into `slot`, as a filled plat_region struct (tests: the same reads for the other paths)."""
