@@ -93,12 +93,14 @@ typedef struct plat_caller_options {
     double filteredReadsFrac;            /* 0.7 */
     int32_t maxVarDist, minVarDist;      /* 15, 9 */
     int32_t useEMLikelihoods, countOnlyExactIndelMatches, calculateFlankScore;                                /* 0, 0, 0 */
-    int32_t assemble, outputRefCalls;    /* 0, 0: anything else is PLAT_ERR_UNSUPPORTED here */
+    int32_t assemble, outputRefCalls;    /* 0, 0 */
     int32_t minMapQual, minBaseQual;     /* 20, 20 */
     int32_t minPosterior;                /* 5 */
     double sbThreshold, scThreshold, abThreshold, minVarFreq;                                                 /* 1e-3, 0.95, 1e-3, 0.05 */
     int32_t badReadsWindow, badReadsThreshold, rmsmqThreshold, qdThreshold, hapScoreThreshold;                /* 11, 15, 40, 10, 4 */
-    int32_t _pad;
+    int32_t refCallBlockSize;            /* 1000 (outputRefCalls=1: window.py:172-219, variantcaller.pyx:584-607) */
+    /* assemble=1 (variantcaller.pyx:496-519, assembler.pyx:1391-1476): tiles of assemblyRegionSize every max(100, min(1000, size / 2)) bases */
+    int32_t assemblyRegionSize, assembleAll, assembleBadReads, assembleBrokenPairs, assemblerKmerSize, noCycles;   /* 1500, 1, 1, 0, 15, 0 */
 } plat_caller_options;
 
 typedef struct plat_caller_stats {
@@ -116,6 +118,9 @@ typedef struct plat_caller_stats {
      * spent waiting for a loaded chunk (a source slower than the callers shows up here); input bytes handed over (bases + qualities) */
     double seconds_load, seconds_source_wait;
     int64_t input_bytes;
+    int64_t n_assembly_tiles, n_assembler_variants;   /* assemble=1: tiles assembled, variants they returned */
+    int64_t n_refcall_records;                        /* outputRefCalls=1: REFCALL lines among n_records */
+    double seconds_assemble;                          /* sum over worker threads: tiles -> device assembler -> variants */
 } plat_caller_stats;
 
 typedef struct plat_caller plat_caller;

@@ -92,6 +92,37 @@ inline std::vector<std::string> py2_set_order(const std::vector<std::string>& na
     return out;
 }
 
+// iteration order of a Python-2 dict holding these integer keys, inserted in this order (dictobject.c: the same open addressing and
+// growth as the set above; hash(int) is the int, -1 -> -2): what `for pos, vars in pop.varsByPos.iteritems()` walks (variantcaller.pyx:584-603)
+inline std::vector<int> py2_int_dict_order(const std::vector<int>& keys) {
+    std::vector<long long> table(8, 0);
+    std::vector<char> usedSlot(8, 0);
+    auto slot = [](const std::vector<long long>& t, const std::vector<char>& u, long long key) -> size_t {
+        const uint64_t h = (uint64_t)(key == -1 ? -2 : key), mask = t.size() - 1;
+        uint64_t i = h & mask, perturb = h;
+        while (u[i & mask] && t[i & mask] != key) { i = 5 * i + perturb + 1; perturb >>= 5; }
+        return (size_t)(i & mask);
+    };
+    size_t used = 0;
+    for (int key : keys) {
+        const size_t j = slot(table, usedSlot, key);
+        if (usedSlot[j]) continue;
+        table[j] = key; usedSlot[j] = 1;
+        ++used;
+        if (used * 3 >= table.size() * 2) {
+            size_t size = 8;
+            while (size <= used * (used > 50000 ? 2 : 4)) size <<= 1;
+            std::vector<long long> gt(size, 0);
+            std::vector<char> gu(size, 0);
+            for (size_t k = 0; k < table.size(); ++k) if (usedSlot[k]) { const size_t q = slot(gt, gu, table[k]); gt[q] = table[k]; gu[q] = 1; }
+            table.swap(gt); usedSlot.swap(gu);
+        }
+    }
+    std::vector<int> out;
+    for (size_t k = 0; k < table.size(); ++k) if (usedSlot[k]) out.push_back((int)table[k]);
+    return out;
+}
+
 // ---- beta-binomial p-values -------------------------------------------------------------------------------------------------
 inline double logFactorial(long x) {                                     // platypusutils.pyx:178-191
     if (x < 15) {
@@ -260,6 +291,20 @@ inline void trimLeftPadding(int& pos, std::string& ref, std::vector<std::string>
         for (std::string& a : alt) a = a.substr(1);
         ++pos;
     }
+}
+
+// one REFCALL line (outputRefCall, variantcaller.pyx:764-867; the text of VCF.write_data for its dictionary): every INFO field of the
+// header missing but END and Size, QUAL as computed by the caller, per sample "./." with the number of reads in the sample's window
+inline void writeRefCallLine(std::string& out, const char* chrom, int windowStart, int windowEnd, char refBase, int qual, const std::vector<int>& nReads) {
+    out += chrom; out += '\t'; out += std::to_string(windowStart + 1); out += "\t.\t";
+    out += refBase; out += '\t'; out += (refBase == 'N' ? 'T' : 'N'); out += '\t';
+    out += std::to_string(qual);
+    out += "\tREFCALL\tBRF=.;END="; out += std::to_string(windowEnd);
+    out += ";FR=.;FS=.;HP=.;HapScore=.;MGOF=.;MMLQ=.;MQ=.;NF=.;NR=.;PP=.;QD=.;ReadPosRankSum=.;SC=.;START=.;SbPval=.;Size=";
+    out += std::to_string(windowEnd - windowStart);
+    out += ";Source=.;TC=.;TCF=.;TCR=.;TR=.;WE=.;WS=.\tGT:GL:GOF:GQ:NR:NV";
+    for (int n : nReads) { out += "\t./.:-1,-1,-1:-1:-1:"; out += std::to_string(n); out += ":0"; }
+    out += '\n';
 }
 
 inline int phred(double p) {                                              // vcfrecords._phred

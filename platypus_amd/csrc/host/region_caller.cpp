@@ -108,8 +108,12 @@ struct Slot {
     Staged<int64_t> p_off, s_aoff, s_moff, s_counts, k_vo, k_ro, k_lo;
     Staged<uint8_t> p_mask, s_added, s_vig;
     Staged<double> p_prior, p_post, k_lik, k_out4;
+    // assembler tiles (assemble=1)
+    Staged<uint8_t> as_ref, as_seq, as_qual, as_mapq, as_blob;
+    Staged<int64_t> as_refoff, as_roff;
+    Staged<int32_t> as_refstart, as_astart, as_aend, as_rbegin, as_src, as_pos, as_end, as_flags, as_cnt, as_status, as_vpos, as_nrem, as_nadd, as_off;
     // many small arrays travel as ONE copy: they are views into these blocks (Layout)
-    Arena a_tab, a_cin, a_cout, a_mout, a_win, a_wout, a_pin, a_sin, a_sout;
+    Arena a_tab, a_cin, a_cout, a_mout, a_win, a_wout, a_pin, a_sin, a_sout, a_asin, a_asout;
     double t_host = 0, t_wait = 0;
 
     void sync(const char* where) {
@@ -289,6 +293,10 @@ struct WindowWork {
     std::vector<std::pair<int, VarList>> byPos;                            // varsByPos, insertion order
     std::vector<VarInfo> info;                                             // vcfInfo in getHaplotypeInfo order
     int firstStatVar = 0, firstSite = 0;
+    bool failed = false;                                                   // raised while it was prepared: logged and skipped, no line of any kind
+    std::string text;                                                      // its record lines (and, with outputRefCalls, the REFCALL lines that belong to it)
+    int64_t nRecords = 0, nRefRecords = 0;
+    int firstFlat = -1;                                                    // outputRefCalls: index of its first flat-prior posterior (one per variant of `vars`)
 };
 
 struct VariantPool {
@@ -299,9 +307,15 @@ struct VariantPool {
     }
 };
 
+// what the region loop writes, in the order it writes it: calling windows and (outputRefCalls=1) reference-call blocks
+struct Item { int kind; int window; std::string text; int64_t nRef = 0; };     // kind 0: windows[window]; 1: a block whose line is already in `text`
+
 struct RegionWork {
     const plat_region* in = nullptr;
     int index = 0;
+    std::vector<Item> items;
+    std::vector<Ptrs> cur;                                                 // the samples' window pointers as the loop last left them (a REFCALL line's NR)
+    VarList asmVariants;                                                   // assembler candidates, tile after tile (variantcaller.pyx:496-519)
     Fasta fa;
     int rlen = 0;
     std::vector<SampleView> samples;
@@ -309,12 +323,14 @@ struct RegionWork {
     VarList variants;
     std::vector<WindowWork> windows;
     std::string text;
-    int64_t nRecords = 0, nCandRecords = 0;
+    int64_t nCandRecords = 0;
     // frees everything but the record text (called by the worker that finished the region, so that the cost of freeing thousands of
     // windows and haplotypes is spread over the workers instead of being paid serially at the end of plat_call_regions)
     void release() {
         std::vector<WindowWork>().swap(windows);
+        std::vector<Item>().swap(items);
         VarList().swap(variants);
+        VarList().swap(asmVariants);
         pool = VariantPool();
     }
 };
@@ -596,6 +612,130 @@ struct Chunk {
     int mergeCap = 2048;
     std::string refBlob;
 
+    // -- A3: the assembler part of generateVariantsInRegion (variantcaller.pyx:496-519): tiles of assemblyRegionSize every
+    // max(100, min(1000, size / 2)) bases, doWeNeedToAssembleThisRegion (:276-321) per tile, the reads loadBAMDataIntoGraph would load
+    // (assembler.pyx:1391-1425: good reads between the window pointers, badReads / brokenMates if the options say so, QCFail reads never)
+    // gathered from the chunk's device table; ALL tiles of the chunk in one plat_assemble_batch
+    struct Tile { int region, assemStart, assemEnd, refStart; };
+    void assembleTiles() {
+        if (!o.assemble) return;
+        Slot& z = s;
+        const auto t0 = Clock::now();
+        const int size = o.assemblyRegionSize;
+        if (size <= 0) throw DeviceError(PLAT_ERR_INVALID, "assemblyRegionSize");
+        const int shift = std::max(100, std::min(1000, size / 2));
+        std::vector<Tile> tiles;
+        std::vector<int64_t> refoff{0}, roff{0};
+        std::vector<int32_t> refstart, astart, aend, rbegin{0}, src;
+        std::string blob;
+        for (RegionWork* rp : regions) {
+            RegionWork& r = *rp;
+            r.cur.assign(r.samples.size(), Ptrs{0, 0, 0, 0, 0, 0});
+            for (int64_t a0 = r.in->start; a0 < r.in->end; a0 += shift) {
+                const int assemStart = (int)a0, assemEnd = (int)std::min<int64_t>(a0 + size, r.in->end);
+                const int refStart = std::max(0, assemStart - size);
+                const std::string refSeq = r.fa.getSequence(refStart, (int64_t)assemEnd + size);
+                // doWeNeedToAssembleThisRegion: the window pointers move to the tile whatever the answer
+                bool need = o.assembleAll != 0;
+                for (size_t i = 0; i < r.samples.size(); ++i) {
+                    Ptrs& p = r.cur[i];
+                    r.samples[i].reads.overlapRange(assemStart, assemEnd, p.gs, p.ge);
+                    r.samples[i].bad.overlapRange(assemStart, assemEnd, p.bs, p.be);
+                    r.samples[i].broken.matePosRange(assemStart, assemEnd, p.ks, p.ke);
+                }
+                for (size_t i = 0; !need && i < r.samples.size(); ++i) {
+                    const Ptrs& p = r.cur[i];
+                    const double n = p.ge - p.gs, nBad = p.be - p.bs;
+                    if (n == 0) continue;
+                    double gaps = 0, improper = 0;                           // countAlignmentGaps / countImproperPairs (cwindow.pyx:598-647): reads + badReads
+                    auto scan = [&](const TableView& tv, int b, int e) {
+                        for (int q = b; q < e; ++q) {
+                            for (int c = tv.t->cig_off[q]; c < tv.t->cig_off[q + 1]; ++c) { const int op = tv.t->cigar[2 * c]; gaps += op >= 1 && op <= 4; }
+                            improper += !(tv.t->flags[q] & 2);
+                        }
+                    };
+                    scan(r.samples[i].reads, p.gs, p.ge); scan(r.samples[i].bad, p.bs, p.be);
+                    if (gaps / n > 2 || improper / (n + nBad) > 0.1) need = true;
+                }
+                if (!need) continue;
+                tiles.push_back(Tile{regionSlot(r.index), assemStart, assemEnd, refStart});
+                blob += refSeq;
+                refoff.push_back((int64_t)blob.size());
+                refstart.push_back(refStart); astart.push_back(assemStart); aend.push_back(assemEnd);
+                for (size_t i = 0; i < r.samples.size(); ++i) {
+                    const Ptrs& p = r.cur[i];
+                    auto take = [&](const TableView& tv, int b, int e) {
+                        for (int q = b; q < e; ++q) {
+                            if (tv.t->flags[q] & 512) continue;               // Read_IsQCFail
+                            src.push_back((int32_t)(tv.base + q));
+                            roff.push_back(roff.back() + tv.rlen(q));
+                        }
+                    };
+                    take(r.samples[i].reads, p.gs, p.ge);
+                    if (o.assembleBadReads) take(r.samples[i].bad, p.bs, p.be);
+                    if (o.assembleBrokenPairs) take(r.samples[i].broken, p.ks, p.ke);
+                }
+                rbegin.push_back((int32_t)src.size());
+            }
+        }
+        const int nT = (int)tiles.size();
+        if (nT > 0) {
+            Layout L;
+            L.add(z.as_ref, blob.size() + PLAT_BLOB_PAD); L.add(z.as_refoff, refoff.size()); L.add(z.as_refstart, refstart.size()); L.add(z.as_astart, astart.size());
+            L.add(z.as_aend, aend.size()); L.add(z.as_rbegin, rbegin.size()); L.add(z.as_src, src.size()); L.add(z.as_roff, roff.size());
+            L.commit(z, z.a_asin);
+            memcpy(z.as_ref.h, blob.data(), blob.size()); memset(z.as_ref.h + blob.size(), 0, PLAT_BLOB_PAD);
+            fill(z, z.as_refoff, refoff); fill(z, z.as_refstart, refstart); fill(z, z.as_astart, astart); fill(z, z.as_aend, aend); fill(z, z.as_rbegin, rbegin);
+            fill(z, z.as_src, src); fill(z, z.as_roff, roff);
+            L.upload(z, z.a_asin);
+            const size_t nR = src.size(), nb = (size_t)roff.back();
+            z.as_seq.reserve(z.ctx, nb + PLAT_BLOB_PAD, false, true, z.stream); z.as_qual.reserve(z.ctx, nb + PLAT_BLOB_PAD, false, true, z.stream);
+            z.as_pos.reserve(z.ctx, nR + 1, false); z.as_end.reserve(z.ctx, nR + 1, false); z.as_flags.reserve(z.ctx, nR + 1, false); z.as_mapq.reserve(z.ctx, nR + 1, false);
+            if (nR) ck(plat_gather_reads(z.ctx, (int64_t)nR, z.as_src.d, z.as_roff.d, z.t_seq.d, z.t_qual.d, z.t_off.d, z.t_pos.d, z.t_end.d, z.t_mapq.d, z.t_flags.d,
+                                         z.as_seq.d, z.as_qual.d, z.as_pos.d, z.as_end.d, z.as_mapq.d, z.as_flags.d, z.stream), "plat_gather_reads(assembler)");
+            plat_assembly_batch ab;
+            memset(&ab, 0, sizeof ab);
+            ab.n_regions = nT; ab.n_reads = (int32_t)nR;
+            ab.ref_seq = z.as_ref.d; ab.ref_off = z.as_refoff.d; ab.ref_start = z.as_refstart.d; ab.assem_start = z.as_astart.d; ab.assem_end = z.as_aend.d;
+            ab.reg_read_begin = z.as_rbegin.d; ab.read_seq = z.as_seq.d; ab.read_qual = z.as_qual.d; ab.read_off = z.as_roff.d;
+            for (;;) {                                                       // room per tile grows until every tile's variants fit
+                Layout LO;
+                LO.add(z.as_cnt, (size_t)nT); LO.add(z.as_status, (size_t)nT); LO.add(z.as_vpos, (size_t)nT * asmMaxVars); LO.add(z.as_nrem, (size_t)nT * asmMaxVars);
+                LO.add(z.as_nadd, (size_t)nT * asmMaxVars); LO.add(z.as_off, (size_t)nT * asmMaxVars); LO.add(z.as_blob, (size_t)nT * asmBlob);
+                LO.commit(z, z.a_asout);
+                ck(plat_assemble_batch(z.ctx, &ab, o.assemblerKmerSize, o.minBaseQual, o.minReads * o.minBaseQual, o.noCycles, asmMaxVars, asmBlob, z.as_cnt.d,
+                                       z.as_vpos.d, z.as_nrem.d, z.as_nadd.d, z.as_off.d, z.as_blob.d, z.as_status.d, z.stream), "plat_assemble_batch");
+                LO.download(z, z.a_asout);
+                z.sync("assembler");
+                bool over = false;
+                for (int g = 0; g < nT; ++g) {
+                    if (z.as_status.h[g] == PLAT_ERR_OVERFLOW) over = true;
+                    else if (z.as_status.h[g] != 0) throw DeviceError(z.as_status.h[g], "plat_assemble_batch(tile)");
+                }
+                if (!over) break;
+                if (asmMaxVars >= (1 << 14)) throw DeviceError(PLAT_ERR_OVERFLOW, "plat_assemble_batch(tile)");
+                asmMaxVars *= 4; asmBlob *= 4;
+            }
+            int64_t nv = 0;
+            for (int g = 0; g < nT; ++g) {                                   // per tile in the reference's sorted() order (the device's), tile after tile
+                RegionWork& r = *regions[(size_t)tiles[(size_t)g].region];
+                const uint8_t* raw = z.as_blob.h + (size_t)g * (size_t)asmBlob;
+                for (int i = 0; i < z.as_cnt.h[g]; ++i) {
+                    const size_t k = (size_t)g * (size_t)asmMaxVars + (size_t)i;
+                    const int off = z.as_off.h[k], nrem = z.as_nrem.h[k], nadd = z.as_nadd.h[k];
+                    r.asmVariants.push_back(r.pool.make(z.as_vpos.h[k], std::string((const char*)raw + off, (size_t)nrem),
+                                                        std::string((const char*)raw + off + nrem, (size_t)nadd), 0, ASSEMBLER_VAR));
+                    ++nv;
+                }
+            }
+            std::lock_guard<std::mutex> g(stMutex);
+            st.n_assembly_tiles += nT; st.n_assembler_variants += nv;
+        }
+        std::lock_guard<std::mutex> g(stMutex);
+        st.seconds_assemble += secs(t0, Clock::now());
+    }
+    int asmMaxVars = 64, asmBlob = 4096;
+
     // -- B1: candidates of one region -> merged, per-sample support filter, left-normalised, filtered (variantcaller.pyx:439-531)
     void regionVariants(RegionWork& r, int scan0) {
         Slot& z = s;
@@ -616,7 +756,7 @@ struct Chunk {
                 everyone.push_back(v);
             }
         };
-        if (!hostTally) {
+        if (!hostTally && o.getVariantsFromBAMs) {
             // merged and filtered on the device (plat_candidates_merge_batch): the scan's candidates in the order of their first records
             for (size_t i = 0; i < r.samples.size(); ++i) {
                 const TableView& tv = r.samples[i].reads;
@@ -636,7 +776,7 @@ struct Chunk {
         std::vector<Key> keys;                                              // this sample's variantHeap: distinct records, first-occurrence order
         std::deque<std::string> addedStore;                                 // (letters of the added bases when the table is not ASCII)
         std::vector<int32_t> table;                                         // open addressing over `keys` (index + 1, 0 = empty)
-        for (size_t i = 0; hostTally && i < r.samples.size(); ++i) {
+        for (size_t i = 0; hostTally && o.getVariantsFromBAMs && i < r.samples.size(); ++i) {
             const TableView& tv = r.samples[i].reads;
             keys.clear();
             size_t tmask = 4095;
@@ -686,6 +826,7 @@ struct Chunk {
             }
         }
         std::stable_sort(everyone.begin(), everyone.end(), variantLess);    // getCandidates(): sorted(values)
+        everyone.insert(everyone.end(), r.asmVariants.begin(), r.asmVariants.end());      // rawBamVariants + assemblerVariants (:521)
         VarList norm;
         for (Variant* v : everyone) norm.push_back(leftNormaliseIndel(v, r.fa, r.rlen, r.pool));
         std::stable_sort(norm.begin(), norm.end(), variantLess);
@@ -702,10 +843,21 @@ struct Chunk {
     }
 
     void regionWindows(RegionWork& r) {
-        WindowOptions wo{o.mergeClusteredVariants, o.maxVarDist, o.minVarDist, o.maxSize, o.largeWindows, r.rlen, o.maxVariants};
+        WindowOptions wo{o.mergeClusteredVariants, o.maxVarDist, o.minVarDist, o.maxSize, o.largeWindows, r.rlen, o.maxVariants, o.outputRefCalls, o.refCallBlockSize};
         std::vector<Window> wins = windowsAndVariants(r.in->start, r.in->end, r.fa.len - 1, r.variants, wo);
+        if (r.cur.size() != r.samples.size()) r.cur.assign(r.samples.size(), Ptrs{0, 0, 0, 0, 0, 0});
         for (Window& win : wins) {
-            if (win.variants.empty() || win.endPos - win.startPos > o.maxSize) continue;       // variantcaller.pyx:560-568
+            if (win.variants.empty()) {                                      // a reference-call block between calling windows (:605-607)
+                if (o.outputRefCalls) {
+                    Item it{1, -1, std::string(), 0};
+                    try {
+                        if (refCallLine(r, it.text, win.startPos, win.endPos, snapshotNR(r.cur), false, 0.0)) it.nRef = 1;
+                    } catch (const WindowError& e) { logWindowFailure(r.in->chrom, win.startPos, win.endPos, e.what()); }
+                    r.items.push_back(std::move(it));
+                }
+                continue;
+            }
+            if (win.endPos - win.startPos > o.maxSize) continue;             // variantcaller.pyx:566-568
             WindowWork w;
             w.region = r.index; w.startPos = win.startPos; w.endPos = win.endPos;
             w.vars = win.variants; w.allVars = win.variants;
@@ -715,10 +867,53 @@ struct Chunk {
                 logWindowFailure(r.in->chrom, w.startPos, w.endPos, e.what());
                 std::lock_guard<std::mutex> g(stMutex);
                 ++st.n_windows_failed;
-                w.live = false; w.greedy = false;
+                w.live = false; w.greedy = false; w.failed = true;
             }
+            r.items.push_back(Item{0, (int)r.windows.size(), std::string(), 0});
             r.windows.push_back(std::move(w));
         }
+    }
+    static std::vector<int> snapshotNR(const std::vector<Ptrs>& ptrs) {
+        std::vector<int> nr;
+        for (const Ptrs& p : ptrs) nr.push_back(p.ge - p.gs);
+        return nr;
+    }
+
+    // outputRefCall (variantcaller.pyx:764-867) for [windowStart, windowEnd): QUAL 0 without coverage somewhere in the block; else the
+    // phred-scaled beta-binomial p-value of seeing no variant read at the block's smallest coverage, capped -- when the block holds
+    // candidates -- by the best candidate's posterior under a flat prior (maxPost).  nReads: the samples' reads between the window
+    // pointers as the loop last left them (the reference does not move them for a block).  Returns false when the reference raises here
+    // (an infinite QUAL: logged and skipped by its try/except).
+    bool refCallLine(const RegionWork& r, std::string& out, int windowStart, int windowEnd, const std::vector<int>& nReads, bool hasVariants, double maxPost) const {
+        long minCov = -1;
+        for (const SampleView& sv : r.samples) {
+            const TableView& tv = sv.reads;
+            const int N = tv.n();
+            for (int p = windowStart; p < windowEnd; ++p) {                  // countReadsCoveringRegion(p, p + 1), cwindow.pyx:176-206
+                long c = 0;
+                if (N > 0) {
+                    int s0 = TableView::lowerBound(tv.t->pos, N, std::max<int64_t>(1, (int64_t)p - tv.longest));
+                    const int e0 = TableView::lowerBound(tv.t->pos, N, (int64_t)p + 1);
+                    while (s0 < N && tv.t->end[s0] <= p) ++s0;
+                    if (s0 > e0) throw WindowError("This should never happen. Read start pointer > read end pointer!!");
+                    c = std::min(e0, N) - s0;
+                }
+                minCov = minCov == -1 ? c : std::min(minCov, c);
+            }
+        }
+        const int phredPValue = (int)(-10 * log10(betaBinomialCDF(0, minCov, 20, 20)));
+        int qual;
+        if (minCov == 0) qual = 0;
+        else if (!hasVariants) qual = phredPValue;
+        else {
+            const double maxProbVar = 1.0 - pow(10.0, -0.1 * maxPost), probRef = 1.0 - maxProbVar;
+            const double v = -10.0 * log10(1.0 - probRef);
+            if (std::isinf(v) || std::isnan(v)) return false;               // int(round(inf)) raises there
+            qual = std::min((int)py2_round0(v), phredPValue);
+        }
+        const std::string ref = r.fa.getSequence(windowStart, (int64_t)windowStart + 1);
+        writeRefCallLine(out, r.in->chrom, windowStart, windowEnd, ref.empty() ? 'N' : ref[0], qual, nReads);
+        return true;
     }
 
     void prepareWindow(RegionWork& r, WindowWork& w) {
@@ -736,6 +931,7 @@ struct Chunk {
             r.samples[i].broken.matePosRange(w.startPos, w.endPos, p.ks, p.ke);
             w.nReads += p.ge - p.gs;
         }
+        r.cur = w.ptrs;                                                     // (the buffers' window pointers now stand on this window)
         if (w.nReads == 0 || (double)w.nReads > o.maxReads) return;
         if ((int)w.vars.size() > o.maxVariants) {
             if (o.skipDifficultWindows) return;
@@ -864,7 +1060,7 @@ struct Chunk {
                 } catch (const WindowError& e) {
                     logWindowFailure(r.in->chrom, w->startPos, w->endPos, e.what());
                     { std::lock_guard<std::mutex> g(stMutex); ++st.n_windows_failed; }
-                    w->greedy = false; w->live = false;
+                    w->greedy = false; w->live = false; w->failed = true;
                 }
             }
             if (active.empty()) break;
@@ -903,7 +1099,7 @@ struct Chunk {
             } catch (const WindowError& e) {
                 logWindowFailure(r.in->chrom, w->startPos, w->endPos, e.what());
                 { std::lock_guard<std::mutex> g(stMutex); ++st.n_windows_failed; }
-                w->greedy = false; w->live = false;
+                w->greedy = false; w->live = false; w->failed = true;
             }
         }
     }
@@ -951,6 +1147,13 @@ struct Chunk {
                 poff.push_back((int64_t)pmask.size());
                 pprior.push_back(calculatePrior(*v, r.fa));
             }
+            if (o.outputRefCalls)                                           // pop.calculatePosterior(v, 1) of outputRefCall: the window's candidates under a flat prior
+                for (Variant* v : w->vars) {
+                    pwin.push_back(w->bw);
+                    for (const Hap& h : w->haps) pmask.push_back(contains(h.variants, v) ? 1 : 0);
+                    poff.push_back((int64_t)pmask.size());
+                    pprior.push_back(0.5);
+                }
         }
         const size_t nV = pwin.size();
         if (nV) {
@@ -977,6 +1180,8 @@ struct Chunk {
         for (WindowWork* w : wins) {
             RegionWork& r = *regions[(size_t)regionSlot(w->region)];
             w->called.clear(); w->calledPost.clear(); w->byPos.clear(); w->info.clear();
+            w->text.clear(); w->nRecords = 0; w->nRefRecords = 0;
+            w->firstFlat = o.outputRefCalls ? (int)(at + w->distinct.size()) : -1;
             for (size_t k = 0; k < w->distinct.size(); ++k, ++at) {
                 const double p = z.p_post.h[at];
                 if (p >= (double)o.minPosterior) {
@@ -987,6 +1192,7 @@ struct Chunk {
                     if (!found) w->byPos.push_back({v->refPos, VarList{v}});
                 }
             }
+            if (o.outputRefCalls) at += w->vars.size();
             // good / bad read ranges of every (window, sample) in the chunk table, for the statistics kernel
             for (size_t i = 0; i < r.samples.size(); ++i) {
                 const Ptrs& p = w->ptrs[i];
@@ -1064,7 +1270,8 @@ struct Chunk {
                 klo.push_back(klo.back() + NL * nInd);
             }
         }
-        if (live.empty()) { countCalled(wins.size()); return; }
+        const std::vector<double> flatPost(z.p_post.h, z.p_post.h + (nV ? nV : 0));     // (p_post's pinned mirror is reused by nothing below, copied for clarity)
+        if (!live.empty()) {
         // E: read statistics + per-site genotype calls
         const size_t nSV = svw.size(), nSites = kwin.size();
         kvih.push_back(0);
@@ -1097,12 +1304,22 @@ struct Chunk {
                                     z.k_ro.d, z.k_vih.d, z.k_ref.d, z.k_lo.d, z.k_ph.d, z.k_lik.d, z.k_out4.d, z.stream), "plat_genotype_call_batch");
         LO.download(z, z.a_sout);
         z.sync("read statistics / genotype calls");
+        }
         lap(6);
-        // F: INFO, FILTER, text
-        for (WindowWork* w : live) {
+        // F: INFO, FILTER, text -- and, with outputRefCalls, the REFCALL lines that belong to a calling window: the blocks between its
+        // called positions (:584-603), or one line for the whole window when nothing in it was called (:605-607)
+        for (WindowWork* w : wins) {
             RegionWork& r = *regions[(size_t)regionSlot(w->region)];
             try {
-                writeWindow(r, *w, klo);
+                if (!w->called.empty()) {
+                    writeWindow(r, *w, klo);
+                    if (o.outputRefCalls && w->byPos.size() > 1) refCallBlocksBetween(r, *w);
+                } else if (o.outputRefCalls) {
+                    double maxPost = 0.0;
+                    for (size_t k = 0; k < w->vars.size(); ++k) { const double p = flatPost[(size_t)w->firstFlat + k]; maxPost = k ? std::max(maxPost, p) : p; }
+                    if (refCallLine(r, w->text, w->startPos, w->endPos, snapshotNR(w->ptrs), !w->vars.empty(), maxPost)) { ++w->nRecords; ++w->nRefRecords; }
+                    else throw WindowError("cannot convert float infinity to integer");
+                }
             } catch (const WindowError& e) {
                 logWindowFailure(r.in->chrom, w->startPos, w->endPos, e.what());
                 std::lock_guard<std::mutex> g(stMutex);
@@ -1111,6 +1328,34 @@ struct Chunk {
         }
         lap(7);
         countCalled(wins.size());                                           // (once per window: a batch that failed half way counted nothing)
+    }
+    // :584-603: reference-call blocks between the called positions of one window, walked in the order a Python-2 dictionary holds its
+    // integer keys (pop.varsByPos.iteritems())
+    void refCallBlocksBetween(RegionWork& r, WindowWork& w) {
+        std::vector<int> keys;
+        for (auto& pv : w.byPos) keys.push_back(pv.first);
+        const std::vector<int> order = py2_int_dict_order(keys);
+        const VarList* last = nullptr;
+        if (o.refCallBlockSize <= 0) throw WindowError("range() arg 3 must not be zero");
+        for (size_t index = 0; index < order.size(); ++index) {
+            const VarList* these = nullptr;
+            for (auto& pv : w.byPos) if (pv.first == order[index]) { these = &pv.second; break; }
+            if (index > 0) {
+                int lastVarPos = (*last)[0]->maxRefPos, nextVarPos = (*these)[0]->minRefPos;
+                for (const Variant* v : *last) lastVarPos = std::max(lastVarPos, v->maxRefPos);
+                for (const Variant* v : *these) nextVarPos = std::min(nextVarPos, v->minRefPos);
+                nextVarPos += 1;
+                if (nextVarPos - lastVarPos > 1)
+                    for (int blockStart = lastVarPos + 1; blockStart < nextVarPos; blockStart += o.refCallBlockSize) {
+                        const int blockEnd = std::min(blockStart + o.refCallBlockSize, nextVarPos - 1);
+                        if (blockStart == blockEnd) continue;
+                        try {
+                            if (refCallLine(r, w.text, blockStart, blockEnd, snapshotNR(w.ptrs), false, 0.0)) { ++w.nRecords; ++w.nRefRecords; }
+                        } catch (const WindowError& e) { logWindowFailure(r.in->chrom, blockStart, blockEnd, e.what()); }
+                    }
+            }
+            last = these;
+        }
     }
     void countCalled(size_t n) { std::lock_guard<std::mutex> g(stMutex); st.n_windows_called += (int64_t)n; }
 
@@ -1176,7 +1421,7 @@ struct Chunk {
         std::vector<std::pair<int, VarList>*> positions;
         for (auto& pv : w.byPos) positions.push_back(&pv);
         std::sort(positions.begin(), positions.end(), [](const std::pair<int, VarList>* a, const std::pair<int, VarList>* b) { return a->first < b->first; });
-        std::string& out = r.text;
+        std::string& out = w.text;
         char buf[128];
         for (size_t pi = 0; pi < positions.size(); ++pi) {
             int POS = positions[pi]->first;
@@ -1281,7 +1526,7 @@ struct Chunk {
             out += "\tGT:GL:GOF:GQ:NR:NV";
             for (const std::string& c : sampleCols) { out += '\t'; out += c; }
             out += '\n';
-            ++r.nRecords;
+            ++w.nRecords;
         }
     }
 
@@ -1295,7 +1540,8 @@ struct Chunk {
         mark = t0;
         uploadReads();
         lap(0);
-        scanCandidates();
+        if (o.getVariantsFromBAMs) scanCandidates();
+        assembleTiles();
         lap(1);
         int scan0 = 0;
         for (RegionWork* r : regions) {
@@ -1320,25 +1566,71 @@ struct Chunk {
             // only the failing ones are skipped (what the reference's per-window try/except does, variantcaller.pyx:568-615).  A failing
             // runtime, an exhausted device or a lost GPU is nobody's window: it ends plat_call_regions with that error.
             if (!windowClassError(e.code)) throw;
-            for (RegionWork* r : regions) { r->text.clear(); r->nRecords = 0; }
+            for (WindowWork* w : wins) { w->text.clear(); w->nRecords = 0; w->nRefRecords = 0; }
             for (WindowWork* w : wins) {
                 std::vector<WindowWork*> one{w};
                 try { callWindows(one); }
                 catch (const DeviceError& e2) {
                     if (!windowClassError(e2.code)) throw;
+                    w->text.clear(); w->nRecords = 0; w->nRefRecords = 0;
                     logWindowFailure(regions[(size_t)regionSlot(w->region)]->in->chrom, w->startPos, w->endPos, e2.what());
                     std::lock_guard<std::mutex> g(stMutex);
                     ++st.n_windows_failed;
                 }
             }
         }
-        int64_t nRec = 0;
-        for (RegionWork* r : regions) { nRec += r->nRecords; r->release(); }
+        // the region's text: what the loop writes, in the order it writes it
+        int64_t nRec = 0, nRef = 0;
+        for (RegionWork* r : regions) {
+            int nHapLast = 0;                                               // haplotypes of the last window set up in this region (Population.nHaplotypes)
+            for (Item& it : r->items) {
+                if (it.kind == 1) { r->text += it.text; nRec += it.nRef; nRef += it.nRef; continue; }
+                WindowWork& w = r->windows[(size_t)it.window];
+                if (w.failed) continue;
+                if (w.live) { r->text += w.text; nRec += w.nRecords; nRef += w.nRefRecords; nHapLast = (int)w.haps.size(); continue; }
+                if (!o.outputRefCalls) continue;
+                // a window the loop left without calling (no reads, too many, one haplotype): outputRefCall on a Population that was reset
+                // and not set up for it.  Its haplotype list is empty but it still holds the haplotype COUNT of the last window it was
+                // set up for, so calculatePosterior's loop raises (logged, skipped) -- unless it never was set up in this region
+                try {
+                    bool ok;
+                    if (w.vars.empty()) ok = refCallLine(*r, r->text, w.startPos, w.endPos, snapshotNR(w.ptrs), false, 0.0);
+                    else {
+                        // (minCov == 0 decides before the posterior is asked for)
+                        if (nHapLast > 0 && !coverageHasAZero(*r, w.startPos, w.endPos)) throw WindowError("list index out of range");
+                        const double prior = 0.5;
+                        const double post = py2_round0(-10.0 * (log10(1.0 * (1.0 - prior)) - log10(prior + 1.0 * (1.0 - prior))));
+                        ok = refCallLine(*r, r->text, w.startPos, w.endPos, snapshotNR(w.ptrs), true, post);
+                    }
+                    if (ok) { ++nRec; ++nRef; }
+                    else throw WindowError("cannot convert float infinity to integer");
+                } catch (const WindowError& e) {
+                    logWindowFailure(r->in->chrom, w.startPos, w.endPos, e.what());
+                    std::lock_guard<std::mutex> g(stMutex);
+                    ++st.n_windows_failed;
+                }
+            }
+            r->release();
+        }
         const double total = secs(t0, Clock::now()), waited = s.t_wait - wait0;
         std::lock_guard<std::mutex> g(stMutex);
-        st.n_windows += nWin; st.n_variants += nVar; st.n_candidate_records += nCand; st.n_records += nRec;
+        st.n_windows += nWin; st.n_variants += nVar; st.n_candidate_records += nCand; st.n_records += nRec; st.n_refcall_records += nRef;
         st.seconds_host += total - waited; st.seconds_device_wait += waited;
         for (int k = 0; k < 8; ++k) st.seconds_stage[k] += stage[k];
+    }
+    bool coverageHasAZero(const RegionWork& r, int windowStart, int windowEnd) const {
+        for (const SampleView& sv : r.samples) {
+            const TableView& tv = sv.reads;
+            const int N = tv.n();
+            if (N == 0) return windowStart < windowEnd;
+            for (int p = windowStart; p < windowEnd; ++p) {
+                int s0 = TableView::lowerBound(tv.t->pos, N, std::max<int64_t>(1, (int64_t)p - tv.longest));
+                const int e0 = TableView::lowerBound(tv.t->pos, N, (int64_t)p + 1);
+                while (s0 < N && tv.t->end[s0] <= p) ++s0;
+                if (std::min(e0, N) - s0 <= 0) return true;
+            }
+        }
+        return false;
     }
 };
 
@@ -1361,6 +1653,8 @@ CALLER_EXPORT void plat_caller_default_options(plat_caller_options* o) {
     o->useEMLikelihoods = 0; o->countOnlyExactIndelMatches = 0; o->calculateFlankScore = 0; o->assemble = 0; o->outputRefCalls = 0; o->minMapQual = 20;
     o->minBaseQual = 20; o->minPosterior = 5; o->sbThreshold = 1e-3; o->scThreshold = 0.95; o->abThreshold = 1e-3; o->minVarFreq = 0.05;
     o->badReadsWindow = 11; o->badReadsThreshold = 15; o->rmsmqThreshold = 40; o->qdThreshold = 10; o->hapScoreThreshold = 4;
+    o->refCallBlockSize = 1000; o->assemblyRegionSize = 1500; o->assembleAll = 1; o->assembleBadReads = 1; o->assembleBrokenPairs = 0; o->assemblerKmerSize = 15;
+    o->noCycles = 0;
 }
 
 CALLER_EXPORT int plat_caller_create(int device, int n_workers, int regions_per_chunk, plat_caller** out) {
@@ -1394,7 +1688,7 @@ CALLER_EXPORT int plat_caller_destroy(plat_caller* c) {
                    z.g_end, z.g_flags, z.o_calls, z.o_iters, z.o_hapscore, z.o_score, z.w_pairoff, z.w_hapoff, z.w_readoff, z.w_gloff, z.w_hapseq, z.w_kind, z.g_seq,
                    z.g_qual, z.g_mapq, z.o_loglik, z.o_gl, z.o_logl, z.o_gof, z.o_freq, z.o_em, z.p_win, z.s_vw, z.s_pos, z.s_min, z.s_max, z.s_nadd, z.s_nrem,
                    z.s_gb, z.s_ge, z.s_bb, z.s_be, z.s_ps, z.s_minq, z.s_nminq, z.k_win, z.k_nvar, z.k_vih, z.k_ref, z.k_ph, z.p_off, z.s_aoff, z.s_moff, z.s_counts,
-                   z.k_vo, z.k_ro, z.k_lo, z.p_mask, z.s_added, z.s_vig, z.p_prior, z.p_post, z.k_lik, z.k_out4, z.t_pack, z.a_tab, z.a_cin, z.a_cout, z.a_mout, z.c_scanbegin, z.c_scanlongest, z.m_cand, z.m_n, z.a_win, z.a_wout,
+                   z.k_vo, z.k_ro, z.k_lo, z.p_mask, z.s_added, z.s_vig, z.p_prior, z.p_post, z.k_lik, z.k_out4, z.t_pack, z.as_seq, z.as_qual, z.as_mapq, z.as_pos, z.as_end, z.as_flags, z.a_asin, z.a_asout, z.a_tab, z.a_cin, z.a_cout, z.a_mout, z.c_scanbegin, z.c_scanlongest, z.m_cand, z.m_n, z.a_win, z.a_wout,
                    z.a_pin, z.a_sin, z.a_sout);
         plat_stream_destroy(z.ctx, z.stream);
         plat_ctx_destroy(z.ctx);
@@ -1431,7 +1725,7 @@ static std::unique_ptr<RegionWork> makeRegionWork(const plat_region* in, int ind
     return r;
 }
 // options.rlen follows the longest read of each region and is kept from the region before when a region has no reads (variantcaller.pyx:476-488)
-static inline int nextRlen(int rlen, int longest, int maxSize) { return longest > 0 ? (longest >= maxSize ? maxSize : longest) : rlen; }
+static inline int nextRlen(int rlen, int longest, int maxSize, int fromBams = 1) { return (fromBams && longest > 0) ? (longest >= maxSize ? maxSize : longest) : rlen; }
 
 // every region already in memory (plat_call_regions)
 struct MemoryFeed : Feed {
@@ -1453,7 +1747,7 @@ struct MemoryFeed : Feed {
 
 // regions loaded on demand by loader threads into a bounded set of slots (plat_call_regions_stream)
 struct StreamFeed : Feed {
-    int n, nSamples, per, nChunks, maxSize;
+    int n, nSamples, per, nChunks, maxSize, fromBams = 1;
     plat_region_load_fn load; void* user;
     std::mutex m;
     std::condition_variable cvLoaded, cvSlot;
@@ -1513,7 +1807,7 @@ struct StreamFeed : Feed {
             if (all) {
                 out.clear();
                 for (int k = a; k < b; ++k) {                                // list order: rlen walks the regions as the reference's loop does
-                    rlen = nextRlen(rlen, longest[(size_t)k], maxSize);
+                    rlen = nextRlen(rlen, longest[(size_t)k], maxSize, fromBams);
                     work[(size_t)k]->rlen = rlen;
                     out.push_back(work[(size_t)k].get());
                 }
@@ -1580,10 +1874,6 @@ static int finishText(std::vector<std::unique_ptr<RegionWork>>& work, char** out
 static int checkCallArgs(plat_caller* c, const plat_caller_options* options, char** out_text, size_t* out_len, int n_regions, int n_samples) {
     if (!c || !options || !out_text || !out_len || n_regions < 0 || n_samples < 1) return PLAT_ERR_INVALID;
     *out_text = nullptr; *out_len = 0;
-    if (options->assemble || options->outputRefCalls) {
-        c->lastError = "assemble=1 and outputRefCalls=1 are not built in the native region loop (use platypus_amd.caller)";
-        return PLAT_ERR_UNSUPPORTED;
-    }
     if (!options->getVariantsFromBAMs && !options->assemble) {
         // (the reference then has no candidates at all unless a source VCF is given, which is not built)
         c->lastError = "getVariantsFromBAMs=0 without assemble=1 leaves no candidate source (source VCFs are not built)";
@@ -1609,7 +1899,7 @@ CALLER_EXPORT int plat_call_regions(plat_caller* c, const plat_region* regions, 
     for (int k = 0; k < n_regions; ++k) {
         int longest = 0;
         std::unique_ptr<RegionWork> r = makeRegionWork(&regions[k], k, n_samples, longest);
-        rlen = nextRlen(rlen, longest, options->maxSize);
+        rlen = nextRlen(rlen, longest, options->maxSize, options->getVariantsFromBAMs);
         r->rlen = rlen;
         work.push_back(std::move(r));
     }
@@ -1644,6 +1934,7 @@ CALLER_EXPORT int plat_call_regions_stream(plat_caller* c, int n_regions, int n_
     static_cast<plat_caller_options&>(o) = *options;
     std::atomic<bool> failed(false);
     StreamFeed feed(n_regions, n_samples, per, options->maxSize, options->rlen, load, user, n_slots, failed);
+    feed.fromBams = options->getVariantsFromBAMs;
     std::vector<std::thread> loaders;
     for (int i = 0; i < std::min(n_loader_threads, std::max(1, n_regions)); ++i) loaders.emplace_back([&feed] { feed.loader(); });
     rc = runWorkers(c, feed, failed, o, n_samples, sample_names, st, std::max(1, feed.nChunks));

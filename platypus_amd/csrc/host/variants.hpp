@@ -306,7 +306,7 @@ inline bool isHaplotypeValid(const VarList& variants) {
 // ---- WindowGenerator (window.py:18-238) -----------------------------------------------------------------------------------------
 struct Window { int startPos, endPos; VarList variants; };
 
-struct WindowOptions { int mergeClusteredVariants, maxVarDist, minVarDist, maxSize, largeWindows, rlen, maxVariants; };
+struct WindowOptions { int mergeClusteredVariants, maxVarDist, minVarDist, maxSize, largeWindows, rlen, maxVariants, outputRefCalls = 0, refCallBlockSize = 1000; };
 
 inline std::vector<Window> windowsAndVariants(int start, int end, int64_t maxContigPos, const VarList& sortedVariants, const WindowOptions& o) {
     // getVariantsByPos: groups of equal refPos, ascending
@@ -338,8 +338,26 @@ inline std::vector<Window> windowsAndVariants(int start, int end, int64_t maxCon
         else bunches.push_back(group);
     }
     std::vector<Window> out;
-    for (VarList& vs : bunches) {
+    // reference-call blocks in the gaps in front of and between the variant windows (window.py:172-219): windows without variants
+    auto refBlocks = [&](int first, int stop) {
+        if (o.refCallBlockSize <= 0) throw WindowError("range() arg 3 must not be zero");
+        for (int blockStart = first; blockStart < stop; blockStart += o.refCallBlockSize) {
+            const int blockEnd = std::min(blockStart + o.refCallBlockSize, stop - 1);
+            if (blockStart != blockEnd) out.push_back(Window{blockStart, blockEnd, VarList()});
+        }
+    };
+    for (size_t index = 0; index < bunches.size(); ++index) {
+        VarList& vs = bunches[index];
         const int lo = minOf(vs), hi = maxOf(vs);
+        if (o.outputRefCalls) {
+            if (index == 0) {
+                const int firstVarPos = std::max(lo + 1, start);
+                if (firstVarPos - start >= 1) refBlocks(start, firstVarPos);
+            } else {
+                const int lastVarPos = maxOf(bunches[index - 1]);
+                if (lo + 1 - lastVarPos > 1) refBlocks(lastVarPos + 1, lo + 1);
+            }
+        }
         Window w;
         w.startPos = std::max(lo - o.minVarDist, start);
         w.endPos = (int)std::min<int64_t>(hi + o.minVarDist, maxContigPos);

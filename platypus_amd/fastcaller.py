@@ -46,7 +46,9 @@ _OPT_FIELDS = [("rlen", C.c_int32), ("minReads", C.c_int32), ("maxReads", C.c_do
                ("assemble", C.c_int32), ("outputRefCalls", C.c_int32), ("minMapQual", C.c_int32), ("minBaseQual", C.c_int32),
                ("minPosterior", C.c_int32), ("sbThreshold", C.c_double), ("scThreshold", C.c_double), ("abThreshold", C.c_double),
                ("minVarFreq", C.c_double), ("badReadsWindow", C.c_int32), ("badReadsThreshold", C.c_int32), ("rmsmqThreshold", C.c_int32),
-               ("qdThreshold", C.c_int32), ("hapScoreThreshold", C.c_int32), ("_pad", C.c_int32)]
+               ("qdThreshold", C.c_int32), ("hapScoreThreshold", C.c_int32), ("refCallBlockSize", C.c_int32),
+               ("assemblyRegionSize", C.c_int32), ("assembleAll", C.c_int32), ("assembleBadReads", C.c_int32), ("assembleBrokenPairs", C.c_int32),
+               ("assemblerKmerSize", C.c_int32), ("noCycles", C.c_int32)]
 
 
 class CallerOptions(C.Structure):
@@ -66,7 +68,8 @@ class CallerStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("n_regions", "n_reads", "n_candidate_records", "n_variants", "n_windows", "n_windows_called",
                                          "n_records", "n_windows_greedy", "n_windows_failed")] + \
                [(k, C.c_double) for k in ("seconds_total", "seconds_host", "seconds_device_wait")] + [("seconds_stage", C.c_double * 8)] + \
-               [("seconds_load", C.c_double), ("seconds_source_wait", C.c_double), ("input_bytes", C.c_int64)]
+               [("seconds_load", C.c_double), ("seconds_source_wait", C.c_double), ("input_bytes", C.c_int64), ("n_assembly_tiles", C.c_int64),
+                ("n_assembler_variants", C.c_int64), ("n_refcall_records", C.c_int64), ("seconds_assemble", C.c_double)]
 
     STAGES = ("upload", "candidate_scan", "variants_windows_haplotypes", "greedy_rounds", "window_batch", "posteriors", "read_stats_calls", "text")
 

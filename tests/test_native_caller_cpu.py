@@ -124,10 +124,56 @@ def test_native_refuses_what_it_does_not_build(fake):
     fasta, work = _work(regs, ["S1"])
     nc = F.NativeCaller(0, 1, 1, lib=fake)
     from platypus_amd._lib import PlatypusDeviceError
-    for bad in (dict(assemble=1), dict(outputRefCalls=1), dict(getVariantsFromBAMs=0)):
+    for bad in (dict(getVariantsFromBAMs=0),):                              # no candidate source at all (source VCFs are not built)
         with pytest.raises(PlatypusDeviceError) as e:
             nc.call_regions([F.RegionReads.from_buffers(c, s, e_, fasta, b) for c, s, e_, b in work], ["S1"], default_options(**bad))
         assert e.value.code == -6
+
+
+def _split_classes(rng):
+    def split(k, i, rs):
+        good, bad, broken = [], [], []
+        for r in rs:
+            u = rng.random()
+            if u < 0.08:
+                r.mapq = int(rng.integers(0, 20)); r.bitFlag |= 512 if u < 0.04 else 0
+                bad.append(r)
+            elif u < 0.12:
+                r.matePos = r.pos + int(rng.integers(-400, 400))
+                broken.append(r)
+            else:
+                good.append(r)
+        return good, bad, broken
+    return split
+
+
+@pytest.mark.parametrize("opt", [dict(assemble=1), dict(assemble=1, getVariantsFromBAMs=0), dict(assemble=1, assemblyRegionSize=700, assembleBrokenPairs=1, assembleBadReads=0),
+                                 dict(assemble=1, assembleAll=0), dict(assemble=1, noCycles=1, assemblerKmerSize=21)])
+def test_native_equals_python_with_the_assembler(fake, opt):
+    """--assemble=1 (variantcaller.pyx:496-519, 276-321; assembler.pyx:1391-1476): tiles of every region of a chunk assembled in one device
+    batch, their variants join the BAM candidates (or stand alone), same text as the Python region loop -- tiling, read selection
+    (badReads / brokenMates / QCFail), doWeNeedToAssembleThisRegion, sources in the INFO field."""
+    rng = np.random.default_rng(12)
+    regs = [synth.config4_region(700 + i, n_samples=2, region_len=2600, snp_rate=3e-3, indel_rate=2.5e-3, read_len=100, depth=30) for i in range(3)]
+    regs[1]["samples"][1] = []
+    txt, st = _both(fake, regs, ["S1", "S2"], extra=_split_classes(rng), workers=2, per_chunk=2, **opt)
+    assert st["n_assembly_tiles"] >= (6 if opt.get("assembleAll", 1) else 0)
+    if opt.get("assembleAll", 1):
+        assert st["n_assembler_variants"] > 5 and "Source=Assembler" in txt or "Platypus,Assembler" in txt
+    if not opt.get("getVariantsFromBAMs", 1):
+        assert "Source=Platypus" not in txt and txt.count("\n") > 3
+
+
+@pytest.mark.parametrize("opt", [dict(outputRefCalls=1), dict(outputRefCalls=1, refCallBlockSize=150, minPosterior=60),
+                                 dict(outputRefCalls=1, refCallBlockSize=37, maxVariants=2, skipDifficultWindows=1), dict(outputRefCalls=1, assemble=1)])
+def test_native_equals_python_with_reference_calls(fake, opt):
+    """--outputRefCalls=1 (variantcaller.pyx:584-607,764-867; window.py:172-219): REFCALL lines for the blocks between calling windows,
+    between the called positions of a window, for windows without a call and for windows the loop leaves uncalled -- the text of the
+    Python region loop (itself pinned by refcall_cases / regionprep_cases and its window-by-window shape)."""
+    regs = [synth.config4_region(400 + i, n_samples=2, region_len=2500, snp_rate=5e-3, indel_rate=1.5e-3, read_len=100, depth=[30, 4, 12][i % 3]) for i in range(4)]
+    regs[2]["samples"][0] = []                                             # a sample without reads: blocks without coverage
+    txt, st = _both(fake, regs, ["S1", "S2"], workers=2, per_chunk=2, **opt)
+    assert st["n_refcall_records"] == txt.count("\tREFCALL\t") >= 20 and st["n_records"] - st["n_refcall_records"] >= 5
 
 
 def test_native_equals_python_on_array_regions(fake):
@@ -153,7 +199,7 @@ def test_native_equals_python_on_array_regions(fake):
 def test_reference_call_blocks_batched_equals_window_by_window(fake):
     """--outputRefCalls=1 (variantcaller.pyx:584-607,764-867): REFCALL lines for the blocks between calling windows, between the
     called positions of a window and for windows without a call; the batched shape of the Python region loop writes what the
-    window-by-window shape writes.  (The native loop does not build them: PLAT_ERR_UNSUPPORTED, covered above.)"""
+    window-by-window shape writes."""
     regs = [synth.config4_region(400 + i, n_samples=2, region_len=2500, snp_rate=5e-3, indel_rate=1.5e-3, read_len=100, depth=[30, 4][i % 2]) for i in range(3)]
     names = ["S1", "S2"]
     fasta, work = _work(regs, names)
