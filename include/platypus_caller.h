@@ -121,6 +121,7 @@ typedef struct plat_caller_stats {
     int64_t n_assembly_tiles, n_assembler_variants;   /* assemble=1: tiles assembled, variants they returned */
     int64_t n_refcall_records;                        /* outputRefCalls=1: REFCALL lines among n_records */
     double seconds_assemble;                          /* sum over worker threads: tiles -> device assembler -> variants */
+    int64_t n_pairs;                                  /* (read, haplotype) pairs of the called windows: entries of the likelihood arrays */
 } plat_caller_stats;
 
 typedef struct plat_caller plat_caller;

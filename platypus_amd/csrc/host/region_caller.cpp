@@ -1129,6 +1129,7 @@ struct Chunk {
             b.endWindow();
         }
         DeviceBatch db = runWindows(z, b, o, true, false);
+        { std::lock_guard<std::mutex> g(stMutex); st.n_pairs += db.nPairs; }
         lap(4);
 
         // D: distinct variants, masks, priors -> posteriors (Population.computeVariantPosteriors, cpopulation.pyx:596-621)

@@ -69,7 +69,7 @@ class CallerStats(C.Structure):
                                          "n_records", "n_windows_greedy", "n_windows_failed")] + \
                [(k, C.c_double) for k in ("seconds_total", "seconds_host", "seconds_device_wait")] + [("seconds_stage", C.c_double * 8)] + \
                [("seconds_load", C.c_double), ("seconds_source_wait", C.c_double), ("input_bytes", C.c_int64), ("n_assembly_tiles", C.c_int64),
-                ("n_assembler_variants", C.c_int64), ("n_refcall_records", C.c_int64), ("seconds_assemble", C.c_double)]
+                ("n_assembler_variants", C.c_int64), ("n_refcall_records", C.c_int64), ("seconds_assemble", C.c_double), ("n_pairs", C.c_int64)]
 
     STAGES = ("upload", "candidate_scan", "variants_windows_haplotypes", "greedy_rounds", "window_batch", "posteriors", "read_stats_calls", "text")
 

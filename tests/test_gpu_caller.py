@@ -295,3 +295,32 @@ def test_streamed_packed_regions_equal_the_region_list_on_the_device():
     st = nc.stats
     assert st["input_bytes"] == st["n_reads"] * 150 and st["seconds_load"] > 0
     assert nc.call_regions([F.region_from_arrays(r, packed=True, pin=True) for r in regs], names, default_options()) == want
+
+
+def test_native_assembler_and_reference_calls_equal_the_python_loop_on_the_device():
+    """--assemble=1 and --outputRefCalls=1 in the native region loop (tiles of a chunk in one plat_assemble_batch on reads gathered from
+    the chunk table; REFCALL blocks, flat-prior posteriors) write the text of the Python region loop; and BASELINE config 3's regions
+    (250 bp reads, indels up to 60 bases) come through end to end with the planted indels called."""
+    from platypus_amd import fastcaller as F
+    regs, names, fasta, work = _array_regions(4, 2, region_len=6000, snp_rate=2e-3, indel_rate=1.5e-3, read_len=150, depth=30)
+    for opt in (dict(assemble=1), dict(outputRefCalls=1, refCallBlockSize=400), dict(assemble=1, outputRefCalls=1, getVariantsFromBAMs=0)):
+        o1, o2 = default_options(**opt), default_options(**opt)
+        py = io.StringIO()
+        caller.callVariantsInRegions(_array_regions(4, 2, region_len=6000, snp_rate=2e-3, indel_rate=1.5e-3, read_len=150, depth=30)[3], fasta, o1, VCF(names), py)
+        nc = F.NativeCaller(0, 2, 2)
+        txt = nc.call_regions([F.region_from_arrays(r, packed=True) for r in regs], names, o2)
+        assert txt == py.getvalue() and txt.count("\n") > 30, opt
+        st = nc.stats
+        if opt.get("assemble"):
+            assert st["n_assembly_tiles"] == 4 * 8 and st["n_assembler_variants"] > 20 and "Assembler" in txt
+        if opt.get("outputRefCalls"):
+            assert st["n_refcall_records"] == txt.count("\tREFCALL\t") > 30
+    from tools import bench_other
+    r = bench_other.config3_end_to_end(0, 64)
+    lines = r["text"].split("\n")[:-1]
+    assert r["tiles"] == 128 and r["assembler_variants"] > 100 and r["windows"] > 80 and r["pairs"] > 10000
+    indels = [ln for ln in lines if len(ln.split("\t")[3]) != len(ln.split("\t")[4])]
+    n_asm = sum("Assembler" in ln for ln in indels)
+    longest = max(abs(len(ln.split("\t")[3]) - len(ln.split("\t")[4].split(",")[0])) for ln in indels)
+    assert len(indels) > 40 and n_asm >= 15, (len(lines), len(indels), n_asm, longest)
+    assert longest >= 20, (len(lines), len(indels), n_asm, longest)          # indels far beyond what a 250 bp read's CIGAR shows reliably

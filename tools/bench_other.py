@@ -24,7 +24,8 @@ class _Solo:
 
     def barrier(self):
         import torch
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
     def reduce(self, seconds, sums):
         return seconds, [float(x) for x in sums]
@@ -128,6 +129,30 @@ def config3(eng, n_regions, steps, warmup, seed=3003, rk=None):
                 planted=sum(len(t) for t in ab["truth"]))
 
 
+CONFIG3_MODEL = dict(indel_max_len=60, indel_p=0.15, n_indel=(1, 3), n_snp=(0, 3), lowq_frac=0.05)
+
+
+def config3_end_to_end(device, n_regions, rk=None, first=0, lib=None, region_kw=None):
+    """BASELINE config 3 END TO END: indel-heavy regions (4.5 kb contig = 1.5 kb region +- 1.5 kb, 1-3 indels of 1..60 bases +
+    0-3 SNPs, 250 bp reads at 30x, 5 % of the bases below Q20) through the native region loop with --assemble=1: assembler tiles of every
+    chunk in one plat_assemble_batch, their variants merged with the BAM candidates, then the called windows through the likelihoods at
+    250 bp (buf = 500), EM, posteriors, records.  Regions are loaded on demand (tools/synth)."""
+    workers = int(os.environ.get("PLAT_CALLER_WORKERS", "16"))
+    kw = dict(flank=1500, read_len=250, model=CONFIG3_MODEL, **(region_kw or {}))
+    r = config4(device, range(first, first + n_regions), 1500, workers, int(os.environ.get("PLAT_CALLER_CHUNK3", "32")), repeats=1, region_kw=kw, rk=rk,
+                options_kw=dict(assemble=1), lib=lib, pin=lib is None)
+    st, T = r["stats"], r["T"]
+    return dict(regions=r["regions"], tiles=int(st["n_assembly_tiles"]), assembler_variants=int(st["n_assembler_variants"]), planted_variants=r["planted"],
+                windows=r["windows"], records=r["records"], reads=r["reads"], pairs=int(st["n_pairs"]), timed_s=T,
+                regions_per_sec=r["regions"] / T, tiles_per_sec=st["n_assembly_tiles"] / T, windows_per_sec=r["windows"] / T,
+                gcups_lower_bound=st["n_pairs"] * 16 * 250 / T / 1e9,
+                gcups_note="(read, haplotype) pairs of the called windows x 16 x 250 band cells / wall time of the WHOLE pipeline: the reference "
+                           "runs at least one DP for every pair it does not skip",
+                host_seconds_per_region=st["seconds_host"] / r["regions"], device_wait_seconds_per_region=st["seconds_device_wait"] / r["regions"],
+                assemble_seconds_per_region=st["seconds_assemble"] / r["regions"], host_threads=r["workers"], regions_per_chunk=r["per_chunk"],
+                text=r["text"])
+
+
 def line_config3(a, rk):
     from platypus_amd.engine import Engine
     rank, world = rk.rank, rk.world
@@ -144,6 +169,7 @@ def line_config3(a, rk):
                                    "1-3 indels + 0-3 SNPs per tile, k = 15, minWeight 40" % nreg, "regions_per_gpu": nreg,
                        "reads_per_step": int(r["ab"]["n_reads"])},
             "variants_found": r["variants"], "variants_planted": r["planted"],
+            "end_to_end": {k: v for k, v in config3_end_to_end(rk.dev_index, nreg, rk=rk, first=rank * nreg).items() if k != "text"},
             "roofline": {"bound": "hbm", "kernel": "k_assemble", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": r["alg_bytes"],
                          "avg_launch_ms": r["kernel_ms"]}}
@@ -156,7 +182,7 @@ def run(a, rk):
 # ---- config 4 -----------------------------------------------------------------------------------------------------------------
 
 def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_samples=1, pin=True, lib=None, region_kw=None, rk=None, packed=True,
-            loaders=None, warm_regions=None):
+            loaders=None, warm_regions=None, options_kw=None):
     """The region pipeline end to end, sustained: the regions `indices` of the job's region list are LOADED ON DEMAND by a region source
     (tools/synth: generated from seed (+) region index inside the library's loader threads into a bounded set of pinned slots -- where the
     reference's BAM loader stands) and called through the native region loop (plat_call_regions_stream: host threads + every device stage
@@ -175,11 +201,11 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
     nc = F.NativeCaller(device, workers, per_chunk, lib=lib)
     nwarm = min(len(indices), warm_regions if warm_regions is not None else 2 * per_chunk * workers)
     if nwarm:                                                                 # every worker's scratch buffers at full size, code paths warm
-        nc.call_stream(nwarm, src.load_fn, src.h, names, default_options(), n_slots, loaders)
+        nc.call_stream(nwarm, src.load_fn, src.h, names, default_options(**(options_kw or {})), n_slots, loaders)
     runs, text, merged, gather, st = [], "", None, None, None
     planted0 = src.planted
     for _ in range(repeats):
-        opts = default_options()
+        opts = default_options(**(options_kw or {}))
         rk.barrier()
         t0 = time.perf_counter()
         text = nc.call_stream(len(indices), src.load_fn, src.h, names, opts, n_slots, loaders)

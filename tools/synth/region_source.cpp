@@ -47,6 +47,9 @@ struct plat_synth {
     std::vector<int32_t> index;                                            // job position -> region id
     uint8_t* mem; size_t slotBytes; int nSlots;
     std::vector<uint8_t> tape;                                             // quality tape
+    // variant model: indel length 1 + min(indelMax - 1, geometric(indelP) - 1); counts Poisson(rate x length) unless a [min, max] range is set
+    int indelMax = 10, nIndelMin = -1, nIndelMax = -1, nSnpMin = -1, nSnpMax = -1;
+    double indelP = 0.4;
     long long planted = 0, reads = 0;                                      // totals over the regions loaded (statistics)
     long long phaseNs[6] = {0, 0, 0, 0, 0, 0};                             // reference, variants, haplotypes, read starts + sort, reads, rest
 };
@@ -87,6 +90,21 @@ SYNTH_EXPORT int plat_synth_create(uint64_t seed, int region_len, int flank, int
         for (int k = 0; k < 2 && i + k < T; ++k) g->tape[i + k] = (uint8_t)std::min(41.0, std::max(2.0, std::floor(35.0 + 5.0 * z[k] + 0.5)));
     }
     *out = g;
+    return 0;
+}
+
+// BASELINE config 3's model: n_indel_min..max indels of 1..indel_max_len bases (geometric, p = indel_p) and n_snp_min..max
+// SNPs per region instead of Poisson counts; lowq_frac of the bases of the quality tape redrawn uniformly below Q20.
+SYNTH_EXPORT int plat_synth_set_model(plat_synth* g, int indel_max_len, double indel_p, int n_indel_min, int n_indel_max, int n_snp_min, int n_snp_max,
+                                      double lowq_frac)
+{
+    if (!g || indel_max_len < 1 || indel_max_len > 1000 || indel_p <= 0 || indel_p > 1 || lowq_frac < 0 || lowq_frac > 1) return -1;
+    g->indelMax = indel_max_len; g->indelP = indel_p;
+    g->nIndelMin = n_indel_min; g->nIndelMax = n_indel_max; g->nSnpMin = n_snp_min; g->nSnpMax = n_snp_max;
+    if (lowq_frac > 0) {
+        Rng r(g->seed, 0xFFFFFFFEull);
+        for (uint8_t& q : g->tape) if (r.uni() < lowq_frac) q = (uint8_t)(2 + r.below(18));
+    }
     return 0;
 }
 
@@ -141,10 +159,11 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
     std::vector<Var>& vars = S.vars;
     vars.clear();
     {
-        const int nSnp = rng.poisson(g->regionLen * g->snpRate + 1e-12), nInd = rng.poisson(g->regionLen * g->indelRate + 1e-12);
+        const int nSnp = g->nSnpMax >= 0 ? g->nSnpMin + (int)rng.below((uint32_t)(g->nSnpMax - g->nSnpMin + 1)) : rng.poisson(g->regionLen * g->snpRate + 1e-12);
+        const int nInd = g->nIndelMax >= 0 ? g->nIndelMin + (int)rng.below((uint32_t)(g->nIndelMax - g->nIndelMin + 1)) : rng.poisson(g->regionLen * g->indelRate + 1e-12);
         S.kinds.assign((size_t)nSnp, 0); S.kinds.insert(S.kinds.end(), (size_t)nInd, 1);
         for (size_t i = S.kinds.size(); i > 1; --i) std::swap(S.kinds[i - 1], S.kinds[rng.below((uint32_t)i)]);
-        const int lo = start + 20, hi = end - 40;
+        const int lo = start + 20, hi = end - 40 - (g->indelMax > 10 ? g->indelMax : 0);
         S.spots.clear();
         if (hi > lo) for (size_t i = 0; i < S.kinds.size(); ++i) S.spots.push_back(lo + (int)rng.below((uint32_t)(hi - lo)));
         std::sort(S.spots.begin(), S.spots.end());
@@ -158,7 +177,7 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
                 vars.push_back(Var{p, 0, 1, std::string(1, B[(cur + 1 + (int)rng.below(3)) & 3])});
                 last = p + 2;
             } else {
-                const int k = 1 + std::min(9, rng.geometric(0.4) - 1);
+                const int k = 1 + std::min(g->indelMax - 1, rng.geometric(g->indelP) - 1);
                 if (rng.uni() < 0.5) {
                     std::string b((size_t)k, 'A');
                     for (char& c : b) c = "ACGT"[rng.below(4)];

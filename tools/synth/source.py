@@ -31,6 +31,7 @@ def load():
         lib.plat_synth_slot_bytes.argtypes = [C.c_int] * 6
         lib.plat_synth_create.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p,
                                           C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+        lib.plat_synth_set_model.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
         lib.plat_synth_destroy.argtypes = [C.c_void_p]
         lib.plat_synth_planted.restype = C.c_longlong
         lib.plat_synth_planted.argtypes = [C.c_void_p]
@@ -46,7 +47,9 @@ class RegionSource:
     (torch, page-locked when `pin`) bound the reads in flight."""
 
     def __init__(self, indices, n_slots, seed=4004, region_len=100000, flank=1000, n_samples=1, depth=30, read_len=150, snp_rate=1e-3, indel_rate=1e-4,
-                 err=1e-3, packed=True, pin=True):
+                 err=1e-3, packed=True, pin=True, model=None):
+        """model: None = config 4 (Poisson counts, indels of 1..10 bases) or dict(indel_max_len, indel_p, n_indel=(min, max), n_snp=(min, max),
+        lowq_frac) = config 3's assembly regions."""
         lib = load()
         self.lib = lib
         self.indices = np.ascontiguousarray(indices, dtype=np.int32)
@@ -62,6 +65,11 @@ class RegionSource:
         if rc != 0:
             raise ValueError("plat_synth_create refused the parameters (%d)" % rc)
         self.h = h
+        if model:
+            rc = lib.plat_synth_set_model(h, model.get("indel_max_len", 10), model.get("indel_p", 0.4), *model.get("n_indel", (-1, -1)), *model.get("n_snp", (-1, -1)),
+                                          model.get("lowq_frac", 0.0))
+            if rc != 0:
+                raise ValueError("plat_synth_set_model refused the parameters")
         self.bytes_per_base = 1 if packed else 2
 
     @property
