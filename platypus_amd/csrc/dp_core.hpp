@@ -205,8 +205,97 @@ struct DP {
     __device__ __forceinline__ int result() const { return (int)(minscore >> 2); }   // (minscore + 0x8000) >> 2, align.c:520
 };
 
+// ---- words built on the fly from the caller's bytes ---------------------------------------------------------------------
+// (round 3: the DP no longer reads a pre-converted tile -- 12 % of the pairs reach it, the other reads' words were built and
+//  written for nothing.)  Eight bases of a read / eight haplotype positions arrive as two 64-bit loads each (bases, qualities or
+//  gap-open penalties; any alignment), and one word costs two instructions: v_perm_b32 puts byte k of the two sources into the
+//  two 16-bit halves, v_pk_lshlrev_b16 shifts them by 9 and by 2 -- (base << 9) | (4 * quality) << 16.
+__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+template <int K>
+__device__ __forceinline__ uint32_t word_of_bytes(uint32_t base4, uint32_t cost4) {     // K = 0..3: byte K of both
+    const uint32_t t = __builtin_amdgcn_perm(cost4, base4, 0x0c000c00u | ((4u + K) << 16) | (uint32_t)K);   // base | cost << 16
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, t) << (u16x2){9, 2}));
+}
+__device__ __forceinline__ void words_of_8(uint64_t bases, uint64_t costs, uint32_t (&out)[8]) {
+    const uint32_t b0 = (uint32_t)bases, b1 = (uint32_t)(bases >> 32), c0 = (uint32_t)costs, c1 = (uint32_t)(costs >> 32);
+    out[0] = word_of_bytes<0>(b0, c0); out[1] = word_of_bytes<1>(b0, c0); out[2] = word_of_bytes<2>(b0, c0); out[3] = word_of_bytes<3>(b0, c0);
+    out[4] = word_of_bytes<0>(b1, c1); out[5] = word_of_bytes<1>(b1, c1); out[6] = word_of_bytes<2>(b1, c1); out[7] = word_of_bytes<3>(b1, c1);
+}
+
 // The 8 forced steps h = 0..7 and the 8 extra steps h = len2..len2+7 are fully unrolled with
-// compile-time lane indices; RW(h) / HW(h) are callables returning the read / haplotype word of step h.
+// compile-time lane indices; RW(h) / HW(h) are callables returning the read / haplotype word of step h, RAWR(h) / RAWW(h)
+// the bytes of the eight steps h..h+7 of the main loop (all of them inside the read).
+struct Raw8 { uint64_t a, b; };                  // eight bases + eight qualities (or gap-open penalties) as they lie in memory
+struct Raw16 { uint64_t a0, a1, b0, b1; };       // sixteen of each
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+__device__ __forceinline__ void load_16_unaligned(const uint8_t* p, uint64_t& lo, uint64_t& hi) {
+    const u32x4_unaligned v = *(const u32x4_unaligned*)p;                  // one global_load_dwordx4
+    lo = v.x | ((uint64_t)v.y << 32); hi = v.z | ((uint64_t)v.w << 32);
+}
+template <bool HAS_N, bool SWAR, class RW, class HW, class RAWR, class RAWW, class RAW16R, class RAW16W>
+__device__ __forceinline__ int dp_run8(DP<HAS_N, SWAR>& dp, int len2, RW rw, HW hw, RAWR raw_r, RAWW raw_w, RAW16R raw16_r, RAW16W raw16_w)
+{
+    const bool l7 = (len2 == 7);
+    {
+        uint32_t r[8], w[8];
+        if (len2 >= 8) { const Raw8 x = raw_r(0), y = raw_w(0); words_of_8(x.a, x.b, r); words_of_8(y.a, y.b, w); }
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { r[k] = rw(k); w[k] = hw(k); }
+        }
+        dp.template step<0, -1>(r[0], w[0]);
+        dp.template step<1, -1>(r[1], w[1]);
+        dp.template step<2, -1>(r[2], w[2]);
+        dp.template step<3, -1>(r[3], w[3]);
+        dp.template step<4, -1>(r[4], w[4]);
+        dp.template step<5, -1>(r[5], w[5]);
+        dp.template step<6, -1>(r[6], w[6]);
+        dp.template step<7, -1>(r[7], w[7], l7);
+    }
+    int h = 8;
+    if (h + 15 < len2) {
+        // 16 steps per trip (the loop-carried register copies are paid once per trip): a lane's bytes lie where no other lane's do, so
+        // a wave's load touches 64 cache lines whatever its width -- 16 bytes per array and trip keep the texture addresser off the
+        // critical path.  The bytes of the NEXT trip are requested before this trip's steps.
+        Raw16 nr = raw16_r(h), nw = raw16_w(h);
+        for (; h + 15 < len2; h += 16) {
+            const Raw16 cr = nr, cw = nw;
+            if (h + 31 < len2) { nr = raw16_r(h + 16); nw = raw16_w(h + 16); }
+            {
+                uint32_t r[8], w[8];
+                words_of_8(cr.a0, cr.b0, r); words_of_8(cw.a0, cw.b0, w);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dp.template step<-1, -1>(r[k], w[k]);
+            }
+            {
+                uint32_t r[8], w[8];
+                words_of_8(cr.a1, cr.b1, r); words_of_8(cw.a1, cw.b1, w);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dp.template step<-1, -1>(r[k], w[k]);
+            }
+        }
+    }
+    if (h + 7 < len2) {
+        const Raw8 x = raw_r(h), y = raw_w(h);
+        uint32_t r[8], w[8];
+        words_of_8(x.a, x.b, r); words_of_8(y.a, y.b, w);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dp.template step<-1, -1>(r[k], w[k]);
+        h += 8;
+    }
+    for (; h < len2; ++h) dp.template step<-1, -1>(rw(h), hw(h));
+    // h == max(len2, 8) here
+    if (!l7) { dp.template step<-1, 0>(rw(h), hw(h)); ++h; }
+    dp.template step<-1, 1>(rw(h), hw(h)); ++h;
+    dp.template step<-1, 2>(rw(h), hw(h)); ++h;
+    dp.template step<-1, 3>(rw(h), hw(h)); ++h;
+    dp.template step<-1, 4>(rw(h), hw(h)); ++h;
+    dp.template step<-1, 5>(rw(h), hw(h)); ++h;
+    dp.template step<-1, 6>(rw(h), hw(h)); ++h;
+    dp.template step<-1, 7>(rw(h), hw(h));
+    return dp.result();
+}
+
 template <bool HAS_N, bool SWAR, class RW, class HW>
 __device__ __forceinline__ int dp_run(DP<HAS_N, SWAR>& dp, int len2, RW rw, HW hw)
 {

@@ -134,11 +134,11 @@ __device__ __forceinline__ int dp_forward_tb(const uint32_t (&w0)[8], int len2, 
 }
 
 // Backtrace (align.c:523-577) fused with calculateFlankScore (align.c:593-644).
-//   hp      : haplotype words of the WHOLE haplotype (base code | 4*gapopen << 16), st = slice start in it
-//   rp/stride: the read's column of the transposed read tile
+//   hwf(x)  : haplotype word (base code | 4*gapopen << 16) of position x of the WHOLE haplotype, st = slice start in it
+//   rwf(y)  : read word of read position y
 // Returns the flank score to subtract.
-__device__ __forceinline__ int tb_flank_score(const TbView& bp, int min_idx, int len2, const uint32_t* __restrict__ hp,
-                                              int st, int hapLen, int hapFlank, const uint32_t* __restrict__ rp, long long stride)
+template <class HWF, class RWF>
+__device__ __forceinline__ int tb_flank_score(const TbView& bp, int min_idx, int len2, HWF hwf, int st, int hapLen, int hapFlank, RWF rwf)
 {
     int s = min_idx;
     int i = s / 2 - len2;
@@ -157,7 +157,7 @@ __device__ __forceinline__ int tb_flank_score(const TbView& bp, int min_idx, int
             cur = 0;
             s -= 2; --x; --y;
             const int xg = st + x;
-            const uint32_t hwd = hp[xg < 0 ? 0 : xg], rwd = rp[(long long)y * stride];
+            const uint32_t hwd = hwf(xg < 0 ? 0 : xg), rwd = rwf(y);
             const bool in = xg < hapFlank || xg >= hapLen - hapFlank;
             if (in && (hwd & 0xFFFFu) != (rwd & 0xFFFFu) && (hwd & 0xFFFFu) != CODE_N) mcost = (int)(rwd >> 18);   // quals[y]
         } else if (state == 1) {                                          // insertion: '-' over read[y]
@@ -165,7 +165,7 @@ __device__ __forceinline__ int tb_flank_score(const TbView& bp, int min_idx, int
             i += s & 1; s -= 1; --y;
             const int xg = st + x;
             if (xg < hapFlank || xg >= hapLen - hapFlank) {
-                open = (int)(hp[xg - 1 < 0 ? 0 : xg - 1] >> 18) + 2;      // localGapOpen[x-1] + nucprior
+                open = (int)(hwf(xg - 1 < 0 ? 0 : xg - 1) >> 18) + 2;     // localGapOpen[x-1] + nucprior
                 ext = 3 + 2;                                              // gapextend + nucprior
             }
         } else {                                                          // deletion: hap[x] over '-'
@@ -173,7 +173,7 @@ __device__ __forceinline__ int tb_flank_score(const TbView& bp, int min_idx, int
             s -= 1; i -= s & 1; --x;
             const int xg = st + x;
             if (xg < hapFlank || xg >= hapLen - hapFlank) {
-                open = (int)(hp[xg < 0 ? 0 : xg] >> 18);                   // localGapOpen[x]
+                open = (int)(hwf(xg < 0 ? 0 : xg) >> 18);                  // localGapOpen[x]
                 ext = 3;
             }
         }

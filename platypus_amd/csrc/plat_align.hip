@@ -3,13 +3,13 @@
 // Pipeline of plat_align_window_batch (one stream, two small host read-backs):
 //   k_validate    input checks + maxima (chaplotype.pyx:180-183 length rule), per-window read-tile shape
 //   k_tile_scan   exclusive scan of the per-window tile sizes
-//   k_prep_reads  one workgroup per window: reads re-laid out as a TRANSPOSED tile of pre-converted words
-//                 tile[w][i][rl] = (base<<9) | (4*qual)<<16  (row i = read position, column rl = read), with 8
-//                 pad rows ('0', 64*4: align.c:223-226) so the DP's 8 extra steps need no branch and a wave's
-//                 64 consecutive reads load 256 contiguous bytes per DP step; plus the rolling 7-mer codes of
-//                 every read (a5 hashReadForMapping, calign.pyx:155-165) and a per-read descriptor.
+//   k_prep_reads  one workgroup per (window, 64 reads): what EVERY read needs and nothing else -- its 2-bit base codes as
+//                 transposed bit planes (= the rolling 7-mer codes of a5 hashReadForMapping, calign.pyx:155-165) and a
+//                 descriptor (length, skip rule, mapq, plain-ACGT flag, quality sum / minimum / count below Q20).
+//                 (Rounds 1-2 also wrote a tile of pre-converted 4-byte DP words per base of every read; since the
+//                 seeding proofs only one pair in eight reaches the DP, which now builds its words from the bytes.)
 //   k_seed        one workgroup per haplotype: bytes staged in LDS, gap-open annotation (a7, chaplotype.pyx:552-590)
-//                 written as haplotype words (base<<9)|(4*gapopen)<<16, 7-mer index in LDS (a4, calign.pyx:94-124),
+//                 written as one byte per haplotype position, 7-mer index in LDS (a4, calign.pyx:94-124),
 //                 then one wave per read: diagonal vote (calign.pyx:206-220) with 16-bit LDS counters and the
 //                 arg-max candidate list in ascending order (calign.pyx:222-233) -> DP jobs
 //   k_dp_jobs     one lane per banded DP (a1, align.c:77-586), see dp_core.hpp
@@ -30,11 +30,11 @@ namespace plat {
 // with one global atomic per such pair.  (A single job counter bumped by every pair saturates one L2
 // atomic unit: ~90 atomics/us, i.e. ~20 ms for 2M pairs -- measured in round 1.)
 struct PairRec { int32_t extra_base, idx0; int16_t ncand, orig_k; uint8_t mapq, pad[3]; };   // ncand: -1 skipped, -2 read < 7 bp, -3 exact match (idx0 = read length), -4 ungapped alignment proven optimal (idx0 = read length, extra_base = score)
-struct Job { uint32_t col; int32_t hap, idx, len; };     // col = tile dword index of the read's column; len 0 = empty slot;
+struct Job { uint32_t col; int32_t hap, idx, len; };     // col = index of the read in the batch; len 0 = empty slot;
                                                          // hap bit 30 (JOB_BIGQ): the read's quality sum forbids the 32-bit SWAR adds
 constexpr int32_t JOB_BIGQ = 1 << 30;
 __device__ __forceinline__ int job_hap(const Job& j) { return j.hap & (JOB_BIGQ - 1); }
-// per-read descriptor: tile column, offset of the k-mer codes, mapping position, len | flags<<16 | mapq<<24
+// per-read descriptor: index of the read in the batch, mapping position, len | flags<<16 | mapq<<24
 // (flags bit0: skipped by the QCFail / overlap < 7 rule; bit1: the read holds a byte other than A, C, G, T;
 //  bit2: quality sum above DP_SWAR_MAX_QSUM -> its DPs use the packed 16-bit adds)
 struct ReadInfo { uint32_t col, aux; int32_t pos; uint32_t lfm; };      // aux bits 0..15: number of bases with quality < LOWQ (the ungapped proof)
@@ -189,7 +189,7 @@ constexpr int PREP_LMAX = 448;          // reads up to this length are staged th
 
 __global__ void __launch_bounds__(256)
 k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const long long* __restrict__ tile_off,
-             uint32_t* __restrict__ tile, uint16_t* __restrict__ codes, ReadInfo* __restrict__ rinfo, long long* cnt, int qoff)
+             uint16_t* __restrict__ codes, ReadInfo* __restrict__ rinfo, long long* cnt, int qoff)
 // qoff = byte offset of the quality image in the dynamic LDS (= 64 * min(longest read, PREP_LMAX) + 16); the bit-plane
 // accumulators of staged windows follow at 2 * qoff (1 KB per 64-base chunk).
 // `codes` holds, per window and in the tile's footprint (2 bytes per tile element), the reads' 2-bit base codes
@@ -215,14 +215,11 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     const int rows = win_rows[w];
     const long long toff = tile_off[w];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    if (toff + (long long)rows * R > 0xFFFFFFFFll) { if (tid == 0 && c0 == 0) set_err(cnt, PLAT_ERR_OVERFLOW); return; }
     const long long blob0 = b.read_off[rb + c0];
     const int nbytes = (int)(b.read_off[rb + c0 + nr] - blob0);
     const bool staged = rows - 8 <= PREP_LMAX;
     // the group's bytes are copied as ALIGNED dwords; the LDS image keeps the blob's misalignment (mis = blob0 & 3)
     const int misS = (int)((uintptr_t)(b.read_seq + blob0) & 3), misQ = (int)((uintptr_t)(b.read_qual + blob0) & 3);
-    unsigned char* lseq = psm + misS;
-    unsigned char* lqual = psm + qoff + misQ;
     if (tid <= nr) s_off[tid] = (int)(b.read_off[rb + c0 + tid] - blob0);
     {   // copy to LDS + 7-bit ASCII check (the DP packs bases as byte << 9 and qualities as 4*q in 16 bits).  Bytes before
         // blob0 / after the group inside the first / last dword belong to neighbouring reads (or the blob's slack).
@@ -260,28 +257,27 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
             const int ov = oe > os ? oe - os : -1;                       // chaplotype.pyx:103-115
             skip = (b.read_flags[r] & 512) || ov < 7;
         }
-        my_ri = ReadInfo{(uint32_t)(toff + c0 + tid), 0u, b.read_pos[r],
+        my_ri = ReadInfo{(uint32_t)r, 0u, b.read_pos[r],
                          (uint32_t)L | ((uint32_t)skip << 16) | ((uint32_t)b.read_mapq[r] << 24)};
     }
     __syncthreads();
     const unsigned char* gs = b.read_seq + blob0;
     const unsigned char* gq = b.read_qual + blob0;
-    // tile: a thread takes 4 consecutive rows i of one read rl; lanes run over rl, so every row store of a wave is
-    // contiguous.  e / nr by multiply-shift (exact for e < 16384, nr <= 64).
+    // a thread takes 4 consecutive bases of one read rl (lanes run over rl).  e / nr by multiply-shift (exact for e < 16384, nr <= 64).
     {
-        const int ngrp = (rows + 3) >> 2;
+        const int ngrp = (rows - 8 + 3) >> 2;            // groups of 4 bases of the window's longest read
         const int ne = ngrp * nr;
         const unsigned M = (1u << 22) / (unsigned)nr + 1u;
         for (int e = tid; e < ne; e += nthr) {
             const int g = ne <= 16384 ? (int)(((unsigned)e * M) >> 22) : e / nr;
             const int rl = e - g * nr;
             const int o = s_off[rl], L = s_off[rl + 1] - o;
-            uint32_t* tp = tile + toff + (long long)(4 * g) * R + c0 + rl;
+            if (4 * g >= L) continue;
             bool dirty = false;
             unsigned qs = 0, qm = 255u, n0 = 0, n1 = 0, nl = 0;
             if (staged) {
                 // the thread's 4 bases and 4 qualities as two dwords (unaligned reads of the LDS images), then 4 at a time
-                const int nval = min(max(L - 4 * g, 0), 4);
+                const int nval = min(L - 4 * g, 4);
                 const unsigned as_ = (unsigned)(misS + o + 4 * g), aq_ = (unsigned)(qoff + misQ + o + 4 * g);
                 const uint32_t* P = (const uint32_t*)psm;
                 const uint32_t keep = nval >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nval)) - 1u);
@@ -302,16 +298,10 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
                 qm = min(min(vqm & 0xFFu, (vqm >> 8) & 0xFFu), min((vqm >> 16) & 0xFFu, vqm >> 24));
                 // bytes >= LOWQ get bit 7 (7-bit qualities; the bytes past the read are 0xFF): the others are the low ones
                 nl = 4u - (unsigned)__popc((((vqm & 0x7F7F7F7Fu) + 0x01010101u * (128u - LOWQ)) | vqm) & 0x80808080u);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t wd = j < nval ? ((((vs >> (8 * j)) & 0x7Fu) << 9) | (((vq >> (8 * j)) & 0xFFu) << 18)) : READ_PAD_WORD;
-                    if (4 * g + j < rows) tp[(long long)j * R] = wd;
-                }
             } else
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = 4 * g + j;
-                uint32_t wd = READ_PAD_WORD;
                 if (i < L) {
                     const unsigned ch = gs[o + i];
                     const unsigned ql = gq[o + i];
@@ -321,17 +311,15 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
                     const unsigned b2 = base2(ch);
                     n0 |= (b2 & 1u) << j;
                     n1 |= (b2 >> 1) << j;
-                    wd = read_word(ch, ql);
                     const unsigned dch = ch - 65u;                               // 'A' 'C' 'G' 'T' = 65 + {0, 2, 6, 19}
                     dirty |= dch > 19u || !((0x80045u >> dch) & 1u);
                 }
-                if (i < rows) tp[(long long)j * R] = wd;
             }
             if (dirty) atomicOr(&s_dirty[rl >> 5], 1u << (rl & 31));
             if (qs) atomicAdd(&s_qsum[rl], qs);
             if (qm < s_qmin[rl]) atomicMin(&s_qmin[rl], qm);   // look first: most threads do not lower the minimum
             if (nl) atomicAdd(&s_nlow[rl], nl);
-            if (staged && 4 * g < rows - 8) {               // the 4 bases of this thread: 4 bits of each plane, inside one 32-bit half
+            if (staged) {                                   // the 4 bases of this thread: 4 bits of each plane, inside one 32-bit half
                 const int c = (4 * g) >> 6, half = ((4 * g) >> 5) & 1, sh = (4 * g) & 31;
                 if (n0) atomicOr(&s_pl[((c * 2 + 0) * 2 + half) * 64 + rl], n0 << sh);
                 if (n1) atomicOr(&s_pl[((c * 2 + 1) * 2 + half) * 64 + rl], n1 << sh);
@@ -574,9 +562,9 @@ __device__ __forceinline__ void seed_build_index(unsigned* table, unsigned short
 __global__ void __launch_bounds__(64)
 k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* __restrict__ win_rows,
        const long long* __restrict__ tile_off, const ReadInfo* __restrict__ rinfo,
-       const uint16_t* __restrict__ codes, uint32_t* __restrict__ hapw, uint8_t* __restrict__ hap_has_n,
+       const uint16_t* __restrict__ codes, uint8_t* __restrict__ gob, uint8_t* __restrict__ hap_has_n,
        PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
-       SlowRec* __restrict__ slow_list, int tsize_max, int maxhap, int shortcuts, const uint32_t* __restrict__ tile,
+       SlowRec* __restrict__ slow_list, int tsize_max, int maxhap, int shortcuts,
        int32_t* __restrict__ dense, long long segcap, const double* __restrict__ mapq_lut, double* __restrict__ out_ll,
        int32_t* __restrict__ out_score)
 {
@@ -670,7 +658,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
                 const u64 v = funnel(P0.me, P1.me, lane);
                 const int run = min(48, (int)__ffsll((long long)~v) - 1);     // trailing ones of v (v never has 64 ones beyond the cap)
                 const int go = s_go[run < 0 ? 48 : run];
-                if (p < hapLen && first_group) hapw[hoff + p] = hap_word(b0, (unsigned)go);
+                if (p < hapLen && first_group) gob[hoff + p] = (uint8_t)go;       // localGapOpen[p]: the DP builds its haplotype words from it
             }
             {   // multiplicity maps of the k-mers at positions 0..hapLen-8: "seen", "seen twice"; lanes past the last k-mer OR in nothing
                 const unsigned code = plane_code(P0.m0, P1.m0, P0.m1, P1.m1, lane);
@@ -1176,15 +1164,20 @@ __global__ void k_dense_total(long long* cnt, long long segcap)
 }
 
 // ------------------------------------------------------------------------------------------------
+// One DP from the caller's bytes: rs / rq = the read's bases and qualities, hs / gs = the haplotype's bases and gap-open penalties
+// at the slice start (calign.pyx:229,256).  Rows past the read's end are the reference's pads ('0', 64: align.c:223-226); the last
+// extra step reads one haplotype position past the slice (a lane that never reaches the result, dp_core.hpp).
 template <bool HAS_N, bool SWAR, bool UNPACKED>
-__device__ __forceinline__ int dp_tile(const uint32_t* __restrict__ rp, int stride, const uint32_t* __restrict__ hp, int len2)
+__device__ __forceinline__ int dp_job(const uint8_t* __restrict__ rs, const uint8_t* __restrict__ rq, const uint8_t* __restrict__ hs,
+                                      const uint8_t* __restrict__ gs, int len2)
 {
     uint32_t w0[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) w0[k] = hp[k];
-    hp += 8;
-    auto rw = [&](int h) -> uint32_t { return rp[(long long)h * stride]; };
-    auto hw = [&](int h) -> uint32_t { return hp[h]; };
+    words_of_8(load_u64_unaligned(hs), load_u64_unaligned(gs), w0);
+    hs += 8; gs += 8;
+    auto rw = [&](int h) -> uint32_t { return h < len2 ? read_word(rs[h], rq[h]) : READ_PAD_WORD; };
+    auto hw = [&](int h) -> uint32_t { return hap_word(hs[h], gs[h]); };
+    auto rw8 = [&](int h) -> Raw8 { return Raw8{load_u64_unaligned(rs + h), load_u64_unaligned(rq + h)}; };
+    auto hw8 = [&](int h) -> Raw8 { return Raw8{load_u64_unaligned(hs + h), load_u64_unaligned(gs + h)}; };
     if (UNPACKED) {
         DPU<HAS_N> dp;
         dp.init(w0);                                                         // gapextend 3, nucprior 2: chaplotype.pyx:607-608
@@ -1192,7 +1185,9 @@ __device__ __forceinline__ int dp_tile(const uint32_t* __restrict__ rp, int stri
     } else {
         DP<HAS_N, SWAR> dp;
         dp.init(w0, 3, 2);
-        return dp_run<HAS_N, SWAR>(dp, len2, rw, hw);
+        auto rw16 = [&](int h) -> Raw16 { Raw16 x; load_16_unaligned(rs + h, x.a0, x.a1); load_16_unaligned(rq + h, x.b0, x.b1); return x; };
+        auto hw16 = [&](int h) -> Raw16 { Raw16 x; load_16_unaligned(hs + h, x.a0, x.a1); load_16_unaligned(gs + h, x.b0, x.b1); return x; };
+        return dp_run8<HAS_N, SWAR>(dp, len2, rw, hw, rw8, hw8, rw16, hw16);
     }
 }
 
@@ -1203,8 +1198,7 @@ __device__ __forceinline__ int dp_tile(const uint32_t* __restrict__ rp, int stri
 // leaves free let the latency-bound kernels of ANOTHER batch (other plat_ctx / stream) run next to it (bench.py --streams).
 template <bool UNPACKED>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32_t* __restrict__ tile,
-          const uint32_t* __restrict__ hapw, const uint8_t* __restrict__ hap_has_n, const Job* __restrict__ jobs,
+k_dp_jobs(plat_window_batch b, const uint8_t* __restrict__ gob, const uint8_t* __restrict__ hap_has_n, const Job* __restrict__ jobs,
           const PairRec* __restrict__ pairs, const double* __restrict__ mapq_lut, long long npairs,
           const int32_t* __restrict__ dense, long long segcap, const long long* __restrict__ cnt, long long extra_cap,
           int32_t* __restrict__ job_score, double* __restrict__ out_ll, int32_t* __restrict__ out_score)
@@ -1220,27 +1214,30 @@ k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32
         const long long j = active ? dense_slot(dense, segcap, cnt, t) : 0;
         Job jb = Job{0, 0, 0, 0};
         if (active) jb = jobs[j];
-        int has_n = 0, stride = 0;
+        int has_n = 0;
         const int hap = job_hap(jb);
         const int bigq = active && (jb.hap & JOB_BIGQ) != 0;
+        const int st = max(0, jb.idx - 8);                                       // calign.pyx:229,256
+        long long hoff = 0, roff = 0;
         if (active) {
             has_n = hap_has_n[hap];
-            const int w = hap_win[hap];
-            stride = b.win_read_begin[w + 1] - b.win_read_begin[w];
+            hoff = b.hap_off[hap] + st;
+            roff = b.read_off[jb.col];
         }
-        const int st = max(0, jb.idx - 8);                                       // calign.pyx:229,256
-        const uint32_t* hp = hapw + (active ? b.hap_off[hap] + st : 0);
-        const uint32_t* rp = tile + jb.col;
+        const uint8_t* hs = b.hap_seq + hoff;
+        const uint8_t* gs = gob + hoff;
+        const uint8_t* rs = b.read_seq + roff;
+        const uint8_t* rq = b.read_qual + roff;
         int sc = 0;
         // wave-uniform choice of the code path: haplotype N's need the extra mask; the 32-bit SWAR adds are only taken when
         // every read of the wave has a quality sum that rules out a carry between the packed halves (dp_core.hpp)
         const bool anyN = __any(has_n), anyBig = UNPACKED || __any(bigq);
         if (anyN) {
-            if (anyBig) { if (active) sc = dp_tile<true, false, UNPACKED>(rp, stride, hp, jb.len); }
-            else        { if (active) sc = dp_tile<true, true, UNPACKED>(rp, stride, hp, jb.len); }
+            if (anyBig) { if (active) sc = dp_job<true, false, UNPACKED>(rs, rq, hs, gs, jb.len); }
+            else        { if (active) sc = dp_job<true, true, UNPACKED>(rs, rq, hs, gs, jb.len); }
         } else {
-            if (anyBig) { if (active) sc = dp_tile<false, false, UNPACKED>(rp, stride, hp, jb.len); }
-            else        { if (active) sc = dp_tile<false, true, UNPACKED>(rp, stride, hp, jb.len); }
+            if (anyBig) { if (active) sc = dp_job<false, false, UNPACKED>(rs, rq, hs, gs, jb.len); }
+            else        { if (active) sc = dp_job<false, true, UNPACKED>(rs, rq, hs, gs, jb.len); }
         }
         if (!active) continue;
         if (j >= npairs) { job_score[j] = sc; continue; }
@@ -1256,8 +1253,8 @@ k_dp_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32
 // reduced by the part of the alignment that lies in the haplotype's flanks (calign.pyx:235-245,261-264).  Jobs
 // [j0, j0+jn) of the list; bpbuf holds 2*(maxread+8) rows of `bstride` 64-bit back-pointer words.
 __global__ void __launch_bounds__(256)
-k_dp_tb_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint32_t* __restrict__ tile,
-             const uint32_t* __restrict__ hapw, const Job* __restrict__ jobs, const PairRec* __restrict__ pairs,
+k_dp_tb_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uint8_t* __restrict__ gob,
+             const Job* __restrict__ jobs, const PairRec* __restrict__ pairs,
              const double* __restrict__ mapq_lut, long long npairs, const int32_t* __restrict__ dense, long long segcap, long long j0, long long jn,
              const long long* __restrict__ cnt, long long extra_cap, unsigned long long* __restrict__ bpbuf, long long bstride, int32_t* __restrict__ job_score,
              double* __restrict__ out_ll, int32_t* __restrict__ out_score)
@@ -1272,22 +1269,27 @@ k_dp_tb_jobs(plat_window_batch b, const int32_t* __restrict__ hap_win, const uin
     {
         const int hap = job_hap(jb);
         const int w = hap_win[hap];
-        const long long stride = b.win_read_begin[w + 1] - b.win_read_begin[w];
         const long long hoff = b.hap_off[hap];
         const int hapLen = (int)(b.hap_off[hap + 1] - hoff), hapFlank = b.win_flank[w];
         const int st = max(0, jb.idx - 8);                                   // calign.pyx:229,256
-        const uint32_t* hfull = hapw + hoff;
-        const uint32_t* hp = hfull + st;
-        const uint32_t* rp = tile + jb.col;
+        const uint8_t* hfull = b.hap_seq + hoff;
+        const uint8_t* gfull = gob + hoff;
+        const uint8_t* rs = b.read_seq + b.read_off[jb.col];
+        const uint8_t* rq = b.read_qual + b.read_off[jb.col];
+        const int len2 = jb.len;
         uint32_t w0[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) w0[k] = hp[k];
-        auto rw = [&](int h) -> uint32_t { return rp[(long long)h * stride]; };
-        auto hw = [&](int h) -> uint32_t { return hp[8 + h]; };
+        for (int k = 0; k < 8; ++k) w0[k] = hap_word(hfull[st + k], gfull[st + k]);
+        auto rw = [&](int h) -> uint32_t { return h < len2 ? read_word(rs[h], rq[h]) : READ_PAD_WORD; };
+        auto hw = [&](int h) -> uint32_t { return hap_word(hfull[st + 8 + h], gfull[st + 8 + h]); };
         const TbView bp{bpbuf + t, (size_t)bstride};
         int midx;
-        sc = dp_forward_tb(w0, jb.len, rw, hw, bp, &midx);
-        if (sc > 0) sc -= tb_flank_score(bp, midx, jb.len, hfull, st, hapLen, hapFlank, rp, stride);
+        sc = dp_forward_tb(w0, len2, rw, hw, bp, &midx);
+        if (sc > 0) {
+            auto hwf = [&](int xg) -> uint32_t { return hap_word(hfull[xg], gfull[xg]); };      // any position of the whole haplotype
+            auto rwf = [&](int y) -> uint32_t { return read_word(rs[y], rq[y]); };
+            sc -= tb_flank_score(bp, midx, len2, hwf, st, hapLen, hapFlank, rwf);
+        }
     }
     if (j >= npairs) { job_score[j] = sc; return; }
     const PairRec pr = pairs[j];
@@ -1451,9 +1453,9 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     // one wave per workgroup (the lazy index build is wave-local); blockIdx.y = group of SEED_CHUNKS x 64 reads
     const int ngroups = (maxR + SEED_CHUNKS * 64 - 1) / (SEED_CHUNKS * 64);
     hipLaunchKernelGGL(k_seed, dim3(b.n_haps, ngroups > 0 ? ngroups : 1), dim3(64), lds, st, b, hap_win, win_rows, tile_off,
-                       (const ReadInfo*)ctx->rinfo.ptr, (const uint16_t*)ctx->codes.ptr, (uint32_t*)ctx->hapw.ptr,
+                       (const ReadInfo*)ctx->rinfo.ptr, (const uint16_t*)ctx->codes.ptr, (uint8_t*)ctx->hapw.ptr,
                        (uint8_t*)ctx->hap_flags.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
-                       (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, shortcuts, (const uint32_t*)ctx->tile.ptr, dense, segcap,
+                       (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, shortcuts, dense, segcap,
                        (const double*)ctx->d_mapq_lut, out_ll, out_score);
     PLAT_EV(ctx, 5, st);                                       // k_seed alone: ev[1] .. ev[5]
     hipLaunchKernelGGL(k_seed_slow, dim3(4096), dim3(64), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
@@ -1526,11 +1528,10 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         tile_total = (long long)(hv.max_read_len + 8) * b.n_reads + 4ll * b.n_windows;     // upper bound of k_tile_scan's total
     }
     const int maxhap = hv.max_hap_len, maxread = hv.max_read_len, maxR = hv.max_reads_per_window;
-    const long long hapblob = hv.hap_blob_len, npairs = hv.n_pairs, readblob = hv.read_blob_len;
+    const long long hapblob = hv.hap_blob_len, npairs = hv.n_pairs;
     if (npairs == 0) return PLAT_OK;
-    if (tile_total > 0xFFFFFFF0ll || readblob > 0xFFFFFFF0ll) return PLAT_ERR_OVERFLOW;   // split the batch: 32-bit tile/code offsets
-    if ((rc = plat_reserve(ctx, ctx->hapw, ((size_t)hapblob + 64) * 4))) return rc;
-    if ((rc = plat_reserve(ctx, ctx->tile, ((size_t)tile_total + 64) * 4))) return rc;
+    if (tile_total > 0x7FFFFFFFF0ll) return PLAT_ERR_OVERFLOW;
+    if ((rc = plat_reserve(ctx, ctx->hapw, (size_t)hapblob + 256))) return rc;           // one gap-open byte per haplotype position
     if ((rc = plat_reserve(ctx, ctx->codes, ((size_t)tile_total + 64) * 2))) return rc;
     if ((rc = plat_reserve(ctx, ctx->pair_rec, (size_t)npairs * sizeof(PairRec)))) return rc;
     if ((rc = plat_reserve(ctx, ctx->slow, (size_t)npairs * sizeof(SlowRec)))) return rc;
@@ -1545,7 +1546,7 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
     const size_t prep_lds = (size_t)2 * prep_qoff + (size_t)((std::min(maxread, PREP_LMAX) + 63) >> 6) * 1024;
     if (prep_lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_reads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
-    hipLaunchKernelGGL(k_prep_reads, dim3(b.n_windows, prep_groups), dim3(256), prep_lds, st, b, win_rows, tile_off, (uint32_t*)ctx->tile.ptr,
+    hipLaunchKernelGGL(k_prep_reads, dim3(b.n_windows, prep_groups), dim3(256), prep_lds, st, b, win_rows, tile_off,
                        (uint16_t*)ctx->codes.ptr, (ReadInfo*)ctx->rinfo.ptr, cnt, prep_qoff);
     long long njobs = 0;
     PLAT_EV(ctx, 1, st);
@@ -1602,7 +1603,7 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         for (long long j0 = 0; j0 < ngrid; j0 += slab) {
             const long long jn = ngrid - j0 < slab ? ngrid - j0 : slab;
             hipLaunchKernelGGL(k_dp_tb_jobs, dim3((unsigned)((jn + 255) / 256)), dim3(256), 0, st, b, hap_win,
-                               (const uint32_t*)ctx->tile.ptr, (const uint32_t*)ctx->hapw.ptr, (const Job*)ctx->jobs.ptr,
+                               (const uint8_t*)ctx->hapw.ptr, (const Job*)ctx->jobs.ptr,
                                (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, segcap, j0, jn, cnt, extra_cap,
                                (unsigned long long*)ctx->tb.ptr, slab, (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
         }
@@ -1613,13 +1614,13 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         const long long want = (ngrid + 255) / 256, fixed = 8ll * ctx->n_cu;
         const dim3 grid((unsigned)(want < fixed ? want : fixed));
         if (dp_impl)
-            hipLaunchKernelGGL(k_dp_jobs<true>, grid, dim3(256), 0, st, b, hap_win, (const uint32_t*)ctx->tile.ptr,
-                               (const uint32_t*)ctx->hapw.ptr, (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
+            hipLaunchKernelGGL(k_dp_jobs<true>, grid, dim3(256), 0, st, b, (const uint8_t*)ctx->hapw.ptr,
+                               (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
                                (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, segcap, cnt, extra_cap,
                                (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
         else
-            hipLaunchKernelGGL(k_dp_jobs<false>, grid, dim3(256), 0, st, b, hap_win, (const uint32_t*)ctx->tile.ptr,
-                               (const uint32_t*)ctx->hapw.ptr, (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
+            hipLaunchKernelGGL(k_dp_jobs<false>, grid, dim3(256), 0, st, b, (const uint8_t*)ctx->hapw.ptr,
+                               (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
                                (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, segcap, cnt, extra_cap,
                                (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
     }
