@@ -191,6 +191,15 @@ def config5(n_windows=2000, n_ind=100, seed=5005):
     return make_snp_windows(n_windows, seed, read_len=150, depth=30, n_ind=n_ind, hap_freq_beta=(0.5, 2.0))
 
 
+def config5_weak_evidence(n_windows=200, n_ind=100, seed=5105, depth=1, lowq_frac=0.8, err=2e-2):
+    """Config 5's geometry with WEAK evidence: 100 samples at `depth`x (1x: a read or two per sample and window), four fifths of the
+    bases below Q20, 2 % substitution errors.  At 30x the
+    genotype likelihoods are so peaked that the EM of Population.call (cpopulation.pyx:384-457) stops after two iterations; here a
+    sample's likelihoods barely separate its genotypes, the haplotype frequencies have to be learned from the whole population and
+    the EM runs for tens of iterations: the workload that measures the EM kernel doing work."""
+    return make_snp_windows(n_windows, seed, read_len=150, depth=depth, n_ind=n_ind, hap_freq_beta=(0.5, 2.0), lowq_frac=lowq_frac, err=err)
+
+
 # ---- BASELINE config 4: regions with reads, for the region pipeline (candidates -> windows -> records) ---------------------
 
 def _read_with_cigar(ref, p0, L, carried):

@@ -124,6 +124,30 @@ def test_population_path_end_to_end_vs_oracle(eng, oracle):
         assert np.array_equal(e[live], em[hb.gl_off[w]:hb.gl_off[w] + hb.n_ind * G].reshape(hb.n_ind, G)[live])
 
 
+def test_em_iterates_on_weak_evidence_and_matches_the_oracle(eng, oracle):
+    """100 samples at 1x with mostly low-quality bases: the EM (cpopulation.pyx:384-457) needs tens of iterations instead of the two of the 30x workloads; frequencies,
+    EM likelihoods, calls and iteration counts of k_em_wide against the oracle's EM on the device's own genotype likelihoods."""
+    hb = synth.config5_weak_evidence(40, 100)
+    db = eng.upload(hb)
+    eng.call_windows(db, want_stats=False)
+    eng.em(db, 100, 0)
+    eng.synchronize()
+    gl = db.gl.cpu().numpy()
+    freq, em = db.freq.cpu().numpy(), db.em.cpu().numpy()
+    calls, iters = db.calls.cpu().numpy().reshape(hb.n_windows, hb.n_ind), db.em_iters.cpu().numpy()
+    assert iters.mean() >= 10 and iters.max() >= 20, (iters.mean(), iters.max())
+    for w in range(hb.n_windows):
+        H = hb.win_hap_begin[w + 1] - hb.win_hap_begin[w]
+        G = H * (H + 1) // 2
+        nr = hb.seg_n_good[w * hb.n_ind:(w + 1) * hb.n_ind]
+        rows = gl[hb.gl_off[w]:hb.gl_off[w] + hb.n_ind * G].reshape(hb.n_ind, G)
+        f, e, c, it, mc = oracle.em_call(nr, rows, 100, 0)
+        assert it == iters[w] and np.array_equal(f, freq[hb.win_hap_begin[w]:hb.win_hap_begin[w + 1]])
+        assert c.tolist() == calls[w].tolist()
+        live = np.asarray(nr) > 0
+        assert np.array_equal(e[live], em[hb.gl_off[w]:hb.gl_off[w] + hb.n_ind * G].reshape(hb.n_ind, G)[live])
+
+
 def test_em_wide_kernel_equals_the_one_wave_kernel(eng, monkeypatch):
     """k_em_wide (likelihoods, responsibilities and the M-step's term streams in LDS) against k_em (one wave per window; PLAT_EM_NARROW=1)
     on the same likelihoods: frequencies, EM likelihoods, calls and iteration counts bit for bit -- with and without useEMLikelihoods,

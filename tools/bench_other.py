@@ -51,10 +51,10 @@ def _time_steps(torch, fn, nsteps, rk=None):
 
 # ---- config 5 -----------------------------------------------------------------------------------------------------------------
 
-def config5(eng, n_windows, n_ind, steps, warmup, seed=5005, rk=None):
+def config5(eng, n_windows, n_ind, steps, warmup, seed=5005, rk=None, weak=False):
     import torch
     from platypus_amd import synth
-    hb = synth.config5(n_windows, n_ind, seed=seed)
+    hb = synth.config5_weak_evidence(n_windows, n_ind, seed=seed + 100) if weak else synth.config5(n_windows, n_ind, seed=seed)
     db = eng.upload(hb)
     st = eng.call_windows(db, want_stats=True)
     eng.em(db, 100, 0)
@@ -270,20 +270,44 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
     return line
 
 
+def _roof(kernel, alg_bytes, ms, note=None):
+    ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    d = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+         "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": ms}
+    if note:
+        d["note"] = note
+    return d
+
+
 def summary(eng):
-    """Compact figures of configs 3 and 5 for the default line (a few seconds each)."""
+    """Configs 3, 4 and 5 at their SURVEY 8(d) sizes for the default line, each with the roofline entry of its dominant kernel."""
     out = {}
+    # config 5: 2 000 windows x 100 samples, as 10 distinct batches of 200 windows (one batch per step)
     r = config5(eng, 200, 100, 10, 2)
     st, hb = r["st"], r["hb"]
-    out["config5_population"] = dict(windows=hb.n_windows, n_ind=hb.n_ind, reads=hb.n_reads, pairs=int(st.n_pairs),
+    out["config5_population"] = dict(windows_per_step=hb.n_windows, steps=r["steps"], n_ind=hb.n_ind, reads=hb.n_reads, pairs=int(st.n_pairs),
                                      ms_per_step=1e3 * r["T"] / r["steps"], gcups=st.cells_reference * r["steps"] / r["T"] / 1e9,
                                      gcups_executed=st.cells_launched * r["steps"] / r["T"] / 1e9,
                                      windows_per_sec=hb.n_windows * r["steps"] / r["T"], kernel_ms=r["kernel_ms"],
-                                     em_iterations_mean=r["em_iterations_mean"])
-    r = config3(eng, 500, 5, 1)
-    out["config3_assembler"] = dict(regions=500, reads=int(r["ab"]["n_reads"]), regions_per_sec=500 * r["steps"] / r["T"],
-                                    kernel_ms=r["kernel_ms"], hbm_frac=r["alg_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                    variants_found=r["variants"], variants_planted=r["planted"])
+                                     em_iterations_mean=r["em_iterations_mean"],
+                                     roofline=_roof("k_dp_jobs", r["dp_alg_bytes"], r["kernel_ms"]["dp"], "VALU-issue bound, see DESIGN.md"))
+    # the same geometry with weak evidence (1x, mostly low-quality bases): the EM iterates
+    r = config5(eng, 200, 100, 10, 2, weak=True)
+    st, hb = r["st"], r["hb"]
+    G = np.diff(hb.win_hap_begin).astype(np.int64)
+    em_bytes = int(8 * hb.n_ind * (G * (G + 1) // 2).sum() * 2 + 8 * G.sum() + 4 * hb.n_ind * hb.n_windows)   # likelihoods in, EM likelihoods + frequencies + calls out
+    out["config5_weak_evidence"] = dict(windows_per_step=hb.n_windows, n_ind=hb.n_ind, reads=hb.n_reads, pairs=int(st.n_pairs),
+                                        ms_per_step=1e3 * r["T"] / r["steps"], windows_per_sec=hb.n_windows * r["steps"] / r["T"],
+                                        kernel_ms=r["kernel_ms"], em_iterations_mean=r["em_iterations_mean"], em_iterations_max=r["em_iterations_max"],
+                                        what="100 samples at 1x, four fifths of the bases below Q20: the EM of Population.call runs for tens of iterations",
+                                        roofline=_roof("k_em_wide", em_bytes, r["kernel_ms"]["em"], "latency bound: a chain of dependent fp64 sums per iteration"))
+    nt = 2000
+    r = config3(eng, nt, 5, 1)
+    e2e = {k: v for k, v in config3_end_to_end(0, nt).items() if k != "text"}
+    out["config3_assembler"] = dict(regions=nt, reads=int(r["ab"]["n_reads"]), regions_per_sec=nt * r["steps"] / r["T"],
+                                    kernel_ms=r["kernel_ms"], variants_found=r["variants"], variants_planted=r["planted"],
+                                    roofline=_roof("k_assemble", r["alg_bytes"], r["kernel_ms"], "latency bound at 4 waves per SIMD, see DESIGN.md"),
+                                    end_to_end=e2e)
     nreg = int(os.environ.get("PLAT_BENCH_CONFIG4_REGIONS", "3875"))           # one GPU's share of the 31 000 regions (SURVEY 8(d) cfg 4)
     r = config4(0, range(nreg), 100000, int(os.environ.get("PLAT_CALLER_WORKERS", "16")), int(os.environ.get("PLAT_CALLER_CHUNK", "4")), repeats=1)
     st = r["stats"]
