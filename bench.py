@@ -434,6 +434,11 @@ def main():
             except Exception:
                 pm = {}
 
+        # the PMC figures are NOT collected by this run (counters need rocprofv3 around the process): they are the last committed pass
+        meas = pm.get("measured") or {}
+        traffic_source = None if not pm else "not measured in this run: profiles/dp_traffic.json <- %s; collected %s at commit %s (tools/profile_round3.sh)" % (
+            pm.get("source", "rocprofv3 --pmc passes"), meas.get("date", "in round %s" % pm.get("round", "?")), meas.get("commit", "?"))
+
         def entry(kernel, alg_bytes, ms, counters, note):
             ach = alg_bytes / (ms * 1e-3) / 1e9
             sec = None
@@ -445,7 +450,7 @@ def main():
                        "busy_cycles_per_launch": counters["busy_cycles_per_launch"], "simds": 1024,
                        "cycles_per_inst_per_simd": cpi, "frac_of_half_rate_issue_peak": 4.2 / cpi}
             return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBPS, "traffic": counters.get("hbm_bytes_per_launch"),
+                    "frac": ach / HBM_PEAK_GBPS, "traffic": counters.get("hbm_bytes_per_launch"), "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": ms, "note": note, "secondary": sec}
         seedk_avg = float(np.mean(seedk_ms))
         # k_seed per launch: haplotype bytes in (1 B/base) + DP haplotype words out (4 B/base), read bit planes in (2 bits/base)
@@ -462,6 +467,7 @@ def main():
         line = {
             "metric": "pair-HMM GCUPS (reference-equivalent band cells/s, read->haplotype likelihood path)",
             "value": cells_ref / T / 1e9,
+            "value_is": "REFERENCE-EQUIVALENT (SURVEY 8(d)): cells of the DPs the reference would run / wall time; see gcups_executed and gcups_all_dp",
             "unit": "GCUPS",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -480,6 +486,16 @@ def main():
             "roofline": roof,
             "roofline_other": roof_other,
         }
+        # the honest pair of whole-step figures next to the per-kernel one: HBM traffic of ALL kernels of a step (PMC) and SURVEY 8(d)'s
+        # dedup'd algorithmic bytes per window (reads 2 L + 12, haplotypes 2 hapLen, 8 bytes per (haplotype, read) out), both over the
+        # pipelined step time
+        alg8d = 2 * int(hb.read_off[-1]) + 12 * hb.n_reads + 2 * int(hb.hap_off[-1]) + 8 * hb.n_pairs
+        line["algorithmic_bytes_8d_per_step"] = int(alg8d)
+        line["algorithmic_frac_8d"] = alg8d / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        if pm.get("step_hbm_bytes"):
+            line["step_traffic_bytes"] = int(pm["step_hbm_bytes"])
+            line["step_hbm_frac"] = pm["step_hbm_bytes"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            line["step_traffic_source"] = traffic_source
         line["record_gather"] = gather
         if world == 1 and not a.no_extras:
             # ---- the same batches with the shortcuts switched off (the library reads the switches per call)

@@ -14,6 +14,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import pmc_summary  # noqa: E402
 
 
+STATS_ONLY = ("plat::k_sum_job_cells", "plat::k_stats")     # launched only when the caller asks for statistics / the profile hooks are on
+
+
 def stats(dirname, out, title):
     paths = glob.glob(dirname + "/*/*_kernel_stats.csv")
     if not paths:
@@ -78,9 +81,10 @@ def main(o):
         d["source"] = "profiles/r03_pmc_hbm.txt (rocprofv3 --pmc, separate passes: FETCH_SIZE, WRITE_SIZE raw counters x 1024; SQ_INSTS_VALU; GRBM_GUI_ACTIVE / 8 XCDs)"
         d["k_seed"] = pack(per["plat::k_seed"])
         d["k_prep_reads"] = pack(per["plat::k_prep_reads"])
-        d["step_hbm_bytes"] = int(sum((v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 for k, v in per.items() if k.startswith("plat::") and v.get("launches", 0) >= 4))
-        d["step_kernels"] = {k: int((v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024) for k, v in per.items() if k.startswith("plat::") and v.get("launches", 0) >= 4}
+        d["step_hbm_bytes"] = int(sum((v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 for k, v in per.items() if k.startswith("plat::") and v.get("launches", 0) >= 4 and k not in STATS_ONLY))
+        d["step_kernels"] = {k: int((v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024) for k, v in per.items() if k.startswith("plat::") and v.get("launches", 0) >= 4 and k not in STATS_ONLY}
         d["measured"] = stamp
+        d["round"] = 3
     if per3 and "plat::k_assemble" in per3:
         d["k_assemble"] = pack(per3["plat::k_assemble"])
         d["k_assemble"]["regions_per_launch"] = 2000
