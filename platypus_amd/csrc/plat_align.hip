@@ -559,52 +559,18 @@ __device__ __forceinline__ void seed_build_index(unsigned* table, unsigned short
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(64)
-k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* __restrict__ win_rows,
-       const long long* __restrict__ tile_off, const ReadInfo* __restrict__ rinfo,
-       const uint16_t* __restrict__ codes, uint8_t* __restrict__ gob, uint8_t* __restrict__ hap_has_n,
-       PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
-       SlowRec* __restrict__ slow_list, int tsize_max, int maxhap, int shortcuts,
-       int32_t* __restrict__ dense, long long segcap, const double* __restrict__ mapq_lut, double* __restrict__ out_ll,
-       int32_t* __restrict__ out_score)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nw64 = ((maxhap + 63) >> 6) + 8;           // plane words incl. slack for the shifted window of a hypothesis
-    unsigned* table = (unsigned*)smem;
-    unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);      // tsize_max = carve size >= 1024 dwords: the multiplicity maps overlay the table
-    u64* h0 = (u64*)(smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 7 & ~(size_t)7));
-    u64* h1 = h0 + nw64;
-    u64* eqp = h1 + nw64;
-    u64* nup = eqp + nw64;
-    int* s_scal = (int*)(nup + nw64);                    // [0] has_n  [1] maxmult, then the gap-open table
+struct SeedPlanes { u64 m0, m1, me; };
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-    const int h = blockIdx.x;
-    if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
-    const int w = hap_win[h];
+// One single-wave workgroup sweeps one haplotype: planes, gap-open bytes, multiplicity maps, nu plane, per-chunk gap-open minima, flags.
+// Returns have_index (the counting table overflowed: the exact maximum came from the index, which then overwrote the maps).
+__device__ __forceinline__ bool seed_sweep(unsigned* table, unsigned short* nxt, u64* h0, u64* h1, u64* eqp, u64* nup, int* s_scal, int nw64,
+                                           const uint8_t* __restrict__ hs, int hapLen, long long hoff, bool first_group, uint8_t* __restrict__ gob,
+                                           long long* cnt, int shortcuts, bool direct, int tsize, unsigned tmask, int nch, bool& stop)
+{
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
-    {   // this workgroup's group of read chunks lies beyond the window's reads: nothing to do
-        const int Rw = b.win_read_begin[w + 1] - b.win_read_begin[w];
-        if (blockIdx.y > 0 && (int)blockIdx.y * SEED_CHUNKS * nw * 64 >= Rw) return;
-    }
-    const bool first_group = blockIdx.y == 0;            // writes the per-haplotype outputs (hapw, has_n)
-    const long long hoff = b.hap_off[h];
-    const int hapLen = (int)(b.hap_off[h + 1] - hoff);
-    const uint8_t* hs = b.hap_seq + hoff;
-
-    const bool direct = hapLen > 4096;
-    int tsize = 64;
-    if (direct) tsize = 16384;
-    else while (tsize < hapLen + hapLen / 4) tsize <<= 1;
-    const unsigned tmask = (unsigned)tsize - 1u;
-    const int nch = (hapLen + 63) >> 6;                  // chunks of 64 haplotype positions
-
-    // Setup, fast part: the proof of hypothesis A only needs the planes, nu and maxmult.  Multiplicities come from two
-    // 16384-bit maps over the 14-bit k-mer codes ("seen at least once / twice"), filled with one LDS atomicOr per k-mer,
-    // plus a 32-entry counting table for the few codes seen three times or more.  The maps overlay the k-mer index, which
-    // is only built (seed_build_index) when some pair of this workgroup needs a look-up: hypothesis B, the no-vote test,
-    // the exact vote, or more than 32 distinct codes of multiplicity >= 3.  (LDS per workgroup decides how many
-    // haplotypes a CU works on at once: 6 KB instead of 9.4 KB with a third map.)
+    stop = false;
     unsigned* seen1 = table;
     unsigned* seen2 = table + 512;
     if (tid < 3) s_scal[tid] = tid == 1;                 // has_n = 0, maxmult = 1, other-than-ACGTN = 0
@@ -627,7 +593,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         // (the loop is written without divergent branches: every `if` on a lane condition costs half a dozen scalar
         //  instructions of exec-mask bookkeeping, and this sweep had three scalar instructions for every vector one)
         auto ldb = [&](int t) -> unsigned { const int p = 64 * t + lane; return p < hapLen ? (unsigned)hs[p] : 0u; };
-        struct Planes { u64 m0, m1, me; };
+        typedef SeedPlanes Planes;
         u64 anyN = 0ull, anyOther = 0ull;                // wave-uniform: a byte 'N' / a byte other than A, C, G, T, N was seen
         unsigned accBits = 0u;                           // per lane: OR of its bytes (7-bit ASCII check after the loop)
         auto mk = [&](int t, unsigned c, unsigned cnext_chunk) -> Planes {
@@ -707,7 +673,7 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         s_gmin[t] = (unsigned char)s_go[longest];
     }
     __syncthreads();
-    if (shortcuts & 256) return;                         // (measurement only, PLAT_SEED_DEBUG: the haplotype sweep alone)
+    if (shortcuts & 256) { stop = true; return false; }  // (measurement only, PLAT_SEED_DEBUG: the haplotype sweep alone)
     if (lane < 32) level = max(level, trip[lane] ? 2 + (int)(trip[lane] >> 16) : 0);
 #pragma unroll
     for (int s2 = 32; s2 > 0; s2 >>= 1) level = max(level, __shfl_xor(level, s2));
@@ -733,6 +699,292 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         seed_build_index(table, nxt, h0, h1, nup, s_scal, hapLen, nch, direct, tsize, tmask, true);
         have_index = true;
     }
+    return have_index;
+}
+
+// ---- the haplotypes of a window share almost everything -----------------------------------------------------------------------
+// They are the window's reference sequence with a few variants applied, so sweeping each of them repeats most of the work.
+// k_seed_base sweeps the FIRST haplotype of every window once and leaves the result in global memory (per window, SEED_BASE_*
+// below: flags, the "seen at least once" map, the four planes, the per-chunk gap-open minima; its gap-open bytes are in `gob`).
+// k_seed then DERIVES a haplotype of the same length that differs from that base in at most SEED_MAXDIFF bases instead of sweeping it:
+// the base's planes, with the chunks the differing bases touch rebuilt; gap-open bytes recomputed within 48 positions of them; and a
+// CONSERVATIVE nu plane instead of multiplicity maps of its own:
+//   * a 7-mer that does not contain a differing base keeps the base's flag.  If it is unique in the base it is unique here as long as
+//     no new 7-mer equals it (checked: a new 7-mer whose code the base has seen at all sends the haplotype to the full sweep); if it is
+//     flagged in the base it stays flagged, even when the copies that made it so are among the <= 7 per difference that disappeared;
+//   * the <= 7 new 7-mers per differing base are unique (none is in the base, and they are checked against each other);
+//   * the largest multiplicity is at most the base's.
+// A flag too many only weakens the proofs (more votes granted to other diagonals, fewer unique windows): a pair may go to the DP that
+// a full sweep would have finished, never the other way round -- the scores are the same.  The base haplotype itself is "derived" with
+// no difference, i.e. loaded.
+constexpr int SEED_MAXDIFF = 8;
+constexpr int SEED_BASE_SCAL = 0, SEED_BASE_SEEN = 16, SEED_BASE_PLANES = 16 + 2048;      // byte offsets inside a window's record
+__host__ __device__ __forceinline__ size_t seed_base_stride(int maxhap) {
+    const size_t nw64 = (((size_t)maxhap + 63) >> 6) + 8;
+    return (size_t)SEED_BASE_PLANES + 32 * nw64 + ((nw64 + 15) & ~(size_t)15);
+}
+
+__device__ __forceinline__ SeedPlanes seed_chunk_planes(int t, unsigned c, unsigned cnext_chunk, int hapLen, int lane) {
+    const int p = 64 * t + lane;
+    unsigned cn = (unsigned)__shfl_down((int)c, 1);
+    const unsigned first_next = (unsigned)__shfl((int)cnext_chunk, 0);
+    cn = lane == 63 ? first_next : cn;
+    const unsigned b2 = base2(c);                                        // bytes past the end are 0 -> code 0
+    SeedPlanes P;
+    P.m0 = __ballot(p < hapLen && (b2 & 1u));
+    P.m1 = __ballot(p < hapLen && (b2 & 2u));
+    P.me = __ballot(p + 1 < hapLen && c == cn && c != (unsigned)'N');
+    return P;
+}
+
+// Returns false when the haplotype has to be swept in full.  base: the window's record; hb / gob_base: the base haplotype's bytes and
+// gap-open bytes; table .. s_gmin: this workgroup's LDS working set (as seed_sweep leaves it); write_gob: store the gap-open bytes.
+__device__ __forceinline__ bool seed_derive(const unsigned char* __restrict__ base, const uint8_t* __restrict__ hb, const uint8_t* __restrict__ gob_base,
+                                            unsigned* table, u64* h0, u64* h1, u64* eqp, u64* nup, int* s_scal, unsigned char* s_gmin, int nw64,
+                                            const uint8_t* __restrict__ hs, int hapLen, bool is_base, bool write_gob, uint8_t* __restrict__ gob,
+                                            long long* cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const int nch = (hapLen + 63) >> 6;                  // <= 64: haplotypes up to 4096 bases are derived
+    const int* bscal = (const int*)(base + SEED_BASE_SCAL);
+    const unsigned* bseen = (const unsigned*)(base + SEED_BASE_SEEN);
+    const u64* bplanes = (const u64*)(base + SEED_BASE_PLANES);
+    const unsigned char* bgmin = base + SEED_BASE_PLANES + 32 * (size_t)nw64;
+    signed char* s_go = (signed char*)(s_scal + 4);
+    auto ldb = [&](int t) -> unsigned { const int p = 64 * t + lane; return p < hapLen ? (unsigned)hs[p] : 0u; };
+    auto ld4 = [&](const uint8_t* q) -> uint32_t { uint32_t v; __builtin_memcpy(&v, q, 4); return v; };
+    // (everything that does not depend on the differences is requested first: the base's planes, minima and flags)
+    u64 pl[2];
+    pl[0] = lane < 4 * nw64 ? bplanes[lane] : 0ull;
+    pl[1] = lane + 64 < 4 * nw64 ? bplanes[lane + 64] : 0ull;
+    const unsigned char gm0 = lane < nch ? bgmin[lane] : (unsigned char)0;
+    const int bs0 = bscal[0], bs1 = bscal[1], bs2 = bscal[2];
+    // a. where it differs from the base, four bases per lane and trip (blobs are followed by PLAT_BLOB_PAD readable bytes); lane j gets
+    // the position of the j-th differing base
+    int ndiff = 0, mypos = -1;
+    uint32_t acc = 0u;
+    if (!is_base)
+        for (int o0 = 0; o0 < hapLen; o0 += 1024) {      // four trips' loads in flight
+            uint32_t xa[4], xd[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int o = o0 + 256 * k + 4 * lane;
+                const bool in = o < hapLen;
+                const uint32_t va = in ? ld4(hs + o) : 0u, vb = in ? ld4(hb + o) : 0u;
+                const int nv = hapLen - o;                // bytes of this dword inside the haplotype
+                const uint32_t keep = nv >= 4 ? 0xFFFFFFFFu : (nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u));
+                xa[k] = va & keep; xd[k] = (va ^ vb) & keep;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc |= xa[k];
+                u64 m = __ballot(xd[k] != 0u);
+                while (m) {                              // (wave-uniform; a handful of trips in the whole haplotype)
+                    const int L = (int)__ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    const uint32_t x = (uint32_t)__shfl((int)xd[k], L);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((x >> (8 * q)) & 0xFFu) {
+                            if (lane == ndiff) mypos = o0 + 256 * k + 4 * L + q;
+                            ++ndiff;
+                        }
+                    if (ndiff > SEED_MAXDIFF) return false;
+                }
+            }
+        }
+    if (acc & 0x80808080u) set_err(cnt, PLAT_ERR_BAD_INPUT);               // 7-bit ASCII only (the DP packs bases as byte << 9)
+    bool newN = false, newOther = false;
+    if (ndiff) {
+        const unsigned a = (lane < ndiff) ? (unsigned)hs[mypos] : (unsigned)'A';
+        newN = __any(a == (unsigned)'N');
+        newOther = __any(a != 'A' && a != 'C' && a != 'G' && a != 'T' && a != 'N');
+    }
+    // b. the base's planes (h0, h1, eq, nu are contiguous), the gap-open table
+    if (lane < 4 * nw64) h0[lane] = pl[0];
+    if (lane + 64 < 4 * nw64) h0[lane + 64] = pl[1];
+    for (int i = lane + 128; i < 4 * nw64; i += 64) h0[i] = bplanes[i];
+    if (lane < 49) s_go[lane] = c_homopol_go[lane];
+    wave_sync();
+    // c. plane words that change: the chunk of a differing base, and the chunk before it when the base is its first (eq looks one base
+    // ahead); gap-open bytes that may change: the 48 positions in front of a changed run bit
+    u64 redo = 0ull, godirty = 0ull;
+    for (int j = 0; j < ndiff; ++j) {
+        const int p = __shfl(mypos, j);
+        redo |= 1ull << (p >> 6);
+        if (p > 0) redo |= 1ull << ((p - 1) >> 6);
+        for (int t = max(p - 49, 0) >> 6; t <= (p >> 6); ++t) godirty |= 1ull << t;
+    }
+    for (u64 m = redo; m; m &= m - 1ull) {
+        const int t = (int)__ffsll((long long)m) - 1;
+        const SeedPlanes Q = seed_chunk_planes(t, ldb(t), ldb(t + 1), hapLen, lane);
+        const u64 val = lane == 0 ? Q.m0 : (lane == 1 ? Q.m1 : Q.me);
+        if (lane < 3) h0[lane * nw64 + t] = val;
+    }
+    wave_sync();
+    // d. gap-open bytes (a7): the base's, four at a time; then the chunks marked above recomputed from the run plane
+    if (write_gob) {
+        for (int o = 4 * lane; o < hapLen; o += 256) {
+            const uint32_t v = ld4(gob_base + o);
+            if (o + 4 <= hapLen) __builtin_memcpy(gob + o, &v, 4);
+            else for (int q = 0; o + q < hapLen; ++q) gob[o + q] = (uint8_t)(v >> (8 * q));
+        }
+        for (u64 m = godirty; m; m &= m - 1ull) {
+            const int t = (int)__ffsll((long long)m) - 1, p = 64 * t + lane;
+            const u64 v = funnel(eqp[t], eqp[t + 1], lane);
+            const int run = min(48, (int)__ffsll((long long)~v) - 1);
+            if (p < hapLen) gob[p] = (uint8_t)s_go[run < 0 ? 48 : run];
+        }
+    }
+    for (int t = lane; t < nch; t += 64) {               // per-chunk minima: the base's, recomputed where a run may have changed
+        unsigned char gm = t < 64 ? gm0 : bgmin[t];
+        if ((godirty >> t) & 1ull) {
+            const u64 e0 = eqp[t], e1 = eqp[t + 1];
+            const int nvalid = min(64, hapLen - 64 * t);
+            u64 left = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+            int longest = 0;
+            while (longest < 48) {
+                left &= funnel(e0, e1, longest);
+                if (left == 0ull) break;
+                ++longest;
+            }
+            gm = (unsigned char)s_go[longest];
+        }
+        s_gmin[t] = gm;
+    }
+    // e. the 7-mers that contain a differing base are new: none of them may be a code the base has seen, nor equal another new one
+    int prev = -1;
+    for (int j = 0; j < ndiff; ++j) {
+        const int p = __shfl(mypos, j);
+        const int sidx = p - 6 + lane;                   // lanes 0..6: the 7-mers starting at p-6 .. p (those not taken by the difference before)
+        const bool valid = lane < 7 && sidx >= 0 && sidx > prev && sidx < hapLen - 7;
+        unsigned code = 0xFFFFFFFFu;
+        if (valid) { const int t = sidx >> 6; code = plane_code(h0[t], h0[t + 1], h1[t], h1[t + 1], sidx & 63); }
+        if (lane < 7) table[7 * j + lane] = code;        // (the index area is free: no index of this haplotype exists yet)
+        if (valid) atomicAnd(&((unsigned*)nup)[sidx >> 5], ~(1u << (sidx & 31)));
+        prev = p;
+    }
+    wave_sync();
+    const int n = 7 * ndiff;
+    const unsigned mycode = lane < n ? table[lane] : 0xFFFFFFFFu;
+    const bool hit = mycode != 0xFFFFFFFFu && ((bseen[mycode >> 5] >> (mycode & 31u)) & 1u);      // the base's "seen at least once" map: one look-up per lane
+    if (__any(hit)) return false;
+    for (int j = 0; j < n; ++j) {
+        const unsigned cj = table[j];
+        if (cj != 0xFFFFFFFFu && __any(lane != j && mycode == cj)) return false;
+    }
+    // f. flags: N / other bytes may only have been added (a flag too many sends pairs to the DP's general path, nothing else)
+    if (lane == 0) { s_scal[0] = bs0 | (newN ? 1 : 0); s_scal[1] = bs1; s_scal[2] = bs2 | (newOther ? 1 : 0); }
+    wave_sync();
+    return true;
+}
+
+// One single-wave workgroup per window: the full sweep of the window's first haplotype (its gap-open bytes and has_n flag are final),
+// left in the window's record for k_seed.  ok = 0 when nothing can be derived from it (counting table overflowed: the index overwrote
+// the maps; haplotype shorter than 16 bases).
+__global__ void __launch_bounds__(64)
+k_seed_base(plat_window_batch b, uint8_t* __restrict__ gob, uint8_t* __restrict__ hap_has_n, long long* cnt, unsigned char* __restrict__ basebuf,
+            int tsize_max, int maxhap, int shortcuts)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nw64 = ((maxhap + 63) >> 6) + 8;
+    unsigned* table = (unsigned*)smem;
+    unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);
+    u64* h0 = (u64*)(smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 7 & ~(size_t)7));
+    u64* h1 = h0 + nw64;
+    u64* eqp = h1 + nw64;
+    u64* nup = eqp + nw64;
+    int* s_scal = (int*)(nup + nw64);
+    unsigned char* s_gmin = (unsigned char*)((unsigned*)(s_scal + 4 + 16) + 32);
+    if (cnt[CNT_ERR] != 0) return;
+    const int w = blockIdx.x, lane = threadIdx.x;
+    unsigned char* rec = basebuf + (size_t)w * seed_base_stride(maxhap);
+    const int h = b.win_hap_begin[w];
+    if (b.win_hap_begin[w + 1] <= h) return;
+    const long long hoff = b.hap_off[h];
+    const int hapLen = (int)(b.hap_off[h + 1] - hoff);
+    const bool direct = hapLen > 4096;
+    int tsize = 64;
+    if (direct) tsize = 16384;
+    else while (tsize < hapLen + hapLen / 4) tsize <<= 1;
+    const unsigned tmask = (unsigned)tsize - 1u;
+    const int nch = (hapLen + 63) >> 6;
+    bool stop = false;
+    const bool have_index = seed_sweep(table, nxt, h0, h1, eqp, nup, s_scal, nw64, b.hap_seq + hoff, hapLen, hoff, true, gob, cnt, shortcuts, direct, tsize,
+                                       tmask, nch, stop);
+    const bool ok = !have_index && !stop && hapLen >= 16 && hapLen <= 4096;
+    if (lane == 0) {
+        hap_has_n[h] = (uint8_t)s_scal[0];
+        int* o = (int*)(rec + SEED_BASE_SCAL);
+        o[0] = s_scal[0]; o[1] = s_scal[1]; o[2] = s_scal[2]; o[3] = ok ? 1 : 0;
+    }
+    if (!ok) return;
+    unsigned* oseen = (unsigned*)(rec + SEED_BASE_SEEN);
+    for (int i = lane; i < 512; i += 64) oseen[i] = table[i];
+    u64* oplanes = (u64*)(rec + SEED_BASE_PLANES);
+    for (int i = lane; i < 4 * nw64; i += 64) oplanes[i] = h0[i];
+    unsigned char* ogmin = rec + SEED_BASE_PLANES + 32 * (size_t)nw64;
+    for (int t = lane; t < nch; t += 64) ogmin[t] = s_gmin[t];
+}
+
+__global__ void __launch_bounds__(64)
+k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* __restrict__ win_rows,
+       const long long* __restrict__ tile_off, const ReadInfo* __restrict__ rinfo,
+       const uint16_t* __restrict__ codes, uint8_t* __restrict__ gob, uint8_t* __restrict__ hap_has_n,
+       PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
+       SlowRec* __restrict__ slow_list, int tsize_max, int maxhap, int shortcuts,
+       int32_t* __restrict__ dense, long long segcap, const double* __restrict__ mapq_lut, double* __restrict__ out_ll,
+       int32_t* __restrict__ out_score, const unsigned char* __restrict__ basebuf)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nw64 = ((maxhap + 63) >> 6) + 8;           // plane words incl. slack for the shifted window of a hypothesis
+    unsigned* table = (unsigned*)smem;
+    unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);      // tsize_max = carve size >= 1024 dwords: the multiplicity maps overlay the table
+    u64* h0 = (u64*)(smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 7 & ~(size_t)7));
+    u64* h1 = h0 + nw64;
+    u64* eqp = h1 + nw64;
+    u64* nup = eqp + nw64;
+    int* s_scal = (int*)(nup + nw64);                    // [0] has_n  [1] maxmult, then the gap-open table
+
+    const int h = blockIdx.x;
+    if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
+    const int w = hap_win[h];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    {   // this workgroup's group of read chunks lies beyond the window's reads: nothing to do
+        const int Rw = b.win_read_begin[w + 1] - b.win_read_begin[w];
+        if (blockIdx.y > 0 && (int)blockIdx.y * SEED_CHUNKS * nw * 64 >= Rw) return;
+    }
+    const bool first_group = blockIdx.y == 0;            // writes the per-haplotype outputs (hapw, has_n)
+    const long long hoff = b.hap_off[h];
+    const int hapLen = (int)(b.hap_off[h + 1] - hoff);
+    const uint8_t* hs = b.hap_seq + hoff;
+
+    const bool direct = hapLen > 4096;
+    int tsize = 64;
+    if (direct) tsize = 16384;
+    else while (tsize < hapLen + hapLen / 4) tsize <<= 1;
+    const unsigned tmask = (unsigned)tsize - 1u;
+    const int nch = (hapLen + 63) >> 6;                  // chunks of 64 haplotype positions
+
+    // Setup, fast part: the proof of hypothesis A only needs the planes, nu and maxmult.  Multiplicities come from two
+    // 16384-bit maps over the 14-bit k-mer codes ("seen at least once / twice"), filled with one LDS atomicOr per k-mer,
+    // plus a 32-entry counting table for the few codes seen three times or more.  The maps overlay the k-mer index, which
+    // is only built (seed_build_index) when some pair of this workgroup needs a look-up: hypothesis B, the no-vote test,
+    // the exact vote, or more than 32 distinct codes of multiplicity >= 3.  (LDS per workgroup decides how many
+    // haplotypes a CU works on at once: 6 KB instead of 9.4 KB with a third map.)
+    unsigned char* s_gmin = (unsigned char*)((unsigned*)(s_scal + 4 + 16) + 32);     // [nw64] smallest gap-open penalty per chunk (seed_sweep)
+    bool stop = false, have_index = false, derived = false;
+    if (basebuf) {                                       // the window's first haplotype was swept by k_seed_base: derive this one from it if possible
+        const unsigned char* rec = basebuf + (size_t)w * seed_base_stride(maxhap);
+        const int hB = b.win_hap_begin[w];
+        const long long hoffB = b.hap_off[hB];
+        if (((const int*)(rec + SEED_BASE_SCAL))[3] != 0 && (int)(b.hap_off[hB + 1] - hoffB) == hapLen)
+            derived = seed_derive(rec, b.hap_seq + hoffB, gob + hoffB, table, h0, h1, eqp, nup, s_scal, s_gmin, nw64, hs, hapLen, h == hB,
+                                  first_group && h != hB, gob + hoff, cnt);
+    }
+    if (!derived) have_index = seed_sweep(table, nxt, h0, h1, eqp, nup, s_scal, nw64, hs, hapLen, hoff, first_group, gob, cnt, shortcuts, direct, tsize, tmask, nch, stop);
+    if (stop) return;
     if (tid == 0 && first_group) hap_has_n[h] = (uint8_t)s_scal[0];
     const int maxmult = s_scal[1];
     const bool hap_plain = s_scal[2] == 0;               // only A, C, G, T, N: equal 2-bit codes of plain read bases mean equal bytes or a haplotype N
@@ -1446,17 +1698,32 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     const size_t lds = lds0 + ((nw64 + 15) & ~(size_t)15);    // k_seed: + one byte per chunk of 64 positions (gap-open minima)
     const size_t lds_slow = lds0 + (size_t)cw * 2;
     if (lds_slow > 160 * 1024 || lds > 160 * 1024) return PLAT_ERR_HAP_TOO_LONG;
-    if (lds > 48 * 1024)
+    if (lds > 48 * 1024) {
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_seed_base, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (lds_slow > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_seed_slow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_slow));
+    // PLAT_SEED_SHARE=1: the windows' first haplotypes are swept once (k_seed_base) and the others derived from them where they can be.
+    // Built, verified and measured in round 3: a quarter fewer vector instructions in k_seed and the same time -- a wave's time is its
+    // chain of latencies, and deriving has as many round trips as sweeping; with k_seed_base's launch on top it is OFF by default.
+    const char* e_sh = getenv("PLAT_SEED_SHARE");          // (read per call)
+    const bool share = maxhap <= 4096 && !(shortcuts & 0x300) && e_sh && e_sh[0] == '1';
+    unsigned char* basebuf = nullptr;
+    if (share) {
+        int rcb = plat_reserve(ctx, ctx->seedbase, (size_t)b.n_windows * seed_base_stride(maxhap) + 64);
+        if (rcb) return rcb;
+        basebuf = (unsigned char*)ctx->seedbase.ptr;
+        hipLaunchKernelGGL(k_seed_base, dim3(b.n_windows), dim3(64), lds, st, b, (uint8_t*)ctx->hapw.ptr, (uint8_t*)ctx->hap_flags.ptr, cnt, basebuf,
+                           tsize_max, maxhap, shortcuts);
+    }
     // one wave per workgroup (the lazy index build is wave-local); blockIdx.y = group of SEED_CHUNKS x 64 reads
     const int ngroups = (maxR + SEED_CHUNKS * 64 - 1) / (SEED_CHUNKS * 64);
     hipLaunchKernelGGL(k_seed, dim3(b.n_haps, ngroups > 0 ? ngroups : 1), dim3(64), lds, st, b, hap_win, win_rows, tile_off,
                        (const ReadInfo*)ctx->rinfo.ptr, (const uint16_t*)ctx->codes.ptr, (uint8_t*)ctx->hapw.ptr,
                        (uint8_t*)ctx->hap_flags.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
                        (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, shortcuts, dense, segcap,
-                       (const double*)ctx->d_mapq_lut, out_ll, out_score);
+                       (const double*)ctx->d_mapq_lut, out_ll, out_score, (const unsigned char*)basebuf);
     PLAT_EV(ctx, 5, st);                                       // k_seed alone: ev[1] .. ev[5]
     hipLaunchKernelGGL(k_seed_slow, dim3(4096), dim3(64), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,

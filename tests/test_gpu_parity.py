@@ -741,3 +741,24 @@ dist.destroy_process_group()
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-1500:]
     assert "MERGED a,b,c" in r.stdout
+
+
+def test_haplotypes_derived_from_the_windows_first_one_give_the_same_scores(eng):
+    """PLAT_SEED_SHARE=1 (off by default): k_seed_base sweeps the first haplotype of every window once, k_seed derives the
+    window's other haplotypes from it (patched planes, conservative uniqueness flags) instead of sweeping them.  Scores and likelihoods
+    are those of the default path on config 2, the hard workload and the stress batches; only the number of DPs launched may grow."""
+    import os
+    from platypus_amd import synth
+    for hb in (synth.config2(1500, seed=9), synth.config2_hard(800, seed=11), _adversarial_batch(5), _adversarial_batch(6, gapped=True), synth.config5(8, 20)):
+        res = {}
+        for mode in ("0", "1"):
+            os.environ["PLAT_SEED_SHARE"] = mode
+            try:
+                db = eng.upload(hb)
+                st = eng.align(db, want_stats=True)
+                eng.synchronize()
+                res[mode] = (db.score.cpu().numpy()[:hb.n_pairs].copy(), db.loglik.cpu().numpy()[:hb.n_pairs].copy(), int(st.n_dp_launched), int(st.n_dp_reference))
+            finally:
+                os.environ.pop("PLAT_SEED_SHARE", None)
+        assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1], res["1"][1])
+        assert res["0"][3] == res["1"][3] and res["0"][2] <= res["1"][2] <= 1.02 * res["0"][2] + 50
