@@ -175,6 +175,26 @@ def rank_launch_command(n, argv, port=None):
             "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota (a container often shows every CPU of
+    the host and is granted a fraction: the round-3 GPU box shows 256 and grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def numa_cpus_of_device(torch, index):
     """CPUs of the NUMA node the GPU hangs off (sysfs), or None when the box does not say."""
     try:
@@ -237,7 +257,7 @@ class Ranks:
         self.dev_index = self.local % ndev if ndev else 0
         self.device = torch.device("cuda", self.dev_index) if ndev else torch.device("cpu")
         self.backend = None
-        self.cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        self.cpus = effective_cpus()
         if "RANK" in os.environ:                # under a launcher (also with one rank): a process group
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -249,7 +269,7 @@ class Ranks:
             else:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
             self.dist = dist
-            self.cpus = pin_rank_cpus(torch, self.rank, self.world, self.dev_index)
+            self.cpus = max(1, min(pin_rank_cpus(torch, self.rank, self.world, self.dev_index), effective_cpus() // max(1, self.world)))
         # tensors of the collectives live where the backend wants them
         self.coll_device = self.device if self.backend in (None, "nccl") else torch.device("cpu")
 

@@ -193,7 +193,13 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
     from tools.synth import source
     rk = rk or _Solo()
     indices = list(indices)
-    loaders = loaders or int(os.environ.get("PLAT_CALLER_LOADERS", str(max(2, min(12, workers)))))
+    if not loaders:
+        try:
+            from bench import effective_cpus
+            granted = effective_cpus()
+        except Exception:
+            granted = workers
+        loaders = int(os.environ.get("PLAT_CALLER_LOADERS", str(max(2, min(12, granted // 2)))))
     n_slots = per_chunk * (workers + 2) + loaders
     kw = dict(region_len=region_len, n_samples=n_samples, packed=packed, pin=pin, **(region_kw or {}))
     src = source.RegionSource(indices, n_slots, **kw)
@@ -237,7 +243,9 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
     rank, world = rk.rank, rk.world
     total = a.regions or 3875 * world
     mine = sharding.regions_for_rank(total, rank, world)
-    workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, getattr(rk, "cpus", 16))))))
+    cpus = getattr(rk, "cpus", 16)                                           # what the box grants this rank (cgroup quota / share of the node)
+    workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus)))))
+    os.environ.setdefault("PLAT_CALLER_LOADERS", str(max(2, min(12, cpus // 2))))
     per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "4"))
     pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1" and lib is None
     packed = os.environ.get("PLAT_CALLER_PACKED", "1") == "1"
@@ -262,7 +270,7 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
             "device_wait_seconds_per_region": st["seconds_device_wait"] / max(1, r["regions"]),
             "source_seconds_per_region": st["seconds_load"] / max(1, r["regions"]),
             "worker_seconds_waiting_for_the_source_per_region": st["seconds_source_wait"] / max(1, r["regions"]),
-            "host_input_bytes_per_region": inb / max(1.0, regs), "h2d_gbytes_per_sec": inb / T / 1e9, "input_blobs_pinned": pin,
+            "host_input_bytes_per_region": inb / max(1.0, regs), "h2d_gbytes_per_sec": inb / T / 1e9, "input_blobs_pinned": pin, "cpus_granted_to_this_rank": cpus,
             "stage_seconds_per_region": {k: v / max(1, r["regions"]) for k, v in st["seconds_stage"].items()},
             "record_gather": r["gather"], "python_region_loop_windows_per_sec_round1": 1100.0}
     if rank == 0:
