@@ -19,7 +19,7 @@ def main(lib=None):
     """lib: a libplat_caller.so handle to use instead of the product one (tests/soak/native_soak_fake.py passes its own)."""
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     t0 = time.time()
-    rounds = lines = windows = greedy = 0
+    rounds = lines = windows = greedy = tiles = refcalls = 0
     seed = 90000
     nc = {}
     while time.time() - t0 < budget:
@@ -51,6 +51,10 @@ def main(lib=None):
             work.append((r["chrom"], r["start"], r["end"], bufs))
         over = dict(maxVariants=[8, 3, 8, 12][seed % 4], mergeClusteredVariants=int(seed % 5 != 1), minPosterior=[5, 0, 5, 20][seed % 4],
                     countOnlyExactIndelMatches=seed % 2, filterVarsByCoverage=int(seed % 6 != 0), maxHaplotypes=[50, 50, 12][seed % 3])
+        if seed % 7 == 0:                                                     # round 3: the assembler, reference calls, packed read tables
+            over.update(assemble=1, assemblyRegionSize=[1500, 700][seed % 2], assembleBrokenPairs=seed % 3 == 0, getVariantsFromBAMs=int(seed % 21 != 0))
+        if seed % 9 == 0:
+            over.update(outputRefCalls=1, refCallBlockSize=[1000, 150, 37][seed % 3])
         py = io.StringIO()
         o1 = default_options(**over)
         windows += caller.callVariantsInRegions(work, fasta, o1, VCF(names), py)
@@ -58,7 +62,8 @@ def main(lib=None):
         if key not in nc:
             nc[key] = F.NativeCaller(0, key[0], key[1], lib=lib)
         o2 = default_options(**over)
-        txt = nc[key].call_regions([F.RegionReads.from_buffers(c, s, e, fasta, b) for c, s, e, b in work], names, o2)
+        txt = nc[key].call_regions([F.RegionReads.from_buffers(c, s, e, fasta, b, packed=bool(seed % 2)) for c, s, e, b in work], names, o2)
+        tiles += nc[key].stats["n_assembly_tiles"]; refcalls += nc[key].stats["n_refcall_records"]
         if txt != py.getvalue() or o1.rlen != o2.rlen:
             print("MISMATCH at seed", seed)
             a, b = py.getvalue().split("\n"), txt.split("\n")
@@ -70,7 +75,7 @@ def main(lib=None):
         lines += txt.count("\n")
         rounds += 1
         seed += 1
-    print(json.dumps(dict(tool="tools/native_soak.py", rounds=rounds, regions=3 * rounds, windows=windows, greedy_windows=greedy, record_lines=lines,
+    print(json.dumps(dict(tool="tools/native_soak.py", rounds=rounds, regions=3 * rounds, windows=windows, greedy_windows=greedy, record_lines=lines, assembly_tiles=tiles, refcall_lines=refcalls,
                           identical=True, seconds=round(time.time() - t0, 1), device="caller library handed in" if lib else "MI355X")))
 
 
