@@ -306,7 +306,7 @@ int plat_candidates_batch(plat_ctx* ctx, const plat_candidate_batch* batch, int 
  *           variantFilter.pyx:359-373 over ReadArray.countReadsCoveringRegion, cwindow.pyx:176-206)
  * for n_scans scans (a scan = the `reads` of one sample of one region) of a batch whose records plat_candidates_batch wrote:
  * the reads of scan g are [scan_read_begin[g], scan_read_begin[g+1]) (sorted by position; read_end = cAlignedRead.end),
- * scan_longest[g] = ReadArray.getLengthOfLongestRead().  Output per scan: out_n[2g] candidates that pass, unordered, 8 ints each at
+ * scan_longest[g] = ReadArray.getLengthOfLongestRead().  Output per scan (out_n[2g] counts only when out_n[2g+1] == 0): out_n[2g] candidates that pass, unordered, 8 ints each at
  * out_cand[8*(g*cap_per_scan + i)]: {id of the first record with this content (read index * max_per_read + k: sort by it for
  * the dictionary's order), reads showing it, reads covering its position, then the record's five fields}.  out_n[2g+1] = 0,
  * PLAT_ERR_BAD_INPUT (a read outside its reference window, or read pointers out of order: the reference raises),

@@ -152,16 +152,15 @@ __device__ __forceinline__ bool rec_same(const plat_candidate_batch& b, const in
 __global__ void __launch_bounds__(MERGE_THREADS)
 k_candidates_merge(plat_candidate_batch b, const int32_t* __restrict__ read_end, const int32_t* __restrict__ scan_read_begin,
                    const int32_t* __restrict__ scan_longest, int max_per_read, const int32_t* __restrict__ rec,
-                   const int32_t* __restrict__ count, const int32_t* __restrict__ status, double min_var_freq, int cap,
-                   int32_t* __restrict__ out_cand, int32_t* __restrict__ out_n)
+                   const int32_t* __restrict__ count, const int32_t* __restrict__ status, int32_t* __restrict__ mtab, int32_t* __restrict__ out_n)
 {
     __shared__ int s_rep[MERGE_SLOTS];                   // smallest record id with this content, -1 empty
     __shared__ int s_cnt[MERGE_SLOTS];
-    __shared__ int s_distinct, s_status, s_need, s_out;
+    __shared__ int s_distinct, s_status, s_need;
     const int g = blockIdx.x, tid = threadIdx.x;
     const int r0 = scan_read_begin[g], N = scan_read_begin[g + 1] - r0;
     for (int i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) { s_rep[i] = -1; s_cnt[i] = 0; }
-    if (tid == 0) { s_distinct = 0; s_status = 0; s_need = 0; s_out = 0; }
+    if (tid == 0) { s_distinct = 0; s_status = 0; s_need = 0; }
     __syncthreads();
     for (int q = tid; q < N; q += MERGE_THREADS) {
         const int r = r0 + q, c = count[r];
@@ -193,44 +192,56 @@ k_candidates_merge(plat_candidate_batch b, const int32_t* __restrict__ read_end,
             out_n[2 * g] = 0;
             out_n[2 * g + 1] = s_status != 0 ? s_status : (s_need > 0 ? -(1 << 20) - s_need : PLAT_ERR_OVERFLOW);   // -(2^20 + needed records per read) | overflow of the table
         }
+        for (int i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) mtab[(size_t)g * 2 * MERGE_SLOTS + i] = -1;      // nothing for the filter kernel
         return;
     }
+    // the tally goes to global memory: the coverage look-ups and the filter run on the whole device (k_candidates_filter), one thread
+    // per slot -- on this one workgroup they were two thirds of the kernel (two binary searches through global memory per distinct record)
+    for (int i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) {
+        mtab[(size_t)g * 2 * MERGE_SLOTS + i] = s_rep[i];
+        mtab[(size_t)g * 2 * MERGE_SLOTS + MERGE_SLOTS + i] = s_cnt[i];
+    }
+    if (tid == 0) { out_n[2 * g] = 0; out_n[2 * g + 1] = 0; }
+}
+
+// per distinct record of a scan: the reads covering its position (ReadArray.countReadsCoveringRegion, cwindow.pyx:176-206) and the
+// per-sample support filter of generateVariantsInRegion (variantcaller.pyx:456-467).  grid = (MERGE_SLOTS / 256, scans).
+__global__ void __launch_bounds__(256)
+k_candidates_filter(plat_candidate_batch b, const int32_t* __restrict__ read_end, const int32_t* __restrict__ scan_read_begin,
+                    const int32_t* __restrict__ scan_longest, const int32_t* __restrict__ rec, const int32_t* __restrict__ mtab, double min_var_freq,
+                    int cap, int32_t* __restrict__ out_cand, int32_t* __restrict__ out_n)
+{
+    const int g = blockIdx.y, sl = blockIdx.x * blockDim.x + threadIdx.x;
+    const int id = mtab[(size_t)g * 2 * MERGE_SLOTS + sl];
+    if (id < 0) return;
+    const int c = mtab[(size_t)g * 2 * MERGE_SLOTS + MERGE_SLOTS + sl];
+    const int r0 = scan_read_begin[g], N = scan_read_begin[g + 1] - r0;
     const int32_t* pos = b.read_pos + r0;
     const int32_t* endp = read_end + r0;
     const int longest = scan_longest[g];
-    for (int sl = tid; sl < MERGE_SLOTS; sl += MERGE_THREADS) {
-        const int id = s_rep[sl];
-        if (id < 0) continue;
-        const int32_t* me = rec + 5ll * id;
-        const int start = me[0], c = s_cnt[sl];
-        // countReadsCoveringRegion(start, start + 1), cwindow.pyx:176-206
-        int total = 0;
-        if (N > 0) {
-            const long long key = (long long)start - longest > 1 ? (long long)start - longest : 1;
-            int lo = 0, hi = N;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)pos[mid] < key) lo = mid + 1; else hi = mid; }
-            int s = lo;
-            lo = 0; hi = N;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (pos[mid] < start + 1) lo = mid + 1; else hi = mid; }
-            const int e = lo;
-            while (s < N && endp[s] <= start) ++s;
-            if (s > e) { s_status = PLAT_ERR_BAD_INPUT; continue; }       // "Read start pointer > read end pointer": the reference raises
-            total = e - s;
-        }
-        const double frac = total == 0 ? 0.0 : (double)c / (double)total;
-        if (frac >= min_var_freq || me[1] != me[2]) {
-            const int at = atomicAdd(&s_out, 1);
-            if (at < cap) {
-                int32_t* o = out_cand + 8ll * ((long long)g * cap + at);
-                o[0] = id; o[1] = c; o[2] = total; o[3] = me[0]; o[4] = me[1]; o[5] = me[2]; o[6] = me[3]; o[7] = me[4];
-            }
-        }
+    const int32_t* me = rec + 5ll * id;
+    const int start = me[0];
+    // countReadsCoveringRegion(start, start + 1), cwindow.pyx:176-206
+    int total = 0;
+    if (N > 0) {
+        const long long key = (long long)start - longest > 1 ? (long long)start - longest : 1;
+        int lo = 0, hi = N;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)pos[mid] < key) lo = mid + 1; else hi = mid; }
+        int s = lo;
+        lo = 0; hi = N;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (pos[mid] < start + 1) lo = mid + 1; else hi = mid; }
+        const int e = lo;
+        while (s < N && endp[s] <= start) ++s;
+        if (s > e) { atomicCAS(&out_n[2 * g + 1], 0, PLAT_ERR_BAD_INPUT); return; }    // "Read start pointer > read end pointer": the reference raises
+        total = e - s;
     }
-    __syncthreads();
-    if (tid == 0) {
-        const bool over = s_out > cap;
-        out_n[2 * g] = over ? 0 : s_out;
-        out_n[2 * g + 1] = s_status != 0 ? s_status : (over ? PLAT_ERR_OVERFLOW : 0);
+    const double frac = total == 0 ? 0.0 : (double)c / (double)total;
+    if (frac >= min_var_freq || me[1] != me[2]) {
+        const int at = atomicAdd(&out_n[2 * g], 1);
+        if (at < cap) {
+            int32_t* o = out_cand + 8ll * ((long long)g * cap + at);
+            o[0] = id; o[1] = c; o[2] = total; o[3] = me[0]; o[4] = me[1]; o[5] = me[2]; o[6] = me[3]; o[7] = me[4];
+        } else atomicCAS(&out_n[2 * g + 1], 0, PLAT_ERR_OVERFLOW);                      // more candidates than the caller's room: its status says so
     }
 }
 }  // namespace plat
@@ -246,8 +257,13 @@ PLAT_EXPORT int plat_candidates_merge_batch(plat_ctx* ctx, const plat_candidate_
     if (!b.ref_seq || !b.read_seq || !b.read_pos || !read_end || !scan_read_begin || !scan_longest || !rec || !count || !status || !out_cand || !out_n)
         return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    int rcm = plat_reserve(ctx, ctx->merge_tab, (size_t)n_scans * 2 * plat::MERGE_SLOTS * sizeof(int32_t));
+    if (rcm) return rcm;
+    int32_t* mtab = (int32_t*)ctx->merge_tab.ptr;
     hipLaunchKernelGGL(plat::k_candidates_merge, dim3((unsigned)n_scans), dim3(plat::MERGE_THREADS), 0, (hipStream_t)stream, b, read_end,
-                       scan_read_begin, scan_longest, max_per_read, rec, count, status, min_var_freq, cap_per_scan, out_cand, out_n);
+                       scan_read_begin, scan_longest, max_per_read, rec, count, status, mtab, out_n);
+    hipLaunchKernelGGL(plat::k_candidates_filter, dim3(plat::MERGE_SLOTS / 256, (unsigned)n_scans), dim3(256), 0, (hipStream_t)stream, b, read_end,
+                       scan_read_begin, scan_longest, rec, (const int32_t*)mtab, min_var_freq, cap_per_scan, out_cand, out_n);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
