@@ -124,7 +124,18 @@ inline std::vector<int> py2_int_dict_order(const std::vector<int>& keys) {
 }
 
 // ---- beta-binomial p-values -------------------------------------------------------------------------------------------------
-inline double logFactorial(long x) {                                     // platypusutils.pyx:178-191
+inline double logFactorialUncached(long x);
+// (memoised per thread: the beta-binomial p-values of a record ask for a dozen log-factorials of read counts, each five pow() calls;
+//  the same function of the same integer gives the same double)
+inline double logFactorial(long x) {
+    constexpr long N = 4096;
+    static thread_local double cache[N];
+    static thread_local unsigned char have[N];
+    if (x < 0 || x >= N) return logFactorialUncached(x);
+    if (!have[x]) { cache[x] = logFactorialUncached(x); have[x] = 1; }
+    return cache[x];
+}
+inline double logFactorialUncached(long x) {                             // platypusutils.pyx:178-191
     if (x < 15) {
         double ans = 0.0;
         for (long i = 1; i <= x; ++i) ans += log((double)i);

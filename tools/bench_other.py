@@ -225,12 +225,13 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
         runs.append((t2 - t0, t1 - t0))
         gather = dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=len(got) if got else None, records=merged.count("\n") if merged is not None else None)
     planted = (src.planted - planted0) // max(1, repeats)
+    phases = {k: v / max(1, (repeats * len(indices) + nwarm)) for k, v in src.phase_seconds.items()}
     nc.close()
     src.close()
     T = float(np.mean([r[0] for r in runs]))
     return dict(T=T, T_call=float(np.mean([r[1] for r in runs])), T_runs=[r[0] for r in runs], text=text, merged=merged, gather=gather, stats=st,
                 regions=len(indices), region_len=region_len, reads=int(st["n_reads"]), windows=int(st["n_windows"]), records=int(st["n_records"]),
-                planted=int(planted), workers=workers, per_chunk=per_chunk, loaders=loaders, n_slots=n_slots, packed=packed,
+                planted=int(planted), workers=workers, per_chunk=per_chunk, loaders=loaders, n_slots=n_slots, packed=packed, source_phases=phases,
                 input_bytes=int(st["input_bytes"]))
 
 
@@ -268,7 +269,7 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
             "timed_s_runs": r["T_runs"], "planted_variants": r["planted"], "seconds_calls_mean_over_ranks": tcall / world,
             "host_seconds_per_region": st["seconds_host"] / max(1, r["regions"]),
             "device_wait_seconds_per_region": st["seconds_device_wait"] / max(1, r["regions"]),
-            "source_seconds_per_region": st["seconds_load"] / max(1, r["regions"]),
+            "source_seconds_per_region": st["seconds_load"] / max(1, r["regions"]), "source_phase_seconds_per_region": r["source_phases"],
             "worker_seconds_waiting_for_the_source_per_region": st["seconds_source_wait"] / max(1, r["regions"]),
             "host_input_bytes_per_region": inb / max(1.0, regs), "h2d_gbytes_per_sec": inb / T / 1e9, "input_blobs_pinned": pin, "cpus_granted_to_this_rank": cpus,
             "stage_seconds_per_region": {k: v / max(1, r["regions"]) for k, v in st["seconds_stage"].items()},
