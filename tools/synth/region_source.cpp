@@ -122,7 +122,7 @@ struct Scratch {
     std::vector<int32_t> h2r[2];
     std::vector<std::pair<int32_t, int32_t>> gaps[2];                      // per haplotype, ascending: hap positions [a, b) a read must not touch to be one plain match
     std::vector<int32_t> i0, posOf, order, tmpOrder;
-    std::vector<uint64_t> draw;
+    std::vector<uint64_t> draw, sdraw;
     std::vector<Var> vars;
     std::vector<int> spots, kinds;
 };
@@ -282,17 +282,28 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
         size_t nc = 0;
         uint8_t tmpS[10064];
         long long toErr = g->err > 0 ? (long long)std::floor(std::log(1.0 - rng.uni()) / std::log(1.0 - g->err)) : (1ll << 62);   // bases until the next substitution error
+        // the per-read fields that need no thought, in tight loops; the draws and starts in sorted order (one gather instead of two
+        // dependent look-ups per read in the big loop)
+        S.tmpOrder.resize((size_t)nReads);
+        int32_t* sI0 = S.tmpOrder.data();
+        for (int k = 0; k < nReads; ++k) sI0[k] = S.i0[(size_t)S.order[(size_t)k]];
+        S.sdraw.resize((size_t)nReads);
+        for (int k = 0; k < nReads; ++k) S.sdraw[(size_t)k] = S.draw[(size_t)S.order[(size_t)k]];
+        for (int k = 0; k < nReads; ++k) off[k] = (int64_t)k * L;
+        for (int k = 0; k < nReads; ++k) { mate[k] = -1; flags[k] = 3 | ((S.sdraw[(size_t)k] & 2) ? 16 : 0); }
+        memset(mapq, 60, (size_t)nReads);
+        size_t gapAt[2] = {0, 0};                                           // reads come sorted: a haplotype's gaps are passed once
         for (int k = 0; k < nReads; ++k) {
-            const int r = S.order[(size_t)k], i0 = S.i0[(size_t)r];
-            const uint64_t w = S.draw[(size_t)r];
+            const int i0 = sI0[k];
+            const uint64_t w = S.sdraw[(size_t)k];
             const int h = (int)(w & 1);
             const uint8_t* src = S.hs[h].data() + i0;
             const int32_t* map = S.h2r[h].data() + i0;
-            off[k] = (int64_t)k * L; pos[k] = map[0]; mate[k] = -1; mapq[k] = 60;
-            flags[k] = 3 | ((w & 2) ? 16 : 0);
+            pos[k] = map[0];
             cigoff[k] = (int32_t)nc;
-            bool plain = true;
-            for (const auto& gp : S.gaps[h]) { if (gp.first >= i0 + L) break; if (gp.second > i0) { plain = false; break; } }
+            const std::vector<std::pair<int32_t, int32_t>>& gv = S.gaps[h];
+            while (gapAt[h] < gv.size() && gv[gapAt[h]].second <= i0) ++gapAt[h];
+            const bool plain = gapAt[h] >= gv.size() || gv[gapAt[h]].first >= i0 + L;
             if (plain) {
                 cigar[2 * nc] = 0; cigar[2 * nc + 1] = (int16_t)L; ++nc;
                 endp[k] = map[0] + L;
