@@ -473,11 +473,11 @@ def main():
                     "frac": ach / HBM_PEAK_GBPS, "traffic": counters.get("hbm_bytes_per_launch"), "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": ms, "note": note, "secondary": sec}
         seedk_avg = float(np.mean(seedk_ms))
-        # k_seed per launch: haplotype bytes in (1 B/base) + DP haplotype words out (4 B/base), read bit planes in (2 bits/base)
+        # k_seed per launch: haplotype bytes in (1 B/base) + gap-open bytes out (1 B/base; 4-byte DP words until round 3), read bit planes in (2 bits/base)
         # + ReadInfo (16 B/read), one PairRec + one Job out per (haplotype, read) pair (32 B); since round 2 the kernel also
         # finishes the pairs that need no DP: their log-likelihood out (8 B), and one dense-list entry (4 B) per pair that does
         dp_per_step = ndp_run / a.steps / max(world, 1)
-        seed_alg = 5 * int(hb.hap_off[-1]) + int(hb.read_off[-1]) // 4 + 16 * hb.n_reads + 32 * hb.n_pairs \
+        seed_alg = 2 * int(hb.hap_off[-1]) + int(hb.read_off[-1]) // 4 + 16 * hb.n_reads + 32 * hb.n_pairs \
             + int(8 * max(hb.n_pairs - dp_per_step, 0) + 4 * dp_per_step)
         r_dp = entry("k_dp_jobs", prof.dp_alg_bytes, dp_avg, pm,
                      "recurrence is VALU-issue bound (packed int16), not HBM bound: see DESIGN.md")
