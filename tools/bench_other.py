@@ -169,7 +169,7 @@ def line_config3(a, rk):
                                    "1-3 indels + 0-3 SNPs per tile, k = 15, minWeight 40" % nreg, "regions_per_gpu": nreg,
                        "reads_per_step": int(r["ab"]["n_reads"])},
             "variants_found": r["variants"], "variants_planted": r["planted"],
-            "end_to_end": {k: v for k, v in config3_end_to_end(rk.dev_index, nreg, rk=rk, first=rank * nreg).items() if k != "text"},
+            "end_to_end": None if a.no_extras else {k: v for k, v in config3_end_to_end(rk.dev_index, nreg, rk=rk, first=rank * nreg).items() if k != "text"},
             "roofline": {"bound": "hbm", "kernel": "k_assemble", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": r["alg_bytes"],
                          "avg_launch_ms": r["kernel_ms"]}}

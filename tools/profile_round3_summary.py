@@ -55,16 +55,17 @@ def main(o):
     b2 = "--steps 12 --warmup 2 --no-cpu-baseline --no-extras --batches 3"
     stats(o + "/stats1", prof + "/r03_kernel_stats.txt", CMD + b2 + " --streams 1   (MI355X; config 2, one batch at a time)")
     stats(o + "/stats3", prof + "/r03_kernel_stats_pipelined.txt", CMD + b2 + "   (MI355X; config 2, default: 3 batches in flight, kernels of different batches overlap)")
-    stats(o + "/stats_c3", prof + "/r03_assemble_stats.txt", CMD + "--config 3 --regions 2000 --steps 5   (MI355X; config 3: 2000 assembly tiles per launch, then 2000 regions end to end)")
+    stats(o + "/stats_c3", prof + "/r03_assemble_stats.txt", CMD + "--config 3 --regions 2000 --steps 5 --no-extras   (MI355X; config 3: 2000 assembly tiles per launch)")
+    stats(o + "/stats_c3e", prof + "/r03_config3_end_to_end_stats.txt", CMD + "--config 3 --regions 2000 --steps 1   (MI355X; config 3 incl. END TO END: 2000 regions through the native region loop with --assemble=1, 32 regions per chunk)")
     stats(o + "/stats_c5", prof + "/r03_config5_stats.txt", CMD + "--config 5 --windows 200 --steps 10 --warmup 2   (MI355X; config 5: 200 windows x 100 samples per step)")
     stats(o + "/stats_c4", prof + "/r03_config4_stats.txt", CMD + "--config 4 --regions 256 --steps 1   (MI355X; config 4: 256 regions x 100 kb streamed through the native region loop)")
-    for f, dst in (("stats3", "r03_bench_line_under_rocprof.json"), ("stats_c3", "r03_bench_config3_under_rocprof.json"), ("stats_c4", "r03_bench_config4_under_rocprof.json"),
+    for f, dst in (("stats3", "r03_bench_line_under_rocprof.json"), ("stats_c3e", "r03_bench_config3_under_rocprof.json"), ("stats_c4", "r03_bench_config4_under_rocprof.json"),
                    ("stats_c5", "r03_bench_config5_under_rocprof.json")):
         p = o + "/" + f + ".json"
         if os.path.exists(p) and open(p).read().startswith("{"):
             open(os.path.join(prof, dst), "w").write(open(p).read())
     per = pmc(o, ["pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ"], prof + "/r03_pmc_hbm.txt", "--steps 4 --warmup 1 --no-cpu-baseline --no-extras --batches 2 --streams 1")
-    per3 = pmc(o, ["pmc3_FETCH_SIZE", "pmc3_WRITE_SIZE", "pmc3_SQ", "pmc3_WAIT"], prof + "/r03_pmc_assemble.txt", "--config 3 --regions 2000 --steps 2")
+    per3 = pmc(o, ["pmc3_FETCH_SIZE", "pmc3_WRITE_SIZE", "pmc3_SQ", "pmc3_WAIT"], prof + "/r03_pmc_assemble.txt", "--config 3 --regions 2000 --steps 2 --no-extras")
     tf = prof + "/dp_traffic.json"
     d = json.load(open(tf)) if os.path.exists(tf) else {}
 
