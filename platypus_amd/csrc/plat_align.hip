@@ -39,7 +39,7 @@ __device__ __forceinline__ int job_hap(const Job& j) { return j.hap & (JOB_BIGQ 
 //  bit2: quality sum above DP_SWAR_MAX_QSUM -> its DPs use the packed 16-bit adds)
 struct ReadInfo { uint32_t col, aux; int32_t pos; uint32_t lfm; };      // aux bits 0..15: number of bases with quality < LOWQ (the ungapped proof)
 constexpr unsigned LOWQ = 20u;
-enum { SHORTCUT_UNGAPPED = 1, SHORTCUT_EXACT = 2, SHORTCUT_NLOW = 4, SHORTCUT_BIGQ = 8 };   // what k_seed may finish without a DP (PLAT_NO_UNGAPPED / PLAT_NO_EXACT
+enum { SHORTCUT_UNGAPPED = 1, SHORTCUT_EXACT = 2, SHORTCUT_NLOW = 4, SHORTCUT_BIGQ = 8, SEED_LEAN = 1024, SEED_XCD = 2048 };   // what k_seed may finish without a DP (PLAT_NO_UNGAPPED / PLAT_NO_EXACT
                                                                          // switch them off; PLAT_NO_NLOW values unique windows by the smallest quality only)
 __device__ __forceinline__ long long job_slot(long long pair, long long npairs, int extra_base, int k) {
     return k == 0 ? pair : npairs + extra_base + (k - 1);
@@ -190,7 +190,7 @@ constexpr int PREP_LMAX = 448;          // reads up to this length are staged th
 __global__ void __launch_bounds__(256)
 k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const long long* __restrict__ tile_off,
              uint16_t* __restrict__ codes, ReadInfo* __restrict__ rinfo, long long* cnt, int qoff)
-// qoff = byte offset of the quality image in the dynamic LDS (= 64 * min(longest read, PREP_LMAX) + 16); the bit-plane
+// qoff = byte offset of the quality image in the dynamic LDS (= 64 * min(longest read, PREP_LMAX) + 32); the bit-plane
 // accumulators of staged windows follow at 2 * qoff (1 KB per 64-base chunk).
 // `codes` holds, per window and in the tile's footprint (2 bytes per tile element), the reads' 2-bit base codes
 // (calign.pyx:69-74 coding: A=1 C=3 G=2 T=0, N=2) as two BIT PLANES, 64 bases per 64-bit word, transposed (see below).
@@ -218,33 +218,8 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     const long long blob0 = b.read_off[rb + c0];
     const int nbytes = (int)(b.read_off[rb + c0 + nr] - blob0);
     const bool staged = rows - 8 <= PREP_LMAX;
-    // the group's bytes are copied as ALIGNED dwords; the LDS image keeps the blob's misalignment (mis = blob0 & 3)
-    const int misS = (int)((uintptr_t)(b.read_seq + blob0) & 3), misQ = (int)((uintptr_t)(b.read_qual + blob0) & 3);
-    if (tid <= nr) s_off[tid] = (int)(b.read_off[rb + c0 + tid] - blob0);
-    {   // copy to LDS + 7-bit ASCII check (the DP packs bases as byte << 9 and qualities as 4*q in 16 bits).  Bytes before
-        // blob0 / after the group inside the first / last dword belong to neighbouring reads (or the blob's slack).
-        const uint32_t* gs4 = (const uint32_t*)(b.read_seq + blob0 - misS);
-        const uint32_t* gq4 = (const uint32_t*)(b.read_qual + blob0 - misQ);
-        const int ndS = (misS + nbytes + 3) >> 2, ndQ = (misQ + nbytes + 3) >> 2;
-        unsigned bad = 0;
-        for (int i = tid; i < ndS; i += nthr) {
-            const uint32_t vs = gs4[i];
-            bad |= vs;
-            if (staged) ((uint32_t*)psm)[i] = vs;
-        }
-        for (int i = tid; i < ndQ; i += nthr) {
-            const uint32_t vq = gq4[i];
-            bad |= vq;
-            if (staged) ((uint32_t*)(psm + qoff))[i] = vq;
-        }
-        if (bad & 0x80808080u) set_err(cnt, PLAT_ERR_BAD_INPUT);
-    }
-    if (tid < 2) s_dirty[tid] = 0u;
-    if (tid < 64) { s_qsum[tid] = 0u; s_qmin[tid] = 255u; s_nlow[tid] = 0u; }
-    unsigned* s_pl = (unsigned*)(psm + 2 * qoff);        // [chunk][plane][half][64 reads] bit-plane accumulators (staged windows)
-    const int nchunks = (rows - 8 + 63) >> 6;
-    if (staged)
-        for (int i = tid; i < nchunks * 256; i += nthr) s_pl[i] = 0u;
+    // the group's bytes are copied as ALIGNED 16-byte vectors; the LDS image keeps the blob's misalignment (mis = address & 15)
+    const int misS = (int)((uintptr_t)(b.read_seq + blob0) & 15), misQ = (int)((uintptr_t)(b.read_qual + blob0) & 15);
     ReadInfo my_ri = ReadInfo{0u, 0u, 0, 0u};            // loaded now, stored at the end together with the "dirty" bit
     if (tid < nr) {
         const int wstart = b.win_start[w], wend = b.win_end[w];
@@ -260,6 +235,55 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
         my_ri = ReadInfo{(uint32_t)r, 0u, b.read_pos[r],
                          (uint32_t)L | ((uint32_t)skip << 16) | ((uint32_t)b.read_mapq[r] << 24)};
     }
+    if (tid <= nr) s_off[tid] = (int)(b.read_off[rb + c0 + tid] - blob0);
+    {   // copy to LDS + 7-bit ASCII check (the DP packs bases as byte << 9 and qualities as 4*q in 16 bits).  The bytes before blob0 /
+        // after the group inside the first / last vector belong to neighbouring reads or to nobody (same 16-byte granule, hence same
+        // page, as a byte of the group): they are copied and not looked at.  A thread has up to four vectors of each blob in flight
+        // before it waits for the first (the copy is one round trip to memory for a group of 64 x 150 bases, not one per vector).
+        const uint4* gs16 = (const uint4*)(b.read_seq + blob0 - misS);
+        const uint4* gq16 = (const uint4*)(b.read_qual + blob0 - misQ);
+        const int nvS = (misS + nbytes + 15) >> 4, nvQ = (misQ + nbytes + 15) >> 4, nvM = max(nvS, nvQ);
+        auto edge = [](uint4 v, int i, int nv, int mis, int nb) -> unsigned {      // the vector's bytes that belong to the group, OR-ed
+            const int lo = i == 0 ? mis : 0, hi = i == nv - 1 ? ((mis + nb - 1) & 15) + 1 : 16;      // bytes [lo, hi) of this vector
+            const unsigned c[4] = {v.x, v.y, v.z, v.w};
+            unsigned acc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int a = max(lo - 4 * k, 0), e = min(hi - 4 * k, 4);
+                if (e > a) acc |= c[k] & (unsigned)(((1ull << (8 * e)) - 1ull) & ~((1ull << (8 * a)) - 1ull));
+            }
+            return acc;
+        };
+        unsigned bad = 0;
+        for (int i0 = tid; i0 < nvM; i0 += 4 * nthr) {
+            uint4 vs[4], vq[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * nthr;
+                vs[k] = i < nvS ? gs16[i] : make_uint4(0u, 0u, 0u, 0u);
+                vq[k] = i < nvQ ? gq16[i] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * nthr;
+                if (i < nvS) {
+                    bad |= (i == 0 || i == nvS - 1) ? edge(vs[k], i, nvS, misS, nbytes) : (vs[k].x | vs[k].y | vs[k].z | vs[k].w);
+                    if (staged) ((uint4*)psm)[i] = vs[k];
+                }
+                if (i < nvQ) {
+                    bad |= (i == 0 || i == nvQ - 1) ? edge(vq[k], i, nvQ, misQ, nbytes) : (vq[k].x | vq[k].y | vq[k].z | vq[k].w);
+                    if (staged) ((uint4*)(psm + qoff))[i] = vq[k];
+                }
+            }
+        }
+        if (bad & 0x80808080u) set_err(cnt, PLAT_ERR_BAD_INPUT);
+    }
+    if (tid < 2) s_dirty[tid] = 0u;
+    if (tid < 64) { s_qsum[tid] = 0u; s_qmin[tid] = 255u; s_nlow[tid] = 0u; }
+    unsigned* s_pl = (unsigned*)(psm + 2 * qoff);        // [chunk][plane][half][64 reads] bit-plane accumulators (staged windows)
+    const int nchunks = (rows - 8 + 63) >> 6;
+    if (staged)
+        for (int i = tid; i < nchunks * 256; i += nthr) s_pl[i] = 0u;
     __syncthreads();
     const unsigned char* gs = b.read_seq + blob0;
     const unsigned char* gq = b.read_qual + blob0;
@@ -946,7 +970,15 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     u64* nup = eqp + nw64;
     int* s_scal = (int*)(nup + nw64);                    // [0] has_n  [1] maxmult, then the gap-open table
 
-    const int h = blockIdx.x;
+    // Workgroups go to the 8 XCDs round robin by their linear id, and each XCD has its own L2: with SEED_XCD (grid.x a multiple of 8) XCD x
+    // takes the x-th eighth of the haplotypes in order, so that the haplotypes of a window -- which all read the window's read planes and
+    // ReadInfo -- run on ONE XCD at about the same time and those bytes leave HBM once, not once per XCD.
+    int h = blockIdx.x;
+    if (shortcuts & SEED_XCD) {
+        const int per = (int)(gridDim.x >> 3);
+        h = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+        if (h >= b.n_haps) return;
+    }
     if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
     const int w = hap_win[h];
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -1271,22 +1303,31 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
         }
         // Decided pairs: the ones that need no DP are finished here (skipped read: 0.0, chaplotype.pyx:345-346; read < 7 bp or exact
         // match: score 0; ungapped alignment proven optimal: its score), the others leave a job in their slot.
+        // (SEED_LEAN, the asynchronous entry point: nobody asks for statistics afterwards, and k_finalize_dense only looks at pairs with
+        // a DP -- the 32 bytes of records of a finished pair, 7 pairs in 8 of a clean batch, are not written at all.)
         bool prim = false;                                   // the pair's primary slot holds a DP
+        const bool recs = !(shortcuts & SEED_LEAN);
         if (valid && decided) {
             if (!live) {
                 const bool sk = skipped || hapshort;
-                pairs[pidx] = PairRec{0, 0, (int16_t)(sk ? -1 : -2), 0, mapq, {0, 0, 0}};
-                jobs[pidx] = Job{ri.col, h, 0, 0};
+                if (recs) {
+                    pairs[pidx] = PairRec{0, 0, (int16_t)(sk ? -1 : -2), 0, mapq, {0, 0, 0}};
+                    jobs[pidx] = Job{ri.col, h, 0, 0};
+                }
                 out_ll[pidx] = sk ? 0.0 : loglik_of(0, mapq_lut, mapq);
                 if (out_score) out_score[pidx] = sk ? -1 : 0;
             } else if (zero) {
-                pairs[pidx] = PairRec{0, L, (int16_t)-3, 0, mapq, {0, 0, 0}};
-                jobs[pidx] = Job{ri.col, h, cidx, 0};
+                if (recs) {
+                    pairs[pidx] = PairRec{0, L, (int16_t)-3, 0, mapq, {0, 0, 0}};
+                    jobs[pidx] = Job{ri.col, h, cidx, 0};
+                }
                 out_ll[pidx] = loglik_of(0, mapq_lut, mapq);
                 if (out_score) out_score[pidx] = 0;
             } else if (ungapped) {
-                pairs[pidx] = PairRec{ung_score, L, (int16_t)-4, 0, mapq, {0, 0, 0}};
-                jobs[pidx] = Job{ri.col, h, cidx, 0};
+                if (recs) {
+                    pairs[pidx] = PairRec{ung_score, L, (int16_t)-4, 0, mapq, {0, 0, 0}};
+                    jobs[pidx] = Job{ri.col, h, cidx, 0};
+                }
                 out_ll[pidx] = loglik_of(ung_score, mapq_lut, mapq);
                 if (out_score) out_score[pidx] = ung_score;
             } else {
@@ -1603,6 +1644,29 @@ k_finalize_multi(const PairRec* __restrict__ pairs, const Job* __restrict__ jobs
     if (out_score) out_score[p] = best;
 }
 
+// The same over the dense list of live job slots (asynchronous entry point: k_seed left no record of the pairs it finished, SEED_LEAN):
+// a pair with several candidate DPs has its primary slot in the list exactly once.
+__global__ void __launch_bounds__(256)
+k_finalize_dense(const PairRec* __restrict__ pairs, const Job* __restrict__ jobs, const int32_t* __restrict__ job_score,
+                 const double* __restrict__ mapq_lut, long long npairs, const int32_t* __restrict__ dense, long long segcap,
+                 const long long* __restrict__ cnt, long long extra_cap, double* __restrict__ out_ll, int32_t* __restrict__ out_score)
+{
+    if (cnt[CNT_ERR] != 0 || cnt[CNT_NEXTRA] > extra_cap) return;
+    long long ndense = 0;
+#pragma unroll
+    for (int k = 0; k < DENSE_SEGS; ++k) ndense += dense_count(cnt, k, segcap);
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < ndense; t += (long long)gridDim.x * blockDim.x) {
+        const long long p = dense_slot(dense, segcap, cnt, t);
+        if (p < 0 || p >= npairs) continue;
+        const PairRec pr = pairs[p];
+        if (pr.ncand < 0 || pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0)) continue;  // finished by k_dp_jobs
+        int ndp;
+        const int best = select_best(pr, p, npairs, jobs, job_score, &ndp);
+        out_ll[p] = loglik_of(best, mapq_lut, pr.mapq);
+        if (out_score) out_score[p] = best;
+    }
+}
+
 // statistics for plat_align_stats (only launched when the caller asks for them)
 __global__ void __launch_bounds__(256)
 k_stats(const PairRec* __restrict__ pairs, const Job* __restrict__ jobs, const int32_t* __restrict__ job_score,
@@ -1719,7 +1783,11 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     }
     // one wave per workgroup (the lazy index build is wave-local); blockIdx.y = group of SEED_CHUNKS x 64 reads
     const int ngroups = (maxR + SEED_CHUNKS * 64 - 1) / (SEED_CHUNKS * 64);
-    hipLaunchKernelGGL(k_seed, dim3(b.n_haps, ngroups > 0 ? ngroups : 1), dim3(64), lds, st, b, hap_win, win_rows, tile_off,
+    const char* e_x = getenv("PLAT_SEED_XCD");             // (read per call; 0 = haplotype h on workgroup h)
+    const bool xcd = !(e_x && e_x[0] == '0') && b.n_haps >= 64;
+    if (xcd) shortcuts |= SEED_XCD;
+    const unsigned gx = xcd ? (unsigned)((b.n_haps + 7) / 8) * 8u : (unsigned)b.n_haps;
+    hipLaunchKernelGGL(k_seed, dim3(gx, ngroups > 0 ? ngroups : 1), dim3(64), lds, st, b, hap_win, win_rows, tile_off,
                        (const ReadInfo*)ctx->rinfo.ptr, (const uint16_t*)ctx->codes.ptr, (uint8_t*)ctx->hapw.ptr,
                        (uint8_t*)ctx->hap_flags.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
                        (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, shortcuts, dense, segcap,
@@ -1809,7 +1877,7 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
 
     const int prep_groups = maxR > 0 ? (maxR + 63) / 64 : 1;
     // LDS image of a group of 64 reads, sized by the batch's longest read: occupancy of this kernel is LDS-limited
-    const int prep_qoff = 64 * ((std::min(maxread, PREP_LMAX) + 3) & ~3) + 16;
+    const int prep_qoff = 64 * ((std::min(maxread, PREP_LMAX) + 3) & ~3) + 32;   // + the 16-byte copy's slack at both ends
     const size_t prep_lds = (size_t)2 * prep_qoff + (size_t)((std::min(maxread, PREP_LMAX) + 63) >> 6) * 1024;
     if (prep_lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_reads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
@@ -1835,7 +1903,7 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         const char* e_bq = getenv("PLAT_UNGAPPED_BIGQ");   // measurement only: lets the ungapped proof take reads in the wrap regime too (tools/ungapped_crosscheck.py --bigq)
         const int shortcuts = ((!calc_flank_score && !no_ungapped) ? SHORTCUT_UNGAPPED : 0) | (no_exact ? 0 : SHORTCUT_EXACT) |
                               ((e_nl && e_nl[0] == '1') ? 0 : SHORTCUT_NLOW) | ((e_bq && e_bq[0] == '1') ? SHORTCUT_BIGQ : 0) |
-                              (e_dbg ? (atoi(e_dbg) & 0x300) : 0);
+                              (e_dbg ? (atoi(e_dbg) & 0x300) : 0) | (async ? SEED_LEAN : 0);
         // the dense list of live job slots is built by the seeding kernels themselves (DENSE_SEGS segments, each able to hold every slot)
         const long long segcap = npairs + extra_cap;
         if ((rc = plat_reserve(ctx, ctx->dense, ((size_t)segcap * DENSE_SEGS + 64) * sizeof(int32_t)))) return rc;
@@ -1892,9 +1960,15 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
                                (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
     }
     PLAT_EV(ctx, 3, st);
-    hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
-                       (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr,
-                       (const int32_t*)ctx->job_score.ptr, ctx->d_mapq_lut, npairs, cnt, extra_cap, out_loglik, out_score);
+    if (async) {
+        const long long want = (ngrid + 255) / 256, fixed = 8ll * ctx->n_cu;
+        hipLaunchKernelGGL(k_finalize_dense, dim3((unsigned)(want < fixed ? std::max(want, 1ll) : fixed)), dim3(256), 0, st,
+                           (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr, (const int32_t*)ctx->job_score.ptr,
+                           ctx->d_mapq_lut, npairs, dense, segcap, cnt, extra_cap, out_loglik, out_score);
+    } else
+        hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
+                           (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr,
+                           (const int32_t*)ctx->job_score.ptr, ctx->d_mapq_lut, npairs, cnt, extra_cap, out_loglik, out_score);
     PLAT_EV(ctx, 4, st);
     if (async) {
         hipLaunchKernelGGL(k_async_epilogue, dim3(1), dim3(1), 0, st, cnt, extra_cap, (long long*)ctx->d_sticky);
