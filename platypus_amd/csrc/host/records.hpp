@@ -23,7 +23,7 @@
 namespace plathost {
 
 // ---- Python 2 semantics ---------------------------------------------------------------------------------------------------
-inline std::string py2_str(double x) {                                   // str(float) of Python 2: "%.12g", ".0" for integral text
+inline std::string py2_str_slow(double x) {                              // str(float) of Python 2: "%.12g", ".0" for integral text
     char buf[64];
     snprintf(buf, sizeof buf, "%.12g", x);
     std::string t(buf);
@@ -33,9 +33,45 @@ inline std::string py2_str(double x) {                                   // str(
     for (size_t k = i; k < t.size(); ++k) if (t[k] < '0' || t[k] > '9') { digits = false; break; }
     return digits ? t + ".0" : t;
 }
+inline char* put_uint(char* p, unsigned long long v) {                   // decimal digits of v at p, returns the end
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+// The same text appended to `out`.  Nearly every float that reaches a record was rounded to two decimals first: a double that IS the
+// double nearest to n/100 with n < 10^11 prints under "%.12g" as the decimal n/100 without its trailing zeros (the twelve significant
+// digits of its exact value round to those of n/100, which has at most eleven), so that text is written straight from n.
+inline void append_py2_str(std::string& out, double x) {
+    const double ax = fabs(x);
+    if (ax < 1e9) {
+        const unsigned long long n = (unsigned long long)(ax * 100.0 + 0.5);
+        if ((double)n / 100.0 == ax) {
+            char buf[32], *p = buf;
+            if (std::signbit(x)) *p++ = '-';
+            p = put_uint(p, n / 100);
+            const unsigned f = (unsigned)(n % 100);
+            *p++ = '.';
+            *p++ = (char)('0' + f / 10);
+            if (f % 10) *p++ = (char)('0' + f % 10);
+            out.append(buf, (size_t)(p - buf));
+            return;
+        }
+    }
+    out += py2_str_slow(x);
+}
+inline std::string py2_str(double x) { std::string t; append_py2_str(t, x); return t; }
+inline void append_int(std::string& out, long long v) {
+    char buf[24], *p = buf;
+    unsigned long long u = (unsigned long long)v;
+    if (v < 0) { *p++ = '-'; u = 0ull - u; }
+    p = put_uint(p, u);
+    out.append(buf, (size_t)(p - buf));
+}
 // round(x, 2) of Python 2: the exact binary value rounded to two decimals, ties away from zero; as a double.
 // A double is an exact tie at two decimals only when it is an odd multiple of 1/8 (x = k/200 dyadic => 25 | k).
-inline double py2_round2(double x) {
+inline double py2_round2_slow(double x) {
     if (std::isnan(x) || std::isinf(x)) return x;
     const double ax = fabs(x);
     char buf[400];
@@ -53,6 +89,21 @@ inline double py2_round2(double x) {
     }
     snprintf(buf, sizeof buf, "%.2f", x);                               // glibc: correctly rounded on the exact value
     return strtod(buf, nullptr);
+}
+// The same without going through text, for |x| < 10^13: 100 |x| = y + e exactly (y the rounded product, e its error from one fused
+// multiply-add); n = y rounded to an integer, ties away from zero.  y - n is exact and a multiple of ulp(y), so unless y sits exactly on
+// a half, e (at most half an ulp) cannot move the exact product across one; when it does sit on a half, the sign of e says on which side
+// the exact product lies (e = 0: a true tie, away from zero).  The result is the double nearest to n/100 -- one correctly rounded division,
+// which is what strtod makes of the decimal text.
+inline double py2_round2(double x) {
+    const double ax = fabs(x);
+    if (!(ax < 1e13)) return py2_round2_slow(x);
+    const double y = ax * 100.0, e = fma(ax, 100.0, -y);
+    double n = floor(y);
+    const double d = y - n;                                              // exact
+    if (d > 0.5 || (d == 0.5 && e >= 0.0)) n += 1.0;
+    const double r = n / 100.0;
+    return std::signbit(x) ? -r : r;
 }
 inline double py2_round0(double x) { return round(x); }                  // ties away from zero
 
@@ -193,6 +244,11 @@ struct Num {                                                              // a P
         if (value() == -1.0) return ".";
         if (isInt) return std::to_string(i);
         return py2_str(d);
+    }
+    void appendTo(std::string& out) const {
+        if (value() == -1.0) { out += '.'; return; }
+        if (isInt) { append_int(out, i); return; }
+        append_py2_str(out, d);
     }
 };
 

@@ -21,6 +21,10 @@
 // on one worker thread with its own plat_ctx and stream; several workers run side by side, so the uploads, kernels and host
 // stages of different chunks overlap.  Same text as platypus_amd/caller.py::callVariantsInRegions (tests/test_native_caller_*.py).
 #include <atomic>
+#ifdef PLAT_HOSTPROF
+#include <x86intrin.h>
+#include <map>
+#endif
 #include <chrono>
 #include <condition_variable>
 #include <cstdarg>
@@ -41,6 +45,34 @@ namespace plathost {
 
 typedef std::chrono::steady_clock Clock;
 static inline double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+#ifdef PLAT_HOSTPROF                                                  // (local measurement builds only: cycle counts of named scopes)
+static std::map<std::string, unsigned long long> g_prof;
+static std::mutex g_profM;
+struct ProfScope { const char* n; unsigned long long t0; ProfScope(const char* n_) : n(n_), t0(__rdtsc()) {}
+                   ~ProfScope() { const unsigned long long d = __rdtsc() - t0; std::lock_guard<std::mutex> g(g_profM); g_prof[n] += d; } };
+#define PROF_CAT2(a, b) a##b
+#define PROF_CAT(a, b) PROF_CAT2(a, b)
+#define PROF(name) ProfScope PROF_CAT(prof_, __LINE__)(name)
+static void profDump(double n) { for (auto& kv : g_prof) fprintf(stderr, "  [prof] %-28s %9.1f kcycles/region\n", kv.first.c_str(), 1e-3 * (double)kv.second / n); g_prof.clear(); }
+#else
+#define PROF(name)
+static void profDump(double) {}
+#endif
+// PLAT_CALLER_TRACE=1 (measurement): of every stage's seconds, the part spent waiting for the device; [8] host, [9] wait (under the stats mutex)
+static double g_stageWait[10];
+static void traceStages(const plat_caller_stats& st) {
+    const char* e = getenv("PLAT_CALLER_TRACE");
+    if (e && e[0] == '1') {
+        static const char* names[8] = {"upload", "candidate_scan", "variants_windows_haplotypes", "greedy_rounds", "window_batch", "posteriors",
+                                       "read_stats_calls", "text"};
+        const double n = (double)std::max<int64_t>(1, st.n_regions);
+        fprintf(stderr, "[plat_caller] per region, worker seconds (of which waiting for the device):");
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f us (%.1f)", names[k], 1e6 * st.seconds_stage[k] / n, 1e6 * g_stageWait[k] / n);
+        fprintf(stderr, "; host %.1f us, wait %.1f us\n", 1e6 * g_stageWait[8] / n, 1e6 * g_stageWait[9] / n);
+        profDump(n);
+    }
+    for (double& x : g_stageWait) x = 0;
+}
 
 struct DeviceError : std::runtime_error {
     int code;
@@ -844,7 +876,8 @@ struct Chunk {
 
     void regionWindows(RegionWork& r) {
         WindowOptions wo{o.mergeClusteredVariants, o.maxVarDist, o.minVarDist, o.maxSize, o.largeWindows, r.rlen, o.maxVariants, o.outputRefCalls, o.refCallBlockSize};
-        std::vector<Window> wins = windowsAndVariants(r.in->start, r.in->end, r.fa.len - 1, r.variants, wo);
+        std::vector<Window> wins;
+        { PROF("s2.windowsAndVariants"); wins = windowsAndVariants(r.in->start, r.in->end, r.fa.len - 1, r.variants, wo); }
         if (r.cur.size() != r.samples.size()) r.cur.assign(r.samples.size(), Ptrs{0, 0, 0, 0, 0, 0});
         for (Window& win : wins) {
             if (win.variants.empty()) {                                      // a reference-call block between calling windows (:605-607)
@@ -862,6 +895,7 @@ struct Chunk {
             w.region = r.index; w.startPos = win.startPos; w.endPos = win.endPos;
             w.vars = win.variants; w.allVars = win.variants;
             try {
+                PROF("s2.prepareWindow");
                 prepareWindow(r, w);
             } catch (const WindowError& e) {
                 logWindowFailure(r.in->chrom, w.startPos, w.endPos, e.what());
@@ -1367,6 +1401,7 @@ struct Chunk {
         for (size_t k = 0; k < w.info.size(); ++k) {
             VarInfo& d = w.info[k];
             const size_t sv = (size_t)w.firstStatVar + k;
+            PROF("text.info");
             infoFieldsFromReadStats(d, z.s_counts.h + 16 * sv, z.s_ps.h + 2 * sv * (size_t)nInd, nInd, z.s_minq.h + z.s_moff.h[sv], z.s_nminq.h[sv]);
             if (d.TR > 0) {                                                // :1400-1409
                 const double qual = strtod(d.PP.c_str(), nullptr);
@@ -1389,6 +1424,7 @@ struct Chunk {
         };
         // vcfFILTER
         for (auto& pv : w.byPos) {
+            PROF("text.filter");
             const VarList& varsAtPos = pv.second;
             const int n = (int)varsAtPos.size();
             const bool failsSC = computeSCValue(infoOf(varsAtPos[0]).SC) > o.scThreshold;
@@ -1423,15 +1459,15 @@ struct Chunk {
         for (auto& pv : w.byPos) positions.push_back(&pv);
         std::sort(positions.begin(), positions.end(), [](const std::pair<int, VarList>* a, const std::pair<int, VarList>* b) { return a->first < b->first; });
         std::string& out = w.text;
-        char buf[128];
         for (size_t pi = 0; pi < positions.size(); ++pi) {
+            PROF("text.record");
             int POS = positions[pi]->first;
             const VarList& variants = positions[pi]->second;
             const int nVariants = (int)variants.size();
             const size_t site = (size_t)w.firstSite + pi;
             std::string ref;
             std::vector<std::string> alt;
-            refAndAlt(POS, variants, r.fa, ref, alt);
+            { PROF("text.record.refalt"); refAndAlt(POS, variants, r.fa, ref, alt); }
             VarInfo& lead = infoOf(variants[0]);
             std::vector<std::string> linefilter, FR, PP;
             std::vector<long long> NF, NR, TR;
@@ -1449,6 +1485,7 @@ struct Chunk {
             std::vector<std::string> sampleCols;
             const int64_t NL = (int64_t)(nVariants + 1) * (nVariants + 2) / 2;
             for (int i = 0; i < nInd; ++i) {
+                PROF("text.record.samplecol");
                 const Ptrs& p = w.ptrs[(size_t)i];
                 if (p.ge - p.gs == 0) { sampleCols.push_back("./.:0,0,0:0:0:0:0"); continue; }        // :498-500
                 const size_t t = site * (size_t)nInd + (size_t)i;
@@ -1456,35 +1493,33 @@ struct Chunk {
                 const double* lik = z.k_lik.h + klo[site] + (int64_t)i * NL;
                 const double gtPost = z.k_out4.h[4 * t], nonRefPost = z.k_out4.h[4 * t + 1], refPost = z.k_out4.h[4 * t + 2], gofValue = z.k_out4.h[4 * t + 3];
                 if (!(index1 == 0 && index2 == 0)) ++nNonRefCalls;
-                std::string GT = std::to_string(index1) + "/" + std::to_string(index2);
-                std::string GL;
-                if (nVariants == 1) {                                       // :524-542
-                    if (phred(nonRefPost) < o.minPosterior) GT = phred(refPost) < o.minPosterior ? "./." : "0/0";
+                // GT : GL : GOF : GQ : NR : NV, written in place; format_formatdata(key=False) then drops the trailing entries made only
+                // of "," and "." -- GT "./." can only be dropped when everything after it is, and the integers after it never are
+                std::string col;
+                const bool oneVar = nVariants == 1;
+                bool noCall = false;
+                if (oneVar) {                                               // :524-542, :550-553
+                    if (phred(nonRefPost) < o.minPosterior) { if (phred(refPost) < o.minPosterior) noCall = true; else col = "0/0"; }
+                    if (infoOf(variants[0]).nReadsPerSample[(size_t)i] < o.minReads) noCall = true;
+                }
+                if (noCall) col = "./.";
+                else if (col.empty()) { append_int(col, index1); col += '/'; append_int(col, index2); }
+                col += ':';
+                if (oneVar) {
                     double top = lik[0];
                     for (int64_t q = 1; q < NL; ++q) top = std::max(top, lik[q]);
                     for (int64_t q = 0; q < NL; ++q) {                   // (FORMAT fields have no numeric missing value: -1.0 stays -1.0)
-                        if (q) GL += ",";
-                        GL += py2_str(py2_round2(log10(std::max(lik[q] / top, 1e-300))));
+                        if (q) col += ',';
+                        append_py2_str(col, py2_round2(log10(std::max(lik[q] / top, 1e-300))));
                     }
-                } else GL = "-1,-1,-1";
-                std::string NRs, NVs;
-                for (int k = 0; k < nVariants; ++k) {
-                    VarInfo& d = infoOf(variants[(size_t)k]);
-                    if (k) { NRs += ","; NVs += ","; }
-                    NRs += std::to_string(d.nReadsPerSample[(size_t)i]); NVs += std::to_string(d.nVarReadsPerSample[(size_t)i]);
-                }
-                if (nVariants == 1 && infoOf(variants[0]).nReadsPerSample[(size_t)i] < o.minReads) GT = "./.";      // :550-553
-                std::vector<std::string> cols{GT, GL, std::to_string((long long)gofValue), std::to_string(phred(gtPost)), NRs, NVs};
-                // format_formatdata(key=False): trailing entries made only of "," and "." are dropped
-                while (cols.size() > 1) {
-                    bool onlyDots = true;
-                    for (char c : cols.back()) if (c != ',' && c != '.') { onlyDots = false; break; }
-                    if (!onlyDots) break;
-                    cols.pop_back();
-                }
-                std::string col;
-                for (size_t q = 0; q < cols.size(); ++q) { if (q) col += ":"; col += cols[q]; }
-                sampleCols.push_back(col);
+                } else col += "-1,-1,-1";
+                col += ':'; append_int(col, (long long)gofValue);
+                col += ':'; append_int(col, phred(gtPost));
+                col += ':';
+                for (int k = 0; k < nVariants; ++k) { if (k) col += ','; append_int(col, infoOf(variants[(size_t)k]).nReadsPerSample[(size_t)i]); }
+                col += ':';
+                for (int k = 0; k < nVariants; ++k) { if (k) col += ','; append_int(col, infoOf(variants[(size_t)k]).nVarReadsPerSample[(size_t)i]); }
+                sampleCols.push_back(std::move(col));
                 maxGof = std::max(maxGof, gofValue);
             }
             const long long MGOF = (long long)py2_round2(maxGof);
@@ -1494,36 +1529,40 @@ struct Chunk {
             for (char c : ref) if (c != 'A' && c != 'C' && c != 'T' && c != 'G') { plain = false; break; }
             if (!plain) continue;                                           // :583-592
             // VCF.write_data
+            PROF("text.record.write");
             out += r.in->chrom; out += '\t';
-            out += std::to_string(POS + 1); out += "\t.\t"; out += ref; out += '\t';
+            append_int(out, POS + 1); out += "\t.\t"; out += ref; out += '\t';
             if (alt.empty()) out += "."; else for (size_t q = 0; q < alt.size(); ++q) { if (q) out += ","; out += alt[q]; }
-            out += '\t'; out += std::to_string(qual); out += '\t';
-            std::vector<std::string> flt = py2_set_order(linefilter);
-            if (flt.empty()) out += "PASS"; else for (size_t q = 0; q < flt.size(); ++q) { if (q) out += ";"; out += flt[q]; }
+            out += '\t'; append_int(out, qual); out += '\t';
+            if (linefilter.empty()) out += "PASS";
+            else {
+                std::vector<std::string> flt = py2_set_order(linefilter);
+                for (size_t q = 0; q < flt.size(); ++q) { if (q) out += ";"; out += flt[q]; }
+            }
             out += '\t';
-            auto joinLL = [](const std::vector<long long>& v) { std::string t; for (size_t q = 0; q < v.size(); ++q) { if (q) t += ","; t += Num::I(v[q]).text(); } return t; };
-            auto joinS = [](const std::vector<std::string>& v) { std::string t; for (size_t q = 0; q < v.size(); ++q) { if (q) t += ","; t += v[q]; } return t; };
+            auto joinLL = [&out](const std::vector<long long>& v) { for (size_t q = 0; q < v.size(); ++q) { if (q) out += ','; Num::I(v[q]).appendTo(out); } };
+            auto joinS = [&out](const std::vector<std::string>& v) { for (size_t q = 0; q < v.size(); ++q) { if (q) out += ','; out += v[q]; } };
             // INFO keys in sorted order: BRF FR HP HapScore MGOF MMLQ MQ NF NR PP QD SC SbPval Source TC TCF TCR TR WE WS
-            out += "BRF="; out += lead.BRF.text();
-            out += ";FR="; out += joinS(FR);
-            out += ";HP="; out += Num::I(lead.HP).text();
-            out += ";HapScore="; out += Num::I(lead.HapScore).text();
-            out += ";MGOF="; out += Num::I(MGOF).text();
-            out += ";MMLQ="; out += Num::I(lead.MMLQ).text();
-            out += ";MQ="; out += lead.MQ.text();
-            out += ";NF="; out += joinLL(NF);
-            out += ";NR="; out += joinLL(NR);
-            out += ";PP="; out += joinS(PP);
-            out += ";QD="; out += lead.QD.text();
+            out += "BRF="; lead.BRF.appendTo(out);
+            out += ";FR="; joinS(FR);
+            out += ";HP="; Num::I(lead.HP).appendTo(out);
+            out += ";HapScore="; Num::I(lead.HapScore).appendTo(out);
+            out += ";MGOF="; Num::I(MGOF).appendTo(out);
+            out += ";MMLQ="; Num::I(lead.MMLQ).appendTo(out);
+            out += ";MQ="; lead.MQ.appendTo(out);
+            out += ";NF="; joinLL(NF);
+            out += ";NR="; joinLL(NR);
+            out += ";PP="; joinS(PP);
+            out += ";QD="; lead.QD.appendTo(out);
             out += ";SC="; out += lead.SC;
-            out += ";SbPval="; out += lead.SbPval.text();
-            out += ";Source="; out += joinS(lead.Source);
-            out += ";TC="; out += Num::I(lead.TC).text();
-            out += ";TCF="; out += Num::I(lead.TCF).text();
-            out += ";TCR="; out += Num::I(lead.TCR).text();
-            out += ";TR="; out += joinLL(TR);
-            snprintf(buf, sizeof buf, ";WE=%s;WS=%s", Num::I(w.endPos).text().c_str(), Num::I(w.startPos).text().c_str());
-            out += buf;
+            out += ";SbPval="; lead.SbPval.appendTo(out);
+            out += ";Source="; joinS(lead.Source);
+            out += ";TC="; Num::I(lead.TC).appendTo(out);
+            out += ";TCF="; Num::I(lead.TCF).appendTo(out);
+            out += ";TCR="; Num::I(lead.TCR).appendTo(out);
+            out += ";TR="; joinLL(TR);
+            out += ";WE="; Num::I(w.endPos).appendTo(out);
+            out += ";WS="; Num::I(w.startPos).appendTo(out);
             out += "\tGT:GL:GOF:GQ:NR:NV";
             for (const std::string& c : sampleCols) { out += '\t'; out += c; }
             out += '\n';
@@ -1531,14 +1570,14 @@ struct Chunk {
         }
     }
 
-    double stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double stage[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stageWait[8] = {0, 0, 0, 0, 0, 0, 0, 0}, waitMark = 0;
     Clock::time_point mark;
-    void lap(int k) { const auto now = Clock::now(); stage[k] += secs(mark, now); mark = now; }
+    void lap(int k) { const auto now = Clock::now(); stage[k] += secs(mark, now); mark = now; stageWait[k] += s.t_wait - waitMark; waitMark = s.t_wait; }
 
     void run() {
         const auto t0 = Clock::now();
         double wait0 = s.t_wait;
-        mark = t0;
+        mark = t0; waitMark = wait0;
         uploadReads();
         lap(0);
         if (o.getVariantsFromBAMs) scanCandidates();
@@ -1546,8 +1585,9 @@ struct Chunk {
         lap(1);
         int scan0 = 0;
         for (RegionWork* r : regions) {
-            regionVariants(*r, scan0);
+            { PROF("s2.regionVariants"); regionVariants(*r, scan0); }
             scan0 += (int)r->samples.size();
+            PROF("s2.regionWindows");
             regionWindows(*r);
         }
         lap(2);
@@ -1617,7 +1657,8 @@ struct Chunk {
         std::lock_guard<std::mutex> g(stMutex);
         st.n_windows += nWin; st.n_variants += nVar; st.n_candidate_records += nCand; st.n_records += nRec; st.n_refcall_records += nRef;
         st.seconds_host += total - waited; st.seconds_device_wait += waited;
-        for (int k = 0; k < 8; ++k) st.seconds_stage[k] += stage[k];
+        for (int k = 0; k < 8; ++k) { st.seconds_stage[k] += stage[k]; g_stageWait[k] += stageWait[k]; }
+        g_stageWait[8] += total - waited; g_stageWait[9] += waited;
     }
     bool coverageHasAZero(const RegionWork& r, int windowStart, int windowEnd) const {
         for (const SampleView& sv : r.samples) {
@@ -1911,6 +1952,7 @@ CALLER_EXPORT int plat_call_regions(plat_caller* c, const plat_region* regions, 
     if ((rc = finishText(work, out_text, out_len)) != PLAT_OK) return rc;
     options->rlen = rlen;
     st.seconds_total = secs(t0, Clock::now());
+    traceStages(st);
     if (stats) *stats = st;
     return PLAT_OK;
 }
@@ -1948,6 +1990,7 @@ CALLER_EXPORT int plat_call_regions_stream(plat_caller* c, int n_regions, int n_
     options->rlen = feed.rlen;
     st.seconds_total = secs(t0, Clock::now());
     st.seconds_load = feed.tLoad; st.seconds_source_wait = feed.tWait;
+    traceStages(st);
     if (stats) *stats = st;
     return PLAT_OK;
 }

@@ -11,6 +11,7 @@
 // (rows of a shared tape of such draws); mapq 60; flags 3 | 16 at random; sorted by position.
 #include <algorithm>
 #include <chrono>
+#include <immintrin.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -47,6 +48,7 @@ struct plat_synth {
     std::vector<int32_t> index;                                            // job position -> region id
     uint8_t* mem; size_t slotBytes; int nSlots;
     std::vector<uint8_t> tape;                                             // quality tape
+    std::vector<uint8_t> tape4;                                            // the same << 2: the quality bits of a packed byte
     // variant model: indel length 1 + min(indelMax - 1, geometric(indelP) - 1); counts Poisson(rate x length) unless a [min, max] range is set
     int indelMax = 10, nIndelMin = -1, nIndelMax = -1, nSnpMin = -1, nSnpMax = -1;
     double indelP = 0.4;
@@ -89,6 +91,8 @@ SYNTH_EXPORT int plat_synth_create(uint64_t seed, int region_len, int flank, int
         const double z[2] = {m * std::cos(6.283185307179586 * u2), m * std::sin(6.283185307179586 * u2)};
         for (int k = 0; k < 2 && i + k < T; ++k) g->tape[i + k] = (uint8_t)std::min(41.0, std::max(2.0, std::floor(35.0 + 5.0 * z[k] + 0.5)));
     }
+    g->tape4.resize(g->tape.size());
+    for (size_t i = 0; i < g->tape.size(); ++i) g->tape4[i] = (uint8_t)(g->tape[i] << 2);
     *out = g;
     return 0;
 }
@@ -104,6 +108,7 @@ SYNTH_EXPORT int plat_synth_set_model(plat_synth* g, int indel_max_len, double i
     if (lowq_frac > 0) {
         Rng r(g->seed, 0xFFFFFFFEull);
         for (uint8_t& q : g->tape) if (r.uni() < lowq_frac) q = (uint8_t)(2 + r.below(18));
+        for (size_t i = 0; i < g->tape.size(); ++i) g->tape4[i] = (uint8_t)(g->tape[i] << 2);
     }
     return 0;
 }
@@ -119,6 +124,7 @@ struct Carve {
 };
 struct Scratch {
     std::vector<uint8_t> hs[2];
+    std::vector<uint8_t> hc[2];                                            // 2-bit codes of hs (+ slack), packed tables only
     std::vector<int32_t> h2r[2];
     std::vector<std::pair<int32_t, int32_t>> gaps[2];                      // per haplotype, ascending: hap positions [a, b) a read must not touch to be one plain match
     std::vector<int32_t> i0, posOf, order, tmpOrder;
@@ -226,6 +232,15 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
             copyTo(n);
         }
         if ((int)S.hs[0].size() < L || (int)S.hs[1].size() < L) return -1;
+        if (g->encoding == PLAT_READS_PACKED)
+            for (int h = 0; h < 2; ++h) {                                   // a read without errors is then one OR of two byte rows
+                const size_t m = S.hs[h].size();
+                S.hc[h].resize(m + 64);
+                const uint8_t* __restrict a = S.hs[h].data();
+                uint8_t* __restrict c = S.hc[h].data();
+                for (size_t i = 0; i < m; ++i) c[i] = (uint8_t)((a[i] >> 1) & 3);
+                memset(c + m, 0, 64);
+            }
         lap(2);
         // ---- read starts: ONE 64-bit draw per read (bit 0 haplotype, bit 1 strand, bits 2..17 quality row, bits 32..63 the start, uniform
         // over the haplotype's stretch of the region), then sorted by reference position (two stable 9-bit radix passes over pos - lo)
@@ -281,7 +296,8 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
         if (!seq || (!qual && g->encoding != PLAT_READS_PACKED) || !off || !pos || !endp || !flags || !mate || !mapq || !cigoff || !cigar) return -3;
         size_t nc = 0;
         uint8_t tmpS[10064];
-        long long toErr = g->err > 0 ? (long long)std::floor(std::log(1.0 - rng.uni()) / std::log(1.0 - g->err)) : (1ll << 62);   // bases until the next substitution error
+        const double logKeep = g->err > 0 ? std::log(1.0 - g->err) : -1.0;
+        long long toErr = g->err > 0 ? (long long)std::floor(std::log(1.0 - rng.uni()) / logKeep) : (1ll << 62);   // bases until the next substitution error
         // the per-read fields that need no thought, in tight loops; the draws and starts in sorted order (one gather instead of two
         // dependent look-ups per read in the big loop)
         S.tmpOrder.resize((size_t)nReads);
@@ -327,27 +343,36 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
             }
             const uint8_t* q = g->tape.data() + ((w >> 2) & 0xFFFFu);
             uint8_t* ds = seq + (size_t)k * L;
-            const uint8_t* s = src;
-            if (toErr < L) {                                                // (rare: one read in six at 0.1 %)
-                memcpy(tmpS, src, (size_t)L);
-                while (toErr < L) {
-                    const char* B = "ACGT";
-                    const char* at = strchr(B, tmpS[toErr]);
-                    tmpS[toErr] = (uint8_t)B[((at ? (int)(at - B) : 0) + 1 + (int)rng.below(3)) & 3];
-                    toErr += 1 + (long long)std::floor(std::log(1.0 - rng.uni()) / std::log(1.0 - g->err));
-                }
-                s = tmpS;
-            }
-            toErr -= L;
             if (g->encoding == PLAT_READS_PACKED) {
+                // one OR of two byte rows in blocks of 32 bytes: what runs past the read lands in the next read's row (written after this
+                // one) or in the table's slack; then the substitution errors, on the codes (A C G T = 0 1 3 2)
                 uint8_t* __restrict d = ds;
-                const uint8_t* __restrict sb = s;
-                const uint8_t* __restrict qb = q;
-                for (int i = 0; i < L; ++i) d[i] = (uint8_t)(((sb[i] >> 1) & 3) | (qb[i] << 2));
+                const uint8_t* __restrict cb = S.hc[h].data() + i0;
+                const uint8_t* __restrict qb = g->tape4.data() + ((w >> 2) & 0xFFFFu);
+                for (int i = 0; i < L; i += 32)
+                    _mm256_storeu_si256((__m256i*)(d + i), _mm256_or_si256(_mm256_loadu_si256((const __m256i*)(cb + i)), _mm256_loadu_si256((const __m256i*)(qb + i))));
+                while (toErr < L) {                                         // (rare: one read in six at 0.1 %)
+                    static const uint8_t idxOf[4] = {0, 1, 3, 2}, codeOf[4] = {0, 1, 3, 2};
+                    const uint8_t c = cb[toErr];
+                    ds[toErr] = (uint8_t)(codeOf[(idxOf[c] + 1 + (int)rng.below(3)) & 3] | qb[toErr]);
+                    toErr += 1 + (long long)std::floor(std::log(1.0 - rng.uni()) / logKeep);
+                }
             } else {
+                const uint8_t* s = src;
+                if (toErr < L) {
+                    memcpy(tmpS, src, (size_t)L);
+                    while (toErr < L) {
+                        const char* B = "ACGT";
+                        const char* at = strchr(B, tmpS[toErr]);
+                        tmpS[toErr] = (uint8_t)B[((at ? (int)(at - B) : 0) + 1 + (int)rng.below(3)) & 3];
+                        toErr += 1 + (long long)std::floor(std::log(1.0 - rng.uni()) / logKeep);
+                    }
+                    s = tmpS;
+                }
                 memcpy(ds, s, (size_t)L);
                 memcpy(qual + (size_t)k * L, q, (size_t)L);
             }
+            toErr -= L;
         }
         lap(4);
         off[nReads] = (int64_t)nb; cigoff[nReads] = (int32_t)nc;
