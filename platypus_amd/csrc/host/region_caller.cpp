@@ -532,8 +532,13 @@ struct Chunk {
                     if (nb && t.encoding == PLAT_READS_PACKED) {            // one byte per base crosses the link; expanded below
                         ck(plat_memcpy_h2d(z.ctx, z.t_pack.d + bo, t.seq, nb, z.stream), "plat_memcpy_h2d(packed)");
                         const size_t ne = (size_t)std::max<int64_t>(t.n_exceptions, 0);
-                        for (size_t e = 0; e < ne; ++e) { z.t_excidx.h[eo + e] = t.exc_index[e]; z.t_excb.h[eo + e] = t.exc_base[e]; z.t_excq.h[eo + e] = t.exc_qual[e]; }
-                        packed.push_back(Pending{bo, nb, eo, ne});
+                        // packed tables that follow each other in the blob are expanded by ONE plat_unpack_reads: the exceptions of the
+                        // later ones are counted from the first one's first byte
+                        const bool joins = !packed.empty() && packed.back().bo + packed.back().nb == bo && packed.back().e0 + packed.back().ne == eo;
+                        const int64_t shift = joins ? (int64_t)(bo - packed.back().bo) : 0;
+                        for (size_t e = 0; e < ne; ++e) { z.t_excidx.h[eo + e] = t.exc_index[e] + shift; z.t_excb.h[eo + e] = t.exc_base[e]; z.t_excq.h[eo + e] = t.exc_qual[e]; }
+                        if (joins) { packed.back().nb += nb; packed.back().ne += ne; }
+                        else packed.push_back(Pending{bo, nb, eo, ne});
                         eo += ne; inBytes += nb + 10 * ne;
                     } else if (nb) {                                       // bases and qualities go straight from the caller's memory
                         ck(plat_memcpy_h2d(z.ctx, z.t_seq.d + bo, t.seq, nb, z.stream), "plat_memcpy_h2d(seq)");
@@ -1901,13 +1906,35 @@ static int runWorkers(plat_caller* c, Feed& feed, std::atomic<bool>& failed, con
     return firstError;
 }
 
-static int finishText(std::vector<std::unique_ptr<RegionWork>>& work, char** out_text, size_t* out_len) {
+// pieces[i] -> out + offset[i], on a few threads when there is enough to move (a whole-genome share is ~100 MB of record text: one thread
+// would spend as long on first-touch page faults of the fresh block as on the copy)
+static void copyPieces(char* out, const std::vector<const char*>& from, const std::vector<size_t>& len, const std::vector<size_t>& at) {
     size_t total = 0;
-    for (auto& r : work) if (r) total += r->text.size();
+    for (size_t l : len) total += l;
+    const size_t n = from.size();
+    const int nT = total < ((size_t)8 << 20) ? 1 : (int)std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency()));
+    auto part = [&](int t) {
+        // thread t takes the pieces whose bytes start in its slice of the output
+        const size_t span = n ? at[n - 1] + len[n - 1] + 1 : 0;            // (offsets may leave gaps between the pieces: they run over the output, not over the bytes copied)
+        const size_t lo = span / (size_t)nT * (size_t)t, hi = t == nT - 1 ? span + 1 : span / (size_t)nT * (size_t)(t + 1);
+        size_t i = (size_t)(std::lower_bound(at.begin(), at.end(), lo) - at.begin());
+        for (; i < n && at[i] < hi; ++i) if (len[i]) memcpy(out + at[i], from[i], len[i]);
+    };
+    if (nT == 1) { part(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < nT; ++t) th.emplace_back(part, t);
+    part(0);
+    for (std::thread& x : th) x.join();
+}
+
+static int finishText(std::vector<std::unique_ptr<RegionWork>>& work, char** out_text, size_t* out_len) {
+    std::vector<const char*> from;
+    std::vector<size_t> len, at;
+    size_t total = 0;
+    for (auto& r : work) if (r) { from.push_back(r->text.data()); len.push_back(r->text.size()); at.push_back(total); total += r->text.size(); }
     char* text = (char*)malloc(total + 1);
     if (!text) return PLAT_ERR_NOMEM;
-    size_t at = 0;
-    for (auto& r : work) if (r) { memcpy(text + at, r->text.data(), r->text.size()); at += r->text.size(); }
+    copyPieces(text, from, len, at);
     text[total] = 0;
     *out_text = text; *out_len = total;
     return PLAT_OK;
@@ -2035,48 +2062,91 @@ static bool mergeLess(const MergeKey& a, const MergeKey& b) {
 }
 }  // namespace plathost
 
+// Three passes: (1) the record lines of every text and their keys, texts cut into slices at line ends and the slices scanned on a few
+// threads; (2) the merge itself over the keys -- a run of lines of one text that stays in front of every other text's head is one block;
+// ties between texts go to the text that comes first (heapq of (key, index) pairs there); (3) the blocks copied into place, again on a
+// few threads.
 CALLER_EXPORT int plat_merge_record_texts(const char* const* texts, const size_t* lengths, int n, char** out_text, size_t* out_len) {
     if (!out_text || !out_len || n < 0 || (n > 0 && (!texts || !lengths))) return PLAT_ERR_INVALID;
+    struct Line { const char* p; const char* eol; MergeKey key; };
     size_t total = 0;
     for (int i = 0; i < n; ++i) total += lengths[i] + 1;
-    char* out = (char*)malloc(total + 1);
-    if (!out) return PLAT_ERR_NOMEM;
-    struct Cur { const char* p; const char* end; const char* eol; MergeKey key; bool live; };
-    std::vector<Cur> cur((size_t)n);
-    auto advance = [](Cur& c) {
-        while (c.p < c.end && (*c.p == '\n' || *c.p == '#')) {             // empty and header lines do not take part
-            const char* e = (const char*)memchr(c.p, '\n', (size_t)(c.end - c.p));
-            c.p = e ? e + 1 : c.end;
-        }
-        c.live = c.p < c.end;
-        if (c.live) {
-            const char* e = (const char*)memchr(c.p, '\n', (size_t)(c.end - c.p));
-            c.eol = e ? e : c.end;
-            c.key = mergeKeyOf(c.p, c.eol);
-        }
-    };
-    for (int i = 0; i < n; ++i) { cur[(size_t)i] = Cur{texts[i], texts[i] + lengths[i], nullptr, MergeKey{}, false}; advance(cur[(size_t)i]); }
-    size_t at = 0;
-    for (;;) {
-        int best = -1;
-        for (int i = 0; i < n; ++i)                                        // (a handful of streams: a scan is as good as a heap)
-            if (cur[(size_t)i].live && (best < 0 || mergeLess(cur[(size_t)i].key, cur[(size_t)best].key))) best = i;
-        if (best < 0) break;
-        Cur& c = cur[(size_t)best];
-        // a run of lines of this stream that stay in front of every other stream's head moves as one block
-        const char* from = c.p;
-        for (;;) {
-            c.p = c.eol < c.end ? c.eol + 1 : c.end;
-            const char* lastEol = c.eol;
-            advance(c);
-            bool still = c.live;
-            for (int i = 0; still && i < n; ++i)
-                if (i != best && cur[(size_t)i].live && (mergeLess(cur[(size_t)i].key, c.key) || (i < best && !mergeLess(c.key, cur[(size_t)i].key)))) still = false;
-            if (!still) { const size_t len = (size_t)(lastEol - from); memcpy(out + at, from, len); at += len; out[at++] = '\n'; break; }
+    // (1)
+    struct Slice { int text; const char* a; const char* b; std::vector<Line> lines; };
+    std::vector<Slice> slices;
+    const size_t sliceBytes = (size_t)4 << 20;
+    for (int i = 0; i < n; ++i) {
+        const char* p = texts[i];
+        const char* end = texts[i] + lengths[i];
+        while (p < end) {
+            const char* q = (size_t)(end - p) > sliceBytes ? p + sliceBytes : end;
+            if (q < end) { const char* e = (const char*)memchr(q, '\n', (size_t)(end - q)); q = e ? e + 1 : end; }
+            slices.push_back(Slice{i, p, q, {}});
+            p = q;
         }
     }
-    out[at] = 0;
-    *out_text = out; *out_len = at;
+    auto scan = [](Slice& sl) {
+        const char* p = sl.a;
+        while (p < sl.b) {
+            const char* e = (const char*)memchr(p, '\n', (size_t)(sl.b - p));
+            const char* eol = e ? e : sl.b;
+            if (*p != '\n' && *p != '#') sl.lines.push_back(Line{p, eol, mergeKeyOf(p, eol)});   // empty and header lines do not take part
+            p = e ? e + 1 : sl.b;
+        }
+    };
+    {
+        const int nT = (int)std::min<size_t>({(size_t)8, slices.size(), std::max<size_t>(1, std::thread::hardware_concurrency())});
+        std::atomic<size_t> next(0);
+        auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < slices.size();) scan(slices[k]); };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nT; ++t) th.emplace_back(work);
+        work();
+        for (std::thread& x : th) x.join();
+    }
+    std::vector<std::vector<Line>> lines((size_t)std::max(n, 0));
+    for (Slice& sl : slices) {
+        std::vector<Line>& L = lines[(size_t)sl.text];
+        if (L.empty()) L.swap(sl.lines); else L.insert(L.end(), sl.lines.begin(), sl.lines.end());
+    }
+    // (2)
+    std::vector<const char*> from;
+    std::vector<size_t> len, at;
+    size_t outAt = 0;
+    std::vector<size_t> cur((size_t)std::max(n, 0), 0);
+    auto live = [&](int i) { return cur[(size_t)i] < lines[(size_t)i].size(); };
+    auto head = [&](int i) -> const MergeKey& { return lines[(size_t)i][cur[(size_t)i]].key; };
+    for (;;) {
+        int best = -1;
+        for (int i = 0; i < n; ++i)                                        // (a handful of texts: a scan is as good as a heap)
+            if (live(i) && (best < 0 || mergeLess(head(i), head(best)))) best = i;
+        if (best < 0) break;
+        // the other texts' smallest head bounds the run
+        int other = -1;
+        for (int i = 0; i < n; ++i) if (i != best && live(i) && (other < 0 || mergeLess(head(i), head(other)))) other = i;
+        const std::vector<Line>& L = lines[(size_t)best];
+        size_t k = cur[(size_t)best] + 1;
+        if (other < 0) k = L.size();
+        else
+            while (k < L.size() && !(mergeLess(head(other), L[k].key) || (other < best && !mergeLess(L[k].key, head(other))))) ++k;
+        // lines [cur, k) of this text: contiguous in it unless empty / header lines lie between them -- those are cut out
+        size_t a = cur[(size_t)best];
+        while (a < k) {
+            size_t b = a + 1;
+            while (b < k && L[b].p == L[b - 1].eol + 1) ++b;
+            const size_t l = (size_t)(L[b - 1].eol - L[a].p) + 1;             // + the newline (written below when the text ends without one)
+            from.push_back(L[a].p); len.push_back(l - 1); at.push_back(outAt);
+            outAt += l;
+            a = b;
+        }
+        cur[(size_t)best] = k;
+    }
+    char* out = (char*)malloc(total + 1);
+    if (!out) return PLAT_ERR_NOMEM;
+    // (3)
+    copyPieces(out, from, len, at);
+    for (size_t i = 0; i < at.size(); ++i) out[at[i] + len[i]] = '\n';
+    out[outAt] = 0;
+    *out_text = out; *out_len = outAt;
     return PLAT_OK;
 }
 

@@ -22,6 +22,12 @@ struct CandEmit {
     }
 };
 
+// 8 bytes from any address (global memory takes unaligned 64-bit loads)
+__device__ __forceinline__ unsigned long long load_u64_bytes(const uint8_t* p) {
+    typedef unsigned long long __attribute__((aligned(1))) u64u;
+    return *(const u64u*)p;
+}
+
 __device__ __forceinline__ bool has_n(const uint8_t* s, int n) {
     for (int i = 0; i < n; ++i) if (s[i] == 'N') return true;
     return false;
@@ -73,29 +79,44 @@ k_candidates(plat_candidate_batch b, int min_flank, int min_base_qual, int gen_s
                 }
             } else if (flag == 0 || flag == 7 || flag == 8) {    // M, =, X
                 if (!(flag == 7 || (length < min_flank && flag == 0)) && gen_snps) {
-                    // getSnpCandidatesFromReadSegment, :529-612
+                    // getSnpCandidatesFromReadSegment, :529-612.  The loop there visits every base; only mismatches change its state
+                    // (a run of mismatches is closed at the first MATCH more than minFlank behind its end -- or by the next mismatch that
+                    // far behind it, which finds the same run and writes the same record), so whole words of equal bases are stepped over:
+                    // 8 bases of the read against 8 of the reference per load.
                     int msr = -1, mer = -1, msd = -1, med = -1;
-                    for (int index = 0; index < length; ++index) {
-                        if (readOffset == 0 && index < min_flank) continue;
-                        if (index + readOffset >= rlen - min_flank) continue;
-                        const int readIndex = index + readOffset;
-                        const int refIndex = (index + refOffset + readStart) - refSeqStart;
-                        if (refIndex < 0 || refIndex >= refLen) { st = PLAT_ERR_BAD_INPUT; break; }   // the reference reads past its buffer here
-                        const uint8_t readChar = readSeq[readIndex], refChar = ref[refIndex];
-                        if (readChar != refChar) {
-                            if (readChar != 'N' && refChar != 'N' && (int)readQual[readIndex] >= min_base_qual) {
-                                if (msr == -1) { msr = mer = refIndex; msd = med = readIndex; }
-                                else if (refIndex - mer <= min_flank) { mer = refIndex; med = readIndex; }
-                                else {
-                                    out.put(msr + refSeqStart, mer - msr + 1, med - msd + 1, roff + msr, soff + msd);
-                                    msr = mer = refIndex; msd = med = readIndex;
-                                }
+                    int lo = (readOffset == 0) ? (min_flank < length ? min_flank : length) : 0;                  // first index looked at
+                    int hi = rlen - min_flank - readOffset;                                                       // one past the last
+                    if (hi > length) hi = length;
+                    // the reference reads past its buffer where refIndex leaves [0, refLen): it stops there (after the bases before)
+                    const int refIndex0 = refOffset + readStart - refSeqStart;                                    // refIndex of index 0
+                    if (lo < hi) {
+                        if (refIndex0 + lo < 0) { st = PLAT_ERR_BAD_INPUT; hi = lo; }
+                        else if (refIndex0 + hi > refLen) { st = PLAT_ERR_BAD_INPUT; hi = refLen - refIndex0; }
+                    }
+                    const uint8_t* rp = readSeq + readOffset;
+                    const uint8_t* fp = ref + refIndex0;
+                    auto mismatch = [&](int index) {
+                        const int readIndex = index + readOffset, refIndex = refIndex0 + index;
+                        const uint8_t readChar = rp[index], refChar = fp[index];
+                        if (readChar != 'N' && refChar != 'N' && (int)readQual[readIndex] >= min_base_qual) {
+                            if (msr == -1) { msr = mer = refIndex; msd = med = readIndex; }
+                            else if (refIndex - mer <= min_flank) { mer = refIndex; med = readIndex; }
+                            else {
+                                out.put(msr + refSeqStart, mer - msr + 1, med - msd + 1, roff + msr, soff + msd);
+                                msr = mer = refIndex; msd = med = readIndex;
                             }
-                        } else if (msr != -1 && refIndex - mer > min_flank) {
-                            out.put(msr + refSeqStart, mer - msr + 1, med - msd + 1, roff + msr, soff + msd);
-                            msr = mer = msd = med = -1;
+                        }
+                    };
+                    int index = lo;
+                    for (; index + 8 <= hi; index += 8) {
+                        unsigned long long x = load_u64_bytes(rp + index) ^ load_u64_bytes(fp + index);
+                        while (x) {
+                            const int j = (__ffsll((long long)x) - 1) >> 3;
+                            mismatch(index + j);
+                            x &= ~(0xFFull << (8 * j));
                         }
                     }
+                    for (; index < hi; ++index) if (rp[index] != fp[index]) mismatch(index);
                     if (msr != -1) out.put(msr + refSeqStart, mer - msr + 1, med - msd + 1, roff + msr, soff + msd);
                 }
                 readOffset += length;
@@ -135,12 +156,17 @@ PLAT_EXPORT int plat_candidates_batch(plat_ctx* ctx, const plat_candidate_batch*
 
 // ------------------------------------------------------------------------------------------------
 // The dictionary step behind the scan (VariantCandidateGenerator.addVariantToList, variant.pyx:499-527) and the per-sample support
-// filter of generateVariantsInRegion (variantcaller.pyx:456-467) for every scan (= region x sample) of a candidate batch:
-// one workgroup per scan, the DISTINCT records (position, removed bases, added bases) in an LDS hash table -- slot = the record
-// with the smallest id (first occurrence: the reference's dictionary order) + the number of reads showing it -- then, per distinct
-// record, the reads covering its position (ReadArray.countReadsCoveringRegion, cwindow.pyx:176-206) and the filter.
+// filter of generateVariantsInRegion (variantcaller.pyx:456-467) for every scan (= region x sample) of a candidate batch.
+// k_candidates_merge: ONE THREAD PER READ puts the read's records into the scan's hash table in global memory (atomics in L2) -- slot =
+// the record with the smallest id among those of equal content (first occurrence: the reference's dictionary order) + the number of reads
+// showing it.  (Round 2 kept the table in LDS, one workgroup per scan: twenty reads per thread one after the other, each a chain of
+// dependent loads -- 140 us for four scans of 20 000 reads, the longest kernel of the region pipeline.)
+// k_candidates_filter: per distinct record, the reads covering its position (ReadArray.countReadsCoveringRegion, cwindow.pyx:176-206)
+// and the filter.
 namespace plat {
-constexpr int MERGE_SLOTS = 8192, MERGE_LIMIT = 6144, MERGE_THREADS = 1024;
+constexpr int MERGE_SLOTS = 8192, MERGE_LIMIT = 6144, MERGE_PROBES = 1024;
+// per scan: rep + 1 [MERGE_SLOTS] (0 = empty) | count [MERGE_SLOTS]; after the tables of all scans, 4 words per scan: distinct, status, need, -
+__device__ __forceinline__ int32_t* merge_flags(int32_t* mtab, int n_scans, int g) { return mtab + (size_t)n_scans * 2 * MERGE_SLOTS + 4 * (size_t)g; }
 
 __device__ __forceinline__ bool rec_same(const plat_candidate_batch& b, const int32_t* x, const int32_t* y) {
     if (x[0] != y[0] || x[1] != y[1] || x[2] != y[2]) return false;
@@ -149,70 +175,67 @@ __device__ __forceinline__ bool rec_same(const plat_candidate_batch& b, const in
     return true;
 }
 
-__global__ void __launch_bounds__(MERGE_THREADS)
-k_candidates_merge(plat_candidate_batch b, const int32_t* __restrict__ read_end, const int32_t* __restrict__ scan_read_begin,
-                   const int32_t* __restrict__ scan_longest, int max_per_read, const int32_t* __restrict__ rec,
-                   const int32_t* __restrict__ count, const int32_t* __restrict__ status, int32_t* __restrict__ mtab, int32_t* __restrict__ out_n)
+__global__ void __launch_bounds__(256)
+k_candidates_merge(plat_candidate_batch b, const int32_t* __restrict__ scan_read_begin, int n_scans, int max_per_read,
+                   const int32_t* __restrict__ rec, const int32_t* __restrict__ count, const int32_t* __restrict__ status,
+                   int32_t* __restrict__ mtab, int32_t* __restrict__ out_n)
 {
-    __shared__ int s_rep[MERGE_SLOTS];                   // smallest record id with this content, -1 empty
-    __shared__ int s_cnt[MERGE_SLOTS];
-    __shared__ int s_distinct, s_status, s_need;
-    const int g = blockIdx.x, tid = threadIdx.x;
+    const int g = blockIdx.y;
     const int r0 = scan_read_begin[g], N = scan_read_begin[g + 1] - r0;
-    for (int i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) { s_rep[i] = -1; s_cnt[i] = 0; }
-    if (tid == 0) { s_distinct = 0; s_status = 0; s_need = 0; }
+    int32_t* tab = mtab + (size_t)g * 2 * MERGE_SLOTS;
+    int32_t* flags = merge_flags(mtab, n_scans, g);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out_n[2 * g] = 0; out_n[2 * g + 1] = 0; }     // (the filter kernel counts into them)
+    // distinct records are counted per workgroup and added once (most records of a scan are sequencing errors seen once: an atomic per
+    // new record on one word of L2 was most of this kernel); a table filling up meanwhile shows as a probe sequence that does not end
+    __shared__ int s_new;
+    if (threadIdx.x == 0) s_new = 0;
     __syncthreads();
-    for (int q = tid; q < N; q += MERGE_THREADS) {
+    const bool full = flags[0] > MERGE_LIMIT;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < N && !full; q += gridDim.x * blockDim.x) {
         const int r = r0 + q, c = count[r];
-        if (status[r] == PLAT_ERR_BAD_INPUT) s_status = PLAT_ERR_BAD_INPUT;
-        if (c > max_per_read) { atomicMax(&s_need, c); continue; }
+        if (status[r] == PLAT_ERR_BAD_INPUT) flags[1] = PLAT_ERR_BAD_INPUT;
+        if (c > max_per_read) { atomicMax(&flags[2], c); continue; }
         for (int k = 0; k < c; ++k) {
-            if (*(volatile int*)&s_distinct > MERGE_LIMIT) break;
             const int id = r * max_per_read + k;
             const int32_t* me = rec + 5ll * id;
             unsigned h = (unsigned)me[0] * 2654435761u + (unsigned)me[1] * 40503u + (unsigned)me[2] * 97u;
             for (int i = 0; i < me[1]; ++i) h = h * 31u + b.ref_seq[(long long)me[3] + i];
             for (int i = 0; i < me[2]; ++i) h = h * 37u + b.read_seq[(long long)me[4] + i];
             unsigned sl = (h ^ (h >> 15)) & (MERGE_SLOTS - 1);
-            for (;;) {
-                int cur = s_rep[sl];
-                if (cur == -1) {
-                    const int old = atomicCAS(&s_rep[sl], -1, id);
-                    if (old == -1) { atomicAdd(&s_distinct, 1); atomicAdd(&s_cnt[sl], 1); break; }
+            bool placed = false;
+            for (int tries = 0; tries < MERGE_PROBES && !placed; ++tries) {
+                int cur = *(volatile int32_t*)&tab[sl];
+                if (cur == 0) {
+                    const int old = atomicCAS(&tab[sl], 0, id + 1);
+                    if (old == 0) { atomicAdd(&s_new, 1); atomicAdd(&tab[MERGE_SLOTS + sl], 1); placed = true; break; }
                     cur = old;
                 }
-                if (cur == id || rec_same(b, rec + 5ll * cur, me)) { atomicMin(&s_rep[sl], id); atomicAdd(&s_cnt[sl], 1); break; }
+                if (cur - 1 == id || rec_same(b, rec + 5ll * (cur - 1), me)) { atomicMin(&tab[sl], id + 1); atomicAdd(&tab[MERGE_SLOTS + sl], 1); placed = true; break; }
                 sl = (sl + 1u) & (MERGE_SLOTS - 1);
             }
+            if (!placed) atomicMax(&flags[0], MERGE_LIMIT + 1);          // the table is (nearly) full
         }
     }
     __syncthreads();
-    if (s_need > 0 || s_status != 0 || s_distinct > MERGE_LIMIT) {
-        if (tid == 0) {
-            out_n[2 * g] = 0;
-            out_n[2 * g + 1] = s_status != 0 ? s_status : (s_need > 0 ? -(1 << 20) - s_need : PLAT_ERR_OVERFLOW);   // -(2^20 + needed records per read) | overflow of the table
-        }
-        for (int i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) mtab[(size_t)g * 2 * MERGE_SLOTS + i] = -1;      // nothing for the filter kernel
-        return;
-    }
-    // the tally goes to global memory: the coverage look-ups and the filter run on the whole device (k_candidates_filter), one thread
-    // per slot -- on this one workgroup they were two thirds of the kernel (two binary searches through global memory per distinct record)
-    for (int i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) {
-        mtab[(size_t)g * 2 * MERGE_SLOTS + i] = s_rep[i];
-        mtab[(size_t)g * 2 * MERGE_SLOTS + MERGE_SLOTS + i] = s_cnt[i];
-    }
-    if (tid == 0) { out_n[2 * g] = 0; out_n[2 * g + 1] = 0; }
+    if (threadIdx.x == 0 && s_new) atomicAdd(&flags[0], s_new);
 }
 
 // per distinct record of a scan: the reads covering its position (ReadArray.countReadsCoveringRegion, cwindow.pyx:176-206) and the
 // per-sample support filter of generateVariantsInRegion (variantcaller.pyx:456-467).  grid = (MERGE_SLOTS / 256, scans).
 __global__ void __launch_bounds__(256)
 k_candidates_filter(plat_candidate_batch b, const int32_t* __restrict__ read_end, const int32_t* __restrict__ scan_read_begin,
-                    const int32_t* __restrict__ scan_longest, const int32_t* __restrict__ rec, const int32_t* __restrict__ mtab, double min_var_freq,
+                    const int32_t* __restrict__ scan_longest, int n_scans, const int32_t* __restrict__ rec, int32_t* __restrict__ mtab, double min_var_freq,
                     int cap, int32_t* __restrict__ out_cand, int32_t* __restrict__ out_n)
 {
     const int g = blockIdx.y, sl = blockIdx.x * blockDim.x + threadIdx.x;
-    const int id = mtab[(size_t)g * 2 * MERGE_SLOTS + sl];
+    const int32_t* flags = merge_flags(mtab, n_scans, g);
+    const int distinct = flags[0], f_status = flags[1], f_need = flags[2];
+    if (f_need > 0 || f_status != 0 || distinct > MERGE_LIMIT) {
+        // -(2^20 + needed records per read) | overflow of the table | a read the scan refused
+        if (sl == 0) out_n[2 * g + 1] = f_status != 0 ? f_status : (f_need > 0 ? -(1 << 20) - f_need : PLAT_ERR_OVERFLOW);
+        return;
+    }
+    const int id = mtab[(size_t)g * 2 * MERGE_SLOTS + sl] - 1;
     if (id < 0) return;
     const int c = mtab[(size_t)g * 2 * MERGE_SLOTS + MERGE_SLOTS + sl];
     const int r0 = scan_read_begin[g], N = scan_read_begin[g + 1] - r0;
@@ -257,13 +280,19 @@ PLAT_EXPORT int plat_candidates_merge_batch(plat_ctx* ctx, const plat_candidate_
     if (!b.ref_seq || !b.read_seq || !b.read_pos || !read_end || !scan_read_begin || !scan_longest || !rec || !count || !status || !out_cand || !out_n)
         return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
-    int rcm = plat_reserve(ctx, ctx->merge_tab, (size_t)n_scans * 2 * plat::MERGE_SLOTS * sizeof(int32_t));
+    const size_t tab_bytes = ((size_t)n_scans * 2 * plat::MERGE_SLOTS + 4 * (size_t)n_scans) * sizeof(int32_t);
+    int rcm = plat_reserve(ctx, ctx->merge_tab, tab_bytes);
     if (rcm) return rcm;
     int32_t* mtab = (int32_t*)ctx->merge_tab.ptr;
-    hipLaunchKernelGGL(plat::k_candidates_merge, dim3((unsigned)n_scans), dim3(plat::MERGE_THREADS), 0, (hipStream_t)stream, b, read_end,
-                       scan_read_begin, scan_longest, max_per_read, rec, count, status, mtab, out_n);
+    PLAT_HIP(ctx, hipMemsetAsync(mtab, 0, tab_bytes, (hipStream_t)stream));
+    // a thread per read when the scans are of one size; a scan with more than its share is walked in strides
+    long long per = ((long long)b.n_reads + n_scans - 1) / n_scans;
+    unsigned gx = (unsigned)((per + 255) / 256);
+    gx = gx < 1 ? 1 : (gx > 4096 ? 4096 : gx);
+    hipLaunchKernelGGL(plat::k_candidates_merge, dim3(gx, (unsigned)n_scans), dim3(256), 0, (hipStream_t)stream, b,
+                       scan_read_begin, n_scans, max_per_read, rec, count, status, mtab, out_n);
     hipLaunchKernelGGL(plat::k_candidates_filter, dim3(plat::MERGE_SLOTS / 256, (unsigned)n_scans), dim3(256), 0, (hipStream_t)stream, b, read_end,
-                       scan_read_begin, scan_longest, rec, (const int32_t*)mtab, min_var_freq, cap_per_scan, out_cand, out_n);
+                       scan_read_begin, scan_longest, n_scans, rec, mtab, min_var_freq, cap_per_scan, out_cand, out_n);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }

@@ -263,8 +263,8 @@ def load():
     return _caller_lib
 
 
-def merge_record_texts(texts, lib=None):
-    """runner.py:301-352 natively: k-way merge of record texts (bytes, each sorted by (chromosome key, position)) -> one str."""
+def merge_record_texts(texts, lib=None, raw=False):
+    """runner.py:301-352 natively: k-way merge of record texts (bytes, each sorted by (chromosome key, position)) -> one str (bytes with raw=True)."""
     lib = lib if lib is not None else load()
     n = len(texts)
     arr = (C.c_char_p * max(n, 1))(*texts)
@@ -274,7 +274,8 @@ def merge_record_texts(texts, lib=None):
     if rc != 0:
         raise _lib.PlatypusDeviceError(rc, "merge failed", "plat_merge_record_texts")
     try:
-        return C.string_at(out, length.value).decode("ascii")
+        merged = C.string_at(out, length.value)
+        return merged if raw else merged.decode("ascii")
     finally:
         lib.plat_caller_free(out)
 
@@ -324,10 +325,11 @@ class NativeCaller:
         self.stats = st.as_dict()
         return out
 
-    def call_stream(self, n_regions, load, user, sample_names, options, n_slots, n_loaders=2):
+    def call_stream(self, n_regions, load, user, sample_names, options, n_slots, n_loaders=2, raw=False):
         """plat_call_regions_stream: regions loaded on demand.  `load`: a plat_region_load_fn -- the address of a native function (int,
         e.g. tools/synth's generator: no Python in the loader threads) or a Python callable (index, slot, region_struct) -> status (wrapped;
-        tests).  Returns the record lines of all regions (str), in region order."""
+        tests).  Returns the record lines of all regions in region order: str, or bytes with raw=True (a whole-genome share is ~100 MB of
+        text: every decode / encode of it is a pass through memory the caller may not want)."""
         nS = len(sample_names)
         keep = None
         if callable(load):
@@ -351,7 +353,9 @@ class NativeCaller:
         if rc != 0:
             raise _lib.PlatypusDeviceError(rc, (self.lib.plat_caller_last_error(self.h) or b"").decode(), "plat_call_regions_stream")
         try:
-            out = C.string_at(text, length.value).decode("ascii")
+            out = C.string_at(text, length.value)
+            if not raw:
+                out = out.decode("ascii")
         finally:
             self.lib.plat_caller_free(text)
         options.rlen = int(o.rlen)

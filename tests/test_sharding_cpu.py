@@ -101,3 +101,21 @@ def test_native_merge_of_record_texts_equals_the_python_merge():
             texts.append(t.encode())
         assert F.merge_record_texts(texts, lib=lib) == want
     assert F.merge_record_texts([], lib=lib) == "" and F.merge_record_texts([b"", b""], lib=lib) == ""
+
+
+def test_native_merge_on_a_text_large_enough_for_its_threads():
+    """Above a few MB the merge scans its texts in slices and copies the blocks on several threads: ~13 MB in three texts (regions dealt out
+    round robin, as ranks get them) against the Python merge."""
+    from platypus_amd import fastcaller as F
+    from tests import fakedev
+    lib = fakedev.fake_caller_lib()
+    pad = "X" * 90
+    streams = [[], [], []]
+    for g in range(900):
+        for p in range(0, 5000, 37):
+            streams[g % 3].append(("r%d" % g, p, "r%d\t%d\t.\tA\tC\t%s" % (g, p + 1, pad)))
+    want = "".join(ln + "\n" for ln in sharding.merge_record_streams(streams))
+    texts = ["".join(ln + "\n" for _, _, ln in s).encode() for s in streams]
+    assert sum(len(t) for t in texts) > 12 << 20
+    got = F.merge_record_texts(texts, lib=lib, raw=True)
+    assert got == want.encode()
