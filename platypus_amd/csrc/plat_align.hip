@@ -1649,8 +1649,15 @@ k_finalize_multi(const PairRec* __restrict__ pairs, const Job* __restrict__ jobs
 __global__ void __launch_bounds__(256)
 k_finalize_dense(const PairRec* __restrict__ pairs, const Job* __restrict__ jobs, const int32_t* __restrict__ job_score,
                  const double* __restrict__ mapq_lut, long long npairs, const int32_t* __restrict__ dense, long long segcap,
-                 const long long* __restrict__ cnt, long long extra_cap, double* __restrict__ out_ll, int32_t* __restrict__ out_score)
+                 const long long* __restrict__ cnt, long long extra_cap, double* __restrict__ out_ll, int32_t* __restrict__ out_score, long long* sticky)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // what the host would have checked after its read-backs is recorded in a pinned host word that plat_stream_sync returns
+        // (first error wins until it is read)
+        long long e = cnt[CNT_ERR];
+        if (e == 0 && cnt[CNT_NEXTRA] > extra_cap) e = PLAT_ERR_OVERFLOW;
+        if (e != 0 && *sticky == 0) *sticky = e;
+    }
     if (cnt[CNT_ERR] != 0 || cnt[CNT_NEXTRA] > extra_cap) return;
     long long ndense = 0;
 #pragma unroll
@@ -1796,7 +1803,8 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     hipLaunchKernelGGL(k_seed_slow, dim3(4096), dim3(64), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
                        (const SlowRec*)ctx->slow.ptr, tsize_max, maxhap, cw, dense, segcap);
-    hipLaunchKernelGGL(k_dense_total, dim3(1), dim3(1), 0, st, cnt, segcap);
+    if (!(shortcuts & SEED_LEAN))                              // (the asynchronous entry point reads nothing back: every kernel sums the segments itself)
+        hipLaunchKernelGGL(k_dense_total, dim3(1), dim3(1), 0, st, cnt, segcap);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -1846,7 +1854,11 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
     PLAT_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)CNT_AREA * sizeof(long long), st));
     plat_batch_hints hv = {};
     if (async) hv = *hints;
-    hipLaunchKernelGGL(k_validate, dim3(2048), dim3(256), 0, st, b, cnt, hap_win, win_rows, calc_flank_score);
+    {   // a wave per window, a thread per haplotype; a small batch (a chunk of the region loop) does not pay for 2048 workgroups
+        const long long want = std::max<long long>(((long long)b.n_windows * 64 + 255) / 256, ((long long)b.n_haps + 255) / 256);
+        hipLaunchKernelGGL(k_validate, dim3((unsigned)std::min<long long>(2048, std::max<long long>(1, want))), dim3(256), 0, st, b, cnt, hap_win,
+                           win_rows, calc_flank_score);
+    }
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, b, win_rows, tile_off, cnt, hv, async ? 1 : 0);
     PLAT_HIP(ctx, hipGetLastError());
     int64_t* hb = ctx->h_readback;
@@ -1964,14 +1976,13 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         const long long want = (ngrid + 255) / 256, fixed = 8ll * ctx->n_cu;
         hipLaunchKernelGGL(k_finalize_dense, dim3((unsigned)(want < fixed ? std::max(want, 1ll) : fixed)), dim3(256), 0, st,
                            (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr, (const int32_t*)ctx->job_score.ptr,
-                           ctx->d_mapq_lut, npairs, dense, segcap, cnt, extra_cap, out_loglik, out_score);
+                           ctx->d_mapq_lut, npairs, dense, segcap, cnt, extra_cap, out_loglik, out_score, (long long*)ctx->d_sticky);
     } else
         hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
                            (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr,
                            (const int32_t*)ctx->job_score.ptr, ctx->d_mapq_lut, npairs, cnt, extra_cap, out_loglik, out_score);
     PLAT_EV(ctx, 4, st);
-    if (async) {
-        hipLaunchKernelGGL(k_async_epilogue, dim3(1), dim3(1), 0, st, cnt, extra_cap, (long long*)ctx->d_sticky);
+    if (async) {                                               // (k_finalize_dense left the batch's verdict in the sticky word)
         PLAT_HIP(ctx, hipGetLastError());
         ctx->ev_valid_align = ctx->profile;
         ctx->prof_dp_jobs = 0; ctx->prof_dp_bytes = 0;

@@ -242,7 +242,7 @@ def _bind(lib):
                                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(CallerStats)]
     lib.plat_call_regions_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(CallerOptions), C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(CallerStats)]
-    lib.plat_merge_record_texts.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.plat_merge_record_texts.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.plat_caller_free.argtypes = [C.c_void_p]
     lib.plat_caller_free.restype = None
     lib.plat_caller_last_error.argtypes = [C.c_void_p]
@@ -263,21 +263,42 @@ def load():
     return _caller_lib
 
 
+def _native_text(lib, ptr, length, raw):
+    """What a call hands back for a malloc'ed text: str; bytes (raw=True); or, raw="view", the block itself as a ctypes char array (no
+    copy; freed with the array) -- a whole-genome share is ~100 MB of record text and every copy of it is a pass through memory."""
+    if raw == "view":
+        import weakref
+        arr = (C.c_char * length).from_address(ptr.value) if length else (C.c_char * 0)()
+        if length:
+            weakref.finalize(arr, lib.plat_caller_free, C.c_void_p(ptr.value))
+        else:
+            lib.plat_caller_free(ptr)
+        return arr
+    try:
+        out = C.string_at(ptr, length)
+        return out if raw else out.decode("ascii")
+    finally:
+        lib.plat_caller_free(ptr)
+
+
+def text_bytes(x):
+    """bytes of a text returned with raw=True / raw="view"."""
+    return x if isinstance(x, bytes) else bytes(x)
+
+
 def merge_record_texts(texts, lib=None, raw=False):
     """runner.py:301-352 natively: k-way merge of record texts (bytes, each sorted by (chromosome key, position)) -> one str (bytes with raw=True)."""
     lib = lib if lib is not None else load()
     n = len(texts)
-    arr = (C.c_char_p * max(n, 1))(*texts)
-    lens = (C.c_size_t * max(n, 1))(*[len(t) for t in texts])
+    keep = [t if isinstance(t, (bytes, C.Array)) else bytes(t) for t in texts]
+    arr = (C.c_void_p * max(n, 1))(*[C.cast(C.c_char_p(t), C.c_void_p).value if isinstance(t, bytes) else C.addressof(t) for t in keep])
+    lens = (C.c_size_t * max(n, 1))(*[len(t) for t in keep])
     out, length = C.c_void_p(), C.c_size_t()
     rc = lib.plat_merge_record_texts(arr, lens, n, C.byref(out), C.byref(length))
+    del keep
     if rc != 0:
         raise _lib.PlatypusDeviceError(rc, "merge failed", "plat_merge_record_texts")
-    try:
-        merged = C.string_at(out, length.value)
-        return merged if raw else merged.decode("ascii")
-    finally:
-        lib.plat_caller_free(out)
+    return _native_text(lib, out, length.value, raw)
 
 
 class NativeCaller:
@@ -352,12 +373,7 @@ class NativeCaller:
         del keep
         if rc != 0:
             raise _lib.PlatypusDeviceError(rc, (self.lib.plat_caller_last_error(self.h) or b"").decode(), "plat_call_regions_stream")
-        try:
-            out = C.string_at(text, length.value)
-            if not raw:
-                out = out.decode("ascii")
-        finally:
-            self.lib.plat_caller_free(text)
+        out = _native_text(self.lib, text, length.value, raw)
         options.rlen = int(o.rlen)
         self.stats = st.as_dict()
         return out

@@ -137,6 +137,7 @@ def config3_end_to_end(device, n_regions, rk=None, first=0, lib=None, region_kw=
     0-3 SNPs, 250 bp reads at 30x, 5 % of the bases below Q20) through the native region loop with --assemble=1: assembler tiles of every
     chunk in one plat_assemble_batch, their variants merged with the BAM candidates, then the called windows through the likelihoods at
     250 bp (buf = 500), EM, posteriors, records.  Regions are loaded on demand (tools/synth)."""
+    from platypus_amd import fastcaller as F
     workers = int(os.environ.get("PLAT_CALLER_WORKERS", "16"))
     kw = dict(flank=1500, read_len=250, model=CONFIG3_MODEL, **(region_kw or {}))
     r = config4(device, range(first, first + n_regions), 1500, workers, int(os.environ.get("PLAT_CALLER_CHUNK3", "32")), repeats=1, region_kw=kw, rk=rk,
@@ -150,7 +151,7 @@ def config3_end_to_end(device, n_regions, rk=None, first=0, lib=None, region_kw=
                            "runs at least one DP for every pair it does not skip",
                 host_seconds_per_region=st["seconds_host"] / r["regions"], device_wait_seconds_per_region=st["seconds_device_wait"] / r["regions"],
                 assemble_seconds_per_region=st["seconds_assemble"] / r["regions"], host_threads=r["workers"], regions_per_chunk=r["per_chunk"],
-                text=r["text"].decode("ascii"))
+                text=F.text_bytes(r["text"]).decode("ascii"))
 
 
 def line_config3(a, rk):
@@ -214,16 +215,16 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
         opts = default_options(**(options_kw or {}))
         rk.barrier()
         t0 = time.perf_counter()
-        text = nc.call_stream(len(indices), src.load_fn, src.h, names, opts, n_slots, loaders, raw=True)      # bytes: no decode / encode passes
+        text = nc.call_stream(len(indices), src.load_fn, src.h, names, opts, n_slots, loaders, raw="view")    # the native block itself: no copy, no decode / encode passes
         t1 = time.perf_counter()
         got = rk.gather(text)                                                # every rank's record lines to rank 0 ...
         if got is not None:
-            merged = F.merge_record_texts(got, lib=lib, raw=True)            # ... merged there by (chromosome, position), runner.py:301-352
+            merged = F.merge_record_texts(got, lib=lib, raw="view")           # ... merged there by (chromosome, position), runner.py:301-352
         t2 = time.perf_counter()
         rk.barrier()
         st = dict(nc.stats)
         runs.append((t2 - t0, t1 - t0))
-        gather = dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=len(got) if got else None, records=merged.count(b"\n") if merged is not None else None)
+        gather = dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=len(got) if got else None, records=F.text_bytes(merged).count(b"\n") if merged is not None else None)
     planted = (src.planted - planted0) // max(1, repeats)
     phases = {k: v / max(1, (repeats * len(indices) + nwarm)) for k, v in src.phase_seconds.items()}
     nc.close()
@@ -240,7 +241,7 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
     synthetic 30x genome), region i -> rank i % N (runner.py:473-474); every rank streams its share through the region loop,
     the record lines travel to rank 0 (sizes all-gather + point to point) and are merged by (chrom, pos) (runner.py:301-352).  The timed
     region covers loading (generating) the regions, the calls, the gather and the merge."""
-    from platypus_amd import sharding
+    from platypus_amd import fastcaller as F, sharding
     rank, world = rk.rank, rk.world
     total = a.regions or 3875 * world
     mine = sharding.regions_for_rank(total, rank, world)
@@ -275,7 +276,7 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
             "stage_seconds_per_region": {k: v / max(1, r["regions"]) for k, v in st["seconds_stage"].items()},
             "record_gather": r["gather"], "python_region_loop_windows_per_sec_round1": 1100.0}
     if rank == 0:
-        line["merged_text"] = r["merged"].decode("ascii")                               # (popped by bench.py before printing; the tests read it)
+        line["merged_text"] = F.text_bytes(r["merged"]).decode("ascii")                               # (popped by bench.py before printing; the tests read it)
     return line
 
 
