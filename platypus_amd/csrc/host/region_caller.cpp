@@ -794,6 +794,7 @@ struct Chunk {
             }
         };
         if (!hostTally && o.getVariantsFromBAMs) {
+            PROF("s2.rv.cands");
             // merged and filtered on the device (plat_candidates_merge_batch): the scan's candidates in the order of their first records
             for (size_t i = 0; i < r.samples.size(); ++i) {
                 const TableView& tv = r.samples[i].reads;
@@ -862,6 +863,7 @@ struct Chunk {
                 if (frac >= o.minVarFreq || k.nadd != k.nrem) pass(k.pos, k.rem, k.nrem, k.add, k.nadd, k.count);
             }
         }
+        PROF("s2.rv.norm_filter");
         std::stable_sort(everyone.begin(), everyone.end(), variantLess);    // getCandidates(): sorted(values)
         everyone.insert(everyone.end(), r.asmVariants.begin(), r.asmVariants.end());      // rawBamVariants + assemblerVariants (:521)
         VarList norm;
@@ -959,10 +961,11 @@ struct Chunk {
         w.hapStart = std::max(0, w.startPos);
         w.hapEnd = (int)std::min<int64_t>(w.endPos, r.fa.len - 1);
         w.endBuf = std::min(2 * r.rlen, 500);                               // chaplotype.pyx:142
-        w.refSeq = haplotypeSequence(r.fa, w.hapStart, w.hapEnd, w.endBuf, VarList());
+        { PROF("s2.pw.refseq"); w.refSeq = haplotypeSequence(r.fa, w.hapStart, w.hapEnd, w.endBuf, VarList()); }
         if (w.refSeq.size() > 16384) throw WindowError("Haplotype is too long. Max allowed length is 16384");
         w.ptrs.resize(r.samples.size());
         w.nReads = 0;
+        PROF("s2.pw.rest");
         for (size_t i = 0; i < r.samples.size(); ++i) {                    // bamReadBuffer.setWindowPointers (cwindow.pyx:655-689)
             Ptrs& p = w.ptrs[i];
             r.samples[i].reads.overlapRange(w.startPos, w.endPos, p.gs, p.ge);
@@ -997,7 +1000,7 @@ struct Chunk {
                     for (int j = i + 1; j < n; ++j) idx[(size_t)j] = idx[(size_t)j - 1] + 1;
                 }
             }
-            finishHaplotypes(r, w, haps);
+            { PROF("s2.pw.finishHaps"); finishHaplotypes(r, w, haps); }
             return;
         }
         // greedy growth of the best haplotypes, one variant at a time (most supported first); the alignments of a step are
@@ -1154,6 +1157,7 @@ struct Chunk {
         BatchBuilder b;
         b.nInd = nInd;
         for (WindowWork* w : wins) {
+            PROF("s4.build");
             RegionWork& r = *regions[(size_t)regionSlot(w->region)];
             w->bw = b.nWindows();
             b.beginWindow(w->hapStart, w->hapEnd, w->endBuf);
@@ -1167,7 +1171,8 @@ struct Chunk {
             }
             b.endWindow();
         }
-        DeviceBatch db = runWindows(z, b, o, true, false);
+        DeviceBatch db;
+        { PROF("s4.runWindows"); db = runWindows(z, b, o, true, false); }
         { std::lock_guard<std::mutex> g(stMutex); st.n_pairs += db.nPairs; }
         lap(4);
 
@@ -1177,6 +1182,7 @@ struct Chunk {
         std::vector<uint8_t> pmask;
         std::vector<double> pprior;
         for (WindowWork* w : wins) {
+            PROF("s5.build");
             RegionWork& r = *regions[(size_t)regionSlot(w->region)];
             w->distinct.clear();
             for (const Hap& h : w->haps)

@@ -189,7 +189,7 @@ constexpr int PREP_LMAX = 448;          // reads up to this length are staged th
 
 __global__ void __launch_bounds__(256)
 k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const long long* __restrict__ tile_off,
-             uint16_t* __restrict__ codes, ReadInfo* __restrict__ rinfo, long long* cnt, int qoff)
+             uint16_t* __restrict__ codes, ReadInfo* __restrict__ rinfo, long long* cnt, int qoff, int xcd)
 // qoff = byte offset of the quality image in the dynamic LDS (= 64 * min(longest read, PREP_LMAX) + 32); the bit-plane
 // accumulators of staged windows follow at 2 * qoff (1 KB per 64-base chunk).
 // `codes` holds, per window and in the tile's footprint (2 bytes per tile element), the reads' 2-bit base codes
@@ -206,7 +206,13 @@ k_prep_reads(plat_window_batch b, const int32_t* __restrict__ win_rows, const lo
     __shared__ unsigned s_qsum[64];                      // sum of the base qualities of read rl (picks the DP's add flavour)
     __shared__ unsigned s_qmin[64];                      // smallest base quality of read rl (k_seed's ungapped-alignment proof)
     __shared__ unsigned s_nlow[64];                      // number of bases of read rl with quality < LOWQ (same proof)
-    const int w = blockIdx.x;
+    // (grid.x a multiple of 8: XCD x -- workgroups go to the XCDs round robin -- takes the x-th eighth of the windows, the eighth whose
+    // haplotypes k_seed gives to the same XCD: what this kernel writes is what that one reads, and some of it is still in that L2)
+    int w = blockIdx.x;
+    if (xcd) {
+        w = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+        if (w >= b.n_windows) return;
+    }
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
     if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
     const int c0 = (int)blockIdx.y * 64;
@@ -1893,8 +1899,13 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
     const size_t prep_lds = (size_t)2 * prep_qoff + (size_t)((std::min(maxread, PREP_LMAX) + 63) >> 6) * 1024;
     if (prep_lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_prep_reads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
-    hipLaunchKernelGGL(k_prep_reads, dim3(b.n_windows, prep_groups), dim3(256), prep_lds, st, b, win_rows, tile_off,
-                       (uint16_t*)ctx->codes.ptr, (ReadInfo*)ctx->rinfo.ptr, cnt, prep_qoff);
+    {
+        const char* e_x = getenv("PLAT_SEED_XCD");           // (read per call; 0 = window w on workgroup w)
+        const bool xcd = !(e_x && e_x[0] == '0') && b.n_windows >= 64;
+        const unsigned gx = xcd ? (unsigned)((b.n_windows + 7) / 8) * 8u : (unsigned)b.n_windows;
+        hipLaunchKernelGGL(k_prep_reads, dim3(gx, prep_groups), dim3(256), prep_lds, st, b, win_rows, tile_off,
+                           (uint16_t*)ctx->codes.ptr, (ReadInfo*)ctx->rinfo.ptr, cnt, prep_qoff, xcd ? 1 : 0);
+    }
     long long njobs = 0;
     PLAT_EV(ctx, 1, st);
     for (int attempt = 0; attempt < 2; ++attempt) {

@@ -200,7 +200,7 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
             granted = effective_cpus()
         except Exception:
             granted = workers
-        loaders = int(os.environ.get("PLAT_CALLER_LOADERS", str(max(2, min(12, granted // 2)))))
+        loaders = int(os.environ.get("PLAT_CALLER_LOADERS", str(max(2, min(12, granted * 5 // 8)))))
     n_slots = per_chunk * (workers + 2) + loaders
     kw = dict(region_len=region_len, n_samples=n_samples, packed=packed, pin=pin, **(region_kw or {}))
     src = source.RegionSource(indices, n_slots, **kw)
@@ -246,12 +246,14 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
     total = a.regions or 3875 * world
     mine = sharding.regions_for_rank(total, rank, world)
     cpus = getattr(rk, "cpus", 16)                                           # what the box grants this rank (cgroup quota / share of the node)
-    workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus)))))
-    os.environ.setdefault("PLAT_CALLER_LOADERS", str(max(2, min(12, cpus // 2))))
+    # worker and loader threads share the rank's CPUs (workers sleep while the device works on their chunk): 10 + 10 on the 16 CPUs one
+    # GPU box grants measured best (tools/run_r3_g.sh: 16 + 8 684 k, 12 + 8 698 k, 10 + 10 727 k windows/s)
+    workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus * 5 // 8)))))
+    os.environ.setdefault("PLAT_CALLER_LOADERS", str(max(2, min(12, cpus * 5 // 8))))
     per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "4"))
     pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1" and lib is None
     packed = os.environ.get("PLAT_CALLER_PACKED", "1") == "1"
-    repeats = max(1, min(a.steps, 3)) if total <= 512 * world else 1
+    repeats = max(1, min(a.steps, 3))                                        # the line is the MEAN over the runs
     r = config4(rk.dev_index, mine, region_len, workers, per_chunk, repeats=repeats, pin=pin, lib=lib, region_kw=region_kw, rk=rk, packed=packed)
     T, (wins, regs, recs, reads, tcall, inb) = rk.reduce(r["T"], [r["windows"], r["regions"], r["records"], r["reads"], r["T_call"], r["input_bytes"]])
     st = r["stats"]
@@ -319,10 +321,16 @@ def summary(eng):
                                     roofline=_roof("k_assemble", r["alg_bytes"], r["kernel_ms"], "latency bound at 4 waves per SIMD, see DESIGN.md"),
                                     end_to_end=e2e)
     nreg = int(os.environ.get("PLAT_BENCH_CONFIG4_REGIONS", "3875"))           # one GPU's share of the 31 000 regions (SURVEY 8(d) cfg 4)
-    r = config4(0, range(nreg), 100000, int(os.environ.get("PLAT_CALLER_WORKERS", "16")), int(os.environ.get("PLAT_CALLER_CHUNK", "4")), repeats=1)
+    try:
+        from bench import effective_cpus
+        cpus = effective_cpus()
+    except Exception:
+        cpus = 16
+    r = config4(0, range(nreg), 100000, int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus * 5 // 8))))),
+                int(os.environ.get("PLAT_CALLER_CHUNK", "4")), repeats=3)     # the mean of three runs over the whole share
     st = r["stats"]
     out["config4_region_pipeline"] = dict(regions=r["regions"], region_len=r["region_len"], reads=r["reads"], windows=r["windows"], records=r["records"],
-                                          planted_variants=r["planted"], timed_s=r["T"], windows_per_sec=r["windows"] / r["T"],
+                                          planted_variants=r["planted"], timed_s=r["T"], timed_s_runs=r["T_runs"], windows_per_sec=r["windows"] / r["T"],
                                           regions_per_sec=r["regions"] / r["T"], reads_per_sec=r["reads"] / r["T"],
                                           host_seconds_per_region=st["seconds_host"] / r["regions"],
                                           device_wait_seconds_per_region=st["seconds_device_wait"] / r["regions"],
@@ -332,5 +340,5 @@ def summary(eng):
                                           host_threads=r["workers"], loader_threads=r["loaders"], regions_per_chunk=r["per_chunk"],
                                           read_encoding="packed (1 B/base)" if r["packed"] else "ascii (2 B/base)",
                                           what="regions generated on demand into pinned slots (region source) -> native region loop -> VCF record text; "
-                                               "one run over the whole share, no best-of")
+                                               "timed_s = the MEAN of three runs over the whole share (timed_s_runs), no best-of")
     return out
