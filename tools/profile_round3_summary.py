@@ -75,7 +75,7 @@ def main(o):
     try:
         commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:
-        commit = None
+        commit = os.environ.get("PLAT_COMMIT")                          # (the GPU box holds a snapshot without .git: the caller passes it)
     stamp = {"date": datetime.date.today().isoformat(), "commit": commit, "round": 3}
     if per:
         d.update(kernel="k_dp_jobs", **pack(per["plat::k_dp_jobs<false>"]))
