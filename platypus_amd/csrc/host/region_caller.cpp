@@ -780,7 +780,12 @@ struct Chunk {
         std::unordered_map<std::string, Variant*> everyoneIndex;
         // a candidate of one sample that passed the support filter joins the all-samples dictionary: equal variants of different
         // samples merge (addVariantToList, variant.pyx:499-527)
+        const bool oneSample = r.samples.size() == 1;                       // a sample's candidates are distinct already: nothing to merge them with
         auto pass = [&](int pos, const char* rem, int nrem, const char* add, int nadd, int count) {
+            if (oneSample) {
+                everyone.push_back(r.pool.make(pos, std::string(rem, (size_t)nrem), std::string(add, (size_t)nadd), count, PLATYPUS_VAR));
+                return;
+            }
             std::string key = std::to_string(pos);
             key += '|'; key.append(rem, (size_t)nrem); key += '|'; key.append(add, (size_t)nadd);
             auto it = everyoneIndex.find(key);

@@ -101,17 +101,23 @@ inline void annotate(const std::string& sequence, std::vector<int>& sizes, std::
     sizes.assign(L, 1); disps.assign(L, 1);
     if (L == 0) return;
     const int ext = L + 80 + MAX_UNIT_LENGTH;
-    std::vector<int> code(ext + MAX_UNIT_LENGTH, 0);
+    // (scratch kept per thread: this runs once per indel candidate of every region)
+    static thread_local std::vector<int> code, nxAll;
+    code.assign((size_t)(ext + MAX_UNIT_LENGTH), 0);
     for (int i = 0; i < L; ++i) {
         const int b = sequence[i] & 0xDF;
         const long long idx = i;
         const int noise = (int)((((idx % 257) * (1 + idx % 257)) / 2 + (idx % 5)) % 4);
         code[i] = b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : noise;
     }
-    std::vector<std::vector<int>> nx(MAX_UNIT_LENGTH);
+    const size_t stride = (size_t)ext + 1;
+    nxAll.resize(stride * MAX_UNIT_LENGTH);
+    int* nx[MAX_UNIT_LENGTH];
     for (int d = 1; d < MAX_UNIT_LENGTH; ++d) {
-        nx[d].assign(ext + 1, ext);
-        for (int i = ext - 1; i >= 0; --i) nx[d][i] = code[i] != code[i + d] ? i : nx[d][i + 1];
+        int* row = nxAll.data() + stride * (size_t)d;
+        nx[d] = row;
+        row[ext] = ext;
+        for (int i = ext - 1; i >= 0; --i) row[i] = code[i] != code[i + d] ? i : row[i + 1];
     }
     for (int g = 0; g < L; g += 4)
         for (int d = 1; d < MAX_UNIT_LENGTH; ++d) {
