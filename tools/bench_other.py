@@ -206,7 +206,9 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
     src = source.RegionSource(indices, n_slots, **kw)
     names = ["S%d" % (i + 1) for i in range(n_samples)]
     nc = F.NativeCaller(device, workers, per_chunk, lib=lib)
-    nwarm = min(len(indices), warm_regions if warm_regions is not None else 2 * per_chunk * workers)
+    # (the timed runs are the steady state of a long job: the warm pass is long enough for every slot, pinned block and scratch buffer to have
+    # been through its first use -- the first of three timed runs was still a fifth slower than the others after 80 regions)
+    nwarm = min(len(indices), warm_regions if warm_regions is not None else max(2 * per_chunk * workers, 512))
     if nwarm:                                                                 # every worker's scratch buffers at full size, code paths warm
         nc.call_stream(nwarm, src.load_fn, src.h, names, default_options(**(options_kw or {})), n_slots, loaders)
     runs, text, merged, gather, st = [], "", None, None, None
