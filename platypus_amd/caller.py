@@ -75,6 +75,14 @@ def _assemblerVariants(regions, refFile, options):
     return out
 
 
+def _py2_heap_order(heap):
+    """The values of a VariantCandidateGenerator.variantHeap in the order the reference's Python-2 dictionary would yield them: keys
+    hash as (refName, refPos, removed, added) (variant.pyx:270-280), were inserted in first-occurrence order and never deleted."""
+    from .vcfrecords import py2_dict_slot_order, py2_variant_hash
+    vs = list(heap.values())
+    return [vs[k] for k in py2_dict_slot_order([py2_variant_hash(v.refName, v.refPos, v.removed, v.added) for v in vs])]
+
+
 def generateVariantsInRegions(regions, refFile, options):
     """generateVariantsInRegion for a list of (chrom, start, end, readBuffers): ONE candidate scan on the device for every
     sample of every region, then the reference's per-sample support filter, merge, left-normalisation and filterVariants.
@@ -111,10 +119,19 @@ def generateVariantsInRegions(regions, refFile, options):
                 tally[key] = tally.get(key, 0) + 1
             for (pos, removed, added), n in tally.items():
                 g.addVariantToList(H.Variant(chrom, pos, removed, added, n, H.PLATYPUS_VAR))
-            for v in g.variantHeap.values():                                     # :456-467: per-sample support, indels always
-                if computeVariantReadSupportFrac(v, b) >= options.minVarFreq or v.nAdded != v.nRemoved:
-                    everyone.addVariantToList(v)
-        merged.append(everyone.getCandidates(0))
+        # :456-467: per-sample support, indels always.  Both dictionaries are walked in the order a Python-2 dict holds Variant keys
+        # (`variantHeap.iteritems()`, `sorted(variantHeap.values())`): it decides the order of candidates that compare equal -- two
+        # alleles of one type and length at one position.  Only then is that order worked out (_py2_heap_order replays the insertions)
+        for exact in (False, True):
+            everyone = mk(chrom, start, end)
+            for g, b in zip(gs, buffers):
+                for v in (_py2_heap_order(g.variantHeap) if exact else g.variantHeap.values()):
+                    if computeVariantReadSupportFrac(v, b) >= options.minVarFreq or v.nAdded != v.nRemoved:
+                        everyone.addVariantToList(H.Variant(v.refName, v.refPos, v.removed, v.added, v.nSupportingReads, v.varSource) if not exact else v)
+            cands = sorted(_py2_heap_order(everyone.variantHeap) if exact else everyone.variantHeap.values())
+            if exact or not any(not (a < c) and not (c < a) for a, c in zip(cands, cands[1:])):
+                break
+        merged.append(cands)
         if longest > 0:                                                          # :476-488
             rlen = options.maxSize if longest >= options.maxSize else longest
         rlens.append(rlen)

@@ -235,6 +235,52 @@ inline double computeStrandBiasPValue(long nFwdReads, long nRevReads, long nFwdV
 }
 
 // ---- INFO -------------------------------------------------------------------------------------------------------------------
+// hash(tuple) of CPython 2.7 (tupleobject.c tuplehash) from the items' hashes, as the unsigned value a dict's table is indexed with
+inline uint64_t py2_tuple_hash(const uint64_t* itemHashes, int n) {
+    uint64_t x = 0x345678ull, mult = 1000003ull;
+    for (int i = 0; i < n; ++i) {
+        const int left = n - 1 - i;
+        x = (x ^ itemHashes[i]) * mult;
+        mult += (uint64_t)(82520ll + left + left);
+    }
+    x += 97531ull;
+    return x == ~0ull ? ~0ull - 1 : x;
+}
+// hash(Variant) there: hash((refName, refPos, removed, added)), variant.pyx:270-280 (refPos >= 0: hash(int) is the int)
+inline uint64_t py2_variant_hash(uint64_t refNameHash, long long refPos, const char* removed, size_t nRemoved, const char* added, size_t nAdded) {
+    const uint64_t h[4] = {refNameHash, (uint64_t)(refPos == -1 ? -2 : refPos), py2_string_hash(std::string(removed, nRemoved)),
+                           py2_string_hash(std::string(added, nAdded))};
+    return py2_tuple_hash(h, 4);
+}
+// Iteration order of a Python-2 dict into which DISTINCT keys with these hashes were inserted in this order and never deleted
+// (dictobject.c: a new key takes the first empty slot of its probe sequence i = 5 i + perturb + 1, perturb >>= 5; the table of 8 slots
+// is rebuilt 4 x used (2 x above 50 000 keys) slots large, in slot order, when it is two thirds full): indices into `hashes`
+inline std::vector<int> py2_dict_slot_order(const std::vector<uint64_t>& hashes) {
+    std::vector<int> table(8, -1);
+    auto place = [&](std::vector<int>& t, int key) {
+        const uint64_t h = hashes[(size_t)key], mask = t.size() - 1;
+        uint64_t i = h & mask, perturb = h;
+        while (t[i & mask] >= 0) { i = 5 * i + perturb + 1; perturb >>= 5; }
+        t[i & mask] = key;
+    };
+    size_t used = 0;
+    for (int key = 0; key < (int)hashes.size(); ++key) {
+        place(table, key);
+        ++used;
+        if (used * 3 >= table.size() * 2) {
+            size_t size = 8;
+            while (size <= used * (used > 50000 ? 2 : 4)) size <<= 1;
+            std::vector<int> grown(size, -1);
+            for (int k : table) if (k >= 0) place(grown, k);
+            table.swap(grown);
+        }
+    }
+    std::vector<int> out;
+    out.reserve(hashes.size());
+    for (int k : table) if (k >= 0) out.push_back(k);
+    return out;
+}
+
 struct Num {                                                              // a Python number as it reaches the text: int or float
     bool isInt = true; long long i = 0; double d = 0.0;
     static Num I(long long v) { Num n; n.isInt = true; n.i = v; n.d = (double)v; return n; }

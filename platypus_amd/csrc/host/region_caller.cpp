@@ -614,6 +614,7 @@ struct Chunk {
             Layout LO;
             LO.add(z.c_cnt, nGood); LO.add(z.c_status, nGood); LO.add(z.c_rec, nGood * (size_t)maxPerRead * 5);
             LO.commit(z, z.a_cout);
+            recArenaBytes = LO.total; recordsOnHost = false;
             ck(plat_candidates_batch(z.ctx, &cb, o.minFlank, o.minBaseQual, o.genSNPs, o.genIndels, maxPerRead, z.t_region.d, z.c_rec.d, z.c_cnt.d,
                                      z.c_status.d, z.stream), "plat_candidates_batch");
             int need = 0;
@@ -637,6 +638,7 @@ struct Chunk {
             }
             LO.download(z, z.a_cout);
             z.sync("candidate scan");
+            recordsOnHost = true;
             for (size_t i = 0; i < nGood; ++i) {
                 if (z.c_status.h[i] == PLAT_ERR_BAD_INPUT) throw DeviceError(PLAT_ERR_BAD_INPUT, "a read reaches outside the reference window handed over");
                 if (z.c_status.h[i] == PLAT_ERR_OVERFLOW) need = std::max(need, z.c_cnt.h[i]);
@@ -774,6 +776,61 @@ struct Chunk {
     int asmMaxVars = 64, asmBlob = 4096;
 
     // -- B1: candidates of one region -> merged, per-sample support filter, left-normalised, filtered (variantcaller.pyx:439-531)
+    // one sample's variantHeap: its distinct records in first-occurrence order with the number of reads showing each (addVariantToList),
+    // from the scan's records on the host
+    struct CandKey { int pos, nrem, nadd, count; const char* rem; const char* add; };
+    void tallySample(const RegionWork& r, size_t i, std::vector<CandKey>& keys, std::deque<std::string>& addedStore, int64_t* nRecords) {
+        Slot& z = s;
+        const TableView& tv = r.samples[i].reads;
+        keys.clear();
+        std::vector<int32_t> table;                                         // open addressing over `keys` (index + 1, 0 = empty)
+        size_t tmask = 4095;
+        table.assign(tmask + 1, 0);
+        auto hashKey = [](const CandKey& k) -> size_t {
+            size_t h = (size_t)k.pos * 1000003u + (size_t)k.nrem * 131u + (size_t)k.nadd;
+            for (int j = 0; j < k.nrem; ++j) h = h * 31u + (unsigned char)k.rem[j];
+            for (int j = 0; j < k.nadd; ++j) h = h * 37u + (unsigned char)k.add[j];
+            return h * 0x9E3779B97F4A7C15ull >> 20;
+        };
+        auto sameKey = [](const CandKey& a, const CandKey& b) {
+            return a.pos == b.pos && a.nrem == b.nrem && a.nadd == b.nadd && memcmp(a.rem, b.rem, (size_t)a.nrem) == 0 && memcmp(a.add, b.add, (size_t)a.nadd) == 0;
+        };
+        const int64_t blobBase = tv.n() ? z.t_off.h[tv.base] : 0;
+        for (int q = 0; q < tv.n(); ++q) {
+            const size_t g = (size_t)(tv.base + q);
+            const int cnt = z.c_cnt.h[g];
+            for (int k = 0; k < cnt; ++k) {
+                const int32_t* rec = z.c_rec.h + 5 * (g * (size_t)maxPerRead + (size_t)k);
+                const char* addp = "";
+                if (rec[2]) {
+                    if (tv.t->encoding == PLAT_READS_ASCII) addp = (const char*)tv.t->seq + (rec[4] - blobBase);
+                    else { addedStore.push_back(tableBases(*tv.t, rec[4] - blobBase, rec[2])); addp = addedStore.back().data(); }
+                }
+                CandKey key{std::max(0, rec[0]), rec[1], rec[2], 1, rec[1] ? refBlob.data() + rec[3] : "", addp};
+                if (nRecords) ++*nRecords;
+                size_t slot = hashKey(key) & tmask;
+                while (table[slot] && !sameKey(keys[(size_t)table[slot] - 1], key)) slot = (slot + 1) & tmask;
+                if (table[slot]) { ++keys[(size_t)table[slot] - 1].count; continue; }    // one more read showing it (addVariantToList)
+                keys.push_back(key);
+                table[slot] = (int32_t)keys.size();
+                if (keys.size() * 2 > tmask) {                          // grow
+                    tmask = tmask * 2 + 1;
+                    table.assign(tmask + 1, 0);
+                    for (size_t e = 0; e < keys.size(); ++e) { size_t s2 = hashKey(keys[e]) & tmask; while (table[s2]) s2 = (s2 + 1) & tmask; table[s2] = (int32_t)e + 1; }
+                }
+            }
+        }
+    }
+    // :456-467: per-sample support, indels always
+    bool passesSupport(const RegionWork& r, size_t i, const CandKey& k) const {
+        int s0, e0;
+        r.samples[i].reads.overlapRange(k.pos, k.pos + 1, s0, e0);
+        const int total = e0 - s0;
+        const double frac = total == 0 ? 0.0 : (double)k.count / total;
+        return frac >= o.minVarFreq || k.nadd != k.nrem;
+    }
+
+    // -- B1: candidates of one region -> merged, per-sample support filter, left-normalised, filtered (variantcaller.pyx:439-531)
     void regionVariants(RegionWork& r, int scan0) {
         Slot& z = s;
         VarList everyone;                                                   // the all-samples generator's variantHeap, insertion order
@@ -815,67 +872,63 @@ struct Chunk {
                 }
             }
         }
-        struct Key { int pos, nrem, nadd, count; const char* rem; const char* add; };
-        std::vector<Key> keys;                                              // this sample's variantHeap: distinct records, first-occurrence order
+        std::vector<CandKey> keys;                                          // a sample's variantHeap: distinct records, first-occurrence order
         std::deque<std::string> addedStore;                                 // (letters of the added bases when the table is not ASCII)
-        std::vector<int32_t> table;                                         // open addressing over `keys` (index + 1, 0 = empty)
         for (size_t i = 0; hostTally && o.getVariantsFromBAMs && i < r.samples.size(); ++i) {
-            const TableView& tv = r.samples[i].reads;
-            keys.clear();
-            size_t tmask = 4095;
-            table.assign(tmask + 1, 0);
-            auto hashKey = [](const Key& k) -> size_t {
-                size_t h = (size_t)k.pos * 1000003u + (size_t)k.nrem * 131u + (size_t)k.nadd;
-                for (int j = 0; j < k.nrem; ++j) h = h * 31u + (unsigned char)k.rem[j];
-                for (int j = 0; j < k.nadd; ++j) h = h * 37u + (unsigned char)k.add[j];
-                return h * 0x9E3779B97F4A7C15ull >> 20;
-            };
-            auto sameKey = [](const Key& a, const Key& b) {
-                return a.pos == b.pos && a.nrem == b.nrem && a.nadd == b.nadd && memcmp(a.rem, b.rem, (size_t)a.nrem) == 0 && memcmp(a.add, b.add, (size_t)a.nadd) == 0;
-            };
-            const int64_t blobBase = tv.n() ? z.t_off.h[tv.base] : 0;
-            for (int q = 0; q < tv.n(); ++q) {
-                const size_t g = (size_t)(tv.base + q);
-                const int cnt = z.c_cnt.h[g];
-                for (int k = 0; k < cnt; ++k) {
-                    const int32_t* rec = z.c_rec.h + 5 * (g * (size_t)maxPerRead + (size_t)k);
-                    const char* addp = "";
-                    if (rec[2]) {
-                        if (tv.t->encoding == PLAT_READS_ASCII) addp = (const char*)tv.t->seq + (rec[4] - blobBase);
-                        else { addedStore.push_back(tableBases(*tv.t, rec[4] - blobBase, rec[2])); addp = addedStore.back().data(); }
-                    }
-                    Key key{std::max(0, rec[0]), rec[1], rec[2], 1, rec[1] ? refBlob.data() + rec[3] : "", addp};
-                    ++r.nCandRecords;
-                    size_t slot = hashKey(key) & tmask;
-                    while (table[slot] && !sameKey(keys[(size_t)table[slot] - 1], key)) slot = (slot + 1) & tmask;
-                    if (table[slot]) { ++keys[(size_t)table[slot] - 1].count; continue; }    // one more read showing it (addVariantToList)
-                    keys.push_back(key);
-                    table[slot] = (int32_t)keys.size();
-                    if (keys.size() * 2 > tmask) {                          // grow
-                        tmask = tmask * 2 + 1;
-                        table.assign(tmask + 1, 0);
-                        for (size_t e = 0; e < keys.size(); ++e) { size_t s2 = hashKey(keys[e]) & tmask; while (table[s2]) s2 = (s2 + 1) & tmask; table[s2] = (int32_t)e + 1; }
+            tallySample(r, i, keys, addedStore, &r.nCandRecords);
+            // Only the candidates that pass become Variant objects (the sample's own heap is not looked at again).
+            for (const CandKey& k : keys) if (passesSupport(r, i, k)) pass(k.pos, k.rem, k.nrem, k.add, k.nadd, k.count);
+        }
+        std::stable_sort(everyone.begin(), everyone.end(), variantLess);    // getCandidates(): sorted(values)
+        // `sorted` is stable: candidates that compare equal (two alleles of one type and length at one position) stay in the order the
+        // all-samples dictionary yields them, a Python-2 dict keyed by Variant (hash of (refName, refPos, removed, added),
+        // variant.pyx:270-280) that was filled while walking each sample's dictionary of the same kind (variantcaller.pyx:457).  Every
+        // other order is decided by the keys, so only a region that holds such a pair pays for replaying the dictionaries.
+        bool ties = false;
+        for (size_t k = 1; k < everyone.size() && !ties; ++k) ties = !variantLess(everyone[k - 1], everyone[k]) && !variantLess(everyone[k], everyone[k - 1]);
+        if (ties && o.getVariantsFromBAMs && !getenv("PLAT_CALLER_FIRST_OCCURRENCE_ORDER")) {      // (the switch: tests only, to show the replay matters)
+            if (!hostTally && !recordsOnHost) {                             // the scan's records are still on the device
+                if (recArenaBytes) ck(plat_memcpy_d2h(z.ctx, z.a_cout.h, z.a_cout.d, recArenaBytes, z.stream), "plat_memcpy_d2h");
+                z.sync("candidate records");
+                recordsOnHost = true;
+            }
+            const uint64_t nameHash = py2_string_hash(r.in->chrom ? std::string(r.in->chrom) : std::string());
+            VarList all;
+            std::vector<uint64_t> allHash;
+            std::unordered_map<std::string, size_t> allIndex;
+            for (size_t i = 0; i < r.samples.size(); ++i) {
+                tallySample(r, i, keys, addedStore, nullptr);
+                std::vector<uint64_t> hs(keys.size());
+                for (size_t k = 0; k < keys.size(); ++k) hs[k] = py2_variant_hash(nameHash, keys[k].pos, keys[k].rem, (size_t)keys[k].nrem, keys[k].add, (size_t)keys[k].nadd);
+                for (int k : py2_dict_slot_order(hs)) {                     // varCandGen.variantHeap.iteritems()
+                    const CandKey& c = keys[(size_t)k];
+                    if (!passesSupport(r, i, c)) continue;
+                    std::string key = std::to_string(c.pos);
+                    key += '|'; key.append(c.rem, (size_t)c.nrem); key += '|'; key.append(c.add, (size_t)c.nadd);
+                    auto it = allIndex.find(key);
+                    if (it != allIndex.end()) {
+                        Variant tmp(c.pos, std::string(), std::string(), c.count, PLATYPUS_VAR);
+                        all[it->second]->addVariant(tmp);
+                    } else {
+                        allIndex.emplace(std::move(key), all.size());
+                        all.push_back(r.pool.make(c.pos, std::string(c.rem, (size_t)c.nrem), std::string(c.add, (size_t)c.nadd), c.count, PLATYPUS_VAR));
+                        allHash.push_back(hs[(size_t)k]);
                     }
                 }
             }
-            // :456-467: per-sample support, indels always; equal variants of different samples merge (addVariantToList).  Only the
-            // candidates that pass become Variant objects (the sample's own heap is not looked at again).
-            for (const Key& k : keys) {
-                int s0, e0;
-                tv.overlapRange(k.pos, k.pos + 1, s0, e0);
-                const int total = e0 - s0;
-                const double frac = total == 0 ? 0.0 : (double)k.count / total;
-                if (frac >= o.minVarFreq || k.nadd != k.nrem) pass(k.pos, k.rem, k.nrem, k.add, k.nadd, k.count);
-            }
+            everyone.clear();
+            for (int k : py2_dict_slot_order(allHash)) everyone.push_back(all[(size_t)k]);     // allSampleVarCandGen.variantHeap.values()
+            std::stable_sort(everyone.begin(), everyone.end(), variantLess);
         }
         PROF("s2.rv.norm_filter");
-        std::stable_sort(everyone.begin(), everyone.end(), variantLess);    // getCandidates(): sorted(values)
         everyone.insert(everyone.end(), r.asmVariants.begin(), r.asmVariants.end());      // rawBamVariants + assemblerVariants (:521)
         VarList norm;
         for (Variant* v : everyone) norm.push_back(leftNormaliseIndel(v, r.fa, r.rlen, r.pool));
         std::stable_sort(norm.begin(), norm.end(), variantLess);
         r.variants = filterVariants(norm, o.minReads, o.minReads, o.maxSize);
     }
+    bool recordsOnHost = false;
+    size_t recArenaBytes = 0;
 
     // -- B2/B3: windows, window pointers, haplotype enumeration (callVariantsInWindow up to Population.setup)
     Hap makeHap(const RegionWork& r, const WindowWork& w, const VarList& vs) const {
@@ -2168,6 +2221,19 @@ CALLER_EXPORT unsigned long long plat_caller_debug_string_hash(const char* s) { 
 CALLER_EXPORT void plat_caller_debug_str(double x, char* out, size_t cap) {
     const std::string t = py2_str(x);
     snprintf(out, cap, "%s", t.c_str());
+}
+CALLER_EXPORT unsigned long long plat_caller_debug_tuple_hash(const unsigned long long* item_hashes, int n) {
+    std::vector<uint64_t> h(item_hashes, item_hashes + n);
+    return (unsigned long long)py2_tuple_hash(h.data(), n);
+}
+CALLER_EXPORT unsigned long long plat_caller_debug_variant_hash(const char* ref_name, long long ref_pos, const char* removed, const char* added) {
+    return (unsigned long long)py2_variant_hash(py2_string_hash(ref_name ? ref_name : ""), ref_pos, removed ? removed : "", removed ? strlen(removed) : 0,
+                                                added ? added : "", added ? strlen(added) : 0);
+}
+CALLER_EXPORT void plat_caller_debug_dict_slot_order(const unsigned long long* hashes, int n, int* out) {
+    std::vector<uint64_t> h(hashes, hashes + n);
+    const std::vector<int> order = py2_dict_slot_order(h);
+    for (int i = 0; i < n; ++i) out[i] = order[(size_t)i];
 }
 // names: '\n'-separated, in insertion order; out: the iteration order of the set, '\n'-separated
 CALLER_EXPORT void plat_caller_debug_set_order(const char* names, char* out, size_t cap) {

@@ -55,6 +55,54 @@ def _py2_string_hash(key):
     return m - 1 if x == m else x
 
 
+def py2_tuple_hash(item_hashes):
+    """hash(tuple) of CPython 2.7 (tupleobject.c) from the items' hashes, unsigned 64-bit."""
+    m = (1 << 64) - 1
+    x, mult, n = 0x345678, 1000003, len(item_hashes)
+    for i, h in enumerate(item_hashes):
+        left = n - 1 - i
+        x = ((x ^ (h & m)) * mult) & m
+        mult = (mult + 82520 + left + left) & m
+    x = (x + 97531) & m
+    return m - 1 if x == m else x
+
+
+def py2_variant_hash(ref_name, ref_pos, removed, added):
+    """hash(Variant) of the reference = hash((refName, refPos, removed, added)), variant.pyx:270-280."""
+    as_str = lambda b: b.decode("latin-1") if isinstance(b, bytes) else b
+    return py2_tuple_hash([_py2_string_hash(as_str(ref_name)), (-2 if ref_pos == -1 else ref_pos) & ((1 << 64) - 1),
+                           _py2_string_hash(as_str(removed)), _py2_string_hash(as_str(added))])
+
+
+def py2_dict_slot_order(hashes):
+    """Iteration order of a Python-2 dict into which DISTINCT keys with these (unsigned) hashes were inserted in this order and never
+    deleted (dictobject.c; see py2_dict_order): indices into `hashes`."""
+    m = (1 << 64) - 1
+
+    def place(table, key):
+        h = hashes[key]
+        mask = len(table) - 1
+        i, perturb = h & mask, h
+        while table[i & mask] is not None:
+            i = (5 * i + perturb + 1) & m
+            perturb >>= 5
+        table[i & mask] = key
+    table, used = [None] * 8, 0
+    for key in range(len(hashes)):
+        place(table, key)
+        used += 1
+        if used * 3 >= len(table) * 2:
+            size = 8
+            while size <= used * (2 if used > 50000 else 4):
+                size <<= 1
+            grown = [None] * size
+            for k in table:
+                if k is not None:
+                    place(grown, k)
+            table = grown
+    return [k for k in table if k is not None]
+
+
 def py2_set_order(names):
     """list(set(names)) under CPython 2.7 (setobject.c): open addressing (i = 5i + perturb + 1, perturb >>= 5) in a table of
     8 slots that is rebuilt four times larger when two thirds full; iteration = slot order."""

@@ -324,3 +324,22 @@ def test_native_assembler_and_reference_calls_equal_the_python_loop_on_the_devic
     longest = max(abs(len(ln.split("\t")[3]) - len(ln.split("\t")[4].split(",")[0])) for ln in indels)
     assert len(indels) > 40 and n_asm >= 15, (len(lines), len(indels), n_asm, longest)
     assert longest >= 20, (len(lines), len(indels), n_asm, longest)          # indels far beyond what a 250 bp read's CIGAR shows reliably
+
+
+@pytest.mark.gpu
+def test_sites_with_two_alleles_take_the_python2_dictionary_order_on_the_device():
+    """The native loop fetches a scan's records from the device only for a region whose candidates hold a pair that compares equal
+    (tests/test_native_caller_cpu.py builds such regions), replays the reference's Python-2 candidate dictionaries for it and ends
+    with the text of the Python loop -- also where the pair's order reaches the text (maxVariants = 1)."""
+    from platypus_amd import fastcaller as F
+    from tests.test_native_caller_cpu import two_allele_regions, _work
+    regs, n_sites = two_allele_regions()
+    names = ["A", "B"]
+    fasta, work = _work(regs, names)
+    for kw in (dict(), dict(maxVariants=1)):
+        py = io.StringIO()
+        caller.callVariantsInRegions(work, fasta, default_options(**kw), VCF(names), py)
+        nc = F.NativeCaller(0, 2, 2)
+        txt = nc.call_regions([F.RegionReads.from_buffers(c, s, e, fasta, b) for c, s, e, b in work], names, default_options(**kw))
+        nc.close()
+        assert txt == py.getvalue() and txt.count("\n") > 20

@@ -248,3 +248,80 @@ def test_runtime_errors_end_the_call_and_window_errors_skip_the_window(fake, mon
     assert again == good and nc.stats["n_windows_failed"] == 0 and nc.stats["n_windows_called"] == nc.stats["n_windows"]
     monkeypatch.delenv("PLAT_FAKE_FAIL_SYNC")
     nc.close()
+
+
+def two_allele_regions():
+    """Regions with sites where the reads show TWO alternative SNP alleles, each in the same number of reads (a tie of type, length
+    and support)."""
+
+    rng = np.random.default_rng(21)
+    regs = [synth.config4_region(900 + i, n_samples=2, region_len=3000, snp_rate=2e-3, indel_rate=5e-4, read_len=100, depth=40) for i in range(4)]
+    n_sites = 0
+    for r in regs[:3]:                                                      # (the fourth region stays as it is: no pair, no replay)
+        taken = {v[0] for v in r["variants"]}
+        sites = [p for p in rng.choice(np.arange(r["start"] + 150, r["end"] - 150), size=40, replace=False).tolist()
+                 if all(abs(p - q) > 12 for q in taken)][:7]
+        for p in sites:
+            taken.add(p)
+            ref_b = r["ref"][p]
+            alts = [b for b in b"ACGT" if b != ref_b]
+            a1, a2 = (alts[k] for k in rng.choice(3, size=2, replace=False))
+            for reads in r["samples"]:                                      # the same number of reads for either allele: a tie of support too
+                cover = [x for x in reads if x["pos"] + 12 <= p < x["pos"] + len(x["seq"]) - 12 and len(x["cigar"]) == 1]
+                for k, x in enumerate(cover[:2 * min(14, len(cover) // 2)]):
+                    s = bytearray(x["seq"])
+                    s[p - x["pos"]] = a1 if k % 2 == 0 else a2
+                    x["seq"] = bytes(s)
+            n_sites += 1
+    return regs, n_sites
+
+
+def test_sites_with_two_alternative_alleles_follow_the_python2_dictionary_order(fake):
+    """Two SNP alleles at one position compare equal under Variant.__richcmp__ (refPos, type, nRemoved): `sorted` keeps them in the
+    order the candidate dictionaries yield them, Python-2 dicts keyed by hash((refName, refPos, removed, added)) (variant.pyx:270-280,
+    :747-751; variantcaller.pyx:457).  Both region loops replay those dictionaries for a region that holds such a pair (and only
+    then); the order they arrive at differs from first-occurrence order for some of the sites below, and decides ALT / PP / FR / NF / NR
+    of the records."""
+    regs, n_sites = two_allele_regions()
+    txt, st = _both(fake, regs, ["A", "B"])
+    multi = [ln.split("\t") for ln in txt.split("\n") if ln and "," in ln.split("\t")[4]]
+    assert n_sites >= 15 and len(multi) >= 3, (n_sites, len(multi))
+    # the dictionary order is not the order of first occurrence: for some of the pairs the candidate list holds the alleles the other way
+    # round than the reads showed them (what reaches the record text of THESE windows is then ordered by haplotype sequence,
+    # mergeHaplotypes, variantcaller.pyx:325-383 -- the candidate order decides where support ties are broken: greedy haplotype
+    # filter, coverage filter)
+    fasta, work = _work(regs, ["A", "B"])
+    cands, _ = caller.generateVariantsInRegions(work, fasta, default_options())
+    flipped = pairs = 0
+    for r, vs in zip(regs, cands):
+        first = {}
+        for x in [x for reads in r["samples"][:1] for x in reads]:
+            if len(x["cigar"]) == 1:
+                for v in vs:
+                    if v.nAdded == 1 and v.nRemoved == 1 and x["pos"] <= v.refPos < x["pos"] + len(x["seq"]) and x["seq"][v.refPos - x["pos"]] == v.added[0]:
+                        first.setdefault((v.refPos, v.added), len(first))
+        for a, c in zip(vs, vs[1:]):
+            if a.refPos == c.refPos and a.nAdded == c.nAdded == 1 and a.nRemoved == c.nRemoved == 1 and (a.refPos, a.added) in first and (c.refPos, c.added) in first:
+                pairs += 1
+                flipped += first[(a.refPos, a.added)] > first[(c.refPos, c.added)]
+    assert pairs >= 12 and 0 < flipped < pairs, (pairs, flipped)
+    # ... and where support ties are broken it reaches the text: with one variant per window allowed (filterVariantsByCoverage keeps the
+    # best supported, the first of equals) the surviving allele of such a pair is the dictionary's first.  Native = Python there too,
+    # and the native loop without its replay (a switch for this test) calls other alleles.
+    top, st = _both(fake, regs, ["A", "B"], maxVariants=1)
+    import os
+    os.environ["PLAT_CALLER_FIRST_OCCURRENCE_ORDER"] = "1"
+    try:
+        nc = F.NativeCaller(0, 2, 2, lib=fake)
+        plain = nc.call_regions([F.RegionReads.from_buffers(c, s_, e, fasta, b) for c, s_, e, b in work], ["A", "B"], default_options(maxVariants=1))
+        nc.close()
+    finally:
+        os.environ.pop("PLAT_CALLER_FIRST_OCCURRENCE_ORDER")
+    assert plain != top and plain.count("\n") == top.count("\n")
+    os.environ["PLAT_CALLER_HOST_TALLY"] = "1"                              # the candidate tally on the host takes the same way
+    try:
+        nc = F.NativeCaller(0, 2, 2, lib=fake)
+        assert nc.call_regions([F.RegionReads.from_buffers(c, s_, e, fasta, b) for c, s_, e, b in work], ["A", "B"], default_options(maxVariants=1)) == top
+        nc.close()
+    finally:
+        os.environ.pop("PLAT_CALLER_HOST_TALLY")

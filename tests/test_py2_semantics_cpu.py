@@ -102,3 +102,40 @@ def test_every_filter_set_vcfFILTER_can_emit_has_one_order_in_both_restatements(
             assert sorted(got) == sorted(names)
             n += 1
     assert n == 256 and len(table) == 256
+
+
+def test_tuple_hash_and_dict_order_of_variant_keys(native):
+    """The candidates of a region leave Python-2 dictionaries keyed by Variant objects, hash((refName, refPos, removed, added))
+    (variant.pyx:270-280; variantcaller.pyx:457, variant.pyx:747-751): tupleobject.c's hash and dictobject.c's slot order, both
+    restatements.  Published CPython 2.7 (64-bit) facts: hash(()) == 3527539, hash((1, 2, 3)) == 2528502973977326415 (the value every
+    "is hash() stable" discussion prints), and a dict of 'a', 'b', 'c' iterates a, c, b (as the set does)."""
+    native.plat_caller_debug_tuple_hash.restype = C.c_ulonglong
+    native.plat_caller_debug_tuple_hash.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    native.plat_caller_debug_variant_hash.restype = C.c_ulonglong
+    native.plat_caller_debug_variant_hash.argtypes = [C.c_char_p, C.c_longlong, C.c_char_p, C.c_char_p]
+    native.plat_caller_debug_dict_slot_order.argtypes = [C.POINTER(C.c_ulonglong), C.c_int, C.POINTER(C.c_int)]
+
+    def n_tuple(hs):
+        return native.plat_caller_debug_tuple_hash((C.c_ulonglong * max(1, len(hs)))(*hs), len(hs))
+
+    def n_order(hs):
+        out = (C.c_int * max(1, len(hs)))()
+        native.plat_caller_debug_dict_slot_order((C.c_ulonglong * max(1, len(hs)))(*hs), len(hs), out)
+        return list(out)[:len(hs)]
+    for items, want in (([], 3527539), ([1, 2, 3], 2528502973977326415)):
+        assert V.py2_tuple_hash(items) == want == n_tuple(items)
+    for keys, want in (("abc", "acb"), ("abcd", "acbd"), ("abcde", "acbed")):
+        hs = [V._py2_string_hash(k) for k in keys]
+        assert "".join(keys[i] for i in V.py2_dict_slot_order(hs)) == want == "".join(keys[i] for i in n_order(hs))
+    ints = [5, 1, 9, 17, 3, 1000003, 64, 8, 16, 24, 32, 40]
+    assert [ints[i] for i in V.py2_dict_slot_order(ints)] == V.py2_dict_order(ints) == [ints[i] for i in n_order(ints)]
+    # both restatements on random keys, through several resizes
+    import random
+    rnd = random.Random(11)
+    for n in (1, 5, 6, 21, 22, 85, 86, 341, 342, 3000):
+        vs = [("r%d" % rnd.randint(0, 3), rnd.randint(0, 10 ** 6), "".join(rnd.choice("ACGT") for _ in range(rnd.randint(0, 4))),
+               "".join(rnd.choice("ACGT") for _ in range(rnd.randint(0, 4)))) for _ in range(n)]
+        vs = list(dict.fromkeys(vs))
+        hs = [V.py2_variant_hash(*v) for v in vs]
+        assert hs == [native.plat_caller_debug_variant_hash(v[0].encode(), v[1], v[2].encode(), v[3].encode()) for v in vs]
+        assert V.py2_dict_slot_order(hs) == n_order(hs) and sorted(n_order(hs)) == list(range(len(vs)))
