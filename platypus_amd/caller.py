@@ -106,10 +106,9 @@ def generateVariantsInRegions(regions, refFile, options):
     gens = [[mk(chrom, start, end) for _ in buffers] for chrom, start, end, buffers in regions]
     scans = [_candidateRegion(g, b.reads.array) for (_, _, _, buffers), gs in zip(regions, gens) for g, b in zip(gs, buffers)]
     found = iter(H.get_engine().candidates(scans, options.minFlank, options.minBaseQual, options.genSNPs, options.genIndels))
-    merged, rlens = [], []
+    heaps, rlens = [], []
     rlen = options.rlen
     for (chrom, start, end, buffers), gs in zip(regions, gens):
-        everyone = mk(chrom, start, end)
         longest = 0
         for g, b in zip(gs, buffers):
             longest = max(longest, b.reads.getLengthOfLongestRead())
@@ -119,28 +118,56 @@ def generateVariantsInRegions(regions, refFile, options):
                 tally[key] = tally.get(key, 0) + 1
             for (pos, removed, added), n in tally.items():
                 g.addVariantToList(H.Variant(chrom, pos, removed, added, n, H.PLATYPUS_VAR))
-        # :456-467: per-sample support, indels always.  Both dictionaries are walked in the order a Python-2 dict holds Variant keys
-        # (`variantHeap.iteritems()`, `sorted(variantHeap.values())`): it decides the order of candidates that compare equal -- two
-        # alleles of one type and length at one position.  Only then is that order worked out (_py2_heap_order replays the insertions)
-        for exact in (False, True):
-            everyone = mk(chrom, start, end)
-            for g, b in zip(gs, buffers):
-                for v in (_py2_heap_order(g.variantHeap) if exact else g.variantHeap.values()):
-                    if computeVariantReadSupportFrac(v, b) >= options.minVarFreq or v.nAdded != v.nRemoved:
-                        everyone.addVariantToList(H.Variant(v.refName, v.refPos, v.removed, v.added, v.nSupportingReads, v.varSource) if not exact else v)
-            cands = sorted(_py2_heap_order(everyone.variantHeap) if exact else everyone.variantHeap.values())
-            if exact or not any(not (a < c) and not (c < a) for a, c in zip(cands, cands[1:])):
-                break
-        merged.append(cands)
+        heaps.append((gs, buffers, chrom, start, end))
         if longest > 0:                                                          # :476-488
             rlen = options.maxSize if longest >= options.maxSize else longest
         rlens.append(rlen)
-    if options.assemble:
-        for cands, extra in zip(merged, _assemblerVariants(regions, refFile, options)):
-            cands.extend(extra)                                                  # rawBamVariants + assemblerVariants (:521)
-    for k, cands in enumerate(merged):
+    extras = _assemblerVariants(regions, refFile, options) if options.assemble else [[] for _ in regions]
+
+    def clone(v):
+        c = H.Variant(v.refName, v.refPos, v.removed, v.added, v.nSupportingReads, v.varSource)
+        c.bamMinPos, c.bamMaxPos = v.bamMinPos, v.bamMaxPos
+        return c
+
+    def candidates(k, exact):
+        """generateVariantsInRegion :456-531 for region k.  :456-467: per-sample support, indels always.  Both candidate dictionaries are
+        walked in the order a Python-2 dict holds Variant keys (`variantHeap.iteritems()`, `sorted(variantHeap.values())`) when `exact`,
+        in first-occurrence order otherwise; on copies, so that the second way starts from untouched variants."""
+        gs, buffers, chrom, start, end = heaps[k]
+        everyone = mk(chrom, start, end)
+        for g, b in zip(gs, buffers):
+            for v in (_py2_heap_order(g.variantHeap) if exact else g.variantHeap.values()):
+                if computeVariantReadSupportFrac(v, b) >= options.minVarFreq or v.nAdded != v.nRemoved:
+                    everyone.addVariantToList(clone(v))
+        cands = sorted(_py2_heap_order(everyone.variantHeap) if exact else everyone.variantHeap.values())
+        cands.extend(clone(v) for v in extras[k])                                # rawBamVariants + assemblerVariants (:521)
         norm = sorted(leftNormaliseIndel(v, refFile, rlens[k]) for v in cands)
-        out[k] = filterVariants(norm, refFile, rlens[k], options.minReads, options.maxSize, options.verbosity, options)
+        return norm, filterVariants(norm, refFile, rlens[k], options.minReads, options.maxSize, options.verbosity, options)
+
+    def order_can_matter(norm, kept):
+        """`sorted` is stable: candidates that compare equal (two alleles of one type and length at one position) stay in dictionary
+        order; every other order is decided by the keys.  It reaches the result where two KEPT variants compare equal, or where a run
+        of equal keys holds a variant twice (equal neighbours merge: who is whose neighbour depends on it) next to a different one."""
+        tied = lambda a, c: not (a < c) and not (c < a)
+        if any(tied(a, c) for a, c in zip(kept, kept[1:])):
+            return True
+        i = 0
+        while i < len(norm):
+            e = i + 1
+            while e < len(norm) and not (norm[i] < norm[e]):
+                e += 1
+            if e - i >= 3:
+                pairs = [(norm[x] == norm[y]) for x in range(i, e) for y in range(x + 1, e)]
+                if any(pairs) and not all(pairs):
+                    return True
+            i = e
+        return False
+
+    for k in range(len(regions)):
+        norm, kept = candidates(k, False)
+        if order_can_matter(norm, kept):                                         # only such a region pays for replaying the dictionaries
+            norm, kept = candidates(k, True)
+        out[k] = kept
     if rlens:
         options.rlen = rlens[-1]
     return out, rlens

@@ -880,13 +880,42 @@ struct Chunk {
             for (const CandKey& k : keys) if (passesSupport(r, i, k)) pass(k.pos, k.rem, k.nrem, k.add, k.nadd, k.count);
         }
         std::stable_sort(everyone.begin(), everyone.end(), variantLess);    // getCandidates(): sorted(values)
+        // rawBamVariants + assemblerVariants (:521), left-normalised, sorted, filtered (:523-531)
+        VarList norm;
+        auto finish = [&](const VarList& raw) {
+            VarList all(raw);
+            all.insert(all.end(), r.asmVariants.begin(), r.asmVariants.end());
+            norm.clear();
+            for (Variant* v : all) norm.push_back(leftNormaliseIndel(v, r.fa, r.rlen, r.pool));
+            std::stable_sort(norm.begin(), norm.end(), variantLess);
+            r.variants = filterVariants(norm, o.minReads, o.minReads, o.maxSize);
+        };
+        std::vector<Variant> asmBackup;                                     // (filterVariants adds the support of equal neighbours up in place)
+        for (const Variant* v : r.asmVariants) asmBackup.push_back(*v);
+        finish(everyone);
         // `sorted` is stable: candidates that compare equal (two alleles of one type and length at one position) stay in the order the
         // all-samples dictionary yields them, a Python-2 dict keyed by Variant (hash of (refName, refPos, removed, added),
         // variant.pyx:270-280) that was filled while walking each sample's dictionary of the same kind (variantcaller.pyx:457).  Every
-        // other order is decided by the keys, so only a region that holds such a pair pays for replaying the dictionaries.
-        bool ties = false;
-        for (size_t k = 1; k < everyone.size() && !ties; ++k) ties = !variantLess(everyone[k - 1], everyone[k]) && !variantLess(everyone[k], everyone[k - 1]);
-        if (ties && o.getVariantsFromBAMs && !getenv("PLAT_CALLER_FIRST_OCCURRENCE_ORDER")) {      // (the switch: tests only, to show the replay matters)
+        // other order is decided by the keys.  That order can only reach the result where two of the variants that are KEPT compare
+        // equal, or where a run of equal keys holds a variant twice (equal neighbours are merged by filterVariants: who is whose
+        // neighbour then depends on it) next to a different one -- most regions hold such pairs only among the sequencing errors that
+        // are dropped.  Only a region where it can matter pays for replaying the dictionaries.
+        bool replay = false;
+        for (size_t k = 1; k < r.variants.size() && !replay; ++k)
+            replay = !variantLess(r.variants[k - 1], r.variants[k]) && !variantLess(r.variants[k], r.variants[k - 1]);
+        for (size_t a = 0; a < norm.size() && !replay;) {
+            size_t e = a + 1;
+            while (e < norm.size() && !variantLess(norm[a], norm[e])) ++e;  // (sorted: not less = equal key)
+            if (e - a >= 3) {
+                bool twice = false, other = false;
+                for (size_t x = a; x < e; ++x)
+                    for (size_t y = x + 1; y < e; ++y) { if (norm[x]->same(*norm[y])) twice = true; else other = true; }
+                replay = twice && other;
+            }
+            a = e;
+        }
+        if (replay && o.getVariantsFromBAMs && !getenv("PLAT_CALLER_FIRST_OCCURRENCE_ORDER")) {      // (the switch: tests only, to show the replay matters)
+            if (getenv("PLAT_CALLER_TRACE")) fprintf(stderr, "[plat_caller] region %s: candidates that compare equal are kept, dictionaries replayed\n", r.in->chrom ? r.in->chrom : "?");
             if (!hostTally && !recordsOnHost) {                             // the scan's records are still on the device
                 if (recArenaBytes) ck(plat_memcpy_d2h(z.ctx, z.a_cout.h, z.a_cout.d, recArenaBytes, z.stream), "plat_memcpy_d2h");
                 z.sync("candidate records");
@@ -919,13 +948,9 @@ struct Chunk {
             everyone.clear();
             for (int k : py2_dict_slot_order(allHash)) everyone.push_back(all[(size_t)k]);     // allSampleVarCandGen.variantHeap.values()
             std::stable_sort(everyone.begin(), everyone.end(), variantLess);
+            for (size_t k = 0; k < asmBackup.size(); ++k) *r.asmVariants[k] = asmBackup[k];
+            finish(everyone);
         }
-        PROF("s2.rv.norm_filter");
-        everyone.insert(everyone.end(), r.asmVariants.begin(), r.asmVariants.end());      // rawBamVariants + assemblerVariants (:521)
-        VarList norm;
-        for (Variant* v : everyone) norm.push_back(leftNormaliseIndel(v, r.fa, r.rlen, r.pool));
-        std::stable_sort(norm.begin(), norm.end(), variantLess);
-        r.variants = filterVariants(norm, o.minReads, o.minReads, o.maxSize);
     }
     bool recordsOnHost = false;
     size_t recArenaBytes = 0;
