@@ -200,7 +200,7 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
             granted = effective_cpus()
         except Exception:
             granted = workers
-        loaders = int(os.environ.get("PLAT_CALLER_LOADERS", str(max(2, min(12, granted * 5 // 8)))))
+        loaders = int(os.environ.get("PLAT_CALLER_LOADERS", str(max(2, min(12, granted // 2)))))
     n_slots = per_chunk * (workers + 2) + loaders
     kw = dict(region_len=region_len, n_samples=n_samples, packed=packed, pin=pin, **(region_kw or {}))
     src = source.RegionSource(indices, n_slots, **kw)
@@ -248,11 +248,12 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
     total = a.regions or 3875 * world
     mine = sharding.regions_for_rank(total, rank, world)
     cpus = getattr(rk, "cpus", 16)                                           # what the box grants this rank (cgroup quota / share of the node)
-    # worker and loader threads share the rank's CPUs (workers sleep while the device works on their chunk): 10 + 10 on the 16 CPUs one
-    # GPU box grants measured best (tools/run_r3_g.sh: 16 + 8 684 k, 12 + 8 698 k, 10 + 10 727 k windows/s)
+    # worker and loader threads share the rank's CPUs (workers sleep while the device works on their chunk): 10 + 8 with six regions per
+    # chunk on the 16 CPUs one GPU box grants (tools/run_c4_sweep4.sh, run_c4_sweep5.sh: the box's own run-to-run spread, +-8 %, is as large
+    # as the differences between 10-12 workers, 6-10 loaders and 4-8 regions per chunk; 16 + 8 and 4 per chunk measured 5 % below)
     workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus * 5 // 8)))))
-    os.environ.setdefault("PLAT_CALLER_LOADERS", str(max(2, min(12, cpus * 5 // 8))))
-    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "4"))
+    os.environ.setdefault("PLAT_CALLER_LOADERS", str(max(2, min(12, cpus // 2))))
+    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "6"))
     pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1" and lib is None
     packed = os.environ.get("PLAT_CALLER_PACKED", "1") == "1"
     repeats = max(1, min(a.steps, 3))                                        # the line is the MEAN over the runs
@@ -329,7 +330,7 @@ def summary(eng):
     except Exception:
         cpus = 16
     r = config4(0, range(nreg), 100000, int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus * 5 // 8))))),
-                int(os.environ.get("PLAT_CALLER_CHUNK", "4")), repeats=3)     # the mean of three runs over the whole share
+                int(os.environ.get("PLAT_CALLER_CHUNK", "6")), repeats=3)     # the mean of three runs over the whole share
     st = r["stats"]
     out["config4_region_pipeline"] = dict(regions=r["regions"], region_len=r["region_len"], reads=r["reads"], windows=r["windows"], records=r["records"],
                                           planted_variants=r["planted"], timed_s=r["T"], timed_s_runs=r["T_runs"], windows_per_sec=r["windows"] / r["T"],
