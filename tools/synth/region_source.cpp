@@ -49,6 +49,7 @@ struct plat_synth {
     uint8_t* mem; size_t slotBytes; int nSlots;
     std::vector<uint8_t> tape;                                             // quality tape
     std::vector<uint8_t> tape4;                                            // the same << 2: the quality bits of a packed byte
+    std::vector<int32_t> gapTape;                                          // 64 K draws of the distance to the next substitution error (geometric)
     // variant model: indel length 1 + min(indelMax - 1, geometric(indelP) - 1); counts Poisson(rate x length) unless a [min, max] range is set
     int indelMax = 10, nIndelMin = -1, nIndelMax = -1, nSnpMin = -1, nSnpMax = -1;
     double indelP = 0.4;
@@ -93,6 +94,12 @@ SYNTH_EXPORT int plat_synth_create(uint64_t seed, int region_len, int flank, int
     }
     g->tape4.resize(g->tape.size());
     for (size_t i = 0; i < g->tape.size(); ++i) g->tape4[i] = (uint8_t)(g->tape[i] << 2);
+    if (err > 0) {                                                           // no logarithm per error in the loaders: a draw picks an entry
+        g->gapTape.resize(1u << 16);
+        Rng rg(seed, 0xFFFFFFFDull);
+        const double logKeep = std::log(1.0 - err);
+        for (int32_t& x : g->gapTape) x = (int32_t)std::min(1e9, std::floor(std::log(1.0 - rg.uni()) / logKeep));
+    }
     *out = g;
     return 0;
 }
@@ -296,8 +303,9 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
         if (!seq || (!qual && g->encoding != PLAT_READS_PACKED) || !off || !pos || !endp || !flags || !mate || !mapq || !cigoff || !cigar) return -3;
         size_t nc = 0;
         uint8_t tmpS[10064];
-        const double logKeep = g->err > 0 ? std::log(1.0 - g->err) : -1.0;
-        long long toErr = g->err > 0 ? (long long)std::floor(std::log(1.0 - rng.uni()) / logKeep) : (1ll << 62);   // bases until the next substitution error
+        const int32_t* gapTape = g->gapTape.data();
+        auto nextGap = [&]() -> long long { return gapTape[rng.next() >> 48]; };
+        long long toErr = g->err > 0 ? nextGap() : (1ll << 62);             // bases until the next substitution error
         // the per-read fields that need no thought, in tight loops; the draws and starts in sorted order (one gather instead of two
         // dependent look-ups per read in the big loop)
         S.tmpOrder.resize((size_t)nReads);
@@ -355,7 +363,7 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
                     static const uint8_t idxOf[4] = {0, 1, 3, 2}, codeOf[4] = {0, 1, 3, 2};
                     const uint8_t c = cb[toErr];
                     ds[toErr] = (uint8_t)(codeOf[(idxOf[c] + 1 + (int)rng.below(3)) & 3] | qb[toErr]);
-                    toErr += 1 + (long long)std::floor(std::log(1.0 - rng.uni()) / logKeep);
+                    toErr += 1 + nextGap();
                 }
             } else {
                 const uint8_t* s = src;
@@ -365,7 +373,7 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
                         const char* B = "ACGT";
                         const char* at = strchr(B, tmpS[toErr]);
                         tmpS[toErr] = (uint8_t)B[((at ? (int)(at - B) : 0) + 1 + (int)rng.below(3)) & 3];
-                        toErr += 1 + (long long)std::floor(std::log(1.0 - rng.uni()) / logKeep);
+                        toErr += 1 + nextGap();
                     }
                     s = tmpS;
                 }
