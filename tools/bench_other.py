@@ -206,9 +206,11 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
     src = source.RegionSource(indices, n_slots, **kw)
     names = ["S%d" % (i + 1) for i in range(n_samples)]
     nc = F.NativeCaller(device, workers, per_chunk, lib=lib)
-    # (the timed runs are the steady state of a long job: the warm pass is long enough for every slot, pinned block and scratch buffer to have
-    # been through its first use -- the first of three timed runs was still a fifth slower than the others after 80 regions)
-    nwarm = min(len(indices), warm_regions if warm_regions is not None else max(2 * per_chunk * workers, 512))
+    # (the timed runs are the steady state of a long job -- a rank's share of a genome is eight such lists --: ONE UNTIMED PASS over the
+    # whole list comes first, as the W untimed steps of the headline do.  After 80 regions the first of three timed runs was still a fifth
+    # slower than the others, after 512 a tenth: slots, pinned blocks, scratch buffers, the allocator's arenas for 95 MB of record text
+    # and the cores' clocks all take their time)
+    nwarm = min(len(indices), warm_regions) if warm_regions is not None else len(indices)
     if nwarm:                                                                 # every worker's scratch buffers at full size, code paths warm
         nc.call_stream(nwarm, src.load_fn, src.h, names, default_options(**(options_kw or {})), n_slots, loaders)
     runs, text, merged, gather, st = [], "", None, None, None
@@ -233,7 +235,7 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
     src.close()
     T = float(np.mean([r[0] for r in runs]))
     return dict(T=T, T_call=float(np.mean([r[1] for r in runs])), T_runs=[r[0] for r in runs], text=text, merged=merged, gather=gather, stats=st,
-                regions=len(indices), region_len=region_len, reads=int(st["n_reads"]), windows=int(st["n_windows"]), records=int(st["n_records"]),
+                regions=len(indices), warm_regions=nwarm, region_len=region_len, reads=int(st["n_reads"]), windows=int(st["n_windows"]), records=int(st["n_records"]),
                 planted=int(planted), workers=workers, per_chunk=per_chunk, loaders=loaders, n_slots=n_slots, packed=packed, source_phases=phases,
                 input_bytes=int(st["input_bytes"]))
 
@@ -279,7 +281,7 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
             "worker_seconds_waiting_for_the_source_per_region": st["seconds_source_wait"] / max(1, r["regions"]),
             "host_input_bytes_per_region": inb / max(1.0, regs), "h2d_gbytes_per_sec": inb / T / 1e9, "input_blobs_pinned": pin, "cpus_granted_to_this_rank": cpus,
             "stage_seconds_per_region": {k: v / max(1, r["regions"]) for k, v in st["seconds_stage"].items()},
-            "record_gather": r["gather"], "python_region_loop_windows_per_sec_round1": 1100.0}
+            "record_gather": r["gather"], "untimed_warm_regions_per_rank": r["warm_regions"], "python_region_loop_windows_per_sec_round1": 1100.0}
     if rank == 0:
         line["merged_text"] = F.text_bytes(r["merged"]).decode("ascii")                               # (popped by bench.py before printing; the tests read it)
     return line
@@ -332,7 +334,7 @@ def summary(eng):
     r = config4(0, range(nreg), 100000, int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus * 5 // 8))))),
                 int(os.environ.get("PLAT_CALLER_CHUNK", "6")), repeats=3)     # the mean of three runs over the whole share
     st = r["stats"]
-    out["config4_region_pipeline"] = dict(regions=r["regions"], region_len=r["region_len"], reads=r["reads"], windows=r["windows"], records=r["records"],
+    out["config4_region_pipeline"] = dict(regions=r["regions"], untimed_warm_regions=r["warm_regions"], region_len=r["region_len"], reads=r["reads"], windows=r["windows"], records=r["records"],
                                           planted_variants=r["planted"], timed_s=r["T"], timed_s_runs=r["T_runs"], windows_per_sec=r["windows"] / r["T"],
                                           regions_per_sec=r["regions"] / r["T"], reads_per_sec=r["reads"] / r["T"],
                                           host_seconds_per_region=st["seconds_host"] / r["regions"],
