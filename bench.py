@@ -482,7 +482,9 @@ def main():
         r_dp = entry("k_dp_jobs", prof.dp_alg_bytes, dp_avg, pm,
                      "recurrence is VALU-issue bound (packed int16), not HBM bound: see DESIGN.md")
         r_seed = entry("k_seed", seed_alg, seedk_avg, pm.get("k_seed", {}),
-                       "LDS k-mer maps + bit-parallel proofs, latency / VALU bound: see DESIGN.md")
+                       "LDS k-mer maps + bit-parallel proofs: bound by vector issue (secondary), not by HBM -- the fraction fell from 0.10 to 0.065 in round 3 "
+                       "because the kernel moves fewer bytes per launch (no 4-byte DP words per haplotype base: algorithmic 235 -> 146 MB; counter "
+                       "traffic 282 -> 140 MB) while its time went from 299 to 281 us; see DESIGN.md section 4")
         roof, roof_other = (r_seed, r_dp) if seedk_avg > dp_avg else (r_dp, r_seed)
         line = {
             "metric": "pair-HMM GCUPS (reference-equivalent band cells/s, read->haplotype likelihood path)",
