@@ -394,6 +394,25 @@ struct BatchBuilder {
         readoff.push_back(readoff.back() + L);
         maxRead = std::max(maxRead, L);
     }
+    void addReads(const TableView& tv, int i0, int i1, int k) {          // reads [i0, i1) of one table: the same as addRead one by one
+        if (i1 <= i0) return;
+        const size_t n = (size_t)(i1 - i0), at = src.size();
+        src.resize(at + n); kind.resize(at + n, (uint8_t)k); readoff.resize(at + n + 1);
+        int32_t* sp = src.data() + at;
+        int64_t* rp = readoff.data() + at;                                 // rp[0] = the running end so far
+        const int64_t* off = tv.t->off;
+        const int32_t base = (int32_t)tv.base;
+        int64_t run = rp[0];
+        int longest = maxRead;
+        for (size_t j = 0; j < n; ++j) {
+            const int i = i0 + (int)j;
+            const int L = (int)(off[i + 1] - off[i]);
+            sp[j] = base + i;
+            run += L; rp[j + 1] = run;
+            longest = std::max(longest, L);
+        }
+        maxRead = longest;
+    }
     void endSegment(int nGood) { segbegin.push_back((int32_t)src.size()); ngood.push_back(nGood); }
     void endWindow() {
         const int H = (int)hapoff.size() - 1 - hapbegin.back(), R = (int)src.size() - readbegin.back();
@@ -402,6 +421,15 @@ struct BatchBuilder {
         pairoff.push_back(pairoff.back() + (int64_t)H * R);
         gloff.push_back(gloff.back() + (int64_t)(H * (H + 1) / 2) * nInd);
         maxR = std::max(maxR, R); maxH = std::max(maxH, H);
+    }
+    // back to empty with the memory kept: the arrays of a chunk are megabytes, and growing them from nothing for every chunk is a
+    // chain of mmap + page faults + copies
+    void reset(int nInd_) {
+        nInd = nInd_;
+        hapbegin.assign(1, 0); readbegin.assign(1, 0); start.clear(); end.clear(); flank.clear(); segbegin.assign(1, 0); ngood.clear(); src.clear();
+        pairoff.assign(1, 0); hapoff.assign(1, 0); readoff.assign(1, 0); gloff.assign(1, 0);
+        kind.clear(); hapseq.clear();
+        maxHap = maxRead = maxR = maxH = 0;
     }
     int nWindows() const { return (int)start.size(); }
     int nHaps() const { return (int)hapoff.size() - 1; }
@@ -1237,8 +1265,9 @@ struct Chunk {
     void callWindows(std::vector<WindowWork*>& wins) {
         if (wins.empty()) return;
         Slot& z = s;
-        BatchBuilder b;
-        b.nInd = nInd;
+        static thread_local BatchBuilder callBatch;                      // (kept from chunk to chunk of this worker thread: see BatchBuilder::reset)
+        BatchBuilder& b = callBatch;
+        b.reset(nInd);
         for (WindowWork* w : wins) {
             PROF("s4.build");
             RegionWork& r = *regions[(size_t)regionSlot(w->region)];
@@ -1247,9 +1276,9 @@ struct Chunk {
             for (const Hap& h : w->haps) b.addHap(h.seq);
             for (size_t i = 0; i < r.samples.size(); ++i) {                // good -> bad -> brokenMates (chaplotype.pyx:341-373)
                 const Ptrs& p = w->ptrs[i];
-                for (int q = p.gs; q < p.ge; ++q) b.addRead(r.samples[i].reads, q, 0);
-                for (int q = p.bs; q < p.be; ++q) b.addRead(r.samples[i].bad, q, 1);
-                for (int q = p.ks; q < p.ke; ++q) b.addRead(r.samples[i].broken, q, 2);
+                b.addReads(r.samples[i].reads, p.gs, p.ge, 0);
+                b.addReads(r.samples[i].bad, p.bs, p.be, 1);
+                b.addReads(r.samples[i].broken, p.ks, p.ke, 2);
                 b.endSegment(p.ge - p.gs);
             }
             b.endWindow();
