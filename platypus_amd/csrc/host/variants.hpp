@@ -96,7 +96,9 @@ inline int rate(int size, int displacement) {                            // tand
 // `length < 0` ("markfull") mode calculate_size_and_displacement uses.  What the C code computes per start position p (group
 // start g = p & ~3) and unit d is the distance from p to the first mismatch between the sequence and itself shifted by d,
 // looking only as far as g + 64 (g + 32 when the shifted second word would start past the end).
-inline void annotate(const std::string& sequence, std::vector<int>& sizes, std::vector<int>& disps) {
+// `upto`: the caller reads positions <= upto only -- a start position p writes [p, p + size) and looks at position p, so nothing that
+// starts behind `upto` can reach what lies before it, and the groups behind it are not walked.
+inline void annotate(const std::string& sequence, std::vector<int>& sizes, std::vector<int>& disps, int upto = 0x7FFFFFFF) {
     const int L = (int)sequence.size();
     sizes.assign(L, 1); disps.assign(L, 1);
     if (L == 0) return;
@@ -119,7 +121,7 @@ inline void annotate(const std::string& sequence, std::vector<int>& sizes, std::
         row[ext] = ext;
         for (int i = ext - 1; i >= 0; --i) row[i] = code[i] != code[i + d] ? i : row[i + 1];
     }
-    for (int g = 0; g < L; g += 4)
+    for (int g = 0; g < L && g <= upto; g += 4)
         for (int d = 1; d < MAX_UNIT_LENGTH; ++d) {
             if (g + d >= L) break;
             const bool second = g + d + 32 < L;
@@ -180,7 +182,7 @@ inline double indelPrior(const Variant& v, const Fasta& fa, int indel_length_and
     std::string sequence;
     try { sequence = fa.getSequence(leftPos + 1, rightPos + 1); } catch (const WindowError&) { sequence.clear(); }
     std::vector<int> sizes, disps;
-    tandem::annotate(sequence, sizes, disps);
+    tandem::annotate(sequence, sizes, disps, rel);
     int prior = indel_prior_model(1)[0] - 33, tract = 255;
     for (int i : {rel - 1, rel}) {
         const int disp = (i >= 0 && i < (int)disps.size()) ? disps[i] : 0;
