@@ -343,3 +343,26 @@ def test_sites_with_two_alleles_take_the_python2_dictionary_order_on_the_device(
         txt = nc.call_regions([F.RegionReads.from_buffers(c, s, e, fasta, b) for c, s, e, b in work], names, default_options(**kw))
         nc.close()
         assert txt == py.getvalue() and txt.count("\n") > 20
+
+
+@pytest.mark.gpu
+def test_more_distinct_candidates_than_the_device_table_holds_fall_back_to_the_host_tally():
+    """A scan with more distinct candidate records than k_candidates_merge's table takes (6 144: here ~15 000, reads with 2 % errors) is
+    reported by the device and tallied on the host instead; reads with more candidates than their slice of the record array make the
+    scan run again with room for them.  The text is the Python loop's either way."""
+    from platypus_amd import fastcaller as F
+    regs = [synth.config4_region(950 + i, n_samples=1, region_len=[25000, 3000][i], snp_rate=2e-3, indel_rate=4e-4, read_len=100, depth=30,
+                                 err=[2e-2, 1e-3][i]) for i in range(2)]
+    names = ["S1"]
+    fasta = H.FastaFile({r["chrom"]: r["ref"] for r in regs})
+    work = []
+    for r in regs:
+        rs = [H.AlignedRead(x["seq"], x["qual"], x["pos"], x["mapq"], x["flag"], end=x["end"], cigarOps=x["cigar"]) for x in r["samples"][0]]
+        work.append((r["chrom"], r["start"], r["end"], [H.bamReadBuffer(rs, [], [], sample="S1")]))
+    py = io.StringIO()
+    caller.callVariantsInRegions(work, fasta, default_options(), VCF(names), py)
+    nc = F.NativeCaller(0, 2, 2)
+    txt = nc.call_regions([F.RegionReads.from_buffers(c, s, e, fasta, b) for c, s, e, b in work], names, default_options())
+    assert nc.stats["n_candidate_records"] > 9000                          # (nearly all of them distinct: sequencing errors)
+    nc.close()
+    assert txt == py.getvalue() and txt.count("\n") > 30
