@@ -456,7 +456,7 @@ def main():
 
         # the PMC figures are NOT collected by this run (counters need rocprofv3 around the process): they are the last committed pass
         meas = pm.get("measured") or {}
-        traffic_source = None if not pm else "not measured in this run: profiles/dp_traffic.json <- %s; collected %s at commit %s (tools/profile_round3.sh)" % (
+        traffic_source = None if not pm else "not measured in this run: profiles/dp_traffic.json <- %s; collected %s at commit %s (tools/profile_round.sh)" % (
             pm.get("source", "rocprofv3 --pmc passes"), meas.get("date", "in round %s" % pm.get("round", "?")), meas.get("commit", "?"))
 
         def entry(kernel, alg_bytes, ms, counters, note):

@@ -1,19 +1,62 @@
 #!/bin/bash
-# One round of profile evidence for profiles/: kernel-trace stats (1 and 3 batches in flight) and three separate PMC passes.
-# Run on the GPU box:  gpurun -- 'bash tools/profile_round.sh'
-set -x
-R=$GRAFT_REPO_ROOT
+# The ONE profiling / evidence script.  Everything kept under profiles/ comes from here.
+#
+#   gpurun --timeout 3000 -- "PLAT_COMMIT=$(git rev-parse --short HEAD) bash tools/profile_round.sh r04 [part ...]"
+#
+# First argument: the round tag the files under profiles/ are named with (r04 -> profiles/r04_*).
+# Parts (default: all but the soaks):
+#   tests   python -m pytest tests -m gpu                               -> $O/pytest_gpu.txt
+#   c2      rocprofv3 --kernel-trace --stats of config 2, one batch at a time and three in flight
+#   c3 c4 c5   the same for configs 3 (tiles + end to end), 4 (256 regions), 5
+#   pmc2    PMC passes of config 2 (FETCH_SIZE | WRITE_SIZE | SQ counters; one pass per set, only --kernel-trace next to --pmc)
+#   pmc3    PMC passes of the assembler (FETCH | WRITE | SQ | wait counters)
+#   pmcseed three SQ passes over k_seed / k_dp_jobs / k_prep_reads (instruction mix, waits, LDS conflicts)
+#   nextk   kernel stats of the "next row" kernels (tools/next_kernels.py)
+#   line    the default bench line, bench.py --config 3/4/5, the two-rank launches on the one GPU
+#   soaks   ungapped cross-check (plain + wrap regime), native region-loop soak, assembler soak; SOAK_SECONDS each (default 400)
+# gpurun only brings back gpurun_out/: the summaries are written to profiles/ on the box AND copied to $O/out; copy them from there.
+TAG=${1:-r04}; shift
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/${TAG}p
+mkdir -p $O
+PARTS=${@:-tests c2 c3 c4 c5 pmc2 pmc3 nextk line}
+T=${SOAK_SECONDS:-400}
+B2="--steps 12 --warmup 2 --no-cpu-baseline --no-extras --batches 3"
 cd /tmp && export TMPDIR=/tmp
-O=$R/gpurun_out/r01c
-rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --streams 1 > $O/stats1.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats3 -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline > $O/stats3.log 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --streams 1 > $O/pmc_$c.log 2>&1
-done
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $O/pmc_SQ -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --streams 1 > $O/pmc_SQ.log 2>&1
+prof() { d=$1; shift; rm -rf $O/$d; rocprofv3 --kernel-trace --stats --output-format csv -d $O/$d -- "$@" > $O/$d.log 2>&1; tail -1 $O/$d.log > $O/$d.json; }
+pmc() { d=$1; c=$2; shift 2; rm -rf $O/$d; rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/$d -- "$@" > $O/$d.log 2>&1; }
+for p in $PARTS; do case $p in
+  tests) (cd $R && python -m pytest tests -q -m gpu 2>&1 | tail -5 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt) ;;
+  c2) prof stats1 python $R/bench.py $B2 --streams 1; prof stats3 python $R/bench.py $B2 ;;
+  c3) prof stats_c3 python $R/bench.py --config 3 --regions 2000 --steps 5 --no-extras; prof stats_c3e python $R/bench.py --config 3 --regions 2000 --steps 1 ;;
+  c4) prof stats_c4 python $R/bench.py --config 4 --regions 256 --steps 1 ;;
+  c5) prof stats_c5 python $R/bench.py --config 5 --windows 200 --steps 10 --warmup 2 ;;
+  pmc2) for c in FETCH_SIZE WRITE_SIZE; do pmc pmc_$c $c python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras --batches 2 --streams 1; done
+        pmc pmc_SQ "SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES" python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras --batches 2 --streams 1 ;;
+  pmc3) for c in FETCH_SIZE WRITE_SIZE; do pmc pmc3_$c $c python $R/bench.py --config 3 --regions 2000 --steps 2 --no-extras; done
+        pmc pmc3_SQ "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" python $R/bench.py --config 3 --regions 2000 --steps 2 --no-extras
+        pmc pmc3_WAIT "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" python $R/bench.py --config 3 --regions 2000 --steps 2 --no-extras ;;
+  pmcseed) S="--steps 3 --warmup 1 --no-cpu-baseline --no-extras --streams 1"
+        pmc seed_a "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES" python $R/bench.py $S
+        pmc seed_b "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" python $R/bench.py $S
+        pmc seed_c "SQ_LDS_BANK_CONFLICT SQ_LDS_ATOMIC_RETURN SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_WAVES SQ_LDS_ADDR_CONFLICT" python $R/bench.py $S
+        (cd $R && python tools/pmc_summary.py $O/seed_a $O/seed_b $O/seed_c 2>&1 | grep "k_seed \|k_dp_jobs\|k_prep" | tee $O/pmc_seed.txt) ;;
+  nextk) prof nextk python $R/tools/next_kernels.py ;;
+  line) (cd $R
+        python bench.py > $O/bench_line.json 2> $O/bench_line.err
+        for c in 3 4 5; do python bench.py --config $c > $O/bench_config$c.json 2> $O/bench_config$c.err; done
+        python bench.py --gpus 2 --steps 100 --no-extras > $O/bench_2ranks.json 2> $O/bench_2ranks.err
+        python bench.py --gpus 2 --config 4 --regions 1024 > $O/bench_c4_2ranks.json 2> $O/bench_c4_2ranks.err
+        tail -c 600 $O/bench_line.json) ;;
+  soaks) (cd $R
+        python tools/ungapped_crosscheck.py $T 70000 --bigq 2>&1 | tail -1 > $O/soak_ungapped_bigq.json
+        python tools/ungapped_crosscheck.py $T 50000 2>&1 | tail -1 > $O/soak_ungapped.json
+        python tools/native_soak.py $T 2>&1 | tail -3 > $O/soak_native.json
+        python tests/soak/assembler_soak.py $T 2>&1 | tail -1 > $O/soak_assembler.json
+        tail -n 3 $O/soak_*.json) ;;
+esac; done
 cd $R
-python tools/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ > $O/pmc_summary.txt 2>&1
-python tools/profile_round_summary.py $O
-find $O -name "*.csv" -size +2M -delete
-head -12 profiles/r01_kernel_stats.txt; cat profiles/dp_traffic.json
+python tools/profile_round_summary.py $O $TAG
+mkdir -p $O/out && cp profiles/${TAG}_* profiles/dp_traffic.json $O/out/ 2>/dev/null
+find $O -name "*.csv" -size +1M -delete
+find $O -name "*.db" -size +1M -delete

@@ -1,53 +1,100 @@
-"""Turn the outputs of tools/profile_round.sh (rocprofv3 CSVs under gpurun_out/<dir>) into the files kept under profiles/."""
+"""Turn the outputs of tools/profile_round.sh (rocprofv3 CSVs under gpurun_out/<tag>p) into the files kept under profiles/ (<tag>_*).
+Only the parts that were run are rewritten.  usage: profile_round_summary.py <dir> <tag>"""
 import csv
+import datetime
 import glob
 import json
 import os
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CMD = "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import pmc_summary  # noqa: E402
+
+
+STATS_ONLY = ("plat::k_sum_job_cells", "plat::k_stats")     # launched only when the caller asks for statistics / the profile hooks are on
 
 
 def stats(dirname, out, title):
-    path = glob.glob(dirname + "/*/*_kernel_stats.csv")[0]
+    paths = glob.glob(dirname + "/*/*_kernel_stats.csv")
+    if not paths:
+        return
     with open(out, "w") as f:
         f.write("# %s\n" % title)
         f.write("%-62s %6s %14s %12s %7s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
-        for r in csv.DictReader(open(path)):
+        for r in csv.DictReader(open(paths[0])):
             f.write("%-62s %6d %14.1f %12.2f %7.2f\n" % (r["Name"].split("(")[0], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e3,
                                                         float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
 
 
-def main(o):
+def pmc(o, names, out, args):
+    dirs = [o + "/" + n for n in names if glob.glob(o + "/" + n + "/*/*_counter_collection.csv")]
+    if not dirs:
+        return None
+    hdr = ("# rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python bench.py %s   (MI355X; tools/profile_round.sh)\n"
+           "# separate passes, one per counter set: %s\n"
+           "# mean per kernel launch; FETCH_SIZE / WRITE_SIZE in KB (raw counters, see MI355X_MICROARCH.md: FETCH_SIZE under-reports 16 B/lane streaming "
+           "reads 2x; these kernels load 1-16 B/lane from scattered addresses -> reported raw)\n# GRBM_GUI_ACTIVE is summed over the 8 XCDs: /8 = busy cycles of the launch\n"
+           % (args, " | ".join(names)))
+    import io
+    buf = io.StringIO()
+    old = sys.stdout
+    sys.stdout = buf
+    try:
+        per = pmc_summary.main(dirs)
+    finally:
+        sys.stdout = old
+    open(out, "w").write(hdr + buf.getvalue())
+    return per
+
+
+def main(o, tag):
     prof = os.path.join(ROOT, "profiles")
-    stats(o + "/stats1", prof + "/r01_kernel_stats.txt",
-          "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 12 --warmup 2 --no-cpu-baseline --streams 1   (MI355X; one batch at a time)")
-    stats(o + "/stats3", prof + "/r01_kernel_stats_pipelined.txt",
-          "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 12 --warmup 2 --no-cpu-baseline   (MI355X; default: 3 batches in flight, "
-          "kernels of different batches overlap and stretch each other)")
-    hdr = ("# rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --streams 1   (MI355X; tools/profile_round.sh)\n"
-           "# three separate passes: C = FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES\n"
-           "# mean per kernel launch; FETCH_SIZE / WRITE_SIZE in KB (raw counters, see MI355X_MICROARCH.md: FETCH_SIZE under-reports 16 B/lane streaming reads 2x; "
-           "these kernels load 1-8 B/lane -> reported raw)\n# GRBM_GUI_ACTIVE is summed over the 8 XCDs: /8 = busy cycles of the launch\n")
-    body = open(o + "/pmc_summary.txt").read()
-    open(prof + "/r01_pmc_hbm.txt", "w").write(hdr + body)
-    per = {}
-    for line in body.split("\n"):
-        if line.startswith("plat::"):
-            name, _, js = line.partition(" ")
-            per[name] = json.loads(js)
+    b2 = "--steps 12 --warmup 2 --no-cpu-baseline --no-extras --batches 3"
+    stats(o + "/stats1", prof + "/" + tag + "_kernel_stats.txt", CMD + b2 + " --streams 1   (MI355X; config 2, one batch at a time)")
+    stats(o + "/stats3", prof + "/" + tag + "_kernel_stats_pipelined.txt", CMD + b2 + "   (MI355X; config 2, default: 3 batches in flight, kernels of different batches overlap)")
+    stats(o + "/stats_c3", prof + "/" + tag + "_assemble_stats.txt", CMD + "--config 3 --regions 2000 --steps 5 --no-extras   (MI355X; config 3: 2000 assembly tiles per launch)")
+    stats(o + "/stats_c3e", prof + "/" + tag + "_config3_end_to_end_stats.txt", CMD + "--config 3 --regions 2000 --steps 1   (MI355X; config 3 incl. END TO END: 2000 regions through the native region loop with --assemble=1, 32 regions per chunk)")
+    stats(o + "/stats_c5", prof + "/" + tag + "_config5_stats.txt", CMD + "--config 5 --windows 200 --steps 10 --warmup 2   (MI355X; config 5: 200 windows x 100 samples per step)")
+    stats(o + "/stats_c4", prof + "/" + tag + "_config4_stats.txt", CMD + "--config 4 --regions 256 --steps 1   (MI355X; config 4: 256 regions x 100 kb streamed through the native region loop)")
+    for f, dst in (("stats3", tag + "_bench_line_under_rocprof.json"), ("stats_c3e", tag + "_bench_config3_under_rocprof.json"), ("stats_c4", tag + "_bench_config4_under_rocprof.json"),
+                   ("stats_c5", tag + "_bench_config5_under_rocprof.json")):
+        p = o + "/" + f + ".json"
+        if os.path.exists(p) and open(p).read().startswith("{"):
+            open(os.path.join(prof, dst), "w").write(open(p).read())
+    per = pmc(o, ["pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ"], prof + "/" + tag + "_pmc_hbm.txt", "--steps 4 --warmup 1 --no-cpu-baseline --no-extras --batches 2 --streams 1")
+    per3 = pmc(o, ["pmc3_FETCH_SIZE", "pmc3_WRITE_SIZE", "pmc3_SQ", "pmc3_WAIT"], prof + "/" + tag + "_pmc_assemble.txt", "--config 3 --regions 2000 --steps 2 --no-extras")
+    tf = prof + "/dp_traffic.json"
+    d = json.load(open(tf)) if os.path.exists(tf) else {}
 
     def pack(k):
         return {"hbm_bytes_per_launch": int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024), "valu_insts_per_launch": int(k["SQ_INSTS_VALU"]),
                 "busy_cycles_per_launch": int(k["GRBM_GUI_ACTIVE"] / 8)}
-    d = {"kernel": "k_dp_jobs"}
-    d.update(pack(per["plat::k_dp_jobs<false>"]))
-    d["source"] = ("profiles/r01_pmc_hbm.txt (rocprofv3 --pmc, separate passes: FETCH_SIZE, WRITE_SIZE raw counters x 1024; SQ_INSTS_VALU; "
-                   "GRBM_GUI_ACTIVE / 8 XCDs)")
-    d["round"] = 1
-    d["k_seed"] = pack(per["plat::k_seed"])
-    json.dump(d, open(prof + "/dp_traffic.json", "w"), indent=1)
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        commit = os.environ.get("PLAT_COMMIT")                          # (the GPU box holds a snapshot without .git: the caller passes it)
+    stamp = {"date": datetime.date.today().isoformat(), "commit": commit, "round": int(tag[1:])}
+    if per:
+        d.update(kernel="k_dp_jobs", **pack(per["plat::k_dp_jobs<false>"]))
+        d["source"] = "profiles/" + tag + "_pmc_hbm.txt (rocprofv3 --pmc, separate passes: FETCH_SIZE, WRITE_SIZE raw counters x 1024; SQ_INSTS_VALU; GRBM_GUI_ACTIVE / 8 XCDs)"
+        d["k_seed"] = pack(per["plat::k_seed"])
+        d["k_prep_reads"] = pack(per["plat::k_prep_reads"])
+        d["step_hbm_bytes"] = int(sum((v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 for k, v in per.items() if k.startswith("plat::") and v.get("launches", 0) >= 4 and k not in STATS_ONLY))
+        d["step_kernels"] = {k: int((v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024) for k, v in per.items() if k.startswith("plat::") and v.get("launches", 0) >= 4 and k not in STATS_ONLY}
+        d["measured"] = stamp
+        d["round"] = int(tag[1:])
+    if per3 and "plat::k_assemble" in per3:
+        d["k_assemble"] = pack(per3["plat::k_assemble"])
+        d["k_assemble"]["regions_per_launch"] = 2000
+        d["k_assemble"]["measured"] = stamp
+        if "SQ_WAIT_ANY" in per3["plat::k_assemble"]:
+            k = per3["plat::k_assemble"]
+            d["k_assemble"]["wait_any_over_wave_cycles"] = k["SQ_WAIT_ANY"] / max(1.0, k["SQ_WAVE_CYCLES"])
+    json.dump(d, open(tf, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r04")
