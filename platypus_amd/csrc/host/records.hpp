@@ -246,11 +246,15 @@ inline uint64_t py2_tuple_hash(const uint64_t* itemHashes, int n) {
     x += 97531ull;
     return x == ~0ull ? ~0ull - 1 : x;
 }
-// hash(Variant) there: hash((refName, refPos, removed, added)), variant.pyx:270-280 (refPos >= 0: hash(int) is the int)
+// hash(Variant) there: hash((refName, refPos, removed, added)), variant.pyx:270-280 (refPos >= 0: hash(int) is the int) -- kept in
+// `public int hashValue` (variant.pxd:31): Cython's hash() is PyObject_Hash -> Py_hash_t, the assignment narrows it to a C int without
+// a check, __hash__ hands the int back (a -1 becomes -2 in the tp_hash slot) and the dictionary probes with the SIGN-EXTENDED low 32 bits
 inline uint64_t py2_variant_hash(uint64_t refNameHash, long long refPos, const char* removed, size_t nRemoved, const char* added, size_t nAdded) {
     const uint64_t h[4] = {refNameHash, (uint64_t)(refPos == -1 ? -2 : refPos), py2_string_hash(std::string(removed, nRemoved)),
                            py2_string_hash(std::string(added, nAdded))};
-    return py2_tuple_hash(h, 4);
+    int64_t narrowed = (int64_t)(int32_t)(uint32_t)py2_tuple_hash(h, 4);
+    if (narrowed == -1) narrowed = -2;
+    return (uint64_t)narrowed;
 }
 // Iteration order of a Python-2 dict into which DISTINCT keys with these hashes were inserted in this order and never deleted
 // (dictobject.c: a new key takes the first empty slot of its probe sequence i = 5 i + perturb + 1, perturb >>= 5; the table of 8 slots

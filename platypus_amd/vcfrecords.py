@@ -68,10 +68,17 @@ def py2_tuple_hash(item_hashes):
 
 
 def py2_variant_hash(ref_name, ref_pos, removed, added):
-    """hash(Variant) of the reference = hash((refName, refPos, removed, added)), variant.pyx:270-280."""
+    """hash(Variant) of the reference = hash((refName, refPos, removed, added)), variant.pyx:270-280, as the dictionary sees it: the
+    value is kept in `public int hashValue` (variant.pxd:31) -- Cython's hash() is PyObject_Hash (Py_hash_t) and the assignment narrows it
+    to a C int without a check -- so the table is probed with the sign-extended low 32 bits (a narrowed -1 leaves tp_hash as -2)."""
     as_str = lambda b: b.decode("latin-1") if isinstance(b, bytes) else b
-    return py2_tuple_hash([_py2_string_hash(as_str(ref_name)), (-2 if ref_pos == -1 else ref_pos) & ((1 << 64) - 1),
-                           _py2_string_hash(as_str(removed)), _py2_string_hash(as_str(added))])
+    h = py2_tuple_hash([_py2_string_hash(as_str(ref_name)), (-2 if ref_pos == -1 else ref_pos) & ((1 << 64) - 1),
+                        _py2_string_hash(as_str(removed)), _py2_string_hash(as_str(added))]) & 0xFFFFFFFF
+    if h >= 1 << 31:
+        h -= 1 << 32
+    if h == -1:
+        h = -2
+    return h & ((1 << 64) - 1)
 
 
 def py2_dict_slot_order(hashes):

@@ -139,3 +139,10 @@ def test_tuple_hash_and_dict_order_of_variant_keys(native):
         hs = [V.py2_variant_hash(*v) for v in vs]
         assert hs == [native.plat_caller_debug_variant_hash(v[0].encode(), v[1], v[2].encode(), v[3].encode()) for v in vs]
         assert V.py2_dict_slot_order(hs) == n_order(hs) and sorted(n_order(hs)) == list(range(len(vs)))
+        # `public int hashValue` (variant.pxd:31): the dictionary sees the sign-extended low 32 bits of the tuple hash
+        for v, h in zip(vs, hs):
+            full = V.py2_tuple_hash([V._py2_string_hash(v[0]), v[1], V._py2_string_hash(v[2]), V._py2_string_hash(v[3])])
+            low = full & 0xFFFFFFFF
+            want = low if low < 1 << 31 else low + (((1 << 32) - 1) << 32)
+            assert h == (want if want != (1 << 64) - 1 else (1 << 64) - 2)
+            assert (h >> 31) in (0, (1 << 33) - 1)
