@@ -291,7 +291,7 @@ def callWindowsBatched(specs, options, refFile):
     hb = H._pack_windows([([h.haplotypeSequence for h in p.haplotypes], p.haplotypes[0].startPos, p.haplotypes[0].endPos,
                            p.haplotypes[0].endBufferSize, p.readBuffers) for p in pops])
     db = eng.upload(hb)
-    eng.call_windows(db, want_stats=False)                                       # likelihoods + genotype likelihoods
+    eng.call_windows(db, want_stats=False, calc_flank_score=int(options.calculateFlankScore))   # likelihoods + genotype likelihoods
     like, score = eng.haplotype_scores(db)
     eng.em(db, 100, int(options.useEMLikelihoods))
     eng.synchronize()

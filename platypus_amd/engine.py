@@ -208,14 +208,15 @@ class Engine:
                                                  db.logl.data_ptr(), db.gof.data_ptr(), self._stream())
         _lib.check(rc, "plat_genotype_window_batch")
 
-    def call_windows(self, db: DeviceBatch, want_stats=True, asynchronous=False):
+    def call_windows(self, db: DeviceBatch, want_stats=True, asynchronous=False, calc_flank_score=0):
         """One pass of the hot path: likelihood arrays, then genotype likelihoods (Population.setup).
-        asynchronous=True: nothing is read back and nothing waits (no statistics; errors surface in synchronize())."""
+        asynchronous=True: nothing is read back and nothing waits (no statistics; errors surface in synchronize()).
+        calc_flank_score = options.calculateFlankScore (chaplotype.pyx:606-612)."""
         if asynchronous and not want_stats:
-            self.align_async(db)
+            self.align_async(db, calc_flank_score=calc_flank_score)
             st = None
         else:
-            st = self.align(db, want_stats=want_stats)
+            st = self.align(db, want_stats=want_stats, calc_flank_score=calc_flank_score)
         self.genotype(db)
         return st
 

@@ -710,6 +710,79 @@ class Py2Set(object):
         return self.used
     def __contains__(self, key):
         return self.table[self._slot(self.table, self.mask, key, py2_hash(key))] is not None
+
+
+def py2_tuple_hash(item_hashes):
+    # tupleobject.c (2.7), unsigned 64-bit
+    x, mult, n = 0x345678, 1000003, len(item_hashes)
+    for i, h in enumerate(item_hashes):
+        left = n - 1 - i
+        x = ((x ^ (h & _M)) * mult) & _M
+        mult = (mult + 82520 + left + left) & _M
+    x = (x + 97531) & _M
+    return _M - 1 if x == _M else x
+
+
+def py2_variant_hash(refName, refPos, removed, added):
+    # Variant.__hash__ (variant.pyx:270-280) as the dictionary sees it: hash((refName, refPos, removed, added)) kept in
+    # `public int hashValue` (variant.pxd:31), i.e. the sign-extended low 32 bits (-1 -> -2)
+    h = py2_tuple_hash([py2_hash(refName), (-2 if refPos == -1 else refPos) & _M, py2_hash(removed), py2_hash(added)]) & 0xFFFFFFFF
+    if h >= 1 << 31:
+        h -= 1 << 32
+    if h == -1:
+        h = -2
+    return h & _M
+
+
+def py2_dict_slot_order(hashes):
+    # dictobject.c (2.7): distinct keys inserted in this order, never deleted -> indices in iteration (slot) order
+    def place(table, key):
+        h = hashes[key]
+        mask = len(table) - 1
+        i, perturb = h & mask, h
+        while table[i & mask] is not None:
+            i = (5 * i + perturb + 1) & _M
+            perturb >>= 5
+        table[i & mask] = key
+    table, used = [None] * 8, 0
+    for key in range(len(hashes)):
+        place(table, key)
+        used += 1
+        if used * 3 >= len(table) * 2:
+            size = 8
+            while size <= used * (2 if used > 50000 else 4):
+                size <<= 1
+            grown = [None] * size
+            for k in table:
+                if k is not None:
+                    place(grown, k)
+            table = grown
+    return [k for k in table if k is not None]
+
+
+class Py2Dict(object):
+    # The candidate dictionaries of the reference (VariantCandidateGenerator.variantHeap, variant.pyx:482: Variant -> Variant) with
+    # the iteration order a Python-2 dict has; only the operations the reference's text uses.
+    def __init__(self):
+        self.order, self.vals = [], {}
+    @staticmethod
+    def _k(v):
+        return (v.refName, v.refPos, v.removed, v.added)
+    def get(self, key, default=None):
+        return self.vals.get(self._k(key), default)
+    def __setitem__(self, key, value):
+        k = self._k(key)
+        if k not in self.vals:
+            self.order.append(k)
+        self.vals[k] = value
+    def __len__(self):
+        return len(self.order)
+    def _slots(self):
+        return [self.order[i] for i in py2_dict_slot_order([py2_variant_hash(*k) for k in self.order])]
+    def values(self):
+        return [self.vals[k] for k in self._slots()]
+    def iteritems(self):
+        return iter([(self.vals[k], self.vals[k]) for k in self._slots()])
 """
 
 VCFINFO_HEAD = r"""
@@ -1100,11 +1173,328 @@ exts = [Extension("calign", ["calign.pyx", "align.c"], include_dirs=["."]),
         Extension("pop_drv", ["pop_drv.pyx"]),
         Extension("hap_drv", ["hap_drv.pyx"], include_dirs=["."], extra_objects=["tandem.o"]),
         Extension("vcf_drv", ["vcf_drv.pyx"]),
-        Extension("win_drv", ["win_drv.pyx"], include_dirs=["."])]
+        Extension("win_drv", ["win_drv.pyx"], include_dirs=["."]),
+        Extension("rgn_drv", ["rgn_drv.pyx"], include_dirs=["."], extra_objects=["tandem.o"])]
 setup(ext_modules=cythonize(exts, language_level=2,
       compiler_directives=dict(cdivision=True, cpow=True, legacy_implicit_noexcept=True,
                                c_string_type='bytes', c_string_encoding='ascii')))
 '''
+
+
+
+# ------------------------------------------------------------------------------------------------
+# Region driver (rgn_drv): the reference's region loop AS TEXT -- variantcaller.pyx:74-141 (callVariantsInWindow), :276-321
+# (doWeNeedToAssembleThisRegion), :325-390 (mergeHaplotypes), :412-531 (generateVariantsInRegion incl. the assembler tiling),
+# :535-615 (callVariantsInRegion) -- compiled in ONE module together with the whole classes they drive: ReadArray /
+# bamReadBuffer (cwindow.pyx:40-766), Haplotype (chaplotype.pyx:119-590,594-676), DiploidGenotype (cgenotype.pyx:85-222),
+# Population (cpopulation.pyx:84-720), VariantCandidateGenerator (variant.pyx:459-751), the filters (variantFilter.pyx), vcfINFO /
+# vcfFILTER (vcfutils.pyx) and the assembler (assembler.pyx:30-1476).  Stand-ins: FastaFile (in memory), loadBAMData (reads come
+# from Python lists through bamReadBuffer.addReadToBuffer, the reference's own QC), outputCallToVCF (a bridge into vcf_drv, where the
+# same reference text runs on native strings as under Python 2), outputRefCall (not part of these cases).
+RGN_HEAD = r"""
+from __future__ import division
+cimport cython
+import cython
+import logging
+import math
+import heapq
+from collections import defaultdict
+from bisect import bisect
+from calign cimport hash_sequence_multihit, hashReadForMapping, mapAndAlignReadToHaplotype
+from calign cimport hash_nucs, hash_size
+from htslibWrapper cimport cAlignedRead
+from py2compat import py2_round, Py2Dict
+logger = logging.getLogger("Log")
+StandardError = Exception
+xrange = range
+round = py2_round          # Python-2 round() (see py2compat.py)
+
+cdef extern from "math.h":
+    double exp(double)
+    double log(double)
+    double log2(double)
+    double log10(double)
+    double fabs(double)
+    double sqrt(double)
+    double pow(double, double)
+    double c_round "round"(double)
+cdef extern from "stdlib.h":
+    void free(void *)
+    void *malloc(size_t)
+    void *calloc(size_t, size_t)
+    void *realloc(void *, size_t)
+cdef extern from "string.h":
+    void *memset(void *buffer, int ch, size_t count)
+    void *memcpy(void *dst, void *src, size_t len)
+
+cdef void* my_malloc(size_t n):
+    return malloc(n)
+cdef void* my_calloc(size_t a, size_t b):
+    return calloc(a, b)
+cdef void* my_realloc(void* p, size_t n):
+    return realloc(p, n)
+cdef void my_free(void* p):
+    free(p)
+
+@@FLAGS@@
+
+from operator import attrgetter
+from itertools import combinations
+from heapq import heappush, heappop, heappushpop
+nSupportingReadsGetter = attrgetter("nSupportingReads")
+
+cdef int SNP = 0
+cdef int MNP = 1
+cdef int INS = 2
+cdef int DEL = 3
+cdef int REP = 4
+cdef int PLATYPUS_VAR = 1
+cdef int FILE_VAR = 2
+cdef int ASSEMBLER_VAR = 4
+cdef double PI = math.pi
+
+cdef class SeqInfo:
+    cdef public long long SeqLength
+    def __init__(self, n):
+        self.SeqLength = n
+
+cdef class FastaFile:
+    # in-memory stand-in for fastafile.pyx:120-207 (file I/O is outside the scope): half-open interval clamped to [0, len-1]; "-" for a
+    # position outside the sequence; setCacheSequence is a no-op
+    cdef public dict refs
+    cdef public dict seqs
+    def __init__(self, seqs):
+        self.seqs = seqs
+        self.refs = dict((k, SeqInfo(len(v))) for k, v in self.seqs.items())
+    def setCacheSequence(self, seqName, beginPos, endPos):
+        pass
+    def getSequence(self, seqName, beginPos, endPos):
+        s = self.seqs[seqName]
+        beginPos = max(0, beginPos)
+        endPos = min(len(s) - 1, endPos)
+        if endPos < beginPos:
+            raise IndexError("Cannot have beginPos = %s, endPos = %s" % (beginPos, endPos))
+        return s[beginPos:endPos]
+    def getCharacter(self, seqName, pos):
+        s = self.seqs[seqName]
+        if pos >= len(s) or pos < 0:
+            return b"-"
+        return s[pos:pos + 1]
+
+# (compressed reads are not part of the fixtures: Read_IsCompressed is never true)
+cdef void compressRead(cAlignedRead* read, char* refSeq, int refStart, int refEnd, int qualBinSize, int fullComp):
+    pass
+cdef void uncompressRead(cAlignedRead* read, char* refSeq, int refStart, int refEnd, int qualBinSize):
+    pass
+cdef void destroyRead(cAlignedRead* r):
+    pass
+variantutils = None        # (--source is not part of the cases)
+def countTotalReadsInRegion(list readBuffers):
+    # debug statistics of variantcaller.pyx:209-272, only printed with verbosity >= 3
+    return 0, 0, 0
+"""
+
+RGN_TAIL = r"""
+# ---- stand-ins and the driver ----------------------------------------------------------------------------------------------
+import vcf_drv
+
+cdef cAlignedRead* rgn_make_read(dict t):
+    # a cAlignedRead as htslibWrapper.pyx:330-420 leaves it: seq / qual / cigarOps in malloc'ed arrays of their own
+    cdef int n = len(t["seq"]), k
+    cdef bytes seq = t["seq"]
+    cdef cAlignedRead* r = <cAlignedRead*>calloc(1, sizeof(cAlignedRead))
+    r.seq = <char*>calloc(n + 1, 1)
+    r.qual = <char*>calloc(n + 1, 1)
+    memcpy(r.seq, <char*>seq, n)
+    for k in range(n):
+        r.qual[k] = t["qual"][k]
+    r.rlen = n
+    r.pos, r.end, r.mapq, r.bitFlag = t["pos"], t["end"], t["mapq"], t["flag"]
+    r.chromID, r.mateChromID, r.insertSize, r.matePos = t["chromID"], t["mateChromID"], t["insertSize"], t["matePos"]
+    r.cigarLen = len(t["cigar"])
+    r.cigarOps = <short*>calloc(2 * len(t["cigar"]) + 2, sizeof(short))
+    for k, (op, ln) in enumerate(t["cigar"]):
+        r.cigarOps[2 * k] = op
+        r.cigarOps[2 * k + 1] = ln
+    r.hash = NULL
+    return r
+
+cdef list rgn_dump_array(ReadArray ra):
+    cdef int i, k
+    cdef cAlignedRead* r
+    out = []
+    for i in range(ra.getSize()):
+        r = ra.array[i]
+        out.append(dict(seq=bytes(r.seq[:r.rlen]).decode(), qual=[r.qual[k] for k in range(r.rlen)], pos=r.pos, end=r.end, mapq=r.mapq,
+                        flag=r.bitFlag, matePos=r.matePos, cigar=[[r.cigarOps[2 * k], r.cigarOps[2 * k + 1]] for k in range(r.cigarLen)]))
+    return out
+
+class Loader(object):
+    # what the caller hands over as `bamFiles`: raw reads per region and sample; `loaded` keeps what loadBAMData returned
+    def __init__(self, regions):
+        self.regions = regions            # {(chrom, start, end): [(sampleName, [raw read dict ...], [raw broken-mate dict ...]) ...]}
+        self.loaded = {}
+
+cdef list loadBAMData(bamFiles, bytes chrom, int start, int end, options, list samples, dict samplesByID, dict samplesByBAM, char* refSeq):
+    # stand-in for platypusutils.pyx:449-686 (BAM reading is outside the scope), the one-sample-per-file shape: per sample a
+    # bamReadBuffer (the reference's constructor), every read through addReadToBuffer (the reference's checkAndTrimRead), broken mates
+    # appended as fetched, then chromID / sortBrokenMates / sortReads / logFilterSummary and the buffers sorted by sample name (:664-686);
+    # the maxReads bail-out of :538-541 returns None
+    cdef bamReadBuffer theReadBuffer
+    cdef cAlignedRead* theRead
+    cdef list readBuffers = []
+    cdef int totalReads = 0
+    cdef int maxReads = options.maxReads
+    for sample, reads, broken in bamFiles.regions[(chrom, start, end)]:
+        theReadBuffer = bamReadBuffer(chrom, start, end, options)
+        theReadBuffer.sample = bytes(sample)
+        for t in reads:
+            theRead = rgn_make_read(t)
+            theReadBuffer.addReadToBuffer(theRead)
+            totalReads += 1
+            if totalReads >= maxReads:
+                return None
+        for t in broken:
+            theRead = rgn_make_read(t)
+            theReadBuffer.brokenMates.append(theRead)
+        readBuffers.append(theReadBuffer)
+    cdef list sortedBuffers = []
+    for theReadBuffer in readBuffers:
+        if theReadBuffer.reads.getSize() > 0:
+            theReadBuffer.chromID = theReadBuffer.reads.array[0].chromID
+        if theReadBuffer.brokenMates.getSize() > 0:
+            theReadBuffer.sortBrokenMates()
+        if not theReadBuffer.isSorted:
+            theReadBuffer.sortReads()
+        theReadBuffer.logFilterSummary()
+        sortedBuffers.append((theReadBuffer.sample, theReadBuffer))
+    sortedBuffers.sort()
+    out = [x[1] for x in sortedBuffers]
+    bamFiles.loaded[(chrom, start, end)] = [dict(sample=theReadBuffer.sample.decode(), reads=rgn_dump_array(theReadBuffer.reads),
+                                                 badReads=rgn_dump_array(theReadBuffer.badReads), brokenMates=rgn_dump_array(theReadBuffer.brokenMates))
+                                            for theReadBuffer in out]
+    return out
+
+def rgn_dec(x):
+    return x.decode() if isinstance(x, bytes) else x
+
+cdef void outputCallToVCF(dict varsByPos, dict vcfInfo, dict vcfFilter, list haplotypes, list genotypes, double* haplotypeFrequencies, double** genotypeLikelihoods, double** gofValues, int** haplotypeIndexes, list readBuffers, int nIndividuals, vcfFile, FastaFile refFile, outputFile, options, list allVariants, int windowStart, int windowEnd) except *:
+    # bridge: the reference's outputCallToVCF text lives in vcf_drv, on native strings as under Python 2; this hands it the window's
+    # Population fields with byte strings decoded and the C arrays as lists (haplotypeIndexes must be the canonical (i, j >= i) order
+    # vcf_drv.window_records assumes)
+    cdef int nHap = len(haplotypes), nG = len(genotypes), i, j, g
+    cdef Variant v
+    cdef Haplotype h
+    cdef bamReadBuffer b
+    smap = {}
+    def sv(Variant x):
+        if id(x) not in smap:
+            smap[id(x)] = vcf_drv.Variant(x.refName.decode(), x.refPos, x.removed.decode(), x.added.decode(), len(smap))
+        return smap[id(x)]
+    svars = [sv(v) for v in allVariants]
+    g = 0
+    for i in range(nHap):
+        for j in range(i, nHap):
+            assert haplotypeIndexes[g][0] == i and haplotypeIndexes[g][1] == j
+            g += 1
+    assert g == nG
+    sVarsByPos = dict((pos, [sv(v) for v in vs]) for pos, vs in varsByPos.items())
+    sInfo = dict((sv(v), dict((key, [rgn_dec(x) for x in val]) for key, val in d.items())) for v, d in vcfInfo.items())
+    sFilter = dict((sv(v), list(f)) for v, f in vcfFilter.items())
+    shaps = [vcf_drv.Haplotype(tuple(sv(v) for v in h.variants)) for h in haplotypes]
+    freqs = [haplotypeFrequencies[i] for i in range(nHap)]
+    gl = [[genotypeLikelihoods[i][g] for g in range(nG)] for i in range(nIndividuals)]
+    gof = [[gofValues[g][i] for i in range(nIndividuals)] for g in range(nG)]
+    nReads = []
+    names = []
+    for b in readBuffers:
+        nReads.append(b.reads.windowEnd - b.reads.windowStart)
+        names.append(b.sample)
+    sFasta = vcf_drv.FastaFile(dict((rgn_dec(k), x.decode()) for k, x in refFile.seqs.items()))
+    vcf_drv.window_records(sVarsByPos, sInfo, sFilter, shaps, freqs, gl, gof, nReads, names, vcfFile, sFasta, outputFile, options, svars, windowStart, windowEnd)
+
+def outputRefCall(chrom, pop, vcfFile, refFile, outputFile, windowIndex, window, options, readBuffers):
+    raise NotImplementedError("outputRefCalls is not part of the region cases (refcall_cases pins outputRefCall)")
+
+def run_regions(list regions, loader, FastaFile refFile, options, windowGenerator, outputFile, vcfFile):
+    # PlatypusSingleProcess.run (variantcaller.pyx:959-977): ONE Population and one options object for the whole region list
+    cdef Population pop = Population(options)
+    samples = sorted(set(name for lst in loader.regions.values() for name, _, _ in lst))
+    for chrom, start, end in regions:
+        callVariantsInRegion(chrom, start, end, loader, refFile, options, windowGenerator, outputFile, vcfFile, samples, {}, {}, pop)
+"""
+
+
+def class_with_attrs(text, header, pxd_lines, extra=""):
+    """Put the attribute declarations a .pxd holds for a cdef class (the lines without a parameter list) into the class body."""
+    attrs = [l for l in pxd_lines if l.strip() and "(" not in l and not l.strip().startswith("#") and l.strip() != "cdef:"]
+    body = "\n".join("    cdef " + l.strip().replace("cdef ", "", 1) if not l.strip().startswith("cdef ") else "    " + l.strip() for l in attrs)
+    assert header in text, header
+    return text.replace(header, header + "\n" + body + "\n" + extra, 1)
+
+
+def region_driver_text(L):
+    """rgn_drv.pyx from the line lists build_scratch read (L = its locals)."""
+    chp, gen, pop, vcu, var, utl, vfl, vpx, cwn, cwp, hpx, cem, vca, asm = (L[k] for k in ("chp", "gen", "pop", "vcu", "var", "utl", "vfl", "vpx", "cwn", "cwp", "hpx", "cem", "vca", "asm"))
+    src = os.path.join(REF, "src")
+    chx = open(os.path.join(src, "cython/chaplotype.pxd")).read().split("\n")
+    gnx = open(os.path.join(src, "cython/cgenotype.pxd")).read().split("\n")
+    ppx = open(os.path.join(src, "cython/cpopulation.pxd")).read().split("\n")
+    # --- cwindow.pyx:40-766: filter-type constants, qsort comparators, ReadArray, bisectReads*, checkAndTrimRead, bamReadBuffer
+    assert cwn[39].startswith("cdef int LOW_QUAL_BASES") and cwn[108].startswith("cdef class ReadArray") and cwn[484].startswith("cdef class bamReadBuffer(object):")
+    assert cwn[765].strip().startswith("qsort(self.brokenMates.array") and cwp[12].startswith("cdef class ReadArray") and cwp[28].startswith("cdef class bamReadBuffer")
+    assert sum(l.strip() == "int abs(int)" for l in cwn[39:766]) == 1
+    cw = "\n".join(l for l in cwn[39:766] if l.strip() != "int abs(int)") + "\n"      # (its C abs(int) would capture cgenotype's abs(double): Cython's own abs serves both)
+    cw = class_with_attrs(cw, "cdef class ReadArray:", cwp[13:19])
+    cw = class_with_attrs(cw, "cdef class bamReadBuffer(object):", cwp[29:52])
+    # --- variant.pyx: as in hap_drv (restated constructor, everything else text), the generator's dictionary is py2compat's Py2Dict
+    assert vpx[67].strip() == "cdef dict variantHeap" and var[481].strip().startswith("self.variantHeap   = {}")
+    vcg = ("cdef class VariantCandidateGenerator:\n" + "\n".join(vpx[44:73]).replace("cdef dict variantHeap", "cdef object variantHeap") + "\n"
+           + "\n".join(var[462:751]).replace("insertedSequence.count('N')", "insertedSequence.count(b'N')").replace('deletedSequence.count("N")', "deletedSequence.count(b'N')")
+           .replace("self.variantHeap   = {}", "self.variantHeap   = Py2Dict()") + "\n")
+    # --- chaplotype.pyx: the WHOLE class (:119-590) with the attributes of chaplotype.pxd, alignReadToHaplotype (:594-676)
+    assert chp[118].strip() == "@cython.final" and chp[119].startswith("cdef class Haplotype:") and chp[589].strip() == "homopol = 0" and chp[591].startswith("####")
+    assert chx[12].strip() == "@cython.final" and chx[13].startswith("cdef class Haplotype:") and chx[14].strip() == "cdef:"
+    hapc = "\n".join(chp[118:590]).replace("bytes(''.join(bitsOfMutatedSeq))", "b''.join(bitsOfMutatedSeq)") + "\n"
+    hapc = class_with_attrs(hapc, "cdef class Haplotype:", chx[15:43])
+    # --- cgenotype.pyx: constants (:23-28), DiploidGenotype (:85-189), generateAllGenotypesFromHaplotypeList (:193-222)
+    assert gen[84].strip() == "@cython.final" and gen[85].startswith("cdef class DiploidGenotype(object):") and gen[192].startswith("cdef list generateAllGenotypesFromHaplotypeList")
+    assert gnx[7].strip() == "@cython.final" and gnx[8].startswith("cdef class DiploidGenotype:")
+    genc = class_with_attrs("\n".join(gen[84:190]) + "\n", "cdef class DiploidGenotype(object):", gnx[9:13])
+    genc = "\n".join(gen[23:28]) + "\n\n" + genc + "\n" + "\n".join(gen[192:222]) + "\n"       # (mLTOT, :23, is chaplotype's too)
+    # --- cpopulation.pyx: the WHOLE class (:84-720); module-qualified vcfutils.* calls unqualified (same module here), C round() renamed
+    assert pop[83].startswith("cdef class Population:") and pop[719].strip() == "self.computeVariantFILTER()" and ppx[11].startswith("cdef class Population:")
+    popc = "\n".join(pop[83:720]).replace("vcfutils.vcfINFO", "vcfINFO").replace("vcfutils.vcfFILTER", "vcfFILTER").replace("round(", "c_round(") + "\n"
+    popc = class_with_attrs(popc, "cdef class Population:", ppx[15:43])
+    # --- variantFilter.pyx pieces
+    assert vfl[358].startswith("cdef double computeVariantReadSupportFrac") and vfl[372].strip() == "return varFrac"
+    assert vfl[625].startswith("cdef list getHaplotypesInWindow") and vfl[649].strip().startswith("return getFilteredHaplotypes")
+    # --- assembler.pyx:30-1476 (whole, with its loader and entry point)
+    assert asm[1428].startswith("cdef list assembleReadsAndDetectVariants") and asm[1475].strip() == "return sorted(theVars)"
+    # --- variantcaller.pyx: the five functions
+    assert vca[73].startswith("cdef void callVariantsInWindow") and vca[140].strip() == "pop.call(maxEMIterations, 1)"
+    assert vca[275].startswith("cdef int doWeNeedToAssembleThisRegion") and vca[320].strip() == "return 0"
+    assert vca[324].startswith("cdef list mergeHaplotypes") and vca[389].strip() == "return mergedHaplotypes"
+    assert vca[411].startswith("cdef list generateVariantsInRegion") and vca[526].strip() == "return filteredVariants"
+    assert vca[534].startswith("cdef void callVariantsInRegion") and vca[614].strip().startswith('logger.warning("Window %s:%s-%s will be skipped"')
+    vct = ("\n".join(vca[73:141]) + "\n\n" + "\n".join(vca[275:321]) + "\n\n" + "\n".join(vca[324:390]) + "\n\n" + "\n".join(vca[411:527]) + "\n\n"
+           + "\n".join(vca[534:615]) + "\n").replace("variantFilter.getHaplotypesInWindow", "getHaplotypesInWindow")
+    drv = (RGN_HEAD.replace("@@FLAGS@@", "\n".join(hpx[233:296])) + cw + "\n"
+           + L["mltot"] + "\n" + chp[63] + "\n" + L["homopol"] + "\n\n" + TANDEM_HEAD + "\n".join(cem[22:36]) + "\n\n" + L["prior_table"] + "\n" + "\n".join(var[93:95]) + "\n\n"
+           + VAR_CLASS + "\n" + L["indel_prior_text"] + "\n\n" + "\n".join(var[218:259]) + "\n\n" + "\n".join(var[269:280]) + "\n\n"
+           + "\n".join(var[281:363]) + "\n\n" + "\n".join(var[260:268]) + "\n\n" + "\n".join(chp[102:115]) + "\n"
+           + hapc + "\n" + "\n".join(chp[593:676]) + "\n\n" + genc + "\n"
+           + "cdef class Population\n" + "cdef class bamReadBufferFwd:\n    pass\n"
+           + "\n".join(utl[734:802]) + "\n\n" + "\n".join(vfl[236:283]) + "\n\n" + "\n".join(vfl[358:373]) + "\n\n" + "\n".join(vfl[376:506]) + "\n\n"
+           + "\n".join(vfl[625:652]) + "\n\n" + vcg
+           + "\n".join(vcu[58:67]) + "\n\n" + "\n".join(vcu[900:944]) + "\n\n" + "\n".join(vcu[960:1073]) + "\n"
+           + "\n".join(utl[177:193]) + "\n\n" + "\n".join(utl[212:219]) + "\n\n"
+           + "\n".join(utl[266:296]) + "\n\n" + "\n".join(utl[305:316]) + "\n\n" + "\n".join(vcu[1155:1223]) + "\n"
+           + "\n".join(vcu[1075:1115]) + "\n\n" + "\n".join(vcu[1117:1153]) + "\n\n" + "\n".join(vcu[1225:1460]) + "\n\n"
+           + "\n".join(vcu[1479:1498]) + "\n\n" + "\n".join(vcu[1501:1627]) + "\n\n"
+           + "\n".join(utl[805:931]).replace('bytes("")', 'b""') + "\n\n" + "\n".join(vfl[97:171]) + "\n\n" + "\n".join(vfl[570:622]) + "\n\n"
+           + popc + "\n" + "\n".join(asm[29:1476]).replace("int strncpy(char* dest, char* source, int n)", "int strncpy(char* dest, char* source, int count)") + "\n\n" + vct + RGN_TAIL)
+    return drv
 
 
 def build_scratch(scratch):
@@ -1267,6 +1657,8 @@ def build_scratch(scratch):
     vdrv += (REFCALL_HEAD + "\n".join(utl[177:193]) + "\n\n" + "\n".join(utl[212:219]) + "\n\n" + "\n".join(utl[266:296]) + "\n\n" + "\n".join(utl[305:316]) + "\n\n"
              + "\n".join(vca[763:867]).replace("def outputRefCall(bytes chrom,", "def outputRefCall(chrom,") + "\n" + REFCALL_TAIL)
     open(os.path.join(scratch, "vcf_drv.pyx"), "w").write(vdrv)
+    asm = open(os.path.join(src, "cython/assembler.pyx")).read().split("\n")
+    open(os.path.join(scratch, "rgn_drv.pyx"), "w").write(region_driver_text(locals()))
     open(os.path.join(scratch, "py2compat.py"), "w").write(PY2COMPAT)
     open(os.path.join(scratch, "setup.py"), "w").write(SETUP)
     r = subprocess.run([sys.executable, "setup.py", "build_ext", "--inplace"], cwd=scratch,
@@ -2522,6 +2914,248 @@ def gen_population(out):
     print("population: %d cases, %d genotype-call records" % (len(cases), sum(len(c["genotype_calls"]) for c in cases)))
 
 
+
+def gen_region(out):
+    """The region loop as the reference runs it (SURVEY 8(f) rank 2 `mergeHaplotypes` and the glue of rank 4): rgn_drv's
+    callVariantsInRegion text (variantcaller.pyx:535-615) over generateVariantsInRegion (:412-531, incl. the assembler tiles and
+    doWeNeedToAssembleThisRegion :276-321), WindowGenerator (window.py text), callVariantsInWindow (:74-141), mergeHaplotypes
+    (:325-390), the whole Population / Haplotype / bamReadBuffer classes, and the record writer of vcf_drv.  One case = one process:
+    a region list called in order with one options object and one Population.  Inputs stored: the contig, the options that differ
+    from the defaults, and per region and sample the read buffers AS LOADED (after addReadToBuffer's QC: reads / badReads /
+    brokenMates); output: the record lines and the windows the reference's try/except skipped."""
+    import io, logging, types
+    import rgn_drv
+    from platypus_amd.options import default_options
+    VCF, infoSig, filterSig, formatSig = build_vcf_writer()
+    swallowed = []
+    sys.unraisablehook = lambda u: swallowed.append(repr(u.exc_value))       # "cdef void" texts would hide an exception
+    wpy = open(os.path.join(REF, "src/python/window.py")).read().split("\n")
+    assert wpy[17].startswith("class WindowGenerator(object):") and wpy[237].strip() == "yield thisWindow"
+    wns = dict(xrange=range, logger=logging_stub())
+    exec(compile("from __future__ import division\n" + "\n".join(wpy[17:238]) + "\n", "window_py_slice", "exec"), wns)
+
+    class Capture(logging.Handler):
+        def __init__(self):
+            logging.Handler.__init__(self, logging.DEBUG)
+            self.msgs, self.merges = [], 0
+        def emit(self, record):
+            if record.levelno >= logging.WARNING:
+                self.msgs.append((record.levelname, record.getMessage()))
+            elif record.getMessage().startswith("Merging haplotypes"):       # mergeHaplotypes, variantcaller.pyx:348
+                self.merges += 1
+    log = logging.getLogger("Log")
+    log.setLevel(logging.DEBUG)
+    log.propagate = False
+    cap = Capture()
+    log.addHandler(cap)
+
+    rng = np.random.default_rng(97531)
+    QBINS = np.array([37, 37, 37, 32, 27, 22, 12, 6, 2], np.uint8)
+
+    def quals(n, noisy):
+        q = np.empty(n, np.uint8)
+        i = 0
+        while i < n:
+            k = int(rng.integers(8, 60))
+            q[i:i + k] = QBINS[int(rng.integers(0, 3 if not noisy else len(QBINS)))] if rng.random() < 0.8 else QBINS[int(rng.integers(0, len(QBINS)))]
+            i += k
+        if rng.random() < 0.25:                                  # a low-quality tail
+            k = int(rng.integers(3, 25)); q[n - k:] = QBINS[int(rng.integers(5, len(QBINS)))]
+        return q
+
+    def plant(ref, lo, hi, n_snp, n_indel, clusters):
+        vs, used = [], set()
+        def free(p_, span):
+            return all(abs(p_ - u) > span for u in used)
+        def add_snp(p_):
+            rem = ref[p_:p_ + 1]; vs.append((p_, rem, bytes([B[(B.index(rem[0]) + 1 + int(rng.integers(0, 3))) % 4]]))); used.add(p_)
+        for _ in range(n_snp):
+            p_ = int(rng.integers(lo, hi))
+            if free(p_, 1):
+                add_snp(p_)
+        for c0, k, gap in clusters:                              # dense clusters: windows with > 5 / > maxVariants variants
+            p_ = c0
+            for _ in range(k):
+                if free(p_, 0) and p_ < hi:
+                    add_snp(p_)
+                p_ += int(rng.integers(2, gap))
+        for _ in range(n_indel):
+            p_ = int(rng.integers(lo, hi))
+            if not free(p_, 12):
+                continue
+            k = int(min(40, rng.geometric(0.25)))
+            if rng.random() < 0.5:
+                vs.append((p_, b"", rnd(rng, k)))
+            else:
+                vs.append((p_, ref[p_ + 1:p_ + 1 + k], b""))
+            used.update(range(p_ - 2, p_ + k + 2))
+        return sorted(vs)
+
+    def make_reads(ref, start, end, L, depth, vs, mode):
+        """raw reads of one sample over [start, end): a diploid donor, paired-end flags, CIGARs as an aligner would write them"""
+        gt = [(int(rng.random() < 0.55), int(rng.random() < 0.55)) for _ in vs]
+        n = int(depth * (end - start + L) / L)
+        reads, broken = [], []
+        starts = np.sort(rng.integers(max(0, start - L + 5), end - 5, n))
+        for p0 in starts.tolist():
+            hap = int(rng.integers(0, 2))
+            carry = [v for v, g in zip(vs, gt) if g[hap]]
+            ln = L if mode != "mixed" else int(rng.choice([L, L - 24, L + 25]))
+            seq, cg, rend = cigar_read(rng, ref, p0, ln, carry)
+            seq = bytearray(seq)
+            for _ in range(int(rng.poisson(0.004 * len(seq) if mode != "noisy" else 0.02 * len(seq)))):
+                seq[int(rng.integers(0, len(seq)))] = B[int(rng.integers(0, 4))]
+            if mode == "gapless" and any(op in (1, 2) for op, _ in cg):      # an aligner that never opens a gap: plain M
+                cg = [(0, len(seq))]; rend = p0 + len(seq)
+            elif rng.random() < 0.04 and len(seq) > 30:                      # soft clip at the head
+                k = int(rng.integers(3, 12)); cg = [(4, k)] + ([(cg[0][0], cg[0][1] - k)] if cg[0][1] > k else []) + cg[1:]
+                if sum(l_ for o, l_ in cg if o in (0, 1, 4)) != len(seq) or cg[1][0] != 0:
+                    cg = [(0, len(seq))]
+                else:
+                    p0 += k
+            q = quals(len(seq), mode == "noisy")
+            rev = bool(rng.random() < 0.5)
+            ins = int(rng.integers(2 * ln + 20, 2 * ln + 300))
+            if rng.random() < 0.06:
+                ins = int(rng.integers(ln + 5, 2 * ln))                      # overlapping mates: trimOverlapping
+            flag = 1 | 2 | (16 if rev else 32) | (64 if rng.random() < 0.5 else 128)
+            mapq = int(rng.choice([60, 60, 60, 60, 45, 29, 12, 0]))
+            mate = p0 - ins + ln if rev else p0 + ins - ln
+            t = rng.random()
+            mchrom = 19
+            if t < 0.02:
+                flag |= 1024                                                 # duplicate
+            elif t < 0.03:
+                flag |= 256                                                  # secondary
+            elif t < 0.05:
+                flag &= ~2                                                   # improper pair -> MATE_DISTANT
+            elif t < 0.06:
+                flag |= 8                                                    # mate unmapped
+            elif t < 0.07:
+                mchrom = 3
+            rec = dict(seq=bytes(seq), qual=q.tolist(), pos=int(p0), end=int(rend), mapq=mapq, flag=int(flag), chromID=19, mateChromID=mchrom,
+                       insertSize=(-ins if rev else ins), matePos=int(max(0, mate)), cigar=[tuple(c) for c in cg])
+            reads.append(rec)
+            if rng.random() < 0.015 and len(reads) > 1:
+                reads.append(dict(rec))                                      # a positional duplicate right behind its twin
+        if mode == "broken":                                                 # mates of broken pairs that map into the region
+            for _ in range(int(0.1 * n)):
+                p0 = int(rng.integers(0, len(ref) - L - 1))
+                seq, cg, rend = cigar_read(rng, ref, p0, L, [])
+                broken.append(dict(seq=bytes(seq), qual=quals(L, False).tolist(), pos=p0, end=rend, mapq=int(rng.choice([60, 30, 3])), flag=1 | 64, chromID=19,
+                                   mateChromID=19, insertSize=0, matePos=int(rng.integers(start, end)), cigar=[tuple(c) for c in cg]))
+        reads.sort(key=lambda r: r["pos"])
+        return reads, broken
+
+    cases = []
+    n_lines = n_windows_skipped = 0
+    scen = [
+        dict(), dict(n_samples=2), dict(n_samples=3, depth=18), dict(L=150), dict(clusters=[(0.3, 7, 9), (0.6, 12, 7)]),
+        dict(clusters=[(0.4, 14, 6)], opts=dict(maxVariants=3)), dict(clusters=[(0.5, 11, 8)], opts=dict(skipDifficultWindows=1)),
+        dict(clusters=[(0.35, 10, 7)], opts=dict(filterVarsByCoverage=0)), dict(clusters=[(0.3, 6, 8), (0.62, 6, 8)], opts=dict(maxHaplotypes=12), n_samples=2),
+        dict(n_indel=7, n_snp=4), dict(n_indel=6, mode="gapless", opts=dict(assemble=1, assemblyRegionSize=700)),
+        dict(n_indel=5, mode="gapless", opts=dict(assemble=1, assemblyRegionSize=600, getVariantsFromBAMs=0), n_samples=2),
+        dict(n_indel=4, opts=dict(assemble=1, assemblyRegionSize=800, assembleAll=0)),
+        dict(n_indel=4, mode="broken", opts=dict(assemble=1, assemblyRegionSize=700, assembleBrokenPairs=1, assembleBadReads=0)),
+        dict(n_indel=3, opts=dict(assemble=1, assemblyRegionSize=700, noCycles=1, assemblerKmerSize=11), lowcomplex=True),
+        dict(empty=[1], n_samples=2), dict(empty=[0, 1], n_samples=2), dict(mode="mixed", L=125), dict(mode="noisy", depth=35),
+        dict(opts=dict(maxReads=70), depth=30, two_regions=True), dict(depth=55, n_samples=2, L=150, n_indel=3), dict(opts=dict(maxSize=60, mergeClusteredVariants=1), clusters=[(0.5, 9, 14)]),
+        dict(opts=dict(mergeClusteredVariants=0)), dict(opts=dict(largeWindows=1), clusters=[(0.4, 9, 8)]), dict(opts=dict(minPosterior=0, minReads=3)),
+        dict(opts=dict(useEMLikelihoods=1), n_samples=3, depth=14), dict(opts=dict(countOnlyExactIndelMatches=1), n_indel=6),
+        dict(opts=dict(minFlank=3, minBaseQual=10, minMapQual=30)), dict(opts=dict(genIndels=0), n_indel=5), dict(opts=dict(genSNPs=0), n_indel=5),
+        dict(two_regions=True), dict(two_regions=True, second_empty=True, L=150), dict(lowcomplex=True, n_indel=5),
+        dict(opts=dict(minVarFreq=0.3), n_samples=2, depth=40), dict(opts=dict(coverageSamplingLevel=8, maxHaplotypes=8), clusters=[(0.45, 9, 9)], depth=45),
+        dict(opts=dict(trimReadFlank=5, trimOverlapping=0, trimAdapter=0, trimSoftClipped=0)), dict(opts=dict(filterDuplicates=0, filterReadsWithDistantMates=0, filterReadsWithUnmappedMates=0)),
+        dict(opts=dict(calculateFlankScore=1), n_indel=4), dict(same_pos_alleles=True, n_samples=2, depth=40),
+        dict(merge_bait=True, n_samples=3, depth=30, n_snp=3, n_indel=0), dict(merge_bait=True, n_samples=3, depth=40, n_snp=2, n_indel=0, lowcomplex=True, L=150),
+    ]
+    for ci, sc in enumerate(scen):
+        L = sc.get("L", 100)
+        nS = sc.get("n_samples", 1)
+        depth = sc.get("depth", 24)
+        mode = sc.get("mode", "plain")
+        reg_len = int(rng.integers(1100, 1900))
+        n = reg_len * (2 if sc.get("two_regions") else 1) + 1400
+        ref = bytearray(rnd(rng, n))
+        if sc.get("lowcomplex"):
+            for _ in range(8):
+                p_ = int(rng.integers(650, n - 700)); k = int(rng.integers(8, 30))
+                if rng.random() < 0.5:
+                    ref[p_:p_ + k] = bytes([B[int(rng.integers(0, 4))]]) * k
+                else:
+                    u = rnd(rng, int(rng.integers(2, 5))); ref[p_:p_ + 2 * k] = (u * (2 * k))[:2 * k]
+        ref = bytes(ref[:n])
+        start = 600
+        regions = [(b"20", start, start + reg_len)]
+        if sc.get("two_regions"):
+            regions.append((b"20", start + reg_len, start + 2 * reg_len))
+        lo, hi = start + 20, regions[-1][2] - 20
+        clusters = [(int(lo + f * (hi - lo)), k, gap) for f, k, gap in sc.get("clusters", [])]
+        vs = plant(ref, lo, hi, sc.get("n_snp", int(rng.integers(3, 9))), sc.get("n_indel", int(rng.integers(0, 3))), clusters)
+        if sc.get("merge_bait"):                                    # three variants, two combinations with ONE sequence: del(A)@p == SNP(A->T)@p + del(T)@p+1
+            baits = []
+            for f in (0.25, 0.5, 0.75):
+                p_ = int(lo + f * (hi - lo))
+                ref = ref[:p_ - 1] + b"GAT" + ref[p_ + 2:]
+                vs = [v for v in vs if abs(v[0] - p_) > 25]
+                baits.append([(p_ - 1, b"A", b""), (p_, b"A", b"T"), (p_, b"T", b"")])
+        if sc.get("same_pos_alleles"):                              # two alternative alleles at one site, one per sample
+            p_ = int((lo + hi) // 2)
+            rem = ref[p_:p_ + 1]
+            alts = [bytes([B[(B.index(rem[0]) + k) % 4]]) for k in (1, 2)]
+            vs = [v for v in vs if abs(v[0] - p_) > 15]
+        names = [("S%d" % (i + 1)).encode() for i in range(nS)]
+        opts = default_options(**sc.get("opts", {}))
+        opts.verbosity = 2
+        opts.bamFiles, opts.refFile = ["fixture.bam"], "fixture.fa"
+        opts.nInd = nS
+        opts.originalMaxHaplotypes = opts.maxHaplotypes                     # variantcaller.pyx:916-923
+        opts.maxHaplotypes = min(257, opts.maxHaplotypes)
+        opts.maxGenotypes = opts.originalMaxHaplotypes * (opts.originalMaxHaplotypes + 1) // 2     # nCombinationsWithReplacement(n, 2)
+        opts.rlen = 150
+        raw = {}
+        for ri, reg in enumerate(regions):
+            per = []
+            for i in range(nS):
+                if i in sc.get("empty", []) or (ri == 1 and sc.get("second_empty")):
+                    per.append((names[i], [], []))
+                    continue
+                svs = vs
+                if sc.get("same_pos_alleles"):
+                    svs = sorted(vs + [(p_, rem, alts[i % 2])])
+                if sc.get("merge_bait"):
+                    svs = sorted(vs + [b_[(i + k) % 3] for k, b_ in enumerate(baits)])
+                reads, broken = make_reads(ref, reg[1], reg[2], L, depth, svs, mode)
+                per.append((names[i], reads, broken))
+            raw[reg] = per
+        loader = rgn_drv.Loader(raw)
+        vf = VCF()
+        vf.setsamples(list(names)); vf.setinfo(infoSig); vf.setfilter(filterSig); vf.setformat(formatSig)
+        stream = io.StringIO()
+        cap.msgs, cap.merges = [], 0
+        rgn_drv.run_regions(list(regions), loader, rgn_drv.FastaFile({b"20": ref}), opts, wns["WindowGenerator"](), stream, vf)
+        lines = stream.getvalue().split("\n")[:-1]
+        skipped = [m for lv, m in cap.msgs if "will be skipped" in m]
+        errors = [m for lv, m in cap.msgs if lv == "ERROR"]
+        n_lines += len(lines); n_windows_skipped += len(skipped)
+        enc = lambda rs: [dict(r, qual="".join(chr(33 + q) for q in r["qual"])) for r in rs]
+        cases.append(dict(scenario=dict((k, v) for k, v in sc.items() if k != "opts"), options=sc.get("opts", {}), ref=ref.decode(),
+                          sample_names=[x.decode() for x in names], planted=[[p_, r.decode(), a.decode()] for p_, r, a in vs],
+                          regions=[dict(chrom=c.decode(), start=s_, end=e_, loaded=(reg in loader.loaded),
+                                        samples=[dict(sample=b["sample"], reads=enc(b["reads"]), badReads=enc(b["badReads"]), brokenMates=enc(b["brokenMates"]))
+                                                 for b in loader.loaded.get(reg, [])])
+                                   for reg in regions for c, s_, e_ in [reg]],
+                          rlen_after=int(opts.rlen), lines=lines, skipped_windows=skipped, errors=errors, haplotype_merges=cap.merges))
+        print("  region case %2d: %d regions, %d samples, %d reads -> %d lines, %d windows skipped, %d haplotype merges%s" % (
+            ci, len(regions), nS, sum(len(b["reads"]) + len(b["badReads"]) for reg in loader.loaded.values() for b in reg), len(lines), len(skipped), cap.merges,
+            ("  ERRORS: %s" % errors[:2]) if errors else ""))
+    log.removeHandler(cap)
+    assert not swallowed, swallowed[:3]
+    with gzip.open(os.path.join(out, "region_cases.json.gz"), "wt") as f:
+        json.dump(cases, f)
+    print("region: %d cases, %d record lines, %d windows skipped by the reference's try/except" % (len(cases), n_lines, n_windows_skipped))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scratch", default="/tmp/platgold")
@@ -2531,7 +3165,7 @@ def main():
         sys.exit("reference tree not found at %s: golden vectors can only be regenerated in the build container" % REF)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     build_scratch(a.scratch)
-    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq", "candidates", "readqc", "infostats", "pvalues", "vcf", "regionprep", "indelprior", "refcall"]
+    todo = a.only.split(",") if a.only else ["dp", "mapalign", "assembler", "population", "haplotype", "filter", "hapseq", "candidates", "readqc", "infostats", "pvalues", "vcf", "regionprep", "indelprior", "refcall", "region"]
     if "dp" in todo:
         gen_dp(HERE)
     if "mapalign" in todo:
@@ -2562,6 +3196,8 @@ def main():
         gen_indelprior(HERE)
     if "refcall" in todo:
         gen_refcall(HERE)
+    if "region" in todo:
+        gen_region(HERE)
 
 
 if __name__ == "__main__":
