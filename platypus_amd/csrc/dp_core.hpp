@@ -2,11 +2,11 @@
 //
 // Reference behaviour: src/c/align.c:77-586 (score-only mode, aln1 == NULL).  The reference keeps
 // 8 x int16 lanes in one SSE register per DP state; here ONE GPU LANE owns ONE whole alignment and
-// keeps the same 8 int16 lanes packed two-per-VGPR (4 VGPRs per state vector), so a wave64 advances
-// 64 alignments per instruction with v_pk_add_u16 / v_pk_min_i16 / v_pk_min_u16 -- genuinely
+// keeps the same 8 int16 lanes packed two-per-VGPR (4 VGPRs per state vector, lanes k and k+4 together), so a wave64
+// advances 64 alignments per instruction with v_pk_add_u16 / v_pk_min_i16 / v_pk_min_u16 -- genuinely
 // 16-bit wrapping arithmetic, i.e. the same values as _mm_add_epi16/_mm_min_epi16 by construction.
-// The reference's lane shifts (_mm_slli/_mm_srli_si128 by one lane) become v_alignbit_b32 across
-// the 4 VGPRs.  No MFMA: this is a min-plus recurrence, not a contraction.
+// The reference's lane shifts (_mm_slli/_mm_srli_si128 by one lane) are a register renaming plus one v_perm_b32
+// (see V8).  No MFMA: this is a min-plus recurrence, not a contraction.
 //
 // Inputs arrive as pre-converted 32-bit WORDS (built once per batch by k_prep_reads / k_seed and
 // then re-used by every DP that touches the base):
@@ -55,36 +55,32 @@ __device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b) {
 }
 __device__ __forceinline__ uint32_t splat16(uint32_t v) { return (v & 0xFFFFu) | (v << 16); }
 
-// 8 x int16 lanes, lane k in v[k>>1], even lanes in the low half.
+// 8 x int16 lanes: lane k and lane k + 4 share a VGPR, v[k & 3] = lane k (k < 4, low half) | lane k + 4 (high half).
+// A one-lane shift then moves whole registers -- v[j] <- v[j -+ 1] is a renaming in unrolled code -- and only the register that
+// receives the fill value and the lane crossing from one half to the other is BUILT, with one v_perm_b32 (round 4; rounds 1-3 kept
+// lanes 2j, 2j+1 together and paid four v_alignbit_b32 per shift, 24 half-rate instructions of the 118 per step).
 struct V8 { uint32_t v[4]; };
 
+// __builtin_amdgcn_perm(a, b, sel): result byte i = byte (sel_i & 3) of b for sel_i in 0..3, of a for sel_i in 4..7
 // lane k <- lane k-1, lane 0 <- low half of fill
 __device__ __forceinline__ void shift_up(V8& a, uint32_t fill) {
-    a.v[3] = __builtin_amdgcn_alignbit(a.v[3], a.v[2], 16);
-    a.v[2] = __builtin_amdgcn_alignbit(a.v[2], a.v[1], 16);
-    a.v[1] = __builtin_amdgcn_alignbit(a.v[1], a.v[0], 16);
-    a.v[0] = (a.v[0] << 16) | (fill & 0xFFFFu);
+    const uint32_t n0 = __builtin_amdgcn_perm(a.v[3], fill, 0x05040100u);       // fill.lo | lane 3 << 16
+    a.v[3] = a.v[2]; a.v[2] = a.v[1]; a.v[1] = a.v[0]; a.v[0] = n0;
 }
 // lane k <- lane k-1, lane 0 <- HIGH half of fill
 __device__ __forceinline__ void shift_up_hi(V8& a, uint32_t fill) {
-    a.v[3] = __builtin_amdgcn_alignbit(a.v[3], a.v[2], 16);
-    a.v[2] = __builtin_amdgcn_alignbit(a.v[2], a.v[1], 16);
-    a.v[1] = __builtin_amdgcn_alignbit(a.v[1], a.v[0], 16);
-    a.v[0] = __builtin_amdgcn_alignbit(a.v[0], fill, 16);          // (a0 << 16) | (fill >> 16)
+    const uint32_t n0 = __builtin_amdgcn_perm(a.v[3], fill, 0x05040302u);       // fill.hi | lane 3 << 16
+    a.v[3] = a.v[2]; a.v[2] = a.v[1]; a.v[1] = a.v[0]; a.v[0] = n0;
 }
 // lane k <- lane k+1, lane 7 <- low half of fill
 __device__ __forceinline__ void shift_down(V8& a, uint32_t fill) {
-    a.v[0] = __builtin_amdgcn_alignbit(a.v[1], a.v[0], 16);
-    a.v[1] = __builtin_amdgcn_alignbit(a.v[2], a.v[1], 16);
-    a.v[2] = __builtin_amdgcn_alignbit(a.v[3], a.v[2], 16);
-    a.v[3] = __builtin_amdgcn_alignbit(fill, a.v[3], 16);          // (a3 >> 16) | (fill << 16)
+    const uint32_t n3 = __builtin_amdgcn_perm(fill, a.v[0], 0x05040302u);       // lane 4 | fill.lo << 16
+    a.v[0] = a.v[1]; a.v[1] = a.v[2]; a.v[2] = a.v[3]; a.v[3] = n3;
 }
 // lane k <- lane k+1, lane 7 <- HIGH half of fill
 __device__ __forceinline__ void shift_down_hi(V8& a, uint32_t fill) {
-    a.v[0] = __builtin_amdgcn_alignbit(a.v[1], a.v[0], 16);
-    a.v[1] = __builtin_amdgcn_alignbit(a.v[2], a.v[1], 16);
-    a.v[2] = __builtin_amdgcn_alignbit(a.v[3], a.v[2], 16);
-    a.v[3] = (a.v[3] >> 16) | (fill & 0xFFFF0000u);
+    const uint32_t n3 = __builtin_amdgcn_perm(fill, a.v[0], 0x07060302u);       // lane 4 | fill.hi << 16
+    a.v[0] = a.v[1]; a.v[1] = a.v[2]; a.v[2] = a.v[3]; a.v[3] = n3;
 }
 
 constexpr uint32_t INF16 = 0x7800u;          // pos_inf, align.c:97 (as a cost; haplotype-N masks, unpacked/traceback variants)
@@ -122,11 +118,11 @@ struct DP {
             d1.v[j] = d2.v[j] = mi1.v[j] = mi2.v[j] = i2p.v[j] = INFB2;
             s2w.v[j] = 0x01FF01FFu;   // never equals a base code; XOR with any code is >= 511
             q2w.v[j] = 0x01000100u;   // 64*4, align.c:159
-            s1w.v[j] = (hw[2 * j] & 0xFFFFu) | (hw[2 * j + 1] << 16);
-            gop.v[j] = (hw[2 * j] >> 16) | (hw[2 * j + 1] & 0xFFFF0000u);
+            s1w.v[j] = (hw[j] & 0xFFFFu) | (hw[j + 4] << 16);                  // lanes j and j + 4
+            gop.v[j] = (hw[j] >> 16) | (hw[j + 4] & 0xFFFF0000u);
             if (HAS_N)
-                s1n.v[j] = ((hw[2 * j] & 0xFFFFu) == CODE_N ? 0u : INF16) |
-                           ((hw[2 * j + 1] & 0xFFFFu) == CODE_N ? 0u : (INF16 << 16));
+                s1n.v[j] = ((hw[j] & 0xFFFFu) == CODE_N ? 0u : INF16) |
+                           ((hw[j + 4] & 0xFFFFu) == CODE_N ? 0u : (INF16 << 16));
             un.v[j] = pk_min_u(add(INFB2, GE), add(INFB2, gop.v[j]));         // i2 = m2 = pos_inf before step 0
         }
     }
@@ -142,8 +138,8 @@ struct DP {
         shift_up(s2w, rw);
         shift_up_hi(q2w, rw);
         if (FL >= 0) {
-            constexpr uint32_t msk = (FL & 1) ? 0xFFFF0000u : 0x0000FFFFu;
-            constexpr int j = (FL >= 0 ? FL : 0) >> 1;
+            constexpr uint32_t msk = (FL & 4) ? 0xFFFF0000u : 0x0000FFFFu;
+            constexpr int j = (FL >= 0 ? FL : 0) & 3;
             mi1.v[j] = mi1.v[j] & ~msk;                          // -0x8000 re-biased = 0
             mi2.v[j] = mi2.v[j] & ~msk;
             // the forced m2 also feeds this step's I (align.c:331-335): redo that lane of un with m2 = -0x8000
@@ -197,8 +193,8 @@ struct DP {
 
     template <int E>
     __device__ __forceinline__ void take(const V8& S) {
-        const uint32_t r = S.v[E >> 1];
-        const unsigned sc = (E & 1) ? (r >> 16) : (r & 0xFFFFu);
+        const uint32_t r = S.v[E & 3];
+        const unsigned sc = (E & 4) ? (r >> 16) : (r & 0xFFFFu);
         minscore = sc < minscore ? sc : minscore;
     }
 
