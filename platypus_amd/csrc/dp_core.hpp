@@ -101,9 +101,13 @@ struct DP {
     // carried between steps: min(M,I) and D of both parities, and un = min(I2 + ge, M2 + go) = the even I of the NEXT
     // step before "+ nucprior" (the odd half-step's gap-open window is the next step's even window).  M and I
     // themselves are transient.  All of them re-biased (see the header of this file).
-    V8 mi1, d1, mi2, d2, un, i2p, s1w, s1n, gop, s2w, q2w;
-    uint32_t GE, NP, FILLI;
+    V8 mi1, d1, mi2, d2, un, i2p, s1w, s1n, gop, gopn, s2w, q2w;
+    uint32_t GE, NP, GENP, FILLI;
     unsigned minscore;
+    // SWAR (no add of this read can wrap, see the header): min(a, b) + np == min(a + np, b + np), so "+ nucprior" is folded into
+    // the two sums of the insertion state -- un / U are carried WITH it (gopn = gop + np rides along as one more window) and the
+    // two adds per register and step that applied it are gone.
+    static constexpr bool FOLD = SWAR;
 
     static __device__ __forceinline__ uint32_t add(uint32_t a, uint32_t b) { return SWAR ? a + b : pk_add(a, b); }
 
@@ -111,7 +115,8 @@ struct DP {
     __device__ __forceinline__ void init(const uint32_t (&hw)[8], int gapextend, int nucprior) {
         GE = splat16((uint32_t)(gapextend * 4));
         NP = splat16((uint32_t)(nucprior * 4));
-        FILLI = (INFB - (uint32_t)(nucprior * 4)) & 0xFFFFu;    // + NP == pos_inf (align.c:483)
+        GENP = GE + NP;
+        FILLI = FOLD ? INFB : (INFB - (uint32_t)(nucprior * 4)) & 0xFFFFu;    // (+ NP ==) pos_inf (align.c:483)
         minscore = INFB;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -123,7 +128,9 @@ struct DP {
             if (HAS_N)
                 s1n.v[j] = ((hw[j] & 0xFFFFu) == CODE_N ? 0u : INF16) |
                            ((hw[j + 4] & 0xFFFFu) == CODE_N ? 0u : (INF16 << 16));
-            un.v[j] = pk_min_u(add(INFB2, GE), add(INFB2, gop.v[j]));         // i2 = m2 = pos_inf before step 0
+            if (FOLD) gopn.v[j] = gop.v[j] + NP;
+            un.v[j] = FOLD ? pk_min_u(add(INFB2, GENP), add(INFB2, gopn.v[j]))
+                           : pk_min_u(add(INFB2, GE), add(INFB2, gop.v[j]));  // i2 = m2 = pos_inf before step 0
         }
     }
 
@@ -143,7 +150,7 @@ struct DP {
             mi1.v[j] = mi1.v[j] & ~msk;                          // -0x8000 re-biased = 0
             mi2.v[j] = mi2.v[j] & ~msk;
             // the forced m2 also feeds this step's I (align.c:331-335): redo that lane of un with m2 = -0x8000
-            const uint32_t uf = pk_min_u(add(i2p.v[j], GE), gop.v[j]);
+            const uint32_t uf = FOLD ? pk_min_u(add(i2p.v[j], GENP), gopn.v[j]) : pk_min_u(add(i2p.v[j], GE), gop.v[j]);
             un.v[j] = (un.v[j] & ~msk) | (uf & msk);
         }
 #pragma unroll
@@ -155,11 +162,12 @@ struct DP {
             uint32_t c = pk_min_u(s1w.v[j] ^ s2w.v[j], q2w.v[j]);
             if (HAS_N) c = pk_min_u(c, s1n.v[j]);
             m1.v[j] = add(S.v[j], c);
-            i1.v[j] = add(un.v[j], NP);
+            i1.v[j] = FOLD ? un.v[j] : add(un.v[j], NP);
         }
         // gap-open vector of the odd half-step (== srli(gap_open) of the even one, lane 7 unused)
-        V8 gopE = gop;
+        V8 gopE = FOLD ? gopn : gop;                                             // (the one U adds: gop + np when folded)
         shift_down_hi(gop, hw);
+        if (FOLD) shift_down_hi(gopn, hw + (NP & 0xFFFF0000u));
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             T.v[j] = pk_min_u(add(d2.v[j], GE), add(mi2.v[j], gop.v[j]));
@@ -168,7 +176,7 @@ struct DP {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             mi1.v[j] = pk_min_u(m1.v[j], i1.v[j]);
-            U.v[j] = pk_min_u(add(i1.v[j], GE), add(m1.v[j], gopE.v[j]));      // -> i2 after shift
+            U.v[j] = pk_min_u(add(i1.v[j], FOLD ? GENP : GE), add(m1.v[j], gopE.v[j]));      // -> i2 after shift
         }
         // ---------------- odd half-step
         shift_down(s1w, hw);
@@ -183,10 +191,11 @@ struct DP {
             uint32_t c = pk_min_u(s1w.v[j] ^ s2w.v[j], q2w.v[j]);
             if (HAS_N) c = pk_min_u(c, s1n.v[j]);
             const uint32_t m2 = add(S.v[j], c);
-            const uint32_t i2 = add(U.v[j], NP);
+            const uint32_t i2 = FOLD ? U.v[j] : add(U.v[j], NP);
             d2.v[j] = pk_min_u(add(d1.v[j], GE), add(mi1.v[j], gop.v[j]));
             mi2.v[j] = pk_min_u(m2, i2);
-            un.v[j] = pk_min_u(add(i2, GE), add(m2, gop.v[j]));               // next step's even I before + np
+            un.v[j] = FOLD ? pk_min_u(add(i2, GENP), add(m2, gopn.v[j]))
+                           : pk_min_u(add(i2, GE), add(m2, gop.v[j]));        // next step's even I before + np (folded: with it)
             if (FL >= 0) i2p.v[j] = i2;
         }
     }
