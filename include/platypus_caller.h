@@ -122,6 +122,15 @@ typedef struct plat_caller_stats {
     int64_t n_refcall_records;                        /* outputRefCalls=1: REFCALL lines among n_records */
     double seconds_assemble;                          /* sum over worker threads: tiles -> device assembler -> variants */
     int64_t n_pairs;                                  /* (read, haplotype) pairs of the called windows: entries of the likelihood arrays */
+    /* plat_caller_count_cells(c, 1) only (else 0): the plat_align_stats of every likelihood batch of the call, greedy rounds included,
+     * summed -- fastAlignmentRoutine calls the reference would make for these windows and their band cells (16 * read length each:
+     * the GCUPS numerator of SURVEY 8(d)), and the same for the DPs the device ran */
+    int64_t n_dp_reference, cells_reference, n_dp_launched, cells_launched;
+    /* ... and, same switch, the likelihood batches' shapes and live kernel times (plat_profile, HIP events on the worker's stream):
+     * number of batches, their haplotype / read bytes, reads, algorithmic bytes of the DP launches (4 * len + 34 per DP), and the
+     * summed durations of k_seed and k_dp_jobs -- what a roofline entry of the region pipeline's largest kernels is computed from */
+    int64_t n_align_batches, align_hap_bytes, align_read_bytes, align_reads, align_dp_bytes;
+    double seconds_kernel_seed, seconds_kernel_dp;
 } plat_caller_stats;
 
 typedef struct plat_caller plat_caller;
@@ -131,6 +140,10 @@ void plat_caller_default_options(plat_caller_options* out);
  * stages together (0 = default). */
 int plat_caller_create(int device, int n_workers, int regions_per_chunk, plat_caller** out);
 int plat_caller_destroy(plat_caller* c);
+/* Measurement switch: on = every likelihood batch goes through the synchronous plat_align_window_batch, whose statistics kernels count
+ * the reference's DPs and band cells (same results, two small read-backs per batch: not for timed runs); the sums are left in
+ * plat_caller_stats.  Off (default) = the asynchronous entry point, nothing counted. */
+int plat_caller_count_cells(plat_caller* c, int on);
 /* Calls every region; the record lines of all regions, in region order, are returned as one malloc'ed,
  * NUL-terminated buffer (*out_text, *out_len without the NUL; free with plat_caller_free).  options->rlen is
  * left at the last region's value, as after the reference's last callVariantsInRegion. */

@@ -119,6 +119,10 @@ typedef Staged<uint8_t> Arena;
 struct Slot {
     plat_ctx* ctx = nullptr;
     void* stream = nullptr;
+    bool countCells = false;                                               // plat_caller_count_cells: likelihood batches through the synchronous entry point
+    int64_t nDpRef = 0, cellsRef = 0, nDpRun = 0, cellsRun = 0;            // ... and their plat_align_stats summed (this worker's share)
+    int64_t nAlign = 0, alignHapBytes = 0, alignReadBytes = 0, alignReads = 0, alignDpBytes = 0;
+    double secSeed = 0.0, secDp = 0.0;
     // chunk read table (device): bases, qualities, offsets, per-read fields, CIGARs; t_pack: the bytes of PLAT_READS_PACKED tables as
     // they crossed the link (expanded into t_seq / t_qual by plat_unpack_reads), t_exc*: their exceptions
     Staged<uint8_t> t_seq, t_qual, t_mapq, t_pack, t_excb, t_excq;
@@ -487,7 +491,20 @@ static DeviceBatch runWindows(Slot& s, const BatchBuilder& b, const Options& o, 
     memset(&h, 0, sizeof h);
     h.max_hap_len = b.maxHap; h.max_read_len = b.maxRead; h.max_reads_per_window = b.maxR;
     h.n_pairs = db.nPairs; h.hap_blob_len = (int64_t)b.hapseq.size(); h.read_blob_len = (int64_t)blob; h.extra_jobs_cap = 0;
-    ck(plat_align_window_batch_async(s.ctx, &wb, &h, o.calculateFlankScore ? 1 : 0, 0, s.o_loglik.d, nullptr, s.stream), "plat_align_window_batch_async");
+    if (s.countCells) {
+        plat_align_stats as;
+        memset(&as, 0, sizeof as);
+        ck(plat_profile_enable(s.ctx, 1), "plat_profile_enable");
+        ck(plat_align_window_batch(s.ctx, &wb, o.calculateFlankScore ? 1 : 0, 0, s.o_loglik.d, nullptr, &as, s.stream), "plat_align_window_batch");
+        s.nDpRef += as.n_dp_reference; s.cellsRef += as.cells_reference; s.nDpRun += as.n_dp_launched; s.cellsRun += as.cells_launched;
+        plat_profile pf;
+        memset(&pf, 0, sizeof pf);
+        ck(plat_profile_last(s.ctx, &pf), "plat_profile_last");
+        ck(plat_profile_enable(s.ctx, 0), "plat_profile_enable");
+        s.nAlign += 1; s.alignHapBytes += (int64_t)b.hapseq.size(); s.alignReadBytes += (int64_t)blob; s.alignReads += db.nReads;
+        s.alignDpBytes += pf.dp_alg_bytes; s.secSeed += 1e-3 * pf.ms_seed_kernel; s.secDp += 1e-3 * pf.ms_dp;
+    } else
+        ck(plat_align_window_batch_async(s.ctx, &wb, &h, o.calculateFlankScore ? 1 : 0, 0, s.o_loglik.d, nullptr, s.stream), "plat_align_window_batch_async");
     if (wantLoglik) s.down(s.o_loglik, (size_t)db.nPairs);
     if (full) {
         const size_t nG = (size_t)db.nGl + 1;
@@ -1805,6 +1822,7 @@ using namespace plathost;
 
 struct plat_caller {
     int device = 0, nWorkers = 1, regionsPerChunk = 4;
+    bool countCells = false;
     std::vector<std::unique_ptr<Slot>> slots;
     std::string lastError;
 };
@@ -1843,6 +1861,12 @@ CALLER_EXPORT int plat_caller_create(int device, int n_workers, int regions_per_
 }
 
 template <class... S> static void releaseAll(plat_ctx* ctx, S&... s) { (void)std::initializer_list<int>{(s.release(ctx), 0)...}; }
+
+CALLER_EXPORT int plat_caller_count_cells(plat_caller* c, int on) {
+    if (!c) return PLAT_ERR_INVALID;
+    c->countCells = on != 0;
+    return PLAT_OK;
+}
 
 CALLER_EXPORT int plat_caller_destroy(plat_caller* c) {
     if (!c) return PLAT_ERR_INVALID;
@@ -2016,10 +2040,19 @@ static int runWorkers(plat_caller* c, Feed& feed, std::atomic<bool>& failed, con
         }
     };
     nThreads = std::max(1, std::min<int>((int)c->slots.size(), nThreads));
+    for (auto& q : c->slots) {
+        q->countCells = c->countCells; q->nDpRef = q->cellsRef = q->nDpRun = q->cellsRun = 0;
+        q->nAlign = q->alignHapBytes = q->alignReadBytes = q->alignReads = q->alignDpBytes = 0; q->secSeed = q->secDp = 0.0;
+    }
     std::vector<std::thread> threads;
     for (int i = 1; i < nThreads; ++i) threads.emplace_back(worker, c->slots[(size_t)i].get());
     worker(c->slots[0].get());
     for (std::thread& t : threads) t.join();
+    for (auto& q : c->slots) {
+        st.n_dp_reference += q->nDpRef; st.cells_reference += q->cellsRef; st.n_dp_launched += q->nDpRun; st.cells_launched += q->cellsRun;
+        st.n_align_batches += q->nAlign; st.align_hap_bytes += q->alignHapBytes; st.align_read_bytes += q->alignReadBytes; st.align_reads += q->alignReads;
+        st.align_dp_bytes += q->alignDpBytes; st.seconds_kernel_seed += q->secSeed; st.seconds_kernel_dp += q->secDp;
+    }
     if (firstError != PLAT_OK) c->lastError = errText;
     return firstError;
 }

@@ -69,7 +69,10 @@ class CallerStats(C.Structure):
                                          "n_records", "n_windows_greedy", "n_windows_failed")] + \
                [(k, C.c_double) for k in ("seconds_total", "seconds_host", "seconds_device_wait")] + [("seconds_stage", C.c_double * 8)] + \
                [("seconds_load", C.c_double), ("seconds_source_wait", C.c_double), ("input_bytes", C.c_int64), ("n_assembly_tiles", C.c_int64),
-                ("n_assembler_variants", C.c_int64), ("n_refcall_records", C.c_int64), ("seconds_assemble", C.c_double), ("n_pairs", C.c_int64)]
+                ("n_assembler_variants", C.c_int64), ("n_refcall_records", C.c_int64), ("seconds_assemble", C.c_double), ("n_pairs", C.c_int64),
+                ("n_dp_reference", C.c_int64), ("cells_reference", C.c_int64), ("n_dp_launched", C.c_int64), ("cells_launched", C.c_int64),
+                ("n_align_batches", C.c_int64), ("align_hap_bytes", C.c_int64), ("align_read_bytes", C.c_int64), ("align_reads", C.c_int64),
+                ("align_dp_bytes", C.c_int64), ("seconds_kernel_seed", C.c_double), ("seconds_kernel_dp", C.c_double)]
 
     STAGES = ("upload", "candidate_scan", "variants_windows_haplotypes", "greedy_rounds", "window_batch", "posteriors", "read_stats_calls", "text")
 
@@ -238,6 +241,7 @@ def _bind(lib):
     lib.plat_caller_default_options.restype = None
     lib.plat_caller_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     lib.plat_caller_destroy.argtypes = [C.c_void_p]
+    lib.plat_caller_count_cells.argtypes = [C.c_void_p, C.c_int]
     lib.plat_call_regions.argtypes = [C.c_void_p, C.POINTER(_Region), C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(CallerOptions),
                                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(CallerStats)]
     lib.plat_call_regions_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(CallerOptions), C.c_void_p, C.c_void_p,
@@ -313,6 +317,13 @@ class NativeCaller:
             raise _lib.PlatypusDeviceError(rc, "plat_caller_create failed (no GPU? the native region loop has no CPU fallback)", "plat_caller_create")
         self.h = h
         self.stats = None
+
+    def count_cells(self, on=True):
+        """Measurement switch (plat_caller_count_cells): the calls that follow count the reference's DPs and band cells into stats
+        (synchronous likelihood batches: not for timed runs)."""
+        rc = self.lib.plat_caller_count_cells(self.h, 1 if on else 0)
+        if rc != 0:
+            raise _lib.PlatypusDeviceError(rc, "plat_caller_count_cells", "plat_caller_count_cells")
 
     def close(self):
         if getattr(self, "h", None):

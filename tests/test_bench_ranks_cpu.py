@@ -70,3 +70,5 @@ def test_config4_two_ranks_give_the_text_of_one_rank(tmp_path):
     assert one["n_gpus"] == 1 and one["record_gather"]["ranks"] == 1
     assert two["merged_text"] == one["merged_text"] and one["merged_text"].count("\n") > 10
     assert two["windows"] == one["windows"] and two["records"] == one["records"] == one["merged_text"].count("\n")
+    # the reference's DPs of the called windows, counted during the untimed pass (plat_caller_count_cells), summed over the ranks
+    assert two["dp_reference"] == one["dp_reference"] > 100 and two["pairs"] == one["pairs"] > 0 and "gcups" in one

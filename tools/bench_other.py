@@ -211,8 +211,16 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
     # slower than the others, after 512 a tenth: slots, pinned blocks, scratch buffers, the allocator's arenas for 95 MB of record text
     # and the cores' clocks all take their time)
     nwarm = min(len(indices), warm_regions) if warm_regions is not None else len(indices)
+    counted = None
     if nwarm:                                                                 # every worker's scratch buffers at full size, code paths warm
+        # The untimed pass also COUNTS: with plat_caller_count_cells on, every likelihood batch goes through the synchronous entry point,
+        # whose statistics kernels count the fastAlignmentRoutine calls the reference would make and their band cells (the GCUPS
+        # numerator) and the DPs the device ran, and the live kernel timers (HIP events) give k_seed / k_dp_jobs durations per batch.  The
+        # timed runs below call the same regions through the asynchronous entry point, counting nothing.
+        nc.count_cells(True)
         nc.call_stream(nwarm, src.load_fn, src.h, names, default_options(**(options_kw or {})), n_slots, loaders)
+        nc.count_cells(False)
+        counted = dict(nc.stats, regions=nwarm)
     runs, text, merged, gather, st = [], "", None, None, None
     planted0 = src.planted
     for _ in range(repeats):
@@ -237,7 +245,31 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
     return dict(T=T, T_call=float(np.mean([r[1] for r in runs])), T_runs=[r[0] for r in runs], text=text, merged=merged, gather=gather, stats=st,
                 regions=len(indices), warm_regions=nwarm, region_len=region_len, reads=int(st["n_reads"]), windows=int(st["n_windows"]), records=int(st["n_records"]),
                 planted=int(planted), workers=workers, per_chunk=per_chunk, loaders=loaders, n_slots=n_slots, packed=packed, source_phases=phases,
-                input_bytes=int(st["input_bytes"]))
+                input_bytes=int(st["input_bytes"]), counted=counted)
+
+
+def config4_gcups(counted, regions, T):
+    """Both halves of BASELINE.json's metric on the WGS workload: the band cells of the DPs the reference would run for the called windows
+    and the greedy rounds (counted by the device's statistics kernels during the untimed pass over the same regions) / the timed wall
+    time; plus the roofline entry of the pipeline's largest kernel from the live timers of that pass."""
+    if not counted or not counted.get("n_dp_reference"):
+        return {}
+    scale = regions / max(1, counted["regions"])                             # (the untimed pass normally covers the whole list: 1.0)
+    out = {"gcups": counted["cells_reference"] * scale / T / 1e9, "gcups_executed": counted["cells_launched"] * scale / T / 1e9,
+           "dp_reference": int(counted["n_dp_reference"] * scale), "dp_launched": int(counted["n_dp_launched"] * scale),
+           "pairs": int(counted["n_pairs"] * scale),
+           "cells_counted_on": "the untimed pass over %d of the %d regions (plat_caller_count_cells: synchronous likelihood batches + statistics kernels)" % (counted["regions"], regions)}
+    nb = max(1, counted["n_align_batches"])
+    ndp = counted["n_dp_launched"]
+    seed_alg = (2 * counted["align_hap_bytes"] + counted["align_read_bytes"] // 4 + 16 * counted["align_reads"] + 32 * counted["n_pairs"]
+                + 8 * max(counted["n_pairs"] - ndp, 0) + 4 * ndp) / nb                   # bench.py's k_seed formula, per launch
+    seed_ms, dp_ms = 1e3 * counted["seconds_kernel_seed"] / nb, 1e3 * counted["seconds_kernel_dp"] / nb
+    if seed_ms > 0 and dp_ms > 0:
+        r_seed = _roof("k_seed", seed_alg, seed_ms, "largest kernel of the region pipeline (one launch per likelihood batch of a chunk of regions); VALU-issue / latency bound, see DESIGN.md")
+        r_dp = _roof("k_dp_jobs", counted["align_dp_bytes"] / nb, dp_ms, "VALU-issue bound")
+        out["roofline"], out["roofline_other"] = (r_seed, r_dp) if seed_ms >= dp_ms else (r_dp, r_seed)
+        out["roofline"]["launches"] = out["roofline_other"]["launches"] = int(counted["n_align_batches"])
+    return out
 
 
 def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
@@ -260,7 +292,12 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
     packed = os.environ.get("PLAT_CALLER_PACKED", "1") == "1"
     repeats = max(1, min(a.steps, 3))                                        # the line is the MEAN over the runs
     r = config4(rk.dev_index, mine, region_len, workers, per_chunk, repeats=repeats, pin=pin, lib=lib, region_kw=region_kw, rk=rk, packed=packed)
-    T, (wins, regs, recs, reads, tcall, inb) = rk.reduce(r["T"], [r["windows"], r["regions"], r["records"], r["reads"], r["T_call"], r["input_bytes"]])
+    cnt = r.get("counted") or {}
+    ckeys = ("cells_reference", "cells_launched", "n_dp_reference", "n_dp_launched", "n_pairs", "regions", "n_align_batches", "align_hap_bytes", "align_read_bytes",
+             "align_reads", "align_dp_bytes", "seconds_kernel_seed", "seconds_kernel_dp")
+    T, red = rk.reduce(r["T"], [r["windows"], r["regions"], r["records"], r["reads"], r["T_call"], r["input_bytes"]] + [float(cnt.get(k, 0)) for k in ckeys])
+    wins, regs, recs, reads, tcall, inb = red[:6]
+    counted_all = dict(zip(ckeys, red[6:]))                                   # summed over the ranks
     st = r["stats"]
     line = {"metric": "variant windows/sec end to end (reads in host memory -> VCF record text)", "value": wins / T, "unit": "windows/s",
             "n_gpus": world, "steps": repeats, "warmup": 1, "ms_per_step": 1e3 * T, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -282,9 +319,26 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
             "host_input_bytes_per_region": inb / max(1.0, regs), "h2d_gbytes_per_sec": inb / T / 1e9, "input_blobs_pinned": pin, "cpus_granted_to_this_rank": cpus,
             "stage_seconds_per_region": {k: v / max(1, r["regions"]) for k, v in st["seconds_stage"].items()},
             "record_gather": r["gather"], "untimed_warm_regions_per_rank": r["warm_regions"], "python_region_loop_windows_per_sec_round1": 1100.0}
+    line.update(config4_gcups(counted_all, regs, T))
     if rank == 0:
+        if lib is None and not getattr(a, "no_cpu_baseline", False):
+            line["cpu_baseline"] = config4_cpu_baseline()
         line["merged_text"] = F.text_bytes(r["merged"]).decode("ascii")                               # (popped by bench.py before printing; the tests read it)
     return line
+
+
+def config4_cpu_baseline(seconds=10.0):
+    """The reference's own kernel (unmodified align.c, oracle/_ref, traceback on) on one host core over the DPs of a bounded sample of
+    config-4 windows: GCUPS, the half of the metric a CPU figure exists for (the reference's region loop itself cannot run here)."""
+    try:
+        from bench import cpu_baseline
+        from platypus_amd import synth
+        hb = synth.config2(150, seed=4004)                    # the same read length, depth and window shape as the windows config 4 calls
+        d = cpu_baseline(hb, seconds)
+        d["sample"] = "150 windows of config-2 shape (150 bp reads, 30x): " + str(d.get("sample", ""))
+        return d
+    except Exception as exc:                                  # pragma: no cover
+        return {"error": repr(exc)[:200]}
 
 
 def _roof(kernel, alg_bytes, ms, note=None):
@@ -344,6 +398,7 @@ def summary(eng):
                                           host_input_bytes_per_region=r["input_bytes"] / r["regions"], h2d_gbytes_per_sec=r["input_bytes"] / r["T"] / 1e9,
                                           host_threads=r["workers"], loader_threads=r["loaders"], regions_per_chunk=r["per_chunk"],
                                           read_encoding="packed (1 B/base)" if r["packed"] else "ascii (2 B/base)",
+                                          **config4_gcups(r.get("counted"), r["regions"], r["T"]),
                                           what="regions generated on demand into pinned slots (region source) -> native region loop -> VCF record text; "
                                                "timed_s = the MEAN of three runs over the whole share (timed_s_runs), no best-of")
     return out
