@@ -42,6 +42,7 @@ cdef extern from "platypus_mi355x.h":
     int plat_malloc(plat_ctx* ctx, size_t nbytes, void** out_dev_ptr) nogil
     int plat_free(plat_ctx* ctx, void* dev_ptr) nogil
     int plat_memcpy_h2d(plat_ctx* ctx, void* dst_dev, const void* src_host, size_t nbytes, void* stream) nogil
+    int plat_memcpy_d2d(plat_ctx* ctx, void* dst_dev, const void* src_dev, size_t nbytes, void* stream) nogil
     int plat_memcpy_d2h(plat_ctx* ctx, void* dst_host, const void* src_dev, size_t nbytes, void* stream) nogil
     int plat_memset(plat_ctx* ctx, void* dst_dev, int value, size_t nbytes, void* stream) nogil
     int plat_stream_sync(plat_ctx* ctx, void* stream) nogil

@@ -63,6 +63,12 @@ typedef struct plat_read_table {
     const int64_t* exc_index;
     const uint8_t* exc_base;
     const uint8_t* exc_qual;
+    /* Optional: DEVICE copies of `seq` (and, PLAT_READS_ASCII, `qual`) for a table whose bytes are already resident in HBM -- a loader
+     * that keeps the reads on the device, or a job that uploaded them earlier.  When set, the chunk table is built with device-to-device
+     * copies and nothing of the blobs crosses the link; `seq` must still be valid host memory (the host reads the inserted bases of the
+     * few candidates it keeps).  NULL (the default): the blobs are copied from `seq` / `qual`. */
+    const uint8_t* dev_seq;
+    const uint8_t* dev_qual;
 } plat_read_table;
 
 /* One bamReadBuffer (cwindow.pyx:485-513): reads and badReads sorted by pos, brokenMates sorted by mate_pos

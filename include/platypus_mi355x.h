@@ -60,6 +60,7 @@ int plat_malloc(plat_ctx* ctx, size_t bytes, void** out_dev_ptr);
 int plat_free(plat_ctx* ctx, void* dev_ptr);
 int plat_memcpy_h2d(plat_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, void* stream);
 int plat_memcpy_d2h(plat_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int plat_memcpy_d2d(plat_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 int plat_memset(plat_ctx* ctx, void* dst_dev, int value, size_t bytes, void* stream);
 int plat_stream_sync(plat_ctx* ctx, void* stream);          /* [syncs] */
 /* a HIP stream of the context's device (hipStream_t as void*), for callers without a HIP runtime binding of their own;

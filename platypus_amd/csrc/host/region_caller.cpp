@@ -574,8 +574,9 @@ struct Chunk {
                     const int n = t.n_reads;
                     tv.base = (int64_t)ri;
                     const size_t nb = (size_t)t.off[n], nc = (size_t)t.cig_off[n];
-                    if (nb && t.encoding == PLAT_READS_PACKED) {            // one byte per base crosses the link; expanded below
-                        ck(plat_memcpy_h2d(z.ctx, z.t_pack.d + bo, t.seq, nb, z.stream), "plat_memcpy_h2d(packed)");
+                    if (nb && t.encoding == PLAT_READS_PACKED) {            // one byte per base crosses the link (or none: dev_seq); expanded below
+                        if (t.dev_seq) ck(plat_memcpy_d2d(z.ctx, z.t_pack.d + bo, t.dev_seq, nb, z.stream), "plat_memcpy_d2d(packed)");
+                        else ck(plat_memcpy_h2d(z.ctx, z.t_pack.d + bo, t.seq, nb, z.stream), "plat_memcpy_h2d(packed)");
                         const size_t ne = (size_t)std::max<int64_t>(t.n_exceptions, 0);
                         // packed tables that follow each other in the blob are expanded by ONE plat_unpack_reads: the exceptions of the
                         // later ones are counted from the first one's first byte
@@ -584,7 +585,10 @@ struct Chunk {
                         for (size_t e = 0; e < ne; ++e) { z.t_excidx.h[eo + e] = t.exc_index[e] + shift; z.t_excb.h[eo + e] = t.exc_base[e]; z.t_excq.h[eo + e] = t.exc_qual[e]; }
                         if (joins) { packed.back().nb += nb; packed.back().ne += ne; }
                         else packed.push_back(Pending{bo, nb, eo, ne});
-                        eo += ne; inBytes += nb + 10 * ne;
+                        eo += ne; inBytes += (t.dev_seq ? 0 : nb) + 10 * ne;
+                    } else if (nb && t.dev_seq && t.dev_qual) {            // resident in HBM already
+                        ck(plat_memcpy_d2d(z.ctx, z.t_seq.d + bo, t.dev_seq, nb, z.stream), "plat_memcpy_d2d(seq)");
+                        ck(plat_memcpy_d2d(z.ctx, z.t_qual.d + bo, t.dev_qual, nb, z.stream), "plat_memcpy_d2d(qual)");
                     } else if (nb) {                                       // bases and qualities go straight from the caller's memory
                         ck(plat_memcpy_h2d(z.ctx, z.t_seq.d + bo, t.seq, nb, z.stream), "plat_memcpy_h2d(seq)");
                         ck(plat_memcpy_h2d(z.ctx, z.t_qual.d + bo, t.qual, nb, z.stream), "plat_memcpy_h2d(qual)");

@@ -129,6 +129,12 @@ PLAT_EXPORT int plat_memcpy_h2d(plat_ctx* ctx, void* dst, const void* src, size_
     return PLAT_OK;
 }
 
+PLAT_EXPORT int plat_memcpy_d2d(plat_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return PLAT_ERR_INVALID;
+    if (bytes) PLAT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PLAT_OK;
+}
+
 PLAT_EXPORT int plat_memcpy_d2h(plat_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {
     if (!ctx || (!dst && bytes) || (!src && bytes)) return PLAT_ERR_INVALID;
     if (bytes) PLAT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));

@@ -25,7 +25,8 @@ READS_ASCII, READS_PACKED = 0, 1
 class _ReadTable(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("encoding", C.c_int32)] + [(k, C.c_void_p) for k in (
         "seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off")] + \
-               [("n_exceptions", C.c_int64), ("exc_index", C.c_void_p), ("exc_base", C.c_void_p), ("exc_qual", C.c_void_p)]
+               [("n_exceptions", C.c_int64), ("exc_index", C.c_void_p), ("exc_base", C.c_void_p), ("exc_qual", C.c_void_p),
+                ("dev_seq", C.c_void_p), ("dev_qual", C.c_void_p)]
 
 
 class _SampleReads(C.Structure):

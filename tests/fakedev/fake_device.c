@@ -65,6 +65,7 @@ API int plat_free(plat_ctx* c, void* p) { (void)c; free(p); return PLAT_OK; }
 API int plat_host_alloc(plat_ctx* c, size_t n, void** out) { return plat_malloc(c, n, out); }
 API int plat_host_free(plat_ctx* c, void* p) { return plat_free(c, p); }
 API int plat_memcpy_h2d(plat_ctx* c, void* d, const void* s, size_t n, void* st) { (void)c; (void)st; if (n) memcpy(d, s, n); return PLAT_OK; }
+API int plat_memcpy_d2d(plat_ctx* c, void* d, const void* s, size_t n, void* st) { (void)c; (void)st; if (n) memcpy(d, s, n); return PLAT_OK; }
 API int plat_memcpy_d2h(plat_ctx* c, void* d, const void* s, size_t n, void* st) { (void)c; (void)st; if (n) memcpy(d, s, n); return PLAT_OK; }
 API int plat_memset(plat_ctx* c, void* d, int v, size_t n, void* st) { (void)c; (void)st; if (n) memset(d, v, n); return PLAT_OK; }
 API int plat_stream_create(plat_ctx* c, void** out) { (void)c; *out = (void*)(uintptr_t)0x10; return PLAT_OK; }

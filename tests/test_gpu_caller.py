@@ -366,3 +366,26 @@ def test_more_distinct_candidates_than_the_device_table_holds_fall_back_to_the_h
     assert nc.stats["n_candidate_records"] > 9000                          # (nearly all of them distinct: sequencing errors)
     nc.close()
     assert txt == py.getvalue() and txt.count("\n") > 30
+
+
+def test_regions_resident_in_hbm_give_the_text_of_streamed_regions():
+    """plat_read_table.dev_seq: a region list generated once and mirrored in HBM (tools/synth resident mode: the chunk tables are built
+    with device-to-device copies, no read byte crosses the link) gives the record text of the same regions generated and uploaded on demand."""
+    import torch
+    from platypus_amd import fastcaller as F
+    from tools.synth import source
+    idx = list(range(12))
+    texts, moved = [], []
+    for resident in (False, True):
+        src = source.RegionSource(idx, len(idx) if resident else 16, region_len=20000, pin=not resident)
+        if resident:
+            src.make_resident(torch.device("cuda", 0), threads=4)
+        nc = F.NativeCaller(0, 3, 2)
+        try:
+            texts.append(nc.call_stream(len(idx), src.load_fn, src.h, ["S1"], default_options(), 16, 2))
+            moved.append(nc.stats["input_bytes"])
+        finally:
+            nc.close()
+            src.close()
+    assert texts[0] == texts[1] and texts[0].count("\n") > 100
+    assert moved[0] > 12 * 20000 * 30 * 0.9 and moved[1] == 0

@@ -183,7 +183,7 @@ def run(a, rk):
 # ---- config 4 -----------------------------------------------------------------------------------------------------------------
 
 def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_samples=1, pin=True, lib=None, region_kw=None, rk=None, packed=True,
-            loaders=None, warm_regions=None, options_kw=None):
+            loaders=None, warm_regions=None, options_kw=None, resident=False):
     """The region pipeline end to end, sustained: the regions `indices` of the job's region list are LOADED ON DEMAND by a region source
     (tools/synth: generated from seed (+) region index inside the library's loader threads into a bounded set of pinned slots -- where the
     reference's BAM loader stands) and called through the native region loop (plat_call_regions_stream: host threads + every device stage
@@ -202,8 +202,15 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
             granted = workers
         loaders = int(os.environ.get("PLAT_CALLER_LOADERS", str(max(2, min(12, granted // 2)))))
     n_slots = per_chunk * (workers + 2) + loaders
-    kw = dict(region_len=region_len, n_samples=n_samples, packed=packed, pin=pin, **(region_kw or {}))
-    src = source.RegionSource(indices, n_slots, **kw)
+    kw = dict(region_len=region_len, n_samples=n_samples, packed=packed, pin=pin and not resident, **(region_kw or {}))
+    # resident: the rank's whole share is generated ONCE, outside the timed region, and its read bytes are uploaded to HBM (one slot per
+    # region, 3.7 MB each: 14 GB for a GPU's WGS share); a timed run then neither generates nor moves read bytes -- "inputs already resident
+    # in HBM when the timed region starts".  Not resident: each region is generated when its turn comes (the source stands where a BAM
+    # loader would) and its bytes cross the link inside the timed region.
+    src = source.RegionSource(indices, len(indices) if resident else n_slots, **kw)
+    if resident:
+        import torch
+        src.make_resident(None if lib is not None else torch.device("cuda", device), threads=max(2, loaders))
     names = ["S%d" % (i + 1) for i in range(n_samples)]
     nc = F.NativeCaller(device, workers, per_chunk, lib=lib)
     # (the timed runs are the steady state of a long job -- a rank's share of a genome is eight such lists --: ONE UNTIMED PASS over the
@@ -245,7 +252,7 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
     return dict(T=T, T_call=float(np.mean([r[1] for r in runs])), T_runs=[r[0] for r in runs], text=text, merged=merged, gather=gather, stats=st,
                 regions=len(indices), warm_regions=nwarm, region_len=region_len, reads=int(st["n_reads"]), windows=int(st["n_windows"]), records=int(st["n_records"]),
                 planted=int(planted), workers=workers, per_chunk=per_chunk, loaders=loaders, n_slots=n_slots, packed=packed, source_phases=phases,
-                input_bytes=int(st["input_bytes"]), counted=counted)
+                input_bytes=int(st["input_bytes"]), counted=counted, resident=bool(resident))
 
 
 def config4_gcups(counted, regions, T):
@@ -291,7 +298,9 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
     pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1" and lib is None
     packed = os.environ.get("PLAT_CALLER_PACKED", "1") == "1"
     repeats = max(1, min(a.steps, 3))                                        # the line is the MEAN over the runs
-    r = config4(rk.dev_index, mine, region_len, workers, per_chunk, repeats=repeats, pin=pin, lib=lib, region_kw=region_kw, rk=rk, packed=packed)
+    resident = os.environ.get("PLAT_CALLER_RESIDENT", "1") == "1"            # 0: regions generated and uploaded inside the timed region (rounds 2-3)
+    r = config4(rk.dev_index, mine, region_len, workers, per_chunk, repeats=repeats, pin=pin, lib=lib, region_kw=region_kw, rk=rk, packed=packed,
+                resident=resident)
     cnt = r.get("counted") or {}
     ckeys = ("cells_reference", "cells_launched", "n_dp_reference", "n_dp_launched", "n_pairs", "regions", "n_align_batches", "align_hap_bytes", "align_read_bytes",
              "align_reads", "align_dp_bytes", "seconds_kernel_seed", "seconds_kernel_dp")
@@ -302,12 +311,16 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
     line = {"metric": "variant windows/sec end to end (reads in host memory -> VCF record text)", "value": wins / T, "unit": "windows/s",
             "n_gpus": world, "steps": repeats, "warmup": 1, "ms_per_step": 1e3 * T, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "BASELINE config 4: %d regions x %d bp for the whole job, 30x 150 bp reads, SNPs 1e-3 + indels 1e-4, one sample, each region "
-                                   "generated from seed (+) index when its turn comes (region source in %d loader threads, %d pinned slots); step = "
+            "config": {"workload": "BASELINE config 4: %d regions x %d bp for the whole job, 30x 150 bp reads, SNPs 1e-3 + indels 1e-4, one sample, %s; step = "
                                    "candidates -> windows -> haplotypes -> likelihoods / EM / posteriors -> INFO / FILTER -> record text for all "
                                    "regions (native region loop, %d host threads, %d regions per chunk), then the gather of the record lines to "
-                                   "rank 0 and their merge; mean of %d timed run(s)" % (total, region_len, r["loaders"], r["n_slots"], r["workers"],
-                                                                                        r["per_chunk"], repeats),
+                                   "rank 0 and their merge; mean of %d timed run(s)" % (
+                                       total, region_len,
+                                       "every region's reads generated from seed (+) index BEFORE the timed region and resident in HBM (plat_read_table.dev_seq; the "
+                                       "per-read arrays in host memory): the timed region moves no read bytes" if r["resident"] else
+                                       "each region generated from seed (+) index when its turn comes (region source in %d loader threads, %d pinned slots)" % (r["loaders"], r["n_slots"]),
+                                       r["workers"], r["per_chunk"], repeats),
+                       "inputs": "resident in HBM" if r["resident"] else "generated and uploaded inside the timed region",
                        "regions": total, "region_len": region_len, "sharding": "region i -> rank i % N, records gathered to rank 0 and merged by (chrom, pos)",
                        "read_encoding": "packed: one byte per base (2-bit base | quality << 2)" if r["packed"] else "ASCII bases + quality bytes"},
             "regions_per_sec": regs / T, "reads_per_sec": reads / T, "records": recs, "windows": wins, "regions": regs, "timed_s": T,

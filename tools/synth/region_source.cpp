@@ -18,6 +18,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
 
 #include "../../include/platypus_caller.h"
 
@@ -53,6 +55,11 @@ struct plat_synth {
     // variant model: indel length 1 + min(indelMax - 1, geometric(indelP) - 1); counts Poisson(rate x length) unless a [min, max] range is set
     int indelMax = 10, nIndelMin = -1, nIndelMax = -1, nSnpMin = -1, nSnpMax = -1;
     double indelP = 0.4;
+    // resident mode (plat_synth_pregenerate): region k of the list lives in slot k for the life of the source; `resident` holds the filled
+    // structs, devDelta the distance from a host address inside `mem` to its device mirror (0: none)
+    std::vector<plat_region> resident;
+    long long devDelta = 0;
+    bool haveMirror = false;
     long long planted = 0, reads = 0;                                      // totals over the regions loaded (statistics)
     long long phaseNs[6] = {0, 0, 0, 0, 0, 0};                             // reference, variants, haplotypes, read starts + sort, reads, rest
 };
@@ -407,3 +414,48 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
 
 // address of the load function, for callers that pass it on as a plain pointer (ctypes)
 SYNTH_EXPORT void* plat_synth_load_fn(void) { return (void*)&plat_synth_load; }
+
+// ---- resident mode: "inputs already resident when the timed region starts" ------------------------------------------------------------
+// Every region of the list is generated ONCE, region k into slot k (needs n_slots >= the number of regions), on n_threads threads; the
+// caller may then upload the whole slot memory to the device in one copy and name the mirror (plat_synth_set_device_mirror): the resident
+// loader hands out the stored structs with dev_seq / dev_qual pointing into it, and a timed run neither generates nor moves read bytes.
+SYNTH_EXPORT int plat_synth_pregenerate(plat_synth* g, int n_threads) {
+    if (!g || (size_t)g->nSlots < g->index.size()) return -1;
+    const int n = (int)g->index.size();
+    g->resident.assign((size_t)n, plat_region());
+    std::atomic<int> next(0), err(0);
+    auto work = [&] {
+        for (int k = next.fetch_add(1); k < n; k = next.fetch_add(1)) {
+            const int rc = plat_synth_load(g, k, k, &g->resident[(size_t)k]);
+            if (rc != 0) err.store(rc);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < std::max(1, n_threads); ++t) th.emplace_back(work);
+    work();
+    for (std::thread& t : th) t.join();
+    return err.load();
+}
+SYNTH_EXPORT int plat_synth_set_device_mirror(plat_synth* g, const void* device_base) {
+    if (!g) return -1;
+    g->haveMirror = device_base != nullptr;
+    g->devDelta = device_base ? (long long)((intptr_t)device_base - (intptr_t)g->mem) : 0;
+    return 0;
+}
+static int plat_synth_load_resident(void* user, int index, int slot, plat_region* out) {
+    (void)slot;
+    plat_synth* g = (plat_synth*)user;
+    if (!g || !out || index < 0 || (size_t)index >= g->resident.size()) return -2;
+    *out = g->resident[(size_t)index];
+    if (g->haveMirror) {
+        // (the per-sample structs live in the slot and are shared by every hand-out: the pointers written are the same every time)
+        plat_sample_reads* sm = const_cast<plat_sample_reads*>(out->samples);
+        for (int i = 0; i < g->nSamples; ++i) {
+            plat_read_table& t = sm[i].reads;
+            t.dev_seq = t.seq + g->devDelta;
+            t.dev_qual = t.encoding == PLAT_READS_ASCII ? t.qual + g->devDelta : nullptr;
+        }
+    }
+    return 0;
+}
+SYNTH_EXPORT void* plat_synth_load_resident_fn(void) { return (void*)&plat_synth_load_resident; }

@@ -17,7 +17,7 @@ _lib = None
 def build():
     hdr = os.path.join(HERE, "..", "..", "include", "platypus_caller.h")
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(hdr)):
-        r = subprocess.run(["g++", "-O3", "-mavx2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", SRC, "-o", LIB], capture_output=True, text=True)
+        r = subprocess.run(["g++", "-O3", "-mavx2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-pthread", SRC, "-o", LIB], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("building libplat_synth.so failed:\n" + r.stderr[-3000:])
     return LIB
@@ -38,6 +38,9 @@ def load():
         lib.plat_synth_phase_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         lib.plat_synth_load_fn.restype = C.c_void_p
         lib.plat_synth_load.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.plat_synth_pregenerate.argtypes = [C.c_void_p, C.c_int]
+        lib.plat_synth_set_device_mirror.argtypes = [C.c_void_p, C.c_void_p]
+        lib.plat_synth_load_resident_fn.restype = C.c_void_p
         _lib = lib
     return _lib
 
@@ -74,7 +77,24 @@ class RegionSource:
 
     @property
     def load_fn(self):
-        return self.lib.plat_synth_load_fn()
+        return self.lib.plat_synth_load_resident_fn() if self.resident else self.lib.plat_synth_load_fn()
+
+    resident = False
+    mirror = None
+
+    def make_resident(self, device=None, threads=8):
+        """Generate every region of the list once (region k -> slot k: the source must have been created with n_slots >= len(indices)) and,
+        with `device` (a torch device), upload the whole slot memory there in one copy: load_fn then hands out stored regions whose read
+        bytes are already in HBM (plat_read_table.dev_seq) -- inputs resident when the timed region starts, as the bench contract has it."""
+        if self.n_slots < len(self.indices):
+            raise ValueError("resident mode keeps one slot per region")
+        rc = self.lib.plat_synth_pregenerate(self.h, int(threads))
+        if rc != 0:
+            raise RuntimeError("plat_synth_pregenerate failed (%d)" % rc)
+        if device is not None:
+            self.mirror = self.buf.to(device)
+            self.lib.plat_synth_set_device_mirror(self.h, self.mirror.data_ptr())
+        self.resident = True
 
     @property
     def planted(self):
