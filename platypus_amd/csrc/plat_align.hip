@@ -46,7 +46,7 @@ __device__ __forceinline__ long long job_slot(long long pair, long long npairs, 
 }
 
 enum { CNT_ERR = 0, CNT_MAXHAP, CNT_MAXREAD, CNT_NEXTRA, CNT_PAIRS_ALIGNED, CNT_NDP_REF, CNT_CELLS_REF, CNT_CELLS_RUN,
-       CNT_NJOBS_RUN, CNT_TILE_TOTAL, CNT_SLOW_SEED, CNT_MAXH, CNT_NDENSE, CNT_HAPBLOB, CNT_NPAIRS, CNT_READBLOB, CNT_T0, CNT_T1, CNT_T2, CNT_T3, CNT_T4, CNT_N };
+       CNT_NJOBS_RUN, CNT_TILE_TOTAL, CNT_SLOW_SEED, CNT_MAXH, CNT_NDENSE, CNT_HAPBLOB, CNT_NPAIRS, CNT_READBLOB, CNT_T0, CNT_T1, CNT_T2, CNT_T3, CNT_T4, CNT_NWAVES, CNT_N };
 static_assert(CNT_N <= 64, "the pinned read-back area holds 64 words");
 
 // The dense list of live DP job slots, built where the jobs are made (k_seed / k_seed_slow): DENSE_SEGS segments of `segcap`
@@ -142,28 +142,47 @@ k_validate(plat_window_batch b, long long* cnt, int32_t* __restrict__ hap_win, i
 // exclusive scan of rows*R per window -> tile_off (dwords); single workgroup
 __global__ void __launch_bounds__(1024)
 k_tile_scan(plat_window_batch b, const int32_t* __restrict__ win_rows, long long* __restrict__ tile_off, long long* cnt,
-            plat_batch_hints hints, int check_hints)
+            plat_batch_hints hints, int check_hints, int32_t* __restrict__ wave_win, int32_t* __restrict__ wave_first, long long wave_cap)
 {
     __shared__ long long part[1024];
+    __shared__ long long part2[1024];
     const int t = threadIdx.x, nt = blockDim.x;
     const int per = (b.n_windows + nt - 1) / nt;
     const int w0 = min(b.n_windows, t * per), w1 = min(b.n_windows, w0 + per);
-    long long s = 0;
-    for (int w = w0; w < w1; ++w) s += ((long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]) + 3) & ~3ll;
-    part[t] = s;
+    // waves of k_pairs per window: ceil(H R / pairs per wave) (plat_align.hip, "the seeding stage as TWO kernels")
+    auto nwaves_of = [&](int w) -> long long {
+        const long long R = b.win_read_begin[w + 1] - b.win_read_begin[w], H = b.win_hap_begin[w + 1] - b.win_hap_begin[w];
+        if (R <= 0 || H <= 0) return 0;
+        const long long pw = R >= 13 ? 64 : 5 * R;
+        return (H * R + pw - 1) / pw;
+    };
+    long long s = 0, s2 = 0;
+    for (int w = w0; w < w1; ++w) {
+        s += ((long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]) + 3) & ~3ll;
+        s2 += nwaves_of(w);
+    }
+    part[t] = s; part2[t] = s2;
     __syncthreads();
     for (int d = 1; d < nt; d <<= 1) {
-        long long v = t >= d ? part[t - d] : 0;
+        long long v = t >= d ? part[t - d] : 0, v2 = t >= d ? part2[t - d] : 0;
         __syncthreads();
-        part[t] += v;
+        part[t] += v; part2[t] += v2;
         __syncthreads();
     }
-    long long run = part[t] - s;
+    long long run = part[t] - s, run2 = part2[t] - s2;
     for (int w = w0; w < w1; ++w) {
         tile_off[w] = run;
         run += ((long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]) + 3) & ~3ll;
+        if (wave_win) {
+            const long long n = nwaves_of(w);
+            wave_first[w] = (int32_t)min(run2, 0x7FFFFFFFll);
+            for (long long k = 0; k < n && run2 + k < wave_cap; ++k) wave_win[run2 + k] = w;
+            run2 += n;
+        }
     }
     if (t == nt - 1) {
+        cnt[CNT_NWAVES] = part2[t] <= wave_cap ? part2[t] : 0;
+        if (wave_win && part2[t] > wave_cap) set_err(cnt, PLAT_ERR_OVERFLOW);       // (cannot happen: the host's bound covers every window shape)
         cnt[CNT_TILE_TOTAL] = part[t];
         // everything the host needs before it can size the scratch buffers travels in ONE read-back of cnt[]
         cnt[CNT_HAPBLOB] = b.hap_off[b.n_haps];
@@ -1376,6 +1395,478 @@ k_seed(plat_window_batch b, const int32_t* __restrict__ hap_win, const int32_t* 
     }
 }
 
+
+// ---- round 4: the seeding stage as TWO kernels -----------------------------------------------------------------------------------------
+// k_seed did two things per haplotype in one single-wave workgroup: the haplotype sweep (planes, gap-open bytes, multiplicity maps) and
+// the per-pair proofs with ONE LANE PER READ of the window -- 34..40 lanes of 64 on a 30x window of 150 bp reads, and that part is two
+// thirds of its vector instructions.  k_sweep keeps the first half and leaves what the proofs read in global memory (per haplotype:
+// flags, largest multiplicity, the planes h0 / h1 / nu, per-chunk gap-open minima: ~0.5 KB); k_pairs packs the window's (haplotype, read)
+// pairs DENSELY, 64 per wave whatever the number of reads, stages the <= SEED_NST haplotype records its pairs touch in LDS and runs the
+// same proofs.  The k-mer index of a haplotype is built in k_pairs only when a pair needs look-ups (hypothesis B, no-vote test), as before.
+constexpr int SEED_NST = 6;            // haplotype records staged per wave of k_pairs: 64 consecutive pairs of a window with R >= 13 reads
+                                       // span at most 6 haplotypes; windows with fewer reads give a wave 5 whole haplotypes (5 R <= 60 pairs)
+__host__ __device__ __forceinline__ int seed_pairs_per_wave(int R) { return R >= 13 ? 64 : 5 * (R > 0 ? R : 1); }
+__host__ __device__ __forceinline__ size_t seed_state_stride(int maxhap) {
+    const size_t nw64 = (((size_t)maxhap + 63) >> 6) + 8;
+    return 16 + 24 * nw64 + ((nw64 + 15) & ~(size_t)15);                   // int scal[4] | u64 h0[nw64], h1[nw64], nu[nw64] | u8 gmin[nw64]
+}
+
+__global__ void __launch_bounds__(64)
+k_sweep(plat_window_batch b, uint8_t* __restrict__ gob, uint8_t* __restrict__ hap_has_n, long long* cnt, int tsize_max, int maxhap, int shortcuts,
+        const unsigned char* __restrict__ basebuf, const int32_t* __restrict__ hap_win, unsigned char* __restrict__ state)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nw64 = ((maxhap + 63) >> 6) + 8;
+    unsigned* table = (unsigned*)smem;
+    unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);
+    u64* h0 = (u64*)(smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 7 & ~(size_t)7));
+    u64* h1 = h0 + nw64;
+    u64* eqp = h1 + nw64;
+    u64* nup = eqp + nw64;
+    int* s_scal = (int*)(nup + nw64);
+    unsigned char* s_gmin = (unsigned char*)((unsigned*)(s_scal + 4 + 16) + 32);
+    int h = blockIdx.x;
+    if (shortcuts & SEED_XCD) {                          // haplotype h on XCD floor(8 h / n): see k_seed
+        const int per = (int)(gridDim.x >> 3);
+        h = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+        if (h >= b.n_haps) return;
+    }
+    if (cnt[CNT_ERR] != 0) return;
+    const int lane = threadIdx.x;
+    const long long hoff = b.hap_off[h];
+    const int hapLen = (int)(b.hap_off[h + 1] - hoff);
+    const uint8_t* hs = b.hap_seq + hoff;
+    const bool direct = hapLen > 4096;
+    int tsize = 64;
+    if (direct) tsize = 16384;
+    else while (tsize < hapLen + hapLen / 4) tsize <<= 1;
+    const unsigned tmask = (unsigned)tsize - 1u;
+    const int nch = (hapLen + 63) >> 6;
+    bool stop = false, derived = false;
+    if (basebuf) {                                       // PLAT_SEED_SHARE=1: derive from the window's first haplotype where possible (see seed_derive)
+        const int w = hap_win[h];
+        const unsigned char* rec = basebuf + (size_t)w * seed_base_stride(maxhap);
+        const int hB = b.win_hap_begin[w];
+        const long long hoffB = b.hap_off[hB];
+        if (((const int*)(rec + SEED_BASE_SCAL))[3] != 0 && (int)(b.hap_off[hB + 1] - hoffB) == hapLen)
+            derived = seed_derive(rec, b.hap_seq + hoffB, gob + hoffB, table, h0, h1, eqp, nup, s_scal, s_gmin, nw64, hs, hapLen, h == hB,
+                                  h != hB, gob + hoff, cnt);
+    }
+    if (!derived) seed_sweep(table, nxt, h0, h1, eqp, nup, s_scal, nw64, hs, hapLen, hoff, true, gob, cnt, shortcuts, direct, tsize, tmask, nch, stop);
+    if (stop) return;
+    unsigned char* rec = state + (size_t)h * seed_state_stride(maxhap);
+    if (lane == 0) hap_has_n[h] = (uint8_t)s_scal[0];
+    if (lane < 4) ((int*)rec)[lane] = lane < 3 ? s_scal[lane] : 0;
+    u64* op = (u64*)(rec + 16);
+    for (int i = lane; i < nw64; i += 64) { op[i] = h0[i]; op[nw64 + i] = h1[i]; op[2 * nw64 + i] = nup[i]; }
+    unsigned char* og = rec + 16 + 24 * (size_t)nw64;
+    for (int t = lane; t < ((nw64 + 15) & ~15); t += 64) og[t] = t < nch ? s_gmin[t] : (unsigned char)0;
+}
+
+// One wave = up to 64 consecutive (haplotype, read) pairs of ONE window, in the order of the window's likelihood block
+// (pair q = hl * R + rl).  wave_win / wave_first (k_tile_scan): wave -> window, window -> its first wave.
+__global__ void __launch_bounds__(64)
+k_pairs(plat_window_batch b, const int32_t* __restrict__ wave_win, const int32_t* __restrict__ wave_first,
+        const long long* __restrict__ tile_off, const ReadInfo* __restrict__ rinfo, const uint16_t* __restrict__ codes,
+        PairRec* __restrict__ pairs, Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt,
+        SlowRec* __restrict__ slow_list, int tsize_max, int maxhap, int shortcuts,
+        int32_t* __restrict__ dense, long long segcap, const double* __restrict__ mapq_lut, double* __restrict__ out_ll,
+        int32_t* __restrict__ out_score, const unsigned char* __restrict__ state)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nw64 = ((maxhap + 63) >> 6) + 8;
+    unsigned* table = (unsigned*)smem;                   // the k-mer index of ONE staged haplotype at a time, built on demand
+    unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);
+    unsigned char* lstate = smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 15 & ~(size_t)15);    // SEED_NST haplotype records
+    const size_t stride = seed_state_stride(maxhap);
+    const long long nwaves = cnt[CNT_NWAVES];            // (the grid is the host's upper bound)
+    long long v = blockIdx.x;
+    if (shortcuts & SEED_XCD) {                          // the waves of a window on ONE XCD (they share its read planes and haplotype records):
+        const long long per = (nwaves + 7) >> 3, idx = (long long)(blockIdx.x >> 3);      // XCD x takes the x-th eighth of the waves there ARE
+        if (idx >= per) return;
+        v = (long long)(blockIdx.x & 7u) * per + idx;
+    }
+    if (cnt[CNT_ERR] != 0 || v >= nwaves) return;
+    const int lane = threadIdx.x;
+    const int w = wave_win[v];
+    const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
+    const int hb = b.win_hap_begin[w], H = b.win_hap_begin[w + 1] - hb;
+    const int PW = seed_pairs_per_wave(R);
+    const long long q0 = (v - (long long)wave_first[w]) * PW, QT = (long long)H * R;
+    if (q0 >= QT) return;
+    const int nq = (int)min((long long)PW, QT - q0);
+    const int hl_lo = (int)(q0 / R), hl_hi = (int)((q0 + nq - 1) / R), nst = hl_hi - hl_lo + 1;      // <= SEED_NST
+    {   // the records of haplotypes hb + hl_lo .. hb + hl_hi are contiguous in `state`
+        const u64* src = (const u64*)(state + (size_t)(hb + hl_lo) * stride);
+        u64* dst = (u64*)lstate;
+        const int nwords = (int)((size_t)nst * stride / 8);
+        for (int i = lane; i < nwords; i += 64) dst[i] = src[i];
+    }
+    wave_sync();
+    const int hapStart = b.win_start[w] - b.win_flank[w];                   // chaplotype.pyx:606
+    const u64* rd2 = (const u64*)(codes + tile_off[w]);
+    {
+        const bool valid = lane < nq;
+        const long long q = q0 + (valid ? lane : 0);
+        const int hl = (int)(q / R), rl = (int)(q - (long long)hl * R), slot = hl - hl_lo;
+        const int h = hb + hl;
+        const unsigned char* rec = lstate + (size_t)slot * stride;
+        const u64* h0 = (const u64*)(rec + 16);
+        const u64* h1 = h0 + nw64;
+        const u64* nup = h1 + nw64;
+        const unsigned char* s_gmin = (const unsigned char*)(nup + nw64);
+        const int has_n = ((const int*)rec)[0], maxmult = ((const int*)rec)[1];
+        const bool hap_plain = ((const int*)rec)[2] == 0;
+        const int hapLen = (int)(b.hap_off[h + 1] - b.hap_off[h]);
+        const int nkp = hapLen - 7;                      // haplotype k-mer positions 0..hapLen-8 (calign.pyx:109)
+        ReadInfo ri = ReadInfo{0, 0, 0, 0};
+        if (valid) ri = rinfo[rb + rl];
+        const int L = (int)(ri.lfm & 0xFFFFu);
+        const int rflags = (int)((ri.lfm >> 16) & 0xFFu);
+        const uint8_t mapq = (uint8_t)(ri.lfm >> 24);
+        const long long pidx = b.pair_off[w] + (long long)hl * R + rl;
+        const bool skipped = (rflags & 1) != 0, tooshort = L < 7;
+        const int hq = h | ((rflags & 4) ? JOB_BIGQ : 0);                   // haplotype index + the read's add-flavour flag
+        const bool hapshort = valid && !skipped && !tooshort && hapLen < L + 15;
+        if (hapshort) set_err(cnt, PLAT_ERR_HAP_TOO_SHORT);
+        const bool live = valid && !skipped && !tooshort && !hapshort;
+        const int nk = live ? L - 7 : 0;
+        const int idx0 = min(ri.pos - hapStart, hapLen - L - 15);           // calign.pyx:252
+        const u64* col = rd2 + (valid ? rl : 0);
+
+        // ---- bit-parallel proof
+        const bool canfast = live && L <= 256;
+        int nCl = canfast ? (L + 63) >> 6 : 0, nCmax = nCl;
+#pragma unroll
+        for (int s2 = 32; s2 > 0; s2 >>= 1) nCmax = max(nCmax, __shfl_xor(nCmax, s2));
+        u64 r0[4], r1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            r0[c] = c < nCl ? col[(long long)(2 * c) * R] : 0ull;
+            r1[c] = c < nCl ? col[(long long)(2 * c + 1) * R] : 0ull;
+        }
+        int dstar = idx0;
+        bool proven = false, triedB = false, exact = false, direct = false;
+        unsigned tmask = 0u;
+        u64 missA[4] = {0ull, 0ull, 0ull, 0ull}, uniqA[4] = {0ull, 0ull, 0ull, 0ull};   // of hypothesis A, when it is proven (see "ungapped" below)
+        bool provenA = false;
+        // pass 0: hypothesis A for every lane (planes only).  Pass s + 1: the lanes of staged haplotype s that A left open need k-mer
+        // look-ups -- that haplotype's index is built (the wave's one index area), hypothesis B is tried, then the no-vote test.
+        bool novote = false;
+        for (int pass = 0; pass <= nst; ++pass) {
+            const int attempt = pass == 0 ? 0 : 1;
+            bool mine = false;
+            if (pass > 0) {
+                mine = live && !proven && slot == pass - 1;
+                if (!__any(mine)) continue;
+                const unsigned char* recs = lstate + (size_t)(pass - 1) * stride;
+                const int hs_ = hb + hl_lo + pass - 1;
+                const int hapLenS = (int)(b.hap_off[hs_ + 1] - b.hap_off[hs_]);
+                direct = hapLenS > 4096;
+                int tsize = 64;
+                if (direct) tsize = 16384;
+                else while (tsize < hapLenS + hapLenS / 4) tsize <<= 1;
+                tmask = (unsigned)tsize - 1u;
+                u64* p0 = (u64*)(recs + 16);
+                seed_build_index(table, nxt, p0, p0 + nw64, p0 + 2 * nw64, (int*)recs, hapLenS, (hapLenS + 63) >> 6, direct, tsize, tmask, false);
+                // hypothesis B for the lanes A could not prove: diagonal of the first haplotype-unique k-mer
+                triedB = false;
+                if (mine && canfast) {
+                    for (int i = 0; i < nk; ++i) {
+                        const unsigned hd = kmer_head(table, read_code(col, R, i), direct, tmask);
+                        if (hd != 0u && nxt[hd] == 0u) {
+                            const int d = (int)hd - i - 1;
+                            if (d != idx0 && d >= 0) { dstar = d; triedB = true; }
+                            break;
+                        }
+                    }
+                }
+            }
+            const bool run = canfast && !proven && dstar >= 0 && (pass == 0 || triedB);
+            if (__any(run)) {
+                const int wq = run ? (dstar >> 6) : 0, sb = dstar & 63;
+                const int nvalid = min(nk, nkp - dstar);                 // k-mers i < nvalid lie on haplotype positions
+                u64 Z[5], NU[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < nCmax) {
+                        const u64 x = (funnel(h0[wq + c], h0[wq + c + 1], sb) ^ r0[c]) | (funnel(h1[wq + c], h1[wq + c + 1], sb) ^ r1[c]);
+                        Z[c] = ~x;
+                        NU[c] = funnel(nup[wq + c], nup[wq + c + 1], sb);
+                    } else { Z[c] = 0ull; NU[c] = 0ull; }
+                }
+                Z[4] = 0ull;
+                u64 P2[5];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) P2[c] = Z[c] & ((Z[c] >> 1) | (Z[c + 1] << 63));
+                P2[4] = 0ull;
+                int C = 0, NUc = 0;
+                u64 U7[4];                               // k-mer i of the read equals the haplotype's at d*+i AND that k-mer is unique in the haplotype
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    U7[c] = 0ull;
+                    if (c < nCmax) {
+                        const u64 P4 = P2[c] & ((P2[c] >> 2) | (P2[c + 1] << 62));
+                        u64 P7 = P4 & ((P2[c] >> 4) | (P2[c + 1] << 60)) & ((Z[c] >> 6) | (Z[c + 1] << 58));
+                        const int nb = nvalid - 64 * c;
+                        const u64 msk = nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull));
+                        P7 &= msk;
+                        C += __popcll(P7);
+                        NUc += __popcll(P7 & NU[c]);
+                        U7[c] = P7 & ~NU[c];
+                    }
+                }
+                const int X = NUc * (maxmult - 1) + (nk - C) * maxmult;
+                if (run && X < C) {
+                    proven = true;
+                    // does the whole read match the haplotype on d*?  (Z: one bit per base, 1 = equal codes)
+                    u64 miss = 0ull;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int nb = L - 64 * c;
+                        const u64 mc = ~Z[c] & (nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull)));
+                        miss |= mc;
+                        if (attempt == 0) { missA[c] = mc; uniqA[c] = U7[c]; }
+                    }
+                    exact = miss == 0ull;
+                    provenA = attempt == 0;
+                }
+            }
+            // no k-mer of the read occurs in the haplotype <=> maxcount == 0 (calign.pyx:222): decided, no candidate.
+            // (tested only for pairs the proof left open)
+            if (pass > 0 && mine && !proven) {
+                novote = true;
+                for (int i = 0; i < nk && novote; ++i)
+                    if (kmer_head(table, read_code(col, R, i), direct, tmask) != 0u) novote = false;
+            }
+            if (pass == 0 && !__any(live && !proven)) break;
+        }
+        const bool decided = !live || novote || proven;
+        int ncand = 0, cidx = idx0;
+        bool orig_in = false;
+        if (live && proven && dstar + L + 15 < hapLen) { ncand = 1; cidx = dstar; orig_in = (idx0 == dstar); }   // calign.pyx:228
+        // The read equals the haplotype on the one candidate diagonal: that DP scores 0 (no cost is negative and the
+        // all-match path costs 0; a haplotype N costs 0 as well, align.c:17,314-318) and calign.pyx:242-247 returns it
+        // at once.  No DP is launched for the pair.
+        const bool zero = (shortcuts & SHORTCUT_EXACT) && ncand == 1 && exact && hap_plain && !((rflags >> 1) & 1);
+        // ---- "ungapped": the read differs from the haplotype in 1..UNG_KMAX bases on the one candidate diagonal d*, which is also
+        // the mapping position, and NO other path of the band can be cheaper than paying those mismatches.  Then the single DP
+        // of the pair returns U = sum of the mismatching bases' qualities and is not launched.  Cost model (align.c:314-335,
+        // 466-484): a mismatch costs qual[y]; a deletion of l bases go[x] + 3 (l - 1); an insertion of l bases go[x] + 2 + 5 (l - 1);
+        // nothing is negative; the band is d*-8 .. d*+7 (needs d* >= 8), the path may start and end on any diagonal.
+        // The one fact every bound uses: where 7-mer i of the read equals the haplotype's 7-mer at d*+i and that 7-mer occurs
+        // ONCE in the haplotype, the read has a mismatch in [i, i+7) on every other diagonal; n such starts inside a stretch the
+        // path spends on ONE other diagonal give ceil(n/7) disjoint windows, together worth V(.) (each holds a mismatching base,
+        // a base costs >= the read's smallest quality m, all but n_low of its bases cost >= 20).  A gap opening costs >= G, the
+        // smallest gap-open penalty of the slice, and an insertion skips read bases: <= 8 when it leaves or rejoins d*, <= 15
+        // otherwise, so a gap in the middle of a stretch spoils <= 21 starts = 3 windows.
+        // A path is a chain of stretches ON d*, which pay exactly the mismatches p_j inside them, and EXCURSIONS, each of which
+        // dodges a run of mismatches j..j'.  If every possible excursion costs at least the qualities it dodges, and a path that
+        // never touches d* costs >= U, no path beats U.  Windows are counted per stretch between two mismatches (they cannot
+        // overlap across a mismatching base): W(a,b) = sum over those stretches of ceil(#unique-matching starts inside [a,b) / 7).
+        // A FURTHER gap inside an excursion spoils the windows it cuts or skips, at a price: a deletion or a one-base insertion
+        // one window for >= G, an insertion of 2..8 two for >= G+7, of 9..15 three for >= G+42; so spoiling windows costs
+        // >= v'' = min((G+7)/2, (G+42)/3) apiece, and windows are worth phi(n) = V(n) with its slopes capped at v''
+        // (= V itself once G >= 33):
+        //   never on d*                                     phi(W(0, L-6)) >= U
+        //   elsewhere, then on d* from after p_j            G + min(phi(W), 7 + phi(W-1)) >= q_1 + .. + q_j,  W = W(0, p_j-6): the gap
+        //                                                   that joins d* is a deletion or a one-base insertion, or a longer
+        //                                                   insertion that costs >= 7 more and skips <= 7 more starts
+        //   on d* up to a gap before p_j, then elsewhere    the same with W = W(p_j+1, L-6) and q_j + .. + q_k
+        //   leaves d* before p_j, rejoins after p_j'        two gaps = an insertion and a deletion of l bases each:
+        //                                                   2G + 8l - 6 + windows, i.e. >= 2G + min(2 + phi(W), 10 + phi(W-1));
+        //                                                   more gaps: >= 2G + max(G, phi(W-2));  W = W(p_j+1, p_j'-6);
+        //                                                   all >= q_j + .. + q_j'
+        // (haplotype without N, read of plain A/C/G/T: equal codes = equal bytes.)
+        int ung_score = -1;
+        int why = 0;                                     // (PLAT_SEED_DEBUG=512: why the pair reached the DP; counted below)
+        {
+            const int mq = (rflags >> 3) & 31;
+            // The proof's cost model is exact arithmetic; align.c adds in wrapping int16 ("no overflow checks", align.c:81).  A read whose
+            // quality sum allows a band cell to pass 0x7FFF (rflags bit 2, the flag that also picks the DP's add flavour, dp_core.hpp)
+            // is left to the DP, which wraps as the reference does.  (The exact-match shortcut above needs no such guard: re-biased
+            // values are unsigned, nothing is below 0, and the all-match path stays at 0 whatever the other cells do.)
+            const bool wrapfree = !(rflags & 4) || (shortcuts & SHORTCUT_BIGQ);      // (SHORTCUT_BIGQ: measurement only, PLAT_UNGAPPED_BIGQ=1)
+            const bool cand = (shortcuts & SHORTCUT_UNGAPPED) && ncand == 1 && orig_in && provenA && !exact && hap_plain && has_n == 0 &&
+                              !((rflags >> 1) & 1) && cidx >= 8 && L >= 32 && wrapfree;
+            int k = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) k += __popcll(missA[c]);
+            const bool part = cand && k >= 1 && k <= UNG_KMAX;
+            why = !(ncand == 1) ? 1 : !orig_in ? 2 : !provenA ? 3 : exact ? 4 : k > UNG_KMAX ? 5 : !cand ? 8 : 0;
+            int kmw = part ? k : 0;                          // most mismatches any lane of the wave has to look at
+#pragma unroll
+            for (int s2 = 32; s2 > 0; s2 >>= 1) kmw = max(kmw, __shfl_xor(kmw, s2));
+            if (kmw > 0) {
+                int cw[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cw[c] = __popcll(uniqA[c]);
+                auto Cpre = [&](int x) -> int {              // unique-matching k-mer starts in [0, x)
+                    x = min(max(x, 0), 256);
+                    const int wi = x >> 6, sh = x & 63;
+                    const u64 wsel = wi == 0 ? uniqA[0] : wi == 1 ? uniqA[1] : wi == 2 ? uniqA[2] : wi == 3 ? uniqA[3] : 0ull;
+                    const int below = (wi > 0 ? cw[0] : 0) + (wi > 1 ? cw[1] : 0) + (wi > 2 ? cw[2] : 0) + (wi > 3 ? cw[3] : 0);
+                    return below + __popcll(wsel & ((1ull << sh) - 1ull));
+                };
+                auto Wof = [&](int n) -> int { return (max(n, 0) + 6) / 7; };
+                // n_low: how many of the read's bases may cost less than LOWQ (n disjoint windows are worth V(n) = mq min(n, n_low) + LOWQ max(n - n_low, 0))
+                const int nlow = (shortcuts & SHORTCUT_NLOW) ? (int)(ri.aux & 0xFFFFu) : 0x7FFF;
+                // the mismatches in read order (lanes with fewer than kmw repeat their last one with quality 0: its tests repeat too)
+                const uint8_t* rq = b.read_qual + b.read_off[rb + (valid ? rl : 0)];
+                u64 mm[4] = {missA[0], missA[1], missA[2], missA[3]};
+                int pp[UNG_KMAX], qq[UNG_KMAX];
+#pragma unroll
+                for (int j = 0; j < UNG_KMAX; ++j) {
+                    pp[j] = j ? pp[j - 1] : 0; qq[j] = 0;
+                    if (j < kmw) {                           // wave-uniform
+                        int pos = -1;
+#pragma unroll
+                        for (int c = 3; c >= 0; --c) if (mm[c]) pos = 64 * c + (int)__ffsll((long long)mm[c]) - 1;
+                        if (part && pos >= 0) { pp[j] = pos; qq[j] = rq[pos]; }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (pos >= 0 && (pos >> 6) == c) mm[c] &= mm[c] - 1ull;
+                    }
+                }
+                int U = 0;
+#pragma unroll
+                for (int j = 0; j < UNG_KMAX; ++j) U += qq[j];
+                const int st = cidx - 8;
+                int G = 127;
+                if (part) for (int t = st >> 6; t <= (st + L + 14) >> 6; ++t) G = min(G, (int)s_gmin[t]);
+                // everything below in units of 1/6 (v'' has a half and a third in it)
+                const int v6 = min(3 * (G + 7), 2 * (G + 42));
+                const int c_lo = min(6 * mq, v6), c_hi = min(6 * max(mq, (int)LOWQ), v6);
+                auto phi6 = [&](int n) -> int { n = max(n, 0); return c_lo * min(n, nlow) + c_hi * max(n - nlow, 0); };
+                // unique-matching starts before p_j - 6 and before p_j + 1 (none start in between: those 7-mers hold the mismatch)
+                int cm6[UNG_KMAX], cp1[UNG_KMAX];
+#pragma unroll
+                for (int j = 0; j < UNG_KMAX; ++j) {
+                    if (j < kmw) { cm6[j] = Cpre(pp[j] - 6); cp1[j] = Cpre(pp[j] + 1); }
+                    else { cm6[j] = cm6[j - (j > 0)]; cp1[j] = cp1[j - (j > 0)]; }
+                }
+                const int Ctot = Cpre(L - 6);
+                int Iw[UNG_KMAX];                            // windows between mismatch j and the next
+#pragma unroll
+                for (int j = 0; j + 1 < UNG_KMAX; ++j) Iw[j] = Wof(cm6[j + 1] - cp1[j]);
+                Iw[UNG_KMAX - 1] = 0;
+                int Wall = Wof(cm6[0]) + Wof(Ctot - cp1[UNG_KMAX - 1]);
+#pragma unroll
+                for (int j = 0; j + 1 < UNG_KMAX; ++j) Wall += Iw[j];
+                int bad = phi6(Wall) < 6 * U ? 10 : 0;       // never on d*
+                // an excursion at the head or the tail of the read: its gap next to d* is a deletion or a one-base insertion
+                // (no window lost) or a longer insertion (>= 7 more, one window lost)
+                auto edge = [&](int W, int T) -> bool { return 6 * (G - T) + min(phi6(W), 42 + phi6(W - 1)) >= 0; };
+                int Rs = 0, Qs = U, Wbefore = Wof(cm6[0]);   // windows before mismatch j
+#pragma unroll
+                for (int j = 0; j < UNG_KMAX; ++j) {
+                    if (j < kmw) {
+                        Rs += qq[j];
+                        if (!bad && !edge(Wbefore, Rs)) bad = 11;                     // elsewhere, then on d* from after p_j
+                        if (!bad && !edge(Wall - Wbefore, Qs)) bad = 12;              // on d* up to a gap before p_j, then elsewhere
+                        Wbefore += Iw[j];
+                        Qs -= qq[j];
+                        int T = qq[j], Wm = 0;
+                        if (!bad && 2 * G + 2 < T) bad = 13;                          // an excursion around p_j alone
+#pragma unroll
+                        for (int j2 = j + 1; j2 < UNG_KMAX; ++j2) {
+                            if (j2 < kmw) {
+                                T += qq[j2];
+                                Wm += Iw[j2 - 1];
+                                const int slack = 6 * (2 * G - T);
+                                const bool two = slack + 12 + phi6(Wm) >= 0 && slack + 60 + phi6(Wm - 1) >= 0;
+                                const bool more = slack + max(6 * G, phi6(Wm - 2)) >= 0;
+                                if (!bad && !(two && more)) bad = 14;
+                            }
+                        }
+                    }
+                }
+                if (part && !bad) ung_score = U;
+                else if (part) why = bad;
+            }
+        }
+        const bool ungapped = ung_score >= 0;
+        // extra job slot for (one candidate that is not the mapping position): one atomic per wave
+        int base = 0;
+        {
+            const bool need = decided && live && ncand == 1 && !orig_in && !zero;
+            const unsigned long long m = __ballot(need);
+            if (m) {
+                int wb = 0;
+                if (lane == 0) wb = (int)atomicAdd((unsigned long long*)&cnt[CNT_NEXTRA], (unsigned long long)__popcll(m));
+                wb = __shfl(wb, 0);
+                base = wb + __popcll(m & ((1ull << lane) - 1ull));
+                if (need && (long long)base + 1 <= (long long)extra_cap) jobs[npairs + base] = Job{ri.col, hq, idx0, L};
+            }
+        }
+        // Decided pairs: the ones that need no DP are finished here (skipped read: 0.0, chaplotype.pyx:345-346; read < 7 bp or exact
+        // match: score 0; ungapped alignment proven optimal: its score), the others leave a job in their slot.
+        // (SEED_LEAN, the asynchronous entry point: nobody asks for statistics afterwards, and k_finalize_dense only looks at pairs with
+        // a DP -- the 32 bytes of records of a finished pair, 7 pairs in 8 of a clean batch, are not written at all.)
+        bool prim = false;                                   // the pair's primary slot holds a DP
+        const bool recs = !(shortcuts & SEED_LEAN);
+        if (valid && decided) {
+            if (!live) {
+                const bool sk = skipped || hapshort;
+                if (recs) {
+                    pairs[pidx] = PairRec{0, 0, (int16_t)(sk ? -1 : -2), 0, mapq, {0, 0, 0}};
+                    jobs[pidx] = Job{ri.col, h, 0, 0};
+                }
+                out_ll[pidx] = sk ? 0.0 : loglik_of(0, mapq_lut, mapq);
+                if (out_score) out_score[pidx] = sk ? -1 : 0;
+            } else if (zero) {
+                if (recs) {
+                    pairs[pidx] = PairRec{0, L, (int16_t)-3, 0, mapq, {0, 0, 0}};
+                    jobs[pidx] = Job{ri.col, h, cidx, 0};
+                }
+                out_ll[pidx] = loglik_of(0, mapq_lut, mapq);
+                if (out_score) out_score[pidx] = 0;
+            } else if (ungapped) {
+                if (recs) {
+                    pairs[pidx] = PairRec{ung_score, L, (int16_t)-4, 0, mapq, {0, 0, 0}};
+                    jobs[pidx] = Job{ri.col, h, cidx, 0};
+                }
+                out_ll[pidx] = loglik_of(ung_score, mapq_lut, mapq);
+                if (out_score) out_score[pidx] = ung_score;
+            } else {
+                jobs[pidx] = Job{ri.col, hq, cidx, L};
+                pairs[pidx] = PairRec{base, idx0, (int16_t)ncand, (int16_t)(orig_in ? 0 : ncand), mapq, {0, 0, 0}};
+                prim = true;
+            }
+        }
+        if (shortcuts & 512) {                              // measurement only
+            for (int r = 0; r < 16; ++r) {
+                const unsigned long long m = __ballot(prim && why == r);
+                if (m && lane == 0) atomicAdd((unsigned long long*)&cnt[32 + r], (unsigned long long)__popcll(m));
+            }
+        }
+        {   // the wave's live job slots join the dense list: primary slots, then the extra ones, room reserved with one atomic
+            const bool extra = decided && live && ncand == 1 && !orig_in && !zero && valid && (long long)base + 1 <= (long long)extra_cap;
+            const unsigned long long m1 = __ballot(prim), m2 = __ballot(extra);
+            const int n1 = __popcll(m1), n2 = __popcll(m2);
+            if (n1 + n2) {
+                const int seg = w % DENSE_SEGS;
+                long long db = 0;
+                if (lane == 0) db = (long long)atomicAdd((unsigned long long*)dense_counter(cnt, seg), (unsigned long long)(n1 + n2));
+                db = ((long long)(unsigned)__shfl((int)db, 0)) | ((long long)__shfl((int)(db >> 32), 0) << 32);
+                if (db + n1 + n2 <= segcap) {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    if (prim) dense[seg * segcap + db + __popcll(m1 & below)] = (int32_t)pidx;
+                    if (extra) dense[seg * segcap + db + n1 + __popcll(m2 & below)] = (int32_t)(npairs + base);
+                }
+            }
+        }
+        // ---- pairs that could not be decided go to the exact vote in k_seed_slow (one wave per pair, spread over the
+        // whole device: a tandem-repeat window would otherwise serialise all its reads on this one wave)
+        const unsigned long long todo = __ballot(valid && !decided);
+        if (todo) {
+            long long sb = 0;
+            if (lane == 0) sb = (long long)atomicAdd((unsigned long long*)&cnt[CNT_SLOW_SEED], (unsigned long long)__popcll(todo));
+            sb = ((long long)(unsigned)__shfl((int)sb, 0)) | ((long long)__shfl((int)(sb >> 32), 0) << 32);
+            if (valid && !decided) slow_list[sb + __popcll(todo & ((1ull << lane) - 1ull))] = SlowRec{h, rl};
+        }
+    }
+}
+
 // k_seed_slow: the exact vote for the pairs k_seed queued.  Persistent grid; a workgroup (one wave) takes groups of 4 (1 when the queue is short)
 // consecutive queue entries (entries of one k_seed wave are consecutive and share their haplotype) and rebuilds the
 // haplotype's planes and k-mer index only when the haplotype changes.  Same LDS carve as k_seed.
@@ -1763,7 +2254,8 @@ PLAT_EXPORT int plat_dp_batch(plat_ctx* ctx, int n, int lmax, const uint8_t* hap
 
 static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStream_t st, long long* cnt, int maxhap,
                              int maxread, int maxR, long long npairs, int extra_cap, const int32_t* hap_win, const int32_t* win_rows,
-                             const long long* tile_off, int shortcuts, int32_t* dense, long long segcap, double* out_ll, int32_t* out_score)
+                             const long long* tile_off, int shortcuts, int32_t* dense, long long segcap, double* out_ll, int32_t* out_score,
+                             const int32_t* wave_win, const int32_t* wave_first, long long wave_cap)
 {
     int tsize_max = 64;                                        // in dwords
     if (maxhap > 4096) tsize_max = 8192;                       // direct mode: 16384 u16 heads
@@ -1800,11 +2292,32 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     const bool xcd = !(e_x && e_x[0] == '0') && b.n_haps >= 64;
     if (xcd) shortcuts |= SEED_XCD;
     const unsigned gx = xcd ? (unsigned)((b.n_haps + 7) / 8) * 8u : (unsigned)b.n_haps;
-    hipLaunchKernelGGL(k_seed, dim3(gx, ngroups > 0 ? ngroups : 1), dim3(64), lds, st, b, hap_win, win_rows, tile_off,
-                       (const ReadInfo*)ctx->rinfo.ptr, (const uint16_t*)ctx->codes.ptr, (uint8_t*)ctx->hapw.ptr,
-                       (uint8_t*)ctx->hap_flags.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
-                       (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, shortcuts, dense, segcap,
-                       (const double*)ctx->d_mapq_lut, out_ll, out_score, (const unsigned char*)basebuf);
+    if (!wave_win)
+        hipLaunchKernelGGL(k_seed, dim3(gx, ngroups > 0 ? ngroups : 1), dim3(64), lds, st, b, hap_win, win_rows, tile_off,
+                           (const ReadInfo*)ctx->rinfo.ptr, (const uint16_t*)ctx->codes.ptr, (uint8_t*)ctx->hapw.ptr,
+                           (uint8_t*)ctx->hap_flags.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
+                           (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, shortcuts, dense, segcap,
+                           (const double*)ctx->d_mapq_lut, out_ll, out_score, (const unsigned char*)basebuf);
+    else {
+        // the seeding stage as two kernels: the haplotype sweeps, then the (haplotype, read) pairs packed 64 to a wave
+        const size_t stride = seed_state_stride(maxhap);
+        int rcs = plat_reserve(ctx, ctx->seedstate, (size_t)(b.n_haps + SEED_NST + 1) * stride + 64);
+        if (rcs) return rcs;
+        const size_t lds_pairs = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 15) & ~(size_t)15) + (size_t)SEED_NST * stride + 64;
+        if (lds_pairs > 160 * 1024) return PLAT_ERR_HAP_TOO_LONG;
+        if (lds > 48 * 1024) PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds_pairs > 48 * 1024) PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pairs));
+        hipLaunchKernelGGL(k_sweep, dim3(gx), dim3(64), lds, st, b, (uint8_t*)ctx->hapw.ptr, (uint8_t*)ctx->hap_flags.ptr, cnt, tsize_max, maxhap, shortcuts,
+                           (const unsigned char*)basebuf, hap_win, (unsigned char*)ctx->seedstate.ptr);
+        if (!(shortcuts & 256)) {                              // (PLAT_SEED_DEBUG=256: the sweeps alone)
+            const bool xw = (shortcuts & SEED_XCD) != 0;
+            const unsigned gp = (unsigned)(xw ? ((wave_cap + 7) / 8) * 8 : wave_cap);
+            hipLaunchKernelGGL(k_pairs, dim3(gp > 0 ? gp : 1), dim3(64), lds_pairs, st, b, wave_win, wave_first, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
+                               (const uint16_t*)ctx->codes.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
+                               (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, shortcuts, dense, segcap, (const double*)ctx->d_mapq_lut, out_ll, out_score,
+                               (const unsigned char*)ctx->seedstate.ptr);
+        }
+    }
     PLAT_EV(ctx, 5, st);                                       // k_seed alone: ev[1] .. ev[5]
     hipLaunchKernelGGL(k_seed_slow, dim3(4096), dim3(64), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
@@ -1865,7 +2378,24 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         hipLaunchKernelGGL(k_validate, dim3((unsigned)std::min<long long>(2048, std::max<long long>(1, want))), dim3(256), 0, st, b, cnt, hap_win,
                            win_rows, calc_flank_score);
     }
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, b, win_rows, tile_off, cnt, hv, async ? 1 : 0);
+    // waves of k_pairs: <= n_pairs / 64 + n_haps / 5 + n_windows (64 pairs per wave; windows with < 13 reads give a wave 5 whole haplotypes)
+    // (asynchronous: the caller stated n_pairs, so the wave map is sized and built right here; synchronous: after the read-back below)
+    const char* e_fused = getenv("PLAT_SEED_FUSED");           // =1: rounds 1-3's single seeding kernel (k_seed) instead of k_sweep + k_pairs (read per call)
+    const bool seed_fused = e_fused && e_fused[0] == '1';
+    auto wave_cap_for = [&](long long np) { return std::min<long long>(np / 64 + b.n_haps / 5 + b.n_windows + 8, 0x7FFFFF00ll); };
+    long long wave_cap = 0;
+    int32_t* wave_win = nullptr;
+    int32_t* wave_first = nullptr;
+    auto reserve_wave_map = [&](long long np) -> int {
+        wave_cap = wave_cap_for(np);
+        const int rcw = plat_reserve(ctx, ctx->seedmap, ((size_t)wave_cap + (size_t)b.n_windows + 16) * sizeof(int32_t));
+        if (rcw) return rcw;
+        wave_first = (int32_t*)ctx->seedmap.ptr;
+        wave_win = wave_first + b.n_windows + 8;
+        return PLAT_OK;
+    };
+    if (async && !seed_fused && (rc = reserve_wave_map(hv.n_pairs))) return rc;
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, b, win_rows, tile_off, cnt, hv, async ? 1 : 0, wave_win, wave_first, wave_cap);
     PLAT_HIP(ctx, hipGetLastError());
     int64_t* hb = ctx->h_readback;
     long long tile_total;
@@ -1877,6 +2407,10 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         hv.max_hap_len = (int)hb[CNT_MAXHAP]; hv.max_read_len = (int)hb[CNT_MAXREAD]; hv.max_reads_per_window = (int)hb[CNT_MAXH];
         hv.hap_blob_len = hb[CNT_HAPBLOB]; hv.n_pairs = hb[CNT_NPAIRS]; hv.read_blob_len = hb[CNT_READBLOB];
         tile_total = hb[CNT_TILE_TOTAL];
+        if (!seed_fused && hv.n_pairs > 0) {                   // the wave map of k_pairs, now that the number of pairs is known (the scan again: same offsets)
+            if ((rc = reserve_wave_map(hv.n_pairs))) return rc;
+            hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, b, win_rows, tile_off, cnt, hv, 0, wave_win, wave_first, wave_cap);
+        }
     } else {
         tile_total = (long long)(hv.max_read_len + 8) * b.n_reads + 4ll * b.n_windows;     // upper bound of k_tile_scan's total
     }
@@ -1931,7 +2465,7 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         const long long segcap = npairs + extra_cap;
         if ((rc = plat_reserve(ctx, ctx->dense, ((size_t)segcap * DENSE_SEGS + 64) * sizeof(int32_t)))) return rc;
         if ((rc = align_seed_launch(ctx, b, st, cnt, maxhap, maxread, maxR, npairs, (int)extra_cap, hap_win, win_rows, tile_off,
-                                    shortcuts, (int32_t*)ctx->dense.ptr, segcap, out_loglik, out_score))) return rc;
+                                    shortcuts, (int32_t*)ctx->dense.ptr, segcap, out_loglik, out_score, wave_win, wave_first, wave_cap))) return rc;
         njobs = npairs + extra_cap;
         if (async) break;                      // job overflow is caught on the device and reported by plat_stream_sync
         PLAT_HIP(ctx, hipMemcpyAsync(hb, cnt, CNT_N * sizeof(long long), hipMemcpyDeviceToHost, st));

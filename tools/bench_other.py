@@ -292,13 +292,15 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
     # worker and loader threads share the rank's CPUs (workers sleep while the device works on their chunk): 10 + 8 with six regions per
     # chunk on the 16 CPUs one GPU box grants (tools/run_c4_sweep4.sh, run_c4_sweep5.sh: the box's own run-to-run spread, +-8 %, is as large
     # as the differences between 10-12 workers, 6-10 loaders and 4-8 regions per chunk; 16 + 8 and 4 per chunk measured 5 % below)
-    workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus * 5 // 8)))))
+    resident = os.environ.get("PLAT_CALLER_RESIDENT", "1") == "1"            # 0: regions generated and uploaded inside the timed region (rounds 2-3)
+    # (resident: the loaders only hand out stored structs, so the workers get the CPUs -- 14 workers x 8 regions per chunk measured best on the
+    #  16 CPUs of a one-GPU box: 1.21 M windows/s against 1.05 M with 10 x 6; 2 CPUs: 0.26 M, 4 CPUs: 0.43 M -- host stages 0.6 ms per region)
+    workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus * (7 if resident else 5) // 8)))))
     os.environ.setdefault("PLAT_CALLER_LOADERS", str(max(2, min(12, cpus // 2))))
-    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "6"))
+    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "8" if resident else "6"))
     pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1" and lib is None
     packed = os.environ.get("PLAT_CALLER_PACKED", "1") == "1"
     repeats = max(1, min(a.steps, 3))                                        # the line is the MEAN over the runs
-    resident = os.environ.get("PLAT_CALLER_RESIDENT", "1") == "1"            # 0: regions generated and uploaded inside the timed region (rounds 2-3)
     r = config4(rk.dev_index, mine, region_len, workers, per_chunk, repeats=repeats, pin=pin, lib=lib, region_kw=region_kw, rk=rk, packed=packed,
                 resident=resident)
     cnt = r.get("counted") or {}
