@@ -111,6 +111,7 @@ k_validate(plat_window_batch b, long long* cnt, int32_t* __restrict__ hap_win, i
             if (lane == 0) { set_err(cnt, PLAT_ERR_BAD_INPUT); win_rows[w] = 8; }
             continue;
         }
+        if (H * R >= 0x7FFFFF00ll && lane == 0) set_err(cnt, PLAT_ERR_OVERFLOW);       // (k_pairs numbers a window's pairs in 31 bits)
         // --calculateFlankScore=1 with hapFlank == 0 dereferences a NULL alignment buffer in the reference (calign.pyx:199-202,261-264)
         if (calc_flank && b.win_flank[w] <= 0 && lane == 0) set_err(cnt, PLAT_ERR_UNSUPPORTED);
         for (int h = h0 + lane; h < h1; h += 64) hap_win[h] = w;
@@ -153,11 +154,11 @@ k_tile_scan(plat_window_batch b, const int32_t* __restrict__ win_rows, long long
     auto nwaves_of = [&](int w) -> long long {
         const long long R = b.win_read_begin[w + 1] - b.win_read_begin[w], H = b.win_hap_begin[w + 1] - b.win_hap_begin[w];
         if (R <= 0 || H <= 0) return 0;
-        const long long pw = R >= 13 ? 64 : 5 * R;
-        return (H * R + pw - 1) / pw;
+        return R >= 13 ? (H * R + 63) >> 6 : (long long)(((unsigned)H + 4u) / 5u);     // 64 pairs per wave, or 5 whole haplotypes (5 R pairs)
     };
     long long s = 0, s2 = 0;
-    for (int w = w0; w < w1; ++w) {
+#pragma unroll 8
+    for (int w = w0; w < w1; ++w) {                      // (unrolled: the loads of eight windows in flight at once -- this single workgroup sits on the batch's critical path)
         s += ((long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]) + 3) & ~3ll;
         s2 += nwaves_of(w);
     }
@@ -170,6 +171,7 @@ k_tile_scan(plat_window_batch b, const int32_t* __restrict__ win_rows, long long
         __syncthreads();
     }
     long long run = part[t] - s, run2 = part2[t] - s2;
+#pragma unroll 4
     for (int w = w0; w < w1; ++w) {
         tile_off[w] = run;
         run += ((long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]) + 3) & ~3ll;
@@ -1492,10 +1494,21 @@ k_pairs(plat_window_batch b, const int32_t* __restrict__ wave_win, const int32_t
     const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
     const int hb = b.win_hap_begin[w], H = b.win_hap_begin[w + 1] - hb;
     const int PW = seed_pairs_per_wave(R);
-    const long long q0 = (v - (long long)wave_first[w]) * PW, QT = (long long)H * R;
+    // (a window's pairs fit 31 bits: k_validate refuses H R >= 2^31)
+    const unsigned q0 = (unsigned)(v - (long long)wave_first[w]) * (unsigned)PW, QT = (unsigned)H * (unsigned)R;
     if (q0 >= QT) return;
-    const int nq = (int)min((long long)PW, QT - q0);
-    const int hl_lo = (int)(q0 / R), hl_hi = (int)((q0 + nq - 1) / R), nst = hl_hi - hl_lo + 1;      // <= SEED_NST
+    const int nq = (int)min((unsigned)PW, QT - q0);
+    const int hl_lo = (int)(q0 / (unsigned)R), hl_hi = (int)((q0 + (unsigned)nq - 1u) / (unsigned)R), nst = hl_hi - hl_lo + 1;      // <= SEED_NST
+    const int r_lo = (int)(q0 - (unsigned)hl_lo * (unsigned)R);             // the first pair's read
+    const int hapStart = b.win_start[w] - b.win_flank[w];                   // chaplotype.pyx:606
+    const u64* rd2 = (const u64*)(codes + tile_off[w]);
+    const bool valid = lane < nq;
+    // lane -> (haplotype, read): r_lo + lane < R + 64, i.e. at most SEED_NST - 1 whole rows further
+    int slot = 0, rl = r_lo + (valid ? lane : 0);
+#pragma unroll
+    for (int k = 0; k < SEED_NST - 1; ++k) if (rl >= R) { rl -= R; ++slot; }
+    ReadInfo ri = ReadInfo{0, 0, 0, 0};
+    if (valid) ri = rinfo[rb + rl];                      // (requested before the records are staged: the two do not depend on each other)
     {   // the records of haplotypes hb + hl_lo .. hb + hl_hi are contiguous in `state`
         const u64* src = (const u64*)(state + (size_t)(hb + hl_lo) * stride);
         u64* dst = (u64*)lstate;
@@ -1503,12 +1516,8 @@ k_pairs(plat_window_batch b, const int32_t* __restrict__ wave_win, const int32_t
         for (int i = lane; i < nwords; i += 64) dst[i] = src[i];
     }
     wave_sync();
-    const int hapStart = b.win_start[w] - b.win_flank[w];                   // chaplotype.pyx:606
-    const u64* rd2 = (const u64*)(codes + tile_off[w]);
     {
-        const bool valid = lane < nq;
-        const long long q = q0 + (valid ? lane : 0);
-        const int hl = (int)(q / R), rl = (int)(q - (long long)hl * R), slot = hl - hl_lo;
+        const int hl = hl_lo + slot;
         const int h = hb + hl;
         const unsigned char* rec = lstate + (size_t)slot * stride;
         const u64* h0 = (const u64*)(rec + 16);
@@ -1519,8 +1528,6 @@ k_pairs(plat_window_batch b, const int32_t* __restrict__ wave_win, const int32_t
         const bool hap_plain = ((const int*)rec)[2] == 0;
         const int hapLen = (int)(b.hap_off[h + 1] - b.hap_off[h]);
         const int nkp = hapLen - 7;                      // haplotype k-mer positions 0..hapLen-8 (calign.pyx:109)
-        ReadInfo ri = ReadInfo{0, 0, 0, 0};
-        if (valid) ri = rinfo[rb + rl];
         const int L = (int)(ri.lfm & 0xFFFFu);
         const int rflags = (int)((ri.lfm >> 16) & 0xFFu);
         const uint8_t mapq = (uint8_t)(ri.lfm >> 24);
