@@ -414,13 +414,14 @@ def main():
 
     # live per-kernel timing of the dominant kernel (HIP events on the launch stream), untimed extra steps
     eng.profile_enable(True)
-    dp_ms, seed_ms, seedk_ms, fin_ms, gen_ms, prep_ms = [], [], [], [], [], []
+    dp_ms, seed_ms, seedk_ms, fin_ms, gen_ms, prep_ms, sweep_ms, pairs_ms = [], [], [], [], [], [], [], []
     prof = None
     for _ in range(5):
         eng.call_windows(db, want_stats=False)
         prof = eng.profile_last()
         dp_ms.append(prof.ms_dp); seed_ms.append(prof.ms_seed); fin_ms.append(prof.ms_finalize)
         gen_ms.append(prof.ms_genotype); prep_ms.append(prof.ms_prepare); seedk_ms.append(prof.ms_seed_kernel)
+        sweep_ms.append(prof.ms_sweep); pairs_ms.append(prof.ms_pairs)
     eng.profile_enable(False)
 
     # the job's one real exchange -- per-rank result records gathered to rank 0 and merged by (chrom, pos)
@@ -481,11 +482,23 @@ def main():
             + int(8 * max(hb.n_pairs - dp_per_step, 0) + 4 * dp_per_step)
         r_dp = entry("k_dp_jobs", prof.dp_alg_bytes, dp_avg, pm,
                      "recurrence is VALU-issue bound (packed int16), not HBM bound: see DESIGN.md")
-        r_seed = entry("k_seed", seed_alg, seedk_avg, pm.get("k_seed", {}),
-                       "LDS k-mer maps + bit-parallel proofs: bound by vector issue (secondary), not by HBM -- the fraction fell from 0.10 to 0.065 in round 3 "
-                       "because the kernel moves fewer bytes per launch (no 4-byte DP words per haplotype base: algorithmic 235 -> 146 MB; counter "
-                       "traffic 282 -> 140 MB) while its time went from 299 to 281 us; see DESIGN.md section 4")
-        roof, roof_other = (r_seed, r_dp) if seedk_avg > dp_avg else (r_dp, r_seed)
+        sweep_avg, pairs_avg = float(np.mean(sweep_ms)), float(np.mean(pairs_ms))
+        if sweep_avg > 0 and pairs_avg > 0:
+            # round 4: the seeding stage is two kernels.  k_sweep per launch: haplotype bytes in, gap-open bytes out (1 B/base each) + one record
+            # out per haplotype (flags, three bit planes, per-chunk minima); k_pairs: those records in, read bit planes in (2 bits/base), ReadInfo
+            # (16 B/read), PairRec + Job (32 B/pair), 8 B of log-likelihood per pair it finishes / 4 B per pair it queues
+            maxhap = int(np.max(np.diff(hb.hap_off)))
+            rec = 16 + 24 * (((maxhap + 63) >> 6) + 8) + (((((maxhap + 63) >> 6) + 8) + 15) & ~15)
+            sweep_alg = 2 * int(hb.hap_off[-1]) + rec * hb.n_haps
+            pairs_alg = rec * hb.n_haps + int(hb.read_off[-1]) // 4 + 16 * hb.n_reads + 32 * hb.n_pairs + int(8 * max(hb.n_pairs - dp_per_step, 0) + 4 * dp_per_step)
+            note = "bit-parallel proofs on bit planes / LDS multiplicity maps: bound by vector issue (64-bit shifts), not by HBM; see DESIGN.md section 4"
+            cands = [r_dp, entry("k_pairs", pairs_alg, pairs_avg, pm.get("k_pairs", {}), note), entry("k_sweep", sweep_alg, sweep_avg, pm.get("k_sweep", {}), note)]
+        else:
+            cands = [r_dp, entry("k_seed", seed_alg, seedk_avg, pm.get("k_seed", {}),
+                                 "LDS k-mer maps + bit-parallel proofs: bound by vector issue (secondary), not by HBM; see DESIGN.md section 4")]
+        cands.sort(key=lambda r: -r["avg_launch_ms"])
+        roof, roof_other = cands[0], cands[1]
+        roof_more = cands[2:]
         line = {
             "metric": "pair-HMM GCUPS (reference-equivalent band cells/s, read->haplotype likelihood path)",
             "value": cells_ref / T / 1e9,
@@ -508,6 +521,10 @@ def main():
             "roofline": roof,
             "roofline_other": roof_other,
         }
+        if roof_more:
+            line["roofline_third"] = roof_more[0]
+        if sweep_avg > 0:
+            line["kernel_ms"]["sweep"], line["kernel_ms"]["pairs"] = sweep_avg, pairs_avg
         # the honest pair of whole-step figures next to the per-kernel one: HBM traffic of ALL kernels of a step (PMC) and SURVEY 8(d)'s
         # dedup'd algorithmic bytes per window (reads 2 L + 12, haplotypes 2 hapLen, 8 bytes per (haplotype, read) out), both over the
         # pipelined step time

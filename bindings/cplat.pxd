@@ -61,6 +61,8 @@ cdef extern from "platypus_mi355x.h":
         float ms_seed_kernel
         int64_t dp_jobs
         int64_t dp_alg_bytes
+        float ms_sweep
+        float ms_pairs
     int plat_profile_enable(plat_ctx* ctx, int on) nogil
     int plat_profile_last(plat_ctx* ctx, plat_profile* out) nogil
 

@@ -84,6 +84,8 @@ typedef struct plat_profile {
     float ms_seed_kernel; /* k_seed alone (the first and largest kernel of the seed stage)         */
     int64_t dp_jobs;      /* DPs in the DP launch                                                 */
     int64_t dp_alg_bytes; /* algorithmic bytes of the DP launch                                   */
+    float ms_sweep;       /* k_sweep alone (round 4: the seeding stage is two kernels; 0 with PLAT_SEED_FUSED=1) */
+    float ms_pairs;       /* k_pairs alone                                                         */
 } plat_profile;
 int plat_profile_enable(plat_ctx* ctx, int on);
 int plat_profile_last(plat_ctx* ctx, plat_profile* out);   /* [syncs] */

@@ -2299,6 +2299,7 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     const bool xcd = !(e_x && e_x[0] == '0') && b.n_haps >= 64;
     if (xcd) shortcuts |= SEED_XCD;
     const unsigned gx = xcd ? (unsigned)((b.n_haps + 7) / 8) * 8u : (unsigned)b.n_haps;
+    ctx->ev_split = 0;
     if (!wave_win)
         hipLaunchKernelGGL(k_seed, dim3(gx, ngroups > 0 ? ngroups : 1), dim3(64), lds, st, b, hap_win, win_rows, tile_off,
                            (const ReadInfo*)ctx->rinfo.ptr, (const uint16_t*)ctx->codes.ptr, (uint8_t*)ctx->hapw.ptr,
@@ -2316,6 +2317,8 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
         if (lds_pairs > 48 * 1024) PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pairs));
         hipLaunchKernelGGL(k_sweep, dim3(gx), dim3(64), lds, st, b, (uint8_t*)ctx->hapw.ptr, (uint8_t*)ctx->hap_flags.ptr, cnt, tsize_max, maxhap, shortcuts,
                            (const unsigned char*)basebuf, hap_win, (unsigned char*)ctx->seedstate.ptr);
+        PLAT_EV(ctx, 8, st);
+        ctx->ev_split = 1;
         if (!(shortcuts & 256)) {                              // (PLAT_SEED_DEBUG=256: the sweeps alone)
             const bool xw = (shortcuts & SEED_XCD) != 0;
             const unsigned gp = (unsigned)(xw ? ((wave_cap + 7) / 8) * 8 : wave_cap);

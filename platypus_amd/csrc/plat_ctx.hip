@@ -71,7 +71,7 @@ PLAT_EXPORT int plat_ctx_destroy(plat_ctx* ctx) {
     if (ctx->h_readback) { e = hipHostFree(ctx->h_readback); (void)e; }
     if (ctx->h_sticky) { e = hipHostFree(ctx->h_sticky); (void)e; }
     if (ctx->sync_event) { e = hipEventDestroy((hipEvent_t)ctx->sync_event); (void)e; }
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 9; ++i)
         if (ctx->ev[i]) { e = hipEventDestroy(ctx->ev[i]); (void)e; }
     delete ctx;
     return PLAT_OK;
@@ -80,7 +80,7 @@ PLAT_EXPORT int plat_ctx_destroy(plat_ctx* ctx) {
 PLAT_EXPORT int plat_profile_enable(plat_ctx* ctx, int on) {
     if (!ctx) return PLAT_ERR_INVALID;
     if (on && !ctx->ev[0])
-        for (int i = 0; i < 8; ++i) PLAT_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+        for (int i = 0; i < 9; ++i) PLAT_HIP(ctx, hipEventCreate(&ctx->ev[i]));
     ctx->profile = on ? 1 : 0;
     ctx->ev_valid_align = ctx->ev_valid_geno = 0;
     return PLAT_OK;
@@ -95,6 +95,10 @@ PLAT_EXPORT int plat_profile_last(plat_ctx* ctx, plat_profile* out) {
         PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_prepare, ctx->ev[0], ctx->ev[1]));
         PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_seed, ctx->ev[1], ctx->ev[2]));
         PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_seed_kernel, ctx->ev[1], ctx->ev[5]));
+        if (ctx->ev_split) {
+            PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_sweep, ctx->ev[1], ctx->ev[8]));
+            PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_pairs, ctx->ev[8], ctx->ev[5]));
+        }
         PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_dp, ctx->ev[2], ctx->ev[3]));
         PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_finalize, ctx->ev[3], ctx->ev[4]));
         out->dp_jobs = ctx->prof_dp_jobs;

@@ -30,8 +30,8 @@ struct plat_ctx {
     void* sync_event = nullptr;         // hipEvent_t with hipEventBlockingSync: plat_stream_sync sleeps on it
     // optional live timing: events 0..5 bracket prepare|seed|dp|finalize, 6..7 bracket genotype
     int profile = 0;
-    hipEvent_t ev[8] = {};
-    int ev_valid_align = 0, ev_valid_geno = 0;
+    hipEvent_t ev[9] = {};          // + 8: between k_sweep and k_pairs
+    int ev_valid_align = 0, ev_valid_geno = 0, ev_split = 0;
     int64_t prof_dp_jobs = 0, prof_dp_bytes = 0;
 };
 

@@ -80,7 +80,9 @@ def main(o, tag):
     if per:
         d.update(kernel="k_dp_jobs", **pack(per["plat::k_dp_jobs<false>"]))
         d["source"] = "profiles/" + tag + "_pmc_hbm.txt (rocprofv3 --pmc, separate passes: FETCH_SIZE, WRITE_SIZE raw counters x 1024; SQ_INSTS_VALU; GRBM_GUI_ACTIVE / 8 XCDs)"
-        d["k_seed"] = pack(per["plat::k_seed"])
+        for kn in ("k_seed", "k_sweep", "k_pairs"):
+            if "plat::" + kn in per:
+                d[kn] = pack(per["plat::" + kn])
         d["k_prep_reads"] = pack(per["plat::k_prep_reads"])
         d["step_hbm_bytes"] = int(sum((v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 for k, v in per.items() if k.startswith("plat::") and v.get("launches", 0) >= 4 and k not in STATS_ONLY))
         d["step_kernels"] = {k: int((v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024) for k, v in per.items() if k.startswith("plat::") and v.get("launches", 0) >= 4 and k not in STATS_ONLY}
