@@ -156,11 +156,31 @@ k_tile_scan(plat_window_batch b, const int32_t* __restrict__ win_rows, long long
         if (R <= 0 || H <= 0) return 0;
         return R >= 13 ? (H * R + 63) >> 6 : (long long)(((unsigned)H + 4u) / 5u);     // 64 pairs per wave, or 5 whole haplotypes (5 R pairs)
     };
+    // Up to TS_KEEP windows per thread (batches of up to 16 k windows): their figures are loaded ONCE, all loads in flight together, and kept
+    // in registers across the scan -- this single workgroup sits on the batch's critical path and its time was two chains of `per`
+    // dependent round trips.  Larger batches take the loops.
+    constexpr int TS_KEEP = 16;
+    const bool keep = per <= TS_KEEP;
+    long long ts[TS_KEEP];
+    int nws[TS_KEEP];
     long long s = 0, s2 = 0;
-#pragma unroll 8
-    for (int w = w0; w < w1; ++w) {                      // (unrolled: the loads of eight windows in flight at once -- this single workgroup sits on the batch's critical path)
-        s += ((long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]) + 3) & ~3ll;
-        s2 += nwaves_of(w);
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < TS_KEEP; ++k) {
+            const int w = w0 + k;
+            ts[k] = 0; nws[k] = 0;
+            if (w < w1) {
+                ts[k] = ((long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]) + 3) & ~3ll;
+                nws[k] = (int)min(nwaves_of(w), 0x7FFFFFFFll);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TS_KEEP; ++k) { s += ts[k]; s2 += nws[k]; }
+    } else {
+        for (int w = w0; w < w1; ++w) {
+            s += ((long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]) + 3) & ~3ll;
+            s2 += nwaves_of(w);
+        }
     }
     part[t] = s; part2[t] = s2;
     __syncthreads();
@@ -171,16 +191,21 @@ k_tile_scan(plat_window_batch b, const int32_t* __restrict__ win_rows, long long
         __syncthreads();
     }
     long long run = part[t] - s, run2 = part2[t] - s2;
-#pragma unroll 4
-    for (int w = w0; w < w1; ++w) {
+    auto emit = [&](int w, long long tsz, long long n) {
         tile_off[w] = run;
-        run += ((long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]) + 3) & ~3ll;
+        run += tsz;
         if (wave_win) {
-            const long long n = nwaves_of(w);
             wave_first[w] = (int32_t)min(run2, 0x7FFFFFFFll);
             for (long long k = 0; k < n && run2 + k < wave_cap; ++k) wave_win[run2 + k] = w;
             run2 += n;
         }
+    };
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < TS_KEEP; ++k) if (w0 + k < w1) emit(w0 + k, ts[k], nws[k]);
+    } else {
+        for (int w = w0; w < w1; ++w)
+            emit(w, ((long long)win_rows[w] * (b.win_read_begin[w + 1] - b.win_read_begin[w]) + 3) & ~3ll, nwaves_of(w));
     }
     if (t == nt - 1) {
         cnt[CNT_NWAVES] = part2[t] <= wave_cap ? part2[t] : 0;
