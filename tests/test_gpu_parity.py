@@ -762,3 +762,33 @@ def test_haplotypes_derived_from_the_windows_first_one_give_the_same_scores(eng)
                 os.environ.pop("PLAT_SEED_SHARE", None)
         assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1], res["1"][1])
         assert res["0"][3] == res["1"][3] and res["0"][2] <= res["1"][2] <= 1.02 * res["0"][2] + 50
+
+
+def test_two_kernel_seeding_equals_the_fused_kernel(eng):
+    """Round 4: the seeding stage is k_sweep (per haplotype) + k_pairs ((haplotype, read) pairs packed 64 to a wave, up to six haplotype
+    records staged per wave, the k-mer index built per staged haplotype on demand); PLAT_SEED_FUSED=1 is rounds 1-3's single kernel.
+    Same scores, likelihoods, reference DPs and launched DPs -- on config 2, the hard workload, the stress batches (tandem repeats: many
+    index builds and slow-path pairs), a population batch (thousands of reads per window) and windows with few reads (R < 13: five whole
+    haplotypes per wave), through both entry points."""
+    import os
+    from platypus_amd import synth
+    few = synth.make_snp_windows(300, 21, read_len=150, depth=4)    # windows of ~5 reads
+    for hb in (synth.config2(1500, seed=9), synth.config2_hard(800, seed=11), _adversarial_batch(5), _adversarial_batch(6, gapped=True),
+               synth.config5(8, 20), few, synth.make_snp_windows(300, 22, read_len=150, depth=12)):      # (~15 reads: 64 pairs span five or six haplotypes)
+        res = {}
+        for mode in ("0", "1"):
+            os.environ["PLAT_SEED_FUSED"] = mode
+            try:
+                db = eng.upload(hb)
+                st = eng.align(db, want_stats=True)
+                eng.synchronize()
+                sync = (db.score.cpu().numpy()[:hb.n_pairs].copy(), db.loglik.cpu().numpy()[:hb.n_pairs].copy(), int(st.n_dp_launched), int(st.n_dp_reference))
+                db2 = eng.upload(hb)
+                eng.align_async(db2)
+                eng.synchronize()
+                res[mode] = sync + (db2.loglik.cpu().numpy()[:hb.n_pairs].copy(),)
+            finally:
+                os.environ.pop("PLAT_SEED_FUSED", None)
+        assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1], res["1"][1])
+        assert res["0"][2:4] == res["1"][2:4]
+        assert np.array_equal(res["0"][4], res["0"][1]) and np.array_equal(res["1"][4], res["1"][1])
