@@ -57,6 +57,7 @@ struct AsmParams {
     int cap;                           // hash slots per region (power of two)
     int max_pos;                       // max k-mer occurrences per region (dense node capacity)
     int timing;                        // PLAT_ASM_TIMING: phase timers on
+    int fused;                         // LDS path: k-mers and AddEdge events of the reads in ONE pass (round 4; PLAT_ASM_FUSED=0: rounds 2-3's passes)
 };
 
 struct AsmNodeE { int end[4]; int w[4]; int n; };   // finalised out-edges
@@ -317,6 +318,28 @@ template <int KW> __device__ inline int asm_lds_node_words(const int* tab, const
         s = (s + 1u) & (unsigned)(ASM_LDS_SLOTS - 1);
     }
 }
+// Fused pass (round 4): the table holds its FINAL words from the start of the reads' pass -- node id << ASM_OFF_BITS | offset of the
+// representative -- so that an edge's nodes are known the moment its k-mers are found: a k-mer met for the first time takes the next
+// read-node id (an id whose insertion loses the race for the slot stays unused: a hole in the node arrays, nothing else).  Returns the
+// slot, or -1 when the node arrays are full (the region is then redone on the global path).
+template <int KW> __device__ inline int asm_lds_insert_final(int* tab, const AsmWords<KW>& K, int k, int roff, const unsigned long long* s_ref, bool refc,
+                                            const uint8_t* ref, const uint8_t* rseq, int n_ref_nodes, int* n_read_nodes, int* rep) {
+    unsigned s = asm_hash_words(K, k) & (unsigned)(ASM_LDS_SLOTS - 1);
+    for (;;) {
+        int v = tab[s];
+        if (v == -1) {
+            const int id = n_ref_nodes + atomicAdd(n_read_nodes, 1);
+            if (id >= ASM_LDS_NODES) return -1;
+            const int word = (int)(((unsigned)id << ASM_OFF_BITS) | (unsigned)roff);
+            const int old = atomicCAS(&tab[s], -1, word);
+            if (old == -1) { rep[id] = 0x40000000 + roff; return (int)s; }
+            v = old;
+        }
+        const int id = (int)((unsigned)v >> ASM_OFF_BITS), o = v & ((1 << ASM_OFF_BITS) - 1);
+        if (asm_eq_words(K, k, id < n_ref_nodes, o, s_ref, refc, ref, rseq)) return (int)s;
+        s = (s + 1u) & (unsigned)(ASM_LDS_SLOTS - 1);
+    }
+}
 // asm_read_edge_q on the words of the edge's k+1 bases (S) and qualities (Q): min quality, or -1 when the edge is filtered
 template <int KW> __device__ __forceinline__ int asm_edge_q_words(const AsmWords<KW>& S, const AsmWords<KW>& Q, int k, int min_qual) {
     const int n = k + 1;
@@ -390,7 +413,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
     unsigned long long tick_ = P.timing ? wall_clock64() : 0ull;
     // LDS path: the successor slot words of the first ASM_LDS_NODES nodes are kept CLEAN between regions (zeroed here once, and by
     // every region for the few nodes it dirtied): a node's first-claimed slot lives in LDS, so most nodes never touch theirs
-    for (int i = tid; i < ASM_LDS_NODES * ASM_MAX_SUCC; i += nthr) { S.succ_cw[i] = 0ull; S.succ_c[i] = 0; }
+    for (int i = tid; i < ASM_LDS_NODES * ASM_MAX_SUCC; i += nthr) { S.succ_cw[i] = 0ull; S.succ_c[i] = 0; S.succ_t[i] = 0xFFFFFFFFu; }
 
     for (int g = blockIdx.x; g < b.n_regions; g += gridDim.x) {
         const uint8_t* ref = b.ref_seq + b.ref_off[g];
@@ -519,8 +542,178 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             // (or if k, the reference or the reads' bytes are beyond what the LDS path packs into its words)
             if (tid == 0) s_lds = (k <= 15 && nRefE < ASM_LDS_LIMIT && refLen < (1 << ASM_OFF_BITS) && blobLen < (1ll << ASM_OFF_BITS)) ? 1 : 0;
             __syncthreads();
+            // ---- LDS path, fused (round 4).  Rounds 2-3 inserted every k-mer (phase A), numbered the nodes (B), and only then ran the AddEdge
+            // events (C) from one 4-byte word per edge that phase A had left in global memory -- 0.5 MB per region written, read, and read
+            // again for the first tickets (D): two thirds of the kernel's HBM traffic.  Now:
+            //   1. the reference's k-mers are inserted and its nodes numbered along the reference (bitmap + ranks, as before); the table then
+            //      holds final words;
+            //   2. the reference's events: first touches, barrier -- every reference node's position is final, reads only come later --, then
+            //      the successor slots: the edge that leaves a node at its FIRST reference occurrence claims the node's LDS-summed slot (bit
+            //      27 of its word); its first ticket is the node's position and needs no word of its own.  Edges of later occurrences (repeats)
+            //      take the global slot words, with their first ticket (atomicMin);
+            //   3. the reads, ONE pass: an edge finds or creates its two nodes (asm_lds_insert_final) and is applied at once.  First tickets are
+            //      kept (one global atomicMin) for every slot but a reference-claimed LDS slot, whose ticket no read can lower;
+            //   4. phase D picks the successors from those tickets: no pass over the events, no event words for the reads at all.
+            bool fused_done = false;
+            if (P.fused && s_lds) {
+                for (int i = tid; i < ASM_LDS_SLOTS; i += nthr) s_tab[i] = -1;
+                for (int i = tid; i < ASM_LDS_NODES; i += nthr) { s_first[i] = 0xFFFFFFFFu; s_wc[i] = 0u; }
+                if (tid == 0) { s_distinct = 0; s_nrefnodes = 0; s_nreadnodes = 0; }
+                asm_sync();
+                int* ev = S.stack;                        // one word per REFERENCE edge (slot of its start k-mer | 1 << 14 | base << 22 | end flag << 30)
+                int* ev_end = S.stack + P.max_pos;
+                constexpr int KW = 2;
+                for (int e = tid; e < nRefE; e += nthr) {
+                    const AsmWords<KW> E = refc ? asm_load_words_lds<KW>(s_ref, e, k + 1) : asm_load_words<KW>(ref + e, k + 1);
+                    const int slot = asm_lds_insert_words(s_tab, asm_kmer_start(E, k), k, e, s_ref, refc, ref, rseq, &s_distinct);
+                    int word = slot | 1 << 14 | (int)(asm_byte_k(E, k) & 0xFFu) << 22;
+                    if (e == nRefE - 1) {
+                        ev_end[e] = asm_lds_insert_words(s_tab, asm_kmer_end(E, k), k, e + 1, s_ref, refc, ref, rseq, &s_distinct);
+                        word |= 1 << 30;
+                    }
+                    ev[e] = word;
+                }
+                asm_sync();
+                // the reference's nodes in the order of their representatives along the reference (ids 0 .. nRefNodes0 - 1)
+                const int refBytes = ((refLen + 16 + 7) >> 3) << 3, nW32 = (refLen >> 5) + 1;
+                const bool ordered = refc && refBytes + 8 * nW32 <= ASM_REF_CACHE && nW32 <= nthr;
+                unsigned* s_bm = (unsigned*)((char*)s_ref + refBytes);
+                unsigned* s_bp = s_bm + nW32;
+                if (ordered) for (int i = tid; i < nW32; i += nthr) s_bm[i] = 0u;
+                __syncthreads();
+                int nRefNodes0 = 0;
+                if (ordered) {
+                    for (int sidx = tid; sidx < ASM_LDS_SLOTS; sidx += nthr) {
+                        const int off = s_tab[sidx];
+                        if (off != -1) atomicOr(&s_bm[off >> 5], 1u << (off & 31));
+                    }
+                    __syncthreads();
+                    const int mine = tid < nW32 ? __popc(s_bm[tid]) : 0;
+                    const int before = asm_block_exscan(mine, s_wsum, nRefNodes0);
+                    if (tid < nW32) s_bp[tid] = (unsigned)before;
+                    __syncthreads();
+                } else nRefNodes0 = s_distinct;
+                for (int sidx = tid; sidx < ASM_LDS_SLOTS; sidx += nthr) {
+                    const int off = s_tab[sidx];
+                    if (off != -1) {
+                        const int id = ordered ? (int)s_bp[off >> 5] + __popc(s_bm[off >> 5] & ((1u << (off & 31)) - 1u)) : atomicAdd(&s_nrefnodes, 1);
+                        S.rep[id] = off;
+                        s_tab[sidx] = (int)(((unsigned)id << ASM_OFF_BITS) | (unsigned)off);
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) s_nrefnodes = nRefNodes0;
+                auto node_of = [&](int slot) -> int { return (int)((unsigned)s_tab[slot] >> ASM_OFF_BITS); };
+                // slot of a successor byte; bytes other than A, C, G, T share slots 4..7 (claimed in the node's global byte word)
+                auto succ_slot = [&](int sn, unsigned c) -> int {
+                    if (c == 'A' || c == 'C' || c == 'G' || c == 'T') return (int)((c >> 1) & 3u);
+                    unsigned* cw = (unsigned*)(S.succ_c + (size_t)sn * ASM_MAX_SUCC) + 1;            // bytes 4..7
+                    for (int j = 0; j < 4; ++j)
+                        for (;;) {
+                            const unsigned wd = *(volatile unsigned*)cw;
+                            const unsigned cur = (wd >> (8 * j)) & 0xFFu;
+                            if (cur == c) return 4 + j;
+                            if (cur != 0u) break;
+                            if (atomicCAS(cw, wd, wd | (c << (8 * j))) == wd) return 4 + j;
+                        }
+                    return -1;
+                };
+                auto global_slot = [&](int sn, int slot, int w, int e) {
+                    if (!(s_wc[sn] >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);                       // (bit 26: the node's global slot words are in use)
+                    atomicAdd(&S.succ_cw[sn * ASM_MAX_SUCC + slot], (1ull << 32) | (unsigned long long)(unsigned)w);
+                    atomicMin(&S.succ_t[sn * ASM_MAX_SUCC + slot], (unsigned)e);
+                };
+                // 2a. first touches and colours of the reference's events
+                for (int e = tid; e < nRefE; e += nthr) {
+                    const int word = ev[e];
+                    const int sn = node_of(word & 0x3FFF);
+                    const int en = node_of((word >> 30 & 1) ? ev_end[e] : (ev[e + 1] & 0x3FFF));
+                    atomicMin(&s_first[sn], 2u * (unsigned)e);
+                    atomicMin(&s_first[en], 2u * (unsigned)e + 1u);
+                    if ((s_wc[sn] >> 30 & 1u) == 0u) atomicOr(&s_wc[sn], 1u << 30);
+                    if ((s_wc[en] >> 30 & 1u) == 0u) atomicOr(&s_wc[en], 1u << 30);
+                    S.ref_node[e] = sn;
+                    if (e == nRefE - 1) S.ref_node[e + 1] = en;
+                }
+                __syncthreads();
+                // 2b. successor slots of the reference's events
+                for (int e = tid; e < nRefE; e += nthr) {
+                    const int word = ev[e];
+                    const int sn = node_of(word & 0x3FFF);
+                    const unsigned c = (unsigned)(word >> 22) & 0xFFu;
+                    const int slot = succ_slot(sn, c);
+                    if (slot < 0) { s_err = PLAT_ERR_UNSUPPORTED; continue; }
+                    if (slot >= 4 && !(s_wc[sn] >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);          // its byte word is in use
+                    const unsigned ft = s_first[sn];
+                    if (slot < 7 && (int)(ft >> 1) + (int)(ft & 1u) == e)                             // the node's first occurrence: the one claim of its LDS slot in this pass
+                        atomicAdd(&s_wc[sn], ((unsigned)(slot + 1) << 23) | (1u << 27) | 1u);
+                    else global_slot(sn, slot, 1, e);
+                }
+                asm_sync();
+                ASM_TICK(1);
+                // 3. the reads
+                bool bad = false;
+                read_pass(std::integral_constant<int, KW>{},
+                    [&](int i, int ro, const AsmWords<KW>& E, int w) -> int {
+                        (void)w;
+                        return asm_lds_insert_final(s_tab, asm_kmer_start(E, k), k, ro + i, s_ref, refc, ref, rseq, nRefNodes0, &s_nreadnodes, S.rep);
+                    },
+                    [&](int t, int off, const AsmWords<KW>& E, int w, int slot0, int nslot) {
+                        if (nslot < 0 && slot0 >= 0)
+                            nslot = asm_lds_insert_final(s_tab, asm_kmer_end(E, k), k, off + 1, s_ref, refc, ref, rseq, nRefNodes0, &s_nreadnodes, S.rep);
+                        if (slot0 < 0 || nslot < 0) return;                                            // node arrays full: the region is redone below
+                        const int e = nRefE + t, sn = node_of(slot0), en = node_of(nslot);
+                        atomicMin(&s_first[sn], 2u * (unsigned)e);
+                        atomicMin(&s_first[en], 2u * (unsigned)e + 1u);
+                        unsigned x = s_wc[sn];
+                        if ((x >> 30 & 2u) == 0u) atomicOr(&s_wc[sn], 2u << 30);
+                        if ((s_wc[en] >> 30 & 2u) == 0u) atomicOr(&s_wc[en], 2u << 30);
+                        const unsigned c = asm_byte_k(E, k) & 0xFFu;
+                        const int slot = succ_slot(sn, c);
+                        if (slot < 0) { bad = true; return; }                                          // > 4 distinct other bytes
+                        if (slot >= 4 && !(x >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);
+                        bool local = false;
+                        if (slot < 7) {
+                            for (;;) {
+                                const unsigned d = (x >> 23) & 7u;
+                                if (d == 0u) {
+                                    const unsigned old = atomicCAS(&s_wc[sn], x, x | (unsigned)(slot + 1) << 23);
+                                    x = old == x ? (x | (unsigned)(slot + 1) << 23) : old;
+                                    continue;
+                                }
+                                local = d == (unsigned)slot + 1u && (x & 0x7FFFFFu) < 0x780000u;
+                                break;
+                            }
+                        }
+                        if (local) {
+                            atomicAdd(&s_wc[sn], (unsigned)w);
+                            if (!(x >> 27 & 1u)) {                                                     // a read claimed this slot: its first ticket is kept globally
+                                if (!(x >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);
+                                atomicMin(&S.succ_t[sn * ASM_MAX_SUCC + slot], (unsigned)e);
+                            }
+                        } else global_slot(sn, slot, w, e);
+                    },
+                    [&](int t) { (void)t; },
+                    [&]() -> bool { return nRefNodes0 + *(volatile int*)&s_nreadnodes > ASM_LDS_LIMIT; });
+                if (bad) s_err = PLAT_ERR_UNSUPPORTED;
+                asm_sync();
+                if (nRefNodes0 + s_nreadnodes > ASM_LDS_LIMIT) {
+                    // more nodes than the LDS takes: leave the global slot words clean and take the global path
+                    for (int n = tid; n < ASM_LDS_NODES; n += nthr)
+                        if (s_wc[n] >> 26 & 1u)
+                            for (int j = 0; j < ASM_MAX_SUCC; ++j) { S.succ_cw[n * ASM_MAX_SUCC + j] = 0ull; S.succ_c[n * ASM_MAX_SUCC + j] = 0; S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu; }
+                    __syncthreads();
+                    if (tid == 0) s_lds = 0;
+                } else {
+                    if (tid == 0) s_n = nRefNodes0 + s_nreadnodes;
+                    fused_done = true;
+                }
+                asm_sync();
+                ASM_TICK(2);
+            }
             bool failed = false;
             for (;;) {
+                if (fused_done) break;
                 const bool lds = s_lds != 0;
                 if (lds) { for (int i = tid; i < ASM_LDS_SLOTS; i += nthr) s_tab[i] = -1; if (tid == 0) s_distinct = 0; }
                 else {
@@ -597,7 +790,9 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     S.succ_w[id * ASM_MAX_SUCC + j] = 0; S.succ_n[id * ASM_MAX_SUCC + j] = -1;
                 }
             };
-            if (lds) {
+            if (fused_done) {
+                // (the fused pass numbered the nodes as it went)
+            } else if (lds) {
                 // Nodes represented by a reference occurrence get the low ids (a slot then tells where its representative lives), in the
                 // order of their representatives along the reference when the LDS has room for a bitmap of the positions: reads arrive
                 // sorted by position and walk along the reference, so the successor slots they update then lie next to each other in
@@ -654,7 +849,9 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             const int nNodes = s_n;
             // ---- phase C: AddEdge events (assembler.pyx:801-827)
             const int nRefNodes = s_nrefnodes;
-            if (lds) {
+            if (fused_done) {
+                // (... and applied the events)
+            } else if (lds) {
                 // one event per thread, from the word phase A left: node words in LDS; the successor slot of the start node is picked by the
                 // byte the edge appends (A, C, G, T: slots 0..3 by the byte's bits; anything else shares slots 4..7 by search), and takes ONE
                 // global atomic: its event count and weight.  Which node a slot leads to is looked up once per slot in phase D; first
@@ -771,11 +968,11 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     for (int j = 0; j < ASM_MAX_SUCC; ++j) used += j == own || (S.succ_cw[n * ASM_MAX_SUCC + j] >> 32) != 0ull;
                     if (used > 1) {
                         s_wc[n] |= 1u << 29;
-                        for (int j = 0; j < ASM_MAX_SUCC; ++j) S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu;
+                        if (!fused_done) for (int j = 0; j < ASM_MAX_SUCC; ++j) S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu;
                     }
                 }
                 asm_sync();
-                {
+                if (!fused_done) {                                  // (the fused pass kept the first tickets as it went)
                     const int* ev = S.stack;
                     for (int e0 = tid; e0 < nEv; e0 += 4 * nthr) {
                       int words[4];
@@ -809,7 +1006,13 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             int bj = -1; unsigned bt = 0xFFFFFFFFu;
                             for (int j = 0; j < ASM_MAX_SUCC; ++j) {
                                 if (j != own && (!dirty || (S.succ_cw[n * ASM_MAX_SUCC + j] >> 32) == 0ull)) continue;
-                                const unsigned t = several ? S.succ_t[n * ASM_MAX_SUCC + j] : 0u;
+                                // first ticket of the slot; fused pass: a node's reference-claimed LDS slot (bit 27) is the edge that leaves
+                                // its first reference occurrence, whose ticket is the node's position
+                                unsigned t = 0u;
+                                if (several) {
+                                    if (fused_done && j == own && (s_wc[n] >> 27 & 1u)) { const unsigned ft = s_first[n]; t = (ft >> 1) + (ft & 1u); }
+                                    else t = S.succ_t[n * ASM_MAX_SUCC + j];
+                                }
                                 if (!firstpick && t <= last) continue;
                                 if (t < bt) { bt = t; bj = j; }
                             }
@@ -834,7 +1037,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         }
                         S.edges[n] = E;
                         if (dirty)                                  // leave the node's slot words clean for the next region
-                            for (int j = 0; j < ASM_MAX_SUCC; ++j) { S.succ_cw[n * ASM_MAX_SUCC + j] = 0ull; S.succ_c[n * ASM_MAX_SUCC + j] = 0; }
+                            for (int j = 0; j < ASM_MAX_SUCC; ++j) { S.succ_cw[n * ASM_MAX_SUCC + j] = 0ull; S.succ_c[n * ASM_MAX_SUCC + j] = 0; S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu; }
                     }
                 };
                 pick_edges(std::integral_constant<int, 2>{});
@@ -855,6 +1058,8 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     last = bt; firstpick = false;
                 }
                 S.edges[n] = E;
+                if (n < ASM_LDS_NODES)                              // the LDS path of the regions that follow expects these words clean
+                    for (int j = 0; j < ASM_MAX_SUCC; ++j) { S.succ_cw[n * ASM_MAX_SUCC + j] = 0ull; S.succ_c[n * ASM_MAX_SUCC + j] = 0; S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu; }
             }
             asm_sync();
             ASM_TICK(4);
@@ -1084,6 +1289,7 @@ PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* ba
     P.kmer = kmer_size; P.min_qual = min_qual; P.min_weight = min_weight; P.no_cycles = no_cycles;
     P.max_vars = max_vars_per_region; P.blob_per_region = blob_per_region; P.cap = cap; P.max_pos = (int)max_pos;
     P.timing = getenv("PLAT_ASM_TIMING") != nullptr;
+    { const char* ef = getenv("PLAT_ASM_FUSED"); P.fused = !(ef && ef[0] == '0'); }
     const size_t per_block = asm_scratch_bytes(cap, (int)max_pos, max_ref, max_reads);
     P.scratch_per_block = (long long)per_block;
     // the kernel is bound by the latency of dependent L2 accesses, not by bandwidth or issue: one region per CU at a time (its graph takes
