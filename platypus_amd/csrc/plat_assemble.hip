@@ -414,6 +414,10 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
     // LDS path: the successor slot words of the first ASM_LDS_NODES nodes are kept CLEAN between regions (zeroed here once, and by
     // every region for the few nodes it dirtied): a node's first-claimed slot lives in LDS, so most nodes never touch theirs
     for (int i = tid; i < ASM_LDS_NODES * ASM_MAX_SUCC; i += nthr) { S.succ_cw[i] = 0ull; S.succ_c[i] = 0; S.succ_t[i] = 0xFFFFFFFFu; }
+    // fused LDS path: the first ticket of a node's LDS-summed slot when a READ claimed it (read-only nodes; a reference-claimed slot's ticket
+    // is the node's position) lives in S.weight[node] -- the LDS path has no other use for that array --, 0xFFFFFFFF between regions
+    unsigned* own_t = (unsigned*)S.weight;
+    for (int i = tid; i < ASM_LDS_NODES; i += nthr) own_t[i] = 0xFFFFFFFFu;
 
     for (int g = blockIdx.x; g < b.n_regions; g += gridDim.x) {
         const uint8_t* ref = b.ref_seq + b.ref_off[g];
@@ -618,9 +622,11 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         }
                     return -1;
                 };
-                auto global_slot = [&](int sn, int slot, int w, int e) {
+                // (the first event of a slot also notes where the slot leads: phase D then neither hashes nor compares)
+                auto global_slot = [&](int sn, int slot, int w, int e, int en) {
                     if (!(s_wc[sn] >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);                       // (bit 26: the node's global slot words are in use)
-                    atomicAdd(&S.succ_cw[sn * ASM_MAX_SUCC + slot], (1ull << 32) | (unsigned long long)(unsigned)w);
+                    const unsigned long long was = atomicAdd(&S.succ_cw[sn * ASM_MAX_SUCC + slot], (1ull << 32) | (unsigned long long)(unsigned)w);
+                    if ((was >> 32) == 0ull) S.succ_n[sn * ASM_MAX_SUCC + slot] = en;
                     atomicMin(&S.succ_t[sn * ASM_MAX_SUCC + slot], (unsigned)e);
                 };
                 // 2a. first touches and colours of the reference's events
@@ -640,14 +646,16 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 for (int e = tid; e < nRefE; e += nthr) {
                     const int word = ev[e];
                     const int sn = node_of(word & 0x3FFF);
+                    const int en = node_of((word >> 30 & 1) ? ev_end[e] : (ev[e + 1] & 0x3FFF));
                     const unsigned c = (unsigned)(word >> 22) & 0xFFu;
                     const int slot = succ_slot(sn, c);
                     if (slot < 0) { s_err = PLAT_ERR_UNSUPPORTED; continue; }
                     if (slot >= 4 && !(s_wc[sn] >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);          // its byte word is in use
                     const unsigned ft = s_first[sn];
-                    if (slot < 7 && (int)(ft >> 1) + (int)(ft & 1u) == e)                             // the node's first occurrence: the one claim of its LDS slot in this pass
+                    if (slot < 7 && (int)(ft >> 1) + (int)(ft & 1u) == e) {                           // the node's first occurrence: the one claim of its LDS slot in this pass
                         atomicAdd(&s_wc[sn], ((unsigned)(slot + 1) << 23) | (1u << 27) | 1u);
-                    else global_slot(sn, slot, 1, e);
+                        S.succ_n[sn * ASM_MAX_SUCC + slot] = en;
+                    } else global_slot(sn, slot, 1, e, en);
                 }
                 asm_sync();
                 ASM_TICK(1);
@@ -678,6 +686,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                                 const unsigned d = (x >> 23) & 7u;
                                 if (d == 0u) {
                                     const unsigned old = atomicCAS(&s_wc[sn], x, x | (unsigned)(slot + 1) << 23);
+                                    if (old == x) S.succ_n[sn * ASM_MAX_SUCC + slot] = en;            // this event claimed the slot
                                     x = old == x ? (x | (unsigned)(slot + 1) << 23) : old;
                                     continue;
                                 }
@@ -687,11 +696,11 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         }
                         if (local) {
                             atomicAdd(&s_wc[sn], (unsigned)w);
-                            if (!(x >> 27 & 1u)) {                                                     // a read claimed this slot: its first ticket is kept globally
-                                if (!(x >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);
-                                atomicMin(&S.succ_t[sn * ASM_MAX_SUCC + slot], (unsigned)e);
+                            if (!(x >> 27 & 1u)) {                                                     // a read claimed this slot: its first ticket in the node's own word (bit 28: in use)
+                                if (!(x >> 28 & 1u)) atomicOr(&s_wc[sn], 1u << 28);
+                                atomicMin(&own_t[sn], (unsigned)e);
                             }
-                        } else global_slot(sn, slot, w, e);
+                        } else global_slot(sn, slot, w, e, en);
                     },
                     [&](int t) { (void)t; },
                     [&]() -> bool { return nRefNodes0 + *(volatile int*)&s_nreadnodes > ASM_LDS_LIMIT; });
@@ -699,9 +708,11 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 asm_sync();
                 if (nRefNodes0 + s_nreadnodes > ASM_LDS_LIMIT) {
                     // more nodes than the LDS takes: leave the global slot words clean and take the global path
-                    for (int n = tid; n < ASM_LDS_NODES; n += nthr)
+                    for (int n = tid; n < ASM_LDS_NODES; n += nthr) {
+                        if (s_wc[n] >> 28 & 1u) own_t[n] = 0xFFFFFFFFu;
                         if (s_wc[n] >> 26 & 1u)
                             for (int j = 0; j < ASM_MAX_SUCC; ++j) { S.succ_cw[n * ASM_MAX_SUCC + j] = 0ull; S.succ_c[n * ASM_MAX_SUCC + j] = 0; S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu; }
+                    }
                     __syncthreads();
                     if (tid == 0) s_lds = 0;
                 } else {
@@ -955,8 +966,9 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             asm_sync();
             ASM_TICK(3);
             if (lds) {                                                        // the node words the later phases read, to the slice
-                for (int n = tid; n < nNodes; n += nthr) { S.first[n] = s_first[n]; S.weight[n] = 0; S.colour[n] = (int)(s_wc[n] >> 30); }
+                for (int n = tid; n < nNodes; n += nthr) { S.first[n] = s_first[n]; if (!fused_done) S.weight[n] = 0; S.colour[n] = (int)(s_wc[n] >> 30); }
                 asm_sync();
+                ASM_TICK(9);
             }
             // ---- phase D: per node, the four successors with the smallest first tickets, in ticket order
             if (lds) {
@@ -972,6 +984,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     }
                 }
                 asm_sync();
+                ASM_TICK(10);
                 if (!fused_done) {                                  // (the fused pass kept the first tickets as it went)
                     const int* ev = S.stack;
                     for (int e0 = tid; e0 < nEv; e0 += 4 * nthr) {
@@ -1040,7 +1053,63 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             for (int j = 0; j < ASM_MAX_SUCC; ++j) { S.succ_cw[n * ASM_MAX_SUCC + j] = 0ull; S.succ_c[n * ASM_MAX_SUCC + j] = 0; S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu; }
                     }
                 };
-                pick_edges(std::integral_constant<int, 2>{});
+                if (!fused_done) pick_edges(std::integral_constant<int, 2>{});
+                else {
+                    // fused pass: every used slot knows its end node (succ_n).  Eight nodes per thread and trip, the one global word most of them
+                    // need -- the end of their only slot -- requested for all eight before the first is used
+                    constexpr int DB = 8;
+                    for (int n0 = tid; n0 < nNodes; n0 += DB * nthr) {
+                        unsigned xs[DB]; int ends[DB];
+#pragma unroll
+                        for (int u = 0; u < DB; ++u) {
+                            const int n = n0 + u * nthr;
+                            xs[u] = n < nNodes ? s_wc[n] : 0u;
+                            const int own = (int)(xs[u] >> 23 & 7u) - 1;
+                            ends[u] = (n < nNodes && own >= 0) ? S.succ_n[n * ASM_MAX_SUCC + own] : -1;
+                        }
+#pragma unroll
+                        for (int u = 0; u < DB; ++u) {
+                            const int n = n0 + u * nthr;
+                            if (n >= nNodes) continue;
+                            const unsigned x = xs[u];
+                            const bool several = (x >> 29 & 1u) != 0u, dirty = (x >> 26 & 1u) != 0u;
+                            const int own = (int)(x >> 23 & 7u) - 1;
+                            // (written field by field: a local AsmNodeE indexed by the pick count would live in scratch memory)
+                            AsmNodeE* Eo = &S.edges[n];
+                            int en_ = 0;
+                            if (!dirty) {
+                                if (own >= 0) { Eo->end[0] = ends[u]; Eo->w[0] = (int)(x & 0x7FFFFFu); en_ = 1; }
+                            } else {
+                                unsigned last = 0; bool firstpick = true;
+                                for (int pick = 0; pick < 4; ++pick) {
+                                    int bj = -1; unsigned bt = 0xFFFFFFFFu;
+                                    for (int j = 0; j < ASM_MAX_SUCC; ++j) {
+                                        if (j != own && (S.succ_cw[n * ASM_MAX_SUCC + j] >> 32) == 0ull) continue;
+                                        unsigned t = 0u;
+                                        if (several) {
+                                            t = S.succ_t[n * ASM_MAX_SUCC + j];                        // (events of the slot that went to the global words)
+                                            if (j == own) {
+                                                if (x >> 27 & 1u) { const unsigned ft = s_first[n]; t = (ft >> 1) + (ft & 1u); }
+                                                else t = min(t, own_t[n]);
+                                            }
+                                        }
+                                        if (!firstpick && t <= last) continue;
+                                        if (t < bt) { bt = t; bj = j; }
+                                    }
+                                    if (bj < 0) break;
+                                    Eo->end[en_] = bj == own ? ends[u] : S.succ_n[n * ASM_MAX_SUCC + bj];
+                                    Eo->w[en_] = (int)(unsigned)S.succ_cw[n * ASM_MAX_SUCC + bj] + (bj == own ? (int)(x & 0x7FFFFFu) : 0);
+                                    ++en_;
+                                    last = bt; firstpick = false;
+                                    if (!several) break;
+                                }
+                                for (int j = 0; j < ASM_MAX_SUCC; ++j) { S.succ_cw[n * ASM_MAX_SUCC + j] = 0ull; S.succ_c[n * ASM_MAX_SUCC + j] = 0; S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu; }
+                            }
+                            Eo->n = en_;
+                            if (x >> 28 & 1u) own_t[n] = 0xFFFFFFFFu;
+                        }
+                    }
+                }
             } else
             for (int n = tid; n < nNodes; n += nthr) {
                 AsmNodeE E; E.n = 0;
@@ -1058,6 +1127,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     last = bt; firstpick = false;
                 }
                 S.edges[n] = E;
+                if (n < ASM_LDS_NODES) S.weight[n] = -1;            // (= 0xFFFFFFFF: the fused LDS path's per-node ticket word)
                 if (n < ASM_LDS_NODES)                              // the LDS path of the regions that follow expects these words clean
                     for (int j = 0; j < ASM_MAX_SUCC; ++j) { S.succ_cw[n * ASM_MAX_SUCC + j] = 0ull; S.succ_c[n * ASM_MAX_SUCC + j] = 0; S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu; }
             }
@@ -1309,7 +1379,7 @@ PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* ba
         PLAT_HIP(ctx, hipStreamSynchronize(st));
         PLAT_HIP(ctx, hipMemcpyFromSymbol(t, HIP_SYMBOL(g_asm_ticks), sizeof t));
         fprintf(stderr, "k_assemble, 10 ns ticks per phase summed over %d workgroups (ticket scan, A insert, B ids, C events, D successors, cycles, E starts, F paths, G variants):", nblk);
-        for (int i = 0; i < 9; ++i) fprintf(stderr, " %llu", t[i]);
+        for (int i = 0; i < 12; ++i) fprintf(stderr, " %llu", t[i]);
         fprintf(stderr, "\n");
         memset(t, 0, sizeof t);
         PLAT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_asm_ticks), t, sizeof t));
