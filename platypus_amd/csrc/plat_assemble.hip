@@ -661,49 +661,142 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 ASM_TICK(1);
                 // 3. the reads
                 bool bad = false;
-                read_pass(std::integral_constant<int, KW>{},
-                    [&](int i, int ro, const AsmWords<KW>& E, int w) -> int {
-                        (void)w;
-                        return asm_lds_insert_final(s_tab, asm_kmer_start(E, k), k, ro + i, s_ref, refc, ref, rseq, nRefNodes0, &s_nreadnodes, S.rep);
-                    },
-                    [&](int t, int off, const AsmWords<KW>& E, int w, int slot0, int nslot) {
-                        if (nslot < 0 && slot0 >= 0)
-                            nslot = asm_lds_insert_final(s_tab, asm_kmer_end(E, k), k, off + 1, s_ref, refc, ref, rseq, nRefNodes0, &s_nreadnodes, S.rep);
-                        if (slot0 < 0 || nslot < 0) return;                                            // node arrays full: the region is redone below
-                        const int e = nRefE + t, sn = node_of(slot0), en = node_of(nslot);
-                        atomicMin(&s_first[sn], 2u * (unsigned)e);
-                        atomicMin(&s_first[en], 2u * (unsigned)e + 1u);
-                        unsigned x = s_wc[sn];
-                        if ((x >> 30 & 2u) == 0u) atomicOr(&s_wc[sn], 2u << 30);
-                        if ((s_wc[en] >> 30 & 2u) == 0u) atomicOr(&s_wc[en], 2u << 30);
-                        const unsigned c = asm_byte_k(E, k) & 0xFFu;
-                        const int slot = succ_slot(sn, c);
-                        if (slot < 0) { bad = true; return; }                                          // > 4 distinct other bytes
-                        if (slot >= 4 && !(x >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);
-                        bool local = false;
-                        if (slot < 7) {
-                            for (;;) {
-                                const unsigned d = (x >> 23) & 7u;
-                                if (d == 0u) {
-                                    const unsigned old = atomicCAS(&s_wc[sn], x, x | (unsigned)(slot + 1) << 23);
-                                    if (old == x) S.succ_n[sn * ASM_MAX_SUCC + slot] = en;            // this event claimed the slot
-                                    x = old == x ? (x | (unsigned)(slot + 1) << 23) : old;
-                                    continue;
+                {
+                    // A wave takes one read at a time; a window of 256 bytes of its bases and of its qualities is held one aligned dword per
+                    // lane (as in read_pass).  The window's edges are worked FOUR ROUNDS OF 64 AT ONCE: the kernel is bound by chains of LDS
+                    // round trips (gather -> table -> representative -> node words), and four independent chains per lane share each wait.
+                    constexpr int WIN = 4 * (64 - 2 * KW) - 3;
+                    struct Meta { int base, cnt, ro; };
+                    struct Win { unsigned dS, dQ; int sS, sQ, nE; };
+                    auto load_meta = [&](int r) -> Meta {
+                        Meta m{0, 0, 0};
+                        if (r < nR) { m.base = S.read_base[r]; m.cnt = S.read_base[r + 1] - m.base; m.ro = (int)(b.read_off[rb + r] - rblob0); }
+                        return m;
+                    };
+                    auto load_win = [&](const Meta& m, int c0) -> Win {
+                        Win w;
+                        w.nE = max(0, min(WIN, m.cnt - c0));
+                        const uintptr_t pS = (uintptr_t)(rseq + m.ro + c0), pQ = (uintptr_t)(rqual + m.ro + c0);
+                        w.sS = (int)(pS & 3); w.sQ = (int)(pQ & 3);
+                        w.dS = (w.nE > 0 && 4 * lane < w.sS + w.nE + k + 1) ? *(const unsigned*)((pS & ~(uintptr_t)3) + 4 * lane) : 0u;
+                        w.dQ = (w.nE > 0 && 4 * lane < w.sQ + w.nE + k + 1) ? *(const unsigned*)((pQ & ~(uintptr_t)3) + 4 * lane) : 0u;
+                        return w;
+                    };
+                    Meta m0 = load_meta(wv), m1 = load_meta(wv + nwv);
+                    Win w0 = load_win(m0, 0);
+                    bool stopped = false;
+                    for (int r = wv; r < nR && !stopped; r += nwv) {
+                        const Meta m2 = load_meta(r + 2 * nwv);
+                        const Win w1 = load_win(m1, 0);
+                        const int base = m0.base, cnt = m0.cnt, ro = m0.ro;
+                        for (int c0 = 0; c0 < cnt; c0 += WIN) {
+                            if (nRefNodes0 + *(volatile int*)&s_nreadnodes > ASM_LDS_LIMIT) { stopped = true; break; }   // (<= 4 x 1024 new k-mers between two looks: the arrays' spare room)
+                            const Win w = c0 == 0 ? w0 : load_win(m0, c0);
+                            const int nE = w.nE;
+                            AsmWords<KW> E[4];
+                            int wq[4], slots[4];
+                            // I. the edges' bytes and quality filter
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int j = 64 * u + lane, i = c0 + j;
+                                wq[u] = -1; slots[u] = -1;
+                                E[u] = asm_mask_words(asm_gather_words<KW>(w.dS, j + w.sS), k + 1);
+                                if (64 * u < nE) {
+                                    const AsmWords<KW> Q = asm_mask_words(asm_gather_words<KW>(w.dQ, j + w.sQ), k + 1);
+                                    if (j < nE) {
+                                        wq[u] = asm_edge_q_words(E[u], Q, k, P.min_qual);
+                                        if (wq[u] == -2) wq[u] = asm_read_edge_q(rseq + ro, rqual + ro, i, k, P.min_qual);
+                                    }
                                 }
-                                local = d == (unsigned)slot + 1u && (x & 0x7FFFFFu) < 0x780000u;
-                                break;
+                            }
+                            // II. the start k-mers of the valid edges, found or created: four probe sequences per lane side by side
+                            {
+                                unsigned sl[4]; bool todo[4];
+                                AsmWords<KW> Ks[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) { Ks[u] = asm_kmer_start(E[u], k); todo[u] = wq[u] >= 0; sl[u] = asm_hash_words(Ks[u], k) & (unsigned)(ASM_LDS_SLOTS - 1); }
+                                while (todo[0] | todo[1] | todo[2] | todo[3]) {
+                                    int v[4];
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) v[u] = todo[u] ? s_tab[sl[u]] : 0;
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u)
+                                        if (todo[u] && v[u] == -1) {                               // an empty slot: a k-mer met for the first time
+                                            const int id = nRefNodes0 + atomicAdd(&s_nreadnodes, 1);
+                                            if (id >= ASM_LDS_NODES) { todo[u] = false; continue; }   // (slots[u] stays -1: the region is redone on the global path)
+                                            const int roff = ro + c0 + 64 * u + lane;
+                                            const int old = atomicCAS(&s_tab[sl[u]], -1, (int)(((unsigned)id << ASM_OFF_BITS) | (unsigned)roff));
+                                            if (old == -1) { S.rep[id] = 0x40000000 + roff; slots[u] = (int)sl[u]; todo[u] = false; }
+                                            else v[u] = old;
+                                        }
+                                    bool eq[4];
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        const int id = (int)((unsigned)v[u] >> ASM_OFF_BITS), o = v[u] & ((1 << ASM_OFF_BITS) - 1);
+                                        eq[u] = todo[u] && asm_eq_words(Ks[u], k, id < nRefNodes0, o, s_ref, refc, ref, rseq);
+                                    }
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u)
+                                        if (todo[u]) {
+                                            if (eq[u]) { slots[u] = (int)sl[u]; todo[u] = false; }
+                                            else sl[u] = (sl[u] + 1u) & (unsigned)(ASM_LDS_SLOTS - 1);
+                                        }
+                                }
+                            }
+                            // III. an edge's end k-mer is the start k-mer of the next edge (the next lane's, or lane 0's of the next round)
+                            int nsl[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                int nx = __shfl_down(slots[u], 1);
+                                const int first_next = u < 3 ? __shfl(slots[u + 1], 0) : -1;
+                                if (lane == 63) nx = first_next;
+                                nsl[u] = nx;
+                            }
+                            // IV. the events
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (wq[u] < 0 || slots[u] < 0) continue;
+                                const int off = ro + c0 + 64 * u + lane;
+                                int nslot = nsl[u];
+                                if (nslot < 0) nslot = asm_lds_insert_final(s_tab, asm_kmer_end(E[u], k), k, off + 1, s_ref, refc, ref, rseq, nRefNodes0, &s_nreadnodes, S.rep);
+                                if (nslot < 0) continue;                                               // node arrays full: the region is redone below
+                                const int w_ = wq[u];
+                                const int e = nRefE + base + c0 + 64 * u + lane, sn = node_of(slots[u]), en = node_of(nslot);
+                                atomicMin(&s_first[sn], 2u * (unsigned)e);
+                                atomicMin(&s_first[en], 2u * (unsigned)e + 1u);
+                                unsigned x = s_wc[sn];
+                                if ((x >> 30 & 2u) == 0u) atomicOr(&s_wc[sn], 2u << 30);
+                                if ((s_wc[en] >> 30 & 2u) == 0u) atomicOr(&s_wc[en], 2u << 30);
+                                const unsigned c = asm_byte_k(E[u], k) & 0xFFu;
+                                const int slot = succ_slot(sn, c);
+                                if (slot < 0) { bad = true; continue; }                                // > 4 distinct other bytes
+                                if (slot >= 4 && !(x >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);
+                                bool local = false;
+                                if (slot < 7) {
+                                    for (;;) {
+                                        const unsigned d = (x >> 23) & 7u;
+                                        if (d == 0u) {
+                                            const unsigned old = atomicCAS(&s_wc[sn], x, x | (unsigned)(slot + 1) << 23);
+                                            if (old == x) S.succ_n[sn * ASM_MAX_SUCC + slot] = en;    // this event claimed the slot
+                                            x = old == x ? (x | (unsigned)(slot + 1) << 23) : old;
+                                            continue;
+                                        }
+                                        local = d == (unsigned)slot + 1u && (x & 0x7FFFFFu) < 0x780000u;
+                                        break;
+                                    }
+                                }
+                                if (local) {
+                                    atomicAdd(&s_wc[sn], (unsigned)w_);
+                                    if (!(x >> 27 & 1u)) {                                             // a read claimed this slot: its first ticket in the node's own word (bit 28: in use)
+                                        if (!(x >> 28 & 1u)) atomicOr(&s_wc[sn], 1u << 28);
+                                        atomicMin(&own_t[sn], (unsigned)e);
+                                    }
+                                } else global_slot(sn, slot, w_, e, en);
                             }
                         }
-                        if (local) {
-                            atomicAdd(&s_wc[sn], (unsigned)w);
-                            if (!(x >> 27 & 1u)) {                                                     // a read claimed this slot: its first ticket in the node's own word (bit 28: in use)
-                                if (!(x >> 28 & 1u)) atomicOr(&s_wc[sn], 1u << 28);
-                                atomicMin(&own_t[sn], (unsigned)e);
-                            }
-                        } else global_slot(sn, slot, w, e, en);
-                    },
-                    [&](int t) { (void)t; },
-                    [&]() -> bool { return nRefNodes0 + *(volatile int*)&s_nreadnodes > ASM_LDS_LIMIT; });
+                        m0 = m1; m1 = m2; w0 = w1;
+                    }
+                }
                 if (bad) s_err = PLAT_ERR_UNSUPPORTED;
                 asm_sync();
                 if (nRefNodes0 + s_nreadnodes > ASM_LDS_LIMIT) {

@@ -144,3 +144,23 @@ def test_config3_shape_regions(eng, oracle):
         assert g == exp
         tot += len(exp)
     assert tot > 0
+
+
+def test_fused_lds_pass_equals_the_three_pass_path(eng, golden_dir):
+    """Round 4: on the LDS path the reads' k-mers and AddEdge events are ONE pass (reference nodes numbered first, ids for read-only nodes as
+    they appear, first tickets kept as the events go); PLAT_ASM_FUSED=0 is rounds 2-3's insert / number / apply / collect-tickets sequence.
+    The same variants in the same order on the reference's golden regions, on fuzz regions with repeats, N runs and low-quality stretches,
+    and on config-3 shaped regions; several regions per workgroup, so the slot words a region leaves clean are met by the next one."""
+    cases = json.load(gzip.open(os.path.join(golden_dir, "assembler_cases.json.gz"), "rt"))
+    regs = [to_region(c) for c in cases if c["noCycles"] == 0] * 3
+    rng = np.random.default_rng(4242)
+    regs += [synth_region(rng, int(rng.integers(300, 2500)), 2, int(rng.choice([75, 100, 150, 250])), int(rng.integers(5, 40)), int(rng.integers(0, 6))) for _ in range(400)]
+    regs += [synth_region(rng, 4500, 2, 250, 30, 4) for _ in range(48)]                      # config-3 shape
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["PLAT_ASM_FUSED"] = mode
+        try:
+            out[mode] = eng.assemble(regs, kmer_size=15, min_qual=20, min_weight=40, no_cycles=0)
+        finally:
+            os.environ.pop("PLAT_ASM_FUSED", None)
+    assert out["1"] == out["0"] and sum(len(v) for v in out["1"]) > 300
