@@ -551,7 +551,10 @@ struct Chunk {
                     else if (t.encoding != PLAT_READS_ASCII) throw DeviceError(PLAT_ERR_INVALID, "plat_read_table.encoding");
                 }
             }
-        const size_t N = nReads[0] + nReads[1] + nReads[2], B = nBytes[0] + nBytes[1] + nBytes[2], Cg = nCig[0] + nCig[1] + nCig[2];
+        // (+ 16 bytes per table: a packed table that is resident on the device is expanded straight from there, and its place in the chunk blob
+        //  is shifted so that source and destination share their misalignment -- the expansion then moves 16 bytes per lane)
+        const size_t nTables = 3 * regions.size() * (regions.empty() ? 0 : regions[0]->samples.size());
+        const size_t N = nReads[0] + nReads[1] + nReads[2], B = nBytes[0] + nBytes[1] + nBytes[2] + 16 * nTables, Cg = nCig[0] + nCig[1] + nCig[2];
         if (N > 0x7FFFFFF0ull) throw DeviceError(PLAT_ERR_OVERFLOW, "chunk read table");
         Slot& z = s;
         z.t_seq.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream); z.t_qual.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream);
@@ -561,7 +564,7 @@ struct Chunk {
         L.add(z.t_cigar, 2 * Cg + 2); L.add(z.t_region, nReads[0] + 1);
         L.add(z.t_excidx, nExc + 1); L.add(z.t_excb, nExc + 1); L.add(z.t_excq, nExc + 1);
         L.commit(z, z.a_tab);
-        struct Pending { size_t bo, nb, e0, ne; };
+        struct Pending { size_t bo, nb, e0, ne; const uint8_t* dev; };       // dev: expand from this device address instead of t_pack + bo
         std::vector<Pending> packed;
         size_t ri = 0, bo = 0, co = 0, eo = 0, inBytes = 0;
         int scan = 0;
@@ -574,17 +577,18 @@ struct Chunk {
                     const int n = t.n_reads;
                     tv.base = (int64_t)ri;
                     const size_t nb = (size_t)t.off[n], nc = (size_t)t.cig_off[n];
+                    if (nb && t.encoding == PLAT_READS_PACKED && t.dev_seq)   // resident: no copy at all; the table's place follows the source's misalignment
+                        bo += (size_t)(((uintptr_t)t.dev_seq - (uintptr_t)(z.t_seq.d + bo)) & 15);
                     if (nb && t.encoding == PLAT_READS_PACKED) {            // one byte per base crosses the link (or none: dev_seq); expanded below
-                        if (t.dev_seq) ck(plat_memcpy_d2d(z.ctx, z.t_pack.d + bo, t.dev_seq, nb, z.stream), "plat_memcpy_d2d(packed)");
-                        else ck(plat_memcpy_h2d(z.ctx, z.t_pack.d + bo, t.seq, nb, z.stream), "plat_memcpy_h2d(packed)");
+                        if (!t.dev_seq) ck(plat_memcpy_h2d(z.ctx, z.t_pack.d + bo, t.seq, nb, z.stream), "plat_memcpy_h2d(packed)");
                         const size_t ne = (size_t)std::max<int64_t>(t.n_exceptions, 0);
                         // packed tables that follow each other in the blob are expanded by ONE plat_unpack_reads: the exceptions of the
                         // later ones are counted from the first one's first byte
-                        const bool joins = !packed.empty() && packed.back().bo + packed.back().nb == bo && packed.back().e0 + packed.back().ne == eo;
+                        const bool joins = !t.dev_seq && !packed.empty() && !packed.back().dev && packed.back().bo + packed.back().nb == bo && packed.back().e0 + packed.back().ne == eo;
                         const int64_t shift = joins ? (int64_t)(bo - packed.back().bo) : 0;
                         for (size_t e = 0; e < ne; ++e) { z.t_excidx.h[eo + e] = t.exc_index[e] + shift; z.t_excb.h[eo + e] = t.exc_base[e]; z.t_excq.h[eo + e] = t.exc_qual[e]; }
                         if (joins) { packed.back().nb += nb; packed.back().ne += ne; }
-                        else packed.push_back(Pending{bo, nb, eo, ne});
+                        else packed.push_back(Pending{bo, nb, eo, ne, t.dev_seq});
                         eo += ne; inBytes += (t.dev_seq ? 0 : nb) + 10 * ne;
                     } else if (nb && t.dev_seq && t.dev_qual) {            // resident in HBM already
                         ck(plat_memcpy_d2d(z.ctx, z.t_seq.d + bo, t.dev_seq, nb, z.stream), "plat_memcpy_d2d(seq)");
@@ -612,7 +616,7 @@ struct Chunk {
         z.t_cigar.h[2 * Cg] = 0; z.t_cigar.h[2 * Cg + 1] = 0;
         L.upload(z, z.a_tab);
         for (const Pending& p : packed)
-            ck(plat_unpack_reads(z.ctx, (int64_t)p.nb, z.t_pack.d + p.bo, z.t_seq.d + p.bo, z.t_qual.d + p.bo, (int64_t)p.ne, z.t_excidx.d + p.e0,
+            ck(plat_unpack_reads(z.ctx, (int64_t)p.nb, p.dev ? p.dev : z.t_pack.d + p.bo, z.t_seq.d + p.bo, z.t_qual.d + p.bo, (int64_t)p.ne, z.t_excidx.d + p.e0,
                                  z.t_excb.d + p.e0, z.t_excq.d + p.e0, z.stream), "plat_unpack_reads");
         nGood = nReads[0]; nScan = scan;
         std::lock_guard<std::mutex> g(stMutex);
