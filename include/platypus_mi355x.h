@@ -19,7 +19,9 @@
  *    Haplotype.cHaplotypeSequence.  Every blob must be followed by >= PLAT_BLOB_PAD readable bytes.
  *  - the caller owns all buffers it passes; the context owns only its internal scratch.
  *  - a context is bound to one GPU and is not thread-safe (the reference is single-threaded per
- *    process: SURVEY.md 8(b)); use one context per process/rank.
+ *    process: SURVEY.md 8(b)); use one context per process/rank -- or, as libplat_caller.so does, one per
+ *    worker thread.  That includes plat_stream_sync: it records and waits on ONE event owned by the
+ *    context, so two threads syncing different streams of the same context at once may return early.
  */
 #ifndef PLATYPUS_MI355X_H
 #define PLATYPUS_MI355X_H

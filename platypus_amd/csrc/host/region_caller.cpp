@@ -676,8 +676,13 @@ struct Chunk {
                 Layout LM;
                 LM.add(z.m_n, (size_t)nScan * 2); LM.add(z.m_cand, (size_t)nScan * mergeCap * 8);
                 LM.commit(z, z.a_mout);
-                ck(plat_candidates_merge_batch(z.ctx, &cb, z.t_end.d, nScan, z.c_scanbegin.d, z.c_scanlongest.d, maxPerRead, z.c_rec.d, z.c_cnt.d,
-                                               z.c_status.d, o.minVarFreq, mergeCap, z.m_cand.d, z.m_n.d, z.stream), "plat_candidates_merge_batch");
+                {
+                    // (its table is 64 KB per scan in the context's scratch: a cohort too wide for it falls back to the host tally, it does not fail the call)
+                    const int rcm = plat_candidates_merge_batch(z.ctx, &cb, z.t_end.d, nScan, z.c_scanbegin.d, z.c_scanlongest.d, maxPerRead, z.c_rec.d, z.c_cnt.d,
+                                                                z.c_status.d, o.minVarFreq, mergeCap, z.m_cand.d, z.m_n.d, z.stream);
+                    if (rcm == PLAT_ERR_NOMEM) { hostTally = true; continue; }
+                    ck(rcm, "plat_candidates_merge_batch");
+                }
                 LM.download(z, z.a_mout);
                 z.sync("candidate scan");
                 for (int g = 0; g < nScan; ++g) {
