@@ -362,6 +362,45 @@ template <int KW> __device__ __forceinline__ int asm_edge_q_words(const AsmWords
     return ((int)mn >= min_qual && !zero) ? (int)mn : -1;
 }
 
+// ---- quality minimum of every edge of a window at once (round 4) ------------------------------------------------------------------
+// The window's quality bytes lie one dword per lane.  Instead of gathering each edge's k + 1 bytes and taking their minimum (a dozen lane
+// exchanges and ~40 byte operations per edge), the lanes compute the SLIDING minimum over n = k + 1 bytes for all 256 positions together
+// -- widths 2, 4, 8, 16 by doubling, each step one lane exchange and one byte-wise minimum --, and an edge fetches its byte.  Bytes must
+// be < 128 (a quality >= 128 is negative as the reference reads it: such a window takes the per-edge code).
+__device__ __forceinline__ unsigned asm_bytemin7(unsigned x, unsigned y) {            // per byte min(x, y), all bytes < 128
+    const unsigned d = (x | 0x80808080u) - y;                                          // bit 7 of a byte: x >= y (no borrow crosses a byte)
+    const unsigned m = (d >> 7) & 0x01010101u;
+    const unsigned mask = (m << 8) - m;                                                // 0xFF where x >= y
+    return (y & mask) | (x & ~mask);
+}
+// v's bytes [t, t + 4) of the window, for a dword-per-lane array (t in 0..11): the lanes that would read past lane 63 get their own value
+__device__ __forceinline__ unsigned asm_window_shift(unsigned v, int t) {
+    const unsigned a = (unsigned)__shfl_down((int)v, t >> 2), b2 = (unsigned)__shfl_down((int)v, (t >> 2) + 1);
+    return __builtin_amdgcn_alignbyte(b2, a, (unsigned)(t & 3));
+}
+__device__ __forceinline__ unsigned asm_sliding_min(unsigned dq, int n) {            // n in 2..16: per byte position b, min of bytes [b, b + n)
+    unsigned a = asm_bytemin7(dq, asm_window_shift(dq, 1));                            // width 2
+    int wdt = 2;
+    if (n >= 4) { a = asm_bytemin7(a, asm_window_shift(a, 2)); wdt = 4; }
+    if (n >= 8) { a = asm_bytemin7(a, asm_window_shift(a, 4)); wdt = 8; }
+    if (n >= 16) { a = asm_bytemin7(a, asm_window_shift(a, 8)); wdt = 16; }
+    if (n > wdt) a = asm_bytemin7(a, asm_window_shift(a, n - wdt));                    // two overlapping windows of the largest width cover n
+    return a;
+}
+// an 'N' among the edge's k + 1 bases?
+template <int KW> __device__ __forceinline__ bool asm_edge_has_n(const AsmWords<KW>& S, int k) {
+    const int n = k + 1;
+    unsigned long long zero = 0ull;
+#pragma unroll
+    for (int c = 0; c < KW; ++c)
+        if (8 * c < n) {
+            const unsigned long long m = asm_tailmask(n - 8 * c);
+            const unsigned long long x = (S.w[c] ^ 0x4E4E4E4E4E4E4E4Eull) | ~m;
+            zero |= (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+        }
+    return zero != 0ull;
+}
+
 // exclusive prefix sum of one value per thread over the workgroup (wave scans by lane shifts, the wave totals through `s_wsum`);
 // every thread gets the total too.  All threads must call it.
 __device__ __forceinline__ int asm_block_exscan(int v, int* s_wsum, int& total) {
@@ -695,17 +734,28 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             const int nE = w.nE;
                             AsmWords<KW> E[4];
                             int wq[4], slots[4];
-                            // I. the edges' bytes and quality filter
+                            // I. the edges' bytes and quality filter (assembler.pyx:1362-1373): the sliding minimum of the window's qualities for
+                            // all its edges at once when every quality byte is below 128, else edge by edge
+                            const bool q7 = k >= 1 && !__any((w.dQ & 0x80808080u) != 0u);
+                            unsigned qmin4 = 0u;
+                            if (q7) qmin4 = asm_sliding_min(w.dQ, k + 1);
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
                                 const int j = 64 * u + lane, i = c0 + j;
                                 wq[u] = -1; slots[u] = -1;
                                 E[u] = asm_mask_words(asm_gather_words<KW>(w.dS, j + w.sS), k + 1);
                                 if (64 * u < nE) {
-                                    const AsmWords<KW> Q = asm_mask_words(asm_gather_words<KW>(w.dQ, j + w.sQ), k + 1);
-                                    if (j < nE) {
-                                        wq[u] = asm_edge_q_words(E[u], Q, k, P.min_qual);
-                                        if (wq[u] == -2) wq[u] = asm_read_edge_q(rseq + ro, rqual + ro, i, k, P.min_qual);
+                                    if (q7) {
+                                        const int pq = j + w.sQ;                                   // the edge's first quality byte in the window
+                                        const unsigned dwq = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (pq >> 2), (int)qmin4);
+                                        const int mq = (int)((dwq >> (8 * (pq & 3))) & 0xFFu);
+                                        if (j < nE) wq[u] = (mq >= P.min_qual && !asm_edge_has_n(E[u], k)) ? mq : -1;
+                                    } else {
+                                        const AsmWords<KW> Q = asm_mask_words(asm_gather_words<KW>(w.dQ, j + w.sQ), k + 1);
+                                        if (j < nE) {
+                                            wq[u] = asm_edge_q_words(E[u], Q, k, P.min_qual);
+                                            if (wq[u] == -2) wq[u] = asm_read_edge_q(rseq + ro, rqual + ro, i, k, P.min_qual);
+                                        }
                                     }
                                 }
                             }
