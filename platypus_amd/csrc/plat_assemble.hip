@@ -57,6 +57,7 @@ struct AsmParams {
     int cap;                           // hash slots per region (power of two)
     int max_pos;                       // max k-mer occurrences per region (dense node capacity)
     int timing;                        // PLAT_ASM_TIMING: phase timers on
+    int debug;                         // PLAT_ASM_DEBUG (measurement only, results are garbage): 1 = no events in the fused reads pass, 2 = no table probes either
     int fused;                         // LDS path: k-mers and AddEdge events of the reads in ONE pass (round 4; PLAT_ASM_FUSED=0: rounds 2-3's passes)
 };
 
@@ -664,8 +665,10 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 // (the first event of a slot also notes where the slot leads: phase D then neither hashes nor compares)
                 auto global_slot = [&](int sn, int slot, int w, int e, int en) {
                     if (!(s_wc[sn] >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);                       // (bit 26: the node's global slot words are in use)
-                    const unsigned long long was = atomicAdd(&S.succ_cw[sn * ASM_MAX_SUCC + slot], (1ull << 32) | (unsigned long long)(unsigned)w);
-                    if ((was >> 32) == 0ull) S.succ_n[sn * ASM_MAX_SUCC + slot] = en;
+                    // (every event of a slot stores the same end node: a plain store -- asking the atomic for its old value to store it once
+                    //  would make the wave wait a global round trip whenever one of its 64 edges leaves the main path, i.e. most rounds)
+                    atomicAdd(&S.succ_cw[sn * ASM_MAX_SUCC + slot], (1ull << 32) | (unsigned long long)(unsigned)w);
+                    S.succ_n[sn * ASM_MAX_SUCC + slot] = en;
                     atomicMin(&S.succ_t[sn * ASM_MAX_SUCC + slot], (unsigned)e);
                 };
                 // 2a. first touches and colours of the reference's events
@@ -732,19 +735,21 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             if (nRefNodes0 + *(volatile int*)&s_nreadnodes > ASM_LDS_LIMIT) { stopped = true; break; }   // (<= 4 x 1024 new k-mers between two looks: the arrays' spare room)
                             const Win w = c0 == 0 ? w0 : load_win(m0, c0);
                             const int nE = w.nE;
-                            AsmWords<KW> E[4];
-                            int wq[4], slots[4];
+                            constexpr int NRB = 2;                               // rounds of 64 edges worked side by side (4 spilled registers in the loop)
                             // I. the edges' bytes and quality filter (assembler.pyx:1362-1373): the sliding minimum of the window's qualities for
                             // all its edges at once when every quality byte is below 128, else edge by edge
                             const bool q7 = k >= 1 && !__any((w.dQ & 0x80808080u) != 0u);
                             unsigned qmin4 = 0u;
                             if (q7) qmin4 = asm_sliding_min(w.dQ, k + 1);
+                            for (int ub = 0; ub < 4 && 64 * ub < nE; ub += NRB) {
+                            AsmWords<KW> E[NRB];
+                            int wq[NRB], slots[NRB];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int j = 64 * u + lane, i = c0 + j;
+                            for (int u = 0; u < NRB; ++u) {
+                                const int j = 64 * (ub + u) + lane, i = c0 + j;
                                 wq[u] = -1; slots[u] = -1;
                                 E[u] = asm_mask_words(asm_gather_words<KW>(w.dS, j + w.sS), k + 1);
-                                if (64 * u < nE) {
+                                if (64 * (ub + u) < nE) {
                                     if (q7) {
                                         const int pq = j + w.sQ;                                   // the edge's first quality byte in the window
                                         const unsigned dwq = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (pq >> 2), (int)qmin4);
@@ -760,33 +765,37 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                                 }
                             }
                             // II. the start k-mers of the valid edges, found or created: four probe sequences per lane side by side
-                            {
-                                unsigned sl[4]; bool todo[4];
-                                AsmWords<KW> Ks[4];
+                            if (!(P.debug & 2)) {
+                                unsigned sl[NRB]; bool todo[NRB];
+                                AsmWords<KW> Ks[NRB];
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) { Ks[u] = asm_kmer_start(E[u], k); todo[u] = wq[u] >= 0; sl[u] = asm_hash_words(Ks[u], k) & (unsigned)(ASM_LDS_SLOTS - 1); }
-                                while (todo[0] | todo[1] | todo[2] | todo[3]) {
-                                    int v[4];
+                                for (int u = 0; u < NRB; ++u) { Ks[u] = asm_kmer_start(E[u], k); todo[u] = wq[u] >= 0; sl[u] = asm_hash_words(Ks[u], k) & (unsigned)(ASM_LDS_SLOTS - 1); }
+                                for (;;) {
+                                    bool anytodo = false;
 #pragma unroll
-                                    for (int u = 0; u < 4; ++u) v[u] = todo[u] ? s_tab[sl[u]] : 0;
+                                    for (int u = 0; u < NRB; ++u) anytodo |= todo[u];
+                                    if (!anytodo) break;
+                                    int v[NRB];
 #pragma unroll
-                                    for (int u = 0; u < 4; ++u)
+                                    for (int u = 0; u < NRB; ++u) v[u] = todo[u] ? s_tab[sl[u]] : 0;
+#pragma unroll
+                                    for (int u = 0; u < NRB; ++u)
                                         if (todo[u] && v[u] == -1) {                               // an empty slot: a k-mer met for the first time
                                             const int id = nRefNodes0 + atomicAdd(&s_nreadnodes, 1);
                                             if (id >= ASM_LDS_NODES) { todo[u] = false; continue; }   // (slots[u] stays -1: the region is redone on the global path)
-                                            const int roff = ro + c0 + 64 * u + lane;
+                                            const int roff = ro + c0 + 64 * (ub + u) + lane;
                                             const int old = atomicCAS(&s_tab[sl[u]], -1, (int)(((unsigned)id << ASM_OFF_BITS) | (unsigned)roff));
                                             if (old == -1) { S.rep[id] = 0x40000000 + roff; slots[u] = (int)sl[u]; todo[u] = false; }
                                             else v[u] = old;
                                         }
-                                    bool eq[4];
+                                    bool eq[NRB];
 #pragma unroll
-                                    for (int u = 0; u < 4; ++u) {
+                                    for (int u = 0; u < NRB; ++u) {
                                         const int id = (int)((unsigned)v[u] >> ASM_OFF_BITS), o = v[u] & ((1 << ASM_OFF_BITS) - 1);
                                         eq[u] = todo[u] && asm_eq_words(Ks[u], k, id < nRefNodes0, o, s_ref, refc, ref, rseq);
                                     }
 #pragma unroll
-                                    for (int u = 0; u < 4; ++u)
+                                    for (int u = 0; u < NRB; ++u)
                                         if (todo[u]) {
                                             if (eq[u]) { slots[u] = (int)sl[u]; todo[u] = false; }
                                             else sl[u] = (sl[u] + 1u) & (unsigned)(ASM_LDS_SLOTS - 1);
@@ -794,24 +803,24 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                                 }
                             }
                             // III. an edge's end k-mer is the start k-mer of the next edge (the next lane's, or lane 0's of the next round)
-                            int nsl[4];
+                            int nsl[NRB];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
+                            for (int u = 0; u < NRB; ++u) {
                                 int nx = __shfl_down(slots[u], 1);
-                                const int first_next = u < 3 ? __shfl(slots[u + 1], 0) : -1;
+                                const int first_next = u + 1 < NRB ? __shfl(slots[u + 1 < NRB ? u + 1 : u], 0) : -1;
                                 if (lane == 63) nx = first_next;
                                 nsl[u] = nx;
                             }
                             // IV. the events
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                if (wq[u] < 0 || slots[u] < 0) continue;
-                                const int off = ro + c0 + 64 * u + lane;
+                            for (int u = 0; u < NRB; ++u) {
+                                if (wq[u] < 0 || slots[u] < 0 || (P.debug & 1)) continue;
+                                const int off = ro + c0 + 64 * (ub + u) + lane;
                                 int nslot = nsl[u];
                                 if (nslot < 0) nslot = asm_lds_insert_final(s_tab, asm_kmer_end(E[u], k), k, off + 1, s_ref, refc, ref, rseq, nRefNodes0, &s_nreadnodes, S.rep);
                                 if (nslot < 0) continue;                                               // node arrays full: the region is redone below
                                 const int w_ = wq[u];
-                                const int e = nRefE + base + c0 + 64 * u + lane, sn = node_of(slots[u]), en = node_of(nslot);
+                                const int e = nRefE + base + c0 + 64 * (ub + u) + lane, sn = node_of(slots[u]), en = node_of(nslot);
                                 atomicMin(&s_first[sn], 2u * (unsigned)e);
                                 atomicMin(&s_first[en], 2u * (unsigned)e + 1u);
                                 unsigned x = s_wc[sn];
@@ -843,7 +852,8 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                                     }
                                 } else global_slot(sn, slot, w_, e, en);
                             }
-                        }
+                                                    }
+}
                         m0 = m1; m1 = m2; w0 = w1;
                     }
                 }
@@ -1503,6 +1513,7 @@ PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* ba
     P.max_vars = max_vars_per_region; P.blob_per_region = blob_per_region; P.cap = cap; P.max_pos = (int)max_pos;
     P.timing = getenv("PLAT_ASM_TIMING") != nullptr;
     { const char* ef = getenv("PLAT_ASM_FUSED"); P.fused = !(ef && ef[0] == '0'); }
+    { const char* ed = getenv("PLAT_ASM_DEBUG"); P.debug = ed ? atoi(ed) : 0; }
     const size_t per_block = asm_scratch_bytes(cap, (int)max_pos, max_ref, max_reads);
     P.scratch_per_block = (long long)per_block;
     // the kernel is bound by the latency of dependent L2 accesses, not by bandwidth or issue: one region per CU at a time (its graph takes
