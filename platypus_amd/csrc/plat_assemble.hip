@@ -388,6 +388,24 @@ __device__ __forceinline__ unsigned asm_sliding_min(unsigned dq, int n) {       
     if (n > wdt) a = asm_bytemin7(a, asm_window_shift(a, n - wdt));                    // two overlapping windows of the largest width cover n
     return a;
 }
+// v's bytes [-t, -t + 4) of the window (t in 1..3): the mirror of asm_window_shift, for arrays that must move towards higher positions
+__device__ __forceinline__ unsigned asm_window_shift_back(unsigned v, int t) {
+    const unsigned prev = (unsigned)__shfl_up((int)v, 1);
+    return __builtin_amdgcn_alignbyte(v, prev, (unsigned)(4 - t));
+}
+// position of the n-th (0-based) set bit of m; n < popcount(m)
+__device__ __forceinline__ int asm_select64(unsigned long long m, int n) {
+    unsigned wd = (unsigned)m;
+    int pos = 0;
+    const int c0 = __popc(wd);
+    if (n >= c0) { n -= c0; wd = (unsigned)(m >> 32); pos = 32; }
+#pragma unroll
+    for (int sh = 16; sh >= 1; sh >>= 1) {
+        const int c = __popc(wd & ((1u << sh) - 1u));
+        if (n >= c) { n -= c; wd >>= sh; pos += sh; }
+    }
+    return pos;
+}
 // an 'N' among the edge's k + 1 bases?
 template <int KW> __device__ __forceinline__ bool asm_edge_has_n(const AsmWords<KW>& S, int k) {
     const int n = k + 1;
@@ -735,125 +753,169 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             if (nRefNodes0 + *(volatile int*)&s_nreadnodes > ASM_LDS_LIMIT) { stopped = true; break; }   // (<= 4 x 1024 new k-mers between two looks: the arrays' spare room)
                             const Win w = c0 == 0 ? w0 : load_win(m0, c0);
                             const int nE = w.nE;
-                            constexpr int NRB = 2;                               // rounds of 64 edges worked side by side (4 spilled registers in the loop)
-                            // I. the edges' bytes and quality filter (assembler.pyx:1362-1373): the sliding minimum of the window's qualities for
-                            // all its edges at once when every quality byte is below 128, else edge by edge
-                            const bool q7 = k >= 1 && !__any((w.dQ & 0x80808080u) != 0u);
-                            unsigned qmin4 = 0u;
-                            if (q7) qmin4 = asm_sliding_min(w.dQ, k + 1);
-                            for (int ub = 0; ub < 4 && 64 * ub < nE; ub += NRB) {
-                            AsmWords<KW> E[NRB];
-                            int wq[NRB], slots[NRB];
+                            constexpr int NRB = 2;                               // edges per lane worked side by side
+                            // `work`: NRB edges per lane (jj[u] = edge index in the window, -1 none; ww[u] = its weight): k-mers found or created,
+                            // then the events.  An edge's end k-mer is the start k-mer of the edge that follows it in the read -- the next lane's
+                            // (or lane 0's of the next u) when that lane holds edge jj + 1.
+                            auto work = [&](const int (&jj)[NRB], const int (&ww)[NRB]) {
+                                AsmWords<KW> E[NRB];
+                                int slots[NRB];
 #pragma unroll
-                            for (int u = 0; u < NRB; ++u) {
-                                const int j = 64 * (ub + u) + lane, i = c0 + j;
-                                wq[u] = -1; slots[u] = -1;
-                                E[u] = asm_mask_words(asm_gather_words<KW>(w.dS, j + w.sS), k + 1);
-                                if (64 * (ub + u) < nE) {
-                                    if (q7) {
-                                        const int pq = j + w.sQ;                                   // the edge's first quality byte in the window
-                                        const unsigned dwq = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (pq >> 2), (int)qmin4);
-                                        const int mq = (int)((dwq >> (8 * (pq & 3))) & 0xFFu);
-                                        if (j < nE) wq[u] = (mq >= P.min_qual && !asm_edge_has_n(E[u], k)) ? mq : -1;
-                                    } else {
-                                        const AsmWords<KW> Q = asm_mask_words(asm_gather_words<KW>(w.dQ, j + w.sQ), k + 1);
-                                        if (j < nE) {
-                                            wq[u] = asm_edge_q_words(E[u], Q, k, P.min_qual);
-                                            if (wq[u] == -2) wq[u] = asm_read_edge_q(rseq + ro, rqual + ro, i, k, P.min_qual);
+                                for (int u = 0; u < NRB; ++u) {
+                                    slots[u] = -1;
+                                    E[u] = asm_mask_words(asm_gather_words<KW>(w.dS, (jj[u] >= 0 ? jj[u] : 0) + w.sS), k + 1);
+                                }
+                                // the start k-mers, found or created: NRB probe sequences per lane side by side
+                                if (!(P.debug & 2)) {
+                                    unsigned sl[NRB]; bool todo[NRB];
+                                    AsmWords<KW> Ks[NRB];
+#pragma unroll
+                                    for (int u = 0; u < NRB; ++u) { Ks[u] = asm_kmer_start(E[u], k); todo[u] = jj[u] >= 0; sl[u] = asm_hash_words(Ks[u], k) & (unsigned)(ASM_LDS_SLOTS - 1); }
+                                    for (;;) {
+                                        bool anytodo = false;
+#pragma unroll
+                                        for (int u = 0; u < NRB; ++u) anytodo |= todo[u];
+                                        if (!anytodo) break;
+                                        int v[NRB];
+#pragma unroll
+                                        for (int u = 0; u < NRB; ++u) v[u] = todo[u] ? s_tab[sl[u]] : 0;
+#pragma unroll
+                                        for (int u = 0; u < NRB; ++u)
+                                            if (todo[u] && v[u] == -1) {                           // an empty slot: a k-mer met for the first time
+                                                const int id = nRefNodes0 + atomicAdd(&s_nreadnodes, 1);
+                                                if (id >= ASM_LDS_NODES) { todo[u] = false; continue; }   // (slots[u] stays -1: the region is redone on the global path)
+                                                const int roff = ro + c0 + jj[u];
+                                                const int old = atomicCAS(&s_tab[sl[u]], -1, (int)(((unsigned)id << ASM_OFF_BITS) | (unsigned)roff));
+                                                if (old == -1) { S.rep[id] = 0x40000000 + roff; slots[u] = (int)sl[u]; todo[u] = false; }
+                                                else v[u] = old;
+                                            }
+                                        bool eq[NRB];
+#pragma unroll
+                                        for (int u = 0; u < NRB; ++u) {
+                                            const int id = (int)((unsigned)v[u] >> ASM_OFF_BITS), o = v[u] & ((1 << ASM_OFF_BITS) - 1);
+                                            eq[u] = todo[u] && asm_eq_words(Ks[u], k, id < nRefNodes0, o, s_ref, refc, ref, rseq);
                                         }
+#pragma unroll
+                                        for (int u = 0; u < NRB; ++u)
+                                            if (todo[u]) {
+                                                if (eq[u]) { slots[u] = (int)sl[u]; todo[u] = false; }
+                                                else sl[u] = (sl[u] + 1u) & (unsigned)(ASM_LDS_SLOTS - 1);
+                                            }
                                     }
                                 }
-                            }
-                            // II. the start k-mers of the valid edges, found or created: four probe sequences per lane side by side
-                            if (!(P.debug & 2)) {
-                                unsigned sl[NRB]; bool todo[NRB];
-                                AsmWords<KW> Ks[NRB];
+                                int nsl[NRB];
 #pragma unroll
-                                for (int u = 0; u < NRB; ++u) { Ks[u] = asm_kmer_start(E[u], k); todo[u] = wq[u] >= 0; sl[u] = asm_hash_words(Ks[u], k) & (unsigned)(ASM_LDS_SLOTS - 1); }
-                                for (;;) {
-                                    bool anytodo = false;
+                                for (int u = 0; u < NRB; ++u) {
+                                    int nx = __shfl_down(slots[u], 1), jn = __shfl_down(jj[u], 1);
+                                    if (lane == 63) {
+                                        nx = u + 1 < NRB ? __shfl(slots[u + 1 < NRB ? u + 1 : u], 0) : -1;
+                                        jn = u + 1 < NRB ? __shfl(jj[u + 1 < NRB ? u + 1 : u], 0) : -1;
+                                    }
+                                    nsl[u] = (jn == jj[u] + 1) ? nx : -1;
+                                }
 #pragma unroll
-                                    for (int u = 0; u < NRB; ++u) anytodo |= todo[u];
-                                    if (!anytodo) break;
-                                    int v[NRB];
-#pragma unroll
-                                    for (int u = 0; u < NRB; ++u) v[u] = todo[u] ? s_tab[sl[u]] : 0;
-#pragma unroll
-                                    for (int u = 0; u < NRB; ++u)
-                                        if (todo[u] && v[u] == -1) {                               // an empty slot: a k-mer met for the first time
-                                            const int id = nRefNodes0 + atomicAdd(&s_nreadnodes, 1);
-                                            if (id >= ASM_LDS_NODES) { todo[u] = false; continue; }   // (slots[u] stays -1: the region is redone on the global path)
-                                            const int roff = ro + c0 + 64 * (ub + u) + lane;
-                                            const int old = atomicCAS(&s_tab[sl[u]], -1, (int)(((unsigned)id << ASM_OFF_BITS) | (unsigned)roff));
-                                            if (old == -1) { S.rep[id] = 0x40000000 + roff; slots[u] = (int)sl[u]; todo[u] = false; }
-                                            else v[u] = old;
+                                for (int u = 0; u < NRB; ++u) {
+                                    if (jj[u] < 0 || slots[u] < 0 || (P.debug & 1)) continue;
+                                    const int off = ro + c0 + jj[u];
+                                    int nslot = nsl[u];
+                                    if (nslot < 0) nslot = asm_lds_insert_final(s_tab, asm_kmer_end(E[u], k), k, off + 1, s_ref, refc, ref, rseq, nRefNodes0, &s_nreadnodes, S.rep);
+                                    if (nslot < 0) continue;                                           // node arrays full: the region is redone below
+                                    const int w_ = ww[u];
+                                    const int e = nRefE + base + c0 + jj[u], sn = node_of(slots[u]), en = node_of(nslot);
+                                    atomicMin(&s_first[sn], 2u * (unsigned)e);
+                                    atomicMin(&s_first[en], 2u * (unsigned)e + 1u);
+                                    unsigned x = s_wc[sn];
+                                    if ((x >> 30 & 2u) == 0u) atomicOr(&s_wc[sn], 2u << 30);
+                                    if ((s_wc[en] >> 30 & 2u) == 0u) atomicOr(&s_wc[en], 2u << 30);
+                                    const unsigned c = asm_byte_k(E[u], k) & 0xFFu;
+                                    const int slot = succ_slot(sn, c);
+                                    if (slot < 0) { bad = true; continue; }                            // > 4 distinct other bytes
+                                    if (slot >= 4 && !(x >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);
+                                    bool local = false;
+                                    if (slot < 7) {
+                                        for (;;) {
+                                            const unsigned d = (x >> 23) & 7u;
+                                            if (d == 0u) {
+                                                const unsigned old = atomicCAS(&s_wc[sn], x, x | (unsigned)(slot + 1) << 23);
+                                                if (old == x) S.succ_n[sn * ASM_MAX_SUCC + slot] = en;    // this event claimed the slot
+                                                x = old == x ? (x | (unsigned)(slot + 1) << 23) : old;
+                                                continue;
+                                            }
+                                            local = d == (unsigned)slot + 1u && (x & 0x7FFFFFu) < 0x780000u;
+                                            break;
                                         }
-                                    bool eq[NRB];
+                                    }
+                                    if (local) {
+                                        atomicAdd(&s_wc[sn], (unsigned)w_);
+                                        if (!(x >> 27 & 1u)) {                                         // a read claimed this slot: its first ticket in the node's own word (bit 28: in use)
+                                            if (!(x >> 28 & 1u)) atomicOr(&s_wc[sn], 1u << 28);
+                                            atomicMin(&own_t[sn], (unsigned)e);
+                                        }
+                                    } else global_slot(sn, slot, w_, e, en);
+                                }
+                            };
+                            // The quality / N filter (assembler.pyx:1362-1373) for ALL edges of the window at once: qualities with the N positions
+                            // zeroed, sliding minimum over k + 1 bytes (needs every quality byte < 128 and min_qual >= 1: else edge by edge below).
+                            // With 5 % of the bases below Q20 more than half of the edges are filtered: the edges that pass are then COMPACTED --
+                            // lane l of batch cb takes the (64 cb + l)-th passing edge (n-th set bit of the rounds' ballots) -- so that the probes
+                            // and events run with full waves (measured before: a third of the lanes active per vector instruction).
+                            const bool q7 = k >= 1 && P.min_qual >= 1 && !__any((w.dQ & 0x80808080u) != 0u);
+                            if (q7) {
+                                const int delta = w.sS - w.sQ;                                      // bases in the qualities' byte positions
+                                const unsigned bq = delta == 0 ? w.dS : (delta > 0 ? asm_window_shift(w.dS, delta) : asm_window_shift_back(w.dS, -delta));
+                                const unsigned xn = bq ^ 0x4E4E4E4Eu;                                 // a zero byte = an 'N'
+                                const unsigned nz = ~(((xn & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xn | 0x7F7F7F7Fu);   // 0x80 in exactly the zero bytes
+                                const unsigned nmask = ((nz >> 7) << 8) - (nz >> 7);                  // 0xFF per N byte
+                                const unsigned qmin4 = asm_sliding_min(w.dQ & ~nmask, k + 1);
+                                unsigned long long vm[4];
+                                int mqv[4], cum[5];
+                                cum[0] = 0;
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const int j = 64 * u + lane, pq = j + w.sQ;
+                                    const unsigned dwq = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (pq >> 2), (int)qmin4);
+                                    mqv[u] = (int)((dwq >> (8 * (pq & 3))) & 0xFFu);
+                                    vm[u] = __ballot(j < nE && mqv[u] >= P.min_qual);
+                                    cum[u + 1] = cum[u] + __popcll(vm[u]);
+                                }
+                                const int V = cum[4];
+                                for (int cb = 0; cb < V; cb += 64 * NRB) {
+                                    int jj[NRB], ww[NRB];
 #pragma unroll
                                     for (int u = 0; u < NRB; ++u) {
-                                        const int id = (int)((unsigned)v[u] >> ASM_OFF_BITS), o = v[u] & ((1 << ASM_OFF_BITS) - 1);
-                                        eq[u] = todo[u] && asm_eq_words(Ks[u], k, id < nRefNodes0, o, s_ref, refc, ref, rseq);
-                                    }
+                                        const int c = cb + 64 * u + lane;
+                                        jj[u] = -1; ww[u] = 0;
+                                        // round of the c-th passing edge, its lane there, and its weight from that lane
+                                        const int ru = c < cum[1] ? 0 : (c < cum[2] ? 1 : (c < cum[3] ? 2 : 3));
+                                        const unsigned long long mk = ru == 0 ? vm[0] : (ru == 1 ? vm[1] : (ru == 2 ? vm[2] : vm[3]));
+                                        const int before = ru == 0 ? cum[0] : (ru == 1 ? cum[1] : (ru == 2 ? cum[2] : cum[3]));
+                                        const int src = c < V ? asm_select64(mk, c - before) : 0;
+                                        int got[4];
 #pragma unroll
-                                    for (int u = 0; u < NRB; ++u)
-                                        if (todo[u]) {
-                                            if (eq[u]) { slots[u] = (int)sl[u]; todo[u] = false; }
-                                            else sl[u] = (sl[u] + 1u) & (unsigned)(ASM_LDS_SLOTS - 1);
+                                        for (int q = 0; q < 4; ++q) got[q] = __builtin_amdgcn_ds_bpermute(4 * src, mqv[q]);
+                                        if (c < V) { jj[u] = 64 * ru + src; ww[u] = ru == 0 ? got[0] : (ru == 1 ? got[1] : (ru == 2 ? got[2] : got[3])); }
+                                    }
+                                    work(jj, ww);
+                                }
+                            } else {
+                                for (int ub = 0; ub < 4 && 64 * ub < nE; ub += NRB) {
+                                    int jj[NRB], ww[NRB];
+#pragma unroll
+                                    for (int u = 0; u < NRB; ++u) {
+                                        const int j = 64 * (ub + u) + lane, i = c0 + j;
+                                        jj[u] = -1; ww[u] = 0;
+                                        const AsmWords<KW> Eq = asm_mask_words(asm_gather_words<KW>(w.dS, j + w.sS), k + 1);
+                                        const AsmWords<KW> Q = asm_mask_words(asm_gather_words<KW>(w.dQ, j + w.sQ), k + 1);
+                                        if (j < nE) {
+                                            int wq = asm_edge_q_words(Eq, Q, k, P.min_qual);
+                                            if (wq == -2) wq = asm_read_edge_q(rseq + ro, rqual + ro, i, k, P.min_qual);
+                                            if (wq >= 0) { jj[u] = j; ww[u] = wq; }
                                         }
+                                    }
+                                    work(jj, ww);
                                 }
                             }
-                            // III. an edge's end k-mer is the start k-mer of the next edge (the next lane's, or lane 0's of the next round)
-                            int nsl[NRB];
-#pragma unroll
-                            for (int u = 0; u < NRB; ++u) {
-                                int nx = __shfl_down(slots[u], 1);
-                                const int first_next = u + 1 < NRB ? __shfl(slots[u + 1 < NRB ? u + 1 : u], 0) : -1;
-                                if (lane == 63) nx = first_next;
-                                nsl[u] = nx;
-                            }
-                            // IV. the events
-#pragma unroll
-                            for (int u = 0; u < NRB; ++u) {
-                                if (wq[u] < 0 || slots[u] < 0 || (P.debug & 1)) continue;
-                                const int off = ro + c0 + 64 * (ub + u) + lane;
-                                int nslot = nsl[u];
-                                if (nslot < 0) nslot = asm_lds_insert_final(s_tab, asm_kmer_end(E[u], k), k, off + 1, s_ref, refc, ref, rseq, nRefNodes0, &s_nreadnodes, S.rep);
-                                if (nslot < 0) continue;                                               // node arrays full: the region is redone below
-                                const int w_ = wq[u];
-                                const int e = nRefE + base + c0 + 64 * (ub + u) + lane, sn = node_of(slots[u]), en = node_of(nslot);
-                                atomicMin(&s_first[sn], 2u * (unsigned)e);
-                                atomicMin(&s_first[en], 2u * (unsigned)e + 1u);
-                                unsigned x = s_wc[sn];
-                                if ((x >> 30 & 2u) == 0u) atomicOr(&s_wc[sn], 2u << 30);
-                                if ((s_wc[en] >> 30 & 2u) == 0u) atomicOr(&s_wc[en], 2u << 30);
-                                const unsigned c = asm_byte_k(E[u], k) & 0xFFu;
-                                const int slot = succ_slot(sn, c);
-                                if (slot < 0) { bad = true; continue; }                                // > 4 distinct other bytes
-                                if (slot >= 4 && !(x >> 26 & 1u)) atomicOr(&s_wc[sn], 1u << 26);
-                                bool local = false;
-                                if (slot < 7) {
-                                    for (;;) {
-                                        const unsigned d = (x >> 23) & 7u;
-                                        if (d == 0u) {
-                                            const unsigned old = atomicCAS(&s_wc[sn], x, x | (unsigned)(slot + 1) << 23);
-                                            if (old == x) S.succ_n[sn * ASM_MAX_SUCC + slot] = en;    // this event claimed the slot
-                                            x = old == x ? (x | (unsigned)(slot + 1) << 23) : old;
-                                            continue;
-                                        }
-                                        local = d == (unsigned)slot + 1u && (x & 0x7FFFFFu) < 0x780000u;
-                                        break;
-                                    }
-                                }
-                                if (local) {
-                                    atomicAdd(&s_wc[sn], (unsigned)w_);
-                                    if (!(x >> 27 & 1u)) {                                             // a read claimed this slot: its first ticket in the node's own word (bit 28: in use)
-                                        if (!(x >> 28 & 1u)) atomicOr(&s_wc[sn], 1u << 28);
-                                        atomicMin(&own_t[sn], (unsigned)e);
-                                    }
-                                } else global_slot(sn, slot, w_, e, en);
-                            }
-                                                    }
-}
+                        }
                         m0 = m1; m1 = m2; w0 = w1;
                     }
                 }
