@@ -46,14 +46,20 @@ namespace plathost {
 typedef std::chrono::steady_clock Clock;
 static inline double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
 #ifdef PLAT_HOSTPROF                                                  // (local measurement builds only: cycle counts of named scopes)
-static std::map<std::string, unsigned long long> g_prof;
-static std::mutex g_profM;
-struct ProfScope { const char* n; unsigned long long t0; ProfScope(const char* n_) : n(n_), t0(__rdtsc()) {}
-                   ~ProfScope() { const unsigned long long d = __rdtsc() - t0; std::lock_guard<std::mutex> g(g_profM); g_prof[n] += d; } };
+static const char* g_profName[256];
+static std::atomic<unsigned long long> g_profCyc[256], g_profCalls[256];
+static std::atomic<int> g_profN{0};
+static int profId(const char* n) { const int k = g_profN.fetch_add(1); g_profName[k] = n; return k; }
+struct ProfScope { int k; unsigned long long t0; ProfScope(int k_) : k(k_), t0(__rdtsc()) {}
+                   ~ProfScope() { g_profCyc[k].fetch_add(__rdtsc() - t0, std::memory_order_relaxed); g_profCalls[k].fetch_add(1, std::memory_order_relaxed); } };
 #define PROF_CAT2(a, b) a##b
 #define PROF_CAT(a, b) PROF_CAT2(a, b)
-#define PROF(name) ProfScope PROF_CAT(prof_, __LINE__)(name)
-static void profDump(double n) { for (auto& kv : g_prof) fprintf(stderr, "  [prof] %-28s %9.1f kcycles/region\n", kv.first.c_str(), 1e-3 * (double)kv.second / n); g_prof.clear(); }
+#define PROF(name) static const int PROF_CAT(profid_, __LINE__) = profId(name); ProfScope PROF_CAT(prof_, __LINE__)(PROF_CAT(profid_, __LINE__))
+static void profDump(double n) {
+    std::map<std::string, std::pair<unsigned long long, unsigned long long>> m;
+    for (int k = 0; k < g_profN.load(); ++k) { m[g_profName[k]].first += g_profCyc[k].exchange(0); m[g_profName[k]].second += g_profCalls[k].exchange(0); }
+    for (auto& kv : m) fprintf(stderr, "  [prof] %-28s %9.1f kcycles/region %8.1f calls/region\n", kv.first.c_str(), 1e-3 * (double)kv.second.first / n, (double)kv.second.second / n);
+}
 #else
 #define PROF(name)
 static void profDump(double) {}
@@ -1107,12 +1113,14 @@ struct Chunk {
         w.ptrs.resize(r.samples.size());
         w.nReads = 0;
         PROF("s2.pw.rest");
+        { PROF("s2.pw.ptrs");
         for (size_t i = 0; i < r.samples.size(); ++i) {                    // bamReadBuffer.setWindowPointers (cwindow.pyx:655-689)
             Ptrs& p = w.ptrs[i];
             r.samples[i].reads.overlapRange(w.startPos, w.endPos, p.gs, p.ge);
             r.samples[i].bad.overlapRange(w.startPos, w.endPos, p.bs, p.be);
             r.samples[i].broken.matePosRange(w.startPos, w.endPos, p.ks, p.ke);
             w.nReads += p.ge - p.gs;
+        }
         }
         r.cur = w.ptrs;                                                     // (the buffers' window pointers now stand on this window)
         if (w.nReads == 0 || (double)w.nReads > o.maxReads) return;
@@ -1133,7 +1141,8 @@ struct Chunk {
                 for (;;) {
                     VarList vs;
                     for (int i : idx) vs.push_back(w.vars[(size_t)i]);
-                    if (isHaplotypeValid(vs)) haps.push_back(makeHap(r, w, vs));
+                    bool valid; { PROF("s2.pw.valid"); valid = isHaplotypeValid(vs); }
+                    if (valid) { PROF("s2.pw.makeHap"); haps.push_back(makeHap(r, w, vs)); }
                     int i = n - 1;
                     while (i >= 0 && idx[(size_t)i] == i + nVars - n) --i;
                     if (i < 0) break;
@@ -1333,7 +1342,7 @@ struct Chunk {
                 pwin.push_back(w->bw);
                 for (const Hap& h : w->haps) pmask.push_back(contains(h.variants, v) ? 1 : 0);
                 poff.push_back((int64_t)pmask.size());
-                pprior.push_back(calculatePrior(*v, r.fa));
+                { PROF("s5.prior"); pprior.push_back(calculatePrior(*v, r.fa)); }
             }
             if (o.outputRefCalls)                                           // pop.calculatePosterior(v, 1) of outputRefCall: the window's candidates under a flat prior
                 for (Variant* v : w->vars) {
@@ -1366,6 +1375,7 @@ struct Chunk {
         size_t at = 0;
         std::vector<WindowWork*> live;
         for (WindowWork* w : wins) {
+            PROF("s6.build");
             RegionWork& r = *regions[(size_t)regionSlot(w->region)];
             w->called.clear(); w->calledPost.clear(); w->byPos.clear(); w->info.clear();
             w->text.clear(); w->nRecords = 0; w->nRefRecords = 0;
@@ -1404,6 +1414,7 @@ struct Chunk {
                     if (!d) {
                         VarInfo n;
                         n.var = v;
+                        PROF("s6.hp_sc");
                         n.HP = homopolymerLengthForOneVariant(*v, r.fa);
                         n.SC = getSequenceContext(*v, r.fa);
                         char buf[64];

@@ -102,15 +102,23 @@ inline void annotate(const std::string& sequence, std::vector<int>& sizes, std::
     const int L = (int)sequence.size();
     sizes.assign(L, 1); disps.assign(L, 1);
     if (L == 0) return;
-    const int ext = L + 80 + MAX_UNIT_LENGTH;
+    // Only start positions p <= upto + 3 are walked, and a first mismatch is looked for no further than the group's start + 64: the
+    // rows of "first mismatch at or after i" end at `ext` = a little past that instead of past the sequence's end (anything at or
+    // beyond `ext` is "further than 64" for every group that is walked, which is all the loop below asks).
+    const int ext = std::min(L + 80 + MAX_UNIT_LENGTH, (int)std::min<long long>(L, (long long)upto + 4) + 68);
     // (scratch kept per thread: this runs once per indel candidate of every region)
     static thread_local std::vector<int> code, nxAll;
     code.assign((size_t)(ext + MAX_UNIT_LENGTH), 0);
-    for (int i = 0; i < L; ++i) {
+    for (int i = 0; i < L && i < ext + MAX_UNIT_LENGTH; ++i) {
         const int b = sequence[i] & 0xDF;
-        const long long idx = i;
-        const int noise = (int)((((idx % 257) * (1 + idx % 257)) / 2 + (idx % 5)) % 4);
-        code[i] = b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : noise;
+        if (b == 'A') code[i] = 0;
+        else if (b == 'C') code[i] = 1;
+        else if (b == 'G') code[i] = 2;
+        else if (b == 'T') code[i] = 3;
+        else {
+            const long long idx = i;
+            code[i] = (int)((((idx % 257) * (1 + idx % 257)) / 2 + (idx % 5)) % 4);
+        }
     }
     const size_t stride = (size_t)ext + 1;
     nxAll.resize(stride * MAX_UNIT_LENGTH);
