@@ -980,18 +980,26 @@ struct Chunk {
         }
         if (replay && o.getVariantsFromBAMs && !getenv("PLAT_CALLER_FIRST_OCCURRENCE_ORDER")) {      // (the switch: tests only, to show the replay matters)
             if (getenv("PLAT_CALLER_TRACE")) fprintf(stderr, "[plat_caller] region %s: candidates that compare equal are kept, dictionaries replayed\n", r.in->chrom ? r.in->chrom : "?");
-            if (!hostTally && !recordsOnHost) {                             // the scan's records are still on the device
-                if (recArenaBytes) ck(plat_memcpy_d2h(z.ctx, z.a_cout.h, z.a_cout.d, recArenaBytes, z.stream), "plat_memcpy_d2h");
+            PROF("s2.rv.replay");
+            if (!hostTally && !recordsOnHost) {                             // the scan's records are still on the device: this region's reads' rows
+                PROF("s2.rv.replay.d2h");
+                for (const SampleView& sv : r.samples) {
+                    const size_t b0 = (size_t)sv.reads.base, n = (size_t)sv.reads.n();
+                    if (!n) continue;
+                    ck(plat_memcpy_d2h(z.ctx, z.c_cnt.h + b0, z.c_cnt.d + b0, n * sizeof(int32_t), z.stream), "plat_memcpy_d2h");
+                    const size_t row = (size_t)maxPerRead * 5;
+                    ck(plat_memcpy_d2h(z.ctx, z.c_rec.h + b0 * row, z.c_rec.d + b0 * row, n * row * sizeof(int32_t), z.stream), "plat_memcpy_d2h");
+                }
                 z.sync("candidate records");
-                recordsOnHost = true;
             }
             const uint64_t nameHash = py2_string_hash(r.in->chrom ? std::string(r.in->chrom) : std::string());
             VarList all;
             std::vector<uint64_t> allHash;
             std::unordered_map<std::string, size_t> allIndex;
             for (size_t i = 0; i < r.samples.size(); ++i) {
-                tallySample(r, i, keys, addedStore, nullptr);
+                { PROF("s2.rv.replay.tally"); tallySample(r, i, keys, addedStore, nullptr); }
                 std::vector<uint64_t> hs(keys.size());
+                PROF("s2.rv.replay.order");
                 for (size_t k = 0; k < keys.size(); ++k) hs[k] = py2_variant_hash(nameHash, keys[k].pos, keys[k].rem, (size_t)keys[k].nrem, keys[k].add, (size_t)keys[k].nadd);
                 for (int k : py2_dict_slot_order(hs)) {                     // varCandGen.variantHeap.iteritems()
                     const CandKey& c = keys[(size_t)k];
@@ -1312,7 +1320,8 @@ struct Chunk {
             RegionWork& r = *regions[(size_t)regionSlot(w->region)];
             w->bw = b.nWindows();
             b.beginWindow(w->hapStart, w->hapEnd, w->endBuf);
-            for (const Hap& h : w->haps) b.addHap(h.seq);
+            { PROF("s4.addHap"); for (const Hap& h : w->haps) b.addHap(h.seq); }
+            PROF("s4.addReads");
             for (size_t i = 0; i < r.samples.size(); ++i) {                // good -> bad -> brokenMates (chaplotype.pyx:341-373)
                 const Ptrs& p = w->ptrs[i];
                 b.addReads(r.samples[i].reads, p.gs, p.ge, 0);
@@ -2340,6 +2349,12 @@ CALLER_EXPORT unsigned long long plat_caller_debug_tuple_hash(const unsigned lon
 CALLER_EXPORT unsigned long long plat_caller_debug_variant_hash(const char* ref_name, long long ref_pos, const char* removed, const char* added) {
     return (unsigned long long)py2_variant_hash(py2_string_hash(ref_name ? ref_name : ""), ref_pos, removed ? removed : "", removed ? strlen(removed) : 0,
                                                 added ? added : "", added ? strlen(added) : 0);
+}
+CALLER_EXPORT double plat_caller_debug_prior(const char* ref, long long ref_len, long long pos, const char* removed, const char* added) {
+    Fasta fa;
+    fa.seq = (const uint8_t*)ref; fa.len = ref_len;
+    Variant v((int)pos, removed ? removed : "", added ? added : "", 1, PLATYPUS_VAR);
+    return calculatePrior(v, fa);
 }
 CALLER_EXPORT void plat_caller_debug_dict_slot_order(const unsigned long long* hashes, int n, int* out) {
     std::vector<uint64_t> h(hashes, hashes + n);

@@ -98,10 +98,81 @@ inline int rate(int size, int displacement) {                            // tand
 // looking only as far as g + 64 (g + 32 when the shifted second word would start past the end).
 // `upto`: the caller reads positions <= upto only -- a start position p writes [p, p + size) and looks at position p, so nothing that
 // starts behind `upto` can reach what lies before it, and the groups behind it are not walked.
+inline int baseCode(const std::string& sequence, int i) {
+    static const struct Lut { int8_t v[256]; Lut() { memset(v, -1, sizeof v); v['A'] = 0; v['C'] = 1; v['G'] = 2; v['T'] = 3; } } lut;
+    const int quick = lut.v[(uint8_t)sequence[(size_t)i] & 0xDF];
+    if (quick >= 0) return quick;
+    const long long idx = i;
+    return (int)((((idx % 257) * (1 + idx % 257)) / 2 + (idx % 5)) % 4);
+}
+// The same for a stretch of at most 256 positions (what indelPrior asks: 200 bases, read up to the indel), with the sequence as two bit
+// planes: "first mismatch at or after p against the sequence shifted by d" is a count of trailing zeros, and only the start positions
+// with a run of min(5, d) matches -- the only ones that can pass the size test -- are visited, in the order of the loops below.
+inline void annotateBits(const std::string& sequence, int L, int ext, std::vector<int>& sizes, std::vector<int>& disps, int upto) {
+    uint64_t lo[6] = {0, 0, 0, 0, 0, 0}, hi[6] = {0, 0, 0, 0, 0, 0};
+    const int nb = std::min(L, ext + MAX_UNIT_LENGTH);
+    for (int i = 0; i < nb; ++i) {
+        const uint64_t c = (uint64_t)baseCode(sequence, i);
+        lo[i >> 6] |= (c & 1u) << (i & 63);
+        hi[i >> 6] |= (c >> 1) << (i & 63);
+    }
+    uint64_t mm[MAX_UNIT_LENGTH][4], cand[MAX_UNIT_LENGTH][4], any[4] = {0, 0, 0, 0};
+    for (int d = 1; d < MAX_UNIT_LENGTH; ++d) {
+        uint64_t z[5];
+        for (int w = 0; w < 4; ++w) {
+            const uint64_t slo = (lo[w] >> d) | (lo[w + 1] << (64 - d)), shi = (hi[w] >> d) | (hi[w + 1] << (64 - d));
+            mm[d][w] = (lo[w] ^ slo) | (hi[w] ^ shi);
+        }
+        for (int w = ext >> 6; w < 4; ++w) mm[d][w] |= w == (ext >> 6) ? ~0ull << (ext & 63) : ~0ull;     // (the rows' end: "no mismatch before ext")
+        for (int w = 0; w < 4; ++w) z[w] = ~mm[d][w];
+        z[4] = 0;
+        const int t = std::min(MIN_PARTIAL_MATCH, d);
+        for (int w = 0; w < 4; ++w) {
+            uint64_t r = z[w];
+            for (int j = 1; j < t; ++j) r &= (z[w] >> j) | (z[w + 1] << (64 - j));
+            cand[d][w] = r;
+            any[w] |= r;
+        }
+    }
+    for (int g = 0; g < L && g <= upto; g += 4) {
+        if (((any[g >> 6] >> (g & 63)) & 0xFu) == 0) continue;
+        for (int d = 1; d < MAX_UNIT_LENGTH; ++d) {
+            if (g + d >= L) break;
+            const unsigned nib = (unsigned)((cand[d][g >> 6] >> (g & 63)) & 0xFu);
+            if (!nib) continue;
+            const bool second = g + d + 32 < L;
+            for (int k = 0; k < 4; ++k) {
+                if (!(nib >> k & 1u)) continue;
+                const int p = g + k;
+                int w = p >> 6;
+                uint64_t bits = mm[d][w] >> (p & 63);
+                int mabs;
+                if (bits) mabs = p + __builtin_ctzll(bits);
+                else { ++w; while (w < 4 && !mm[d][w]) ++w; mabs = w < 4 ? 64 * w + __builtin_ctzll(mm[d][w]) : ext; }
+                int m = mabs - g;
+                if (m > 31) m = second ? std::min(m, 64) : 32;
+                int size = m - k;
+                const int pos = p;
+                if (pos + d + size > L) size = L - d - pos;
+                size += d;
+                if (size < d + std::min(MIN_PARTIAL_MATCH, d)) continue;
+                if (pos >= L) continue;
+                if (rate(sizes[pos], disps[pos]) < rate(size, d)) {
+                    sizes[pos] = size; disps[pos] = d;
+                    for (int i = pos + 1; i < std::min(L, pos + size); ++i) { sizes[i] = size; disps[i] = d; }
+                }
+            }
+        }
+    }
+}
 inline void annotate(const std::string& sequence, std::vector<int>& sizes, std::vector<int>& disps, int upto = 0x7FFFFFFF) {
     const int L = (int)sequence.size();
     sizes.assign(L, 1); disps.assign(L, 1);
     if (L == 0) return;
+    {
+        const int extB = std::min(L + 80 + MAX_UNIT_LENGTH, (int)std::min<long long>(L, (long long)upto + 4) + 68);
+        if (extB + MAX_UNIT_LENGTH <= 256) { annotateBits(sequence, L, extB, sizes, disps, upto); return; }
+    }
     // Only start positions p <= upto + 3 are walked, and a first mismatch is looked for no further than the group's start + 64: the
     // rows of "first mismatch at or after i" end at `ext` = a little past that instead of past the sequence's end (anything at or
     // beyond `ext` is "further than 64" for every group that is walked, which is all the loop below asks).
@@ -189,7 +260,7 @@ inline double indelPrior(const Variant& v, const Fasta& fa, int indel_length_and
     const int leftPos = std::max(0, v.refPos - context), rightPos = v.refPos + context, rel = v.refPos - leftPos;
     std::string sequence;
     try { sequence = fa.getSequence(leftPos + 1, rightPos + 1); } catch (const WindowError&) { sequence.clear(); }
-    std::vector<int> sizes, disps;
+    static thread_local std::vector<int> sizes, disps;                                         // (kept per thread: once per indel candidate)
     tandem::annotate(sequence, sizes, disps, rel);
     int prior = indel_prior_model(1)[0] - 33, tract = 255;
     for (int i : {rel - 1, rel}) {

@@ -146,3 +146,19 @@ def test_tuple_hash_and_dict_order_of_variant_keys(native):
             want = low if low < 1 << 31 else low + (((1 << 32) - 1) << 32)
             assert h == (want if want != (1 << 64) - 1 else (1 << 64) - 2)
             assert (h >> 31) in (0, (1 << 33) - 1)
+
+
+def test_native_variant_prior_matches_reference_golden(native, golden_dir):
+    """Variant.calculatePrior of the native host (variants.hpp: indelPrior over the bit-plane form of tandem.c's annotate for the
+    200-base context) for the 2400 indels in repeats / plain sequence / at contig ends whose priors the reference's own text gave."""
+    import gzip, json, os
+    native.plat_caller_debug_prior.restype = C.c_double
+    native.plat_caller_debug_prior.argtypes = [C.c_char_p, C.c_longlong, C.c_longlong, C.c_char_p, C.c_char_p]
+    g = json.load(gzip.open(os.path.join(golden_dir, "indelprior_cases.json.gz"), "rt"))
+    n = 0
+    for c in g["priors"]:
+        ref = c["ref"].encode()
+        for v in c["variants"]:
+            assert native.plat_caller_debug_prior(ref, len(ref), v["pos"], v["removed"].encode(), v["added"].encode()) == v["prior"], v
+            n += 1
+    assert n == 2400

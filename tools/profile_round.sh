@@ -58,5 +58,6 @@ esac; done
 cd $R
 python tools/profile_round_summary.py $O $TAG
 mkdir -p $O/out && cp profiles/${TAG}_* profiles/dp_traffic.json $O/out/ 2>/dev/null
+for f in $O/bench_*.json $O/soak_*.json; do [ -s "$f" ] && cp $f $O/out/${TAG}_$(basename $f); done     # the lines / soaks of THIS run
 find $O -name "*.csv" -size +1M -delete
 find $O -name "*.db" -size +1M -delete
