@@ -62,6 +62,66 @@ inline void append_py2_str(std::string& out, double x) {
     out += py2_str_slow(x);
 }
 inline std::string py2_str(double x) { std::string t; append_py2_str(t, x); return t; }
+// the same writers on a character pointer (the record line is written into space reserved for it); each returns the new end
+inline char* put_chars(char* p, const char* s, size_t n) { memcpy(p, s, n); return p + n; }
+inline char* put_str(char* p, const std::string& s) { memcpy(p, s.data(), s.size()); return p + s.size(); }
+template <size_t N> inline char* put_lit(char* p, const char (&s)[N]) { memcpy(p, s, N - 1); return p + (N - 1); }
+inline char* put_int(char* p, long long v) {
+    unsigned long long u = (unsigned long long)v;
+    if (v < 0) { *p++ = '-'; u = 0ull - u; }
+    return put_uint(p, u);
+}
+inline char* put_py2_str(char* p, double x) {                             // at most 32 characters
+    const double ax = fabs(x);
+    if (ax < 1e9) {
+        const unsigned long long n = (unsigned long long)(ax * 100.0 + 0.5);
+        if ((double)n / 100.0 == ax) {
+            if (std::signbit(x)) *p++ = '-';
+            p = put_uint(p, n / 100);
+            const unsigned f = (unsigned)(n % 100);
+            *p++ = '.';
+            *p++ = (char)('0' + f / 10);
+            if (f % 10) *p++ = (char)('0' + f % 10);
+            return p;
+        }
+    }
+    const std::string t = py2_str_slow(x);
+    return put_str(p, t);
+}
+// "%.0f" % x and "%1.4f" % x (the PP and FR fields) without printf for the values that occur: both print the decimal nearest to the
+// double's EXACT value (ties to even).  x * 10^d is computed with its rounding error (fma); the shortcut is taken only when the product is
+// far enough from a tie for that error not to matter, everything else goes through snprintf.
+inline void append_fixed(std::string& out, double x, int decimals) {     // decimals 0 or 4
+    if (!std::signbit(x) && x < (decimals == 4 ? 1e5 : 1e9)) {        // (x * 1e4 < 1e9: its rounding error stays below 6e-8)
+        const double scale = decimals == 4 ? 1e4 : 1.0;
+        const double y = x * scale, err = fma(x, scale, -y);              // x * scale == y + err exactly
+        const double fl = floor(y), frac = y - fl;                        // (exact: y < 2^44)
+        const double d = fabs(frac - 0.5);
+        if (d > 1e-6 || decimals == 0) {
+            unsigned long long n = (unsigned long long)fl;
+            if (decimals == 0) {                                          // y == x: a tie is exact, round half to even
+                if (frac > 0.5 || (frac == 0.5 && (n & 1ull))) ++n;
+            } else if (frac > 0.5) ++n;
+            (void)err;
+            char buf[40], *q = buf;
+            if (decimals == 0) q = put_uint(q, n);
+            else {
+                q = put_uint(q, n / 10000);
+                unsigned f = (unsigned)(n % 10000);
+                *q++ = '.';
+                *q++ = (char)('0' + f / 1000); f %= 1000;
+                *q++ = (char)('0' + f / 100); f %= 100;
+                *q++ = (char)('0' + f / 10);
+                *q++ = (char)('0' + f % 10);
+            }
+            out.append(buf, (size_t)(q - buf));
+            return;
+        }
+    }
+    char buf[400];
+    snprintf(buf, sizeof buf, decimals == 4 ? "%1.4f" : "%.0f", x);
+    out += buf;
+}
 inline void append_int(std::string& out, long long v) {
     char buf[24], *p = buf;
     unsigned long long u = (unsigned long long)v;
@@ -300,6 +360,11 @@ struct Num {                                                              // a P
         if (isInt) { append_int(out, i); return; }
         append_py2_str(out, d);
     }
+    char* put(char* p) const {                                            // the same characters at p (at most 32)
+        if (value() == -1.0) { *p++ = '.'; return p; }
+        if (isInt) return put_int(p, i);
+        return put_py2_str(p, d);
+    }
 };
 
 struct VarInfo {                                                          // vcfInfo[variant]
@@ -317,12 +382,18 @@ struct VarInfo {                                                          // vcf
 
 // chaplotype.pyx:462-498
 inline int homopolymerLengthForOneVariant(const Variant& v, const Fasta& fa) {
-    const std::string left = fa.getSequence(v.refPos - 20, v.refPos), right = fa.getSequence(v.refPos + 1, v.refPos + 21);
-    if (left.empty() || right.empty()) return 0;
+    // the two getSequence intervals [refPos - 20, refPos) and [refPos + 1, refPos + 21) as views of the reference (clamped and checked as
+    // getSequence does, fastafile.pyx:173-207)
+    const int64_t lb = std::max<int64_t>(0, (int64_t)v.refPos - 20), le = std::min<int64_t>(fa.len - 1, v.refPos);
+    const int64_t rb = std::max<int64_t>(0, (int64_t)v.refPos + 1), re = std::min<int64_t>(fa.len - 1, (int64_t)v.refPos + 21);
+    if (le < lb || re < rb) throw WindowError("Cannot have beginPos > endPos in getSequence");
+    const char* left = (const char*)fa.seq + lb; const char* right = (const char*)fa.seq + rb;
+    const int64_t nL = le - lb, nR = re - rb;
+    if (nL == 0 || nR == 0) return 0;
     int nl = 0, nr = 0;
-    for (size_t i = left.size(); i-- > 0 && left[i] == left.back();) ++nl;
-    for (size_t i = 0; i < right.size() && right[i] == right[0]; ++i) ++nr;
-    return left.back() != right[0] ? std::max(nl, nr) : nl + nr;
+    for (int64_t i = nL; i-- > 0 && left[i] == left[nL - 1];) ++nl;
+    for (int64_t i = 0; i < nR && right[i] == right[0]; ++i) ++nr;
+    return left[nL - 1] != right[0] ? std::max(nl, nr) : nl + nr;
 }
 inline std::string getSequenceContext(const Variant& v, const Fasta& fa) { return fa.getSequence(v.refPos - 10, v.refPos + 11); }   // :500-506
 
@@ -351,10 +422,14 @@ inline void infoFieldsFromReadStats(VarInfo& d, const int64_t* c, const int32_t*
     const float rms = (float)sumsq;                                       // `cdef float RMSMQ`: the quotient is a C float too
     if (TC + TC_bad > 0 && rms > 0) d.MQ = Num::D(py2_round2(sqrt((double)(rms / (float)(TC + TC_bad)))));
     else d.MQ = Num::I(0);
-    if (nminq > 0) {
-        std::vector<int> q(minq, minq + nminq);
-        std::sort(q.begin(), q.end());
-        d.MMLQ = q[q.size() / 2];
+    if (nminq > 0) {                                                      // sorted(...)[n // 2]: the element a full sort would leave there
+        int small[256];
+        std::vector<int> big;
+        int* q = small;
+        if (nminq > 256) { big.assign(minq, minq + nminq); q = big.data(); }
+        else memcpy(small, minq, (size_t)nminq * sizeof(int));
+        std::nth_element(q, q + nminq / 2, q + nminq);
+        d.MMLQ = q[nminq / 2];
     } else d.MMLQ = 100;
 }
 

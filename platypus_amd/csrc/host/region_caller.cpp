@@ -195,12 +195,28 @@ struct TableView {
     int longest = 0;                                                      // getLengthOfLongestRead (:167-172)
     int n() const { return t->n_reads; }
     static int lowerBound(const int32_t* a, int n, int64_t key) { return (int)(std::lower_bound(a, a + n, key, [](int32_t x, int64_t k) { return (int64_t)x < k; }) - a); }
+    // the same index, found by galloping away from `hint` (the loop's windows ascend: the last window's pointer is a few reads away)
+    static int lowerBoundNear(const int32_t* a, int n, int64_t key, int hint) {
+        int lo, hi;                                                       // answer in [lo, hi]
+        hint = std::min(std::max(hint, 0), n);
+        if (hint < n && (int64_t)a[hint] < key) {
+            int step = 1; lo = hint + 1;
+            while (lo + step <= n && lo + step - 1 < n && (int64_t)a[lo + step - 1] < key) { lo += step; step <<= 1; }
+            hi = std::min(n, lo + step - 1);
+        } else {
+            int step = 1; hi = hint;
+            while (hi - step >= 0 && (int64_t)a[hi - step] >= key) { hi -= step; step <<= 1; }
+            lo = std::max(0, hi - step + 1);
+        }
+        return lo + lowerBound(a + lo, hi - lo, key);
+    }
     // shared body of countReadsCoveringRegion (:176-206) and setWindowPointers (:208-234)
-    void overlapRange(int start, int end, int& s, int& e) const {
+    void overlapRange(int start, int end, int& s, int& e, int hintS = -1, int hintE = -1) const {
         const int N = n();
         if (N == 0) { s = e = 0; return; }
-        s = lowerBound(t->pos, N, std::max<int64_t>(1, (int64_t)start - longest));
-        e = lowerBound(t->pos, N, end);
+        const int64_t keyS = std::max<int64_t>(1, (int64_t)start - longest);
+        s = hintS >= 0 ? lowerBoundNear(t->pos, N, keyS, hintS) : lowerBound(t->pos, N, keyS);
+        e = hintE >= 0 ? lowerBoundNear(t->pos, N, end, hintE) : lowerBound(t->pos, N, end);
         while (s < N && t->end[s] <= start) ++s;
         if (s > e) throw WindowError("This should never happen. Read start pointer > read end pointer!!");
         e = std::min(e, N);
@@ -245,12 +261,16 @@ struct Hap {
 // chaplotype.pyx:127-191 + getMutatedSequence :397-449.  startPos / endPos already clamped as the constructor does.
 static std::string haplotypeSequence(const Fasta& fa, int startPos, int endPos, int endBuf, const VarList& variants) {
     if (variants.empty()) return fa.getSequence((int64_t)startPos - endBuf, (int64_t)endPos + endBuf);
-    std::string out = fa.getSequence((int64_t)startPos - endBuf, startPos);
+    std::string out;
+    size_t extra = 0;
+    for (const Variant* v : variants) extra += v->added.size();
+    out.reserve((size_t)std::max(0, endPos - startPos) + 2 * (size_t)endBuf + extra + 16);
+    fa.appendSequence(out, (int64_t)startPos - endBuf, startPos);
     int cur = startPos;
     const Variant* first = variants[0];
-    if (first->refPos != cur) { out += fa.getSequence(cur, first->refPos); cur = first->refPos; }
+    if (first->refPos != cur) { fa.appendSequence(out, cur, first->refPos); cur = first->refPos; }
     for (const Variant* v : variants) {
-        if (v->refPos > cur) { out += fa.getSequence(cur, v->refPos); cur = v->refPos; }
+        if (v->refPos > cur) { fa.appendSequence(out, cur, v->refPos); cur = v->refPos; }
         if (v->nAdded == v->nRemoved) { out += v->added; cur += v->nRemoved; }
         else {
             if (v->added.empty() || v->removed.empty()) {
@@ -260,8 +280,8 @@ static std::string haplotypeSequence(const Fasta& fa, int startPos, int endPos, 
             out += v->added;
         }
     }
-    if (cur < endPos) out += fa.getSequence(cur, endPos);
-    out += fa.getSequence(endPos, (int64_t)endPos + endBuf);
+    if (cur < endPos) fa.appendSequence(out, cur, endPos);
+    fa.appendSequence(out, endPos, (int64_t)endPos + endBuf);
     return out;
 }
 
@@ -1041,6 +1061,7 @@ struct Chunk {
         std::vector<Window> wins;
         { PROF("s2.windowsAndVariants"); wins = windowsAndVariants(r.in->start, r.in->end, r.fa.len - 1, r.variants, wo); }
         if (r.cur.size() != r.samples.size()) r.cur.assign(r.samples.size(), Ptrs{0, 0, 0, 0, 0, 0});
+        r.windows.reserve(r.windows.size() + wins.size()); r.items.reserve(r.items.size() + wins.size());
         for (Window& win : wins) {
             if (win.variants.empty()) {                                      // a reference-call block between calling windows (:605-607)
                 if (o.outputRefCalls) {
@@ -1124,7 +1145,7 @@ struct Chunk {
         { PROF("s2.pw.ptrs");
         for (size_t i = 0; i < r.samples.size(); ++i) {                    // bamReadBuffer.setWindowPointers (cwindow.pyx:655-689)
             Ptrs& p = w.ptrs[i];
-            r.samples[i].reads.overlapRange(w.startPos, w.endPos, p.gs, p.ge);
+            r.samples[i].reads.overlapRange(w.startPos, w.endPos, p.gs, p.ge, r.cur[i].gs, r.cur[i].ge);
             r.samples[i].bad.overlapRange(w.startPos, w.endPos, p.bs, p.be);
             r.samples[i].broken.matePosRange(w.startPos, w.endPos, p.ks, p.ke);
             w.nReads += p.ge - p.gs;
@@ -1193,7 +1214,15 @@ struct Chunk {
         for (Hap& h : haps) all.push_back(std::move(h));
         std::vector<size_t> order(all.size());
         for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return all[a].seq < all[b].seq; });
+        // (a stable sort: insertion sort for the handful of haplotypes a window has -- same order, no scratch buffer)
+        if (order.size() <= 16) {
+            for (size_t i = 1; i < order.size(); ++i) {
+                const size_t x = order[i];
+                size_t j = i;
+                while (j > 0 && all[x].seq < all[order[j - 1]].seq) { order[j] = order[j - 1]; --j; }
+                order[j] = x;
+            }
+        } else std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return all[a].seq < all[b].seq; });
         std::vector<Hap> merged;
         int last = -1;
         for (size_t k : order) {
@@ -1426,9 +1455,9 @@ struct Chunk {
                         PROF("s6.hp_sc");
                         n.HP = homopolymerLengthForOneVariant(*v, r.fa);
                         n.SC = getSequenceContext(*v, r.fa);
-                        char buf[64];
-                        snprintf(buf, sizeof buf, "%.0f", w->calledPost[(size_t)ci]);
-                        n.PP = buf;
+                        n.PP.clear();
+                        append_fixed(n.PP, w->calledPost[(size_t)ci], 0);                   // "%.0f"
+
                         n.FRsum = freq[h];
                         w->info.push_back(std::move(n));
                     } else d->FRsum += freq[h];
@@ -1581,9 +1610,8 @@ struct Chunk {
                 if (qual > 2500) d.QD = Num::I(o.qdThreshold + 10);
                 else d.QD = Num::D((qual + (-10 * log10(calculatePrior(*d.var, r.fa)))) / (double)d.TR);
             } else d.QD = Num::I(0);
-            char buf[64];
-            snprintf(buf, sizeof buf, "%1.4f", d.FRsum);
-            d.FRtext = buf;
+            d.FRtext.clear();
+            append_fixed(d.FRtext, d.FRsum, 4);                                             // "%1.4f"
             d.HapScore = hapScore;
             d.Source.clear();
             if (d.var->varSource & PLATYPUS_VAR) d.Source.push_back("Platypus");
@@ -1632,6 +1660,7 @@ struct Chunk {
         for (auto& pv : w.byPos) positions.push_back(&pv);
         std::sort(positions.begin(), positions.end(), [](const std::pair<int, VarList>* a, const std::pair<int, VarList>* b) { return a->first < b->first; });
         std::string& out = w.text;
+        out.reserve(out.size() + positions.size() * (size_t)(320 + 40 * nInd));                  // (a record line is ~300 characters: no regrowth on the way)
         for (size_t pi = 0; pi < positions.size(); ++pi) {
             PROF("text.record");
             int POS = positions[pi]->first;
@@ -1703,42 +1732,55 @@ struct Chunk {
             if (!plain) continue;                                           // :583-592
             // VCF.write_data
             PROF("text.record.write");
-            out += r.in->chrom; out += '\t';
-            append_int(out, POS + 1); out += "\t.\t"; out += ref; out += '\t';
-            if (alt.empty()) out += "."; else for (size_t q = 0; q < alt.size(); ++q) { if (q) out += ","; out += alt[q]; }
-            out += '\t'; append_int(out, qual); out += '\t';
-            if (linefilter.empty()) out += "PASS";
+            // (written through a pointer into space reserved for the whole line: a bound on its length first)
+            const size_t chromLen = strlen(r.in->chrom);
+            size_t bound = chromLen + ref.size() + lead.SC.size() + 768 + 80 * (size_t)nVariants;          // literals 130, 15 numbers of at most 32, 3 counts per variant
+            for (const std::string& a : alt) bound += a.size() + 1;
+            for (const std::string& f : linefilter) bound += f.size() + 1;
+            for (const std::string& c : sampleCols) bound += c.size() + 1;
+            for (const std::string& t : FR) bound += t.size() + 1;
+            for (const std::string& t : PP) bound += t.size() + 1;
+            for (const std::string& t : lead.Source) bound += t.size() + 1;
+            const size_t at0 = out.size();
+            out.resize(at0 + bound);
+            char* p = &out[at0];
+            p = put_chars(p, r.in->chrom, chromLen); *p++ = '\t';
+            p = put_int(p, POS + 1); p = put_lit(p, "\t.\t"); p = put_str(p, ref); *p++ = '\t';
+            if (alt.empty()) *p++ = '.'; else for (size_t q = 0; q < alt.size(); ++q) { if (q) *p++ = ','; p = put_str(p, alt[q]); }
+            *p++ = '\t'; p = put_int(p, qual); *p++ = '\t';
+            if (linefilter.empty()) p = put_lit(p, "PASS");
             else {
                 std::vector<std::string> flt = py2_set_order(linefilter);
-                for (size_t q = 0; q < flt.size(); ++q) { if (q) out += ";"; out += flt[q]; }
+                for (size_t q = 0; q < flt.size(); ++q) { if (q) *p++ = ';'; p = put_str(p, flt[q]); }
             }
-            out += '\t';
-            auto joinLL = [&out](const std::vector<long long>& v) { for (size_t q = 0; q < v.size(); ++q) { if (q) out += ','; Num::I(v[q]).appendTo(out); } };
-            auto joinS = [&out](const std::vector<std::string>& v) { for (size_t q = 0; q < v.size(); ++q) { if (q) out += ','; out += v[q]; } };
+            *p++ = '\t';
+            auto joinLL = [&p](const std::vector<long long>& v) { for (size_t q = 0; q < v.size(); ++q) { if (q) *p++ = ','; p = Num::I(v[q]).put(p); } };
+            auto joinS = [&p](const std::vector<std::string>& v) { for (size_t q = 0; q < v.size(); ++q) { if (q) *p++ = ','; p = put_str(p, v[q]); } };
             // INFO keys in sorted order: BRF FR HP HapScore MGOF MMLQ MQ NF NR PP QD SC SbPval Source TC TCF TCR TR WE WS
-            out += "BRF="; lead.BRF.appendTo(out);
-            out += ";FR="; joinS(FR);
-            out += ";HP="; Num::I(lead.HP).appendTo(out);
-            out += ";HapScore="; Num::I(lead.HapScore).appendTo(out);
-            out += ";MGOF="; Num::I(MGOF).appendTo(out);
-            out += ";MMLQ="; Num::I(lead.MMLQ).appendTo(out);
-            out += ";MQ="; lead.MQ.appendTo(out);
-            out += ";NF="; joinLL(NF);
-            out += ";NR="; joinLL(NR);
-            out += ";PP="; joinS(PP);
-            out += ";QD="; lead.QD.appendTo(out);
-            out += ";SC="; out += lead.SC;
-            out += ";SbPval="; lead.SbPval.appendTo(out);
-            out += ";Source="; joinS(lead.Source);
-            out += ";TC="; Num::I(lead.TC).appendTo(out);
-            out += ";TCF="; Num::I(lead.TCF).appendTo(out);
-            out += ";TCR="; Num::I(lead.TCR).appendTo(out);
-            out += ";TR="; joinLL(TR);
-            out += ";WE="; Num::I(w.endPos).appendTo(out);
-            out += ";WS="; Num::I(w.startPos).appendTo(out);
-            out += "\tGT:GL:GOF:GQ:NR:NV";
-            for (const std::string& c : sampleCols) { out += '\t'; out += c; }
-            out += '\n';
+            p = put_lit(p, "BRF="); p = lead.BRF.put(p);
+            p = put_lit(p, ";FR="); joinS(FR);
+            p = put_lit(p, ";HP="); p = Num::I(lead.HP).put(p);
+            p = put_lit(p, ";HapScore="); p = Num::I(lead.HapScore).put(p);
+            p = put_lit(p, ";MGOF="); p = Num::I(MGOF).put(p);
+            p = put_lit(p, ";MMLQ="); p = Num::I(lead.MMLQ).put(p);
+            p = put_lit(p, ";MQ="); p = lead.MQ.put(p);
+            p = put_lit(p, ";NF="); joinLL(NF);
+            p = put_lit(p, ";NR="); joinLL(NR);
+            p = put_lit(p, ";PP="); joinS(PP);
+            p = put_lit(p, ";QD="); p = lead.QD.put(p);
+            p = put_lit(p, ";SC="); p = put_str(p, lead.SC);
+            p = put_lit(p, ";SbPval="); p = lead.SbPval.put(p);
+            p = put_lit(p, ";Source="); joinS(lead.Source);
+            p = put_lit(p, ";TC="); p = Num::I(lead.TC).put(p);
+            p = put_lit(p, ";TCF="); p = Num::I(lead.TCF).put(p);
+            p = put_lit(p, ";TCR="); p = Num::I(lead.TCR).put(p);
+            p = put_lit(p, ";TR="); joinLL(TR);
+            p = put_lit(p, ";WE="); p = Num::I(w.endPos).put(p);
+            p = put_lit(p, ";WS="); p = Num::I(w.startPos).put(p);
+            p = put_lit(p, "\tGT:GL:GOF:GQ:NR:NV");
+            for (const std::string& c : sampleCols) { *p++ = '\t'; p = put_str(p, c); }
+            *p++ = '\n';
+            out.resize((size_t)(p - out.data()));
             ++w.nRecords;
         }
     }
@@ -2355,6 +2397,11 @@ CALLER_EXPORT double plat_caller_debug_prior(const char* ref, long long ref_len,
     fa.seq = (const uint8_t*)ref; fa.len = ref_len;
     Variant v((int)pos, removed ? removed : "", added ? added : "", 1, PLATYPUS_VAR);
     return calculatePrior(v, fa);
+}
+CALLER_EXPORT void plat_caller_debug_fixed(double x, int decimals, char* out, size_t cap) {
+    std::string t;
+    append_fixed(t, x, decimals);
+    snprintf(out, cap, "%s", t.c_str());
 }
 CALLER_EXPORT void plat_caller_debug_dict_slot_order(const unsigned long long* hashes, int n, int* out) {
     std::vector<uint64_t> h(hashes, hashes + n);

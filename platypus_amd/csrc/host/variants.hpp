@@ -38,6 +38,12 @@ struct Fasta {
         if (endPos < beginPos) throw WindowError("Cannot have beginPos > endPos in getSequence");
         return std::string((const char*)seq + beginPos, (size_t)(endPos - beginPos));
     }
+    void appendSequence(std::string& out, int64_t beginPos, int64_t endPos) const {        // out += getSequence(beginPos, endPos), no temporary
+        beginPos = std::max<int64_t>(0, beginPos);
+        endPos = std::min<int64_t>(len - 1, endPos);
+        if (endPos < beginPos) throw WindowError("Cannot have beginPos > endPos in getSequence");
+        out.append((const char*)seq + beginPos, (size_t)(endPos - beginPos));
+    }
     char getCharacter(int64_t pos) const { return (pos >= len || pos < 0) ? '-' : (char)seq[pos]; }   // :120-132
 };
 

@@ -2007,13 +2007,8 @@ __device__ __forceinline__ int dp_job(const uint8_t* __restrict__ rs, const uint
     } else {
         DP<HAS_N, SWAR> dp;
         dp.init(w0, 3, 2);
-#ifdef PLAT_DP_NOLOAD                                                        // (measurement builds only: the main loop without its loads; results are wrong)
-        auto rw16 = [&](int h) -> Raw16 { Raw16 x; x.a0 = 0x4143474141434754ull + (unsigned)h; x.a1 = x.a0 ^ 0x0202ull; x.b0 = 0x2323232323232323ull; x.b1 = x.b0; return x; };
-        auto hw16 = [&](int h) -> Raw16 { Raw16 x; x.a0 = 0x4143474141434754ull + (unsigned)(h >> 1); x.a1 = x.a0 ^ 0x0404ull; x.b0 = 0x1414141414141414ull; x.b1 = x.b0; return x; };
-#else
         auto rw16 = [&](int h) -> Raw16 { Raw16 x; load_16_unaligned(rs + h, x.a0, x.a1); load_16_unaligned(rq + h, x.b0, x.b1); return x; };
         auto hw16 = [&](int h) -> Raw16 { Raw16 x; load_16_unaligned(hs + h, x.a0, x.a1); load_16_unaligned(gs + h, x.b0, x.b1); return x; };
-#endif
         return dp_run8<HAS_N, SWAR>(dp, len2, rw, hw, rw8, hw8, rw16, hw16);
     }
 }

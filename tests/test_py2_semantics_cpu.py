@@ -162,3 +162,21 @@ def test_native_variant_prior_matches_reference_golden(native, golden_dir):
             assert native.plat_caller_debug_prior(ref, len(ref), v["pos"], v["removed"].encode(), v["added"].encode()) == v["prior"], v
             n += 1
     assert n == 2400
+
+
+def test_fixed_point_text_equals_printf(native):
+    """The PP ("%.0f") and FR ("%1.4f") fields are written without printf where the rounding cannot be in doubt: the same characters as
+    Python's % operator (the C library's printf) for ties, values next to ties, roll-overs, large, negative and non-finite values."""
+    import random
+    native.plat_caller_debug_fixed.argtypes = [C.c_double, C.c_int, C.c_char_p, C.c_size_t]
+    rng = random.Random(11)
+    xs = [0.0, -0.0, 0.5, 1.5, 2.5, 3.5, 0.49999999999999994, 0.99995, 0.99994999, 0.00005, 0.00015, 0.12345, 0.12355, 0.5 / 3, 1.0, 1e-300, 1e5, 99999.99995,
+          1e9, 1e15, 1e22, -3.7, 2500.5, 2501.5, float("inf"), float("nan"), 12345.67895, 0.30000000000000004, 1.00005, 7.00015]
+    xs += [rng.random() for _ in range(20000)] + [rng.random() * 3000 for _ in range(20000)]
+    xs += [(k + 0.5) / 10000.0 for k in range(0, 20000, 7)] + [k + 0.5 for k in range(0, 3000)]
+    xs += [math.nextafter((k + 0.5) / 10000.0, d) for k in range(0, 20000, 13) for d in (0.0, 1.0)]
+    buf = C.create_string_buffer(512)
+    for x in xs:
+        for dec, fmt in ((0, "%.0f"), (4, "%1.4f")):
+            native.plat_caller_debug_fixed(x, dec, buf, 512)
+            assert buf.value.decode() == fmt % x, (x, dec)
