@@ -41,13 +41,14 @@ constexpr int ASM_MAX_SUCC = 8;        // distinct successor bytes tracked per n
 constexpr int ASM_MAX_TASKS = 512;     // bubble-start (node, edge) pairs per region
 constexpr int ASM_POOL = 1 << 20;      // path elements per region, shared by its tasks (bump-allocated)
 constexpr int ASM_MAX_FIN = 21;        // finished paths per task before the reference aborts (assembler.pyx:1052)
-constexpr int ASM_THREADS = 1024;      // threads per workgroup (one workgroup per CU: the graph takes most of the LDS)
+constexpr int ASM_THREADS = 768;       // threads per workgroup (one workgroup per CU: the graph takes most of the LDS)
 constexpr int ASM_LDS_SLOTS = 16384;   // k-mer table in LDS: 64 KB
 constexpr int ASM_LDS_NODES = 11264;   // per-node first-touch codes and (weight | colour << 30) words in LDS: 2 x 44 KB
 constexpr int ASM_LDS_LIMIT = ASM_LDS_NODES - ASM_THREADS;   // distinct k-mers the LDS path takes (threads in flight may overshoot by one each)
 constexpr int ASM_REF_CACHE = 7552;    // bytes of the region's reference kept in LDS (k-mers of reads are compared with their representative, which is a
                                        // reference k-mer whenever the reference holds one: the reference's k-mers are inserted first)
 constexpr int ASM_LDS_BYTES = (ASM_LDS_SLOTS + 2 * ASM_LDS_NODES) * 4 + ASM_REF_CACHE;
+constexpr int ASM_STK = 28;            // pending path elements per bubble walk (the reference aborts a walk with more than 20, assembler.pyx:1052-1057)
 constexpr int ASM_OFF_BITS = 18;       // LDS path: a table slot packs (node id << 18 | byte offset of the representative)
 static_assert(ASM_LDS_NODES < ASM_LDS_SLOTS * 3 / 4, "the table must stay sparse");
 
@@ -91,6 +92,11 @@ struct AsmScratch {
 
 __host__ __device__ inline size_t asm_align(size_t x) { return (x + 15) & ~(size_t)15; }
 
+// ints of the slice's `stack`: the DFS stack of the cycle check (2 per node), later the walks' stacks and the list of finished paths
+__host__ __device__ inline size_t asm_stack_ints(int max_pos) {
+    const size_t a = (size_t)max_pos * 2, b = (size_t)ASM_MAX_TASKS * (2 * ASM_MAX_FIN + ASM_STK) + 64;
+    return a > b ? a : b;
+}
 __host__ __device__ inline size_t asm_scratch_bytes(int cap, int max_pos, int max_ref, int max_reads) {
     size_t b = 0;
     b += asm_align((size_t)cap * 4) * 2;
@@ -106,7 +112,7 @@ __host__ __device__ inline size_t asm_scratch_bytes(int cap, int max_pos, int ma
     b += asm_align((size_t)ASM_MAX_TASKS * ASM_MAX_FIN * 4);
     b += asm_align((size_t)ASM_POOL * 3 * 4);
     b += asm_align((size_t)(ASM_MAX_TASKS + 1) * 4);
-    b += asm_align((size_t)max_pos * 2 * 4);
+    b += asm_align(asm_stack_ints(max_pos) * 4);
     return b;
 }
 
@@ -134,7 +140,7 @@ __device__ inline AsmScratch asm_carve(char* p, int cap, int max_pos, int max_re
     s.task_fin = (int*)take((size_t)ASM_MAX_TASKS * ASM_MAX_FIN * 4);
     s.arena = (int*)take((size_t)ASM_POOL * 3 * 4);
     s.var_task_off = (int*)take((size_t)(ASM_MAX_TASKS + 1) * 4);
-    s.stack = (int*)take((size_t)max_pos * 2 * 4);
+    s.stack = (int*)take(asm_stack_ints(max_pos) * 4);
     return s;
 }
 
@@ -459,7 +465,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
            int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob,
            int32_t* status)
 {
-    __shared__ int s_n, s_ntasks, s_err, s_cycle, s_k, s_pool, s_distinct, s_lds, s_nrefnodes, s_nreadnodes;
+    __shared__ int s_n, s_ntasks, s_err, s_cycle, s_k, s_pool, s_distinct, s_lds, s_nrefnodes, s_nreadnodes, s_nv;
     extern __shared__ __attribute__((aligned(16))) int s_tab[];  // [ASM_LDS_SLOTS] the k-mer table, then the node words, then the reference
     unsigned* s_first = (unsigned*)(s_tab + ASM_LDS_SLOTS);      // [ASM_LDS_NODES] min touch code (2*ticket + isEnd)
     unsigned* s_wc = s_first + ASM_LDS_NODES;                    // [ASM_LDS_NODES] weight | colour << 30
@@ -475,6 +481,9 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
     // fused LDS path: the first ticket of a node's LDS-summed slot when a READ claimed it (read-only nodes; a reference-claimed slot's ticket
     // is the node's position) lives in S.weight[node] -- the LDS path has no other use for that array --, 0xFFFFFFFF between regions
     unsigned* own_t = (unsigned*)S.weight;
+    // ... and the node that slot leads to in own_n[node] (S.succ_w, which only the global path sums into): one dense word per node
+    // instead of a word in the node's row of eight -- a 32-byte sector written and read back per node
+    int* own_n = S.succ_w;
     for (int i = tid; i < ASM_LDS_NODES; i += nthr) own_t[i] = 0xFFFFFFFFu;
 
     for (int g = blockIdx.x; g < b.n_regions; g += gridDim.x) {
@@ -491,6 +500,37 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             for (int i = tid; 8 * i < refLen + 16; i += nthr) s_ref[i] = asm_ld8(ref + 8 * i);
         const long long blobLen = nR > 0 ? b.read_off[rb + nR] - rblob0 : 0;
         asm_sync();
+
+        // Fast path of the phases after the graph is built (round 4; fused LDS path, noCycles off): the k-mer table is not needed once the
+        // successors are picked, so its 64 KB take (a) ONE WORD PER NODE -- end node | weight >= min_weight << 14 | number of out-edges << 15
+        // -- which is the whole out-edge list of the nodes with at most one successor (all but the branch points, whose AsmNodeE stays in
+        // global memory), (b) the tasks' finished-path counts and (c) the first ASM_LDS_ARENA path elements of the bubble walks.  First
+        // touches and colours are read from the node words in LDS.  The walks of phases E-G are chains of dependent loads: in LDS a step
+        // costs ~0.1 us instead of a global round trip.
+        // Layout of the table's words on the fast path: [0, nNodes) edge words, then one finished-path count per task, then the tasks' stacks
+        // of pending path elements (when they fit: else in the slice), then path elements (node, parent, depth) up to the table's end.
+        bool fast = false, ldsStk = false;
+        int* const s_edge = s_tab;
+        int* s_tnfin = s_tab; int* s_stk = s_tab; int* s_arena = s_tab;
+        int arenaCap = 0;
+        auto colour_of = [&](int n) -> int { return fast ? (int)(s_wc[n] >> 30) : S.colour[n]; };
+        auto first_of = [&](int n) -> unsigned { return fast ? s_first[n] : S.first[n]; };
+        auto edges_of = [&](int n, int (&end)[4], bool (&heavy)[4]) -> int {            // out-edges in pick order; heavy: weight >= min_weight
+            if (fast) {
+                const int wd = s_edge[n], cnt = wd >> 15 & 7;
+                if (cnt <= 1) { end[0] = wd & 0x3FFF; heavy[0] = (wd >> 14 & 1) != 0; return cnt; }
+            }
+            const AsmNodeE& E = S.edges[n];
+            const int cnt = E.n;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < cnt) { end[i] = E.end[i]; heavy[i] = E.w[i] >= P.min_weight; }
+            return cnt;
+        };
+        auto arena_get = [&](int e, int f) -> int { return e < arenaCap ? s_arena[3 * e + f] : S.arena[3 * e + f]; };
+        auto arena_set = [&](int e, int node, int parent, int depth) {
+            int* A = e < arenaCap ? s_arena + 3 * e : S.arena + 3 * e;
+            A[0] = node; A[1] = parent; A[2] = depth;
+        };
 
         for (;;) {   // (re)build with the current k (assembler.pyx:1453-1469: k += 5 while cycles, noCycles only)
             const int k = s_k;
@@ -714,7 +754,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     const unsigned ft = s_first[sn];
                     if (slot < 7 && (int)(ft >> 1) + (int)(ft & 1u) == e) {                           // the node's first occurrence: the one claim of its LDS slot in this pass
                         atomicAdd(&s_wc[sn], ((unsigned)(slot + 1) << 23) | (1u << 27) | 1u);
-                        S.succ_n[sn * ASM_MAX_SUCC + slot] = en;
+                        own_n[sn] = en;
                     } else global_slot(sn, slot, 1, e, en);
                 }
                 asm_sync();
@@ -753,7 +793,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             if (nRefNodes0 + *(volatile int*)&s_nreadnodes > ASM_LDS_LIMIT) { stopped = true; break; }   // (<= 4 x 1024 new k-mers between two looks: the arrays' spare room)
                             const Win w = c0 == 0 ? w0 : load_win(m0, c0);
                             const int nE = w.nE;
-                            constexpr int NRB = 2;                               // edges per lane worked side by side
+                            constexpr int NRB = ASM_THREADS <= 512 ? 4 : 2;      // edges per lane worked side by side (registers: 254 per lane at 512 threads, 128 at 1024)
                             // `work`: NRB edges per lane (jj[u] = edge index in the window, -1 none; ww[u] = its weight): k-mers found or created,
                             // then the events.  An edge's end k-mer is the start k-mer of the edge that follows it in the read -- the next lane's
                             // (or lane 0's of the next u) when that lane holds edge jj + 1.
@@ -837,7 +877,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                                             const unsigned d = (x >> 23) & 7u;
                                             if (d == 0u) {
                                                 const unsigned old = atomicCAS(&s_wc[sn], x, x | (unsigned)(slot + 1) << 23);
-                                                if (old == x) S.succ_n[sn * ASM_MAX_SUCC + slot] = en;    // this event claimed the slot
+                                                if (old == x) own_n[sn] = en;                              // this event claimed the slot
                                                 x = old == x ? (x | (unsigned)(slot + 1) << 23) : old;
                                                 continue;
                                             }
@@ -1180,11 +1220,12 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             });
             asm_sync();
             ASM_TICK(3);
-            if (lds) {                                                        // the node words the later phases read, to the slice
+            fast = lds && fused_done && !P.no_cycles;
+            if (lds && !fast) {                                               // the node words the later phases read, to the slice
                 for (int n = tid; n < nNodes; n += nthr) { S.first[n] = s_first[n]; if (!fused_done) S.weight[n] = 0; S.colour[n] = (int)(s_wc[n] >> 30); }
                 asm_sync();
-                ASM_TICK(9);
             }
+            ASM_TICK(9);
             // ---- phase D: per node, the four successors with the smallest first tickets, in ticket order
             if (lds) {
                 // nodes with more than one successor slot in use (few): their slots' first tickets from a second pass over the events
@@ -1280,7 +1321,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             const int n = n0 + u * nthr;
                             xs[u] = n < nNodes ? s_wc[n] : 0u;
                             const int own = (int)(xs[u] >> 23 & 7u) - 1;
-                            ends[u] = (n < nNodes && own >= 0) ? S.succ_n[n * ASM_MAX_SUCC + own] : -1;
+                            ends[u] = (n < nNodes && own >= 0) ? own_n[n] : -1;
                         }
 #pragma unroll
                         for (int u = 0; u < DB; ++u) {
@@ -1291,36 +1332,51 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             const int own = (int)(x >> 23 & 7u) - 1;
                             // (written field by field: a local AsmNodeE indexed by the pick count would live in scratch memory)
                             AsmNodeE* Eo = &S.edges[n];
-                            int en_ = 0;
+                            int en_ = 0, end0 = 0, w0 = 0;
                             if (!dirty) {
-                                if (own >= 0) { Eo->end[0] = ends[u]; Eo->w[0] = (int)(x & 0x7FFFFFu); en_ = 1; }
+                                if (own >= 0) {
+                                    end0 = ends[u]; w0 = (int)(x & 0x7FFFFFu); en_ = 1;
+                                    if (!fast) { Eo->end[0] = end0; Eo->w[0] = w0; }           // (fast path: the node's edge word says it all)
+                                }
+                                if (!fast) Eo->n = en_;
                             } else {
+                                // the node's slot words, all requested before the first is looked at (a branch point's picks were a chain of
+                                // dependent global round trips: most of this phase's time)
+                                unsigned long long cw[ASM_MAX_SUCC]; unsigned tt[ASM_MAX_SUCC]; int nn[ASM_MAX_SUCC];
+#pragma unroll
+                                for (int j = 0; j < ASM_MAX_SUCC; ++j) {
+                                    cw[j] = S.succ_cw[n * ASM_MAX_SUCC + j]; tt[j] = S.succ_t[n * ASM_MAX_SUCC + j]; nn[j] = S.succ_n[n * ASM_MAX_SUCC + j];
+                                }
                                 unsigned last = 0; bool firstpick = true;
                                 for (int pick = 0; pick < 4; ++pick) {
-                                    int bj = -1; unsigned bt = 0xFFFFFFFFu;
+                                    int bj = -1, bend = 0, bw = 0; unsigned bt = 0xFFFFFFFFu;
+#pragma unroll
                                     for (int j = 0; j < ASM_MAX_SUCC; ++j) {
-                                        if (j != own && (S.succ_cw[n * ASM_MAX_SUCC + j] >> 32) == 0ull) continue;
+                                        if (j != own && (cw[j] >> 32) == 0ull) continue;
                                         unsigned t = 0u;
                                         if (several) {
-                                            t = S.succ_t[n * ASM_MAX_SUCC + j];                        // (events of the slot that went to the global words)
+                                            t = tt[j];                                                      // (events of the slot that went to the global words)
                                             if (j == own) {
                                                 if (x >> 27 & 1u) { const unsigned ft = s_first[n]; t = (ft >> 1) + (ft & 1u); }
                                                 else t = min(t, own_t[n]);
                                             }
                                         }
                                         if (!firstpick && t <= last) continue;
-                                        if (t < bt) { bt = t; bj = j; }
+                                        if (t < bt) { bt = t; bj = j; bend = j == own ? ends[u] : nn[j]; bw = (int)(unsigned)cw[j] + (j == own ? (int)(x & 0x7FFFFFu) : 0); }
                                     }
                                     if (bj < 0) break;
-                                    Eo->end[en_] = bj == own ? ends[u] : S.succ_n[n * ASM_MAX_SUCC + bj];
-                                    Eo->w[en_] = (int)(unsigned)S.succ_cw[n * ASM_MAX_SUCC + bj] + (bj == own ? (int)(x & 0x7FFFFFu) : 0);
+                                    Eo->end[en_] = bend;
+                                    Eo->w[en_] = bw;
+                                    if (en_ == 0) { end0 = bend; w0 = bw; }
                                     ++en_;
                                     last = bt; firstpick = false;
                                     if (!several) break;
                                 }
+                                Eo->n = en_;
+#pragma unroll
                                 for (int j = 0; j < ASM_MAX_SUCC; ++j) { S.succ_cw[n * ASM_MAX_SUCC + j] = 0ull; S.succ_c[n * ASM_MAX_SUCC + j] = 0; S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu; }
                             }
-                            Eo->n = en_;
+                            if (fast) s_edge[n] = en_ > 0 ? (end0 | (w0 >= P.min_weight ? 1 << 14 : 0) | en_ << 15) : 0;
                             if (x >> 28 & 1u) own_t[n] = 0xFFFFFFFFu;
                         }
                     }
@@ -1392,11 +1448,13 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     int n = -1, cnt = 0, mask = 0;
                     if (i < i1) {
                         n = S.ref_node[i];
-                        const unsigned ft = S.first[n];
-                        if ((int)(ft >> 1) + (int)(ft & 1u) == i && S.colour[n] == 3) {        // first occurrence of this k-mer; assembler.pyx:1144
-                            const AsmNodeE& E = S.edges[n];
-                            for (int j = 0; j < E.n; ++j)
-                                if (S.colour[E.end[j]] == 2) { mask |= 1 << j; ++cnt; }           // assembler.pyx:1153
+                        const unsigned ft = first_of(n);
+                        if ((int)(ft >> 1) + (int)(ft & 1u) == i && colour_of(n) == 3) {       // first occurrence of this k-mer; assembler.pyx:1144
+                            int end[4]; bool heavy[4];
+                            const int ne = edges_of(n, end, heavy);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (j < ne && colour_of(end[j]) == 2) { mask |= 1 << j; ++cnt; }   // assembler.pyx:1153
                         }
                     }
                     int total;
@@ -1412,37 +1470,55 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             asm_sync();
             ASM_TICK(6);
             const int nTasks = s_ntasks;
+            arenaCap = 0; ldsStk = false;
+            if (fast) {
+                s_tnfin = s_tab + nNodes;
+                s_stk = s_tnfin + nTasks;
+                ldsStk = nNodes + nTasks + ASM_STK * nTasks + 3 * 256 <= ASM_LDS_SLOTS;
+                s_arena = ldsStk ? s_stk + ASM_STK * nTasks : s_stk;
+                arenaCap = (int)((s_tab + ASM_LDS_SLOTS - s_arena) / 3);
+            }
             // ---- phase F: getVariantPathsThroughGraphFromNode (assembler.pyx:1027-1112), one thread per start edge
             for (int t = tid; t < nTasks; t += nthr) {
-                int* A = S.arena;
-                int stk[28]; int top = 0, nfin = 0;
+                // (the stack of pending elements in LDS, or in the slice: a local array indexed by `top` would live in scratch memory,
+                //  a global round trip for every push and pop)
+                int* const stk = ldsStk ? s_stk + ASM_STK * t : S.stack + ASM_STK * t;
+                int top = 0, nfin = 0;
                 const int e0 = atomicAdd(&s_pool, 2);
                 bool aborted = false, overflow = e0 + 2 > ASM_POOL;
                 if (!overflow) {
-                    A[3 * e0] = S.task_node[t]; A[3 * e0 + 1] = -1; A[3 * e0 + 2] = 1;
-                    A[3 * e0 + 3] = S.edges[S.task_node[t]].end[S.task_edge[t]]; A[3 * e0 + 4] = e0; A[3 * e0 + 5] = 2;
+                    const int tn = S.task_node[t], te = S.task_edge[t];
+                    int end[4]; bool heavy[4];
+                    edges_of(tn, end, heavy);
+                    const int first = te == 0 ? end[0] : (te == 1 ? end[1] : (te == 2 ? end[2] : end[3]));
+                    arena_set(e0, tn, -1, 1);
+                    arena_set(e0 + 1, first, e0, 2);
                     stk[top++] = e0 + 1;
                 }
                 while (top > 0) {
                     const int pe = stk[--top];
                     if (top > 20 || nfin > 20) { aborted = true; break; }          // assembler.pyx:1052-1057
-                    const int endn = A[3 * pe];
+                    const int endn = arena_get(pe, 0);
                     // checkPathForCycles (:999-1023): a path is only ever extended from a cycle-free path, so it
                     // suffices to compare its last node with its ancestors
                     bool cyc = false;
-                    for (int a = A[3 * pe + 1]; a >= 0; a = A[3 * a + 1]) if (A[3 * a] == endn) { cyc = true; break; }
+                    for (int a = arena_get(pe, 1); a >= 0; a = arena_get(a, 1)) if (arena_get(a, 0) == endn) { cyc = true; break; }
                     if (cyc) continue;
-                    const int col = S.colour[endn];
+                    const int col = colour_of(endn);
                     if (col == 3) { S.task_fin[t * ASM_MAX_FIN + nfin] = pe; ++nfin; }
                     else if (col == 1) continue;
                     else {
-                        const AsmNodeE& E = S.edges[endn];
-                        for (int i = 0; i < E.n; ++i) {                            // assembler.pyx:1091-1107
-                            const int c2 = S.colour[E.end[i]];
-                            if (E.w[i] >= P.min_weight || c2 == 3 || c2 == 1) {
+                        int end[4]; bool heavy[4];
+                        const int ne = edges_of(endn, end, heavy);
+                        const int depth = arena_get(pe, 2);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {                              // assembler.pyx:1091-1107
+                            if (i >= ne || overflow) continue;
+                            const int c2 = colour_of(end[i]);
+                            if (heavy[i] || c2 == 3 || c2 == 1) {
                                 const int na = atomicAdd(&s_pool, 1);
-                                if (na >= ASM_POOL) { overflow = true; break; }
-                                A[3 * na] = E.end[i]; A[3 * na + 1] = pe; A[3 * na + 2] = A[3 * pe + 2] + 1;
+                                if (na >= ASM_POOL) { overflow = true; continue; }
+                                arena_set(na, end[i], pe, depth + 1);
                                 stk[top++] = na;
                             }
                         }
@@ -1451,6 +1527,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 }
                 if (overflow) s_err = PLAT_ERR_OVERFLOW;
                 S.task_nfin[t] = aborted ? 0 : nfin;
+                if (fast) s_tnfin[t] = aborted ? 0 : nfin;
             }
             asm_sync();
             ASM_TICK(7);
@@ -1459,45 +1536,96 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
         asm_sync();
 
         // ---- phase G/H: variants in emission order, then the stable sort of sorted(theVars) (assembler.pyx:1476)
-        if (tid == 0) {
+        int32_t* vp = var_pos + (size_t)g * P.max_vars; int32_t* vr = var_nrem + (size_t)g * P.max_vars;
+        int32_t* va = var_nadd + (size_t)g * P.max_vars; int32_t* vo = var_off + (size_t)g * P.max_vars;
+        uint8_t* vb = var_blob + (size_t)g * P.blob_per_region;
+        // extractVarFromBubblePath (:1196-1291) for the finished path whose last element is `last`: false = no variant (:1213-1218);
+        // else the path's bytes (first byte of every node) in pathb[0, plen) and the trimmed variant: position s, rl reference bytes at
+        // r, al path bytes from pathb[ao]  (suffix trim first, :1253, then prefix trim advancing the position, :1262-1270)
+        auto extract = [&](int t, int last, uint8_t* pathb, int& s, int& rl, int& al, int& ao, const uint8_t*& r) -> bool {
+            const int plen = arena_get(last, 2);
+            const int startn = S.task_node[t], endn = arena_get(last, 0);
+            const unsigned fs = first_of(startn), fe = first_of(endn);
+            s = refStart + (int)(fs >> 1) + (int)(fs & 1u);
+            const int te = refStart + (int)(fe >> 1) + (int)(fe & 1u);
+            if (te < s) return false;
+            rl = te - s + 1; al = plen;
+            r = ref + (s - refStart);
+            int e = last;
+            for (int d = plen - 1; d >= 0; --d) { pathb[d] = asm_ptr(ref, rseq, S.rep[arena_get(e, 0)])[0]; e = arena_get(e, 1); }
+            while (al > 0 && rl > 0 && r[rl - 1] == pathb[al - 1]) { --rl; --al; }
+            ao = 0;
+            while (al > 0 && rl > 0 && r[0] == pathb[ao]) { ++r; ++ao; --rl; --al; ++s; }
+            return true;
+        };
+        bool serialG = true;
+        if (fast) {
+            // one thread per finished path: the paths in emission order (tasks in order, each task's paths in the order they finished),
+            // their bytes side by side in the slice (the DFS stack of the cycle check is free), output slots from scans over the paths
+            const int err0 = s_err;
+            const int nTasks = err0 == 0 ? s_ntasks : 0;
+            const int mynf = tid < nTasks ? s_tnfin[tid] : 0;                 // (ASM_MAX_TASKS <= threads)
+            int NP;
+            const int pbase = asm_block_exscan(mynf, s_wsum, NP);
+            int* plast = S.stack; int* ptask = S.stack + NP;
+            for (int f = 0; f < mynf; ++f) { plast[pbase + f] = S.task_fin[tid * ASM_MAX_FIN + f]; ptask[pbase + f] = tid; }
+            asm_sync();
+            uint8_t* pbytes = (uint8_t*)(S.stack + 2 * NP);
+            const long long pcap = (long long)asm_stack_ints(P.max_pos) * 4 - 8ll * NP;
+            int nvBase = 0, blobBase = 0, err = err0;
+            bool fallback = false;
+            for (int c0 = 0; c0 < NP; c0 += nthr) {
+                const int p = c0 + tid;
+                int t = 0, last = 0, plen = 0;
+                if (p < NP) { last = plast[p]; t = ptask[p]; plen = arena_get(last, 2); }
+                int tot;
+                const int off = asm_block_exscan(plen, s_wsum, tot);
+                if ((long long)tot > pcap) { fallback = true; break; }       // (never seen: a path is tens of nodes)
+                int s = 0, rl = 0, al = 0, ao = 0;
+                const uint8_t* r = ref;
+                const bool valid = p < NP && extract(t, last, pbytes + off, s, rl, al, ao, r);
+                int totv, totb;
+                const int vi = asm_block_exscan(valid ? 1 : 0, s_wsum, totv);
+                const int bo = asm_block_exscan(valid ? rl + al : 0, s_wsum, totb);
+                if (nvBase + totv > P.max_vars || blobBase + totb > P.blob_per_region) { err = PLAT_ERR_OVERFLOW; break; }
+                if (valid) {
+                    const int nv = nvBase + vi, blob = blobBase + bo;
+                    vp[nv] = s > 0 ? s : 0;                                        // variant.pyx:121
+                    vr[nv] = rl; va[nv] = al; vo[nv] = blob;
+                    for (int i = 0; i < rl; ++i) vb[blob + i] = r[i];
+                    for (int i = 0; i < al; ++i) vb[blob + rl + i] = pbytes[off + ao + i];
+                }
+                nvBase += totv; blobBase += totb;
+                __syncthreads();                                                  // (the bytes of this chunk are done with)
+            }
+            asm_sync();
+            if (!fallback) {
+                serialG = false;
+                if (tid == 0) { s_nv = err ? 0 : nvBase; s_err = err; }
+            }
+        }
+        if (serialG && tid == 0) {
             int nv = 0, blob = 0, err = s_err;
-            const int k = s_k;
             const int nTasks = (err == 0 && !(P.no_cycles && s_cycle)) ? s_ntasks : 0;
-            int32_t* vp = var_pos + (size_t)g * P.max_vars; int32_t* vr = var_nrem + (size_t)g * P.max_vars;
-            int32_t* va = var_nadd + (size_t)g * P.max_vars; int32_t* vo = var_off + (size_t)g * P.max_vars;
-            uint8_t* vb = var_blob + (size_t)g * P.blob_per_region;
-            (void)k;
             for (int t = 0; t < nTasks && err == 0; ++t) {
-                const int* A = S.arena;
-                for (int f = 0; f < S.task_nfin[t] && err == 0; ++f) {             // extractVarFromBubblePath :1196-1291
-                    const int last = S.task_fin[t * ASM_MAX_FIN + f];
-                    const int plen = A[3 * last + 2];
-                    const int startn = S.task_node[t], endn = A[3 * last];
-                    const unsigned fs = S.first[startn], fe = S.first[endn];
-                    int s = refStart + (int)(fs >> 1) + (int)(fs & 1u), te = refStart + (int)(fe >> 1) + (int)(fe & 1u);
-                    if (te < s) continue;                                          // :1213-1218
-                    int rl = te - s + 1, al = plen;
-                    const uint8_t* r = ref + (s - refStart);
-                    // alt = first byte of every node on the path; element `last` is the path's last node.  The path is walked once
-                    // (parent pointers) into a byte buffer: the DFS stack of the cycle check is free by now
-                    // suffix trim first (:1253), then prefix trim advancing the position (:1262-1270)
+                for (int f = 0; f < S.task_nfin[t] && err == 0; ++f) {
+                    int s, rl, al, ao;
+                    const uint8_t* r;
                     uint8_t* pathb = (uint8_t*)S.stack;
-                    {
-                        int e = last;
-                        for (int d = plen - 1; d >= 0; --d) { pathb[d] = asm_ptr(ref, rseq, S.rep[A[3 * e]])[0]; e = A[3 * e + 1]; }
-                    }
-                    auto alt_at = [&](int q) -> uint8_t { return pathb[q]; };
-                    while (al > 0 && rl > 0 && r[rl - 1] == alt_at(al - 1)) { --rl; --al; }
-                    int ao = 0;
-                    while (al > 0 && rl > 0 && r[0] == alt_at(ao)) { ++r; ++ao; --rl; --al; ++s; }
+                    if (!extract(t, S.task_fin[t * ASM_MAX_FIN + f], pathb, s, rl, al, ao, r)) continue;
                     if (nv >= P.max_vars || blob + rl + al > P.blob_per_region) { err = PLAT_ERR_OVERFLOW; break; }
                     vp[nv] = s > 0 ? s : 0;                                        // variant.pyx:121
                     vr[nv] = rl; va[nv] = al; vo[nv] = blob;
                     for (int i = 0; i < rl; ++i) vb[blob + i] = r[i];
-                    for (int i = 0; i < al; ++i) vb[blob + rl + i] = alt_at(ao + i);
+                    for (int i = 0; i < al; ++i) vb[blob + rl + i] = pathb[ao + i];
                     blob += rl + al; ++nv;
                 }
             }
+            s_nv = err ? 0 : nv; s_err = err;
+        }
+        asm_sync();
+        if (tid == 0) {
+            const int nv = s_nv, err = s_err;
             // stable insertion sort by (pos, varType, nRemoved)  (Variant.__richcmp__ '<', variant.pyx:282-363)
             auto vtype = [&](int i) { const int a = va[i], rr = vr[i]; return rr == a ? (a == 1 ? 0 : 1) : (rr == 0 ? 2 : (a == 0 ? 3 : 4)); };
             for (int i = 1; i < nv; ++i) {
