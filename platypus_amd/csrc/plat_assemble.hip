@@ -782,12 +782,16 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         w.dQ = (w.nE > 0 && 4 * lane < w.sQ + w.nE + k + 1) ? *(const unsigned*)((pQ & ~(uintptr_t)3) + 4 * lane) : 0u;
                         return w;
                     };
-                    Meta m0 = load_meta(wv), m1 = load_meta(wv + nwv);
-                    Win w0 = load_win(m0, 0);
+                    // (the first windows of the next TWO reads are on their way while this one is worked on, their offsets one read further:
+                    //  a window's global round trip is longer than the work on one window)
+                    Meta m0 = load_meta(wv), m1 = load_meta(wv + nwv), m2 = load_meta(wv + 2 * nwv);
+                    Win w0 = load_win(m0, 0), w1 = load_win(m1, 0);
                     bool stopped = false;
+                    unsigned long long sec_[5] = {0, 0, 0, 0, 0}, secT_ = P.timing ? clock64() : 0ull;          // (PLAT_ASM_TIMING: shader-clock cycles of the first wave per section)
+#define ASM_SEC(i) do { if (P.timing) { const unsigned long long n_ = clock64(); sec_[i] += n_ - secT_; secT_ = n_; } } while (0)
                     for (int r = wv; r < nR && !stopped; r += nwv) {
-                        const Meta m2 = load_meta(r + 2 * nwv);
-                        const Win w1 = load_win(m1, 0);
+                        const Meta m3 = load_meta(r + 3 * nwv);
+                        const Win w2 = load_win(m2, 0);
                         const int base = m0.base, cnt = m0.cnt, ro = m0.ro;
                         for (int c0 = 0; c0 < cnt; c0 += WIN) {
                             if (nRefNodes0 + *(volatile int*)&s_nreadnodes > ASM_LDS_LIMIT) { stopped = true; break; }   // (<= 4 x 1024 new k-mers between two looks: the arrays' spare room)
@@ -798,6 +802,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             // then the events.  An edge's end k-mer is the start k-mer of the edge that follows it in the read -- the next lane's
                             // (or lane 0's of the next u) when that lane holds edge jj + 1.
                             auto work = [&](const int (&jj)[NRB], const int (&ww)[NRB]) {
+                                ASM_SEC(1);
                                 AsmWords<KW> E[NRB];
                                 int slots[NRB];
 #pragma unroll
@@ -805,6 +810,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                                     slots[u] = -1;
                                     E[u] = asm_mask_words(asm_gather_words<KW>(w.dS, (jj[u] >= 0 ? jj[u] : 0) + w.sS), k + 1);
                                 }
+                                ASM_SEC(2);
                                 // the start k-mers, found or created: NRB probe sequences per lane side by side
                                 if (!(P.debug & 2)) {
                                     unsigned sl[NRB]; bool todo[NRB];
@@ -843,6 +849,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                                             }
                                     }
                                 }
+                                ASM_SEC(3);
                                 int nsl[NRB];
 #pragma unroll
                                 for (int u = 0; u < NRB; ++u) {
@@ -893,6 +900,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                                         }
                                     } else global_slot(sn, slot, w_, e, en);
                                 }
+                                ASM_SEC(4);
                             };
                             // The quality / N filter (assembler.pyx:1362-1373) for ALL edges of the window at once: qualities with the N positions
                             // zeroed, sliding minimum over k + 1 bytes (needs every quality byte < 128 and min_qual >= 1: else edge by edge below).
@@ -956,8 +964,11 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                                 }
                             }
                         }
-                        m0 = m1; m1 = m2; w0 = w1;
+                        m0 = m1; m1 = m2; m2 = m3; w0 = w1; w1 = w2;
+                        ASM_SEC(0);
                     }
+                    if (P.timing && tid == 0) for (int i = 0; i < 5; ++i) atomicAdd(&g_asm_ticks[11 + i], sec_[i]);
+#undef ASM_SEC
                 }
                 if (bad) s_err = PLAT_ERR_UNSUPPORTED;
                 asm_sync();
@@ -1723,7 +1734,7 @@ PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* ba
         PLAT_HIP(ctx, hipStreamSynchronize(st));
         PLAT_HIP(ctx, hipMemcpyFromSymbol(t, HIP_SYMBOL(g_asm_ticks), sizeof t));
         fprintf(stderr, "k_assemble, 10 ns ticks per phase summed over %d workgroups (ticket scan, A insert, B ids, C events, D successors, cycles, E starts, F paths, G variants):", nblk);
-        for (int i = 0; i < 12; ++i) fprintf(stderr, " %llu", t[i]);
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", t[i]);       // (11..15: the first wave's shader-clock cycles in the read loop -- rest, validity, gather, probes, events)
         fprintf(stderr, "\n");
         memset(t, 0, sizeof t);
         PLAT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_asm_ticks), t, sizeof t));
