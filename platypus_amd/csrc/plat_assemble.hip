@@ -58,7 +58,8 @@ struct AsmParams {
     int cap;                           // hash slots per region (power of two)
     int max_pos;                       // max k-mer occurrences per region (dense node capacity)
     int timing;                        // PLAT_ASM_TIMING: phase timers on
-    int debug;                         // PLAT_ASM_DEBUG (measurement only, results are garbage): 1 = no events in the fused reads pass, 2 = no table probes either
+    int debug;                         // PLAT_ASM_DEBUG: 1 = no events in the fused reads pass, 2 = no table probes either (measurement only, results are garbage);
+                                       // 4 = walk stacks in the slice and path elements in the global arena, 8 = variants extracted by one thread (tests: same results)
     int fused;                         // LDS path: k-mers and AddEdge events of the reads in ONE pass (round 4; PLAT_ASM_FUSED=0: rounds 2-3's passes)
 };
 
@@ -782,16 +783,19 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         w.dQ = (w.nE > 0 && 4 * lane < w.sQ + w.nE + k + 1) ? *(const unsigned*)((pQ & ~(uintptr_t)3) + 4 * lane) : 0u;
                         return w;
                     };
-                    // (the first windows of the next TWO reads are on their way while this one is worked on, their offsets one read further:
-                    //  a window's global round trip is longer than the work on one window)
-                    Meta m0 = load_meta(wv), m1 = load_meta(wv + nwv), m2 = load_meta(wv + 2 * nwv);
-                    Win w0 = load_win(m0, 0), w1 = load_win(m1, 0);
+                    // (two windows ahead instead of one was measured: no faster -- the loads are not late -- and eight more live registers)
+                    Meta m0 = load_meta(wv), m1 = load_meta(wv + nwv);
+                    Win w0 = load_win(m0, 0);
                     bool stopped = false;
-                    unsigned long long sec_[5] = {0, 0, 0, 0, 0}, secT_ = P.timing ? clock64() : 0ull;          // (PLAT_ASM_TIMING: shader-clock cycles of the first wave per section)
-#define ASM_SEC(i) do { if (P.timing) { const unsigned long long n_ = clock64(); sec_[i] += n_ - secT_; secT_ = n_; } } while (0)
+#ifdef PLAT_ASM_SECTIONS                                                     // (measurement builds: shader-clock cycles of the first wave per section of the loop;
+                    unsigned long long sec_[5] = {0, 0, 0, 0, 0}, secT_ = clock64();         //  compiled out by default: twelve live registers in a kernel that spills)
+#define ASM_SEC(i) do { const unsigned long long n_ = clock64(); sec_[i] += n_ - secT_; secT_ = n_; } while (0)
+#else
+#define ASM_SEC(i) do { } while (0)
+#endif
                     for (int r = wv; r < nR && !stopped; r += nwv) {
-                        const Meta m3 = load_meta(r + 3 * nwv);
-                        const Win w2 = load_win(m2, 0);
+                        const Meta m2 = load_meta(r + 2 * nwv);
+                        const Win w1 = load_win(m1, 0);
                         const int base = m0.base, cnt = m0.cnt, ro = m0.ro;
                         for (int c0 = 0; c0 < cnt; c0 += WIN) {
                             if (nRefNodes0 + *(volatile int*)&s_nreadnodes > ASM_LDS_LIMIT) { stopped = true; break; }   // (<= 4 x 1024 new k-mers between two looks: the arrays' spare room)
@@ -964,10 +968,12 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                                 }
                             }
                         }
-                        m0 = m1; m1 = m2; m2 = m3; w0 = w1; w1 = w2;
+                        m0 = m1; m1 = m2; w0 = w1;
                         ASM_SEC(0);
                     }
+#ifdef PLAT_ASM_SECTIONS
                     if (P.timing && tid == 0) for (int i = 0; i < 5; ++i) atomicAdd(&g_asm_ticks[11 + i], sec_[i]);
+#endif
 #undef ASM_SEC
                 }
                 if (bad) s_err = PLAT_ERR_UNSUPPORTED;
@@ -1486,8 +1492,10 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 s_tnfin = s_tab + nNodes;
                 s_stk = s_tnfin + nTasks;
                 ldsStk = nNodes + nTasks + ASM_STK * nTasks + 3 * 256 <= ASM_LDS_SLOTS;
+                if (P.debug & 4) ldsStk = false;                                      // (tests: the stacks in the slice ...
                 s_arena = ldsStk ? s_stk + ASM_STK * nTasks : s_stk;
                 arenaCap = (int)((s_tab + ASM_LDS_SLOTS - s_arena) / 3);
+                if (P.debug & 4) arenaCap = arenaCap < 24 ? arenaCap : 24;           //  ... and all but a few path elements in the global arena)
             }
             // ---- phase F: getVariantPathsThroughGraphFromNode (assembler.pyx:1027-1112), one thread per start edge
             for (int t = tid; t < nTasks; t += nthr) {
@@ -1591,7 +1599,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 if (p < NP) { last = plast[p]; t = ptask[p]; plen = arena_get(last, 2); }
                 int tot;
                 const int off = asm_block_exscan(plen, s_wsum, tot);
-                if ((long long)tot > pcap) { fallback = true; break; }       // (never seen: a path is tens of nodes)
+                if ((long long)tot > pcap || (P.debug & 8)) { fallback = true; break; }       // (never seen: a path is tens of nodes; debug 8: tests)
                 int s = 0, rl = 0, al = 0, ao = 0;
                 const uint8_t* r = ref;
                 const bool valid = p < NP && extract(t, last, pbytes + off, s, rl, al, ao, r);
@@ -1734,7 +1742,7 @@ PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* ba
         PLAT_HIP(ctx, hipStreamSynchronize(st));
         PLAT_HIP(ctx, hipMemcpyFromSymbol(t, HIP_SYMBOL(g_asm_ticks), sizeof t));
         fprintf(stderr, "k_assemble, 10 ns ticks per phase summed over %d workgroups (ticket scan, A insert, B ids, C events, D successors, cycles, E starts, F paths, G variants):", nblk);
-        for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", t[i]);       // (11..15: the first wave's shader-clock cycles in the read loop -- rest, validity, gather, probes, events)
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", t[i]);       // (11..15, builds with -DPLAT_ASM_SECTIONS: the first wave's shader-clock cycles in the read loop -- rest, validity, gather, probes, events)
         fprintf(stderr, "\n");
         memset(t, 0, sizeof t);
         PLAT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_asm_ticks), t, sizeof t));

@@ -164,3 +164,25 @@ def test_fused_lds_pass_equals_the_three_pass_path(eng, golden_dir):
         finally:
             os.environ.pop("PLAT_ASM_FUSED", None)
     assert out["1"] == out["0"] and sum(len(v) for v in out["1"]) > 300
+
+
+def test_walks_in_the_slice_equal_walks_in_lds(eng, golden_dir):
+    """Round 4: after the successors are picked the k-mer table's LDS holds an edge word per node, the bubble walks' stacks and their first
+    path elements, and the variants are extracted one finished path per thread.  PLAT_ASM_DEBUG=4 puts the stacks and all but 24 path
+    elements in the workgroup's slice of global memory (what a region with hundreds of bubble starts falls back to), 8 extracts the
+    variants with one thread (the fallback when the paths' bytes do not fit): the same variants in the same order, on the reference's
+    golden regions, fuzz regions and config-3 shaped regions with many sequencing-error branches."""
+    cases = json.load(gzip.open(os.path.join(golden_dir, "assembler_cases.json.gz"), "rt"))
+    regs = [to_region(c) for c in cases if c["noCycles"] == 0]
+    rng = np.random.default_rng(777)
+    regs += [synth_region(rng, int(rng.integers(300, 3000)), int(rng.choice([1, 2, 4])), int(rng.choice([100, 150, 250])), int(rng.integers(10, 60)), int(rng.integers(0, 7))) for _ in range(300)]
+    regs += [synth_region(rng, 4500, 2, 250, 60, 6) for _ in range(32)]                      # config-3 shape at twice the depth: more error branches
+    out = {}
+    for mode in ("", "4", "8", "12"):
+        if mode:
+            os.environ["PLAT_ASM_DEBUG"] = mode
+        try:
+            out[mode] = eng.assemble(regs, kmer_size=15, min_qual=20, min_weight=40, no_cycles=0)
+        finally:
+            os.environ.pop("PLAT_ASM_DEBUG", None)
+    assert out["4"] == out[""] and out["8"] == out[""] and out["12"] == out[""] and sum(len(v) for v in out[""]) > 300
