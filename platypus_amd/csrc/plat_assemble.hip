@@ -29,7 +29,12 @@
 // Measured on BASELINE config 3 (2000 tiles, PLAT_ASM_TIMING=1 prints the split): 84 k regions/s with the table in LDS but
 // three global atomics and two hash look-ups per event; 123 k with reference-first insertion + LDS reference + one look-up per
 // event; 141 k with the window loads; 174 k with one global atomic per event; 183 k with ordered ids; 214 k with the
-// first-claimed slot's weight in LDS; 246 k with the slot words kept clean between regions.  A region with more distinct k-mers than ASM_LDS_LIMIT (deep or very divergent data),
+// first-claimed slot's weight in LDS; 246 k with the slot words kept clean between regions.
+// Round 4 (the fused pass, see "LDS path, fused" below): k-mers and events of the reads in one pass 278 k; the edges that pass the
+// quality rule compacted before the probes 322 k; phases D-G on LDS (edge word per node in the table's space, walk stacks, path
+// elements, one thread per finished path) with 768 threads per workgroup -- the register budget decides: 1024 threads spill
+// 139-175 registers to slots that live in HBM -- and the claimed slots' end nodes in a dense array: 336 k, 1.19 GB of HBM traffic
+// per 2000 tiles (round 3: 4.76).  A region with more distinct k-mers than ASM_LDS_LIMIT (deep or very divergent data),
 // k > 15, or a reference / read blob beyond 2^18 bytes is done with table, node words and successor lists in the workgroup's
 // slice of a global scratch buffer (the "global path", the round-1 code).
 #include "plat_internal.hpp"

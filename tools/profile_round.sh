@@ -40,7 +40,7 @@ for p in $PARTS; do case $p in
         pmc seed_a "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES" python $R/bench.py $S
         pmc seed_b "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" python $R/bench.py $S
         pmc seed_c "SQ_LDS_BANK_CONFLICT SQ_LDS_ATOMIC_RETURN SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_WAVES SQ_LDS_ADDR_CONFLICT" python $R/bench.py $S
-        (cd $R && python tools/pmc_summary.py $O/seed_a $O/seed_b $O/seed_c 2>&1 | grep "k_seed \|k_dp_jobs\|k_prep" | tee $O/pmc_seed.txt) ;;
+        (cd $R && python tools/pmc_summary.py $O/seed_a $O/seed_b $O/seed_c 2>&1 | grep "plat::\|k_dp_jobs" | tee $O/pmc_seed.txt) ;;
   nextk) prof nextk python $R/tools/next_kernels.py ;;
   line) (cd $R
         python bench.py > $O/bench_line.json 2> $O/bench_line.err
@@ -58,6 +58,7 @@ esac; done
 cd $R
 python tools/profile_round_summary.py $O $TAG
 mkdir -p $O/out && cp profiles/${TAG}_* profiles/dp_traffic.json $O/out/ 2>/dev/null
+[ -s $O/pmc_seed.txt ] && { echo "# rocprofv3 --kernel-trace --pmc <C> (three passes: instruction mix | waits and busy | LDS) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --streams 1; mean per launch (SQ_*_CYCLES / ACTIVE / WAIT counters in units of 4 cycles)"; cat $O/pmc_seed.txt; } > $O/out/${TAG}_pmc_kernels.txt
 for f in $O/bench_*.json $O/soak_*.json; do [ -s "$f" ] && cp $f $O/out/${TAG}_$(basename $f); done     # the lines / soaks of THIS run
 find $O -name "*.csv" -size +1M -delete
 find $O -name "*.db" -size +1M -delete
