@@ -375,9 +375,9 @@ struct VarInfo {                                                          // vcf
     Num ABPV, SbPval, BRF, MQ, QD;
     long long TR = 0, NF = 0, NR = 0, TC = 0, TCR = 0, TCF = 0;
     int MMLQ = 100, HapScore = 0;
-    std::vector<int> nReadsPerSample, nVarReadsPerSample;
-    std::vector<std::string> Source;
-    std::vector<std::string> filters;                                     // vcfFilter[variant]
+    SmallVec<int, 4> nReadsPerSample, nVarReadsPerSample;
+    SmallVec<const char*, 4> Source;                                      // (string literals)
+    SmallVec<const char*, 8> filters;                                     // vcfFilter[variant] (string literals)
 };
 
 // chaplotype.pyx:462-498

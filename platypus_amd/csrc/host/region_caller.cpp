@@ -326,13 +326,14 @@ static void heapPushPop(std::vector<ScoredHap>& h, ScoredHap item) {
 }
 
 // ---- per-window and per-region working state ---------------------------------------------------------------------------------------
-struct Ptrs { int gs, ge, bs, be, ks, ke; };                               // window pointers of one sample: reads, badReads, brokenMates
+struct Ptrs { int gs, ge, bs, be, ks, ke; };
+typedef SmallVec<Ptrs, 2> PtrList;                                        // one per sample                               // window pointers of one sample: reads, badReads, brokenMates
 
 struct WindowWork {
     int region = 0, startPos = 0, endPos = 0;
     VarList vars;                                                          // window["variants"] (after filterVariantsByCoverage)
     VarList allVars;                                                       // the unfiltered list callVariantsInWindow keeps as `variants`
-    std::vector<Ptrs> ptrs;
+    PtrList ptrs;
     int nReads = 0;
     int hapStart = 0, hapEnd = 0, endBuf = 0;                              // Haplotype.startPos / endPos / endBufferSize
     std::string refSeq;                                                    // reference haplotype
@@ -348,7 +349,7 @@ struct WindowWork {
     std::vector<std::pair<int, int>> sampled;                              // (sample, local index in reads table)
     // results
     int bw = -1;                                                           // window index in the device batch
-    std::vector<Variant*> distinct;                                        // _distinctVariants
+    VarList distinct;                                                      // _distinctVariants
     std::vector<double> posterior;                                         // aligned with distinct
     VarList called;                                                        // variantPosteriors keys, in insertion order
     std::vector<double> calledPost;
@@ -376,7 +377,7 @@ struct RegionWork {
     const plat_region* in = nullptr;
     int index = 0;
     std::vector<Item> items;
-    std::vector<Ptrs> cur;                                                 // the samples' window pointers as the loop last left them (a REFCALL line's NR)
+    PtrList cur;                                                           // the samples' window pointers as the loop last left them (a REFCALL line's NR)
     VarList asmVariants;                                                   // assembler candidates, tile after tile (variantcaller.pyx:496-519)
     Fasta fa;
     int rlen = 0;
@@ -1090,7 +1091,7 @@ struct Chunk {
             r.windows.push_back(std::move(w));
         }
     }
-    static std::vector<int> snapshotNR(const std::vector<Ptrs>& ptrs) {
+    static std::vector<int> snapshotNR(const PtrList& ptrs) {
         std::vector<int> nr;
         for (const Ptrs& p : ptrs) nr.push_back(p.ge - p.gs);
         return nr;
@@ -1162,8 +1163,9 @@ struct Chunk {
         const int nVars = (int)w.vars.size();
         const double lg = log2((double)maxHaplotypes);
         if (nVars <= lg || (o.filterVarsByCoverage && o.maxVariants <= lg)) {
-            std::vector<Hap> haps;
-            std::vector<int> idx;
+            static thread_local std::vector<Hap> haps;                      // (storage reused from window to window of this thread)
+            haps.clear();
+            SmallVec<int, 8> idx;
             for (int n = 1; n <= nVars; ++n) {                             // itertools.combinations order
                 idx.resize((size_t)n);
                 for (int i = 0; i < n; ++i) idx[(size_t)i] = i;
@@ -1206,13 +1208,15 @@ struct Chunk {
 
     // mergeHaplotypes (variantcaller.pyx:325-383) over [reference haplotype] + haps; a window with one haplotype is not called
     void finishHaplotypes(RegionWork& r, WindowWork& w, std::vector<Hap>& haps) {
-        std::vector<Hap> all;
+        static thread_local std::vector<Hap> all;
+        all.clear();
         all.reserve(haps.size() + 1);
         Hap ref;
         ref.seq = w.refSeq;
         all.push_back(std::move(ref));
         for (Hap& h : haps) all.push_back(std::move(h));
-        std::vector<size_t> order(all.size());
+        SmallVec<size_t, 16> order;
+        order.resize(all.size());
         for (size_t i = 0; i < order.size(); ++i) order[i] = i;
         // (a stable sort: insertion sort for the handful of haplotypes a window has -- same order, no scratch buffer)
         if (order.size() <= 16) {
@@ -1224,6 +1228,7 @@ struct Chunk {
             }
         } else std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return all[a].seq < all[b].seq; });
         std::vector<Hap> merged;
+        merged.reserve(all.size());
         int last = -1;
         for (size_t k : order) {
             if (last < 0) { last = (int)k; continue; }
@@ -1487,7 +1492,7 @@ struct Chunk {
                 mtot += std::max(ngood, 1);
             }
             // call sites: varThisPosInHap / haplotypeIsRefAtThisPos per VCF position (vcfutils.pyx:400-426)
-            std::vector<std::pair<int, VarList>*> positions;
+            SmallVec<std::pair<int, VarList>*, 8> positions;
             for (auto& pv : w->byPos) positions.push_back(&pv);
             std::sort(positions.begin(), positions.end(), [](const std::pair<int, VarList>* a, const std::pair<int, VarList>* bb) { return a->first < bb->first; });
             w->firstSite = (int)kwin.size();
@@ -1656,7 +1661,7 @@ struct Chunk {
             }
         }
         // outputCallToVCF
-        std::vector<std::pair<int, VarList>*> positions;
+        SmallVec<std::pair<int, VarList>*, 8> positions;
         for (auto& pv : w.byPos) positions.push_back(&pv);
         std::sort(positions.begin(), positions.end(), [](const std::pair<int, VarList>* a, const std::pair<int, VarList>* b) { return a->first < b->first; });
         std::string& out = w.text;
@@ -1667,15 +1672,16 @@ struct Chunk {
             const VarList& variants = positions[pi]->second;
             const int nVariants = (int)variants.size();
             const size_t site = (size_t)w.firstSite + pi;
-            std::string ref;
-            std::vector<std::string> alt;
+            // (the record's lists live from record to record of this thread: their storage is reused)
+            static thread_local std::string ref;
+            static thread_local std::vector<std::string> alt, linefilter, FR, PP, sampleCols;
+            SmallVec<long long, 4> NF, NR, TR;
+            linefilter.clear(); FR.clear(); PP.clear(); sampleCols.clear();
             { PROF("text.record.refalt"); refAndAlt(POS, variants, r.fa, ref, alt); }
             VarInfo& lead = infoOf(variants[0]);
-            std::vector<std::string> linefilter, FR, PP;
-            std::vector<long long> NF, NR, TR;
             for (Variant* v : variants) {
                 VarInfo& d = infoOf(v);
-                for (const std::string& f : d.filters) linefilter.push_back(f);
+                for (const char* f : d.filters) linefilter.emplace_back(f);
                 FR.push_back(d.FRtext); PP.push_back(d.PP); NF.push_back(d.NF); NR.push_back(d.NR); TR.push_back(d.TR);
             }
             int qual = 0;
@@ -1684,7 +1690,6 @@ struct Chunk {
             // per-sample columns
             double maxGof = 0.0;
             int nNonRefCalls = 0;
-            std::vector<std::string> sampleCols;
             const int64_t NL = (int64_t)(nVariants + 1) * (nVariants + 2) / 2;
             for (int i = 0; i < nInd; ++i) {
                 PROF("text.record.samplecol");
@@ -1740,7 +1745,7 @@ struct Chunk {
             for (const std::string& c : sampleCols) bound += c.size() + 1;
             for (const std::string& t : FR) bound += t.size() + 1;
             for (const std::string& t : PP) bound += t.size() + 1;
-            for (const std::string& t : lead.Source) bound += t.size() + 1;
+            bound += 32;                                                       // Source: at most Platypus,Assembler,File
             const size_t at0 = out.size();
             out.resize(at0 + bound);
             char* p = &out[at0];
@@ -1754,7 +1759,7 @@ struct Chunk {
                 for (size_t q = 0; q < flt.size(); ++q) { if (q) *p++ = ';'; p = put_str(p, flt[q]); }
             }
             *p++ = '\t';
-            auto joinLL = [&p](const std::vector<long long>& v) { for (size_t q = 0; q < v.size(); ++q) { if (q) *p++ = ','; p = Num::I(v[q]).put(p); } };
+            auto joinLL = [&p](const SmallVec<long long, 4>& v) { for (size_t q = 0; q < v.size(); ++q) { if (q) *p++ = ','; p = Num::I(v[q]).put(p); } };
             auto joinS = [&p](const std::vector<std::string>& v) { for (size_t q = 0; q < v.size(); ++q) { if (q) *p++ = ','; p = put_str(p, v[q]); } };
             // INFO keys in sorted order: BRF FR HP HapScore MGOF MMLQ MQ NF NR PP QD SC SbPval Source TC TCF TCR TR WE WS
             p = put_lit(p, "BRF="); p = lead.BRF.put(p);
@@ -1770,7 +1775,7 @@ struct Chunk {
             p = put_lit(p, ";QD="); p = lead.QD.put(p);
             p = put_lit(p, ";SC="); p = put_str(p, lead.SC);
             p = put_lit(p, ";SbPval="); p = lead.SbPval.put(p);
-            p = put_lit(p, ";Source="); joinS(lead.Source);
+            p = put_lit(p, ";Source="); for (size_t q = 0; q < lead.Source.size(); ++q) { if (q) *p++ = ','; p = put_chars(p, lead.Source[q], strlen(lead.Source[q])); }
             p = put_lit(p, ";TC="); p = Num::I(lead.TC).put(p);
             p = put_lit(p, ";TCF="); p = Num::I(lead.TCF).put(p);
             p = put_lit(p, ";TCR="); p = Num::I(lead.TCR).put(p);

@@ -16,6 +16,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
+#include <initializer_list>
+#include <new>
+#include <type_traits>
+#include <utility>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -83,7 +88,61 @@ inline bool variantLess(const Variant* a, const Variant* b) {
     if (a->varType != b->varType) return a->varType < b->varType;
     return a->nRemoved < b->nRemoved;
 }
-typedef std::vector<Variant*> VarList;
+// A vector of trivially copyable elements whose first N live inside the object: the loop's lists of variants hold one to three elements
+// (a window's variants, a haplotype's, the variants at a position) and were a heap allocation each -- a third of the host's cycles per
+// region went to new / delete.  The subset of std::vector's interface the host uses, same semantics.
+template <class T, int N> struct SmallVec {
+    static_assert(std::is_trivially_copyable<T>::value, "SmallVec holds plain values");
+    typedef T value_type; typedef T* iterator; typedef const T* const_iterator;
+    T* p; uint32_t n, cap; T inl[N];
+    SmallVec() : p(inl), n(0), cap(N) {}
+    SmallVec(std::initializer_list<T> l) : SmallVec() { append(l.begin(), l.end()); }
+    SmallVec(const SmallVec& o) : SmallVec() { append(o.begin(), o.end()); }
+    SmallVec(SmallVec&& o) noexcept : SmallVec() { take(o); }
+    template <class It> SmallVec(It a, It b) : SmallVec() { append(a, b); }
+    ~SmallVec() { if (p != inl) free(p); }
+    SmallVec& operator=(const SmallVec& o) { if (this != &o) { n = 0; append(o.begin(), o.end()); } return *this; }
+    SmallVec& operator=(SmallVec&& o) noexcept { if (this != &o) { if (p != inl) free(p); p = inl; n = 0; cap = N; take(o); } return *this; }
+    void take(SmallVec& o) {
+        if (o.p != o.inl) { p = o.p; n = o.n; cap = o.cap; o.p = o.inl; o.n = 0; o.cap = N; }
+        else { memcpy(inl, o.inl, sizeof(T) * o.n); n = o.n; o.n = 0; }
+    }
+    void reserve(size_t c) {
+        if (c <= cap) return;
+        size_t nc = cap * 2 > c ? cap * 2 : c;
+        T* q = (T*)malloc(nc * sizeof(T));
+        if (!q) throw std::bad_alloc();
+        memcpy(q, p, sizeof(T) * n);
+        if (p != inl) free(p);
+        p = q; cap = (uint32_t)nc;
+    }
+    template <class It> void append(It a, It b) { const size_t m = (size_t)(b - a); reserve(n + m); for (size_t i = 0; i < m; ++i) p[n + i] = a[i]; n += (uint32_t)m; }
+    template <class It> void insert(const_iterator pos, It a, It b) {
+        const size_t at = (size_t)(pos - p), m = (size_t)(b - a);
+        reserve(n + m);
+        memmove(p + at + m, p + at, sizeof(T) * (n - at));
+        for (size_t i = 0; i < m; ++i) p[at + i] = a[i];
+        n += (uint32_t)m;
+    }
+    void push_back(const T& v) { if (n == cap) reserve((size_t)n + 1); p[n++] = v; }
+    template <class... A> T& emplace_back(A&&... a) { push_back(T(std::forward<A>(a)...)); return p[n - 1]; }
+    void pop_back() { --n; }
+    void clear() { n = 0; }
+    void resize(size_t m) { reserve(m); for (size_t i = n; i < m; ++i) p[i] = T(); n = (uint32_t)m; }
+    void resize(size_t m, const T& v) { reserve(m); for (size_t i = n; i < m; ++i) p[i] = v; n = (uint32_t)m; }
+    void assign(size_t m, const T& v) { n = 0; resize(m, v); }
+    template <class It> void assign(It a, It b) { n = 0; append(a, b); }
+    void swap(SmallVec& o) { SmallVec t(std::move(o)); o = std::move(*this); *this = std::move(t); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T* data() { return p; } const T* data() const { return p; }
+    T* begin() { return p; } T* end() { return p + n; }
+    const T* begin() const { return p; } const T* end() const { return p + n; }
+    T& operator[](size_t i) { return p[i]; } const T& operator[](size_t i) const { return p[i]; }
+    T& back() { return p[n - 1]; } const T& back() const { return p[n - 1]; }
+    T& front() { return p[0]; } const T& front() const { return p[0]; }
+};
+typedef SmallVec<Variant*, 6> VarList;
 inline bool contains(const VarList& vs, const Variant* v) {
     for (const Variant* x : vs) if (x == v || x->same(*v)) return true;
     return false;

@@ -5,6 +5,7 @@ config-2 line), and the default run carries a compact summary of each under `oth
     config 4  the region pipeline: reads in host memory -> VCF text, windows/s end to end
     config 5  population mode: 100 samples per window, likelihoods + genotype likelihoods + EM, GCUPS and windows/s
 """
+import json
 import os
 import sys
 import time
@@ -163,6 +164,7 @@ def line_config3(a, rk):
     r = config3(eng, nreg, steps, a.warmup, seed=3003 + rank, rk=rk)
     T, (regs,) = rk.reduce(r["T"], [nreg * steps])
     ach = r["alg_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9
+    traffic, traffic_source = _asm_traffic(nreg)
     return {"metric": "assembly tiles/s (assembleReadsAndDetectVariants, coloured de-Bruijn graph + bubble walk)", "value": regs / T,
             "unit": "regions/s", "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": 1e3 * T / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -172,8 +174,9 @@ def line_config3(a, rk):
             "variants_found": r["variants"], "variants_planted": r["planted"],
             "end_to_end": None if a.no_extras else {k: v for k, v in config3_end_to_end(rk.dev_index, nreg, rk=rk, first=rank * nreg).items() if k != "text"},
             "roofline": {"bound": "hbm", "kernel": "k_assemble", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": r["alg_bytes"],
-                         "avg_launch_ms": r["kernel_ms"]}}
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": r["alg_bytes"], "avg_launch_ms": r["kernel_ms"],
+                         "note": "vector issue + LDS round trips at 3 waves per SIMD (768-thread workgroups: the graph takes the CU's LDS), see DESIGN.md section 4"}}
 
 
 def run(a, rk):
@@ -356,6 +359,19 @@ def config4_cpu_baseline(seconds=10.0):
         return {"error": repr(exc)[:200]}
 
 
+def _asm_traffic(nreg):
+    """(bytes per launch, where from) of k_assemble out of profiles/dp_traffic.json -- counters need rocprofv3 around the process, so the
+    figure of the last profiled run is quoted (scaled to this launch's regions), never measured here."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "dp_traffic.json")))["k_assemble"]
+        per = float(d["hbm_bytes_per_launch"]) / float(d["regions_per_launch"])
+        m = d.get("measured", {})
+        return int(per * nreg), "not measured in this run: profiles/dp_traffic.json <- profiles/r%02d_pmc_assemble.txt (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, %d tiles per launch); collected %s at commit %s" % (
+            int(m.get("round", 0)), int(d["regions_per_launch"]), m.get("date"), m.get("commit"))
+    except Exception:
+        return None, None
+
+
 def _roof(kernel, alg_bytes, ms, note=None):
     ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     d = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
@@ -392,7 +408,7 @@ def summary(eng):
     e2e = {k: v for k, v in config3_end_to_end(0, nt).items() if k != "text"}
     out["config3_assembler"] = dict(regions=nt, reads=int(r["ab"]["n_reads"]), regions_per_sec=nt * r["steps"] / r["T"],
                                     kernel_ms=r["kernel_ms"], variants_found=r["variants"], variants_planted=r["planted"],
-                                    roofline=_roof("k_assemble", r["alg_bytes"], r["kernel_ms"], "latency bound at 4 waves per SIMD, see DESIGN.md"),
+                                    roofline=_roof("k_assemble", r["alg_bytes"], r["kernel_ms"], "vector issue + LDS round trips at 3 waves per SIMD, see DESIGN.md"),
                                     end_to_end=e2e)
     nreg = int(os.environ.get("PLAT_BENCH_CONFIG4_REGIONS", "3875"))           # one GPU's share of the 31 000 regions (SURVEY 8(d) cfg 4)
     try:
