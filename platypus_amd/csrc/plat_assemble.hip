@@ -46,7 +46,7 @@ constexpr int ASM_MAX_SUCC = 8;        // distinct successor bytes tracked per n
 constexpr int ASM_MAX_TASKS = 512;     // bubble-start (node, edge) pairs per region
 constexpr int ASM_POOL = 1 << 20;      // path elements per region, shared by its tasks (bump-allocated)
 constexpr int ASM_MAX_FIN = 21;        // finished paths per task before the reference aborts (assembler.pyx:1052)
-constexpr int ASM_THREADS = 768;       // threads per workgroup (one workgroup per CU: the graph takes most of the LDS)
+constexpr int ASM_THREADS = 1024;      // threads per workgroup (one workgroup per CU: the graph takes most of the LDS)
 constexpr int ASM_LDS_SLOTS = 16384;   // k-mer table in LDS: 64 KB
 constexpr int ASM_LDS_NODES = 11264;   // per-node first-touch codes and (weight | colour << 30) words in LDS: 2 x 44 KB
 constexpr int ASM_LDS_LIMIT = ASM_LDS_NODES - ASM_THREADS;   // distinct k-mers the LDS path takes (threads in flight may overshoot by one each)
@@ -461,10 +461,18 @@ __device__ __forceinline__ void asm_sync() {
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
+// workgroup barrier alone (it carries the workgroup-scope release / acquire): for the phase boundaries where what the next phase reads
+// from global memory was written with PLAIN stores by this workgroup (or is input) -- a CU's waves share its vector L1, which is
+// write-through, so nothing can be stale.  The agent-scope invalidate above empties that L1 -- the next phase then fetches everything
+// again from L2, its spilled registers included -- and with ~25 boundaries per region that was a quarter of the kernel's time: it stays
+// only where words updated by L2 ATOMICS are read back by plain loads (the slot words before phase D; every boundary of the
+// three-pass and global paths).
+__device__ __forceinline__ void asm_sync_wg() { __syncthreads(); }
 
 // measurement only (PLAT_ASM_TIMING=1): 100 MHz ticks the first thread of every workgroup spent up to each phase boundary, summed
 __device__ unsigned long long g_asm_ticks[16];
-#define ASM_TICK(i) do { if (P.timing && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_asm_ticks[i], now_ - tick_); tick_ = now_; } } while (0)
+#define ASM_FRESH() asm volatile("" : "+v"(tid))
+#define ASM_TICK(i) do { ASM_FRESH(); if (P.timing && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_asm_ticks[i], now_ - tick_); tick_ = now_; } } while (0)
 
 __global__ void __launch_bounds__(ASM_THREADS)
 k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int max_reads, int32_t* var_count,
@@ -477,7 +485,10 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
     unsigned* s_wc = s_first + ASM_LDS_NODES;                    // [ASM_LDS_NODES] weight | colour << 30
     unsigned long long* s_ref = (unsigned long long*)(s_wc + ASM_LDS_NODES);   // [ASM_REF_CACHE / 8] the region's reference bytes
     __shared__ int s_wsum[64];
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    // (`tid` is made opaque at every phase boundary -- ASM_TICK -- so that what the compiler derives from it, 64-bit per-thread offsets of
+    //  every strided loop, is recomputed per phase instead of being held, and spilled, across the whole kernel)
+    int tid = threadIdx.x;
+    const int nthr = blockDim.x;
     AsmScratch S = asm_carve(scratch + (size_t)blockIdx.x * P.scratch_per_block, P.cap, P.max_pos, max_ref, max_reads);
     const int capmask = P.cap - 1;
     unsigned long long tick_ = P.timing ? wall_clock64() : 0ull;
@@ -505,7 +516,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
         if (refc)
             for (int i = tid; 8 * i < refLen + 16; i += nthr) s_ref[i] = asm_ld8(ref + 8 * i);
         const long long blobLen = nR > 0 ? b.read_off[rb + nR] - rblob0 : 0;
-        asm_sync();
+        asm_sync_wg(); ASM_FRESH();
 
         // Fast path of the phases after the graph is built (round 4; fused LDS path, noCycles off): the k-mer table is not needed once the
         // successors are picked, so its 64 KB take (a) ONE WORD PER NODE -- end node | weight >= min_weight << 14 | number of out-edges << 15
@@ -516,6 +527,8 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
         // Layout of the table's words on the fast path: [0, nNodes) edge words, then one finished-path count per task, then the tasks' stacks
         // of pending path elements (when they fit: else in the slice), then path elements (node, parent, depth) up to the table's end.
         bool fast = false, ldsStk = false;
+        bool relax = false;                                  // the fused LDS path is running: phase boundaries without the L1 invalidate (asm_sync_wg)
+        auto sync_phase = [&]() { if (relax) asm_sync_wg(); else asm_sync(); };
         int* const s_edge = s_tab;
         int* s_tnfin = s_tab; int* s_stk = s_tab; int* s_arena = s_tab;
         int arenaCap = 0;
@@ -560,13 +573,13 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     acc += L - k - 1 > 0 ? L - k - 1 : 0;
                 }
             }
-            asm_sync();
+            asm_sync_wg(); ASM_FRESH();
             ASM_TICK(0);
             const int nReadE = S.read_base[nR];
             const int nEv = nRefE + nReadE;
             if ((long long)nEv + 2ll * (nR + 1) > (long long)P.max_pos) {                       // distinct k-mers <= occurrences
                 if (tid == 0) s_err = PLAT_ERR_OVERFLOW;
-                asm_sync();
+                asm_sync(); ASM_FRESH();
                 break;
             }
             // every AddEdge event: the reference's edges one per thread, then the reads one per wave at a time (lanes over the read's
@@ -585,13 +598,13 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     }
                 }
             };
-            const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
             // LDS path: the edges of the reads, one read per wave at a time.  A window of 256 bytes of the read's bases and one of its
             // qualities are loaded one aligned dword per lane; the lanes then take the window's edges in rounds of 64, each gathering
             // its k+1 bytes from the other lanes.  stage1(i, ro, E, w) -> tag >= 0 for every valid edge; stage2(ticket offset, ro + i,
             // E, w, tag, tag of the next edge or -1) after the wave has exchanged tags; skipped(ticket offset) for a filtered edge.
             auto read_pass = [&](auto KWc, auto&& stage1, auto&& stage2, auto&& skipped, auto&& stop) {
                 constexpr int KW = decltype(KWc)::value;
+                const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
                 constexpr int WIN = 4 * (64 - 2 * KW) - 3;     // edges per window: the last one still finds its 2 KW + 1 dwords in lanes <= 63
                 // A wave's reads are a chain of dependent round trips (the read's offsets, then its bytes): the offsets of the read after
                 // next and the first window of the next read are requested before the current read is worked on.
@@ -663,11 +676,13 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             //      kept (one global atomicMin) for every slot but a reference-claimed LDS slot, whose ticket no read can lower;
             //   4. phase D picks the successors from those tickets: no pass over the events, no event words for the reads at all.
             bool fused_done = false;
+            relax = false;
             if (P.fused && s_lds) {
+                relax = true;
                 for (int i = tid; i < ASM_LDS_SLOTS; i += nthr) s_tab[i] = -1;
                 for (int i = tid; i < ASM_LDS_NODES; i += nthr) { s_first[i] = 0xFFFFFFFFu; s_wc[i] = 0u; }
                 if (tid == 0) { s_distinct = 0; s_nrefnodes = 0; s_nreadnodes = 0; }
-                asm_sync();
+                asm_sync_wg(); ASM_FRESH();
                 int* ev = S.stack;                        // one word per REFERENCE edge (slot of its start k-mer | 1 << 14 | base << 22 | end flag << 30)
                 int* ev_end = S.stack + P.max_pos;
                 constexpr int KW = 2;
@@ -681,7 +696,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     }
                     ev[e] = word;
                 }
-                asm_sync();
+                asm_sync_wg(); ASM_FRESH();
                 // the reference's nodes in the order of their representatives along the reference (ids 0 .. nRefNodes0 - 1)
                 const int refBytes = ((refLen + 16 + 7) >> 3) << 3, nW32 = (refLen >> 5) + 1;
                 const bool ordered = refc && refBytes + 8 * nW32 <= ASM_REF_CACHE && nW32 <= nthr;
@@ -763,11 +778,12 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         own_n[sn] = en;
                     } else global_slot(sn, slot, 1, e, en);
                 }
-                asm_sync();
+                asm_sync_wg(); ASM_FRESH();
                 ASM_TICK(1);
                 // 3. the reads
                 bool bad = false;
                 {
+                    const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
                     // A wave takes one read at a time; a window of 256 bytes of its bases and of its qualities is held one aligned dword per
                     // lane (as in read_pass).  The window's edges are worked FOUR ROUNDS OF 64 AT ONCE: the kernel is bound by chains of LDS
                     // round trips (gather -> table -> representative -> node words), and four independent chains per lane share each wait.
@@ -982,7 +998,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
 #undef ASM_SEC
                 }
                 if (bad) s_err = PLAT_ERR_UNSUPPORTED;
-                asm_sync();
+                asm_sync_wg(); ASM_FRESH();
                 if (nRefNodes0 + s_nreadnodes > ASM_LDS_LIMIT) {
                     // more nodes than the LDS takes: leave the global slot words clean and take the global path
                     for (int n = tid; n < ASM_LDS_NODES; n += nthr) {
@@ -992,11 +1008,12 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     }
                     __syncthreads();
                     if (tid == 0) s_lds = 0;
+                    relax = false;
                 } else {
                     if (tid == 0) s_n = nRefNodes0 + s_nreadnodes;
                     fused_done = true;
                 }
-                asm_sync();
+                asm_sync(); ASM_FRESH();
                 ASM_TICK(2);
             }
             bool failed = false;
@@ -1008,7 +1025,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     if ((long long)nEv * 4 > (long long)P.cap * 3) { failed = true; break; }
                     for (int i = tid; i < P.cap; i += nthr) S.key[i] = -1;
                 }
-                asm_sync();
+                asm_sync(); ASM_FRESH();
                 if (lds) {
                     // every edge leaves a word for phase C: table slot of its start k-mer | weight << 14 | appended base << 22 |
                     // (its end k-mer was inserted by this edge and its slot is in ev_end) << 30;  -1 for a filtered edge
@@ -1055,7 +1072,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         return true;
                     });
                 }
-                asm_sync();
+                asm_sync(); ASM_FRESH();
                 if (!lds || s_distinct <= ASM_LDS_LIMIT) break;
                 __syncthreads();
                 if (tid == 0) s_lds = 0;                                    // more distinct k-mers than the LDS table takes: global table
@@ -1063,7 +1080,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             }
             if (failed) {
                 if (tid == 0) s_err = PLAT_ERR_OVERFLOW;
-                asm_sync();
+                asm_sync(); ASM_FRESH();
                 break;
             }
             ASM_TICK(1);
@@ -1132,7 +1149,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 for (int sidx = tid; sidx < P.cap; sidx += nthr)
                     if (S.key[sidx] != -1) { const int id = atomicAdd(&s_n, 1); S.slot_id[sidx] = id; init_node(id, S.key[sidx]); }
             }
-            asm_sync();
+            asm_sync(); ASM_FRESH();
             ASM_TICK(2);
             const int nNodes = s_n;
             // ---- phase C: AddEdge events (assembler.pyx:801-827)
@@ -1240,12 +1257,12 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 S.succ_n[sn * ASM_MAX_SUCC + slot] = en;
                 return true;
             });
-            asm_sync();
+            asm_sync(); ASM_FRESH();
             ASM_TICK(3);
             fast = lds && fused_done && !P.no_cycles;
             if (lds && !fast) {                                               // the node words the later phases read, to the slice
                 for (int n = tid; n < nNodes; n += nthr) { S.first[n] = s_first[n]; if (!fused_done) S.weight[n] = 0; S.colour[n] = (int)(s_wc[n] >> 30); }
-                asm_sync();
+                asm_sync(); ASM_FRESH();
             }
             ASM_TICK(9);
             // ---- phase D: per node, the four successors with the smallest first tickets, in ticket order
@@ -1261,7 +1278,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         if (!fused_done) for (int j = 0; j < ASM_MAX_SUCC; ++j) S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu;
                     }
                 }
-                asm_sync();
+                sync_phase(); ASM_FRESH();
                 ASM_TICK(10);
                 if (!fused_done) {                                  // (the fused pass kept the first tickets as it went)
                     const int* ev = S.stack;
@@ -1283,7 +1300,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                       }
                     }
                 }
-                asm_sync();
+                asm_sync(); ASM_FRESH();
                 auto pick_edges = [&](auto KWc) {
                     constexpr int KW = decltype(KWc)::value;
                     for (int n = tid; n < nNodes; n += nthr) {
@@ -1424,7 +1441,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 if (n < ASM_LDS_NODES)                              // the LDS path of the regions that follow expects these words clean
                     for (int j = 0; j < ASM_MAX_SUCC; ++j) { S.succ_cw[n * ASM_MAX_SUCC + j] = 0ull; S.succ_c[n * ASM_MAX_SUCC + j] = 0; S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu; }
             }
-            asm_sync();
+            sync_phase(); ASM_FRESH();
             ASM_TICK(4);
             // ---- noCycles: detectCyclesInGraph_Recursive (assembler.pyx:831-898), iterative, one thread
             if (P.no_cycles) {
@@ -1455,7 +1472,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     s_cycle = cyc;
                     if (cyc && k <= 50) s_k = k + 5;
                 }
-                asm_sync();
+                asm_sync(); ASM_FRESH();
                 if (s_cycle && k <= 50) continue;          // rebuild with a longer k
                 if (s_cycle) break;                        // k > 50 and still cyclic: no variants (assembler.pyx:1454-1457)
             }
@@ -1489,7 +1506,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     __syncthreads();
                 }
             }
-            asm_sync();
+            sync_phase(); ASM_FRESH();
             ASM_TICK(6);
             const int nTasks = s_ntasks;
             arenaCap = 0; ldsStk = false;
@@ -1553,11 +1570,11 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 S.task_nfin[t] = aborted ? 0 : nfin;
                 if (fast) s_tnfin[t] = aborted ? 0 : nfin;
             }
-            asm_sync();
+            sync_phase(); ASM_FRESH();
             ASM_TICK(7);
             break;
         }
-        asm_sync();
+        sync_phase(); ASM_FRESH();
 
         // ---- phase G/H: variants in emission order, then the stable sort of sorted(theVars) (assembler.pyx:1476)
         int32_t* vp = var_pos + (size_t)g * P.max_vars; int32_t* vr = var_nrem + (size_t)g * P.max_vars;
@@ -1593,7 +1610,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             const int pbase = asm_block_exscan(mynf, s_wsum, NP);
             int* plast = S.stack; int* ptask = S.stack + NP;
             for (int f = 0; f < mynf; ++f) { plast[pbase + f] = S.task_fin[tid * ASM_MAX_FIN + f]; ptask[pbase + f] = tid; }
-            asm_sync();
+            asm_sync_wg(); ASM_FRESH();
             uint8_t* pbytes = (uint8_t*)(S.stack + 2 * NP);
             const long long pcap = (long long)asm_stack_ints(P.max_pos) * 4 - 8ll * NP;
             int nvBase = 0, blobBase = 0, err = err0;
@@ -1622,7 +1639,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 nvBase += totv; blobBase += totb;
                 __syncthreads();                                                  // (the bytes of this chunk are done with)
             }
-            asm_sync();
+            asm_sync_wg(); ASM_FRESH();
             if (!fallback) {
                 serialG = false;
                 if (tid == 0) { s_nv = err ? 0 : nvBase; s_err = err; }
@@ -1647,7 +1664,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             }
             s_nv = err ? 0 : nv; s_err = err;
         }
-        asm_sync();
+        sync_phase(); ASM_FRESH();
         if (tid == 0) {
             const int nv = s_nv, err = s_err;
             // stable insertion sort by (pos, varType, nRemoved)  (Variant.__richcmp__ '<', variant.pyx:282-363)
@@ -1665,7 +1682,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
         }
         if (s_lds == 0)                                   // a region done on the global path has written successor bytes of low node ids
             for (int i = tid; i < ASM_LDS_NODES * ASM_MAX_SUCC; i += nthr) S.succ_c[i] = 0;
-        asm_sync();
+        sync_phase(); ASM_FRESH();
         ASM_TICK(8);
     }
 }

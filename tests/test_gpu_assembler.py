@@ -186,3 +186,20 @@ def test_walks_in_the_slice_equal_walks_in_lds(eng, golden_dir):
         finally:
             os.environ.pop("PLAT_ASM_DEBUG", None)
     assert out["4"] == out[""] and out["8"] == out[""] and out["12"] == out[""] and sum(len(v) for v in out[""]) > 300
+
+
+def test_a_dozen_regions_per_workgroup_fused_equals_three_pass(eng):
+    """The fused LDS path leaves the L1 invalidate out of the phase boundaries where only plainly stored words are read back (a workgroup
+    barrier is enough inside a CU) and keeps it where words updated by L2 atomics are read by plain loads; the three-pass path keeps it at
+    every boundary.  3 000 regions in one launch = a dozen regions after one another on every workgroup, whose slices and LDS still hold
+    the region before: the same variants from both paths."""
+    rng = np.random.default_rng(90210)
+    regs = [synth_region(rng, int(rng.integers(300, 1300)), 2, int(rng.choice([100, 150])), int(rng.integers(8, 30)), int(rng.integers(0, 5))) for _ in range(3000)]
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["PLAT_ASM_FUSED"] = mode
+        try:
+            out[mode] = eng.assemble(regs, kmer_size=15, min_qual=20, min_weight=40, no_cycles=0)
+        finally:
+            os.environ.pop("PLAT_ASM_FUSED", None)
+    assert out["1"] == out["0"] and sum(len(v) for v in out["1"]) > 2000
