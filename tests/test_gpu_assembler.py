@@ -194,7 +194,7 @@ def test_a_dozen_regions_per_workgroup_fused_equals_three_pass(eng):
     every boundary.  3 000 regions in one launch = a dozen regions after one another on every workgroup, whose slices and LDS still hold
     the region before: the same variants from both paths."""
     rng = np.random.default_rng(90210)
-    regs = [synth_region(rng, int(rng.integers(300, 1300)), 2, int(rng.choice([100, 150])), int(rng.integers(8, 30)), int(rng.integers(0, 5))) for _ in range(3000)]
+    regs = [synth_region(rng, int(rng.integers(400, 1300)), 2, int(rng.choice([100, 150])), int(rng.integers(8, 30)), int(rng.integers(0, 5))) for _ in range(3000)]
     out = {}
     for mode in ("1", "0"):
         os.environ["PLAT_ASM_FUSED"] = mode
