@@ -32,9 +32,10 @@
 // first-claimed slot's weight in LDS; 246 k with the slot words kept clean between regions.
 // Round 4 (the fused pass, see "LDS path, fused" below): k-mers and events of the reads in one pass 278 k; the edges that pass the
 // quality rule compacted before the probes 322 k; phases D-G on LDS (edge word per node in the table's space, walk stacks, path
-// elements, one thread per finished path) with 768 threads per workgroup -- the register budget decides: 1024 threads spill
-// 139-175 registers to slots that live in HBM -- and the claimed slots' end nodes in a dense array: 336 k, 1.19 GB of HBM traffic
-// per 2000 tiles (round 3: 4.76).  A region with more distinct k-mers than ASM_LDS_LIMIT (deep or very divergent data),
+// elements, one thread per finished path) and the claimed slots' end nodes in a dense array 336 k (768 threads: at 1024 the kernel
+// spilled 139-175 registers to slots that live in HBM); phase boundaries without the L1 invalidate where only plainly stored words
+// are read back (asm_sync_wg) 404 k; per-thread values re-derived per phase + no machine LICM (32 spilled registers) and 1024
+// threads again: 449-458 k, 1.10 GB of HBM traffic per 2000 tiles (round 3: 4.76).  A region with more distinct k-mers than ASM_LDS_LIMIT (deep or very divergent data),
 // k > 15, or a reference / read blob beyond 2^18 bytes is done with table, node words and successor lists in the workgroup's
 // slice of a global scratch buffer (the "global path", the round-1 code).
 #include "plat_internal.hpp"
@@ -46,7 +47,7 @@ constexpr int ASM_MAX_SUCC = 8;        // distinct successor bytes tracked per n
 constexpr int ASM_MAX_TASKS = 512;     // bubble-start (node, edge) pairs per region
 constexpr int ASM_POOL = 1 << 20;      // path elements per region, shared by its tasks (bump-allocated)
 constexpr int ASM_MAX_FIN = 21;        // finished paths per task before the reference aborts (assembler.pyx:1052)
-constexpr int ASM_THREADS = 1024;      // threads per workgroup (one workgroup per CU: the graph takes most of the LDS)
+constexpr int ASM_THREADS = 1024;      // threads per workgroup (one workgroup per CU: the graph takes the LDS) = 128 registers per lane: see the Makefile's note on spills
 constexpr int ASM_LDS_SLOTS = 16384;   // k-mer table in LDS: 64 KB
 constexpr int ASM_LDS_NODES = 11264;   // per-node first-touch codes and (weight | colour << 30) words in LDS: 2 x 44 KB
 constexpr int ASM_LDS_LIMIT = ASM_LDS_NODES - ASM_THREADS;   // distinct k-mers the LDS path takes (threads in flight may overshoot by one each)
