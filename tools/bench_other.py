@@ -176,7 +176,7 @@ def line_config3(a, rk):
             "roofline": {"bound": "hbm", "kernel": "k_assemble", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": r["alg_bytes"], "avg_launch_ms": r["kernel_ms"],
-                         "note": "vector issue + LDS round trips at 3 waves per SIMD (768-thread workgroups: the graph takes the CU's LDS), see DESIGN.md section 4"}}
+                         "note": "vector issue + LDS round trips at 4 waves per SIMD (one 1024-thread workgroup per CU: the graph takes the CU's LDS), see DESIGN.md section 4"}}
 
 
 def run(a, rk):
@@ -408,7 +408,7 @@ def summary(eng):
     e2e = {k: v for k, v in config3_end_to_end(0, nt).items() if k != "text"}
     out["config3_assembler"] = dict(regions=nt, reads=int(r["ab"]["n_reads"]), regions_per_sec=nt * r["steps"] / r["T"],
                                     kernel_ms=r["kernel_ms"], variants_found=r["variants"], variants_planted=r["planted"],
-                                    roofline=_roof("k_assemble", r["alg_bytes"], r["kernel_ms"], "vector issue + LDS round trips at 3 waves per SIMD, see DESIGN.md"),
+                                    roofline=_roof("k_assemble", r["alg_bytes"], r["kernel_ms"], "vector issue + LDS round trips at 4 waves per SIMD, see DESIGN.md"),
                                     end_to_end=e2e)
     nreg = int(os.environ.get("PLAT_BENCH_CONFIG4_REGIONS", "3875"))           # one GPU's share of the 31 000 regions (SURVEY 8(d) cfg 4)
     try:
