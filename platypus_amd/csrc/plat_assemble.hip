@@ -54,6 +54,7 @@ constexpr int ASM_LDS_LIMIT = ASM_LDS_NODES - ASM_THREADS;   // distinct k-mers 
 constexpr int ASM_REF_CACHE = 7552;    // bytes of the region's reference kept in LDS (k-mers of reads are compared with their representative, which is a
                                        // reference k-mer whenever the reference holds one: the reference's k-mers are inserted first)
 constexpr int ASM_LDS_BYTES = (ASM_LDS_SLOTS + 2 * ASM_LDS_NODES) * 4 + ASM_REF_CACHE;
+constexpr int ASM_PATH = 64;           // nodes of the walk's current path kept as an array (16 bits each) for the cycle check; deeper paths walk the parent links
 constexpr int ASM_STK = 28;            // pending path elements per bubble walk (the reference aborts a walk with more than 20, assembler.pyx:1052-1057)
 constexpr int ASM_OFF_BITS = 18;       // LDS path: a table slot packs (node id << 18 | byte offset of the representative)
 static_assert(ASM_LDS_NODES < ASM_LDS_SLOTS * 3 / 4, "the table must stay sparse");
@@ -527,11 +528,11 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
         // costs ~0.1 us instead of a global round trip.
         // Layout of the table's words on the fast path: [0, nNodes) edge words, then one finished-path count per task, then the tasks' stacks
         // of pending path elements (when they fit: else in the slice), then path elements (node, parent, depth) up to the table's end.
-        bool fast = false, ldsStk = false;
+        bool fast = false, ldsStk = false, ldsPath = false;
         bool relax = false;                                  // the fused LDS path is running: phase boundaries without the L1 invalidate (asm_sync_wg)
         auto sync_phase = [&]() { if (relax) asm_sync_wg(); else asm_sync(); };
         int* const s_edge = s_tab;
-        int* s_tnfin = s_tab; int* s_stk = s_tab; int* s_arena = s_tab;
+        int* s_tnfin = s_tab; int* s_stk = s_tab; int* s_path = s_tab; int* s_arena = s_tab;
         int arenaCap = 0;
         auto colour_of = [&](int n) -> int { return fast ? (int)(s_wc[n] >> 30) : S.colour[n]; };
         auto first_of = [&](int n) -> unsigned { return fast ? s_first[n] : S.first[n]; };
@@ -1510,13 +1511,16 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             sync_phase(); ASM_FRESH();
             ASM_TICK(6);
             const int nTasks = s_ntasks;
-            arenaCap = 0; ldsStk = false;
+            arenaCap = 0; ldsStk = false; ldsPath = false;
             if (fast) {
                 s_tnfin = s_tab + nNodes;
                 s_stk = s_tnfin + nTasks;
                 ldsStk = nNodes + nTasks + ASM_STK * nTasks + 3 * 256 <= ASM_LDS_SLOTS;
-                if (P.debug & 4) ldsStk = false;                                      // (tests: the stacks in the slice ...
-                s_arena = ldsStk ? s_stk + ASM_STK * nTasks : s_stk;
+                if (P.debug & 4) ldsStk = false;                                      // (tests: the stacks in the slice, no path arrays ...
+                // ... and (when they fit too) the walks' current paths, 16 bytes aligned for the vector loads of the cycle check
+                s_path = s_tab + ((nNodes + nTasks + ASM_STK * nTasks + 3) & ~3);
+                ldsPath = ldsStk && (int)(s_path - s_tab) + (ASM_PATH / 2) * nTasks + 3 * 256 <= ASM_LDS_SLOTS;
+                s_arena = ldsPath ? s_path + (ASM_PATH / 2) * nTasks : (ldsStk ? s_stk + ASM_STK * nTasks : s_stk);
                 arenaCap = (int)((s_tab + ASM_LDS_SLOTS - s_arena) / 3);
                 if (P.debug & 4) arenaCap = arenaCap < 24 ? arenaCap : 24;           //  ... and all but a few path elements in the global arena)
             }
@@ -1525,6 +1529,11 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 // (the stack of pending elements in LDS, or in the slice: a local array indexed by `top` would live in scratch memory,
                 //  a global round trip for every push and pop)
                 int* const stk = ldsStk ? s_stk + ASM_STK * t : S.stack + ASM_STK * t;
+                // The nodes of the CURRENT path by depth (pn[d], d = 1 .. ASM_PATH - 1).  The walk pops last-pushed-first, so between
+                // the expansion of an element of depth d - 1 and the pop of one of its children only elements of depth >= d are popped:
+                // when an element of depth d is popped, pn[1 .. d - 1] are its ancestors.  checkPathForCycles is then a scan of that
+                // array -- loads that do not depend on each other -- instead of a chain of parent links, one LDS round trip each.
+                unsigned short* const pn = ldsPath ? (unsigned short*)(s_path + (ASM_PATH / 2) * t) : nullptr;
                 int top = 0, nfin = 0;
                 const int e0 = atomicAdd(&s_pool, 2);
                 bool aborted = false, overflow = e0 + 2 > ASM_POOL;
@@ -1536,6 +1545,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     arena_set(e0, tn, -1, 1);
                     arena_set(e0 + 1, first, e0, 2);
                     stk[top++] = e0 + 1;
+                    if (pn) pn[1] = (unsigned short)tn;
                 }
                 while (top > 0) {
                     const int pe = stk[--top];
@@ -1544,7 +1554,21 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     // checkPathForCycles (:999-1023): a path is only ever extended from a cycle-free path, so it
                     // suffices to compare its last node with its ancestors
                     bool cyc = false;
-                    for (int a = arena_get(pe, 1); a >= 0; a = arena_get(a, 1)) if (arena_get(a, 0) == endn) { cyc = true; break; }
+                    const int depth = arena_get(pe, 2);
+                    if (pn && depth <= ASM_PATH) {
+                        const uint4* pv = (const uint4*)pn;
+                        const unsigned want = (unsigned)endn;
+                        for (int j0 = 0; j0 < depth; j0 += 8) {
+                            const uint4 v = pv[j0 >> 3];
+                            const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int a0 = j0 + 2 * q;
+                                cyc |= (a0 >= 1 && a0 < depth && (wd[q] & 0xFFFFu) == want) || (a0 + 1 < depth && (wd[q] >> 16) == want);
+                            }
+                        }
+                    } else
+                        for (int a = arena_get(pe, 1); a >= 0; a = arena_get(a, 1)) if (arena_get(a, 0) == endn) { cyc = true; break; }
                     if (cyc) continue;
                     const int col = colour_of(endn);
                     if (col == 3) { S.task_fin[t * ASM_MAX_FIN + nfin] = pe; ++nfin; }
@@ -1552,7 +1576,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     else {
                         int end[4]; bool heavy[4];
                         const int ne = edges_of(endn, end, heavy);
-                        const int depth = arena_get(pe, 2);
+                        if (pn && depth < ASM_PATH) pn[depth] = (unsigned short)endn;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {                              // assembler.pyx:1091-1107
                             if (i >= ne || overflow) continue;
