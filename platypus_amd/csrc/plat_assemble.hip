@@ -954,6 +954,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                                     cum[u + 1] = cum[u] + __popcll(vm[u]);
                                 }
                                 const int V = cum[4];
+                                const unsigned mq4 = (unsigned)mqv[0] | (unsigned)mqv[1] << 8 | (unsigned)mqv[2] << 16 | (unsigned)mqv[3] << 24;   // (each < 128)
                                 for (int cb = 0; cb < V; cb += 64 * NRB) {
                                     int jj[NRB], ww[NRB];
 #pragma unroll
@@ -965,10 +966,8 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                                         const unsigned long long mk = ru == 0 ? vm[0] : (ru == 1 ? vm[1] : (ru == 2 ? vm[2] : vm[3]));
                                         const int before = ru == 0 ? cum[0] : (ru == 1 ? cum[1] : (ru == 2 ? cum[2] : cum[3]));
                                         const int src = c < V ? asm_select64(mk, c - before) : 0;
-                                        int got[4];
-#pragma unroll
-                                        for (int q = 0; q < 4; ++q) got[q] = __builtin_amdgcn_ds_bpermute(4 * src, mqv[q]);
-                                        if (c < V) { jj[u] = 64 * ru + src; ww[u] = ru == 0 ? got[0] : (ru == 1 ? got[1] : (ru == 2 ? got[2] : got[3])); }
+                                        const unsigned got = (unsigned)__builtin_amdgcn_ds_bpermute(4 * src, (int)mq4);   // (the four rounds' weights of lane src, a byte each)
+                                        if (c < V) { jj[u] = 64 * ru + src; ww[u] = (int)((got >> (8 * ru)) & 0xFFu); }
                                     }
                                     work(jj, ww);
                                 }
