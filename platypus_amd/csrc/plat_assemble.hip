@@ -474,6 +474,8 @@ __device__ __forceinline__ void asm_sync_wg() { __syncthreads(); }
 
 // measurement only (PLAT_ASM_TIMING=1): 100 MHz ticks the first thread of every workgroup spent up to each phase boundary, summed
 __device__ unsigned long long g_asm_ticks[16];
+// `tid` made opaque to the compiler (after every barrier): what it derived from the old value -- the 64-bit per-thread offsets of every
+// strided loop -- is dead from there on instead of being carried, and spilled, across the kernel
 #define ASM_FRESH() asm volatile("" : "+v"(tid))
 #define ASM_TICK(i) do { ASM_FRESH(); if (P.timing && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_asm_ticks[i], now_ - tick_); tick_ = now_; } } while (0)
 
