@@ -1272,7 +1272,8 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             // ---- phase D: per node, the four successors with the smallest first tickets, in ticket order
             if (lds) {
                 // nodes with more than one successor slot in use (few): their slots' first tickets from a second pass over the events
-                for (int n = tid; n < nNodes; n += nthr) {
+                // (the fused path counts a node's used slots where it picks them, from the slot words it has loaded anyway: no pass here)
+                for (int n = tid; n < nNodes && !fused_done; n += nthr) {
                     if (!(s_wc[n] >> 26 & 1u)) continue;               // only its LDS slot, or none
                     int used = 0;
                     const int own = (int)(s_wc[n] >> 23 & 7u) - 1;      // the slot summed in the LDS word, -1 none
@@ -1282,7 +1283,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                         if (!fused_done) for (int j = 0; j < ASM_MAX_SUCC; ++j) S.succ_t[n * ASM_MAX_SUCC + j] = 0xFFFFFFFFu;
                     }
                 }
-                sync_phase(); ASM_FRESH();
+                if (!fused_done) { sync_phase(); ASM_FRESH(); }
                 ASM_TICK(10);
                 if (!fused_done) {                                  // (the fused pass kept the first tickets as it went)
                     const int* ev = S.stack;
@@ -1304,7 +1305,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                       }
                     }
                 }
-                asm_sync(); ASM_FRESH();
+                if (!fused_done) { asm_sync(); ASM_FRESH(); }           // (fused: nothing was written since the fence that ended the pass over the reads)
                 auto pick_edges = [&](auto KWc) {
                     constexpr int KW = decltype(KWc)::value;
                     for (int n = tid; n < nNodes; n += nthr) {
@@ -1371,7 +1372,8 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                             const int n = n0 + u * nthr;
                             if (n >= nNodes) continue;
                             const unsigned x = xs[u];
-                            const bool several = (x >> 29 & 1u) != 0u, dirty = (x >> 26 & 1u) != 0u;
+                            const bool dirty = (x >> 26 & 1u) != 0u;
+                            bool several = false;                                                  // more than one slot in use (counted below)
                             const int own = (int)(x >> 23 & 7u) - 1;
                             // (written field by field: a local AsmNodeE indexed by the pick count would live in scratch memory)
                             AsmNodeE* Eo = &S.edges[n];
@@ -1389,6 +1391,12 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
 #pragma unroll
                                 for (int j = 0; j < ASM_MAX_SUCC; ++j) {
                                     cw[j] = S.succ_cw[n * ASM_MAX_SUCC + j]; tt[j] = S.succ_t[n * ASM_MAX_SUCC + j]; nn[j] = S.succ_n[n * ASM_MAX_SUCC + j];
+                                }
+                                {
+                                    int used = 0;
+#pragma unroll
+                                    for (int j = 0; j < ASM_MAX_SUCC; ++j) used += j == own || (cw[j] >> 32) != 0ull;
+                                    several = used > 1;
                                 }
                                 unsigned last = 0; bool firstpick = true;
                                 for (int pick = 0; pick < 4; ++pick) {
