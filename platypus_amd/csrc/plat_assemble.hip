@@ -1153,7 +1153,8 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 for (int sidx = tid; sidx < P.cap; sidx += nthr)
                     if (S.key[sidx] != -1) { const int id = atomicAdd(&s_n, 1); S.slot_id[sidx] = id; init_node(id, S.key[sidx]); }
             }
-            asm_sync(); ASM_FRESH();
+            if (fused_done) asm_sync_wg(); else asm_sync();       // (fused: only s_n, in LDS, was written since the fence that ended the pass over the reads)
+            ASM_FRESH();
             ASM_TICK(2);
             const int nNodes = s_n;
             // ---- phase C: AddEdge events (assembler.pyx:801-827)
@@ -1261,7 +1262,7 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 S.succ_n[sn * ASM_MAX_SUCC + slot] = en;
                 return true;
             });
-            asm_sync(); ASM_FRESH();
+            if (!fused_done) { asm_sync(); ASM_FRESH(); }        // (fused: phase C is empty)
             ASM_TICK(3);
             fast = lds && fused_done && !P.no_cycles;
             if (lds && !fast) {                                               // the node words the later phases read, to the slice
