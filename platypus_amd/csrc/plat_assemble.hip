@@ -1651,20 +1651,22 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             const long long pcap = (long long)asm_stack_ints(P.max_pos) * 4 - 8ll * NP;
             int nvBase = 0, blobBase = 0, err = err0;
             bool fallback = false;
-            for (int c0 = 0; c0 < NP; c0 += nthr) {
+            // one chunk of paths: `scan(value, total)` = exclusive prefix over the chunk's threads.  A region has a dozen finished paths: up to 64
+            // are the first wave's alone, with shuffles -- no workgroup-wide scans, no barriers.
+            auto chunk = [&](int c0, auto&& scan) -> bool {                      // false: stop (fallback or overflow)
                 const int p = c0 + tid;
                 int t = 0, last = 0, plen = 0;
                 if (p < NP) { last = plast[p]; t = ptask[p]; plen = arena_get(last, 2); }
                 int tot;
-                const int off = asm_block_exscan(plen, s_wsum, tot);
-                if ((long long)tot > pcap || (P.debug & 8)) { fallback = true; break; }       // (never seen: a path is tens of nodes; debug 8: tests)
+                const int off = scan(plen, tot);
+                if ((long long)tot > pcap || (P.debug & 8)) { fallback = true; return false; }     // (never seen: a path is tens of nodes; debug 8: tests)
                 int s = 0, rl = 0, al = 0, ao = 0;
                 const uint8_t* r = ref;
                 const bool valid = p < NP && extract(t, last, pbytes + off, s, rl, al, ao, r);
                 int totv, totb;
-                const int vi = asm_block_exscan(valid ? 1 : 0, s_wsum, totv);
-                const int bo = asm_block_exscan(valid ? rl + al : 0, s_wsum, totb);
-                if (nvBase + totv > P.max_vars || blobBase + totb > P.blob_per_region) { err = PLAT_ERR_OVERFLOW; break; }
+                const int vi = scan(valid ? 1 : 0, totv);
+                const int bo = scan(valid ? rl + al : 0, totb);
+                if (nvBase + totv > P.max_vars || blobBase + totb > P.blob_per_region) { err = PLAT_ERR_OVERFLOW; return false; }
                 if (valid) {
                     const int nv = nvBase + vi, blob = blobBase + bo;
                     vp[nv] = s > 0 ? s : 0;                                        // variant.pyx:121
@@ -1673,8 +1675,22 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                     for (int i = 0; i < al; ++i) vb[blob + rl + i] = pbytes[off + ao + i];
                 }
                 nvBase += totv; blobBase += totb;
-                __syncthreads();                                                  // (the bytes of this chunk are done with)
-            }
+                return true;
+            };
+            if (NP <= 64) {
+                if (tid < 64)
+                    chunk(0, [&](int v, int& tot) -> int {
+                        int x = v;
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if ((tid & 63) >= d) x += y; }
+                        tot = __shfl(x, 63);
+                        return x - v;
+                    });
+            } else
+                for (int c0 = 0; c0 < NP; c0 += nthr) {
+                    if (!chunk(c0, [&](int v, int& tot) -> int { return asm_block_exscan(v, s_wsum, tot); })) break;
+                    __syncthreads();                                              // (the bytes of this chunk are done with)
+                }
             asm_sync_wg(); ASM_FRESH();
             if (!fallback) {
                 serialG = false;
