@@ -35,7 +35,7 @@
 // elements, one thread per finished path) and the claimed slots' end nodes in a dense array 336 k (768 threads: at 1024 the kernel
 // spilled 139-175 registers to slots that live in HBM); phase boundaries without the L1 invalidate where only plainly stored words
 // are read back (asm_sync_wg) 404 k; per-thread values re-derived per phase + no machine LICM (32 spilled registers) and 1024
-// threads again 449-458 k; colour bits by unconditional LDS atomics, the walk's path array, used slots counted in phase D: 529 k, 1.05 GB of
+// threads again 449-458 k; colour bits by unconditional LDS atomics, the walk's path array, used slots counted in phase D, one L1 invalidate per region: 545 k, 1.05 GB of
 // HBM traffic per 2000 tiles (round 3: 252 k, 4.76 GB).  A region with more distinct k-mers than ASM_LDS_LIMIT (deep or very divergent data),
 // k > 15, or a reference / read blob beyond 2^18 bytes is done with table, node words and successor lists in the workgroup's
 // slice of a global scratch buffer (the "global path", the round-1 code).
