@@ -790,8 +790,9 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
                 {
                     const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
                     // A wave takes one read at a time; a window of 256 bytes of its bases and of its qualities is held one aligned dword per
-                    // lane (as in read_pass).  The window's edges are worked FOUR ROUNDS OF 64 AT ONCE: the kernel is bound by chains of LDS
-                    // round trips (gather -> table -> representative -> node words), and four independent chains per lane share each wait.
+                    // lane (as in read_pass).  The window's edges that pass the quality / N rule are compacted and worked NRB rounds of 64 side by
+                    // side (`work` below): the pass is bound by vector issue plus chains of LDS round trips (gather -> table -> representative ->
+                    // node words), and independent chains per lane share each wait (four rounds at once spilled registers: two are kept).
                     constexpr int WIN = 4 * (64 - 2 * KW) - 3;
                     struct Meta { int base, cnt, ro; };
                     struct Win { unsigned dS, dQ; int sS, sQ, nE; };
