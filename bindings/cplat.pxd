@@ -12,7 +12,7 @@
 #     int fastAlignmentRoutine(...)                                  src/c/align.h:8-10
 # Every declaration below is checked by the compiler against the header: bindings/plat_binding_check.pyx cimports this
 # file and tests/test_binding_cpu.py builds it with Cython 3 and links it to the library.
-from libc.stdint cimport int16_t, int32_t, int64_t, uint8_t
+from libc.stdint cimport int16_t, int32_t, int64_t, uint8_t, uint32_t
 
 cdef extern from "platypus_mi355x.h":
     int PLAT_ABI_VERSION
@@ -163,6 +163,88 @@ cdef extern from "platypus_mi355x.h":
                                     const int32_t* scan_read_begin, const int32_t* scan_longest, int max_per_read, const int32_t* rec,
                                     const int32_t* count, const int32_t* status, double min_var_freq, int cap_per_scan,
                                     int32_t* out_cand, int32_t* out_n, void* stream) nogil
+
+    # ---- candidates -> variants -> windows -> haplotypes -> the window batch, one sample per region (variantcaller.pyx:456-531,
+    #      platypusutils.pyx:806-931, variantFilter.pyx:98-171,377-441, window.py:49-238, chaplotype.pyx:127-191,397-449)
+    ctypedef struct plat_stage_b_options:
+        int32_t minReads
+        int32_t maxSize
+        int32_t mergeClusteredVariants
+        int32_t maxVarDist
+        int32_t minVarDist
+        int32_t largeWindows
+        int32_t maxVariants
+        int32_t maxHaplotypes
+        int32_t filterVarsByCoverage
+        int32_t skipDifficultWindows
+        double maxReads
+    ctypedef struct plat_stage_b_in:
+        int32_t n_regions
+        int32_t cap_per_scan
+        const int32_t* cand
+        const int32_t* cand_n
+        const uint8_t* ref_seq
+        const int64_t* ref_off
+        const int32_t* ref_seq_start
+        const int32_t* contig_len
+        const int32_t* region_start
+        const int32_t* region_end
+        const int32_t* region_rlen
+        const uint8_t* read_seq
+        const int64_t* read_off
+        const int32_t* read_pos
+        const int32_t* read_end
+        const int32_t* tab_begin
+        const int32_t* tab_n
+        const int32_t* tab_longest
+        const int32_t* broken_mate_pos
+        int32_t broken_base
+        int32_t cap_vars
+        int32_t cap_windows
+        int32_t cap_added
+        int32_t cap_batch_windows
+        int32_t cap_batch_haps
+        int32_t cap_batch_reads
+        int64_t cap_hap_bytes
+    ctypedef struct plat_stage_b_out:
+        int32_t* hdr
+        int32_t* var_pos
+        int32_t* var_nrem
+        int32_t* var_nadd
+        int32_t* var_support
+        int32_t* var_bam_min
+        int32_t* var_bam_max
+        int32_t* var_rem_pos
+        int32_t* var_add_off
+        uint8_t* added
+        int32_t* win_start
+        int32_t* win_end
+        int32_t* win_var_first
+        int32_t* win_var_n
+        int32_t* win_flags
+        int32_t* win_ptrs
+        int32_t* win_n_haps
+        int32_t* win_batch
+        int32_t* b_hap_begin
+        int32_t* b_read_begin
+        int32_t* b_start
+        int32_t* b_end
+        int32_t* b_flank
+        int64_t* b_pair_off
+        int64_t* b_gl_off
+        int32_t* b_seg_begin
+        int32_t* b_n_good
+        int64_t* b_hap_off
+        uint32_t* b_hap_mask
+        uint8_t* b_hap_seq
+        uint8_t* hap_scratch
+        int64_t* b_read_off
+        int32_t* b_read_src
+        uint8_t* b_read_kind
+        int64_t* totals
+        int32_t* scratch
+    int plat_stage_b_batch(plat_ctx* ctx, const plat_stage_b_in* batch, const plat_stage_b_options* options, const plat_stage_b_out* out,
+                           void* stream) nogil
 
     # ---- checkAndTrimRead (cwindow.pyx:332-481)
     ctypedef struct plat_readqc_batch:

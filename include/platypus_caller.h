@@ -137,6 +137,10 @@ typedef struct plat_caller_stats {
      * summed durations of k_seed and k_dp_jobs -- what a roofline entry of the region pipeline's largest kernels is computed from */
     int64_t n_align_batches, align_hap_bytes, align_read_bytes, align_reads, align_dp_bytes;
     double seconds_kernel_seed, seconds_kernel_dp;
+    double seconds_kernel_sweep, seconds_kernel_pairs;   /* the two kernels of the seeding stage on their own (seed = sweep + pairs) */
+    /* stage B (candidates -> variants -> windows -> haplotypes -> window batch): regions the device did (plat_stage_b_batch), regions
+     * and single windows it left to the host's code (cohorts, assembly and reference-call runs never go to the device: not counted) */
+    int64_t n_regions_stage_b_device, n_regions_stage_b_host, n_windows_stage_b_host;
 } plat_caller_stats;
 
 typedef struct plat_caller plat_caller;

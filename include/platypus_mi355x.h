@@ -322,6 +322,77 @@ int plat_candidates_merge_batch(plat_ctx* ctx, const plat_candidate_batch* batch
                                 const int32_t* rec, const int32_t* count, const int32_t* status, double min_var_freq,
                                 int cap_per_scan, int32_t* out_cand, int32_t* out_n, void* stream);
 
+/* ---- candidates -> variants -> calling windows -> haplotypes -> the window batch, on the device ----------
+ * Replaces, for regions with ONE sample, what callVariantsInRegion does between the candidate generator and Population.setup:
+ *   sorted(varCandGen.getCandidates())                                             variantcaller.pyx:456-470, variant.pyx:282-363
+ *   leftNormaliseIndel(v, refFile, maxReadLength)                                  platypusutils.pyx:806-931
+ *   filterVariants(sorted(...), refFile, maxReadLength, minSupport, maxDiff, ...)  variantFilter.pyx:98-171
+ *   WindowGenerator.getBunchesOfVariants / WindowsAndVariants                      window.py:49-127,140-238
+ *   bamReadBuffer.setWindowPointers                                                cwindow.pyx:176-264,655-689
+ *   getFilteredHaplotypes, the `nVars <= log2(maxHaplotypes)` branch: every combination of the window's variants that
+ *   isHaplotypeValid accepts                                                       variantFilter.pyx:377-441, platypusutils.pyx:735-802
+ *   Haplotype.__init__ / getMutatedSequence (the haplotypes' bytes)                chaplotype.pyx:127-191,397-449
+ *   mergeHaplotypes' sorted(haplotypes) (the ORDER; two equal sequences are left to the caller)    variantcaller.pyx:325-383
+ * Input: the candidates plat_candidates_merge_batch left on the device (cand / cand_n = its out_cand / out_n, cap_per_scan), the
+ * reference windows and the read table the scan saw, and per region g its three read arrays inside that table
+ * (tab_begin/tab_n/tab_longest[3g + k], k = 0 reads, 1 badReads, 2 brokenMates; broken_mate_pos[i] = mate position of read
+ * tab_begin[3g+2] + i, indexed from broken_base).
+ * Output, per region g (all device memory of the caller):
+ *   hdr[8g..]   {status, n_variants, n_windows, candidate records, bytes used of the added-bases blob, 0, 0, 0}; status 0, or
+ *               PLAT_SB_HOST: this region needs the caller's own code (more candidates / variants / windows than the capacities, an
+ *               indel at the edge of its reference window, an order that depends on a Python dictionary, an exception the reference
+ *               would raise, ...) -- nothing else of the region is valid then.
+ *   variants    [g*cap_vars + i]: var_pos, var_nrem, var_nadd, var_support (nSupportingReads), var_bam_min, var_bam_max
+ *               (bamMinPos / bamMaxPos), var_rem_pos (contig coordinate of the removed bases), var_add_off (offset of the added
+ *               bases in added[g*cap_added ..]); sorted as the reference's list is.
+ *   windows     [g*cap_windows + k]: win_start, win_end, win_var_first, win_var_n (its variants = a run of the region's list),
+ *               win_flags (PLAT_SBW_*), win_ptrs[6 * ..] = {reads begin, end, badReads begin, end, brokenMates begin, end} (indices
+ *               inside the region's arrays), win_n_haps (reference haplotype included), win_batch (index in the window batch or -1).
+ * and, for the windows with win_flags == 0, a complete window batch in the arrays of `wb` (the plat_window_batch the likelihood
+ * kernels take: windows in (region, window) order, haplotypes sorted by sequence, reads good -> bad -> brokenMates as indices
+ * read_src[] into the read table + read_kind[]; read_off from the table's lengths; seg_begin / seg_n_good / gl_off for one sample)
+ * plus hap_mask[h] = which of its window's variants haplotype h carries (bit i = variant win_var_first + i).
+ *   totals[16]  {windows, haplotypes, reads, pairs, genotype likelihoods, haplotype bytes, read bytes, longest haplotype, most reads
+ *               of a window, most haplotypes of a window, overflow (a batch capacity was too small: nothing of the batch is valid), ...}
+ * No host round trip inside; the caller reads hdr / totals back once. */
+#define PLAT_SB_HOST 1
+#define PLAT_SBW_SKIP 1          /* no reads / too many reads / skipDifficultWindows: the loop does not call this window */
+#define PLAT_SBW_HOST 2          /* the caller prepares this window itself (greedy haplotype filter, filterVariantsByCoverage, an exception) */
+#define PLAT_SBW_DUPLICATE 4     /* in the batch, but two of its haplotypes have the same sequence: mergeHaplotypes is the caller's */
+typedef struct plat_stage_b_options {
+    int32_t minReads, maxSize, mergeClusteredVariants, maxVarDist, minVarDist, largeWindows, maxVariants, maxHaplotypes;
+    int32_t filterVarsByCoverage, skipDifficultWindows;
+    double maxReads;
+} plat_stage_b_options;
+typedef struct plat_stage_b_in {
+    int32_t n_regions, cap_per_scan;
+    const int32_t* cand; const int32_t* cand_n;
+    const uint8_t* ref_seq; const int64_t* ref_off; const int32_t* ref_seq_start; const int32_t* contig_len;
+    const int32_t* region_start; const int32_t* region_end; const int32_t* region_rlen;    /* [n_regions]; rlen: options.rlen as the loop carries it */
+    const uint8_t* read_seq; const int64_t* read_off; const int32_t* read_pos; const int32_t* read_end;
+    const int32_t* tab_begin; const int32_t* tab_n; const int32_t* tab_longest;            /* [3 * n_regions] */
+    const int32_t* broken_mate_pos; int32_t broken_base;
+    /* capacities */
+    int32_t cap_vars, cap_windows, cap_added;
+    int32_t cap_batch_windows, cap_batch_haps, cap_batch_reads; int64_t cap_hap_bytes;
+} plat_stage_b_in;
+typedef struct plat_stage_b_out {
+    int32_t* hdr;
+    int32_t* var_pos; int32_t* var_nrem; int32_t* var_nadd; int32_t* var_support; int32_t* var_bam_min; int32_t* var_bam_max;
+    int32_t* var_rem_pos; int32_t* var_add_off; uint8_t* added;
+    int32_t* win_start; int32_t* win_end; int32_t* win_var_first; int32_t* win_var_n; int32_t* win_flags; int32_t* win_ptrs;
+    int32_t* win_n_haps; int32_t* win_batch;
+    /* the window batch */
+    int32_t* b_hap_begin; int32_t* b_read_begin; int32_t* b_start; int32_t* b_end; int32_t* b_flank;       /* [cap_batch_windows (+1)] */
+    int64_t* b_pair_off; int64_t* b_gl_off; int32_t* b_seg_begin; int32_t* b_n_good;                          /* [cap_batch_windows (+1)] */
+    int64_t* b_hap_off; uint32_t* b_hap_mask; uint8_t* b_hap_seq; uint8_t* hap_scratch;                      /* [cap_batch_haps + 1], [cap_hap_bytes] x 2 */
+    int64_t* b_read_off; int32_t* b_read_src; uint8_t* b_read_kind;                                           /* [cap_batch_reads (+1)] */
+    int64_t* totals;                                                                                           /* [16] */
+    int32_t* scratch;                                                                                          /* [8 * n_regions * cap_windows + 64] */
+} plat_stage_b_out;
+int plat_stage_b_batch(plat_ctx* ctx, const plat_stage_b_in* batch, const plat_stage_b_options* options,
+                       const plat_stage_b_out* out, void* stream);
+
 /* ---- read QC / trimming ----------------------------------------------------------------------------
  * Replaces  cdef int checkAndTrimRead(theRead, theLastRead, ...)   cwindow.pyx:332-481
  * as driven by bamReadBuffer.addReadToBuffer (:560-595) for whole streams of reads: read r's

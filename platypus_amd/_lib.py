@@ -132,6 +132,7 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_candidates_merge_batch": (C.c_int, [C.c_void_p, C.POINTER(CandidateBatch), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "plat_stage_b_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_read_qc_batch": (C.c_int, [C.c_void_p, C.POINTER(ReadQCBatch), C.POINTER(ReadQCOptions), C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_variant_read_stats_batch": (C.c_int, [C.c_void_p, C.POINTER(InfoStatsBatch), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p]),

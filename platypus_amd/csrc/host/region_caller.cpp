@@ -128,7 +128,7 @@ struct Slot {
     bool countCells = false;                                               // plat_caller_count_cells: likelihood batches through the synchronous entry point
     int64_t nDpRef = 0, cellsRef = 0, nDpRun = 0, cellsRun = 0;            // ... and their plat_align_stats summed (this worker's share)
     int64_t nAlign = 0, alignHapBytes = 0, alignReadBytes = 0, alignReads = 0, alignDpBytes = 0;
-    double secSeed = 0.0, secDp = 0.0;
+    double secSeed = 0.0, secDp = 0.0, secSweep = 0.0, secPairs = 0.0;
     // chunk read table (device): bases, qualities, offsets, per-read fields, CIGARs; t_pack: the bytes of PLAT_READS_PACKED tables as
     // they crossed the link (expanded into t_seq / t_qual by plat_unpack_reads), t_exc*: their exceptions
     Staged<uint8_t> t_seq, t_qual, t_mapq, t_pack, t_excb, t_excq;
@@ -154,8 +154,18 @@ struct Slot {
     Staged<uint8_t> as_ref, as_seq, as_qual, as_mapq, as_blob;
     Staged<int64_t> as_refoff, as_roff;
     Staged<int32_t> as_refstart, as_astart, as_aend, as_rbegin, as_src, as_pos, as_end, as_flags, as_cnt, as_status, as_vpos, as_nrem, as_nadd, as_off;
+    // stage B on the device (plat_stage_b_batch): what it reads, what comes back, and the window batch it leaves on the device
+    Staged<int32_t> sb_rstart, sb_rend, sb_rlen, sb_tabbegin, sb_tabn, sb_tablongest, sb_matepos;
+    Staged<int32_t> sb_hdr, sb_vpos, sb_vnrem, sb_vnadd, sb_vsupp, sb_vbmin, sb_vbmax, sb_vrempos, sb_vaddoff, sb_wstart, sb_wend, sb_wvfirst, sb_wvn, sb_wflags,
+                    sb_wptrs, sb_wnhaps, sb_wbatch;
+    Staged<uint8_t> sb_added;
+    Staged<uint32_t> sb_hapmask;
+    Staged<int64_t> sb_totals;
+    Staged<int32_t> d_hapbegin, d_readbegin, d_start, d_end, d_flank, d_segbegin, d_ngood, d_src, d_scratch;                 // device only
+    Staged<int64_t> d_pairoff, d_gloff, d_hapoff, d_readoff;
+    Staged<uint8_t> d_hapseq, d_haptmp, d_kind;
     // many small arrays travel as ONE copy: they are views into these blocks (Layout)
-    Arena a_tab, a_cin, a_cout, a_mout, a_win, a_wout, a_pin, a_sin, a_sout, a_asin, a_asout;
+    Arena a_tab, a_cin, a_cout, a_mout, a_win, a_wout, a_pin, a_sin, a_sout, a_asin, a_asout, a_bin, a_bout;
     double t_host = 0, t_wait = 0;
 
     void sync(const char* where) {
@@ -185,6 +195,11 @@ struct Layout {
         for (Item& it : items) { *it.h = a.h + it.off; *it.d = a.d + it.off; }
     }
     void upload(Slot& s, Arena& a) { if (total) ck(plat_memcpy_h2d(s.ctx, a.d, a.h, total, s.stream), "plat_memcpy_h2d"); }
+    // only the first `nItems` arrays (they lie in the order they were added)
+    void downloadFirst(Slot& s, Arena& a, size_t nItems) {
+        const size_t bytes = nItems >= items.size() ? total : items[nItems].off;
+        if (bytes) ck(plat_memcpy_d2h(s.ctx, a.h, a.d, bytes, s.stream), "plat_memcpy_d2h");
+    }
     void download(Slot& s, Arena& a) { if (total) ck(plat_memcpy_d2h(s.ctx, a.h, a.d, total, s.stream), "plat_memcpy_d2h"); }
 };
 
@@ -349,6 +364,8 @@ struct WindowWork {
     std::vector<std::pair<int, int>> sampled;                              // (sample, local index in reads table)
     // results
     int bw = -1;                                                           // window index in the device batch
+    int hapBegin = 0;                                                      // index of its first haplotype there
+    bool onDevice = false;                                                 // prepared by plat_stage_b_batch: its batch entries are on the device already
     VarList distinct;                                                      // _distinctVariants
     std::vector<double> posterior;                                         // aligned with distinct
     VarList called;                                                        // variantPosteriors keys, in insertion order
@@ -477,10 +494,67 @@ struct DeviceBatch {                                                       // wh
     plat_window_batch wb;
     int nWindows = 0, nHaps = 0, nReads = 0, nInd = 0, maxH = 0;
     int64_t nPairs = 0, nGl = 0;
+    // per window: first haplotype, first genotype likelihood, good reads, first read of the (one) segment -- device arrays
+    const int32_t* hapbegin = nullptr; const int64_t* gloff = nullptr; const int32_t* ngood = nullptr; const int32_t* segbegin = nullptr;
+    const int32_t* src = nullptr; const int64_t* readoff = nullptr;
+    int maxHap = 0, maxRead = 0, maxR = 0;
+    int64_t hapBlob = 0, readBlob = 0;
 };
 
-// Upload a BatchBuilder, gather its reads from the chunk table and run Haplotype.alignReads for all of it; full = also
-// Population.setup, HapScore and EM.  Results are copied to the pinned host mirrors; waits for them.
+// The likelihood part of a window batch whose arrays are on the device (db.wb all but the gathered reads): gather its reads from the chunk
+// table and run Haplotype.alignReads for all of it; full = also Population.setup, HapScore and EM.  Results are copied to the pinned host
+// mirrors; waits for them.
+static void runBatch(Slot& s, DeviceBatch& db, const Options& o, bool full, bool wantLoglik) {
+    const size_t blob = (size_t)db.readBlob;
+    s.g_seq.reserve(s.ctx, blob + PLAT_BLOB_PAD, false, true, s.stream); s.g_qual.reserve(s.ctx, blob + PLAT_BLOB_PAD, false, true, s.stream);
+    const size_t nR = (size_t)db.nReads;
+    s.g_pos.reserve(s.ctx, nR + 1, false); s.g_end.reserve(s.ctx, nR + 1, false); s.g_flags.reserve(s.ctx, nR + 1, false); s.g_mapq.reserve(s.ctx, nR + 1, false);
+    ck(plat_gather_reads(s.ctx, (int64_t)nR, db.src, db.readoff, s.t_seq.d, s.t_qual.d, s.t_off.d, s.t_pos.d, s.t_end.d, s.t_mapq.d,
+                         s.t_flags.d, s.g_seq.d, s.g_qual.d, s.g_pos.d, s.g_end.d, s.g_mapq.d, s.g_flags.d, s.stream), "plat_gather_reads");
+    plat_window_batch& wb = db.wb;
+    wb.n_windows = db.nWindows; wb.n_haps = db.nHaps; wb.n_reads = db.nReads;
+    wb.read_seq = s.g_seq.d; wb.read_qual = s.g_qual.d; wb.read_pos = s.g_pos.d; wb.read_end = s.g_end.d;
+    wb.read_mapq = s.g_mapq.d; wb.read_flags = s.g_flags.d;
+    s.o_loglik.reserve(s.ctx, (size_t)db.nPairs + 1, wantLoglik);
+    plat_batch_hints h;
+    memset(&h, 0, sizeof h);
+    h.max_hap_len = db.maxHap; h.max_read_len = db.maxRead; h.max_reads_per_window = db.maxR;
+    h.n_pairs = db.nPairs; h.hap_blob_len = db.hapBlob; h.read_blob_len = (int64_t)blob; h.extra_jobs_cap = 0;
+    if (s.countCells) {
+        plat_align_stats as;
+        memset(&as, 0, sizeof as);
+        ck(plat_profile_enable(s.ctx, 1), "plat_profile_enable");
+        ck(plat_align_window_batch(s.ctx, &wb, o.calculateFlankScore ? 1 : 0, 0, s.o_loglik.d, nullptr, &as, s.stream), "plat_align_window_batch");
+        s.nDpRef += as.n_dp_reference; s.cellsRef += as.cells_reference; s.nDpRun += as.n_dp_launched; s.cellsRun += as.cells_launched;
+        plat_profile pf;
+        memset(&pf, 0, sizeof pf);
+        ck(plat_profile_last(s.ctx, &pf), "plat_profile_last");
+        ck(plat_profile_enable(s.ctx, 0), "plat_profile_enable");
+        s.nAlign += 1; s.alignHapBytes += db.hapBlob; s.alignReadBytes += (int64_t)blob; s.alignReads += db.nReads;
+        s.alignDpBytes += pf.dp_alg_bytes; s.secSeed += 1e-3 * pf.ms_seed_kernel; s.secDp += 1e-3 * pf.ms_dp;
+        s.secSweep += 1e-3 * pf.ms_sweep; s.secPairs += 1e-3 * pf.ms_pairs;
+    } else
+        ck(plat_align_window_batch_async(s.ctx, &wb, &h, o.calculateFlankScore ? 1 : 0, 0, s.o_loglik.d, nullptr, s.stream), "plat_align_window_batch_async");
+    if (wantLoglik) s.down(s.o_loglik, (size_t)db.nPairs);
+    if (full) {
+        const size_t nG = (size_t)db.nGl + 1;
+        s.o_gl.reserve(s.ctx, nG, false); s.o_logl.reserve(s.ctx, nG, false); s.o_gof.reserve(s.ctx, nG, false); s.o_em.reserve(s.ctx, nG, false);
+        Layout LO;
+        LO.add(s.o_freq, (size_t)db.nHaps); LO.add(s.o_calls, (size_t)db.nWindows * db.nInd); LO.add(s.o_hapscore, (size_t)db.nWindows);
+        LO.commit(s, s.a_wout);
+        s.o_iters.reserve(s.ctx, (size_t)db.nWindows + 1, false);
+        ck(plat_genotype_window_batch(s.ctx, &wb, db.nInd, db.segbegin, db.ngood, s.o_loglik.d, db.gloff, s.o_gl.d, s.o_logl.d, s.o_gof.d,
+                                      s.stream), "plat_genotype_window_batch");
+        ck(plat_haplotype_score_batch(s.ctx, &wb, db.nInd, db.maxH, db.segbegin, db.ngood, s.o_loglik.d, nullptr, s.o_hapscore.d, s.stream),
+           "plat_haplotype_score_batch");
+        ck(plat_em_window_batch(s.ctx, db.nWindows, db.nInd, db.maxH, db.hapbegin, db.gloff, db.ngood, s.o_gl.d, 100, o.useEMLikelihoods,
+                                s.o_freq.d, s.o_em.d, s.o_calls.d, s.o_iters.d, s.stream), "plat_em_window_batch");
+        LO.download(s, s.a_wout);
+    }
+    s.sync("window batch");
+}
+
+// Upload a BatchBuilder and run it (runBatch)
 static DeviceBatch runWindows(Slot& s, const BatchBuilder& b, const Options& o, bool full, bool wantLoglik) {
     DeviceBatch db;
     db.nWindows = b.nWindows(); db.nHaps = b.nHaps(); db.nReads = b.nReads(); db.nInd = b.nInd; db.maxH = b.maxH;
@@ -500,55 +574,14 @@ static DeviceBatch runWindows(Slot& s, const BatchBuilder& b, const Options& o, 
         memset(s.w_hapseq.h + b.hapseq.size(), 0, PLAT_BLOB_PAD);
         L.upload(s, s.a_win);
     }
-    const size_t blob = (size_t)b.readoff.back();
-    s.g_seq.reserve(s.ctx, blob + PLAT_BLOB_PAD, false, true, s.stream); s.g_qual.reserve(s.ctx, blob + PLAT_BLOB_PAD, false, true, s.stream);
-    const size_t nR = (size_t)db.nReads;
-    s.g_pos.reserve(s.ctx, nR + 1, false); s.g_end.reserve(s.ctx, nR + 1, false); s.g_flags.reserve(s.ctx, nR + 1, false); s.g_mapq.reserve(s.ctx, nR + 1, false);
-    ck(plat_gather_reads(s.ctx, (int64_t)nR, s.w_src.d, s.w_readoff.d, s.t_seq.d, s.t_qual.d, s.t_off.d, s.t_pos.d, s.t_end.d, s.t_mapq.d,
-                         s.t_flags.d, s.g_seq.d, s.g_qual.d, s.g_pos.d, s.g_end.d, s.g_mapq.d, s.g_flags.d, s.stream), "plat_gather_reads");
     plat_window_batch& wb = db.wb;
     memset(&wb, 0, sizeof wb);
-    wb.n_windows = db.nWindows; wb.n_haps = db.nHaps; wb.n_reads = db.nReads;
     wb.win_hap_begin = s.w_hapbegin.d; wb.win_read_begin = s.w_readbegin.d; wb.win_start = s.w_start.d; wb.win_end = s.w_end.d;
     wb.win_flank = s.w_flank.d; wb.pair_off = s.w_pairoff.d; wb.hap_seq = s.w_hapseq.d; wb.hap_off = s.w_hapoff.d;
-    wb.read_seq = s.g_seq.d; wb.read_qual = s.g_qual.d; wb.read_off = s.w_readoff.d; wb.read_pos = s.g_pos.d; wb.read_end = s.g_end.d;
-    wb.read_mapq = s.g_mapq.d; wb.read_flags = s.g_flags.d; wb.read_kind = s.w_kind.d;
-    s.o_loglik.reserve(s.ctx, (size_t)db.nPairs + 1, wantLoglik);
-    plat_batch_hints h;
-    memset(&h, 0, sizeof h);
-    h.max_hap_len = b.maxHap; h.max_read_len = b.maxRead; h.max_reads_per_window = b.maxR;
-    h.n_pairs = db.nPairs; h.hap_blob_len = (int64_t)b.hapseq.size(); h.read_blob_len = (int64_t)blob; h.extra_jobs_cap = 0;
-    if (s.countCells) {
-        plat_align_stats as;
-        memset(&as, 0, sizeof as);
-        ck(plat_profile_enable(s.ctx, 1), "plat_profile_enable");
-        ck(plat_align_window_batch(s.ctx, &wb, o.calculateFlankScore ? 1 : 0, 0, s.o_loglik.d, nullptr, &as, s.stream), "plat_align_window_batch");
-        s.nDpRef += as.n_dp_reference; s.cellsRef += as.cells_reference; s.nDpRun += as.n_dp_launched; s.cellsRun += as.cells_launched;
-        plat_profile pf;
-        memset(&pf, 0, sizeof pf);
-        ck(plat_profile_last(s.ctx, &pf), "plat_profile_last");
-        ck(plat_profile_enable(s.ctx, 0), "plat_profile_enable");
-        s.nAlign += 1; s.alignHapBytes += (int64_t)b.hapseq.size(); s.alignReadBytes += (int64_t)blob; s.alignReads += db.nReads;
-        s.alignDpBytes += pf.dp_alg_bytes; s.secSeed += 1e-3 * pf.ms_seed_kernel; s.secDp += 1e-3 * pf.ms_dp;
-    } else
-        ck(plat_align_window_batch_async(s.ctx, &wb, &h, o.calculateFlankScore ? 1 : 0, 0, s.o_loglik.d, nullptr, s.stream), "plat_align_window_batch_async");
-    if (wantLoglik) s.down(s.o_loglik, (size_t)db.nPairs);
-    if (full) {
-        const size_t nG = (size_t)db.nGl + 1;
-        s.o_gl.reserve(s.ctx, nG, false); s.o_logl.reserve(s.ctx, nG, false); s.o_gof.reserve(s.ctx, nG, false); s.o_em.reserve(s.ctx, nG, false);
-        Layout LO;
-        LO.add(s.o_freq, (size_t)db.nHaps); LO.add(s.o_calls, (size_t)db.nWindows * db.nInd); LO.add(s.o_hapscore, (size_t)db.nWindows);
-        LO.commit(s, s.a_wout);
-        s.o_iters.reserve(s.ctx, (size_t)db.nWindows + 1, false);
-        ck(plat_genotype_window_batch(s.ctx, &wb, db.nInd, s.w_segbegin.d, s.w_ngood.d, s.o_loglik.d, s.w_gloff.d, s.o_gl.d, s.o_logl.d, s.o_gof.d,
-                                      s.stream), "plat_genotype_window_batch");
-        ck(plat_haplotype_score_batch(s.ctx, &wb, db.nInd, db.maxH, s.w_segbegin.d, s.w_ngood.d, s.o_loglik.d, nullptr, s.o_hapscore.d, s.stream),
-           "plat_haplotype_score_batch");
-        ck(plat_em_window_batch(s.ctx, db.nWindows, db.nInd, db.maxH, s.w_hapbegin.d, s.w_gloff.d, s.w_ngood.d, s.o_gl.d, 100, o.useEMLikelihoods,
-                                s.o_freq.d, s.o_em.d, s.o_calls.d, s.o_iters.d, s.stream), "plat_em_window_batch");
-        LO.download(s, s.a_wout);
-    }
-    s.sync("window batch");
+    wb.read_off = s.w_readoff.d; wb.read_kind = s.w_kind.d;
+    db.hapbegin = s.w_hapbegin.d; db.gloff = s.w_gloff.d; db.ngood = s.w_ngood.d; db.segbegin = s.w_segbegin.d; db.src = s.w_src.d; db.readoff = s.w_readoff.d;
+    db.maxHap = b.maxHap; db.maxRead = b.maxRead; db.maxR = b.maxR; db.hapBlob = (int64_t)b.hapseq.size(); db.readBlob = b.readoff.back();
+    runBatch(s, db, o, full, wantLoglik);
     return db;
 }
 
@@ -578,10 +611,9 @@ struct Chunk {
                     else if (t.encoding != PLAT_READS_ASCII) throw DeviceError(PLAT_ERR_INVALID, "plat_read_table.encoding");
                 }
             }
-        // (+ 16 bytes per table: a packed table that is resident on the device is expanded straight from there, and its place in the chunk blob
-        //  is shifted so that source and destination share their misalignment -- the expansion then moves 16 bytes per lane)
-        const size_t nTables = 3 * regions.size() * (regions.empty() ? 0 : regions[0]->samples.size());
-        const size_t N = nReads[0] + nReads[1] + nReads[2], B = nBytes[0] + nBytes[1] + nBytes[2] + 16 * nTables, Cg = nCig[0] + nCig[1] + nCig[2];
+        // (tables lie back to back in the chunk blob: read i's bytes are [t_off[i], t_off[i + 1]) for every consumer.  A packed table that is
+        //  resident on the device is expanded straight from there; plat_unpack_reads reads a source of another misalignment with unaligned loads)
+        const size_t N = nReads[0] + nReads[1] + nReads[2], B = nBytes[0] + nBytes[1] + nBytes[2], Cg = nCig[0] + nCig[1] + nCig[2];
         if (N > 0x7FFFFFF0ull) throw DeviceError(PLAT_ERR_OVERFLOW, "chunk read table");
         Slot& z = s;
         z.t_seq.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream); z.t_qual.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream);
@@ -604,8 +636,6 @@ struct Chunk {
                     const int n = t.n_reads;
                     tv.base = (int64_t)ri;
                     const size_t nb = (size_t)t.off[n], nc = (size_t)t.cig_off[n];
-                    if (nb && t.encoding == PLAT_READS_PACKED && t.dev_seq)   // resident: no copy at all; the table's place follows the source's misalignment
-                        bo += (size_t)(((uintptr_t)t.dev_seq - (uintptr_t)(z.t_seq.d + bo)) & 15);
                     if (nb && t.encoding == PLAT_READS_PACKED) {            // one byte per base crosses the link (or none: dev_seq); expanded below
                         if (!t.dev_seq) ck(plat_memcpy_h2d(z.ctx, z.t_pack.d + bo, t.seq, nb, z.stream), "plat_memcpy_h2d(packed)");
                         const size_t ne = (size_t)std::max<int64_t>(t.n_exceptions, 0);
@@ -628,6 +658,7 @@ struct Chunk {
                     for (int i = 0; i < n; ++i) {
                         z.t_off.h[ri + i] = (int64_t)bo + t.off[i];
                         z.t_cigoff.h[ri + i] = (int32_t)(co + (size_t)t.cig_off[i]);
+                        maxReadLen = std::max(maxReadLen, (int)(t.off[i + 1] - t.off[i]));
                     }
                     if (n) {
                         memcpy(z.t_pos.h + ri, t.pos, sizeof(int32_t) * (size_t)n); memcpy(z.t_end.h + ri, t.end, sizeof(int32_t) * (size_t)n);
@@ -645,13 +676,13 @@ struct Chunk {
         for (const Pending& p : packed)
             ck(plat_unpack_reads(z.ctx, (int64_t)p.nb, p.dev ? p.dev : z.t_pack.d + p.bo, z.t_seq.d + p.bo, z.t_qual.d + p.bo, (int64_t)p.ne, z.t_excidx.d + p.e0,
                                  z.t_excb.d + p.e0, z.t_excq.d + p.e0, z.stream), "plat_unpack_reads");
-        nGood = nReads[0]; nScan = scan;
+        nGood = nReads[0]; nScan = scan; nBad = nReads[1]; nBroken = nReads[2];
         std::lock_guard<std::mutex> g(stMutex);
         st.n_reads += (int64_t)N;
         st.input_bytes += (int64_t)inBytes;
     }
-    size_t nGood = 0;
-    int nScan = 0;
+    size_t nGood = 0, nBad = 0, nBroken = 0;
+    int nScan = 0, maxReadLen = 0;
     int maxPerRead = 8;
 
     // -- A2: VariantCandidateGenerator.addCandidatesFromReads over the `reads` of every (region, sample) (variant.pyx:459-751)
@@ -680,7 +711,7 @@ struct Chunk {
             L.upload(z, z.a_cin);
         }
         refBlob.swap(blob);
-        if (nGood == 0) { hostTally = true; return; }                       // nothing to scan: the (empty) host tally
+        if (nGood == 0) { hostTally = true; deviceB = false; return; }      // nothing to scan: the (empty) host tally
         plat_candidate_batch cb;
         memset(&cb, 0, sizeof cb);
         cb.n_regions = nScan; cb.n_reads = (int32_t)nGood;
@@ -707,19 +738,26 @@ struct Chunk {
                     // (its table is 64 KB per scan in the context's scratch: a cohort too wide for it falls back to the host tally, it does not fail the call)
                     const int rcm = plat_candidates_merge_batch(z.ctx, &cb, z.t_end.d, nScan, z.c_scanbegin.d, z.c_scanlongest.d, maxPerRead, z.c_rec.d, z.c_cnt.d,
                                                                 z.c_status.d, o.minVarFreq, mergeCap, z.m_cand.d, z.m_n.d, z.stream);
-                    if (rcm == PLAT_ERR_NOMEM) { hostTally = true; continue; }
-                    ck(rcm, "plat_candidates_merge_batch");
+                    // (no room for the table: the records this scan has just written are merged on the host instead -- they are NOT scanned again;
+                    //  a device that is really out of memory fails the next allocation of the chunk with the same code, loudly)
+                    if (rcm == PLAT_ERR_NOMEM) hostTally = true;
+                    else ck(rcm, "plat_candidates_merge_batch");
                 }
-                LM.download(z, z.a_mout);
-                z.sync("candidate scan");
-                for (int g = 0; g < nScan; ++g) {
-                    const int st_ = z.m_n.h[2 * g + 1];
-                    if (st_ == PLAT_ERR_BAD_INPUT) throw DeviceError(PLAT_ERR_BAD_INPUT, "a read reaches outside the reference window handed over, or read pointers out of order");
-                    if (st_ <= -(1 << 20)) need = std::max(need, -st_ - (1 << 20));
-                    else if (st_ != 0) hostTally = true;                    // more distinct records / candidates than the kernel takes
+                if (!hostTally) {
+                    lmLayout = LM;
+                    if (deviceB) launchStageB();
+                    if (deviceB) LM.downloadFirst(z, z.a_mout, 1);                              // (only the counts: the candidates stay on the device)
+                    else LM.download(z, z.a_mout);
+                    z.sync("candidate scan");
+                    for (int g = 0; g < nScan; ++g) {
+                        const int st_ = z.m_n.h[2 * g + 1];
+                        if (st_ == PLAT_ERR_BAD_INPUT) throw DeviceError(PLAT_ERR_BAD_INPUT, "a read reaches outside the reference window handed over, or read pointers out of order");
+                        if (st_ <= -(1 << 20)) need = std::max(need, -st_ - (1 << 20));
+                        else if (st_ != 0) hostTally = true;                // more distinct records / candidates than the kernel takes
+                    }
+                    if (!need && !hostTally) break;
+                    if (need) { maxPerRead = need; continue; }
                 }
-                if (!need && !hostTally) break;
-                if (need) { maxPerRead = need; continue; }
             }
             LO.download(z, z.a_cout);
             z.sync("candidate scan");
@@ -731,10 +769,187 @@ struct Chunk {
             if (!need) break;
             maxPerRead = need;                                              // a read with more candidates than its slice: again with room for it
         }
+        if (hostTally) deviceB = false;
     }
     bool hostTally = false;
     int mergeCap = 2048;
     std::string refBlob;
+    Layout lmLayout;
+
+    // -- B on the device (plat_stage_b_batch): regions with one sample, candidates from the reads alone, no reference-call blocks
+    bool deviceB = false;
+    DeviceBatch devBatch;
+    int capV = 768, capW = 512, capA = 4096;
+    Layout sbOut;
+    bool eligibleDeviceB() const {
+        if (nInd != 1 || o.assemble || o.outputRefCalls || !o.getVariantsFromBAMs || o.maxHaplotypes < 3 || regions.empty()) return false;
+        const char* e = getenv("PLAT_CALLER_HOST_B");                       // (measurements / tests: stage B on the host)
+        return !(e && e[0] == '1');
+    }
+    void launchStageB() {
+        Slot& z = s;
+        const size_t nR = regions.size();
+        size_t nBr = 0;
+        for (RegionWork* r : regions) nBr += (size_t)r->samples[0].broken.n();
+        Layout LI;
+        LI.add(z.sb_rstart, nR); LI.add(z.sb_rend, nR); LI.add(z.sb_rlen, nR); LI.add(z.sb_tabbegin, 3 * nR); LI.add(z.sb_tabn, 3 * nR); LI.add(z.sb_tablongest, 3 * nR);
+        LI.add(z.sb_matepos, nBr + 1);
+        LI.commit(z, z.a_bin);
+        size_t mo = 0;
+        for (size_t g = 0; g < nR; ++g) {
+            RegionWork& r = *regions[g];
+            SampleView& sv = r.samples[0];
+            z.sb_rstart.h[g] = r.in->start; z.sb_rend.h[g] = r.in->end; z.sb_rlen.h[g] = r.rlen;
+            const TableView* tv[3] = {&sv.reads, &sv.bad, &sv.broken};
+            for (int k = 0; k < 3; ++k) { z.sb_tabbegin.h[3 * g + k] = (int32_t)tv[k]->base; z.sb_tabn.h[3 * g + k] = tv[k]->n(); z.sb_tablongest.h[3 * g + k] = tv[k]->longest; }
+            if (sv.broken.n()) memcpy(z.sb_matepos.h + mo, sv.broken.t->mate_pos, sizeof(int32_t) * (size_t)sv.broken.n());
+            mo += (size_t)sv.broken.n();
+        }
+        z.sb_matepos.h[mo] = 0;
+        LI.upload(z, z.a_bin);
+        const size_t capBW = nR * (size_t)capW, capBH = nR * 2048, capBR = std::max<size_t>(4 * (nGood + nBad + nBroken), 65536), capHB = capBH * 1280;
+        Layout LO;
+        LO.add(z.sb_hdr, 8 * nR); LO.add(z.sb_totals, 16);
+        LO.add(z.sb_vpos, nR * capV); LO.add(z.sb_vnrem, nR * capV); LO.add(z.sb_vnadd, nR * capV); LO.add(z.sb_vsupp, nR * capV); LO.add(z.sb_vbmin, nR * capV);
+        LO.add(z.sb_vbmax, nR * capV); LO.add(z.sb_vrempos, nR * capV); LO.add(z.sb_vaddoff, nR * capV); LO.add(z.sb_added, nR * capA);
+        LO.add(z.sb_wstart, capBW); LO.add(z.sb_wend, capBW); LO.add(z.sb_wvfirst, capBW); LO.add(z.sb_wvn, capBW); LO.add(z.sb_wflags, capBW); LO.add(z.sb_wnhaps, capBW);
+        LO.add(z.sb_wbatch, capBW); LO.add(z.sb_wptrs, 6 * capBW); LO.add(z.sb_hapmask, capBH);
+        LO.commit(z, z.a_bout);
+        sbOut = LO;
+        z.d_hapbegin.reserve(z.ctx, capBW + 2, false); z.d_readbegin.reserve(z.ctx, capBW + 2, false); z.d_start.reserve(z.ctx, capBW + 2, false);
+        z.d_end.reserve(z.ctx, capBW + 2, false); z.d_flank.reserve(z.ctx, capBW + 2, false); z.d_segbegin.reserve(z.ctx, capBW + 2, false);
+        z.d_ngood.reserve(z.ctx, capBW + 2, false); z.d_pairoff.reserve(z.ctx, capBW + 2, false); z.d_gloff.reserve(z.ctx, capBW + 2, false);
+        z.d_hapoff.reserve(z.ctx, capBH + 2, false); z.d_hapseq.reserve(z.ctx, capHB + PLAT_BLOB_PAD, false, true, z.stream); z.d_haptmp.reserve(z.ctx, capHB + PLAT_BLOB_PAD, false);
+        z.d_readoff.reserve(z.ctx, capBR + 2, false); z.d_src.reserve(z.ctx, capBR + 2, false); z.d_kind.reserve(z.ctx, capBR + 2, false);
+        z.d_scratch.reserve(z.ctx, 8 * capBW + 64, false);
+        plat_stage_b_in in;
+        memset(&in, 0, sizeof in);
+        in.n_regions = (int32_t)nR; in.cap_per_scan = mergeCap; in.cand = z.m_cand.d; in.cand_n = z.m_n.d;
+        in.ref_seq = z.c_ref.d; in.ref_off = z.c_refoff.d; in.ref_seq_start = z.c_rss.d; in.contig_len = z.c_clen.d;
+        in.region_start = z.sb_rstart.d; in.region_end = z.sb_rend.d; in.region_rlen = z.sb_rlen.d;
+        in.read_seq = z.t_seq.d; in.read_off = z.t_off.d; in.read_pos = z.t_pos.d; in.read_end = z.t_end.d;
+        in.tab_begin = z.sb_tabbegin.d; in.tab_n = z.sb_tabn.d; in.tab_longest = z.sb_tablongest.d; in.broken_mate_pos = z.sb_matepos.d; in.broken_base = (int32_t)(nGood + nBad);
+        in.cap_vars = capV; in.cap_windows = capW; in.cap_added = capA;
+        in.cap_batch_windows = (int32_t)capBW; in.cap_batch_haps = (int32_t)capBH; in.cap_batch_reads = (int32_t)capBR; in.cap_hap_bytes = (int64_t)capHB;
+        plat_stage_b_options so;
+        memset(&so, 0, sizeof so);
+        so.minReads = o.minReads; so.maxSize = o.maxSize; so.mergeClusteredVariants = o.mergeClusteredVariants; so.maxVarDist = o.maxVarDist; so.minVarDist = o.minVarDist;
+        so.largeWindows = o.largeWindows; so.maxVariants = o.maxVariants; so.maxHaplotypes = o.maxHaplotypes; so.filterVarsByCoverage = o.filterVarsByCoverage;
+        so.skipDifficultWindows = o.skipDifficultWindows; so.maxReads = o.maxReads;
+        plat_stage_b_out ob;
+        memset(&ob, 0, sizeof ob);
+        ob.hdr = z.sb_hdr.d; ob.var_pos = z.sb_vpos.d; ob.var_nrem = z.sb_vnrem.d; ob.var_nadd = z.sb_vnadd.d; ob.var_support = z.sb_vsupp.d; ob.var_bam_min = z.sb_vbmin.d;
+        ob.var_bam_max = z.sb_vbmax.d; ob.var_rem_pos = z.sb_vrempos.d; ob.var_add_off = z.sb_vaddoff.d; ob.added = z.sb_added.d;
+        ob.win_start = z.sb_wstart.d; ob.win_end = z.sb_wend.d; ob.win_var_first = z.sb_wvfirst.d; ob.win_var_n = z.sb_wvn.d; ob.win_flags = z.sb_wflags.d;
+        ob.win_ptrs = z.sb_wptrs.d; ob.win_n_haps = z.sb_wnhaps.d; ob.win_batch = z.sb_wbatch.d;
+        ob.b_hap_begin = z.d_hapbegin.d; ob.b_read_begin = z.d_readbegin.d; ob.b_start = z.d_start.d; ob.b_end = z.d_end.d; ob.b_flank = z.d_flank.d;
+        ob.b_pair_off = z.d_pairoff.d; ob.b_gl_off = z.d_gloff.d; ob.b_seg_begin = z.d_segbegin.d; ob.b_n_good = z.d_ngood.d;
+        ob.b_hap_off = z.d_hapoff.d; ob.b_hap_mask = z.sb_hapmask.d; ob.b_hap_seq = z.d_hapseq.d; ob.hap_scratch = z.d_haptmp.d;
+        ob.b_read_off = z.d_readoff.d; ob.b_read_src = z.d_src.d; ob.b_read_kind = z.d_kind.d; ob.totals = z.sb_totals.d; ob.scratch = z.d_scratch.d;
+        const int rc = plat_stage_b_batch(z.ctx, &in, &so, &ob, z.stream);
+        if (rc == PLAT_ERR_UNSUPPORTED) { deviceB = false; return; }        // (a device library without this stage: the host's own code)
+        ck(rc, "plat_stage_b_batch");
+        LO.download(z, z.a_bout);
+    }
+
+    // what plat_stage_b_batch left: Variant / WindowWork objects for the stages behind it.  A region (or window) the device flagged goes
+    // through the host's own regionVariants / regionWindows (prepareWindow).
+    void stageBFromDevice() {
+        Slot& z = s;
+        const size_t nR = regions.size();
+        if (z.sb_totals.h[10] != 0) {                                      // a batch capacity was too small: the whole chunk on the host
+            deviceB = false;
+            lmLayout.download(z, z.a_mout);
+            z.sync("candidates");
+            int scan0 = 0;
+            for (RegionWork* r : regions) { regionVariants(*r, scan0); ++scan0; regionWindows(*r); }
+            std::lock_guard<std::mutex> g(stMutex);
+            st.n_regions_stage_b_host += (int64_t)nR;
+            return;
+        }
+        bool rows = false;
+        for (size_t g = 0; g < nR; ++g)
+            if (z.sb_hdr.h[8 * g] != 0) {                                   // this region's candidates for the host's code
+                const size_t at = g * (size_t)mergeCap * 8, n = (size_t)std::max(0, z.m_n.h[2 * g]) * 8;
+                if (n) ck(plat_memcpy_d2h(z.ctx, z.m_cand.h + at, z.m_cand.d + at, n * sizeof(int32_t), z.stream), "plat_memcpy_d2h");
+                rows = true;
+            }
+        if (rows) z.sync("candidates");
+        int hapRun = 0;
+        int64_t nHostRegions = 0, nHostWindows = 0;
+        for (size_t g = 0; g < nR; ++g) {
+            RegionWork& r = *regions[g];
+            const int32_t* hdr = z.sb_hdr.h + 8 * g;
+            if (hdr[0] != 0) { regionVariants(r, (int)g); regionWindows(r); ++nHostRegions; continue; }
+            PROF("s2.fillRegion");
+            const int nV = hdr[1], nW = hdr[2];
+            r.nCandRecords += hdr[3];
+            r.variants.clear();
+            const uint8_t* blob = z.sb_added.h + g * (size_t)capA;
+            for (int i = 0; i < nV; ++i) {
+                const size_t k = g * (size_t)capV + (size_t)i;
+                const int nrem = z.sb_vnrem.h[k], nadd = z.sb_vnadd.h[k];
+                Variant* v = r.pool.make(z.sb_vpos.h[k], std::string((const char*)r.fa.seq + z.sb_vrempos.h[k], (size_t)nrem),
+                                         std::string((const char*)blob + z.sb_vaddoff.h[k], (size_t)nadd), z.sb_vsupp.h[k], PLATYPUS_VAR);
+                v->bamMinPos = z.sb_vbmin.h[k]; v->bamMaxPos = z.sb_vbmax.h[k];
+                r.variants.push_back(v);
+            }
+            if (r.cur.size() != r.samples.size()) r.cur.assign(r.samples.size(), Ptrs{0, 0, 0, 0, 0, 0});
+            r.windows.reserve(r.windows.size() + (size_t)nW); r.items.reserve(r.items.size() + (size_t)nW);
+            for (int q = 0; q < nW; ++q) {
+                const size_t k = g * (size_t)capW + (size_t)q;
+                WindowWork w;
+                w.region = r.index; w.startPos = z.sb_wstart.h[k]; w.endPos = z.sb_wend.h[k];
+                const int vf = z.sb_wvfirst.h[k], vn = z.sb_wvn.h[k], flags = z.sb_wflags.h[k], nH = z.sb_wnhaps.h[k], bw = z.sb_wbatch.h[k];
+                for (int i = 0; i < vn; ++i) w.vars.push_back(r.variants[(size_t)(vf + i)]);
+                w.allVars = w.vars;
+                const int hap0 = hapRun;
+                if (bw >= 0) hapRun += nH;
+                if (flags & (PLAT_SBW_HOST | PLAT_SBW_DUPLICATE)) {         // the greedy filter, filterVariantsByCoverage, mergeHaplotypes, an exception: the host's code
+                    ++nHostWindows;
+                    try { prepareWindow(r, w); }
+                    catch (const WindowError& e) {
+                        logWindowFailure(r.in->chrom, w.startPos, w.endPos, e.what());
+                        std::lock_guard<std::mutex> gd(stMutex);
+                        ++st.n_windows_failed;
+                        w.live = false; w.greedy = false; w.failed = true;
+                    }
+                } else {
+                    w.hapStart = std::max(0, w.startPos);
+                    w.hapEnd = (int)std::min<int64_t>(w.endPos, r.fa.len - 1);
+                    w.endBuf = std::min(2 * r.rlen, 500);
+                    const int32_t* pp = z.sb_wptrs.h + 6 * k;
+                    w.ptrs.resize(1);
+                    w.ptrs[0] = Ptrs{pp[0], pp[1], pp[2], pp[3], pp[4], pp[5]};
+                    w.nReads = pp[1] - pp[0];
+                    r.cur = w.ptrs;
+                    if (flags == 0) {
+                        w.live = true; w.onDevice = true; w.bw = bw; w.hapBegin = hap0;
+                        w.haps.resize((size_t)nH);
+                        for (int h = 0; h < nH; ++h) {
+                            const uint32_t m = z.sb_hapmask.h[hap0 + h];
+                            for (int i = 0; i < vn; ++i) if (m >> i & 1u) w.haps[(size_t)h].variants.push_back(w.vars[(size_t)i]);
+                        }
+                    }
+                }
+                r.items.push_back(Item{0, (int)r.windows.size(), std::string(), 0});
+                r.windows.push_back(std::move(w));
+            }
+        }
+        // the batch the device built
+        DeviceBatch& db = devBatch;
+        db = DeviceBatch();
+        const int64_t* T = z.sb_totals.h;
+        db.nWindows = (int)T[0]; db.nHaps = (int)T[1]; db.nReads = (int)T[2]; db.nPairs = T[3]; db.nGl = T[4]; db.hapBlob = T[5]; db.readBlob = T[6];
+        db.maxHap = (int)T[7]; db.maxR = (int)T[8]; db.maxH = (int)T[9]; db.maxRead = maxReadLen; db.nInd = 1;
+        memset(&db.wb, 0, sizeof db.wb);
+        db.wb.win_hap_begin = z.d_hapbegin.d; db.wb.win_read_begin = z.d_readbegin.d; db.wb.win_start = z.d_start.d; db.wb.win_end = z.d_end.d;
+        db.wb.win_flank = z.d_flank.d; db.wb.pair_off = z.d_pairoff.d; db.wb.hap_seq = z.d_hapseq.d; db.wb.hap_off = z.d_hapoff.d;
+        db.wb.read_off = z.d_readoff.d; db.wb.read_kind = z.d_kind.d;
+        db.hapbegin = z.d_hapbegin.d; db.gloff = z.d_gloff.d; db.ngood = z.d_ngood.d; db.segbegin = z.d_segbegin.d; db.src = z.d_src.d; db.readoff = z.d_readoff.d;
+        std::lock_guard<std::mutex> g(stMutex);
+        st.n_regions_stage_b_device += (int64_t)nR - nHostRegions; st.n_regions_stage_b_host += nHostRegions; st.n_windows_stage_b_host += nHostWindows;
+    }
 
     // -- A3: the assembler part of generateVariantsInRegion (variantcaller.pyx:496-519): tiles of assemblyRegionSize every
     // max(100, min(1000, size / 2)) bases, doWeNeedToAssembleThisRegion (:276-321) per tile, the reads loadBAMDataIntoGraph would load
@@ -1343,13 +1558,15 @@ struct Chunk {
     int regionSlot(int regionIndex) const { return regionIndex - regions[0]->index; }
 
     // -- C..F for a list of windows
-    void callWindows(std::vector<WindowWork*>& wins) {
+    // fromDevice: the windows are those plat_stage_b_batch prepared -- their batch is on the device already (devBatch), w->bw / w->hapBegin are set
+    void callWindows(std::vector<WindowWork*>& wins, bool fromDevice = false) {
         if (wins.empty()) return;
         Slot& z = s;
         static thread_local BatchBuilder callBatch;                      // (kept from chunk to chunk of this worker thread: see BatchBuilder::reset)
         BatchBuilder& b = callBatch;
         b.reset(nInd);
         for (WindowWork* w : wins) {
+            if (fromDevice) break;
             PROF("s4.build");
             RegionWork& r = *regions[(size_t)regionSlot(w->region)];
             w->bw = b.nWindows();
@@ -1366,8 +1583,18 @@ struct Chunk {
             b.endWindow();
         }
         DeviceBatch db;
-        { PROF("s4.runWindows"); db = runWindows(z, b, o, true, false); }
-        { std::lock_guard<std::mutex> g(stMutex); st.n_pairs += db.nPairs; }
+        if (fromDevice) { PROF("s4.runBatch"); db = devBatch; runBatch(z, db, o, true, false); }
+        else {
+            PROF("s4.runWindows");
+            db = runWindows(z, b, o, true, false);
+            for (WindowWork* w : wins) w->hapBegin = b.hapbegin[(size_t)w->bw];
+        }
+        {
+            int64_t np = db.nPairs;
+            if (fromDevice) { np = 0; for (WindowWork* w : wins) { int nr = 0; for (const Ptrs& p : w->ptrs) nr += (p.ge - p.gs) + (p.be - p.bs) + (p.ke - p.ks); np += (int64_t)w->haps.size() * nr; } }
+            std::lock_guard<std::mutex> g(stMutex);
+            st.n_pairs += np;                                               // (of the windows CALLED from this batch)
+        }
         lap(4);
 
         // D: distinct variants, masks, priors -> posteriors (Population.computeVariantPosteriors, cpopulation.pyx:596-621)
@@ -1403,7 +1630,7 @@ struct Chunk {
             fill(z, z.p_win, pwin); fill(z, z.p_off, poff); fill(z, z.p_mask, pmask); fill(z, z.p_prior, pprior);
             z.p_post.reserve(z.ctx, nV + 1);
             L.upload(z, z.a_pin);
-            ck(plat_variant_posterior_batch(z.ctx, (int)nV, nInd, db.maxH, z.w_hapbegin.d, z.w_gloff.d, z.w_ngood.d, z.o_gl.d, z.o_freq.d, z.p_win.d,
+            ck(plat_variant_posterior_batch(z.ctx, (int)nV, nInd, db.maxH, db.hapbegin, db.gloff, db.ngood, z.o_gl.d, z.o_freq.d, z.p_win.d,
                                             z.p_off.d, z.p_mask.d, z.p_prior.d, z.p_post.d, z.stream), "plat_variant_posterior_batch");
             z.down(z.p_post, nV);
             z.sync("posteriors");
@@ -1417,6 +1644,7 @@ struct Chunk {
         int64_t mtot = 0;
         size_t at = 0;
         std::vector<WindowWork*> live;
+        sgb.assign((size_t)db.nWindows * (size_t)nInd, 0); sge.assign(sgb.size(), 0); sbb.assign(sgb.size(), 0); sbe.assign(sgb.size(), 0);
         for (WindowWork* w : wins) {
             PROF("s6.build");
             RegionWork& r = *regions[(size_t)regionSlot(w->region)];
@@ -1435,14 +1663,16 @@ struct Chunk {
             }
             if (o.outputRefCalls) at += w->vars.size();
             // good / bad read ranges of every (window, sample) in the chunk table, for the statistics kernel
+            // (indexed by the window's place in the BATCH: a batch the device built also holds windows that are not called from it)
             for (size_t i = 0; i < r.samples.size(); ++i) {
                 const Ptrs& p = w->ptrs[i];
-                sgb.push_back((int32_t)(r.samples[i].reads.base + p.gs)); sge.push_back((int32_t)(r.samples[i].reads.base + p.ge));
-                sbb.push_back((int32_t)(r.samples[i].bad.base + p.bs)); sbe.push_back((int32_t)(r.samples[i].bad.base + p.be));
+                const size_t seg = (size_t)w->bw * (size_t)nInd + i;
+                sgb[seg] = (int32_t)(r.samples[i].reads.base + p.gs); sge[seg] = (int32_t)(r.samples[i].reads.base + p.ge);
+                sbb[seg] = (int32_t)(r.samples[i].bad.base + p.bs); sbe[seg] = (int32_t)(r.samples[i].bad.base + p.be);
             }
             if (w->called.empty()) continue;
             live.push_back(w);
-            const double* freq = z.o_freq.h + b.hapbegin[(size_t)w->bw];
+            const double* freq = z.o_freq.h + w->hapBegin;
             const int32_t* calls = z.o_calls.h + (size_t)w->bw * (size_t)nInd;
             for (size_t h = 0; h < w->haps.size(); ++h) {
                 VarList seen;                                               // Haplotype.vcfINFO(): a dictionary over the haplotype's variants
@@ -1542,7 +1772,7 @@ struct Chunk {
         ib.read_flags = z.t_flags.d; ib.cigar = z.t_cigar.d; ib.cig_off = z.t_cigoff.d;
         ck(plat_variant_read_stats_batch(z.ctx, &ib, o.badReadsWindow, o.countOnlyExactIndelMatches, z.s_counts.d, z.s_ps.d, z.s_minq.d, z.s_nminq.d, z.stream),
            "plat_variant_read_stats_batch");
-        ck(plat_genotype_call_batch(z.ctx, (int)nSites, nInd, z.w_hapbegin.d, z.w_gloff.d, z.o_gl.d, z.o_gof.d, z.o_freq.d, z.k_win.d, z.k_nvar.d, z.k_vo.d,
+        ck(plat_genotype_call_batch(z.ctx, (int)nSites, nInd, db.hapbegin, db.gloff, z.o_gl.d, z.o_gof.d, z.o_freq.d, z.k_win.d, z.k_nvar.d, z.k_vo.d,
                                     z.k_ro.d, z.k_vih.d, z.k_ref.d, z.k_lo.d, z.k_ph.d, z.k_lik.d, z.k_out4.d, z.stream), "plat_genotype_call_batch");
         LO.download(z, z.a_sout);
         z.sync("read statistics / genotype calls");
@@ -1800,24 +2030,51 @@ struct Chunk {
         mark = t0; waitMark = wait0;
         uploadReads();
         lap(0);
+        deviceB = eligibleDeviceB();
         if (o.getVariantsFromBAMs) scanCandidates();
         assembleTiles();
         lap(1);
-        int scan0 = 0;
-        for (RegionWork* r : regions) {
-            { PROF("s2.regionVariants"); regionVariants(*r, scan0); }
-            scan0 += (int)r->samples.size();
-            PROF("s2.regionWindows");
-            regionWindows(*r);
+        if (deviceB) stageBFromDevice();
+        else {
+            int scan0 = 0;
+            for (RegionWork* r : regions) {
+                { PROF("s2.regionVariants"); regionVariants(*r, scan0); }
+                scan0 += (int)r->samples.size();
+                PROF("s2.regionWindows");
+                regionWindows(*r);
+            }
         }
         lap(2);
         greedyRounds();
         lap(3);
-        std::vector<WindowWork*> wins;
+        std::vector<WindowWork*> wins, devWins;
         int64_t nWin = 0, nVar = 0, nCand = 0;
         for (RegionWork* r : regions) {
             nVar += (int64_t)r->variants.size(); nCand += r->nCandRecords;
-            for (WindowWork& w : r->windows) if (w.live) { ++nWin; wins.push_back(&w); }
+            for (WindowWork& w : r->windows) if (w.live) { ++nWin; (w.onDevice ? devWins : wins).push_back(&w); }
+        }
+        if (!devWins.empty()) {
+            try {
+                callWindows(devWins, true);
+            } catch (const DeviceError& e) {
+                // a window the device refuses takes the batch with it: the batch's windows are prepared again by the host's code and go
+                // through the per-window retry below with the others
+                if (!windowClassError(e.code)) throw;
+                for (WindowWork* w : devWins) {
+                    RegionWork& r = *regions[(size_t)regionSlot(w->region)];
+                    w->text.clear(); w->nRecords = 0; w->nRefRecords = 0; w->onDevice = false; w->haps.clear(); w->live = false;
+                    try { prepareWindow(r, *w); }
+                    catch (const WindowError& e2) {
+                        logWindowFailure(r.in->chrom, w->startPos, w->endPos, e2.what());
+                        std::lock_guard<std::mutex> g(stMutex);
+                        ++st.n_windows_failed;
+                        w->live = false; w->greedy = false; w->failed = true;
+                    }
+                }
+                greedyRounds();
+                wins.clear();
+                for (RegionWork* r : regions) for (WindowWork& w : r->windows) if (w.live && !w.onDevice) wins.push_back(&w);
+            }
         }
         try {
             callWindows(wins);
@@ -1958,7 +2215,8 @@ CALLER_EXPORT int plat_caller_destroy(plat_caller* c) {
                    z.g_qual, z.g_mapq, z.o_loglik, z.o_gl, z.o_logl, z.o_gof, z.o_freq, z.o_em, z.p_win, z.s_vw, z.s_pos, z.s_min, z.s_max, z.s_nadd, z.s_nrem,
                    z.s_gb, z.s_ge, z.s_bb, z.s_be, z.s_ps, z.s_minq, z.s_nminq, z.k_win, z.k_nvar, z.k_vih, z.k_ref, z.k_ph, z.p_off, z.s_aoff, z.s_moff, z.s_counts,
                    z.k_vo, z.k_ro, z.k_lo, z.p_mask, z.s_added, z.s_vig, z.p_prior, z.p_post, z.k_lik, z.k_out4, z.t_pack, z.as_seq, z.as_qual, z.as_mapq, z.as_pos, z.as_end, z.as_flags, z.a_asin, z.a_asout, z.a_tab, z.a_cin, z.a_cout, z.a_mout, z.c_scanbegin, z.c_scanlongest, z.m_cand, z.m_n, z.a_win, z.a_wout,
-                   z.a_pin, z.a_sin, z.a_sout);
+                   z.a_pin, z.a_sin, z.a_sout, z.a_bin, z.a_bout, z.d_hapbegin, z.d_readbegin, z.d_start, z.d_end, z.d_flank, z.d_segbegin, z.d_ngood, z.d_src,
+                   z.d_scratch, z.d_pairoff, z.d_gloff, z.d_hapoff, z.d_readoff, z.d_hapseq, z.d_haptmp, z.d_kind);
         plat_stream_destroy(z.ctx, z.stream);
         plat_ctx_destroy(z.ctx);
     }
@@ -2122,7 +2380,7 @@ static int runWorkers(plat_caller* c, Feed& feed, std::atomic<bool>& failed, con
     nThreads = std::max(1, std::min<int>((int)c->slots.size(), nThreads));
     for (auto& q : c->slots) {
         q->countCells = c->countCells; q->nDpRef = q->cellsRef = q->nDpRun = q->cellsRun = 0;
-        q->nAlign = q->alignHapBytes = q->alignReadBytes = q->alignReads = q->alignDpBytes = 0; q->secSeed = q->secDp = 0.0;
+        q->nAlign = q->alignHapBytes = q->alignReadBytes = q->alignReads = q->alignDpBytes = 0; q->secSeed = q->secDp = q->secSweep = q->secPairs = 0.0;
     }
     std::vector<std::thread> threads;
     for (int i = 1; i < nThreads; ++i) threads.emplace_back(worker, c->slots[(size_t)i].get());
@@ -2132,6 +2390,7 @@ static int runWorkers(plat_caller* c, Feed& feed, std::atomic<bool>& failed, con
         st.n_dp_reference += q->nDpRef; st.cells_reference += q->cellsRef; st.n_dp_launched += q->nDpRun; st.cells_launched += q->cellsRun;
         st.n_align_batches += q->nAlign; st.align_hap_bytes += q->alignHapBytes; st.align_read_bytes += q->alignReadBytes; st.align_reads += q->alignReads;
         st.align_dp_bytes += q->alignDpBytes; st.seconds_kernel_seed += q->secSeed; st.seconds_kernel_dp += q->secDp;
+        st.seconds_kernel_sweep += q->secSweep; st.seconds_kernel_pairs += q->secPairs;
     }
     if (firstError != PLAT_OK) c->lastError = errText;
     return firstError;

@@ -116,15 +116,22 @@ template <class T, int N> struct SmallVec {
         if (p != inl) free(p);
         p = q; cap = (uint32_t)nc;
     }
-    template <class It> void append(It a, It b) { const size_t m = (size_t)(b - a); reserve(n + m); for (size_t i = 0; i < m; ++i) p[n + i] = a[i]; n += (uint32_t)m; }
+    // (a range of the vector itself would dangle once reserve() moves the block: not supported, and checked)
+    template <class It> static bool outside(const SmallVec& v, It a) { const void* q = (const void*)&*a; return q < (const void*)v.p || q >= (const void*)(v.p + v.cap); }
+    template <class It> void append(It a, It b) {
+        const size_t m = (size_t)(b - a);
+        if (m && !outside(*this, a)) throw std::logic_error("SmallVec::append from itself");
+        reserve(n + m); for (size_t i = 0; i < m; ++i) p[n + i] = a[i]; n += (uint32_t)m;
+    }
     template <class It> void insert(const_iterator pos, It a, It b) {
         const size_t at = (size_t)(pos - p), m = (size_t)(b - a);
+        if (m && !outside(*this, a)) throw std::logic_error("SmallVec::insert from itself");
         reserve(n + m);
         memmove(p + at + m, p + at, sizeof(T) * (n - at));
         for (size_t i = 0; i < m; ++i) p[at + i] = a[i];
         n += (uint32_t)m;
     }
-    void push_back(const T& v) { if (n == cap) reserve((size_t)n + 1); p[n++] = v; }
+    void push_back(const T& v) { const T tmp = v; if (n == cap) reserve((size_t)n + 1); p[n++] = tmp; }   // (v may be an element of this vector: std::vector allows it)
     template <class... A> T& emplace_back(A&&... a) { push_back(T(std::forward<A>(a)...)); return p[n - 1]; }
     void pop_back() { --n; }
     void clear() { n = 0; }

@@ -589,17 +589,22 @@ PLAT_EXPORT int plat_gather_reads(plat_ctx* ctx, int64_t n_dst, const int32_t* s
 
 // ---- read tables packed at one byte per base (plat_unpack_reads) ----------------------------------------------------------
 namespace plat {
-// 16 packed bytes per thread: one 128-bit load, two 128-bit stores.  The three arrays may start anywhere as long as they share their
+// 16 packed bytes per thread: one 128-bit load (two 64-bit ones from any address when the source does not share the outputs' alignment:
+// global memory takes unaligned loads), two 128-bit stores.  The two OUTPUT arrays may start anywhere as long as they share their
 // misalignment `mis` (a read table inside a chunk's blob does): thread t takes the 16-byte line [16 t - mis, 16 t - mis + 16) of them,
 // clipped to [0, n) at the two ends.
 __global__ void __launch_bounds__(256)
-k_unpack_reads(long long n, int mis, int vec, const uint8_t* __restrict__ packed, uint8_t* __restrict__ out_seq, uint8_t* __restrict__ out_qual)
+k_unpack_reads(long long n, int mis, int vec, int src_aligned, const uint8_t* __restrict__ packed, uint8_t* __restrict__ out_seq, uint8_t* __restrict__ out_qual)
 {
     const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 16 - mis;
     if (i0 >= n) return;
     if (vec && i0 >= 0 && i0 + 16 <= n) {
-        const uint4 v = *(const uint4*)(packed + i0);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t w[4];
+        if (src_aligned) { const uint4 v = *(const uint4*)(packed + i0); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+        else {
+            const unsigned long long lo = load_u64_bytes(packed + i0), hi = load_u64_bytes(packed + i0 + 8);
+            w[0] = (uint32_t)lo; w[1] = (uint32_t)(lo >> 32); w[2] = (uint32_t)hi; w[3] = (uint32_t)(hi >> 32);
+        }
         uint32_t sq[4], ql[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -636,12 +641,13 @@ PLAT_EXPORT int plat_unpack_reads(plat_ctx* ctx, int64_t n_bytes, const uint8_t*
     if (n_bytes == 0) return PLAT_OK;
     if (!packed || !out_seq || !out_qual || (n_exc > 0 && (!exc_index || !exc_base || !exc_qual))) return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
-    // lanes work on 16-byte lines of the arrays: possible when the three share their misalignment (else byte by byte)
+    // lanes work on 16-byte lines of the OUTPUT arrays: possible when the two share their misalignment (else byte by byte); a source
+    // with another misalignment (a resident table expanded into its place in a chunk's blob) is read with unaligned loads
     const int m0 = (int)((uintptr_t)packed & 15), m1 = (int)((uintptr_t)out_seq & 15), m2 = (int)((uintptr_t)out_qual & 15);
-    const int vec = m0 == m1 && m0 == m2, mis = vec ? m0 : 0;              // (not shared: every thread walks its own 16 bytes)
+    const int vec = m1 == m2, mis = vec ? m1 : 0;                          // (not shared: every thread walks its own 16 bytes)
     const long long nthr = (n_bytes + mis + 15) / 16;
     hipLaunchKernelGGL(plat::k_unpack_reads, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n_bytes,
-                       mis, vec, packed, out_seq, out_qual);
+                       mis, vec, (int)(m0 == mis), packed, out_seq, out_qual);
     if (n_exc > 0)
         hipLaunchKernelGGL(plat::k_unpack_exceptions, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n_exc,
                            (long long)n_bytes, exc_index, exc_base, exc_qual, out_seq, out_qual);

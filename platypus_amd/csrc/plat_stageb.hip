@@ -1,0 +1,731 @@
+// plat_stageb.hip -- what callVariantsInRegion does between the candidate generator and Population.setup, on the device
+// (SURVEY.md 8(f) ranks 1-2): sorted candidates -> leftNormaliseIndel -> filterVariants -> calling windows -> window pointers ->
+// every valid combination of a window's variants as a haplotype -> haplotype bytes, sorted -> the window batch the likelihood
+// kernels take.  One sample per region (the cohort case stays with the caller).  Reference:
+//   variantcaller.pyx:456-470,523-531    sorted(getCandidates()), leftNormaliseIndel, sorted, filterVariants
+//   variant.pyx:282-363                  Variant.__richcmp__: (refPos, varType, nRemoved)
+//   platypusutils.pyx:806-931            leftNormaliseIndel
+//   variantFilter.pyx:98-171             filterVariants
+//   window.py:49-127,140-238             getBunchesOfVariants, WindowsAndVariants
+//   cwindow.pyx:176-264,655-689          ReadArray.setWindowPointers / setWindowPointersBasedOnMatePos
+//   variantFilter.pyx:377-441            getFilteredHaplotypes (the branch that enumerates), platypusutils.pyx:735-802 isHaplotypeValid
+//   chaplotype.pyx:127-191,397-449       Haplotype.__init__, getMutatedSequence
+//   variantcaller.pyx:325-383            mergeHaplotypes: sorted(haplotypes) (equal sequences are left to the caller)
+//
+// Five small kernels, no host round trip between them:
+//   k_sb_variants  one workgroup per region: the region's candidates in LDS; rank sort by the reference's key; one WAVE per indel
+//                  walks the reference for its leftmost / rightmost placement (64 positions per step, ballot); second sort; runs of
+//                  equal variants merged (supports summed); the filter; then one lane bunches the survivors into windows (the
+//                  bunching is a sequential rule over ~100 positions, on LDS)
+//   k_sb_windows   one thread per window: window pointers by binary search in the read table, the decision (call / skip / the
+//                  caller's greedy filter), the valid combinations counted and their lengths summed
+//   k_sb_scan      one workgroup: exclusive scans over the windows -> where each window's haplotypes, reads, pairs and bytes go
+//   k_sb_haps      one wave per window: haplotype bytes (every lane finds the segment its byte comes from), lexicographic ranks by
+//                  wave-wide comparisons from the first variant on, bytes copied in rank order
+//   k_sb_reads     one wave per window: read indices, kinds and offsets of the window's reads
+// Anything the reference would raise on, anything whose order depends on a Python dictionary and anything beyond the capacities is
+// flagged for the caller (region or window) instead of being guessed.
+#include "plat_internal.hpp"
+
+namespace plat {
+
+constexpr int SB_CAP = 1024;                      // candidates of a region held in LDS (more: the caller's own code)
+constexpr int SB_MAXCOMB = 5;                     // a window with more variants than this goes through the greedy filter (the caller's)
+
+struct SbIn {
+    plat_stage_b_in b;
+    plat_stage_b_options o;
+};
+
+__device__ __forceinline__ int sb_type(int nrem, int nadd) {          // variant.pyx:49-53,127-140: SNP 0, MNP 1, INS 2, DEL 3, REP 4
+    if (nrem == nadd) return nadd == 1 ? 0 : 1;
+    if (nrem == 0) return 2;
+    if (nadd == 0) return 3;
+    return 4;
+}
+
+// exclusive scan over the 256 threads of a workgroup; total in *tot (LDS scratch of 8 ints)
+__device__ __forceinline__ int sb_block_scan(int v, int* wsum, int* tot) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w; ++k) base += wsum[k];
+    if (threadIdx.x == blockDim.x - 1) *tot = base + x;
+    __syncthreads();
+    return base + x - v;
+}
+
+struct SbRegion {                                  // per-region LDS state of k_sb_variants
+    unsigned long long key[SB_CAP];                // pos << 32 | type << 28 | nrem
+    int id[SB_CAP];                                // first-record id (the dictionary's insertion order), then: rank in the first sort
+    int pos[SB_CAP], nrem[SB_CAP], nadd[SB_CAP], supp[SB_CAP], remc[SB_CAP], addo[SB_CAP], bmin[SB_CAP], bmax[SB_CAP];
+    unsigned short perm[SB_CAP];                   // sorted position -> element
+    unsigned char head[SB_CAP], keep[SB_CAP];
+    int list[SB_CAP];
+    int wsum[8], tot, nIndel, addedUsed, status, nKept;
+};
+
+// the added bases of element e: in the read table (addo >= 0) or, once normalised, in the region's own blob (addo = -(offset + 1))
+__device__ __forceinline__ const uint8_t* sb_added(const SbRegion& R, int e, const uint8_t* read_seq, const uint8_t* blob) {
+    const int a = R.addo[e];
+    return a >= 0 ? read_seq + a : blob + (-(a + 1));
+}
+__device__ __forceinline__ bool sb_same(const SbRegion& R, int a, int b, const uint8_t* read_seq, const uint8_t* blob) {   // Variant.__richcmp__ == (variant.pyx:282-300)
+    if (R.pos[a] != R.pos[b] || R.nrem[a] != R.nrem[b] || R.nadd[a] != R.nadd[b]) return false;
+    const uint8_t* x = sb_added(R, a, read_seq, blob);
+    const uint8_t* y = sb_added(R, b, read_seq, blob);
+    for (int i = 0; i < R.nadd[a]; ++i) if (x[i] != y[i]) return false;
+    return true;                                                       // (removed bases: the reference's own at pos, equal when pos and nrem are)
+}
+
+__global__ void __launch_bounds__(256)
+k_sb_variants(SbIn in, plat_stage_b_out out)
+{
+    extern __shared__ __align__(16) unsigned char sb_lds[];
+    SbRegion& R = *(SbRegion*)sb_lds;
+    const plat_stage_b_in& b = in.b;
+    const plat_stage_b_options& o = in.o;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int32_t* hdr = out.hdr + 8 * g;
+    const int n = b.cand_n[2 * g];
+    if (tid == 0) { R.status = 0; R.nIndel = 0; R.addedUsed = 0; R.nKept = 0; }
+    __syncthreads();
+    if (b.cand_n[2 * g + 1] != 0 || n > SB_CAP || n > b.cap_per_scan) {                  // (the merge kernel's own verdict is the caller's to read)
+        if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = hdr[3] = hdr[4] = hdr[5] = hdr[6] = hdr[7] = 0; }
+        return;
+    }
+    const long long roff = b.ref_off[g];
+    const int refLen = (int)(b.ref_off[g + 1] - roff), rss = b.ref_seq_start[g], contigLen = b.contig_len[g];
+    const uint8_t* ref = b.ref_seq + roff;                             // ref[x - rss] = contig base x for rss <= x < rss + refLen
+    uint8_t* blob = out.added + (long long)g * b.cap_added;
+    const int rlen = b.region_rlen[g];
+    long long nrec = 0;
+    // ---- load; key of the reference's order
+    for (int i = tid; i < n; i += 256) {
+        const int32_t* c = b.cand + 8ll * ((long long)g * b.cap_per_scan + i);
+        const int pos = c[3] < 0 ? 0 : c[3], nrem = c[4], nadd = c[5];
+        R.id[i] = c[0]; R.supp[i] = c[1]; R.pos[i] = pos; R.nrem[i] = nrem; R.nadd[i] = nadd;
+        R.remc[i] = nrem ? rss + c[6] - (int)roff : pos;             // contig coordinate of the removed bases (c[6]: offset in the reference blob)
+        R.addo[i] = nadd ? c[7] : 0;
+        R.bmin[i] = pos; R.bmax[i] = pos;
+        R.key[i] = (unsigned long long)(unsigned)pos << 32 | (unsigned long long)sb_type(nrem, nadd) << 28 | (unsigned)(nrem & 0x0FFFFFFF);
+        nrec += c[1];
+        if (nrem > 0x0FFFFFF || nadd > 0xFFFF) atomicOr(&R.status, 1);
+    }
+    {   // candidate records of the region (a statistic of the caller)
+        for (int d = 32; d; d >>= 1) nrec += __shfl_down(nrec, d, 64);
+        __syncthreads();
+        if (lane == 0) R.wsum[wv] = (int)nrec;
+        __syncthreads();
+        if (tid == 0) hdr[3] = R.wsum[0] + R.wsum[1] + R.wsum[2] + R.wsum[3];
+        __syncthreads();
+    }
+    // ---- first sort: (refPos, varType, nRemoved), equal keys in the dictionary's insertion order (sorted() is stable)
+    for (int i = tid; i < n; i += 256) {
+        const unsigned long long k = R.key[i]; const int id = R.id[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) { const unsigned long long kj = R.key[j]; r += (kj < k) || (kj == k && R.id[j] < id); }
+        R.list[i] = r;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) R.id[i] = R.list[i];          // id := rank in the first sort (the tie-break of the second)
+    __syncthreads();
+    // ---- leftNormaliseIndel: pure insertions / deletions at refPos >= 100
+    for (int i = tid; i < n; i += 256) {
+        const int nrem = R.nrem[i], nadd = R.nadd[i];
+        if (nrem != nadd && !(nrem > 0 && nadd > 0) && R.pos[i] >= 100) R.list[atomicAdd(&R.nIndel, 1)] = i;
+    }
+    __syncthreads();
+    for (int q = wv; q < R.nIndel; q += 4) {                           // one wave per indel
+        const int e = R.list[q];
+        const int pos = R.pos[e], nrem = R.nrem[e], nadd = R.nadd[e];
+        const int window = (nadd > nrem ? nadd : nrem) + rlen;
+        const int seqMax = contigLen - 1;
+        const int wmin = pos - window > 1 ? pos - window : 1, wmax = pos + window < seqMax ? pos + window : seqMax;
+        const int Lr = wmax - wmin, cut = pos - wmin;
+        // the reference window handed over must hold [wmin, wmax); an indel whose tail ref[cut + nrem + 1:] would be empty sits at the
+        // contig's end: the caller's code
+        if (wmin < rss || wmax > rss + refLen || Lr < 1 || cut + nrem + 1 >= Lr) { if (lane == 0) atomicOr(&R.status, 1); continue; }
+        const uint8_t* rw = ref + (wmin - rss);                        // ref string of the function: rw[0 .. Lr)
+        const uint8_t* add = b.read_seq + R.addo[e];
+        const int Lh = Lr - nrem + nadd, nmin = Lr < Lh ? Lr : Lh;
+        auto hapAt = [&](int i) -> int { return i <= cut ? rw[i] : (i < cut + 1 + nadd ? add[i - cut - 1] : rw[i - nadd + nrem]); };
+        // rightmost placement: first mismatch from the left (hap == ref up to cut)
+        int fwd = nmin;
+        for (int i0 = cut + 1; i0 < nmin; i0 += 64) {
+            const int i = i0 + lane;
+            const bool mm = i < nmin && hapAt(i) != rw[i];
+            const unsigned long long m = __ballot(mm);
+            if (m) { fwd = i0 + __builtin_ctzll(m); break; }
+        }
+        const int maxPos = wmin + fwd + nrem;
+        // leftmost placement: first mismatch from the right (the tails behind the indel are the same bytes)
+        int back = -1;
+        for (int k0 = Lr - (cut + nrem + 1); k0 < nmin; k0 += 64) {
+            const int k = k0 + lane;
+            const bool mm = k < nmin && hapAt(Lh - 1 - k) != rw[Lr - 1 - k];
+            const unsigned long long m = __ballot(mm);
+            if (m) { back = k0 + __builtin_ctzll(m); break; }
+        }
+        if (back < 0) continue;                                        // no mismatch at all: the variant stays as it is
+        const int first = Lr - back - nrem, newPos = wmin + first - 1;
+        if (first < 0) { if (lane == 0) atomicOr(&R.status, 1); continue; }   // "Error in variant conversion to standard format"
+        int off = 0;
+        if (nadd) {
+            if (lane == 0) off = atomicAdd(&R.addedUsed, nadd);
+            off = __shfl(off, 0, 64);
+            if (off + nadd > b.cap_added) { if (lane == 0) atomicOr(&R.status, 1); continue; }
+            for (int i = lane; i < nadd; i += 64) blob[off + i] = (uint8_t)hapAt(first + i);
+        }
+        if (lane == 0) {
+            R.pos[e] = newPos; R.bmin[e] = newPos; R.bmax[e] = maxPos;
+            if (nrem) R.remc[e] = wmin + first;
+            if (nadd) R.addo[e] = -(off + 1);
+            R.key[e] = (unsigned long long)(unsigned)newPos << 32 | (R.key[e] & 0xFFFFFFFFull);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- second sort (stable on the first)
+    for (int i = tid; i < n; i += 256) {
+        const unsigned long long k = R.key[i]; const int id = R.id[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) { const unsigned long long kj = R.key[j]; r += (kj < k) || (kj == k && R.id[j] < id); }
+        R.perm[r] = (unsigned short)i;
+    }
+    __syncthreads();
+    // ---- filterVariants: runs of equal variants (each compared with the run's first: equality is transitive) are merged into the first
+    for (int r = tid; r < n; r += 256) R.head[r] = r == 0 || !sb_same(R, R.perm[r], R.perm[r - 1], b.read_seq, blob);
+    __syncthreads();
+    for (int r = tid; r < n; r += 256) {
+        R.keep[r] = 0;
+        if (!R.head[r]) continue;
+        const int e = R.perm[r];
+        int supp = R.supp[e], mn = R.bmin[e], mx = R.bmax[e], q = r + 1;
+        for (; q < n && !R.head[q]; ++q) { const int f = R.perm[q]; supp += R.supp[f]; mn = min(mn, R.bmin[f]); mx = max(mx, R.bmax[f]); }
+        R.supp[e] = supp; R.bmin[e] = mn; R.bmax[e] = mx;              // (Variant.addVariant, variant.pyx:261-268)
+        const int size = max(R.nadd[e], R.nrem[e]);
+        // every candidate here comes from the reads alone (varSource == PLATYPUS_VAR); minSupport == options.minReads (variantcaller.pyx:526)
+        if (q == n) R.keep[r] = supp >= o.minReads;                     // the last run: no size test (variantFilter.pyx:160-169)
+        else R.keep[r] = supp >= o.minReads && size <= o.maxSize;
+    }
+    __syncthreads();
+    // ---- orders that depend on how a Python-2 dictionary iterates: not decided here
+    //  (a) three or more candidates with one key among which one variant occurs twice next to a different one
+    for (int r = tid; r < n; r += 256) {
+        const unsigned long long k = R.key[R.perm[r]];
+        if (r > 0 && R.key[R.perm[r - 1]] == k) continue;
+        int m = 1;
+        while (r + m < n && R.key[R.perm[r + m]] == k) ++m;
+        if (m < 3) continue;
+        bool twice = false, other = false;
+        if (m > 48) twice = other = true;
+        for (int x = 0; x < m && m <= 48; ++x)
+            for (int y = x + 1; y < m; ++y) { if (sb_same(R, R.perm[r + x], R.perm[r + y], b.read_seq, blob)) twice = true; else other = true; }
+        if (twice && other) atomicOr(&R.status, 1);
+    }
+    // ---- the survivors, in order
+    {
+        const int per = (n + 255) / 256, r0 = tid * per, r1 = min(n, r0 + per);
+        int cnt = 0;
+        for (int r = r0; r < r1; ++r) cnt += R.keep[r];
+        int at = sb_block_scan(cnt, R.wsum, &R.tot);
+        for (int r = r0; r < r1; ++r) if (R.keep[r]) R.list[at++] = R.perm[r];
+    }
+    __syncthreads();
+    const int nk = R.tot;
+    //  (b) two survivors that compare equal
+    for (int k = tid + 1; k < nk; k += 256) if (R.key[R.list[k]] == R.key[R.list[k - 1]]) atomicOr(&R.status, 1);
+    if (nk > b.cap_vars) atomicOr(&R.status, 1);
+    __syncthreads();
+    if (R.status) { if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; } return; }
+    // ---- the region's variants out (+ the added bases of those that still live in the read table)
+    for (int k = tid; k < nk; k += 256) {
+        const int e = R.list[k];
+        const long long v = (long long)g * b.cap_vars + k;
+        out.var_pos[v] = R.pos[e]; out.var_nrem[v] = R.nrem[e]; out.var_nadd[v] = R.nadd[e]; out.var_support[v] = R.supp[e];
+        out.var_bam_min[v] = R.bmin[e]; out.var_bam_max[v] = R.bmax[e]; out.var_rem_pos[v] = R.remc[e];
+        int ao = 0;
+        if (R.nadd[e]) {
+            if (R.addo[e] < 0) ao = -(R.addo[e] + 1);
+            else {
+                ao = atomicAdd(&R.addedUsed, R.nadd[e]);
+                if (ao + R.nadd[e] > b.cap_added) { atomicOr(&R.status, 1); ao = 0; }
+                else for (int i = 0; i < R.nadd[e]; ++i) blob[ao + i] = b.read_seq[R.addo[e] + i];
+            }
+        }
+        out.var_add_off[v] = ao;
+    }
+    __syncthreads();
+    // ---- windows: WindowGenerator.getBunchesOfVariants over the variants inside [start, end), one lane (a sequential rule)
+    if (tid == 0) {
+        const int start = b.region_start[g], end = b.region_end[g], maxContigPos = contigLen - 1;
+        const int maxSpan = o.largeWindows == 1 ? o.maxSize : rlen;
+        int nw = 0, st = R.status;
+        bool haveBunch = false;
+        int bMin = 0, bMax = 0, bCount = 0, bFirst = 0;
+        auto emit = [&]() {
+            const int ws = max(bMin - o.minVarDist, start), we = min(bMax + o.minVarDist, maxContigPos);
+            if (we - ws > o.maxSize) return;                           // variantcaller.pyx:566-568
+            if (nw >= b.cap_windows) { st = 1; return; }
+            const long long w = (long long)g * b.cap_windows + nw;
+            out.win_start[w] = ws; out.win_end[w] = we; out.win_var_first[w] = bFirst; out.win_var_n[w] = bCount;
+            ++nw;
+        };
+        int k = 0;
+        while (k < nk && R.pos[R.list[k]] < start) ++k;
+        while (k < nk) {
+            const int p = R.pos[R.list[k]];
+            if (p >= end) break;
+            int gMin = p, gMax = p, gCount = 0;                        // the variants at one position (getVariantsByPos)
+            const int gFirst = k;
+            for (; k < nk && R.pos[R.list[k]] == p; ++k) { const int e = R.list[k]; gMax = max(gMax, max(p, p + R.nrem[e] - 1)); ++gCount; }
+            if (!haveBunch) { haveBunch = true; bMin = gMin; bMax = gMax; bCount = gCount; bFirst = gFirst; continue; }
+            const int gap = gMin - bMax;
+            bool merge;
+            if (bMax >= gMin) merge = true;                            // overlapping variants always share a window
+            else if (!o.mergeClusteredVariants || gap >= o.maxVarDist) merge = false;
+            else if (gMax - bMin > maxSpan) merge = false;
+            else if (bCount + gCount <= o.maxVariants) merge = true;
+            else merge = gap < o.minVarDist;
+            if (merge) { bMin = min(bMin, gMin); bMax = max(bMax, gMax); bCount += gCount; }
+            else { emit(); bMin = gMin; bMax = gMax; bCount = gCount; bFirst = gFirst; }
+        }
+        if (haveBunch) emit();
+        if (st) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; }
+        else { hdr[0] = 0; hdr[1] = nk; hdr[2] = nw; hdr[4] = R.addedUsed; hdr[5] = hdr[6] = hdr[7] = 0; }
+    }
+}
+
+// ---- a haplotype of a window as segments of the reference and added bases (getMutatedSequence, chaplotype.pyx:397-449) -------------
+// Walks the variants of `mask` (bit i = variant first + i of the region's list); calls seg(kind, source, length): kind 0 = contig bases
+// [source, source + length), kind 1 = added bases of variant `source`.  Returns the length, or -1 where the reference raises
+// ("Cannot have beginPos > endPos in getSequence").
+struct SbWin { int hapStart, hapEnd, endBuf, contigLen; };
+template <class F>
+__device__ __forceinline__ int sb_walk_hap(const SbWin& w, unsigned mask, int nv, const int32_t* vpos, const int32_t* vnrem, const int32_t* vnadd, F&& seg)
+{
+    int L = 0;
+    bool bad = false;
+    auto refSeg = [&](int bpos, int epos) {                           // FastaFile.getSequence(bpos, epos), fastafile.pyx:173-207
+        if (bpos < 0) bpos = 0;
+        if (epos > w.contigLen - 1) epos = w.contigLen - 1;
+        if (epos < bpos) { bad = true; return; }
+        if (epos > bpos) { seg(0, bpos, epos - bpos); L += epos - bpos; }
+    };
+    refSeg(w.hapStart - w.endBuf, w.hapStart);
+    int cur = w.hapStart;
+    bool firstSeen = false;
+    for (int i = 0; i < nv; ++i) {
+        if (!(mask >> i & 1u)) continue;
+        const int p = vpos[i], nrem = vnrem[i], nadd = vnadd[i];
+        if (!firstSeen) { firstSeen = true; if (p != cur) { refSeg(cur, p); cur = p; } }
+        if (p > cur) { refSeg(cur, p); cur = p; }
+        if (nadd == nrem) { seg(1, i, nadd); L += nadd; cur += nrem; }
+        else {
+            if (nadd == 0 || nrem == 0) { if (p == cur) { if (p >= 0 && p < w.contigLen) seg(0, p, 1); else seg(2, '-', 1); L += 1; cur += 1; } }
+            cur += nrem;
+            if (nadd) { seg(1, i, nadd); L += nadd; }
+        }
+    }
+    if (cur < w.hapEnd) refSeg(cur, w.hapEnd);
+    refSeg(w.hapEnd, w.hapEnd + w.endBuf);
+    return bad ? -1 : L;
+}
+
+// isHaplotypeValid (platypusutils.pyx:735-802): consecutive variants must not overlap; a SNP / MNP may end where an indel starts
+__device__ __forceinline__ bool sb_valid(unsigned mask, int nv, const int32_t* vpos, const int32_t* vnrem, const int32_t* vnadd) {
+    int last = -1;
+    for (int i = 0; i < nv; ++i) {
+        if (!(mask >> i & 1u)) continue;
+        if (last >= 0) {
+            const int amax = max(vpos[last], vpos[last] + vnrem[last] - 1), bmin = vpos[i];
+            if (amax > bmin) return false;
+            if (amax == bmin && !(vnadd[last] == vnrem[last] && vnadd[i] != vnrem[i])) return false;
+        }
+        last = i;
+    }
+    return true;
+}
+// the k-th subset of nv variants in itertools.combinations order over sizes 1, 2, ... (k from 0); 0 when there is none
+__device__ __forceinline__ unsigned sb_next_comb(unsigned prev, int nv) {
+    // combinations of one size ascend lexicographically by index tuple = descend by the bit-reversed mask
+    auto rev = [nv](unsigned m) { unsigned r = 0; for (int i = 0; i < nv; ++i) if (m >> i & 1u) r |= 1u << (nv - 1 - i); return r; };
+    const int size = prev ? __popc(prev) : 0;
+    if (prev) {
+        for (unsigned r = rev(prev); r-- > 0;) if (__popc(r) == size) return rev(r);
+    }
+    if (size + 1 > nv) return 0;
+    unsigned r = ((1u << (size + 1)) - 1u) << (nv - size - 1);        // the first of the next size: indices 0 .. size
+    return rev(r);
+}
+
+// ReadArray.setWindowPointers (cwindow.pyx:176-234): first read that may overlap [start, end) / first read starting at or behind end
+__device__ __forceinline__ int sb_lower_bound(const int32_t* a, int n, long long key) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)a[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256)
+k_sb_windows(SbIn in, plat_stage_b_out out)
+{
+    const plat_stage_b_in& b = in.b;
+    const plat_stage_b_options& o = in.o;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = (int)(t / b.cap_windows), k = (int)(t % b.cap_windows);
+    if (g >= b.n_regions) return;
+    const int32_t* hdr = out.hdr + 8 * g;
+    int32_t* sc = out.scratch + 8 * t;                                 // {flags, haplotypes, reads, haplotype bytes, read bytes, longest haplotype, 0, 0}
+    if (hdr[0] != 0 || k >= hdr[2]) { sc[0] = -1; return; }
+    const long long w = (long long)g * b.cap_windows + k;
+    const int ws = out.win_start[w], we = out.win_end[w], nv = out.win_var_n[w];
+    const int contigLen = b.contig_len[g], rlen = b.region_rlen[g];
+    int flags = 0, ptr[6] = {0, 0, 0, 0, 0, 0};
+    // window pointers of the three read arrays
+    for (int a = 0; a < 3; ++a) {
+        const int N = b.tab_n[3 * g + a], base = b.tab_begin[3 * g + a], longest = b.tab_longest[3 * g + a];
+        int s = 0, e = 0;
+        if (N > 0) {
+            const long long keyS = (long long)ws - longest > 1 ? (long long)ws - longest : 1;
+            if (a < 2) {
+                s = sb_lower_bound(b.read_pos + base, N, keyS);
+                e = sb_lower_bound(b.read_pos + base, N, we);
+                while (s < N && b.read_end[base + s] <= ws) ++s;
+            } else {                                                  // setWindowPointersBasedOnMatePos (:236-264)
+                const int32_t* mp = b.broken_mate_pos + (base - b.broken_base);
+                s = sb_lower_bound(mp, N, keyS);
+                e = sb_lower_bound(mp, N, we);
+            }
+            if (s > e) flags = PLAT_SBW_HOST;                          // "Read start pointer > read end pointer": the reference raises
+            if (e > N) e = N;
+        }
+        ptr[2 * a] = s; ptr[2 * a + 1] = e;
+    }
+    for (int q = 0; q < 6; ++q) out.win_ptrs[6 * w + q] = ptr[q];
+    const int nGood = ptr[1] - ptr[0];
+    SbWin W;
+    W.hapStart = ws > 0 ? ws : 0; W.hapEnd = we < contigLen - 1 ? we : contigLen - 1; W.endBuf = 2 * rlen < 500 ? 2 * rlen : 500; W.contigLen = contigLen;
+    // the reference window handed over must hold every byte a haplotype can take
+    const int rss = b.ref_seq_start[g], refLen = (int)(b.ref_off[g + 1] - b.ref_off[g]);
+    const int lo = W.hapStart - W.endBuf > 0 ? W.hapStart - W.endBuf : 0, hi = min(W.hapEnd + W.endBuf, contigLen - 1);
+    if (lo < rss || hi > rss + refLen) flags = PLAT_SBW_HOST;
+    for (int i = 0; i < nv; ++i) {                                     // (an indel's anchor base is read at its position: getCharacter reaches the contig's last base, getSequence never does)
+        const int p = out.var_pos[(long long)g * b.cap_vars + out.win_var_first[w] + i];
+        if (p < rss || p >= rss + refLen) flags = PLAT_SBW_HOST;
+    }
+    int nHaps = 0, maxLen = 0;
+    long long hapBytes = 0;
+    if (!flags) {
+        const int32_t* vpos = out.var_pos + (long long)g * b.cap_vars + out.win_var_first[w];
+        const int32_t* vnrem = out.var_nrem + (long long)g * b.cap_vars + out.win_var_first[w];
+        const int32_t* vnadd = out.var_nadd + (long long)g * b.cap_vars + out.win_var_first[w];
+        auto none = [](int, int, int) {};
+        const int refL = sb_walk_hap(W, 0u, 0, vpos, vnrem, vnadd, none);
+        if (refL < 0 || refL > 16384) flags = PLAT_SBW_HOST;          // (raises there: logged, the window is skipped -- the caller reproduces it)
+        else if (nGood == 0 || (double)nGood > o.maxReads) flags = PLAT_SBW_SKIP;
+        else if (nv > o.maxVariants) flags = o.skipDifficultWindows ? PLAT_SBW_SKIP : PLAT_SBW_HOST;   // filterVariantsByCoverage: the caller's
+        else {
+            const double lg = log2((double)(o.maxHaplotypes - 1));
+            if (!((double)nv <= lg || (o.filterVarsByCoverage && (double)o.maxVariants <= lg)) || nv > SB_MAXCOMB) flags = PLAT_SBW_HOST;   // the greedy filter
+        }
+        if (!flags) {
+            nHaps = 1; hapBytes = refL; maxLen = refL;
+            for (unsigned m = sb_next_comb(0u, nv); m; m = sb_next_comb(m, nv)) {
+                if (!sb_valid(m, nv, vpos, vnrem, vnadd)) continue;
+                const int L = sb_walk_hap(W, m, nv, vpos, vnrem, vnadd, none);
+                if (L < 0 || L > 16384) { flags = PLAT_SBW_HOST; break; }
+                ++nHaps; hapBytes += L; maxLen = max(maxLen, L);
+            }
+        }
+    }
+    long long readBytes = 0;
+    int nReads = 0;
+    if (!flags) {
+        for (int a = 0; a < 3; ++a) {
+            const int base = b.tab_begin[3 * g + a];
+            nReads += ptr[2 * a + 1] - ptr[2 * a];
+            readBytes += b.read_off[base + ptr[2 * a + 1]] - b.read_off[base + ptr[2 * a]];
+        }
+        if (readBytes > 0x7FFFFFFF || hapBytes > 0x7FFFFFFF) flags = PLAT_SBW_HOST;
+    }
+    out.win_flags[w] = flags; out.win_n_haps[w] = flags ? 0 : nHaps; out.win_batch[w] = -1;
+    sc[0] = flags; sc[1] = nHaps; sc[2] = nReads; sc[3] = (int)hapBytes; sc[4] = (int)readBytes; sc[5] = maxLen; sc[6] = 0; sc[7] = 0;
+}
+
+// ---- where every window of the batch goes: exclusive scans in (region, window) order, one workgroup ------------------------------
+__global__ void __launch_bounds__(1024)
+k_sb_scan(SbIn in, plat_stage_b_out out)
+{
+    const plat_stage_b_in& b = in.b;
+    __shared__ long long part[1024][6];
+    __shared__ int mx[1024][3];
+    const int tid = threadIdx.x;
+    const long long total = (long long)b.n_regions * b.cap_windows;
+    const long long per = (total + 1023) / 1024, t0 = tid * per, t1 = t0 + per < total ? t0 + per : total;
+    long long s[6] = {0, 0, 0, 0, 0, 0};                               // windows, haplotypes, reads, pairs, haplotype bytes, read bytes
+    int m0 = 0, m1 = 0, m2 = 0;
+    for (long long t = t0; t < t1; ++t) {
+        const int32_t* sc = out.scratch + 8 * t;
+        if (sc[0] != 0) continue;
+        s[0] += 1; s[1] += sc[1]; s[2] += sc[2]; s[3] += (long long)sc[1] * sc[2]; s[4] += sc[3]; s[5] += sc[4];
+        m0 = max(m0, sc[5]); m1 = max(m1, sc[2]); m2 = max(m2, sc[1]);
+    }
+    for (int q = 0; q < 6; ++q) part[tid][q] = s[q];
+    mx[tid][0] = m0; mx[tid][1] = m1; mx[tid][2] = m2;
+    __syncthreads();
+    if (tid == 0) {
+        long long run[6] = {0, 0, 0, 0, 0, 0};
+        int a0 = 0, a1 = 0, a2 = 0;
+        for (int i = 0; i < 1024; ++i) {
+            for (int q = 0; q < 6; ++q) { const long long v = part[i][q]; part[i][q] = run[q]; run[q] += v; }
+            a0 = max(a0, mx[i][0]); a1 = max(a1, mx[i][1]); a2 = max(a2, mx[i][2]);
+        }
+        long long gl = 0;
+        const bool over = run[0] > b.cap_batch_windows || run[1] > b.cap_batch_haps || run[2] > b.cap_batch_reads || run[4] > b.cap_hap_bytes;
+        out.totals[0] = run[0]; out.totals[1] = run[1]; out.totals[2] = run[2]; out.totals[3] = run[3]; out.totals[4] = gl;
+        out.totals[5] = run[4]; out.totals[6] = run[5]; out.totals[7] = a0; out.totals[8] = a1; out.totals[9] = a2; out.totals[10] = over ? 1 : 0;
+        for (int q = 11; q < 16; ++q) out.totals[q] = 0;
+        if (!over) {                                                   // the arrays' closing entries
+            const int nw = (int)run[0];
+            out.b_hap_begin[nw] = (int)run[1]; out.b_read_begin[nw] = (int)run[2]; out.b_pair_off[nw] = run[3]; out.b_seg_begin[nw] = (int)run[2];
+            out.b_hap_off[run[1]] = run[4]; out.b_read_off[run[2]] = run[5];
+        }
+    }
+    __syncthreads();
+    if (out.totals[10]) return;
+    for (int q = 0; q < 6; ++q) s[q] = part[tid][q];
+    for (long long t = t0; t < t1; ++t) {
+        int32_t* sc = out.scratch + 8 * t;
+        if (sc[0] != 0) continue;
+        const int bw = (int)s[0];
+        const int g = (int)(t / b.cap_windows);
+        const long long w = t;
+        out.win_batch[w] = bw;
+        out.b_hap_begin[bw] = (int)s[1]; out.b_read_begin[bw] = (int)s[2]; out.b_pair_off[bw] = s[3]; out.b_seg_begin[bw] = (int)s[2];
+        out.b_n_good[bw] = out.win_ptrs[6 * w + 1] - out.win_ptrs[6 * w];
+        const int contigLen = b.contig_len[g], rlen = b.region_rlen[g];
+        const int ws = out.win_start[w], we = out.win_end[w];
+        out.b_start[bw] = ws > 0 ? ws : 0; out.b_end[bw] = we < contigLen - 1 ? we : contigLen - 1; out.b_flank[bw] = 2 * rlen < 500 ? 2 * rlen : 500;
+        sc[6] = (int)s[4]; sc[7] = (int)s[5];                          // byte offsets of its haplotypes / reads
+        s[0] += 1; s[1] += sc[1]; s[2] += sc[2]; s[3] += (long long)sc[1] * sc[2]; s[4] += sc[3]; s[5] += sc[4];
+    }
+}
+
+// genotype-likelihood offsets need H (H + 1) / 2 per window: a second tiny scan (one thread per 1024th, same pattern) would do; they are
+// a function of b_hap_begin alone, so one thread per window computes its own prefix from the haplotype counts with a wave scan below
+__global__ void __launch_bounds__(256)
+k_sb_gloff(SbIn in, plat_stage_b_out out)
+{
+    // one workgroup: windows in order, G = H (H + 1) / 2 (one sample)
+    __shared__ int wsum[8];
+    __shared__ int tot;
+    __shared__ long long carry;
+    if (out.totals[10]) return;
+    const int nw = (int)out.totals[0];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int w0 = 0; w0 < nw; w0 += 256) {
+        const int w = w0 + threadIdx.x;
+        int G = 0;
+        if (w < nw) { const int H = out.b_hap_begin[w + 1] - out.b_hap_begin[w]; G = H * (H + 1) / 2; }
+        const int ex = sb_block_scan(G, wsum, &tot);
+        if (w < nw) out.b_gl_off[w] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out.b_gl_off[nw] = carry; out.totals[4] = carry; }
+}
+
+// ---- haplotype bytes, sorted ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_sb_haps(SbIn in, plat_stage_b_out out)
+{
+    const plat_stage_b_in& b = in.b;
+    __shared__ unsigned s_mask[4][32];
+    __shared__ int s_len[4][32], s_rank[4][32], s_off[4][32];
+    __shared__ int s_seg[4][24][3];                                    // segments of the haplotype being written: kind, source, length
+    if (out.totals[10]) return;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + wv;
+    if (t >= (long long)b.n_regions * b.cap_windows) return;
+    const int32_t* sc = out.scratch + 8 * t;
+    if (sc[0] != 0) return;
+    const int g = (int)(t / b.cap_windows);
+    const long long w = t;
+    const int bw = out.win_batch[w], nv = out.win_var_n[w], nH = sc[1], hb = out.b_hap_begin[bw];
+    const long long byte0 = sc[6];
+    const long long v0 = (long long)g * b.cap_vars + out.win_var_first[w];
+    const int32_t* vpos = out.var_pos + v0;
+    const int32_t* vnrem = out.var_nrem + v0;
+    const int32_t* vnadd = out.var_nadd + v0;
+    const int32_t* vadd = out.var_add_off + v0;
+    const uint8_t* added = out.added + (long long)g * b.cap_added;
+    const int contigLen = b.contig_len[g], rlen = b.region_rlen[g], rss = b.ref_seq_start[g];
+    const uint8_t* ref = b.ref_seq + b.ref_off[g];
+    SbWin W;
+    const int ws = out.win_start[w], we = out.win_end[w];
+    W.hapStart = ws > 0 ? ws : 0; W.hapEnd = we < contigLen - 1 ? we : contigLen - 1; W.endBuf = 2 * rlen < 500 ? 2 * rlen : 500; W.contigLen = contigLen;
+    // the valid combinations in the reference's order (haplotype 0 = the reference)
+    if (lane == 0) {
+        auto none = [](int, int, int) {};
+        int h = 0;
+        s_mask[wv][0] = 0u; s_len[wv][0] = sb_walk_hap(W, 0u, 0, vpos, vnrem, vnadd, none); h = 1;
+        for (unsigned m = sb_next_comb(0u, nv); m && h < 32; m = sb_next_comb(m, nv)) {
+            if (!sb_valid(m, nv, vpos, vnrem, vnadd)) continue;
+            s_mask[wv][h] = m; s_len[wv][h] = sb_walk_hap(W, m, nv, vpos, vnrem, vnadd, none); ++h;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    uint8_t* tmp = out.hap_scratch + byte0;
+    // bytes of every haplotype into the scratch blob, enumeration order
+    {
+        long long at = 0;
+        for (int h = 0; h < nH; ++h) {
+            const unsigned m = s_mask[wv][h];
+            int nseg = 0;
+            if (lane == 0) {
+                auto put = [&](int kind, int src, int len) { if (nseg < 24) { s_seg[wv][nseg][0] = kind; s_seg[wv][nseg][1] = src; s_seg[wv][nseg][2] = len; } ++nseg; };
+                sb_walk_hap(W, m, nv, vpos, vnrem, vnadd, put);
+            }
+            nseg = __shfl(nseg, 0, 64);
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            const int L = s_len[wv][h];
+            for (int p = lane; p < L; p += 64) {
+                int q = p, k = 0;
+                while (k < nseg - 1 && q >= s_seg[wv][k][2]) { q -= s_seg[wv][k][2]; ++k; }
+                const int kind = s_seg[wv][k][0], src = s_seg[wv][k][1];
+                uint8_t c;
+                if (kind == 0) c = ref[src + q - rss];
+                else if (kind == 1) c = added[vadd[src] + q];
+                else c = (uint8_t)src;
+                tmp[at + p] = c;
+            }
+            s_off[wv][h] = (int)at;
+            at += L;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __threadfence();                                                   // (the scratch bytes are read back by other lanes below)
+    __builtin_amdgcn_wave_barrier();
+    // ranks: sorted(haplotypes) compares the byte strings; equal strings keep their order (and are flagged: mergeHaplotypes is the caller's)
+    if (lane < 32) s_rank[wv][lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    int dup = 0;
+    // every haplotype is the reference up to the window's first variant: comparisons start there
+    int common = 0;
+    if (nv > 0) { const int lo = W.hapStart - W.endBuf > 0 ? W.hapStart - W.endBuf : 0; common = max(0, min(vpos[0], W.hapEnd) - lo); }
+    for (int i = 0; i < nH; ++i)
+        for (int j = i + 1; j < nH; ++j) {
+            const int Li = s_len[wv][i], Lj = s_len[wv][j], Lm = min(Li, Lj);
+            const uint8_t* x = tmp + s_off[wv][i];
+            const uint8_t* y = tmp + s_off[wv][j];
+            int cmp = 0;
+            for (int p0 = min(common, Lm); p0 < Lm && cmp == 0; p0 += 64) {
+                const int p = p0 + lane;
+                const int cx = p < Lm ? x[p] : 0, cy = p < Lm ? y[p] : 0;
+                const unsigned long long mm = __ballot(cx != cy);
+                if (mm) { const int f = __builtin_ctzll(mm); const int ax = __shfl(cx, f, 64), ay = __shfl(cy, f, 64); cmp = ax < ay ? -1 : 1; }
+            }
+            if (cmp == 0) cmp = Li < Lj ? -1 : (Li > Lj ? 1 : 0);
+            if (cmp == 0) dup = 1;
+            if (lane == 0) { if (cmp <= 0) s_rank[wv][j] += 1; else s_rank[wv][i] += 1; }
+            __builtin_amdgcn_wave_barrier();
+        }
+    __threadfence_block();
+    // final place of every haplotype: after the shorter-ranked ones
+    if (lane < nH) {
+        int off = 0;
+        for (int k = 0; k < nH; ++k) if (s_rank[wv][k] < s_rank[wv][lane]) off += s_len[wv][k];
+        const int r = s_rank[wv][lane];
+        out.b_hap_off[hb + r] = byte0 + off;
+        out.b_hap_mask[hb + r] = s_mask[wv][lane];
+        s_rank[wv][lane] = off;                                         // rank no longer needed: now the byte offset inside the window
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    uint8_t* dst = out.b_hap_seq + byte0;
+    for (int h = 0; h < nH; ++h) {
+        const int L = s_len[wv][h], so = s_off[wv][h], to = s_rank[wv][h];
+        for (int p = lane; p < L; p += 64) dst[to + p] = tmp[so + p];
+    }
+    if (dup && lane == 0) out.win_flags[w] = PLAT_SBW_DUPLICATE;
+}
+
+// ---- the reads of every window: indices into the read table, kinds, offsets ---------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_sb_reads(SbIn in, plat_stage_b_out out)
+{
+    const plat_stage_b_in& b = in.b;
+    if (out.totals[10]) return;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + wv;
+    if (t >= (long long)b.n_regions * b.cap_windows) return;
+    const int32_t* sc = out.scratch + 8 * t;
+    if (sc[0] != 0) return;
+    const int g = (int)(t / b.cap_windows);
+    const long long w = t;
+    const int bw = out.win_batch[w];
+    int at = out.b_read_begin[bw];
+    long long bytes = sc[7];
+    for (int a = 0; a < 3; ++a) {
+        const int base = b.tab_begin[3 * g + a], s = out.win_ptrs[6 * w + 2 * a], e = out.win_ptrs[6 * w + 2 * a + 1];
+        if (e <= s) continue;
+        const long long o0 = b.read_off[base + s];
+        for (int i = s + lane; i < e; i += 64) {
+            out.b_read_src[at + (i - s)] = base + i;
+            out.b_read_kind[at + (i - s)] = (uint8_t)a;
+            out.b_read_off[at + (i - s)] = bytes + (b.read_off[base + i] - o0);
+        }
+        bytes += b.read_off[base + e] - o0;
+        at += e - s;
+    }
+}
+
+}  // namespace plat
+
+PLAT_EXPORT int plat_stage_b_batch(plat_ctx* ctx, const plat_stage_b_in* batch, const plat_stage_b_options* options,
+                                   const plat_stage_b_out* outp, void* stream)
+{
+    if (!ctx || !batch || !options || !outp) return PLAT_ERR_INVALID;
+    const plat_stage_b_in& b = *batch;
+    const plat_stage_b_out& o = *outp;
+    if (b.n_regions < 0 || b.cap_per_scan < 1 || b.cap_vars < 1 || b.cap_windows < 1 || b.cap_added < 1 || b.cap_batch_windows < 1 || b.cap_batch_haps < 1 ||
+        b.cap_batch_reads < 1 || b.cap_hap_bytes < 1)
+        return PLAT_ERR_INVALID;
+    if (b.n_regions == 0) return PLAT_OK;
+    if (!b.cand || !b.cand_n || !b.ref_seq || !b.ref_off || !b.ref_seq_start || !b.contig_len || !b.region_start || !b.region_end || !b.region_rlen ||
+        !b.read_seq || !b.read_off || !b.read_pos || !b.read_end || !b.tab_begin || !b.tab_n || !b.tab_longest || !b.broken_mate_pos)
+        return PLAT_ERR_INVALID;
+    if (!o.hdr || !o.var_pos || !o.var_nrem || !o.var_nadd || !o.var_support || !o.var_bam_min || !o.var_bam_max || !o.var_rem_pos || !o.var_add_off ||
+        !o.added || !o.win_start || !o.win_end || !o.win_var_first || !o.win_var_n || !o.win_flags || !o.win_ptrs || !o.win_n_haps || !o.win_batch ||
+        !o.b_hap_begin || !o.b_read_begin || !o.b_start || !o.b_end || !o.b_flank || !o.b_pair_off || !o.b_gl_off || !o.b_seg_begin || !o.b_n_good ||
+        !o.b_hap_off || !o.b_hap_mask || !o.b_hap_seq || !o.hap_scratch || !o.b_read_off || !o.b_read_src || !o.b_read_kind || !o.totals || !o.scratch)
+        return PLAT_ERR_INVALID;
+    if (options->maxHaplotypes < 3) return PLAT_ERR_UNSUPPORTED;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    plat::SbIn in;
+    in.b = b; in.o = *options;
+    hipStream_t st = (hipStream_t)stream;
+    const long long slots = (long long)b.n_regions * b.cap_windows;
+    static bool once = false;
+    if (!once) {
+        PLAT_HIP(ctx, hipFuncSetAttribute((const void*)plat::k_sb_variants, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(plat::SbRegion)));
+        once = true;
+    }
+    hipLaunchKernelGGL(plat::k_sb_variants, dim3((unsigned)b.n_regions), dim3(256), sizeof(plat::SbRegion), st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_windows, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_scan, dim3(1), dim3(1024), 0, st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_gloff, dim3(1), dim3(256), 0, st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_haps, dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_reads, dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, st, in, o);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}

@@ -73,7 +73,9 @@ class CallerStats(C.Structure):
                 ("n_assembler_variants", C.c_int64), ("n_refcall_records", C.c_int64), ("seconds_assemble", C.c_double), ("n_pairs", C.c_int64),
                 ("n_dp_reference", C.c_int64), ("cells_reference", C.c_int64), ("n_dp_launched", C.c_int64), ("cells_launched", C.c_int64),
                 ("n_align_batches", C.c_int64), ("align_hap_bytes", C.c_int64), ("align_read_bytes", C.c_int64), ("align_reads", C.c_int64),
-                ("align_dp_bytes", C.c_int64), ("seconds_kernel_seed", C.c_double), ("seconds_kernel_dp", C.c_double)]
+                ("align_dp_bytes", C.c_int64), ("seconds_kernel_seed", C.c_double), ("seconds_kernel_dp", C.c_double),
+                ("seconds_kernel_sweep", C.c_double), ("seconds_kernel_pairs", C.c_double), ("n_regions_stage_b_device", C.c_int64),
+                ("n_regions_stage_b_host", C.c_int64), ("n_windows_stage_b_host", C.c_int64)]
 
     STAGES = ("upload", "candidate_scan", "variants_windows_haplotypes", "greedy_rounds", "window_batch", "posteriors", "read_stats_calls", "text")
 

@@ -322,6 +322,13 @@ static int fk_cmp(const void* a, const void* b) {
     if (c) return c;
     return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);
 }
+/* stage B on the device: this stand-in has none -- the native region loop then runs its own (host) stage B, which is what the CPU suite pins */
+API int plat_stage_b_batch(plat_ctx* c, const plat_stage_b_in* b, const plat_stage_b_options* o, const plat_stage_b_out* out, void* stream)
+{
+    (void)c; (void)b; (void)o; (void)out; (void)stream;
+    return PLAT_ERR_UNSUPPORTED;
+}
+
 API int plat_candidates_merge_batch(plat_ctx* c, const plat_candidate_batch* b, const int32_t* read_end, int n_scans,
                                     const int32_t* scan_read_begin, const int32_t* scan_longest, int max_per_read, const int32_t* rec,
                                     const int32_t* count, const int32_t* status, double min_var_freq, int cap, int32_t* out_cand,

@@ -283,13 +283,19 @@ def config4_gcups(counted, regions, T):
 
 
 def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
-    """STRONG scaling: ONE region list for the whole job (`--regions`; default 3 875 per GPU = one GPU's share of the 31 000 regions of the
-    synthetic 30x genome), region i -> rank i % N (runner.py:473-474); every rank streams its share through the region loop,
+    """ONE region list for the whole job, region i -> rank i % N (runner.py:473-474); every rank streams its share through the region loop,
     the record lines travel to rank 0 (sizes all-gather + point to point) and are merged by (chrom, pos) (runner.py:301-352).  The timed
-    region covers loading (generating) the regions, the calls, the gather and the merge."""
+    region covers the calls, the gather and the merge (and, when the inputs are not resident, loading = generating the regions).
+
+    Which scaling the N = 1, 2, 4, 8 lines form is said on the line, never implied:
+      default     WEAK: the list grows with the job, 3 875 regions per GPU (N = 8 is the 31 000 regions of the synthetic 30x genome, SURVEY
+                  8(d) cfg 4; N = 1 one GPU's share of it).  Efficiency basis: windows/s(N) / (N x windows/s(1)).
+      --strong    STRONG: the SAME list for every N (`--regions`, default 31 000 = the whole genome): T(1) / (N x T(N)), north_star's figure.
+      --regions R without --strong: R regions for the whole job whatever N (a strong line too, and labelled so)."""
     from platypus_amd import fastcaller as F, sharding
     rank, world = rk.rank, rk.world
-    total = a.regions or 3875 * world
+    strong = bool(getattr(a, "strong", False)) or bool(a.regions)
+    total = (a.regions or (31000 if strong else 3875 * world))
     mine = sharding.regions_for_rank(total, rank, world)
     cpus = getattr(rk, "cpus", 16)                                           # what the box grants this rank (cgroup quota / share of the node)
     # worker and loader threads share the rank's CPUs (workers sleep while the device works on their chunk): 10 + 8 with six regions per
@@ -314,7 +320,7 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
     counted_all = dict(zip(ckeys, red[6:]))                                   # summed over the ranks
     st = r["stats"]
     line = {"metric": "variant windows/sec end to end (reads in host memory -> VCF record text)", "value": wins / T, "unit": "windows/s",
-            "n_gpus": world, "steps": repeats, "warmup": 1, "ms_per_step": 1e3 * T, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "n_gpus": world, "steps": repeats, "warmup": 1, "ms_per_step": 1e3 * T, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
             "config": {"workload": "BASELINE config 4: %d regions x %d bp for the whole job, 30x 150 bp reads, SNPs 1e-3 + indels 1e-4, one sample, %s; step = "
                                    "candidates -> windows -> haplotypes -> likelihoods / EM / posteriors -> INFO / FILTER -> record text for all "
@@ -336,7 +342,13 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
             "worker_seconds_waiting_for_the_source_per_region": st["seconds_source_wait"] / max(1, r["regions"]),
             "host_input_bytes_per_region": inb / max(1.0, regs), "h2d_gbytes_per_sec": inb / T / 1e9, "input_blobs_pinned": pin, "cpus_granted_to_this_rank": cpus,
             "stage_seconds_per_region": {k: v / max(1, r["regions"]) for k, v in st["seconds_stage"].items()},
-            "record_gather": r["gather"], "untimed_warm_regions_per_rank": r["warm_regions"], "python_region_loop_windows_per_sec_round1": 1100.0}
+            "record_gather": r["gather"], "untimed_warm_regions_per_rank": r["warm_regions"], "python_region_loop_windows_per_sec_round1": 1100.0,
+            # what an efficiency figure over the N = 1, 2, 4, 8 lines has to be computed from (the driver computes it, not this line)
+            "scaling_efficiency_basis": {"scaling": "strong" if strong else "weak", "timed_s": T, "regions": int(regs), "windows": int(wins), "ranks": world,
+                                         "regions_per_rank": int(regs) // max(1, world), "cpus_per_rank": cpus, "host_threads_per_rank": r["workers"],
+                                         "formula": "T(1) / (N x T(N)) over lines with equal `regions`" if strong else
+                                                    "windows_per_sec(N) / (N x windows_per_sec(1)): `regions` grows with N (3 875 per GPU)",
+                                         "inside_timed_region": "region calls of every rank + gather of the record text to rank 0 + (chrom, pos) merge"}}
     line.update(config4_gcups(counted_all, regs, T))
     if rank == 0:
         if lib is None and not getattr(a, "no_cpu_baseline", False):
