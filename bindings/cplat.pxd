@@ -237,7 +237,6 @@ cdef extern from "platypus_mi355x.h":
         int64_t* b_hap_off
         uint32_t* b_hap_mask
         uint8_t* b_hap_seq
-        uint8_t* hap_scratch
         int64_t* b_read_off
         int32_t* b_read_src
         uint8_t* b_read_kind
@@ -245,6 +244,31 @@ cdef extern from "platypus_mi355x.h":
         int32_t* scratch
     int plat_stage_b_batch(plat_ctx* ctx, const plat_stage_b_in* batch, const plat_stage_b_options* options, const plat_stage_b_out* out,
                            void* stream) nogil
+
+    ctypedef struct plat_unpack_piece:
+        const uint8_t* src
+        int64_t dst
+        int64_t n
+    int plat_unpack_reads_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual,
+                                 int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream) nogil
+
+    # ---- a chunk's read table from tables resident on the device
+    ctypedef struct plat_table_desc:
+        const int64_t* off
+        const int32_t* pos
+        const int32_t* end
+        const uint8_t* mapq
+        const int32_t* flags
+        const int16_t* cigar
+        const int32_t* cig_off
+        int32_t n
+        int32_t scan
+        int64_t first_read
+        int64_t first_byte
+        int64_t first_pair
+    int plat_concat_read_tables(plat_ctx* ctx, int n_tables, int max_reads_per_table, const plat_table_desc* desc, int64_t* dst_off, int32_t* dst_pos,
+                                int32_t* dst_end, uint8_t* dst_mapq, int32_t* dst_flags, int32_t* dst_cig_off, int16_t* dst_cigar, int32_t* dst_region,
+                                int64_t n_total_reads, int64_t total_bytes, int64_t total_pairs, void* stream) nogil
 
     # ---- checkAndTrimRead (cwindow.pyx:332-481)
     ctypedef struct plat_readqc_batch:

@@ -69,6 +69,16 @@ typedef struct plat_read_table {
      * few candidates it keeps).  NULL (the default): the blobs are copied from `seq` / `qual`. */
     const uint8_t* dev_seq;
     const uint8_t* dev_qual;
+    /* Optional, same idea for the per-read arrays: DEVICE copies of off / pos / end / mapq / flags / cigar / cig_off (all seven or none).
+     * When every table of a chunk has them (and dev_seq), the chunk's read table is put together on the device (plat_concat_read_tables)
+     * and no per-read array crosses the link; the host arrays must still be valid (window pointers of the host's own stages). */
+    const int64_t* dev_off;
+    const int32_t* dev_pos;
+    const int32_t* dev_end;
+    const uint8_t* dev_mapq;
+    const int32_t* dev_flags;
+    const int16_t* dev_cigar;
+    const int32_t* dev_cig_off;
 } plat_read_table;
 
 /* One bamReadBuffer (cwindow.pyx:485-513): reads and badReads sorted by pos, brokenMates sorted by mate_pos

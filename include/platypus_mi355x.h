@@ -322,6 +322,28 @@ int plat_candidates_merge_batch(plat_ctx* ctx, const plat_candidate_batch* batch
                                 const int32_t* rec, const int32_t* count, const int32_t* status, double min_var_freq,
                                 int cap_per_scan, int32_t* out_cand, int32_t* out_n, void* stream);
 
+/* plat_unpack_reads for many pieces in ONE launch: piece k = n packed bytes at src (device memory: uploaded, or resident) expanded to
+ * out_seq / out_qual [dst, dst + n).  `pieces` is device memory.  The exceptions of all pieces follow in one pass: exc_index holds byte
+ * indices into out_seq / out_qual (ascending not required).                                                                        */
+typedef struct plat_unpack_piece { const uint8_t* src; int64_t dst, n; } plat_unpack_piece;
+int plat_unpack_reads_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual,
+                             int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream);
+
+/* ---- a chunk's read table from read tables that are resident on the device --------------------------------------------------------
+ * Replaces  the loader's copy of a bamReadBuffer's reads into the arrays the kernels above take (no reference counterpart: the
+ *           reference walks cAlignedRead pointers, cwindow.pyx:485-595).
+ * n_tables tables, table t described by desc[t] (device memory): its seven per-read arrays on the device, n reads, and where it goes
+ * in the destination: first read index, first byte of its bases in the chunk blob, first CIGAR pair, and the scan id written to
+ * dst_region[] for its reads (or -1: none).  Writes dst_off (+ byte base), dst_pos, dst_end, dst_mapq, dst_flags, dst_cig_off (+ pair
+ * base), dst_cigar, dst_region and the closing entries dst_off[N] = total_bytes, dst_cig_off[N] = total_pairs, one zero CIGAR pair.    */
+typedef struct plat_table_desc {
+    const int64_t* off; const int32_t* pos; const int32_t* end; const uint8_t* mapq; const int32_t* flags; const int16_t* cigar; const int32_t* cig_off;
+    int32_t n, scan; int64_t first_read, first_byte, first_pair;
+} plat_table_desc;
+int plat_concat_read_tables(plat_ctx* ctx, int n_tables, int max_reads_per_table, const plat_table_desc* desc, int64_t* dst_off, int32_t* dst_pos,
+                            int32_t* dst_end, uint8_t* dst_mapq, int32_t* dst_flags, int32_t* dst_cig_off, int16_t* dst_cigar,
+                            int32_t* dst_region, int64_t n_total_reads, int64_t total_bytes, int64_t total_pairs, void* stream);
+
 /* ---- candidates -> variants -> calling windows -> haplotypes -> the window batch, on the device ----------
  * Replaces, for regions with ONE sample, what callVariantsInRegion does between the candidate generator and Population.setup:
  *   sorted(varCandGen.getCandidates())                                             variantcaller.pyx:456-470, variant.pyx:282-363
@@ -351,14 +373,15 @@ int plat_candidates_merge_batch(plat_ctx* ctx, const plat_candidate_batch* batch
  * and, for the windows with win_flags == 0, a complete window batch in the arrays of `wb` (the plat_window_batch the likelihood
  * kernels take: windows in (region, window) order, haplotypes sorted by sequence, reads good -> bad -> brokenMates as indices
  * read_src[] into the read table + read_kind[]; read_off from the table's lengths; seg_begin / seg_n_good / gl_off for one sample)
- * plus hap_mask[h] = which of its window's variants haplotype h carries (bit i = variant win_var_first + i).
+ * plus b_hap_mask[h] = which of its window's variants haplotype h carries (bit i = variant win_var_first + i).
  *   totals[16]  {windows, haplotypes, reads, pairs, genotype likelihoods, haplotype bytes, read bytes, longest haplotype, most reads
  *               of a window, most haplotypes of a window, overflow (a batch capacity was too small: nothing of the batch is valid), ...}
  * No host round trip inside; the caller reads hdr / totals back once. */
 #define PLAT_SB_HOST 1
 #define PLAT_SBW_SKIP 1          /* no reads / too many reads / skipDifficultWindows: the loop does not call this window */
 #define PLAT_SBW_HOST 2          /* the caller prepares this window itself (greedy haplotype filter, filterVariantsByCoverage, an exception) */
-#define PLAT_SBW_DUPLICATE 4     /* in the batch, but two of its haplotypes have the same sequence: mergeHaplotypes is the caller's */
+#define PLAT_SBW_DUPLICATE 4     /* in the batch, but two of its haplotypes have the same sequence (or agree on more bytes than the
+                                  * device looks at): mergeHaplotypes / the order is the caller's */
 typedef struct plat_stage_b_options {
     int32_t minReads, maxSize, mergeClusteredVariants, maxVarDist, minVarDist, largeWindows, maxVariants, maxHaplotypes;
     int32_t filterVarsByCoverage, skipDifficultWindows;
@@ -385,10 +408,10 @@ typedef struct plat_stage_b_out {
     /* the window batch */
     int32_t* b_hap_begin; int32_t* b_read_begin; int32_t* b_start; int32_t* b_end; int32_t* b_flank;       /* [cap_batch_windows (+1)] */
     int64_t* b_pair_off; int64_t* b_gl_off; int32_t* b_seg_begin; int32_t* b_n_good;                          /* [cap_batch_windows (+1)] */
-    int64_t* b_hap_off; uint32_t* b_hap_mask; uint8_t* b_hap_seq; uint8_t* hap_scratch;                      /* [cap_batch_haps + 1], [cap_hap_bytes] x 2 */
+    int64_t* b_hap_off; uint32_t* b_hap_mask; uint8_t* b_hap_seq;                                            /* [cap_batch_haps + 1], [cap_hap_bytes] */
     int64_t* b_read_off; int32_t* b_read_src; uint8_t* b_read_kind;                                           /* [cap_batch_reads (+1)] */
     int64_t* totals;                                                                                           /* [16] */
-    int32_t* scratch;                                                                                          /* [8 * n_regions * cap_windows + 64] */
+    int32_t* scratch;                                                                                          /* [24 * n_regions * cap_windows + 48 * n_regions + 64] */
 } plat_stage_b_out;
 int plat_stage_b_batch(plat_ctx* ctx, const plat_stage_b_in* batch, const plat_stage_b_options* options,
                        const plat_stage_b_out* out, void* stream);

@@ -133,6 +133,8 @@ struct Slot {
     // they crossed the link (expanded into t_seq / t_qual by plat_unpack_reads), t_exc*: their exceptions
     Staged<uint8_t> t_seq, t_qual, t_mapq, t_pack, t_excb, t_excq;
     Staged<int64_t> t_excidx;
+    Staged<plat_table_desc> t_desc;
+    Staged<plat_unpack_piece> t_pieces;
     Staged<int64_t> t_off;
     Staged<int32_t> t_pos, t_end, t_flags, t_cigoff, t_region;
     Staged<int16_t> t_cigar;
@@ -163,9 +165,9 @@ struct Slot {
     Staged<int64_t> sb_totals;
     Staged<int32_t> d_hapbegin, d_readbegin, d_start, d_end, d_flank, d_segbegin, d_ngood, d_src, d_scratch;                 // device only
     Staged<int64_t> d_pairoff, d_gloff, d_hapoff, d_readoff;
-    Staged<uint8_t> d_hapseq, d_haptmp, d_kind;
+    Staged<uint8_t> d_hapseq, d_kind;
     // many small arrays travel as ONE copy: they are views into these blocks (Layout)
-    Arena a_tab, a_cin, a_cout, a_mout, a_win, a_wout, a_pin, a_sin, a_sout, a_asin, a_asout, a_bin, a_bout;
+    Arena a_tab, a_desc, a_cin, a_cout, a_mout, a_win, a_wout, a_pin, a_sin, a_sout, a_asin, a_asout, a_bin, a_bout;
     double t_host = 0, t_wait = 0;
 
     void sync(const char* where) {
@@ -195,6 +197,10 @@ struct Layout {
         for (Item& it : items) { *it.h = a.h + it.off; *it.d = a.d + it.off; }
     }
     void upload(Slot& s, Arena& a) { if (total) ck(plat_memcpy_h2d(s.ctx, a.d, a.h, total, s.stream), "plat_memcpy_h2d"); }
+    void uploadFirst(Slot& s, Arena& a, size_t nItems) {
+        const size_t bytes = nItems >= items.size() ? total : items[nItems].off;
+        if (bytes) ck(plat_memcpy_h2d(s.ctx, a.d, a.h, bytes, s.stream), "plat_memcpy_h2d");
+    }
     // only the first `nItems` arrays (they lie in the order they were added)
     void downloadFirst(Slot& s, Arena& a, size_t nItems) {
         const size_t bytes = nItems >= items.size() ? total : items[nItems].off;
@@ -207,7 +213,9 @@ struct Layout {
 struct TableView {
     const plat_read_table* t = nullptr;
     int64_t base = 0;                                                     // index of its first read in the chunk's device table
+    int64_t blobBase = 0;                                                 // first byte of its bases in the chunk's blob
     int longest = 0;                                                      // getLengthOfLongestRead (:167-172)
+    int maxLen = 0;                                                       // most bases of a read
     int n() const { return t->n_reads; }
     static int lowerBound(const int32_t* a, int n, int64_t key) { return (int)(std::lower_bound(a, a + n, key, [](int32_t x, int64_t k) { return (int64_t)x < k; }) - a); }
     // the same index, found by galloping away from `hint` (the loop's windows ascend: the last window's pointer is a few reads away)
@@ -265,6 +273,11 @@ static int longestRead(const plat_read_table& t) {
     int m = 0;
     for (int i = 0; i < t.n_reads; ++i) m = std::max(m, t.end[i] - t.pos[i]);
     return m;
+}
+static int mostBases(const plat_read_table& t) {
+    int64_t m = 0;
+    for (int i = 0; i < t.n_reads; ++i) m = std::max(m, t.off[i + 1] - t.off[i]);
+    return (int)m;
 }
 
 // ---- haplotypes ---------------------------------------------------------------------------------------------------------------
@@ -618,11 +631,26 @@ struct Chunk {
         Slot& z = s;
         z.t_seq.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream); z.t_qual.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream);
         if (anyPacked) z.t_pack.reserve(z.ctx, B + PLAT_BLOB_PAD, false, true, z.stream);
+        // every table with its per-read arrays on the device already: the chunk table is put together there (plat_concat_read_tables)
+        bool cols = true;
+        for (RegionWork* r : regions)
+            for (SampleView& sv : r->samples)
+                for (const TableView* tv : {&sv.reads, &sv.bad, &sv.broken}) {
+                    const plat_read_table& t = *tv->t;
+                    if (t.n_reads && !(t.dev_off && t.dev_pos && t.dev_end && t.dev_mapq && t.dev_flags && t.dev_cigar && t.dev_cig_off && t.dev_seq)) cols = false;
+                }
         Layout L;
+        L.add(z.t_excidx, nExc + 1); L.add(z.t_excb, nExc + 1); L.add(z.t_excq, nExc + 1);
         L.add(z.t_off, N + 1); L.add(z.t_pos, N + 1); L.add(z.t_end, N + 1); L.add(z.t_flags, N + 1); L.add(z.t_mapq, N + 1); L.add(z.t_cigoff, N + 1);
         L.add(z.t_cigar, 2 * Cg + 2); L.add(z.t_region, nReads[0] + 1);
-        L.add(z.t_excidx, nExc + 1); L.add(z.t_excb, nExc + 1); L.add(z.t_excq, nExc + 1);
         L.commit(z, z.a_tab);
+        Layout LD;
+        size_t nDesc = 0;
+        int mostPerTable = 0;
+        const size_t nTables = 3 * regions.size() * (regions.empty() ? 0 : regions[0]->samples.size());
+        LD.add(z.t_pieces, nTables + 1);
+        if (cols) LD.add(z.t_desc, nTables + 1);
+        LD.commit(z, z.a_desc);
         struct Pending { size_t bo, nb, e0, ne; const uint8_t* dev; };       // dev: expand from this device address instead of t_pack + bo
         std::vector<Pending> packed;
         size_t ri = 0, bo = 0, co = 0, eo = 0, inBytes = 0;
@@ -634,16 +662,16 @@ struct Chunk {
                     TableView& tv = k == 0 ? sv.reads : (k == 1 ? sv.bad : sv.broken);
                     const plat_read_table& t = *tv.t;
                     const int n = t.n_reads;
-                    tv.base = (int64_t)ri;
+                    tv.base = (int64_t)ri; tv.blobBase = (int64_t)bo;
+                    maxReadLen = std::max(maxReadLen, tv.maxLen);
                     const size_t nb = (size_t)t.off[n], nc = (size_t)t.cig_off[n];
                     if (nb && t.encoding == PLAT_READS_PACKED) {            // one byte per base crosses the link (or none: dev_seq); expanded below
                         if (!t.dev_seq) ck(plat_memcpy_h2d(z.ctx, z.t_pack.d + bo, t.seq, nb, z.stream), "plat_memcpy_h2d(packed)");
                         const size_t ne = (size_t)std::max<int64_t>(t.n_exceptions, 0);
-                        // packed tables that follow each other in the blob are expanded by ONE plat_unpack_reads: the exceptions of the
-                        // later ones are counted from the first one's first byte
-                        const bool joins = !t.dev_seq && !packed.empty() && !packed.back().dev && packed.back().bo + packed.back().nb == bo && packed.back().e0 + packed.back().ne == eo;
-                        const int64_t shift = joins ? (int64_t)(bo - packed.back().bo) : 0;
-                        for (size_t e = 0; e < ne; ++e) { z.t_excidx.h[eo + e] = t.exc_index[e] + shift; z.t_excb.h[eo + e] = t.exc_base[e]; z.t_excq.h[eo + e] = t.exc_qual[e]; }
+                        // every packed table of the chunk is expanded by ONE launch (plat_unpack_reads_pieces): tables that follow each other in
+                        // t_pack join into one piece; exceptions are indexed from the chunk blob's first byte
+                        const bool joins = !t.dev_seq && !packed.empty() && !packed.back().dev && packed.back().bo + packed.back().nb == bo;
+                        for (size_t e = 0; e < ne; ++e) { z.t_excidx.h[eo + e] = t.exc_index[e] + (int64_t)bo; z.t_excb.h[eo + e] = t.exc_base[e]; z.t_excq.h[eo + e] = t.exc_qual[e]; }
                         if (joins) { packed.back().nb += nb; packed.back().ne += ne; }
                         else packed.push_back(Pending{bo, nb, eo, ne, t.dev_seq});
                         eo += ne; inBytes += (t.dev_seq ? 0 : nb) + 10 * ne;
@@ -655,10 +683,20 @@ struct Chunk {
                         ck(plat_memcpy_h2d(z.ctx, z.t_qual.d + bo, t.qual, nb, z.stream), "plat_memcpy_h2d(qual)");
                         inBytes += 2 * nb;
                     }
+                    if (cols) {
+                        if (n) {
+                            plat_table_desc& d = z.t_desc.h[nDesc++];
+                            d.off = t.dev_off; d.pos = t.dev_pos; d.end = t.dev_end; d.mapq = t.dev_mapq; d.flags = t.dev_flags; d.cigar = t.dev_cigar; d.cig_off = t.dev_cig_off;
+                            d.n = n; d.scan = k == 0 ? scan : -1; d.first_read = (int64_t)ri; d.first_byte = (int64_t)bo; d.first_pair = (int64_t)co;
+                            mostPerTable = std::max(mostPerTable, n);
+                        }
+                        ri += (size_t)n; bo += nb; co += nc;
+                        ++scan;
+                        continue;
+                    }
                     for (int i = 0; i < n; ++i) {
                         z.t_off.h[ri + i] = (int64_t)bo + t.off[i];
                         z.t_cigoff.h[ri + i] = (int32_t)(co + (size_t)t.cig_off[i]);
-                        maxReadLen = std::max(maxReadLen, (int)(t.off[i + 1] - t.off[i]));
                     }
                     if (n) {
                         memcpy(z.t_pos.h + ri, t.pos, sizeof(int32_t) * (size_t)n); memcpy(z.t_end.h + ri, t.end, sizeof(int32_t) * (size_t)n);
@@ -670,12 +708,30 @@ struct Chunk {
                     ++scan;
                 }
         }
-        z.t_off.h[N] = (int64_t)bo; z.t_cigoff.h[N] = (int32_t)Cg;
-        z.t_cigar.h[2 * Cg] = 0; z.t_cigar.h[2 * Cg + 1] = 0;
-        L.upload(z, z.a_tab);
-        for (const Pending& p : packed)
-            ck(plat_unpack_reads(z.ctx, (int64_t)p.nb, p.dev ? p.dev : z.t_pack.d + p.bo, z.t_seq.d + p.bo, z.t_qual.d + p.bo, (int64_t)p.ne, z.t_excidx.d + p.e0,
-                                 z.t_excb.d + p.e0, z.t_excq.d + p.e0, z.stream), "plat_unpack_reads");
+        if (cols) {
+            L.uploadFirst(z, z.a_tab, 3);                                   // (the exceptions of packed tables; the per-read arrays are made on the device)
+            if (nDesc) {
+                LD.upload(z, z.a_desc);
+                ck(plat_concat_read_tables(z.ctx, (int)nDesc, mostPerTable, z.t_desc.d, z.t_off.d, z.t_pos.d, z.t_end.d, z.t_mapq.d, z.t_flags.d, z.t_cigoff.d, z.t_cigar.d,
+                                           z.t_region.d, (int64_t)N, (int64_t)bo, (int64_t)Cg, z.stream), "plat_concat_read_tables");
+            }
+        }
+        if (!cols || !nDesc) {
+            z.t_off.h[N] = (int64_t)bo; z.t_cigoff.h[N] = (int32_t)Cg;
+            z.t_cigar.h[2 * Cg] = 0; z.t_cigar.h[2 * Cg + 1] = 0;
+            L.upload(z, z.a_tab);
+        }
+        if (!packed.empty()) {
+            size_t most = 0;
+            for (size_t q = 0; q < packed.size(); ++q) {
+                const Pending& p = packed[q];
+                z.t_pieces.h[q] = plat_unpack_piece{p.dev ? p.dev : z.t_pack.d + p.bo, (int64_t)p.bo, (int64_t)p.nb};
+                most = std::max(most, p.nb);
+            }
+            ck(plat_memcpy_h2d(z.ctx, z.t_pieces.d, z.t_pieces.h, packed.size() * sizeof(plat_unpack_piece), z.stream), "plat_memcpy_h2d(pieces)");
+            ck(plat_unpack_reads_pieces(z.ctx, (int)packed.size(), (int64_t)most, z.t_pieces.d, z.t_seq.d, z.t_qual.d, (int64_t)bo, (int64_t)eo, z.t_excidx.d, z.t_excb.d,
+                                        z.t_excq.d, z.stream), "plat_unpack_reads_pieces");
+        }
         nGood = nReads[0]; nScan = scan; nBad = nReads[1]; nBroken = nReads[2];
         std::lock_guard<std::mutex> g(stMutex);
         st.n_reads += (int64_t)N;
@@ -819,9 +875,9 @@ struct Chunk {
         z.d_hapbegin.reserve(z.ctx, capBW + 2, false); z.d_readbegin.reserve(z.ctx, capBW + 2, false); z.d_start.reserve(z.ctx, capBW + 2, false);
         z.d_end.reserve(z.ctx, capBW + 2, false); z.d_flank.reserve(z.ctx, capBW + 2, false); z.d_segbegin.reserve(z.ctx, capBW + 2, false);
         z.d_ngood.reserve(z.ctx, capBW + 2, false); z.d_pairoff.reserve(z.ctx, capBW + 2, false); z.d_gloff.reserve(z.ctx, capBW + 2, false);
-        z.d_hapoff.reserve(z.ctx, capBH + 2, false); z.d_hapseq.reserve(z.ctx, capHB + PLAT_BLOB_PAD, false, true, z.stream); z.d_haptmp.reserve(z.ctx, capHB + PLAT_BLOB_PAD, false);
+        z.d_hapoff.reserve(z.ctx, capBH + 2, false); z.d_hapseq.reserve(z.ctx, capHB + PLAT_BLOB_PAD, false, true, z.stream);
         z.d_readoff.reserve(z.ctx, capBR + 2, false); z.d_src.reserve(z.ctx, capBR + 2, false); z.d_kind.reserve(z.ctx, capBR + 2, false);
-        z.d_scratch.reserve(z.ctx, 8 * capBW + 64, false);
+        z.d_scratch.reserve(z.ctx, 24 * capBW + 48 * nR + 64, false);
         plat_stage_b_in in;
         memset(&in, 0, sizeof in);
         in.n_regions = (int32_t)nR; in.cap_per_scan = mergeCap; in.cand = z.m_cand.d; in.cand_n = z.m_n.d;
@@ -844,7 +900,7 @@ struct Chunk {
         ob.win_ptrs = z.sb_wptrs.d; ob.win_n_haps = z.sb_wnhaps.d; ob.win_batch = z.sb_wbatch.d;
         ob.b_hap_begin = z.d_hapbegin.d; ob.b_read_begin = z.d_readbegin.d; ob.b_start = z.d_start.d; ob.b_end = z.d_end.d; ob.b_flank = z.d_flank.d;
         ob.b_pair_off = z.d_pairoff.d; ob.b_gl_off = z.d_gloff.d; ob.b_seg_begin = z.d_segbegin.d; ob.b_n_good = z.d_ngood.d;
-        ob.b_hap_off = z.d_hapoff.d; ob.b_hap_mask = z.sb_hapmask.d; ob.b_hap_seq = z.d_hapseq.d; ob.hap_scratch = z.d_haptmp.d;
+        ob.b_hap_off = z.d_hapoff.d; ob.b_hap_mask = z.sb_hapmask.d; ob.b_hap_seq = z.d_hapseq.d;
         ob.b_read_off = z.d_readoff.d; ob.b_read_src = z.d_src.d; ob.b_read_kind = z.d_kind.d; ob.totals = z.sb_totals.d; ob.scratch = z.d_scratch.d;
         const int rc = plat_stage_b_batch(z.ctx, &in, &so, &ob, z.stream);
         if (rc == PLAT_ERR_UNSUPPORTED) { deviceB = false; return; }        // (a device library without this stage: the host's own code)
@@ -887,6 +943,7 @@ struct Chunk {
             r.variants.clear();
             const uint8_t* blob = z.sb_added.h + g * (size_t)capA;
             for (int i = 0; i < nV; ++i) {
+                PROF("s2.fill.variant");
                 const size_t k = g * (size_t)capV + (size_t)i;
                 const int nrem = z.sb_vnrem.h[k], nadd = z.sb_vnadd.h[k];
                 Variant* v = r.pool.make(z.sb_vpos.h[k], std::string((const char*)r.fa.seq + z.sb_vrempos.h[k], (size_t)nrem),
@@ -897,8 +954,11 @@ struct Chunk {
             if (r.cur.size() != r.samples.size()) r.cur.assign(r.samples.size(), Ptrs{0, 0, 0, 0, 0, 0});
             r.windows.reserve(r.windows.size() + (size_t)nW); r.items.reserve(r.items.size() + (size_t)nW);
             for (int q = 0; q < nW; ++q) {
+                PROF("s2.fill.window");
                 const size_t k = g * (size_t)capW + (size_t)q;
-                WindowWork w;
+                r.items.push_back(Item{0, (int)r.windows.size(), std::string(), 0});
+                r.windows.emplace_back();                                   // (filled in place: a WindowWork is two dozen containers to move otherwise)
+                WindowWork& w = r.windows.back();
                 w.region = r.index; w.startPos = z.sb_wstart.h[k]; w.endPos = z.sb_wend.h[k];
                 const int vf = z.sb_wvfirst.h[k], vn = z.sb_wvn.h[k], flags = z.sb_wflags.h[k], nH = z.sb_wnhaps.h[k], bw = z.sb_wbatch.h[k];
                 for (int i = 0; i < vn; ++i) w.vars.push_back(r.variants[(size_t)(vf + i)]);
@@ -932,8 +992,6 @@ struct Chunk {
                         }
                     }
                 }
-                r.items.push_back(Item{0, (int)r.windows.size(), std::string(), 0});
-                r.windows.push_back(std::move(w));
             }
         }
         // the batch the device built
@@ -1095,7 +1153,7 @@ struct Chunk {
         auto sameKey = [](const CandKey& a, const CandKey& b) {
             return a.pos == b.pos && a.nrem == b.nrem && a.nadd == b.nadd && memcmp(a.rem, b.rem, (size_t)a.nrem) == 0 && memcmp(a.add, b.add, (size_t)a.nadd) == 0;
         };
-        const int64_t blobBase = tv.n() ? z.t_off.h[tv.base] : 0;
+        const int64_t blobBase = tv.blobBase;
         for (int q = 0; q < tv.n(); ++q) {
             const size_t g = (size_t)(tv.base + q);
             const int cnt = z.c_cnt.h[g];
@@ -1161,7 +1219,7 @@ struct Chunk {
             for (size_t i = 0; i < r.samples.size(); ++i) {
                 const TableView& tv = r.samples[i].reads;
                 const int g = scan0 + (int)i, n = z.m_n.h[2 * g];
-                const int64_t blobBase = tv.n() ? z.t_off.h[tv.base] : 0;
+                const int64_t blobBase = tv.blobBase;
                 std::vector<const int32_t*> cands((size_t)n);
                 for (int k = 0; k < n; ++k) cands[(size_t)k] = z.m_cand.h + 8 * ((size_t)g * (size_t)mergeCap + (size_t)k);
                 std::sort(cands.begin(), cands.end(), [](const int32_t* a, const int32_t* b) { return a[0] < b[0]; });
@@ -2215,8 +2273,8 @@ CALLER_EXPORT int plat_caller_destroy(plat_caller* c) {
                    z.g_qual, z.g_mapq, z.o_loglik, z.o_gl, z.o_logl, z.o_gof, z.o_freq, z.o_em, z.p_win, z.s_vw, z.s_pos, z.s_min, z.s_max, z.s_nadd, z.s_nrem,
                    z.s_gb, z.s_ge, z.s_bb, z.s_be, z.s_ps, z.s_minq, z.s_nminq, z.k_win, z.k_nvar, z.k_vih, z.k_ref, z.k_ph, z.p_off, z.s_aoff, z.s_moff, z.s_counts,
                    z.k_vo, z.k_ro, z.k_lo, z.p_mask, z.s_added, z.s_vig, z.p_prior, z.p_post, z.k_lik, z.k_out4, z.t_pack, z.as_seq, z.as_qual, z.as_mapq, z.as_pos, z.as_end, z.as_flags, z.a_asin, z.a_asout, z.a_tab, z.a_cin, z.a_cout, z.a_mout, z.c_scanbegin, z.c_scanlongest, z.m_cand, z.m_n, z.a_win, z.a_wout,
-                   z.a_pin, z.a_sin, z.a_sout, z.a_bin, z.a_bout, z.d_hapbegin, z.d_readbegin, z.d_start, z.d_end, z.d_flank, z.d_segbegin, z.d_ngood, z.d_src,
-                   z.d_scratch, z.d_pairoff, z.d_gloff, z.d_hapoff, z.d_readoff, z.d_hapseq, z.d_haptmp, z.d_kind);
+                   z.a_pin, z.a_sin, z.a_sout, z.a_bin, z.a_bout, z.a_desc, z.d_hapbegin, z.d_readbegin, z.d_start, z.d_end, z.d_flank, z.d_segbegin, z.d_ngood, z.d_src,
+                   z.d_scratch, z.d_pairoff, z.d_gloff, z.d_hapoff, z.d_readoff, z.d_hapseq, z.d_kind);
         plat_stream_destroy(z.ctx, z.stream);
         plat_ctx_destroy(z.ctx);
     }
@@ -2246,6 +2304,7 @@ static std::unique_ptr<RegionWork> makeRegionWork(const plat_region* in, int ind
         SampleView& sv = r->samples[(size_t)i];
         sv.reads.t = &sr.reads; sv.bad.t = &sr.bad_reads; sv.broken.t = &sr.broken_mates;
         sv.reads.longest = longestRead(sr.reads); sv.bad.longest = longestRead(sr.bad_reads); sv.broken.longest = longestRead(sr.broken_mates);
+        sv.reads.maxLen = mostBases(sr.reads); sv.bad.maxLen = mostBases(sr.bad_reads); sv.broken.maxLen = mostBases(sr.broken_mates);
         longest = std::max(longest, sv.reads.longest);
     }
     longestOut = longest;

@@ -654,3 +654,108 @@ PLAT_EXPORT int plat_unpack_reads(plat_ctx* ctx, int64_t n_bytes, const uint8_t*
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
+
+
+namespace plat {
+// k_unpack_reads for a list of pieces: blockIdx.y = piece; lanes work on 16-byte lines of the piece's place in the output
+__global__ void __launch_bounds__(256)
+k_unpack_pieces(const plat_unpack_piece* __restrict__ pieces, uint8_t* __restrict__ out_seq, uint8_t* __restrict__ out_qual, int same_base_alignment)
+{
+    const plat_unpack_piece pc = pieces[blockIdx.y];
+    const uint8_t* packed = pc.src;
+    uint8_t* oseq = out_seq + pc.dst;
+    uint8_t* oqual = out_qual + pc.dst;
+    const long long n = pc.n;
+    const int mis = same_base_alignment ? (int)((uintptr_t)oseq & 15) : 0;
+    const bool srcAligned = (((uintptr_t)packed - (uintptr_t)mis) & 15) == 0 || (((uintptr_t)packed & 15) == (unsigned)mis);
+    const long long lines = (n + mis + 15) / 16;
+    for (long long ln = (long long)blockIdx.x * blockDim.x + threadIdx.x; ln < lines; ln += (long long)gridDim.x * blockDim.x) {
+        const long long i0 = ln * 16 - mis;
+        if (same_base_alignment && i0 >= 0 && i0 + 16 <= n) {
+            uint32_t w[4];
+            if (srcAligned) { const uint4 v = *(const uint4*)(packed + i0); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+            else {
+                const unsigned long long lo = load_u64_bytes(packed + i0), hi = load_u64_bytes(packed + i0 + 8);
+                w[0] = (uint32_t)lo; w[1] = (uint32_t)(lo >> 32); w[2] = (uint32_t)hi; w[3] = (uint32_t)(hi >> 32);
+            }
+            uint32_t sq[4], ql[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t code = w[k] & 0x03030303u;
+                sq[k] = __builtin_amdgcn_perm(0u, 0x47544341u, code);
+                ql[k] = (w[k] >> 2) & 0x3F3F3F3Fu;
+            }
+            *(uint4*)(oseq + i0) = make_uint4(sq[0], sq[1], sq[2], sq[3]);
+            *(uint4*)(oqual + i0) = make_uint4(ql[0], ql[1], ql[2], ql[3]);
+        } else {
+            for (long long i = i0 < 0 ? 0 : i0; i < n && i < i0 + 16; ++i) {
+                const unsigned bb = packed[i];
+                oseq[i] = (uint8_t)((0x47544341u >> (8u * (bb & 3u))) & 0xFFu);
+                oqual[i] = (uint8_t)(bb >> 2);
+            }
+        }
+    }
+}
+}  // namespace plat
+
+PLAT_EXPORT int plat_unpack_reads_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual,
+                                         int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream)
+{
+    if (!ctx || n_pieces < 0 || max_piece_bytes < 0 || total_bytes < 0 || n_exc < 0) return PLAT_ERR_INVALID;
+    if (n_pieces == 0) return PLAT_OK;
+    if (!pieces || !out_seq || !out_qual || (n_exc > 0 && (!exc_index || !exc_base || !exc_qual))) return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    const int same = ((uintptr_t)out_seq & 15) == ((uintptr_t)out_qual & 15);
+    long long gx = (max_piece_bytes / 16 + 256) / 256;
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(plat::k_unpack_pieces, dim3((unsigned)gx, (unsigned)n_pieces), dim3(256), 0, (hipStream_t)stream, pieces, out_seq, out_qual, same);
+    if (n_exc > 0)
+        hipLaunchKernelGGL(plat::k_unpack_exceptions, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n_exc,
+                           (long long)total_bytes, exc_index, exc_base, exc_qual, out_seq, out_qual);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}
+
+// ---- a chunk's read table put together on the device from resident tables (plat_concat_read_tables) ----------------------------------
+namespace plat {
+__global__ void __launch_bounds__(256)
+k_concat_tables(const plat_table_desc* __restrict__ desc, int64_t* __restrict__ dst_off, int32_t* __restrict__ dst_pos, int32_t* __restrict__ dst_end,
+                uint8_t* __restrict__ dst_mapq, int32_t* __restrict__ dst_flags, int32_t* __restrict__ dst_cig_off, int16_t* __restrict__ dst_cigar,
+                int32_t* __restrict__ dst_region, long long n_total, long long total_bytes, long long total_pairs)
+{
+    const plat_table_desc d = desc[blockIdx.y];
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += stride) {
+        const long long r = d.first_read + i;
+        dst_off[r] = d.first_byte + d.off[i];
+        dst_pos[r] = d.pos[i]; dst_end[r] = d.end[i]; dst_mapq[r] = d.mapq[i]; dst_flags[r] = d.flags[i];
+        const int c0 = d.cig_off[i], c1 = d.cig_off[i + 1];
+        dst_cig_off[r] = (int32_t)(d.first_pair + c0);
+        for (int c = c0; c < c1; ++c) {
+            dst_cigar[2 * (d.first_pair + c)] = d.cigar[2 * c];
+            dst_cigar[2 * (d.first_pair + c) + 1] = d.cigar[2 * c + 1];
+        }
+        if (d.scan >= 0) dst_region[r] = d.scan;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        dst_off[n_total] = total_bytes; dst_cig_off[n_total] = (int32_t)total_pairs;
+        dst_cigar[2 * total_pairs] = 0; dst_cigar[2 * total_pairs + 1] = 0;
+    }
+}
+}  // namespace plat
+
+PLAT_EXPORT int plat_concat_read_tables(plat_ctx* ctx, int n_tables, int max_reads_per_table, const plat_table_desc* desc, int64_t* dst_off, int32_t* dst_pos,
+                                        int32_t* dst_end, uint8_t* dst_mapq, int32_t* dst_flags, int32_t* dst_cig_off, int16_t* dst_cigar,
+                                        int32_t* dst_region, int64_t n_total_reads, int64_t total_bytes, int64_t total_pairs, void* stream)
+{
+    if (!ctx || n_tables < 0 || max_reads_per_table < 0 || n_total_reads < 0) return PLAT_ERR_INVALID;
+    if (!dst_off || !dst_pos || !dst_end || !dst_mapq || !dst_flags || !dst_cig_off || !dst_cigar || !dst_region) return PLAT_ERR_INVALID;
+    if (n_tables < 1 || !desc) return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned gx = (unsigned)((max_reads_per_table + 255) / 256);
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    hipLaunchKernelGGL(plat::k_concat_tables, dim3(gx, (unsigned)n_tables), dim3(256), 0, (hipStream_t)stream, desc, dst_off, dst_pos, dst_end,
+                       dst_mapq, dst_flags, dst_cig_off, dst_cigar, dst_region, (long long)n_total_reads, (long long)total_bytes, (long long)total_pairs);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}

@@ -12,15 +12,16 @@
 //   chaplotype.pyx:127-191,397-449       Haplotype.__init__, getMutatedSequence
 //   variantcaller.pyx:325-383            mergeHaplotypes: sorted(haplotypes) (equal sequences are left to the caller)
 //
-// Five small kernels, no host round trip between them:
+// Five small kernels, no host round trip between them (windows keep the order (region, window) in the batch):
 //   k_sb_variants  one workgroup per region: the region's candidates in LDS; rank sort by the reference's key; one WAVE per indel
 //                  walks the reference for its leftmost / rightmost placement (64 positions per step, ballot); second sort; runs of
 //                  equal variants merged (supports summed); the filter; then one lane bunches the survivors into windows (the
 //                  bunching is a sequential rule over ~100 positions, on LDS)
-//   k_sb_windows   one thread per window: window pointers by binary search in the read table, the decision (call / skip / the
-//                  caller's greedy filter), the valid combinations counted and their lengths summed
-//   k_sb_scan      one workgroup: exclusive scans over the windows -> where each window's haplotypes, reads, pairs and bytes go
-//   k_sb_haps      one wave per window: haplotype bytes (every lane finds the segment its byte comes from), lexicographic ranks by
+//   k_sb_windows   one workgroup per region, one thread per window: window pointers by binary search in the read table, the decision
+//                  (call / skip / the caller's greedy filter), the valid combinations counted and their lengths summed; then the
+//                  prefix sums of the region's windows
+//   k_sb_scan      one wave: exclusive scan over the REGIONS -> where each region's windows, haplotypes, reads, pairs and bytes go
+//   k_sb_haps      one workgroup per window: haplotype bytes (every lane finds the segment its byte comes from), lexicographic ranks by
 //                  wave-wide comparisons from the first variant on, bytes copied in rank order
 //   k_sb_reads     one wave per window: read indices, kinds and offsets of the window's reads
 // Anything the reference would raise on, anything whose order depends on a Python dictionary and anything beyond the capacities is
@@ -30,6 +31,7 @@
 namespace plat {
 
 constexpr int SB_CAP = 1024;                      // candidates of a region held in LDS (more: the caller's own code)
+constexpr int SB_THREADS = 1024;                  // k_sb_variants: 16 waves (16 indels walk the reference side by side)
 constexpr int SB_MAXCOMB = 5;                     // a window with more variants than this goes through the greedy filter (the caller's)
 
 struct SbIn {
@@ -44,7 +46,7 @@ __device__ __forceinline__ int sb_type(int nrem, int nadd) {          // variant
     return 4;
 }
 
-// exclusive scan over the 256 threads of a workgroup; total in *tot (LDS scratch of 8 ints)
+// exclusive scan over the threads of a workgroup (up to 16 waves); total in *tot (LDS scratch of 16 ints)
 __device__ __forceinline__ int sb_block_scan(int v, int* wsum, int* tot) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int x = v;
@@ -66,7 +68,7 @@ struct SbRegion {                                  // per-region LDS state of k_
     unsigned short perm[SB_CAP];                   // sorted position -> element
     unsigned char head[SB_CAP], keep[SB_CAP];
     int list[SB_CAP];
-    int wsum[8], tot, nIndel, addedUsed, status, nKept;
+    int wsum[16], tot, nIndel, addedUsed, status, nKept;
 };
 
 // the added bases of element e: in the read table (addo >= 0) or, once normalised, in the region's own blob (addo = -(offset + 1))
@@ -82,7 +84,7 @@ __device__ __forceinline__ bool sb_same(const SbRegion& R, int a, int b, const u
     return true;                                                       // (removed bases: the reference's own at pos, equal when pos and nrem are)
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_sb_variants(SbIn in, plat_stage_b_out out)
 {
     extern __shared__ __align__(16) unsigned char sb_lds[];
@@ -105,7 +107,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out)
     const int rlen = b.region_rlen[g];
     long long nrec = 0;
     // ---- load; key of the reference's order
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += SB_THREADS) {
         const int32_t* c = b.cand + 8ll * ((long long)g * b.cap_per_scan + i);
         const int pos = c[3] < 0 ? 0 : c[3], nrem = c[4], nadd = c[5];
         R.id[i] = c[0]; R.supp[i] = c[1]; R.pos[i] = pos; R.nrem[i] = nrem; R.nadd[i] = nadd;
@@ -121,26 +123,26 @@ k_sb_variants(SbIn in, plat_stage_b_out out)
         __syncthreads();
         if (lane == 0) R.wsum[wv] = (int)nrec;
         __syncthreads();
-        if (tid == 0) hdr[3] = R.wsum[0] + R.wsum[1] + R.wsum[2] + R.wsum[3];
+        if (tid == 0) { int t = 0; for (int k = 0; k < SB_THREADS / 64; ++k) t += R.wsum[k]; hdr[3] = t; }
         __syncthreads();
     }
     // ---- first sort: (refPos, varType, nRemoved), equal keys in the dictionary's insertion order (sorted() is stable)
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += SB_THREADS) {
         const unsigned long long k = R.key[i]; const int id = R.id[i];
         int r = 0;
         for (int j = 0; j < n; ++j) { const unsigned long long kj = R.key[j]; r += (kj < k) || (kj == k && R.id[j] < id); }
         R.list[i] = r;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) R.id[i] = R.list[i];          // id := rank in the first sort (the tie-break of the second)
+    for (int i = tid; i < n; i += SB_THREADS) R.id[i] = R.list[i];          // id := rank in the first sort (the tie-break of the second)
     __syncthreads();
     // ---- leftNormaliseIndel: pure insertions / deletions at refPos >= 100
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += SB_THREADS) {
         const int nrem = R.nrem[i], nadd = R.nadd[i];
         if (nrem != nadd && !(nrem > 0 && nadd > 0) && R.pos[i] >= 100) R.list[atomicAdd(&R.nIndel, 1)] = i;
     }
     __syncthreads();
-    for (int q = wv; q < R.nIndel; q += 4) {                           // one wave per indel
+    for (int q = wv; q < R.nIndel; q += SB_THREADS / 64) {                           // one wave per indel
         const int e = R.list[q];
         const int pos = R.pos[e], nrem = R.nrem[e], nadd = R.nadd[e];
         const int window = (nadd > nrem ? nadd : nrem) + rlen;
@@ -191,7 +193,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out)
     __threadfence_block();
     __syncthreads();
     // ---- second sort (stable on the first)
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += SB_THREADS) {
         const unsigned long long k = R.key[i]; const int id = R.id[i];
         int r = 0;
         for (int j = 0; j < n; ++j) { const unsigned long long kj = R.key[j]; r += (kj < k) || (kj == k && R.id[j] < id); }
@@ -199,9 +201,9 @@ k_sb_variants(SbIn in, plat_stage_b_out out)
     }
     __syncthreads();
     // ---- filterVariants: runs of equal variants (each compared with the run's first: equality is transitive) are merged into the first
-    for (int r = tid; r < n; r += 256) R.head[r] = r == 0 || !sb_same(R, R.perm[r], R.perm[r - 1], b.read_seq, blob);
+    for (int r = tid; r < n; r += SB_THREADS) R.head[r] = r == 0 || !sb_same(R, R.perm[r], R.perm[r - 1], b.read_seq, blob);
     __syncthreads();
-    for (int r = tid; r < n; r += 256) {
+    for (int r = tid; r < n; r += SB_THREADS) {
         R.keep[r] = 0;
         if (!R.head[r]) continue;
         const int e = R.perm[r];
@@ -216,7 +218,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out)
     __syncthreads();
     // ---- orders that depend on how a Python-2 dictionary iterates: not decided here
     //  (a) three or more candidates with one key among which one variant occurs twice next to a different one
-    for (int r = tid; r < n; r += 256) {
+    for (int r = tid; r < n; r += SB_THREADS) {
         const unsigned long long k = R.key[R.perm[r]];
         if (r > 0 && R.key[R.perm[r - 1]] == k) continue;
         int m = 1;
@@ -230,7 +232,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out)
     }
     // ---- the survivors, in order
     {
-        const int per = (n + 255) / 256, r0 = tid * per, r1 = min(n, r0 + per);
+        const int per = (n + SB_THREADS - 1) / SB_THREADS, r0 = tid * per, r1 = min(n, r0 + per);
         int cnt = 0;
         for (int r = r0; r < r1; ++r) cnt += R.keep[r];
         int at = sb_block_scan(cnt, R.wsum, &R.tot);
@@ -239,12 +241,12 @@ k_sb_variants(SbIn in, plat_stage_b_out out)
     __syncthreads();
     const int nk = R.tot;
     //  (b) two survivors that compare equal
-    for (int k = tid + 1; k < nk; k += 256) if (R.key[R.list[k]] == R.key[R.list[k - 1]]) atomicOr(&R.status, 1);
+    for (int k = tid + 1; k < nk; k += SB_THREADS) if (R.key[R.list[k]] == R.key[R.list[k - 1]]) atomicOr(&R.status, 1);
     if (nk > b.cap_vars) atomicOr(&R.status, 1);
     __syncthreads();
     if (R.status) { if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; } return; }
     // ---- the region's variants out (+ the added bases of those that still live in the read table)
-    for (int k = tid; k < nk; k += 256) {
+    for (int k = tid; k < nk; k += SB_THREADS) {
         const int e = R.list[k];
         const long long v = (long long)g * b.cap_vars + k;
         out.var_pos[v] = R.pos[e]; out.var_nrem[v] = R.nrem[e]; out.var_nadd[v] = R.nadd[e]; out.var_support[v] = R.supp[e];
@@ -371,17 +373,21 @@ __device__ __forceinline__ int sb_lower_bound(const int32_t* a, int n, long long
     return lo;
 }
 
-__global__ void __launch_bounds__(256)
-k_sb_windows(SbIn in, plat_stage_b_out out)
+// scratch of the stage (ints): per window slot t eight ints {flags, haplotypes, reads, haplotype bytes, read bytes, longest haplotype, -, -} at
+// 8 t; eight int64 at 8 S + 16 t: the exclusive prefix INSIDE its region of {windows, haplotypes, reads, pairs, haplotype bytes, read bytes,
+// genotype likelihoods}; per region g 24 int64 at 24 S + 48 g: [0..6] the region's totals of the same, [7..9] maxima (haplotype length, reads,
+// haplotypes of a window), [10..16] the region's base in the batch (k_sb_scan).  S = n_regions x cap_windows.
+__device__ __forceinline__ int32_t* sb_slot(const plat_stage_b_out& out, long long t) { return out.scratch + 8 * t; }
+__device__ __forceinline__ long long* sb_prefix(const plat_stage_b_in& b, const plat_stage_b_out& out, long long t) {
+    return (long long*)(out.scratch + 8ll * b.n_regions * b.cap_windows) + 8 * t;
+}
+__device__ __forceinline__ long long* sb_region(const plat_stage_b_in& b, const plat_stage_b_out& out, int g) {
+    return (long long*)(out.scratch + 24ll * b.n_regions * b.cap_windows) + 24 * g;
+}
+
+// one window: window pointers, the decision, the valid combinations counted
+static __device__ void sb_one_window(const plat_stage_b_in& b, const plat_stage_b_options& o, const plat_stage_b_out& out, int g, int k, int32_t* sc)
 {
-    const plat_stage_b_in& b = in.b;
-    const plat_stage_b_options& o = in.o;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int g = (int)(t / b.cap_windows), k = (int)(t % b.cap_windows);
-    if (g >= b.n_regions) return;
-    const int32_t* hdr = out.hdr + 8 * g;
-    int32_t* sc = out.scratch + 8 * t;                                 // {flags, haplotypes, reads, haplotype bytes, read bytes, longest haplotype, 0, 0}
-    if (hdr[0] != 0 || k >= hdr[2]) { sc[0] = -1; return; }
     const long long w = (long long)g * b.cap_windows + k;
     const int ws = out.win_start[w], we = out.win_end[w], nv = out.win_var_n[w];
     const int contigLen = b.contig_len[g], rlen = b.region_rlen[g];
@@ -421,9 +427,16 @@ k_sb_windows(SbIn in, plat_stage_b_out out)
     int nHaps = 0, maxLen = 0;
     long long hapBytes = 0;
     if (!flags) {
-        const int32_t* vpos = out.var_pos + (long long)g * b.cap_vars + out.win_var_first[w];
-        const int32_t* vnrem = out.var_nrem + (long long)g * b.cap_vars + out.win_var_first[w];
-        const int32_t* vnadd = out.var_nadd + (long long)g * b.cap_vars + out.win_var_first[w];
+        // (the fields of the window's first variants in registers: the walks below read them dozens of times)
+        int32_t vpos[SB_MAXCOMB], vnrem[SB_MAXCOMB], vnadd[SB_MAXCOMB];
+        {
+            const long long v0 = (long long)g * b.cap_vars + out.win_var_first[w];
+#pragma unroll
+            for (int i = 0; i < SB_MAXCOMB; ++i) {
+                const bool in = i < nv;
+                vpos[i] = in ? out.var_pos[v0 + i] : 0; vnrem[i] = in ? out.var_nrem[v0 + i] : 0; vnadd[i] = in ? out.var_nadd[v0 + i] : 0;
+            }
+        }
         auto none = [](int, int, int) {};
         const int refL = sb_walk_hap(W, 0u, 0, vpos, vnrem, vnadd, none);
         if (refL < 0 || refL > 16384) flags = PLAT_SBW_HOST;          // (raises there: logged, the window is skipped -- the caller reproduces it)
@@ -457,138 +470,177 @@ k_sb_windows(SbIn in, plat_stage_b_out out)
     sc[0] = flags; sc[1] = nHaps; sc[2] = nReads; sc[3] = (int)hapBytes; sc[4] = (int)readBytes; sc[5] = maxLen; sc[6] = 0; sc[7] = 0;
 }
 
-// ---- where every window of the batch goes: exclusive scans in (region, window) order, one workgroup ------------------------------
-__global__ void __launch_bounds__(1024)
+
+// exclusive scan of a 64-bit value over the 256 threads of a workgroup, total in *tot
+__device__ __forceinline__ long long sb_block_scan64(long long v, long long* wsum, long long* tot) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    long long x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const long long y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    long long base = 0;
+    for (int k = 0; k < w; ++k) base += wsum[k];
+    if (threadIdx.x == blockDim.x - 1) *tot = base + x;
+    __syncthreads();
+    return base + x - v;
+}
+
+// one workgroup per region: its windows (one per thread, 256 at a time), then their prefix sums inside the region
+__global__ void __launch_bounds__(256)
+k_sb_windows(SbIn in, plat_stage_b_out out)
+{
+    const plat_stage_b_in& b = in.b;
+    __shared__ long long wsum[4], tot, carry[7];
+    __shared__ int mx[3];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int32_t* hdr = out.hdr + 8 * g;
+    const int nW = hdr[0] != 0 ? 0 : hdr[2];
+    if (tid < 7) carry[tid] = 0;
+    if (tid < 3) mx[tid] = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < nW; k0 += 256) {
+        const int k = k0 + tid;
+        const long long t = (long long)g * b.cap_windows + k;
+        long long v[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (k < nW) {
+            int32_t* sc = sb_slot(out, t);
+            sb_one_window(b, in.o, out, g, k, sc);
+            if (sc[0] == 0) {
+                v[0] = 1; v[1] = sc[1]; v[2] = sc[2]; v[3] = (long long)sc[1] * sc[2]; v[4] = sc[3]; v[5] = sc[4]; v[6] = (long long)sc[1] * (sc[1] + 1) / 2;
+                atomicMax(&mx[0], sc[5]); atomicMax(&mx[1], sc[2]); atomicMax(&mx[2], sc[1]);
+            }
+        }
+        long long* pf = k < nW ? sb_prefix(b, out, t) : nullptr;
+        for (int q = 0; q < 7; ++q) {
+            const long long ex = sb_block_scan64(v[q], wsum, &tot);
+            if (pf) pf[q] = carry[q] + ex;
+            __syncthreads();
+            if (tid == 0) carry[q] += tot;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        long long* rg = sb_region(b, out, g);
+        for (int q = 0; q < 7; ++q) rg[q] = carry[q];
+        rg[7] = mx[0]; rg[8] = mx[1]; rg[9] = mx[2];
+    }
+}
+
+// ---- where every region's windows go in the batch: exclusive scan over the regions, one wave -------------------------------------------
+__global__ void __launch_bounds__(64)
 k_sb_scan(SbIn in, plat_stage_b_out out)
 {
     const plat_stage_b_in& b = in.b;
-    __shared__ long long part[1024][6];
-    __shared__ int mx[1024][3];
-    const int tid = threadIdx.x;
-    const long long total = (long long)b.n_regions * b.cap_windows;
-    const long long per = (total + 1023) / 1024, t0 = tid * per, t1 = t0 + per < total ? t0 + per : total;
-    long long s[6] = {0, 0, 0, 0, 0, 0};                               // windows, haplotypes, reads, pairs, haplotype bytes, read bytes
+    const int lane = threadIdx.x;
+    long long carry[7] = {0, 0, 0, 0, 0, 0, 0};
     int m0 = 0, m1 = 0, m2 = 0;
-    for (long long t = t0; t < t1; ++t) {
-        const int32_t* sc = out.scratch + 8 * t;
-        if (sc[0] != 0) continue;
-        s[0] += 1; s[1] += sc[1]; s[2] += sc[2]; s[3] += (long long)sc[1] * sc[2]; s[4] += sc[3]; s[5] += sc[4];
-        m0 = max(m0, sc[5]); m1 = max(m1, sc[2]); m2 = max(m2, sc[1]);
-    }
-    for (int q = 0; q < 6; ++q) part[tid][q] = s[q];
-    mx[tid][0] = m0; mx[tid][1] = m1; mx[tid][2] = m2;
-    __syncthreads();
-    if (tid == 0) {
-        long long run[6] = {0, 0, 0, 0, 0, 0};
-        int a0 = 0, a1 = 0, a2 = 0;
-        for (int i = 0; i < 1024; ++i) {
-            for (int q = 0; q < 6; ++q) { const long long v = part[i][q]; part[i][q] = run[q]; run[q] += v; }
-            a0 = max(a0, mx[i][0]); a1 = max(a1, mx[i][1]); a2 = max(a2, mx[i][2]);
+    for (int g0 = 0; g0 < b.n_regions; g0 += 64) {
+        const int g = g0 + lane;
+        long long* rg = g < b.n_regions ? sb_region(b, out, g) : nullptr;
+        for (int q = 0; q < 7; ++q) {
+            const long long v = rg ? rg[q] : 0;
+            long long x = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const long long y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+            if (rg) rg[10 + q] = carry[q] + x - v;
+            carry[q] += __shfl(x, 63, 64);
         }
-        long long gl = 0;
+        if (rg) { m0 = max(m0, (int)rg[7]); m1 = max(m1, (int)rg[8]); m2 = max(m2, (int)rg[9]); }
+    }
+#pragma unroll
+    for (int d = 32; d; d >>= 1) { m0 = max(m0, __shfl_xor(m0, d, 64)); m1 = max(m1, __shfl_xor(m1, d, 64)); m2 = max(m2, __shfl_xor(m2, d, 64)); }
+    if (lane == 0) {
+        const long long* run = carry;
         const bool over = run[0] > b.cap_batch_windows || run[1] > b.cap_batch_haps || run[2] > b.cap_batch_reads || run[4] > b.cap_hap_bytes;
-        out.totals[0] = run[0]; out.totals[1] = run[1]; out.totals[2] = run[2]; out.totals[3] = run[3]; out.totals[4] = gl;
-        out.totals[5] = run[4]; out.totals[6] = run[5]; out.totals[7] = a0; out.totals[8] = a1; out.totals[9] = a2; out.totals[10] = over ? 1 : 0;
+        out.totals[0] = run[0]; out.totals[1] = run[1]; out.totals[2] = run[2]; out.totals[3] = run[3]; out.totals[4] = run[6];
+        out.totals[5] = run[4]; out.totals[6] = run[5]; out.totals[7] = m0; out.totals[8] = m1; out.totals[9] = m2; out.totals[10] = over ? 1 : 0;
         for (int q = 11; q < 16; ++q) out.totals[q] = 0;
         if (!over) {                                                   // the arrays' closing entries
             const int nw = (int)run[0];
             out.b_hap_begin[nw] = (int)run[1]; out.b_read_begin[nw] = (int)run[2]; out.b_pair_off[nw] = run[3]; out.b_seg_begin[nw] = (int)run[2];
+            out.b_gl_off[nw] = run[6];
             out.b_hap_off[run[1]] = run[4]; out.b_read_off[run[2]] = run[5];
         }
     }
-    __syncthreads();
-    if (out.totals[10]) return;
-    for (int q = 0; q < 6; ++q) s[q] = part[tid][q];
-    for (long long t = t0; t < t1; ++t) {
-        int32_t* sc = out.scratch + 8 * t;
-        if (sc[0] != 0) continue;
-        const int bw = (int)s[0];
-        const int g = (int)(t / b.cap_windows);
-        const long long w = t;
-        out.win_batch[w] = bw;
-        out.b_hap_begin[bw] = (int)s[1]; out.b_read_begin[bw] = (int)s[2]; out.b_pair_off[bw] = s[3]; out.b_seg_begin[bw] = (int)s[2];
-        out.b_n_good[bw] = out.win_ptrs[6 * w + 1] - out.win_ptrs[6 * w];
-        const int contigLen = b.contig_len[g], rlen = b.region_rlen[g];
-        const int ws = out.win_start[w], we = out.win_end[w];
-        out.b_start[bw] = ws > 0 ? ws : 0; out.b_end[bw] = we < contigLen - 1 ? we : contigLen - 1; out.b_flank[bw] = 2 * rlen < 500 ? 2 * rlen : 500;
-        sc[6] = (int)s[4]; sc[7] = (int)s[5];                          // byte offsets of its haplotypes / reads
-        s[0] += 1; s[1] += sc[1]; s[2] += sc[2]; s[3] += (long long)sc[1] * sc[2]; s[4] += sc[3]; s[5] += sc[4];
-    }
-}
-
-// genotype-likelihood offsets need H (H + 1) / 2 per window: a second tiny scan (one thread per 1024th, same pattern) would do; they are
-// a function of b_hap_begin alone, so one thread per window computes its own prefix from the haplotype counts with a wave scan below
-__global__ void __launch_bounds__(256)
-k_sb_gloff(SbIn in, plat_stage_b_out out)
-{
-    // one workgroup: windows in order, G = H (H + 1) / 2 (one sample)
-    __shared__ int wsum[8];
-    __shared__ int tot;
-    __shared__ long long carry;
-    if (out.totals[10]) return;
-    const int nw = (int)out.totals[0];
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int w0 = 0; w0 < nw; w0 += 256) {
-        const int w = w0 + threadIdx.x;
-        int G = 0;
-        if (w < nw) { const int H = out.b_hap_begin[w + 1] - out.b_hap_begin[w]; G = H * (H + 1) / 2; }
-        const int ex = sb_block_scan(G, wsum, &tot);
-        if (w < nw) out.b_gl_off[w] = carry + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) carry += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { out.b_gl_off[nw] = carry; out.totals[4] = carry; }
 }
 
 // ---- haplotype bytes, sorted ------------------------------------------------------------------------------------------------------
+// One workgroup (four waves) per window, haplotype h handled by wave h % 4.  Every haplotype of a window is the reference up to the
+// window's first variant: the SB_STAGE bytes behind that point are staged in LDS and sorted(haplotypes) is decided there (two strings that
+// agree on all of them and go on are left to the caller: a tandem repeat longer than the stage); then each haplotype's bytes are written
+// once, straight to their place in rank order.
+constexpr int SB_STAGE = 384;
 __global__ void __launch_bounds__(256)
 k_sb_haps(SbIn in, plat_stage_b_out out)
 {
     const plat_stage_b_in& b = in.b;
-    __shared__ unsigned s_mask[4][32];
-    __shared__ int s_len[4][32], s_rank[4][32], s_off[4][32];
-    __shared__ int s_seg[4][24][3];                                    // segments of the haplotype being written: kind, source, length
+    __shared__ unsigned s_mask[32];
+    __shared__ int s_len[32], s_rank[32], s_off[32], s_dup;
+    __shared__ int s_seg[4][24][3];                                    // segments of the haplotype a wave is writing: kind, source, length
+    __shared__ int32_t s_vpos[8], s_vnrem[8], s_vnadd[8], s_vadd[8];
+    __shared__ __align__(16) uint8_t s_stage[32][SB_STAGE];
     if (out.totals[10]) return;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long t = (long long)blockIdx.x * 4 + wv;
-    if (t >= (long long)b.n_regions * b.cap_windows) return;
-    const int32_t* sc = out.scratch + 8 * t;
-    if (sc[0] != 0) return;
-    const int g = (int)(t / b.cap_windows);
-    const long long w = t;
-    const int bw = out.win_batch[w], nv = out.win_var_n[w], nH = sc[1], hb = out.b_hap_begin[bw];
-    const long long byte0 = sc[6];
-    const long long v0 = (long long)g * b.cap_vars + out.win_var_first[w];
-    const int32_t* vpos = out.var_pos + v0;
-    const int32_t* vnrem = out.var_nrem + v0;
-    const int32_t* vnadd = out.var_nadd + v0;
-    const int32_t* vadd = out.var_add_off + v0;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int g = blockIdx.y;
+    const int nWin = out.hdr[8 * g] != 0 ? 0 : out.hdr[8 * g + 2];
+    const long long* rg = sb_region(b, out, g);
     const uint8_t* added = out.added + (long long)g * b.cap_added;
-    const int contigLen = b.contig_len[g], rlen = b.region_rlen[g], rss = b.ref_seq_start[g];
     const uint8_t* ref = b.ref_seq + b.ref_off[g];
-    SbWin W;
-    const int ws = out.win_start[w], we = out.win_end[w];
-    W.hapStart = ws > 0 ? ws : 0; W.hapEnd = we < contigLen - 1 ? we : contigLen - 1; W.endBuf = 2 * rlen < 500 ? 2 * rlen : 500; W.contigLen = contigLen;
-    // the valid combinations in the reference's order (haplotype 0 = the reference)
-    if (lane == 0) {
-        auto none = [](int, int, int) {};
-        int h = 0;
-        s_mask[wv][0] = 0u; s_len[wv][0] = sb_walk_hap(W, 0u, 0, vpos, vnrem, vnadd, none); h = 1;
-        for (unsigned m = sb_next_comb(0u, nv); m && h < 32; m = sb_next_comb(m, nv)) {
-            if (!sb_valid(m, nv, vpos, vnrem, vnadd)) continue;
-            s_mask[wv][h] = m; s_len[wv][h] = sb_walk_hap(W, m, nv, vpos, vnrem, vnadd, none); ++h;
+    const int contigLen = b.contig_len[g], rlen = b.region_rlen[g], rss = b.ref_seq_start[g];
+    for (int kw = blockIdx.x; kw < nWin; kw += gridDim.x) {
+        __syncthreads();
+        const long long t = (long long)g * b.cap_windows + kw;
+        const int32_t* sc = sb_slot(out, t);
+        if (sc[0] != 0) continue;
+        const long long* pf = sb_prefix(b, out, t);
+        const long long w = t;
+        const int bw = (int)(rg[10] + pf[0]), nv = out.win_var_n[w], nH = sc[1], hb = (int)(rg[11] + pf[1]);
+        const long long byte0 = rg[14] + pf[4];
+        const int ws = out.win_start[w], we = out.win_end[w];
+        if (tid == 0) {                                                // the window's entries in the batch arrays
+            const int rb = (int)(rg[12] + pf[2]);
+            out.win_batch[w] = bw;
+            out.b_hap_begin[bw] = hb; out.b_read_begin[bw] = rb; out.b_pair_off[bw] = rg[13] + pf[3]; out.b_seg_begin[bw] = rb; out.b_gl_off[bw] = rg[16] + pf[6];
+            out.b_n_good[bw] = out.win_ptrs[6 * w + 1] - out.win_ptrs[6 * w];
+            out.b_start[bw] = ws > 0 ? ws : 0; out.b_end[bw] = we < contigLen - 1 ? we : contigLen - 1; out.b_flank[bw] = 2 * rlen < 500 ? 2 * rlen : 500;
         }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    uint8_t* tmp = out.hap_scratch + byte0;
-    // bytes of every haplotype into the scratch blob, enumeration order
-    {
-        long long at = 0;
-        for (int h = 0; h < nH; ++h) {
-            const unsigned m = s_mask[wv][h];
+        const long long v0 = (long long)g * b.cap_vars + out.win_var_first[w];
+        if (tid < 8) {                                                 // the window's variants in LDS: the walks read them dozens of times
+            const bool in = tid < nv;
+            s_vpos[tid] = in ? out.var_pos[v0 + tid] : 0; s_vnrem[tid] = in ? out.var_nrem[v0 + tid] : 0; s_vnadd[tid] = in ? out.var_nadd[v0 + tid] : 0;
+            s_vadd[tid] = in ? out.var_add_off[v0 + tid] : 0;
+        }
+        if (tid < 32) s_rank[tid] = 0;
+        __syncthreads();
+        const int32_t* vpos = s_vpos;
+        const int32_t* vnrem = s_vnrem;
+        const int32_t* vnadd = s_vnadd;
+        const int32_t* vadd = s_vadd;
+        SbWin W;
+        W.hapStart = ws > 0 ? ws : 0; W.hapEnd = we < contigLen - 1 ? we : contigLen - 1; W.endBuf = 2 * rlen < 500 ? 2 * rlen : 500; W.contigLen = contigLen;
+        // the valid combinations in the reference's order (haplotype 0 = the reference) and their lengths
+        if (tid == 0) {
+            auto none = [](int, int, int) {};
+            int h = 0;
+            s_mask[0] = 0u; s_len[0] = sb_walk_hap(W, 0u, 0, vpos, vnrem, vnadd, none); h = 1;
+            for (unsigned m = sb_next_comb(0u, nv); m && h < 32; m = sb_next_comb(m, nv)) {
+                if (!sb_valid(m, nv, vpos, vnrem, vnadd)) continue;
+                s_mask[h] = m; s_len[h] = sb_walk_hap(W, m, nv, vpos, vnrem, vnadd, none); ++h;
+            }
+            s_dup = 0;
+        }
+        __syncthreads();
+        int common = 0;
+        if (nv > 0) { const int lo = W.hapStart - W.endBuf > 0 ? W.hapStart - W.endBuf : 0; common = max(0, min(vpos[0], W.hapEnd) - lo); }
+        // byte p of the haplotype whose segments are in s_seg[wv]
+        auto byteAt = [&](int p, int nseg) -> uint8_t {
+            int q = p, k = 0;
+            while (k < nseg - 1 && q >= s_seg[wv][k][2]) { q -= s_seg[wv][k][2]; ++k; }
+            const int kind = s_seg[wv][k][0], src = s_seg[wv][k][1];
+            return kind == 0 ? ref[src + q - rss] : (kind == 1 ? added[vadd[src] + q] : (uint8_t)src);
+        };
+        auto segments = [&](unsigned m) -> int {
             int nseg = 0;
             if (lane == 0) {
                 auto put = [&](int kind, int src, int len) { if (nseg < 24) { s_seg[wv][nseg][0] = kind; s_seg[wv][nseg][1] = src; s_seg[wv][nseg][2] = len; } ++nseg; };
@@ -597,66 +649,60 @@ k_sb_haps(SbIn in, plat_stage_b_out out)
             nseg = __shfl(nseg, 0, 64);
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
-            const int L = s_len[wv][h];
-            for (int p = lane; p < L; p += 64) {
-                int q = p, k = 0;
-                while (k < nseg - 1 && q >= s_seg[wv][k][2]) { q -= s_seg[wv][k][2]; ++k; }
-                const int kind = s_seg[wv][k][0], src = s_seg[wv][k][1];
-                uint8_t c;
-                if (kind == 0) c = ref[src + q - rss];
-                else if (kind == 1) c = added[vadd[src] + q];
-                else c = (uint8_t)src;
-                tmp[at + p] = c;
-            }
-            s_off[wv][h] = (int)at;
-            at += L;
+            return nseg;
+        };
+        for (int h = wv; h < nH; h += 4) {                             // the bytes behind the common prefix into the stage
+            const int nseg = segments(s_mask[h]);
+            const int L = s_len[h], n = min(SB_STAGE, L - common);
+            for (int p = lane; p < n; p += 64) s_stage[h][p] = byteAt(common + p, nseg);
             __builtin_amdgcn_wave_barrier();
         }
-    }
-    __threadfence();                                                   // (the scratch bytes are read back by other lanes below)
-    __builtin_amdgcn_wave_barrier();
-    // ranks: sorted(haplotypes) compares the byte strings; equal strings keep their order (and are flagged: mergeHaplotypes is the caller's)
-    if (lane < 32) s_rank[wv][lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    int dup = 0;
-    // every haplotype is the reference up to the window's first variant: comparisons start there
-    int common = 0;
-    if (nv > 0) { const int lo = W.hapStart - W.endBuf > 0 ? W.hapStart - W.endBuf : 0; common = max(0, min(vpos[0], W.hapEnd) - lo); }
-    for (int i = 0; i < nH; ++i)
-        for (int j = i + 1; j < nH; ++j) {
-            const int Li = s_len[wv][i], Lj = s_len[wv][j], Lm = min(Li, Lj);
-            const uint8_t* x = tmp + s_off[wv][i];
-            const uint8_t* y = tmp + s_off[wv][j];
-            int cmp = 0;
-            for (int p0 = min(common, Lm); p0 < Lm && cmp == 0; p0 += 64) {
-                const int p = p0 + lane;
-                const int cx = p < Lm ? x[p] : 0, cy = p < Lm ? y[p] : 0;
-                const unsigned long long mm = __ballot(cx != cy);
-                if (mm) { const int f = __builtin_ctzll(mm); const int ax = __shfl(cx, f, 64), ay = __shfl(cy, f, 64); cmp = ax < ay ? -1 : 1; }
+        __syncthreads();
+        // ranks: sorted(haplotypes) compares the byte strings; equal strings keep their order (and are flagged: mergeHaplotypes is the caller's)
+        int pairNo = 0;
+        for (int i = 0; i < nH; ++i)
+            for (int j = i + 1; j < nH; ++j, ++pairNo) {
+                if ((pairNo & 3) != wv) continue;
+                const int Li = s_len[i] - common, Lj = s_len[j] - common, Lm = min(min(Li, Lj), SB_STAGE);
+                int cmp = 0;
+                for (int p0 = 0; p0 < Lm && cmp == 0; p0 += 64) {
+                    const int p = p0 + lane;
+                    const int cx = p < Lm ? s_stage[i][p] : 0, cy = p < Lm ? s_stage[j][p] : 0;
+                    const unsigned long long mm = __ballot(cx != cy);
+                    if (mm) { const int f = __builtin_ctzll(mm); const int ax = __shfl(cx, f, 64), ay = __shfl(cy, f, 64); cmp = ax < ay ? -1 : 1; }
+                }
+                bool undecided = false;
+                if (cmp == 0) {
+                    if (Lm == SB_STAGE && (Li > SB_STAGE || Lj > SB_STAGE)) undecided = true;   // they agree on the whole stage and go on
+                    else cmp = Li < Lj ? -1 : (Li > Lj ? 1 : 0);
+                }
+                if (lane == 0) { if (cmp == 0 || undecided) s_dup = 1; atomicAdd(&s_rank[cmp <= 0 ? j : i], 1); }
             }
-            if (cmp == 0) cmp = Li < Lj ? -1 : (Li > Lj ? 1 : 0);
-            if (cmp == 0) dup = 1;
-            if (lane == 0) { if (cmp <= 0) s_rank[wv][j] += 1; else s_rank[wv][i] += 1; }
+        __syncthreads();
+        // final place of every haplotype: behind those of smaller rank
+        int myOff = 0;
+        if (tid < nH) {
+            for (int k = 0; k < nH; ++k) if (s_rank[k] < s_rank[tid]) myOff += s_len[k];
+            const int r = s_rank[tid];
+            out.b_hap_off[hb + r] = byte0 + myOff;
+            out.b_hap_mask[hb + r] = s_mask[tid];
+            s_off[tid] = myOff;
+        }
+        __syncthreads();
+        uint8_t* dst = out.b_hap_seq + byte0;
+        for (int h = wv; h < nH; h += 4) {                             // the bytes, once, to their place
+            const int nseg = segments(s_mask[h]);
+            const int L = s_len[h], to = s_off[h];
+            int p = lane;
+            for (; p + 192 < L; p += 256) {                            // (four loads in flight per lane)
+                const uint8_t c0 = byteAt(p, nseg), c1 = byteAt(p + 64, nseg), c2 = byteAt(p + 128, nseg), c3 = byteAt(p + 192, nseg);
+                dst[to + p] = c0; dst[to + p + 64] = c1; dst[to + p + 128] = c2; dst[to + p + 192] = c3;
+            }
+            for (; p < L; p += 64) dst[to + p] = byteAt(p, nseg);
             __builtin_amdgcn_wave_barrier();
         }
-    __threadfence_block();
-    // final place of every haplotype: after the shorter-ranked ones
-    if (lane < nH) {
-        int off = 0;
-        for (int k = 0; k < nH; ++k) if (s_rank[wv][k] < s_rank[wv][lane]) off += s_len[wv][k];
-        const int r = s_rank[wv][lane];
-        out.b_hap_off[hb + r] = byte0 + off;
-        out.b_hap_mask[hb + r] = s_mask[wv][lane];
-        s_rank[wv][lane] = off;                                         // rank no longer needed: now the byte offset inside the window
+        if (tid == 0 && s_dup) out.win_flags[w] = PLAT_SBW_DUPLICATE;
     }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    uint8_t* dst = out.b_hap_seq + byte0;
-    for (int h = 0; h < nH; ++h) {
-        const int L = s_len[wv][h], so = s_off[wv][h], to = s_rank[wv][h];
-        for (int p = lane; p < L; p += 64) dst[to + p] = tmp[so + p];
-    }
-    if (dup && lane == 0) out.win_flags[w] = PLAT_SBW_DUPLICATE;
 }
 
 // ---- the reads of every window: indices into the read table, kinds, offsets ---------------------------------------------------------
@@ -666,26 +712,29 @@ k_sb_reads(SbIn in, plat_stage_b_out out)
     const plat_stage_b_in& b = in.b;
     if (out.totals[10]) return;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long t = (long long)blockIdx.x * 4 + wv;
-    if (t >= (long long)b.n_regions * b.cap_windows) return;
-    const int32_t* sc = out.scratch + 8 * t;
-    if (sc[0] != 0) return;
-    const int g = (int)(t / b.cap_windows);
-    const long long w = t;
-    const int bw = out.win_batch[w];
-    int at = out.b_read_begin[bw];
-    long long bytes = sc[7];
-    for (int a = 0; a < 3; ++a) {
-        const int base = b.tab_begin[3 * g + a], s = out.win_ptrs[6 * w + 2 * a], e = out.win_ptrs[6 * w + 2 * a + 1];
-        if (e <= s) continue;
-        const long long o0 = b.read_off[base + s];
-        for (int i = s + lane; i < e; i += 64) {
-            out.b_read_src[at + (i - s)] = base + i;
-            out.b_read_kind[at + (i - s)] = (uint8_t)a;
-            out.b_read_off[at + (i - s)] = bytes + (b.read_off[base + i] - o0);
+    const int g = blockIdx.y;
+    const int nWin = out.hdr[8 * g] != 0 ? 0 : out.hdr[8 * g + 2];
+    const long long* rg = sb_region(b, out, g);
+    for (int kw = blockIdx.x * 4 + wv; kw < nWin; kw += gridDim.x * 4) {
+        const long long t = (long long)g * b.cap_windows + kw;
+        const int32_t* sc = sb_slot(out, t);
+        if (sc[0] != 0) continue;
+        const long long* pf = sb_prefix(b, out, t);
+        const long long w = t;
+        int at = (int)(rg[12] + pf[2]);
+        long long bytes = rg[15] + pf[5];
+        for (int a = 0; a < 3; ++a) {
+            const int base = b.tab_begin[3 * g + a], s = out.win_ptrs[6 * w + 2 * a], e = out.win_ptrs[6 * w + 2 * a + 1];
+            if (e <= s) continue;
+            const long long o0 = b.read_off[base + s];
+            for (int i = s + lane; i < e; i += 64) {
+                out.b_read_src[at + (i - s)] = base + i;
+                out.b_read_kind[at + (i - s)] = (uint8_t)a;
+                out.b_read_off[at + (i - s)] = bytes + (b.read_off[base + i] - o0);
+            }
+            bytes += b.read_off[base + e] - o0;
+            at += e - s;
         }
-        bytes += b.read_off[base + e] - o0;
-        at += e - s;
     }
 }
 
@@ -707,25 +756,23 @@ PLAT_EXPORT int plat_stage_b_batch(plat_ctx* ctx, const plat_stage_b_in* batch, 
     if (!o.hdr || !o.var_pos || !o.var_nrem || !o.var_nadd || !o.var_support || !o.var_bam_min || !o.var_bam_max || !o.var_rem_pos || !o.var_add_off ||
         !o.added || !o.win_start || !o.win_end || !o.win_var_first || !o.win_var_n || !o.win_flags || !o.win_ptrs || !o.win_n_haps || !o.win_batch ||
         !o.b_hap_begin || !o.b_read_begin || !o.b_start || !o.b_end || !o.b_flank || !o.b_pair_off || !o.b_gl_off || !o.b_seg_begin || !o.b_n_good ||
-        !o.b_hap_off || !o.b_hap_mask || !o.b_hap_seq || !o.hap_scratch || !o.b_read_off || !o.b_read_src || !o.b_read_kind || !o.totals || !o.scratch)
+        !o.b_hap_off || !o.b_hap_mask || !o.b_hap_seq || !o.b_read_off || !o.b_read_src || !o.b_read_kind || !o.totals || !o.scratch)
         return PLAT_ERR_INVALID;
     if (options->maxHaplotypes < 3) return PLAT_ERR_UNSUPPORTED;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
     plat::SbIn in;
     in.b = b; in.o = *options;
     hipStream_t st = (hipStream_t)stream;
-    const long long slots = (long long)b.n_regions * b.cap_windows;
     static bool once = false;
     if (!once) {
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)plat::k_sb_variants, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(plat::SbRegion)));
         once = true;
     }
-    hipLaunchKernelGGL(plat::k_sb_variants, dim3((unsigned)b.n_regions), dim3(256), sizeof(plat::SbRegion), st, in, o);
-    hipLaunchKernelGGL(plat::k_sb_windows, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, in, o);
-    hipLaunchKernelGGL(plat::k_sb_scan, dim3(1), dim3(1024), 0, st, in, o);
-    hipLaunchKernelGGL(plat::k_sb_gloff, dim3(1), dim3(256), 0, st, in, o);
-    hipLaunchKernelGGL(plat::k_sb_haps, dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, st, in, o);
-    hipLaunchKernelGGL(plat::k_sb_reads, dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_variants, dim3((unsigned)b.n_regions), dim3(plat::SB_THREADS), sizeof(plat::SbRegion), st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_windows, dim3((unsigned)b.n_regions), dim3(256), 0, st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_scan, dim3(1), dim3(64), 0, st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_haps, dim3(48, (unsigned)b.n_regions), dim3(256), 0, st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_reads, dim3(12, (unsigned)b.n_regions), dim3(256), 0, st, in, o);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }

@@ -26,7 +26,8 @@ class _ReadTable(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("encoding", C.c_int32)] + [(k, C.c_void_p) for k in (
         "seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off")] + \
                [("n_exceptions", C.c_int64), ("exc_index", C.c_void_p), ("exc_base", C.c_void_p), ("exc_qual", C.c_void_p),
-                ("dev_seq", C.c_void_p), ("dev_qual", C.c_void_p)]
+                ("dev_seq", C.c_void_p), ("dev_qual", C.c_void_p)] + [(k, C.c_void_p) for k in (
+                    "dev_off", "dev_pos", "dev_end", "dev_mapq", "dev_flags", "dev_cigar", "dev_cig_off")]
 
 
 class _SampleReads(C.Structure):

@@ -322,6 +322,43 @@ static int fk_cmp(const void* a, const void* b) {
     if (c) return c;
     return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);
 }
+API int plat_unpack_reads_pieces(plat_ctx* c, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual,
+                                 int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream)
+{
+    (void)c; (void)stream; (void)max_piece_bytes;
+    for (int k = 0; k < n_pieces; ++k)
+        for (int64_t i = 0; i < pieces[k].n; ++i) {
+            const unsigned b = pieces[k].src[i];
+            out_seq[pieces[k].dst + i] = (uint8_t)"ACTG"[b & 3u];
+            out_qual[pieces[k].dst + i] = (uint8_t)(b >> 2);
+        }
+    for (int64_t e = 0; e < n_exc; ++e)
+        if (exc_index[e] >= 0 && exc_index[e] < total_bytes) { out_seq[exc_index[e]] = exc_base[e]; out_qual[exc_index[e]] = exc_qual[e]; }
+    return PLAT_OK;
+}
+
+API int plat_concat_read_tables(plat_ctx* c, int n_tables, int max_reads_per_table, const plat_table_desc* desc, int64_t* dst_off, int32_t* dst_pos,
+                                int32_t* dst_end, uint8_t* dst_mapq, int32_t* dst_flags, int32_t* dst_cig_off, int16_t* dst_cigar, int32_t* dst_region,
+                                int64_t n_total, int64_t total_bytes, int64_t total_pairs, void* stream)
+{
+    (void)c; (void)stream; (void)max_reads_per_table;
+    if (n_tables < 1 || !desc) return PLAT_ERR_INVALID;
+    for (int t = 0; t < n_tables; ++t) {
+        const plat_table_desc* d = &desc[t];
+        for (int i = 0; i < d->n; ++i) {
+            const int64_t r = d->first_read + i;
+            dst_off[r] = d->first_byte + d->off[i];
+            dst_pos[r] = d->pos[i]; dst_end[r] = d->end[i]; dst_mapq[r] = d->mapq[i]; dst_flags[r] = d->flags[i];
+            dst_cig_off[r] = (int32_t)(d->first_pair + d->cig_off[i]);
+            for (int q = d->cig_off[i]; q < d->cig_off[i + 1]; ++q) { dst_cigar[2 * (d->first_pair + q)] = d->cigar[2 * q]; dst_cigar[2 * (d->first_pair + q) + 1] = d->cigar[2 * q + 1]; }
+            if (d->scan >= 0) dst_region[r] = d->scan;
+        }
+    }
+    dst_off[n_total] = total_bytes; dst_cig_off[n_total] = (int32_t)total_pairs;
+    dst_cigar[2 * total_pairs] = 0; dst_cigar[2 * total_pairs + 1] = 0;
+    return PLAT_OK;
+}
+
 /* stage B on the device: this stand-in has none -- the native region loop then runs its own (host) stage B, which is what the CPU suite pins */
 API int plat_stage_b_batch(plat_ctx* c, const plat_stage_b_in* b, const plat_stage_b_options* o, const plat_stage_b_out* out, void* stream)
 {

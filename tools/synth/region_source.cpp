@@ -454,6 +454,11 @@ static int plat_synth_load_resident(void* user, int index, int slot, plat_region
             plat_read_table& t = sm[i].reads;
             t.dev_seq = t.seq + g->devDelta;
             t.dev_qual = t.encoding == PLAT_READS_ASCII ? t.qual + g->devDelta : nullptr;
+            // (the whole slot is mirrored: the per-read arrays are resident too)
+            auto dev = [g](const void* p) { return (const void*)((const uint8_t*)p + g->devDelta); };
+            t.dev_off = (const int64_t*)dev(t.off); t.dev_pos = (const int32_t*)dev(t.pos); t.dev_end = (const int32_t*)dev(t.end);
+            t.dev_mapq = (const uint8_t*)dev(t.mapq); t.dev_flags = (const int32_t*)dev(t.flags); t.dev_cigar = (const int16_t*)dev(t.cigar);
+            t.dev_cig_off = (const int32_t*)dev(t.cig_off);
         }
     }
     return 0;
