@@ -337,6 +337,10 @@ def main():
                          "(1 = strictly one batch at a time)")
     ap.add_argument("--sync-entry", action="store_true",
                     help="time plat_align_window_batch (two internal read-backs) instead of plat_align_window_batch_async")
+    ap.add_argument("--strong", action="store_true", help="config 4 / the WGS block: ONE region list for every N (--regions, default 31000 = the whole synthetic "
+                                                          "genome) instead of 3875 regions per GPU: a strong-scaling line")
+    ap.add_argument("--no-wgs", action="store_true", help="default line: leave out the WGS block (config 4 on this job's GPUs, gather + merge inside its timed region)")
+    ap.add_argument("--min-seconds", type=float, default=0.25, help="a step is made of as many passes (one batch each) as it takes for the K timed steps to last this long")
     ap.add_argument("--selftest-ranks", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
@@ -390,10 +394,10 @@ def main():
                 engs[j].synchronize()           # also raises any error an asynchronous step recorded on the device
         torch.cuda.synchronize()
 
-    def timed(nsteps, dbl=dbs):
+    def timed(nsteps, dbl=dbs, passes=1):
         barrier()
         t0 = time.perf_counter()
-        for i in range(nsteps):
+        for i in range(nsteps * passes):
             step(i, dbl, want_stats=False, asynchronous=not a.sync_entry)
         sync_all()
         t1 = time.perf_counter()
@@ -404,10 +408,17 @@ def main():
     for i in range(max(a.warmup, 1) * S):
         step(i, want_stats=False, asynchronous=not a.sync_entry)
     sync_all()
-    wall = timed(a.steps)
+    # A step = P consecutive passes, one resident batch each, P chosen so that the K timed steps last at least --min-seconds (a driver run
+    # with --steps 20 would otherwise time 9 ms): the figure does not hang on twenty launches.  P comes from an untimed probe, the same on
+    # every rank (max over ranks).
+    probe = timed(2 * S) / (2 * S)
+    P = max(1, int(np.ceil(a.min_seconds / max(a.steps * probe, 1e-9)))) if a.min_seconds > 0 else 1
+    P = int(rk.reduce(float(P), [0.0])[0])
+    wall = timed(a.steps, passes=P)
+    NP = a.steps * P                            # passes inside the timed region
 
-    def over_steps(f):                          # sum of a per-batch statistic over the K timed steps
-        return float(sum(f(sts[i % B], hbs[i % B]) for i in range(a.steps)))
+    def over_steps(f):                          # sum of a per-batch statistic over the passes of the K timed steps
+        return float(sum(f(sts[i % B], hbs[i % B]) for i in range(NP)))
     T, (cells_ref, cells_run, nwin, ndp_ref, ndp_run) = rk.reduce(wall, [
         over_steps(lambda q, h: q.cells_reference), over_steps(lambda q, h: q.cells_launched), over_steps(lambda q, h: h.n_windows),
         over_steps(lambda q, h: q.n_dp_reference), over_steps(lambda q, h: q.n_dp_launched)])
@@ -442,8 +453,20 @@ def main():
     except Exception as exc:                    # pragma: no cover
         gather = {"error": repr(exc)[:200]}
 
+    # BASELINE.json's metric is quoted on the synthetic 30x WGS (config 4): the job's GPUs call this job's share of the genome through the
+    # native region loop -- inputs resident in HBM, the gather of the record text to rank 0 and the (chrom, pos) merge INSIDE the timed
+    # region -- and the figures go to the TOP LEVEL of the line (`wgs`).  Every rank takes part (the gather is a collective).
+    wgs = None
+    if not a.no_wgs:
+        from types import SimpleNamespace
+        from tools import bench_other
+        try:
+            wgs = bench_other.line_config4(SimpleNamespace(regions=a.regions, steps=3, strong=a.strong, no_cpu_baseline=True), rk, resident=True)
+        except Exception as exc:                # pragma: no cover
+            wgs = {"error": repr(exc)[:300]}
     if rank == 0:
         ms_step = 1e3 * T / a.steps
+        ms_pass = 1e3 * T / NP
         dp_avg = float(np.mean(dp_ms))
         # roofline entries of the two kernels that share the top of the profile: k_dp_jobs (the recurrence) and k_seed
         # (candidate diagonals + the ungapped-alignment proof).  `roofline` is the one with the longer launch.
@@ -477,7 +500,7 @@ def main():
         # k_seed per launch: haplotype bytes in (1 B/base) + gap-open bytes out (1 B/base; 4-byte DP words until round 3), read bit planes in (2 bits/base)
         # + ReadInfo (16 B/read), one PairRec + one Job out per (haplotype, read) pair (32 B); since round 2 the kernel also
         # finishes the pairs that need no DP: their log-likelihood out (8 B), and one dense-list entry (4 B) per pair that does
-        dp_per_step = ndp_run / a.steps / max(world, 1)
+        dp_per_step = ndp_run / NP / max(world, 1)
         seed_alg = 2 * int(hb.hap_off[-1]) + int(hb.read_off[-1]) // 4 + 16 * hb.n_reads + 32 * hb.n_pairs \
             + int(8 * max(hb.n_pairs - dp_per_step, 0) + 4 * dp_per_step)
         r_dp = entry("k_dp_jobs", prof.dp_alg_bytes, dp_avg, pm,
@@ -507,14 +530,18 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: %d windows/GPU per step, 150 bp reads, 30x, <=8 haplotypes/window, SNP-only; "
-                                   "step = alignReads for all haplotypes + genotype likelihoods" % nwin_batch,
-                       "windows_per_gpu": nwin_batch, "read_len": 150, "depth": 30, "sharding": "windows by rank, no collective",
+            "config": {"workload": "BASELINE config 2: %d windows/GPU per pass, 150 bp reads, 30x, <=8 haplotypes/window, SNP-only; "
+                                   "pass = alignReads for all haplotypes + genotype likelihoods of one resident batch; step = %d pass(es) over "
+                                   "consecutive batches (so that the %d timed steps last >= %.2f s)" % (nwin_batch, P, a.steps, a.min_seconds),
+                       "windows_per_gpu": nwin_batch, "passes_per_step": P, "ms_per_pass": ms_pass, "read_len": 150, "depth": 30,
+                       "sharding": "windows by rank, no collective",
                        "entry": "plat_align_window_batch" if a.sync_entry else "plat_align_window_batch_async",
                        "batches_in_flight": S, "distinct_resident_batches": B, "timed_region_ms": 1e3 * T},
             "windows_per_sec": nwin / T,
+            "windows_per_sec_is": "config 2's windows (likelihoods + genotype likelihoods only); the end-to-end figure of the WGS job is wgs.windows_per_sec",
             "gcups_executed": cells_run / T / 1e9,
-            "dp_reference_per_step": ndp_ref / a.steps, "dp_launched_per_step": ndp_run / a.steps,
+            "dp_reference_per_step": ndp_ref / NP, "dp_launched_per_step": ndp_run / NP,
+            "per_step_figures_are": "per PASS (one batch of %d windows per GPU): dp_*_per_step, kernel_ms, algorithmic bytes, traffic" % nwin_batch,
             "kernel_ms": {"prepare": float(np.mean(prep_ms)), "seed": float(np.mean(seed_ms)), "seed_kernel": seedk_avg, "dp": dp_avg,
                           "finalize": float(np.mean(fin_ms)), "genotype": float(np.mean(gen_ms))},
             "dp_kernel_gcups": 4.0 * (prof.dp_alg_bytes - 34 * prof.dp_jobs) / (dp_avg * 1e-3) / 1e9,
@@ -530,12 +557,26 @@ def main():
         # pipelined step time
         alg8d = 2 * int(hb.read_off[-1]) + 12 * hb.n_reads + 2 * int(hb.hap_off[-1]) + 8 * hb.n_pairs
         line["algorithmic_bytes_8d_per_step"] = int(alg8d)
-        line["algorithmic_frac_8d"] = alg8d / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        line["algorithmic_frac_8d"] = alg8d / (ms_pass * 1e-3) / 1e9 / HBM_PEAK_GBPS
         if pm.get("step_hbm_bytes"):
             line["step_traffic_bytes"] = int(pm["step_hbm_bytes"])
-            line["step_hbm_frac"] = pm["step_hbm_bytes"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            line["step_hbm_frac"] = pm["step_hbm_bytes"] / (ms_pass * 1e-3) / 1e9 / HBM_PEAK_GBPS
             line["step_traffic_source"] = traffic_source
         line["record_gather"] = gather
+        if wgs is not None:
+            wgs.pop("merged_text", None)
+            keep = ("windows_per_sec", "gcups", "gcups_executed", "roofline", "roofline_other", "scaling", "scaling_efficiency_basis", "regions", "windows", "records",
+                    "regions_per_sec", "reads_per_sec", "timed_s", "timed_s_runs", "host_seconds_per_region", "device_wait_seconds_per_region",
+                    "stage_seconds_per_region", "record_gather", "cpus_granted_to_this_rank", "dp_reference", "dp_launched", "stage_b", "inputs", "config", "error")
+            wgs["windows_per_sec"] = wgs.get("value")
+            line["wgs"] = {k: wgs[k] for k in keep if k in wgs}
+            line["wgs"]["what"] = ("BASELINE config 4 on this job's GPUs: the synthetic 30x genome's regions (3 875 per GPU unless --strong), region i -> rank i % N, "
+                                   "reads resident in HBM; timed: candidates -> variants -> windows -> haplotypes (device) -> likelihoods / EM / posteriors -> records "
+                                   "for all regions, + gather of the record text to rank 0 + (chrom, pos) merge")
+            for k in ("windows_per_sec", "gcups", "gcups_executed"):
+                if k in wgs:
+                    line["wgs_" + k] = wgs[k]
+            line["wgs_cpus_per_rank"] = wgs.get("cpus_granted_to_this_rank")
         if world == 1 and not a.no_extras:
             # ---- the same batches with the shortcuts switched off (the library reads the switches per call)
             def mode(nsteps, dbl=dbs, hbl=hbs, **env):
@@ -544,6 +585,8 @@ def main():
                     for i in range(S):
                         step(i, dbl, want_stats=False, asynchronous=not a.sync_entry)
                     sync_all()
+                    pr = timed(2 * S, dbl) / (2 * S)
+                    nsteps = max(nsteps, int(np.ceil(a.min_seconds / max(pr, 1e-9))))
                     t_ = timed(nsteps, dbl)
                 cells = sum(st_[i % len(st_)].cells_reference for i in range(nsteps))
                 run_ = sum(st_[i % len(st_)].cells_launched for i in range(nsteps))
@@ -571,8 +614,11 @@ def main():
                 from tools import bench_other
                 line["other_configs"] = bench_other.summary(eng)
                 c4 = line["other_configs"].get("config4_region_pipeline") or {}
-                if "windows_per_sec" in c4:      # north_star's second metric: reads in host memory -> VCF record text (config 4, this GPU)
+                if "windows_per_sec" in c4:      # the same job with every region generated and uploaded INSIDE the timed region (rounds 2-3's shape)
                     line["windows_per_sec_end_to_end"] = c4["windows_per_sec"]
+                    if "wgs" in line:
+                        line["wgs"]["streamed"] = {k: c4[k] for k in ("windows_per_sec", "gcups", "gcups_executed", "regions", "timed_s", "host_seconds_per_region",
+                                                                       "device_wait_seconds_per_region", "h2d_gbytes_per_sec", "what") if k in c4}
             except Exception as exc:            # pragma: no cover
                 line["other_configs"] = {"error": repr(exc)[:300]}
         if world == 1 and not a.no_cpu_baseline:

@@ -35,18 +35,18 @@ def test_launch_command_is_the_drivers_form():
     assert cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")
 
 
-def _args(regions):
-    return SimpleNamespace(regions=regions, steps=1, warmup=1, gpus=2, config=4, windows=None)
+def _args(regions, strong=False):
+    return SimpleNamespace(regions=regions, steps=1, warmup=1, gpus=2, config=4, windows=None, strong=strong)
 
 
-def _rank_worker(rank, world, port, out_path):
+def _rank_worker(rank, world, port, out_path, regions=5, strong=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), PLAT_DIST_BACKEND="gloo", PLAT_CALLER_WORKERS="2", PLAT_CALLER_CHUNK="2")
+                      MASTER_PORT=str(port), PLAT_DIST_BACKEND="gloo", PLAT_CALLER_WORKERS="2", PLAT_CALLER_CHUNK="2", PLAT_BENCH_WGS_REGIONS_PER_GPU="3")
     import bench
     from tests import fakedev
     from tools import bench_other
     rk = bench.Ranks(world, need_gpu=False)
-    line = bench_other.line_config4(_args(5), rk, lib=fakedev.fake_caller_lib(), region_len=3000, region_kw=REGION_KW)
+    line = bench_other.line_config4(_args(regions, strong), rk, lib=fakedev.fake_caller_lib(), region_len=3000, region_kw=REGION_KW)
     if rank == 0:
         json.dump(line, open(out_path, "w"))
     rk.close()
@@ -66,9 +66,40 @@ def test_config4_two_ranks_give_the_text_of_one_rank(tmp_path):
         os.environ.pop(k, None)
     os.environ.update(PLAT_CALLER_WORKERS="2", PLAT_CALLER_CHUNK="2")
     one = bench_other.line_config4(_args(5), bench.Ranks(1, need_gpu=False), lib=fakedev.fake_caller_lib(), region_len=3000, region_kw=REGION_KW)
-    assert two["n_gpus"] == 2 and two["record_gather"]["ranks"] == 2 and two["scaling"] == "strong"
+    assert two["n_gpus"] == 2 and two["record_gather"]["ranks"] == 2 and two["scaling"] == "strong" and one["scaling"] == "strong"
+    assert two["regions"] == one["regions"] == 5                             # --regions R: the SAME list whatever N
+    assert two["scaling_efficiency_basis"]["scaling"] == "strong" and two["scaling_efficiency_basis"]["regions"] == 5 and two["scaling_efficiency_basis"]["ranks"] == 2
     assert one["n_gpus"] == 1 and one["record_gather"]["ranks"] == 1
     assert two["merged_text"] == one["merged_text"] and one["merged_text"].count("\n") > 10
     assert two["windows"] == one["windows"] and two["records"] == one["records"] == one["merged_text"].count("\n")
     # the reference's DPs of the called windows, counted during the untimed pass (plat_caller_count_cells), summed over the ranks
     assert two["dp_reference"] == one["dp_reference"] > 100 and two["pairs"] == one["pairs"] > 0 and "gcups" in one
+
+
+def test_config4_scaling_label_follows_the_region_list(tmp_path):
+    """Default: the list grows with the job (a share per GPU) and the line says "weak"; --strong: one list (8 shares) for every N and the
+    line says "strong" -- the two N = 1 / N = 2 pairs an efficiency figure may be computed from are never mixed up."""
+    import torch.multiprocessing as mp
+    import bench
+    from tests import fakedev
+    from tools import bench_other
+    lib = fakedev.fake_caller_lib()
+    os.environ.update(PLAT_CALLER_WORKERS="2", PLAT_CALLER_CHUNK="2", PLAT_BENCH_WGS_REGIONS_PER_GPU="3")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    rk1 = bench.Ranks(1, need_gpu=False)
+    weak1 = bench_other.line_config4(_args(None), rk1, lib=lib, region_len=3000, region_kw=REGION_KW)
+    strong1 = bench_other.line_config4(_args(None, strong=True), rk1, lib=lib, region_len=3000, region_kw=REGION_KW)
+    assert weak1["scaling"] == "weak" and weak1["regions"] == 3 and weak1["scaling_efficiency_basis"]["regions_per_rank"] == 3
+    assert strong1["scaling"] == "strong" and strong1["regions"] == 24
+    out = {}
+    for name, (regions, strong) in dict(weak=(None, False), strong=(None, True)).items():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        out[name] = str(tmp_path / (name + ".json"))
+        mp.spawn(_rank_worker, args=(2, port, out[name], regions, strong), nprocs=2, join=True)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    weak2, strong2 = json.load(open(out["weak"])), json.load(open(out["strong"]))
+    assert weak2["scaling"] == "weak" and weak2["regions"] == 6 and weak2["scaling_efficiency_basis"]["regions_per_rank"] == 3
+    assert strong2["scaling"] == "strong" and strong2["regions"] == strong1["regions"] == 24
+    assert strong2["merged_text"] == strong1["merged_text"]

@@ -274,15 +274,28 @@ def config4_gcups(counted, regions, T):
     seed_alg = (2 * counted["align_hap_bytes"] + counted["align_read_bytes"] // 4 + 16 * counted["align_reads"] + 32 * counted["n_pairs"]
                 + 8 * max(counted["n_pairs"] - ndp, 0) + 4 * ndp) / nb                   # bench.py's k_seed formula, per launch
     seed_ms, dp_ms = 1e3 * counted["seconds_kernel_seed"] / nb, 1e3 * counted["seconds_kernel_dp"] / nb
+    sweep_ms, pairs_ms = 1e3 * counted.get("seconds_kernel_sweep", 0.0) / nb, 1e3 * counted.get("seconds_kernel_pairs", 0.0) / nb
     if seed_ms > 0 and dp_ms > 0:
-        r_seed = _roof("k_seed", seed_alg, seed_ms, "largest kernel of the region pipeline (one launch per likelihood batch of a chunk of regions); VALU-issue / latency bound, see DESIGN.md")
-        r_dp = _roof("k_dp_jobs", counted["align_dp_bytes"] / nb, dp_ms, "VALU-issue bound")
-        out["roofline"], out["roofline_other"] = (r_seed, r_dp) if seed_ms >= dp_ms else (r_dp, r_seed)
-        out["roofline"]["launches"] = out["roofline_other"]["launches"] = int(counted["n_align_batches"])
+        note = "one launch per likelihood batch of a chunk of regions; VALU-issue / latency bound at this size, see DESIGN.md"
+        cands = [_roof("k_dp_jobs", counted["align_dp_bytes"] / nb, dp_ms, "VALU-issue bound")]
+        if sweep_ms > 0 and pairs_ms > 0:
+            # the seeding stage is two kernels: k_sweep (haplotype bytes in, gap-open bytes + records out) and k_pairs (records + read planes in,
+            # pair records / likelihoods out); the stage's bytes split as bench.py splits them on config 2
+            hapb, nh = counted["align_hap_bytes"] / nb, max(1.0, counted["align_hap_bytes"] / nb / 650.0)
+            rec = 16 + 24 * 19 + 32
+            cands.append(_roof("k_sweep", 2 * hapb + rec * nh, sweep_ms, note))
+            cands.append(_roof("k_pairs", max(seed_alg - 2 * hapb, 0.0) + rec * nh, pairs_ms, note))
+        else:
+            cands.append(_roof("k_seed", seed_alg, seed_ms, note))          # (PLAT_SEED_FUSED=1: the one-kernel seeding)
+        cands.sort(key=lambda d: -d["avg_launch_ms"])
+        out["roofline"], out["roofline_other"] = cands[0], cands[1]
+        for d in cands:
+            d["launches"] = int(counted["n_align_batches"])
+        out["dp_per_launch"] = counted["n_dp_launched"] / nb
     return out
 
 
-def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
+def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=None):
     """ONE region list for the whole job, region i -> rank i % N (runner.py:473-474); every rank streams its share through the region loop,
     the record lines travel to rank 0 (sizes all-gather + point to point) and are merged by (chrom, pos) (runner.py:301-352).  The timed
     region covers the calls, the gather and the merge (and, when the inputs are not resident, loading = generating the regions).
@@ -295,18 +308,22 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
     from platypus_amd import fastcaller as F, sharding
     rank, world = rk.rank, rk.world
     strong = bool(getattr(a, "strong", False)) or bool(a.regions)
-    total = (a.regions or (31000 if strong else 3875 * world))
+    per_gpu = int(os.environ.get("PLAT_BENCH_WGS_REGIONS_PER_GPU", "3875"))   # (tests shrink the share; 3 875 = 31 000 / 8)
+    total = (a.regions or (8 * per_gpu if strong else per_gpu * world))
     mine = sharding.regions_for_rank(total, rank, world)
     cpus = getattr(rk, "cpus", 16)                                           # what the box grants this rank (cgroup quota / share of the node)
     # worker and loader threads share the rank's CPUs (workers sleep while the device works on their chunk): 10 + 8 with six regions per
     # chunk on the 16 CPUs one GPU box grants (tools/run_c4_sweep4.sh, run_c4_sweep5.sh: the box's own run-to-run spread, +-8 %, is as large
     # as the differences between 10-12 workers, 6-10 loaders and 4-8 regions per chunk; 16 + 8 and 4 per chunk measured 5 % below)
-    resident = os.environ.get("PLAT_CALLER_RESIDENT", "1") == "1"            # 0: regions generated and uploaded inside the timed region (rounds 2-3)
+    if resident is None:
+        resident = os.environ.get("PLAT_CALLER_RESIDENT", "1") == "1"        # 0: regions generated and uploaded inside the timed region (rounds 2-3)
     # (resident: the loaders only hand out stored structs, so the workers get the CPUs -- 14 workers x 8 regions per chunk measured best on the
     #  16 CPUs of a one-GPU box: 1.21 M windows/s against 1.05 M with 10 x 6; 2 CPUs: 0.26 M, 4 CPUs: 0.43 M -- host stages 0.6 ms per region)
     workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus * (7 if resident else 5) // 8)))))
     os.environ.setdefault("PLAT_CALLER_LOADERS", str(max(2, min(12, cpus // 2))))
-    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "8" if resident else "6"))
+    # (round 5: stage B on the device -- the host no longer pays per region for a chunk's size, and the kernels of a chunk are latency bound:
+    #  48 regions per chunk measured 2.0 M windows/s against 1.25 M with 8)
+    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "48" if resident else "16"))
     pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1" and lib is None
     packed = os.environ.get("PLAT_CALLER_PACKED", "1") == "1"
     repeats = max(1, min(a.steps, 3))                                        # the line is the MEAN over the runs
@@ -314,7 +331,7 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
                 resident=resident)
     cnt = r.get("counted") or {}
     ckeys = ("cells_reference", "cells_launched", "n_dp_reference", "n_dp_launched", "n_pairs", "regions", "n_align_batches", "align_hap_bytes", "align_read_bytes",
-             "align_reads", "align_dp_bytes", "seconds_kernel_seed", "seconds_kernel_dp")
+             "align_reads", "align_dp_bytes", "seconds_kernel_seed", "seconds_kernel_dp", "seconds_kernel_sweep", "seconds_kernel_pairs")
     T, red = rk.reduce(r["T"], [r["windows"], r["regions"], r["records"], r["reads"], r["T_call"], r["input_bytes"]] + [float(cnt.get(k, 0)) for k in ckeys])
     wins, regs, recs, reads, tcall, inb = red[:6]
     counted_all = dict(zip(ckeys, red[6:]))                                   # summed over the ranks
@@ -349,6 +366,9 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None):
                                          "formula": "T(1) / (N x T(N)) over lines with equal `regions`" if strong else
                                                     "windows_per_sec(N) / (N x windows_per_sec(1)): `regions` grows with N (3 875 per GPU)",
                                          "inside_timed_region": "region calls of every rank + gather of the record text to rank 0 + (chrom, pos) merge"}}
+    line["inputs"] = "resident in HBM" if r["resident"] else "generated and uploaded inside the timed region"
+    line["stage_b"] = {"regions_on_the_device": int(st.get("n_regions_stage_b_device", 0)), "regions_left_to_the_host": int(st.get("n_regions_stage_b_host", 0)),
+                       "windows_left_to_the_host": int(st.get("n_windows_stage_b_host", 0)), "of_this_ranks_regions": r["regions"]}
     line.update(config4_gcups(counted_all, regs, T))
     if rank == 0:
         if lib is None and not getattr(a, "no_cpu_baseline", False):
@@ -429,7 +449,7 @@ def summary(eng):
     except Exception:
         cpus = 16
     r = config4(0, range(nreg), 100000, int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus * 5 // 8))))),
-                int(os.environ.get("PLAT_CALLER_CHUNK", "6")), repeats=3)     # the mean of three runs over the whole share
+                int(os.environ.get("PLAT_CALLER_CHUNK_STREAMED", "16")), repeats=3)     # the mean of three runs over the whole share
     st = r["stats"]
     out["config4_region_pipeline"] = dict(regions=r["regions"], untimed_warm_regions=r["warm_regions"], region_len=r["region_len"], reads=r["reads"], windows=r["windows"], records=r["records"],
                                           planted_variants=r["planted"], timed_s=r["T"], timed_s_runs=r["T_runs"], windows_per_sec=r["windows"] / r["T"],
