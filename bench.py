@@ -339,6 +339,7 @@ def main():
                     help="time plat_align_window_batch (two internal read-backs) instead of plat_align_window_batch_async")
     ap.add_argument("--strong", action="store_true", help="config 4 / the WGS block: ONE region list for every N (--regions, default 31000 = the whole synthetic "
                                                           "genome) instead of 3875 regions per GPU: a strong-scaling line")
+    ap.add_argument("--no-other-configs", action="store_true", help="default line: leave out other_configs (configs 3, 4 streamed, 5)")
     ap.add_argument("--no-wgs", action="store_true", help="default line: leave out the WGS block (config 4 on this job's GPUs, gather + merge inside its timed region)")
     ap.add_argument("--min-seconds", type=float, default=0.25, help="a step is made of as many passes (one batch each) as it takes for the K timed steps to last this long")
     ap.add_argument("--selftest-ranks", action="store_true", help=argparse.SUPPRESS)
@@ -611,6 +612,8 @@ def main():
                 "without_low_quality_valuation": hard_nolow, "all_dp": hard_alldp}
             del dh
             try:
+                if a.no_other_configs:
+                    raise RuntimeError("left out (--no-other-configs)")
                 from tools import bench_other
                 line["other_configs"] = bench_other.summary(eng)
                 c4 = line["other_configs"].get("config4_region_pipeline") or {}

@@ -1,0 +1,212 @@
+// chunk.hpp -- one chunk of regions going through the stages on one worker thread
+// (native region loop, libplat_caller.so: see region_caller.cpp for the stage map and the reference citations)
+#pragma once
+#include "caller_common.hpp"
+
+namespace plathost {
+
+// ---- the chunk pipeline ----------------------------------------------------------------------------------------------------------------
+// One chunk of regions on one worker: members and the stages' entry points; the stages themselves are stage_a.hpp ... stage_f.hpp.
+struct Chunk {
+    Slot& s;
+    const Options& o;
+    int nInd;
+    const char* const* names;
+    std::vector<RegionWork*> regions;
+    plat_caller_stats& st;
+    std::mutex& stMutex;
+
+    void uploadReads();
+    size_t nGood = 0, nBad = 0, nBroken = 0;
+    int nScan = 0, maxReadLen = 0;
+    int maxPerRead = 8;
+
+    void scanCandidates();
+    bool hostTally = false;
+    int mergeCap = 2048;
+    std::string refBlob;
+    Layout lmLayout;
+
+    // -- B on the device (plat_stage_b_batch): regions with one sample, candidates from the reads alone, no reference-call blocks
+    bool deviceB = false;
+    DeviceBatch devBatch;
+    int capV = 768, capW = 512, capA = 4096;
+    Layout sbOut;
+    bool eligibleDeviceB() const;
+    void launchStageB();
+
+    void stageBFromDevice();
+
+    // -- A3: the assembler part of generateVariantsInRegion (variantcaller.pyx:496-519): tiles of assemblyRegionSize every
+    // max(100, min(1000, size / 2)) bases, doWeNeedToAssembleThisRegion (:276-321) per tile, the reads loadBAMDataIntoGraph would load
+    // (assembler.pyx:1391-1425: good reads between the window pointers, badReads / brokenMates if the options say so, QCFail reads never)
+    // gathered from the chunk's device table; ALL tiles of the chunk in one plat_assemble_batch
+    struct Tile { int region, assemStart, assemEnd, refStart; };
+    void assembleTiles();
+    int asmMaxVars = 64, asmBlob = 4096;
+
+    // -- B1: candidates of one region -> merged, per-sample support filter, left-normalised, filtered (variantcaller.pyx:439-531)
+    // one sample's variantHeap: its distinct records in first-occurrence order with the number of reads showing each (addVariantToList),
+    // from the scan's records on the host
+    struct CandKey { int pos, nrem, nadd, count; const char* rem; const char* add; };
+    void tallySample(const RegionWork& r, size_t i, std::vector<CandKey>& keys, std::deque<std::string>& addedStore, int64_t* nRecords);
+    bool passesSupport(const RegionWork& r, size_t i, const CandKey& k) const;
+
+    void regionVariants(RegionWork& r, int scan0);
+    bool recordsOnHost = false;
+    size_t recArenaBytes = 0;
+
+    Hap makeHap(const RegionWork& r, const WindowWork& w, const VarList& vs) const;
+
+    void regionWindows(RegionWork& r);
+    static std::vector<int> snapshotNR(const PtrList& ptrs);
+
+    bool refCallLine(const RegionWork& r, std::string& out, int windowStart, int windowEnd, const std::vector<int>& nReads, bool hasVariants, double maxPost) const;
+
+    void prepareWindow(RegionWork& r, WindowWork& w);
+
+    void finishHaplotypes(RegionWork& r, WindowWork& w, std::vector<Hap>& haps);
+
+    void greedyRounds();
+    static void pushScored(WindowWork& w, const ScoredHap& item, int originalMax);
+    int regionSlot(int regionIndex) const { return regionIndex - regions[0]->index; }
+
+    void callWindows(std::vector<WindowWork*>& wins, bool fromDevice = false);
+    void refCallBlocksBetween(RegionWork& r, WindowWork& w);
+    void countCalled(size_t n) { std::lock_guard<std::mutex> g(stMutex); st.n_windows_called += (int64_t)n; }
+
+    void writeWindow(RegionWork& r, WindowWork& w, const std::vector<int64_t>& klo);
+
+    double stage[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stageWait[8] = {0, 0, 0, 0, 0, 0, 0, 0}, waitMark = 0;
+    Clock::time_point mark;
+    void lap(int k) { const auto now = Clock::now(); stage[k] += secs(mark, now); mark = now; stageWait[k] += s.t_wait - waitMark; waitMark = s.t_wait; }
+
+    void run() {
+        const auto t0 = Clock::now();
+        double wait0 = s.t_wait;
+        mark = t0; waitMark = wait0;
+        uploadReads();
+        lap(0);
+        deviceB = eligibleDeviceB();
+        if (o.getVariantsFromBAMs) scanCandidates();
+        assembleTiles();
+        lap(1);
+        if (deviceB) stageBFromDevice();
+        else {
+            int scan0 = 0;
+            for (RegionWork* r : regions) {
+                { PROF("s2.regionVariants"); regionVariants(*r, scan0); }
+                scan0 += (int)r->samples.size();
+                PROF("s2.regionWindows");
+                regionWindows(*r);
+            }
+        }
+        lap(2);
+        greedyRounds();
+        lap(3);
+        std::vector<WindowWork*> wins, devWins;
+        int64_t nWin = 0, nVar = 0, nCand = 0;
+        for (RegionWork* r : regions) {
+            nVar += (int64_t)r->variants.size(); nCand += r->nCandRecords;
+            for (WindowWork& w : r->windows) if (w.live) { ++nWin; (w.onDevice ? devWins : wins).push_back(&w); }
+        }
+        if (!devWins.empty()) {
+            try {
+                callWindows(devWins, true);
+            } catch (const DeviceError& e) {
+                // a window the device refuses takes the batch with it: the batch's windows are prepared again by the host's code and go
+                // through the per-window retry below with the others
+                if (!windowClassError(e.code)) throw;
+                for (WindowWork* w : devWins) {
+                    RegionWork& r = *regions[(size_t)regionSlot(w->region)];
+                    w->text.clear(); w->nRecords = 0; w->nRefRecords = 0; w->onDevice = false; w->haps.clear(); w->live = false;
+                    try { prepareWindow(r, *w); }
+                    catch (const WindowError& e2) {
+                        logWindowFailure(r.in->chrom, w->startPos, w->endPos, e2.what());
+                        std::lock_guard<std::mutex> g(stMutex);
+                        ++st.n_windows_failed;
+                        w->live = false; w->greedy = false; w->failed = true;
+                    }
+                }
+                greedyRounds();
+                wins.clear();
+                for (RegionWork* r : regions) for (WindowWork& w : r->windows) if (w.live && !w.onDevice) wins.push_back(&w);
+            }
+        }
+        try {
+            callWindows(wins);
+        } catch (const DeviceError& e) {
+            // Only what a single WINDOW can be guilty of is retried: one window the device refuses (bad input, a haplotype too long or
+            // too short, a size that overflows) would take every other window of the chunk with it, so they are called one at a time and
+            // only the failing ones are skipped (what the reference's per-window try/except does, variantcaller.pyx:568-615).  A failing
+            // runtime, an exhausted device or a lost GPU is nobody's window: it ends plat_call_regions with that error.
+            if (!windowClassError(e.code)) throw;
+            for (WindowWork* w : wins) { w->text.clear(); w->nRecords = 0; w->nRefRecords = 0; }
+            for (WindowWork* w : wins) {
+                std::vector<WindowWork*> one{w};
+                try { callWindows(one); }
+                catch (const DeviceError& e2) {
+                    if (!windowClassError(e2.code)) throw;
+                    w->text.clear(); w->nRecords = 0; w->nRefRecords = 0;
+                    logWindowFailure(regions[(size_t)regionSlot(w->region)]->in->chrom, w->startPos, w->endPos, e2.what());
+                    std::lock_guard<std::mutex> g(stMutex);
+                    ++st.n_windows_failed;
+                }
+            }
+        }
+        // the region's text: what the loop writes, in the order it writes it
+        int64_t nRec = 0, nRef = 0;
+        for (RegionWork* r : regions) {
+            int nHapLast = 0;                                               // haplotypes of the last window set up in this region (Population.nHaplotypes)
+            for (Item& it : r->items) {
+                if (it.kind == 1) { r->text += it.text; nRec += it.nRef; nRef += it.nRef; continue; }
+                WindowWork& w = r->windows[(size_t)it.window];
+                if (w.failed) continue;
+                if (w.live) { r->text += w.text; nRec += w.nRecords; nRef += w.nRefRecords; nHapLast = (int)w.haps.size(); continue; }
+                if (!o.outputRefCalls) continue;
+                // a window the loop left without calling (no reads, too many, one haplotype): outputRefCall on a Population that was reset
+                // and not set up for it.  Its haplotype list is empty but it still holds the haplotype COUNT of the last window it was
+                // set up for, so calculatePosterior's loop raises (logged, skipped) -- unless it never was set up in this region
+                try {
+                    bool ok;
+                    if (w.vars.empty()) ok = refCallLine(*r, r->text, w.startPos, w.endPos, snapshotNR(w.ptrs), false, 0.0);
+                    else {
+                        // (minCov == 0 decides before the posterior is asked for)
+                        if (nHapLast > 0 && !coverageHasAZero(*r, w.startPos, w.endPos)) throw WindowError("list index out of range");
+                        const double prior = 0.5;
+                        const double post = py2_round0(-10.0 * (log10(1.0 * (1.0 - prior)) - log10(prior + 1.0 * (1.0 - prior))));
+                        ok = refCallLine(*r, r->text, w.startPos, w.endPos, snapshotNR(w.ptrs), true, post);
+                    }
+                    if (ok) { ++nRec; ++nRef; }
+                    else throw WindowError("cannot convert float infinity to integer");
+                } catch (const WindowError& e) {
+                    logWindowFailure(r->in->chrom, w.startPos, w.endPos, e.what());
+                    std::lock_guard<std::mutex> g(stMutex);
+                    ++st.n_windows_failed;
+                }
+            }
+            r->release();
+        }
+        const double total = secs(t0, Clock::now()), waited = s.t_wait - wait0;
+        std::lock_guard<std::mutex> g(stMutex);
+        st.n_windows += nWin; st.n_variants += nVar; st.n_candidate_records += nCand; st.n_records += nRec; st.n_refcall_records += nRef;
+        st.seconds_host += total - waited; st.seconds_device_wait += waited;
+        for (int k = 0; k < 8; ++k) { st.seconds_stage[k] += stage[k]; g_stageWait[k] += stageWait[k]; }
+        g_stageWait[8] += total - waited; g_stageWait[9] += waited;
+    }
+    bool coverageHasAZero(const RegionWork& r, int windowStart, int windowEnd) const {
+        for (const SampleView& sv : r.samples) {
+            const TableView& tv = sv.reads;
+            const int N = tv.n();
+            if (N == 0) return windowStart < windowEnd;
+            for (int p = windowStart; p < windowEnd; ++p) {
+                int s0 = TableView::lowerBound(tv.t->pos, N, std::max<int64_t>(1, (int64_t)p - tv.longest));
+                const int e0 = TableView::lowerBound(tv.t->pos, N, (int64_t)p + 1);
+                while (s0 < N && tv.t->end[s0] <= p) ++s0;
+                if (std::min(e0, N) - s0 <= 0) return true;
+            }
+        }
+        return false;
+    }
+};
+}  // namespace plathost

@@ -55,6 +55,7 @@ static_assert(CNT_N <= 64, "the pinned read-back area holds 64 words");
 // other counters; k_dense_total copies them into cnt[] for the host and sums them.
 constexpr int DENSE_SEGS = 8;
 constexpr int DENSE_CNT_STRIDE = 512;                    // in long longs
+constexpr int CNT_DP_TILE = 60;                           // k_dp_jobs' tile counter (dynamic tiles)
 constexpr int CNT_AREA = 64 + DENSE_SEGS * DENSE_CNT_STRIDE;   // long longs reserved (and zeroed) for counters per batch
 __device__ __forceinline__ long long* dense_counter(long long* cnt, int seg) { return cnt + 64 + seg * DENSE_CNT_STRIDE; }
 __device__ __forceinline__ long long dense_count(const long long* cnt, int seg, long long segcap) {
@@ -2022,16 +2023,27 @@ template <bool UNPACKED>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_dp_jobs(plat_window_batch b, const uint8_t* __restrict__ gob, const uint8_t* __restrict__ hap_has_n, const Job* __restrict__ jobs,
           const PairRec* __restrict__ pairs, const double* __restrict__ mapq_lut, long long npairs,
-          const int32_t* __restrict__ dense, long long segcap, const long long* __restrict__ cnt, long long extra_cap,
-          int32_t* __restrict__ job_score, double* __restrict__ out_ll, int32_t* __restrict__ out_score)
+          const int32_t* __restrict__ dense, long long segcap, long long* __restrict__ cnt, long long extra_cap,
+          int32_t* __restrict__ job_score, double* __restrict__ out_ll, int32_t* __restrict__ out_score, int dyn)
 {
     if (cnt[CNT_ERR] != 0 || cnt[CNT_NEXTRA] > extra_cap) return;   // refused batch / job overflow (reported by the host)
     // a fixed grid walks the dense list in tiles of 256 jobs (the list's length is only known on the device)
     long long ndense = 0;
 #pragma unroll
     for (int k = 0; k < DENSE_SEGS; ++k) ndense += dense_count(cnt, k, segcap);
-    for (long long t0 = (long long)blockIdx.x * blockDim.x; t0 < ndense; t0 += (long long)gridDim.x * blockDim.x) {
-        const long long t = t0 + threadIdx.x;
+    // dyn: every WAVE pulls tiles of 64 jobs with one atomic (cnt[CNT_DP_TILE], zeroed with the batch's counters) until the list is empty --
+    // the waves of a launch that is several rounds deep finish together instead of in the order the fixed stride dealt them their tiles
+    const int lane = threadIdx.x & 63;
+    long long t0 = dyn ? 0 : (long long)blockIdx.x * blockDim.x;
+    for (;;) {
+        if (dyn) {
+            unsigned long long x = 0;
+            if (lane == 0) x = atomicAdd((unsigned long long*)&cnt[CNT_DP_TILE], 1ull);
+            t0 = 64ll * (long long)(((unsigned long long)(unsigned)__shfl((int)x, 0)) | ((unsigned long long)(unsigned)__shfl((int)(x >> 32), 0) << 32));
+        }
+        if (t0 >= ndense) break;
+        const long long t = t0 + (dyn ? lane : (int)threadIdx.x);
+        const long long t0next = t0 + (long long)gridDim.x * blockDim.x;
         const bool active = t < ndense;
         const long long j = active ? dense_slot(dense, segcap, cnt, t) : 0;
         Job jb = Job{0, 0, 0, 0};
@@ -2061,13 +2073,17 @@ k_dp_jobs(plat_window_batch b, const uint8_t* __restrict__ gob, const uint8_t* _
             if (anyBig) { if (active) sc = dp_job<false, false, UNPACKED>(rs, rq, hs, gs, jb.len); }
             else        { if (active) sc = dp_job<false, true, UNPACKED>(rs, rq, hs, gs, jb.len); }
         }
-        if (!active) continue;
-        if (j >= npairs) { job_score[j] = sc; continue; }
-        const PairRec pr = pairs[j];                                             // read after the DP: nothing of it is live across the loop
-        if (pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0)) {
-            out_ll[j] = loglik_of(sc, mapq_lut, pr.mapq);
-            if (out_score) out_score[j] = sc;
-        } else job_score[j] = sc;
+        if (active) {
+            if (j >= npairs) job_score[j] = sc;
+            else {
+                const PairRec pr = pairs[j];                                     // read after the DP: nothing of it is live across the loop
+                if (pr.ncand == 0 || (pr.ncand == 1 && pr.orig_k == 0)) {
+                    out_ll[j] = loglik_of(sc, mapq_lut, pr.mapq);
+                    if (out_score) out_score[j] = sc;
+                } else job_score[j] = sc;
+            }
+        }
+        if (!dyn) t0 = t0next;
     }
 }
 
@@ -2129,7 +2145,10 @@ k_dp_rows(int n, int lmax, const uint8_t* __restrict__ haps, const uint8_t* __re
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const size_t ho = (size_t)j * (lmax + 15), ro = (size_t)j * lmax;
-    out[j] = dp_score_bytes(haps + ho, gos + ho, reads + ro, quals + ro, len2[j], gapextend, nucprior);
+    // The production constants go through the job kernel's own core (16 bytes per array and trip, dp_run8): its loads reach up to 16
+    // bytes past a row's end, i.e. into the next row -- every row but the last takes it; the last row (and other constants) goes byte by byte.
+    if (gapextend == 3 && nucprior == 2 && lmax >= 16 && j + 1 < n) out[j] = dp_job<true, false, false>(reads + ro, quals + ro, haps + ho, gos + ho, len2[j]);
+    else out[j] = dp_score_bytes(haps + ho, gos + ho, reads + ro, quals + ro, len2[j], gapextend, nucprior);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2539,17 +2558,25 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         if (dp_impl < 0) { const char* e = getenv("PLAT_DP_IMPL"); dp_impl = e ? (strcmp(e, "unpacked") == 0) : 0; }   // packed measured faster
         // a fixed grid walks the list (its length lives on the device): two rounds of the blocks a device holds at 4 waves/SIMD
         const long long want = (ngrid + 255) / 256, fixed = 8ll * ctx->n_cu;
-        const dim3 grid((unsigned)(want < fixed ? want : fixed));
+        // PLAT_DP_TILES=1 (measurement, round 5): every wave pulls 64-job tiles with one atomic instead of walking the list with a fixed
+        // stride.  Measured SLOWER on both shapes -- config 2 (3 328 tiles, one per wave) k_dp_jobs 137 -> 180 us, every reference DP
+        // executed (24.5 k tiles) 4 008 -> 3 971 GCUPS: thousands of atomics on one L2 address (~90 per us) cost more than the uneven
+        // last round they remove.  Off by default.
+        static int dp_dyn = -1;
+        if (dp_dyn < 0) { const char* e = getenv("PLAT_DP_TILES"); dp_dyn = e ? (e[0] == '1') : 0; }
+        // dynamic tiles: exactly the blocks the device holds at 4 waves/SIMD (4 per CU), each wave pulling tiles until none is left
+        const long long resident = 4ll * ctx->n_cu;
+        const dim3 grid((unsigned)(dp_dyn ? (want < resident ? want : resident) : (want < fixed ? want : fixed)));
         if (dp_impl)
             hipLaunchKernelGGL(k_dp_jobs<true>, grid, dim3(256), 0, st, b, (const uint8_t*)ctx->hapw.ptr,
                                (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
                                (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, segcap, cnt, extra_cap,
-                               (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
+                               (int32_t*)ctx->job_score.ptr, out_loglik, out_score, dp_dyn);
         else
             hipLaunchKernelGGL(k_dp_jobs<false>, grid, dim3(256), 0, st, b, (const uint8_t*)ctx->hapw.ptr,
                                (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
                                (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, segcap, cnt, extra_cap,
-                               (int32_t*)ctx->job_score.ptr, out_loglik, out_score);
+                               (int32_t*)ctx->job_score.ptr, out_loglik, out_score, dp_dyn);
     }
     PLAT_EV(ctx, 3, st);
     if (async) {

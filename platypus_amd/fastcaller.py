@@ -227,12 +227,12 @@ def aligned_reads_from_arrays(s):
 def build(verbose=False):
     """g++ the host library and link it to libplat_mi355x.so (built first if needed)."""
     _lib.build()
-    srcs = [os.path.join(HOST_SRC, f) for f in ("region_caller.cpp", "records.hpp", "variants.hpp")]
+    srcs = [os.path.join(HOST_SRC, f) for f in sorted(os.listdir(HOST_SRC)) if f.endswith((".cpp", ".hpp"))]
     if os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max([os.path.getmtime(f) for f in srcs] + [os.path.getmtime(_lib.LIB_PATH)]):
         return LIB_PATH
     # (-O3: the region loop is many small functions over small containers; +10 % windows/s over -O2 on the same box.  No -march: the library
     #  travels between machines; no fast-math: the records' numbers are the reference's)
-    cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-fvisibility=hidden", srcs[0], "-o", LIB_PATH,
+    cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-fvisibility=hidden", os.path.join(HOST_SRC, "region_caller.cpp"), "-o", LIB_PATH,
            "-L" + HERE, "-lplat_mi355x", "-Wl,-rpath,$ORIGIN"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose:

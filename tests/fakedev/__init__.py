@@ -46,8 +46,8 @@ def fake_caller_lib():
     from platypus_amd import fastcaller as F
     build()
     out = os.path.join(HERE, "libplat_caller_fake.so")
-    srcs = [os.path.join(F.HOST_SRC, f) for f in ("region_caller.cpp", "records.hpp", "variants.hpp")]
+    srcs = [os.path.join(F.HOST_SRC, f) for f in sorted(os.listdir(F.HOST_SRC)) if f.endswith((".cpp", ".hpp"))]
     if not os.path.exists(out) or os.path.getmtime(out) < max([os.path.getmtime(f) for f in srcs] + [os.path.getmtime(FAKE_LIB)]):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-fvisibility=hidden", srcs[0], "-o", out,
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-fvisibility=hidden", os.path.join(F.HOST_SRC, "region_caller.cpp"), "-o", out,
                         "-L" + HERE, "-lplat_fake", "-Wl,-rpath," + HERE], check=True)
     return F._bind(C.CDLL(out))
