@@ -183,6 +183,8 @@ cdef extern from "platypus_mi355x.h":
         int32_t cap_per_scan
         const int32_t* cand
         const int32_t* cand_n
+        const int32_t* cand_rec
+        const int64_t* region_name_hash
         const uint8_t* ref_seq
         const int64_t* ref_off
         const int32_t* ref_seq_start

@@ -151,6 +151,7 @@ typedef struct plat_caller_stats {
     /* stage B (candidates -> variants -> windows -> haplotypes -> window batch): regions the device did (plat_stage_b_batch), regions
      * and single windows it left to the host's code (cohorts, assembly and reference-call runs never go to the device: not counted) */
     int64_t n_regions_stage_b_device, n_regions_stage_b_host, n_windows_stage_b_host;
+    int64_t n_regions_dict_replay_device;   /* of the device's regions: those whose order needed the Python-2 dictionaries replayed (on the device) */
 } plat_caller_stats;
 
 typedef struct plat_caller plat_caller;

@@ -360,7 +360,8 @@ int plat_concat_read_tables(plat_ctx* ctx, int n_tables, int max_reads_per_table
  * (tab_begin/tab_n/tab_longest[3g + k], k = 0 reads, 1 badReads, 2 brokenMates; broken_mate_pos[i] = mate position of read
  * tab_begin[3g+2] + i, indexed from broken_base).
  * Output, per region g (all device memory of the caller):
- *   hdr[8g..]   {status, n_variants, n_windows, candidate records, bytes used of the added-bases blob, 0, 0, 0}; status 0, or
+ *   hdr[8g..]   {status, n_variants, n_windows, candidate records, bytes used of the added-bases blob, why (status != 0: 1 capacity /
+ *               an exception, 2 dictionary too large to replay, 4 windows, 5 the merge's own verdict), dictionaries replayed, 0}; status 0, or
  *               PLAT_SB_HOST: this region needs the caller's own code (more candidates / variants / windows than the capacities, an
  *               indel at the edge of its reference window, an order that depends on a Python dictionary, an exception the reference
  *               would raise, ...) -- nothing else of the region is valid then.
@@ -390,6 +391,11 @@ typedef struct plat_stage_b_options {
 typedef struct plat_stage_b_in {
     int32_t n_regions, cap_per_scan;
     const int32_t* cand; const int32_t* cand_n;
+    /* for the replay of the candidate generator's Python-2 dictionaries where an order depends on them: the scan's records (out_rec of
+     * plat_candidates_batch) and per region hash(refName) as CPython 2.7 computes it for the contig's name; either NULL: such a region is
+     * flagged PLAT_SB_HOST instead.  (The distinct records themselves are read from the context's merge table: call this right behind
+     * plat_candidates_merge_batch, on the same context and stream.) */
+    const int32_t* cand_rec; const int64_t* region_name_hash;
     const uint8_t* ref_seq; const int64_t* ref_off; const int32_t* ref_seq_start; const int32_t* contig_len;
     const int32_t* region_start; const int32_t* region_end; const int32_t* region_rlen;    /* [n_regions]; rlen: options.rlen as the loop carries it */
     const uint8_t* read_seq; const int64_t* read_off; const int32_t* read_pos; const int32_t* read_end;

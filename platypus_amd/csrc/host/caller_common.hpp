@@ -141,7 +141,7 @@ struct Slot {
                     sb_wptrs, sb_wnhaps, sb_wbatch;
     Staged<uint8_t> sb_added;
     Staged<uint32_t> sb_hapmask;
-    Staged<int64_t> sb_totals;
+    Staged<int64_t> sb_totals, sb_namehash;
     Staged<int32_t> d_hapbegin, d_readbegin, d_start, d_end, d_flank, d_segbegin, d_ngood, d_src, d_scratch;                 // device only
     Staged<int64_t> d_pairoff, d_gloff, d_hapoff, d_readoff;
     Staged<uint8_t> d_hapseq, d_kind;

@@ -18,13 +18,14 @@ inline void Chunk::launchStageB() {
     for (RegionWork* r : regions) nBr += (size_t)r->samples[0].broken.n();
     Layout LI;
     LI.add(z.sb_rstart, nR); LI.add(z.sb_rend, nR); LI.add(z.sb_rlen, nR); LI.add(z.sb_tabbegin, 3 * nR); LI.add(z.sb_tabn, 3 * nR); LI.add(z.sb_tablongest, 3 * nR);
-    LI.add(z.sb_matepos, nBr + 1);
+    LI.add(z.sb_matepos, nBr + 1); LI.add(z.sb_namehash, nR);
     LI.commit(z, z.a_bin);
     size_t mo = 0;
     for (size_t g = 0; g < nR; ++g) {
         RegionWork& r = *regions[g];
         SampleView& sv = r.samples[0];
         z.sb_rstart.h[g] = r.in->start; z.sb_rend.h[g] = r.in->end; z.sb_rlen.h[g] = r.rlen;
+        z.sb_namehash.h[g] = (int64_t)py2_string_hash(r.in->chrom ? std::string(r.in->chrom) : std::string());      // (the dictionaries of Variants hash the contig's name)
         const TableView* tv[3] = {&sv.reads, &sv.bad, &sv.broken};
         for (int k = 0; k < 3; ++k) { z.sb_tabbegin.h[3 * g + k] = (int32_t)tv[k]->base; z.sb_tabn.h[3 * g + k] = tv[k]->n(); z.sb_tablongest.h[3 * g + k] = tv[k]->longest; }
         if (sv.broken.n()) memcpy(z.sb_matepos.h + mo, sv.broken.t->mate_pos, sizeof(int32_t) * (size_t)sv.broken.n());
@@ -50,6 +51,7 @@ inline void Chunk::launchStageB() {
     plat_stage_b_in in;
     memset(&in, 0, sizeof in);
     in.n_regions = (int32_t)nR; in.cap_per_scan = mergeCap; in.cand = z.m_cand.d; in.cand_n = z.m_n.d;
+    in.cand_rec = getenv("PLAT_CALLER_NO_DEVICE_REPLAY") ? nullptr : z.c_rec.d; in.region_name_hash = z.sb_namehash.d;
     in.ref_seq = z.c_ref.d; in.ref_off = z.c_refoff.d; in.ref_seq_start = z.c_rss.d; in.contig_len = z.c_clen.d;
     in.region_start = z.sb_rstart.d; in.region_end = z.sb_rend.d; in.region_rlen = z.sb_rlen.d;
     in.read_seq = z.t_seq.d; in.read_off = z.t_off.d; in.read_pos = z.t_pos.d; in.read_end = z.t_end.d;
@@ -101,13 +103,14 @@ inline void Chunk::stageBFromDevice() {
         }
     if (rows) z.sync("candidates");
     int hapRun = 0;
-    int64_t nHostRegions = 0, nHostWindows = 0;
+    int64_t nHostRegions = 0, nHostWindows = 0, nReplayed = 0;
     for (size_t g = 0; g < nR; ++g) {
         RegionWork& r = *regions[g];
         const int32_t* hdr = z.sb_hdr.h + 8 * g;
         if (hdr[0] != 0) { regionVariants(r, (int)g); regionWindows(r); ++nHostRegions; continue; }
         PROF("s2.fillRegion");
         const int nV = hdr[1], nW = hdr[2];
+        nReplayed += hdr[6] != 0;
         r.nCandRecords += hdr[3];
         r.variants.clear();
         const uint8_t* blob = z.sb_added.h + g * (size_t)capA;
@@ -175,7 +178,7 @@ inline void Chunk::stageBFromDevice() {
     db.wb.read_off = z.d_readoff.d; db.wb.read_kind = z.d_kind.d;
     db.hapbegin = z.d_hapbegin.d; db.gloff = z.d_gloff.d; db.ngood = z.d_ngood.d; db.segbegin = z.d_segbegin.d; db.src = z.d_src.d; db.readoff = z.d_readoff.d;
     std::lock_guard<std::mutex> g(stMutex);
-    st.n_regions_stage_b_device += (int64_t)nR - nHostRegions; st.n_regions_stage_b_host += nHostRegions; st.n_windows_stage_b_host += nHostWindows;
+    st.n_regions_stage_b_device += (int64_t)nR - nHostRegions; st.n_regions_stage_b_host += nHostRegions; st.n_windows_stage_b_host += nHostWindows; st.n_regions_dict_replay_device += nReplayed;
 }
 
 }  // namespace plathost

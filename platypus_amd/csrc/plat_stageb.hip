@@ -32,6 +32,7 @@ namespace plat {
 
 constexpr int SB_CAP = 1024;                      // candidates of a region held in LDS (more: the caller's own code)
 constexpr int SB_THREADS = 1024;                  // k_sb_variants: 16 waves (16 indels walk the reference side by side)
+constexpr int SB_DICT_CAP = 5400;               // distinct records of a scan whose dictionary fits 8192 slots (a resize at 5462 keys would need 32768)
 constexpr int SB_MAXCOMB = 5;                     // a window with more variants than this goes through the greedy filter (the caller's)
 
 struct SbIn {
@@ -69,6 +70,14 @@ struct SbRegion {                                  // per-region LDS state of k_
     unsigned char head[SB_CAP], keep[SB_CAP];
     int list[SB_CAP];
     int wsum[16], tot, nIndel, addedUsed, status, nKept;
+    // the Python-2 dictionaries of the candidate generator, replayed when an order depends on them (sb_dict_order)
+    int dId[SB_DICT_CAP];                          // first-record ids of ALL distinct records of the scan, ascending = insertion order
+    int dHash[SB_DICT_CAP];                        // hash(Variant) narrowed to a C int (variant.pxd:31); before that: scratch of the sort
+    unsigned short dCand[SB_DICT_CAP];             // candidate index + 1 of the record (0: it did not pass the support filter)
+    unsigned short dOrd[SB_DICT_CAP];              // keys in the order the dictionary yields them
+    unsigned short dScr[SB_DICT_CAP];              // a table's keys in slot order while it is rebuilt
+    unsigned short dP2[SB_CAP], dO2[SB_CAP], dS2[SB_CAP];   // the second dictionary: its keys (distinct-record indices), its order, rebuild scratch
+    int dN, dN2;
 };
 
 // the added bases of element e: in the read table (addo >= 0) or, once normalised, in the region's own blob (addo = -(offset + 1))
@@ -84,8 +93,91 @@ __device__ __forceinline__ bool sb_same(const SbRegion& R, int a, int b, const u
     return true;                                                       // (removed bases: the reference's own at pos, equal when pos and nrem are)
 }
 
+// ---- CPython 2.7 on the device: hash(Variant) and the iteration order of a dict (what variantcaller.pyx:456-470 walks) ---------------------
+// hash(str), stringobject.c (64-bit build)
+__device__ __forceinline__ unsigned long long sb_py2_string_hash(const uint8_t* p, int n) {
+    if (n == 0) return 0ull;
+    unsigned long long x = (unsigned long long)p[0] << 7;
+    for (int i = 0; i < n; ++i) x = (1000003ull * x) ^ p[i];
+    x ^= (unsigned long long)n;
+    return x == ~0ull ? ~0ull - 1 : x;
+}
+// hash((refName, refPos, removed, added)) (tupleobject.c) kept in a C int (variant.pyx:270-280, variant.pxd:31): the dictionary probes
+// with the sign-extended low 32 bits, -1 -> -2
+__device__ __forceinline__ int sb_py2_variant_hash(unsigned long long nameHash, int refPos, const uint8_t* rem, int nrem, const uint8_t* add, int nadd) {
+    const unsigned long long h[4] = {nameHash, (unsigned long long)(long long)refPos, sb_py2_string_hash(rem, nrem), sb_py2_string_hash(add, nadd)};
+    unsigned long long x = 0x345678ull, mult = 1000003ull;
+    for (int i = 0; i < 4; ++i) { x = (x ^ h[i]) * mult; mult += (unsigned long long)(82520ll + 2 * (3 - i)); }
+    x += 97531ull;
+    if (x == ~0ull) x = ~0ull - 1;
+    int narrowed = (int)(unsigned)x;
+    return narrowed == -1 ? -2 : narrowed;
+}
+// Iteration order of a Python-2 dict into which `n` distinct keys (0 .. n-1, hashes H[key] as the dictionary sees them) were inserted in
+// that order (dictobject.c: a new key takes the first empty slot of its probe sequence i = 5 i + perturb + 1, perturb >>= 5; the table of
+// 8 slots is rebuilt 4 x used slots large, in slot order, when two thirds full).  The WHOLE workgroup runs it, exactly:
+//  * between two rebuilds the table has one size and the keys enter it in a known order -- the keys of the old table in its slot order,
+//    then the new ones: key of priority p;
+//  * the slot a key ends in is the first of its probe sequence that no key of HIGHER priority ends in.  So every key claims its current
+//    slot with an atomicMin of its priority; who does not hold its slot afterwards moves one probe on; a key, once beaten for a slot, is
+//    beaten for good (a slot only ever passes to higher priorities), so nobody has to go back.  Rounds repeat until nobody moves:
+//    as many as the longest probe chain, a few dozen, instead of one insertion after the other;
+//  * the slot order of the finished table (a scan) is the next table's insertion order.
+// owner: 8192 words; step: one byte per key; ord: out (and the old table's order in between); tmp: n entries.  n <= SB_DICT_CAP.
+__device__ void sb_py2_dict_order(int n, const int* __restrict__ H, unsigned* owner, unsigned char* step, unsigned short* ord, unsigned short* tmp,
+                                  int* wsum, int* tot, int* flag)
+{
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    int size = 8, m = 0;                                               // m keys are in the table (ord[0..m): its slot order)
+    for (;;) {
+        const int lim = (2 * size + 2) / 3;                            // the insertion that makes used * 3 >= size * 2
+        const int e1 = n < lim ? n : lim;                              // keys m .. e1-1 enter this table; priority p -> key: p < m ? ord[p] : p
+        const unsigned long long mask = (unsigned long long)size - 1;
+        for (int i = tid; i < size; i += nthr) owner[i] = 0xFFFFFFFFu;
+        for (int p = tid; p < e1; p += nthr) step[p] = 0;
+        __syncthreads();
+        auto slotOf = [&](int p) -> unsigned {
+            const int key = p < m ? (int)ord[p] : p;
+            const unsigned long long h = (unsigned long long)(long long)H[key];
+            unsigned long long i = h & mask, perturb = h;
+            for (int t = step[p]; t > 0; --t) { i = 5 * i + perturb + 1; perturb >>= 5; }
+            return (unsigned)(i & mask);
+        };
+        for (;;) {
+            if (tid == 0) *flag = 0;
+            for (int p = tid; p < e1; p += nthr) atomicMin(&owner[slotOf(p)], (unsigned)p);
+            __syncthreads();
+            bool moved = false;
+            for (int p = tid; p < e1; p += nthr) if (owner[slotOf(p)] != (unsigned)p) { step[p] = (unsigned char)(step[p] + 1); moved = true; }
+            if (moved) *flag = 1;
+            __syncthreads();
+            if (!*flag) break;
+            __syncthreads();
+        }
+        // the table's slot order
+        {
+            const int per = (size + nthr - 1) / nthr, s0 = tid * per, s1 = min(size, s0 + per);
+            int cnt = 0;
+            for (int i = s0; i < s1; ++i) cnt += owner[i] != 0xFFFFFFFFu;
+            int at = sb_block_scan(cnt, wsum, tot);
+            for (int i = s0; i < s1; ++i) if (owner[i] != 0xFFFFFFFFu) { const int p = (int)owner[i]; tmp[at++] = (unsigned short)(p < m ? (int)ord[p] : p); }
+        }
+        __syncthreads();
+        for (int i = tid; i < e1; i += nthr) ord[i] = tmp[i];
+        __syncthreads();
+        m = e1;
+        if (e1 * 3 >= size * 2) {                                      // rebuilt 4 x used large (also behind the LAST key: the final table is the new one)
+            int ns = 8;
+            while (ns <= e1 * 4) ns <<= 1;
+            size = ns;
+            continue;
+        }
+        if (e1 == n) break;
+    }
+}
+
 __global__ void __launch_bounds__(1024)
-k_sb_variants(SbIn in, plat_stage_b_out out)
+k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
 {
     extern __shared__ __align__(16) unsigned char sb_lds[];
     SbRegion& R = *(SbRegion*)sb_lds;
@@ -94,10 +186,10 @@ k_sb_variants(SbIn in, plat_stage_b_out out)
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int32_t* hdr = out.hdr + 8 * g;
     const int n = b.cand_n[2 * g];
-    if (tid == 0) { R.status = 0; R.nIndel = 0; R.addedUsed = 0; R.nKept = 0; }
+    if (tid == 0) { R.status = 0; R.nIndel = 0; R.addedUsed = 0; R.nKept = 0; R.dN2 = 0; }
     __syncthreads();
     if (b.cand_n[2 * g + 1] != 0 || n > SB_CAP || n > b.cap_per_scan) {                  // (the merge kernel's own verdict is the caller's to read)
-        if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = hdr[3] = hdr[4] = hdr[5] = hdr[6] = hdr[7] = 0; }
+        if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = hdr[3] = hdr[4] = hdr[6] = hdr[7] = 0; hdr[5] = 5; }
         return;
     }
     const long long roff = b.ref_off[g];
@@ -105,12 +197,17 @@ k_sb_variants(SbIn in, plat_stage_b_out out)
     const uint8_t* ref = b.ref_seq + roff;                             // ref[x - rss] = contig base x for rss <= x < rss + refLen
     uint8_t* blob = out.added + (long long)g * b.cap_added;
     const int rlen = b.region_rlen[g];
+    int nk = 0;
+    // Pass 0 orders candidates of one key by their first records (the order a dictionary yields them in unless two of its keys met in a
+    // slot).  Where the result can depend on the real order -- see (a), (b) below -- the dictionaries are replayed (sb_replay) and pass 1
+    // runs with their order as the tie-break, which is what the reference did in the first place.
+    for (int pass = 0; pass < 2; ++pass) {
     long long nrec = 0;
     // ---- load; key of the reference's order
     for (int i = tid; i < n; i += SB_THREADS) {
         const int32_t* c = b.cand + 8ll * ((long long)g * b.cap_per_scan + i);
         const int pos = c[3] < 0 ? 0 : c[3], nrem = c[4], nadd = c[5];
-        R.id[i] = c[0]; R.supp[i] = c[1]; R.pos[i] = pos; R.nrem[i] = nrem; R.nadd[i] = nadd;
+        R.id[i] = pass ? (int)R.dOrd[i] : c[0]; R.supp[i] = c[1]; R.pos[i] = pos; R.nrem[i] = nrem; R.nadd[i] = nadd;
         R.remc[i] = nrem ? rss + c[6] - (int)roff : pos;             // contig coordinate of the removed bases (c[6]: offset in the reference blob)
         R.addo[i] = nadd ? c[7] : 0;
         R.bmin[i] = pos; R.bmax[i] = pos;
@@ -228,7 +325,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out)
         if (m > 48) twice = other = true;
         for (int x = 0; x < m && m <= 48; ++x)
             for (int y = x + 1; y < m; ++y) { if (sb_same(R, R.perm[r + x], R.perm[r + y], b.read_seq, blob)) twice = true; else other = true; }
-        if (twice && other) atomicOr(&R.status, 1);
+        if (twice && other && pass == 0) atomicOr(&R.status, 2);
     }
     // ---- the survivors, in order
     {
@@ -239,12 +336,71 @@ k_sb_variants(SbIn in, plat_stage_b_out out)
         for (int r = r0; r < r1; ++r) if (R.keep[r]) R.list[at++] = R.perm[r];
     }
     __syncthreads();
-    const int nk = R.tot;
+    nk = R.tot;
     //  (b) two survivors that compare equal
-    for (int k = tid + 1; k < nk; k += SB_THREADS) if (R.key[R.list[k]] == R.key[R.list[k - 1]]) atomicOr(&R.status, 1);
+    for (int k = tid + 1; k < nk; k += SB_THREADS) if (pass == 0 && R.key[R.list[k]] == R.key[R.list[k - 1]]) atomicOr(&R.status, 2);
     if (nk > b.cap_vars) atomicOr(&R.status, 1);
     __syncthreads();
-    if (R.status) { if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; } return; }
+    const int st0 = R.status;
+    __syncthreads();
+    if (st0 & 1) { if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; hdr[5] = 1; } return; }
+    if (!(st0 & 2)) break;
+    // ---- the order depends on the dictionaries: replay them (variantcaller.pyx:456-470: the sample's variantHeap walked with iteritems(),
+    // what passes the support filter put into the all-samples generator's variantHeap, its values() sorted)
+    {
+        const int32_t* tab = mtab + (size_t)g * 2 * 8192;
+        if (tid == 0) { R.dN = 0; R.dN2 = 0; }
+        __syncthreads();
+        for (int sl = tid; sl < 8192; sl += SB_THREADS) {                // every distinct record of the scan (the merge kernel's table)
+            const int id = tab[sl] - 1;
+            if (id >= 0) { const int k = atomicAdd(&R.dN, 1); if (k < SB_DICT_CAP) R.dHash[k] = id; }
+        }
+        __syncthreads();
+        const int n1 = R.dN;
+        if (n1 > SB_DICT_CAP || !b.cand_rec || !b.region_name_hash) { if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; hdr[5] = 2; } return; }
+        for (int i = tid; i < n1; i += SB_THREADS) {                     // ascending first-record id = the order they entered the dictionary
+            const int id = R.dHash[i];
+            int r = 0;
+            for (int j = 0; j < n1; ++j) r += R.dHash[j] < id;
+            R.dId[r] = id;
+        }
+        __syncthreads();
+        const unsigned long long nameHash = (unsigned long long)b.region_name_hash[g];
+        for (int i = tid; i < n1; i += SB_THREADS) {
+            const int32_t* me = b.cand_rec + 5ll * R.dId[i];
+            R.dHash[i] = sb_py2_variant_hash(nameHash, me[0] < 0 ? 0 : me[0], b.ref_seq + me[3], me[1], b.read_seq + me[4], me[2]);
+            R.dCand[i] = 0;
+        }
+        __syncthreads();
+        for (int c = tid; c < n; c += SB_THREADS) {                      // which of them are candidates (passed the support filter)
+            const int id = b.cand[8ll * ((long long)g * b.cap_per_scan + c)];
+            int lo = 0, hi = n1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (R.dId[mid] < id) lo = mid + 1; else hi = mid; }
+            if (lo < n1 && R.dId[lo] == id) R.dCand[lo] = (unsigned short)(c + 1);
+        }
+        __syncthreads();
+        // (scratch of the replay: the candidate arrays of pass 0 are dead -- pass 1 loads them again)
+        unsigned* owner = (unsigned*)R.key;                               // 8192 words = key, id, pos, nrem, nadd, supp, remc
+        unsigned char* step = (unsigned char*)R.addo;                    // one byte per key (addo, bmin: 8 KB)
+        sb_py2_dict_order(n1, R.dHash, owner, step, R.dOrd, R.dScr, R.wsum, &R.tot, &R.dN2);
+        // the sample's dictionary walked in its order: the keys that pass enter the second dictionary in that order
+        if (tid == 0) {
+            int m = 0;
+            for (int r = 0; r < n1 && m < SB_CAP; ++r) if (R.dCand[R.dOrd[r]]) { R.dP2[m] = R.dOrd[r]; R.dId[m] = R.dHash[R.dOrd[r]]; ++m; }
+            R.dN = m;
+        }
+        __syncthreads();
+        const int m2 = R.dN;
+        sb_py2_dict_order(m2, R.dId, owner, step, R.dO2, R.dS2, R.wsum, &R.tot, &R.dN2);
+        // rank of every candidate in the second dictionary's order: candidate -> rank in dOrd (free now)
+        for (int r = tid; r < m2; r += SB_THREADS) R.dOrd[R.dCand[R.dP2[R.dO2[r]]] - 1] = (unsigned short)r;
+        __syncthreads();
+        if (tid == 0) { R.dN2 = m2; R.status = 0; R.nIndel = 0; R.addedUsed = 0; }
+        __syncthreads();
+        if (R.dN2 != n) { if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; hdr[5] = 3; } return; }   // (every candidate is a distinct record: cannot happen)
+    }
+    }   // pass
+    if (tid == 0) hdr[5] = 0;
     // ---- the region's variants out (+ the added bases of those that still live in the read table)
     for (int k = tid; k < nk; k += SB_THREADS) {
         const int e = R.list[k];
@@ -298,8 +454,8 @@ k_sb_variants(SbIn in, plat_stage_b_out out)
             else { emit(); bMin = gMin; bMax = gMax; bCount = gCount; bFirst = gFirst; }
         }
         if (haveBunch) emit();
-        if (st) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; }
-        else { hdr[0] = 0; hdr[1] = nk; hdr[2] = nw; hdr[4] = R.addedUsed; hdr[5] = hdr[6] = hdr[7] = 0; }
+        if (st) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; hdr[5] = 4; }
+        else { hdr[0] = 0; hdr[1] = nk; hdr[2] = nw; hdr[4] = R.addedUsed; hdr[5] = 0; hdr[6] = R.dN2 > 0; hdr[7] = 0; }
     }
 }
 
@@ -759,6 +915,7 @@ PLAT_EXPORT int plat_stage_b_batch(plat_ctx* ctx, const plat_stage_b_in* batch, 
         !o.b_hap_off || !o.b_hap_mask || !o.b_hap_seq || !o.b_read_off || !o.b_read_src || !o.b_read_kind || !o.totals || !o.scratch)
         return PLAT_ERR_INVALID;
     if (options->maxHaplotypes < 3) return PLAT_ERR_UNSUPPORTED;
+    if (!ctx->merge_tab.ptr) return PLAT_ERR_INVALID;                  // (plat_candidates_merge_batch of THIS context comes first: its table of distinct records is read)
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
     plat::SbIn in;
     in.b = b; in.o = *options;
@@ -768,7 +925,8 @@ PLAT_EXPORT int plat_stage_b_batch(plat_ctx* ctx, const plat_stage_b_in* batch, 
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)plat::k_sb_variants, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(plat::SbRegion)));
         once = true;
     }
-    hipLaunchKernelGGL(plat::k_sb_variants, dim3((unsigned)b.n_regions), dim3(plat::SB_THREADS), sizeof(plat::SbRegion), st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_variants, dim3((unsigned)b.n_regions), dim3(plat::SB_THREADS), sizeof(plat::SbRegion), st, in, o,
+                       (const int32_t*)ctx->merge_tab.ptr);
     hipLaunchKernelGGL(plat::k_sb_windows, dim3((unsigned)b.n_regions), dim3(256), 0, st, in, o);
     hipLaunchKernelGGL(plat::k_sb_scan, dim3(1), dim3(64), 0, st, in, o);
     hipLaunchKernelGGL(plat::k_sb_haps, dim3(48, (unsigned)b.n_regions), dim3(256), 0, st, in, o);

@@ -137,3 +137,58 @@ def test_an_indel_in_a_repeat_is_moved_left_on_the_device_as_on_the_host():
     pos = {int(ln.split("\t")[1]): ln.split("\t") for ln in dev.split("\n") if ln}
     assert 700 in pos and pos[700][3] == "CA" and pos[700][4] == "C", sorted(pos)          # VCF POS is 1-based: the base before the run
     assert 1000 in pos and pos[1000][3] == "A" and pos[1000][4] == "ACT", sorted(pos)
+
+
+def _two_allele_work(seed, n_regions=4, n_sites=9, **kw):
+    """One-sample regions with sites where the reads show TWO alternative SNP alleles in the same number of reads: a tie of position, type,
+    length and support -- `sorted` keeps such a pair in the order the candidate generator's Python-2 dictionaries yield it."""
+    rng = np.random.default_rng(seed)
+    regs = [synth.config4_region(i, seed=seed, n_samples=1, **kw) for i in range(n_regions)]
+    planted = 0
+    for r in regs[:-1]:                                                     # (the last region stays as it is: no pair, no replay)
+        taken = {v[0] for v in r["variants"]}
+        sites = [p for p in rng.choice(np.arange(r["start"] + 150, r["end"] - 150), size=60, replace=False).tolist() if all(abs(p - q) > 12 for q in taken)][:n_sites]
+        for p in sites:
+            taken.add(p)
+            alts = [b for b in b"ACGT" if b != r["ref"][p]]
+            a1, a2 = (alts[k] for k in rng.choice(3, size=2, replace=False))
+            reads = r["samples"][0]
+            cover = [x for x in reads if x["pos"] + 12 <= p < x["pos"] + len(x["seq"]) - 12 and len(x["cigar"]) == 1]
+            for k, x in enumerate(cover[:2 * min(14, len(cover) // 2)]):
+                sq = bytearray(x["seq"])
+                sq[p - x["pos"]] = a1 if k % 2 == 0 else a2
+                x["seq"] = bytes(sq)
+            planted += 1
+    fasta = H.FastaFile({r["chrom"]: r["ref"] for r in regs})
+    work = [(r["chrom"], r["start"], r["end"], [H.bamReadBuffer([H.AlignedRead(x["seq"], x["qual"], x["pos"], x["mapq"], x["flag"], end=x["end"], cigarOps=x["cigar"])
+                                                                 for x in r["samples"][0]], sample="S1")]) for r in regs]
+    return fasta, work, planted
+
+
+@pytest.mark.parametrize("over", [dict(), dict(maxVariants=1), dict(maxVariants=2, minPosterior=0)])
+def test_the_python2_dictionaries_are_replayed_on_the_device(over):
+    """variantcaller.pyx:456-470: candidates that compare equal keep the order of two Python-2 dicts keyed by hash(Variant).  The device
+    replays them (k_sb_variants: CPython's string / tuple hashes, the C-int narrowing of variant.pxd:31, open addressing with perturbation,
+    the 4 x growth in slot order) for the regions that hold such a pair; the text is that of the host's own replay (the code the reference
+    goldens pin) and of the Python loop, also where the pair's order decides what is kept (maxVariants = 1)."""
+    fasta, work, planted = _two_allele_work(7400, region_len=3000, snp_rate=2e-3, indel_rate=5e-4, read_len=100, depth=40)
+    assert planted >= 20
+    dev, sd = _native(work, fasta, 4, False, **over)
+    host, sh = _native(work, fasta, 4, True, **over)
+    assert sd["n_regions_dict_replay_device"] == 3 and sd["n_regions_stage_b_device"] == 4, sd
+    assert dev == host
+    old = os.environ.get("PLAT_CALLER_NO_DEVICE_REPLAY")
+    os.environ["PLAT_CALLER_NO_DEVICE_REPLAY"] = "1"                         # the same regions flagged for the host instead
+    try:
+        flagged, sf = _native(work, fasta, 4, False, **over)
+    finally:
+        if old is None:
+            os.environ.pop("PLAT_CALLER_NO_DEVICE_REPLAY", None)
+        else:
+            os.environ["PLAT_CALLER_NO_DEVICE_REPLAY"] = old
+    assert sf["n_regions_stage_b_host"] == 3 and sf["n_regions_dict_replay_device"] == 0 and flagged == dev
+    py = io.StringIO()
+    caller.callVariantsInRegions(work, fasta, default_options(**over), VCF(["S1"]), py)
+    assert dev == py.getvalue()
+    multi = [ln for ln in dev.split("\n") if ln and "," in ln.split("\t")[4]]
+    assert len(multi) >= 3 or over

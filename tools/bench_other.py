@@ -368,7 +368,8 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
                                          "inside_timed_region": "region calls of every rank + gather of the record text to rank 0 + (chrom, pos) merge"}}
     line["inputs"] = "resident in HBM" if r["resident"] else "generated and uploaded inside the timed region"
     line["stage_b"] = {"regions_on_the_device": int(st.get("n_regions_stage_b_device", 0)), "regions_left_to_the_host": int(st.get("n_regions_stage_b_host", 0)),
-                       "windows_left_to_the_host": int(st.get("n_windows_stage_b_host", 0)), "of_this_ranks_regions": r["regions"]}
+                       "windows_left_to_the_host": int(st.get("n_windows_stage_b_host", 0)), "of_this_ranks_regions": r["regions"],
+                       "regions_with_dictionaries_replayed_on_the_device": int(st.get("n_regions_dict_replay_device", 0))}
     line.update(config4_gcups(counted_all, regs, T))
     if rank == 0:
         if lib is None and not getattr(a, "no_cpu_baseline", False):
