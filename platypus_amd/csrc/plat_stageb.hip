@@ -145,7 +145,17 @@ __device__ void sb_py2_dict_order(int n, const int* __restrict__ H, unsigned* ow
         };
         for (;;) {
             if (tid == 0) *flag = 0;
-            for (int p = tid; p < e1; p += nthr) atomicMin(&owner[slotOf(p)], (unsigned)p);
+            // claim: a key walks its probe sequence past every slot a higher priority holds (beaten once, beaten for good) and takes the
+            // first it can; whoever it displaces finds out below and walks on in the next round
+            for (int p = tid; p < e1; p += nthr) {
+                const int key = p < m ? (int)ord[p] : p;
+                const unsigned long long h = (unsigned long long)(long long)H[key];
+                unsigned long long i = h & mask, perturb = h;
+                int t = step[p];
+                for (int q = t; q > 0; --q) { i = 5 * i + perturb + 1; perturb >>= 5; }
+                while (atomicMin(&owner[(unsigned)(i & mask)], (unsigned)p) < (unsigned)p) { i = 5 * i + perturb + 1; perturb >>= 5; ++t; }
+                step[p] = (unsigned char)t;
+            }
             __syncthreads();
             bool moved = false;
             for (int p = tid; p < e1; p += nthr) if (owner[slotOf(p)] != (unsigned)p) { step[p] = (unsigned char)(step[p] + 1); moved = true; }
@@ -349,6 +359,9 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
     // what passes the support filter put into the all-samples generator's variantHeap, its values() sorted)
     {
         const int32_t* tab = mtab + (size_t)g * 2 * 8192;
+#ifdef PLAT_SB_TIMING
+        const long long tq0 = wall_clock64();
+#endif
         if (tid == 0) { R.dN = 0; R.dN2 = 0; }
         __syncthreads();
         for (int sl = tid; sl < 8192; sl += SB_THREADS) {                // every distinct record of the scan (the merge kernel's table)
@@ -358,13 +371,52 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
         __syncthreads();
         const int n1 = R.dN;
         if (n1 > SB_DICT_CAP || !b.cand_rec || !b.region_name_hash) { if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; hdr[5] = 2; } return; }
-        for (int i = tid; i < n1; i += SB_THREADS) {                     // ascending first-record id = the order they entered the dictionary
-            const int id = R.dHash[i];
-            int r = 0;
-            for (int j = 0; j < n1; ++j) r += R.dHash[j] < id;
-            R.dId[r] = id;
+        // ascending first-record id = the order they entered the dictionary.  The ids of a scan spread evenly over its reads' range: 1024
+        // buckets of equal width hold two or three each -- count, scan, scatter, then rank inside the bucket
+        {
+            int* bcnt = (int*)R.key;                                     // 1024 counters, 1024 starts (the pass-0 arrays are dead)
+            int* bstart = bcnt + 1024;
+            int lo = 0x7FFFFFFF, hi = 0;
+            for (int i = tid; i < n1; i += SB_THREADS) { lo = min(lo, R.dHash[i]); hi = max(hi, R.dHash[i]); }
+            for (int d = 32; d; d >>= 1) { lo = min(lo, __shfl_xor(lo, d, 64)); hi = max(hi, __shfl_xor(hi, d, 64)); }
+            if (lane == 0) { R.wsum[wv] = lo; }
+            bcnt[tid] = 0;
+            __syncthreads();
+            lo = R.wsum[0];
+            for (int k = 1; k < SB_THREADS / 64; ++k) lo = min(lo, R.wsum[k]);
+            __syncthreads();
+            if (lane == 0) R.wsum[wv] = hi;
+            __syncthreads();
+            hi = R.wsum[0];
+            for (int k = 1; k < SB_THREADS / 64; ++k) hi = max(hi, R.wsum[k]);
+            __syncthreads();
+            int sh = 0;
+            while (((hi - lo) >> sh) >= 1024) ++sh;
+            for (int i = tid; i < n1; i += SB_THREADS) atomicAdd(&bcnt[(R.dHash[i] - lo) >> sh], 1);
+            __syncthreads();
+            const int mine = bcnt[tid];
+            const int ex = sb_block_scan(mine, R.wsum, &R.tot);
+            bstart[tid] = ex;
+            bcnt[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n1; i += SB_THREADS) {                 // scatter into the bucket's stretch of dId (any order inside it)
+                const int id = R.dHash[i], bk = (id - lo) >> sh;
+                R.dId[bstart[bk] + atomicAdd(&bcnt[bk], 1)] = id;
+            }
+            __syncthreads();
+            for (int i = tid; i < n1; i += SB_THREADS) {                 // rank inside the bucket -> final place (through dHash: dId is being read)
+                const int id = R.dId[i], bk = (id - lo) >> sh, b0 = bstart[bk], b1 = b0 + bcnt[bk];
+                int r = 0;
+                for (int j = b0; j < b1; ++j) r += R.dId[j] < id;
+                R.dHash[b0 + r] = id;
+            }
+            __syncthreads();
+            for (int i = tid; i < n1; i += SB_THREADS) R.dId[i] = R.dHash[i];
         }
         __syncthreads();
+#ifdef PLAT_SB_TIMING
+        const long long tq1 = wall_clock64();
+#endif
         const unsigned long long nameHash = (unsigned long long)b.region_name_hash[g];
         for (int i = tid; i < n1; i += SB_THREADS) {
             const int32_t* me = b.cand_rec + 5ll * R.dId[i];
@@ -380,21 +432,33 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
         }
         __syncthreads();
         // (scratch of the replay: the candidate arrays of pass 0 are dead -- pass 1 loads them again)
+#ifdef PLAT_SB_TIMING
+        const long long tq2 = wall_clock64();
+#endif
         unsigned* owner = (unsigned*)R.key;                               // 8192 words = key, id, pos, nrem, nadd, supp, remc
         unsigned char* step = (unsigned char*)R.addo;                    // one byte per key (addo, bmin: 8 KB)
         sb_py2_dict_order(n1, R.dHash, owner, step, R.dOrd, R.dScr, R.wsum, &R.tot, &R.dN2);
+#ifdef PLAT_SB_TIMING
+        const long long tq3 = wall_clock64();
+#endif
         // the sample's dictionary walked in its order: the keys that pass enter the second dictionary in that order
-        if (tid == 0) {
-            int m = 0;
-            for (int r = 0; r < n1 && m < SB_CAP; ++r) if (R.dCand[R.dOrd[r]]) { R.dP2[m] = R.dOrd[r]; R.dId[m] = R.dHash[R.dOrd[r]]; ++m; }
-            R.dN = m;
+        {
+            const int per = (n1 + SB_THREADS - 1) / SB_THREADS, r0 = tid * per, r1 = min(n1, r0 + per);
+            int cnt = 0;
+            for (int r = r0; r < r1; ++r) cnt += R.dCand[R.dOrd[r]] != 0;
+            int at = sb_block_scan(cnt, R.wsum, &R.tot);
+            for (int r = r0; r < r1; ++r) if (R.dCand[R.dOrd[r]] && at < SB_CAP) { R.dP2[at] = R.dOrd[r]; R.dId[at] = R.dHash[R.dOrd[r]]; ++at; }
         }
         __syncthreads();
-        const int m2 = R.dN;
+        const int m2 = min(R.tot, SB_CAP);
         sb_py2_dict_order(m2, R.dId, owner, step, R.dO2, R.dS2, R.wsum, &R.tot, &R.dN2);
         // rank of every candidate in the second dictionary's order: candidate -> rank in dOrd (free now)
         for (int r = tid; r < m2; r += SB_THREADS) R.dOrd[R.dCand[R.dP2[R.dO2[r]]] - 1] = (unsigned short)r;
         __syncthreads();
+#ifdef PLAT_SB_TIMING
+        if (tid == 0) printf("[sb replay] region %d: %d distinct, %d candidates; gather+sort %lld us, hash+mark %lld us, dict1 %lld us, dict2+ranks %lld us\n", g, n1, m2,
+                             (tq1 - tq0) / 100, (tq2 - tq1) / 100, (tq3 - tq2) / 100, (wall_clock64() - tq3) / 100);
+#endif
         if (tid == 0) { R.dN2 = m2; R.status = 0; R.nIndel = 0; R.addedUsed = 0; }
         __syncthreads();
         if (R.dN2 != n) { if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; hdr[5] = 3; } return; }   // (every candidate is a distinct record: cannot happen)
