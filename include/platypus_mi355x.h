@@ -381,8 +381,8 @@ int plat_concat_read_tables(plat_ctx* ctx, int n_tables, int max_reads_per_table
 #define PLAT_SB_HOST 1
 #define PLAT_SBW_SKIP 1          /* no reads / too many reads / skipDifficultWindows: the loop does not call this window */
 #define PLAT_SBW_HOST 2          /* the caller prepares this window itself (greedy haplotype filter, filterVariantsByCoverage, an exception) */
-#define PLAT_SBW_DUPLICATE 4     /* in the batch, but two of its haplotypes have the same sequence (or agree on more bytes than the
-                                  * device looks at): mergeHaplotypes / the order is the caller's */
+#define PLAT_SBW_DUPLICATE 4     /* in the batch, but two of its haplotypes have the same sequence and an indel among their variants (or
+                                  * agree on more bytes than the device looks at): mergeHaplotypes / the order is the caller's */
 typedef struct plat_stage_b_options {
     int32_t minReads, maxSize, mergeClusteredVariants, maxVarDist, minVarDist, largeWindows, maxVariants, maxHaplotypes;
     int32_t filterVarsByCoverage, skipDifficultWindows;
@@ -417,7 +417,7 @@ typedef struct plat_stage_b_out {
     int64_t* b_hap_off; uint32_t* b_hap_mask; uint8_t* b_hap_seq;                                            /* [cap_batch_haps + 1], [cap_hap_bytes] */
     int64_t* b_read_off; int32_t* b_read_src; uint8_t* b_read_kind;                                           /* [cap_batch_reads (+1)] */
     int64_t* totals;                                                                                           /* [16] */
-    int32_t* scratch;                                                                                          /* [24 * n_regions * cap_windows + 48 * n_regions + 64] */
+    int32_t* scratch;                                                                                          /* [56 * n_regions * cap_windows + 48 * n_regions + 64] */
 } plat_stage_b_out;
 int plat_stage_b_batch(plat_ctx* ctx, const plat_stage_b_in* batch, const plat_stage_b_options* options,
                        const plat_stage_b_out* out, void* stream);

@@ -47,7 +47,7 @@ inline void Chunk::launchStageB() {
     z.d_ngood.reserve(z.ctx, capBW + 2, false); z.d_pairoff.reserve(z.ctx, capBW + 2, false); z.d_gloff.reserve(z.ctx, capBW + 2, false);
     z.d_hapoff.reserve(z.ctx, capBH + 2, false); z.d_hapseq.reserve(z.ctx, capHB + PLAT_BLOB_PAD, false, true, z.stream);
     z.d_readoff.reserve(z.ctx, capBR + 2, false); z.d_src.reserve(z.ctx, capBR + 2, false); z.d_kind.reserve(z.ctx, capBR + 2, false);
-    z.d_scratch.reserve(z.ctx, 24 * capBW + 48 * nR + 64, false);
+    z.d_scratch.reserve(z.ctx, 56 * capBW + 48 * nR + 64, false);
     plat_stage_b_in in;
     memset(&in, 0, sizeof in);
     in.n_regions = (int32_t)nR; in.cap_per_scan = mergeCap; in.cand = z.m_cand.d; in.cand_n = z.m_n.d;

@@ -12,7 +12,7 @@
 //   chaplotype.pyx:127-191,397-449       Haplotype.__init__, getMutatedSequence
 //   variantcaller.pyx:325-383            mergeHaplotypes: sorted(haplotypes) (equal sequences are left to the caller)
 //
-// Five small kernels, no host round trip between them (windows keep the order (region, window) in the batch):
+// Seven small kernels, no host round trip between them (windows keep the order (region, window) in the batch):
 //   k_sb_variants  one workgroup per region: the region's candidates in LDS; rank sort by the reference's key; one WAVE per indel
 //                  walks the reference for its leftmost / rightmost placement (64 positions per step, ballot); second sort; runs of
 //                  equal variants merged (supports summed); the filter; then one lane bunches the survivors into windows (the
@@ -20,12 +20,16 @@
 //   k_sb_windows   one workgroup per region, one thread per window: window pointers by binary search in the read table, the decision
 //                  (call / skip / the caller's greedy filter), the valid combinations counted and their lengths summed; then the
 //                  prefix sums of the region's windows
+//   k_sb_haps_rank one workgroup per window: the bytes behind the haplotypes' common prefix staged in LDS (every lane finds the segment its
+//                  byte comes from), lexicographic ranks by wave-wide comparisons, haplotypes with one sequence merged by prior product
+//   k_sb_prefix    one workgroup per region: prefix sums of its windows' counts
 //   k_sb_scan      one wave: exclusive scan over the REGIONS -> where each region's windows, haplotypes, reads, pairs and bytes go
-//   k_sb_haps      one workgroup per window: haplotype bytes (every lane finds the segment its byte comes from), lexicographic ranks by
-//                  wave-wide comparisons from the first variant on, bytes copied in rank order
+//   k_sb_haps_write  one workgroup per window: every haplotype's bytes written once, in rank order
 //   k_sb_reads     one wave per window: read indices, kinds and offsets of the window's reads
 // Anything the reference would raise on, anything whose order depends on a Python dictionary and anything beyond the capacities is
 // flagged for the caller (region or window) instead of being guessed.
+#include <math.h>
+
 #include "plat_internal.hpp"
 
 namespace plat {
@@ -38,6 +42,7 @@ constexpr int SB_MAXCOMB = 5;                     // a window with more variants
 struct SbIn {
     plat_stage_b_in b;
     plat_stage_b_options o;
+    double pow01[16];                              // pow(0.1, k) of the HOST's libm (variant.pyx:243: the prior of a multi-nucleotide variant)
 };
 
 __device__ __forceinline__ int sb_type(int nrem, int nadd) {          // variant.pyx:49-53,127-140: SNP 0, MNP 1, INS 2, DEL 3, REP 4
@@ -604,6 +609,10 @@ __device__ __forceinline__ long long* sb_prefix(const plat_stage_b_in& b, const 
 __device__ __forceinline__ long long* sb_region(const plat_stage_b_in& b, const plat_stage_b_out& out, int g) {
     return (long long*)(out.scratch + 24ll * b.n_regions * b.cap_windows) + 24 * g;
 }
+// ... and per window slot 32 words behind the regions' block: the masks of its haplotypes in their final (sorted) order
+__device__ __forceinline__ uint32_t* sb_masks(const plat_stage_b_in& b, const plat_stage_b_out& out, long long t) {
+    return (uint32_t*)(out.scratch + 24ll * b.n_regions * b.cap_windows + 48ll * b.n_regions) + 32 * t;
+}
 
 // one window: window pointers, the decision, the valid combinations counted
 static __device__ void sb_one_window(const plat_stage_b_in& b, const plat_stage_b_options& o, const plat_stage_b_out& out, int g, int k, int32_t* sc)
@@ -706,9 +715,20 @@ __device__ __forceinline__ long long sb_block_scan64(long long v, long long* wsu
     return base + x - v;
 }
 
-// one workgroup per region: its windows (one per thread, 256 at a time), then their prefix sums inside the region
+// one workgroup per region: its windows, one per thread
 __global__ void __launch_bounds__(256)
 k_sb_windows(SbIn in, plat_stage_b_out out)
+{
+    const plat_stage_b_in& b = in.b;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int32_t* hdr = out.hdr + 8 * g;
+    const int nW = hdr[0] != 0 ? 0 : hdr[2];
+    for (int k = tid; k < nW; k += 256) sb_one_window(b, in.o, out, g, k, sb_slot(out, (long long)g * b.cap_windows + k));
+}
+
+// one workgroup per region, behind k_sb_haps_rank (which knows how many haplotypes a window keeps): prefix sums of the region's windows
+__global__ void __launch_bounds__(256)
+k_sb_prefix(SbIn in, plat_stage_b_out out)
 {
     const plat_stage_b_in& b = in.b;
     __shared__ long long wsum[4], tot, carry[7];
@@ -724,8 +744,7 @@ k_sb_windows(SbIn in, plat_stage_b_out out)
         const long long t = (long long)g * b.cap_windows + k;
         long long v[7] = {0, 0, 0, 0, 0, 0, 0};
         if (k < nW) {
-            int32_t* sc = sb_slot(out, t);
-            sb_one_window(b, in.o, out, g, k, sc);
+            const int32_t* sc = sb_slot(out, t);
             if (sc[0] == 0) {
                 v[0] = 1; v[1] = sc[1]; v[2] = sc[2]; v[3] = (long long)sc[1] * sc[2]; v[4] = sc[3]; v[5] = sc[4]; v[6] = (long long)sc[1] * (sc[1] + 1) / 2;
                 atomicMax(&mx[0], sc[5]); atomicMax(&mx[1], sc[2]); atomicMax(&mx[2], sc[1]);
@@ -785,53 +804,45 @@ k_sb_scan(SbIn in, plat_stage_b_out out)
     }
 }
 
-// ---- haplotype bytes, sorted ------------------------------------------------------------------------------------------------------
+// ---- haplotypes of a window: sorted, equal ones merged (k_sb_haps_rank), then their bytes (k_sb_haps_write) ----------------------------
 // One workgroup (four waves) per window, haplotype h handled by wave h % 4.  Every haplotype of a window is the reference up to the
 // window's first variant: the SB_STAGE bytes behind that point are staged in LDS and sorted(haplotypes) is decided there (two strings that
-// agree on all of them and go on are left to the caller: a tandem repeat longer than the stage); then each haplotype's bytes are written
-// once, straight to their place in rank order.
+// agree on all of them and go on are left to the caller: a tandem repeat longer than the stage).  mergeHaplotypes (variantcaller.pyx:
+// 325-383): of haplotypes with one sequence the one with the largest product of its variants' priors stays (the first of them on a tie)
+// -- decided here when all their variants are SNPs / multi-nucleotide variants (variant.pyx:219-259: 1e-3 / 3; 5e-5 x 0.1^(nDiffs-1) x 0.9
+// with the host's pow), left to the caller when an indel is among them (its prior needs the repeat annotation).
 constexpr int SB_STAGE = 384;
 __global__ void __launch_bounds__(256)
-k_sb_haps(SbIn in, plat_stage_b_out out)
+k_sb_haps_rank(SbIn in, plat_stage_b_out out)
 {
     const plat_stage_b_in& b = in.b;
     __shared__ unsigned s_mask[32];
-    __shared__ int s_len[32], s_rank[32], s_off[32], s_dup;
-    __shared__ int s_seg[4][24][3];                                    // segments of the haplotype a wave is writing: kind, source, length
-    __shared__ int32_t s_vpos[8], s_vnrem[8], s_vnadd[8], s_vadd[8];
+    __shared__ int s_len[32], s_rank[32], s_dup, s_eq[32], s_drop[32];
+    __shared__ double s_prior[32];
+    __shared__ int s_seg[4][24][3];                                    // segments of the haplotype a wave is staging: kind, source, length
+    __shared__ int32_t s_vpos[8], s_vnrem[8], s_vnadd[8], s_vadd[8], s_vrem[8];
     __shared__ __align__(16) uint8_t s_stage[32][SB_STAGE];
-    if (out.totals[10]) return;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
     const int g = blockIdx.y;
     const int nWin = out.hdr[8 * g] != 0 ? 0 : out.hdr[8 * g + 2];
-    const long long* rg = sb_region(b, out, g);
     const uint8_t* added = out.added + (long long)g * b.cap_added;
     const uint8_t* ref = b.ref_seq + b.ref_off[g];
     const int contigLen = b.contig_len[g], rlen = b.region_rlen[g], rss = b.ref_seq_start[g];
     for (int kw = blockIdx.x; kw < nWin; kw += gridDim.x) {
         __syncthreads();
         const long long t = (long long)g * b.cap_windows + kw;
-        const int32_t* sc = sb_slot(out, t);
+        int32_t* sc = sb_slot(out, t);
         if (sc[0] != 0) continue;
-        const long long* pf = sb_prefix(b, out, t);
         const long long w = t;
-        const int bw = (int)(rg[10] + pf[0]), nv = out.win_var_n[w], nH = sc[1], hb = (int)(rg[11] + pf[1]);
-        const long long byte0 = rg[14] + pf[4];
+        const int nv = out.win_var_n[w], nH = sc[1];
         const int ws = out.win_start[w], we = out.win_end[w];
-        if (tid == 0) {                                                // the window's entries in the batch arrays
-            const int rb = (int)(rg[12] + pf[2]);
-            out.win_batch[w] = bw;
-            out.b_hap_begin[bw] = hb; out.b_read_begin[bw] = rb; out.b_pair_off[bw] = rg[13] + pf[3]; out.b_seg_begin[bw] = rb; out.b_gl_off[bw] = rg[16] + pf[6];
-            out.b_n_good[bw] = out.win_ptrs[6 * w + 1] - out.win_ptrs[6 * w];
-            out.b_start[bw] = ws > 0 ? ws : 0; out.b_end[bw] = we < contigLen - 1 ? we : contigLen - 1; out.b_flank[bw] = 2 * rlen < 500 ? 2 * rlen : 500;
-        }
         const long long v0 = (long long)g * b.cap_vars + out.win_var_first[w];
         if (tid < 8) {                                                 // the window's variants in LDS: the walks read them dozens of times
-            const bool in = tid < nv;
-            s_vpos[tid] = in ? out.var_pos[v0 + tid] : 0; s_vnrem[tid] = in ? out.var_nrem[v0 + tid] : 0; s_vnadd[tid] = in ? out.var_nadd[v0 + tid] : 0;
-            s_vadd[tid] = in ? out.var_add_off[v0 + tid] : 0;
+            const bool in_ = tid < nv;
+            s_vpos[tid] = in_ ? out.var_pos[v0 + tid] : 0; s_vnrem[tid] = in_ ? out.var_nrem[v0 + tid] : 0; s_vnadd[tid] = in_ ? out.var_nadd[v0 + tid] : 0;
+            s_vadd[tid] = in_ ? out.var_add_off[v0 + tid] : 0; s_vrem[tid] = in_ ? out.var_rem_pos[v0 + tid] : 0;
         }
-        if (tid < 32) s_rank[tid] = 0;
+        if (tid < 32) { s_rank[tid] = 0; s_eq[tid] = -1; s_drop[tid] = 0; }
         __syncthreads();
         const int32_t* vpos = s_vpos;
         const int32_t* vnrem = s_vnrem;
@@ -853,32 +864,26 @@ k_sb_haps(SbIn in, plat_stage_b_out out)
         __syncthreads();
         int common = 0;
         if (nv > 0) { const int lo = W.hapStart - W.endBuf > 0 ? W.hapStart - W.endBuf : 0; common = max(0, min(vpos[0], W.hapEnd) - lo); }
-        // byte p of the haplotype whose segments are in s_seg[wv]
-        auto byteAt = [&](int p, int nseg) -> uint8_t {
-            int q = p, k = 0;
-            while (k < nseg - 1 && q >= s_seg[wv][k][2]) { q -= s_seg[wv][k][2]; ++k; }
-            const int kind = s_seg[wv][k][0], src = s_seg[wv][k][1];
-            return kind == 0 ? ref[src + q - rss] : (kind == 1 ? added[vadd[src] + q] : (uint8_t)src);
-        };
-        auto segments = [&](unsigned m) -> int {
+        for (int h = wv; h < nH; h += 4) {                             // the bytes behind the common prefix into the stage
             int nseg = 0;
             if (lane == 0) {
                 auto put = [&](int kind, int src, int len) { if (nseg < 24) { s_seg[wv][nseg][0] = kind; s_seg[wv][nseg][1] = src; s_seg[wv][nseg][2] = len; } ++nseg; };
-                sb_walk_hap(W, m, nv, vpos, vnrem, vnadd, put);
+                sb_walk_hap(W, s_mask[h], nv, vpos, vnrem, vnadd, put);
             }
             nseg = __shfl(nseg, 0, 64);
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
-            return nseg;
-        };
-        for (int h = wv; h < nH; h += 4) {                             // the bytes behind the common prefix into the stage
-            const int nseg = segments(s_mask[h]);
             const int L = s_len[h], n = min(SB_STAGE, L - common);
-            for (int p = lane; p < n; p += 64) s_stage[h][p] = byteAt(common + p, nseg);
+            for (int p = lane; p < n; p += 64) {
+                int q = common + p, k = 0;
+                while (k < nseg - 1 && q >= s_seg[wv][k][2]) { q -= s_seg[wv][k][2]; ++k; }
+                const int kind = s_seg[wv][k][0], src = s_seg[wv][k][1];
+                s_stage[h][p] = kind == 0 ? ref[src + q - rss] : (kind == 1 ? added[vadd[src] + q] : (uint8_t)src);
+            }
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
-        // ranks: sorted(haplotypes) compares the byte strings; equal strings keep their order (and are flagged: mergeHaplotypes is the caller's)
+        // ranks: sorted(haplotypes) compares the byte strings; equal strings keep their order
         int pairNo = 0;
         for (int i = 0; i < nH; ++i)
             for (int j = i + 1; j < nH; ++j, ++pairNo) {
@@ -896,32 +901,151 @@ k_sb_haps(SbIn in, plat_stage_b_out out)
                     if (Lm == SB_STAGE && (Li > SB_STAGE || Lj > SB_STAGE)) undecided = true;   // they agree on the whole stage and go on
                     else cmp = Li < Lj ? -1 : (Li > Lj ? 1 : 0);
                 }
-                if (lane == 0) { if (cmp == 0 || undecided) s_dup = 1; atomicAdd(&s_rank[cmp <= 0 ? j : i], 1); }
+                if (lane == 0) {
+                    if (undecided) s_dup = 1;
+                    else if (cmp == 0) atomicMax(&s_eq[j], i);          // j has the sequence of an earlier haplotype: mergeHaplotypes
+                    atomicAdd(&s_rank[cmp <= 0 ? j : i], 1);
+                }
             }
         __syncthreads();
-        // final place of every haplotype: behind those of smaller rank
-        int myOff = 0;
+        // mergeHaplotypes over the runs of equal sequences (in sorted order = insertion order inside a run): the largest prior product stays
+        if (tid == 0 && !s_dup) {
+            bool any = false;
+            for (int h = 0; h < nH; ++h) any = any || s_eq[h] >= 0;
+            if (any) {
+                for (int h = 0; h < nH && !s_dup; ++h) {               // prior product of every haplotype that has a twin
+                    bool twin = s_eq[h] >= 0;
+                    for (int k = 0; k < nH && !twin; ++k) twin = s_eq[k] == h;
+                    if (!twin) continue;
+                    double pr = 1.0;
+                    for (int i = 0; i < nv; ++i) {
+                        if (!(s_mask[h] >> i & 1u)) continue;
+                        const int na = vnadd[i], nr = vnrem[i];
+                        double p1;
+                        if (na == 1 && nr == 1) p1 = 1e-3 / 3;
+                        else if (na == nr) {
+                            int nd = 0;
+                            for (int q = 0; q < na; ++q) nd += added[vadd[i] + q] != ref[s_vrem[i] + q - rss];
+                            if (nd < 1 || nd > 16) { s_dup = 1; break; }
+                            p1 = 5e-5 * in.pow01[nd - 1] * (1.0 - 0.1);
+                        } else { s_dup = 1; break; }                     // an indel: its prior needs the repeat annotation -- the caller's
+                        pr *= p1 < 1e-10 ? 1e-10 : p1;
+                    }
+                    s_prior[h] = pr;
+                }
+                if (!s_dup) {
+                    // runs: haplotypes with one sequence share the smallest index among them (s_eq chains point to earlier twins)
+                    for (int h = 0; h < nH; ++h) {
+                        int root = h;
+                        while (s_eq[root] >= 0) root = s_eq[root];
+                        if (root != h) continue;
+                        int best = h;                                    // `last` of the reference's loop: replaced only by a LARGER product
+                        for (int k = h + 1; k < nH; ++k) {
+                            int rk = k;
+                            while (s_eq[rk] >= 0) rk = s_eq[rk];
+                            if (rk != h) continue;
+                            // (sorted order inside a run = index order: equal strings keep their order)
+                            if (s_prior[k] > s_prior[best]) { s_drop[best] = 1; best = k; } else s_drop[k] = 1;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (s_dup) { if (tid == 0) out.win_flags[w] = PLAT_SBW_DUPLICATE; }   // (stays in the batch with every haplotype; the caller prepares it itself)
+        // final order: rank among the haplotypes that stay
         if (tid < nH) {
-            for (int k = 0; k < nH; ++k) if (s_rank[k] < s_rank[tid]) myOff += s_len[k];
-            const int r = s_rank[tid];
-            out.b_hap_off[hb + r] = byte0 + myOff;
-            out.b_hap_mask[hb + r] = s_mask[tid];
-            s_off[tid] = myOff;
+            int r = 0;
+            for (int k = 0; k < nH; ++k) if (!s_drop[k] && (s_rank[k] < s_rank[tid] || (s_rank[k] == s_rank[tid] && k < tid))) ++r;
+            if (!s_drop[tid]) sb_masks(b, out, t)[r] = s_mask[tid];
+        }
+        if (tid == 0) {
+            int keep = 0, bytes = 0, mxl = 0;
+            for (int k = 0; k < nH; ++k) if (!s_drop[k]) { ++keep; bytes += s_len[k]; mxl = max(mxl, s_len[k]); }
+            if (keep <= 1) { sc[0] = PLAT_SBW_SKIP; out.win_flags[w] = PLAT_SBW_SKIP; out.win_n_haps[w] = 0; }   // one haplotype left: the loop does not call the window
+            else { sc[1] = keep; sc[3] = bytes; sc[5] = mxl; out.win_n_haps[w] = keep; }
+        }
+    }
+}
+
+// the bytes of every haplotype, once, straight to their place: one workgroup per window, wave per haplotype
+__global__ void __launch_bounds__(256)
+k_sb_haps_write(SbIn in, plat_stage_b_out out)
+{
+    const plat_stage_b_in& b = in.b;
+    __shared__ int s_len[32], s_off[32];
+    __shared__ int s_seg[4][24][3];
+    __shared__ int32_t s_vpos[8], s_vnrem[8], s_vnadd[8], s_vadd[8];
+    if (out.totals[10]) return;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int g = blockIdx.y;
+    const int nWin = out.hdr[8 * g] != 0 ? 0 : out.hdr[8 * g + 2];
+    const long long* rg = sb_region(b, out, g);
+    const uint8_t* added = out.added + (long long)g * b.cap_added;
+    const uint8_t* ref = b.ref_seq + b.ref_off[g];
+    const int contigLen = b.contig_len[g], rlen = b.region_rlen[g], rss = b.ref_seq_start[g];
+    for (int kw = blockIdx.x; kw < nWin; kw += gridDim.x) {
+        __syncthreads();
+        const long long t = (long long)g * b.cap_windows + kw;
+        const int32_t* sc = sb_slot(out, t);
+        if (sc[0] != 0) continue;
+        const long long* pf = sb_prefix(b, out, t);
+        const long long w = t;
+        const int bw = (int)(rg[10] + pf[0]), nv = out.win_var_n[w], nH = sc[1], hb = (int)(rg[11] + pf[1]);
+        const long long byte0 = rg[14] + pf[4];
+        const int ws = out.win_start[w], we = out.win_end[w];
+        const uint32_t* masks = sb_masks(b, out, t);
+        if (tid == 0) {                                                // the window's entries in the batch arrays
+            const int rb = (int)(rg[12] + pf[2]);
+            out.win_batch[w] = bw;
+            out.b_hap_begin[bw] = hb; out.b_read_begin[bw] = rb; out.b_pair_off[bw] = rg[13] + pf[3]; out.b_seg_begin[bw] = rb; out.b_gl_off[bw] = rg[16] + pf[6];
+            out.b_n_good[bw] = out.win_ptrs[6 * w + 1] - out.win_ptrs[6 * w];
+            out.b_start[bw] = ws > 0 ? ws : 0; out.b_end[bw] = we < contigLen - 1 ? we : contigLen - 1; out.b_flank[bw] = 2 * rlen < 500 ? 2 * rlen : 500;
+        }
+        const long long v0 = (long long)g * b.cap_vars + out.win_var_first[w];
+        if (tid < 8) {
+            const bool in_ = tid < nv;
+            s_vpos[tid] = in_ ? out.var_pos[v0 + tid] : 0; s_vnrem[tid] = in_ ? out.var_nrem[v0 + tid] : 0; s_vnadd[tid] = in_ ? out.var_nadd[v0 + tid] : 0;
+            s_vadd[tid] = in_ ? out.var_add_off[v0 + tid] : 0;
+        }
+        __syncthreads();
+        SbWin W;
+        W.hapStart = ws > 0 ? ws : 0; W.hapEnd = we < contigLen - 1 ? we : contigLen - 1; W.endBuf = 2 * rlen < 500 ? 2 * rlen : 500; W.contigLen = contigLen;
+        if (tid < nH) { auto none = [](int, int, int) {}; s_len[tid] = sb_walk_hap(W, masks[tid], nv, s_vpos, s_vnrem, s_vnadd, none); }
+        __syncthreads();
+        if (tid < nH) {
+            int off = 0;
+            for (int k = 0; k < tid; ++k) off += s_len[k];
+            s_off[tid] = off;
+            out.b_hap_off[hb + tid] = byte0 + off;
+            out.b_hap_mask[hb + tid] = masks[tid];
         }
         __syncthreads();
         uint8_t* dst = out.b_hap_seq + byte0;
-        for (int h = wv; h < nH; h += 4) {                             // the bytes, once, to their place
-            const int nseg = segments(s_mask[h]);
+        for (int h = wv; h < nH; h += 4) {
+            int nseg = 0;
+            if (lane == 0) {
+                auto put = [&](int kind, int src, int len) { if (nseg < 24) { s_seg[wv][nseg][0] = kind; s_seg[wv][nseg][1] = src; s_seg[wv][nseg][2] = len; } ++nseg; };
+                sb_walk_hap(W, masks[h], nv, s_vpos, s_vnrem, s_vnadd, put);
+            }
+            nseg = __shfl(nseg, 0, 64);
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            auto byteAt = [&](int p) -> uint8_t {
+                int q = p, k = 0;
+                while (k < nseg - 1 && q >= s_seg[wv][k][2]) { q -= s_seg[wv][k][2]; ++k; }
+                const int kind = s_seg[wv][k][0], src = s_seg[wv][k][1];
+                return kind == 0 ? ref[src + q - rss] : (kind == 1 ? added[s_vadd[src] + q] : (uint8_t)src);
+            };
             const int L = s_len[h], to = s_off[h];
             int p = lane;
             for (; p + 192 < L; p += 256) {                            // (four loads in flight per lane)
-                const uint8_t c0 = byteAt(p, nseg), c1 = byteAt(p + 64, nseg), c2 = byteAt(p + 128, nseg), c3 = byteAt(p + 192, nseg);
+                const uint8_t c0 = byteAt(p), c1 = byteAt(p + 64), c2 = byteAt(p + 128), c3 = byteAt(p + 192);
                 dst[to + p] = c0; dst[to + p + 64] = c1; dst[to + p + 128] = c2; dst[to + p + 192] = c3;
             }
-            for (; p < L; p += 64) dst[to + p] = byteAt(p, nseg);
+            for (; p < L; p += 64) dst[to + p] = byteAt(p);
             __builtin_amdgcn_wave_barrier();
         }
-        if (tid == 0 && s_dup) out.win_flags[w] = PLAT_SBW_DUPLICATE;
     }
 }
 
@@ -983,6 +1107,7 @@ PLAT_EXPORT int plat_stage_b_batch(plat_ctx* ctx, const plat_stage_b_in* batch, 
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
     plat::SbIn in;
     in.b = b; in.o = *options;
+    for (int k = 0; k < 16; ++k) in.pow01[k] = pow(0.1, (double)k);    // (host libm: what Variant.calculatePrior multiplies with)
     hipStream_t st = (hipStream_t)stream;
     static bool once = false;
     if (!once) {
@@ -992,8 +1117,10 @@ PLAT_EXPORT int plat_stage_b_batch(plat_ctx* ctx, const plat_stage_b_in* batch, 
     hipLaunchKernelGGL(plat::k_sb_variants, dim3((unsigned)b.n_regions), dim3(plat::SB_THREADS), sizeof(plat::SbRegion), st, in, o,
                        (const int32_t*)ctx->merge_tab.ptr);
     hipLaunchKernelGGL(plat::k_sb_windows, dim3((unsigned)b.n_regions), dim3(256), 0, st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_haps_rank, dim3(48, (unsigned)b.n_regions), dim3(256), 0, st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_prefix, dim3((unsigned)b.n_regions), dim3(256), 0, st, in, o);
     hipLaunchKernelGGL(plat::k_sb_scan, dim3(1), dim3(64), 0, st, in, o);
-    hipLaunchKernelGGL(plat::k_sb_haps, dim3(48, (unsigned)b.n_regions), dim3(256), 0, st, in, o);
+    hipLaunchKernelGGL(plat::k_sb_haps_write, dim3(48, (unsigned)b.n_regions), dim3(256), 0, st, in, o);
     hipLaunchKernelGGL(plat::k_sb_reads, dim3(12, (unsigned)b.n_regions), dim3(256), 0, st, in, o);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
