@@ -254,6 +254,8 @@ cdef extern from "platypus_mi355x.h":
     int plat_unpack_reads_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual,
                                  int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream) nogil
 
+    int plat_copy_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* dst_blob, void* stream) nogil
+
     # ---- a chunk's read table from tables resident on the device
     ctypedef struct plat_table_desc:
         const int64_t* off

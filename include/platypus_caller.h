@@ -95,6 +95,10 @@ typedef struct plat_region {
     const uint8_t* contig_seq;
     int64_t contig_len;
     const plat_sample_reads* samples;   /* [n_samples] */
+    /* Optional: a DEVICE copy of contig_seq (a reference that is resident in HBM).  When every region of a chunk has one, the chunk's
+     * reference windows are put together on the device (plat_copy_pieces) and no reference byte crosses the link; contig_seq must still
+     * be valid host memory. */
+    const uint8_t* dev_contig_seq;
 } plat_region;
 
 /* The callVariants options the region loop reads (names and defaults of runner.py:519-597). */

@@ -329,6 +329,10 @@ typedef struct plat_unpack_piece { const uint8_t* src; int64_t dst, n; } plat_un
 int plat_unpack_reads_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual,
                              int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream);
 
+/* n pieces of device memory copied into one blob in ONE launch: piece k = n bytes at src -> dst_blob[dst, dst + n) (any alignment).
+ * `pieces` is device memory (the struct of plat_unpack_reads_pieces).                                                              */
+int plat_copy_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* dst_blob, void* stream);
+
 /* ---- a chunk's read table from read tables that are resident on the device --------------------------------------------------------
  * Replaces  the loader's copy of a bamReadBuffer's reads into the arrays the kernels above take (no reference counterpart: the
  *           reference walks cAlignedRead pointers, cwindow.pyx:485-595).
@@ -361,7 +365,8 @@ int plat_concat_read_tables(plat_ctx* ctx, int n_tables, int max_reads_per_table
  * tab_begin[3g+2] + i, indexed from broken_base).
  * Output, per region g (all device memory of the caller):
  *   hdr[8g..]   {status, n_variants, n_windows, candidate records, bytes used of the added-bases blob, why (status != 0: 1 capacity /
- *               an exception, 2 dictionary too large to replay, 4 windows, 5 the merge's own verdict), dictionaries replayed, 0}; status 0, or
+ *               an exception, 2 dictionary too large to replay, 4 windows, 5 the merge's own verdict, 6 cap_vars / cap_windows / cap_added too
+ *               small for this region), dictionaries replayed, 0}; status 0, or
  *               PLAT_SB_HOST: this region needs the caller's own code (more candidates / variants / windows than the capacities, an
  *               indel at the edge of its reference window, an order that depends on a Python dictionary, an exception the reference
  *               would raise, ...) -- nothing else of the region is valid then.

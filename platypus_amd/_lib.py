@@ -135,6 +135,7 @@ SIGNATURES = {
     "plat_stage_b_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_unpack_reads_pieces": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
+    "plat_copy_pieces": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_concat_read_tables": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_int64] * 3 + [C.c_void_p]),
     "plat_read_qc_batch": (C.c_int, [C.c_void_p, C.POINTER(ReadQCBatch), C.POINTER(ReadQCOptions), C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_variant_read_stats_batch": (C.c_int, [C.c_void_p, C.POINTER(InfoStatsBatch), C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -118,7 +118,8 @@ struct Slot {
     Staged<int32_t> t_pos, t_end, t_flags, t_cigoff, t_region;
     Staged<int16_t> t_cigar;
     // candidate scan
-    Staged<uint8_t> c_ref;
+    Staged<uint8_t> c_ref, c_refdev;
+    Staged<plat_unpack_piece> c_pieces;
     Staged<int64_t> c_refoff;
     Staged<int32_t> c_rss, c_clen, c_rec, c_cnt, c_status, c_scanbegin, c_scanlongest, m_cand, m_n;
     // window batch
@@ -147,6 +148,8 @@ struct Slot {
     Staged<uint8_t> d_hapseq, d_kind;
     // many small arrays travel as ONE copy: they are views into these blocks (Layout)
     Arena a_tab, a_desc, a_cin, a_cout, a_mout, a_win, a_wout, a_pin, a_sin, a_sout, a_asin, a_asout, a_bin, a_bout;
+    // per-region capacities of plat_stage_b_batch's outputs (they are downloaded whole): doubled when a region does not fit
+    int sbCapV = 320, sbCapW = 192, sbCapA = 2048;
     double t_host = 0, t_wait = 0;
 
     void sync(const char* where) {

@@ -24,13 +24,23 @@ struct Chunk {
     void scanCandidates();
     bool hostTally = false;
     int mergeCap = 2048;
-    std::string refBlob;
+    std::string refBlob;                                                   // the chunk's reference windows on the host (hostRefBlob())
+    const uint8_t* refDev = nullptr;                                        // ... and on the device
+    const std::string& hostRefBlob() {
+        if (refBlob.empty())
+            for (RegionWork* r : regions)
+                for (size_t i = 0; i < r->samples.size(); ++i) {
+                    const int64_t a = std::max<int64_t>(0, (int64_t)r->in->start - 2000), e = std::min<int64_t>((int64_t)r->in->end + 2000, r->fa.len - 1);
+                    refBlob.append((const char*)r->fa.seq + a, (size_t)(e - a));
+                }
+        return refBlob;
+    }
     Layout lmLayout;
 
     // -- B on the device (plat_stage_b_batch): regions with one sample, candidates from the reads alone, no reference-call blocks
     bool deviceB = false;
     DeviceBatch devBatch;
-    int capV = 768, capW = 512, capA = 4096;
+    int capV = 0, capW = 0, capA = 0;                                       // (of this chunk: the worker's current ones, Slot::sbCap*)
     Layout sbOut;
     bool eligibleDeviceB() const;
     void launchStageB();

@@ -140,32 +140,54 @@ inline void Chunk::scanCandidates() {
     Slot& z = s;
     std::vector<int64_t> refoff{0};
     std::vector<int32_t> rss, clen, scanbegin, scanlongest;
-    std::string blob;
+    // every region with its contig on the device already: the reference windows are put together there (plat_copy_pieces)
+    bool refResident = !regions.empty();
+    for (RegionWork* r : regions) refResident = refResident && r->in->dev_contig_seq != nullptr;
+    std::vector<plat_unpack_piece> pieces;
+    size_t blobLen = 0, mostRef = 0;
     for (RegionWork* r : regions)
         for (size_t i = 0; i < r->samples.size(); ++i) {
             scanbegin.push_back((int32_t)r->samples[i].reads.base); scanlongest.push_back(r->samples[i].reads.longest);
             const int64_t a = std::max<int64_t>(0, (int64_t)r->in->start - 2000);                   // variant.pyx:486-488
             const int64_t e = std::min<int64_t>((int64_t)r->in->end + 2000, r->fa.len - 1);
-            blob += r->fa.getSequence(a, e);
-            refoff.push_back((int64_t)blob.size());
+            if (e < a) throw WindowError("Cannot have beginPos > endPos in getSequence");
+            if (refResident) pieces.push_back(plat_unpack_piece{r->in->dev_contig_seq + a, (int64_t)blobLen, e - a});
+            blobLen += (size_t)(e - a); mostRef = std::max(mostRef, (size_t)(e - a));
+            refoff.push_back((int64_t)blobLen);
             rss.push_back((int32_t)a); clen.push_back((int32_t)r->fa.len);
         }
     {
         Layout L;
         scanbegin.push_back((int32_t)nGood);
-        L.add(z.c_ref, blob.size() + PLAT_BLOB_PAD); L.add(z.c_refoff, refoff.size()); L.add(z.c_rss, rss.size()); L.add(z.c_clen, clen.size());
+        L.add(z.c_refoff, refoff.size()); L.add(z.c_rss, rss.size()); L.add(z.c_clen, clen.size());
         L.add(z.c_scanbegin, scanbegin.size()); L.add(z.c_scanlongest, scanlongest.size());
+        if (refResident) L.add(z.c_pieces, pieces.size() + 1); else L.add(z.c_ref, blobLen + PLAT_BLOB_PAD);
         L.commit(z, z.a_cin);
-        memcpy(z.c_ref.h, blob.data(), blob.size()); memset(z.c_ref.h + blob.size(), 0, PLAT_BLOB_PAD);
         fill(z, z.c_refoff, refoff); fill(z, z.c_rss, rss); fill(z, z.c_clen, clen); fill(z, z.c_scanbegin, scanbegin); fill(z, z.c_scanlongest, scanlongest);
+        if (refResident) {
+            for (size_t q = 0; q < pieces.size(); ++q) z.c_pieces.h[q] = pieces[q];
+            z.c_refdev.reserve(z.ctx, blobLen + PLAT_BLOB_PAD, false, true, z.stream);
+            refDev = z.c_refdev.d;
+        } else {
+            size_t at = 0;
+            for (RegionWork* r : regions)
+                for (size_t i = 0; i < r->samples.size(); ++i) {
+                    const int64_t a = std::max<int64_t>(0, (int64_t)r->in->start - 2000), e = std::min<int64_t>((int64_t)r->in->end + 2000, r->fa.len - 1);
+                    memcpy(z.c_ref.h + at, r->fa.seq + a, (size_t)(e - a));
+                    at += (size_t)(e - a);
+                }
+            memset(z.c_ref.h + blobLen, 0, PLAT_BLOB_PAD);
+            refDev = z.c_ref.d;
+        }
         L.upload(z, z.a_cin);
+        if (refResident) ck(plat_copy_pieces(z.ctx, (int)pieces.size(), (int64_t)mostRef, z.c_pieces.d, z.c_refdev.d, z.stream), "plat_copy_pieces");
     }
-    refBlob.swap(blob);
+    refBlob.clear();                                                    // (the host's copy of the windows is made when a host stage asks for it: hostRefBlob)
     if (nGood == 0) { hostTally = true; deviceB = false; return; }      // nothing to scan: the (empty) host tally
     plat_candidate_batch cb;
     memset(&cb, 0, sizeof cb);
     cb.n_regions = nScan; cb.n_reads = (int32_t)nGood;
-    cb.ref_seq = z.c_ref.d; cb.ref_off = z.c_refoff.d; cb.ref_seq_start = z.c_rss.d; cb.contig_len = z.c_clen.d;
+    cb.ref_seq = refDev; cb.ref_off = z.c_refoff.d; cb.ref_seq_start = z.c_rss.d; cb.contig_len = z.c_clen.d;
     cb.read_seq = z.t_seq.d; cb.read_qual = z.t_qual.d; cb.read_off = z.t_off.d; cb.read_pos = z.t_pos.d; cb.read_flags = z.t_flags.d;
     cb.cigar = z.t_cigar.d; cb.cig_off = z.t_cigoff.d;
     hostTally = getenv("PLAT_CALLER_HOST_TALLY") != nullptr;         // (measurements / tests: merge the records on the host)

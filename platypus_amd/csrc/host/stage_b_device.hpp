@@ -14,6 +14,11 @@ inline bool Chunk::eligibleDeviceB() const {
 inline void Chunk::launchStageB() {
     Slot& z = s;
     const size_t nR = regions.size();
+    capV = z.sbCapV; capW = z.sbCapW; capA = z.sbCapA;
+    for (RegionWork* r : regions) {                                     // (a long region gets room in proportion: ~1.5 variants / kb of the synthetic genome, x 2)
+        const int len = std::max(0, r->in->end - r->in->start);
+        capV = std::min(1024, std::max(capV, len / 300)); capW = std::min(1024, std::max(capW, len / 500));
+    }
     size_t nBr = 0;
     for (RegionWork* r : regions) nBr += (size_t)r->samples[0].broken.n();
     Layout LI;
@@ -33,7 +38,7 @@ inline void Chunk::launchStageB() {
     }
     z.sb_matepos.h[mo] = 0;
     LI.upload(z, z.a_bin);
-    const size_t capBW = nR * (size_t)capW, capBH = nR * 2048, capBR = std::max<size_t>(4 * (nGood + nBad + nBroken), 65536), capHB = capBH * 1280;
+    const size_t capBW = nR * (size_t)capW, capBH = nR * 1024, capBR = std::max<size_t>(4 * (nGood + nBad + nBroken), 65536), capHB = capBH * 1280;
     Layout LO;
     LO.add(z.sb_hdr, 8 * nR); LO.add(z.sb_totals, 16);
     LO.add(z.sb_vpos, nR * capV); LO.add(z.sb_vnrem, nR * capV); LO.add(z.sb_vnadd, nR * capV); LO.add(z.sb_vsupp, nR * capV); LO.add(z.sb_vbmin, nR * capV);
@@ -52,7 +57,7 @@ inline void Chunk::launchStageB() {
     memset(&in, 0, sizeof in);
     in.n_regions = (int32_t)nR; in.cap_per_scan = mergeCap; in.cand = z.m_cand.d; in.cand_n = z.m_n.d;
     in.cand_rec = getenv("PLAT_CALLER_NO_DEVICE_REPLAY") ? nullptr : z.c_rec.d; in.region_name_hash = z.sb_namehash.d;
-    in.ref_seq = z.c_ref.d; in.ref_off = z.c_refoff.d; in.ref_seq_start = z.c_rss.d; in.contig_len = z.c_clen.d;
+    in.ref_seq = refDev; in.ref_off = z.c_refoff.d; in.ref_seq_start = z.c_rss.d; in.contig_len = z.c_clen.d;
     in.region_start = z.sb_rstart.d; in.region_end = z.sb_rend.d; in.region_rlen = z.sb_rlen.d;
     in.read_seq = z.t_seq.d; in.read_off = z.t_off.d; in.read_pos = z.t_pos.d; in.read_end = z.t_end.d;
     in.tab_begin = z.sb_tabbegin.d; in.tab_n = z.sb_tabn.d; in.tab_longest = z.sb_tablongest.d; in.broken_mate_pos = z.sb_matepos.d; in.broken_base = (int32_t)(nGood + nBad);
@@ -107,7 +112,10 @@ inline void Chunk::stageBFromDevice() {
     for (size_t g = 0; g < nR; ++g) {
         RegionWork& r = *regions[g];
         const int32_t* hdr = z.sb_hdr.h + 8 * g;
-        if (hdr[0] != 0) { regionVariants(r, (int)g); regionWindows(r); ++nHostRegions; continue; }
+        if (hdr[0] != 0) {
+            if (hdr[5] == 6) { z.sbCapV = std::min(2 * capV, 1024); z.sbCapW = std::min(2 * capW, 1024); z.sbCapA = std::min(2 * capA, 1 << 16); }   // more room from the next chunk on
+            regionVariants(r, (int)g); regionWindows(r); ++nHostRegions; continue;
+        }
         PROF("s2.fillRegion");
         const int nV = hdr[1], nW = hdr[2];
         nReplayed += hdr[6] != 0;

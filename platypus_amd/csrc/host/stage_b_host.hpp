@@ -32,7 +32,7 @@ inline void Chunk::tallySample(const RegionWork& r, size_t i, std::vector<CandKe
                 if (tv.t->encoding == PLAT_READS_ASCII) addp = (const char*)tv.t->seq + (rec[4] - blobBase);
                 else { addedStore.push_back(tableBases(*tv.t, rec[4] - blobBase, rec[2])); addp = addedStore.back().data(); }
             }
-            CandKey key{std::max(0, rec[0]), rec[1], rec[2], 1, rec[1] ? refBlob.data() + rec[3] : "", addp};
+            CandKey key{std::max(0, rec[0]), rec[1], rec[2], 1, rec[1] ? hostRefBlob().data() + rec[3] : "", addp};
             if (nRecords) ++*nRecords;
             size_t slot = hashKey(key) & tmask;
             while (table[slot] && !sameKey(keys[(size_t)table[slot] - 1], key)) slot = (slot + 1) & tmask;
@@ -95,7 +95,7 @@ inline void Chunk::regionVariants(RegionWork& r, int scan0) {
             for (const int32_t* c : cands) {
                 r.nCandRecords += c[1];
                 const std::string added = tableBases(*tv.t, c[7] - blobBase, c[5]);
-                pass(std::max(0, c[3]), c[4] ? refBlob.data() + c[6] : "", c[4], added.data(), c[5], c[1]);
+                pass(std::max(0, c[3]), c[4] ? hostRefBlob().data() + c[6] : "", c[4], added.data(), c[5], c[1]);
             }
         }
     }

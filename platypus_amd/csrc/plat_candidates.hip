@@ -557,9 +557,16 @@ k_gather_reads(long long n_dst, const int32_t* __restrict__ src_index, const int
     for (long long d = (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6); d < n_dst; d += nw) {
         const int s = src_index[d];
         const long long so = src_off[s], n = src_off[s + 1] - so, to = dst_off[d];
-        for (long long i = lane; i < n; i += 64) {
-            dst_seq[to + i] = src_seq[so + i];
-            dst_qual[to + i] = src_qual[so + i];
+        // lanes 0..31 move the bases, 32..63 the qualities, 8 bytes at a time from and to any address (global memory takes unaligned
+        // 64-bit loads and stores): a 150-base read is ONE load and ONE store per lane (it was three byte loads and stores per array)
+        {
+            typedef unsigned long long __attribute__((aligned(1))) u64u;
+            const uint8_t* src = lane < 32 ? src_seq + so : src_qual + so;
+            uint8_t* dst = lane < 32 ? dst_seq + to : dst_qual + to;
+            const int l = lane & 31;
+            const long long n8 = n & ~7ll;
+            for (long long i = 8ll * l; i < n8; i += 256) *(u64u*)(dst + i) = *(const u64u*)(src + i);
+            for (long long i = n8 + l; i < n; i += 32) dst[i] = src[i];
         }
         if (lane == 0) { dst_pos[d] = src_pos[s]; dst_end[d] = src_end[s]; dst_mapq[d] = src_mapq[s]; dst_flags[d] = src_flags[s]; }
     }
@@ -756,6 +763,36 @@ PLAT_EXPORT int plat_concat_read_tables(plat_ctx* ctx, int n_tables, int max_rea
     gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
     hipLaunchKernelGGL(plat::k_concat_tables, dim3(gx, (unsigned)n_tables), dim3(256), 0, (hipStream_t)stream, desc, dst_off, dst_pos, dst_end,
                        dst_mapq, dst_flags, dst_cig_off, dst_cigar, dst_region, (long long)n_total_reads, (long long)total_bytes, (long long)total_pairs);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}
+
+
+// ---- pieces of device memory into one blob (plat_copy_pieces) -----------------------------------------------------------------------------
+namespace plat {
+__global__ void __launch_bounds__(256)
+k_copy_pieces(const plat_unpack_piece* __restrict__ pieces, uint8_t* __restrict__ dst_blob)
+{
+    typedef unsigned long long __attribute__((aligned(1))) u64u;
+    const plat_unpack_piece pc = pieces[blockIdx.y];
+    const uint8_t* src = pc.src;
+    uint8_t* dst = dst_blob + pc.dst;
+    const long long n8 = pc.n & ~7ll;
+    const long long stride = 8ll * gridDim.x * blockDim.x;
+    for (long long i = 8ll * ((long long)blockIdx.x * blockDim.x + threadIdx.x); i < n8; i += stride) *(u64u*)(dst + i) = *(const u64u*)(src + i);
+    if (blockIdx.x == 0) for (long long i = n8 + threadIdx.x; i < pc.n; i += blockDim.x) dst[i] = src[i];
+}
+}  // namespace plat
+
+PLAT_EXPORT int plat_copy_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* dst_blob, void* stream)
+{
+    if (!ctx || n_pieces < 0 || max_piece_bytes < 0) return PLAT_ERR_INVALID;
+    if (n_pieces == 0) return PLAT_OK;
+    if (!pieces || !dst_blob) return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    long long gx = (max_piece_bytes / 8 + 256) / 256;
+    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+    hipLaunchKernelGGL(plat::k_copy_pieces, dim3((unsigned)gx, (unsigned)n_pieces), dim3(256), 0, (hipStream_t)stream, pieces, dst_blob);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }

@@ -292,7 +292,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
         if (nadd) {
             if (lane == 0) off = atomicAdd(&R.addedUsed, nadd);
             off = __shfl(off, 0, 64);
-            if (off + nadd > b.cap_added) { if (lane == 0) atomicOr(&R.status, 1); continue; }
+            if (off + nadd > b.cap_added) { if (lane == 0) atomicOr(&R.status, 5); continue; }
             for (int i = lane; i < nadd; i += 64) blob[off + i] = (uint8_t)hapAt(first + i);
         }
         if (lane == 0) {
@@ -354,11 +354,11 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
     nk = R.tot;
     //  (b) two survivors that compare equal
     for (int k = tid + 1; k < nk; k += SB_THREADS) if (pass == 0 && R.key[R.list[k]] == R.key[R.list[k - 1]]) atomicOr(&R.status, 2);
-    if (nk > b.cap_vars) atomicOr(&R.status, 1);
+    if (nk > b.cap_vars) atomicOr(&R.status, 5);                      // (bit 2: a capacity of the caller, not an exception)
     __syncthreads();
     const int st0 = R.status;
     __syncthreads();
-    if (st0 & 1) { if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; hdr[5] = 1; } return; }
+    if (st0 & 1) { if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; hdr[5] = (st0 & 4) ? 6 : 1; } return; }
     if (!(st0 & 2)) break;
     // ---- the order depends on the dictionaries: replay them (variantcaller.pyx:456-470: the sample's variantHeap walked with iteritems(),
     // what passes the support filter put into the all-samples generator's variantHeap, its values() sorted)
@@ -481,7 +481,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
             if (R.addo[e] < 0) ao = -(R.addo[e] + 1);
             else {
                 ao = atomicAdd(&R.addedUsed, R.nadd[e]);
-                if (ao + R.nadd[e] > b.cap_added) { atomicOr(&R.status, 1); ao = 0; }
+                if (ao + R.nadd[e] > b.cap_added) { atomicOr(&R.status, 5); ao = 0; }
                 else for (int i = 0; i < R.nadd[e]; ++i) blob[ao + i] = b.read_seq[R.addo[e] + i];
             }
         }
@@ -498,7 +498,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
         auto emit = [&]() {
             const int ws = max(bMin - o.minVarDist, start), we = min(bMax + o.minVarDist, maxContigPos);
             if (we - ws > o.maxSize) return;                           // variantcaller.pyx:566-568
-            if (nw >= b.cap_windows) { st = 1; return; }
+            if (nw >= b.cap_windows) { st = 5; return; }
             const long long w = (long long)g * b.cap_windows + nw;
             out.win_start[w] = ws; out.win_end[w] = we; out.win_var_first[w] = bFirst; out.win_var_n[w] = bCount;
             ++nw;
@@ -523,7 +523,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
             else { emit(); bMin = gMin; bMax = gMax; bCount = gCount; bFirst = gFirst; }
         }
         if (haveBunch) emit();
-        if (st) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; hdr[5] = 4; }
+        if (st) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; hdr[5] = (st & 4) ? 6 : 4; }
         else { hdr[0] = 0; hdr[1] = nk; hdr[2] = nw; hdr[4] = R.addedUsed; hdr[5] = 0; hdr[6] = R.dN2 > 0; hdr[7] = 0; }
     }
 }

@@ -36,7 +36,7 @@ class _SampleReads(C.Structure):
 
 class _Region(C.Structure):
     _fields_ = [("chrom", C.c_char_p), ("start", C.c_int32), ("end", C.c_int32), ("contig_seq", C.c_void_p),
-                ("contig_len", C.c_int64), ("samples", C.POINTER(_SampleReads))]
+                ("contig_len", C.c_int64), ("samples", C.POINTER(_SampleReads)), ("dev_contig_seq", C.c_void_p)]
 
 
 _OPT_FIELDS = [("rlen", C.c_int32), ("minReads", C.c_int32), ("maxReads", C.c_double), ("maxSize", C.c_int32), ("largeWindows", C.c_int32),

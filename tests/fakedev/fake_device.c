@@ -337,6 +337,13 @@ API int plat_unpack_reads_pieces(plat_ctx* c, int n_pieces, int64_t max_piece_by
     return PLAT_OK;
 }
 
+API int plat_copy_pieces(plat_ctx* c, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* dst_blob, void* stream)
+{
+    (void)c; (void)stream; (void)max_piece_bytes;
+    for (int k = 0; k < n_pieces; ++k) memcpy(dst_blob + pieces[k].dst, pieces[k].src, (size_t)pieces[k].n);
+    return PLAT_OK;
+}
+
 API int plat_concat_read_tables(plat_ctx* c, int n_tables, int max_reads_per_table, const plat_table_desc* desc, int64_t* dst_off, int32_t* dst_pos,
                                 int32_t* dst_end, uint8_t* dst_mapq, int32_t* dst_flags, int32_t* dst_cig_off, int16_t* dst_cigar, int32_t* dst_region,
                                 int64_t n_total, int64_t total_bytes, int64_t total_pairs, void* stream)

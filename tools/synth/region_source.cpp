@@ -448,6 +448,7 @@ static int plat_synth_load_resident(void* user, int index, int slot, plat_region
     if (!g || !out || index < 0 || (size_t)index >= g->resident.size()) return -2;
     *out = g->resident[(size_t)index];
     if (g->haveMirror) {
+        out->dev_contig_seq = out->contig_seq + g->devDelta;            // (the slot holds the contig too: the reference is resident)
         // (the per-sample structs live in the slot and are shared by every hand-out: the pointers written are the same every time)
         plat_sample_reads* sm = const_cast<plat_sample_reads*>(out->samples);
         for (int i = 0; i < g->nSamples; ++i) {
