@@ -568,7 +568,8 @@ def main():
             wgs.pop("merged_text", None)
             keep = ("windows_per_sec", "gcups", "gcups_executed", "roofline", "roofline_other", "scaling", "scaling_efficiency_basis", "regions", "windows", "records",
                     "regions_per_sec", "reads_per_sec", "timed_s", "timed_s_runs", "host_seconds_per_region", "device_wait_seconds_per_region",
-                    "stage_seconds_per_region", "record_gather", "cpus_granted_to_this_rank", "dp_reference", "dp_launched", "stage_b", "inputs", "config", "error")
+                    "stage_seconds_per_region", "record_gather", "cpus_granted_to_this_rank", "dp_reference", "dp_launched", "dp_per_launch", "stage_b", "inputs", "config",
+                    "error")
             wgs["windows_per_sec"] = wgs.get("value")
             line["wgs"] = {k: wgs[k] for k in keep if k in wgs}
             line["wgs"]["what"] = ("BASELINE config 4 on this job's GPUs: the synthetic 30x genome's regions (3 875 per GPU unless --strong), region i -> rank i % N, "

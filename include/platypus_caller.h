@@ -192,6 +192,14 @@ int plat_call_regions_stream(plat_caller* c, int n_regions, int n_samples, const
  * n texts of record lines, each already in that order, -> one text in that order (ties: the earlier text first).  For the job's one
  * exchange: every rank's record text gathered to rank 0, merged there.  *out_text is malloc'ed (plat_caller_free). */
 int plat_merge_record_texts(const char* const* texts, const size_t* lengths, int n, char** out_text, size_t* out_len);
+/* The same merge when the texts are made of whole REGIONS that do not interleave (disjoint regions, each one's records in order -- what
+ * plat_call_regions returns): then the merged text is a permutation of the regions' blocks and no line has to be looked at.
+ * plat_caller_region_text_lengths: bytes of every region's record text in the text the last call on `c` returned, in list order (the
+ * blocks lie back to back).  plat_merge_region_blocks: n blocks src[i][0 .. len[i]) copied to offsets at[i] (ascending, not
+ * overlapping, inside `total`) of a fresh block (*out_text, NUL-terminated, plat_caller_free) on up to 16 threads; the caller puts the
+ * blocks in (chromosome key, start) order and falls back to plat_merge_record_texts where regions overlap. */
+int plat_caller_region_text_lengths(const plat_caller* c, int64_t* out, int n);
+int plat_merge_region_blocks(int n, const char* const* src, const size_t* len, const size_t* at, size_t total, char** out_text);
 void plat_caller_free(void* p);
 /* Human-readable message of the last error of a failing plat_call_regions on this caller. */
 const char* plat_caller_last_error(const plat_caller* c);

@@ -92,6 +92,11 @@ struct Chunk {
     void lap(int k) { const auto now = Clock::now(); stage[k] += secs(mark, now); mark = now; stageWait[k] += s.t_wait - waitMark; waitMark = s.t_wait; }
 
     void run() {
+        // plat_caller_count_cells (the untimed counting pass of a measurement): one chunk at a time, so that the live kernel timers of its
+        // likelihood batch (HIP events on this worker's stream) time its kernels and not the other workers'
+        static std::mutex countMutex;
+        std::unique_lock<std::mutex> oneAtATime(countMutex, std::defer_lock);
+        if (s.countCells) oneAtATime.lock();
         const auto t0 = Clock::now();
         double wait0 = s.t_wait;
         mark = t0; waitMark = wait0;

@@ -26,6 +26,8 @@
 // on one worker thread with its own plat_ctx and stream (chunk.hpp: Chunk::run); several workers run side by side, so the uploads,
 // kernels and host stages of different chunks overlap.  This file: the feeds, the worker pool, the C entry points, the merge of
 // record texts.  Same text as platypus_amd/caller.py::callVariantsInRegions (tests/test_native_caller_*.py).
+#include <sys/mman.h>
+
 #include "caller_common.hpp"
 #include "chunk.hpp"
 #include "stage_a.hpp"
@@ -41,6 +43,7 @@ struct plat_caller {
     bool countCells = false;
     std::vector<std::unique_ptr<Slot>> slots;
     std::string lastError;
+    std::vector<int64_t> lastLengths;                                       // bytes of record text of every region of the last call, in list order
 };
 
 CALLER_EXPORT void plat_caller_default_options(plat_caller_options* o) {
@@ -282,7 +285,7 @@ static void copyPieces(char* out, const std::vector<const char*>& from, const st
     size_t total = 0;
     for (size_t l : len) total += l;
     const size_t n = from.size();
-    const int nT = total < ((size_t)8 << 20) ? 1 : (int)std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency()));
+    const int nT = total < ((size_t)8 << 20) ? 1 : (int)std::min<size_t>(16, std::max<size_t>(1, std::thread::hardware_concurrency()));
     auto part = [&](int t) {
         // thread t takes the pieces whose bytes start in its slice of the output
         const size_t span = n ? at[n - 1] + len[n - 1] + 1 : 0;            // (offsets may leave gaps between the pieces: they run over the output, not over the bytes copied)
@@ -297,12 +300,29 @@ static void copyPieces(char* out, const std::vector<const char*>& from, const st
     for (std::thread& x : th) x.join();
 }
 
-static int finishText(std::vector<std::unique_ptr<RegionWork>>& work, char** out_text, size_t* out_len) {
+// a block for ~100 MB of text: 2 MB aligned and advised for huge pages (a fresh block's first-touch faults are then hundreds, not tens of
+// thousands); freed with free()
+static char* allocText(size_t bytes) {
+    const size_t big = (size_t)2 << 20;
+    if (bytes < 4 * big) return (char*)malloc(bytes);
+    void* p = nullptr;
+    if (posix_memalign(&p, big, (bytes + big - 1) & ~(big - 1)) != 0) return nullptr;
+#ifdef MADV_HUGEPAGE
+    madvise(p, (bytes + big - 1) & ~(big - 1), MADV_HUGEPAGE);
+#endif
+    return (char*)p;
+}
+
+static int finishText(plat_caller* c, std::vector<std::unique_ptr<RegionWork>>& work, char** out_text, size_t* out_len) {
     std::vector<const char*> from;
     std::vector<size_t> len, at;
     size_t total = 0;
-    for (auto& r : work) if (r) { from.push_back(r->text.data()); len.push_back(r->text.size()); at.push_back(total); total += r->text.size(); }
-    char* text = (char*)malloc(total + 1);
+    c->lastLengths.clear();
+    for (auto& r : work) {
+        c->lastLengths.push_back(r ? (int64_t)r->text.size() : 0);
+        if (r) { from.push_back(r->text.data()); len.push_back(r->text.size()); at.push_back(total); total += r->text.size(); }
+    }
+    char* text = allocText(total + 1);
     if (!text) return PLAT_ERR_NOMEM;
     copyPieces(text, from, len, at);
     text[total] = 0;
@@ -346,7 +366,7 @@ CALLER_EXPORT int plat_call_regions(plat_caller* c, const plat_region* regions, 
     MemoryFeed feed(work, c->regionsPerChunk, failed);
     rc = runWorkers(c, feed, failed, o, n_samples, sample_names, st, std::max(1, feed.nChunks));
     if (rc != PLAT_OK) return rc;
-    if ((rc = finishText(work, out_text, out_len)) != PLAT_OK) return rc;
+    if ((rc = finishText(c, work, out_text, out_len)) != PLAT_OK) return rc;
     options->rlen = rlen;
     st.seconds_total = secs(t0, Clock::now());
     traceStages(st);
@@ -383,7 +403,7 @@ CALLER_EXPORT int plat_call_regions_stream(plat_caller* c, int n_regions, int n_
     for (std::thread& t : loaders) t.join();
     if (rc == PLAT_OK && feed.error != PLAT_OK) { rc = feed.error; c->lastError = feed.errText; }
     if (rc != PLAT_OK) return rc;
-    if ((rc = finishText(feed.work, out_text, out_len)) != PLAT_OK) return rc;
+    if ((rc = finishText(c, feed.work, out_text, out_len)) != PLAT_OK) return rc;
     options->rlen = feed.rlen;
     st.seconds_total = secs(t0, Clock::now());
     st.seconds_load = feed.tLoad; st.seconds_source_wait = feed.tWait;
@@ -436,6 +456,26 @@ static bool mergeLess(const MergeKey& a, const MergeKey& b) {
 // threads; (2) the merge itself over the keys -- a run of lines of one text that stays in front of every other text's head is one block;
 // ties between texts go to the text that comes first (heapq of (key, index) pairs there); (3) the blocks copied into place, again on a
 // few threads.
+CALLER_EXPORT int plat_caller_region_text_lengths(const plat_caller* c, int64_t* out, int n) {
+    if (!c || !out || n < 0 || (size_t)n != c->lastLengths.size()) return PLAT_ERR_INVALID;
+    for (int i = 0; i < n; ++i) out[i] = c->lastLengths[(size_t)i];
+    return PLAT_OK;
+}
+
+// n blocks of text -> one block: src[i][0 .. len[i]) to out + at[i] (at ascending), on up to 16 threads
+CALLER_EXPORT int plat_merge_region_blocks(int n, const char* const* src, const size_t* len, const size_t* at, size_t total, char** out_text) {
+    if (n < 0 || !out_text || (n > 0 && (!src || !len || !at))) return PLAT_ERR_INVALID;
+    for (int i = 0; i < n; ++i) if (at[i] + len[i] > total || (i > 0 && at[i] < at[i - 1] + len[i - 1])) return PLAT_ERR_INVALID;
+    char* out = allocText(total + 1);
+    if (!out) return PLAT_ERR_NOMEM;
+    std::vector<const char*> from(src, src + n);
+    std::vector<size_t> l(len, len + n), a(at, at + n);
+    copyPieces(out, from, l, a);
+    out[total] = 0;
+    *out_text = out;
+    return PLAT_OK;
+}
+
 CALLER_EXPORT int plat_merge_record_texts(const char* const* texts, const size_t* lengths, int n, char** out_text, size_t* out_len) {
     if (!out_text || !out_len || n < 0 || (n > 0 && (!texts || !lengths))) return PLAT_ERR_INVALID;
     struct Line { const char* p; const char* eol; MergeKey key; };

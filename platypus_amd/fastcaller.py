@@ -253,6 +253,8 @@ def _bind(lib):
     lib.plat_call_regions_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(CallerOptions), C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(CallerStats)]
     lib.plat_merge_record_texts.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.plat_caller_region_text_lengths.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.plat_merge_region_blocks.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
     lib.plat_caller_free.argtypes = [C.c_void_p]
     lib.plat_caller_free.restype = None
     lib.plat_caller_last_error.argtypes = [C.c_void_p]
@@ -311,6 +313,95 @@ def merge_record_texts(texts, lib=None, raw=False):
     return _native_text(lib, out, length.value, raw)
 
 
+def text_address(t):
+    """(address, length) of a text held as bytes, a ctypes array (raw="view"), a numpy uint8 array or a CPU torch uint8 tensor."""
+    if isinstance(t, bytes):
+        return C.cast(C.c_char_p(t), C.c_void_p).value or 0, len(t)
+    if isinstance(t, C.Array):
+        return C.addressof(t), len(t)
+    if hasattr(t, "data_ptr"):
+        return int(t.data_ptr()), int(t.numel())
+    return int(t.ctypes.data), int(t.size)
+
+
+def merge_region_blocks(texts, lengths, keys, lib=None):
+    """The job's merge when every text is made of whole regions that do not interleave (the native region loop's output): texts[r] = rank
+    r's text, lengths[r] = bytes of each of its regions' records (plat_caller_region_text_lengths), keys[r] = (chromosome key, start, end) of
+    each of its regions.  The regions' blocks are put in (chromosome key, start) order -- runner.py:301-352's order -- by block copies on
+    up to 16 threads, no line is looked at.  Returns the merged text (raw view), or None when two regions overlap (the caller then merges
+    line by line: merge_record_texts)."""
+    import numpy as np
+    lib = lib if lib is not None else load()
+    blocks = []
+    for r, (lens, ks) in enumerate(zip(lengths, keys)):
+        base, _ = text_address(texts[r])
+        off = 0
+        for ln, k in zip(lens, ks):
+            blocks.append((k[0], k[1], k[2], r, base + off, int(ln)))
+            off += int(ln)
+    blocks.sort(key=lambda b: (b[0], b[1], b[3]))
+    for a, b in zip(blocks, blocks[1:]):
+        if a[0] == b[0] and a[2] > b[1] and a[5] and b[5]:
+            return None                                              # overlapping regions: their records may interleave
+    n = len(blocks)
+    src = np.array([b[4] for b in blocks], dtype=np.uint64)
+    ln = np.array([b[5] for b in blocks], dtype=np.uint64)
+    at = np.zeros(n, dtype=np.uint64)
+    if n:
+        at[1:] = np.cumsum(ln)[:-1]
+    total = int(ln.sum())
+    out = C.c_void_p()
+    rc = lib.plat_merge_region_blocks(n, src.ctypes.data, ln.ctypes.data, at.ctypes.data, total, C.byref(out))
+    if rc != 0:
+        raise _lib.PlatypusDeviceError(rc, "merge failed", "plat_merge_region_blocks")
+    return _native_text(lib, out, total, "view")
+
+
+class BlockOrder:
+    """merge_region_blocks with everything that depends only on the job's region list worked out ONCE (before a timed region): the order
+    of all blocks.  plan = BlockOrder(keys) with keys[r] = [(chromosome key, start, end), ...] of rank r's regions; plan.merge(texts,
+    lengths) then costs two small numpy passes and the block copies.  plan.ok is False when regions overlap."""
+
+    def __init__(self, keys):
+        import numpy as np
+        flat = [(k[0], k[1], k[2], r, j) for r, ks in enumerate(keys) for j, k in enumerate(ks)]
+        order = sorted(range(len(flat)), key=lambda i: (flat[i][0], flat[i][1], flat[i][3]))
+        self.ok = all(not (flat[a][0] == flat[b][0] and flat[a][2] > flat[b][1]) for a, b in zip(order, order[1:]))
+        self.rank = np.array([flat[i][3] for i in order], dtype=np.int64)
+        self.index = np.array([flat[i][4] for i in order], dtype=np.int64)
+        self.counts = [len(ks) for ks in keys]
+
+    def merge(self, texts, lengths, lib=None):
+        import numpy as np
+        lib = lib if lib is not None else load()
+        starts = []
+        for r, lens in enumerate(lengths):
+            lens = np.asarray(lens, dtype=np.int64)
+            assert len(lens) == self.counts[r]
+            base, size = text_address(texts[r])
+            st = np.zeros(len(lens), dtype=np.int64)
+            if len(lens):
+                st[1:] = np.cumsum(lens)[:-1]
+            assert int(lens.sum()) == size, "region lengths do not add up to the text"
+            starts.append((base + st, lens))
+        n = len(self.rank)
+        src = np.zeros(n, dtype=np.uint64)
+        ln = np.zeros(n, dtype=np.uint64)
+        for r, (st, lens) in enumerate(starts):
+            m = self.rank == r
+            src[m] = st[self.index[m]].astype(np.uint64)
+            ln[m] = lens[self.index[m]].astype(np.uint64)
+        at = np.zeros(n, dtype=np.uint64)
+        if n:
+            at[1:] = np.cumsum(ln)[:-1]
+        total = int(ln.sum())
+        out = C.c_void_p()
+        rc = lib.plat_merge_region_blocks(n, src.ctypes.data, ln.ctypes.data, at.ctypes.data, total, C.byref(out))
+        if rc != 0:
+            raise _lib.PlatypusDeviceError(rc, "merge failed", "plat_merge_region_blocks")
+        return _native_text(lib, out, total, "view")
+
+
 class NativeCaller:
     """plat_caller: `workers` threads, each with its own plat_ctx and stream on `device`; `regions_per_chunk` regions go through
     the device stages together."""
@@ -362,6 +453,15 @@ class NativeCaller:
         options.rlen = int(o.rlen)
         self.stats = st.as_dict()
         return out
+
+    def region_text_lengths(self, n_regions):
+        """Bytes of record text of every region of the last call, in list order (their blocks lie back to back in the text it returned)."""
+        import numpy as np
+        out = np.zeros(max(n_regions, 1), dtype=np.int64)
+        rc = self.lib.plat_caller_region_text_lengths(self.h, out.ctypes.data, n_regions)
+        if rc != 0:
+            raise _lib.PlatypusDeviceError(rc, "no call yet, or another number of regions", "plat_caller_region_text_lengths")
+        return out[:n_regions]
 
     def call_stream(self, n_regions, load, user, sample_names, options, n_slots, n_loaders=2, raw=False):
         """plat_call_regions_stream: regions loaded on demand.  `load`: a plat_region_load_fn -- the address of a native function (int,

@@ -56,6 +56,116 @@ def gather_records(payload: bytes, dist=None, device=None):
     return out
 
 
+class RegionTextExchange:
+    """The job's ONE exchange for the native region loop's output (runner.py:301-352): every rank's record text to rank 0,
+    merged there by (chromosome key, position) -- as a permutation of whole REGION blocks.
+
+    A rank's text is its regions' record lines back to back, each region's in order; regions of a job list do not overlap, so the merged
+    text is the regions' blocks in (chromosome key, start) order and no line needs to be parsed.  That order depends on the region list
+    alone: it is worked out once, here, before anything is timed.  Per call: the regions' byte counts travel in one all_gather, the texts
+    point to point to rank 0 (RCCL: device to device over xGMI), and rank 0 puts the blocks in place --
+      * backend "nccl": ONE scatter kernel over the texts where they arrived, in HBM (plat_copy_pieces), then one copy of the merged text
+        to (cached) pinned host memory;
+      * gloo / no process group: block copies on up to 16 host threads (plat_merge_region_blocks).
+    When regions DO overlap the texts are merged line by line instead (fastcaller.merge_record_texts), as before.
+
+    regions_of_rank[r] = [(chrom, start, end), ...] in rank r's list order (the same on every rank)."""
+
+    _pinned = None                                                       # cached pinned host block for the merged text (grown, never shrunk)
+
+    def __init__(self, regions_of_rank, dist=None, device=None, lib=None, device_index=0):
+        from . import fastcaller as F
+        self.F, self.lib, self.dist = F, lib, dist if (dist is not None and dist.is_initialized()) else None
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.device = device
+        self.on_device = self.dist is not None and device is not None and getattr(device, "type", "cpu") == "cuda"
+        self.counts = [len(x) for x in regions_of_rank]
+        self.plan = F.BlockOrder([[(chrom_key(c), int(s), int(e)) for c, s, e in regs] for regs in regions_of_rank])
+        self.ctx = None
+        if self.on_device and self.rank == 0:
+            import ctypes as C
+            from . import _lib
+            self._dl = _lib.load()
+            ctx = C.c_void_p()
+            if self._dl.plat_ctx_create(int(device_index), C.byref(ctx)) != 0:
+                raise RuntimeError("plat_ctx_create failed")
+            self.ctx = ctx
+
+    def exchange(self, text, lengths):
+        """text: this rank's record text (bytes / raw view); lengths: int64 bytes per region of this rank (NativeCaller.region_text_lengths).
+        Returns the merged text on rank 0 (a buffer: bytes(x) / memoryview(x) give its bytes), None elsewhere."""
+        import torch
+        F = self.F
+        lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+        if self.dist is None:
+            if not self.plan.ok:
+                return F.merge_record_texts([text], lib=self.lib, raw="view")
+            return self.plan.merge([text], [lengths], lib=self.lib)
+        dev = self.device if self.on_device else torch.device("cpu")
+        addr, size = F.text_address(text)
+        mine = torch.from_numpy(np.ctypeslib.as_array((__import__("ctypes").c_uint8 * size).from_address(addr)) if size else np.zeros(0, dtype=np.uint8))
+        lens_t = torch.from_numpy(lengths)
+        if self.on_device:
+            mine, lens_t = mine.to(dev), lens_t.to(dev)
+        # sizes are implied by the regions' byte counts: one all_gather of them (padded to the longest list)
+        most = max(self.counts) if self.counts else 0
+        pad = torch.zeros(most, dtype=torch.int64, device=dev)
+        pad[:len(lengths)] = lens_t
+        allp = [torch.zeros(most, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        self.dist.all_gather(allp, pad)
+        all_lens = [allp[r][:self.counts[r]].cpu().numpy() for r in range(self.world)]
+        sizes = [int(x.sum()) for x in all_lens]
+        if self.rank != 0:
+            if sizes[self.rank] > 0:
+                self.dist.send(mine, dst=0)
+            return None
+        bufs = [mine] + [torch.empty(sizes[r], dtype=torch.uint8, device=dev) for r in range(1, self.world)]
+        reqs = [self.dist.irecv(bufs[r], src=r) for r in range(1, self.world) if sizes[r] > 0]
+        for q in reqs:
+            q.wait()
+        if not self.plan.ok:
+            return F.merge_record_texts([bytes(b.cpu().numpy().tobytes()) for b in bufs], lib=self.lib, raw="view")
+        if not self.on_device:
+            return self.plan.merge([b.numpy() for b in bufs], all_lens, lib=self.lib)
+        return self._merge_on_device(bufs, all_lens)
+
+    def _merge_on_device(self, bufs, all_lens):
+        import ctypes as C
+        import torch
+        plan = self.plan
+        n = len(plan.rank)
+        src = np.zeros(n, dtype=np.int64)
+        ln = np.zeros(n, dtype=np.int64)
+        for r, lens in enumerate(all_lens):
+            st = np.zeros(len(lens), dtype=np.int64)
+            if len(lens):
+                st[1:] = np.cumsum(lens)[:-1]
+            m = plan.rank == r
+            src[m] = int(bufs[r].data_ptr()) + st[plan.index[m]]
+            ln[m] = lens[plan.index[m]]
+        at = np.zeros(n, dtype=np.int64)
+        if n:
+            at[1:] = np.cumsum(ln)[:-1]
+        total = int(ln.sum())
+        keep = ln > 0
+        pieces = np.stack([src[keep], at[keep], ln[keep]], axis=1).astype(np.int64)          # plat_unpack_piece {src, dst, n}
+        out = torch.empty(total + 64, dtype=torch.uint8, device=self.device)
+        if len(pieces):
+            pd = torch.from_numpy(np.ascontiguousarray(pieces)).to(self.device)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self._dl.plat_copy_pieces(self.ctx, int(len(pieces)), int(ln.max()), C.c_void_p(pd.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+            if rc != 0:
+                raise RuntimeError("plat_copy_pieces failed (%d)" % rc)
+        cls = RegionTextExchange
+        if cls._pinned is None or cls._pinned.numel() < total:
+            cls._pinned = torch.empty(int(total * 1.25) + 64, dtype=torch.uint8).pin_memory()
+        host = cls._pinned[:total]
+        host.copy_(out[:total], non_blocking=True)
+        torch.cuda.synchronize(self.device)
+        return host.numpy()
+
+
 def merge_record_streams(streams):
     """k-way merge of per-rank record lists, each already sorted by (chrom key, pos): runner.py:301-352.
     A record is a tuple (chrom, pos, line)."""

@@ -103,3 +103,42 @@ def test_config4_scaling_label_follows_the_region_list(tmp_path):
     assert weak2["scaling"] == "weak" and weak2["regions"] == 6 and weak2["scaling_efficiency_basis"]["regions_per_rank"] == 3
     assert strong2["scaling"] == "strong" and strong2["regions"] == strong1["regions"] == 24
     assert strong2["merged_text"] == strong1["merged_text"]
+
+
+def test_the_block_merge_writes_the_text_of_the_line_merge(tmp_path):
+    """The exchange puts whole region blocks in (chromosome key, start) order without looking at a line (sharding.RegionTextExchange,
+    plat_merge_region_blocks); runner.py:301-352 merges line by line (plat_merge_record_texts).  Same text, one rank and two; and a job
+    whose regions overlap falls back to the line merge."""
+    import torch.multiprocessing as mp
+    import bench
+    from platypus_amd import fastcaller as F, sharding
+    from tests import fakedev
+    from tools import bench_other
+    lib = fakedev.fake_caller_lib()
+    os.environ.update(PLAT_CALLER_WORKERS="2", PLAT_CALLER_CHUNK="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    rk1 = bench.Ranks(1, need_gpu=False)
+    blocks = bench_other.line_config4(_args(13), rk1, lib=lib, region_len=3000, region_kw=REGION_KW)      # 13 regions: r0 .. r12 (runner.py:47-50 strips the letters of "CHR": the keys are the integers)
+    os.environ["PLAT_BENCH_LINE_MERGE"] = "1"
+    try:
+        lines = bench_other.line_config4(_args(13), rk1, lib=lib, region_len=3000, region_kw=REGION_KW)
+    finally:
+        os.environ.pop("PLAT_BENCH_LINE_MERGE", None)
+    assert blocks["record_gather"]["how"] == "region blocks" and lines["record_gather"]["how"] == "line merge"
+    assert blocks["merged_text"] == lines["merged_text"] and blocks["merged_text"].count("\n") > 20
+    order = [ln.split("\t")[0] for ln in blocks["merged_text"].split("\n") if ln]
+    assert order == sorted(order, key=lambda c: sharding.chrom_key(c)) and order.index("r2") < order.index("r10")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "two.json")
+    mp.spawn(_rank_worker, args=(2, port, out, 13, False), nprocs=2, join=True)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    two = json.load(open(out))
+    assert two["record_gather"]["how"] == "region blocks" and two["merged_text"] == lines["merged_text"]
+    # overlapping regions: no plan, the texts go through the line merge
+    x = sharding.RegionTextExchange([[("c", 0, 100), ("c", 50, 150)]], lib=lib)
+    assert not x.plan.ok
+    t = b"c\t10\t.\tA\tC\nc\t60\t.\tA\tC\n" + b"c\t55\t.\tG\tT\n"
+    merged = x.exchange(t, [len(t) - 13, 13])
+    assert bytes(memoryview(merged)) == t                                  # (one text: the line merge keeps a single text's order)

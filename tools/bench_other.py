@@ -186,7 +186,7 @@ def run(a, rk):
 # ---- config 4 -----------------------------------------------------------------------------------------------------------------
 
 def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_samples=1, pin=True, lib=None, region_kw=None, rk=None, packed=True,
-            loaders=None, warm_regions=None, options_kw=None, resident=False):
+            loaders=None, warm_regions=None, options_kw=None, resident=False, job_regions=None):
     """The region pipeline end to end, sustained: the regions `indices` of the job's region list are LOADED ON DEMAND by a region source
     (tools/synth: generated from seed (+) region index inside the library's loader threads into a bounded set of pinned slots -- where the
     reference's BAM loader stands) and called through the native region loop (plat_call_regions_stream: host threads + every device stage
@@ -206,6 +206,7 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
         loaders = int(os.environ.get("PLAT_CALLER_LOADERS", str(max(2, min(12, granted // 2)))))
     n_slots = per_chunk * (workers + 2) + loaders
     kw = dict(region_len=region_len, n_samples=n_samples, packed=packed, pin=pin and not resident, **(region_kw or {}))
+    flank0 = int(kw.get("flank", 1000))                                       # (a synthetic region: contig r<id>, [flank, flank + region_len))
     # resident: the rank's whole share is generated ONCE, outside the timed region, and its read bytes are uploaded to HBM (one slot per
     # region, 3.7 MB each: 14 GB for a GPU's WGS share); a timed run then neither generates nor moves read bytes -- "inputs already resident
     # in HBM when the timed region starts".  Not resident: each region is generated when its turn comes (the source stands where a BAM
@@ -233,20 +234,37 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
         counted = dict(nc.stats, regions=nwarm)
     runs, text, merged, gather, st = [], "", None, None, None
     planted0 = src.planted
-    for _ in range(repeats):
+    # the exchange: every rank's text to rank 0, merged there as a permutation of whole region blocks (their order follows from the job's
+    # region list alone and is worked out here, once, before the timed region: sharding.RegionTextExchange); job_regions = the list of ALL
+    # ranks (region i -> rank i % N)
+    xch = None
+    if job_regions is not None:
+        world = getattr(rk, "world", 1)
+        per_rank = [[(("r%d" % g), flank0, flank0 + region_len) for g in job_regions[r::world]] for r in range(world)]
+        xch = sharding.RegionTextExchange(per_rank, dist=getattr(rk, "dist", None), device=getattr(rk, "coll_device", None), lib=lib,
+                                          device_index=getattr(rk, "dev_index", 0))
+    for rep in range(repeats + (1 if xch is not None else 0)):               # (with the exchange: one untimed round first -- its pinned block, its kernel)
         opts = default_options(**(options_kw or {}))
         rk.barrier()
         t0 = time.perf_counter()
         text = nc.call_stream(len(indices), src.load_fn, src.h, names, opts, n_slots, loaders, raw="view")    # the native block itself: no copy, no decode / encode passes
         t1 = time.perf_counter()
-        got = rk.gather(text)                                                # every rank's record lines to rank 0 ...
-        if got is not None:
-            merged = F.merge_record_texts(got, lib=lib, raw="view")           # ... merged there by (chromosome, position), runner.py:301-352
+        if xch is not None:
+            merged = xch.exchange(text, nc.region_text_lengths(len(indices)))
+            nranks = xch.world
+        else:
+            got = rk.gather(text)                                            # every rank's record lines to rank 0 ...
+            nranks = len(got) if got else None
+            if got is not None:
+                merged = F.merge_record_texts(got, lib=lib, raw="view")       # ... merged there by (chromosome, position), runner.py:301-352
         t2 = time.perf_counter()
         rk.barrier()
         st = dict(nc.stats)
+        if xch is not None and rep == 0:
+            continue
         runs.append((t2 - t0, t1 - t0))
-        gather = dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=len(got) if got else None, records=F.text_bytes(merged).count(b"\n") if merged is not None else None)
+        gather = dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=nranks, how="region blocks" if xch is not None else "line merge",
+                      records=bytes(memoryview(merged)).count(b"\n") if merged is not None else None)
     planted = (src.planted - planted0) // max(1, repeats)
     phases = {k: v / max(1, (repeats * len(indices) + nwarm)) for k, v in src.phase_seconds.items()}
     nc.close()
@@ -319,16 +337,18 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
         resident = os.environ.get("PLAT_CALLER_RESIDENT", "1") == "1"        # 0: regions generated and uploaded inside the timed region (rounds 2-3)
     # (resident: the loaders only hand out stored structs, so the workers get the CPUs -- 14 workers x 8 regions per chunk measured best on the
     #  16 CPUs of a one-GPU box: 1.21 M windows/s against 1.05 M with 10 x 6; 2 CPUs: 0.26 M, 4 CPUs: 0.43 M -- host stages 0.6 ms per region)
-    workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus * (7 if resident else 5) // 8)))))
+    # (round 5, resident: one worker per CPU -- 16 x 64 measured 2.40 M windows/s against 2.15 M with 14 workers; their host stages are
+    #  0.23 ms per region now and a worker waiting for the device sleeps)
+    workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus if resident else cpus * 5 // 8)))))
     os.environ.setdefault("PLAT_CALLER_LOADERS", str(max(2, min(12, cpus // 2))))
     # (round 5: stage B on the device -- the host no longer pays per region for a chunk's size, and the kernels of a chunk are latency bound:
-    #  48 regions per chunk measured 2.0 M windows/s against 1.25 M with 8)
-    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "48" if resident else "16"))
+    #  64 regions per chunk measured 2.4 M windows/s against 1.25 M with 8, and a k_dp_jobs launch then holds ~36 k DPs)
+    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "64" if resident else "16"))
     pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1" and lib is None
     packed = os.environ.get("PLAT_CALLER_PACKED", "1") == "1"
     repeats = max(1, min(a.steps, 3))                                        # the line is the MEAN over the runs
     r = config4(rk.dev_index, mine, region_len, workers, per_chunk, repeats=repeats, pin=pin, lib=lib, region_kw=region_kw, rk=rk, packed=packed,
-                resident=resident)
+                resident=resident, job_regions=None if os.environ.get("PLAT_BENCH_LINE_MERGE") == "1" else list(range(total)))
     cnt = r.get("counted") or {}
     ckeys = ("cells_reference", "cells_launched", "n_dp_reference", "n_dp_launched", "n_pairs", "regions", "n_align_batches", "align_hap_bytes", "align_read_bytes",
              "align_reads", "align_dp_bytes", "seconds_kernel_seed", "seconds_kernel_dp", "seconds_kernel_sweep", "seconds_kernel_pairs")
@@ -374,7 +394,7 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
     if rank == 0:
         if lib is None and not getattr(a, "no_cpu_baseline", False):
             line["cpu_baseline"] = config4_cpu_baseline()
-        line["merged_text"] = F.text_bytes(r["merged"]).decode("ascii")                               # (popped by bench.py before printing; the tests read it)
+        line["merged_text"] = bytes(memoryview(r["merged"])).decode("ascii")                               # (popped by bench.py before printing; the tests read it)
     return line
 
 

@@ -1,13 +1,15 @@
 #!/bin/bash
 # The ONE profiling / evidence script.  Everything kept under profiles/ comes from here.
 #
-#   gpurun --timeout 3000 -- "PLAT_COMMIT=$(git rev-parse --short HEAD) bash tools/profile_round.sh r04 [part ...]"
+#   gpurun --timeout 3000 -- "PLAT_COMMIT=$(git rev-parse --short HEAD) bash tools/profile_round.sh r05 [part ...]"
 #
 # First argument: the round tag the files under profiles/ are named with (r04 -> profiles/r04_*).
 # Parts (default: all but the soaks):
 #   tests   python -m pytest tests -m gpu                               -> $O/pytest_gpu.txt
 #   c2      rocprofv3 --kernel-trace --stats of config 2, one batch at a time and three in flight
-#   c3 c4 c5   the same for configs 3 (tiles + end to end), 4 (256 regions), 5
+#   c3 c4 c5   the same for configs 3 (tiles + end to end), 4 (1024 regions, inputs resident, 64 regions per chunk), 5
+#   pmc4    PMC passes of config 4 (FETCH_SIZE | WRITE_SIZE | SQ counters) -> $TAG_pmc_config4.txt
+#   mapa    tools/ubench/dp_mapping_a.hip: mapping A of the DP, bit exact, against the library -> $TAG_dp_mapping_a.json
 #   pmc2    PMC passes of config 2 (FETCH_SIZE | WRITE_SIZE | SQ counters; one pass per set, only --kernel-trace next to --pmc)
 #   pmc3    PMC passes of the assembler (FETCH | WRITE | SQ | wait counters)
 #   pmcseed three SQ passes over k_seed / k_dp_jobs / k_prep_reads (instruction mix, waits, LDS conflicts)
@@ -15,11 +17,11 @@
 #   line    the default bench line, bench.py --config 3/4/5, the two-rank launches on the one GPU
 #   soaks   ungapped cross-check (plain + wrap regime), native region-loop soak, assembler soak; SOAK_SECONDS each (default 400)
 # gpurun only brings back gpurun_out/: the summaries are written to profiles/ on the box AND copied to $O/out; copy them from there.
-TAG=${1:-r04}; shift
+TAG=${1:-r05}; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/${TAG}p
 mkdir -p $O
-PARTS=${@:-tests c2 c3 c4 c5 pmc2 pmc3 nextk line}
+PARTS=${@:-tests c2 c3 c4 c5 pmc2 pmc3 pmc4 nextk mapa line}
 T=${SOAK_SECONDS:-400}
 B2="--steps 12 --warmup 2 --no-cpu-baseline --no-extras --batches 3"
 cd /tmp && export TMPDIR=/tmp
@@ -29,7 +31,10 @@ for p in $PARTS; do case $p in
   tests) (cd $R && python -m pytest tests -q -m gpu 2>&1 | tail -5 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt) ;;
   c2) prof stats1 python $R/bench.py $B2 --streams 1; prof stats3 python $R/bench.py $B2 ;;
   c3) prof stats_c3 python $R/bench.py --config 3 --regions 2000 --steps 5 --no-extras; prof stats_c3e python $R/bench.py --config 3 --regions 2000 --steps 1 ;;
-  c4) prof stats_c4 python $R/bench.py --config 4 --regions 256 --steps 1 ;;
+  c4) prof stats_c4 python $R/bench.py --config 4 --regions 1024 --steps 1 --no-cpu-baseline ;;
+  pmc4) for c in FETCH_SIZE WRITE_SIZE; do pmc pmc4_$c $c python $R/bench.py --config 4 --regions 512 --steps 1 --no-cpu-baseline; done
+        pmc pmc4_SQ "SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES" python $R/bench.py --config 4 --regions 512 --steps 1 --no-cpu-baseline ;;
+  mapa) (cd $R && hipcc --offload-arch=gfx950 -O3 -o /tmp/dp_mapping_a tools/ubench/dp_mapping_a.hip -Lplatypus_amd -lplat_mi355x && LD_LIBRARY_PATH=platypus_amd /tmp/dp_mapping_a 400000 150 | tail -1 > $O/dp_mapping_a.json; cat $O/dp_mapping_a.json) ;;
   c5) prof stats_c5 python $R/bench.py --config 5 --windows 200 --steps 10 --warmup 2 ;;
   pmc2) for c in FETCH_SIZE WRITE_SIZE; do pmc pmc_$c $c python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras --batches 2 --streams 1; done
         pmc pmc_SQ "SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES" python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras --batches 2 --streams 1 ;;
@@ -47,6 +52,7 @@ for p in $PARTS; do case $p in
         for c in 3 4 5; do python bench.py --config $c > $O/bench_config$c.json 2> $O/bench_config$c.err; done
         python bench.py --gpus 2 --steps 100 --no-extras > $O/bench_2ranks.json 2> $O/bench_2ranks.err
         python bench.py --gpus 2 --config 4 --regions 1024 > $O/bench_c4_2ranks.json 2> $O/bench_c4_2ranks.err
+        PLAT_CALLER_WORKERS=3 PLAT_CALLER_LOADERS=2 taskset -c 0,1 python bench.py --config 4 --regions 1024 --steps 3 --no-cpu-baseline > $O/bench_config4_2cpus.json 2> $O/bench_config4_2cpus.err
         tail -c 600 $O/bench_line.json) ;;
   soaks) (cd $R
         python tools/ungapped_crosscheck.py $T 70000 --bigq 2>&1 | tail -1 > $O/soak_ungapped_bigq.json
@@ -59,6 +65,6 @@ cd $R
 python tools/profile_round_summary.py $O $TAG
 mkdir -p $O/out && cp profiles/${TAG}_* profiles/dp_traffic.json $O/out/ 2>/dev/null
 [ -s $O/pmc_seed.txt ] && { echo "# rocprofv3 --kernel-trace --pmc <C> (three passes: instruction mix | waits and busy | LDS) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --streams 1; mean per launch (SQ_*_CYCLES / ACTIVE / WAIT counters in units of 4 cycles)"; cat $O/pmc_seed.txt; } > $O/out/${TAG}_pmc_kernels.txt
-for f in $O/bench_*.json $O/soak_*.json; do [ -s "$f" ] && cp $f $O/out/${TAG}_$(basename $f); done     # the lines / soaks of THIS run
+for f in $O/bench_*.json $O/soak_*.json $O/dp_mapping_a.json; do [ -s "$f" ] && grep "^{" $f | tail -1 > $O/out/${TAG}_$(basename $f); done     # the lines / soaks of THIS run (gloo writes to stdout too: the JSON line only)
 find $O -name "*.csv" -size +1M -delete
 find $O -name "*.db" -size +1M -delete

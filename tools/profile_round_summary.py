@@ -58,13 +58,14 @@ def main(o, tag):
     stats(o + "/stats_c3", prof + "/" + tag + "_assemble_stats.txt", CMD + "--config 3 --regions 2000 --steps 5 --no-extras   (MI355X; config 3: 2000 assembly tiles per launch)")
     stats(o + "/stats_c3e", prof + "/" + tag + "_config3_end_to_end_stats.txt", CMD + "--config 3 --regions 2000 --steps 1   (MI355X; config 3 incl. END TO END: 2000 regions through the native region loop with --assemble=1, 32 regions per chunk)")
     stats(o + "/stats_c5", prof + "/" + tag + "_config5_stats.txt", CMD + "--config 5 --windows 200 --steps 10 --warmup 2   (MI355X; config 5: 200 windows x 100 samples per step)")
-    stats(o + "/stats_c4", prof + "/" + tag + "_config4_stats.txt", CMD + "--config 4 --regions 256 --steps 1   (MI355X; config 4: 256 regions x 100 kb streamed through the native region loop)")
+    stats(o + "/stats_c4", prof + "/" + tag + "_config4_stats.txt", CMD + "--config 4 --regions 1024 --steps 1 --no-cpu-baseline   (MI355X; config 4: 1024 regions x 100 kb, inputs resident in HBM, through the native region loop, 64 regions per chunk: one untimed counting pass + one timed pass = 32 chunks)")
     for f, dst in (("stats3", tag + "_bench_line_under_rocprof.json"), ("stats_c3e", tag + "_bench_config3_under_rocprof.json"), ("stats_c4", tag + "_bench_config4_under_rocprof.json"),
                    ("stats_c5", tag + "_bench_config5_under_rocprof.json")):
         p = o + "/" + f + ".json"
         if os.path.exists(p) and open(p).read().startswith("{"):
             open(os.path.join(prof, dst), "w").write(open(p).read())
     per = pmc(o, ["pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ"], prof + "/" + tag + "_pmc_hbm.txt", "--steps 4 --warmup 1 --no-cpu-baseline --no-extras --batches 2 --streams 1")
+    pmc(o, ["pmc4_FETCH_SIZE", "pmc4_WRITE_SIZE", "pmc4_SQ"], prof + "/" + tag + "_pmc_config4.txt", "--config 4 --regions 512 --steps 1 --no-cpu-baseline")
     per3 = pmc(o, ["pmc3_FETCH_SIZE", "pmc3_WRITE_SIZE", "pmc3_SQ", "pmc3_WAIT"], prof + "/" + tag + "_pmc_assemble.txt", "--config 3 --regions 2000 --steps 2 --no-extras")
     tf = prof + "/dp_traffic.json"
     d = json.load(open(tf)) if os.path.exists(tf) else {}
@@ -99,4 +100,4 @@ def main(o, tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r04")
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r05")
