@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <cstdarg>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -499,7 +500,9 @@ struct DeviceBatch {                                                       // wh
 // The likelihood part of a window batch whose arrays are on the device (db.wb all but the gathered reads): gather its reads from the chunk
 // table and run Haplotype.alignReads for all of it; full = also Population.setup, HapScore and EM.  Results are copied to the pinned host
 // mirrors; waits for them.
-static void runBatch(Slot& s, DeviceBatch& db, const Options& o, bool full, bool wantLoglik) {
+// `tail`: what the caller wants launched behind the batch on the same stream before the ONE wait (the posteriors: their inputs do not depend on
+// the batch's results, only their kernel does)
+static void runBatch(Slot& s, DeviceBatch& db, const Options& o, bool full, bool wantLoglik, const std::function<void(DeviceBatch&)>* tail = nullptr) {
     const size_t blob = (size_t)db.readBlob;
     s.g_seq.reserve(s.ctx, blob + PLAT_BLOB_PAD, false, true, s.stream); s.g_qual.reserve(s.ctx, blob + PLAT_BLOB_PAD, false, true, s.stream);
     const size_t nR = (size_t)db.nReads;
@@ -546,11 +549,12 @@ static void runBatch(Slot& s, DeviceBatch& db, const Options& o, bool full, bool
                                 s.o_freq.d, s.o_em.d, s.o_calls.d, s.o_iters.d, s.stream), "plat_em_window_batch");
         LO.download(s, s.a_wout);
     }
+    if (tail) (*tail)(db);
     s.sync("window batch");
 }
 
 // Upload a BatchBuilder and run it (runBatch)
-static DeviceBatch runWindows(Slot& s, const BatchBuilder& b, const Options& o, bool full, bool wantLoglik) {
+static DeviceBatch runWindows(Slot& s, const BatchBuilder& b, const Options& o, bool full, bool wantLoglik, const std::function<void(DeviceBatch&)>* tail = nullptr) {
     DeviceBatch db;
     db.nWindows = b.nWindows(); db.nHaps = b.nHaps(); db.nReads = b.nReads(); db.nInd = b.nInd; db.maxH = b.maxH;
     db.nPairs = b.pairoff.back(); db.nGl = b.gloff.back();
@@ -576,7 +580,7 @@ static DeviceBatch runWindows(Slot& s, const BatchBuilder& b, const Options& o, 
     wb.read_off = s.w_readoff.d; wb.read_kind = s.w_kind.d;
     db.hapbegin = s.w_hapbegin.d; db.gloff = s.w_gloff.d; db.ngood = s.w_ngood.d; db.segbegin = s.w_segbegin.d; db.src = s.w_src.d; db.readoff = s.w_readoff.d;
     db.maxHap = b.maxHap; db.maxRead = b.maxRead; db.maxR = b.maxR; db.hapBlob = (int64_t)b.hapseq.size(); db.readBlob = b.readoff.back();
-    runBatch(s, db, o, full, wantLoglik);
+    runBatch(s, db, o, full, wantLoglik, tail);
     return db;
 }
 

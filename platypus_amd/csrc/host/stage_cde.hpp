@@ -30,11 +30,51 @@ inline void Chunk::callWindows(std::vector<WindowWork*>& wins, bool fromDevice) 
         }
         b.endWindow();
     }
+    // D: distinct variants, masks, priors -> posteriors (Population.computeVariantPosteriors, cpopulation.pyx:596-621).  What the kernel is
+    // given depends on the windows alone: it is put together and launched behind the batch (same stream), and the batch's one wait covers it
+    size_t nV = 0;
+    const std::function<void(DeviceBatch&)> posteriors = [&](DeviceBatch& dbb) {
+        std::vector<int32_t> pwin;
+        std::vector<int64_t> poff{0};
+        std::vector<uint8_t> pmask;
+        std::vector<double> pprior;
+        for (WindowWork* w : wins) {
+            PROF("s5.build");
+            RegionWork& r = *regions[(size_t)regionSlot(w->region)];
+            w->distinct.clear();
+            for (const Hap& h : w->haps)
+                for (Variant* v : h.variants) if (!contains(w->distinct, v)) w->distinct.push_back(v);
+            for (Variant* v : w->distinct) {
+                pwin.push_back(w->bw);
+                for (const Hap& h : w->haps) pmask.push_back(contains(h.variants, v) ? 1 : 0);
+                poff.push_back((int64_t)pmask.size());
+                { PROF("s5.prior"); pprior.push_back(calculatePrior(*v, r.fa)); }
+            }
+            if (o.outputRefCalls)                                       // pop.calculatePosterior(v, 1) of outputRefCall: the window's candidates under a flat prior
+                for (Variant* v : w->vars) {
+                    pwin.push_back(w->bw);
+                    for (const Hap& h : w->haps) pmask.push_back(contains(h.variants, v) ? 1 : 0);
+                    poff.push_back((int64_t)pmask.size());
+                    pprior.push_back(0.5);
+                }
+        }
+        nV = pwin.size();
+        if (!nV) return;
+        Layout L;
+        L.add(z.p_win, nV); L.add(z.p_off, nV + 1); L.add(z.p_mask, pmask.size()); L.add(z.p_prior, nV);
+        L.commit(z, z.a_pin);
+        fill(z, z.p_win, pwin); fill(z, z.p_off, poff); fill(z, z.p_mask, pmask); fill(z, z.p_prior, pprior);
+        z.p_post.reserve(z.ctx, nV + 1);
+        L.upload(z, z.a_pin);
+        ck(plat_variant_posterior_batch(z.ctx, (int)nV, nInd, dbb.maxH, dbb.hapbegin, dbb.gloff, dbb.ngood, z.o_gl.d, z.o_freq.d, z.p_win.d,
+                                        z.p_off.d, z.p_mask.d, z.p_prior.d, z.p_post.d, z.stream), "plat_variant_posterior_batch");
+        z.down(z.p_post, nV);
+    };
     DeviceBatch db;
-    if (fromDevice) { PROF("s4.runBatch"); db = devBatch; runBatch(z, db, o, true, false); }
+    if (fromDevice) { PROF("s4.runBatch"); db = devBatch; runBatch(z, db, o, true, false, &posteriors); }
     else {
         PROF("s4.runWindows");
-        db = runWindows(z, b, o, true, false);
+        db = runWindows(z, b, o, true, false, &posteriors);
         for (WindowWork* w : wins) w->hapBegin = b.hapbegin[(size_t)w->bw];
     }
     {
@@ -44,45 +84,6 @@ inline void Chunk::callWindows(std::vector<WindowWork*>& wins, bool fromDevice) 
         st.n_pairs += np;                                               // (of the windows CALLED from this batch)
     }
     lap(4);
-
-    // D: distinct variants, masks, priors -> posteriors (Population.computeVariantPosteriors, cpopulation.pyx:596-621)
-    std::vector<int32_t> pwin;
-    std::vector<int64_t> poff{0};
-    std::vector<uint8_t> pmask;
-    std::vector<double> pprior;
-    for (WindowWork* w : wins) {
-        PROF("s5.build");
-        RegionWork& r = *regions[(size_t)regionSlot(w->region)];
-        w->distinct.clear();
-        for (const Hap& h : w->haps)
-            for (Variant* v : h.variants) if (!contains(w->distinct, v)) w->distinct.push_back(v);
-        for (Variant* v : w->distinct) {
-            pwin.push_back(w->bw);
-            for (const Hap& h : w->haps) pmask.push_back(contains(h.variants, v) ? 1 : 0);
-            poff.push_back((int64_t)pmask.size());
-            { PROF("s5.prior"); pprior.push_back(calculatePrior(*v, r.fa)); }
-        }
-        if (o.outputRefCalls)                                           // pop.calculatePosterior(v, 1) of outputRefCall: the window's candidates under a flat prior
-            for (Variant* v : w->vars) {
-                pwin.push_back(w->bw);
-                for (const Hap& h : w->haps) pmask.push_back(contains(h.variants, v) ? 1 : 0);
-                poff.push_back((int64_t)pmask.size());
-                pprior.push_back(0.5);
-            }
-    }
-    const size_t nV = pwin.size();
-    if (nV) {
-        Layout L;
-        L.add(z.p_win, nV); L.add(z.p_off, nV + 1); L.add(z.p_mask, pmask.size()); L.add(z.p_prior, nV);
-        L.commit(z, z.a_pin);
-        fill(z, z.p_win, pwin); fill(z, z.p_off, poff); fill(z, z.p_mask, pmask); fill(z, z.p_prior, pprior);
-        z.p_post.reserve(z.ctx, nV + 1);
-        L.upload(z, z.a_pin);
-        ck(plat_variant_posterior_batch(z.ctx, (int)nV, nInd, db.maxH, db.hapbegin, db.gloff, db.ngood, z.o_gl.d, z.o_freq.d, z.p_win.d,
-                                        z.p_off.d, z.p_mask.d, z.p_prior.d, z.p_post.d, z.stream), "plat_variant_posterior_batch");
-        z.down(z.p_post, nV);
-        z.sync("posteriors");
-    }
     lap(5);
     // varsByPos, INFO variants (getHaplotypeInfo order, vcfutils.pyx:1118-1152), read statistics and call sites of the live windows
     std::vector<int32_t> svw, spos, smin, smax, snadd, snrem, sgb, sge, sbb, sbe, kwin, knvar, kvih, kref;
