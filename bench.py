@@ -462,7 +462,7 @@ def main():
         from types import SimpleNamespace
         from tools import bench_other
         try:
-            wgs = bench_other.line_config4(SimpleNamespace(regions=a.regions, steps=3, strong=a.strong, no_cpu_baseline=True), rk, resident=True)
+            wgs = bench_other.line_config4(SimpleNamespace(regions=a.regions, steps=5, warmup=2, strong=a.strong, no_cpu_baseline=True), rk, resident=True)
         except Exception as exc:                # pragma: no cover
             wgs = {"error": repr(exc)[:300]}
     if rank == 0:

@@ -186,7 +186,7 @@ def run(a, rk):
 # ---- config 4 -----------------------------------------------------------------------------------------------------------------
 
 def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_samples=1, pin=True, lib=None, region_kw=None, rk=None, packed=True,
-            loaders=None, warm_regions=None, options_kw=None, resident=False, job_regions=None):
+            loaders=None, warm_regions=None, options_kw=None, resident=False, job_regions=None, warm_rounds=2):
     """The region pipeline end to end, sustained: the regions `indices` of the job's region list are LOADED ON DEMAND by a region source
     (tools/synth: generated from seed (+) region index inside the library's loader threads into a bounded set of pinned slots -- where the
     reference's BAM loader stands) and called through the native region loop (plat_call_regions_stream: host threads + every device stage
@@ -243,7 +243,9 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
         per_rank = [[(("r%d" % g), flank0, flank0 + region_len) for g in job_regions[r::world]] for r in range(world)]
         xch = sharding.RegionTextExchange(per_rank, dist=getattr(rk, "dist", None), device=getattr(rk, "coll_device", None), lib=lib,
                                           device_index=getattr(rk, "dev_index", 0))
-    for rep in range(repeats + (1 if xch is not None else 0)):               # (with the exchange: one untimed round first -- its pinned block, its kernel)
+    nplain = (max(1, min(int(warm_rounds), 3)) if xch is not None else 0)     # untimed rounds of the TIMED shape behind the counting pass (a run is
+                                                                              # 0.1 s: allocator arenas, clocks and the exchange's pinned block settle over the first two or three)
+    for rep in range(repeats + nplain):
         opts = default_options(**(options_kw or {}))
         rk.barrier()
         t0 = time.perf_counter()
@@ -260,7 +262,7 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
         t2 = time.perf_counter()
         rk.barrier()
         st = dict(nc.stats)
-        if xch is not None and rep == 0:
+        if rep < nplain:
             continue
         runs.append((t2 - t0, t1 - t0))
         gather = dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=nranks, how="region blocks" if xch is not None else "line merge",
@@ -273,7 +275,7 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
     return dict(T=T, T_call=float(np.mean([r[1] for r in runs])), T_runs=[r[0] for r in runs], text=text, merged=merged, gather=gather, stats=st,
                 regions=len(indices), warm_regions=nwarm, region_len=region_len, reads=int(st["n_reads"]), windows=int(st["n_windows"]), records=int(st["n_records"]),
                 planted=int(planted), workers=workers, per_chunk=per_chunk, loaders=loaders, n_slots=n_slots, packed=packed, source_phases=phases,
-                input_bytes=int(st["input_bytes"]), counted=counted, resident=bool(resident))
+                input_bytes=int(st["input_bytes"]), counted=counted, resident=bool(resident), warm_rounds_plain=nplain)
 
 
 def config4_gcups(counted, regions, T):
@@ -346,9 +348,10 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
     per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "64" if resident else "16"))
     pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1" and lib is None
     packed = os.environ.get("PLAT_CALLER_PACKED", "1") == "1"
-    repeats = max(1, min(a.steps, 3))                                        # the line is the MEAN over the runs
+    repeats = max(1, min(a.steps, 8))                                        # the line is the MEAN over the runs (a run is ~0.1 s: up to eight of them)
     r = config4(rk.dev_index, mine, region_len, workers, per_chunk, repeats=repeats, pin=pin, lib=lib, region_kw=region_kw, rk=rk, packed=packed,
-                resident=resident, job_regions=None if os.environ.get("PLAT_BENCH_LINE_MERGE") == "1" else list(range(total)))
+                resident=resident, job_regions=None if os.environ.get("PLAT_BENCH_LINE_MERGE") == "1" else list(range(total)),
+                warm_rounds=getattr(a, "warmup", 2) or 2)
     cnt = r.get("counted") or {}
     ckeys = ("cells_reference", "cells_launched", "n_dp_reference", "n_dp_launched", "n_pairs", "regions", "n_align_batches", "align_hap_bytes", "align_read_bytes",
              "align_reads", "align_dp_bytes", "seconds_kernel_seed", "seconds_kernel_dp", "seconds_kernel_sweep", "seconds_kernel_pairs")
@@ -357,7 +360,7 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
     counted_all = dict(zip(ckeys, red[6:]))                                   # summed over the ranks
     st = r["stats"]
     line = {"metric": "variant windows/sec end to end (reads in host memory -> VCF record text)", "value": wins / T, "unit": "windows/s",
-            "n_gpus": world, "steps": repeats, "warmup": 1, "ms_per_step": 1e3 * T, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "n_gpus": world, "steps": repeats, "warmup": 1 + r.get("warm_rounds_plain", 0), "ms_per_step": 1e3 * T, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
             "config": {"workload": "BASELINE config 4: %d regions x %d bp for the whole job, 30x 150 bp reads, SNPs 1e-3 + indels 1e-4, one sample, %s; step = "
                                    "candidates -> windows -> haplotypes -> likelihoods / EM / posteriors -> INFO / FILTER -> record text for all "
