@@ -137,12 +137,13 @@ def config3_end_to_end(device, n_regions, rk=None, first=0, lib=None, region_kw=
     """BASELINE config 3 END TO END: indel-heavy regions (4.5 kb contig = 1.5 kb region +- 1.5 kb, 1-3 indels of 1..60 bases +
     0-3 SNPs, 250 bp reads at 30x, 5 % of the bases below Q20) through the native region loop with --assemble=1: assembler tiles of every
     chunk in one plat_assemble_batch, their variants merged with the BAM candidates, then the called windows through the likelihoods at
-    250 bp (buf = 500), EM, posteriors, records.  Regions are loaded on demand (tools/synth)."""
+    250 bp (buf = 500), EM, posteriors, records.  Inputs resident in HBM (round 5; PLAT_CALLER_RESIDENT3=0: loaded on demand by tools/synth)."""
     from platypus_amd import fastcaller as F
     workers = int(os.environ.get("PLAT_CALLER_WORKERS", "16"))
     kw = dict(flank=1500, read_len=250, model=CONFIG3_MODEL, **(region_kw or {}))
-    r = config4(device, range(first, first + n_regions), 1500, workers, int(os.environ.get("PLAT_CALLER_CHUNK3", "32")), repeats=1, region_kw=kw, rk=rk,
-                options_kw=dict(assemble=1), lib=lib, pin=lib is None)
+    resident = lib is None and os.environ.get("PLAT_CALLER_RESIDENT3", "1") == "1"      # inputs resident in HBM, as on the config-4 line (0: loaded on demand, rounds 2-4)
+    r = config4(device, range(first, first + n_regions), 1500, workers, int(os.environ.get("PLAT_CALLER_CHUNK3", "64" if resident else "32")), repeats=3 if resident else 1,
+                region_kw=kw, rk=rk, options_kw=dict(assemble=1), lib=lib, pin=lib is None, resident=resident)
     st, T = r["stats"], r["T"]
     return dict(regions=r["regions"], tiles=int(st["n_assembly_tiles"]), assembler_variants=int(st["n_assembler_variants"]), planted_variants=r["planted"],
                 windows=r["windows"], records=r["records"], reads=r["reads"], pairs=int(st["n_pairs"]), timed_s=T,
@@ -152,6 +153,7 @@ def config3_end_to_end(device, n_regions, rk=None, first=0, lib=None, region_kw=
                            "runs at least one DP for every pair it does not skip",
                 host_seconds_per_region=st["seconds_host"] / r["regions"], device_wait_seconds_per_region=st["seconds_device_wait"] / r["regions"],
                 assemble_seconds_per_region=st["seconds_assemble"] / r["regions"], host_threads=r["workers"], regions_per_chunk=r["per_chunk"],
+                inputs="resident in HBM" if r["resident"] else "loaded on demand inside the timed region", timed_s_runs=r["T_runs"],
                 text=F.text_bytes(r["text"]).decode("ascii"))
 
 
@@ -243,7 +245,7 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
         per_rank = [[(("r%d" % g), flank0, flank0 + region_len) for g in job_regions[r::world]] for r in range(world)]
         xch = sharding.RegionTextExchange(per_rank, dist=getattr(rk, "dist", None), device=getattr(rk, "coll_device", None), lib=lib,
                                           device_index=getattr(rk, "dev_index", 0))
-    nplain = (max(1, min(int(warm_rounds), 3)) if xch is not None else 0)     # untimed rounds of the TIMED shape behind the counting pass (a run is
+    nplain = (max(1, min(int(warm_rounds), 3)) if (xch is not None or resident) else 0)     # untimed rounds of the TIMED shape behind the counting pass (a run is
                                                                               # 0.1 s: allocator arenas, clocks and the exchange's pinned block settle over the first two or three)
     for rep in range(repeats + nplain):
         opts = default_options(**(options_kw or {}))
