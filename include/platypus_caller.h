@@ -156,6 +156,8 @@ typedef struct plat_caller_stats {
      * and single windows it left to the host's code (cohorts, assembly and reference-call runs never go to the device: not counted) */
     int64_t n_regions_stage_b_device, n_regions_stage_b_host, n_windows_stage_b_host;
     int64_t n_regions_dict_replay_device;   /* of the device's regions: those whose order needed the Python-2 dictionaries replayed (on the device) */
+    double seconds_worker_cpu;              /* sum over worker threads of the CPU time (CLOCK_THREAD_CPUTIME_ID) their chunks took: next to seconds_host (wall
+                                             * time outside waits) it says whether the workers had their cores to themselves */
 } plat_caller_stats;
 
 typedef struct plat_caller plat_caller;

@@ -7,6 +7,7 @@
 #include <map>
 #endif
 #include <chrono>
+#include <time.h>
 #include <condition_variable>
 #include <cstdarg>
 #include <deque>
@@ -25,6 +26,7 @@ namespace plathost {
 
 typedef std::chrono::steady_clock Clock;
 static inline double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+static inline double threadCpuSeconds() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 #ifdef PLAT_HOSTPROF                                                  // (local measurement builds only: cycle counts of named scopes)
 static const char* g_profName[256];
 static std::atomic<unsigned long long> g_profCyc[256], g_profCalls[256];

@@ -98,6 +98,7 @@ struct Chunk {
         std::unique_lock<std::mutex> oneAtATime(countMutex, std::defer_lock);
         if (s.countCells) oneAtATime.lock();
         const auto t0 = Clock::now();
+        const double cpu0 = threadCpuSeconds();
         double wait0 = s.t_wait;
         mark = t0; waitMark = wait0;
         uploadReads();
@@ -205,7 +206,7 @@ struct Chunk {
         const double total = secs(t0, Clock::now()), waited = s.t_wait - wait0;
         std::lock_guard<std::mutex> g(stMutex);
         st.n_windows += nWin; st.n_variants += nVar; st.n_candidate_records += nCand; st.n_records += nRec; st.n_refcall_records += nRef;
-        st.seconds_host += total - waited; st.seconds_device_wait += waited;
+        st.seconds_host += total - waited; st.seconds_device_wait += waited; st.seconds_worker_cpu += threadCpuSeconds() - cpu0;
         for (int k = 0; k < 8; ++k) { st.seconds_stage[k] += stage[k]; g_stageWait[k] += stageWait[k]; }
         g_stageWait[8] += total - waited; g_stageWait[9] += waited;
     }

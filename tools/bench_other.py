@@ -8,6 +8,7 @@ config-2 line), and the default run carries a compact summary of each under `oth
 import json
 import os
 import sys
+import resource
 import time
 
 import numpy as np
@@ -250,6 +251,7 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
     for rep in range(repeats + nplain):
         opts = default_options(**(options_kw or {}))
         rk.barrier()
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         text = nc.call_stream(len(indices), src.load_fn, src.h, names, opts, n_slots, loaders, raw="view")    # the native block itself: no copy, no decode / encode passes
         t1 = time.perf_counter()
@@ -262,11 +264,12 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
             if got is not None:
                 merged = F.merge_record_texts(got, lib=lib, raw="view")       # ... merged there by (chromosome, position), runner.py:301-352
         t2 = time.perf_counter()
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
         rk.barrier()
         st = dict(nc.stats)
         if rep < nplain:
             continue
-        runs.append((t2 - t0, t1 - t0))
+        runs.append((t2 - t0, t1 - t0, ru1.ru_utime - ru0.ru_utime, ru1.ru_stime - ru0.ru_stime))
         gather = dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=nranks, how="region blocks" if xch is not None else "line merge",
                       records=bytes(memoryview(merged)).count(b"\n") if merged is not None else None)
     planted = (src.planted - planted0) // max(1, repeats)
@@ -274,7 +277,8 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
     nc.close()
     src.close()
     T = float(np.mean([r[0] for r in runs]))
-    return dict(T=T, T_call=float(np.mean([r[1] for r in runs])), T_runs=[r[0] for r in runs], text=text, merged=merged, gather=gather, stats=st,
+    return dict(T=T, T_call=float(np.mean([r[1] for r in runs])), T_runs=[r[0] for r in runs], cpu_user_s=float(np.mean([r[2] for r in runs])),
+                cpu_sys_s=float(np.mean([r[3] for r in runs])), text=text, merged=merged, gather=gather, stats=st,
                 regions=len(indices), warm_regions=nwarm, region_len=region_len, reads=int(st["n_reads"]), windows=int(st["n_windows"]), records=int(st["n_records"]),
                 planted=int(planted), workers=workers, per_chunk=per_chunk, loaders=loaders, n_slots=n_slots, packed=packed, source_phases=phases,
                 input_bytes=int(st["input_bytes"]), counted=counted, resident=bool(resident), warm_rounds_plain=nplain)
@@ -343,7 +347,10 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
     #  16 CPUs of a one-GPU box: 1.21 M windows/s against 1.05 M with 10 x 6; 2 CPUs: 0.26 M, 4 CPUs: 0.43 M -- host stages 0.6 ms per region)
     # (round 5, resident: one worker per CPU -- 16 x 64 measured 2.40 M windows/s against 2.15 M with 14 workers; their host stages are
     #  0.23 ms per region now and a worker waiting for the device sleeps)
-    workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(16, cpus if resident else cpus * 5 // 8)))))
+    # (later in round 5: plat_stream_sync naps between polls of its event instead of the runtime's blocking wait, which burned 0.085 ms of CPU
+    #  per region while "blocked" -- a waiting worker now costs nothing, so there are three workers for two CPUs: 24 x 64 with 8 hardware
+    #  queues measured 3.4-3.5 M windows/s against 3.2-3.3 M with 16; 2 CPUs: 3 workers 0.71 M)
+    workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(24, cpus * 3 // 2 if resident else cpus * 5 // 8)))))
     os.environ.setdefault("PLAT_CALLER_LOADERS", str(max(2, min(12, cpus // 2))))
     # (round 5: stage B on the device -- the host no longer pays per region for a chunk's size, and the kernels of a chunk are latency bound:
     #  64 regions per chunk measured 2.4 M windows/s against 1.25 M with 8, and a k_dp_jobs launch then holds ~36 k DPs)
@@ -377,8 +384,11 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
                        "regions": total, "region_len": region_len, "sharding": "region i -> rank i % N, records gathered to rank 0 and merged by (chrom, pos)",
                        "read_encoding": "packed: one byte per base (2-bit base | quality << 2)" if r["packed"] else "ASCII bases + quality bytes"},
             "regions_per_sec": regs / T, "reads_per_sec": reads / T, "records": recs, "windows": wins, "regions": regs, "timed_s": T,
-            "timed_s_runs": r["T_runs"], "planted_variants": r["planted"], "seconds_calls_mean_over_ranks": tcall / world,
+            "timed_s_runs": r["T_runs"], "process_cpu_seconds_per_run": {"user": r["cpu_user_s"], "sys": r["cpu_sys_s"],
+                                                                           "cpus_busy": (r["cpu_user_s"] + r["cpu_sys_s"]) / r["T"]},
+            "planted_variants": r["planted"], "seconds_calls_mean_over_ranks": tcall / world,
             "host_seconds_per_region": st["seconds_host"] / max(1, r["regions"]),
+            "worker_cpu_seconds_per_region": st.get("seconds_worker_cpu", 0.0) / max(1, r["regions"]),
             "device_wait_seconds_per_region": st["seconds_device_wait"] / max(1, r["regions"]),
             "source_seconds_per_region": st["seconds_load"] / max(1, r["regions"]), "source_phase_seconds_per_region": r["source_phases"],
             "worker_seconds_waiting_for_the_source_per_region": st["seconds_source_wait"] / max(1, r["regions"]),
