@@ -361,3 +361,10 @@ cdef extern from "platypus_mi355x.h":
     int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* batch, int kmer_size, int min_qual, int min_weight, int no_cycles,
                             int max_vars_per_region, int blob_per_region, int32_t* var_count, int32_t* var_pos, int32_t* var_nrem,
                             int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob, int32_t* status, void* stream) nogil
+    ctypedef struct plat_assembly_hints:
+        int32_t max_ref_len
+        int32_t max_reads_per_region
+        int64_t max_positions
+    int plat_assemble_batch_async(plat_ctx* ctx, const plat_assembly_batch* batch, const plat_assembly_hints* hints, int kmer_size, int min_qual,
+                                  int min_weight, int no_cycles, int max_vars_per_region, int blob_per_region, int32_t* var_count, int32_t* var_pos,
+                                  int32_t* var_nrem, int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob, int32_t* status, void* stream) nogil

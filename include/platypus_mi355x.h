@@ -562,6 +562,20 @@ int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* batch, int kme
                         int min_weight, int no_cycles, int max_vars_per_region, int blob_per_region,
                         int32_t* var_count, int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd,
                         int32_t* var_off, uint8_t* var_blob, int32_t* status, void* stream);
+/* The same without the read-back that sizes the graphs: plat_assemble_batch learns the longest reference window, the most reads
+ * and the most k-mer positions of a tile from the device and WAITS for them; a caller that built the batch knows them.  Nothing
+ * is read back and the call never waits.  hints: max_ref_len >= ref_off[g+1] - ref_off[g], max_reads_per_region >=
+ * reg_read_begin[g+1] - reg_read_begin[g], max_positions >= reference bytes + read bytes + 2 * reads + 2 of every tile g.  The device
+ * checks them: hints that do not cover the batch give status[g] = PLAT_ERR_BAD_HINTS for EVERY tile (PLAT_ERR_BAD_INPUT for offsets
+ * out of order) and no variants.                                                                     */
+typedef struct plat_assembly_hints {
+    int32_t max_ref_len, max_reads_per_region;
+    int64_t max_positions;
+} plat_assembly_hints;
+int plat_assemble_batch_async(plat_ctx* ctx, const plat_assembly_batch* batch, const plat_assembly_hints* hints, int kmer_size,
+                              int min_qual, int min_weight, int no_cycles, int max_vars_per_region, int blob_per_region,
+                              int32_t* var_count, int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd,
+                              int32_t* var_off, uint8_t* var_blob, int32_t* status, void* stream);
 
 #ifdef __cplusplus
 }

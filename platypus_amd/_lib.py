@@ -63,6 +63,10 @@ class AssemblyBatch(C.Structure):
                 ("read_off", C.c_void_p)]
 
 
+class AssemblyHints(C.Structure):
+    _fields_ = [("max_ref_len", C.c_int32), ("max_reads_per_region", C.c_int32), ("max_positions", C.c_int64)]
+
+
 class CandidateBatch(C.Structure):
     _fields_ = [("n_regions", C.c_int32), ("n_reads", C.c_int32), ("ref_seq", C.c_void_p), ("ref_off", C.c_void_p),
                 ("ref_seq_start", C.c_void_p), ("contig_len", C.c_void_p), ("read_seq", C.c_void_p),
@@ -143,6 +147,9 @@ SIGNATURES = {
     "plat_assemble_batch": (C.c_int, [C.c_void_p, C.POINTER(AssemblyBatch), C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "plat_assemble_batch_async": (C.c_int, [C.c_void_p, C.POINTER(AssemblyBatch), C.POINTER(AssemblyHints), C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -52,7 +52,13 @@ struct Chunk {
     // (assembler.pyx:1391-1425: good reads between the window pointers, badReads / brokenMates if the options say so, QCFail reads never)
     // gathered from the chunk's device table; ALL tiles of the chunk in one plat_assemble_batch
     struct Tile { int region, assemStart, assemEnd, refStart; };
-    void assembleTiles();
+    void assembleLaunch();
+    void assembleEnqueue();
+    void assembleCollect();
+    std::vector<Tile> asmTiles;
+    plat_assembly_batch asmBatch;
+    plat_assembly_hints asmHints;
+    int asmN = 0;
     int asmMaxVars = 64, asmBlob = 4096;
 
     // -- B1: candidates of one region -> merged, per-sample support filter, left-normalised, filtered (variantcaller.pyx:439-531)
@@ -104,8 +110,9 @@ struct Chunk {
         uploadReads();
         lap(0);
         deviceB = eligibleDeviceB();
+        assembleLaunch();
         if (o.getVariantsFromBAMs) scanCandidates();
-        assembleTiles();
+        assembleCollect();
         lap(1);
         if (deviceB) stageBFromDevice();
         else {

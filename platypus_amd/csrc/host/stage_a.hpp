@@ -218,8 +218,11 @@ inline void Chunk::scanCandidates() {
             if (!hostTally) {
                 lmLayout = LM;
                 if (deviceB) launchStageB();
+                // (host stage B may have to replay a region's dictionaries from the scan's records: a chunk of small regions brings them
+                //  along now -- one copy behind the merge's -- instead of two copies and a wait per region that needs them later)
+                const bool recordsAlong = !deviceB && LO.total <= ((size_t)4 << 20);
                 if (deviceB) LM.downloadFirst(z, z.a_mout, 1);                              // (only the counts: the candidates stay on the device)
-                else LM.download(z, z.a_mout);
+                else { LM.download(z, z.a_mout); if (recordsAlong) LO.download(z, z.a_cout); }
                 z.sync("candidate scan");
                 for (int g = 0; g < nScan; ++g) {
                     const int st_ = z.m_n.h[2 * g + 1];
@@ -227,7 +230,7 @@ inline void Chunk::scanCandidates() {
                     if (st_ <= -(1 << 20)) need = std::max(need, -st_ - (1 << 20));
                     else if (st_ != 0) hostTally = true;                // more distinct records / candidates than the kernel takes
                 }
-                if (!need && !hostTally) break;
+                if (!need && !hostTally) { recordsOnHost = recordsAlong; break; }
                 if (need) { maxPerRead = need; continue; }
             }
         }
@@ -244,14 +247,19 @@ inline void Chunk::scanCandidates() {
     if (hostTally) deviceB = false;
 }
 
-inline void Chunk::assembleTiles() {
+// assemble=1: the tiles of every region of the chunk in ONE assembler launch (variantcaller.pyx:496-519).  Two halves: assembleLaunch() puts the
+// batch together, sizes it itself (plat_assemble_batch_async: no read-back, no wait) and leaves launch + download on the stream BEFORE the
+// candidate scan's work, so that the scan's one wait covers the assembler too; assembleCollect() turns the tuples into Variants.
+inline void Chunk::assembleLaunch() {
+    asmN = 0;
     if (!o.assemble) return;
     Slot& z = s;
     const auto t0 = Clock::now();
     const int size = o.assemblyRegionSize;
     if (size <= 0) throw DeviceError(PLAT_ERR_INVALID, "assemblyRegionSize");
     const int shift = std::max(100, std::min(1000, size / 2));
-    std::vector<Tile> tiles;
+    std::vector<Tile>& tiles = asmTiles;
+    tiles.clear();
     std::vector<int64_t> refoff{0}, roff{0};
     std::vector<int32_t> refstart, astart, aend, rbegin{0}, src;
     std::string blob;
@@ -320,20 +328,47 @@ inline void Chunk::assembleTiles() {
         z.as_pos.reserve(z.ctx, nR + 1, false); z.as_end.reserve(z.ctx, nR + 1, false); z.as_flags.reserve(z.ctx, nR + 1, false); z.as_mapq.reserve(z.ctx, nR + 1, false);
         if (nR) ck(plat_gather_reads(z.ctx, (int64_t)nR, z.as_src.d, z.as_roff.d, z.t_seq.d, z.t_qual.d, z.t_off.d, z.t_pos.d, z.t_end.d, z.t_mapq.d, z.t_flags.d,
                                      z.as_seq.d, z.as_qual.d, z.as_pos.d, z.as_end.d, z.as_mapq.d, z.as_flags.d, z.stream), "plat_gather_reads(assembler)");
-        plat_assembly_batch ab;
+        plat_assembly_batch& ab = asmBatch;
         memset(&ab, 0, sizeof ab);
         ab.n_regions = nT; ab.n_reads = (int32_t)nR;
         ab.ref_seq = z.as_ref.d; ab.ref_off = z.as_refoff.d; ab.ref_start = z.as_refstart.d; ab.assem_start = z.as_astart.d; ab.assem_end = z.as_aend.d;
         ab.reg_read_begin = z.as_rbegin.d; ab.read_seq = z.as_seq.d; ab.read_qual = z.as_qual.d; ab.read_off = z.as_roff.d;
+        memset(&asmHints, 0, sizeof asmHints);
+        for (int g = 0; g < nT; ++g) {
+            const int64_t rl = refoff[(size_t)g + 1] - refoff[(size_t)g], nr = rbegin[(size_t)g + 1] - rbegin[(size_t)g];
+            const int64_t bytes = roff[(size_t)rbegin[(size_t)g + 1]] - roff[(size_t)rbegin[(size_t)g]];
+            asmHints.max_ref_len = std::max<int32_t>(asmHints.max_ref_len, (int32_t)rl);
+            asmHints.max_reads_per_region = std::max<int32_t>(asmHints.max_reads_per_region, (int32_t)nr);
+            asmHints.max_positions = std::max<int64_t>(asmHints.max_positions, rl + 2 + bytes + 2 * nr);
+        }
+        asmN = nT;
+        assembleEnqueue();
+    }
+    std::lock_guard<std::mutex> g(stMutex);
+    st.seconds_assemble += secs(t0, Clock::now());
+}
+
+inline void Chunk::assembleEnqueue() {
+    Slot& z = s;
+    const int nT = asmN;
+    Layout LO;
+    LO.add(z.as_cnt, (size_t)nT); LO.add(z.as_status, (size_t)nT); LO.add(z.as_vpos, (size_t)nT * asmMaxVars); LO.add(z.as_nrem, (size_t)nT * asmMaxVars);
+    LO.add(z.as_nadd, (size_t)nT * asmMaxVars); LO.add(z.as_off, (size_t)nT * asmMaxVars); LO.add(z.as_blob, (size_t)nT * asmBlob);
+    LO.commit(z, z.a_asout);
+    ck(plat_assemble_batch_async(z.ctx, &asmBatch, &asmHints, o.assemblerKmerSize, o.minBaseQual, o.minReads * o.minBaseQual, o.noCycles, asmMaxVars, asmBlob,
+                                 z.as_cnt.d, z.as_vpos.d, z.as_nrem.d, z.as_nadd.d, z.as_off.d, z.as_blob.d, z.as_status.d, z.stream), "plat_assemble_batch_async");
+    LO.download(z, z.a_asout);
+}
+
+inline void Chunk::assembleCollect() {
+    if (!o.assemble || asmN == 0) return;
+    Slot& z = s;
+    const auto t0 = Clock::now();
+    const int nT = asmN;
+    const std::vector<Tile>& tiles = asmTiles;
+    {
         for (;;) {                                                       // room per tile grows until every tile's variants fit
-            Layout LO;
-            LO.add(z.as_cnt, (size_t)nT); LO.add(z.as_status, (size_t)nT); LO.add(z.as_vpos, (size_t)nT * asmMaxVars); LO.add(z.as_nrem, (size_t)nT * asmMaxVars);
-            LO.add(z.as_nadd, (size_t)nT * asmMaxVars); LO.add(z.as_off, (size_t)nT * asmMaxVars); LO.add(z.as_blob, (size_t)nT * asmBlob);
-            LO.commit(z, z.a_asout);
-            ck(plat_assemble_batch(z.ctx, &ab, o.assemblerKmerSize, o.minBaseQual, o.minReads * o.minBaseQual, o.noCycles, asmMaxVars, asmBlob, z.as_cnt.d,
-                                   z.as_vpos.d, z.as_nrem.d, z.as_nadd.d, z.as_off.d, z.as_blob.d, z.as_status.d, z.stream), "plat_assemble_batch");
-            LO.download(z, z.a_asout);
-            z.sync("assembler");
+            z.sync("assembler");                                         // (already over when the scan's wait covered it)
             bool over = false;
             for (int g = 0; g < nT; ++g) {
                 if (z.as_status.h[g] == PLAT_ERR_OVERFLOW) over = true;
@@ -342,6 +377,7 @@ inline void Chunk::assembleTiles() {
             if (!over) break;
             if (asmMaxVars >= (1 << 14)) throw DeviceError(PLAT_ERR_OVERFLOW, "plat_assemble_batch(tile)");
             asmMaxVars *= 4; asmBlob *= 4;
+            assembleEnqueue();
         }
         int64_t nv = 0;
         for (int g = 0; g < nT; ++g) {                                   // per tile in the reference's sorted() order (the device's), tile after tile

@@ -482,8 +482,14 @@ __device__ unsigned long long g_asm_ticks[16];
 __global__ void __launch_bounds__(ASM_THREADS)
 k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int max_reads, int32_t* var_count,
            int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob,
-           int32_t* status)
+           int32_t* status, const long long* __restrict__ verdict)
 {
+    // (plat_assemble_batch_async: the sizes came from the caller instead of a read-back; k_asm_check left its verdict here -- a batch that
+    //  does not fit them is refused as a whole, tile by tile, before anything is carved out of the scratch)
+    if (verdict && verdict[3] != 0) {
+        for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < b.n_regions; g += gridDim.x * blockDim.x) { status[g] = (int)verdict[3]; var_count[g] = 0; }
+        return;
+    }
     __shared__ int s_n, s_ntasks, s_err, s_cycle, s_k, s_pool, s_distinct, s_lds, s_nrefnodes, s_nreadnodes, s_nv;
     extern __shared__ __attribute__((aligned(16))) int s_tab[];  // [ASM_LDS_SLOTS] the k-mer table, then the node words, then the reference
     unsigned* s_first = (unsigned*)(s_tab + ASM_LDS_SLOTS);      // [ASM_LDS_NODES] min touch code (2*ticket + isEnd)
@@ -1756,9 +1762,27 @@ __global__ void k_asm_sizes(plat_assembly_batch b, long long* out /* [0]=max ref
     atomicMax((unsigned long long*)&out[2], (unsigned long long)pos);
 }
 
+// the caller's sizes against the batch (plat_assemble_batch_async): out[3] = 0 or the error every tile is refused with
+__global__ void k_asm_check(plat_assembly_batch b, long long max_ref, long long max_reads, long long max_pos, long long* out)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= b.n_regions) return;
+    const long long rl = b.ref_off[g + 1] - b.ref_off[g];
+    const int r0 = b.reg_read_begin[g], r1 = b.reg_read_begin[g + 1];
+    if (rl < 0 || rl >= 0x40000000ll || r1 < r0) { out[3] = PLAT_ERR_BAD_INPUT; return; }
+    const long long bytes = r1 > r0 ? b.read_off[r1] - b.read_off[r0] : 0;
+    if (bytes < 0 || bytes >= 0x3FFFFFFFll) { out[3] = PLAT_ERR_BAD_INPUT; return; }
+    if (rl > max_ref || r1 - r0 > max_reads || rl + 2 + bytes + 2 * (long long)(r1 - r0) > max_pos) out[3] = PLAT_ERR_BAD_HINTS;
+}
+
 }  // namespace plat
 
 using namespace plat;
+
+static int asm_launch(plat_ctx* ctx, const plat_assembly_batch& b, int kmer_size, int min_qual, int min_weight, int no_cycles,
+                      int max_vars_per_region, int blob_per_region, int max_ref, int max_reads, long long max_pos_raw,
+                      int32_t* var_count, int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob,
+                      int32_t* status, const long long* verdict, hipStream_t st);
 
 PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* batch, int kmer_size, int min_qual,
                                     int min_weight, int no_cycles, int max_vars_per_region, int blob_per_region,
@@ -1786,9 +1810,45 @@ PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* ba
     PLAT_HIP(ctx, hipMemcpyAsync(hb, d_sz, 4 * sizeof(long long), hipMemcpyDeviceToHost, st));
     PLAT_HIP(ctx, hipStreamSynchronize(st));
     if (hb[3] != 0) return (int)hb[3];
-    const int max_ref = (int)hb[0], max_reads = (int)hb[1];
+    return asm_launch(ctx, b, kmer_size, min_qual, min_weight, no_cycles, max_vars_per_region, blob_per_region, (int)hb[0], (int)hb[1], hb[2],
+                      var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status, nullptr, st);
+}
+
+PLAT_EXPORT int plat_assemble_batch_async(plat_ctx* ctx, const plat_assembly_batch* batch, const plat_assembly_hints* hints, int kmer_size, int min_qual,
+                                          int min_weight, int no_cycles, int max_vars_per_region, int blob_per_region,
+                                          int32_t* var_count, int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd,
+                                          int32_t* var_off, uint8_t* var_blob, int32_t* status, void* stream)
+{
+    if (!ctx || !batch || !hints) return PLAT_ERR_INVALID;
+    const plat_assembly_batch b = *batch;
+    if (b.n_regions < 0 || b.n_reads < 0 || kmer_size < 5 || kmer_size > 200 || max_vars_per_region <= 0 || blob_per_region <= 0 ||
+        hints->max_ref_len < 0 || hints->max_reads_per_region < 0 || hints->max_positions < 0 || hints->max_positions >= 0x3FFFFFF0ll)
+        return PLAT_ERR_INVALID;
+    if (b.n_regions == 0) return PLAT_OK;
+    if (!b.ref_seq || !b.ref_off || !b.ref_start || !b.assem_start || !b.assem_end || !b.reg_read_begin ||
+        !b.read_off || !var_count || !var_pos || !var_nrem || !var_nadd || !var_off || !var_blob || !status)
+        return PLAT_ERR_INVALID;
+    if (b.n_reads > 0 && (!b.read_seq || !b.read_qual)) return PLAT_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = plat_reserve(ctx, ctx->counters, 64 * sizeof(long long));
+    if (rc) return rc;
+    long long* d_sz = (long long*)ctx->counters.ptr;
+    PLAT_HIP(ctx, hipMemsetAsync(d_sz, 0, 8 * sizeof(long long), st));
+    hipLaunchKernelGGL(k_asm_check, dim3((b.n_regions + 255) / 256), dim3(256), 0, st, b, (long long)hints->max_ref_len, (long long)hints->max_reads_per_region,
+                       (long long)hints->max_positions, d_sz);
+    return asm_launch(ctx, b, kmer_size, min_qual, min_weight, no_cycles, max_vars_per_region, blob_per_region, hints->max_ref_len, hints->max_reads_per_region,
+                      hints->max_positions, var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status, d_sz, st);
+}
+
+static int asm_launch(plat_ctx* ctx, const plat_assembly_batch& b, int kmer_size, int min_qual, int min_weight, int no_cycles,
+                      int max_vars_per_region, int blob_per_region, int max_ref, int max_reads, long long max_pos_raw,
+                      int32_t* var_count, int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob,
+                      int32_t* status, const long long* verdict, hipStream_t st)
+{
+    int rc;
     // k may grow to 55 under noCycles, which only lowers the number of edges: size for the initial k
-    long long max_pos = hb[2] + 16;
+    long long max_pos = max_pos_raw + 16;
     if (max_pos > 0x3FFFFFFFll) return PLAT_ERR_OVERFLOW;
     int cap = 1024;
     while ((long long)cap * 3 < max_pos * 4 * 2) cap <<= 1;     // load factor <= 3/8 even if every occurrence were distinct
@@ -1810,7 +1870,7 @@ PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* ba
     const int lds_bytes = ASM_LDS_BYTES;
     PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipLaunchKernelGGL(k_assemble, dim3(nblk), dim3(ASM_THREADS), lds_bytes, st, b, P, (char*)ctx->asm_scratch.ptr, max_ref, max_reads,
-                       var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status);
+                       var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status, verdict);
     PLAT_HIP(ctx, hipGetLastError());
     if (P.timing) {
         unsigned long long t[16];

@@ -479,16 +479,20 @@ class Engine:
         """HBM image of the host arrays of plat_assembly_batch (dict as synth.config3 returns) + output buffers."""
         return AssemblyDeviceBatch(ab, self.device, max_vars, blob_per_region)
 
-    def assemble_device(self, adb, kmer_size=15, min_qual=20, min_weight=40, no_cycles=0):
-        """plat_assemble_batch on a resident batch; enqueues only, results stay in HBM (adb.results() reads them)."""
-        rc = self.lib.plat_assemble_batch(self.ctx, C.byref(adb.struct), kmer_size, min_qual, min_weight, no_cycles, adb.max_vars,
-                                          adb.blob_per_region, adb.cnt.data_ptr(), adb.pos.data_ptr(), adb.nrem.data_ptr(),
-                                          adb.nadd.data_ptr(), adb.off.data_ptr(), adb.blob.data_ptr(), adb.status.data_ptr(),
-                                          self._stream())
+    def assemble_device(self, adb, kmer_size=15, min_qual=20, min_weight=40, no_cycles=0, hints=None):
+        """plat_assemble_batch on a resident batch; enqueues only, results stay in HBM (adb.results() reads them).  hints = (longest
+        reference window, most reads of a tile, most k-mer positions of a tile): plat_assemble_batch_async, which reads nothing back."""
+        tail = (adb.max_vars, adb.blob_per_region, adb.cnt.data_ptr(), adb.pos.data_ptr(), adb.nrem.data_ptr(), adb.nadd.data_ptr(), adb.off.data_ptr(),
+                adb.blob.data_ptr(), adb.status.data_ptr(), self._stream())
+        if hints is None:
+            rc = self.lib.plat_assemble_batch(self.ctx, C.byref(adb.struct), kmer_size, min_qual, min_weight, no_cycles, *tail)
+        else:
+            h = _lib.AssemblyHints(int(hints[0]), int(hints[1]), int(hints[2]))
+            rc = self.lib.plat_assemble_batch_async(self.ctx, C.byref(adb.struct), C.byref(h), kmer_size, min_qual, min_weight, no_cycles, *tail)
         _lib.check(rc, "plat_assemble_batch")
 
     def assemble(self, regions, kmer_size=15, min_qual=20, min_weight=40, no_cycles=0, max_vars=512,
-                 blob_per_region=1 << 16):
+                 blob_per_region=1 << 16, hints=None):
         """assembleReadsAndDetectVariants for a list of regions.
 
         `regions`: list of dicts {ref: bytes, ref_start, assem_start, assem_end, seqs: [bytes], quals: [bytes]}
@@ -509,7 +513,10 @@ class Engine:
                   read_qual=np.frombuffer(b"".join(q for r in regions for q in r["quals"]), dtype=np.uint8),
                   read_off=np.concatenate([[0], np.cumsum(rl)]))
         adb = self.upload_assembly(ab, max_vars, blob_per_region)
-        self.assemble_device(adb, kmer_size, min_qual, min_weight, no_cycles)
+        if hints == "exact":                                               # what a caller that built the batch knows
+            per = [int(ref_len[g]) + 2 + sum(len(q) for q in regions[g]["seqs"]) + 2 * int(nreads[g]) for g in range(nG)]
+            hints = (int(ref_len.max()), int(nreads.max()), max(per))
+        self.assemble_device(adb, kmer_size, min_qual, min_weight, no_cycles, hints)
         return adb.results()
 
     def profile_enable(self, on=True):

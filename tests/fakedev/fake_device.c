@@ -499,3 +499,21 @@ API int plat_assemble_batch(plat_ctx* c, const plat_assembly_batch* b, int kmer_
     }
     return PLAT_OK;
 }
+
+API int plat_assemble_batch_async(plat_ctx* c, const plat_assembly_batch* b, const plat_assembly_hints* hints, int kmer_size, int min_qual, int min_weight,
+                                  int no_cycles, int max_vars, int blob_per_region, int32_t* var_count, int32_t* var_pos, int32_t* var_nrem,
+                                  int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob, int32_t* status, void* stream)
+{
+    if (!hints) return PLAT_ERR_INVALID;
+    for (int g = 0; g < b->n_regions; ++g) {                            /* the device's check of the caller's sizes */
+        const long long rl = b->ref_off[g + 1] - b->ref_off[g];
+        const int r0 = b->reg_read_begin[g], r1 = b->reg_read_begin[g + 1];
+        const long long bytes = r1 > r0 ? b->read_off[r1] - b->read_off[r0] : 0;
+        if (rl > hints->max_ref_len || r1 - r0 > hints->max_reads_per_region || rl + 2 + bytes + 2ll * (r1 - r0) > hints->max_positions) {
+            for (int k = 0; k < b->n_regions; ++k) { status[k] = PLAT_ERR_BAD_HINTS; var_count[k] = 0; }
+            return PLAT_OK;
+        }
+    }
+    return plat_assemble_batch(c, b, kmer_size, min_qual, min_weight, no_cycles, max_vars, blob_per_region, var_count, var_pos, var_nrem, var_nadd, var_off,
+                               var_blob, status, stream);
+}

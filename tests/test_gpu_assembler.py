@@ -203,3 +203,24 @@ def test_a_dozen_regions_per_workgroup_fused_equals_three_pass(eng):
         finally:
             os.environ.pop("PLAT_ASM_FUSED", None)
     assert out["1"] == out["0"] and sum(len(v) for v in out["1"]) > 2000
+
+
+def test_async_entry_with_the_callers_sizes_equals_the_entry_that_reads_them_back(eng, golden_dir):
+    """plat_assemble_batch_async (the region loop's entry: sizes from the caller, no read-back, no wait) = plat_assemble_batch on the
+    reference's goldens; hints that do not cover the batch refuse EVERY tile (PLAT_ERR_BAD_HINTS), loudly."""
+    from platypus_amd import _lib
+    cases = json.load(gzip.open(os.path.join(golden_dir, "assembler_cases.json.gz"), "rt"))
+    for nc in (0, 1):
+        sel = [to_region(c) for c in cases if c["noCycles"] == nc]
+        want = eng.assemble(sel, no_cycles=nc)
+        assert eng.assemble(sel, no_cycles=nc, hints="exact") == want
+        assert any(want)
+    sel = [to_region(c) for c in cases[:6]]
+    ref_len = max(len(r["ref"]) for r in sel)
+    nreads = max(len(r["seqs"]) for r in sel)
+    npos = max(len(r["ref"]) + 2 + sum(len(q) for q in r["seqs"]) + 2 * len(r["seqs"]) for r in sel)
+    assert eng.assemble(sel, hints=(ref_len, nreads, npos)) == eng.assemble(sel)
+    for bad in ((ref_len - 1, nreads, npos), (ref_len, nreads - 1, npos), (ref_len, nreads, npos - 1)):
+        with pytest.raises(_lib.PlatypusDeviceError) as e:
+            eng.assemble(sel, hints=bad)
+        assert e.value.code == -10                      # PLAT_ERR_BAD_HINTS

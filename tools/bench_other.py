@@ -155,6 +155,8 @@ def config3_end_to_end(device, n_regions, rk=None, first=0, lib=None, region_kw=
                 host_seconds_per_region=st["seconds_host"] / r["regions"], device_wait_seconds_per_region=st["seconds_device_wait"] / r["regions"],
                 assemble_seconds_per_region=st["seconds_assemble"] / r["regions"], host_threads=r["workers"], regions_per_chunk=r["per_chunk"],
                 inputs="resident in HBM" if r["resident"] else "loaded on demand inside the timed region", timed_s_runs=r["T_runs"],
+                call_seconds=r["T_call"], native_call_seconds=st["seconds_total"], source_wait_seconds_per_region=st["seconds_source_wait"] / r["regions"],
+                load_seconds_per_region=st["seconds_load"] / r["regions"], process_cpu_seconds_per_run=r["cpu_user_s"] + r["cpu_sys_s"],
                 text=F.text_bytes(r["text"]).decode("ascii"))
 
 
