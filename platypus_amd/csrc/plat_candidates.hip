@@ -108,15 +108,38 @@ k_candidates(plat_candidate_batch b, int min_flank, int min_base_qual, int gen_s
                         }
                     };
                     int index = lo;
-                    for (; index + 8 <= hi; index += 8) {
-                        unsigned long long x = load_u64_bytes(rp + index) ^ load_u64_bytes(fp + index);
-                        while (x) {
-                            const int j = (__ffsll((long long)x) - 1) >> 3;
-                            mismatch(index + j);
-                            x &= ~(0xFFull << (8 * j));
+                    // (round 5: 32 bases per trip -- the eight loads of a trip do not depend on one another, so a trip waits for memory once
+                    //  where four trips of 8 bases waited four times: the walk is a chain of such waits, not a stream.  The last trip reads
+                    //  past `hi` -- blobs are followed by PLAT_BLOB_PAD readable bytes -- and masks what it read there.)
+                    constexpr int CAND_TRIP = 4;                                     // words of 8 bases per trip
+                    static_assert(PLAT_BLOB_PAD >= 8 * CAND_TRIP, "the last trip of the mismatch scan reads past a blob's end");
+                    for (; index < hi; index += 8 * CAND_TRIP) {
+                        const int nleft = hi - index;
+                        unsigned long long x4[CAND_TRIP];
+#pragma unroll
+                        for (int q = 0; q < CAND_TRIP; ++q) x4[q] = load_u64_bytes(rp + index + 8 * q) ^ load_u64_bytes(fp + index + 8 * q);
+                        if (nleft < 8 * CAND_TRIP) {
+#pragma unroll
+                            for (int q = 0; q < CAND_TRIP; ++q) {
+                                const int nb = nleft - 8 * q;
+                                if (nb <= 0) x4[q] = 0ull;
+                                else if (nb < 8) x4[q] &= (1ull << (8 * nb)) - 1ull;
+                            }
+                        }
+                        unsigned long long any = 0ull;
+#pragma unroll
+                        for (int q = 0; q < CAND_TRIP; ++q) any |= x4[q];
+                        if (any == 0ull) continue;
+#pragma unroll
+                        for (int q = 0; q < CAND_TRIP; ++q) {
+                            unsigned long long x = x4[q];
+                            while (x) {
+                                const int j = (__ffsll((long long)x) - 1) >> 3;
+                                mismatch(index + 8 * q + j);
+                                x &= ~(0xFFull << (8 * j));
+                            }
                         }
                     }
-                    for (; index < hi; ++index) if (rp[index] != fp[index]) mismatch(index);
                     if (msr != -1) out.put(msr + refSeqStart, mer - msr + 1, med - msd + 1, roff + msr, soff + msd);
                 }
                 readOffset += length;
