@@ -137,19 +137,39 @@ static std::unique_ptr<RegionWork> makeRegionWork(const plat_region* in, int ind
 // options.rlen follows the longest read of each region and is kept from the region before when a region has no reads (variantcaller.pyx:476-488)
 static inline int nextRlen(int rlen, int longest, int maxSize, int fromBams = 1) { return (fromBams && longest > 0) ? (longest >= maxSize ? maxSize : longest) : rlen; }
 
+// Where the chunks of a call begin: whole chunks of `per` regions while every worker gets the same number of them, and what is left of the
+// list in one more round of EQUAL smaller chunks, one per worker -- with 61 chunks for 24 workers thirteen workers did three chunks while
+// eleven did two and then watched; 48 whole chunks + 24 of half the size end together (PLAT_CALLER_EVEN_TAIL=0: chunks of `per` to the end).
+static std::vector<int> chunkBounds(int n, int per, int workers) {
+    std::vector<int> b{0};
+    static const bool even = [] { const char* e = getenv("PLAT_CALLER_EVEN_TAIL"); return !(e && e[0] == '0'); }();
+    int at = 0;
+    if (even && workers > 1 && n > per * workers) {
+        const int rounds = n / (per * workers);
+        for (int k = 0; k < rounds * workers; ++k) { at += per; b.push_back(at); }
+        const int rest = n - at;                                           // < per * workers: no chunk of the last round is larger than `per`
+        if (rest >= 2 * workers)
+            for (int w = 0; w < workers; ++w) { at += rest / workers + (w < rest % workers ? 1 : 0); b.push_back(at); }
+    }
+    while (at < n) { at = std::min(n, at + per); b.push_back(at); }
+    return b;
+}
+
 // every region already in memory (plat_call_regions)
 struct MemoryFeed : Feed {
     std::vector<std::unique_ptr<RegionWork>>& work;
-    int per, nChunks;
+    std::vector<int> bound;
+    int nChunks;
     std::atomic<int> nextChunk{0};
     std::atomic<bool>& failed;
-    MemoryFeed(std::vector<std::unique_ptr<RegionWork>>& w, int per_, std::atomic<bool>& f) : work(w), per(per_), nChunks(((int)w.size() + per_ - 1) / per_), failed(f) {}
+    MemoryFeed(std::vector<std::unique_ptr<RegionWork>>& w, int per_, int workers, std::atomic<bool>& f)
+        : work(w), bound(chunkBounds((int)w.size(), per_, workers)), nChunks((int)bound.size() - 1), failed(f) {}
     bool next(std::vector<RegionWork*>& out) override {
         if (failed.load()) return false;
         const int ch = nextChunk.fetch_add(1);
         if (ch >= nChunks) return false;
         out.clear();
-        for (int k = ch * per; k < std::min((int)work.size(), (ch + 1) * per); ++k) out.push_back(work[(size_t)k].get());
+        for (int k = bound[(size_t)ch]; k < bound[(size_t)ch + 1]; ++k) out.push_back(work[(size_t)k].get());
         return true;
     }
     void done(const std::vector<RegionWork*>&) override {}
@@ -167,13 +187,17 @@ struct StreamFeed : Feed {
     std::vector<int> slotOf, longest;
     std::vector<char> loaded;
     std::vector<int> chunkLoaded;                                          // regions of a chunk that are in: the workers are woken when a CHUNK is complete
+    std::vector<int> bound, chunkOf;                                       // chunk c = regions [bound[c], bound[c + 1]) (chunkBounds)
     int nextToLoad = 0, nextChunk = 0, rlen, error = PLAT_OK;
     std::string errText;
     std::atomic<bool>& failed;
     double tLoad = 0, tWait = 0;
-    StreamFeed(int n_, int nS, int per_, int maxSize_, int rlen0, plat_region_load_fn l, void* u, int nSlots, std::atomic<bool>& f)
-        : n(n_), nSamples(nS), per(per_), nChunks((n_ + per_ - 1) / per_), maxSize(maxSize_), load(l), user(u), work((size_t)n_), desc((size_t)n_),
-          slotOf((size_t)n_, -1), longest((size_t)n_, 0), loaded((size_t)n_, 0), chunkLoaded((size_t)((n_ + per_ - 1) / per_), 0), rlen(rlen0), failed(f) {
+    StreamFeed(int n_, int nS, int per_, int workers, int maxSize_, int rlen0, plat_region_load_fn l, void* u, int nSlots, std::atomic<bool>& f)
+        : n(n_), nSamples(nS), per(per_), nChunks(0), maxSize(maxSize_), load(l), user(u), work((size_t)n_), desc((size_t)n_),
+          slotOf((size_t)n_, -1), longest((size_t)n_, 0), loaded((size_t)n_, 0), bound(chunkBounds(n_, per_, workers)), chunkOf((size_t)n_, 0), rlen(rlen0), failed(f) {
+        nChunks = (int)bound.size() - 1;
+        chunkLoaded.assign((size_t)nChunks, 0);
+        for (int c = 0; c < nChunks; ++c) for (int k = bound[(size_t)c]; k < bound[(size_t)c + 1]; ++k) chunkOf[(size_t)k] = c;
         for (int k = nSlots - 1; k >= 0; --k) freeSlots.push_back(k);
     }
     void fail(int code, const std::string& what) {
@@ -206,8 +230,8 @@ struct StreamFeed : Feed {
             tLoad += dt;
             // (one wake-up per chunk, not per region: a notify_all per region had every waiting worker re-check its chunk under this mutex
             //  thousands of times per call -- 5 ms of a 20 ms call with 20 workers)
-            const int ch = idx / per, size = std::min(n, (ch + 1) * per) - ch * per;
-            if (++chunkLoaded[(size_t)ch] == size) cvLoaded.notify_all();
+            const int ch = chunkOf[(size_t)idx];
+            if (++chunkLoaded[(size_t)ch] == bound[(size_t)ch + 1] - bound[(size_t)ch]) cvLoaded.notify_all();
         }
     }
     bool next(std::vector<RegionWork*>& out) override {
@@ -215,7 +239,7 @@ struct StreamFeed : Feed {
         std::unique_lock<std::mutex> g(m);
         for (;;) {
             if (failed.load() || nextChunk >= nChunks) return false;
-            const int ch = nextChunk, a = ch * per, b = std::min(n, (ch + 1) * per);
+            const int ch = nextChunk, a = bound[(size_t)ch], b = bound[(size_t)ch + 1];
             if (chunkLoaded[(size_t)ch] == b - a) {
                 out.clear();
                 for (int k = a; k < b; ++k) {                                // list order: rlen walks the regions as the reference's loop does
@@ -365,7 +389,7 @@ CALLER_EXPORT int plat_call_regions(plat_caller* c, const plat_region* regions, 
         work.push_back(std::move(r));
     }
     std::atomic<bool> failed(false);
-    MemoryFeed feed(work, c->regionsPerChunk, failed);
+    MemoryFeed feed(work, c->regionsPerChunk, (int)c->slots.size(), failed);
     rc = runWorkers(c, feed, failed, o, n_samples, sample_names, st, std::max(1, feed.nChunks));
     if (rc != PLAT_OK) return rc;
     if ((rc = finishText(c, work, out_text, out_len)) != PLAT_OK) return rc;
@@ -395,7 +419,7 @@ CALLER_EXPORT int plat_call_regions_stream(plat_caller* c, int n_regions, int n_
     Options o;
     static_cast<plat_caller_options&>(o) = *options;
     std::atomic<bool> failed(false);
-    StreamFeed feed(n_regions, n_samples, per, options->maxSize, options->rlen, load, user, n_slots, failed);
+    StreamFeed feed(n_regions, n_samples, per, nWorkers, options->maxSize, options->rlen, load, user, n_slots, failed);
     feed.fromBams = options->getVariantsFromBAMs;
     std::vector<std::thread> loaders;
     for (int i = 0; i < std::min(n_loader_threads, std::max(1, n_regions)); ++i) loaders.emplace_back([&feed] { feed.loader(); });

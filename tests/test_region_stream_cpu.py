@@ -145,3 +145,28 @@ def test_native_region_source_of_the_benchmark(fake):
                 rp += ln
         assert qp == t["off"][k + 1] and rp == t["end"][k]
     assert mism / total < 0.01
+
+
+def test_the_last_round_of_smaller_equal_chunks_changes_nothing(fake):
+    """chunkBounds (region_caller.cpp): whole chunks while every worker gets the same number, the rest of the list as ONE more round of
+    equal smaller chunks -- 2 workers x 5 regions per chunk on 28 regions = 4 whole chunks + 2 chunks of 4 (not 5 and 3; never a chunk
+    LARGER than the caller's regions_per_chunk: n_slots is sized by it).  The text, rlen and the statistics are those of one worker
+    walking chunks of 5 to the end; list and stream entry."""
+    regs = _regions(28)
+    names = ["S1", "S2"]
+    rr = [F.region_from_arrays(r, packed=(i % 3 == 0)) for i, r in enumerate(regs)]
+    o0 = default_options()
+    one = F.NativeCaller(0, 1, 5, lib=fake)
+    want = one.call_regions(rr, names, o0)
+    nwin = one.stats["n_windows"]
+    one.close()
+    assert want.count("\n") > 40
+    nc = F.NativeCaller(0, 2, 5, lib=fake)
+    o1, o2 = default_options(), default_options()
+    assert nc.call_regions(rr, names, o1) == want and nc.stats["n_windows"] == nwin and o1.rlen == o0.rlen
+
+    def load(index, slot, out):
+        rr[index].fill(out, 2)
+        return 0
+    assert nc.call_stream(len(rr), load, None, names, o2, n_slots=15, n_loaders=2) == want and o2.rlen == o0.rlen
+    nc.close()

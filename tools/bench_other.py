@@ -140,10 +140,10 @@ def config3_end_to_end(device, n_regions, rk=None, first=0, lib=None, region_kw=
     chunk in one plat_assemble_batch, their variants merged with the BAM candidates, then the called windows through the likelihoods at
     250 bp (buf = 500), EM, posteriors, records.  Inputs resident in HBM (round 5; PLAT_CALLER_RESIDENT3=0: loaded on demand by tools/synth)."""
     from platypus_amd import fastcaller as F
-    workers = int(os.environ.get("PLAT_CALLER_WORKERS", "16"))
+    workers = int(os.environ.get("PLAT_CALLER_WORKERS", "20"))
     kw = dict(flank=1500, read_len=250, model=CONFIG3_MODEL, **(region_kw or {}))
     resident = lib is None and os.environ.get("PLAT_CALLER_RESIDENT3", "1") == "1"      # inputs resident in HBM, as on the config-4 line (0: loaded on demand, rounds 2-4)
-    r = config4(device, range(first, first + n_regions), 1500, workers, int(os.environ.get("PLAT_CALLER_CHUNK3", "64" if resident else "32")), repeats=3 if resident else 1,
+    r = config4(device, range(first, first + n_regions), 1500, workers, int(os.environ.get("PLAT_CALLER_CHUNK3", "100" if resident else "32")), repeats=3 if resident else 1,
                 region_kw=kw, rk=rk, options_kw=dict(assemble=1), lib=lib, pin=lib is None, resident=resident)
     st, T = r["stats"], r["T"]
     return dict(regions=r["regions"], tiles=int(st["n_assembly_tiles"]), assembler_variants=int(st["n_assembler_variants"]), planted_variants=r["planted"],
