@@ -172,10 +172,6 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
-    # The region loop keeps a dozen or two streams busy with chains of small kernels; the runtime maps streams onto 4 hardware queues by
-    # default, and chains that share a queue run one behind the other.  8 queues measured +3-5 % on the WGS job (12, 16: no further gain);
-    # read when the runtime initialises, so it is set before anything touches the device.  The caller's own setting wins.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
         # torch is the device-memory/stream plumbing of the Python host and ships its own libamdhip64:
         # import it first so the process holds ONE HIP runtime (loading /opt/rocm's copy first and torch's

@@ -567,7 +567,10 @@ PLAT_EXPORT int plat_variant_read_stats_batch(plat_ctx* ctx, const plat_infostat
 
 // ---- window read slices out of a resident read table (plat_gather_reads) --------------------------------------------------
 namespace plat {
-// one wave per destination read: 64 bytes of bases and 64 of qualities per pass, coalesced on both sides
+// Four destination reads per wave, sixteen lanes each: lanes 0-7 of the sixteen move the bases, 8-15 the qualities, 16 bytes at a time
+// from and to any address (global memory takes unaligned 64-bit loads and stores).  A read's copy is a chain of three dependent loads
+// (index -> offsets -> bytes) that a wave waits out whatever its width: with one read per wave (rounds 3-4) the 230 k reads of a chunk of
+// 64 regions were 28 rounds of waves on the chip, 76-85 us for 86 MB; four per wave share each wait.
 __global__ void __launch_bounds__(256)
 k_gather_reads(long long n_dst, const int32_t* __restrict__ src_index, const int64_t* __restrict__ dst_off,
                const uint8_t* __restrict__ src_seq, const uint8_t* __restrict__ src_qual, const int64_t* __restrict__ src_off,
@@ -575,23 +578,23 @@ k_gather_reads(long long n_dst, const int32_t* __restrict__ src_index, const int
                const int32_t* __restrict__ src_flags, uint8_t* __restrict__ dst_seq, uint8_t* __restrict__ dst_qual,
                int32_t* __restrict__ dst_pos, int32_t* __restrict__ dst_end, uint8_t* __restrict__ dst_mapq, int32_t* __restrict__ dst_flags)
 {
-    const int lane = threadIdx.x & 63;
-    const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
-    for (long long d = (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6); d < n_dst; d += nw) {
+    typedef unsigned long long __attribute__((aligned(1))) u64u;
+    const int l16 = threadIdx.x & 15, l8 = l16 & 7;
+    const long long ng = ((long long)gridDim.x * blockDim.x) >> 4;
+    for (long long d = (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4); d < n_dst; d += ng) {
         const int s = src_index[d];
         const long long so = src_off[s], n = src_off[s + 1] - so, to = dst_off[d];
-        // lanes 0..31 move the bases, 32..63 the qualities, 8 bytes at a time from and to any address (global memory takes unaligned
-        // 64-bit loads and stores): a 150-base read is ONE load and ONE store per lane (it was three byte loads and stores per array)
-        {
-            typedef unsigned long long __attribute__((aligned(1))) u64u;
-            const uint8_t* src = lane < 32 ? src_seq + so : src_qual + so;
-            uint8_t* dst = lane < 32 ? dst_seq + to : dst_qual + to;
-            const int l = lane & 31;
-            const long long n8 = n & ~7ll;
-            for (long long i = 8ll * l; i < n8; i += 256) *(u64u*)(dst + i) = *(const u64u*)(src + i);
-            for (long long i = n8 + l; i < n; i += 32) dst[i] = src[i];
-        }
-        if (lane == 0) { dst_pos[d] = src_pos[s]; dst_end[d] = src_end[s]; dst_mapq[d] = src_mapq[s]; dst_flags[d] = src_flags[s]; }
+        const uint8_t* src = l16 < 8 ? src_seq + so : src_qual + so;
+        uint8_t* dst = l16 < 8 ? dst_seq + to : dst_qual + to;
+        if (n >= 16) {                                                  // pieces of 16 bytes; the last one ends AT the read's end (it may overlap the one before)
+            const long long np = (n + 15) >> 4;
+            for (long long k = l8; k < np; k += 8) {
+                const long long i = k + 1 < np ? 16 * k : n - 16;
+                const unsigned long long a = *(const u64u*)(src + i), c = *(const u64u*)(src + i + 8);
+                *(u64u*)(dst + i) = a; *(u64u*)(dst + i + 8) = c;
+            }
+        } else for (long long i = l8; i < n; i += 8) dst[i] = src[i];
+        if (l16 == 0) { dst_pos[d] = src_pos[s]; dst_end[d] = src_end[s]; dst_mapq[d] = src_mapq[s]; dst_flags[d] = src_flags[s]; }
     }
 }
 }  // namespace plat
@@ -608,7 +611,7 @@ PLAT_EXPORT int plat_gather_reads(plat_ctx* ctx, int64_t n_dst, const int32_t* s
         !dst_qual || !dst_pos || !dst_end || !dst_mapq || !dst_flags)
         return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
-    const long long nblk = (n_dst + 3) / 4;
+    const long long nblk = (n_dst + 15) / 16;                         // 256 threads = 16 reads
     hipLaunchKernelGGL(plat::k_gather_reads, dim3((unsigned)(nblk < 65535 * 8 ? nblk : 65535 * 8)), dim3(256), 0, (hipStream_t)stream, (long long)n_dst,
                        src_index, dst_off, src_seq, src_qual, src_off, src_pos, src_end, src_mapq, src_flags, dst_seq, dst_qual, dst_pos,
                        dst_end, dst_mapq, dst_flags);

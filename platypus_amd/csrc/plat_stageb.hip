@@ -201,6 +201,13 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int32_t* hdr = out.hdr + 8 * g;
     const int n = b.cand_n[2 * g];
+#ifdef PLAT_SB_TIMING
+    long long tm_[12]; int tmn_ = 0;
+#define SB_MARK() do { if (tmn_ < 12) tm_[tmn_++] = wall_clock64(); } while (0)
+    SB_MARK();
+#else
+#define SB_MARK() do { } while (0)
+#endif
     if (tid == 0) { R.status = 0; R.nIndel = 0; R.addedUsed = 0; R.nKept = 0; R.dN2 = 0; }
     __syncthreads();
     if (b.cand_n[2 * g + 1] != 0 || n > SB_CAP || n > b.cap_per_scan) {                  // (the merge kernel's own verdict is the caller's to read)
@@ -238,6 +245,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
         if (tid == 0) { int t = 0; for (int k = 0; k < SB_THREADS / 64; ++k) t += R.wsum[k]; hdr[3] = t; }
         __syncthreads();
     }
+    SB_MARK();
     // ---- first sort: (refPos, varType, nRemoved), equal keys in the dictionary's insertion order (sorted() is stable)
     for (int i = tid; i < n; i += SB_THREADS) {
         const unsigned long long k = R.key[i]; const int id = R.id[i];
@@ -248,6 +256,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
     __syncthreads();
     for (int i = tid; i < n; i += SB_THREADS) R.id[i] = R.list[i];          // id := rank in the first sort (the tie-break of the second)
     __syncthreads();
+    SB_MARK();
     // ---- leftNormaliseIndel: pure insertions / deletions at refPos >= 100
     for (int i = tid; i < n; i += SB_THREADS) {
         const int nrem = R.nrem[i], nadd = R.nadd[i];
@@ -304,6 +313,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
     }
     __threadfence_block();
     __syncthreads();
+    SB_MARK();
     // ---- second sort (stable on the first)
     for (int i = tid; i < n; i += SB_THREADS) {
         const unsigned long long k = R.key[i]; const int id = R.id[i];
@@ -312,6 +322,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
         R.perm[r] = (unsigned short)i;
     }
     __syncthreads();
+    SB_MARK();
     // ---- filterVariants: runs of equal variants (each compared with the run's first: equality is transitive) are merged into the first
     for (int r = tid; r < n; r += SB_THREADS) R.head[r] = r == 0 || !sb_same(R, R.perm[r], R.perm[r - 1], b.read_seq, blob);
     __syncthreads();
@@ -469,6 +480,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
         if (R.dN2 != n) { if (tid == 0) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; hdr[5] = 3; } return; }   // (every candidate is a distinct record: cannot happen)
     }
     }   // pass
+    SB_MARK();
     if (tid == 0) hdr[5] = 0;
     // ---- the region's variants out (+ the added bases of those that still live in the read table)
     for (int k = tid; k < nk; k += SB_THREADS) {
@@ -488,6 +500,7 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
         out.var_add_off[v] = ao;
     }
     __syncthreads();
+    SB_MARK();
     // ---- windows: WindowGenerator.getBunchesOfVariants over the variants inside [start, end), one lane (a sequential rule)
     if (tid == 0) {
         const int start = b.region_start[g], end = b.region_end[g], maxContigPos = contigLen - 1;
@@ -525,7 +538,13 @@ k_sb_variants(SbIn in, plat_stage_b_out out, const int32_t* __restrict__ mtab)
         if (haveBunch) emit();
         if (st) { hdr[0] = PLAT_SB_HOST; hdr[1] = hdr[2] = 0; hdr[5] = (st & 4) ? 6 : 4; }
         else { hdr[0] = 0; hdr[1] = nk; hdr[2] = nw; hdr[4] = R.addedUsed; hdr[5] = 0; hdr[6] = R.dN2 > 0; hdr[7] = 0; }
+#ifdef PLAT_SB_TIMING
+        SB_MARK();
+        if (g < 2) { printf("[sb variants] region %d: %d candidates, %d variants, %d windows, replay %d; us between marks:", g, n, nk, nw, R.dN2 > 0);
+                     for (int i = 1; i < tmn_; ++i) printf(" %lld", (tm_[i] - tm_[i - 1]) / 100); printf("\n"); }
+#endif
     }
+#undef SB_MARK
 }
 
 // ---- a haplotype of a window as segments of the reference and added bases (getMutatedSequence, chaplotype.pyx:397-449) -------------

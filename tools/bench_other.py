@@ -350,8 +350,8 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
     # (round 5, resident: one worker per CPU -- 16 x 64 measured 2.40 M windows/s against 2.15 M with 14 workers; their host stages are
     #  0.23 ms per region now and a worker waiting for the device sleeps)
     # (later in round 5: plat_stream_sync naps between polls of its event instead of the runtime's blocking wait, which burned 0.085 ms of CPU
-    #  per region while "blocked" -- a waiting worker now costs nothing, so there are three workers for two CPUs: 24 x 64 with 8 hardware
-    #  queues measured 3.4-3.5 M windows/s against 3.2-3.3 M with 16; 2 CPUs: 3 workers 0.71 M)
+    #  per region while "blocked" -- a waiting worker now costs nothing, so there are three workers for two CPUs: 24 x 64 measured
+    #  3.4-3.5 M windows/s against 3.2-3.3 M with 16; GPU_MAX_HW_QUEUES 4 (the default), 8, 16: the same, 24: 40 % slower; 2 CPUs: 3 workers 0.71 M)
     workers = int(os.environ.get("PLAT_CALLER_WORKERS", str(max(2, min(24, cpus * 3 // 2 if resident else cpus * 5 // 8)))))
     os.environ.setdefault("PLAT_CALLER_LOADERS", str(max(2, min(12, cpus // 2))))
     # (round 5: stage B on the device -- the host no longer pays per region for a chunk's size, and the kernels of a chunk are latency bound:
