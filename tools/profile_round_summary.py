@@ -29,6 +29,25 @@ def stats(dirname, out, title):
                                                         float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
 
 
+def quantiles(dirname, out, title):
+    """min / first quartile / median / mean of every kernel's launches in a kernel trace: with a dozen chunks in flight a launch is stretched by
+    the kernels it shares the chip with; the low end of the distribution is the kernel by itself (the serialized counting pass)."""
+    paths = glob.glob(dirname + "/*/*_kernel_trace.csv")
+    if not paths:
+        return
+    import collections
+    import statistics
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(paths[0])):
+        d[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    with open(out, "w") as f:
+        f.write("# %s\n" % title)
+        f.write("%-42s %6s %9s %9s %9s %9s\n" % ("kernel", "calls", "min_us", "q25_us", "median_us", "mean_us"))
+        for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+            v.sort()
+            f.write("%-42s %6d %9.1f %9.1f %9.1f %9.1f\n" % (k[:42], len(v), v[0], v[len(v) // 4], statistics.median(v), sum(v) / len(v)))
+
+
 def pmc(o, names, out, args):
     dirs = [o + "/" + n for n in names if glob.glob(o + "/" + n + "/*/*_counter_collection.csv")]
     if not dirs:
@@ -58,7 +77,8 @@ def main(o, tag):
     stats(o + "/stats_c3", prof + "/" + tag + "_assemble_stats.txt", CMD + "--config 3 --regions 2000 --steps 5 --no-extras   (MI355X; config 3: 2000 assembly tiles per launch)")
     stats(o + "/stats_c3e", prof + "/" + tag + "_config3_end_to_end_stats.txt", CMD + "--config 3 --regions 2000 --steps 1   (MI355X; config 3 incl. END TO END: 2000 regions through the native region loop with --assemble=1, 32 regions per chunk)")
     stats(o + "/stats_c5", prof + "/" + tag + "_config5_stats.txt", CMD + "--config 5 --windows 200 --steps 10 --warmup 2   (MI355X; config 5: 200 windows x 100 samples per step)")
-    stats(o + "/stats_c4", prof + "/" + tag + "_config4_stats.txt", CMD + "--config 4 --regions 1024 --steps 1 --no-cpu-baseline   (MI355X; config 4: 1024 regions x 100 kb, inputs resident in HBM, through the native region loop, 64 regions per chunk: one untimed counting pass + one timed pass = 32 chunks)")
+    stats(o + "/stats_c4", prof + "/" + tag + "_config4_stats.txt", CMD + "--config 4 --regions 1024 --steps 1 --no-cpu-baseline   (MI355X; config 4: 1024 regions x 100 kb, inputs resident in HBM, through the native region loop, 24 host threads x 64 regions per chunk: one serialized counting pass, two warm rounds and one timed pass; avg_us is stretched by the kernels of the other chunks running at the same time -- r05_config4_overlap.json says how many)")
+    quantiles(o + "/stats_c4", prof + "/" + tag + "_config4_kernel_quantiles.txt", "the launches of `" + CMD + "--config 4 --regions 1024 --steps 1 --no-cpu-baseline` per kernel: a chunk = 64 regions x 100 kb; min / q25 = the kernel by itself, median / mean = with the other chunks' kernels on the chip")
     for f, dst in (("stats3", tag + "_bench_line_under_rocprof.json"), ("stats_c3e", tag + "_bench_config3_under_rocprof.json"), ("stats_c4", tag + "_bench_config4_under_rocprof.json"),
                    ("stats_c5", tag + "_bench_config5_under_rocprof.json")):
         p = o + "/" + f + ".json"
