@@ -18,7 +18,7 @@ STATS_ONLY = ("plat::k_sum_job_cells", "plat::k_stats")     # launched only when
 
 
 def stats(dirname, out, title):
-    paths = glob.glob(dirname + "/*/*_kernel_stats.csv")
+    paths = sorted(glob.glob(dirname + "/*/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)      # (a directory merged back from several runs: the newest)
     if not paths:
         return
     with open(out, "w") as f:
@@ -32,7 +32,7 @@ def stats(dirname, out, title):
 def quantiles(dirname, out, title):
     """min / first quartile / median / mean of every kernel's launches in a kernel trace: with a dozen chunks in flight a launch is stretched by
     the kernels it shares the chip with; the low end of the distribution is the kernel by itself (the serialized counting pass)."""
-    paths = glob.glob(dirname + "/*/*_kernel_trace.csv")
+    paths = sorted(glob.glob(dirname + "/*/*_kernel_trace.csv"), key=os.path.getmtime, reverse=True)
     if not paths:
         return
     import collections
@@ -78,6 +78,7 @@ def main(o, tag):
     stats(o + "/stats_c3e", prof + "/" + tag + "_config3_end_to_end_stats.txt", CMD + "--config 3 --regions 2000 --steps 1   (MI355X; config 3 incl. END TO END: 2000 regions through the native region loop with --assemble=1, 32 regions per chunk)")
     stats(o + "/stats_c5", prof + "/" + tag + "_config5_stats.txt", CMD + "--config 5 --windows 200 --steps 10 --warmup 2   (MI355X; config 5: 200 windows x 100 samples per step)")
     stats(o + "/stats_c4", prof + "/" + tag + "_config4_stats.txt", CMD + "--config 4 --regions 1024 --steps 1 --no-cpu-baseline   (MI355X; config 4: 1024 regions x 100 kb, inputs resident in HBM, through the native region loop, 24 host threads x 64 regions per chunk: one serialized counting pass, two warm rounds and one timed pass; avg_us is stretched by the kernels of the other chunks running at the same time -- r05_config4_overlap.json says how many)")
+    stats(o + "/nextk", prof + "/" + tag + "_next_kernels.txt", "rocprofv3 --kernel-trace --stats --output-format csv -- python tools/next_kernels.py   (MI355X; the kernels of the SURVEY 8(f) \"next\" rows on their own, sizes in the script)")
     quantiles(o + "/stats_c4", prof + "/" + tag + "_config4_kernel_quantiles.txt", "the launches of `" + CMD + "--config 4 --regions 1024 --steps 1 --no-cpu-baseline` per kernel: a chunk = 64 regions x 100 kb; min / q25 = the kernel by itself, median / mean = with the other chunks' kernels on the chip")
     for f, dst in (("stats3", tag + "_bench_line_under_rocprof.json"), ("stats_c3e", tag + "_bench_config3_under_rocprof.json"), ("stats_c4", tag + "_bench_config4_under_rocprof.json"),
                    ("stats_c5", tag + "_bench_config5_under_rocprof.json")):
