@@ -429,7 +429,9 @@ def main():
     dp_ms, seed_ms, seedk_ms, fin_ms, gen_ms, prep_ms, sweep_ms, pairs_ms = [], [], [], [], [], [], [], []
     prof = None
     for _ in range(5):
-        eng.call_windows(db, want_stats=False)
+        # (the entry point the timed passes use: the asynchronous one leaves no record of the pairs k_pairs finishes, the synchronous one
+        #  writes 32 bytes per pair -- its k_pairs is 13 % longer, and rocprof of the timed command would not agree with it)
+        eng.call_windows(db, want_stats=False, asynchronous=not a.sync_entry)
         prof = eng.profile_last()
         dp_ms.append(prof.ms_dp); seed_ms.append(prof.ms_seed); fin_ms.append(prof.ms_finalize)
         gen_ms.append(prof.ms_genotype); prep_ms.append(prof.ms_prepare); seedk_ms.append(prof.ms_seed_kernel)
