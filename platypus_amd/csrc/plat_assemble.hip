@@ -482,7 +482,7 @@ __device__ unsigned long long g_asm_ticks[16];
 __global__ void __launch_bounds__(ASM_THREADS)
 k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int max_reads, int32_t* var_count,
            int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob,
-           int32_t* status, const long long* __restrict__ verdict)
+           int32_t* status, const long long* __restrict__ verdict, long long* work)
 {
     // (plat_assemble_batch_async: the sizes came from the caller instead of a read-back; k_asm_check left its verdict here -- a batch that
     //  does not fit them is refused as a whole, tile by tile, before anything is carved out of the scratch)
@@ -514,7 +514,10 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
     int* own_n = S.succ_w;
     for (int i = tid; i < ASM_LDS_NODES; i += nthr) own_t[i] = 0xFFFFFFFFu;
 
-    for (int g = blockIdx.x; g < b.n_regions; g += gridDim.x) {
+    // Tiles are handed out as workgroups finish (one atomic per tile on a counter the launch zeroes): with 2 000 tiles for 256 workgroups a
+    // static split gives some workgroups eight tiles and others seven, and tiles differ in depth and in what their bubbles hold.
+    __shared__ int s_next_g;
+    for (int g = blockIdx.x; g < b.n_regions;) {
         const uint8_t* ref = b.ref_seq + b.ref_off[g];
         const int refLen = (int)(b.ref_off[g + 1] - b.ref_off[g]);
         const int refStart = b.ref_start[g], aStart = b.assem_start[g], aEnd = b.assem_end[g];
@@ -1743,6 +1746,11 @@ k_assemble(plat_assembly_batch b, AsmParams P, char* scratch, int max_ref, int m
             for (int i = tid; i < ASM_LDS_NODES * ASM_MAX_SUCC; i += nthr) S.succ_c[i] = 0;
         sync_phase(); ASM_FRESH();
         ASM_TICK(8);
+        if (work) {
+            if (tid == 0) s_next_g = (int)gridDim.x + (int)atomicAdd((unsigned long long*)work, 1ull);
+            __syncthreads();
+            g = s_next_g;
+        } else g += gridDim.x;
     }
 }
 
@@ -1782,7 +1790,7 @@ using namespace plat;
 static int asm_launch(plat_ctx* ctx, const plat_assembly_batch& b, int kmer_size, int min_qual, int min_weight, int no_cycles,
                       int max_vars_per_region, int blob_per_region, int max_ref, int max_reads, long long max_pos_raw,
                       int32_t* var_count, int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob,
-                      int32_t* status, const long long* verdict, hipStream_t st);
+                      int32_t* status, const long long* verdict, long long* work, hipStream_t st);
 
 PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* batch, int kmer_size, int min_qual,
                                     int min_weight, int no_cycles, int max_vars_per_region, int blob_per_region,
@@ -1811,7 +1819,7 @@ PLAT_EXPORT int plat_assemble_batch(plat_ctx* ctx, const plat_assembly_batch* ba
     PLAT_HIP(ctx, hipStreamSynchronize(st));
     if (hb[3] != 0) return (int)hb[3];
     return asm_launch(ctx, b, kmer_size, min_qual, min_weight, no_cycles, max_vars_per_region, blob_per_region, (int)hb[0], (int)hb[1], hb[2],
-                      var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status, nullptr, st);
+                      var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status, nullptr, d_sz + 4, st);
 }
 
 PLAT_EXPORT int plat_assemble_batch_async(plat_ctx* ctx, const plat_assembly_batch* batch, const plat_assembly_hints* hints, int kmer_size, int min_qual,
@@ -1838,13 +1846,13 @@ PLAT_EXPORT int plat_assemble_batch_async(plat_ctx* ctx, const plat_assembly_bat
     hipLaunchKernelGGL(k_asm_check, dim3((b.n_regions + 255) / 256), dim3(256), 0, st, b, (long long)hints->max_ref_len, (long long)hints->max_reads_per_region,
                        (long long)hints->max_positions, d_sz);
     return asm_launch(ctx, b, kmer_size, min_qual, min_weight, no_cycles, max_vars_per_region, blob_per_region, hints->max_ref_len, hints->max_reads_per_region,
-                      hints->max_positions, var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status, d_sz, st);
+                      hints->max_positions, var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status, d_sz, d_sz + 4, st);
 }
 
 static int asm_launch(plat_ctx* ctx, const plat_assembly_batch& b, int kmer_size, int min_qual, int min_weight, int no_cycles,
                       int max_vars_per_region, int blob_per_region, int max_ref, int max_reads, long long max_pos_raw,
                       int32_t* var_count, int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd, int32_t* var_off, uint8_t* var_blob,
-                      int32_t* status, const long long* verdict, hipStream_t st)
+                      int32_t* status, const long long* verdict, long long* work, hipStream_t st)
 {
     int rc;
     // k may grow to 55 under noCycles, which only lowers the number of edges: size for the initial k
@@ -1870,7 +1878,7 @@ static int asm_launch(plat_ctx* ctx, const plat_assembly_batch& b, int kmer_size
     const int lds_bytes = ASM_LDS_BYTES;
     PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipLaunchKernelGGL(k_assemble, dim3(nblk), dim3(ASM_THREADS), lds_bytes, st, b, P, (char*)ctx->asm_scratch.ptr, max_ref, max_reads,
-                       var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status, verdict);
+                       var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status, verdict, getenv("PLAT_ASM_STATIC") ? nullptr : work);   // (PLAT_ASM_STATIC: tile g on workgroup g % grid, for A/B runs)
     PLAT_HIP(ctx, hipGetLastError());
     if (P.timing) {
         unsigned long long t[16];
