@@ -66,7 +66,7 @@ PLAT_EXPORT int plat_ctx_destroy(plat_ctx* ctx) {
     if (!ctx) return PLAT_ERR_INVALID;
     hipError_t e;
     plat_scratch* all[] = {&ctx->hapw, &ctx->tile, &ctx->codes, &ctx->rinfo, &ctx->hap_flags, &ctx->pair_rec,
-                           &ctx->jobs, &ctx->job_score, &ctx->counters, &ctx->asm_scratch, &ctx->tb, &ctx->slow, &ctx->dense, &ctx->pop_scratch, &ctx->seedbase, &ctx->merge_tab, &ctx->seedmap, &ctx->seedstate};
+                           &ctx->jobs, &ctx->job_score, &ctx->counters, &ctx->asm_scratch, &ctx->tb, &ctx->slow, &ctx->dense, &ctx->pop_scratch, &ctx->seedbase, &ctx->merge_tab, &ctx->seedmap, &ctx->seedstate, &ctx->asm_sig};
     for (plat_scratch* s : all)
         if (s->ptr) { e = hipFree(s->ptr); (void)e; }
     if (ctx->d_mapq_lut) { e = hipFree(ctx->d_mapq_lut); (void)e; }

@@ -21,7 +21,8 @@ struct plat_ctx {
     size_t lds_max = 0;
     double* d_mapq_lut = nullptr;       // log(1 - exp(mLTOT*mapq)), chaplotype.pyx:621, host libm
     // device scratch (grow-only)
-    plat_scratch hapw, tile, codes, rinfo, hap_flags, pair_rec, jobs, job_score, counters, asm_scratch, tb, slow, dense, pop_scratch, seedbase, merge_tab, seedmap, seedstate;
+    plat_scratch hapw, tile, codes, rinfo, hap_flags, pair_rec, jobs, job_score, counters, asm_scratch, tb, slow, dense, pop_scratch, seedbase, merge_tab, seedmap, seedstate, asm_sig;
+    unsigned long long asm_epoch = 0;   // counts the (re)allocations of asm_scratch: part of the signature k_assemble leaves in asm_sig
     // pinned host read-back area
     int64_t* h_readback = nullptr;
     // asynchronous entry points: first device-side error since the last plat_stream_sync (pinned, device-visible)
