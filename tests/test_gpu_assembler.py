@@ -224,3 +224,34 @@ def test_async_entry_with_the_callers_sizes_equals_the_entry_that_reads_them_bac
         with pytest.raises(_lib.PlatypusDeviceError) as e:
             eng.assemble(sel, hints=bad)
         assert e.value.code == -10                      # PLAT_ERR_BAD_HINTS
+
+
+def test_a_slice_kept_clean_across_launches_gives_the_variants_of_a_fresh_context(eng, monkeypatch):
+    """Round 5: a workgroup that ends a launch on the fused path without an error leaves the signature of its slice of the scratch behind,
+    and the next launch with the same layout skips the stores that establish the clean slot words.  A sequence of launches on ONE context
+    that keeps, drops and re-establishes that promise -- fused (k = 15), again (kept), the global path (k = 21: dropped), fused again,
+    a launch whose tiles overflow their output room (error: dropped), fused again, the three-pass path (PLAT_ASM_FUSED=0: dropped),
+    fused -- gives launch by launch what a context without the promise (PLAT_ASM_NO_KEEP=1) gives."""
+    from platypus_amd import _lib
+    from platypus_amd.engine import Engine
+    rng = np.random.default_rng(5005)
+    sets = [[synth_region(rng, 4500, 2, 250, 30, 4) for _ in range(40)] for _ in range(3)]
+    plan = [(0, 15, {}), (1, 15, {}), (0, 21, {}), (2, 15, {}), (1, 15, dict(max_vars=1)), (0, 15, {}), (2, 15, dict(env="PLAT_ASM_FUSED")), (1, 15, {}), (1, 15, {})]
+
+    def run(e):
+        out = []
+        for which, k, kw in plan:
+            if kw.get("env"):
+                monkeypatch.setenv(kw["env"], "0")
+            try:
+                out.append(e.assemble(sets[which], kmer_size=k, max_vars=kw.get("max_vars", 512)))
+            except _lib.PlatypusDeviceError as err:
+                out.append(("error", err.code))
+            if kw.get("env"):
+                monkeypatch.delenv(kw["env"])
+        return out
+    got = run(Engine(0))
+    monkeypatch.setenv("PLAT_ASM_NO_KEEP", "1")
+    want = run(Engine(0))
+    assert got == want
+    assert got[4] == ("error", -8) and sum(len(v) for v in got[0]) > 20 and got[0] == got[5] and got[1] == got[7] == got[8]
