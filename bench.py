@@ -568,7 +568,7 @@ def main():
         line["record_gather"] = gather
         if wgs is not None:
             wgs.pop("merged_text", None)
-            keep = ("windows_per_sec", "gcups", "gcups_executed", "roofline", "roofline_other", "scaling", "scaling_efficiency_basis", "regions", "windows", "records",
+            keep = ("windows_per_sec", "gcups", "gcups_executed", "roofline", "roofline_other", "roofline_more", "scaling", "scaling_efficiency_basis", "regions", "windows", "records",
                     "regions_per_sec", "reads_per_sec", "timed_s", "timed_s_runs", "host_seconds_per_region", "device_wait_seconds_per_region",
                     "stage_seconds_per_region", "record_gather", "cpus_granted_to_this_rank", "dp_reference", "dp_launched", "dp_per_launch", "stage_b", "inputs", "config",
                     "error")

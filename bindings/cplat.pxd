@@ -63,6 +63,8 @@ cdef extern from "platypus_mi355x.h":
         int64_t dp_alg_bytes
         float ms_sweep
         float ms_pairs
+        float ms_unpack
+        float ms_candidates
     int plat_profile_enable(plat_ctx* ctx, int on) nogil
     int plat_profile_last(plat_ctx* ctx, plat_profile* out) nogil
 

@@ -158,6 +158,11 @@ typedef struct plat_caller_stats {
     int64_t n_regions_dict_replay_device;   /* of the device's regions: those whose order needed the Python-2 dictionaries replayed (on the device) */
     double seconds_worker_cpu;              /* sum over worker threads of the CPU time (CLOCK_THREAD_CPUTIME_ID) their chunks took: next to seconds_host (wall
                                              * time outside waits) it says whether the workers had their cores to themselves */
+    /* plat_caller_count_cells(c, 1) only: the two widest kernels of a chunk's read table, live (HIP events on the worker's stream): summed
+     * durations, launches and ALGORITHMIC bytes -- k_unpack_pieces: one packed byte in, a base and a quality out per base of the resident
+     * tables expanded; k_candidates: the bases of the chunk's reads once (what the scan has to read) */
+    double seconds_kernel_unpack, seconds_kernel_candidates;
+    int64_t unpack_bytes, candidates_bytes, n_unpack_launches, n_candidates_launches;
 } plat_caller_stats;
 
 typedef struct plat_caller plat_caller;

@@ -88,6 +88,8 @@ typedef struct plat_profile {
     int64_t dp_alg_bytes; /* algorithmic bytes of the DP launch                                   */
     float ms_sweep;       /* k_sweep alone (round 4: the seeding stage is two kernels; 0 with PLAT_SEED_FUSED=1) */
     float ms_pairs;       /* k_pairs alone                                                         */
+    float ms_unpack;      /* the last plat_unpack_reads_pieces launch on this context since the profile was switched on (0: none) */
+    float ms_candidates;  /* the last plat_candidates_batch launch (k_candidates)                     */
 } plat_profile;
 int plat_profile_enable(plat_ctx* ctx, int on);
 int plat_profile_last(plat_ctx* ctx, plat_profile* out);   /* [syncs] */

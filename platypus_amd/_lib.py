@@ -47,7 +47,7 @@ class AlignStats(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("ms_prepare", C.c_float), ("ms_seed", C.c_float), ("ms_dp", C.c_float), ("ms_finalize", C.c_float),
                 ("ms_genotype", C.c_float), ("ms_seed_kernel", C.c_float), ("dp_jobs", C.c_int64), ("dp_alg_bytes", C.c_int64),
-                ("ms_sweep", C.c_float), ("ms_pairs", C.c_float)]
+                ("ms_sweep", C.c_float), ("ms_pairs", C.c_float), ("ms_unpack", C.c_float), ("ms_candidates", C.c_float)]
 
 
 class BatchHints(C.Structure):

@@ -110,7 +110,8 @@ struct Slot {
     bool countCells = false;                                               // plat_caller_count_cells: likelihood batches through the synchronous entry point
     int64_t nDpRef = 0, cellsRef = 0, nDpRun = 0, cellsRun = 0;            // ... and their plat_align_stats summed (this worker's share)
     int64_t nAlign = 0, alignHapBytes = 0, alignReadBytes = 0, alignReads = 0, alignDpBytes = 0;
-    double secSeed = 0.0, secDp = 0.0, secSweep = 0.0, secPairs = 0.0;
+    double secSeed = 0.0, secDp = 0.0, secSweep = 0.0, secPairs = 0.0, secUnpack = 0.0, secCand = 0.0;
+    int64_t unpackBytes = 0, candBytes = 0, nUnpack = 0, nCand = 0;
     // chunk read table (device): bases, qualities, offsets, per-read fields, CIGARs; t_pack: the bytes of PLAT_READS_PACKED tables as
     // they crossed the link (expanded into t_seq / t_qual by plat_unpack_reads), t_exc*: their exceptions
     Staged<uint8_t> t_seq, t_qual, t_mapq, t_pack, t_excb, t_excq;

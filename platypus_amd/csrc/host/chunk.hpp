@@ -70,6 +70,7 @@ struct Chunk {
 
     void regionVariants(RegionWork& r, int scan0);
     bool recordsOnHost = false;
+    int64_t tabPackedBytes = 0, tabBlobBytes = 0;                          // this chunk's table: packed bytes expanded on the device, bytes of bases in all
     size_t recArenaBytes = 0;
 
     Hap makeHap(const RegionWork& r, const WindowWork& w, const VarList& vs) const;
@@ -107,11 +108,21 @@ struct Chunk {
         const double cpu0 = threadCpuSeconds();
         double wait0 = s.t_wait;
         mark = t0; waitMark = wait0;
+        if (s.countCells) ck(plat_profile_enable(s.ctx, 1), "plat_profile_enable");     // (the counting pass: live timers of the table kernels too)
         uploadReads();
         lap(0);
         deviceB = eligibleDeviceB();
         assembleLaunch();
         if (o.getVariantsFromBAMs) scanCandidates();
+        if (s.countCells) {
+            plat_profile pf;
+            memset(&pf, 0, sizeof pf);
+            ck(plat_profile_last(s.ctx, &pf), "plat_profile_last");
+            ck(plat_profile_enable(s.ctx, 0), "plat_profile_enable");
+            if (getenv("PLAT_CALLER_TRACE")) fprintf(stderr, "[plat_caller] table kernels: unpack %.3f ms (%lld packed bytes), candidates %.3f ms (%lld bytes)\n", pf.ms_unpack, (long long)tabPackedBytes, pf.ms_candidates, (long long)tabBlobBytes);
+            if (pf.ms_unpack > 0) { s.secUnpack += 1e-3 * pf.ms_unpack; s.unpackBytes += 3 * tabPackedBytes; s.nUnpack += 1; }      // one byte in, two out per base
+            if (pf.ms_candidates > 0) { s.secCand += 1e-3 * pf.ms_candidates; s.candBytes += tabBlobBytes; s.nCand += 1; }           // the bases once: what the scan has to read
+        }
         assembleCollect();
         lap(1);
         if (deviceB) stageBFromDevice();

@@ -289,7 +289,7 @@ static int runWorkers(plat_caller* c, Feed& feed, std::atomic<bool>& failed, con
     nThreads = std::max(1, std::min<int>((int)c->slots.size(), nThreads));
     for (auto& q : c->slots) {
         q->countCells = c->countCells; q->nDpRef = q->cellsRef = q->nDpRun = q->cellsRun = 0;
-        q->nAlign = q->alignHapBytes = q->alignReadBytes = q->alignReads = q->alignDpBytes = 0; q->secSeed = q->secDp = q->secSweep = q->secPairs = 0.0;
+        q->nAlign = q->alignHapBytes = q->alignReadBytes = q->alignReads = q->alignDpBytes = 0; q->secSeed = q->secDp = q->secSweep = q->secPairs = q->secUnpack = q->secCand = 0.0; q->unpackBytes = q->candBytes = q->nUnpack = q->nCand = 0;
     }
     std::vector<std::thread> threads;
     for (int i = 1; i < nThreads; ++i) threads.emplace_back(worker, c->slots[(size_t)i].get());
@@ -300,6 +300,8 @@ static int runWorkers(plat_caller* c, Feed& feed, std::atomic<bool>& failed, con
         st.n_align_batches += q->nAlign; st.align_hap_bytes += q->alignHapBytes; st.align_read_bytes += q->alignReadBytes; st.align_reads += q->alignReads;
         st.align_dp_bytes += q->alignDpBytes; st.seconds_kernel_seed += q->secSeed; st.seconds_kernel_dp += q->secDp;
         st.seconds_kernel_sweep += q->secSweep; st.seconds_kernel_pairs += q->secPairs;
+        st.seconds_kernel_unpack += q->secUnpack; st.seconds_kernel_candidates += q->secCand; st.unpack_bytes += q->unpackBytes; st.candidates_bytes += q->candBytes;
+        st.n_unpack_launches += q->nUnpack; st.n_candidates_launches += q->nCand;
     }
     if (firstError != PLAT_OK) c->lastError = errText;
     return firstError;

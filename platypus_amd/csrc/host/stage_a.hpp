@@ -128,7 +128,9 @@ inline void Chunk::uploadReads() {
         ck(plat_memcpy_h2d(z.ctx, z.t_pieces.d, z.t_pieces.h, packed.size() * sizeof(plat_unpack_piece), z.stream), "plat_memcpy_h2d(pieces)");
         ck(plat_unpack_reads_pieces(z.ctx, (int)packed.size(), (int64_t)most, z.t_pieces.d, z.t_seq.d, z.t_qual.d, (int64_t)bo, (int64_t)eo, z.t_excidx.d, z.t_excb.d,
                                     z.t_excq.d, z.stream), "plat_unpack_reads_pieces");
+        for (const Pending& p : packed) tabPackedBytes += (int64_t)p.nb;
     }
+    tabBlobBytes = (int64_t)bo;
     nGood = nReads[0]; nScan = scan; nBad = nReads[1]; nBroken = nReads[2];
     std::lock_guard<std::mutex> g(stMutex);
     st.n_reads += (int64_t)N;

@@ -171,8 +171,11 @@ PLAT_EXPORT int plat_candidates_batch(plat_ctx* ctx, const plat_candidate_batch*
         !b.read_pos || !b.read_flags || !b.cigar || !b.cig_off || !read_region || !out_rec || !out_count || !out_status)
         return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    PLAT_EV_TAB(ctx, 2, (hipStream_t)stream);
     hipLaunchKernelGGL(plat::k_candidates, dim3((unsigned)((b.n_reads + 63) / 64)), dim3(64), 0, (hipStream_t)stream, b,
                        min_flank, min_base_qual, gen_snps, gen_indels, max_per_read, read_region, out_rec, out_count, out_status);
+    PLAT_EV_TAB(ctx, 3, (hipStream_t)stream);
+    ctx->ev_valid_cand = ctx->profile;
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -741,7 +744,10 @@ PLAT_EXPORT int plat_unpack_reads_pieces(plat_ctx* ctx, int n_pieces, int64_t ma
     const int same = ((uintptr_t)out_seq & 15) == ((uintptr_t)out_qual & 15);
     long long gx = (max_piece_bytes / 16 + 256) / 256;
     gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    PLAT_EV_TAB(ctx, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(plat::k_unpack_pieces, dim3((unsigned)gx, (unsigned)n_pieces), dim3(256), 0, (hipStream_t)stream, pieces, out_seq, out_qual, same);
+    PLAT_EV_TAB(ctx, 1, (hipStream_t)stream);
+    ctx->ev_valid_unpack = ctx->profile;
     if (n_exc > 0)
         hipLaunchKernelGGL(plat::k_unpack_exceptions, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n_exc,
                            (long long)total_bytes, exc_index, exc_base, exc_qual, out_seq, out_qual);

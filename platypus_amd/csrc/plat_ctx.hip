@@ -75,6 +75,8 @@ PLAT_EXPORT int plat_ctx_destroy(plat_ctx* ctx) {
     if (ctx->sync_event) { e = hipEventDestroy((hipEvent_t)ctx->sync_event); (void)e; }
     for (int i = 0; i < 9; ++i)
         if (ctx->ev[i]) { e = hipEventDestroy(ctx->ev[i]); (void)e; }
+    for (int i = 0; i < 4; ++i)
+        if (ctx->ev_tab[i]) { e = hipEventDestroy(ctx->ev_tab[i]); (void)e; }
     delete ctx;
     return PLAT_OK;
 }
@@ -83,8 +85,10 @@ PLAT_EXPORT int plat_profile_enable(plat_ctx* ctx, int on) {
     if (!ctx) return PLAT_ERR_INVALID;
     if (on && !ctx->ev[0])
         for (int i = 0; i < 9; ++i) PLAT_HIP(ctx, hipEventCreate(&ctx->ev[i]));
+    if (on && !ctx->ev_tab[0])
+        for (int i = 0; i < 4; ++i) PLAT_HIP(ctx, hipEventCreate(&ctx->ev_tab[i]));
     ctx->profile = on ? 1 : 0;
-    ctx->ev_valid_align = ctx->ev_valid_geno = 0;
+    ctx->ev_valid_align = ctx->ev_valid_geno = ctx->ev_valid_unpack = ctx->ev_valid_cand = 0;
     return PLAT_OK;
 }
 
@@ -109,6 +113,14 @@ PLAT_EXPORT int plat_profile_last(plat_ctx* ctx, plat_profile* out) {
     if (ctx->ev_valid_geno) {
         PLAT_HIP(ctx, hipEventSynchronize(ctx->ev[7]));
         PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_genotype, ctx->ev[6], ctx->ev[7]));
+    }
+    if (ctx->ev_valid_unpack) {
+        PLAT_HIP(ctx, hipEventSynchronize(ctx->ev_tab[1]));
+        PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_unpack, ctx->ev_tab[0], ctx->ev_tab[1]));
+    }
+    if (ctx->ev_valid_cand) {
+        PLAT_HIP(ctx, hipEventSynchronize(ctx->ev_tab[3]));
+        PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_candidates, ctx->ev_tab[2], ctx->ev_tab[3]));
     }
     return PLAT_OK;
 }

@@ -33,6 +33,8 @@ struct plat_ctx {
     int profile = 0;
     hipEvent_t ev[9] = {};          // + 8: between k_sweep and k_pairs
     int ev_valid_align = 0, ev_valid_geno = 0, ev_split = 0;
+    hipEvent_t ev_tab[4] = {};      // around k_unpack_pieces (0, 1) and k_candidates (2, 3)
+    int ev_valid_unpack = 0, ev_valid_cand = 0;
     int64_t prof_dp_jobs = 0, prof_dp_bytes = 0;
 };
 
@@ -45,6 +47,7 @@ struct plat_ctx {
         }                                                     \
     } while (0)
 
+#define PLAT_EV_TAB(ctx, i, st) do { if ((ctx)->profile) PLAT_HIP(ctx, hipEventRecord((ctx)->ev_tab[i], st)); } while (0)
 #define PLAT_EV(ctx, i, st) do { if ((ctx)->profile) PLAT_HIP(ctx, hipEventRecord((ctx)->ev[i], st)); } while (0)
 
 static inline int plat_reserve(plat_ctx* ctx, plat_scratch& s, size_t bytes) {

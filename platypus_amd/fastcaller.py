@@ -77,7 +77,8 @@ class CallerStats(C.Structure):
                 ("align_dp_bytes", C.c_int64), ("seconds_kernel_seed", C.c_double), ("seconds_kernel_dp", C.c_double),
                 ("seconds_kernel_sweep", C.c_double), ("seconds_kernel_pairs", C.c_double), ("n_regions_stage_b_device", C.c_int64),
                 ("n_regions_stage_b_host", C.c_int64), ("n_windows_stage_b_host", C.c_int64), ("n_regions_dict_replay_device", C.c_int64),
-                ("seconds_worker_cpu", C.c_double)]
+                ("seconds_worker_cpu", C.c_double), ("seconds_kernel_unpack", C.c_double), ("seconds_kernel_candidates", C.c_double),
+                ("unpack_bytes", C.c_int64), ("candidates_bytes", C.c_int64), ("n_unpack_launches", C.c_int64), ("n_candidates_launches", C.c_int64)]
 
     STAGES = ("upload", "candidate_scan", "variants_windows_haplotypes", "greedy_rounds", "window_batch", "posteriors", "read_stats_calls", "text")
 

@@ -315,10 +315,24 @@ def config4_gcups(counted, regions, T):
             cands.append(_roof("k_pairs", max(seed_alg - 2 * hapb, 0.0) + rec * nh, pairs_ms, note))
         else:
             cands.append(_roof("k_seed", seed_alg, seed_ms, note))          # (PLAT_SEED_FUSED=1: the one-kernel seeding)
-        cands.sort(key=lambda d: -d["avg_launch_ms"])
-        out["roofline"], out["roofline_other"] = cands[0], cands[1]
         for d in cands:
             d["launches"] = int(counted["n_align_batches"])
+        # ... and the two widest kernels of a chunk's READ TABLE (round 5: live timers in the counting pass): k_candidates, the scan of every
+        # base of the chunk (bytes = the bases once), and k_unpack_pieces, the expansion of the resident packed tables (one byte in, a base
+        # and a quality out) -- the one kernel of the loop that runs at the HBM roofline
+        nc_, nu_ = counted.get("n_candidates_launches", 0), counted.get("n_unpack_launches", 0)
+        if nc_ > 0:
+            d = _roof("k_candidates", counted["candidates_bytes"] / nc_, 1e3 * counted["seconds_kernel_candidates"] / nc_,
+                      "one launch per chunk of regions: a lane walks a read 32 bases per trip; bound by the chain of its waits for memory, not by bandwidth")
+            d["launches"] = int(nc_); cands.append(d)
+        if nu_ > 0:
+            d = _roof("k_unpack_pieces", counted["unpack_bytes"] / nu_, 1e3 * counted["seconds_kernel_unpack"] / nu_,
+                      "one launch per chunk of regions: streams the packed tables, 16 bytes per lane in, 2 x 16 out")
+            d["launches"] = int(nu_); cands.append(d)
+        cands.sort(key=lambda d: -d["avg_launch_ms"])
+        out["roofline"], out["roofline_other"] = cands[0], cands[1]
+        if len(cands) > 2:
+            out["roofline_more"] = cands[2:]
         out["dp_per_launch"] = counted["n_dp_launched"] / nb
     return out
 
@@ -365,7 +379,8 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
                 warm_rounds=getattr(a, "warmup", 2) or 2)
     cnt = r.get("counted") or {}
     ckeys = ("cells_reference", "cells_launched", "n_dp_reference", "n_dp_launched", "n_pairs", "regions", "n_align_batches", "align_hap_bytes", "align_read_bytes",
-             "align_reads", "align_dp_bytes", "seconds_kernel_seed", "seconds_kernel_dp", "seconds_kernel_sweep", "seconds_kernel_pairs")
+             "align_reads", "align_dp_bytes", "seconds_kernel_seed", "seconds_kernel_dp", "seconds_kernel_sweep", "seconds_kernel_pairs",
+             "seconds_kernel_unpack", "seconds_kernel_candidates", "unpack_bytes", "candidates_bytes", "n_unpack_launches", "n_candidates_launches")
     T, red = rk.reduce(r["T"], [r["windows"], r["regions"], r["records"], r["reads"], r["T_call"], r["input_bytes"]] + [float(cnt.get(k, 0)) for k in ckeys])
     wins, regs, recs, reads, tcall, inb = red[:6]
     counted_all = dict(zip(ckeys, red[6:]))                                   # summed over the ranks
