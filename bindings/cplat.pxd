@@ -346,6 +346,8 @@ cdef extern from "platypus_mi355x.h":
     int plat_variant_read_stats_batch(plat_ctx* ctx, const plat_infostats_batch* batch, int bad_reads_window,
                                       int count_only_exact_indel_matches, int64_t* out_counts, int32_t* out_per_sample,
                                       int32_t* out_minq, int32_t* out_nminq, void* stream) nogil
+    int plat_variant_info_batch(plat_ctx* ctx, int n_vars, const int64_t* counts, const int64_t* minq_off, const int32_t* minq,
+                                const int32_t* n_minq, double* out_terms, int32_t* out_mmlq, void* stream) nogil
 
     # ---- assembleReadsAndDetectVariants (assembler.pxd:3)
     ctypedef struct plat_assembly_batch:

@@ -509,6 +509,23 @@ int plat_variant_read_stats_batch(plat_ctx* ctx, const plat_infostats_batch* bat
                                   int count_only_exact_indel_matches, int64_t* out_counts, int32_t* out_per_sample,
                                   int32_t* out_minq, int32_t* out_nminq, void* stream);
 
+/* ---- the loops of two INFO fields, from the counts above ------------------------------------------------
+ * Replaces, per variant, the work inside
+ *     computeAlleleBiasPValue / computeStrandBiasPValue   vcfutils.pyx:1156-1222   (INFO ABPV -- used by the alleleBias filter -- and SbPval)
+ *     betaBinomialCDF, threeFTwo, logBetaFunction          platypusutils.pyx:178-315
+ *     sorted(minBaseQualsInWindow)[n // 2]                  vcfutils.pyx:1390-1399   (INFO MMLQ)
+ * that is a LOOP: the hypergeometric series 3F2 (|k - n + 1| terms), the sums of log-factorials (a table of the reference's own
+ * logFactorial, made with the HOST's libm when the context is created), the median.  What is left to the caller are the three libm
+ * calls of a CDF on these terms, so that the value has the bits the host's code gives:
+ *     cdf = max(1e-30, 1 - exp((terms[1] + log(terms[2])) - terms[3]))
+ * counts / minq_off / minq / n_minq: the outputs of plat_variant_read_stats_batch, still on the device.
+ * out_terms[8 v + 0..3] allele bias, [8 v + 4..7] strand bias: [0] = 0: the function returns [1] as it is (its early exits; the allele
+ * bias value is then final, min(p, 1 - p) included); 1: [1..3] are the terms of betaBinomialCDF(k, n, alpha, beta) above (allele bias:
+ * the caller still takes min(p, 1 - p)); 2: an argument of logFactorial beyond the table (4096): the caller computes the field itself.
+ * out_mmlq[v] = the median as the reference takes it, 100 when the variant has no entries.                                       */
+int plat_variant_info_batch(plat_ctx* ctx, int n_vars, const int64_t* counts, const int64_t* minq_off, const int32_t* minq,
+                            const int32_t* n_minq, double* out_terms, int32_t* out_mmlq, void* stream);
+
 /* ---- read tables that crossed the link at one byte per base --------------------------------------------
  * The loader's decode loop (htslibWrapper.pyx:330-370: 4-bit BAM code -> letter, quality byte copied, one pass over every base)
  * may write ONE byte per base instead of two: bits 0..1 = (letter >> 1) & 3 (A 0, C 1, T 2, G 3), bits 2..7 = quality 0..63

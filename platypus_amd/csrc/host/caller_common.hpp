@@ -135,7 +135,9 @@ struct Slot {
     Staged<int32_t> p_win, s_vw, s_pos, s_min, s_max, s_nadd, s_nrem, s_gb, s_ge, s_bb, s_be, s_ps, s_minq, s_nminq, k_win, k_nvar, k_vih, k_ref, k_ph;
     Staged<int64_t> p_off, s_aoff, s_moff, s_counts, k_vo, k_ro, k_lo;
     Staged<uint8_t> p_mask, s_added, s_vig;
-    Staged<double> p_prior, p_post, k_lik, k_out4;
+    Staged<double> p_prior, p_post, k_lik, k_out4, s_terms;
+    Staged<int32_t> s_mmlq;
+    bool infoOnDevice = false;                                            // this chunk's s_terms / s_mmlq are valid (plat_variant_info_batch)
     // assembler tiles (assemble=1)
     Staged<uint8_t> as_ref, as_seq, as_qual, as_mapq, as_blob;
     Staged<int64_t> as_refoff, as_roff;

@@ -410,11 +410,22 @@ inline double computeSCValue(const std::string& sequence) {               // vcf
 
 // the INFO fields vcfINFO derives from its per-read loop (vcfutils.pyx:1392-1440), from the counters of
 // plat_variant_read_stats_batch: counts[16] = TC, TC_bad, TR, TC_ab, TR_ab, NR_sb, NF_sb, TCR, TCF, TCR_sb, TCF_sb, NR, NF, nGood, nBad, sumsq
-inline void infoFieldsFromReadStats(VarInfo& d, const int64_t* c, const int32_t* perSample, int nInd, const int32_t* minq, int nminq) {
+// terms != nullptr: the loops were done on the device (plat_variant_info_batch: per p-value {state, logBeta term, threeFTwo, denominator});
+// the libm calls of betaBinomialCDF stay here, so the doubles are the ones the functions above give
+inline double cdfFromTerms(const double* t) { return std::max(1e-30, 1.0 - exp((t[1] + log(t[2])) - t[3])); }
+inline void infoFieldsFromReadStats(VarInfo& d, const int64_t* c, const int32_t* perSample, int nInd, const int32_t* minq, int nminq,
+                                    const double* terms = nullptr, int mmlqDevice = -1) {
     const long long TC = c[0], TC_bad = c[1], TR = c[2], TC_ab = c[3], TR_ab = c[4], NR_sb = c[5], NF_sb = c[6], TCR = c[7], TCF = c[8],
                     TCR_sb = c[9], TCF_sb = c[10], NR = c[11], NF = c[12], nGood = c[13], nBad = c[14], sumsq = c[15];
-    d.ABPV = Num::D(py2_round2(computeAlleleBiasPValue(TC_ab, TR_ab)));
-    d.SbPval = Num::D(py2_round2(computeStrandBiasPValue(TCF_sb, TCR_sb, NF_sb, NR_sb)));
+    double abpv, sbpv;
+    if (terms && terms[0] == 0.0) abpv = terms[1];
+    else if (terms && terms[0] == 1.0) { const double p = cdfFromTerms(terms); abpv = std::min(p, 1.0 - p); }
+    else abpv = computeAlleleBiasPValue(TC_ab, TR_ab);
+    if (terms && terms[4] == 0.0) sbpv = terms[5];
+    else if (terms && terms[4] == 1.0) sbpv = cdfFromTerms(terms + 4);
+    else sbpv = computeStrandBiasPValue(TCF_sb, TCR_sb, NF_sb, NR_sb);
+    d.ABPV = Num::D(py2_round2(abpv));
+    d.SbPval = Num::D(py2_round2(sbpv));
     d.TR = TR; d.NF = NF; d.NR = NR; d.TC = TC; d.TCR = TCR; d.TCF = TCF;
     d.BRF = Num::D(py2_round2((double)nBad / (double)(nGood + nBad)));
     d.nReadsPerSample.resize(nInd); d.nVarReadsPerSample.resize(nInd);
@@ -422,7 +433,8 @@ inline void infoFieldsFromReadStats(VarInfo& d, const int64_t* c, const int32_t*
     const float rms = (float)sumsq;                                       // `cdef float RMSMQ`: the quotient is a C float too
     if (TC + TC_bad > 0 && rms > 0) d.MQ = Num::D(py2_round2(sqrt((double)(rms / (float)(TC + TC_bad)))));
     else d.MQ = Num::I(0);
-    if (nminq > 0) {                                                      // sorted(...)[n // 2]: the element a full sort would leave there
+    if (mmlqDevice >= 0) d.MMLQ = mmlqDevice;
+    else if (nminq > 0) {                                                 // sorted(...)[n // 2]: the element a full sort would leave there
         int small[256];
         std::vector<int> big;
         int* q = small;

@@ -210,6 +210,7 @@ inline void Chunk::callWindows(std::vector<WindowWork*>& wins, bool fromDevice) 
     L.upload(z, z.a_sin);
     LO.add(z.s_counts, nSV * 16); LO.add(z.s_ps, nSV * (size_t)nInd * 2); LO.add(z.s_nminq, nSV); LO.add(z.s_minq, (size_t)mtot);
     LO.add(z.k_ph, nSites * (size_t)nInd * 2); LO.add(z.k_lik, (size_t)klo.back()); LO.add(z.k_out4, nSites * (size_t)nInd * 4);
+    LO.add(z.s_terms, nSV * 8); LO.add(z.s_mmlq, nSV);
     LO.commit(z, z.a_sout);
     plat_infostats_batch ib;
     memset(&ib, 0, sizeof ib);
@@ -221,6 +222,13 @@ inline void Chunk::callWindows(std::vector<WindowWork*>& wins, bool fromDevice) 
     ib.read_flags = z.t_flags.d; ib.cigar = z.t_cigar.d; ib.cig_off = z.t_cigoff.d;
     ck(plat_variant_read_stats_batch(z.ctx, &ib, o.badReadsWindow, o.countOnlyExactIndelMatches, z.s_counts.d, z.s_ps.d, z.s_minq.d, z.s_nminq.d, z.stream),
        "plat_variant_read_stats_batch");
+    {   // the loops of ABPV / SbPval / MMLQ behind it, on the device (the host keeps the libm calls; a device library without it: the host's loops)
+        static const bool hostInfo = getenv("PLAT_CALLER_HOST_INFO") != nullptr;
+        const int rci = hostInfo ? PLAT_ERR_UNSUPPORTED
+                                 : plat_variant_info_batch(z.ctx, (int)nSV, z.s_counts.d, z.s_moff.d, z.s_minq.d, z.s_nminq.d, z.s_terms.d, z.s_mmlq.d, z.stream);
+        if (rci != PLAT_ERR_UNSUPPORTED) ck(rci, "plat_variant_info_batch");
+        z.infoOnDevice = rci == PLAT_OK;
+    }
     ck(plat_genotype_call_batch(z.ctx, (int)nSites, nInd, db.hapbegin, db.gloff, z.o_gl.d, z.o_gof.d, z.o_freq.d, z.k_win.d, z.k_nvar.d, z.k_vo.d,
                                 z.k_ro.d, z.k_vih.d, z.k_ref.d, z.k_lo.d, z.k_ph.d, z.k_lik.d, z.k_out4.d, z.stream), "plat_genotype_call_batch");
     LO.download(z, z.a_sout);

@@ -50,7 +50,8 @@ inline void Chunk::writeWindow(RegionWork& r, WindowWork& w, const std::vector<i
         VarInfo& d = w.info[k];
         const size_t sv = (size_t)w.firstStatVar + k;
         PROF("text.info");
-        infoFieldsFromReadStats(d, z.s_counts.h + 16 * sv, z.s_ps.h + 2 * sv * (size_t)nInd, nInd, z.s_minq.h + z.s_moff.h[sv], z.s_nminq.h[sv]);
+        infoFieldsFromReadStats(d, z.s_counts.h + 16 * sv, z.s_ps.h + 2 * sv * (size_t)nInd, nInd, z.s_minq.h + z.s_moff.h[sv], z.s_nminq.h[sv],
+                                z.infoOnDevice ? z.s_terms.h + 8 * sv : nullptr, z.infoOnDevice ? z.s_mmlq.h[sv] : -1);
         if (d.TR > 0) {                                                // :1400-1409
             const double qual = strtod(d.PP.c_str(), nullptr);
             if (qual > 2500) d.QD = Num::I(o.qdThreshold + 10);

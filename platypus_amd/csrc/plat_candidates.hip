@@ -7,6 +7,8 @@
 // any ordering step.  Merging equal variants and counting their supporting reads (addVariantToList, :499-527) is a
 // dictionary operation over the few records that come back; it stays on the host (hostapi.VariantCandidateGenerator).
 #include "plat_internal.hpp"
+#include <mutex>
+#include <math.h>
 
 namespace plat {
 
@@ -563,6 +565,124 @@ PLAT_EXPORT int plat_variant_read_stats_batch(plat_ctx* ctx, const plat_infostat
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(plat::k_variant_read_stats, dim3(b.n_vars), dim3(64), 0, (hipStream_t)stream, b, bad_reads_window,
                        count_only_exact_indel_matches, out_counts, out_per_sample, out_minq, out_nminq);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}
+
+// ---- the loops of INFO ABPV / SbPval / MMLQ on the device (plat_variant_info_batch) -----------------------------------------------------
+namespace plat {
+constexpr int LOGFACT_N = 4096;
+// betaBinomialCDF(k, n, alpha, beta) as its three terms (platypusutils.pyx:267-315): t[1] = logBeta(beta + n - k - 1, alpha + k + 1),
+// t[2] = threeFTwo(k, n, alpha, beta), t[3] = logBeta(alpha, beta) + logBeta(n - k, k + 2) + log(n + 1).  Returns the state word: 1, or 2
+// when a log-factorial lies beyond the table.  (k == n is the caller's: the function returns 1.0 there.)
+__device__ __forceinline__ double cdf_terms(long long k, long long n, long long alpha, long long beta, const double* __restrict__ LF, double* t)
+{
+    const double* LOGI = LF + LOGFACT_N;                                  // LOGI[m - 1] = log((double)m), m = 1 .. 4096
+    auto in = [](long long x) { return x >= 0 && x < LOGFACT_N; };
+    const long long x1 = beta + n - k - 1, y1 = alpha + k + 1, x3 = n - k, y3 = k + 2;
+    if (!in(x1 - 1) || !in(y1 - 1) || !in(x1 + y1 - 1) || !in(alpha - 1) || !in(beta - 1) || !in(alpha + beta - 1) || !in(x3 - 1) || !in(y3 - 1) ||
+        !in(x3 + y3 - 1) || n + 1 < 1 || n + 1 > LOGFACT_N)
+        return 2.0;
+    auto logBeta = [&](long long x, long long y) { return (LF[x - 1] + LF[y - 1]) - LF[x + y - 1]; };
+    const double a_2 = (double)alpha + (double)k + 1.0, a_3 = (double)k - (double)n + 1.0, b_1 = (double)k + 2.0,
+                 b_2 = -(double)beta - (double)n + (double)k + 2.0;
+    double theSum = 1.0, lastTerm = 1.0;
+    const long long m = k - n + 1 < 0 ? -(k - n + 1) : k - n + 1;
+    for (long long i = 1; i <= m; ++i) {
+        const double di = (double)i;
+        const double newTerm = lastTerm * (a_2 + di - 1) * (a_3 + di - 1) / ((b_1 + di - 1) * (b_2 + di - 1));
+        theSum += newTerm;
+        lastTerm = newTerm;
+    }
+    t[1] = logBeta(x1, y1);
+    t[2] = theSum;
+    t[3] = logBeta(alpha, beta) + logBeta(x3, y3) + LOGI[n];              // log((double)(n + 1))
+    return 1.0;
+}
+
+// one wave per variant: lane 0 the two p-values' terms, the wave the median
+__global__ void __launch_bounds__(64)
+k_variant_info(int n_vars, const int64_t* __restrict__ counts, const int64_t* __restrict__ minq_off, const int32_t* __restrict__ minq,
+               const int32_t* __restrict__ n_minq, const double* __restrict__ LF, double* __restrict__ out_terms, int32_t* __restrict__ out_mmlq)
+{
+    const int v = blockIdx.x, lane = threadIdx.x;
+    if (v >= n_vars) return;
+    const int64_t* c = counts + 16ll * v;
+    if (lane == 0) {
+        double* t = out_terms + 8ll * v;
+        // computeAlleleBiasPValue(totalReads = TC_ab, variantReads = TR_ab), vcfutils.pyx:1156-1173
+        const long long total = c[3], var = c[4];
+        t[0] = 0.0; t[1] = 1.0; t[2] = 0.0; t[3] = 0.0;
+        if (!(total > 0 && (double)var / (double)total >= 0.5) && total != 0) {
+            if (var == total) { t[1] = 0.0; }                            // betaBinomialCDF == 1.0: min(1.0, 0.0)
+            else t[0] = cdf_terms(var, total, 20, 20, LF, t);
+        }
+        // computeStrandBiasPValue(nFwdReads = TCF_sb, nRevReads = TCR_sb, nFwdVarReads = NF_sb, nRevVarReads = NR_sb), :1177-1222
+        double* u = t + 4;
+        const long long nF = c[10], nR = c[9], vF = c[6], vR = c[5];
+        u[0] = 0.0; u[1] = 1.0; u[2] = 0.0; u[3] = 0.0;
+        if (!(nF == 0 || nR == 0) && nF + nR > 0 && vF + vR > 0) {
+            const bool useForward = !(nF < nR);
+            const double freq = (double)(useForward ? nF : nR) / (double)(nF + nR);
+            long long alpha, beta;
+            if (freq < 0.5) { alpha = 20; beta = (long long)((double)alpha / freq - (double)alpha); }
+            else if (freq > 0.5) { beta = 20; alpha = (long long)((double)beta * freq / (1.0 - freq)); }
+            else alpha = beta = 20;
+            const long long k = useForward ? vF : vR, n = vF + vR;
+            if (k == n) u[1] = 1.0;                                      // betaBinomialCDF's own early exit
+            else u[0] = cdf_terms(k, n, alpha, beta, LF, u);
+        }
+    }
+    // sorted(values)[n // 2]: the element with n // 2 smaller-or-earlier-equal ones in front of it
+    const int n = n_minq[v];
+    const int32_t* q = minq + minq_off[v];
+    int med = 100;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const int mine = i < n ? q[i] : 0;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { const int o = q[j]; rank += (o < mine) || (o == mine && j < i); }
+        const unsigned long long hit = __ballot(i < n && rank == n / 2);
+        if (hit) med = __shfl(mine, (int)__builtin_ctzll(hit), 64);
+    }
+    if (lane == 0) out_mmlq[v] = med;
+}
+}  // namespace plat
+
+PLAT_EXPORT int plat_variant_info_batch(plat_ctx* ctx, int n_vars, const int64_t* counts, const int64_t* minq_off, const int32_t* minq,
+                                        const int32_t* n_minq, double* out_terms, int32_t* out_mmlq, void* stream)
+{
+    if (!ctx || n_vars < 0) return PLAT_ERR_INVALID;
+    if (n_vars == 0) return PLAT_OK;
+    if (!counts || !minq_off || !minq || !n_minq || !out_terms || !out_mmlq) return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_logfact) {
+        // logFactorial as the reference computes it (platypusutils.pyx:178-191: a sum of logs below 15, Stirling's series with pow() above) and
+        // log(m), both with the HOST's libm: the device adds table entries, it never calls a transcendental function for these fields
+        static double lut[2 * plat::LOGFACT_N];
+        static bool made = false;
+        static std::mutex mk;
+        {
+            std::lock_guard<std::mutex> g(mk);
+            if (!made) {
+                for (int x = 0; x < plat::LOGFACT_N; ++x) {
+                    double ans = 0.0;
+                    if (x < 15) for (int i = 1; i <= x; ++i) ans += log((double)i);
+                    else {
+                        const double y = (double)x;
+                        ans = (y * log(y) + log(2.0 * M_PI * y) / 2 - y + (pow(y, -1)) / 12 - (pow(y, -3)) / 360 + (pow(y, -5)) / 1260 - (pow(y, -7)) / 1680 + (pow(y, -9)) / 1188);
+                    }
+                    lut[x] = ans;
+                    lut[plat::LOGFACT_N + x] = log((double)(x + 1));
+                }
+                made = true;
+            }
+        }
+        PLAT_HIP(ctx, hipMalloc(&ctx->d_logfact, sizeof(lut)));
+        PLAT_HIP(ctx, hipMemcpy(ctx->d_logfact, lut, sizeof(lut), hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(plat::k_variant_info, dim3((unsigned)n_vars), dim3(64), 0, (hipStream_t)stream, n_vars, counts, minq_off, minq, n_minq,
+                       (const double*)ctx->d_logfact, out_terms, out_mmlq);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }

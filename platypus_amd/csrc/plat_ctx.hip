@@ -70,6 +70,7 @@ PLAT_EXPORT int plat_ctx_destroy(plat_ctx* ctx) {
     for (plat_scratch* s : all)
         if (s->ptr) { e = hipFree(s->ptr); (void)e; }
     if (ctx->d_mapq_lut) { e = hipFree(ctx->d_mapq_lut); (void)e; }
+    if (ctx->d_logfact) { e = hipFree(ctx->d_logfact); (void)e; }
     if (ctx->h_readback) { e = hipHostFree(ctx->h_readback); (void)e; }
     if (ctx->h_sticky) { e = hipHostFree(ctx->h_sticky); (void)e; }
     if (ctx->sync_event) { e = hipEventDestroy((hipEvent_t)ctx->sync_event); (void)e; }

@@ -20,6 +20,7 @@ struct plat_ctx {
     int n_cu = 0;
     size_t lds_max = 0;
     double* d_mapq_lut = nullptr;       // log(1 - exp(mLTOT*mapq)), chaplotype.pyx:621, host libm
+    double* d_logfact = nullptr;        // logFactorial(0 .. 4095) then log(1 .. 4096) (platypusutils.pyx:178-191), host libm: plat_variant_info_batch
     // device scratch (grow-only)
     plat_scratch hapw, tile, codes, rinfo, hap_flags, pair_rec, jobs, job_score, counters, asm_scratch, tb, slow, dense, pop_scratch, seedbase, merge_tab, seedmap, seedstate, asm_sig;
     unsigned long long asm_epoch = 0;   // counts the (re)allocations of asm_scratch: part of the signature k_assemble leaves in asm_sig

@@ -477,6 +477,9 @@ API int plat_variant_read_stats_batch(plat_ctx* c, const plat_infostats_batch* b
     return PLAT_OK;
 }
 
+API int plat_variant_info_batch(plat_ctx* c, int n, const int64_t* counts, const int64_t* mo, const int32_t* mq, const int32_t* nm, double* t, int32_t* m, void* st)
+{ (void)c; (void)n; (void)counts; (void)mo; (void)mq; (void)nm; (void)t; (void)m; (void)st; return PLAT_ERR_UNSUPPORTED; }   /* the host's own loops then */
+
 API int plat_assemble_batch(plat_ctx* c, const plat_assembly_batch* b, int kmer_size, int min_qual, int min_weight, int no_cycles,
                             int max_vars, int blob_per_region, int32_t* var_count, int32_t* var_pos, int32_t* var_nrem, int32_t* var_nadd,
                             int32_t* var_off, uint8_t* var_blob, int32_t* status, void* stream)
