@@ -398,12 +398,17 @@ inline int homopolymerLengthForOneVariant(const Variant& v, const Fasta& fa) {
 inline std::string getSequenceContext(const Variant& v, const Fasta& fa) { return fa.getSequence(v.refPos - 10, v.refPos + 11); }   // :500-506
 
 inline double computeSCValue(const std::string& sequence) {               // vcfutils.pyx:1480-1498
-    int counts[256] = {0};
+    // the two most frequent characters of the 21-base context: counted among the characters that occur (a table of 256 counters was
+    // cleared and scanned per called position)
+    static thread_local int counts[256];                                  // all zero between calls
     for (unsigned char c : sequence) ++counts[c];
     int best = 0, second = 0;
-    for (int c = 0; c < 256; ++c) {
-        if (counts[c] > best) { second = best; best = counts[c]; }
-        else if (counts[c] > second) second = counts[c];
+    for (unsigned char c : sequence) {
+        const int n = counts[c];
+        if (n == 0) continue;                                             // this character was taken already
+        counts[c] = 0;
+        if (n > best) { second = best; best = n; }
+        else if (n > second) second = n;
     }
     return (double)(best + second) / (double)sequence.size();
 }
