@@ -65,6 +65,9 @@ int plat_memcpy_d2h(plat_ctx* ctx, void* dst_host, const void* src_dev, size_t b
 int plat_memcpy_d2d(plat_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 int plat_memset(plat_ctx* ctx, void* dst_dev, int value, size_t bytes, void* stream);
 int plat_stream_sync(plat_ctx* ctx, void* stream);          /* [syncs] */
+/* plat_stream_sync waits asleep: it polls an event every PLAT_SYNC_POLL_US microseconds (environment, default 40; 0 = the
+ * runtime's blocking hipEventSynchronize; PLAT_SYNC_SPIN=1 = hipStreamSynchronize).  While it naps it lowers the CALLING thread's
+ * timer slack (prctl PR_SET_TIMERSLACK) to 2 us and puts the previous value back before it returns. */
 /* a HIP stream of the context's device (hipStream_t as void*), for callers without a HIP runtime binding of their own;
  * pinned (page-locked) host memory for staging buffers: copies from / to it are asynchronous and run at link speed */
 int plat_stream_create(plat_ctx* ctx, void** out_stream);

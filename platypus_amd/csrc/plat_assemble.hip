@@ -1894,13 +1894,25 @@ static int asm_launch(plat_ctx* ctx, const plat_assembly_batch& b, int kmer_size
         if ((rc = plat_reserve(ctx, ctx->asm_sig, 4096 * sizeof(unsigned long long)))) return rc;
         PLAT_HIP(ctx, hipMemsetAsync(ctx->asm_sig.ptr, 0, 4096 * sizeof(unsigned long long), st));
     }
+    unsigned long long* wg_sig = (nblk <= 4096 && !getenv("PLAT_ASM_NO_KEEP")) ? (unsigned long long*)ctx->asm_sig.ptr : nullptr;
+    // A launch only rewrites wg_sig[] of the workgroups it runs, and a slice sits at blockIdx.x * per_block: a launch with ANOTHER layout (or one
+    // that ran without the signature array) overwrites slices of workgroups whose stored signature it never touches.  Every stored signature is
+    // therefore made stale -- the epoch is part of it and only grows -- whenever the layout differs from the previous launch's.
+    {
+        unsigned long long lay = 0xCBF29CE484222325ull;
+        for (unsigned long long v : {(unsigned long long)per_block, (unsigned long long)cap, (unsigned long long)max_pos, (unsigned long long)max_ref, (unsigned long long)max_reads})
+            lay = (lay ^ v) * 0x100000001B3ull + (lay >> 31);
+        lay |= 1ull;
+        if (lay != ctx->asm_last_layout || !ctx->asm_last_kept) ++ctx->asm_epoch;
+        ctx->asm_last_layout = lay;
+        ctx->asm_last_kept = wg_sig != nullptr;
+    }
     // the layout of a workgroup's slice: what asm_carve is given + where the slices lie (never 0)
     unsigned long long sig = 0x9E3779B97F4A7C15ull;
     for (unsigned long long v : {(unsigned long long)(uintptr_t)ctx->asm_scratch.ptr, (unsigned long long)per_block, (unsigned long long)cap, (unsigned long long)max_pos,
                                  (unsigned long long)max_ref, (unsigned long long)max_reads, ctx->asm_epoch})
         sig = (sig ^ v) * 0x100000001B3ull + (sig >> 29);
     sig |= 1ull;
-    unsigned long long* wg_sig = (nblk <= 4096 && !getenv("PLAT_ASM_NO_KEEP")) ? (unsigned long long*)ctx->asm_sig.ptr : nullptr;
     const int lds_bytes = ASM_LDS_BYTES;
     PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipLaunchKernelGGL(k_assemble, dim3(nblk), dim3(ASM_THREADS), lds_bytes, st, b, P, (char*)ctx->asm_scratch.ptr, max_ref, max_reads,

@@ -304,6 +304,7 @@ PLAT_EXPORT int plat_candidates_merge_batch(plat_ctx* ctx, const plat_candidate_
 {
     if (!ctx || !batch || n_scans < 0 || max_per_read < 1 || cap_per_scan < 1) return PLAT_ERR_INVALID;
     if (n_scans == 0) return PLAT_OK;
+    if (n_scans > PLAT_GRID_Y_MAX) return PLAT_ERR_OVERFLOW;       // (one scan = one region of a chunk; the merge table is per scan)
     const plat_candidate_batch b = *batch;
     if (!b.ref_seq || !b.read_seq || !b.read_pos || !read_end || !scan_read_begin || !scan_longest || !rec || !count || !status || !out_cand || !out_n)
         return PLAT_ERR_INVALID;
@@ -865,7 +866,10 @@ PLAT_EXPORT int plat_unpack_reads_pieces(plat_ctx* ctx, int n_pieces, int64_t ma
     long long gx = (max_piece_bytes / 16 + 256) / 256;
     gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
     PLAT_EV_TAB(ctx, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(plat::k_unpack_pieces, dim3((unsigned)gx, (unsigned)n_pieces), dim3(256), 0, (hipStream_t)stream, pieces, out_seq, out_qual, same);
+    for (int p0 = 0; p0 < n_pieces; p0 += PLAT_GRID_Y_MAX) {      // (gridDim.y holds at most 65 535 pieces: one launch per batch of them)
+        const int np = n_pieces - p0 < PLAT_GRID_Y_MAX ? n_pieces - p0 : PLAT_GRID_Y_MAX;
+        hipLaunchKernelGGL(plat::k_unpack_pieces, dim3((unsigned)gx, (unsigned)np), dim3(256), 0, (hipStream_t)stream, pieces + p0, out_seq, out_qual, same);
+    }
     PLAT_EV_TAB(ctx, 1, (hipStream_t)stream);
     ctx->ev_valid_unpack = ctx->profile;
     if (n_exc > 0)
@@ -913,8 +917,11 @@ PLAT_EXPORT int plat_concat_read_tables(plat_ctx* ctx, int n_tables, int max_rea
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
     unsigned gx = (unsigned)((max_reads_per_table + 255) / 256);
     gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
-    hipLaunchKernelGGL(plat::k_concat_tables, dim3(gx, (unsigned)n_tables), dim3(256), 0, (hipStream_t)stream, desc, dst_off, dst_pos, dst_end,
-                       dst_mapq, dst_flags, dst_cig_off, dst_cigar, dst_region, (long long)n_total_reads, (long long)total_bytes, (long long)total_pairs);
+    for (int t0 = 0; t0 < n_tables; t0 += PLAT_GRID_Y_MAX) {      // (every batch's first block also writes the table's closing entries: the same values)
+        const int nt = n_tables - t0 < PLAT_GRID_Y_MAX ? n_tables - t0 : PLAT_GRID_Y_MAX;
+        hipLaunchKernelGGL(plat::k_concat_tables, dim3(gx, (unsigned)nt), dim3(256), 0, (hipStream_t)stream, desc + t0, dst_off, dst_pos, dst_end,
+                           dst_mapq, dst_flags, dst_cig_off, dst_cigar, dst_region, (long long)n_total_reads, (long long)total_bytes, (long long)total_pairs);
+    }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -944,7 +951,10 @@ PLAT_EXPORT int plat_copy_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
     long long gx = (max_piece_bytes / 8 + 256) / 256;
     gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
-    hipLaunchKernelGGL(plat::k_copy_pieces, dim3((unsigned)gx, (unsigned)n_pieces), dim3(256), 0, (hipStream_t)stream, pieces, dst_blob);
+    for (int p0 = 0; p0 < n_pieces; p0 += PLAT_GRID_Y_MAX) {      // (a whole job's regions are one piece each in the exchange: more than gridDim.y holds)
+        const int np = n_pieces - p0 < PLAT_GRID_Y_MAX ? n_pieces - p0 : PLAT_GRID_Y_MAX;
+        hipLaunchKernelGGL(plat::k_copy_pieces, dim3((unsigned)gx, (unsigned)np), dim3(256), 0, (hipStream_t)stream, pieces + p0, dst_blob);
+    }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }

@@ -210,16 +210,22 @@ PLAT_EXPORT int plat_stream_sync(plat_ctx* ctx, void* stream) {
         PLAT_HIP(ctx, hipEventRecord((hipEvent_t)ctx->sync_event, (hipStream_t)stream));
         if (poll_ns == 0) PLAT_HIP(ctx, hipEventSynchronize((hipEvent_t)ctx->sync_event));
         else {
-            static thread_local bool slack = false;                          // (the default timer slack of 50 us would double every nap)
-            if (!slack) { prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0); slack = true; }
+            // (the default timer slack of 50 us would double every nap: 2 us while THIS wait lasts; the calling thread may be the
+            //  application's own -- worker 0 of plat_call_regions runs on the caller -- so its slack is put back before returning)
+            const int slack0 = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+            bool napped = false;
+            hipError_t bad = hipSuccess;
             for (;;) {
                 const hipError_t q = hipEventQuery((hipEvent_t)ctx->sync_event);
                 if (q == hipSuccess) break;
-                if (q != hipErrorNotReady) PLAT_HIP(ctx, q);
+                if (q != hipErrorNotReady) { bad = q; break; }
                 (void)hipGetLastError();                                     // (hipErrorNotReady is sticky in hipGetLastError otherwise)
+                if (!napped) { if (slack0 > 2000) prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0); napped = true; }
                 timespec ts{0, poll_ns};
                 nanosleep(&ts, nullptr);
             }
+            if (napped && slack0 > 2000) prctl(PR_SET_TIMERSLACK, (unsigned long)slack0, 0, 0, 0);
+            if (bad != hipSuccess) PLAT_HIP(ctx, bad);
         }
     }
     if (ctx->h_sticky && ctx->h_sticky[0] != 0) {          // error recorded by an asynchronous call since the last sync

@@ -8,6 +8,7 @@
 #include "../../include/platypus_mi355x.h"
 
 #define PLAT_EXPORT extern "C" __attribute__((visibility("default")))
+#define PLAT_GRID_Y_MAX 65535          /* HIP's limit on gridDim.y: launches that put a list in y go in batches of this many */
 
 struct plat_scratch {
     void* ptr = nullptr;
@@ -23,7 +24,10 @@ struct plat_ctx {
     double* d_logfact = nullptr;        // logFactorial(0 .. 4095) then log(1 .. 4096) (platypusutils.pyx:178-191), host libm: plat_variant_info_batch
     // device scratch (grow-only)
     plat_scratch hapw, tile, codes, rinfo, hap_flags, pair_rec, jobs, job_score, counters, asm_scratch, tb, slow, dense, pop_scratch, seedbase, merge_tab, seedmap, seedstate, asm_sig;
-    unsigned long long asm_epoch = 0;   // counts the (re)allocations of asm_scratch: part of the signature k_assemble leaves in asm_sig
+    unsigned long long asm_epoch = 0;   // counts the (re)allocations of asm_scratch AND the changes of the slice layout between launches: part of the signature k_assemble leaves in asm_sig
+    unsigned long long asm_last_layout = 0;   // the previous launch's slice layout (sizes asm_carve is given)
+    bool sb_attr_set = false;           // k_sb_variants' dynamic-LDS limit has been raised on this context's device
+    bool asm_last_kept = false;         // ... and whether it maintained asm_sig (a launch without it dirties slices behind the signatures' back)
     // pinned host read-back area
     int64_t* h_readback = nullptr;
     // asynchronous entry points: first device-side error since the last plat_stream_sync (pinned, device-visible)

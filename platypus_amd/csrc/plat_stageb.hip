@@ -1128,10 +1128,9 @@ PLAT_EXPORT int plat_stage_b_batch(plat_ctx* ctx, const plat_stage_b_in* batch, 
     in.b = b; in.o = *options;
     for (int k = 0; k < 16; ++k) in.pow01[k] = pow(0.1, (double)k);    // (host libm: what Variant.calculatePrior multiplies with)
     hipStream_t st = (hipStream_t)stream;
-    static bool once = false;
-    if (!once) {
+    if (!ctx->sb_attr_set) {                                            // (the attribute is per device: remembered per context, as k_assemble's launch sets its own)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)plat::k_sb_variants, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(plat::SbRegion)));
-        once = true;
+        ctx->sb_attr_set = true;
     }
     hipLaunchKernelGGL(plat::k_sb_variants, dim3((unsigned)b.n_regions), dim3(plat::SB_THREADS), sizeof(plat::SbRegion), st, in, o,
                        (const int32_t*)ctx->merge_tab.ptr);

@@ -71,8 +71,6 @@ class RegionTextExchange:
 
     regions_of_rank[r] = [(chrom, start, end), ...] in rank r's list order (the same on every rank)."""
 
-    _pinned = None                                                       # cached pinned host block for the merged text (grown, never shrunk)
-
     def __init__(self, regions_of_rank, dist=None, device=None, lib=None, device_index=0):
         from . import fastcaller as F
         self.F, self.lib, self.dist = F, lib, dist if (dist is not None and dist.is_initialized()) else None
@@ -83,6 +81,7 @@ class RegionTextExchange:
         self.counts = [len(x) for x in regions_of_rank]
         self.plan = F.BlockOrder([[(chrom_key(c), int(s), int(e)) for c, s, e in regs] for regs in regions_of_rank])
         self.ctx = None
+        self._pinned = None                                              # this exchange's pinned host block for the merged text (grown, never shrunk)
         if self.on_device and self.rank == 0:
             import ctypes as C
             from . import _lib
@@ -92,9 +91,23 @@ class RegionTextExchange:
                 raise RuntimeError("plat_ctx_create failed")
             self.ctx = ctx
 
+    def close(self):
+        """Give the device context back (rank 0 of an "nccl" job holds one for the scatter kernel)."""
+        ctx, self.ctx = self.ctx, None
+        if ctx is not None:
+            try:
+                self._dl.plat_ctx_destroy(ctx)
+            except Exception:                                            # pragma: no cover  (interpreter shutdown)
+                pass
+        self._pinned = None
+
+    def __del__(self):
+        self.close()
+
     def exchange(self, text, lengths):
         """text: this rank's record text (bytes / raw view); lengths: int64 bytes per region of this rank (NativeCaller.region_text_lengths).
-        Returns the merged text on rank 0 (a buffer: bytes(x) / memoryview(x) give its bytes), None elsewhere."""
+        Returns the merged text on rank 0 (a buffer: bytes(x) / memoryview(x) give its bytes), None elsewhere.  Under "nccl" the buffer is
+        a view of this object's pinned block: it holds the text until the NEXT exchange() of the same object (copy it to keep it longer)."""
         import torch
         F = self.F
         lengths = np.ascontiguousarray(lengths, dtype=np.int64)
@@ -157,10 +170,9 @@ class RegionTextExchange:
             rc = self._dl.plat_copy_pieces(self.ctx, int(len(pieces)), int(ln.max()), C.c_void_p(pd.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(stream))
             if rc != 0:
                 raise RuntimeError("plat_copy_pieces failed (%d)" % rc)
-        cls = RegionTextExchange
-        if cls._pinned is None or cls._pinned.numel() < total:
-            cls._pinned = torch.empty(int(total * 1.25) + 64, dtype=torch.uint8).pin_memory()
-        host = cls._pinned[:total]
+        if self._pinned is None or self._pinned.numel() < total:
+            self._pinned = torch.empty(int(total * 1.25) + 64, dtype=torch.uint8).pin_memory()
+        host = self._pinned[:total]
         host.copy_(out[:total], non_blocking=True)
         torch.cuda.synchronize(self.device)
         return host.numpy()

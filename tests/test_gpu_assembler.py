@@ -255,3 +255,23 @@ def test_a_slice_kept_clean_across_launches_gives_the_variants_of_a_fresh_contex
     want = run(Engine(0))
     assert got == want
     assert got[4] == ("error", -8) and sum(len(v) for v in got[0]) > 20 and got[0] == got[5] and got[1] == got[7] == got[8]
+
+
+def test_a_launch_with_another_layout_makes_every_kept_slice_stale(eng, monkeypatch):
+    """Round 6: a slice sits at blockIdx.x * per_block and a launch only rewrites the signatures of the workgroups it
+    runs.  A (40 tiles), B (10 larger tiles: a larger per_block, so B's slices 0..9 cover A's slices 10 and up), A again on ONE context:
+    the third launch must not trust the signatures A left for workgroups 10..39.  Launch by launch the variants of a context without
+    the promise (PLAT_ASM_NO_KEEP=1); several rounds, so that a layout that comes back is seen with stale, not absent, signatures."""
+    from platypus_amd.engine import Engine
+    rng = np.random.default_rng(6006)
+    many = [synth_region(rng, 3000, 2, 150, 30, 4) for _ in range(40)]
+    few = [synth_region(rng, 6000, 3, 250, 40, 5) for _ in range(10)]
+    plan = [many, few, many, many, few, few, many]
+
+    def run(e):
+        return [e.assemble(s, kmer_size=15) for s in plan]
+    got = run(Engine(0))
+    monkeypatch.setenv("PLAT_ASM_NO_KEEP", "1")
+    want = run(Engine(0))
+    assert got == want
+    assert got[0] == got[2] == got[3] == got[6] and got[1] == got[4] == got[5] and sum(len(v) for v in got[0]) > 20

@@ -154,3 +154,31 @@ def test_concat_read_tables(eng):
     for k in ("pos", "end", "mapq", "flags"):
         assert np.array_equal(g[k][:N], np.concatenate(want[k]))
     assert np.array_equal(g["cigar"], np.concatenate(want["cigar"] + [[0, 0]])) and np.array_equal(g["region"][:N], np.concatenate(want["region"]))
+
+
+def test_more_pieces_than_a_grid_dimension_holds(eng):
+    """Round 6: the pieces of a launch sit in gridDim.y (at most 65 535); a job-wide exchange hands plat_copy_pieces one piece per
+    region.  70 000 pieces of 0..40 bytes: copied and unpacked exactly, the bytes between them untouched."""
+    import torch
+    from platypus_amd import _lib
+    rng = np.random.default_rng(66)
+    n = 70000
+    sizes = rng.integers(0, 41, n).astype(np.int64)
+    gaps = rng.integers(0, 3, n).astype(np.int64)
+    src_at = np.cumsum(sizes + 1) - (sizes + 1)
+    dst_at = np.cumsum(sizes + gaps) - (sizes + gaps) + 5
+    blob = rng.integers(0, 256, int(src_at[-1] + sizes[-1] + 64)).astype(np.uint8)
+    dblob = _dev(eng, blob, np.uint8)
+    pieces = np.stack([dblob.data_ptr() + src_at, dst_at, sizes], axis=1).astype(np.int64)
+    pc = _dev(eng, pieces.reshape(-1), np.int64)
+    total = int(dst_at[-1] + sizes[-1] + 64)
+    oraw, oseq, oqual = (torch.full((total,), 0xEE, dtype=torch.uint8, device=eng.device) for _ in range(3))
+    _lib.check(eng.lib.plat_copy_pieces(eng.ctx, n, int(sizes.max()), pc.data_ptr(), oraw.data_ptr(), eng._stream()), "plat_copy_pieces")
+    _lib.check(eng.lib.plat_unpack_reads_pieces(eng.ctx, n, int(sizes.max()), pc.data_ptr(), oseq.data_ptr(), oqual.data_ptr(), total, 0, 0, 0, 0, eng._stream()),
+               "plat_unpack_reads_pieces")
+    eng._sync()
+    wr, ws, wq = (np.full(total, 0xEE, dtype=np.uint8) for _ in range(3))
+    idx = np.concatenate([np.arange(d, d + k) for d, k in zip(dst_at, sizes)])
+    val = np.concatenate([blob[a:a + k] for a, k in zip(src_at, sizes)])
+    wr[idx] = val; ws[idx] = np.frombuffer(b"ACTG", dtype=np.uint8)[val & 3]; wq[idx] = val >> 2
+    assert np.array_equal(oraw.cpu().numpy(), wr) and np.array_equal(oseq.cpu().numpy(), ws) and np.array_equal(oqual.cpu().numpy(), wq)
