@@ -1,22 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: pair-HMM GCUPS (+ variant windows/sec) on BASELINE config 2.
+"""bench.py -- headline benchmark: BASELINE.json's metric on its own workload, the synthetic 30x WGS (config 4).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of synthetic windows that is already resident
-in HBM: haplotype k-mer index + gap-open annotation + diagonal vote + candidate DPs + candidate
-selection + log-likelihood arrays (Haplotype.alignReads for every haplotype) + genotype likelihoods
-(Population.setup).  `--batches` DISTINCT batches (different seeds) are resident per GPU and consecutive
-steps walk through them, so no step re-reads the inputs of the step before it.  Windows shard across
-ranks with no data-path collective (weak scaling: every rank owns its own batches generated from
-seed+rank); the only collectives are the barriers and the max-over-ranks timing reduction.
+Default line (round 6): BASELINE config 4.  One "step" = one pass of the hot path over this rank's share of the genome's regions
+(3 875 regions x 100 kb per GPU = 31 000 / 8; `--strong`: the 31 000 regions for every N), reads already resident in HBM: candidates ->
+variants -> windows -> haplotypes (device) -> pair-HMM likelihoods / genotype likelihoods / EM / posteriors -> VCF record text through the
+native region loop, then the job's ONE exchange (record text to rank 0, RCCL under "nccl") and the merge -- all inside the timed region.
+`value` = pair-HMM GCUPS, reference-equivalent (band cells of the fastAlignmentRoutine calls the reference would make for
+the called windows / wall time); `config.windows_per_sec` = the metric's second half; `roofline` = the loop's dominant kernel by summed
+live launch time (deterministic: tools/bench_other.config4_gcups); `cpu_baseline` = the unmodified reference align.c on the host's cores.
+Region i -> rank i % N, no data-path collective (runner.py:470-500).
 
-GCUPS counts REFERENCE-EQUIVALENT work: sum over the fastAlignmentRoutine calls the
-reference would make of 16*len2 band cells, divided by wall time.  What the device actually ran is
-reported next to it (`gcups_executed`, `dp_launched_per_step`), and so are the figures without the two
-shortcuts (`gcups_all_dp`: every reference DP executed) and on reads the shortcuts like less
-(`hard_workload`).  `--config 3|4|5` puts another BASELINE config on the line instead (same contract).
+At N = 1 the line also carries `config2` (the batched pair-HMM of BASELINE config 2 on resident batches: reference-equivalent and
+executed GCUPS, every reference DP executed, the hard workload, k_dp_jobs' roofline) and `other_configs` (3, 4 streamed, 5).
+`--config 2|3|4|5` puts that config alone on the line (same contract); `--config 4` is the default line without the sub-blocks.
 """
 import argparse
 import ctypes as C
@@ -323,9 +322,9 @@ def selftest_ranks(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 10 passes over the WGS share; --config 2: 400 steps)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5), help="BASELINE config on the line (default 2, the headline)")
+    ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4, 5), help="one BASELINE config alone on the line (default: config 4 = the metric's workload, with the config-2 and other-config sub-blocks at N = 1)")
     ap.add_argument("--windows", type=int, default=None, help="windows per GPU per batch (config 2: 10000; config 5: 200)")
     ap.add_argument("--regions", type=int, default=None, help="config 3: assembly tiles per GPU per step (2000); config 4: regions of the WHOLE job "
                                                               "(default 3875 per GPU), region i -> rank i %% N")
@@ -340,7 +339,7 @@ def main():
     ap.add_argument("--strong", action="store_true", help="config 4 / the WGS block: ONE region list for every N (--regions, default 31000 = the whole synthetic "
                                                           "genome) instead of 3875 regions per GPU: a strong-scaling line")
     ap.add_argument("--no-other-configs", action="store_true", help="default line: leave out other_configs (configs 3, 4 streamed, 5)")
-    ap.add_argument("--no-wgs", action="store_true", help="default line: leave out the WGS block (config 4 on this job's GPUs, gather + merge inside its timed region)")
+    ap.add_argument("--no-wgs", action="store_true", help=argparse.SUPPRESS)     # (round 5: the config-2 line carried a wgs block; accepted, ignored)
     ap.add_argument("--min-seconds", type=float, default=0.25, help="a step is made of as many passes (one batch each) as it takes for the K timed steps to last this long")
     ap.add_argument("--selftest-ranks", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
@@ -354,15 +353,61 @@ def main():
 
     import torch
     rk = Ranks(a.gpus)
-    rank, local, world, dist = rk.rank, rk.dev_index, rk.world, rk.dist
-    if a.config != 2:
+    if a.config in (3, 5):
         from tools import bench_other
+        a.steps = a.steps or 20
         line = bench_other.run(a, rk)
-        if rank == 0:
-            line.pop("merged_text", None)
-            print(json.dumps(line))
-        rk.close()
-        return
+    elif a.config == 2:
+        a.steps = a.steps or 400
+        line = line_config2(a, rk)
+    else:
+        line = line_wgs(a, rk)
+    if rk.rank == 0 and line is not None:
+        line.pop("merged_text", None)
+        print(json.dumps(line))
+    rk.close()
+
+
+def line_wgs(a, rk):
+    """The default line: BASELINE config 4 on this job's GPUs (tools/bench_other.line_config4: value / config / roofline / cpu_baseline are the WGS
+    job's), + at N = 1 the config-2 sub-block and the other configs."""
+    from types import SimpleNamespace
+    from tools import bench_other
+    a.steps = a.steps or 10
+    sub = a.config is None and rk.world == 1 and not a.no_extras
+    line = bench_other.line_config4(a, rk, resident=True)
+    if rk.rank != 0:
+        if sub:
+            pass
+        return None
+    if sub:
+        try:
+            a2 = SimpleNamespace(steps=20, warmup=3, windows=None, batches=a.batches, streams=a.streams, sync_entry=a.sync_entry, min_seconds=a.min_seconds,
+                                 no_extras=False, no_other_configs=True, no_cpu_baseline=True)
+            c2 = line_config2(a2, rk)
+            keep = ("metric", "value", "value_is", "unit", "steps", "ms_per_step", "config", "windows_per_sec", "gcups_executed", "dp_reference_per_step", "dp_launched_per_step",
+                    "kernel_ms", "dp_kernel_gcups", "roofline", "roofline_other", "roofline_third", "algorithmic_frac_8d", "step_hbm_frac", "gcups_all_dp", "all_dp",
+                    "exact_match_shortcut_only", "hard_workload")
+            line["config2"] = {k: c2[k] for k in keep if k in c2}
+        except Exception as exc:                # pragma: no cover
+            line["config2"] = {"error": repr(exc)[:300]}
+        try:
+            if a.no_other_configs:
+                raise RuntimeError("left out (--no-other-configs)")
+            from platypus_amd.engine import Engine
+            line["other_configs"] = bench_other.summary(Engine(rk.dev_index))
+            c4 = line["other_configs"].get("config4_region_pipeline") or {}
+            if "windows_per_sec" in c4:         # the same job with every region generated and uploaded INSIDE the timed region (rounds 2-3's shape)
+                line["config"]["windows_per_sec_streamed_inputs"] = c4["windows_per_sec"]
+        except Exception as exc:                # pragma: no cover
+            line["other_configs"] = {"error": repr(exc)[:300]}
+    return line
+
+
+def line_config2(a, rk):
+    """BASELINE config 2 alone: the batched pair-HMM (alignReads for all haplotypes + genotype likelihoods) over resident batches of 10 000 windows."""
+    import torch
+    rank, local, world, dist = rk.rank, rk.dev_index, rk.world, rk.dist
     from platypus_amd import synth
     from platypus_amd.engine import Engine
     from concurrent.futures import ThreadPoolExecutor
@@ -456,17 +501,6 @@ def main():
     except Exception as exc:                    # pragma: no cover
         gather = {"error": repr(exc)[:200]}
 
-    # BASELINE.json's metric is quoted on the synthetic 30x WGS (config 4): the job's GPUs call this job's share of the genome through the
-    # native region loop -- inputs resident in HBM, the gather of the record text to rank 0 and the (chrom, pos) merge INSIDE the timed
-    # region -- and the figures go to the TOP LEVEL of the line (`wgs`).  Every rank takes part (the gather is a collective).
-    wgs = None
-    if not a.no_wgs:
-        from types import SimpleNamespace
-        from tools import bench_other
-        try:
-            wgs = bench_other.line_config4(SimpleNamespace(regions=a.regions, steps=5, warmup=2, strong=a.strong, no_cpu_baseline=True), rk, resident=True)
-        except Exception as exc:                # pragma: no cover
-            wgs = {"error": repr(exc)[:300]}
     if rank == 0:
         ms_step = 1e3 * T / a.steps
         ms_pass = 1e3 * T / NP
@@ -506,7 +540,11 @@ def main():
         dp_per_step = ndp_run / NP / max(world, 1)
         seed_alg = 2 * int(hb.hap_off[-1]) + int(hb.read_off[-1]) // 4 + 16 * hb.n_reads + 32 * hb.n_pairs \
             + int(8 * max(hb.n_pairs - dp_per_step, 0) + 4 * dp_per_step)
-        r_dp = entry("k_dp_jobs", prof.dp_alg_bytes, dp_avg, pm,
+        # (the asynchronous entry keeps no count of the DPs it launched -- plat_profile.dp_alg_bytes is 0 there --: the bytes come from the synchronous
+        #  statistics pass over the same batch: cells_launched = 16 x length summed over the launched DPs, so cells / 4 + 34 per DP = 4 x length + 34)
+        dp_jobs0 = int(sts[0].n_dp_launched)
+        dp_alg_bytes = int(sts[0].cells_launched) // 4 + 34 * dp_jobs0
+        r_dp = entry("k_dp_jobs", dp_alg_bytes, dp_avg, pm,
                      "recurrence is VALU-issue bound (packed int16), not HBM bound: see DESIGN.md")
         sweep_avg, pairs_avg = float(np.mean(sweep_ms)), float(np.mean(pairs_ms))
         if sweep_avg > 0 and pairs_avg > 0:
@@ -522,9 +560,11 @@ def main():
         else:
             cands = [r_dp, entry("k_seed", seed_alg, seedk_avg, pm.get("k_seed", {}),
                                  "LDS k-mer maps + bit-parallel proofs: bound by vector issue (secondary), not by HBM; see DESIGN.md section 4")]
-        cands.sort(key=lambda r: -r["avg_launch_ms"])
-        roof, roof_other = cands[0], cands[1]
-        roof_more = cands[2:]
+        # the sub-block's `roofline` is ALWAYS k_dp_jobs -- the dominant kernel of config 2 by every rocprofv3 --stats summary kept under profiles/ --, never
+        # the winner of a 1 % HIP-event tie with k_pairs; the seeding kernels follow by launch time
+        rest = sorted(cands[1:], key=lambda r: -r["avg_launch_ms"])
+        roof, roof_other = cands[0], rest[0]
+        roof_more = rest[1:]
         line = {
             "metric": "pair-HMM GCUPS (reference-equivalent band cells/s, read->haplotype likelihood path)",
             "value": cells_ref / T / 1e9,
@@ -541,13 +581,13 @@ def main():
                        "entry": "plat_align_window_batch" if a.sync_entry else "plat_align_window_batch_async",
                        "batches_in_flight": S, "distinct_resident_batches": B, "timed_region_ms": 1e3 * T},
             "windows_per_sec": nwin / T,
-            "windows_per_sec_is": "config 2's windows (likelihoods + genotype likelihoods only); the end-to-end figure of the WGS job is wgs.windows_per_sec",
+            "windows_per_sec_is": "config 2's windows (likelihoods + genotype likelihoods only); the end-to-end figure is the WGS job's (the default line)",
             "gcups_executed": cells_run / T / 1e9,
             "dp_reference_per_step": ndp_ref / NP, "dp_launched_per_step": ndp_run / NP,
             "per_step_figures_are": "per PASS (one batch of %d windows per GPU): dp_*_per_step, kernel_ms, algorithmic bytes, traffic" % nwin_batch,
             "kernel_ms": {"prepare": float(np.mean(prep_ms)), "seed": float(np.mean(seed_ms)), "seed_kernel": seedk_avg, "dp": dp_avg,
                           "finalize": float(np.mean(fin_ms)), "genotype": float(np.mean(gen_ms))},
-            "dp_kernel_gcups": 4.0 * (prof.dp_alg_bytes - 34 * prof.dp_jobs) / (dp_avg * 1e-3) / 1e9,
+            "dp_kernel_gcups": 4.0 * (dp_alg_bytes - 34 * dp_jobs0) / (dp_avg * 1e-3) / 1e9,
             "roofline": roof,
             "roofline_other": roof_other,
         }
@@ -566,21 +606,6 @@ def main():
             line["step_hbm_frac"] = pm["step_hbm_bytes"] / (ms_pass * 1e-3) / 1e9 / HBM_PEAK_GBPS
             line["step_traffic_source"] = traffic_source
         line["record_gather"] = gather
-        if wgs is not None:
-            wgs.pop("merged_text", None)
-            keep = ("windows_per_sec", "gcups", "gcups_executed", "roofline", "roofline_other", "roofline_more", "scaling", "scaling_efficiency_basis", "regions", "windows", "records",
-                    "regions_per_sec", "reads_per_sec", "timed_s", "timed_s_runs", "host_seconds_per_region", "device_wait_seconds_per_region",
-                    "stage_seconds_per_region", "record_gather", "cpus_granted_to_this_rank", "dp_reference", "dp_launched", "dp_per_launch", "stage_b", "inputs", "config",
-                    "error")
-            wgs["windows_per_sec"] = wgs.get("value")
-            line["wgs"] = {k: wgs[k] for k in keep if k in wgs}
-            line["wgs"]["what"] = ("BASELINE config 4 on this job's GPUs: the synthetic 30x genome's regions (3 875 per GPU unless --strong), region i -> rank i % N, "
-                                   "reads resident in HBM; timed: candidates -> variants -> windows -> haplotypes (device) -> likelihoods / EM / posteriors -> records "
-                                   "for all regions, + gather of the record text to rank 0 + (chrom, pos) merge")
-            for k in ("windows_per_sec", "gcups", "gcups_executed"):
-                if k in wgs:
-                    line["wgs_" + k] = wgs[k]
-            line["wgs_cpus_per_rank"] = wgs.get("cpus_granted_to_this_rank")
         if world == 1 and not a.no_extras:
             # ---- the same batches with the shortcuts switched off (the library reads the switches per call)
             def mode(nsteps, dbl=dbs, hbl=hbs, **env):
@@ -619,18 +644,12 @@ def main():
                     raise RuntimeError("left out (--no-other-configs)")
                 from tools import bench_other
                 line["other_configs"] = bench_other.summary(eng)
-                c4 = line["other_configs"].get("config4_region_pipeline") or {}
-                if "windows_per_sec" in c4:      # the same job with every region generated and uploaded INSIDE the timed region (rounds 2-3's shape)
-                    line["windows_per_sec_end_to_end"] = c4["windows_per_sec"]
-                    if "wgs" in line:
-                        line["wgs"]["streamed"] = {k: c4[k] for k in ("windows_per_sec", "gcups", "gcups_executed", "regions", "timed_s", "host_seconds_per_region",
-                                                                       "device_wait_seconds_per_region", "h2d_gbytes_per_sec", "what") if k in c4}
             except Exception as exc:            # pragma: no cover
                 line["other_configs"] = {"error": repr(exc)[:300]}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hb)
-        print(json.dumps(line))
-    rk.close()
+        return line
+    return None
 
 
 if __name__ == "__main__":

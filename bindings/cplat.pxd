@@ -67,6 +67,8 @@ cdef extern from "platypus_mi355x.h":
         float ms_candidates
     int plat_profile_enable(plat_ctx* ctx, int on) nogil
     int plat_profile_last(plat_ctx* ctx, plat_profile* out) nogil
+    const char* plat_kernel_timer_name(int id) nogil
+    int plat_kernel_times(plat_ctx* ctx, double* out_ms, int64_t* out_launches) nogil
 
     # ---- fastAlignmentRoutine, score only (src/c/align.h:8-10)
     int plat_dp_batch(plat_ctx* ctx, int n, int lmax, const uint8_t* hap_slices, const uint8_t* reads, const uint8_t* quals,

@@ -163,6 +163,10 @@ typedef struct plat_caller_stats {
      * tables expanded; k_candidates: the bases of the chunk's reads once (what the scan has to read) */
     double seconds_kernel_unpack, seconds_kernel_candidates;
     int64_t unpack_bytes, candidates_bytes, n_unpack_launches, n_candidates_launches;
+    /* plat_caller_count_cells(c, 1) only (round 6): EVERY kernel of the chunks, live -- summed launch durations (ms) and launches per kernel id
+     * (PLAT_KT_* of platypus_mi355x.h, names from plat_kernel_timer_name): the ranking a roofline entry's kernel is chosen by */
+    double kernel_ms[32];
+    int64_t kernel_launches[32];
 } plat_caller_stats;
 
 typedef struct plat_caller plat_caller;

@@ -97,6 +97,21 @@ typedef struct plat_profile {
 int plat_profile_enable(plat_ctx* ctx, int on);
 int plat_profile_last(plat_ctx* ctx, plat_profile* out);   /* [syncs] */
 
+/* The same for EVERY kernel of the region loop's chunk (round 6): while the profile is on, each launch listed below is bracketed by
+ * its own pair of HIP events on the launch stream; plat_kernel_times [syncs] resolves the pairs recorded since the last call and ADDS
+ * each launch's duration (ms) and 1 to out_ms[id] / out_launches[id] (arrays of PLAT_KT_COUNT entries, the caller zeroes them).  A kernel
+ * shares the chip only with what the caller lets run beside it: bench.py's counting pass runs one chunk at a time. */
+enum {
+    PLAT_KT_CANDIDATES = 0, PLAT_KT_CAND_MERGE, PLAT_KT_CAND_FILTER, PLAT_KT_UNPACK_PIECES, PLAT_KT_CONCAT_TABLES, PLAT_KT_COPY_PIECES,
+    PLAT_KT_GATHER_READS, PLAT_KT_SB_VARIANTS, PLAT_KT_SB_WINDOWS, PLAT_KT_SB_HAPS_RANK, PLAT_KT_SB_PREFIX, PLAT_KT_SB_SCAN,
+    PLAT_KT_SB_HAPS_WRITE, PLAT_KT_SB_READS, PLAT_KT_VALIDATE, PLAT_KT_TILE_SCAN, PLAT_KT_PREP_READS, PLAT_KT_SWEEP, PLAT_KT_PAIRS,
+    PLAT_KT_SEED_SLOW, PLAT_KT_DP_JOBS, PLAT_KT_FINALIZE, PLAT_KT_GENOTYPE, PLAT_KT_HAPLOTYPE_SCORE, PLAT_KT_EM, PLAT_KT_VARIANT_POSTERIOR,
+    PLAT_KT_VARIANT_READ_STATS, PLAT_KT_VARIANT_INFO, PLAT_KT_GENOTYPE_CALL, PLAT_KT_ASSEMBLE, PLAT_KT_READ_QC, PLAT_KT_OTHER,
+    PLAT_KT_COUNT
+};
+const char* plat_kernel_timer_name(int id);                 /* "k_candidates", ...; NULL outside 0 .. PLAT_KT_COUNT-1 */
+int plat_kernel_times(plat_ctx* ctx, double* out_ms, int64_t* out_launches);   /* [syncs] */
+
 /* ---- a1: fastAlignmentRoutine, score only -------------------------------------------------------
  * Replaces  int fastAlignmentRoutine(seq1, seq2, qual2, len1, len2, gapextend, nucprior,
  *                                    localgapopen, aln1=NULL, aln2=NULL, firstpos)

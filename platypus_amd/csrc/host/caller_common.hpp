@@ -112,6 +112,8 @@ struct Slot {
     int64_t nAlign = 0, alignHapBytes = 0, alignReadBytes = 0, alignReads = 0, alignDpBytes = 0;
     double secSeed = 0.0, secDp = 0.0, secSweep = 0.0, secPairs = 0.0, secUnpack = 0.0, secCand = 0.0;
     int64_t unpackBytes = 0, candBytes = 0, nUnpack = 0, nCand = 0;
+    double ktMs[PLAT_KT_COUNT] = {};                                       // plat_kernel_times of this worker's chunks (counting pass)
+    int64_t ktLaunches[PLAT_KT_COUNT] = {};
     // chunk read table (device): bases, qualities, offsets, per-read fields, CIGARs; t_pack: the bytes of PLAT_READS_PACKED tables as
     // they crossed the link (expanded into t_seq / t_qual by plat_unpack_reads), t_exc*: their exceptions
     Staged<uint8_t> t_seq, t_qual, t_mapq, t_pack, t_excb, t_excq;
@@ -531,8 +533,7 @@ static void runBatch(Slot& s, DeviceBatch& db, const Options& o, bool full, bool
         s.nDpRef += as.n_dp_reference; s.cellsRef += as.cells_reference; s.nDpRun += as.n_dp_launched; s.cellsRun += as.cells_launched;
         plat_profile pf;
         memset(&pf, 0, sizeof pf);
-        ck(plat_profile_last(s.ctx, &pf), "plat_profile_last");
-        ck(plat_profile_enable(s.ctx, 0), "plat_profile_enable");
+        ck(plat_profile_last(s.ctx, &pf), "plat_profile_last");     // (the profile stays on: Chunk::run collects every kernel's timers at its end)
         s.nAlign += 1; s.alignHapBytes += db.hapBlob; s.alignReadBytes += (int64_t)blob; s.alignReads += db.nReads;
         s.alignDpBytes += pf.dp_alg_bytes; s.secSeed += 1e-3 * pf.ms_seed_kernel; s.secDp += 1e-3 * pf.ms_dp;
         s.secSweep += 1e-3 * pf.ms_sweep; s.secPairs += 1e-3 * pf.ms_pairs;

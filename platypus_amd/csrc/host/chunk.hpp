@@ -118,7 +118,6 @@ struct Chunk {
             plat_profile pf;
             memset(&pf, 0, sizeof pf);
             ck(plat_profile_last(s.ctx, &pf), "plat_profile_last");
-            ck(plat_profile_enable(s.ctx, 0), "plat_profile_enable");
             if (getenv("PLAT_CALLER_TRACE")) fprintf(stderr, "[plat_caller] table kernels: unpack %.3f ms (%lld packed bytes), candidates %.3f ms (%lld bytes)\n", pf.ms_unpack, (long long)tabPackedBytes, pf.ms_candidates, (long long)tabBlobBytes);
             if (pf.ms_unpack > 0) { s.secUnpack += 1e-3 * pf.ms_unpack; s.unpackBytes += 3 * tabPackedBytes; s.nUnpack += 1; }      // one byte in, two out per base
             if (pf.ms_candidates > 0) { s.secCand += 1e-3 * pf.ms_candidates; s.candBytes += tabBlobBytes; s.nCand += 1; }           // the bases once: what the scan has to read
@@ -220,6 +219,10 @@ struct Chunk {
                 }
             }
             r->release();
+        }
+        if (s.countCells) {                                                 // every kernel of this chunk, live (HIP events around each launch)
+            ck(plat_kernel_times(s.ctx, s.ktMs, s.ktLaunches), "plat_kernel_times");
+            ck(plat_profile_enable(s.ctx, 0), "plat_profile_enable");
         }
         const double total = secs(t0, Clock::now()), waited = s.t_wait - wait0;
         std::lock_guard<std::mutex> g(stMutex);

@@ -290,6 +290,7 @@ static int runWorkers(plat_caller* c, Feed& feed, std::atomic<bool>& failed, con
     for (auto& q : c->slots) {
         q->countCells = c->countCells; q->nDpRef = q->cellsRef = q->nDpRun = q->cellsRun = 0;
         q->nAlign = q->alignHapBytes = q->alignReadBytes = q->alignReads = q->alignDpBytes = 0; q->secSeed = q->secDp = q->secSweep = q->secPairs = q->secUnpack = q->secCand = 0.0; q->unpackBytes = q->candBytes = q->nUnpack = q->nCand = 0;
+        for (int k = 0; k < PLAT_KT_COUNT; ++k) { q->ktMs[k] = 0.0; q->ktLaunches[k] = 0; }
     }
     std::vector<std::thread> threads;
     for (int i = 1; i < nThreads; ++i) threads.emplace_back(worker, c->slots[(size_t)i].get());
@@ -302,6 +303,7 @@ static int runWorkers(plat_caller* c, Feed& feed, std::atomic<bool>& failed, con
         st.seconds_kernel_sweep += q->secSweep; st.seconds_kernel_pairs += q->secPairs;
         st.seconds_kernel_unpack += q->secUnpack; st.seconds_kernel_candidates += q->secCand; st.unpack_bytes += q->unpackBytes; st.candidates_bytes += q->candBytes;
         st.n_unpack_launches += q->nUnpack; st.n_candidates_launches += q->nCand;
+        for (int k = 0; k < PLAT_KT_COUNT && k < 32; ++k) { st.kernel_ms[k] += q->ktMs[k]; st.kernel_launches[k] += q->ktLaunches[k]; }
     }
     if (firstError != PLAT_OK) c->lastError = errText;
     return firstError;

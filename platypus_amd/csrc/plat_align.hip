@@ -2359,23 +2359,23 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
         if (lds_pairs > 160 * 1024) return PLAT_ERR_HAP_TOO_LONG;
         if (lds > 48 * 1024) PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (lds_pairs > 48 * 1024) PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pairs));
-        hipLaunchKernelGGL(k_sweep, dim3(gx), dim3(64), lds, st, b, (uint8_t*)ctx->hapw.ptr, (uint8_t*)ctx->hap_flags.ptr, cnt, tsize_max, maxhap, shortcuts,
-                           (const unsigned char*)basebuf, hap_win, (unsigned char*)ctx->seedstate.ptr);
+        { PLAT_KT_BEGIN(ctx, PLAT_KT_SWEEP, st); hipLaunchKernelGGL(k_sweep, dim3(gx), dim3(64), lds, st, b, (uint8_t*)ctx->hapw.ptr, (uint8_t*)ctx->hap_flags.ptr, cnt, tsize_max, maxhap, shortcuts,
+                           (const unsigned char*)basebuf, hap_win, (unsigned char*)ctx->seedstate.ptr); PLAT_KT_END(ctx, PLAT_KT_SWEEP, st); }
         PLAT_EV(ctx, 8, st);
         ctx->ev_split = 1;
         if (!(shortcuts & 256)) {                              // (PLAT_SEED_DEBUG=256: the sweeps alone)
             const bool xw = (shortcuts & SEED_XCD) != 0;
             const unsigned gp = (unsigned)(xw ? ((wave_cap + 7) / 8) * 8 : wave_cap);
-            hipLaunchKernelGGL(k_pairs, dim3(gp > 0 ? gp : 1), dim3(64), lds_pairs, st, b, wave_win, wave_first, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
+            { PLAT_KT_BEGIN(ctx, PLAT_KT_PAIRS, st); hipLaunchKernelGGL(k_pairs, dim3(gp > 0 ? gp : 1), dim3(64), lds_pairs, st, b, wave_win, wave_first, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
                                (const uint16_t*)ctx->codes.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
                                (SlowRec*)ctx->slow.ptr, tsize_max, maxhap, shortcuts, dense, segcap, (const double*)ctx->d_mapq_lut, out_ll, out_score,
-                               (const unsigned char*)ctx->seedstate.ptr);
+                               (const unsigned char*)ctx->seedstate.ptr); PLAT_KT_END(ctx, PLAT_KT_PAIRS, st); }
         }
     }
     PLAT_EV(ctx, 5, st);                                       // k_seed alone: ev[1] .. ev[5]
-    hipLaunchKernelGGL(k_seed_slow, dim3(4096), dim3(64), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_SEED_SLOW, st); hipLaunchKernelGGL(k_seed_slow, dim3(4096), dim3(64), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
-                       (const SlowRec*)ctx->slow.ptr, tsize_max, maxhap, cw, dense, segcap);
+                       (const SlowRec*)ctx->slow.ptr, tsize_max, maxhap, cw, dense, segcap); PLAT_KT_END(ctx, PLAT_KT_SEED_SLOW, st); }
     if (!(shortcuts & SEED_LEAN))                              // (the asynchronous entry point reads nothing back: every kernel sums the segments itself)
         hipLaunchKernelGGL(k_dense_total, dim3(1), dim3(1), 0, st, cnt, segcap);
     PLAT_HIP(ctx, hipGetLastError());
@@ -2429,8 +2429,8 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
     if (async) hv = *hints;
     {   // a wave per window, a thread per haplotype; a small batch (a chunk of the region loop) does not pay for 2048 workgroups
         const long long want = std::max<long long>(((long long)b.n_windows * 64 + 255) / 256, ((long long)b.n_haps + 255) / 256);
-        hipLaunchKernelGGL(k_validate, dim3((unsigned)std::min<long long>(2048, std::max<long long>(1, want))), dim3(256), 0, st, b, cnt, hap_win,
-                           win_rows, calc_flank_score);
+        { PLAT_KT_BEGIN(ctx, PLAT_KT_VALIDATE, st); hipLaunchKernelGGL(k_validate, dim3((unsigned)std::min<long long>(2048, std::max<long long>(1, want))), dim3(256), 0, st, b, cnt, hap_win,
+                           win_rows, calc_flank_score); PLAT_KT_END(ctx, PLAT_KT_VALIDATE, st); }
     }
     // waves of k_pairs: <= n_pairs / 64 + n_haps / 5 + n_windows (64 pairs per wave; windows with < 13 reads give a wave 5 whole haplotypes)
     // (asynchronous: the caller stated n_pairs, so the wave map is sized and built right here; synchronous: after the read-back below)
@@ -2449,7 +2449,7 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         return PLAT_OK;
     };
     if (async && !seed_fused && (rc = reserve_wave_map(hv.n_pairs))) return rc;
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, b, win_rows, tile_off, cnt, hv, async ? 1 : 0, wave_win, wave_first, wave_cap);
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_TILE_SCAN, st); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, b, win_rows, tile_off, cnt, hv, async ? 1 : 0, wave_win, wave_first, wave_cap); PLAT_KT_END(ctx, PLAT_KT_TILE_SCAN, st); }
     PLAT_HIP(ctx, hipGetLastError());
     int64_t* hb = ctx->h_readback;
     long long tile_total;
@@ -2463,7 +2463,7 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         tile_total = hb[CNT_TILE_TOTAL];
         if (!seed_fused && hv.n_pairs > 0) {                   // the wave map of k_pairs, now that the number of pairs is known (the scan again: same offsets)
             if ((rc = reserve_wave_map(hv.n_pairs))) return rc;
-            hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, b, win_rows, tile_off, cnt, hv, 0, wave_win, wave_first, wave_cap);
+            { PLAT_KT_BEGIN(ctx, PLAT_KT_TILE_SCAN, st); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, b, win_rows, tile_off, cnt, hv, 0, wave_win, wave_first, wave_cap); PLAT_KT_END(ctx, PLAT_KT_TILE_SCAN, st); }
         }
     } else {
         tile_total = (long long)(hv.max_read_len + 8) * b.n_reads + 4ll * b.n_windows;     // upper bound of k_tile_scan's total
@@ -2491,8 +2491,8 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         const char* e_x = getenv("PLAT_SEED_XCD");           // (read per call; 0 = window w on workgroup w)
         const bool xcd = !(e_x && e_x[0] == '0') && b.n_windows >= 64;
         const unsigned gx = xcd ? (unsigned)((b.n_windows + 7) / 8) * 8u : (unsigned)b.n_windows;
-        hipLaunchKernelGGL(k_prep_reads, dim3(gx, prep_groups), dim3(256), prep_lds, st, b, win_rows, tile_off,
-                           (uint16_t*)ctx->codes.ptr, (ReadInfo*)ctx->rinfo.ptr, cnt, prep_qoff, xcd ? 1 : 0);
+        { PLAT_KT_BEGIN(ctx, PLAT_KT_PREP_READS, st); hipLaunchKernelGGL(k_prep_reads, dim3(gx, prep_groups), dim3(256), prep_lds, st, b, win_rows, tile_off,
+                           (uint16_t*)ctx->codes.ptr, (ReadInfo*)ctx->rinfo.ptr, cnt, prep_qoff, xcd ? 1 : 0); PLAT_KT_END(ctx, PLAT_KT_PREP_READS, st); }
     }
     long long njobs = 0;
     PLAT_EV(ctx, 1, st);
@@ -2568,26 +2568,26 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         const long long resident = 4ll * ctx->n_cu;
         const dim3 grid((unsigned)(dp_dyn ? (want < resident ? want : resident) : (want < fixed ? want : fixed)));
         if (dp_impl)
-            hipLaunchKernelGGL(k_dp_jobs<true>, grid, dim3(256), 0, st, b, (const uint8_t*)ctx->hapw.ptr,
+            { PLAT_KT_BEGIN(ctx, PLAT_KT_DP_JOBS, st); hipLaunchKernelGGL(k_dp_jobs<true>, grid, dim3(256), 0, st, b, (const uint8_t*)ctx->hapw.ptr,
                                (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
                                (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, segcap, cnt, extra_cap,
-                               (int32_t*)ctx->job_score.ptr, out_loglik, out_score, dp_dyn);
+                               (int32_t*)ctx->job_score.ptr, out_loglik, out_score, dp_dyn); PLAT_KT_END(ctx, PLAT_KT_DP_JOBS, st); }
         else
-            hipLaunchKernelGGL(k_dp_jobs<false>, grid, dim3(256), 0, st, b, (const uint8_t*)ctx->hapw.ptr,
+            { PLAT_KT_BEGIN(ctx, PLAT_KT_DP_JOBS, st); hipLaunchKernelGGL(k_dp_jobs<false>, grid, dim3(256), 0, st, b, (const uint8_t*)ctx->hapw.ptr,
                                (const uint8_t*)ctx->hap_flags.ptr, (const Job*)ctx->jobs.ptr,
                                (const PairRec*)ctx->pair_rec.ptr, ctx->d_mapq_lut, npairs, dense, segcap, cnt, extra_cap,
-                               (int32_t*)ctx->job_score.ptr, out_loglik, out_score, dp_dyn);
+                               (int32_t*)ctx->job_score.ptr, out_loglik, out_score, dp_dyn); PLAT_KT_END(ctx, PLAT_KT_DP_JOBS, st); }
     }
     PLAT_EV(ctx, 3, st);
     if (async) {
         const long long want = (ngrid + 255) / 256, fixed = 8ll * ctx->n_cu;
-        hipLaunchKernelGGL(k_finalize_dense, dim3((unsigned)(want < fixed ? std::max(want, 1ll) : fixed)), dim3(256), 0, st,
+        { PLAT_KT_BEGIN(ctx, PLAT_KT_FINALIZE, st); hipLaunchKernelGGL(k_finalize_dense, dim3((unsigned)(want < fixed ? std::max(want, 1ll) : fixed)), dim3(256), 0, st,
                            (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr, (const int32_t*)ctx->job_score.ptr,
-                           ctx->d_mapq_lut, npairs, dense, segcap, cnt, extra_cap, out_loglik, out_score, (long long*)ctx->d_sticky);
+                           ctx->d_mapq_lut, npairs, dense, segcap, cnt, extra_cap, out_loglik, out_score, (long long*)ctx->d_sticky); PLAT_KT_END(ctx, PLAT_KT_FINALIZE, st); }
     } else
-        hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
+        { PLAT_KT_BEGIN(ctx, PLAT_KT_FINALIZE, st); hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st,
                            (const PairRec*)ctx->pair_rec.ptr, (const Job*)ctx->jobs.ptr,
-                           (const int32_t*)ctx->job_score.ptr, ctx->d_mapq_lut, npairs, cnt, extra_cap, out_loglik, out_score);
+                           (const int32_t*)ctx->job_score.ptr, ctx->d_mapq_lut, npairs, cnt, extra_cap, out_loglik, out_score); PLAT_KT_END(ctx, PLAT_KT_FINALIZE, st); }
     PLAT_EV(ctx, 4, st);
     if (async) {                                               // (k_finalize_dense left the batch's verdict in the sticky word)
         PLAT_HIP(ctx, hipGetLastError());

@@ -1915,8 +1915,8 @@ static int asm_launch(plat_ctx* ctx, const plat_assembly_batch& b, int kmer_size
     sig |= 1ull;
     const int lds_bytes = ASM_LDS_BYTES;
     PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL(k_assemble, dim3(nblk), dim3(ASM_THREADS), lds_bytes, st, b, P, (char*)ctx->asm_scratch.ptr, max_ref, max_reads,
-                       var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status, verdict, getenv("PLAT_ASM_STATIC") ? nullptr : work, wg_sig, sig);   // (PLAT_ASM_STATIC: tile g on workgroup g % grid, for A/B runs)
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_ASSEMBLE, st); hipLaunchKernelGGL(k_assemble, dim3(nblk), dim3(ASM_THREADS), lds_bytes, st, b, P, (char*)ctx->asm_scratch.ptr, max_ref, max_reads,
+                       var_count, var_pos, var_nrem, var_nadd, var_off, var_blob, status, verdict, getenv("PLAT_ASM_STATIC") ? nullptr : work, wg_sig, sig); PLAT_KT_END(ctx, PLAT_KT_ASSEMBLE, st); }   // (PLAT_ASM_STATIC: tile g on workgroup g % grid, for A/B runs)
     PLAT_HIP(ctx, hipGetLastError());
     if (P.timing) {
         unsigned long long t[16];

@@ -174,8 +174,8 @@ PLAT_EXPORT int plat_candidates_batch(plat_ctx* ctx, const plat_candidate_batch*
         return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
     PLAT_EV_TAB(ctx, 2, (hipStream_t)stream);
-    hipLaunchKernelGGL(plat::k_candidates, dim3((unsigned)((b.n_reads + 63) / 64)), dim3(64), 0, (hipStream_t)stream, b,
-                       min_flank, min_base_qual, gen_snps, gen_indels, max_per_read, read_region, out_rec, out_count, out_status);
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_CANDIDATES, (hipStream_t)stream); hipLaunchKernelGGL(plat::k_candidates, dim3((unsigned)((b.n_reads + 63) / 64)), dim3(64), 0, (hipStream_t)stream, b,
+                       min_flank, min_base_qual, gen_snps, gen_indels, max_per_read, read_region, out_rec, out_count, out_status); PLAT_KT_END(ctx, PLAT_KT_CANDIDATES, (hipStream_t)stream); }
     PLAT_EV_TAB(ctx, 3, (hipStream_t)stream);
     ctx->ev_valid_cand = ctx->profile;
     PLAT_HIP(ctx, hipGetLastError());
@@ -318,10 +318,10 @@ PLAT_EXPORT int plat_candidates_merge_batch(plat_ctx* ctx, const plat_candidate_
     long long per = ((long long)b.n_reads + n_scans - 1) / n_scans;
     unsigned gx = (unsigned)((per + 255) / 256);
     gx = gx < 1 ? 1 : (gx > 4096 ? 4096 : gx);
-    hipLaunchKernelGGL(plat::k_candidates_merge, dim3(gx, (unsigned)n_scans), dim3(256), 0, (hipStream_t)stream, b,
-                       scan_read_begin, n_scans, max_per_read, rec, count, status, mtab, out_n);
-    hipLaunchKernelGGL(plat::k_candidates_filter, dim3(plat::MERGE_SLOTS / 256, (unsigned)n_scans), dim3(256), 0, (hipStream_t)stream, b, read_end,
-                       scan_read_begin, scan_longest, n_scans, rec, mtab, min_var_freq, cap_per_scan, out_cand, out_n);
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_CAND_MERGE, (hipStream_t)stream); hipLaunchKernelGGL(plat::k_candidates_merge, dim3(gx, (unsigned)n_scans), dim3(256), 0, (hipStream_t)stream, b,
+                       scan_read_begin, n_scans, max_per_read, rec, count, status, mtab, out_n); PLAT_KT_END(ctx, PLAT_KT_CAND_MERGE, (hipStream_t)stream); }
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_CAND_FILTER, (hipStream_t)stream); hipLaunchKernelGGL(plat::k_candidates_filter, dim3(plat::MERGE_SLOTS / 256, (unsigned)n_scans), dim3(256), 0, (hipStream_t)stream, b, read_end,
+                       scan_read_begin, scan_longest, n_scans, rec, mtab, min_var_freq, cap_per_scan, out_cand, out_n); PLAT_KT_END(ctx, PLAT_KT_CAND_FILTER, (hipStream_t)stream); }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -409,8 +409,8 @@ PLAT_EXPORT int plat_read_qc_batch(plat_ctx* ctx, const plat_readqc_batch* batch
         !b.insert_size || !b.mate_pos || !b.cigar || !b.cig_off || !b.stream_of || !out_ok || !out_reason)
         return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(plat::k_read_qc, dim3((unsigned)((b.n_reads + 63) / 64)), dim3(64), 0, (hipStream_t)stream, b, *options,
-                       out_ok, out_reason);
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_READ_QC, (hipStream_t)stream); hipLaunchKernelGGL(plat::k_read_qc, dim3((unsigned)((b.n_reads + 63) / 64)), dim3(64), 0, (hipStream_t)stream, b, *options,
+                       out_ok, out_reason); PLAT_KT_END(ctx, PLAT_KT_READ_QC, (hipStream_t)stream); }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -564,8 +564,8 @@ PLAT_EXPORT int plat_variant_read_stats_batch(plat_ctx* ctx, const plat_infostat
         !b.cig_off || !out_counts || !out_per_sample || !out_minq || !out_nminq)
         return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(plat::k_variant_read_stats, dim3(b.n_vars), dim3(64), 0, (hipStream_t)stream, b, bad_reads_window,
-                       count_only_exact_indel_matches, out_counts, out_per_sample, out_minq, out_nminq);
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_VARIANT_READ_STATS, (hipStream_t)stream); hipLaunchKernelGGL(plat::k_variant_read_stats, dim3(b.n_vars), dim3(64), 0, (hipStream_t)stream, b, bad_reads_window,
+                       count_only_exact_indel_matches, out_counts, out_per_sample, out_minq, out_nminq); PLAT_KT_END(ctx, PLAT_KT_VARIANT_READ_STATS, (hipStream_t)stream); }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -682,8 +682,8 @@ PLAT_EXPORT int plat_variant_info_batch(plat_ctx* ctx, int n_vars, const int64_t
         PLAT_HIP(ctx, hipMalloc(&ctx->d_logfact, sizeof(lut)));
         PLAT_HIP(ctx, hipMemcpy(ctx->d_logfact, lut, sizeof(lut), hipMemcpyHostToDevice));
     }
-    hipLaunchKernelGGL(plat::k_variant_info, dim3((unsigned)n_vars), dim3(64), 0, (hipStream_t)stream, n_vars, counts, minq_off, minq, n_minq,
-                       (const double*)ctx->d_logfact, out_terms, out_mmlq);
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_VARIANT_INFO, (hipStream_t)stream); hipLaunchKernelGGL(plat::k_variant_info, dim3((unsigned)n_vars), dim3(64), 0, (hipStream_t)stream, n_vars, counts, minq_off, minq, n_minq,
+                       (const double*)ctx->d_logfact, out_terms, out_mmlq); PLAT_KT_END(ctx, PLAT_KT_VARIANT_INFO, (hipStream_t)stream); }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -736,9 +736,9 @@ PLAT_EXPORT int plat_gather_reads(plat_ctx* ctx, int64_t n_dst, const int32_t* s
         return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
     const long long nblk = (n_dst + 15) / 16;                         // 256 threads = 16 reads
-    hipLaunchKernelGGL(plat::k_gather_reads, dim3((unsigned)(nblk < 65535 * 8 ? nblk : 65535 * 8)), dim3(256), 0, (hipStream_t)stream, (long long)n_dst,
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_GATHER_READS, (hipStream_t)stream); hipLaunchKernelGGL(plat::k_gather_reads, dim3((unsigned)(nblk < 65535 * 8 ? nblk : 65535 * 8)), dim3(256), 0, (hipStream_t)stream, (long long)n_dst,
                        src_index, dst_off, src_seq, src_qual, src_off, src_pos, src_end, src_mapq, src_flags, dst_seq, dst_qual, dst_pos,
-                       dst_end, dst_mapq, dst_flags);
+                       dst_end, dst_mapq, dst_flags); PLAT_KT_END(ctx, PLAT_KT_GATHER_READS, (hipStream_t)stream); }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -868,7 +868,7 @@ PLAT_EXPORT int plat_unpack_reads_pieces(plat_ctx* ctx, int n_pieces, int64_t ma
     PLAT_EV_TAB(ctx, 0, (hipStream_t)stream);
     for (int p0 = 0; p0 < n_pieces; p0 += PLAT_GRID_Y_MAX) {      // (gridDim.y holds at most 65 535 pieces: one launch per batch of them)
         const int np = n_pieces - p0 < PLAT_GRID_Y_MAX ? n_pieces - p0 : PLAT_GRID_Y_MAX;
-        hipLaunchKernelGGL(plat::k_unpack_pieces, dim3((unsigned)gx, (unsigned)np), dim3(256), 0, (hipStream_t)stream, pieces + p0, out_seq, out_qual, same);
+        { PLAT_KT_BEGIN(ctx, PLAT_KT_UNPACK_PIECES, (hipStream_t)stream); hipLaunchKernelGGL(plat::k_unpack_pieces, dim3((unsigned)gx, (unsigned)np), dim3(256), 0, (hipStream_t)stream, pieces + p0, out_seq, out_qual, same); PLAT_KT_END(ctx, PLAT_KT_UNPACK_PIECES, (hipStream_t)stream); }
     }
     PLAT_EV_TAB(ctx, 1, (hipStream_t)stream);
     ctx->ev_valid_unpack = ctx->profile;
@@ -919,8 +919,8 @@ PLAT_EXPORT int plat_concat_read_tables(plat_ctx* ctx, int n_tables, int max_rea
     gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
     for (int t0 = 0; t0 < n_tables; t0 += PLAT_GRID_Y_MAX) {      // (every batch's first block also writes the table's closing entries: the same values)
         const int nt = n_tables - t0 < PLAT_GRID_Y_MAX ? n_tables - t0 : PLAT_GRID_Y_MAX;
-        hipLaunchKernelGGL(plat::k_concat_tables, dim3(gx, (unsigned)nt), dim3(256), 0, (hipStream_t)stream, desc + t0, dst_off, dst_pos, dst_end,
-                           dst_mapq, dst_flags, dst_cig_off, dst_cigar, dst_region, (long long)n_total_reads, (long long)total_bytes, (long long)total_pairs);
+        { PLAT_KT_BEGIN(ctx, PLAT_KT_CONCAT_TABLES, (hipStream_t)stream); hipLaunchKernelGGL(plat::k_concat_tables, dim3(gx, (unsigned)nt), dim3(256), 0, (hipStream_t)stream, desc + t0, dst_off, dst_pos, dst_end,
+                           dst_mapq, dst_flags, dst_cig_off, dst_cigar, dst_region, (long long)n_total_reads, (long long)total_bytes, (long long)total_pairs); PLAT_KT_END(ctx, PLAT_KT_CONCAT_TABLES, (hipStream_t)stream); }
     }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
@@ -953,7 +953,7 @@ PLAT_EXPORT int plat_copy_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_
     gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
     for (int p0 = 0; p0 < n_pieces; p0 += PLAT_GRID_Y_MAX) {      // (a whole job's regions are one piece each in the exchange: more than gridDim.y holds)
         const int np = n_pieces - p0 < PLAT_GRID_Y_MAX ? n_pieces - p0 : PLAT_GRID_Y_MAX;
-        hipLaunchKernelGGL(plat::k_copy_pieces, dim3((unsigned)gx, (unsigned)np), dim3(256), 0, (hipStream_t)stream, pieces + p0, dst_blob);
+        { PLAT_KT_BEGIN(ctx, PLAT_KT_COPY_PIECES, (hipStream_t)stream); hipLaunchKernelGGL(plat::k_copy_pieces, dim3((unsigned)gx, (unsigned)np), dim3(256), 0, (hipStream_t)stream, pieces + p0, dst_blob); PLAT_KT_END(ctx, PLAT_KT_COPY_PIECES, (hipStream_t)stream); }
     }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;

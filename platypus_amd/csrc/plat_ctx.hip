@@ -78,6 +78,8 @@ PLAT_EXPORT int plat_ctx_destroy(plat_ctx* ctx) {
         if (ctx->ev[i]) { e = hipEventDestroy(ctx->ev[i]); (void)e; }
     for (int i = 0; i < 4; ++i)
         if (ctx->ev_tab[i]) { e = hipEventDestroy(ctx->ev_tab[i]); (void)e; }
+    for (int i = 0; i < ctx->kt_pending_n; ++i) { e = hipEventDestroy(ctx->kt_pending[i].a); e = hipEventDestroy(ctx->kt_pending[i].b); (void)e; }
+    for (int i = 0; i < ctx->kt_pool_n; ++i) { e = hipEventDestroy(ctx->kt_pool[i]); (void)e; }
     delete ctx;
     return PLAT_OK;
 }
@@ -123,6 +125,30 @@ PLAT_EXPORT int plat_profile_last(plat_ctx* ctx, plat_profile* out) {
         PLAT_HIP(ctx, hipEventSynchronize(ctx->ev_tab[3]));
         PLAT_HIP(ctx, hipEventElapsedTime(&out->ms_candidates, ctx->ev_tab[2], ctx->ev_tab[3]));
     }
+    return PLAT_OK;
+}
+
+PLAT_EXPORT const char* plat_kernel_timer_name(int id) {
+    static const char* names[PLAT_KT_COUNT] = {
+        "k_candidates", "k_candidates_merge", "k_candidates_filter", "k_unpack_pieces", "k_concat_tables", "k_copy_pieces", "k_gather_reads",
+        "k_sb_variants", "k_sb_windows", "k_sb_haps_rank", "k_sb_prefix", "k_sb_scan", "k_sb_haps_write", "k_sb_reads", "k_validate", "k_tile_scan",
+        "k_prep_reads", "k_sweep", "k_pairs", "k_seed_slow", "k_dp_jobs", "k_finalize", "k_genotype", "k_haplotype_score", "k_em",
+        "k_variant_posterior", "k_variant_read_stats", "k_variant_info", "k_genotype_call", "k_assemble", "k_read_qc", "other"};
+    return id >= 0 && id < PLAT_KT_COUNT ? names[id] : nullptr;
+}
+
+PLAT_EXPORT int plat_kernel_times(plat_ctx* ctx, double* out_ms, int64_t* out_launches) {
+    if (!ctx || !out_ms || !out_launches) return PLAT_ERR_INVALID;
+    for (int k = 0; k < ctx->kt_pending_n; ++k) {
+        plat_ctx::KtPair& q = ctx->kt_pending[k];
+        if (q.closed) {
+            PLAT_HIP(ctx, hipEventSynchronize(q.b));
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, q.a, q.b) == hipSuccess) { out_ms[q.id] += (double)ms; out_launches[q.id] += 1; }
+        }
+        ctx->kt_pool[ctx->kt_pool_n++] = q.a; ctx->kt_pool[ctx->kt_pool_n++] = q.b;
+    }
+    ctx->kt_pending_n = 0; ctx->kt_open = -1;
     return PLAT_OK;
 }
 

@@ -146,8 +146,8 @@ PLAT_EXPORT int plat_genotype_window_batch(plat_ctx* ctx, const plat_window_batc
     if (nblk > 0x7FFFFFFFll) return PLAT_ERR_INVALID;
     ctx->ev_valid_geno = 0;
     PLAT_EV(ctx, 6, (hipStream_t)stream);
-    hipLaunchKernelGGL(plat::k_genotype, dim3((unsigned)nblk), dim3(64), 0, (hipStream_t)stream, *batch, n_ind, nunits,
-                       seg_read_begin, seg_n_good, loglik, gl_off, out_gl, out_logl, out_gof);
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_GENOTYPE, (hipStream_t)stream); hipLaunchKernelGGL(plat::k_genotype, dim3((unsigned)nblk), dim3(64), 0, (hipStream_t)stream, *batch, n_ind, nunits,
+                       seg_read_begin, seg_n_good, loglik, gl_off, out_gl, out_logl, out_gof); PLAT_KT_END(ctx, PLAT_KT_GENOTYPE, (hipStream_t)stream); }
     PLAT_HIP(ctx, hipGetLastError());
     PLAT_EV(ctx, 7, (hipStream_t)stream);
     ctx->ev_valid_geno = ctx->profile;

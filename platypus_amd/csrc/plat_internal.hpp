@@ -41,6 +41,14 @@ struct plat_ctx {
     hipEvent_t ev_tab[4] = {};      // around k_unpack_pieces (0, 1) and k_candidates (2, 3)
     int ev_valid_unpack = 0, ev_valid_cand = 0;
     int64_t prof_dp_jobs = 0, prof_dp_bytes = 0;
+    // generic kernel timers (plat_kernel_times)
+    struct KtPair { int id; hipEvent_t a, b; bool closed; };
+    static constexpr int KT_PENDING = 512;
+    KtPair kt_pending[KT_PENDING];
+    hipEvent_t kt_pool[2 * KT_PENDING + 2];
+    int kt_pending_n = 0, kt_pool_n = 0, kt_open = -1;
+    double kt_ms[PLAT_KT_COUNT] = {};
+    int64_t kt_launches[PLAT_KT_COUNT] = {};
 };
 
 #define PLAT_HIP(ctx, call)                                   \
@@ -51,6 +59,27 @@ struct plat_ctx {
             return _e == hipErrorOutOfMemory ? PLAT_ERR_NOMEM : PLAT_ERR_HIP; \
         }                                                     \
     } while (0)
+
+// ---- generic live kernel timers (plat_kernel_times): a pair of HIP events around a launch while the profile is on, resolved and summed per
+// kernel id when the caller asks.  Off: one test of ctx->profile per launch.
+static inline void plat_kt_mark(plat_ctx* ctx, int id, hipStream_t st, bool end) {
+    if (!ctx->profile || id < 0 || id >= PLAT_KT_COUNT) return;
+    if (!end) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (ctx->kt_pool_n >= 2) { a = ctx->kt_pool[--ctx->kt_pool_n]; b = ctx->kt_pool[--ctx->kt_pool_n]; }
+        else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        if (ctx->kt_pending_n >= plat_ctx::KT_PENDING) { ctx->kt_pool[ctx->kt_pool_n++] = a; ctx->kt_pool[ctx->kt_pool_n++] = b; return; }   // (too many unresolved pairs: this launch is not timed)
+        ctx->kt_pending[ctx->kt_pending_n] = {id, a, b, false};
+        ctx->kt_open = ctx->kt_pending_n++;
+        (void)hipEventRecord(a, st);
+    } else if (ctx->kt_open >= 0 && ctx->kt_pending[ctx->kt_open].id == id) {
+        (void)hipEventRecord(ctx->kt_pending[ctx->kt_open].b, st);
+        ctx->kt_pending[ctx->kt_open].closed = true;
+        ctx->kt_open = -1;
+    }
+}
+#define PLAT_KT_BEGIN(ctx, id, st) plat_kt_mark(ctx, id, (hipStream_t)(st), false)
+#define PLAT_KT_END(ctx, id, st) plat_kt_mark(ctx, id, (hipStream_t)(st), true)
 
 #define PLAT_EV_TAB(ctx, i, st) do { if ((ctx)->profile) PLAT_HIP(ctx, hipEventRecord((ctx)->ev_tab[i], st)); } while (0)
 #define PLAT_EV(ctx, i, st) do { if ((ctx)->profile) PLAT_HIP(ctx, hipEventRecord((ctx)->ev[i], st)); } while (0)

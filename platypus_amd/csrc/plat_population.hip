@@ -556,8 +556,8 @@ PLAT_EXPORT int plat_em_window_batch(plat_ctx* ctx, int n_windows, int n_ind, in
         const size_t lds_wide = wide + (use_streams ? streams : 0);
         if (lds_wide > 48 * 1024)
             PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_em_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide));
-        hipLaunchKernelGGL(k_em_wide, dim3(n_windows), dim3(threads), lds_wide, (hipStream_t)stream, n_ind, win_hap_begin, gl_off, n_reads, gl,
-                           max_iters, use_em_likelihoods, out_freq, out_em, out_call, out_iters, max_haps_per_window, (int)maxG, use_streams, (long long*)ctx->d_sticky);
+        { PLAT_KT_BEGIN(ctx, PLAT_KT_EM, (hipStream_t)stream); hipLaunchKernelGGL(k_em_wide, dim3(n_windows), dim3(threads), lds_wide, (hipStream_t)stream, n_ind, win_hap_begin, gl_off, n_reads, gl,
+                           max_iters, use_em_likelihoods, out_freq, out_em, out_call, out_iters, max_haps_per_window, (int)maxG, use_streams, (long long*)ctx->d_sticky); PLAT_KT_END(ctx, PLAT_KT_EM, (hipStream_t)stream); }
         PLAT_HIP(ctx, hipGetLastError());
         return PLAT_OK;
     }
@@ -565,8 +565,8 @@ PLAT_EXPORT int plat_em_window_batch(plat_ctx* ctx, int n_windows, int n_ind, in
     if (csr_in_lds) lds += csr_bytes;
     if (lds > 48 * 1024)
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_em, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_em, dim3(n_windows), dim3(64), lds, (hipStream_t)stream, n_ind, win_hap_begin, gl_off, n_reads, gl,
-                       max_iters, use_em_likelihoods, out_freq, out_em, out_call, out_iters, max_haps_per_window, csr_in_lds, (long long*)ctx->d_sticky);
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_EM, (hipStream_t)stream); hipLaunchKernelGGL(k_em, dim3(n_windows), dim3(64), lds, (hipStream_t)stream, n_ind, win_hap_begin, gl_off, n_reads, gl,
+                       max_iters, use_em_likelihoods, out_freq, out_em, out_call, out_iters, max_haps_per_window, csr_in_lds, (long long*)ctx->d_sticky); PLAT_KT_END(ctx, PLAT_KT_EM, (hipStream_t)stream); }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -587,9 +587,9 @@ PLAT_EXPORT int plat_variant_posterior_batch(plat_ctx* ctx, int n_vars, int n_in
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
     int rc = plat_reserve(ctx, ctx->pop_scratch, (size_t)n_vars * 2 * n_ind * sizeof(double));
     if (rc) return rc;
-    hipLaunchKernelGGL(k_variant_posterior, dim3(n_vars), dim3(64), lds, (hipStream_t)stream, n_ind, win_hap_begin, gl_off,
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_VARIANT_POSTERIOR, (hipStream_t)stream); hipLaunchKernelGGL(k_variant_posterior, dim3(n_vars), dim3(64), lds, (hipStream_t)stream, n_ind, win_hap_begin, gl_off,
                        n_reads, gl, freq, var_window, var_mask_off, hap_has_var, prior, (double*)ctx->pop_scratch.ptr,
-                       out_posterior);
+                       out_posterior); PLAT_KT_END(ctx, PLAT_KT_VARIANT_POSTERIOR, (hipStream_t)stream); }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -608,9 +608,9 @@ PLAT_EXPORT int plat_genotype_call_batch(plat_ctx* ctx, int n_sites, int n_ind, 
         return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
     const long long n = (long long)n_sites * n_ind;
-    hipLaunchKernelGGL(k_genotype_call, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n_sites, n_ind,
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_GENOTYPE_CALL, (hipStream_t)stream); hipLaunchKernelGGL(k_genotype_call, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n_sites, n_ind,
                        win_hap_begin, gl_off, gl, gof, freq, site_window, site_nvar, site_vih_off, site_ref_off, var_in_hap,
-                       is_ref, lik_off, out_phased, out_lik, out4);
+                       is_ref, lik_off, out_phased, out_lik, out4); PLAT_KT_END(ctx, PLAT_KT_GENOTYPE_CALL, (hipStream_t)stream); }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }
@@ -626,8 +626,8 @@ PLAT_EXPORT int plat_haplotype_score_batch(plat_ctx* ctx, const plat_window_batc
     if (lds > 64 * 1024) return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
     const unsigned nblk = (unsigned)((batch->n_windows + 64 / HS_GROUP - 1) / (64 / HS_GROUP));
-    hipLaunchKernelGGL(k_haplotype_score, dim3(nblk), dim3(64), lds, (hipStream_t)stream, *batch, n_ind, max_haps_per_window,
-                       seg_read_begin, seg_n_good, loglik, out_hap_like, out_hap_score);
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_HAPLOTYPE_SCORE, (hipStream_t)stream); hipLaunchKernelGGL(k_haplotype_score, dim3(nblk), dim3(64), lds, (hipStream_t)stream, *batch, n_ind, max_haps_per_window,
+                       seg_read_begin, seg_n_good, loglik, out_hap_like, out_hap_score); PLAT_KT_END(ctx, PLAT_KT_HAPLOTYPE_SCORE, (hipStream_t)stream); }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }

@@ -1132,14 +1132,14 @@ PLAT_EXPORT int plat_stage_b_batch(plat_ctx* ctx, const plat_stage_b_in* batch, 
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)plat::k_sb_variants, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(plat::SbRegion)));
         ctx->sb_attr_set = true;
     }
-    hipLaunchKernelGGL(plat::k_sb_variants, dim3((unsigned)b.n_regions), dim3(plat::SB_THREADS), sizeof(plat::SbRegion), st, in, o,
-                       (const int32_t*)ctx->merge_tab.ptr);
-    hipLaunchKernelGGL(plat::k_sb_windows, dim3((unsigned)b.n_regions), dim3(256), 0, st, in, o);
-    hipLaunchKernelGGL(plat::k_sb_haps_rank, dim3(48, (unsigned)b.n_regions), dim3(256), 0, st, in, o);
-    hipLaunchKernelGGL(plat::k_sb_prefix, dim3((unsigned)b.n_regions), dim3(256), 0, st, in, o);
-    hipLaunchKernelGGL(plat::k_sb_scan, dim3(1), dim3(64), 0, st, in, o);
-    hipLaunchKernelGGL(plat::k_sb_haps_write, dim3(48, (unsigned)b.n_regions), dim3(256), 0, st, in, o);
-    hipLaunchKernelGGL(plat::k_sb_reads, dim3(12, (unsigned)b.n_regions), dim3(256), 0, st, in, o);
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_SB_VARIANTS, st); hipLaunchKernelGGL(plat::k_sb_variants, dim3((unsigned)b.n_regions), dim3(plat::SB_THREADS), sizeof(plat::SbRegion), st, in, o,
+                       (const int32_t*)ctx->merge_tab.ptr); PLAT_KT_END(ctx, PLAT_KT_SB_VARIANTS, st); }
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_SB_WINDOWS, st); hipLaunchKernelGGL(plat::k_sb_windows, dim3((unsigned)b.n_regions), dim3(256), 0, st, in, o); PLAT_KT_END(ctx, PLAT_KT_SB_WINDOWS, st); }
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_SB_HAPS_RANK, st); hipLaunchKernelGGL(plat::k_sb_haps_rank, dim3(48, (unsigned)b.n_regions), dim3(256), 0, st, in, o); PLAT_KT_END(ctx, PLAT_KT_SB_HAPS_RANK, st); }
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_SB_PREFIX, st); hipLaunchKernelGGL(plat::k_sb_prefix, dim3((unsigned)b.n_regions), dim3(256), 0, st, in, o); PLAT_KT_END(ctx, PLAT_KT_SB_PREFIX, st); }
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_SB_SCAN, st); hipLaunchKernelGGL(plat::k_sb_scan, dim3(1), dim3(64), 0, st, in, o); PLAT_KT_END(ctx, PLAT_KT_SB_SCAN, st); }
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_SB_HAPS_WRITE, st); hipLaunchKernelGGL(plat::k_sb_haps_write, dim3(48, (unsigned)b.n_regions), dim3(256), 0, st, in, o); PLAT_KT_END(ctx, PLAT_KT_SB_HAPS_WRITE, st); }
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_SB_READS, st); hipLaunchKernelGGL(plat::k_sb_reads, dim3(12, (unsigned)b.n_regions), dim3(256), 0, st, in, o); PLAT_KT_END(ctx, PLAT_KT_SB_READS, st); }
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }

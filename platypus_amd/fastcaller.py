@@ -78,13 +78,15 @@ class CallerStats(C.Structure):
                 ("seconds_kernel_sweep", C.c_double), ("seconds_kernel_pairs", C.c_double), ("n_regions_stage_b_device", C.c_int64),
                 ("n_regions_stage_b_host", C.c_int64), ("n_windows_stage_b_host", C.c_int64), ("n_regions_dict_replay_device", C.c_int64),
                 ("seconds_worker_cpu", C.c_double), ("seconds_kernel_unpack", C.c_double), ("seconds_kernel_candidates", C.c_double),
-                ("unpack_bytes", C.c_int64), ("candidates_bytes", C.c_int64), ("n_unpack_launches", C.c_int64), ("n_candidates_launches", C.c_int64)]
+                ("unpack_bytes", C.c_int64), ("candidates_bytes", C.c_int64), ("n_unpack_launches", C.c_int64), ("n_candidates_launches", C.c_int64),
+                ("kernel_ms", C.c_double * 32), ("kernel_launches", C.c_int64 * 32)]
 
     STAGES = ("upload", "candidate_scan", "variants_windows_haplotypes", "greedy_rounds", "window_batch", "posteriors", "read_stats_calls", "text")
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "seconds_stage"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("seconds_stage", "kernel_ms", "kernel_launches")}
         d["seconds_stage"] = dict(zip(self.STAGES, list(self.seconds_stage)))
+        d["kernel_ms"], d["kernel_launches"] = list(self.kernel_ms), list(self.kernel_launches)
         return d
 
 

@@ -17,13 +17,13 @@
 #   line    the default bench line, bench.py --config 3/4/5, the two-rank launches on the one GPU
 #   soaks   ungapped cross-check (plain + wrap regime), native region-loop soak, assembler soak; SOAK_SECONDS each (default 400)
 # gpurun only brings back gpurun_out/: the summaries are written to profiles/ on the box AND copied to $O/out; copy them from there.
-TAG=${1:-r05}; shift
+TAG=${1:-r06}; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/${TAG}p
 mkdir -p $O
 PARTS=${@:-tests c2 c3 c4 c5 pmc2 pmc3 pmc4 nextk mapa line}
 T=${SOAK_SECONDS:-400}
-B2="--steps 12 --warmup 2 --no-cpu-baseline --no-extras --no-wgs --batches 3"
+B2="--config 2 --steps 12 --warmup 2 --no-cpu-baseline --no-extras --batches 3"
 cd /tmp && export TMPDIR=/tmp
 prof() { d=$1; shift; rm -rf $O/$d; rocprofv3 --kernel-trace --stats --output-format csv -d $O/$d -- "$@" > $O/$d.log 2>&1; tail -1 $O/$d.log > $O/$d.json; }
 pmc() { d=$1; c=$2; shift 2; rm -rf $O/$d; rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/$d -- "$@" > $O/$d.log 2>&1; }
@@ -37,12 +37,12 @@ for p in $PARTS; do case $p in
         pmc pmc4_SQ "SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES" python $R/bench.py --config 4 --regions 512 --steps 1 --no-cpu-baseline ;;
   mapa) (cd $R && hipcc --offload-arch=gfx950 -O3 -o /tmp/dp_mapping_a tools/ubench/dp_mapping_a.hip -Lplatypus_amd -lplat_mi355x && LD_LIBRARY_PATH=platypus_amd /tmp/dp_mapping_a 400000 150 | tail -1 > $O/dp_mapping_a.json; cat $O/dp_mapping_a.json) ;;
   c5) prof stats_c5 python $R/bench.py --config 5 --windows 200 --steps 10 --warmup 2 ;;
-  pmc2) for c in FETCH_SIZE WRITE_SIZE; do pmc pmc_$c $c python $R/bench.py --steps 4 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-extras --no-wgs --batches 2 --streams 1; done
-        pmc pmc_SQ "SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES" python $R/bench.py --steps 4 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-extras --no-wgs --batches 2 --streams 1 ;;
+  pmc2) for c in FETCH_SIZE WRITE_SIZE; do pmc pmc_$c $c python $R/bench.py --config 2 --steps 4 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-extras --batches 2 --streams 1; done
+        pmc pmc_SQ "SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES" python $R/bench.py --config 2 --steps 4 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-extras --batches 2 --streams 1 ;;
   pmc3) for c in FETCH_SIZE WRITE_SIZE; do pmc pmc3_$c $c python $R/bench.py --config 3 --regions 2000 --steps 2 --no-extras; done
         pmc pmc3_SQ "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" python $R/bench.py --config 3 --regions 2000 --steps 2 --no-extras
         pmc pmc3_WAIT "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" python $R/bench.py --config 3 --regions 2000 --steps 2 --no-extras ;;
-  pmcseed) S="--steps 3 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-extras --no-wgs --streams 1"
+  pmcseed) S="--config 2 --steps 3 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-extras --streams 1"
         pmc seed_a "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES" python $R/bench.py $S
         pmc seed_b "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" python $R/bench.py $S
         pmc seed_c "SQ_LDS_BANK_CONFLICT SQ_LDS_ATOMIC_RETURN SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_WAVES SQ_LDS_ADDR_CONFLICT" python $R/bench.py $S
@@ -51,7 +51,7 @@ for p in $PARTS; do case $p in
   line) (cd $R
         python bench.py > $O/bench_line.json 2> $O/bench_line.err
         for c in 3 4 5; do python bench.py --config $c > $O/bench_config$c.json 2> $O/bench_config$c.err; done
-        python bench.py --gpus 2 --steps 100 --no-extras > $O/bench_2ranks.json 2> $O/bench_2ranks.err
+        python bench.py --gpus 2 --steps 5 --no-extras > $O/bench_2ranks.json 2> $O/bench_2ranks.err
         python bench.py --gpus 2 --config 4 --regions 1024 > $O/bench_c4_2ranks.json 2> $O/bench_c4_2ranks.err
         PLAT_CALLER_LOADERS=2 taskset -c 0,1 python bench.py --config 4 --regions 1024 --steps 3 --no-cpu-baseline > $O/bench_config4_2cpus.json 2> $O/bench_config4_2cpus.err
         tail -c 600 $O/bench_line.json) ;;

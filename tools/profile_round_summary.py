@@ -71,7 +71,7 @@ def pmc(o, names, out, args):
 
 def main(o, tag):
     prof = os.path.join(ROOT, "profiles")
-    b2 = "--steps 12 --warmup 2 --no-cpu-baseline --no-extras --no-wgs --batches 3"
+    b2 = "--config 2 --steps 12 --warmup 2 --no-cpu-baseline --no-extras --batches 3"
     stats(o + "/stats1", prof + "/" + tag + "_kernel_stats.txt", CMD + b2 + " --streams 1   (MI355X; config 2, one batch at a time)")
     stats(o + "/stats3", prof + "/" + tag + "_kernel_stats_pipelined.txt", CMD + b2 + "   (MI355X; config 2, default: 3 batches in flight, kernels of different batches overlap)")
     stats(o + "/stats_c3", prof + "/" + tag + "_assemble_stats.txt", CMD + "--config 3 --regions 2000 --steps 5 --no-extras   (MI355X; config 3: 2000 assembly tiles per launch)")
@@ -85,7 +85,7 @@ def main(o, tag):
         p = o + "/" + f + ".json"
         if os.path.exists(p) and open(p).read().startswith("{"):
             open(os.path.join(prof, dst), "w").write(open(p).read())
-    per = pmc(o, ["pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ"], prof + "/" + tag + "_pmc_hbm.txt", "--steps 4 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-extras --no-wgs --batches 2 --streams 1")
+    per = pmc(o, ["pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ"], prof + "/" + tag + "_pmc_hbm.txt", "--config 2 --steps 4 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-extras --batches 2 --streams 1")
     pmc(o, ["pmc4_FETCH_SIZE", "pmc4_WRITE_SIZE", "pmc4_SQ"], prof + "/" + tag + "_pmc_config4.txt", "--config 4 --regions 512 --steps 1 --no-cpu-baseline")
     per3 = pmc(o, ["pmc3_FETCH_SIZE", "pmc3_WRITE_SIZE", "pmc3_SQ", "pmc3_WAIT"], prof + "/" + tag + "_pmc_assemble.txt", "--config 3 --regions 2000 --steps 2 --no-extras")
     tf = prof + "/dp_traffic.json"
