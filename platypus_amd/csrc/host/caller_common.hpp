@@ -531,6 +531,8 @@ static void runBatch(Slot& s, DeviceBatch& db, const Options& o, bool full, bool
         ck(plat_profile_enable(s.ctx, 1), "plat_profile_enable");
         ck(plat_align_window_batch(s.ctx, &wb, o.calculateFlankScore ? 1 : 0, 0, s.o_loglik.d, nullptr, &as, s.stream), "plat_align_window_batch");
         s.nDpRef += as.n_dp_reference; s.cellsRef += as.cells_reference; s.nDpRun += as.n_dp_launched; s.cellsRun += as.cells_launched;
+        if (getenv("PLAT_CALLER_TRACE")) fprintf(stderr, "[plat_caller] likelihood batch: %d windows, %d haplotypes (longest %d), %lld pairs, %lld for the exact vote, %lld DPs launched / %lld reference\n",
+                                                 db.nWindows, db.nHaps, db.maxHap, (long long)db.nPairs, (long long)as.n_seed_fallback, (long long)as.n_dp_launched, (long long)as.n_dp_reference);
         plat_profile pf;
         memset(&pf, 0, sizeof pf);
         ck(plat_profile_last(s.ctx, &pf), "plat_profile_last");     // (the profile stays on: Chunk::run collects every kernel's timers at its end)

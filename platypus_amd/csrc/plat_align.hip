@@ -1900,10 +1900,14 @@ k_pairs(plat_window_batch b, const int32_t* __restrict__ wave_win, const int32_t
     }
 }
 
-// k_seed_slow: the exact vote for the pairs k_seed queued.  Persistent grid; a workgroup (one wave) takes groups of 4 (1 when the queue is short)
-// consecutive queue entries (entries of one k_seed wave are consecutive and share their haplotype) and rebuilds the
-// haplotype's planes and k-mer index only when the haplotype changes.  Same LDS carve as k_seed.
-__global__ void __launch_bounds__(64)
+// k_seed_slow: the exact vote for the pairs the seeding kernels queued.  Round 6: a workgroup is FOUR waves and takes groups of SLOW_GROUP
+// consecutive queue entries (entries queued by one wave are consecutive and mostly share their haplotype).  Inside a group every run of
+// entries of one haplotype costs ONE index build, made by all 256 threads together; its waves then vote for one entry each, each wave in
+// its own set of diagonal counters.  (Before: one wave per workgroup, one build per entry -- a few thousand single-wave workgroups of
+// 30-40 KB of LDS each, five to a CU: 143-155 us per chunk of the WGS job for a few thousand pairs.)  Same LDS carve as k_seed up to the
+// counters, of which there are SLOW_WAVES sets.
+constexpr int SLOW_WAVES = 4, SLOW_GROUP = 4;
+__global__ void __launch_bounds__(64 * SLOW_WAVES)
 k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long long* __restrict__ tile_off,
             const ReadInfo* __restrict__ rinfo, const uint16_t* __restrict__ codes, PairRec* __restrict__ pairs,
             Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt, const SlowRec* __restrict__ slow_list,
@@ -1916,62 +1920,63 @@ k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long
     u64* h0 = (u64*)(smem + (size_t)tsize_max * 4 + (((size_t)maxhap + 2) * 2 + 7 & ~(size_t)7));
     u64* h1 = h0 + nw64;
     u64* nup = h1 + 2 * nw64;
-    unsigned* counts = (unsigned*)(nup + nw64);
-    int* s_scal = (int*)(counts + (cw >> 1));
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwv = (int)blockDim.x >> 6;   // (SLOW_WAVES waves, fewer when the counters of a long haplotype would not fit)
+    unsigned* counts = (unsigned*)(nup + nw64) + (size_t)wave * (size_t)(cw >> 1);      // this wave's diagonal counters
+    int* s_scal = (int*)((unsigned*)(nup + nw64) + (size_t)nwv * (size_t)(cw >> 1));
     long long nslow = cnt[CNT_SLOW_SEED];
     if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
     if (nslow > npairs) nslow = npairs;
+    if ((long long)SLOW_GROUP * blockIdx.x >= nslow) return;                              // (most workgroups of a launch: nothing queued for them)
     for (int j = lane; j < (cw >> 1); j += 64) counts[j] = 0u;
-    int cur = -1, hapLen = 0, tsize = 64;
-    bool direct = false;
-    unsigned tmask = 0;
-    const long long G = nslow <= 4 * (long long)gridDim.x ? 1 : 4;       // few entries: one each, for the shortest critical path
-    for (long long g = blockIdx.x; G * g < nslow; g += gridDim.x) {
-        for (long long e = G * g; e < min(nslow, G * g + G); ++e) {
-            const SlowRec rec = slow_list[e];
-            const int h = rec.hap, w = hap_win[h];
-            if (h != cur) {
-                cur = h;
-                const long long hoff = b.hap_off[h];
-                hapLen = (int)(b.hap_off[h + 1] - hoff);
-                const uint8_t* hs = b.hap_seq + hoff;
-                direct = hapLen > 4096;
-                tsize = 64;
-                if (direct) tsize = 16384;
-                else while (tsize < hapLen + hapLen / 4) tsize <<= 1;
-                tmask = (unsigned)tsize - 1u;
-                const int nch = (hapLen + 63) >> 6;
-                __syncthreads();
-                for (int i = lane; i < 2 * nw64; i += 64) h0[i] = 0ull;                  // h0, h1 contiguous
-                __syncthreads();
-                for (int t0 = 0; t0 < nch; t0 += 16) {           // 16 chunks of bytes per memory round trip
-                    unsigned by[16];
+    for (long long g = blockIdx.x; SLOW_GROUP * g < nslow; g += gridDim.x) {
+        const long long gEnd = min(nslow, SLOW_GROUP * g + SLOW_GROUP);
+        long long e = SLOW_GROUP * g;
+        while (e < gEnd) {                                                                // (uniform over the workgroup: everyone reads the same entries)
+            const int h = slow_list[e].hap, w = hap_win[h];
+            long long run = e + 1;
+            while (run < gEnd && slow_list[run].hap == h) ++run;
+            const long long hoff = b.hap_off[h];
+            const int hapLen = (int)(b.hap_off[h + 1] - hoff);
+            const uint8_t* hs = b.hap_seq + hoff;
+            const bool direct = hapLen > 4096;
+            int tsize = 64;
+            if (direct) tsize = 16384;
+            else while (tsize < hapLen + hapLen / 4) tsize <<= 1;
+            const unsigned tmask = (unsigned)tsize - 1u;
+            const int nch = (hapLen + 63) >> 6;
+            __syncthreads();                                                             // (the votes of the run before are over: the table may go)
+            for (int i = tid; i < 2 * nw64; i += 64 * nwv) h0[i] = 0ull;                 // h0, h1 contiguous
+            __syncthreads();
+            for (int t0 = 16 * wave; t0 < nch; t0 += 16 * nwv) {                   // 16 chunks of bytes per memory round trip and wave
+                unsigned by[16];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const int p = 64 * (t0 + k) + lane;
-                        by[k] = p < hapLen ? (unsigned)hs[p] : 0u;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const int p = 64 * (t0 + k) + lane;
-                        const unsigned b2 = p < hapLen ? base2(by[k]) : 0u;
-                        const u64 m0 = __ballot(b2 & 1u), m1 = __ballot(b2 & 2u);
-                        if (lane == 0 && t0 + k < nch) { h0[t0 + k] = m0; h1[t0 + k] = m1; }
-                    }
+                for (int k = 0; k < 16; ++k) {
+                    const int p = 64 * (t0 + k) + lane;
+                    by[k] = p < hapLen ? (unsigned)hs[p] : 0u;
                 }
-                __syncthreads();
-                seed_build_index(table, nxt, h0, h1, nup, s_scal, hapLen, nch, direct, tsize, tmask, false);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int p = 64 * (t0 + k) + lane;
+                    const unsigned b2 = p < hapLen ? base2(by[k]) : 0u;
+                    const u64 m0 = __ballot(b2 & 1u), m1 = __ballot(b2 & 2u);
+                    if (lane == 0 && t0 + k < nch) { h0[t0 + k] = m0; h1[t0 + k] = m1; }
+                }
             }
+            __syncthreads();
+            seed_build_index(table, nxt, h0, h1, nup, s_scal, hapLen, nch, direct, tsize, tmask, false);
             const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
-            const ReadInfo ri = rinfo[rb + rec.rl];
-            const int L = (int)(ri.lfm & 0xFFFFu);
             const int hapStart = b.win_start[w] - b.win_flank[w];                        // chaplotype.pyx:606
-            const int idx0 = min(ri.pos - hapStart, hapLen - L - 15);                    // calign.pyx:252
-            const long long pidx = b.pair_off[w] + (long long)(h - b.win_hap_begin[w]) * R + rec.rl;
-            const u64* scp = (const u64*)(codes + tile_off[w]) + rec.rl;
-            seed_exact_vote(table, nxt, counts, direct, tmask, hapLen, h | (((ri.lfm >> 18) & 1u) ? JOB_BIGQ : 0), scp, R, L, idx0, ri.col, (int)(ri.lfm >> 24), pidx,
-                            npairs, extra_cap, jobs, pairs, cnt, dense, segcap, w % DENSE_SEGS);
+            for (long long q = e + wave; q < run; q += nwv) {                      // one entry per wave at a time
+                const int rl = slow_list[q].rl;
+                const ReadInfo ri = rinfo[rb + rl];
+                const int L = (int)(ri.lfm & 0xFFFFu);
+                const int idx0 = min(ri.pos - hapStart, hapLen - L - 15);                // calign.pyx:252
+                const long long pidx = b.pair_off[w] + (long long)(h - b.win_hap_begin[w]) * R + rl;
+                const u64* scp = (const u64*)(codes + tile_off[w]) + rl;
+                seed_exact_vote(table, nxt, counts, direct, tmask, hapLen, h | (((ri.lfm >> 18) & 1u) ? JOB_BIGQ : 0), scp, R, L, idx0, ri.col, (int)(ri.lfm >> 24), pidx,
+                                npairs, extra_cap, jobs, pairs, cnt, dense, segcap, w % DENSE_SEGS);
+            }
+            e = run;
         }
     }
 }
@@ -2316,7 +2321,9 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     const size_t nw64 = (((size_t)maxhap + 63) >> 6) + 8;
     const size_t lds0 = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 7) & ~(size_t)7) + 4 * nw64 * 8 + 16 + 64 + 128;
     const size_t lds = lds0 + ((nw64 + 15) & ~(size_t)15);    // k_seed: + one byte per chunk of 64 positions (gap-open minima)
-    const size_t lds_slow = lds0 + (size_t)cw * 2;
+    int slow_waves = SLOW_WAVES;                                // (a set of diagonal counters per wave; fewer waves when long haplotypes make the sets large)
+    while (slow_waves > 1 && lds0 + (size_t)slow_waves * (size_t)cw * 2 > 64 * 1024) slow_waves >>= 1;
+    const size_t lds_slow = lds0 + (size_t)slow_waves * (size_t)cw * 2;
     if (lds_slow > 160 * 1024 || lds > 160 * 1024) return PLAT_ERR_HAP_TOO_LONG;
     if (lds > 48 * 1024) {
         PLAT_HIP(ctx, hipFuncSetAttribute((const void*)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2373,7 +2380,7 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
         }
     }
     PLAT_EV(ctx, 5, st);                                       // k_seed alone: ev[1] .. ev[5]
-    { PLAT_KT_BEGIN(ctx, PLAT_KT_SEED_SLOW, st); hipLaunchKernelGGL(k_seed_slow, dim3(4096), dim3(64), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_SEED_SLOW, st); hipLaunchKernelGGL(k_seed_slow, dim3(2048), dim3(64 * slow_waves), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
                        (const SlowRec*)ctx->slow.ptr, tsize_max, maxhap, cw, dense, segcap); PLAT_KT_END(ctx, PLAT_KT_SEED_SLOW, st); }
     if (!(shortcuts & SEED_LEAN))                              // (the asynchronous entry point reads nothing back: every kernel sums the segments itself)
