@@ -28,18 +28,27 @@ typedef std::chrono::steady_clock Clock;
 static inline double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
 static inline double threadCpuSeconds() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 #ifdef PLAT_HOSTPROF                                                  // (local measurement builds only: cycle counts of named scopes)
+// per-thread counters (a scope costs two rdtsc and two plain adds: shared atomics cost more than most of the scopes they measured); the
+// threads' blocks are linked into a list and summed by profDump
 static const char* g_profName[256];
-static std::atomic<unsigned long long> g_profCyc[256], g_profCalls[256];
 static std::atomic<int> g_profN{0};
+struct ProfBlock { unsigned long long cyc[256] = {}, calls[256] = {}; ProfBlock* next = nullptr; };
+static std::atomic<ProfBlock*> g_profBlocks{nullptr};
+static ProfBlock* profMine() {
+    static thread_local ProfBlock* mine = nullptr;
+    if (!mine) { mine = new ProfBlock(); ProfBlock* h = g_profBlocks.load(); do { mine->next = h; } while (!g_profBlocks.compare_exchange_weak(h, mine)); }
+    return mine;
+}
 static int profId(const char* n) { const int k = g_profN.fetch_add(1); g_profName[k] = n; return k; }
-struct ProfScope { int k; unsigned long long t0; ProfScope(int k_) : k(k_), t0(__rdtsc()) {}
-                   ~ProfScope() { g_profCyc[k].fetch_add(__rdtsc() - t0, std::memory_order_relaxed); g_profCalls[k].fetch_add(1, std::memory_order_relaxed); } };
+struct ProfScope { int k; ProfBlock* b; unsigned long long t0; ProfScope(int k_) : k(k_), b(profMine()), t0(__rdtsc()) {}
+                   ~ProfScope() { b->cyc[k] += __rdtsc() - t0; b->calls[k] += 1; } };
 #define PROF_CAT2(a, b) a##b
 #define PROF_CAT(a, b) PROF_CAT2(a, b)
 #define PROF(name) static const int PROF_CAT(profid_, __LINE__) = profId(name); ProfScope PROF_CAT(prof_, __LINE__)(PROF_CAT(profid_, __LINE__))
 static void profDump(double n) {
     std::map<std::string, std::pair<unsigned long long, unsigned long long>> m;
-    for (int k = 0; k < g_profN.load(); ++k) { m[g_profName[k]].first += g_profCyc[k].exchange(0); m[g_profName[k]].second += g_profCalls[k].exchange(0); }
+    for (ProfBlock* b = g_profBlocks.load(); b; b = b->next)
+        for (int k = 0; k < g_profN.load(); ++k) { m[g_profName[k]].first += b->cyc[k]; m[g_profName[k]].second += b->calls[k]; b->cyc[k] = 0; b->calls[k] = 0; }
     for (auto& kv : m) fprintf(stderr, "  [prof] %-28s %9.1f kcycles/region %8.1f calls/region\n", kv.first.c_str(), 1e-3 * (double)kv.second.first / n, (double)kv.second.second / n);
 }
 #else

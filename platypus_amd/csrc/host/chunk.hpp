@@ -109,11 +109,11 @@ struct Chunk {
         double wait0 = s.t_wait;
         mark = t0; waitMark = wait0;
         if (s.countCells) ck(plat_profile_enable(s.ctx, 1), "plat_profile_enable");     // (the counting pass: live timers of the table kernels too)
-        uploadReads();
+        { PROF("s0.uploadReads"); uploadReads(); }
         lap(0);
         deviceB = eligibleDeviceB();
         assembleLaunch();
-        if (o.getVariantsFromBAMs) scanCandidates();
+        if (o.getVariantsFromBAMs) { PROF("s1.scanCandidates"); scanCandidates(); }
         if (s.countCells) {
             plat_profile pf;
             memset(&pf, 0, sizeof pf);
@@ -188,9 +188,15 @@ struct Chunk {
             }
         }
         // the region's text: what the loop writes, in the order it writes it
+        PROF("s7.assemble_text_release");
         int64_t nRec = 0, nRef = 0;
         for (RegionWork* r : regions) {
             int nHapLast = 0;                                               // haplotypes of the last window set up in this region (Population.nHaplotypes)
+            {   // (the region's text in one allocation: it is the sum of its items' texts but for the rare lines written here)
+                size_t need = r->text.size() + 256;
+                for (const Item& it : r->items) need += it.kind == 1 ? it.text.size() : r->windows[(size_t)it.window].text.size();
+                r->text.reserve(need);
+            }
             for (Item& it : r->items) {
                 if (it.kind == 1) { r->text += it.text; nRec += it.nRef; nRef += it.nRef; continue; }
                 WindowWork& w = r->windows[(size_t)it.window];
@@ -218,7 +224,7 @@ struct Chunk {
                     ++st.n_windows_failed;
                 }
             }
-            r->release();
+            { PROF("s7.release"); r->release(); }
         }
         if (s.countCells) {                                                 // every kernel of this chunk, live (HIP events around each launch)
             ck(plat_kernel_times(s.ctx, s.ktMs, s.ktLaunches), "plat_kernel_times");

@@ -33,10 +33,26 @@ inline std::string py2_str_slow(double x) {                              // str(
     for (size_t k = i; k < t.size(); ++k) if (t[k] < '0' || t[k] > '9') { digits = false; break; }
     return digits ? t + ".0" : t;
 }
-inline char* put_uint(char* p, unsigned long long v) {                   // decimal digits of v at p, returns the end
+// decimal digits of v at p, returns the end.  Two digits per division from a table; 32-bit arithmetic for the values that fit (nearly all
+// numbers of a record: positions, counts, phred values)
+static const char DIGIT_PAIRS[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+inline char* put_u32(char* p, uint32_t v) {
+    char tmp[12];
+    int n = 0;
+    while (v >= 100) { const uint32_t q = v / 100, r = v - q * 100; tmp[n++] = DIGIT_PAIRS[2 * r + 1]; tmp[n++] = DIGIT_PAIRS[2 * r]; v = q; }
+    if (v >= 10) { tmp[n++] = DIGIT_PAIRS[2 * v + 1]; tmp[n++] = DIGIT_PAIRS[2 * v]; }
+    else tmp[n++] = (char)('0' + v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+inline char* put_uint(char* p, unsigned long long v) {
+    if (v <= 0xFFFFFFFFull) return put_u32(p, (uint32_t)v);
     char tmp[24];
     int n = 0;
-    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (v >= 100) { const unsigned long long q = v / 100; const unsigned r = (unsigned)(v - q * 100); tmp[n++] = DIGIT_PAIRS[2 * r + 1]; tmp[n++] = DIGIT_PAIRS[2 * r]; v = q; }
+    if (v >= 10) { tmp[n++] = DIGIT_PAIRS[2 * v + 1]; tmp[n++] = DIGIT_PAIRS[2 * v]; }
+    else tmp[n++] = (char)('0' + v);
     while (n) *p++ = tmp[--n];
     return p;
 }
@@ -203,6 +219,43 @@ inline std::vector<std::string> py2_set_order(const std::vector<std::string>& na
     return out;
 }
 
+// The same for a short list of C-string names (the FILTER column: at most eight distinct names, repeated per variant of the record), without
+// a heap allocation: distinct names in the order list(set(names)) gives.  out must hold n pointers; returns the number written.
+inline int py2_set_order_names(const char* const* names, int n, const char** out) {
+    const char* table[64];                                                // 8 slots, rebuilt 4 x used when two thirds full: 8 distinct names never pass 32 slots
+    uint64_t hashes[64];
+    int size = 8, used = 0;
+    for (int k = 0; k < size; ++k) table[k] = nullptr;
+    auto slot = [&](const char* const* t, int sz, const char* key, uint64_t h) -> int {
+        const uint64_t mask = (uint64_t)sz - 1;
+        uint64_t i = h & mask, perturb = h;
+        while (t[i & mask] && strcmp(t[i & mask], key) != 0) { i = 5 * i + perturb + 1; perturb >>= 5; }
+        return (int)(i & mask);
+    };
+    for (int q = 0; q < n; ++q) {
+        const char* key = names[q];
+        const uint64_t h = py2_string_hash(std::string(key));             // (names of at most ten characters: in-object strings)
+        const int j = slot(table, size, key, h);
+        if (table[j]) continue;
+        table[j] = key; hashes[j] = h;
+        ++used;
+        if (used * 3 >= size * 2) {
+            int nsize = 8;
+            while (nsize <= used * 4) nsize <<= 1;
+            if (nsize > 64) nsize = 64;                                   // (cannot happen with the header's eight filter names)
+            const char* grown[64];
+            uint64_t gh[64];
+            for (int k = 0; k < nsize; ++k) grown[k] = nullptr;
+            for (int k = 0; k < size; ++k) if (table[k]) { const int g = slot(grown, nsize, table[k], hashes[k]); grown[g] = table[k]; gh[g] = hashes[k]; }
+            for (int k = 0; k < nsize; ++k) { table[k] = grown[k]; hashes[k] = gh[k]; }
+            size = nsize;
+        }
+    }
+    int m = 0;
+    for (int k = 0; k < size; ++k) if (table[k]) out[m++] = table[k];
+    return m;
+}
+
 // iteration order of a Python-2 dict holding these integer keys, inserted in this order (dictobject.c: the same open addressing and
 // growth as the set above; hash(int) is the int, -1 -> -2): what `for pos, vars in pop.varsByPos.iteritems()` walks (variantcaller.pyx:584-603)
 inline std::vector<int> py2_int_dict_order(const std::vector<int>& keys) {
@@ -367,10 +420,20 @@ struct Num {                                                              // a P
     }
 };
 
+// a short text held inside the object (the 21-base sequence context of a variant: one heap block per called variant otherwise)
+struct InlineStr {
+    char c[31]; uint8_t n = 0;
+    size_t size() const { return n; }
+    const char* data() const { return c; }
+    const char* begin() const { return c; }
+    const char* end() const { return c + n; }
+    void assign(const char* s, size_t len) { n = (uint8_t)std::min<size_t>(len, sizeof c); memcpy(c, s, n); }
+};
 struct VarInfo {                                                          // vcfInfo[variant]
     Variant* var = nullptr;
     int HP = 0;
-    std::string SC, PP, FRtext;
+    InlineStr SC;
+    std::string PP, FRtext;
     double FRsum = 0.0;
     Num ABPV, SbPval, BRF, MQ, QD;
     long long TR = 0, NF = 0, NR = 0, TC = 0, TCR = 0, TCF = 0;
@@ -396,8 +459,13 @@ inline int homopolymerLengthForOneVariant(const Variant& v, const Fasta& fa) {
     return left[nL - 1] != right[0] ? std::max(nl, nr) : nl + nr;
 }
 inline std::string getSequenceContext(const Variant& v, const Fasta& fa) { return fa.getSequence(v.refPos - 10, v.refPos + 11); }   // :500-506
+inline void getSequenceContext(const Variant& v, const Fasta& fa, InlineStr& out) {       // the same interval, clamped and checked as getSequence does
+    const int64_t b = std::max<int64_t>(0, (int64_t)v.refPos - 10), e = std::min<int64_t>(fa.len - 1, (int64_t)v.refPos + 11);
+    if (e < b) throw WindowError("Cannot have beginPos > endPos in getSequence");
+    out.assign((const char*)fa.seq + b, (size_t)(e - b));
+}
 
-inline double computeSCValue(const std::string& sequence) {               // vcfutils.pyx:1480-1498
+template <class Str> inline double computeSCValue(const Str& sequence) {  // vcfutils.pyx:1480-1498
     // the two most frequent characters of the 21-base context: counted among the characters that occur (a table of 256 counters was
     // cleared and scanned per called position)
     static thread_local int counts[256];                                  // all zero between calls

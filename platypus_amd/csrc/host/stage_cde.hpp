@@ -121,6 +121,7 @@ inline void Chunk::callWindows(std::vector<WindowWork*>& wins, bool fromDevice) 
         }
         if (w->called.empty()) continue;
         live.push_back(w);
+        w->info.reserve(w->called.size());
         const double* freq = z.o_freq.h + w->hapBegin;
         const int32_t* calls = z.o_calls.h + (size_t)w->bw * (size_t)nInd;
         for (size_t h = 0; h < w->haps.size(); ++h) {
@@ -138,7 +139,7 @@ inline void Chunk::callWindows(std::vector<WindowWork*>& wins, bool fromDevice) 
                     n.var = v;
                     PROF("s6.hp_sc");
                     n.HP = homopolymerLengthForOneVariant(*v, r.fa);
-                    n.SC = getSequenceContext(*v, r.fa);
+                    getSequenceContext(*v, r.fa, n.SC);
                     n.PP.clear();
                     append_fixed(n.PP, w->calledPost[(size_t)ci], 0);                   // "%.0f"
 
@@ -193,6 +194,7 @@ inline void Chunk::callWindows(std::vector<WindowWork*>& wins, bool fromDevice) 
     }
     const std::vector<double> flatPost(z.p_post.h, z.p_post.h + (nV ? nV : 0));     // (p_post's pinned mirror is reused by nothing below, copied for clarity)
     if (!live.empty()) {
+    PROF("s6.launch");
     // E: read statistics + per-site genotype calls
     const size_t nSV = svw.size(), nSites = kwin.size();
     kvih.push_back(0);

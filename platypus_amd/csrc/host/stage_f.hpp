@@ -52,6 +52,7 @@ inline void Chunk::writeWindow(RegionWork& r, WindowWork& w, const std::vector<i
         PROF("text.info");
         infoFieldsFromReadStats(d, z.s_counts.h + 16 * sv, z.s_ps.h + 2 * sv * (size_t)nInd, nInd, z.s_minq.h + z.s_moff.h[sv], z.s_nminq.h[sv],
                                 z.infoOnDevice ? z.s_terms.h + 8 * sv : nullptr, z.infoOnDevice ? z.s_mmlq.h[sv] : -1);
+        PROF("text.info.qd");
         if (d.TR > 0) {                                                // :1400-1409
             const double qual = strtod(d.PP.c_str(), nullptr);
             if (qual > 2500) d.QD = Num::I(o.qdThreshold + 10);
@@ -108,70 +109,50 @@ inline void Chunk::writeWindow(RegionWork& r, WindowWork& w, const std::vector<i
     std::sort(positions.begin(), positions.end(), [](const std::pair<int, VarList>* a, const std::pair<int, VarList>* b) { return a->first < b->first; });
     std::string& out = w.text;
     out.reserve(out.size() + positions.size() * (size_t)(320 + 40 * nInd));                  // (a record line is ~300 characters: no regrowth on the way)
+    // (the record's scratch lives from record to record of this thread: its storage is reused)
+    static thread_local std::string ref;
+    static thread_local std::vector<std::string> alt;
+    static thread_local std::vector<char> line;
+    struct SampleCall { int index1, index2, gq; long long gof; bool empty, noCall, refCall; };
+    static thread_local std::vector<SampleCall> calls;
     for (size_t pi = 0; pi < positions.size(); ++pi) {
         PROF("text.record");
         int POS = positions[pi]->first;
         const VarList& variants = positions[pi]->second;
         const int nVariants = (int)variants.size();
         const size_t site = (size_t)w.firstSite + pi;
-        // (the record's lists live from record to record of this thread: their storage is reused)
-        static thread_local std::string ref;
-        static thread_local std::vector<std::string> alt, linefilter, FR, PP, sampleCols;
-        SmallVec<long long, 4> NF, NR, TR;
-        linefilter.clear(); FR.clear(); PP.clear(); sampleCols.clear();
         { PROF("text.record.refalt"); refAndAlt(POS, variants, r.fa, ref, alt); }
-        VarInfo& lead = infoOf(variants[0]);
-        for (Variant* v : variants) {
-            VarInfo& d = infoOf(v);
-            for (const char* f : d.filters) linefilter.emplace_back(f);
-            FR.push_back(d.FRtext); PP.push_back(d.PP); NF.push_back(d.NF); NR.push_back(d.NR); TR.push_back(d.TR);
-        }
+        SmallVec<VarInfo*, 4> infos;                                       // vcfInfo[v] of the record's variants, in their order
+        for (Variant* v : variants) infos.push_back(&infoOf(v));
+        VarInfo& lead = *infos[0];
         int qual = 0;
-        bool first = true;
-        for (const std::string& pp : PP) { const int q = atoi(pp.c_str()); if (first || q > qual) qual = q; first = false; }
-        // per-sample columns
+        for (int k = 0; k < nVariants; ++k) { const int q = atoi(infos[(size_t)k]->PP.c_str()); if (k == 0 || q > qual) qual = q; }
+        // per-sample calls first: MGOF (an INFO field) and the decision to write the record at all depend on them
         double maxGof = 0.0;
         int nNonRefCalls = 0;
         const int64_t NL = (int64_t)(nVariants + 1) * (nVariants + 2) / 2;
+        const bool oneVar = nVariants == 1;
+        calls.resize((size_t)nInd);
         for (int i = 0; i < nInd; ++i) {
             PROF("text.record.samplecol");
+            SampleCall& c = calls[(size_t)i];
             const Ptrs& p = w.ptrs[(size_t)i];
-            if (p.ge - p.gs == 0) { sampleCols.push_back("./.:0,0,0:0:0:0:0"); continue; }        // :498-500
+            c.empty = p.ge - p.gs == 0;                                    // :498-500
+            if (c.empty) continue;
             const size_t t = site * (size_t)nInd + (size_t)i;
-            const int index1 = z.k_ph.h[2 * t], index2 = z.k_ph.h[2 * t + 1];
-            const double* lik = z.k_lik.h + klo[site] + (int64_t)i * NL;
+            c.index1 = z.k_ph.h[2 * t]; c.index2 = z.k_ph.h[2 * t + 1];
             const double gtPost = z.k_out4.h[4 * t], nonRefPost = z.k_out4.h[4 * t + 1], refPost = z.k_out4.h[4 * t + 2], gofValue = z.k_out4.h[4 * t + 3];
-            if (!(index1 == 0 && index2 == 0)) ++nNonRefCalls;
-            // GT : GL : GOF : GQ : NR : NV, written in place; format_formatdata(key=False) then drops the trailing entries made only
-            // of "," and "." -- GT "./." can only be dropped when everything after it is, and the integers after it never are
-            std::string col;
-            const bool oneVar = nVariants == 1;
-            bool noCall = false;
-            if (oneVar) {                                               // :524-542, :550-553
-                if (phred(nonRefPost) < o.minPosterior) { if (phred(refPost) < o.minPosterior) noCall = true; else col = "0/0"; }
-                if (infoOf(variants[0]).nReadsPerSample[(size_t)i] < o.minReads) noCall = true;
+            if (!(c.index1 == 0 && c.index2 == 0)) ++nNonRefCalls;
+            c.noCall = false; c.refCall = false;
+            if (oneVar) {                                                   // :524-542, :550-553
+                if (phred(nonRefPost) < o.minPosterior) { if (phred(refPost) < o.minPosterior) c.noCall = true; else c.refCall = true; }
+                if (lead.nReadsPerSample[(size_t)i] < o.minReads) c.noCall = true;
             }
-            if (noCall) col = "./.";
-            else if (col.empty()) { append_int(col, index1); col += '/'; append_int(col, index2); }
-            col += ':';
-            if (oneVar) {
-                double top = lik[0];
-                for (int64_t q = 1; q < NL; ++q) top = std::max(top, lik[q]);
-                for (int64_t q = 0; q < NL; ++q) {                   // (FORMAT fields have no numeric missing value: -1.0 stays -1.0)
-                    if (q) col += ',';
-                    append_py2_str(col, py2_round2(log10(std::max(lik[q] / top, 1e-300))));
-                }
-            } else col += "-1,-1,-1";
-            col += ':'; append_int(col, (long long)gofValue);
-            col += ':'; append_int(col, phred(gtPost));
-            col += ':';
-            for (int k = 0; k < nVariants; ++k) { if (k) col += ','; append_int(col, infoOf(variants[(size_t)k]).nReadsPerSample[(size_t)i]); }
-            col += ':';
-            for (int k = 0; k < nVariants; ++k) { if (k) col += ','; append_int(col, infoOf(variants[(size_t)k]).nVarReadsPerSample[(size_t)i]); }
-            sampleCols.push_back(std::move(col));
+            c.gof = (long long)gofValue; c.gq = phred(gtPost);
             maxGof = std::max(maxGof, gofValue);
         }
         const long long MGOF = (long long)py2_round2(maxGof);
+        PROF("text.record.tail");
         if (!(nNonRefCalls > 0 || o.minPosterior == 0 || o.outputRefCalls == 1)) continue;
         trimLeftPadding(POS, ref, alt);
         bool plain = true;
@@ -179,55 +160,80 @@ inline void Chunk::writeWindow(RegionWork& r, WindowWork& w, const std::vector<i
         if (!plain) continue;                                           // :583-592
         // VCF.write_data
         PROF("text.record.write");
-        // (written through a pointer into space reserved for the whole line: a bound on its length first)
+        // (written through a pointer into this thread's line buffer: a bound on the line's length first)
         const size_t chromLen = strlen(r.in->chrom);
-        size_t bound = chromLen + ref.size() + lead.SC.size() + 768 + 80 * (size_t)nVariants;          // literals 130, 15 numbers of at most 32, 3 counts per variant
+        size_t bound = chromLen + ref.size() + lead.SC.size() + 800 + 96 * (size_t)nVariants;          // literals 130, 15 numbers of at most 32, 3 counts + FR + PP per variant
         for (const std::string& a : alt) bound += a.size() + 1;
-        for (const std::string& f : linefilter) bound += f.size() + 1;
-        for (const std::string& c : sampleCols) bound += c.size() + 1;
-        for (const std::string& t : FR) bound += t.size() + 1;
-        for (const std::string& t : PP) bound += t.size() + 1;
-        bound += 32;                                                       // Source: at most Platypus,Assembler,File
-        const size_t at0 = out.size();
-        out.resize(at0 + bound);
-        char* p = &out[at0];
+        for (int k = 0; k < nVariants; ++k) bound += 12 * infos[(size_t)k]->filters.size() + infos[(size_t)k]->FRtext.size() + infos[(size_t)k]->PP.size();
+        bound += (size_t)nInd * (64 + 33 * (size_t)NL + 24 * (size_t)nVariants);
+        if (line.size() < bound) line.resize(bound + bound / 2);
+        char* const line0 = line.data();
+        char* p = line0;
         p = put_chars(p, r.in->chrom, chromLen); *p++ = '\t';
         p = put_int(p, POS + 1); p = put_lit(p, "\t.\t"); p = put_str(p, ref); *p++ = '\t';
         if (alt.empty()) *p++ = '.'; else for (size_t q = 0; q < alt.size(); ++q) { if (q) *p++ = ','; p = put_str(p, alt[q]); }
         *p++ = '\t'; p = put_int(p, qual); *p++ = '\t';
-        if (linefilter.empty()) p = put_lit(p, "PASS");
-        else {
-            std::vector<std::string> flt = py2_set_order(linefilter);
-            for (size_t q = 0; q < flt.size(); ++q) { if (q) *p++ = ';'; p = put_str(p, flt[q]); }
+        {
+            const char* names[64]; const char* ordered[64];
+            int nf = 0;
+            for (int k = 0; k < nVariants; ++k) for (const char* f : infos[(size_t)k]->filters) if (nf < 64) names[nf++] = f;
+            if (nf == 0) p = put_lit(p, "PASS");
+            else {
+                const int m = py2_set_order_names(names, nf, ordered);
+                for (int q = 0; q < m; ++q) { if (q) *p++ = ';'; p = put_chars(p, ordered[q], strlen(ordered[q])); }
+            }
         }
         *p++ = '\t';
-        auto joinLL = [&p](const SmallVec<long long, 4>& v) { for (size_t q = 0; q < v.size(); ++q) { if (q) *p++ = ','; p = Num::I(v[q]).put(p); } };
-        auto joinS = [&p](const std::vector<std::string>& v) { for (size_t q = 0; q < v.size(); ++q) { if (q) *p++ = ','; p = put_str(p, v[q]); } };
         // INFO keys in sorted order: BRF FR HP HapScore MGOF MMLQ MQ NF NR PP QD SC SbPval Source TC TCF TCR TR WE WS
         p = put_lit(p, "BRF="); p = lead.BRF.put(p);
-        p = put_lit(p, ";FR="); joinS(FR);
+        p = put_lit(p, ";FR="); for (int k = 0; k < nVariants; ++k) { if (k) *p++ = ','; p = put_str(p, infos[(size_t)k]->FRtext); }
         p = put_lit(p, ";HP="); p = Num::I(lead.HP).put(p);
         p = put_lit(p, ";HapScore="); p = Num::I(lead.HapScore).put(p);
         p = put_lit(p, ";MGOF="); p = Num::I(MGOF).put(p);
         p = put_lit(p, ";MMLQ="); p = Num::I(lead.MMLQ).put(p);
         p = put_lit(p, ";MQ="); p = lead.MQ.put(p);
-        p = put_lit(p, ";NF="); joinLL(NF);
-        p = put_lit(p, ";NR="); joinLL(NR);
-        p = put_lit(p, ";PP="); joinS(PP);
+        p = put_lit(p, ";NF="); for (int k = 0; k < nVariants; ++k) { if (k) *p++ = ','; p = Num::I(infos[(size_t)k]->NF).put(p); }
+        p = put_lit(p, ";NR="); for (int k = 0; k < nVariants; ++k) { if (k) *p++ = ','; p = Num::I(infos[(size_t)k]->NR).put(p); }
+        p = put_lit(p, ";PP="); for (int k = 0; k < nVariants; ++k) { if (k) *p++ = ','; p = put_str(p, infos[(size_t)k]->PP); }
         p = put_lit(p, ";QD="); p = lead.QD.put(p);
-        p = put_lit(p, ";SC="); p = put_str(p, lead.SC);
+        p = put_lit(p, ";SC="); p = put_chars(p, lead.SC.data(), lead.SC.size());
         p = put_lit(p, ";SbPval="); p = lead.SbPval.put(p);
         p = put_lit(p, ";Source="); for (size_t q = 0; q < lead.Source.size(); ++q) { if (q) *p++ = ','; p = put_chars(p, lead.Source[q], strlen(lead.Source[q])); }
         p = put_lit(p, ";TC="); p = Num::I(lead.TC).put(p);
         p = put_lit(p, ";TCF="); p = Num::I(lead.TCF).put(p);
         p = put_lit(p, ";TCR="); p = Num::I(lead.TCR).put(p);
-        p = put_lit(p, ";TR="); joinLL(TR);
+        p = put_lit(p, ";TR="); for (int k = 0; k < nVariants; ++k) { if (k) *p++ = ','; p = Num::I(infos[(size_t)k]->TR).put(p); }
         p = put_lit(p, ";WE="); p = Num::I(w.endPos).put(p);
         p = put_lit(p, ";WS="); p = Num::I(w.startPos).put(p);
         p = put_lit(p, "\tGT:GL:GOF:GQ:NR:NV");
-        for (const std::string& c : sampleCols) { *p++ = '\t'; p = put_str(p, c); }
+        // per-sample columns GT : GL : GOF : GQ : NR : NV, written in place; format_formatdata(key=False) then drops the trailing entries made only
+        // of "," and "." -- GT "./." can only be dropped when everything after it is, and the integers after it never are
+        for (int i = 0; i < nInd; ++i) {
+            const SampleCall& c = calls[(size_t)i];
+            *p++ = '\t';
+            if (c.empty) { p = put_lit(p, "./.:0,0,0:0:0:0:0"); continue; }
+            if (c.noCall) p = put_lit(p, "./.");
+            else if (c.refCall) p = put_lit(p, "0/0");
+            else { p = put_int(p, c.index1); *p++ = '/'; p = put_int(p, c.index2); }
+            *p++ = ':';
+            if (oneVar) {
+                const double* lik = z.k_lik.h + klo[site] + (int64_t)i * NL;
+                double top = lik[0];
+                for (int64_t q = 1; q < NL; ++q) top = std::max(top, lik[q]);
+                for (int64_t q = 0; q < NL; ++q) {                   // (FORMAT fields have no numeric missing value: -1.0 stays -1.0)
+                    if (q) *p++ = ',';
+                    p = put_py2_str(p, py2_round2(log10(std::max(lik[q] / top, 1e-300))));
+                }
+            } else p = put_lit(p, "-1,-1,-1");
+            *p++ = ':'; p = put_int(p, c.gof);
+            *p++ = ':'; p = put_int(p, c.gq);
+            *p++ = ':';
+            for (int k = 0; k < nVariants; ++k) { if (k) *p++ = ','; p = put_int(p, infos[(size_t)k]->nReadsPerSample[(size_t)i]); }
+            *p++ = ':';
+            for (int k = 0; k < nVariants; ++k) { if (k) *p++ = ','; p = put_int(p, infos[(size_t)k]->nVarReadsPerSample[(size_t)i]); }
+        }
         *p++ = '\n';
-        out.resize((size_t)(p - out.data()));
+        out.append(line0, (size_t)(p - line0));
         ++w.nRecords;
     }
 }

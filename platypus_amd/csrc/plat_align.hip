@@ -574,6 +574,66 @@ __device__ __forceinline__ void seed_exact_vote(const unsigned* table, const uns
     for (int j = lane; j < ((n + 2) >> 1); j += 64) counts[j] = 0u;
 }
 
+// The vote of seed_exact_vote WITHOUT its reservations (round 6): the arg-max diagonals of one pair are left, ascending, in an LDS record
+// (at most SLOW_MAXC of them; `sncand` says how many there are), so that a workgroup can reserve the job slots and dense-list entries of a
+// whole group of pairs with ONE returning atomic per counter -- ~11 k pairs per launch of the WGS job each asked the same two addresses,
+// and the L2 serves ~90 of those per microsecond.  `counts` zero on entry and on exit.
+constexpr int SLOW_MAXC = 32;
+struct SlowOut {
+    long long pidx; int32_t h, sL, sidx0; uint32_t scol; int32_t smapq, sncand, orig_in, orig_k, seg, njobs, sbase, fits; long long db;
+    uint16_t cand[SLOW_MAXC];
+};
+__device__ __forceinline__ void seed_vote_collect(const unsigned* table, const unsigned short* nxt, unsigned* counts, bool direct,
+                                                  unsigned tmask, int hapLen, const u64* scp, int R, int sL, int sidx0, SlowOut* o)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = hapLen + sL, snk = sL - 7, j0i = sidx0 + sL;
+    unsigned mymax = 0;
+    for (int i = lane; i < snk; i += 64) {                                 // pass 1: diagonal vote, calign.pyx:209-220
+        unsigned hidx = kmer_head(table, read_code(scp, R, i), direct, tmask);
+        while (hidx != 0u) {
+            const int j = (int)hidx - i - 1 + sL;
+            const unsigned sh = 16u * (unsigned)(j & 1);
+            const unsigned c = ((atomicAdd(&counts[j >> 1], 1u << sh) >> sh) & 0x7FFFu) + 1u;
+            mymax = max(mymax, c);
+            hidx = nxt[hidx];
+        }
+    }
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) mymax = max(mymax, (unsigned)__shfl_xor((int)mymax, s2));
+    const unsigned maxcount = mymax;
+    const bool s_orig_in = maxcount > 0 && j0i >= 0 && j0i < n && CNT16(counts, j0i) == maxcount && sidx0 + sL + 15 < hapLen;
+    int k = 0, orig_k = -1;
+    for (int j0 = 0; j0 < n; j0 += 64) {                                   // the arg-max diagonals that may be aligned (calign.pyx:228), ascending (:223)
+        const int j = j0 + lane;
+        const bool is = maxcount > 0 && j < n && CNT16(counts, j) == maxcount && (j - sL) + sL + 15 < hapLen;
+        const unsigned long long bal = __ballot(is);
+        if (is) { const int at = k + __popcll(bal & ((1ull << lane) - 1ull)); if (at < SLOW_MAXC) o->cand[at] = (uint16_t)j; }
+        if (s_orig_in && j0i >= j0 && j0i < j0 + 64) orig_k = k + __popcll(bal & ((1ull << (j0i - j0)) - 1ull));
+        k += __popcll(bal);
+    }
+    for (int j = lane; j < ((n + 2) >> 1); j += 64) counts[j] = 0u;        // all counters back to zero
+    if (lane == 0) { o->sncand = k; o->orig_in = s_orig_in ? 1 : 0; o->orig_k = s_orig_in ? orig_k : k; o->njobs = k + (s_orig_in ? 0 : 1); }
+}
+// ... and what seed_exact_vote writes for the pair, from the record: sbase / fits / db were reserved for the whole group by the caller
+__device__ __forceinline__ void seed_vote_emit(const SlowOut* o, long long npairs, Job* __restrict__ jobs, PairRec* __restrict__ pairs,
+                                               int32_t* __restrict__ dense, long long segcap)
+{
+    const int lane = threadIdx.x & 63;
+    const int sncand = o->sncand, sL = o->sL, h = o->h, sbase = o->sbase, njobs = o->njobs;
+    const bool fits = o->fits != 0, s_orig_in = o->orig_in != 0;
+    const long long spidx = o->pidx;
+    const uint32_t scol = o->scol;
+    for (int k = lane; k < sncand; k += 64)
+        if (fits || k == 0) jobs[job_slot(spidx, npairs, sbase, k)] = Job{scol, h, (int)o->cand[k] - sL, sL};
+    if (lane == 0) {
+        if (!s_orig_in && (fits || sncand == 0)) jobs[job_slot(spidx, npairs, sbase, sncand)] = Job{scol, h, o->sidx0, sL};
+        pairs[spidx] = PairRec{sbase, o->sidx0, (int16_t)sncand, (int16_t)o->orig_k, (uint8_t)o->smapq, {0, 0, 0}};
+    }
+    if (fits && o->db >= 0 && o->db + njobs <= segcap)
+        for (int k = lane; k < njobs; k += 64) dense[o->seg * segcap + o->db + k] = (int32_t)job_slot(spidx, npairs, sbase, k);
+}
+
 // a4: the haplotype's k-mer index (hash_sequence_multihit, calign.pyx:94-124) in LDS: positions 0..hapLen-8, entry =
 // (code+1)<<16 | (pos+1) in an open-addressing table (or u16 heads indexed by code when direct), equal codes chained
 // through nxt[] from the LAST position to the first.  exact_mult: also walk the chains for the largest multiplicity.
@@ -1900,20 +1960,29 @@ k_pairs(plat_window_batch b, const int32_t* __restrict__ wave_win, const int32_t
     }
 }
 
-// k_seed_slow: the exact vote for the pairs the seeding kernels queued.  Round 6: a workgroup is FOUR waves and takes groups of SLOW_GROUP
-// consecutive queue entries (entries queued by one wave are consecutive and mostly share their haplotype).  Inside a group every run of
-// entries of one haplotype costs ONE index build, made by all 256 threads together; its waves then vote for one entry each, each wave in
-// its own set of diagonal counters.  (Before: one wave per workgroup, one build per entry -- a few thousand single-wave workgroups of
-// 30-40 KB of LDS each, five to a CU: 143-155 us per chunk of the WGS job for a few thousand pairs.)  Same LDS carve as k_seed up to the
-// counters, of which there are SLOW_WAVES sets.
-constexpr int SLOW_WAVES = 4, SLOW_GROUP = 4;
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
+// k_seed_slow: the exact vote for the pairs the seeding kernels queued (a few hundred per launch on config 2, ~11 k per launch of the WGS
+// job: every read over a tandem repeat, for every haplotype of its window).  Round 6: a workgroup is SLOW_WAVES waves and takes groups of
+// SLOW_GROUP consecutive queue entries (the entries one seeding wave queued are consecutive and mostly share their haplotype).  Inside a
+// group every run of entries of one haplotype costs ONE index build, made by all the threads together (measured: a build by one wave is 18
+// of the 27 us a pair cost -- linear probing at load 0.65, the slowest of 64 lanes sets each round's time); its waves then vote for one entry
+// each, each wave in its own diagonal counters, leaving the pair's arg-max diagonals in an LDS record.  Then the job slots and dense-list
+// entries of the whole group are reserved with ONE returning atomic per counter (before: two per pair on the same two addresses, ~23 k per
+// launch against the L2's ~90 per microsecond and address) and the waves write their pairs' jobs.  Same LDS carve as k_seed up to the
+// counters, of which there is one set per wave.
+constexpr int SLOW_WAVES = 4, SLOW_GROUP = 32;
+__device__ unsigned long long g_slow_ticks[8];            // PLAT_SLOW_TIMING=1 (measurement): thread 0's 100 MHz ticks per phase, summed over groups
 __global__ void __launch_bounds__(64 * SLOW_WAVES)
 k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long long* __restrict__ tile_off,
             const ReadInfo* __restrict__ rinfo, const uint16_t* __restrict__ codes, PairRec* __restrict__ pairs,
             Job* __restrict__ jobs, long long npairs, int extra_cap, long long* cnt, const SlowRec* __restrict__ slow_list,
-            int tsize_max, int maxhap, int cw, int32_t* __restrict__ dense, long long segcap)
+            int tsize_max, int maxhap, int cw, int32_t* __restrict__ dense, long long segcap, int timing, int group)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ SlowOut s_out[SLOW_GROUP];
+    __shared__ SlowRec s_ent[SLOW_GROUP];
+    __shared__ long long s_dbase[DENSE_SEGS];
     const int nw64 = ((maxhap + 63) >> 6) + 8;
     unsigned* table = (unsigned*)smem;
     unsigned short* nxt = (unsigned short*)(smem + (size_t)tsize_max * 4);
@@ -1926,15 +1995,23 @@ k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long
     long long nslow = cnt[CNT_SLOW_SEED];
     if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
     if (nslow > npairs) nslow = npairs;
-    if ((long long)SLOW_GROUP * blockIdx.x >= nslow) return;                              // (most workgroups of a launch: nothing queued for them)
+    if ((long long)group * blockIdx.x >= nslow) return;                              // (most workgroups of a launch: nothing queued for them)
     for (int j = lane; j < (cw >> 1); j += 64) counts[j] = 0u;
-    for (long long g = blockIdx.x; SLOW_GROUP * g < nslow; g += gridDim.x) {
-        const long long gEnd = min(nslow, SLOW_GROUP * g + SLOW_GROUP);
-        long long e = SLOW_GROUP * g;
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[4] = {0, 0, 0, 0};
+#define SLOW_TICK(i) do { if (timing) tk[i] = wall_clock64(); } while (0)
+    for (long long g = blockIdx.x; group * g < nslow; g += gridDim.x) {
+        const long long e0 = group * g, gEnd = min(nslow, e0 + group);
+        const int nent = (int)(gEnd - e0);
+        long long e = e0;
+        acc[0] = acc[1] = acc[2] = 0;
+        __syncthreads();
+        if (tid < nent) s_ent[tid] = slow_list[e0 + tid];                                 // the group's entries in one round trip (a load per entry and thread before)
+        __syncthreads();
         while (e < gEnd) {                                                                // (uniform over the workgroup: everyone reads the same entries)
-            const int h = slow_list[e].hap, w = hap_win[h];
+            SLOW_TICK(0);
+            const int h = s_ent[e - e0].hap, w = hap_win[h];
             long long run = e + 1;
-            while (run < gEnd && slow_list[run].hap == h) ++run;
+            while (run < gEnd && s_ent[run - e0].hap == h) ++run;
             const long long hoff = b.hap_off[h];
             const int hapLen = (int)(b.hap_off[h + 1] - hoff);
             const uint8_t* hs = b.hap_seq + hoff;
@@ -1947,7 +2024,7 @@ k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long
             __syncthreads();                                                             // (the votes of the run before are over: the table may go)
             for (int i = tid; i < 2 * nw64; i += 64 * nwv) h0[i] = 0ull;                 // h0, h1 contiguous
             __syncthreads();
-            for (int t0 = 16 * wave; t0 < nch; t0 += 16 * nwv) {                   // 16 chunks of bytes per memory round trip and wave
+            for (int t0 = 16 * wave; t0 < nch; t0 += 16 * nwv) {                          // 16 chunks of bytes per memory round trip and wave
                 unsigned by[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
@@ -1963,22 +2040,78 @@ k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long
                 }
             }
             __syncthreads();
+            SLOW_TICK(1);
             seed_build_index(table, nxt, h0, h1, nup, s_scal, hapLen, nch, direct, tsize, tmask, false);
+            SLOW_TICK(2);
             const int rb = b.win_read_begin[w], R = b.win_read_begin[w + 1] - rb;
             const int hapStart = b.win_start[w] - b.win_flank[w];                        // chaplotype.pyx:606
-            for (long long q = e + wave; q < run; q += nwv) {                      // one entry per wave at a time
-                const int rl = slow_list[q].rl;
+            for (long long q = e + wave; q < run; q += nwv) {                             // one entry per wave at a time: the vote, its arg-max diagonals into the record
+                const int rl = s_ent[q - e0].rl;
                 const ReadInfo ri = rinfo[rb + rl];
                 const int L = (int)(ri.lfm & 0xFFFFu);
                 const int idx0 = min(ri.pos - hapStart, hapLen - L - 15);                // calign.pyx:252
                 const long long pidx = b.pair_off[w] + (long long)(h - b.win_hap_begin[w]) * R + rl;
                 const u64* scp = (const u64*)(codes + tile_off[w]) + rl;
-                seed_exact_vote(table, nxt, counts, direct, tmask, hapLen, h | (((ri.lfm >> 18) & 1u) ? JOB_BIGQ : 0), scp, R, L, idx0, ri.col, (int)(ri.lfm >> 24), pidx,
-                                npairs, extra_cap, jobs, pairs, cnt, dense, segcap, w % DENSE_SEGS);
+                SlowOut* o = &s_out[q - e0];
+                const int hflag = h | (((ri.lfm >> 18) & 1u) ? JOB_BIGQ : 0);
+                seed_vote_collect(table, nxt, counts, direct, tmask, hapLen, scp, R, L, idx0, o);
+                if (lane == 0) { o->pidx = pidx; o->h = hflag; o->sL = L; o->sidx0 = idx0; o->scol = ri.col; o->smapq = (int)(ri.lfm >> 24); o->seg = w % DENSE_SEGS; }
+                wave_lds_sync();
+                if (o->sncand > SLOW_MAXC) {
+                    // more arg-max diagonals than the record holds (long tandem repeats): this pair alone, with its own reservations
+                    seed_exact_vote(table, nxt, counts, direct, tmask, hapLen, hflag, scp, R, L, idx0, ri.col, (int)(ri.lfm >> 24), pidx,
+                                    npairs, extra_cap, jobs, pairs, cnt, dense, segcap, w % DENSE_SEGS);
+                    if (lane == 0) o->njobs = -1;
+                }
             }
+            SLOW_TICK(3);
+            if (timing) { acc[0] += tk[1] - tk[0]; acc[1] += tk[2] - tk[1]; acc[2] += tk[3] - tk[2]; }
             e = run;
         }
+        __syncthreads();
+        SLOW_TICK(4);
+        // ONE reservation per counter for the group, by the first wave (a lane per entry; SLOW_GROUP <= 64): extra job slots (pairs with more than
+        // one job) first -- whether a pair's jobs fit decides whether it joins the dense list --, then the dense list per segment
+        if (wave == 0) {
+            const bool mine = lane < nent && s_out[lane < nent ? lane : 0].njobs >= 0;
+            const int nj = mine ? s_out[lane].njobs : 0, seg = mine ? s_out[lane].seg : -1;
+            int ex = nj > 1 ? nj - 1 : 0, exIncl = ex;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(exIncl, d); if (lane >= d) exIncl += v; }
+            const int exTotal = __shfl(exIncl, 63);
+            long long base = 0;
+            if (lane == 0 && exTotal > 0) base = (long long)atomicAdd((unsigned long long*)&cnt[CNT_NEXTRA], (unsigned long long)exTotal);
+            base = ((long long)(unsigned)__shfl((int)base, 0)) | ((long long)__shfl((int)(base >> 32), 0) << 32);
+            const int sbase = nj > 1 ? (int)(base + exIncl - ex) : 0;
+            const bool fits = nj <= 1 || (long long)sbase + (nj - 1) <= (long long)extra_cap;
+            long long db = -1;
+            int mytot = 0;
+#pragma unroll
+            for (int k = 0; k < DENSE_SEGS; ++k) {
+                const int v = (mine && fits && seg == k) ? nj : 0;
+                int incl = v;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+                const int tot = __shfl(incl, 63);
+                if (seg == k && mine && fits) db = incl - v;
+                if (lane == k) mytot = tot;
+            }
+            if (lane < DENSE_SEGS) s_dbase[lane] = mytot > 0 ? (long long)atomicAdd((unsigned long long*)dense_counter(cnt, lane), (unsigned long long)mytot) : 0;
+            wave_lds_sync();
+            if (mine) { SlowOut& o = s_out[lane]; o.sbase = sbase; o.fits = fits ? 1 : 0; o.db = db >= 0 ? db + s_dbase[seg] : -1; }
+        }
+        __syncthreads();
+        SLOW_TICK(5);
+        for (int t = wave; t < nent; t += nwv)
+            if (s_out[t].njobs >= 0) seed_vote_emit(&s_out[t], npairs, jobs, pairs, dense, segcap);
+        __syncthreads();
+        SLOW_TICK(6);
+        if (timing && tid == 0) {
+            atomicAdd(&g_slow_ticks[0], acc[0]); atomicAdd(&g_slow_ticks[1], acc[1]); atomicAdd(&g_slow_ticks[2], acc[2]);
+            atomicAdd(&g_slow_ticks[3], tk[5] - tk[4]); atomicAdd(&g_slow_ticks[4], tk[6] - tk[5]); atomicAdd(&g_slow_ticks[7], 1ull);
+        }
     }
+#undef SLOW_TICK
 }
 
 
@@ -2321,7 +2454,10 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     const size_t nw64 = (((size_t)maxhap + 63) >> 6) + 8;
     const size_t lds0 = (size_t)tsize_max * 4 + ((((size_t)maxhap + 2) * 2 + 7) & ~(size_t)7) + 4 * nw64 * 8 + 16 + 64 + 128;
     const size_t lds = lds0 + ((nw64 + 15) & ~(size_t)15);    // k_seed: + one byte per chunk of 64 positions (gap-open minima)
+    int slow_group = 8;                                         // entries per workgroup round (<= SLOW_GROUP); PLAT_SLOW_GROUP / PLAT_SLOW_WAVES: measurements
+    if (const char* eg = getenv("PLAT_SLOW_GROUP")) slow_group = atoi(eg) > 0 && atoi(eg) <= SLOW_GROUP ? atoi(eg) : slow_group;
     int slow_waves = SLOW_WAVES;                                // (a set of diagonal counters per wave; fewer waves when long haplotypes make the sets large)
+    if (const char* ew = getenv("PLAT_SLOW_WAVES")) slow_waves = atoi(ew) > 0 && atoi(ew) <= SLOW_WAVES ? atoi(ew) : slow_waves;
     while (slow_waves > 1 && lds0 + (size_t)slow_waves * (size_t)cw * 2 > 64 * 1024) slow_waves >>= 1;
     const size_t lds_slow = lds0 + (size_t)slow_waves * (size_t)cw * 2;
     if (lds_slow > 160 * 1024 || lds > 160 * 1024) return PLAT_ERR_HAP_TOO_LONG;
@@ -2382,7 +2518,16 @@ static int align_seed_launch(plat_ctx* ctx, const plat_window_batch& b, hipStrea
     PLAT_EV(ctx, 5, st);                                       // k_seed alone: ev[1] .. ev[5]
     { PLAT_KT_BEGIN(ctx, PLAT_KT_SEED_SLOW, st); hipLaunchKernelGGL(k_seed_slow, dim3(2048), dim3(64 * slow_waves), lds_slow, st, b, hap_win, tile_off, (const ReadInfo*)ctx->rinfo.ptr,
                        (const uint16_t*)ctx->codes.ptr, (PairRec*)ctx->pair_rec.ptr, (Job*)ctx->jobs.ptr, npairs, extra_cap, cnt,
-                       (const SlowRec*)ctx->slow.ptr, tsize_max, maxhap, cw, dense, segcap); PLAT_KT_END(ctx, PLAT_KT_SEED_SLOW, st); }
+                       (const SlowRec*)ctx->slow.ptr, tsize_max, maxhap, cw, dense, segcap, getenv("PLAT_SLOW_TIMING") ? 1 : 0, slow_group); PLAT_KT_END(ctx, PLAT_KT_SEED_SLOW, st); }
+    if (getenv("PLAT_SLOW_TIMING")) {
+        unsigned long long t[8];
+        PLAT_HIP(ctx, hipStreamSynchronize(st));
+        PLAT_HIP(ctx, hipMemcpyFromSymbol(t, HIP_SYMBOL(g_slow_ticks), sizeof t));
+        fprintf(stderr, "k_seed_slow: %llu groups; thread 0's mean us per group: loads + planes %.1f builds %.1f votes %.1f reserve %.1f emit %.1f\n", t[7],
+                0.01 * t[0] / (t[7] ? t[7] : 1), 0.01 * t[1] / (t[7] ? t[7] : 1), 0.01 * t[2] / (t[7] ? t[7] : 1), 0.01 * t[3] / (t[7] ? t[7] : 1), 0.01 * t[4] / (t[7] ? t[7] : 1));
+        memset(t, 0, sizeof t);
+        PLAT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_slow_ticks), t, sizeof t));
+    }
     if (!(shortcuts & SEED_LEAN))                              // (the asynchronous entry point reads nothing back: every kernel sums the segments itself)
         hipLaunchKernelGGL(k_dense_total, dim3(1), dim3(1), 0, st, cnt, segcap);
     PLAT_HIP(ctx, hipGetLastError());
