@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Default line (round 6): BASELINE config 4.  One "step" = one pass of the hot path over this rank's share of the genome's regions
-(3 875 regions x 100 kb per GPU = 31 000 / 8; `--strong`: the 31 000 regions for every N), reads already resident in HBM: candidates ->
+(the 31 000 regions x 100 kb of the synthetic genome, region i -> rank i % N: ONE GPU takes the whole genome; `--weak`: 3 875 regions per GPU), reads already resident in HBM: candidates ->
 variants -> windows -> haplotypes (device) -> pair-HMM likelihoods / genotype likelihoods / EM / posteriors -> VCF record text through the
 native region loop, then the job's ONE exchange (record text to rank 0, RCCL under "nccl") and the merge -- all inside the timed region.
 `value` = pair-HMM GCUPS, reference-equivalent (band cells of the fastAlignmentRoutine calls the reference would make for
@@ -336,8 +336,8 @@ def main():
                          "(1 = strictly one batch at a time)")
     ap.add_argument("--sync-entry", action="store_true",
                     help="time plat_align_window_batch (two internal read-backs) instead of plat_align_window_batch_async")
-    ap.add_argument("--strong", action="store_true", help="config 4 / the WGS block: ONE region list for every N (--regions, default 31000 = the whole synthetic "
-                                                          "genome) instead of 3875 regions per GPU: a strong-scaling line")
+    ap.add_argument("--strong", action="store_true", help="(the default since round 6) ONE region list for every N: the 31000 regions of the whole synthetic genome")
+    ap.add_argument("--weak", action="store_true", help="config 4: 3875 regions per GPU (the share of a GPU of an 8-GPU job) instead of the whole genome for every N: a weak-scaling line")
     ap.add_argument("--no-other-configs", action="store_true", help="default line: leave out other_configs (configs 3, 4 streamed, 5)")
     ap.add_argument("--no-wgs", action="store_true", help=argparse.SUPPRESS)     # (round 5: the config-2 line carried a wgs block; accepted, ignored)
     ap.add_argument("--min-seconds", type=float, default=0.25, help="a step is made of as many passes (one batch each) as it takes for the K timed steps to last this long")

@@ -56,6 +56,43 @@ inline char* put_uint(char* p, unsigned long long v) {
     while (n) *p++ = tmp[--n];
     return p;
 }
+// "%.12g" of Python 2's str(float) WITHOUT printf for 1e-4 <= |x| < 1e12 (fixed notation there): the twelve significant digits of the
+// double's EXACT value, round half to even.  x * 10^(11 - k) (k = the decimal exponent; the power is exact) is formed with its rounding
+// error (fma): prod + err is the exact product, prod < 2^40 so its fraction is exact; the shortcut is taken only when the exact
+// fraction is farther than 1e-3 from a half (err < 1e-4), everything else goes through snprintf.  Returns nullptr when it does not apply.
+inline char* put_g12_fast(char* p, double x) {
+    static const double P10[27] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22,
+                                   1e-1, 1e-2, 1e-3, 1e-4};
+    const double ax = fabs(x);
+    if (!(ax >= 1e-4 && ax < 1e12)) return nullptr;
+    int k;                                                                  // 10^k <= ax < 10^(k+1)
+    if (ax >= 1.0) { k = 0; while (k < 11 && ax >= P10[k + 1]) ++k; }
+    else { k = -1; while (k > -4 && ax < P10[22 - k]) --k; }                // P10[23] = 1e-1 ... P10[26] = 1e-4
+    const double sc = P10[11 - k];                                          // 10^(11 - k), exact (exponent 0 .. 15)
+    const double prod = ax * sc, err = fma(ax, sc, -prod);
+    if (!(prod >= 1e11 * 0.999999 && prod < 1e12 * 1.000001)) return nullptr;
+    double fl = floor(prod);
+    const double frac = (prod - fl) + err;                                  // exact fraction of the exact product (|err| < 1e-4)
+    if (fabs(frac - 0.5) < 1e-3 || frac < -0.25 || frac > 1.25) return nullptr;
+    unsigned long long n = (unsigned long long)fl + (frac > 0.5 ? 1ull : 0ull);
+    if (n < 100000000000ull) return nullptr;                                // (k was one too large: cannot happen with exact comparisons; be safe)
+    if (n >= 1000000000000ull) { n /= 10; ++k; if (k >= 12) return nullptr; }   // rounded up to the next power of ten
+    char d[12];
+    for (int i = 11; i >= 0; --i) { d[i] = (char)('0' + n % 10); n /= 10; }
+    int last = 11;
+    while (last > 0 && d[last] == '0') --last;                              // %g strips trailing zeros
+    if (std::signbit(x)) *p++ = '-';
+    if (k >= 0) {
+        for (int i = 0; i <= k; ++i) *p++ = d[i];
+        if (last > k) { *p++ = '.'; for (int i = k + 1; i <= last; ++i) *p++ = d[i]; }
+        else { *p++ = '.'; *p++ = '0'; }                                    // digits only: str(float) appends ".0"
+    } else {
+        *p++ = '0'; *p++ = '.';
+        for (int i = -1; i > k; --i) *p++ = '0';
+        for (int i = 0; i <= last; ++i) *p++ = d[i];
+    }
+    return p;
+}
 // The same text appended to `out`.  Nearly every float that reaches a record was rounded to two decimals first: a double that IS the
 // double nearest to n/100 with n < 10^11 prints under "%.12g" as the decimal n/100 without its trailing zeros (the twelve significant
 // digits of its exact value round to those of n/100, which has at most eleven), so that text is written straight from n.
@@ -75,6 +112,8 @@ inline void append_py2_str(std::string& out, double x) {
             return;
         }
     }
+    char buf[40];
+    if (char* q = put_g12_fast(buf, x)) { out.append(buf, (size_t)(q - buf)); return; }
     out += py2_str_slow(x);
 }
 inline std::string py2_str(double x) { std::string t; append_py2_str(t, x); return t; }
@@ -101,6 +140,7 @@ inline char* put_py2_str(char* p, double x) {                             // at 
             return p;
         }
     }
+    if (char* q = put_g12_fast(p, x)) return q;
     const std::string t = py2_str_slow(x);
     return put_str(p, t);
 }

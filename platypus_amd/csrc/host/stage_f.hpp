@@ -169,6 +169,7 @@ inline void Chunk::writeWindow(RegionWork& r, WindowWork& w, const std::vector<i
         if (line.size() < bound) line.resize(bound + bound / 2);
         char* const line0 = line.data();
         char* p = line0;
+        { PROF("tw.prefix");
         p = put_chars(p, r.in->chrom, chromLen); *p++ = '\t';
         p = put_int(p, POS + 1); p = put_lit(p, "\t.\t"); p = put_str(p, ref); *p++ = '\t';
         if (alt.empty()) *p++ = '.'; else for (size_t q = 0; q < alt.size(); ++q) { if (q) *p++ = ','; p = put_str(p, alt[q]); }
@@ -184,6 +185,8 @@ inline void Chunk::writeWindow(RegionWork& r, WindowWork& w, const std::vector<i
             }
         }
         *p++ = '\t';
+        }
+        { PROF("tw.info");
         // INFO keys in sorted order: BRF FR HP HapScore MGOF MMLQ MQ NF NR PP QD SC SbPval Source TC TCF TCR TR WE WS
         p = put_lit(p, "BRF="); p = lead.BRF.put(p);
         p = put_lit(p, ";FR="); for (int k = 0; k < nVariants; ++k) { if (k) *p++ = ','; p = put_str(p, infos[(size_t)k]->FRtext); }
@@ -206,6 +209,8 @@ inline void Chunk::writeWindow(RegionWork& r, WindowWork& w, const std::vector<i
         p = put_lit(p, ";WE="); p = Num::I(w.endPos).put(p);
         p = put_lit(p, ";WS="); p = Num::I(w.startPos).put(p);
         p = put_lit(p, "\tGT:GL:GOF:GQ:NR:NV");
+        }
+        { PROF("tw.samples");
         // per-sample columns GT : GL : GOF : GQ : NR : NV, written in place; format_formatdata(key=False) then drops the trailing entries made only
         // of "," and "." -- GT "./." can only be dropped when everything after it is, and the integers after it never are
         for (int i = 0; i < nInd; ++i) {
@@ -232,6 +237,8 @@ inline void Chunk::writeWindow(RegionWork& r, WindowWork& w, const std::vector<i
             *p++ = ':';
             for (int k = 0; k < nVariants; ++k) { if (k) *p++ = ','; p = put_int(p, infos[(size_t)k]->nVarReadsPerSample[(size_t)i]); }
         }
+        }
+        PROF("tw.append");
         *p++ = '\n';
         out.append(line0, (size_t)(p - line0));
         ++w.nRecords;

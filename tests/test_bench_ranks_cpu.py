@@ -36,7 +36,7 @@ def test_launch_command_is_the_drivers_form():
 
 
 def _args(regions, strong=False):
-    return SimpleNamespace(regions=regions, steps=1, warmup=1, gpus=2, config=4, windows=None, strong=strong)
+    return SimpleNamespace(regions=regions, steps=1, warmup=1, gpus=2, config=4, windows=None, strong=strong, weak=not strong and regions is None)
 
 
 def _rank_worker(rank, world, port, out_path, regions=5, strong=False):
@@ -77,7 +77,7 @@ def test_config4_two_ranks_give_the_text_of_one_rank(tmp_path):
 
 
 def test_config4_scaling_label_follows_the_region_list(tmp_path):
-    """Default: the list grows with the job (a share per GPU) and the line says "weak"; --strong: one list (8 shares) for every N and the
+    """--weak: the list grows with the job (a share per GPU) and the line says "weak"; the default (--strong): one list (8 shares) for every N and the
     line says "strong" -- the two N = 1 / N = 2 pairs an efficiency figure may be computed from are never mixed up."""
     import torch.multiprocessing as mp
     import bench
@@ -125,7 +125,26 @@ def test_the_block_merge_writes_the_text_of_the_line_merge(tmp_path):
         lines = bench_other.line_config4(_args(13), rk1, lib=lib, region_len=3000, region_kw=REGION_KW)
     finally:
         os.environ.pop("PLAT_BENCH_LINE_MERGE", None)
-    assert blocks["record_gather"]["how"] == "region blocks" and lines["record_gather"]["how"] == "line merge"
+    assert blocks["record_gather"]["how"].startswith("one rank") and lines["record_gather"]["how"] == "line merge"      # (one rank, list in order: its text IS the merged text)
+    # ... and the block copies themselves on one rank: the same 13 regions listed in REVERSE (the order of the blocks is then a real permutation)
+    from platypus_amd import fastcaller as Fc
+    import numpy as np
+    txt = blocks["merged_text"].encode()
+    starts = [0]
+    cur = None
+    for ln in txt.split(b"\n")[:-1]:
+        c = ln.split(b"\t", 1)[0]
+        if cur is not None and c != cur:
+            starts.append(starts[-1] + run)
+            run = 0
+        run = (run if cur == c else 0) + len(ln) + 1
+        cur = c
+    lens = np.diff(np.array(starts + [len(txt)], dtype=np.int64))
+    chroms = [txt[a:].split(b"\t", 1)[0].decode() for a in starts]
+    rev = Fc.BlockOrder([[(sharding.chrom_key(c), 500, 3500) for c in reversed(chroms)]])
+    assert rev.ok and not rev.identity
+    back = b"".join(txt[a:a + n] for a, n in reversed(list(zip(starts, lens))))
+    assert bytes(memoryview(rev.merge([back], [lens[::-1]], lib=lib))) == txt
     assert blocks["merged_text"] == lines["merged_text"] and blocks["merged_text"].count("\n") > 20
     order = [ln.split("\t")[0] for ln in blocks["merged_text"].split("\n") if ln]
     assert order == sorted(order, key=lambda c: sharding.chrom_key(c)) and order.index("r2") < order.index("r10")

@@ -285,7 +285,8 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
         if rep == repeats + nplain - 1:
             rk.barrier()
             T_bracket = time.perf_counter() - T_bracket
-            gather = dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=nranks, how="region blocks" if xch is not None else "line merge",
+            gather = dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=nranks, how=("one rank, regions in order: its text is the merged text (nothing copied)" if (xch is not None and xch.world == 1 and xch.plan.identity and xch.plan.ok)
+                                                                                 else "region blocks") if xch is not None else "line merge",
                           records=bytes(memoryview(merged)).count(b"\n") if merged is not None else None)
     planted = (src.planted - planted0) // max(1, repeats)
     phases = {k: v / max(1, (repeats * len(indices) + nwarm)) for k, v in src.phase_seconds.items()}
@@ -428,13 +429,13 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
     region covers the calls, the gather and the merge (and, when the inputs are not resident, loading = generating the regions).
 
     Which scaling the N = 1, 2, 4, 8 lines form is said on the line, never implied:
-      default     WEAK: the list grows with the job, 3 875 regions per GPU (N = 8 is the 31 000 regions of the synthetic 30x genome, SURVEY
-                  8(d) cfg 4; N = 1 one GPU's share of it).  Efficiency basis: windows/s(N) / (N x windows/s(1)).
-      --strong    STRONG: the SAME list for every N (`--regions`, default 31 000 = the whole genome): T(1) / (N x T(N)), north_star's figure.
-      --regions R without --strong: R regions for the whole job whatever N (a strong line too, and labelled so)."""
+      default     STRONG (round 6): the SAME list for every N -- the 31 000 regions of the synthetic 30x genome (SURVEY 8(d) cfg 4), region i -> rank
+                  i % N; one GPU takes the whole genome (112 GB of packed reads resident in its 288 GB).  Efficiency: T(1) / (N x T(N)) = value(N) / (N x value(1)).
+      --weak      WEAK: the list grows with the job, 3 875 regions per GPU (= what a GPU of an 8-GPU job gets).  windows/s(N) / (N x windows/s(1)).
+      --regions R R regions for the whole job whatever N (a strong line too, and labelled so)."""
     from platypus_amd import fastcaller as F, sharding
     rank, world = rk.rank, rk.world
-    strong = bool(getattr(a, "strong", False)) or bool(a.regions)
+    strong = not bool(getattr(a, "weak", False)) or bool(a.regions)          # round 6: the job is the whole synthetic genome unless --weak asks for a share per GPU
     per_gpu = int(os.environ.get("PLAT_BENCH_WGS_REGIONS_PER_GPU", "3875"))   # (tests shrink the share; 3 875 = 31 000 / 8)
     total = (a.regions or (8 * per_gpu if strong else per_gpu * world))
     mine = sharding.regions_for_rank(total, rank, world)
@@ -455,7 +456,9 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
     os.environ.setdefault("PLAT_CALLER_LOADERS", str(max(2, min(12, cpus // 2))))
     # (round 5: stage B on the device -- the host no longer pays per region for a chunk's size, and the kernels of a chunk are latency bound:
     #  64 regions per chunk measured 2.4 M windows/s against 1.25 M with 8, and a k_dp_jobs launch then holds ~36 k DPs)
-    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", "64" if resident else "16"))
+    # (round 6, the whole genome on one GPU: 128 regions per chunk -- the latency-bound kernels of a chunk cost the same for 64 and 128 regions, 22.7 -> 16.5 us
+    #  of kernel time per region -- measured 5.1 M windows/s against 4.97 M with 64 and 4.8 M with 256; a short list keeps 64: more chunks than workers)
+    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", ("128" if len(mine) >= 12000 else "64") if resident else "16"))
     pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1" and lib is None
     packed = os.environ.get("PLAT_CALLER_PACKED", "1") == "1"
     repeats = max(1, min(int(a.steps or 10), 200))                           # K steps = K runs over the rank's share, timed in one bracket (a run is ~0.1 s)
