@@ -107,7 +107,40 @@ CALLER_EXPORT int plat_caller_destroy(plat_caller* c) {
 }
 
 CALLER_EXPORT const char* plat_caller_last_error(const plat_caller* c) { return c ? c->lastError.c_str() : ""; }
-CALLER_EXPORT void plat_caller_free(void* p) { free(p); }
+// Large text blocks are kept for the next call instead of going back to the system: a whole genome's record text is ~0.8 GB, and a fresh
+// block of that size is 0.2 M first-touch page faults (or 400 huge ones) plus their release per call -- 30-60 ms of a 0.5 s pass.  At most
+// two blocks are kept (the caller typically still holds the previous call's text while the next is written).
+static std::mutex g_textMutex;
+static std::vector<std::pair<void*, size_t>> g_textLive, g_textSpare;     // (big blocks handed out; blocks given back and kept), with capacities
+static void* takeSpareText(size_t bytes) {
+    std::lock_guard<std::mutex> g(g_textMutex);
+    for (size_t i = 0; i < g_textSpare.size(); ++i)
+        if (g_textSpare[i].second >= bytes && g_textSpare[i].second <= 2 * bytes + ((size_t)64 << 20)) {
+            const std::pair<void*, size_t> b = g_textSpare[i];
+            g_textSpare.erase(g_textSpare.begin() + (long)i);
+            g_textLive.push_back(b);
+            return b.first;
+        }
+    return nullptr;
+}
+CALLER_EXPORT void plat_caller_free(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_textMutex);
+        for (size_t i = 0; i < g_textLive.size(); ++i)
+            if (g_textLive[i].first == p) {
+                const std::pair<void*, size_t> b = g_textLive[i];
+                g_textLive.erase(g_textLive.begin() + (long)i);
+                if (g_textSpare.size() < 2) { g_textSpare.push_back(b); return; }
+                // (two spares already: the smallest of the three goes back to the system)
+                size_t k = 0;
+                for (size_t j = 1; j < g_textSpare.size(); ++j) if (g_textSpare[j].second < g_textSpare[k].second) k = j;
+                if (g_textSpare[k].second < b.second) { p = g_textSpare[k].first; g_textSpare[k] = b; }
+                break;
+            }
+    }
+    free(p);
+}
 
 // ---- where the chunks of a call come from -----------------------------------------------------------------------------------------------
 // (a worker asks for its next chunk of regions, calls it, and hands it back)
@@ -335,11 +368,14 @@ static void copyPieces(char* out, const std::vector<const char*>& from, const st
 static char* allocText(size_t bytes) {
     const size_t big = (size_t)2 << 20;
     if (bytes < 4 * big) return (char*)malloc(bytes);
+    if (void* spare = takeSpareText(bytes)) return (char*)spare;
     void* p = nullptr;
-    if (posix_memalign(&p, big, (bytes + big - 1) & ~(big - 1)) != 0) return nullptr;
+    const size_t cap = (bytes + bytes / 16 + big - 1) & ~(big - 1);       // (a little room: the next call's text is rarely the same size to the byte)
+    if (posix_memalign(&p, big, cap) != 0) return nullptr;
 #ifdef MADV_HUGEPAGE
-    madvise(p, (bytes + big - 1) & ~(big - 1), MADV_HUGEPAGE);
+    madvise(p, cap, MADV_HUGEPAGE);
 #endif
+    { std::lock_guard<std::mutex> g(g_textMutex); g_textLive.push_back({p, cap}); }
     return (char*)p;
 }
 
