@@ -67,6 +67,7 @@ cdef extern from "platypus_mi355x.h":
         float ms_candidates
     int plat_profile_enable(plat_ctx* ctx, int on) nogil
     int plat_profile_last(plat_ctx* ctx, plat_profile* out) nogil
+    int plat_sync_poll_us(plat_ctx* ctx, int microseconds) nogil
     const char* plat_kernel_timer_name(int id) nogil
     int plat_kernel_times(plat_ctx* ctx, double* out_ms, int64_t* out_launches) nogil
 

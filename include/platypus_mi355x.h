@@ -65,7 +65,10 @@ int plat_memcpy_d2h(plat_ctx* ctx, void* dst_host, const void* src_dev, size_t b
 int plat_memcpy_d2d(plat_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 int plat_memset(plat_ctx* ctx, void* dst_dev, int value, size_t bytes, void* stream);
 int plat_stream_sync(plat_ctx* ctx, void* stream);          /* [syncs] */
-/* plat_stream_sync waits asleep: it polls an event every PLAT_SYNC_POLL_US microseconds (environment, default 40; 0 = the
+int plat_sync_poll_us(plat_ctx* ctx, int microseconds);     /* how often plat_stream_sync looks at its event (default 40; 0 = hipEventSynchronize) */
+/* plat_stream_sync waits asleep: it polls an event every plat_sync_poll_us microseconds (default 40: a caller whose waits last a
+ * millisecond or more asks for more -- every look is a system call and a runtime query, and with two dozen waiting threads they add up:
+ * the native region loop uses 500) -- or every PLAT_SYNC_POLL_US microseconds when the environment says so (0 = the
  * runtime's blocking hipEventSynchronize; PLAT_SYNC_SPIN=1 = hipStreamSynchronize).  While it naps it lowers the CALLING thread's
  * timer slack (prctl PR_SET_TIMERSLACK) to 2 us and puts the previous value back before it returns. */
 /* a HIP stream of the context's device (hipStream_t as void*), for callers without a HIP runtime binding of their own;

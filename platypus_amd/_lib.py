@@ -117,6 +117,7 @@ SIGNATURES = {
     "plat_unpack_reads": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "plat_profile_last": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
+    "plat_sync_poll_us": (C.c_int, [C.c_void_p, C.c_int]),
     "plat_kernel_timer_name": (C.c_char_p, [C.c_int]),
     "plat_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "plat_dp_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -222,6 +222,12 @@ PLAT_EXPORT int plat_host_free(plat_ctx* ctx, void* p) {
     return PLAT_OK;
 }
 
+PLAT_EXPORT int plat_sync_poll_us(plat_ctx* ctx, int microseconds) {
+    if (!ctx || microseconds < 0) return PLAT_ERR_INVALID;
+    ctx->sync_poll_ns = (long)microseconds * 1000L;
+    return PLAT_OK;
+}
+
 PLAT_EXPORT int plat_stream_sync(plat_ctx* ctx, void* stream) {
     if (!ctx) return PLAT_ERR_INVALID;
     // The waiting thread SLEEPS instead of spinning on the stream: a caller with many worker threads, most of them waiting for the
@@ -230,7 +236,8 @@ PLAT_EXPORT int plat_stream_sync(plat_ctx* ctx, void* stream) {
     // inside 0.09 ms of waiting -- so the default is a poll of the event every PLAT_SYNC_POLL_US microseconds (40) with the thread
     // asleep in between; PLAT_SYNC_POLL_US=0: hipEventSynchronize; PLAT_SYNC_SPIN=1: hipStreamSynchronize, the runtime's default wait.
     static const bool spin = [] { const char* e = getenv("PLAT_SYNC_SPIN"); return e && e[0] == '1'; }();
-    static const long poll_ns = [] { const char* e = getenv("PLAT_SYNC_POLL_US"); const long v = e ? atol(e) : 40; return (v < 0 ? 0 : v) * 1000L; }();
+    static const long env_poll_ns = [] { const char* e = getenv("PLAT_SYNC_POLL_US"); const long v = e ? atol(e) : -1; return v < 0 ? -1L : v * 1000L; }();
+    const long poll_ns = env_poll_ns >= 0 ? env_poll_ns : ctx->sync_poll_ns;          // (the environment wins over plat_sync_poll_us: measurements)
     if (spin || !ctx->sync_event) PLAT_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     else {
         PLAT_HIP(ctx, hipEventRecord((hipEvent_t)ctx->sync_event, (hipStream_t)stream));

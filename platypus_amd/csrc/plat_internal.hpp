@@ -34,6 +34,7 @@ struct plat_ctx {
     int64_t* h_sticky = nullptr;
     void* d_sticky = nullptr;
     void* sync_event = nullptr;         // hipEvent_t with hipEventBlockingSync: plat_stream_sync sleeps on it
+    long sync_poll_ns = 40000;          // ... polling it this often (plat_sync_poll_us)
     // optional live timing: events 0..5 bracket prepare|seed|dp|finalize, 6..7 bracket genotype
     int profile = 0;
     hipEvent_t ev[9] = {};          // + 8: between k_sweep and k_pairs

@@ -84,6 +84,7 @@ API int plat_stream_sync(plat_ctx* c, void* s) {
 API void plat_fake_reset_sync_count(void) { g_sync_calls = 0; }
 API int plat_profile_enable(plat_ctx* c, int on) { (void)c; (void)on; return PLAT_OK; }
 API int plat_profile_last(plat_ctx* c, plat_profile* p) { (void)c; memset(p, 0, sizeof(*p)); return PLAT_OK; }
+API int plat_sync_poll_us(plat_ctx* c, int us) { (void)c; return us < 0 ? PLAT_ERR_INVALID : PLAT_OK; }
 API const char* plat_kernel_timer_name(int id) { return id >= 0 && id < PLAT_KT_COUNT ? "fake" : NULL; }
 API int plat_kernel_times(plat_ctx* c, double* ms, int64_t* n) { (void)c; (void)ms; (void)n; return PLAT_OK; }
 API int plat_dp_batch(plat_ctx* c, int n, int lmax, const uint8_t* a, const uint8_t* b, const uint8_t* q, const uint8_t* g,
