@@ -27,6 +27,18 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     assert line["record_gather"]["records"] == 23 and line["in_order"]
 
 
+def test_bench_gpus_8_is_eight_ranks():
+    """The driver's largest form, `bench.py --gpus 8`: eight ranks (gloo here), the size all_gather, the point-to-point payloads and the ordered
+    merge on rank 0 -- the launch path of an 8-GPU node without the devices."""
+    env = dict(os.environ, PLAT_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--selftest-ranks"], capture_output=True, text=True,
+                       env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.split("\n") if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["record_gather"]["ranks"] == 8 and line["record_gather"]["records"] == 23 and line["in_order"] and line["records_sum"] == 23
+
+
 def test_launch_command_is_the_drivers_form():
     import bench
     cmd = bench.rank_launch_command(8, ["--gpus", "8", "--steps", "5"], port=29511)

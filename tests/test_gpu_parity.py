@@ -792,3 +792,52 @@ def test_two_kernel_seeding_equals_the_fused_kernel(eng):
         assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1], res["1"][1])
         assert res["0"][2:4] == res["1"][2:4]
         assert np.array_equal(res["0"][4], res["0"][1]) and np.array_equal(res["1"][4], res["1"][1])
+
+
+def test_region_text_exchange_over_rccl_with_two_ranks():
+    """The job's one exchange between REAL ranks (runner.py:301-352): two processes, one GPU each, backend "nccl" (= RCCL over
+    xGMI): each rank's per-region text blocks travel device to device to rank 0 and are put in (chromosome key, start) order there by
+    plat_copy_pieces; the merged text is what the line merge of the same texts gives.  Needs two visible GPUs: skipped on a one-GPU box,
+    runs on the driver's multi-GPU node."""
+    import os, socket, subprocess, sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL wants one device per rank)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from platypus_amd import sharding, fastcaller as F
+rank = int(os.environ["RANK"]); world = 2
+torch.cuda.set_device(rank)
+dev = torch.device("cuda", rank)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+regions = [("r%%d" %% g, 1000, 4000) for g in range(11)]                      # region g -> rank g %% 2 (runner.py:473-474)
+per_rank = [regions[r::world] for r in range(world)]
+def block(g):                                                                # a region's record lines (regions 3 and 8 call nothing)
+    return b"" if g in (3, 8) else b"".join(b"r%%d\t%%d\t.\tA\tC\tline %%d of region %%d\n" %% (g, 1001 + 7 * k, k, g) for k in range(1 + g %% 4))
+mine = [g for g in range(11) if g %% world == rank]
+text = b"".join(block(g) for g in mine)
+lens = np.array([len(block(g)) for g in mine], dtype=np.int64)
+x = sharding.RegionTextExchange(per_rank, dist=dist, device=dev, device_index=rank)
+for _ in range(2):                                                           # twice: the pinned block and the context are reused
+    merged = x.exchange(text, lens)
+    if rank == 0:
+        want = F.text_bytes(F.merge_record_texts([b"".join(block(g) for g in range(11) if g %% world == r) for r in range(world)], raw=True))
+        assert bytes(memoryview(merged)) == want == b"".join(block(g) for g in sorted(range(11), key=lambda g: sharding.chrom_key("r%%d" %% g)))
+    else:
+        assert merged is None
+x.close()
+dist.barrier()
+if rank == 0:
+    print("EXCHANGED over", dist.get_backend())
+dist.destroy_process_group()
+''' % root
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-1500:] for o in outs)
+    assert "EXCHANGED over nccl" in outs[0][0]
