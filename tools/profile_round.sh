@@ -7,8 +7,8 @@
 # Parts (default: all but the soaks):
 #   tests   python -m pytest tests -m gpu                               -> $O/pytest_gpu.txt
 #   c2      rocprofv3 --kernel-trace --stats of config 2, one batch at a time and three in flight
-#   c3 c4 c5   the same for configs 3 (tiles + end to end), 4 (1024 regions, inputs resident, 64 regions per chunk), 5
-#   pmc4    PMC passes of config 4 (FETCH_SIZE | WRITE_SIZE | SQ counters) -> $TAG_pmc_config4.txt
+#   c3 c4 c5   the same for configs 3 (tiles + end to end), 4 (4096 regions, inputs resident, 128 regions per chunk as the whole-genome line), 5
+#   pmc4    PMC passes of config 4 (FETCH_SIZE | WRITE_SIZE | SQ counters) -> $TAG_pmc_config4.txt, profiles/wgs_profile.json (what bench.py's line quotes)
 #   mapa    tools/ubench/dp_mapping_a.hip: mapping A of the DP, bit exact, against the library -> $TAG_dp_mapping_a.json
 #   pmc2    PMC passes of config 2 (FETCH_SIZE | WRITE_SIZE | SQ counters; one pass per set, only --kernel-trace next to --pmc)
 #   pmc3    PMC passes of the assembler (FETCH | WRITE | SQ | wait counters)
@@ -31,10 +31,10 @@ for p in $PARTS; do case $p in
   tests) (cd $R && python -m pytest tests -q -m gpu 2>&1 | tail -5 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt) ;;
   c2) prof stats1 python $R/bench.py $B2 --streams 1; prof stats3 python $R/bench.py $B2 ;;
   c3) prof stats_c3 python $R/bench.py --config 3 --regions 2000 --steps 5 --no-extras; prof stats_c3e python $R/bench.py --config 3 --regions 2000 --steps 1 ;;
-  c4) prof stats_c4 python $R/bench.py --config 4 --regions 1024 --steps 1 --no-cpu-baseline
+  c4) PLAT_CALLER_CHUNK=128 prof stats_c4 python $R/bench.py --config 4 --regions 4096 --steps 1 --no-cpu-baseline
       f=$(ls $O/stats_c4/*/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$f" ] && python $R/tools/trace_overlap.py $f 3 300 > $O/config4_overlap.json ;;
-  pmc4) for c in FETCH_SIZE WRITE_SIZE; do pmc pmc4_$c $c python $R/bench.py --config 4 --regions 512 --steps 1 --no-cpu-baseline; done
-        pmc pmc4_SQ "SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES" python $R/bench.py --config 4 --regions 512 --steps 1 --no-cpu-baseline ;;
+  pmc4) for c in FETCH_SIZE WRITE_SIZE; do PLAT_CALLER_CHUNK=128 pmc pmc4_$c $c python $R/bench.py --config 4 --regions 4096 --steps 1 --no-cpu-baseline; done
+        PLAT_CALLER_CHUNK=128 pmc pmc4_SQ "SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES" python $R/bench.py --config 4 --regions 4096 --steps 1 --no-cpu-baseline ;;
   mapa) (cd $R && hipcc --offload-arch=gfx950 -O3 -o /tmp/dp_mapping_a tools/ubench/dp_mapping_a.hip -Lplatypus_amd -lplat_mi355x && LD_LIBRARY_PATH=platypus_amd /tmp/dp_mapping_a 400000 150 | tail -1 > $O/dp_mapping_a.json; cat $O/dp_mapping_a.json) ;;
   c5) prof stats_c5 python $R/bench.py --config 5 --windows 200 --steps 10 --warmup 2 ;;
   pmc2) for c in FETCH_SIZE WRITE_SIZE; do pmc pmc_$c $c python $R/bench.py --config 2 --steps 4 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-extras --batches 2 --streams 1; done
@@ -52,8 +52,8 @@ for p in $PARTS; do case $p in
         python bench.py > $O/bench_line.json 2> $O/bench_line.err
         for c in 3 4 5; do python bench.py --config $c > $O/bench_config$c.json 2> $O/bench_config$c.err; done
         python bench.py --gpus 2 --steps 5 --no-extras > $O/bench_2ranks.json 2> $O/bench_2ranks.err
-        python bench.py --gpus 2 --config 4 --regions 1024 > $O/bench_c4_2ranks.json 2> $O/bench_c4_2ranks.err
-        PLAT_CALLER_LOADERS=2 taskset -c 0,1 python bench.py --config 4 --regions 1024 --steps 3 --no-cpu-baseline > $O/bench_config4_2cpus.json 2> $O/bench_config4_2cpus.err
+        python bench.py --gpus 2 --config 4 --regions 4096 > $O/bench_c4_2ranks.json 2> $O/bench_c4_2ranks.err
+        PLAT_CALLER_LOADERS=2 taskset -c 0,1 python bench.py --config 4 --regions 4096 --steps 3 --no-cpu-baseline > $O/bench_config4_2cpus.json 2> $O/bench_config4_2cpus.err
         tail -c 600 $O/bench_line.json) ;;
   soaks) (cd $R
         python tools/ungapped_crosscheck.py $T 70000 --bigq 2>&1 | tail -1 > $O/soak_ungapped_bigq.json
@@ -64,7 +64,7 @@ for p in $PARTS; do case $p in
 esac; done
 cd $R
 python tools/profile_round_summary.py $O $TAG
-mkdir -p $O/out && cp profiles/${TAG}_* profiles/dp_traffic.json $O/out/ 2>/dev/null
+mkdir -p $O/out && cp profiles/${TAG}_* profiles/dp_traffic.json profiles/wgs_profile.json $O/out/ 2>/dev/null
 [ -s $O/pmc_seed.txt ] && { echo "# rocprofv3 --kernel-trace --pmc <C> (three passes: instruction mix | waits and busy | LDS) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --streams 1; mean per launch (SQ_*_CYCLES / ACTIVE / WAIT counters in units of 4 cycles)"; cat $O/pmc_seed.txt; } > $O/out/${TAG}_pmc_kernels.txt
 for f in $O/bench_*.json $O/soak_*.json $O/dp_mapping_a.json $O/config4_overlap.json; do [ -s "$f" ] && grep "^[{[]" $f | tail -1 > $O/out/${TAG}_$(basename $f); done     # the lines / soaks of THIS run (gloo writes to stdout too: the JSON line only)
 find $O -name "*.csv" -size +1M -delete

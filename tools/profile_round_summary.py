@@ -69,6 +69,65 @@ def pmc(o, names, out, args):
     return per
 
 
+STREAMING_16B = ("k_unpack_pieces", "k_copy_pieces")
+C4 = "--config 4 --regions 4096 --steps 1 --no-cpu-baseline  [PLAT_CALLER_CHUNK=128]"
+
+
+def short_kernel(name):
+    """rocprofv3's kernel name -> the library's timer name (plat_kernel_timer_name)."""
+    k = name.split("(")[0].replace("void ", "").replace("plat::", "").split("<")[0].strip()
+    return {"k_em_wide": "k_em", "k_finalize_dense": "k_finalize", "k_finalize_multi": "k_finalize"}.get(k, k)
+
+
+def wgs_profile(o, prof, tag, per4):
+    """profiles/wgs_profile.json: what bench.py's WGS line may quote -- the rocprofv3 --stats ranking of the region loop's kernels, their PMC
+    bytes per launch, and the hash of the kernel sources they were collected from (bench.py refuses the figures of other sources)."""
+    paths = sorted(glob.glob(o + "/stats_c4/*/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)
+    if not paths and not per4:
+        return
+    sys.path.insert(0, ROOT)
+    from tools import bench_other
+    tf = prof + "/wgs_profile.json"
+    d = json.load(open(tf)) if os.path.exists(tf) else {}
+    here = bench_other.kernel_source_hash()
+    if d.get("kernel_source_hash") != here:
+        d = {}                                                          # (figures of other sources are not mixed with these)
+    d["kernel_source_hash"] = here
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        commit = os.environ.get("PLAT_COMMIT")
+    d["measured"] = {"date": datetime.date.today().isoformat(), "commit": commit, "round": int(tag[1:])}
+    d["command"] = CMD + C4
+    if paths:
+        tot = {}
+        for r in csv.DictReader(open(paths[0])):
+            if "plat::" in r["Name"]:
+                k = short_kernel(r["Name"])
+                t = tot.setdefault(k, [0.0, 0])
+                t[0] += float(r["TotalDurationNs"]) / 1e3; t[1] += int(r["Calls"])
+        d["ranking"] = [k for k, _ in sorted(tot.items(), key=lambda kv: -kv[1][0])]
+        d["stats"] = {k: {"total_us": round(v[0], 1), "calls": v[1], "avg_us": round(v[0] / max(1, v[1]), 2)} for k, v in tot.items()}
+        d["ranking_source"] = "profiles/" + tag + "_config4_stats.txt (rocprofv3 --kernel-trace --stats)"
+    if per4:
+        ks = d.setdefault("kernels", {})
+        for name, v in per4.items():
+            if "plat::" not in name or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+                continue
+            k = short_kernel(name)
+            e = ks.setdefault(k, {"hbm_bytes_per_launch": 0, "launches": 0})
+            n = int(v.get("launches", 1))
+            # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports HALF the bytes of a wide coalesced streaming read (16 B per lane): doubled for the
+            # kernels that read that way (the unpack and the piece copies); every other access width is uncalibrated there and stays raw.  KB -> bytes.
+            fc = 2.0 if k in STREAMING_16B else 1.0
+            e["fetch_correction"] = fc
+            # (several rocprof names can map to one timer: the launches' bytes are averaged over all of them)
+            e["hbm_bytes_per_launch"] = int((e["hbm_bytes_per_launch"] * e["launches"] + (fc * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 * n) / max(1, e["launches"] + n))
+            e["launches"] += n
+        d["source"] = "profiles/" + tag + "_pmc_config4.txt (rocprofv3 --pmc, separate passes: FETCH_SIZE and WRITE_SIZE in KB x 1024, mean per launch; FETCH_SIZE x 2 for the 16-byte-per-lane streaming kernels as MI355X_MICROARCH.md prescribes for gfx950, raw elsewhere)"
+    json.dump(d, open(tf, "w"), indent=1)
+
+
 def main(o, tag):
     prof = os.path.join(ROOT, "profiles")
     b2 = "--config 2 --steps 12 --warmup 2 --no-cpu-baseline --no-extras --batches 3"
@@ -77,16 +136,17 @@ def main(o, tag):
     stats(o + "/stats_c3", prof + "/" + tag + "_assemble_stats.txt", CMD + "--config 3 --regions 2000 --steps 5 --no-extras   (MI355X; config 3: 2000 assembly tiles per launch)")
     stats(o + "/stats_c3e", prof + "/" + tag + "_config3_end_to_end_stats.txt", CMD + "--config 3 --regions 2000 --steps 1   (MI355X; config 3 incl. END TO END: 2000 regions through the native region loop with --assemble=1, 32 regions per chunk)")
     stats(o + "/stats_c5", prof + "/" + tag + "_config5_stats.txt", CMD + "--config 5 --windows 200 --steps 10 --warmup 2   (MI355X; config 5: 200 windows x 100 samples per step)")
-    stats(o + "/stats_c4", prof + "/" + tag + "_config4_stats.txt", CMD + "--config 4 --regions 1024 --steps 1 --no-cpu-baseline   (MI355X; config 4: 1024 regions x 100 kb, inputs resident in HBM, through the native region loop, 24 host threads x 64 regions per chunk: one serialized counting pass, two warm rounds and one timed pass; avg_us is stretched by the kernels of the other chunks running at the same time -- r05_config4_overlap.json says how many)")
+    stats(o + "/stats_c4", prof + "/" + tag + "_config4_stats.txt", CMD + C4 + "   (MI355X; config 4: 4096 regions x 100 kb of the synthetic genome, inputs resident in HBM, through the native region loop, 24 host threads x 128 regions per chunk as the whole-genome line runs: one serialized counting pass, two warm rounds and one timed pass; avg_us is stretched by the kernels of the other chunks running at the same time -- " + tag + "_config4_overlap.json says how many)")
     stats(o + "/nextk", prof + "/" + tag + "_next_kernels.txt", "rocprofv3 --kernel-trace --stats --output-format csv -- python tools/next_kernels.py   (MI355X; the kernels of the SURVEY 8(f) \"next\" rows on their own, sizes in the script)")
-    quantiles(o + "/stats_c4", prof + "/" + tag + "_config4_kernel_quantiles.txt", "the launches of `" + CMD + "--config 4 --regions 1024 --steps 1 --no-cpu-baseline` per kernel: a chunk = 64 regions x 100 kb; min / q25 = the kernel by itself, median / mean = with the other chunks' kernels on the chip")
+    quantiles(o + "/stats_c4", prof + "/" + tag + "_config4_kernel_quantiles.txt", "the launches of `" + CMD + C4 + "` per kernel: a chunk = 128 regions x 100 kb; min / q25 = the kernel by itself, median / mean = with the other chunks' kernels on the chip")
     for f, dst in (("stats3", tag + "_bench_line_under_rocprof.json"), ("stats_c3e", tag + "_bench_config3_under_rocprof.json"), ("stats_c4", tag + "_bench_config4_under_rocprof.json"),
                    ("stats_c5", tag + "_bench_config5_under_rocprof.json")):
         p = o + "/" + f + ".json"
         if os.path.exists(p) and open(p).read().startswith("{"):
             open(os.path.join(prof, dst), "w").write(open(p).read())
     per = pmc(o, ["pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ"], prof + "/" + tag + "_pmc_hbm.txt", "--config 2 --steps 4 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-extras --batches 2 --streams 1")
-    pmc(o, ["pmc4_FETCH_SIZE", "pmc4_WRITE_SIZE", "pmc4_SQ"], prof + "/" + tag + "_pmc_config4.txt", "--config 4 --regions 512 --steps 1 --no-cpu-baseline")
+    per4 = pmc(o, ["pmc4_FETCH_SIZE", "pmc4_WRITE_SIZE", "pmc4_SQ"], prof + "/" + tag + "_pmc_config4.txt", C4)
+    wgs_profile(o, prof, tag, per4)
     per3 = pmc(o, ["pmc3_FETCH_SIZE", "pmc3_WRITE_SIZE", "pmc3_SQ", "pmc3_WAIT"], prof + "/" + tag + "_pmc_assemble.txt", "--config 3 --regions 2000 --steps 2 --no-extras")
     tf = prof + "/dp_traffic.json"
     d = json.load(open(tf)) if os.path.exists(tf) else {}
