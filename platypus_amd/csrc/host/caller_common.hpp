@@ -389,13 +389,61 @@ struct WindowWork {
     std::string text;                                                      // its record lines (and, with outputRefCalls, the REFCALL lines that belong to it)
     int64_t nRecords = 0, nRefRecords = 0;
     int firstFlat = -1;                                                    // outputRefCalls: index of its first flat-prior posterior (one per variant of `vars`)
+    // A fresh window in a recycled object (WindowList): every member back to its initial value, the containers EMPTY BUT WITH THEIR STORAGE --
+    // a window is five heap blocks (haplotypes, text, positions, INFO, posteriors) that were allocated and freed once per window and pass.
+    void reset() {
+        region = 0; startPos = 0; endPos = 0;
+        vars.clear(); allVars.clear(); ptrs.clear();
+        nReads = 0; hapStart = 0; hapEnd = 0; endBuf = 0;
+        refSeq.clear(); haps.clear(); live = false;
+        greedy = false; byCoverage.clear(); step = 0; heap.clear(); cands.clear(); sampledSeg.clear(); sampled.clear();
+        bw = -1; hapBegin = 0; onDevice = false;
+        distinct.clear(); posterior.clear(); called.clear(); calledPost.clear(); byPos.clear(); info.clear();
+        firstStatVar = 0; firstSite = 0; failed = false; text.clear(); nRecords = 0; nRefRecords = 0; firstFlat = -1;
+    }
+};
+// The windows of a region: a vector whose elements outlive the region -- a worker keeps the storage of the regions it has finished and hands
+// it to the regions of its next chunk (Chunk::run), so that in the steady state a window costs no allocation at all.  The part of
+// std::vector's interface the loop uses; [0, n) are the region's windows, the objects behind them are spares.
+struct WindowList {
+    std::vector<WindowWork> store;
+    size_t n = 0;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void reserve(size_t k) { if (k > store.capacity()) store.reserve(std::max(k, 2 * store.capacity())); }
+    WindowWork& emplace_back() {
+        if (n < store.size()) store[n].reset(); else store.emplace_back();
+        return store[n++];
+    }
+    void push_back(WindowWork&& w) { if (n < store.size()) store[n] = std::move(w); else store.push_back(std::move(w)); ++n; }
+    WindowWork& back() { return store[n - 1]; }
+    WindowWork& operator[](size_t i) { return store[i]; }
+    const WindowWork& operator[](size_t i) const { return store[i]; }
+    WindowWork* begin() { return store.data(); }
+    WindowWork* end() { return store.data() + n; }
 };
 
+// The Variants of a region: objects with stable addresses in blocks of 64 that OUTLIVE the region -- a worker hands the blocks of the regions it
+// has finished to the regions of its next chunk (Chunk::run), a recycled object is assigned to (its strings keep their storage).
 struct VariantPool {
-    std::deque<Variant> store;
+    static constexpr size_t BLOCK = 64;
+    std::vector<std::unique_ptr<Variant[]>> blocks;
+    size_t n = 0;
+    Variant* next() {
+        if (n == blocks.size() * BLOCK) blocks.emplace_back(new Variant[BLOCK]);
+        Variant* v = &blocks[n / BLOCK][n % BLOCK];
+        ++n;
+        return v;
+    }
     Variant* make(int pos, const std::string& rem, const std::string& add, int nSupp, int source) {
-        store.emplace_back(pos, rem, add, nSupp, source);
-        return &store.back();
+        Variant* v = next();
+        v->assign(pos, rem.data(), rem.size(), add.data(), add.size(), nSupp, source);
+        return v;
+    }
+    Variant* make(int pos, const char* rem, size_t nrem, const char* add, size_t nadd, int nSupp, int source) {
+        Variant* v = next();
+        v->assign(pos, rem, nrem, add, nadd, nSupp, source);
+        return v;
     }
 };
 
@@ -413,13 +461,17 @@ struct RegionWork {
     std::vector<SampleView> samples;
     VariantPool pool;
     VarList variants;
-    std::vector<WindowWork> windows;
+    WindowList windows;
     std::string text;
     int64_t nCandRecords = 0;
     // frees everything but the record text (called by the worker that finished the region, so that the cost of freeing thousands of
     // windows and haplotypes is spread over the workers instead of being paid serially at the end of plat_call_regions)
-    void release() {
-        std::vector<WindowWork>().swap(windows);
+    // (spare: where the worker keeps window storage for its next chunk's regions; nullptr: freed)
+    void release(std::vector<std::vector<WindowWork>>* spare = nullptr, std::vector<std::unique_ptr<Variant[]>>* spareVariants = nullptr) {
+        if (spare && spare->size() < 512 && !windows.store.empty()) { spare->emplace_back(); spare->back().swap(windows.store); }
+        else std::vector<WindowWork>().swap(windows.store);
+        windows.n = 0;
+        if (spareVariants && spareVariants->size() < 2048) for (auto& b : pool.blocks) spareVariants->push_back(std::move(b));
         std::vector<Item>().swap(items);
         VarList().swap(variants);
         VarList().swap(asmVariants);

@@ -98,6 +98,11 @@ struct Chunk {
     Clock::time_point mark;
     void lap(int k) { const auto now = Clock::now(); stage[k] += secs(mark, now); mark = now; stageWait[k] += s.t_wait - waitMark; waitMark = s.t_wait; }
 
+    // window storage of the regions this worker thread has finished, for the regions of its next chunks (WindowList)
+    static std::vector<std::vector<WindowWork>>& spareWindows() { static thread_local std::vector<std::vector<WindowWork>> spare; return spare; }
+
+    static std::vector<std::unique_ptr<Variant[]>>& spareVariants() { static thread_local std::vector<std::unique_ptr<Variant[]>> spare; return spare; }
+
     void run() {
         // plat_caller_count_cells (the untimed counting pass of a measurement): one chunk at a time, so that the live kernel timers of its
         // likelihood batch (HIP events on this worker's stream) time its kernels and not the other workers'
@@ -109,6 +114,14 @@ struct Chunk {
         double wait0 = s.t_wait;
         mark = t0; waitMark = wait0;
         if (s.countCells) ck(plat_profile_enable(s.ctx, 1), "plat_profile_enable");     // (the counting pass: live timers of the table kernels too)
+        {   // every region starts with the window storage of a region this worker finished earlier, if there is one
+            std::vector<std::vector<WindowWork>>& spare = spareWindows();
+            for (RegionWork* r : regions)
+                if (!spare.empty() && r->windows.store.empty()) { r->windows.store.swap(spare.back()); spare.pop_back(); r->windows.n = 0; }
+            std::vector<std::unique_ptr<Variant[]>>& sv = spareVariants();
+            for (RegionWork* r : regions)                               // ... and with two blocks of Variant objects (128: a region of the WGS job holds ~90)
+                for (int k = 0; k < 2 && !sv.empty() && r->pool.blocks.size() < 2 && r->pool.n == 0; ++k) { r->pool.blocks.push_back(std::move(sv.back())); sv.pop_back(); }
+        }
         { PROF("s0.uploadReads"); uploadReads(); }
         lap(0);
         deviceB = eligibleDeviceB();
@@ -224,7 +237,7 @@ struct Chunk {
                     ++st.n_windows_failed;
                 }
             }
-            { PROF("s7.release"); r->release(); }
+            { PROF("s7.release"); r->release(&spareWindows(), &spareVariants()); }
         }
         if (s.countCells) {                                                 // every kernel of this chunk, live (HIP events around each launch)
             ck(plat_kernel_times(s.ctx, s.ktMs, s.ktLaunches), "plat_kernel_times");

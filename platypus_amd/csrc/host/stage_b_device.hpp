@@ -126,8 +126,8 @@ inline void Chunk::stageBFromDevice() {
             PROF("s2.fill.variant");
             const size_t k = g * (size_t)capV + (size_t)i;
             const int nrem = z.sb_vnrem.h[k], nadd = z.sb_vnadd.h[k];
-            Variant* v = r.pool.make(z.sb_vpos.h[k], std::string((const char*)r.fa.seq + z.sb_vrempos.h[k], (size_t)nrem),
-                                     std::string((const char*)blob + z.sb_vaddoff.h[k], (size_t)nadd), z.sb_vsupp.h[k], PLATYPUS_VAR);
+            Variant* v = r.pool.make(z.sb_vpos.h[k], (const char*)r.fa.seq + z.sb_vrempos.h[k], (size_t)nrem,
+                                     (const char*)blob + z.sb_vaddoff.h[k], (size_t)nadd, z.sb_vsupp.h[k], PLATYPUS_VAR);
             v->bamMinPos = z.sb_vbmin.h[k]; v->bamMaxPos = z.sb_vbmax.h[k];
             r.variants.push_back(v);
         }

@@ -61,9 +61,15 @@ struct Variant {
     double prior = -1.0;                                                // cached calculatePrior (< 0: not yet)
 
     Variant() {}
-    Variant(int pos, std::string rem, std::string add, int nSupp, int source) {
+    Variant(int pos, std::string rem, std::string add, int nSupp, int source) { removed = std::move(rem); added = std::move(add); init(pos, nSupp, source); }
+    // the same into an object that exists already (VariantPool recycles its objects: the strings keep their storage)
+    void assign(int pos, const char* rem, size_t nrem, const char* add, size_t nadd, int nSupp, int source) {
+        removed.assign(rem, nrem); added.assign(add, nadd);
+        init(pos, nSupp, source);
+    }
+    void init(int pos, int nSupp, int source) {
         refPos = std::max(0, pos);
-        removed = std::move(rem); added = std::move(add);
+        prior = -1.0;
         nRemoved = (int)removed.size(); nAdded = (int)added.size();
         nSupportingReads = nSupp; varSource = source;
         minRefPos = refPos;
