@@ -2709,7 +2709,9 @@ static int align_impl(plat_ctx* ctx, const plat_window_batch* batch, const plat_
         static int dp_impl = -1;                 // 1 = one int16 lane per VGPR (dp_unpacked.hpp), 0 = packed (dp_core.hpp)
         if (dp_impl < 0) { const char* e = getenv("PLAT_DP_IMPL"); dp_impl = e ? (strcmp(e, "unpacked") == 0) : 0; }   // packed measured faster
         // a fixed grid walks the list (its length lives on the device): two rounds of the blocks a device holds at 4 waves/SIMD
-        const long long want = (ngrid + 255) / 256, fixed = 8ll * ctx->n_cu;
+        static int dp_mult = -1;                                   // workgroups of the fixed grid per CU (PLAT_DP_GRID_PER_CU: measurements)
+        if (dp_mult < 0) { const char* e = getenv("PLAT_DP_GRID_PER_CU"); dp_mult = e && atoi(e) > 0 ? atoi(e) : 8; }
+        const long long want = (ngrid + 255) / 256, fixed = (long long)dp_mult * ctx->n_cu;
         // PLAT_DP_TILES=1 (measurement, round 5): every wave pulls 64-job tiles with one atomic instead of walking the list with a fixed
         // stride.  Measured SLOWER on both shapes -- config 2 (3 328 tiles, one per wave) k_dp_jobs 137 -> 180 us, every reference DP
         // executed (24.5 k tiles) 4 008 -> 3 971 GCUPS: thousands of atomics on one L2 address (~90 per us) cost more than the uneven

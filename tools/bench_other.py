@@ -303,12 +303,13 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
 
 
 def kernel_source_hash():
-    """sha256 over the sources the kernels and the host loop are built from: what a stored profile (profiles/wgs_profile.json) must carry to be quoted."""
+    """sha256 over the sources libplat_mi355x.so is built from (the kernels + their build flags): what a stored profile (profiles/wgs_profile.json)
+    must carry for its counters to be quoted."""
     import glob
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "platypus_amd", "csrc")
-    for f in sorted(glob.glob(base + "/*.hip") + glob.glob(base + "/*.hpp") + glob.glob(base + "/host/*") + [base + "/Makefile"]):
+    for f in sorted(glob.glob(base + "/*.hip") + glob.glob(base + "/*.hpp") + [base + "/Makefile"]):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

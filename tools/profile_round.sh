@@ -13,6 +13,7 @@
 #   pmc2    PMC passes of config 2 (FETCH_SIZE | WRITE_SIZE | SQ counters; one pass per set, only --kernel-trace next to --pmc)
 #   pmc3    PMC passes of the assembler (FETCH | WRITE | SQ | wait counters)
 #   pmcseed three SQ passes over k_seed / k_dp_jobs / k_prep_reads (instruction mix, waits, LDS conflicts)
+#   dpstall where k_dp_jobs' wave cycles go: parked on waits / issue stalls / active (SQ counters), config 2 as it runs and with every DP executed
 #   nextk   kernel stats of the "next row" kernels (tools/next_kernels.py)
 #   line    the default bench line, bench.py --config 3/4/5, the two-rank launches on the one GPU
 #   soaks   ungapped cross-check (plain + wrap regime), native region-loop soak, assembler soak; SOAK_SECONDS each (default 400)
@@ -47,6 +48,15 @@ for p in $PARTS; do case $p in
         pmc seed_b "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" python $R/bench.py $S
         pmc seed_c "SQ_LDS_BANK_CONFLICT SQ_LDS_ATOMIC_RETURN SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_WAVES SQ_LDS_ADDR_CONFLICT" python $R/bench.py $S
         (cd $R && python tools/pmc_summary.py $O/seed_a $O/seed_b $O/seed_c 2>&1 | grep "plat::\|k_dp_jobs" | tee $O/pmc_seed.txt) ;;
+  dpstall) S="--config 2 --steps 3 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-extras --streams 1 --batches 2"
+        # where k_dp_jobs' cycles go (MI355X_MICROARCH.md: WAIT_ANY = wave parked on s_waitcnt / barrier, WAIT_INST_ANY = issue stall, ACTIVE_INST_ANY:
+        # the three are disjoint and add up to WAVE_CYCLES), on config 2 as it runs and with every reference DP executed (a full grid)
+        pmc dps_a "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES" python $R/bench.py $S
+        pmc dps_b "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE" python $R/bench.py $S
+        PLAT_NO_UNGAPPED=1 PLAT_NO_EXACT=1 pmc dps_all_a "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES" python $R/bench.py $S
+        (cd $R && { echo "# rocprofv3 --kernel-trace --pmc <C> -- python bench.py $S   (MI355X; mean per launch; SQ_*_CYCLES / WAIT / ACTIVE counters in units of 4 cycles, summed over the SIMDs)"
+          echo "# config 2 as it runs (0.21 M DPs per launch):"; python tools/pmc_summary.py $O/dps_a $O/dps_b 2>&1 | grep "k_dp_jobs\|k_pairs\|k_sweep"
+          echo "# PLAT_NO_UNGAPPED=1 PLAT_NO_EXACT=1: every reference DP executed (1.57 M DPs per launch):"; python tools/pmc_summary.py $O/dps_all_a 2>&1 | grep "k_dp_jobs"; } > $O/dp_stalls.txt; cat $O/dp_stalls.txt) ;;
   nextk) prof nextk python $R/tools/next_kernels.py ;;
   line) (cd $R
         python bench.py > $O/bench_line.json 2> $O/bench_line.err
@@ -66,6 +76,7 @@ cd $R
 python tools/profile_round_summary.py $O $TAG
 mkdir -p $O/out && cp profiles/${TAG}_* profiles/dp_traffic.json profiles/wgs_profile.json $O/out/ 2>/dev/null
 [ -s $O/pmc_seed.txt ] && { echo "# rocprofv3 --kernel-trace --pmc <C> (three passes: instruction mix | waits and busy | LDS) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --streams 1; mean per launch (SQ_*_CYCLES / ACTIVE / WAIT counters in units of 4 cycles)"; cat $O/pmc_seed.txt; } > $O/out/${TAG}_pmc_kernels.txt
+[ -s $O/dp_stalls.txt ] && cp $O/dp_stalls.txt $O/out/${TAG}_dp_stalls.txt
 for f in $O/bench_*.json $O/soak_*.json $O/dp_mapping_a.json $O/config4_overlap.json; do [ -s "$f" ] && grep "^[{[]" $f | tail -1 > $O/out/${TAG}_$(basename $f); done     # the lines / soaks of THIS run (gloo writes to stdout too: the JSON line only)
 find $O -name "*.csv" -size +1M -delete
 find $O -name "*.db" -size +1M -delete
