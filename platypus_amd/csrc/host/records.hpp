@@ -474,6 +474,8 @@ struct VarInfo {                                                          // vcf
     int HP = 0;
     InlineStr SC;
     std::string PP, FRtext;
+    double PPnum = 0.0; int PPint = 0;                                    // float(PP) and int(float(PP)) as the text gives them: parsed once (setPP)
+    void setPP(double posterior) { PP.clear(); append_fixed(PP, posterior, 0); PPnum = strtod(PP.c_str(), nullptr); PPint = atoi(PP.c_str()); }   // "%.0f"
     double FRsum = 0.0;
     Num ABPV, SbPval, BRF, MQ, QD;
     long long TR = 0, NF = 0, NR = 0, TC = 0, TCR = 0, TCF = 0;

@@ -130,18 +130,17 @@ inline void Chunk::callWindows(std::vector<WindowWork*>& wins, bool fromDevice) 
                 if (contains(seen, v)) continue;
                 seen.push_back(v);
                 int ci = -1;
-                for (size_t c = 0; c < w->called.size(); ++c) if (w->called[c]->same(*v)) { ci = (int)c; break; }
+                for (size_t c = 0; c < w->called.size(); ++c) if (w->called[c] == v || w->called[c]->same(*v)) { ci = (int)c; break; }
                 if (ci < 0) continue;
                 VarInfo* d = nullptr;
-                for (VarInfo& x : w->info) if (x.var->same(*v)) { d = &x; break; }
+                for (VarInfo& x : w->info) if (x.var == v || x.var->same(*v)) { d = &x; break; }
                 if (!d) {
                     VarInfo n;
                     n.var = v;
                     PROF("s6.hp_sc");
                     n.HP = homopolymerLengthForOneVariant(*v, r.fa);
                     getSequenceContext(*v, r.fa, n.SC);
-                    n.PP.clear();
-                    append_fixed(n.PP, w->calledPost[(size_t)ci], 0);                   // "%.0f"
+                    n.setPP(w->calledPost[(size_t)ci]);                                // "%.0f"
 
                     n.FRsum = freq[h];
                     w->info.push_back(std::move(n));

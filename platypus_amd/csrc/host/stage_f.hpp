@@ -54,7 +54,7 @@ inline void Chunk::writeWindow(RegionWork& r, WindowWork& w, const std::vector<i
                                 z.infoOnDevice ? z.s_terms.h + 8 * sv : nullptr, z.infoOnDevice ? z.s_mmlq.h[sv] : -1);
         PROF("text.info.qd");
         if (d.TR > 0) {                                                // :1400-1409
-            const double qual = strtod(d.PP.c_str(), nullptr);
+            const double qual = d.PPnum;
             if (qual > 2500) d.QD = Num::I(o.qdThreshold + 10);
             else d.QD = Num::D((qual + (-10 * log10(calculatePrior(*d.var, r.fa)))) / (double)d.TR);
         } else d.QD = Num::I(0);
@@ -68,6 +68,7 @@ inline void Chunk::writeWindow(RegionWork& r, WindowWork& w, const std::vector<i
         d.filters.clear();
     }
     auto infoOf = [&](const Variant* v) -> VarInfo& {
+        for (VarInfo& d : w.info) if (d.var == v) return d;                  // (nearly always the same object)
         for (VarInfo& d : w.info) if (d.var->same(*v)) return d;
         throw WindowError("variant without INFO");
     };
@@ -84,7 +85,7 @@ inline void Chunk::writeWindow(RegionWork& r, WindowWork& w, const std::vector<i
             d.filters.clear();
             if (failsSC) d.filters.push_back("SC");
             BRF = d.BRF.value();
-            bestQual = std::max(bestQual, atoi(d.PP.c_str()));
+            bestQual = std::max(bestQual, d.PPint);
             fMMLQ += d.MMLQ < o.badReadsThreshold;
             fQD += d.QD.value() < (double)o.qdThreshold;
             fHap += d.HapScore > o.hapScoreThreshold;
@@ -126,7 +127,7 @@ inline void Chunk::writeWindow(RegionWork& r, WindowWork& w, const std::vector<i
         for (Variant* v : variants) infos.push_back(&infoOf(v));
         VarInfo& lead = *infos[0];
         int qual = 0;
-        for (int k = 0; k < nVariants; ++k) { const int q = atoi(infos[(size_t)k]->PP.c_str()); if (k == 0 || q > qual) qual = q; }
+        for (int k = 0; k < nVariants; ++k) { const int q = infos[(size_t)k]->PPint; if (k == 0 || q > qual) qual = q; }
         // per-sample calls first: MGOF (an INFO field) and the decision to write the record at all depend on them
         double maxGof = 0.0;
         int nNonRefCalls = 0;
