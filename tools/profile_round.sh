@@ -7,7 +7,8 @@
 # Parts (default: all but the soaks):
 #   tests   python -m pytest tests -m gpu                               -> $O/pytest_gpu.txt
 #   c2      rocprofv3 --kernel-trace --stats of config 2, one batch at a time and three in flight
-#   c3 c4 c5   the same for configs 3 (tiles + end to end), 4 (4096 regions, inputs resident, 128 regions per chunk as the whole-genome line), 5
+#   c3 c4 c5   the same for configs 3 (tiles + end to end), 4 (12288 regions, inputs resident, 128 regions per chunk as the whole-genome line), 5
+#   c4solo  config 4 with ONE worker (no two kernels at once): every kernel's duration by itself, the basis bench.py's live timers and the roofline use
 #   pmc4    PMC passes of config 4 (FETCH_SIZE | WRITE_SIZE | SQ counters) -> $TAG_pmc_config4.txt, profiles/wgs_profile.json (what bench.py's line quotes)
 #   mapa    tools/ubench/dp_mapping_a.hip: mapping A of the DP, bit exact, against the library -> $TAG_dp_mapping_a.json
 #   pmc2    PMC passes of config 2 (FETCH_SIZE | WRITE_SIZE | SQ counters; one pass per set, only --kernel-trace next to --pmc)
@@ -32,10 +33,11 @@ for p in $PARTS; do case $p in
   tests) (cd $R && python -m pytest tests -q -m gpu 2>&1 | tail -5 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt) ;;
   c2) prof stats1 python $R/bench.py $B2 --streams 1; prof stats3 python $R/bench.py $B2 ;;
   c3) prof stats_c3 python $R/bench.py --config 3 --regions 2000 --steps 5 --no-extras; prof stats_c3e python $R/bench.py --config 3 --regions 2000 --steps 1 ;;
-  c4) PLAT_CALLER_CHUNK=128 prof stats_c4 python $R/bench.py --config 4 --regions 4096 --steps 1 --no-cpu-baseline
+  c4) PLAT_CALLER_CHUNK=128 prof stats_c4 python $R/bench.py --config 4 --regions 12288 --steps 1 --no-cpu-baseline
       f=$(ls $O/stats_c4/*/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$f" ] && python $R/tools/trace_overlap.py $f 3 300 > $O/config4_overlap.json ;;
-  pmc4) for c in FETCH_SIZE WRITE_SIZE; do PLAT_CALLER_CHUNK=128 pmc pmc4_$c $c python $R/bench.py --config 4 --regions 4096 --steps 1 --no-cpu-baseline; done
-        PLAT_CALLER_CHUNK=128 pmc pmc4_SQ "SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES" python $R/bench.py --config 4 --regions 4096 --steps 1 --no-cpu-baseline ;;
+  c4solo) PLAT_CALLER_WORKERS=1 PLAT_CALLER_CHUNK=128 prof stats_c4solo python $R/bench.py --config 4 --regions 2048 --steps 1 --no-cpu-baseline ;;
+  pmc4) for c in FETCH_SIZE WRITE_SIZE; do PLAT_CALLER_CHUNK=128 pmc pmc4_$c $c python $R/bench.py --config 4 --regions 12288 --steps 1 --no-cpu-baseline; done
+        PLAT_CALLER_CHUNK=128 pmc pmc4_SQ "SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES" python $R/bench.py --config 4 --regions 12288 --steps 1 --no-cpu-baseline ;;
   mapa) (cd $R && hipcc --offload-arch=gfx950 -O3 -o /tmp/dp_mapping_a tools/ubench/dp_mapping_a.hip -Lplatypus_amd -lplat_mi355x && LD_LIBRARY_PATH=platypus_amd /tmp/dp_mapping_a 400000 150 | tail -1 > $O/dp_mapping_a.json; cat $O/dp_mapping_a.json) ;;
   c5) prof stats_c5 python $R/bench.py --config 5 --windows 200 --steps 10 --warmup 2 ;;
   pmc2) for c in FETCH_SIZE WRITE_SIZE; do pmc pmc_$c $c python $R/bench.py --config 2 --steps 4 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-extras --batches 2 --streams 1; done

@@ -70,7 +70,8 @@ def pmc(o, names, out, args):
 
 
 STREAMING_16B = ("k_unpack_pieces", "k_copy_pieces")
-C4 = "--config 4 --regions 4096 --steps 1 --no-cpu-baseline  [PLAT_CALLER_CHUNK=128]"
+C4 = "--config 4 --regions 12288 --steps 1 --no-cpu-baseline  [PLAT_CALLER_CHUNK=128]"
+C4SOLO = "--config 4 --regions 2048 --steps 1 --no-cpu-baseline  [PLAT_CALLER_WORKERS=1 PLAT_CALLER_CHUNK=128]"
 
 
 def short_kernel(name):
@@ -82,7 +83,8 @@ def short_kernel(name):
 def wgs_profile(o, prof, tag, per4):
     """profiles/wgs_profile.json: what bench.py's WGS line may quote -- the rocprofv3 --stats ranking of the region loop's kernels, their PMC
     bytes per launch, and the hash of the kernel sources they were collected from (bench.py refuses the figures of other sources)."""
-    paths = sorted(glob.glob(o + "/stats_c4/*/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)
+    solo = sorted(glob.glob(o + "/stats_c4solo/*/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)
+    paths = solo or sorted(glob.glob(o + "/stats_c4/*/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)
     if not paths and not per4:
         return
     sys.path.insert(0, ROOT)
@@ -108,7 +110,8 @@ def wgs_profile(o, prof, tag, per4):
                 t[0] += float(r["TotalDurationNs"]) / 1e3; t[1] += int(r["Calls"])
         d["ranking"] = [k for k, _ in sorted(tot.items(), key=lambda kv: -kv[1][0])]
         d["stats"] = {k: {"total_us": round(v[0], 1), "calls": v[1], "avg_us": round(v[0] / max(1, v[1]), 2)} for k, v in tot.items()}
-        d["ranking_source"] = "profiles/" + tag + "_config4_stats.txt (rocprofv3 --kernel-trace --stats)"
+        d["ranking_source"] = ("profiles/" + tag + "_config4_stats_one_worker.txt (rocprofv3 --kernel-trace --stats, one host worker: every kernel by itself -- the basis of the live timers; "
+                               "with 24 workers the bandwidth-bound k_unpack_pieces stretches most and leads " + tag + "_config4_stats.txt)") if solo else "profiles/" + tag + "_config4_stats.txt (rocprofv3 --kernel-trace --stats)"
     if per4:
         ks = d.setdefault("kernels", {})
         for name, v in per4.items():
@@ -136,8 +139,9 @@ def main(o, tag):
     stats(o + "/stats_c3", prof + "/" + tag + "_assemble_stats.txt", CMD + "--config 3 --regions 2000 --steps 5 --no-extras   (MI355X; config 3: 2000 assembly tiles per launch)")
     stats(o + "/stats_c3e", prof + "/" + tag + "_config3_end_to_end_stats.txt", CMD + "--config 3 --regions 2000 --steps 1   (MI355X; config 3 incl. END TO END: 2000 regions through the native region loop with --assemble=1, 32 regions per chunk)")
     stats(o + "/stats_c5", prof + "/" + tag + "_config5_stats.txt", CMD + "--config 5 --windows 200 --steps 10 --warmup 2   (MI355X; config 5: 200 windows x 100 samples per step)")
-    stats(o + "/stats_c4", prof + "/" + tag + "_config4_stats.txt", CMD + C4 + "   (MI355X; config 4: 4096 regions x 100 kb of the synthetic genome, inputs resident in HBM, through the native region loop, 24 host threads x 128 regions per chunk as the whole-genome line runs: one serialized counting pass, two warm rounds and one timed pass; avg_us is stretched by the kernels of the other chunks running at the same time -- " + tag + "_config4_overlap.json says how many)")
+    stats(o + "/stats_c4", prof + "/" + tag + "_config4_stats.txt", CMD + C4 + "   (MI355X; config 4: 12 288 regions x 100 kb of the synthetic genome, inputs resident in HBM, through the native region loop, 24 host threads x 128 regions per chunk as the whole-genome line runs: one serialized counting pass, two warm rounds and one timed pass; avg_us is stretched by the kernels of the other chunks running at the same time -- " + tag + "_config4_overlap.json says how many)")
     stats(o + "/nextk", prof + "/" + tag + "_next_kernels.txt", "rocprofv3 --kernel-trace --stats --output-format csv -- python tools/next_kernels.py   (MI355X; the kernels of the SURVEY 8(f) \"next\" rows on their own, sizes in the script)")
+    stats(o + "/stats_c4solo", prof + "/" + tag + "_config4_stats_one_worker.txt", CMD + C4SOLO + "   (MI355X; config 4 with ONE host worker: no two kernels of the loop ever share the chip, avg_us = the kernel by itself on a chunk of 128 regions -- what bench.py's live timers (kernel_time_ranking) measure in its counting pass and what the line's roofline is computed from)")
     quantiles(o + "/stats_c4", prof + "/" + tag + "_config4_kernel_quantiles.txt", "the launches of `" + CMD + C4 + "` per kernel: a chunk = 128 regions x 100 kb; min / q25 = the kernel by itself, median / mean = with the other chunks' kernels on the chip")
     for f, dst in (("stats3", tag + "_bench_line_under_rocprof.json"), ("stats_c3e", tag + "_bench_config3_under_rocprof.json"), ("stats_c4", tag + "_bench_config4_under_rocprof.json"),
                    ("stats_c5", tag + "_bench_config5_under_rocprof.json")):
