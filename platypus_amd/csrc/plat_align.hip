@@ -1995,6 +1995,9 @@ k_seed_slow(plat_window_batch b, const int32_t* __restrict__ hap_win, const long
     long long nslow = cnt[CNT_SLOW_SEED];
     if (cnt[CNT_ERR] != 0) return;                       // an earlier stage refused the batch
     if (nslow > npairs) nslow = npairs;
+    // entries per workgroup round: as few as fill the grid once -- a launch with a few hundred entries (config 2) gives every entry its own workgroup
+    // (its entries share no haplotype and a group is worked through run by run), one with ten thousand (a chunk of the WGS job) takes `group` at a time
+    group = (int)min((long long)group, max(1ll, (nslow + (long long)gridDim.x - 1) / (long long)gridDim.x));
     if ((long long)group * blockIdx.x >= nslow) return;                              // (most workgroups of a launch: nothing queued for them)
     for (int j = lane; j < (cw >> 1); j += 64) counts[j] = 0u;
     unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[4] = {0, 0, 0, 0};
