@@ -530,7 +530,7 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
         line["value"], line["unit"] = line["gcups"], "GCUPS"
         line["value_is"] = line["config"]["gcups_is"]
     if rank == 0:
-        if lib is None and not getattr(a, "no_cpu_baseline", False):
+        if lib is None and world == 1 and not getattr(a, "no_cpu_baseline", False):      # (rank 0 at N = 1 only: the bench contract)
             line["cpu_baseline"] = config4_cpu_baseline()
         line["merged_text"] = bytes(memoryview(r["merged"])).decode("ascii")                               # (popped by bench.py before printing; the tests read it)
     return line
