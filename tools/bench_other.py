@@ -459,7 +459,10 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
     #  64 regions per chunk measured 2.4 M windows/s against 1.25 M with 8, and a k_dp_jobs launch then holds ~36 k DPs)
     # (round 6, the whole genome on one GPU: 128 regions per chunk -- the latency-bound kernels of a chunk cost the same for 64 and 128 regions, 22.7 -> 16.5 us
     #  of kernel time per region -- measured 5.1 M windows/s against 4.97 M with 64 and 4.8 M with 256; a short list keeps 64: more chunks than workers)
-    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", ("128" if len(mine) >= 12000 else "64") if resident else "16"))
+    #  A SHORT list (a rank of an 8-GPU job: 3 875 regions) wants four chunks per worker more than it wants wide launches -- its 0.08 s are mostly the
+    #  pipeline filling and draining: 24 / 32 / 40 / 48 / 64 / 96 / 128 per chunk measured 4.35 / 4.76 / 4.32-4.73 / 4.30 / 4.10 / 3.69 / 4.08 M windows/s (+-8 % run to run))
+    auto_chunk = max(32, min(128, (len(mine) // max(1, 4 * workers)) // 8 * 8))
+    per_chunk = int(os.environ.get("PLAT_CALLER_CHUNK", str(auto_chunk) if resident else "16"))
     pin = os.environ.get("PLAT_CALLER_PINNED", "1") == "1" and lib is None
     packed = os.environ.get("PLAT_CALLER_PACKED", "1") == "1"
     repeats = max(1, min(int(a.steps or 10), 200))                           # K steps = K runs over the rank's share, timed in one bracket (a run is ~0.1 s)
