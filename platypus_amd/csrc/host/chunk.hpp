@@ -46,6 +46,35 @@ struct Chunk {
     void launchStageB();
 
     void stageBFromDevice();
+    // D's inputs (distinct variants, haplotype masks, priors: Population.computeVariantPosteriors, cpopulation.pyx:596-621) of a list of windows, in list order
+    struct PosteriorInputs {
+        std::vector<int32_t> pwin;
+        std::vector<int64_t> poff{0};
+        std::vector<uint8_t> pmask;
+        std::vector<double> pprior;
+        size_t windows = 0;
+        void clear() { pwin.clear(); poff.assign(1, 0); pmask.clear(); pprior.clear(); windows = 0; }
+        void add(RegionWork& r, WindowWork& w, bool refCalls) {
+            ++windows;
+            w.distinct.clear();
+            for (const Hap& h : w.haps)
+                for (Variant* v : h.variants) if (!contains(w.distinct, v)) w.distinct.push_back(v);
+            for (Variant* v : w.distinct) {
+                pwin.push_back(w.bw);
+                for (const Hap& h : w.haps) pmask.push_back(contains(h.variants, v) ? 1 : 0);
+                poff.push_back((int64_t)pmask.size());
+                { PROF("s5.prior"); pprior.push_back(calculatePrior(*v, r.fa)); }
+            }
+            if (refCalls)                                               // pop.calculatePosterior(v, 1) of outputRefCall: the window's candidates under a flat prior
+                for (Variant* v : w.vars) {
+                    pwin.push_back(w.bw);
+                    for (const Hap& h : w.haps) pmask.push_back(contains(h.variants, v) ? 1 : 0);
+                    poff.push_back((int64_t)pmask.size());
+                    pprior.push_back(0.5);
+                }
+        }
+    };
+    PosteriorInputs prePosterior;                                           // of the windows the device prepared, in the order callWindows(devWins) lists them
 
     // -- A3: the assembler part of generateVariantsInRegion (variantcaller.pyx:496-519): tiles of assemblyRegionSize every
     // max(100, min(1000, size / 2)) bases, doWeNeedToAssembleThisRegion (:276-321) per tile, the reads loadBAMDataIntoGraph would load

@@ -99,6 +99,7 @@ inline void Chunk::stageBFromDevice() {
         st.n_regions_stage_b_host += (int64_t)nR;
         return;
     }
+    prePosterior.clear();
     bool rows = false;
     for (size_t g = 0; g < nR; ++g)
         if (z.sb_hdr.h[8 * g] != 0) {                                   // this region's candidates for the host's code
@@ -170,6 +171,7 @@ inline void Chunk::stageBFromDevice() {
                         const uint32_t m = z.sb_hapmask.h[hap0 + h];
                         for (int i = 0; i < vn; ++i) if (m >> i & 1u) w.haps[(size_t)h].variants.push_back(w.vars[(size_t)i]);
                     }
+                    { PROF("s5.build"); prePosterior.add(r, w, false); }  // (the posterior kernel's inputs for this window, while it is in the caches)
                 }
             }
         }

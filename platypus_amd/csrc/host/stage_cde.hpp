@@ -34,30 +34,16 @@ inline void Chunk::callWindows(std::vector<WindowWork*>& wins, bool fromDevice) 
     // given depends on the windows alone: it is put together and launched behind the batch (same stream), and the batch's one wait covers it
     size_t nV = 0;
     const std::function<void(DeviceBatch&)> posteriors = [&](DeviceBatch& dbb) {
-        std::vector<int32_t> pwin;
-        std::vector<int64_t> poff{0};
-        std::vector<uint8_t> pmask;
-        std::vector<double> pprior;
-        for (WindowWork* w : wins) {
-            PROF("s5.build");
-            RegionWork& r = *regions[(size_t)regionSlot(w->region)];
-            w->distinct.clear();
-            for (const Hap& h : w->haps)
-                for (Variant* v : h.variants) if (!contains(w->distinct, v)) w->distinct.push_back(v);
-            for (Variant* v : w->distinct) {
-                pwin.push_back(w->bw);
-                for (const Hap& h : w->haps) pmask.push_back(contains(h.variants, v) ? 1 : 0);
-                poff.push_back((int64_t)pmask.size());
-                { PROF("s5.prior"); pprior.push_back(calculatePrior(*v, r.fa)); }
-            }
-            if (o.outputRefCalls)                                       // pop.calculatePosterior(v, 1) of outputRefCall: the window's candidates under a flat prior
-                for (Variant* v : w->vars) {
-                    pwin.push_back(w->bw);
-                    for (const Hap& h : w->haps) pmask.push_back(contains(h.variants, v) ? 1 : 0);
-                    poff.push_back((int64_t)pmask.size());
-                    pprior.push_back(0.5);
-                }
-        }
+        // (a device-built batch's inputs were put together window by window while stage B's output was turned into objects -- the windows were in
+        //  the caches then; this pass over a chunk's ten thousand windows is one of four the host makes, and each one starts cold)
+        PosteriorInputs local;
+        const bool pre = fromDevice && prePosterior.windows == wins.size() && !wins.empty();
+        PosteriorInputs& pi = pre ? prePosterior : local;
+        if (!pre) for (WindowWork* w : wins) { PROF("s5.build"); pi.add(*regions[(size_t)regionSlot(w->region)], *w, o.outputRefCalls != 0); }
+        std::vector<int32_t>& pwin = pi.pwin;
+        std::vector<int64_t>& poff = pi.poff;
+        std::vector<uint8_t>& pmask = pi.pmask;
+        std::vector<double>& pprior = pi.pprior;
         nV = pwin.size();
         if (!nV) return;
         Layout L;
