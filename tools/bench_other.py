@@ -87,6 +87,26 @@ def config5(eng, n_windows, n_ind, steps, warmup, seed=5005, rk=None, weak=False
                 dp_jobs=int(prof[-1].dp_jobs))
 
 
+def config5_end_to_end(device, n_regions=48, region_len=5000, n_samples=100, rk=None, first=0, lib=None):
+    """BASELINE config 5 END TO END (round 6): regions of 100 samples at 30x each through the native region loop (plat_call_regions_stream) -- candidates of
+    every sample's reads, the cohort's windows and haplotypes (HOST stage B: the device stage takes one sample), one likelihood batch of windows x 100 samples,
+    EM over the cohort, posteriors, per-sample genotype calls, records with 100 sample columns.  Regions loaded on demand (the reads of 100 samples are
+    45 MB per 5 kb region as packed bytes)."""
+    from platypus_amd import fastcaller as F
+    workers = int(os.environ.get("PLAT_CALLER_WORKERS5", "8"))
+    r = config4(device, range(first, first + n_regions), region_len, workers, int(os.environ.get("PLAT_CALLER_CHUNK5", "2")), repeats=2, n_samples=n_samples,
+                rk=rk, lib=lib, pin=lib is None, resident=False, region_kw=dict(flank=1000))
+    st, T = r["stats"], r["T"]
+    out = dict(regions=r["regions"], region_len=region_len, n_samples=n_samples, reads=r["reads"], windows=r["windows"], records=r["records"], pairs=int(st["n_pairs"]),
+               timed_s=T, windows_per_sec=r["windows"] / T, regions_per_sec=r["regions"] / T, reads_per_sec=r["reads"] / T,
+               host_seconds_per_region=st["seconds_host"] / r["regions"], device_wait_seconds_per_region=st["seconds_device_wait"] / r["regions"],
+               host_threads=r["workers"], regions_per_chunk=r["per_chunk"], inputs="loaded on demand inside the timed region",
+               stage_b={"regions_on_the_device": int(st.get("n_regions_stage_b_device", 0)), "regions_left_to_the_host": int(st.get("n_regions_stage_b_host", 0)),
+                        "why": "plat_stage_b_batch takes one-sample regions: a cohort's variants / windows / haplotypes are made by host/stage_b_host.hpp"})
+    out.update({k: v for k, v in config4_gcups(r.get("counted"), r["regions"], T).items() if k in ("gcups", "gcups_executed", "dp_reference", "dp_launched", "pairs")})
+    return out
+
+
 def line_config5(a, rk):
     from platypus_amd.engine import Engine
     rank, world = rk.rank, rk.world
@@ -105,6 +125,7 @@ def line_config5(a, rk):
                        "windows_per_gpu": nwin, "n_ind": 100, "reads_per_step": hb.n_reads, "pairs_per_step": hb.n_pairs},
             "windows_per_sec": nw / T, "gcups_executed": run / T / 1e9, "kernel_ms": r["kernel_ms"],
             "em_iterations_mean": r["em_iterations_mean"], "em_iterations_max": r["em_iterations_max"],
+            "end_to_end": None if getattr(a, "no_extras", False) else config5_end_to_end(rk.dev_index, rk=rk, first=rank * 48),
             "roofline": {"bound": "hbm", "kernel": "k_dp_jobs", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": r["dp_alg_bytes"],
                          "avg_launch_ms": dp_ms}}
@@ -587,6 +608,10 @@ def summary(eng):
                                      windows_per_sec=hb.n_windows * r["steps"] / r["T"], kernel_ms=r["kernel_ms"],
                                      em_iterations_mean=r["em_iterations_mean"],
                                      roofline=_roof("k_dp_jobs", r["dp_alg_bytes"], r["kernel_ms"]["dp"], "VALU-issue bound, see DESIGN.md"))
+    try:
+        out["config5_population"]["end_to_end"] = config5_end_to_end(0)
+    except Exception as exc:                                  # pragma: no cover
+        out["config5_population"]["end_to_end"] = {"error": repr(exc)[:200]}
     # the same geometry with weak evidence (1x, mostly low-quality bases): the EM iterates
     r = config5(eng, 200, 100, 10, 2, weak=True)
     st, hb = r["st"], r["hb"]
