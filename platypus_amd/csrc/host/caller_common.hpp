@@ -113,7 +113,9 @@ template <class T> struct Staged {
 };
 typedef Staged<uint8_t> Arena;
 
+struct SparePools;                                                         // window / Variant storage a worker keeps between chunks AND calls (defined behind WindowWork)
 struct Slot {
+    SparePools* spare = nullptr;                                           // (made by the worker's first chunk, freed by plat_caller_destroy)
     plat_ctx* ctx = nullptr;
     void* stream = nullptr;
     bool countCells = false;                                               // plat_caller_count_cells: likelihood batches through the synchronous entry point
@@ -425,6 +427,10 @@ struct WindowList {
 
 // The Variants of a region: objects with stable addresses in blocks of 64 that OUTLIVE the region -- a worker hands the blocks of the regions it
 // has finished to the regions of its next chunk (Chunk::run), a recycled object is assigned to (its strings keep their storage).
+struct SparePools {
+    std::vector<std::vector<WindowWork>> windows;
+    std::vector<std::unique_ptr<Variant[]>> variants;
+};
 struct VariantPool {
     static constexpr size_t BLOCK = 64;
     std::vector<std::unique_ptr<Variant[]>> blocks;

@@ -127,10 +127,11 @@ struct Chunk {
     Clock::time_point mark;
     void lap(int k) { const auto now = Clock::now(); stage[k] += secs(mark, now); mark = now; stageWait[k] += s.t_wait - waitMark; waitMark = s.t_wait; }
 
-    // window storage of the regions this worker thread has finished, for the regions of its next chunks (WindowList)
-    static std::vector<std::vector<WindowWork>>& spareWindows() { static thread_local std::vector<std::vector<WindowWork>> spare; return spare; }
+    // window storage of the regions this worker has finished, for the regions of its next chunks (WindowList) -- kept in the worker's Slot, so
+    // that the next CALL starts with it too (the worker threads themselves live for one call)
+    std::vector<std::vector<WindowWork>>& spareWindows() { if (!s.spare) s.spare = new SparePools(); return s.spare->windows; }
 
-    static std::vector<std::unique_ptr<Variant[]>>& spareVariants() { static thread_local std::vector<std::unique_ptr<Variant[]>> spare; return spare; }
+    std::vector<std::unique_ptr<Variant[]>>& spareVariants() { if (!s.spare) s.spare = new SparePools(); return s.spare->variants; }
 
     void run() {
         // plat_caller_count_cells (the untimed counting pass of a measurement): one chunk at a time, so that the live kernel timers of its

@@ -104,6 +104,7 @@ CALLER_EXPORT int plat_caller_destroy(plat_caller* c) {
                    z.d_scratch, z.d_pairoff, z.d_gloff, z.d_hapoff, z.d_readoff, z.d_hapseq, z.d_kind, z.c_refdev);
         plat_stream_destroy(z.ctx, z.stream);
         plat_ctx_destroy(z.ctx);
+        delete z.spare; z.spare = nullptr;
     }
     delete c;
     return PLAT_OK;
