@@ -113,9 +113,9 @@ template <class T> struct Staged {
 };
 typedef Staged<uint8_t> Arena;
 
-struct SparePools;                                                         // window / Variant storage a worker keeps between chunks AND calls (defined behind WindowWork)
+struct SparePools;                                                         // window / Variant storage a worker keeps between the chunks of a call (defined behind WindowWork)
 struct Slot {
-    SparePools* spare = nullptr;                                           // (made by the worker's first chunk, freed by plat_caller_destroy)
+    SparePools* spare = nullptr;                                           // (made by the worker's first chunk of a call, freed when its chunks run out)
     plat_ctx* ctx = nullptr;
     void* stream = nullptr;
     bool countCells = false;                                               // plat_caller_count_cells: likelihood batches through the synchronous entry point

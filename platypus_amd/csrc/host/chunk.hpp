@@ -127,8 +127,8 @@ struct Chunk {
     Clock::time_point mark;
     void lap(int k) { const auto now = Clock::now(); stage[k] += secs(mark, now); mark = now; stageWait[k] += s.t_wait - waitMark; waitMark = s.t_wait; }
 
-    // window storage of the regions this worker has finished, for the regions of its next chunks (WindowList) -- kept in the worker's Slot, so
-    // that the next CALL starts with it too (the worker threads themselves live for one call)
+    // window storage of the regions this worker has finished, for the regions of its next chunks (WindowList) -- in the worker's Slot; the worker
+    // frees it when the call's chunks run out (region_caller.cpp: keeping it for the next call measured slower)
     std::vector<std::vector<WindowWork>>& spareWindows() { if (!s.spare) s.spare = new SparePools(); return s.spare->windows; }
 
     std::vector<std::unique_ptr<Variant[]>>& spareVariants() { if (!s.spare) s.spare = new SparePools(); return s.spare->variants; }

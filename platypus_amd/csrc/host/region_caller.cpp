@@ -322,6 +322,11 @@ static int runWorkers(plat_caller* c, Feed& feed, std::atomic<bool>& failed, con
             }
             feed.done(regs);
         }
+        // every worker frees its own spare storage when it runs out of chunks.  Keeping it for the next CALL (PLAT_CALLER_KEEP_SPARE=1) measured SLOWER on the
+        // whole-genome job: 5.8-6.1 M windows/s against 6.5-6.6 M, 0.207 against 0.172 ms of worker CPU per region -- the next call's worker is a new thread,
+        // often on the other NUMA node, and inherits ten thousand cold windows; freeing them all on one thread at the end of the call: 5.0 M
+        static const bool keep = [] { const char* e = getenv("PLAT_CALLER_KEEP_SPARE"); return e && e[0] == '1'; }();
+        if (!keep) { delete slot->spare; slot->spare = nullptr; }
     };
     nThreads = std::max(1, std::min<int>((int)c->slots.size(), nThreads));
     for (auto& q : c->slots) {

@@ -527,6 +527,13 @@ class Engine:
         _lib.check(self.lib.plat_profile_last(self.ctx, C.byref(p)), "plat_profile_last")
         return p
 
+    def kernel_times(self):
+        """{kernel name: (summed ms, launches)} of the launches bracketed since the profile was switched on / the last call (plat_kernel_times)."""
+        ms = (C.c_double * 32)()
+        n = (C.c_int64 * 32)()
+        _lib.check(self.lib.plat_kernel_times(self.ctx, ms, n), "plat_kernel_times")
+        return {(self.lib.plat_kernel_timer_name(i) or b"?").decode(): (float(ms[i]), int(n[i])) for i in range(32) if n[i]}
+
     def synchronize(self):
         """Waits for the stream and raises the first error an asynchronous call recorded since the last synchronize()."""
         _lib.check(self.lib.plat_stream_sync(self.ctx, self._stream()), "plat_stream_sync")

@@ -280,3 +280,32 @@ def test_vcf_records_end_to_end_match_reference_golden(golden_dir, oracle):
         assert out.getvalue().split("\n")[:-1] == c["lines"]
         nlines += len(c["lines"])
     assert nlines > 50
+
+
+@pytest.mark.gpu
+def test_every_kernel_of_a_call_is_timed_and_the_poll_interval_is_checked():
+    """Round 6: plat_kernel_times brackets every launch of the calls made while the profile is on (bench.py's roofline kernel is chosen from these
+    sums); plat_sync_poll_us takes an interval and refuses a negative one; a wait with a long interval still returns the batch's results."""
+    import numpy as np
+    from platypus_amd import synth, _lib
+    from platypus_amd.engine import Engine
+    eng = Engine(0)
+    hb = synth.config2(300, seed=77)
+    db = eng.upload(hb)
+    eng.call_windows(db, want_stats=False)
+    eng.synchronize()
+    want = db.score.cpu().numpy()[:hb.n_pairs].copy()
+    eng.profile_enable(True)
+    for _ in range(3):
+        eng.call_windows(db, want_stats=False, asynchronous=True)
+    eng.synchronize()
+    t = eng.kernel_times()
+    eng.profile_enable(False)
+    for k in ("k_prep_reads", "k_sweep", "k_pairs", "k_seed_slow", "k_dp_jobs", "k_finalize", "k_genotype"):
+        assert t[k][1] == 3 and 0.0 < t[k][0] < 50.0, (k, t.get(k))
+    assert eng.kernel_times() == {}                                             # resolved pairs are handed out once
+    assert eng.lib.plat_sync_poll_us(eng.ctx, -1) == -1 and eng.lib.plat_sync_poll_us(eng.ctx, 2000) == 0
+    eng.call_windows(db, want_stats=False, asynchronous=True)
+    eng.synchronize()
+    assert np.array_equal(db.score.cpu().numpy()[:hb.n_pairs], want)
+    assert eng.lib.plat_sync_poll_us(eng.ctx, 40) == 0
