@@ -515,10 +515,17 @@ def line_config2(a, rk):
             except Exception:
                 pm = {}
 
-        # the PMC figures are NOT collected by this run (counters need rocprofv3 around the process): they are the last committed pass
+        # the PMC figures are NOT collected by this run (counters need rocprofv3 around the process): they are the last committed pass -- and they are
+        # quoted only when that pass was made from THESE kernel sources (hash of csrc/*.hip, *.hpp, Makefile); otherwise traffic is null and says why
         meas = pm.get("measured") or {}
-        traffic_source = None if not pm else "not measured in this run: profiles/dp_traffic.json <- %s; collected %s at commit %s (tools/profile_round.sh)" % (
-            pm.get("source", "rocprofv3 --pmc passes"), meas.get("date", "in round %s" % pm.get("round", "?")), meas.get("commit", "?"))
+        from tools import bench_other as _bo
+        here = _bo.kernel_source_hash()
+        if pm and pm.get("kernel_source_hash") != here:
+            traffic_source = "null: profiles/dp_traffic.json was collected from other kernel sources (hash %s, this build %s) -- counters are never collected by this run" % (pm.get("kernel_source_hash"), here)
+            pm = {}
+        else:
+            traffic_source = None if not pm else "not measured in this run: profiles/dp_traffic.json <- %s; collected %s at commit %s (tools/profile_round.sh): same kernel sources as this build (hash %s)" % (
+                pm.get("source", "rocprofv3 --pmc passes"), meas.get("date", "in round %s" % pm.get("round", "?")), meas.get("commit", "?"), here)
 
         def entry(kernel, alg_bytes, ms, counters, note):
             ach = alg_bytes / (ms * 1e-3) / 1e9

@@ -579,6 +579,8 @@ def _asm_traffic(nreg):
     figure of the last profiled run is quoted (scaled to this launch's regions), never measured here."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "dp_traffic.json")))["k_assemble"]
+        if d.get("kernel_source_hash") != kernel_source_hash():
+            return None, "null: profiles/dp_traffic.json's k_assemble counters were collected from other kernel sources (hash %s, this build %s)" % (d.get("kernel_source_hash"), kernel_source_hash())
         per = float(d["hbm_bytes_per_launch"]) / float(d["regions_per_launch"])
         m = d.get("measured", {})
         return int(per * nreg), "not measured in this run: profiles/dp_traffic.json <- profiles/r%02d_pmc_assemble.txt (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, %d tiles per launch); collected %s at commit %s" % (

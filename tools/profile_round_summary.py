@@ -163,7 +163,10 @@ def main(o, tag):
     except Exception:
         commit = os.environ.get("PLAT_COMMIT")                          # (the GPU box holds a snapshot without .git: the caller passes it)
     stamp = {"date": datetime.date.today().isoformat(), "commit": commit, "round": int(tag[1:])}
+    sys.path.insert(0, ROOT)
+    from tools import bench_other
     if per:
+        d["kernel_source_hash"] = bench_other.kernel_source_hash()      # (bench.py quotes these counters only for a build of the same kernel sources)
         d.update(kernel="k_dp_jobs", **pack(per["plat::k_dp_jobs<false>"]))
         d["source"] = "profiles/" + tag + "_pmc_hbm.txt (rocprofv3 --pmc, separate passes: FETCH_SIZE, WRITE_SIZE raw counters x 1024; SQ_INSTS_VALU; GRBM_GUI_ACTIVE / 8 XCDs)"
         for kn in ("k_seed", "k_sweep", "k_pairs"):
@@ -178,6 +181,7 @@ def main(o, tag):
         d["k_assemble"] = pack(per3["plat::k_assemble"])
         d["k_assemble"]["regions_per_launch"] = 2000
         d["k_assemble"]["measured"] = stamp
+        d["k_assemble"]["kernel_source_hash"] = bench_other.kernel_source_hash()
         if "SQ_WAIT_ANY" in per3["plat::k_assemble"]:
             k = per3["plat::k_assemble"]
             d["k_assemble"]["wait_any_over_wave_cycles"] = k["SQ_WAIT_ANY"] / max(1.0, k["SQ_WAVE_CYCLES"])
