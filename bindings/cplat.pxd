@@ -70,6 +70,7 @@ cdef extern from "platypus_mi355x.h":
     int plat_sync_poll_us(plat_ctx* ctx, int microseconds) nogil
     const char* plat_kernel_timer_name(int id) nogil
     int plat_kernel_times(plat_ctx* ctx, double* out_ms, int64_t* out_launches) nogil
+    int plat_kernel_timer_only(plat_ctx* ctx, int id) nogil
 
     # ---- fastAlignmentRoutine, score only (src/c/align.h:8-10)
     int plat_dp_batch(plat_ctx* ctx, int n, int lmax, const uint8_t* hap_slices, const uint8_t* reads, const uint8_t* quals,
@@ -259,6 +260,14 @@ cdef extern from "platypus_mi355x.h":
     int plat_unpack_reads_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual,
                                  int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream) nogil
 
+    int plat_unpack_reads_pieces_codes(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual,
+                                       uint32_t* out_codes, int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base,
+                                       const uint8_t* exc_qual, void* stream) nogil
+    int plat_ref_codes(plat_ctx* ctx, int n_regions, const uint8_t* ref_seq, const int64_t* ref_off, int64_t n_bytes, uint32_t* out_codes,
+                       int32_t* out_irregular, void* stream) nogil
+    int plat_candidates_batch_codes(plat_ctx* ctx, const plat_candidate_batch* batch, const uint32_t* read_codes, const uint32_t* ref_codes,
+                                    const int32_t* ref_irregular, int min_flank, int min_base_qual, int gen_snps, int gen_indels, int max_per_read,
+                                    const int32_t* read_region, int32_t* out_rec, int32_t* out_count, int32_t* out_status, void* stream) nogil
     int plat_copy_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* dst_blob, void* stream) nogil
 
     # ---- a chunk's read table from tables resident on the device

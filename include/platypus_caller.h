@@ -180,6 +180,9 @@ int plat_caller_destroy(plat_caller* c);
  * the reference's DPs and band cells (same results, two small read-backs per batch: not for timed runs); the sums are left in
  * plat_caller_stats.  Off (default) = the asynchronous entry point, nothing counted. */
 int plat_caller_count_cells(plat_caller* c, int on);
+/* Measurement switch: the calls that follow time ONE kernel of the loop (id = PLAT_KT_* of platypus_mi355x.h; < 0: none) with HIP events around its
+ * launches, inside the ordinary asynchronous calls: stats.kernel_ms[id] / kernel_launches[id] then hold its summed duration and launches. */
+int plat_caller_time_kernel(plat_caller* c, int id);
 /* Calls every region; the record lines of all regions, in region order, are returned as one malloc'ed,
  * NUL-terminated buffer (*out_text, *out_len without the NUL; free with plat_caller_free).  options->rlen is
  * left at the last region's value, as after the reference's last callVariantsInRegion. */

@@ -114,6 +114,9 @@ enum {
 };
 const char* plat_kernel_timer_name(int id);                 /* "k_candidates", ...; NULL outside 0 .. PLAT_KT_COUNT-1 */
 int plat_kernel_times(plat_ctx* ctx, double* out_ms, int64_t* out_launches);   /* [syncs] */
+/* ONE kernel timed while the profile is off (id < 0: none): two events per launch of that kernel, nothing else changes -- how bench.py times the
+ * line's roofline kernel INSIDE its timed region, next to whatever shares the chip with it there.                                              */
+int plat_kernel_timer_only(plat_ctx* ctx, int id);
 
 /* ---- a1: fastAlignmentRoutine, score only -------------------------------------------------------
  * Replaces  int fastAlignmentRoutine(seq1, seq2, qual2, len1, len2, gapextend, nucprior,
@@ -351,6 +354,25 @@ int plat_candidates_merge_batch(plat_ctx* ctx, const plat_candidate_batch* batch
 typedef struct plat_unpack_piece { const uint8_t* src; int64_t dst, n; } plat_unpack_piece;
 int plat_unpack_reads_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual,
                              int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream);
+
+/* The scan on 2-bit base codes (round 6).  A code is (ASCII >> 1) & 3: A 0, C 1, T 2, G 3 (N counts as 3); base i of a blob sits at bits
+ * 2 (i & 15) of dword i >> 4.  Equal bytes have equal codes, so the mismatch scan of plat_candidates_batch can compare 32 bases per 64-bit word
+ * and look at bytes only where codes differ -- the same records as long as a position with equal codes and different bytes can only be one the
+ * reference's loop ignores: true when the reads hold A, C, G, T, N only (THE CALLER'S PROMISE for the read blob; what a PLAT_READS_PACKED
+ * table expands to unless an exception carries another byte) and for every reference region without other bytes (found here: the others
+ * are scanned byte by byte).
+ *   plat_unpack_reads_pieces_codes  = plat_unpack_reads_pieces + out_codes[(total_bytes + 15) / 16 + 8] (zeroed and filled by the call)
+ *   plat_ref_codes                  codes of the reference blob (n_bytes = ref_off[n_regions]; out_codes[(n_bytes + 15) / 16 + 8]) and
+ *                                   out_irregular[g] = 1 where region g holds a byte other than A, C, G, T, N
+ *   plat_candidates_batch_codes     = plat_candidates_batch on them (both code buffers 8-byte aligned)                                       */
+int plat_unpack_reads_pieces_codes(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual,
+                                   uint32_t* out_codes, int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base,
+                                   const uint8_t* exc_qual, void* stream);
+int plat_ref_codes(plat_ctx* ctx, int n_regions, const uint8_t* ref_seq, const int64_t* ref_off, int64_t n_bytes, uint32_t* out_codes,
+                   int32_t* out_irregular, void* stream);
+int plat_candidates_batch_codes(plat_ctx* ctx, const plat_candidate_batch* batch, const uint32_t* read_codes, const uint32_t* ref_codes,
+                                const int32_t* ref_irregular, int min_flank, int min_base_qual, int gen_snps, int gen_indels, int max_per_read,
+                                const int32_t* read_region, int32_t* out_rec, int32_t* out_count, int32_t* out_status, void* stream);
 
 /* n pieces of device memory copied into one blob in ONE launch: piece k = n bytes at src -> dst_blob[dst, dst + n) (any alignment).
  * `pieces` is device memory (the struct of plat_unpack_reads_pieces).                                                              */

@@ -120,6 +120,7 @@ SIGNATURES = {
     "plat_sync_poll_us": (C.c_int, [C.c_void_p, C.c_int]),
     "plat_kernel_timer_name": (C.c_char_p, [C.c_int]),
     "plat_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "plat_kernel_timer_only": (C.c_int, [C.c_void_p, C.c_int]),
     "plat_dp_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "plat_align_window_batch": (C.c_int, [C.c_void_p, C.POINTER(WindowBatch), C.c_int, C.c_int, C.c_void_p,
@@ -142,6 +143,11 @@ SIGNATURES = {
     "plat_stage_b_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_unpack_reads_pieces": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
+    "plat_unpack_reads_pieces_codes": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "plat_ref_codes": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "plat_candidates_batch_codes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_copy_pieces": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plat_concat_read_tables": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_int64] * 3 + [C.c_void_p]),
     "plat_read_qc_batch": (C.c_int, [C.c_void_p, C.POINTER(ReadQCBatch), C.POINTER(ReadQCOptions), C.c_void_p, C.c_void_p, C.c_void_p]),

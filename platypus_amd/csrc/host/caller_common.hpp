@@ -119,6 +119,7 @@ struct Slot {
     plat_ctx* ctx = nullptr;
     void* stream = nullptr;
     bool countCells = false;                                               // plat_caller_count_cells: likelihood batches through the synchronous entry point
+    int timeKernel = -1;                                                   // plat_caller_time_kernel: this kernel's launches are timed in the ordinary calls
     int64_t nDpRef = 0, cellsRef = 0, nDpRun = 0, cellsRun = 0;            // ... and their plat_align_stats summed (this worker's share)
     int64_t nAlign = 0, alignHapBytes = 0, alignReadBytes = 0, alignReads = 0, alignDpBytes = 0;
     double secSeed = 0.0, secDp = 0.0, secSweep = 0.0, secPairs = 0.0, secUnpack = 0.0, secCand = 0.0;
@@ -136,6 +137,8 @@ struct Slot {
     Staged<int16_t> t_cigar;
     // candidate scan
     Staged<uint8_t> c_ref, c_refdev;
+    Staged<uint32_t> t_codes, c_refcodes;                                   // 2-bit base codes of the chunk's read blob / reference blob (the scan on codes, round 6)
+    Staged<int32_t> c_refirr;                                               // per scan: the reference window holds a byte other than A, C, G, T, N
     Staged<plat_unpack_piece> c_pieces;
     Staged<int64_t> c_refoff;
     Staged<int32_t> c_rss, c_clen, c_rec, c_cnt, c_status, c_scanbegin, c_scanlongest, m_cand, m_n;

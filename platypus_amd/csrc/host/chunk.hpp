@@ -99,6 +99,7 @@ struct Chunk {
 
     void regionVariants(RegionWork& r, int scan0);
     bool recordsOnHost = false;
+    bool readCodes = false;                                                 // the chunk's read blob has its 2-bit codes in s.t_codes (every table packed, exceptions A/C/G/T/N only)
     int64_t tabPackedBytes = 0, tabBlobBytes = 0;                          // this chunk's table: packed bytes expanded on the device, bytes of bases in all
     size_t recArenaBytes = 0;
 
@@ -162,8 +163,10 @@ struct Chunk {
             memset(&pf, 0, sizeof pf);
             ck(plat_profile_last(s.ctx, &pf), "plat_profile_last");
             if (getenv("PLAT_CALLER_TRACE")) fprintf(stderr, "[plat_caller] table kernels: unpack %.3f ms (%lld packed bytes), candidates %.3f ms (%lld bytes)\n", pf.ms_unpack, (long long)tabPackedBytes, pf.ms_candidates, (long long)tabBlobBytes);
-            if (pf.ms_unpack > 0) { s.secUnpack += 1e-3 * pf.ms_unpack; s.unpackBytes += 3 * tabPackedBytes; s.nUnpack += 1; }      // one byte in, two out per base
-            if (pf.ms_candidates > 0) { s.secCand += 1e-3 * pf.ms_candidates; s.candBytes += tabBlobBytes; s.nCand += 1; }           // the bases once: what the scan has to read
+            // one byte in, two out per base (+ a quarter: the 2-bit codes, when the chunk has them); the scan has to read the bases once: as 2-bit codes when it
+            // runs on them (qualities and bytes only where codes differ), as bytes otherwise
+            if (pf.ms_unpack > 0) { s.secUnpack += 1e-3 * pf.ms_unpack; s.unpackBytes += 3 * tabPackedBytes + (readCodes ? tabPackedBytes / 4 : 0); s.nUnpack += 1; }
+            if (pf.ms_candidates > 0) { s.secCand += 1e-3 * pf.ms_candidates; s.candBytes += readCodes ? tabBlobBytes / 4 : tabBlobBytes; s.nCand += 1; }
         }
         assembleCollect();
         lap(1);
@@ -272,7 +275,7 @@ struct Chunk {
         if (s.countCells) {                                                 // every kernel of this chunk, live (HIP events around each launch)
             ck(plat_kernel_times(s.ctx, s.ktMs, s.ktLaunches), "plat_kernel_times");
             ck(plat_profile_enable(s.ctx, 0), "plat_profile_enable");
-        }
+        } else if (s.timeKernel >= 0) ck(plat_kernel_times(s.ctx, s.ktMs, s.ktLaunches), "plat_kernel_times");   // (one kernel, timed inside the ordinary run: its launches are over)
         const double total = secs(t0, Clock::now()), waited = s.t_wait - wait0;
         std::lock_guard<std::mutex> g(stMutex);
         st.n_windows += nWin; st.n_variants += nVar; st.n_candidate_records += nCand; st.n_records += nRec; st.n_refcall_records += nRef;

@@ -41,6 +41,7 @@ using namespace plathost;
 struct plat_caller {
     int device = 0, nWorkers = 1, regionsPerChunk = 4;
     bool countCells = false;
+    int timeKernel = -1;                                                    // plat_caller_time_kernel
     std::vector<std::unique_ptr<Slot>> slots;
     std::string lastError;
     std::vector<int64_t> lastLengths;                                       // bytes of record text of every region of the last call, in list order
@@ -90,6 +91,13 @@ CALLER_EXPORT int plat_caller_count_cells(plat_caller* c, int on) {
     return PLAT_OK;
 }
 
+CALLER_EXPORT int plat_caller_time_kernel(plat_caller* c, int id) {
+    if (!c || id >= PLAT_KT_COUNT) return PLAT_ERR_INVALID;
+    c->timeKernel = id < 0 ? -1 : id;
+    for (auto& q : c->slots) { q->timeKernel = c->timeKernel; plat_kernel_timer_only(q->ctx, c->timeKernel); }
+    return PLAT_OK;
+}
+
 CALLER_EXPORT int plat_caller_destroy(plat_caller* c) {
     if (!c) return PLAT_ERR_INVALID;
     for (auto& q : c->slots) {
@@ -101,7 +109,7 @@ CALLER_EXPORT int plat_caller_destroy(plat_caller* c) {
                    z.s_gb, z.s_ge, z.s_bb, z.s_be, z.s_ps, z.s_minq, z.s_nminq, z.k_win, z.k_nvar, z.k_vih, z.k_ref, z.k_ph, z.p_off, z.s_aoff, z.s_moff, z.s_counts,
                    z.k_vo, z.k_ro, z.k_lo, z.p_mask, z.s_added, z.s_vig, z.p_prior, z.p_post, z.k_lik, z.k_out4, z.t_pack, z.as_seq, z.as_qual, z.as_mapq, z.as_pos, z.as_end, z.as_flags, z.a_asin, z.a_asout, z.a_tab, z.a_cin, z.a_cout, z.a_mout, z.c_scanbegin, z.c_scanlongest, z.m_cand, z.m_n, z.a_win, z.a_wout,
                    z.a_pin, z.a_sin, z.a_sout, z.a_bin, z.a_bout, z.a_desc, z.d_hapbegin, z.d_readbegin, z.d_start, z.d_end, z.d_flank, z.d_segbegin, z.d_ngood, z.d_src,
-                   z.d_scratch, z.d_pairoff, z.d_gloff, z.d_hapoff, z.d_readoff, z.d_hapseq, z.d_kind, z.c_refdev);
+                   z.d_scratch, z.d_pairoff, z.d_gloff, z.d_hapoff, z.d_readoff, z.d_hapseq, z.d_kind, z.c_refdev, z.t_codes, z.c_refcodes, z.c_refirr);
         plat_stream_destroy(z.ctx, z.stream);
         plat_ctx_destroy(z.ctx);
         delete z.spare; z.spare = nullptr;

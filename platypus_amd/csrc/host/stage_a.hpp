@@ -8,7 +8,7 @@ namespace plathost {
 // -- A: one device table for every read of the chunk; layout: all `reads` of every (region, sample), then all badReads, then all brokenMates
 inline void Chunk::uploadReads() {
     size_t nReads[3] = {0, 0, 0}, nBytes[3] = {0, 0, 0}, nCig[3] = {0, 0, 0}, nExc = 0;
-    bool anyPacked = false;
+    bool anyPacked = false, allPacked = true, excRegular = true;
     for (RegionWork* r : regions)
         for (SampleView& sv : r->samples) {
             TableView* tv[3] = {&sv.reads, &sv.bad, &sv.broken};
@@ -19,6 +19,7 @@ inline void Chunk::uploadReads() {
                 nCig[k] += (size_t)t.cig_off[t.n_reads];
                 if (t.encoding == PLAT_READS_PACKED) { anyPacked = true; nExc += (size_t)std::max<int64_t>(t.n_exceptions, 0); }
                 else if (t.encoding != PLAT_READS_ASCII) throw DeviceError(PLAT_ERR_INVALID, "plat_read_table.encoding");
+                else if (t.n_reads) allPacked = false;
             }
         }
     // (tables lie back to back in the chunk blob: read i's bytes are [t_off[i], t_off[i + 1]) for every consumer.  A packed table that is
@@ -68,7 +69,11 @@ inline void Chunk::uploadReads() {
                     // every packed table of the chunk is expanded by ONE launch (plat_unpack_reads_pieces): tables that follow each other in
                     // t_pack join into one piece; exceptions are indexed from the chunk blob's first byte
                     const bool joins = !t.dev_seq && !packed.empty() && !packed.back().dev && packed.back().bo + packed.back().nb == bo;
-                    for (size_t e = 0; e < ne; ++e) { z.t_excidx.h[eo + e] = t.exc_index[e] + (int64_t)bo; z.t_excb.h[eo + e] = t.exc_base[e]; z.t_excq.h[eo + e] = t.exc_qual[e]; }
+                    for (size_t e = 0; e < ne; ++e) {
+                        z.t_excidx.h[eo + e] = t.exc_index[e] + (int64_t)bo; z.t_excb.h[eo + e] = t.exc_base[e]; z.t_excq.h[eo + e] = t.exc_qual[e];
+                        const uint8_t eb = t.exc_base[e];
+                        excRegular = excRegular && (eb == 'A' || eb == 'C' || eb == 'G' || eb == 'T' || eb == 'N');
+                    }
                     if (joins) { packed.back().nb += nb; packed.back().ne += ne; }
                     else packed.push_back(Pending{bo, nb, eo, ne, t.dev_seq});
                     eo += ne; inBytes += (t.dev_seq ? 0 : nb) + 10 * ne;
@@ -126,8 +131,20 @@ inline void Chunk::uploadReads() {
             most = std::max(most, p.nb);
         }
         ck(plat_memcpy_h2d(z.ctx, z.t_pieces.d, z.t_pieces.h, packed.size() * sizeof(plat_unpack_piece), z.stream), "plat_memcpy_h2d(pieces)");
-        ck(plat_unpack_reads_pieces(z.ctx, (int)packed.size(), (int64_t)most, z.t_pieces.d, z.t_seq.d, z.t_qual.d, (int64_t)bo, (int64_t)eo, z.t_excidx.d, z.t_excb.d,
-                                    z.t_excq.d, z.stream), "plat_unpack_reads_pieces");
+        // the bases' 2-bit codes next to the bytes when every read of the chunk comes out of a packed table and no exception carries a byte other than
+        // A, C, G, T, N (the promise plat_candidates_batch_codes asks for); a device library without the entry point: the byte scan
+        static const bool noCodes = getenv("PLAT_CALLER_NO_CODES") != nullptr;         // (measurements / tests: the byte scan)
+        int rcu = PLAT_ERR_UNSUPPORTED;
+        if (allPacked && excRegular && !noCodes) {
+            z.t_codes.reserve(z.ctx, (bo + 15) / 16 + 16, false);
+            rcu = plat_unpack_reads_pieces_codes(z.ctx, (int)packed.size(), (int64_t)most, z.t_pieces.d, z.t_seq.d, z.t_qual.d, z.t_codes.d, (int64_t)bo, (int64_t)eo,
+                                                 z.t_excidx.d, z.t_excb.d, z.t_excq.d, z.stream);
+            if (rcu != PLAT_ERR_UNSUPPORTED) ck(rcu, "plat_unpack_reads_pieces_codes");
+        }
+        readCodes = rcu == PLAT_OK;
+        if (!readCodes)
+            ck(plat_unpack_reads_pieces(z.ctx, (int)packed.size(), (int64_t)most, z.t_pieces.d, z.t_seq.d, z.t_qual.d, (int64_t)bo, (int64_t)eo, z.t_excidx.d, z.t_excb.d,
+                                        z.t_excq.d, z.stream), "plat_unpack_reads_pieces");
         for (const Pending& p : packed) tabPackedBytes += (int64_t)p.nb;
     }
     tabBlobBytes = (int64_t)bo;
@@ -200,8 +217,18 @@ inline void Chunk::scanCandidates() {
         LO.add(z.c_cnt, nGood); LO.add(z.c_status, nGood); LO.add(z.c_rec, nGood * (size_t)maxPerRead * 5);
         LO.commit(z, z.a_cout);
         recArenaBytes = LO.total; recordsOnHost = false;
-        ck(plat_candidates_batch(z.ctx, &cb, o.minFlank, o.minBaseQual, o.genSNPs, o.genIndels, maxPerRead, z.t_region.d, z.c_rec.d, z.c_cnt.d,
-                                 z.c_status.d, z.stream), "plat_candidates_batch");
+        int rcs = PLAT_ERR_UNSUPPORTED;
+        if (readCodes) {                                                // the scan on 2-bit codes: the reference blob's codes first (a few MB per chunk)
+            z.c_refcodes.reserve(z.ctx, (blobLen + 15) / 16 + 16, false); z.c_refirr.reserve(z.ctx, (size_t)nScan + 1, false);
+            rcs = plat_ref_codes(z.ctx, nScan, refDev, z.c_refoff.d, (int64_t)blobLen, z.c_refcodes.d, z.c_refirr.d, z.stream);
+            if (rcs == PLAT_OK)
+                rcs = plat_candidates_batch_codes(z.ctx, &cb, z.t_codes.d, z.c_refcodes.d, z.c_refirr.d, o.minFlank, o.minBaseQual, o.genSNPs, o.genIndels, maxPerRead,
+                                                  z.t_region.d, z.c_rec.d, z.c_cnt.d, z.c_status.d, z.stream);
+            if (rcs != PLAT_ERR_UNSUPPORTED) ck(rcs, "plat_candidates_batch_codes");
+        }
+        if (rcs != PLAT_OK)
+            ck(plat_candidates_batch(z.ctx, &cb, o.minFlank, o.minBaseQual, o.genSNPs, o.genIndels, maxPerRead, z.t_region.d, z.c_rec.d, z.c_cnt.d,
+                                     z.c_status.d, z.stream), "plat_candidates_batch");
         int need = 0;
         if (!hostTally) {
             // addVariantToList + the per-sample support filter on the device (variant.pyx:499-527, variantcaller.pyx:456-467)

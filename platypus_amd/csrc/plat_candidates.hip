@@ -159,6 +159,209 @@ k_candidates(plat_candidate_batch b, int min_flank, int min_base_qual, int gen_s
     status[r] = st;
 }
 
+// ---- the scan on 2-bit base codes (round 6) --------------------------------------------------------------------------------------------
+// k_candidates walks a read 8 bases per 64-bit word, 40 scattered loads for 150 bases and the same again for the reference: 1.07 GB of traffic
+// per chunk of 128 regions against the 0.42 GB it has to read.  Equal bases have equal codes, so the mismatch scan can run on the codes -- 32 bases
+// per word, one aligned load each for read and reference, the whole read in ONE round of loads -- and look at the bytes only where the codes
+// differ: a position whose codes differ is a mismatch of the bytes or holds a byte that is not A, C, G, T (then the byte test of the
+// reference's loop decides, as before); a position whose codes are equal while its bytes differ can only hold such a byte -- an N (which the loop
+// ignores anyway: variant.pyx:560-567) or, in an "irregular" reference region (any other byte), anything: those regions take the byte scan.
+__global__ void __launch_bounds__(256)
+k_ref_codes(const uint8_t* __restrict__ ref, const int64_t* __restrict__ ref_off, int n_regions, long long n_bytes, uint32_t* __restrict__ codes,
+            int32_t* __restrict__ irregular)
+{
+    const long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x;        // one dword of codes = 16 bases
+    if (16 * d >= n_bytes) return;
+    uint32_t cw = 0;
+    bool odd = false;
+    for (int k = 0; k < 16; ++k) {
+        const long long i = 16 * d + k;
+        const unsigned b = i < n_bytes ? ref[i] : (unsigned)'A';
+        cw |= ((b >> 1) & 3u) << (2 * k);
+        odd = odd || !(b == 'A' || b == 'C' || b == 'G' || b == 'T' || b == 'N');
+    }
+    codes[d] = cw;
+    if (odd)
+        for (int k = 0; k < 16; ++k) {
+            const long long i = 16 * d + k;
+            if (i >= n_bytes) break;
+            const unsigned b = ref[i];
+            if (b == 'A' || b == 'C' || b == 'G' || b == 'T' || b == 'N') continue;
+            int lo = 0, hi = n_regions;                                           // the region this byte belongs to: ref_off[g] <= i < ref_off[g + 1]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ref_off[mid] <= i) lo = mid; else hi = mid; }
+            irregular[lo] = 1;
+        }
+}
+
+// 32 bases of a code stream from base index i (any alignment): two aligned words and a funnel shift
+__device__ __forceinline__ unsigned long long codes_at(const unsigned long long* __restrict__ c, long long i) {
+    const long long w = i >> 5;
+    const int sh = 2 * (int)(i & 31);
+    const unsigned long long lo = c[w];
+    if (sh == 0) return lo;
+    return (lo >> sh) | (c[w + 1] << (64 - sh));
+}
+
+__global__ void __launch_bounds__(64)
+k_candidates_codes(plat_candidate_batch b, const unsigned long long* __restrict__ read_codes, const unsigned long long* __restrict__ ref_codes,
+                   const int32_t* __restrict__ ref_irregular, int min_flank, int min_base_qual, int gen_snps, int gen_indels, int max_per_read,
+                   const int32_t* __restrict__ read_region, int32_t* __restrict__ rec, int32_t* __restrict__ count, int32_t* __restrict__ status)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= b.n_reads) return;
+    int st = 0;
+    CandEmit out{rec + 5ll * (long long)r * max_per_read, 0, max_per_read};
+    if (!(b.read_flags[r] & 512)) {                      // Read_IsQCFail reads are skipped, variant.pyx:729-731
+        const int g = read_region[r];
+        const long long roff = b.ref_off[g];
+        const int refLen = (int)(b.ref_off[g + 1] - roff), refSeqStart = b.ref_seq_start[g], contigLen = b.contig_len[g];
+        const bool byBytes = ref_irregular[g] != 0;      // a reference byte other than A, C, G, T, N in this region: the byte scan
+        const uint8_t* ref = b.ref_seq + roff;
+        const long long soff = b.read_off[r];
+        const uint8_t* readSeq = b.read_seq + soff;
+        const uint8_t* readQual = b.read_qual + soff;
+        const int rlen = (int)(b.read_off[r + 1] - soff);
+        const int readStart = b.read_pos[r];
+        const int16_t* ops = b.cigar + 2ll * b.cig_off[r];
+        const int cigarLength = b.cig_off[r + 1] - b.cig_off[r];
+        int refOffset = 0, readOffset = 0;
+        for (int ci = 0; ci < cigarLength; ++ci) {       // getVariantCandidatesFromSingleRead, :614-720
+            const int flag = ops[2 * ci], length = ops[2 * ci + 1];
+            if (flag == 1 || flag == 2) {                // insertion / deletion: needs a match of >= minFlank on one side
+                bool flanked = false;
+                if (ci > 0 && ops[2 * ci - 2] == 0 && ops[2 * ci - 1] >= min_flank) flanked = true;
+                else if (ci < cigarLength - 1 && ops[2 * ci + 2] == 0 && ops[2 * ci + 3] >= min_flank) flanked = true;
+                if (flag == 1) {
+                    if (flanked && gen_indels && !has_n(readSeq + readOffset, length))
+                        out.put(readStart + refOffset - 1, 0, length, -1, soff + readOffset);
+                    readOffset += length;
+                } else {
+                    if (flanked) {
+                        int a = readStart + refOffset, e = a + length;   // refFile.getSequence(rname, a, a + length): clamped to [0, contigLen - 1], fastafile.pyx:186-187
+                        if (a < 0) a = 0;
+                        if (e > contigLen - 1) e = contigLen - 1;
+                        const int n = e > a ? e - a : 0;
+                        if (a - refSeqStart < 0 || a - refSeqStart + n > refLen) st = PLAT_ERR_BAD_INPUT;   // outside the window handed over
+                        else if (gen_indels && !has_n(ref + (a - refSeqStart), n))
+                            out.put(readStart + refOffset - 1, n, 0, roff + (a - refSeqStart), -1);
+                    }
+                    refOffset += length;
+                }
+            } else if (flag == 0 || flag == 7 || flag == 8) {    // M, =, X
+                if (!(flag == 7 || (length < min_flank && flag == 0)) && gen_snps) {
+                    // getSnpCandidatesFromReadSegment, :529-612: only mismatches change the loop's state (k_candidates has the argument)
+                    int msr = -1, mer = -1, msd = -1, med = -1;
+                    int lo = (readOffset == 0) ? (min_flank < length ? min_flank : length) : 0;                  // first index looked at
+                    int hi = rlen - min_flank - readOffset;                                                       // one past the last
+                    if (hi > length) hi = length;
+                    const int refIndex0 = refOffset + readStart - refSeqStart;                                    // refIndex of index 0
+                    if (lo < hi) {
+                        if (refIndex0 + lo < 0) { st = PLAT_ERR_BAD_INPUT; hi = lo; }
+                        else if (refIndex0 + hi > refLen) { st = PLAT_ERR_BAD_INPUT; hi = refLen - refIndex0; }
+                    }
+                    const uint8_t* rp = readSeq + readOffset;
+                    const uint8_t* fp = ref + refIndex0;
+                    auto mismatch = [&](int index) {
+                        const int readIndex = index + readOffset, refIndex = refIndex0 + index;
+                        const uint8_t readChar = rp[index], refChar = fp[index];
+                        if (readChar != refChar && readChar != 'N' && refChar != 'N' && (int)readQual[readIndex] >= min_base_qual) {
+                            if (msr == -1) { msr = mer = refIndex; msd = med = readIndex; }
+                            else if (refIndex - mer <= min_flank) { mer = refIndex; med = readIndex; }
+                            else {
+                                out.put(msr + refSeqStart, mer - msr + 1, med - msd + 1, roff + msr, soff + msd);
+                                msr = mer = refIndex; msd = med = readIndex;
+                            }
+                        }
+                    };
+                    if (byBytes) {
+                        for (int index = lo; index < hi; ++index) if (rp[index] != fp[index]) mismatch(index);
+                    } else {
+                        // 32 bases per word; CODE_TRIP words (160 bases: a whole 150-base read) are requested together
+                        constexpr int CODE_TRIP = 5;
+                        const long long rb = soff + readOffset, fb = roff + refIndex0;                           // blob index of index 0, read and reference
+                        for (int index = lo; index < hi; index += 32 * CODE_TRIP) {
+                            unsigned long long x[CODE_TRIP];
+#pragma unroll
+                            for (int q = 0; q < CODE_TRIP; ++q) {
+                                const int at = index + 32 * q;
+                                x[q] = at < hi ? codes_at(read_codes, rb + at) ^ codes_at(ref_codes, fb + at) : 0ull;
+                            }
+#pragma unroll
+                            for (int q = 0; q < CODE_TRIP; ++q) {
+                                const int at = index + 32 * q, nb = hi - at;
+                                if (nb <= 0) continue;
+                                unsigned long long y = x[q];
+                                if (nb < 32) y &= (1ull << (2 * nb)) - 1ull;
+                                y = (y | (y >> 1)) & 0x5555555555555555ull;                                         // one bit per base whose codes differ
+                                while (y) {
+                                    const int j = (__ffsll((long long)y) - 1) >> 1;
+                                    mismatch(at + j);
+                                    y &= y - 1ull;
+                                }
+                            }
+                        }
+                    }
+                    if (msr != -1) out.put(msr + refSeqStart, mer - msr + 1, med - msd + 1, roff + msr, soff + msd);
+                }
+                readOffset += length;
+                refOffset += length;
+            } else if (flag == 3) {                      // N: skipped reference
+                refOffset += length;
+            } else if (flag == 4) {                      // soft clip: bases present in the read, positions were moved back
+                readOffset += length;
+                if (ci == 0) refOffset += length;
+            }                                            // H, P, anything else: nothing
+        }
+    }
+    if (out.n > max_per_read && st == 0) st = PLAT_ERR_OVERFLOW;
+    count[r] = out.n;
+    status[r] = st;
+}
+
+}  // namespace plat
+
+PLAT_EXPORT int plat_ref_codes(plat_ctx* ctx, int n_regions, const uint8_t* ref_seq, const int64_t* ref_off, int64_t n_bytes, uint32_t* out_codes,
+                               int32_t* out_irregular, void* stream)
+{
+    if (!ctx || n_regions < 0 || n_bytes < 0) return PLAT_ERR_INVALID;
+    if (n_regions == 0 || n_bytes == 0) return PLAT_OK;
+    if (!ref_seq || !ref_off || !out_codes || !out_irregular) return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    PLAT_HIP(ctx, hipMemsetAsync(out_irregular, 0, (size_t)n_regions * sizeof(int32_t), (hipStream_t)stream));
+    const long long nd = (n_bytes + 15) / 16;
+    PLAT_HIP(ctx, hipMemsetAsync(out_codes + nd, 0, 8 * sizeof(uint32_t), (hipStream_t)stream));      // (the scan reads a 64-bit word past the last base)
+    hipLaunchKernelGGL(plat::k_ref_codes, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ref_seq, ref_off, n_regions, (long long)n_bytes,
+                       out_codes, out_irregular);
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}
+
+PLAT_EXPORT int plat_candidates_batch_codes(plat_ctx* ctx, const plat_candidate_batch* batch, const uint32_t* read_codes, const uint32_t* ref_codes,
+                                            const int32_t* ref_irregular, int min_flank, int min_base_qual, int gen_snps, int gen_indels, int max_per_read,
+                                            const int32_t* read_region, int32_t* out_rec, int32_t* out_count, int32_t* out_status, void* stream)
+{
+    if (!ctx || !batch || max_per_read < 1 || min_flank < 0 || !read_codes || !ref_codes || !ref_irregular) return PLAT_ERR_INVALID;
+    if (((uintptr_t)read_codes & 7) || ((uintptr_t)ref_codes & 7)) return PLAT_ERR_INVALID;             // (read as 64-bit words)
+    const plat_candidate_batch b = *batch;
+    if (b.n_regions < 0 || b.n_reads < 0) return PLAT_ERR_INVALID;
+    if (b.n_reads == 0) return PLAT_OK;
+    if (!b.ref_seq || !b.ref_off || !b.ref_seq_start || !b.contig_len || !b.read_seq || !b.read_qual || !b.read_off ||
+        !b.read_pos || !b.read_flags || !b.cigar || !b.cig_off || !read_region || !out_rec || !out_count || !out_status)
+        return PLAT_ERR_INVALID;
+    PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    PLAT_EV_TAB(ctx, 2, (hipStream_t)stream);
+    { PLAT_KT_BEGIN(ctx, PLAT_KT_CANDIDATES, (hipStream_t)stream);
+      hipLaunchKernelGGL(plat::k_candidates_codes, dim3((unsigned)((b.n_reads + 63) / 64)), dim3(64), 0, (hipStream_t)stream, b, (const unsigned long long*)read_codes,
+                         (const unsigned long long*)ref_codes, ref_irregular, min_flank, min_base_qual, gen_snps, gen_indels, max_per_read, read_region, out_rec, out_count,
+                         out_status);
+      PLAT_KT_END(ctx, PLAT_KT_CANDIDATES, (hipStream_t)stream); }
+    PLAT_EV_TAB(ctx, 3, (hipStream_t)stream);
+    ctx->ev_valid_cand = ctx->profile;
+    PLAT_HIP(ctx, hipGetLastError());
+    return PLAT_OK;
+}
+
+namespace plat {
 }  // namespace plat
 
 PLAT_EXPORT int plat_candidates_batch(plat_ctx* ctx, const plat_candidate_batch* batch, int min_flank, int min_base_qual,
@@ -781,13 +984,18 @@ k_unpack_reads(long long n, int mis, int vec, int src_aligned, const uint8_t* __
 }
 __global__ void __launch_bounds__(256)
 k_unpack_exceptions(long long n_exc, long long n, const int64_t* __restrict__ idx, const uint8_t* __restrict__ eb, const uint8_t* __restrict__ eq,
-                    uint8_t* __restrict__ out_seq, uint8_t* __restrict__ out_qual)
+                    uint8_t* __restrict__ out_seq, uint8_t* __restrict__ out_qual, uint32_t* __restrict__ codes = nullptr)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_exc) return;
     const long long i = idx[k];
     if (i < 0 || i >= n) return;
     out_seq[i] = eb[k]; out_qual[i] = eq[k];
+    if (codes) {                                                           // the base's code follows its byte: (ASCII >> 1) & 3
+        const unsigned sh = 2u * (unsigned)(i & 15);
+        atomicAnd(&codes[i >> 4], ~(3u << sh));
+        atomicOr(&codes[i >> 4], (((unsigned)eb[k] >> 1) & 3u) << sh);
+    }
 }
 }  // namespace plat
 
@@ -816,8 +1024,12 @@ PLAT_EXPORT int plat_unpack_reads(plat_ctx* ctx, int64_t n_bytes, const uint8_t*
 namespace plat {
 // k_unpack_reads for a list of pieces: blockIdx.y = piece; lanes work on 16-byte lines of the piece's place in the output
 __global__ void __launch_bounds__(256)
-k_unpack_pieces(const plat_unpack_piece* __restrict__ pieces, uint8_t* __restrict__ out_seq, uint8_t* __restrict__ out_qual, int same_base_alignment)
+k_unpack_pieces(const plat_unpack_piece* __restrict__ pieces, uint8_t* __restrict__ out_seq, uint8_t* __restrict__ out_qual, int same_base_alignment,
+                uint32_t* __restrict__ codes)
 {
+    // codes (round 6, may be null): the bases again as 2 bits each (A 0, C 1, T 2, G 3 = the packed byte's low bits = (ASCII >> 1) & 3), base i of the
+    // blob at bits 2 (i & 15) of dword i >> 4 -- what plat_candidates_batch_codes compares 32 bases per 64-bit word.  A whole line of 16 bases is one
+    // plain store; the bases of a partial line (a piece's first and last) are OR-ed in, the buffer having been zeroed by the caller.
     const plat_unpack_piece pc = pieces[blockIdx.y];
     const uint8_t* packed = pc.src;
     uint8_t* oseq = out_seq + pc.dst;
@@ -844,37 +1056,69 @@ k_unpack_pieces(const plat_unpack_piece* __restrict__ pieces, uint8_t* __restric
             }
             *(uint4*)(oseq + i0) = make_uint4(sq[0], sq[1], sq[2], sq[3]);
             *(uint4*)(oqual + i0) = make_uint4(ql[0], ql[1], ql[2], ql[3]);
+            if (codes) {
+                uint32_t cw = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t t = w[k] & 0x03030303u;
+                    t = (t | (t >> 6)) & 0x000F000Fu;
+                    cw |= ((t | (t >> 12)) & 0xFFu) << (8 * k);
+                }
+                const long long at = pc.dst + i0;                          // blob index of the line's first base
+                if ((at & 15) == 0) codes[at >> 4] = cw;
+                else for (int k = 0; k < 16; ++k) atomicOr(&codes[(at + k) >> 4], ((cw >> (2 * k)) & 3u) << (2 * ((at + k) & 15)));
+            }
         } else {
             for (long long i = i0 < 0 ? 0 : i0; i < n && i < i0 + 16; ++i) {
                 const unsigned bb = packed[i];
                 oseq[i] = (uint8_t)((0x47544341u >> (8u * (bb & 3u))) & 0xFFu);
                 oqual[i] = (uint8_t)(bb >> 2);
+                if (codes) atomicOr(&codes[(pc.dst + i) >> 4], (bb & 3u) << (2 * ((pc.dst + i) & 15)));
             }
         }
     }
 }
 }  // namespace plat
 
+static int unpack_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual, uint32_t* out_codes,
+                         int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream);
+
 PLAT_EXPORT int plat_unpack_reads_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual,
                                          int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream)
+{
+    return unpack_pieces(ctx, n_pieces, max_piece_bytes, pieces, out_seq, out_qual, nullptr, total_bytes, n_exc, exc_index, exc_base, exc_qual, stream);
+}
+
+PLAT_EXPORT int plat_unpack_reads_pieces_codes(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual,
+                                               uint32_t* out_codes, int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base,
+                                               const uint8_t* exc_qual, void* stream)
+{
+    if (!out_codes) return PLAT_ERR_INVALID;
+    return unpack_pieces(ctx, n_pieces, max_piece_bytes, pieces, out_seq, out_qual, out_codes, total_bytes, n_exc, exc_index, exc_base, exc_qual, stream);
+}
+
+static int unpack_pieces(plat_ctx* ctx, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual, uint32_t* out_codes,
+                         int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base, const uint8_t* exc_qual, void* stream)
 {
     if (!ctx || n_pieces < 0 || max_piece_bytes < 0 || total_bytes < 0 || n_exc < 0) return PLAT_ERR_INVALID;
     if (n_pieces == 0) return PLAT_OK;
     if (!pieces || !out_seq || !out_qual || (n_exc > 0 && (!exc_index || !exc_base || !exc_qual))) return PLAT_ERR_INVALID;
     PLAT_HIP(ctx, hipSetDevice(ctx->device));
+    // (the code words of partial lines are OR-ed in: the buffer starts as zeros; + 8 words: plat_candidates_batch_codes reads a 64-bit word past the last base)
+    if (out_codes) PLAT_HIP(ctx, hipMemsetAsync(out_codes, 0, ((size_t)(total_bytes + 15) / 16 + 8) * sizeof(uint32_t), (hipStream_t)stream));
     const int same = ((uintptr_t)out_seq & 15) == ((uintptr_t)out_qual & 15);
     long long gx = (max_piece_bytes / 16 + 256) / 256;
     gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
     PLAT_EV_TAB(ctx, 0, (hipStream_t)stream);
     for (int p0 = 0; p0 < n_pieces; p0 += PLAT_GRID_Y_MAX) {      // (gridDim.y holds at most 65 535 pieces: one launch per batch of them)
         const int np = n_pieces - p0 < PLAT_GRID_Y_MAX ? n_pieces - p0 : PLAT_GRID_Y_MAX;
-        { PLAT_KT_BEGIN(ctx, PLAT_KT_UNPACK_PIECES, (hipStream_t)stream); hipLaunchKernelGGL(plat::k_unpack_pieces, dim3((unsigned)gx, (unsigned)np), dim3(256), 0, (hipStream_t)stream, pieces + p0, out_seq, out_qual, same); PLAT_KT_END(ctx, PLAT_KT_UNPACK_PIECES, (hipStream_t)stream); }
+        { PLAT_KT_BEGIN(ctx, PLAT_KT_UNPACK_PIECES, (hipStream_t)stream); hipLaunchKernelGGL(plat::k_unpack_pieces, dim3((unsigned)gx, (unsigned)np), dim3(256), 0, (hipStream_t)stream, pieces + p0, out_seq, out_qual, same, out_codes); PLAT_KT_END(ctx, PLAT_KT_UNPACK_PIECES, (hipStream_t)stream); }
     }
     PLAT_EV_TAB(ctx, 1, (hipStream_t)stream);
     ctx->ev_valid_unpack = ctx->profile;
     if (n_exc > 0)
         hipLaunchKernelGGL(plat::k_unpack_exceptions, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n_exc,
-                           (long long)total_bytes, exc_index, exc_base, exc_qual, out_seq, out_qual);
+                           (long long)total_bytes, exc_index, exc_base, exc_qual, out_seq, out_qual, out_codes);
     PLAT_HIP(ctx, hipGetLastError());
     return PLAT_OK;
 }

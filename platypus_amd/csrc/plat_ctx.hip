@@ -137,6 +137,12 @@ PLAT_EXPORT const char* plat_kernel_timer_name(int id) {
     return id >= 0 && id < PLAT_KT_COUNT ? names[id] : nullptr;
 }
 
+PLAT_EXPORT int plat_kernel_timer_only(plat_ctx* ctx, int id) {
+    if (!ctx || id >= PLAT_KT_COUNT) return PLAT_ERR_INVALID;
+    ctx->kt_single = id < 0 ? -1 : id;
+    return PLAT_OK;
+}
+
 PLAT_EXPORT int plat_kernel_times(plat_ctx* ctx, double* out_ms, int64_t* out_launches) {
     if (!ctx || !out_ms || !out_launches) return PLAT_ERR_INVALID;
     for (int k = 0; k < ctx->kt_pending_n; ++k) {

@@ -48,6 +48,7 @@ struct plat_ctx {
     KtPair kt_pending[KT_PENDING];
     hipEvent_t kt_pool[2 * KT_PENDING + 2];
     int kt_pending_n = 0, kt_pool_n = 0, kt_open = -1;
+    int kt_single = -1;                  // plat_kernel_timer_only: this one kernel is timed even while the profile is off
     double kt_ms[PLAT_KT_COUNT] = {};
     int64_t kt_launches[PLAT_KT_COUNT] = {};
 };
@@ -64,12 +65,12 @@ struct plat_ctx {
 // ---- generic live kernel timers (plat_kernel_times): a pair of HIP events around a launch while the profile is on, resolved and summed per
 // kernel id when the caller asks.  Off: one test of ctx->profile per launch.
 static inline void plat_kt_mark(plat_ctx* ctx, int id, hipStream_t st, bool end) {
-    if (!ctx->profile || id < 0 || id >= PLAT_KT_COUNT) return;
+    if (id < 0 || id >= PLAT_KT_COUNT || !(ctx->profile || ctx->kt_single == id)) return;
     if (!end) {
+        if (ctx->kt_pending_n >= plat_ctx::KT_PENDING) return;               // (too many unresolved pairs: this launch is not timed -- and takes no events)
         hipEvent_t a = nullptr, b = nullptr;
         if (ctx->kt_pool_n >= 2) { a = ctx->kt_pool[--ctx->kt_pool_n]; b = ctx->kt_pool[--ctx->kt_pool_n]; }
         else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-        if (ctx->kt_pending_n >= plat_ctx::KT_PENDING) { ctx->kt_pool[ctx->kt_pool_n++] = a; ctx->kt_pool[ctx->kt_pool_n++] = b; return; }   // (too many unresolved pairs: this launch is not timed)
         ctx->kt_pending[ctx->kt_pending_n] = {id, a, b, false};
         ctx->kt_open = ctx->kt_pending_n++;
         (void)hipEventRecord(a, st);

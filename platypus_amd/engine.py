@@ -315,7 +315,17 @@ class Engine:
         return [(ph[s], lik[lik_off[s]:lik_off[s + 1]].reshape(hb.n_ind, int(NL[s])), out4[s]) for s in range(nS)]
 
     # ---- VariantCandidateGenerator ------------------------------------------------------
-    def candidates(self, regions, min_flank=10, min_base_qual=20, gen_snps=1, gen_indels=1, max_per_read=64):
+    @staticmethod
+    def base_codes(blob):
+        """The 2-bit codes of a byte blob as the device lays them out ((ASCII >> 1) & 3, base i at bits 2 (i & 15) of dword i >> 4), + 8 zero words."""
+        a = np.frombuffer(bytes(blob), dtype=np.uint8)
+        n = (len(a) + 15) // 16
+        c = np.zeros(n * 16, dtype=np.uint32)
+        c[:len(a)] = (a >> 1) & 3
+        words = (c.reshape(n, 16) << (2 * np.arange(16, dtype=np.uint32))).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+        return np.concatenate([words, np.zeros(8, dtype=np.uint32)])
+
+    def candidates(self, regions, min_flank=10, min_base_qual=20, gen_snps=1, gen_indels=1, max_per_read=64, codes=False):
         """VariantCandidateGenerator.addCandidatesFromReads for a list of regions.
 
         `regions`: list of dicts {ref: bytes (contig[ref_seq_start:...]), ref_seq_start, contig_len, reads: [dict(seq, qual,
@@ -353,8 +363,21 @@ class Engine:
             rec = torch.empty(nR * max_per_read * 5, dtype=torch.int32, device=self.device)
             cnt = torch.empty(nR, dtype=torch.int32, device=self.device)
             stt = torch.empty(nR, dtype=torch.int32, device=self.device)
-            rc = self.lib.plat_candidates_batch(self.ctx, C.byref(b), min_flank, min_base_qual, gen_snps, gen_indels, max_per_read,
-                                                t["region_of"].data_ptr(), rec.data_ptr(), cnt.data_ptr(), stt.data_ptr(), self._stream())
+            if codes:
+                # the scan on 2-bit codes (plat_candidates_batch_codes): the reads' codes from the host here (the region loop gets them from the unpack
+                # kernel), the reference's from plat_ref_codes; the caller promises reads of A, C, G, T, N only
+                rc_t = dev(self.base_codes(seq_blob), np.uint32)
+                fc_t = torch.zeros((len(ref_blob) + 15) // 16 + 16, dtype=torch.int32, device=self.device)
+                irr = torch.zeros(nG + 1, dtype=torch.int32, device=self.device)
+                _lib.check(self.lib.plat_ref_codes(self.ctx, nG, t["ref"].data_ptr(), t["ref_off"].data_ptr(), len(ref_blob), fc_t.data_ptr(), irr.data_ptr(),
+                                                   self._stream()), "plat_ref_codes")
+                rc = self.lib.plat_candidates_batch_codes(self.ctx, C.byref(b), rc_t.data_ptr(), fc_t.data_ptr(), irr.data_ptr(), min_flank, min_base_qual, gen_snps,
+                                                          gen_indels, max_per_read, t["region_of"].data_ptr(), rec.data_ptr(), cnt.data_ptr(), stt.data_ptr(),
+                                                          self._stream())
+                self.last_ref_irregular = irr
+            else:
+                rc = self.lib.plat_candidates_batch(self.ctx, C.byref(b), min_flank, min_base_qual, gen_snps, gen_indels, max_per_read,
+                                                    t["region_of"].data_ptr(), rec.data_ptr(), cnt.data_ptr(), stt.data_ptr(), self._stream())
             _lib.check(rc, "plat_candidates_batch")
             self._sync()
             cnt_h, st_h = cnt.cpu().numpy(), stt.cpu().numpy()

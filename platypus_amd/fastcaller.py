@@ -252,6 +252,7 @@ def _bind(lib):
     lib.plat_caller_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     lib.plat_caller_destroy.argtypes = [C.c_void_p]
     lib.plat_caller_count_cells.argtypes = [C.c_void_p, C.c_int]
+    lib.plat_caller_time_kernel.argtypes = [C.c_void_p, C.c_int]
     lib.plat_call_regions.argtypes = [C.c_void_p, C.POINTER(_Region), C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(CallerOptions),
                                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(CallerStats)]
     lib.plat_call_regions_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(CallerOptions), C.c_void_p, C.c_void_p,
@@ -424,6 +425,11 @@ class NativeCaller:
             raise _lib.PlatypusDeviceError(rc, "plat_caller_create failed (no GPU? the native region loop has no CPU fallback)", "plat_caller_create")
         self.h = h
         self.stats = None
+
+    def time_kernel(self, kernel_id):
+        """Measurement switch (plat_caller_time_kernel): the calls that follow time this one kernel (id of plat_kernel_timer_name; -1: none) inside the
+        ordinary asynchronous runs; stats["kernel_ms"][id] / ["kernel_launches"][id] hold its summed duration and launches."""
+        self.lib.plat_caller_time_kernel(self.h, int(kernel_id))
 
     def count_cells(self, on=True):
         """Measurement switch (plat_caller_count_cells): the calls that follow count the reference's DPs and band cells into stats

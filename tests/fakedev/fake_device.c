@@ -86,6 +86,7 @@ API int plat_profile_enable(plat_ctx* c, int on) { (void)c; (void)on; return PLA
 API int plat_profile_last(plat_ctx* c, plat_profile* p) { (void)c; memset(p, 0, sizeof(*p)); return PLAT_OK; }
 API int plat_sync_poll_us(plat_ctx* c, int us) { (void)c; return us < 0 ? PLAT_ERR_INVALID : PLAT_OK; }
 API const char* plat_kernel_timer_name(int id) { return id >= 0 && id < PLAT_KT_COUNT ? "fake" : NULL; }
+API int plat_kernel_timer_only(plat_ctx* c, int id) { (void)c; return id >= PLAT_KT_COUNT ? PLAT_ERR_INVALID : PLAT_OK; }
 API int plat_kernel_times(plat_ctx* c, double* ms, int64_t* n) { (void)c; (void)ms; (void)n; return PLAT_OK; }
 API int plat_dp_batch(plat_ctx* c, int n, int lmax, const uint8_t* a, const uint8_t* b, const uint8_t* q, const uint8_t* g,
                       const int32_t* l, int ge, int np_, int32_t* o, void* st)
@@ -340,6 +341,17 @@ API int plat_unpack_reads_pieces(plat_ctx* c, int n_pieces, int64_t max_piece_by
     return PLAT_OK;
 }
 
+/* the scan on 2-bit codes: not in the fake device (the host's loop falls back to plat_unpack_reads_pieces + plat_candidates_batch) */
+API int plat_unpack_reads_pieces_codes(plat_ctx* c, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* out_seq, uint8_t* out_qual,
+                                       uint32_t* out_codes, int64_t total_bytes, int64_t n_exc, const int64_t* exc_index, const uint8_t* exc_base,
+                                       const uint8_t* exc_qual, void* stream)
+{ (void)c; (void)n_pieces; (void)max_piece_bytes; (void)pieces; (void)out_seq; (void)out_qual; (void)out_codes; (void)total_bytes; (void)n_exc; (void)exc_index; (void)exc_base; (void)exc_qual; (void)stream; return PLAT_ERR_UNSUPPORTED; }
+API int plat_ref_codes(plat_ctx* c, int n_regions, const uint8_t* ref_seq, const int64_t* ref_off, int64_t n_bytes, uint32_t* out_codes, int32_t* out_irregular, void* stream)
+{ (void)c; (void)n_regions; (void)ref_seq; (void)ref_off; (void)n_bytes; (void)out_codes; (void)out_irregular; (void)stream; return PLAT_ERR_UNSUPPORTED; }
+API int plat_candidates_batch_codes(plat_ctx* c, const plat_candidate_batch* b, const uint32_t* read_codes, const uint32_t* ref_codes, const int32_t* ref_irregular,
+                                    int min_flank, int min_base_qual, int gen_snps, int gen_indels, int max_per_read, const int32_t* read_region, int32_t* out_rec,
+                                    int32_t* out_count, int32_t* out_status, void* stream)
+{ (void)c; (void)b; (void)read_codes; (void)ref_codes; (void)ref_irregular; (void)min_flank; (void)min_base_qual; (void)gen_snps; (void)gen_indels; (void)max_per_read; (void)read_region; (void)out_rec; (void)out_count; (void)out_status; (void)stream; return PLAT_ERR_UNSUPPORTED; }
 API int plat_copy_pieces(plat_ctx* c, int n_pieces, int64_t max_piece_bytes, const plat_unpack_piece* pieces, uint8_t* dst_blob, void* stream)
 {
     (void)c; (void)stream; (void)max_piece_bytes;

@@ -87,7 +87,7 @@ def test_caller_library_builds_and_matches_its_header(tmp_path):
     text = open(os.path.join(ROOT, "include", "platypus_caller.h")).read()
     declared = set(re.findall(r"\b(plat_(?:call|merge)[a-z0-9_]*)\s*\(", text))
     assert declared == {"plat_caller_default_options", "plat_caller_create", "plat_caller_destroy", "plat_call_regions", "plat_call_regions_stream",
-                        "plat_caller_free", "plat_caller_last_error", "plat_merge_record_texts", "plat_caller_count_cells",
+                        "plat_caller_free", "plat_caller_last_error", "plat_merge_record_texts", "plat_caller_count_cells", "plat_caller_time_kernel",
                             "plat_caller_region_text_lengths", "plat_merge_region_blocks"}
     for name in declared:
         assert hasattr(lib, name), name

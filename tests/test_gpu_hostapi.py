@@ -309,3 +309,60 @@ def test_every_kernel_of_a_call_is_timed_and_the_poll_interval_is_checked():
     eng.synchronize()
     assert np.array_equal(db.score.cpu().numpy()[:hb.n_pairs], want)
     assert eng.lib.plat_sync_poll_us(eng.ctx, 40) == 0
+
+
+def test_the_scan_on_two_bit_codes_gives_the_records_of_the_byte_scan(golden_dir):
+    """Round 6: plat_candidates_batch_codes (32 bases per word on 2-bit codes, bytes looked at only where codes differ) = plat_candidates_batch, record
+    for record, on the reference's golden reads and on generated regions with what could tell them apart: N in reads and reference (N shares G's
+    code), low qualities, soft clips, insertions and deletions, reads hanging over the window's ends, and reference regions with other bytes
+    (lowercase, IUPAC), which plat_ref_codes must flag so that they take the byte scan."""
+    import gzip, json, os
+    import numpy as np
+    eng = H.get_engine()
+    cases = json.load(gzip.open(os.path.join(golden_dir, "candidate_cases.json.gz"), "rt"))
+    regions = []
+    for c in cases:
+        reads = [dict(seq=r["seq"].encode(), qual=bytes(r["qual"]), pos=r["pos"], flag=r["flag"], cigar=[tuple(x) for x in r["cigar"]]) for r in c["reads"]]
+        if all(set(r["seq"]) <= set(b"ACGTN") for r in reads):
+            regions.append(dict(ref=c["ref"].encode(), ref_seq_start=0, contig_len=len(c["ref"]), reads=reads))
+    assert len(regions) > 20
+    rng = np.random.default_rng(606)
+    B = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for k in range(60):
+        L = int(rng.integers(400, 1500))
+        ref = B[rng.integers(0, 4, L)].copy()
+        if k % 3 == 0:
+            ref[rng.integers(0, L, 5)] = ord("N")
+        if k % 5 == 1:
+            ref[rng.integers(0, L, 3)] = np.frombuffer(b"aRy", dtype=np.uint8)          # an irregular region: bytes the codes cannot tell from A / C / T
+        reads = []
+        for _ in range(int(rng.integers(5, 60))):
+            n = int(rng.integers(30, 151))
+            p = int(rng.integers(0, L - n - 20))
+            seq = ref[p:p + n].copy()
+            seq[seq > 90] = ord("A")                                                    # (reads hold A, C, G, T, N only: the caller's promise)
+            for _m in range(int(rng.integers(0, 6))):
+                seq[int(rng.integers(0, n))] = B[int(rng.integers(0, 4))]
+            if rng.random() < 0.3:
+                seq[int(rng.integers(0, n))] = ord("N")
+            qual = rng.integers(0, 41, n).astype(np.uint8)
+            cig, t = [(0, n)], rng.random()
+            if t < 0.2 and n > 60:
+                a = int(rng.integers(15, n - 30)); d = int(rng.integers(1, 8))
+                cig = [(0, a), (2, d), (0, n - a)]                                      # a deletion: the read's tail is compared d bases further on
+            elif t < 0.4 and n > 60:
+                a = int(rng.integers(15, n - 30)); i = int(rng.integers(1, 8))
+                cig = [(0, a), (1, i), (0, n - a - i)]
+            elif t < 0.5:
+                sc = int(rng.integers(1, 12))
+                cig = [(4, sc), (0, n - sc)]
+            reads.append(dict(seq=bytes(seq), qual=bytes(qual), pos=p, flag=int(512 if rng.random() < 0.05 else 0), cigar=cig))
+        regions.append(dict(ref=bytes(ref), ref_seq_start=0, contig_len=L, reads=reads))
+    for lo in range(0, len(regions), 40):
+        part = regions[lo:lo + 40]
+        want = eng.candidates(part, 10, 20, 1, 1)
+        got = eng.candidates(part, 10, 20, 1, 1, codes=True)
+        assert got == want
+        irr = eng.last_ref_irregular.cpu().numpy()[:len(part)]
+        assert [int(x) for x in irr] == [int(any(ch not in b"ACGTN" for ch in g["ref"])) for g in part]
+    assert sum(len(x) for x in want) > 0

@@ -182,3 +182,35 @@ def test_more_pieces_than_a_grid_dimension_holds(eng):
     val = np.concatenate([blob[a:a + k] for a, k in zip(src_at, sizes)])
     wr[idx] = val; ws[idx] = np.frombuffer(b"ACTG", dtype=np.uint8)[val & 3]; wq[idx] = val >> 2
     assert np.array_equal(oraw.cpu().numpy(), wr) and np.array_equal(oseq.cpu().numpy(), ws) and np.array_equal(oqual.cpu().numpy(), wq)
+
+
+def test_unpack_pieces_also_writes_the_two_bit_codes(eng):
+    """plat_unpack_reads_pieces_codes = plat_unpack_reads_pieces + the bases' 2-bit codes ((ASCII >> 1) & 3, base i at bits 2 (i & 15) of dword i >> 4):
+    pieces that start and end anywhere inside a 16-base line (their partial lines are OR-ed in, neighbours share a dword), exceptions patched behind them."""
+    import torch
+    from platypus_amd import _lib
+    from platypus_amd.engine import Engine
+    rng = np.random.default_rng(14)
+    sizes = [0, 1, 7, 15, 16, 17, 33, 100, 1000, 4097, 0, 31, 50000, 5, 16, 48]
+    blob = rng.integers(0, 256, sum(sizes) + 64).astype(np.uint8)
+    dblob = _dev(eng, blob, np.uint8)
+    triples, at, dst = [], 0, 0
+    for n in sizes:
+        triples.append((dblob.data_ptr() + at, dst, n))
+        at += n; dst += n                                                    # back to back in the output, as a chunk's tables are
+    total = dst
+    exc_i = np.array([triples[8][1] + 3, triples[12][1] + 777, triples[12][1] + 778], dtype=np.int64)
+    exc_b, exc_q = np.frombuffer(b"NNT", dtype=np.uint8).copy(), np.array([0, 2, 70], dtype=np.uint8)
+    pc = _pieces(eng, triples)
+    oseq = torch.zeros(total + PAD, dtype=torch.uint8, device=eng.device)
+    oqual = torch.zeros(total + PAD, dtype=torch.uint8, device=eng.device)
+    codes = torch.full(((total + 15) // 16 + 8,), -1, dtype=torch.int32, device=eng.device)
+    di, db, dq = _dev(eng, exc_i, np.int64), _dev(eng, exc_b, np.uint8), _dev(eng, exc_q, np.uint8)
+    _lib.check(eng.lib.plat_unpack_reads_pieces_codes(eng.ctx, len(triples), max(sizes), pc.data_ptr(), oseq.data_ptr(), oqual.data_ptr(), codes.data_ptr(), total,
+                                                      len(exc_i), di.data_ptr(), db.data_ptr(), dq.data_ptr(), eng._stream()), "plat_unpack_reads_pieces_codes")
+    eng._sync()
+    seq = oseq.cpu().numpy()[:total]
+    want = np.frombuffer(b"ACTG", dtype=np.uint8)[blob[:total] & 3].copy()
+    want[exc_i] = exc_b
+    assert np.array_equal(seq, want)
+    assert np.array_equal(codes.cpu().numpy().view(np.uint32), Engine.base_codes(bytes(want)))

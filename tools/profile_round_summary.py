@@ -84,8 +84,8 @@ def wgs_profile(o, prof, tag, per4):
     """profiles/wgs_profile.json: what bench.py's WGS line may quote -- the rocprofv3 --stats ranking of the region loop's kernels, their PMC
     bytes per launch, and the hash of the kernel sources they were collected from (bench.py refuses the figures of other sources)."""
     solo = sorted(glob.glob(o + "/stats_c4solo/*/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)
-    paths = solo or sorted(glob.glob(o + "/stats_c4/*/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)
-    if not paths and not per4:
+    paths = sorted(glob.glob(o + "/stats_c4/*/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)
+    if not paths and not per4 and not solo:
         return
     sys.path.insert(0, ROOT)
     from tools import bench_other
@@ -110,8 +110,17 @@ def wgs_profile(o, prof, tag, per4):
                 t[0] += float(r["TotalDurationNs"]) / 1e3; t[1] += int(r["Calls"])
         d["ranking"] = [k for k, _ in sorted(tot.items(), key=lambda kv: -kv[1][0])]
         d["stats"] = {k: {"total_us": round(v[0], 1), "calls": v[1], "avg_us": round(v[0] / max(1, v[1]), 2)} for k, v in tot.items()}
-        d["ranking_source"] = ("profiles/" + tag + "_config4_stats_one_worker.txt (rocprofv3 --kernel-trace --stats, one host worker: every kernel by itself -- the basis of the live timers; "
-                               "with 24 workers the bandwidth-bound k_unpack_pieces stretches most and leads " + tag + "_config4_stats.txt)") if solo else "profiles/" + tag + "_config4_stats.txt (rocprofv3 --kernel-trace --stats)"
+        d["ranking_source"] = "profiles/" + tag + "_config4_stats.txt (rocprofv3 --kernel-trace --stats of bench.py --config 4 with its 24 workers: the kernels as they share the chip in the timed region)"
+    if solo:
+        tot = {}
+        for r in csv.DictReader(open(solo[0])):
+            if "plat::" in r["Name"]:
+                k = short_kernel(r["Name"])
+                t = tot.setdefault(k, [0.0, 0])
+                t[0] += float(r["TotalDurationNs"]) / 1e3; t[1] += int(r["Calls"])
+        d["ranking_by_itself"] = [k for k, _ in sorted(tot.items(), key=lambda kv: -kv[1][0])]
+        d["stats_by_itself"] = {k: {"total_us": round(v[0], 1), "calls": v[1], "avg_us": round(v[0] / max(1, v[1]), 2)} for k, v in tot.items()}
+        d["ranking_by_itself_source"] = "profiles/" + tag + "_config4_stats_one_worker.txt (one host worker: every kernel by itself -- what the counting pass's live timers measure)"
     if per4:
         ks = d.setdefault("kernels", {})
         for name, v in per4.items():
