@@ -77,7 +77,7 @@ C4SOLO = "--config 4 --regions 2048 --steps 1 --no-cpu-baseline  [PLAT_CALLER_WO
 def short_kernel(name):
     """rocprofv3's kernel name -> the library's timer name (plat_kernel_timer_name)."""
     k = name.split("(")[0].replace("void ", "").replace("plat::", "").split("<")[0].strip()
-    return {"k_em_wide": "k_em", "k_finalize_dense": "k_finalize", "k_finalize_multi": "k_finalize"}.get(k, k)
+    return {"k_em_wide": "k_em", "k_finalize_dense": "k_finalize", "k_finalize_multi": "k_finalize", "k_candidates_codes": "k_candidates"}.get(k, k)
 
 
 def wgs_profile(o, prof, tag, per4):
