@@ -173,3 +173,22 @@ def test_the_block_merge_writes_the_text_of_the_line_merge(tmp_path):
     t = b"c\t10\t.\tA\tC\nc\t60\t.\tA\tC\n" + b"c\t55\t.\tG\tT\n"
     merged = x.exchange(t, [len(t) - 13, 13])
     assert bytes(memoryview(merged)) == t                                  # (one text: the line merge keeps a single text's order)
+
+
+def test_the_roofline_kernel_is_chosen_from_the_profile_only_when_it_is_this_builds(tmp_path, monkeypatch):
+    """bench.py's roofline kernel: the first kernel of profiles/wgs_profile.json's rocprof ranking when that file carries THIS build's kernel-source hash,
+    else the kernel with the largest summed live time; and config4_gcups hands out the file's traffic only in the first case."""
+    from tools import bench_other
+    kms = {"k_sb_variants": 50.0, "k_unpack_pieces": 40.0, "k_candidates": 30.0, "k_dp_jobs": 10.0, "other": 99.0}
+    prof = {"kernel_source_hash": "feedfacefeedface", "ranking": ["k_nonexistent", "k_unpack_pieces", "k_sb_variants"], "ranking_source": "a test",
+            "kernels": {"k_unpack_pieces": {"hbm_bytes_per_launch": 1234}}, "measured": {"date": "d", "commit": "c"}}
+    monkeypatch.setattr(bench_other, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "wgs_profile.json").write_text(json.dumps(prof))
+    monkeypatch.setattr(bench_other, "kernel_source_hash", lambda: "0123456789abcdef")
+    k, how, order = bench_other.choose_roofline_kernel(kms)
+    assert k == "k_sb_variants" and order[:3] == ["k_sb_variants", "k_unpack_pieces", "k_candidates"] and "other kernel sources" in how
+    monkeypatch.setattr(bench_other, "kernel_source_hash", lambda: "feedfacefeedface")
+    k, how, order = bench_other.choose_roofline_kernel(kms)
+    assert k == "k_unpack_pieces" and "rocprofv3" in how and order[0] == "k_sb_variants"
+    assert bench_other.choose_roofline_kernel({"other": 1.0})[0] is None

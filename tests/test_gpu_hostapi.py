@@ -304,6 +304,17 @@ def test_every_kernel_of_a_call_is_timed_and_the_poll_interval_is_checked():
     for k in ("k_prep_reads", "k_sweep", "k_pairs", "k_seed_slow", "k_dp_jobs", "k_finalize", "k_genotype"):
         assert t[k][1] == 3 and 0.0 < t[k][0] < 50.0, (k, t.get(k))
     assert eng.kernel_times() == {}                                             # resolved pairs are handed out once
+    # ONE kernel timed while the profile is off (how bench.py times its roofline kernel inside the timed steps)
+    assert eng.lib.plat_kernel_timer_only(eng.ctx, 20) == 0                     # PLAT_KT_DP_JOBS
+    for _ in range(2):
+        eng.call_windows(db, want_stats=False, asynchronous=True)
+    eng.synchronize()
+    t1 = eng.kernel_times()
+    assert list(t1) == ["k_dp_jobs"] and t1["k_dp_jobs"][1] == 2 and t1["k_dp_jobs"][0] > 0
+    assert eng.lib.plat_kernel_timer_only(eng.ctx, -1) == 0 and eng.lib.plat_kernel_timer_only(eng.ctx, 32) == -1
+    eng.call_windows(db, want_stats=False, asynchronous=True)
+    eng.synchronize()
+    assert eng.kernel_times() == {}
     assert eng.lib.plat_sync_poll_us(eng.ctx, -1) == -1 and eng.lib.plat_sync_poll_us(eng.ctx, 2000) == 0
     eng.call_windows(db, want_stats=False, asynchronous=True)
     eng.synchronize()
