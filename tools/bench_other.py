@@ -287,11 +287,13 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
     # share + the exchange + the merge on rank 0), barrier + synchronize; nothing between the runs but the exchange itself (a collective).
     # The untimed rounds before them have the same shape and a barrier each.
     T_bracket = None
+    cg0 = cg1 = None
     for rep in range(repeats + nplain):
         opts = default_options(**(options_kw or {}))
         if rep <= nplain:
             rk.barrier()
             if rep == nplain:
+                cg0 = cgroup_cpu_stat()
                 T_bracket = time.perf_counter()
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
@@ -316,6 +318,7 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
         if rep == repeats + nplain - 1:
             rk.barrier()
             T_bracket = time.perf_counter() - T_bracket
+            cg1 = cgroup_cpu_stat()
             gather = dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=nranks, how=("one rank, regions in order: its text is the merged text (nothing copied)" if (xch is not None and xch.world == 1 and xch.plan.identity and xch.plan.ok)
                                                                                  else "region blocks") if xch is not None else "line merge",
                           records=bytes(memoryview(merged)).count(b"\n") if merged is not None else None)
@@ -330,7 +333,29 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
                 cpu_sys_s=float(np.mean([r[3] for r in runs])), text=text, merged=merged, gather=gather, stats=st,
                 regions=len(indices), warm_regions=nwarm, region_len=region_len, reads=int(st["n_reads"]), windows=int(st["n_windows"]), records=int(st["n_records"]),
                 planted=int(planted), workers=workers, per_chunk=per_chunk, loaders=loaders, n_slots=n_slots, packed=packed, source_phases=phases,
-                input_bytes=int(st["input_bytes"]), counted=counted, resident=bool(resident), warm_rounds_plain=nplain)
+                input_bytes=int(st["input_bytes"]), counted=counted, resident=bool(resident), warm_rounds_plain=nplain, cgroup_cpu=cgroup_cpu_delta(cg0, cg1))
+
+
+def cgroup_cpu_stat():
+    """The process's cgroup-v2 CPU accounting (cpu.stat + cpu.max), or None: how much CPU TIME the box grants (quota / period) and how often the
+    kernel's bandwidth controller stopped every thread of the job for the rest of a period because the quota was spent."""
+    try:
+        st = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat").read().strip().splitlines())
+        mx = open("/sys/fs/cgroup/cpu.max").read().split()
+        return dict(st={k: int(v) for k, v in st.items()}, quota_us=None if mx[0] == "max" else int(mx[0]), period_us=int(mx[1]))
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def cgroup_cpu_delta(a, b):
+    """What the timed region did to the cgroup's counters (both ends read inside the bracket's barriers): periods, periods in which the quota ran
+    out (every thread of the job is then parked until the period ends), the CPU time used."""
+    if not a or not b:
+        return None
+    d = {k: b["st"].get(k, 0) - a["st"].get(k, 0) for k in ("nr_periods", "nr_throttled", "throttled_usec", "usage_usec")}
+    return dict(quota_cpus=None if a["quota_us"] is None else a["quota_us"] / a["period_us"], period_ms=a["period_us"] / 1e3, periods=d["nr_periods"],
+                periods_throttled=d["nr_throttled"], throttled_cpu_seconds=d["throttled_usec"] / 1e6, cpu_seconds_used=d["usage_usec"] / 1e6,
+                what="cgroup v2 cpu.stat over the timed region (all processes of the box's cgroup: every rank when ranks share it)")
 
 
 def kernel_source_hash():
@@ -567,7 +592,7 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
             "device_wait_seconds_per_region": st["seconds_device_wait"] / max(1, r["regions"]),
             "source_seconds_per_region": st["seconds_load"] / max(1, r["regions"]), "source_phase_seconds_per_region": r["source_phases"],
             "worker_seconds_waiting_for_the_source_per_region": st["seconds_source_wait"] / max(1, r["regions"]),
-            "host_input_bytes_per_region": inb / max(1.0, regs), "h2d_gbytes_per_sec": inb / T / 1e9, "input_blobs_pinned": pin, "cpus_granted_to_this_rank": cpus,
+            "host_input_bytes_per_region": inb / max(1.0, regs), "h2d_gbytes_per_sec": inb / T / 1e9, "input_blobs_pinned": pin, "cpus_granted_to_this_rank": cpus, "cgroup_cpu": r.get("cgroup_cpu"),
             "stage_seconds_per_region": {k: v / max(1, r["regions"]) for k, v in st["seconds_stage"].items()},
             "record_gather": r["gather"], "untimed_warm_regions_per_rank": r["warm_regions"], "python_region_loop_windows_per_sec_round1": 1100.0,
             # what an efficiency figure over the N = 1, 2, 4, 8 lines has to be computed from (the driver computes it, not this line)
@@ -594,6 +619,10 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
                            "step": "one pass of the native region loop over this rank's regions + the exchange of the record text to rank 0 + the merge",
                            "gcups_is": "REFERENCE-EQUIVALENT (SURVEY 8(d)): band cells of the fastAlignmentRoutine calls the reference would make for the called windows / wall time; "
                                        "gcups_executed counts only the DPs the device ran"})
+    cg = r.get("cgroup_cpu")
+    if cg:                                                                    # what bounds the job on this box: the cgroup's CPU-time quota (rank 0's view of its cgroup)
+        line["config"].update({"cpu_quota_cpus": cg["quota_cpus"], "cpus_busy": round((r["cpu_user_s"] + r["cpu_sys_s"]) / r["T"], 2),
+                               "cpu_quota_periods_throttled": "%d of %d" % (cg["periods_throttled"], cg["periods"])})
     if line.get("gcups") is not None:
         line["metric"] = "pair-HMM GCUPS + variant windows/sec (synthetic 30x WGS): value = reference-equivalent GCUPS of the whole job, config.windows_per_sec = variant windows/sec end to end"
         line["value"], line["unit"] = line["gcups"], "GCUPS"
