@@ -100,7 +100,7 @@ def config5_end_to_end(device, n_regions=48, region_len=5000, n_samples=100, rk=
     out = dict(regions=r["regions"], region_len=region_len, n_samples=n_samples, reads=r["reads"], windows=r["windows"], records=r["records"], pairs=int(st["n_pairs"]),
                timed_s=T, windows_per_sec=r["windows"] / T, regions_per_sec=r["regions"] / T, reads_per_sec=r["reads"] / T,
                host_seconds_per_region=st["seconds_host"] / r["regions"], device_wait_seconds_per_region=st["seconds_device_wait"] / r["regions"],
-               host_threads=r["workers"], regions_per_chunk=r["per_chunk"], inputs="loaded on demand inside the timed region",
+               host_threads=r["workers"], cpus_granted_to_this_rank=getattr(rk, "cpus", None), regions_per_chunk=r["per_chunk"], inputs="loaded on demand inside the timed region",
                stage_b={"regions_on_the_device": int(st.get("n_regions_stage_b_device", 0)), "regions_left_to_the_host": int(st.get("n_regions_stage_b_host", 0)),
                         "why": "plat_stage_b_batch takes one-sample regions: a cohort's variants / windows / haplotypes are made by host/stage_b_host.hpp"})
     out.update({k: v for k, v in config4_gcups(r.get("counted"), r["regions"], T).items() if k in ("gcups", "gcups_executed", "dp_reference", "dp_launched", "pairs")})
@@ -174,7 +174,7 @@ def config3_end_to_end(device, n_regions, rk=None, first=0, lib=None, region_kw=
                 gcups_note="(read, haplotype) pairs of the called windows x 16 x 250 band cells / wall time of the WHOLE pipeline: the reference "
                            "runs at least one DP for every pair it does not skip",
                 host_seconds_per_region=st["seconds_host"] / r["regions"], device_wait_seconds_per_region=st["seconds_device_wait"] / r["regions"],
-                assemble_seconds_per_region=st["seconds_assemble"] / r["regions"], host_threads=r["workers"], regions_per_chunk=r["per_chunk"],
+                assemble_seconds_per_region=st["seconds_assemble"] / r["regions"], host_threads=r["workers"], cpus_granted_to_this_rank=getattr(rk, "cpus", None), regions_per_chunk=r["per_chunk"],
                 inputs="resident in HBM" if r["resident"] else "loaded on demand inside the timed region", timed_s_runs=r["T_runs"],
                 call_seconds=r["T_call"], native_call_seconds=st["seconds_total"], source_wait_seconds_per_region=st["seconds_source_wait"] / r["regions"],
                 load_seconds_per_region=st["seconds_load"] / r["regions"], process_cpu_seconds_per_run=r["cpu_user_s"] + r["cpu_sys_s"],
@@ -722,7 +722,7 @@ def summary(eng):
                                           source_seconds_per_region=st["seconds_load"] / r["regions"],
                                           worker_seconds_waiting_for_the_source_per_region=st["seconds_source_wait"] / r["regions"],
                                           host_input_bytes_per_region=r["input_bytes"] / r["regions"], h2d_gbytes_per_sec=r["input_bytes"] / r["T"] / 1e9,
-                                          host_threads=r["workers"], loader_threads=r["loaders"], regions_per_chunk=r["per_chunk"],
+                                          host_threads=r["workers"], cpus_granted_to_this_rank=cpus, loader_threads=r["loaders"], regions_per_chunk=r["per_chunk"],
                                           read_encoding="packed (1 B/base)" if r["packed"] else "ascii (2 B/base)",
                                           **config4_gcups(r.get("counted"), r["regions"], r["T"]),
                                           what="regions generated on demand into pinned slots (region source) -> native region loop -> VCF record text; "
