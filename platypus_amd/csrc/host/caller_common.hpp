@@ -114,18 +114,7 @@ template <class T> struct Staged {
 typedef Staged<uint8_t> Arena;
 
 struct SparePools;                                                         // window / Variant storage a worker keeps between the chunks of a call (defined behind WindowWork)
-// CPU permits (PLAT_CALLER_CPU_PERMITS=n, measurement: off by default).  A box that grants the job n CPUs of TIME per period (a cgroup quota) parks
-// EVERY thread of the job for the rest of a period in which the workers together used more: with permits at most n workers run host stages at once
-// (a permit is given back for the length of every wait on the device), the others sleep on the condition variable instead of spending the quota.
-struct CpuPermits {
-    std::mutex m; std::condition_variable cv; int free_ = 0;
-    explicit CpuPermits(int n) : free_(n) {}
-    void acquire() { std::unique_lock<std::mutex> g(m); cv.wait(g, [&] { return free_ > 0; }); --free_; }
-    void release() { { std::lock_guard<std::mutex> g(m); ++free_; } cv.notify_one(); }
-};
-
 struct Slot {
-    CpuPermits* permits = nullptr;                                         // (set for the length of a call by runWorkers)
     SparePools* spare = nullptr;                                           // (made by the worker's first chunk of a call, freed when its chunks run out)
     plat_ctx* ctx = nullptr;
     void* stream = nullptr;
@@ -187,9 +176,7 @@ struct Slot {
 
     void sync(const char* where) {
         const auto t0 = Clock::now();
-        if (permits) permits->release();
         const int rc = plat_stream_sync(ctx, stream);
-        if (permits) permits->acquire();
         t_wait += secs(t0, Clock::now());
         ck(rc, where);
     }

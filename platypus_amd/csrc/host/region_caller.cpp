@@ -313,18 +313,9 @@ static int runWorkers(plat_caller* c, Feed& feed, std::atomic<bool>& failed, con
     std::mutex stMutex, errMutex;
     int firstError = PLAT_OK;
     std::string errText;
-    std::unique_ptr<CpuPermits> permits;
-    if (const char* e = getenv("PLAT_CALLER_CPU_PERMITS")) if (atoi(e) > 0) permits.reset(new CpuPermits(atoi(e)));
     auto worker = [&](Slot* slot) {
         std::vector<RegionWork*> regs;
-        slot->permits = permits.get();
-        struct Held {                                                       // a worker holds a permit while it works on a chunk, not while it waits for one
-            CpuPermits* p;
-            explicit Held(CpuPermits* q) : p(q) { if (p) p->acquire(); }
-            ~Held() { if (p) p->release(); }
-        };
         while (feed.next(regs)) {
-            Held held(permits.get());
             Chunk chunk{*slot, o, n_samples, sample_names, regs, st, stMutex};
             try {
                 chunk.run();
