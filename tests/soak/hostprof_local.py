@@ -1,11 +1,11 @@
-"""Host cycle profile of the native region loop WITHOUT a GPU: libplat_caller's sources built with -DPLAT_HOSTPROF (per-thread cycle counters of
+"""TEST INFRASTRUCTURE (it runs on tests/fakedev, the oracle-backed stand-in: not under tools/).  Host cycle profile of the native region loop WITHOUT a GPU: libplat_caller's sources built with -DPLAT_HOSTPROF (per-thread cycle counters of
 the named scopes, csrc/host/caller_common.hpp) against the CPU stand-in of the device library (tests/fakedev: the C ABI on the parity oracle), one
 worker over N synthetic config-4 regions.  What it is good for: the host stages that do not depend on who computed the numbers -- INFO / FILTER
 arithmetic, record text (text.*), the read-statistics / genotype-call inputs (s6.*), window and Variant objects -- in kcycles per region, before and
 after a change to csrc/host; the device-side scopes (s1, s4.runWindows, s6.launch) are the stand-in's own CPU time and mean nothing here, and stage
 B runs on the host (the stand-in has no plat_stage_b_batch).  The GPU box's profile of the real job is tools/hostprof.sh.
 
-    python tools/hostprof_local.py [regions=8]          # prints the [prof] lines of the last pass and a hash of the record text
+    python tests/soak/hostprof_local.py [regions=8]          # prints the [prof] lines of the last pass and a hash of the record text
 """
 import ctypes as C
 import hashlib
@@ -14,7 +14,7 @@ import subprocess
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 

@@ -192,3 +192,20 @@ def test_the_roofline_kernel_is_chosen_from_the_profile_only_when_it_is_this_bui
     k, how, order = bench_other.choose_roofline_kernel(kms)
     assert k == "k_unpack_pieces" and "rocprofv3" in how and order[0] == "k_sb_variants"
     assert bench_other.choose_roofline_kernel({"other": 1.0})[0] is None
+
+
+def test_cgroup_cpu_accounting_of_the_timed_region():
+    """The line says what CPU time the box granted the job and how often the quota ran out inside the timed bracket (bench_other.cgroup_cpu_stat at
+    both ends, cgroup_cpu_delta): differences of cpu.stat's counters, the quota in CPUs; None where the box has no cgroup-v2 files (this container)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_other as B
+    a = dict(st=dict(nr_periods=100, nr_throttled=7, throttled_usec=1_000_000, usage_usec=50_000_000), quota_us=1_600_000, period_us=100_000)
+    b = dict(st=dict(nr_periods=144, nr_throttled=37, throttled_usec=6_882_983, usage_usec=115_662_849), quota_us=1_600_000, period_us=100_000)
+    d = B.cgroup_cpu_delta(a, b)
+    assert d["quota_cpus"] == 16.0 and d["period_ms"] == 100.0 and d["periods"] == 44 and d["periods_throttled"] == 30
+    assert abs(d["throttled_cpu_seconds"] - 5.882983) < 1e-9 and abs(d["cpu_seconds_used"] - 65.662849) < 1e-9
+    nolimit = dict(st=dict(nr_periods=0), quota_us=None, period_us=100_000)
+    assert B.cgroup_cpu_delta(nolimit, nolimit)["quota_cpus"] is None
+    assert B.cgroup_cpu_delta(None, b) is None and B.cgroup_cpu_delta(a, None) is None
+    st = B.cgroup_cpu_stat()                                                 # whatever this machine has: a record with the three parts, or None
+    assert st is None or {"st", "quota_us", "period_us"} <= set(st)

@@ -281,7 +281,7 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
         per_rank = [[(("r%d" % g), flank0, flank0 + region_len) for g in job_regions[r::world]] for r in range(world)]
         xch = sharding.RegionTextExchange(per_rank, dist=getattr(rk, "dist", None), device=getattr(rk, "coll_device", None), lib=lib,
                                           device_index=getattr(rk, "dev_index", 0))
-    nplain = (max(1, min(int(warm_rounds), 3)) if (xch is not None or resident) else 0)     # untimed rounds of the TIMED shape behind the counting pass (a run is
+    nplain = (max(1, min(int(warm_rounds), 32)) if (xch is not None or resident) else 0)     # untimed rounds of the TIMED shape behind the counting pass (a run is
                                                                               # 0.1 s: allocator arenas, clocks and the exchange's pinned block settle over the first two or three)
     # The K timed runs (= the K steps of the bench contract) are bracketed ONCE: barrier + device synchronize, K x (region calls of this rank's
     # share + the exchange + the merge on rank 0), barrier + synchronize; nothing between the runs but the exchange itself (a collective).
