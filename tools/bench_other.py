@@ -287,13 +287,14 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
     # share + the exchange + the merge on rank 0), barrier + synchronize; nothing between the runs but the exchange itself (a collective).
     # The untimed rounds before them have the same shape and a barrier each.
     T_bracket = None
-    cg0 = cg1 = None
+    cg0 = cg1 = th0 = th1 = None
     for rep in range(repeats + nplain):
         opts = default_options(**(options_kw or {}))
         if rep <= nplain:
             rk.barrier()
             if rep == nplain:
                 cg0 = cgroup_cpu_stat()
+                th0 = thread_cpu_seconds()
                 T_bracket = time.perf_counter()
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
@@ -319,6 +320,7 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
             rk.barrier()
             T_bracket = time.perf_counter() - T_bracket
             cg1 = cgroup_cpu_stat()
+            th1 = thread_cpu_seconds()
             gather = dict(rk.describe(), ms=1e3 * (t2 - t1), ranks=nranks, how=("one rank, regions in order: its text is the merged text (nothing copied)" if (xch is not None and xch.world == 1 and xch.plan.identity and xch.plan.ok)
                                                                                  else "region blocks") if xch is not None else "line merge",
                           records=bytes(memoryview(merged)).count(b"\n") if merged is not None else None)
@@ -333,7 +335,8 @@ def config4(device, indices, region_len, workers, per_chunk, repeats=1, n_sample
                 cpu_sys_s=float(np.mean([r[3] for r in runs])), text=text, merged=merged, gather=gather, stats=st,
                 regions=len(indices), warm_regions=nwarm, region_len=region_len, reads=int(st["n_reads"]), windows=int(st["n_windows"]), records=int(st["n_records"]),
                 planted=int(planted), workers=workers, per_chunk=per_chunk, loaders=loaders, n_slots=n_slots, packed=packed, source_phases=phases,
-                input_bytes=int(st["input_bytes"]), counted=counted, resident=bool(resident), warm_rounds_plain=nplain, cgroup_cpu=cgroup_cpu_delta(cg0, cg1))
+                input_bytes=int(st["input_bytes"]), counted=counted, resident=bool(resident), warm_rounds_plain=nplain, cgroup_cpu=cgroup_cpu_delta(cg0, cg1),
+                thread_cpu=thread_cpu_delta(th0, th1, repeats))
 
 
 def cgroup_cpu_stat():
@@ -345,6 +348,37 @@ def cgroup_cpu_stat():
         return dict(st={k: int(v) for k, v in st.items()}, quota_us=None if mx[0] == "max" else int(mx[0]), period_us=int(mx[1]))
     except (OSError, ValueError, IndexError):
         return None
+
+
+def thread_cpu_seconds():
+    """CPU seconds (user + system) of every thread of this process that is alive now: {tid: (name, seconds)} from /proc/self/task."""
+    out = {}
+    try:
+        tick = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                f = open("/proc/self/task/%s/stat" % tid).read()
+                name = f[f.index("(") + 1:f.rindex(")")]
+                rest = f[f.rindex(")") + 2:].split()
+                out[int(tid)] = (name, (int(rest[11]) + int(rest[12])) / tick)
+            except (OSError, ValueError, IndexError):
+                pass
+    except (OSError, ValueError):
+        return None
+    return out
+
+
+def thread_cpu_delta(a, b, steps):
+    """CPU seconds per step of the threads that lived through the whole timed region (the interpreter's thread, the loaders of the region
+    source, the HIP / ROCr runtime's own threads -- the region loop's workers are made per call and are NOT among them: their time is
+    worker_cpu_seconds_per_region), by thread name, largest first."""
+    if not a or not b:
+        return None
+    by = {}
+    for tid, (name, sec) in b.items():
+        if tid in a:
+            by[name] = by.get(name, 0.0) + (sec - a[tid][1]) / max(1, steps)
+    return dict(sorted(((k, round(v, 4)) for k, v in by.items() if v > 0), key=lambda kv: -kv[1]))
 
 
 def cgroup_cpu_delta(a, b):
@@ -592,7 +626,7 @@ def line_config4(a, rk, lib=None, region_len=100000, region_kw=None, resident=No
             "device_wait_seconds_per_region": st["seconds_device_wait"] / max(1, r["regions"]),
             "source_seconds_per_region": st["seconds_load"] / max(1, r["regions"]), "source_phase_seconds_per_region": r["source_phases"],
             "worker_seconds_waiting_for_the_source_per_region": st["seconds_source_wait"] / max(1, r["regions"]),
-            "host_input_bytes_per_region": inb / max(1.0, regs), "h2d_gbytes_per_sec": inb / T / 1e9, "input_blobs_pinned": pin, "cpus_granted_to_this_rank": cpus, "cgroup_cpu": r.get("cgroup_cpu"),
+            "host_input_bytes_per_region": inb / max(1.0, regs), "h2d_gbytes_per_sec": inb / T / 1e9, "input_blobs_pinned": pin, "cpus_granted_to_this_rank": cpus, "cgroup_cpu": r.get("cgroup_cpu"), "cpu_seconds_per_step_of_the_threads_that_outlive_a_call": r.get("thread_cpu"),
             "stage_seconds_per_region": {k: v / max(1, r["regions"]) for k, v in st["seconds_stage"].items()},
             "record_gather": r["gather"], "untimed_warm_regions_per_rank": r["warm_regions"], "python_region_loop_windows_per_sec_round1": 1100.0,
             # what an efficiency figure over the N = 1, 2, 4, 8 lines has to be computed from (the driver computes it, not this line)
