@@ -79,6 +79,13 @@ typedef struct plat_read_table {
     const int32_t* dev_flags;
     const int16_t* dev_cigar;
     const int32_t* dev_cig_off;
+    /* Optional: what a loader knows of its table anyway -- ReadArray keeps the length of its longest read as reads are appended
+     * (cwindow.pyx:124,173-174,272; variantcaller.pyx:476-488 sets options.rlen from it).  longest_read = max(end[r] - pos[r]),
+     * most_bases = max(off[r+1] - off[r]) over the table's reads: EXACT values, or 0 = not known (the library then walks pos / end / off of every
+     * read of the region once, 16 bytes per read of cold host memory: a tenth of the region loop's CPU time on the 30x WGS job).
+     * PLAT_CALLER_CHECK_HINTS=1: every hint is checked against the arrays and a wrong one refused (PLAT_ERR_BAD_INPUT). */
+    int32_t longest_read;
+    int32_t most_bases;
 } plat_read_table;
 
 /* One bamReadBuffer (cwindow.pyx:485-513): reads and badReads sorted by pos, brokenMates sorted by mate_pos

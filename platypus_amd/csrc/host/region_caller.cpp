@@ -172,8 +172,17 @@ static std::unique_ptr<RegionWork> makeRegionWork(const plat_region* in, int ind
         const plat_sample_reads& sr = in->samples[i];
         SampleView& sv = r->samples[(size_t)i];
         sv.reads.t = &sr.reads; sv.bad.t = &sr.bad_reads; sv.broken.t = &sr.broken_mates;
-        sv.reads.longest = longestRead(sr.reads); sv.bad.longest = longestRead(sr.bad_reads); sv.broken.longest = longestRead(sr.broken_mates);
-        sv.reads.maxLen = mostBases(sr.reads); sv.bad.maxLen = mostBases(sr.bad_reads); sv.broken.maxLen = mostBases(sr.broken_mates);
+        // (the loader's own figures when it gives them: plat_read_table.longest_read / most_bases; walked here otherwise)
+        static const bool check = [] { const char* e = getenv("PLAT_CALLER_CHECK_HINTS"); return e && e[0] == '1'; }();
+        const plat_read_table* tabs[3] = {&sr.reads, &sr.bad_reads, &sr.broken_mates};
+        TableView* views[3] = {&sv.reads, &sv.bad, &sv.broken};
+        for (int k = 0; k < 3; ++k) {
+            const plat_read_table& t = *tabs[k];
+            if (check && ((t.longest_read > 0 && t.longest_read != longestRead(t)) || (t.most_bases > 0 && t.most_bases != mostBases(t)) || t.longest_read < 0 || t.most_bases < 0))
+                throw std::runtime_error("plat_read_table.longest_read / most_bases do not describe the table's reads");
+            views[k]->longest = t.longest_read > 0 ? t.longest_read : longestRead(t);
+            views[k]->maxLen = t.most_bases > 0 ? t.most_bases : mostBases(t);
+        }
         longest = std::max(longest, sv.reads.longest);
     }
     longestOut = longest;
@@ -440,7 +449,9 @@ CALLER_EXPORT int plat_call_regions(plat_caller* c, const plat_region* regions, 
     int rlen = options->rlen;
     for (int k = 0; k < n_regions; ++k) {
         int longest = 0;
-        std::unique_ptr<RegionWork> r = makeRegionWork(&regions[k], k, n_samples, longest);
+        std::unique_ptr<RegionWork> r;
+        try { r = makeRegionWork(&regions[k], k, n_samples, longest); }
+        catch (const std::exception& e) { c->lastError = e.what(); return PLAT_ERR_BAD_INPUT; }          // (a hint that does not describe its table, PLAT_CALLER_CHECK_HINTS=1)
         rlen = nextRlen(rlen, longest, options->maxSize, options->getVariantsFromBAMs);
         r->rlen = rlen;
         work.push_back(std::move(r));

@@ -27,7 +27,8 @@ class _ReadTable(C.Structure):
         "seq", "qual", "off", "pos", "end", "mapq", "flags", "mate_pos", "cigar", "cig_off")] + \
                [("n_exceptions", C.c_int64), ("exc_index", C.c_void_p), ("exc_base", C.c_void_p), ("exc_qual", C.c_void_p),
                 ("dev_seq", C.c_void_p), ("dev_qual", C.c_void_p)] + [(k, C.c_void_p) for k in (
-                    "dev_off", "dev_pos", "dev_end", "dev_mapq", "dev_flags", "dev_cigar", "dev_cig_off")]
+                    "dev_off", "dev_pos", "dev_end", "dev_mapq", "dev_flags", "dev_cigar", "dev_cig_off")] + \
+               [("longest_read", C.c_int32), ("most_bases", C.c_int32)]       # optional: the loader's own figures (0 = not known)
 
 
 class _SampleReads(C.Structure):
@@ -143,6 +144,9 @@ class ReadTable:
             if self.exc is not None:
                 t.n_exceptions = len(self.exc[0])
                 t.exc_index, t.exc_base, t.exc_qual = (a.ctypes.data for a in self.exc)
+            if self.n:                                                       # what ReadArray knows of itself (cwindow.pyx:173-174): one numpy pass here, none in the library
+                t.longest_read = max(0, int((self.end[:self.n].astype(np.int64) - self.pos[:self.n]).max()))
+                t.most_bases = max(0, int(np.diff(self.off[:self.n + 1]).max()))
             self._struct = t
         return t
 

@@ -325,3 +325,42 @@ def test_sites_with_two_alternative_alleles_follow_the_python2_dictionary_order(
         nc.close()
     finally:
         os.environ.pop("PLAT_CALLER_HOST_TALLY")
+
+
+def test_the_loaders_own_figures_for_its_tables(fake, monkeypatch):
+    """plat_read_table.longest_read / most_bases (optional: what ReadArray knows of itself as reads are appended, cwindow.pyx:173-174,272): the same
+    text with the figures (the tables of fastcaller.ReadTable carry them), without them (0: the library walks the arrays) -- and, with
+    PLAT_CALLER_CHECK_HINTS=1, a figure that does not describe its table is refused instead of believed."""
+    monkeypatch.setenv("PLAT_CALLER_CHECK_HINTS", "1")
+    regs = [synth.config4_region(60 + i, n_samples=2, region_len=2500, snp_rate=4e-3, indel_rate=2e-3, read_len=100, depth=20) for i in range(3)]
+    names = ["A", "B"]
+    fasta, work = _work(regs, names)
+
+    def call(edit=None):
+        rr = [F.RegionReads.from_buffers(c, s, e, fasta, b) for c, s, e, b in work]
+        for r in rr:
+            for tabs in r.samples:
+                for t in tabs:
+                    st = t.struct()
+                    if t.n:
+                        assert st.longest_read == int((t.end.astype(np.int64) - t.pos).max()) and st.most_bases == int(np.diff(t.off).max())
+                    if edit:
+                        edit(st)
+        nc = F.NativeCaller(0, 2, 2, lib=fake)
+        try:
+            return nc.call_regions(rr, names, default_options())
+        finally:
+            nc.close()
+
+    with_figures = call()
+    assert with_figures.count("\n") > 10
+
+    def forget(st):
+        st.longest_read = 0; st.most_bases = 0
+    assert call(forget) == with_figures
+
+    def lie(st):
+        if st.n_reads:
+            st.longest_read += 1
+    with pytest.raises(Exception):
+        call(lie)

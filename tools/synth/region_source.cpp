@@ -398,6 +398,11 @@ SYNTH_EXPORT int plat_synth_load(void* user, int index, int slot, plat_region* o
         plat_read_table& t = sr.reads;
         t.n_reads = nReads; t.encoding = g->encoding; t.seq = seq; t.qual = qual ? qual : seq; t.off = off; t.pos = pos; t.end = endp; t.mapq = mapq;
         t.flags = flags; t.mate_pos = mate; t.cigar = cigar; t.cig_off = cigoff;
+        {   // what a loader knows of its reads as it appends them (ReadArray.__longestRead, cwindow.pyx:173-174): handed over with the table
+            int lg = 0; int64_t mb = 0;
+            for (int r = 0; r < nReads; ++r) { lg = std::max(lg, endp[r] - pos[r]); mb = std::max<int64_t>(mb, off[r + 1] - off[r]); }
+            t.longest_read = lg; t.most_bases = (int32_t)mb;
+        }
         static const int64_t zero64[1] = {0};
         static const int32_t zero32[1] = {0};
         for (plat_read_table* e : {&sr.bad_reads, &sr.broken_mates}) {
