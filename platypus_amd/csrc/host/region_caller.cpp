@@ -162,7 +162,8 @@ struct Feed {
     virtual ~Feed() {}
 };
 
-static std::unique_ptr<RegionWork> makeRegionWork(const plat_region* in, int index, int n_samples, int& longestOut) {
+static bool checkHints() { const char* e = getenv("PLAT_CALLER_CHECK_HINTS"); return e && e[0] == '1'; }     // (read once per call of the library, not once per process)
+static std::unique_ptr<RegionWork> makeRegionWork(const plat_region* in, int index, int n_samples, int& longestOut, bool check) {
     std::unique_ptr<RegionWork> r(new RegionWork());
     r->in = in; r->index = index;
     r->fa.seq = in->contig_seq; r->fa.len = in->contig_len;
@@ -173,7 +174,6 @@ static std::unique_ptr<RegionWork> makeRegionWork(const plat_region* in, int ind
         SampleView& sv = r->samples[(size_t)i];
         sv.reads.t = &sr.reads; sv.bad.t = &sr.bad_reads; sv.broken.t = &sr.broken_mates;
         // (the loader's own figures when it gives them: plat_read_table.longest_read / most_bases; walked here otherwise)
-        static const bool check = [] { const char* e = getenv("PLAT_CALLER_CHECK_HINTS"); return e && e[0] == '1'; }();
         const plat_read_table* tabs[3] = {&sr.reads, &sr.bad_reads, &sr.broken_mates};
         TableView* views[3] = {&sv.reads, &sv.bad, &sv.broken};
         for (int k = 0; k < 3; ++k) {
@@ -246,6 +246,7 @@ struct StreamFeed : Feed {
     std::string errText;
     std::atomic<bool>& failed;
     double tLoad = 0, tWait = 0;
+    const bool check = checkHints();
     StreamFeed(int n_, int nS, int per_, int workers, int maxSize_, int rlen0, plat_region_load_fn l, void* u, int nSlots, std::atomic<bool>& f)
         : n(n_), nSamples(nS), per(per_), nChunks(0), maxSize(maxSize_), load(l), user(u), work((size_t)n_), desc((size_t)n_),
           slotOf((size_t)n_, -1), longest((size_t)n_, 0), loaded((size_t)n_, 0), bound(chunkBounds(n_, per_, workers)), chunkOf((size_t)n_, 0), rlen(rlen0), failed(f) {
@@ -276,7 +277,7 @@ struct StreamFeed : Feed {
             if (rc != PLAT_OK) { fail(rc, "the region source failed for region " + std::to_string(idx)); return; }
             int lg = 0;
             std::unique_ptr<RegionWork> r;
-            try { r = makeRegionWork(&desc[(size_t)idx], idx, nSamples, lg); }
+            try { r = makeRegionWork(&desc[(size_t)idx], idx, nSamples, lg, check); }
             catch (const std::exception& e) { fail(PLAT_ERR_BAD_INPUT, e.what()); return; }
             const double dt = secs(t0, Clock::now());
             std::lock_guard<std::mutex> g(m);
@@ -447,10 +448,11 @@ CALLER_EXPORT int plat_call_regions(plat_caller* c, const plat_region* regions, 
     static_cast<plat_caller_options&>(o) = *options;
     std::vector<std::unique_ptr<RegionWork>> work;
     int rlen = options->rlen;
+    const bool check = checkHints();
     for (int k = 0; k < n_regions; ++k) {
         int longest = 0;
         std::unique_ptr<RegionWork> r;
-        try { r = makeRegionWork(&regions[k], k, n_samples, longest); }
+        try { r = makeRegionWork(&regions[k], k, n_samples, longest, check); }
         catch (const std::exception& e) { c->lastError = e.what(); return PLAT_ERR_BAD_INPUT; }          // (a hint that does not describe its table, PLAT_CALLER_CHECK_HINTS=1)
         rlen = nextRlen(rlen, longest, options->maxSize, options->getVariantsFromBAMs);
         r->rlen = rlen;
